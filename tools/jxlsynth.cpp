@@ -1,0 +1,548 @@
+// tools/jxlsynth.cpp -- synthetic JPEG XL stream generator (test/bench infrastructure).
+//
+// No encoder or sample file exists offline, so this tool writes the streams
+// the tests and bench.py decode: VarDCT frames (all 27 transform types, rANS with clustered
+// contexts, optional custom block-context map / coefficient orders / HF presets / multiple passes)
+// and Modular frames (single- and multi-group, RCT / Palette, prefix codes with LZ77, weighted
+// predictor). Streams are synthesised in the *coefficient / residual domain*: the LF image comes
+// from a smooth procedural picture, HF coefficients are sparse with frequency-decaying
+// magnitudes so that size and symbol statistics resemble a distance-1 encode. The reference
+// decoder (oracle/_ref) is the judge of validity; what a stream decodes to is defined by it.
+//
+// usage: jxlsynth vardct  W H SEED OUT [key=value ...]
+//        jxlsynth modular W H SEED OUT [key=value ...]
+#include "jxlsynth_common.hpp"
+#include "jxlsynth_modular.hpp"
+#include <cmath>
+#include <map>
+
+using namespace synth;
+
+// ------------------------------------------------------------------------------------------------
+// options
+
+struct Options {
+	std::map<std::string, std::string> kv;
+	int geti(const char *k, int def) const { auto it = kv.find(k); return it == kv.end() ? def : atoi(it->second.c_str()); }
+	double getd(const char *k, double def) const { auto it = kv.find(k); return it == kv.end() ? def : atof(it->second.c_str()); }
+	std::string gets(const char *k, const char *def) const { auto it = kv.find(k); return it == kv.end() ? def : it->second; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// procedural source picture (deterministic, cheap): low-frequency sinusoids + value noise +
+// hard-edged rectangles, sRGB in [0,1]
+
+struct Picture {
+	uint64_t seed;
+	struct Rect { int x0, y0, x1, y1; float r, g, b; };
+	std::vector<Rect> rects;
+	float fx[6], fy[6], ph[6], amp[6][3];
+	int W, H;
+	Picture(int w, int h, uint64_t s) : seed(s), W(w), H(h) {
+		SplitMix64 rng(s ^ 0x4A34304Aull);
+		for (int i = 0; i < 6; ++i) {
+			fx[i] = (float) (rng.unit() * 6.0 / w); fy[i] = (float) (rng.unit() * 6.0 / h); ph[i] = (float) (rng.unit() * 6.28318);
+			for (int c = 0; c < 3; ++c) amp[i][c] = (float) (rng.unit() * 0.09);
+		}
+		int nrect = 24;
+		for (int i = 0; i < nrect; ++i) {
+			Rect r; r.x0 = (int) rng.below((uint32_t) w); r.y0 = (int) rng.below((uint32_t) h);
+			r.x1 = r.x0 + 8 + (int) rng.below((uint32_t) std::max(9, w / 4)); r.y1 = r.y0 + 8 + (int) rng.below((uint32_t) std::max(9, h / 4));
+			r.r = (float) (rng.unit() * 0.3 - 0.15); r.g = (float) (rng.unit() * 0.3 - 0.15); r.b = (float) (rng.unit() * 0.3 - 0.15);
+			rects.push_back(r);
+		}
+	}
+	static float hash01(uint64_t a) { a *= 0x9e3779b97f4a7c15ull; a ^= a >> 29; a *= 0xbf58476d1ce4e5b9ull; a ^= a >> 32; return (float) (a & 0xffffff) * (1.0f / 16777216.0f); }
+	float vnoise(float x, float y, int oct, int ch) const {
+		float sc = (float) (1 << oct) * 4.0f / (float) std::max(W, H);
+		float u = x * sc, v = y * sc; int iu = (int) u, iv = (int) v; float fu = u - (float) iu, fv = v - (float) iv;
+		auto hv = [&](int a, int b) { return hash01(seed * 31 + (uint64_t) a * 73856093ull + (uint64_t) b * 19349663ull + (uint64_t) oct * 83492791ull + (uint64_t) ch * 2654435761ull); };
+		float su = fu * fu * (3 - 2 * fu), sv = fv * fv * (3 - 2 * fv);
+		return (hv(iu, iv) * (1 - su) + hv(iu + 1, iv) * su) * (1 - sv) + (hv(iu, iv + 1) * (1 - su) + hv(iu + 1, iv + 1) * su) * sv;
+	}
+	void rgb(float x, float y, float out[3]) const {
+		for (int c = 0; c < 3; ++c) {
+			float v = 0.5f;
+			for (int i = 0; i < 6; ++i) v += amp[i][c] * sinf(fx[i] * x * 6.28318f + fy[i] * y * 6.28318f + ph[i] + (float) c);
+			for (int o = 0; o < 3; ++o) v += (vnoise(x, y, o, c) - 0.5f) * (0.16f / (float) (1 << o));
+			out[c] = v;
+		}
+		for (const Rect &r : rects) if (x >= (float) r.x0 && x < (float) r.x1 && y >= (float) r.y0 && y < (float) r.y1) { out[0] += r.r; out[1] += r.g; out[2] += r.b; }
+		for (int c = 0; c < 3; ++c) out[c] = std::min(0.92f, std::max(0.08f, out[c]));
+	}
+};
+
+// ------------------------------------------------------------------------------------------------
+// headers
+
+static void write_size_header(BitWriter &bw, int w, int h) {  // inverse of j40.h:3008
+	if (w % 8 == 0 && h % 8 == 0 && w <= 256 && h <= 256) {
+		bw.put(1, 1); bw.put((uint64_t) (h / 8 - 1), 5);
+		if (w == h) bw.put(1, 3); else { bw.put(0, 3); bw.put((uint64_t) (w / 8 - 1), 5); }
+	} else {
+		bw.put(0, 1); bw.u32(h, 1, 9, 1, 13, 1, 18, 1, 30);
+		if (w == h) bw.put(1, 3); else { bw.put(0, 3); bw.u32(w, 1, 9, 1, 13, 1, 18, 1, 30); }
+	}
+}
+
+static void write_toc_entry(BitWriter &bw, size_t size) { bw.u32((int64_t) size, 0, 10, 1024, 14, 17408, 22, 4211712, 30); }  // j40.h:5529
+
+// transform table: the decoder's view (J40__DCT_SELECT, j40.h:4591): log rows, log columns, order
+static const int8_t DCTSEL[27][3] = {
+	{3,3,0},{3,3,1},{3,3,1},{3,3,1},{4,4,2},{5,5,3},{4,3,4},{3,4,4},{5,3,5},{3,5,5},{5,4,6},{4,5,6},{3,3,1},{3,3,1},
+	{3,3,1},{3,3,1},{3,3,1},{3,3,1},{6,6,7},{6,5,8},{5,6,8},{7,7,9},{7,6,10},{6,7,10},{8,8,11},{8,7,12},{7,8,12},
+};
+
+// coefficient-context tables (spec constants as used at j40.h:6935-6947), pre-doubled
+static const int8_t FREQ_CTX2[64] = {
+	-1, 0, 2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 30, 32, 32, 34, 34, 36, 36, 38, 38, 40, 40, 42, 42, 44, 44,
+	46, 46, 46, 46, 48, 48, 48, 48, 50, 50, 50, 50, 52, 52, 52, 52, 54, 54, 54, 54, 56, 56, 56, 56, 58, 58, 58, 58, 60, 60, 60, 60,
+};
+static int nnz_ctx2(int q) {
+	static const int16_t LIMIT[8] = {2, 3, 5, 9, 13, 21, 33, 64}, VALUE[8] = {0, 62, 124, 186, 246, 304, 360, 412};
+	for (int i = 0; i < 8; ++i) if (q < LIMIT[i]) return VALUE[i];
+	return 412;
+}
+
+struct LfGroupW {
+	int left, top, w, h, w8, h8, w64, h64;
+	std::vector<int32_t> blocks;               // per cell: (dctsel + 2) << 20 | voff, 1 << 20 | voff, or 0
+	struct VB { int x8, y8, dctsel, hfmul_m1; };
+	std::vector<VB> vbs;
+	Channel lfq[3];                            // Y, X, B order as streamed
+	Channel xfromy, bfromy, blockinfo, sharp;
+	std::vector<uint8_t> lfidx;
+};
+
+static int run_vardct(int W, int H, uint64_t seed, const char *out, const Options &opt) {
+	SplitMix64 rng(seed * 0x100000001b3ull + 12345);
+	const int global_scale = opt.geti("global_scale", 8192), quant_lf = opt.geti("quant_lf", 4);
+	const double density = opt.getd("density", 0.22), decay = opt.getd("decay", 0.965);
+	const int max_log = opt.geti("maxlog", 6);              // largest transform side (log2) used in the mix
+	const int coverage = opt.geti("coverage", 1);           // 1: force every transform type <= maxlog at least once per frame
+	const int custom_bctx = opt.geti("bctx", 0);            // custom block context map with LF/QF thresholds
+	const int num_presets = opt.geti("presets", 1);
+	const int custom_orders = opt.geti("orders", 0);
+	const int num_passes = opt.geti("passes", 1);
+	const int nonzero_header = opt.geti("fullheader", (num_passes > 1) ? 1 : 0);
+	const int x_qm = opt.geti("xqm", 3), b_qm = opt.geti("bqm", 2);
+	const int skip_smooth = opt.geti("nosmooth", 0);
+	const int small_clusters = opt.geti("simpleclusters", 0); // <= 8 clusters: simple cluster-map form
+	const int log_alpha = opt.geti("logalpha", 7);
+	const int container = opt.geti("container", 0);
+
+	const int gcols = (W + 255) / 256, grows = (H + 255) / 256, num_groups = gcols * grows;
+	const int ggcols = (W + 2047) / 2048, ggrows = (H + 2047) / 2048, num_lf_groups = ggcols * ggrows;
+	if (num_groups < 2 && num_passes == 1) die("vardct: need at least 2 groups (single-section VarDCT order quirk, SURVEY section 0 fact 8)");
+
+	Picture pic(W, H, seed);
+
+	// ---- forward opsin (numerical inverse of the decoder's default inverse matrix, j40.h:3109) ----
+	const double inv[3][3] = {
+		{11.031566901960783, -9.866943921568629, -0.16462299647058826},
+		{-3.254147380392157, 4.418770392156863, -0.16462299647058826},
+		{-3.6588512862745097, 2.7129230470588235, 1.9459282392156863}};
+	double fwd[3][3];
+	{
+		double a = inv[0][0], b = inv[0][1], c = inv[0][2], d = inv[1][0], e = inv[1][1], f = inv[1][2], g = inv[2][0], h = inv[2][1], i = inv[2][2];
+		double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+		fwd[0][0] = (e * i - f * h) / det; fwd[0][1] = (c * h - b * i) / det; fwd[0][2] = (b * f - c * e) / det;
+		fwd[1][0] = (f * g - d * i) / det; fwd[1][1] = (a * i - c * g) / det; fwd[1][2] = (c * d - a * f) / det;
+		fwd[2][0] = (d * h - e * g) / det; fwd[2][1] = (b * g - a * h) / det; fwd[2][2] = (a * e - b * d) / det;
+	}
+	const double bias = -0.0037930732552754493, cbias = cbrt(bias);
+	auto to_xyb = [&](const float rgb[3], double xyb[3]) {
+		double lin[3];
+		for (int c = 0; c < 3; ++c) { double v = rgb[c]; lin[c] = v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4); }
+		double mix[3];
+		for (int c = 0; c < 3; ++c) mix[c] = cbrt(fwd[c][0] * lin[0] + fwd[c][1] * lin[1] + fwd[c][2] * lin[2] - bias) + cbias;
+		xyb[0] = (mix[0] - mix[1]) * 0.5; xyb[1] = (mix[0] + mix[1]) * 0.5; xyb[2] = mix[2];
+	};
+	// LF dequant steps (j40.h:6562): m_lf_scaled / (global_scale * quant_lf) * 65536
+	const double m_lf[3] = {1.0 / 4096, 1.0 / 512, 1.0 / 256};
+	double lfstep[3]; for (int c = 0; c < 3; ++c) lfstep[c] = m_lf[c] / ((double) global_scale * quant_lf) * 65536.0;
+
+	const int custom_cfl = opt.geti("cfl", 0);
+	const double kx_lf = custom_cfl ? 0.125 + 3.0 / 128.0 : 0.0, kb_lf = custom_cfl ? 0.75 - 2.0 / 128.0 : 1.0;
+
+	// ---- block context configuration ----
+	int nb_lf_thr[3] = {0, 0, 0}, lf_thr[3][4] = {{0}}, nb_qf_thr = 0, qf_thr[4] = {0};
+	std::vector<uint8_t> bctx_map;
+	int nb_block_ctx = 15;
+	static const uint8_t DEFAULT_BLKCTX[39] = {0, 1, 2, 2, 3, 3, 4, 5, 6, 6, 6, 6, 6, 7, 8, 9, 9, 10, 11, 12, 13, 14, 14, 14, 14, 14, 7, 8, 9, 9, 10, 11, 12, 13, 14, 14, 14, 14, 14};
+	if (!custom_bctx) bctx_map.assign(DEFAULT_BLKCTX, DEFAULT_BLKCTX + 39);
+	else {
+		nb_lf_thr[0] = 1; lf_thr[0][0] = 3;                // X
+		nb_lf_thr[1] = 2; lf_thr[1][0] = 60; lf_thr[1][1] = 140;  // Y
+		nb_lf_thr[2] = 1; lf_thr[2][0] = 50;               // B
+		nb_qf_thr = 2; qf_thr[0] = 4; qf_thr[1] = 9;
+		int size = 39 * 2 * 3 * 2 * 3;
+		nb_block_ctx = 11;
+		bctx_map.resize((size_t) size);
+		for (int i = 0; i < size; ++i) bctx_map[(size_t) i] = (uint8_t) ((i * 7 + i / 13) % nb_block_ctx);
+		for (int i = 0; i < nb_block_ctx; ++i) bctx_map[(size_t) i] = (uint8_t) i;  // every cluster id present
+	}
+	const int lfidx_size = (nb_lf_thr[0] + 1) * (nb_lf_thr[1] + 1) * (nb_lf_thr[2] + 1);
+
+	// ---- per LF group: LF image, varblock layout, HF metadata ----
+	std::vector<LfGroupW> ggs((size_t) num_lf_groups);
+	std::vector<int> forced;  // transform types still to be placed once (coverage)
+	if (coverage) for (int t = 0; t < 27; ++t) if (std::max(DCTSEL[t][0], DCTSEL[t][1]) <= max_log) forced.push_back(t);
+	// weights of the random mix (8x8-class transforms dominate, like a d1 encode)
+	const int mixw[27] = {40, 3, 2, 3, 14, 6, 6, 6, 2, 2, 3, 3, 3, 3, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1};
+	for (int ggy = 0, ggi = 0; ggy < ggrows; ++ggy) for (int ggx = 0; ggx < ggcols; ++ggx, ++ggi) {
+		LfGroupW &gg = ggs[(size_t) ggi];
+		gg.left = ggx * 2048; gg.top = ggy * 2048; gg.w = std::min(2048, W - gg.left); gg.h = std::min(2048, H - gg.top);
+		gg.w8 = (gg.w + 7) / 8; gg.h8 = (gg.h + 7) / 8; gg.w64 = (gg.w + 63) / 64; gg.h64 = (gg.h + 63) / 64;
+		for (int c = 0; c < 3; ++c) gg.lfq[c] = Channel(gg.w8, gg.h8);
+		for (int y = 0; y < gg.h8; ++y) for (int x = 0; x < gg.w8; ++x) {
+			float rgb[3]; double xyb[3];
+			pic.rgb((float) (gg.left + x * 8) + 3.5f, (float) (gg.top + y * 8) + 3.5f, rgb);
+			to_xyb(rgb, xyb);
+			gg.lfq[0].at(x, y) = (int32_t) lrint(xyb[1] / lfstep[1]);  // streamed order: Y, X, B
+			gg.lfq[1].at(x, y) = (int32_t) lrint(xyb[0] / lfstep[0]);
+			// the decoder adds kb_lf * Y to the LF of B and kx_lf * Y to X (j40.h:7115-7116, 7159-7171)
+			double yq = (double) gg.lfq[0].at(x, y) * lfstep[1];
+			gg.lfq[1].at(x, y) = (int32_t) lrint((xyb[0] - kx_lf * yq) / lfstep[0]);
+			gg.lfq[2].at(x, y) = (int32_t) lrint((xyb[2] - kb_lf * yq) / lfstep[2]);
+		}
+		gg.lfidx.assign((size_t) gg.w8 * (size_t) gg.h8, 0);
+		for (int y = 0; y < gg.h8; ++y) for (int x = 0; x < gg.w8; ++x) {  // j40.h:6566-6570
+			auto cnt = [&](int v, const int *thr, int n) { int k = 0; for (int t = 0; t < n; ++t) k += v > thr[t]; return k; };
+			int xi = cnt(gg.lfq[1].at(x, y), lf_thr[0], nb_lf_thr[0]), yi = cnt(gg.lfq[0].at(x, y), lf_thr[1], nb_lf_thr[1]), bi = cnt(gg.lfq[2].at(x, y), lf_thr[2], nb_lf_thr[2]);
+			gg.lfidx[(size_t) y * (size_t) gg.w8 + (size_t) x] = (uint8_t) ((xi * (nb_lf_thr[0] + 1) + bi) * (nb_lf_thr[2] + 1) + yi);
+		}
+		gg.blocks.assign((size_t) gg.w8 * (size_t) gg.h8, 0);
+		for (int y0 = 0; y0 < gg.h8; ++y0) for (int x0 = 0; x0 < gg.w8; ++x0) {
+			if (gg.blocks[(size_t) y0 * (size_t) gg.w8 + (size_t) x0]) continue;
+			auto fits = [&](int t) {
+				int vw8 = 1 << (DCTSEL[t][1] - 3), vh8 = 1 << (DCTSEL[t][0] - 3);
+				int x1 = x0 + vw8 - 1, y1 = y0 + vh8 - 1;
+				if (x1 >= gg.w8 || y1 >= gg.h8 || (x0 >> 5) != (x1 >> 5) || (y0 >> 5) != (y1 >> 5)) return false;  // j40.h:6659-6660
+				for (int y = y0; y <= y1; ++y) for (int x = x0; x <= x1; ++x) if (gg.blocks[(size_t) y * (size_t) gg.w8 + (size_t) x]) return false;
+				return true;
+			};
+			int t = -1;
+			for (size_t k = 0; k < forced.size(); ++k) if (fits(forced[k])) { t = forced[k]; forced.erase(forced.begin() + (long) k); break; }
+			if (t < 0) {
+				int total = 0; for (int k = 0; k < 27; ++k) if (std::max(DCTSEL[k][0], DCTSEL[k][1]) <= max_log) total += mixw[k];
+				int pick = (int) rng.below((uint32_t) total);
+				for (int k = 0; k < 27; ++k) if (std::max(DCTSEL[k][0], DCTSEL[k][1]) <= max_log) { if (pick < mixw[k]) { t = k; break; } pick -= mixw[k]; }
+				if (!fits(t)) t = 0;
+			}
+			int vw8 = 1 << (DCTSEL[t][1] - 3), vh8 = 1 << (DCTSEL[t][0] - 3), voff = (int) gg.vbs.size();
+			for (int y = y0; y < y0 + vh8; ++y) for (int x = x0; x < x0 + vw8; ++x) gg.blocks[(size_t) y * (size_t) gg.w8 + (size_t) x] = 1 << 20 | voff;
+			gg.blocks[(size_t) y0 * (size_t) gg.w8 + (size_t) x0] = (t + 2) << 20 | voff;
+			gg.vbs.push_back({x0, y0, t, 3 + (int) rng.below(10)});
+		}
+		gg.xfromy = Channel(gg.w64, gg.h64); gg.bfromy = Channel(gg.w64, gg.h64);
+		for (auto &v : gg.xfromy.px) v = (int32_t) rng.below(9) - 4;
+		for (auto &v : gg.bfromy.px) v = (int32_t) rng.below(13) - 6;
+		gg.blockinfo = Channel((int) gg.vbs.size(), 2);
+		for (size_t i = 0; i < gg.vbs.size(); ++i) { gg.blockinfo.at((int) i, 0) = gg.vbs[i].dctsel; gg.blockinfo.at((int) i, 1) = gg.vbs[i].hfmul_m1; }
+		gg.sharp = Channel(gg.w8, gg.h8);
+		for (auto &v : gg.sharp.px) v = (int32_t) rng.below(8);
+	}
+
+	// ---- global MA tree: splits on stream index (property 1) and channel (property 0) ----
+	MATree tree;
+	{
+		int lf_y = tree.leaf(5), lf_x = tree.leaf(5), lf_b = tree.leaf(4);
+		int lf_yhi = tree.leaf(5);
+		int lf_ysplit = tree.branch(9, 120, lf_yhi, lf_y);          // W+N-NW > 120
+		int lf_xb = tree.branch(0, 1, lf_b, lf_x);
+		int lf = tree.branch(0, 0, lf_xb, lf_ysplit);               // channel > 0 ?
+		int cfl = tree.leaf(1), binfo = tree.leaf(0), sharp = tree.leaf(2);
+		int meta_hi = tree.branch(0, 2, sharp, binfo);
+		int meta = tree.branch(0, 1, meta_hi, cfl);
+		int root = tree.branch(1, 2 * num_lf_groups, meta, lf);     // sidx > 2*num_lf_groups  <=> HF metadata stream
+		tree.finalise(root);
+	}
+	CodeSpecW treespec; treespec.init(6, std::vector<uint8_t>(6, 0), 1); treespec.log_alpha = 6; treespec.cfg[0] = HybridCfg{4, 1, 0};
+	StreamEncoder tree_enc(treespec); tree_tokens(tree, tree_enc); count_stream(treespec, tree_enc);
+
+	CodeSpecW gspec;  // global code spec shared by every LF-group Modular stream
+	{
+		std::vector<uint8_t> map((size_t) tree.num_ctx);
+		for (int i = 0; i < tree.num_ctx; ++i) map[(size_t) i] = (uint8_t) i;
+		gspec.init(tree.num_ctx, map, tree.num_ctx);
+		gspec.log_alpha = 8;
+		for (auto &c : gspec.cfg) c = HybridCfg{4, 2, 0};
+	}
+	WPParams wpp;
+	std::vector<StreamEncoder> lfq_enc, meta_enc;
+	for (int ggi = 0; ggi < num_lf_groups; ++ggi) {
+		LfGroupW &gg = ggs[(size_t) ggi];
+		lfq_enc.emplace_back(gspec); meta_enc.emplace_back(gspec);
+		std::vector<Channel> ch{gg.lfq[0], gg.lfq[1], gg.lfq[2]};
+		for (int c = 0; c < 3; ++c) encode_channel(tree, ch, c, 1 + ggi, wpp, lfq_enc.back());
+		std::vector<Channel> mc{gg.xfromy, gg.bfromy, gg.blockinfo, gg.sharp};
+		for (int c = 0; c < 4; ++c) encode_channel(tree, mc, c, 1 + 2 * num_lf_groups + ggi, wpp, meta_enc.back());
+		count_stream(gspec, lfq_enc.back()); count_stream(gspec, meta_enc.back());
+	}
+
+	// ---- HF coefficients: tokens per (pass, group) with the decoder's context model ----
+	const int ctx_per_preset = 495 * nb_block_ctx;
+	std::vector<CodeSpecW> cspec((size_t) num_passes);
+	std::vector<std::vector<StreamEncoder>> hf_enc((size_t) num_passes);
+	std::vector<int> group_preset((size_t) num_groups);
+	for (int g = 0; g < num_groups; ++g) group_preset[(size_t) g] = num_presets > 1 ? (int) rng.below((uint32_t) num_presets) : 0;
+	for (int pass = 0; pass < num_passes; ++pass) {
+		CodeSpecW &cs = cspec[(size_t) pass];
+		const int nctx = ctx_per_preset * num_presets;
+		std::vector<uint8_t> map((size_t) nctx);
+		int nclusters = 0;
+		for (int ctx = 0; ctx < nctx; ++ctx) {
+			int preset = ctx / ctx_per_preset, r = ctx % ctx_per_preset, cl;
+			if (r < 37 * nb_block_ctx) {            // number-of-nonzeros contexts
+				int k = r / nb_block_ctx, b = r % nb_block_ctx;
+				cl = small_clusters ? (k < 8 ? 0 : 1) : (k < 4 ? 0 : k < 12 ? 1 : k < 24 ? 2 : 3) * 3 + b % 3;
+			} else {                                // coefficient contexts
+				int q = r - 37 * nb_block_ctx, b = q / 458, s = q % 458;
+				cl = small_clusters ? 2 + std::min(5, s / 80) : 12 + (s / 46) * 3 + b % 3;
+			}
+			if (!small_clusters && num_presets > 1 && preset == 1) cl = (cl * 5 + 3) % 42;  // presets share clusters differently
+			map[(size_t) ctx] = (uint8_t) cl; nclusters = std::max(nclusters, cl + 1);
+		}
+		{   // cluster ids must be dense (j40.h:2584-2588): compact them
+			std::vector<int> remap((size_t) nclusters, -1); int next = 0;
+			for (auto &m : map) { if (remap[m] < 0) remap[m] = next++; m = (uint8_t) remap[m]; }
+			nclusters = next;
+		}
+		cs.init(nctx, map, nclusters);
+		cs.log_alpha = log_alpha;
+		for (int c = 0; c < nclusters; ++c) cs.cfg[(size_t) c] = (c & 1) ? HybridCfg{4, 1, 1} : HybridCfg{4, 2, 0};
+		hf_enc[(size_t) pass].reserve((size_t) num_groups);
+	}
+	// custom coefficient orders: Lehmer codes per (pass, order, channel); the writer only needs them
+	// in the header because coefficients are synthesised in scan-index space
+	const int LOG_ORDER_SIZE[13][2] = {{3,3},{3,3},{4,4},{5,5},{3,4},{3,5},{4,5},{6,6},{5,6},{7,7},{6,7},{8,8},{7,8}};
+	std::vector<std::vector<std::vector<uint32_t>>> lehmer((size_t) num_passes);  // [pass][order*3+c] -> values
+	int used_orders_mask = 0;
+	if (custom_orders) {
+		used_orders_mask = (1 << 0) | (1 << 2) | (1 << 4);
+		for (int pass = 0; pass < num_passes; ++pass) {
+			lehmer[(size_t) pass].assign(13 * 3, {});
+			for (int o = 0; o < 13; ++o) if (used_orders_mask >> o & 1) for (int c = 0; c < 3; ++c) {
+				int size = 1 << (LOG_ORDER_SIZE[o][0] + LOG_ORDER_SIZE[o][1]), skip = size / 64;
+				int end = 6 + (int) rng.below(10);
+				std::vector<uint32_t> v;
+				for (int i = 0; i < end; ++i) v.push_back(rng.below((uint32_t) std::min(24, size - skip - i)));
+				lehmer[(size_t) pass][(size_t) (o * 3 + c)] = v;
+			}
+		}
+	}
+
+	for (int pass = 0; pass < num_passes; ++pass) {
+		for (int g = 0; g < num_groups; ++g) {
+			hf_enc[(size_t) pass].emplace_back(cspec[(size_t) pass]);
+			StreamEncoder &enc = hf_enc[(size_t) pass].back();
+			const int grow = g / gcols, gcol = g % gcols, ggi = (grow / 8) * ggcols + gcol / 8;
+			const LfGroupW &gg = ggs[(size_t) ggi];
+			const int gx8 = (gcol % 8) * 32, gy8 = (grow % 8) * 32;
+			const int gw = std::min(W, (gcol + 1) * 256) - gcol * 256, gh = std::min(H, (grow + 1) * 256) - grow * 256;
+			const int gw8 = (gw + 7) / 8, gh8 = (gh + 7) / 8;
+			const int ctxoff = ctx_per_preset * group_preset[(size_t) g];
+			std::vector<std::array<int8_t, 3>> nonzeros((size_t) gw8 * (size_t) gh8, std::array<int8_t, 3>{0, 0, 0});
+			for (int y8 = 0; y8 < gh8; ++y8) for (int x8 = 0; x8 < gw8; ++x8) {
+				int cell = gg.blocks[(size_t) (gy8 + y8) * (size_t) gg.w8 + (size_t) (gx8 + x8)];
+				int dctsel = cell >> 20;
+				if (dctsel < 2) continue;
+				dctsel -= 2;
+				const LfGroupW::VB &vb = gg.vbs[(size_t) (cell & 0xfffff)];
+				const int log_rows = DCTSEL[dctsel][0], log_cols = DCTSEL[dctsel][1], log_size = log_rows + log_cols, order_idx = DCTSEL[dctsel][2];
+				int qfidx = 0; for (int j = 0; j < nb_qf_thr; ++j) qfidx += vb.hfmul_m1 >= qf_thr[j];
+				int lfidx = gg.lfidx[(size_t) (gy8 + y8) * (size_t) gg.w8 + (size_t) (gx8 + x8)];
+				int bctx0 = (order_idx * (nb_qf_thr + 1) + qfidx) * lfidx_size + lfidx, bctxc = 13 * (nb_qf_thr + 1) * lfidx_size;
+				const int nzpos = y8 * gw8 + x8;
+				for (int cyxb = 0; cyxb < 3; ++cyxb) {
+					const int c = cyxb == 0 ? 1 : cyxb == 1 ? 0 : 2;
+					const int bctx = bctx_map[(size_t) (bctx0 + bctxc * cyxb)];
+					// choose the non-zero positions: Bernoulli with frequency decay; X/B sparser than Y
+					const int size = 1 << log_size, first = size >> 6;
+					double p = density * (c == 1 ? 1.0 : c == 0 ? 0.35 : 0.55) / (double) num_passes;
+					std::vector<std::pair<int, int>> coefs;  // (scan index, value)
+					double pk = p; const double dk = pow(decay, 64.0 / (double) size);
+					for (int i = first; i < size; ++i) {
+						if (rng.unit() < pk) {
+							int mag = 1; while (mag < 40 && rng.unit() < 0.33) ++mag;
+							coefs.push_back({i, rng.below(2) ? mag : -mag});
+						}
+						pk *= dk;
+					}
+					int nz = (int) coefs.size();
+					if (nz > (63 << (log_size - 6))) { coefs.resize((size_t) (63 << (log_size - 6))); nz = (int) coefs.size(); }
+					int pred;
+					if (x8 > 0) pred = y8 > 0 ? (nonzeros[(size_t) nzpos - 1][(size_t) c] + nonzeros[(size_t) (nzpos - gw8)][(size_t) c] + 1) >> 1 : nonzeros[(size_t) nzpos - 1][(size_t) c];
+					else pred = y8 > 0 ? nonzeros[(size_t) (nzpos - gw8)][(size_t) c] : 32;
+					int nzctx = ctxoff + bctx + (pred < 8 ? pred : 4 + pred / 2) * nb_block_ctx;
+					enc.add((uint32_t) nzctx, (uint32_t) nz);
+					int qnz = (nz + (1 << (log_size - 6)) - 1) >> (log_size - 6);
+					for (int i = 0; i < (1 << (log_rows - 3)); ++i) for (int j = 0; j < (1 << (log_cols - 3)); ++j)
+						if (y8 + i < gh8 && x8 + j < gw8) nonzeros[(size_t) (nzpos + i * gw8 + j)][(size_t) c] = (int8_t) qnz;
+					const int cctx = ctxoff + 458 * bctx + 37 * nb_block_ctx;
+					int prev = nz <= (1 << (log_size - 4)), remaining = nz;
+					size_t next = 0;
+					for (int i = first; remaining > 0 && i < size; ++i) {
+						int ctx = cctx + nnz_ctx2((remaining + (1 << (log_size - 6)) - 1) >> (log_size - 6)) + FREQ_CTX2[i >> (log_size - 6)] + prev;
+						int v = 0;
+						if (next < coefs.size() && coefs[next].first == i) v = coefs[next++].second;
+						enc.add((uint32_t) ctx, pack_signed(v));
+						prev = v != 0; remaining -= prev;
+					}
+				}
+			}
+			count_stream(cspec[(size_t) pass], enc);
+		}
+	}
+
+	// ---- assemble sections ----
+	std::vector<std::vector<uint8_t>> sections;
+	{   // LfGlobal (j40.h:6257)
+		BitWriter bw;
+		bw.put(1, 1);                                            // LF channel dequantisation: default
+		bw.u32(global_scale, 1, 11, 2049, 11, 4097, 12, 8193, 16);
+		bw.u32(quant_lf, 16, 0, 1, 5, 1, 8, 1, 16);
+		if (!custom_bctx) bw.put(1, 1);
+		else {
+			bw.put(0, 1);
+			for (int i = 0; i < 3; ++i) {
+				bw.put((uint64_t) nb_lf_thr[i], 4);
+				for (int j = 0; j < nb_lf_thr[i]; ++j) bw.u32(pack_signed(lf_thr[i][j]), 0, 4, 16, 8, 272, 16, 65808, 32);
+			}
+			bw.put((uint64_t) nb_qf_thr, 4);
+			for (int j = 0; j < nb_qf_thr; ++j) bw.u32(qf_thr[j] - 1, 0, 2, 4, 3, 12, 5, 44, 8);
+			write_cluster_map(bw, bctx_map, nb_block_ctx);
+		}
+		if (!custom_cfl) bw.put(1, 1);                   // LF channel correlation: default
+		else { bw.put(0, 1); bw.u32(128, 84, 0, 256, 0, 2, 8, 258, 16); bw.f16(0.125f); bw.f16(0.75f); bw.put(127 + 3, 8); bw.put(127 - 2, 8); }
+		bw.put(1, 1);                                            // global tree present
+		write_code_spec(bw, treespec); tree_enc.flush(bw);
+		write_code_spec(bw, gspec);
+		bw.pad();
+		sections.push_back(bw.bytes);
+	}
+	for (int ggi = 0; ggi < num_lf_groups; ++ggi) {  // LfGroup (j40.h:6722)
+		LfGroupW &gg = ggs[(size_t) ggi];
+		BitWriter bw;
+		bw.put(0, 2);                                            // extra_precision
+		write_modular_header(bw, true, nullptr, {});
+		lfq_enc[(size_t) ggi].flush(bw);
+		bw.put((uint64_t) (gg.vbs.size() - 1), ceil_lg((uint32_t) (gg.w8 * gg.h8)));
+		write_modular_header(bw, true, nullptr, {});
+		meta_enc[(size_t) ggi].flush(bw);
+		bw.pad();
+		sections.push_back(bw.bytes);
+	}
+	{   // HfGlobal + HfPass (j40.h:6819)
+		BitWriter bw;
+		bw.put(1, 1);                                            // all dequantisation matrices default
+		bw.put((uint64_t) (num_presets - 1), ceil_lg((uint32_t) num_groups));
+		for (int pass = 0; pass < num_passes; ++pass) {
+			if (!used_orders_mask) bw.put(2, 2);                 // used_orders = 0
+			else {
+				bw.put(3, 2); bw.put((uint64_t) used_orders_mask, 13);
+				CodeSpecW ospec; ospec.init(8, std::vector<uint8_t>(8, 0), 1); ospec.log_alpha = 6; ospec.cfg[0] = HybridCfg{4, 1, 0};
+				StreamEncoder oenc(ospec);
+				for (int o = 0; o < 13; ++o) if (used_orders_mask >> o & 1) for (int c = 0; c < 3; ++c) {
+					const auto &v = lehmer[(size_t) pass][(size_t) (o * 3 + c)];
+					int size = 1 << (LOG_ORDER_SIZE[o][0] + LOG_ORDER_SIZE[o][1]);
+					oenc.add((uint32_t) std::min(7, ceil_lg((uint32_t) size + 1)), (uint32_t) v.size());  // j40.h:5437
+					uint32_t prev = 0;
+					for (uint32_t x : v) { oenc.add((uint32_t) std::min(7, ceil_lg(prev + 1)), x); prev = x; }
+				}
+				count_stream(ospec, oenc);
+				write_code_spec(bw, ospec); oenc.flush(bw);
+			}
+			write_code_spec(bw, cspec[(size_t) pass]);
+		}
+		bw.pad();
+		sections.push_back(bw.bytes);
+	}
+	for (int pass = 0; pass < num_passes; ++pass) for (int g = 0; g < num_groups; ++g) {  // PassGroup (j40.h:7007)
+		BitWriter bw;
+		bw.put((uint64_t) group_preset[(size_t) g], ceil_lg((uint32_t) num_presets));
+		hf_enc[(size_t) pass][(size_t) g].flush(bw);
+		bw.pad();
+		sections.push_back(bw.bytes);
+	}
+
+	// ---- codestream ----
+	BitWriter cs;
+	cs.put(0xff, 8); cs.put(0x0a, 8);
+	write_size_header(cs, W, H);
+	cs.put(1, 1);   // ImageMetadata.all_default: 8-bit, XYB, no extra channels
+	cs.put(1, 1);   // default_m
+	cs.pad();       // frame header starts byte aligned (j40.h:5228)
+	if (!nonzero_header) cs.put(1, 1);  // FrameHeader.all_default
+	else {
+		cs.put(0, 1);
+		cs.put(0, 2);                       // regular frame
+		cs.put(0, 1);                       // VarDCT
+		cs.u64(skip_smooth ? 128 : 0);      // flags
+		cs.put(0, 2);                       // log_upsampling (xyb_encoded, so no do_ycbcr bit; no extra channels)
+		cs.put((uint64_t) x_qm, 3); cs.put((uint64_t) b_qm, 3);
+		cs.u32(num_passes, 1, 0, 2, 0, 3, 0, 4, 3);
+		if (num_passes > 1) {
+			cs.u32(0, 0, 0, 1, 0, 2, 0, 3, 1);                  // num_ds = 0
+			for (int i = 0; i < num_passes - 1; ++i) cs.put(0, 2);  // shift[i]
+		}
+		cs.put(0, 1);                       // have_crop
+		cs.u32(0, 0, 0, 1, 0, 2, 0, 3, 2);  // blend mode: replace
+		cs.put(1, 1);                       // is_last
+		cs.u32(0, 0, 0, 0, 4, 16, 5, 48, 10);  // name length 0
+		cs.put(0, 1);                       // restoration: !all_default (the reference mis-parses all_default = 1)
+		cs.put(0, 1);                       // gab disabled
+		cs.put(0, 2);                       // epf iterations 0
+		cs.u64(0);                          // restoration extensions
+		cs.u64(0);                          // frame extensions
+	}
+	// TOC (j40.h:5505-5531)
+	cs.put(0, 1);  // not permuted
+	cs.pad();
+	for (const auto &s : sections) write_toc_entry(cs, s.size());
+	cs.pad();
+	for (const auto &s : sections) cs.append_bytes(s);
+
+	std::vector<uint8_t> file;
+	if (!container) file = cs.bytes;
+	else {
+		// ISOBMFF wrapping (j40.h:1479): signature box, ftyp, then the codestream split over two jxlp boxes
+		static const uint8_t HEAD[32] = {0, 0, 0, 0x0c, 'J', 'X', 'L', ' ', 0x0d, 0x0a, 0x87, 0x0a, 0, 0, 0, 0x14, 'f', 't', 'y', 'p', 'j', 'x', 'l', ' ', 0, 0, 0, 0, 'j', 'x', 'l', ' '};
+		file.assign(HEAD, HEAD + 32);
+		auto box = [&](const char *type, const uint8_t *p, size_t n, int jxlp_index) {
+			size_t total = 8 + n + (jxlp_index != -1 ? 4 : 0);
+			uint8_t hd[8] = {(uint8_t) (total >> 24), (uint8_t) (total >> 16), (uint8_t) (total >> 8), (uint8_t) total, (uint8_t) type[0], (uint8_t) type[1], (uint8_t) type[2], (uint8_t) type[3]};
+			file.insert(file.end(), hd, hd + 8);
+			if (jxlp_index != -1) { uint32_t idx = (uint32_t) jxlp_index; uint8_t ix[4] = {(uint8_t) (idx >> 24), (uint8_t) (idx >> 16), (uint8_t) (idx >> 8), (uint8_t) idx}; file.insert(file.end(), ix, ix + 4); }
+			file.insert(file.end(), p, p + n);
+		};
+		if (container == 1) box("jxlc", cs.bytes.data(), cs.bytes.size(), -1);
+		else {
+			size_t half = cs.bytes.size() / 3;
+			// NOTE the reference treats a jxlp index *without* the top bit as "last" (j40.h:1557, inverted
+			// w.r.t. ISO 18181-2); order the flags the way it accepts
+			box("jxlp", cs.bytes.data(), half, (int) 0x80000000u);
+			static const uint8_t junk[5] = {1, 2, 3, 4, 5};
+			box("xml ", junk, 5, -1);
+			box("jxlp", cs.bytes.data() + half, cs.bytes.size() - half, 1);
+		}
+	}
+	if (!write_file(out, file)) die("cannot write output");
+	double bpp = 8.0 * (double) file.size() / ((double) W * H);
+	fprintf(stderr, "vardct %dx%d: %zu bytes (%.3f bpp), %d groups, %d LF groups, %d passes\n", W, H, file.size(), bpp, num_groups, num_lf_groups, num_passes);
+	return 0;
+}
+
+int run_modular(int, int, uint64_t, const char *, const Options &) { die("modular: not built yet"); }
+
+int main(int argc, char **argv) {
+	if (argc < 6) { fprintf(stderr, "usage: %s vardct|modular W H SEED OUT [key=value ...]\n", argv[0]); return 1; }
+	Options opt;
+	for (int i = 6; i < argc; ++i) { std::string a = argv[i]; size_t eq = a.find('='); if (eq == std::string::npos) die("options are key=value"); opt.kv[a.substr(0, eq)] = a.substr(eq + 1); }
+	int W = atoi(argv[2]), H = atoi(argv[3]); uint64_t seed = strtoull(argv[4], nullptr, 0);
+	if (W <= 0 || H <= 0) die("bad dimensions");
+	if (!strcmp(argv[1], "vardct")) return run_vardct(W, H, seed, argv[5], opt);
+	if (!strcmp(argv[1], "modular")) return run_modular(W, H, seed, argv[5], opt);
+	die("unknown mode");
+}

@@ -1,0 +1,262 @@
+// tools/jxlsynth_modular.hpp -- Modular sub-bitstream *encoder* for the synthetic stream generator
+// (test/bench infrastructure). Inverse of the reference's MA-tree reader (j40__tree, j40.h:3461),
+// Modular header (j40__modular_header, j40.h:3717) and per-pixel decode loop
+// (j40__modular_channel, j40.h:4127).
+#pragma once
+#include "jxlsynth_common.hpp"
+
+namespace synth {
+
+struct TreeNode {
+	// branch: prop >= 0 (property index), go to `left` if property value > threshold else `right`
+	// leaf:   prop < 0
+	int prop = -1;
+	int threshold = 0;
+	int left = -1, right = -1;      // node indices (builder order, any)
+	int predictor = 5, offset = 0, mul_shift = 0, mul_bits = 0;  // multiplier = (mul_bits + 1) << mul_shift
+	int ctx = -1;                   // assigned in BFS order when serialised
+};
+
+struct MATree {
+	std::vector<TreeNode> nodes;    // nodes[0] = root
+	std::vector<int> bfs;           // serialisation order
+	int num_ctx = 0;
+	int leaf(int predictor, int offset = 0, int mul_shift = 0, int mul_bits = 0) {
+		TreeNode n; n.predictor = predictor; n.offset = offset; n.mul_shift = mul_shift; n.mul_bits = mul_bits;
+		nodes.push_back(n); return (int) nodes.size() - 1;
+	}
+	int branch(int prop, int threshold, int left, int right) {
+		TreeNode n; n.prop = prop; n.threshold = threshold; n.left = left; n.right = right;
+		nodes.push_back(n); return (int) nodes.size() - 1;
+	}
+	// the reader numbers leaves in the order it meets them, which is breadth-first (j40.h:3475-3494)
+	void finalise(int root) {
+		bfs.clear(); num_ctx = 0;
+		std::vector<int> queue{root};
+		for (size_t h = 0; h < queue.size(); ++h) {
+			int id = queue[h]; bfs.push_back(id);
+			if (nodes[(size_t) id].prop >= 0) { queue.push_back(nodes[(size_t) id].left); queue.push_back(nodes[(size_t) id].right); }
+			else nodes[(size_t) id].ctx = num_ctx++;
+		}
+		rootidx = root;
+	}
+	int rootidx = 0;
+	bool uses_wp() const {
+		for (const auto &n : nodes) if ((n.prop < 0 && n.predictor == 6) || n.prop == 15) return true;
+		return false;
+	}
+};
+
+// the six tree contexts: 1 = property + 1 (0 = leaf), 0 = threshold, 2 = predictor, 3 = offset,
+// 4 = multiplier shift, 5 = multiplier bits (j40.h:3485-3501)
+inline void tree_tokens(const MATree &t, StreamEncoder &enc) {
+	for (int id : t.bfs) {
+		const TreeNode &n = t.nodes[(size_t) id];
+		if (n.prop >= 0) {
+			enc.add(1, (uint32_t) (n.prop + 1));
+			enc.add(0, pack_signed(n.threshold));
+		} else {
+			enc.add(1, 0);
+			enc.add(2, (uint32_t) n.predictor);
+			enc.add(3, pack_signed(n.offset));
+			enc.add(4, (uint32_t) n.mul_shift);
+			enc.add(5, (uint32_t) n.mul_bits);
+		}
+	}
+}
+
+// a channel being encoded: values are what the decoder must reconstruct
+struct Channel {
+	int w = 0, h = 0;
+	std::vector<int32_t> px;
+	Channel() {}
+	Channel(int w_, int h_) : w(w_), h(h_), px((size_t) w_ * (size_t) h_, 0) {}
+	int32_t &at(int x, int y) { return px[(size_t) y * (size_t) w + (size_t) x]; }
+	int32_t at(int x, int y) const { return px[(size_t) y * (size_t) w + (size_t) x]; }
+};
+
+struct WPParams { int p1 = 16, p2 = 10, p3[5] = {7, 7, 7, 0, 0}, w[4] = {13, 12, 12, 12}; };
+
+// weighted ("self-correcting") predictor state, restating what the decoder keeps (j40.h:3997-4111)
+struct WPState {
+	int width = 0; WPParams params; bool on = false;
+	std::vector<std::array<int64_t, 5>> err;   // two rows
+	int64_t pred[5] = {0, 0, 0, 0, 0};
+	int64_t te_w = 0, te_n = 0, te_nw = 0, te_ne = 0;
+	void init(int w, const WPParams &p) { width = w; params = p; on = true; err.assign((size_t) w * 2, std::array<int64_t, 5>{0, 0, 0, 0, 0}); }
+	static int64_t div24(int64_t i) { return ((int64_t) 1 << 24) / (i + 1); }
+	void before(int x, int y, int64_t pw, int64_t pn, int64_t pnw, int64_t pne, int64_t pnn) {
+		if (!on) return;
+		static const std::array<int64_t, 5> ZERO{0, 0, 0, 0, 0};
+		const std::array<int64_t, 5> *cur = &err[(size_t) ((y & 1) ? width : 0)], *prv = &err[(size_t) ((y & 1) ? 0 : width)];
+		const auto &ew = x > 0 ? cur[x - 1] : ZERO;
+		const auto &en = y > 0 ? prv[x] : ZERO;
+		const auto &enw = x > 0 && y > 0 ? prv[x - 1] : en;
+		const auto &ene = x + 1 < width && y > 0 ? prv[x + 1] : en;
+		const auto &eww = x > 1 ? cur[x - 2] : ZERO;
+		const auto &ew2 = x + 1 < width ? ZERO : ew;
+		te_w = x > 0 ? cur[x - 1][4] : 0;
+		te_n = y > 0 ? prv[x][4] : 0;
+		te_nw = x > 0 && y > 0 ? prv[x - 1][4] : te_n;
+		te_ne = x + 1 < width && y > 0 ? prv[x + 1][4] : te_n;
+		pred[0] = (pw + pne - pn) * 8;
+		pred[1] = pn * 8 - (((te_w + te_n + te_ne) * params.p1) >> 5);
+		pred[2] = pw * 8 - (((te_w + te_n + te_nw) * params.p2) >> 5);
+		pred[3] = pn * 8 - ((te_nw * params.p3[0] + te_n * params.p3[1] + te_ne * params.p3[2] + (pnn - pn) * 8 * params.p3[3] + (pnw - pw) * 8 * params.p3[4]) >> 5);
+		int64_t w[4], wsum = 0, sum = 0;
+		for (int i = 0; i < 4; ++i) {
+			int64_t errsum = en[(size_t) i] + ew[(size_t) i] + enw[(size_t) i] + eww[(size_t) i] + ene[(size_t) i] + ew2[(size_t) i];
+			int shift = std::max(floor_lg64((uint64_t) errsum + 1) - 5, 0);
+			w[i] = 4 + ((int64_t) params.w[i] * div24(errsum >> shift) >> shift);
+		}
+		int logw = floor_lg64((uint64_t) (w[0] + w[1] + w[2] + w[3])) - 4;
+		for (int i = 0; i < 4; ++i) { w[i] >>= logw; wsum += w[i]; sum += pred[i] * w[i]; }
+		pred[4] = (sum + (wsum >> 1) - 1) * div24(wsum - 1) >> 24;
+		if (((te_n ^ te_w) | (te_n ^ te_nw)) <= 0) {
+			int64_t lo = std::min(pw, std::min(pn, pne)) * 8, hi = std::max(pw, std::max(pn, pne)) * 8;
+			pred[4] = std::min(std::max(lo, pred[4]), hi);
+		}
+	}
+	void after(int x, int y, int64_t val) {
+		if (!on) return;
+		auto &e = err[(size_t) ((y & 1) ? width : 0) + (size_t) x];
+		for (int i = 0; i < 4; ++i) { int64_t d = pred[i] - val * 8; e[(size_t) i] = ((d < 0 ? -d : d) + 3) >> 3; }
+		e[4] = pred[4] - val * 8;
+	}
+	static int floor_lg64(uint64_t x) { return 63 - __builtin_clzll(x); }
+};
+
+struct Neigh { int64_t w, n, nw, ne, nn, nee, ww, nww; };
+
+inline Neigh neighbours(const Channel &c, int x, int y) {  // edge rules of j40.h:3981-3988
+	Neigh p;
+	p.w = x > 0 ? c.at(x - 1, y) : y > 0 ? c.at(x, y - 1) : 0;
+	p.n = y > 0 ? c.at(x, y - 1) : p.w;
+	p.nw = x > 0 && y > 0 ? c.at(x - 1, y - 1) : p.w;
+	p.ne = x + 1 < c.w && y > 0 ? c.at(x + 1, y - 1) : p.n;
+	p.nn = y > 1 ? c.at(x, y - 2) : p.n;
+	p.nee = x + 2 < c.w && y > 0 ? c.at(x + 2, y - 1) : p.ne;
+	p.ww = x > 1 ? c.at(x - 2, y) : p.w;
+	p.nww = x > 1 && y > 0 ? c.at(x - 2, y - 1) : p.ww;
+	return p;
+}
+
+inline int64_t clamp_grad(int64_t w, int64_t n, int64_t nw) { int64_t lo = std::min(w, n), hi = std::max(w, n); return std::min(std::max(lo, w + n - nw), hi); }
+
+inline int64_t predict(int pred, const Neigh &p, const WPState &wp) {  // j40.h:4080-4100
+	switch (pred) {
+	case 0: return 0;
+	case 1: return p.w;
+	case 2: return p.n;
+	case 3: return (p.w + p.n) / 2;
+	case 4: return std::llabs(p.n - p.nw) < std::llabs(p.w - p.nw) ? p.w : p.n;
+	case 5: return clamp_grad(p.w, p.n, p.nw);
+	case 6: return (wp.pred[4] + 3) >> 3;
+	case 7: return p.ne;
+	case 8: return p.nw;
+	case 9: return p.ww;
+	case 10: return (p.w + p.nw) / 2;
+	case 11: return (p.n + p.nw) / 2;
+	case 12: return (p.n + p.ne) / 2;
+	case 13: return (6 * p.n - 2 * p.nn + 7 * p.w + p.ww + p.nee + 3 * p.ne + 8) / 16;
+	}
+	die("bad predictor");
+}
+
+// Encodes one channel of a Modular image into `enc` (decode order), mirroring the decoder's tree
+// walk. `chans`/`cidx` give access to previous channels for properties >= 16; `sidx` is the stream
+// index property. `lossy_quant` > 1 quantises residuals (the channel is updated with what the
+// decoder will reconstruct, so later predictions stay in sync).
+inline void encode_channel(const MATree &tree, std::vector<Channel> &chans, int cidx, int64_t sidx, const WPParams &wpp, StreamEncoder &enc) {
+	Channel &c = chans[(size_t) cidx];
+	if (c.w == 0 || c.h == 0) return;
+	WPState wp;
+	if (tree.uses_wp()) wp.init(c.w, wpp);
+	std::vector<int> refc;
+	for (int i = cidx - 1; i >= 0; --i) if (chans[(size_t) i].w == c.w && chans[(size_t) i].h == c.h) refc.push_back(i);
+	for (int y = 0; y < c.h; ++y) for (int x = 0; x < c.w; ++x) {
+		Neigh p = neighbours(c, x, y);
+		wp.before(x, y, p.w, p.n, p.nw, p.ne, p.nn);
+		int id = tree.rootidx;
+		while (tree.nodes[(size_t) id].prop >= 0) {
+			const TreeNode &n = tree.nodes[(size_t) id];
+			int64_t val;
+			switch (n.prop) {
+			case 0: val = cidx; break;
+			case 1: val = sidx; break;
+			case 2: val = y; break;
+			case 3: val = x; break;
+			case 4: val = std::llabs(p.n); break;
+			case 5: val = std::llabs(p.w); break;
+			case 6: val = p.n; break;
+			case 7: val = p.w; break;
+			case 8: val = x > 0 ? p.w - (p.ww + p.nw - p.nww) : p.w; break;
+			case 9: val = p.w + p.n - p.nw; break;
+			case 10: val = p.w - p.nw; break;
+			case 11: val = p.nw - p.n; break;
+			case 12: val = p.n - p.ne; break;
+			case 13: val = p.n - p.nn; break;
+			case 14: val = p.w - p.ww; break;
+			case 15:
+				val = wp.te_w;
+				if (std::llabs(val) < std::llabs(wp.te_n)) val = wp.te_n;
+				if (std::llabs(val) < std::llabs(wp.te_nw)) val = wp.te_nw;
+				if (std::llabs(val) < std::llabs(wp.te_ne)) val = wp.te_ne;
+				break;
+			default: {
+				int r = (n.prop - 16) / 4;
+				if (r >= (int) refc.size()) die("tree references a missing previous channel");
+				const Channel &rc = chans[(size_t) refc[(size_t) r]];
+				val = rc.at(x, y);
+				if ((n.prop - 16) & 2) {
+					int64_t rw = x > 0 ? rc.at(x - 1, y) : 0, rn = y > 0 ? rc.at(x, y - 1) : rw, rnw = x > 0 && y > 0 ? rc.at(x - 1, y - 1) : rw;
+					val -= clamp_grad(rw, rn, rnw);
+				}
+				if ((n.prop - 16) & 1) val = std::llabs(val);
+				// NOTE the reader tests bits of ~prop = prop index; (prop index & 2) / (& 1)
+			} }
+			id = val > n.threshold ? n.left : n.right;
+		}
+		const TreeNode &lf = tree.nodes[(size_t) id];
+		int64_t mult = (int64_t) (lf.mul_bits + 1) << lf.mul_shift;
+		int64_t pr = predict(lf.predictor, p, wp);
+		int64_t target = c.at(x, y);
+		int64_t diff = target - pr - lf.offset;
+		int64_t q = mult == 1 ? diff : (diff >= 0 ? (diff + mult / 2) / mult : -((-diff + mult / 2) / mult));
+		int64_t recon = q * mult + lf.offset + pr;
+		if (recon < -32768 || recon > 32767) die("modular sample out of int16 range");
+		c.at(x, y) = (int32_t) recon;
+		enc.add((uint32_t) lf.ctx, pack_signed((int32_t) q));
+		wp.after(x, y, recon);
+	}
+}
+
+struct TransformW { int kind = 0; int begin_c = 0, rct_type = 0; int num_c = 0, nb_colours = 0, nb_deltas = 0, d_pred = 0; };
+
+// Modular header (j40.h:3730-3819)
+inline void write_modular_header(BitWriter &bw, bool use_global_tree, const WPParams *custom_wp, const std::vector<TransformW> &tr) {
+	bw.put(use_global_tree ? 1 : 0, 1);
+	if (!custom_wp) bw.put(1, 1);
+	else {
+		bw.put(0, 1);
+		bw.put((uint64_t) custom_wp->p1, 5); bw.put((uint64_t) custom_wp->p2, 5);
+		for (int i = 0; i < 5; ++i) bw.put((uint64_t) custom_wp->p3[i], 5);
+		for (int i = 0; i < 4; ++i) bw.put((uint64_t) custom_wp->w[i], 4);
+	}
+	bw.u32((int64_t) tr.size(), 0, 0, 1, 0, 2, 4, 18, 8);
+	for (const TransformW &t : tr) {
+		bw.put((uint64_t) t.kind, 2);
+		if (t.kind == 0) {
+			bw.u32(t.begin_c, 0, 3, 8, 6, 72, 10, 1096, 13);
+			bw.u32(t.rct_type, 6, 0, 0, 2, 2, 4, 10, 6);
+		} else if (t.kind == 1) {
+			bw.u32(t.begin_c, 0, 3, 8, 6, 72, 10, 1096, 13);
+			bw.u32(t.num_c, 1, 0, 3, 0, 4, 0, 1, 13);
+			bw.u32(t.nb_colours, 0, 8, 256, 10, 1280, 12, 5376, 16);
+			bw.u32(t.nb_deltas, 0, 0, 1, 8, 257, 10, 1281, 16);
+			bw.put((uint64_t) t.d_pred, 4);
+		} else die("unsupported transform in writer");
+	}
+}
+
+} // namespace synth
