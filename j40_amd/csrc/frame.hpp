@@ -1,0 +1,128 @@
+// j40_amd/csrc/frame.hpp -- host-side parse of everything in front of the per-group hot path:
+// container, image metadata, frame header, TOC, LfGlobal, HfGlobal/HfPass and the LfGroup sections
+// (LF image, varblock layout, LLF coefficients). Produces the tables the HIP kernels consume.
+//
+// Reference behaviour (all host-only rows of SURVEY.md section 2): j40__container (j40.h:1479),
+// j40__image_metadata (3104), j40__frame_header (5163), j40__read_toc (5479), j40__lf_global (6257),
+// j40__lf_group (6722), j40__hf_global (6819), j40__load_dq_matrix (4828), j40__natural_order (4980).
+#pragma once
+#include "modular.hpp"
+#include <array>
+
+namespace j40hip {
+
+struct ExtraChannel { int32_t type = 0, bpp = 8, exp_bits = 0, dim_shift = 0; bool alpha_associated = false; };
+enum { EC_ALPHA = 0, EC_SPOT = 2, EC_BLACK = 4, EC_CFA = 5 };
+
+struct ImageMeta {
+	int32_t width = 0, height = 0;
+	int32_t bpp = 8, exp_bits = 0;
+	bool have_animation = false, anim_have_timecodes = false;
+	bool modular_16bit_buffers = true;
+	std::vector<ExtraChannel> ec;
+	bool xyb_encoded = true, want_icc = false, grey = false;
+	float intensity_target = 255.0f;
+	float opsin_inv_mat[3][3];
+	float opsin_bias[3];
+	float quant_bias[3];
+	float quant_bias_num = 0.145f;
+};
+
+struct FrameHeader {
+	bool is_last = true;
+	int32_t type = 0;
+	bool is_modular = false;
+	bool has_noise = false, has_patches = false, has_splines = false, use_lf_frame = false, skip_adapt_lf_smooth = false;
+	bool do_ycbcr = false;
+	int32_t jpeg_upsampling = 0;
+	int32_t group_size_shift = 8;
+	int32_t x_qm_scale = 3, b_qm_scale = 2;
+	int32_t num_passes = 1;
+	int32_t x0 = 0, y0 = 0, width = 0, height = 0;
+	int32_t grows = 0, gcolumns = 0, ggrows = 0, ggcolumns = 0;
+	int64_t num_groups = 0, num_lf_groups = 0;
+};
+
+struct Section { size_t offset = 0, size = 0; };  // byte range inside the codestream
+
+struct Toc {
+	bool single = false;
+	Section single_section;               // when the frame has exactly one section
+	Section lf_global, hf_global;
+	std::vector<Section> lf_groups;       // [num_lf_groups]
+	std::vector<Section> pass_groups;     // [num_passes * num_groups], pass-major
+	size_t end_offset = 0;
+};
+
+struct DqMatrix {
+	int32_t mode = 0;                     // 0 library, 7 raw, else the coded parameter form
+	int32_t n = 0, m = 0;
+	std::vector<std::array<float, 3>> params;
+	bool loaded = false;                  // expanded to one weight per coefficient
+};
+
+struct VarblockInfo { int32_t coeffoff_qfidx; float hfmul_inv; int32_t x8, y8, dctsel; };
+
+struct LfGroup {
+	int32_t idx = 0, left = 0, top = 0, width = 0, height = 0, width8 = 0, height8 = 0, width64 = 0, height64 = 0;
+	std::vector<int32_t> blocks;          // [height8 * width8]: (dctsel + 2) << 20 | varblock, 1 << 20 | varblock
+	std::vector<uint8_t> lfindices;       // [height8 * width8]
+	std::vector<VarblockInfo> varblocks;
+	std::vector<float> llfcoeffs[3];      // [height8 * width8], indexed by coefficient offset / 64
+	std::vector<int16_t> xfromy, bfromy;  // [height64 * width64]
+	bool loaded = false;
+};
+
+struct Frame {
+	ImageMeta im;
+	FrameHeader fh;
+	Toc toc;
+
+	// LfGlobal
+	float m_lf_scaled[3] = {1.0f / 4096.0f, 1.0f / 512.0f, 1.0f / 256.0f};
+	int32_t global_scale = 0, quant_lf = 0;
+	int32_t lf_thr[3][15], qf_thr[15];
+	int32_t nb_lf_thr[3] = {0, 0, 0}, nb_qf_thr = 0;
+	std::vector<uint8_t> block_ctx_map;
+	int32_t nb_block_ctx = 0;
+	float inv_colour_factor = 1.0f / 84.0f, base_corr_x = 0.0f, base_corr_b = 1.0f;
+	int32_t x_factor_lf = 0, b_factor_lf = 0;
+	std::vector<TreeNode> global_tree;
+	CodeSpec global_codespec;
+	Modular gmodular;                     // frame-sized Modular image (Modular frames, extra channels)
+	int32_t num_gm_channels = 0;          // channels already decoded inside LfGlobal
+	// where the not-yet-decoded global Modular pixel data would start is irrelevant: it is decoded here
+
+	// HfGlobal / HfPass
+	DqMatrix dq_matrix[17];
+	int32_t num_hf_presets = 0;
+	std::vector<int32_t> order_lehmer[11][13][3];
+	bool order_has_lehmer[11][13][3];
+	std::vector<int32_t> orders[11][13][3];   // expanded coefficient orders (only those in use)
+	CodeSpec coeff_codespec[11];
+	uint32_t dct_select_used = 0, order_used = 0;
+
+	std::vector<LfGroup> lf_groups;
+	size_t single_pass_group_bitpos = 0;  // single-section VarDCT frames: where the pass group starts
+};
+
+// locates the codestream inside `data` (bare codestream or ISOBMFF container); if the codestream is
+// split over several boxes it is reassembled into `storage`
+void extract_codestream(const uint8_t *data, size_t size, const uint8_t **cs, size_t *cs_size, std::vector<uint8_t> *storage);
+
+// parses headers, TOC, LfGlobal, HfGlobal and every LfGroup section. `threads` > 1 decodes LfGroup
+// sections concurrently (they are independent given LfGlobal)
+void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads);
+
+struct GroupInfo { int32_t ggidx, gx_in_gg, gy_in_gg, gw, gh; };
+GroupInfo group_info(const FrameHeader &fh, int64_t gidx);  // j40.h:7734
+
+struct DctSelect { int8_t log_rows, log_columns, param_idx, order_idx; };
+extern const DctSelect DCT_SELECT[27];
+extern const int8_t LOG_ORDER_SIZE[13][2];
+
+void natural_order(int32_t log_rows, int32_t log_columns, std::vector<int32_t> *out);
+void load_dq_matrix(int32_t idx, DqMatrix *dq);
+void forward_dct2d_scaled_for_llf(float *buf, float *scratch, int32_t log_rows, int32_t log_columns);
+
+} // namespace j40hip

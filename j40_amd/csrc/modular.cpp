@@ -1,0 +1,427 @@
+// j40_amd/csrc/modular.cpp -- see modular.hpp
+#include "modular.hpp"
+#include <algorithm>
+
+namespace j40hip {
+
+void read_tree(BitReader &br, int32_t max_tree_size, int32_t depth_limit, std::vector<TreeNode> *tree, CodeSpec *codespec) {  // j40.h:3461
+	CodeSpec treespec;
+	read_code_spec(br, 6, &treespec);
+	CodeState code(&treespec);
+	std::vector<TreeNode> t;
+	int32_t ctx_id = 0, nodes_left = 1, depth = 0, nodes_upto_this_depth = 1;
+	while (nodes_left-- > 0) {  // nodes arrive level by level
+		if ((int32_t) t.size() == nodes_upto_this_depth) {
+			J40HIP_SHOULD(++depth <= depth_limit, "tlim");
+			nodes_upto_this_depth += nodes_left + 1;
+		}
+		int32_t prop = decode_symbol(br, code, 1, 0);
+		TreeNode n;
+		if (prop > 0) {
+			n.prop = prop - 1;
+			n.value = unpack_signed(decode_symbol(br, code, 0, 0));
+			n.a = ++nodes_left;
+			n.b = ++nodes_left;
+		} else {
+			int32_t predictor = decode_symbol(br, code, 2, 0);
+			n.prop = -1 - predictor;
+			n.value = ctx_id++;
+			n.a = unpack_signed(decode_symbol(br, code, 3, 0));
+			int32_t shift = decode_symbol(br, code, 4, 0);
+			J40HIP_SHOULD(shift < 31, "tree");
+			int32_t val = decode_symbol(br, code, 5, 0);
+			J40HIP_SHOULD(((val + 1) >> (31 - shift)) == 0, "tree");
+			n.b = (val + 1) << shift;
+		}
+		t.push_back(n);
+		J40HIP_SHOULD((int64_t) t.size() + nodes_left <= max_tree_size, "tlim");
+	}
+	finish_code(br, code);
+	read_code_spec(br, ctx_id, codespec);
+	tree->swap(t);
+}
+
+bool tree_uses_wp(const std::vector<TreeNode> &tree) {  // j40.h:4142-4152
+	for (const TreeNode &n : tree) if (n.prop == 15 || n.prop == -1 - 6) return true;
+	return false;
+}
+
+static bool equal_sized(const Plane *b, const Plane *e) {  // j40.h:1094
+	if (b >= e) return false;
+	const Plane &c = *b;
+	bool shift_should_match = c.vshift >= 0 && c.hshift >= 0;
+	for (const Plane *p = b + 1; p < e; ++p) {
+		if (c.width != p->width || c.height != p->height) return false;
+		if (shift_should_match && (c.vshift != p->vshift || c.hshift != p->hshift)) return false;
+	}
+	return true;
+}
+
+void read_modular_header(BitReader &br, const std::vector<TreeNode> *global_tree, const CodeSpec *global_codespec, Modular *m) {  // j40.h:3717
+	std::vector<Plane> &channel = m->channel;
+	int32_t nb_meta = 0;
+	m->use_global_tree = br.u(1);
+	J40HIP_SHOULD(!m->use_global_tree || (global_tree && !global_tree->empty()), "mtre");
+	if (!br.u(1)) {  // custom weighted-predictor parameters
+		m->wp.p1 = (int8_t) br.u(5); m->wp.p2 = (int8_t) br.u(5);
+		for (int i = 0; i < 5; ++i) m->wp.p3[i] = (int8_t) br.u(5);
+		for (int i = 0; i < 4; ++i) m->wp.w[i] = (int8_t) br.u(4);
+	}
+	int32_t nb_transforms = br.u32(0, 0, 1, 0, 2, 4, 18, 8);
+	J40HIP_SHOULD(nb_transforms <= 8, "xlim");  // level-5 limit, j40.h:1173
+	for (int32_t i = 0; i < nb_transforms; ++i) {
+		Transform tr;
+		tr.kind = (Transform::Kind) br.u(2);
+		int32_t num_channels = (int32_t) channel.size();
+		switch (tr.kind) {
+		case Transform::RCT: {
+			tr.begin_c = br.u32(0, 3, 8, 6, 72, 10, 1096, 13);
+			tr.rct_type = br.u32(6, 0, 0, 2, 2, 4, 10, 6);
+			J40HIP_SHOULD(tr.rct_type < 42, "rctt");
+			J40HIP_SHOULD(tr.begin_c + 3 <= num_channels, "rctc");
+			J40HIP_SHOULD(tr.begin_c >= nb_meta || tr.begin_c + 3 <= nb_meta, "rctc");
+			J40HIP_SHOULD(equal_sized(channel.data() + tr.begin_c, channel.data() + tr.begin_c + 3), "rtcd");
+			break;
+		}
+		case Transform::PALETTE: {
+			tr.begin_c = br.u32(0, 3, 8, 6, 72, 10, 1096, 13);
+			tr.num_c = br.u32(1, 0, 3, 0, 4, 0, 1, 13);
+			int32_t end_c = tr.begin_c + tr.num_c;
+			tr.nb_colours = br.u32(0, 8, 256, 10, 1280, 12, 5376, 16);
+			tr.nb_deltas = br.u32(0, 0, 1, 8, 257, 10, 1281, 16);
+			tr.d_pred = (int32_t) br.u(4);
+			J40HIP_SHOULD(tr.d_pred < 14, "palp");
+			J40HIP_SHOULD(end_c <= num_channels, "palc");
+			if (tr.begin_c < nb_meta) { J40HIP_SHOULD(end_c <= nb_meta, "palc"); nb_meta += 2 - tr.num_c; }
+			else nb_meta += 1;
+			J40HIP_SHOULD(equal_sized(channel.data() + tr.begin_c, channel.data() + end_c), "pald");
+			Plane input = channel[(size_t) tr.begin_c], pal;
+			pal.width = tr.nb_colours; pal.height = tr.num_c; pal.hshift = 0; pal.vshift = -1;
+			std::vector<Plane> next;
+			next.push_back(pal);
+			next.insert(next.end(), channel.begin(), channel.begin() + tr.begin_c);
+			next.push_back(input);
+			next.insert(next.end(), channel.begin() + end_c, channel.end());
+			channel.swap(next);
+			break;
+		}
+		case Transform::SQUEEZE:
+			J40HIP_RAISE("TODO");  // the reference stops here as well (j40.h:3812)
+		default: J40HIP_RAISE("xfm?");
+		}
+		m->transforms.push_back(tr);
+	}
+	J40HIP_SHOULD((int32_t) channel.size() <= 256, "xlim");
+	if (m->use_global_tree) {
+		m->tree = global_tree; m->codespec = global_codespec;
+	} else {
+		int64_t max_tree_size = 1024;
+		for (const Plane &c : channel) max_tree_size += (int64_t) c.width * c.height;
+		if (max_tree_size > (1 << 20)) max_tree_size = 1 << 20;
+		read_tree(br, (int32_t) max_tree_size, 64, &m->own_tree, &m->own_codespec);
+		m->tree = &m->own_tree; m->codespec = &m->own_codespec;
+	}
+	m->nb_meta_channels = nb_meta;
+	m->dist_mult = 0;
+	for (size_t i = (size_t) nb_meta; i < channel.size(); ++i) m->dist_mult = std::max(m->dist_mult, channel[i].width);
+	m->dist_mult = std::min(m->dist_mult, 1 << 21);
+}
+
+void allocate_modular(Modular *m) { for (Plane &c : m->channel) c.allocate(); }
+
+// ------------------------------------------------------------------------------------------------
+// prediction (16-bit buffers: samples int16, intermediates int32; j40.h:3938-4125 with P = 16)
+
+namespace {
+
+struct Neigh { int32_t w, n, nw, ne, nn, nee, ww, nww; };
+
+inline Neigh neighbours(const Plane &c, int32_t x, int32_t y) {  // j40.h:3965
+	const int16_t *px = c.row(y); const int32_t stride = c.width, width = c.width;
+	Neigh p;
+	p.w = x > 0 ? px[x - 1] : y > 0 ? px[x - stride] : 0;
+	p.n = y > 0 ? px[x - stride] : p.w;
+	p.nw = x > 0 && y > 0 ? px[(x - 1) - stride] : p.w;
+	p.ne = x + 1 < width && y > 0 ? px[(x + 1) - stride] : p.n;
+	p.nn = y > 1 ? px[x - 2 * stride] : p.n;
+	p.nee = x + 2 < width && y > 0 ? px[(x + 2) - stride] : p.ne;
+	p.ww = x > 1 ? px[x - 2] : p.w;
+	p.nww = x > 1 && y > 0 ? px[(x - 2) - stride] : p.ww;
+	return p;
+}
+
+inline int32_t clamped_gradient(int32_t w, int32_t n, int32_t nw) {
+	int32_t lo = std::min(w, n), hi = std::max(w, n);
+	return std::min(std::max(lo, w + n - nw), hi);
+}
+
+inline int32_t div24(int32_t i) { return (int32_t) (((int64_t) 1 << 24) / (i + 1)); }  // J40__24DIVP1, j40.h:3905
+
+struct WeightedPredictor {  // j40.h:3997-4119
+	bool on = false;
+	int32_t width = 0;
+	WPParams params;
+	std::vector<int32_t> errors;  // [2 * width][5]
+	int32_t pred[5] = {0, 0, 0, 0, 0};
+	int32_t trueerrw = 0, trueerrn = 0, trueerrnw = 0, trueerrne = 0;
+
+	void init(const WPParams &p, int32_t w) { on = true; width = w; params = p; errors.assign((size_t) w * 10, 0); reset_scalars(); }
+	void reset_scalars() { for (int i = 0; i < 5; ++i) pred[i] = 0; trueerrw = trueerrn = trueerrnw = trueerrne = 0; }
+	void reset() { if (on) std::fill(errors.begin(), errors.end(), 0); reset_scalars(); }
+
+	void before_predict(int32_t x, int32_t y, const Neigh &p) {
+		if (!on) return;
+		static const int32_t ZERO[5] = {0, 0, 0, 0, 0};
+		const int32_t *err = errors.data() + (size_t) ((y & 1) ? width : 0) * 5;
+		const int32_t *nerr = errors.data() + (size_t) ((y & 1) ? 0 : width) * 5;
+		const int32_t *errw = x > 0 ? err + (x - 1) * 5 : ZERO;
+		const int32_t *errn = y > 0 ? nerr + x * 5 : ZERO;
+		const int32_t *errnw = x > 0 && y > 0 ? nerr + (x - 1) * 5 : errn;
+		const int32_t *errne = x + 1 < width && y > 0 ? nerr + (x + 1) * 5 : errn;
+		const int32_t *errww = x > 1 ? err + (x - 2) * 5 : ZERO;
+		const int32_t *errw2 = x + 1 < width ? ZERO : errw;
+		trueerrw = x > 0 ? err[(x - 1) * 5 + 4] : 0;
+		trueerrn = y > 0 ? nerr[x * 5 + 4] : 0;
+		trueerrnw = x > 0 && y > 0 ? nerr[(x - 1) * 5 + 4] : trueerrn;
+		trueerrne = x + 1 < width && y > 0 ? nerr[(x + 1) * 5 + 4] : trueerrn;
+		pred[0] = (p.w + p.ne - p.n) * 8;
+		pred[1] = p.n * 8 - (((trueerrw + trueerrn + trueerrne) * params.p1) >> 5);
+		pred[2] = p.w * 8 - (((trueerrw + trueerrn + trueerrnw) * params.p2) >> 5);
+		pred[3] = p.n * 8 - ((trueerrnw * params.p3[0] + trueerrn * params.p3[1] + trueerrne * params.p3[2] +
+			(p.nn - p.n) * 8 * params.p3[3] + (p.nw - p.w) * 8 * params.p3[4]) >> 5);
+		int32_t w[4], wsum = 0, sum = 0;
+		for (int i = 0; i < 4; ++i) {
+			int32_t errsum = errn[i] + errw[i] + errnw[i] + errww[i] + errne[i] + errw2[i];
+			int32_t shift = std::max(floor_lg32((uint32_t) errsum + 1) - 5, 0);
+			w[i] = (int32_t) (4 + ((int64_t) params.w[i] * div24(errsum >> shift) >> shift));
+		}
+		int32_t logw = floor_lg32((uint32_t) (w[0] + w[1] + w[2] + w[3])) - 4;
+		for (int i = 0; i < 4; ++i) { w[i] >>= logw; wsum += w[i]; sum += pred[i] * w[i]; }
+		pred[4] = (int32_t) (((int64_t) sum + (wsum >> 1) - 1) * div24(wsum - 1) >> 24);
+		if (((trueerrn ^ trueerrw) | (trueerrn ^ trueerrnw)) <= 0) {
+			int32_t lo = std::min(p.w, std::min(p.n, p.ne)) * 8, hi = std::max(p.w, std::max(p.n, p.ne)) * 8;
+			pred[4] = std::min(std::max(lo, pred[4]), hi);
+		}
+	}
+	void after_predict(int32_t x, int32_t y, int32_t val) {
+		if (!on) return;
+		int32_t *e = errors.data() + ((size_t) ((y & 1) ? width : 0) + (size_t) x) * 5;
+		for (int i = 0; i < 4; ++i) { int32_t d = pred[i] - val * 8; e[i] = ((d < 0 ? -d : d) + 3) >> 3; }
+		e[4] = pred[4] - val * 8;
+	}
+};
+
+inline int32_t predict(int32_t predictor, const WeightedPredictor &wp, const Neigh &p) {  // j40.h:4080
+	switch (predictor) {
+	case 0: return 0;
+	case 1: return p.w;
+	case 2: return p.n;
+	case 3: return (p.w + p.n) / 2;
+	case 4: return std::abs(p.n - p.nw) < std::abs(p.w - p.nw) ? p.w : p.n;
+	case 5: return clamped_gradient(p.w, p.n, p.nw);
+	case 6: return (wp.pred[4] + 3) >> 3;
+	case 7: return p.ne;
+	case 8: return p.nw;
+	case 9: return p.ww;
+	case 10: return (p.w + p.nw) / 2;
+	case 11: return (p.n + p.nw) / 2;
+	case 12: return (p.n + p.ne) / 2;
+	case 13: return (6 * p.n - 2 * p.nn + 7 * p.w + p.ww + p.nee + 3 * p.ne + 8) / 16;
+	default: J40HIP_RAISE("pred");
+	}
+}
+
+} // namespace
+
+void decode_modular_channel(BitReader &br, Modular &m, CodeState &code, int32_t cidx, int64_t sidx) {  // j40.h:4127
+	Plane &c = m.channel[(size_t) cidx];
+	if (c.empty()) return;
+	const TreeNode *tree = m.tree->data();
+	WeightedPredictor wp;
+	if (tree_uses_wp(*m.tree)) wp.init(m.wp, c.width);
+	std::vector<int32_t> refc;  // earlier channels with identical geometry, nearest first (j40.h:4156-4165)
+	for (int32_t i = cidx - 1; i >= 0; --i) {
+		const Plane &r = m.channel[(size_t) i];
+		if (c.width != r.width || c.height != r.height || c.hshift != r.hshift || c.vshift != r.vshift) continue;
+		refc.push_back(i);
+	}
+	for (int32_t y = 0; y < c.height; ++y) {
+		int16_t *out = c.row(y);
+		for (int32_t x = 0; x < c.width; ++x) {
+			const TreeNode *n = tree;
+			Neigh p = neighbours(c, x, y);
+			wp.before_predict(x, y, p);
+			while (n->prop >= 0) {
+				int32_t val;
+				switch (n->prop) {
+				case 0: val = cidx; break;
+				case 1: val = (int32_t) sidx; break;
+				case 2: val = y; break;
+				case 3: val = x; break;
+				case 4: val = std::abs(p.n); break;
+				case 5: val = std::abs(p.w); break;
+				case 6: val = p.n; break;
+				case 7: val = p.w; break;
+				case 8: val = x > 0 ? p.w - (p.ww + p.nw - p.nww) : p.w; break;
+				case 9: val = p.w + p.n - p.nw; break;
+				case 10: val = p.w - p.nw; break;
+				case 11: val = p.nw - p.n; break;
+				case 12: val = p.n - p.ne; break;
+				case 13: val = p.n - p.nn; break;
+				case 14: val = p.w - p.ww; break;
+				case 15:
+					val = wp.trueerrw;
+					if (std::abs(val) < std::abs(wp.trueerrn)) val = wp.trueerrn;
+					if (std::abs(val) < std::abs(wp.trueerrnw)) val = wp.trueerrnw;
+					if (std::abs(val) < std::abs(wp.trueerrne)) val = wp.trueerrne;
+					break;
+				default: {
+					int32_t r = (n->prop - 16) / 4;
+					J40HIP_SHOULD(r < (int32_t) refc.size(), "trec");
+					const Plane &rc = m.channel[(size_t) refc[(size_t) r]];
+					val = rc.row(y)[x];
+					if (n->prop & 2) {
+						int32_t rw = x > 0 ? rc.row(y)[x - 1] : 0;
+						int32_t rn = y > 0 ? rc.row(y - 1)[x] : rw;
+						int32_t rnw = x > 0 && y > 0 ? rc.row(y - 1)[x - 1] : rw;
+						val -= clamped_gradient(rw, rn, rnw);
+					}
+					if (n->prop & 1) val = std::abs(val);
+				} }
+				n += val > n->value ? n->a : n->b;
+			}
+			int32_t v = decode_symbol(br, code, n->value, m.dist_mult);
+			v = unpack_signed(v) * n->b + n->a;
+			v += predict(-1 - n->prop, wp, p);
+			J40HIP_SHOULD(-32768 <= v && v <= 32767, "povf");
+			out[x] = (int16_t) v;
+			wp.after_predict(x, y, v);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// inverse transforms
+
+static void inverse_rct(Modular &m, const Transform &tr) {  // j40.h:4318
+	static const uint8_t PERM[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
+	Plane c[3];
+	for (int i = 0; i < 3; ++i) c[i] = std::move(m.channel[(size_t) (tr.begin_c + i)]);
+	if (!c[0].empty()) {
+		const size_t n = c[0].px.size();
+		int16_t *p0 = c[0].px.data(), *p1 = c[1].px.data(), *p2 = c[2].px.data();
+		switch (tr.rct_type % 7) {
+		case 0: break;
+		case 1: for (size_t i = 0; i < n; ++i) p2[i] = (int16_t) (p2[i] + p0[i]); break;
+		case 2: for (size_t i = 0; i < n; ++i) p2[i] = (int16_t) (p1[i] + p0[i]); break;
+		case 3: for (size_t i = 0; i < n; ++i) { p1[i] = (int16_t) (p1[i] + p0[i]); p2[i] = (int16_t) (p2[i] + p0[i]); } break;
+		case 4: for (size_t i = 0; i < n; ++i) { int16_t a = p0[i], b = p2[i]; p1[i] = (int16_t) (p1[i] + (int16_t) (a / 2 + b / 2 + (a & b & 1))); } break;
+		case 5: for (size_t i = 0; i < n; ++i) { p1[i] = (int16_t) ((int32_t) p1[i] + p0[i] + (p2[i] >> 1)); p2[i] = (int16_t) (p2[i] + p0[i]); } break;
+		case 6:
+			for (size_t i = 0; i < n; ++i) {
+				int32_t tmp = (int32_t) p0[i] - ((int32_t) p2[i] >> 1);
+				int32_t q1 = (int32_t) p2[i] + tmp;
+				int32_t q2 = tmp - ((int32_t) p1[i] >> 1);
+				p0[i] = (int16_t) (q2 + p1[i]); p1[i] = (int16_t) q1; p2[i] = (int16_t) q2;
+			}
+			break;
+		}
+	}
+	for (int i = 0; i < 3; ++i) m.channel[(size_t) (tr.begin_c + PERM[tr.rct_type / 7][i])] = std::move(c[i]);
+}
+
+// the spec's 72 palette delta triples; entry 2k is triple k, entry 2k + 1 its negation (j40.h:4275)
+static const int16_t PALETTE_DELTA_BASE[72][3] = {
+	{0, 0, 0}, {4, 4, 4}, {11, 0, 0}, {0, 0, -13}, {0, -12, 0}, {-10, -10, -10}, {-18, -18, -18}, {-27, -27, -27},
+	{-18, -18, 0}, {0, 0, -32}, {-32, 0, 0}, {-37, -37, -37}, {0, -32, -32}, {24, 24, 45}, {50, 50, 50}, {-45, -24, -24},
+	{-24, -45, -45}, {0, -24, -24}, {-34, -34, 0}, {-24, 0, -24}, {-45, -45, -24}, {64, 64, 64}, {-32, 0, -32}, {0, -32, 0},
+	{-32, 0, 32}, {-24, -45, -24}, {45, 24, 45}, {24, -24, -45}, {-45, -24, 24}, {80, 80, 80}, {64, 0, 0}, {0, 0, -64},
+	{0, -64, -64}, {-24, -24, 45}, {96, 96, 96}, {64, 64, 0}, {45, -24, -24}, {34, -34, 0}, {112, 112, 112}, {24, -45, -45},
+	{45, 45, -24}, {0, -32, 32}, {24, -24, 45}, {0, 96, 96}, {45, -24, 24}, {24, -45, -24}, {-24, -45, 24}, {0, -64, 0},
+	{96, 0, 0}, {128, 128, 128}, {64, 0, 64}, {144, 144, 144}, {96, 96, 0}, {-36, -36, 36}, {45, -24, -45}, {45, -45, -24},
+	{0, 0, -96}, {0, 128, 128}, {0, 96, 0}, {45, 24, -45}, {-128, 0, 0}, {24, -45, 24}, {-45, 24, -45}, {64, 0, -64},
+	{64, -64, -64}, {96, 0, 96}, {45, -45, 24}, {24, 45, -45}, {64, 64, -64}, {128, 128, 0}, {0, 0, -128}, {-24, 45, -45},
+};
+int16_t palette_delta(int32_t entry, int32_t channel) {
+	int16_t v = PALETTE_DELTA_BASE[entry >> 1][channel];
+	return (entry & 1) ? (int16_t) -v : v;
+}
+
+static void inverse_palette(Modular &m, const Transform &tr) {  // j40.h:4402
+	const int32_t first = tr.begin_c + 1, bpp = m.bpp;
+	const int32_t width = m.channel[(size_t) first].width, height = m.channel[(size_t) first].height;
+	const bool use_pred = tr.nb_deltas > 0, use_wp = use_pred && tr.d_pred == 6;
+	const bool index_empty = m.channel[(size_t) first].empty();
+	// make room: the index channel ends up as the last restored colour channel
+	for (int32_t i = 0; i < tr.num_c - 1; ++i) {
+		Plane p; p.width = width; p.height = height;
+		if (!index_empty) p.allocate(); else { p.width = p.height = 0; }
+		m.channel.insert(m.channel.begin() + first, std::move(p));
+	}
+	const int32_t last = tr.begin_c + tr.num_c;
+	WeightedPredictor wp;
+	if (use_wp) wp.init(m.wp, width);
+	if (!index_empty) for (int32_t i = 0; i < tr.num_c; ++i) {
+		const int16_t *palp = tr.nb_colours > 0 ? m.channel[0].row(i) : nullptr;
+		Plane &c = m.channel[(size_t) (first + i)];
+		Plane &idxc = m.channel[(size_t) last];
+		for (int32_t y = 0; y < height; ++y) {
+			const int16_t *idxline = idxc.row(y);
+			int16_t *line = c.row(y);
+			for (int32_t x = 0; x < width; ++x) {
+				int16_t idx = idxline[x], val;
+				const bool is_delta = idx < tr.nb_deltas;
+				if (idx < 0) {
+					if (i < 3) {
+						idx = (int16_t) (~idx % 143);
+						val = palette_delta(idx + 1, i);
+						if (bpp > 8) val = (int16_t) (val << (std::min(bpp, 24) - 8));
+					} else val = 0;
+				} else if (idx < tr.nb_colours) {
+					val = palp[idx];
+				} else {
+					idx = (int16_t) (idx - tr.nb_colours);
+					if (idx < 64) {
+						val = (int16_t) ((i < 3 ? idx >> (2 * i) : 0) * (((int32_t) 1 << bpp) - 1) / 4 + ((int32_t) 1 << std::max(0, bpp - 3)));
+					} else {
+						val = (int16_t) (idx - 64);
+						for (int32_t j = 0; j < i; ++j) val = (int16_t) (val / 5);
+						val = (int16_t) ((val % 5) * ((1 << bpp) - 1) / 4);
+					}
+				}
+				if (use_pred) {
+					Neigh p = neighbours(c, x, y);
+					wp.before_predict(x, y, p);
+					if (is_delta) val = (int16_t) (val + predict(tr.d_pred, wp, p));
+					wp.after_predict(x, y, val);
+				}
+				line[x] = val;
+			}
+		}
+		wp.reset();
+	}
+	m.channel.erase(m.channel.begin());
+}
+
+void inverse_transforms(Modular &m) {  // j40.h:4506
+	if (m.channel.empty()) return;
+	for (size_t i = m.transforms.size(); i-- > 0; ) {
+		const Transform &tr = m.transforms[i];
+		switch (tr.kind) {
+		case Transform::RCT: inverse_rct(m, tr); break;
+		case Transform::PALETTE: inverse_palette(m, tr); break;
+		default: J40HIP_RAISE("TODO");
+		}
+	}
+}
+
+void decode_modular_image(BitReader &br, const std::vector<TreeNode> *global_tree, const CodeSpec *global_codespec, int64_t sidx, Modular *m) {
+	read_modular_header(br, global_tree, global_codespec, m);
+	allocate_modular(m);
+	CodeState code(m->codespec);
+	for (int32_t c = 0; c < (int32_t) m->channel.size(); ++c) decode_modular_channel(br, *m, code, c, sidx);
+	finish_code(br, code);
+	inverse_transforms(*m);
+}
+
+} // namespace j40hip
