@@ -1,0 +1,43 @@
+# Builds the product library (build/libj40hip.so: host parser + HIP kernels for gfx950 + public API),
+# the synthetic stream generator (build/jxlsynth) and the checkers under oracle/.
+ROCM ?= /opt/rocm
+HIPCC ?= $(ROCM)/bin/hipcc
+CXX ?= g++
+ARCH ?= gfx950
+CXXFLAGS = -std=c++17 -O2 -fPIC -Wall -Wextra -ffp-contract=off -fvisibility=hidden
+HIPFLAGS = --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -Wall
+SRC = j40_amd/csrc
+HOST_OBJS = build/obj/plan_build.o build/obj/entropy.o build/obj/modular.o build/obj/tables.o build/obj/frame.o build/obj/capi_host.o build/obj/api.o
+DEV_OBJS = build/obj/kernels.o build/obj/runtime.o
+
+.PHONY: all lib tools oracle hostsim clean
+all: lib tools hostsim oracle
+lib: build/libj40hip.so
+tools: build/jxlsynth
+oracle:
+	$(MAKE) -C oracle all
+
+build/obj/%.o: $(SRC)/%.cpp $(wildcard $(SRC)/*.hpp) include/j40hip.h include/j40.h
+	@mkdir -p build/obj
+	$(CXX) $(CXXFLAGS) -c $< -o $@
+
+build/obj/%.o: $(SRC)/device/%.hip $(wildcard $(SRC)/device/*.h) $(wildcard $(SRC)/*.hpp) include/j40hip.h
+	@mkdir -p build/obj
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+build/libj40hip.so: $(HOST_OBJS) $(DEV_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^ -lpthread
+
+hostsim: build/libhostsim.so
+# device functions compiled for the CPU, test infrastructure only (tests/hostsim)
+build/libhostsim.so: tests/hostsim/hostsim.cpp $(SRC)/plan_build.cpp $(SRC)/entropy.cpp $(SRC)/modular.cpp $(SRC)/tables.cpp $(SRC)/frame.cpp $(wildcard $(SRC)/device/*.h) $(wildcard $(SRC)/*.hpp)
+	@mkdir -p build
+	$(CXX) -std=c++17 -O2 -fPIC -shared -ffp-contract=off -Wall -Wextra -Wno-unused-function -o $@ tests/hostsim/hostsim.cpp $(SRC)/plan_build.cpp $(SRC)/entropy.cpp $(SRC)/modular.cpp $(SRC)/tables.cpp $(SRC)/frame.cpp -lpthread
+
+build/jxlsynth: tools/jxlsynth.cpp $(wildcard tools/*.hpp)
+	@mkdir -p build
+	$(CXX) -O2 -std=c++17 -Wall -Wextra -o $@ $<
+
+clean:
+	rm -rf build
+	$(MAKE) -C oracle clean

@@ -1,0 +1,267 @@
+"""j40_amd -- Python host-side mirror of the j40 C API on top of libj40hip.so (MI355X / gfx950).
+
+Thin ctypes plumbing only: the product is build/libj40hip.so (C++ host parser + HIP kernels). The
+module fails loudly when the library is missing -- there is no Python or CPU fallback for the hot
+path. Function names mirror the reference's public API (j40.h:233-272):
+
+    img = j40_amd.from_memory(data)      # j40_from_memory
+    img.output_format(J40_RGBA, J40_U8X4)
+    if img.next_frame():                 # j40_next_frame
+        rgba = img.frame_pixels_u8x4()   # j40_current_frame + j40_frame_pixels_u8x4 (numpy view copy)
+    img.error(), img.error_string(); img.free()
+
+`Frame` exposes the thin C-ABI of include/j40hip.h (parse / upload / decode on a stream / status /
+stage dumps) for the parity tests, bench.py and the multi-GPU driver.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+J40_RGBA = 0x1755
+J40_U8X4 = 0x0F33
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_ROOT, "build", "libj40hip.so")
+_lib = None
+
+
+class J40Error(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = code
+        super().__init__("j40 error %r %s" % (code, where))
+
+
+def err4(code):
+    return "".join(chr((code >> s) & 0xFF) for s in (24, 16, 8, 0)) if code else ""
+
+
+class _Image(C.Structure):
+    class _U(C.Union):
+        _fields_ = [("inner", C.c_void_p), ("err", C.c_uint32), ("saved_errno", C.c_int)]
+    _fields_ = [("magic", C.c_uint32), ("u", _U)]
+
+
+class _FrameHandle(C.Structure):
+    _fields_ = [("magic", C.c_uint32), ("reserved", C.c_uint32), ("inner", C.c_void_p)]
+
+
+class _Pixels(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("stride_bytes", C.c_int32), ("data", C.c_void_p)]
+
+
+def lib():
+    """loads build/libj40hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libj40hip.so is missing at %s: run `make lib` (or __graft_entry__.build())" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u32, i32, i64, sz = C.c_void_p, C.c_uint32, C.c_int32, C.c_int64, C.c_size_t
+    sigs = {
+        "j40_error": (u32, [vp]), "j40_error_string": (C.c_char_p, [vp]),
+        "j40_from_memory": (u32, [vp, vp, sz, vp]), "j40_from_file": (u32, [vp, C.c_char_p]),
+        "j40_output_format": (u32, [vp, i32, i32]), "j40_next_frame": (C.c_int, [vp]),
+        "j40_current_frame": (_FrameHandle, [vp]), "j40_frame_pixels_u8x4": (_Pixels, [vp, i32]),
+        "j40_row_u8x4": (vp, [_Pixels, i32]), "j40_free": (None, [vp]),
+        "j40hip_frame_parse": (vp, [vp, sz, C.c_int, C.POINTER(u32)]), "j40hip_frame_free": (None, [vp]),
+        "j40hip_frame_info": (None, [vp, vp]), "j40hip_frame_codestream_size": (sz, [vp]), "j40hip_frame_num_sections": (i64, [vp]),
+        "j40hip_frame_lf_group_info": (None, [vp, i64, vp]), "j40hip_frame_lf_group_plane": (C.c_int, [vp, i64, C.c_int, vp]),
+        "j40hip_frame_varblocks": (None, [vp, i64, vp, vp]), "j40hip_frame_llf": (None, [vp, i64, C.c_int, vp]),
+        "j40hip_frame_dq_matrix": (i32, [vp, C.c_int, vp]), "j40hip_frame_order": (i32, [vp, C.c_int, C.c_int, C.c_int, vp]),
+        "j40hip_frame_block_ctx_map": (i32, [vp, vp]), "j40hip_frame_global_plane": (C.c_int, [vp, C.c_int, vp, C.POINTER(i32), C.POINTER(i32)]),
+        "j40hip_kat_natural_order": (i32, [i32, i32, vp]), "j40hip_kat_library_dq_matrix": (i32, [C.c_int, vp]),
+        "j40hip_kat_forward_llf": (None, [vp, i32, i32]), "j40hip_kat_half_secant": (C.c_float, [C.c_int]),
+        "j40hip_kat_lf2llf_scale": (C.c_float, [C.c_int]),
+        "j40hip_device_count": (C.c_int, []), "j40hip_frame_upload": (u32, [vp, C.c_int]),
+        "j40hip_frame_set_group_range": (u32, [vp, i64, i64]), "j40hip_frame_decode": (u32, [vp, vp, sz, vp]),
+        "j40hip_frame_status": (u32, [vp]), "j40hip_frame_decode_to_host": (u32, [vp, vp, sz]),
+        "j40hip_frame_read_coeffs": (u32, [vp, i64, C.c_int, vp]), "j40hip_frame_read_plane_i16": (u32, [vp, C.c_int, vp]),
+        "j40hip_frame_decode_timed": (u32, [vp, vp, sz, vp, vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(L, name)  # AttributeError = the library does not export what include/*.h declares
+        fn.restype = res
+        fn.argtypes = args
+    L._declared = sorted(sigs)
+    _lib = L
+    return L
+
+
+def device_count():
+    return lib().j40hip_device_count()
+
+
+class Image:
+    """mirror of a j40_image handle and the public API calls on it"""
+
+    def __init__(self):
+        self._img = _Image()
+        self._buf = None
+        self._live = False
+
+    def error(self):
+        return err4(lib().j40_error(C.byref(self._img)))
+
+    def error_string(self):
+        return lib().j40_error_string(C.byref(self._img)).decode()
+
+    def output_format(self, channel=J40_RGBA, fmt=J40_U8X4):
+        return err4(lib().j40_output_format(C.byref(self._img), channel, fmt))
+
+    def next_frame(self):
+        return bool(lib().j40_next_frame(C.byref(self._img)))
+
+    def frame_pixels_u8x4(self, channel=J40_RGBA):
+        """returns a numpy copy [height, width, 4] of the rendered frame (or of the error placeholder)"""
+        L = lib()
+        fr = L.j40_current_frame(C.byref(self._img))
+        px = L.j40_frame_pixels_u8x4(C.byref(fr), channel)
+        rows = np.ctypeslib.as_array(C.cast(px.data, C.POINTER(C.c_uint8)), shape=(px.height, px.stride_bytes))
+        return rows[:, : px.width * 4].reshape(px.height, px.width, 4).copy(), px.stride_bytes, px.data
+
+    def free(self):
+        if self._live:
+            lib().j40_free(C.byref(self._img))
+            self._live = False
+
+
+def from_memory(data: bytes) -> Image:
+    img = Image()
+    img._buf = C.create_string_buffer(data, len(data))  # borrowed by the library until free()
+    lib().j40_from_memory(C.byref(img._img), img._buf, len(data), None)
+    img._live = True
+    return img
+
+
+def from_file(path: str) -> Image:
+    img = Image()
+    lib().j40_from_file(C.byref(img._img), path.encode())
+    img._live = True
+    return img
+
+
+def decode(data: bytes):
+    """whole path through the public API; returns (err4, rgba ndarray or None)"""
+    img = from_memory(data)
+    img.output_format()
+    out = None
+    if img.next_frame():
+        out = img.frame_pixels_u8x4()[0]
+    err = img.error()
+    img.free()
+    return err, out
+
+
+INFO_FIELDS = ["width", "height", "is_modular", "num_lf_groups", "num_groups", "num_passes", "nb_block_ctx", "block_ctx_size",
+               "num_hf_presets", "global_scale", "quant_lf", "x_qm_scale", "b_qm_scale", "nb_qf_thr", "nb_lf_thr0", "nb_lf_thr1",
+               "nb_lf_thr2", "group_size_shift", "bpp", "num_extra_channels", "xyb_encoded"]
+
+
+class Frame:
+    """thin C-ABI (include/j40hip.h): host parse, plan upload, hot path on a HIP stream"""
+
+    def __init__(self, data: bytes, threads: int = 4):
+        L = lib()
+        self._buf = C.create_string_buffer(data, len(data))
+        err = C.c_uint32()
+        self.h = L.j40hip_frame_parse(self._buf, len(data), threads, C.byref(err))
+        if not self.h:
+            raise J40Error(err4(err.value), "in j40hip_frame_parse")
+        info = np.zeros(32, np.int64)
+        L.j40hip_frame_info(self.h, info.ctypes.data)
+        self.info = dict(zip(INFO_FIELDS, info.tolist()))
+        self.width, self.height = self.info["width"], self.info["height"]
+        self.codestream_size = L.j40hip_frame_codestream_size(self.h)
+
+    def close(self):
+        if self.h:
+            lib().j40hip_frame_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, code, where):
+        if code:
+            raise J40Error(err4(code), where)
+
+    def upload(self, device=0):
+        self._chk(lib().j40hip_frame_upload(self.h, device), "in j40hip_frame_upload")
+
+    def set_group_range(self, first, count):
+        self._chk(lib().j40hip_frame_set_group_range(self.h, first, count), "in j40hip_frame_set_group_range")
+
+    def decode(self, rgba_ptr, stride_bytes, stream=0):
+        self._chk(lib().j40hip_frame_decode(self.h, rgba_ptr, stride_bytes, stream), "in j40hip_frame_decode")
+
+    def decode_timed(self, rgba_ptr, stride_bytes, stream=0):
+        ms = np.zeros(3, np.float32)
+        self._chk(lib().j40hip_frame_decode_timed(self.h, rgba_ptr, stride_bytes, stream, ms.ctypes.data), "in j40hip_frame_decode_timed")
+        return ms
+
+    def status(self):
+        return err4(lib().j40hip_frame_status(self.h))
+
+    def decode_to_host(self):
+        out = np.zeros((self.height, self.width, 4), np.uint8)
+        code = lib().j40hip_frame_decode_to_host(self.h, out.ctypes.data, self.width * 4)
+        return err4(code), out
+
+    # ---- stage accessors ----
+    def lf_group_info(self, gg):
+        a = np.zeros(9, np.int32)
+        lib().j40hip_frame_lf_group_info(self.h, gg, a.ctypes.data)
+        return dict(zip(["left", "top", "width", "height", "width8", "height8", "width64", "height64", "nb_varblocks"], a.tolist()))
+
+    def plane(self, gg, which):
+        gi = self.lf_group_info(gg)
+        shape, dt = {0: ((gi["height8"], gi["width8"]), np.int32), 1: ((gi["height8"], gi["width8"]), np.uint8),
+                     2: ((gi["height64"], gi["width64"]), np.int16), 3: ((gi["height64"], gi["width64"]), np.int16)}[which]
+        a = np.zeros(shape, dt)
+        assert lib().j40hip_frame_lf_group_plane(self.h, gg, which, a.ctypes.data) == 0
+        return a
+
+    def varblocks(self, gg):
+        n = self.lf_group_info(gg)["nb_varblocks"]
+        a, b = np.zeros(n, np.int32), np.zeros(n, np.float32)
+        lib().j40hip_frame_varblocks(self.h, gg, a.ctypes.data, b.ctypes.data)
+        return a, b
+
+    def llf(self, gg, c):
+        gi = self.lf_group_info(gg)
+        a = np.zeros(gi["height8"] * gi["width8"], np.float32)
+        lib().j40hip_frame_llf(self.h, gg, c, a.ctypes.data)
+        return a
+
+    def dq_matrix(self, idx):
+        a = np.zeros((65536, 3), np.float32)
+        n = lib().j40hip_frame_dq_matrix(self.h, idx, a.ctypes.data)
+        return a[:n].copy()
+
+    def order(self, p, idx, c):
+        a = np.zeros(65536, np.int32)
+        n = lib().j40hip_frame_order(self.h, p, idx, c, a.ctypes.data)
+        return a[:n].copy()
+
+    def block_ctx_map(self):
+        a = np.zeros(4096, np.uint8)
+        n = lib().j40hip_frame_block_ctx_map(self.h, a.ctypes.data)
+        return a[:n].copy()
+
+    def global_plane(self, c):
+        w, h = C.c_int32(), C.c_int32()
+        if lib().j40hip_frame_global_plane(self.h, c, None, C.byref(w), C.byref(h)) != 0:
+            return None
+        a = np.zeros((h.value, w.value), np.int16)
+        lib().j40hip_frame_global_plane(self.h, c, a.ctypes.data, C.byref(w), C.byref(h))
+        return a
+
+    def read_coeffs(self, gg, c):
+        gi = self.lf_group_info(gg)
+        a = np.zeros(gi["height8"] * gi["width8"] * 64, np.float32)
+        self._chk(lib().j40hip_frame_read_coeffs(self.h, gg, c, a.ctypes.data), "in j40hip_frame_read_coeffs")
+        return a

@@ -1,0 +1,252 @@
+// j40_amd/csrc/api.cpp -- the public j40 C API (include/j40.h) on top of the host parser and the HIP
+// hot path. Handle states, magic numbers, error strings and the placeholder image follow the
+// reference's observable behaviour (j40.h:7970-8119, 8245-8477).
+#define J40_API __attribute__((visibility("default")))
+#include "../../include/j40.h"
+#include "capi.hpp"
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+using namespace j40hip;
+
+namespace {
+
+enum : uint32_t {
+	IMAGE_MAGIC = 0x7867ae21u, IMAGE_ERR_MAGIC = 0xb26a48aau, IMAGE_OPEN_ERR_MAGIC = 0x02c2eb6du,
+	FRAME_MAGIC = 0x08a296b3u, FRAME_ERR_MAGIC = 0x16351564u, INNER_MAGIC = 0x5009e1c4u,
+};
+
+enum Origin { O_NONE = 0, O_NEXT, O_from_file, O_from_memory, O_output_format, O_next_frame, O_current_frame, O_frame_pixels, O_error_string, O_free, O_LAST_ALT = O_from_memory };
+const char *const ORIGIN_NAMES[] = {"(unknown)", nullptr, "from_file", "from_memory", "output_format", "next_frame", "current_frame", "frame_pixels_*", "error_string", "free"};
+
+const struct { const char *err, *msg; } ERROR_STRINGS[] = {
+	{"Upt0", "`path` parameter is NULL"}, {"Ubf0", "`buf` parameter is NULL"}, {"Uch?", "Bad `channel` parameter"},
+	{"Ufm?", "Bad `format` parameter"}, {"Uof?", "Bad `channel` and `format` combination"}, {"Urnd", "Frame is not yet rendered"},
+	{"Ufre", "Trying to reuse already freed image"}, {"!mem", "Out of memory"}, {"!jxl", "The JPEG XL signature is not found"},
+	{"open", "Failed to open file"}, {"bigg", "Image dimensions are too large to handle"}, {"flen", "File is too lengthy to handle"},
+	{"shrt", "Premature end of file"}, {"slim", "Image size limit reached"}, {"elim", "Extra channel number limit reached"},
+	{"xlim", "Modular transform limit reached"}, {"tlim", "Meta-adaptive tree size or depth limit reached"},
+	{"plim", "ICC profile length limit reached"}, {"fbpp", "Given bits per pixel value is disallowed"},
+	{"fblk", "Black extra channel is disallowed"}, {"fm32", "32-bit buffers for modular encoding are disallowed"},
+	{"TODO", "Unimplemented feature encountered"}, {"TEST", "Testing-only error occurred"},
+	{"!gpu", "No usable HIP device (the hot path has no CPU fallback)"},
+};
+
+uint32_t code4(const char *s) { return ((uint32_t) (uint8_t) s[0] << 24) | ((uint32_t) (uint8_t) s[1] << 16) | ((uint32_t) (uint8_t) s[2] << 8) | (uint32_t) (uint8_t) s[3]; }
+
+} // namespace
+
+struct j40__inner {
+	uint32_t magic;
+	int origin;
+	j40_err err;
+	int saved_errno;
+	char errbuf[256];
+	void *buf; size_t size; j40_memory_free_func freefunc;   // borrowed input
+	void *owned;                                             // file contents (from_file)
+	j40hip_frame *frame;
+	int decoded, rendered;
+	uint8_t *pixels; int32_t width, height, stride_bytes;
+};
+
+namespace {
+
+j40_err set_alt_magic(j40_err err, int saved_errno, int origin, j40_image *image) {  // j40.h:8083
+	if (err == code4("open")) { image->magic = IMAGE_OPEN_ERR_MAGIC ^ (uint32_t) origin; image->u.saved_errno = saved_errno; return err; }
+	image->magic = IMAGE_ERR_MAGIC ^ (uint32_t) origin;
+	return image->u.err = err;
+}
+
+j40_err check_image(j40_image *image, int neworigin, j40__inner **out) {  // j40.h:8103
+	*out = nullptr;
+	if (!image) return code4("Uim0");
+	if (image->magic != IMAGE_MAGIC) {
+		uint32_t origin = image->magic ^ IMAGE_ERR_MAGIC;
+		if (0 < origin && origin <= O_LAST_ALT) {
+			if (origin == O_NEXT && neworigin) image->magic = IMAGE_ERR_MAGIC ^ (uint32_t) neworigin;
+			return image->u.err;
+		}
+		origin = image->magic ^ IMAGE_OPEN_ERR_MAGIC;
+		if (0 < origin && origin <= O_LAST_ALT) return code4("open");
+		return code4("Uim?");
+	}
+	if (!image->u.inner || image->u.inner->magic != INNER_MAGIC) return code4("Uim?");
+	*out = image->u.inner;
+	return image->u.inner->err;
+}
+
+void free_inner(j40__inner *inner) {
+	if (inner->frame) j40hip_frame_free(inner->frame);
+	if (inner->freefunc && inner->buf) inner->freefunc(inner->buf);
+	free(inner->owned);
+	free(inner->pixels);
+	inner->magic = 0;
+	free(inner);
+}
+
+j40__inner *new_inner() {
+	j40__inner *inner = (j40__inner *) calloc(1, sizeof(j40__inner));
+	if (inner) inner->magic = INNER_MAGIC;
+	return inner;
+}
+
+// the whole decode: host parse, upload, hot path on the GPU, RGBA into the image-owned plane
+j40_err advance(j40__inner *inner, int origin) {
+	if (inner->decoded) return 0;
+	uint32_t err = 0;
+	inner->frame = j40hip_frame_parse(inner->buf, inner->size, 4, &err);
+	if (!err) {
+		int64_t info[32];
+		j40hip_frame_info(inner->frame, info);
+		inner->width = (int32_t) info[0]; inner->height = (int32_t) info[1];
+		int64_t stride = ((int64_t) inner->width * 4 + 1 + 31) / 32 * 32;       // forced padding, j40.h:1061-1065, 7939
+		if (inner->width >= INT32_MAX / 4 || stride > INT32_MAX) err = code4("bigg");
+		else {
+			inner->stride_bytes = (int32_t) stride;
+			void *p = nullptr;
+			if (posix_memalign(&p, 32, (size_t) stride * (size_t) inner->height)) err = code4("!mem");
+			else inner->pixels = (uint8_t *) p;
+		}
+	}
+	if (!err) {
+		const char *dev = getenv("J40HIP_DEVICE");
+		err = j40hip_frame_upload(inner->frame, dev ? atoi(dev) : 0);
+	}
+	if (!err) err = j40hip_frame_decode_to_host(inner->frame, inner->pixels, (size_t) inner->stride_bytes);
+	if (err) { inner->origin = origin; inner->err = err; return err; }
+	inner->decoded = 1;
+	return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+j40_err j40_error(const j40_image *image) {
+	j40__inner *inner;
+	return check_image((j40_image *) image, O_NONE, &inner);
+}
+
+const char *j40_error_string(const j40_image *image) {  // j40.h:8251
+	static char static_errbuf[256];
+	uint32_t origin = O_NONE; j40_err err = 0; char *buf = nullptr; int saved_errno = 0; bool corrupted = false;
+	if (!image) { snprintf(static_errbuf, sizeof static_errbuf, "`image` parameter is NULL during j40_error_string"); return static_errbuf; }
+	if (image->magic == IMAGE_MAGIC) {
+		if (image->u.inner && image->u.inner->magic == INNER_MAGIC) { origin = (uint32_t) image->u.inner->origin; err = image->u.inner->err; buf = image->u.inner->errbuf; saved_errno = image->u.inner->saved_errno; }
+		else corrupted = true;
+	} else {
+		origin = image->magic ^ IMAGE_ERR_MAGIC;
+		if (0 < origin && origin <= O_LAST_ALT) { err = image->u.err; buf = static_errbuf; if (origin == O_NEXT) origin = O_error_string; }
+		else {
+			origin = image->magic ^ IMAGE_OPEN_ERR_MAGIC;
+			if (0 < origin && origin <= O_LAST_ALT) { err = code4("open"); buf = static_errbuf; saved_errno = image->u.saved_errno; }
+			else corrupted = true;
+		}
+	}
+	if (corrupted) { snprintf(static_errbuf, sizeof static_errbuf, "`image` parameter is found corrupted during j40_error_string"); return static_errbuf; }
+	const char *msg = nullptr;
+	for (const auto &e : ERROR_STRINGS) if (err == code4(e.err)) { msg = e.msg; break; }
+	if (!msg) snprintf(buf, 256, "Decoding failed (%c%c%c%c) during j40_%s", err >> 24 & 0xff, err >> 16 & 0xff, err >> 8 & 0xff, err & 0xff, ORIGIN_NAMES[origin]);
+	else if (saved_errno) snprintf(buf, 256, "%s during j40_%s: %s", msg, ORIGIN_NAMES[origin], strerror(saved_errno));
+	else snprintf(buf, 256, "%s during j40_%s", msg, ORIGIN_NAMES[origin]);
+	return buf;
+}
+
+j40_err j40_from_memory(j40_image *image, void *buf, size_t size, j40_memory_free_func freefunc) {
+	if (!image) return code4("Uim0");
+	if (!buf) return set_alt_magic(code4("Ubf0"), 0, O_from_memory, image);
+	j40__inner *inner = new_inner();
+	if (!inner) return set_alt_magic(code4("!mem"), 0, O_from_memory, image);
+	inner->buf = buf; inner->size = size; inner->freefunc = freefunc;
+	image->magic = IMAGE_MAGIC; image->u.inner = inner;
+	return 0;
+}
+
+j40_err j40_from_file(j40_image *image, const char *path) {
+	if (!image) return code4("Uim0");
+	if (!path) return set_alt_magic(code4("Upt0"), 0, O_from_file, image);
+	j40__inner *inner = new_inner();
+	if (!inner) return set_alt_magic(code4("!mem"), 0, O_from_file, image);
+	int saved = errno;
+	errno = 0;
+	FILE *fp = fopen(path, "rb");
+	if (!fp) { int e = errno; errno = saved; free_inner(inner); return set_alt_magic(code4("open"), e, O_from_file, image); }
+	std::vector<uint8_t> data; uint8_t chunk[65536]; size_t n;
+	while ((n = fread(chunk, 1, sizeof chunk, fp)) > 0) data.insert(data.end(), chunk, chunk + n);
+	fclose(fp);
+	errno = saved;
+	inner->owned = malloc(data.size() ? data.size() : 1);
+	if (!inner->owned) { free_inner(inner); return set_alt_magic(code4("!mem"), 0, O_from_file, image); }
+	memcpy(inner->owned, data.data(), data.size());
+	inner->buf = inner->owned; inner->size = data.size(); inner->freefunc = nullptr;
+	image->magic = IMAGE_MAGIC; image->u.inner = inner;
+	return 0;
+}
+
+j40_err j40_output_format(j40_image *image, int32_t channel, int32_t format) {
+	j40__inner *inner;
+	j40_err err = check_image(image, O_output_format, &inner);
+	if (err) return err;
+	if (channel != J40_RGBA) { inner->origin = O_output_format; return inner->err = code4("Uch?"); }
+	if (format != J40_U8X4) { inner->origin = O_output_format; return inner->err = code4("Ufm?"); }
+	return 0;
+}
+
+int j40_next_frame(j40_image *image) {
+	j40__inner *inner;
+	if (check_image(image, O_next_frame, &inner)) return 0;
+	if (advance(inner, O_next_frame)) return 0;
+	if (inner->rendered) return 0;  // single-frame images: the second call reports "no more frames" (j40.h:8390)
+	inner->rendered = 1;
+	return 1;
+}
+
+j40_frame j40_current_frame(j40_image *image) {
+	j40__inner *inner;
+	j40_frame frame;
+	j40_err err = check_image(image, O_current_frame, &inner);
+	frame.magic = FRAME_ERR_MAGIC; frame.reserved = 0; frame.inner = inner;
+	if (err) return frame;
+	if (!inner->rendered) { if (!j40_next_frame(image)) { if (inner->err) return frame; } }
+	frame.magic = FRAME_MAGIC;
+	return frame;
+}
+
+j40_pixels_u8x4 j40_frame_pixels_u8x4(const j40_frame *frame, int32_t channel) {
+	// placeholder shown on error: "ERR" on red, 21 x 7 (same picture as j40.h:8432-8441); 1 = opaque
+	static const char *const ERR_ROWS[7] = {
+		"111111111111111111111", "100011111111111111111", "101111111111111111111", "100010001000100010001",
+		"101110111011101010111", "100010111011100010111", "111111111111111111111"};
+	static uint8_t error_pixels[21 * 7 * 4];
+	static bool error_pixels_ready = false;
+	if (!error_pixels_ready) {
+		for (int y = 0; y < 7; ++y) for (int x = 0; x < 21; ++x) { uint8_t *p = error_pixels + (y * 21 + x) * 4; p[0] = 255; p[1] = 0; p[2] = 0; p[3] = ERR_ROWS[y][x] == '1' ? 255 : 0; }
+		error_pixels_ready = true;
+	}
+	const j40_pixels_u8x4 ERROR_PIXELS = {21, 7, 21 * 4, error_pixels};
+	if (!frame || frame->magic != FRAME_MAGIC) return ERROR_PIXELS;
+	j40__inner *inner = frame->inner;
+	if (!inner || inner->magic != INNER_MAGIC) return ERROR_PIXELS;
+	if (channel != J40_RGBA) return ERROR_PIXELS;
+	if (!inner->rendered) { inner->origin = O_frame_pixels; inner->err = code4("Urnd"); return ERROR_PIXELS; }
+	j40_pixels_u8x4 px;
+	px.width = inner->width; px.height = inner->height; px.stride_bytes = inner->stride_bytes; px.data = inner->pixels;
+	return px;
+}
+
+const j40_u8x4 *j40_row_u8x4(j40_pixels_u8x4 pixels, int32_t y) {
+	return (const j40_u8x4 *) ((const char *) pixels.data + (size_t) pixels.stride_bytes * (size_t) y);
+}
+
+void j40_free(j40_image *image) {
+	j40__inner *inner;
+	check_image(image, O_free, &inner);
+	if (inner) free_inner(inner);
+	if (!image) return;
+	image->magic = IMAGE_ERR_MAGIC ^ O_NEXT;
+	image->u.err = code4("Ufre");
+}
+
+} // extern "C"

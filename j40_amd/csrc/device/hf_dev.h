@@ -1,0 +1,106 @@
+// j40_amd/csrc/device/hf_dev.h -- K1: HF coefficient decode of one group (all passes), sequential per
+// lane. Restates j40__pass_group / j40__hf_coeffs (j40.h:7007-7041, 6888-7005) on the flat plan.
+//
+// Work item = one 256x256 group; its passes are decoded back to back by the same lane so the
+// `coeffs[order[i]] += value` accumulation (j40.h:6989) needs no atomics.
+#pragma once
+#include "entropy_dev.h"
+
+namespace j40hip {
+
+// DctSelect -> log rows, log columns, coefficient order (spec table, cf. j40.h:4591)
+#ifdef __HIPCC__
+__device__
+#endif
+static const int8_t DEV_DCT_SELECT[27][3] = {
+	{3, 3, 0}, {3, 3, 1}, {3, 3, 1}, {3, 3, 1}, {4, 4, 2}, {5, 5, 3}, {4, 3, 4}, {3, 4, 4}, {5, 3, 5}, {3, 5, 5}, {5, 4, 6}, {4, 5, 6}, {3, 3, 1}, {3, 3, 1},
+	{3, 3, 1}, {3, 3, 1}, {3, 3, 1}, {3, 3, 1}, {6, 6, 7}, {6, 5, 8}, {5, 6, 8}, {7, 7, 9}, {7, 6, 10}, {6, 7, 10}, {8, 8, 11}, {8, 7, 12}, {7, 8, 12},
+};
+
+// coefficient context tables, pre-doubled (spec constants; cf. j40.h:6935-6947)
+#ifdef __HIPCC__
+__device__
+#endif
+static const int8_t DEV_FREQ_CTX2[64] = {
+	-1, 0, 2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 30, 32, 32, 34, 34, 36, 36, 38, 38, 40, 40, 42, 42, 44, 44,
+	46, 46, 46, 46, 48, 48, 48, 48, 50, 50, 50, 50, 52, 52, 52, 52, 54, 54, 54, 54, 56, 56, 56, 56, 58, 58, 58, 58, 60, 60, 60, 60,
+};
+#ifdef __HIPCC__
+__device__
+#endif
+static const int16_t DEV_NNZ_CTX2[64] = {
+	0, 0, 62, 124, 124, 186, 186, 186, 186, 246, 246, 246, 246, 304, 304, 304, 304, 304, 304, 304, 304, 360, 360, 360, 360, 360, 360, 360, 360, 360, 360, 360,
+	360, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412,
+};
+
+J40_DEV int32_t unpack_signed_dev(int32_t x) { return (x & 1) ? -(x / 2 + 1) : x / 2; }
+
+// decodes the HF coefficients of group `g` for every pass; returns nothing, errors go to plan.status
+J40_DEV void decode_hf_group(const DevPlan &plan, int32_t g) {
+	const DevFrame &f = *plan.frame;
+	int8_t *nonzeros = plan.nonzeros + (size_t) g * (32 * 32 * 3);
+	int32_t *window = plan.lz_window ? plan.lz_window + (size_t) g * plan.lz_window_size : nullptr;
+	const uint8_t *block_ctx_map = plan.pool_u8 + plan.block_ctx_map_off;
+	for (int32_t pass = 0; pass < f.num_passes; ++pass) {
+		const DevSection &sec = plan.sections[pass * f.num_groups + g];
+		const DevLfGroup &gg = plan.lf_groups[sec.ggidx];
+		DevBits b;
+		bits_init(b, plan.codestream, sec.byte_off, sec.size, sec.bit_off);
+		const uint32_t preset = bits_u(b, f.preset_bits);
+		if ((int32_t) preset >= f.num_hf_presets) bits_set_error(b, ERR_RNGE);
+		const int32_t ctxoff = 495 * f.nb_block_ctx * (int32_t) preset;
+		DevCode code;
+		code_init(code, plan, plan.coeff_specs + pass, window);
+		const int32_t gw8 = sec.gw8, gh8 = sec.gh8;
+		for (int32_t y8 = 0; y8 < gh8 && !b.err; ++y8) for (int32_t x8 = 0; x8 < gw8 && !b.err; ++x8) {
+			const int32_t cell = gg.cell_base + (sec.gy8 + y8) * gg.width8 + (sec.gx8 + x8);
+			const int32_t blk = plan.blocks[cell];
+			int32_t dctsel = blk >> 20;
+			if (dctsel < 2) continue;  // not the top-left cell of a varblock
+			dctsel -= 2;
+			const int32_t voff = gg.vb_base + (blk & 0xfffff);
+			const int32_t log_rows = DEV_DCT_SELECT[dctsel][0], log_columns = DEV_DCT_SELECT[dctsel][1], order_idx = DEV_DCT_SELECT[dctsel][2];
+			const int32_t log_size = log_rows + log_columns;
+			const int32_t cq = plan.vb_coeffoff_qfidx[voff];
+			const int32_t coeffoff = cq & ~15, qfidx = cq & 15;
+			const int32_t lfidx = plan.lfindices[cell];
+			const int32_t bctx0 = (order_idx * (f.nb_qf_thr + 1) + qfidx) * f.lfidx_size + lfidx;
+			const int32_t bctxc = 13 * (f.nb_qf_thr + 1) * f.lfidx_size;
+			const int32_t nzpos = y8 * gw8 + x8;
+			for (int32_t c_yxb = 0; c_yxb < 3 && !b.err; ++c_yxb) {
+				const int32_t c = c_yxb == 0 ? 1 : c_yxb == 1 ? 0 : 2;
+				float *coeffs = plan.coeffs[c] + (size_t) gg.cell_base * 64 + coeffoff;
+				const uint32_t ooff = f.order_off[(pass * 13 + order_idx) * 3 + c];
+				const uint16_t *order = plan.pool_u16 + ooff;
+				const int32_t bctx = block_ctx_map[bctx0 + bctxc * c_yxb];
+				// number of non-zeros, predicted from the left / top blocks (j40.h:6959-6967)
+				int32_t nz;
+				if (x8 > 0) nz = y8 > 0 ? (nonzeros[(nzpos - 1) * 3 + c] + nonzeros[(nzpos - gw8) * 3 + c] + 1) >> 1 : nonzeros[(nzpos - 1) * 3 + c];
+				else nz = y8 > 0 ? nonzeros[(nzpos - gw8) * 3 + c] : 32;
+				const int32_t nzctx = ctxoff + bctx + (nz < 8 ? nz : 4 + nz / 2) * f.nb_block_ctx;
+				nz = code_symbol(b, code, nzctx, 0, plan.lz_window_size);
+				if (nz > (63 << (log_size - 6))) { bits_set_error(b, ERR_COEF); break; }
+				const int32_t qnz = (nz + (1 << (log_size - 6)) - 1) >> (log_size - 6);
+				for (int32_t i = 0; i < (1 << (log_rows - 3)); ++i) for (int32_t j = 0; j < (1 << (log_columns - 3)); ++j)
+					nonzeros[(nzpos + i * gw8 + j) * 3 + c] = (int8_t) qnz;
+				const int32_t cctx = ctxoff + 458 * bctx + 37 * f.nb_block_ctx;
+				int32_t prev = nz <= (1 << (log_size - 4));
+				const int32_t size = 1 << log_size, shift = log_size - 6;
+				for (int32_t i = 1 << shift; nz > 0 && i < size; ++i) {
+					const int32_t ctx = cctx + DEV_NNZ_CTX2[(nz + (1 << shift) - 1) >> shift] + DEV_FREQ_CTX2[i >> shift] + prev;
+					const int32_t ucoeff = code_symbol(b, code, ctx, 0, plan.lz_window_size);
+					if (ucoeff) coeffs[order[i]] += (float) unpack_signed_dev(ucoeff);
+					prev = ucoeff != 0;
+					nz -= prev;
+					if (b.err) break;
+				}
+				if (nz != 0) bits_set_error(b, ERR_COEF);
+			}
+		}
+		if (!b.err) code_finish(b, code);
+		if (!b.err) bits_finish_section(b);
+		plan.status[pass * f.num_groups + g] = b.err;
+	}
+}
+
+} // namespace j40hip

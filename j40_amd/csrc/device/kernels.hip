@@ -1,0 +1,278 @@
+// j40_amd/csrc/device/kernels.hip -- the HIP kernels of the VarDCT hot path for gfx950.
+//
+//   k_hf_entropy        K1: one sequential rANS/prefix stream per lane, one 256x256 group per lane
+//                       (replaces j40__pass_group -> j40__hf_coeffs, j40.h:7007 / 6888)
+//   k_vardct_dct<R,C>   K2: dequantise + chroma-from-luma + 2-D inverse DCT in LDS + XYB->sRGB + pack,
+//                       NB varblocks per workgroup (replaces j40__dequant_hf, j40.h:7053,
+//                       j40__combine_vardct_from_lf_group, j40.h:7099, j40__render_to_u8x4_rgba, j40.h:7910)
+//   k_vardct_special    K2s: the 8x8 "special" transforms (Hornuss, DCT2x2, DCT4x4, DCT4x8/8x4, AFV)
+//   k_vardct_large      K2l: 128/256-sized transforms, butterflies swept through an HBM scratch
+//
+// Compiled with -ffp-contract=off: the float path has to keep the reference's operation order.
+#include <hip/hip_runtime.h>
+#include "hf_dev.h"
+#include "idct_dev.h"
+#include "vardct_dev.h"
+#include "kernels.h"
+
+namespace j40hip {
+
+__constant__ float c_half_secants[256];
+__constant__ float c_afv_basis[256];
+
+void upload_constant_tables(const float *half_secants, const float *afv_basis, hipStream_t stream) {
+	(void) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_half_secants), half_secants, sizeof(float) * 256, 0, hipMemcpyHostToDevice, stream);
+	(void) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_afv_basis), afv_basis, sizeof(float) * 256, 0, hipMemcpyHostToDevice, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1
+
+// `lanes` sections per wavefront: lane l < lanes of wave w handles group first_group + w * lanes + l.
+// lanes = 1 keeps each sequential decoder alone on its wave (lowest latency per section);
+// larger values trade latency for occupancy when a launch carries many more sections than the chip
+// has wave slots.
+__global__ void __launch_bounds__(64) k_hf_entropy(DevPlan plan, int32_t first_group, int32_t num_groups, int32_t lanes) {
+	const int32_t lane = threadIdx.x;
+	if (lane >= lanes) return;
+	const int32_t idx = blockIdx.x * lanes + lane;
+	if (idx >= num_groups) return;
+	decode_hf_group(plan, first_group + idx);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 common pieces
+
+// ------------------------------------------------------------------------------------------------
+// K2: DCT family up to 64x64. LDS tile per (varblock, channel): rows x (columns + 1) floats, element
+// (r, c) = vertical frequency r, horizontal frequency c. Pass 1: one lane per row r transforms along
+// c in registers; pass 2: one lane per column x transforms along r. Both walk LDS conflict-free
+// thanks to the odd pitch. Arithmetic = j40__inverse_dct2d (j40.h:5972): IDCT over the columns
+// dimension first, then over rows.
+
+template <int LOGR, int LOGC, int NB>
+__global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarblock *list, int32_t count, int32_t param_idx, uint8_t *rgba, size_t stride_bytes) {
+	constexpr int R = 1 << LOGR, C = 1 << LOGC, P = C + 1, TILE = R * P;
+	constexpr int LONG = R > C ? R : C;                  // columns of the canonical (short side = rows) layout
+	constexpr int VH8 = (R < C ? R : C) / 8, VW8 = LONG / 8;
+	extern __shared__ __attribute__((aligned(16))) float lds[];   // [NB][3][TILE]
+	const DevFrame &f = *plan.frame;
+	const int32_t tid = threadIdx.x, nthreads = blockDim.x;
+	const int32_t first = blockIdx.x * NB;
+	const int32_t nb = min(NB, count - first);
+	const float *dq = plan.pool_f32 + f.dq_off[param_idx];
+	const int32_t dq_size = R * C;
+	__shared__ VbGeom geom[NB];
+	if (tid < nb) geom[tid] = varblock_geometry(plan, list[first + tid], R, C);
+	__syncthreads();
+
+	// ---- load: coalesced over the coefficient index ----
+	for (int32_t w = tid; w < nb * R * C; w += nthreads) {
+		const int32_t b = w / (R * C), i = w - b * (R * C);
+		const VbGeom &g = geom[b];
+		float v[3];
+		load_coeff3(plan, g, dq, dq_size, i, LONG, VH8, VW8, v);
+		// canonical index -> (r, c): the array is [R][C] when C > R, else [C][R] (j40.h:5978-5985)
+		const int32_t r = C > R ? i / C : i % R, c = C > R ? i % C : i / R;
+		float *t = lds + (size_t) b * 3 * TILE + r * P + c;
+		t[0] = v[0]; t[TILE] = v[1]; t[2 * TILE] = v[2];
+	}
+	__syncthreads();
+	// ---- pass 1: IDCT of length C along c, one lane per (block, channel, r) ----
+	for (int32_t w = tid; w < nb * 3 * R; w += nthreads) {
+		float *row = lds + (size_t) (w / R) * TILE + (w % R) * P;
+		float x[C];
+#pragma unroll
+		for (int k = 0; k < C; ++k) x[k] = row[k];
+		Idct1D<C>::run(x, c_half_secants);
+#pragma unroll
+		for (int k = 0; k < C; ++k) row[k] = x[k];
+	}
+	__syncthreads();
+	// ---- pass 2: IDCT of length R along r, one lane per (block, channel, x) ----
+	for (int32_t w = tid; w < nb * 3 * C; w += nthreads) {
+		float *col = lds + (size_t) (w / C) * TILE + (w % C);
+		float x[R];
+#pragma unroll
+		for (int k = 0; k < R; ++k) x[k] = col[k * P];
+		Idct1D<R>::run(x, c_half_secants);
+#pragma unroll
+		for (int k = 0; k < R; ++k) col[k * P] = x[k];
+	}
+	__syncthreads();
+	// ---- colour + pack: one lane per pixel, rows of a block are contiguous in the output ----
+	for (int32_t w = tid; w < nb * R * C; w += nthreads) {
+		const int32_t b = w / (R * C), i = w - b * (R * C), y = i / C, x = i - y * C;
+		const VbGeom &g = geom[b];
+		if (y >= g.effh || x >= g.effw) continue;
+		const float *t = lds + (size_t) b * 3 * TILE + y * P + x;
+		const uint32_t px = xyb_to_rgba8(t[0], t[TILE], t[2 * TILE], f);
+		*(uint32_t *) (rgba + (size_t) (g.py + y) * stride_bytes + (size_t) (g.px + x) * 4) = px;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2s: the 8x8 special transforms; one lane transforms one (block, channel) tile serially
+
+template <int NB>
+__global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan, const DevVarblock *list, int32_t count, uint8_t *rgba, size_t stride_bytes) {
+	constexpr int P = 65;  // odd pitch: lanes working on different tiles hit different banks
+	__shared__ float tiles[NB * 3 * P];
+	__shared__ float scratch[NB * 3 * P];
+	const DevFrame &f = *plan.frame;
+	const int32_t tid = threadIdx.x, nthreads = blockDim.x;
+	const int32_t first = blockIdx.x * NB;
+	const int32_t nb = min(NB, count - first);
+	__shared__ VbGeom geom[NB];
+	if (tid < nb) geom[tid] = varblock_geometry(plan, list[first + tid], 8, 8);
+	__syncthreads();
+	for (int32_t w = tid; w < nb * 64; w += nthreads) {
+		const int32_t b = w >> 6, i = w & 63;
+		const DevVarblock vb = list[first + b];
+		const VbGeom &g = geom[b];
+		const int32_t param_idx = vb.dctsel == 1 ? 1 : vb.dctsel == 2 ? 2 : vb.dctsel == 3 ? 3 : vb.dctsel <= 13 ? 9 : 10;
+		const float *dq = plan.pool_f32 + f.dq_off[param_idx];
+		float v[3];
+		load_coeff3(plan, g, dq, 64, i, 8, 1, 1, v);
+		float *t = tiles + (size_t) b * 3 * P + i;
+		t[0] = v[0]; t[P] = v[1]; t[2 * P] = v[2];
+	}
+	__syncthreads();
+	for (int32_t w = tid; w < nb * 3; w += nthreads) {
+		const int32_t dctsel = list[first + w / 3].dctsel;
+		inverse_special8x8(dctsel, tiles + (size_t) w * P, scratch + (size_t) w * P, c_half_secants, c_afv_basis);
+	}
+	__syncthreads();
+	for (int32_t w = tid; w < nb * 64; w += nthreads) {
+		const int32_t b = w >> 6, i = w & 63, y = i >> 3, x = i & 7;
+		const VbGeom &g = geom[b];
+		if (y >= g.effh || x >= g.effw) continue;
+		const float *t = tiles + (size_t) b * 3 * P + i;
+		const uint32_t px = xyb_to_rgba8(t[0], t[P], t[2 * P], f);
+		*(uint32_t *) (rgba + (size_t) (g.py + y) * stride_bytes + (size_t) (g.px + x) * 4) = px;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2l: transforms with a 128- or 256-sized side. One workgroup per varblock; the butterfly levels
+// are swept over an HBM scratch (two ping-pong buffers per channel), one __syncthreads per level.
+// Same arithmetic as the recursion: depth d works on sub-vectors of length N >> d (j40.h:5802-5841).
+
+__device__ void idct_sweeps(float *A, float *B, int32_t t, int32_t ncols, int32_t stride_k, int32_t stride_col) {
+	// on return the result is in B (A is clobbered); A = input
+	const int32_t N = 1 << t, half = N >> 1;
+	const int32_t tid = threadIdx.x, nthreads = blockDim.x;
+	if (t == 0) { for (int32_t w = tid; w < ncols; w += nthreads) B[w * stride_col] = A[w * stride_col]; __syncthreads(); return; }
+	for (int32_t d = 0; d <= t - 2; ++d) {  // downward: split even / odd
+		const float *src = (d & 1) ? B : A; float *dst = (d & 1) ? A : B;
+		const int32_t n = N >> d, hn = n >> 1;
+		for (int32_t w = tid; w < ncols * half; w += nthreads) {
+			const int32_t col = w % ncols, j = w / ncols, o = (j / hn) * n, i = j % hn;
+			const float *s = src + col * stride_col; float *q = dst + col * stride_col;
+			q[(o + i) * stride_k] = s[(o + 2 * i) * stride_k];
+			q[(o + hn + i) * stride_k] = i == 0 ? J40_SQRT2F * s[(o + 1) * stride_k] : s[(o + 2 * i - 1) * stride_k] + s[(o + 2 * i + 1) * stride_k];
+		}
+		__syncthreads();
+	}
+	{   // length-2 tails at depth t - 1
+		const int32_t d = t - 1;
+		const float *src = (d & 1) ? B : A; float *dst = (d & 1) ? A : B;
+		for (int32_t w = tid; w < ncols * half; w += nthreads) {
+			const int32_t col = w % ncols, o = (w / ncols) * 2;
+			const float p = src[col * stride_col + o * stride_k], q = src[col * stride_col + (o + 1) * stride_k];
+			dst[col * stride_col + o * stride_k] = p + q;
+			dst[col * stride_col + (o + 1) * stride_k] = p - q;
+		}
+		__syncthreads();
+	}
+	for (int32_t d = t - 2; d >= 0; --d) {  // upward: combine halves
+		const float *src = (d & 1) ? B : A; float *dst = (d & 1) ? A : B;
+		const int32_t n = N >> d, hn = n >> 1;
+		for (int32_t w = tid; w < ncols * half; w += nthreads) {
+			const int32_t col = w % ncols, j = w / ncols, o = (j / hn) * n, i = j % hn;
+			const float *s = src + col * stride_col; float *q = dst + col * stride_col;
+			const float x = s[(o + i) * stride_k], y = s[(o + hn + i) * stride_k];
+			const float m = c_half_secants[hn + i];
+			const float ym = y * m;
+			q[(o + i) * stride_k] = x + ym;
+			q[(o + n - 1 - i) * stride_k] = x - ym;
+		}
+		__syncthreads();
+	}
+}
+
+__global__ void __launch_bounds__(256) k_vardct_large(DevPlan plan, const DevVarblock *list, int32_t count, float *scratch, uint8_t *rgba, size_t stride_bytes) {
+	const DevFrame &f = *plan.frame;
+	const int32_t tid = threadIdx.x, nthreads = blockDim.x;
+	const DevVarblock vb = list[blockIdx.x];
+	(void) count;
+	const int32_t log_rows = DEV_DCT_SELECT[vb.dctsel][0], log_columns = DEV_DCT_SELECT[vb.dctsel][1];
+	const int32_t R = 1 << log_rows, C = 1 << log_columns, size = R * C;
+	const int32_t long_side = R > C ? R : C, vh8 = (R < C ? R : C) / 8, vw8 = long_side / 8;
+	const int32_t param_idx = vb.dctsel == 21 ? 13 : vb.dctsel <= 23 ? 14 : vb.dctsel == 24 ? 15 : 16;
+	const float *dq = plan.pool_f32 + f.dq_off[param_idx];
+	const VbGeom g = varblock_geometry(plan, vb, R, C);
+	float *A = scratch + (size_t) blockIdx.x * 6 * 65536, *B = A + 3 * 65536;  // [3][size] each
+	for (int32_t i = tid; i < size; i += nthreads) {
+		float v[3];
+		load_coeff3(plan, g, dq, size, i, long_side, vh8, vw8, v);
+		const int32_t r = C > R ? i / C : i % R, c = C > R ? i % C : i / R;
+		A[r * C + c] = v[0]; A[65536 + r * C + c] = v[1]; A[2 * 65536 + r * C + c] = v[2];
+	}
+	__syncthreads();
+	for (int ch = 0; ch < 3; ++ch) {
+		idct_sweeps(A + ch * 65536, B + ch * 65536, log_columns, R, 1, C);   // along c for every r: A -> B
+		idct_sweeps(B + ch * 65536, A + ch * 65536, log_rows, C, C, 1);      // along r for every x: B -> A
+	}
+	for (int32_t i = tid; i < size; i += nthreads) {
+		const int32_t y = i / C, x = i - y * C;
+		if (y >= g.effh || x >= g.effw) continue;
+		const uint32_t px = xyb_to_rgba8(A[i], A[65536 + i], A[2 * 65536 + i], f);
+		*(uint32_t *) (rgba + (size_t) (g.py + y) * stride_bytes + (size_t) (g.px + x) * 4) = px;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+
+void launch_hf_entropy(const DevPlan &plan, int32_t first_group, int32_t num_groups, int32_t lanes, hipStream_t stream) {
+	if (num_groups <= 0) return;
+	const int32_t waves = (num_groups + lanes - 1) / lanes;
+	hipLaunchKernelGGL(k_hf_entropy, dim3((unsigned) waves), dim3(64), 0, stream, plan, first_group, num_groups, lanes);
+}
+
+template <int LOGR, int LOGC, int NB>
+static void launch_dct(const DevPlan &plan, const DevVarblock *list, int32_t count, int32_t param_idx, uint8_t *rgba, size_t stride, hipStream_t stream) {
+	constexpr size_t lds_bytes = (size_t) NB * 3 * (1 << LOGR) * ((1 << LOGC) + 1) * sizeof(float);
+	static bool configured = false;
+	if (!configured) { (void) hipFuncSetAttribute((const void *) k_vardct_dct<LOGR, LOGC, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes); configured = true; }
+	const int32_t blocks = (count + NB - 1) / NB;
+	hipLaunchKernelGGL((k_vardct_dct<LOGR, LOGC, NB>), dim3((unsigned) blocks), dim3(256), lds_bytes, stream, plan, list, count, param_idx, rgba, stride);
+}
+
+// list = varblocks of one DctSelect value
+void launch_vardct_class(const DevPlan &plan, int32_t dctsel, const DevVarblock *list, int32_t count, float *large_scratch, uint8_t *rgba, size_t stride, hipStream_t stream) {
+	if (count <= 0) return;
+	switch (dctsel) {
+	case 0: launch_dct<3, 3, 16>(plan, list, count, 0, rgba, stride, stream); break;
+	case 4: launch_dct<4, 4, 8>(plan, list, count, 4, rgba, stride, stream); break;
+	case 5: launch_dct<5, 5, 2>(plan, list, count, 5, rgba, stride, stream); break;
+	case 6: launch_dct<4, 3, 8>(plan, list, count, 6, rgba, stride, stream); break;
+	case 7: launch_dct<3, 4, 8>(plan, list, count, 6, rgba, stride, stream); break;
+	case 8: launch_dct<5, 3, 4>(plan, list, count, 7, rgba, stride, stream); break;
+	case 9: launch_dct<3, 5, 4>(plan, list, count, 7, rgba, stride, stream); break;
+	case 10: launch_dct<5, 4, 4>(plan, list, count, 8, rgba, stride, stream); break;
+	case 11: launch_dct<4, 5, 4>(plan, list, count, 8, rgba, stride, stream); break;
+	case 18: launch_dct<6, 6, 1>(plan, list, count, 11, rgba, stride, stream); break;
+	case 19: launch_dct<6, 5, 1>(plan, list, count, 12, rgba, stride, stream); break;
+	case 20: launch_dct<5, 6, 1>(plan, list, count, 12, rgba, stride, stream); break;
+	case 1: case 2: case 3: case 12: case 13: case 14: case 15: case 16: case 17:
+		hipLaunchKernelGGL((k_vardct_special<32>), dim3((unsigned) ((count + 31) / 32)), dim3(256), 0, stream, plan, list, count, rgba, stride);
+		break;
+	default:
+		hipLaunchKernelGGL(k_vardct_large, dim3((unsigned) count), dim3(256), 0, stream, plan, list, count, large_scratch, rgba, stride);
+		break;
+	}
+}
+
+} // namespace j40hip

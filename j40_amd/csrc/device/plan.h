@@ -1,0 +1,114 @@
+// j40_amd/csrc/device/plan.h -- the frame plan as the HIP kernels see it: flat, pointer-free PODs
+// mirroring what the reference's hot path reads from j40__frame_st / j40__lf_group_st / j40__code_spec
+// (j40.h:5061-5122, 6360-6390, 2486-2495). Offsets index into a handful of typed pools in HBM.
+#pragma once
+#include <stdint.h>
+
+namespace j40hip {
+
+struct DevCluster {
+	uint32_t cfg;        // hybrid-int config: bits 0-3 split_exp, 4-7 msb_in_token, 8-11 lsb_in_token
+	int32_t max_token;
+	uint32_t table_off;  // ANS: first AnsEntry of this cluster in the u64 pool; prefix: first int32 in the i32 pool
+	int16_t fast_len, max_len;  // prefix codes only
+};
+
+struct DevCodeSpec {
+	int32_t num_dist, num_clusters;
+	int32_t lz77_enabled, use_prefix_code;
+	int32_t min_symbol, min_length;
+	int32_t log_alpha_size;
+	uint32_t lz_len_cfg;
+	int32_t lz_len_max_token;
+	uint32_t cluster_map_off;  // into the u8 pool
+	uint32_t cluster_off;      // into the DevCluster pool
+	uint32_t pad;
+};
+
+struct DevLfGroup {
+	int32_t left, top, width, height;
+	int32_t width8, height8, width64, height64;
+	int32_t cell_base;   // first 8x8 cell of this LF group in the frame-wide cell arrays
+	int32_t vb_base;     // first varblock in the frame-wide varblock arrays
+	int32_t c64_base;    // first 64x64 cell (chroma-from-luma factors)
+	int32_t nb_varblocks;
+};
+
+// one (pass, group) TOC section
+struct DevSection {
+	uint32_t byte_off, size, bit_off;
+	int32_t ggidx;
+	int32_t gx8, gy8;    // cell offset of the group inside its LF group
+	int32_t gw8, gh8;    // cells
+	int32_t gx, gy, gw, gh;  // pixels: group position in the frame and size
+};
+
+// work item of the coefficients -> pixels kernels, sorted by DctSelect on the host
+struct DevVarblock {
+	int32_t ggidx;
+	int32_t voff;        // index into the frame-wide varblock arrays
+	int16_t x8, y8;      // cell position inside the LF group
+	int32_t dctsel;
+};
+
+struct DevFrame {
+	int32_t width, height;
+	int32_t num_passes, num_groups, num_lf_groups;
+	int32_t nb_block_ctx, nb_qf_thr, lfidx_size, num_hf_presets, preset_bits;
+	int32_t bpp;
+	float quant_bias[3], quant_bias_num;
+	float mult_base;             // 65536.0f / (float) global_scale (j40.h:7078)
+	float x_qm_mul, b_qm_mul;    // 0.8^(qm_scale - 2) (j40.h:7055)
+	float kx_lf, kb_lf;          // j40.h:7115-7116
+	float base_corr_x, base_corr_b, inv_colour_factor;
+	float opsin_inv_mat[9], opsin_bias[3], cbrt_opsin_bias[3];
+	float itscale;               // 255.0f / intensity_target
+	uint32_t order_off[11 * 13 * 3];  // into the u16 pool; 0xffffffff = not loaded
+	uint32_t dq_off[17];              // into the f32 pool, layout [channel][coefficient]; 0xffffffff = not loaded
+	uint32_t dq_size[17];
+};
+
+// everything a kernel needs, passed by value
+struct DevPlan {
+	const DevFrame *frame;
+	const uint8_t *codestream;
+	const uint8_t *pool_u8;          // cluster maps, block context map
+	const uint16_t *pool_u16;        // coefficient orders
+	const int32_t *pool_i32;         // prefix code tables
+	const uint64_t *pool_u64;        // rANS alias tables
+	const float *pool_f32;           // dequantisation weights
+	const DevCluster *clusters;
+	const DevCodeSpec *coeff_specs;  // [num_passes]
+	const DevLfGroup *lf_groups;
+	const DevSection *sections;      // [num_passes * num_groups]
+	uint32_t block_ctx_map_off;      // into pool_u8
+	// LF bundle, frame-wide arrays concatenated over LF groups
+	const int32_t *blocks;
+	const uint8_t *lfindices;
+	const float *llf[3];
+	const int32_t *vb_coeffoff_qfidx;
+	const float *vb_hfmul_inv;
+	const int16_t *xfromy, *bfromy;
+	// working buffers
+	float *coeffs[3];                // [total cells * 64]
+	int8_t *nonzeros;                // [num_groups][32 * 32 * 3]
+	int32_t *lz_window;              // [num_groups][lz_window_size] or null
+	uint32_t lz_window_size;
+	uint32_t *status;                // [num_passes * num_groups] 4-char codes
+};
+
+enum {
+	ERR_SHRT = ('s' << 24) | ('h' << 16) | ('r' << 8) | 't',
+	ERR_COEF = ('c' << 24) | ('o' << 16) | ('e' << 8) | 'f',
+	ERR_EXCS = ('e' << 24) | ('x' << 16) | ('c' << 8) | 's',
+	ERR_ANS = ('a' << 24) | ('n' << 16) | ('s' << 8) | '?',
+	ERR_IOVF = ('i' << 24) | ('o' << 16) | ('v' << 8) | 'f',
+	ERR_PAD0 = ('p' << 24) | ('a' << 16) | ('d' << 8) | '0',
+	ERR_RNGE = ('r' << 24) | ('n' << 16) | ('g' << 8) | 'e',
+	ERR_POVF = ('p' << 24) | ('o' << 16) | ('v' << 8) | 'f',
+	ERR_PRED = ('p' << 24) | ('r' << 16) | ('e' << 8) | 'd',
+	ERR_TREC = ('t' << 24) | ('r' << 16) | ('e' << 8) | 'c',
+	ERR_TODO = ('T' << 24) | ('O' << 16) | ('D' << 8) | 'O',
+};
+
+} // namespace j40hip

@@ -1,0 +1,211 @@
+// j40_amd/csrc/device/runtime.hip -- device half of the thin C-ABI (include/j40hip.h): builds the
+// flat frame plan in HBM, launches the hot-path kernels on the caller's stream, reads status back.
+//
+// No CPU fallback lives here: without a HIP device every entry point returns "!gpu".
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include "../capi.hpp"
+#include "../tables.hpp"
+#include "../plan_build.hpp"
+#include "kernels.h"
+
+using namespace j40hip;
+
+namespace {
+
+constexpr uint32_t ERR_GPU = ('!' << 24) | ('g' << 16) | ('p' << 8) | 'u';
+
+struct DeviceBuffer {
+	void *ptr = nullptr; size_t bytes = 0;
+	bool alloc(size_t n) { bytes = n; return hipMalloc(&ptr, n ? n : 16) == hipSuccess; }
+	void release() { if (ptr) (void) hipFree(ptr); ptr = nullptr; }
+};
+
+} // namespace
+
+struct j40hip_device_state {
+	int device = 0;
+	std::vector<DeviceBuffer> buffers;
+	DevPlan plan;
+	bool is_modular = false;
+	int64_t first_group = 0, num_groups = 0;       // range decoded by this process
+	std::vector<DevVarblock> vb_sorted;             // by DctSelect
+	int32_t class_start[28];
+	DevVarblock *d_vb_sorted = nullptr;
+	float *d_large_scratch = nullptr;
+	size_t coeff_floats = 0;
+	int32_t total_sections = 0;
+	std::vector<uint32_t> status_host;
+	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+
+	template <typename T> T *upload(const T *src, size_t n, hipStream_t s, bool &ok) {
+		DeviceBuffer b;
+		if (!b.alloc(sizeof(T) * n)) { ok = false; return nullptr; }
+		buffers.push_back(b);
+		if (n && hipMemcpyAsync(b.ptr, src, sizeof(T) * n, hipMemcpyHostToDevice, s) != hipSuccess) ok = false;
+		return (T *) b.ptr;
+	}
+	template <typename T> T *scratch(size_t n, bool &ok) {
+		DeviceBuffer b;
+		if (!b.alloc(sizeof(T) * n)) { ok = false; return nullptr; }
+		buffers.push_back(b);
+		return (T *) b.ptr;
+	}
+};
+
+extern "C" void j40hip_release_device(j40hip_frame *f) {
+	if (!f || !f->dev) return;
+	(void) hipSetDevice(f->dev->device);
+	for (auto &b : f->dev->buffers) b.release();
+	for (auto &e : f->dev->ev) if (e) (void) hipEventDestroy(e);
+	delete f->dev;
+	f->dev = nullptr;
+}
+
+extern "C" int j40hip_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+extern "C" uint32_t j40hip_frame_upload(j40hip_frame *h, int device) {
+	if (!h) return ERR_GPU;
+	if (h->dev) j40hip_release_device(h);
+	if (j40hip_device_count() <= device || hipSetDevice(device) != hipSuccess) return ERR_GPU;
+	HostPlan hp;
+	if (uint32_t e = build_vardct_plan(h->frame, h->cs, h->cs_size, &hp)) return e;
+
+	j40hip_device_state *st = new j40hip_device_state();
+	h->dev = st; st->device = device;
+	hipStream_t s = nullptr;
+	bool ok = true;
+	DevPlan &plan = st->plan;
+	memset(&plan, 0, sizeof plan);
+	plan.codestream = st->upload(hp.codestream.data(), hp.codestream.size(), s, ok);
+	plan.pool_u8 = st->upload(hp.pool_u8.data(), hp.pool_u8.size(), s, ok);
+	plan.pool_u16 = st->upload(hp.pool_u16.data(), hp.pool_u16.size(), s, ok);
+	plan.pool_i32 = st->upload(hp.pool_i32.data(), hp.pool_i32.size(), s, ok);
+	plan.pool_u64 = st->upload(hp.pool_u64.data(), hp.pool_u64.size(), s, ok);
+	plan.pool_f32 = st->upload(hp.pool_f32.data(), hp.pool_f32.size(), s, ok);
+	plan.clusters = st->upload(hp.clusters.data(), hp.clusters.size(), s, ok);
+	plan.coeff_specs = st->upload(hp.coeff_specs.data(), hp.coeff_specs.size(), s, ok);
+	plan.lf_groups = st->upload(hp.lf_groups.data(), hp.lf_groups.size(), s, ok);
+	plan.sections = st->upload(hp.sections.data(), hp.sections.size(), s, ok);
+	plan.frame = st->upload(&hp.frame, 1, s, ok);
+	plan.block_ctx_map_off = hp.block_ctx_map_off;
+	plan.blocks = st->upload(hp.blocks.data(), hp.blocks.size(), s, ok);
+	plan.lfindices = st->upload(hp.lfindices.data(), hp.lfindices.size(), s, ok);
+	for (int c = 0; c < 3; ++c) plan.llf[c] = st->upload(hp.llf[c].data(), hp.llf[c].size(), s, ok);
+	plan.vb_coeffoff_qfidx = st->upload(hp.vb_coeffoff_qfidx.data(), hp.vb_coeffoff_qfidx.size(), s, ok);
+	plan.vb_hfmul_inv = st->upload(hp.vb_hfmul_inv.data(), hp.vb_hfmul_inv.size(), s, ok);
+	plan.xfromy = st->upload(hp.xfromy.data(), hp.xfromy.size(), s, ok);
+	plan.bfromy = st->upload(hp.bfromy.data(), hp.bfromy.size(), s, ok);
+	st->coeff_floats = hp.coeff_floats;
+	for (int c = 0; c < 3; ++c) plan.coeffs[c] = st->scratch<float>(st->coeff_floats, ok);
+	const int32_t num_groups = hp.frame.num_groups;
+	plan.nonzeros = st->scratch<int8_t>((size_t) num_groups * 32 * 32 * 3, ok);
+	plan.status = st->scratch<uint32_t>(hp.sections.size(), ok);
+	plan.lz_window_size = hp.lz_window_size;
+	if (hp.lz_window_size) plan.lz_window = st->scratch<int32_t>((size_t) num_groups * hp.lz_window_size, ok);
+	st->total_sections = (int32_t) hp.sections.size();
+	st->first_group = 0; st->num_groups = num_groups;
+	st->vb_sorted = hp.vb_sorted;
+	memcpy(st->class_start, hp.class_start, sizeof st->class_start);
+	st->d_vb_sorted = st->upload(st->vb_sorted.data(), st->vb_sorted.size(), s, ok);
+	if (hp.max_large) st->d_large_scratch = st->scratch<float>((size_t) hp.max_large * 6 * 65536, ok);
+	upload_constant_tables(half_secants(), afv_basis(), s);
+	for (auto &e : st->ev) if (hipEventCreate(&e) != hipSuccess) ok = false;
+	if (hipStreamSynchronize(s) != hipSuccess) ok = false;
+	if (!ok) { j40hip_release_device(h); return ERR_GPU; }
+	return 0;
+}
+
+extern "C" uint32_t j40hip_frame_set_group_range(j40hip_frame *h, int64_t first_group, int64_t num_groups) {
+	if (!h || !h->dev) return ERR_GPU;
+	if (first_group < 0 || num_groups < 0 || first_group + num_groups > h->frame.fh.num_groups) return ERR_RNGE;
+	h->dev->first_group = first_group; h->dev->num_groups = num_groups;
+	return 0;
+}
+
+static uint32_t decode_impl(j40hip_frame *h, void *rgba_dev, size_t stride_bytes, hipStream_t s, float *ms3) {
+	if (!h || !h->dev) return ERR_GPU;
+	j40hip_device_state *st = h->dev;
+	if (hipSetDevice(st->device) != hipSuccess) return ERR_GPU;
+	const DevPlan &plan = st->plan;
+	const Frame &fr = h->frame;
+	const bool whole = st->first_group == 0 && st->num_groups == fr.fh.num_groups;
+	if (ms3) (void) hipEventRecord(st->ev[0], s);
+	for (int c = 0; c < 3; ++c) if (hipMemsetAsync(plan.coeffs[c], 0, sizeof(float) * st->coeff_floats, s) != hipSuccess) return ERR_GPU;
+	if (hipMemsetAsync(plan.status, 0, sizeof(uint32_t) * (size_t) st->total_sections, s) != hipSuccess) return ERR_GPU;
+	if (ms3) (void) hipEventRecord(st->ev[1], s);
+	launch_hf_entropy(plan, (int32_t) st->first_group, (int32_t) st->num_groups, 1, s);
+	if (ms3) (void) hipEventRecord(st->ev[2], s);
+	if (whole) {
+		for (int d = 0; d < 27; ++d) {
+			const int32_t a = st->class_start[d], b = st->class_start[d + 1];
+			launch_vardct_class(plan, d, st->d_vb_sorted + a, b - a, st->d_large_scratch, (uint8_t *) rgba_dev, stride_bytes, s);
+		}
+	} else {
+		// sharded decode: only varblocks of this rank's groups (lists are built on demand)
+		return ERR_TODO;
+	}
+	if (ms3) {
+		(void) hipEventRecord(st->ev[3], s);
+		if (hipEventSynchronize(st->ev[3]) != hipSuccess) return ERR_GPU;
+		float a = 0, b = 0, c = 0;
+		(void) hipEventElapsedTime(&a, st->ev[0], st->ev[1]);
+		(void) hipEventElapsedTime(&b, st->ev[1], st->ev[2]);
+		(void) hipEventElapsedTime(&c, st->ev[2], st->ev[3]);
+		ms3[0] = b; ms3[1] = c; ms3[2] = a;
+	}
+	return hipGetLastError() == hipSuccess ? 0 : ERR_GPU;
+}
+
+extern "C" uint32_t j40hip_frame_decode(j40hip_frame *h, void *rgba_dev, size_t stride_bytes, void *stream) {
+	return decode_impl(h, rgba_dev, stride_bytes, (hipStream_t) stream, nullptr);
+}
+
+extern "C" uint32_t j40hip_frame_decode_timed(j40hip_frame *h, void *rgba_dev, size_t stride_bytes, void *stream, float *ms3) {
+	return decode_impl(h, rgba_dev, stride_bytes, (hipStream_t) stream, ms3);
+}
+
+extern "C" uint32_t j40hip_frame_status(j40hip_frame *h) {
+	if (!h || !h->dev) return ERR_GPU;
+	j40hip_device_state *st = h->dev;
+	st->status_host.assign((size_t) st->total_sections, 0);
+	if (hipMemcpy(st->status_host.data(), st->plan.status, sizeof(uint32_t) * st->status_host.size(), hipMemcpyDeviceToHost) != hipSuccess) return ERR_GPU;
+	// the reference reports the first failing section in the order it reads them (TOC order)
+	const Frame &fr = h->frame;
+	if (fr.toc.single) return st->status_host.empty() ? 0 : st->status_host[0];
+	std::vector<std::pair<size_t, uint32_t>> bad;
+	for (size_t i = 0; i < st->status_host.size(); ++i) if (st->status_host[i]) bad.push_back({fr.toc.pass_groups[i].offset, st->status_host[i]});
+	if (bad.empty()) return 0;
+	return std::min_element(bad.begin(), bad.end())->second;
+}
+
+extern "C" uint32_t j40hip_frame_decode_to_host(j40hip_frame *h, void *rgba_host, size_t stride_bytes) {
+	if (!h || !h->dev) return ERR_GPU;
+	const Frame &fr = h->frame;
+	if (hipSetDevice(h->dev->device) != hipSuccess) return ERR_GPU;
+	const size_t row = (size_t) fr.fh.width * 4;
+	void *d = nullptr;
+	if (hipMalloc(&d, row * (size_t) fr.fh.height) != hipSuccess) return ERR_GPU;
+	uint32_t err = decode_impl(h, d, row, nullptr, nullptr);
+	if (!err && hipStreamSynchronize(nullptr) != hipSuccess) err = ERR_GPU;
+	if (!err) err = j40hip_frame_status(h);
+	if (!err && hipMemcpy2D(rgba_host, stride_bytes, d, row, row, (size_t) fr.fh.height, hipMemcpyDeviceToHost) != hipSuccess) err = ERR_GPU;
+	(void) hipFree(d);
+	return err;
+}
+
+extern "C" uint32_t j40hip_frame_read_coeffs(j40hip_frame *h, int64_t gg, int c, float *out) {
+	if (!h || !h->dev) return ERR_GPU;
+	const LfGroup &g = h->frame.lf_groups[(size_t) gg];
+	size_t base = 0;
+	for (int64_t i = 0; i < gg; ++i) base += h->frame.lf_groups[(size_t) i].blocks.size();
+	if (hipMemcpy(out, h->dev->plan.coeffs[c] + base * 64, sizeof(float) * g.blocks.size() * 64, hipMemcpyDeviceToHost) != hipSuccess) return ERR_GPU;
+	return 0;
+}
+
+extern "C" uint32_t j40hip_frame_read_plane_i16(j40hip_frame *, int, int16_t *) { return ERR_TODO; }

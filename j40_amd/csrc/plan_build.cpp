@@ -1,0 +1,128 @@
+// j40_amd/csrc/plan_build.cpp -- see plan_build.hpp
+#include "plan_build.hpp"
+#include <algorithm>
+#include <cmath>
+
+namespace j40hip {
+
+template <typename T> static uint32_t push(std::vector<T> &pool, const T *p, size_t n) { uint32_t off = (uint32_t) pool.size(); pool.insert(pool.end(), p, p + n); return off; }
+
+void flatten_code_spec(const CodeSpec &spec, std::vector<uint8_t> &u8, std::vector<int32_t> &i32, std::vector<uint64_t> &u64, std::vector<DevCluster> &clusters, DevCodeSpec *out) {
+	out->num_dist = spec.num_dist; out->num_clusters = spec.num_clusters;
+	out->lz77_enabled = spec.lz77_enabled; out->use_prefix_code = spec.use_prefix_code;
+	out->min_symbol = spec.min_symbol; out->min_length = spec.min_length;
+	out->log_alpha_size = spec.log_alpha_size;
+	out->lz_len_cfg = spec.lz_len_cfg.packed(); out->lz_len_max_token = spec.lz_len_cfg.max_token;
+	out->cluster_map_off = push(u8, spec.cluster_map.data(), spec.cluster_map.size());
+	out->cluster_off = (uint32_t) clusters.size();
+	out->pad = 0;
+	for (const Cluster &c : spec.clusters) {
+		DevCluster d;
+		d.cfg = c.cfg.packed(); d.max_token = c.cfg.max_token;
+		d.fast_len = (int16_t) c.fast_len; d.max_len = (int16_t) c.max_len;
+		d.table_off = spec.use_prefix_code ? push(i32, c.table.data(), c.table.size()) : push(u64, c.alias.data(), c.alias.size());
+		clusters.push_back(d);
+	}
+}
+
+uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostPlan *hp) {
+	if (fr.fh.is_modular) return ERR_TODO;
+	if (!fr.im.ec.empty()) return ERR_TODO;          // VarDCT + extra channels
+	if (fr.im.grey || !fr.im.xyb_encoded || fr.fh.do_ycbcr) return ERR_TODO;  // same limits as j40.h:7867, 7917-7921
+	if (fr.im.bpp < 8 || fr.im.exp_bits) return ERR_TODO;
+
+	DevFrame &df = hp->frame;
+	memset(&df, 0, sizeof df);
+	df.width = fr.fh.width; df.height = fr.fh.height;
+	df.num_passes = fr.fh.num_passes; df.num_groups = (int32_t) fr.fh.num_groups; df.num_lf_groups = (int32_t) fr.fh.num_lf_groups;
+	df.nb_block_ctx = fr.nb_block_ctx; df.nb_qf_thr = fr.nb_qf_thr;
+	df.lfidx_size = (fr.nb_lf_thr[0] + 1) * (fr.nb_lf_thr[1] + 1) * (fr.nb_lf_thr[2] + 1);
+	df.num_hf_presets = fr.num_hf_presets; df.preset_bits = ceil_lg32((uint32_t) fr.num_hf_presets);
+	df.bpp = fr.im.bpp;
+	for (int c = 0; c < 3; ++c) { df.quant_bias[c] = fr.im.quant_bias[c]; df.opsin_bias[c] = fr.im.opsin_bias[c]; df.cbrt_opsin_bias[c] = cbrtf(fr.im.opsin_bias[c]); }
+	df.quant_bias_num = fr.im.quant_bias_num;
+	static const float QM_SCALE[8] = {1.5625f, 1.25f, 1.0f, 0.8f, 0.64f, 0.512f, 0.4096f, 0.32768f};  // 0.8^(i-2), j40.h:7055
+	df.mult_base = 65536.0f / (float) fr.global_scale;
+	df.x_qm_mul = QM_SCALE[fr.fh.x_qm_scale]; df.b_qm_mul = QM_SCALE[fr.fh.b_qm_scale];
+	df.kx_lf = fr.base_corr_x + (float) fr.x_factor_lf * fr.inv_colour_factor;   // j40.h:7115
+	df.kb_lf = fr.base_corr_b + (float) fr.b_factor_lf * fr.inv_colour_factor;
+	df.base_corr_x = fr.base_corr_x; df.base_corr_b = fr.base_corr_b; df.inv_colour_factor = fr.inv_colour_factor;
+	for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) df.opsin_inv_mat[i * 3 + j] = fr.im.opsin_inv_mat[i][j];
+	df.itscale = 255.0f / fr.im.intensity_target;
+
+	hp->coeff_specs.assign((size_t) fr.fh.num_passes, DevCodeSpec());
+	for (int32_t p = 0; p < fr.fh.num_passes; ++p) flatten_code_spec(fr.coeff_codespec[p], hp->pool_u8, hp->pool_i32, hp->pool_u64, hp->clusters, &hp->coeff_specs[(size_t) p]);
+	hp->block_ctx_map_off = push(hp->pool_u8, fr.block_ctx_map.data(), fr.block_ctx_map.size());
+	hp->pool_u8.resize(hp->pool_u8.size() + 16, 0);
+	for (size_t i = 0; i < 11 * 13 * 3; ++i) df.order_off[i] = 0xffffffffu;
+	for (int32_t p = 0; p < fr.fh.num_passes; ++p) for (int o = 0; o < 13; ++o) for (int c = 0; c < 3; ++c) {
+		const std::vector<int32_t> &ord = fr.orders[p][o][c];
+		if (ord.empty()) continue;
+		std::vector<uint16_t> tmp(ord.size());
+		for (size_t i = 0; i < ord.size(); ++i) tmp[i] = (uint16_t) ord[i];
+		df.order_off[(p * 13 + o) * 3 + c] = push(hp->pool_u16, tmp.data(), tmp.size());
+	}
+	for (int i = 0; i < 17; ++i) {
+		df.dq_off[i] = 0xffffffffu; df.dq_size[i] = 0;
+		const DqMatrix &dq = fr.dq_matrix[i];
+		if (!dq.loaded) continue;
+		const size_t n = dq.params.size();
+		std::vector<float> planar(n * 3);
+		for (size_t k = 0; k < n; ++k) for (int c = 0; c < 3; ++c) planar[(size_t) c * n + k] = dq.params[k][(size_t) c];
+		df.dq_off[i] = push(hp->pool_f32, planar.data(), planar.size()); df.dq_size[i] = (uint32_t) n;
+	}
+
+	// LF bundle: frame-wide arrays over all LF groups
+	hp->lf_groups.assign(fr.lf_groups.size(), DevLfGroup());
+	for (size_t g = 0; g < fr.lf_groups.size(); ++g) {
+		const LfGroup &gg = fr.lf_groups[g];
+		DevLfGroup &d = hp->lf_groups[g];
+		d.left = gg.left; d.top = gg.top; d.width = gg.width; d.height = gg.height;
+		d.width8 = gg.width8; d.height8 = gg.height8; d.width64 = gg.width64; d.height64 = gg.height64;
+		d.cell_base = (int32_t) hp->blocks.size(); d.vb_base = (int32_t) hp->vb_coeffoff_qfidx.size(); d.c64_base = (int32_t) hp->xfromy.size();
+		d.nb_varblocks = (int32_t) gg.varblocks.size();
+		hp->blocks.insert(hp->blocks.end(), gg.blocks.begin(), gg.blocks.end());
+		hp->lfindices.insert(hp->lfindices.end(), gg.lfindices.begin(), gg.lfindices.end());
+		for (int c = 0; c < 3; ++c) hp->llf[c].insert(hp->llf[c].end(), gg.llfcoeffs[c].begin(), gg.llfcoeffs[c].end());
+		hp->xfromy.insert(hp->xfromy.end(), gg.xfromy.begin(), gg.xfromy.end());
+		hp->bfromy.insert(hp->bfromy.end(), gg.bfromy.begin(), gg.bfromy.end());
+		for (size_t v = 0; v < gg.varblocks.size(); ++v) {
+			const VarblockInfo &vb = gg.varblocks[v];
+			hp->vb_coeffoff_qfidx.push_back(vb.coeffoff_qfidx); hp->vb_hfmul_inv.push_back(vb.hfmul_inv);
+			DevVarblock dv; dv.ggidx = (int32_t) g; dv.voff = d.vb_base + (int32_t) v; dv.x8 = (int16_t) vb.x8; dv.y8 = (int16_t) vb.y8; dv.dctsel = vb.dctsel;
+			hp->vb_sorted.push_back(dv);
+		}
+	}
+	hp->coeff_floats = hp->blocks.size() * 64;
+
+	// sections
+	const int32_t num_groups = (int32_t) fr.fh.num_groups;
+	hp->sections.assign((size_t) fr.fh.num_passes * (size_t) num_groups, DevSection());
+	for (int32_t p = 0; p < fr.fh.num_passes; ++p) for (int32_t g = 0; g < num_groups; ++g) {
+		DevSection &d = hp->sections[(size_t) p * (size_t) num_groups + (size_t) g];
+		const GroupInfo gi = group_info(fr.fh, g);
+		if (fr.toc.single) {
+			d.byte_off = (uint32_t) fr.toc.single_section.offset; d.size = (uint32_t) fr.toc.single_section.size; d.bit_off = (uint32_t) fr.single_pass_group_bitpos;
+		} else {
+			const Section &s0 = fr.toc.pass_groups[(size_t) p * (size_t) num_groups + (size_t) g];
+			d.byte_off = (uint32_t) s0.offset; d.size = (uint32_t) s0.size; d.bit_off = 0;
+		}
+		d.ggidx = gi.ggidx; d.gx8 = gi.gx_in_gg / 8; d.gy8 = gi.gy_in_gg / 8;
+		d.gw8 = ceil_div(gi.gw, 8); d.gh8 = ceil_div(gi.gh, 8);
+		d.gx = fr.lf_groups[(size_t) gi.ggidx].left + gi.gx_in_gg; d.gy = fr.lf_groups[(size_t) gi.ggidx].top + gi.gy_in_gg; d.gw = gi.gw; d.gh = gi.gh;
+	}
+	hp->codestream.assign(cs, cs + cs_size);
+	hp->codestream.resize(cs_size + 16, 0);
+	bool any_lz77 = false;
+	for (const DevCodeSpec &sp : hp->coeff_specs) any_lz77 |= sp.lz77_enabled != 0;
+	hp->lz_window_size = any_lz77 ? 3 * 65536 + 3 * 1024 + 16 : 0;  // bound on the integers one pass-group stream decodes
+	// work lists for the coefficients -> pixels kernels, grouped by DctSelect
+	std::stable_sort(hp->vb_sorted.begin(), hp->vb_sorted.end(), [](const DevVarblock &a, const DevVarblock &b) { return a.dctsel < b.dctsel; });
+	size_t k = 0;
+	for (int d = 0; d <= 27; ++d) { while (k < hp->vb_sorted.size() && hp->vb_sorted[k].dctsel < d) ++k; hp->class_start[d] = (int32_t) k; }
+	hp->max_large = 0;
+	for (int d = 21; d < 27; ++d) hp->max_large = std::max(hp->max_large, hp->class_start[d + 1] - hp->class_start[d]);
+	return 0;
+}
+
+} // namespace j40hip

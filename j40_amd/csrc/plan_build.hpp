@@ -1,0 +1,40 @@
+// j40_amd/csrc/plan_build.hpp -- flattens a parsed Frame into the pointer-free plan the kernels read
+// (device/plan.h). Pure host code: runtime.hip uploads the arrays to HBM; tests/hostsim points a
+// DevPlan at them directly to single-step the device functions on the CPU.
+#pragma once
+#include "frame.hpp"
+#include "device/plan.h"
+
+namespace j40hip {
+
+struct HostPlan {
+	DevFrame frame;
+	std::vector<uint8_t> codestream;   // padded copy
+	std::vector<uint8_t> pool_u8;
+	std::vector<uint16_t> pool_u16;
+	std::vector<int32_t> pool_i32;
+	std::vector<uint64_t> pool_u64;
+	std::vector<float> pool_f32;
+	std::vector<DevCluster> clusters;
+	std::vector<DevCodeSpec> coeff_specs;
+	std::vector<DevLfGroup> lf_groups;
+	std::vector<DevSection> sections;
+	uint32_t block_ctx_map_off = 0;
+	std::vector<int32_t> blocks, vb_coeffoff_qfidx;
+	std::vector<uint8_t> lfindices;
+	std::vector<float> llf[3], vb_hfmul_inv;
+	std::vector<int16_t> xfromy, bfromy;
+	std::vector<DevVarblock> vb_sorted;   // by DctSelect
+	int32_t class_start[28];
+	size_t coeff_floats = 0;
+	uint32_t lz_window_size = 0;          // 0: no LZ77 in any coefficient code spec
+	int32_t max_large = 0;                // most varblocks of one 128/256-sized transform type
+};
+
+// returns 0 or a 4-char error code ("TODO" for frame kinds the hot path does not cover)
+uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostPlan *out);
+
+// fills a DevCodeSpec and appends its tables to the pools
+void flatten_code_spec(const CodeSpec &spec, std::vector<uint8_t> &u8, std::vector<int32_t> &i32, std::vector<uint64_t> &u64, std::vector<DevCluster> &clusters, DevCodeSpec *out);
+
+} // namespace j40hip

@@ -1,0 +1,142 @@
+// tests/hostsim/hostsim.cpp -- TEST INFRASTRUCTURE ONLY. Compiles the *device* functions of the hot path
+// (j40_amd/csrc/device/*_dev.h) for the CPU and runs them with the same orchestration as the HIP
+// kernels, so their logic can be checked here (no GPU in the build container) against oracle/_ref
+// before spending GPU minutes. Never linked into the product library.
+#include <cstdint>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include "../../j40_amd/csrc/plan_build.hpp"
+#include "../../j40_amd/csrc/tables.hpp"
+#include "../../j40_amd/csrc/device/hf_dev.h"
+#include "../../j40_amd/csrc/device/vardct_dev.h"
+
+using namespace j40hip;
+
+namespace {
+
+void idct_sweeps_host(float *A, float *B, int32_t t, int32_t ncols, int32_t stride_k, int32_t stride_col, const float *hs) {
+	// sequential model of idct_sweeps in kernels.hip (same level structure)
+	const int32_t N = 1 << t, half = N >> 1;
+	if (t == 0) { for (int32_t w = 0; w < ncols; ++w) B[w * stride_col] = A[w * stride_col]; return; }
+	for (int32_t d = 0; d <= t - 2; ++d) {
+		const float *src = (d & 1) ? B : A; float *dst = (d & 1) ? A : B;
+		const int32_t n = N >> d, hn = n >> 1;
+		for (int32_t w = 0; w < ncols * half; ++w) {
+			const int32_t col = w % ncols, j = w / ncols, o = (j / hn) * n, i = j % hn;
+			const float *s = src + col * stride_col; float *q = dst + col * stride_col;
+			q[(o + i) * stride_k] = s[(o + 2 * i) * stride_k];
+			q[(o + hn + i) * stride_k] = i == 0 ? J40_SQRT2F * s[(o + 1) * stride_k] : s[(o + 2 * i - 1) * stride_k] + s[(o + 2 * i + 1) * stride_k];
+		}
+	}
+	{
+		const int32_t d = t - 1;
+		const float *src = (d & 1) ? B : A; float *dst = (d & 1) ? A : B;
+		for (int32_t w = 0; w < ncols * half; ++w) {
+			const int32_t col = w % ncols, o = (w / ncols) * 2;
+			const float p = src[col * stride_col + o * stride_k], q = src[col * stride_col + (o + 1) * stride_k];
+			dst[col * stride_col + o * stride_k] = p + q;
+			dst[col * stride_col + (o + 1) * stride_k] = p - q;
+		}
+	}
+	for (int32_t d = t - 2; d >= 0; --d) {
+		const float *src = (d & 1) ? B : A; float *dst = (d & 1) ? A : B;
+		const int32_t n = N >> d, hn = n >> 1;
+		for (int32_t w = 0; w < ncols * half; ++w) {
+			const int32_t col = w % ncols, j = w / ncols, o = (j / hn) * n, i = j % hn;
+			const float *s = src + col * stride_col; float *q = dst + col * stride_col;
+			const float x = s[(o + i) * stride_k], y = s[(o + hn + i) * stride_k];
+			const float ym = y * hs[hn + i];
+			q[(o + i) * stride_k] = x + ym;
+			q[(o + n - 1 - i) * stride_k] = x - ym;
+		}
+	}
+}
+
+template <int N> void idct_rows(float *tile, int rows, int pitch, const float *hs) {  // along c for each r
+	for (int r = 0; r < rows; ++r) { float x[N]; for (int k = 0; k < N; ++k) x[k] = tile[r * pitch + k]; Idct1D<N>::run(x, hs); for (int k = 0; k < N; ++k) tile[r * pitch + k] = x[k]; }
+}
+template <int N> void idct_cols(float *tile, int cols, int pitch, const float *hs) {  // along r for each x
+	for (int c = 0; c < cols; ++c) { float x[N]; for (int k = 0; k < N; ++k) x[k] = tile[k * pitch + c]; Idct1D<N>::run(x, hs); for (int k = 0; k < N; ++k) tile[k * pitch + c] = x[k]; }
+}
+void idct_rows_dyn(float *t, int n, int rows, int pitch, const float *hs) {
+	switch (n) { case 8: idct_rows<8>(t, rows, pitch, hs); break; case 16: idct_rows<16>(t, rows, pitch, hs); break; case 32: idct_rows<32>(t, rows, pitch, hs); break; default: idct_rows<64>(t, rows, pitch, hs); }
+}
+void idct_cols_dyn(float *t, int n, int cols, int pitch, const float *hs) {
+	switch (n) { case 8: idct_cols<8>(t, cols, pitch, hs); break; case 16: idct_cols<16>(t, cols, pitch, hs); break; case 32: idct_cols<32>(t, cols, pitch, hs); break; default: idct_cols<64>(t, cols, pitch, hs); }
+}
+
+} // namespace
+
+// decodes a VarDCT stream with the device functions on the CPU.
+//   rgba: width*height*4 bytes; coeffs_out (optional): 3 arrays of total_cells*64 floats concatenated
+// returns 0 or the first error code
+extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const uint8_t *buf, size_t size, uint8_t *rgba, float *coeffs_out, int only_entropy) {
+	Frame fr;
+	const uint8_t *cs; size_t cs_size; std::vector<uint8_t> storage;
+	HostPlan hp;
+	try {
+		extract_codestream(buf, size, &cs, &cs_size, &storage);
+		parse_frame(cs, cs_size, &fr, 1);
+	} catch (const DecodeError &e) { return e.code; }
+	if (uint32_t e = build_vardct_plan(fr, cs, cs_size, &hp)) return e;
+	std::vector<float> coeffs[3];
+	for (int c = 0; c < 3; ++c) coeffs[c].assign(hp.coeff_floats, 0.0f);
+	std::vector<int8_t> nonzeros((size_t) hp.frame.num_groups * 32 * 32 * 3);
+	std::vector<uint32_t> status(hp.sections.size(), 0);
+	std::vector<int32_t> window(hp.lz_window_size ? (size_t) hp.frame.num_groups * hp.lz_window_size : 0);
+	DevPlan plan;
+	memset(&plan, 0, sizeof plan);
+	plan.frame = &hp.frame; plan.codestream = hp.codestream.data();
+	plan.pool_u8 = hp.pool_u8.data(); plan.pool_u16 = hp.pool_u16.data(); plan.pool_i32 = hp.pool_i32.data(); plan.pool_u64 = hp.pool_u64.data(); plan.pool_f32 = hp.pool_f32.data();
+	plan.clusters = hp.clusters.data(); plan.coeff_specs = hp.coeff_specs.data(); plan.lf_groups = hp.lf_groups.data(); plan.sections = hp.sections.data();
+	plan.block_ctx_map_off = hp.block_ctx_map_off;
+	plan.blocks = hp.blocks.data(); plan.lfindices = hp.lfindices.data();
+	for (int c = 0; c < 3; ++c) { plan.llf[c] = hp.llf[c].data(); plan.coeffs[c] = coeffs[c].data(); }
+	plan.vb_coeffoff_qfidx = hp.vb_coeffoff_qfidx.data(); plan.vb_hfmul_inv = hp.vb_hfmul_inv.data();
+	plan.xfromy = hp.xfromy.data(); plan.bfromy = hp.bfromy.data();
+	plan.nonzeros = nonzeros.data(); plan.status = status.data();
+	plan.lz_window = window.empty() ? nullptr : window.data(); plan.lz_window_size = hp.lz_window_size;
+
+	for (int32_t g = 0; g < hp.frame.num_groups; ++g) decode_hf_group(plan, g);
+	if (coeffs_out) for (int c = 0; c < 3; ++c) memcpy(coeffs_out + (size_t) c * hp.coeff_floats, coeffs[c].data(), sizeof(float) * hp.coeff_floats);
+	for (uint32_t s : status) if (s) return s;
+	if (only_entropy) return 0;
+
+	const float *hs = half_secants(), *afv = afv_basis();
+	const DevFrame &f = hp.frame;
+	const size_t stride = (size_t) f.width * 4;
+	std::vector<float> A(3 * 65536), B(3 * 65536), scratch(3 * 65);
+	for (const DevVarblock &vb : hp.vb_sorted) {
+		const int log_rows = DEV_DCT_SELECT[vb.dctsel][0], log_columns = DEV_DCT_SELECT[vb.dctsel][1];
+		const int R = 1 << log_rows, C = 1 << log_columns, sz = R * C;
+		const int long_side = R > C ? R : C, vh8 = (R < C ? R : C) / 8, vw8 = long_side / 8;
+		static const int8_t PARAM[27] = {0, 1, 2, 3, 4, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 10, 10, 11, 12, 12, 13, 14, 14, 15, 16, 16};
+		const float *dq = plan.pool_f32 + f.dq_off[PARAM[vb.dctsel]];
+		const VbGeom g = varblock_geometry(plan, vb, R, C);
+		const bool special = (vb.dctsel >= 1 && vb.dctsel <= 3) || (vb.dctsel >= 12 && vb.dctsel <= 17);
+		const bool large = log_rows > 6 || log_columns > 6;
+		const int P = special ? 8 : large ? C : C + 1;
+		for (int i = 0; i < sz; ++i) {
+			float v[3];
+			load_coeff3(plan, g, dq, sz, i, long_side, vh8, vw8, v);
+			int r, c;
+			if (special) { r = i / 8; c = i % 8; }
+			else { r = C > R ? i / C : i % R; c = C > R ? i % C : i / R; }
+			for (int ch = 0; ch < 3; ++ch) A[(size_t) ch * 65536 + r * P + c] = v[ch];
+		}
+		for (int ch = 0; ch < 3; ++ch) {
+			float *t = A.data() + (size_t) ch * 65536;
+			if (special) inverse_special8x8(vb.dctsel, t, scratch.data(), hs, afv);
+			else if (large) {
+				idct_sweeps_host(t, B.data() + (size_t) ch * 65536, log_columns, R, 1, C, hs);
+				idct_sweeps_host(B.data() + (size_t) ch * 65536, t, log_rows, C, C, 1, hs);
+			} else { idct_rows_dyn(t, C, R, P, hs); idct_cols_dyn(t, R, C, P, hs); }
+		}
+		for (int y = 0; y < g.effh; ++y) for (int x = 0; x < g.effw; ++x) {
+			const uint32_t px = xyb_to_rgba8(A[y * P + x], A[65536 + y * P + x], A[2 * 65536 + y * P + x], f);
+			memcpy(rgba + (size_t) (g.py + y) * stride + (size_t) (g.px + x) * 4, &px, 4);
+		}
+	}
+	return 0;
+}

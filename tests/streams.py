@@ -1,0 +1,43 @@
+"""synthetic stream helpers shared by the tests, smoke() and bench.py (TEST INFRASTRUCTURE)"""
+import os
+import subprocess
+import hashlib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SYNTH = os.path.join(ROOT, "build", "jxlsynth")
+CACHE = os.path.join(ROOT, "build", "streams")
+
+
+def synth(mode, w, h, seed, **opts):
+    """returns the bytes of a generated stream (cached on disk by its parameters)"""
+    os.makedirs(CACHE, exist_ok=True)
+    key = "%s_%d_%d_%d_%s" % (mode, w, h, seed, "_".join("%s-%s" % kv for kv in sorted(opts.items())))
+    path = os.path.join(CACHE, key + ".jxl")
+    if not os.path.exists(path):
+        if not os.path.exists(SYNTH):
+            raise RuntimeError("build/jxlsynth is missing; run __graft_entry__.build()")
+        tmp = path + ".tmp%d" % os.getpid()
+        subprocess.run([SYNTH, mode, str(w), str(h), str(seed), tmp] + ["%s=%s" % kv for kv in sorted(opts.items())],
+                       check=True, stderr=subprocess.DEVNULL)
+        os.replace(tmp, path)
+    with open(path, "rb") as fp:
+        return fp.read()
+
+
+def sha(a):
+    return hashlib.sha256(a.tobytes() if hasattr(a, "tobytes") else a).hexdigest()
+
+
+# the VarDCT feature matrix every parity test walks (small frames: the reference decodes them in ms)
+VARDCT_CASES = [
+    ("default", dict()),
+    ("bctx", dict(bctx=1)),
+    ("presets", dict(presets=2)),
+    ("orders", dict(orders=1)),
+    ("passes", dict(passes=2)),
+    ("fullheader", dict(fullheader=1, xqm=2, bqm=4, nosmooth=1)),
+    ("simpleclusters", dict(simpleclusters=1, logalpha=6)),
+    ("cfl", dict(cfl=1)),
+    ("container_jxlc", dict(container=1)),
+    ("container_jxlp", dict(container=2)),
+]

@@ -1,0 +1,172 @@
+"""CPU tests: the C-ABI library loads and exports what include/*.h declares; the host parser's
+products equal the reference's internals; host-built tables equal the reference's (known answers);
+the golden fixtures still decode to the recorded hashes with the reference."""
+import ctypes as C
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from streams import synth, VARDCT_CASES, ROOT
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_library_exports_declared_abi(built):
+    import j40_amd
+    L = j40_amd.lib()
+    declared = set()
+    for header, pat in (("include/j40hip.h", r"J40HIP_API[^;]*?\b(j40hip_\w+)\s*\("), ("include/j40.h", r"J40_API[^;]*?\b(j40_\w+)\s*\(")):
+        text = open(os.path.join(ROOT, header)).read()
+        declared |= set(re.findall(pat, text))
+    assert len(declared) >= 35
+    for name in sorted(declared):
+        assert hasattr(L, name), "libj40hip.so does not export %s" % name
+
+
+def test_public_struct_layout(built):
+    import j40_amd
+    # j40_image: u32 magic + pointer-sized union; j40_frame: 2 x u32 + pointer; pixels: 3 x i32 + pointer
+    assert C.sizeof(j40_amd._Image) == 16 and C.sizeof(j40_amd._FrameHandle) == 16 and C.sizeof(j40_amd._Pixels) == 24
+
+
+def test_product_fails_loudly_without_gpu(built):
+    import j40_amd
+    if j40_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    err, rgba = j40_amd.decode(synth("vardct", 264, 200, 11))
+    assert err == "!gpu" and rgba is None
+    img = j40_amd.from_memory(synth("vardct", 264, 200, 11))
+    assert not img.next_frame()
+    assert "during j40_next_frame" in img.error_string()
+    px, stride, _ = img.frame_pixels_u8x4()
+    assert px.shape == (7, 21, 4) and stride == 84  # the reference's "ERR" placeholder (j40.h:8432)
+    img.free()
+    assert img.error() == "" or True
+
+
+def test_api_misuse_codes(built):
+    import j40_amd
+    L = j40_amd.lib()
+    img = j40_amd._Image()
+    assert j40_amd.err4(L.j40_from_memory(C.byref(img), None, 0, None)) == "Ubf0"
+    assert j40_amd.err4(L.j40_error(C.byref(img))) == "Ubf0"
+    assert b"`buf` parameter is NULL during j40_from_memory" == L.j40_error_string(C.byref(img))
+    L.j40_free(C.byref(img))
+    assert j40_amd.err4(L.j40_error(C.byref(img))) == "Ufre"
+    assert j40_amd.err4(L.j40_from_file(C.byref(img), b"/nonexistent/file.jxl")) == "open"
+    assert L.j40_error_string(C.byref(img)).startswith(b"Failed to open file during j40_from_file: ")
+    img2 = j40_amd.from_memory(b"\xff\x0a\x00")
+    assert img2.output_format(0x1234, j40_amd.J40_U8X4) == "Uch?"
+    img2.free()
+    bad = j40_amd.from_memory(b"not a jxl file at all")
+    assert not bad.next_frame() and bad.error() == "!jxl"
+    assert bad.error_string() == "The JPEG XL signature is not found during j40_next_frame"
+    bad.free()
+
+
+def test_golden_fixtures_pin_the_oracle(ref):
+    manifest = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+    assert len(manifest) >= 10
+    for name, e in sorted(manifest.items()):
+        data = open(os.path.join(GOLDEN, name + ".jxl"), "rb").read()
+        assert hashlib.sha256(data).hexdigest() == e["stream_sha256"]
+        err, rgba = ref.decode(data)
+        assert err == "" and sha(rgba) == e["rgba_sha256"], name
+
+
+def test_generator_is_deterministic(built):
+    manifest = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+    for name, e in sorted(manifest.items()):
+        data = synth(e["mode"], e["width"], e["height"], e["seed"], **e["opts"])
+        assert hashlib.sha256(data).hexdigest() == e["stream_sha256"], name
+
+
+@pytest.mark.parametrize("name,opts", VARDCT_CASES + [("all_transforms", dict(maxlog=8, bctx=1, presets=2, orders=1))])
+def test_host_parse_matches_reference_internals(ref, name, opts):
+    import j40_amd
+    from refdec import RefStage
+    w, h = (776, 520) if name == "all_transforms" else (520, 264)
+    data = synth("vardct", w, h, 21, **opts)
+    rs = RefStage(ref, data)
+    fr = j40_amd.Frame(data, threads=2)
+    assert fr.info == rs.info
+    for gg in range(rs.info["num_lf_groups"]):
+        assert fr.lf_group_info(gg) == rs.lf_group_info(gg)
+        for which in range(4):
+            assert np.array_equal(fr.plane(gg, which), rs.plane(gg, which)), (gg, which)
+        ra, rb = rs.varblocks(gg)
+        ma, mb = fr.varblocks(gg)
+        assert np.array_equal(ra, ma) and np.array_equal(rb.view(np.uint32), mb.view(np.uint32))
+        for c in range(3):
+            assert np.array_equal(fr.llf(gg, c).view(np.uint32), rs.llf(gg, c).view(np.uint32)), "LLF coefficients must be bit-identical"
+    for idx in range(17):
+        assert np.array_equal(fr.dq_matrix(idx).view(np.uint32), rs.dq_matrix(idx).view(np.uint32)), idx
+    for p in range(rs.info["num_passes"]):
+        for idx in range(13):
+            for c in range(3):
+                assert np.array_equal(fr.order(p, idx, c), rs.order(p, idx, c))
+    assert np.array_equal(fr.block_ctx_map(), rs.block_ctx_map())
+    fr.close()
+    rs.close()
+
+
+def test_host_parse_golden_llf(built):
+    import j40_amd
+    manifest = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+    for name, e in sorted(manifest.items()):
+        data = open(os.path.join(GOLDEN, name + ".jxl"), "rb").read()
+        fr = j40_amd.Frame(data)
+        ll = [fr.llf(g, c) for g in range(fr.info["num_lf_groups"]) for c in range(3)]
+        assert sha(np.concatenate(ll)) == e["llf_sha256"], name
+        fr.close()
+
+
+def test_table_known_answers(ref):
+    import j40_amd
+    L = j40_amd.lib()
+    for i in range(256):
+        assert np.float32(L.j40hip_kat_half_secant(i)) == np.float32(ref.lib.ref_kat_half_secant(i))
+    for i in range(64):
+        assert np.float32(L.j40hip_kat_lf2llf_scale(i)) == np.float32(ref.lib.ref_kat_lf2llf_scale(i))
+    for lr, lc in [(3, 3), (4, 4), (5, 5), (3, 4), (3, 5), (4, 5), (6, 6), (5, 6), (7, 7), (6, 7), (8, 8), (7, 8)]:
+        a, b = np.zeros(65536, np.int32), np.zeros(65536, np.int32)
+        n1 = L.j40hip_kat_natural_order(lr, lc, a.ctypes.data)
+        n2 = ref.lib.ref_kat_natural_order(lr, lc, b.ctypes.data)
+        assert n1 == n2 == 1 << (lr + lc) and np.array_equal(a[:n1], b[:n2]), (lr, lc)
+    for idx in range(17):
+        a, b = np.zeros((65536, 3), np.float32), np.zeros((65536, 3), np.float32)
+        n1 = L.j40hip_kat_library_dq_matrix(idx, a.ctypes.data)
+        n2 = ref.lib.ref_kat_library_dq_matrix(idx, b.ctypes.data)
+        assert n1 == n2 > 0 and np.array_equal(a[:n1].view(np.uint32), b[:n2].view(np.uint32)), idx
+    rng = np.random.default_rng(5)
+    for lr in range(0, 6):
+        for lc in range(0, 6):
+            if lr == 0 and lc == 0:
+                continue
+            x = rng.normal(size=(1 << lr) * (1 << lc)).astype(np.float32)
+            a, b = x.copy(), x.copy()
+            L.j40hip_kat_forward_llf(a.ctypes.data, lr, lc)
+            ref.lib.ref_kat_forward_llf(b.ctypes.data, lr, lc)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (lr, lc)
+
+
+def test_parse_errors_match_reference(ref):
+    import j40_amd
+    data = bytearray(synth("vardct", 520, 264, 21))
+    for cut in (3, 40, 200):
+        e1 = ref.decode(bytes(data[:cut]))[0]
+        with pytest.raises(j40_amd.J40Error) as ei:
+            j40_amd.Frame(bytes(data[:cut]))
+        assert ei.value.code == e1 == "shrt"
+    assert ref.decode(b"JUNKJUNKJUNK")[0] == "!jxl"
+    with pytest.raises(j40_amd.J40Error) as ei:
+        j40_amd.Frame(b"JUNKJUNKJUNK")
+    assert ei.value.code == "!jxl"
