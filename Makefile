@@ -32,7 +32,7 @@ hostsim: build/libhostsim.so
 # device functions compiled for the CPU, test infrastructure only (tests/hostsim)
 build/libhostsim.so: tests/hostsim/hostsim.cpp $(SRC)/plan_build.cpp $(SRC)/entropy.cpp $(SRC)/modular.cpp $(SRC)/tables.cpp $(SRC)/frame.cpp $(wildcard $(SRC)/device/*.h) $(wildcard $(SRC)/*.hpp)
 	@mkdir -p build
-	$(CXX) -std=c++17 -O2 -fPIC -shared -ffp-contract=off -Wall -Wextra -Wno-unused-function -o $@ tests/hostsim/hostsim.cpp $(SRC)/plan_build.cpp $(SRC)/entropy.cpp $(SRC)/modular.cpp $(SRC)/tables.cpp $(SRC)/frame.cpp -lpthread
+	$(CXX) -std=c++17 -O2 -fPIC -shared -ffp-contract=off -Wall -Wextra -Wno-unused-function -Wno-unknown-pragmas -o $@ tests/hostsim/hostsim.cpp $(SRC)/plan_build.cpp $(SRC)/entropy.cpp $(SRC)/modular.cpp $(SRC)/tables.cpp $(SRC)/frame.cpp -lpthread
 
 build/jxlsynth: tools/jxlsynth.cpp $(wildcard tools/*.hpp)
 	@mkdir -p build

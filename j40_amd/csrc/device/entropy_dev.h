@@ -23,35 +23,44 @@
 namespace j40hip {
 
 struct DevBits {
-	const uint8_t *base;   // start of the codestream buffer (padded with >= 8 readable bytes)
+	const uint8_t *base;   // start of the codestream buffer: 4-byte aligned, padded with >= 8 readable bytes
 	uint32_t pos, end;     // next unread byte / end of the section, relative to base
 	uint64_t bits;
 	int32_t nbits;
 	uint32_t err;          // first error (sticky)
+	uint32_t ahead;        // the aligned 32-bit word at `pos`, loaded one refill ahead of its use
 };
 
 J40_DEV void bits_set_error(DevBits &b, uint32_t e) { if (!b.err) b.err = e; }
 
+J40_DEV uint32_t bits_load32(const uint8_t *p) { return *(const uint32_t *) p; }
+
 J40_DEV void bits_init(DevBits &b, const uint8_t *base, uint32_t byte_off, uint32_t size, uint32_t bit_off) {
 	b.base = base; b.pos = byte_off + (bit_off >> 3); b.end = byte_off + size; b.bits = 0; b.nbits = 0; b.err = 0;
-	uint32_t rem = bit_off & 7;
+	const uint32_t rem = bit_off & 7;
 	if (rem) {  // start in the middle of a byte (single-section frames)
 		if (b.pos < b.end) { b.bits = (uint64_t) base[b.pos++] >> rem; b.nbits = 8 - (int32_t) rem; }
 		else bits_set_error(b, ERR_SHRT);
 	}
+	while ((b.pos & 3) && b.pos < b.end) { b.bits |= (uint64_t) base[b.pos++] << b.nbits; b.nbits += 8; }  // reach word alignment
+	b.ahead = bits_load32(base + (b.pos & ~3u));  // inside the padded buffer even when pos == end
 }
 
-// tops the accumulator up to >= 32 valid bits (as long as the section has bytes left); bytes past
-// the section end are never consumed
+// tops the accumulator up to >= 32 valid bits (as long as the section has bytes left); bytes past the
+// section end are never consumed. The word consumed here was requested at the previous refill, so
+// its memory latency overlaps with decoding instead of stalling this lane.
 J40_DEV void bits_refill(DevBits &b) {
 	if (b.nbits > 32) return;
-	uint32_t avail = b.end - b.pos;
+	const uint32_t avail = b.end - b.pos;
 	if (avail >= 4) {
-		uint32_t w = (uint32_t) b.base[b.pos] | ((uint32_t) b.base[b.pos + 1] << 8) | ((uint32_t) b.base[b.pos + 2] << 16) | ((uint32_t) b.base[b.pos + 3] << 24);
+		const uint32_t w = b.ahead;
+		b.pos += 4;
+		b.ahead = bits_load32(b.base + b.pos);
 		b.bits |= (uint64_t) w << b.nbits;
-		b.nbits += 32; b.pos += 4;
-	} else {
-		while (avail-- > 0) { b.bits |= (uint64_t) b.base[b.pos++] << b.nbits; b.nbits += 8; }
+		b.nbits += 32;
+	} else if (avail) {
+		b.bits |= (uint64_t) (b.ahead & ((1u << (8 * avail)) - 1)) << b.nbits;
+		b.nbits += 8 * (int32_t) avail; b.pos += avail;
 	}
 }
 
@@ -60,7 +69,7 @@ J40_DEV uint32_t bits_u(DevBits &b, int32_t n) {  // n in [0, 31]
 		bits_refill(b);
 		if (b.nbits < n) { bits_set_error(b, ERR_SHRT); b.bits = 0; b.nbits = 0; return 0; }
 	}
-	uint32_t v = (uint32_t) b.bits & ((1u << n) - 1);
+	const uint32_t v = (uint32_t) b.bits & ((1u << n) - 1);
 	b.bits >>= n; b.nbits -= n;
 	return v;
 }
@@ -85,23 +94,27 @@ J40_DEV void bits_finish_section(DevBits &b) {
 // ------------------------------------------------------------------------------------------------
 
 struct DevCode {
-	const DevCodeSpec *spec;
-	const DevCluster *clusters;
-	const uint8_t *cluster_map;
-	const uint64_t *pool_u64;
-	const int32_t *pool_i32;
+	// the code spec's scalars, copied once so that the per-symbol path never goes back to memory for them
+	int32_t use_prefix_code, lz77_enabled, min_symbol, min_length, num_dist;
+	uint32_t lz_len_cfg; int32_t lz_len_max_token;
+	// tables; may point into LDS (staged by the kernel) or HBM
+	const DevCluster *clusters;      // this spec's clusters
+	const uint8_t *cluster_map;      // this spec's context -> cluster map
+	const uint64_t *alias;           // base that DevCluster::table_off indexes (ANS)
+	const int32_t *prefix;           // base that DevCluster::table_off indexes (prefix codes)
 	uint32_t ans_state;
 	int32_t log_bucket;
 	// LZ77
 	int32_t num_to_copy, copy_pos, num_decoded;
-	int32_t *window; uint32_t window_mask_ok;  // window == nullptr: LZ77 unavailable
+	int32_t *window;                 // nullptr: LZ77 unavailable
 };
 
-J40_DEV void code_init(DevCode &c, const DevPlan &plan, const DevCodeSpec *spec, int32_t *window) {
-	c.spec = spec; c.clusters = plan.clusters + spec->cluster_off; c.cluster_map = plan.pool_u8 + spec->cluster_map_off;
-	c.pool_u64 = plan.pool_u64; c.pool_i32 = plan.pool_i32;
-	c.ans_state = 0; c.log_bucket = 12 - spec->log_alpha_size;
-	c.num_to_copy = c.copy_pos = c.num_decoded = 0; c.window = window; c.window_mask_ok = 0;
+J40_DEV void code_init(DevCode &c, const DevCodeSpec &spec, const DevCluster *clusters, const uint8_t *cluster_map, const uint64_t *alias, const int32_t *prefix, int32_t *window) {
+	c.use_prefix_code = spec.use_prefix_code; c.lz77_enabled = spec.lz77_enabled; c.min_symbol = spec.min_symbol; c.min_length = spec.min_length;
+	c.num_dist = spec.num_dist; c.lz_len_cfg = spec.lz_len_cfg; c.lz_len_max_token = spec.lz_len_max_token;
+	c.clusters = clusters; c.cluster_map = cluster_map; c.alias = alias; c.prefix = prefix;
+	c.ans_state = 0; c.log_bucket = 12 - spec.log_alpha_size;
+	c.num_to_copy = c.copy_pos = c.num_decoded = 0; c.window = window;
 }
 
 J40_DEV int32_t hybrid_int_dev(DevBits &b, int32_t token, uint32_t cfg, int32_t max_token) {  // j40.h:2313
@@ -120,7 +133,7 @@ J40_DEV int32_t hybrid_int_dev(DevBits &b, int32_t token, uint32_t cfg, int32_t 
 J40_DEV int32_t ans_symbol(DevBits &b, DevCode &c, const DevCluster &cl) {  // j40.h:2441
 	if (c.ans_state == 0) { c.ans_state = bits_u(b, 16); c.ans_state |= bits_u(b, 16) << 16; }
 	const uint32_t idx = c.ans_state & 0xfff, i = idx >> c.log_bucket, pos = idx & ((1u << c.log_bucket) - 1);
-	const uint64_t e = c.pool_u64[cl.table_off + i];
+	const uint64_t e = c.alias[cl.table_off + i];
 	const bool aliased = pos >= (uint32_t) (e & 0xff);
 	const uint32_t symbol = aliased ? (uint32_t) (e >> 20) & 0xff : i;
 	const uint32_t offset = aliased ? (uint32_t) (e >> 8) & 0xfff : 0;
@@ -131,7 +144,7 @@ J40_DEV int32_t ans_symbol(DevBits &b, DevCode &c, const DevCluster &cl) {  // j
 }
 
 J40_DEV int32_t prefix_symbol(DevBits &b, const DevCode &c, const DevCluster &cl) {  // j40.h:2256
-	const int32_t *table = c.pool_i32 + cl.table_off;
+	const int32_t *table = c.prefix + cl.table_off;
 	const uint32_t window = bits_peek16(b);
 	int32_t entry = table[window & ((1u << cl.fast_len) - 1)];
 	int32_t used = 0;
@@ -147,7 +160,7 @@ J40_DEV int32_t prefix_symbol(DevBits &b, const DevCode &c, const DevCluster &cl
 }
 
 J40_DEV int32_t cluster_token(DevBits &b, DevCode &c, const DevCluster &cl) {
-	return c.spec->use_prefix_code ? prefix_symbol(b, c, cl) : ans_symbol(b, c, cl);
+	return c.use_prefix_code ? prefix_symbol(b, c, cl) : ans_symbol(b, c, cl);
 }
 
 // LZ77 special distances, (dx + 7) * 16 + dy (spec table; cf. j40.h:2834)
@@ -167,9 +180,8 @@ static const uint8_t LZ77_SPECIAL_DISTANCES[120] = {
 // window_size symbols (sized from the section's symbol bound on the host), so indices do not wrap
 // before the reference's 2^20 mask would
 J40_DEV int32_t code_lz77_copy(DevBits &b, DevCode &c, int32_t token, int32_t dist_mult) {
-	const DevCodeSpec *spec = c.spec;
-	const DevCluster &lz = c.clusters[c.cluster_map[spec->num_dist - 1]];
-	const int32_t num_to_copy = hybrid_int_dev(b, token - spec->min_symbol, spec->lz_len_cfg, spec->lz_len_max_token) + spec->min_length;
+	const DevCluster &lz = c.clusters[c.cluster_map[c.num_dist - 1]];
+	const int32_t num_to_copy = hybrid_int_dev(b, token - c.min_symbol, c.lz_len_cfg, c.lz_len_max_token) + c.min_length;
 	token = cluster_token(b, c, lz);
 	int32_t distance = hybrid_int_dev(b, token, lz.cfg, lz.max_token);
 	if (!dist_mult) ++distance;
@@ -187,13 +199,12 @@ J40_DEV int32_t code_lz77_copy(DevBits &b, DevCode &c, int32_t token, int32_t di
 }
 
 J40_DEV int32_t code_symbol(DevBits &b, DevCode &c, int32_t ctx, int32_t dist_mult, uint32_t window_size) {  // j40.h:2804
-	const DevCodeSpec *spec = c.spec;
 	if (c.num_to_copy == 0) {
 		const DevCluster &cl = c.clusters[c.cluster_map[ctx]];
 		int32_t token = cluster_token(b, c, cl);
-		if (token < spec->min_symbol) {
+		if (token < c.min_symbol) {
 			token = hybrid_int_dev(b, token, cl.cfg, cl.max_token);
-			if (spec->lz77_enabled) {
+			if (c.lz77_enabled) {
 				if (!c.window || (uint32_t) c.num_decoded >= window_size) { bits_set_error(b, ERR_TODO); return token; }
 				c.window[c.num_decoded++] = token;
 			}
@@ -212,7 +223,7 @@ J40_DEV int32_t code_symbol(DevBits &b, DevCode &c, int32_t ctx, int32_t dist_mu
 }
 
 J40_DEV void code_finish(DevBits &b, DevCode &c) {  // j40.h:2884
-	if (!c.spec->use_prefix_code) {
+	if (!c.use_prefix_code) {
 		if (c.ans_state) { if (c.ans_state != 0x130000) bits_set_error(b, ERR_ANS); }
 		else { if (bits_u(b, 16) != 0x0000) bits_set_error(b, ERR_ANS); if (bits_u(b, 16) != 0x0013) bits_set_error(b, ERR_ANS); }
 	}

@@ -35,71 +35,100 @@ static const int16_t DEV_NNZ_CTX2[64] = {
 
 J40_DEV int32_t unpack_signed_dev(int32_t x) { return (x & 1) ? -(x / 2 + 1) : x / 2; }
 
-// decodes the HF coefficients of group `g` for every pass; returns nothing, errors go to plan.status
+// what one section decode reads besides the bitstream. The kernel stages these in LDS when they fit
+// (the serial decoder then never waits on HBM for a table), otherwise they point into HBM.
+struct HfTables {
+	const DevCluster *clusters;      // of this pass' code spec
+	const uint8_t *cluster_map;
+	const uint64_t *alias;
+	const int32_t *prefix;
+	const uint8_t *block_ctx_map;
+	const int16_t *nnz_ctx2;         // DEV_NNZ_CTX2
+	const int8_t *freq_ctx2;         // DEV_FREQ_CTX2
+	const DevGroupBlock *blocks;     // this group's varblocks in visiting order
+	int32_t nblocks;
+	int8_t *nonzeros;                // [32 * 32][3] scratch
+	int32_t *window;                 // LZ77 window or nullptr
+};
+
+// decodes one (pass, group) section. SCAN: single-pass frames store each coefficient at its scan
+// position (plain store; the pixel kernels undo the order), otherwise accumulate at the canonical
+// position like j40.h:6989.
+template <bool SCAN>
+J40_DEV uint32_t decode_hf_section(const DevPlan &plan, const DevFrame &f, const DevCodeSpec &spec, const HfTables &t, int32_t pass, const DevSection &sec) {
+	const DevLfGroup &gg = plan.lf_groups[sec.ggidx];
+	DevBits b;
+	bits_init(b, plan.codestream, sec.byte_off, sec.size, sec.bit_off);
+	const uint32_t preset = bits_u(b, f.preset_bits);
+	if ((int32_t) preset >= f.num_hf_presets) bits_set_error(b, ERR_RNGE);
+	const int32_t ctxoff = 495 * f.nb_block_ctx * (int32_t) preset;
+	DevCode code;
+	code_init(code, spec, t.clusters, t.cluster_map, t.alias, t.prefix, t.window);
+	const int32_t gw8 = sec.gw8;
+	const int32_t nb_block_ctx = f.nb_block_ctx, nb_qf1 = f.nb_qf_thr + 1, lfidx_size = f.lfidx_size;
+	const int32_t bctxc = 13 * nb_qf1 * lfidx_size;
+	const size_t cell64 = (size_t) gg.cell_base * 64;
+	for (int32_t k = 0; k < t.nblocks && !b.err; ++k) {
+		const DevGroupBlock gb = t.blocks[k];
+		const int32_t dctsel = gb.pos_dct >> 10, nzpos = ((gb.pos_dct >> 5) & 31) * gw8 + (gb.pos_dct & 31);
+		const int32_t x8 = gb.pos_dct & 31, y8 = (gb.pos_dct >> 5) & 31;
+		const int32_t log_rows = DEV_DCT_SELECT[dctsel][0], log_columns = DEV_DCT_SELECT[dctsel][1], order_idx = DEV_DCT_SELECT[dctsel][2];
+		const int32_t log_size = log_rows + log_columns, shift = log_size - 6, size = 1 << log_size;
+		const int32_t coeffoff = (int32_t) (gb.coeffoff_qfidx & ~15u), qfidx = (int32_t) (gb.coeffoff_qfidx & 15u);
+		const int32_t bctx0 = (order_idx * nb_qf1 + qfidx) * lfidx_size + gb.lfidx;
+		for (int32_t c_yxb = 0; c_yxb < 3 && !b.err; ++c_yxb) {
+			const int32_t c = c_yxb == 0 ? 1 : c_yxb == 1 ? 0 : 2;
+			float *coeffs = plan.coeffs[c] + cell64 + coeffoff;
+			const int32_t bctx = t.block_ctx_map[bctx0 + bctxc * c_yxb];
+			// number of non-zeros, predicted from the left / top blocks (j40.h:6959-6967)
+			int32_t nz;
+			if (x8 > 0) nz = y8 > 0 ? (t.nonzeros[(nzpos - 1) * 3 + c] + t.nonzeros[(nzpos - gw8) * 3 + c] + 1) >> 1 : t.nonzeros[(nzpos - 1) * 3 + c];
+			else nz = y8 > 0 ? t.nonzeros[(nzpos - gw8) * 3 + c] : 32;
+			const int32_t nzctx = ctxoff + bctx + (nz < 8 ? nz : 4 + nz / 2) * nb_block_ctx;
+			nz = code_symbol(b, code, nzctx, 0, plan.lz_window_size);
+			if (nz > (63 << shift)) { bits_set_error(b, ERR_COEF); break; }
+			const int32_t qnz = (nz + (1 << shift) - 1) >> shift;
+			for (int32_t i = 0; i < (1 << (log_rows - 3)); ++i) for (int32_t j = 0; j < (1 << (log_columns - 3)); ++j)
+				t.nonzeros[(nzpos + i * gw8 + j) * 3 + c] = (int8_t) qnz;
+			const int32_t cctx = ctxoff + 458 * bctx + 37 * nb_block_ctx;
+			int32_t prev = nz <= (size >> 4);
+			const uint16_t *order = SCAN ? nullptr : plan.pool_u16 + f.order_off[(pass * 13 + order_idx) * 3 + c];
+			for (int32_t i = 1 << shift; nz > 0 && i < size; ++i) {
+				const int32_t ctx = cctx + t.nnz_ctx2[(nz + (1 << shift) - 1) >> shift] + t.freq_ctx2[i >> shift] + prev;
+				const int32_t ucoeff = code_symbol(b, code, ctx, 0, plan.lz_window_size);
+				if (ucoeff) {
+					const float v = (float) unpack_signed_dev(ucoeff);
+					if (SCAN) coeffs[i] = v; else coeffs[order[i]] += v;
+				}
+				prev = ucoeff != 0;
+				nz -= prev;
+				if (b.err) break;
+			}
+			if (nz != 0) bits_set_error(b, ERR_COEF);
+		}
+	}
+	if (!b.err) code_finish(b, code);
+	if (!b.err) bits_finish_section(b);
+	return b.err;
+}
+
+// whole group, all passes, every table read straight from HBM (used by tests/hostsim and as the
+// kernel's fallback when a frame's tables do not fit the LDS budget)
 J40_DEV void decode_hf_group(const DevPlan &plan, int32_t g) {
 	const DevFrame &f = *plan.frame;
-	int8_t *nonzeros = plan.nonzeros + (size_t) g * (32 * 32 * 3);
-	int32_t *window = plan.lz_window ? plan.lz_window + (size_t) g * plan.lz_window_size : nullptr;
-	const uint8_t *block_ctx_map = plan.pool_u8 + plan.block_ctx_map_off;
+	HfTables t;
+	t.block_ctx_map = plan.pool_u8 + plan.block_ctx_map_off;
+	t.nnz_ctx2 = DEV_NNZ_CTX2; t.freq_ctx2 = DEV_FREQ_CTX2;
+	t.blocks = plan.group_blocks + plan.group_block_start[g];
+	t.nblocks = (int32_t) (plan.group_block_start[g + 1] - plan.group_block_start[g]);
+	t.nonzeros = plan.nonzeros + (size_t) g * (32 * 32 * 3);
+	t.window = plan.lz_window ? plan.lz_window + (size_t) g * plan.lz_window_size : nullptr;
 	for (int32_t pass = 0; pass < f.num_passes; ++pass) {
+		const DevCodeSpec &spec = plan.coeff_specs[pass];
+		t.clusters = plan.clusters + spec.cluster_off; t.cluster_map = plan.pool_u8 + spec.cluster_map_off;
+		t.alias = plan.pool_u64; t.prefix = plan.pool_i32;
 		const DevSection &sec = plan.sections[pass * f.num_groups + g];
-		const DevLfGroup &gg = plan.lf_groups[sec.ggidx];
-		DevBits b;
-		bits_init(b, plan.codestream, sec.byte_off, sec.size, sec.bit_off);
-		const uint32_t preset = bits_u(b, f.preset_bits);
-		if ((int32_t) preset >= f.num_hf_presets) bits_set_error(b, ERR_RNGE);
-		const int32_t ctxoff = 495 * f.nb_block_ctx * (int32_t) preset;
-		DevCode code;
-		code_init(code, plan, plan.coeff_specs + pass, window);
-		const int32_t gw8 = sec.gw8, gh8 = sec.gh8;
-		for (int32_t y8 = 0; y8 < gh8 && !b.err; ++y8) for (int32_t x8 = 0; x8 < gw8 && !b.err; ++x8) {
-			const int32_t cell = gg.cell_base + (sec.gy8 + y8) * gg.width8 + (sec.gx8 + x8);
-			const int32_t blk = plan.blocks[cell];
-			int32_t dctsel = blk >> 20;
-			if (dctsel < 2) continue;  // not the top-left cell of a varblock
-			dctsel -= 2;
-			const int32_t voff = gg.vb_base + (blk & 0xfffff);
-			const int32_t log_rows = DEV_DCT_SELECT[dctsel][0], log_columns = DEV_DCT_SELECT[dctsel][1], order_idx = DEV_DCT_SELECT[dctsel][2];
-			const int32_t log_size = log_rows + log_columns;
-			const int32_t cq = plan.vb_coeffoff_qfidx[voff];
-			const int32_t coeffoff = cq & ~15, qfidx = cq & 15;
-			const int32_t lfidx = plan.lfindices[cell];
-			const int32_t bctx0 = (order_idx * (f.nb_qf_thr + 1) + qfidx) * f.lfidx_size + lfidx;
-			const int32_t bctxc = 13 * (f.nb_qf_thr + 1) * f.lfidx_size;
-			const int32_t nzpos = y8 * gw8 + x8;
-			for (int32_t c_yxb = 0; c_yxb < 3 && !b.err; ++c_yxb) {
-				const int32_t c = c_yxb == 0 ? 1 : c_yxb == 1 ? 0 : 2;
-				float *coeffs = plan.coeffs[c] + (size_t) gg.cell_base * 64 + coeffoff;
-				const uint32_t ooff = f.order_off[(pass * 13 + order_idx) * 3 + c];
-				const uint16_t *order = plan.pool_u16 + ooff;
-				const int32_t bctx = block_ctx_map[bctx0 + bctxc * c_yxb];
-				// number of non-zeros, predicted from the left / top blocks (j40.h:6959-6967)
-				int32_t nz;
-				if (x8 > 0) nz = y8 > 0 ? (nonzeros[(nzpos - 1) * 3 + c] + nonzeros[(nzpos - gw8) * 3 + c] + 1) >> 1 : nonzeros[(nzpos - 1) * 3 + c];
-				else nz = y8 > 0 ? nonzeros[(nzpos - gw8) * 3 + c] : 32;
-				const int32_t nzctx = ctxoff + bctx + (nz < 8 ? nz : 4 + nz / 2) * f.nb_block_ctx;
-				nz = code_symbol(b, code, nzctx, 0, plan.lz_window_size);
-				if (nz > (63 << (log_size - 6))) { bits_set_error(b, ERR_COEF); break; }
-				const int32_t qnz = (nz + (1 << (log_size - 6)) - 1) >> (log_size - 6);
-				for (int32_t i = 0; i < (1 << (log_rows - 3)); ++i) for (int32_t j = 0; j < (1 << (log_columns - 3)); ++j)
-					nonzeros[(nzpos + i * gw8 + j) * 3 + c] = (int8_t) qnz;
-				const int32_t cctx = ctxoff + 458 * bctx + 37 * f.nb_block_ctx;
-				int32_t prev = nz <= (1 << (log_size - 4));
-				const int32_t size = 1 << log_size, shift = log_size - 6;
-				for (int32_t i = 1 << shift; nz > 0 && i < size; ++i) {
-					const int32_t ctx = cctx + DEV_NNZ_CTX2[(nz + (1 << shift) - 1) >> shift] + DEV_FREQ_CTX2[i >> shift] + prev;
-					const int32_t ucoeff = code_symbol(b, code, ctx, 0, plan.lz_window_size);
-					if (ucoeff) coeffs[order[i]] += (float) unpack_signed_dev(ucoeff);
-					prev = ucoeff != 0;
-					nz -= prev;
-					if (b.err) break;
-				}
-				if (nz != 0) bits_set_error(b, ERR_COEF);
-			}
-		}
-		if (!b.err) code_finish(b, code);
-		if (!b.err) bits_finish_section(b);
-		plan.status[pass * f.num_groups + g] = b.err;
+		plan.status[pass * f.num_groups + g] = f.scan_order_coeffs ? decode_hf_section<true>(plan, f, spec, t, pass, sec) : decode_hf_section<false>(plan, f, spec, t, pass, sec);
 	}
 }
 

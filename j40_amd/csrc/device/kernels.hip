@@ -28,16 +28,84 @@ void upload_constant_tables(const float *half_secants, const float *afv_basis, h
 // ------------------------------------------------------------------------------------------------
 // K1
 
-// `lanes` sections per wavefront: lane l < lanes of wave w handles group first_group + w * lanes + l.
-// lanes = 1 keeps each sequential decoder alone on its wave (lowest latency per section);
-// larger values trade latency for occupancy when a launch carries many more sections than the chip
-// has wave slots.
-__global__ void __launch_bounds__(64) k_hf_entropy(DevPlan plan, int32_t first_group, int32_t num_groups, int32_t lanes) {
-	const int32_t lane = threadIdx.x;
-	if (lane >= lanes) return;
-	const int32_t idx = blockIdx.x * lanes + lane;
-	if (idx >= num_groups) return;
-	decode_hf_group(plan, first_group + idx);
+// One wavefront per group, HF_WAVES groups per workgroup. Lane 0 of each wave runs the sequential
+// decoder; all lanes of the workgroup first stage what the decoder keeps touching into LDS:
+//   shared by the workgroup: context -> cluster map, cluster descriptors, rANS alias / prefix tables
+//                            of the current pass, block context map, the two small context tables
+//   per wave:                the group's block list (visiting order) and its non-zero-count scratch
+// so the serial path waits on LDS (~64 cycles) instead of HBM/L2 (500-900 cycles) for every symbol.
+// The bitstream itself is read through a one-word-ahead prefetch (entropy_dev.h).
+struct HfLdsLayout {
+	uint32_t off_bctx, off_nnz, off_freq, off_map, off_clusters, off_tables, off_wave;  // byte offsets
+	uint32_t wave_bytes, off_wave_blocks;  // per-wave area: nonzeros first, then the block list
+	uint32_t total;
+};
+
+template <bool TABLES_IN_LDS>
+__global__ void __launch_bounds__(64 * HF_WAVES) k_hf_entropy(DevPlan plan, int32_t first_group, int32_t num_groups, HfLdsLayout lay) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t hf_lds[];
+	const DevFrame &f = *plan.frame;
+	const int32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const int32_t local = blockIdx.x * HF_WAVES + wave;
+	const bool active = local < num_groups;
+	const int32_t g = first_group + local;
+
+	uint8_t *l_bctx = hf_lds + lay.off_bctx;
+	int16_t *l_nnz = (int16_t *) (hf_lds + lay.off_nnz);
+	int8_t *l_freq = (int8_t *) (hf_lds + lay.off_freq);
+	uint8_t *l_map = hf_lds + lay.off_map;
+	DevCluster *l_clusters = (DevCluster *) (hf_lds + lay.off_clusters);
+	uint8_t *l_tables = hf_lds + lay.off_tables;
+	int8_t *l_nonzeros = (int8_t *) (hf_lds + lay.off_wave + wave * lay.wave_bytes);
+	DevGroupBlock *l_blocks = (DevGroupBlock *) (hf_lds + lay.off_wave + wave * lay.wave_bytes + lay.off_wave_blocks);
+
+	// frame-level tables
+	{
+		const uint8_t *src = plan.pool_u8 + plan.block_ctx_map_off;
+		const int32_t n = 39 * f.lfidx_size * (f.nb_qf_thr + 1);
+		for (int32_t i = tid; i < n; i += blockDim.x) l_bctx[i] = src[i];
+		if (tid < 64) { l_nnz[tid] = DEV_NNZ_CTX2[tid]; l_freq[tid] = DEV_FREQ_CTX2[tid]; }
+	}
+	HfTables t;
+	t.block_ctx_map = l_bctx; t.nnz_ctx2 = l_nnz; t.freq_ctx2 = l_freq;
+	t.nonzeros = l_nonzeros;
+	t.window = plan.lz_window && active ? plan.lz_window + (size_t) g * plan.lz_window_size : nullptr;
+	t.nblocks = 0; t.blocks = l_blocks;
+	if (active) {
+		const uint32_t b0 = plan.group_block_start[g], b1 = plan.group_block_start[g + 1];
+		t.nblocks = (int32_t) (b1 - b0);
+		const uint64_t *src = (const uint64_t *) (plan.group_blocks + b0);   // 8-byte entries
+		uint64_t *dst = (uint64_t *) l_blocks;
+		for (int32_t i = lane; i < t.nblocks; i += 64) dst[i] = src[i];
+	}
+	for (int32_t pass = 0; pass < f.num_passes; ++pass) {
+		const DevCodeSpec &spec = plan.coeff_specs[pass];
+		if (TABLES_IN_LDS) {
+			__syncthreads();  // everyone is done with the previous pass' tables
+			const uint8_t *msrc = plan.pool_u8 + spec.cluster_map_off;
+			for (int32_t i = tid; i < spec.num_dist; i += blockDim.x) l_map[i] = msrc[i];
+			// tables of this spec's clusters are contiguous in their pool: copy the span, rebase offsets
+			const DevCluster *csrc = plan.clusters + spec.cluster_off;
+			const uint32_t base_off = csrc[0].table_off;
+			for (int32_t i = tid; i < spec.num_clusters; i += blockDim.x) { DevCluster c = csrc[i]; c.table_off -= base_off; l_clusters[i] = c; }
+			if (spec.use_prefix_code) {
+				const int32_t *src = plan.pool_i32 + base_off; int32_t *dst = (int32_t *) l_tables;
+				for (uint32_t i = tid; i < spec.table_span; i += blockDim.x) dst[i] = src[i];
+			} else {
+				const uint64_t *src = plan.pool_u64 + base_off; uint64_t *dst = (uint64_t *) l_tables;
+				for (uint32_t i = tid; i < spec.table_span; i += blockDim.x) dst[i] = src[i];
+			}
+			t.clusters = l_clusters; t.cluster_map = l_map; t.alias = (const uint64_t *) l_tables; t.prefix = (const int32_t *) l_tables;
+		} else {
+			t.clusters = plan.clusters + spec.cluster_off; t.cluster_map = plan.pool_u8 + spec.cluster_map_off;
+			t.alias = plan.pool_u64; t.prefix = plan.pool_i32;
+		}
+		__syncthreads();
+		if (active && lane == 0) {
+			const DevSection &sec = plan.sections[pass * f.num_groups + g];
+			plan.status[pass * f.num_groups + g] = f.scan_order_coeffs ? decode_hf_section<true>(plan, f, spec, t, pass, sec) : decode_hf_section<false>(plan, f, spec, t, pass, sec);
+		}
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -51,7 +119,7 @@ __global__ void __launch_bounds__(64) k_hf_entropy(DevPlan plan, int32_t first_g
 // dimension first, then over rows.
 
 template <int LOGR, int LOGC, int NB>
-__global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarblock *list, int32_t count, int32_t param_idx, uint8_t *rgba, size_t stride_bytes) {
+__global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarblock *list, int32_t count, int32_t param_idx, int32_t order_idx, uint8_t *rgba, size_t stride_bytes) {
 	constexpr int R = 1 << LOGR, C = 1 << LOGC, P = C + 1, TILE = R * P;
 	constexpr int LONG = R > C ? R : C;                  // columns of the canonical (short side = rows) layout
 	constexpr int VH8 = (R < C ? R : C) / 8, VW8 = LONG / 8;
@@ -62,6 +130,7 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarbl
 	const int32_t nb = min(NB, count - first);
 	const float *dq = plan.pool_f32 + f.dq_off[param_idx];
 	const int32_t dq_size = R * C;
+	const uint16_t *inv_order = f.scan_order_coeffs ? plan.pool_u16 + f.inv_order_off[order_idx * 3] : nullptr;
 	__shared__ VbGeom geom[NB];
 	if (tid < nb) geom[tid] = varblock_geometry(plan, list[first + tid], R, C);
 	__syncthreads();
@@ -71,7 +140,7 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarbl
 		const int32_t b = w / (R * C), i = w - b * (R * C);
 		const VbGeom &g = geom[b];
 		float v[3];
-		load_coeff3(plan, g, dq, dq_size, i, LONG, VH8, VW8, v);
+		load_coeff3(plan, g, dq, dq_size, i, LONG, VH8, VW8, v, inv_order);
 		// canonical index -> (r, c): the array is [R][C] when C > R, else [C][R] (j40.h:5978-5985)
 		const int32_t r = C > R ? i / C : i % R, c = C > R ? i % C : i / R;
 		float *t = lds + (size_t) b * 3 * TILE + r * P + c;
@@ -132,8 +201,9 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan, const DevV
 		const VbGeom &g = geom[b];
 		const int32_t param_idx = vb.dctsel == 1 ? 1 : vb.dctsel == 2 ? 2 : vb.dctsel == 3 ? 3 : vb.dctsel <= 13 ? 9 : 10;
 		const float *dq = plan.pool_f32 + f.dq_off[param_idx];
+		const uint16_t *inv_order = f.scan_order_coeffs ? plan.pool_u16 + f.inv_order_off[1 * 3] : nullptr;  // all 8x8 specials share order 1
 		float v[3];
-		load_coeff3(plan, g, dq, 64, i, 8, 1, 1, v);
+		load_coeff3(plan, g, dq, 64, i, 8, 1, 1, v, inv_order);
 		float *t = tiles + (size_t) b * 3 * P + i;
 		t[0] = v[0]; t[P] = v[1]; t[2 * P] = v[2];
 	}
@@ -211,11 +281,12 @@ __global__ void __launch_bounds__(256) k_vardct_large(DevPlan plan, const DevVar
 	const int32_t long_side = R > C ? R : C, vh8 = (R < C ? R : C) / 8, vw8 = long_side / 8;
 	const int32_t param_idx = vb.dctsel == 21 ? 13 : vb.dctsel <= 23 ? 14 : vb.dctsel == 24 ? 15 : 16;
 	const float *dq = plan.pool_f32 + f.dq_off[param_idx];
+	const uint16_t *inv_order = f.scan_order_coeffs ? plan.pool_u16 + f.inv_order_off[DEV_DCT_SELECT[vb.dctsel][2] * 3] : nullptr;
 	const VbGeom g = varblock_geometry(plan, vb, R, C);
 	float *A = scratch + (size_t) blockIdx.x * 6 * 65536, *B = A + 3 * 65536;  // [3][size] each
 	for (int32_t i = tid; i < size; i += nthreads) {
 		float v[3];
-		load_coeff3(plan, g, dq, size, i, long_side, vh8, vw8, v);
+		load_coeff3(plan, g, dq, size, i, long_side, vh8, vw8, v, inv_order);
 		const int32_t r = C > R ? i / C : i % R, c = C > R ? i % C : i / R;
 		A[r * C + c] = v[0]; A[65536 + r * C + c] = v[1]; A[2 * 65536 + r * C + c] = v[2];
 	}
@@ -235,37 +306,57 @@ __global__ void __launch_bounds__(256) k_vardct_large(DevPlan plan, const DevVar
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 
-void launch_hf_entropy(const DevPlan &plan, int32_t first_group, int32_t num_groups, int32_t lanes, hipStream_t stream) {
+void launch_hf_entropy(const DevPlan &plan, const HfLaunchInfo &info, int32_t first_group, int32_t num_groups, hipStream_t stream) {
 	if (num_groups <= 0) return;
-	const int32_t waves = (num_groups + lanes - 1) / lanes;
-	hipLaunchKernelGGL(k_hf_entropy, dim3((unsigned) waves), dim3(64), 0, stream, plan, first_group, num_groups, lanes);
+	HfLdsLayout lay;
+	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+	uint32_t off = 0;
+	lay.off_bctx = off; off = align16(off + info.block_ctx_size);
+	lay.off_nnz = off; off += 128;
+	lay.off_freq = off; off += 64;
+	const bool in_lds = info.tables_fit_lds;
+	lay.off_map = off; off = align16(off + (in_lds ? info.max_num_dist : 0));
+	lay.off_clusters = off; off = align16(off + (in_lds ? info.max_clusters * (uint32_t) sizeof(DevCluster) : 0));
+	lay.off_tables = off; off = align16(off + (in_lds ? info.max_table_bytes : 0));
+	lay.off_wave = off;
+	lay.off_wave_blocks = 32 * 32 * 3;
+	lay.wave_bytes = align16(lay.off_wave_blocks + 1024 * (uint32_t) sizeof(DevGroupBlock));
+	lay.total = lay.off_wave + HF_WAVES * lay.wave_bytes;
+	const unsigned blocks = (unsigned) ((num_groups + HF_WAVES - 1) / HF_WAVES);
+	if (in_lds) {
+		static bool configured = false;
+		if (!configured) { (void) hipFuncSetAttribute((const void *) k_hf_entropy<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); configured = true; }
+		hipLaunchKernelGGL(k_hf_entropy<true>, dim3(blocks), dim3(64 * HF_WAVES), lay.total, stream, plan, first_group, num_groups, lay);
+	} else {
+		hipLaunchKernelGGL(k_hf_entropy<false>, dim3(blocks), dim3(64 * HF_WAVES), lay.total, stream, plan, first_group, num_groups, lay);
+	}
 }
 
 template <int LOGR, int LOGC, int NB>
-static void launch_dct(const DevPlan &plan, const DevVarblock *list, int32_t count, int32_t param_idx, uint8_t *rgba, size_t stride, hipStream_t stream) {
+static void launch_dct(const DevPlan &plan, const DevVarblock *list, int32_t count, int32_t param_idx, int32_t order_idx, uint8_t *rgba, size_t stride, hipStream_t stream) {
 	constexpr size_t lds_bytes = (size_t) NB * 3 * (1 << LOGR) * ((1 << LOGC) + 1) * sizeof(float);
 	static bool configured = false;
 	if (!configured) { (void) hipFuncSetAttribute((const void *) k_vardct_dct<LOGR, LOGC, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes); configured = true; }
 	const int32_t blocks = (count + NB - 1) / NB;
-	hipLaunchKernelGGL((k_vardct_dct<LOGR, LOGC, NB>), dim3((unsigned) blocks), dim3(256), lds_bytes, stream, plan, list, count, param_idx, rgba, stride);
+	hipLaunchKernelGGL((k_vardct_dct<LOGR, LOGC, NB>), dim3((unsigned) blocks), dim3(256), lds_bytes, stream, plan, list, count, param_idx, order_idx, rgba, stride);
 }
 
 // list = varblocks of one DctSelect value
 void launch_vardct_class(const DevPlan &plan, int32_t dctsel, const DevVarblock *list, int32_t count, float *large_scratch, uint8_t *rgba, size_t stride, hipStream_t stream) {
 	if (count <= 0) return;
 	switch (dctsel) {
-	case 0: launch_dct<3, 3, 16>(plan, list, count, 0, rgba, stride, stream); break;
-	case 4: launch_dct<4, 4, 8>(plan, list, count, 4, rgba, stride, stream); break;
-	case 5: launch_dct<5, 5, 2>(plan, list, count, 5, rgba, stride, stream); break;
-	case 6: launch_dct<4, 3, 8>(plan, list, count, 6, rgba, stride, stream); break;
-	case 7: launch_dct<3, 4, 8>(plan, list, count, 6, rgba, stride, stream); break;
-	case 8: launch_dct<5, 3, 4>(plan, list, count, 7, rgba, stride, stream); break;
-	case 9: launch_dct<3, 5, 4>(plan, list, count, 7, rgba, stride, stream); break;
-	case 10: launch_dct<5, 4, 4>(plan, list, count, 8, rgba, stride, stream); break;
-	case 11: launch_dct<4, 5, 4>(plan, list, count, 8, rgba, stride, stream); break;
-	case 18: launch_dct<6, 6, 1>(plan, list, count, 11, rgba, stride, stream); break;
-	case 19: launch_dct<6, 5, 1>(plan, list, count, 12, rgba, stride, stream); break;
-	case 20: launch_dct<5, 6, 1>(plan, list, count, 12, rgba, stride, stream); break;
+	case 0: launch_dct<3, 3, 16>(plan, list, count, 0, 0, rgba, stride, stream); break;
+	case 4: launch_dct<4, 4, 8>(plan, list, count, 4, 2, rgba, stride, stream); break;
+	case 5: launch_dct<5, 5, 2>(plan, list, count, 5, 3, rgba, stride, stream); break;
+	case 6: launch_dct<4, 3, 8>(plan, list, count, 6, 4, rgba, stride, stream); break;
+	case 7: launch_dct<3, 4, 8>(plan, list, count, 6, 4, rgba, stride, stream); break;
+	case 8: launch_dct<5, 3, 4>(plan, list, count, 7, 5, rgba, stride, stream); break;
+	case 9: launch_dct<3, 5, 4>(plan, list, count, 7, 5, rgba, stride, stream); break;
+	case 10: launch_dct<5, 4, 4>(plan, list, count, 8, 6, rgba, stride, stream); break;
+	case 11: launch_dct<4, 5, 4>(plan, list, count, 8, 6, rgba, stride, stream); break;
+	case 18: launch_dct<6, 6, 1>(plan, list, count, 11, 7, rgba, stride, stream); break;
+	case 19: launch_dct<6, 5, 1>(plan, list, count, 12, 8, rgba, stride, stream); break;
+	case 20: launch_dct<5, 6, 1>(plan, list, count, 12, 8, rgba, stride, stream); break;
 	case 1: case 2: case 3: case 12: case 13: case 14: case 15: case 16: case 17:
 		hipLaunchKernelGGL((k_vardct_special<32>), dim3((unsigned) ((count + 31) / 32)), dim3(256), 0, stream, plan, list, count, rgba, stride);
 		break;

@@ -22,7 +22,7 @@ struct DevCodeSpec {
 	int32_t lz_len_max_token;
 	uint32_t cluster_map_off;  // into the u8 pool
 	uint32_t cluster_off;      // into the DevCluster pool
-	uint32_t pad;
+	uint32_t table_span;       // elements this spec's alias (u64) / prefix (i32) tables occupy in their pool, contiguous
 };
 
 struct DevLfGroup {
@@ -41,6 +41,15 @@ struct DevSection {
 	int32_t gx8, gy8;    // cell offset of the group inside its LF group
 	int32_t gw8, gh8;    // cells
 	int32_t gx, gy, gw, gh;  // pixels: group position in the frame and size
+};
+
+// K1 work list: the varblocks of one group in the order j40__hf_coeffs visits them (raster order of
+// their top-left cells, j40.h:6907-6915), with everything the context model needs
+struct DevGroupBlock {
+	uint32_t coeffoff_qfidx;  // as j40__varblock (j40.h:6352): coefficient offset | qf index
+	uint16_t pos_dct;         // bits 0-9: y8 * 32 + x8 inside the group; bits 10-14: DctSelect
+	uint8_t lfidx;
+	uint8_t pad;
 };
 
 // work item of the coefficients -> pixels kernels, sorted by DctSelect on the host
@@ -66,6 +75,10 @@ struct DevFrame {
 	uint32_t order_off[11 * 13 * 3];  // into the u16 pool; 0xffffffff = not loaded
 	uint32_t dq_off[17];              // into the f32 pool, layout [channel][coefficient]; 0xffffffff = not loaded
 	uint32_t dq_size[17];
+	// single-pass frames: K1 stores coefficients in *scan order* (no order lookup on the serial path) and
+	// the pixel kernels gather through the inverse order: inv_order[j] = scan position of canonical index j
+	int32_t scan_order_coeffs;
+	uint32_t inv_order_off[13 * 3];   // into the u16 pool
 };
 
 // everything a kernel needs, passed by value
@@ -81,6 +94,8 @@ struct DevPlan {
 	const DevCodeSpec *coeff_specs;  // [num_passes]
 	const DevLfGroup *lf_groups;
 	const DevSection *sections;      // [num_passes * num_groups]
+	const DevGroupBlock *group_blocks;   // concatenated per group
+	const uint32_t *group_block_start;   // [num_groups + 1]
 	uint32_t block_ctx_map_off;      // into pool_u8
 	// LF bundle, frame-wide arrays concatenated over LF groups
 	const int32_t *blocks;
@@ -95,6 +110,17 @@ struct DevPlan {
 	int32_t *lz_window;              // [num_groups][lz_window_size] or null
 	uint32_t lz_window_size;
 	uint32_t *status;                // [num_passes * num_groups] 4-char codes
+};
+
+enum { HF_WAVES = 4 };  // groups (wavefronts) per K1 workgroup
+
+// what the host knows about the entropy tables' sizes, to lay out K1's LDS
+struct HfLaunchInfo {
+	uint32_t block_ctx_size;     // bytes
+	uint32_t max_num_dist;       // largest context count over the passes
+	uint32_t max_clusters;
+	uint32_t max_table_bytes;    // largest alias / prefix table span over the passes
+	bool tables_fit_lds;
 };
 
 enum {

@@ -36,6 +36,7 @@ struct j40hip_device_state {
 	float *d_large_scratch = nullptr;
 	size_t coeff_floats = 0;
 	int32_t total_sections = 0;
+	HfLaunchInfo hf;
 	std::vector<uint32_t> status_host;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 
@@ -92,6 +93,9 @@ extern "C" uint32_t j40hip_frame_upload(j40hip_frame *h, int device) {
 	plan.coeff_specs = st->upload(hp.coeff_specs.data(), hp.coeff_specs.size(), s, ok);
 	plan.lf_groups = st->upload(hp.lf_groups.data(), hp.lf_groups.size(), s, ok);
 	plan.sections = st->upload(hp.sections.data(), hp.sections.size(), s, ok);
+	plan.group_blocks = st->upload(hp.group_blocks.data(), hp.group_blocks.size(), s, ok);
+	plan.group_block_start = st->upload(hp.group_block_start.data(), hp.group_block_start.size(), s, ok);
+	st->hf = hp.hf;
 	plan.frame = st->upload(&hp.frame, 1, s, ok);
 	plan.block_ctx_map_off = hp.block_ctx_map_off;
 	plan.blocks = st->upload(hp.blocks.data(), hp.blocks.size(), s, ok);
@@ -139,7 +143,7 @@ static uint32_t decode_impl(j40hip_frame *h, void *rgba_dev, size_t stride_bytes
 	for (int c = 0; c < 3; ++c) if (hipMemsetAsync(plan.coeffs[c], 0, sizeof(float) * st->coeff_floats, s) != hipSuccess) return ERR_GPU;
 	if (hipMemsetAsync(plan.status, 0, sizeof(uint32_t) * (size_t) st->total_sections, s) != hipSuccess) return ERR_GPU;
 	if (ms3) (void) hipEventRecord(st->ev[1], s);
-	launch_hf_entropy(plan, (int32_t) st->first_group, (int32_t) st->num_groups, 1, s);
+	launch_hf_entropy(plan, st->hf, (int32_t) st->first_group, (int32_t) st->num_groups, s);
 	if (ms3) (void) hipEventRecord(st->ev[2], s);
 	if (whole) {
 		for (int d = 0; d < 27; ++d) {
@@ -205,6 +209,7 @@ extern "C" uint32_t j40hip_frame_read_coeffs(j40hip_frame *h, int64_t gg, int c,
 	size_t base = 0;
 	for (int64_t i = 0; i < gg; ++i) base += h->frame.lf_groups[(size_t) i].blocks.size();
 	if (hipMemcpy(out, h->dev->plan.coeffs[c] + base * 64, sizeof(float) * g.blocks.size() * 64, hipMemcpyDeviceToHost) != hipSuccess) return ERR_GPU;
+	coeffs_scan_to_canonical(h->frame, (size_t) gg, c, out);
 	return 0;
 }
 

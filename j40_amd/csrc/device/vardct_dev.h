@@ -36,7 +36,7 @@ J40_DEV VbGeom varblock_geometry(const DevPlan &plan, const DevVarblock &vb, int
 
 // loads coefficient `i` (canonical layout index) of all three channels: dequantised, chroma-from-luma
 // applied, LLF corner substituted (j40.h:7086-7094, 7157-7172)
-J40_DEV void load_coeff3(const DevPlan &plan, const VbGeom &g, const float *dq, int32_t dq_size, int32_t i, int32_t long_side, int32_t vh8, int32_t vw8, float out[3]) {
+J40_DEV void load_coeff3(const DevPlan &plan, const VbGeom &g, const float *dq, int32_t dq_size, int32_t i, int32_t long_side, int32_t vh8, int32_t vw8, float out[3], const uint16_t *inv_order = nullptr) {
 	const DevFrame &f = *plan.frame;
 	const int32_t srow = i / long_side, scol = i - srow * long_side;
 	if (srow < vh8 && scol < vw8) {
@@ -45,9 +45,11 @@ J40_DEV void load_coeff3(const DevPlan &plan, const VbGeom &g, const float *dq, 
 		out[0] = lx + ly * f.kx_lf; out[1] = ly; out[2] = lb + ly * f.kb_lf;
 		return;
 	}
-	const float qx = dequant_coeff(plan.coeffs[0][g.coeff_base + i], f.quant_bias[0], f.quant_bias_num, g.mult[0], dq[i]);
-	const float qy = dequant_coeff(plan.coeffs[1][g.coeff_base + i], f.quant_bias[1], f.quant_bias_num, g.mult[1], dq[dq_size + i]);
-	const float qb = dequant_coeff(plan.coeffs[2][g.coeff_base + i], f.quant_bias[2], f.quant_bias_num, g.mult[2], dq[2 * dq_size + i]);
+	// scan-order storage (single-pass frames): canonical index i lives at scan position inv_order[c][i]
+	const int32_t ix = inv_order ? inv_order[i] : i, iy = inv_order ? inv_order[dq_size + i] : i, ib = inv_order ? inv_order[2 * dq_size + i] : i;
+	const float qx = dequant_coeff(plan.coeffs[0][g.coeff_base + ix], f.quant_bias[0], f.quant_bias_num, g.mult[0], dq[i]);
+	const float qy = dequant_coeff(plan.coeffs[1][g.coeff_base + iy], f.quant_bias[1], f.quant_bias_num, g.mult[1], dq[dq_size + i]);
+	const float qb = dequant_coeff(plan.coeffs[2][g.coeff_base + ib], f.quant_bias[2], f.quant_bias_num, g.mult[2], dq[2 * dq_size + i]);
 	out[0] = qx + qy * g.kx_hf; out[1] = qy; out[2] = qb + qy * g.kb_hf;
 }
 

@@ -15,13 +15,29 @@ void flatten_code_spec(const CodeSpec &spec, std::vector<uint8_t> &u8, std::vect
 	out->lz_len_cfg = spec.lz_len_cfg.packed(); out->lz_len_max_token = spec.lz_len_cfg.max_token;
 	out->cluster_map_off = push(u8, spec.cluster_map.data(), spec.cluster_map.size());
 	out->cluster_off = (uint32_t) clusters.size();
-	out->pad = 0;
+	const size_t span0 = spec.use_prefix_code ? i32.size() : u64.size();
 	for (const Cluster &c : spec.clusters) {
 		DevCluster d;
 		d.cfg = c.cfg.packed(); d.max_token = c.cfg.max_token;
 		d.fast_len = (int16_t) c.fast_len; d.max_len = (int16_t) c.max_len;
 		d.table_off = spec.use_prefix_code ? push(i32, c.table.data(), c.table.size()) : push(u64, c.alias.data(), c.alias.size());
 		clusters.push_back(d);
+	}
+	out->table_span = (uint32_t) ((spec.use_prefix_code ? i32.size() : u64.size()) - span0);
+}
+
+void coeffs_scan_to_canonical(const Frame &fr, size_t ggidx, int c, float *data) {
+	if (fr.fh.num_passes != 1) return;
+	const LfGroup &gg = fr.lf_groups[ggidx];
+	std::vector<float> tmp;
+	for (const VarblockInfo &vb : gg.varblocks) {
+		const DctSelect &d = DCT_SELECT[vb.dctsel];
+		const std::vector<int32_t> &order = fr.orders[0][d.order_idx][c];
+		const size_t size = (size_t) 1 << (d.log_rows + d.log_columns);
+		float *blk = data + (vb.coeffoff_qfidx & ~15);
+		tmp.assign(blk, blk + size);
+		std::fill(blk, blk + size, 0.0f);
+		for (size_t i = size / 64; i < size; ++i) blk[order[i]] = tmp[i];
 	}
 }
 
@@ -111,6 +127,34 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 		d.gw8 = ceil_div(gi.gw, 8); d.gh8 = ceil_div(gi.gh, 8);
 		d.gx = fr.lf_groups[(size_t) gi.ggidx].left + gi.gx_in_gg; d.gy = fr.lf_groups[(size_t) gi.ggidx].top + gi.gy_in_gg; d.gw = gi.gw; d.gh = gi.gh;
 	}
+	// per-group block lists for K1, in the visiting order of j40__hf_coeffs
+	hp->group_block_start.assign((size_t) num_groups + 1, 0);
+	for (int32_t g = 0; g < num_groups; ++g) {
+		hp->group_block_start[(size_t) g] = (uint32_t) hp->group_blocks.size();
+		const DevSection &d = hp->sections[(size_t) g];
+		const LfGroup &gg = fr.lf_groups[(size_t) d.ggidx];
+		for (int32_t y8 = 0; y8 < d.gh8; ++y8) for (int32_t x8 = 0; x8 < d.gw8; ++x8) {
+			const size_t cell = (size_t) (d.gy8 + y8) * (size_t) gg.width8 + (size_t) (d.gx8 + x8);
+			const int32_t blk = gg.blocks[cell];
+			if ((blk >> 20) < 2) continue;
+			DevGroupBlock gb;
+			gb.coeffoff_qfidx = (uint32_t) gg.varblocks[(size_t) (blk & 0xfffff)].coeffoff_qfidx;
+			gb.pos_dct = (uint16_t) ((y8 * 32 + x8) | (((blk >> 20) - 2) << 10));
+			gb.lfidx = gg.lfindices[cell]; gb.pad = 0;
+			hp->group_blocks.push_back(gb);
+		}
+	}
+	hp->group_block_start[(size_t) num_groups] = (uint32_t) hp->group_blocks.size();
+	// inverse coefficient orders (single-pass frames store coefficients in scan order)
+	df.scan_order_coeffs = fr.fh.num_passes == 1;
+	for (int i = 0; i < 13 * 3; ++i) df.inv_order_off[i] = 0xffffffffu;
+	if (df.scan_order_coeffs) for (int o = 0; o < 13; ++o) for (int ch = 0; ch < 3; ++ch) {
+		const std::vector<int32_t> &ord = fr.orders[0][o][ch];
+		if (ord.empty()) continue;
+		std::vector<uint16_t> inv(ord.size());
+		for (size_t i = 0; i < ord.size(); ++i) inv[(size_t) ord[i]] = (uint16_t) i;
+		df.inv_order_off[o * 3 + ch] = push(hp->pool_u16, inv.data(), inv.size());
+	}
 	hp->codestream.assign(cs, cs + cs_size);
 	hp->codestream.resize(cs_size + 16, 0);
 	bool any_lz77 = false;
@@ -120,6 +164,19 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 	std::stable_sort(hp->vb_sorted.begin(), hp->vb_sorted.end(), [](const DevVarblock &a, const DevVarblock &b) { return a.dctsel < b.dctsel; });
 	size_t k = 0;
 	for (int d = 0; d <= 27; ++d) { while (k < hp->vb_sorted.size() && hp->vb_sorted[k].dctsel < d) ++k; hp->class_start[d] = (int32_t) k; }
+	// K1's LDS budget
+	HfLaunchInfo &hf = hp->hf;
+	hf.block_ctx_size = (uint32_t) fr.block_ctx_map.size(); hf.max_num_dist = hf.max_clusters = hf.max_table_bytes = 0;
+	for (const DevCodeSpec &sp : hp->coeff_specs) {
+		hf.max_num_dist = std::max<uint32_t>(hf.max_num_dist, (uint32_t) sp.num_dist);
+		hf.max_clusters = std::max<uint32_t>(hf.max_clusters, (uint32_t) sp.num_clusters);
+		hf.max_table_bytes = std::max<uint32_t>(hf.max_table_bytes, sp.table_span * (sp.use_prefix_code ? 4u : 8u));
+	}
+	{
+		const uint32_t per_wave = 32 * 32 * 3 + 1024 * (uint32_t) sizeof(DevGroupBlock) + 16;
+		const uint32_t fixed = hf.block_ctx_size + 256 + 64 + HF_WAVES * per_wave;
+		hf.tables_fit_lds = fixed + hf.max_num_dist + hf.max_clusters * (uint32_t) sizeof(DevCluster) + hf.max_table_bytes + 64 <= 150u * 1024u;
+	}
 	hp->max_large = 0;
 	for (int d = 21; d < 27; ++d) hp->max_large = std::max(hp->max_large, hp->class_start[d + 1] - hp->class_start[d]);
 	return 0;

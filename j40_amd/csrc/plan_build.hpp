@@ -19,6 +19,8 @@ struct HostPlan {
 	std::vector<DevCodeSpec> coeff_specs;
 	std::vector<DevLfGroup> lf_groups;
 	std::vector<DevSection> sections;
+	std::vector<DevGroupBlock> group_blocks;
+	std::vector<uint32_t> group_block_start;
 	uint32_t block_ctx_map_off = 0;
 	std::vector<int32_t> blocks, vb_coeffoff_qfidx;
 	std::vector<uint8_t> lfindices;
@@ -28,11 +30,17 @@ struct HostPlan {
 	int32_t class_start[28];
 	size_t coeff_floats = 0;
 	uint32_t lz_window_size = 0;          // 0: no LZ77 in any coefficient code spec
-	int32_t max_large = 0;                // most varblocks of one 128/256-sized transform type
+	int32_t max_large = 0;
+	HfLaunchInfo hf;                     // sizes that shape K1's LDS layout                // most varblocks of one 128/256-sized transform type
 };
 
 // returns 0 or a 4-char error code ("TODO" for frame kinds the hot path does not cover)
 uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostPlan *out);
+
+// single-pass frames keep HF coefficients in scan order on the device (DevFrame::scan_order_coeffs);
+// this rewrites LF group `gg`, channel c in place into the canonical layout the reference uses
+// (coeffs[order[i]], j40.h:6989) -- for stage dumps / parity tests
+void coeffs_scan_to_canonical(const Frame &fr, size_t gg, int c, float *data);
 
 // fills a DevCodeSpec and appends its tables to the pools
 void flatten_code_spec(const CodeSpec &spec, std::vector<uint8_t> &u8, std::vector<int32_t> &i32, std::vector<uint64_t> &u64, std::vector<DevCluster> &clusters, DevCodeSpec *out);

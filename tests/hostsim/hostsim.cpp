@@ -91,6 +91,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 	plan.pool_u8 = hp.pool_u8.data(); plan.pool_u16 = hp.pool_u16.data(); plan.pool_i32 = hp.pool_i32.data(); plan.pool_u64 = hp.pool_u64.data(); plan.pool_f32 = hp.pool_f32.data();
 	plan.clusters = hp.clusters.data(); plan.coeff_specs = hp.coeff_specs.data(); plan.lf_groups = hp.lf_groups.data(); plan.sections = hp.sections.data();
 	plan.block_ctx_map_off = hp.block_ctx_map_off;
+	plan.group_blocks = hp.group_blocks.data(); plan.group_block_start = hp.group_block_start.data();
 	plan.blocks = hp.blocks.data(); plan.lfindices = hp.lfindices.data();
 	for (int c = 0; c < 3; ++c) { plan.llf[c] = hp.llf[c].data(); plan.coeffs[c] = coeffs[c].data(); }
 	plan.vb_coeffoff_qfidx = hp.vb_coeffoff_qfidx.data(); plan.vb_hfmul_inv = hp.vb_hfmul_inv.data();
@@ -99,7 +100,11 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 	plan.lz_window = window.empty() ? nullptr : window.data(); plan.lz_window_size = hp.lz_window_size;
 
 	for (int32_t g = 0; g < hp.frame.num_groups; ++g) decode_hf_group(plan, g);
-	if (coeffs_out) for (int c = 0; c < 3; ++c) memcpy(coeffs_out + (size_t) c * hp.coeff_floats, coeffs[c].data(), sizeof(float) * hp.coeff_floats);
+	if (coeffs_out) for (int c = 0; c < 3; ++c) {
+		float *dst = coeffs_out + (size_t) c * hp.coeff_floats;
+		memcpy(dst, coeffs[c].data(), sizeof(float) * hp.coeff_floats);
+		for (size_t gg = 0; gg < fr.lf_groups.size(); ++gg) coeffs_scan_to_canonical(fr, gg, c, dst + (size_t) hp.lf_groups[gg].cell_base * 64);
+	}
 	for (uint32_t s : status) if (s) return s;
 	if (only_entropy) return 0;
 
@@ -119,7 +124,8 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 		const int P = special ? 8 : large ? C : C + 1;
 		for (int i = 0; i < sz; ++i) {
 			float v[3];
-			load_coeff3(plan, g, dq, sz, i, long_side, vh8, vw8, v);
+			const uint16_t *inv_order = f.scan_order_coeffs ? plan.pool_u16 + f.inv_order_off[DEV_DCT_SELECT[vb.dctsel][2] * 3] : nullptr;
+			load_coeff3(plan, g, dq, sz, i, long_side, vh8, vw8, v, inv_order);
 			int r, c;
 			if (special) { r = i / 8; c = i % 8; }
 			else { r = C > R ? i / C : i % R; c = C > R ? i % C : i / R; }
