@@ -22,6 +22,20 @@
 
 namespace j40hip {
 
+// In the latency-oriented launch every lane of a wavefront decodes the SAME section, so all decoder
+// state is wave-uniform. Values that come back from memory land in vector registers; pulling them
+// into scalar registers (v_readfirstlane) lets the compiler keep the whole serial decoder on the
+// scalar unit: scalar branches instead of exec-mask juggling, 1-cycle SALU ops instead of dependent
+// VALU ops. UNI = false is the throughput-oriented mode (one section per lane, divergent).
+template <bool UNI> J40_DEV uint32_t uni(uint32_t v) {
+#ifdef __HIPCC__
+	if (UNI) return (uint32_t) __builtin_amdgcn_readfirstlane((int) v);
+#endif
+	return v;
+}
+template <bool UNI> J40_DEV int32_t uni(int32_t v) { return (int32_t) uni<UNI>((uint32_t) v); }
+template <bool UNI> J40_DEV uint64_t uni64(uint64_t v) { return (uint64_t) uni<UNI>((uint32_t) v) | ((uint64_t) uni<UNI>((uint32_t) (v >> 32)) << 32); }
+
 struct DevBits {
 	const uint8_t *base;   // start of the codestream buffer: 4-byte aligned, padded with >= 8 readable bytes
 	uint32_t pos, end;     // next unread byte / end of the section, relative to base
@@ -35,27 +49,27 @@ J40_DEV void bits_set_error(DevBits &b, uint32_t e) { if (!b.err) b.err = e; }
 
 J40_DEV uint32_t bits_load32(const uint8_t *p) { return *(const uint32_t *) p; }
 
-J40_DEV void bits_init(DevBits &b, const uint8_t *base, uint32_t byte_off, uint32_t size, uint32_t bit_off) {
+template <bool UNI> J40_DEV void bits_init(DevBits &b, const uint8_t *base, uint32_t byte_off, uint32_t size, uint32_t bit_off) {
 	b.base = base; b.pos = byte_off + (bit_off >> 3); b.end = byte_off + size; b.bits = 0; b.nbits = 0; b.err = 0;
 	const uint32_t rem = bit_off & 7;
 	if (rem) {  // start in the middle of a byte (single-section frames)
-		if (b.pos < b.end) { b.bits = (uint64_t) base[b.pos++] >> rem; b.nbits = 8 - (int32_t) rem; }
+		if (b.pos < b.end) { b.bits = (uint64_t) (uni<UNI>((uint32_t) base[b.pos++]) >> rem); b.nbits = 8 - (int32_t) rem; }
 		else bits_set_error(b, ERR_SHRT);
 	}
-	while ((b.pos & 3) && b.pos < b.end) { b.bits |= (uint64_t) base[b.pos++] << b.nbits; b.nbits += 8; }  // reach word alignment
-	b.ahead = bits_load32(base + (b.pos & ~3u));  // inside the padded buffer even when pos == end
+	while ((b.pos & 3) && b.pos < b.end) { b.bits |= (uint64_t) uni<UNI>((uint32_t) base[b.pos++]) << b.nbits; b.nbits += 8; }  // reach word alignment
+	b.ahead = uni<UNI>(bits_load32(base + (b.pos & ~3u)));  // inside the padded buffer even when pos == end
 }
 
 // tops the accumulator up to >= 32 valid bits (as long as the section has bytes left); bytes past the
 // section end are never consumed. The word consumed here was requested at the previous refill, so
 // its memory latency overlaps with decoding instead of stalling this lane.
-J40_DEV void bits_refill(DevBits &b) {
+template <bool UNI> J40_DEV void bits_refill(DevBits &b) {
 	if (b.nbits > 32) return;
 	const uint32_t avail = b.end - b.pos;
 	if (avail >= 4) {
 		const uint32_t w = b.ahead;
 		b.pos += 4;
-		b.ahead = bits_load32(b.base + b.pos);
+		b.ahead = uni<UNI>(bits_load32(b.base + b.pos));
 		b.bits |= (uint64_t) w << b.nbits;
 		b.nbits += 32;
 	} else if (avail) {
@@ -64,9 +78,9 @@ J40_DEV void bits_refill(DevBits &b) {
 	}
 }
 
-J40_DEV uint32_t bits_u(DevBits &b, int32_t n) {  // n in [0, 31]
+template <bool UNI> J40_DEV uint32_t bits_u(DevBits &b, int32_t n) {  // n in [0, 31]
 	if (b.nbits < n) {
-		bits_refill(b);
+		bits_refill<UNI>(b);
 		if (b.nbits < n) { bits_set_error(b, ERR_SHRT); b.bits = 0; b.nbits = 0; return 0; }
 	}
 	const uint32_t v = (uint32_t) b.bits & ((1u << n) - 1);
@@ -76,7 +90,7 @@ J40_DEV uint32_t bits_u(DevBits &b, int32_t n) {  // n in [0, 31]
 
 // at least 16 bits visible if the section has them; missing bits read as zero (prefix codes at the
 // very end of a section, j40.h:2258-2261)
-J40_DEV uint32_t bits_peek16(DevBits &b) { if (b.nbits < 16) bits_refill(b); return (uint32_t) b.bits & 0xffff; }
+template <bool UNI> J40_DEV uint32_t bits_peek16(DevBits &b) { if (b.nbits < 16) bits_refill<UNI>(b); return (uint32_t) b.bits & 0xffff; }
 J40_DEV void bits_consume(DevBits &b, int32_t n) {
 	if (n > b.nbits) { bits_set_error(b, ERR_SHRT); b.bits = 0; b.nbits = 0; return; }
 	b.bits >>= n; b.nbits -= n;
@@ -117,50 +131,61 @@ J40_DEV void code_init(DevCode &c, const DevCodeSpec &spec, const DevCluster *cl
 	c.num_to_copy = c.copy_pos = c.num_decoded = 0; c.window = window;
 }
 
-J40_DEV int32_t hybrid_int_dev(DevBits &b, int32_t token, uint32_t cfg, int32_t max_token) {  // j40.h:2313
+template <bool UNI> J40_DEV int32_t hybrid_int_dev(DevBits &b, int32_t token, uint32_t cfg, int32_t max_token) {  // j40.h:2313
 	const int32_t split_exp = (int32_t) (cfg & 15), msb = (int32_t) ((cfg >> 4) & 15), lsb = (int32_t) ((cfg >> 8) & 15);
 	const int32_t split = 1 << split_exp;
 	if (token < split) return token;
 	if (token > max_token) { token = max_token; bits_set_error(b, ERR_IOVF); }
 	const int32_t in_token = msb + lsb;
 	const int32_t midbits = split_exp - in_token + ((token - split) >> in_token);
-	const int32_t mid = (int32_t) bits_u(b, midbits);
+	const int32_t mid = (int32_t) bits_u<UNI>(b, midbits);
 	const int32_t top = 1 << msb;
 	const int32_t lo = token & ((1 << lsb) - 1), hi = (token >> lsb) & (top - 1);
 	return ((top | hi) << (midbits + lsb)) | ((mid << lsb) | lo);
 }
 
-J40_DEV int32_t ans_symbol(DevBits &b, DevCode &c, const DevCluster &cl) {  // j40.h:2441
-	if (c.ans_state == 0) { c.ans_state = bits_u(b, 16); c.ans_state |= bits_u(b, 16) << 16; }
+template <bool UNI> J40_DEV int32_t ans_symbol(DevBits &b, DevCode &c, uint32_t table_off) {  // j40.h:2441
+	if (c.ans_state == 0) { c.ans_state = bits_u<UNI>(b, 16); c.ans_state |= bits_u<UNI>(b, 16) << 16; }
 	const uint32_t idx = c.ans_state & 0xfff, i = idx >> c.log_bucket, pos = idx & ((1u << c.log_bucket) - 1);
-	const uint64_t e = c.alias[cl.table_off + i];
+	const uint64_t e = uni64<UNI>(c.alias[table_off + i]);
 	const bool aliased = pos >= (uint32_t) (e & 0xff);
 	const uint32_t symbol = aliased ? (uint32_t) (e >> 20) & 0xff : i;
 	const uint32_t offset = aliased ? (uint32_t) (e >> 8) & 0xfff : 0;
 	const uint32_t d = aliased ? (uint32_t) (e >> 28) & 0x1fff : (uint32_t) (e >> 41) & 0x1fff;
 	c.ans_state = d * (c.ans_state >> 12) + offset + pos;
-	if (c.ans_state < (1u << 16)) c.ans_state = (c.ans_state << 16) | bits_u(b, 16);
+	if (c.ans_state < (1u << 16)) c.ans_state = (c.ans_state << 16) | bits_u<UNI>(b, 16);
 	return (int32_t) symbol;
 }
 
-J40_DEV int32_t prefix_symbol(DevBits &b, const DevCode &c, const DevCluster &cl) {  // j40.h:2256
-	const int32_t *table = c.prefix + cl.table_off;
-	const uint32_t window = bits_peek16(b);
-	int32_t entry = table[window & ((1u << cl.fast_len) - 1)];
+template <bool UNI> J40_DEV int32_t prefix_symbol(DevBits &b, const DevCode &c, uint32_t table_off, int32_t fast_len, int32_t max_len) {  // j40.h:2256
+	const int32_t *table = c.prefix + table_off;
+	const uint32_t window = bits_peek16<UNI>(b);
+	int32_t entry = uni<UNI>(table[window & ((1u << fast_len) - 1)]);
 	int32_t used = 0;
-	if (entry < 0 && cl.fast_len < cl.max_len) {
+	if (entry < 0 && fast_len < max_len) {
 		const int32_t *ovf = table - entry;
-		const uint32_t rest = window >> cl.fast_len;
+		const uint32_t rest = window >> fast_len;
 		int32_t code_len, guard = 0;
-		do { entry = *ovf++; code_len = entry & 15; } while ((uint32_t) ((entry >> 4) & 0xfff) != (rest & ((1u << code_len) - 1)) && ++guard < 32768);
-		used = cl.fast_len;
+		do { entry = uni<UNI>(*ovf++); code_len = entry & 15; } while ((uint32_t) ((entry >> 4) & 0xfff) != (rest & ((1u << code_len) - 1)) && ++guard < 32768);
+		used = fast_len;
 	}
 	bits_consume(b, used + (entry & 15));
 	return entry >> 16;
 }
 
-J40_DEV int32_t cluster_token(DevBits &b, DevCode &c, const DevCluster &cl) {
-	return c.use_prefix_code ? prefix_symbol(b, c, cl) : ans_symbol(b, c, cl);
+// a cluster descriptor pulled into (scalar) registers
+struct ClusterRegs { uint32_t cfg; int32_t max_token; uint32_t table_off; int32_t fast_len, max_len; };
+template <bool UNI> J40_DEV ClusterRegs load_cluster(const DevCode &c, int32_t ctx) {
+	const uint32_t cl = uni<UNI>((uint32_t) c.cluster_map[ctx]);
+	const uint32_t *p = (const uint32_t *) (c.clusters + cl);   // {cfg, max_token, table_off, fast_len | max_len << 16}
+	ClusterRegs r;
+	r.cfg = uni<UNI>(p[0]); r.max_token = (int32_t) uni<UNI>(p[1]); r.table_off = uni<UNI>(p[2]);
+	r.fast_len = r.max_len = 0;
+	if (c.use_prefix_code) { const uint32_t fm = uni<UNI>(p[3]); r.fast_len = (int32_t) (int16_t) (fm & 0xffff); r.max_len = (int32_t) (int16_t) (fm >> 16); }
+	return r;
+}
+template <bool UNI> J40_DEV int32_t cluster_token(DevBits &b, DevCode &c, const ClusterRegs &cl) {
+	return c.use_prefix_code ? prefix_symbol<UNI>(b, c, cl.table_off, cl.fast_len, cl.max_len) : ans_symbol<UNI>(b, c, cl.table_off);
 }
 
 // LZ77 special distances, (dx + 7) * 16 + dy (spec table; cf. j40.h:2834)
@@ -179,15 +204,15 @@ static const uint8_t LZ77_SPECIAL_DISTANCES[120] = {
 // the LZ77 window holds the last `window_size` decoded integers; sections never decode more than
 // window_size symbols (sized from the section's symbol bound on the host), so indices do not wrap
 // before the reference's 2^20 mask would
-J40_DEV int32_t code_lz77_copy(DevBits &b, DevCode &c, int32_t token, int32_t dist_mult) {
-	const DevCluster &lz = c.clusters[c.cluster_map[c.num_dist - 1]];
-	const int32_t num_to_copy = hybrid_int_dev(b, token - c.min_symbol, c.lz_len_cfg, c.lz_len_max_token) + c.min_length;
-	token = cluster_token(b, c, lz);
-	int32_t distance = hybrid_int_dev(b, token, lz.cfg, lz.max_token);
+template <bool UNI> J40_DEV int32_t code_lz77_copy(DevBits &b, DevCode &c, int32_t token, int32_t dist_mult) {
+	const ClusterRegs lz = load_cluster<UNI>(c, c.num_dist - 1);
+	const int32_t num_to_copy = hybrid_int_dev<UNI>(b, token - c.min_symbol, c.lz_len_cfg, c.lz_len_max_token) + c.min_length;
+	token = cluster_token<UNI>(b, c, lz);
+	int32_t distance = hybrid_int_dev<UNI>(b, token, lz.cfg, lz.max_token);
 	if (!dist_mult) ++distance;
 	else if (distance >= 120) distance -= 119;
 	else {
-		const int32_t special = LZ77_SPECIAL_DISTANCES[distance];
+		const int32_t special = (int32_t) uni<UNI>((uint32_t) LZ77_SPECIAL_DISTANCES[distance]);
 		distance = ((special >> 4) - 7) + dist_mult * (special & 7);
 		if (distance < 1) distance = 1;
 	}
@@ -198,34 +223,37 @@ J40_DEV int32_t code_lz77_copy(DevBits &b, DevCode &c, int32_t token, int32_t di
 	return 0;
 }
 
-J40_DEV int32_t code_symbol(DevBits &b, DevCode &c, int32_t ctx, int32_t dist_mult, uint32_t window_size) {  // j40.h:2804
+template <bool UNI> J40_DEV int32_t code_symbol(DevBits &b, DevCode &c, int32_t ctx, int32_t dist_mult, uint32_t window_size) {  // j40.h:2804
+#ifdef J40_COUNT_HOOK
+	J40_COUNT_HOOK;
+#endif
 	if (c.num_to_copy == 0) {
-		const DevCluster &cl = c.clusters[c.cluster_map[ctx]];
-		int32_t token = cluster_token(b, c, cl);
+		const ClusterRegs cl = load_cluster<UNI>(c, ctx);
+		int32_t token = cluster_token<UNI>(b, c, cl);
 		if (token < c.min_symbol) {
-			token = hybrid_int_dev(b, token, cl.cfg, cl.max_token);
+			token = hybrid_int_dev<UNI>(b, token, cl.cfg, cl.max_token);
 			if (c.lz77_enabled) {
 				if (!c.window || (uint32_t) c.num_decoded >= window_size) { bits_set_error(b, ERR_TODO); return token; }
 				c.window[c.num_decoded++] = token;
 			}
 			return token;
 		}
-		code_lz77_copy(b, c, token, dist_mult);
+		code_lz77_copy<UNI>(b, c, token, dist_mult);
 	}
 	// copy one integer out of the window
 	--c.num_to_copy;
 	if (!c.window || (uint32_t) c.num_decoded >= window_size) { bits_set_error(b, ERR_TODO); c.num_to_copy = 0; return 0; }
 	// positions before the first decoded symbol read as zero (the reference zero-fills, j40.h:2858)
-	const int32_t v = c.copy_pos < c.num_decoded ? c.window[c.copy_pos] : 0;
+	const int32_t v = c.copy_pos < c.num_decoded ? uni<UNI>(c.window[c.copy_pos]) : 0;
 	++c.copy_pos;
 	c.window[c.num_decoded++] = v;
 	return v;
 }
 
-J40_DEV void code_finish(DevBits &b, DevCode &c) {  // j40.h:2884
+template <bool UNI> J40_DEV void code_finish(DevBits &b, DevCode &c) {  // j40.h:2884
 	if (!c.use_prefix_code) {
 		if (c.ans_state) { if (c.ans_state != 0x130000) bits_set_error(b, ERR_ANS); }
-		else { if (bits_u(b, 16) != 0x0000) bits_set_error(b, ERR_ANS); if (bits_u(b, 16) != 0x0013) bits_set_error(b, ERR_ANS); }
+		else { if (bits_u<UNI>(b, 16) != 0x0000) bits_set_error(b, ERR_ANS); if (bits_u<UNI>(b, 16) != 0x0013) bits_set_error(b, ERR_ANS); }
 	}
 }
 

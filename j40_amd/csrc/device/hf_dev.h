@@ -54,12 +54,12 @@ struct HfTables {
 // decodes one (pass, group) section. SCAN: single-pass frames store each coefficient at its scan
 // position (plain store; the pixel kernels undo the order), otherwise accumulate at the canonical
 // position like j40.h:6989.
-template <bool SCAN>
+template <bool SCAN, bool UNI>
 J40_DEV uint32_t decode_hf_section(const DevPlan &plan, const DevFrame &f, const DevCodeSpec &spec, const HfTables &t, int32_t pass, const DevSection &sec) {
 	const DevLfGroup &gg = plan.lf_groups[sec.ggidx];
 	DevBits b;
-	bits_init(b, plan.codestream, sec.byte_off, sec.size, sec.bit_off);
-	const uint32_t preset = bits_u(b, f.preset_bits);
+	bits_init<UNI>(b, plan.codestream, sec.byte_off, sec.size, sec.bit_off);
+	const uint32_t preset = bits_u<UNI>(b, f.preset_bits);
 	if ((int32_t) preset >= f.num_hf_presets) bits_set_error(b, ERR_RNGE);
 	const int32_t ctxoff = 495 * f.nb_block_ctx * (int32_t) preset;
 	DevCode code;
@@ -69,23 +69,25 @@ J40_DEV uint32_t decode_hf_section(const DevPlan &plan, const DevFrame &f, const
 	const int32_t bctxc = 13 * nb_qf1 * lfidx_size;
 	const size_t cell64 = (size_t) gg.cell_base * 64;
 	for (int32_t k = 0; k < t.nblocks && !b.err; ++k) {
-		const DevGroupBlock gb = t.blocks[k];
+		DevGroupBlock gb;
+		{ const uint32_t *p = (const uint32_t *) (t.blocks + k); gb.coeffoff_qfidx = uni<UNI>(p[0]); const uint32_t w = uni<UNI>(p[1]); gb.pos_dct = (uint16_t) w; gb.lfidx = (uint8_t) (w >> 16); gb.pad = 0; }
 		const int32_t dctsel = gb.pos_dct >> 10, nzpos = ((gb.pos_dct >> 5) & 31) * gw8 + (gb.pos_dct & 31);
 		const int32_t x8 = gb.pos_dct & 31, y8 = (gb.pos_dct >> 5) & 31;
-		const int32_t log_rows = DEV_DCT_SELECT[dctsel][0], log_columns = DEV_DCT_SELECT[dctsel][1], order_idx = DEV_DCT_SELECT[dctsel][2];
+		const int32_t log_rows = uni<UNI>((int32_t) DEV_DCT_SELECT[dctsel][0]), log_columns = uni<UNI>((int32_t) DEV_DCT_SELECT[dctsel][1]), order_idx = uni<UNI>((int32_t) DEV_DCT_SELECT[dctsel][2]);
 		const int32_t log_size = log_rows + log_columns, shift = log_size - 6, size = 1 << log_size;
 		const int32_t coeffoff = (int32_t) (gb.coeffoff_qfidx & ~15u), qfidx = (int32_t) (gb.coeffoff_qfidx & 15u);
 		const int32_t bctx0 = (order_idx * nb_qf1 + qfidx) * lfidx_size + gb.lfidx;
 		for (int32_t c_yxb = 0; c_yxb < 3 && !b.err; ++c_yxb) {
 			const int32_t c = c_yxb == 0 ? 1 : c_yxb == 1 ? 0 : 2;
 			float *coeffs = plan.coeffs[c] + cell64 + coeffoff;
-			const int32_t bctx = t.block_ctx_map[bctx0 + bctxc * c_yxb];
+			const int32_t bctx = uni<UNI>((int32_t) t.block_ctx_map[bctx0 + bctxc * c_yxb]);
 			// number of non-zeros, predicted from the left / top blocks (j40.h:6959-6967)
 			int32_t nz;
 			if (x8 > 0) nz = y8 > 0 ? (t.nonzeros[(nzpos - 1) * 3 + c] + t.nonzeros[(nzpos - gw8) * 3 + c] + 1) >> 1 : t.nonzeros[(nzpos - 1) * 3 + c];
 			else nz = y8 > 0 ? t.nonzeros[(nzpos - gw8) * 3 + c] : 32;
+			nz = uni<UNI>(nz);
 			const int32_t nzctx = ctxoff + bctx + (nz < 8 ? nz : 4 + nz / 2) * nb_block_ctx;
-			nz = code_symbol(b, code, nzctx, 0, plan.lz_window_size);
+			nz = code_symbol<UNI>(b, code, nzctx, 0, plan.lz_window_size);
 			if (nz > (63 << shift)) { bits_set_error(b, ERR_COEF); break; }
 			const int32_t qnz = (nz + (1 << shift) - 1) >> shift;
 			for (int32_t i = 0; i < (1 << (log_rows - 3)); ++i) for (int32_t j = 0; j < (1 << (log_columns - 3)); ++j)
@@ -94,11 +96,11 @@ J40_DEV uint32_t decode_hf_section(const DevPlan &plan, const DevFrame &f, const
 			int32_t prev = nz <= (size >> 4);
 			const uint16_t *order = SCAN ? nullptr : plan.pool_u16 + f.order_off[(pass * 13 + order_idx) * 3 + c];
 			for (int32_t i = 1 << shift; nz > 0 && i < size; ++i) {
-				const int32_t ctx = cctx + t.nnz_ctx2[(nz + (1 << shift) - 1) >> shift] + t.freq_ctx2[i >> shift] + prev;
-				const int32_t ucoeff = code_symbol(b, code, ctx, 0, plan.lz_window_size);
+				const int32_t ctx = cctx + uni<UNI>((int32_t) t.nnz_ctx2[(nz + (1 << shift) - 1) >> shift]) + uni<UNI>((int32_t) t.freq_ctx2[i >> shift]) + prev;
+				const int32_t ucoeff = code_symbol<UNI>(b, code, ctx, 0, plan.lz_window_size);
 				if (ucoeff) {
 					const float v = (float) unpack_signed_dev(ucoeff);
-					if (SCAN) coeffs[i] = v; else coeffs[order[i]] += v;
+					if (SCAN) coeffs[i] = v; else coeffs[uni<UNI>((uint32_t) order[i])] += v;
 				}
 				prev = ucoeff != 0;
 				nz -= prev;
@@ -107,7 +109,7 @@ J40_DEV uint32_t decode_hf_section(const DevPlan &plan, const DevFrame &f, const
 			if (nz != 0) bits_set_error(b, ERR_COEF);
 		}
 	}
-	if (!b.err) code_finish(b, code);
+	if (!b.err) code_finish<UNI>(b, code);
 	if (!b.err) bits_finish_section(b);
 	return b.err;
 }
@@ -128,7 +130,7 @@ J40_DEV void decode_hf_group(const DevPlan &plan, int32_t g) {
 		t.clusters = plan.clusters + spec.cluster_off; t.cluster_map = plan.pool_u8 + spec.cluster_map_off;
 		t.alias = plan.pool_u64; t.prefix = plan.pool_i32;
 		const DevSection &sec = plan.sections[pass * f.num_groups + g];
-		plan.status[pass * f.num_groups + g] = f.scan_order_coeffs ? decode_hf_section<true>(plan, f, spec, t, pass, sec) : decode_hf_section<false>(plan, f, spec, t, pass, sec);
+		plan.status[pass * f.num_groups + g] = f.scan_order_coeffs ? decode_hf_section<true, false>(plan, f, spec, t, pass, sec) : decode_hf_section<false, false>(plan, f, spec, t, pass, sec);
 	}
 }
 

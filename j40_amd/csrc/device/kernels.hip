@@ -45,7 +45,8 @@ template <bool TABLES_IN_LDS>
 __global__ void __launch_bounds__(64 * HF_WAVES) k_hf_entropy(DevPlan plan, int32_t first_group, int32_t num_groups, HfLdsLayout lay) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t hf_lds[];
 	const DevFrame &f = *plan.frame;
-	const int32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const int32_t tid = threadIdx.x, lane = tid & 63;
+	const int32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction
 	const int32_t local = blockIdx.x * HF_WAVES + wave;
 	const bool active = local < num_groups;
 	const int32_t g = first_group + local;
@@ -101,9 +102,12 @@ __global__ void __launch_bounds__(64 * HF_WAVES) k_hf_entropy(DevPlan plan, int3
 			t.alias = plan.pool_u64; t.prefix = plan.pool_i32;
 		}
 		__syncthreads();
-		if (active && lane == 0) {
+		if (active) {
+			// every lane of the wave runs the same (scalarised) decoder on the same section; duplicate
+			// stores hit the same addresses with the same values
 			const DevSection &sec = plan.sections[pass * f.num_groups + g];
-			plan.status[pass * f.num_groups + g] = f.scan_order_coeffs ? decode_hf_section<true>(plan, f, spec, t, pass, sec) : decode_hf_section<false>(plan, f, spec, t, pass, sec);
+			const uint32_t err = f.scan_order_coeffs ? decode_hf_section<true, true>(plan, f, spec, t, pass, sec) : decode_hf_section<false, true>(plan, f, spec, t, pass, sec);
+			if (lane == 0) plan.status[pass * f.num_groups + g] = err;
 		}
 	}
 }
