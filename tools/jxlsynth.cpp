@@ -117,7 +117,7 @@ struct LfGroupW {
 static int run_vardct(int W, int H, uint64_t seed, const char *out, const Options &opt) {
 	SplitMix64 rng(seed * 0x100000001b3ull + 12345);
 	const int global_scale = opt.geti("global_scale", 8192), quant_lf = opt.geti("quant_lf", 4);
-	const double density = opt.getd("density", 0.22), decay = opt.getd("decay", 0.965);
+	const double density = opt.getd("density", 0.80), decay = opt.getd("decay", 0.84);
 	const int max_log = opt.geti("maxlog", 6);              // largest transform side (log2) used in the mix
 	const int coverage = opt.geti("coverage", 1);           // 1: force every transform type <= maxlog at least once per frame
 	const int custom_bctx = opt.geti("bctx", 0);            // custom block context map with LF/QF thresholds
@@ -363,12 +363,15 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 					double p = density * (c == 1 ? 1.0 : c == 0 ? 0.35 : 0.55) / (double) num_passes;
 					std::vector<std::pair<int, int>> coefs;  // (scan index, value)
 					double pk = p; const double dk = pow(decay, 64.0 / (double) size);
-					for (int i = first; i < size; ++i) {
+					// d1-like statistics: non-zeros concentrate at low frequencies (so the scan ends early, as an
+					// encoder's would) and low frequencies carry the larger magnitudes
+					double cont = opt.getd("cont", 0.86);
+					for (int i = first; i < size && pk > 2e-3; ++i) {
 						if (rng.unit() < pk) {
-							int mag = 1; while (mag < 40 && rng.unit() < 0.33) ++mag;
+							int mag = 1; while (mag < 40 && rng.unit() < cont) ++mag;
 							coefs.push_back({i, rng.below(2) ? mag : -mag});
 						}
-						pk *= dk;
+						pk *= dk; cont = 0.3 + (cont - 0.3) * pow(dk, 0.6);
 					}
 					int nz = (int) coefs.size();
 					if (nz > (63 << (log_size - 6))) { coefs.resize((size_t) (63 << (log_size - 6))); nz = (int) coefs.size(); }
