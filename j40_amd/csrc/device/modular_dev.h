@@ -1,0 +1,282 @@
+// j40_amd/csrc/device/modular_dev.h -- Modular hot path as per-lane device functions: per-pixel MA-tree
+// walk + prediction + entropy decode of one group (K3), inverse RCT / Palette (K4), plane -> RGBA
+// u8x4 pack (K5). Integer-exact restatement of j40__modular_channel16 (j40.h:4127-4240),
+// j40__inverse_rct16 / j40__inverse_palette16 (j40.h:4318, 4402) and j40__render_to_u8x4_rgba (j40.h:7910).
+#pragma once
+#include "entropy_dev.h"
+
+namespace j40hip {
+
+struct ModNeigh { int32_t w, n, nw, ne, nn, nee, ww, nww; };
+
+// neighbours inside the group's own rectangle (x, y and width are group-local; j40.h:3965-3990)
+J40_DEV ModNeigh mod_neighbours(const int16_t *px /* row y, column 0 of the rectangle */, int32_t stride, int32_t width, int32_t x, int32_t y) {
+	ModNeigh p;
+	p.w = x > 0 ? px[x - 1] : y > 0 ? px[x - stride] : 0;
+	p.n = y > 0 ? px[x - stride] : p.w;
+	p.nw = x > 0 && y > 0 ? px[(x - 1) - stride] : p.w;
+	p.ne = x + 1 < width && y > 0 ? px[(x + 1) - stride] : p.n;
+	p.nn = y > 1 ? px[x - 2 * stride] : p.n;
+	p.nee = x + 2 < width && y > 0 ? px[(x + 2) - stride] : p.ne;
+	p.ww = x > 1 ? px[x - 2] : p.w;
+	p.nww = x > 1 && y > 0 ? px[(x - 2) - stride] : p.ww;
+	return p;
+}
+
+J40_DEV int32_t mod_abs(int32_t v) { return v < 0 ? -v : v; }
+J40_DEV int32_t mod_min(int32_t a, int32_t b) { return a < b ? a : b; }
+J40_DEV int32_t mod_max(int32_t a, int32_t b) { return a > b ? a : b; }
+J40_DEV int32_t mod_gradient(int32_t w, int32_t n, int32_t nw) { const int32_t lo = mod_min(w, n), hi = mod_max(w, n); return mod_min(mod_max(lo, w + n - nw), hi); }
+J40_DEV int32_t mod_floor_lg(uint32_t x) { return 31 - __builtin_clz(x); }
+J40_DEV int32_t mod_div24(int32_t i) { return (int32_t) (((int64_t) 1 << 24) / (i + 1)); }  // J40__24DIVP1, j40.h:3905
+
+// weighted predictor (j40.h:3997-4119); `errors` = [2 * width][5] int32 rows, zero-initialised
+struct ModWP {
+	int32_t on, width;
+	int32_t p1, p2, p3[5], w[4];
+	int32_t *errors;
+	int32_t pred[5];
+	int32_t trueerrw, trueerrn, trueerrnw, trueerrne;
+};
+
+J40_DEV void wp_before(ModWP &s, int32_t x, int32_t y, const ModNeigh &p) {
+	if (!s.on) return;
+	const int32_t *err = s.errors + (size_t) ((y & 1) ? s.width : 0) * 5, *nerr = s.errors + (size_t) ((y & 1) ? 0 : s.width) * 5;
+	int32_t errw[5], errn[5], errnw[5], errne[5], errww[5], errw2[5];
+	for (int i = 0; i < 5; ++i) {
+		errw[i] = x > 0 ? err[(x - 1) * 5 + i] : 0;
+		errn[i] = y > 0 ? nerr[x * 5 + i] : 0;
+		errnw[i] = x > 0 && y > 0 ? nerr[(x - 1) * 5 + i] : errn[i];
+		errne[i] = x + 1 < s.width && y > 0 ? nerr[(x + 1) * 5 + i] : errn[i];
+		errww[i] = x > 1 ? err[(x - 2) * 5 + i] : 0;
+		errw2[i] = x + 1 < s.width ? 0 : errw[i];
+	}
+	s.trueerrw = errw[4];
+	s.trueerrn = errn[4];
+	s.trueerrnw = x > 0 && y > 0 ? errnw[4] : s.trueerrn;
+	s.trueerrne = x + 1 < s.width && y > 0 ? errne[4] : s.trueerrn;
+	s.pred[0] = (p.w + p.ne - p.n) * 8;
+	s.pred[1] = p.n * 8 - (((s.trueerrw + s.trueerrn + s.trueerrne) * s.p1) >> 5);
+	s.pred[2] = p.w * 8 - (((s.trueerrw + s.trueerrn + s.trueerrnw) * s.p2) >> 5);
+	s.pred[3] = p.n * 8 - ((s.trueerrnw * s.p3[0] + s.trueerrn * s.p3[1] + s.trueerrne * s.p3[2] + (p.nn - p.n) * 8 * s.p3[3] + (p.nw - p.w) * 8 * s.p3[4]) >> 5);
+	int32_t wgt[4], wsum = 0, sum = 0;
+	for (int i = 0; i < 4; ++i) {
+		const int32_t errsum = errn[i] + errw[i] + errnw[i] + errww[i] + errne[i] + errw2[i];
+		const int32_t shift = mod_max(mod_floor_lg((uint32_t) errsum + 1) - 5, 0);
+		wgt[i] = (int32_t) (4 + ((int64_t) s.w[i] * mod_div24(errsum >> shift) >> shift));
+	}
+	const int32_t logw = mod_floor_lg((uint32_t) (wgt[0] + wgt[1] + wgt[2] + wgt[3])) - 4;
+	for (int i = 0; i < 4; ++i) { wgt[i] >>= logw; wsum += wgt[i]; sum += s.pred[i] * wgt[i]; }
+	s.pred[4] = (int32_t) (((int64_t) sum + (wsum >> 1) - 1) * mod_div24(wsum - 1) >> 24);
+	if (((s.trueerrn ^ s.trueerrw) | (s.trueerrn ^ s.trueerrnw)) <= 0) {
+		const int32_t lo = mod_min(p.w, mod_min(p.n, p.ne)) * 8, hi = mod_max(p.w, mod_max(p.n, p.ne)) * 8;
+		s.pred[4] = mod_min(mod_max(lo, s.pred[4]), hi);
+	}
+}
+
+J40_DEV void wp_after(ModWP &s, int32_t x, int32_t y, int32_t val) {
+	if (!s.on) return;
+	int32_t *e = s.errors + ((size_t) ((y & 1) ? s.width : 0) + (size_t) x) * 5;
+	for (int i = 0; i < 4; ++i) e[i] = (mod_abs(s.pred[i] - val * 8) + 3) >> 3;
+	e[4] = s.pred[4] - val * 8;
+}
+
+J40_DEV int32_t mod_predict(int32_t predictor, const ModWP &wp, const ModNeigh &p, uint32_t *err) {  // j40.h:4080
+	switch (predictor) {
+	case 0: return 0;
+	case 1: return p.w;
+	case 2: return p.n;
+	case 3: return (p.w + p.n) / 2;
+	case 4: return mod_abs(p.n - p.nw) < mod_abs(p.w - p.nw) ? p.w : p.n;
+	case 5: return mod_gradient(p.w, p.n, p.nw);
+	case 6: return (wp.pred[4] + 3) >> 3;
+	case 7: return p.ne;
+	case 8: return p.nw;
+	case 9: return p.ww;
+	case 10: return (p.w + p.nw) / 2;
+	case 11: return (p.n + p.nw) / 2;
+	case 12: return (p.n + p.ne) / 2;
+	case 13: return (6 * p.n - 2 * p.nn + 7 * p.w + p.ww + p.nee + 3 * p.ne + 8) / 16;
+	default: if (!*err) *err = ERR_PRED; return 0;
+	}
+}
+
+// K3: one pass-group section = every not-yet-decoded channel of the group's rectangle, one stream
+J40_DEV uint32_t decode_modular_section(const DevModPlan &plan, int32_t g) {
+	const DevModFrame &f = *plan.frame;
+	const DevModSection &sec = plan.sections[g];
+	const DevCodeSpec &spec = *plan.spec;
+	DevBits b;
+	bits_init<false>(b, plan.codestream, sec.byte_off, sec.size, sec.bit_off);
+	DevCode code;
+	int32_t *window = plan.lz_window ? plan.lz_window + (size_t) g * plan.lz_window_size : nullptr;
+	code_init(code, spec, plan.clusters + spec.cluster_off, plan.pool_u8 + spec.cluster_map_off, plan.pool_u64, plan.pool_i32, window);
+	// LZ77 distance multiplier: widest non-meta channel of this sub-image (j40.h:3841-3844)
+	int32_t dist_mult = 0;
+	for (int32_t cidx = 0; cidx < sec.num_channels; ++cidx) if (!plan.plane_meta[sec.first_channel + cidx]) dist_mult = mod_max(dist_mult, sec.gw);
+	dist_mult = mod_min(dist_mult, 1 << 21);
+	ModWP wp;
+	wp.on = f.tree_uses_wp; wp.width = sec.gw;
+	wp.p1 = sec.wp[0]; wp.p2 = sec.wp[1];
+	for (int i = 0; i < 5; ++i) wp.p3[i] = sec.wp[2 + i];
+	for (int i = 0; i < 4; ++i) wp.w[i] = sec.wp[7 + i];
+	wp.errors = plan.wp_scratch ? plan.wp_scratch + (size_t) g * (size_t) (2 * f.max_width * 5) : nullptr;
+	for (int i = 0; i < 5; ++i) wp.pred[i] = 0;
+	wp.trueerrw = wp.trueerrn = wp.trueerrnw = wp.trueerrne = 0;
+	uint32_t err = 0;
+	for (int32_t cidx = 0; cidx < sec.num_channels && !b.err && !err; ++cidx) {
+		const int32_t ch = sec.first_channel + cidx;
+		const int32_t stride = plan.plane_w[ch];
+		// image channels: the section's rectangle; meta channels (palette): the whole plane
+		const int32_t meta = plan.plane_meta[ch];
+		const int32_t gx = meta ? 0 : sec.gx, gy = meta ? 0 : sec.gy, gw = meta ? plan.plane_w[ch] : sec.gw, gh = meta ? plan.plane_h[ch] : sec.gh;
+		if (gw <= 0 || gh <= 0) continue;
+		int16_t *base = plan.planes[ch] + (size_t) gy * (size_t) stride + (size_t) gx;
+		wp.width = gw;
+		if (wp.on) { for (int32_t i = 0; i < 2 * gw * 5; ++i) wp.errors[i] = 0; for (int i = 0; i < 5; ++i) wp.pred[i] = 0; wp.trueerrw = wp.trueerrn = wp.trueerrnw = wp.trueerrne = 0; }
+		for (int32_t y = 0; y < gh && !b.err && !err; ++y) {
+			int16_t *row = base + (size_t) y * (size_t) stride;
+			for (int32_t x = 0; x < gw; ++x) {
+				const ModNeigh p = mod_neighbours(row, stride, gw, x, y);
+				wp_before(wp, x, y, p);
+				const DevTreeNode *n = plan.tree;
+				DevTreeNode node = *n;
+				while (node.prop >= 0) {
+					int32_t val;
+					switch (node.prop) {
+					case 0: val = cidx; break;
+					case 1: val = sec.sidx; break;
+					case 2: val = y; break;
+					case 3: val = x; break;
+					case 4: val = mod_abs(p.n); break;
+					case 5: val = mod_abs(p.w); break;
+					case 6: val = p.n; break;
+					case 7: val = p.w; break;
+					case 8: val = x > 0 ? p.w - (p.ww + p.nw - p.nww) : p.w; break;
+					case 9: val = p.w + p.n - p.nw; break;
+					case 10: val = p.w - p.nw; break;
+					case 11: val = p.nw - p.n; break;
+					case 12: val = p.n - p.ne; break;
+					case 13: val = p.n - p.nn; break;
+					case 14: val = p.w - p.ww; break;
+					case 15:
+						val = wp.trueerrw;
+						if (mod_abs(val) < mod_abs(wp.trueerrn)) val = wp.trueerrn;
+						if (mod_abs(val) < mod_abs(wp.trueerrnw)) val = wp.trueerrnw;
+						if (mod_abs(val) < mod_abs(wp.trueerrne)) val = wp.trueerrne;
+						break;
+					default: {
+						// "previous channel" properties: the r-th earlier channel of this sub-image with the same
+						// geometry, nearest first (j40.h:4156-4165)
+						int32_t r = (node.prop - 16) / 4, rc = -1;
+						for (int32_t k = cidx - 1; k >= 0; --k) {
+							const int32_t cand = sec.first_channel + k;
+							if (plan.plane_meta[cand] != meta || (meta && (plan.plane_w[cand] != gw || plan.plane_h[cand] != gh))) continue;
+							if (r-- == 0) { rc = cand; break; }
+						}
+						if (rc < 0) { err = ERR_TREC; val = 0; break; }
+						const int32_t rstride = plan.plane_w[rc];
+						const int16_t *rrow = plan.planes[rc] + (size_t) (gy + y) * (size_t) rstride + (size_t) gx;
+						val = rrow[x];
+						if (node.prop & 2) {
+							const int32_t rw = x > 0 ? rrow[x - 1] : 0;
+							const int32_t rn = y > 0 ? rrow[x - rstride] : rw;
+							const int32_t rnw = x > 0 && y > 0 ? rrow[x - 1 - rstride] : rw;
+							val -= mod_gradient(rw, rn, rnw);
+						}
+						if (node.prop & 1) val = mod_abs(val);
+					} }
+					if (err) break;
+					n += val > node.value ? node.a : node.b;
+					node = *n;
+				}
+				if (err) break;
+				int32_t v = code_symbol<false>(b, code, node.value, dist_mult, plan.lz_window_size);
+				v = ((v & 1) ? -(v / 2 + 1) : v / 2) * node.b + node.a;
+				v += mod_predict(-1 - node.prop, wp, p, &err);
+				if (v < -32768 || v > 32767) { err = ERR_POVF; break; }
+				row[x] = (int16_t) v;
+				wp_after(wp, x, y, v);
+				if (b.err) break;
+			}
+		}
+	}
+	if (!b.err && !err) code_finish<false>(b, code);
+	if (!b.err && !err) bits_finish_section(b);
+	return b.err ? b.err : err;
+}
+
+// K4a: inverse RCT of one pixel (j40.h:4341-4393); values are int16 with wrap-around like the reference
+J40_DEV void inverse_rct_pixel(int32_t type7, int16_t &a, int16_t &bb, int16_t &c) {
+	const int16_t p0 = a, p1 = bb, p2 = c;
+	switch (type7) {
+	case 0: break;
+	case 1: c = (int16_t) (p2 + p0); break;
+	case 2: c = (int16_t) (p1 + p0); break;
+	case 3: bb = (int16_t) (p1 + p0); c = (int16_t) (p2 + p0); break;
+	case 4: bb = (int16_t) (p1 + (int16_t) (p0 / 2 + p2 / 2 + (p0 & p2 & 1))); break;
+	case 5: bb = (int16_t) ((int32_t) p1 + p0 + (p2 >> 1)); c = (int16_t) (p2 + p0); break;
+	default: {
+		const int32_t tmp = (int32_t) p0 - ((int32_t) p2 >> 1);
+		const int32_t q1 = (int32_t) p2 + tmp;
+		const int32_t q2 = tmp - ((int32_t) p1 >> 1);
+		a = (int16_t) (q2 + p1); bb = (int16_t) q1; c = (int16_t) q2;
+	} }
+}
+
+// the spec's 72 palette delta triples; entry 2k is triple k, entry 2k + 1 its negation (j40.h:4275)
+#ifdef __HIPCC__
+__device__
+#endif
+static const int16_t DEV_PALETTE_DELTAS[72][3] = {
+	{0, 0, 0}, {4, 4, 4}, {11, 0, 0}, {0, 0, -13}, {0, -12, 0}, {-10, -10, -10}, {-18, -18, -18}, {-27, -27, -27},
+	{-18, -18, 0}, {0, 0, -32}, {-32, 0, 0}, {-37, -37, -37}, {0, -32, -32}, {24, 24, 45}, {50, 50, 50}, {-45, -24, -24},
+	{-24, -45, -45}, {0, -24, -24}, {-34, -34, 0}, {-24, 0, -24}, {-45, -45, -24}, {64, 64, 64}, {-32, 0, -32}, {0, -32, 0},
+	{-32, 0, 32}, {-24, -45, -24}, {45, 24, 45}, {24, -24, -45}, {-45, -24, 24}, {80, 80, 80}, {64, 0, 0}, {0, 0, -64},
+	{0, -64, -64}, {-24, -24, 45}, {96, 96, 96}, {64, 64, 0}, {45, -24, -24}, {34, -34, 0}, {112, 112, 112}, {24, -45, -45},
+	{45, 45, -24}, {0, -32, 32}, {24, -24, 45}, {0, 96, 96}, {45, -24, 24}, {24, -45, -24}, {-24, -45, 24}, {0, -64, 0},
+	{96, 0, 0}, {128, 128, 128}, {64, 0, 64}, {144, 144, 144}, {96, 96, 0}, {-36, -36, 36}, {45, -24, -45}, {45, -45, -24},
+	{0, 0, -96}, {0, 128, 128}, {0, 96, 0}, {45, 24, -45}, {-128, 0, 0}, {24, -45, 24}, {-45, 24, -45}, {64, 0, -64},
+	{64, -64, -64}, {96, 0, 96}, {45, -45, 24}, {24, 45, -45}, {64, 64, -64}, {128, 128, 0}, {0, 0, -128}, {-24, 45, -45},
+};
+
+// K4b: palette look-up for output channel i of one pixel, before the optional delta prediction
+// (j40.h:4446-4468)
+J40_DEV int16_t palette_value(int16_t idx, int32_t i, const int16_t *palrow /* row i of the palette or null */, int32_t nb_colours, int32_t bpp) {
+	int16_t val;
+	if (idx < 0) {
+		if (i < 3) {
+			idx = (int16_t) (~idx % 143);
+			const int32_t entry = idx + 1;
+			val = DEV_PALETTE_DELTAS[entry >> 1][i];
+			if (entry & 1) val = (int16_t) -val;
+			if (bpp > 8) val = (int16_t) (val << ((bpp < 24 ? bpp : 24) - 8));
+		} else val = 0;
+	} else if (idx < nb_colours) {
+		val = palrow[idx];
+	} else {
+		idx = (int16_t) (idx - nb_colours);
+		if (idx < 64) {
+			val = (int16_t) ((i < 3 ? idx >> (2 * i) : 0) * (((int32_t) 1 << bpp) - 1) / 4 + ((int32_t) 1 << (bpp - 3 > 0 ? bpp - 3 : 0)));
+		} else {
+			val = (int16_t) (idx - 64);
+			for (int32_t j = 0; j < i; ++j) val = (int16_t) (val / 5);
+			val = (int16_t) ((val % 5) * ((1 << bpp) - 1) / 4);
+		}
+	}
+	return val;
+}
+
+// K5: one pixel of j40__render_to_u8x4_rgba (j40.h:7947-7953)
+J40_DEV uint32_t pack_rgba8(int32_t r, int32_t g, int32_t b2, int32_t a, int32_t bpp) {
+	const int32_t maxpixel = (1 << bpp) - 1, maxpixel2 = 1 << (bpp - 1);
+	const int32_t v[4] = {r, g, b2, a};
+	uint32_t out = 0;
+	for (int i = 0; i < 4; ++i) {
+		const int32_t p = v[i] < 0 ? 0 : v[i] > maxpixel ? maxpixel : v[i];
+		out |= (uint32_t) ((p * 255 + maxpixel2) / maxpixel) << (8 * i);
+	}
+	return out;
+}
+
+} // namespace j40hip

@@ -112,6 +112,52 @@ struct DevPlan {
 	uint32_t *status;                // [num_passes * num_groups] 4-char codes
 };
 
+// ---- Modular frames ----
+
+// MA tree node, same 16-byte layout as the host's TreeNode (modular.hpp):
+//   branch: prop >= 0, value = threshold, a / b = relative offsets of the (> threshold) / (<=) child
+//   leaf:   prop = -1 - predictor, value = context, a = offset, b = multiplier
+struct DevTreeNode { int32_t prop, value, a, b; };
+
+// one pass-group section of a Modular frame, header already parsed on the host
+struct DevModSection {
+	uint32_t byte_off, size, bit_off;   // bit_off: where the channel residuals start
+	int32_t gx, gy, gw, gh;             // group rectangle in the frame
+	int32_t sidx;                       // stream index property (j40.h:7013; 0 for LfGlobal)
+	int32_t first_channel, num_channels;  // channels of the global image this section codes
+	int8_t wp[12];                      // weighted predictor parameters p1, p2, p3[5], w[4] (j40.h:3551)
+};
+
+struct DevTransform { int32_t kind, begin_c, rct_type, num_c, nb_colours, nb_deltas, d_pred, pad; };
+
+enum { MOD_MAX_CHANNELS = 16 };
+
+struct DevModFrame {
+	int32_t width, height, num_groups, bpp;
+	int32_t num_sections;           // LfGlobal's channel data (if any) + one per group
+	int32_t num_channels;           // channels of the global Modular image as coded (before inverse transforms)
+	int32_t tree_uses_wp, num_tree_nodes;
+	int32_t max_width;              // widest rectangle any section decodes (sizes the weighted-predictor rows)
+};
+
+struct DevModPlan {
+	const DevModFrame *frame;
+	const uint8_t *codestream;
+	const uint8_t *pool_u8;
+	const int32_t *pool_i32;
+	const uint64_t *pool_u64;
+	const DevCluster *clusters;
+	const DevCodeSpec *spec;          // the global code spec
+	const DevTreeNode *tree;
+	const DevModSection *sections;    // [num_sections]
+	int16_t *planes[MOD_MAX_CHANNELS];        // sample planes of the coded channels, tightly packed rows
+	int32_t plane_w[MOD_MAX_CHANNELS], plane_h[MOD_MAX_CHANNELS];
+	int32_t plane_meta[MOD_MAX_CHANNELS];     // 1: meta channel (palette), decoded whole and never a "previous channel" of image channels
+	int32_t *wp_scratch;              // [num_sections][2 * max_width * 5] weighted-predictor error rows
+	int32_t *lz_window; uint32_t lz_window_size;
+	uint32_t *status;                 // [num_sections]
+};
+
 enum { HF_WAVES = 4 };  // groups (wavefronts) per K1 workgroup
 
 // what the host knows about the entropy tables' sizes, to lay out K1's LDS

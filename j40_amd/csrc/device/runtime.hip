@@ -37,6 +37,17 @@ struct j40hip_device_state {
 	size_t coeff_floats = 0;
 	int32_t total_sections = 0;
 	HfLaunchInfo hf;
+	// Modular frames
+	DevModPlan mod;
+	int32_t mod_sections = 0;
+	std::vector<uint32_t> mod_section_offsets;
+	struct ModOp { int kind; int16_t *a, *b, *c; const int16_t *src, *aux; size_t n; int32_t p0, p1, p2, p3, p4, p5; int16_t *const *dst_list; const int8_t *wpp; };
+	std::vector<ModOp> mod_ops;          // inverse transforms, in execution order
+	std::vector<int16_t *> final_planes; // channel list after the inverse transforms
+	std::vector<int32_t> final_w, final_h;
+	int32_t alpha_channel = -1;
+	int32_t *pal_wp_scratch = nullptr;
+	uint32_t *mod_extra_status = nullptr;
 	std::vector<uint32_t> status_host;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 
@@ -70,10 +81,127 @@ extern "C" int j40hip_device_count(void) {
 	return n;
 }
 
+static uint32_t upload_modular(j40hip_frame *h, int device) {
+	HostModPlan hp;
+	if (uint32_t e = build_modular_plan(h->frame, h->cs, h->cs_size, &hp)) return e;
+	j40hip_device_state *st = new j40hip_device_state();
+	h->dev = st; st->device = device; st->is_modular = true;
+	hipStream_t s = nullptr;
+	bool ok = true;
+	DevModPlan &plan = st->mod;
+	memset(&plan, 0, sizeof plan);
+	plan.frame = st->upload(&hp.frame, 1, s, ok);
+	plan.codestream = st->upload(hp.codestream.data(), hp.codestream.size(), s, ok);
+	plan.pool_u8 = st->upload(hp.pool_u8.data(), hp.pool_u8.size(), s, ok);
+	plan.pool_i32 = st->upload(hp.pool_i32.data(), hp.pool_i32.size(), s, ok);
+	plan.pool_u64 = st->upload(hp.pool_u64.data(), hp.pool_u64.size(), s, ok);
+	plan.clusters = st->upload(hp.clusters.data(), hp.clusters.size(), s, ok);
+	plan.spec = st->upload(&hp.spec, 1, s, ok);
+	plan.tree = st->upload(hp.tree.data(), hp.tree.size(), s, ok);
+	plan.sections = st->upload(hp.sections.data(), hp.sections.size(), s, ok);
+	st->mod_sections = (int32_t) hp.sections.size();
+	for (const DevModSection &sec : hp.sections) st->mod_section_offsets.push_back(sec.byte_off);
+	const int32_t nch = hp.frame.num_channels;
+	struct Ref { int16_t *p; int32_t w, h; };
+	std::vector<Ref> planes;
+	for (int32_t c = 0; c < nch; ++c) {
+		const size_t n = (size_t) std::max(hp.plane_w[(size_t) c], 0) * (size_t) std::max(hp.plane_h[(size_t) c], 0);
+		int16_t *p = st->scratch<int16_t>(n ? n : 1, ok);
+		plan.planes[c] = p; plan.plane_w[c] = hp.plane_w[(size_t) c]; plan.plane_h[c] = hp.plane_h[(size_t) c]; plan.plane_meta[c] = hp.plane_meta[(size_t) c];
+		planes.push_back({p, hp.plane_w[(size_t) c], hp.plane_h[(size_t) c]});
+	}
+	bool palette_wp = false;
+	for (const Transform &t : hp.transforms) palette_wp |= t.kind == Transform::PALETTE && t.nb_deltas > 0 && t.d_pred == 6;
+	if (hp.frame.tree_uses_wp) plan.wp_scratch = st->scratch<int32_t>((size_t) hp.sections.size() * (size_t) (2 * hp.frame.max_width * 5) + 16, ok);
+	if (palette_wp) st->pal_wp_scratch = st->scratch<int32_t>((size_t) 2 * (size_t) hp.frame.width * 5 + 16, ok);
+	plan.lz_window_size = hp.lz_window_size;
+	if (hp.lz_window_size) plan.lz_window = st->scratch<int32_t>((size_t) hp.sections.size() * hp.lz_window_size, ok);
+	plan.status = st->scratch<uint32_t>(hp.sections.size() + 1, ok);
+	st->mod_extra_status = const_cast<uint32_t *>(plan.status) + hp.sections.size();
+	st->total_sections = (int32_t) hp.sections.size();
+
+	// inverse transforms, last to first (j40.h:4513-4521), resolved to plane pointers now
+	static const uint8_t PERM[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
+	for (size_t ti = hp.transforms.size(); ti-- > 0; ) {
+		const Transform &t = hp.transforms[ti];
+		if (t.kind == Transform::RCT) {
+			j40hip_device_state::ModOp op; memset(&op, 0, sizeof op);
+			Ref c[3] = {planes[(size_t) t.begin_c], planes[(size_t) t.begin_c + 1], planes[(size_t) t.begin_c + 2]};
+			op.kind = 0; op.a = c[0].p; op.b = c[1].p; op.c = c[2].p; op.n = (size_t) c[0].w * (size_t) c[0].h; op.p0 = t.rct_type % 7;
+			st->mod_ops.push_back(op);
+			for (int i = 0; i < 3; ++i) planes[(size_t) (t.begin_c + PERM[t.rct_type / 7][i])] = c[i];
+		} else if (t.kind == Transform::PALETTE) {
+			const int32_t first = t.begin_c + 1;
+			const Ref idx = planes[(size_t) first], pal = planes[0];
+			const size_t n = (size_t) idx.w * (size_t) idx.h;
+			std::vector<Ref> outs;
+			for (int32_t i = 0; i < t.num_c - 1; ++i) outs.push_back({st->scratch<int16_t>(n ? n : 1, ok), idx.w, idx.h});
+			outs.push_back(idx);   // the index channel becomes the last colour channel, in place
+			if (t.nb_deltas > 0) {
+				std::vector<int16_t *> ptrs; for (const Ref &o : outs) ptrs.push_back(o.p);
+				int8_t wpp[12]; { const WPParams &wp = h->frame.gmodular.wp; wpp[0] = wp.p1; wpp[1] = wp.p2; for (int i = 0; i < 5; ++i) wpp[2 + i] = wp.p3[i]; for (int i = 0; i < 4; ++i) wpp[7 + i] = wp.w[i]; wpp[11] = 0; }
+				j40hip_device_state::ModOp op; memset(&op, 0, sizeof op);
+				op.kind = 2; op.src = idx.p; op.aux = pal.p; op.p0 = pal.w; op.p1 = t.num_c; op.p2 = idx.w; op.p3 = idx.h; op.p4 = t.nb_colours; op.p5 = t.nb_deltas | (t.d_pred << 24);
+				op.dst_list = st->upload(ptrs.data(), ptrs.size(), s, ok);
+				op.wpp = st->upload(wpp, 12, s, ok);
+				st->mod_ops.push_back(op);
+			} else {
+				for (int32_t i = 0; i < t.num_c; ++i) {
+					j40hip_device_state::ModOp op; memset(&op, 0, sizeof op);
+					op.kind = 1; op.src = idx.p; op.aux = t.nb_colours > 0 ? pal.p + (size_t) i * (size_t) pal.w : nullptr; op.a = outs[(size_t) i].p; op.n = n; op.p0 = i; op.p1 = t.nb_colours;
+					st->mod_ops.push_back(op);
+				}
+			}
+			std::vector<Ref> next(planes.begin() + 1, planes.begin() + first);
+			next.insert(next.end(), outs.begin(), outs.end());
+			next.insert(next.end(), planes.begin() + first + 1, planes.end());
+			planes.swap(next);
+		} else { ok = false; }
+	}
+	for (const Ref &p : planes) { st->final_planes.push_back(p.p); st->final_w.push_back(p.w); st->final_h.push_back(p.h); }
+	st->alpha_channel = hp.alpha_channel;
+	// the renderer needs three full-size colour planes (j40.h:7923)
+	bool renderable = planes.size() >= 3;
+	for (size_t c = 0; renderable && c < 3; ++c) renderable = planes[c].w == hp.frame.width && planes[c].h == hp.frame.height;
+	if (st->alpha_channel >= 0) renderable = renderable && (size_t) st->alpha_channel < planes.size() && planes[(size_t) st->alpha_channel].w == hp.frame.width && planes[(size_t) st->alpha_channel].h == hp.frame.height;
+	for (auto &e : st->ev) if (hipEventCreate(&e) != hipSuccess) ok = false;
+	if (hipStreamSynchronize(s) != hipSuccess) ok = false;
+	if (!ok) { j40hip_release_device(h); return ERR_GPU; }
+	if (!renderable) { j40hip_release_device(h); return ERR_TODO; }
+	return 0;
+}
+
+static uint32_t decode_modular(j40hip_frame *h, void *rgba_dev, size_t stride_bytes, hipStream_t s, float *ms3) {
+	j40hip_device_state *st = h->dev;
+	const DevModPlan &plan = st->mod;
+	const Frame &fr = h->frame;
+	if (ms3) (void) hipEventRecord(st->ev[0], s);
+	if (hipMemsetAsync(plan.status, 0, sizeof(uint32_t) * ((size_t) st->total_sections + 1), s) != hipSuccess) return ERR_GPU;
+	if (ms3) (void) hipEventRecord(st->ev[1], s);
+	launch_modular_sections(plan, st->mod_sections, s);
+	if (ms3) (void) hipEventRecord(st->ev[2], s);
+	for (const auto &op : st->mod_ops) {
+		if (op.kind == 0) launch_inverse_rct(op.a, op.b, op.c, op.n, op.p0, s);
+		else if (op.kind == 1) launch_inverse_palette_plain(op.src, op.aux, op.a, op.n, op.p0, op.p1, fr.im.bpp, s);
+		else launch_inverse_palette_predicted(op.src, op.aux, op.p0, op.dst_list, op.p1, op.p2, op.p3, op.p4, op.p5 & 0xffffff, op.p5 >> 24, fr.im.bpp, op.wpp, st->pal_wp_scratch, st->mod_extra_status, s);
+	}
+	launch_pack_planes(st->final_planes[0], st->final_planes[1], st->final_planes[2], st->alpha_channel >= 0 ? st->final_planes[(size_t) st->alpha_channel] : nullptr,
+		fr.fh.width, fr.fh.height, fr.im.bpp, (uint8_t *) rgba_dev, stride_bytes, s);
+	if (ms3) {
+		(void) hipEventRecord(st->ev[3], s);
+		if (hipEventSynchronize(st->ev[3]) != hipSuccess) return ERR_GPU;
+		float a = 0, b = 0, c = 0;
+		(void) hipEventElapsedTime(&a, st->ev[0], st->ev[1]); (void) hipEventElapsedTime(&b, st->ev[1], st->ev[2]); (void) hipEventElapsedTime(&c, st->ev[2], st->ev[3]);
+		ms3[0] = b; ms3[1] = c; ms3[2] = a;
+	}
+	return hipGetLastError() == hipSuccess ? 0 : ERR_GPU;
+}
+
 extern "C" uint32_t j40hip_frame_upload(j40hip_frame *h, int device) {
 	if (!h) return ERR_GPU;
 	if (h->dev) j40hip_release_device(h);
 	if (j40hip_device_count() <= device || hipSetDevice(device) != hipSuccess) return ERR_GPU;
+	if (h->frame.fh.is_modular) return upload_modular(h, device);
 	HostPlan hp;
 	if (uint32_t e = build_vardct_plan(h->frame, h->cs, h->cs_size, &hp)) return e;
 
@@ -136,6 +264,7 @@ static uint32_t decode_impl(j40hip_frame *h, void *rgba_dev, size_t stride_bytes
 	if (!h || !h->dev) return ERR_GPU;
 	j40hip_device_state *st = h->dev;
 	if (hipSetDevice(st->device) != hipSuccess) return ERR_GPU;
+	if (st->is_modular) return decode_modular(h, rgba_dev, stride_bytes, s, ms3);
 	const DevPlan &plan = st->plan;
 	const Frame &fr = h->frame;
 	const bool whole = st->first_group == 0 && st->num_groups == fr.fh.num_groups;
@@ -177,6 +306,14 @@ extern "C" uint32_t j40hip_frame_decode_timed(j40hip_frame *h, void *rgba_dev, s
 extern "C" uint32_t j40hip_frame_status(j40hip_frame *h) {
 	if (!h || !h->dev) return ERR_GPU;
 	j40hip_device_state *st = h->dev;
+	if (st->is_modular) {
+		st->status_host.assign((size_t) st->total_sections + 1, 0);
+		if (hipMemcpy(st->status_host.data(), st->mod.status, sizeof(uint32_t) * st->status_host.size(), hipMemcpyDeviceToHost) != hipSuccess) return ERR_GPU;
+		std::vector<std::pair<size_t, uint32_t>> bad;
+		for (size_t i = 0; i < (size_t) st->total_sections; ++i) if (st->status_host[i]) bad.push_back({st->mod_section_offsets[i], st->status_host[i]});
+		if (!bad.empty()) return std::min_element(bad.begin(), bad.end())->second;
+		return st->status_host[(size_t) st->total_sections];
+	}
 	st->status_host.assign((size_t) st->total_sections, 0);
 	if (hipMemcpy(st->status_host.data(), st->plan.status, sizeof(uint32_t) * st->status_host.size(), hipMemcpyDeviceToHost) != hipSuccess) return ERR_GPU;
 	// the reference reports the first failing section in the order it reads them (TOC order)
@@ -204,7 +341,7 @@ extern "C" uint32_t j40hip_frame_decode_to_host(j40hip_frame *h, void *rgba_host
 }
 
 extern "C" uint32_t j40hip_frame_read_coeffs(j40hip_frame *h, int64_t gg, int c, float *out) {
-	if (!h || !h->dev) return ERR_GPU;
+	if (!h || !h->dev || h->dev->is_modular) return ERR_GPU;
 	const LfGroup &g = h->frame.lf_groups[(size_t) gg];
 	size_t base = 0;
 	for (int64_t i = 0; i < gg; ++i) base += h->frame.lf_groups[(size_t) i].blocks.size();
@@ -213,4 +350,11 @@ extern "C" uint32_t j40hip_frame_read_coeffs(j40hip_frame *h, int64_t gg, int c,
 	return 0;
 }
 
-extern "C" uint32_t j40hip_frame_read_plane_i16(j40hip_frame *, int, int16_t *) { return ERR_TODO; }
+extern "C" uint32_t j40hip_frame_read_plane_i16(j40hip_frame *h, int c, int16_t *out) {
+	if (!h || !h->dev || !h->dev->is_modular) return ERR_GPU;
+	j40hip_device_state *st = h->dev;
+	if (c < 0 || (size_t) c >= st->final_planes.size()) return ERR_RNGE;
+	const size_t n = (size_t) st->final_w[(size_t) c] * (size_t) st->final_h[(size_t) c];
+	if (hipMemcpy(out, st->final_planes[(size_t) c], n * 2, hipMemcpyDeviceToHost) != hipSuccess) return ERR_GPU;
+	return 0;
+}

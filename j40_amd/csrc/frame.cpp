@@ -427,6 +427,13 @@ static void read_lf_global(BitReader &br, Frame *f) {
 		allocate_modular(&f->gmodular);
 		if (fh.width <= (1 << fh.group_size_shift) && fh.height <= (1 << fh.group_size_shift)) f->num_gm_channels = (int32_t) f->gmodular.channel.size();
 		else f->num_gm_channels = f->gmodular.nb_meta_channels;
+		if (fh.is_modular) {
+			// the channel data that follows (j40.h:6334-6337) is decoded by the HIP Modular kernel, which
+			// continues from this bit position inside the section
+			f->gm_data_bitpos = br.bit_position();
+			f->gm_data_pending = true;
+			return;
+		}
 		CodeState code(f->gmodular.codespec);
 		for (int32_t i = 0; i < f->num_gm_channels; ++i) decode_modular_channel(br, f->gmodular, code, i, 0);
 		finish_code(br, code);
@@ -663,7 +670,8 @@ void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
 		// the reference reads them (j40.h:8189-8199)
 		BitReader sr(cs + f->toc.single_section.offset, f->toc.single_section.size);
 		read_lf_global(sr, f);
-		if (!f->fh.is_modular) read_hf_global(sr, f);
+		if (f->fh.is_modular) return;   // LfGroup / PassGroup read nothing for single-group Modular frames (j40.h:6731, 7024)
+		read_hf_global(sr, f);
 		read_lf_group(sr, f, &f->lf_groups[0]);
 		if (!f->fh.is_modular) {
 			// the pass group continues in the middle of this section: the device reader starts at a bit offset
@@ -682,7 +690,7 @@ void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
 	{
 		BitReader sr(cs + f->toc.lf_global.offset, f->toc.lf_global.size);
 		read_lf_global(sr, f);
-		sr.no_more_bytes();
+		if (!f->gm_data_pending) sr.no_more_bytes();
 	}
 	if (f->fh.is_modular) {
 		J40HIP_SHOULD(f->toc.hf_global.size == 0, "excs");

@@ -103,7 +103,10 @@ struct Frame {
 	uint32_t dct_select_used = 0, order_used = 0;
 
 	std::vector<LfGroup> lf_groups;
-	size_t single_pass_group_bitpos = 0;  // single-section VarDCT frames: where the pass group starts
+	size_t single_pass_group_bitpos = 0;
+	// Modular frames: LfGlobal's channel data is left to the device; it starts at this bit of the section
+	bool gm_data_pending = false;
+	size_t gm_data_bitpos = 0;  // single-section VarDCT frames: where the pass group starts
 };
 
 // locates the codestream inside `data` (bare codestream or ISOBMFF container); if the codestream is

@@ -182,4 +182,84 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 	return 0;
 }
 
+uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostModPlan *hp) {
+	if (!fr.fh.is_modular) return ERR_TODO;
+	const Modular &gm = fr.gmodular;
+	const int32_t nch = (int32_t) gm.channel.size();
+	if (nch > MOD_MAX_CHANNELS) return ERR_TODO;
+	// what the reference's renderer accepts (j40.h:7917-7936)
+	if (fr.im.bpp < 8 || fr.im.exp_bits || !fr.im.modular_16bit_buffers) return ERR_TODO;
+	if (fr.im.xyb_encoded || fr.fh.do_ycbcr) return ERR_TODO;   // XYB / YCbCr Modular frames: colour transform not covered
+	if (fr.global_tree.empty()) return E4("mtre");
+	DevModFrame &df = hp->frame;
+	memset(&df, 0, sizeof df);
+	df.width = fr.fh.width; df.height = fr.fh.height; df.num_groups = (int32_t) fr.fh.num_groups; df.bpp = fr.im.bpp;
+	df.num_channels = nch;
+	df.tree_uses_wp = tree_uses_wp(fr.global_tree); df.num_tree_nodes = (int32_t) fr.global_tree.size();
+	for (const TreeNode &n : fr.global_tree) hp->tree.push_back(DevTreeNode{n.prop, n.value, n.a, n.b});
+	flatten_code_spec(fr.global_codespec, hp->pool_u8, hp->pool_i32, hp->pool_u64, hp->clusters, &hp->spec);
+	hp->pool_u8.resize(hp->pool_u8.size() + 16, 0);
+	hp->transforms = gm.transforms;
+	int32_t max_width = 1;
+	for (const Plane &p : gm.channel) { hp->plane_w.push_back(p.width); hp->plane_h.push_back(p.height); hp->plane_meta.push_back(p.vshift < 0); }
+	auto wp_bytes = [](const WPParams &wp, int8_t *out) { out[0] = wp.p1; out[1] = wp.p2; for (int i = 0; i < 5; ++i) out[2 + i] = wp.p3[i]; for (int i = 0; i < 4; ++i) out[7 + i] = wp.w[i]; out[11] = 0; };
+	// LfGlobal's own channel data: every channel for single-group frames, only meta channels otherwise
+	if (fr.gm_data_pending) {
+		// (with zero channels this still validates the stream's final rANS state and the section end)
+		DevModSection s;
+		memset(&s, 0, sizeof s);
+		const Section &ls = fr.toc.single ? fr.toc.single_section : fr.toc.lf_global;
+		s.byte_off = (uint32_t) ls.offset; s.size = (uint32_t) ls.size; s.bit_off = (uint32_t) fr.gm_data_bitpos;
+		s.gx = s.gy = 0; s.gw = fr.fh.width; s.gh = fr.fh.height; s.sidx = 0;
+		s.first_channel = 0; s.num_channels = fr.num_gm_channels;
+		wp_bytes(gm.wp, s.wp);
+		hp->sections.push_back(s);
+		for (int32_t c = 0; c < fr.num_gm_channels; ++c) max_width = std::max(max_width, hp->plane_meta[(size_t) c] ? hp->plane_w[(size_t) c] : fr.fh.width);
+	} else return ERR_TODO;
+	if (!fr.toc.single && fr.num_gm_channels < nch) {
+		const int32_t num_groups = (int32_t) fr.fh.num_groups;
+		if (fr.fh.num_passes != 1) return ERR_TODO;
+		for (int32_t g = 0; g < num_groups; ++g) {
+			const Section &ps = fr.toc.pass_groups[(size_t) g];
+			const GroupInfo gi = group_info(fr.fh, g);
+			const LfGroup &gg = fr.lf_groups[(size_t) gi.ggidx];
+			// the section starts with a Modular header for the group's sub-image (j40.h:7024-7026)
+			Modular m; m.bpp = fr.im.bpp;
+			for (int32_t c = fr.num_gm_channels; c < nch; ++c) { Plane p; p.width = gi.gw; p.height = gi.gh; m.channel.push_back(p); }
+			BitReader br(cs + ps.offset, ps.size);
+			try { read_modular_header(br, &fr.global_tree, &fr.global_codespec, &m); } catch (const DecodeError &e) { return e.code; }
+			if (!m.use_global_tree || !m.transforms.empty()) return ERR_TODO;   // local trees / local transforms stay on the to-do list
+			DevModSection s;
+			memset(&s, 0, sizeof s);
+			s.byte_off = (uint32_t) ps.offset; s.size = (uint32_t) ps.size; s.bit_off = (uint32_t) br.bit_position();
+			s.gx = gg.left + gi.gx_in_gg; s.gy = gg.top + gi.gy_in_gg; s.gw = gi.gw; s.gh = gi.gh;
+			s.sidx = (int32_t) (1 + 3 * fr.fh.num_lf_groups + 17 + g);
+			s.first_channel = fr.num_gm_channels; s.num_channels = nch - fr.num_gm_channels;
+			wp_bytes(m.wp, s.wp);
+			hp->sections.push_back(s);
+			max_width = std::max(max_width, gi.gw);
+		}
+	}
+	df.num_sections = (int32_t) hp->sections.size();
+	df.max_width = max_width;
+	// where the alpha channel ends up after the inverse transforms: colour channels are 0..2, extra
+	// channels follow (j40.h:7923-7936); the transforms above preserve that tail order
+	hp->alpha_channel = -1;
+	for (size_t i = 0; i < fr.im.ec.size(); ++i) if (fr.im.ec[i].type == EC_ALPHA) {
+		if (fr.im.ec[i].bpp != fr.im.bpp || fr.im.ec[i].exp_bits != fr.im.exp_bits || fr.im.ec[i].dim_shift || fr.im.ec[i].alpha_associated) return ERR_TODO;
+		hp->alpha_channel = 3 + (int32_t) i;
+		break;
+	}
+	hp->lz_window_size = 0;
+	if (hp->spec.lz77_enabled) {
+		// integers decoded by one section: at most all samples of its rectangle in every channel
+		size_t most = 0;
+		for (const DevModSection &s : hp->sections) most = std::max(most, (size_t) s.num_channels * (size_t) s.gw * (size_t) s.gh);
+		hp->lz_window_size = (uint32_t) std::min<size_t>(most + 16, (size_t) 1 << 26);
+	}
+	hp->codestream.assign(cs, cs + cs_size);
+	hp->codestream.resize(cs_size + 16, 0);
+	return 0;
+}
+
 } // namespace j40hip

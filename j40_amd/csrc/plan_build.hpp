@@ -42,6 +42,28 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 // (coeffs[order[i]], j40.h:6989) -- for stage dumps / parity tests
 void coeffs_scan_to_canonical(const Frame &fr, size_t gg, int c, float *data);
 
+// ---- Modular frames ----
+struct HostModPlan {
+	DevModFrame frame;
+	std::vector<uint8_t> codestream;
+	std::vector<uint8_t> pool_u8;
+	std::vector<int32_t> pool_i32;
+	std::vector<uint64_t> pool_u64;
+	std::vector<DevCluster> clusters;
+	DevCodeSpec spec;
+	std::vector<DevTreeNode> tree;
+	std::vector<DevModSection> sections;
+	std::vector<int32_t> plane_w, plane_h, plane_meta;   // coded channels
+	std::vector<Transform> transforms;                    // global transforms in coded order
+	int32_t alpha_channel = -1;                           // index (after inverse transforms) of the first alpha extra channel
+	uint32_t lz_window_size = 0;
+};
+
+// parses every pass-group section's Modular header on the host (a few bits each) and lays out the
+// device plan; returns 0 or a 4-char code ("TODO": local trees / local transforms / layouts the
+// reference itself refuses)
+uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostModPlan *out);
+
 // fills a DevCodeSpec and appends its tables to the pools
 void flatten_code_spec(const CodeSpec &spec, std::vector<uint8_t> &u8, std::vector<int32_t> &i32, std::vector<uint64_t> &u64, std::vector<DevCluster> &clusters, DevCodeSpec *out);
 

@@ -10,6 +10,7 @@
 #include "../../j40_amd/csrc/tables.hpp"
 #include "../../j40_amd/csrc/device/hf_dev.h"
 #include "../../j40_amd/csrc/device/vardct_dev.h"
+#include "../../j40_amd/csrc/device/modular_dev.h"
 
 using namespace j40hip;
 
@@ -68,7 +69,87 @@ void idct_cols_dyn(float *t, int n, int cols, int pitch, const float *hs) {
 
 } // namespace
 
-// decodes a VarDCT stream with the device functions on the CPU.
+// Modular frames: K3 / K4 / K5 device functions with the runtime's orchestration (device/runtime.hip)
+static uint32_t hostsim_decode_modular(const Frame &fr, const uint8_t *cs, size_t cs_size, uint8_t *rgba) {
+	HostModPlan hp;
+	if (uint32_t e = build_modular_plan(fr, cs, cs_size, &hp)) return e;
+	const int32_t nch = hp.frame.num_channels;
+	std::vector<std::vector<int16_t>> store((size_t) nch);
+	DevModPlan plan;
+	memset(&plan, 0, sizeof plan);
+	plan.frame = &hp.frame; plan.codestream = hp.codestream.data(); plan.pool_u8 = hp.pool_u8.data(); plan.pool_i32 = hp.pool_i32.data(); plan.pool_u64 = hp.pool_u64.data();
+	plan.clusters = hp.clusters.data(); plan.spec = &hp.spec; plan.tree = hp.tree.data(); plan.sections = hp.sections.data();
+	struct Ref { int16_t *p; int32_t w, h; };
+	std::vector<Ref> planes;
+	for (int32_t c = 0; c < nch; ++c) {
+		store[(size_t) c].assign((size_t) std::max(hp.plane_w[(size_t) c], 0) * (size_t) std::max(hp.plane_h[(size_t) c], 0) + 1, 0);
+		plan.planes[c] = store[(size_t) c].data(); plan.plane_w[c] = hp.plane_w[(size_t) c]; plan.plane_h[c] = hp.plane_h[(size_t) c]; plan.plane_meta[c] = hp.plane_meta[(size_t) c];
+		planes.push_back({plan.planes[c], plan.plane_w[c], plan.plane_h[c]});
+	}
+	std::vector<int32_t> wps((size_t) hp.sections.size() * (size_t) (2 * hp.frame.max_width * 5) + 16), window(hp.lz_window_size ? (size_t) hp.sections.size() * hp.lz_window_size : 0);
+	std::vector<uint32_t> status(hp.sections.size() + 1, 0);
+	plan.wp_scratch = hp.frame.tree_uses_wp ? wps.data() : nullptr;
+	plan.lz_window = window.empty() ? nullptr : window.data(); plan.lz_window_size = hp.lz_window_size; plan.status = status.data();
+	for (int32_t sct = 0; sct < hp.frame.num_sections; ++sct) status[(size_t) sct] = decode_modular_section(plan, sct);
+	for (uint32_t e : status) if (e) return e;
+	static const uint8_t PERM[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
+	std::vector<std::vector<int16_t>> extra;
+	extra.reserve(64);
+	for (size_t ti = hp.transforms.size(); ti-- > 0; ) {
+		const Transform &t = hp.transforms[ti];
+		if (t.kind == Transform::RCT) {
+			Ref c[3] = {planes[(size_t) t.begin_c], planes[(size_t) t.begin_c + 1], planes[(size_t) t.begin_c + 2]};
+			const size_t n = (size_t) c[0].w * (size_t) c[0].h;
+			for (size_t i = 0; i < n; ++i) inverse_rct_pixel(t.rct_type % 7, c[0].p[i], c[1].p[i], c[2].p[i]);
+			for (int i = 0; i < 3; ++i) planes[(size_t) (t.begin_c + PERM[t.rct_type / 7][i])] = c[i];
+		} else {
+			const int32_t first = t.begin_c + 1;
+			const Ref idx = planes[(size_t) first], pal = planes[0];
+			const size_t n = (size_t) idx.w * (size_t) idx.h;
+			std::vector<Ref> outs;
+			for (int32_t i = 0; i < t.num_c - 1; ++i) { extra.emplace_back(n + 1, 0); outs.push_back({extra.back().data(), idx.w, idx.h}); }
+			outs.push_back(idx);
+			ModWP wp;
+			const WPParams &gp = fr.gmodular.wp;
+			wp.on = t.nb_deltas > 0 && t.d_pred == 6; wp.width = idx.w; std::vector<int32_t> errs((size_t) 2 * (size_t) idx.w * 5 + 16, 0); wp.errors = errs.data();
+			wp.p1 = gp.p1; wp.p2 = gp.p2; for (int i = 0; i < 5; ++i) wp.p3[i] = gp.p3[i]; for (int i = 0; i < 4; ++i) wp.w[i] = gp.w[i];
+			uint32_t err = 0;
+			for (int32_t i = 0; i < t.num_c; ++i) {
+				const int16_t *palrow = t.nb_colours > 0 ? pal.p + (size_t) i * (size_t) pal.w : nullptr;
+				std::fill(errs.begin(), errs.end(), 0);
+				for (int k = 0; k < 5; ++k) wp.pred[k] = 0;
+				wp.trueerrw = wp.trueerrn = wp.trueerrnw = wp.trueerrne = 0;
+				for (int32_t y = 0; y < idx.h; ++y) for (int32_t x = 0; x < idx.w; ++x) {
+					const int16_t index = idx.p[(size_t) y * (size_t) idx.w + (size_t) x];
+					int16_t val = palette_value(index, i, palrow, t.nb_colours, fr.im.bpp);
+					if (t.nb_deltas > 0) {
+						int16_t *line = outs[(size_t) i].p + (size_t) y * (size_t) idx.w;
+						const ModNeigh p = mod_neighbours(line, idx.w, idx.w, x, y);
+						wp_before(wp, x, y, p);
+						if (index < t.nb_deltas) val = (int16_t) (val + mod_predict(t.d_pred, wp, p, &err));
+						wp_after(wp, x, y, val);
+					}
+					outs[(size_t) i].p[(size_t) y * (size_t) idx.w + (size_t) x] = val;
+				}
+			}
+			if (err) return err;
+			std::vector<Ref> next(planes.begin() + 1, planes.begin() + first);
+			next.insert(next.end(), outs.begin(), outs.end());
+			next.insert(next.end(), planes.begin() + first + 1, planes.end());
+			planes.swap(next);
+		}
+	}
+	const int32_t W = hp.frame.width, H = hp.frame.height;
+	if (planes.size() < 3) return ERR_TODO;
+	const int32_t opaque = (1 << fr.im.bpp) - 1;
+	for (size_t i = 0; i < (size_t) W * (size_t) H; ++i) {
+		const uint32_t px = pack_rgba8(planes[0].p[i], planes[1].p[i], planes[2].p[i], hp.alpha_channel >= 0 ? planes[(size_t) hp.alpha_channel].p[i] : opaque, fr.im.bpp);
+		memcpy(rgba + i * 4, &px, 4);
+	}
+	return 0;
+}
+
+// decodes a stream with the device functions on the CPU.
 //   rgba: width*height*4 bytes; coeffs_out (optional): 3 arrays of total_cells*64 floats concatenated
 // returns 0 or the first error code
 extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const uint8_t *buf, size_t size, uint8_t *rgba, float *coeffs_out, int only_entropy) {
@@ -79,6 +160,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 		extract_codestream(buf, size, &cs, &cs_size, &storage);
 		parse_frame(cs, cs_size, &fr, 1);
 	} catch (const DecodeError &e) { return e.code; }
+	if (fr.fh.is_modular) return hostsim_decode_modular(fr, cs, cs_size, rgba);
 	if (uint32_t e = build_vardct_plan(fr, cs, cs_size, &hp)) return e;
 	std::vector<float> coeffs[3];
 	for (int c = 0; c < 3; ++c) coeffs[c].assign(hp.coeff_floats, 0.0f);

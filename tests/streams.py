@@ -41,3 +41,20 @@ VARDCT_CASES = [
     ("container_jxlc", dict(container=1)),
     ("container_jxlp", dict(container=2)),
 ]
+
+# the Modular feature matrix (width, height, options); all decode bit-exactly
+MODULAR_CASES = [
+    ("single_group_gradient", 256, 256, dict()),
+    ("fjxl_like_rgba", 256, 256, dict(alpha=1, prefix=1, lz77=1)),          # config 1 shape: single section, alpha, RCT 6, prefix codes + LZ77
+    ("multi_group", 600, 300, dict()),
+    ("property_tree", 600, 300, dict(tree=1)),
+    ("weighted_predictor", 600, 300, dict(tree=2)),
+    ("previous_channel_props_alpha", 600, 300, dict(tree=3, alpha=1)),
+    ("palette", 600, 300, dict(palette=1)),
+    ("palette_deltas_synthetic_alpha", 600, 300, dict(palette=2, alpha=1)),
+    ("palette_delta_prediction", 300, 200, dict(palette=3)),
+    ("rct_permuted_prefix", 600, 300, dict(rct=13, prefix=1)),
+    ("no_rct_group128_lz77", 200, 100, dict(rct=-1, groupshift=7, lz77=1)),
+    ("palette_prediction_wp_tree", 160, 120, dict(palette=3, tree=2)),
+    ("container", 300, 200, dict(container=1, tree=1)),
+]

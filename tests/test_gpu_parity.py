@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from streams import synth, VARDCT_CASES, ROOT
+from streams import synth, VARDCT_CASES, MODULAR_CASES, ROOT
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(ROOT, "tests", "golden")
@@ -64,6 +64,38 @@ def test_hf_coefficients_bit_exact(gpu, ref, name, opts):
     rs.close()
 
 
+@pytest.mark.parametrize("name,w,h,opts", MODULAR_CASES)
+def test_modular_bit_exact(gpu, ref, name, w, h, opts):
+    data = synth("modular", w, h, 71, **opts)
+    err, rgba = gpu.decode(data)
+    assert err == ""
+    rerr, expect = ref.decode(data)
+    assert rerr == "" and np.array_equal(rgba, expect), "Modular output must be bit-exact"
+
+
+def test_modular_2048_multi_group_bit_exact(gpu, ref):
+    data = synth("modular", 2048, 2048, 12, tree=1)
+    err, rgba = gpu.decode(data)
+    assert err == "" and np.array_equal(rgba, ref.decode(data)[1])
+
+
+def test_modular_corruption_is_reported(gpu, ref):
+    data = bytearray(synth("modular", 600, 300, 71, tree=1))
+    rng = np.random.default_rng(11)
+    rejected = 0
+    for _ in range(8):
+        m = bytearray(data)
+        m[int(rng.integers(len(m) // 2, len(m) - 4))] ^= 0x10
+        rerr, rexp = ref.decode(bytes(m))
+        err, rgba = gpu.decode(bytes(m))
+        if rerr == "":
+            assert err == "" and np.array_equal(rgba, rexp)
+        else:
+            assert err != ""
+            rejected += 1
+    assert rejected >= 1
+
+
 def test_golden_fixtures(gpu):
     manifest = json.load(open(os.path.join(GOLDEN, "manifest.json")))
     for name, e in sorted(manifest.items()):
@@ -72,6 +104,10 @@ def test_golden_fixtures(gpu):
         fr.upload(0)
         err, rgba = fr.decode_to_host()
         assert err == "", name
+        if e["mode"] == "modular":
+            assert sha(rgba) == e["rgba_sha256"], name   # integer path: bit-exact
+            fr.close()
+            continue
         co = [fr.read_coeffs(g, c) for g in range(fr.info["num_lf_groups"]) for c in range(3)]
         assert sha(np.concatenate(co)) == e["coeffs_sha256"], name
         if sha(rgba) != e["rgba_sha256"]:

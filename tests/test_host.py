@@ -123,6 +123,8 @@ def test_host_parse_golden_llf(built):
     manifest = json.load(open(os.path.join(GOLDEN, "manifest.json")))
     for name, e in sorted(manifest.items()):
         data = open(os.path.join(GOLDEN, name + ".jxl"), "rb").read()
+        if e["mode"] != "vardct":
+            continue
         fr = j40_amd.Frame(data)
         ll = [fr.llf(g, c) for g in range(fr.info["num_lf_groups"]) for c in range(3)]
         assert sha(np.concatenate(ll)) == e["llf_sha256"], name

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from streams import synth, VARDCT_CASES, ROOT
+from streams import synth, VARDCT_CASES, MODULAR_CASES, ROOT
 
 
 @pytest.fixture(scope="module")
@@ -39,3 +39,14 @@ def test_device_functions_on_cpu_match_reference(ref, sim, name, opts):
     d = np.abs(rs.rgba().astype(np.int32) - rgba.astype(np.int32))
     assert d.max() <= 1
     rs.close()
+
+
+@pytest.mark.parametrize("name,w,h,opts", MODULAR_CASES)
+def test_modular_device_functions_on_cpu_are_bit_exact(ref, sim, name, w, h, opts):
+    data = synth("modular", w, h, 61, **opts)
+    err, expect = ref.decode(data)
+    assert err == ""
+    rgba = np.zeros(expect.shape, np.uint8)
+    buf = C.create_string_buffer(data, len(data))
+    assert sim.hostsim_decode(buf, len(data), rgba.ctypes.data, None, 0) == 0
+    assert np.array_equal(rgba, expect)

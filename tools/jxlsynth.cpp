@@ -537,7 +537,266 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 	return 0;
 }
 
-int run_modular(int, int, uint64_t, const char *, const Options &) { die("modular: not built yet"); }
+// ------------------------------------------------------------------------------------------------
+// Modular frames (lossless-style): RGB or RGBA, global RCT and/or Palette, MA tree with a choice of
+// predictors (incl. the weighted predictor), ANS or prefix codes, optional LZ77 run-lengths.
+// Single-group frames put everything into LfGlobal (one section, j40.h:6329-6336); larger frames
+// code every group's rectangle in its own PassGroup section (j40.h:7024-7033).
+
+static void forward_rct(std::vector<Channel> &ch, int first, int type) {
+	// exact inverse of the decoder's RCT for the un-permuted types (j40.h:4341-4393)
+	const size_t n = ch[(size_t) first].px.size();
+	int32_t *a = ch[(size_t) first].px.data(), *b = ch[(size_t) first + 1].px.data(), *c = ch[(size_t) first + 2].px.data();
+	for (size_t i = 0; i < n; ++i) {
+		int32_t p0 = a[i], p1 = b[i], p2 = c[i];
+		switch (type % 7) {
+		case 0: break;
+		case 1: c[i] = p2 - p0; break;
+		case 2: c[i] = p2 - p0; b[i] = p1; break;   // decoder: out2 = in1 + in0 (needs in1 == in2 - in0; see below)
+		case 3: b[i] = p1 - p0; c[i] = p2 - p0; break;
+		case 4: b[i] = p1 - ((p0 >> 1) + (p2 >> 1) + (p0 & p2 & 1)); break;
+		case 5: c[i] = p2 - p0; b[i] = p1 - p0 - ((p2 - p0) >> 1); break;
+		case 6: { int32_t co = p0 - p2, tmp = p2 + (co >> 1), cg = p1 - tmp, y = tmp + (cg >> 1); a[i] = y; b[i] = co; c[i] = cg; break; }
+		}
+	}
+}
+
+int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt) {
+	SplitMix64 rng(seed * 0x9e3779b97f4a7c15ull + 777);
+	const int alpha = opt.geti("alpha", 0);
+	const int group_shift = opt.geti("groupshift", 8);
+	const int rct = opt.geti("rct", 6);                   // -1: none
+	const int use_prefix = opt.geti("prefix", 0);
+	const int lz77 = opt.geti("lz77", 0);
+	const int tree_kind = opt.geti("tree", 0);            // 0 gradient, 1 per-channel leaves + property splits, 2 weighted predictor, 3 previous-channel properties
+	const int palette = opt.geti("palette", 0);           // 0 none, 1 plain palette, 2 with deltas / synthetic colours, 3 with delta prediction
+	const int container = opt.geti("container", 0);
+	const int bpp = 8;
+	const int gdim = 1 << group_shift;
+	const int gcols = (W + gdim - 1) / gdim, grows = (H + gdim - 1) / gdim, num_groups = gcols * grows;
+	const int num_lf_groups = ((W + 8 * gdim - 1) / (8 * gdim)) * ((H + 8 * gdim - 1) / (8 * gdim));
+	const bool single = num_groups == 1;
+	const int ncolour = 3, nch = ncolour + (alpha ? 1 : 0);
+
+	// ---- source picture -> channels: colour first, then extra channels (the renderer takes channels
+	//      0..2 as RGB and 3.. as extra channels, j40.h:7923-7936) ----
+	Picture pic(W, H, seed);
+	std::vector<Channel> ch;
+	for (int c = 0; c < nch; ++c) ch.emplace_back(W, H);
+	const int colour0 = 0;               // index of the first colour channel
+	for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+		float rgb[3]; pic.rgb((float) x, (float) y, rgb);
+		// flat regions + a bit of texture so that run-lengths and the predictors both get work
+		for (int c = 0; c < 3; ++c) {
+			int v = (int) (rgb[c] * 255.0f);
+			v = (v / 6) * 6 + (int) (Picture::hash01((uint64_t) x * 7919 + (uint64_t) y * 104729 + (uint64_t) c + seed) < 0.08f);
+			ch[(size_t) (colour0 + c)].at(x, y) = std::min(255, std::max(0, v));
+		}
+		if (alpha) ch[3].at(x, y) = ((x / 37 + y / 29) & 3) == 0 ? 128 + ((x * 3 + y) & 63) : 255;
+	}
+
+	// ---- global transforms (coded order = forward order; the decoder undoes them last to first) ----
+	std::vector<TransformW> transforms;
+	if (palette) {
+		// replace the colour channels by a palette (meta channel 0) + an index channel
+		const int nb_colours = palette == 2 ? 24 : 40;
+		const int nb_deltas = palette == 3 ? 6 : 0;
+		Channel pal(nb_colours, 3), idx(W, H);
+		for (int i = 0; i < nb_colours; ++i) for (int c = 0; c < 3; ++c) pal.at(i, c) = i < nb_deltas ? (int32_t) rng.below(9) - 4 : (int32_t) rng.below(256);
+		for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+			int v = (ch[(size_t) colour0].at(x, y) * 3 + ch[(size_t) colour0 + 1].at(x, y) * 5 + ch[(size_t) colour0 + 2].at(x, y)) / 9;
+			int i = (v * nb_colours) >> 8;
+			if (palette == 2) { if (((x ^ y) & 31) == 5) i = -1 - (int) rng.below(140); else if (((x + 2 * y) & 63) == 9) i = nb_colours + (int) rng.below(64 + 125); }
+			idx.at(x, y) = i;
+		}
+		std::vector<Channel> next;
+		next.push_back(pal);
+		next.push_back(idx);
+		for (int c = 3; c < nch; ++c) next.push_back(ch[(size_t) c]);
+		ch.swap(next);
+		TransformW t; t.kind = 1; t.begin_c = colour0; t.num_c = 3; t.nb_colours = nb_colours; t.nb_deltas = nb_deltas; t.d_pred = palette == 3 ? 5 : 0;
+		transforms.push_back(t);
+	} else if (rct >= 0) {
+		if (rct / 7 == 0 && rct % 7 != 2) forward_rct(ch, colour0, rct);   // other types: the picture is taken as already transformed
+		TransformW t; t.kind = 0; t.begin_c = colour0; t.rct_type = rct;
+		transforms.push_back(t);
+	}
+	const int nb_meta = palette ? 1 : 0;
+	const int total_ch = (int) ch.size();
+
+	// ---- MA tree ----
+	MATree tree;
+	{
+		int root;
+		if (tree_kind == 0) root = tree.leaf(5);
+		else if (tree_kind == 1) {
+			int l0 = tree.leaf(5), l1 = tree.leaf(4), l2 = tree.leaf(13), l3 = tree.leaf(1), l4 = tree.leaf(2, 0, 0, 0), l5 = tree.leaf(12), l6 = tree.leaf(7), l7 = tree.leaf(3);
+			int a = tree.branch(9, 100, l0, l1);      // W + N - NW
+			int b = tree.branch(4, 40, l2, l3);       // |N|
+			int c = tree.branch(12, -3, l4, l5);      // N - NE
+			int d = tree.branch(3, 7, l6, l7);        // x
+			int e = tree.branch(0, 1, a, b);          // channel index
+			int f = tree.branch(2, 5, c, d);          // y
+			root = tree.branch(10, 0, e, f);          // W - NW
+		} else if (tree_kind == 2) {
+			int l0 = tree.leaf(6), l1 = tree.leaf(6), l2 = tree.leaf(5), l3 = tree.leaf(6);
+			int a = tree.branch(15, 8, l0, l1);       // max weighted-predictor error
+			int b = tree.branch(15, -8, l2, l3);
+			root = tree.branch(0, 1, a, b);
+		} else {
+			int l0 = tree.leaf(5), l1 = tree.leaf(5), l2 = tree.leaf(1), l3 = tree.leaf(2), l4 = tree.leaf(5);
+			int a = tree.branch(16, 10, l0, l1);      // previous channel sample
+			int b = tree.branch(19, 4, l2, l3);       // |previous channel sample - its gradient|
+			int c = tree.branch(17, 60, a, b);        // |previous channel sample|
+			root = tree.branch(0, 0, c, l4);          // channel 0 has no previous channel
+		}
+		tree.finalise(root);
+	}
+	CodeSpecW treespec; treespec.init(6, std::vector<uint8_t>(6, 0), 1); treespec.log_alpha = 6; treespec.cfg[0] = HybridCfg{4, 1, 0};
+	StreamEncoder tree_enc(treespec); tree_tokens(tree, tree_enc); count_stream(treespec, tree_enc);
+
+	CodeSpecW gspec;
+	{
+		const int nctx = tree.num_ctx;
+		std::vector<uint8_t> map((size_t) (nctx + (lz77 ? 1 : 0)));
+		const int ncl = std::min(nctx, 3);
+		for (int i = 0; i < nctx; ++i) map[(size_t) i] = (uint8_t) (i % ncl);
+		int nclusters = ncl;
+		if (lz77) { map[(size_t) nctx] = (uint8_t) ncl; nclusters = ncl + 1; }   // the distance context gets its own cluster
+		gspec.lz77 = lz77 != 0;
+		gspec.init(nctx, map, nclusters);
+		gspec.lz_min_symbol = 224; gspec.lz_min_length = 3; gspec.lz_len_cfg = HybridCfg{0, 0, 0};
+		gspec.use_prefix = use_prefix != 0; gspec.log_alpha = 8;
+		for (auto &c : gspec.cfg) c = use_prefix ? HybridCfg{4, 2, 0} : HybridCfg{4, 1, 1};
+	}
+	WPParams wpp;
+
+	// encodes the listed channels (sub-rectangles already cut out) into one stream; LZ77 replaces runs
+	// of equal tokens ("previous symbol" = distance code 1 with a non-zero dist_mult, j40.h:2834)
+	auto encode_image = [&](std::vector<Channel> &chs, int first, int64_t sidx, StreamEncoder &enc) {
+		StreamEncoder raw(gspec);
+		for (int c = first; c < (int) chs.size(); ++c) encode_channel(tree, chs, c, sidx, wpp, raw);
+		if (!lz77) { enc.items = raw.items; return; }
+		// run-length pass over the residual tokens: a run of >= 3 identical (cluster, token, extra) items
+		// after its first occurrence becomes one copy with distance 1
+		const auto &it = raw.items;
+		for (size_t i = 0; i < it.size(); ) {
+			size_t j = i + 1;
+			while (j < it.size() && it[j].token == it[i].token && it[j].extra == it[i].extra && it[i].nextra == 0 && it[j].nextra == 0 && it[i].token < 16) ++j;
+			enc.items.push_back(it[i]);
+			size_t run = j - i - 1;
+			if (run >= 3 && it[i].token < 16) {
+				// the copied *values* are hybrid-decoded integers; with split_exp 4 a token < 16 is its own value
+				uint32_t cl = it[i + 1].cluster;
+				HToken t = hybrid_encode((uint32_t) run - (uint32_t) gspec.lz_min_length, gspec.lz_len_cfg);
+				enc.items.push_back({cl, t.token + (uint32_t) gspec.lz_min_symbol, t.extra, (uint8_t) t.nextra});
+				uint32_t lzcl = gspec.cluster_map[(size_t) gspec.total_dist() - 1];
+				HToken d = hybrid_encode(1, gspec.cfg[lzcl]);   // special distance code 1 = previous symbol
+				enc.items.push_back({lzcl, d.token, d.extra, (uint8_t) d.nextra});
+				i = j;
+			} else i = i + 1;
+		}
+	};
+
+	std::vector<StreamEncoder> encs;
+	std::vector<uint8_t> section_is_group;
+	if (single) {
+		encs.emplace_back(gspec);
+		encode_image(ch, 0, 0, encs.back());
+	} else {
+		// meta channels (palette) are decoded inside LfGlobal (num_gm_channels = nb_meta_channels, j40.h:6332)
+		encs.emplace_back(gspec);
+		if (nb_meta) { std::vector<Channel> meta(ch.begin(), ch.begin() + nb_meta); encode_image(meta, 0, 0, encs.back()); }
+		for (int g = 0; g < num_groups; ++g) {
+			const int gx = (g % gcols) * gdim, gy = (g / gcols) * gdim, gw = std::min(gdim, W - gx), gh = std::min(gdim, H - gy);
+			std::vector<Channel> sub;
+			for (int c = nb_meta; c < total_ch; ++c) {
+				Channel s2(gw, gh);
+				for (int y = 0; y < gh; ++y) for (int x = 0; x < gw; ++x) s2.at(x, y) = ch[(size_t) c].at(gx + x, gy + y);
+				sub.push_back(s2);
+			}
+			encs.emplace_back(gspec);
+			// stream index of a pass group (j40.h:7013): 1 + 3 * num_lf_groups + 17 + pass * num_groups + gidx
+			encode_image(sub, 0, 1 + 3 * num_lf_groups + 17 + g, encs.back());
+		}
+	}
+	for (auto &e : encs) count_stream(gspec, e);
+
+	// ---- sections ----
+	std::vector<std::vector<uint8_t>> sections;
+	{
+		BitWriter bw;
+		bw.put(1, 1);                 // LF channel dequantisation: default
+		bw.put(1, 1);                 // global tree present
+		write_code_spec(bw, treespec); tree_enc.flush(bw);
+		write_code_spec(bw, gspec);
+		write_modular_header(bw, true, nullptr, transforms);
+		encs[0].flush(bw);
+		bw.pad();
+		sections.push_back(bw.bytes);
+	}
+	if (!single) {
+		for (int i = 0; i < num_lf_groups; ++i) sections.push_back({});
+		sections.push_back({});       // HfGlobal must be empty for Modular frames (j40.h:7825)
+		for (int g = 0; g < num_groups; ++g) {
+			BitWriter bw;
+			write_modular_header(bw, true, nullptr, {});
+			encs[(size_t) g + 1].flush(bw);
+			bw.pad();
+			sections.push_back(bw.bytes);
+		}
+	}
+
+	// ---- codestream ----
+	BitWriter cs;
+	cs.put(0xff, 8); cs.put(0x0a, 8);
+	write_size_header(cs, W, H);
+	cs.put(0, 1);                       // ImageMetadata: not all_default
+	cs.put(0, 1);                       // no extra fields
+	cs.put(0, 1); cs.put(0, 2);         // integer samples, 8 bits
+	(void) bpp;
+	cs.put(1, 1);                       // modular_16bit_buffers
+	if (alpha) { cs.put(1, 2); cs.put(1, 1); } else cs.put(0, 2);   // num_extra_channels (+ d_alpha)
+	cs.put(0, 1);                       // xyb_encoded = 0
+	cs.put(1, 1);                       // ColourEncoding.all_default (sRGB)
+	cs.put(0, 2);                       // extensions
+	cs.put(1, 1);                       // default_m
+	cs.pad();
+	cs.put(0, 1);                       // FrameHeader: not all_default
+	cs.put(0, 2);                       // regular frame
+	cs.put(1, 1);                       // modular
+	cs.u64(0);                          // flags
+	cs.put(0, 1);                       // do_ycbcr
+	cs.put(0, 2);                       // log_upsampling
+	if (alpha) cs.put(0, 2);            // extra channel upsampling
+	cs.put((uint64_t) (group_shift - 7), 2);
+	cs.u32(1, 1, 0, 2, 0, 3, 0, 4, 3);  // one pass
+	cs.put(0, 1);                       // have_crop
+	cs.u32(0, 0, 0, 1, 0, 2, 0, 3, 2);  // blend mode (colour)
+	if (alpha) cs.u32(0, 0, 0, 1, 0, 2, 0, 3, 2);  // blend mode (extra channel)
+	cs.put(1, 1);                       // is_last
+	cs.u32(0, 0, 0, 0, 4, 16, 5, 48, 10);
+	cs.put(0, 1); cs.put(0, 1); cs.put(0, 2); cs.u64(0);   // restoration: explicit, gab off, epf 0, no extensions
+	cs.u64(0);                          // frame extensions
+	cs.put(0, 1);                       // TOC not permuted
+	cs.pad();
+	for (const auto &sct : sections) write_toc_entry(cs, sct.size());
+	cs.pad();
+	for (const auto &sct : sections) cs.append_bytes(sct);
+	std::vector<uint8_t> file = cs.bytes;
+	if (container) {
+		static const uint8_t HEAD[32] = {0, 0, 0, 0x0c, 'J', 'X', 'L', ' ', 0x0d, 0x0a, 0x87, 0x0a, 0, 0, 0, 0x14, 'f', 't', 'y', 'p', 'j', 'x', 'l', ' ', 0, 0, 0, 0, 'j', 'x', 'l', ' '};
+		file.assign(HEAD, HEAD + 32);
+		size_t total = 8 + cs.bytes.size();
+		uint8_t hd[8] = {(uint8_t) (total >> 24), (uint8_t) (total >> 16), (uint8_t) (total >> 8), (uint8_t) total, 'j', 'x', 'l', 'c'};
+		file.insert(file.end(), hd, hd + 8);
+		file.insert(file.end(), cs.bytes.begin(), cs.bytes.end());
+	}
+	if (!write_file(out, file)) die("cannot write output");
+	fprintf(stderr, "modular %dx%d: %zu bytes (%.3f bpp), %d groups%s\n", W, H, file.size(), 8.0 * (double) file.size() / ((double) W * H), num_groups, single ? " (single section)" : "");
+	return 0;
+}
+
 
 int main(int argc, char **argv) {
 	if (argc < 6) { fprintf(stderr, "usage: %s vardct|modular W H SEED OUT [key=value ...]\n", argv[0]); return 1; }
