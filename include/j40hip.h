@@ -53,6 +53,75 @@ J40HIP_API int32_t j40hip_frame_block_ctx_map(const j40hip_frame *f, uint8_t *ou
 /* Modular planes decoded on the host inside LfGlobal (j40.h:6334-6336): returns 0 and fills w*h int16 */
 J40HIP_API int j40hip_frame_global_plane(const j40hip_frame *f, int c, int16_t *out, int32_t *w, int32_t *h);
 
+/* ---- plan views: what crosses the seam, as plain C arrays (mirrors of j40__frame_st, j40.h:5061-5122,
+ *      j40__lf_group_st, j40.h:6360-6390, j40__code_spec, j40.h:2486-2495, j40__modular, j40.h:3553-3564).
+ *      Pointers stay valid until j40hip_frame_free. Used by the CPU oracle (oracle/hotpath_oracle.c) so
+ *      that it can be driven behind exactly the same boundary as the HIP kernels. ---- */
+
+typedef struct {
+	int32_t split_exp, msb_in_token, lsb_in_token;   /* hybrid integer config (j40.h:2283) */
+	const int16_t *D;              /* ANS: distribution, 1 << log_alpha_size entries summing to 4096 */
+	const uint8_t *lengths;        /* prefix code: code length per symbol */
+	int32_t alphabet_size;         /* prefix code: number of symbols */
+} j40hip_cluster_view;
+
+typedef struct {
+	int32_t num_dist, num_clusters;
+	int32_t lz77_enabled, use_prefix_code, min_symbol, min_length, log_alpha_size;
+	int32_t lz_len_split_exp, lz_len_msb, lz_len_lsb;
+	const uint8_t *cluster_map;    /* [num_dist] */
+	const j40hip_cluster_view *clusters;
+} j40hip_codespec_view;
+
+typedef struct {
+	int32_t left, top, width, height, width8, height8, width64, height64, nb_varblocks;
+	const int32_t *blocks;         /* [height8 * width8], (DctSelect + 2) << 20 | varblock or 1 << 20 | varblock */
+	const uint8_t *lfindices;      /* [height8 * width8] */
+	const float *llfcoeffs[3];     /* [height8 * width8] */
+	const int32_t *coeffoff_qfidx; /* [nb_varblocks] */
+	const float *hfmul_inv;        /* [nb_varblocks] */
+	const int16_t *xfromy, *bfromy;/* [height64 * width64] */
+} j40hip_lf_group_view;
+
+typedef struct { uint32_t byte_off, size, bit_off; int32_t ggidx, gx_in_gg, gy_in_gg, gw, gh; } j40hip_section_view;
+
+typedef struct {
+	int32_t width, height, num_passes, num_groups, num_lf_groups;
+	int32_t nb_block_ctx, nb_qf_thr, nb_lf_thr[3], num_hf_presets, bpp;
+	int32_t global_scale, x_qm_scale, b_qm_scale, x_factor_lf, b_factor_lf;
+	float quant_bias[3], quant_bias_num, base_corr_x, base_corr_b, inv_colour_factor;
+	float opsin_inv_mat[9], opsin_bias[3], intensity_target;
+	const uint8_t *codestream; size_t codestream_size;
+	const uint8_t *block_ctx_map; int32_t block_ctx_size;
+	const j40hip_codespec_view *coeff_specs;     /* [num_passes] */
+	const int32_t *orders[11 * 13 * 3];           /* [pass][order][channel] -> coefficient order or NULL */
+	const float *dq_matrix[17]; int32_t dq_size[17];  /* [size][3] dequantisation weights or NULL */
+	const j40hip_lf_group_view *lf_groups;       /* [num_lf_groups] */
+	const j40hip_section_view *sections;         /* [num_passes * num_groups] */
+} j40hip_vardct_view;
+
+typedef struct { int32_t prop, value, a, b; } j40hip_tree_node;   /* see j40_amd/csrc/modular.hpp */
+typedef struct { int32_t kind, begin_c, rct_type, num_c, nb_colours, nb_deltas, d_pred; } j40hip_transform_view;
+typedef struct {
+	uint32_t byte_off, size, bit_off; int32_t gx, gy, gw, gh, sidx, first_channel, num_channels;
+	int8_t wp[12];                 /* weighted predictor parameters p1, p2, p3[5], w[4] */
+} j40hip_modular_section_view;
+
+typedef struct {
+	int32_t width, height, bpp, num_channels, num_sections, num_transforms, num_tree_nodes, alpha_channel;
+	const uint8_t *codestream; size_t codestream_size;
+	const j40hip_codespec_view *codespec;
+	const j40hip_tree_node *tree;
+	const int32_t *channel_w, *channel_h, *channel_meta;   /* coded channels */
+	const j40hip_transform_view *transforms;
+	const j40hip_modular_section_view *sections;
+	int8_t global_wp[12];
+} j40hip_modular_view;
+
+/* fill the views for a parsed frame; return 0 or a 4-char code ("TODO" for frames the hot path does not cover) */
+J40HIP_API uint32_t j40hip_frame_vardct_view(j40hip_frame *f, j40hip_vardct_view *out);
+J40HIP_API uint32_t j40hip_frame_modular_view(j40hip_frame *f, j40hip_modular_view *out);
+
 /* host table builders exposed for known-answer tests against the reference's internals */
 J40HIP_API int32_t j40hip_kat_natural_order(int32_t log_rows, int32_t log_columns, int32_t *out);          /* j40.h:4980 */
 J40HIP_API int32_t j40hip_kat_library_dq_matrix(int idx, float *out_n_by_3);                              /* j40.h:4828 */

@@ -2,6 +2,7 @@
 #pragma once
 #include "../../include/j40hip.h"
 #include "frame.hpp"
+#include "plan_build.hpp"
 
 struct j40hip_device_state;  // defined in device/runtime.hip
 
@@ -11,6 +12,20 @@ struct j40hip_frame {
 	std::vector<uint8_t> cs_storage;
 	j40hip::Frame frame;
 	j40hip_device_state *dev = nullptr;
+	// backing storage of the plan views (include/j40hip.h)
+	struct Views {
+		std::vector<std::vector<j40hip_cluster_view>> clusters;
+		std::vector<j40hip_codespec_view> specs;
+		std::vector<j40hip_lf_group_view> lf_groups;
+		std::vector<j40hip_section_view> sections;
+		std::vector<std::vector<float>> dq;
+		std::vector<j40hip_tree_node> tree;
+		std::vector<int32_t> ch_w, ch_h, ch_meta;
+		std::vector<j40hip_transform_view> transforms;
+		std::vector<j40hip_modular_section_view> mod_sections;
+		std::vector<std::vector<int32_t>> vb_coeffoff_qfidx;
+		std::vector<std::vector<float>> vb_hfmul_inv;
+	} views;
 };
 
 // implemented next to the kernels; a no-op when nothing was uploaded

@@ -93,6 +93,103 @@ int j40hip_frame_global_plane(const j40hip_frame *h, int c, int16_t *out, int32_
 	return 0;
 }
 
+static void fill_codespec_view(j40hip_frame *h, const CodeSpec &spec, j40hip_codespec_view *v) {
+	h->views.clusters.emplace_back();
+	std::vector<j40hip_cluster_view> &cl = h->views.clusters.back();
+	for (const Cluster &c : spec.clusters) {
+		j40hip_cluster_view cv;
+		cv.split_exp = c.cfg.split_exp; cv.msb_in_token = c.cfg.msb_in_token; cv.lsb_in_token = c.cfg.lsb_in_token;
+		cv.D = c.D.empty() ? nullptr : c.D.data(); cv.lengths = c.lengths.empty() ? nullptr : c.lengths.data(); cv.alphabet_size = (int32_t) c.lengths.size();
+		cl.push_back(cv);
+	}
+	v->num_dist = spec.num_dist; v->num_clusters = spec.num_clusters; v->lz77_enabled = spec.lz77_enabled; v->use_prefix_code = spec.use_prefix_code;
+	v->min_symbol = spec.min_symbol; v->min_length = spec.min_length; v->log_alpha_size = spec.log_alpha_size;
+	v->lz_len_split_exp = spec.lz_len_cfg.split_exp; v->lz_len_msb = spec.lz_len_cfg.msb_in_token; v->lz_len_lsb = spec.lz_len_cfg.lsb_in_token;
+	v->cluster_map = spec.cluster_map.data(); v->clusters = cl.data();
+}
+
+uint32_t j40hip_frame_vardct_view(j40hip_frame *h, j40hip_vardct_view *v) {
+	const Frame &f = h->frame;
+	if (f.fh.is_modular || !f.im.ec.empty() || f.im.grey || !f.im.xyb_encoded || f.fh.do_ycbcr || f.im.bpp < 8 || f.im.exp_bits) return E4("TODO");
+	memset(v, 0, sizeof *v);
+	h->views = j40hip_frame::Views();
+	h->views.clusters.reserve(16);
+	v->width = f.fh.width; v->height = f.fh.height; v->num_passes = f.fh.num_passes; v->num_groups = (int32_t) f.fh.num_groups; v->num_lf_groups = (int32_t) f.fh.num_lf_groups;
+	v->nb_block_ctx = f.nb_block_ctx; v->nb_qf_thr = f.nb_qf_thr; for (int i = 0; i < 3; ++i) v->nb_lf_thr[i] = f.nb_lf_thr[i];
+	v->num_hf_presets = f.num_hf_presets; v->bpp = f.im.bpp;
+	v->global_scale = f.global_scale; v->x_qm_scale = f.fh.x_qm_scale; v->b_qm_scale = f.fh.b_qm_scale; v->x_factor_lf = f.x_factor_lf; v->b_factor_lf = f.b_factor_lf;
+	for (int i = 0; i < 3; ++i) { v->quant_bias[i] = f.im.quant_bias[i]; v->opsin_bias[i] = f.im.opsin_bias[i]; for (int j = 0; j < 3; ++j) v->opsin_inv_mat[i * 3 + j] = f.im.opsin_inv_mat[i][j]; }
+	v->quant_bias_num = f.im.quant_bias_num; v->base_corr_x = f.base_corr_x; v->base_corr_b = f.base_corr_b; v->inv_colour_factor = f.inv_colour_factor;
+	v->intensity_target = f.im.intensity_target;
+	v->codestream = h->cs; v->codestream_size = h->cs_size;
+	v->block_ctx_map = f.block_ctx_map.data(); v->block_ctx_size = (int32_t) f.block_ctx_map.size();
+	h->views.specs.assign((size_t) f.fh.num_passes, j40hip_codespec_view());
+	for (int32_t p = 0; p < f.fh.num_passes; ++p) fill_codespec_view(h, f.coeff_codespec[p], &h->views.specs[(size_t) p]);
+	v->coeff_specs = h->views.specs.data();
+	for (int32_t p = 0; p < f.fh.num_passes; ++p) for (int o = 0; o < 13; ++o) for (int c = 0; c < 3; ++c)
+		v->orders[(p * 13 + o) * 3 + c] = f.orders[p][o][c].empty() ? nullptr : f.orders[p][o][c].data();
+	h->views.dq.assign(17, {});
+	for (int i = 0; i < 17; ++i) if (f.dq_matrix[i].loaded) {
+		for (const auto &w : f.dq_matrix[i].params) for (int c = 0; c < 3; ++c) h->views.dq[(size_t) i].push_back(w[(size_t) c]);
+		v->dq_matrix[i] = h->views.dq[(size_t) i].data(); v->dq_size[i] = (int32_t) f.dq_matrix[i].params.size();
+	}
+	for (const LfGroup &g : f.lf_groups) {
+		j40hip_lf_group_view gv;
+		gv.left = g.left; gv.top = g.top; gv.width = g.width; gv.height = g.height; gv.width8 = g.width8; gv.height8 = g.height8; gv.width64 = g.width64; gv.height64 = g.height64;
+		gv.nb_varblocks = (int32_t) g.varblocks.size(); gv.blocks = g.blocks.data(); gv.lfindices = g.lfindices.data();
+		for (int c = 0; c < 3; ++c) gv.llfcoeffs[c] = g.llfcoeffs[c].data();
+		gv.coeffoff_qfidx = nullptr; gv.hfmul_inv = nullptr; gv.xfromy = g.xfromy.data(); gv.bfromy = g.bfromy.data();
+		h->views.lf_groups.push_back(gv);
+	}
+	h->views.vb_coeffoff_qfidx.assign(f.lf_groups.size(), {}); h->views.vb_hfmul_inv.assign(f.lf_groups.size(), {});
+	for (size_t g = 0; g < f.lf_groups.size(); ++g) {
+		for (const VarblockInfo &vb : f.lf_groups[g].varblocks) { h->views.vb_coeffoff_qfidx[g].push_back(vb.coeffoff_qfidx); h->views.vb_hfmul_inv[g].push_back(vb.hfmul_inv); }
+		h->views.lf_groups[g].coeffoff_qfidx = h->views.vb_coeffoff_qfidx[g].data(); h->views.lf_groups[g].hfmul_inv = h->views.vb_hfmul_inv[g].data();
+	}
+	v->lf_groups = h->views.lf_groups.data();
+	const int32_t ng = (int32_t) f.fh.num_groups;
+	for (int32_t p = 0; p < f.fh.num_passes; ++p) for (int32_t g = 0; g < ng; ++g) {
+		const GroupInfo gi = group_info(f.fh, g);
+		j40hip_section_view s;
+		if (f.toc.single) { s.byte_off = (uint32_t) f.toc.single_section.offset; s.size = (uint32_t) f.toc.single_section.size; s.bit_off = (uint32_t) f.single_pass_group_bitpos; }
+		else { const Section &sec = f.toc.pass_groups[(size_t) p * (size_t) ng + (size_t) g]; s.byte_off = (uint32_t) sec.offset; s.size = (uint32_t) sec.size; s.bit_off = 0; }
+		s.ggidx = gi.ggidx; s.gx_in_gg = gi.gx_in_gg; s.gy_in_gg = gi.gy_in_gg; s.gw = gi.gw; s.gh = gi.gh;
+		h->views.sections.push_back(s);
+	}
+	v->sections = h->views.sections.data();
+	return 0;
+}
+
+uint32_t j40hip_frame_modular_view(j40hip_frame *h, j40hip_modular_view *v) {
+	HostModPlan hp;
+	if (uint32_t e = build_modular_plan(h->frame, h->cs, h->cs_size, &hp)) return e;
+	const Frame &f = h->frame;
+	memset(v, 0, sizeof *v);
+	h->views = j40hip_frame::Views();
+	h->views.clusters.reserve(4);
+	v->width = f.fh.width; v->height = f.fh.height; v->bpp = f.im.bpp; v->num_channels = hp.frame.num_channels; v->num_sections = hp.frame.num_sections;
+	v->alpha_channel = hp.alpha_channel;
+	v->codestream = h->cs; v->codestream_size = h->cs_size;
+	h->views.specs.assign(1, j40hip_codespec_view());
+	fill_codespec_view(h, f.global_codespec, &h->views.specs[0]);
+	v->codespec = h->views.specs.data();
+	for (const TreeNode &n : f.global_tree) h->views.tree.push_back(j40hip_tree_node{n.prop, n.value, n.a, n.b});
+	v->tree = h->views.tree.data(); v->num_tree_nodes = (int32_t) h->views.tree.size();
+	h->views.ch_w = hp.plane_w; h->views.ch_h = hp.plane_h; h->views.ch_meta = hp.plane_meta;
+	v->channel_w = h->views.ch_w.data(); v->channel_h = h->views.ch_h.data(); v->channel_meta = h->views.ch_meta.data();
+	for (const Transform &t : hp.transforms) h->views.transforms.push_back(j40hip_transform_view{(int32_t) t.kind, t.begin_c, t.rct_type, t.num_c, t.nb_colours, t.nb_deltas, t.d_pred});
+	v->transforms = h->views.transforms.data(); v->num_transforms = (int32_t) h->views.transforms.size();
+	for (const DevModSection &s : hp.sections) {
+		j40hip_modular_section_view sv;
+		sv.byte_off = s.byte_off; sv.size = s.size; sv.bit_off = s.bit_off; sv.gx = s.gx; sv.gy = s.gy; sv.gw = s.gw; sv.gh = s.gh; sv.sidx = s.sidx;
+		sv.first_channel = s.first_channel; sv.num_channels = s.num_channels; memcpy(sv.wp, s.wp, 12);
+		h->views.mod_sections.push_back(sv);
+	}
+	v->sections = h->views.mod_sections.data();
+	{ const WPParams &wp = f.gmodular.wp; v->global_wp[0] = wp.p1; v->global_wp[1] = wp.p2; for (int i = 0; i < 5; ++i) v->global_wp[2 + i] = wp.p3[i]; for (int i = 0; i < 4; ++i) v->global_wp[7 + i] = wp.w[i]; v->global_wp[11] = 0; }
+	return 0;
+}
+
 int32_t j40hip_kat_natural_order(int32_t log_rows, int32_t log_columns, int32_t *out) {
 	std::vector<int32_t> o;
 	natural_order(log_rows, log_columns, &o);

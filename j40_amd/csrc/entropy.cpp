@@ -106,10 +106,11 @@ static void build_prefix_table(const std::vector<int32_t> &lengths, Cluster *out
 		for (size_t j = i; j < ovf.size(); ++j) if (!done[j] && ovf[j].prefix == ovf[i].prefix) { table[(size_t) pos++] = ovf[j].entry; done[j] = true; }
 	}
 	out->fast_len = fast_len; out->max_len = max_len; out->table.swap(table);
+	out->lengths.assign(lengths.begin(), lengths.end());
 }
 
 static void read_prefix_tree(BitReader &br, int32_t alphabet, Cluster *out) {  // j40.h:2049
-	if (alphabet == 1) { out->fast_len = out->max_len = 0; out->table.assign(1, 0); return; }
+	if (alphabet == 1) { out->fast_len = out->max_len = 0; out->table.assign(1, 0); out->lengths.assign(1, 0); return; }
 	int32_t hskip = (int32_t) br.u(2);
 	if (hskip == 1) {  // simple code, RFC 7932 section 3.4
 		int32_t nsym = (int32_t) br.u(2) + 1, syms[4] = {0, 0, 0, 0};
@@ -120,7 +121,7 @@ static void read_prefix_tree(BitReader &br, int32_t alphabet, Cluster *out) {  /
 		std::vector<int32_t> lengths((size_t) alphabet, 0);
 		bool tree_select = nsym == 4 && br.u(1);
 		switch (nsym) {
-		case 1: out->fast_len = out->max_len = 0; out->table.assign(1, syms[0] << 16); return;
+		case 1: out->fast_len = out->max_len = 0; out->table.assign(1, syms[0] << 16); out->lengths.assign((size_t) alphabet, 0); out->lengths[(size_t) syms[0]] = 255; return;  // 255: the only symbol, zero bits
 		case 2: lengths[(size_t) syms[0]] = lengths[(size_t) syms[1]] = 1; break;
 		case 3: lengths[(size_t) syms[0]] = 1; lengths[(size_t) syms[1]] = lengths[(size_t) syms[2]] = 2; break;
 		default:

@@ -34,6 +34,7 @@ struct Cluster {
 	// entry = symbol << 16 | (code >> fast_len) << 4 | (len - fast_len); negative = -overflow index
 	int32_t fast_len = 0, max_len = 0;
 	std::vector<int32_t> table;
+	std::vector<uint8_t> lengths;   // per symbol, kept for the plan view (oracle builds its own decoder from them)
 };
 
 struct CodeSpec {

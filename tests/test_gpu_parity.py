@@ -96,6 +96,27 @@ def test_modular_corruption_is_reported(gpu, ref):
     assert rejected >= 1
 
 
+def test_hip_path_against_cpu_oracle(gpu):
+    """HIP kernels vs the plain-C restatement (oracle/hotpath_oracle.c), both behind the same plan seam"""
+    import ctypes as C
+    D = C.CDLL(os.path.join(ROOT, "build", "liboracle_driver.so"))
+    D.oracle_run.restype = C.c_uint32
+    D.oracle_run.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    cases = [("vardct", 776, 520, dict(maxlog=8, bctx=1, presets=2, orders=1)), ("vardct", 520, 264, dict(passes=2)),
+             ("modular", 600, 300, dict(tree=2)), ("modular", 256, 256, dict(alpha=1, prefix=1, lz77=1)), ("modular", 600, 300, dict(palette=2, alpha=1))]
+    for mode, w, h, opts in cases:
+        data = synth(mode, w, h, 91, **opts)
+        expect = np.zeros((h, w, 4), np.uint8)
+        buf = C.create_string_buffer(data, len(data))
+        assert D.oracle_run(buf, len(data), expect.ctypes.data, None) == 0
+        err, rgba = gpu.decode(data)
+        assert err == ""
+        if mode == "modular":
+            assert np.array_equal(rgba, expect)
+        else:
+            assert compare(rgba, expect)[0] <= 1
+
+
 def test_golden_fixtures(gpu):
     manifest = json.load(open(os.path.join(GOLDEN, "manifest.json")))
     for name, e in sorted(manifest.items()):
