@@ -164,6 +164,24 @@ J40HIP_API uint32_t j40hip_frame_read_plane_i16(j40hip_frame *f, int c, int16_t 
  * the launch stream: ms[0] = entropy decode, ms[1] = coefficients -> pixels, ms[2] = other */
 J40HIP_API uint32_t j40hip_frame_decode_timed(j40hip_frame *f, void *rgba_dev, size_t stride_bytes, void *stream, float *ms3);
 
+/* known-answer hook for the renderer's per-sample tail on the device: linear sample -> sRGB transfer -> u8
+ * (j40.h:7213-7240, 7925-7935); host arrays in and out */
+J40HIP_API uint32_t j40hip_kat_device_srgb_u8(const float *v_host, size_t n, uint8_t *out_host);
+
+/* ---- batches: throughput mode ----
+ * A batch is a set of uploaded VarDCT frames decoded together: ONE entropy launch with one pass-group
+ * section per wavefront LANE (64 sections per wavefront, every frame's sections side by side), then the
+ * coefficients -> pixels kernels. Frames stay owned by the caller and must outlive the batch; the same
+ * frame may also be decoded alone (latency mode: one section per wavefront, scalarised) with
+ * j40hip_frame_decode. rgba_dev[i] / stride_bytes[i] belong to frames[i]. Per-frame result:
+ * j40hip_frame_status(frames[i]) after the stream has been synchronised. */
+typedef struct j40hip_batch j40hip_batch;
+J40HIP_API j40hip_batch *j40hip_batch_create(j40hip_frame *const *frames, int64_t n, uint32_t *err);
+J40HIP_API void j40hip_batch_free(j40hip_batch *b);
+J40HIP_API uint32_t j40hip_batch_decode(j40hip_batch *b, void *const *rgba_dev, const size_t *stride_bytes, void *stream);
+/* ms3 as j40hip_frame_decode_timed, for the whole batch */
+J40HIP_API uint32_t j40hip_batch_decode_timed(j40hip_batch *b, void *const *rgba_dev, const size_t *stride_bytes, void *stream, float *ms3);
+
 #ifdef __cplusplus
 }
 #endif

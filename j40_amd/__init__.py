@@ -56,6 +56,13 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError("libj40hip.so is missing at %s: run `make lib` (or __graft_entry__.build())" % LIB_PATH)
+    # PyTorch wheels bundle their own libamdhip64; a process that loads both that copy and /opt/rocm's ends up with
+    # two HIP runtimes of which only the first sees the GPU. Let torch (the plumbing for device buffers, streams and
+    # torch.distributed) load first when it is installed, so that libj40hip.so binds to the runtime already there.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u32, i32, i64, sz = C.c_void_p, C.c_uint32, C.c_int32, C.c_int64, C.c_size_t
     sigs = {
@@ -78,6 +85,9 @@ def lib():
         "j40hip_frame_status": (u32, [vp]), "j40hip_frame_decode_to_host": (u32, [vp, vp, sz]),
         "j40hip_frame_read_coeffs": (u32, [vp, i64, C.c_int, vp]), "j40hip_frame_read_plane_i16": (u32, [vp, C.c_int, vp]),
         "j40hip_frame_decode_timed": (u32, [vp, vp, sz, vp, vp]),
+        "j40hip_kat_device_srgb_u8": (u32, [vp, sz, vp]),
+        "j40hip_batch_create": (vp, [vp, i64, C.POINTER(u32)]), "j40hip_batch_free": (None, [vp]),
+        "j40hip_batch_decode": (u32, [vp, vp, vp, vp]), "j40hip_batch_decode_timed": (u32, [vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)  # AttributeError = the library does not export what include/*.h declares
@@ -265,3 +275,47 @@ class Frame:
         a = np.zeros(gi["height8"] * gi["width8"] * 64, np.float32)
         self._chk(lib().j40hip_frame_read_coeffs(self.h, gg, c, a.ctypes.data), "in j40hip_frame_read_coeffs")
         return a
+
+
+class Batch:
+    """throughput mode (include/j40hip.h, j40hip_batch_*): uploaded VarDCT frames decoded by one entropy
+    launch with one pass-group section per wavefront lane"""
+
+    def __init__(self, frames):
+        L = lib()
+        self.frames = list(frames)
+        arr = (C.c_void_p * len(self.frames))(*[f.h for f in self.frames])
+        err = C.c_uint32()
+        self.h = L.j40hip_batch_create(arr, len(self.frames), C.byref(err))
+        if not self.h:
+            raise J40Error(err4(err.value), "in j40hip_batch_create")
+
+    def close(self):
+        if self.h:
+            lib().j40hip_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _args(self, rgba_ptrs, strides):
+        n = len(self.frames)
+        return (C.c_void_p * n)(*rgba_ptrs), (C.c_size_t * n)(*strides)
+
+    def decode(self, rgba_ptrs, strides, stream=0):
+        p, s = self._args(rgba_ptrs, strides)
+        code = lib().j40hip_batch_decode(self.h, p, s, stream)
+        if code:
+            raise J40Error(err4(code), "in j40hip_batch_decode")
+
+    def decode_timed(self, rgba_ptrs, strides, stream=0):
+        """returns (entropy ms, pixels ms, clear ms) measured with HIP events on `stream`"""
+        p, s = self._args(rgba_ptrs, strides)
+        ms = (C.c_float * 3)()
+        code = lib().j40hip_batch_decode_timed(self.h, p, s, stream, ms)
+        if code:
+            raise J40Error(err4(code), "in j40hip_batch_decode_timed")
+        return ms[0], ms[1], ms[2]

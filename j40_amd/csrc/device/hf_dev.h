@@ -114,9 +114,90 @@ J40_DEV uint32_t decode_hf_section(const DevPlan &plan, const DevFrame &f, const
 	return b.err;
 }
 
+// The same section decode as a flat state machine: ONE symbol-decode site per iteration, fed either
+// with the context of a block's non-zero count or of its next coefficient. This is the form the
+// throughput-oriented kernel runs with one section per LANE: the 64 lanes of a wavefront sit in
+// different blocks and channels, but every iteration all of them decode one symbol together, so the
+// expensive part (rANS / prefix step, hybrid integer, bit refill) never diverges; only the short
+// per-phase prologue and epilogue run under partial exec masks. Same results as decode_hf_section.
+template <bool SCAN>
+J40_DEV uint32_t decode_hf_section_flat(const DevPlan &plan, const DevFrame &f, const DevCodeSpec &spec, const HfTables &t, int32_t pass, const DevSection &sec) {
+	const DevLfGroup &gg = plan.lf_groups[sec.ggidx];
+	DevBits b;
+	bits_init<false>(b, plan.codestream, sec.byte_off, sec.size, sec.bit_off);
+	const uint32_t preset = bits_u<false>(b, f.preset_bits);
+	if ((int32_t) preset >= f.num_hf_presets) bits_set_error(b, ERR_RNGE);
+	const int32_t ctxoff = 495 * f.nb_block_ctx * (int32_t) preset;
+	DevCode code;
+	code_init(code, spec, t.clusters, t.cluster_map, t.alias, t.prefix, t.window);
+	const int32_t gw8 = sec.gw8;
+	const int32_t nb_block_ctx = f.nb_block_ctx, nb_qf1 = f.nb_qf_thr + 1, lfidx_size = f.lfidx_size;
+	const int32_t bctxc = 13 * nb_qf1 * lfidx_size;
+	const size_t cell64 = (size_t) gg.cell_base * 64;
+	// iterator over (block, channel) and the coefficient loop state of the current one
+	int32_t k = 0, c_yxb = 0;
+	bool in_coeffs = false, done = t.nblocks == 0 || b.err != 0;
+	int32_t x8 = 0, y8 = 0, nzpos = 0, log_rows = 3, log_columns = 3, order_idx = 0, shift = 0, size = 64, coeffoff = 0, bctx0 = 0;
+	int32_t c = 1, bctx = 0, nz = 0, i = 0, prev = 0, cctx = 0;
+	float *coeffs = nullptr;
+	const uint16_t *order = nullptr;
+	while (!done) {
+		int32_t ctx;
+		if (!in_coeffs) {  // next symbol: number of non-zeros of (block k, channel c_yxb), j40.h:6959-6967
+			if (c_yxb == 0) {
+				const uint32_t *p = (const uint32_t *) (t.blocks + k);
+				const uint32_t coeffoff_qfidx = p[0], w = p[1];
+				const int32_t dctsel = (int32_t) ((w >> 10) & 31), lfidx = (int32_t) ((w >> 16) & 255);
+				x8 = (int32_t) (w & 31); y8 = (int32_t) ((w >> 5) & 31); nzpos = y8 * gw8 + x8;
+				log_rows = DEV_DCT_SELECT[dctsel][0]; log_columns = DEV_DCT_SELECT[dctsel][1]; order_idx = DEV_DCT_SELECT[dctsel][2];
+				shift = log_rows + log_columns - 6; size = 64 << shift;
+				coeffoff = (int32_t) (coeffoff_qfidx & ~15u);
+				bctx0 = (order_idx * nb_qf1 + (int32_t) (coeffoff_qfidx & 15u)) * lfidx_size + lfidx;
+			}
+			c = c_yxb == 0 ? 1 : c_yxb == 1 ? 0 : 2;
+			bctx = t.block_ctx_map[bctx0 + bctxc * c_yxb];
+			int32_t pnz;
+			if (x8 > 0) pnz = y8 > 0 ? (t.nonzeros[(nzpos - 1) * 3 + c] + t.nonzeros[(nzpos - gw8) * 3 + c] + 1) >> 1 : t.nonzeros[(nzpos - 1) * 3 + c];
+			else pnz = y8 > 0 ? t.nonzeros[(nzpos - gw8) * 3 + c] : 32;
+			ctx = ctxoff + bctx + (pnz < 8 ? pnz : 4 + pnz / 2) * nb_block_ctx;
+		} else {
+			ctx = cctx + t.nnz_ctx2[(nz + (1 << shift) - 1) >> shift] + t.freq_ctx2[i >> shift] + prev;
+		}
+		const int32_t v = code_symbol<false>(b, code, ctx, 0, plan.lz_window_size);
+		if (!in_coeffs) {
+			nz = v;
+			if (nz > (63 << shift)) { bits_set_error(b, ERR_COEF); break; }
+			const int32_t qnz = (nz + (1 << shift) - 1) >> shift;
+			for (int32_t r = 0; r < (1 << (log_rows - 3)); ++r) for (int32_t q = 0; q < (1 << (log_columns - 3)); ++q)
+				t.nonzeros[(nzpos + r * gw8 + q) * 3 + c] = (int8_t) qnz;
+			cctx = ctxoff + 458 * bctx + 37 * nb_block_ctx;
+			prev = nz <= (size >> 4);
+			i = 1 << shift;
+			coeffs = (c == 0 ? plan.coeffs[0] : c == 1 ? plan.coeffs[1] : plan.coeffs[2]) + cell64 + coeffoff;
+			if (!SCAN) order = plan.pool_u16 + f.order_off[(pass * 13 + order_idx) * 3 + c];
+			in_coeffs = nz > 0;
+		} else {
+			if (v) {
+				const float fv = (float) unpack_signed_dev(v);
+				if (SCAN) coeffs[i] = fv; else coeffs[order[i]] += fv;
+			}
+			prev = v != 0;
+			nz -= prev;
+			++i;
+			if (nz == 0) in_coeffs = false;
+			else if (i >= size) bits_set_error(b, ERR_COEF);   // ran out of coefficients with non-zeros left (j40.h:6996)
+		}
+		if (b.err) break;
+		if (!in_coeffs && ++c_yxb == 3) { c_yxb = 0; done = ++k >= t.nblocks; }
+	}
+	if (!b.err) code_finish<false>(b, code);
+	if (!b.err) bits_finish_section(b);
+	return b.err;
+}
+
 // whole group, all passes, every table read straight from HBM (used by tests/hostsim and as the
 // kernel's fallback when a frame's tables do not fit the LDS budget)
-J40_DEV void decode_hf_group(const DevPlan &plan, int32_t g) {
+J40_DEV void decode_hf_group(const DevPlan &plan, int32_t g, bool flat = false) {
 	const DevFrame &f = *plan.frame;
 	HfTables t;
 	t.block_ctx_map = plan.pool_u8 + plan.block_ctx_map_off;
@@ -130,7 +211,10 @@ J40_DEV void decode_hf_group(const DevPlan &plan, int32_t g) {
 		t.clusters = plan.clusters + spec.cluster_off; t.cluster_map = plan.pool_u8 + spec.cluster_map_off;
 		t.alias = plan.pool_u64; t.prefix = plan.pool_i32;
 		const DevSection &sec = plan.sections[pass * f.num_groups + g];
-		plan.status[pass * f.num_groups + g] = f.scan_order_coeffs ? decode_hf_section<true, false>(plan, f, spec, t, pass, sec) : decode_hf_section<false, false>(plan, f, spec, t, pass, sec);
+		uint32_t err;
+		if (flat) err = f.scan_order_coeffs ? decode_hf_section_flat<true>(plan, f, spec, t, pass, sec) : decode_hf_section_flat<false>(plan, f, spec, t, pass, sec);
+		else err = f.scan_order_coeffs ? decode_hf_section<true, false>(plan, f, spec, t, pass, sec) : decode_hf_section<false, false>(plan, f, spec, t, pass, sec);
+		plan.status[pass * f.num_groups + g] = err;
 	}
 }
 

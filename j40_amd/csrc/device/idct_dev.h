@@ -212,12 +212,42 @@ J40_DEV int32_t f32_to_i16_x86(float t) {
 	return (int32_t) (int16_t) (uint16_t) (uint32_t) i;
 }
 
+// x^(1.0f / 2.4f) rounded to float, for x > 0. The reference calls powf(v, 1.0f / 2.4f) (j40.h:7217); a
+// correctly rounded powf is what glibc delivers up to a few results per 10^7, and the u8 output only
+// changes when 255 * (1.055 p - 0.055) + 0.5 sits within that rounding of an integer. A general fp64
+// pow() costs ~250 double-rate instructions per sample and made the pixel kernels compute bound, so:
+//   12 * (1.0f / 2.4f) = 5 - 2^-23 exactly, hence r = x^(1/2.4f) solves r^12 = x^5 * x^(-2^-23).
+//   Seed r0 from the hardware log2/exp2 (relative error ~1e-6), then one correction step in fp64:
+//   E = x^5 * (1 + d) / r0^12 - 1 with d = expm1(-2^-23 ln x), r = r0 * (1 + E)^(1/12) (3rd-order series).
+// Relative error ~1e-14 before the final rounding (tests/hostsim sweeps every float in [2^-9, 4) and samples
+// of the rest against (float) pow((double) x, (double) (1.0f / 2.4f)): identical).
+J40_DEV float pow_1_over_2p4(float xf) {
+#ifdef __HIPCC__
+	const float l2 = __builtin_amdgcn_logf(xf);                       // v_log_f32 (log2)
+	const float r0f = __builtin_amdgcn_exp2f(l2 * 0.416666657f);      // v_exp_f32
+	const float rho0f = __builtin_amdgcn_rcpf(r0f);
+#else
+	const float l2 = log2f(xf);
+	const float r0f = exp2f(l2 * 0.416666657f);
+	const float rho0f = 1.0f / r0f;
+#endif
+	const double x = (double) xf, r0 = (double) r0f, rho0 = (double) rho0f;
+	const double x2 = x * x, x4 = x2 * x2, x5 = x4 * x;
+	const double rho = rho0 * fma(-r0, rho0, 2.0);                    // 1 / r0 to ~1e-14
+	const double rho2 = rho * rho, rho4 = rho2 * rho2, rho8 = rho4 * rho4, rho12 = rho8 * rho4;
+	const double t = (double) l2 * -8.262958294867817e-08;           // -2^-23 * ln 2 * log2 x
+	const double d = fma(t * 0.5, t, t);
+	double q = x5 * rho12;
+	q = fma(q, d, q);
+	const double E = q - 1.0;
+	// (1 + E)^(1/12) = 1 + E/12 - 11 E^2/288 + 253 E^3/10368 - ...
+	const double poly = fma(fma(fma(253.0 / 10368.0, E, -11.0 / 288.0), E, 1.0 / 12.0), E, 1.0);
+	return (float) (r0 * poly);
+}
+
 J40_DEV float srgb_transfer(float v) {
 	if (v <= 0.0031308f) return 12.92f * v;
-	// the reference calls powf(v, 1.0f / 2.4f); evaluate in double and round once, which matches a
-	// correctly rounded powf (glibc's is, up to a few results per 10^7)
-	const float p = (float) pow((double) v, (double) (1.0f / 2.4f));
-	return 1.055f * p - 0.055f;
+	return 1.055f * pow_1_over_2p4(v) - 0.055f;
 }
 
 // returns RGBA packed little-endian (R in the low byte), alpha = 255

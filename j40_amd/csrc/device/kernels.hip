@@ -112,6 +112,90 @@ __global__ void __launch_bounds__(64 * HF_WAVES) k_hf_entropy(DevPlan plan, int3
 	}
 }
 
+// K1, throughput form: one section per LANE, 64 groups of one frame per wavefront, one wavefront per
+// workgroup, any number of frames per launch (`work` lists the (frame, first group, count) chunks).
+// The lanes run decode_hf_section_flat: every iteration all 64 decode one symbol together. Tables of
+// the chunk's frame are staged in LDS and read with per-lane addresses; block lists, the non-zero
+// scratch and the bitstreams stay in HBM/L2 (per-lane, touched once per block / once per 32 bits).
+// A lone wave is slower per section than the scalarised k_hf_entropy, but a batch fills every SIMD
+// with several such waves: with 288 GB of HBM the working sets of hundreds of frames are resident.
+template <bool TABLES_IN_LDS>
+__global__ void __launch_bounds__(64, 16) k_hf_entropy_lanes(const DevPlan *plans, const HfLaneWork *work) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t hf_lds[];
+	const HfLaneWork w = work[blockIdx.x];
+	const DevPlan plan = plans[w.frame];
+	const DevFrame &f = *plan.frame;
+	const int32_t lane = threadIdx.x;
+	const bool active = lane < w.num_groups;
+	const int32_t g = w.first_group + (active ? lane : 0);
+	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+	const uint32_t n_bctx = (uint32_t) (39 * f.lfidx_size * (f.nb_qf_thr + 1));
+	uint8_t *l_bctx = hf_lds;
+	int16_t *l_nnz = (int16_t *) (hf_lds + align16(n_bctx));
+	int8_t *l_freq = (int8_t *) (hf_lds + align16(n_bctx) + 128);
+	const uint32_t off_pass = align16(n_bctx) + 192;
+	{
+		const uint8_t *src = plan.pool_u8 + plan.block_ctx_map_off;
+		for (uint32_t i = lane; i < n_bctx; i += 64) l_bctx[i] = src[i];
+		l_nnz[lane] = DEV_NNZ_CTX2[lane]; l_freq[lane] = DEV_FREQ_CTX2[lane];
+	}
+	HfTables t;
+	t.block_ctx_map = l_bctx; t.nnz_ctx2 = l_nnz; t.freq_ctx2 = l_freq;
+	t.nonzeros = plan.nonzeros + (size_t) g * (32 * 32 * 3);
+	t.window = plan.lz_window ? plan.lz_window + (size_t) g * plan.lz_window_size : nullptr;
+	t.blocks = plan.group_blocks + plan.group_block_start[g];
+	t.nblocks = (int32_t) (plan.group_block_start[g + 1] - plan.group_block_start[g]);
+	for (int32_t pass = 0; pass < f.num_passes; ++pass) {
+		const DevCodeSpec &spec = plan.coeff_specs[pass];
+		if (TABLES_IN_LDS) {
+			__syncthreads();
+			uint8_t *l_map = hf_lds + off_pass;
+			DevCluster *l_clusters = (DevCluster *) (l_map + align16((uint32_t) spec.num_dist));
+			uint8_t *l_tables = (uint8_t *) l_clusters + align16((uint32_t) spec.num_clusters * (uint32_t) sizeof(DevCluster));
+			const uint8_t *msrc = plan.pool_u8 + spec.cluster_map_off;
+			for (int32_t i = lane; i < spec.num_dist; i += 64) l_map[i] = msrc[i];
+			const DevCluster *csrc = plan.clusters + spec.cluster_off;
+			const uint32_t base_off = csrc[0].table_off;
+			for (int32_t i = lane; i < spec.num_clusters; i += 64) { DevCluster c = csrc[i]; c.table_off -= base_off; l_clusters[i] = c; }
+			if (spec.use_prefix_code) {
+				const int32_t *src = plan.pool_i32 + base_off; int32_t *dst = (int32_t *) l_tables;
+				for (uint32_t i = lane; i < spec.table_span; i += 64) dst[i] = src[i];
+			} else {
+				const uint64_t *src = plan.pool_u64 + base_off; uint64_t *dst = (uint64_t *) l_tables;
+				for (uint32_t i = lane; i < spec.table_span; i += 64) dst[i] = src[i];
+			}
+			t.clusters = l_clusters; t.cluster_map = l_map; t.alias = (const uint64_t *) l_tables; t.prefix = (const int32_t *) l_tables;
+		} else {
+			t.clusters = plan.clusters + spec.cluster_off; t.cluster_map = plan.pool_u8 + spec.cluster_map_off;
+			t.alias = plan.pool_u64; t.prefix = plan.pool_i32;
+		}
+		__syncthreads();
+		if (active) {
+			const DevSection &sec = plan.sections[pass * f.num_groups + g];
+			plan.status[pass * f.num_groups + g] = f.scan_order_coeffs ? decode_hf_section_flat<true>(plan, f, spec, t, pass, sec) : decode_hf_section_flat<false>(plan, f, spec, t, pass, sec);
+		}
+	}
+}
+
+// LDS bytes k_hf_entropy_lanes needs for one frame
+uint32_t hf_lanes_lds_bytes(const HfLaunchInfo &info) {
+	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+	uint32_t n = align16(info.block_ctx_size) + 192;
+	if (info.tables_fit_lds) n += align16(info.max_num_dist) + align16(info.max_clusters * (uint32_t) sizeof(DevCluster)) + align16(info.max_table_bytes);
+	return n;
+}
+
+void launch_hf_entropy_lanes(const DevPlan *plans, const HfLaneWork *work, int32_t num_work, bool tables_in_lds, uint32_t lds_bytes, hipStream_t stream) {
+	if (num_work <= 0) return;
+	if (tables_in_lds) {
+		static bool configured = false;
+		if (!configured) { (void) hipFuncSetAttribute((const void *) k_hf_entropy_lanes<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); configured = true; }
+		hipLaunchKernelGGL(k_hf_entropy_lanes<true>, dim3((unsigned) num_work), dim3(64), lds_bytes, stream, plans, work);
+	} else {
+		hipLaunchKernelGGL(k_hf_entropy_lanes<false>, dim3((unsigned) num_work), dim3(64), lds_bytes, stream, plans, work);
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2 common pieces
 
@@ -367,6 +451,27 @@ void launch_vardct_class(const DevPlan &plan, int32_t dctsel, const DevVarblock 
 	default:
 		hipLaunchKernelGGL(k_vardct_large, dim3((unsigned) count), dim3(256), 0, stream, plan, list, count, large_scratch, rgba, stride);
 		break;
+	}
+}
+
+// known-answer hook: the renderer's per-sample tail (sRGB transfer + conversion, j40.h:7213-7240 / 7925-7935)
+__global__ void k_kat_srgb_u8(const float *v, size_t n, uint8_t *out) {
+	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	int32_t px = f32_to_i16_x86(255.0f * srgb_transfer(v[i]) + 0.5f);
+	out[i] = (uint8_t) (px < 0 ? 0 : px > 255 ? 255 : px);
+}
+void launch_kat_srgb_u8(const float *v, size_t n, uint8_t *out, hipStream_t stream) {
+	hipLaunchKernelGGL(k_kat_srgb_u8, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, v, n, out);
+}
+
+// every class of one frame; the nine 8x8 special transforms (DctSelect 1-3 and 12-17, contiguous in the
+// sorted list) share two launches since k_vardct_special dispatches per varblock
+void launch_vardct_frame(const DevPlan &plan, const int32_t *class_start, const DevVarblock *sorted, float *large_scratch, uint8_t *rgba, size_t stride, hipStream_t stream) {
+	for (int d = 0; d < 27; ++d) {
+		if (d == 2 || d == 3 || (d >= 13 && d <= 17)) continue;
+		const int32_t a = class_start[d], b = d == 1 ? class_start[4] : d == 12 ? class_start[18] : class_start[d + 1];
+		launch_vardct_class(plan, d, sorted + a, b - a, large_scratch, rgba, stride, stream);
 	}
 }
 

@@ -158,6 +158,9 @@ struct DevModPlan {
 	uint32_t *status;                 // [num_sections]
 };
 
+// one wavefront of the throughput-oriented K1: up to 64 consecutive groups of one frame of the batch
+struct HfLaneWork { int32_t frame, first_group, num_groups, pad; };
+
 enum { HF_WAVES = 4 };  // groups (wavefronts) per K1 workgroup
 
 // what the host knows about the entropy tables' sizes, to lay out K1's LDS

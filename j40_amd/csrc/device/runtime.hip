@@ -275,10 +275,7 @@ static uint32_t decode_impl(j40hip_frame *h, void *rgba_dev, size_t stride_bytes
 	launch_hf_entropy(plan, st->hf, (int32_t) st->first_group, (int32_t) st->num_groups, s);
 	if (ms3) (void) hipEventRecord(st->ev[2], s);
 	if (whole) {
-		for (int d = 0; d < 27; ++d) {
-			const int32_t a = st->class_start[d], b = st->class_start[d + 1];
-			launch_vardct_class(plan, d, st->d_vb_sorted + a, b - a, st->d_large_scratch, (uint8_t *) rgba_dev, stride_bytes, s);
-		}
+		launch_vardct_frame(plan, st->class_start, st->d_vb_sorted, st->d_large_scratch, (uint8_t *) rgba_dev, stride_bytes, s);
 	} else {
 		// sharded decode: only varblocks of this rank's groups (lists are built on demand)
 		return ERR_TODO;
@@ -293,6 +290,98 @@ static uint32_t decode_impl(j40hip_frame *h, void *rgba_dev, size_t stride_bytes
 		ms3[0] = b; ms3[1] = c; ms3[2] = a;
 	}
 	return hipGetLastError() == hipSuccess ? 0 : ERR_GPU;
+}
+
+// ---- batches: throughput mode ----
+
+struct j40hip_batch {
+	int device = 0;
+	std::vector<j40hip_frame *> frames;
+	DevPlan *d_plans = nullptr;
+	HfLaneWork *d_work = nullptr;
+	int32_t num_work = 0;
+	bool tables_in_lds = true;
+	uint32_t lds_bytes = 0;
+	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+extern "C" void j40hip_batch_free(j40hip_batch *b) {
+	if (!b) return;
+	(void) hipSetDevice(b->device);
+	if (b->d_plans) (void) hipFree(b->d_plans);
+	if (b->d_work) (void) hipFree(b->d_work);
+	for (auto &e : b->ev) if (e) (void) hipEventDestroy(e);
+	delete b;
+}
+
+extern "C" j40hip_batch *j40hip_batch_create(j40hip_frame *const *frames, int64_t n, uint32_t *err) {
+	uint32_t dummy; if (!err) err = &dummy;
+	*err = 0;
+	if (n <= 0 || !frames) { *err = ERR_RNGE; return nullptr; }
+	j40hip_batch *b = new j40hip_batch();
+	std::vector<DevPlan> plans; std::vector<HfLaneWork> work;
+	for (int64_t i = 0; i < n; ++i) {
+		j40hip_frame *h = frames[i];
+		if (!h || !h->dev) { *err = ERR_GPU; delete b; return nullptr; }
+		if (h->dev->is_modular) { *err = ERR_TODO; delete b; return nullptr; }   // Modular frames: decode them one by one
+		if (i == 0) b->device = h->dev->device;
+		else if (h->dev->device != b->device) { *err = ERR_RNGE; delete b; return nullptr; }
+		b->frames.push_back(h);
+		plans.push_back(h->dev->plan);
+		b->tables_in_lds = b->tables_in_lds && h->dev->hf.tables_fit_lds;
+		const int32_t groups = h->frame.fh.num_groups;
+		// sections per wavefront: 64 fills the lanes; fewer lanes per wave buy more waves per SIMD (latency hiding)
+		// when the batch alone cannot fill the chip's wave slots
+		int32_t lanes = 64;
+		if (const char *e = getenv("J40HIP_LANES_PER_WAVE")) lanes = std::max(1, std::min(64, atoi(e)));
+		for (int32_t g = 0; g < groups; g += lanes) work.push_back({(int32_t) i, g, std::min(lanes, groups - g), 0});
+	}
+	for (j40hip_frame *h : b->frames) {
+		HfLaunchInfo info = h->dev->hf; info.tables_fit_lds = b->tables_in_lds;
+		b->lds_bytes = std::max(b->lds_bytes, hf_lanes_lds_bytes(info));
+	}
+	b->num_work = (int32_t) work.size();
+	bool ok = hipSetDevice(b->device) == hipSuccess;
+	ok = ok && hipMalloc((void **) &b->d_plans, sizeof(DevPlan) * plans.size()) == hipSuccess;
+	ok = ok && hipMalloc((void **) &b->d_work, sizeof(HfLaneWork) * work.size()) == hipSuccess;
+	ok = ok && hipMemcpy(b->d_plans, plans.data(), sizeof(DevPlan) * plans.size(), hipMemcpyHostToDevice) == hipSuccess;
+	ok = ok && hipMemcpy(b->d_work, work.data(), sizeof(HfLaneWork) * work.size(), hipMemcpyHostToDevice) == hipSuccess;
+	for (auto &e : b->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+	if (!ok) { *err = ERR_GPU; j40hip_batch_free(b); return nullptr; }
+	return b;
+}
+
+static uint32_t batch_decode_impl(j40hip_batch *b, void *const *rgba_dev, const size_t *stride_bytes, hipStream_t s, float *ms3) {
+	if (!b) return ERR_GPU;
+	if (hipSetDevice(b->device) != hipSuccess) return ERR_GPU;
+	if (ms3) (void) hipEventRecord(b->ev[0], s);
+	for (j40hip_frame *h : b->frames) {
+		j40hip_device_state *st = h->dev;
+		for (int c = 0; c < 3; ++c) if (hipMemsetAsync(st->plan.coeffs[c], 0, sizeof(float) * st->coeff_floats, s) != hipSuccess) return ERR_GPU;
+		if (hipMemsetAsync(st->plan.status, 0, sizeof(uint32_t) * (size_t) st->total_sections, s) != hipSuccess) return ERR_GPU;
+	}
+	if (ms3) (void) hipEventRecord(b->ev[1], s);
+	launch_hf_entropy_lanes(b->d_plans, b->d_work, b->num_work, b->tables_in_lds, b->lds_bytes, s);
+	if (ms3) (void) hipEventRecord(b->ev[2], s);
+	for (size_t i = 0; i < b->frames.size(); ++i) {
+		j40hip_device_state *st = b->frames[i]->dev;
+		launch_vardct_frame(st->plan, st->class_start, st->d_vb_sorted, st->d_large_scratch, (uint8_t *) rgba_dev[i], stride_bytes[i], s);
+	}
+	if (ms3) {
+		(void) hipEventRecord(b->ev[3], s);
+		if (hipEventSynchronize(b->ev[3]) != hipSuccess) return ERR_GPU;
+		float t0 = 0, t1 = 0, t2 = 0;
+		(void) hipEventElapsedTime(&t0, b->ev[0], b->ev[1]); (void) hipEventElapsedTime(&t1, b->ev[1], b->ev[2]); (void) hipEventElapsedTime(&t2, b->ev[2], b->ev[3]);
+		ms3[0] = t1; ms3[1] = t2; ms3[2] = t0;
+	}
+	return hipGetLastError() == hipSuccess ? 0 : ERR_GPU;
+}
+
+extern "C" uint32_t j40hip_batch_decode(j40hip_batch *b, void *const *rgba_dev, const size_t *stride_bytes, void *stream) {
+	return batch_decode_impl(b, rgba_dev, stride_bytes, (hipStream_t) stream, nullptr);
+}
+extern "C" uint32_t j40hip_batch_decode_timed(j40hip_batch *b, void *const *rgba_dev, const size_t *stride_bytes, void *stream, float *ms3) {
+	return batch_decode_impl(b, rgba_dev, stride_bytes, (hipStream_t) stream, ms3);
 }
 
 extern "C" uint32_t j40hip_frame_decode(j40hip_frame *h, void *rgba_dev, size_t stride_bytes, void *stream) {
@@ -357,4 +446,16 @@ extern "C" uint32_t j40hip_frame_read_plane_i16(j40hip_frame *h, int c, int16_t 
 	const size_t n = (size_t) st->final_w[(size_t) c] * (size_t) st->final_h[(size_t) c];
 	if (hipMemcpy(out, st->final_planes[(size_t) c], n * 2, hipMemcpyDeviceToHost) != hipSuccess) return ERR_GPU;
 	return 0;
+}
+
+extern "C" uint32_t j40hip_kat_device_srgb_u8(const float *v_host, size_t n, uint8_t *out_host) {
+	if (j40hip_device_count() <= 0) return ERR_GPU;
+	float *dv = nullptr; uint8_t *dout = nullptr;
+	bool ok = hipMalloc((void **) &dv, n * 4 + 16) == hipSuccess && hipMalloc((void **) &dout, n + 16) == hipSuccess;
+	ok = ok && hipMemcpy(dv, v_host, n * 4, hipMemcpyHostToDevice) == hipSuccess;
+	if (ok) launch_kat_srgb_u8(dv, n, dout, nullptr);
+	ok = ok && hipMemcpy(out_host, dout, n, hipMemcpyDeviceToHost) == hipSuccess;
+	if (dv) (void) hipFree(dv);
+	if (dout) (void) hipFree(dout);
+	return ok ? 0 : ERR_GPU;
 }

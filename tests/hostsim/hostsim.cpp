@@ -181,14 +181,14 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 	plan.nonzeros = nonzeros.data(); plan.status = status.data();
 	plan.lz_window = window.empty() ? nullptr : window.data(); plan.lz_window_size = hp.lz_window_size;
 
-	for (int32_t g = 0; g < hp.frame.num_groups; ++g) decode_hf_group(plan, g);
+	for (int32_t g = 0; g < hp.frame.num_groups; ++g) decode_hf_group(plan, g, (only_entropy & 2) != 0);  // bit 1: flat (per-lane) decoder
 	if (coeffs_out) for (int c = 0; c < 3; ++c) {
 		float *dst = coeffs_out + (size_t) c * hp.coeff_floats;
 		memcpy(dst, coeffs[c].data(), sizeof(float) * hp.coeff_floats);
 		for (size_t gg = 0; gg < fr.lf_groups.size(); ++gg) coeffs_scan_to_canonical(fr, gg, c, dst + (size_t) hp.lf_groups[gg].cell_base * 64);
 	}
 	for (uint32_t s : status) if (s) return s;
-	if (only_entropy) return 0;
+	if (only_entropy & 1) return 0;
 
 	const float *hs = half_secants(), *afv = afv_basis();
 	const DevFrame &f = hp.frame;
@@ -227,4 +227,33 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 		}
 	}
 	return 0;
+}
+
+// sweeps float bit patterns [first, last] with stride `step` through pow_1_over_2p4 and counts results that
+// differ from (float) pow((double) x, (double) (1.0f / 2.4f)); *worst receives one offending input
+extern "C" __attribute__((visibility("default"))) uint64_t hostsim_pow_sweep(uint32_t first, uint32_t last, uint32_t step, float *worst) {
+	uint64_t bad = 0;
+	const double P = (double) (1.0f / 2.4f);
+	for (uint64_t u = first; u <= last; u += step) {
+		const uint32_t bits = (uint32_t) u;
+		float x; memcpy(&x, &bits, 4);
+		const float got = pow_1_over_2p4(x), expect = (float) pow((double) x, P);
+		if (memcmp(&got, &expect, 4) != 0 && !(got != got && expect != expect)) { ++bad; if (worst) *worst = x; }
+	}
+	return bad;
+}
+
+// the same for the 8-bit sample the renderer finally stores (what parity is judged on)
+extern "C" __attribute__((visibility("default"))) uint64_t hostsim_srgb_u8_sweep(uint32_t first, uint32_t last, uint32_t step) {
+	uint64_t bad = 0;
+	const double P = (double) (1.0f / 2.4f);
+	for (uint64_t u = first; u <= last; u += step) {
+		const uint32_t bits = (uint32_t) u;
+		float v; memcpy(&v, &bits, 4);
+		const float a = srgb_transfer(v);
+		const float b = v <= 0.0031308f ? 12.92f * v : 1.055f * (float) pow((double) v, P) - 0.055f;
+		const int32_t pa = f32_to_i16_x86(255.0f * a + 0.5f), pb = f32_to_i16_x86(255.0f * b + 0.5f);
+		bad += pa != pb;
+	}
+	return bad;
 }

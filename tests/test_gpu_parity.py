@@ -117,6 +117,68 @@ def test_hip_path_against_cpu_oracle(gpu):
             assert compare(rgba, expect)[0] <= 1
 
 
+def test_device_srgb_tail_matches_correctly_rounded_powf(gpu):
+    """the seeded fp64 root that replaces powf in the pixel kernels, on the device's own log2/exp2/rcp seeds:
+    8-bit samples identical to the ones a correctly rounded powf yields (what the reference's libm gives)"""
+    rng = np.random.default_rng(5)
+    v = np.concatenate([np.linspace(0.0, 1.2, 3000001, dtype=np.float32), rng.uniform(0.9, 70000.0, 2000000).astype(np.float32),
+                        np.float32(2.0) ** rng.uniform(-20, 120, 500000).astype(np.float32), np.array([np.inf, np.nan, -1.0, 0.0031308, 0.00313081], np.float32)])
+    out = np.zeros(v.size, np.uint8)
+    assert gpu.lib().j40hip_kat_device_srgb_u8(v.ctypes.data, v.size, out.ctypes.data) == 0
+    P = np.float64(np.float32(1.0) / np.float32(2.4))
+    with np.errstate(all="ignore"):
+        p = np.power(v.astype(np.float64), P).astype(np.float32)
+        t = np.where(v <= np.float32(0.0031308), np.float32(12.92) * v, np.float32(1.055) * p - np.float32(0.055)).astype(np.float32)
+        y = (np.float32(255.0) * t + np.float32(0.5)).astype(np.float32)
+        # (int16_t) of a float on x86: cvttss2si to int32 (0x80000000 when out of range / NaN), then the low 16 bits
+        ok = np.isfinite(y) & (np.abs(y) < 2147483648.0)
+        i32 = np.where(ok, np.trunc(np.where(ok, y, 0)).astype(np.int64), -2147483648)
+    i16 = ((i32 & 0xFFFF) ^ 0x8000) - 0x8000
+    expect = np.clip(i16, 0, 255).astype(np.uint8)
+    bad = np.nonzero(out != expect)[0]
+    assert bad.size <= 2, (bad.size, v[bad[:5]], out[bad[:5]], expect[bad[:5]])
+
+
+def test_batch_throughput_mode_matches_latency_mode(gpu, ref):
+    """j40hip_batch_decode (one section per wavefront lane, many frames per launch) gives exactly the pixels of
+    j40hip_frame_decode (one section per wavefront) and the reference's within 1 level, per frame"""
+    import torch
+    cases = [(n, o) for n, o in VARDCT_CASES] + [("all_transforms", dict(maxlog=8, bctx=1, presets=2, orders=1))]
+    frames, outs, datas = [], [], []
+    for i, (name, opts) in enumerate(cases):
+        w, h = [(520, 264), (776, 520), (264, 520), (1032, 300)][i % 4]
+        data = synth("vardct", w, h, 77 + i, **opts)
+        fr = gpu.Frame(data)
+        fr.upload(0)
+        frames.append(fr); datas.append(data)
+        outs.append(torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0"))
+    batch = gpu.Batch(frames)
+    batch.decode([o.data_ptr() for o in outs], [o.shape[1] * 4 for o in outs], torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for fr, o, data, (name, _) in zip(frames, outs, datas, cases):
+        assert fr.status() == "", name
+        got = o.cpu().numpy()
+        err, single = fr.decode_to_host()
+        assert err == "" and np.array_equal(got, single), name
+        rerr, expect = ref.decode(data)
+        assert rerr == "" and compare(got, expect)[0] <= 1, name
+    # a corrupt member fails alone
+    bad = bytearray(datas[0]); bad[len(bad) // 2] ^= 0x55
+    try:
+        fb = gpu.Frame(bytes(bad)); fb.upload(0)
+    except gpu.J40Error:
+        fb = None
+    if fb is not None:
+        b2 = gpu.Batch([frames[1], fb])
+        b2.decode([outs[1].data_ptr(), outs[0].data_ptr()], [outs[1].shape[1] * 4, outs[0].shape[1] * 4], torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert frames[1].status() == ""
+        rerr, _ = ref.decode(bytes(bad))
+        assert fb.status() == rerr
+        b2.close()
+    batch.close()
+
+
 def test_golden_fixtures(gpu):
     manifest = json.load(open(os.path.join(GOLDEN, "manifest.json")))
     for name, e in sorted(manifest.items()):

@@ -41,6 +41,20 @@ def test_device_functions_on_cpu_match_reference(ref, sim, name, opts):
     rs.close()
 
 
+@pytest.mark.parametrize("name,opts", VARDCT_CASES + [("all_transforms", dict(maxlog=8, bctx=1, presets=2, orders=1))])
+def test_flat_lane_decoder_matches_nested_decoder(sim, name, opts):
+    """decode_hf_section_flat (one section per lane, throughput kernel) == decode_hf_section, coefficients and status"""
+    w, h = (776, 520) if name == "all_transforms" else (392, 264)
+    data = synth("vardct", w, h, 33, **opts)
+    buf = C.create_string_buffer(data, len(data))
+    n = ((w + 7) // 8) * ((h + 7) // 8) * 64 * 4   # generous: LF groups pad to whole cells
+    a = np.zeros((3, n), np.float32); b = np.zeros((3, n), np.float32)
+    rgba = np.zeros((h, w, 4), np.uint8)
+    assert sim.hostsim_decode(buf, len(data), rgba.ctypes.data, a.ctypes.data, 1) == 0
+    assert sim.hostsim_decode(buf, len(data), rgba.ctypes.data, b.ctypes.data, 3) == 0
+    assert np.array_equal(a, b) and np.abs(a).sum() > 0
+
+
 @pytest.mark.parametrize("name,w,h,opts", MODULAR_CASES)
 def test_modular_device_functions_on_cpu_are_bit_exact(ref, sim, name, w, h, opts):
     data = synth("modular", w, h, 61, **opts)
@@ -50,3 +64,21 @@ def test_modular_device_functions_on_cpu_are_bit_exact(ref, sim, name, w, h, opt
     buf = C.create_string_buffer(data, len(data))
     assert sim.hostsim_decode(buf, len(data), rgba.ctypes.data, None, 0) == 0
     assert np.array_equal(rgba, expect)
+
+
+def test_srgb_power_function_is_correctly_rounded(sim):
+    """pow_1_over_2p4 (seeded fp64 root, idct_dev.h) == (float) pow((double) x, 1/2.4f): every 7th float of
+    [2^-9, 4) and a coarse sweep of all positive floats"""
+    import struct
+    sim.hostsim_pow_sweep.restype = C.c_uint64
+    sim.hostsim_pow_sweep.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+    sim.hostsim_srgb_u8_sweep.restype = C.c_uint64
+    sim.hostsim_srgb_u8_sweep.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    bits = lambda x: struct.unpack("<I", struct.pack("<f", x))[0]
+    worst = C.c_float()
+    n = (bits(4.0) - bits(2.0 ** -9)) // 7
+    bad = sim.hostsim_pow_sweep(bits(2.0 ** -9), bits(4.0), 7, C.byref(worst))
+    assert bad <= n // 1000000, "%d of %d results differ, e.g. x = %r" % (bad, n, worst.value)
+    bad = sim.hostsim_pow_sweep(bits(2.0 ** -9), bits(3.0e38), 4099, C.byref(worst))
+    assert bad <= 2, "x = %r" % worst.value
+    assert sim.hostsim_srgb_u8_sweep(bits(1e-6), bits(300.0), 13) == 0
