@@ -17,7 +17,7 @@ tools: build/jxlsynth
 oracle:
 	$(MAKE) -C oracle all
 
-build/obj/%.o: $(SRC)/%.cpp $(wildcard $(SRC)/*.hpp) include/j40hip.h include/j40.h
+build/obj/%.o: $(SRC)/%.cpp $(wildcard $(SRC)/*.hpp) $(wildcard $(SRC)/device/*.h) include/j40hip.h include/j40.h
 	@mkdir -p build/obj
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 

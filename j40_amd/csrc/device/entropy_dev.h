@@ -20,6 +20,17 @@
 #endif
 #endif
 
+// Address-space qualifiers. A pointer the compiler cannot trace back to a kernel argument or a __shared__
+// object is "generic" and costs flat_load / flat_store (slower, and they occupy both the LDS and the
+// vector-memory counters). Pointers that are known to be global / LDS are declared as such.
+#ifdef __HIPCC__
+#define J40_GLOBAL __attribute__((address_space(1)))
+#define J40_LDS __attribute__((address_space(3)))
+#else
+#define J40_GLOBAL
+#define J40_LDS
+#endif
+
 namespace j40hip {
 
 // In the latency-oriented launch every lane of a wavefront decodes the SAME section, so all decoder
@@ -37,7 +48,7 @@ template <bool UNI> J40_DEV int32_t uni(int32_t v) { return (int32_t) uni<UNI>((
 template <bool UNI> J40_DEV uint64_t uni64(uint64_t v) { return (uint64_t) uni<UNI>((uint32_t) v) | ((uint64_t) uni<UNI>((uint32_t) (v >> 32)) << 32); }
 
 struct DevBits {
-	const uint8_t *base;   // start of the codestream buffer: 4-byte aligned, padded with >= 8 readable bytes
+	const J40_GLOBAL uint8_t *base;   // start of the codestream buffer (HBM): 4-byte aligned, padded with >= 8 readable bytes
 	uint32_t pos, end;     // next unread byte / end of the section, relative to base
 	uint64_t bits;
 	int32_t nbits;
@@ -47,17 +58,17 @@ struct DevBits {
 
 J40_DEV void bits_set_error(DevBits &b, uint32_t e) { if (!b.err) b.err = e; }
 
-J40_DEV uint32_t bits_load32(const uint8_t *p) { return *(const uint32_t *) p; }
+J40_DEV uint32_t bits_load32(const J40_GLOBAL uint8_t *p) { return *(const J40_GLOBAL uint32_t *) p; }
 
 template <bool UNI> J40_DEV void bits_init(DevBits &b, const uint8_t *base, uint32_t byte_off, uint32_t size, uint32_t bit_off) {
-	b.base = base; b.pos = byte_off + (bit_off >> 3); b.end = byte_off + size; b.bits = 0; b.nbits = 0; b.err = 0;
+	b.base = (const J40_GLOBAL uint8_t *) base; b.pos = byte_off + (bit_off >> 3); b.end = byte_off + size; b.bits = 0; b.nbits = 0; b.err = 0;
 	const uint32_t rem = bit_off & 7;
 	if (rem) {  // start in the middle of a byte (single-section frames)
-		if (b.pos < b.end) { b.bits = (uint64_t) (uni<UNI>((uint32_t) base[b.pos++]) >> rem); b.nbits = 8 - (int32_t) rem; }
+		if (b.pos < b.end) { b.bits = (uint64_t) (uni<UNI>((uint32_t) b.base[b.pos++]) >> rem); b.nbits = 8 - (int32_t) rem; }
 		else bits_set_error(b, ERR_SHRT);
 	}
-	while ((b.pos & 3) && b.pos < b.end) { b.bits |= (uint64_t) uni<UNI>((uint32_t) base[b.pos++]) << b.nbits; b.nbits += 8; }  // reach word alignment
-	b.ahead = uni<UNI>(bits_load32(base + (b.pos & ~3u)));  // inside the padded buffer even when pos == end
+	while ((b.pos & 3) && b.pos < b.end) { b.bits |= (uint64_t) uni<UNI>((uint32_t) b.base[b.pos++]) << b.nbits; b.nbits += 8; }  // reach word alignment
+	b.ahead = uni<UNI>(bits_load32(b.base + (b.pos & ~3u)));  // inside the padded buffer even when pos == end
 }
 
 // tops the accumulator up to >= 32 valid bits (as long as the section has bytes left); bytes past the

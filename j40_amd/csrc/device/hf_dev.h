@@ -65,22 +65,20 @@ J40_DEV uint32_t decode_hf_section(const DevPlan &plan, const DevFrame &f, const
 	DevCode code;
 	code_init(code, spec, t.clusters, t.cluster_map, t.alias, t.prefix, t.window);
 	const int32_t gw8 = sec.gw8;
-	const int32_t nb_block_ctx = f.nb_block_ctx, nb_qf1 = f.nb_qf_thr + 1, lfidx_size = f.lfidx_size;
-	const int32_t bctxc = 13 * nb_qf1 * lfidx_size;
+	const int32_t nb_block_ctx = f.nb_block_ctx;
 	const size_t cell64 = (size_t) gg.cell_base * 64;
 	for (int32_t k = 0; k < t.nblocks && !b.err; ++k) {
 		DevGroupBlock gb;
-		{ const uint32_t *p = (const uint32_t *) (t.blocks + k); gb.coeffoff_qfidx = uni<UNI>(p[0]); const uint32_t w = uni<UNI>(p[1]); gb.pos_dct = (uint16_t) w; gb.lfidx = (uint8_t) (w >> 16); gb.pad = 0; }
+		{ const uint32_t *p = (const uint32_t *) (t.blocks + k); gb.coeffoff_qfidx = uni<UNI>(p[0]); const uint32_t w = uni<UNI>(p[1]); gb.pos_dct = (uint16_t) w; gb.bctx3 = (uint16_t) (w >> 16); }
 		const int32_t dctsel = gb.pos_dct >> 10, nzpos = ((gb.pos_dct >> 5) & 31) * gw8 + (gb.pos_dct & 31);
 		const int32_t x8 = gb.pos_dct & 31, y8 = (gb.pos_dct >> 5) & 31;
 		const int32_t log_rows = uni<UNI>((int32_t) DEV_DCT_SELECT[dctsel][0]), log_columns = uni<UNI>((int32_t) DEV_DCT_SELECT[dctsel][1]), order_idx = uni<UNI>((int32_t) DEV_DCT_SELECT[dctsel][2]);
 		const int32_t log_size = log_rows + log_columns, shift = log_size - 6, size = 1 << log_size;
-		const int32_t coeffoff = (int32_t) (gb.coeffoff_qfidx & ~15u), qfidx = (int32_t) (gb.coeffoff_qfidx & 15u);
-		const int32_t bctx0 = (order_idx * nb_qf1 + qfidx) * lfidx_size + gb.lfidx;
+		const int32_t coeffoff = (int32_t) (gb.coeffoff_qfidx & ~15u);
 		for (int32_t c_yxb = 0; c_yxb < 3 && !b.err; ++c_yxb) {
 			const int32_t c = c_yxb == 0 ? 1 : c_yxb == 1 ? 0 : 2;
 			float *coeffs = plan.coeffs[c] + cell64 + coeffoff;
-			const int32_t bctx = uni<UNI>((int32_t) t.block_ctx_map[bctx0 + bctxc * c_yxb]);
+			const int32_t bctx = (gb.bctx3 >> (4 * c_yxb)) & 15;
 			// number of non-zeros, predicted from the left / top blocks (j40.h:6959-6967)
 			int32_t nz;
 			if (x8 > 0) nz = y8 > 0 ? (t.nonzeros[(nzpos - 1) * 3 + c] + t.nonzeros[(nzpos - gw8) * 3 + c] + 1) >> 1 : t.nonzeros[(nzpos - 1) * 3 + c];
@@ -131,13 +129,12 @@ J40_DEV uint32_t decode_hf_section_flat(const DevPlan &plan, const DevFrame &f, 
 	DevCode code;
 	code_init(code, spec, t.clusters, t.cluster_map, t.alias, t.prefix, t.window);
 	const int32_t gw8 = sec.gw8;
-	const int32_t nb_block_ctx = f.nb_block_ctx, nb_qf1 = f.nb_qf_thr + 1, lfidx_size = f.lfidx_size;
-	const int32_t bctxc = 13 * nb_qf1 * lfidx_size;
+	const int32_t nb_block_ctx = f.nb_block_ctx;
 	const size_t cell64 = (size_t) gg.cell_base * 64;
 	// iterator over (block, channel) and the coefficient loop state of the current one
 	int32_t k = 0, c_yxb = 0;
 	bool in_coeffs = false, done = t.nblocks == 0 || b.err != 0;
-	int32_t x8 = 0, y8 = 0, nzpos = 0, log_rows = 3, log_columns = 3, order_idx = 0, shift = 0, size = 64, coeffoff = 0, bctx0 = 0;
+	int32_t x8 = 0, y8 = 0, nzpos = 0, log_rows = 3, log_columns = 3, order_idx = 0, shift = 0, size = 64, coeffoff = 0, bctx3 = 0;
 	int32_t c = 1, bctx = 0, nz = 0, i = 0, prev = 0, cctx = 0;
 	float *coeffs = nullptr;
 	const uint16_t *order = nullptr;
@@ -147,15 +144,15 @@ J40_DEV uint32_t decode_hf_section_flat(const DevPlan &plan, const DevFrame &f, 
 			if (c_yxb == 0) {
 				const uint32_t *p = (const uint32_t *) (t.blocks + k);
 				const uint32_t coeffoff_qfidx = p[0], w = p[1];
-				const int32_t dctsel = (int32_t) ((w >> 10) & 31), lfidx = (int32_t) ((w >> 16) & 255);
+				const int32_t dctsel = (int32_t) ((w >> 10) & 31);
+				bctx3 = (int32_t) (w >> 16);
 				x8 = (int32_t) (w & 31); y8 = (int32_t) ((w >> 5) & 31); nzpos = y8 * gw8 + x8;
 				log_rows = DEV_DCT_SELECT[dctsel][0]; log_columns = DEV_DCT_SELECT[dctsel][1]; order_idx = DEV_DCT_SELECT[dctsel][2];
 				shift = log_rows + log_columns - 6; size = 64 << shift;
 				coeffoff = (int32_t) (coeffoff_qfidx & ~15u);
-				bctx0 = (order_idx * nb_qf1 + (int32_t) (coeffoff_qfidx & 15u)) * lfidx_size + lfidx;
 			}
 			c = c_yxb == 0 ? 1 : c_yxb == 1 ? 0 : 2;
-			bctx = t.block_ctx_map[bctx0 + bctxc * c_yxb];
+			bctx = (bctx3 >> (4 * c_yxb)) & 15;
 			int32_t pnz;
 			if (x8 > 0) pnz = y8 > 0 ? (t.nonzeros[(nzpos - 1) * 3 + c] + t.nonzeros[(nzpos - gw8) * 3 + c] + 1) >> 1 : t.nonzeros[(nzpos - 1) * 3 + c];
 			else pnz = y8 > 0 ? t.nonzeros[(nzpos - gw8) * 3 + c] : 32;

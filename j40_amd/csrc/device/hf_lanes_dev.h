@@ -1,0 +1,226 @@
+// j40_amd/csrc/device/hf_lanes_dev.h -- K1, throughput form: the HF coefficient decode of one pass-group
+// section per wavefront LANE, specialised for what real VarDCT streams use (rANS, no LZ77). Restates
+// j40__hf_coeffs (j40.h:6888-7005) + j40__code / j40__ans_code / j40__hybrid_int (2804, 2441, 2313) as a
+// flat state machine: every iteration each of the 64 lanes decodes exactly one symbol -- the non-zero
+// count of its next (block, channel) or the next coefficient -- so the rANS step, the hybrid integer and
+// the bit refill are executed convergently; only the short per-phase prologue / epilogue diverge.
+//
+// What makes an iteration cheap:
+//   * branch-light: a divergent `if` costs exec-mask bookkeeping plus a branch whether or not it is taken,
+//     so the per-symbol path is written with selects. One refill point per iteration tops the 64-bit window
+//     up to > 32 bits without a branch; the rANS renormalisation and the hybrid integer's extra bits are
+//     taken unconditionally with a length of 0 when they do not apply. Only the rare cases branch: first
+//     symbol of a section, more than ~17 extra bits, errors.
+//   * the bit position is absolute (8 * pos - nbits), so "ran past the section" is one compare per symbol
+//     instead of end-of-section logic inside every read; the padded codestream makes over-reads harmless;
+//   * per symbol: context -> cluster (LDS byte), then the 64-bit alias entry and the cluster's hybrid-integer
+//     config word side by side (both LDS, both addressed by the cluster): a chain of two LDS reads;
+//   * every pointer carries its address space (LDS tables, global block lists / bitstream / coefficients) --
+//     no flat accesses; per-lane addresses are 32-bit offsets from wave-uniform bases;
+//   * the non-zero-count predictor (left / top neighbour, j40.h:6959-6963) needs only the count of the last block
+//     written into each of the group's 32 cell columns: blocks arrive in raster order of their top-left cell and
+//     tile the group, so "last block in column x - 1" covers (x - 1, y) and "last block in column x" covers
+//     (x, y - 1). 96 bytes per lane in LDS replace the 3 KB per group scratch in HBM and its dependent loads;
+//   * the next block's descriptor is requested while the current block is being decoded; the block contexts
+//     come with the descriptor (looked up on the host);
+//   * the three coefficient planes are one allocation (plane c at c * coeff_stride), so a lane's channel is
+//     an offset, not a pointer select.
+// Specs with prefix codes or LZ77, and tables beyond the LDS budget, take decode_hf_section_flat (hf_dev.h).
+#pragma once
+#include "hf_dev.h"
+
+namespace j40hip {
+
+// LDS-resident tables of one frame / pass (staged by the kernel, or plain arrays under tests/hostsim)
+struct LaneTables {
+	const J40_LDS uint8_t *ctx_map;       // [num_dist] context -> cluster
+	const J40_LDS uint32_t *cluster_cfg;  // [cluster] split_exp | msb_in_token << 4 | lsb_in_token << 8 | max_token << 12
+	const J40_LDS uint64_t *alias;        // [cluster << log_alpha_size | bucket], AnsEntry (entropy.hpp)
+	const J40_LDS int16_t *nnz_ctx2;
+	const J40_LDS int8_t *freq_ctx2;
+	const J40_LDS uint32_t *dct_info;     // [DctSelect] log_rows | log_columns << 8 | order_idx << 16
+	int32_t log_alpha, log_bucket;
+};
+
+// the frame scalars the decoder needs, copied out of DevFrame once (wave-uniform)
+struct LaneFrame {
+	int32_t nb_block_ctx, num_hf_presets, preset_bits;
+	const J40_GLOBAL uint32_t *order_off;  // DevFrame::order_off
+};
+
+// wave-uniform global bases of one frame; per-lane state only holds 32-bit offsets into them
+struct LaneGlobals {
+	const J40_GLOBAL uint8_t *codestream;
+	const J40_GLOBAL uint32_t *group_blocks;   // DevGroupBlock as two words
+	J40_GLOBAL float *coeffs;                  // plane c at c * coeff_stride
+	const J40_GLOBAL uint16_t *pool_u16;       // coefficient orders (multi-pass frames)
+	uint32_t coeff_stride;
+};
+
+// LSB-first bit window over the 4-byte aligned codestream buffer. Absolute position of the next unread
+// bit = 8 * pos - nbits. Reads never fail; the caller compares the position with the section end.
+struct LaneBits {
+	const J40_GLOBAL uint8_t *base;
+	uint64_t bits;     // bits at and above nbits are zero
+	int32_t nbits;
+	uint32_t pos;      // byte offset of the next word to append (multiple of 4)
+	uint32_t ahead;    // the word at pos, requested one refill early
+};
+
+J40_DEV uint32_t lane_load32(const J40_GLOBAL uint8_t *base, uint32_t pos) { return *(const J40_GLOBAL uint32_t *) (base + pos); }
+
+J40_DEV void lane_bits_init(LaneBits &b, const J40_GLOBAL uint8_t *base, uint32_t start_bit) {
+	b.base = base;
+	const uint32_t pos0 = (start_bit >> 3) & ~3u, skip = start_bit - 8u * pos0;   // skip < 32
+	b.bits = (uint64_t) (lane_load32(base, pos0) >> skip);
+	b.nbits = 32 - (int32_t) skip;
+	b.pos = pos0 + 4;
+	b.ahead = lane_load32(base, b.pos);
+}
+
+// > 32 bits buffered afterwards; no branch: the append is a select, the next word is always (re)requested
+J40_DEV void lane_bits_refill(LaneBits &b) {
+	const bool need = b.nbits <= 32;
+	const uint64_t add = (uint64_t) b.ahead << (need ? b.nbits : 0);
+	b.bits |= need ? add : 0;
+	b.nbits += need ? 32 : 0;
+	b.pos += need ? 4u : 0u;
+	b.ahead = lane_load32(b.base, b.pos);
+}
+
+J40_DEV uint32_t lane_bits_take(LaneBits &b, int32_t n) {   // 0 <= n <= 31, n <= nbits
+	const uint32_t v = (uint32_t) b.bits & ((1u << n) - 1u);
+	b.bits >>= n; b.nbits -= n;
+	return v;
+}
+
+J40_DEV uint32_t lane_bit_position(const LaneBits &b) { return 8u * b.pos - (uint32_t) b.nbits; }
+
+// one symbol: rANS step (j40.h:2441-2466) + hybrid integer (j40.h:2313-2334). *err receives the error the
+// reference would have raised first ("shrt" while renormalising, then "iovf", then "shrt" in the extra bits).
+J40_DEV int32_t lane_symbol(LaneBits &b, uint32_t &state, const LaneTables &t, int32_t ctx, uint32_t end_bit, uint32_t *err) {
+	const uint32_t cl = t.ctx_map[ctx];
+	if (state == 0) {   // first symbol of the section (j40.h:2445-2449); the window holds > 32 bits
+		state = lane_bits_take(b, 16); state |= lane_bits_take(b, 16) << 16;
+		lane_bits_refill(b);
+	}
+	const uint32_t idx = state & 0xfff, i = idx >> t.log_bucket, pos = idx & ((1u << t.log_bucket) - 1);
+	const uint64_t e = t.alias[(cl << t.log_alpha) + i];
+	const uint32_t m = t.cluster_cfg[cl];
+	const uint32_t elo = (uint32_t) e, ehi = (uint32_t) (e >> 32);
+	const bool aliased = pos >= (elo & 0xff);
+	const int32_t token = (int32_t) (aliased ? (elo >> 20) & 0xff : i);
+	const uint32_t offset = aliased ? (elo >> 8) & 0xfff : 0;
+	const uint32_t d = aliased ? (uint32_t) (e >> 28) & 0x1fff : (ehi >> 9) & 0x1fff;
+	state = d * (state >> 12) + offset + pos;
+	const bool renorm = state < (1u << 16);
+	const uint32_t low = lane_bits_take(b, renorm ? 16 : 0);
+	state = renorm ? (state << 16) | low : state;
+	const bool short1 = lane_bit_position(b) > end_bit;
+	// hybrid integer, computed for every token and selected at the end
+	const int32_t split_exp = (int32_t) (m & 15), split = 1 << split_exp;
+	const bool big = token >= split;
+	const int32_t mt = (int32_t) (m >> 12);
+	const bool iovf = big && token > mt;
+	const int32_t tok = iovf ? mt : token;
+	const int32_t msb = (int32_t) ((m >> 4) & 15), lsb = (int32_t) ((m >> 8) & 15), in_token = msb + lsb;
+	const int32_t midbits = big ? split_exp - in_token + ((tok - split) >> in_token) : 0;
+	if (midbits > b.nbits) lane_bits_refill(b);   // rare: more than ~17 extra bits (nbits <= 31 here, so the refill appends)
+	const int32_t mid = (int32_t) lane_bits_take(b, midbits);
+	const bool short2 = lane_bit_position(b) > end_bit;
+	const int32_t top = 1 << msb;
+	const int32_t lo = tok & ((1 << lsb) - 1), hi = (tok >> lsb) & (top - 1);
+	const int32_t value = ((top | hi) << (midbits + lsb)) | ((mid << lsb) | lo);
+	*err = short1 ? (uint32_t) ERR_SHRT : iovf ? (uint32_t) ERR_IOVF : short2 ? (uint32_t) ERR_SHRT : 0u;
+	return big ? value : token;
+}
+
+// decodes one (pass, group) section; same results and status codes as decode_hf_section (hf_dev.h).
+// cols[(c * 32 + x) * col_stride]: non-zero count (per 8x8 cell) of the last block written into cell column x, channel c
+template <bool SCAN>
+J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t, const LaneGlobals &G, const DevSection &sec, uint32_t cell_base,
+		uint32_t block_first, int32_t nblocks, J40_LDS int8_t *cols, int32_t col_stride, int32_t pass) {
+	const uint32_t start_bit = 8u * sec.byte_off + sec.bit_off, end_bit = 8u * (sec.byte_off + sec.size);
+	LaneBits b;
+	lane_bits_init(b, G.codestream, start_bit);
+	lane_bits_refill(b);
+	uint32_t err = 0;
+	const uint32_t preset = lane_bits_take(b, f.preset_bits);
+	if (lane_bit_position(b) > end_bit) err = ERR_SHRT;
+	else if ((int32_t) preset >= f.num_hf_presets) err = ERR_RNGE;
+	const int32_t nb_block_ctx = f.nb_block_ctx;
+	const int32_t ctxoff = 495 * nb_block_ctx * (int32_t) preset;
+	const uint32_t cell64 = cell_base * 64u;
+	int32_t k = 0, c_yxb = 0;
+	bool in_coeffs = false, done = nblocks == 0 || err != 0;
+	uint32_t state = 0;
+	int32_t x8 = 0, y8 = 0, log_columns = 3, order_idx = 0, shift = 0, size = 64;
+	uint32_t coeffoff = 0, coeff_at = 0, bctx3 = 0;
+	int32_t c = 1, bctx = 0, nz = 0, i = 0, prev = 0, cctx = 0;
+	const J40_GLOBAL uint16_t *order = nullptr;
+	uint32_t next0 = 0, next1 = 0;   // descriptor of block k, requested one block ahead
+	if (!done) { const J40_GLOBAL uint32_t *p = G.group_blocks + 2u * block_first; next0 = p[0]; next1 = p[1]; }
+	while (!done) {
+		lane_bits_refill(b);
+		int32_t ctx;
+		if (!in_coeffs) {  // next symbol: number of non-zeros of (block k, channel c_yxb), j40.h:6959-6967
+			if (c_yxb == 0) {
+				const uint32_t w = next1;
+				coeffoff = next0 & ~15u;
+				if (k + 1 < nblocks) { const J40_GLOBAL uint32_t *p = G.group_blocks + 2u * (block_first + (uint32_t) k + 1u); next0 = p[0]; next1 = p[1]; }
+				x8 = (int32_t) (w & 31); y8 = (int32_t) ((w >> 5) & 31); bctx3 = w >> 16;
+				const uint32_t di = t.dct_info[(w >> 10) & 31];
+				log_columns = (int32_t) ((di >> 8) & 255); order_idx = (int32_t) (di >> 16);
+				shift = (int32_t) (di & 255) + log_columns - 6; size = 64 << shift;
+			}
+			c = c_yxb == 0 ? 1 : c_yxb == 1 ? 0 : 2;
+			bctx = (int32_t) ((bctx3 >> (4 * c_yxb)) & 15);
+			const J40_LDS int8_t *col = cols + (c * 32 + x8) * col_stride;
+			const int32_t left = x8 > 0 ? col[-col_stride] : -1, topv = y8 > 0 ? col[0] : -1;
+			const int32_t pnz = left < 0 ? (topv < 0 ? 32 : topv) : topv < 0 ? left : (left + topv + 1) >> 1;
+			ctx = ctxoff + bctx + (pnz < 8 ? pnz : 4 + pnz / 2) * nb_block_ctx;
+		} else {
+			ctx = cctx + t.nnz_ctx2[(nz + (1 << shift) - 1) >> shift] + t.freq_ctx2[i >> shift] + prev;
+		}
+		uint32_t serr;
+		const int32_t v = lane_symbol(b, state, t, ctx, end_bit, &serr);
+		if (serr) { err = serr; break; }
+		if (!in_coeffs) {
+			nz = v;
+			if (nz > (63 << shift)) { err = ERR_COEF; break; }
+			const int8_t qnz = (int8_t) ((nz + (1 << shift) - 1) >> shift);
+			J40_LDS int8_t *col = cols + (c * 32 + x8) * col_stride;
+			for (int32_t q = 0; q < (1 << (log_columns - 3)); ++q) col[q * col_stride] = qnz;
+			cctx = ctxoff + 458 * bctx + 37 * nb_block_ctx;
+			prev = nz <= (size >> 4);
+			i = 1 << shift;
+			coeff_at = (uint32_t) c * G.coeff_stride + cell64 + coeffoff;
+			if (!SCAN) order = G.pool_u16 + f.order_off[(pass * 13 + order_idx) * 3 + c];
+			in_coeffs = nz > 0;
+		} else {
+			if (v) {
+				const float fv = (float) unpack_signed_dev(v);
+				if (SCAN) G.coeffs[coeff_at + (uint32_t) i] = fv; else G.coeffs[coeff_at + order[i]] += fv;
+			}
+			prev = v != 0;
+			nz -= prev;
+			++i;
+			if (nz == 0) in_coeffs = false;
+			else if (i >= size) { err = ERR_COEF; break; }   // non-zeros left but no coefficient left (j40.h:6996)
+		}
+		if (!in_coeffs && ++c_yxb == 3) { c_yxb = 0; done = ++k >= nblocks; }
+	}
+	if (!err) {   // j40.h:2884-2893: the final state, or the untouched initial state, must be 0x130000
+		if (state == 0) { lane_bits_refill(b); state = lane_bits_take(b, 16); state |= lane_bits_take(b, 16) << 16; if (lane_bit_position(b) > end_bit) err = ERR_SHRT; }
+		if (!err && state != 0x130000) err = ERR_ANS;
+	}
+	if (!err) {   // the section ends here: zero padding up to the byte boundary, then no byte left (j40.h:2011)
+		const uint32_t at = lane_bit_position(b), padn = (0u - at) & 7u;
+		if (padn > (uint32_t) b.nbits) lane_bits_refill(b);
+		if (lane_bits_take(b, (int32_t) padn)) err = ERR_PAD0;
+		else if (at + padn != end_bit) err = at + padn > end_bit ? (uint32_t) ERR_SHRT : (uint32_t) ERR_EXCS;
+	}
+	return err;
+}
+
+} // namespace j40hip

@@ -250,8 +250,28 @@ J40_DEV float srgb_transfer(float v) {
 	return 1.055f * pow_1_over_2p4(v) - 0.055f;
 }
 
-// returns RGBA packed little-endian (R in the low byte), alpha = 255
-J40_DEV uint32_t xyb_to_rgba8(float sx, float sy, float sb, const DevFrame &f) {
+// The 8-bit sample as a function of the linear value v is a non-decreasing step function (every stage --
+// transfer curve, scale, + 0.5, truncation, clamp -- is monotone) as long as the int16 wrap-around of the
+// reference's conversion stays out of reach, i.e. for -9 < v < 50000. So the sample is the number of thresholds
+// thr[1..255] that are <= v, where thr[k] = smallest float with sample >= k (built on the host from the exact
+// formula by bisection over the floats, tables.cpp). A cheap estimate good to a small fraction of a level picks
+// k0, two table reads settle it exactly: same bytes as the long way at a fraction of the instructions (the
+// transfer function was ~40 % of the pixel kernels' issue slots). thr[0] = -inf, thr[256] = thr[257] = +inf.
+J40_DEV int32_t srgb_u8_from_thresholds(float v, const J40_LDS float *thr) {
+#ifdef __HIPCC__
+	const float p = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(v) * 0.416666657f);
+#else
+	const float p = exp2f(log2f(v) * 0.416666657f);
+#endif
+	const float est = v <= 0.0031308f ? 3294.6f * v + 0.5f : 269.025f * p - 13.525f;   // 255 * (12.92 v | 1.055 p - 0.055) + 0.5
+	int32_t k = (int32_t) (est < 0.0f ? 0.0f : est > 255.0f ? 255.0f : est);
+	k += (int32_t) (v >= thr[k + 1]) - (int32_t) (v < thr[k]);
+	return k;
+}
+
+// returns RGBA packed little-endian (R in the low byte), alpha = 255. thr: threshold table for 8-bit frames
+// (see above) or nullptr for the long way.
+J40_DEV uint32_t xyb_to_rgba8(float sx, float sy, float sb, const DevFrame &f, const J40_LDS float *thr = nullptr) {
 	float p[3] = {sy + sx, sy - sx, sb};
 	float s[3];
 #pragma unroll
@@ -264,13 +284,23 @@ J40_DEV uint32_t xyb_to_rgba8(float sx, float sy, float sb, const DevFrame &f) {
 	uint32_t out = 0xff000000u;
 #pragma unroll
 	for (int c = 0; c < 3; ++c) {
-		float v = s[0] * f.opsin_inv_mat[c * 3] + s[1] * f.opsin_inv_mat[c * 3 + 1] + s[2] * f.opsin_inv_mat[c * 3 + 2];
-		v = srgb_transfer(v);
-		int32_t px = f32_to_i16_x86(fmax * v + 0.5f);
-		px = px < 0 ? 0 : px > maxpixel ? maxpixel : px;
-		out |= (uint32_t) ((px * 255 + maxpixel2) / maxpixel) << (8 * c);
+		const float v = s[0] * f.opsin_inv_mat[c * 3] + s[1] * f.opsin_inv_mat[c * 3 + 1] + s[2] * f.opsin_inv_mat[c * 3 + 2];
+		int32_t px;
+		if (thr && v > -9.0f && v < 50000.0f) px = srgb_u8_from_thresholds(v, thr);
+		else {
+			px = f32_to_i16_x86(fmax * srgb_transfer(v) + 0.5f);
+			px = px < 0 ? 0 : px > maxpixel ? maxpixel : px;
+			px = (px * 255 + maxpixel2) / maxpixel;
+		}
+		out |= (uint32_t) px << (8 * c);
 	}
 	return out;
+}
+
+// host: the sample the long way, for one linear value of an 8-bit frame (table construction and tests)
+J40_DEV int32_t srgb_u8_exact8(float v) {
+	int32_t px = f32_to_i16_x86(255.0f * srgb_transfer(v) + 0.5f);
+	return px < 0 ? 0 : px > 255 ? 255 : px;
 }
 
 } // namespace j40hip

@@ -10,7 +10,9 @@
 //
 // Compiled with -ffp-contract=off: the float path has to keep the reference's operation order.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "hf_dev.h"
+#include "hf_lanes_dev.h"
 #include "idct_dev.h"
 #include "vardct_dev.h"
 #include "kernels.h"
@@ -19,8 +21,16 @@ namespace j40hip {
 
 __constant__ float c_half_secants[256];
 __constant__ float c_afv_basis[256];
+__constant__ float c_srgb_thr[258];
 
-void upload_constant_tables(const float *half_secants, const float *afv_basis, hipStream_t stream) {
+// the pixel kernels keep the sRGB threshold table (idct_dev.h) in LDS; 8-bit frames only
+#define J40_STAGE_SRGB_THRESHOLDS(f) \
+	__shared__ float s_srgb_thr[258]; \
+	for (int32_t i_ = threadIdx.x; i_ < 258; i_ += blockDim.x) s_srgb_thr[i_] = c_srgb_thr[i_]; \
+	const J40_LDS float *srgb_thr = (f).bpp == 8 ? (const J40_LDS float *) s_srgb_thr : (const J40_LDS float *) nullptr
+
+void upload_constant_tables(const float *half_secants, const float *afv_basis, const float *srgb_thr, hipStream_t stream) {
+	(void) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_srgb_thr), srgb_thr, sizeof(float) * 258, 0, hipMemcpyHostToDevice, stream);
 	(void) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_half_secants), half_secants, sizeof(float) * 256, 0, hipMemcpyHostToDevice, stream);
 	(void) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_afv_basis), afv_basis, sizeof(float) * 256, 0, hipMemcpyHostToDevice, stream);
 }
@@ -120,10 +130,18 @@ __global__ void __launch_bounds__(64 * HF_WAVES) k_hf_entropy(DevPlan plan, int3
 // A lone wave is slower per section than the scalarised k_hf_entropy, but a batch fills every SIMD
 // with several such waves: with 288 GB of HBM the working sets of hundreds of frames are resident.
 template <bool TABLES_IN_LDS>
-__global__ void __launch_bounds__(64, 16) k_hf_entropy_lanes(const DevPlan *plans, const HfLaneWork *work) {
+__global__ void __launch_bounds__(64) k_hf_entropy_lanes(const DevPlan *plans, const HfLaneWork *work) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t hf_lds[];
 	const HfLaneWork w = work[blockIdx.x];
-	const DevPlan plan = plans[w.frame];
+	DevPlan plan = plans[w.frame];
+	// pointers loaded from memory are generic to the compiler (flat_load/flat_store: slower, and they tie up both
+	// the LDS and the vector-memory counters); tell it that every plan pointer is a global address
+#define J40_TO_GLOBAL(p) p = (std::remove_reference<decltype((p))>::type) (__attribute__((address_space(1))) void *) (void *) (p)
+	J40_TO_GLOBAL(plan.frame); J40_TO_GLOBAL(plan.codestream); J40_TO_GLOBAL(plan.pool_u8); J40_TO_GLOBAL(plan.pool_u16); J40_TO_GLOBAL(plan.pool_i32);
+	J40_TO_GLOBAL(plan.pool_u64); J40_TO_GLOBAL(plan.pool_f32); J40_TO_GLOBAL(plan.clusters); J40_TO_GLOBAL(plan.coeff_specs); J40_TO_GLOBAL(plan.lf_groups);
+	J40_TO_GLOBAL(plan.sections); J40_TO_GLOBAL(plan.group_blocks); J40_TO_GLOBAL(plan.group_block_start); J40_TO_GLOBAL(plan.coeffs[0]); J40_TO_GLOBAL(plan.coeffs[1]);
+	J40_TO_GLOBAL(plan.coeffs[2]); J40_TO_GLOBAL(plan.nonzeros); J40_TO_GLOBAL(plan.lz_window); J40_TO_GLOBAL(plan.status);
+#undef J40_TO_GLOBAL
 	const DevFrame &f = *plan.frame;
 	const int32_t lane = threadIdx.x;
 	const bool active = lane < w.num_groups;
@@ -177,6 +195,99 @@ __global__ void __launch_bounds__(64, 16) k_hf_entropy_lanes(const DevPlan *plan
 	}
 }
 
+// copies a POD made of 32-bit words out of global memory (address-space qualified structs have no copy constructor)
+template <typename T> __device__ __forceinline__ T load_global_pod(const J40_GLOBAL T *src) {
+	static_assert(sizeof(T) % 4 == 0, "word-sized PODs only");
+	T out;
+	const J40_GLOBAL uint32_t *p = (const J40_GLOBAL uint32_t *) src;
+	uint32_t *q = (uint32_t *) &out;
+#pragma unroll
+	for (unsigned i = 0; i < sizeof(T) / 4; ++i) q[i] = p[i];
+	return out;
+}
+
+// K1, throughput form, fast path (hf_lanes_dev.h): rANS specs without LZ77 whose packed tables fit in LDS.
+// Same launch geometry as k_hf_entropy_lanes: one wavefront per workgroup, up to 64 groups of one frame per
+// wavefront, any number of frames per launch.
+__global__ void __launch_bounds__(256) k_hf_lanes(const DevPlan *plans, const HfLaneWork *work, uint32_t lds_tables_bytes) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t hf_lds[];
+	// blockDim.x / 64 wavefronts per workgroup, all on the same frame (the host pads the work list), sharing its tables
+	const int32_t tid = threadIdx.x, lane = tid & 63;
+	const HfLaneWork w = work[blockIdx.x * (blockDim.x >> 6) + (tid >> 6)];
+	const J40_GLOBAL DevPlan &plan = ((const J40_GLOBAL DevPlan *) plans)[w.frame];
+	const J40_GLOBAL DevFrame &df = *(const J40_GLOBAL DevFrame *) plan.frame;
+	const bool active = lane < w.num_groups;
+	const int32_t g = w.first_group + (active && !w.pad ? lane : 0);   // pad != 0: experiment, every lane decodes the chunk's first group
+	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+	LaneFrame f;
+	f.nb_block_ctx = df.nb_block_ctx; f.num_hf_presets = df.num_hf_presets; f.preset_bits = df.preset_bits;
+	f.order_off = df.order_off;
+	const int32_t num_passes = df.num_passes, num_groups = df.num_groups, scan = df.scan_order_coeffs;
+	LaneGlobals G;
+	G.codestream = (const J40_GLOBAL uint8_t *) plan.codestream;
+	G.group_blocks = (const J40_GLOBAL uint32_t *) plan.group_blocks;
+	G.coeffs = (J40_GLOBAL float *) plan.coeffs[0];
+	G.pool_u16 = (const J40_GLOBAL uint16_t *) plan.pool_u16;
+	G.coeff_stride = plan.coeff_stride;
+	const J40_GLOBAL uint8_t *pool_u8 = (const J40_GLOBAL uint8_t *) plan.pool_u8;
+	const J40_GLOBAL int32_t *pool_i32 = (const J40_GLOBAL int32_t *) plan.pool_i32;
+	const J40_GLOBAL uint64_t *pool_u64 = (const J40_GLOBAL uint64_t *) plan.pool_u64;
+	const J40_GLOBAL DevCodeSpec *specs = (const J40_GLOBAL DevCodeSpec *) plan.coeff_specs;
+	const J40_GLOBAL DevCluster *clusters = (const J40_GLOBAL DevCluster *) plan.clusters;
+	const J40_GLOBAL DevSection *sections = (const J40_GLOBAL DevSection *) plan.sections;
+	const J40_GLOBAL DevLfGroup *lf_groups = (const J40_GLOBAL DevLfGroup *) plan.lf_groups;
+	const J40_GLOBAL uint32_t *block_start = (const J40_GLOBAL uint32_t *) plan.group_block_start;
+	J40_GLOBAL uint32_t *status = (J40_GLOBAL uint32_t *) plan.status;
+
+	J40_LDS uint8_t *lds = (J40_LDS uint8_t *) hf_lds;
+	J40_LDS int16_t *l_nnz = (J40_LDS int16_t *) lds;
+	J40_LDS int8_t *l_freq = (J40_LDS int8_t *) (lds + 128);
+	J40_LDS uint32_t *l_dct = (J40_LDS uint32_t *) (lds + 192);
+	const uint32_t off_pass = 192 + 112;
+	if (tid < 64) { l_nnz[tid] = DEV_NNZ_CTX2[tid]; l_freq[tid] = DEV_FREQ_CTX2[tid]; }
+	if (tid < 27) l_dct[tid] = (uint32_t) DEV_DCT_SELECT[tid][0] | ((uint32_t) DEV_DCT_SELECT[tid][1] << 8) | ((uint32_t) DEV_DCT_SELECT[tid][2] << 16);
+	LaneTables t;
+	t.nnz_ctx2 = l_nnz; t.freq_ctx2 = l_freq; t.dct_info = l_dct;
+	// per-wave column predictor state behind the tables: [3][32][64 lanes] bytes
+	J40_LDS int8_t *l_cols = (J40_LDS int8_t *) (lds + lds_tables_bytes + (uint32_t) (tid >> 6) * HF_LANE_COLS_BYTES) + lane;
+	const uint32_t block_first = block_start[g];
+	const int32_t nblocks = (int32_t) (block_start[g + 1] - block_first);
+	for (int32_t pass = 0; pass < num_passes; ++pass) {
+		const J40_GLOBAL DevCodeSpec &spec = specs[pass];
+		__syncthreads();   // previous pass' tables are no longer in use
+		const int32_t num_dist = spec.num_dist, num_clusters = spec.num_clusters, log_alpha = spec.log_alpha_size;
+		J40_LDS uint8_t *l_map = lds + off_pass;
+		J40_LDS uint32_t *l_cfg = (J40_LDS uint32_t *) (lds + off_pass + align16((uint32_t) num_dist));
+		J40_LDS uint64_t *l_alias = (J40_LDS uint64_t *) ((J40_LDS uint8_t *) l_cfg + align16(4u * (uint32_t) num_clusters));
+		{
+			const J40_GLOBAL uint32_t *msrc = (const J40_GLOBAL uint32_t *) (pool_u8 + spec.cluster_map_off);   // the u8 pool keeps 4-byte alignment per table
+			J40_LDS uint32_t *mdst = (J40_LDS uint32_t *) l_map;
+			for (int32_t i = tid; i < (num_dist + 3) / 4; i += blockDim.x) mdst[i] = msrc[i];
+			const J40_GLOBAL int32_t *csrc = pool_i32 + spec.lane_cfg_off;
+			for (int32_t i = tid; i < num_clusters; i += blockDim.x) l_cfg[i] = (uint32_t) csrc[i];
+			const J40_GLOBAL uint64_t *asrc = pool_u64 + clusters[spec.cluster_off].table_off;
+			for (uint32_t i = tid; i < ((uint32_t) num_clusters << log_alpha); i += blockDim.x) l_alias[i] = asrc[i];
+		}
+		t.ctx_map = l_map; t.cluster_cfg = l_cfg; t.alias = l_alias; t.log_alpha = log_alpha; t.log_bucket = 12 - log_alpha;
+		__syncthreads();
+		if (active) {
+			const DevSection sec = load_global_pod(sections + (pass * num_groups + g));
+			const uint32_t cell_base = (uint32_t) lf_groups[sec.ggidx].cell_base;
+			status[pass * num_groups + g] = scan ? decode_hf_section_lane<true>(f, t, G, sec, cell_base, block_first, nblocks, l_cols, 64, pass)
+			                                     : decode_hf_section_lane<false>(f, t, G, sec, cell_base, block_first, nblocks, l_cols, 64, pass);
+		}
+	}
+}
+
+// num_work must be a multiple of waves_per_wg, each aligned run of waves_per_wg entries on one frame
+void launch_hf_lanes(const DevPlan *plans, const HfLaneWork *work, int32_t num_work, int32_t waves_per_wg, uint32_t lds_bytes, hipStream_t stream) {
+	if (num_work <= 0) return;
+	static bool configured = false;
+	if (!configured) { (void) hipFuncSetAttribute((const void *) k_hf_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); configured = true; }
+	const uint32_t tables = (lds_bytes + 15u) & ~15u;
+	hipLaunchKernelGGL(k_hf_lanes, dim3((unsigned) (num_work / waves_per_wg)), dim3(64u * (unsigned) waves_per_wg), tables + (uint32_t) waves_per_wg * HF_LANE_COLS_BYTES, stream, plans, work, tables);
+}
+
 // LDS bytes k_hf_entropy_lanes needs for one frame
 uint32_t hf_lanes_lds_bytes(const HfLaunchInfo &info) {
 	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
@@ -220,6 +331,7 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarbl
 	const int32_t dq_size = R * C;
 	const uint16_t *inv_order = f.scan_order_coeffs ? plan.pool_u16 + f.inv_order_off[order_idx * 3] : nullptr;
 	__shared__ VbGeom geom[NB];
+	J40_STAGE_SRGB_THRESHOLDS(f);
 	if (tid < nb) geom[tid] = varblock_geometry(plan, list[first + tid], R, C);
 	__syncthreads();
 
@@ -263,7 +375,7 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarbl
 		const VbGeom &g = geom[b];
 		if (y >= g.effh || x >= g.effw) continue;
 		const float *t = lds + (size_t) b * 3 * TILE + y * P + x;
-		const uint32_t px = xyb_to_rgba8(t[0], t[TILE], t[2 * TILE], f);
+		const uint32_t px = xyb_to_rgba8(t[0], t[TILE], t[2 * TILE], f, srgb_thr);
 		*(uint32_t *) (rgba + (size_t) (g.py + y) * stride_bytes + (size_t) (g.px + x) * 4) = px;
 	}
 }
@@ -281,6 +393,7 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan, const DevV
 	const int32_t first = blockIdx.x * NB;
 	const int32_t nb = min(NB, count - first);
 	__shared__ VbGeom geom[NB];
+	J40_STAGE_SRGB_THRESHOLDS(f);
 	if (tid < nb) geom[tid] = varblock_geometry(plan, list[first + tid], 8, 8);
 	__syncthreads();
 	for (int32_t w = tid; w < nb * 64; w += nthreads) {
@@ -306,7 +419,7 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan, const DevV
 		const VbGeom &g = geom[b];
 		if (y >= g.effh || x >= g.effw) continue;
 		const float *t = tiles + (size_t) b * 3 * P + i;
-		const uint32_t px = xyb_to_rgba8(t[0], t[P], t[2 * P], f);
+		const uint32_t px = xyb_to_rgba8(t[0], t[P], t[2 * P], f, srgb_thr);
 		*(uint32_t *) (rgba + (size_t) (g.py + y) * stride_bytes + (size_t) (g.px + x) * 4) = px;
 	}
 }
@@ -370,6 +483,7 @@ __global__ void __launch_bounds__(256) k_vardct_large(DevPlan plan, const DevVar
 	const int32_t param_idx = vb.dctsel == 21 ? 13 : vb.dctsel <= 23 ? 14 : vb.dctsel == 24 ? 15 : 16;
 	const float *dq = plan.pool_f32 + f.dq_off[param_idx];
 	const uint16_t *inv_order = f.scan_order_coeffs ? plan.pool_u16 + f.inv_order_off[DEV_DCT_SELECT[vb.dctsel][2] * 3] : nullptr;
+	J40_STAGE_SRGB_THRESHOLDS(f);
 	const VbGeom g = varblock_geometry(plan, vb, R, C);
 	float *A = scratch + (size_t) blockIdx.x * 6 * 65536, *B = A + 3 * 65536;  // [3][size] each
 	for (int32_t i = tid; i < size; i += nthreads) {
@@ -386,7 +500,7 @@ __global__ void __launch_bounds__(256) k_vardct_large(DevPlan plan, const DevVar
 	for (int32_t i = tid; i < size; i += nthreads) {
 		const int32_t y = i / C, x = i - y * C;
 		if (y >= g.effh || x >= g.effw) continue;
-		const uint32_t px = xyb_to_rgba8(A[i], A[65536 + i], A[2 * 65536 + i], f);
+		const uint32_t px = xyb_to_rgba8(A[i], A[65536 + i], A[2 * 65536 + i], f, srgb_thr);
 		*(uint32_t *) (rgba + (size_t) (g.py + y) * stride_bytes + (size_t) (g.px + x) * 4) = px;
 	}
 }
@@ -456,10 +570,16 @@ void launch_vardct_class(const DevPlan &plan, int32_t dctsel, const DevVarblock 
 
 // known-answer hook: the renderer's per-sample tail (sRGB transfer + conversion, j40.h:7213-7240 / 7925-7935)
 __global__ void k_kat_srgb_u8(const float *v, size_t n, uint8_t *out) {
+	__shared__ float s_thr[258];
+	for (int32_t i = threadIdx.x; i < 258; i += blockDim.x) s_thr[i] = c_srgb_thr[i];
+	__syncthreads();
 	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	int32_t px = f32_to_i16_x86(255.0f * srgb_transfer(v[i]) + 0.5f);
-	out[i] = (uint8_t) (px < 0 ? 0 : px > 255 ? 255 : px);
+	const float x = v[i];
+	int32_t px;
+	if (x > -9.0f && x < 50000.0f) px = srgb_u8_from_thresholds(x, (const J40_LDS float *) s_thr);   // as xyb_to_rgba8 does for 8-bit frames
+	else { px = f32_to_i16_x86(255.0f * srgb_transfer(x) + 0.5f); px = px < 0 ? 0 : px > 255 ? 255 : px; }
+	out[i] = (uint8_t) px;
 }
 void launch_kat_srgb_u8(const float *v, size_t n, uint8_t *out, hipStream_t stream) {
 	hipLaunchKernelGGL(k_kat_srgb_u8, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, v, n, out);

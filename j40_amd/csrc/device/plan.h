@@ -23,6 +23,9 @@ struct DevCodeSpec {
 	uint32_t cluster_map_off;  // into the u8 pool
 	uint32_t cluster_off;      // into the DevCluster pool
 	uint32_t table_span;       // elements this spec's alias (u64) / prefix (i32) tables occupy in their pool, contiguous
+	// throughput-form K1 (hf_lanes_dev.h), rANS specs without LZ77 and with uniformly sized alias tables only, else
+	// 0xffffffff: one word per cluster in the i32 pool, hybrid config | min(max_token, 0xfffff) << 12
+	uint32_t lane_cfg_off;
 };
 
 struct DevLfGroup {
@@ -48,8 +51,7 @@ struct DevSection {
 struct DevGroupBlock {
 	uint32_t coeffoff_qfidx;  // as j40__varblock (j40.h:6352): coefficient offset | qf index
 	uint16_t pos_dct;         // bits 0-9: y8 * 32 + x8 inside the group; bits 10-14: DctSelect
-	uint8_t lfidx;
-	uint8_t pad;
+	uint16_t bctx3;           // block context (j40.h:6951-6953, < 16) of channel Y | X << 4 | B << 8, looked up on the host
 };
 
 // work item of the coefficients -> pixels kernels, sorted by DctSelect on the host
@@ -105,7 +107,8 @@ struct DevPlan {
 	const float *vb_hfmul_inv;
 	const int16_t *xfromy, *bfromy;
 	// working buffers
-	float *coeffs[3];                // [total cells * 64]
+	float *coeffs[3];                // [total cells * 64]; one allocation: coeffs[c] = coeffs[0] + c * coeff_stride
+	uint32_t coeff_stride;
 	int8_t *nonzeros;                // [num_groups][32 * 32 * 3]
 	int32_t *lz_window;              // [num_groups][lz_window_size] or null
 	uint32_t lz_window_size;
@@ -161,7 +164,8 @@ struct DevModPlan {
 // one wavefront of the throughput-oriented K1: up to 64 consecutive groups of one frame of the batch
 struct HfLaneWork { int32_t frame, first_group, num_groups, pad; };
 
-enum { HF_WAVES = 4 };  // groups (wavefronts) per K1 workgroup
+enum { HF_WAVES = 4 };
+enum { HF_LANE_COLS_BYTES = 3 * 32 * 64 };   // k_hf_lanes: per-wavefront column state of the non-zero-count predictor  // groups (wavefronts) per K1 workgroup
 
 // what the host knows about the entropy tables' sizes, to lay out K1's LDS
 struct HfLaunchInfo {
@@ -170,6 +174,8 @@ struct HfLaunchInfo {
 	uint32_t max_clusters;
 	uint32_t max_table_bytes;    // largest alias / prefix table span over the passes
 	bool tables_fit_lds;
+	bool lanes_fast;             // every pass: rANS without LZ77, and hf_lanes_dev.h's tables fit the LDS budget
+	uint32_t lanes_lds_bytes;    // LDS k_hf_lanes needs for this frame's tables (plus HF_LANE_COLS_BYTES per wavefront)
 };
 
 enum {

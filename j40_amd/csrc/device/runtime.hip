@@ -234,7 +234,12 @@ extern "C" uint32_t j40hip_frame_upload(j40hip_frame *h, int device) {
 	plan.xfromy = st->upload(hp.xfromy.data(), hp.xfromy.size(), s, ok);
 	plan.bfromy = st->upload(hp.bfromy.data(), hp.bfromy.size(), s, ok);
 	st->coeff_floats = hp.coeff_floats;
-	for (int c = 0; c < 3; ++c) plan.coeffs[c] = st->scratch<float>(st->coeff_floats, ok);
+	{   // the three coefficient planes are one allocation (hf_lanes_dev.h addresses a lane's channel by offset)
+		const size_t stride = (st->coeff_floats + 63) & ~(size_t) 63;
+		float *base = st->scratch<float>(3 * stride, ok);
+		for (int c = 0; c < 3; ++c) plan.coeffs[c] = base ? base + (size_t) c * stride : nullptr;
+		plan.coeff_stride = (uint32_t) stride;
+	}
 	const int32_t num_groups = hp.frame.num_groups;
 	plan.nonzeros = st->scratch<int8_t>((size_t) num_groups * 32 * 32 * 3, ok);
 	plan.status = st->scratch<uint32_t>(hp.sections.size(), ok);
@@ -246,7 +251,7 @@ extern "C" uint32_t j40hip_frame_upload(j40hip_frame *h, int device) {
 	memcpy(st->class_start, hp.class_start, sizeof st->class_start);
 	st->d_vb_sorted = st->upload(st->vb_sorted.data(), st->vb_sorted.size(), s, ok);
 	if (hp.max_large) st->d_large_scratch = st->scratch<float>((size_t) hp.max_large * 6 * 65536, ok);
-	upload_constant_tables(half_secants(), afv_basis(), s);
+	upload_constant_tables(half_secants(), afv_basis(), srgb_u8_thresholds(), s);
 	for (auto &e : st->ev) if (hipEventCreate(&e) != hipSuccess) ok = false;
 	if (hipStreamSynchronize(s) != hipSuccess) ok = false;
 	if (!ok) { j40hip_release_device(h); return ERR_GPU; }
@@ -269,7 +274,7 @@ static uint32_t decode_impl(j40hip_frame *h, void *rgba_dev, size_t stride_bytes
 	const Frame &fr = h->frame;
 	const bool whole = st->first_group == 0 && st->num_groups == fr.fh.num_groups;
 	if (ms3) (void) hipEventRecord(st->ev[0], s);
-	for (int c = 0; c < 3; ++c) if (hipMemsetAsync(plan.coeffs[c], 0, sizeof(float) * st->coeff_floats, s) != hipSuccess) return ERR_GPU;
+	if (hipMemsetAsync(plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) plan.coeff_stride, s) != hipSuccess) return ERR_GPU;
 	if (hipMemsetAsync(plan.status, 0, sizeof(uint32_t) * (size_t) st->total_sections, s) != hipSuccess) return ERR_GPU;
 	if (ms3) (void) hipEventRecord(st->ev[1], s);
 	launch_hf_entropy(plan, st->hf, (int32_t) st->first_group, (int32_t) st->num_groups, s);
@@ -302,6 +307,9 @@ struct j40hip_batch {
 	int32_t num_work = 0;
 	bool tables_in_lds = true;
 	uint32_t lds_bytes = 0;
+	int32_t waves_per_wg = 1;
+	bool lanes_fast = true;          // every frame qualifies for k_hf_lanes
+	uint32_t lanes_lds_bytes = 0;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -329,12 +337,24 @@ extern "C" j40hip_batch *j40hip_batch_create(j40hip_frame *const *frames, int64_
 		b->frames.push_back(h);
 		plans.push_back(h->dev->plan);
 		b->tables_in_lds = b->tables_in_lds && h->dev->hf.tables_fit_lds;
-		const int32_t groups = h->frame.fh.num_groups;
-		// sections per wavefront: 64 fills the lanes; fewer lanes per wave buy more waves per SIMD (latency hiding)
-		// when the batch alone cannot fill the chip's wave slots
-		int32_t lanes = 64;
-		if (const char *e = getenv("J40HIP_LANES_PER_WAVE")) lanes = std::max(1, std::min(64, atoi(e)));
-		for (int32_t g = 0; g < groups; g += lanes) work.push_back({(int32_t) i, g, std::min(lanes, groups - g), 0});
+		b->lanes_fast = b->lanes_fast && h->dev->hf.lanes_fast;
+		b->lanes_lds_bytes = std::max(b->lanes_lds_bytes, h->dev->hf.lanes_lds_bytes);
+	}
+	// Launch geometry of the entropy kernel. Sections per wavefront: 64 fills the lanes. Wavefronts per workgroup
+	// share one copy of their frame's tables in LDS: with few wavefronts in the batch, one per workgroup spreads them
+	// over the CUs; with many, sharing keeps the tables from capping the wavefronts a CU can hold.
+	int32_t lanes = 64, total_waves = 0;
+	if (const char *e = getenv("J40HIP_LANES_PER_WAVE")) lanes = std::max(1, std::min(64, atoi(e)));
+	for (j40hip_frame *h : b->frames) total_waves += (h->frame.fh.num_groups + lanes - 1) / lanes;
+	int cus = 256;
+	{ hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, b->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount; }
+	b->waves_per_wg = total_waves <= 2 * cus ? 1 : total_waves <= 4 * cus ? 2 : 4;
+	if (const char *e = getenv("J40HIP_WAVES_PER_WG")) b->waves_per_wg = std::max(1, std::min(4, atoi(e)));
+	for (size_t i = 0; i < b->frames.size(); ++i) {
+		const int32_t groups = b->frames[i]->frame.fh.num_groups;
+		const int32_t exp_same = getenv("J40HIP_EXP_SAME_GROUP") ? 1 : 0;   // timing experiment only (wrong pixels)
+		for (int32_t g = 0; g < groups; g += lanes) work.push_back({(int32_t) i, g, std::min(lanes, groups - g), exp_same});
+		while (work.size() % (size_t) b->waves_per_wg) work.push_back({(int32_t) i, 0, 0, 0});   // a workgroup stays on one frame
 	}
 	for (j40hip_frame *h : b->frames) {
 		HfLaunchInfo info = h->dev->hf; info.tables_fit_lds = b->tables_in_lds;
@@ -357,11 +377,12 @@ static uint32_t batch_decode_impl(j40hip_batch *b, void *const *rgba_dev, const 
 	if (ms3) (void) hipEventRecord(b->ev[0], s);
 	for (j40hip_frame *h : b->frames) {
 		j40hip_device_state *st = h->dev;
-		for (int c = 0; c < 3; ++c) if (hipMemsetAsync(st->plan.coeffs[c], 0, sizeof(float) * st->coeff_floats, s) != hipSuccess) return ERR_GPU;
+		if (hipMemsetAsync(st->plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) st->plan.coeff_stride, s) != hipSuccess) return ERR_GPU;
 		if (hipMemsetAsync(st->plan.status, 0, sizeof(uint32_t) * (size_t) st->total_sections, s) != hipSuccess) return ERR_GPU;
 	}
 	if (ms3) (void) hipEventRecord(b->ev[1], s);
-	launch_hf_entropy_lanes(b->d_plans, b->d_work, b->num_work, b->tables_in_lds, b->lds_bytes, s);
+	if (b->lanes_fast && !getenv("J40HIP_GENERIC_LANES")) launch_hf_lanes(b->d_plans, b->d_work, b->num_work, b->waves_per_wg, b->lanes_lds_bytes, s);
+	else launch_hf_entropy_lanes(b->d_plans, b->d_work, b->num_work, b->tables_in_lds, b->lds_bytes, s);
 	if (ms3) (void) hipEventRecord(b->ev[2], s);
 	for (size_t i = 0; i < b->frames.size(); ++i) {
 		j40hip_device_state *st = b->frames[i]->dev;
@@ -453,7 +474,7 @@ extern "C" uint32_t j40hip_kat_device_srgb_u8(const float *v_host, size_t n, uin
 	float *dv = nullptr; uint8_t *dout = nullptr;
 	bool ok = hipMalloc((void **) &dv, n * 4 + 16) == hipSuccess && hipMalloc((void **) &dout, n + 16) == hipSuccess;
 	ok = ok && hipMemcpy(dv, v_host, n * 4, hipMemcpyHostToDevice) == hipSuccess;
-	if (ok) launch_kat_srgb_u8(dv, n, dout, nullptr);
+	if (ok) { upload_constant_tables(half_secants(), afv_basis(), srgb_u8_thresholds(), nullptr); launch_kat_srgb_u8(dv, n, dout, nullptr); }
 	ok = ok && hipMemcpy(out_host, dout, n, hipMemcpyDeviceToHost) == hipSuccess;
 	if (dv) (void) hipFree(dv);
 	if (dout) (void) hipFree(dout);

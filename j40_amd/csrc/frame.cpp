@@ -662,7 +662,13 @@ void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
 	J40HIP_SHOULD(f->fh.is_last, "TODO");
 	J40HIP_SHOULD(f->fh.type == 0, "TODO");
 	read_toc(br, f->fh, &f->toc);
-	J40HIP_SHOULD(f->toc.end_offset <= cs_size, "shrt");
+	{   // a truncated codestream fails where the reference fails: in the first section (in reading order) that
+		// needs the missing bytes, not up front. Sections are clipped to the bytes that exist; readers raise "shrt".
+		auto clip = [cs_size](Section &s) { if (s.offset >= cs_size) { s.offset = cs_size; s.size = 0; } else s.size = std::min(s.size, cs_size - s.offset); };
+		clip(f->toc.single_section); clip(f->toc.lf_global); clip(f->toc.hf_global);
+		for (Section &s : f->toc.lf_groups) clip(s);
+		for (Section &s : f->toc.pass_groups) clip(s);
+	}
 	allocate_lf_groups(f);
 
 	if (f->toc.single) {

@@ -13,7 +13,9 @@ void flatten_code_spec(const CodeSpec &spec, std::vector<uint8_t> &u8, std::vect
 	out->min_symbol = spec.min_symbol; out->min_length = spec.min_length;
 	out->log_alpha_size = spec.log_alpha_size;
 	out->lz_len_cfg = spec.lz_len_cfg.packed(); out->lz_len_max_token = spec.lz_len_cfg.max_token;
+	while (u8.size() & 3) u8.push_back(0);   // kernels stage the map with 32-bit copies
 	out->cluster_map_off = push(u8, spec.cluster_map.data(), spec.cluster_map.size());
+	while (u8.size() & 3) u8.push_back(0);
 	out->cluster_off = (uint32_t) clusters.size();
 	const size_t span0 = spec.use_prefix_code ? i32.size() : u64.size();
 	for (const Cluster &c : spec.clusters) {
@@ -24,6 +26,14 @@ void flatten_code_spec(const CodeSpec &spec, std::vector<uint8_t> &u8, std::vect
 		clusters.push_back(d);
 	}
 	out->table_span = (uint32_t) ((spec.use_prefix_code ? i32.size() : u64.size()) - span0);
+	out->lane_cfg_off = 0xffffffffu;
+	bool uniform = !spec.use_prefix_code && !spec.lz77_enabled && spec.num_clusters <= 256;
+	for (const Cluster &c : spec.clusters) uniform = uniform && c.alias.size() == ((size_t) 1 << spec.log_alpha_size);
+	if (uniform) {   // hf_lanes_dev.h; tokens are < 256, so clamping max_token keeps `token > max_token` intact
+		std::vector<int32_t> cfg;
+		for (const Cluster &c : spec.clusters) cfg.push_back((int32_t) (c.cfg.packed() | ((uint32_t) std::min(c.cfg.max_token, 0xfffff) << 12)));
+		out->lane_cfg_off = push(i32, cfg.data(), cfg.size());
+	}
 }
 
 void coeffs_scan_to_canonical(const Frame &fr, size_t ggidx, int c, float *data) {
@@ -140,7 +150,13 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 			DevGroupBlock gb;
 			gb.coeffoff_qfidx = (uint32_t) gg.varblocks[(size_t) (blk & 0xfffff)].coeffoff_qfidx;
 			gb.pos_dct = (uint16_t) ((y8 * 32 + x8) | (((blk >> 20) - 2) << 10));
-			gb.lfidx = gg.lfindices[cell]; gb.pad = 0;
+			{   // block context per channel: block_ctx_map[(c_yxb * 13 + order) * (nb_qf_thr + 1) + qfidx) * lfidx_size + lfidx]
+				const int32_t dctsel = (blk >> 20) - 2, nb_qf1 = fr.nb_qf_thr + 1, lfidx_size = df.lfidx_size;
+				const int32_t bctx0 = (DCT_SELECT[dctsel].order_idx * nb_qf1 + (int32_t) (gb.coeffoff_qfidx & 15u)) * lfidx_size + gg.lfindices[cell];
+				uint32_t v = 0;
+				for (int32_t c_yxb = 0; c_yxb < 3; ++c_yxb) v |= (uint32_t) (fr.block_ctx_map[(size_t) (bctx0 + 13 * nb_qf1 * lfidx_size * c_yxb)] & 15) << (4 * c_yxb);
+				gb.bctx3 = (uint16_t) v;
+			}
 			hp->group_blocks.push_back(gb);
 		}
 	}
@@ -176,6 +192,16 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 		const uint32_t per_wave = 32 * 32 * 3 + 1024 * (uint32_t) sizeof(DevGroupBlock) + 16;
 		const uint32_t fixed = hf.block_ctx_size + 256 + 64 + HF_WAVES * per_wave;
 		hf.tables_fit_lds = fixed + hf.max_num_dist + hf.max_clusters * (uint32_t) sizeof(DevCluster) + hf.max_table_bytes + 64 <= 150u * 1024u;
+	}
+	{
+		auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+		hf.lanes_fast = true; hf.lanes_lds_bytes = 0;
+		for (const DevCodeSpec &sp : hp->coeff_specs) {
+			hf.lanes_fast = hf.lanes_fast && sp.lane_cfg_off != 0xffffffffu;
+			const uint32_t n = 128 + 64 + 112 + align16((uint32_t) sp.num_dist) + align16(4u * (uint32_t) sp.num_clusters) + 8u * ((uint32_t) sp.num_clusters << sp.log_alpha_size);
+			hf.lanes_lds_bytes = std::max(hf.lanes_lds_bytes, n);
+		}
+		hf.lanes_fast = hf.lanes_fast && hf.lanes_lds_bytes + 4u * HF_LANE_COLS_BYTES <= 156u * 1024u && hp->coeff_floats * 3 * sizeof(float) < 0xffffffffull;
 	}
 	hp->max_large = 0;
 	for (int d = 21; d < 27; ++d) hp->max_large = std::max(hp->max_large, hp->class_start[d + 1] - hp->class_start[d]);

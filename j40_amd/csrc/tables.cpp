@@ -74,6 +74,31 @@ static const float AFV_BASIS_TABLE[256] = {
 };
 const float *afv_basis() { return AFV_BASIS_TABLE; }
 
+// thr[k] = smallest float v in (-9, 50000) whose 8-bit sample (j40.h:7213-7240 then 7925-7935 with bpp = 8) is >= k
+const float *srgb_u8_thresholds() {
+	static float table[258];
+	static std::once_flag once;
+	std::call_once(once, []() {
+		auto sample = [](float v) -> int {   // the reference's arithmetic with a correctly rounded powf
+			float t = v <= 0.0031308f ? 12.92f * v : 1.055f * (float) pow((double) v, (double) (1.0f / 2.4f)) - 0.055f;
+			const float y = 255.0f * t + 0.5f;
+			int32_t i = !(y > -2147483904.0f && y < 2147483648.0f) ? (int32_t) 0x80000000u : (int32_t) y;
+			i = (int32_t) (int16_t) (uint16_t) (uint32_t) i;
+			return i < 0 ? 0 : i > 255 ? 255 : i;
+		};
+		// positive floats order like their bit patterns; every threshold is positive (sample(0) = 0)
+		auto from_bits = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+		uint32_t top; { const float t = 50000.0f; memcpy(&top, &t, 4); }
+		table[0] = -INFINITY; table[256] = table[257] = INFINITY;
+		for (int k = 1; k <= 255; ++k) {
+			uint32_t lo = 0, hi = top;   // sample(lo) < k <= sample(hi)
+			while (hi - lo > 1) { const uint32_t mid = lo + (hi - lo) / 2; if (sample(from_bits(mid)) >= k) hi = mid; else lo = mid; }
+			table[k] = from_bits(hi);
+		}
+	});
+	return table;
+}
+
 // ------------------------------------------------------------------------------------------------
 // default ("library") dequantisation parameters, ISO 18181-1 with the corrections the reference
 // applies (j40.h:4630-4690). Stored per parameter set as rows of {X, Y, B}.

@@ -9,6 +9,7 @@
 #include "../../j40_amd/csrc/plan_build.hpp"
 #include "../../j40_amd/csrc/tables.hpp"
 #include "../../j40_amd/csrc/device/hf_dev.h"
+#include "../../j40_amd/csrc/device/hf_lanes_dev.h"
 #include "../../j40_amd/csrc/device/vardct_dev.h"
 #include "../../j40_amd/csrc/device/modular_dev.h"
 
@@ -162,8 +163,8 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 	} catch (const DecodeError &e) { return e.code; }
 	if (fr.fh.is_modular) return hostsim_decode_modular(fr, cs, cs_size, rgba);
 	if (uint32_t e = build_vardct_plan(fr, cs, cs_size, &hp)) return e;
-	std::vector<float> coeffs[3];
-	for (int c = 0; c < 3; ++c) coeffs[c].assign(hp.coeff_floats, 0.0f);
+	std::vector<float> coeff_store(3 * hp.coeff_floats, 0.0f);   // one allocation, plane c at c * coeff_floats (as on the device)
+	float *coeffs[3] = {coeff_store.data(), coeff_store.data() + hp.coeff_floats, coeff_store.data() + 2 * hp.coeff_floats};
 	std::vector<int8_t> nonzeros((size_t) hp.frame.num_groups * 32 * 32 * 3);
 	std::vector<uint32_t> status(hp.sections.size(), 0);
 	std::vector<int32_t> window(hp.lz_window_size ? (size_t) hp.frame.num_groups * hp.lz_window_size : 0);
@@ -175,16 +176,41 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 	plan.block_ctx_map_off = hp.block_ctx_map_off;
 	plan.group_blocks = hp.group_blocks.data(); plan.group_block_start = hp.group_block_start.data();
 	plan.blocks = hp.blocks.data(); plan.lfindices = hp.lfindices.data();
-	for (int c = 0; c < 3; ++c) { plan.llf[c] = hp.llf[c].data(); plan.coeffs[c] = coeffs[c].data(); }
+	for (int c = 0; c < 3; ++c) { plan.llf[c] = hp.llf[c].data(); plan.coeffs[c] = coeffs[c]; }
+	plan.coeff_stride = (uint32_t) hp.coeff_floats;
 	plan.vb_coeffoff_qfidx = hp.vb_coeffoff_qfidx.data(); plan.vb_hfmul_inv = hp.vb_hfmul_inv.data();
 	plan.xfromy = hp.xfromy.data(); plan.bfromy = hp.bfromy.data();
 	plan.nonzeros = nonzeros.data(); plan.status = status.data();
 	plan.lz_window = window.empty() ? nullptr : window.data(); plan.lz_window_size = hp.lz_window_size;
 
+	if (only_entropy & 4) {   // bit 2: the throughput kernel's fast path (hf_lanes_dev.h), tables laid out as the kernel stages them
+		if (!hp.hf.lanes_fast) return ERR_TODO;
+		const DevFrame &df = hp.frame;
+		LaneFrame lf = {df.nb_block_ctx, df.num_hf_presets, df.preset_bits, df.order_off};
+		LaneGlobals G = {plan.codestream, (const uint32_t *) plan.group_blocks, plan.coeffs[0], plan.pool_u16, plan.coeff_stride};
+		std::vector<int8_t> cols(3 * 32);
+		std::vector<uint32_t> dct(27);
+		for (int d = 0; d < 27; ++d) dct[(size_t) d] = (uint32_t) DEV_DCT_SELECT[d][0] | ((uint32_t) DEV_DCT_SELECT[d][1] << 8) | ((uint32_t) DEV_DCT_SELECT[d][2] << 16);
+		for (int32_t pass = 0; pass < df.num_passes; ++pass) {
+			const DevCodeSpec &spec = hp.coeff_specs[(size_t) pass];
+			LaneTables t;
+			t.ctx_map = plan.pool_u8 + spec.cluster_map_off; t.cluster_cfg = (const uint32_t *) (plan.pool_i32 + spec.lane_cfg_off);
+			t.alias = plan.pool_u64 + plan.clusters[spec.cluster_off].table_off;
+			t.nnz_ctx2 = DEV_NNZ_CTX2; t.freq_ctx2 = DEV_FREQ_CTX2; t.dct_info = dct.data();
+			t.log_alpha = spec.log_alpha_size; t.log_bucket = 12 - spec.log_alpha_size;
+			for (int32_t g = 0; g < df.num_groups; ++g) {
+				const DevSection &sec = plan.sections[pass * df.num_groups + g];
+				const uint32_t b0 = plan.group_block_start[g], b1 = plan.group_block_start[g + 1];
+				const uint32_t cell_base = (uint32_t) plan.lf_groups[sec.ggidx].cell_base;
+				status[(size_t) (pass * df.num_groups + g)] = df.scan_order_coeffs ? decode_hf_section_lane<true>(lf, t, G, sec, cell_base, b0, (int32_t) (b1 - b0), cols.data(), 1, pass)
+					: decode_hf_section_lane<false>(lf, t, G, sec, cell_base, b0, (int32_t) (b1 - b0), cols.data(), 1, pass);
+			}
+		}
+	} else
 	for (int32_t g = 0; g < hp.frame.num_groups; ++g) decode_hf_group(plan, g, (only_entropy & 2) != 0);  // bit 1: flat (per-lane) decoder
 	if (coeffs_out) for (int c = 0; c < 3; ++c) {
 		float *dst = coeffs_out + (size_t) c * hp.coeff_floats;
-		memcpy(dst, coeffs[c].data(), sizeof(float) * hp.coeff_floats);
+		memcpy(dst, coeffs[c], sizeof(float) * hp.coeff_floats);
 		for (size_t gg = 0; gg < fr.lf_groups.size(); ++gg) coeffs_scan_to_canonical(fr, gg, c, dst + (size_t) hp.lf_groups[gg].cell_base * 64);
 	}
 	for (uint32_t s : status) if (s) return s;
@@ -222,7 +248,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 			} else { idct_rows_dyn(t, C, R, P, hs); idct_cols_dyn(t, R, C, P, hs); }
 		}
 		for (int y = 0; y < g.effh; ++y) for (int x = 0; x < g.effw; ++x) {
-			const uint32_t px = xyb_to_rgba8(A[y * P + x], A[65536 + y * P + x], A[2 * 65536 + y * P + x], f);
+			const uint32_t px = xyb_to_rgba8(A[y * P + x], A[65536 + y * P + x], A[2 * 65536 + y * P + x], f, f.bpp == 8 ? srgb_u8_thresholds() : nullptr);
 			memcpy(rgba + (size_t) (g.py + y) * stride + (size_t) (g.px + x) * 4, &px, 4);
 		}
 	}
@@ -252,8 +278,10 @@ extern "C" __attribute__((visibility("default"))) uint64_t hostsim_srgb_u8_sweep
 		float v; memcpy(&v, &bits, 4);
 		const float a = srgb_transfer(v);
 		const float b = v <= 0.0031308f ? 12.92f * v : 1.055f * (float) pow((double) v, P) - 0.055f;
-		const int32_t pa = f32_to_i16_x86(255.0f * a + 0.5f), pb = f32_to_i16_x86(255.0f * b + 0.5f);
+		int32_t pa = f32_to_i16_x86(255.0f * a + 0.5f), pb = f32_to_i16_x86(255.0f * b + 0.5f);
+		pa = pa < 0 ? 0 : pa > 255 ? 255 : pa; pb = pb < 0 ? 0 : pb > 255 ? 255 : pb;
 		bad += pa != pb;
+		if (v > -9.0f && v < 50000.0f) bad += srgb_u8_from_thresholds(v, srgb_u8_thresholds()) != pb;   // the table path of the pixel kernels
 	}
 	return bad;
 }

@@ -53,6 +53,13 @@ def test_flat_lane_decoder_matches_nested_decoder(sim, name, opts):
     assert sim.hostsim_decode(buf, len(data), rgba.ctypes.data, a.ctypes.data, 1) == 0
     assert sim.hostsim_decode(buf, len(data), rgba.ctypes.data, b.ctypes.data, 3) == 0
     assert np.array_equal(a, b) and np.abs(a).sum() > 0
+    # the rANS / no-LZ77 fast path of the throughput kernel (hf_lanes_dev.h); other specs report TODO and take the flat decoder
+    c = np.zeros((3, n), np.float32)
+    err = sim.hostsim_decode(buf, len(data), rgba.ctypes.data, c.ctypes.data, 5)
+    if opts.get("prefix") or opts.get("lz77"):
+        assert err == 0x544F444F
+    else:
+        assert err == 0 and np.array_equal(a, c)
 
 
 @pytest.mark.parametrize("name,w,h,opts", MODULAR_CASES)
@@ -82,3 +89,30 @@ def test_srgb_power_function_is_correctly_rounded(sim):
     bad = sim.hostsim_pow_sweep(bits(2.0 ** -9), bits(3.0e38), 4099, C.byref(worst))
     assert bad <= 2, "x = %r" % worst.value
     assert sim.hostsim_srgb_u8_sweep(bits(1e-6), bits(300.0), 13) == 0
+
+
+def test_lane_decoder_reports_the_same_errors_on_corrupt_streams(sim, ref):
+    """bit flips in the pass-group sections: the throughput decoder (hf_lanes_dev.h), the nested decoder and the
+    reference agree on the 4-char code (or on success)"""
+    rng = np.random.default_rng(11)
+    data = synth("vardct", 392, 264, 35)
+    n = 392 * 264 * 64 // 16
+    a = np.zeros((3, n), np.float32); rgba = np.zeros((264, 392, 4), np.uint8)
+    seen = set()
+    for trial in range(60):
+        bad = bytearray(data)
+        lo = len(bad) // 3   # past the headers and LF sections: the HF sections make up the tail
+        for _ in range(1 + trial % 3):
+            pos = int(rng.integers(lo, len(bad)))
+            bad[pos] ^= 1 << int(rng.integers(0, 8))
+        if trial % 7 == 0:
+            bad = bad[:len(bad) - 1 - trial]   # truncated last section
+        buf = C.create_string_buffer(bytes(bad), len(bad))
+        e1 = sim.hostsim_decode(buf, len(bad), rgba.ctypes.data, a.ctypes.data, 1)
+        e2 = sim.hostsim_decode(buf, len(bad), rgba.ctypes.data, a.ctypes.data, 5)
+        assert e1 == e2, (trial, hex(e1), hex(e2))
+        rerr, _ = ref.decode(bytes(bad))
+        code = "".join(chr((e1 >> s) & 255) for s in (24, 16, 8, 0)) if e1 else ""
+        assert code == rerr, (trial, code, rerr)
+        seen.add(code)
+    assert len(seen) >= 3, seen
