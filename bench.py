@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- Mpixels/s RGBA-u8x4 decode of a synthetic 8K VarDCT (d1-like) frame on MI355X.
 
-A *step* is one pass of the hot path over one frame whose inputs (codestream, code specs, orders,
-dequant tables, LF bundle) are already resident in HBM: coefficient clear + entropy decode of every
-pass-group section (K1) + dequant / chroma-from-luma / inverse transforms / XYB->sRGB / RGBA pack
-(K2 family). Output stays in HBM. Host parsing and PCIe copies are outside the timed region and
-reported separately (`e2e_*` fields).
+A *step* is one pass of the hot path over one batch of frames (`--batch`, default 128 per GPU) whose inputs
+(codestreams, code specs, orders, dequant tables, LF bundles) are already resident in HBM: coefficient clear +
+entropy decode of every pass-group section (K1) + dequant / chroma-from-luma / inverse transforms /
+XYB->sRGB / RGBA pack (K2 family). Outputs stay in HBM. Host parsing and PCIe copies are outside the timed
+region. Two launch modes exist: the throughput mode (default; one section per wavefront LANE, every frame of the
+batch in one entropy launch -- 288 GB of HBM hold the working sets of hundreds of 8K frames) and the latency
+mode (`--batch 1`; one section per wavefront, scalarised decoder; reports `e2e_*` fields for a single frame).
+The default run also times one frame in latency mode and reports it as `latency_mode`.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): frames are independent units, so every
 rank decodes its own frame (weak scaling, no data-path collective); `value` is the whole-job
@@ -51,13 +54,14 @@ def cpu_baseline(data, width, height, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=7680)
     ap.add_argument("--height", type=int, default=4320)
     ap.add_argument("--seed", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1, help="frames per step per GPU; > 1 uses the throughput mode (j40hip_batch_*: one section per lane)")
+    ap.add_argument("--batch", type=int, default=128, help="frames per step per GPU; > 1 uses the throughput mode (j40hip_batch_*: one section per lane), 1 the latency mode")
     ap.add_argument("--distinct", type=int, default=4, help="number of distinct streams a batch cycles through")
+    ap.add_argument("--streams", type=int, default=1, help="throughput mode: sub-batches in flight on separate HIP streams")
     ap.add_argument("--shard-groups", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -162,9 +166,10 @@ def main():
 
 
 def bench_batch(args, torch, j40_amd, synth, dist, dev, rank, local_rank, world, frame0, data0, out0):
-    """throughput mode: `--batch` frames per step, one entropy launch for all of them"""
-    W, H, B = args.width, args.height, args.batch
-    sptr = torch.cuda.current_stream(dev).cuda_stream
+    """throughput mode. A step decodes `--batch` frames; they are organised as `--streams` sub-batches, each with its
+    own HIP stream, launched back to back so that one sub-batch's entropy kernel (latency bound, few issue slots)
+    overlaps the pixel kernels (VALU bound) of another. Every launch is measured with HIP events on its own stream."""
+    W, H, B, S = args.width, args.height, args.batch, max(1, min(args.streams, args.batch))
     datas = [data0] + [synth("vardct", W, H, args.seed + 1000 * (i + 1) + rank) for i in range(min(args.distinct, B) - 1)]
     frames, outs = [frame0], [out0]
     for i in range(1, B):
@@ -172,27 +177,36 @@ def bench_batch(args, torch, j40_amd, synth, dist, dev, rank, local_rank, world,
         fr.upload(local_rank)
         frames.append(fr)
         outs.append(torch.empty((H, W, 4), dtype=torch.uint8, device=dev))
-    batch = j40_amd.Batch(frames)
-    ptrs, strides = [o.data_ptr() for o in outs], [W * 4] * B
-    for _ in range(max(args.warmup, 1)):
-        batch.decode(ptrs, strides, sptr)
+    subs = []
+    for k in range(S):
+        idx = list(range(k, B, S))
+        subs.append({"batch": j40_amd.Batch([frames[i] for i in idx]), "ptrs": [outs[i].data_ptr() for i in idx], "strides": [W * 4] * len(idx),
+                     "stream": torch.cuda.Stream(device=dev), "n": len(idx)})
+    main = torch.cuda.current_stream(dev)
+
+    def run_step(slot, stagger=False):
+        for k, sb in enumerate(subs):
+            if stagger and k > 0:   # start one entropy launch behind the previous sub-batch: from then on the streams stay out of phase
+                subs[k - 1]["batch"].wait_stage(slot, 2, sb["stream"].cuda_stream)
+            sb["batch"].decode_recorded(sb["ptrs"], sb["strides"], sb["stream"].cuda_stream, slot)
+
+    for w in range(max(args.warmup, 1)):
+        run_step(0, stagger=(w == 0))
     torch.cuda.synchronize(dev)
     for fr in frames:
         assert fr.status() == "", "decode error: " + fr.status()
     # the batch path must give the pixels of the single-frame path
     check = torch.empty_like(out0)
-    frame0.decode(check.data_ptr(), W * 4, sptr)
+    frame0.decode(check.data_ptr(), W * 4, main.cuda_stream)
     torch.cuda.synchronize(dev)
     assert torch.equal(check, out0) or os.environ.get("J40HIP_EXP_SAME_GROUP"), "batch and single-frame decodes differ"
     del check
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
-    k1_ms, k2_ms, misc_ms = [], [], []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        a, b, c = batch.decode_timed(ptrs, strides, sptr)
-        k1_ms.append(a); k2_ms.append(b); misc_ms.append(c)
+    for step in range(args.steps):
+        run_step(step)
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
@@ -201,24 +215,47 @@ def bench_batch(args, torch, j40_amd, synth, dist, dev, rank, local_rank, world,
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    for fr in frames:
+        assert fr.status() == "", "decode error: " + fr.status()
     if rank != 0:
         return
+    # dominant kernel: the entropy launch of a sub-batch; average duration and algorithmic bytes per launch
+    k1_ms, k2_ms, misc_ms = [], [], []
+    for step in range(args.steps):
+        for sb in subs:
+            a, b_, c = sb["batch"].elapsed(step)
+            k1_ms.append(a); k2_ms.append(b_); misc_ms.append(c)
     value = W * H * B * args.steps * world / elapsed / 1e6
-    alg_bytes = sum(4 * W * H + len(datas[i % len(datas)]) for i in range(B))
+    alg_total = sum(4 * W * H + len(datas[i % len(datas)]) for i in range(B))
+    alg_per_launch = alg_total / S
     k1 = sum(k1_ms) / len(k1_ms) / 1e3
-    achieved = alg_bytes / k1 / 1e9
+    achieved = alg_per_launch / k1 / 1e9
     result = {
         "metric": "Mpixels/s RGBA-u8x4 decode, 8K VarDCT d1",
         "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%d x %dx%d VarDCT d1-like synthetic frames per GPU per step (tools/jxlsynth, %d distinct streams, %.3f bpp, %d pass groups each), throughput mode, inputs resident in HBM"
-                               % (B, W, H, len(datas), 8.0 * len(data0) / (W * H), frame0.info["num_groups"]),
-                   "frame_pixels": W * H, "frames_per_step": B, "codestream_bytes": len(data0), "parallelism": "frames x%d" % world},
+        "config": {"workload": "%d x %dx%d VarDCT d1-like synthetic frames per GPU per step (tools/jxlsynth, %d distinct streams, %.3f bpp, %d pass groups each), throughput mode: %d sub-batches on their own HIP streams, inputs resident in HBM"
+                               % (B, W, H, len(datas), 8.0 * len(data0) / (W * H), frame0.info["num_groups"], S),
+                   "frame_pixels": W * H, "frames_per_step": B, "streams": S, "codestream_bytes": len(data0), "parallelism": "frames x%d" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": None,
-                     "kernel": "k_hf_entropy_lanes", "kernel_ms": round(k1 * 1e3, 4), "algorithmic_bytes_per_launch": alg_bytes},
-        "kernels_ms": {"k_hf_entropy_lanes": round(k1 * 1e3, 4), "vardct_to_rgba_kernels": round(sum(k2_ms) / len(k2_ms), 4), "clear_coefficients": round(sum(misc_ms) / len(misc_ms), 4)},
+                     "kernel": "k_hf_lanes", "kernel_ms": round(k1 * 1e3, 4), "launches_per_step": S, "algorithmic_bytes_per_launch": int(alg_per_launch)},
+        "kernels_ms": {"k_hf_lanes (per launch, %d frames)" % subs[0]["n"]: round(k1 * 1e3, 4), "vardct_to_rgba_kernels (per sub-batch)": round(sum(k2_ms) / len(k2_ms), 4),
+                       "clear_coefficients (per sub-batch)": round(sum(misc_ms) / len(misc_ms), 4)},
     }
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure comes from the
+    # committed rocprofv3 passes of this same command (profiles/pmc_traffic.json) and is only reported for a matching launch
+    try:
+        pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if pt.get("frames_per_launch") == subs[0]["n"] and (W, H) == (7680, 4320):
+            result["roofline"]["traffic"] = int((pt["fetch_size_kb"] + pt["write_size_kb"]) * 1000)
+            result["roofline"]["traffic_source"] = pt["source"]
+    except (OSError, ValueError, KeyError):
+        pass
+    # the same frame alone, latency mode (one section per wavefront)
+    lat = [frame0.decode_timed(out0.data_ptr(), W * 4, main.cuda_stream) for _ in range(3)]
+    result["latency_mode"] = {"frame_ms": round(float(min(sum(map(float, m)) for m in lat)), 3), "k_hf_entropy_ms": round(float(min(float(m[0]) for m in lat)), 3),
+                              "mpixels_per_s": round(W * H / min(sum(map(float, m)) for m in lat) / 1e3, 1)}
     if not args.no_cpu_baseline:
         cb = cpu_baseline(data0, W, H)
         if cb:

@@ -181,6 +181,13 @@ J40HIP_API void j40hip_batch_free(j40hip_batch *b);
 J40HIP_API uint32_t j40hip_batch_decode(j40hip_batch *b, void *const *rgba_dev, const size_t *stride_bytes, void *stream);
 /* ms3 as j40hip_frame_decode_timed, for the whole batch */
 J40HIP_API uint32_t j40hip_batch_decode_timed(j40hip_batch *b, void *const *rgba_dev, const size_t *stride_bytes, void *stream, float *ms3);
+/* asynchronous timed decode: records the stage events in `slot` (0..4095) and returns without waiting, so that
+ * batches on different streams overlap (one batch's entropy kernel with another's pixel kernels);
+ * j40hip_batch_elapsed reads a slot's ms3 once its stream has been synchronised */
+J40HIP_API uint32_t j40hip_batch_decode_recorded(j40hip_batch *b, void *const *rgba_dev, const size_t *stride_bytes, void *stream, int32_t slot);
+J40HIP_API uint32_t j40hip_batch_elapsed(j40hip_batch *b, int32_t slot, float *ms3);
+/* `stream` waits for stage 1 (cleared), 2 (entropy decoded) or 3 (pixels written) of the decode recorded in `slot` */
+J40HIP_API uint32_t j40hip_batch_wait_stage(j40hip_batch *b, int32_t slot, int32_t stage, void *stream);
 
 #ifdef __cplusplus
 }

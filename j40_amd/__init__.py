@@ -88,6 +88,7 @@ def lib():
         "j40hip_kat_device_srgb_u8": (u32, [vp, sz, vp]),
         "j40hip_batch_create": (vp, [vp, i64, C.POINTER(u32)]), "j40hip_batch_free": (None, [vp]),
         "j40hip_batch_decode": (u32, [vp, vp, vp, vp]), "j40hip_batch_decode_timed": (u32, [vp, vp, vp, vp, vp]),
+        "j40hip_batch_decode_recorded": (u32, [vp, vp, vp, vp, i32]), "j40hip_batch_elapsed": (u32, [vp, i32, vp]), "j40hip_batch_wait_stage": (u32, [vp, i32, i32, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)  # AttributeError = the library does not export what include/*.h declares
@@ -310,6 +311,26 @@ class Batch:
         code = lib().j40hip_batch_decode(self.h, p, s, stream)
         if code:
             raise J40Error(err4(code), "in j40hip_batch_decode")
+
+    def decode_recorded(self, rgba_ptrs, strides, stream, slot):
+        """asynchronous: stage events go to `slot`; read them with elapsed(slot) after synchronising the stream"""
+        p, s = self._args(rgba_ptrs, strides)
+        code = lib().j40hip_batch_decode_recorded(self.h, p, s, stream, slot)
+        if code:
+            raise J40Error(err4(code), "in j40hip_batch_decode_recorded")
+
+    def wait_stage(self, slot, stage, stream):
+        """`stream` waits for stage 1 (cleared) / 2 (entropy decoded) / 3 (pixels written) of the decode recorded in `slot`"""
+        code = lib().j40hip_batch_wait_stage(self.h, slot, stage, stream)
+        if code:
+            raise J40Error(err4(code), "in j40hip_batch_wait_stage")
+
+    def elapsed(self, slot):
+        ms = (C.c_float * 3)()
+        code = lib().j40hip_batch_elapsed(self.h, slot, ms)
+        if code:
+            raise J40Error(err4(code), "in j40hip_batch_elapsed")
+        return ms[0], ms[1], ms[2]
 
     def decode_timed(self, rgba_ptrs, strides, stream=0):
         """returns (entropy ms, pixels ms, clear ms) measured with HIP events on `stream`"""

@@ -269,9 +269,38 @@ J40_DEV int32_t srgb_u8_from_thresholds(float v, const J40_LDS float *thr) {
 	return k;
 }
 
+// the long way for one linear value: transfer curve, conversion with the reference's int16 quirk, clamp, scaling to 8 bits
+// (j40.h:7213-7240, 7925-7935). Kept out of line: the pixel kernels almost never need it (8-bit frames, values inside
+// (-9, 50000)), and inlined it bloats their inner loops.
+#ifdef __HIPCC__
+__device__ __attribute__((noinline))
+#else
+static inline
+#endif
+int32_t srgb_sample_slow(float v, int32_t bpp) {
+	const int32_t maxpixel = (1 << bpp) - 1, maxpixel2 = 1 << (bpp - 1);
+	int32_t px = f32_to_i16_x86((float) maxpixel * srgb_transfer(v) + 0.5f);
+	px = px < 0 ? 0 : px > maxpixel ? maxpixel : px;
+	return (px * 255 + maxpixel2) / maxpixel;
+}
+
+// the frame constants of the colour conversion, copied out of DevFrame once per kernel so that they live in (scalar)
+// registers instead of being re-read from memory after every pixel store
+struct ColourConsts {
+	float cbrt_opsin_bias[3], opsin_bias[3], itscale, m[9];
+	int32_t bpp;
+};
+J40_DEV ColourConsts load_colour_consts(const DevFrame &f) {
+	ColourConsts c;
+	for (int i = 0; i < 3; ++i) { c.cbrt_opsin_bias[i] = f.cbrt_opsin_bias[i]; c.opsin_bias[i] = f.opsin_bias[i]; }
+	for (int i = 0; i < 9; ++i) c.m[i] = f.opsin_inv_mat[i];
+	c.itscale = f.itscale; c.bpp = f.bpp;
+	return c;
+}
+
 // returns RGBA packed little-endian (R in the low byte), alpha = 255. thr: threshold table for 8-bit frames
-// (see above) or nullptr for the long way.
-J40_DEV uint32_t xyb_to_rgba8(float sx, float sy, float sb, const DevFrame &f, const J40_LDS float *thr = nullptr) {
+// (see above) or nullptr for the long way. XYB -> linear RGB: j40.h:7208-7212.
+J40_DEV uint32_t xyb_to_rgba8(float sx, float sy, float sb, const ColourConsts &f, const J40_LDS float *thr) {
 	float p[3] = {sy + sx, sy - sx, sb};
 	float s[3];
 #pragma unroll
@@ -279,22 +308,19 @@ J40_DEV uint32_t xyb_to_rgba8(float sx, float sy, float sb, const DevFrame &f, c
 		const float pp = p[c] - f.cbrt_opsin_bias[c];
 		s[c] = (pp * pp * pp + f.opsin_bias[c]) * f.itscale;
 	}
-	const int32_t maxpixel = (1 << f.bpp) - 1, maxpixel2 = 1 << (f.bpp - 1);
-	const float fmax = (float) maxpixel;
 	uint32_t out = 0xff000000u;
 #pragma unroll
 	for (int c = 0; c < 3; ++c) {
-		const float v = s[0] * f.opsin_inv_mat[c * 3] + s[1] * f.opsin_inv_mat[c * 3 + 1] + s[2] * f.opsin_inv_mat[c * 3 + 2];
+		const float v = s[0] * f.m[c * 3] + s[1] * f.m[c * 3 + 1] + s[2] * f.m[c * 3 + 2];
 		int32_t px;
 		if (thr && v > -9.0f && v < 50000.0f) px = srgb_u8_from_thresholds(v, thr);
-		else {
-			px = f32_to_i16_x86(fmax * srgb_transfer(v) + 0.5f);
-			px = px < 0 ? 0 : px > maxpixel ? maxpixel : px;
-			px = (px * 255 + maxpixel2) / maxpixel;
-		}
+		else px = srgb_sample_slow(v, f.bpp);
 		out |= (uint32_t) px << (8 * c);
 	}
 	return out;
+}
+J40_DEV uint32_t xyb_to_rgba8(float sx, float sy, float sb, const DevFrame &f, const J40_LDS float *thr = nullptr) {
+	return xyb_to_rgba8(sx, sy, sb, load_colour_consts(f), thr);
 }
 
 // host: the sample the long way, for one linear value of an 8-bit frame (table construction and tests)

@@ -329,22 +329,65 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarbl
 	const int32_t nb = min(NB, count - first);
 	const float *dq = plan.pool_f32 + f.dq_off[param_idx];
 	const int32_t dq_size = R * C;
+	const ColourConsts cc = load_colour_consts(f);
+	const float qbias0 = f.quant_bias[0], qbias1 = f.quant_bias[1], qbias2 = f.quant_bias[2], qbias_num = f.quant_bias_num, kx_lf = f.kx_lf, kb_lf = f.kb_lf;
 	const uint16_t *inv_order = f.scan_order_coeffs ? plan.pool_u16 + f.inv_order_off[order_idx * 3] : nullptr;
 	__shared__ VbGeom geom[NB];
+	__shared__ size_t g_out[NB];   // byte offset of each block's top-left pixel in the output
 	J40_STAGE_SRGB_THRESHOLDS(f);
-	if (tid < nb) geom[tid] = varblock_geometry(plan, list[first + tid], R, C);
+	if (tid < nb) { const VbGeom g = varblock_geometry(plan, list[first + tid], R, C); geom[tid] = g; g_out[tid] = (size_t) g.py * stride_bytes + (size_t) g.px * 4; }
 	__syncthreads();
 
-	// ---- load: coalesced over the coefficient index ----
-	for (int32_t w = tid; w < nb * R * C; w += nthreads) {
-		const int32_t b = w / (R * C), i = w - b * (R * C);
-		const VbGeom &g = geom[b];
-		float v[3];
-		load_coeff3(plan, g, dq, dq_size, i, LONG, VH8, VW8, v, inv_order);
-		// canonical index -> (r, c): the array is [R][C] when C > R, else [C][R] (j40.h:5978-5985)
-		const int32_t r = C > R ? i / C : i % R, c = C > R ? i % C : i / R;
-		float *t = lds + (size_t) b * 3 * TILE + r * P + c;
-		t[0] = v[0]; t[TILE] = v[1]; t[2 * TILE] = v[2];
+	// ---- load: dequantise + chroma-from-luma + LLF into the LDS tiles ----
+	constexpr int N = R * C;
+	constexpr int PAR = N >= 256 ? 1 : 256 / N;   // blocks a pass of the 256 lanes covers
+	constexpr int PER = N >= 256 ? N / 256 : 1;   // coefficient positions per lane
+	if (f.scan_order_coeffs && f.order_same[order_idx]) {
+		// Single-pass frames keep coefficients in scan order (K1 stores them as they come). A lane owns scan position j
+		// for every block of the workgroup: its canonical index, dequantisation weights and tile address are loaded once,
+		// the coefficient reads are contiguous, and since the non-zeros sit at the front of the scan whole wavefronts
+		// see nothing but zeros and skip the arithmetic (0 dequantises to +0 exactly).
+		const uint16_t *order = plan.pool_u16 + f.order_off[order_idx * 3];   // pass 0, shared by the three channels
+#pragma unroll
+		for (int k = 0; k < PER; ++k) {
+			const int32_t j = N >= 256 ? tid + 256 * k : tid % N;
+			const int32_t i = order[j];
+			const float dq0 = dq[i], dq1 = dq[N + i], dq2 = dq[2 * N + i];
+			const int32_t r = C > R ? i / C : i % R, c = C > R ? i % C : i / R;   // canonical index -> tile position (j40.h:5978-5985)
+			const int32_t at = r * P + c;
+			const bool is_llf = j < N / 64;                                       // the scan starts with the LLF positions (j40.h:6975)
+			const int32_t llf_at = (i / LONG) * VW8 + (i % LONG);
+			for (int32_t b = N >= 256 ? 0 : tid / N; b < nb; b += PAR) {
+				const VbGeom &g = geom[b];
+				float *t = lds + (size_t) b * 3 * TILE + at;
+				float vx = 0.0f, vy = 0.0f, vb = 0.0f;
+				float qx = 0.0f, qy = 0.0f, qb = 0.0f;
+				if (!is_llf) { qx = plan.coeffs[0][g.coeff_base + j]; qy = plan.coeffs[1][g.coeff_base + j]; qb = plan.coeffs[2][g.coeff_base + j]; }
+				if (__ballot(qx != 0.0f || qy != 0.0f || qb != 0.0f)) {
+					const float dx = dequant_coeff(qx, qbias0, qbias_num, g.mult[0], dq0);
+					const float dy = dequant_coeff(qy, qbias1, qbias_num, g.mult[1], dq1);
+					const float db = dequant_coeff(qb, qbias2, qbias_num, g.mult[2], dq2);
+					vx = dx + dy * g.kx_hf; vy = dy; vb = db + dy * g.kb_hf;
+				}
+				if (is_llf) {
+					const int32_t l = g.llf_base + llf_at;
+					const float lx = plan.llf[0][l], ly = plan.llf[1][l], lb = plan.llf[2][l];
+					vx = lx + ly * kx_lf; vy = ly; vb = lb + ly * kb_lf;
+				}
+				t[0] = vx; t[TILE] = vy; t[2 * TILE] = vb;
+			}
+		}
+	} else {
+		// multi-pass frames (canonical storage) and per-channel orders: coalesced over the canonical index
+		for (int32_t w = tid; w < nb * R * C; w += nthreads) {
+			const int32_t b = w / (R * C), i = w - b * (R * C);
+			const VbGeom &g = geom[b];
+			float v[3];
+			load_coeff3(plan, g, dq, dq_size, i, LONG, VH8, VW8, v, inv_order);
+			const int32_t r = C > R ? i / C : i % R, c = C > R ? i % C : i / R;
+			float *t = lds + (size_t) b * 3 * TILE + r * P + c;
+			t[0] = v[0]; t[TILE] = v[1]; t[2 * TILE] = v[2];
+		}
 	}
 	__syncthreads();
 	// ---- pass 1: IDCT of length C along c, one lane per (block, channel, r) ----
@@ -369,14 +412,19 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarbl
 		for (int k = 0; k < R; ++k) col[k * P] = x[k];
 	}
 	__syncthreads();
-	// ---- colour + pack: one lane per pixel, rows of a block are contiguous in the output ----
-	for (int32_t w = tid; w < nb * R * C; w += nthreads) {
-		const int32_t b = w / (R * C), i = w - b * (R * C), y = i / C, x = i - y * C;
-		const VbGeom &g = geom[b];
-		if (y >= g.effh || x >= g.effw) continue;
-		const float *t = lds + (size_t) b * 3 * TILE + y * P + x;
-		const uint32_t px = xyb_to_rgba8(t[0], t[TILE], t[2 * TILE], f, srgb_thr);
-		*(uint32_t *) (rgba + (size_t) (g.py + y) * stride_bytes + (size_t) (g.px + x) * 4) = px;
+	// ---- colour + pack: a lane owns pixel position (y, x) for every block of the workgroup ----
+#pragma unroll
+	for (int k = 0; k < PER; ++k) {
+		const int32_t p = N >= 256 ? tid + 256 * k : tid % N;
+		const int32_t y = p / C, x = p % C;
+		const uint32_t in_block = (uint32_t) y * (uint32_t) stride_bytes + (uint32_t) x * 4u;   // a block spans < 4 GB of output
+		for (int32_t b = N >= 256 ? 0 : tid / N; b < nb; b += PAR) {
+			const VbGeom &g = geom[b];
+			if (y >= g.effh || x >= g.effw) continue;
+			const float *t = lds + (size_t) b * 3 * TILE + y * P + x;
+			const uint32_t px = xyb_to_rgba8(t[0], t[TILE], t[2 * TILE], cc, srgb_thr);
+			*(uint32_t *) (rgba + g_out[b] + in_block) = px;
+		}
 	}
 }
 
@@ -394,6 +442,7 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan, const DevV
 	const int32_t nb = min(NB, count - first);
 	__shared__ VbGeom geom[NB];
 	J40_STAGE_SRGB_THRESHOLDS(f);
+	const ColourConsts cc = load_colour_consts(f);
 	if (tid < nb) geom[tid] = varblock_geometry(plan, list[first + tid], 8, 8);
 	__syncthreads();
 	for (int32_t w = tid; w < nb * 64; w += nthreads) {
@@ -419,7 +468,7 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan, const DevV
 		const VbGeom &g = geom[b];
 		if (y >= g.effh || x >= g.effw) continue;
 		const float *t = tiles + (size_t) b * 3 * P + i;
-		const uint32_t px = xyb_to_rgba8(t[0], t[P], t[2 * P], f, srgb_thr);
+		const uint32_t px = xyb_to_rgba8(t[0], t[P], t[2 * P], cc, srgb_thr);
 		*(uint32_t *) (rgba + (size_t) (g.py + y) * stride_bytes + (size_t) (g.px + x) * 4) = px;
 	}
 }
@@ -484,6 +533,7 @@ __global__ void __launch_bounds__(256) k_vardct_large(DevPlan plan, const DevVar
 	const float *dq = plan.pool_f32 + f.dq_off[param_idx];
 	const uint16_t *inv_order = f.scan_order_coeffs ? plan.pool_u16 + f.inv_order_off[DEV_DCT_SELECT[vb.dctsel][2] * 3] : nullptr;
 	J40_STAGE_SRGB_THRESHOLDS(f);
+	const ColourConsts cc = load_colour_consts(f);
 	const VbGeom g = varblock_geometry(plan, vb, R, C);
 	float *A = scratch + (size_t) blockIdx.x * 6 * 65536, *B = A + 3 * 65536;  // [3][size] each
 	for (int32_t i = tid; i < size; i += nthreads) {
@@ -500,7 +550,7 @@ __global__ void __launch_bounds__(256) k_vardct_large(DevPlan plan, const DevVar
 	for (int32_t i = tid; i < size; i += nthreads) {
 		const int32_t y = i / C, x = i - y * C;
 		if (y >= g.effh || x >= g.effw) continue;
-		const uint32_t px = xyb_to_rgba8(A[i], A[65536 + i], A[2 * 65536 + i], f, srgb_thr);
+		const uint32_t px = xyb_to_rgba8(A[i], A[65536 + i], A[2 * 65536 + i], cc, srgb_thr);
 		*(uint32_t *) (rgba + (size_t) (g.py + y) * stride_bytes + (size_t) (g.px + x) * 4) = px;
 	}
 }

@@ -81,6 +81,7 @@ struct DevFrame {
 	// the pixel kernels gather through the inverse order: inv_order[j] = scan position of canonical index j
 	int32_t scan_order_coeffs;
 	uint32_t inv_order_off[13 * 3];   // into the u16 pool
+	int32_t order_same[13];           // pass 0: the three channels share one coefficient order (the usual case)
 };
 
 // everything a kernel needs, passed by value

@@ -311,6 +311,7 @@ struct j40hip_batch {
 	bool lanes_fast = true;          // every frame qualifies for k_hf_lanes
 	uint32_t lanes_lds_bytes = 0;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	std::vector<hipEvent_t> slots;   // 4 events per recorded decode (j40hip_batch_decode_recorded)
 };
 
 extern "C" void j40hip_batch_free(j40hip_batch *b) {
@@ -319,6 +320,7 @@ extern "C" void j40hip_batch_free(j40hip_batch *b) {
 	if (b->d_plans) (void) hipFree(b->d_plans);
 	if (b->d_work) (void) hipFree(b->d_work);
 	for (auto &e : b->ev) if (e) (void) hipEventDestroy(e);
+	for (auto &e : b->slots) if (e) (void) hipEventDestroy(e);
 	delete b;
 }
 
@@ -371,31 +373,60 @@ extern "C" j40hip_batch *j40hip_batch_create(j40hip_frame *const *frames, int64_
 	return b;
 }
 
-static uint32_t batch_decode_impl(j40hip_batch *b, void *const *rgba_dev, const size_t *stride_bytes, hipStream_t s, float *ms3) {
+// ev: four events to record around the three stages (clear | entropy | pixels), or nullptr
+static uint32_t batch_enqueue(j40hip_batch *b, void *const *rgba_dev, const size_t *stride_bytes, hipStream_t s, hipEvent_t *ev) {
 	if (!b) return ERR_GPU;
 	if (hipSetDevice(b->device) != hipSuccess) return ERR_GPU;
-	if (ms3) (void) hipEventRecord(b->ev[0], s);
+	if (ev) (void) hipEventRecord(ev[0], s);
 	for (j40hip_frame *h : b->frames) {
 		j40hip_device_state *st = h->dev;
 		if (hipMemsetAsync(st->plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) st->plan.coeff_stride, s) != hipSuccess) return ERR_GPU;
 		if (hipMemsetAsync(st->plan.status, 0, sizeof(uint32_t) * (size_t) st->total_sections, s) != hipSuccess) return ERR_GPU;
 	}
-	if (ms3) (void) hipEventRecord(b->ev[1], s);
+	if (ev) (void) hipEventRecord(ev[1], s);
 	if (b->lanes_fast && !getenv("J40HIP_GENERIC_LANES")) launch_hf_lanes(b->d_plans, b->d_work, b->num_work, b->waves_per_wg, b->lanes_lds_bytes, s);
 	else launch_hf_entropy_lanes(b->d_plans, b->d_work, b->num_work, b->tables_in_lds, b->lds_bytes, s);
-	if (ms3) (void) hipEventRecord(b->ev[2], s);
+	if (ev) (void) hipEventRecord(ev[2], s);
 	for (size_t i = 0; i < b->frames.size(); ++i) {
 		j40hip_device_state *st = b->frames[i]->dev;
 		launch_vardct_frame(st->plan, st->class_start, st->d_vb_sorted, st->d_large_scratch, (uint8_t *) rgba_dev[i], stride_bytes[i], s);
 	}
-	if (ms3) {
-		(void) hipEventRecord(b->ev[3], s);
-		if (hipEventSynchronize(b->ev[3]) != hipSuccess) return ERR_GPU;
-		float t0 = 0, t1 = 0, t2 = 0;
-		(void) hipEventElapsedTime(&t0, b->ev[0], b->ev[1]); (void) hipEventElapsedTime(&t1, b->ev[1], b->ev[2]); (void) hipEventElapsedTime(&t2, b->ev[2], b->ev[3]);
-		ms3[0] = t1; ms3[1] = t2; ms3[2] = t0;
-	}
+	if (ev) (void) hipEventRecord(ev[3], s);
 	return hipGetLastError() == hipSuccess ? 0 : ERR_GPU;
+}
+
+static uint32_t events_to_ms(hipEvent_t *ev, float *ms3) {
+	if (hipEventSynchronize(ev[3]) != hipSuccess) return ERR_GPU;
+	float t0 = 0, t1 = 0, t2 = 0;
+	(void) hipEventElapsedTime(&t0, ev[0], ev[1]); (void) hipEventElapsedTime(&t1, ev[1], ev[2]); (void) hipEventElapsedTime(&t2, ev[2], ev[3]);
+	ms3[0] = t1; ms3[1] = t2; ms3[2] = t0;
+	return 0;
+}
+
+static uint32_t batch_decode_impl(j40hip_batch *b, void *const *rgba_dev, const size_t *stride_bytes, hipStream_t s, float *ms3) {
+	if (!b) return ERR_GPU;
+	if (uint32_t e = batch_enqueue(b, rgba_dev, stride_bytes, s, ms3 ? b->ev : nullptr)) return e;
+	return ms3 ? events_to_ms(b->ev, ms3) : 0;
+}
+
+// asynchronous variant of the timed decode: records the stage events in `slot` and returns; the caller reads them
+// with j40hip_batch_elapsed once the stream has been synchronised (keeps several batches in flight on different
+// streams while still measuring every launch)
+extern "C" uint32_t j40hip_batch_decode_recorded(j40hip_batch *b, void *const *rgba_dev, const size_t *stride_bytes, void *stream, int32_t slot) {
+	if (!b || slot < 0 || slot >= 4096) return ERR_RNGE;
+	if (hipSetDevice(b->device) != hipSuccess) return ERR_GPU;
+	while (b->slots.size() < 4 * ((size_t) slot + 1)) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return ERR_GPU; b->slots.push_back(e); }
+	return batch_enqueue(b, rgba_dev, stride_bytes, (hipStream_t) stream, b->slots.data() + 4 * (size_t) slot);
+}
+// makes `stream` wait until stage `stage` (1: cleared, 2: entropy decoded, 3: pixels written) of the decode recorded in
+// `slot` has completed; used to stagger batches on different streams
+extern "C" uint32_t j40hip_batch_wait_stage(j40hip_batch *b, int32_t slot, int32_t stage, void *stream) {
+	if (!b || slot < 0 || stage < 0 || stage > 3 || b->slots.size() < 4 * ((size_t) slot + 1)) return ERR_RNGE;
+	return hipStreamWaitEvent((hipStream_t) stream, b->slots[4 * (size_t) slot + (size_t) stage], 0) == hipSuccess ? 0 : ERR_GPU;
+}
+extern "C" uint32_t j40hip_batch_elapsed(j40hip_batch *b, int32_t slot, float *ms3) {
+	if (!b || slot < 0 || b->slots.size() < 4 * ((size_t) slot + 1)) return ERR_RNGE;
+	return events_to_ms(b->slots.data() + 4 * (size_t) slot, ms3);
 }
 
 extern "C" uint32_t j40hip_batch_decode(j40hip_batch *b, void *const *rgba_dev, const size_t *stride_bytes, void *stream) {

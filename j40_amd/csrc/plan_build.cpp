@@ -164,6 +164,7 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 	// inverse coefficient orders (single-pass frames store coefficients in scan order)
 	df.scan_order_coeffs = fr.fh.num_passes == 1;
 	for (int i = 0; i < 13 * 3; ++i) df.inv_order_off[i] = 0xffffffffu;
+	for (int o = 0; o < 13; ++o) df.order_same[o] = !fr.orders[0][o][0].empty() && fr.orders[0][o][0] == fr.orders[0][o][1] && fr.orders[0][o][0] == fr.orders[0][o][2];
 	if (df.scan_order_coeffs) for (int o = 0; o < 13; ++o) for (int ch = 0; ch < 3; ++ch) {
 		const std::vector<int32_t> &ord = fr.orders[0][o][ch];
 		if (ord.empty()) continue;
