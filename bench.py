@@ -98,8 +98,8 @@ def main():
     t0 = time.perf_counter()
     frame.upload(local_rank)
     t_upload = time.perf_counter() - t0
-    if args.shard_groups and world > 1:
-        raise SystemExit("--shard-groups is driven by j40_amd.sharding (see tests/test_sharding.py); not part of the default bench")
+    if args.shard_groups:
+        return bench_sharded(args, torch, j40_amd, dist, dev, rank, local_rank, world, data)
 
     out = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev)
@@ -163,6 +163,54 @@ def main():
             result["cpu_baseline"] = cb
     del host
     print(json.dumps(result))
+
+
+def bench_sharded(args, torch, j40_amd, dist, dev, rank, local_rank, world, data):
+    """the north star's single-frame mode: every step decodes ONE frame whose pass groups are split in row bands over the
+    ranks (j40_amd.sharding): codestream broadcast from rank 0, per-rank partial decode, RGBA bands gathered on rank 0
+    over RCCL. Strong scaling of a latency-bound step: see DESIGN.md section 6 for why this does not speed a frame up."""
+    from j40_amd import sharding
+    W, H = args.width, args.height
+    if dist is not None:
+        data = sharding.broadcast_bytes(data, dist, dev)
+    frame = j40_amd.Frame(data, threads=min(8, os.cpu_count() or 1))
+    frame.upload(local_rank)
+    first, count, y0, y1 = sharding.rank_share(W, H, frame.info["group_size_shift"], world, rank)
+    frame.set_group_range(first, count)
+    full = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
+    sptr = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        if count:
+            frame.decode(full.data_ptr(), W * 4, sptr)
+        return sharding.gather_bands(full[y0:y1], W, H, frame.info["group_size_shift"], dist) if dist is not None else full
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    assert frame.status() == ""
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+    print(json.dumps({
+        "metric": "Mpixels/s RGBA-u8x4 decode, 8K VarDCT d1", "value": round(W * H * args.steps / elapsed / 1e6, 2), "unit": "Mpixels/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "one %dx%d VarDCT d1-like synthetic frame per step, pass groups split in %d row bands, RGBA gathered on rank 0" % (W, H, world),
+                   "frame_pixels": W * H, "codestream_bytes": len(data), "parallelism": "group rows x%d" % world}}))
 
 
 def bench_batch(args, torch, j40_amd, synth, dist, dev, rank, local_rank, world, frame0, data0, out0):

@@ -33,6 +33,8 @@ struct j40hip_device_state {
 	std::vector<DevVarblock> vb_sorted;             // by DctSelect
 	int32_t class_start[28];
 	DevVarblock *d_vb_sorted = nullptr;
+	// sharded decode (j40hip_frame_set_group_range): the varblocks of the selected groups, same layout as vb_sorted
+	DevVarblock *d_vb_range = nullptr; int32_t range_class_start[28]; size_t vb_range_capacity = 0;
 	float *d_large_scratch = nullptr;
 	size_t coeff_floats = 0;
 	int32_t total_sections = 0;
@@ -261,7 +263,31 @@ extern "C" uint32_t j40hip_frame_upload(j40hip_frame *h, int device) {
 extern "C" uint32_t j40hip_frame_set_group_range(j40hip_frame *h, int64_t first_group, int64_t num_groups) {
 	if (!h || !h->dev) return ERR_GPU;
 	if (first_group < 0 || num_groups < 0 || first_group + num_groups > h->frame.fh.num_groups) return ERR_RNGE;
-	h->dev->first_group = first_group; h->dev->num_groups = num_groups;
+	j40hip_device_state *st = h->dev;
+	if (st->is_modular) return first_group == 0 && num_groups == h->frame.fh.num_groups ? 0 : ERR_TODO;   // Modular frames are decoded whole
+	st->first_group = first_group; st->num_groups = num_groups;
+	if (first_group == 0 && num_groups == h->frame.fh.num_groups) return 0;
+	// varblocks never straddle a group (the largest transform is one group wide), so the pixel kernels' work lists are
+	// the full lists filtered by the group of each block's top-left pixel
+	const FrameHeader &fh = h->frame.fh;
+	const int32_t shift = fh.group_size_shift;
+	std::vector<DevVarblock> sel;
+	for (const DevVarblock &vb : st->vb_sorted) {
+		const LfGroup &gg = h->frame.lf_groups[(size_t) vb.ggidx];
+		const int64_t px = gg.left + vb.x8 * 8, py = gg.top + vb.y8 * 8;
+		const int64_t gid = (py >> shift) * fh.gcolumns + (px >> shift);
+		if (gid >= first_group && gid < first_group + num_groups) sel.push_back(vb);
+	}
+	size_t k = 0;   // sel keeps the DctSelect order of vb_sorted
+	for (int d = 0; d <= 27; ++d) { while (k < sel.size() && sel[k].dctsel < d) ++k; st->range_class_start[d] = (int32_t) k; }
+	if (hipSetDevice(st->device) != hipSuccess) return ERR_GPU;
+	if (sel.size() > st->vb_range_capacity) {
+		bool ok = true;
+		st->d_vb_range = st->scratch<DevVarblock>(sel.size(), ok);
+		if (!ok) return ERR_GPU;
+		st->vb_range_capacity = sel.size();
+	}
+	if (!sel.empty() && hipMemcpy(st->d_vb_range, sel.data(), sizeof(DevVarblock) * sel.size(), hipMemcpyHostToDevice) != hipSuccess) return ERR_GPU;
 	return 0;
 }
 
@@ -282,8 +308,8 @@ static uint32_t decode_impl(j40hip_frame *h, void *rgba_dev, size_t stride_bytes
 	if (whole) {
 		launch_vardct_frame(plan, st->class_start, st->d_vb_sorted, st->d_large_scratch, (uint8_t *) rgba_dev, stride_bytes, s);
 	} else {
-		// sharded decode: only varblocks of this rank's groups (lists are built on demand)
-		return ERR_TODO;
+		// sharded decode: only the varblocks of this process' groups
+		launch_vardct_frame(plan, st->range_class_start, st->d_vb_range, st->d_large_scratch, (uint8_t *) rgba_dev, stride_bytes, s);
 	}
 	if (ms3) {
 		(void) hipEventRecord(st->ev[3], s);

@@ -150,6 +150,10 @@ static uint32_t hostsim_decode_modular(const Frame &fr, const uint8_t *cs, size_
 	return 0;
 }
 
+// group range for the next hostsim_decode calls (mirrors j40hip_frame_set_group_range; count < 0: every group)
+static int64_t g_first_group = 0, g_group_count = -1;
+extern "C" __attribute__((visibility("default"))) void hostsim_set_group_range(int64_t first, int64_t count) { g_first_group = first; g_group_count = count; }
+
 // decodes a stream with the device functions on the CPU.
 //   rgba: width*height*4 bytes; coeffs_out (optional): 3 arrays of total_cells*64 floats concatenated
 // returns 0 or the first error code
@@ -207,7 +211,10 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 			}
 		}
 	} else
-	for (int32_t g = 0; g < hp.frame.num_groups; ++g) decode_hf_group(plan, g, (only_entropy & 2) != 0);  // bit 1: flat (per-lane) decoder
+	for (int32_t g = 0; g < hp.frame.num_groups; ++g) {
+		if (g_group_count >= 0 && (g < g_first_group || g >= g_first_group + g_group_count)) continue;
+		decode_hf_group(plan, g, (only_entropy & 2) != 0);  // bit 1: flat (per-lane) decoder
+	}
 	if (coeffs_out) for (int c = 0; c < 3; ++c) {
 		float *dst = coeffs_out + (size_t) c * hp.coeff_floats;
 		memcpy(dst, coeffs[c], sizeof(float) * hp.coeff_floats);
@@ -221,6 +228,11 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 	const size_t stride = (size_t) f.width * 4;
 	std::vector<float> A(3 * 65536), B(3 * 65536), scratch(3 * 65);
 	for (const DevVarblock &vb : hp.vb_sorted) {
+		if (g_group_count >= 0) {   // sharded decode: varblocks of the selected groups only
+			const LfGroup &lg = fr.lf_groups[(size_t) vb.ggidx];
+			const int64_t gid = ((int64_t) (lg.top + vb.y8 * 8) >> fr.fh.group_size_shift) * fr.fh.gcolumns + ((int64_t) (lg.left + vb.x8 * 8) >> fr.fh.group_size_shift);
+			if (gid < g_first_group || gid >= g_first_group + g_group_count) continue;
+		}
 		const int log_rows = DEV_DCT_SELECT[vb.dctsel][0], log_columns = DEV_DCT_SELECT[vb.dctsel][1];
 		const int R = 1 << log_rows, C = 1 << log_columns, sz = R * C;
 		const int long_side = R > C ? R : C, vh8 = (R < C ? R : C) / 8, vw8 = long_side / 8;

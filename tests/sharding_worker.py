@@ -1,0 +1,58 @@
+"""worker of tests/test_sharding.py: one rank of a world_size-N gloo job on the CPU. The per-band decode is done by the
+CPU checker (tests/hostsim: the device functions compiled for the host) instead of the HIP kernels; everything around it
+-- band arithmetic, codestream broadcast, padded gather, reassembly -- is the code the GPU path runs (j40_amd.sharding)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def hostsim_band_decoder():
+    import torch
+    import j40_amd
+    from j40_amd import sharding
+    S = C.CDLL(os.path.join(ROOT, "build", "libhostsim.so"))
+    S.hostsim_decode.restype = C.c_uint32
+    S.hostsim_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+    S.hostsim_set_group_range.argtypes = [C.c_int64, C.c_int64]
+
+    def decode_band(data, rank, world):
+        fr = j40_amd.Frame(data)   # host parse only (no device involved)
+        w, h, shift = fr.width, fr.height, fr.info["group_size_shift"]
+        fr.close()
+        first, count, y0, y1 = sharding.rank_share(w, h, shift, world, rank)
+        full = np.full((h, w, 4), 7, np.uint8)   # pixels outside the band must stay untouched
+        if count:
+            buf = C.create_string_buffer(data, len(data))
+            S.hostsim_set_group_range(first, count)
+            err = S.hostsim_decode(buf, len(data), full.ctypes.data, None, 0)
+            S.hostsim_set_group_range(0, -1)
+            assert err == 0, hex(err)
+            assert np.all(full[:y0] == 7) and np.all(full[y1:] == 7), "a band decode wrote outside its rows"
+        return torch.from_numpy(full[y0:y1].copy()), (w, h, shift)
+
+    return decode_band
+
+
+def run(rank, world, port, stream_path, out_path):
+    import torch
+    import torch.distributed as dist
+    from j40_amd import sharding
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    data = open(stream_path, "rb").read() if rank == 0 else b""
+    frame = sharding.decode_sharded(data, dist, hostsim_band_decoder())
+    if rank == 0:
+        np.save(out_path, frame.numpy())
+    else:
+        assert frame is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5])

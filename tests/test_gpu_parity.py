@@ -179,6 +179,33 @@ def test_batch_throughput_mode_matches_latency_mode(gpu, ref):
     batch.close()
 
 
+def test_group_ranges_decode_disjoint_parts_of_the_frame(gpu, ref):
+    """j40hip_frame_set_group_range (the per-rank share of a sharded decode): three ranges written into one buffer give
+    the pixels of a whole decode, and each range touches only its own groups"""
+    import torch
+    from j40_amd import sharding
+    w, h = 776, 600   # 4 x 3 groups
+    data = synth("vardct", w, h, 59, maxlog=8)
+    fr = gpu.Frame(data)
+    fr.upload(0)
+    err, whole = fr.decode_to_host()
+    assert err == ""
+    out = torch.full((h, w, 4), 9, dtype=torch.uint8, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    for rank in range(3):
+        first, count, y0, y1 = sharding.rank_share(w, h, fr.info["group_size_shift"], 3, rank)
+        fr.set_group_range(first, count)
+        before = out.clone()
+        fr.decode(out.data_ptr(), w * 4, stream)
+        torch.cuda.synchronize()
+        assert fr.status() == ""
+        assert torch.equal(out[:y0], before[:y0]) and torch.equal(out[y1:], before[y1:])
+    assert np.array_equal(out.cpu().numpy(), whole)
+    fr.set_group_range(0, fr.info["num_groups"])
+    rerr, expect = ref.decode(data)
+    assert rerr == "" and compare(whole, expect)[0] <= 1
+
+
 def test_golden_fixtures(gpu):
     manifest = json.load(open(os.path.join(GOLDEN, "manifest.json")))
     for name, e in sorted(manifest.items()):
