@@ -154,6 +154,10 @@ J40HIP_API uint32_t j40hip_frame_status(j40hip_frame *f);
 /* Convenience for the public API: decode + copy to host rows of `stride_bytes`. Synchronous. */
 J40HIP_API uint32_t j40hip_frame_decode_to_host(j40hip_frame *f, void *rgba_host, size_t stride_bytes);
 
+/* By default the pixel kernels zero every coefficient they consume (the planes are clean for the next decode without a
+ * clear); keep = 1 leaves the coefficients in place for j40hip_frame_read_coeffs and clears before each decode instead. */
+J40HIP_API uint32_t j40hip_frame_keep_coefficients(j40hip_frame *f, int keep);
+
 /* Stage dumps for parity tests (device -> host copies, synchronous):
  *   quantised HF coefficients of LF group gg, channel c (f32[w8*h8*64], as j40__hf_coeffs leaves them) */
 J40HIP_API uint32_t j40hip_frame_read_coeffs(j40hip_frame *f, int64_t gg, int c, float *out);

@@ -200,7 +200,6 @@ J40_DEV float dequant_coeff(float q, float quant_bias_c, float quant_bias_num, f
 	if (-1.0f <= q && q <= 1.0f) q *= quant_bias_c; else q -= quant_bias_num / q;
 	return q * (mult_c / dq);
 }
-
 // ---- XYB -> sRGB -> clamped u8 (j40.h:7208-7237, 7947-7953) ----
 
 // float -> int16 the way the reference's x86 build does it: cvttss2si (truncate, "integer

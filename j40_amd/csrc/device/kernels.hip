@@ -21,16 +21,16 @@ namespace j40hip {
 
 __constant__ float c_half_secants[256];
 __constant__ float c_afv_basis[256];
-__constant__ float c_srgb_thr[258];
+__device__ float c_srgb_thr[SRGB_TABLE_FLOATS];
 
 // the pixel kernels keep the sRGB threshold table (idct_dev.h) in LDS; 8-bit frames only
 #define J40_STAGE_SRGB_THRESHOLDS(f) \
-	__shared__ float s_srgb_thr[258]; \
-	for (int32_t i_ = threadIdx.x; i_ < 258; i_ += blockDim.x) s_srgb_thr[i_] = c_srgb_thr[i_]; \
+	__shared__ float s_srgb_thr[SRGB_TABLE_FLOATS]; \
+	for (int32_t i_ = threadIdx.x; i_ < SRGB_TABLE_FLOATS; i_ += blockDim.x) s_srgb_thr[i_] = c_srgb_thr[i_]; \
 	const J40_LDS float *srgb_thr = (f).bpp == 8 ? (const J40_LDS float *) s_srgb_thr : (const J40_LDS float *) nullptr
 
 void upload_constant_tables(const float *half_secants, const float *afv_basis, const float *srgb_thr, hipStream_t stream) {
-	(void) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_srgb_thr), srgb_thr, sizeof(float) * 258, 0, hipMemcpyHostToDevice, stream);
+	(void) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_srgb_thr), srgb_thr, sizeof(float) * SRGB_TABLE_FLOATS, 0, hipMemcpyHostToDevice, stream);
 	(void) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_half_secants), half_secants, sizeof(float) * 256, 0, hipMemcpyHostToDevice, stream);
 	(void) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_afv_basis), afv_basis, sizeof(float) * 256, 0, hipMemcpyHostToDevice, stream);
 }
@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(256) k_hf_lanes(const DevPlan *plans, const Hf
 	const J40_GLOBAL DevPlan &plan = ((const J40_GLOBAL DevPlan *) plans)[w.frame];
 	const J40_GLOBAL DevFrame &df = *(const J40_GLOBAL DevFrame *) plan.frame;
 	const bool active = lane < w.num_groups;
-	const int32_t g = w.first_group + (active && !w.pad ? lane : 0);   // pad != 0: experiment, every lane decodes the chunk's first group
+	const int32_t g = w.first_group + (active ? lane : 0);
 	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
 	LaneFrame f;
 	f.nb_block_ctx = df.nb_block_ctx; f.num_hf_presets = df.num_hf_presets; f.preset_bits = df.preset_bits;
@@ -362,8 +362,16 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarbl
 				float *t = lds + (size_t) b * 3 * TILE + at;
 				float vx = 0.0f, vy = 0.0f, vb = 0.0f;
 				float qx = 0.0f, qy = 0.0f, qb = 0.0f;
-				if (!is_llf) { qx = plan.coeffs[0][g.coeff_base + j]; qy = plan.coeffs[1][g.coeff_base + j]; qb = plan.coeffs[2][g.coeff_base + j]; }
+				if (!is_llf) {
+					qx = plan.coeffs[0][g.coeff_base + j]; qy = plan.coeffs[1][g.coeff_base + j]; qb = plan.coeffs[2][g.coeff_base + j];
+					if (plan.clear_after_read) {   // leave the planes all-zero for the next decode (DevPlan::clear_after_read)
+						if (qx != 0.0f) plan.coeffs[0][g.coeff_base + j] = 0.0f;
+						if (qy != 0.0f) plan.coeffs[1][g.coeff_base + j] = 0.0f;
+						if (qb != 0.0f) plan.coeffs[2][g.coeff_base + j] = 0.0f;
+					}
+				}
 				if (__ballot(qx != 0.0f || qy != 0.0f || qb != 0.0f)) {
+					// the work list is sorted by block multiplier within a transform type, so the three divisions are rare
 					const float dx = dequant_coeff(qx, qbias0, qbias_num, g.mult[0], dq0);
 					const float dy = dequant_coeff(qy, qbias1, qbias_num, g.mult[1], dq1);
 					const float db = dequant_coeff(qb, qbias2, qbias_num, g.mult[2], dq2);
@@ -620,8 +628,8 @@ void launch_vardct_class(const DevPlan &plan, int32_t dctsel, const DevVarblock 
 
 // known-answer hook: the renderer's per-sample tail (sRGB transfer + conversion, j40.h:7213-7240 / 7925-7935)
 __global__ void k_kat_srgb_u8(const float *v, size_t n, uint8_t *out) {
-	__shared__ float s_thr[258];
-	for (int32_t i = threadIdx.x; i < 258; i += blockDim.x) s_thr[i] = c_srgb_thr[i];
+	__shared__ float s_thr[SRGB_TABLE_FLOATS];
+	for (int32_t i = threadIdx.x; i < SRGB_TABLE_FLOATS; i += blockDim.x) s_thr[i] = c_srgb_thr[i];
 	__syncthreads();
 	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;

@@ -110,6 +110,9 @@ struct DevPlan {
 	// working buffers
 	float *coeffs[3];                // [total cells * 64]; one allocation: coeffs[c] = coeffs[0] + c * coeff_stride
 	uint32_t coeff_stride;
+	// 1: the pixel kernels write a zero back over every non-zero coefficient they read, so the planes are all-zero again when
+	// the decode ends and the next one needs no clear (a 400 MB memset per 8K frame otherwise). 0: planes are kept (stage dumps).
+	int32_t clear_after_read;
 	int8_t *nonzeros;                // [num_groups][32 * 32 * 3]
 	int32_t *lz_window;              // [num_groups][lz_window_size] or null
 	uint32_t lz_window_size;
@@ -164,6 +167,9 @@ struct DevModPlan {
 
 // one wavefront of the throughput-oriented K1: up to 64 consecutive groups of one frame of the batch
 struct HfLaneWork { int32_t frame, first_group, num_groups, pad; };
+
+// sRGB threshold table of the pixel kernels (idct_dev.h, srgb_u8_from_thresholds)
+enum { SRGB_TABLE_FLOATS = 258 };
 
 enum { HF_WAVES = 4 };
 enum { HF_LANE_COLS_BYTES = 3 * 32 * 64 };   // k_hf_lanes: per-wavefront column state of the non-zero-count predictor  // groups (wavefronts) per K1 workgroup

@@ -241,6 +241,8 @@ extern "C" uint32_t j40hip_frame_upload(j40hip_frame *h, int device) {
 		float *base = st->scratch<float>(3 * stride, ok);
 		for (int c = 0; c < 3; ++c) plan.coeffs[c] = base ? base + (size_t) c * stride : nullptr;
 		plan.coeff_stride = (uint32_t) stride;
+		plan.clear_after_read = 1;   // the planes start out zero and the pixel kernels keep them that way
+		if (base && hipMemsetAsync(base, 0, sizeof(float) * 3 * stride, s) != hipSuccess) ok = false;
 	}
 	const int32_t num_groups = hp.frame.num_groups;
 	plan.nonzeros = st->scratch<int8_t>((size_t) num_groups * 32 * 32 * 3, ok);
@@ -300,7 +302,7 @@ static uint32_t decode_impl(j40hip_frame *h, void *rgba_dev, size_t stride_bytes
 	const Frame &fr = h->frame;
 	const bool whole = st->first_group == 0 && st->num_groups == fr.fh.num_groups;
 	if (ms3) (void) hipEventRecord(st->ev[0], s);
-	if (hipMemsetAsync(plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) plan.coeff_stride, s) != hipSuccess) return ERR_GPU;
+	if (!plan.clear_after_read && hipMemsetAsync(plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) plan.coeff_stride, s) != hipSuccess) return ERR_GPU;
 	if (hipMemsetAsync(plan.status, 0, sizeof(uint32_t) * (size_t) st->total_sections, s) != hipSuccess) return ERR_GPU;
 	if (ms3) (void) hipEventRecord(st->ev[1], s);
 	launch_hf_entropy(plan, st->hf, (int32_t) st->first_group, (int32_t) st->num_groups, s);
@@ -338,6 +340,11 @@ struct j40hip_batch {
 	uint32_t lanes_lds_bytes = 0;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 	std::vector<hipEvent_t> slots;   // 4 events per recorded decode (j40hip_batch_decode_recorded)
+	// the pixel kernels of different frames are independent and individually too small to fill the GPU: they are spread
+	// over a few side streams that fork after the entropy launch and join before anything else runs on the caller's stream
+	std::vector<hipStream_t> side;
+	std::vector<hipEvent_t> side_done;
+	hipEvent_t fork = nullptr;
 };
 
 extern "C" void j40hip_batch_free(j40hip_batch *b) {
@@ -347,6 +354,9 @@ extern "C" void j40hip_batch_free(j40hip_batch *b) {
 	if (b->d_work) (void) hipFree(b->d_work);
 	for (auto &e : b->ev) if (e) (void) hipEventDestroy(e);
 	for (auto &e : b->slots) if (e) (void) hipEventDestroy(e);
+	for (auto &e : b->side_done) if (e) (void) hipEventDestroy(e);
+	for (auto &st : b->side) if (st) (void) hipStreamDestroy(st);
+	if (b->fork) (void) hipEventDestroy(b->fork);
 	delete b;
 }
 
@@ -380,8 +390,7 @@ extern "C" j40hip_batch *j40hip_batch_create(j40hip_frame *const *frames, int64_
 	if (const char *e = getenv("J40HIP_WAVES_PER_WG")) b->waves_per_wg = std::max(1, std::min(4, atoi(e)));
 	for (size_t i = 0; i < b->frames.size(); ++i) {
 		const int32_t groups = b->frames[i]->frame.fh.num_groups;
-		const int32_t exp_same = getenv("J40HIP_EXP_SAME_GROUP") ? 1 : 0;   // timing experiment only (wrong pixels)
-		for (int32_t g = 0; g < groups; g += lanes) work.push_back({(int32_t) i, g, std::min(lanes, groups - g), exp_same});
+		for (int32_t g = 0; g < groups; g += lanes) work.push_back({(int32_t) i, g, std::min(lanes, groups - g), 0});
 		while (work.size() % (size_t) b->waves_per_wg) work.push_back({(int32_t) i, 0, 0, 0});   // a workgroup stays on one frame
 	}
 	for (j40hip_frame *h : b->frames) {
@@ -395,6 +404,17 @@ extern "C" j40hip_batch *j40hip_batch_create(j40hip_frame *const *frames, int64_
 	ok = ok && hipMemcpy(b->d_plans, plans.data(), sizeof(DevPlan) * plans.size(), hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMemcpy(b->d_work, work.data(), sizeof(HfLaneWork) * work.size(), hipMemcpyHostToDevice) == hipSuccess;
 	for (auto &e : b->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+	{
+		int nside = (int) std::min<size_t>(16, b->frames.size());
+		if (const char *e = getenv("J40HIP_SIDE_STREAMS")) nside = std::max(0, std::min(32, atoi(e)));
+		if (nside < 2) nside = 0;
+		for (int i = 0; i < nside && ok; ++i) {
+			hipStream_t st = nullptr; hipEvent_t ev = nullptr;
+			ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+			b->side.push_back(st); b->side_done.push_back(ev);
+		}
+		ok = ok && hipEventCreateWithFlags(&b->fork, hipEventDisableTiming) == hipSuccess;
+	}
 	if (!ok) { *err = ERR_GPU; j40hip_batch_free(b); return nullptr; }
 	return b;
 }
@@ -406,16 +426,28 @@ static uint32_t batch_enqueue(j40hip_batch *b, void *const *rgba_dev, const size
 	if (ev) (void) hipEventRecord(ev[0], s);
 	for (j40hip_frame *h : b->frames) {
 		j40hip_device_state *st = h->dev;
-		if (hipMemsetAsync(st->plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) st->plan.coeff_stride, s) != hipSuccess) return ERR_GPU;
+		if (!st->plan.clear_after_read && hipMemsetAsync(st->plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) st->plan.coeff_stride, s) != hipSuccess) return ERR_GPU;
 		if (hipMemsetAsync(st->plan.status, 0, sizeof(uint32_t) * (size_t) st->total_sections, s) != hipSuccess) return ERR_GPU;
 	}
 	if (ev) (void) hipEventRecord(ev[1], s);
 	if (b->lanes_fast && !getenv("J40HIP_GENERIC_LANES")) launch_hf_lanes(b->d_plans, b->d_work, b->num_work, b->waves_per_wg, b->lanes_lds_bytes, s);
 	else launch_hf_entropy_lanes(b->d_plans, b->d_work, b->num_work, b->tables_in_lds, b->lds_bytes, s);
 	if (ev) (void) hipEventRecord(ev[2], s);
-	for (size_t i = 0; i < b->frames.size(); ++i) {
-		j40hip_device_state *st = b->frames[i]->dev;
-		launch_vardct_frame(st->plan, st->class_start, st->d_vb_sorted, st->d_large_scratch, (uint8_t *) rgba_dev[i], stride_bytes[i], s);
+	if (b->side.empty()) {
+		for (size_t i = 0; i < b->frames.size(); ++i) {
+			j40hip_device_state *st = b->frames[i]->dev;
+			launch_vardct_frame(st->plan, st->class_start, st->d_vb_sorted, st->d_large_scratch, (uint8_t *) rgba_dev[i], stride_bytes[i], s);
+		}
+	} else {
+		if (hipEventRecord(b->fork, s) != hipSuccess) return ERR_GPU;
+		for (hipStream_t side : b->side) if (hipStreamWaitEvent(side, b->fork, 0) != hipSuccess) return ERR_GPU;
+		for (size_t i = 0; i < b->frames.size(); ++i) {
+			j40hip_device_state *st = b->frames[i]->dev;
+			launch_vardct_frame(st->plan, st->class_start, st->d_vb_sorted, st->d_large_scratch, (uint8_t *) rgba_dev[i], stride_bytes[i], b->side[i % b->side.size()]);
+		}
+		for (size_t k = 0; k < b->side.size(); ++k) {
+			if (hipEventRecord(b->side_done[k], b->side[k]) != hipSuccess || hipStreamWaitEvent(s, b->side_done[k], 0) != hipSuccess) return ERR_GPU;
+		}
 	}
 	if (ev) (void) hipEventRecord(ev[3], s);
 	return hipGetLastError() == hipSuccess ? 0 : ERR_GPU;
@@ -505,6 +537,18 @@ extern "C" uint32_t j40hip_frame_decode_to_host(j40hip_frame *h, void *rgba_host
 	if (!err && hipMemcpy2D(rgba_host, stride_bytes, d, row, row, (size_t) fr.fh.height, hipMemcpyDeviceToHost) != hipSuccess) err = ERR_GPU;
 	(void) hipFree(d);
 	return err;
+}
+
+// stage dumps need the coefficients after the decode: keep = 1 switches the clear-after-read off (and the clear before the
+// entropy launch back on). Takes effect for decodes of this frame issued afterwards; batches copy the setting when created.
+extern "C" uint32_t j40hip_frame_keep_coefficients(j40hip_frame *h, int keep) {
+	if (!h || !h->dev || h->dev->is_modular) return ERR_GPU;
+	j40hip_device_state *st = h->dev;
+	if (hipSetDevice(st->device) != hipSuccess) return ERR_GPU;
+	// whatever the previous mode left behind, start from clean planes
+	if (hipMemset(st->plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) st->plan.coeff_stride) != hipSuccess) return ERR_GPU;
+	st->plan.clear_after_read = keep ? 0 : 1;
+	return 0;
 }
 
 extern "C" uint32_t j40hip_frame_read_coeffs(j40hip_frame *h, int64_t gg, int c, float *out) {

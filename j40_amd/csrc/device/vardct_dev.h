@@ -47,9 +47,15 @@ J40_DEV void load_coeff3(const DevPlan &plan, const VbGeom &g, const float *dq, 
 	}
 	// scan-order storage (single-pass frames): canonical index i lives at scan position inv_order[c][i]
 	const int32_t ix = inv_order ? inv_order[i] : i, iy = inv_order ? inv_order[dq_size + i] : i, ib = inv_order ? inv_order[2 * dq_size + i] : i;
-	const float qx = dequant_coeff(plan.coeffs[0][g.coeff_base + ix], f.quant_bias[0], f.quant_bias_num, g.mult[0], dq[i]);
-	const float qy = dequant_coeff(plan.coeffs[1][g.coeff_base + iy], f.quant_bias[1], f.quant_bias_num, g.mult[1], dq[dq_size + i]);
-	const float qb = dequant_coeff(plan.coeffs[2][g.coeff_base + ib], f.quant_bias[2], f.quant_bias_num, g.mult[2], dq[2 * dq_size + i]);
+	const float cx = plan.coeffs[0][g.coeff_base + ix], cy = plan.coeffs[1][g.coeff_base + iy], cb = plan.coeffs[2][g.coeff_base + ib];
+	if (plan.clear_after_read) {   // leave the planes all-zero for the next decode
+		if (cx != 0.0f) plan.coeffs[0][g.coeff_base + ix] = 0.0f;
+		if (cy != 0.0f) plan.coeffs[1][g.coeff_base + iy] = 0.0f;
+		if (cb != 0.0f) plan.coeffs[2][g.coeff_base + ib] = 0.0f;
+	}
+	const float qx = dequant_coeff(cx, f.quant_bias[0], f.quant_bias_num, g.mult[0], dq[i]);
+	const float qy = dequant_coeff(cy, f.quant_bias[1], f.quant_bias_num, g.mult[1], dq[dq_size + i]);
+	const float qb = dequant_coeff(cb, f.quant_bias[2], f.quant_bias_num, g.mult[2], dq[2 * dq_size + i]);
 	out[0] = qx + qy * g.kx_hf; out[1] = qy; out[2] = qb + qy * g.kb_hf;
 }
 

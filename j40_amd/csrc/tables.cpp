@@ -7,6 +7,7 @@
 // dequantisation weights are evaluated with libm in the reference's operation order (j40.h:4780-4957).
 #include "frame.hpp"
 #include "tables.hpp"
+#include "device/plan.h"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -76,7 +77,7 @@ const float *afv_basis() { return AFV_BASIS_TABLE; }
 
 // thr[k] = smallest float v in (-9, 50000) whose 8-bit sample (j40.h:7213-7240 then 7925-7935 with bpp = 8) is >= k
 const float *srgb_u8_thresholds() {
-	static float table[258];
+	static float table[SRGB_TABLE_FLOATS];
 	static std::once_flag once;
 	std::call_once(once, []() {
 		auto sample = [](float v) -> int {   // the reference's arithmetic with a correctly rounded powf

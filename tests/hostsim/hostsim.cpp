@@ -182,6 +182,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 	plan.blocks = hp.blocks.data(); plan.lfindices = hp.lfindices.data();
 	for (int c = 0; c < 3; ++c) { plan.llf[c] = hp.llf[c].data(); plan.coeffs[c] = coeffs[c]; }
 	plan.coeff_stride = (uint32_t) hp.coeff_floats;
+	plan.clear_after_read = 1;
 	plan.vb_coeffoff_qfidx = hp.vb_coeffoff_qfidx.data(); plan.vb_hfmul_inv = hp.vb_hfmul_inv.data();
 	plan.xfromy = hp.xfromy.data(); plan.bfromy = hp.bfromy.data();
 	plan.nonzeros = nonzeros.data(); plan.status = status.data();
@@ -264,6 +265,8 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 			memcpy(rgba + (size_t) (g.py + y) * stride + (size_t) (g.px + x) * 4, &px, 4);
 		}
 	}
+	// clear-after-read: a whole decode leaves the planes all-zero
+	if (g_group_count < 0) for (float v : coeff_store) if (v != 0.0f) return ERR_EXCS;
 	return 0;
 }
 

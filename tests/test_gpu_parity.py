@@ -55,8 +55,16 @@ def test_hf_coefficients_bit_exact(gpu, ref, name, opts):
     rs = RefStage(ref, data)
     fr = gpu.Frame(data)
     fr.upload(0)
-    err, _ = fr.decode_to_host()
+    err, first = fr.decode_to_host()            # default mode: the pixel kernels zero the coefficients they consume ...
     assert err == ""
+    for g in range(rs.info["num_lf_groups"]):
+        for c in range(3):
+            assert not fr.read_coeffs(g, c).any(), "the coefficient planes must be clean after a decode"
+    err, second = fr.decode_to_host()           # ... so a second decode needs no clear and gives the same pixels
+    assert err == "" and np.array_equal(first, second)
+    fr.keep_coefficients(True)                  # stage dump mode
+    err, third = fr.decode_to_host()
+    assert err == "" and np.array_equal(first, third)
     for g in range(rs.info["num_lf_groups"]):
         for c in range(3):
             assert np.array_equal(fr.read_coeffs(g, c), rs.coeffs(g, c)), (g, c)
@@ -212,6 +220,8 @@ def test_golden_fixtures(gpu):
         data = open(os.path.join(GOLDEN, name + ".jxl"), "rb").read()
         fr = gpu.Frame(data)
         fr.upload(0)
+        if e["mode"] != "modular":
+            fr.keep_coefficients(True)
         err, rgba = fr.decode_to_host()
         assert err == "", name
         if e["mode"] == "modular":
