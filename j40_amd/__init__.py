@@ -21,7 +21,7 @@ J40_RGBA = 0x1755
 J40_U8X4 = 0x0F33
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_ROOT, "build", "libj40hip.so")
+LIB_PATH = os.environ.get("J40HIP_LIB") or os.path.join(_ROOT, "build", "libj40hip.so")
 _lib = None
 
 

@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarbl
 	__shared__ VbGeom geom[NB];
 	__shared__ size_t g_out[NB];   // byte offset of each block's top-left pixel in the output
 	J40_STAGE_SRGB_THRESHOLDS(f);
-	if (tid < nb) { const VbGeom g = varblock_geometry(plan, list[first + tid], R, C); geom[tid] = g; g_out[tid] = (size_t) g.py * stride_bytes + (size_t) g.px * 4; }
+	if (tid < nb) { const VbGeom g = varblock_geometry(plan, list[first + tid]); geom[tid] = g; g_out[tid] = (size_t) g.py * stride_bytes + (size_t) g.px * 4; }
 	__syncthreads();
 
 	// ---- load: dequantise + chroma-from-luma + LLF into the LDS tiles ----
@@ -348,30 +348,49 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarbl
 		// the coefficient reads are contiguous, and since the non-zeros sit at the front of the scan whole wavefronts
 		// see nothing but zeros and skip the arithmetic (0 dequantises to +0 exactly).
 		const uint16_t *order = plan.pool_u16 + f.order_off[order_idx * 3];   // pass 0, shared by the three channels
+		constexpr int NBI = N >= 256 ? NB : (NB + PAR - 1) / PAR;             // blocks a lane visits
+		const int32_t b0 = N >= 256 ? 0 : tid / N;
+		// every coefficient of the lane is requested before the first one is used: one exposed memory latency per
+		// workgroup instead of one per block
+		float q[PER][NBI][3];
+		int32_t idx[PER];
 #pragma unroll
 		for (int k = 0; k < PER; ++k) {
 			const int32_t j = N >= 256 ? tid + 256 * k : tid % N;
-			const int32_t i = order[j];
+			idx[k] = order[j];
+#pragma unroll
+			for (int bi = 0; bi < NBI; ++bi) {
+				const int32_t b = b0 + bi * PAR;
+				q[k][bi][0] = q[k][bi][1] = q[k][bi][2] = 0.0f;
+				if (b < nb && j >= N / 64) {   // the scan starts with the LLF positions (j40.h:6975), which carry no HF coefficient
+					const int32_t at = geom[b].coeff_base + j;
+					q[k][bi][0] = plan.coeffs[0][at]; q[k][bi][1] = plan.coeffs[1][at]; q[k][bi][2] = plan.coeffs[2][at];
+				}
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < PER; ++k) {
+			const int32_t j = N >= 256 ? tid + 256 * k : tid % N;
+			const int32_t i = idx[k];
 			const float dq0 = dq[i], dq1 = dq[N + i], dq2 = dq[2 * N + i];
 			const int32_t r = C > R ? i / C : i % R, c = C > R ? i % C : i / R;   // canonical index -> tile position (j40.h:5978-5985)
 			const int32_t at = r * P + c;
-			const bool is_llf = j < N / 64;                                       // the scan starts with the LLF positions (j40.h:6975)
+			const bool is_llf = j < N / 64;
 			const int32_t llf_at = (i / LONG) * VW8 + (i % LONG);
-			for (int32_t b = N >= 256 ? 0 : tid / N; b < nb; b += PAR) {
+#pragma unroll
+			for (int bi = 0; bi < NBI; ++bi) {
+				const int32_t b = b0 + bi * PAR;
+				if (b >= nb) break;
 				const VbGeom &g = geom[b];
 				float *t = lds + (size_t) b * 3 * TILE + at;
 				float vx = 0.0f, vy = 0.0f, vb = 0.0f;
-				float qx = 0.0f, qy = 0.0f, qb = 0.0f;
-				if (!is_llf) {
-					qx = plan.coeffs[0][g.coeff_base + j]; qy = plan.coeffs[1][g.coeff_base + j]; qb = plan.coeffs[2][g.coeff_base + j];
-					if (plan.clear_after_read) {   // leave the planes all-zero for the next decode (DevPlan::clear_after_read)
-						if (qx != 0.0f) plan.coeffs[0][g.coeff_base + j] = 0.0f;
-						if (qy != 0.0f) plan.coeffs[1][g.coeff_base + j] = 0.0f;
-						if (qb != 0.0f) plan.coeffs[2][g.coeff_base + j] = 0.0f;
-					}
+				const float qx = q[k][bi][0], qy = q[k][bi][1], qb = q[k][bi][2];
+				if (plan.clear_after_read) {   // leave the planes all-zero for the next decode (DevPlan::clear_after_read)
+					if (qx != 0.0f) plan.coeffs[0][g.coeff_base + j] = 0.0f;
+					if (qy != 0.0f) plan.coeffs[1][g.coeff_base + j] = 0.0f;
+					if (qb != 0.0f) plan.coeffs[2][g.coeff_base + j] = 0.0f;
 				}
 				if (__ballot(qx != 0.0f || qy != 0.0f || qb != 0.0f)) {
-					// the work list is sorted by block multiplier within a transform type, so the three divisions are rare
 					const float dx = dequant_coeff(qx, qbias0, qbias_num, g.mult[0], dq0);
 					const float dy = dequant_coeff(qy, qbias1, qbias_num, g.mult[1], dq1);
 					const float db = dequant_coeff(qb, qbias2, qbias_num, g.mult[2], dq2);
@@ -399,6 +418,7 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarbl
 	}
 	__syncthreads();
 	// ---- pass 1: IDCT of length C along c, one lane per (block, channel, r) ----
+#ifndef J40_EXP_NOPASS
 	for (int32_t w = tid; w < nb * 3 * R; w += nthreads) {
 		float *row = lds + (size_t) (w / R) * TILE + (w % R) * P;
 		float x[C];
@@ -420,6 +440,7 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarbl
 		for (int k = 0; k < R; ++k) col[k * P] = x[k];
 	}
 	__syncthreads();
+#endif
 	// ---- colour + pack: a lane owns pixel position (y, x) for every block of the workgroup ----
 #pragma unroll
 	for (int k = 0; k < PER; ++k) {
@@ -430,7 +451,11 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarbl
 			const VbGeom &g = geom[b];
 			if (y >= g.effh || x >= g.effw) continue;
 			const float *t = lds + (size_t) b * 3 * TILE + y * P + x;
+#ifdef J40_EXP_NOCOLOUR
+			const uint32_t px = __float_as_uint(t[0] + t[TILE] + t[2 * TILE]);
+#else
 			const uint32_t px = xyb_to_rgba8(t[0], t[TILE], t[2 * TILE], cc, srgb_thr);
+#endif
 			*(uint32_t *) (rgba + g_out[b] + in_block) = px;
 		}
 	}
@@ -451,7 +476,7 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan, const DevV
 	__shared__ VbGeom geom[NB];
 	J40_STAGE_SRGB_THRESHOLDS(f);
 	const ColourConsts cc = load_colour_consts(f);
-	if (tid < nb) geom[tid] = varblock_geometry(plan, list[first + tid], 8, 8);
+	if (tid < nb) geom[tid] = varblock_geometry(plan, list[first + tid]);
 	__syncthreads();
 	for (int32_t w = tid; w < nb * 64; w += nthreads) {
 		const int32_t b = w >> 6, i = w & 63;
@@ -542,7 +567,7 @@ __global__ void __launch_bounds__(256) k_vardct_large(DevPlan plan, const DevVar
 	const uint16_t *inv_order = f.scan_order_coeffs ? plan.pool_u16 + f.inv_order_off[DEV_DCT_SELECT[vb.dctsel][2] * 3] : nullptr;
 	J40_STAGE_SRGB_THRESHOLDS(f);
 	const ColourConsts cc = load_colour_consts(f);
-	const VbGeom g = varblock_geometry(plan, vb, R, C);
+	const VbGeom g = varblock_geometry(plan, vb);
 	float *A = scratch + (size_t) blockIdx.x * 6 * 65536, *B = A + 3 * 65536;  // [3][size] each
 	for (int32_t i = tid; i < size; i += nthreads) {
 		float v[3];

@@ -54,12 +54,17 @@ struct DevGroupBlock {
 	uint16_t bctx3;           // block context (j40.h:6951-6953, < 16) of channel Y | X << 4 | B << 8, looked up on the host
 };
 
-// work item of the coefficients -> pixels kernels, sorted by DctSelect on the host
+// work item of the coefficients -> pixels kernels, sorted by DctSelect on the host. Self-contained: everything the kernels
+// need to place and scale the block is resolved on the host, so a workgroup starts with one 32-byte read per block instead of
+// a chain of dependent loads (list -> varblock arrays -> LF group -> chroma-from-luma cell).
 struct DevVarblock {
-	int32_t ggidx;
-	int32_t voff;        // index into the frame-wide varblock arrays
-	int16_t x8, y8;      // cell position inside the LF group
-	int32_t dctsel;
+	int32_t coeff_base;   // index of the block's first coefficient in plan.coeffs[c]
+	int32_t llf_base;     // index of the block's first LLF coefficient in plan.llf[c]
+	float mult1;          // 65536 / global_scale / HfMul (j40.h:7078-7080), the Y channel's multiplier
+	int32_t c64;          // index of the block's 64x64 cell in plan.xfromy / bfromy
+	int32_t px, py;       // top-left pixel in the frame
+	uint16_t effw, effh;  // visible size
+	uint8_t dctsel, pad[3];
 };
 
 struct DevFrame {

@@ -275,9 +275,7 @@ extern "C" uint32_t j40hip_frame_set_group_range(j40hip_frame *h, int64_t first_
 	const int32_t shift = fh.group_size_shift;
 	std::vector<DevVarblock> sel;
 	for (const DevVarblock &vb : st->vb_sorted) {
-		const LfGroup &gg = h->frame.lf_groups[(size_t) vb.ggidx];
-		const int64_t px = gg.left + vb.x8 * 8, py = gg.top + vb.y8 * 8;
-		const int64_t gid = (py >> shift) * fh.gcolumns + (px >> shift);
+		const int64_t gid = ((int64_t) vb.py >> shift) * fh.gcolumns + ((int64_t) vb.px >> shift);
 		if (gid >= first_group && gid < first_group + num_groups) sel.push_back(vb);
 	}
 	size_t k = 0;   // sel keeps the DctSelect order of vb_sorted

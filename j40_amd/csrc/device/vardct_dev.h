@@ -7,7 +7,6 @@
 namespace j40hip {
 
 struct VbGeom {
-	const DevLfGroup *gg;
 	int32_t coeff_base;   // index of the block's first coefficient in plan.coeffs[c]
 	int32_t llf_base;     // index of the block's first LLF coefficient in plan.llf[c]
 	float mult[3];
@@ -16,21 +15,14 @@ struct VbGeom {
 	int32_t effw, effh;   // visible size
 };
 
-J40_DEV VbGeom varblock_geometry(const DevPlan &plan, const DevVarblock &vb, int32_t rows, int32_t columns) {
+J40_DEV VbGeom varblock_geometry(const DevPlan &plan, const DevVarblock &vb) {
 	const DevFrame &f = *plan.frame;
 	VbGeom g;
-	g.gg = plan.lf_groups + vb.ggidx;
-	const int32_t coeffoff = plan.vb_coeffoff_qfidx[vb.voff] & ~15;
-	g.coeff_base = g.gg->cell_base * 64 + coeffoff;
-	g.llf_base = g.gg->cell_base + (coeffoff >> 6);
-	const float m1 = f.mult_base * plan.vb_hfmul_inv[vb.voff];   // j40.h:7078-7080
-	g.mult[1] = m1; g.mult[0] = m1 * f.x_qm_mul; g.mult[2] = m1 * f.b_qm_mul;
-	const int32_t c64 = g.gg->c64_base + (vb.y8 / 8) * g.gg->width64 + (vb.x8 / 8);
-	g.kx_hf = f.base_corr_x + f.inv_colour_factor * (float) plan.xfromy[c64];   // j40.h:7138-7143
-	g.kb_hf = f.base_corr_b + f.inv_colour_factor * (float) plan.bfromy[c64];
-	g.px = g.gg->left + vb.x8 * 8; g.py = g.gg->top + vb.y8 * 8;
-	g.effh = (g.gg->height - vb.y8 * 8 < rows ? g.gg->height - vb.y8 * 8 : rows);
-	g.effw = (g.gg->width - vb.x8 * 8 < columns ? g.gg->width - vb.x8 * 8 : columns);
+	g.coeff_base = vb.coeff_base; g.llf_base = vb.llf_base;
+	g.mult[1] = vb.mult1; g.mult[0] = vb.mult1 * f.x_qm_mul; g.mult[2] = vb.mult1 * f.b_qm_mul;   // j40.h:7078-7080
+	g.kx_hf = f.base_corr_x + f.inv_colour_factor * (float) plan.xfromy[vb.c64];   // j40.h:7138-7143
+	g.kb_hf = f.base_corr_b + f.inv_colour_factor * (float) plan.bfromy[vb.c64];
+	g.px = vb.px; g.py = vb.py; g.effw = vb.effw; g.effh = vb.effh;
 	return g;
 }
 

@@ -115,7 +115,16 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 		for (size_t v = 0; v < gg.varblocks.size(); ++v) {
 			const VarblockInfo &vb = gg.varblocks[v];
 			hp->vb_coeffoff_qfidx.push_back(vb.coeffoff_qfidx); hp->vb_hfmul_inv.push_back(vb.hfmul_inv);
-			DevVarblock dv; dv.ggidx = (int32_t) g; dv.voff = d.vb_base + (int32_t) v; dv.x8 = (int16_t) vb.x8; dv.y8 = (int16_t) vb.y8; dv.dctsel = vb.dctsel;
+			DevVarblock dv;
+			memset(&dv, 0, sizeof dv);
+			const DctSelect &ds = DCT_SELECT[vb.dctsel];
+			const int32_t coeffoff = vb.coeffoff_qfidx & ~15;
+			dv.coeff_base = d.cell_base * 64 + coeffoff; dv.llf_base = d.cell_base + (coeffoff >> 6);
+			dv.mult1 = df.mult_base * vb.hfmul_inv;
+			dv.c64 = d.c64_base + (vb.y8 / 8) * gg.width64 + (vb.x8 / 8);
+			dv.px = gg.left + vb.x8 * 8; dv.py = gg.top + vb.y8 * 8;
+			dv.effh = (uint16_t) std::min(gg.height - vb.y8 * 8, 1 << ds.log_rows); dv.effw = (uint16_t) std::min(gg.width - vb.x8 * 8, 1 << ds.log_columns);
+			dv.dctsel = (uint8_t) vb.dctsel;
 			hp->vb_sorted.push_back(dv);
 		}
 	}

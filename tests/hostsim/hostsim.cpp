@@ -230,8 +230,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 	std::vector<float> A(3 * 65536), B(3 * 65536), scratch(3 * 65);
 	for (const DevVarblock &vb : hp.vb_sorted) {
 		if (g_group_count >= 0) {   // sharded decode: varblocks of the selected groups only
-			const LfGroup &lg = fr.lf_groups[(size_t) vb.ggidx];
-			const int64_t gid = ((int64_t) (lg.top + vb.y8 * 8) >> fr.fh.group_size_shift) * fr.fh.gcolumns + ((int64_t) (lg.left + vb.x8 * 8) >> fr.fh.group_size_shift);
+			const int64_t gid = ((int64_t) vb.py >> fr.fh.group_size_shift) * fr.fh.gcolumns + ((int64_t) vb.px >> fr.fh.group_size_shift);
 			if (gid < g_first_group || gid >= g_first_group + g_group_count) continue;
 		}
 		const int log_rows = DEV_DCT_SELECT[vb.dctsel][0], log_columns = DEV_DCT_SELECT[vb.dctsel][1];
@@ -239,7 +238,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 		const int long_side = R > C ? R : C, vh8 = (R < C ? R : C) / 8, vw8 = long_side / 8;
 		static const int8_t PARAM[27] = {0, 1, 2, 3, 4, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 10, 10, 11, 12, 12, 13, 14, 14, 15, 16, 16};
 		const float *dq = plan.pool_f32 + f.dq_off[PARAM[vb.dctsel]];
-		const VbGeom g = varblock_geometry(plan, vb, R, C);
+		const VbGeom g = varblock_geometry(plan, vb);
 		const bool special = (vb.dctsel >= 1 && vb.dctsel <= 3) || (vb.dctsel >= 12 && vb.dctsel <= 17);
 		const bool large = log_rows > 6 || log_columns > 6;
 		const int P = special ? 8 : large ? C : C + 1;
