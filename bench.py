@@ -47,6 +47,7 @@ def cpu_baseline(data, width, height, budget_s=12.0):
         if err:
             return None
     best = min(times)
+    cpu_baseline.last_pixels = out.reshape(height, width, 4)
     return {"value": round(width * height / best / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "reference",
             "sample": "%d full decodes of the same %dx%d stream through the reference's public API (best of %d, %.2f s each), 1 of %d host cores" % (len(times), width, height, len(times), best, os.cpu_count() or 1)}
 
@@ -308,6 +309,11 @@ def bench_batch(args, torch, j40_amd, synth, dist, dev, rank, local_rank, world,
         cb = cpu_baseline(data0, W, H)
         if cb:
             result["cpu_baseline"] = cb
+            # parity at the full size: the frame the batch decoded against the reference's pixels (bar: 1 level)
+            import numpy as np
+            d = np.abs(out0.cpu().numpy().astype(np.int16) - cpu_baseline.last_pixels.astype(np.int16))
+            result["parity_vs_reference"] = {"max_abs_diff": int(d.max()), "differing_samples": int((d > 0).sum()), "samples": int(d.size)}
+            assert d.max() <= 1, "GPU and reference pixels differ by more than one level"
     print(json.dumps(result))
 
 

@@ -40,6 +40,9 @@ VARDCT_CASES = [
     ("cfl", dict(cfl=1)),
     ("container_jxlc", dict(container=1)),
     ("container_jxlp", dict(container=2)),
+    ("hf_prefix_codes", dict(hfprefix=1)),                  # HF coefficient streams with prefix codes (fast encoders)
+    ("hf_lz77", dict(hflz77=1)),                            # ... with LZ77 copies
+    ("hf_prefix_lz77_passes", dict(hfprefix=1, hflz77=1, passes=2)),
 ]
 
 # the Modular feature matrix (width, height, options); all decode bit-exactly

@@ -18,7 +18,7 @@ def sim(built):
     return S
 
 
-@pytest.mark.parametrize("name,opts", VARDCT_CASES[:8] + [("all_transforms", dict(maxlog=8, bctx=1, presets=2, orders=1))])
+@pytest.mark.parametrize("name,opts", VARDCT_CASES[:8] + VARDCT_CASES[10:] + [("all_transforms", dict(maxlog=8, bctx=1, presets=2, orders=1))])
 def test_device_functions_on_cpu_match_reference(ref, sim, name, opts):
     from refdec import RefStage
     w, h = (776, 520) if name == "all_transforms" else (392, 264)
@@ -56,7 +56,7 @@ def test_flat_lane_decoder_matches_nested_decoder(sim, name, opts):
     # the rANS / no-LZ77 fast path of the throughput kernel (hf_lanes_dev.h); other specs report TODO and take the flat decoder
     c = np.zeros((3, n), np.float32)
     err = sim.hostsim_decode(buf, len(data), rgba.ctypes.data, c.ctypes.data, 5)
-    if opts.get("prefix") or opts.get("lz77"):
+    if opts.get("hfprefix") or opts.get("hflz77"):
         assert err == 0x544F444F
     else:
         assert err == 0 and np.array_equal(a, c)

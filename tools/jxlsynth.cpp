@@ -283,6 +283,8 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 
 	// ---- HF coefficients: tokens per (pass, group) with the decoder's context model ----
 	const int ctx_per_preset = 495 * nb_block_ctx;
+	const int hf_prefix = opt.geti("hfprefix", 0);          // HF coefficient streams with prefix codes instead of rANS
+	const int hf_lz77 = opt.geti("hflz77", 0);              // ... with LZ77 copies for runs of equal small values
 	std::vector<CodeSpecW> cspec((size_t) num_passes);
 	std::vector<std::vector<StreamEncoder>> hf_enc((size_t) num_passes);
 	std::vector<int> group_preset((size_t) num_groups);
@@ -309,9 +311,12 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 			for (auto &m : map) { if (remap[m] < 0) remap[m] = next++; m = (uint8_t) remap[m]; }
 			nclusters = next;
 		}
+		if (hf_lz77) { map.push_back((uint8_t) nclusters); ++nclusters; cs.lz77 = true; }   // the distance context gets its own cluster
 		cs.init(nctx, map, nclusters);
-		cs.log_alpha = log_alpha;
-		for (int c = 0; c < nclusters; ++c) cs.cfg[(size_t) c] = (c & 1) ? HybridCfg{4, 1, 1} : HybridCfg{4, 2, 0};
+		cs.lz_min_symbol = 224; cs.lz_min_length = 3; cs.lz_len_cfg = HybridCfg{0, 0, 0};
+		cs.use_prefix = hf_prefix != 0;
+		cs.log_alpha = (hf_lz77 || hf_prefix) ? 8 : log_alpha;
+		for (int c = 0; c < nclusters; ++c) cs.cfg[(size_t) c] = (c & 1) && !hf_lz77 ? HybridCfg{4, 1, 1} : HybridCfg{4, 2, 0};
 		hf_enc[(size_t) pass].reserve((size_t) num_groups);
 	}
 	// custom coefficient orders: Lehmer codes per (pass, order, channel); the writer only needs them
@@ -394,6 +399,28 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 						prev = v != 0; remaining -= prev;
 					}
 				}
+			}
+			if (hf_lz77) {
+				// run-length pass: a run of >= 3 identical small values after its first occurrence becomes one copy with
+				// distance 1 (dist_mult is 0 for coefficient streams, so the coded distance value is distance - 1, j40.h:2851)
+				const CodeSpecW &cs = cspec[(size_t) pass];
+				std::vector<StreamEncoder::Item> out;
+				const auto &it = enc.items;
+				for (size_t i = 0; i < it.size(); ) {
+					size_t j = i + 1;
+					while (j < it.size() && it[j].token == it[i].token && it[i].nextra == 0 && it[j].nextra == 0 && it[i].token < 16) ++j;
+					out.push_back(it[i]);
+					const size_t run = j - i - 1;
+					if (run >= 3 && it[i].token < 16) {
+						HToken t = hybrid_encode((uint32_t) run - (uint32_t) cs.lz_min_length, cs.lz_len_cfg);
+						out.push_back({it[i + 1].cluster, t.token + (uint32_t) cs.lz_min_symbol, t.extra, (uint8_t) t.nextra});
+						const uint32_t lzcl = cs.cluster_map[(size_t) cs.total_dist() - 1];
+						HToken d = hybrid_encode(0, cs.cfg[lzcl]);
+						out.push_back({lzcl, d.token, d.extra, (uint8_t) d.nextra});
+						i = j;
+					} else i = i + 1;
+				}
+				enc.items.swap(out);
 			}
 			count_stream(cspec[(size_t) pass], enc);
 		}
