@@ -4,6 +4,7 @@
 // No CPU fallback lives here: without a HIP device every entry point returns "!gpu".
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <mutex>
 #include <cmath>
 #include "../capi.hpp"
 #include "../tables.hpp"
@@ -22,11 +23,67 @@ struct DeviceBuffer {
 	void release() { if (ptr) (void) hipFree(ptr); ptr = nullptr; }
 };
 
+// Device memory is recycled across frames: hipMalloc / hipFree of a 1.2 GB working set cost far more than an 8K decode.
+// Blocks go back to a per-device free list when a frame lets go of them (after a device synchronisation) and are handed
+// out again to requests of similar size. A block remembers whether its coefficient planes are all-zero ("clean": the
+// pixel kernels leave them that way), so a recycled working set needs no 400 MB clear either.
+struct CachedBlock { void *ptr; size_t bytes; bool clean; };
+std::mutex g_cache_mutex;
+std::vector<CachedBlock> g_cache[16];
+size_t g_cached_bytes[16];
+constexpr size_t CACHE_LIMIT_BYTES = (size_t) 48 << 30;
+
+void *cache_acquire(int device, size_t bytes, size_t *got, bool *clean) {
+	bytes = (bytes + 4095) & ~(size_t) 4095;
+	if (device >= 0 && device < 16) {
+		std::lock_guard<std::mutex> lock(g_cache_mutex);
+		auto &list = g_cache[device];
+		for (size_t i = 0; i < list.size(); ++i) if (list[i].bytes >= bytes && list[i].bytes <= bytes + bytes / 4) {
+			CachedBlock b = list[i];
+			list.erase(list.begin() + (long) i);
+			g_cached_bytes[device] -= b.bytes;
+			*got = b.bytes; *clean = b.clean;
+			return b.ptr;
+		}
+	}
+	void *p = nullptr;
+	if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+	*got = bytes; *clean = false;
+	return p;
+}
+
+void cache_release(int device, void *ptr, size_t bytes, bool clean) {
+	if (!ptr) return;
+	if (device >= 0 && device < 16) {
+		std::lock_guard<std::mutex> lock(g_cache_mutex);
+		if (g_cached_bytes[device] + bytes <= CACHE_LIMIT_BYTES) {
+			g_cache[device].push_back({ptr, bytes, clean});
+			g_cached_bytes[device] += bytes;
+			return;
+		}
+	}
+	(void) hipFree(ptr);
+}
+
+// host-side staging of the plan: every array lands in one blob at a 256-byte aligned offset, one copy moves it
+struct Stager {
+	std::vector<uint8_t> blob;
+	template <typename T> size_t put(const T *src, size_t n) {
+		const size_t off = (blob.size() + 255) & ~(size_t) 255;
+		blob.resize(off + sizeof(T) * n + 16);
+		if (n) memcpy(blob.data() + off, src, sizeof(T) * n);
+		return off;
+	}
+};
+
 } // namespace
 
 struct j40hip_device_state {
 	int device = 0;
 	std::vector<DeviceBuffer> buffers;
+	void *plan_block = nullptr, *work_block = nullptr;   // VarDCT frames: the uploaded plan and the working set (recycled, see cache_acquire)
+	size_t plan_block_bytes = 0, work_block_bytes = 0;
+	bool work_clean = false;                              // the coefficient planes in work_block are all-zero
 	DevPlan plan;
 	bool is_modular = false;
 	int64_t first_group = 0, num_groups = 0;       // range decoded by this process
@@ -71,6 +128,11 @@ struct j40hip_device_state {
 extern "C" void j40hip_release_device(j40hip_frame *f) {
 	if (!f || !f->dev) return;
 	(void) hipSetDevice(f->dev->device);
+	if (f->dev->plan_block || f->dev->work_block) {
+		(void) hipDeviceSynchronize();   // nothing may still be running on memory that is about to be handed to another frame
+		cache_release(f->dev->device, f->dev->plan_block, f->dev->plan_block_bytes, false);
+		cache_release(f->dev->device, f->dev->work_block, f->dev->work_block_bytes, f->dev->work_clean);
+	}
 	for (auto &b : f->dev->buffers) b.release();
 	for (auto &e : f->dev->ev) if (e) (void) hipEventDestroy(e);
 	delete f->dev;
@@ -213,48 +275,63 @@ extern "C" uint32_t j40hip_frame_upload(j40hip_frame *h, int device) {
 	bool ok = true;
 	DevPlan &plan = st->plan;
 	memset(&plan, 0, sizeof plan);
-	plan.codestream = st->upload(hp.codestream.data(), hp.codestream.size(), s, ok);
-	plan.pool_u8 = st->upload(hp.pool_u8.data(), hp.pool_u8.size(), s, ok);
-	plan.pool_u16 = st->upload(hp.pool_u16.data(), hp.pool_u16.size(), s, ok);
-	plan.pool_i32 = st->upload(hp.pool_i32.data(), hp.pool_i32.size(), s, ok);
-	plan.pool_u64 = st->upload(hp.pool_u64.data(), hp.pool_u64.size(), s, ok);
-	plan.pool_f32 = st->upload(hp.pool_f32.data(), hp.pool_f32.size(), s, ok);
-	plan.clusters = st->upload(hp.clusters.data(), hp.clusters.size(), s, ok);
-	plan.coeff_specs = st->upload(hp.coeff_specs.data(), hp.coeff_specs.size(), s, ok);
-	plan.lf_groups = st->upload(hp.lf_groups.data(), hp.lf_groups.size(), s, ok);
-	plan.sections = st->upload(hp.sections.data(), hp.sections.size(), s, ok);
-	plan.group_blocks = st->upload(hp.group_blocks.data(), hp.group_blocks.size(), s, ok);
-	plan.group_block_start = st->upload(hp.group_block_start.data(), hp.group_block_start.size(), s, ok);
 	st->hf = hp.hf;
-	plan.frame = st->upload(&hp.frame, 1, s, ok);
-	plan.block_ctx_map_off = hp.block_ctx_map_off;
-	plan.blocks = st->upload(hp.blocks.data(), hp.blocks.size(), s, ok);
-	plan.lfindices = st->upload(hp.lfindices.data(), hp.lfindices.size(), s, ok);
-	for (int c = 0; c < 3; ++c) plan.llf[c] = st->upload(hp.llf[c].data(), hp.llf[c].size(), s, ok);
-	plan.vb_coeffoff_qfidx = st->upload(hp.vb_coeffoff_qfidx.data(), hp.vb_coeffoff_qfidx.size(), s, ok);
-	plan.vb_hfmul_inv = st->upload(hp.vb_hfmul_inv.data(), hp.vb_hfmul_inv.size(), s, ok);
-	plan.xfromy = st->upload(hp.xfromy.data(), hp.xfromy.size(), s, ok);
-	plan.bfromy = st->upload(hp.bfromy.data(), hp.bfromy.size(), s, ok);
-	st->coeff_floats = hp.coeff_floats;
-	{   // the three coefficient planes are one allocation (hf_lanes_dev.h addresses a lane's channel by offset)
-		const size_t stride = (st->coeff_floats + 63) & ~(size_t) 63;
-		float *base = st->scratch<float>(3 * stride, ok);
-		for (int c = 0; c < 3; ++c) plan.coeffs[c] = base ? base + (size_t) c * stride : nullptr;
-		plan.coeff_stride = (uint32_t) stride;
-		plan.clear_after_read = 1;   // the planes start out zero and the pixel kernels keep them that way
-		if (base && hipMemsetAsync(base, 0, sizeof(float) * 3 * stride, s) != hipSuccess) ok = false;
-	}
-	const int32_t num_groups = hp.frame.num_groups;
-	plan.nonzeros = st->scratch<int8_t>((size_t) num_groups * 32 * 32 * 3, ok);
-	plan.status = st->scratch<uint32_t>(hp.sections.size(), ok);
-	plan.lz_window_size = hp.lz_window_size;
-	if (hp.lz_window_size) plan.lz_window = st->scratch<int32_t>((size_t) num_groups * hp.lz_window_size, ok);
-	st->total_sections = (int32_t) hp.sections.size();
-	st->first_group = 0; st->num_groups = num_groups;
 	st->vb_sorted = hp.vb_sorted;
 	memcpy(st->class_start, hp.class_start, sizeof st->class_start);
-	st->d_vb_sorted = st->upload(st->vb_sorted.data(), st->vb_sorted.size(), s, ok);
-	if (hp.max_large) st->d_large_scratch = st->scratch<float>((size_t) hp.max_large * 6 * 65536, ok);
+	Stager sg;
+	const size_t o_cs = sg.put(hp.codestream.data(), hp.codestream.size()), o_u8 = sg.put(hp.pool_u8.data(), hp.pool_u8.size());
+	const size_t o_u16 = sg.put(hp.pool_u16.data(), hp.pool_u16.size()), o_i32 = sg.put(hp.pool_i32.data(), hp.pool_i32.size());
+	const size_t o_u64 = sg.put(hp.pool_u64.data(), hp.pool_u64.size()), o_f32 = sg.put(hp.pool_f32.data(), hp.pool_f32.size());
+	const size_t o_cl = sg.put(hp.clusters.data(), hp.clusters.size()), o_spec = sg.put(hp.coeff_specs.data(), hp.coeff_specs.size());
+	const size_t o_lfg = sg.put(hp.lf_groups.data(), hp.lf_groups.size()), o_sec = sg.put(hp.sections.data(), hp.sections.size());
+	const size_t o_gb = sg.put(hp.group_blocks.data(), hp.group_blocks.size()), o_gbs = sg.put(hp.group_block_start.data(), hp.group_block_start.size());
+	const size_t o_frame = sg.put(&hp.frame, 1), o_blocks = sg.put(hp.blocks.data(), hp.blocks.size()), o_lfi = sg.put(hp.lfindices.data(), hp.lfindices.size());
+	size_t o_llf[3]; for (int c = 0; c < 3; ++c) o_llf[c] = sg.put(hp.llf[c].data(), hp.llf[c].size());
+	const size_t o_vbc = sg.put(hp.vb_coeffoff_qfidx.data(), hp.vb_coeffoff_qfidx.size()), o_vbh = sg.put(hp.vb_hfmul_inv.data(), hp.vb_hfmul_inv.size());
+	const size_t o_xfy = sg.put(hp.xfromy.data(), hp.xfromy.size()), o_bfy = sg.put(hp.bfromy.data(), hp.bfromy.size());
+	const size_t o_vbs = sg.put(st->vb_sorted.data(), st->vb_sorted.size());
+	bool dummy_clean = false;
+	st->plan_block = cache_acquire(device, sg.blob.size(), &st->plan_block_bytes, &dummy_clean);
+	if (!st->plan_block || hipMemcpyAsync(st->plan_block, sg.blob.data(), sg.blob.size(), hipMemcpyHostToDevice, s) != hipSuccess) ok = false;
+	uint8_t *pb = (uint8_t *) st->plan_block;
+	plan.codestream = pb + o_cs; plan.pool_u8 = pb + o_u8; plan.pool_u16 = (const uint16_t *) (pb + o_u16); plan.pool_i32 = (const int32_t *) (pb + o_i32);
+	plan.pool_u64 = (const uint64_t *) (pb + o_u64); plan.pool_f32 = (const float *) (pb + o_f32); plan.clusters = (const DevCluster *) (pb + o_cl);
+	plan.coeff_specs = (const DevCodeSpec *) (pb + o_spec); plan.lf_groups = (const DevLfGroup *) (pb + o_lfg); plan.sections = (const DevSection *) (pb + o_sec);
+	plan.group_blocks = (const DevGroupBlock *) (pb + o_gb); plan.group_block_start = (const uint32_t *) (pb + o_gbs); plan.frame = (const DevFrame *) (pb + o_frame);
+	plan.block_ctx_map_off = hp.block_ctx_map_off;
+	plan.blocks = (const int32_t *) (pb + o_blocks); plan.lfindices = pb + o_lfi;
+	for (int c = 0; c < 3; ++c) plan.llf[c] = (const float *) (pb + o_llf[c]);
+	plan.vb_coeffoff_qfidx = (const int32_t *) (pb + o_vbc); plan.vb_hfmul_inv = (const float *) (pb + o_vbh);
+	plan.xfromy = (const int16_t *) (pb + o_xfy); plan.bfromy = (const int16_t *) (pb + o_bfy);
+	st->d_vb_sorted = (DevVarblock *) (pb + o_vbs);
+	// working set: the three coefficient planes (one allocation: hf_lanes_dev.h addresses a lane's channel by offset), the
+	// non-zero scratch, status words, LZ77 windows, the scratch of the 128/256-sized transforms
+	st->coeff_floats = hp.coeff_floats;
+	const int32_t num_groups = hp.frame.num_groups;
+	{
+		auto align = [](size_t v) { return (v + 255) & ~(size_t) 255; };
+		const size_t stride = (st->coeff_floats + 63) & ~(size_t) 63;
+		const size_t w_coeffs = 0, coeff_bytes = sizeof(float) * 3 * stride;
+		const size_t w_nz = align(w_coeffs + coeff_bytes), w_status = align(w_nz + (size_t) num_groups * 32 * 32 * 3);
+		const size_t w_lz = align(w_status + sizeof(uint32_t) * hp.sections.size()), lz_bytes = sizeof(int32_t) * (size_t) num_groups * hp.lz_window_size;
+		const size_t w_large = align(w_lz + lz_bytes), large_bytes = sizeof(float) * (size_t) hp.max_large * 6 * 65536;
+		st->work_block = cache_acquire(device, w_large + large_bytes + 256, &st->work_block_bytes, &st->work_clean);
+		uint8_t *wb = (uint8_t *) st->work_block;
+		if (!wb) ok = false;
+		else {
+			for (int c = 0; c < 3; ++c) plan.coeffs[c] = (float *) (wb + w_coeffs) + (size_t) c * stride;
+			plan.coeff_stride = (uint32_t) stride;
+			plan.clear_after_read = 1;   // the planes start out zero and the pixel kernels keep them that way
+			if (!st->work_clean && hipMemsetAsync(wb + w_coeffs, 0, coeff_bytes, s) != hipSuccess) ok = false;
+			st->work_clean = true;
+			plan.nonzeros = (int8_t *) (wb + w_nz); plan.status = (uint32_t *) (wb + w_status);
+			plan.lz_window_size = hp.lz_window_size;
+			plan.lz_window = hp.lz_window_size ? (int32_t *) (wb + w_lz) : nullptr;
+			st->d_large_scratch = hp.max_large ? (float *) (wb + w_large) : nullptr;
+		}
+	}
+	st->total_sections = (int32_t) hp.sections.size();
+	st->first_group = 0; st->num_groups = num_groups;
 	upload_constant_tables(half_secants(), afv_basis(), srgb_u8_thresholds(), s);
 	for (auto &e : st->ev) if (hipEventCreate(&e) != hipSuccess) ok = false;
 	if (hipStreamSynchronize(s) != hipSuccess) ok = false;
@@ -299,6 +376,7 @@ static uint32_t decode_impl(j40hip_frame *h, void *rgba_dev, size_t stride_bytes
 	const DevPlan &plan = st->plan;
 	const Frame &fr = h->frame;
 	const bool whole = st->first_group == 0 && st->num_groups == fr.fh.num_groups;
+	st->work_clean = false;   // until the pixel kernels of this decode are known to have been enqueued
 	if (ms3) (void) hipEventRecord(st->ev[0], s);
 	if (!plan.clear_after_read && hipMemsetAsync(plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) plan.coeff_stride, s) != hipSuccess) return ERR_GPU;
 	if (hipMemsetAsync(plan.status, 0, sizeof(uint32_t) * (size_t) st->total_sections, s) != hipSuccess) return ERR_GPU;
@@ -424,6 +502,7 @@ static uint32_t batch_enqueue(j40hip_batch *b, void *const *rgba_dev, const size
 	if (ev) (void) hipEventRecord(ev[0], s);
 	for (j40hip_frame *h : b->frames) {
 		j40hip_device_state *st = h->dev;
+		st->work_clean = false;
 		if (!st->plan.clear_after_read && hipMemsetAsync(st->plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) st->plan.coeff_stride, s) != hipSuccess) return ERR_GPU;
 		if (hipMemsetAsync(st->plan.status, 0, sizeof(uint32_t) * (size_t) st->total_sections, s) != hipSuccess) return ERR_GPU;
 	}
@@ -448,7 +527,9 @@ static uint32_t batch_enqueue(j40hip_batch *b, void *const *rgba_dev, const size
 		}
 	}
 	if (ev) (void) hipEventRecord(ev[3], s);
-	return hipGetLastError() == hipSuccess ? 0 : ERR_GPU;
+	if (hipGetLastError() != hipSuccess) return ERR_GPU;
+	for (j40hip_frame *h : b->frames) h->dev->work_clean = h->dev->plan.clear_after_read != 0;
+	return 0;
 }
 
 static uint32_t events_to_ms(hipEvent_t *ev, float *ms3) {
@@ -525,15 +606,19 @@ extern "C" uint32_t j40hip_frame_status(j40hip_frame *h) {
 extern "C" uint32_t j40hip_frame_decode_to_host(j40hip_frame *h, void *rgba_host, size_t stride_bytes) {
 	if (!h || !h->dev) return ERR_GPU;
 	const Frame &fr = h->frame;
-	if (hipSetDevice(h->dev->device) != hipSuccess) return ERR_GPU;
-	const size_t row = (size_t) fr.fh.width * 4;
-	void *d = nullptr;
-	if (hipMalloc(&d, row * (size_t) fr.fh.height) != hipSuccess) return ERR_GPU;
-	uint32_t err = decode_impl(h, d, row, nullptr, nullptr);
+	const int device = h->dev->device;
+	if (hipSetDevice(device) != hipSuccess) return ERR_GPU;
+	// the device image uses the caller's row stride, so one contiguous copy brings it back
+	const size_t bytes = stride_bytes * (size_t) fr.fh.height;
+	size_t got = 0; bool clean = false;
+	void *d = cache_acquire(device, bytes, &got, &clean);
+	if (!d) return ERR_GPU;
+	uint32_t err = decode_impl(h, d, stride_bytes, nullptr, nullptr);
 	if (!err && hipStreamSynchronize(nullptr) != hipSuccess) err = ERR_GPU;
 	if (!err) err = j40hip_frame_status(h);
-	if (!err && hipMemcpy2D(rgba_host, stride_bytes, d, row, row, (size_t) fr.fh.height, hipMemcpyDeviceToHost) != hipSuccess) err = ERR_GPU;
-	(void) hipFree(d);
+	if (!err && hipMemcpy(rgba_host, d, bytes, hipMemcpyDeviceToHost) != hipSuccess) err = ERR_GPU;
+	(void) hipDeviceSynchronize();
+	cache_release(device, d, got, false);
 	return err;
 }
 
@@ -546,6 +631,7 @@ extern "C" uint32_t j40hip_frame_keep_coefficients(j40hip_frame *h, int keep) {
 	// whatever the previous mode left behind, start from clean planes
 	if (hipMemset(st->plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) st->plan.coeff_stride) != hipSuccess) return ERR_GPU;
 	st->plan.clear_after_read = keep ? 0 : 1;
+	st->work_clean = !keep;
 	return 0;
 }
 
