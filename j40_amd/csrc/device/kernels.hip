@@ -418,7 +418,6 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarbl
 	}
 	__syncthreads();
 	// ---- pass 1: IDCT of length C along c, one lane per (block, channel, r) ----
-#ifndef J40_EXP_NOPASS
 	for (int32_t w = tid; w < nb * 3 * R; w += nthreads) {
 		float *row = lds + (size_t) (w / R) * TILE + (w % R) * P;
 		float x[C];
@@ -440,7 +439,6 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarbl
 		for (int k = 0; k < R; ++k) col[k * P] = x[k];
 	}
 	__syncthreads();
-#endif
 	// ---- colour + pack: a lane owns pixel position (y, x) for every block of the workgroup ----
 #pragma unroll
 	for (int k = 0; k < PER; ++k) {
@@ -451,11 +449,7 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarbl
 			const VbGeom &g = geom[b];
 			if (y >= g.effh || x >= g.effw) continue;
 			const float *t = lds + (size_t) b * 3 * TILE + y * P + x;
-#ifdef J40_EXP_NOCOLOUR
-			const uint32_t px = __float_as_uint(t[0] + t[TILE] + t[2 * TILE]);
-#else
 			const uint32_t px = xyb_to_rgba8(t[0], t[TILE], t[2 * TILE], cc, srgb_thr);
-#endif
 			*(uint32_t *) (rgba + g_out[b] + in_block) = px;
 		}
 	}

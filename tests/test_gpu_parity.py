@@ -194,6 +194,10 @@ def test_batch_throughput_mode_matches_latency_mode(gpu, ref):
         assert frames[1].status() == ""
         rerr, _ = ref.decode(bytes(bad))
         assert fb.status() == rerr
+        # a failed decode leaves the coefficient planes clean too (whatever its sections stored was consumed and zeroed)
+        for g in range(fb.info["num_lf_groups"]):
+            for c in range(3):
+                assert not fb.read_coeffs(g, c).any()
         b2.close()
     batch.close()
 
