@@ -652,12 +652,48 @@ static void prepare_tables(Frame *f) {  // j40.h:7694-7732
 
 // ------------------------------------------------------------------------------------------------
 
+// ICC stream (j40.h:3351-3393): like the reference, decoded and discarded -- the renderer always produces sRGB
+static void skip_icc(BitReader &br) {
+	const uint64_t enc_size = br.u64();
+	CodeSpec spec;
+	read_code_spec(br, 41, &spec);
+	CodeState code(&spec);
+	uint64_t index = 0, output_size = 0;
+	{   // output size: a varint of bytes coded with context 0
+		int32_t shift = 0;
+		for (;;) {
+			J40HIP_SHOULD(index++ < enc_size, "icc?");
+			const int32_t b = decode_symbol(br, code, 0, 0);
+			output_size |= (uint64_t) (b & 0x7f) << shift;
+			if (b < 128) break;
+			shift += 7;
+			J40HIP_SHOULD(shift < 63, "vint");
+		}
+	}
+	J40HIP_SHOULD(output_size <= ((uint64_t) 1 << 22), "plim");   // main profile, level 5 (j40.h:1172)
+	J40HIP_SHOULD(output_size >= enc_size / 21, "icc?");
+	int32_t byte = 0, prev = 0, pprev = 0;
+	auto kind = [](int32_t v) { return (97 <= (v | 32) && (v | 32) <= 122) ? 0 : (v == 44 || v == 46 || (48 <= v && v < 58)) ? 1 : 4; };
+	for (; index < enc_size; ++index) {
+		pprev = prev; prev = byte;
+		int32_t ctx = 0;
+		if (index > 128) {
+			if (prev < 16) ctx = prev < 2 ? prev + 3 : 5;
+			else if (prev > 240) ctx = 6 + (prev == 255);
+			else ctx = kind(prev) == 0 ? 1 : kind(prev) == 1 ? 2 : 8;
+			ctx += 8 * (pprev < 16 ? 2 : pprev > 240 ? 3 : kind(pprev));
+		}
+		byte = decode_symbol(br, code, ctx, 0);
+	}
+	finish_code(br, code);
+}
+
 void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
 	memset(f->order_has_lehmer, 0, sizeof f->order_has_lehmer);
 	BitReader br(cs, cs_size);
 	J40HIP_SHOULD(br.u(16) == 0x0aff, "!jxl");
 	read_image_metadata(br, &f->im);
-	J40HIP_SHOULD(!f->im.want_icc, "TODO");  // ICC streams: not handled yet
+	if (f->im.want_icc) skip_icc(br);
 	read_frame_header(br, f->im, &f->fh);
 	J40HIP_SHOULD(f->fh.is_last, "TODO");
 	J40HIP_SHOULD(f->fh.type == 0, "TODO");

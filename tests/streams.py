@@ -43,6 +43,7 @@ VARDCT_CASES = [
     ("hf_prefix_codes", dict(hfprefix=1)),                  # HF coefficient streams with prefix codes (fast encoders)
     ("hf_lz77", dict(hflz77=1)),                            # ... with LZ77 copies
     ("hf_prefix_lz77_passes", dict(hfprefix=1, hflz77=1, passes=2)),
+    ("icc_profile", dict(icc=700)),                         # want_icc: the ICC stream is decoded and discarded like in the reference
 ]
 
 # the Modular feature matrix (width, height, options); all decode bit-exactly
@@ -60,4 +61,5 @@ MODULAR_CASES = [
     ("no_rct_group128_lz77", 200, 100, dict(rct=-1, groupshift=7, lz77=1)),
     ("palette_prediction_wp_tree", 160, 120, dict(palette=3, tree=2)),
     ("container", 300, 200, dict(container=1, tree=1)),
+    ("icc_profile", 256, 256, dict(icc=500, alpha=1)),
 ]

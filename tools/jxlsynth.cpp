@@ -501,8 +501,24 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 	BitWriter cs;
 	cs.put(0xff, 8); cs.put(0x0a, 8);
 	write_size_header(cs, W, H);
-	cs.put(1, 1);   // ImageMetadata.all_default: 8-bit, XYB, no extra channels
-	cs.put(1, 1);   // default_m
+	const int icc_bytes = opt.geti("icc", 0);                // > 0: ColourEncoding with want_icc and an ICC stream of that many coded bytes
+	if (!icc_bytes) {
+		cs.put(1, 1);   // ImageMetadata.all_default: 8-bit, XYB, no extra channels
+		cs.put(1, 1);   // default_m
+	} else {
+		cs.put(0, 1);                       // ImageMetadata: not all_default
+		cs.put(0, 1);                       // no extra fields
+		cs.put(0, 1); cs.put(0, 2);         // integer samples, 8 bits
+		cs.put(1, 1);                       // modular_16bit_buffers
+		cs.put(0, 2);                       // no extra channels
+		cs.put(1, 1);                       // xyb_encoded
+		cs.put(0, 1);                       // ColourEncoding: not all_default
+		cs.put(1, 1);                       // want_icc
+		cs.put(0, 2);                       // colour_space = RGB (enum selector 0)
+		cs.put(0, 2);                       // extensions
+		cs.put(1, 1);                       // default_m
+		write_icc_stream(cs, rng, icc_bytes);
+	}
 	cs.pad();       // frame header starts byte aligned (j40.h:5228)
 	if (!nonzero_header) cs.put(1, 1);  // FrameHeader.all_default
 	else {
@@ -785,9 +801,12 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	cs.put(1, 1);                       // modular_16bit_buffers
 	if (alpha) { cs.put(1, 2); cs.put(1, 1); } else cs.put(0, 2);   // num_extra_channels (+ d_alpha)
 	cs.put(0, 1);                       // xyb_encoded = 0
-	cs.put(1, 1);                       // ColourEncoding.all_default (sRGB)
+	const int icc_bytes = opt.geti("icc", 0);
+	if (!icc_bytes) cs.put(1, 1);       // ColourEncoding.all_default (sRGB)
+	else { cs.put(0, 1); cs.put(1, 1); cs.put(0, 2); }   // want_icc, colour_space = RGB
 	cs.put(0, 2);                       // extensions
 	cs.put(1, 1);                       // default_m
+	if (icc_bytes) write_icc_stream(cs, rng, icc_bytes);
 	cs.pad();
 	cs.put(0, 1);                       // FrameHeader: not all_default
 	cs.put(0, 2);                       // regular frame

@@ -496,4 +496,46 @@ inline bool write_file(const char *path, const std::vector<uint8_t> &bytes) {
 	return n == bytes.size();
 }
 
+// ICC stream as the reference reads it (j40.h:3351-3393): enc_size, a 41-context code spec, the output size as a varint
+// coded with context 0, then the remaining enc_size - (varint bytes) command/data bytes with the previous-two-bytes
+// context model. The reference decodes and discards the bytes, so their content is free.
+template <typename RNG> static inline void write_icc_stream(BitWriter &bw, RNG &rng, int enc_size) {
+	CodeSpecW spec;
+	std::vector<uint8_t> map(41);
+	for (int i = 0; i < 41; ++i) map[(size_t) i] = (uint8_t) (i == 0 ? 0 : 1 + i % 2);
+	spec.init(41, map, 3);
+	spec.log_alpha = 8;
+	for (auto &c : spec.cfg) c = HybridCfg{4, 2, 0};
+	StreamEncoder enc(spec);
+	uint64_t index = 0;
+	{   // output_size = enc_size (every byte produces at least one output byte in the reference's model)
+		uint64_t v = (uint64_t) enc_size;
+		do { uint32_t b = (uint32_t) (v & 0x7f); v >>= 7; if (v) b |= 0x80; enc.add(0, b); ++index; } while (v);
+	}
+	int byte = 0, prev = 0, pprev = 0;
+	for (; index < (uint64_t) enc_size; ++index) {
+		pprev = prev; prev = byte;
+		int ctx = 0;
+		if (index > 128) {
+			if (prev < 16) ctx = prev < 2 ? prev + 3 : 5;
+			else if (prev > 240) ctx = 6 + (prev == 255);
+			else if (97 <= (prev | 32) && (prev | 32) <= 122) ctx = 1;
+			else if (prev == 44 || prev == 46 || (48 <= prev && prev < 58)) ctx = 2;
+			else ctx = 8;
+			if (pprev < 16) ctx += 2 * 8;
+			else if (pprev > 240) ctx += 3 * 8;
+			else if (97 <= (pprev | 32) && (pprev | 32) <= 122) ctx += 0 * 8;
+			else if (pprev == 44 || pprev == 46 || (48 <= pprev && pprev < 58)) ctx += 1 * 8;
+			else ctx += 4 * 8;
+		}
+		const uint32_t r = rng.below(8);
+		byte = r < 3 ? (int) rng.below(256) : r < 5 ? 'a' + (int) rng.below(26) : r == 5 ? '0' + (int) rng.below(10) : r == 6 ? 0 : 255;
+		enc.add((uint32_t) ctx, (uint32_t) byte);
+	}
+	count_stream(spec, enc);
+	bw.u64((uint64_t) enc_size);
+	write_code_spec(bw, spec);
+	enc.flush(bw);
+}
+
 } // namespace synth
