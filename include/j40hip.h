@@ -88,6 +88,7 @@ typedef struct { uint32_t byte_off, size, bit_off; int32_t ggidx, gx_in_gg, gy_i
 typedef struct {
 	int32_t width, height, num_passes, num_groups, num_lf_groups;
 	int32_t nb_block_ctx, nb_qf_thr, nb_lf_thr[3], num_hf_presets, bpp;
+	int32_t sections_have_trailer;   /* extra channels: a Modular sub-image follows the coefficients of each section (not decoded) */
 	int32_t global_scale, x_qm_scale, b_qm_scale, x_factor_lf, b_factor_lf;
 	float quant_bias[3], quant_bias_num, base_corr_x, base_corr_b, inv_colour_factor;
 	float opsin_inv_mat[9], opsin_bias[3], intensity_target;

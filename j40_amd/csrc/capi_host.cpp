@@ -110,13 +110,14 @@ static void fill_codespec_view(j40hip_frame *h, const CodeSpec &spec, j40hip_cod
 
 uint32_t j40hip_frame_vardct_view(j40hip_frame *h, j40hip_vardct_view *v) {
 	const Frame &f = h->frame;
-	if (f.fh.is_modular || !f.im.ec.empty() || f.im.grey || !f.im.xyb_encoded || f.fh.do_ycbcr || f.im.bpp < 8 || f.im.exp_bits) return E4("TODO");
+	if (f.fh.is_modular || f.im.grey || !f.im.xyb_encoded || f.fh.do_ycbcr || f.im.bpp < 8 || f.im.exp_bits) return E4("TODO");
 	memset(v, 0, sizeof *v);
 	h->views = j40hip_frame::Views();
 	h->views.clusters.reserve(16);
 	v->width = f.fh.width; v->height = f.fh.height; v->num_passes = f.fh.num_passes; v->num_groups = (int32_t) f.fh.num_groups; v->num_lf_groups = (int32_t) f.fh.num_lf_groups;
 	v->nb_block_ctx = f.nb_block_ctx; v->nb_qf_thr = f.nb_qf_thr; for (int i = 0; i < 3; ++i) v->nb_lf_thr[i] = f.nb_lf_thr[i];
 	v->num_hf_presets = f.num_hf_presets; v->bpp = f.im.bpp;
+	v->sections_have_trailer = (int32_t) f.gmodular.channel.size() > f.num_gm_channels;
 	v->global_scale = f.global_scale; v->x_qm_scale = f.fh.x_qm_scale; v->b_qm_scale = f.fh.b_qm_scale; v->x_factor_lf = f.x_factor_lf; v->b_factor_lf = f.b_factor_lf;
 	for (int i = 0; i < 3; ++i) { v->quant_bias[i] = f.im.quant_bias[i]; v->opsin_bias[i] = f.im.opsin_bias[i]; for (int j = 0; j < 3; ++j) v->opsin_inv_mat[i * 3 + j] = f.im.opsin_inv_mat[i][j]; }
 	v->quant_bias_num = f.im.quant_bias_num; v->base_corr_x = f.base_corr_x; v->base_corr_b = f.base_corr_b; v->inv_colour_factor = f.inv_colour_factor;

@@ -108,7 +108,7 @@ J40_DEV uint32_t decode_hf_section(const DevPlan &plan, const DevFrame &f, const
 		}
 	}
 	if (!b.err) code_finish<UNI>(b, code);
-	if (!b.err) bits_finish_section(b);
+	if (!b.err && !f.sections_have_trailer) bits_finish_section(b);
 	return b.err;
 }
 
@@ -188,7 +188,7 @@ J40_DEV uint32_t decode_hf_section_flat(const DevPlan &plan, const DevFrame &f, 
 		if (!in_coeffs && ++c_yxb == 3) { c_yxb = 0; done = ++k >= t.nblocks; }
 	}
 	if (!b.err) code_finish<false>(b, code);
-	if (!b.err) bits_finish_section(b);
+	if (!b.err && !f.sections_have_trailer) bits_finish_section(b);
 	return b.err;
 }
 

@@ -86,7 +86,11 @@ struct DevFrame {
 	// the pixel kernels gather through the inverse order: inv_order[j] = scan position of canonical index j
 	int32_t scan_order_coeffs;
 	uint32_t inv_order_off[13 * 3];   // into the u16 pool
-	int32_t order_same[13];           // pass 0: the three channels share one coefficient order (the usual case)
+	int32_t order_same[13];
+	// frames with extra channels: a Modular sub-image follows the HF coefficients in every pass-group section (j40.h:7024-7034).
+	// The reference decodes it and then drops it (j40__combine_vardct replaces the channel list, j40.h:7868-7870: the output is
+	// opaque); here it is not decoded, so a section does not have to end where its coefficients end.
+	int32_t sections_have_trailer;           // pass 0: the three channels share one coefficient order (the usual case)
 };
 
 // everything a kernel needs, passed by value

@@ -53,7 +53,6 @@ void coeffs_scan_to_canonical(const Frame &fr, size_t ggidx, int c, float *data)
 
 uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostPlan *hp) {
 	if (fr.fh.is_modular) return ERR_TODO;
-	if (!fr.im.ec.empty()) return ERR_TODO;          // VarDCT + extra channels
 	if (fr.im.grey || !fr.im.xyb_encoded || fr.fh.do_ycbcr) return ERR_TODO;  // same limits as j40.h:7867, 7917-7921
 	if (fr.im.bpp < 8 || fr.im.exp_bits) return ERR_TODO;
 
@@ -65,6 +64,7 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 	df.lfidx_size = (fr.nb_lf_thr[0] + 1) * (fr.nb_lf_thr[1] + 1) * (fr.nb_lf_thr[2] + 1);
 	df.num_hf_presets = fr.num_hf_presets; df.preset_bits = ceil_lg32((uint32_t) fr.num_hf_presets);
 	df.bpp = fr.im.bpp;
+	df.sections_have_trailer = (int32_t) fr.gmodular.channel.size() > fr.num_gm_channels;
 	for (int c = 0; c < 3; ++c) { df.quant_bias[c] = fr.im.quant_bias[c]; df.opsin_bias[c] = fr.im.opsin_bias[c]; df.cbrt_opsin_bias[c] = cbrtf(fr.im.opsin_bias[c]); }
 	df.quant_bias_num = fr.im.quant_bias_num;
 	static const float QM_SCALE[8] = {1.5625f, 1.25f, 1.0f, 0.8f, 0.64f, 0.512f, 0.4096f, 0.32768f};  // 0.8^(i-2), j40.h:7055

@@ -271,7 +271,9 @@ static uint32_t hf_coeffs(const j40hip_vardct_view *v, int pass, const j40hip_se
 		}
 	}
 	if (!b.err) ocode_finish(&b, code);
-	if (!b.err) obits_finish(&b);
+	/* extra channels: the group's Modular sub-image follows (j40.h:7024-7034); the reference decodes and then drops it
+	 * (j40.h:7868-7870), this restatement of the pixel path stops at the coefficients */
+	if (!b.err && !v->sections_have_trailer) obits_finish(&b);
 	free(nonzeros);
 	return b.err;
 }

@@ -43,7 +43,8 @@ VARDCT_CASES = [
     ("hf_prefix_codes", dict(hfprefix=1)),                  # HF coefficient streams with prefix codes (fast encoders)
     ("hf_lz77", dict(hflz77=1)),                            # ... with LZ77 copies
     ("hf_prefix_lz77_passes", dict(hfprefix=1, hflz77=1, passes=2)),
-    ("icc_profile", dict(icc=700)),                         # want_icc: the ICC stream is decoded and discarded like in the reference
+    ("icc_profile", dict(icc=700)),
+    ("alpha_extra_channel", dict(alpha=1)),                 # Modular sub-image after the HF coefficients of every group; the reference outputs opaque pixels                         # want_icc: the ICC stream is decoded and discarded like in the reference
 ]
 
 # the Modular feature matrix (width, height, options); all decode bit-exactly

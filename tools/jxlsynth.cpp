@@ -281,6 +281,27 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 		count_stream(gspec, lfq_enc.back()); count_stream(gspec, meta_enc.back());
 	}
 
+	// ---- optional alpha extra channel: a Modular sub-image per pass group, coded after the group's HF coefficients
+	//      (j40.h:7024-7034) with the global tree and code spec ----
+	const int with_alpha = opt.geti("alpha", 0);
+	if (with_alpha && num_passes > 1) die("vardct: alpha with several passes is not generated");
+	std::vector<StreamEncoder> alpha_enc;
+	if (with_alpha) {
+		Channel alpha(W, H);
+		for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+			int v = (x * 3 + y * 2) / 4 + (int) rng.below(5) - 2 + (((x / 40) + (y / 24)) % 3 == 0 ? 90 : 0);
+			alpha.at(x, y) = std::max(0, std::min(255, v));
+		}
+		for (int g = 0; g < num_groups; ++g) {
+			const int gx = (g % gcols) * 256, gy = (g / gcols) * 256, gw = std::min(256, W - gx), gh = std::min(256, H - gy);
+			std::vector<Channel> sub(1, Channel(gw, gh));
+			for (int y = 0; y < gh; ++y) for (int x = 0; x < gw; ++x) sub[0].at(x, y) = alpha.at(gx + x, gy + y);
+			alpha_enc.emplace_back(gspec);
+			encode_channel(tree, sub, 0, 1 + 3 * num_lf_groups + 17 + g, wpp, alpha_enc.back());
+			count_stream(gspec, alpha_enc.back());
+		}
+	}
+
 	// ---- HF coefficients: tokens per (pass, group) with the decoder's context model ----
 	const int ctx_per_preset = 495 * nb_block_ctx;
 	const int hf_prefix = opt.geti("hfprefix", 0);          // HF coefficient streams with prefix codes instead of rANS
@@ -449,6 +470,10 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 		bw.put(1, 1);                                            // global tree present
 		write_code_spec(bw, treespec); tree_enc.flush(bw);
 		write_code_spec(bw, gspec);
+		if (with_alpha) {   // the global Modular image (extra channels only): header, no channel decoded here (j40.h:6329-6338)
+			write_modular_header(bw, true, nullptr, {});
+			StreamEncoder none(gspec); none.flush(bw);
+		}
 		bw.pad();
 		sections.push_back(bw.bytes);
 	}
@@ -493,6 +518,7 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 		BitWriter bw;
 		bw.put((uint64_t) group_preset[(size_t) g], ceil_lg((uint32_t) num_presets));
 		hf_enc[(size_t) pass][(size_t) g].flush(bw);
+		if (with_alpha) { write_modular_header(bw, true, nullptr, {}); alpha_enc[(size_t) g].flush(bw); }
 		bw.pad();
 		sections.push_back(bw.bytes);
 	}
@@ -502,9 +528,19 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 	cs.put(0xff, 8); cs.put(0x0a, 8);
 	write_size_header(cs, W, H);
 	const int icc_bytes = opt.geti("icc", 0);                // > 0: ColourEncoding with want_icc and an ICC stream of that many coded bytes
-	if (!icc_bytes) {
+	if (!icc_bytes && !with_alpha) {
 		cs.put(1, 1);   // ImageMetadata.all_default: 8-bit, XYB, no extra channels
 		cs.put(1, 1);   // default_m
+	} else if (!icc_bytes) {
+		cs.put(0, 1);                       // ImageMetadata: not all_default
+		cs.put(0, 1);                       // no extra fields
+		cs.put(0, 1); cs.put(0, 2);         // integer samples, 8 bits
+		cs.put(1, 1);                       // modular_16bit_buffers
+		cs.put(1, 2); cs.put(1, 1);         // one extra channel, d_alpha
+		cs.put(1, 1);                       // xyb_encoded
+		cs.put(1, 1);                       // ColourEncoding.all_default
+		cs.put(0, 2);                       // extensions
+		cs.put(1, 1);                       // default_m
 	} else {
 		cs.put(0, 1);                       // ImageMetadata: not all_default
 		cs.put(0, 1);                       // no extra fields
