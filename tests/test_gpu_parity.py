@@ -229,6 +229,44 @@ def test_group_ranges_decode_disjoint_parts_of_the_frame(gpu, ref):
     assert rerr == "" and compare(whole, expect)[0] <= 1
 
 
+def test_baseline_config_sizes(gpu, ref):
+    """BASELINE.json's configurations at (or near) their full sizes against the reference: config 1 (256x256 Modular RGBA,
+    single section, prefix codes + LZ77), config 2 (3840x2160 VarDCT, latency mode), config 5 (a batch of 1920x1080 VarDCT
+    frames, throughput mode: 40 groups per frame, i.e. partially filled wavefronts), config 4's shape at 2048x2048
+    (multi-group Modular with a global RCT). Config 3 (7680x4320) is compared with the reference inside bench.py."""
+    import torch
+    data = synth("modular", 256, 256, 101, alpha=1, prefix=1, lz77=1)
+    err, rgba = gpu.decode(data)
+    rerr, expect = ref.decode(data)
+    assert err == rerr == "" and np.array_equal(rgba, expect)
+
+    data = synth("vardct", 3840, 2160, 102)
+    err, rgba = gpu.decode(data)
+    rerr, expect = ref.decode(data)
+    assert err == rerr == "" and compare(rgba, expect)[0] <= 1
+
+    frames, outs, datas = [], [], []
+    for i in range(6):
+        d = synth("vardct", 1920, 1080, 110 + i % 3)
+        fr = gpu.Frame(d); fr.upload(0)
+        frames.append(fr); datas.append(d)
+        outs.append(torch.zeros((1080, 1920, 4), dtype=torch.uint8, device="cuda:0"))
+    batch = gpu.Batch(frames)
+    batch.decode([o.data_ptr() for o in outs], [1920 * 4] * len(outs), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for fr, o, d in zip(frames[:3], outs[:3], datas[:3]):
+        assert fr.status() == ""
+        rerr, expect = ref.decode(d)
+        assert rerr == "" and compare(o.cpu().numpy(), expect)[0] <= 1
+    assert torch.equal(outs[0], outs[3]) and torch.equal(outs[2], outs[5])
+    batch.close()
+
+    data = synth("modular", 2048, 2048, 103)
+    err, rgba = gpu.decode(data)
+    rerr, expect = ref.decode(data)
+    assert err == rerr == "" and np.array_equal(rgba, expect)
+
+
 def test_golden_fixtures(gpu):
     manifest = json.load(open(os.path.join(GOLDEN, "manifest.json")))
     for name, e in sorted(manifest.items()):
