@@ -10,16 +10,21 @@ namespace j40hip {
 struct ModNeigh { int32_t w, n, nw, ne, nn, nee, ww, nww; };
 
 // neighbours inside the group's own rectangle (x, y and width are group-local; j40.h:3965-3990)
+template <bool UNI = false>
 J40_DEV ModNeigh mod_neighbours(const int16_t *px /* row y, column 0 of the rectangle */, int32_t stride, int32_t width, int32_t x, int32_t y) {
 	ModNeigh p;
-	p.w = x > 0 ? px[x - 1] : y > 0 ? px[x - stride] : 0;
-	p.n = y > 0 ? px[x - stride] : p.w;
-	p.nw = x > 0 && y > 0 ? px[(x - 1) - stride] : p.w;
-	p.ne = x + 1 < width && y > 0 ? px[(x + 1) - stride] : p.n;
-	p.nn = y > 1 ? px[x - 2 * stride] : p.n;
-	p.nee = x + 2 < width && y > 0 ? px[(x + 2) - stride] : p.ne;
-	p.ww = x > 1 ? px[x - 2] : p.w;
-	p.nww = x > 1 && y > 0 ? px[(x - 2) - stride] : p.ww;
+	// every sample that exists is requested first (independent loads), the fallbacks are resolved afterwards
+	const int32_t vw = x > 0 ? px[x - 1] : 0, vn = y > 0 ? px[x - stride] : 0, vnw = x > 0 && y > 0 ? px[(x - 1) - stride] : 0;
+	const int32_t vne = x + 1 < width && y > 0 ? px[(x + 1) - stride] : 0, vnn = y > 1 ? px[x - 2 * stride] : 0;
+	const int32_t vnee = x + 2 < width && y > 0 ? px[(x + 2) - stride] : 0, vww = x > 1 ? px[x - 2] : 0, vnww = x > 1 && y > 0 ? px[(x - 2) - stride] : 0;
+	p.w = uni<UNI>(x > 0 ? vw : y > 0 ? vn : 0);
+	p.n = uni<UNI>(y > 0 ? vn : p.w);
+	p.nw = uni<UNI>(x > 0 && y > 0 ? vnw : p.w);
+	p.ne = uni<UNI>(x + 1 < width && y > 0 ? vne : p.n);
+	p.nn = uni<UNI>(y > 1 ? vnn : p.n);
+	p.nee = uni<UNI>(x + 2 < width && y > 0 ? vnee : p.ne);
+	p.ww = uni<UNI>(x > 1 ? vww : p.w);
+	p.nww = uni<UNI>(x > 1 && y > 0 ? vnww : p.ww);
 	return p;
 }
 
@@ -39,16 +44,17 @@ struct ModWP {
 	int32_t trueerrw, trueerrn, trueerrnw, trueerrne;
 };
 
+template <bool UNI = false>
 J40_DEV void wp_before(ModWP &s, int32_t x, int32_t y, const ModNeigh &p) {
 	if (!s.on) return;
 	const int32_t *err = s.errors + (size_t) ((y & 1) ? s.width : 0) * 5, *nerr = s.errors + (size_t) ((y & 1) ? 0 : s.width) * 5;
 	int32_t errw[5], errn[5], errnw[5], errne[5], errww[5], errw2[5];
 	for (int i = 0; i < 5; ++i) {
-		errw[i] = x > 0 ? err[(x - 1) * 5 + i] : 0;
-		errn[i] = y > 0 ? nerr[x * 5 + i] : 0;
-		errnw[i] = x > 0 && y > 0 ? nerr[(x - 1) * 5 + i] : errn[i];
-		errne[i] = x + 1 < s.width && y > 0 ? nerr[(x + 1) * 5 + i] : errn[i];
-		errww[i] = x > 1 ? err[(x - 2) * 5 + i] : 0;
+		errw[i] = uni<UNI>(x > 0 ? err[(x - 1) * 5 + i] : 0);
+		errn[i] = uni<UNI>(y > 0 ? nerr[x * 5 + i] : 0);
+		errnw[i] = uni<UNI>(x > 0 && y > 0 ? nerr[(x - 1) * 5 + i] : errn[i]);
+		errne[i] = uni<UNI>(x + 1 < s.width && y > 0 ? nerr[(x + 1) * 5 + i] : errn[i]);
+		errww[i] = uni<UNI>(x > 1 ? err[(x - 2) * 5 + i] : 0);
 		errw2[i] = x + 1 < s.width ? 0 : errw[i];
 	}
 	s.trueerrw = errw[4];
@@ -101,16 +107,39 @@ J40_DEV int32_t mod_predict(int32_t predictor, const ModWP &wp, const ModNeigh &
 	}
 }
 
-// K3: one pass-group section = every not-yet-decoded channel of the group's rectangle, one stream
-J40_DEV uint32_t decode_modular_section(const DevModPlan &plan, int32_t g) {
-	const DevModFrame &f = *plan.frame;
-	const DevModSection &sec = plan.sections[g];
+// what the per-pixel loop keeps touching: the kernel stages these in LDS when they fit, else they point into HBM
+struct ModTables {
+	const DevTreeNode *tree;
+	const DevCluster *clusters;      // of the global code spec
+	const uint8_t *cluster_map;
+	const uint64_t *alias;           // base DevCluster::table_off indexes
+	const int32_t *prefix;
+	int32_t *rows;                   // ring of three rows, [3][rows_width] int32, or nullptr: neighbours are read back from the plane
+	int32_t rows_width;
+	int32_t *wp_errors;              // weighted-predictor error rows [2 * width][5] in LDS, or nullptr: the HBM scratch
+	int32_t wp_errors_width;
+};
+J40_DEV ModTables mod_tables_in_hbm(const DevModPlan &plan) {
+	const DevCodeSpec &spec = *plan.spec;
+	ModTables t = {plan.tree, plan.clusters + spec.cluster_off, plan.pool_u8 + spec.cluster_map_off, plan.pool_u64, plan.pool_i32, nullptr, 0, nullptr, 0};
+	return t;
+}
+
+// K3: one pass-group section = every not-yet-decoded channel of the group's rectangle, one stream.
+// UNI: every lane of the wavefront runs this on the same section (wave-uniform decoder state, see entropy_dev.h).
+// RING: neighbours come from t.rows and the weighted predictor's rows from t.wp_errors (both sized for the widest rectangle of
+// the frame by the caller), never from HBM -- a compile-time choice so that their address space stays static.
+template <bool UNI, bool RING>
+J40_DEV uint32_t decode_modular_section(const DevModPlan &plan, const ModTables &t, int32_t g) {
+	// by value: references into HBM would be re-read after every sample store (the compiler cannot rule out aliasing)
+	const DevModFrame f = *plan.frame;
+	const DevModSection sec = plan.sections[g];
 	const DevCodeSpec &spec = *plan.spec;
 	DevBits b;
-	bits_init<false>(b, plan.codestream, sec.byte_off, sec.size, sec.bit_off);
+	bits_init<UNI>(b, plan.codestream, sec.byte_off, sec.size, sec.bit_off);
 	DevCode code;
 	int32_t *window = plan.lz_window ? plan.lz_window + (size_t) g * plan.lz_window_size : nullptr;
-	code_init(code, spec, plan.clusters + spec.cluster_off, plan.pool_u8 + spec.cluster_map_off, plan.pool_u64, plan.pool_i32, window);
+	code_init(code, spec, t.clusters, t.cluster_map, t.alias, t.prefix, window);
 	// LZ77 distance multiplier: widest non-meta channel of this sub-image (j40.h:3841-3844)
 	int32_t dist_mult = 0;
 	for (int32_t cidx = 0; cidx < sec.num_channels; ++cidx) if (!plan.plane_meta[sec.first_channel + cidx]) dist_mult = mod_max(dist_mult, sec.gw);
@@ -120,7 +149,7 @@ J40_DEV uint32_t decode_modular_section(const DevModPlan &plan, int32_t g) {
 	wp.p1 = sec.wp[0]; wp.p2 = sec.wp[1];
 	for (int i = 0; i < 5; ++i) wp.p3[i] = sec.wp[2 + i];
 	for (int i = 0; i < 4; ++i) wp.w[i] = sec.wp[7 + i];
-	wp.errors = plan.wp_scratch ? plan.wp_scratch + (size_t) g * (size_t) (2 * f.max_width * 5) : nullptr;
+	wp.errors = nullptr;
 	for (int i = 0; i < 5; ++i) wp.pred[i] = 0;
 	wp.trueerrw = wp.trueerrn = wp.trueerrnw = wp.trueerrne = 0;
 	uint32_t err = 0;
@@ -133,14 +162,41 @@ J40_DEV uint32_t decode_modular_section(const DevModPlan &plan, int32_t g) {
 		if (gw <= 0 || gh <= 0) continue;
 		int16_t *base = plan.planes[ch] + (size_t) gy * (size_t) stride + (size_t) gx;
 		wp.width = gw;
-		if (wp.on) { for (int32_t i = 0; i < 2 * gw * 5; ++i) wp.errors[i] = 0; for (int i = 0; i < 5; ++i) wp.pred[i] = 0; wp.trueerrw = wp.trueerrn = wp.trueerrnw = wp.trueerrne = 0; }
+		constexpr bool ring = RING;
+		if (wp.on) {
+			if (RING) wp.errors = t.wp_errors; else wp.errors = plan.wp_scratch + (size_t) g * (size_t) (2 * f.max_width * 5);
+			for (int32_t i = 0; i < 2 * gw * 5; ++i) wp.errors[i] = 0;
+			for (int i = 0; i < 5; ++i) wp.pred[i] = 0;
+			wp.trueerrw = wp.trueerrn = wp.trueerrnw = wp.trueerrne = 0;
+		}
 		for (int32_t y = 0; y < gh && !b.err && !err; ++y) {
 			int16_t *row = base + (size_t) y * (size_t) stride;
+			int32_t *cur = t.rows + (y % 3) * t.rows_width;
+			const int32_t *prev = t.rows + ((y + 2) % 3) * t.rows_width, *pprev = t.rows + ((y + 1) % 3) * t.rows_width;
+			// RING: the neighbourhood slides along the row in registers -- of the eight neighbours only NN and the sample that
+			// will be NEE of the next pixel are fetched per pixel (rows hold 3 spare entries, so x + 3 is always addressable;
+			// entries outside the rectangle and the rows above the first are never selected)
+			int32_t r_nww = 0, r_nw = 0, r_n = 0, r_ne = 0, r_nee = 0, c_w = 0, c_ww = 0;
+			if (ring) { r_n = uni<UNI>(prev[0]); r_ne = uni<UNI>(prev[1]); r_nee = uni<UNI>(prev[2]); }
 			for (int32_t x = 0; x < gw; ++x) {
-				const ModNeigh p = mod_neighbours(row, stride, gw, x, y);
-				wp_before(wp, x, y, p);
-				const DevTreeNode *n = plan.tree;
-				DevTreeNode node = *n;
+				ModNeigh p;
+				int32_t r_next = 0;
+				if (ring) {
+					const int32_t vnn = uni<UNI>(pprev[x]);
+					r_next = uni<UNI>(prev[x + 3]);
+					p.w = x > 0 ? c_w : y > 0 ? r_n : 0;
+					p.n = y > 0 ? r_n : p.w;
+					p.nw = x > 0 && y > 0 ? r_nw : p.w;
+					p.ne = x + 1 < gw && y > 0 ? r_ne : p.n;
+					p.nn = y > 1 ? vnn : p.n;
+					p.nee = x + 2 < gw && y > 0 ? r_nee : p.ne;
+					p.ww = x > 1 ? c_ww : p.w;
+					p.nww = x > 1 && y > 0 ? r_nww : p.ww;
+				} else p = mod_neighbours<UNI>(row, stride, gw, x, y);
+				wp_before<UNI>(wp, x, y, p);
+				const DevTreeNode *n = t.tree;
+				DevTreeNode node;
+				{ const int32_t *w4 = (const int32_t *) n; node.prop = uni<UNI>(w4[0]); node.value = uni<UNI>(w4[1]); node.a = uni<UNI>(w4[2]); node.b = uni<UNI>(w4[3]); }
 				while (node.prop >= 0) {
 					int32_t val;
 					switch (node.prop) {
@@ -177,31 +233,32 @@ J40_DEV uint32_t decode_modular_section(const DevModPlan &plan, int32_t g) {
 						if (rc < 0) { err = ERR_TREC; val = 0; break; }
 						const int32_t rstride = plan.plane_w[rc];
 						const int16_t *rrow = plan.planes[rc] + (size_t) (gy + y) * (size_t) rstride + (size_t) gx;
-						val = rrow[x];
+						val = uni<UNI>((int32_t) rrow[x]);
 						if (node.prop & 2) {
-							const int32_t rw = x > 0 ? rrow[x - 1] : 0;
-							const int32_t rn = y > 0 ? rrow[x - rstride] : rw;
-							const int32_t rnw = x > 0 && y > 0 ? rrow[x - 1 - rstride] : rw;
+							const int32_t rw = uni<UNI>(x > 0 ? (int32_t) rrow[x - 1] : 0);
+							const int32_t rn = uni<UNI>(y > 0 ? (int32_t) rrow[x - rstride] : rw);
+							const int32_t rnw = uni<UNI>(x > 0 && y > 0 ? (int32_t) rrow[x - 1 - rstride] : rw);
 							val -= mod_gradient(rw, rn, rnw);
 						}
 						if (node.prop & 1) val = mod_abs(val);
 					} }
 					if (err) break;
 					n += val > node.value ? node.a : node.b;
-					node = *n;
+					{ const int32_t *w4 = (const int32_t *) n; node.prop = uni<UNI>(w4[0]); node.value = uni<UNI>(w4[1]); node.a = uni<UNI>(w4[2]); node.b = uni<UNI>(w4[3]); }
 				}
 				if (err) break;
-				int32_t v = code_symbol<false>(b, code, node.value, dist_mult, plan.lz_window_size);
+				int32_t v = code_symbol<UNI>(b, code, node.value, dist_mult, plan.lz_window_size);
 				v = ((v & 1) ? -(v / 2 + 1) : v / 2) * node.b + node.a;
 				v += mod_predict(-1 - node.prop, wp, p, &err);
 				if (v < -32768 || v > 32767) { err = ERR_POVF; break; }
 				row[x] = (int16_t) v;
+				if (ring) { cur[x] = v; c_ww = c_w; c_w = v; r_nww = r_nw; r_nw = r_n; r_n = r_ne; r_ne = r_nee; r_nee = r_next; }
 				wp_after(wp, x, y, v);
 				if (b.err) break;
 			}
 		}
 	}
-	if (!b.err && !err) code_finish<false>(b, code);
+	if (!b.err && !err) code_finish<UNI>(b, code);
 	if (!b.err && !err) bits_finish_section(b);
 	return b.err ? b.err : err;
 }

@@ -16,10 +16,43 @@
 
 namespace j40hip {
 
-__global__ void __launch_bounds__(64) k_modular_sections(DevModPlan plan) {
-	if (threadIdx.x != 0) return;
+// One section per wavefront, one wavefront per workgroup. Every lane runs the same (wave-uniform) decoder, so the serial
+// per-pixel loop lives on the scalar unit like k_hf_entropy's. IN_LDS: the MA tree, the code spec's tables, the three most
+// recent rows of the channel being decoded and the weighted predictor's error rows all live in LDS (the usual case; the
+// template keeps their address space static, a run-time choice would turn every access into a flat one), so the tree
+// walk, the symbol decode and the neighbour fetch wait on LDS instead of L2 -- a sample that was just stored to the plane is
+// not in the vector L1, and the previous pixel is the next one's W neighbour.
+template <bool IN_LDS>
+__global__ void __launch_bounds__(64) k_modular_sections(DevModPlan plan, int32_t rows_width, int32_t wp_width) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t mod_lds[];
+	const int32_t lane = threadIdx.x;
+	const DevCodeSpec &spec = *plan.spec;
+	ModTables t = mod_tables_in_hbm(plan);
+	if (IN_LDS) {
+		auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+		const DevModFrame &f = *plan.frame;
+		uint32_t off = 0;
+		DevTreeNode *l_tree = (DevTreeNode *) mod_lds; off = align16((uint32_t) f.num_tree_nodes * (uint32_t) sizeof(DevTreeNode));
+		uint32_t *l_map = (uint32_t *) (mod_lds + off); off = align16(off + (uint32_t) spec.num_dist + 4);
+		DevCluster *l_clusters = (DevCluster *) (mod_lds + off); off = align16(off + (uint32_t) spec.num_clusters * (uint32_t) sizeof(DevCluster));
+		uint8_t *l_tab = mod_lds + off; off = align16(off + (spec.use_prefix_code ? 4u : 8u) * spec.table_span);
+		int32_t *l_rows = (int32_t *) (mod_lds + off); off = align16(off + 12u * (uint32_t) rows_width);   // rows_width = widest rectangle + 4 spare entries
+		int32_t *l_wp = (int32_t *) (mod_lds + off);
+		{ const uint4 *src = (const uint4 *) plan.tree; uint4 *dst = (uint4 *) l_tree; for (int32_t i = lane; i < f.num_tree_nodes; i += 64) dst[i] = src[i]; }
+		{ const uint32_t *src = (const uint32_t *) (plan.pool_u8 + spec.cluster_map_off); for (int32_t i = lane; i < (spec.num_dist + 3) / 4; i += 64) l_map[i] = src[i]; }   // 4-byte aligned table (plan_build.cpp)
+		const DevCluster *csrc = plan.clusters + spec.cluster_off;
+		const uint32_t base_off = csrc[0].table_off;
+		for (int32_t i = lane; i < spec.num_clusters; i += 64) { DevCluster c = csrc[i]; c.table_off -= base_off; l_clusters[i] = c; }
+		if (spec.use_prefix_code) { const int32_t *src = plan.pool_i32 + base_off; int32_t *dst = (int32_t *) l_tab; for (uint32_t i = lane; i < spec.table_span; i += 64) dst[i] = src[i]; }
+		else { const uint64_t *src = plan.pool_u64 + base_off; uint64_t *dst = (uint64_t *) l_tab; for (uint32_t i = lane; i < spec.table_span; i += 64) dst[i] = src[i]; }
+		t.tree = l_tree; t.cluster_map = (const uint8_t *) l_map; t.clusters = l_clusters; t.alias = (const uint64_t *) l_tab; t.prefix = (const int32_t *) l_tab;
+		t.rows = l_rows; t.rows_width = rows_width;
+		if (wp_width) { t.wp_errors = l_wp; t.wp_errors_width = wp_width; }
+		__syncthreads();
+	}
 	const int32_t s = blockIdx.x;
-	plan.status[s] = decode_modular_section(plan, s);
+	const uint32_t err = decode_modular_section<true, IN_LDS>(plan, t, s);
+	if (lane == 0) plan.status[s] = err;
 }
 
 __global__ void __launch_bounds__(256) k_inverse_rct(int16_t *a, int16_t *b, int16_t *c, size_t n, int32_t type7) {
@@ -60,8 +93,8 @@ __global__ void __launch_bounds__(64) k_inverse_palette_predicted(const int16_t 
 				const int16_t index = idxline[x];
 				const bool is_delta = index < nb_deltas;
 				int16_t val = palette_value(index, i, palrow, nb_colours, bpp);
-				const ModNeigh p = mod_neighbours(line, width, width, x, y);
-				wp_before(wp, x, y, p);
+				const ModNeigh p = mod_neighbours<false>(line, width, width, x, y);
+				wp_before<false>(wp, x, y, p);
 				if (is_delta) val = (int16_t) (val + mod_predict(d_pred, wp, p, &err));
 				wp_after(wp, x, y, val);
 				line[x] = val;
@@ -82,8 +115,19 @@ __global__ void __launch_bounds__(256) k_pack_planes(const int16_t *r, const int
 
 static unsigned grid_for(size_t n) { size_t b = (n + 255) / 256; return (unsigned) (b < 1 ? 1 : b > 8192 ? 8192 : b); }
 
-void launch_modular_sections(const DevModPlan &plan, int32_t num_sections, hipStream_t stream) {
-	if (num_sections > 0) hipLaunchKernelGGL(k_modular_sections, dim3((unsigned) num_sections), dim3(64), 0, stream, plan);
+void launch_modular_sections(const DevModPlan &plan, int32_t num_sections, const ModLaunchInfo &info, hipStream_t stream) {
+	if (num_sections <= 0) return;
+	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+	const uint32_t wp_bytes = info.uses_wp ? align16(40u * (uint32_t) info.max_width) : 0;
+	const uint32_t lds = align16((uint32_t) info.num_tree_nodes * (uint32_t) sizeof(DevTreeNode)) + align16((uint32_t) info.num_dist + 4)
+		+ align16((uint32_t) info.num_clusters * (uint32_t) sizeof(DevCluster)) + align16(info.table_bytes) + align16(12u * (uint32_t) (info.max_width + 4)) + wp_bytes + 64;
+	if (lds <= 156u * 1024u) {
+		static bool configured = false;
+		if (!configured) { (void) hipFuncSetAttribute((const void *) k_modular_sections<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); configured = true; }
+		hipLaunchKernelGGL(k_modular_sections<true>, dim3((unsigned) num_sections), dim3(64), lds, stream, plan, info.max_width + 4, info.uses_wp ? info.max_width : 0);
+	} else {
+		hipLaunchKernelGGL(k_modular_sections<false>, dim3((unsigned) num_sections), dim3(64), 0, stream, plan, 0, 0);
+	}
 }
 void launch_inverse_rct(int16_t *a, int16_t *b, int16_t *c, size_t n, int32_t type7, hipStream_t stream) {
 	if (n) hipLaunchKernelGGL(k_inverse_rct, dim3(grid_for(n)), dim3(256), 0, stream, a, b, c, n, type7);

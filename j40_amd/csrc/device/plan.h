@@ -194,6 +194,9 @@ struct HfLaunchInfo {
 	uint32_t lanes_lds_bytes;    // LDS k_hf_lanes needs for this frame's tables (plus HF_LANE_COLS_BYTES per wavefront)
 };
 
+// sizes the host knows about a Modular frame's tree and code tables, to lay out k_modular_sections' LDS
+struct ModLaunchInfo { int32_t num_tree_nodes, num_dist, num_clusters; uint32_t table_bytes; int32_t max_width, uses_wp; };
+
 enum {
 	ERR_SHRT = ('s' << 24) | ('h' << 16) | ('r' << 8) | 't',
 	ERR_COEF = ('c' << 24) | ('o' << 16) | ('e' << 8) | 'f',

@@ -99,6 +99,7 @@ struct j40hip_device_state {
 	// Modular frames
 	DevModPlan mod;
 	int32_t mod_sections = 0;
+	ModLaunchInfo mod_info = {0, 0, 0, 0, 0, 0};
 	std::vector<uint32_t> mod_section_offsets;
 	struct ModOp { int kind; int16_t *a, *b, *c; const int16_t *src, *aux; size_t n; int32_t p0, p1, p2, p3, p4, p5; int16_t *const *dst_list; const int8_t *wpp; };
 	std::vector<ModOp> mod_ops;          // inverse transforms, in execution order
@@ -164,6 +165,7 @@ static uint32_t upload_modular(j40hip_frame *h, int device) {
 	plan.tree = st->upload(hp.tree.data(), hp.tree.size(), s, ok);
 	plan.sections = st->upload(hp.sections.data(), hp.sections.size(), s, ok);
 	st->mod_sections = (int32_t) hp.sections.size();
+	st->mod_info = {(int32_t) hp.tree.size(), hp.spec.num_dist, hp.spec.num_clusters, hp.spec.table_span * (hp.spec.use_prefix_code ? 4u : 8u), hp.frame.max_width, hp.frame.tree_uses_wp};
 	for (const DevModSection &sec : hp.sections) st->mod_section_offsets.push_back(sec.byte_off);
 	const int32_t nch = hp.frame.num_channels;
 	struct Ref { int16_t *p; int32_t w, h; };
@@ -242,7 +244,7 @@ static uint32_t decode_modular(j40hip_frame *h, void *rgba_dev, size_t stride_by
 	if (ms3) (void) hipEventRecord(st->ev[0], s);
 	if (hipMemsetAsync(plan.status, 0, sizeof(uint32_t) * ((size_t) st->total_sections + 1), s) != hipSuccess) return ERR_GPU;
 	if (ms3) (void) hipEventRecord(st->ev[1], s);
-	launch_modular_sections(plan, st->mod_sections, s);
+	launch_modular_sections(plan, st->mod_sections, st->mod_info, s);
 	if (ms3) (void) hipEventRecord(st->ev[2], s);
 	for (const auto &op : st->mod_ops) {
 		if (op.kind == 0) launch_inverse_rct(op.a, op.b, op.c, op.n, op.p0, s);
