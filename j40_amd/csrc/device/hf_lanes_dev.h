@@ -160,7 +160,14 @@ J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t,
 	const J40_GLOBAL uint16_t *order = nullptr;
 	uint32_t next0 = 0, next1 = 0;   // descriptor of block k, requested one block ahead
 	if (!done) { const J40_GLOBAL uint32_t *p = G.group_blocks + 2u * block_first; next0 = p[0]; next1 = p[1]; }
-	while (!done) {
+	for (uint32_t turn = 0; !done; ++turn) {
+		// Block starts are rare (3 per block against dozens of coefficient symbols) but with 64 lanes some lane starts a block in
+		// nearly every iteration, and then the whole wavefront walks the block-start code. It is therefore only executed every
+		// NZ_PERIOD-th iteration: a lane that reaches a block start in between sits out until then (J40_LANE_NZ_PERIOD = 1: never)
+#ifndef J40_LANE_NZ_PERIOD
+#define J40_LANE_NZ_PERIOD 4
+#endif
+		if (!in_coeffs && (turn % J40_LANE_NZ_PERIOD) != 0) continue;
 		lane_bits_refill(b);
 		int32_t ctx;
 		if (!in_coeffs) {  // next symbol: number of non-zeros of (block k, channel c_yxb), j40.h:6959-6967
