@@ -139,6 +139,12 @@ J40HIP_API int j40hip_device_count(void);
  * and allocates the working buffers. Returns 0 or a 4-char error ("!gpu": no device / HIP error). */
 J40HIP_API uint32_t j40hip_frame_upload(j40hip_frame *f, int device);
 
+/* Single-pass frames keep their quantised coefficients as per-block event lists sized from the section sizes. A section
+ * with more non-zero coefficients than its region holds reports "evof" (j40hip_frame_status); j40hip_frame_decode_to_host
+ * and the public API then repeat the decode with dense planes on their own, callers of the asynchronous entry points
+ * call this and upload / decode again. */
+J40HIP_API void j40hip_frame_force_dense(j40hip_frame *f, int dense);
+
 /* Section subset decoded by this process (multi-GPU sharding by pass-group section):
  * groups [first_group, first_group + num_groups) of every pass. Default: all. */
 J40HIP_API uint32_t j40hip_frame_set_group_range(j40hip_frame *f, int64_t first_group, int64_t num_groups);
@@ -154,10 +160,6 @@ J40HIP_API uint32_t j40hip_frame_status(j40hip_frame *f);
 
 /* Convenience for the public API: decode + copy to host rows of `stride_bytes`. Synchronous. */
 J40HIP_API uint32_t j40hip_frame_decode_to_host(j40hip_frame *f, void *rgba_host, size_t stride_bytes);
-
-/* By default the pixel kernels zero every coefficient they consume (the planes are clean for the next decode without a
- * clear); keep = 1 leaves the coefficients in place for j40hip_frame_read_coeffs and clears before each decode instead. */
-J40HIP_API uint32_t j40hip_frame_keep_coefficients(j40hip_frame *f, int keep);
 
 /* Stage dumps for parity tests (device -> host copies, synchronous):
  *   quantised HF coefficients of LF group gg, channel c (f32[w8*h8*64], as j40__hf_coeffs leaves them) */

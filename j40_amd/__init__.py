@@ -84,7 +84,7 @@ def lib():
         "j40hip_frame_set_group_range": (u32, [vp, i64, i64]), "j40hip_frame_decode": (u32, [vp, vp, sz, vp]),
         "j40hip_frame_status": (u32, [vp]), "j40hip_frame_decode_to_host": (u32, [vp, vp, sz]),
         "j40hip_frame_read_coeffs": (u32, [vp, i64, C.c_int, vp]), "j40hip_frame_read_plane_i16": (u32, [vp, C.c_int, vp]),
-        "j40hip_frame_decode_timed": (u32, [vp, vp, sz, vp, vp]), "j40hip_frame_keep_coefficients": (u32, [vp, C.c_int]),
+        "j40hip_frame_decode_timed": (u32, [vp, vp, sz, vp, vp]), "j40hip_frame_force_dense": (None, [vp, C.c_int]),
         "j40hip_kat_device_srgb_u8": (u32, [vp, sz, vp]),
         "j40hip_batch_create": (vp, [vp, i64, C.POINTER(u32)]), "j40hip_batch_free": (None, [vp]),
         "j40hip_batch_decode": (u32, [vp, vp, vp, vp]), "j40hip_batch_decode_timed": (u32, [vp, vp, vp, vp, vp]),
@@ -203,8 +203,9 @@ class Frame:
     def upload(self, device=0):
         self._chk(lib().j40hip_frame_upload(self.h, device), "in j40hip_frame_upload")
 
-    def keep_coefficients(self, keep=True):
-        self._chk(lib().j40hip_frame_keep_coefficients(self.h, 1 if keep else 0), "in j40hip_frame_keep_coefficients")
+    def force_dense(self, dense=True):
+        """dense coefficient planes instead of event lists for the next upload (what the library does by itself after "evof")"""
+        lib().j40hip_frame_force_dense(self.h, 1 if dense else 0)
 
     def set_group_range(self, first, count):
         self._chk(lib().j40hip_frame_set_group_range(self.h, first, count), "in j40hip_frame_set_group_range")

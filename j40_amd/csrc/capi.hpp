@@ -12,6 +12,7 @@ struct j40hip_frame {
 	std::vector<uint8_t> cs_storage;
 	j40hip::Frame frame;
 	j40hip_device_state *dev = nullptr;
+	bool force_dense = false;        // upload with dense coefficient planes (set after a decode ran out of event space, ERR_EVOF)
 	// backing storage of the plan views (include/j40hip.h)
 	struct Views {
 		std::vector<std::vector<j40hip_cluster_view>> clusters;

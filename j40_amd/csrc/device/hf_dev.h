@@ -49,11 +49,13 @@ struct HfTables {
 	int32_t nblocks;
 	int8_t *nonzeros;                // [32 * 32][3] scratch
 	int32_t *window;                 // LZ77 window or nullptr
+	uint32_t block_first;            // ordinal of blocks[0] in plan.group_blocks / plan.block_events
+	uint32_t ev_first, ev_end;       // this group's region of plan.events (sparse coefficients)
 };
 
-// decodes one (pass, group) section. SCAN: single-pass frames store each coefficient at its scan
-// position (plain store; the pixel kernels undo the order), otherwise accumulate at the canonical
-// position like j40.h:6989.
+// decodes one (pass, group) section. SCAN: single-pass frames append one event {scan position, value} per non-zero
+// coefficient (DevPlan::events; the pixel kernels undo the order), otherwise accumulate at the canonical position of the
+// dense planes like j40.h:6989.
 template <bool SCAN, bool UNI>
 J40_DEV uint32_t decode_hf_section(const DevPlan &plan, const DevFrame &f, const DevCodeSpec &spec, const HfTables &t, int32_t pass, const DevSection &sec) {
 	const DevLfGroup &gg = plan.lf_groups[sec.ggidx];
@@ -67,7 +69,9 @@ J40_DEV uint32_t decode_hf_section(const DevPlan &plan, const DevFrame &f, const
 	const int32_t gw8 = sec.gw8;
 	const int32_t nb_block_ctx = f.nb_block_ctx;
 	const size_t cell64 = (size_t) gg.cell_base * 64;
+	uint32_t ev_at = t.ev_first;
 	for (int32_t k = 0; k < t.nblocks && !b.err; ++k) {
+		if (SCAN) plan.block_events[4 * (size_t) (t.block_first + (uint32_t) k)] = ev_at;
 		DevGroupBlock gb;
 		{ const uint32_t *p = (const uint32_t *) (t.blocks + k); gb.coeffoff_qfidx = uni<UNI>(p[0]); const uint32_t w = uni<UNI>(p[1]); gb.pos_dct = (uint16_t) w; gb.bctx3 = (uint16_t) (w >> 16); }
 		const int32_t dctsel = gb.pos_dct >> 10, nzpos = ((gb.pos_dct >> 5) & 31) * gw8 + (gb.pos_dct & 31);
@@ -77,7 +81,8 @@ J40_DEV uint32_t decode_hf_section(const DevPlan &plan, const DevFrame &f, const
 		const int32_t coeffoff = (int32_t) (gb.coeffoff_qfidx & ~15u);
 		for (int32_t c_yxb = 0; c_yxb < 3 && !b.err; ++c_yxb) {
 			const int32_t c = c_yxb == 0 ? 1 : c_yxb == 1 ? 0 : 2;
-			float *coeffs = plan.coeffs[c] + cell64 + coeffoff;
+			float *coeffs = SCAN ? nullptr : plan.coeffs[c] + cell64 + coeffoff;
+			const uint32_t chan_first = ev_at;
 			const int32_t bctx = (gb.bctx3 >> (4 * c_yxb)) & 15;
 			// number of non-zeros, predicted from the left / top blocks (j40.h:6959-6967)
 			int32_t nz;
@@ -97,13 +102,17 @@ J40_DEV uint32_t decode_hf_section(const DevPlan &plan, const DevFrame &f, const
 				const int32_t ctx = cctx + uni<UNI>((int32_t) t.nnz_ctx2[(nz + (1 << shift) - 1) >> shift]) + uni<UNI>((int32_t) t.freq_ctx2[i >> shift]) + prev;
 				const int32_t ucoeff = code_symbol<UNI>(b, code, ctx, 0, plan.lz_window_size);
 				if (ucoeff) {
-					const float v = (float) unpack_signed_dev(ucoeff);
-					if (SCAN) coeffs[i] = v; else coeffs[uni<UNI>((uint32_t) order[i])] += v;
+					if (SCAN) {
+						if (ev_at >= t.ev_end) { bits_set_error(b, ERR_EVOF); break; }
+						CoeffEvent ev; ev.pos = (uint32_t) i; ev.value = unpack_signed_dev(ucoeff);
+						plan.events[ev_at++] = ev;
+					} else coeffs[uni<UNI>((uint32_t) order[i])] += (float) unpack_signed_dev(ucoeff);
 				}
 				prev = ucoeff != 0;
 				nz -= prev;
 				if (b.err) break;
 			}
+			if (SCAN) plan.block_events[4 * (size_t) (t.block_first + (uint32_t) k) + 1 + (size_t) c_yxb] = ev_at - chan_first;
 			if (nz != 0) bits_set_error(b, ERR_COEF);
 		}
 	}
@@ -138,6 +147,7 @@ J40_DEV uint32_t decode_hf_section_flat(const DevPlan &plan, const DevFrame &f, 
 	int32_t c = 1, bctx = 0, nz = 0, i = 0, prev = 0, cctx = 0;
 	float *coeffs = nullptr;
 	const uint16_t *order = nullptr;
+	uint32_t ev_at = t.ev_first, chan_first = t.ev_first;
 	while (!done) {
 		int32_t ctx;
 		if (!in_coeffs) {  // next symbol: number of non-zeros of (block k, channel c_yxb), j40.h:6959-6967
@@ -145,6 +155,7 @@ J40_DEV uint32_t decode_hf_section_flat(const DevPlan &plan, const DevFrame &f, 
 				const uint32_t *p = (const uint32_t *) (t.blocks + k);
 				const uint32_t coeffoff_qfidx = p[0], w = p[1];
 				const int32_t dctsel = (int32_t) ((w >> 10) & 31);
+				if (SCAN) plan.block_events[4 * (size_t) (t.block_first + (uint32_t) k)] = ev_at;
 				bctx3 = (int32_t) (w >> 16);
 				x8 = (int32_t) (w & 31); y8 = (int32_t) ((w >> 5) & 31); nzpos = y8 * gw8 + x8;
 				log_rows = DEV_DCT_SELECT[dctsel][0]; log_columns = DEV_DCT_SELECT[dctsel][1]; order_idx = DEV_DCT_SELECT[dctsel][2];
@@ -170,18 +181,24 @@ J40_DEV uint32_t decode_hf_section_flat(const DevPlan &plan, const DevFrame &f, 
 			cctx = ctxoff + 458 * bctx + 37 * nb_block_ctx;
 			prev = nz <= (size >> 4);
 			i = 1 << shift;
-			coeffs = (c == 0 ? plan.coeffs[0] : c == 1 ? plan.coeffs[1] : plan.coeffs[2]) + cell64 + coeffoff;
-			if (!SCAN) order = plan.pool_u16 + f.order_off[(pass * 13 + order_idx) * 3 + c];
+			if (!SCAN) {
+				coeffs = (c == 0 ? plan.coeffs[0] : c == 1 ? plan.coeffs[1] : plan.coeffs[2]) + cell64 + coeffoff;
+				order = plan.pool_u16 + f.order_off[(pass * 13 + order_idx) * 3 + c];
+			}
+			chan_first = ev_at;
 			in_coeffs = nz > 0;
+			if (SCAN && !in_coeffs) plan.block_events[4 * (size_t) (t.block_first + (uint32_t) k) + 1 + (size_t) c_yxb] = 0;
 		} else {
 			if (v) {
-				const float fv = (float) unpack_signed_dev(v);
-				if (SCAN) coeffs[i] = fv; else coeffs[order[i]] += fv;
+				if (SCAN) {
+					if (ev_at >= t.ev_end) bits_set_error(b, ERR_EVOF);
+					else { CoeffEvent ev; ev.pos = (uint32_t) i; ev.value = unpack_signed_dev(v); plan.events[ev_at++] = ev; }
+				} else coeffs[order[i]] += (float) unpack_signed_dev(v);
 			}
 			prev = v != 0;
 			nz -= prev;
 			++i;
-			if (nz == 0) in_coeffs = false;
+			if (nz == 0) { in_coeffs = false; if (SCAN) plan.block_events[4 * (size_t) (t.block_first + (uint32_t) k) + 1 + (size_t) c_yxb] = ev_at - chan_first; }
 			else if (i >= size) bits_set_error(b, ERR_COEF);   // ran out of coefficients with non-zeros left (j40.h:6996)
 		}
 		if (b.err) break;
@@ -203,14 +220,16 @@ J40_DEV void decode_hf_group(const DevPlan &plan, int32_t g, bool flat = false) 
 	t.nblocks = (int32_t) (plan.group_block_start[g + 1] - plan.group_block_start[g]);
 	t.nonzeros = plan.nonzeros + (size_t) g * (32 * 32 * 3);
 	t.window = plan.lz_window ? plan.lz_window + (size_t) g * plan.lz_window_size : nullptr;
+	t.block_first = plan.group_block_start[g];
+	t.ev_first = f.sparse_coeffs ? plan.ev_range[2 * g] : 0; t.ev_end = f.sparse_coeffs ? plan.ev_range[2 * g + 1] : 0;
 	for (int32_t pass = 0; pass < f.num_passes; ++pass) {
 		const DevCodeSpec &spec = plan.coeff_specs[pass];
 		t.clusters = plan.clusters + spec.cluster_off; t.cluster_map = plan.pool_u8 + spec.cluster_map_off;
 		t.alias = plan.pool_u64; t.prefix = plan.pool_i32;
 		const DevSection &sec = plan.sections[pass * f.num_groups + g];
 		uint32_t err;
-		if (flat) err = f.scan_order_coeffs ? decode_hf_section_flat<true>(plan, f, spec, t, pass, sec) : decode_hf_section_flat<false>(plan, f, spec, t, pass, sec);
-		else err = f.scan_order_coeffs ? decode_hf_section<true, false>(plan, f, spec, t, pass, sec) : decode_hf_section<false, false>(plan, f, spec, t, pass, sec);
+		if (flat) err = f.sparse_coeffs ? decode_hf_section_flat<true>(plan, f, spec, t, pass, sec) : decode_hf_section_flat<false>(plan, f, spec, t, pass, sec);
+		else err = f.sparse_coeffs ? decode_hf_section<true, false>(plan, f, spec, t, pass, sec) : decode_hf_section<false, false>(plan, f, spec, t, pass, sec);
 		plan.status[pass * f.num_groups + g] = err;
 	}
 }

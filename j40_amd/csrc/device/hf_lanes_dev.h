@@ -52,7 +52,9 @@ struct LaneFrame {
 struct LaneGlobals {
 	const J40_GLOBAL uint8_t *codestream;
 	const J40_GLOBAL uint32_t *group_blocks;   // DevGroupBlock as two words
-	J40_GLOBAL float *coeffs;                  // plane c at c * coeff_stride
+	J40_GLOBAL float *coeffs;                  // dense planes (multi-pass frames): plane c at c * coeff_stride
+	J40_GLOBAL CoeffEvent *events;             // sparse coefficients (single-pass frames), see DevPlan::events
+	J40_GLOBAL uint32_t *block_events;
 	const J40_GLOBAL uint16_t *pool_u16;       // coefficient orders (multi-pass frames)
 	uint32_t coeff_stride;
 };
@@ -139,7 +141,7 @@ J40_DEV int32_t lane_symbol(LaneBits &b, uint32_t &state, const LaneTables &t, i
 // cols[(c * 32 + x) * col_stride]: non-zero count (per 8x8 cell) of the last block written into cell column x, channel c
 template <bool SCAN>
 J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t, const LaneGlobals &G, const DevSection &sec, uint32_t cell_base,
-		uint32_t block_first, int32_t nblocks, J40_LDS int8_t *cols, int32_t col_stride, int32_t pass) {
+		uint32_t block_first, int32_t nblocks, uint32_t ev_first, uint32_t ev_end, J40_LDS int8_t *cols, int32_t col_stride, int32_t pass) {
 	const uint32_t start_bit = 8u * sec.byte_off + sec.bit_off, end_bit = 8u * (sec.byte_off + sec.size);
 	LaneBits b;
 	lane_bits_init(b, G.codestream, start_bit);
@@ -158,6 +160,7 @@ J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t,
 	uint32_t coeffoff = 0, coeff_at = 0, bctx3 = 0;
 	int32_t c = 1, bctx = 0, nz = 0, i = 0, prev = 0, cctx = 0;
 	const J40_GLOBAL uint16_t *order = nullptr;
+	uint32_t ev_at = ev_first, chan_first = ev_first;   // SCAN: next free event of this section's region, first event of the current channel
 	uint32_t next0 = 0, next1 = 0;   // descriptor of block k, requested one block ahead
 	if (!done) { const J40_GLOBAL uint32_t *p = G.group_blocks + 2u * block_first; next0 = p[0]; next1 = p[1]; }
 	for (uint32_t turn = 0; !done; ++turn) {
@@ -174,6 +177,7 @@ J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t,
 			if (c_yxb == 0) {
 				const uint32_t w = next1;
 				coeffoff = next0 & ~15u;
+				if (SCAN) G.block_events[4u * (block_first + (uint32_t) k)] = ev_at;
 				if (k + 1 < nblocks) { const J40_GLOBAL uint32_t *p = G.group_blocks + 2u * (block_first + (uint32_t) k + 1u); next0 = p[0]; next1 = p[1]; }
 				x8 = (int32_t) (w & 31); y8 = (int32_t) ((w >> 5) & 31); bctx3 = w >> 16;
 				const uint32_t di = t.dct_info[(w >> 10) & 31];
@@ -201,18 +205,24 @@ J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t,
 			cctx = ctxoff + 458 * bctx + 37 * nb_block_ctx;
 			prev = nz <= (size >> 4);
 			i = 1 << shift;
-			coeff_at = (uint32_t) c * G.coeff_stride + cell64 + coeffoff;
-			if (!SCAN) order = G.pool_u16 + f.order_off[(pass * 13 + order_idx) * 3 + c];
+			if (!SCAN) {
+				coeff_at = (uint32_t) c * G.coeff_stride + cell64 + coeffoff;
+				order = G.pool_u16 + f.order_off[(pass * 13 + order_idx) * 3 + c];
+			}
+			chan_first = ev_at;
 			in_coeffs = nz > 0;
+			if (SCAN && !in_coeffs) G.block_events[4u * (block_first + (uint32_t) k) + 1u + (uint32_t) c_yxb] = 0;
 		} else {
 			if (v) {
-				const float fv = (float) unpack_signed_dev(v);
-				if (SCAN) G.coeffs[coeff_at + (uint32_t) i] = fv; else G.coeffs[coeff_at + order[i]] += fv;
+				if (SCAN) {   // one sequential 8-byte store per non-zero coefficient
+					if (ev_at >= ev_end) { err = ERR_EVOF; break; }
+					((J40_GLOBAL uint64_t *) G.events)[ev_at++] = (uint64_t) (uint32_t) i | ((uint64_t) (uint32_t) unpack_signed_dev(v) << 32);   // CoeffEvent {pos, value}
+				} else G.coeffs[coeff_at + order[i]] += (float) unpack_signed_dev(v);
 			}
 			prev = v != 0;
 			nz -= prev;
 			++i;
-			if (nz == 0) in_coeffs = false;
+			if (nz == 0) { in_coeffs = false; if (SCAN) G.block_events[4u * (block_first + (uint32_t) k) + 1u + (uint32_t) c_yxb] = ev_at - chan_first; }
 			else if (i >= size) { err = ERR_COEF; break; }   // non-zeros left but no coefficient left (j40.h:6996)
 		}
 		if (!in_coeffs && ++c_yxb == 3) { c_yxb = 0; done = ++k >= nblocks; }

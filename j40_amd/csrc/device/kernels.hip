@@ -82,8 +82,11 @@ __global__ void __launch_bounds__(64 * HF_WAVES) k_hf_entropy(DevPlan plan, int3
 	t.nonzeros = l_nonzeros;
 	t.window = plan.lz_window && active ? plan.lz_window + (size_t) g * plan.lz_window_size : nullptr;
 	t.nblocks = 0; t.blocks = l_blocks;
+	t.block_first = 0; t.ev_first = t.ev_end = 0;
 	if (active) {
 		const uint32_t b0 = plan.group_block_start[g], b1 = plan.group_block_start[g + 1];
+		t.block_first = b0;
+		if (f.sparse_coeffs) { t.ev_first = plan.ev_range[2 * g]; t.ev_end = plan.ev_range[2 * g + 1]; }
 		t.nblocks = (int32_t) (b1 - b0);
 		const uint64_t *src = (const uint64_t *) (plan.group_blocks + b0);   // 8-byte entries
 		uint64_t *dst = (uint64_t *) l_blocks;
@@ -116,7 +119,7 @@ __global__ void __launch_bounds__(64 * HF_WAVES) k_hf_entropy(DevPlan plan, int3
 			// every lane of the wave runs the same (scalarised) decoder on the same section; duplicate
 			// stores hit the same addresses with the same values
 			const DevSection &sec = plan.sections[pass * f.num_groups + g];
-			const uint32_t err = f.scan_order_coeffs ? decode_hf_section<true, true>(plan, f, spec, t, pass, sec) : decode_hf_section<false, true>(plan, f, spec, t, pass, sec);
+			const uint32_t err = f.sparse_coeffs ? decode_hf_section<true, true>(plan, f, spec, t, pass, sec) : decode_hf_section<false, true>(plan, f, spec, t, pass, sec);
 			if (lane == 0) plan.status[pass * f.num_groups + g] = err;
 		}
 	}
@@ -141,6 +144,7 @@ __global__ void __launch_bounds__(64) k_hf_entropy_lanes(const DevPlan *plans, c
 	J40_TO_GLOBAL(plan.pool_u64); J40_TO_GLOBAL(plan.pool_f32); J40_TO_GLOBAL(plan.clusters); J40_TO_GLOBAL(plan.coeff_specs); J40_TO_GLOBAL(plan.lf_groups);
 	J40_TO_GLOBAL(plan.sections); J40_TO_GLOBAL(plan.group_blocks); J40_TO_GLOBAL(plan.group_block_start); J40_TO_GLOBAL(plan.coeffs[0]); J40_TO_GLOBAL(plan.coeffs[1]);
 	J40_TO_GLOBAL(plan.coeffs[2]); J40_TO_GLOBAL(plan.nonzeros); J40_TO_GLOBAL(plan.lz_window); J40_TO_GLOBAL(plan.status);
+	J40_TO_GLOBAL(plan.events); J40_TO_GLOBAL(plan.ev_range); J40_TO_GLOBAL(plan.block_events);
 #undef J40_TO_GLOBAL
 	const DevFrame &f = *plan.frame;
 	const int32_t lane = threadIdx.x;
@@ -163,6 +167,8 @@ __global__ void __launch_bounds__(64) k_hf_entropy_lanes(const DevPlan *plans, c
 	t.window = plan.lz_window ? plan.lz_window + (size_t) g * plan.lz_window_size : nullptr;
 	t.blocks = plan.group_blocks + plan.group_block_start[g];
 	t.nblocks = (int32_t) (plan.group_block_start[g + 1] - plan.group_block_start[g]);
+	t.block_first = plan.group_block_start[g];
+	t.ev_first = f.sparse_coeffs ? plan.ev_range[2 * g] : 0; t.ev_end = f.sparse_coeffs ? plan.ev_range[2 * g + 1] : 0;
 	for (int32_t pass = 0; pass < f.num_passes; ++pass) {
 		const DevCodeSpec &spec = plan.coeff_specs[pass];
 		if (TABLES_IN_LDS) {
@@ -190,7 +196,7 @@ __global__ void __launch_bounds__(64) k_hf_entropy_lanes(const DevPlan *plans, c
 		__syncthreads();
 		if (active) {
 			const DevSection &sec = plan.sections[pass * f.num_groups + g];
-			plan.status[pass * f.num_groups + g] = f.scan_order_coeffs ? decode_hf_section_flat<true>(plan, f, spec, t, pass, sec) : decode_hf_section_flat<false>(plan, f, spec, t, pass, sec);
+			plan.status[pass * f.num_groups + g] = f.sparse_coeffs ? decode_hf_section_flat<true>(plan, f, spec, t, pass, sec) : decode_hf_section_flat<false>(plan, f, spec, t, pass, sec);
 		}
 	}
 }
@@ -222,11 +228,13 @@ __global__ void __launch_bounds__(256) k_hf_lanes(const DevPlan *plans, const Hf
 	LaneFrame f;
 	f.nb_block_ctx = df.nb_block_ctx; f.num_hf_presets = df.num_hf_presets; f.preset_bits = df.preset_bits; f.sections_have_trailer = df.sections_have_trailer;
 	f.order_off = df.order_off;
-	const int32_t num_passes = df.num_passes, num_groups = df.num_groups, scan = df.scan_order_coeffs;
+	const int32_t num_passes = df.num_passes, num_groups = df.num_groups, scan = df.sparse_coeffs;
 	LaneGlobals G;
 	G.codestream = (const J40_GLOBAL uint8_t *) plan.codestream;
 	G.group_blocks = (const J40_GLOBAL uint32_t *) plan.group_blocks;
 	G.coeffs = (J40_GLOBAL float *) plan.coeffs[0];
+	G.events = (J40_GLOBAL CoeffEvent *) plan.events; G.block_events = (J40_GLOBAL uint32_t *) plan.block_events;
+	const J40_GLOBAL uint32_t *ev_range = (const J40_GLOBAL uint32_t *) plan.ev_range;
 	G.pool_u16 = (const J40_GLOBAL uint16_t *) plan.pool_u16;
 	G.coeff_stride = plan.coeff_stride;
 	const J40_GLOBAL uint8_t *pool_u8 = (const J40_GLOBAL uint8_t *) plan.pool_u8;
@@ -273,8 +281,8 @@ __global__ void __launch_bounds__(256) k_hf_lanes(const DevPlan *plans, const Hf
 		if (active) {
 			const DevSection sec = load_global_pod(sections + (pass * num_groups + g));
 			const uint32_t cell_base = (uint32_t) lf_groups[sec.ggidx].cell_base;
-			status[pass * num_groups + g] = scan ? decode_hf_section_lane<true>(f, t, G, sec, cell_base, block_first, nblocks, l_cols, 64, pass)
-			                                     : decode_hf_section_lane<false>(f, t, G, sec, cell_base, block_first, nblocks, l_cols, 64, pass);
+			status[pass * num_groups + g] = scan ? decode_hf_section_lane<true>(f, t, G, sec, cell_base, block_first, nblocks, ev_range[2 * g], ev_range[2 * g + 1], l_cols, 64, pass)
+			                                     : decode_hf_section_lane<false>(f, t, G, sec, cell_base, block_first, nblocks, 0, 0, l_cols, 64, pass);
 		}
 	}
 }
@@ -331,86 +339,45 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarbl
 	const int32_t dq_size = R * C;
 	const ColourConsts cc = load_colour_consts(f);
 	const float qbias0 = f.quant_bias[0], qbias1 = f.quant_bias[1], qbias2 = f.quant_bias[2], qbias_num = f.quant_bias_num, kx_lf = f.kx_lf, kb_lf = f.kb_lf;
-	const uint16_t *inv_order = f.scan_order_coeffs ? plan.pool_u16 + f.inv_order_off[order_idx * 3] : nullptr;
 	__shared__ VbGeom geom[NB];
+	__shared__ int32_t g_blk[NB];  // ordinal of each block (DevPlan::block_events)
 	__shared__ size_t g_out[NB];   // byte offset of each block's top-left pixel in the output
 	J40_STAGE_SRGB_THRESHOLDS(f);
-	if (tid < nb) { const VbGeom g = varblock_geometry(plan, list[first + tid]); geom[tid] = g; g_out[tid] = (size_t) g.py * stride_bytes + (size_t) g.px * 4; }
-	__syncthreads();
-
-	// ---- load: dequantise + chroma-from-luma + LLF into the LDS tiles ----
+	if (tid < nb) {
+		const DevVarblock vb = list[first + tid];
+		const VbGeom g = varblock_geometry(plan, vb);
+		geom[tid] = g; g_blk[tid] = vb.blk; g_out[tid] = (size_t) g.py * stride_bytes + (size_t) g.px * 4;
+	}
 	constexpr int N = R * C;
 	constexpr int PAR = N >= 256 ? 1 : 256 / N;   // blocks a pass of the 256 lanes covers
-	constexpr int PER = N >= 256 ? N / 256 : 1;   // coefficient positions per lane
-	if (f.scan_order_coeffs && f.order_same[order_idx]) {
-		// Single-pass frames keep coefficients in scan order (K1 stores them as they come). A lane owns scan position j
-		// for every block of the workgroup: its canonical index, dequantisation weights and tile address are loaded once,
-		// the coefficient reads are contiguous, and since the non-zeros sit at the front of the scan whole wavefronts
-		// see nothing but zeros and skip the arithmetic (0 dequantises to +0 exactly).
-		const uint16_t *order = plan.pool_u16 + f.order_off[order_idx * 3];   // pass 0, shared by the three channels
-		constexpr int NBI = N >= 256 ? NB : (NB + PAR - 1) / PAR;             // blocks a lane visits
-		const int32_t b0 = N >= 256 ? 0 : tid / N;
-		// every coefficient of the lane is requested before the first one is used: one exposed memory latency per
-		// workgroup instead of one per block
-		float q[PER][NBI][3];
-		int32_t idx[PER];
-#pragma unroll
-		for (int k = 0; k < PER; ++k) {
-			const int32_t j = N >= 256 ? tid + 256 * k : tid % N;
-			idx[k] = order[j];
-#pragma unroll
-			for (int bi = 0; bi < NBI; ++bi) {
-				const int32_t b = b0 + bi * PAR;
-				q[k][bi][0] = q[k][bi][1] = q[k][bi][2] = 0.0f;
-				if (b < nb && j >= N / 64) {   // the scan starts with the LLF positions (j40.h:6975), which carry no HF coefficient
-					const int32_t at = geom[b].coeff_base + j;
-					q[k][bi][0] = plan.coeffs[0][at]; q[k][bi][1] = plan.coeffs[1][at]; q[k][bi][2] = plan.coeffs[2][at];
-				}
-			}
+	constexpr int PER = N >= 256 ? N / 256 : 1;   // pixel positions per lane
+	// ---- load: dequantise + chroma-from-luma + LLF into the LDS tiles ----
+	if (f.sparse_coeffs) {
+		// single-pass frames: zero the tiles, scatter each block's coefficient events into them (one wavefront per block: the
+		// work is proportional to the non-zeros), write the LLF corner, then apply chroma-from-luma in place (vardct_dev.h)
+		for (int32_t w = tid; w < nb * 3 * TILE; w += nthreads) lds[w] = 0.0f;
+		__syncthreads();
+		const uint16_t *order = plan.pool_u16 + f.order_off[order_idx * 3];   // pass 0; the three channels' orders are consecutive
+		const TileMap map = {R, C, P, 0};
+		const float qbias[3] = {qbias0, qbias1, qbias2};
+		for (int32_t b = tid >> 6; b < nb; b += nthreads >> 6) {
+			float *tile = lds + (size_t) b * 3 * TILE;
+			tile_scatter_events(plan, geom[b], g_blk[b], order, dq, N, map, tile, TILE, qbias, qbias_num, tid & 63, 64);
+			tile_fill_llf(plan, geom[b], LONG, VH8, VW8, map, tile, TILE, kx_lf, kb_lf, tid & 63, 64);
 		}
-#pragma unroll
-		for (int k = 0; k < PER; ++k) {
-			const int32_t j = N >= 256 ? tid + 256 * k : tid % N;
-			const int32_t i = idx[k];
-			const float dq0 = dq[i], dq1 = dq[N + i], dq2 = dq[2 * N + i];
-			const int32_t r = C > R ? i / C : i % R, c = C > R ? i % C : i / R;   // canonical index -> tile position (j40.h:5978-5985)
-			const int32_t at = r * P + c;
-			const bool is_llf = j < N / 64;
-			const int32_t llf_at = (i / LONG) * VW8 + (i % LONG);
-#pragma unroll
-			for (int bi = 0; bi < NBI; ++bi) {
-				const int32_t b = b0 + bi * PAR;
-				if (b >= nb) break;
-				const VbGeom &g = geom[b];
-				float *t = lds + (size_t) b * 3 * TILE + at;
-				float vx = 0.0f, vy = 0.0f, vb = 0.0f;
-				const float qx = q[k][bi][0], qy = q[k][bi][1], qb = q[k][bi][2];
-				if (plan.clear_after_read) {   // leave the planes all-zero for the next decode (DevPlan::clear_after_read)
-					if (qx != 0.0f) plan.coeffs[0][g.coeff_base + j] = 0.0f;
-					if (qy != 0.0f) plan.coeffs[1][g.coeff_base + j] = 0.0f;
-					if (qb != 0.0f) plan.coeffs[2][g.coeff_base + j] = 0.0f;
-				}
-				if (__ballot(qx != 0.0f || qy != 0.0f || qb != 0.0f)) {
-					const float dx = dequant_coeff(qx, qbias0, qbias_num, g.mult[0], dq0);
-					const float dy = dequant_coeff(qy, qbias1, qbias_num, g.mult[1], dq1);
-					const float db = dequant_coeff(qb, qbias2, qbias_num, g.mult[2], dq2);
-					vx = dx + dy * g.kx_hf; vy = dy; vb = db + dy * g.kb_hf;
-				}
-				if (is_llf) {
-					const int32_t l = g.llf_base + llf_at;
-					const float lx = plan.llf[0][l], ly = plan.llf[1][l], lb = plan.llf[2][l];
-					vx = lx + ly * kx_lf; vy = ly; vb = lb + ly * kb_lf;
-				}
-				t[0] = vx; t[TILE] = vy; t[2 * TILE] = vb;
-			}
+		__syncthreads();
+		for (int32_t w = tid; w < nb * N; w += nthreads) {
+			const int32_t b = w / N, i = w - b * N;
+			tile_apply_cfl(geom[b], i + 1, LONG, VH8, VW8, map, lds + (size_t) b * 3 * TILE, TILE, i, N);   // this lane's position only
 		}
 	} else {
-		// multi-pass frames (canonical storage) and per-channel orders: coalesced over the canonical index
+		// multi-pass frames: dense planes in canonical order, coalesced over the canonical index
+		__syncthreads();
 		for (int32_t w = tid; w < nb * R * C; w += nthreads) {
 			const int32_t b = w / (R * C), i = w - b * (R * C);
 			const VbGeom &g = geom[b];
 			float v[3];
-			load_coeff3(plan, g, dq, dq_size, i, LONG, VH8, VW8, v, inv_order);
+			load_coeff3(plan, g, dq, dq_size, i, LONG, VH8, VW8, v);
 			const int32_t r = C > R ? i / C : i % R, c = C > R ? i % C : i / R;
 			float *t = lds + (size_t) b * 3 * TILE + r * P + c;
 			t[0] = v[0]; t[TILE] = v[1]; t[2 * TILE] = v[2];
@@ -470,19 +437,34 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan, const DevV
 	__shared__ VbGeom geom[NB];
 	J40_STAGE_SRGB_THRESHOLDS(f);
 	const ColourConsts cc = load_colour_consts(f);
-	if (tid < nb) geom[tid] = varblock_geometry(plan, list[first + tid]);
-	__syncthreads();
-	for (int32_t w = tid; w < nb * 64; w += nthreads) {
-		const int32_t b = w >> 6, i = w & 63;
-		const DevVarblock vb = list[first + b];
-		const VbGeom &g = geom[b];
-		const int32_t param_idx = vb.dctsel == 1 ? 1 : vb.dctsel == 2 ? 2 : vb.dctsel == 3 ? 3 : vb.dctsel <= 13 ? 9 : 10;
-		const float *dq = plan.pool_f32 + f.dq_off[param_idx];
-		const uint16_t *inv_order = f.scan_order_coeffs ? plan.pool_u16 + f.inv_order_off[1 * 3] : nullptr;  // all 8x8 specials share order 1
-		float v[3];
-		load_coeff3(plan, g, dq, 64, i, 8, 1, 1, v, inv_order);
-		float *t = tiles + (size_t) b * 3 * P + i;
-		t[0] = v[0]; t[P] = v[1]; t[2 * P] = v[2];
+	__shared__ int32_t g_blk[NB], g_param[NB];
+	if (tid < nb) {
+		const DevVarblock vb = list[first + tid];
+		geom[tid] = varblock_geometry(plan, vb); g_blk[tid] = vb.blk;
+		g_param[tid] = vb.dctsel == 1 ? 1 : vb.dctsel == 2 ? 2 : vb.dctsel == 3 ? 3 : vb.dctsel <= 13 ? 9 : 10;
+	}
+	if (f.sparse_coeffs) {
+		for (int32_t w = tid; w < nb * 3 * P; w += nthreads) tiles[w] = 0.0f;
+		__syncthreads();
+		const uint16_t *order = plan.pool_u16 + f.order_off[1 * 3];   // all 8x8 specials share order 1
+		const TileMap map = {8, 8, 8, 1};
+		const float qbias[3] = {f.quant_bias[0], f.quant_bias[1], f.quant_bias[2]};
+		for (int32_t b = tid >> 6; b < nb; b += nthreads >> 6) {
+			float *tile = tiles + (size_t) b * 3 * P;
+			tile_scatter_events(plan, geom[b], g_blk[b], order, plan.pool_f32 + f.dq_off[g_param[b]], 64, map, tile, P, qbias, f.quant_bias_num, tid & 63, 64);
+			tile_fill_llf(plan, geom[b], 8, 1, 1, map, tile, P, f.kx_lf, f.kb_lf, tid & 63, 64);
+		}
+		__syncthreads();
+		for (int32_t w = tid; w < nb * 64; w += nthreads) tile_apply_cfl(geom[w >> 6], (w & 63) + 1, 8, 1, 1, map, tiles + (size_t) (w >> 6) * 3 * P, P, w & 63, 64);
+	} else {
+		__syncthreads();
+		for (int32_t w = tid; w < nb * 64; w += nthreads) {
+			const int32_t b = w >> 6, i = w & 63;
+			float v[3];
+			load_coeff3(plan, geom[b], plan.pool_f32 + f.dq_off[g_param[b]], 64, i, 8, 1, 1, v);
+			float *t = tiles + (size_t) b * 3 * P + i;
+			t[0] = v[0]; t[P] = v[1]; t[2 * P] = v[2];
+		}
 	}
 	__syncthreads();
 	for (int32_t w = tid; w < nb * 3; w += nthreads) {
@@ -558,16 +540,28 @@ __global__ void __launch_bounds__(256) k_vardct_large(DevPlan plan, const DevVar
 	const int32_t long_side = R > C ? R : C, vh8 = (R < C ? R : C) / 8, vw8 = long_side / 8;
 	const int32_t param_idx = vb.dctsel == 21 ? 13 : vb.dctsel <= 23 ? 14 : vb.dctsel == 24 ? 15 : 16;
 	const float *dq = plan.pool_f32 + f.dq_off[param_idx];
-	const uint16_t *inv_order = f.scan_order_coeffs ? plan.pool_u16 + f.inv_order_off[DEV_DCT_SELECT[vb.dctsel][2] * 3] : nullptr;
 	J40_STAGE_SRGB_THRESHOLDS(f);
 	const ColourConsts cc = load_colour_consts(f);
 	const VbGeom g = varblock_geometry(plan, vb);
 	float *A = scratch + (size_t) blockIdx.x * 6 * 65536, *B = A + 3 * 65536;  // [3][size] each
-	for (int32_t i = tid; i < size; i += nthreads) {
-		float v[3];
-		load_coeff3(plan, g, dq, size, i, long_side, vh8, vw8, v, inv_order);
-		const int32_t r = C > R ? i / C : i % R, c = C > R ? i % C : i / R;
-		A[r * C + c] = v[0]; A[65536 + r * C + c] = v[1]; A[2 * 65536 + r * C + c] = v[2];
+	if (f.sparse_coeffs) {   // the tiles live in the HBM scratch here (stores are visible to the workgroup after a barrier + fence)
+		for (int32_t i = tid; i < size; i += nthreads) { A[i] = 0.0f; A[65536 + i] = 0.0f; A[2 * 65536 + i] = 0.0f; }
+		__threadfence_block(); __syncthreads();
+		const uint16_t *order = plan.pool_u16 + f.order_off[DEV_DCT_SELECT[vb.dctsel][2] * 3];
+		const TileMap map = {R, C, C, 0};
+		const float qbias[3] = {f.quant_bias[0], f.quant_bias[1], f.quant_bias[2]};
+		tile_scatter_events(plan, g, vb.blk, order, dq, size, map, A, 65536, qbias, f.quant_bias_num, tid, nthreads);
+		tile_fill_llf(plan, g, long_side, vh8, vw8, map, A, 65536, f.kx_lf, f.kb_lf, tid, nthreads);
+		__threadfence_block(); __syncthreads();
+		tile_apply_cfl(g, size, long_side, vh8, vw8, map, A, 65536, tid, nthreads);
+		__threadfence_block();
+	} else {
+		for (int32_t i = tid; i < size; i += nthreads) {
+			float v[3];
+			load_coeff3(plan, g, dq, size, i, long_side, vh8, vw8, v);
+			const int32_t r = C > R ? i / C : i % R, c = C > R ? i % C : i / R;
+			A[r * C + c] = v[0]; A[65536 + r * C + c] = v[1]; A[2 * 65536 + r * C + c] = v[2];
+		}
 	}
 	__syncthreads();
 	for (int ch = 0; ch < 3; ++ch) {

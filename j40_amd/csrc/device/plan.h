@@ -65,6 +65,8 @@ struct DevVarblock {
 	int32_t px, py;       // top-left pixel in the frame
 	uint16_t effw, effh;  // visible size
 	uint8_t dctsel, pad[3];
+	int32_t blk;          // ordinal of the block in plan.group_blocks / plan.block_events
+	int32_t pad2;
 };
 
 struct DevFrame {
@@ -82,16 +84,16 @@ struct DevFrame {
 	uint32_t order_off[11 * 13 * 3];  // into the u16 pool; 0xffffffff = not loaded
 	uint32_t dq_off[17];              // into the f32 pool, layout [channel][coefficient]; 0xffffffff = not loaded
 	uint32_t dq_size[17];
-	// single-pass frames: K1 stores coefficients in *scan order* (no order lookup on the serial path) and
-	// the pixel kernels gather through the inverse order: inv_order[j] = scan position of canonical index j
-	int32_t scan_order_coeffs;
-	uint32_t inv_order_off[13 * 3];   // into the u16 pool
-	int32_t order_same[13];
+	// single-pass frames: the entropy kernel does not fill dense coefficient planes; it appends (scan position, value)
+	// events per block, see DevPlan::events. 0: dense planes in canonical order, accumulated over the passes (j40.h:6989)
+	int32_t sparse_coeffs;
 	// frames with extra channels: a Modular sub-image follows the HF coefficients in every pass-group section (j40.h:7024-7034).
 	// The reference decodes it and then drops it (j40__combine_vardct replaces the channel list, j40.h:7868-7870: the output is
 	// opaque); here it is not decoded, so a section does not have to end where its coefficients end.
 	int32_t sections_have_trailer;           // pass 0: the three channels share one coefficient order (the usual case)
 };
+
+struct CoeffEvent { uint32_t pos; int32_t value; };   // one non-zero quantised HF coefficient: scan position inside its block
 
 // everything a kernel needs, passed by value
 struct DevPlan {
@@ -119,9 +121,16 @@ struct DevPlan {
 	// working buffers
 	float *coeffs[3];                // [total cells * 64]; one allocation: coeffs[c] = coeffs[0] + c * coeff_stride
 	uint32_t coeff_stride;
-	// 1: the pixel kernels write a zero back over every non-zero coefficient they read, so the planes are all-zero again when
-	// the decode ends and the next one needs no clear (a 400 MB memset per 8K frame otherwise). 0: planes are kept (stage dumps).
-	int32_t clear_after_read;
+	// Sparse coefficients (DevFrame::sparse_coeffs). At typical qualities two thirds of the quantised HF coefficients are zero,
+	// and a dense plane costs 12 B/pixel to clear, to fill with scattered 4-byte stores and to read back. Instead the entropy
+	// kernel appends one event {scan position, value} per non-zero coefficient to its section's region of `events` -- sequential
+	// 8-byte stores -- and notes per block where its events start and how many each channel has (emission order Y, X, B:
+	// block_events[4 * blk] = first event, [+1..+3] = counts). The pixel kernels zero a tile in LDS and scatter the events
+	// into it, so dequantisation work is proportional to the non-zeros. ev_range[2 * g], [2 * g + 1]: first / end event
+	// index of group g's region (sized on the host from the section's byte size; running out of it is ERR_EVOF).
+	CoeffEvent *events;
+	const uint32_t *ev_range;
+	uint32_t *block_events;
 	int8_t *nonzeros;                // [num_groups][32 * 32 * 3]
 	int32_t *lz_window;              // [num_groups][lz_window_size] or null
 	uint32_t lz_window_size;
@@ -209,6 +218,7 @@ enum {
 	ERR_PRED = ('p' << 24) | ('r' << 16) | ('e' << 8) | 'd',
 	ERR_TREC = ('t' << 24) | ('r' << 16) | ('e' << 8) | 'c',
 	ERR_TODO = ('T' << 24) | ('O' << 16) | ('D' << 8) | 'O',
+	ERR_EVOF = ('e' << 24) | ('v' << 16) | ('o' << 8) | 'f',   // a section's event region is full: decode the frame with dense planes
 };
 
 } // namespace j40hip

@@ -83,7 +83,8 @@ struct j40hip_device_state {
 	std::vector<DeviceBuffer> buffers;
 	void *plan_block = nullptr, *work_block = nullptr;   // VarDCT frames: the uploaded plan and the working set (recycled, see cache_acquire)
 	size_t plan_block_bytes = 0, work_block_bytes = 0;
-	bool work_clean = false;                              // the coefficient planes in work_block are all-zero
+	bool force_dense = false;                             // dense coefficient planes although the frame has one pass (after ERR_EVOF)
+	size_t num_blocks = 0;                                // entries of plan.block_events / 4
 	DevPlan plan;
 	bool is_modular = false;
 	int64_t first_group = 0, num_groups = 0;       // range decoded by this process
@@ -132,7 +133,7 @@ extern "C" void j40hip_release_device(j40hip_frame *f) {
 	if (f->dev->plan_block || f->dev->work_block) {
 		(void) hipDeviceSynchronize();   // nothing may still be running on memory that is about to be handed to another frame
 		cache_release(f->dev->device, f->dev->plan_block, f->dev->plan_block_bytes, false);
-		cache_release(f->dev->device, f->dev->work_block, f->dev->work_block_bytes, f->dev->work_clean);
+		cache_release(f->dev->device, f->dev->work_block, f->dev->work_block_bytes, false);
 	}
 	for (auto &b : f->dev->buffers) b.release();
 	for (auto &e : f->dev->ev) if (e) (void) hipEventDestroy(e);
@@ -269,10 +270,11 @@ extern "C" uint32_t j40hip_frame_upload(j40hip_frame *h, int device) {
 	if (j40hip_device_count() <= device || hipSetDevice(device) != hipSuccess) return ERR_GPU;
 	if (h->frame.fh.is_modular) return upload_modular(h, device);
 	HostPlan hp;
+	hp.force_dense = h->force_dense;
 	if (uint32_t e = build_vardct_plan(h->frame, h->cs, h->cs_size, &hp)) return e;
 
 	j40hip_device_state *st = new j40hip_device_state();
-	h->dev = st; st->device = device;
+	h->dev = st; st->device = device; st->force_dense = h->force_dense;
 	hipStream_t s = nullptr;
 	bool ok = true;
 	DevPlan &plan = st->plan;
@@ -292,6 +294,7 @@ extern "C" uint32_t j40hip_frame_upload(j40hip_frame *h, int device) {
 	const size_t o_vbc = sg.put(hp.vb_coeffoff_qfidx.data(), hp.vb_coeffoff_qfidx.size()), o_vbh = sg.put(hp.vb_hfmul_inv.data(), hp.vb_hfmul_inv.size());
 	const size_t o_xfy = sg.put(hp.xfromy.data(), hp.xfromy.size()), o_bfy = sg.put(hp.bfromy.data(), hp.bfromy.size());
 	const size_t o_vbs = sg.put(st->vb_sorted.data(), st->vb_sorted.size());
+	const size_t o_evr = sg.put(hp.ev_range.data(), hp.ev_range.size());
 	bool dummy_clean = false;
 	st->plan_block = cache_acquire(device, sg.blob.size(), &st->plan_block_bytes, &dummy_clean);
 	if (!st->plan_block || hipMemcpyAsync(st->plan_block, sg.blob.data(), sg.blob.size(), hipMemcpyHostToDevice, s) != hipSuccess) ok = false;
@@ -306,26 +309,30 @@ extern "C" uint32_t j40hip_frame_upload(j40hip_frame *h, int device) {
 	plan.vb_coeffoff_qfidx = (const int32_t *) (pb + o_vbc); plan.vb_hfmul_inv = (const float *) (pb + o_vbh);
 	plan.xfromy = (const int16_t *) (pb + o_xfy); plan.bfromy = (const int16_t *) (pb + o_bfy);
 	st->d_vb_sorted = (DevVarblock *) (pb + o_vbs);
-	// working set: the three coefficient planes (one allocation: hf_lanes_dev.h addresses a lane's channel by offset), the
-	// non-zero scratch, status words, LZ77 windows, the scratch of the 128/256-sized transforms
+	plan.ev_range = (const uint32_t *) (pb + o_evr);
+	// working set: the coefficients -- event lists plus the per-block table (single-pass frames) or three dense planes in one
+	// allocation (multi-pass frames; hf_lanes_dev.h addresses a lane's channel by offset) --, the non-zero scratch, status
+	// words, LZ77 windows, the scratch of the 128/256-sized transforms
 	st->coeff_floats = hp.coeff_floats;
+	st->num_blocks = hp.group_blocks.size();
 	const int32_t num_groups = hp.frame.num_groups;
 	{
 		auto align = [](size_t v) { return (v + 255) & ~(size_t) 255; };
+		const bool sparse = hp.frame.sparse_coeffs != 0;
 		const size_t stride = (st->coeff_floats + 63) & ~(size_t) 63;
-		const size_t w_coeffs = 0, coeff_bytes = sizeof(float) * 3 * stride;
-		const size_t w_nz = align(w_coeffs + coeff_bytes), w_status = align(w_nz + (size_t) num_groups * 32 * 32 * 3);
+		const size_t coeff_bytes = sparse ? sizeof(CoeffEvent) * hp.ev_capacity : sizeof(float) * 3 * stride;
+		const size_t w_coeffs = 0, w_blk = align(w_coeffs + coeff_bytes), blk_bytes = sparse ? sizeof(uint32_t) * 4 * st->num_blocks : 0;
+		const size_t w_nz = align(w_blk + blk_bytes), w_status = align(w_nz + (size_t) num_groups * 32 * 32 * 3);
 		const size_t w_lz = align(w_status + sizeof(uint32_t) * hp.sections.size()), lz_bytes = sizeof(int32_t) * (size_t) num_groups * hp.lz_window_size;
 		const size_t w_large = align(w_lz + lz_bytes), large_bytes = sizeof(float) * (size_t) hp.max_large * 6 * 65536;
-		st->work_block = cache_acquire(device, w_large + large_bytes + 256, &st->work_block_bytes, &st->work_clean);
+		bool unused_clean = false;
+		st->work_block = cache_acquire(device, w_large + large_bytes + 256, &st->work_block_bytes, &unused_clean);
 		uint8_t *wb = (uint8_t *) st->work_block;
 		if (!wb) ok = false;
 		else {
-			for (int c = 0; c < 3; ++c) plan.coeffs[c] = (float *) (wb + w_coeffs) + (size_t) c * stride;
+			if (sparse) { plan.events = (CoeffEvent *) (wb + w_coeffs); plan.block_events = (uint32_t *) (wb + w_blk); }
+			else for (int c = 0; c < 3; ++c) plan.coeffs[c] = (float *) (wb + w_coeffs) + (size_t) c * stride;
 			plan.coeff_stride = (uint32_t) stride;
-			plan.clear_after_read = 1;   // the planes start out zero and the pixel kernels keep them that way
-			if (!st->work_clean && hipMemsetAsync(wb + w_coeffs, 0, coeff_bytes, s) != hipSuccess) ok = false;
-			st->work_clean = true;
 			plan.nonzeros = (int8_t *) (wb + w_nz); plan.status = (uint32_t *) (wb + w_status);
 			plan.lz_window_size = hp.lz_window_size;
 			plan.lz_window = hp.lz_window_size ? (int32_t *) (wb + w_lz) : nullptr;
@@ -340,6 +347,8 @@ extern "C" uint32_t j40hip_frame_upload(j40hip_frame *h, int device) {
 	if (!ok) { j40hip_release_device(h); return ERR_GPU; }
 	return 0;
 }
+
+extern "C" void j40hip_frame_force_dense(j40hip_frame *h, int dense) { if (h) h->force_dense = dense != 0; }
 
 extern "C" uint32_t j40hip_frame_set_group_range(j40hip_frame *h, int64_t first_group, int64_t num_groups) {
 	if (!h || !h->dev) return ERR_GPU;
@@ -370,6 +379,14 @@ extern "C" uint32_t j40hip_frame_set_group_range(j40hip_frame *h, int64_t first_
 	return 0;
 }
 
+// sparse coefficients: the per-block table (a block the entropy kernel does not reach must read as "no events");
+// dense planes: the planes themselves, since the passes accumulate into them
+static uint32_t clear_before_decode(j40hip_device_state *st, hipStream_t s) {
+	const DevPlan &plan = st->plan;
+	if (plan.events) return hipMemsetAsync(plan.block_events, 0, sizeof(uint32_t) * 4 * st->num_blocks, s) == hipSuccess ? 0 : ERR_GPU;
+	return hipMemsetAsync(plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) plan.coeff_stride, s) == hipSuccess ? 0 : ERR_GPU;
+}
+
 static uint32_t decode_impl(j40hip_frame *h, void *rgba_dev, size_t stride_bytes, hipStream_t s, float *ms3) {
 	if (!h || !h->dev) return ERR_GPU;
 	j40hip_device_state *st = h->dev;
@@ -378,9 +395,8 @@ static uint32_t decode_impl(j40hip_frame *h, void *rgba_dev, size_t stride_bytes
 	const DevPlan &plan = st->plan;
 	const Frame &fr = h->frame;
 	const bool whole = st->first_group == 0 && st->num_groups == fr.fh.num_groups;
-	st->work_clean = false;   // until the pixel kernels of this decode are known to have been enqueued
 	if (ms3) (void) hipEventRecord(st->ev[0], s);
-	if (!plan.clear_after_read && hipMemsetAsync(plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) plan.coeff_stride, s) != hipSuccess) return ERR_GPU;
+	if (uint32_t e = clear_before_decode(st, s)) return e;
 	if (hipMemsetAsync(plan.status, 0, sizeof(uint32_t) * (size_t) st->total_sections, s) != hipSuccess) return ERR_GPU;
 	if (ms3) (void) hipEventRecord(st->ev[1], s);
 	launch_hf_entropy(plan, st->hf, (int32_t) st->first_group, (int32_t) st->num_groups, s);
@@ -504,8 +520,7 @@ static uint32_t batch_enqueue(j40hip_batch *b, void *const *rgba_dev, const size
 	if (ev) (void) hipEventRecord(ev[0], s);
 	for (j40hip_frame *h : b->frames) {
 		j40hip_device_state *st = h->dev;
-		st->work_clean = false;
-		if (!st->plan.clear_after_read && hipMemsetAsync(st->plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) st->plan.coeff_stride, s) != hipSuccess) return ERR_GPU;
+		if (uint32_t e = clear_before_decode(st, s)) return e;
 		if (hipMemsetAsync(st->plan.status, 0, sizeof(uint32_t) * (size_t) st->total_sections, s) != hipSuccess) return ERR_GPU;
 	}
 	if (ev) (void) hipEventRecord(ev[1], s);
@@ -529,9 +544,7 @@ static uint32_t batch_enqueue(j40hip_batch *b, void *const *rgba_dev, const size
 		}
 	}
 	if (ev) (void) hipEventRecord(ev[3], s);
-	if (hipGetLastError() != hipSuccess) return ERR_GPU;
-	for (j40hip_frame *h : b->frames) h->dev->work_clean = h->dev->plan.clear_after_read != 0;
-	return 0;
+	return hipGetLastError() == hipSuccess ? 0 : ERR_GPU;
 }
 
 static uint32_t events_to_ms(hipEvent_t *ev, float *ms3) {
@@ -618,32 +631,44 @@ extern "C" uint32_t j40hip_frame_decode_to_host(j40hip_frame *h, void *rgba_host
 	uint32_t err = decode_impl(h, d, stride_bytes, nullptr, nullptr);
 	if (!err && hipStreamSynchronize(nullptr) != hipSuccess) err = ERR_GPU;
 	if (!err) err = j40hip_frame_status(h);
+	if (err == ERR_EVOF) {   // a section with more non-zero coefficients than its event region holds: decode with dense planes
+		h->force_dense = true;
+		err = j40hip_frame_upload(h, device);
+		if (!err) err = decode_impl(h, d, stride_bytes, nullptr, nullptr);
+		if (!err && hipStreamSynchronize(nullptr) != hipSuccess) err = ERR_GPU;
+		if (!err) err = j40hip_frame_status(h);
+	}
 	if (!err && hipMemcpy(rgba_host, d, bytes, hipMemcpyDeviceToHost) != hipSuccess) err = ERR_GPU;
 	(void) hipDeviceSynchronize();
 	cache_release(device, d, got, false);
 	return err;
 }
 
-// stage dumps need the coefficients after the decode: keep = 1 switches the clear-after-read off (and the clear before the
-// entropy launch back on). Takes effect for decodes of this frame issued afterwards; batches copy the setting when created.
-extern "C" uint32_t j40hip_frame_keep_coefficients(j40hip_frame *h, int keep) {
-	if (!h || !h->dev || h->dev->is_modular) return ERR_GPU;
-	j40hip_device_state *st = h->dev;
-	if (hipSetDevice(st->device) != hipSuccess) return ERR_GPU;
-	// whatever the previous mode left behind, start from clean planes
-	if (hipMemset(st->plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) st->plan.coeff_stride) != hipSuccess) return ERR_GPU;
-	st->plan.clear_after_read = keep ? 0 : 1;
-	st->work_clean = !keep;
-	return 0;
-}
-
 extern "C" uint32_t j40hip_frame_read_coeffs(j40hip_frame *h, int64_t gg, int c, float *out) {
 	if (!h || !h->dev || h->dev->is_modular) return ERR_GPU;
+	j40hip_device_state *st = h->dev;
 	const LfGroup &g = h->frame.lf_groups[(size_t) gg];
 	size_t base = 0;
 	for (int64_t i = 0; i < gg; ++i) base += h->frame.lf_groups[(size_t) i].blocks.size();
-	if (hipMemcpy(out, h->dev->plan.coeffs[c] + base * 64, sizeof(float) * g.blocks.size() * 64, hipMemcpyDeviceToHost) != hipSuccess) return ERR_GPU;
-	coeffs_scan_to_canonical(h->frame, (size_t) gg, c, out);
+	if (!st->plan.events) {   // dense planes, canonical order
+		return hipMemcpy(out, st->plan.coeffs[c] + base * 64, sizeof(float) * g.blocks.size() * 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : ERR_GPU;
+	}
+	// sparse: expand the events of this LF group's blocks into the canonical layout the reference keeps
+	std::vector<uint32_t> table(4 * st->num_blocks);
+	if (hipMemcpy(table.data(), st->plan.block_events, sizeof(uint32_t) * table.size(), hipMemcpyDeviceToHost) != hipSuccess) return ERR_GPU;
+	memset(out, 0, sizeof(float) * g.blocks.size() * 64);
+	std::vector<CoeffEvent> ev;
+	for (const DevVarblock &vb : st->vb_sorted) {
+		if ((size_t) vb.llf_base < base || (size_t) vb.llf_base >= base + g.blocks.size()) continue;   // another LF group's block
+		const uint32_t *be = table.data() + 4 * (size_t) vb.blk;
+		const uint32_t skip = c == 1 ? 0 : c == 0 ? be[1] : be[1] + be[2], n = be[c == 1 ? 1 : c == 0 ? 2 : 3];   // emission order Y, X, B
+		if (!n) continue;
+		ev.resize(n);
+		if (hipMemcpy(ev.data(), st->plan.events + be[0] + skip, sizeof(CoeffEvent) * n, hipMemcpyDeviceToHost) != hipSuccess) return ERR_GPU;
+		const std::vector<int32_t> &order = h->frame.orders[0][DCT_SELECT[vb.dctsel].order_idx][(size_t) c];
+		float *blk = out + ((size_t) vb.llf_base - base) * 64;
+		for (const CoeffEvent &e : ev) blk[order[e.pos]] = (float) e.value;
+	}
 	return 0;
 }
 

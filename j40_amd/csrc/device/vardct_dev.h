@@ -26,9 +26,9 @@ J40_DEV VbGeom varblock_geometry(const DevPlan &plan, const DevVarblock &vb) {
 	return g;
 }
 
-// loads coefficient `i` (canonical layout index) of all three channels: dequantised, chroma-from-luma
-// applied, LLF corner substituted (j40.h:7086-7094, 7157-7172)
-J40_DEV void load_coeff3(const DevPlan &plan, const VbGeom &g, const float *dq, int32_t dq_size, int32_t i, int32_t long_side, int32_t vh8, int32_t vw8, float out[3], const uint16_t *inv_order = nullptr) {
+// loads coefficient `i` (canonical layout index) of all three channels from the dense planes (multi-pass frames):
+// dequantised, chroma-from-luma applied, LLF corner substituted (j40.h:7086-7094, 7157-7172)
+J40_DEV void load_coeff3(const DevPlan &plan, const VbGeom &g, const float *dq, int32_t dq_size, int32_t i, int32_t long_side, int32_t vh8, int32_t vw8, float out[3]) {
 	const DevFrame &f = *plan.frame;
 	const int32_t srow = i / long_side, scol = i - srow * long_side;
 	if (srow < vh8 && scol < vw8) {
@@ -37,19 +37,57 @@ J40_DEV void load_coeff3(const DevPlan &plan, const VbGeom &g, const float *dq, 
 		out[0] = lx + ly * f.kx_lf; out[1] = ly; out[2] = lb + ly * f.kb_lf;
 		return;
 	}
-	// scan-order storage (single-pass frames): canonical index i lives at scan position inv_order[c][i]
-	const int32_t ix = inv_order ? inv_order[i] : i, iy = inv_order ? inv_order[dq_size + i] : i, ib = inv_order ? inv_order[2 * dq_size + i] : i;
-	const float cx = plan.coeffs[0][g.coeff_base + ix], cy = plan.coeffs[1][g.coeff_base + iy], cb = plan.coeffs[2][g.coeff_base + ib];
-	if (plan.clear_after_read) {   // leave the planes all-zero for the next decode
-		if (cx != 0.0f) plan.coeffs[0][g.coeff_base + ix] = 0.0f;
-		if (cy != 0.0f) plan.coeffs[1][g.coeff_base + iy] = 0.0f;
-		if (cb != 0.0f) plan.coeffs[2][g.coeff_base + ib] = 0.0f;
-	}
-	const float qx = dequant_coeff(cx, f.quant_bias[0], f.quant_bias_num, g.mult[0], dq[i]);
-	const float qy = dequant_coeff(cy, f.quant_bias[1], f.quant_bias_num, g.mult[1], dq[dq_size + i]);
-	const float qb = dequant_coeff(cb, f.quant_bias[2], f.quant_bias_num, g.mult[2], dq[2 * dq_size + i]);
+	const float qx = dequant_coeff(plan.coeffs[0][g.coeff_base + i], f.quant_bias[0], f.quant_bias_num, g.mult[0], dq[i]);
+	const float qy = dequant_coeff(plan.coeffs[1][g.coeff_base + i], f.quant_bias[1], f.quant_bias_num, g.mult[1], dq[dq_size + i]);
+	const float qb = dequant_coeff(plan.coeffs[2][g.coeff_base + i], f.quant_bias[2], f.quant_bias_num, g.mult[2], dq[2 * dq_size + i]);
 	out[0] = qx + qy * g.kx_hf; out[1] = qy; out[2] = qb + qy * g.kb_hf;
 }
 
+// ---- sparse coefficients (DevPlan::events) -> LDS tiles ----
+// A tile holds one channel of one block; `TileMap` says where canonical index i lives in it. The three channel tiles are
+// `cstride` floats apart. Steps, all cooperative over lanes `lane, lane + nlanes, ...` (tests: 0, 1):
+//   1. the caller zeroes the tiles;  2. tile_scatter_events: dequantised non-zeros;  3. tile_fill_llf: the LLF corner;
+//   4. (after a barrier) tile_apply_cfl: X += kx * Y, B += kb * Y outside the LLF corner.
+// Same values as load_coeff3 computes per position: a zero coefficient dequantises to +0 and 0 + 0 * k = +0.
+struct TileMap {
+	int32_t rows, columns, pitch, linear;   // linear: the 8x8 special transforms keep canonical index i at i
+	J40_DEVM int32_t at(int32_t i) const {
+		if (linear) return i;
+		const int32_t r = columns > rows ? i / columns : i % rows, c = columns > rows ? i % columns : i / rows;   // j40.h:5978-5985
+		return r * pitch + c;
+	}
+};
+
+J40_DEV void tile_scatter_events(const DevPlan &plan, const VbGeom &g, int32_t blk, const uint16_t *order /* pass 0: [3][n] */, const float *dq /* [3][n] */, int32_t n,
+		const TileMap &map, float *tile, int32_t cstride, const float quant_bias[3], float quant_bias_num, int32_t lane, int32_t nlanes) {
+	const uint32_t *be = plan.block_events + 4 * (size_t) blk;
+	const uint32_t first = be[0], n0 = be[1], n1 = be[2], total = n0 + n1 + be[3];
+	for (uint32_t e = (uint32_t) lane; e < total; e += (uint32_t) nlanes) {
+		const int32_t c = e < n0 ? 1 : e < n0 + n1 ? 0 : 2;   // events come in the order the channels are coded: Y, X, B
+		const CoeffEvent ev = plan.events[first + e];
+		const int32_t i = order[c * n + (int32_t) ev.pos];
+		tile[c * cstride + map.at(i)] = dequant_coeff((float) ev.value, quant_bias[c], quant_bias_num, g.mult[c], dq[c * n + i]);
+	}
+}
+
+J40_DEV void tile_fill_llf(const DevPlan &plan, const VbGeom &g, int32_t long_side, int32_t vh8, int32_t vw8, const TileMap &map, float *tile, int32_t cstride, float kx_lf, float kb_lf,
+		int32_t lane, int32_t nlanes) {
+	for (int32_t k = lane; k < vh8 * vw8; k += nlanes) {
+		const int32_t srow = k / vw8, scol = k - srow * vw8, at = map.at(srow * long_side + scol), l = g.llf_base + k;
+		const float lx = plan.llf[0][l], ly = plan.llf[1][l], lb = plan.llf[2][l];
+		tile[at] = lx + ly * kx_lf; tile[cstride + at] = ly; tile[2 * cstride + at] = lb + ly * kb_lf;
+	}
+}
+
+J40_DEV void tile_apply_cfl(const VbGeom &g, int32_t n, int32_t long_side, int32_t vh8, int32_t vw8, const TileMap &map, float *tile, int32_t cstride, int32_t lane, int32_t nlanes) {
+	for (int32_t i = lane; i < n; i += nlanes) {
+		const int32_t srow = i / long_side, scol = i - srow * long_side;
+		if (srow < vh8 && scol < vw8) continue;   // the LLF corner carries its own factors (j40.h:7158-7172)
+		const int32_t at = map.at(i);
+		const float y = tile[cstride + at];
+		tile[at] = tile[at] + y * g.kx_hf;
+		tile[2 * cstride + at] = tile[2 * cstride + at] + y * g.kb_hf;
+	}
+}
 
 } // namespace j40hip

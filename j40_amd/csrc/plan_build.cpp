@@ -36,21 +36,6 @@ void flatten_code_spec(const CodeSpec &spec, std::vector<uint8_t> &u8, std::vect
 	}
 }
 
-void coeffs_scan_to_canonical(const Frame &fr, size_t ggidx, int c, float *data) {
-	if (fr.fh.num_passes != 1) return;
-	const LfGroup &gg = fr.lf_groups[ggidx];
-	std::vector<float> tmp;
-	for (const VarblockInfo &vb : gg.varblocks) {
-		const DctSelect &d = DCT_SELECT[vb.dctsel];
-		const std::vector<int32_t> &order = fr.orders[0][d.order_idx][c];
-		const size_t size = (size_t) 1 << (d.log_rows + d.log_columns);
-		float *blk = data + (vb.coeffoff_qfidx & ~15);
-		tmp.assign(blk, blk + size);
-		std::fill(blk, blk + size, 0.0f);
-		for (size_t i = size / 64; i < size; ++i) blk[order[i]] = tmp[i];
-	}
-}
-
 uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostPlan *hp) {
 	if (fr.fh.is_modular) return ERR_TODO;
 	if (fr.im.grey || !fr.im.xyb_encoded || fr.fh.do_ycbcr) return ERR_TODO;  // same limits as j40.h:7867, 7917-7921
@@ -125,6 +110,7 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 			dv.px = gg.left + vb.x8 * 8; dv.py = gg.top + vb.y8 * 8;
 			dv.effh = (uint16_t) std::min(gg.height - vb.y8 * 8, 1 << ds.log_rows); dv.effw = (uint16_t) std::min(gg.width - vb.x8 * 8, 1 << ds.log_columns);
 			dv.dctsel = (uint8_t) vb.dctsel;
+			dv.pad2 = (int32_t) g; dv.blk = (int32_t) v;   // resolved to the block's ordinal once the group lists exist
 			hp->vb_sorted.push_back(dv);
 		}
 	}
@@ -147,6 +133,8 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 		d.gx = fr.lf_groups[(size_t) gi.ggidx].left + gi.gx_in_gg; d.gy = fr.lf_groups[(size_t) gi.ggidx].top + gi.gy_in_gg; d.gw = gi.gw; d.gh = gi.gh;
 	}
 	// per-group block lists for K1, in the visiting order of j40__hf_coeffs
+	std::vector<std::vector<int32_t>> ordinal(fr.lf_groups.size());   // [LF group][varblock] -> position in group_blocks
+	for (size_t g = 0; g < fr.lf_groups.size(); ++g) ordinal[g].assign(fr.lf_groups[g].varblocks.size(), -1);
 	hp->group_block_start.assign((size_t) num_groups + 1, 0);
 	for (int32_t g = 0; g < num_groups; ++g) {
 		hp->group_block_start[(size_t) g] = (uint32_t) hp->group_blocks.size();
@@ -166,20 +154,27 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 				for (int32_t c_yxb = 0; c_yxb < 3; ++c_yxb) v |= (uint32_t) (fr.block_ctx_map[(size_t) (bctx0 + 13 * nb_qf1 * lfidx_size * c_yxb)] & 15) << (4 * c_yxb);
 				gb.bctx3 = (uint16_t) v;
 			}
+			ordinal[(size_t) d.ggidx][(size_t) (blk & 0xfffff)] = (int32_t) hp->group_blocks.size();
 			hp->group_blocks.push_back(gb);
 		}
 	}
 	hp->group_block_start[(size_t) num_groups] = (uint32_t) hp->group_blocks.size();
-	// inverse coefficient orders (single-pass frames store coefficients in scan order)
-	df.scan_order_coeffs = fr.fh.num_passes == 1;
-	for (int i = 0; i < 13 * 3; ++i) df.inv_order_off[i] = 0xffffffffu;
-	for (int o = 0; o < 13; ++o) df.order_same[o] = !fr.orders[0][o][0].empty() && fr.orders[0][o][0] == fr.orders[0][o][1] && fr.orders[0][o][0] == fr.orders[0][o][2];
-	if (df.scan_order_coeffs) for (int o = 0; o < 13; ++o) for (int ch = 0; ch < 3; ++ch) {
-		const std::vector<int32_t> &ord = fr.orders[0][o][ch];
-		if (ord.empty()) continue;
-		std::vector<uint16_t> inv(ord.size());
-		for (size_t i = 0; i < ord.size(); ++i) inv[(size_t) ord[i]] = (uint16_t) i;
-		df.inv_order_off[o * 3 + ch] = push(hp->pool_u16, inv.data(), inv.size());
+	for (DevVarblock &dv : hp->vb_sorted) dv.blk = ordinal[(size_t) dv.pad2][(size_t) dv.blk];   // (LF group, varblock) were parked in pad2 / blk
+	for (DevVarblock &dv : hp->vb_sorted) dv.pad2 = 0;
+	// single-pass frames: sparse coefficients (DevPlan::events). A group's region is sized from its section: a non-zero
+	// coefficient costs bits, 6 events per byte is far beyond what entropy coding reaches on real data; a section that still
+	// overflows it fails with ERR_EVOF and the frame is decoded with dense planes instead (runtime.hip).
+	df.sparse_coeffs = fr.fh.num_passes == 1 && !hp->force_dense;
+	hp->ev_range.clear(); hp->ev_capacity = 0;
+	if (df.sparse_coeffs) {
+		for (int32_t g = 0; g < num_groups; ++g) {
+			const DevSection &d = hp->sections[(size_t) g];
+			const size_t worst = (size_t) d.gw8 * (size_t) d.gh8 * 64 * 3, cap = std::min(worst, (size_t) d.size * 6 + 256);
+			hp->ev_range.push_back((uint32_t) hp->ev_capacity);
+			hp->ev_capacity += cap;
+			hp->ev_range.push_back((uint32_t) hp->ev_capacity);
+		}
+		if (hp->ev_capacity >= 0xffffffffull) { df.sparse_coeffs = 0; hp->ev_range.clear(); hp->ev_capacity = 0; }
 	}
 	hp->codestream.assign(cs, cs + cs_size);
 	hp->codestream.resize(cs_size + 16, 0);

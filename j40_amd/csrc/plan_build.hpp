@@ -27,6 +27,9 @@ struct HostPlan {
 	std::vector<float> llf[3], vb_hfmul_inv;
 	std::vector<int16_t> xfromy, bfromy;
 	std::vector<DevVarblock> vb_sorted;   // by DctSelect
+	bool force_dense = false;             // in: dense coefficient planes even for single-pass frames (fallback after ERR_EVOF)
+	std::vector<uint32_t> ev_range;       // sparse coefficients: [2 * group] first / end event of the group's region
+	size_t ev_capacity = 0;               // events in total
 	int32_t class_start[28];
 	size_t coeff_floats = 0;
 	uint32_t lz_window_size = 0;          // 0: no LZ77 in any coefficient code spec
@@ -40,7 +43,6 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 // single-pass frames keep HF coefficients in scan order on the device (DevFrame::scan_order_coeffs);
 // this rewrites LF group `gg`, channel c in place into the canonical layout the reference uses
 // (coeffs[order[i]], j40.h:6989) -- for stage dumps / parity tests
-void coeffs_scan_to_canonical(const Frame &fr, size_t gg, int c, float *data);
 
 // ---- Modular frames ----
 struct HostModPlan {

@@ -185,7 +185,10 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 	plan.blocks = hp.blocks.data(); plan.lfindices = hp.lfindices.data();
 	for (int c = 0; c < 3; ++c) { plan.llf[c] = hp.llf[c].data(); plan.coeffs[c] = coeffs[c]; }
 	plan.coeff_stride = (uint32_t) hp.coeff_floats;
-	plan.clear_after_read = 1;
+	// sparse coefficients (single-pass frames): event lists + per-block table, the table cleared like the runtime does
+	std::vector<CoeffEvent> events(hp.ev_capacity + 1);
+	std::vector<uint32_t> block_events(4 * hp.group_blocks.size() + 4, 0);
+	if (hp.frame.sparse_coeffs) { plan.events = events.data(); plan.ev_range = hp.ev_range.data(); plan.block_events = block_events.data(); }
 	plan.vb_coeffoff_qfidx = hp.vb_coeffoff_qfidx.data(); plan.vb_hfmul_inv = hp.vb_hfmul_inv.data();
 	plan.xfromy = hp.xfromy.data(); plan.bfromy = hp.bfromy.data();
 	plan.nonzeros = nonzeros.data(); plan.status = status.data();
@@ -195,7 +198,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 		if (!hp.hf.lanes_fast) return ERR_TODO;
 		const DevFrame &df = hp.frame;
 		LaneFrame lf = {df.nb_block_ctx, df.num_hf_presets, df.preset_bits, df.sections_have_trailer, df.order_off};
-		LaneGlobals G = {plan.codestream, (const uint32_t *) plan.group_blocks, plan.coeffs[0], plan.pool_u16, plan.coeff_stride};
+		LaneGlobals G = {plan.codestream, (const uint32_t *) plan.group_blocks, plan.coeffs[0], plan.events, plan.block_events, plan.pool_u16, plan.coeff_stride};
 		std::vector<int8_t> cols(3 * 32);
 		std::vector<uint32_t> dct(27);
 		for (int d = 0; d < 27; ++d) dct[(size_t) d] = (uint32_t) DEV_DCT_SELECT[d][0] | ((uint32_t) DEV_DCT_SELECT[d][1] << 8) | ((uint32_t) DEV_DCT_SELECT[d][2] << 16);
@@ -210,8 +213,8 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 				const DevSection &sec = plan.sections[pass * df.num_groups + g];
 				const uint32_t b0 = plan.group_block_start[g], b1 = plan.group_block_start[g + 1];
 				const uint32_t cell_base = (uint32_t) plan.lf_groups[sec.ggidx].cell_base;
-				status[(size_t) (pass * df.num_groups + g)] = df.scan_order_coeffs ? decode_hf_section_lane<true>(lf, t, G, sec, cell_base, b0, (int32_t) (b1 - b0), cols.data(), 1, pass)
-					: decode_hf_section_lane<false>(lf, t, G, sec, cell_base, b0, (int32_t) (b1 - b0), cols.data(), 1, pass);
+				status[(size_t) (pass * df.num_groups + g)] = df.sparse_coeffs ? decode_hf_section_lane<true>(lf, t, G, sec, cell_base, b0, (int32_t) (b1 - b0), hp.ev_range[2 * (size_t) g], hp.ev_range[2 * (size_t) g + 1], cols.data(), 1, pass)
+					: decode_hf_section_lane<false>(lf, t, G, sec, cell_base, b0, (int32_t) (b1 - b0), 0, 0, cols.data(), 1, pass);
 			}
 		}
 	} else
@@ -219,10 +222,15 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 		if (g_group_count >= 0 && (g < g_first_group || g >= g_first_group + g_group_count)) continue;
 		decode_hf_group(plan, g, (only_entropy & 2) != 0);  // bit 1: flat (per-lane) decoder
 	}
-	if (coeffs_out) for (int c = 0; c < 3; ++c) {
+	if (coeffs_out) for (int c = 0; c < 3; ++c) {   // canonical layout, as the reference keeps them
 		float *dst = coeffs_out + (size_t) c * hp.coeff_floats;
 		memcpy(dst, coeffs[c], sizeof(float) * hp.coeff_floats);
-		for (size_t gg = 0; gg < fr.lf_groups.size(); ++gg) coeffs_scan_to_canonical(fr, gg, c, dst + (size_t) hp.lf_groups[gg].cell_base * 64);
+		if (hp.frame.sparse_coeffs) for (const DevVarblock &vb : hp.vb_sorted) {
+			const uint32_t *be = block_events.data() + 4 * (size_t) vb.blk;
+			const uint32_t skip = c == 1 ? 0 : c == 0 ? be[1] : be[1] + be[2], n = be[c == 1 ? 1 : c == 0 ? 2 : 3];
+			const std::vector<int32_t> &order = fr.orders[0][DCT_SELECT[vb.dctsel].order_idx][(size_t) c];
+			for (uint32_t e = 0; e < n; ++e) { const CoeffEvent &ev = events[be[0] + skip + e]; dst[(size_t) vb.coeff_base + (size_t) order[ev.pos]] = (float) ev.value; }
+		}
 	}
 	for (uint32_t s : status) if (s) return s;
 	if (only_entropy & 1) return 0;
@@ -245,10 +253,16 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 		const bool special = (vb.dctsel >= 1 && vb.dctsel <= 3) || (vb.dctsel >= 12 && vb.dctsel <= 17);
 		const bool large = log_rows > 6 || log_columns > 6;
 		const int P = special ? 8 : large ? C : C + 1;
-		for (int i = 0; i < sz; ++i) {
+		if (f.sparse_coeffs) {   // the pixel kernels' way: zeroed tiles, scattered events, LLF corner, chroma-from-luma in place
+			for (int ch = 0; ch < 3; ++ch) std::fill(A.begin() + (size_t) ch * 65536, A.begin() + (size_t) ch * 65536 + std::min<size_t>(65536, (size_t) R * (size_t) P), 0.0f);
+			const TileMap map = {R, C, P, special ? 1 : 0};
+			const uint16_t *order = plan.pool_u16 + f.order_off[DEV_DCT_SELECT[vb.dctsel][2] * 3];
+			tile_scatter_events(plan, g, vb.blk, order, dq, sz, map, A.data(), 65536, f.quant_bias, f.quant_bias_num, 0, 1);
+			tile_fill_llf(plan, g, long_side, vh8, vw8, map, A.data(), 65536, f.kx_lf, f.kb_lf, 0, 1);
+			tile_apply_cfl(g, sz, long_side, vh8, vw8, map, A.data(), 65536, 0, 1);
+		} else for (int i = 0; i < sz; ++i) {
 			float v[3];
-			const uint16_t *inv_order = f.scan_order_coeffs ? plan.pool_u16 + f.inv_order_off[DEV_DCT_SELECT[vb.dctsel][2] * 3] : nullptr;
-			load_coeff3(plan, g, dq, sz, i, long_side, vh8, vw8, v, inv_order);
+			load_coeff3(plan, g, dq, sz, i, long_side, vh8, vw8, v);
 			int r, c;
 			if (special) { r = i / 8; c = i % 8; }
 			else { r = C > R ? i / C : i % R; c = C > R ? i % C : i / R; }
@@ -267,8 +281,6 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 			memcpy(rgba + (size_t) (g.py + y) * stride + (size_t) (g.px + x) * 4, &px, 4);
 		}
 	}
-	// clear-after-read: a whole decode leaves the planes all-zero
-	if (g_group_count < 0) for (float v : coeff_store) if (v != 0.0f) return ERR_EXCS;
 	return 0;
 }
 

@@ -55,19 +55,21 @@ def test_hf_coefficients_bit_exact(gpu, ref, name, opts):
     rs = RefStage(ref, data)
     fr = gpu.Frame(data)
     fr.upload(0)
-    err, first = fr.decode_to_host()            # default mode: the pixel kernels zero the coefficients they consume ...
+    err, first = fr.decode_to_host()
     assert err == ""
     for g in range(rs.info["num_lf_groups"]):
         for c in range(3):
-            assert not fr.read_coeffs(g, c).any(), "the coefficient planes must be clean after a decode"
-    err, second = fr.decode_to_host()           # ... so a second decode needs no clear and gives the same pixels
-    assert err == "" and np.array_equal(first, second)
-    fr.keep_coefficients(True)                  # stage dump mode
-    err, third = fr.decode_to_host()
-    assert err == "" and np.array_equal(first, third)
-    for g in range(rs.info["num_lf_groups"]):
-        for c in range(3):
             assert np.array_equal(fr.read_coeffs(g, c), rs.coeffs(g, c)), (g, c)
+    err, second = fr.decode_to_host()           # decoding again on the same working set gives the same pixels
+    assert err == "" and np.array_equal(first, second)
+    if rs.info["num_passes"] == 1:              # single-pass frames use event lists; dense planes (the fallback after "evof") agree
+        fr.force_dense(True)
+        fr.upload(0)
+        err, third = fr.decode_to_host()
+        assert err == "" and np.array_equal(first, third)
+        for g in range(rs.info["num_lf_groups"]):
+            for c in range(3):
+                assert np.array_equal(fr.read_coeffs(g, c), rs.coeffs(g, c)), (g, c)
     fr.close()
     rs.close()
 
@@ -194,10 +196,6 @@ def test_batch_throughput_mode_matches_latency_mode(gpu, ref):
         assert frames[1].status() == ""
         rerr, _ = ref.decode(bytes(bad))
         assert fb.status() == rerr
-        # a failed decode leaves the coefficient planes clean too (whatever its sections stored was consumed and zeroed)
-        for g in range(fb.info["num_lf_groups"]):
-            for c in range(3):
-                assert not fb.read_coeffs(g, c).any()
         b2.close()
     batch.close()
 
@@ -273,8 +271,6 @@ def test_golden_fixtures(gpu):
         data = open(os.path.join(GOLDEN, name + ".jxl"), "rb").read()
         fr = gpu.Frame(data)
         fr.upload(0)
-        if e["mode"] != "modular":
-            fr.keep_coefficients(True)
         err, rgba = fr.decode_to_host()
         assert err == "", name
         if e["mode"] == "modular":
