@@ -137,6 +137,12 @@ J40_DEV int32_t lane_symbol(LaneBits &b, uint32_t &state, const LaneTables &t, i
 	return big ? value : token;
 }
 
+// the entry of DevPlan::block_events of a finished block {first event, n_Y, n_X, n_B}, one 16-byte store
+J40_DEV void lane_store_block_events(const LaneGlobals &G, uint32_t blk, uint32_t first, uint32_t n0, uint32_t n1, uint32_t n2) {
+	J40_GLOBAL uint64_t *e = (J40_GLOBAL uint64_t *) (G.block_events + 4u * blk);
+	e[0] = (uint64_t) first | ((uint64_t) n0 << 32); e[1] = (uint64_t) n1 | ((uint64_t) n2 << 32);
+}
+
 // decodes one (pass, group) section; same results and status codes as decode_hf_section (hf_dev.h).
 // cols[(c * 32 + x) * col_stride]: non-zero count (per 8x8 cell) of the last block written into cell column x, channel c
 template <bool SCAN>
@@ -161,6 +167,7 @@ J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t,
 	int32_t c = 1, bctx = 0, nz = 0, i = 0, prev = 0, cctx = 0;
 	const J40_GLOBAL uint16_t *order = nullptr;
 	uint32_t ev_at = ev_first, chan_first = ev_first;   // SCAN: next free event of this section's region, first event of the current channel
+	uint32_t blk_first = ev_first, blk_n0 = 0, blk_n1 = 0;   // the block's table entry, stored in one piece after its third channel
 	uint32_t next0 = 0, next1 = 0;   // descriptor of block k, requested one block ahead
 	if (!done) { const J40_GLOBAL uint32_t *p = G.group_blocks + 2u * block_first; next0 = p[0]; next1 = p[1]; }
 	for (uint32_t turn = 0; !done; ++turn) {
@@ -174,10 +181,16 @@ J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t,
 		lane_bits_refill(b);
 		int32_t ctx;
 		if (!in_coeffs) {  // next symbol: number of non-zeros of (block k, channel c_yxb), j40.h:6959-6967
+			if (SCAN) {   // the channel before this one is complete: book its event count here, off the per-coefficient path
+				const uint32_t n = ev_at - chan_first;
+				if (c_yxb == 1) blk_n0 = n; else if (c_yxb == 2) blk_n1 = n;
+				else if (k > 0) lane_store_block_events(G, block_first + (uint32_t) k - 1u, blk_first, blk_n0, blk_n1, n);
+				chan_first = ev_at;
+			}
 			if (c_yxb == 0) {
 				const uint32_t w = next1;
 				coeffoff = next0 & ~15u;
-				if (SCAN) G.block_events[4u * (block_first + (uint32_t) k)] = ev_at;
+				blk_first = ev_at;
 				if (k + 1 < nblocks) { const J40_GLOBAL uint32_t *p = G.group_blocks + 2u * (block_first + (uint32_t) k + 1u); next0 = p[0]; next1 = p[1]; }
 				x8 = (int32_t) (w & 31); y8 = (int32_t) ((w >> 5) & 31); bctx3 = w >> 16;
 				const uint32_t di = t.dct_info[(w >> 10) & 31];
@@ -209,9 +222,7 @@ J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t,
 				coeff_at = (uint32_t) c * G.coeff_stride + cell64 + coeffoff;
 				order = G.pool_u16 + f.order_off[(pass * 13 + order_idx) * 3 + c];
 			}
-			chan_first = ev_at;
 			in_coeffs = nz > 0;
-			if (SCAN && !in_coeffs) G.block_events[4u * (block_first + (uint32_t) k) + 1u + (uint32_t) c_yxb] = 0;
 		} else {
 			if (v) {
 				if (SCAN) {   // one sequential 8-byte store per non-zero coefficient
@@ -222,11 +233,12 @@ J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t,
 			prev = v != 0;
 			nz -= prev;
 			++i;
-			if (nz == 0) { in_coeffs = false; if (SCAN) G.block_events[4u * (block_first + (uint32_t) k) + 1u + (uint32_t) c_yxb] = ev_at - chan_first; }
+			if (nz == 0) in_coeffs = false;
 			else if (i >= size) { err = ERR_COEF; break; }   // non-zeros left but no coefficient left (j40.h:6996)
 		}
 		if (!in_coeffs && ++c_yxb == 3) { c_yxb = 0; done = ++k >= nblocks; }
 	}
+	if (SCAN && !err && nblocks > 0) lane_store_block_events(G, block_first + (uint32_t) nblocks - 1u, blk_first, blk_n0, blk_n1, ev_at - chan_first);   // the last block
 	if (!err) {   // j40.h:2884-2893: the final state, or the untouched initial state, must be 0x130000
 		if (state == 0) { lane_bits_refill(b); state = lane_bits_take(b, 16); state |= lane_bits_take(b, 16) << 16; if (lane_bit_position(b) > end_bit) err = ERR_SHRT; }
 		if (!err && state != 0x130000) err = ERR_ANS;

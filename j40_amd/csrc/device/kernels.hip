@@ -340,35 +340,32 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarbl
 	const ColourConsts cc = load_colour_consts(f);
 	const float qbias0 = f.quant_bias[0], qbias1 = f.quant_bias[1], qbias2 = f.quant_bias[2], qbias_num = f.quant_bias_num, kx_lf = f.kx_lf, kb_lf = f.kb_lf;
 	__shared__ VbGeom geom[NB];
-	__shared__ int32_t g_blk[NB];  // ordinal of each block (DevPlan::block_events)
-	__shared__ size_t g_out[NB];   // byte offset of each block's top-left pixel in the output
+	__shared__ uint32_t g_be[NB][4];   // each block's entry of DevPlan::block_events
+	__shared__ size_t g_out[NB];       // byte offset of each block's top-left pixel in the output
 	J40_STAGE_SRGB_THRESHOLDS(f);
 	if (tid < nb) {
 		const DevVarblock vb = list[first + tid];
 		const VbGeom g = varblock_geometry(plan, vb);
-		geom[tid] = g; g_blk[tid] = vb.blk; g_out[tid] = (size_t) g.py * stride_bytes + (size_t) g.px * 4;
+		geom[tid] = g; g_out[tid] = (size_t) g.py * stride_bytes + (size_t) g.px * 4;
+		if (f.sparse_coeffs) { const uint32_t *be = plan.block_events + 4 * (size_t) vb.blk; for (int k = 0; k < 4; ++k) g_be[tid][k] = be[k]; }
 	}
 	constexpr int N = R * C;
 	constexpr int PAR = N >= 256 ? 1 : 256 / N;   // blocks a pass of the 256 lanes covers
 	constexpr int PER = N >= 256 ? N / 256 : 1;   // pixel positions per lane
 	// ---- load: dequantise + chroma-from-luma + LLF into the LDS tiles ----
 	if (f.sparse_coeffs) {
-		// single-pass frames: zero the tiles, scatter each block's coefficient events into them (one wavefront per block: the
-		// work is proportional to the non-zeros), write the LLF corner, then apply chroma-from-luma in place (vardct_dev.h)
+		// single-pass frames: zero the tiles, then scatter each block's coefficient events into them (one wavefront per block:
+		// the work is proportional to the non-zeros; chroma-from-luma rides along) and write the LLF corner (vardct_dev.h)
 		for (int32_t w = tid; w < nb * 3 * TILE; w += nthreads) lds[w] = 0.0f;
 		__syncthreads();
 		const uint16_t *order = plan.pool_u16 + f.order_off[order_idx * 3];   // pass 0; the three channels' orders are consecutive
+		const float *dq_scan = plan.pool_f32 + f.dq_scan_off[param_idx];
 		const TileMap map = {R, C, P, 0};
 		const float qbias[3] = {qbias0, qbias1, qbias2};
 		for (int32_t b = tid >> 6; b < nb; b += nthreads >> 6) {
 			float *tile = lds + (size_t) b * 3 * TILE;
-			tile_scatter_events(plan, geom[b], g_blk[b], order, dq, N, map, tile, TILE, qbias, qbias_num, tid & 63, 64);
+			tile_scatter_events(plan, geom[b], g_be[b], order, dq_scan, N, map, tile, TILE, qbias, qbias_num, tid & 63, 64);
 			tile_fill_llf(plan, geom[b], LONG, VH8, VW8, map, tile, TILE, kx_lf, kb_lf, tid & 63, 64);
-		}
-		__syncthreads();
-		for (int32_t w = tid; w < nb * N; w += nthreads) {
-			const int32_t b = w / N, i = w - b * N;
-			tile_apply_cfl(geom[b], i + 1, LONG, VH8, VW8, map, lds + (size_t) b * 3 * TILE, TILE, i, N);   // this lane's position only
 		}
 	} else {
 		// multi-pass frames: dense planes in canonical order, coalesced over the canonical index
@@ -437,10 +434,12 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan, const DevV
 	__shared__ VbGeom geom[NB];
 	J40_STAGE_SRGB_THRESHOLDS(f);
 	const ColourConsts cc = load_colour_consts(f);
-	__shared__ int32_t g_blk[NB], g_param[NB];
+	__shared__ int32_t g_param[NB];
+	__shared__ uint32_t g_be[NB][4];
 	if (tid < nb) {
 		const DevVarblock vb = list[first + tid];
-		geom[tid] = varblock_geometry(plan, vb); g_blk[tid] = vb.blk;
+		geom[tid] = varblock_geometry(plan, vb);
+		if (f.sparse_coeffs) { const uint32_t *be = plan.block_events + 4 * (size_t) vb.blk; for (int k = 0; k < 4; ++k) g_be[tid][k] = be[k]; }
 		g_param[tid] = vb.dctsel == 1 ? 1 : vb.dctsel == 2 ? 2 : vb.dctsel == 3 ? 3 : vb.dctsel <= 13 ? 9 : 10;
 	}
 	if (f.sparse_coeffs) {
@@ -451,11 +450,9 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan, const DevV
 		const float qbias[3] = {f.quant_bias[0], f.quant_bias[1], f.quant_bias[2]};
 		for (int32_t b = tid >> 6; b < nb; b += nthreads >> 6) {
 			float *tile = tiles + (size_t) b * 3 * P;
-			tile_scatter_events(plan, geom[b], g_blk[b], order, plan.pool_f32 + f.dq_off[g_param[b]], 64, map, tile, P, qbias, f.quant_bias_num, tid & 63, 64);
+			tile_scatter_events(plan, geom[b], g_be[b], order, plan.pool_f32 + f.dq_scan_off[g_param[b]], 64, map, tile, P, qbias, f.quant_bias_num, tid & 63, 64);
 			tile_fill_llf(plan, geom[b], 8, 1, 1, map, tile, P, f.kx_lf, f.kb_lf, tid & 63, 64);
 		}
-		__syncthreads();
-		for (int32_t w = tid; w < nb * 64; w += nthreads) tile_apply_cfl(geom[w >> 6], (w & 63) + 1, 8, 1, 1, map, tiles + (size_t) (w >> 6) * 3 * P, P, w & 63, 64);
 	} else {
 		__syncthreads();
 		for (int32_t w = tid; w < nb * 64; w += nthreads) {
@@ -550,10 +547,8 @@ __global__ void __launch_bounds__(256) k_vardct_large(DevPlan plan, const DevVar
 		const uint16_t *order = plan.pool_u16 + f.order_off[DEV_DCT_SELECT[vb.dctsel][2] * 3];
 		const TileMap map = {R, C, C, 0};
 		const float qbias[3] = {f.quant_bias[0], f.quant_bias[1], f.quant_bias[2]};
-		tile_scatter_events(plan, g, vb.blk, order, dq, size, map, A, 65536, qbias, f.quant_bias_num, tid, nthreads);
+		tile_scatter_events(plan, g, plan.block_events + 4 * (size_t) vb.blk, order, plan.pool_f32 + f.dq_scan_off[param_idx], size, map, A, 65536, qbias, f.quant_bias_num, tid, nthreads);
 		tile_fill_llf(plan, g, long_side, vh8, vw8, map, A, 65536, f.kx_lf, f.kb_lf, tid, nthreads);
-		__threadfence_block(); __syncthreads();
-		tile_apply_cfl(g, size, long_side, vh8, vw8, map, A, 65536, tid, nthreads);
 		__threadfence_block();
 	} else {
 		for (int32_t i = tid; i < size; i += nthreads) {

@@ -84,6 +84,9 @@ struct DevFrame {
 	uint32_t order_off[11 * 13 * 3];  // into the u16 pool; 0xffffffff = not loaded
 	uint32_t dq_off[17];              // into the f32 pool, layout [channel][coefficient]; 0xffffffff = not loaded
 	uint32_t dq_size[17];
+	// single-pass frames: the same weights gathered through pass 0's coefficient order, dq_scan[c][pos] = dq[c][order[c][pos]], so
+	// that an event's weight is found from its scan position without waiting for the order lookup; 0xffffffff = not built
+	uint32_t dq_scan_off[17];
 	// single-pass frames: the entropy kernel does not fill dense coefficient planes; it appends (scan position, value)
 	// events per block, see DevPlan::events. 0: dense planes in canonical order, accumulated over the passes (j40.h:6989)
 	int32_t sparse_coeffs;

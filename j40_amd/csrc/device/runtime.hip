@@ -330,7 +330,10 @@ extern "C" uint32_t j40hip_frame_upload(j40hip_frame *h, int device) {
 		uint8_t *wb = (uint8_t *) st->work_block;
 		if (!wb) ok = false;
 		else {
-			if (sparse) { plan.events = (CoeffEvent *) (wb + w_coeffs); plan.block_events = (uint32_t *) (wb + w_blk); }
+			if (sparse) {
+				plan.events = (CoeffEvent *) (wb + w_coeffs); plan.block_events = (uint32_t *) (wb + w_blk);
+				if (hipMemsetAsync(plan.block_events, 0, blk_bytes, s) != hipSuccess) ok = false;   // recycled memory: no entry may point outside the event list
+			}
 			else for (int c = 0; c < 3; ++c) plan.coeffs[c] = (float *) (wb + w_coeffs) + (size_t) c * stride;
 			plan.coeff_stride = (uint32_t) stride;
 			plan.nonzeros = (int8_t *) (wb + w_nz); plan.status = (uint32_t *) (wb + w_status);
@@ -379,11 +382,12 @@ extern "C" uint32_t j40hip_frame_set_group_range(j40hip_frame *h, int64_t first_
 	return 0;
 }
 
-// sparse coefficients: the per-block table (a block the entropy kernel does not reach must read as "no events");
-// dense planes: the planes themselves, since the passes accumulate into them
+// dense planes are cleared before every decode (the passes accumulate into them). Sparse coefficients need nothing: the per-block
+// table is cleared once per upload, and an entry the entropy kernel does not rewrite (a section failed before reaching the
+// block) still describes events of this frame's previous decode -- in range, and the frame is reported as failed anyway.
 static uint32_t clear_before_decode(j40hip_device_state *st, hipStream_t s) {
 	const DevPlan &plan = st->plan;
-	if (plan.events) return hipMemsetAsync(plan.block_events, 0, sizeof(uint32_t) * 4 * st->num_blocks, s) == hipSuccess ? 0 : ERR_GPU;
+	if (plan.events) return 0;
 	return hipMemsetAsync(plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) plan.coeff_stride, s) == hipSuccess ? 0 : ERR_GPU;
 }
 

@@ -46,8 +46,8 @@ J40_DEV void load_coeff3(const DevPlan &plan, const VbGeom &g, const float *dq, 
 // ---- sparse coefficients (DevPlan::events) -> LDS tiles ----
 // A tile holds one channel of one block; `TileMap` says where canonical index i lives in it. The three channel tiles are
 // `cstride` floats apart. Steps, all cooperative over lanes `lane, lane + nlanes, ...` (tests: 0, 1):
-//   1. the caller zeroes the tiles;  2. tile_scatter_events: dequantised non-zeros;  3. tile_fill_llf: the LLF corner;
-//   4. (after a barrier) tile_apply_cfl: X += kx * Y, B += kb * Y outside the LLF corner.
+//   1. the caller zeroes the tiles (and synchronises);  2. tile_scatter_events: dequantised non-zeros with their
+//   chroma-from-luma contributions;  3. tile_fill_llf: the LLF corner (no event lands there).
 // Same values as load_coeff3 computes per position: a zero coefficient dequantises to +0 and 0 + 0 * k = +0.
 struct TileMap {
 	int32_t rows, columns, pitch, linear;   // linear: the 8x8 special transforms keep canonical index i at i
@@ -58,15 +58,30 @@ struct TileMap {
 	}
 };
 
-J40_DEV void tile_scatter_events(const DevPlan &plan, const VbGeom &g, int32_t blk, const uint16_t *order /* pass 0: [3][n] */, const float *dq /* [3][n] */, int32_t n,
+// `be`: the block's entry of DevPlan::block_events (first event, counts in emission order Y, X, B). `dq_scan`: the weights in
+// scan order (DevFrame::dq_scan_off). Chroma-from-luma rides along: a Y coefficient also contributes kx * Y to X and kb * Y to B
+// at its position, so X and B are accumulated (x + kx * y has two addends, and IEEE addition commutes, so the order in which
+// the two arrive does not matter; +0 + v = v). On the device the accumulation is an LDS / global atomic add.
+J40_DEV void tile_add(float *p, float v) {
+#ifdef __HIPCC__
+	atomicAdd(p, v);
+#else
+	*p += v;
+#endif
+}
+J40_DEV void tile_scatter_events(const DevPlan &plan, const VbGeom &g, const uint32_t be[4], const uint16_t *order /* pass 0: [3][n] */, const float *dq_scan /* [3][n] */, int32_t n,
 		const TileMap &map, float *tile, int32_t cstride, const float quant_bias[3], float quant_bias_num, int32_t lane, int32_t nlanes) {
-	const uint32_t *be = plan.block_events + 4 * (size_t) blk;
 	const uint32_t first = be[0], n0 = be[1], n1 = be[2], total = n0 + n1 + be[3];
 	for (uint32_t e = (uint32_t) lane; e < total; e += (uint32_t) nlanes) {
 		const int32_t c = e < n0 ? 1 : e < n0 + n1 ? 0 : 2;   // events come in the order the channels are coded: Y, X, B
 		const CoeffEvent ev = plan.events[first + e];
-		const int32_t i = order[c * n + (int32_t) ev.pos];
-		tile[c * cstride + map.at(i)] = dequant_coeff((float) ev.value, quant_bias[c], quant_bias_num, g.mult[c], dq[c * n + i]);
+		const int32_t at = map.at(order[c * n + (int32_t) ev.pos]);
+		const float v = dequant_coeff((float) ev.value, quant_bias[c], quant_bias_num, g.mult[c], dq_scan[c * n + (int32_t) ev.pos]);
+		if (c == 1) {
+			tile[cstride + at] = v;
+			tile_add(tile + at, v * g.kx_hf);
+			tile_add(tile + 2 * cstride + at, v * g.kb_hf);
+		} else tile_add(tile + c * cstride + at, v);
 	}
 }
 
@@ -76,17 +91,6 @@ J40_DEV void tile_fill_llf(const DevPlan &plan, const VbGeom &g, int32_t long_si
 		const int32_t srow = k / vw8, scol = k - srow * vw8, at = map.at(srow * long_side + scol), l = g.llf_base + k;
 		const float lx = plan.llf[0][l], ly = plan.llf[1][l], lb = plan.llf[2][l];
 		tile[at] = lx + ly * kx_lf; tile[cstride + at] = ly; tile[2 * cstride + at] = lb + ly * kb_lf;
-	}
-}
-
-J40_DEV void tile_apply_cfl(const VbGeom &g, int32_t n, int32_t long_side, int32_t vh8, int32_t vw8, const TileMap &map, float *tile, int32_t cstride, int32_t lane, int32_t nlanes) {
-	for (int32_t i = lane; i < n; i += nlanes) {
-		const int32_t srow = i / long_side, scol = i - srow * long_side;
-		if (srow < vh8 && scol < vw8) continue;   // the LLF corner carries its own factors (j40.h:7158-7172)
-		const int32_t at = map.at(i);
-		const float y = tile[cstride + at];
-		tile[at] = tile[at] + y * g.kx_hf;
-		tile[2 * cstride + at] = tile[2 * cstride + at] + y * g.kb_hf;
 	}
 }
 

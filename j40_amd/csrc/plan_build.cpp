@@ -81,6 +81,19 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 		std::vector<float> planar(n * 3);
 		for (size_t k = 0; k < n; ++k) for (int c = 0; c < 3; ++c) planar[(size_t) c * n + k] = dq.params[k][(size_t) c];
 		df.dq_off[i] = push(hp->pool_f32, planar.data(), planar.size()); df.dq_size[i] = (uint32_t) n;
+		// weights in scan order (DevFrame::dq_scan_off); every parameter set has one coefficient order
+		static const int8_t ORDER_OF_PARAM[17] = {0, 1, 1, 1, 2, 3, 4, 5, 6, 1, 1, 7, 8, 9, 10, 11, 12};
+		df.dq_scan_off[i] = 0xffffffffu;
+		if (fr.fh.num_passes == 1) {
+			std::vector<float> scan(n * 3);
+			bool have = true;
+			for (int c = 0; c < 3 && have; ++c) {
+				const std::vector<int32_t> &ord = fr.orders[0][ORDER_OF_PARAM[i]][(size_t) c];
+				have = ord.size() == n;
+				for (size_t k = 0; k < n && have; ++k) scan[(size_t) c * n + k] = planar[(size_t) c * n + (size_t) ord[k]];
+			}
+			if (have) df.dq_scan_off[i] = push(hp->pool_f32, scan.data(), scan.size());
+		}
 	}
 
 	// LF bundle: frame-wide arrays over all LF groups

@@ -257,9 +257,8 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 			for (int ch = 0; ch < 3; ++ch) std::fill(A.begin() + (size_t) ch * 65536, A.begin() + (size_t) ch * 65536 + std::min<size_t>(65536, (size_t) R * (size_t) P), 0.0f);
 			const TileMap map = {R, C, P, special ? 1 : 0};
 			const uint16_t *order = plan.pool_u16 + f.order_off[DEV_DCT_SELECT[vb.dctsel][2] * 3];
-			tile_scatter_events(plan, g, vb.blk, order, dq, sz, map, A.data(), 65536, f.quant_bias, f.quant_bias_num, 0, 1);
+			tile_scatter_events(plan, g, plan.block_events + 4 * (size_t) vb.blk, order, plan.pool_f32 + f.dq_scan_off[PARAM[vb.dctsel]], sz, map, A.data(), 65536, f.quant_bias, f.quant_bias_num, 0, 1);
 			tile_fill_llf(plan, g, long_side, vh8, vw8, map, A.data(), 65536, f.kx_lf, f.kb_lf, 0, 1);
-			tile_apply_cfl(g, sz, long_side, vh8, vw8, map, A.data(), 65536, 0, 1);
 		} else for (int i = 0; i < sz; ++i) {
 			float v[3];
 			load_coeff3(plan, g, dq, sz, i, long_side, vh8, vw8, v);
