@@ -265,6 +265,32 @@ def test_baseline_config_sizes(gpu, ref):
     assert err == rerr == "" and np.array_equal(rgba, expect)
 
 
+def test_full_event_region_falls_back_to_dense_planes(ref):
+    """a section with more non-zero coefficients than its event region holds reports "evof" on the asynchronous path and is
+    decoded with dense planes by the synchronous one (run in a subprocess: the region size is fixed when the library loads)"""
+    import subprocess, sys
+    code = """
+import sys, os
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, torch, j40_amd
+from streams import synth
+data = synth("vardct", 520, 264, 71)
+fr = j40_amd.Frame(data); fr.upload(0)
+out = torch.zeros((264, 520, 4), dtype=torch.uint8, device="cuda:0")
+fr.decode(out.data_ptr(), 520 * 4, torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
+assert fr.status() == "evof", fr.status()
+err, rgba = j40_amd.decode(data)          # public API: falls back by itself
+assert err == "", err
+np.save(sys.argv[1], rgba)
+""" % (ROOT, ROOT)
+    out = os.path.join(ROOT, "build", "evof_test.npy")
+    env = dict(os.environ, J40HIP_EVENTS_PER_BYTE="0")
+    subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=600)
+    data = synth("vardct", 520, 264, 71)
+    rerr, expect = ref.decode(data)
+    assert rerr == "" and compare(np.load(out), expect)[0] <= 1
+
+
 def test_golden_fixtures(gpu):
     manifest = json.load(open(os.path.join(GOLDEN, "manifest.json")))
     for name, e in sorted(manifest.items()):
