@@ -106,13 +106,17 @@ typedef struct { int32_t kind, begin_c, rct_type, num_c, nb_colours, nb_deltas, 
 typedef struct {
 	uint32_t byte_off, size, bit_off; int32_t gx, gy, gw, gh, sidx, first_channel, num_channels;
 	int8_t wp[12];                 /* weighted predictor parameters p1, p2, p3[5], w[4] */
+	/* the section's MA tree = tree[tree_off .. tree_off + tree_nodes) and its code spec = codespec[spec_idx]:
+	 * the global pair, or the section's own when its header says use_global_tree = 0 (j40.h:3740-3746) */
+	uint32_t tree_off; int32_t tree_nodes, spec_idx;
 } j40hip_modular_section_view;
 
 typedef struct {
 	int32_t width, height, bpp, num_channels, num_sections, num_transforms, num_tree_nodes, alpha_channel;
 	const uint8_t *codestream; size_t codestream_size;
-	const j40hip_codespec_view *codespec;
-	const j40hip_tree_node *tree;
+	const j40hip_codespec_view *codespec;     /* [num_codespecs] */
+	const j40hip_tree_node *tree;              /* [num_tree_nodes]: every tree in use, back to back */
+	int32_t num_codespecs;
 	const int32_t *channel_w, *channel_h, *channel_meta;   /* coded channels */
 	const j40hip_transform_view *transforms;
 	const j40hip_modular_section_view *sections;

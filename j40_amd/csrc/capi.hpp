@@ -17,6 +17,7 @@ struct j40hip_frame {
 	struct Views {
 		std::vector<std::vector<j40hip_cluster_view>> clusters;
 		std::vector<j40hip_codespec_view> specs;
+		std::vector<j40hip::CodeSpec> host_specs;
 		std::vector<j40hip_lf_group_view> lf_groups;
 		std::vector<j40hip_section_view> sections;
 		std::vector<std::vector<float>> dq;

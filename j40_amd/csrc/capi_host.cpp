@@ -167,14 +167,15 @@ uint32_t j40hip_frame_modular_view(j40hip_frame *h, j40hip_modular_view *v) {
 	const Frame &f = h->frame;
 	memset(v, 0, sizeof *v);
 	h->views = j40hip_frame::Views();
-	h->views.clusters.reserve(4);
+	h->views.clusters.reserve(hp.host_specs.size() + 1);
 	v->width = f.fh.width; v->height = f.fh.height; v->bpp = f.im.bpp; v->num_channels = hp.frame.num_channels; v->num_sections = hp.frame.num_sections;
 	v->alpha_channel = hp.alpha_channel;
 	v->codestream = h->cs; v->codestream_size = h->cs_size;
-	h->views.specs.assign(1, j40hip_codespec_view());
-	fill_codespec_view(h, f.global_codespec, &h->views.specs[0]);
-	v->codespec = h->views.specs.data();
-	for (const TreeNode &n : f.global_tree) h->views.tree.push_back(j40hip_tree_node{n.prop, n.value, n.a, n.b});
+	h->views.specs.assign(hp.host_specs.size(), j40hip_codespec_view());
+	h->views.host_specs = hp.host_specs;   // the views point into these
+	for (size_t i = 0; i < hp.host_specs.size(); ++i) fill_codespec_view(h, h->views.host_specs[i], &h->views.specs[i]);
+	v->codespec = h->views.specs.data(); v->num_codespecs = (int32_t) h->views.specs.size();
+	for (const DevTreeNode &n : hp.tree) h->views.tree.push_back(j40hip_tree_node{n.prop, n.value, n.a, n.b});
 	v->tree = h->views.tree.data(); v->num_tree_nodes = (int32_t) h->views.tree.size();
 	h->views.ch_w = hp.plane_w; h->views.ch_h = hp.plane_h; h->views.ch_meta = hp.plane_meta;
 	v->channel_w = h->views.ch_w.data(); v->channel_h = h->views.ch_h.data(); v->channel_meta = h->views.ch_meta.data();
@@ -184,6 +185,7 @@ uint32_t j40hip_frame_modular_view(j40hip_frame *h, j40hip_modular_view *v) {
 		j40hip_modular_section_view sv;
 		sv.byte_off = s.byte_off; sv.size = s.size; sv.bit_off = s.bit_off; sv.gx = s.gx; sv.gy = s.gy; sv.gw = s.gw; sv.gh = s.gh; sv.sidx = s.sidx;
 		sv.first_channel = s.first_channel; sv.num_channels = s.num_channels; memcpy(sv.wp, s.wp, 12);
+		sv.tree_off = s.tree_off; sv.tree_nodes = s.tree_nodes; sv.spec_idx = s.spec_idx;
 		h->views.mod_sections.push_back(sv);
 	}
 	v->sections = h->views.mod_sections.data();

@@ -119,9 +119,10 @@ struct ModTables {
 	int32_t *wp_errors;              // weighted-predictor error rows [2 * width][5] in LDS, or nullptr: the HBM scratch
 	int32_t wp_errors_width;
 };
-J40_DEV ModTables mod_tables_in_hbm(const DevModPlan &plan) {
-	const DevCodeSpec &spec = *plan.spec;
-	ModTables t = {plan.tree, plan.clusters + spec.cluster_off, plan.pool_u8 + spec.cluster_map_off, plan.pool_u64, plan.pool_i32, nullptr, 0, nullptr, 0};
+J40_DEV ModTables mod_tables_in_hbm(const DevModPlan &plan, int32_t g) {
+	const DevModSection &sec = plan.sections[g];
+	const DevCodeSpec &spec = plan.spec[sec.spec_idx];
+	ModTables t = {plan.tree + sec.tree_off, plan.clusters + spec.cluster_off, plan.pool_u8 + spec.cluster_map_off, plan.pool_u64, plan.pool_i32, nullptr, 0, nullptr, 0};
 	return t;
 }
 
@@ -134,7 +135,7 @@ J40_DEV uint32_t decode_modular_section(const DevModPlan &plan, const ModTables 
 	// by value: references into HBM would be re-read after every sample store (the compiler cannot rule out aliasing)
 	const DevModFrame f = *plan.frame;
 	const DevModSection sec = plan.sections[g];
-	const DevCodeSpec &spec = *plan.spec;
+	const DevCodeSpec &spec = plan.spec[sec.spec_idx];
 	DevBits b;
 	bits_init<UNI>(b, plan.codestream, sec.byte_off, sec.size, sec.bit_off);
 	DevCode code;
@@ -145,7 +146,7 @@ J40_DEV uint32_t decode_modular_section(const DevModPlan &plan, const ModTables 
 	for (int32_t cidx = 0; cidx < sec.num_channels; ++cidx) if (!plan.plane_meta[sec.first_channel + cidx]) dist_mult = mod_max(dist_mult, sec.gw);
 	dist_mult = mod_min(dist_mult, 1 << 21);
 	ModWP wp;
-	wp.on = f.tree_uses_wp; wp.width = sec.gw;
+	wp.on = sec.uses_wp; wp.width = sec.gw;
 	wp.p1 = sec.wp[0]; wp.p2 = sec.wp[1];
 	for (int i = 0; i < 5; ++i) wp.p3[i] = sec.wp[2 + i];
 	for (int i = 0; i < 4; ++i) wp.w[i] = sec.wp[7 + i];

@@ -26,19 +26,20 @@ template <bool IN_LDS>
 __global__ void __launch_bounds__(64) k_modular_sections(DevModPlan plan, int32_t rows_width, int32_t wp_width) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t mod_lds[];
 	const int32_t lane = threadIdx.x;
-	const DevCodeSpec &spec = *plan.spec;
-	ModTables t = mod_tables_in_hbm(plan);
+	const DevModSection &msec = plan.sections[blockIdx.x];
+	const DevCodeSpec &spec = plan.spec[msec.spec_idx];
+	ModTables t = mod_tables_in_hbm(plan, blockIdx.x);
 	if (IN_LDS) {
 		auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
-		const DevModFrame &f = *plan.frame;
+		const int32_t tree_nodes = msec.tree_nodes;
 		uint32_t off = 0;
-		DevTreeNode *l_tree = (DevTreeNode *) mod_lds; off = align16((uint32_t) f.num_tree_nodes * (uint32_t) sizeof(DevTreeNode));
+		DevTreeNode *l_tree = (DevTreeNode *) mod_lds; off = align16((uint32_t) tree_nodes * (uint32_t) sizeof(DevTreeNode));
 		uint32_t *l_map = (uint32_t *) (mod_lds + off); off = align16(off + (uint32_t) spec.num_dist + 4);
 		DevCluster *l_clusters = (DevCluster *) (mod_lds + off); off = align16(off + (uint32_t) spec.num_clusters * (uint32_t) sizeof(DevCluster));
 		uint8_t *l_tab = mod_lds + off; off = align16(off + (spec.use_prefix_code ? 4u : 8u) * spec.table_span);
 		int32_t *l_rows = (int32_t *) (mod_lds + off); off = align16(off + 12u * (uint32_t) rows_width);   // rows_width = widest rectangle + 4 spare entries
 		int32_t *l_wp = (int32_t *) (mod_lds + off);
-		{ const uint4 *src = (const uint4 *) plan.tree; uint4 *dst = (uint4 *) l_tree; for (int32_t i = lane; i < f.num_tree_nodes; i += 64) dst[i] = src[i]; }
+		{ const uint4 *src = (const uint4 *) (plan.tree + msec.tree_off); uint4 *dst = (uint4 *) l_tree; for (int32_t i = lane; i < tree_nodes; i += 64) dst[i] = src[i]; }
 		{ const uint32_t *src = (const uint32_t *) (plan.pool_u8 + spec.cluster_map_off); for (int32_t i = lane; i < (spec.num_dist + 3) / 4; i += 64) l_map[i] = src[i]; }   // 4-byte aligned table (plan_build.cpp)
 		const DevCluster *csrc = plan.clusters + spec.cluster_off;
 		const uint32_t base_off = csrc[0].table_off;

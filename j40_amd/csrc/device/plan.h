@@ -154,6 +154,9 @@ struct DevModSection {
 	int32_t sidx;                       // stream index property (j40.h:7013; 0 for LfGlobal)
 	int32_t first_channel, num_channels;  // channels of the global image this section codes
 	int8_t wp[12];                      // weighted predictor parameters p1, p2, p3[5], w[4] (j40.h:3551)
+	// the MA tree and code spec this section decodes with: the global ones, or its own (use_global_tree = 0, j40.h:3740)
+	uint32_t tree_off;                  // first node in DevModPlan::tree
+	int32_t tree_nodes, spec_idx, uses_wp;
 };
 
 struct DevTransform { int32_t kind, begin_c, rct_type, num_c, nb_colours, nb_deltas, d_pred, pad; };
@@ -175,8 +178,8 @@ struct DevModPlan {
 	const int32_t *pool_i32;
 	const uint64_t *pool_u64;
 	const DevCluster *clusters;
-	const DevCodeSpec *spec;          // the global code spec
-	const DevTreeNode *tree;
+	const DevCodeSpec *spec;          // code specs: [0] the global one, then the sections' own (DevModSection::spec_idx)
+	const DevTreeNode *tree;          // the global tree first, then the sections' own trees (DevModSection::tree_off)
 	const DevModSection *sections;    // [num_sections]
 	int16_t *planes[MOD_MAX_CHANNELS];        // sample planes of the coded channels, tightly packed rows
 	int32_t plane_w[MOD_MAX_CHANNELS], plane_h[MOD_MAX_CHANNELS];

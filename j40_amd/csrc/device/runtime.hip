@@ -162,11 +162,11 @@ static uint32_t upload_modular(j40hip_frame *h, int device) {
 	plan.pool_i32 = st->upload(hp.pool_i32.data(), hp.pool_i32.size(), s, ok);
 	plan.pool_u64 = st->upload(hp.pool_u64.data(), hp.pool_u64.size(), s, ok);
 	plan.clusters = st->upload(hp.clusters.data(), hp.clusters.size(), s, ok);
-	plan.spec = st->upload(&hp.spec, 1, s, ok);
+	plan.spec = st->upload(hp.specs.data(), hp.specs.size(), s, ok);
 	plan.tree = st->upload(hp.tree.data(), hp.tree.size(), s, ok);
 	plan.sections = st->upload(hp.sections.data(), hp.sections.size(), s, ok);
 	st->mod_sections = (int32_t) hp.sections.size();
-	st->mod_info = {(int32_t) hp.tree.size(), hp.spec.num_dist, hp.spec.num_clusters, hp.spec.table_span * (hp.spec.use_prefix_code ? 4u : 8u), hp.frame.max_width, hp.frame.tree_uses_wp};
+	st->mod_info = {hp.max_tree_nodes, hp.max_num_dist, hp.max_clusters, hp.max_table_bytes, hp.frame.max_width, hp.any_wp ? 1 : 0};
 	for (const DevModSection &sec : hp.sections) st->mod_section_offsets.push_back(sec.byte_off);
 	const int32_t nch = hp.frame.num_channels;
 	struct Ref { int16_t *p; int32_t w, h; };

@@ -235,14 +235,30 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 	// what the reference's renderer accepts (j40.h:7917-7936)
 	if (fr.im.bpp < 8 || fr.im.exp_bits || !fr.im.modular_16bit_buffers) return ERR_TODO;
 	if (fr.im.xyb_encoded || fr.fh.do_ycbcr) return ERR_TODO;   // XYB / YCbCr Modular frames: colour transform not covered
-	if (fr.global_tree.empty()) return E4("mtre");
 	DevModFrame &df = hp->frame;
 	memset(&df, 0, sizeof df);
 	df.width = fr.fh.width; df.height = fr.fh.height; df.num_groups = (int32_t) fr.fh.num_groups; df.bpp = fr.im.bpp;
 	df.num_channels = nch;
-	df.tree_uses_wp = tree_uses_wp(fr.global_tree); df.num_tree_nodes = (int32_t) fr.global_tree.size();
-	for (const TreeNode &n : fr.global_tree) hp->tree.push_back(DevTreeNode{n.prop, n.value, n.a, n.b});
-	flatten_code_spec(fr.global_codespec, hp->pool_u8, hp->pool_i32, hp->pool_u64, hp->clusters, &hp->spec);
+	// trees and code specs: the global pair once (when a header refers to it), own pairs per section (use_global_tree = 0)
+	int32_t global_spec = -1; uint32_t global_tree_off = 0;
+	auto attach = [&](const Modular &m, DevModSection *s) {
+		const bool own = !m.use_global_tree;
+		if (!own && global_spec >= 0) { s->tree_off = global_tree_off; s->tree_nodes = (int32_t) fr.global_tree.size(); s->spec_idx = global_spec; }
+		else {
+			const std::vector<TreeNode> &tree = *m.tree;
+			s->tree_off = (uint32_t) hp->tree.size(); s->tree_nodes = (int32_t) tree.size(); s->spec_idx = (int32_t) hp->specs.size();
+			for (const TreeNode &n : tree) hp->tree.push_back(DevTreeNode{n.prop, n.value, n.a, n.b});
+			hp->specs.emplace_back(); hp->host_specs.push_back(*m.codespec);
+			flatten_code_spec(*m.codespec, hp->pool_u8, hp->pool_i32, hp->pool_u64, hp->clusters, &hp->specs.back());
+			if (!own) { global_spec = s->spec_idx; global_tree_off = s->tree_off; }
+		}
+		s->uses_wp = tree_uses_wp(*m.tree);
+		const DevCodeSpec &sp = hp->specs[(size_t) s->spec_idx];
+		hp->max_tree_nodes = std::max(hp->max_tree_nodes, s->tree_nodes);
+		hp->max_num_dist = std::max(hp->max_num_dist, sp.num_dist); hp->max_clusters = std::max(hp->max_clusters, sp.num_clusters);
+		hp->max_table_bytes = std::max(hp->max_table_bytes, sp.table_span * (sp.use_prefix_code ? 4u : 8u));
+		hp->any_lz77 = hp->any_lz77 || sp.lz77_enabled; hp->any_wp = hp->any_wp || s->uses_wp;
+	};
 	hp->pool_u8.resize(hp->pool_u8.size() + 16, 0);
 	hp->transforms = gm.transforms;
 	int32_t max_width = 1;
@@ -258,6 +274,8 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 		s.gx = s.gy = 0; s.gw = fr.fh.width; s.gh = fr.fh.height; s.sidx = 0;
 		s.first_channel = 0; s.num_channels = fr.num_gm_channels;
 		wp_bytes(gm.wp, s.wp);
+		if (!gm.tree || gm.tree->empty() || !gm.codespec) return E4("mtre");
+		attach(gm, &s);
 		hp->sections.push_back(s);
 		for (int32_t c = 0; c < fr.num_gm_channels; ++c) max_width = std::max(max_width, hp->plane_meta[(size_t) c] ? hp->plane_w[(size_t) c] : fr.fh.width);
 	} else return ERR_TODO;
@@ -273,7 +291,7 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 			for (int32_t c = fr.num_gm_channels; c < nch; ++c) { Plane p; p.width = gi.gw; p.height = gi.gh; m.channel.push_back(p); }
 			BitReader br(cs + ps.offset, ps.size);
 			try { read_modular_header(br, &fr.global_tree, &fr.global_codespec, &m); } catch (const DecodeError &e) { return e.code; }
-			if (!m.use_global_tree || !m.transforms.empty()) return ERR_TODO;   // local trees / local transforms stay on the to-do list
+			if (!m.transforms.empty()) return ERR_TODO;   // transforms local to a group stay on the to-do list
 			DevModSection s;
 			memset(&s, 0, sizeof s);
 			s.byte_off = (uint32_t) ps.offset; s.size = (uint32_t) ps.size; s.bit_off = (uint32_t) br.bit_position();
@@ -281,6 +299,7 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 			s.sidx = (int32_t) (1 + 3 * fr.fh.num_lf_groups + 17 + g);
 			s.first_channel = fr.num_gm_channels; s.num_channels = nch - fr.num_gm_channels;
 			wp_bytes(m.wp, s.wp);
+			attach(m, &s);
 			hp->sections.push_back(s);
 			max_width = std::max(max_width, gi.gw);
 		}
@@ -296,7 +315,8 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 		break;
 	}
 	hp->lz_window_size = 0;
-	if (hp->spec.lz77_enabled) {
+	df.tree_uses_wp = hp->any_wp; df.num_tree_nodes = hp->max_tree_nodes;
+	if (hp->any_lz77) {
 		// integers decoded by one section: at most all samples of its rectangle in every channel
 		size_t most = 0;
 		for (const DevModSection &s : hp->sections) most = std::max(most, (size_t) s.num_channels * (size_t) s.gw * (size_t) s.gh);

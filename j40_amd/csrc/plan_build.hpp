@@ -52,8 +52,11 @@ struct HostModPlan {
 	std::vector<int32_t> pool_i32;
 	std::vector<uint64_t> pool_u64;
 	std::vector<DevCluster> clusters;
-	DevCodeSpec spec;
-	std::vector<DevTreeNode> tree;
+	std::vector<DevCodeSpec> specs;                       // [0] global, then per-section own specs
+	std::vector<DevTreeNode> tree;                        // global tree, then the sections' own trees
+	std::vector<CodeSpec> host_specs;                     // the parsed form of `specs`, same order (for the oracle's view)
+	int32_t max_tree_nodes = 0, max_num_dist = 0, max_clusters = 0; uint32_t max_table_bytes = 0;   // over the specs / trees, for the kernel's LDS layout
+	bool any_lz77 = false, any_wp = false;
 	std::vector<DevModSection> sections;
 	std::vector<int32_t> plane_w, plane_h, plane_meta;   // coded channels
 	std::vector<Transform> transforms;                    // global transforms in coded order
@@ -62,7 +65,7 @@ struct HostModPlan {
 };
 
 // parses every pass-group section's Modular header on the host (a few bits each) and lays out the
-// device plan; returns 0 or a 4-char code ("TODO": local trees / local transforms / layouts the
+// device plan; returns 0 or a 4-char code ("TODO": local transforms / layouts the
 // reference itself refuses)
 uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostModPlan *out);
 

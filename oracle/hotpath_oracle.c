@@ -606,11 +606,14 @@ static void set_wp(owp *wp, const int8_t *params) { int i; wp->p1 = params[0]; w
 
 /* one section: the listed channels of the global image, restricted to the section's rectangle
  * (whole plane for meta channels) -- j40__modular_channel16, j40.h:4127 */
-static uint32_t modular_section(const j40hip_modular_view *v, const j40hip_modular_section_view *sec, oplane *planes, ocode *code, int uses_wp) {
+static uint32_t modular_section(const j40hip_modular_view *v, const j40hip_modular_section_view *sec, oplane *planes, ocode *code) {
+	const j40hip_tree_node *tree = v->tree + sec->tree_off;   /* the global tree or the section's own (j40.h:3740-3746) */
+	int32_t uses_wp = 0, ti;
 	obits b;
 	owp wp;
 	uint32_t err = 0;
 	int32_t cidx, dist_mult = 0, k;
+	for (ti = 0; ti < sec->tree_nodes; ++ti) if (tree[ti].prop == 15 || tree[ti].prop == -1 - 6) uses_wp = 1;
 	obits_init(&b, v->codestream, sec->byte_off, sec->size, sec->bit_off);
 	ocode_restart(code);
 	for (cidx = 0; cidx < sec->num_channels; ++cidx) if (!planes[sec->first_channel + cidx].meta) dist_mult = imax32(dist_mult, sec->gw);
@@ -627,7 +630,7 @@ static uint32_t modular_section(const j40hip_modular_view *v, const j40hip_modul
 		for (y = 0; y < gh && !b.err && !err; ++y) {
 			int16_t *row = pl->px + (size_t) (gy + y) * (size_t) pl->w + (size_t) gx;
 			for (x = 0; x < gw; ++x) {
-				const j40hip_tree_node *n = v->tree;
+				const j40hip_tree_node *n = tree;
 				oneigh p = neighbours(row, pl->w, gw, x, y);
 				int32_t val;
 				wp_before(&wp, x, y, &p);
@@ -694,18 +697,19 @@ static const int16_t PALETTE_DELTAS[72][3] = {  /* spec table; entry 2k = triple
 ORACLE_API uint32_t oracle_decode_modular(const j40hip_modular_view *v, uint8_t *rgba) {
 	static const uint8_t PERM[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
 	oplane planes[64];
-	int32_t nplanes = v->num_channels, c, s, t, i, uses_wp = 0;
-	ocode code;
+	int32_t nplanes = v->num_channels, c, s, t, i;
+	ocode *codes;
 	uint32_t err = 0;
 	size_t k, npx = (size_t) v->width * (size_t) v->height;
 	for (c = 0; c < nplanes; ++c) {
 		planes[c].w = v->channel_w[c]; planes[c].h = v->channel_h[c]; planes[c].meta = v->channel_meta[c];
 		planes[c].px = (int16_t *) calloc((size_t) imax32(planes[c].w, 0) * (size_t) imax32(planes[c].h, 0) + 1, sizeof(int16_t));
 	}
-	for (i = 0; i < v->num_tree_nodes; ++i) if (v->tree[i].prop == 15 || v->tree[i].prop == -1 - 6) uses_wp = 1;
-	ocode_init(&code, v->codespec);
-	for (s = 0; s < v->num_sections && !err; ++s) err = modular_section(v, &v->sections[s], planes, &code, uses_wp);
-	ocode_free(&code);
+	codes = (ocode *) calloc((size_t) v->num_codespecs, sizeof(ocode));
+	for (i = 0; i < v->num_codespecs; ++i) ocode_init(&codes[i], &v->codespec[i]);
+	for (s = 0; s < v->num_sections && !err; ++s) err = modular_section(v, &v->sections[s], planes, &codes[v->sections[s].spec_idx]);
+	for (i = 0; i < v->num_codespecs; ++i) ocode_free(&codes[i]);
+	free(codes);
 	for (t = v->num_transforms - 1; t >= 0 && !err; --t) {
 		const j40hip_transform_view *tr = &v->transforms[t];
 		if (tr->kind == 0) {  /* inverse RCT, j40.h:4318 */

@@ -79,7 +79,7 @@ static uint32_t hostsim_decode_modular(const Frame &fr, const uint8_t *cs, size_
 	DevModPlan plan;
 	memset(&plan, 0, sizeof plan);
 	plan.frame = &hp.frame; plan.codestream = hp.codestream.data(); plan.pool_u8 = hp.pool_u8.data(); plan.pool_i32 = hp.pool_i32.data(); plan.pool_u64 = hp.pool_u64.data();
-	plan.clusters = hp.clusters.data(); plan.spec = &hp.spec; plan.tree = hp.tree.data(); plan.sections = hp.sections.data();
+	plan.clusters = hp.clusters.data(); plan.spec = hp.specs.data(); plan.tree = hp.tree.data(); plan.sections = hp.sections.data();
 	struct Ref { int16_t *p; int32_t w, h; };
 	std::vector<Ref> planes;
 	for (int32_t c = 0; c < nch; ++c) {
@@ -91,10 +91,12 @@ static uint32_t hostsim_decode_modular(const Frame &fr, const uint8_t *cs, size_
 	std::vector<uint32_t> status(hp.sections.size() + 1, 0);
 	plan.wp_scratch = hp.frame.tree_uses_wp ? wps.data() : nullptr;
 	plan.lz_window = window.empty() ? nullptr : window.data(); plan.lz_window_size = hp.lz_window_size; plan.status = status.data();
-	ModTables mt = mod_tables_in_hbm(plan);
 	std::vector<int32_t> ring(3 * ((size_t) hp.frame.max_width + 4) + 8, 0x7fff0000), wperr(10 * (size_t) hp.frame.max_width + 8);
-	mt.rows = ring.data(); mt.rows_width = hp.frame.max_width + 4; mt.wp_errors = wperr.data(); mt.wp_errors_width = hp.frame.max_width;   // as the kernel lays them out in LDS
-	for (int32_t sct = 0; sct < hp.frame.num_sections; ++sct) status[(size_t) sct] = (sct & 1) ? decode_modular_section<false, true>(plan, mt, sct) : decode_modular_section<false, false>(plan, mt, sct);   // both neighbour sources
+	for (int32_t sct = 0; sct < hp.frame.num_sections; ++sct) {
+		ModTables mt = mod_tables_in_hbm(plan, sct);
+		mt.rows = ring.data(); mt.rows_width = hp.frame.max_width + 4; mt.wp_errors = wperr.data(); mt.wp_errors_width = hp.frame.max_width;   // as the kernel lays them out in LDS
+		status[(size_t) sct] = (sct & 1) ? decode_modular_section<false, true>(plan, mt, sct) : decode_modular_section<false, false>(plan, mt, sct);   // both neighbour sources
+	}
 	for (uint32_t e : status) if (e) return e;
 	static const uint8_t PERM[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
 	std::vector<std::vector<int16_t>> extra;

@@ -63,4 +63,7 @@ MODULAR_CASES = [
     ("palette_prediction_wp_tree", 160, 120, dict(palette=3, tree=2)),
     ("container", 300, 200, dict(container=1, tree=1)),
     ("icc_profile", 256, 256, dict(icc=500, alpha=1)),
+    ("local_tree_copy", 600, 300, dict(localtree=1, tree=1)),               # every other group: use_global_tree = 0, own code spec
+    ("local_tree_wp_prefix_lz77_alpha", 600, 300, dict(localtree=2, prefix=1, lz77=1, alpha=1)),  # local tree needs WP, global does not
+    ("local_tree_under_wp_global", 520, 520, dict(localtree=2, tree=2, groupshift=7)),
 ]

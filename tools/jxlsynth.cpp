@@ -734,27 +734,48 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	CodeSpecW treespec; treespec.init(6, std::vector<uint8_t>(6, 0), 1); treespec.log_alpha = 6; treespec.cfg[0] = HybridCfg{4, 1, 0};
 	StreamEncoder tree_enc(treespec); tree_tokens(tree, tree_enc); count_stream(treespec, tree_enc);
 
-	CodeSpecW gspec;
-	{
-		const int nctx = tree.num_ctx;
+	auto make_spec = [&](const MATree &t) {
+		CodeSpecW sp;
+		const int nctx = t.num_ctx;
 		std::vector<uint8_t> map((size_t) (nctx + (lz77 ? 1 : 0)));
 		const int ncl = std::min(nctx, 3);
 		for (int i = 0; i < nctx; ++i) map[(size_t) i] = (uint8_t) (i % ncl);
 		int nclusters = ncl;
 		if (lz77) { map[(size_t) nctx] = (uint8_t) ncl; nclusters = ncl + 1; }   // the distance context gets its own cluster
-		gspec.lz77 = lz77 != 0;
-		gspec.init(nctx, map, nclusters);
-		gspec.lz_min_symbol = 224; gspec.lz_min_length = 3; gspec.lz_len_cfg = HybridCfg{0, 0, 0};
-		gspec.use_prefix = use_prefix != 0; gspec.log_alpha = 8;
-		for (auto &c : gspec.cfg) c = use_prefix ? HybridCfg{4, 2, 0} : HybridCfg{4, 1, 1};
+		sp.lz77 = lz77 != 0;
+		sp.init(nctx, map, nclusters);
+		sp.lz_min_symbol = 224; sp.lz_min_length = 3; sp.lz_len_cfg = HybridCfg{0, 0, 0};
+		sp.use_prefix = use_prefix != 0; sp.log_alpha = 8;
+		for (auto &c : sp.cfg) c = use_prefix ? HybridCfg{4, 2, 0} : HybridCfg{4, 1, 1};
+		return sp;
+	};
+	CodeSpecW gspec = make_spec(tree);
+	// localtree=1: every other group section repeats the global MA tree with its own code spec
+	// (use_global_tree = 0, j40.h:3740); localtree=2: those sections use a different tree, one that
+	// needs the weighted predictor whatever the global tree does
+	const int local_tree = opt.geti("localtree", 0);
+	MATree ltree = tree;
+	if (local_tree == 2) {
+		ltree = MATree();
+		int l0 = ltree.leaf(6), l1 = ltree.leaf(5), l2 = ltree.leaf(4), l3 = ltree.leaf(1, 2, 0, 0);
+		int a = ltree.branch(15, 8, l0, l1);      // max weighted-predictor error
+		int b = ltree.branch(3, 100, l2, l3);     // x
+		ltree.finalise(ltree.branch(2, 17, a, b)); // y
 	}
+	StreamEncoder ltree_enc(treespec);
+	if (local_tree) { tree_tokens(ltree, ltree_enc); count_stream(treespec, ltree_enc); }
+	const StreamEncoder ltree_saved = ltree_enc;   // flush() consumes the items
+	const CodeSpecW lspec_proto = make_spec(ltree);
 	WPParams wpp;
+	const CodeSpecW &gspec_ref = gspec;
 
 	// encodes the listed channels (sub-rectangles already cut out) into one stream; LZ77 replaces runs
 	// of equal tokens ("previous symbol" = distance code 1 with a non-zero dist_mult, j40.h:2834)
-	auto encode_image = [&](std::vector<Channel> &chs, int first, int64_t sidx, StreamEncoder &enc) {
+	auto encode_image = [&](std::vector<Channel> &chs, int first, int64_t sidx, StreamEncoder &enc, bool local = false) {
+		const MATree &use_tree = local ? ltree : tree;
+		const CodeSpecW &gspec = local ? lspec_proto : gspec_ref;   // same cluster layout rules, the section's own contexts
 		StreamEncoder raw(gspec);
-		for (int c = first; c < (int) chs.size(); ++c) encode_channel(tree, chs, c, sidx, wpp, raw);
+		for (int c = first; c < (int) chs.size(); ++c) encode_channel(use_tree, chs, c, sidx, wpp, raw);
 		if (!lz77) { enc.items = raw.items; return; }
 		// run-length pass over the residual tokens: a run of >= 3 identical (cluster, token, extra) items
 		// after its first occurrence becomes one copy with distance 1
@@ -794,12 +815,17 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 				for (int y = 0; y < gh; ++y) for (int x = 0; x < gw; ++x) s2.at(x, y) = ch[(size_t) c].at(gx + x, gy + y);
 				sub.push_back(s2);
 			}
+			const bool local = local_tree && (((size_t) g + 1) & 1);
 			encs.emplace_back(gspec);
 			// stream index of a pass group (j40.h:7013): 1 + 3 * num_lf_groups + 17 + pass * num_groups + gidx
-			encode_image(sub, 0, 1 + 3 * num_lf_groups + 17 + g, encs.back());
+			encode_image(sub, 0, 1 + 3 * num_lf_groups + 17 + g, encs.back(), local);
 		}
 	}
-	for (auto &e : encs) count_stream(gspec, e);
+	std::vector<CodeSpecW> lspec(encs.size(), lspec_proto);
+	for (size_t i = 0; i < encs.size(); ++i) {
+		if (local_tree && !single && i >= 1 && (i & 1)) { encs[i].spec = &lspec[i]; count_stream(lspec[i], encs[i]); }
+		else count_stream(gspec, encs[i]);
+	}
 
 	// ---- sections ----
 	std::vector<std::vector<uint8_t>> sections;
@@ -819,7 +845,12 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 		sections.push_back({});       // HfGlobal must be empty for Modular frames (j40.h:7825)
 		for (int g = 0; g < num_groups; ++g) {
 			BitWriter bw;
-			write_modular_header(bw, true, nullptr, {});
+			if (local_tree && (((size_t) g + 1) & 1)) {
+				write_modular_header(bw, false, nullptr, {});
+				StreamEncoder te = ltree_saved;
+				write_code_spec(bw, treespec); te.flush(bw);
+				write_code_spec(bw, lspec[(size_t) g + 1]);
+			} else write_modular_header(bw, true, nullptr, {});
 			encs[(size_t) g + 1].flush(bw);
 			bw.pad();
 			sections.push_back(bw.bytes);
