@@ -109,6 +109,9 @@ typedef struct {
 	/* the section's MA tree = tree[tree_off .. tree_off + tree_nodes) and its code spec = codespec[spec_idx]:
 	 * the global pair, or the section's own when its header says use_global_tree = 0 (j40.h:3740-3746) */
 	uint32_t tree_off; int32_t tree_nodes, spec_idx;
+	/* RCTs of the section's own header (j40.h:3757), undone over its rectangle before the global transforms
+	 * (j40.h:7030): pairs {begin_c relative to first_channel, rct_type} at local_rct + 2 * local_off */
+	int32_t local_off, local_count;
 } j40hip_modular_section_view;
 
 typedef struct {
@@ -120,6 +123,7 @@ typedef struct {
 	const int32_t *channel_w, *channel_h, *channel_meta;   /* coded channels */
 	const j40hip_transform_view *transforms;
 	const j40hip_modular_section_view *sections;
+	const int32_t *local_rct;
 	int8_t global_wp[12];
 } j40hip_modular_view;
 

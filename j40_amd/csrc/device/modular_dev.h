@@ -282,6 +282,29 @@ J40_DEV void inverse_rct_pixel(int32_t type7, int16_t &a, int16_t &bb, int16_t &
 	} }
 }
 
+// K4a': the RCTs a pass-group section lists in its own header, undone last to first over the section's
+// rectangle (j40__inverse_transform on the group's sub-image, j40.h:7030, before it is pasted, j40.h:3688).
+// The reference renames the three planes by the permutation type / 7; here the samples move.
+J40_DEV void section_inverse_rcts(const DevModPlan &plan, int32_t s, int32_t lane, int32_t nlanes) {
+	const DevModSection sec = plan.sections[s];
+	if (sec.local_count <= 0) return;
+	for (int32_t i = lane; i < sec.gw * sec.gh; i += nlanes) {
+		const int32_t y = i / sec.gw, x = i - y * sec.gw;
+		for (int32_t k = sec.local_count; k-- > 0; ) {
+			const int32_t begin = sec.first_channel + plan.local_rct[2 * (sec.local_off + k)], type = plan.local_rct[2 * (sec.local_off + k) + 1];
+			const size_t at = (size_t) (sec.gy + y) * (size_t) plan.plane_w[begin] + (size_t) (sec.gx + x);
+			int16_t p[3] = {plan.planes[begin][at], plan.planes[begin + 1][at], plan.planes[begin + 2][at]};
+			inverse_rct_pixel(type % 7, p[0], p[1], p[2]);
+			const int32_t perm = type / 7;
+			// output channel PERM[perm][j] takes transformed channel j (j40.h:4395-4398)
+			const int32_t d0 = perm == 0 || perm == 3 ? 0 : perm == 1 || perm == 4 ? 1 : 2;
+			const int32_t d1 = perm == 0 || perm == 5 ? 1 : perm == 1 || perm == 3 ? 2 : 0;
+			const int32_t d2 = 3 - d0 - d1;
+			plan.planes[begin + d0][at] = p[0]; plan.planes[begin + d1][at] = p[1]; plan.planes[begin + d2][at] = p[2];
+		}
+	}
+}
+
 // the spec's 72 palette delta triples; entry 2k is triple k, entry 2k + 1 its negation (j40.h:4275)
 #ifdef __HIPCC__
 __device__

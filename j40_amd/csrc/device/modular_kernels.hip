@@ -56,6 +56,11 @@ __global__ void __launch_bounds__(64) k_modular_sections(DevModPlan plan, int32_
 	if (lane == 0) plan.status[s] = err;
 }
 
+// one workgroup per section that lists transforms of its own; runs after K3 (kernel boundary = the planes are visible)
+__global__ void __launch_bounds__(256) k_section_inverse_rcts(DevModPlan plan) {
+	section_inverse_rcts(plan, (int32_t) blockIdx.x, (int32_t) threadIdx.x, 256);
+}
+
 __global__ void __launch_bounds__(256) k_inverse_rct(int16_t *a, int16_t *b, int16_t *c, size_t n, int32_t type7) {
 	for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
 		int16_t p0 = a[i], p1 = b[i], p2 = c[i];
@@ -129,6 +134,9 @@ void launch_modular_sections(const DevModPlan &plan, int32_t num_sections, const
 	} else {
 		hipLaunchKernelGGL(k_modular_sections<false>, dim3((unsigned) num_sections), dim3(64), 0, stream, plan, 0, 0);
 	}
+}
+void launch_section_inverse_rcts(const DevModPlan &plan, int32_t num_sections, hipStream_t stream) {
+	if (num_sections > 0) hipLaunchKernelGGL(k_section_inverse_rcts, dim3((unsigned) num_sections), dim3(256), 0, stream, plan);
 }
 void launch_inverse_rct(int16_t *a, int16_t *b, int16_t *c, size_t n, int32_t type7, hipStream_t stream) {
 	if (n) hipLaunchKernelGGL(k_inverse_rct, dim3(grid_for(n)), dim3(256), 0, stream, a, b, c, n, type7);

@@ -157,6 +157,9 @@ struct DevModSection {
 	// the MA tree and code spec this section decodes with: the global ones, or its own (use_global_tree = 0, j40.h:3740)
 	uint32_t tree_off;                  // first node in DevModPlan::tree
 	int32_t tree_nodes, spec_idx, uses_wp;
+	// reversible colour transforms listed in the section's own header (j40.h:3757), undone over the section's
+	// rectangle after its channels are decoded (j40.h:7030): pairs {begin_c, rct_type} at DevModPlan::local_rct + 2 * local_off
+	int32_t local_off, local_count;
 };
 
 struct DevTransform { int32_t kind, begin_c, rct_type, num_c, nb_colours, nb_deltas, d_pred, pad; };
@@ -181,6 +184,7 @@ struct DevModPlan {
 	const DevCodeSpec *spec;          // code specs: [0] the global one, then the sections' own (DevModSection::spec_idx)
 	const DevTreeNode *tree;          // the global tree first, then the sections' own trees (DevModSection::tree_off)
 	const DevModSection *sections;    // [num_sections]
+	const int32_t *local_rct;         // {begin_c (section-relative), rct_type} pairs of the sections' own transforms
 	int16_t *planes[MOD_MAX_CHANNELS];        // sample planes of the coded channels, tightly packed rows
 	int32_t plane_w[MOD_MAX_CHANNELS], plane_h[MOD_MAX_CHANNELS];
 	int32_t plane_meta[MOD_MAX_CHANNELS];     // 1: meta channel (palette), decoded whole and never a "previous channel" of image channels

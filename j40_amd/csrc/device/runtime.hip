@@ -100,6 +100,7 @@ struct j40hip_device_state {
 	// Modular frames
 	DevModPlan mod;
 	int32_t mod_sections = 0;
+	bool mod_local_rcts = false;
 	ModLaunchInfo mod_info = {0, 0, 0, 0, 0, 0};
 	std::vector<uint32_t> mod_section_offsets;
 	struct ModOp { int kind; int16_t *a, *b, *c; const int16_t *src, *aux; size_t n; int32_t p0, p1, p2, p3, p4, p5; int16_t *const *dst_list; const int8_t *wpp; };
@@ -165,6 +166,8 @@ static uint32_t upload_modular(j40hip_frame *h, int device) {
 	plan.spec = st->upload(hp.specs.data(), hp.specs.size(), s, ok);
 	plan.tree = st->upload(hp.tree.data(), hp.tree.size(), s, ok);
 	plan.sections = st->upload(hp.sections.data(), hp.sections.size(), s, ok);
+	st->mod_local_rcts = !hp.local_rct.empty();
+	if (st->mod_local_rcts) plan.local_rct = st->upload(hp.local_rct.data(), hp.local_rct.size(), s, ok);
 	st->mod_sections = (int32_t) hp.sections.size();
 	st->mod_info = {hp.max_tree_nodes, hp.max_num_dist, hp.max_clusters, hp.max_table_bytes, hp.frame.max_width, hp.any_wp ? 1 : 0};
 	for (const DevModSection &sec : hp.sections) st->mod_section_offsets.push_back(sec.byte_off);
@@ -246,6 +249,7 @@ static uint32_t decode_modular(j40hip_frame *h, void *rgba_dev, size_t stride_by
 	if (hipMemsetAsync(plan.status, 0, sizeof(uint32_t) * ((size_t) st->total_sections + 1), s) != hipSuccess) return ERR_GPU;
 	if (ms3) (void) hipEventRecord(st->ev[1], s);
 	launch_modular_sections(plan, st->mod_sections, st->mod_info, s);
+	if (st->mod_local_rcts) launch_section_inverse_rcts(plan, st->mod_sections, s);
 	if (ms3) (void) hipEventRecord(st->ev[2], s);
 	for (const auto &op : st->mod_ops) {
 		if (op.kind == 0) launch_inverse_rct(op.a, op.b, op.c, op.n, op.p0, s);

@@ -234,7 +234,8 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 	if (nch > MOD_MAX_CHANNELS) return ERR_TODO;
 	// what the reference's renderer accepts (j40.h:7917-7936)
 	if (fr.im.bpp < 8 || fr.im.exp_bits || !fr.im.modular_16bit_buffers) return ERR_TODO;
-	if (fr.im.xyb_encoded || fr.fh.do_ycbcr) return ERR_TODO;   // XYB / YCbCr Modular frames: colour transform not covered
+	// a Modular frame flagged XYB or YCbCr gets no colour transform in the reference (j40.h:8209-8210 runs only the
+	// Modular inverse transforms, j40.h:7910 renders the first three channels as they are): same here
 	DevModFrame &df = hp->frame;
 	memset(&df, 0, sizeof df);
 	df.width = fr.fh.width; df.height = fr.fh.height; df.num_groups = (int32_t) fr.fh.num_groups; df.bpp = fr.im.bpp;
@@ -291,9 +292,15 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 			for (int32_t c = fr.num_gm_channels; c < nch; ++c) { Plane p; p.width = gi.gw; p.height = gi.gh; m.channel.push_back(p); }
 			BitReader br(cs + ps.offset, ps.size);
 			try { read_modular_header(br, &fr.global_tree, &fr.global_codespec, &m); } catch (const DecodeError &e) { return e.code; }
-			if (!m.transforms.empty()) return ERR_TODO;   // transforms local to a group stay on the to-do list
 			DevModSection s;
 			memset(&s, 0, sizeof s);
+			// the group's own transforms: RCTs are undone over its rectangle; a palette of its own stays on the to-do list
+			s.local_off = (int32_t) (hp->local_rct.size() / 2);
+			for (const Transform &t : m.transforms) {
+				if (t.kind != Transform::RCT || t.begin_c < 0 || t.begin_c + 3 > nch - fr.num_gm_channels) return ERR_TODO;
+				hp->local_rct.push_back(t.begin_c); hp->local_rct.push_back(t.rct_type);
+				++s.local_count;
+			}
 			s.byte_off = (uint32_t) ps.offset; s.size = (uint32_t) ps.size; s.bit_off = (uint32_t) br.bit_position();
 			s.gx = gg.left + gi.gx_in_gg; s.gy = gg.top + gi.gy_in_gg; s.gw = gi.gw; s.gh = gi.gh;
 			s.sidx = (int32_t) (1 + 3 * fr.fh.num_lf_groups + 17 + g);

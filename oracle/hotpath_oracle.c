@@ -693,6 +693,20 @@ static const int16_t PALETTE_DELTAS[72][3] = {  /* spec table; entry 2k = triple
 	{96, 0, 0}, {128, 128, 128}, {64, 0, 64}, {144, 144, 144}, {96, 96, 0}, {-36, -36, 36}, {45, -24, -45}, {45, -45, -24}, {0, 0, -96}, {0, 128, 128}, {0, 96, 0}, {45, 24, -45},
 	{-128, 0, 0}, {24, -45, 24}, {-45, 24, -45}, {64, 0, -64}, {64, -64, -64}, {96, 0, 96}, {45, -45, 24}, {24, 45, -45}, {64, 64, -64}, {128, 128, 0}, {0, 0, -128}, {-24, 45, -45}};
 
+/* one pixel of the inverse RCT, types 0..6 (j40.h:4341-4393); int16 results wrap like the reference's */
+static void rct_pixel(int32_t type7, int16_t *q0, int16_t *q1, int16_t *q2) {
+	int16_t a = *q0, b = *q1, d = *q2;
+	switch (type7) {
+	case 0: break;
+	case 1: *q2 = (int16_t) (d + a); break;
+	case 2: *q2 = (int16_t) (b + a); break;
+	case 3: *q1 = (int16_t) (b + a); *q2 = (int16_t) (d + a); break;
+	case 4: *q1 = (int16_t) (b + (int16_t) (a / 2 + d / 2 + (a & d & 1))); break;
+	case 5: *q1 = (int16_t) ((int32_t) b + a + (d >> 1)); *q2 = (int16_t) (d + a); break;
+	default: { int32_t tmp = (int32_t) a - ((int32_t) d >> 1), r1 = (int32_t) d + tmp, r2 = tmp - ((int32_t) b >> 1); *q0 = (int16_t) (r2 + b); *q1 = (int16_t) r1; *q2 = (int16_t) r2; }
+	}
+}
+
 /* Decodes a Modular frame described by `v` into tightly packed RGBA; returns 0 or the first error */
 ORACLE_API uint32_t oracle_decode_modular(const j40hip_modular_view *v, uint8_t *rgba) {
 	static const uint8_t PERM[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
@@ -710,6 +724,21 @@ ORACLE_API uint32_t oracle_decode_modular(const j40hip_modular_view *v, uint8_t 
 	for (s = 0; s < v->num_sections && !err; ++s) err = modular_section(v, &v->sections[s], planes, &codes[v->sections[s].spec_idx]);
 	for (i = 0; i < v->num_codespecs; ++i) ocode_free(&codes[i]);
 	free(codes);
+	/* transforms of a group's own header act on the group's sub-image before it is pasted (j40.h:7030-7032):
+	 * same thing as undoing them over the group's rectangle of the frame planes, last to first */
+	for (s = 0; s < v->num_sections && !err; ++s) {
+		const j40hip_modular_section_view *sec = &v->sections[s];
+		for (t = sec->local_count - 1; t >= 0; --t) {
+			int32_t begin = sec->first_channel + v->local_rct[2 * (sec->local_off + t)], type = v->local_rct[2 * (sec->local_off + t) + 1], x, y;
+			for (y = 0; y < sec->gh; ++y) for (x = 0; x < sec->gw; ++x) {
+				size_t at = (size_t) (sec->gy + y) * (size_t) planes[begin].w + (size_t) (sec->gx + x);
+				int16_t q[3];
+				for (i = 0; i < 3; ++i) q[i] = planes[begin + i].px[at];
+				rct_pixel(type % 7, &q[0], &q[1], &q[2]);
+				for (i = 0; i < 3; ++i) planes[begin + PERM[type / 7][i]].px[at] = q[i];
+			}
+		}
+	}
 	for (t = v->num_transforms - 1; t >= 0 && !err; --t) {
 		const j40hip_transform_view *tr = &v->transforms[t];
 		if (tr->kind == 0) {  /* inverse RCT, j40.h:4318 */
@@ -718,18 +747,7 @@ ORACLE_API uint32_t oracle_decode_modular(const j40hip_modular_view *v, uint8_t 
 			size_t n;
 			for (i = 0; i < 3; ++i) ch[i] = planes[tr->begin_c + i];
 			p0 = ch[0].px; p1 = ch[1].px; p2 = ch[2].px; n = (size_t) ch[0].w * (size_t) ch[0].h;
-			for (k = 0; k < n; ++k) {
-				int16_t a = p0[k], b = p1[k], d = p2[k];
-				switch (tr->rct_type % 7) {
-				case 0: break;
-				case 1: p2[k] = (int16_t) (d + a); break;
-				case 2: p2[k] = (int16_t) (b + a); break;
-				case 3: p1[k] = (int16_t) (b + a); p2[k] = (int16_t) (d + a); break;
-				case 4: p1[k] = (int16_t) (b + (int16_t) (a / 2 + d / 2 + (a & d & 1))); break;
-				case 5: p1[k] = (int16_t) ((int32_t) b + a + (d >> 1)); p2[k] = (int16_t) (d + a); break;
-				default: { int32_t tmp = (int32_t) a - ((int32_t) d >> 1), q1 = (int32_t) d + tmp, q2 = tmp - ((int32_t) b >> 1); p0[k] = (int16_t) (q2 + b); p1[k] = (int16_t) q1; p2[k] = (int16_t) q2; }
-				}
-			}
+			for (k = 0; k < n; ++k) rct_pixel(tr->rct_type % 7, &p0[k], &p1[k], &p2[k]);
 			for (i = 0; i < 3; ++i) planes[tr->begin_c + PERM[tr->rct_type / 7][i]] = ch[i];
 		} else if (tr->kind == 1) {  /* inverse palette, j40.h:4402 */
 			int32_t first = tr->begin_c + 1, last = tr->begin_c + tr->num_c, width = planes[first].w, height = planes[first].h, x, y, j;

@@ -27,7 +27,7 @@ def main():
     cases = [("vardct_" + name, "vardct", 264, 200, 11 + i, opts) for i, (name, opts) in enumerate(VARDCT_CASES)]
     cases.append(("vardct_all_transforms", "vardct", 776, 520, 9, dict(maxlog=8, bctx=1, presets=2, orders=1)))
     for i, (name, w, h, opts) in enumerate(MODULAR_CASES):
-        if w * h <= 100 * 1000 or name in ("multi_group", "local_tree_wp_prefix_lz77_alpha"):
+        if w * h <= 100 * 1000 or name in ("multi_group", "local_tree_wp_prefix_lz77_alpha", "local_rct_per_group"):
             cases.append(("modular_" + name, "modular", min(w, 300), min(h, 200) if name != "fjxl_like_rgba" else h, 51 + i, opts))
     for name, mode, w, h, seed, opts in cases:
         data = synth(mode, w, h, seed, **opts)

@@ -98,6 +98,8 @@ static uint32_t hostsim_decode_modular(const Frame &fr, const uint8_t *cs, size_
 		status[(size_t) sct] = (sct & 1) ? decode_modular_section<false, true>(plan, mt, sct) : decode_modular_section<false, false>(plan, mt, sct);   // both neighbour sources
 	}
 	for (uint32_t e : status) if (e) return e;
+	plan.local_rct = hp.local_rct.data();
+	for (int32_t sct = 0; sct < hp.frame.num_sections; ++sct) for (int32_t lane = 0; lane < 3; ++lane) section_inverse_rcts(plan, sct, lane, 3);
 	static const uint8_t PERM[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
 	std::vector<std::vector<int16_t>> extra;
 	extra.reserve(64);

@@ -799,6 +799,8 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	};
 
 	std::vector<StreamEncoder> encs;
+	std::vector<std::vector<TransformW>> group_tr;
+	const int local_rct = opt.geti("localrct", -1);
 	std::vector<uint8_t> section_is_group;
 	if (single) {
 		encs.emplace_back(gspec);
@@ -816,6 +818,17 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 				sub.push_back(s2);
 			}
 			const bool local = local_tree && (((size_t) g + 1) & 1);
+			// localrct=K: the group's header lists one or two RCTs of its own (j40.h:3757-3773), type varying by group
+			group_tr.emplace_back();
+			if (local_rct >= 0 && sub.size() >= 3) {
+				const int t1 = (local_rct + 5 * g) % 42, t2 = (3 * t1 + 1) % 42;
+				TransformW a; a.kind = 0; a.begin_c = 0; a.rct_type = t1; group_tr.back().push_back(a);
+				if (t1 / 7 == 0 && t1 % 7 != 2) forward_rct(sub, 0, t1);
+				if (g % 3 == 2) {
+					TransformW b; b.kind = 0; b.begin_c = (int) sub.size() - 3; b.rct_type = t2; group_tr.back().push_back(b);
+					if (t2 / 7 == 0 && t2 % 7 != 2) forward_rct(sub, b.begin_c, t2);
+				}
+			}
 			encs.emplace_back(gspec);
 			// stream index of a pass group (j40.h:7013): 1 + 3 * num_lf_groups + 17 + pass * num_groups + gidx
 			encode_image(sub, 0, 1 + 3 * num_lf_groups + 17 + g, encs.back(), local);
@@ -846,11 +859,11 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 		for (int g = 0; g < num_groups; ++g) {
 			BitWriter bw;
 			if (local_tree && (((size_t) g + 1) & 1)) {
-				write_modular_header(bw, false, nullptr, {});
+				write_modular_header(bw, false, nullptr, group_tr[(size_t) g]);
 				StreamEncoder te = ltree_saved;
 				write_code_spec(bw, treespec); te.flush(bw);
 				write_code_spec(bw, lspec[(size_t) g + 1]);
-			} else write_modular_header(bw, true, nullptr, {});
+			} else write_modular_header(bw, true, nullptr, group_tr[(size_t) g]);
 			encs[(size_t) g + 1].flush(bw);
 			bw.pad();
 			sections.push_back(bw.bytes);
@@ -867,7 +880,10 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	(void) bpp;
 	cs.put(1, 1);                       // modular_16bit_buffers
 	if (alpha) { cs.put(1, 2); cs.put(1, 1); } else cs.put(0, 2);   // num_extra_channels (+ d_alpha)
-	cs.put(0, 1);                       // xyb_encoded = 0
+	// xyb=1 / ycbcr=1: the frame is flagged XYB / YCbCr; the reference applies no colour transform to Modular
+	// frames (j40.h:8209-8210, 7910) and renders the three channels as they are
+	const int flag_xyb = opt.geti("xyb", 0), flag_ycbcr = opt.geti("ycbcr", 0);
+	cs.put(flag_xyb ? 1 : 0, 1);        // xyb_encoded
 	const int icc_bytes = opt.geti("icc", 0);
 	if (!icc_bytes) cs.put(1, 1);       // ColourEncoding.all_default (sRGB)
 	else { cs.put(0, 1); cs.put(1, 1); cs.put(0, 2); }   // want_icc, colour_space = RGB
@@ -879,7 +895,8 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	cs.put(0, 2);                       // regular frame
 	cs.put(1, 1);                       // modular
 	cs.u64(0);                          // flags
-	cs.put(0, 1);                       // do_ycbcr
+	if (!flag_xyb) cs.put(flag_ycbcr ? 1 : 0, 1);   // do_ycbcr
+	if (!flag_xyb && flag_ycbcr) cs.put(0, 6);      // jpeg_upsampling: none
 	cs.put(0, 2);                       // log_upsampling
 	if (alpha) cs.put(0, 2);            // extra channel upsampling
 	cs.put((uint64_t) (group_shift - 7), 2);
