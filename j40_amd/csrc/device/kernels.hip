@@ -318,6 +318,18 @@ void launch_hf_entropy_lanes(const DevPlan *plans, const HfLaneWork *work, int32
 // ------------------------------------------------------------------------------------------------
 // K2 common pieces
 
+// exclusive prefix sums of the per-block event counts held by lanes 0..NB-1 of the first wavefront (`mine`, 0 for lanes
+// past the last block) -> prefix[0..NB]; visible to the workgroup after its next barrier
+template <int NB>
+__device__ __forceinline__ void stage_event_prefix(uint32_t mine, uint32_t *prefix, int32_t tid) {
+	if (tid >= 64) return;
+	uint32_t incl = mine;
+#pragma unroll
+	for (int d = 1; d < NB; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if (tid >= d) incl += up; }
+	if (tid < NB) prefix[tid + 1] = incl;
+	if (tid == 0) prefix[0] = 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: DCT family up to 64x64. LDS tile per (varblock, channel): rows x (columns + 1) floats, element
 // (r, c) = vertical frequency r, horizontal frequency c. Pass 1: one lane per row r transforms along
@@ -342,31 +354,32 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarbl
 	__shared__ VbGeom geom[NB];
 	__shared__ uint32_t g_be[NB][4];   // each block's entry of DevPlan::block_events
 	__shared__ size_t g_out[NB];       // byte offset of each block's top-left pixel in the output
+	__shared__ uint32_t ev_prefix[NB + 1];   // events of the blocks before each block (tiles_scatter_events)
 	J40_STAGE_SRGB_THRESHOLDS(f);
+	uint32_t nevents = 0;
 	if (tid < nb) {
 		const DevVarblock vb = list[first + tid];
 		const VbGeom g = varblock_geometry(plan, vb);
 		geom[tid] = g; g_out[tid] = (size_t) g.py * stride_bytes + (size_t) g.px * 4;
-		if (f.sparse_coeffs) { const uint32_t *be = plan.block_events + 4 * (size_t) vb.blk; for (int k = 0; k < 4; ++k) g_be[tid][k] = be[k]; }
+		if (f.sparse_coeffs) { const uint32_t *be = plan.block_events + 4 * (size_t) vb.blk; for (int k = 0; k < 4; ++k) g_be[tid][k] = be[k]; nevents = be[1] + be[2] + be[3]; }
 	}
+	stage_event_prefix<NB>(nevents, ev_prefix, tid);
 	constexpr int N = R * C;
 	constexpr int PAR = N >= 256 ? 1 : 256 / N;   // blocks a pass of the 256 lanes covers
 	constexpr int PER = N >= 256 ? N / 256 : 1;   // pixel positions per lane
 	// ---- load: dequantise + chroma-from-luma + LLF into the LDS tiles ----
 	if (f.sparse_coeffs) {
-		// single-pass frames: zero the tiles, then scatter each block's coefficient events into them (one wavefront per block:
-		// the work is proportional to the non-zeros; chroma-from-luma rides along) and write the LLF corner (vardct_dev.h)
+		// single-pass frames: zero the tiles, then scatter the blocks' coefficient events into them (one lane per event over
+		// the whole workgroup: the work is proportional to the non-zeros; chroma-from-luma rides along) and write the LLF
+		// corners (vardct_dev.h). No event lands in an LLF corner, so the two need no barrier between them.
 		for (int32_t w = tid; w < nb * 3 * TILE; w += nthreads) lds[w] = 0.0f;
 		__syncthreads();
 		const uint16_t *order = plan.pool_u16 + f.order_off[order_idx * 3];   // pass 0; the three channels' orders are consecutive
 		const float *dq_scan = plan.pool_f32 + f.dq_scan_off[param_idx];
 		const TileMap map = {R, C, P, 0};
 		const float qbias[3] = {qbias0, qbias1, qbias2};
-		for (int32_t b = tid >> 6; b < nb; b += nthreads >> 6) {
-			float *tile = lds + (size_t) b * 3 * TILE;
-			tile_scatter_events(plan, geom[b], g_be[b], order, dq_scan, N, map, tile, TILE, qbias, qbias_num, tid & 63, 64);
-			tile_fill_llf(plan, geom[b], LONG, VH8, VW8, map, tile, TILE, kx_lf, kb_lf, tid & 63, 64);
-		}
+		tiles_scatter_events<NB>(plan, geom, g_be, ev_prefix, order, dq_scan, N, map, lds, 3 * TILE, TILE, qbias, qbias_num, tid, nthreads);
+		tiles_fill_llf(plan, geom, nb, LONG, VH8, VW8, map, lds, 3 * TILE, TILE, kx_lf, kb_lf, tid, nthreads);
 	} else {
 		// multi-pass frames: dense planes in canonical order, coalesced over the canonical index
 		__syncthreads();

@@ -69,19 +69,51 @@ J40_DEV void tile_add(float *p, float v) {
 	*p += v;
 #endif
 }
-J40_DEV void tile_scatter_events(const DevPlan &plan, const VbGeom &g, const uint32_t be[4], const uint16_t *order /* pass 0: [3][n] */, const float *dq_scan /* [3][n] */, int32_t n,
+// event `e` (0-based within the block) of the block whose entry of DevPlan::block_events is `be`
+template <typename BE, typename GEOM, typename TILE>
+J40_DEV void tile_scatter_one(const DevPlan &plan, const GEOM &g, const BE &be, uint32_t e, const uint16_t *order /* pass 0: [3][n] */, const float *dq_scan /* [3][n] */, int32_t n,
+		const TileMap &map, TILE tile, int32_t cstride, const float quant_bias[3], float quant_bias_num) {
+	const uint32_t first = be[0], n0 = be[1], n1 = be[2];
+	const int32_t c = e < n0 ? 1 : e < n0 + n1 ? 0 : 2;   // events come in the order the channels are coded: Y, X, B
+	const CoeffEvent ev = plan.events[first + e];
+	const int32_t at = map.at(order[c * n + (int32_t) ev.pos]);
+	const float v = dequant_coeff((float) ev.value, quant_bias[c], quant_bias_num, g.mult[c], dq_scan[c * n + (int32_t) ev.pos]);
+	if (c == 1) {
+		tile[cstride + at] = v;
+		tile_add(&tile[at], v * g.kx_hf);
+		tile_add(&tile[2 * cstride + at], v * g.kb_hf);
+	} else tile_add(&tile[c * cstride + at], v);
+}
+J40_DEV void tile_scatter_events(const DevPlan &plan, const VbGeom &g, const uint32_t be[4], const uint16_t *order, const float *dq_scan, int32_t n,
 		const TileMap &map, float *tile, int32_t cstride, const float quant_bias[3], float quant_bias_num, int32_t lane, int32_t nlanes) {
-	const uint32_t first = be[0], n0 = be[1], n1 = be[2], total = n0 + n1 + be[3];
+	const uint32_t total = be[1] + be[2] + be[3];
+	for (uint32_t e = (uint32_t) lane; e < total; e += (uint32_t) nlanes) tile_scatter_one(plan, g, be, e, order, dq_scan, n, map, tile, cstride, quant_bias, quant_bias_num);
+}
+
+// The pixel kernels' form: the events of all `nb` blocks of a workgroup as one list shared by every lane, so that small blocks
+// with a dozen non-zeros do not cost a wavefront each. prefix[b] = events of blocks 0..b-1, prefix[b] = total for b >= nb
+// (b <= NB, a power of two); tiles of consecutive blocks are `bstride` floats apart.
+template <int NB>
+J40_DEV void tiles_scatter_events(const DevPlan &plan, const VbGeom *geom, const uint32_t (*be)[4], const uint32_t *prefix, const uint16_t *order, const float *dq_scan, int32_t n,
+		const TileMap &map, float *tiles, int32_t bstride, int32_t cstride, const float quant_bias[3], float quant_bias_num, int32_t lane, int32_t nlanes) {
+	const uint32_t total = prefix[NB];
 	for (uint32_t e = (uint32_t) lane; e < total; e += (uint32_t) nlanes) {
-		const int32_t c = e < n0 ? 1 : e < n0 + n1 ? 0 : 2;   // events come in the order the channels are coded: Y, X, B
-		const CoeffEvent ev = plan.events[first + e];
-		const int32_t at = map.at(order[c * n + (int32_t) ev.pos]);
-		const float v = dequant_coeff((float) ev.value, quant_bias[c], quant_bias_num, g.mult[c], dq_scan[c * n + (int32_t) ev.pos]);
-		if (c == 1) {
-			tile[cstride + at] = v;
-			tile_add(tile + at, v * g.kx_hf);
-			tile_add(tile + 2 * cstride + at, v * g.kb_hf);
-		} else tile_add(tile + c * cstride + at, v);
+		int32_t b = 0;
+#pragma unroll
+		for (int32_t step = NB >> 1; step >= 1; step >>= 1) if (prefix[b + step] <= e) b += step;
+		tile_scatter_one(plan, geom[b], be[b], e - prefix[b], order, dq_scan, n, map, tiles + (size_t) b * (size_t) bstride, cstride, quant_bias, quant_bias_num);
+	}
+}
+// LLF corners of all `nb` blocks, one lane per (block, LLF position)
+J40_DEV void tiles_fill_llf(const DevPlan &plan, const VbGeom *geom, int32_t nb, int32_t long_side, int32_t vh8, int32_t vw8, const TileMap &map, float *tiles, int32_t bstride, int32_t cstride,
+		float kx_lf, float kb_lf, int32_t lane, int32_t nlanes) {
+	const int32_t per = vh8 * vw8;
+	for (int32_t w = lane; w < nb * per; w += nlanes) {
+		const int32_t b = w / per, k = w - b * per;
+		const int32_t srow = k / vw8, scol = k - srow * vw8, at = map.at(srow * long_side + scol), l = geom[b].llf_base + k;
+		const float lx = plan.llf[0][l], ly = plan.llf[1][l], lb = plan.llf[2][l];
+		float *tile = tiles + (size_t) b * (size_t) bstride;
+		tile[at] = lx + ly * kx_lf; tile[cstride + at] = ly; tile[2 * cstride + at] = lb + ly * kb_lf;
 	}
 }
 

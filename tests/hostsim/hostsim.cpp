@@ -261,8 +261,15 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 			for (int ch = 0; ch < 3; ++ch) std::fill(A.begin() + (size_t) ch * 65536, A.begin() + (size_t) ch * 65536 + std::min<size_t>(65536, (size_t) R * (size_t) P), 0.0f);
 			const TileMap map = {R, C, P, special ? 1 : 0};
 			const uint16_t *order = plan.pool_u16 + f.order_off[DEV_DCT_SELECT[vb.dctsel][2] * 3];
-			tile_scatter_events(plan, g, plan.block_events + 4 * (size_t) vb.blk, order, plan.pool_f32 + f.dq_scan_off[PARAM[vb.dctsel]], sz, map, A.data(), 65536, f.quant_bias, f.quant_bias_num, 0, 1);
-			tile_fill_llf(plan, g, long_side, vh8, vw8, map, A.data(), 65536, f.kx_lf, f.kb_lf, 0, 1);
+			const uint32_t *be = plan.block_events + 4 * (size_t) vb.blk;
+			if (vb.blk & 1) {   // both forms the kernels use
+				tile_scatter_events(plan, g, be, order, plan.pool_f32 + f.dq_scan_off[PARAM[vb.dctsel]], sz, map, A.data(), 65536, f.quant_bias, f.quant_bias_num, 0, 1);
+				tile_fill_llf(plan, g, long_side, vh8, vw8, map, A.data(), 65536, f.kx_lf, f.kb_lf, 0, 1);
+			} else {
+				const uint32_t be1[1][4] = {{be[0], be[1], be[2], be[3]}}, prefix[2] = {0, be[1] + be[2] + be[3]};
+				for (int lane = 0; lane < 3; ++lane) tiles_scatter_events<1>(plan, &g, be1, prefix, order, plan.pool_f32 + f.dq_scan_off[PARAM[vb.dctsel]], sz, map, A.data(), 0, 65536, f.quant_bias, f.quant_bias_num, lane, 3);
+				tiles_fill_llf(plan, &g, 1, long_side, vh8, vw8, map, A.data(), 0, 65536, f.kx_lf, f.kb_lf, 0, 1);
+			}
 		} else for (int i = 0; i < sz; ++i) {
 			float v[3];
 			load_coeff3(plan, g, dq, sz, i, long_side, vh8, vw8, v);
