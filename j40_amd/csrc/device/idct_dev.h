@@ -253,19 +253,21 @@ J40_DEV float srgb_transfer(float v) {
 // transfer curve, scale, + 0.5, truncation, clamp -- is monotone) as long as the int16 wrap-around of the
 // reference's conversion stays out of reach, i.e. for -9 < v < 50000. So the sample is the number of thresholds
 // thr[1..255] that are <= v, where thr[k] = smallest float with sample >= k (built on the host from the exact
-// formula by bisection over the floats, tables.cpp). A cheap estimate good to a small fraction of a level picks
-// k0, two table reads settle it exactly: same bytes as the long way at a fraction of the instructions (the
-// transfer function was ~40 % of the pixel kernels' issue slots). thr[0] = -inf, thr[256] = thr[257] = +inf.
+// formula by bisection over the floats, tables.cpp). The floats sharing their top 16 bits form a bucket narrower
+// than one step; a byte table behind the thresholds gives the sample at the bucket's low end and one comparison
+// with the next threshold settles it: same bytes as the long way in a dozen instructions and no transcendental
+// (the transfer function was ~40 % of the pixel kernels' issue slots). thr[0] = -inf, thr[256] = thr[257] = +inf.
 J40_DEV int32_t srgb_u8_from_thresholds(float v, const J40_LDS float *thr) {
+	int32_t bits;
 #ifdef __HIPCC__
-	const float p = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(v) * 0.416666657f);
+	bits = __float_as_int(v);
 #else
-	const float p = exp2f(log2f(v) * 0.416666657f);
+	memcpy(&bits, &v, 4);
 #endif
-	const float est = v <= 0.0031308f ? 3294.6f * v + 0.5f : 269.025f * p - 13.525f;   // 255 * (12.92 v | 1.055 p - 0.055) + 0.5
-	int32_t k = (int32_t) (est < 0.0f ? 0.0f : est > 255.0f ? 255.0f : est);
-	k += (int32_t) (v >= thr[k + 1]) - (int32_t) (v < thr[k]);
-	return k;
+	int32_t b = bits >> 16;   // negative values land below the first bucket
+	b = (b < SRGB_BUCKET_LO ? SRGB_BUCKET_LO : b > SRGB_BUCKET_HI ? SRGB_BUCKET_HI : b) - SRGB_BUCKET_LO;
+	const int32_t k = ((const J40_LDS uint8_t *) (thr + SRGB_THRESHOLDS))[b];
+	return k + (int32_t) (v >= thr[k + 1]);
 }
 
 // the long way for one linear value: transfer curve, conversion with the reference's int16 quirk, clamp, scaling to 8 bits
@@ -297,8 +299,9 @@ J40_DEV ColourConsts load_colour_consts(const DevFrame &f) {
 	return c;
 }
 
-// returns RGBA packed little-endian (R in the low byte), alpha = 255. thr: threshold table for 8-bit frames
-// (see above) or nullptr for the long way. XYB -> linear RGB: j40.h:7208-7212.
+// returns RGBA packed little-endian (R in the low byte), alpha = 255. thr: the threshold table (see above), used for 8-bit
+// frames; other depths go the long way. (The choice is made on f.bpp, not on the pointer: a null test on an LDS pointer was
+// folded to "always null" by the compiler and every pixel took the long way.) XYB -> linear RGB: j40.h:7208-7212.
 J40_DEV uint32_t xyb_to_rgba8(float sx, float sy, float sb, const ColourConsts &f, const J40_LDS float *thr) {
 	float p[3] = {sy + sx, sy - sx, sb};
 	float s[3];
@@ -307,18 +310,20 @@ J40_DEV uint32_t xyb_to_rgba8(float sx, float sy, float sb, const ColourConsts &
 		const float pp = p[c] - f.cbrt_opsin_bias[c];
 		s[c] = (pp * pp * pp + f.opsin_bias[c]) * f.itscale;
 	}
-	uint32_t out = 0xff000000u;
+	float v[3];
 #pragma unroll
-	for (int c = 0; c < 3; ++c) {
-		const float v = s[0] * f.m[c * 3] + s[1] * f.m[c * 3 + 1] + s[2] * f.m[c * 3 + 2];
-		int32_t px;
-		if (thr && v > -9.0f && v < 50000.0f) px = srgb_u8_from_thresholds(v, thr);
-		else px = srgb_sample_slow(v, f.bpp);
-		out |= (uint32_t) px << (8 * c);
+	for (int c = 0; c < 3; ++c) v[c] = s[0] * f.m[c * 3] + s[1] * f.m[c * 3 + 1] + s[2] * f.m[c * 3 + 2];
+	const float vmin = fminf(fminf(v[0], v[1]), v[2]), vmax = fmaxf(fmaxf(v[0], v[1]), v[2]);
+	uint32_t out = 0xff000000u;
+	if (f.bpp == 8 && vmin > -9.0f && vmax < 50000.0f && v[0] == v[0] && v[1] == v[1] && v[2] == v[2]) {   // (fmin / fmax drop NaNs)
+#pragma unroll
+		for (int c = 0; c < 3; ++c) out |= (uint32_t) srgb_u8_from_thresholds(v[c], thr) << (8 * c);
+	} else {
+		for (int c = 0; c < 3; ++c) out |= (uint32_t) srgb_sample_slow(v[c], f.bpp) << (8 * c);
 	}
 	return out;
 }
-J40_DEV uint32_t xyb_to_rgba8(float sx, float sy, float sb, const DevFrame &f, const J40_LDS float *thr = nullptr) {
+J40_DEV uint32_t xyb_to_rgba8(float sx, float sy, float sb, const DevFrame &f, const J40_LDS float *thr) {
 	return xyb_to_rgba8(sx, sy, sb, load_colour_consts(f), thr);
 }
 

@@ -13,6 +13,7 @@ void launch_hf_lanes(const DevPlan *plans, const HfLaneWork *work, int32_t num_w
 void launch_vardct_class(const DevPlan &plan, int32_t dctsel, const DevVarblock *list, int32_t count, float *large_scratch, uint8_t *rgba, size_t stride, hipStream_t stream);
 
 
+void launch_vardct_batch(const K2Frame *frames_dev, int32_t nframes, const int32_t *host_class_start, hipStream_t stream);
 void launch_vardct_frame(const DevPlan &plan, const int32_t *class_start, const DevVarblock *sorted, float *large_scratch, uint8_t *rgba, size_t stride, hipStream_t stream);
 
 void launch_kat_srgb_u8(const float *v, size_t n, uint8_t *out, hipStream_t stream);

@@ -27,7 +27,7 @@ __device__ float c_srgb_thr[SRGB_TABLE_FLOATS];
 #define J40_STAGE_SRGB_THRESHOLDS(f) \
 	__shared__ float s_srgb_thr[SRGB_TABLE_FLOATS]; \
 	for (int32_t i_ = threadIdx.x; i_ < SRGB_TABLE_FLOATS; i_ += blockDim.x) s_srgb_thr[i_] = c_srgb_thr[i_]; \
-	const J40_LDS float *srgb_thr = (f).bpp == 8 ? (const J40_LDS float *) s_srgb_thr : (const J40_LDS float *) nullptr
+	const J40_LDS float *srgb_thr = (const J40_LDS float *) s_srgb_thr
 
 void upload_constant_tables(const float *half_secants, const float *afv_basis, const float *srgb_thr, hipStream_t stream) {
 	(void) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_srgb_thr), srgb_thr, sizeof(float) * SRGB_TABLE_FLOATS, 0, hipMemcpyHostToDevice, stream);
@@ -318,6 +318,17 @@ void launch_hf_entropy_lanes(const DevPlan *plans, const HfLaneWork *work, int32
 // ------------------------------------------------------------------------------------------------
 // K2 common pieces
 
+// batch-wide launches (BATCH): blockIdx.y picks the frame, whose plan, list, count and output replace the kernel arguments;
+// returns false for workgroups past the end of their frame's list (the grid is sized for the longest one)
+template <bool BATCH>
+__device__ __forceinline__ bool k2_bind(const K2Frame *batch, int32_t class_a, int32_t class_b, int32_t per_wg, const DevVarblock *&list, int32_t &count, uint8_t *&rgba, size_t &stride, float *&scratch) {
+	if (!BATCH) return true;
+	const K2Frame &fr = batch[blockIdx.y];
+	const int32_t a = fr.class_start[class_a];
+	list = fr.sorted + a; count = fr.class_start[class_b] - a; rgba = fr.rgba; stride = fr.stride; scratch = fr.large_scratch;
+	return (int32_t) blockIdx.x * per_wg < count;
+}
+
 // exclusive prefix sums of the per-block event counts held by lanes 0..NB-1 of the first wavefront (`mine`, 0 for lanes
 // past the last block) -> prefix[0..NB]; visible to the workgroup after its next barrier
 template <int NB>
@@ -337,8 +348,11 @@ __device__ __forceinline__ void stage_event_prefix(uint32_t mine, uint32_t *pref
 // thanks to the odd pitch. Arithmetic = j40__inverse_dct2d (j40.h:5972): IDCT over the columns
 // dimension first, then over rows.
 
-template <int LOGR, int LOGC, int NB>
-__global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarblock *list, int32_t count, int32_t param_idx, int32_t order_idx, uint8_t *rgba, size_t stride_bytes) {
+template <int LOGR, int LOGC, int NB, bool BATCH>
+__global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan_arg, const DevVarblock *list, int32_t count, int32_t param_idx, int32_t order_idx, uint8_t *rgba, size_t stride_bytes,
+		const K2Frame *batch, int32_t class_a, int32_t class_b) {
+	const DevPlan &plan = BATCH ? batch[blockIdx.y].plan : plan_arg;
+	{ float *unused = nullptr; if (!k2_bind<BATCH>(batch, class_a, class_b, NB, list, count, rgba, stride_bytes, unused)) return; }
 	constexpr int R = 1 << LOGR, C = 1 << LOGC, P = C + 1, TILE = R * P;
 	constexpr int LONG = R > C ? R : C;                  // columns of the canonical (short side = rows) layout
 	constexpr int VH8 = (R < C ? R : C) / 8, VW8 = LONG / 8;
@@ -435,8 +449,10 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan, const DevVarbl
 // ------------------------------------------------------------------------------------------------
 // K2s: the 8x8 special transforms; one lane transforms one (block, channel) tile serially
 
-template <int NB>
-__global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan, const DevVarblock *list, int32_t count, uint8_t *rgba, size_t stride_bytes) {
+template <int NB, bool BATCH>
+__global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const DevVarblock *list, int32_t count, uint8_t *rgba, size_t stride_bytes, const K2Frame *batch, int32_t class_a, int32_t class_b) {
+	const DevPlan &plan = BATCH ? batch[blockIdx.y].plan : plan_arg;
+	{ float *unused = nullptr; if (!k2_bind<BATCH>(batch, class_a, class_b, NB, list, count, rgba, stride_bytes, unused)) return; }
 	constexpr int P = 65;  // odd pitch: lanes working on different tiles hit different banks
 	__shared__ float tiles[NB * 3 * P];
 	__shared__ float scratch[NB * 3 * P];
@@ -540,7 +556,10 @@ __device__ void idct_sweeps(float *A, float *B, int32_t t, int32_t ncols, int32_
 	}
 }
 
-__global__ void __launch_bounds__(256) k_vardct_large(DevPlan plan, const DevVarblock *list, int32_t count, float *scratch, uint8_t *rgba, size_t stride_bytes) {
+template <bool BATCH>
+__global__ void __launch_bounds__(256) k_vardct_large(DevPlan plan_arg, const DevVarblock *list, int32_t count, float *scratch, uint8_t *rgba, size_t stride_bytes, const K2Frame *batch, int32_t class_a, int32_t class_b) {
+	const DevPlan &plan = BATCH ? batch[blockIdx.y].plan : plan_arg;
+	if (!k2_bind<BATCH>(batch, class_a, class_b, 1, list, count, rgba, stride_bytes, scratch)) return;
 	const DevFrame &f = *plan.frame;
 	const int32_t tid = threadIdx.x, nthreads = blockDim.x;
 	const DevVarblock vb = list[blockIdx.x];
@@ -613,38 +632,52 @@ void launch_hf_entropy(const DevPlan &plan, const HfLaunchInfo &info, int32_t fi
 	}
 }
 
+// `batch` = nullptr: one frame, everything in the kernel arguments. Otherwise `nframes` frames in one launch (blockIdx.y), the
+// grid sized for `count` = the longest list of the class over the frames; plan / list / rgba / stride are then ignored.
+struct K2Launch { const K2Frame *batch; int32_t nframes, class_a, class_b; };
+
 template <int LOGR, int LOGC, int NB>
-static void launch_dct(const DevPlan &plan, const DevVarblock *list, int32_t count, int32_t param_idx, int32_t order_idx, uint8_t *rgba, size_t stride, hipStream_t stream) {
+static void launch_dct(const DevPlan &plan, const DevVarblock *list, int32_t count, int32_t param_idx, int32_t order_idx, uint8_t *rgba, size_t stride, const K2Launch &bl, hipStream_t stream) {
 	constexpr size_t lds_bytes = (size_t) NB * 3 * (1 << LOGR) * ((1 << LOGC) + 1) * sizeof(float);
 	static bool configured = false;
-	if (!configured) { (void) hipFuncSetAttribute((const void *) k_vardct_dct<LOGR, LOGC, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes); configured = true; }
+	if (!configured) {
+		(void) hipFuncSetAttribute((const void *) k_vardct_dct<LOGR, LOGC, NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
+		(void) hipFuncSetAttribute((const void *) k_vardct_dct<LOGR, LOGC, NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
+		configured = true;
+	}
 	const int32_t blocks = (count + NB - 1) / NB;
-	hipLaunchKernelGGL((k_vardct_dct<LOGR, LOGC, NB>), dim3((unsigned) blocks), dim3(256), lds_bytes, stream, plan, list, count, param_idx, order_idx, rgba, stride);
+	if (bl.batch) hipLaunchKernelGGL((k_vardct_dct<LOGR, LOGC, NB, true>), dim3((unsigned) blocks, (unsigned) bl.nframes), dim3(256), lds_bytes, stream, plan, list, count, param_idx, order_idx, rgba, stride, bl.batch, bl.class_a, bl.class_b);
+	else hipLaunchKernelGGL((k_vardct_dct<LOGR, LOGC, NB, false>), dim3((unsigned) blocks), dim3(256), lds_bytes, stream, plan, list, count, param_idx, order_idx, rgba, stride, bl.batch, 0, 0);
 }
 
-// list = varblocks of one DctSelect value
-void launch_vardct_class(const DevPlan &plan, int32_t dctsel, const DevVarblock *list, int32_t count, float *large_scratch, uint8_t *rgba, size_t stride, hipStream_t stream) {
+// list = varblocks of one DctSelect value (of a run of values for the 8x8 specials)
+static void launch_vardct_class_impl(const DevPlan &plan, int32_t dctsel, const DevVarblock *list, int32_t count, float *large_scratch, uint8_t *rgba, size_t stride, const K2Launch &bl, hipStream_t stream) {
 	if (count <= 0) return;
 	switch (dctsel) {
-	case 0: launch_dct<3, 3, 16>(plan, list, count, 0, 0, rgba, stride, stream); break;
-	case 4: launch_dct<4, 4, 8>(plan, list, count, 4, 2, rgba, stride, stream); break;
-	case 5: launch_dct<5, 5, 2>(plan, list, count, 5, 3, rgba, stride, stream); break;
-	case 6: launch_dct<4, 3, 8>(plan, list, count, 6, 4, rgba, stride, stream); break;
-	case 7: launch_dct<3, 4, 8>(plan, list, count, 6, 4, rgba, stride, stream); break;
-	case 8: launch_dct<5, 3, 4>(plan, list, count, 7, 5, rgba, stride, stream); break;
-	case 9: launch_dct<3, 5, 4>(plan, list, count, 7, 5, rgba, stride, stream); break;
-	case 10: launch_dct<5, 4, 4>(plan, list, count, 8, 6, rgba, stride, stream); break;
-	case 11: launch_dct<4, 5, 4>(plan, list, count, 8, 6, rgba, stride, stream); break;
-	case 18: launch_dct<6, 6, 1>(plan, list, count, 11, 7, rgba, stride, stream); break;
-	case 19: launch_dct<6, 5, 1>(plan, list, count, 12, 8, rgba, stride, stream); break;
-	case 20: launch_dct<5, 6, 1>(plan, list, count, 12, 8, rgba, stride, stream); break;
+	case 0: launch_dct<3, 3, 16>(plan, list, count, 0, 0, rgba, stride, bl, stream); break;
+	case 4: launch_dct<4, 4, 8>(plan, list, count, 4, 2, rgba, stride, bl, stream); break;
+	case 5: launch_dct<5, 5, 2>(plan, list, count, 5, 3, rgba, stride, bl, stream); break;
+	case 6: launch_dct<4, 3, 8>(plan, list, count, 6, 4, rgba, stride, bl, stream); break;
+	case 7: launch_dct<3, 4, 8>(plan, list, count, 6, 4, rgba, stride, bl, stream); break;
+	case 8: launch_dct<5, 3, 4>(plan, list, count, 7, 5, rgba, stride, bl, stream); break;
+	case 9: launch_dct<3, 5, 4>(plan, list, count, 7, 5, rgba, stride, bl, stream); break;
+	case 10: launch_dct<5, 4, 4>(plan, list, count, 8, 6, rgba, stride, bl, stream); break;
+	case 11: launch_dct<4, 5, 4>(plan, list, count, 8, 6, rgba, stride, bl, stream); break;
+	case 18: launch_dct<6, 6, 1>(plan, list, count, 11, 7, rgba, stride, bl, stream); break;
+	case 19: launch_dct<6, 5, 1>(plan, list, count, 12, 8, rgba, stride, bl, stream); break;
+	case 20: launch_dct<5, 6, 1>(plan, list, count, 12, 8, rgba, stride, bl, stream); break;
 	case 1: case 2: case 3: case 12: case 13: case 14: case 15: case 16: case 17:
-		hipLaunchKernelGGL((k_vardct_special<32>), dim3((unsigned) ((count + 31) / 32)), dim3(256), 0, stream, plan, list, count, rgba, stride);
+		if (bl.batch) hipLaunchKernelGGL((k_vardct_special<32, true>), dim3((unsigned) ((count + 31) / 32), (unsigned) bl.nframes), dim3(256), 0, stream, plan, list, count, rgba, stride, bl.batch, bl.class_a, bl.class_b);
+		else hipLaunchKernelGGL((k_vardct_special<32, false>), dim3((unsigned) ((count + 31) / 32)), dim3(256), 0, stream, plan, list, count, rgba, stride, bl.batch, 0, 0);
 		break;
 	default:
-		hipLaunchKernelGGL(k_vardct_large, dim3((unsigned) count), dim3(256), 0, stream, plan, list, count, large_scratch, rgba, stride);
+		if (bl.batch) hipLaunchKernelGGL(k_vardct_large<true>, dim3((unsigned) count, (unsigned) bl.nframes), dim3(256), 0, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, bl.class_a, bl.class_b);
+		else hipLaunchKernelGGL(k_vardct_large<false>, dim3((unsigned) count), dim3(256), 0, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, 0, 0);
 		break;
 	}
+}
+void launch_vardct_class(const DevPlan &plan, int32_t dctsel, const DevVarblock *list, int32_t count, float *large_scratch, uint8_t *rgba, size_t stride, hipStream_t stream) {
+	launch_vardct_class_impl(plan, dctsel, list, count, large_scratch, rgba, stride, K2Launch{nullptr, 1, 0, 0}, stream);
 }
 
 // known-answer hook: the renderer's per-sample tail (sRGB transfer + conversion, j40.h:7213-7240 / 7925-7935)
@@ -666,11 +699,22 @@ void launch_kat_srgb_u8(const float *v, size_t n, uint8_t *out, hipStream_t stre
 
 // every class of one frame; the nine 8x8 special transforms (DctSelect 1-3 and 12-17, contiguous in the
 // sorted list) share two launches since k_vardct_special dispatches per varblock
+static bool class_range(int d, int *a, int *b) {
+	if (d == 2 || d == 3 || (d >= 13 && d <= 17)) return false;
+	*a = d; *b = d == 1 ? 4 : d == 12 ? 18 : d + 1;
+	return true;
+}
 void launch_vardct_frame(const DevPlan &plan, const int32_t *class_start, const DevVarblock *sorted, float *large_scratch, uint8_t *rgba, size_t stride, hipStream_t stream) {
-	for (int d = 0; d < 27; ++d) {
-		if (d == 2 || d == 3 || (d >= 13 && d <= 17)) continue;
-		const int32_t a = class_start[d], b = d == 1 ? class_start[4] : d == 12 ? class_start[18] : class_start[d + 1];
-		launch_vardct_class(plan, d, sorted + a, b - a, large_scratch, rgba, stride, stream);
+	for (int d = 0, a, b; d < 27; ++d) if (class_range(d, &a, &b))
+		launch_vardct_class(plan, d, sorted + class_start[a], class_start[b] - class_start[a], large_scratch, rgba, stride, stream);
+}
+// the same for `nframes` frames at once: one launch per class, blockIdx.y = frame. host_class_start: [nframes][28]
+void launch_vardct_batch(const K2Frame *frames_dev, int32_t nframes, const int32_t *host_class_start, hipStream_t stream) {
+	const DevPlan none = DevPlan();
+	for (int d = 0, a, b; d < 27; ++d) if (class_range(d, &a, &b)) {
+		int32_t longest = 0;
+		for (int32_t i = 0; i < nframes; ++i) longest = std::max(longest, host_class_start[28 * i + b] - host_class_start[28 * i + a]);
+		launch_vardct_class_impl(none, d, nullptr, longest, nullptr, nullptr, 0, K2Launch{frames_dev, nframes, a, b}, stream);
 	}
 }
 

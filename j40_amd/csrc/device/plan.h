@@ -61,12 +61,12 @@ struct DevVarblock {
 	int32_t coeff_base;   // index of the block's first coefficient in plan.coeffs[c]
 	int32_t llf_base;     // index of the block's first LLF coefficient in plan.llf[c]
 	float mult1;          // 65536 / global_scale / HfMul (j40.h:7078-7080), the Y channel's multiplier
-	int32_t c64;          // index of the block's 64x64 cell in plan.xfromy / bfromy
+	float kx_hf;          // chroma-from-luma factors of the block's 64x64 cell: base_corr + inv_colour_factor * x/bfromy (j40.h:7138-7143)
 	int32_t px, py;       // top-left pixel in the frame
 	uint16_t effw, effh;  // visible size
 	uint8_t dctsel, pad[3];
 	int32_t blk;          // ordinal of the block in plan.group_blocks / plan.block_events
-	int32_t pad2;
+	float kb_hf;
 };
 
 struct DevFrame {
@@ -193,11 +193,23 @@ struct DevModPlan {
 	uint32_t *status;                 // [num_sections]
 };
 
+// one frame of a batch-wide launch of the pixel kernels (blockIdx.y): what the single-frame launch passes as kernel arguments
+struct K2Frame {
+	DevPlan plan;
+	const DevVarblock *sorted;     // the frame's varblocks sorted by DctSelect
+	float *large_scratch;
+	uint8_t *rgba; size_t stride;  // where this decode writes
+	int32_t class_start[28];
+};
+
 // one wavefront of the throughput-oriented K1: up to 64 consecutive groups of one frame of the batch
 struct HfLaneWork { int32_t frame, first_group, num_groups, pad; };
 
 // sRGB threshold table of the pixel kernels (idct_dev.h, srgb_u8_from_thresholds)
-enum { SRGB_TABLE_FLOATS = 258 };
+// 258 thresholds, then SRGB_BUCKETS bytes: the sample at the low end of each bucket of linear values, a bucket being the floats
+// that share their top 16 bits (sign, exponent, 7 mantissa bits), from 2^-13 (SRGB_BUCKET_LO) up to 1.0 (SRGB_BUCKET_HI)
+enum { SRGB_THRESHOLDS = 258, SRGB_BUCKET_LO = (127 - 13) << 7, SRGB_BUCKET_HI = 127 << 7, SRGB_BUCKETS = SRGB_BUCKET_HI - SRGB_BUCKET_LO + 4,
+       SRGB_TABLE_FLOATS = SRGB_THRESHOLDS + SRGB_BUCKETS / 4 };
 
 enum { HF_WAVES = 4 };
 enum { HF_LANE_COLS_BYTES = 3 * 32 * 64 };   // k_hf_lanes: per-wavefront column state of the non-zero-count predictor  // groups (wavefronts) per K1 workgroup

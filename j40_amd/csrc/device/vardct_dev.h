@@ -20,8 +20,7 @@ J40_DEV VbGeom varblock_geometry(const DevPlan &plan, const DevVarblock &vb) {
 	VbGeom g;
 	g.coeff_base = vb.coeff_base; g.llf_base = vb.llf_base;
 	g.mult[1] = vb.mult1; g.mult[0] = vb.mult1 * f.x_qm_mul; g.mult[2] = vb.mult1 * f.b_qm_mul;   // j40.h:7078-7080
-	g.kx_hf = f.base_corr_x + f.inv_colour_factor * (float) plan.xfromy[vb.c64];   // j40.h:7138-7143
-	g.kb_hf = f.base_corr_b + f.inv_colour_factor * (float) plan.bfromy[vb.c64];
+	g.kx_hf = vb.kx_hf; g.kb_hf = vb.kb_hf;
 	g.px = vb.px; g.py = vb.py; g.effw = vb.effw; g.effh = vb.effh;
 	return g;
 }
@@ -70,8 +69,8 @@ J40_DEV void tile_add(float *p, float v) {
 #endif
 }
 // event `e` (0-based within the block) of the block whose entry of DevPlan::block_events is `be`
-template <typename BE, typename GEOM, typename TILE>
-J40_DEV void tile_scatter_one(const DevPlan &plan, const GEOM &g, const BE &be, uint32_t e, const uint16_t *order /* pass 0: [3][n] */, const float *dq_scan /* [3][n] */, int32_t n,
+template <typename BE, typename GEOM, typename TILE, typename ORD, typename DQ>
+J40_DEV void tile_scatter_one(const DevPlan &plan, const GEOM &g, const BE &be, uint32_t e, ORD order /* pass 0: [3][n] */, DQ dq_scan /* [3][n] */, int32_t n,
 		const TileMap &map, TILE tile, int32_t cstride, const float quant_bias[3], float quant_bias_num) {
 	const uint32_t first = be[0], n0 = be[1], n1 = be[2];
 	const int32_t c = e < n0 ? 1 : e < n0 + n1 ? 0 : 2;   // events come in the order the channels are coded: Y, X, B
@@ -93,8 +92,8 @@ J40_DEV void tile_scatter_events(const DevPlan &plan, const VbGeom &g, const uin
 // The pixel kernels' form: the events of all `nb` blocks of a workgroup as one list shared by every lane, so that small blocks
 // with a dozen non-zeros do not cost a wavefront each. prefix[b] = events of blocks 0..b-1, prefix[b] = total for b >= nb
 // (b <= NB, a power of two); tiles of consecutive blocks are `bstride` floats apart.
-template <int NB>
-J40_DEV void tiles_scatter_events(const DevPlan &plan, const VbGeom *geom, const uint32_t (*be)[4], const uint32_t *prefix, const uint16_t *order, const float *dq_scan, int32_t n,
+template <int NB, typename ORD, typename DQ>
+J40_DEV void tiles_scatter_events(const DevPlan &plan, const VbGeom *geom, const uint32_t (*be)[4], const uint32_t *prefix, ORD order, DQ dq_scan, int32_t n,
 		const TileMap &map, float *tiles, int32_t bstride, int32_t cstride, const float quant_bias[3], float quant_bias_num, int32_t lane, int32_t nlanes) {
 	const uint32_t total = prefix[NB];
 	for (uint32_t e = (uint32_t) lane; e < total; e += (uint32_t) nlanes) {

@@ -96,6 +96,7 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 		}
 	}
 
+	std::vector<int32_t> vb_lf_group;   // LF group of each entry of vb_sorted, until the block ordinals are resolved
 	// LF bundle: frame-wide arrays over all LF groups
 	hp->lf_groups.assign(fr.lf_groups.size(), DevLfGroup());
 	for (size_t g = 0; g < fr.lf_groups.size(); ++g) {
@@ -119,12 +120,14 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 			const int32_t coeffoff = vb.coeffoff_qfidx & ~15;
 			dv.coeff_base = d.cell_base * 64 + coeffoff; dv.llf_base = d.cell_base + (coeffoff >> 6);
 			dv.mult1 = df.mult_base * vb.hfmul_inv;
-			dv.c64 = d.c64_base + (vb.y8 / 8) * gg.width64 + (vb.x8 / 8);
+			const size_t c64 = (size_t) (vb.y8 / 8) * (size_t) gg.width64 + (size_t) (vb.x8 / 8);
+			dv.kx_hf = fr.base_corr_x + fr.inv_colour_factor * (float) gg.xfromy[c64];   // j40.h:7138-7143, one factor per varblock
+			dv.kb_hf = fr.base_corr_b + fr.inv_colour_factor * (float) gg.bfromy[c64];
 			dv.px = gg.left + vb.x8 * 8; dv.py = gg.top + vb.y8 * 8;
 			dv.effh = (uint16_t) std::min(gg.height - vb.y8 * 8, 1 << ds.log_rows); dv.effw = (uint16_t) std::min(gg.width - vb.x8 * 8, 1 << ds.log_columns);
 			dv.dctsel = (uint8_t) vb.dctsel;
-			dv.pad2 = (int32_t) g; dv.blk = (int32_t) v;   // resolved to the block's ordinal once the group lists exist
-			hp->vb_sorted.push_back(dv);
+			dv.blk = (int32_t) v;   // resolved to the block's ordinal once the group lists exist
+			hp->vb_sorted.push_back(dv); vb_lf_group.push_back((int32_t) g);
 		}
 	}
 	hp->coeff_floats = hp->blocks.size() * 64;
@@ -172,8 +175,7 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 		}
 	}
 	hp->group_block_start[(size_t) num_groups] = (uint32_t) hp->group_blocks.size();
-	for (DevVarblock &dv : hp->vb_sorted) dv.blk = ordinal[(size_t) dv.pad2][(size_t) dv.blk];   // (LF group, varblock) were parked in pad2 / blk
-	for (DevVarblock &dv : hp->vb_sorted) dv.pad2 = 0;
+	for (size_t i = 0; i < hp->vb_sorted.size(); ++i) hp->vb_sorted[i].blk = ordinal[(size_t) vb_lf_group[i]][(size_t) hp->vb_sorted[i].blk];   // blk held the varblock's index in its LF group
 	// single-pass frames: sparse coefficients (DevPlan::events). A group's region is sized from its section: a non-zero
 	// coefficient costs bits, 6 events per byte is far beyond what entropy coding reaches on real data; a section that still
 	// overflows it fails with ERR_EVOF and the frame is decoded with dense planes instead (runtime.hip).

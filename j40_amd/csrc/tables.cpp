@@ -96,6 +96,16 @@ const float *srgb_u8_thresholds() {
 			while (hi - lo > 1) { const uint32_t mid = lo + (hi - lo) / 2; if (sample(from_bits(mid)) >= k) hi = mid; else lo = mid; }
 			table[k] = from_bits(hi);
 		}
+		// the buckets: sample at the bucket's smallest float (bucket 0 also takes everything below 2^-13, the last one everything
+		// from 1.0 up); a bucket must not span more than one step for the device's single comparison to settle the sample
+		uint8_t *bucket = (uint8_t *) (table + SRGB_THRESHOLDS);
+		memset(bucket, 0, SRGB_BUCKETS);
+		for (int32_t b = 0; b <= SRGB_BUCKET_HI - SRGB_BUCKET_LO; ++b) {
+			const float lo = from_bits((uint32_t) (b + SRGB_BUCKET_LO) << 16);
+			int k = 0; while (k < 255 && table[k + 1] <= lo) ++k;
+			bucket[b] = (uint8_t) (b == 0 ? 0 : k);
+			if (b > 0 && (int) bucket[b] - (int) bucket[b - 1] > 1) abort();   // cannot happen: the steepest bucket spans 0.66 of a step
+		}
 	});
 	return table;
 }

@@ -287,7 +287,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 			} else { idct_rows_dyn(t, C, R, P, hs); idct_cols_dyn(t, R, C, P, hs); }
 		}
 		for (int y = 0; y < g.effh; ++y) for (int x = 0; x < g.effw; ++x) {
-			const uint32_t px = xyb_to_rgba8(A[y * P + x], A[65536 + y * P + x], A[2 * 65536 + y * P + x], f, f.bpp == 8 ? srgb_u8_thresholds() : nullptr);
+			const uint32_t px = xyb_to_rgba8(A[y * P + x], A[65536 + y * P + x], A[2 * 65536 + y * P + x], f, srgb_u8_thresholds());
 			memcpy(rgba + (size_t) (g.py + y) * stride + (size_t) (g.px + x) * 4, &px, 4);
 		}
 	}
@@ -304,6 +304,25 @@ extern "C" __attribute__((visibility("default"))) uint64_t hostsim_pow_sweep(uin
 		float x; memcpy(&x, &bits, 4);
 		const float got = pow_1_over_2p4(x), expect = (float) pow((double) x, P);
 		if (memcmp(&got, &expect, 4) != 0 && !(got != got && expect != expect)) { ++bad; if (worst) *worst = x; }
+	}
+	return bad;
+}
+
+// the table path at every place where it could be off by one: each threshold, each bucket edge, their neighbouring floats,
+// and a few values outside (0, 1)
+extern "C" __attribute__((visibility("default"))) uint64_t hostsim_srgb_u8_edges() {
+	const float *thr = srgb_u8_thresholds();
+	const double P = (double) (1.0f / 2.4f);
+	std::vector<float> probe = {0.0f, -0.0f, -1e-30f, -0.5f, -8.99f, 1e-30f, 1.0f, 1.5f, 100.0f, 49999.0f};
+	auto around = [&](uint32_t bits) { for (int d = -2; d <= 2; ++d) { const uint32_t u = bits + (uint32_t) d; float x; memcpy(&x, &u, 4); probe.push_back(x); } };
+	for (int k = 1; k <= 255; ++k) { uint32_t u; memcpy(&u, &thr[k], 4); around(u); }
+	for (uint32_t b = SRGB_BUCKET_LO - 2; b <= SRGB_BUCKET_HI + 2; ++b) around(b << 16);
+	uint64_t bad = 0;
+	for (float v : probe) {
+		const float t = v <= 0.0031308f ? 12.92f * v : 1.055f * (float) pow((double) v, P) - 0.055f;
+		int32_t px = f32_to_i16_x86(255.0f * t + 0.5f);
+		px = px < 0 ? 0 : px > 255 ? 255 : px;
+		bad += srgb_u8_from_thresholds(v, thr) != px;
 	}
 	return bad;
 }

@@ -183,6 +183,18 @@ def test_batch_throughput_mode_matches_latency_mode(gpu, ref):
         assert err == "" and np.array_equal(got, single), name
         rerr, expect = ref.decode(data)
         assert rerr == "" and compare(got, expect)[0] <= 1, name
+    # the alternative launch form of the pixel kernels: one launch per transform class over all frames (blockIdx.y = frame)
+    os.environ["J40HIP_K2_BATCHED"] = "1"
+    try:
+        bw = gpu.Batch(frames)
+    finally:
+        del os.environ["J40HIP_K2_BATCHED"]
+    again = [torch.zeros_like(o) for o in outs]
+    bw.decode([o.data_ptr() for o in again], [o.shape[1] * 4 for o in again], torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for o, a, (name, _) in zip(outs, again, cases):
+        assert torch.equal(o, a), name
+    bw.close()
     # a corrupt member fails alone
     bad = bytearray(datas[0]); bad[len(bad) // 2] ^= 0x55
     try:

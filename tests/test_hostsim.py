@@ -89,6 +89,8 @@ def test_srgb_power_function_is_correctly_rounded(sim):
     bad = sim.hostsim_pow_sweep(bits(2.0 ** -9), bits(3.0e38), 4099, C.byref(worst))
     assert bad <= 2, "x = %r" % worst.value
     assert sim.hostsim_srgb_u8_sweep(bits(1e-6), bits(300.0), 13) == 0
+    sim.hostsim_srgb_u8_edges.restype = C.c_uint64
+    assert sim.hostsim_srgb_u8_edges() == 0, "every threshold and bucket edge of the table path, +- 2 floats"
 
 
 def test_lane_decoder_reports_the_same_errors_on_corrupt_streams(sim, ref):
