@@ -80,14 +80,16 @@ J40_DEV void lane_bits_init(LaneBits &b, const J40_GLOBAL uint8_t *base, uint32_
 	b.ahead = lane_load32(base, b.pos);
 }
 
-// > 32 bits buffered afterwards; no branch: the append is a select, the next word is always (re)requested
+// > 32 bits buffered afterwards. The append is needed once in several symbols; it is a (divergent) branch so that the load of
+// the word after next is issued only then and has all the symbols until the next append to arrive: requesting it in every
+// iteration made every iteration wait for the request of the one before (and, vmcnt being shared, for its stores)
 J40_DEV void lane_bits_refill(LaneBits &b) {
-	const bool need = b.nbits <= 32;
-	const uint64_t add = (uint64_t) b.ahead << (need ? b.nbits : 0);
-	b.bits |= need ? add : 0;
-	b.nbits += need ? 32 : 0;
-	b.pos += need ? 4u : 0u;
-	b.ahead = lane_load32(b.base, b.pos);
+	if (b.nbits <= 32) {
+		b.bits |= (uint64_t) b.ahead << b.nbits;
+		b.nbits += 32;
+		b.pos += 4u;
+		b.ahead = lane_load32(b.base, b.pos);
+	}
 }
 
 J40_DEV uint32_t lane_bits_take(LaneBits &b, int32_t n) {   // 0 <= n <= 31, n <= nbits
@@ -206,12 +208,11 @@ J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t,
 		} else {
 			ctx = cctx + t.nnz_ctx2[(nz + (1 << shift) - 1) >> shift] + t.freq_ctx2[i >> shift] + prev;
 		}
-		uint32_t serr;
-		const int32_t v = lane_symbol(b, state, t, ctx, end_bit, &serr);
-		if (serr) { err = serr; break; }
+		uint32_t e2;   // the first error of this iteration; set instead of leaving the loop midway so that the epilogues stay select-shaped
+		const int32_t v = lane_symbol(b, state, t, ctx, end_bit, &e2);
 		if (!in_coeffs) {
 			nz = v;
-			if (nz > (63 << shift)) { err = ERR_COEF; break; }
+			e2 = e2 ? e2 : nz > (63 << shift) ? (uint32_t) ERR_COEF : 0u;
 			const int8_t qnz = (int8_t) ((nz + (1 << shift) - 1) >> shift);
 			J40_LDS int8_t *col = cols + (c * 32 + x8) * col_stride;
 			for (int32_t q = 0; q < (1 << (log_columns - 3)); ++q) col[q * col_stride] = qnz;
@@ -224,19 +225,26 @@ J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t,
 			}
 			in_coeffs = nz > 0;
 		} else {
-			if (v) {
-				if (SCAN) {   // one sequential 8-byte store per non-zero coefficient
-					if (ev_at >= ev_end) { err = ERR_EVOF; break; }
-					((J40_GLOBAL uint64_t *) G.events)[ev_at++] = (uint64_t) (uint32_t) i | ((uint64_t) (uint32_t) unpack_signed_dev(v) << 32);   // CoeffEvent {pos, value}
-				} else G.coeffs[coeff_at + order[i]] += (float) unpack_signed_dev(v);
-			}
+			const bool nonzero = v != 0 && e2 == 0;
+			if (SCAN) {   // one sequential 8-byte store per non-zero coefficient
+				const bool full = nonzero && ev_at >= ev_end;
+				if (nonzero && !full) ((J40_GLOBAL uint64_t *) G.events)[ev_at] = (uint64_t) (uint32_t) i | ((uint64_t) (uint32_t) unpack_signed_dev(v) << 32);   // CoeffEvent {pos, value}
+				ev_at += nonzero && !full ? 1u : 0u;
+				e2 = e2 ? e2 : full ? (uint32_t) ERR_EVOF : 0u;
+			} else if (nonzero) G.coeffs[coeff_at + order[i]] += (float) unpack_signed_dev(v);
 			prev = v != 0;
 			nz -= prev;
 			++i;
-			if (nz == 0) in_coeffs = false;
-			else if (i >= size) { err = ERR_COEF; break; }   // non-zeros left but no coefficient left (j40.h:6996)
+			in_coeffs = nz != 0;
+			e2 = e2 ? e2 : in_coeffs && i >= size ? (uint32_t) ERR_COEF : 0u;   // non-zeros left but no coefficient left (j40.h:6996)
 		}
-		if (!in_coeffs && ++c_yxb == 3) { c_yxb = 0; done = ++k >= nblocks; }
+		const bool next_channel = !in_coeffs && e2 == 0;
+		c_yxb += next_channel ? 1 : 0;
+		const bool next_block = next_channel && c_yxb == 3;
+		c_yxb = next_block ? 0 : c_yxb;
+		k += next_block ? 1 : 0;
+		err = e2 ? e2 : err;
+		done = e2 != 0 || (next_block && k >= nblocks);
 	}
 	if (SCAN && !err && nblocks > 0) lane_store_block_events(G, block_first + (uint32_t) nblocks - 1u, blk_first, blk_n0, blk_n1, ev_at - chan_first);   // the last block
 	if (!err) {   // j40.h:2884-2893: the final state, or the untouched initial state, must be 0x130000
