@@ -177,7 +177,7 @@ J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t,
 		// nearly every iteration, and then the whole wavefront walks the block-start code. It is therefore only executed every
 		// NZ_PERIOD-th iteration: a lane that reaches a block start in between sits out until then (J40_LANE_NZ_PERIOD = 1: never)
 #ifndef J40_LANE_NZ_PERIOD
-#define J40_LANE_NZ_PERIOD 4
+#define J40_LANE_NZ_PERIOD 8
 #endif
 		if (!in_coeffs && (turn % J40_LANE_NZ_PERIOD) != 0) continue;
 		lane_bits_refill(b);

@@ -455,7 +455,6 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const 
 	{ float *unused = nullptr; if (!k2_bind<BATCH>(batch, class_a, class_b, NB, list, count, rgba, stride_bytes, unused)) return; }
 	constexpr int P = 65;  // odd pitch: lanes working on different tiles hit different banks
 	__shared__ float tiles[NB * 3 * P];
-	__shared__ float scratch[NB * 3 * P];
 	const DevFrame &f = *plan.frame;
 	const int32_t tid = threadIdx.x, nthreads = blockDim.x;
 	const int32_t first = blockIdx.x * NB;
@@ -493,9 +492,17 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const 
 		}
 	}
 	__syncthreads();
+	// one lane per (block, channel): the tile and the workspace live in registers (the transforms are fully unrolled,
+	// constant indices throughout), so the serial chain is arithmetic only and the LDS holds just the tiles
 	for (int32_t w = tid; w < nb * 3; w += nthreads) {
 		const int32_t dctsel = list[first + w / 3].dctsel;
-		inverse_special8x8(dctsel, tiles + (size_t) w * P, scratch + (size_t) w * P, c_half_secants, c_afv_basis);
+		float *tile = tiles + (size_t) w * P;
+		float buf[64], work[64];
+#pragma unroll
+		for (int i = 0; i < 64; ++i) buf[i] = tile[i];
+		inverse_special8x8(dctsel, buf, work, c_half_secants, c_afv_basis);
+#pragma unroll
+		for (int i = 0; i < 64; ++i) tile[i] = buf[i];
 	}
 	__syncthreads();
 	for (int32_t w = tid; w < nb * 64; w += nthreads) {
