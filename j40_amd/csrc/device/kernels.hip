@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan_arg, const DevV
 		const float *dq_scan = plan.pool_f32 + f.dq_scan_off[param_idx];
 		const TileMap map = {R, C, P, 0};
 		const float qbias[3] = {qbias0, qbias1, qbias2};
-		tiles_scatter_events<NB>(plan, geom, g_be, ev_prefix, order, dq_scan, N, map, lds, 3 * TILE, TILE, qbias, qbias_num, tid, nthreads);
+		tiles_scatter_events<NB>(plan, geom, g_be, ev_prefix, order, dq_scan, nullptr, N, map, lds, 3 * TILE, TILE, qbias, qbias_num, tid, nthreads);
 		tiles_fill_llf(plan, geom, nb, LONG, VH8, VW8, map, lds, 3 * TILE, TILE, kx_lf, kb_lf, tid, nthreads);
 	} else {
 		// multi-pass frames: dense planes in canonical order, coalesced over the canonical index
@@ -463,24 +463,24 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const 
 	J40_STAGE_SRGB_THRESHOLDS(f);
 	const ColourConsts cc = load_colour_consts(f);
 	__shared__ int32_t g_param[NB];
-	__shared__ uint32_t g_be[NB][4];
+	__shared__ uint32_t g_be[NB][4], g_dq[NB], ev_prefix[NB + 1];
+	uint32_t nevents = 0;
 	if (tid < nb) {
 		const DevVarblock vb = list[first + tid];
 		geom[tid] = varblock_geometry(plan, vb);
-		if (f.sparse_coeffs) { const uint32_t *be = plan.block_events + 4 * (size_t) vb.blk; for (int k = 0; k < 4; ++k) g_be[tid][k] = be[k]; }
+		if (f.sparse_coeffs) { const uint32_t *be = plan.block_events + 4 * (size_t) vb.blk; for (int k = 0; k < 4; ++k) g_be[tid][k] = be[k]; nevents = be[1] + be[2] + be[3]; }
 		g_param[tid] = vb.dctsel == 1 ? 1 : vb.dctsel == 2 ? 2 : vb.dctsel == 3 ? 3 : vb.dctsel <= 13 ? 9 : 10;
+		g_dq[tid] = (uint32_t) f.dq_scan_off[g_param[tid]];
 	}
+	stage_event_prefix<NB>(nevents, ev_prefix, tid);
 	if (f.sparse_coeffs) {
 		for (int32_t w = tid; w < nb * 3 * P; w += nthreads) tiles[w] = 0.0f;
 		__syncthreads();
 		const uint16_t *order = plan.pool_u16 + f.order_off[1 * 3];   // all 8x8 specials share order 1
 		const TileMap map = {8, 8, 8, 1};
 		const float qbias[3] = {f.quant_bias[0], f.quant_bias[1], f.quant_bias[2]};
-		for (int32_t b = tid >> 6; b < nb; b += nthreads >> 6) {
-			float *tile = tiles + (size_t) b * 3 * P;
-			tile_scatter_events(plan, geom[b], g_be[b], order, plan.pool_f32 + f.dq_scan_off[g_param[b]], 64, map, tile, P, qbias, f.quant_bias_num, tid & 63, 64);
-			tile_fill_llf(plan, geom[b], 8, 1, 1, map, tile, P, f.kx_lf, f.kb_lf, tid & 63, 64);
-		}
+		tiles_scatter_events<NB>(plan, geom, g_be, ev_prefix, order, plan.pool_f32, g_dq, 64, map, tiles, 3 * P, P, qbias, f.quant_bias_num, tid, nthreads);
+		tiles_fill_llf(plan, geom, nb, 8, 1, 1, map, tiles, 3 * P, P, f.kx_lf, f.kb_lf, tid, nthreads);
 	} else {
 		__syncthreads();
 		for (int32_t w = tid; w < nb * 64; w += nthreads) {

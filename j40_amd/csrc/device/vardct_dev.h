@@ -92,15 +92,16 @@ J40_DEV void tile_scatter_events(const DevPlan &plan, const VbGeom &g, const uin
 // The pixel kernels' form: the events of all `nb` blocks of a workgroup as one list shared by every lane, so that small blocks
 // with a dozen non-zeros do not cost a wavefront each. prefix[b] = events of blocks 0..b-1, prefix[b] = total for b >= nb
 // (b <= NB, a power of two); tiles of consecutive blocks are `bstride` floats apart.
+// dq_block: nullptr, or per block the offset to add to dq_scan (blocks of different transforms in one workgroup: the 8x8 specials)
 template <int NB, typename ORD, typename DQ>
-J40_DEV void tiles_scatter_events(const DevPlan &plan, const VbGeom *geom, const uint32_t (*be)[4], const uint32_t *prefix, ORD order, DQ dq_scan, int32_t n,
+J40_DEV void tiles_scatter_events(const DevPlan &plan, const VbGeom *geom, const uint32_t (*be)[4], const uint32_t *prefix, ORD order, DQ dq_scan, const uint32_t *dq_block, int32_t n,
 		const TileMap &map, float *tiles, int32_t bstride, int32_t cstride, const float quant_bias[3], float quant_bias_num, int32_t lane, int32_t nlanes) {
 	const uint32_t total = prefix[NB];
 	for (uint32_t e = (uint32_t) lane; e < total; e += (uint32_t) nlanes) {
 		int32_t b = 0;
 #pragma unroll
 		for (int32_t step = NB >> 1; step >= 1; step >>= 1) if (prefix[b + step] <= e) b += step;
-		tile_scatter_one(plan, geom[b], be[b], e - prefix[b], order, dq_scan, n, map, tiles + (size_t) b * (size_t) bstride, cstride, quant_bias, quant_bias_num);
+		tile_scatter_one(plan, geom[b], be[b], e - prefix[b], order, dq_block ? dq_scan + dq_block[b] : dq_scan, n, map, tiles + (size_t) b * (size_t) bstride, cstride, quant_bias, quant_bias_num);
 	}
 }
 // LLF corners of all `nb` blocks, one lane per (block, LLF position)

@@ -267,7 +267,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 				tile_fill_llf(plan, g, long_side, vh8, vw8, map, A.data(), 65536, f.kx_lf, f.kb_lf, 0, 1);
 			} else {
 				const uint32_t be1[1][4] = {{be[0], be[1], be[2], be[3]}}, prefix[2] = {0, be[1] + be[2] + be[3]};
-				for (int lane = 0; lane < 3; ++lane) tiles_scatter_events<1>(plan, &g, be1, prefix, order, plan.pool_f32 + f.dq_scan_off[PARAM[vb.dctsel]], sz, map, A.data(), 0, 65536, f.quant_bias, f.quant_bias_num, lane, 3);
+				for (int lane = 0; lane < 3; ++lane) tiles_scatter_events<1>(plan, &g, be1, prefix, order, plan.pool_f32 + f.dq_scan_off[PARAM[vb.dctsel]], (const uint32_t *) nullptr, sz, map, A.data(), 0, 65536, f.quant_bias, f.quant_bias_num, lane, 3);
 				tiles_fill_llf(plan, &g, 1, long_side, vh8, vw8, map, A.data(), 0, 65536, f.kx_lf, f.kb_lf, 0, 1);
 			}
 		} else for (int i = 0; i < sz; ++i) {

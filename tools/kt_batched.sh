@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/kt_batched --output-format csv -- python $R/bench.py --batch 128 --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/kt_batched.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/kt_batched --output-format csv -- env J40HIP_K2_BATCHED=1 python $R/bench.py --batch 128 --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/kt_batched.log 2>&1
 cd $R; f=$(ls gpurun_out/kt_batched/*/*kernel_stats.csv | head -1); python - "$f" <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
