@@ -547,7 +547,8 @@ static uint32_t batch_enqueue(j40hip_batch *b, void *const *rgba_dev, const size
 	for (j40hip_frame *h : b->frames) {
 		j40hip_device_state *st = h->dev;
 		if (uint32_t e = clear_before_decode(st, s)) return e;
-		if (hipMemsetAsync(st->plan.status, 0, sizeof(uint32_t) * (size_t) st->total_sections, s) != hipSuccess) return ERR_GPU;
+		// (no need to clear the status words: a batch decodes every section of every frame and the entropy kernels store
+		// each section's status unconditionally -- 256 tiny fills were 4 % of a step)
 	}
 	if (ev) (void) hipEventRecord(ev[1], s);
 	if (b->lanes_fast && !getenv("J40HIP_GENERIC_LANES")) launch_hf_lanes(b->d_plans, b->d_work, b->num_work, b->waves_per_wg, b->lanes_lds_bytes, s);
