@@ -89,6 +89,30 @@ def test_modular_2048_multi_group_bit_exact(gpu, ref):
     assert err == "" and np.array_equal(rgba, ref.decode(data)[1])
 
 
+def test_modular_16384_full_size_by_periodicity(gpu, ref):
+    """BASELINE.json config 4 at its full size: 16384 x 16384 Modular, 4096 pass groups, global RCT. The stream is the
+    1024 x 1024 picture tiled 16 x 16 (jxlsynth repeat=16 reuses the encoded group sections), so two size-independent
+    properties pin the result: the 1024 x 1024 stream decodes bit-exactly like the reference, and the large frame is that
+    picture repeated -- every one of the 4096 sections landed where it belongs."""
+    import torch
+    base = synth("modular", 1024, 1024, 21, tree=1)
+    rerr, tile = ref.decode(base)
+    assert rerr == ""
+    data = synth("modular", 16384, 16384, 21, tree=1, repeat=16)
+    fr = gpu.Frame(data)
+    assert (fr.width, fr.height) == (16384, 16384)
+    fr.upload(0)
+    out = torch.zeros((16384, 16384, 4), dtype=torch.uint8, device="cuda:0")
+    ms = fr.decode_timed(out.data_ptr(), 16384 * 4, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert fr.status() == ""
+    print("16384x16384 Modular: sections %.1f ms, transforms + pack %.1f ms" % (ms[0], ms[1]))
+    t = torch.from_numpy(tile).to("cuda:0")
+    tiled = out.view(16, 1024, 16, 1024, 4)
+    assert bool((tiled == t.view(1, 1024, 1, 1024, 4)).all())
+    fr.close()
+
+
 def test_modular_corruption_is_reported(gpu, ref):
     data = bytearray(synth("modular", 600, 300, 71, tree=1))
     rng = np.random.default_rng(11)

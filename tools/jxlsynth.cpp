@@ -652,6 +652,15 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	const int container = opt.geti("container", 0);
 	const int bpp = 8;
 	const int gdim = 1 << group_shift;
+	// repeat=K: the frame is the (W/K) x (H/K) picture tiled K x K times. Only the base picture is synthesised and encoded; its
+	// group sections are reused (no tree here looks at the stream index), which makes 16384 x 16384 streams cheap to write
+	const int repeat = opt.geti("repeat", 1);
+	const int Wfull = W, Hfull = H;
+	if (repeat > 1) {
+		if (W % (repeat * gdim) || H % (repeat * gdim)) die("repeat: the base picture must be whole groups");
+		W /= repeat; H /= repeat;
+		if (W == gdim && H == gdim) die("repeat: the base picture must have more than one group");
+	}
 	const int gcols = (W + gdim - 1) / gdim, grows = (H + gdim - 1) / gdim, num_groups = gcols * grows;
 	const int num_lf_groups = ((W + 8 * gdim - 1) / (8 * gdim)) * ((H + 8 * gdim - 1) / (8 * gdim));
 	const bool single = num_groups == 1;
@@ -853,8 +862,10 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 		bw.pad();
 		sections.push_back(bw.bytes);
 	}
+	const int gcols_full = (Wfull + gdim - 1) / gdim, grows_full = (Hfull + gdim - 1) / gdim;
+	const int num_lf_groups_full = ((Wfull + 8 * gdim - 1) / (8 * gdim)) * ((Hfull + 8 * gdim - 1) / (8 * gdim));
 	if (!single) {
-		for (int i = 0; i < num_lf_groups; ++i) sections.push_back({});
+		for (int i = 0; i < num_lf_groups_full; ++i) sections.push_back({});
 		sections.push_back({});       // HfGlobal must be empty for Modular frames (j40.h:7825)
 		for (int g = 0; g < num_groups; ++g) {
 			BitWriter bw;
@@ -868,12 +879,18 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 			bw.pad();
 			sections.push_back(bw.bytes);
 		}
+		if (repeat > 1) {   // lay the base picture's group sections out over the full frame
+			const size_t first = sections.size() - (size_t) num_groups;
+			std::vector<std::vector<uint8_t>> base(sections.begin() + (long) first, sections.end());
+			sections.resize(first);
+			for (int gy = 0; gy < grows_full; ++gy) for (int gx = 0; gx < gcols_full; ++gx) sections.push_back(base[(size_t) (gy % grows) * (size_t) gcols + (size_t) (gx % gcols)]);
+		}
 	}
 
 	// ---- codestream ----
 	BitWriter cs;
 	cs.put(0xff, 8); cs.put(0x0a, 8);
-	write_size_header(cs, W, H);
+	write_size_header(cs, Wfull, Hfull);
 	cs.put(0, 1);                       // ImageMetadata: not all_default
 	cs.put(0, 1);                       // no extra fields
 	cs.put(0, 1); cs.put(0, 2);         // integer samples, 8 bits
@@ -923,7 +940,7 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 		file.insert(file.end(), cs.bytes.begin(), cs.bytes.end());
 	}
 	if (!write_file(out, file)) die("cannot write output");
-	fprintf(stderr, "modular %dx%d: %zu bytes (%.3f bpp), %d groups%s\n", W, H, file.size(), 8.0 * (double) file.size() / ((double) W * H), num_groups, single ? " (single section)" : "");
+	fprintf(stderr, "modular %dx%d: %zu bytes (%.3f bpp), %d groups%s\n", Wfull, Hfull, file.size(), 8.0 * (double) file.size() / ((double) Wfull * Hfull), gcols_full * grows_full, single ? " (single section)" : "");
 	return 0;
 }
 
