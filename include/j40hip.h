@@ -127,6 +127,10 @@ typedef struct {
 	int8_t global_wp[12];
 } j40hip_modular_view;
 
+/* The seam for a host that parses the bitstream itself (a patched j40): a frame handle built from the
+ * view instead of from a bitstream; then j40hip_frame_upload / j40hip_frame_decode* as usual. Everything is copied. */
+J40HIP_API j40hip_frame *j40hip_frame_from_vardct_view(const j40hip_vardct_view *v, uint32_t *err);
+
 /* fill the views for a parsed frame; return 0 or a 4-char code ("TODO" for frames the hot path does not cover) */
 J40HIP_API uint32_t j40hip_frame_vardct_view(j40hip_frame *f, j40hip_vardct_view *out);
 J40HIP_API uint32_t j40hip_frame_modular_view(j40hip_frame *f, j40hip_modular_view *out);

@@ -19,6 +19,87 @@ j40hip_frame *j40hip_frame_parse(const void *buf, size_t size, int threads, uint
 	return h;
 }
 
+// The seam for a host that has done its own parsing (a patched j40: INTEGRATION.md): a frame handle built from the plan view
+// instead of from a bitstream. Everything is copied except the codestream, which must outlive the handle.
+j40hip_frame *j40hip_frame_from_vardct_view(const j40hip_vardct_view *v, uint32_t *err) {
+	uint32_t code = 0;
+	j40hip_frame *h = new j40hip_frame();
+	try {
+		if (!v || !v->codestream || v->num_passes < 1 || v->num_passes > 11 || v->num_groups < 1 || v->num_lf_groups < 1 || v->width < 1 || v->height < 1) J40HIP_RAISE("rnge");
+		// kernels read the bit window up to 16 bytes past a section: keep a padded copy
+		h->cs_storage.assign(v->codestream, v->codestream + v->codestream_size);
+		h->cs_storage.resize(v->codestream_size + 16, 0);
+		h->cs = h->cs_storage.data(); h->cs_size = v->codestream_size;
+		Frame &f = h->frame;
+		f.im.width = v->width; f.im.height = v->height; f.im.bpp = v->bpp; f.im.exp_bits = 0; f.im.xyb_encoded = true; f.im.grey = false;
+		f.im.intensity_target = v->intensity_target; f.im.quant_bias_num = v->quant_bias_num;
+		for (int i = 0; i < 3; ++i) { f.im.opsin_bias[i] = v->opsin_bias[i]; f.im.quant_bias[i] = v->quant_bias[i]; for (int j = 0; j < 3; ++j) f.im.opsin_inv_mat[i][j] = v->opsin_inv_mat[3 * i + j]; }
+		FrameHeader &fh = f.fh;
+		fh.is_modular = false; fh.do_ycbcr = false; fh.group_size_shift = 8; fh.num_passes = v->num_passes;
+		fh.x_qm_scale = v->x_qm_scale; fh.b_qm_scale = v->b_qm_scale; fh.width = v->width; fh.height = v->height;
+		fh.gcolumns = (v->width + 255) / 256; fh.grows = (v->height + 255) / 256; fh.ggcolumns = (v->width + 2047) / 2048; fh.ggrows = (v->height + 2047) / 2048;
+		fh.num_groups = (int64_t) fh.gcolumns * fh.grows; fh.num_lf_groups = (int64_t) fh.ggcolumns * fh.ggrows;
+		if (fh.num_groups != v->num_groups || fh.num_lf_groups != v->num_lf_groups) J40HIP_RAISE("rnge");
+		f.global_scale = v->global_scale; f.nb_block_ctx = v->nb_block_ctx; f.nb_qf_thr = v->nb_qf_thr; for (int i = 0; i < 3; ++i) f.nb_lf_thr[i] = v->nb_lf_thr[i];
+		f.block_ctx_map.assign(v->block_ctx_map, v->block_ctx_map + v->block_ctx_size);
+		f.inv_colour_factor = v->inv_colour_factor; f.base_corr_x = v->base_corr_x; f.base_corr_b = v->base_corr_b; f.x_factor_lf = v->x_factor_lf; f.b_factor_lf = v->b_factor_lf;
+		f.num_hf_presets = v->num_hf_presets;
+		f.num_gm_channels = 0; f.gmodular.channel.resize(v->sections_have_trailer ? 1 : 0);
+		for (int32_t p = 0; p < v->num_passes; ++p) {
+			const j40hip_codespec_view &sv = v->coeff_specs[p];
+			CodeSpec &cs = f.coeff_codespec[p];
+			cs.num_dist = sv.num_dist; cs.num_clusters = sv.num_clusters; cs.lz77_enabled = sv.lz77_enabled != 0; cs.use_prefix_code = sv.use_prefix_code != 0;
+			cs.min_symbol = sv.min_symbol; cs.min_length = sv.min_length; cs.log_alpha_size = sv.log_alpha_size;
+			cs.lz_len_cfg.split_exp = sv.lz_len_split_exp; cs.lz_len_cfg.msb_in_token = sv.lz_len_msb; cs.lz_len_cfg.lsb_in_token = sv.lz_len_lsb;
+			cs.cluster_map.assign(sv.cluster_map, sv.cluster_map + sv.num_dist + (sv.lz77_enabled ? 1 : 0));
+			cs.clusters.resize((size_t) sv.num_clusters);
+			for (int32_t c = 0; c < sv.num_clusters; ++c) {
+				const j40hip_cluster_view &cv = sv.clusters[c];
+				Cluster &cl = cs.clusters[(size_t) c];
+				cl.cfg.split_exp = cv.split_exp; cl.cfg.msb_in_token = cv.msb_in_token; cl.cfg.lsb_in_token = cv.lsb_in_token;
+				if (cs.use_prefix_code) cl.lengths.assign(cv.lengths, cv.lengths + cv.alphabet_size);
+				else cl.D.assign(cv.D, cv.D + ((size_t) 1 << sv.log_alpha_size));
+			}
+			finish_code_spec_tables(&cs);
+			for (int o = 0; o < 13; ++o) for (int c = 0; c < 3; ++c) if (const int32_t *ord = v->orders[(p * 13 + o) * 3 + c])
+				f.orders[p][o][c].assign(ord, ord + ((size_t) 1 << (LOG_ORDER_SIZE[o][0] + LOG_ORDER_SIZE[o][1])));
+		}
+		for (int i = 0; i < 17; ++i) if (v->dq_matrix[i]) {
+			DqMatrix &dq = f.dq_matrix[i];
+			dq.params.resize((size_t) v->dq_size[i]);
+			for (int32_t k = 0; k < v->dq_size[i]; ++k) for (int c = 0; c < 3; ++c) dq.params[(size_t) k][(size_t) c] = v->dq_matrix[i][3 * k + c];
+			dq.loaded = true;
+		}
+		f.lf_groups.resize((size_t) v->num_lf_groups);
+		for (int32_t g = 0; g < v->num_lf_groups; ++g) {
+			const j40hip_lf_group_view &gv = v->lf_groups[g];
+			LfGroup &gg = f.lf_groups[(size_t) g];
+			gg.idx = g; gg.left = gv.left; gg.top = gv.top; gg.width = gv.width; gg.height = gv.height; gg.width8 = gv.width8; gg.height8 = gv.height8; gg.width64 = gv.width64; gg.height64 = gv.height64;
+			const size_t cells = (size_t) gv.width8 * (size_t) gv.height8, c64 = (size_t) gv.width64 * (size_t) gv.height64;
+			gg.blocks.assign(gv.blocks, gv.blocks + cells); gg.lfindices.assign(gv.lfindices, gv.lfindices + cells);
+			for (int c = 0; c < 3; ++c) gg.llfcoeffs[c].assign(gv.llfcoeffs[c], gv.llfcoeffs[c] + cells);
+			gg.xfromy.assign(gv.xfromy, gv.xfromy + c64); gg.bfromy.assign(gv.bfromy, gv.bfromy + c64);
+			gg.varblocks.assign((size_t) gv.nb_varblocks, VarblockInfo{0, 0.0f, 0, 0, 0});
+			for (int32_t y = 0; y < gv.height8; ++y) for (int32_t x = 0; x < gv.width8; ++x) {   // a varblock's top-left cell names its transform
+				const int32_t cell = gv.blocks[(size_t) y * (size_t) gv.width8 + (size_t) x], sel = cell >> 20, vi = cell & 0xfffff;
+				if (sel < 2) continue;
+				if (vi >= gv.nb_varblocks || sel - 2 >= 27) J40HIP_RAISE("rnge");
+				gg.varblocks[(size_t) vi] = VarblockInfo{gv.coeffoff_qfidx[vi], gv.hfmul_inv[vi], x, y, sel - 2};
+			}
+			gg.loaded = true;
+		}
+		const size_t nsec = (size_t) v->num_passes * (size_t) v->num_groups;
+		f.toc.single = nsec == 1 && v->sections[0].bit_off != 0;
+		f.toc.pass_groups.resize(nsec);
+		for (size_t i = 0; i < nsec; ++i) { f.toc.pass_groups[i].offset = v->sections[i].byte_off; f.toc.pass_groups[i].size = v->sections[i].size; }
+		if (f.toc.single) { f.toc.single_section = f.toc.pass_groups[0]; f.single_pass_group_bitpos = v->sections[0].bit_off; }
+	} catch (const DecodeError &e) { code = e.code; }
+	catch (const std::bad_alloc &) { code = E4("!mem"); }
+	if (err) *err = code;
+	if (code) { delete h; return nullptr; }
+	return h;
+}
+
 void j40hip_frame_free(j40hip_frame *f) {
 	if (!f) return;
 	j40hip_release_device(f);

@@ -393,6 +393,26 @@ void read_code_spec(BitReader &br, int32_t num_dist, CodeSpec *spec) {  // j40.h
 	spec->num_dist = num_dist;
 }
 
+void finish_code_spec_tables(CodeSpec *spec) {
+	for (Cluster &cl : spec->clusters) {
+		if (spec->use_prefix_code) {
+			// the two zero-bit forms first (read_prefix_tree): an alphabet of one symbol, a simple code naming a single symbol (255)
+			int32_t only = -1;
+			for (size_t i = 0; i < cl.lengths.size(); ++i) if (cl.lengths[i] == 255) only = (int32_t) i;
+			if (cl.lengths.size() <= 1) { cl.fast_len = cl.max_len = 0; cl.table.assign(1, 0); cl.lengths.assign(1, 0); }
+			else if (only >= 0) { cl.fast_len = cl.max_len = 0; cl.table.assign(1, only << 16); }
+			else {
+				std::vector<int32_t> lengths(cl.lengths.begin(), cl.lengths.end());
+				for (int32_t l : lengths) if (l > 15) J40HIP_RAISE("hufd");
+				build_prefix_table(lengths, &cl);
+			}
+		} else {
+			if ((int32_t) cl.D.size() != (1 << spec->log_alpha_size)) J40HIP_RAISE("ans?");
+			build_alias_table(cl.D, spec->log_alpha_size, &cl.alias);
+		}
+	}
+}
+
 static inline int32_t cluster_token(BitReader &br, const CodeSpec *spec, const Cluster &cl, uint32_t *ans_state) {
 	if (spec->use_prefix_code) return prefix_decode(br, cl.fast_len, cl.max_len, cl.table.data());
 	return ans_decode(br, ans_state, 12 - spec->log_alpha_size, cl.alias.data());

@@ -51,6 +51,9 @@ struct CodeSpec {
 
 HybridCfg read_hybrid_cfg(BitReader &br, int32_t log_alpha_size);
 void read_cluster_map(BitReader &br, int32_t num_dist, int32_t max_allowed, int32_t *num_clusters, std::vector<uint8_t> *map);
+// builds the decoding tables (alias map / prefix LUT) of every cluster from its D / lengths (specs that were not read from a
+// bitstream: j40hip_frame_from_vardct_view). Throws DecodeError on distributions the reader would have refused.
+void finish_code_spec_tables(CodeSpec *spec);
 // num_dist < 0: LZ77 is not allowed for this spec (j40.h:2710)
 void read_code_spec(BitReader &br, int32_t num_dist, CodeSpec *spec);
 

@@ -26,3 +26,30 @@ __attribute__((visibility("default"))) uint32_t oracle_run(const void *buf, size
 	j40hip_frame_free(f);
 	return err;
 }
+
+/* the seam in the other direction: parse -> view -> j40hip_frame_from_vardct_view (a second handle that never saw the
+ * bitstream's headers) -> its view -> the oracle. mode 1: decode that second handle on the GPU instead (rgba = host buffer
+ * of width * 4 bytes per row). */
+__attribute__((visibility("default"))) uint32_t seam_roundtrip(const void *buf, size_t size, uint8_t *rgba, int mode) {
+	uint32_t err = 0;
+	int64_t info[32];
+	j40hip_vardct_view v, v2;
+	j40hip_frame *f = j40hip_frame_parse(buf, size, 1, &err), *g;
+	if (!f) return err;
+	err = j40hip_frame_vardct_view(f, &v);
+	if (err) { j40hip_frame_free(f); return err; }
+	g = j40hip_frame_from_vardct_view(&v, &err);
+	if (g) {
+		j40hip_frame_info(g, info);
+		if (mode == 1) {
+			err = j40hip_frame_upload(g, 0);
+			if (!err) err = j40hip_frame_decode_to_host(g, rgba, (size_t) info[0] * 4);
+		} else {
+			err = j40hip_frame_vardct_view(g, &v2);
+			if (!err) err = oracle_decode_vardct(&v2, rgba, NULL);
+		}
+		j40hip_frame_free(g);
+	}
+	j40hip_frame_free(f);
+	return err;
+}

@@ -113,6 +113,24 @@ def test_modular_16384_full_size_by_periodicity(gpu, ref):
     fr.close()
 
 
+def test_seam_frame_from_view_decodes_on_the_gpu(gpu, ref):
+    """the seam for a host with its own parser: parse -> plan view -> j40hip_frame_from_vardct_view -> upload -> decode gives
+    the pixels of the direct path (multi-pass, presets, custom orders, prefix codes + LZ77 among the cases)"""
+    import ctypes as C
+    D = C.CDLL(os.path.join(ROOT, "build", "liboracle_driver.so"))
+    D.seam_roundtrip.restype = C.c_uint32
+    D.seam_roundtrip.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+    for i, (name, opts) in enumerate(VARDCT_CASES + [("all_transforms", dict(maxlog=8, bctx=1, presets=2, orders=1))]):
+        w, h = (776, 520) if name == "all_transforms" else (392, 264)
+        data = synth("vardct", w, h, 81, **opts)
+        err, direct = gpu.decode(data)
+        assert err == ""
+        rgba = np.zeros((h, w, 4), np.uint8)
+        buf = C.create_string_buffer(data, len(data))
+        assert D.seam_roundtrip(buf, len(data), rgba.ctypes.data, 1) == 0, name
+        assert np.array_equal(rgba, direct), name
+
+
 def test_modular_corruption_is_reported(gpu, ref):
     data = bytearray(synth("modular", 600, 300, 71, tree=1))
     rng = np.random.default_rng(11)

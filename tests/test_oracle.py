@@ -83,3 +83,20 @@ def test_restatement_reports_reference_errors(ref, oracle):
             assert err4(err) == rerr
             seen += 1
     assert seen >= 1
+
+
+@pytest.mark.parametrize("name,opts", VARDCT_CASES + [("all_transforms", dict(maxlog=8, bctx=1, presets=2, orders=1))])
+def test_seam_frame_from_view_carries_everything(ref, built, name, opts):
+    """j40hip_frame_from_vardct_view: a handle built from the plan view alone (what a host with its own parser hands over,
+    INTEGRATION.md) yields the same view again -- the CPU checker decodes it to the reference's pixels"""
+    D = C.CDLL(os.path.join(ROOT, "build", "liboracle_driver.so"))
+    D.seam_roundtrip.restype = C.c_uint32
+    D.seam_roundtrip.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+    w, h = (776, 520) if name == "all_transforms" else (392, 264)
+    data = synth("vardct", w, h, 81, **opts)
+    rerr, expect = ref.decode(data)
+    assert rerr == ""
+    rgba = np.zeros((h, w, 4), np.uint8)
+    buf = C.create_string_buffer(data, len(data))
+    assert D.seam_roundtrip(buf, len(data), rgba.ctypes.data, 0) == 0
+    assert np.array_equal(rgba, expect)
