@@ -394,7 +394,10 @@ void read_code_spec(BitReader &br, int32_t num_dist, CodeSpec *spec) {  // j40.h
 }
 
 void finish_code_spec_tables(CodeSpec *spec) {
+	auto max_token = [](HybridCfg &c) { c.max_token = (1 << c.split_exp) + ((30 - c.split_exp) << (c.lsb_in_token + c.msb_in_token)) - 1; };   // as read_hybrid_cfg
+	max_token(spec->lz_len_cfg);
 	for (Cluster &cl : spec->clusters) {
+		max_token(cl.cfg);
 		if (spec->use_prefix_code) {
 			// the two zero-bit forms first (read_prefix_tree): an alphabet of one symbol, a simple code naming a single symbol (255)
 			int32_t only = -1;
