@@ -68,7 +68,7 @@ template <bool UNI> J40_DEV void bits_init(DevBits &b, const uint8_t *base, uint
 		else bits_set_error(b, ERR_SHRT);
 	}
 	while ((b.pos & 3) && b.pos < b.end) { b.bits |= (uint64_t) uni<UNI>((uint32_t) b.base[b.pos++]) << b.nbits; b.nbits += 8; }  // reach word alignment
-	b.ahead = uni<UNI>(bits_load32(b.base + (b.pos & ~3u)));  // inside the padded buffer even when pos == end
+	b.ahead = bits_load32(b.base + (b.pos & ~3u));  // inside the padded buffer even when pos == end; made uniform where it is consumed
 }
 
 // tops the accumulator up to >= 32 valid bits (as long as the section has bytes left); bytes past the
@@ -78,13 +78,13 @@ template <bool UNI> J40_DEV void bits_refill(DevBits &b) {
 	if (b.nbits > 32) return;
 	const uint32_t avail = b.end - b.pos;
 	if (avail >= 4) {
-		const uint32_t w = b.ahead;
+		const uint32_t w = uni<UNI>(b.ahead);   // (the readfirstlane sits here, at the use: next to the load it would wait for the load)
 		b.pos += 4;
-		b.ahead = uni<UNI>(bits_load32(b.base + b.pos));
+		b.ahead = bits_load32(b.base + b.pos);
 		b.bits |= (uint64_t) w << b.nbits;
 		b.nbits += 32;
 	} else if (avail) {
-		b.bits |= (uint64_t) (b.ahead & ((1u << (8 * avail)) - 1)) << b.nbits;
+		b.bits |= (uint64_t) (uni<UNI>(b.ahead) & ((1u << (8 * avail)) - 1)) << b.nbits;
 		b.nbits += 8 * (int32_t) avail; b.pos += avail;
 	}
 }
