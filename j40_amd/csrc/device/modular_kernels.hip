@@ -23,12 +23,13 @@ namespace j40hip {
 // walk, the symbol decode and the neighbour fetch wait on LDS instead of L2 -- a sample that was just stored to the plane is
 // not in the vector L1, and the previous pixel is the next one's W neighbour.
 template <bool IN_LDS>
-__global__ void __launch_bounds__(64) k_modular_sections(DevModPlan plan, int32_t rows_width, int32_t wp_width) {
+__global__ void __launch_bounds__(64) k_modular_sections(DevModPlan plan, int32_t first_section, int32_t rows_width, int32_t wp_width) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t mod_lds[];
 	const int32_t lane = threadIdx.x;
-	const DevModSection &msec = plan.sections[blockIdx.x];
+	const int32_t s = first_section + (int32_t) blockIdx.x;
+	const DevModSection &msec = plan.sections[s];
 	const DevCodeSpec &spec = plan.spec[msec.spec_idx];
-	ModTables t = mod_tables_in_hbm(plan, blockIdx.x);
+	ModTables t = mod_tables_in_hbm(plan, s);
 	if (IN_LDS) {
 		auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
 		const int32_t tree_nodes = msec.tree_nodes;
@@ -51,14 +52,13 @@ __global__ void __launch_bounds__(64) k_modular_sections(DevModPlan plan, int32_
 		if (wp_width) { t.wp_errors = l_wp; t.wp_errors_width = wp_width; }
 		__syncthreads();
 	}
-	const int32_t s = blockIdx.x;
 	const uint32_t err = decode_modular_section<true, IN_LDS>(plan, t, s);
 	if (lane == 0) plan.status[s] = err;
 }
 
 // one workgroup per section that lists transforms of its own; runs after K3 (kernel boundary = the planes are visible)
-__global__ void __launch_bounds__(256) k_section_inverse_rcts(DevModPlan plan) {
-	section_inverse_rcts(plan, (int32_t) blockIdx.x, (int32_t) threadIdx.x, 256);
+__global__ void __launch_bounds__(256) k_section_inverse_rcts(DevModPlan plan, int32_t first_section) {
+	section_inverse_rcts(plan, first_section + (int32_t) blockIdx.x, (int32_t) threadIdx.x, 256);
 }
 
 __global__ void __launch_bounds__(256) k_inverse_rct(int16_t *a, int16_t *b, int16_t *c, size_t n, int32_t type7) {
@@ -121,7 +121,8 @@ __global__ void __launch_bounds__(256) k_pack_planes(const int16_t *r, const int
 
 static unsigned grid_for(size_t n) { size_t b = (n + 255) / 256; return (unsigned) (b < 1 ? 1 : b > 8192 ? 8192 : b); }
 
-void launch_modular_sections(const DevModPlan &plan, int32_t num_sections, const ModLaunchInfo &info, hipStream_t stream) {
+// sections [first_section, first_section + num_sections): the passes of a multi-pass frame are launched one after the other
+void launch_modular_sections(const DevModPlan &plan, int32_t first_section, int32_t num_sections, const ModLaunchInfo &info, hipStream_t stream) {
 	if (num_sections <= 0) return;
 	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
 	const uint32_t wp_bytes = info.uses_wp ? align16(40u * (uint32_t) info.max_width) : 0;
@@ -130,13 +131,13 @@ void launch_modular_sections(const DevModPlan &plan, int32_t num_sections, const
 	if (lds <= 156u * 1024u) {
 		static bool configured = false;
 		if (!configured) { (void) hipFuncSetAttribute((const void *) k_modular_sections<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); configured = true; }
-		hipLaunchKernelGGL(k_modular_sections<true>, dim3((unsigned) num_sections), dim3(64), lds, stream, plan, info.max_width + 4, info.uses_wp ? info.max_width : 0);
+		hipLaunchKernelGGL(k_modular_sections<true>, dim3((unsigned) num_sections), dim3(64), lds, stream, plan, first_section, info.max_width + 4, info.uses_wp ? info.max_width : 0);
 	} else {
-		hipLaunchKernelGGL(k_modular_sections<false>, dim3((unsigned) num_sections), dim3(64), 0, stream, plan, 0, 0);
+		hipLaunchKernelGGL(k_modular_sections<false>, dim3((unsigned) num_sections), dim3(64), 0, stream, plan, first_section, 0, 0);
 	}
 }
-void launch_section_inverse_rcts(const DevModPlan &plan, int32_t num_sections, hipStream_t stream) {
-	if (num_sections > 0) hipLaunchKernelGGL(k_section_inverse_rcts, dim3((unsigned) num_sections), dim3(256), 0, stream, plan);
+void launch_section_inverse_rcts(const DevModPlan &plan, int32_t first_section, int32_t num_sections, hipStream_t stream) {
+	if (num_sections > 0) hipLaunchKernelGGL(k_section_inverse_rcts, dim3((unsigned) num_sections), dim3(256), 0, stream, plan, first_section);
 }
 void launch_inverse_rct(int16_t *a, int16_t *b, int16_t *c, size_t n, int32_t type7, hipStream_t stream) {
 	if (n) hipLaunchKernelGGL(k_inverse_rct, dim3(grid_for(n)), dim3(256), 0, stream, a, b, c, n, type7);

@@ -99,7 +99,7 @@ struct j40hip_device_state {
 	HfLaunchInfo hf;
 	// Modular frames
 	DevModPlan mod;
-	int32_t mod_sections = 0;
+	int32_t mod_sections = 0, mod_passes = 1, mod_sections_per_pass = 0;   // sections = LfGlobal's (0 or 1) + passes * per_pass
 	bool mod_local_rcts = false;
 	ModLaunchInfo mod_info = {0, 0, 0, 0, 0, 0};
 	std::vector<uint32_t> mod_section_offsets;
@@ -168,7 +168,7 @@ static uint32_t upload_modular(j40hip_frame *h, int device) {
 	plan.sections = st->upload(hp.sections.data(), hp.sections.size(), s, ok);
 	st->mod_local_rcts = !hp.local_rct.empty();
 	if (st->mod_local_rcts) plan.local_rct = st->upload(hp.local_rct.data(), hp.local_rct.size(), s, ok);
-	st->mod_sections = (int32_t) hp.sections.size();
+	st->mod_sections = (int32_t) hp.sections.size(); st->mod_passes = hp.num_passes; st->mod_sections_per_pass = hp.sections_per_pass;
 	st->mod_info = {hp.max_tree_nodes, hp.max_num_dist, hp.max_clusters, hp.max_table_bytes, hp.frame.max_width, hp.any_wp ? 1 : 0};
 	for (const DevModSection &sec : hp.sections) st->mod_section_offsets.push_back(sec.byte_off);
 	const int32_t nch = hp.frame.num_channels;
@@ -248,8 +248,12 @@ static uint32_t decode_modular(j40hip_frame *h, void *rgba_dev, size_t stride_by
 	if (ms3) (void) hipEventRecord(st->ev[0], s);
 	if (hipMemsetAsync(plan.status, 0, sizeof(uint32_t) * ((size_t) st->total_sections + 1), s) != hipSuccess) return ERR_GPU;
 	if (ms3) (void) hipEventRecord(st->ev[1], s);
-	launch_modular_sections(plan, st->mod_sections, st->mod_info, s);
-	if (st->mod_local_rcts) launch_section_inverse_rcts(plan, st->mod_sections, s);
+	// LfGlobal's section and the first pass together, then every further pass on its own: a pass rewrites what the one before
+	// it wrote (j40.h:7025-7033), so they must not overlap; the sections' own RCTs only matter for the last pass
+	const int32_t per_pass = st->mod_sections_per_pass, lead = st->mod_sections - per_pass * st->mod_passes;
+	launch_modular_sections(plan, 0, lead + per_pass, st->mod_info, s);
+	for (int32_t p = 1; p < st->mod_passes; ++p) launch_modular_sections(plan, lead + p * per_pass, per_pass, st->mod_info, s);
+	if (st->mod_local_rcts) launch_section_inverse_rcts(plan, lead + (st->mod_passes - 1) * per_pass, per_pass, s);
 	if (ms3) (void) hipEventRecord(st->ev[2], s);
 	for (const auto &op : st->mod_ops) {
 		if (op.kind == 0) launch_inverse_rct(op.a, op.b, op.c, op.n, op.p0, s);

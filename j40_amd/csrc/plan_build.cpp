@@ -284,9 +284,11 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 	} else return ERR_TODO;
 	if (!fr.toc.single && fr.num_gm_channels < nch) {
 		const int32_t num_groups = (int32_t) fr.fh.num_groups;
-		if (fr.fh.num_passes != 1) return ERR_TODO;
-		for (int32_t g = 0; g < num_groups; ++g) {
-			const Section &ps = fr.toc.pass_groups[(size_t) g];
+		// every pass codes all channels of every group again (the reference's j40__pass_group ignores the passes' shift
+		// ranges, j40.h:7025, 3702): decoded in order, the last pass stays
+		hp->num_passes = fr.fh.num_passes; hp->sections_per_pass = num_groups;
+		for (int32_t pass = 0; pass < fr.fh.num_passes; ++pass) for (int32_t g = 0; g < num_groups; ++g) {
+			const Section &ps = fr.toc.pass_groups[(size_t) pass * (size_t) num_groups + (size_t) g];
 			const GroupInfo gi = group_info(fr.fh, g);
 			const LfGroup &gg = fr.lf_groups[(size_t) gi.ggidx];
 			// the section starts with a Modular header for the group's sub-image (j40.h:7024-7026)
@@ -300,12 +302,13 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 			s.local_off = (int32_t) (hp->local_rct.size() / 2);
 			for (const Transform &t : m.transforms) {
 				if (t.kind != Transform::RCT || t.begin_c < 0 || t.begin_c + 3 > nch - fr.num_gm_channels) return ERR_TODO;
+				if (pass + 1 < fr.fh.num_passes) continue;   // overwritten by the next pass before anything reads it
 				hp->local_rct.push_back(t.begin_c); hp->local_rct.push_back(t.rct_type);
 				++s.local_count;
 			}
 			s.byte_off = (uint32_t) ps.offset; s.size = (uint32_t) ps.size; s.bit_off = (uint32_t) br.bit_position();
 			s.gx = gg.left + gi.gx_in_gg; s.gy = gg.top + gi.gy_in_gg; s.gw = gi.gw; s.gh = gi.gh;
-			s.sidx = (int32_t) (1 + 3 * fr.fh.num_lf_groups + 17 + g);
+			s.sidx = (int32_t) (1 + 3 * fr.fh.num_lf_groups + 17 + pass * num_groups + g);
 			s.first_channel = fr.num_gm_channels; s.num_channels = nch - fr.num_gm_channels;
 			wp_bytes(m.wp, s.wp);
 			attach(m, &s);

@@ -57,7 +57,8 @@ struct HostModPlan {
 	std::vector<CodeSpec> host_specs;                     // the parsed form of `specs`, same order (for the oracle's view)
 	int32_t max_tree_nodes = 0, max_num_dist = 0, max_clusters = 0; uint32_t max_table_bytes = 0;   // over the specs / trees, for the kernel's LDS layout
 	bool any_lz77 = false, any_wp = false;
-	std::vector<DevModSection> sections;
+	std::vector<DevModSection> sections;                  // LfGlobal's channel data, then num_passes * sections_per_pass group sections, pass-major
+	int32_t num_passes = 1, sections_per_pass = 0;
 	std::vector<int32_t> local_rct;                       // {begin_c, rct_type} pairs, DevModSection::local_off / local_count
 	std::vector<int32_t> plane_w, plane_h, plane_meta;   // coded channels
 	std::vector<Transform> transforms;                    // global transforms in coded order

@@ -68,6 +68,8 @@ MODULAR_CASES = [
     ("local_tree_under_wp_global", 520, 520, dict(localtree=2, tree=2, groupshift=7)),
     ("flagged_xyb_rendered_raw", 300, 200, dict(xyb=1)),                     # the reference applies no colour transform to Modular frames
     ("flagged_ycbcr_rendered_raw_alpha", 300, 200, dict(ycbcr=1, alpha=1)),
+    ("two_passes_last_one_stays", 600, 300, dict(passes=2, tree=1)),         # every pass codes the groups again (j40.h:7025-7033)
+    ("three_passes_local_rct_local_tree_alpha", 520, 300, dict(passes=3, localrct=4, localtree=2, alpha=1)),
     ("local_rct_per_group", 600, 300, dict(localrct=4, alpha=1)),            # every group lists RCTs of its own (one or two)
     ("local_rct_local_tree_no_global_rct", 520, 520, dict(localrct=13, localtree=2, rct=-1, groupshift=7)),
 ]

@@ -654,7 +654,9 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	const int gdim = 1 << group_shift;
 	// repeat=K: the frame is the (W/K) x (H/K) picture tiled K x K times. Only the base picture is synthesised and encoded; its
 	// group sections are reused (no tree here looks at the stream index), which makes 16384 x 16384 streams cheap to write
+	const int num_passes = opt.geti("passes", 1);
 	const int repeat = opt.geti("repeat", 1);
+	if (repeat > 1 && num_passes > 1) die("repeat and passes do not combine");
 	const int Wfull = W, Hfull = H;
 	if (repeat > 1) {
 		if (W % (repeat * gdim) || H % (repeat * gdim)) die("repeat: the base picture must be whole groups");
@@ -818,19 +820,21 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 		// meta channels (palette) are decoded inside LfGlobal (num_gm_channels = nb_meta_channels, j40.h:6332)
 		encs.emplace_back(gspec);
 		if (nb_meta) { std::vector<Channel> meta(ch.begin(), ch.begin() + nb_meta); encode_image(meta, 0, 0, encs.back()); }
-		for (int g = 0; g < num_groups; ++g) {
+		// passes=P: every pass codes the whole group again (the reference decodes and pastes all channels in each pass,
+		// j40.h:7025-7033, so the last pass is what stays); earlier passes carry a perturbed picture
+		for (int pass = 0; pass < num_passes; ++pass) for (int g = 0; g < num_groups; ++g) {
 			const int gx = (g % gcols) * gdim, gy = (g / gcols) * gdim, gw = std::min(gdim, W - gx), gh = std::min(gdim, H - gy);
 			std::vector<Channel> sub;
 			for (int c = nb_meta; c < total_ch; ++c) {
 				Channel s2(gw, gh);
-				for (int y = 0; y < gh; ++y) for (int x = 0; x < gw; ++x) s2.at(x, y) = ch[(size_t) c].at(gx + x, gy + y);
+				for (int y = 0; y < gh; ++y) for (int x = 0; x < gw; ++x) s2.at(x, y) = ch[(size_t) c].at(gx + x, gy + y) ^ (pass + 1 < num_passes ? ((x + 2 * y + pass) & 3) : 0);
 				sub.push_back(s2);
 			}
-			const bool local = local_tree && (((size_t) g + 1) & 1);
+			const bool local = local_tree && (((size_t) (pass * num_groups + g) + 1) & 1);
 			// localrct=K: the group's header lists one or two RCTs of its own (j40.h:3757-3773), type varying by group
 			group_tr.emplace_back();
 			if (local_rct >= 0 && sub.size() >= 3) {
-				const int t1 = (local_rct + 5 * g) % 42, t2 = (3 * t1 + 1) % 42;
+				const int t1 = (local_rct + 5 * (g + pass)) % 42, t2 = (3 * t1 + 1) % 42;
 				TransformW a; a.kind = 0; a.begin_c = 0; a.rct_type = t1; group_tr.back().push_back(a);
 				if (t1 / 7 == 0 && t1 % 7 != 2) forward_rct(sub, 0, t1);
 				if (g % 3 == 2) {
@@ -840,7 +844,7 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 			}
 			encs.emplace_back(gspec);
 			// stream index of a pass group (j40.h:7013): 1 + 3 * num_lf_groups + 17 + pass * num_groups + gidx
-			encode_image(sub, 0, 1 + 3 * num_lf_groups + 17 + g, encs.back(), local);
+			encode_image(sub, 0, 1 + 3 * num_lf_groups + 17 + pass * num_groups + g, encs.back(), local);
 		}
 	}
 	std::vector<CodeSpecW> lspec(encs.size(), lspec_proto);
@@ -867,7 +871,7 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	if (!single) {
 		for (int i = 0; i < num_lf_groups_full; ++i) sections.push_back({});
 		sections.push_back({});       // HfGlobal must be empty for Modular frames (j40.h:7825)
-		for (int g = 0; g < num_groups; ++g) {
+		for (int g = 0; g < num_passes * num_groups; ++g) {
 			BitWriter bw;
 			if (local_tree && (((size_t) g + 1) & 1)) {
 				write_modular_header(bw, false, nullptr, group_tr[(size_t) g]);
@@ -917,7 +921,11 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	cs.put(0, 2);                       // log_upsampling
 	if (alpha) cs.put(0, 2);            // extra channel upsampling
 	cs.put((uint64_t) (group_shift - 7), 2);
-	cs.u32(1, 1, 0, 2, 0, 3, 0, 4, 3);  // one pass
+	cs.u32(num_passes, 1, 0, 2, 0, 3, 0, 4, 3);
+	if (num_passes > 1) {
+		cs.u32(0, 0, 0, 1, 0, 2, 0, 3, 1);                  // num_ds = 0
+		for (int i = 0; i < num_passes - 1; ++i) cs.put(0, 2);  // shift[i]
+	}
 	cs.put(0, 1);                       // have_crop
 	cs.u32(0, 0, 0, 1, 0, 2, 0, 3, 2);  // blend mode (colour)
 	if (alpha) cs.u32(0, 0, 0, 1, 0, 2, 0, 3, 2);  // blend mode (extra channel)
