@@ -79,15 +79,15 @@ def main():
         import __graft_entry__
         if not os.path.exists(j40_amd.LIB_PATH) or not os.path.exists(os.path.join(ROOT, "build", "jxlsynth")):
             __graft_entry__.build()
+    if not torch.cuda.is_available() or j40_amd.device_count() == 0:
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)   # before the first collective: RCCL binds a rank to its current device
+    dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend="nccl", device_id=dev)
         dist.barrier()
-    if not torch.cuda.is_available() or j40_amd.device_count() == 0:
-        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
     W, H = args.width, args.height
     # every rank decodes its own frame (distinct seed) unless the groups of one frame are sharded
