@@ -131,6 +131,37 @@ def test_seam_frame_from_view_decodes_on_the_gpu(gpu, ref):
         assert np.array_equal(rgba, direct), name
 
 
+def test_reference_cli_source_unchanged_runs_on_the_hip_library(gpu, tmp_path):
+    """drop-in at the source level: the reference's own command-line decoder (dj40.c, not a line changed) built against
+    include/j40.h + libj40hip.so (oracle/Makefile `dropin`) writes the same PNGs as the reference's own build, and reports a
+    corrupt file the same way"""
+    import subprocess
+    exe_ref, exe_hip = os.path.join(ROOT, "oracle", "_ref", "dj40-ref"), os.path.join(ROOT, "oracle", "_ref", "dj40-hip")
+    if not (os.path.exists(exe_ref) and os.path.exists(exe_hip)):
+        pytest.skip("oracle/_ref/dj40-* not built (needs the reference sources at build time)")
+    cases = [("modular", 600, 300, dict(tree=1, alpha=1)), ("modular", 256, 256, dict(alpha=1, prefix=1, lz77=1)),
+             ("vardct", 520, 264, dict()), ("vardct", 776, 520, dict(maxlog=8, bctx=1, presets=2, orders=1))]
+    for i, (mode, w, h, opts) in enumerate(cases):
+        src = tmp_path / ("in%d.jxl" % i)
+        src.write_bytes(synth(mode, w, h, 300 + i, **opts))
+        outs = []
+        for exe in (exe_ref, exe_hip):
+            png = tmp_path / ("out%d_%s.png" % (i, os.path.basename(exe)))
+            r = subprocess.run([exe, str(src), str(png)], capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, (exe, r.stderr)
+            assert "%dx%d frame read." % (w, h) in r.stderr
+            outs.append(png.read_bytes())
+        if outs[0] != outs[1]:   # VarDCT may differ by one level
+            from PIL import Image
+            import io
+            a, b = (np.asarray(Image.open(io.BytesIO(o))).astype(np.int32) for o in outs)
+            assert mode == "vardct" and np.abs(a - b).max() <= 1
+    bad = bytearray(synth("vardct", 520, 264, 300)); bad[len(bad) // 2] ^= 0x55
+    src = tmp_path / "bad.jxl"; src.write_bytes(bytes(bad))
+    msgs = [subprocess.run([exe, str(src), str(tmp_path / "bad.png")], capture_output=True, text=True, timeout=120) for exe in (exe_ref, exe_hip)]
+    assert msgs[0].returncode == msgs[1].returncode == 1 and msgs[0].stderr == msgs[1].stderr, (msgs[0].stderr, msgs[1].stderr)
+
+
 def test_modular_corruption_is_reported(gpu, ref):
     data = bytearray(synth("modular", 600, 300, 71, tree=1))
     rng = np.random.default_rng(11)
