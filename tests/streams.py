@@ -44,6 +44,7 @@ VARDCT_CASES = [
     ("hf_lz77", dict(hflz77=1)),                            # ... with LZ77 copies
     ("hf_prefix_lz77_passes", dict(hfprefix=1, hflz77=1, passes=2)),
     ("icc_profile", dict(icc=700)),
+    ("permuted_toc_two_passes", dict(permute=1, passes=2)),  # sections stored in a shuffled order, Lehmer-coded permutation in the TOC
     ("alpha_extra_channel", dict(alpha=1)),                 # Modular sub-image after the HF coefficients of every group; the reference outputs opaque pixels                         # want_icc: the ICC stream is decoded and discarded like in the reference
 ]
 
@@ -70,6 +71,7 @@ MODULAR_CASES = [
     ("flagged_ycbcr_rendered_raw_alpha", 300, 200, dict(ycbcr=1, alpha=1)),
     ("two_passes_last_one_stays", 600, 300, dict(passes=2, tree=1)),         # every pass codes the groups again (j40.h:7025-7033)
     ("three_passes_local_rct_local_tree_alpha", 520, 300, dict(passes=3, localrct=4, localtree=2, alpha=1)),
+    ("permuted_toc", 600, 300, dict(permute=1, tree=1, alpha=1)),
     ("local_rct_per_group", 600, 300, dict(localrct=4, alpha=1)),            # every group lists RCTs of its own (one or two)
     ("local_rct_local_tree_no_global_rct", 520, 520, dict(localrct=13, localtree=2, rct=-1, groupshift=7)),
 ]

@@ -87,6 +87,38 @@ static void write_size_header(BitWriter &bw, int w, int h) {  // inverse of j40.
 
 static void write_toc_entry(BitWriter &bw, size_t size) { bw.u32((int64_t) size, 0, 10, 1024, 14, 17408, 22, 4211712, 30); }  // j40.h:5529
 
+// TOC + sections (j40.h:5505-5543). permute != 0: the sections are stored in a shuffled order and the TOC carries the
+// Lehmer-coded permutation that puts them back (the decoder applies it to the list of stored sections, j40.h:5540).
+static void write_toc_and_sections(BitWriter &cs, const std::vector<std::vector<uint8_t>> &sections, int permute, SplitMix64 &rng) {
+	const size_t n = sections.size();
+	std::vector<size_t> stored_at(n);   // logical section i is the stored_at[i]-th stored one
+	for (size_t i = 0; i < n; ++i) stored_at[i] = i;
+	if (!permute || n < 3) cs.put(0, 1);
+	else {
+		const size_t end = n - 1 - (size_t) rng.below((uint32_t) std::min<size_t>(n - 2, 5));
+		std::vector<uint32_t> lehmer(end);
+		for (size_t i = 0; i < end; ++i) lehmer[i] = rng.below((uint32_t) std::min<size_t>(n - i, 40));
+		{   // what the decoder's j40__apply_permutation makes of the stored list
+			size_t *target = stored_at.data();
+			for (uint32_t x : lehmer) { size_t tmp = target[x]; memmove(target + 1, target, sizeof(size_t) * x); target[0] = tmp; ++target; }
+		}
+		cs.put(1, 1);
+		CodeSpecW pspec; pspec.init(8, std::vector<uint8_t>(8, 0), 1); pspec.log_alpha = 6; pspec.cfg[0] = HybridCfg{4, 1, 0};
+		StreamEncoder penc(pspec);
+		penc.add((uint32_t) std::min(7, ceil_lg((uint32_t) n + 1)), (uint32_t) end);   // j40.h:5437
+		uint32_t prev = 0;
+		for (uint32_t x : lehmer) { penc.add((uint32_t) std::min(7, ceil_lg(prev + 1)), x); prev = x; }
+		count_stream(pspec, penc);
+		write_code_spec(cs, pspec); penc.flush(cs);
+	}
+	cs.pad();
+	std::vector<const std::vector<uint8_t> *> stored(n, nullptr);
+	for (size_t i = 0; i < n; ++i) stored[stored_at[i]] = &sections[i];
+	for (const auto *s : stored) write_toc_entry(cs, s->size());
+	cs.pad();
+	for (const auto *s : stored) cs.append_bytes(*s);
+}
+
 // transform table: the decoder's view (J40__DCT_SELECT, j40.h:4591): log rows, log columns, order
 static const int8_t DCTSEL[27][3] = {
 	{3,3,0},{3,3,1},{3,3,1},{3,3,1},{4,4,2},{5,5,3},{4,3,4},{3,4,4},{5,3,5},{3,5,5},{5,4,6},{4,5,6},{3,3,1},{3,3,1},
@@ -580,11 +612,7 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 		cs.u64(0);                          // frame extensions
 	}
 	// TOC (j40.h:5505-5531)
-	cs.put(0, 1);  // not permuted
-	cs.pad();
-	for (const auto &s : sections) write_toc_entry(cs, s.size());
-	cs.pad();
-	for (const auto &s : sections) cs.append_bytes(s);
+	write_toc_and_sections(cs, sections, opt.geti("permute", 0), rng);
 
 	std::vector<uint8_t> file;
 	if (!container) file = cs.bytes;
@@ -933,11 +961,7 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	cs.u32(0, 0, 0, 0, 4, 16, 5, 48, 10);
 	cs.put(0, 1); cs.put(0, 1); cs.put(0, 2); cs.u64(0);   // restoration: explicit, gab off, epf 0, no extensions
 	cs.u64(0);                          // frame extensions
-	cs.put(0, 1);                       // TOC not permuted
-	cs.pad();
-	for (const auto &sct : sections) write_toc_entry(cs, sct.size());
-	cs.pad();
-	for (const auto &sct : sections) cs.append_bytes(sct);
+	write_toc_and_sections(cs, sections, opt.geti("permute", 0), rng);
 	std::vector<uint8_t> file = cs.bytes;
 	if (container) {
 		static const uint8_t HEAD[32] = {0, 0, 0, 0x0c, 'J', 'X', 'L', ' ', 0x0d, 0x0a, 0x87, 0x0a, 0, 0, 0, 0x14, 'f', 't', 'y', 'p', 'j', 'x', 'l', ' ', 0, 0, 0, 0, 'j', 'x', 'l', ' '};
