@@ -46,6 +46,8 @@ VARDCT_CASES = [
     ("icc_profile", dict(icc=700)),
     ("permuted_toc_two_passes", dict(permute=1, passes=2)),  # sections stored in a shuffled order, Lehmer-coded permutation in the TOC
     ("alpha_extra_channel", dict(alpha=1)),                 # Modular sub-image after the HF coefficients of every group; the reference outputs opaque pixels                         # want_icc: the ICC stream is decoded and discarded like in the reference
+    ("bit_depth_12", dict(bpp=12, cfl=1)),                  # more than 8 bits: the long way through the transfer curve, scaling to 8 bits at the end
+    ("bit_depth_15", dict(bpp=15)),
 ]
 
 # the Modular feature matrix (width, height, options); all decode bit-exactly
@@ -74,4 +76,6 @@ MODULAR_CASES = [
     ("permuted_toc", 600, 300, dict(permute=1, tree=1, alpha=1)),
     ("local_rct_per_group", 600, 300, dict(localrct=4, alpha=1)),            # every group lists RCTs of its own (one or two)
     ("local_rct_local_tree_no_global_rct", 520, 520, dict(localrct=13, localtree=2, rct=-1, groupshift=7)),
+    ("bit_depth_10", 600, 300, dict(bpp=10, tree=1)),
+    ("bit_depth_14_wp_rct", 300, 200, dict(bpp=14, tree=2, rct=13)),
 ]

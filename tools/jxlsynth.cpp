@@ -87,6 +87,12 @@ static void write_size_header(BitWriter &bw, int w, int h) {  // inverse of j40.
 
 static void write_toc_entry(BitWriter &bw, size_t size) { bw.u32((int64_t) size, 0, 10, 1024, 14, 17408, 22, 4211712, 30); }  // j40.h:5529
 
+// BitDepth of ImageMetadata (j40.h:3175-3190): integer samples, U32(8, 10, 12, 1 + u(6)) bits
+static void write_bit_depth(BitWriter &cs, int bpp) {
+	cs.put(0, 1);   // not float
+	if (bpp == 8) cs.put(0, 2); else if (bpp == 10) cs.put(1, 2); else if (bpp == 12) cs.put(2, 2); else { cs.put(3, 2); cs.put((uint64_t) (bpp - 1), 6); }
+}
+
 // TOC + sections (j40.h:5505-5543). permute != 0: the sections are stored in a shuffled order and the TOC carries the
 // Lehmer-coded permutation that puts them back (the decoder applies it to the list of stored sections, j40.h:5540).
 static void write_toc_and_sections(BitWriter &cs, const std::vector<std::vector<uint8_t>> &sections, int permute, SplitMix64 &rng) {
@@ -560,7 +566,19 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 	cs.put(0xff, 8); cs.put(0x0a, 8);
 	write_size_header(cs, W, H);
 	const int icc_bytes = opt.geti("icc", 0);                // > 0: ColourEncoding with want_icc and an ICC stream of that many coded bytes
-	if (!icc_bytes && !with_alpha) {
+	const int img_bpp = opt.geti("bpp", 8);   // 9..15: the renderer's scaling to 8 bits and the long way through the transfer curve get work
+	if (img_bpp != 8 && (icc_bytes || with_alpha)) die("vardct: bpp combines with neither icc nor alpha here");
+	if (img_bpp != 8) {
+		cs.put(0, 1);                       // ImageMetadata: not all_default
+		cs.put(0, 1);                       // no extra fields
+		write_bit_depth(cs, img_bpp);
+		cs.put(1, 1);                       // modular_16bit_buffers
+		cs.put(0, 2);                       // no extra channels
+		cs.put(1, 1);                       // xyb_encoded
+		cs.put(1, 1);                       // ColourEncoding.all_default
+		cs.put(0, 2);                       // extensions
+		cs.put(1, 1);                       // default_m
+	} else if (!icc_bytes && !with_alpha) {
 		cs.put(1, 1);   // ImageMetadata.all_default: 8-bit, XYB, no extra channels
 		cs.put(1, 1);   // default_m
 	} else if (!icc_bytes) {
@@ -678,7 +696,9 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	const int tree_kind = opt.geti("tree", 0);            // 0 gradient, 1 per-channel leaves + property splits, 2 weighted predictor, 3 previous-channel properties
 	const int palette = opt.geti("palette", 0);           // 0 none, 1 plain palette, 2 with deltas / synthetic colours, 3 with delta prediction
 	const int container = opt.geti("container", 0);
-	const int bpp = 8;
+	const int bpp = opt.geti("bpp", 8);   // 8..15 (16-bit buffers)
+	if (bpp < 8 || bpp > 15) die("modular: bpp 8..15");
+	if (bpp != 8 && alpha) die("modular: the default alpha channel has 8 bits; the reference refuses a different colour depth");
 	const int gdim = 1 << group_shift;
 	// repeat=K: the frame is the (W/K) x (H/K) picture tiled K x K times. Only the base picture is synthesised and encoded; its
 	// group sections are reused (no tree here looks at the stream index), which makes 16384 x 16384 streams cheap to write
@@ -708,7 +728,7 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 		for (int c = 0; c < 3; ++c) {
 			int v = (int) (rgb[c] * 255.0f);
 			v = (v / 6) * 6 + (int) (Picture::hash01((uint64_t) x * 7919 + (uint64_t) y * 104729 + (uint64_t) c + seed) < 0.08f);
-			ch[(size_t) (colour0 + c)].at(x, y) = std::min(255, std::max(0, v));
+			ch[(size_t) (colour0 + c)].at(x, y) = std::min(255, std::max(0, v)) * ((1 << bpp) - 1) / 255;
 		}
 		if (alpha) ch[3].at(x, y) = ((x / 37 + y / 29) & 3) == 0 ? 128 + ((x * 3 + y) & 63) : 255;
 	}
@@ -925,8 +945,7 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	write_size_header(cs, Wfull, Hfull);
 	cs.put(0, 1);                       // ImageMetadata: not all_default
 	cs.put(0, 1);                       // no extra fields
-	cs.put(0, 1); cs.put(0, 2);         // integer samples, 8 bits
-	(void) bpp;
+	write_bit_depth(cs, bpp);
 	cs.put(1, 1);                       // modular_16bit_buffers
 	if (alpha) { cs.put(1, 2); cs.put(1, 1); } else cs.put(0, 2);   // num_extra_channels (+ d_alpha)
 	// xyb=1 / ycbcr=1: the frame is flagged XYB / YCbCr; the reference applies no colour transform to Modular
