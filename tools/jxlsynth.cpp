@@ -87,6 +87,44 @@ static void write_size_header(BitWriter &bw, int w, int h) {  // inverse of j40.
 
 static void write_toc_entry(BitWriter &bw, size_t size) { bw.u32((int64_t) size, 0, 10, 1024, 14, 17408, 22, 4211712, 30); }  // j40.h:5529
 
+// IEEE half for values that are exactly representable (all the parameters below are)
+static uint32_t f16_bits(float v) {
+	if (v == 0.0f) return 0;
+	uint32_t u; memcpy(&u, &v, 4);
+	const uint32_t sign = u >> 31, mant = u & 0x7fffff; const int e = (int) ((u >> 23) & 0xff) - 127 + 15;
+	if (e <= 0 || e >= 31 || (mant & 0x1fff)) die("f16: value not exactly representable");
+	return sign << 15 | (uint32_t) e << 10 | mant >> 13;
+}
+
+// dq=1: the dequantisation matrices of HfGlobal in their coded forms (j40.h:4696-4760) instead of "all default": band
+// parameters for DCT8, the Hornuss, DCT2x2, DCT4x4, DCT4x8 and AFV forms (the reference accepts the coded forms only for the
+// 8x8 matrices, band parameters included: HOW[6].requires8x8, j40.h:4751); values near the library's, rounded to halves. Scaled parameters are stored divided by 64.
+static void write_dq_matrices(BitWriter &bw) {
+	auto params = [&](const std::vector<std::array<float, 3>> &p, size_t first, size_t count, size_t scaled) {   // channel-major, as read (j40.h:4738)
+		for (int c = 0; c < 3; ++c) for (size_t j = 0; j < count; ++j) bw.put(f16_bits(p[first + j][(size_t) c] / (j < scaled ? 64.0f : 1.0f)), 16);
+	};
+	auto bands = [&](const std::vector<std::array<float, 3>> &p) { bw.put((uint64_t) (p.size() - 1), 4); params(p, 0, p.size(), 1); };
+	const std::vector<std::array<float, 3>> dct8 = {{3136, 576, 512}, {0, 0, -2}, {-0.5f, -0.25f, -1}, {-0.5f, -0.25f, 0}, {-0.5f, -0.25f, -1}, {-2, -0.25f, -2}};
+	const std::vector<std::array<float, 3>> b4x4 = {{2176, 384, 112}, {0, 0, -0.25f}, {0, 0, -0.25f}, {0, 0, -0.5f}};
+	const std::vector<std::array<float, 3>> b4x8 = {{2176, 768, 512}, {-1, -1, -1.5f}, {-0.75f, -1, -1.5f}, {-0.625f, -0.25f, -1.5f}};
+	for (int idx = 0; idx < 17; ++idx) {
+		switch (idx) {
+		case 0: bw.put(6, 3); bands(dct8); break;
+		case 1: { bw.put(1, 3); const std::vector<std::array<float, 3>> p = {{256, 64, 16}, {3200, 896, 192}, {3072, 832, 208}}; params(p, 0, 3, 3); break; }
+		case 2: { bw.put(2, 3); const std::vector<std::array<float, 3>> p = {{3840, 960, 640}, {2560, 640, 320}, {1280, 320, 128}, {640, 180, 64}, {480, 140, 32}, {300, 120, 16}}; params(p, 0, 6, 6); break; }
+		case 3: { bw.put(3, 3); const std::vector<std::array<float, 3>> p = {{1, 1, 1}, {2, 1, 0.5f}}; params(p, 0, 2, 2); bands(b4x4); break; }
+		case 9: { bw.put(4, 3); const std::vector<std::array<float, 3>> p = {{1, 0.75f, 1.5f}}; params(p, 0, 1, 0); bands(b4x8); break; }
+		case 10: {
+			bw.put(5, 3);
+			const std::vector<std::array<float, 3>> p = {{3072, 1024, 384}, {3072, 1024, 384}, {256, 48, 12}, {256, 48, 12}, {256, 48, 12}, {416, 56, 22}, {0, 0, -0.25f}, {0, 0, -0.25f}, {0, 0, -0.25f}};
+			params(p, 0, 9, 6); bands(b4x8); bands(b4x4);
+			break;
+		}
+		default: bw.put(0, 3);   // library
+		}
+	}
+}
+
 // BitDepth of ImageMetadata (j40.h:3175-3190): integer samples, U32(8, 10, 12, 1 + u(6)) bits
 static void write_bit_depth(BitWriter &cs, int bpp) {
 	cs.put(0, 1);   // not float
@@ -529,7 +567,8 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 	}
 	{   // HfGlobal + HfPass (j40.h:6819)
 		BitWriter bw;
-		bw.put(1, 1);                                            // all dequantisation matrices default
+		if (opt.geti("dq", 0)) { bw.put(0, 1); write_dq_matrices(bw); }
+		else bw.put(1, 1);                                       // all dequantisation matrices default
 		bw.put((uint64_t) (num_presets - 1), ceil_lg((uint32_t) num_groups));
 		for (int pass = 0; pass < num_passes; ++pass) {
 			if (!used_orders_mask) bw.put(2, 2);                 // used_orders = 0
