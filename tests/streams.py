@@ -48,7 +48,7 @@ VARDCT_CASES = [
     ("alpha_extra_channel", dict(alpha=1)),                 # Modular sub-image after the HF coefficients of every group; the reference outputs opaque pixels                         # want_icc: the ICC stream is decoded and discarded like in the reference
     ("bit_depth_12", dict(bpp=12, cfl=1)),                  # more than 8 bits: the long way through the transfer curve, scaling to 8 bits at the end
     ("bit_depth_15", dict(bpp=15)),
-    ("custom_dequant_matrices", dict(dq=1)),                # HfGlobal codes the 8x8 matrices in the Hornuss / DCT2x2 / DCT4x4 / DCT4x8 / AFV / band forms
+    ("custom_dequant_matrices", dict(dq=2)),                # HfGlobal codes the 8x8 matrices in the Hornuss / DCT2x2 / DCT4x4 / DCT4x8 / AFV / band forms and two larger ones raw (Modular sub-images)
 ]
 
 # the Modular feature matrix (width, height, options); all decode bit-exactly

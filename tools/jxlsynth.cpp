@@ -99,7 +99,7 @@ static uint32_t f16_bits(float v) {
 // dq=1: the dequantisation matrices of HfGlobal in their coded forms (j40.h:4696-4760) instead of "all default": band
 // parameters for DCT8, the Hornuss, DCT2x2, DCT4x4, DCT4x8 and AFV forms (the reference accepts the coded forms only for the
 // 8x8 matrices, band parameters included: HOW[6].requires8x8, j40.h:4751); values near the library's, rounded to halves. Scaled parameters are stored divided by 64.
-static void write_dq_matrices(BitWriter &bw) {
+static void write_dq_matrices(BitWriter &bw, std::vector<std::pair<int, StreamEncoder>> &raw) {
 	auto params = [&](const std::vector<std::array<float, 3>> &p, size_t first, size_t count, size_t scaled) {   // channel-major, as read (j40.h:4738)
 		for (int c = 0; c < 3; ++c) for (size_t j = 0; j < count; ++j) bw.put(f16_bits(p[first + j][(size_t) c] / (j < scaled ? 64.0f : 1.0f)), 16);
 	};
@@ -120,8 +120,15 @@ static void write_dq_matrices(BitWriter &bw) {
 			params(p, 0, 9, 6); bands(b4x8); bands(b4x4);
 			break;
 		}
-		default: bw.put(0, 3);   // library
-		}
+		default: {
+			StreamEncoder *enc = nullptr;
+			for (auto &r : raw) if (r.first == idx) enc = &r.second;
+			if (!enc) { bw.put(0, 3); break; }   // library
+			// raw (j40.h:4712-4745): a denominator, then the weights times it as a three-channel Modular image
+			bw.put(7, 3); bw.put(f16_bits(2.0f), 16);
+			write_modular_header(bw, true, nullptr, {});
+			enc->flush(bw);
+		} }
 	}
 }
 
@@ -357,6 +364,17 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 		count_stream(gspec, lfq_enc.back()); count_stream(gspec, meta_enc.back());
 	}
 
+	// dq=2: two of the larger matrices in raw form (DCT32x32 and DCT8x16), coded with the global tree and code spec
+	std::vector<std::pair<int, StreamEncoder>> dq_raw;
+	if (opt.geti("dq", 0) >= 2) for (int idx : {5, 6}) {
+		const int ncols = idx == 5 ? 32 : 16, nrows = idx == 5 ? 32 : 8;
+		std::vector<Channel> mc;
+		for (int c = 0; c < 3; ++c) { Channel m(ncols, nrows); for (int y = 0; y < nrows; ++y) for (int x = 0; x < ncols; ++x) m.at(x, y) = 300 + 90 * (x + y) * (c + 1) + 17 * ((x * 5 + y * 3 + c) & 7); mc.push_back(m); }
+		dq_raw.emplace_back(idx, StreamEncoder(gspec));
+		for (int c = 0; c < 3; ++c) encode_channel(tree, mc, c, 1 + 3 * num_lf_groups + idx, wpp, dq_raw.back().second);
+		count_stream(gspec, dq_raw.back().second);
+	}
+
 	// ---- optional alpha extra channel: a Modular sub-image per pass group, coded after the group's HF coefficients
 	//      (j40.h:7024-7034) with the global tree and code spec ----
 	const int with_alpha = opt.geti("alpha", 0);
@@ -567,7 +585,7 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 	}
 	{   // HfGlobal + HfPass (j40.h:6819)
 		BitWriter bw;
-		if (opt.geti("dq", 0)) { bw.put(0, 1); write_dq_matrices(bw); }
+		if (opt.geti("dq", 0)) { bw.put(0, 1); write_dq_matrices(bw, dq_raw); }
 		else bw.put(1, 1);                                       // all dequantisation matrices default
 		bw.put((uint64_t) (num_presets - 1), ceil_lg((uint32_t) num_groups));
 		for (int pass = 0; pass < num_passes; ++pass) {
