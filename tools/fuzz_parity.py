@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""random generator options x sizes x seeds: the device headers compiled for the CPU (build/libhostsim.so) against the
+reference (oracle/_ref). CPU only; a cheap way to look for parity bugs between GPU runs.  python tools/fuzz_parity.py [n] [seed]
+With a third argument "gpu" the product library decodes instead (public API, needs an MI355X)."""
+import ctypes as C, os, random, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+from streams import synth
+from refdec import Ref
+
+
+def pick_vardct(r):
+    o = {}
+    if r.random() < .3: o["bctx"] = 1
+    if r.random() < .3: o["presets"] = r.choice([2, 3])
+    if r.random() < .3: o["orders"] = 1
+    if r.random() < .3: o["passes"] = r.choice([2, 3])
+    if r.random() < .2: o["cfl"] = 1
+    if r.random() < .2: o["simpleclusters"] = 1; o["logalpha"] = r.choice([5, 6, 7, 8])
+    if r.random() < .2: o["hfprefix"] = 1
+    if r.random() < .2: o["hflz77"] = 1
+    if r.random() < .2: o["dq"] = r.choice([1, 2])
+    if r.random() < .2: o["permute"] = 1
+    if r.random() < .15: o["container"] = r.choice([1, 2])
+    if r.random() < .3: o["maxlog"] = r.choice([4, 5, 6, 7, 8])
+    if r.random() < .15 and "passes" not in o: o["alpha"] = 1
+    elif r.random() < .15: o["bpp"] = r.choice([9, 10, 12, 15])
+    return o
+
+
+def pick_modular(r):
+    o = {}
+    if r.random() < .6: o["tree"] = r.choice([1, 2, 3])
+    p = r.random()
+    if p < .25: o["palette"] = r.choice([1, 2, 3])
+    elif p < .5: o["rct"] = r.choice([-1] + list(range(42)))
+    if r.random() < .3: o["prefix"] = 1
+    if r.random() < .3: o["lz77"] = 1
+    if r.random() < .3: o["groupshift"] = r.choice([7, 8, 9])
+    if r.random() < .25: o["localtree"] = r.choice([1, 2])
+    if r.random() < .25 and "palette" not in o: o["localrct"] = r.randrange(42)
+    if r.random() < .2: o["passes"] = r.choice([2, 3])
+    elif r.random() < .2: o["permute"] = 1
+    if r.random() < .3: o["alpha"] = 1
+    elif r.random() < .2: o["bpp"] = r.choice([9, 10, 12, 14])
+    if r.random() < .1: o["xyb"] = 1
+    return o
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    r = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    on_gpu = len(sys.argv) > 3 and sys.argv[3] == "gpu"
+    if on_gpu:
+        import torch   # (loads the HIP runtime the library is to share)
+        import j40_amd
+    ref = Ref()
+    S = C.CDLL(os.path.join(ROOT, "build", "libhostsim.so"))
+    S.hostsim_decode.restype = C.c_uint32
+    S.hostsim_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+    bad = skipped = errors = 0
+    for i in range(n):
+        mode = r.choice(["vardct", "modular"])
+        w, h = r.randrange(260 if mode == "vardct" else 9, 900), r.randrange(8, 700)
+        if mode == "vardct" and w * h < 257 * 8 * 2: h = 264
+        o = pick_vardct(r) if mode == "vardct" else pick_modular(r)
+        seed = r.randrange(1 << 20)
+        try:
+            d = synth(mode, w, h, seed, **o)
+        except Exception as e:   # option combinations the generator refuses
+            skipped += 1
+            continue
+        e, px = ref.decode(d)
+        if on_gpu:
+            mine, out = j40_amd.decode(d)
+            if out is None: out = np.zeros((h, w, 4), np.uint8)
+        else:
+            out = np.zeros((h, w, 4), np.uint8)
+            buf = C.create_string_buffer(d, len(d))
+            code = S.hostsim_decode(buf, len(d), out.ctypes.data, None, 0)
+            mine = "" if code == 0 else code.to_bytes(4, "big").decode("latin1")
+        errors += e != ""
+        ok = mine == e and (e != "" or (np.array_equal(px, out) if mode == "modular" else np.abs(px.astype(int) - out).max() <= 1))
+        if not ok:
+            bad += 1
+            print("MISMATCH", mode, w, h, seed, o, repr(e), repr(mine))
+    print("%d cases (%d refused by the generator, %d that the reference rejects), %d mismatches" % (n, skipped, errors, bad))
+
+
+if __name__ == "__main__":
+    main()
