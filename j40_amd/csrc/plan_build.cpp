@@ -192,6 +192,7 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 		}
 		if (hp->ev_capacity >= 0xffffffffull) { df.sparse_coeffs = 0; hp->ev_range.clear(); hp->ev_capacity = 0; }
 	}
+	hp->codestream.reserve(cs_size + 16);   // (assign + resize without it reallocates and copies the stream a second time)
 	hp->codestream.assign(cs, cs + cs_size);
 	hp->codestream.resize(cs_size + 16, 0);
 	bool any_lz77 = false;
@@ -334,6 +335,7 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 		for (const DevModSection &s : hp->sections) most = std::max(most, (size_t) s.num_channels * (size_t) s.gw * (size_t) s.gh);
 		hp->lz_window_size = (uint32_t) std::min<size_t>(most + 16, (size_t) 1 << 26);
 	}
+	hp->codestream.reserve(cs_size + 16);   // (assign + resize without it reallocates and copies the stream a second time)
 	hp->codestream.assign(cs, cs + cs_size);
 	hp->codestream.resize(cs_size + 16, 0);
 	return 0;
