@@ -112,6 +112,11 @@ typedef struct {
 	/* RCTs of the section's own header (j40.h:3757), undone over its rectangle before the global transforms
 	 * (j40.h:7030): pairs {begin_c relative to first_channel, rct_type} at local_rct + 2 * local_off */
 	int32_t local_off, local_count;
+	/* a section whose own header lists a palette decodes into a sub-image of its own (the reference's j40__pass_group does that
+	 * for every section, j40.h:7024-7032): num_channels planes sub_w/h/meta[sub_off ..], its transforms
+	 * sub_transforms[sub_tr_off .. sub_tr_off + sub_tr_count) undone there, then the channels pasted over the rectangle unless
+	 * sub_paste is 0 (an earlier pass of a multi-pass frame). sub_off < 0: no sub-image, channels first_channel ... of the frame */
+	int32_t sub_off, sub_tr_off, sub_tr_count, sub_paste;
 } j40hip_modular_section_view;
 
 typedef struct {
@@ -124,6 +129,8 @@ typedef struct {
 	const j40hip_transform_view *transforms;
 	const j40hip_modular_section_view *sections;
 	const int32_t *local_rct;
+	const int32_t *sub_w, *sub_h, *sub_meta;
+	const j40hip_transform_view *sub_transforms;
 	int8_t global_wp[12];
 } j40hip_modular_view;
 

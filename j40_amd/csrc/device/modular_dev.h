@@ -130,6 +130,24 @@ J40_DEV ModTables mod_tables_in_hbm(const DevModPlan &plan, int32_t g) {
 // UNI: every lane of the wavefront runs this on the same section (wave-uniform decoder state, see entropy_dev.h).
 // RING: neighbours come from t.rows and the weighted predictor's rows from t.wp_errors (both sized for the widest rectangle of
 // the frame by the caller), never from HBM -- a compile-time choice so that their address space stays static.
+// where coded channel `cidx` of a section lives: top-left sample of its rectangle, row pitch, size, meta flag
+struct ModChan { int16_t *base; int32_t stride, gw, gh, meta; };
+J40_DEV ModChan mod_channel(const DevModPlan &plan, const DevModSection &sec, int32_t cidx) {
+	ModChan c;
+	if (sec.sub_off >= 0) {   // a plane of the section's own sub-image
+		const DevSubPlane sp = plan.sub_planes[sec.sub_off + cidx];
+		c.base = sp.ptr; c.stride = sp.w; c.gw = sp.w; c.gh = sp.h; c.meta = sp.meta;
+		return c;
+	}
+	const int32_t ch = sec.first_channel + cidx;
+	c.meta = plan.plane_meta[ch]; c.stride = plan.plane_w[ch];
+	// image channels: the section's rectangle; meta channels (palette): the whole plane
+	const int32_t gx = c.meta ? 0 : sec.gx, gy = c.meta ? 0 : sec.gy;
+	c.gw = c.meta ? plan.plane_w[ch] : sec.gw; c.gh = c.meta ? plan.plane_h[ch] : sec.gh;
+	c.base = plan.planes[ch] + (size_t) gy * (size_t) c.stride + (size_t) gx;
+	return c;
+}
+
 template <bool UNI, bool RING>
 J40_DEV uint32_t decode_modular_section(const DevModPlan &plan, const ModTables &t, int32_t g) {
 	// by value: references into HBM would be re-read after every sample store (the compiler cannot rule out aliasing)
@@ -143,7 +161,7 @@ J40_DEV uint32_t decode_modular_section(const DevModPlan &plan, const ModTables 
 	code_init(code, spec, t.clusters, t.cluster_map, t.alias, t.prefix, window);
 	// LZ77 distance multiplier: widest non-meta channel of this sub-image (j40.h:3841-3844)
 	int32_t dist_mult = 0;
-	for (int32_t cidx = 0; cidx < sec.num_channels; ++cidx) if (!plan.plane_meta[sec.first_channel + cidx]) dist_mult = mod_max(dist_mult, sec.gw);
+	for (int32_t cidx = 0; cidx < sec.num_channels; ++cidx) { const ModChan c = mod_channel(plan, sec, cidx); if (!c.meta) dist_mult = mod_max(dist_mult, c.gw); }
 	dist_mult = mod_min(dist_mult, 1 << 21);
 	ModWP wp;
 	wp.on = sec.uses_wp; wp.width = sec.gw;
@@ -155,13 +173,10 @@ J40_DEV uint32_t decode_modular_section(const DevModPlan &plan, const ModTables 
 	wp.trueerrw = wp.trueerrn = wp.trueerrnw = wp.trueerrne = 0;
 	uint32_t err = 0;
 	for (int32_t cidx = 0; cidx < sec.num_channels && !b.err && !err; ++cidx) {
-		const int32_t ch = sec.first_channel + cidx;
-		const int32_t stride = plan.plane_w[ch];
-		// image channels: the section's rectangle; meta channels (palette): the whole plane
-		const int32_t meta = plan.plane_meta[ch];
-		const int32_t gx = meta ? 0 : sec.gx, gy = meta ? 0 : sec.gy, gw = meta ? plan.plane_w[ch] : sec.gw, gh = meta ? plan.plane_h[ch] : sec.gh;
+		const ModChan chan = mod_channel(plan, sec, cidx);
+		const int32_t stride = chan.stride, meta = chan.meta, gw = chan.gw, gh = chan.gh;
 		if (gw <= 0 || gh <= 0) continue;
-		int16_t *base = plan.planes[ch] + (size_t) gy * (size_t) stride + (size_t) gx;
+		int16_t *base = chan.base;
 		wp.width = gw;
 		constexpr bool ring = RING;
 		if (wp.on) {
@@ -226,14 +241,15 @@ J40_DEV uint32_t decode_modular_section(const DevModPlan &plan, const ModTables 
 						// "previous channel" properties: the r-th earlier channel of this sub-image with the same
 						// geometry, nearest first (j40.h:4156-4165)
 						int32_t r = (node.prop - 16) / 4, rc = -1;
+						ModChan ref;
 						for (int32_t k = cidx - 1; k >= 0; --k) {
-							const int32_t cand = sec.first_channel + k;
-							if (plan.plane_meta[cand] != meta || (meta && (plan.plane_w[cand] != gw || plan.plane_h[cand] != gh))) continue;
-							if (r-- == 0) { rc = cand; break; }
+							ref = mod_channel(plan, sec, k);
+							if (ref.meta != meta || ref.gw != gw || ref.gh != gh) continue;
+							if (r-- == 0) { rc = k; break; }
 						}
 						if (rc < 0) { err = ERR_TREC; val = 0; break; }
-						const int32_t rstride = plan.plane_w[rc];
-						const int16_t *rrow = plan.planes[rc] + (size_t) (gy + y) * (size_t) rstride + (size_t) gx;
+						const int32_t rstride = ref.stride;
+						const int16_t *rrow = ref.base + (size_t) y * (size_t) rstride;
 						val = uni<UNI>((int32_t) rrow[x]);
 						if (node.prop & 2) {
 							const int32_t rw = uni<UNI>(x > 0 ? (int32_t) rrow[x - 1] : 0);

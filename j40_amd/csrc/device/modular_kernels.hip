@@ -61,6 +61,14 @@ __global__ void __launch_bounds__(256) k_section_inverse_rcts(DevModPlan plan, i
 	section_inverse_rcts(plan, first_section + (int32_t) blockIdx.x, (int32_t) threadIdx.x, 256);
 }
 
+// rows of a tightly packed sub-image plane over a rectangle of a frame plane (j40__combine_modular_from_pass_group, j40.h:3688)
+__global__ void __launch_bounds__(256) k_paste_plane(const int16_t *src, int32_t w, size_t n, int16_t *dst, int32_t dst_stride) {
+	for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
+		const size_t y = i / (size_t) w, x = i - y * (size_t) w;
+		dst[y * (size_t) dst_stride + x] = src[i];
+	}
+}
+
 __global__ void __launch_bounds__(256) k_inverse_rct(int16_t *a, int16_t *b, int16_t *c, size_t n, int32_t type7) {
 	for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
 		int16_t p0 = a[i], p1 = b[i], p2 = c[i];
@@ -138,6 +146,10 @@ void launch_modular_sections(const DevModPlan &plan, int32_t first_section, int3
 }
 void launch_section_inverse_rcts(const DevModPlan &plan, int32_t first_section, int32_t num_sections, hipStream_t stream) {
 	if (num_sections > 0) hipLaunchKernelGGL(k_section_inverse_rcts, dim3((unsigned) num_sections), dim3(256), 0, stream, plan, first_section);
+}
+void launch_paste_plane(const int16_t *src, int32_t w, int32_t h, int16_t *dst, int32_t dst_stride, hipStream_t stream) {
+	const size_t n = (size_t) w * (size_t) h;
+	if (n) hipLaunchKernelGGL(k_paste_plane, dim3(grid_for(n)), dim3(256), 0, stream, src, w, n, dst, dst_stride);
 }
 void launch_inverse_rct(int16_t *a, int16_t *b, int16_t *c, size_t n, int32_t type7, hipStream_t stream) {
 	if (n) hipLaunchKernelGGL(k_inverse_rct, dim3(grid_for(n)), dim3(256), 0, stream, a, b, c, n, type7);

@@ -160,7 +160,14 @@ struct DevModSection {
 	// reversible colour transforms listed in the section's own header (j40.h:3757), undone over the section's
 	// rectangle after its channels are decoded (j40.h:7030): pairs {begin_c, rct_type} at DevModPlan::local_rct + 2 * local_off
 	int32_t local_off, local_count;
+	// a section whose own header lists a palette decodes into planes of its own (DevModPlan::sub_planes[sub_off ..], one per coded
+	// channel, tightly packed) -- the sub-image the reference allocates (j40.h:7024-7031); the host then schedules its inverse
+	// transforms and pastes the result into the frame planes. -1: the channels are the frame planes first_channel ...
+	int32_t sub_off;
+	int32_t pad;
 };
+
+struct DevSubPlane { int16_t *ptr; int32_t w, h, meta, pad; };
 
 struct DevTransform { int32_t kind, begin_c, rct_type, num_c, nb_colours, nb_deltas, d_pred, pad; };
 
@@ -185,6 +192,7 @@ struct DevModPlan {
 	const DevTreeNode *tree;          // the global tree first, then the sections' own trees (DevModSection::tree_off)
 	const DevModSection *sections;    // [num_sections]
 	const int32_t *local_rct;         // {begin_c (section-relative), rct_type} pairs of the sections' own transforms
+	const DevSubPlane *sub_planes;    // planes of the sections that decode into a sub-image of their own (DevModSection::sub_off)
 	int16_t *planes[MOD_MAX_CHANNELS];        // sample planes of the coded channels, tightly packed rows
 	int32_t plane_w[MOD_MAX_CHANNELS], plane_h[MOD_MAX_CHANNELS];
 	int32_t plane_meta[MOD_MAX_CHANNELS];     // 1: meta channel (palette), decoded whole and never a "previous channel" of image channels

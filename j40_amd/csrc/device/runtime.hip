@@ -104,7 +104,8 @@ struct j40hip_device_state {
 	ModLaunchInfo mod_info = {0, 0, 0, 0, 0, 0};
 	std::vector<uint32_t> mod_section_offsets;
 	struct ModOp { int kind; int16_t *a, *b, *c; const int16_t *src, *aux; size_t n; int32_t p0, p1, p2, p3, p4, p5; int16_t *const *dst_list; const int8_t *wpp; };
-	std::vector<ModOp> mod_ops;          // inverse transforms, in execution order
+	std::vector<ModOp> mod_ops;          // inverse transforms of the frame, in execution order
+	std::vector<ModOp> mod_sub_ops;      // before them: inverse transforms of the sections' own sub-images and their paste (kind 3)
 	std::vector<int16_t *> final_planes; // channel list after the inverse transforms
 	std::vector<int32_t> final_w, final_h;
 	int32_t alpha_channel = -1;
@@ -190,43 +191,76 @@ static uint32_t upload_modular(j40hip_frame *h, int device) {
 	st->mod_extra_status = const_cast<uint32_t *>(plan.status) + hp.sections.size();
 	st->total_sections = (int32_t) hp.sections.size();
 
-	// inverse transforms, last to first (j40.h:4513-4521), resolved to plane pointers now
+	// inverse transforms, last to first (j40.h:4513-4521), resolved to plane pointers now: of the frame, and before that of the
+	// sub-images of the sections that list a palette of their own (undone there, then pasted over the section's rectangle)
 	static const uint8_t PERM[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
-	for (size_t ti = hp.transforms.size(); ti-- > 0; ) {
-		const Transform &t = hp.transforms[ti];
-		if (t.kind == Transform::RCT) {
-			j40hip_device_state::ModOp op; memset(&op, 0, sizeof op);
-			Ref c[3] = {planes[(size_t) t.begin_c], planes[(size_t) t.begin_c + 1], planes[(size_t) t.begin_c + 2]};
-			op.kind = 0; op.a = c[0].p; op.b = c[1].p; op.c = c[2].p; op.n = (size_t) c[0].w * (size_t) c[0].h; op.p0 = t.rct_type % 7;
-			st->mod_ops.push_back(op);
-			for (int i = 0; i < 3; ++i) planes[(size_t) (t.begin_c + PERM[t.rct_type / 7][i])] = c[i];
-		} else if (t.kind == Transform::PALETTE) {
-			const int32_t first = t.begin_c + 1;
-			const Ref idx = planes[(size_t) first], pal = planes[0];
-			const size_t n = (size_t) idx.w * (size_t) idx.h;
-			std::vector<Ref> outs;
-			for (int32_t i = 0; i < t.num_c - 1; ++i) outs.push_back({st->scratch<int16_t>(n ? n : 1, ok), idx.w, idx.h});
-			outs.push_back(idx);   // the index channel becomes the last colour channel, in place
-			if (t.nb_deltas > 0) {
-				std::vector<int16_t *> ptrs; for (const Ref &o : outs) ptrs.push_back(o.p);
-				int8_t wpp[12]; { const WPParams &wp = h->frame.gmodular.wp; wpp[0] = wp.p1; wpp[1] = wp.p2; for (int i = 0; i < 5; ++i) wpp[2 + i] = wp.p3[i]; for (int i = 0; i < 4; ++i) wpp[7 + i] = wp.w[i]; wpp[11] = 0; }
+	auto schedule = [&](std::vector<Ref> &planes, const std::vector<Transform> &trs, const int8_t *wpb, std::vector<j40hip_device_state::ModOp> &ops) {
+		for (size_t ti = trs.size(); ti-- > 0; ) {
+			const Transform &t = trs[ti];
+			if (t.kind == Transform::RCT) {
 				j40hip_device_state::ModOp op; memset(&op, 0, sizeof op);
-				op.kind = 2; op.src = idx.p; op.aux = pal.p; op.p0 = pal.w; op.p1 = t.num_c; op.p2 = idx.w; op.p3 = idx.h; op.p4 = t.nb_colours; op.p5 = t.nb_deltas | (t.d_pred << 24);
-				op.dst_list = st->upload(ptrs.data(), ptrs.size(), s, ok);
-				op.wpp = st->upload(wpp, 12, s, ok);
-				st->mod_ops.push_back(op);
-			} else {
-				for (int32_t i = 0; i < t.num_c; ++i) {
+				Ref c[3] = {planes[(size_t) t.begin_c], planes[(size_t) t.begin_c + 1], planes[(size_t) t.begin_c + 2]};
+				op.kind = 0; op.a = c[0].p; op.b = c[1].p; op.c = c[2].p; op.n = (size_t) c[0].w * (size_t) c[0].h; op.p0 = t.rct_type % 7;
+				ops.push_back(op);
+				for (int i = 0; i < 3; ++i) planes[(size_t) (t.begin_c + PERM[t.rct_type / 7][i])] = c[i];
+			} else if (t.kind == Transform::PALETTE) {
+				const int32_t first = t.begin_c + 1;
+				const Ref idx = planes[(size_t) first], pal = planes[0];
+				const size_t n = (size_t) idx.w * (size_t) idx.h;
+				std::vector<Ref> outs;
+				for (int32_t i = 0; i < t.num_c - 1; ++i) outs.push_back({st->scratch<int16_t>(n ? n : 1, ok), idx.w, idx.h});
+				outs.push_back(idx);   // the index channel becomes the last colour channel, in place
+				if (t.nb_deltas > 0) {
+					std::vector<int16_t *> ptrs; for (const Ref &o : outs) ptrs.push_back(o.p);
 					j40hip_device_state::ModOp op; memset(&op, 0, sizeof op);
-					op.kind = 1; op.src = idx.p; op.aux = t.nb_colours > 0 ? pal.p + (size_t) i * (size_t) pal.w : nullptr; op.a = outs[(size_t) i].p; op.n = n; op.p0 = i; op.p1 = t.nb_colours;
-					st->mod_ops.push_back(op);
+					op.kind = 2; op.src = idx.p; op.aux = pal.p; op.p0 = pal.w; op.p1 = t.num_c; op.p2 = idx.w; op.p3 = idx.h; op.p4 = t.nb_colours; op.p5 = t.nb_deltas | (t.d_pred << 24);
+					op.dst_list = st->upload(ptrs.data(), ptrs.size(), s, ok);
+					op.wpp = st->upload(wpb, 12, s, ok);
+					ops.push_back(op);
+				} else {
+					for (int32_t i = 0; i < t.num_c; ++i) {
+						j40hip_device_state::ModOp op; memset(&op, 0, sizeof op);
+						op.kind = 1; op.src = idx.p; op.aux = t.nb_colours > 0 ? pal.p + (size_t) i * (size_t) pal.w : nullptr; op.a = outs[(size_t) i].p; op.n = n; op.p0 = i; op.p1 = t.nb_colours;
+						ops.push_back(op);
+					}
 				}
+				std::vector<Ref> next(planes.begin() + 1, planes.begin() + first);
+				next.insert(next.end(), outs.begin(), outs.end());
+				next.insert(next.end(), planes.begin() + first + 1, planes.end());
+				planes.swap(next);
+			} else { ok = false; }
+		}
+	};
+	if (!hp.sub_images.empty()) {
+		std::vector<DevSubPlane> subp(hp.sub_w.size());
+		int32_t widest = hp.frame.width;
+		for (size_t k = 0; k < subp.size(); ++k) {
+			const size_t n = (size_t) hp.sub_w[k] * (size_t) hp.sub_h[k];
+			subp[k] = DevSubPlane{st->scratch<int16_t>(n ? n : 1, ok), hp.sub_w[k], hp.sub_h[k], hp.sub_meta[k], 0};
+			widest = std::max(widest, hp.sub_w[k]);
+		}
+		plan.sub_planes = st->upload(subp.data(), subp.size(), s, ok);
+		for (const HostModPlan::SubImage &si : hp.sub_images) {
+			if (!si.paste) continue;
+			for (const Transform &t : si.transforms) palette_wp |= t.kind == Transform::PALETTE && t.nb_deltas > 0 && t.d_pred == 6;
+			std::vector<Ref> sp;
+			for (int32_t k = 0; k < si.num_planes; ++k) sp.push_back({subp[(size_t) (si.first_plane + k)].ptr, subp[(size_t) (si.first_plane + k)].w, subp[(size_t) (si.first_plane + k)].h});
+			schedule(sp, si.transforms, si.wp, st->mod_sub_ops);
+			const DevModSection &sec = hp.sections[(size_t) si.section];
+			for (size_t c = 0; c < sp.size() && ok; ++c) {   // paste: rows of the sub-image over the section's rectangle
+				const Ref &dst = planes[(size_t) sec.first_channel + c];
+				if (sp[c].w != sec.gw || sp[c].h != sec.gh || (size_t) sec.first_channel + c >= planes.size()) { ok = false; break; }
+				j40hip_device_state::ModOp op; memset(&op, 0, sizeof op);
+				op.kind = 3; op.src = sp[c].p; op.a = dst.p + (size_t) sec.gy * (size_t) dst.w + (size_t) sec.gx; op.p0 = sp[c].w; op.p1 = sp[c].h; op.p2 = dst.w;
+				st->mod_sub_ops.push_back(op);
 			}
-			std::vector<Ref> next(planes.begin() + 1, planes.begin() + first);
-			next.insert(next.end(), outs.begin(), outs.end());
-			next.insert(next.end(), planes.begin() + first + 1, planes.end());
-			planes.swap(next);
-		} else { ok = false; }
+		}
+		if (palette_wp && !st->pal_wp_scratch) st->pal_wp_scratch = st->scratch<int32_t>((size_t) 2 * (size_t) widest * 5 + 16, ok);
+	}
+	{
+		int8_t gwp[12]; const WPParams &wp = h->frame.gmodular.wp;
+		gwp[0] = wp.p1; gwp[1] = wp.p2; for (int i = 0; i < 5; ++i) gwp[2 + i] = wp.p3[i]; for (int i = 0; i < 4; ++i) gwp[7 + i] = wp.w[i]; gwp[11] = 0;
+		schedule(planes, hp.transforms, gwp, st->mod_ops);
 	}
 	for (const Ref &p : planes) { st->final_planes.push_back(p.p); st->final_w.push_back(p.w); st->final_h.push_back(p.h); }
 	st->alpha_channel = hp.alpha_channel;
@@ -255,10 +289,11 @@ static uint32_t decode_modular(j40hip_frame *h, void *rgba_dev, size_t stride_by
 	for (int32_t p = 1; p < st->mod_passes; ++p) launch_modular_sections(plan, lead + p * per_pass, per_pass, st->mod_info, s);
 	if (st->mod_local_rcts) launch_section_inverse_rcts(plan, lead + (st->mod_passes - 1) * per_pass, per_pass, s);
 	if (ms3) (void) hipEventRecord(st->ev[2], s);
-	for (const auto &op : st->mod_ops) {
+	for (const std::vector<j40hip_device_state::ModOp> *ops : {&st->mod_sub_ops, &st->mod_ops}) for (const auto &op : *ops) {
 		if (op.kind == 0) launch_inverse_rct(op.a, op.b, op.c, op.n, op.p0, s);
 		else if (op.kind == 1) launch_inverse_palette_plain(op.src, op.aux, op.a, op.n, op.p0, op.p1, fr.im.bpp, s);
-		else launch_inverse_palette_predicted(op.src, op.aux, op.p0, op.dst_list, op.p1, op.p2, op.p3, op.p4, op.p5 & 0xffffff, op.p5 >> 24, fr.im.bpp, op.wpp, st->pal_wp_scratch, st->mod_extra_status, s);
+		else if (op.kind == 2) launch_inverse_palette_predicted(op.src, op.aux, op.p0, op.dst_list, op.p1, op.p2, op.p3, op.p4, op.p5 & 0xffffff, op.p5 >> 24, fr.im.bpp, op.wpp, st->pal_wp_scratch, st->mod_extra_status, s);
+		else launch_paste_plane(op.src, op.p0, op.p1, op.a, op.p2, s);
 	}
 	launch_pack_planes(st->final_planes[0], st->final_planes[1], st->final_planes[2], st->alpha_channel >= 0 ? st->final_planes[(size_t) st->alpha_channel] : nullptr,
 		fr.fh.width, fr.fh.height, fr.im.bpp, (uint8_t *) rgba_dev, stride_bytes, s);

@@ -273,6 +273,7 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 		// (with zero channels this still validates the stream's final rANS state and the section end)
 		DevModSection s;
 		memset(&s, 0, sizeof s);
+		s.sub_off = -1;
 		const Section &ls = fr.toc.single ? fr.toc.single_section : fr.toc.lf_global;
 		s.byte_off = (uint32_t) ls.offset; s.size = (uint32_t) ls.size; s.bit_off = (uint32_t) fr.gm_data_bitpos;
 		s.gx = s.gy = 0; s.gw = fr.fh.width; s.gh = fr.fh.height; s.sidx = 0;
@@ -299,9 +300,21 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 			try { read_modular_header(br, &fr.global_tree, &fr.global_codespec, &m); } catch (const DecodeError &e) { return e.code; }
 			DevModSection s;
 			memset(&s, 0, sizeof s);
-			// the group's own transforms: RCTs are undone over its rectangle; a palette of its own stays on the to-do list
+			s.sub_off = -1;
+			// the group's own transforms. RCTs only: undone in place over the group's rectangle. With a palette the channel list of
+			// the section differs from the frame's: it decodes into a sub-image of its own, the host undoes its transforms there
 			s.local_off = (int32_t) (hp->local_rct.size() / 2);
-			for (const Transform &t : m.transforms) {
+			bool own_palette = false;
+			for (const Transform &t : m.transforms) own_palette = own_palette || t.kind == Transform::PALETTE;
+			if (own_palette) {
+				HostModPlan::SubImage si;
+				si.section = (int32_t) hp->sections.size(); si.first_plane = (int32_t) hp->sub_w.size(); si.num_planes = (int32_t) m.channel.size();
+				si.transforms = m.transforms; si.paste = pass + 1 == fr.fh.num_passes;
+				wp_bytes(m.wp, si.wp);
+				for (const Plane &p : m.channel) { hp->sub_w.push_back(p.width); hp->sub_h.push_back(p.height); hp->sub_meta.push_back(p.vshift < 0); max_width = std::max(max_width, p.width); }
+				hp->sub_images.push_back(si);
+				s.sub_off = si.first_plane;
+			} else for (const Transform &t : m.transforms) {
 				if (t.kind != Transform::RCT || t.begin_c < 0 || t.begin_c + 3 > nch - fr.num_gm_channels) return ERR_TODO;
 				if (pass + 1 < fr.fh.num_passes) continue;   // overwritten by the next pass before anything reads it
 				hp->local_rct.push_back(t.begin_c); hp->local_rct.push_back(t.rct_type);
@@ -310,7 +323,7 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 			s.byte_off = (uint32_t) ps.offset; s.size = (uint32_t) ps.size; s.bit_off = (uint32_t) br.bit_position();
 			s.gx = gg.left + gi.gx_in_gg; s.gy = gg.top + gi.gy_in_gg; s.gw = gi.gw; s.gh = gi.gh;
 			s.sidx = (int32_t) (1 + 3 * fr.fh.num_lf_groups + 17 + pass * num_groups + g);
-			s.first_channel = fr.num_gm_channels; s.num_channels = nch - fr.num_gm_channels;
+			s.first_channel = fr.num_gm_channels; s.num_channels = own_palette ? (int32_t) m.channel.size() : nch - fr.num_gm_channels;
 			wp_bytes(m.wp, s.wp);
 			attach(m, &s);
 			hp->sections.push_back(s);
@@ -332,7 +345,11 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 	if (hp->any_lz77) {
 		// integers decoded by one section: at most all samples of its rectangle in every channel
 		size_t most = 0;
-		for (const DevModSection &s : hp->sections) most = std::max(most, (size_t) s.num_channels * (size_t) s.gw * (size_t) s.gh);
+		for (const DevModSection &s : hp->sections) {
+			size_t n = (size_t) s.num_channels * (size_t) s.gw * (size_t) s.gh;
+			if (s.sub_off >= 0) { n = 0; for (int32_t c = 0; c < s.num_channels; ++c) n += (size_t) hp->sub_w[(size_t) (s.sub_off + c)] * (size_t) hp->sub_h[(size_t) (s.sub_off + c)]; }
+			most = std::max(most, n);
+		}
 		hp->lz_window_size = (uint32_t) std::min<size_t>(most + 16, (size_t) 1 << 26);
 	}
 	hp->codestream.reserve(cs_size + 16);   // (assign + resize without it reallocates and copies the stream a second time)

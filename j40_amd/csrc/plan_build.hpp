@@ -60,6 +60,16 @@ struct HostModPlan {
 	std::vector<DevModSection> sections;                  // LfGlobal's channel data, then num_passes * sections_per_pass group sections, pass-major
 	int32_t num_passes = 1, sections_per_pass = 0;
 	std::vector<int32_t> local_rct;                       // {begin_c, rct_type} pairs, DevModSection::local_off / local_count
+	// sections that list a palette of their own decode into a sub-image of their own (DevModSection::sub_off): its coded channels,
+	// its transforms (undone on the sub-image, then the channels are pasted over the section's rectangle, j40.h:7030-7032)
+	struct SubImage {
+		int32_t section, first_plane, num_planes;
+		std::vector<Transform> transforms;
+		int8_t wp[12];
+		bool paste;                                       // false: an earlier pass of a multi-pass frame, decoded for its status only
+	};
+	std::vector<SubImage> sub_images;
+	std::vector<int32_t> sub_w, sub_h, sub_meta;          // the sub-images' planes, SubImage::first_plane ...
 	std::vector<int32_t> plane_w, plane_h, plane_meta;   // coded channels
 	std::vector<Transform> transforms;                    // global transforms in coded order
 	int32_t alpha_channel = -1;                           // index (after inverse transforms) of the first alpha extra channel

@@ -707,6 +707,67 @@ static void rct_pixel(int32_t type7, int16_t *q0, int16_t *q1, int16_t *q2) {
 	}
 }
 
+/* undoes `trs` last to first on the image planes[0 .. *np) (j40__inverse_transform, j40.h:4506): the frame, or the sub-image of a
+ * section with a palette of its own. wpb: the weighted predictor parameters of that image's header. */
+static uint32_t undo_transforms(oplane *planes, int32_t *np, const j40hip_transform_view *trs, int32_t ntr, const int8_t *wpb, int32_t bpp) {
+	static const uint8_t PERM[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
+	uint32_t err = 0;
+	int32_t t, i;
+	size_t k;
+	for (t = ntr - 1; t >= 0 && !err; --t) {
+		const j40hip_transform_view *tr = &trs[t];
+		if (tr->kind == 0) {  /* inverse RCT, j40.h:4318 */
+			oplane ch[3];
+			int16_t *p0, *p1, *p2;
+			size_t n;
+			for (i = 0; i < 3; ++i) ch[i] = planes[tr->begin_c + i];
+			p0 = ch[0].px; p1 = ch[1].px; p2 = ch[2].px; n = (size_t) ch[0].w * (size_t) ch[0].h;
+			for (k = 0; k < n; ++k) rct_pixel(tr->rct_type % 7, &p0[k], &p1[k], &p2[k]);
+			for (i = 0; i < 3; ++i) planes[tr->begin_c + PERM[tr->rct_type / 7][i]] = ch[i];
+		} else if (tr->kind == 1) {  /* inverse palette, j40.h:4402 */
+			int32_t first = tr->begin_c + 1, last = tr->begin_c + tr->num_c, width = planes[first].w, height = planes[first].h, x, y, j;
+			int use_pred = tr->nb_deltas > 0;
+			owp wp;
+			memmove(planes + last, planes + first, sizeof(oplane) * (size_t) ((*np) - first));
+			(*np) += last - first;
+			for (i = first; i < last; ++i) { planes[i].w = width; planes[i].h = height; planes[i].meta = 0; planes[i].px = (int16_t *) calloc((size_t) width * (size_t) height + 1, sizeof(int16_t)); }
+			memset(&wp, 0, sizeof wp);
+			set_wp(&wp, wpb);
+			wp.on = use_pred && tr->d_pred == 6; wp.width = width;
+			wp.errors = wp.on ? (int32_t (*)[5]) calloc((size_t) width * 2, sizeof(int32_t[5])) : NULL;
+			for (i = 0; i < tr->num_c; ++i) {
+				const int16_t *palp = tr->nb_colours > 0 ? planes[0].px + (size_t) i * (size_t) planes[0].w : NULL;
+				oplane *dst = &planes[first + i], *idxc = &planes[last];
+				wp_reset(&wp);
+				for (y = 0; y < height; ++y) for (x = 0; x < width; ++x) {
+					int16_t idx = idxc->px[(size_t) y * (size_t) width + (size_t) x], val;
+					int is_delta = idx < tr->nb_deltas;
+					if (idx < 0) {
+						if (i < 3) { int32_t e; idx = (int16_t) (~idx % 143); e = idx + 1; val = PALETTE_DELTAS[e >> 1][i]; if (e & 1) val = (int16_t) -val; if (bpp > 8) val = (int16_t) (val << (imin32(bpp, 24) - 8)); }
+						else val = 0;
+					} else if (idx < tr->nb_colours) val = palp[idx];
+					else {
+						idx = (int16_t) (idx - tr->nb_colours);
+						if (idx < 64) val = (int16_t) ((i < 3 ? idx >> (2 * i) : 0) * (((int32_t) 1 << bpp) - 1) / 4 + ((int32_t) 1 << imax32(0, bpp - 3)));
+						else { val = (int16_t) (idx - 64); for (j = 0; j < i; ++j) val = (int16_t) (val / 5); val = (int16_t) ((val % 5) * ((1 << bpp) - 1) / 4); }
+					}
+					if (use_pred) {
+						oneigh p = neighbours(dst->px + (size_t) y * (size_t) width, width, width, x, y);
+						wp_before(&wp, x, y, &p);
+						if (is_delta) val = (int16_t) (val + predict(tr->d_pred, &wp, &p, &err));
+						wp_after(&wp, x, y, val);
+					}
+					dst->px[(size_t) y * (size_t) width + (size_t) x] = val;
+				}
+			}
+			free(wp.errors);
+			free(planes[0].px);
+			memmove(planes, planes + 1, sizeof(oplane) * (size_t) --(*np));
+		} else err = E4('T', 'O', 'D', 'O');
+	}
+	return err;
+}
+
 /* Decodes a Modular frame described by `v` into tightly packed RGBA; returns 0 or the first error */
 ORACLE_API uint32_t oracle_decode_modular(const j40hip_modular_view *v, uint8_t *rgba) {
 	static const uint8_t PERM[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
@@ -721,7 +782,27 @@ ORACLE_API uint32_t oracle_decode_modular(const j40hip_modular_view *v, uint8_t 
 	}
 	codes = (ocode *) calloc((size_t) v->num_codespecs, sizeof(ocode));
 	for (i = 0; i < v->num_codespecs; ++i) ocode_init(&codes[i], &v->codespec[i]);
-	for (s = 0; s < v->num_sections && !err; ++s) err = modular_section(v, &v->sections[s], planes, &codes[v->sections[s].spec_idx]);
+	for (s = 0; s < v->num_sections && !err; ++s) {
+		const j40hip_modular_section_view *sec = &v->sections[s];
+		if (sec->sub_off < 0) { err = modular_section(v, sec, planes, &codes[sec->spec_idx]); continue; }
+		{   /* the section's own sub-image: decode, undo its transforms, paste */
+			oplane sp[64];
+			j40hip_modular_section_view whole = *sec;
+			int32_t nsp = sec->num_channels, y;
+			for (c = 0; c < nsp; ++c) {
+				sp[c].w = v->sub_w[sec->sub_off + c]; sp[c].h = v->sub_h[sec->sub_off + c]; sp[c].meta = v->sub_meta[sec->sub_off + c];
+				sp[c].px = (int16_t *) calloc((size_t) sp[c].w * (size_t) sp[c].h + 1, sizeof(int16_t));
+			}
+			whole.gx = whole.gy = 0; whole.first_channel = 0;
+			err = modular_section(v, &whole, sp, &codes[sec->spec_idx]);
+			if (!err && sec->sub_paste) {
+				err = undo_transforms(sp, &nsp, v->sub_transforms + sec->sub_tr_off, sec->sub_tr_count, sec->wp, v->bpp);
+				for (c = 0; c < nsp && !err; ++c) for (y = 0; y < sp[c].h; ++y)
+					memcpy(planes[sec->first_channel + c].px + (size_t) (sec->gy + y) * (size_t) planes[sec->first_channel + c].w + (size_t) sec->gx, sp[c].px + (size_t) y * (size_t) sp[c].w, sizeof(int16_t) * (size_t) sp[c].w);
+			}
+			for (c = 0; c < nsp; ++c) free(sp[c].px);
+		}
+	}
 	for (i = 0; i < v->num_codespecs; ++i) ocode_free(&codes[i]);
 	free(codes);
 	/* transforms of a group's own header act on the group's sub-image before it is pasted (j40.h:7030-7032):
@@ -739,57 +820,9 @@ ORACLE_API uint32_t oracle_decode_modular(const j40hip_modular_view *v, uint8_t 
 			}
 		}
 	}
-	for (t = v->num_transforms - 1; t >= 0 && !err; --t) {
-		const j40hip_transform_view *tr = &v->transforms[t];
-		if (tr->kind == 0) {  /* inverse RCT, j40.h:4318 */
-			oplane ch[3];
-			int16_t *p0, *p1, *p2;
-			size_t n;
-			for (i = 0; i < 3; ++i) ch[i] = planes[tr->begin_c + i];
-			p0 = ch[0].px; p1 = ch[1].px; p2 = ch[2].px; n = (size_t) ch[0].w * (size_t) ch[0].h;
-			for (k = 0; k < n; ++k) rct_pixel(tr->rct_type % 7, &p0[k], &p1[k], &p2[k]);
-			for (i = 0; i < 3; ++i) planes[tr->begin_c + PERM[tr->rct_type / 7][i]] = ch[i];
-		} else if (tr->kind == 1) {  /* inverse palette, j40.h:4402 */
-			int32_t first = tr->begin_c + 1, last = tr->begin_c + tr->num_c, width = planes[first].w, height = planes[first].h, x, y, j;
-			int use_pred = tr->nb_deltas > 0;
-			owp wp;
-			memmove(planes + last, planes + first, sizeof(oplane) * (size_t) (nplanes - first));
-			nplanes += last - first;
-			for (i = first; i < last; ++i) { planes[i].w = width; planes[i].h = height; planes[i].meta = 0; planes[i].px = (int16_t *) calloc((size_t) width * (size_t) height + 1, sizeof(int16_t)); }
-			memset(&wp, 0, sizeof wp);
-			set_wp(&wp, v->global_wp);
-			wp.on = use_pred && tr->d_pred == 6; wp.width = width;
-			wp.errors = wp.on ? (int32_t (*)[5]) calloc((size_t) width * 2, sizeof(int32_t[5])) : NULL;
-			for (i = 0; i < tr->num_c; ++i) {
-				const int16_t *palp = tr->nb_colours > 0 ? planes[0].px + (size_t) i * (size_t) planes[0].w : NULL;
-				oplane *dst = &planes[first + i], *idxc = &planes[last];
-				wp_reset(&wp);
-				for (y = 0; y < height; ++y) for (x = 0; x < width; ++x) {
-					int16_t idx = idxc->px[(size_t) y * (size_t) width + (size_t) x], val;
-					int is_delta = idx < tr->nb_deltas;
-					if (idx < 0) {
-						if (i < 3) { int32_t e; idx = (int16_t) (~idx % 143); e = idx + 1; val = PALETTE_DELTAS[e >> 1][i]; if (e & 1) val = (int16_t) -val; if (v->bpp > 8) val = (int16_t) (val << (imin32(v->bpp, 24) - 8)); }
-						else val = 0;
-					} else if (idx < tr->nb_colours) val = palp[idx];
-					else {
-						idx = (int16_t) (idx - tr->nb_colours);
-						if (idx < 64) val = (int16_t) ((i < 3 ? idx >> (2 * i) : 0) * (((int32_t) 1 << v->bpp) - 1) / 4 + ((int32_t) 1 << imax32(0, v->bpp - 3)));
-						else { val = (int16_t) (idx - 64); for (j = 0; j < i; ++j) val = (int16_t) (val / 5); val = (int16_t) ((val % 5) * ((1 << v->bpp) - 1) / 4); }
-					}
-					if (use_pred) {
-						oneigh p = neighbours(dst->px + (size_t) y * (size_t) width, width, width, x, y);
-						wp_before(&wp, x, y, &p);
-						if (is_delta) val = (int16_t) (val + predict(tr->d_pred, &wp, &p, &err));
-						wp_after(&wp, x, y, val);
-					}
-					dst->px[(size_t) y * (size_t) width + (size_t) x] = val;
-				}
-			}
-			free(wp.errors);
-			free(planes[0].px);
-			memmove(planes, planes + 1, sizeof(oplane) * (size_t) --nplanes);
-		} else err = E4('T', 'O', 'D', 'O');
-	}
+	/* sections with a palette of their own: transforms of the sub-image, then the paste (j40.h:7030-7032) happened in the loop
+	 * above; now the frame's transforms */
+	if (!err) err = undo_transforms(planes, &nplanes, v->transforms, v->num_transforms, v->global_wp, v->bpp);
 	if (!err && nplanes >= 3) for (k = 0; k < npx; ++k) {  /* j40__render_to_u8x4_rgba, j40.h:7910 */
 		for (c = 0; c < 3; ++c) rgba[k * 4 + (size_t) c] = render_u8(planes[c].px[k], v->bpp);
 		rgba[k * 4 + 3] = v->alpha_channel >= 0 ? render_u8(planes[v->alpha_channel].px[k], v->bpp) : 255;

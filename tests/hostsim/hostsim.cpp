@@ -87,6 +87,10 @@ static uint32_t hostsim_decode_modular(const Frame &fr, const uint8_t *cs, size_
 		plan.planes[c] = store[(size_t) c].data(); plan.plane_w[c] = hp.plane_w[(size_t) c]; plan.plane_h[c] = hp.plane_h[(size_t) c]; plan.plane_meta[c] = hp.plane_meta[(size_t) c];
 		planes.push_back({plan.planes[c], plan.plane_w[c], plan.plane_h[c]});
 	}
+	std::vector<std::vector<int16_t>> sub_store(hp.sub_w.size());
+	std::vector<DevSubPlane> subp(hp.sub_w.size());
+	for (size_t k = 0; k < hp.sub_w.size(); ++k) { sub_store[k].assign((size_t) hp.sub_w[k] * (size_t) hp.sub_h[k] + 1, 0); subp[k] = DevSubPlane{sub_store[k].data(), hp.sub_w[k], hp.sub_h[k], hp.sub_meta[k], 0}; }
+	plan.sub_planes = subp.data();
 	std::vector<int32_t> wps((size_t) hp.sections.size() * (size_t) (2 * hp.frame.max_width * 5) + 16), window(hp.lz_window_size ? (size_t) hp.sections.size() * hp.lz_window_size : 0);
 	std::vector<uint32_t> status(hp.sections.size() + 1, 0);
 	plan.wp_scratch = hp.frame.tree_uses_wp ? wps.data() : nullptr;
@@ -103,8 +107,10 @@ static uint32_t hostsim_decode_modular(const Frame &fr, const uint8_t *cs, size_
 	static const uint8_t PERM[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
 	std::vector<std::vector<int16_t>> extra;
 	extra.reserve(64);
-	for (size_t ti = hp.transforms.size(); ti-- > 0; ) {
-		const Transform &t = hp.transforms[ti];
+	// undoes `trs` last to first on the image `planes` (the frame, or the sub-image of a section with a palette of its own)
+	auto undo = [&](std::vector<Ref> &planes, const std::vector<Transform> &trs, const int8_t *wpb) -> uint32_t {
+	for (size_t ti = trs.size(); ti-- > 0; ) {
+		const Transform &t = trs[ti];
 		if (t.kind == Transform::RCT) {
 			Ref c[3] = {planes[(size_t) t.begin_c], planes[(size_t) t.begin_c + 1], planes[(size_t) t.begin_c + 2]};
 			const size_t n = (size_t) c[0].w * (size_t) c[0].h;
@@ -118,9 +124,8 @@ static uint32_t hostsim_decode_modular(const Frame &fr, const uint8_t *cs, size_
 			for (int32_t i = 0; i < t.num_c - 1; ++i) { extra.emplace_back(n + 1, 0); outs.push_back({extra.back().data(), idx.w, idx.h}); }
 			outs.push_back(idx);
 			ModWP wp;
-			const WPParams &gp = fr.gmodular.wp;
 			wp.on = t.nb_deltas > 0 && t.d_pred == 6; wp.width = idx.w; std::vector<int32_t> errs((size_t) 2 * (size_t) idx.w * 5 + 16, 0); wp.errors = errs.data();
-			wp.p1 = gp.p1; wp.p2 = gp.p2; for (int i = 0; i < 5; ++i) wp.p3[i] = gp.p3[i]; for (int i = 0; i < 4; ++i) wp.w[i] = gp.w[i];
+			wp.p1 = wpb[0]; wp.p2 = wpb[1]; for (int i = 0; i < 5; ++i) wp.p3[i] = wpb[2 + i]; for (int i = 0; i < 4; ++i) wp.w[i] = wpb[7 + i];
 			uint32_t err = 0;
 			for (int32_t i = 0; i < t.num_c; ++i) {
 				const int16_t *palrow = t.nb_colours > 0 ? pal.p + (size_t) i * (size_t) pal.w : nullptr;
@@ -147,6 +152,21 @@ static uint32_t hostsim_decode_modular(const Frame &fr, const uint8_t *cs, size_
 			planes.swap(next);
 		}
 	}
+	return 0;
+	};
+	// sections with a palette of their own: their sub-image's transforms, then the paste over the section's rectangle (j40.h:7030-7032)
+	for (const HostModPlan::SubImage &si : hp.sub_images) if (si.paste) {
+		std::vector<Ref> sp;
+		for (int32_t k = 0; k < si.num_planes; ++k) sp.push_back({subp[(size_t) (si.first_plane + k)].ptr, hp.sub_w[(size_t) (si.first_plane + k)], hp.sub_h[(size_t) (si.first_plane + k)]});
+		if (uint32_t e = undo(sp, si.transforms, si.wp)) return e;
+		const DevModSection &sec = hp.sections[(size_t) si.section];
+		for (size_t c = 0; c < sp.size(); ++c) {
+			const Ref &dst = planes[(size_t) sec.first_channel + c];
+			for (int32_t y = 0; y < sp[c].h; ++y) memcpy(dst.p + (size_t) (sec.gy + y) * (size_t) dst.w + (size_t) sec.gx, sp[c].p + (size_t) y * (size_t) sp[c].w, sizeof(int16_t) * (size_t) sp[c].w);
+		}
+	}
+	{ int8_t gwp[12]; const WPParams &gp = fr.gmodular.wp; gwp[0] = gp.p1; gwp[1] = gp.p2; for (int i = 0; i < 5; ++i) gwp[2 + i] = gp.p3[i]; for (int i = 0; i < 4; ++i) gwp[7 + i] = gp.w[i]; gwp[11] = 0;
+	  if (uint32_t e = undo(planes, hp.transforms, gwp)) return e; }
 	const int32_t W = hp.frame.width, H = hp.frame.height;
 	if (planes.size() < 3) return ERR_TODO;
 	const int32_t opaque = (1 << fr.im.bpp) - 1;

@@ -79,4 +79,8 @@ MODULAR_CASES = [
     ("local_rct_local_tree_no_global_rct", 520, 520, dict(localrct=13, localtree=2, rct=-1, groupshift=7)),
     ("bit_depth_10", 600, 300, dict(bpp=10, tree=1)),
     ("bit_depth_14_wp_rct", 300, 200, dict(bpp=14, tree=2, rct=13)),
+    ("local_palette", 600, 300, dict(localpalette=1, tree=1)),                 # every other group: a palette of its own -> decoded in a sub-image, pasted
+    ("local_palette_deltas_alpha_prefix_lz77", 520, 300, dict(localpalette=2, alpha=1, prefix=1, lz77=1, groupshift=7)),
+    ("local_palette_predicted_two_passes", 600, 300, dict(localpalette=3, passes=2, tree=2, rct=-1)),
+    ("local_palette_beside_local_rct_local_tree", 300, 200, dict(localpalette=1, localrct=5, localtree=2, groupshift=7)),
 ]

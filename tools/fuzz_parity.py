@@ -40,6 +40,7 @@ def pick_modular(r):
     if r.random() < .3: o["groupshift"] = r.choice([7, 8, 9])
     if r.random() < .25: o["localtree"] = r.choice([1, 2])
     if r.random() < .25 and "palette" not in o: o["localrct"] = r.randrange(42)
+    if r.random() < .25 and "palette" not in o and o.get("tree") != 3: o["localpalette"] = r.choice([1, 2, 3])
     if r.random() < .2: o["passes"] = r.choice([2, 3])
     elif r.random() < .2: o["permute"] = 1
     if r.random() < .3: o["alpha"] = 1

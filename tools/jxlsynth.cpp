@@ -917,6 +917,7 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	std::vector<StreamEncoder> encs;
 	std::vector<std::vector<TransformW>> group_tr;
 	const int local_rct = opt.geti("localrct", -1);
+	const int local_palette = opt.geti("localpalette", 0);
 	std::vector<uint8_t> section_is_group;
 	if (single) {
 		encs.emplace_back(gspec);
@@ -938,7 +939,26 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 			const bool local = local_tree && (((size_t) (pass * num_groups + g) + 1) & 1);
 			// localrct=K: the group's header lists one or two RCTs of its own (j40.h:3757-3773), type varying by group
 			group_tr.emplace_back();
-			if (local_rct >= 0 && sub.size() >= 3) {
+			// localpalette=K (1 plain, 2 with deltas and synthetic colours, 3 with delta prediction): every other group replaces its
+			// three colour channels by a palette of its own + an index channel (j40.h:3774-3799); those groups list no RCT
+			const bool own_palette = local_palette && sub.size() >= 3 && ((g + pass) & 1) == 0;
+			if (own_palette) {
+				const int nb_colours = local_palette == 2 ? 20 : 33, nb_deltas = local_palette == 3 ? 5 : 0;
+				Channel pal(nb_colours, 3), idx(gw, gh);
+				for (int i = 0; i < nb_colours; ++i) for (int c = 0; c < 3; ++c) pal.at(i, c) = i < nb_deltas ? (int32_t) rng.below(9) - 4 : (int32_t) rng.below(256);
+				for (int y = 0; y < gh; ++y) for (int x = 0; x < gw; ++x) {
+					int v = (sub[0].at(x, y) * 3 + sub[1].at(x, y) * 5 + sub[2].at(x, y)) / 9;
+					int i = ((v & 255) * nb_colours) >> 8;
+					if (local_palette == 2) { if (((x ^ y) & 31) == 5) i = -1 - (int) rng.below(140); else if (((x + 2 * y) & 63) == 9) i = nb_colours + (int) rng.below(64 + 125); }
+					idx.at(x, y) = i;
+				}
+				std::vector<Channel> next{pal, idx};
+				for (size_t c = 3; c < sub.size(); ++c) next.push_back(sub[c]);
+				sub.swap(next);
+				TransformW t; t.kind = 1; t.begin_c = 0; t.num_c = 3; t.nb_colours = nb_colours; t.nb_deltas = nb_deltas; t.d_pred = local_palette == 3 ? 5 : 0;
+				group_tr.back().push_back(t);
+			}
+			if (local_rct >= 0 && sub.size() >= 3 && !own_palette) {
 				const int t1 = (local_rct + 5 * (g + pass)) % 42, t2 = (3 * t1 + 1) % 42;
 				TransformW a; a.kind = 0; a.begin_c = 0; a.rct_type = t1; group_tr.back().push_back(a);
 				if (t1 / 7 == 0 && t1 % 7 != 2) forward_rct(sub, 0, t1);
