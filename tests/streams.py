@@ -83,4 +83,5 @@ MODULAR_CASES = [
     ("local_palette_deltas_alpha_prefix_lz77", 520, 300, dict(localpalette=2, alpha=1, prefix=1, lz77=1, groupshift=7)),
     ("local_palette_predicted_two_passes", 600, 300, dict(localpalette=3, passes=2, tree=2, rct=-1)),
     ("local_palette_beside_local_rct_local_tree", 300, 200, dict(localpalette=1, localrct=5, localtree=2, groupshift=7)),
+    ("four_extra_channels_alpha_last", 600, 300, dict(extra=3, alpha=1, tree=3, localrct=7)),   # depth channels ahead of the alpha channel
 ]

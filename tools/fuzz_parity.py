@@ -43,6 +43,7 @@ def pick_modular(r):
     if r.random() < .25 and "palette" not in o and o.get("tree") != 3: o["localpalette"] = r.choice([1, 2, 3])
     if r.random() < .2: o["passes"] = r.choice([2, 3])
     elif r.random() < .2: o["permute"] = 1
+    if r.random() < .2: o["extra"] = r.choice([1, 2, 3])
     if r.random() < .3: o["alpha"] = 1
     elif r.random() < .2: o["bpp"] = r.choice([9, 10, 12, 14])
     if r.random() < .1: o["xyb"] = 1

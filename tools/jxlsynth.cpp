@@ -771,7 +771,10 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	const int gcols = (W + gdim - 1) / gdim, grows = (H + gdim - 1) / gdim, num_groups = gcols * grows;
 	const int num_lf_groups = ((W + 8 * gdim - 1) / (8 * gdim)) * ((H + 8 * gdim - 1) / (8 * gdim));
 	const bool single = num_groups == 1;
-	const int ncolour = 3, nch = ncolour + (alpha ? 1 : 0);
+	// extra=K: K more extra channels (type depth, same bit depth) ahead of the alpha channel, so that alpha is not the first one
+	const int extra = opt.geti("extra", 0);
+	if (extra < 0 || extra + (alpha ? 1 : 0) > 4) die("modular: at most four extra channels (j40.h:3247)");
+	const int ncolour = 3, nch = ncolour + extra + (alpha ? 1 : 0);
 
 	// ---- source picture -> channels: colour first, then extra channels (the renderer takes channels
 	//      0..2 as RGB and 3.. as extra channels, j40.h:7923-7936) ----
@@ -787,7 +790,8 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 			v = (v / 6) * 6 + (int) (Picture::hash01((uint64_t) x * 7919 + (uint64_t) y * 104729 + (uint64_t) c + seed) < 0.08f);
 			ch[(size_t) (colour0 + c)].at(x, y) = std::min(255, std::max(0, v)) * ((1 << bpp) - 1) / 255;
 		}
-		if (alpha) ch[3].at(x, y) = ((x / 37 + y / 29) & 3) == 0 ? 128 + ((x * 3 + y) & 63) : 255;
+		for (int k = 0; k < extra; ++k) ch[(size_t) (3 + k)].at(x, y) = (((x >> 3) * (k + 2) + (y >> 2)) & 31) * ((1 << bpp) - 1) / 31;
+		if (alpha) ch[(size_t) (3 + extra)].at(x, y) = ((x / 37 + y / 29) & 3) == 0 ? 128 + ((x * 3 + y) & 63) : 255;
 	}
 
 	// ---- global transforms (coded order = forward order; the decoder undoes them last to first) ----
@@ -1024,7 +1028,18 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	cs.put(0, 1);                       // no extra fields
 	write_bit_depth(cs, bpp);
 	cs.put(1, 1);                       // modular_16bit_buffers
-	if (alpha) { cs.put(1, 2); cs.put(1, 1); } else cs.put(0, 2);   // num_extra_channels (+ d_alpha)
+	{   // num_extra_channels U32(0, 1, 2 + u(4), 1 + u(12)), then one ExtraChannelInfo each (j40.h:3247-3290)
+		const int nec = extra + (alpha ? 1 : 0);
+		if (nec == 0) cs.put(0, 2); else if (nec == 1) cs.put(1, 2); else { cs.put(2, 2); cs.put((uint64_t) (nec - 2), 4); }
+		for (int k = 0; k < extra; ++k) {
+			cs.put(0, 1);                   // not the default alpha
+			cs.put(1, 2);                   // type: enum selector 1 = depth
+			write_bit_depth(cs, bpp);
+			cs.put(0, 2);                   // dim_shift 0
+			cs.put(0, 2);                   // no name
+		}
+		if (alpha) cs.put(1, 1);            // d_alpha
+	}
 	// xyb=1 / ycbcr=1: the frame is flagged XYB / YCbCr; the reference applies no colour transform to Modular
 	// frames (j40.h:8209-8210, 7910) and renders the three channels as they are
 	const int flag_xyb = opt.geti("xyb", 0), flag_ycbcr = opt.geti("ycbcr", 0);
@@ -1043,7 +1058,7 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	if (!flag_xyb) cs.put(flag_ycbcr ? 1 : 0, 1);   // do_ycbcr
 	if (!flag_xyb && flag_ycbcr) cs.put(0, 6);      // jpeg_upsampling: none
 	cs.put(0, 2);                       // log_upsampling
-	if (alpha) cs.put(0, 2);            // extra channel upsampling
+	for (int k = 0; k < extra + (alpha ? 1 : 0); ++k) cs.put(0, 2);   // extra channel upsampling
 	cs.put((uint64_t) (group_shift - 7), 2);
 	cs.u32(num_passes, 1, 0, 2, 0, 3, 0, 4, 3);
 	if (num_passes > 1) {
@@ -1052,7 +1067,7 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	}
 	cs.put(0, 1);                       // have_crop
 	cs.u32(0, 0, 0, 1, 0, 2, 0, 3, 2);  // blend mode (colour)
-	if (alpha) cs.u32(0, 0, 0, 1, 0, 2, 0, 3, 2);  // blend mode (extra channel)
+	for (int k = 0; k < extra + (alpha ? 1 : 0); ++k) cs.u32(0, 0, 0, 1, 0, 2, 0, 3, 2);  // blend mode (extra channels)
 	cs.put(1, 1);                       // is_last
 	cs.u32(0, 0, 0, 0, 4, 16, 5, 48, 10);
 	cs.put(0, 1); cs.put(0, 1); cs.put(0, 2); cs.u64(0);   // restoration: explicit, gab off, epf 0, no extensions
