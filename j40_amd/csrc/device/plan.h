@@ -138,6 +138,8 @@ struct DevPlan {
 	int32_t *lz_window;              // [num_groups][lz_window_size] or null
 	uint32_t lz_window_size;
 	uint32_t *status;                // [num_passes * num_groups] 4-char codes
+	uint32_t *section_end_bit;       // [num_passes * num_groups] or null: where each section's HF coefficients ended (absolute bit),
+	                                 // written by the latency-form entropy kernel of frames whose sections go on with a Modular sub-image
 };
 
 // ---- Modular frames ----

@@ -101,6 +101,7 @@ struct j40hip_device_state {
 	DevModPlan mod;
 	int32_t mod_sections = 0, mod_passes = 1, mod_sections_per_pass = 0;   // sections = LfGlobal's (0 or 1) + passes * per_pass
 	bool mod_local_rcts = false;
+	bool has_trailers = false;           // VarDCT frame whose sections go on with the extra channels' Modular sub-image
 	ModLaunchInfo mod_info = {0, 0, 0, 0, 0, 0};
 	std::vector<uint32_t> mod_section_offsets;
 	struct ModOp { int kind; int16_t *a, *b, *c; const int16_t *src, *aux; size_t n; int32_t p0, p1, p2, p3, p4, p5; int16_t *const *dst_list; const int8_t *wpp; };
@@ -366,7 +367,8 @@ extern "C" uint32_t j40hip_frame_upload(j40hip_frame *h, int device) {
 		const size_t coeff_bytes = sparse ? sizeof(CoeffEvent) * hp.ev_capacity : sizeof(float) * 3 * stride;
 		const size_t w_coeffs = 0, w_blk = align(w_coeffs + coeff_bytes), blk_bytes = sparse ? sizeof(uint32_t) * 4 * st->num_blocks : 0;
 		const size_t w_nz = align(w_blk + blk_bytes), w_status = align(w_nz + (size_t) num_groups * 32 * 32 * 3);
-		const size_t w_lz = align(w_status + sizeof(uint32_t) * hp.sections.size()), lz_bytes = sizeof(int32_t) * (size_t) num_groups * hp.lz_window_size;
+		const size_t w_endbit = align(w_status + sizeof(uint32_t) * hp.sections.size());
+		const size_t w_lz = align(w_endbit + (hp.frame.sections_have_trailer ? sizeof(uint32_t) * hp.sections.size() : 0)), lz_bytes = sizeof(int32_t) * (size_t) num_groups * hp.lz_window_size;
 		const size_t w_large = align(w_lz + lz_bytes), large_bytes = sizeof(float) * (size_t) hp.max_large * 6 * 65536;
 		bool unused_clean = false;
 		st->work_block = cache_acquire(device, w_large + large_bytes + 256, &st->work_block_bytes, &unused_clean);
@@ -380,12 +382,14 @@ extern "C" uint32_t j40hip_frame_upload(j40hip_frame *h, int device) {
 			else for (int c = 0; c < 3; ++c) plan.coeffs[c] = (float *) (wb + w_coeffs) + (size_t) c * stride;
 			plan.coeff_stride = (uint32_t) stride;
 			plan.nonzeros = (int8_t *) (wb + w_nz); plan.status = (uint32_t *) (wb + w_status);
+			plan.section_end_bit = hp.frame.sections_have_trailer ? (uint32_t *) (wb + w_endbit) : nullptr;
 			plan.lz_window_size = hp.lz_window_size;
 			plan.lz_window = hp.lz_window_size ? (int32_t *) (wb + w_lz) : nullptr;
 			st->d_large_scratch = hp.max_large ? (float *) (wb + w_large) : nullptr;
 		}
 	}
 	st->total_sections = (int32_t) hp.sections.size();
+	st->has_trailers = hp.frame.sections_have_trailer != 0;
 	st->first_group = 0; st->num_groups = num_groups;
 	upload_constant_tables(half_secants(), afv_basis(), srgb_u8_thresholds(), s);
 	for (auto &e : st->ev) if (hipEventCreate(&e) != hipSuccess) ok = false;
@@ -434,6 +438,64 @@ static uint32_t clear_before_decode(j40hip_device_state *st, hipStream_t s) {
 	return hipMemsetAsync(plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) plan.coeff_stride, s) == hipSuccess ? 0 : ERR_GPU;
 }
 
+// VarDCT frames with extra channels (latency path): decodes the Modular sub-image that follows the HF coefficients in every
+// section -- into planes nobody reads, the reference drops them too (j40.h:7868) -- so that damage there is reported like the
+// reference reports it. Needs the entropy kernel's results on the host (where each section's coefficients ended), i.e. it
+// synchronises the stream; the statuses it finds are written back into the frame's status array.
+static uint32_t validate_trailers(j40hip_frame *h, hipStream_t s) {
+	j40hip_device_state *st = h->dev;
+	const Frame &fr = h->frame;
+	const size_t n = (size_t) st->total_sections;
+	std::vector<uint32_t> end_bits(n), status(n);
+	if (hipMemcpyAsync(end_bits.data(), st->plan.section_end_bit, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, s) != hipSuccess) return ERR_GPU;
+	if (hipMemcpyAsync(status.data(), st->plan.status, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, s) != hipSuccess) return ERR_GPU;
+	if (hipStreamSynchronize(s) != hipSuccess) return ERR_GPU;
+	HostModPlan hp;
+	std::vector<std::pair<int32_t, uint32_t>> header_errors;
+	std::vector<int32_t> section_of;
+	if (uint32_t e = build_trailer_plan(fr, h->cs, h->cs_size, end_bits.data(), status.data(), &hp, &header_errors, &section_of)) return e;
+	j40hip_device_state tmp;   // owns the buffers of this validation only
+	tmp.device = st->device;
+	bool ok = true;
+	std::vector<uint32_t> found(hp.sections.size(), 0);
+	if (!hp.sections.empty()) {
+		DevModPlan plan;
+		memset(&plan, 0, sizeof plan);
+		plan.frame = tmp.upload(&hp.frame, 1, s, ok);
+		plan.codestream = st->plan.codestream;
+		plan.pool_u8 = tmp.upload(hp.pool_u8.data(), hp.pool_u8.size(), s, ok);
+		plan.pool_i32 = tmp.upload(hp.pool_i32.data(), hp.pool_i32.size(), s, ok);
+		plan.pool_u64 = tmp.upload(hp.pool_u64.data(), hp.pool_u64.size(), s, ok);
+		plan.clusters = tmp.upload(hp.clusters.data(), hp.clusters.size(), s, ok);
+		plan.spec = tmp.upload(hp.specs.data(), hp.specs.size(), s, ok);
+		plan.tree = tmp.upload(hp.tree.data(), hp.tree.size(), s, ok);
+		plan.sections = tmp.upload(hp.sections.data(), hp.sections.size(), s, ok);
+		std::vector<DevSubPlane> subp(hp.sub_w.size());
+		size_t total = 0;
+		for (size_t k = 0; k < subp.size(); ++k) total += (size_t) hp.sub_w[k] * (size_t) hp.sub_h[k] + 1;
+		int16_t *pool = tmp.scratch<int16_t>(total + 1, ok);
+		for (size_t k = 0, at = 0; k < subp.size() && pool; ++k) { subp[k] = DevSubPlane{pool + at, hp.sub_w[k], hp.sub_h[k], hp.sub_meta[k], 0}; at += (size_t) hp.sub_w[k] * (size_t) hp.sub_h[k] + 1; }
+		plan.sub_planes = tmp.upload(subp.data(), subp.size(), s, ok);
+		if (hp.frame.tree_uses_wp) plan.wp_scratch = tmp.scratch<int32_t>(hp.sections.size() * (size_t) (2 * hp.frame.max_width * 5) + 16, ok);
+		plan.lz_window_size = hp.lz_window_size;
+		if (hp.lz_window_size) plan.lz_window = tmp.scratch<int32_t>(hp.sections.size() * hp.lz_window_size, ok);
+		plan.status = tmp.scratch<uint32_t>(hp.sections.size() + 1, ok);
+		if (ok) {
+			const ModLaunchInfo info = {hp.max_tree_nodes, hp.max_num_dist, hp.max_clusters, hp.max_table_bytes, hp.frame.max_width, hp.any_wp ? 1 : 0};
+			launch_modular_sections(plan, 0, (int32_t) hp.sections.size(), info, s);
+			ok = hipMemcpyAsync(found.data(), plan.status, sizeof(uint32_t) * found.size(), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+		}
+	}
+	bool any = false;
+	for (size_t i = 0; i < found.size(); ++i) if (found[i]) { status[(size_t) section_of[i]] = found[i]; any = true; }
+	for (const auto &e : header_errors) { status[(size_t) e.first] = e.second; any = true; }
+	if (ok && any) ok = hipMemcpyAsync(st->plan.status, status.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+	else if (ok) ok = hipStreamSynchronize(s) == hipSuccess;
+	for (auto &b : tmp.buffers) b.release();
+	tmp.buffers.clear();
+	return ok ? 0 : ERR_GPU;
+}
+
 static uint32_t decode_impl(j40hip_frame *h, void *rgba_dev, size_t stride_bytes, hipStream_t s, float *ms3) {
 	if (!h || !h->dev) return ERR_GPU;
 	j40hip_device_state *st = h->dev;
@@ -463,7 +525,9 @@ static uint32_t decode_impl(j40hip_frame *h, void *rgba_dev, size_t stride_bytes
 		(void) hipEventElapsedTime(&c, st->ev[2], st->ev[3]);
 		ms3[0] = b; ms3[1] = c; ms3[2] = a;
 	}
-	return hipGetLastError() == hipSuccess ? 0 : ERR_GPU;
+	if (hipGetLastError() != hipSuccess) return ERR_GPU;
+	if (st->has_trailers && whole) return validate_trailers(h, s);   // (synchronises `s`)
+	return 0;
 }
 
 // ---- batches: throughput mode ----

@@ -230,6 +230,27 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 	return 0;
 }
 
+// the MA tree and the code spec a section decodes with: the global pair (flattened once, when the first header refers to it)
+// or the section's own (use_global_tree = 0)
+static void attach_tables(const Frame &fr, HostModPlan *hp, int32_t &global_spec, uint32_t &global_tree_off, const Modular &m, DevModSection *s) {
+	const bool own = !m.use_global_tree;
+	if (!own && global_spec >= 0) { s->tree_off = global_tree_off; s->tree_nodes = (int32_t) fr.global_tree.size(); s->spec_idx = global_spec; }
+	else {
+		const std::vector<TreeNode> &tree = *m.tree;
+		s->tree_off = (uint32_t) hp->tree.size(); s->tree_nodes = (int32_t) tree.size(); s->spec_idx = (int32_t) hp->specs.size();
+		for (const TreeNode &n : tree) hp->tree.push_back(DevTreeNode{n.prop, n.value, n.a, n.b});
+		hp->specs.emplace_back(); hp->host_specs.push_back(*m.codespec);
+		flatten_code_spec(*m.codespec, hp->pool_u8, hp->pool_i32, hp->pool_u64, hp->clusters, &hp->specs.back());
+		if (!own) { global_spec = s->spec_idx; global_tree_off = s->tree_off; }
+	}
+	s->uses_wp = tree_uses_wp(*m.tree);
+	const DevCodeSpec &sp = hp->specs[(size_t) s->spec_idx];
+	hp->max_tree_nodes = std::max(hp->max_tree_nodes, s->tree_nodes);
+	hp->max_num_dist = std::max(hp->max_num_dist, sp.num_dist); hp->max_clusters = std::max(hp->max_clusters, sp.num_clusters);
+	hp->max_table_bytes = std::max(hp->max_table_bytes, sp.table_span * (sp.use_prefix_code ? 4u : 8u));
+	hp->any_lz77 = hp->any_lz77 || sp.lz77_enabled; hp->any_wp = hp->any_wp || s->uses_wp;
+}
+
 uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostModPlan *hp) {
 	if (!fr.fh.is_modular) return ERR_TODO;
 	const Modular &gm = fr.gmodular;
@@ -245,24 +266,7 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 	df.num_channels = nch;
 	// trees and code specs: the global pair once (when a header refers to it), own pairs per section (use_global_tree = 0)
 	int32_t global_spec = -1; uint32_t global_tree_off = 0;
-	auto attach = [&](const Modular &m, DevModSection *s) {
-		const bool own = !m.use_global_tree;
-		if (!own && global_spec >= 0) { s->tree_off = global_tree_off; s->tree_nodes = (int32_t) fr.global_tree.size(); s->spec_idx = global_spec; }
-		else {
-			const std::vector<TreeNode> &tree = *m.tree;
-			s->tree_off = (uint32_t) hp->tree.size(); s->tree_nodes = (int32_t) tree.size(); s->spec_idx = (int32_t) hp->specs.size();
-			for (const TreeNode &n : tree) hp->tree.push_back(DevTreeNode{n.prop, n.value, n.a, n.b});
-			hp->specs.emplace_back(); hp->host_specs.push_back(*m.codespec);
-			flatten_code_spec(*m.codespec, hp->pool_u8, hp->pool_i32, hp->pool_u64, hp->clusters, &hp->specs.back());
-			if (!own) { global_spec = s->spec_idx; global_tree_off = s->tree_off; }
-		}
-		s->uses_wp = tree_uses_wp(*m.tree);
-		const DevCodeSpec &sp = hp->specs[(size_t) s->spec_idx];
-		hp->max_tree_nodes = std::max(hp->max_tree_nodes, s->tree_nodes);
-		hp->max_num_dist = std::max(hp->max_num_dist, sp.num_dist); hp->max_clusters = std::max(hp->max_clusters, sp.num_clusters);
-		hp->max_table_bytes = std::max(hp->max_table_bytes, sp.table_span * (sp.use_prefix_code ? 4u : 8u));
-		hp->any_lz77 = hp->any_lz77 || sp.lz77_enabled; hp->any_wp = hp->any_wp || s->uses_wp;
-	};
+	auto attach = [&](const Modular &m, DevModSection *s) { attach_tables(fr, hp, global_spec, global_tree_off, m, s); };
 	hp->pool_u8.resize(hp->pool_u8.size() + 16, 0);
 	hp->transforms = gm.transforms;
 	int32_t max_width = 1;
@@ -355,6 +359,62 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 	hp->codestream.reserve(cs_size + 16);   // (assign + resize without it reallocates and copies the stream a second time)
 	hp->codestream.assign(cs, cs + cs_size);
 	hp->codestream.resize(cs_size + 16, 0);
+	return 0;
+}
+
+// VarDCT frames with extra channels: after its HF coefficients every pass-group section carries the extra channels of the group
+// as a Modular sub-image (j40.h:7024-7033). The reference decodes it and later drops it with the rest of the Modular image
+// (j40__combine_vardct, j40.h:7868), so it never reaches the pixels, but damage in it is reported. The entropy kernel leaves the
+// bit where each section's coefficients end; this lays out a Modular decode of what follows, into planes nobody reads.
+// end_bits / k1_status: per section (pass-major), from the device. Sections that already failed are left out; a header that does
+// not parse yields that section's error in trailer_errors (section index, code).
+uint32_t build_trailer_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, const uint32_t *end_bits, const uint32_t *k1_status, HostModPlan *hp,
+		std::vector<std::pair<int32_t, uint32_t>> *trailer_errors, std::vector<int32_t> *section_of) {
+	const Modular &gm = fr.gmodular;
+	const int32_t nch = (int32_t) gm.channel.size();
+	if (nch <= fr.num_gm_channels || nch > MOD_MAX_CHANNELS) return ERR_TODO;
+	DevModFrame &df = hp->frame;
+	memset(&df, 0, sizeof df);
+	df.width = fr.fh.width; df.height = fr.fh.height; df.num_groups = (int32_t) fr.fh.num_groups; df.bpp = fr.im.bpp; df.num_channels = 0;
+	int32_t global_spec = -1, max_width = 1; uint32_t global_tree_off = 0;
+	hp->pool_u8.resize(hp->pool_u8.size() + 16, 0);
+	auto wp_bytes = [](const WPParams &wp, int8_t *out) { out[0] = wp.p1; out[1] = wp.p2; for (int i = 0; i < 5; ++i) out[2 + i] = wp.p3[i]; for (int i = 0; i < 4; ++i) out[7 + i] = wp.w[i]; out[11] = 0; };
+	const int32_t num_groups = (int32_t) fr.fh.num_groups;
+	for (int32_t pass = 0; pass < fr.fh.num_passes; ++pass) for (int32_t g = 0; g < num_groups; ++g) {
+		const int32_t idx = pass * num_groups + g;
+		if (k1_status[idx]) continue;
+		const Section &ps = fr.toc.single ? fr.toc.single_section : fr.toc.pass_groups[(size_t) idx];
+		const GroupInfo gi = group_info(fr.fh, g);
+		Modular m; m.bpp = fr.im.bpp;
+		for (int32_t c = fr.num_gm_channels; c < nch; ++c) { Plane p; p.width = gi.gw; p.height = gi.gh; m.channel.push_back(p); }
+		const size_t start = (size_t) end_bits[idx];
+		if (start < 8 * ps.offset || start > 8 * (ps.offset + ps.size)) { trailer_errors->push_back({idx, E4("shrt")}); continue; }
+		BitReader br(cs + ps.offset, ps.size);
+		try { br.skip_bits((int64_t) (start - 8 * ps.offset)); read_modular_header(br, &fr.global_tree, &fr.global_codespec, &m); }
+		catch (const DecodeError &e) { trailer_errors->push_back({idx, e.code}); continue; }
+		DevModSection s;
+		memset(&s, 0, sizeof s);
+		s.byte_off = (uint32_t) ps.offset; s.size = (uint32_t) ps.size; s.bit_off = (uint32_t) br.bit_position();
+		s.gx = s.gy = 0; s.gw = gi.gw; s.gh = gi.gh;
+		s.sidx = (int32_t) (1 + 3 * fr.fh.num_lf_groups + 17 + idx);
+		s.first_channel = 0; s.num_channels = (int32_t) m.channel.size();
+		s.sub_off = (int32_t) hp->sub_w.size();   // everything lands in planes of the section's own
+		for (const Plane &p : m.channel) { hp->sub_w.push_back(p.width); hp->sub_h.push_back(p.height); hp->sub_meta.push_back(p.vshift < 0); max_width = std::max(max_width, p.width); }
+		wp_bytes(m.wp, s.wp);
+		attach_tables(fr, hp, global_spec, global_tree_off, m, &s);
+		hp->sections.push_back(s);
+		section_of->push_back(idx);
+	}
+	(void) cs_size;
+	df.num_sections = (int32_t) hp->sections.size();
+	df.max_width = max_width;
+	df.tree_uses_wp = hp->any_wp; df.num_tree_nodes = hp->max_tree_nodes;
+	hp->lz_window_size = 0;
+	if (hp->any_lz77) {
+		size_t most = 0;
+		for (const DevModSection &s : hp->sections) { size_t n = 0; for (int32_t c = 0; c < s.num_channels; ++c) n += (size_t) hp->sub_w[(size_t) (s.sub_off + c)] * (size_t) hp->sub_h[(size_t) (s.sub_off + c)]; most = std::max(most, n); }
+		hp->lz_window_size = (uint32_t) std::min<size_t>(most + 16, (size_t) 1 << 26);
+	}
 	return 0;
 }
 

@@ -81,6 +81,11 @@ struct HostModPlan {
 // reference itself refuses)
 uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostModPlan *out);
 
+// VarDCT frames with extra channels: the Modular sub-images behind the HF coefficients of every pass-group section, laid out for
+// K3 (plan_build.cpp); sections: those whose coefficients decoded, section_of[i] = their index in the frame
+uint32_t build_trailer_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, const uint32_t *end_bits, const uint32_t *k1_status, HostModPlan *hp,
+		std::vector<std::pair<int32_t, uint32_t>> *trailer_errors, std::vector<int32_t> *section_of);
+
 // fills a DevCodeSpec and appends its tables to the pools
 void flatten_code_spec(const CodeSpec &spec, std::vector<uint8_t> &u8, std::vector<int32_t> &i32, std::vector<uint64_t> &u64, std::vector<DevCluster> &clusters, DevCodeSpec *out);
 

@@ -217,6 +217,8 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 	plan.xfromy = hp.xfromy.data(); plan.bfromy = hp.bfromy.data();
 	plan.nonzeros = nonzeros.data(); plan.status = status.data();
 	plan.lz_window = window.empty() ? nullptr : window.data(); plan.lz_window_size = hp.lz_window_size;
+	std::vector<uint32_t> end_bits(status.size(), 0);
+	plan.section_end_bit = hp.frame.sections_have_trailer ? end_bits.data() : nullptr;
 
 	if (only_entropy & 4) {   // bit 2: the throughput kernel's fast path (hf_lanes_dev.h), tables laid out as the kernel stages them
 		if (!hp.hf.lanes_fast) return ERR_TODO;
@@ -255,6 +257,30 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 			const std::vector<int32_t> &order = fr.orders[0][DCT_SELECT[vb.dctsel].order_idx][(size_t) c];
 			for (uint32_t e = 0; e < n; ++e) { const CoeffEvent &ev = events[be[0] + skip + e]; dst[(size_t) vb.coeff_base + (size_t) order[ev.pos]] = (float) ev.value; }
 		}
+	}
+	// the Modular sub-images behind the coefficients (VarDCT frames with extra channels), as runtime.hip's validate_trailers does
+	if (hp.frame.sections_have_trailer && !(only_entropy & 4) && g_group_count < 0) {
+		HostModPlan tp;
+		std::vector<std::pair<int32_t, uint32_t>> header_errors;
+		std::vector<int32_t> section_of;
+		if (uint32_t e = build_trailer_plan(fr, hp.codestream.data(), hp.codestream.size() - 16, end_bits.data(), status.data(), &tp, &header_errors, &section_of)) return e;
+		DevModPlan mp;
+		memset(&mp, 0, sizeof mp);
+		mp.frame = &tp.frame; mp.codestream = hp.codestream.data(); mp.pool_u8 = tp.pool_u8.data(); mp.pool_i32 = tp.pool_i32.data(); mp.pool_u64 = tp.pool_u64.data();
+		mp.clusters = tp.clusters.data(); mp.spec = tp.specs.data(); mp.tree = tp.tree.data(); mp.sections = tp.sections.data();
+		std::vector<std::vector<int16_t>> store(tp.sub_w.size());
+		std::vector<DevSubPlane> subp(tp.sub_w.size());
+		for (size_t k = 0; k < subp.size(); ++k) { store[k].assign((size_t) tp.sub_w[k] * (size_t) tp.sub_h[k] + 1, 0); subp[k] = DevSubPlane{store[k].data(), tp.sub_w[k], tp.sub_h[k], tp.sub_meta[k], 0}; }
+		mp.sub_planes = subp.data();
+		std::vector<int32_t> wps(tp.sections.size() * (size_t) (2 * tp.frame.max_width * 5) + 16), win(tp.lz_window_size ? tp.sections.size() * tp.lz_window_size : 0);
+		std::vector<uint32_t> tstatus(tp.sections.size() + 1, 0);
+		mp.wp_scratch = tp.frame.tree_uses_wp ? wps.data() : nullptr;
+		mp.lz_window = win.empty() ? nullptr : win.data(); mp.lz_window_size = tp.lz_window_size; mp.status = tstatus.data();
+		for (int32_t i = 0; i < tp.frame.num_sections; ++i) {
+			const ModTables mt = mod_tables_in_hbm(mp, i);
+			if (const uint32_t e = decode_modular_section<false, false>(mp, mt, i)) status[(size_t) section_of[(size_t) i]] = e;
+		}
+		for (const auto &e : header_errors) status[(size_t) e.first] = e.second;
 	}
 	for (uint32_t s : status) if (s) return s;
 	if (only_entropy & 1) return 0;

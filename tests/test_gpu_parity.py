@@ -455,3 +455,23 @@ def test_corrupt_sections_report_reference_errors(gpu, ref):
     assert checked >= 1
     err, _ = gpu.decode(bytes(data[: len(data) - 100]))
     assert err == "shrt"
+
+
+def test_damage_in_extra_channel_sub_images_is_reported(gpu, ref):
+    """VarDCT frame with an alpha channel: every pass-group section goes on with the channel's Modular sub-image after the HF
+    coefficients. The reference decodes it (and later drops it); damage there must give the reference's error code, not pass
+    unnoticed (runtime.hip: validate_trailers)"""
+    data = synth("vardct", 520, 264, 33, alpha=1)
+    rng = np.random.default_rng(5)
+    seen = {}
+    for _ in range(40):
+        mutated = bytearray(data)
+        pos = int(rng.integers(len(data) // 3, len(data)))
+        mutated[pos] ^= 1 << int(rng.integers(0, 8))
+        rerr, rexp = ref.decode(bytes(mutated))
+        err, rgba = gpu.decode(bytes(mutated))
+        assert err == rerr, (pos, rerr, err)
+        if rerr == "":
+            assert compare(rgba, rexp)[0] <= 1
+        seen[rerr] = seen.get(rerr, 0) + 1
+    assert sum(v for k, v in seen.items() if k) >= 10, seen

@@ -118,3 +118,23 @@ def test_lane_decoder_reports_the_same_errors_on_corrupt_streams(sim, ref):
         assert code == rerr, (trial, code, rerr)
         seen.add(code)
     assert len(seen) >= 3, seen
+
+
+def test_damage_behind_the_coefficients_of_alpha_frames(sim, ref):
+    """VarDCT + alpha: the Modular sub-image behind each section's HF coefficients is decoded for its status (build_trailer_plan +
+    the K3 section decoder), so bit flips anywhere in the sections give the reference's code"""
+    data = synth("vardct", 520, 264, 33, alpha=1)
+    rng = np.random.default_rng(5)
+    out = np.zeros((264, 520, 4), np.uint8)
+    sim.hostsim_decode.restype = C.c_uint32
+    sim.hostsim_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+    rejected = 0
+    for _ in range(60):
+        mutated = bytearray(data)
+        mutated[int(rng.integers(len(data) // 3, len(data)))] ^= 1 << int(rng.integers(0, 8))
+        rerr, _ = ref.decode(bytes(mutated))
+        buf = C.create_string_buffer(bytes(mutated), len(mutated))
+        code = sim.hostsim_decode(buf, len(mutated), out.ctypes.data, None, 0)
+        assert ("" if code == 0 else code.to_bytes(4, "big").decode("latin1")) == rerr
+        rejected += rerr != ""
+    assert rejected >= 30
