@@ -88,7 +88,9 @@ typedef struct { uint32_t byte_off, size, bit_off; int32_t ggidx, gx_in_gg, gy_i
 typedef struct {
 	int32_t width, height, num_passes, num_groups, num_lf_groups;
 	int32_t nb_block_ctx, nb_qf_thr, nb_lf_thr[3], num_hf_presets, bpp;
-	int32_t sections_have_trailer;   /* extra channels: a Modular sub-image follows the coefficients of each section (not decoded) */
+	int32_t sections_have_trailer;   /* extra channels: a Modular sub-image follows the coefficients of each section */
+	int32_t check_section_end;       /* single-section frames only: zero padding + no bytes left at the section's end (the reference checks
+	                                    nothing in frames with several sections, j40.h:7778-7795) */
 	int32_t global_scale, x_qm_scale, b_qm_scale, x_factor_lf, b_factor_lf;
 	float quant_bias[3], quant_bias_num, base_corr_x, base_corr_b, inv_colour_factor;
 	float opsin_inv_mat[9], opsin_bias[3], intensity_target;
@@ -121,6 +123,7 @@ typedef struct {
 
 typedef struct {
 	int32_t width, height, bpp, num_channels, num_sections, num_transforms, num_tree_nodes, alpha_channel;
+	int32_t check_section_end;     /* as in j40hip_vardct_view */
 	const uint8_t *codestream; size_t codestream_size;
 	const j40hip_codespec_view *codespec;     /* [num_codespecs] */
 	const j40hip_tree_node *tree;              /* [num_tree_nodes]: every tree in use, back to back */
@@ -137,6 +140,12 @@ typedef struct {
 /* The seam for a host that parses the bitstream itself (a patched j40): a frame handle built from the
  * view instead of from a bitstream; then j40hip_frame_upload / j40hip_frame_decode* as usual. Everything is copied. */
 J40HIP_API j40hip_frame *j40hip_frame_from_vardct_view(const j40hip_vardct_view *v, uint32_t *err);
+
+/* What the reference reports after a frame that decoded cleanly: "excs" when bytes follow the frame and the reference gets to see
+ * them -- always for single-section frames; for frames with several sections only if the frame ends within the first 64 KB its main
+ * buffer holds (j40__seek_buffer, j40.h:1745-1760: otherwise the buffer is emptied, not refilled, and j40__no_more_bytes passes).
+ * Bare codestreams only; 0 otherwise. The public API (api.cpp) applies it after a successful decode. */
+J40HIP_API uint32_t j40hip_frame_after_frame_status(const j40hip_frame *f);
 
 /* fill the views for a parsed frame; return 0 or a 4-char code ("TODO" for frames the hot path does not cover) */
 J40HIP_API uint32_t j40hip_frame_vardct_view(j40hip_frame *f, j40hip_vardct_view *out);

@@ -115,6 +115,7 @@ j40_err advance(j40__inner *inner, int origin) {
 		err = j40hip_frame_upload(inner->frame, dev ? atoi(dev) : 0);
 	}
 	if (!err) err = j40hip_frame_decode_to_host(inner->frame, inner->pixels, (size_t) inner->stride_bytes);
+	if (!err) err = j40hip_frame_after_frame_status(inner->frame);   // bytes behind the frame (j40__no_more_bytes, j40.h:8215)
 	if (err) { inner->origin = origin; inner->err = err; return err; }
 	inner->decoded = 1;
 	return 0;

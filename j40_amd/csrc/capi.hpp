@@ -10,6 +10,7 @@ struct j40hip_frame {
 	const uint8_t *cs = nullptr;     // codestream bytes (inside the caller's buffer, or cs_storage)
 	size_t cs_size = 0;
 	std::vector<uint8_t> cs_storage;
+	bool bare_codestream = false;    // the input was the codestream itself, no container around it
 	j40hip::Frame frame;
 	j40hip_device_state *dev = nullptr;
 	bool force_dense = false;        // upload with dense coefficient planes (set after a decode ran out of event space, ERR_EVOF)

@@ -11,6 +11,7 @@ j40hip_frame *j40hip_frame_parse(const void *buf, size_t size, int threads, uint
 	uint32_t code = 0;
 	try {
 		extract_codestream((const uint8_t *) buf, size, &h->cs, &h->cs_size, &h->cs_storage);
+		h->bare_codestream = h->cs == (const uint8_t *) buf && h->cs_size == size;
 		parse_frame(h->cs, h->cs_size, &h->frame, threads);
 	} catch (const DecodeError &e) { code = e.code; }
 	catch (const std::bad_alloc &) { code = E4("!mem"); }
@@ -98,6 +99,14 @@ j40hip_frame *j40hip_frame_from_vardct_view(const j40hip_vardct_view *v, uint32_
 	if (err) *err = code;
 	if (code) { delete h; return nullptr; }
 	return h;
+}
+
+uint32_t j40hip_frame_after_frame_status(const j40hip_frame *h) {
+	if (!h || !h->bare_codestream) return 0;   // (container input or a handle built from a view: not modelled)
+	const size_t end = h->frame.toc.end_offset;
+	if (end >= h->cs_size) return 0;
+	if (h->frame.toc.single) return E4("excs");
+	return end < std::min<size_t>(h->cs_size, 0x10000) ? E4("excs") : 0;
 }
 
 void j40hip_frame_free(j40hip_frame *f) {
@@ -199,6 +208,7 @@ uint32_t j40hip_frame_vardct_view(j40hip_frame *h, j40hip_vardct_view *v) {
 	v->nb_block_ctx = f.nb_block_ctx; v->nb_qf_thr = f.nb_qf_thr; for (int i = 0; i < 3; ++i) v->nb_lf_thr[i] = f.nb_lf_thr[i];
 	v->num_hf_presets = f.num_hf_presets; v->bpp = f.im.bpp;
 	v->sections_have_trailer = (int32_t) f.gmodular.channel.size() > f.num_gm_channels;
+	v->check_section_end = f.toc.single && !v->sections_have_trailer;
 	v->global_scale = f.global_scale; v->x_qm_scale = f.fh.x_qm_scale; v->b_qm_scale = f.fh.b_qm_scale; v->x_factor_lf = f.x_factor_lf; v->b_factor_lf = f.b_factor_lf;
 	for (int i = 0; i < 3; ++i) { v->quant_bias[i] = f.im.quant_bias[i]; v->opsin_bias[i] = f.im.opsin_bias[i]; for (int j = 0; j < 3; ++j) v->opsin_inv_mat[i * 3 + j] = f.im.opsin_inv_mat[i][j]; }
 	v->quant_bias_num = f.im.quant_bias_num; v->base_corr_x = f.base_corr_x; v->base_corr_b = f.base_corr_b; v->inv_colour_factor = f.inv_colour_factor;
@@ -251,6 +261,7 @@ uint32_t j40hip_frame_modular_view(j40hip_frame *h, j40hip_modular_view *v) {
 	h->views.clusters.reserve(hp.host_specs.size() + 1);
 	v->width = f.fh.width; v->height = f.fh.height; v->bpp = f.im.bpp; v->num_channels = hp.frame.num_channels; v->num_sections = hp.frame.num_sections;
 	v->alpha_channel = hp.alpha_channel;
+	v->check_section_end = hp.frame.check_section_end;
 	v->codestream = h->cs; v->codestream_size = h->cs_size;
 	h->views.specs.assign(hp.host_specs.size(), j40hip_codespec_view());
 	h->views.host_specs = hp.host_specs;   // the views point into these

@@ -44,7 +44,7 @@ struct LaneTables {
 
 // the frame scalars the decoder needs, copied out of DevFrame once (wave-uniform)
 struct LaneFrame {
-	int32_t nb_block_ctx, num_hf_presets, preset_bits, sections_have_trailer;
+	int32_t nb_block_ctx, num_hf_presets, preset_bits, check_section_end;   // (DevFrame::check_section_end)
 	const J40_GLOBAL uint32_t *order_off;  // DevFrame::order_off
 };
 
@@ -251,11 +251,11 @@ J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t,
 		if (state == 0) { lane_bits_refill(b); state = lane_bits_take(b, 16); state |= lane_bits_take(b, 16) << 16; if (lane_bit_position(b) > end_bit) err = ERR_SHRT; }
 		if (!err && state != 0x130000) err = ERR_ANS;
 	}
-	if (!err && !f.sections_have_trailer) {   // the section ends here: zero padding up to the byte boundary, then no byte left (j40.h:2011)
+	if (!err && f.check_section_end) {   // single-section frames: zero padding up to the byte boundary, then no byte of the section left (j40.h:8203, 7796)
 		const uint32_t at = lane_bit_position(b), padn = (0u - at) & 7u;
 		if (padn > (uint32_t) b.nbits) lane_bits_refill(b);
 		if (lane_bits_take(b, (int32_t) padn)) err = ERR_PAD0;
-		else if (at + padn != end_bit) err = at + padn > end_bit ? (uint32_t) ERR_SHRT : (uint32_t) ERR_EXCS;
+		else if (at + padn != end_bit) err = ERR_SHRT;
 	}
 	return err;
 }

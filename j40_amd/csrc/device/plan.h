@@ -94,6 +94,11 @@ struct DevFrame {
 	// The reference decodes it and then drops it (j40__combine_vardct replaces the channel list, j40.h:7868-7870: the output is
 	// opaque); here it is not decoded, so a section does not have to end where its coefficients end.
 	int32_t sections_have_trailer;           // pass 0: the three channels share one coefficient order (the usual case)
+	// Whether the end of a section is checked. Only in frames that are one section (then: zero padding to the byte boundary,
+	// j40.h:8203, and bytes left over are `shrt`, j40.h:7796-7803). In frames with several sections the reference checks
+	// nothing: j40__finish_section_state (j40.h:7778-7795) runs j40__no_more_bytes on the section's own state and returns the
+	// parent's error code, so `pad0` / `excs` never surface -- junk behind a section's data is accepted, and so it is here.
+	int32_t check_section_end;
 };
 
 struct CoeffEvent { uint32_t pos; int32_t value; };   // one non-zero quantised HF coefficient: scan position inside its block
@@ -181,6 +186,7 @@ struct DevModFrame {
 	int32_t num_channels;           // channels of the global Modular image as coded (before inverse transforms)
 	int32_t tree_uses_wp, num_tree_nodes;
 	int32_t max_width;              // widest rectangle any section decodes (sizes the weighted-predictor rows)
+	int32_t check_section_end;      // see DevFrame::check_section_end
 };
 
 struct DevModPlan {

@@ -725,21 +725,21 @@ void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
 		// group reads nothing (j40.h:7024-7025) and the section has to end here
 		J40HIP_SHOULD(f->num_gm_channels == (int32_t) f->gmodular.channel.size(), "TODO");
 		sr.zero_pad_to_byte();
-		J40HIP_SHOULD(sr.byte_position() == f->toc.single_section.size, "excs");
+		J40HIP_SHOULD(sr.byte_position() == f->toc.single_section.size, "shrt");   // bytes of the section left over (j40__end_of_frame, j40.h:7796-7803)
 		return;
 	}
 
 	{
 		BitReader sr(cs + f->toc.lf_global.offset, f->toc.lf_global.size);
 		read_lf_global(sr, f);
-		if (!f->gm_data_pending) sr.no_more_bytes();
+		// (no check that the section ends here, in none of the sections of a frame that has several: the reference's
+		// j40__finish_section_state runs j40__no_more_bytes on the section's own state and returns the parent's, j40.h:7778-7795)
 	}
 	if (f->fh.is_modular) {
 		J40HIP_SHOULD(f->toc.hf_global.size == 0, "excs");
 	} else {
 		BitReader sr(cs + f->toc.hf_global.offset, f->toc.hf_global.size);
 		read_hf_global(sr, f);
-		sr.no_more_bytes();
 	}
 	// LfGroup sections are independent of each other
 	const int64_t n = f->fh.num_lf_groups;
@@ -753,7 +753,6 @@ void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
 			try {
 				BitReader sr(cs + f->toc.lf_groups[(size_t) i].offset, f->toc.lf_groups[(size_t) i].size);
 				read_lf_group(sr, f, &f->lf_groups[(size_t) i]);
-				sr.no_more_bytes();
 			} catch (const DecodeError &e) { errs[(size_t) i] = e.code; }
 		}
 	};

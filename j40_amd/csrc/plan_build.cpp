@@ -50,6 +50,7 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 	df.num_hf_presets = fr.num_hf_presets; df.preset_bits = ceil_lg32((uint32_t) fr.num_hf_presets);
 	df.bpp = fr.im.bpp;
 	df.sections_have_trailer = (int32_t) fr.gmodular.channel.size() > fr.num_gm_channels;
+	df.check_section_end = fr.toc.single && !df.sections_have_trailer;
 	for (int c = 0; c < 3; ++c) { df.quant_bias[c] = fr.im.quant_bias[c]; df.opsin_bias[c] = fr.im.opsin_bias[c]; df.cbrt_opsin_bias[c] = cbrtf(fr.im.opsin_bias[c]); }
 	df.quant_bias_num = fr.im.quant_bias_num;
 	static const float QM_SCALE[8] = {1.5625f, 1.25f, 1.0f, 0.8f, 0.64f, 0.512f, 0.4096f, 0.32768f};  // 0.8^(i-2), j40.h:7055
@@ -264,6 +265,7 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 	memset(&df, 0, sizeof df);
 	df.width = fr.fh.width; df.height = fr.fh.height; df.num_groups = (int32_t) fr.fh.num_groups; df.bpp = fr.im.bpp;
 	df.num_channels = nch;
+	df.check_section_end = fr.toc.single;
 	// trees and code specs: the global pair once (when a header refers to it), own pairs per section (use_global_tree = 0)
 	int32_t global_spec = -1; uint32_t global_tree_off = 0;
 	auto attach = [&](const Modular &m, DevModSection *s) { attach_tables(fr, hp, global_spec, global_tree_off, m, s); };

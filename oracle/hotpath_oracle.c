@@ -52,7 +52,7 @@ static void obits_finish(obits *b) {  /* j40__no_more_bytes, j40.h:2011 */
 	int n = b->nbits & 7;
 	if (b->bits & (((uint64_t) 1 << n) - 1)) { if (!b->err) b->err = E4('p', 'a', 'd', '0'); }
 	b->bits >>= n; b->nbits -= n;
-	if ((b->nbits != 0 || b->p != b->end) && !b->err) b->err = E4('e', 'x', 'c', 's');
+	if ((b->nbits != 0 || b->p != b->end) && !b->err) b->err = E4('s', 'h', 'r', 't');   /* single-section frames: j40__end_of_frame, j40.h:7796-7803 */
 }
 
 /* ---------------------------------------------------------------------------------------------- */
@@ -273,7 +273,7 @@ static uint32_t hf_coeffs(const j40hip_vardct_view *v, int pass, const j40hip_se
 	if (!b.err) ocode_finish(&b, code);
 	/* extra channels: the group's Modular sub-image follows (j40.h:7024-7034); the reference decodes and then drops it
 	 * (j40.h:7868-7870), this restatement of the pixel path stops at the coefficients */
-	if (!b.err && !v->sections_have_trailer) obits_finish(&b);
+	if (!b.err && v->check_section_end) obits_finish(&b);   /* never in frames with several sections: j40.h:7778-7795 drops that error */
 	free(nonzeros);
 	return b.err;
 }
@@ -681,7 +681,7 @@ static uint32_t modular_section(const j40hip_modular_view *v, const j40hip_modul
 		free(wp.errors); wp.errors = NULL;
 	}
 	if (!b.err && !err) ocode_finish(&b, code);
-	if (!b.err && !err) obits_finish(&b);
+	if (!b.err && !err && v->check_section_end) obits_finish(&b);
 	return b.err ? b.err : err;
 }
 

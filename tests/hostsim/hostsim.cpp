@@ -223,7 +223,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 	if (only_entropy & 4) {   // bit 2: the throughput kernel's fast path (hf_lanes_dev.h), tables laid out as the kernel stages them
 		if (!hp.hf.lanes_fast) return ERR_TODO;
 		const DevFrame &df = hp.frame;
-		LaneFrame lf = {df.nb_block_ctx, df.num_hf_presets, df.preset_bits, df.sections_have_trailer, df.order_off};
+		LaneFrame lf = {df.nb_block_ctx, df.num_hf_presets, df.preset_bits, df.check_section_end, df.order_off};
 		LaneGlobals G = {plan.codestream, (const uint32_t *) plan.group_blocks, plan.coeffs[0], plan.events, plan.block_events, plan.pool_u16, plan.coeff_stride};
 		std::vector<int8_t> cols(3 * 32);
 		std::vector<uint32_t> dct(27);

@@ -475,3 +475,29 @@ def test_damage_in_extra_channel_sub_images_is_reported(gpu, ref):
             assert compare(rgba, rexp)[0] <= 1
         seen[rerr] = seen.get(rerr, 0) + 1
     assert sum(v for k, v in seen.items() if k) >= 10, seen
+
+
+def test_section_ends_and_bytes_behind_the_frame_like_the_reference(gpu, ref):
+    """junk behind the sections' data (accepted in multi-section frames, `shrt` in single-section ones), bytes behind the frame
+    (`excs` when the reference's main buffer still holds them, j40hip_frame_after_frame_status), damaged prefix-coded sections"""
+    for mode, w, h, o in [("modular", 600, 300, dict(slack=2)), ("modular", 256, 256, dict(slack=2)), ("vardct", 520, 264, dict(slack=3)),
+                          ("vardct", 520, 264, dict(slack=1, alpha=1)), ("modular", 600, 300, dict(slack=1, prefix=1, lz77=1))]:
+        d = synth(mode, w, h, 9, **o)
+        rerr, px = ref.decode(d)
+        err, out = gpu.decode(d)
+        assert err == rerr, (mode, o, rerr, err)
+        if rerr == "":
+            assert compare(out, px)[0] <= (0 if mode == "modular" else 1)
+    for mode, w, h, o in [("modular", 600, 300, dict()), ("modular", 256, 256, dict()), ("modular", 600, 300, dict(palette=1)), ("vardct", 520, 264, dict()), ("vardct", 1100, 700, dict())]:
+        d = synth(mode, w, h, 9, **o) + b"\x00\x01\x02"
+        rerr, _ = ref.decode(d)
+        err, _ = gpu.decode(d)
+        assert err == rerr, (mode, w, h, o, rerr, err)
+    d = synth("modular", 762, 8, 236738, prefix=1, lz77=1)
+    rng = np.random.default_rng(3)
+    for _ in range(30):
+        b = bytearray(d)
+        b[int(rng.integers(len(d) // 4, len(d)))] ^= 1 << int(rng.integers(8))
+        rerr, px = ref.decode(bytes(b))
+        err, out = gpu.decode(bytes(b))
+        assert err == rerr and (rerr != "" or np.array_equal(px, out))

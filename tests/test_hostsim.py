@@ -138,3 +138,35 @@ def test_damage_behind_the_coefficients_of_alpha_frames(sim, ref):
         assert ("" if code == 0 else code.to_bytes(4, "big").decode("latin1")) == rerr
         rejected += rerr != ""
     assert rejected >= 30
+
+
+def test_section_ends_are_checked_the_way_the_reference_checks_them(sim, ref):
+    """In frames with several sections the reference notices neither junk behind a section's data nor a section that stops short of
+    its end (j40__finish_section_state drops the error of its own j40__no_more_bytes, j40.h:7778-7795); single-section frames get
+    `pad0` / `shrt`. Prefix-coded streams have no final-state check, so this decides whether a damaged stream is accepted."""
+    sim.hostsim_decode.restype = C.c_uint32
+    sim.hostsim_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+
+    def mine(d, w, h):
+        out = np.zeros((h, w, 4), np.uint8)
+        buf = C.create_string_buffer(d, len(d))
+        code = sim.hostsim_decode(buf, len(d), out.ctypes.data, None, 0)
+        return ("" if code == 0 else code.to_bytes(4, "big").decode("latin1")), out
+
+    for mode, w, h, o in [("modular", 600, 300, dict(slack=2)), ("modular", 256, 256, dict(slack=2)), ("vardct", 520, 264, dict(slack=3)),
+                          ("vardct", 520, 264, dict(slack=1, alpha=1)), ("modular", 600, 300, dict(slack=1, prefix=1, lz77=1)),
+                          ("vardct", 200, 200, dict(slack=2, passes=2)), ("vardct", 392, 264, dict(slack=1, hfprefix=1))]:
+        d = synth(mode, w, h, 9, **o)
+        rerr, px = ref.decode(d)
+        err, out = mine(d, w, h)
+        assert err == rerr, (mode, o, rerr, err)
+        if rerr == "":
+            assert np.abs(px.astype(int) - out).max() <= (0 if mode == "modular" else 1)
+    d = synth("modular", 762, 8, 236738, prefix=1, lz77=1)   # prefix codes: a flipped bit desynchronises the rest of the section
+    rng = np.random.default_rng(3)
+    for _ in range(80):
+        b = bytearray(d)
+        b[int(rng.integers(len(d) // 4, len(d)))] ^= 1 << int(rng.integers(8))
+        rerr, px = ref.decode(bytes(b))
+        err, out = mine(bytes(b), 762, 8)
+        assert err == rerr and (rerr != "" or np.array_equal(px, out))

@@ -2,12 +2,19 @@
 """random generator options x sizes x seeds: the device headers compiled for the CPU (build/libhostsim.so) against the
 reference (oracle/_ref). CPU only; a cheap way to look for parity bugs between GPU runs.  python tools/fuzz_parity.py [n] [seed]
 With a third argument "gpu" the product library decodes instead (public API, needs an MI355X)."""
-import ctypes as C, os, random, sys
+import ctypes as C, os, random, subprocess, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
-from streams import synth
+from streams import SYNTH
 from refdec import Ref
+
+
+def synth(mode, w, h, seed, **opts):
+    """like streams.synth, but without leaving the stream in the on-disk cache (hundreds of them would travel to the GPU box)"""
+    with tempfile.NamedTemporaryFile(suffix=".jxl") as tmp:
+        subprocess.run([SYNTH, mode, str(w), str(h), str(seed), tmp.name] + ["%s=%s" % kv for kv in sorted(opts.items())], check=True, stderr=subprocess.DEVNULL)
+        return open(tmp.name, "rb").read()
 
 
 def pick_vardct(r):
@@ -73,6 +80,8 @@ def main():
         except Exception as e:   # option combinations the generator refuses
             skipped += 1
             continue
+        if r.random() < .3:   # one flipped bit somewhere behind the headers: the error code must match, too
+            b = bytearray(d); b[r.randrange(len(d) // 3, len(d))] ^= 1 << r.randrange(8); d = bytes(b)
         e, px = ref.decode(d)
         if on_gpu:
             mine, out = j40_amd.decode(d)

@@ -140,7 +140,11 @@ static void write_bit_depth(BitWriter &cs, int bpp) {
 
 // TOC + sections (j40.h:5505-5543). permute != 0: the sections are stored in a shuffled order and the TOC carries the
 // Lehmer-coded permutation that puts them back (the decoder applies it to the list of stored sections, j40.h:5540).
-static void write_toc_and_sections(BitWriter &cs, const std::vector<std::vector<uint8_t>> &sections, int permute, SplitMix64 &rng) {
+static void write_toc_and_sections(BitWriter &cs, const std::vector<std::vector<uint8_t>> &sections_in, int permute, SplitMix64 &rng, int slack = 0) {
+	// slack=K: K junk bytes behind the data of every non-empty section. The reference does not notice them in frames with more
+	// than one section (j40__finish_section_state drops the error of its own j40__no_more_bytes, j40.h:7778-7795)
+	std::vector<std::vector<uint8_t>> sections = sections_in;
+	if (slack) for (auto &s : sections) if (!s.empty()) for (int k = 0; k < slack; ++k) s.push_back((uint8_t) (0xa5 + 17 * k));
 	const size_t n = sections.size();
 	std::vector<size_t> stored_at(n);   // logical section i is the stored_at[i]-th stored one
 	for (size_t i = 0; i < n; ++i) stored_at[i] = i;
@@ -687,7 +691,7 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 		cs.u64(0);                          // frame extensions
 	}
 	// TOC (j40.h:5505-5531)
-	write_toc_and_sections(cs, sections, opt.geti("permute", 0), rng);
+	write_toc_and_sections(cs, sections, opt.geti("permute", 0), rng, opt.geti("slack", 0));
 
 	std::vector<uint8_t> file;
 	if (!container) file = cs.bytes;
@@ -1072,7 +1076,7 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	cs.u32(0, 0, 0, 0, 4, 16, 5, 48, 10);
 	cs.put(0, 1); cs.put(0, 1); cs.put(0, 2); cs.u64(0);   // restoration: explicit, gab off, epf 0, no extensions
 	cs.u64(0);                          // frame extensions
-	write_toc_and_sections(cs, sections, opt.geti("permute", 0), rng);
+	write_toc_and_sections(cs, sections, opt.geti("permute", 0), rng, opt.geti("slack", 0));
 	std::vector<uint8_t> file = cs.bytes;
 	if (container) {
 		static const uint8_t HEAD[32] = {0, 0, 0, 0x0c, 'J', 'X', 'L', ' ', 0x0d, 0x0a, 0x87, 0x0a, 0, 0, 0, 0x14, 'f', 't', 'y', 'p', 'j', 'x', 'l', ' ', 0, 0, 0, 0, 'j', 'x', 'l', ' '};
