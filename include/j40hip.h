@@ -119,6 +119,7 @@ typedef struct {
 	 * sub_transforms[sub_tr_off .. sub_tr_off + sub_tr_count) undone there, then the channels pasted over the rectangle unless
 	 * sub_paste is 0 (an earlier pass of a multi-pass frame). sub_off < 0: no sub-image, channels first_channel ... of the frame */
 	int32_t sub_off, sub_tr_off, sub_tr_count, sub_paste;
+	uint32_t preset_status;        /* != 0: the section's own Modular header did not parse; this is its status, nothing is decoded */
 } j40hip_modular_section_view;
 
 typedef struct {

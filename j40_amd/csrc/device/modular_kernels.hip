@@ -28,6 +28,7 @@ __global__ void __launch_bounds__(64) k_modular_sections(DevModPlan plan, int32_
 	const int32_t lane = threadIdx.x;
 	const int32_t s = first_section + (int32_t) blockIdx.x;
 	const DevModSection &msec = plan.sections[s];
+	if (msec.preset_status) { if (lane == 0) plan.status[s] = msec.preset_status; return; }
 	const DevCodeSpec &spec = plan.spec[msec.spec_idx];
 	ModTables t = mod_tables_in_hbm(plan, s);
 	if (IN_LDS) {

@@ -171,7 +171,9 @@ struct DevModSection {
 	// channel, tightly packed) -- the sub-image the reference allocates (j40.h:7024-7031); the host then schedules its inverse
 	// transforms and pastes the result into the frame planes. -1: the channels are the frame planes first_channel ...
 	int32_t sub_off;
-	int32_t pad;
+	// != 0: the section's own Modular header did not parse (on the host); nothing is decoded and this becomes the section's status,
+	// so that it takes its place among the other sections' errors (the first failing section in stream order is reported)
+	uint32_t preset_status;
 };
 
 struct DevSubPlane { int16_t *ptr; int32_t w, h, meta, pad; };

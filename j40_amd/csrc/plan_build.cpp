@@ -303,10 +303,15 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 			Modular m; m.bpp = fr.im.bpp;
 			for (int32_t c = fr.num_gm_channels; c < nch; ++c) { Plane p; p.width = gi.gw; p.height = gi.gh; m.channel.push_back(p); }
 			BitReader br(cs + ps.offset, ps.size);
-			try { read_modular_header(br, &fr.global_tree, &fr.global_codespec, &m); } catch (const DecodeError &e) { return e.code; }
 			DevModSection s;
 			memset(&s, 0, sizeof s);
 			s.sub_off = -1;
+			try { read_modular_header(br, &fr.global_tree, &fr.global_codespec, &m); }
+			catch (const DecodeError &e) {   // reported in its place among the sections (an earlier section's data may fail first)
+				s.byte_off = (uint32_t) ps.offset; s.size = (uint32_t) ps.size; s.preset_status = e.code;
+				hp->sections.push_back(s);
+				continue;
+			}
 			// the group's own transforms. RCTs only: undone in place over the group's rectangle. With a palette the channel list of
 			// the section differs from the frame's: it decodes into a sub-image of its own, the host undoes its transforms there
 			s.local_off = (int32_t) (hp->local_rct.size() / 2);

@@ -784,6 +784,7 @@ ORACLE_API uint32_t oracle_decode_modular(const j40hip_modular_view *v, uint8_t 
 	for (i = 0; i < v->num_codespecs; ++i) ocode_init(&codes[i], &v->codespec[i]);
 	for (s = 0; s < v->num_sections && !err; ++s) {
 		const j40hip_modular_section_view *sec = &v->sections[s];
+		if (sec->preset_status) { err = sec->preset_status; break; }
 		if (sec->sub_off < 0) { err = modular_section(v, sec, planes, &codes[sec->spec_idx]); continue; }
 		{   /* the section's own sub-image: decode, undo its transforms, paste */
 			oplane sp[64];

@@ -97,6 +97,7 @@ static uint32_t hostsim_decode_modular(const Frame &fr, const uint8_t *cs, size_
 	plan.lz_window = window.empty() ? nullptr : window.data(); plan.lz_window_size = hp.lz_window_size; plan.status = status.data();
 	std::vector<int32_t> ring(3 * ((size_t) hp.frame.max_width + 4) + 8, 0x7fff0000), wperr(10 * (size_t) hp.frame.max_width + 8);
 	for (int32_t sct = 0; sct < hp.frame.num_sections; ++sct) {
+		if (hp.sections[(size_t) sct].preset_status) { status[(size_t) sct] = hp.sections[(size_t) sct].preset_status; continue; }
 		ModTables mt = mod_tables_in_hbm(plan, sct);
 		mt.rows = ring.data(); mt.rows_width = hp.frame.max_width + 4; mt.wp_errors = wperr.data(); mt.wp_errors_width = hp.frame.max_width;   // as the kernel lays them out in LDS
 		status[(size_t) sct] = (sct & 1) ? decode_modular_section<false, true>(plan, mt, sct) : decode_modular_section<false, false>(plan, mt, sct);   // both neighbour sources

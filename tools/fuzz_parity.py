@@ -61,6 +61,9 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     r = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     on_gpu = len(sys.argv) > 3 and sys.argv[3] == "gpu"
+    flip_share = float(os.environ.get("FUZZ_FLIPS", "0.3"))
+    flip_from = float(os.environ.get("FUZZ_FROM", "0.33"))   # flips land in [this share of the file, end): 0 includes the headers
+    flip_to = int(os.environ.get("FUZZ_TO", str(1 << 62)))           # ... or in the first FUZZ_TO bytes
     if on_gpu:
         import torch   # (loads the HIP runtime the library is to share)
         import j40_amd
@@ -80,8 +83,10 @@ def main():
         except Exception as e:   # option combinations the generator refuses
             skipped += 1
             continue
-        if r.random() < .3:   # one flipped bit somewhere behind the headers: the error code must match, too
-            b = bytearray(d); b[r.randrange(len(d) // 3, len(d))] ^= 1 << r.randrange(8); d = bytes(b)
+        if r.random() < flip_share:   # one flipped bit somewhere behind the headers: the error code must match, too
+            b = bytearray(d)   # (not in the size header: the buffers here are sized from the clean stream)
+            b[r.randrange(max(12, int(len(d) * flip_from)), min(len(d), flip_to))] ^= 1 << r.randrange(8)
+            d = bytes(b)
         e, px = ref.decode(d)
         if on_gpu:
             mine, out = j40_amd.decode(d)
