@@ -11,6 +11,7 @@ struct j40hip_frame {
 	size_t cs_size = 0;
 	std::vector<uint8_t> cs_storage;
 	bool bare_codestream = false;    // the input was the codestream itself, no container around it
+	int container_stray_tail = 0;    // container input: 1..7 bytes behind the last box (not enough for a box header)
 	j40hip::Frame frame;
 	j40hip_device_state *dev = nullptr;
 	bool force_dense = false;        // upload with dense coefficient planes (set after a decode ran out of event space, ERR_EVOF)

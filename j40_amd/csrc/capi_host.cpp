@@ -10,7 +10,7 @@ j40hip_frame *j40hip_frame_parse(const void *buf, size_t size, int threads, uint
 	j40hip_frame *h = new j40hip_frame();
 	uint32_t code = 0;
 	try {
-		extract_codestream((const uint8_t *) buf, size, &h->cs, &h->cs_size, &h->cs_storage);
+		extract_codestream((const uint8_t *) buf, size, &h->cs, &h->cs_size, &h->cs_storage, &h->container_stray_tail);
 		h->bare_codestream = h->cs == (const uint8_t *) buf && h->cs_size == size;
 		parse_frame(h->cs, h->cs_size, &h->frame, threads);
 	} catch (const DecodeError &e) { code = e.code; }
@@ -102,8 +102,13 @@ j40hip_frame *j40hip_frame_from_vardct_view(const j40hip_vardct_view *v, uint32_
 }
 
 uint32_t j40hip_frame_after_frame_status(const j40hip_frame *h) {
-	if (!h || !h->bare_codestream) return 0;   // (container input or a handle built from a view: not modelled)
+	if (!h) return 0;
 	const size_t end = h->frame.toc.end_offset;
+	if (!h->bare_codestream) {
+		// container: the reference asks for the next box when it looks behind the frame, and a header cut short is `shrt`
+		// (j40__box_header); like above it only looks while its main buffer still covers the end of the frame
+		return h->container_stray_tail && (h->frame.toc.single || end < 0x10000) ? E4("shrt") : 0;
+	}
 	if (end >= h->cs_size) return 0;
 	if (h->frame.toc.single) return E4("excs");
 	return end < std::min<size_t>(h->cs_size, 0x10000) ? E4("excs") : 0;

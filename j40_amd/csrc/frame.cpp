@@ -14,7 +14,8 @@ namespace j40hip {
 
 static uint32_t be32(const uint8_t *p) { return ((uint32_t) p[0] << 24) | ((uint32_t) p[1] << 16) | ((uint32_t) p[2] << 8) | p[3]; }
 
-void extract_codestream(const uint8_t *data, size_t size, const uint8_t **cs, size_t *cs_size, std::vector<uint8_t> *storage) {
+void extract_codestream(const uint8_t *data, size_t size, const uint8_t **cs, size_t *cs_size, std::vector<uint8_t> *storage, int *stray_tail) {
+	if (stray_tail) *stray_tail = 0;
 	static const uint8_t SIGNATURE[32] = {0, 0, 0, 0x0c, 'J', 'X', 'L', ' ', 0x0d, 0x0a, 0x87, 0x0a, 0, 0, 0, 0x14, 'f', 't', 'y', 'p', 'j', 'x', 'l', ' ', 0, 0, 0, 0, 'j', 'x', 'l', ' '};
 	J40HIP_SHOULD(size >= 2, "shrt");
 	if (data[0] == 0xff && data[1] == 0x0a) { *cs = data; *cs_size = size; return; }
@@ -26,8 +27,13 @@ void extract_codestream(const uint8_t *data, size_t size, const uint8_t **cs, si
 	bool seen_jxlc = false, seen_jxlp = false, seen_jxll = false, seen_jxli = false;
 	struct Piece { size_t off, len; };
 	std::vector<Piece> pieces;
+	// The reference maps boxes on demand (j40__container, j40.h:1479): once the codestream is complete it never looks at what
+	// follows, and a codestream box that is cut off yields the bytes that are there (the decoder then runs out of data in whatever
+	// section that hits). Same here: stop behind `jxlc` / the last `jxlp`, and take a truncated codestream box as far as it goes.
+	bool complete = false, no_more_codestream = false;
 	while (pos < size) {
-		J40HIP_SHOULD(size - pos >= 8, "shrt");
+		if (size - pos < 8) { J40HIP_SHOULD(!pieces.empty(), "shrt"); if (stray_tail) *stray_tail = (int) (size - pos); break; }
+		if (complete) break;
 		uint64_t box = be32(data + pos);
 		uint32_t type = be32(data + pos + 4);
 		size_t header = 8, payload;
@@ -39,19 +45,24 @@ void extract_codestream(const uint8_t *data, size_t size, const uint8_t **cs, si
 		} else if (box != 0) J40HIP_SHOULD(box >= 8, "boxx");
 		bool to_eof = box == 0;
 		payload = to_eof ? size - pos - header : (size_t) box - header;
-		J40HIP_SHOULD(to_eof || payload <= size - pos - header, "shrt");
+		const bool cut_off = !to_eof && payload > size - pos - header;
+		if (cut_off) {
+			if (type != 0x6a786c63 && type != 0x6a786c70) { J40HIP_SHOULD(!pieces.empty(), "shrt"); break; }   // junk behind the codestream
+			payload = size - pos - header; to_eof = true;
+		}
 		size_t body = pos + header;
 		switch (type) {
 		case 0x6a786c6c: J40HIP_SHOULD(!seen_jxll, "box?"); seen_jxll = true; break;          // jxll
 		case 0x6a786c69: J40HIP_SHOULD(!seen_jxli, "box?"); seen_jxli = true; break;          // jxli
 		case 0x6a786c63:                                                                       // jxlc
 			J40HIP_SHOULD(!seen_jxlc && !seen_jxlp, "box?");
-			seen_jxlc = true; pieces.push_back({body, payload});
+			seen_jxlc = true; pieces.push_back({body, payload}); complete = true;
 			break;
 		case 0x6a786c70:                                                                       // jxlp
-			J40HIP_SHOULD(!seen_jxlc, "box?");
+			J40HIP_SHOULD(!seen_jxlc && !no_more_codestream, "box?");
 			J40HIP_SHOULD(payload >= 4, "jxlp");
-			seen_jxlp = true; pieces.push_back({body + 4, payload - 4});                       // the sequence index is not interpreted
+			seen_jxlp = true; pieces.push_back({body + 4, payload - 4});                       // the sequence index is not interpreted ...
+			if (!(data[body] >> 7)) no_more_codestream = true;                                 // ... except for this (j40.h:1557, as the reference has it)
 			break;
 		case 0x62726f62:                                                                       // brob
 			J40HIP_SHOULD(payload > 4, "brot");

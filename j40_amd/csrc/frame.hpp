@@ -111,7 +111,8 @@ struct Frame {
 
 // locates the codestream inside `data` (bare codestream or ISOBMFF container); if the codestream is
 // split over several boxes it is reassembled into `storage`
-void extract_codestream(const uint8_t *data, size_t size, const uint8_t **cs, size_t *cs_size, std::vector<uint8_t> *storage);
+// stray_tail (optional): 1..7 when that many bytes follow the last box of a container -- too few for a box header
+void extract_codestream(const uint8_t *data, size_t size, const uint8_t **cs, size_t *cs_size, std::vector<uint8_t> *storage, int *stray_tail = nullptr);
 
 // parses headers, TOC, LfGlobal, HfGlobal and every LfGroup section. `threads` > 1 decodes LfGroup
 // sections concurrently (they are independent given LfGlobal)

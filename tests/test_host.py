@@ -172,3 +172,26 @@ def test_parse_errors_match_reference(ref):
     with pytest.raises(j40_amd.J40Error) as ei:
         j40_amd.Frame(b"JUNKJUNKJUNK")
     assert ei.value.code == "!jxl"
+
+
+def test_bytes_behind_the_frame_like_the_reference(ref):
+    """what follows a frame that decodes cleanly: `excs` for bare codestreams and `shrt` for 1-7 stray bytes behind a container's
+    last box -- but only while the reference's 64 KB main buffer still covers the end of the frame (j40__seek_buffer empties it
+    otherwise and the final j40__no_more_bytes passes); 8 bytes or more behind a container are taken for a box and skipped"""
+    import ctypes as C
+    import j40_amd
+    L = j40_amd.lib()
+    L.j40hip_frame_after_frame_status.restype = C.c_uint32
+    L.j40hip_frame_after_frame_status.argtypes = [C.c_void_p]
+    cases = [("vardct", 520, 264, dict()), ("vardct", 520, 264, dict(container=1)), ("vardct", 520, 264, dict(container=2)),
+             ("modular", 600, 300, dict()), ("modular", 600, 300, dict(container=1)), ("modular", 256, 256, dict()), ("modular", 256, 256, dict(container=1)),
+             ("modular", 300, 200, dict(palette=1)), ("modular", 300, 200, dict(container=1, palette=1))]
+    for mode, w, h, o in cases:
+        data = synth(mode, w, h, 9, **o)
+        for n in (0, 1, 3, 7, 8, 12, 40):
+            d = data + bytes(range(1, n + 1))
+            rerr = ref.decode(d)[0]
+            fr = j40_amd.Frame(d)
+            code = L.j40hip_frame_after_frame_status(fr.h)
+            assert ("" if code == 0 else code.to_bytes(4, "big").decode("latin1")) == rerr, (mode, w, h, o, n, rerr)
+            fr.close()
