@@ -139,7 +139,8 @@ typedef struct {
 } j40hip_modular_view;
 
 /* The seam for a host that parses the bitstream itself (a patched j40): a frame handle built from the
- * view instead of from a bitstream; then j40hip_frame_upload / j40hip_frame_decode* as usual. Everything is copied. */
+ * view instead of from a bitstream; then j40hip_frame_upload / j40hip_frame_decode* as usual. Everything is copied. (The view does
+ * not carry the global MA tree, so for frames with extra channels the sub-images behind the coefficients are not validated.) */
 J40HIP_API j40hip_frame *j40hip_frame_from_vardct_view(const j40hip_vardct_view *v, uint32_t *err);
 
 /* What the reference reports after a frame that decoded cleanly: "excs" when bytes follow the frame and the reference gets to see

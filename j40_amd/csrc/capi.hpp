@@ -11,6 +11,8 @@ struct j40hip_frame {
 	size_t cs_size = 0;
 	std::vector<uint8_t> cs_storage;
 	bool bare_codestream = false;    // the input was the codestream itself, no container around it
+	bool from_view = false;          // built by j40hip_frame_from_vardct_view: no global MA tree / code spec, so the extra channels'
+	                                 // sub-images behind the coefficients cannot be validated (runtime.hip: validate_trailers)
 	int container_stray_tail = 0;    // container input: 1..7 bytes behind the last box (not enough for a box header)
 	j40hip::Frame frame;
 	j40hip_device_state *dev = nullptr;

@@ -31,6 +31,7 @@ j40hip_frame *j40hip_frame_from_vardct_view(const j40hip_vardct_view *v, uint32_
 		h->cs_storage.assign(v->codestream, v->codestream + v->codestream_size);
 		h->cs_storage.resize(v->codestream_size + 16, 0);
 		h->cs = h->cs_storage.data(); h->cs_size = v->codestream_size;
+		h->from_view = true;
 		Frame &f = h->frame;
 		f.im.width = v->width; f.im.height = v->height; f.im.bpp = v->bpp; f.im.exp_bits = 0; f.im.xyb_encoded = true; f.im.grey = false;
 		f.im.intensity_target = v->intensity_target; f.im.quant_bias_num = v->quant_bias_num;

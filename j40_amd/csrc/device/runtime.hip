@@ -389,7 +389,7 @@ extern "C" uint32_t j40hip_frame_upload(j40hip_frame *h, int device) {
 		}
 	}
 	st->total_sections = (int32_t) hp.sections.size();
-	st->has_trailers = hp.frame.sections_have_trailer != 0;
+	st->has_trailers = hp.frame.sections_have_trailer != 0 && !h->from_view;
 	st->first_group = 0; st->num_groups = num_groups;
 	upload_constant_tables(half_secants(), afv_basis(), srgb_u8_thresholds(), s);
 	for (auto &e : st->ev) if (hipEventCreate(&e) != hipSuccess) ok = false;
