@@ -106,7 +106,19 @@ struct BitReader {
 		J40HIP_SHOULD((bits & ((1u << n) - 1)) == 0, "pad0");
 		bits >>= n; nbits -= n;
 	}
-	void skip_bits(int64_t n) {  // j40.h:1892
+	// j40__skip as the reference has it (j40.h:1892-1911): when the accumulator already holds n bits it drops them and then falls
+	// through to the general case with n unchanged, i.e. it skips another n >> 3 bytes and n & 7 bits -- 2n bits in all.
+	// Header fields that are "skipped" (extensions, the EPF sigma placeholder) land where the reference lands only this way;
+	// the accumulator is filled exactly like the reference's, so the condition is the same.
+	void skip_bits_like_reference(int64_t n) {
+		if (nbits >= n) { bits >>= (int) n; nbits -= (int) n; }
+		else { n -= nbits; bits = 0; nbits = 0; }
+		int64_t bytes = n >> 3;
+		J40HIP_SHOULD(end - ptr >= bytes, "shrt");
+		ptr += bytes;
+		(void) u((int) (n & 7));
+	}
+	void skip_bits(int64_t n) {  // what j40__skip means to do
 		if (nbits >= n) { bits >>= (int) n; nbits -= (int) n; return; }
 		n -= nbits; bits = 0; nbits = 0;
 		int64_t bytes = n >> 3;

@@ -112,9 +112,21 @@ static void read_bit_depth(BitReader &br, int32_t *bpp, int32_t *exp_bits) {  //
 	}
 }
 
-static void skip_name(BitReader &br) {  // j40.h:3050 (content is validated as UTF-8 there; only consumed here)
+// j40__name (j40.h:3050): the name is validated as UTF-8 the way the reference does it -- including `i + c < len` where `<=` was
+// meant, which makes the last character of every name fail: any non-empty name is a `name` error there, and so it is here
+static void skip_name(BitReader &br) {
 	int32_t len = br.u32(0, 0, 0, 4, 16, 5, 48, 10);
-	for (int32_t i = 0; i < len; ++i) (void) br.u(8);
+	std::vector<uint8_t> buf((size_t) len + 1, 0);
+	for (int32_t i = 0; i < len; ++i) buf[(size_t) i] = (uint8_t) br.u(8);
+	for (int32_t i = 0; i < len; ) {
+		int32_t c = buf[(size_t) i++];
+		const int32_t cc = buf[(size_t) i];   // the terminating zero keeps this in range
+		c = c < 0x80 ? 0 : c < 0xc2 ? -1 : c < 0xe0 ? 1 :
+			c < 0xf0 ? ((c == 0xe0 ? cc >= 0xa0 : c == 0xed ? cc < 0xa0 : true) ? 2 : -1) :
+			c < 0xf5 ? ((c == 0xf0 ? cc >= 0x90 : c == 0xf4 ? cc < 0x90 : true) ? 3 : -1) : -1;
+		J40HIP_SHOULD(c >= 0 && i + c < len, "name");
+		while (c-- > 0) J40HIP_SHOULD((buf[(size_t) i++] & 0xc0) == 0x80, "name");
+	}
 }
 
 static void read_extensions(BitReader &br) {  // j40.h:3088
@@ -125,7 +137,7 @@ static void read_extensions(BitReader &br) {  // j40.h:3088
 		J40HIP_SHOULD(n <= (uint64_t) INT64_MAX - (uint64_t) nbits, "flen");
 		nbits += (int64_t) n;
 	}
-	br.skip_bits(nbits);
+	br.skip_bits_like_reference(nbits);
 }
 
 static void read_customxy(BitReader &br) {
@@ -322,7 +334,7 @@ static void read_frame_header(BitReader &br, const ImageMeta &im, FrameHeader *f
 			int32_t epf_iters = all_default ? 2 : (int32_t) br.u(2);
 			if (epf_iters) {
 				if (!f->is_modular && br.u(1)) for (int i = 0; i < 8; ++i) (void) br.f16();
-				if (br.u(1)) { for (int i = 0; i < 3; ++i) (void) br.f16(); br.skip_bits(32); }
+				if (br.u(1)) { for (int i = 0; i < 3; ++i) (void) br.f16(); br.skip_bits_like_reference(32); }
 				if (br.u(1)) { if (!f->is_modular) (void) br.f16(); for (int i = 0; i < 3; ++i) (void) br.f16(); }
 				if (f->is_modular) (void) br.f16();
 			}
