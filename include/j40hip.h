@@ -89,6 +89,8 @@ typedef struct {
 	int32_t width, height, num_passes, num_groups, num_lf_groups;
 	int32_t nb_block_ctx, nb_qf_thr, nb_lf_thr[3], num_hf_presets, bpp;
 	int32_t sections_have_trailer;   /* extra channels: a Modular sub-image follows the coefficients of each section */
+	uint32_t single_declared_end;    /* single-section frames: the TOC's end of the section (byte offset); the section itself is readable to the
+	                                    end of the codestream, ending short of this is shrt, past it excs (j40.h:7796-7803) */
 	int32_t check_section_end;       /* single-section frames only: zero padding + no bytes left at the section's end (the reference checks
 	                                    nothing in frames with several sections, j40.h:7778-7795) */
 	int32_t global_scale, x_qm_scale, b_qm_scale, x_factor_lf, b_factor_lf;
@@ -125,6 +127,7 @@ typedef struct {
 typedef struct {
 	int32_t width, height, bpp, num_channels, num_sections, num_transforms, num_tree_nodes, alpha_channel;
 	int32_t check_section_end;     /* as in j40hip_vardct_view */
+	uint32_t single_declared_end;
 	const uint8_t *codestream; size_t codestream_size;
 	const j40hip_codespec_view *codespec;     /* [num_codespecs] */
 	const j40hip_tree_node *tree;              /* [num_tree_nodes]: every tree in use, back to back */

@@ -94,7 +94,7 @@ j40hip_frame *j40hip_frame_from_vardct_view(const j40hip_vardct_view *v, uint32_
 		f.toc.single = nsec == 1 && v->sections[0].bit_off != 0;
 		f.toc.pass_groups.resize(nsec);
 		for (size_t i = 0; i < nsec; ++i) { f.toc.pass_groups[i].offset = v->sections[i].byte_off; f.toc.pass_groups[i].size = v->sections[i].size; }
-		if (f.toc.single) { f.toc.single_section = f.toc.pass_groups[0]; f.single_pass_group_bitpos = v->sections[0].bit_off; }
+		if (f.toc.single) { f.toc.single_section = f.toc.pass_groups[0]; f.single_pass_group_bitpos = v->sections[0].bit_off; f.toc.single_declared_end = v->single_declared_end; }
 	} catch (const DecodeError &e) { code = e.code; }
 	catch (const std::bad_alloc &) { code = E4("!mem"); }
 	if (err) *err = code;
@@ -206,7 +206,7 @@ static void fill_codespec_view(j40hip_frame *h, const CodeSpec &spec, j40hip_cod
 
 uint32_t j40hip_frame_vardct_view(j40hip_frame *h, j40hip_vardct_view *v) {
 	const Frame &f = h->frame;
-	if (f.fh.is_modular || f.im.grey || !f.im.xyb_encoded || f.fh.do_ycbcr || f.im.bpp < 8 || f.im.exp_bits) return E4("TODO");
+	if (f.fh.is_modular || f.im.grey || f.fh.do_ycbcr || f.im.bpp < 8 || f.im.exp_bits) return E4("TODO");
 	memset(v, 0, sizeof *v);
 	h->views = j40hip_frame::Views();
 	h->views.clusters.reserve(16);
@@ -215,6 +215,7 @@ uint32_t j40hip_frame_vardct_view(j40hip_frame *h, j40hip_vardct_view *v) {
 	v->num_hf_presets = f.num_hf_presets; v->bpp = f.im.bpp;
 	v->sections_have_trailer = (int32_t) f.gmodular.channel.size() > f.num_gm_channels;
 	v->check_section_end = f.toc.single && !v->sections_have_trailer;
+	v->single_declared_end = (uint32_t) f.toc.single_declared_end;
 	v->global_scale = f.global_scale; v->x_qm_scale = f.fh.x_qm_scale; v->b_qm_scale = f.fh.b_qm_scale; v->x_factor_lf = f.x_factor_lf; v->b_factor_lf = f.b_factor_lf;
 	for (int i = 0; i < 3; ++i) { v->quant_bias[i] = f.im.quant_bias[i]; v->opsin_bias[i] = f.im.opsin_bias[i]; for (int j = 0; j < 3; ++j) v->opsin_inv_mat[i * 3 + j] = f.im.opsin_inv_mat[i][j]; }
 	v->quant_bias_num = f.im.quant_bias_num; v->base_corr_x = f.base_corr_x; v->base_corr_b = f.base_corr_b; v->inv_colour_factor = f.inv_colour_factor;
@@ -267,7 +268,7 @@ uint32_t j40hip_frame_modular_view(j40hip_frame *h, j40hip_modular_view *v) {
 	h->views.clusters.reserve(hp.host_specs.size() + 1);
 	v->width = f.fh.width; v->height = f.fh.height; v->bpp = f.im.bpp; v->num_channels = hp.frame.num_channels; v->num_sections = hp.frame.num_sections;
 	v->alpha_channel = hp.alpha_channel;
-	v->check_section_end = hp.frame.check_section_end;
+	v->check_section_end = hp.frame.check_section_end; v->single_declared_end = hp.frame.single_declared_end;
 	v->codestream = h->cs; v->codestream_size = h->cs_size;
 	h->views.specs.assign(hp.host_specs.size(), j40hip_codespec_view());
 	h->views.host_specs = hp.host_specs;   // the views point into these

@@ -111,11 +111,13 @@ J40_DEV void bits_consume(DevBits &b, int32_t n) {
 // (j40__no_more_bytes, j40.h:2011)
 // (only called for frames that are a single section, see DevFrame::check_section_end: zero padding, j40.h:8203; bytes of the
 // section left unread are `shrt`, j40__end_of_frame, j40.h:7796-7803)
-J40_DEV void bits_finish_section(DevBits &b) {
+J40_DEV void bits_finish_section(DevBits &b, uint32_t declared_end) {
 	int32_t n = b.nbits & 7;
 	if ((uint32_t) b.bits & ((1u << n) - 1)) bits_set_error(b, ERR_PAD0);
 	b.bits >>= n; b.nbits -= n;
-	if (b.nbits != 0 || b.pos != b.end) bits_set_error(b, ERR_SHRT);
+	const uint32_t at = b.pos - (uint32_t) (b.nbits >> 3);   // first byte not consumed
+	if (at < declared_end) bits_set_error(b, ERR_SHRT);
+	else if (at > declared_end) bits_set_error(b, ERR_EXCS);
 }
 
 // ------------------------------------------------------------------------------------------------

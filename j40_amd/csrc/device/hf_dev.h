@@ -117,7 +117,7 @@ J40_DEV uint32_t decode_hf_section(const DevPlan &plan, const DevFrame &f, const
 		}
 	}
 	if (!b.err) code_finish<UNI>(b, code);
-	if (!b.err && f.check_section_end) bits_finish_section(b);
+	if (!b.err && f.check_section_end) bits_finish_section(b, f.single_declared_end);
 	if (f.sections_have_trailer && plan.section_end_bit) plan.section_end_bit[&sec - plan.sections] = 8u * b.pos - (uint32_t) b.nbits;   // the extra channels' sub-image starts here
 	return b.err;
 }
@@ -206,7 +206,7 @@ J40_DEV uint32_t decode_hf_section_flat(const DevPlan &plan, const DevFrame &f, 
 		if (!in_coeffs && ++c_yxb == 3) { c_yxb = 0; done = ++k >= t.nblocks; }
 	}
 	if (!b.err) code_finish<false>(b, code);
-	if (!b.err && f.check_section_end) bits_finish_section(b);
+	if (!b.err && f.check_section_end) bits_finish_section(b, f.single_declared_end);
 	if (f.sections_have_trailer && plan.section_end_bit) plan.section_end_bit[&sec - plan.sections] = 8u * b.pos - (uint32_t) b.nbits;   // the extra channels' sub-image starts here
 	return b.err;
 }

@@ -45,6 +45,7 @@ struct LaneTables {
 // the frame scalars the decoder needs, copied out of DevFrame once (wave-uniform)
 struct LaneFrame {
 	int32_t nb_block_ctx, num_hf_presets, preset_bits, check_section_end;   // (DevFrame::check_section_end)
+	uint32_t single_declared_end;
 	const J40_GLOBAL uint32_t *order_off;  // DevFrame::order_off
 };
 
@@ -255,7 +256,7 @@ J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t,
 		const uint32_t at = lane_bit_position(b), padn = (0u - at) & 7u;
 		if (padn > (uint32_t) b.nbits) lane_bits_refill(b);
 		if (lane_bits_take(b, (int32_t) padn)) err = ERR_PAD0;
-		else if (at + padn != end_bit) err = ERR_SHRT;
+		else if (at + padn != 8u * f.single_declared_end) err = at + padn < 8u * f.single_declared_end ? (uint32_t) ERR_SHRT : (uint32_t) ERR_EXCS;
 	}
 	return err;
 }

@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256) k_hf_lanes(const DevPlan *plans, const Hf
 	const int32_t g = w.first_group + (active ? lane : 0);
 	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
 	LaneFrame f;
-	f.nb_block_ctx = df.nb_block_ctx; f.num_hf_presets = df.num_hf_presets; f.preset_bits = df.preset_bits; f.check_section_end = df.check_section_end;
+	f.nb_block_ctx = df.nb_block_ctx; f.num_hf_presets = df.num_hf_presets; f.preset_bits = df.preset_bits; f.check_section_end = df.check_section_end; f.single_declared_end = df.single_declared_end;
 	f.order_off = df.order_off;
 	const int32_t num_passes = df.num_passes, num_groups = df.num_groups, scan = df.sparse_coeffs;
 	LaneGlobals G;

@@ -276,7 +276,7 @@ J40_DEV uint32_t decode_modular_section(const DevModPlan &plan, const ModTables 
 		}
 	}
 	if (!b.err && !err) code_finish<UNI>(b, code);
-	if (!b.err && !err && f.check_section_end) bits_finish_section(b);
+	if (!b.err && !err && f.check_section_end) bits_finish_section(b, f.single_declared_end);
 	return b.err ? b.err : err;
 }
 

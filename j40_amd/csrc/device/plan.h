@@ -99,6 +99,8 @@ struct DevFrame {
 	// nothing: j40__finish_section_state (j40.h:7778-7795) runs j40__no_more_bytes on the section's own state and returns the
 	// parent's error code, so `pad0` / `excs` never surface -- junk behind a section's data is accepted, and so it is here.
 	int32_t check_section_end;
+	uint32_t single_declared_end;            // single-section frames: where the TOC says the section ends (byte offset); it is readable to the
+	                                         // end of the codestream, stopping short of this is `shrt`, going past it `excs` (j40.h:7796-7803)
 };
 
 struct CoeffEvent { uint32_t pos; int32_t value; };   // one non-zero quantised HF coefficient: scan position inside its block
@@ -189,6 +191,7 @@ struct DevModFrame {
 	int32_t tree_uses_wp, num_tree_nodes;
 	int32_t max_width;              // widest rectangle any section decodes (sizes the weighted-predictor rows)
 	int32_t check_section_end;      // see DevFrame::check_section_end
+	uint32_t single_declared_end;   // see DevFrame::single_declared_end
 };
 
 struct DevModPlan {

@@ -724,6 +724,10 @@ void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
 	{   // a truncated codestream fails where the reference fails: in the first section (in reading order) that
 		// needs the missing bytes, not up front. Sections are clipped to the bytes that exist; readers raise "shrt".
 		auto clip = [cs_size](Section &s) { if (s.offset >= cs_size) { s.offset = cs_size; s.size = 0; } else s.size = std::min(s.size, cs_size - s.offset); };
+		if (f->toc.single) {
+			f->toc.single_declared_end = f->toc.single_section.offset + f->toc.single_section.size;
+			f->toc.single_section.size = cs_size > f->toc.single_section.offset ? cs_size - f->toc.single_section.offset : 0;
+		}
 		clip(f->toc.single_section); clip(f->toc.lf_global); clip(f->toc.hf_global);
 		for (Section &s : f->toc.lf_groups) clip(s);
 		for (Section &s : f->toc.pass_groups) clip(s);
@@ -748,7 +752,11 @@ void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
 		// group reads nothing (j40.h:7024-7025) and the section has to end here
 		J40HIP_SHOULD(f->num_gm_channels == (int32_t) f->gmodular.channel.size(), "TODO");
 		sr.zero_pad_to_byte();
-		J40HIP_SHOULD(sr.byte_position() == f->toc.single_section.size, "shrt");   // bytes of the section left over (j40__end_of_frame, j40.h:7796-7803)
+		{   // j40__end_of_frame, j40.h:7796-7803: short of the TOC entry's end is `shrt`, beyond it `excs`
+			const size_t at = f->toc.single_section.offset + sr.byte_position();
+			J40HIP_SHOULD(at >= f->toc.single_declared_end, "shrt");
+			J40HIP_SHOULD(at == f->toc.single_declared_end, "excs");
+		}
 		return;
 	}
 

@@ -47,7 +47,9 @@ struct Section { size_t offset = 0, size = 0; };  // byte range inside the codes
 
 struct Toc {
 	bool single = false;
-	Section single_section;               // when the frame has exactly one section
+	Section single_section;               // when the frame has exactly one section: readable to the end of the codestream like in the
+	                                      // reference, which reads such a frame from its main state (no section boundary) ...
+	size_t single_declared_end = 0;       // ... and compares where it ended with the TOC entry afterwards (j40__end_of_frame, j40.h:7796)
 	Section lf_global, hf_global;
 	std::vector<Section> lf_groups;       // [num_lf_groups]
 	std::vector<Section> pass_groups;     // [num_passes * num_groups], pass-major

@@ -105,8 +105,11 @@ void read_modular_header(BitReader &br, const std::vector<TreeNode> *global_tree
 			channel.swap(next);
 			break;
 		}
-		case Transform::SQUEEZE:
-			J40HIP_RAISE("TODO");  // the reference stops here as well (j40.h:3812)
+		case Transform::SQUEEZE: {   // the reference reads the parameters, then stops (j40.h:3794-3812): running out of bytes in them wins
+			const int32_t num_sq = br.u32(0, 0, 1, 4, 9, 6, 41, 8);
+			for (int32_t j = 0; j < num_sq; ++j) { br.u(2); br.u32(0, 3, 8, 6, 72, 10, 1096, 13); br.u32(1, 0, 2, 0, 3, 0, 4, 4); }
+			J40HIP_RAISE("TODO");
+		}
 		default: J40HIP_RAISE("xfm?");
 		}
 		m->transforms.push_back(tr);

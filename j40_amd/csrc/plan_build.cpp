@@ -38,7 +38,9 @@ void flatten_code_spec(const CodeSpec &spec, std::vector<uint8_t> &u8, std::vect
 
 uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostPlan *hp) {
 	if (fr.fh.is_modular) return ERR_TODO;
-	if (fr.im.grey || !fr.im.xyb_encoded || fr.fh.do_ycbcr) return ERR_TODO;  // same limits as j40.h:7867, 7917-7921
+	// same limits as j40.h:7867, 7917-7921. (A VarDCT frame of an image without xyb_encoded passes them: the reference
+	// runs the XYB inverse with the default opsin matrix on it all the same, j40.h:7206-7233, and so does K2.)
+	if (fr.im.grey || fr.fh.do_ycbcr) return ERR_TODO;
 	if (fr.im.bpp < 8 || fr.im.exp_bits) return ERR_TODO;
 
 	DevFrame &df = hp->frame;
@@ -51,6 +53,7 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 	df.bpp = fr.im.bpp;
 	df.sections_have_trailer = (int32_t) fr.gmodular.channel.size() > fr.num_gm_channels;
 	df.check_section_end = fr.toc.single && !df.sections_have_trailer;
+	df.single_declared_end = (uint32_t) fr.toc.single_declared_end;
 	for (int c = 0; c < 3; ++c) { df.quant_bias[c] = fr.im.quant_bias[c]; df.opsin_bias[c] = fr.im.opsin_bias[c]; df.cbrt_opsin_bias[c] = cbrtf(fr.im.opsin_bias[c]); }
 	df.quant_bias_num = fr.im.quant_bias_num;
 	static const float QM_SCALE[8] = {1.5625f, 1.25f, 1.0f, 0.8f, 0.64f, 0.512f, 0.4096f, 0.32768f};  // 0.8^(i-2), j40.h:7055
@@ -266,6 +269,7 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 	df.width = fr.fh.width; df.height = fr.fh.height; df.num_groups = (int32_t) fr.fh.num_groups; df.bpp = fr.im.bpp;
 	df.num_channels = nch;
 	df.check_section_end = fr.toc.single;
+	df.single_declared_end = (uint32_t) fr.toc.single_declared_end;
 	// trees and code specs: the global pair once (when a header refers to it), own pairs per section (use_global_tree = 0)
 	int32_t global_spec = -1; uint32_t global_tree_off = 0;
 	auto attach = [&](const Modular &m, DevModSection *s) { attach_tables(fr, hp, global_spec, global_tree_off, m, s); };

@@ -48,11 +48,13 @@ static uint32_t obits_u(obits *b, int n) {
 	b->bits >>= n; b->nbits -= n;
 	return v;
 }
-static void obits_finish(obits *b) {  /* j40__no_more_bytes, j40.h:2011 */
+static void obits_finish(obits *b, const uint8_t *base, uint32_t declared_end) {  /* single-section frames: j40.h:8203, 7796-7803 */
 	int n = b->nbits & 7;
 	if (b->bits & (((uint64_t) 1 << n) - 1)) { if (!b->err) b->err = E4('p', 'a', 'd', '0'); }
 	b->bits >>= n; b->nbits -= n;
-	if ((b->nbits != 0 || b->p != b->end) && !b->err) b->err = E4('s', 'h', 'r', 't');   /* single-section frames: j40__end_of_frame, j40.h:7796-7803 */
+	{ const uint32_t at = (uint32_t) (b->p - base) - (uint32_t) (b->nbits >> 3);
+	  if (!b->err && at < declared_end) b->err = E4('s', 'h', 'r', 't');
+	  else if (!b->err && at > declared_end) b->err = E4('e', 'x', 'c', 's'); }
 }
 
 /* ---------------------------------------------------------------------------------------------- */
@@ -273,7 +275,7 @@ static uint32_t hf_coeffs(const j40hip_vardct_view *v, int pass, const j40hip_se
 	if (!b.err) ocode_finish(&b, code);
 	/* extra channels: the group's Modular sub-image follows (j40.h:7024-7034); the reference decodes and then drops it
 	 * (j40.h:7868-7870), this restatement of the pixel path stops at the coefficients */
-	if (!b.err && v->check_section_end) obits_finish(&b);   /* never in frames with several sections: j40.h:7778-7795 drops that error */
+	if (!b.err && v->check_section_end) obits_finish(&b, v->codestream, v->single_declared_end);   /* never in frames with several sections: j40.h:7778-7795 drops that error */
 	free(nonzeros);
 	return b.err;
 }
@@ -681,7 +683,7 @@ static uint32_t modular_section(const j40hip_modular_view *v, const j40hip_modul
 		free(wp.errors); wp.errors = NULL;
 	}
 	if (!b.err && !err) ocode_finish(&b, code);
-	if (!b.err && !err && v->check_section_end) obits_finish(&b);
+	if (!b.err && !err && v->check_section_end) obits_finish(&b, v->codestream, v->single_declared_end);
 	return b.err ? b.err : err;
 }
 

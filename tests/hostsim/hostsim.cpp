@@ -102,7 +102,12 @@ static uint32_t hostsim_decode_modular(const Frame &fr, const uint8_t *cs, size_
 		mt.rows = ring.data(); mt.rows_width = hp.frame.max_width + 4; mt.wp_errors = wperr.data(); mt.wp_errors_width = hp.frame.max_width;   // as the kernel lays them out in LDS
 		status[(size_t) sct] = (sct & 1) ? decode_modular_section<false, true>(plan, mt, sct) : decode_modular_section<false, false>(plan, mt, sct);   // both neighbour sources
 	}
-	for (uint32_t e : status) if (e) return e;
+	{   // like j40hip_frame_status: the reference reports the first failing section in file order (j40.h:5608)
+		uint32_t first = 0, first_off = 0xffffffffu;
+		for (size_t i = 0; i < hp.sections.size(); ++i) if (status[i] && hp.sections[i].byte_off < first_off) { first = status[i]; first_off = hp.sections[i].byte_off; }
+		if (first) return first;
+		if (status.back()) return status.back();
+	}
 	plan.local_rct = hp.local_rct.data();
 	for (int32_t sct = 0; sct < hp.frame.num_sections; ++sct) for (int32_t lane = 0; lane < 3; ++lane) section_inverse_rcts(plan, sct, lane, 3);
 	static const uint8_t PERM[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
@@ -224,7 +229,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 	if (only_entropy & 4) {   // bit 2: the throughput kernel's fast path (hf_lanes_dev.h), tables laid out as the kernel stages them
 		if (!hp.hf.lanes_fast) return ERR_TODO;
 		const DevFrame &df = hp.frame;
-		LaneFrame lf = {df.nb_block_ctx, df.num_hf_presets, df.preset_bits, df.check_section_end, df.order_off};
+		LaneFrame lf = {df.nb_block_ctx, df.num_hf_presets, df.preset_bits, df.check_section_end, df.single_declared_end, df.order_off};
 		LaneGlobals G = {plan.codestream, (const uint32_t *) plan.group_blocks, plan.coeffs[0], plan.events, plan.block_events, plan.pool_u16, plan.coeff_stride};
 		std::vector<int8_t> cols(3 * 32);
 		std::vector<uint32_t> dct(27);
@@ -283,7 +288,11 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 		}
 		for (const auto &e : header_errors) status[(size_t) e.first] = e.second;
 	}
-	for (uint32_t s : status) if (s) return s;
+	{
+		uint32_t first = 0, first_off = 0xffffffffu;
+		for (size_t i = 0; i < status.size(); ++i) if (status[i] && hp.sections[i].byte_off < first_off) { first = status[i]; first_off = hp.sections[i].byte_off; }
+		if (first) return first;
+	}
 	if (only_entropy & 1) return 0;
 
 	const float *hs = half_secants(), *afv = afv_basis();

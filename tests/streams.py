@@ -49,6 +49,7 @@ VARDCT_CASES = [
     ("bit_depth_12", dict(bpp=12, cfl=1)),                  # more than 8 bits: the long way through the transfer curve, scaling to 8 bits at the end
     ("bit_depth_15", dict(bpp=15)),
     ("custom_dequant_matrices", dict(dq=2)),                # HfGlobal codes the 8x8 matrices in the Hornuss / DCT2x2 / DCT4x4 / DCT4x8 / AFV / band forms and two larger ones raw (Modular sub-images)
+    ("not_xyb_encoded_decoded_as_xyb", dict(alpha=1, fullheader=1, noxyb=1)),   # reference quirk: the XYB inverse runs on any VarDCT frame (j40.h:7206)
 ]
 
 # the Modular feature matrix (width, height, options); all decode bit-exactly

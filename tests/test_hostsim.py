@@ -170,3 +170,27 @@ def test_section_ends_are_checked_the_way_the_reference_checks_them(sim, ref):
         rerr, px = ref.decode(bytes(b))
         err, out = mine(bytes(b), 762, 8)
         assert err == rerr and (rerr != "" or np.array_equal(px, out))
+
+
+def test_every_header_bit_flip_ends_like_in_the_reference(sim, ref):
+    """Each bit of the first bytes of small streams flipped in turn (image and frame headers, TOC, the start of LfGlobal): same verdict as the
+    reference, error code included. Covers what the sweep found: a single-section frame is read to the end of the codestream and its
+    end compared with the TOC entry afterwards (`shrt` / `excs`, j40.h:7884-7896); Squeeze parameters are read before the decoder
+    gives up on them (j40.h:3794-3812); the first failing section in FILE order is the one reported when the TOC is permuted
+    (j40.h:5608); VarDCT frames of images without xyb_encoded go through the XYB inverse regardless (j40.h:7206)."""
+    sim.hostsim_decode.restype = C.c_uint32
+    sim.hostsim_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+    for mode, w, h, seed, nbytes, o in [("modular", 300, 200, 5, 40, {}), ("modular", 40, 30, 21, 70, dict(tree=2, alpha=1)),
+                                        ("vardct", 264, 136, 4, 40, dict(dq=2, alpha=1)), ("vardct", 520, 264, 3, 70, dict(passes=2, permute=1))]:
+        d = synth(mode, w, h, seed, **o)
+        for byte in range(2, min(len(d), nbytes)):
+            for bit in range(8):
+                b = bytearray(d); b[byte] ^= 1 << bit; b = bytes(b)
+                rerr, px = ref.decode(b)
+                if rerr == "" and px.shape[:2] != (h, w): continue   # (a flip in the size header; the buffers here are sized for the clean stream)
+                out = np.zeros((h, w, 4), np.uint8)
+                buf = C.create_string_buffer(b, len(b))
+                code = sim.hostsim_decode(buf, len(b), out.ctypes.data, None, 0)
+                err = "" if code == 0 else code.to_bytes(4, "big").decode("latin1")
+                assert err == rerr, (mode, w, h, seed, o, byte, bit, rerr, err)
+                if rerr == "": assert np.abs(px.astype(int) - out).max() <= (0 if mode == "modular" else 1), (mode, byte, bit)

@@ -31,7 +31,9 @@ def pick_vardct(r):
     if r.random() < .2: o["permute"] = 1
     if r.random() < .15: o["container"] = r.choice([1, 2])
     if r.random() < .3: o["maxlog"] = r.choice([4, 5, 6, 7, 8])
-    if r.random() < .15 and "passes" not in o: o["alpha"] = 1
+    if r.random() < .15 and "passes" not in o:
+        o["alpha"] = 1
+        if r.random() < .4: o["fullheader"] = 1; o["noxyb"] = r.choice([0, 1])
     elif r.random() < .15: o["bpp"] = r.choice([9, 10, 12, 15])
     return o
 

@@ -629,6 +629,8 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 	const int icc_bytes = opt.geti("icc", 0);                // > 0: ColourEncoding with want_icc and an ICC stream of that many coded bytes
 	const int img_bpp = opt.geti("bpp", 8);   // 9..15: the renderer's scaling to 8 bits and the long way through the transfer curve get work
 	if (img_bpp != 8 && (icc_bytes || with_alpha)) die("vardct: bpp combines with neither icc nor alpha here");
+	const int noxyb = opt.geti("noxyb", 0);
+	if (noxyb && (!with_alpha || icc_bytes || !nonzero_header || x_qm != 3 || b_qm != 2)) die("vardct: noxyb wants alpha=1 fullheader=1 and the default qm scales");
 	if (img_bpp != 8) {
 		cs.put(0, 1);                       // ImageMetadata: not all_default
 		cs.put(0, 1);                       // no extra fields
@@ -648,7 +650,7 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 		cs.put(0, 1); cs.put(0, 2);         // integer samples, 8 bits
 		cs.put(1, 1);                       // modular_16bit_buffers
 		cs.put(1, 2); cs.put(1, 1);         // one extra channel, d_alpha
-		cs.put(1, 1);                       // xyb_encoded
+		cs.put(noxyb ? 0 : 1, 1);           // xyb_encoded (noxyb=1: the reference runs the XYB inverse on VarDCT frames regardless, j40.h:7206)
 		cs.put(1, 1);                       // ColourEncoding.all_default
 		cs.put(0, 2);                       // extensions
 		cs.put(1, 1);                       // default_m
@@ -673,15 +675,17 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 		cs.put(0, 2);                       // regular frame
 		cs.put(0, 1);                       // VarDCT
 		cs.u64(skip_smooth ? 128 : 0);      // flags
-		cs.put(0, 2);                       // log_upsampling (xyb_encoded, so no do_ycbcr bit; no extra channels)
-		cs.put((uint64_t) x_qm, 3); cs.put((uint64_t) b_qm, 3);
+		if (noxyb) cs.put(0, 1);            // do_ycbcr (read only without xyb_encoded)
+		cs.put(0, 2);                       // log_upsampling
+		for (int i = 0; i < with_alpha; ++i) cs.put(0, 2);   // ec_log_upsampling
+		if (!noxyb) { cs.put((uint64_t) x_qm, 3); cs.put((uint64_t) b_qm, 3); }
 		cs.u32(num_passes, 1, 0, 2, 0, 3, 0, 4, 3);
 		if (num_passes > 1) {
 			cs.u32(0, 0, 0, 1, 0, 2, 0, 3, 1);                  // num_ds = 0
 			for (int i = 0; i < num_passes - 1; ++i) cs.put(0, 2);  // shift[i]
 		}
 		cs.put(0, 1);                       // have_crop
-		cs.u32(0, 0, 0, 1, 0, 2, 0, 3, 2);  // blend mode: replace
+		for (int i = -1; i < with_alpha; ++i) cs.u32(0, 0, 0, 1, 0, 2, 0, 3, 2);  // blend mode: replace (the frame's, then each extra channel's, j40.h:5299)
 		cs.put(1, 1);                       // is_last
 		cs.u32(0, 0, 0, 0, 4, 16, 5, 48, 10);  // name length 0
 		cs.put(0, 1);                       // restoration: !all_default (the reference mis-parses all_default = 1)
