@@ -17,6 +17,29 @@ def synth(mode, w, h, seed, **opts):
         return open(tmp.name, "rb").read()
 
 
+def decode_in_child(ref, d):
+    """ref.decode(d) in a forked child: damaged streams can crash the reference itself (it segfaults on some flips in a permuted TOC's
+    sections); that is reported as "CRSH", not as the end of the sweep."""
+    rd, wr = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        try:
+            err, px = ref.decode(d)
+            with os.fdopen(wr, "wb") as f:
+                f.write(("%-4s" % err).encode("latin1"))
+                if err == "": f.write(np.array(px.shape[:2], np.int32).tobytes() + np.ascontiguousarray(px).tobytes())
+        finally:
+            os._exit(0)
+    os.close(wr)
+    with os.fdopen(rd, "rb") as f: data = f.read()
+    _, status = os.waitpid(pid, 0)
+    if status != 0 or len(data) < 4: return "CRSH", None
+    err = data[:4].decode("latin1").strip()
+    if err: return err, None
+    hh, ww = np.frombuffer(data[4:12], np.int32)
+    return "", np.frombuffer(data[12:], np.uint8).reshape(hh, ww, 4)
+
+
 def pick_vardct(r):
     o = {}
     if r.random() < .3: o["bctx"] = 1
@@ -74,7 +97,7 @@ def main():
     S = C.CDLL(os.path.join(ROOT, "build", "libhostsim.so"))
     S.hostsim_decode.restype = C.c_uint32
     S.hostsim_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
-    bad = skipped = errors = 0
+    bad = skipped = errors = crashed = 0
     for i in range(n):
         mode = r.choice(["vardct", "modular"])
         w, h = r.randrange(260 if mode == "vardct" else 9, 900), r.randrange(8, 700)
@@ -86,14 +109,20 @@ def main():
         except Exception as e:   # option combinations the generator refuses
             skipped += 1
             continue
+        damaged = False
         if r.random() < flip_share:   # one flipped bit somewhere behind the headers: the error code must match, too
             b = bytearray(d)   # (not in the size header: the buffers here are sized from the clean stream)
             b[r.randrange(max(12, int(len(d) * flip_from)), min(len(d), flip_to))] ^= 1 << r.randrange(8)
-            d = bytes(b)
+            d = bytes(b); damaged = True
         clean_len = len(d)
         if r.random() < cut_share:   # a truncated file, or junk behind it
             d = d[:r.randrange(20, len(d))] if r.random() < .7 else d + bytes(r.randrange(256) for _ in range(r.randrange(1, 40)))
-        e, px = ref.decode(d)
+        if os.environ.get("FUZZ_VERBOSE"): print(i, mode, w, h, seed, o, len(d), clean_len, flush=True); open("/tmp/fuzz_last.jxl", "wb").write(d)
+        e, px = decode_in_child(ref, d) if (len(d) != clean_len or damaged) and not on_gpu else ref.decode(d)   # (no fork once HIP is up)
+        if e == "CRSH":
+            crashed += 1
+            print("the reference crashed on", mode, w, h, seed, o, "(damaged stream)")
+            continue
         if on_gpu:
             mine, out = j40_amd.decode(d)
             if out is None: out = np.zeros((h, w, 4), np.uint8)
@@ -109,7 +138,7 @@ def main():
         if not ok:
             bad += 1
             print("MISMATCH", mode, w, h, seed, o, repr(e), repr(mine))
-    print("%d cases (%d refused by the generator, %d that the reference rejects), %d mismatches" % (n, skipped, errors, bad))
+    print("%d cases (%d refused by the generator, %d that the reference rejects, %d that crash it), %d mismatches" % (n, skipped, errors, crashed, bad))
 
 
 if __name__ == "__main__":
