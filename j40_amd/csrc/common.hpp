@@ -61,7 +61,9 @@ struct BitReader {
 	}
 	// peeks up to 16 bits without failing at the end of the range (missing bits read as zero), for
 	// prefix codes that may be shorter than their maximum length at the very end (j40.h:2258-2261)
-	uint32_t peek16() { if (nbits < 16) refill(); return (uint32_t) (bits & 0xffff); }
+	// `need` is the length the reference asks its accumulator for at this place (`nbits < max_len`, j40.h:2261): refilling at the same
+	// moments keeps the accumulator's fill identical, which j40__skip's behaviour depends on (see skip_bits_like_reference)
+	uint32_t peek16(int need) { if (nbits < need) refill(); return (uint32_t) (bits & 0xffff); }
 	void consume(int n) {
 		if (n > nbits) { bits = 0; nbits = 0; J40HIP_RAISE("shrt"); }  // j40.h:2267-2271
 		bits >>= n; nbits -= n;

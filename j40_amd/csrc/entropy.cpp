@@ -38,8 +38,8 @@ static inline int32_t hybrid_int(BitReader &br, int32_t token, const HybridCfg &
 // ------------------------------------------------------------------------------------------------
 // prefix codes (RFC 7932 section 3)
 
-static inline int32_t prefix_decode(BitReader &br, int32_t fast_len, int32_t max_len, const int32_t *table) {  // j40.h:2256
-	uint32_t window = br.peek16();
+static inline int32_t prefix_decode(BitReader &br, int32_t fast_len, int32_t max_len, const int32_t *table, int32_t need = 0) {  // j40.h:2256
+	uint32_t window = br.peek16(need ? need : max_len);
 	int32_t entry = table[window & ((1u << fast_len) - 1)];
 	int32_t used = 0;
 	if (entry < 0 && fast_len < max_len) {
@@ -138,7 +138,7 @@ static void read_prefix_tree(BitReader &br, int32_t alphabet, Cluster *out) {  /
 	for (; nread < 18 && total < 32; ++nread) {
 		// fixed code over 0..5: 00->0 01->3 10->4 110->2 1110->1 1111->5 (bits in read order)
 		int32_t v;
-		uint32_t w = br.peek16();
+		uint32_t w = br.peek16(4);   // L0MAXLEN (j40.h:2120)
 		if ((w & 3) == 0) { v = 0; br.consume(2); }
 		else if ((w & 3) == 2) { v = 3; br.consume(2); }
 		else if ((w & 3) == 1) { v = 4; br.consume(2); }
@@ -155,7 +155,7 @@ static void read_prefix_tree(BitReader &br, int32_t alphabet, Cluster *out) {  /
 	int32_t prev = 8, rep_nonzero = 0, rep_zero = 0, i = 0;
 	total = 0;
 	while (i < alphabet && total < 32768) {
-		int32_t code = prefix_decode(br, l1.fast_len, l1.max_len, l1.table.data());
+		int32_t code = prefix_decode(br, l1.fast_len, l1.max_len, l1.table.data(), 5);   // L1MAXLEN (j40.h:2150)
 		if (code < 16) {
 			lengths[(size_t) i++] = code;
 			if (code) { total += 32768 >> code; prev = code; }
@@ -219,7 +219,7 @@ static void read_ans_distribution(BitReader &br, int32_t log_alpha_size, std::ve
 		std::vector<int32_t> codes;  // >= 0 log count, < 0 negated repeat
 		int32_t omit_log = -1, i = 0;
 		while (i < alpha) {
-			uint32_t w = br.peek16();
+			uint32_t w = br.peek16(7);   // j40.h:2655
 			int32_t code;
 			if ((w & 15) != 1) { code = PRIMARY_VAL[w & 15]; br.consume(PRIMARY_LEN[w & 15]); }
 			else if ((w >> 4) & 1) { code = 0; br.consume(5); }

@@ -181,9 +181,11 @@ def test_every_header_bit_flip_ends_like_in_the_reference(sim, ref):
     sim.hostsim_decode.restype = C.c_uint32
     sim.hostsim_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
     for mode, w, h, seed, nbytes, o in [("modular", 300, 200, 5, 40, {}), ("modular", 40, 30, 21, 70, dict(tree=2, alpha=1)),
-                                        ("vardct", 264, 136, 4, 40, dict(dq=2, alpha=1)), ("vardct", 520, 264, 3, 70, dict(passes=2, permute=1))]:
+                                        ("vardct", 264, 136, 4, 40, dict(dq=2, alpha=1)), ("vardct", 520, 264, 3, 70, dict(passes=2, permute=1)),
+                                        ("modular", 64, 48, 3, 124, dict(icc=60))]:   # (frame header behind an ICC stream: extension skips
+                                                                                      # depend on the accumulator's fill, j40.h:1895)
         d = synth(mode, w, h, seed, **o)
-        for byte in range(2, min(len(d), nbytes)):
+        for byte in range(2 if nbytes < 100 else 100, min(len(d), nbytes)):
             for bit in range(8):
                 b = bytearray(d); b[byte] ^= 1 << bit; b = bytes(b)
                 rerr, px = ref.decode(b)

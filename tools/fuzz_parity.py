@@ -2,7 +2,7 @@
 """random generator options x sizes x seeds: the device headers compiled for the CPU (build/libhostsim.so) against the
 reference (oracle/_ref). CPU only; a cheap way to look for parity bugs between GPU runs.  python tools/fuzz_parity.py [n] [seed]
 With a third argument "gpu" the product library decodes instead (public API, needs an MI355X)."""
-import ctypes as C, os, random, subprocess, sys, tempfile
+import ctypes as C, os, random, signal, subprocess, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
@@ -24,6 +24,7 @@ def decode_in_child(ref, d):
     pid = os.fork()
     if pid == 0:
         try:
+            signal.alarm(60)   # ... or hang it (a flipped jxlp box size does): the alarm ends the child
             err, px = ref.decode(d)
             with os.fdopen(wr, "wb") as f:
                 f.write(("%-4s" % err).encode("latin1"))
