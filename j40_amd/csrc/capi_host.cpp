@@ -108,6 +108,9 @@ uint32_t j40hip_frame_after_frame_status(const j40hip_frame *h) {
 	if (!h->bare_codestream) {
 		// container: the reference asks for the next box when it looks behind the frame, and a header cut short is `shrt`
 		// (j40__box_header); like above it only looks while its main buffer still covers the end of the frame
+		// A frame of several sections whose TOC adds up to more than the boxes hold: the reference seeks to the frame's end after the
+		// last section (j40__end_of_frame, j40.h:7894) and runs out of boxes -- `shrt` (a bare codestream lets that seek pass)
+		if (!h->frame.toc.single && end > h->cs_size) return E4("shrt");
 		return h->container_stray_tail && (h->frame.toc.single || end < 0x10000) ? E4("shrt") : 0;
 	}
 	if (end >= h->cs_size) return 0;

@@ -27,7 +27,7 @@ def main():
         for byte in range(min(len(d), nbytes)):
             for bit in range(8):
                 b = bytearray(d); b[byte] ^= 1 << bit; b = bytes(b)
-                e, px = decode_in_child(ref, b)
+                e, px = decode_in_child(ref, b, 10)
                 if e == "CRSH":
                     crashed += 1; print("reference crashed or hung:", mode, seed, o, byte, bit, flush=True)
                     continue

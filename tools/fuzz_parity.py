@@ -17,14 +17,14 @@ def synth(mode, w, h, seed, **opts):
         return open(tmp.name, "rb").read()
 
 
-def decode_in_child(ref, d):
+def decode_in_child(ref, d, limit=60):
     """ref.decode(d) in a forked child: damaged streams can crash the reference itself (it segfaults on some flips in a permuted TOC's
     sections); that is reported as "CRSH", not as the end of the sweep."""
     rd, wr = os.pipe()
     pid = os.fork()
     if pid == 0:
         try:
-            signal.alarm(60)   # ... or hang it (a flipped jxlp box size does): the alarm ends the child
+            signal.alarm(limit)   # ... or hang it (a flipped jxlp box size does): the alarm ends the child
             err, px = ref.decode(d)
             with os.fdopen(wr, "wb") as f:
                 f.write(("%-4s" % err).encode("latin1"))
