@@ -106,7 +106,9 @@ typedef struct {
 } j40hip_vardct_view;
 
 typedef struct { int32_t prop, value, a, b; } j40hip_tree_node;   /* see j40_amd/csrc/modular.hpp */
-typedef struct { int32_t kind, begin_c, rct_type, num_c, nb_colours, nb_deltas, d_pred; } j40hip_transform_view;
+/* kind 0 RCT, 1 Palette, 2 one Squeeze step (channels [begin_c, begin_c + num_c) halved along rows if `horizontal`, else along
+ * columns; residual channels right behind them if `in_place`, else at the end of the list) */
+typedef struct { int32_t kind, begin_c, rct_type, num_c, nb_colours, nb_deltas, d_pred, horizontal, in_place; } j40hip_transform_view;
 typedef struct {
 	uint32_t byte_off, size, bit_off; int32_t gx, gy, gw, gh, sidx, first_channel, num_channels;
 	int8_t wp[12];                 /* weighted predictor parameters p1, p2, p3[5], w[4] */
@@ -122,6 +124,9 @@ typedef struct {
 	 * sub_paste is 0 (an earlier pass of a multi-pass frame). sub_off < 0: no sub-image, channels first_channel ... of the frame */
 	int32_t sub_off, sub_tr_off, sub_tr_count, sub_paste;
 	uint32_t preset_status;        /* != 0: the section's own Modular header did not parse; this is its status, nothing is decoded */
+	/* frames whose channels differ in size (after a Squeeze): the section's channels as explicit rectangles,
+	 * chan_rects[6 * (chan_off + i)] = {channel, x0, y0, width, height, hshift | vshift << 8}; -1: first_channel ... over gx, gy, gw, gh */
+	int32_t chan_off;
 } j40hip_modular_section_view;
 
 typedef struct {
@@ -139,6 +144,7 @@ typedef struct {
 	const int32_t *sub_w, *sub_h, *sub_meta;
 	const j40hip_transform_view *sub_transforms;
 	int8_t global_wp[12];
+	const int32_t *chan_rects;
 } j40hip_modular_view;
 
 /* The seam for a host that parses the bitstream itself (a patched j40): a frame handle built from the

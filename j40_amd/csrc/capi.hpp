@@ -29,7 +29,7 @@ struct j40hip_frame {
 		std::vector<int32_t> ch_w, ch_h, ch_meta;
 		std::vector<j40hip_transform_view> transforms;
 		std::vector<j40hip_modular_section_view> mod_sections;
-		std::vector<int32_t> local_rct, sub_w, sub_h, sub_meta;
+		std::vector<int32_t> local_rct, sub_w, sub_h, sub_meta, chan_rects;
 		std::vector<j40hip_transform_view> sub_transforms;
 		std::vector<std::vector<int32_t>> vb_coeffoff_qfidx;
 		std::vector<std::vector<float>> vb_hfmul_inv;

@@ -281,23 +281,25 @@ uint32_t j40hip_frame_modular_view(j40hip_frame *h, j40hip_modular_view *v) {
 	v->tree = h->views.tree.data(); v->num_tree_nodes = (int32_t) h->views.tree.size();
 	h->views.ch_w = hp.plane_w; h->views.ch_h = hp.plane_h; h->views.ch_meta = hp.plane_meta;
 	v->channel_w = h->views.ch_w.data(); v->channel_h = h->views.ch_h.data(); v->channel_meta = h->views.ch_meta.data();
-	for (const Transform &t : hp.transforms) h->views.transforms.push_back(j40hip_transform_view{(int32_t) t.kind, t.begin_c, t.rct_type, t.num_c, t.nb_colours, t.nb_deltas, t.d_pred});
+	for (const Transform &t : hp.transforms) h->views.transforms.push_back(j40hip_transform_view{(int32_t) t.kind, t.begin_c, t.rct_type, t.num_c, t.nb_colours, t.nb_deltas, t.d_pred, t.horizontal ? 1 : 0, t.in_place ? 1 : 0});
 	v->transforms = h->views.transforms.data(); v->num_transforms = (int32_t) h->views.transforms.size();
 	for (const DevModSection &s : hp.sections) {
 		j40hip_modular_section_view sv;
 		sv.byte_off = s.byte_off; sv.size = s.size; sv.bit_off = s.bit_off; sv.gx = s.gx; sv.gy = s.gy; sv.gw = s.gw; sv.gh = s.gh; sv.sidx = s.sidx;
 		sv.first_channel = s.first_channel; sv.num_channels = s.num_channels; memcpy(sv.wp, s.wp, 12);
-		sv.tree_off = s.tree_off; sv.tree_nodes = s.tree_nodes; sv.spec_idx = s.spec_idx; sv.local_off = s.local_off; sv.local_count = s.local_count; sv.sub_off = s.sub_off; sv.sub_tr_off = sv.sub_tr_count = sv.sub_paste = 0; sv.preset_status = s.preset_status;
+		sv.tree_off = s.tree_off; sv.tree_nodes = s.tree_nodes; sv.spec_idx = s.spec_idx; sv.local_off = s.local_off; sv.local_count = s.local_count; sv.sub_off = s.sub_off; sv.sub_tr_off = sv.sub_tr_count = sv.sub_paste = 0; sv.preset_status = s.preset_status; sv.chan_off = s.chan_off;
 		h->views.mod_sections.push_back(sv);
 	}
 	v->sections = h->views.mod_sections.data();
 	h->views.local_rct = hp.local_rct; v->local_rct = h->views.local_rct.data();
+	for (const DevChanRect &r : hp.chan_rects) for (int32_t x : {r.plane, r.x0, r.y0, r.w, r.h, r.shifts}) h->views.chan_rects.push_back(x);
+	v->chan_rects = h->views.chan_rects.data();
 	h->views.sub_w = hp.sub_w; h->views.sub_h = hp.sub_h; h->views.sub_meta = hp.sub_meta;
 	v->sub_w = h->views.sub_w.data(); v->sub_h = h->views.sub_h.data(); v->sub_meta = h->views.sub_meta.data();
 	for (const HostModPlan::SubImage &si : hp.sub_images) {
 		j40hip_modular_section_view &sv = h->views.mod_sections[(size_t) si.section];
 		sv.sub_tr_off = (int32_t) h->views.sub_transforms.size(); sv.sub_tr_count = (int32_t) si.transforms.size(); sv.sub_paste = si.paste;
-		for (const Transform &t : si.transforms) h->views.sub_transforms.push_back(j40hip_transform_view{(int32_t) t.kind, t.begin_c, t.rct_type, t.num_c, t.nb_colours, t.nb_deltas, t.d_pred});
+		for (const Transform &t : si.transforms) h->views.sub_transforms.push_back(j40hip_transform_view{(int32_t) t.kind, t.begin_c, t.rct_type, t.num_c, t.nb_colours, t.nb_deltas, t.d_pred, t.horizontal ? 1 : 0, t.in_place ? 1 : 0});
 	}
 	v->sub_transforms = h->views.sub_transforms.data();
 	{ const WPParams &wp = f.gmodular.wp; v->global_wp[0] = wp.p1; v->global_wp[1] = wp.p2; for (int i = 0; i < 5; ++i) v->global_wp[2 + i] = wp.p3[i]; for (int i = 0; i < 4; ++i) v->global_wp[7 + i] = wp.w[i]; v->global_wp[11] = 0; }

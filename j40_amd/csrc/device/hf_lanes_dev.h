@@ -150,7 +150,7 @@ J40_DEV void lane_store_block_events(const LaneGlobals &G, uint32_t blk, uint32_
 // cols[(c * 32 + x) * col_stride]: non-zero count (per 8x8 cell) of the last block written into cell column x, channel c
 template <bool SCAN>
 J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t, const LaneGlobals &G, const DevSection &sec, uint32_t cell_base,
-		uint32_t block_first, int32_t nblocks, uint32_t ev_first, uint32_t ev_end, J40_LDS int8_t *cols, int32_t col_stride, int32_t pass) {
+		uint32_t block_first, int32_t nblocks, uint32_t ev_first, uint32_t ev_end, J40_LDS int8_t *cols, int32_t col_stride, int32_t pass, J40_GLOBAL uint32_t *end_bit_out = nullptr) {
 	const uint32_t start_bit = 8u * sec.byte_off + sec.bit_off, end_bit = 8u * (sec.byte_off + sec.size);
 	LaneBits b;
 	lane_bits_init(b, G.codestream, start_bit);
@@ -258,6 +258,7 @@ J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t,
 		if (lane_bits_take(b, (int32_t) padn)) err = ERR_PAD0;
 		else if (at + padn != 8u * f.single_declared_end) err = at + padn < 8u * f.single_declared_end ? (uint32_t) ERR_SHRT : (uint32_t) ERR_EXCS;
 	}
+	if (end_bit_out) *end_bit_out = lane_bit_position(b);   // frames with extra channels: their Modular sub-image starts here (validate_trailers, runtime.hip)
 	return err;
 }
 

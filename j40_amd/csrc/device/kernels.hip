@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(64) k_hf_entropy_lanes(const DevPlan *plans, c
 	J40_TO_GLOBAL(plan.pool_u64); J40_TO_GLOBAL(plan.pool_f32); J40_TO_GLOBAL(plan.clusters); J40_TO_GLOBAL(plan.coeff_specs); J40_TO_GLOBAL(plan.lf_groups);
 	J40_TO_GLOBAL(plan.sections); J40_TO_GLOBAL(plan.group_blocks); J40_TO_GLOBAL(plan.group_block_start); J40_TO_GLOBAL(plan.coeffs[0]); J40_TO_GLOBAL(plan.coeffs[1]);
 	J40_TO_GLOBAL(plan.coeffs[2]); J40_TO_GLOBAL(plan.nonzeros); J40_TO_GLOBAL(plan.lz_window); J40_TO_GLOBAL(plan.status);
-	J40_TO_GLOBAL(plan.events); J40_TO_GLOBAL(plan.ev_range); J40_TO_GLOBAL(plan.block_events);
+	J40_TO_GLOBAL(plan.events); J40_TO_GLOBAL(plan.ev_range); J40_TO_GLOBAL(plan.block_events); J40_TO_GLOBAL(plan.section_end_bit);
 #undef J40_TO_GLOBAL
 	const DevFrame &f = *plan.frame;
 	const int32_t lane = threadIdx.x;
@@ -246,6 +246,7 @@ __global__ void __launch_bounds__(256) k_hf_lanes(const DevPlan *plans, const Hf
 	const J40_GLOBAL DevLfGroup *lf_groups = (const J40_GLOBAL DevLfGroup *) plan.lf_groups;
 	const J40_GLOBAL uint32_t *block_start = (const J40_GLOBAL uint32_t *) plan.group_block_start;
 	J40_GLOBAL uint32_t *status = (J40_GLOBAL uint32_t *) plan.status;
+	J40_GLOBAL uint32_t *end_bits = df.sections_have_trailer ? (J40_GLOBAL uint32_t *) plan.section_end_bit : nullptr;
 
 	J40_LDS uint8_t *lds = (J40_LDS uint8_t *) hf_lds;
 	J40_LDS int16_t *l_nnz = (J40_LDS int16_t *) lds;
@@ -281,8 +282,8 @@ __global__ void __launch_bounds__(256) k_hf_lanes(const DevPlan *plans, const Hf
 		if (active) {
 			const DevSection sec = load_global_pod(sections + (pass * num_groups + g));
 			const uint32_t cell_base = (uint32_t) lf_groups[sec.ggidx].cell_base;
-			status[pass * num_groups + g] = scan ? decode_hf_section_lane<true>(f, t, G, sec, cell_base, block_first, nblocks, ev_range[2 * g], ev_range[2 * g + 1], l_cols, 64, pass)
-			                                     : decode_hf_section_lane<false>(f, t, G, sec, cell_base, block_first, nblocks, 0, 0, l_cols, 64, pass);
+			status[pass * num_groups + g] = scan ? decode_hf_section_lane<true>(f, t, G, sec, cell_base, block_first, nblocks, ev_range[2 * g], ev_range[2 * g + 1], l_cols, 64, pass, end_bits ? end_bits + (pass * num_groups + g) : nullptr)
+			                                     : decode_hf_section_lane<false>(f, t, G, sec, cell_base, block_first, nblocks, 0, 0, l_cols, 64, pass, end_bits ? end_bits + (pass * num_groups + g) : nullptr);
 		}
 	}
 }

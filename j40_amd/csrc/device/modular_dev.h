@@ -131,20 +131,26 @@ J40_DEV ModTables mod_tables_in_hbm(const DevModPlan &plan, int32_t g) {
 // RING: neighbours come from t.rows and the weighted predictor's rows from t.wp_errors (both sized for the widest rectangle of
 // the frame by the caller), never from HBM -- a compile-time choice so that their address space stays static.
 // where coded channel `cidx` of a section lives: top-left sample of its rectangle, row pitch, size, meta flag
-struct ModChan { int16_t *base; int32_t stride, gw, gh, meta; };
+struct ModChan { int16_t *base; int32_t stride, gw, gh, meta, shifts; };
 J40_DEV ModChan mod_channel(const DevModPlan &plan, const DevModSection &sec, int32_t cidx) {
 	ModChan c;
 	if (sec.sub_off >= 0) {   // a plane of the section's own sub-image
 		const DevSubPlane sp = plan.sub_planes[sec.sub_off + cidx];
-		c.base = sp.ptr; c.stride = sp.w; c.gw = sp.w; c.gh = sp.h; c.meta = sp.meta;
+		c.base = sp.ptr; c.stride = sp.w; c.gw = sp.w; c.gh = sp.h; c.meta = sp.meta; c.shifts = 0;
 		return c;
 	}
-	const int32_t ch = sec.first_channel + cidx;
-	c.meta = plan.plane_meta[ch]; c.stride = plan.plane_w[ch];
+	if (sec.chan_off >= 0) {   // frames with channels of different sizes: an explicit rectangle
+		const DevChanRect r = plan.chan_rects[sec.chan_off + cidx];
+		const DevPlaneRef p = plan.planes[r.plane];
+		c.base = p.ptr + (size_t) r.y0 * (size_t) p.w + (size_t) r.x0; c.stride = p.w; c.gw = r.w; c.gh = r.h; c.meta = p.meta; c.shifts = r.shifts;
+		return c;
+	}
+	const DevPlaneRef p = plan.planes[sec.first_channel + cidx];
+	c.meta = p.meta; c.stride = p.w; c.shifts = 0;
 	// image channels: the section's rectangle; meta channels (palette): the whole plane
 	const int32_t gx = c.meta ? 0 : sec.gx, gy = c.meta ? 0 : sec.gy;
-	c.gw = c.meta ? plan.plane_w[ch] : sec.gw; c.gh = c.meta ? plan.plane_h[ch] : sec.gh;
-	c.base = plan.planes[ch] + (size_t) gy * (size_t) c.stride + (size_t) gx;
+	c.gw = c.meta ? p.w : sec.gw; c.gh = c.meta ? p.h : sec.gh;
+	c.base = p.ptr + (size_t) gy * (size_t) c.stride + (size_t) gx;
 	return c;
 }
 
@@ -244,7 +250,7 @@ J40_DEV uint32_t decode_modular_section(const DevModPlan &plan, const ModTables 
 						ModChan ref;
 						for (int32_t k = cidx - 1; k >= 0; --k) {
 							ref = mod_channel(plan, sec, k);
-							if (ref.meta != meta || ref.gw != gw || ref.gh != gh) continue;
+							if (ref.meta != meta || ref.gw != gw || ref.gh != gh || ref.shifts != chan.shifts) continue;
 							if (r-- == 0) { rc = k; break; }
 						}
 						if (rc < 0) { err = ERR_TREC; val = 0; break; }
@@ -304,19 +310,20 @@ J40_DEV void inverse_rct_pixel(int32_t type7, int16_t &a, int16_t &bb, int16_t &
 J40_DEV void section_inverse_rcts(const DevModPlan &plan, int32_t s, int32_t lane, int32_t nlanes) {
 	const DevModSection sec = plan.sections[s];
 	if (sec.local_count <= 0) return;
-	for (int32_t i = lane; i < sec.gw * sec.gh; i += nlanes) {
-		const int32_t y = i / sec.gw, x = i - y * sec.gw;
-		for (int32_t k = sec.local_count; k-- > 0; ) {
-			const int32_t begin = sec.first_channel + plan.local_rct[2 * (sec.local_off + k)], type = plan.local_rct[2 * (sec.local_off + k) + 1];
-			const size_t at = (size_t) (sec.gy + y) * (size_t) plan.plane_w[begin] + (size_t) (sec.gx + x);
-			int16_t p[3] = {plan.planes[begin][at], plan.planes[begin + 1][at], plan.planes[begin + 2][at]};
+	for (int32_t k = sec.local_count; k-- > 0; ) {
+		const int32_t begin = plan.local_rct[2 * (sec.local_off + k)], type = plan.local_rct[2 * (sec.local_off + k) + 1];
+		const ModChan ch[3] = {mod_channel(plan, sec, begin), mod_channel(plan, sec, begin + 1), mod_channel(plan, sec, begin + 2)};
+		const int32_t perm = type / 7;
+		// output channel PERM[perm][j] takes transformed channel j (j40.h:4395-4398)
+		const int32_t d0 = perm == 0 || perm == 3 ? 0 : perm == 1 || perm == 4 ? 1 : 2;
+		const int32_t d1 = perm == 0 || perm == 5 ? 1 : perm == 1 || perm == 3 ? 2 : 0;
+		const int32_t d2 = 3 - d0 - d1;
+		for (int32_t i = lane; i < ch[0].gw * ch[0].gh; i += nlanes) {
+			const int32_t y = i / ch[0].gw, x = i - y * ch[0].gw;
+			const size_t at = (size_t) y * (size_t) ch[0].stride + (size_t) x;   // the three channels are equal-sized planes of one image
+			int16_t p[3] = {ch[0].base[at], ch[1].base[at], ch[2].base[at]};
 			inverse_rct_pixel(type % 7, p[0], p[1], p[2]);
-			const int32_t perm = type / 7;
-			// output channel PERM[perm][j] takes transformed channel j (j40.h:4395-4398)
-			const int32_t d0 = perm == 0 || perm == 3 ? 0 : perm == 1 || perm == 4 ? 1 : 2;
-			const int32_t d1 = perm == 0 || perm == 5 ? 1 : perm == 1 || perm == 3 ? 2 : 0;
-			const int32_t d2 = 3 - d0 - d1;
-			plan.planes[begin + d0][at] = p[0]; plan.planes[begin + d1][at] = p[1]; plan.planes[begin + d2][at] = p[2];
+			ch[d0].base[at] = p[0]; ch[d1].base[at] = p[1]; ch[d2].base[at] = p[2];
 		}
 	}
 }

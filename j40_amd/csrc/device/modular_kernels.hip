@@ -7,11 +7,15 @@
 //   k_inverse_rct        K4: inverse reversible colour transform, one lane per pixel (j40.h:4318)
 //   k_inverse_palette*   K4: palette look-up (one lane per pixel) or, with delta prediction, the
 //                        serial form (j40.h:4402)
+//   k_unsqueeze_h/_v     K4: one inverse Squeeze step (ISO 18181-1; squeeze_dev.h): an average and a residual channel
+//                        joined along rows / columns. The recurrence runs along the squeezed axis, lines across it are
+//                        independent: one lane per line, rows staged through LDS so that HBM sees whole 128-byte pieces
 //   k_pack_planes        K5: int16 planes -> clamped RGBA u8x4 (j40.h:7910)
 //
 // Integer work throughout: results are bit-exact with the reference.
 #include <hip/hip_runtime.h>
 #include "modular_dev.h"
+#include "squeeze_dev.h"
 #include "kernels.h"
 
 namespace j40hip {
@@ -119,6 +123,51 @@ __global__ void __launch_bounds__(64) k_inverse_palette_predicted(const int16_t 
 	if (err) *status = err;
 }
 
+// horizontal step: out[y][2k], out[y][2k + 1] from avg[y][k], res[y][k]. One wavefront takes 64 rows; it walks along them in
+// pieces of SQZ_CHUNK pairs: the pieces of all 64 rows are loaded with one coalesced 128-byte read per row into LDS (odd pitch
+// in dwords: a lane walking its own row hits its own bank), each lane runs the recurrence over its row's piece, and the
+// 2 * SQZ_CHUNK results per row go out as two coalesced 128-byte writes. `left` (the sample before the pair) stays in a register.
+enum { SQZ_CHUNK = 64 };
+__global__ void __launch_bounds__(64) k_unsqueeze_h(const int16_t *avg, const int16_t *res, int16_t *out, int32_t aw, int32_t ah, int32_t rw) {
+	__shared__ int16_t s_avg[64][SQZ_CHUNK + 2], s_res[64][SQZ_CHUNK + 2], s_out[64][2 * SQZ_CHUNK + 2];
+	const int32_t lane = threadIdx.x, y0 = (int32_t) blockIdx.x * 64, rows = min(64, ah - y0), ow = aw + rw;
+	int32_t left = 0;
+	for (int32_t x0 = 0; x0 < aw; x0 += SQZ_CHUNK) {
+		for (int32_t r = 0; r < rows; ++r) {
+			const size_t ra = (size_t) (y0 + r) * (size_t) aw, rr = (size_t) (y0 + r) * (size_t) rw;
+			if (x0 + lane < aw) s_avg[r][lane] = avg[ra + (size_t) (x0 + lane)];
+			if (lane == 0 && x0 + SQZ_CHUNK < aw) s_avg[r][SQZ_CHUNK] = avg[ra + (size_t) (x0 + SQZ_CHUNK)];
+			if (x0 + lane < rw) s_res[r][lane] = res[rr + (size_t) (x0 + lane)];
+		}
+		__syncthreads();
+		if (lane < rows) {
+			const int32_t n = min(SQZ_CHUNK, rw - x0);   // pairs in this piece (<= 0 behind the last residual)
+			for (int32_t k = 0; k < n; ++k) {
+				const int32_t a = s_avg[lane][k], next = x0 + k + 1 < aw ? (int32_t) s_avg[lane][k + 1] : a;
+				int32_t p, q;
+				unsqueeze_pair(a, s_res[lane][k], x0 + k > 0 ? left : a, next, &p, &q);
+				s_out[lane][2 * k] = (int16_t) p; s_out[lane][2 * k + 1] = (int16_t) q;
+				left = (int16_t) q;
+			}
+			if (aw > rw && aw - 1 >= x0 && aw - 1 < x0 + SQZ_CHUNK) s_out[lane][2 * (aw - 1 - x0)] = s_avg[lane][aw - 1 - x0];   // odd width: the last average passes through
+		}
+		__syncthreads();
+		for (int32_t r = 0; r < rows; ++r) {
+			const size_t ro = (size_t) (y0 + r) * (size_t) ow + (size_t) (2 * x0);
+			if (2 * x0 + lane < ow) out[ro + (size_t) lane] = s_out[r][lane];
+			if (2 * x0 + 64 + lane < ow) out[ro + 64 + (size_t) lane] = s_out[r][64 + lane];
+		}
+		__syncthreads();
+	}
+}
+
+// vertical step: one lane per column; consecutive lanes touch consecutive samples of a row, so every access is coalesced
+__global__ void __launch_bounds__(256) k_unsqueeze_v(const int16_t *avg, const int16_t *res, int16_t *out, int32_t aw, int32_t ah, int32_t rh) {
+	const int32_t x = (int32_t) (blockIdx.x * blockDim.x + threadIdx.x);
+	if (x >= aw) return;
+	unsqueeze_line(avg + x, aw, rh > 0 ? res + x : avg + x, aw, ah, rh, out + x, aw);
+}
+
 __global__ void __launch_bounds__(256) k_pack_planes(const int16_t *r, const int16_t *g, const int16_t *b, const int16_t *a, int32_t width, int32_t height, int32_t bpp, uint8_t *rgba, size_t stride_bytes) {
 	const size_t n = (size_t) width * (size_t) height;
 	const int32_t opaque = (1 << bpp) - 1;
@@ -161,6 +210,12 @@ void launch_inverse_palette_plain(const int16_t *idx, const int16_t *palrow, int
 void launch_inverse_palette_predicted(const int16_t *idx, const int16_t *pal, int32_t pal_stride, int16_t *const *dst_dev, int32_t num_c, int32_t width, int32_t height,
 		int32_t nb_colours, int32_t nb_deltas, int32_t d_pred, int32_t bpp, const int8_t *wpp_dev, int32_t *wp_scratch, uint32_t *status, hipStream_t stream) {
 	hipLaunchKernelGGL(k_inverse_palette_predicted, dim3(1), dim3(64), 0, stream, idx, pal, pal_stride, dst_dev, num_c, width, height, nb_colours, nb_deltas, d_pred, bpp, wpp_dev, wp_scratch, status);
+}
+// avg: aw x ah, res: rw x rh; horizontal: rh == ah, out is (aw + rw) x ah; vertical: rw == aw, out is aw x (ah + rh)
+void launch_inverse_squeeze(const int16_t *avg, const int16_t *res, int16_t *out, int32_t aw, int32_t ah, int32_t rw, int32_t rh, bool horizontal, hipStream_t stream) {
+	if (aw <= 0 || ah <= 0) return;
+	if (horizontal) hipLaunchKernelGGL(k_unsqueeze_h, dim3((unsigned) ((ah + 63) / 64)), dim3(64), 0, stream, avg, res, out, aw, ah, rw);
+	else hipLaunchKernelGGL(k_unsqueeze_v, dim3((unsigned) ((aw + 255) / 256)), dim3(256), 0, stream, avg, res, out, aw, ah, rh);
 }
 void launch_pack_planes(const int16_t *r, const int16_t *g, const int16_t *b, const int16_t *a, int32_t width, int32_t height, int32_t bpp, uint8_t *rgba, size_t stride, hipStream_t stream) {
 	hipLaunchKernelGGL(k_pack_planes, dim3(grid_for((size_t) width * (size_t) height)), dim3(256), 0, stream, r, g, b, a, width, height, bpp, rgba, stride);

@@ -176,13 +176,22 @@ struct DevModSection {
 	// != 0: the section's own Modular header did not parse (on the host); nothing is decoded and this becomes the section's status,
 	// so that it takes its place among the other sections' errors (the first failing section in stream order is reported)
 	uint32_t preset_status;
+	// frames whose channels differ in size (Squeeze): the section's channels as explicit rectangles,
+	// DevModPlan::chan_rects[chan_off .. chan_off + num_channels). -1: first_channel ... over the rectangle above
+	int32_t chan_off;
 };
+
+// a coded channel of the frame (or a plane of a section's sub-image): tightly packed int16 rows
+struct DevPlaneRef { int16_t *ptr; int32_t w, h, meta, pad; };
+// one channel of one section: a rectangle of plane `plane`; shifts = hshift | vshift << 8 of the channel (matched when the MA
+// tree looks for "previous channels" of the same geometry)
+struct DevChanRect { int32_t plane, x0, y0, w, h, shifts; };
 
 struct DevSubPlane { int16_t *ptr; int32_t w, h, meta, pad; };
 
 struct DevTransform { int32_t kind, begin_c, rct_type, num_c, nb_colours, nb_deltas, d_pred, pad; };
 
-enum { MOD_MAX_CHANNELS = 16 };
+enum { MOD_MAX_CHANNELS = 256 };   // the reference's limit on channels while transforms are undone (j40.h:1173)
 
 struct DevModFrame {
 	int32_t width, height, num_groups, bpp;
@@ -206,9 +215,9 @@ struct DevModPlan {
 	const DevModSection *sections;    // [num_sections]
 	const int32_t *local_rct;         // {begin_c (section-relative), rct_type} pairs of the sections' own transforms
 	const DevSubPlane *sub_planes;    // planes of the sections that decode into a sub-image of their own (DevModSection::sub_off)
-	int16_t *planes[MOD_MAX_CHANNELS];        // sample planes of the coded channels, tightly packed rows
-	int32_t plane_w[MOD_MAX_CHANNELS], plane_h[MOD_MAX_CHANNELS];
-	int32_t plane_meta[MOD_MAX_CHANNELS];     // 1: meta channel (palette), decoded whole and never a "previous channel" of image channels
+	const DevPlaneRef *planes;        // [num_channels] sample planes of the coded channels; meta = 1: meta channel (palette), decoded
+	                                  // whole and never a "previous channel" of image channels
+	const DevChanRect *chan_rects;    // DevModSection::chan_off
 	int32_t *wp_scratch;              // [num_sections][2 * max_width * 5] weighted-predictor error rows
 	int32_t *lz_window; uint32_t lz_window_size;
 	uint32_t *status;                 // [num_sections]

@@ -16,10 +16,18 @@ using namespace j40hip;
 namespace {
 
 constexpr uint32_t ERR_GPU = ('!' << 24) | ('g' << 16) | ('p' << 8) | 'u';
+constexpr uint32_t ERR_MEM = ('!' << 24) | ('m' << 16) | ('e' << 8) | 'm';
+
+// no exception crosses the C ABI: a parse error keeps its code, anything else (std::bad_alloc from a vector, ...) is "!mem"
+template <typename F> uint32_t guarded(F f) {
+	try { return f(); }
+	catch (const DecodeError &e) { return e.code; }
+	catch (const std::exception &) { return ERR_MEM; }
+}
 
 struct DeviceBuffer {
 	void *ptr = nullptr; size_t bytes = 0;
-	bool alloc(size_t n) { bytes = n; return hipMalloc(&ptr, n ? n : 16) == hipSuccess; }
+	bool alloc(size_t n);
 	void release() { if (ptr) (void) hipFree(ptr); ptr = nullptr; }
 };
 
@@ -31,7 +39,20 @@ struct CachedBlock { void *ptr; size_t bytes; bool clean; };
 std::mutex g_cache_mutex;
 std::vector<CachedBlock> g_cache[16];
 size_t g_cached_bytes[16];
-constexpr size_t CACHE_LIMIT_BYTES = (size_t) 48 << 30;
+// upper bound on what the cache keeps (J40HIP_CACHE_GB overrides; 0 disables recycling). When an allocation fails the cache is
+// emptied and the allocation tried again (cache_trim), so idle blocks never turn into a spurious "!gpu"
+size_t cache_limit_bytes() {
+	static const size_t limit = [] { const char *e = getenv("J40HIP_CACHE_GB"); return (size_t) (e ? std::max(0, atoi(e)) : 48) << 30; }();
+	return limit;
+}
+
+// frees every cached block of `device` (they are idle by construction: blocks enter the cache after a device synchronisation)
+void cache_trim(int device) {
+	if (device < 0 || device >= 16) return;
+	std::lock_guard<std::mutex> lock(g_cache_mutex);
+	for (CachedBlock &b : g_cache[device]) (void) hipFree(b.ptr);
+	g_cache[device].clear(); g_cached_bytes[device] = 0;
+}
 
 void *cache_acquire(int device, size_t bytes, size_t *got, bool *clean) {
 	bytes = (bytes + 4095) & ~(size_t) 4095;
@@ -47,7 +68,12 @@ void *cache_acquire(int device, size_t bytes, size_t *got, bool *clean) {
 		}
 	}
 	void *p = nullptr;
-	if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+	if (hipMalloc(&p, bytes) != hipSuccess) {
+		// out of device memory while blocks sit idle in the cache: give them back and try once more
+		(void) hipGetLastError();
+		cache_trim(device);
+		if (hipMalloc(&p, bytes) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+	}
 	*got = bytes; *clean = false;
 	return p;
 }
@@ -56,13 +82,22 @@ void cache_release(int device, void *ptr, size_t bytes, bool clean) {
 	if (!ptr) return;
 	if (device >= 0 && device < 16) {
 		std::lock_guard<std::mutex> lock(g_cache_mutex);
-		if (g_cached_bytes[device] + bytes <= CACHE_LIMIT_BYTES) {
+		if (g_cached_bytes[device] + bytes <= cache_limit_bytes()) {
 			g_cache[device].push_back({ptr, bytes, clean});
 			g_cached_bytes[device] += bytes;
 			return;
 		}
 	}
 	(void) hipFree(ptr);
+}
+
+bool DeviceBuffer::alloc(size_t n) {
+	bytes = n;
+	if (hipMalloc(&ptr, n ? n : 16) == hipSuccess) return true;
+	(void) hipGetLastError();
+	int device = 0;
+	if (hipGetDevice(&device) == hipSuccess) cache_trim(device);
+	return hipMalloc(&ptr, n ? n : 16) == hipSuccess;
 }
 
 // host-side staging of the plan: every array lands in one blob at a 256-byte aligned offset, one copy moves it
@@ -102,6 +137,7 @@ struct j40hip_device_state {
 	int32_t mod_sections = 0, mod_passes = 1, mod_sections_per_pass = 0;   // sections = LfGlobal's (0 or 1) + passes * per_pass
 	bool mod_local_rcts = false;
 	bool has_trailers = false;           // VarDCT frame whose sections go on with the extra channels' Modular sub-image
+	bool trailers_pending = false;       // ... decoded by a batch since: j40hip_frame_status validates the sub-images before it reports
 	ModLaunchInfo mod_info = {0, 0, 0, 0, 0, 0};
 	std::vector<uint32_t> mod_section_offsets;
 	struct ModOp { int kind; int16_t *a, *b, *c; const int16_t *src, *aux; size_t n; int32_t p0, p1, p2, p3, p4, p5; int16_t *const *dst_list; const int8_t *wpp; };
@@ -176,11 +212,19 @@ static uint32_t upload_modular(j40hip_frame *h, int device) {
 	const int32_t nch = hp.frame.num_channels;
 	struct Ref { int16_t *p; int32_t w, h; };
 	std::vector<Ref> planes;
-	for (int32_t c = 0; c < nch; ++c) {
-		const size_t n = (size_t) std::max(hp.plane_w[(size_t) c], 0) * (size_t) std::max(hp.plane_h[(size_t) c], 0);
-		int16_t *p = st->scratch<int16_t>(n ? n : 1, ok);
-		plan.planes[c] = p; plan.plane_w[c] = hp.plane_w[(size_t) c]; plan.plane_h[c] = hp.plane_h[(size_t) c]; plan.plane_meta[c] = hp.plane_meta[(size_t) c];
-		planes.push_back({p, hp.plane_w[(size_t) c], hp.plane_h[(size_t) c]});
+	{
+		// the coded channels: one allocation, each plane at a 256-byte aligned offset (a squeezed 16384 x 16384 frame has 70+ of them)
+		std::vector<size_t> at((size_t) nch); size_t total = 0;
+		for (int32_t c = 0; c < nch; ++c) { at[(size_t) c] = total; total += ((size_t) std::max(hp.plane_w[(size_t) c], 0) * (size_t) std::max(hp.plane_h[(size_t) c], 0) * 2 + 2 + 255) & ~(size_t) 255; }
+		uint8_t *blockp = (uint8_t *) st->scratch<uint8_t>(total ? total : 256, ok);
+		std::vector<DevPlaneRef> refs((size_t) nch);
+		for (int32_t c = 0; c < nch; ++c) {
+			int16_t *p = blockp ? (int16_t *) (blockp + at[(size_t) c]) : nullptr;
+			refs[(size_t) c] = DevPlaneRef{p, hp.plane_w[(size_t) c], hp.plane_h[(size_t) c], hp.plane_meta[(size_t) c], 0};
+			planes.push_back({p, hp.plane_w[(size_t) c], hp.plane_h[(size_t) c]});
+		}
+		plan.planes = st->upload(refs.data(), refs.size(), s, ok);
+		if (!hp.chan_rects.empty()) plan.chan_rects = st->upload(hp.chan_rects.data(), hp.chan_rects.size(), s, ok);
 	}
 	bool palette_wp = false;
 	for (const Transform &t : hp.transforms) palette_wp |= t.kind == Transform::PALETTE && t.nb_deltas > 0 && t.d_pred == 6;
@@ -229,6 +273,23 @@ static uint32_t upload_modular(j40hip_frame *h, int device) {
 				next.insert(next.end(), outs.begin(), outs.end());
 				next.insert(next.end(), planes.begin() + first + 1, planes.end());
 				planes.swap(next);
+			} else if (t.kind == Transform::SQUEEZE) {
+				// one step: every squeezed channel and its residual channel are joined into a new plane (the recurrence runs along
+				// the squeezed axis, so it is not done in place); the residual channels then leave the list
+				const int32_t nc = (int32_t) planes.size(), end_c = t.begin_c + t.num_c, offset = t.in_place ? end_c : nc - t.num_c;
+				if (t.begin_c < 0 || t.num_c < 1 || end_c > nc || offset + t.num_c > nc || offset < end_c) { ok = false; break; }
+				for (int32_t c = t.begin_c; c < end_c; ++c) {
+					const Ref avg = planes[(size_t) c], res = planes[(size_t) (offset + c - t.begin_c)];
+					Ref out = {nullptr, t.horizontal ? avg.w + res.w : avg.w, t.horizontal ? avg.h : avg.h + res.h};
+					if ((t.horizontal ? res.h != avg.h || (res.w != avg.w && res.w != avg.w - 1) : res.w != avg.w || (res.h != avg.h && res.h != avg.h - 1))) { ok = false; break; }
+					const size_t n = (size_t) std::max(out.w, 0) * (size_t) std::max(out.h, 0);
+					out.p = st->scratch<int16_t>(n ? n : 1, ok);
+					j40hip_device_state::ModOp op; memset(&op, 0, sizeof op);
+					op.kind = 4; op.src = avg.p; op.aux = res.p; op.a = out.p; op.p0 = avg.w; op.p1 = avg.h; op.p2 = res.w; op.p3 = res.h; op.p4 = t.horizontal ? 1 : 0;
+					ops.push_back(op);
+					planes[(size_t) c] = out;
+				}
+				if (ok) planes.erase(planes.begin() + offset, planes.begin() + offset + t.num_c);
 			} else { ok = false; }
 		}
 	};
@@ -294,6 +355,7 @@ static uint32_t decode_modular(j40hip_frame *h, void *rgba_dev, size_t stride_by
 		if (op.kind == 0) launch_inverse_rct(op.a, op.b, op.c, op.n, op.p0, s);
 		else if (op.kind == 1) launch_inverse_palette_plain(op.src, op.aux, op.a, op.n, op.p0, op.p1, fr.im.bpp, s);
 		else if (op.kind == 2) launch_inverse_palette_predicted(op.src, op.aux, op.p0, op.dst_list, op.p1, op.p2, op.p3, op.p4, op.p5 & 0xffffff, op.p5 >> 24, fr.im.bpp, op.wpp, st->pal_wp_scratch, st->mod_extra_status, s);
+		else if (op.kind == 4) launch_inverse_squeeze(op.src, op.aux, op.a, op.p0, op.p1, op.p2, op.p3, op.p4 != 0, s);
 		else launch_paste_plane(op.src, op.p0, op.p1, op.a, op.p2, s);
 	}
 	launch_pack_planes(st->final_planes[0], st->final_planes[1], st->final_planes[2], st->alpha_channel >= 0 ? st->final_planes[(size_t) st->alpha_channel] : nullptr,
@@ -308,7 +370,7 @@ static uint32_t decode_modular(j40hip_frame *h, void *rgba_dev, size_t stride_by
 	return hipGetLastError() == hipSuccess ? 0 : ERR_GPU;
 }
 
-extern "C" uint32_t j40hip_frame_upload(j40hip_frame *h, int device) {
+static uint32_t j40hip_frame_upload_body(j40hip_frame *h, int device) {
 	if (!h) return ERR_GPU;
 	if (h->dev) j40hip_release_device(h);
 	if (j40hip_device_count() <= device || hipSetDevice(device) != hipSuccess) return ERR_GPU;
@@ -400,7 +462,7 @@ extern "C" uint32_t j40hip_frame_upload(j40hip_frame *h, int device) {
 
 extern "C" void j40hip_frame_force_dense(j40hip_frame *h, int dense) { if (h) h->force_dense = dense != 0; }
 
-extern "C" uint32_t j40hip_frame_set_group_range(j40hip_frame *h, int64_t first_group, int64_t num_groups) {
+static uint32_t j40hip_frame_set_group_range_body(j40hip_frame *h, int64_t first_group, int64_t num_groups) {
 	if (!h || !h->dev) return ERR_GPU;
 	if (first_group < 0 || num_groups < 0 || first_group + num_groups > h->frame.fh.num_groups) return ERR_RNGE;
 	j40hip_device_state *st = h->dev;
@@ -504,6 +566,7 @@ static uint32_t decode_impl(j40hip_frame *h, void *rgba_dev, size_t stride_bytes
 	const DevPlan &plan = st->plan;
 	const Frame &fr = h->frame;
 	const bool whole = st->first_group == 0 && st->num_groups == fr.fh.num_groups;
+	st->trailers_pending = false;
 	if (ms3) (void) hipEventRecord(st->ev[0], s);
 	if (uint32_t e = clear_before_decode(st, s)) return e;
 	if (hipMemsetAsync(plan.status, 0, sizeof(uint32_t) * (size_t) st->total_sections, s) != hipSuccess) return ERR_GPU;
@@ -536,6 +599,7 @@ struct j40hip_batch {
 	int device = 0;
 	std::vector<j40hip_frame *> frames;
 	DevPlan *d_plans = nullptr;
+	std::vector<DevPlan> plans_host;   // what d_plans holds (batch_enqueue re-uploads it when a member was uploaded again)
 	HfLaneWork *d_work = nullptr;
 	int32_t num_work = 0;
 	bool tables_in_lds = true;
@@ -572,7 +636,7 @@ extern "C" void j40hip_batch_free(j40hip_batch *b) {
 	delete b;
 }
 
-extern "C" j40hip_batch *j40hip_batch_create(j40hip_frame *const *frames, int64_t n, uint32_t *err) {
+static j40hip_batch *batch_create_body(j40hip_frame *const *frames, int64_t n, uint32_t *err) {
 	uint32_t dummy; if (!err) err = &dummy;
 	*err = 0;
 	if (n <= 0 || !frames) { *err = ERR_RNGE; return nullptr; }
@@ -610,6 +674,7 @@ extern "C" j40hip_batch *j40hip_batch_create(j40hip_frame *const *frames, int64_
 		b->lds_bytes = std::max(b->lds_bytes, hf_lanes_lds_bytes(info));
 	}
 	b->num_work = (int32_t) work.size();
+	b->plans_host = plans;
 	bool ok = hipSetDevice(b->device) == hipSuccess;
 	ok = ok && hipMalloc((void **) &b->d_plans, sizeof(DevPlan) * plans.size()) == hipSuccess;
 	ok = ok && hipMalloc((void **) &b->d_work, sizeof(HfLaneWork) * work.size()) == hipSuccess;
@@ -646,9 +711,23 @@ extern "C" j40hip_batch *j40hip_batch_create(j40hip_frame *const *frames, int64_
 static uint32_t batch_enqueue(j40hip_batch *b, void *const *rgba_dev, const size_t *stride_bytes, hipStream_t s, hipEvent_t *ev) {
 	if (!b) return ERR_GPU;
 	if (hipSetDevice(b->device) != hipSuccess) return ERR_GPU;
+	// a member that was uploaded again since the batch was made (j40hip_frame_force_dense + j40hip_frame_upload after "evof")
+	// has a new plan in new blocks: the array the entropy kernel reads is brought up to date, stream-ordered behind the
+	// launches of an earlier decode that may still be reading it. A member without device state fails the batch.
+	{
+		bool changed = false;
+		for (size_t i = 0; i < b->frames.size(); ++i) {
+			j40hip_device_state *st = b->frames[i]->dev;
+			if (!st || st->is_modular || st->device != b->device) return ERR_GPU;
+			if (memcmp(&b->plans_host[i], &st->plan, sizeof(DevPlan)) != 0) { b->plans_host[i] = st->plan; changed = true; }
+		}
+		if (changed && hipMemcpyAsync(b->d_plans, b->plans_host.data(), sizeof(DevPlan) * b->plans_host.size(), hipMemcpyHostToDevice, s) != hipSuccess) return ERR_GPU;
+		if (changed && hipStreamSynchronize(s) != hipSuccess) return ERR_GPU;   // (pageable source: the copy must have left the vector)
+	}
 	if (ev) (void) hipEventRecord(ev[0], s);
 	for (j40hip_frame *h : b->frames) {
 		j40hip_device_state *st = h->dev;
+		st->trailers_pending = st->has_trailers;
 		if (uint32_t e = clear_before_decode(st, s)) return e;
 		// (no need to clear the status words: a batch decodes every section of every frame and the entropy kernels store
 		// each section's status unconditionally -- 256 tiny fills were 4 % of a step)
@@ -714,7 +793,7 @@ extern "C" uint32_t j40hip_batch_decode_recorded(j40hip_batch *b, void *const *r
 	if (!b || slot < 0 || slot >= 4096) return ERR_RNGE;
 	if (hipSetDevice(b->device) != hipSuccess) return ERR_GPU;
 	while (b->slots.size() < 4 * ((size_t) slot + 1)) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return ERR_GPU; b->slots.push_back(e); }
-	return batch_enqueue(b, rgba_dev, stride_bytes, (hipStream_t) stream, b->slots.data() + 4 * (size_t) slot);
+	return guarded([&] { return batch_enqueue(b, rgba_dev, stride_bytes, (hipStream_t) stream, b->slots.data() + 4 * (size_t) slot); });
 }
 // makes `stream` wait until stage `stage` (1: cleared, 2: entropy decoded, 3: pixels written) of the decode recorded in
 // `slot` has completed; used to stagger batches on different streams
@@ -728,21 +807,21 @@ extern "C" uint32_t j40hip_batch_elapsed(j40hip_batch *b, int32_t slot, float *m
 }
 
 extern "C" uint32_t j40hip_batch_decode(j40hip_batch *b, void *const *rgba_dev, const size_t *stride_bytes, void *stream) {
-	return batch_decode_impl(b, rgba_dev, stride_bytes, (hipStream_t) stream, nullptr);
+	return guarded([&] { return batch_decode_impl(b, rgba_dev, stride_bytes, (hipStream_t) stream, nullptr); });
 }
 extern "C" uint32_t j40hip_batch_decode_timed(j40hip_batch *b, void *const *rgba_dev, const size_t *stride_bytes, void *stream, float *ms3) {
-	return batch_decode_impl(b, rgba_dev, stride_bytes, (hipStream_t) stream, ms3);
+	return guarded([&] { return batch_decode_impl(b, rgba_dev, stride_bytes, (hipStream_t) stream, ms3); });
 }
 
 extern "C" uint32_t j40hip_frame_decode(j40hip_frame *h, void *rgba_dev, size_t stride_bytes, void *stream) {
-	return decode_impl(h, rgba_dev, stride_bytes, (hipStream_t) stream, nullptr);
+	return guarded([&] { return decode_impl(h, rgba_dev, stride_bytes, (hipStream_t) stream, nullptr); });
 }
 
 extern "C" uint32_t j40hip_frame_decode_timed(j40hip_frame *h, void *rgba_dev, size_t stride_bytes, void *stream, float *ms3) {
-	return decode_impl(h, rgba_dev, stride_bytes, (hipStream_t) stream, ms3);
+	return guarded([&] { return decode_impl(h, rgba_dev, stride_bytes, (hipStream_t) stream, ms3); });
 }
 
-extern "C" uint32_t j40hip_frame_status(j40hip_frame *h) {
+static uint32_t j40hip_frame_status_body(j40hip_frame *h) {
 	if (!h || !h->dev) return ERR_GPU;
 	j40hip_device_state *st = h->dev;
 	if (st->is_modular) {
@@ -752,6 +831,13 @@ extern "C" uint32_t j40hip_frame_status(j40hip_frame *h) {
 		for (size_t i = 0; i < (size_t) st->total_sections; ++i) if (st->status_host[i]) bad.push_back({st->mod_section_offsets[i], st->status_host[i]});
 		if (!bad.empty()) return std::min_element(bad.begin(), bad.end())->second;
 		return st->status_host[(size_t) st->total_sections];
+	}
+	if (st->trailers_pending) {
+		// the frame was last decoded by a batch (asynchronous: it cannot stop for the host in the middle): the extra channels'
+		// sub-images behind the coefficients are checked now, so that both modes report damage in them like the reference
+		st->trailers_pending = false;
+		if (hipSetDevice(st->device) != hipSuccess) return ERR_GPU;
+		if (uint32_t e = validate_trailers(h, nullptr)) return e;
 	}
 	st->status_host.assign((size_t) st->total_sections, 0);
 	if (hipMemcpy(st->status_host.data(), st->plan.status, sizeof(uint32_t) * st->status_host.size(), hipMemcpyDeviceToHost) != hipSuccess) return ERR_GPU;
@@ -764,7 +850,7 @@ extern "C" uint32_t j40hip_frame_status(j40hip_frame *h) {
 	return std::min_element(bad.begin(), bad.end())->second;
 }
 
-extern "C" uint32_t j40hip_frame_decode_to_host(j40hip_frame *h, void *rgba_host, size_t stride_bytes) {
+static uint32_t j40hip_frame_decode_to_host_body(j40hip_frame *h, void *rgba_host, size_t stride_bytes) {
 	if (!h || !h->dev) return ERR_GPU;
 	const Frame &fr = h->frame;
 	const int device = h->dev->device;
@@ -837,4 +923,13 @@ extern "C" uint32_t j40hip_kat_device_srgb_u8(const float *v_host, size_t n, uin
 	if (dv) (void) hipFree(dv);
 	if (dout) (void) hipFree(dout);
 	return ok ? 0 : ERR_GPU;
+}
+
+// ---- the guarded entry points of the functions above ----
+extern "C" uint32_t j40hip_frame_upload(j40hip_frame *h, int device) { return guarded([&] { return j40hip_frame_upload_body(h, device); }); }
+extern "C" uint32_t j40hip_frame_set_group_range(j40hip_frame *h, int64_t first_group, int64_t num_groups) { return guarded([&] { return j40hip_frame_set_group_range_body(h, first_group, num_groups); }); }
+extern "C" uint32_t j40hip_frame_status(j40hip_frame *h) { return guarded([&] { return j40hip_frame_status_body(h); }); }
+extern "C" uint32_t j40hip_frame_decode_to_host(j40hip_frame *h, void *rgba_host, size_t stride_bytes) { return guarded([&] { return j40hip_frame_decode_to_host_body(h, rgba_host, stride_bytes); }); }
+extern "C" j40hip_batch *j40hip_batch_create(j40hip_frame *const *frames, int64_t n, uint32_t *err) {
+	try { return batch_create_body(frames, n, err); } catch (const std::exception &) { if (err) *err = ERR_MEM; return nullptr; }
 }

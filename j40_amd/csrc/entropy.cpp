@@ -1,6 +1,7 @@
 // j40_amd/csrc/entropy.cpp -- see entropy.hpp
 #include "entropy.hpp"
 #include <cmath>
+#include <algorithm>
 
 namespace j40hip {
 
@@ -109,6 +110,11 @@ static void build_prefix_table(const std::vector<int32_t> &lengths, Cluster *out
 	out->lengths.assign(lengths.begin(), lengths.end());
 }
 
+bool rfc_simple_code_order() {
+	static const bool on = [] { const char *e = getenv("J40HIP_RFC_SIMPLE_CODES"); return e && atoi(e) != 0; }();
+	return on;
+}
+
 static void read_prefix_tree(BitReader &br, int32_t alphabet, Cluster *out) {  // j40.h:2049
 	if (alphabet == 1) { out->fast_len = out->max_len = 0; out->table.assign(1, 0); out->lengths.assign(1, 0); return; }
 	int32_t hskip = (int32_t) br.u(2);
@@ -126,7 +132,20 @@ static void read_prefix_tree(BitReader &br, int32_t alphabet, Cluster *out) {  /
 		case 3: lengths[(size_t) syms[0]] = 1; lengths[(size_t) syms[1]] = lengths[(size_t) syms[2]] = 2; break;
 		default:
 			if (tree_select) { lengths[(size_t) syms[0]] = 1; lengths[(size_t) syms[1]] = 2; lengths[(size_t) syms[2]] = lengths[(size_t) syms[3]] = 3; }
-			else for (int i = 0; i < 4; ++i) lengths[(size_t) syms[i]] = 2;  // RFC order: symbols sorted
+			else if (rfc_simple_code_order()) for (int i = 0; i < 4; ++i) lengths[(size_t) syms[i]] = 2;   // RFC 7932: canonical code over the sorted symbols
+			else {
+				// The reference fills this template's table with symref {0, 1, 2, 3} at the index made of the bits in READ order
+				// (j40.h:2090, 2112): the sorted symbols 1 and 2 swap places against RFC 7932's canonical code ("10" reads as index 1).
+				// Same table here by default -- results identical to the reference's; J40HIP_RFC_SIMPLE_CODES=1 selects the RFC order.
+				// The view marks the four symbols with length 2 | 128 so that a table can be rebuilt from the lengths alone.
+				std::sort(syms, syms + 4);
+				out->fast_len = out->max_len = 2;
+				out->table.assign(5, 0);
+				for (int i = 0; i < 4; ++i) out->table[(size_t) i] = (syms[i] << 16) | 2;
+				out->lengths.assign((size_t) alphabet, 0);
+				for (int i = 0; i < 4; ++i) out->lengths[(size_t) syms[i]] = 2 | 128;
+				return;
+			}
 		}
 		build_prefix_table(lengths, out);
 		return;
@@ -406,6 +425,15 @@ void finish_code_spec_tables(CodeSpec *spec) {
 			else if (only >= 0) { cl.fast_len = cl.max_len = 0; cl.table.assign(1, only << 16); }
 			else {
 				std::vector<int32_t> lengths(cl.lengths.begin(), cl.lengths.end());
+				{   // the reference-ordered NSYM = 4 template (read_prefix_tree): four symbols marked 2 | 128
+					std::vector<int32_t> marked;
+					for (size_t i = 0; i < lengths.size(); ++i) if (lengths[i] == (2 | 128)) marked.push_back((int32_t) i);
+					if (marked.size() == 4) {
+						cl.fast_len = cl.max_len = 2; cl.table.assign(5, 0);
+						for (int i = 0; i < 4; ++i) cl.table[(size_t) i] = (marked[(size_t) i] << 16) | 2;
+						continue;
+					}
+				}
 				for (int32_t l : lengths) if (l > 15) J40HIP_RAISE("hufd");
 				build_prefix_table(lengths, &cl);
 			}

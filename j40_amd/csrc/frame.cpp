@@ -447,9 +447,16 @@ static void read_lf_global(BitReader &br, Frame *f) {
 	}
 	if (!f->gmodular.channel.empty()) {
 		read_modular_header(br, &f->global_tree, &f->global_codespec, &f->gmodular);
-		allocate_modular(&f->gmodular);
-		if (fh.width <= (1 << fh.group_size_shift) && fh.height <= (1 << fh.group_size_shift)) f->num_gm_channels = (int32_t) f->gmodular.channel.size();
-		else f->num_gm_channels = f->gmodular.nb_meta_channels;
+		// LfGlobal codes the meta channels and the channels behind them that fit into one group; the rest is left to the
+		// LfGroup / pass-group sections. Without Squeeze that is the reference's rule (every channel of a frame no larger
+		// than a group, else the meta channels only, j40.h:6329-6333); after a Squeeze the small channels qualify too
+		{
+			const int32_t gdim = 1 << fh.group_size_shift, nch = (int32_t) f->gmodular.channel.size();
+			int32_t n = f->gmodular.nb_meta_channels;
+			while (n < nch && f->gmodular.channel[(size_t) n].width <= gdim && f->gmodular.channel[(size_t) n].height <= gdim) ++n;
+			f->num_gm_channels = n;
+		}
+		if (!fh.is_modular) allocate_modular(&f->gmodular);   // (Modular frames are decoded on the device: no host planes)
 		if (fh.is_modular) {
 			// the channel data that follows (j40.h:6334-6337) is decoded by the HIP Modular kernel, which
 			// continues from this bit position inside the section
@@ -785,6 +792,7 @@ void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
 				BitReader sr(cs + f->toc.lf_groups[(size_t) i].offset, f->toc.lf_groups[(size_t) i].size);
 				read_lf_group(sr, f, &f->lf_groups[(size_t) i]);
 			} catch (const DecodeError &e) { errs[(size_t) i] = e.code; }
+			catch (const std::exception &) { errs[(size_t) i] = E4("!mem"); }   // (an exception leaving a thread would end the process)
 		}
 	};
 	int nthreads = (int) std::min<int64_t>(threads < 1 ? 1 : threads, n);
@@ -794,7 +802,11 @@ void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
 		for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
 		for (auto &t : pool) t.join();
 	}
-	for (uint32_t e : errs) if (e) raise(e);  // first failing section in TOC order
+	{   // the first failing section in the order the reference reads them: by offset (a permuted TOC stores them out of index order, j40.h:5608)
+		size_t best = SIZE_MAX; uint32_t code = 0;
+		for (size_t i = 0; i < errs.size(); ++i) if (errs[i] && f->toc.lf_groups[i].offset < best) { best = f->toc.lf_groups[i].offset; code = errs[i]; }
+		if (code) raise(code);
+	}
 	(void) first_err;
 	if (!f->fh.is_modular) prepare_tables(f);
 }

@@ -1,5 +1,6 @@
 // j40_amd/csrc/modular.cpp -- see modular.hpp
 #include "modular.hpp"
+#include "device/squeeze_dev.h"
 #include <algorithm>
 
 namespace j40hip {
@@ -105,10 +106,27 @@ void read_modular_header(BitReader &br, const std::vector<TreeNode> *global_tree
 			channel.swap(next);
 			break;
 		}
-		case Transform::SQUEEZE: {   // the reference reads the parameters, then stops (j40.h:3794-3812): running out of bytes in them wins
+		case Transform::SQUEEZE: {
+			// The reference reads the parameters and then stops with "TODO" (j40.h:3794-3812); here the transform is carried
+			// out (ISO 18181-1; device/squeeze_dev.h). Each step becomes a transform of its own, like the reference stores them.
 			const int32_t num_sq = br.u32(0, 0, 1, 4, 9, 6, 41, 8);
-			for (int32_t j = 0; j < num_sq; ++j) { br.u(2); br.u32(0, 3, 8, 6, 72, 10, 1096, 13); br.u32(1, 0, 2, 0, 3, 0, 4, 4); }
-			J40HIP_RAISE("TODO");
+			std::vector<Transform> steps;
+			if (num_sq == 0) default_squeeze_steps(channel, nb_meta, &steps);
+			else for (int32_t j = 0; j < num_sq; ++j) {
+				Transform st; st.kind = Transform::SQUEEZE;
+				st.horizontal = br.u(1) != 0; st.in_place = br.u(1) != 0;
+				st.begin_c = br.u32(0, 3, 8, 6, 72, 10, 1096, 13); st.num_c = br.u32(1, 0, 2, 0, 3, 0, 4, 4);
+				steps.push_back(st);
+			}
+			for (const Transform &st : steps) {
+				const int32_t nc = (int32_t) channel.size(), end_c = st.begin_c + st.num_c;
+				J40HIP_SHOULD(st.num_c >= 1 && end_c <= nc, "sqzc");
+				if (st.begin_c < nb_meta) J40HIP_SHOULD(st.in_place && end_c <= nb_meta, "sqzc");   // meta channels: in place, not across the border
+				J40HIP_SHOULD(nc + st.num_c <= 256, "xlim");
+				apply_squeeze_meta(st, &channel, &nb_meta);
+				m->transforms.push_back(st);
+			}
+			continue;   // (already recorded, step by step)
 		}
 		default: J40HIP_RAISE("xfm?");
 		}
@@ -406,6 +424,69 @@ static void inverse_palette(Modular &m, const Transform &tr) {  // j40.h:4402
 	m.channel.erase(m.channel.begin());
 }
 
+// one Squeeze step undone: every squeezed channel is joined with its residual channel (device/squeeze_dev.h); the
+// residual channels then leave the list. Empty planes (header-only images) only change their sizes.
+static void inverse_squeeze(Modular &m, const Transform &tr) {
+	const int32_t nc = (int32_t) m.channel.size(), end_c = tr.begin_c + tr.num_c;
+	const int32_t offset = tr.in_place ? end_c : nc - tr.num_c;
+	for (int32_t c = tr.begin_c; c < end_c; ++c) {
+		Plane &avg = m.channel[(size_t) c]; const Plane &res = m.channel[(size_t) (offset + c - tr.begin_c)];
+		Plane out;
+		out.width = tr.horizontal ? avg.width + res.width : avg.width; out.height = tr.horizontal ? avg.height : avg.height + res.height;
+		out.hshift = (int8_t) (avg.hshift - (tr.horizontal ? 1 : 0)); out.vshift = (int8_t) (avg.vshift - (tr.horizontal ? 0 : 1));
+		const bool allocated = avg.px.size() == (size_t) std::max(avg.width, 0) * (size_t) std::max(avg.height, 0) && res.px.size() == (size_t) std::max(res.width, 0) * (size_t) std::max(res.height, 0);
+		if (allocated) {
+			out.allocate();
+			if (!out.empty()) {
+				if (tr.horizontal) for (int32_t y = 0; y < out.height; ++y)
+					unsqueeze_line(avg.row(y), 1, res.width > 0 ? res.row(y) : avg.row(y), 1, avg.width, res.width, out.row(y), 1);
+				else for (int32_t x = 0; x < out.width; ++x)
+					unsqueeze_line(avg.px.data() + x, avg.width, res.height > 0 ? res.px.data() + x : avg.px.data() + x, res.width, avg.height, res.height, out.px.data() + x, out.width);
+			}
+		}
+		avg = std::move(out);
+	}
+	m.channel.erase(m.channel.begin() + offset, m.channel.begin() + offset + tr.num_c);
+	if (tr.begin_c < m.nb_meta_channels) m.nb_meta_channels -= tr.num_c;
+}
+
+void apply_squeeze_meta(const Transform &tr, std::vector<Plane> *channel, int32_t *nb_meta) {
+	const int32_t end_c = tr.begin_c + tr.num_c;
+	const int32_t offset = tr.in_place ? end_c : (int32_t) channel->size();
+	if (tr.begin_c < *nb_meta) *nb_meta += tr.num_c;
+	for (int32_t c = tr.begin_c; c < end_c; ++c) {
+		Plane &ch = (*channel)[(size_t) c];
+		Plane res; res.hshift = ch.hshift; res.vshift = ch.vshift;
+		if (tr.horizontal) {
+			const int32_t w = ch.width; ch.width = (w + 1) / 2; res.width = w - ch.width; res.height = ch.height;
+			if (ch.hshift >= 0) { ++ch.hshift; res.hshift = ch.hshift; }
+		} else {
+			const int32_t h = ch.height; ch.height = (h + 1) / 2; res.height = h - ch.height; res.width = ch.width;
+			if (ch.vshift >= 0) { ++ch.vshift; res.vshift = ch.vshift; }
+		}
+		channel->insert(channel->begin() + offset + (c - tr.begin_c), res);
+	}
+}
+
+void default_squeeze_steps(const std::vector<Plane> &channel, int32_t nb_meta, std::vector<Transform> *out) {
+	const int32_t first = nb_meta, count = (int32_t) channel.size() - first;
+	if (count <= 0) return;
+	int32_t w = channel[(size_t) first].width, h = channel[(size_t) first].height;
+	Transform st; st.kind = Transform::SQUEEZE;
+	if (count > 2 && channel[(size_t) first + 1].width == w && channel[(size_t) first + 1].height == h) {
+		// channels 1 and 2 are taken to be chroma: squeezed once in each direction first, residuals at the end of the list
+		st.begin_c = first + 1; st.num_c = 2; st.in_place = false;
+		st.horizontal = true; out->push_back(st);
+		st.horizontal = false; out->push_back(st);
+	}
+	st.begin_c = first; st.num_c = count; st.in_place = true;
+	if (h >= w && h > 8) { st.horizontal = false; out->push_back(st); h = (h + 1) / 2; }
+	while (w > 8 || h > 8) {
+		if (w > 8) { st.horizontal = true; out->push_back(st); w = (w + 1) / 2; }
+		if (h > 8) { st.horizontal = false; out->push_back(st); h = (h + 1) / 2; }
+	}
+}
+
 void inverse_transforms(Modular &m) {  // j40.h:4506
 	if (m.channel.empty()) return;
 	for (size_t i = m.transforms.size(); i-- > 0; ) {
@@ -413,6 +494,7 @@ void inverse_transforms(Modular &m) {  // j40.h:4506
 		switch (tr.kind) {
 		case Transform::RCT: inverse_rct(m, tr); break;
 		case Transform::PALETTE: inverse_palette(m, tr); break;
+		case Transform::SQUEEZE: inverse_squeeze(m, tr); break;
 		default: J40HIP_RAISE("TODO");
 		}
 	}

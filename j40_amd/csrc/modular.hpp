@@ -22,7 +22,11 @@ struct Transform {
 	enum Kind { RCT = 0, PALETTE = 1, SQUEEZE = 2 } kind = RCT;
 	int32_t begin_c = 0, rct_type = 0;
 	int32_t num_c = 0, nb_colours = 0, nb_deltas = 0, d_pred = 0;
+	// Squeeze, one step: channels [begin_c, begin_c + num_c) were halved along one axis; their residual channels sit behind
+	// them (in_place) or at the end of the channel list (ISO 18181-1 Squeeze; the reference stops at "TODO", j40.h:3812)
+	bool horizontal = false, in_place = false;
 };
+
 
 // int16 sample plane (the reference's Main-profile level 5 limits force 16-bit Modular buffers,
 // j40.h:1173, 3169)
@@ -59,6 +63,10 @@ void read_modular_header(BitReader &br, const std::vector<TreeNode> *global_tree
 void allocate_modular(Modular *m);
 void decode_modular_channel(BitReader &br, Modular &m, CodeState &code, int32_t cidx, int64_t sidx);
 void inverse_transforms(Modular &m);
+// channel list bookkeeping of one Squeeze step (forward direction, header time): sizes, shifts, residual channels inserted
+void apply_squeeze_meta(const Transform &tr, std::vector<Plane> *channel, int32_t *nb_meta);
+// the default Squeeze parameter list for a channel list (num_sq = 0 in the bitstream)
+void default_squeeze_steps(const std::vector<Plane> &channel, int32_t nb_meta, std::vector<Transform> *out);
 
 // convenience: header, every channel, finish, inverse transforms
 void decode_modular_image(BitReader &br, const std::vector<TreeNode> *global_tree, const CodeSpec *global_codespec, int64_t sidx, Modular *m);

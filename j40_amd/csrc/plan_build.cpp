@@ -37,6 +37,7 @@ void flatten_code_spec(const CodeSpec &spec, std::vector<uint8_t> &u8, std::vect
 }
 
 uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostPlan *hp) {
+	if (cs_size + 16 >= ((size_t) 1 << 29)) return ERR_TODO;   // the kernels address the codestream with 32-bit BIT positions
 	if (fr.fh.is_modular) return ERR_TODO;
 	// same limits as j40.h:7867, 7917-7921. (A VarDCT frame of an image without xyb_encoded passes them: the reference
 	// runs the XYB inverse with the default opsin matrix on it all the same, j40.h:7206-7233, and so does K2.)
@@ -257,6 +258,7 @@ static void attach_tables(const Frame &fr, HostModPlan *hp, int32_t &global_spec
 
 uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostModPlan *hp) {
 	if (!fr.fh.is_modular) return ERR_TODO;
+	if (cs_size + 16 >= ((size_t) 1 << 29)) return ERR_TODO;   // the kernels address the codestream with 32-bit BIT positions
 	const Modular &gm = fr.gmodular;
 	const int32_t nch = (int32_t) gm.channel.size();
 	if (nch > MOD_MAX_CHANNELS) return ERR_TODO;
@@ -278,12 +280,92 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 	int32_t max_width = 1;
 	for (const Plane &p : gm.channel) { hp->plane_w.push_back(p.width); hp->plane_h.push_back(p.height); hp->plane_meta.push_back(p.vshift < 0); }
 	auto wp_bytes = [](const WPParams &wp, int8_t *out) { out[0] = wp.p1; out[1] = wp.p2; for (int i = 0; i < 5; ++i) out[2 + i] = wp.p3[i]; for (int i = 0; i < 4; ++i) out[7 + i] = wp.w[i]; out[11] = 0; };
+	bool shifted = false;
+	for (const Transform &t : gm.transforms) shifted = shifted || t.kind == Transform::SQUEEZE;
+	if (shifted) {
+		// Squeeze leaves channels of different sizes and shifts: every section lists its channels as explicit rectangles, and
+		// the channels are dealt out to the sections by their shifts (ISO 18181-1; the reference stops before this point with
+		// "TODO", j40.h:3812, 6731-6737): LfGlobal codes the meta channels and the channels behind them that fit one group;
+		// an LfGroup section the channels shifted by 3 or more in both directions, over its 8-groups-wide area; a pass-group
+		// section the rest over its own area. A channel's rectangle is the area shifted down and clipped to the channel.
+		if (!fr.gm_data_pending || fr.fh.num_passes != 1) return ERR_TODO;
+		if (!gm.tree || gm.tree->empty() || !gm.codespec) return E4("mtre");
+		const int32_t gdim = 1 << fr.fh.group_size_shift;
+		auto add_rects = [&](DevModSection *s, const std::vector<int32_t> &chans, int32_t left, int32_t top, int32_t dim, bool whole, Modular *m) {
+			s->chan_off = (int32_t) hp->chan_rects.size(); s->num_channels = 0;
+			for (int32_t c : chans) {
+				const Plane &p = gm.channel[(size_t) c];
+				DevChanRect r; r.plane = c; r.shifts = (int32_t) (uint8_t) p.hshift | ((int32_t) (uint8_t) p.vshift << 8);
+				if (whole || p.vshift < 0) { r.x0 = r.y0 = 0; r.w = p.width; r.h = p.height; }
+				else {
+					r.x0 = left >> p.hshift; r.y0 = top >> p.vshift;
+					r.w = std::min(dim >> p.hshift, p.width - r.x0); r.h = std::min(dim >> p.vshift, p.height - r.y0);
+					if (r.w <= 0 || r.h <= 0) continue;
+				}
+				hp->chan_rects.push_back(r); ++s->num_channels;
+				max_width = std::max(max_width, r.w);
+				if (m) { Plane q; q.width = r.w; q.height = r.h; q.hshift = p.hshift; q.vshift = p.vshift; m->channel.push_back(q); }
+			}
+		};
+		{
+			DevModSection s;
+			memset(&s, 0, sizeof s);
+			s.sub_off = -1;
+			const Section &ls = fr.toc.single ? fr.toc.single_section : fr.toc.lf_global;
+			s.byte_off = (uint32_t) ls.offset; s.size = (uint32_t) ls.size; s.bit_off = (uint32_t) fr.gm_data_bitpos;
+			s.gw = fr.fh.width; s.gh = fr.fh.height; s.sidx = 0;
+			std::vector<int32_t> chans;
+			for (int32_t c = 0; c < fr.num_gm_channels; ++c) chans.push_back(c);
+			add_rects(&s, chans, 0, 0, 0, true, nullptr);
+			wp_bytes(gm.wp, s.wp);
+			attach(gm, &s);
+			hp->sections.push_back(s);
+		}
+		// one section of a group-like area: its own Modular header first (no transforms of its own are taken here)
+		auto add_section = [&](const Section &ps, const std::vector<int32_t> &chans, int32_t left, int32_t top, int32_t dim, int64_t sidx) -> uint32_t {
+			DevModSection s;
+			memset(&s, 0, sizeof s);
+			s.sub_off = -1;
+			Modular m; m.bpp = fr.im.bpp;
+			add_rects(&s, chans, left, top, dim, false, &m);
+			if (s.num_channels == 0) return 0;   // nothing is coded for this area
+			s.byte_off = (uint32_t) ps.offset; s.size = (uint32_t) ps.size; s.gx = left; s.gy = top; s.gw = s.gh = dim; s.sidx = (int32_t) sidx;
+			BitReader br(cs + ps.offset, ps.size);
+			try { read_modular_header(br, &fr.global_tree, &fr.global_codespec, &m); }
+			catch (const DecodeError &e) { s.preset_status = e.code; s.num_channels = 0; hp->sections.push_back(s); return 0; }
+			if (!m.transforms.empty()) return ERR_TODO;
+			s.bit_off = (uint32_t) br.bit_position();
+			wp_bytes(m.wp, s.wp);
+			attach(m, &s);
+			hp->sections.push_back(s);
+			return 0;
+		};
+		if (!fr.toc.single && fr.num_gm_channels < nch) {
+			std::vector<int32_t> lf_chans, hf_chans;
+			for (int32_t c = fr.num_gm_channels; c < nch; ++c) {
+				const Plane &p = gm.channel[(size_t) c];
+				if (p.hshift < 0 || p.vshift < 0) return ERR_TODO;   // a meta channel behind an image channel
+				(p.hshift >= 3 && p.vshift >= 3 ? lf_chans : hf_chans).push_back(c);
+			}
+			for (int64_t gg = 0; gg < fr.fh.num_lf_groups; ++gg) {
+				const LfGroup &g = fr.lf_groups[(size_t) gg];
+				if (uint32_t e = add_section(fr.toc.lf_groups[(size_t) gg], lf_chans, g.left, g.top, gdim * 8, 1 + fr.fh.num_lf_groups + gg)) return e;
+			}
+			const int32_t num_groups = (int32_t) fr.fh.num_groups;
+			hp->num_passes = 1; hp->sections_per_pass = 0;   // (one launch decodes every section)
+			for (int32_t g = 0; g < num_groups; ++g) {
+				const GroupInfo gi = group_info(fr.fh, g);
+				const LfGroup &gg = fr.lf_groups[(size_t) gi.ggidx];
+				if (uint32_t e = add_section(fr.toc.pass_groups[(size_t) g], hf_chans, gg.left + gi.gx_in_gg, gg.top + gi.gy_in_gg, gdim, 1 + 3 * fr.fh.num_lf_groups + 17 + g)) return e;
+			}
+		}
+	} else
 	// LfGlobal's own channel data: every channel for single-group frames, only meta channels otherwise
 	if (fr.gm_data_pending) {
 		// (with zero channels this still validates the stream's final rANS state and the section end)
 		DevModSection s;
 		memset(&s, 0, sizeof s);
-		s.sub_off = -1;
+		s.sub_off = -1; s.chan_off = -1;
 		const Section &ls = fr.toc.single ? fr.toc.single_section : fr.toc.lf_global;
 		s.byte_off = (uint32_t) ls.offset; s.size = (uint32_t) ls.size; s.bit_off = (uint32_t) fr.gm_data_bitpos;
 		s.gx = s.gy = 0; s.gw = fr.fh.width; s.gh = fr.fh.height; s.sidx = 0;
@@ -294,7 +376,7 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 		hp->sections.push_back(s);
 		for (int32_t c = 0; c < fr.num_gm_channels; ++c) max_width = std::max(max_width, hp->plane_meta[(size_t) c] ? hp->plane_w[(size_t) c] : fr.fh.width);
 	} else return ERR_TODO;
-	if (!fr.toc.single && fr.num_gm_channels < nch) {
+	if (!shifted && !fr.toc.single && fr.num_gm_channels < nch) {
 		const int32_t num_groups = (int32_t) fr.fh.num_groups;
 		// every pass codes all channels of every group again (the reference's j40__pass_group ignores the passes' shift
 		// ranges, j40.h:7025, 3702): decoded in order, the last pass stays
@@ -309,7 +391,7 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 			BitReader br(cs + ps.offset, ps.size);
 			DevModSection s;
 			memset(&s, 0, sizeof s);
-			s.sub_off = -1;
+			s.sub_off = -1; s.chan_off = -1;
 			try { read_modular_header(br, &fr.global_tree, &fr.global_codespec, &m); }
 			catch (const DecodeError &e) {   // reported in its place among the sections (an earlier section's data may fail first)
 				s.byte_off = (uint32_t) ps.offset; s.size = (uint32_t) ps.size; s.preset_status = e.code;
@@ -362,6 +444,7 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 		size_t most = 0;
 		for (const DevModSection &s : hp->sections) {
 			size_t n = (size_t) s.num_channels * (size_t) s.gw * (size_t) s.gh;
+			if (s.chan_off >= 0) { n = 0; for (int32_t c = 0; c < s.num_channels; ++c) n += (size_t) hp->chan_rects[(size_t) (s.chan_off + c)].w * (size_t) hp->chan_rects[(size_t) (s.chan_off + c)].h; }
 			if (s.sub_off >= 0) { n = 0; for (int32_t c = 0; c < s.num_channels; ++c) n += (size_t) hp->sub_w[(size_t) (s.sub_off + c)] * (size_t) hp->sub_h[(size_t) (s.sub_off + c)]; }
 			most = std::max(most, n);
 		}
@@ -382,6 +465,7 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 uint32_t build_trailer_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, const uint32_t *end_bits, const uint32_t *k1_status, HostModPlan *hp,
 		std::vector<std::pair<int32_t, uint32_t>> *trailer_errors, std::vector<int32_t> *section_of) {
 	const Modular &gm = fr.gmodular;
+	if (cs_size + 16 >= ((size_t) 1 << 29)) return ERR_TODO;   // the kernels address the codestream with 32-bit BIT positions
 	const int32_t nch = (int32_t) gm.channel.size();
 	if (nch <= fr.num_gm_channels || nch > MOD_MAX_CHANNELS) return ERR_TODO;
 	DevModFrame &df = hp->frame;
@@ -405,6 +489,7 @@ uint32_t build_trailer_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 		catch (const DecodeError &e) { trailer_errors->push_back({idx, e.code}); continue; }
 		DevModSection s;
 		memset(&s, 0, sizeof s);
+		s.chan_off = -1;
 		s.byte_off = (uint32_t) ps.offset; s.size = (uint32_t) ps.size; s.bit_off = (uint32_t) br.bit_position();
 		s.gx = s.gy = 0; s.gw = gi.gw; s.gh = gi.gh;
 		s.sidx = (int32_t) (1 + 3 * fr.fh.num_lf_groups + 17 + idx);

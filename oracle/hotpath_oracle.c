@@ -14,7 +14,8 @@
  * (oracle/_ref/libj40ref.so, compiled from /root/reference by oracle/Makefile) on the whole stream
  * matrix and against the committed golden fixtures (tests/golden/manifest.json): bit-exact RGBA for
  * Modular and -- built, like the reference, without FMA contraction and with the same libm -- for
- * VarDCT as well. Squeeze is not implemented by the reference (j40.h:3812, 4518) and is not restated.
+ * VarDCT as well. Squeeze is not implemented by the reference (j40.h:3812, 4518): the inverse step here restates ISO 18181-1
+ * instead -- PARITY UNPINNED for that one transform (no libjxl in this image); tests pin it by lossless round trips.
  *
  * Build: gcc -O2 -ffp-contract=off (see oracle/Makefile); no -march=native (j40.h:5834).
  */
@@ -127,9 +128,17 @@ static int32_t hybrid(obits *b, int32_t token, int split_exp, int msb, int lsb) 
 
 /* canonical prefix code decoded one bit at a time from the code lengths (RFC 7932 section 3.2) */
 static int32_t prefix_symbol(obits *b, const j40hip_cluster_view *cl) {
-	int32_t count[16] = {0}, first_code = 0, first_index = 0, code = 0, len, s, only = -1;
-	for (s = 0; s < cl->alphabet_size; ++s) { if (cl->lengths[s] == 255) only = s; else ++count[cl->lengths[s]]; }
+	int32_t count[16] = {0}, first_code = 0, first_index = 0, code = 0, len, s, only = -1, marked = 0;
+	for (s = 0; s < cl->alphabet_size; ++s) { if (cl->lengths[s] == 255) only = s; else if (cl->lengths[s] == (2 | 128)) ++marked; else ++count[cl->lengths[s]]; }
 	if (only >= 0) return only;
+	if (marked == 4) {
+		/* simple code, NSYM = 4, tree-select 0: the reference's table holds the sorted symbols at the index made of the two bits in
+		 * read order (template {2,2,2,2} with symref {0,1,2,3}, j40.h:2090, 2112) -- not RFC 7932's canonical assignment */
+		int32_t k = (int32_t) obits_u(b, 1);
+		k |= (int32_t) obits_u(b, 1) << 1;
+		if (b->err) return 0;
+		for (s = 0; s < cl->alphabet_size; ++s) if (cl->lengths[s] == (2 | 128) && k-- == 0) return s;
+	}
 	if (cl->alphabet_size <= 1) return 0;
 	count[0] = 0;
 	for (len = 1; len <= 15; ++len) {
@@ -606,6 +615,21 @@ static int32_t predict(int pred, const owp *wp, const oneigh *p, uint32_t *err) 
 
 static void set_wp(owp *wp, const int8_t *params) { int i; wp->p1 = params[0]; wp->p2 = params[1]; for (i = 0; i < 5; ++i) wp->p3[i] = params[2 + i]; for (i = 0; i < 4; ++i) wp->w[i] = params[7 + i]; }
 
+/* where channel `cidx` of a section lives: its plane and the rectangle of it the section codes. Frames whose channels differ in
+ * size (after a Squeeze) list explicit rectangles; otherwise the section's rectangle (the whole plane for meta channels) */
+typedef struct { oplane *pl; int32_t gx, gy, gw, gh, shifts; } ochan;
+static ochan section_channel(const j40hip_modular_view *v, const j40hip_modular_section_view *sec, oplane *planes, int32_t cidx) {
+	ochan c;
+	if (sec->chan_off >= 0) {
+		const int32_t *r = v->chan_rects + 6 * (sec->chan_off + cidx);
+		c.pl = &planes[r[0]]; c.gx = r[1]; c.gy = r[2]; c.gw = r[3]; c.gh = r[4]; c.shifts = r[5];
+		return c;
+	}
+	c.pl = &planes[sec->first_channel + cidx]; c.shifts = 0;
+	c.gx = c.pl->meta ? 0 : sec->gx; c.gy = c.pl->meta ? 0 : sec->gy; c.gw = c.pl->meta ? c.pl->w : sec->gw; c.gh = c.pl->meta ? c.pl->h : sec->gh;
+	return c;
+}
+
 /* one section: the listed channels of the global image, restricted to the section's rectangle
  * (whole plane for meta channels) -- j40__modular_channel16, j40.h:4127 */
 static uint32_t modular_section(const j40hip_modular_view *v, const j40hip_modular_section_view *sec, oplane *planes, ocode *code) {
@@ -618,13 +642,17 @@ static uint32_t modular_section(const j40hip_modular_view *v, const j40hip_modul
 	for (ti = 0; ti < sec->tree_nodes; ++ti) if (tree[ti].prop == 15 || tree[ti].prop == -1 - 6) uses_wp = 1;
 	obits_init(&b, v->codestream, sec->byte_off, sec->size, sec->bit_off);
 	ocode_restart(code);
-	for (cidx = 0; cidx < sec->num_channels; ++cidx) if (!planes[sec->first_channel + cidx].meta) dist_mult = imax32(dist_mult, sec->gw);
+	for (cidx = 0; cidx < sec->num_channels; ++cidx) {
+		ochan oc = section_channel(v, sec, planes, cidx);
+		if (!oc.pl->meta) dist_mult = imax32(dist_mult, oc.gw);
+	}
 	dist_mult = imin32(dist_mult, 1 << 21);
 	memset(&wp, 0, sizeof wp);
 	set_wp(&wp, sec->wp);
 	for (cidx = 0; cidx < sec->num_channels && !b.err && !err; ++cidx) {
-		oplane *pl = &planes[sec->first_channel + cidx];
-		int32_t gx = pl->meta ? 0 : sec->gx, gy = pl->meta ? 0 : sec->gy, gw = pl->meta ? pl->w : sec->gw, gh = pl->meta ? pl->h : sec->gh, x, y;
+		ochan oc = section_channel(v, sec, planes, cidx);
+		oplane *pl = oc.pl;
+		int32_t gx = oc.gx, gy = oc.gy, gw = oc.gw, gh = oc.gh, x, y;
 		if (gw <= 0 || gh <= 0) continue;
 		wp.on = uses_wp; wp.width = gw;
 		wp.errors = uses_wp ? (int32_t (*)[5]) calloc((size_t) gw * 2, sizeof(int32_t[5])) : NULL;
@@ -650,16 +678,17 @@ static uint32_t modular_section(const j40hip_modular_view *v, const j40hip_modul
 						if (iabs32(val) < iabs32(wp.trueerrne)) val = wp.trueerrne;
 						break;
 					default: {
-						int32_t r = (n->prop - 16) / 4;
+						int32_t r = (n->prop - 16) / 4, rgx = 0, rgy = 0;
 						const oplane *rc = NULL;
 						const int16_t *rrow;
 						for (k = cidx - 1; k >= 0; --k) {  /* earlier channels of equal geometry, nearest first */
-							const oplane *cand = &planes[sec->first_channel + k];
-							if (cand->meta != pl->meta || (pl->meta && (cand->w != gw || cand->h != gh))) continue;
-							if (r-- == 0) { rc = cand; break; }
+							ochan oc2 = section_channel(v, sec, planes, k);
+							const oplane *cand = oc2.pl;
+							if (cand->meta != pl->meta || oc2.gw != gw || oc2.gh != gh || oc2.shifts != oc.shifts) continue;
+							if (r-- == 0) { rc = cand; rgx = oc2.gx; rgy = oc2.gy; break; }
 						}
 						if (!rc) { err = E4('t', 'r', 'e', 'c'); val = 0; break; }
-						rrow = rc->px + (size_t) (gy + y) * (size_t) rc->w + (size_t) gx;
+						rrow = rc->px + (size_t) (rgy + y) * (size_t) rc->w + (size_t) rgx;
 						val = rrow[x];
 						if (n->prop & 2) {
 							int32_t rw = x > 0 ? rrow[x - 1] : 0, rn = y > 0 ? rrow[x - rc->w] : rw, rnw = x > 0 && y > 0 ? rrow[x - 1 - rc->w] : rw;
@@ -765,6 +794,47 @@ static uint32_t undo_transforms(oplane *planes, int32_t *np, const j40hip_transf
 			free(wp.errors);
 			free(planes[0].px);
 			memmove(planes, planes + 1, sizeof(oplane) * (size_t) --(*np));
+		} else if (tr->kind == 2) {
+			/* one inverse Squeeze step (ISO 18181-1; the reference stops at "TODO", j40.h:4518): every squeezed channel is joined with
+			 * its residual channel along rows (horizontal) or columns, then the residual channels leave the list.
+			 * out[2k] = A, out[2k + 1] = A - diff, diff = residual[k] + tendency(out[2k - 1], avg[k], avg[k + 1]), A = avg[k] + diff / 2 */
+			int32_t end_c = tr->begin_c + tr->num_c, offset = tr->in_place ? end_c : *np - tr->num_c, c;
+			for (c = tr->begin_c; c < end_c; ++c) {
+				oplane *avg = &planes[c], *res = &planes[offset + c - tr->begin_c], out;
+				int32_t line, nlines, n_avg, n_res, kk;
+				out.meta = avg->meta;
+				out.w = tr->horizontal ? avg->w + res->w : avg->w; out.h = tr->horizontal ? avg->h : avg->h + res->h;
+				out.px = (int16_t *) calloc((size_t) imax32(out.w, 0) * (size_t) imax32(out.h, 0) + 1, sizeof(int16_t));
+				nlines = tr->horizontal ? out.h : out.w; n_avg = tr->horizontal ? avg->w : avg->h; n_res = tr->horizontal ? res->w : res->h;
+				for (line = 0; line < nlines; ++line) {
+					/* element (line, k) of a plane: row `line`, column k for the horizontal step; row k, column `line` for the vertical one */
+					#define SQ_AT(pl, k) ((pl)->px[tr->horizontal ? (size_t) line * (size_t) (pl)->w + (size_t) (k) : (size_t) (k) * (size_t) (pl)->w + (size_t) line])
+					int32_t left = 0;
+					for (kk = 0; kk < n_res; ++kk) {
+						int32_t a = SQ_AT(avg, kk), next = kk + 1 < n_avg ? SQ_AT(avg, kk + 1) : a, B = kk > 0 ? left : a, diff = 0, A;
+						if (B >= a && a >= next) {
+							diff = (4 * B - 3 * next - a + 6) / 12;
+							if (diff - (diff & 1) > 2 * (B - a)) diff = 2 * (B - a) + 1;
+							if (diff + (diff & 1) > 2 * (a - next)) diff = 2 * (a - next);
+						} else if (B <= a && a <= next) {
+							diff = (4 * B - 3 * next - a - 6) / 12;
+							if (diff + (diff & 1) < 2 * (B - a)) diff = 2 * (B - a) - 1;
+							if (diff - (diff & 1) < 2 * (a - next)) diff = 2 * (a - next);
+						}
+						diff += SQ_AT(res, kk);
+						A = a + diff / 2;
+						SQ_AT(&out, 2 * kk) = (int16_t) A; SQ_AT(&out, 2 * kk + 1) = (int16_t) (A - diff);
+						left = (int16_t) (A - diff);
+					}
+					if (n_avg > n_res) SQ_AT(&out, 2 * n_res) = SQ_AT(avg, n_res);
+					#undef SQ_AT
+				}
+				free(avg->px);
+				*avg = out;
+			}
+			for (c = 0; c < tr->num_c; ++c) free(planes[offset + c].px);
+			memmove(planes + offset, planes + offset + tr->num_c, sizeof(oplane) * (size_t) (*np - offset - tr->num_c));
+			*np -= tr->num_c;
 		} else err = E4('T', 'O', 'D', 'O');
 	}
 	return err;
@@ -773,7 +843,7 @@ static uint32_t undo_transforms(oplane *planes, int32_t *np, const j40hip_transf
 /* Decodes a Modular frame described by `v` into tightly packed RGBA; returns 0 or the first error */
 ORACLE_API uint32_t oracle_decode_modular(const j40hip_modular_view *v, uint8_t *rgba) {
 	static const uint8_t PERM[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
-	oplane planes[64];
+	oplane planes[320];
 	int32_t nplanes = v->num_channels, c, s, t, i;
 	ocode *codes;
 	uint32_t err = 0;

@@ -12,6 +12,7 @@
 #include "../../j40_amd/csrc/device/hf_lanes_dev.h"
 #include "../../j40_amd/csrc/device/vardct_dev.h"
 #include "../../j40_amd/csrc/device/modular_dev.h"
+#include "../../j40_amd/csrc/device/squeeze_dev.h"
 
 using namespace j40hip;
 
@@ -82,11 +83,13 @@ static uint32_t hostsim_decode_modular(const Frame &fr, const uint8_t *cs, size_
 	plan.clusters = hp.clusters.data(); plan.spec = hp.specs.data(); plan.tree = hp.tree.data(); plan.sections = hp.sections.data();
 	struct Ref { int16_t *p; int32_t w, h; };
 	std::vector<Ref> planes;
+	std::vector<DevPlaneRef> refs((size_t) nch);
 	for (int32_t c = 0; c < nch; ++c) {
 		store[(size_t) c].assign((size_t) std::max(hp.plane_w[(size_t) c], 0) * (size_t) std::max(hp.plane_h[(size_t) c], 0) + 1, 0);
-		plan.planes[c] = store[(size_t) c].data(); plan.plane_w[c] = hp.plane_w[(size_t) c]; plan.plane_h[c] = hp.plane_h[(size_t) c]; plan.plane_meta[c] = hp.plane_meta[(size_t) c];
-		planes.push_back({plan.planes[c], plan.plane_w[c], plan.plane_h[c]});
+		refs[(size_t) c] = DevPlaneRef{store[(size_t) c].data(), hp.plane_w[(size_t) c], hp.plane_h[(size_t) c], hp.plane_meta[(size_t) c], 0};
+		planes.push_back({refs[(size_t) c].ptr, refs[(size_t) c].w, refs[(size_t) c].h});
 	}
+	plan.planes = refs.data(); plan.chan_rects = hp.chan_rects.data();
 	std::vector<std::vector<int16_t>> sub_store(hp.sub_w.size());
 	std::vector<DevSubPlane> subp(hp.sub_w.size());
 	for (size_t k = 0; k < hp.sub_w.size(); ++k) { sub_store[k].assign((size_t) hp.sub_w[k] * (size_t) hp.sub_h[k] + 1, 0); subp[k] = DevSubPlane{sub_store[k].data(), hp.sub_w[k], hp.sub_h[k], hp.sub_meta[k], 0}; }
@@ -112,7 +115,7 @@ static uint32_t hostsim_decode_modular(const Frame &fr, const uint8_t *cs, size_
 	for (int32_t sct = 0; sct < hp.frame.num_sections; ++sct) for (int32_t lane = 0; lane < 3; ++lane) section_inverse_rcts(plan, sct, lane, 3);
 	static const uint8_t PERM[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
 	std::vector<std::vector<int16_t>> extra;
-	extra.reserve(64);
+	extra.reserve(1024);
 	// undoes `trs` last to first on the image `planes` (the frame, or the sub-image of a section with a palette of its own)
 	auto undo = [&](std::vector<Ref> &planes, const std::vector<Transform> &trs, const int8_t *wpb) -> uint32_t {
 	for (size_t ti = trs.size(); ti-- > 0; ) {
@@ -122,6 +125,19 @@ static uint32_t hostsim_decode_modular(const Frame &fr, const uint8_t *cs, size_
 			const size_t n = (size_t) c[0].w * (size_t) c[0].h;
 			for (size_t i = 0; i < n; ++i) inverse_rct_pixel(t.rct_type % 7, c[0].p[i], c[1].p[i], c[2].p[i]);
 			for (int i = 0; i < 3; ++i) planes[(size_t) (t.begin_c + PERM[t.rct_type / 7][i])] = c[i];
+		} else if (t.kind == Transform::SQUEEZE) {   // as the runtime schedules it: a new plane per squeezed channel (device/runtime.hip)
+			const int32_t nc = (int32_t) planes.size(), end_c = t.begin_c + t.num_c, offset = t.in_place ? end_c : nc - t.num_c;
+			for (int32_t c = t.begin_c; c < end_c; ++c) {
+				const Ref avg = planes[(size_t) c], res = planes[(size_t) (offset + c - t.begin_c)];
+				Ref out = {nullptr, t.horizontal ? avg.w + res.w : avg.w, t.horizontal ? avg.h : avg.h + res.h};
+				extra.emplace_back((size_t) std::max(out.w, 0) * (size_t) std::max(out.h, 0) + 1, 0); out.p = extra.back().data();
+				if (t.horizontal) for (int32_t y = 0; y < out.h; ++y)
+					unsqueeze_line(avg.p + (size_t) y * (size_t) avg.w, 1, res.w > 0 ? res.p + (size_t) y * (size_t) res.w : avg.p, 1, avg.w, res.w, out.p + (size_t) y * (size_t) out.w, 1);
+				else for (int32_t x = 0; x < out.w; ++x)
+					unsqueeze_line(avg.p + x, avg.w, res.h > 0 ? res.p + x : avg.p, res.w, avg.h, res.h, out.p + x, out.w);
+				planes[(size_t) c] = out;
+			}
+			planes.erase(planes.begin() + offset, planes.begin() + offset + t.num_c);
 		} else {
 			const int32_t first = t.begin_c + 1;
 			const Ref idx = planes[(size_t) first], pal = planes[0];

@@ -49,7 +49,7 @@ def test_product_fails_loudly_without_gpu(built):
     px, stride, _ = img.frame_pixels_u8x4()
     assert px.shape == (7, 21, 4) and stride == 84  # the reference's "ERR" placeholder (j40.h:8432)
     img.free()
-    assert img.error() == "" or True
+    assert img.error() == "Ufre"   # j40.h:8475-8476: a freed image answers every call with "Ufre"
 
 
 def test_api_misuse_codes(built):

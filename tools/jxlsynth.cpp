@@ -770,8 +770,17 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	const int num_passes = opt.geti("passes", 1);
 	const int repeat = opt.geti("repeat", 1);
 	if (repeat > 1 && num_passes > 1) die("repeat and passes do not combine");
+	// squeeze=1: a Squeeze transform with the default parameter list behind the RCT (the "progressive" lossless form); 2: the same list
+	// written out explicitly; 3: a short explicit list with residual channels appended (not in place) and partial channel ranges.
+	// Squeeze couples neighbouring groups, so with repeat=K the base picture is tiled first and the whole frame is transformed;
+	// group sections with identical content (most of them, the picture being periodic) are encoded once and shared.
+	const int squeeze = opt.geti("squeeze", 0);
+	if (squeeze && (num_passes > 1 || opt.geti("palette", 0) || opt.geti("localrct", -1) >= 0 || opt.geti("localpalette", 0) || opt.geti("localtree", 0))) die("squeeze combines with rct / tree / prefix / lz77 / alpha / extra / bpp / repeat only");
 	const int Wfull = W, Hfull = H;
-	if (repeat > 1) {
+	const int tile_w = W / repeat, tile_h = H / repeat;   // the picture that is synthesised
+	if (repeat > 1 && squeeze) {
+		if (W % repeat || H % repeat) die("repeat: the frame must be whole tiles");
+	} else if (repeat > 1) {
 		if (W % (repeat * gdim) || H % (repeat * gdim)) die("repeat: the base picture must be whole groups");
 		W /= repeat; H /= repeat;
 		if (W == gdim && H == gdim) die("repeat: the base picture must have more than one group");
@@ -786,11 +795,12 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 
 	// ---- source picture -> channels: colour first, then extra channels (the renderer takes channels
 	//      0..2 as RGB and 3.. as extra channels, j40.h:7923-7936) ----
-	Picture pic(W, H, seed);
+	const int pic_w = squeeze ? tile_w : W, pic_h = squeeze ? tile_h : H;
+	Picture pic(pic_w, pic_h, seed);
 	std::vector<Channel> ch;
-	for (int c = 0; c < nch; ++c) ch.emplace_back(W, H);
+	for (int c = 0; c < nch; ++c) ch.emplace_back(pic_w, pic_h);
 	const int colour0 = 0;               // index of the first colour channel
-	for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+	for (int y = 0; y < pic_h; ++y) for (int x = 0; x < pic_w; ++x) {
 		float rgb[3]; pic.rgb((float) x, (float) y, rgb);
 		// flat regions + a bit of texture so that run-lengths and the predictors both get work
 		for (int c = 0; c < 3; ++c) {
@@ -801,6 +811,22 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 		for (int k = 0; k < extra; ++k) ch[(size_t) (3 + k)].at(x, y) = (((x >> 3) * (k + 2) + (y >> 2)) & 31) * ((1 << bpp) - 1) / 31;
 		if (alpha) ch[(size_t) (3 + extra)].at(x, y) = ((x / 37 + y / 29) & 3) == 0 ? 128 + ((x * 3 + y) & 63) : 255;
 	}
+
+	if (squeeze && repeat > 1) {   // lay the tile out over the whole frame
+		for (Channel &c : ch) {
+			Channel full(W, H);
+			for (int y = 0; y < H; ++y) for (int x0 = 0; x0 < W; x0 += tile_w) memcpy(&full.at(x0, y), &c.at(0, y % tile_h), sizeof(int32_t) * (size_t) tile_w);
+			c = std::move(full);
+		}
+	}
+
+	// fourvalues=1: samples take four values only; with the zero predictor (tree=4) and no RCT every residual token is one of four
+	// symbols, which makes prefix-coded streams use the NSYM = 4 simple code (simple4=1|2 chooses its tree-select-0 form)
+	if (opt.geti("fourvalues", 0)) for (Channel &c : ch) for (int y = 0; y < c.h; ++y) for (int x = 0; x < c.w; ++x) {
+		const float r = Picture::hash01((uint64_t) x * 7919 + (uint64_t) y * 104729 + seed);
+		c.at(x, y) = r < 0.55f ? 0 : r < 0.8f ? 1 : r < 0.93f ? 2 : 3;
+	}
+	simple4_mode() = opt.geti("simple4", 0);
 
 	// ---- global transforms (coded order = forward order; the decoder undoes them last to first) ----
 	std::vector<TransformW> transforms;
@@ -829,6 +855,21 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 		transforms.push_back(t);
 	}
 	const int nb_meta = palette ? 1 : 0;
+	if (squeeze) {
+		TransformW t; t.kind = 2;
+		std::vector<SqueezeStep> steps = default_squeeze_steps(ch, nb_meta);
+		if (squeeze == 3) {
+			steps.clear();
+			SqueezeStep a; a.horizontal = true; a.in_place = true; a.begin_c = 0; a.num_c = 3; steps.push_back(a);
+			a.horizontal = false; steps.push_back(a);
+			a.horizontal = true; a.in_place = false; a.begin_c = 1; a.num_c = 2; steps.push_back(a);
+			a.horizontal = false; a.in_place = true; a.begin_c = 0; a.num_c = 1; steps.push_back(a);
+			a.horizontal = false; a.in_place = false; a.begin_c = 0; a.num_c = (int) ch.size() >= 4 ? 4 : 3; steps.push_back(a);   // (with alpha: reaches into the residuals / the alpha channel)
+		}
+		if (squeeze >= 2) t.sq = steps;
+		for (const SqueezeStep &st : steps) forward_squeeze_step(ch, st);
+		transforms.push_back(t);
+	}
 	const int total_ch = (int) ch.size();
 
 	// ---- MA tree ----
@@ -836,6 +877,7 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	{
 		int root;
 		if (tree_kind == 0) root = tree.leaf(5);
+		else if (tree_kind == 4) root = tree.leaf(0);   // the zero predictor: residual = sample
 		else if (tree_kind == 1) {
 			int l0 = tree.leaf(5), l1 = tree.leaf(4), l2 = tree.leaf(13), l3 = tree.leaf(1), l4 = tree.leaf(2, 0, 0, 0), l5 = tree.leaf(12), l6 = tree.leaf(7), l7 = tree.leaf(3);
 			int a = tree.branch(9, 100, l0, l1);      // W + N - NW
@@ -931,9 +973,46 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	const int local_rct = opt.geti("localrct", -1);
 	const int local_palette = opt.geti("localpalette", 0);
 	std::vector<uint8_t> section_is_group;
+	// squeeze, frames larger than a group: which encoder (index into encs) holds each LfGroup / pass-group section; -1 = nothing coded there
+	std::vector<int> sq_lf_enc, sq_group_enc;
 	if (single) {
 		encs.emplace_back(gspec);
 		encode_image(ch, 0, 0, encs.back());
+	} else if (squeeze) {
+		// The decoder deals the channels out by size and shift (ISO 18181-1): LfGlobal takes the meta channels and the channels behind
+		// them that fit one group; an LfGroup section the channels shifted by >= 3 both ways, over its 8-groups-wide area; a pass-group
+		// section the others over its own area. A channel's rectangle is the area shifted down, clipped to the channel.
+		int num_gm = nb_meta;
+		while (num_gm < total_ch && ch[(size_t) num_gm].w <= gdim && ch[(size_t) num_gm].h <= gdim) ++num_gm;
+		encs.emplace_back(gspec);
+		{ std::vector<Channel> head(ch.begin(), ch.begin() + num_gm); if (num_gm) encode_image(head, 0, 0, encs.back()); }
+		std::map<uint64_t, int> seen;   // content hash of a section's channels -> its encoder
+		auto cut = [&](bool lf, int left, int top, int dim, int64_t sidx) -> int {
+			std::vector<Channel> sub;
+			uint64_t hsh = 1469598103934665603ull;
+			auto mix = [&](uint64_t v) { hsh = (hsh ^ v) * 1099511628211ull; };
+			for (int c = num_gm; c < total_ch; ++c) {
+				const Channel &full = ch[(size_t) c];
+				if ((full.hshift >= 3 && full.vshift >= 3) != lf) continue;
+				const int x0 = left >> full.hshift, y0 = top >> full.vshift, w = std::min(dim >> full.hshift, full.w - x0), h = std::min(dim >> full.vshift, full.h - y0);
+				if (w <= 0 || h <= 0) continue;
+				Channel s2(w, h); s2.hshift = full.hshift; s2.vshift = full.vshift;
+				for (int y = 0; y < h; ++y) memcpy(&s2.at(0, y), full.px.data() + (size_t) (y0 + y) * (size_t) full.w + (size_t) x0, sizeof(int32_t) * (size_t) w);
+				mix((uint64_t) w << 32 | (uint32_t) h); mix((uint64_t) full.hshift << 8 | (uint64_t) full.vshift);
+				for (int32_t v : s2.px) mix((uint32_t) v);
+				sub.push_back(std::move(s2));
+			}
+			if (sub.empty()) return -1;
+			auto it = seen.find(hsh);
+			if (it != seen.end()) return it->second;
+			encs.emplace_back(gspec);
+			encode_image(sub, 0, sidx, encs.back());
+			seen[hsh] = (int) encs.size() - 1;
+			return (int) encs.size() - 1;
+		};
+		const int lfdim = gdim * 8, lfcols = (W + lfdim - 1) / lfdim;
+		for (int gg = 0; gg < num_lf_groups; ++gg) sq_lf_enc.push_back(cut(true, (gg % lfcols) * lfdim, (gg / lfcols) * lfdim, lfdim, 1 + num_lf_groups + gg));
+		for (int g = 0; g < num_groups; ++g) sq_group_enc.push_back(cut(false, (g % gcols) * gdim, (g / gcols) * gdim, gdim, 1 + 3 * num_lf_groups + 17 + g));
 	} else {
 		// meta channels (palette) are decoded inside LfGlobal (num_gm_channels = nb_meta_channels, j40.h:6332)
 		encs.emplace_back(gspec);
@@ -1005,7 +1084,23 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	}
 	const int gcols_full = (Wfull + gdim - 1) / gdim, grows_full = (Hfull + gdim - 1) / gdim;
 	const int num_lf_groups_full = ((Wfull + 8 * gdim - 1) / (8 * gdim)) * ((Hfull + 8 * gdim - 1) / (8 * gdim));
-	if (!single) {
+	if (!single && squeeze) {
+		std::vector<std::vector<uint8_t>> done(encs.size());   // a shared encoder is serialised once
+		auto section_of = [&](int e) -> std::vector<uint8_t> {
+			if (e < 0) return {};
+			if (done[(size_t) e].empty()) {
+				BitWriter bw;
+				write_modular_header(bw, true, nullptr, {});
+				encs[(size_t) e].flush(bw);
+				bw.pad();
+				done[(size_t) e] = bw.bytes;
+			}
+			return done[(size_t) e];
+		};
+		for (int e : sq_lf_enc) sections.push_back(section_of(e));
+		sections.push_back({});       // HfGlobal: empty in Modular frames
+		for (int e : sq_group_enc) sections.push_back(section_of(e));
+	} else if (!single) {
 		for (int i = 0; i < num_lf_groups_full; ++i) sections.push_back({});
 		sections.push_back({});       // HfGlobal must be empty for Modular frames (j40.h:7825)
 		for (int g = 0; g < num_passes * num_groups; ++g) {

@@ -202,6 +202,7 @@ inline std::vector<int> huffman_lengths(const std::vector<uint64_t> &freq, int m
 // writes one prefix code tree for an alphabet of `count` symbols (count > 1) given per-symbol
 // lengths; chooses the simple form for <= 4 used symbols (avoiding the NSYM=4/tree-select-0
 // template the reference mis-orders) and the complex form otherwise
+inline int &simple4_mode() { static int mode = 0; return mode; }   // generator option simple4=0|1|2, see write_prefix_tree
 inline void write_prefix_tree(BitWriter &bw, PrefixCode &pc) {
 	const int count = pc.alphabet;
 	std::vector<int> used; for (int s = 0; s < count; ++s) if (pc.len[s]) used.push_back(s);
@@ -221,6 +222,18 @@ inline void write_prefix_tree(BitWriter &bw, PrefixCode &pc) {
 		if (nsym == 3) {  // lengths 1,2,2; the two length-2 symbols are sorted by the reader
 			for (int s : used) bw.put((uint64_t) s, symbits);
 			pc.len.assign((size_t) count, 0); pc.len[used[0]] = 1; pc.len[used[1]] = pc.len[used[2]] = 2; pc.assign_codes(); return;
+		}
+		if (simple4_mode()) {
+			// nsym == 4 with tree-select 0: four 2-bit codes over the sorted symbols. The reference decodes this template with symbol
+			// k of the sorted four at the index made of the two bits in READ order (j40.h:2090, 2112), i.e. MSB-first code
+			// (k & 1) << 1 | k >> 1 -- sorted symbols 1 and 2 swapped against RFC 7932's canonical code. Mode 1 writes what the
+			// reference reads, mode 2 what an RFC 7932 encoder writes (tests/test_host.py documents the difference).
+			std::sort(used.begin(), used.end());
+			for (int s : used) bw.put((uint64_t) s, symbits);
+			bw.put(0, 1);
+			pc.len.assign((size_t) count, 0); pc.code.assign((size_t) count, 0);
+			for (int k = 0; k < 4; ++k) { pc.len[used[(size_t) k]] = 2; pc.code[used[(size_t) k]] = simple4_mode() == 1 ? (uint32_t) (((k & 1) << 1) | (k >> 1)) : (uint32_t) k; }
+			return;
 		}
 		// nsym == 4 with tree-select 1: lengths 1,2,3,3 (the two length-3 symbols are sorted)
 		for (int s : used) bw.put((uint64_t) s, symbits);

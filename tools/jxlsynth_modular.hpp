@@ -68,6 +68,7 @@ inline void tree_tokens(const MATree &t, StreamEncoder &enc) {
 // a channel being encoded: values are what the decoder must reconstruct
 struct Channel {
 	int w = 0, h = 0;
+	int hshift = 0, vshift = 0;     // how often the channel was halved by Squeeze steps (decides which section codes it)
 	std::vector<int32_t> px;
 	Channel() {}
 	Channel(int w_, int h_) : w(w_), h(h_), px((size_t) w_ * (size_t) h_, 0) {}
@@ -173,7 +174,7 @@ inline void encode_channel(const MATree &tree, std::vector<Channel> &chans, int 
 	WPState wp;
 	if (tree.uses_wp()) wp.init(c.w, wpp);
 	std::vector<int> refc;
-	for (int i = cidx - 1; i >= 0; --i) if (chans[(size_t) i].w == c.w && chans[(size_t) i].h == c.h) refc.push_back(i);
+	for (int i = cidx - 1; i >= 0; --i) if (chans[(size_t) i].w == c.w && chans[(size_t) i].h == c.h && chans[(size_t) i].hshift == c.hshift && chans[(size_t) i].vshift == c.vshift) refc.push_back(i);
 	for (int y = 0; y < c.h; ++y) for (int x = 0; x < c.w; ++x) {
 		Neigh p = neighbours(c, x, y);
 		wp.before(x, y, p.w, p.n, p.nw, p.ne, p.nn);
@@ -231,7 +232,85 @@ inline void encode_channel(const MATree &tree, std::vector<Channel> &chans, int 
 	}
 }
 
-struct TransformW { int kind = 0; int begin_c = 0, rct_type = 0; int num_c = 0, nb_colours = 0, nb_deltas = 0, d_pred = 0; };
+// ---- Squeeze, forward direction (ISO 18181-1; the decoder's half is j40_amd/csrc/device/squeeze_dev.h). Written from the
+// standard's formulas independently of the decoder: avg = (A + B + (A > B)) >> 1, residual = A - B - tendency ----
+struct SqueezeStep { bool horizontal = true, in_place = true; int begin_c = 0, num_c = 1; };
+
+inline int64_t smooth_tendency(int64_t B, int64_t a, int64_t n) {
+	int64_t diff = 0;
+	if (B >= a && a >= n) {
+		diff = (4 * B - 3 * n - a + 6) / 12;
+		if (diff - (diff & 1) > 2 * (B - a)) diff = 2 * (B - a) + 1;
+		if (diff + (diff & 1) > 2 * (a - n)) diff = 2 * (a - n);
+	} else if (B <= a && a <= n) {
+		diff = (4 * B - 3 * n - a - 6) / 12;
+		if (diff + (diff & 1) < 2 * (B - a)) diff = 2 * (B - a) - 1;
+		if (diff - (diff & 1) < 2 * (a - n)) diff = 2 * (a - n);
+	}
+	return diff;
+}
+
+// one line of n samples (element stride `st`) -> ceil(n / 2) averages and floor(n / 2) residuals
+inline void squeeze_line(const int32_t *in, size_t st, int n, int32_t *avg, size_t ast, int32_t *res, size_t rst) {
+	const int na = (n + 1) / 2, nr = n / 2;
+	for (int k = 0; k < nr; ++k) { const int64_t A = in[(size_t) (2 * k) * st], B = in[(size_t) (2 * k + 1) * st]; avg[(size_t) k * ast] = (int32_t) ((A + B + (A > B)) >> 1); }
+	if (na > nr) avg[(size_t) nr * ast] = in[(size_t) (n - 1) * st];
+	for (int k = 0; k < nr; ++k) {
+		const int64_t A = in[(size_t) (2 * k) * st], B = in[(size_t) (2 * k + 1) * st], a = avg[(size_t) k * ast];
+		const int64_t next = k + 1 < na ? avg[(size_t) (k + 1) * ast] : a, left = k > 0 ? in[(size_t) (2 * k - 1) * st] : a;
+		res[(size_t) k * rst] = (int32_t) (A - B - smooth_tendency(left, a, next));
+	}
+}
+
+// the channel list after one step: squeezed channels halved in place, residual channels behind them or at the end
+inline void forward_squeeze_step(std::vector<Channel> &chs, const SqueezeStep &st) {
+	const int end_c = st.begin_c + st.num_c;
+	if (st.begin_c < 0 || st.num_c < 1 || end_c > (int) chs.size()) die("squeeze step out of range");
+	std::vector<Channel> residuals;
+	for (int c = st.begin_c; c < end_c; ++c) {
+		Channel &in = chs[(size_t) c];
+		Channel avg, res;
+		if (st.horizontal) {
+			avg = Channel((in.w + 1) / 2, in.h); res = Channel(in.w / 2, in.h);
+			for (int y = 0; y < in.h; ++y) squeeze_line(in.px.data() + (size_t) y * (size_t) in.w, 1, in.w, avg.px.data() + (size_t) y * (size_t) avg.w, 1, res.px.data() + (size_t) y * (size_t) res.w, 1);
+			avg.hshift = res.hshift = in.hshift + 1; avg.vshift = res.vshift = in.vshift;
+		} else {
+			avg = Channel(in.w, (in.h + 1) / 2); res = Channel(in.w, in.h / 2);
+			for (int x = 0; x < in.w; ++x) squeeze_line(in.px.data() + x, (size_t) in.w, in.h, avg.px.data() + x, (size_t) in.w, res.px.data() + x, (size_t) in.w);
+			avg.hshift = res.hshift = in.hshift; avg.vshift = res.vshift = in.vshift + 1;
+		}
+		in = std::move(avg);
+		residuals.push_back(std::move(res));
+	}
+	const size_t offset = st.in_place ? (size_t) end_c : chs.size();
+	chs.insert(chs.begin() + (long) offset, std::make_move_iterator(residuals.begin()), std::make_move_iterator(residuals.end()));
+}
+
+// the parameter list a decoder assumes when the bitstream gives none (num_sq = 0)
+inline std::vector<SqueezeStep> default_squeeze_steps(const std::vector<Channel> &chs, int nb_meta) {
+	std::vector<SqueezeStep> out;
+	const int first = nb_meta, count = (int) chs.size() - first;
+	if (count <= 0) return out;
+	int w = chs[(size_t) first].w, h = chs[(size_t) first].h;
+	SqueezeStep st;
+	if (count > 2 && chs[(size_t) first + 1].w == w && chs[(size_t) first + 1].h == h) {
+		st.begin_c = first + 1; st.num_c = 2; st.in_place = false;
+		st.horizontal = true; out.push_back(st);
+		st.horizontal = false; out.push_back(st);
+	}
+	st.begin_c = first; st.num_c = count; st.in_place = true;
+	if (h >= w && h > 8) { st.horizontal = false; out.push_back(st); h = (h + 1) / 2; }
+	while (w > 8 || h > 8) {
+		if (w > 8) { st.horizontal = true; out.push_back(st); w = (w + 1) / 2; }
+		if (h > 8) { st.horizontal = false; out.push_back(st); h = (h + 1) / 2; }
+	}
+	return out;
+}
+
+struct TransformW {
+	int kind = 0; int begin_c = 0, rct_type = 0; int num_c = 0, nb_colours = 0, nb_deltas = 0, d_pred = 0;
+	std::vector<SqueezeStep> sq;    // kind 2: the explicit parameter list; empty = the default list
+};
 
 // Modular header (j40.h:3730-3819)
 inline void write_modular_header(BitWriter &bw, bool use_global_tree, const WPParams *custom_wp, const std::vector<TransformW> &tr) {
@@ -255,6 +334,13 @@ inline void write_modular_header(BitWriter &bw, bool use_global_tree, const WPPa
 			bw.u32(t.nb_colours, 0, 8, 256, 10, 1280, 12, 5376, 16);
 			bw.u32(t.nb_deltas, 0, 0, 1, 8, 257, 10, 1281, 16);
 			bw.put((uint64_t) t.d_pred, 4);
+		} else if (t.kind == 2) {
+			bw.u32((int64_t) t.sq.size(), 0, 0, 1, 4, 9, 6, 41, 8);
+			for (const SqueezeStep &q : t.sq) {
+				bw.put(q.horizontal ? 1 : 0, 1); bw.put(q.in_place ? 1 : 0, 1);
+				bw.u32(q.begin_c, 0, 3, 8, 6, 72, 10, 1096, 13);
+				bw.u32(q.num_c, 1, 0, 2, 0, 3, 0, 4, 4);
+			}
 		} else die("unsupported transform in writer");
 	}
 }
