@@ -474,6 +474,24 @@ def test_damage_in_extra_channel_sub_images_is_reported(gpu, ref):
         if rerr == "":
             assert compare(rgba, rexp)[0] <= 1
         seen[rerr] = seen.get(rerr, 0) + 1
+        # throughput mode (j40hip_batch_decode) must agree with latency mode on every one of these streams: the batch cannot stop
+        # for the host in the middle, so the sub-images are validated when the status is asked for (runtime.hip: trailers_pending)
+        import torch
+        try:
+            fr = gpu.Frame(bytes(mutated))
+        except gpu.J40Error as e:
+            assert e.code == rerr
+            continue
+        fr.upload(0)
+        out = torch.zeros((264, 520, 4), dtype=torch.uint8, device="cuda:0")
+        batch = gpu.Batch([fr])
+        batch.decode([out.data_ptr()], [520 * 4], torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        if rerr != "excs":   # (bytes behind the frame are the public API's business: j40hip_frame_after_frame_status)
+            assert fr.status() == rerr, ("batch", pos, rerr, fr.status())
+        if rerr == "":
+            assert compare(out.cpu().numpy(), rexp)[0] <= 1
+        batch.close(); fr.close()
     assert sum(v for k, v in seen.items() if k) >= 10, seen
 
 
