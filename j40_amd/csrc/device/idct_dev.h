@@ -1,6 +1,6 @@
 // j40_amd/csrc/device/idct_dev.h -- inverse transforms and colour conversion as per-lane device
-// functions: the variable-block inverse DCT family (Perera-Liu radix-2 butterflies), the ten 8x8
-// "special" transforms, dequantisation, XYB -> sRGB and the u8 pack.
+// functions: the variable-block inverse DCT family (Perera-Liu radix-2 butterflies), dequantisation,
+// XYB -> sRGB and the u8 pack. (The 8x8 "special" transforms live in special8_dev.h.)
 //
 // Bit parity with the reference's float path needs its exact operation order and no FMA
 // contraction (compiled with -ffp-contract=off; see the note at j40.h:5834). Each function cites the
@@ -49,250 +49,6 @@ template <> struct Idct1D<2> {
 	static J40_DEVM void run(float *x, const float *) { const float p = x[0], q = x[1]; x[0] = p + q; x[1] = p - q; }
 };
 template <> struct Idct1D<1> { static J40_DEVM void run(float *, const float *) {} };
-
-// strided variant working in memory (LDS or global), for the 8x8 specials: length N, elements at
-// v[i * stride]
-template <int N> J40_DEV void idct1d_strided(float *v, int stride, const float *hs) {
-	float x[N];
-#pragma unroll
-	for (int i = 0; i < N; ++i) x[i] = v[i * stride];
-	Idct1D<N>::run(x, hs);
-#pragma unroll
-	for (int i = 0; i < N; ++i) v[i * stride] = x[i];
-}
-
-// (the loops below have constant bounds and are fully unrolled on the device, so that a caller holding `buf` and `scratch` in
-// local arrays gets them in registers: k_vardct_special)
-#ifdef __HIPCC__
-#define J40_UNROLL _Pragma("unroll")
-#else
-#define J40_UNROLL
-#endif
-// ---- the 8x8 special transforms; `buf` holds 64 coefficients in, 64 samples out (row-major 8x8),
-//      `scratch` is 64 floats of private workspace ----
-
-J40_DEV void aux_idct2x2(float *out, const float *in, int x, int y, int S2) {  // j40.h:5993
-	const int p = y * 8 + x, q = (y * 2) * 8 + (x * 2);
-	const float c00 = in[p], c01 = in[p + S2], c10 = in[p + S2 * 8], c11 = in[p + S2 * 9];
-	out[q] = c00 + c01 + c10 + c11;
-	out[q + 1] = c00 + c01 - c10 - c11;
-	out[q + 8] = c00 - c01 + c10 - c11;
-	out[q + 9] = c00 - c01 - c10 + c11;
-}
-
-J40_DEV void inverse_dct2x2_pyramid(float *buf, float *scratch) {  // DctSelect 2, j40.h:6002
-	{ float t[4]; { const float c00 = buf[0], c01 = buf[1], c10 = buf[8], c11 = buf[9];
-		t[0] = c00 + c01 + c10 + c11; t[1] = c00 + c01 - c10 - c11; t[2] = c00 - c01 + c10 - c11; t[3] = c00 - c01 - c10 + c11; }
-	  buf[0] = t[0]; buf[1] = t[1]; buf[8] = t[2]; buf[9] = t[3]; }
-	J40_UNROLL
-	for (int i = 0; i < 64; ++i)
-		scratch[i] = buf[i];
-	J40_UNROLL
-	for (int y = 0; y < 2; ++y)
-		J40_UNROLL
-		for (int x = 0; x < 2; ++x)
-			aux_idct2x2(scratch, buf, x, y, 2);
-	J40_UNROLL
-	for (int y = 0; y < 4; ++y)
-		J40_UNROLL
-		for (int x = 0; x < 4; ++x)
-			aux_idct2x2(buf, scratch, x, y, 4);
-}
-
-// columnar 4-point IDCTs over `rep` interleaved columns: out/in layout [4][rep]
-J40_DEV void idct4_columns(float *out, const float *in, int rep, const float *hs) {
-	J40_UNROLL
-	for (int r = 0; r < rep; ++r)
-		{
-		float x[4] = {in[r], in[rep + r], in[2 * rep + r], in[3 * rep + r]};
-		Idct1D<4>::run(x, hs);
-		out[r] = x[0]; out[rep + r] = x[1]; out[2 * rep + r] = x[2]; out[3 * rep + r] = x[3];
-	}
-}
-J40_DEV void idct8_columns(float *out, const float *in, int rep, const float *hs) {
-	J40_UNROLL
-	for (int r = 0; r < rep; ++r)
-		{
-		float x[8];
-		J40_UNROLL
-		for (int i = 0; i < 8; ++i)
-			x[i] = in[i * rep + r];
-		Idct1D<8>::run(x, hs);
-		J40_UNROLL
-		for (int i = 0; i < 8; ++i)
-			out[i * rep + r] = x[i];
-	}
-}
-
-J40_DEV void inverse_dct4x4_quad(float *buf, float *scratch, const float *hs) {  // DctSelect 3, j40.h:6015
-	{ const float c00 = buf[0], c01 = buf[1], c10 = buf[8], c11 = buf[9];
-	  buf[0] = c00 + c01 + c10 + c11; buf[1] = c00 + c01 - c10 - c11; buf[8] = c00 - c01 + c10 - c11; buf[9] = c00 - c01 - c10 + c11; }
-	idct4_columns(scratch, buf, 16, hs);
-	J40_UNROLL
-	for (int y = 0; y < 8; ++y)
-		J40_UNROLL
-		for (int x = 0; x < 8; ++x)
-			buf[x * 8 + y] = scratch[y * 8 + x];
-	idct4_columns(scratch, buf, 16, hs);
-	J40_UNROLL
-	for (int y = 0; y < 4; ++y)
-		J40_UNROLL
-		for (int x = 0; x < 4; ++x)
-			{
-		buf[y * 8 + x] = scratch[(y * 2) * 8 + (x * 2)];
-		buf[y * 8 + (x + 4)] = scratch[(y * 2 + 1) * 8 + (x * 2)];
-		buf[(y + 4) * 8 + x] = scratch[(y * 2) * 8 + (x * 2 + 1)];
-		buf[(y + 4) * 8 + (x + 4)] = scratch[(y * 2 + 1) * 8 + (x * 2 + 1)];
-	}
-}
-
-J40_DEV void inverse_hornuss(float *buf, float *scratch) {  // DctSelect 1, j40.h:6046
-	J40_UNROLL
-	for (int i = 0; i < 64; ++i)
-		scratch[i] = buf[i];
-	aux_idct2x2(scratch, buf, 0, 0, 1);
-	J40_UNROLL
-	for (int y = 0; y < 2; ++y)
-		J40_UNROLL
-		for (int x = 0; x < 2; ++x)
-			{
-		const int pos00 = y * 8 + x, pos11 = (y + 2) * 8 + (x + 2);
-		float rsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-		J40_UNROLL
-		for (int iy = 0; iy < 4; ++iy)
-			J40_UNROLL
-			for (int ix = 0; ix < 4; ++ix)
-				rsum[ix] += scratch[(y + iy * 2) * 8 + (x + ix * 2)];
-		const float sample11 = scratch[pos00] - (rsum[0] + rsum[1] + rsum[2] + rsum[3] - scratch[pos00]) * 0.0625f;
-		scratch[pos00] = scratch[pos11];
-		scratch[pos11] = 0.0f;
-		J40_UNROLL
-		for (int iy = 0; iy < 4; ++iy)
-			J40_UNROLL
-			for (int ix = 0; ix < 4; ++ix)
-				buf[(4 * y + iy) * 8 + (4 * x + ix)] = scratch[(y + iy * 2) * 8 + (x + ix * 2)] + sample11;
-	}
-}
-
-J40_DEV void inverse_dct8x4(float *buf, float *scratch, const float *hs) {  // DctSelect 13 ("DCT32"), j40.h:6067
-	{ const float t = buf[0] + buf[8]; buf[8] = buf[0] - buf[8]; buf[0] = t; }
-	// two 4x8 coefficient matrices from even / odd rows: view buf as [4][16], IDCT4 down the columns
-	idct4_columns(scratch, buf, 16, hs);
-	J40_UNROLL
-	for (int y = 0; y < 8; ++y)
-		J40_UNROLL
-		for (int x = 0; x < 8; ++x)
-			buf[x * 8 + y] = scratch[y * 8 + x];
-	idct8_columns(scratch, buf, 8, hs);
-	J40_UNROLL
-	for (int y = 0; y < 8; ++y)
-		J40_UNROLL
-		for (int x = 0; x < 8; ++x)
-			buf[y * 8 + (((x & 1) << 2) | (x >> 1))] = scratch[y * 8 + x];
-}
-
-J40_DEV void inverse_dct4x8(float *buf, float *scratch, const float *hs) {  // DctSelect 12 ("DCT23"), j40.h:6087
-	J40_UNROLL
-	for (int i = 0; i < 64; ++i)
-		scratch[i] = buf[i];
-	scratch[0] = buf[0] + buf[8];
-	scratch[8] = buf[0] - buf[8];
-	J40_UNROLL
-	for (int y = 0; y < 8; ++y)
-		J40_UNROLL
-		for (int x = 0; x < 8; ++x)
-			buf[x * 8 + y] = scratch[y * 8 + x];
-	idct8_columns(scratch, buf, 8, hs);
-	J40_UNROLL
-	for (int y = 0; y < 8; ++y)
-		J40_UNROLL
-		for (int x = 0; x < 8; ++x)
-			buf[x * 8 + y] = scratch[y * 8 + x];
-	idct4_columns(scratch, buf, 16, hs);
-	J40_UNROLL
-	for (int y = 0; y < 8; ++y)
-		{ const int oy = ((y & 1) << 2) | (y >> 1); for (int x = 0; x < 8; ++x) buf[oy * 8 + x] = scratch[y * 8 + x]; }
-}
-
-J40_DEV void inverse_afv(float *buf, float *scratch, int flipx, int flipy, const float *hs, const float *afv_basis) {  // DctSelect 14-17, j40.h:6183
-	float *bufafv = buf, *buf22 = buf + 16, *buf32 = buf + 32;
-	float *safv = scratch, *s22 = scratch + 16, *s32 = scratch + 32;
-	J40_UNROLL
-	for (int y = 0; y < 8; y += 2)
-		J40_UNROLL
-		for (int x = 0; x < 8; ++x)
-			scratch[(x % 2) * 16 + (y / 2) * 4 + (x / 2)] = buf[y * 8 + x];
-	J40_UNROLL
-	for (int y = 1; y < 8; y += 2)
-		J40_UNROLL
-		for (int x = 0; x < 8; ++x)
-			s32[x * 4 + (y / 2)] = buf[y * 8 + x];
-	safv[0] = (buf[0] + buf[1] + buf[8]) * 4.0f;
-	s22[0] = buf[0] - buf[1] + buf[8];
-	s32[0] = buf[0] - buf[8];
-	J40_UNROLL
-	for (int i = 0; i < 16; ++i)
-		{  // AFV 4x4: dense 16x16 basis product (j40.h:6176-6180)
-		float sum = 0.0f;
-		J40_UNROLL
-		for (int j = 0; j < 16; ++j)
-			sum += safv[j] * afv_basis[i * 16 + j];
-		bufafv[i] = sum;
-	}
-	idct4_columns(buf22, s22, 4, hs);
-	idct8_columns(buf32, s32, 4, hs);
-	J40_UNROLL
-	for (int y = 0; y < 4; ++y)
-		{
-		J40_UNROLL
-		for (int x = 0; x < 4; ++x)
-			safv[y * 4 + x] = bufafv[y * 4 + x];
-		J40_UNROLL
-		for (int x = 0; x < 4; ++x)
-			s22[x * 4 + y] = buf22[y * 4 + x];
-	}
-	J40_UNROLL
-	for (int y = 0; y < 8; ++y)
-		J40_UNROLL
-		for (int x = 0; x < 4; ++x)
-			s32[x * 8 + y] = buf32[y * 4 + x];
-	idct4_columns(buf22, s22, 4, hs);
-	idct4_columns(buf32, s32, 8, hs);
-	J40_UNROLL
-	for (int i = 16; i < 64; ++i)
-		scratch[i] = buf[i];
-	J40_UNROLL
-	for (int y = 0; y < 4; ++y)
-		{
-		const int ay = flipy ? 7 - y : y;
-		const int dct22pos = (flipy * 4 + y) * 8 + (!flipx * 4);
-		const int dct23pos = (!flipy * 4 + y) * 8;
-		J40_UNROLL
-		for (int x = 0; x < 4; ++x)
-			buf[ay * 8 + (flipx ? 7 - x : x)] = safv[y * 4 + x];
-		J40_UNROLL
-		for (int x = 0; x < 4; ++x)
-			buf[dct22pos + x] = s22[y * 4 + x];
-		J40_UNROLL
-		for (int x = 0; x < 8; ++x)
-			buf[dct23pos + x] = s32[y * 8 + x];
-	}
-}
-
-// dispatch for the 8x8 class other than plain DCT8x8 (j40.h:7178-7187)
-J40_DEV void inverse_special8x8(int dctsel, float *buf, float *scratch, const float *hs, const float *afv_basis) {
-	switch (dctsel) {
-	case 1: inverse_hornuss(buf, scratch); break;
-	case 2: inverse_dct2x2_pyramid(buf, scratch); break;
-	case 3: inverse_dct4x4_quad(buf, scratch, hs); break;
-	case 12: inverse_dct4x8(buf, scratch, hs); break;
-	case 13: inverse_dct8x4(buf, scratch, hs); break;
-	case 14: inverse_afv(buf, scratch, 0, 0, hs, afv_basis); break;
-	case 15: inverse_afv(buf, scratch, 1, 0, hs, afv_basis); break;
-	case 16: inverse_afv(buf, scratch, 0, 1, hs, afv_basis); break;
-	default: inverse_afv(buf, scratch, 1, 1, hs, afv_basis); break;
-	}
-}
 
 // ---- dequantisation (j40__dequant_hf, j40.h:7086-7094) ----
 J40_DEV float dequant_coeff(float q, float quant_bias_c, float quant_bias_num, float mult_c, float dq) {

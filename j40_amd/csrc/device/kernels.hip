@@ -15,6 +15,7 @@
 #include "hf_lanes_dev.h"
 #include "idct_dev.h"
 #include "vardct_dev.h"
+#include "special8_dev.h"
 #include "kernels.h"
 
 namespace j40hip {
@@ -448,14 +449,17 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan_arg, const DevV
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2s: the 8x8 special transforms; one lane transforms one (block, channel) tile serially
+// K2s: the 8x8 special transforms (special8_dev.h), cooperative: eight lanes per (block, channel) tile, two phases with a
+// barrier between them. The 256 lanes of a workgroup are 32 tiles x 8 lanes; a workgroup's NB blocks x 3 channels = 96 tiles
+// take three rounds per phase. Tiles are 65 floats apart (odd: the eight tiles of a wavefront start in different banks).
 
 template <int NB, bool BATCH>
 __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const DevVarblock *list, int32_t count, uint8_t *rgba, size_t stride_bytes, const K2Frame *batch, int32_t class_a, int32_t class_b) {
 	const DevPlan &plan = BATCH ? batch[blockIdx.y].plan : plan_arg;
 	{ float *unused = nullptr; if (!k2_bind<BATCH>(batch, class_a, class_b, NB, list, count, rgba, stride_bytes, unused)) return; }
-	constexpr int P = 65;  // odd pitch: lanes working on different tiles hit different banks
-	__shared__ float tiles[NB * 3 * P];
+	constexpr int P = 65;
+	__shared__ float tiles[NB * 3 * P];   // coefficients in, samples out
+	__shared__ float work[NB * 3 * P];    // between the two phases
 	const DevFrame &f = *plan.frame;
 	const int32_t tid = threadIdx.x, nthreads = blockDim.x;
 	const int32_t first = blockIdx.x * NB;
@@ -463,13 +467,14 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const 
 	__shared__ VbGeom geom[NB];
 	J40_STAGE_SRGB_THRESHOLDS(f);
 	const ColourConsts cc = load_colour_consts(f);
-	__shared__ int32_t g_param[NB];
+	__shared__ int32_t g_param[NB], g_sel[NB];
 	__shared__ uint32_t g_be[NB][4], g_dq[NB], ev_prefix[NB + 1];
 	uint32_t nevents = 0;
 	if (tid < nb) {
 		const DevVarblock vb = list[first + tid];
 		geom[tid] = varblock_geometry(plan, vb);
 		if (f.sparse_coeffs) { const uint32_t *be = plan.block_events + 4 * (size_t) vb.blk; for (int k = 0; k < 4; ++k) g_be[tid][k] = be[k]; nevents = be[1] + be[2] + be[3]; }
+		g_sel[tid] = vb.dctsel;
 		g_param[tid] = vb.dctsel == 1 ? 1 : vb.dctsel == 2 ? 2 : vb.dctsel == 3 ? 3 : vb.dctsel <= 13 ? 9 : 10;
 		g_dq[tid] = (uint32_t) f.dq_scan_off[g_param[tid]];
 	}
@@ -493,18 +498,12 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const 
 		}
 	}
 	__syncthreads();
-	// one lane per (block, channel): the tile and the workspace live in registers (the transforms are fully unrolled,
-	// constant indices throughout), so the serial chain is arithmetic only and the LDS holds just the tiles
-	for (int32_t w = tid; w < nb * 3; w += nthreads) {
-		const int32_t dctsel = list[first + w / 3].dctsel;
-		float *tile = tiles + (size_t) w * P;
-		float buf[64], work[64];
-#pragma unroll
-		for (int i = 0; i < 64; ++i) buf[i] = tile[i];
-		inverse_special8x8(dctsel, buf, work, c_half_secants, c_afv_basis);
-#pragma unroll
-		for (int i = 0; i < 64; ++i) tile[i] = buf[i];
-	}
+	const int32_t lane8 = tid & 7;
+	for (int32_t tile = tid >> 3; tile < nb * 3; tile += nthreads >> 3)
+		special8_phase0(g_sel[tile / 3], lane8, tiles + tile * P, work + tile * P, c_half_secants, c_afv_basis);
+	__syncthreads();
+	for (int32_t tile = tid >> 3; tile < nb * 3; tile += nthreads >> 3)
+		special8_phase1(g_sel[tile / 3], lane8, work + tile * P, tiles + tile * P, c_half_secants);
 	__syncthreads();
 	for (int32_t w = tid; w < nb * 64; w += nthreads) {
 		const int32_t b = w >> 6, i = w & 63, y = i >> 3, x = i & 7;

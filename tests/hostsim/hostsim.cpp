@@ -11,6 +11,7 @@
 #include "../../j40_amd/csrc/device/hf_dev.h"
 #include "../../j40_amd/csrc/device/hf_lanes_dev.h"
 #include "../../j40_amd/csrc/device/vardct_dev.h"
+#include "../../j40_amd/csrc/device/special8_dev.h"
 #include "../../j40_amd/csrc/device/modular_dev.h"
 #include "../../j40_amd/csrc/device/squeeze_dev.h"
 
@@ -352,7 +353,11 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 		}
 		for (int ch = 0; ch < 3; ++ch) {
 			float *t = A.data() + (size_t) ch * 65536;
-			if (special) inverse_special8x8(vb.dctsel, t, scratch.data(), hs, afv);
+			if (special) {   // the cooperative form (k_vardct_special): two phases of eight lanes; here one lane after the other, in an
+				// order that changes with the block so that a dependence between the lanes of a phase would show
+				for (int l = 0; l < 8; ++l) special8_phase0(vb.dctsel, (vb.blk & 1) ? 7 - l : l, t, scratch.data(), hs, afv);
+				for (int l = 0; l < 8; ++l) special8_phase1(vb.dctsel, (vb.blk & 2) ? 7 - l : l, scratch.data(), t, hs);
+			}
 			else if (large) {
 				idct_sweeps_host(t, B.data() + (size_t) ch * 65536, log_columns, R, 1, C, hs);
 				idct_sweeps_host(B.data() + (size_t) ch * 65536, t, log_rows, C, C, 1, hs);
@@ -364,6 +369,17 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 		}
 	}
 	return 0;
+}
+
+// known-answer hook: one 8x8 special transform (DctSelect 1-3, 12-17) through the cooperative device functions; `order` permutes
+// the lanes of both phases (0: ascending, 1: descending, 2: odd lanes first)
+extern "C" __attribute__((visibility("default"))) void hostsim_special8(int dctsel, float *tile64, int order) {
+	float mid[64];
+	for (int k = 0; k < 64; ++k) mid[k] = -12345.0f;
+	auto lane_of = [order](int l) { return order == 0 ? l : order == 1 ? 7 - l : (l < 4 ? 2 * l + 1 : 2 * (l - 4)); };
+	for (int l = 0; l < 8; ++l) special8_phase0(dctsel, lane_of(l), tile64, mid, half_secants(), afv_basis());
+	for (int k = 0; k < 64; ++k) tile64[k] = -54321.0f;   // phase 1 must rewrite every sample
+	for (int l = 0; l < 8; ++l) special8_phase1(dctsel, lane_of(l), mid, tile64, half_secants());
 }
 
 // sweeps float bit patterns [first, last] with stride `step` through pow_1_over_2p4 and counts results that

@@ -246,3 +246,23 @@ def test_nsym4_simple_prefix_code_follows_the_reference_and_documents_the_rfc_di
     res = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, J40HIP_RFC_SIMPLE_CODES="1"), capture_output=True, check=True)
     rfc = np.frombuffer(res.stdout, np.uint8).reshape(h, w, 4)
     assert np.array_equal(rfc, intended)
+
+
+@pytest.mark.parametrize("sel", [1, 2, 3, 12, 13, 14, 15, 16, 17])
+def test_cooperative_special_transforms_equal_the_reference_bit_for_bit(sim, ref, sel):
+    """The nine 8x8 special transforms as k_vardct_special runs them (special8_dev.h: eight lanes per tile, two out-of-place
+    phases) against the reference's routines (j40.h:5993-6246 via ref_kat_inverse_by_dctsel): identical floats, whatever the
+    order in which the lanes of a phase run."""
+    sim.hostsim_special8.argtypes = [C.c_int, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(sel)
+    for trial in range(120):
+        a = (rng.standard_normal(64) * (10.0 ** rng.integers(-3, 3))).astype(np.float32)
+        if trial % 3 == 0:
+            a[rng.integers(0, 64, 40)] = 0
+        expect = a.copy()
+        scratch = np.zeros(256, np.float32)
+        ref.lib.ref_kat_inverse_by_dctsel(expect.ctypes.data, scratch.ctypes.data, sel)
+        for order in (0, 1, 2):
+            got = a.copy()
+            sim.hostsim_special8(sel, got.ctypes.data, order)
+            assert np.array_equal(expect.view(np.uint32), got.view(np.uint32)), (sel, trial, order)
