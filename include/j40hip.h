@@ -235,6 +235,40 @@ J40HIP_API uint32_t j40hip_batch_elapsed(j40hip_batch *b, int32_t slot, float *m
 /* `stream` waits for stage 1 (cleared), 2 (entropy decoded) or 3 (pixels written) of the decode recorded in `slot` */
 J40HIP_API uint32_t j40hip_batch_wait_stage(j40hip_batch *b, int32_t slot, int32_t stage, void *stream);
 
+/* a batch object re-used for other members (keeps its device arrays, streams and events); the previous members' decodes must be complete */
+J40HIP_API uint32_t j40hip_batch_reset(j40hip_batch *b, j40hip_frame *const *frames, int64_t n);
+
+/* ---- building blocks for pipelines ---- */
+/* j40hip_frame_upload with the copies enqueued on `stream` (the plan is staged in pinned memory owned by the calling thread, so the
+ * copy is a real asynchronous DMA beside other streams' kernels); returns when they have completed */
+J40HIP_API uint32_t j40hip_frame_upload_on(j40hip_frame *f, int device, void *stream);
+/* frees the calling thread's pinned staging buffer (call before a thread that uploaded frames exits) */
+J40HIP_API void j40hip_thread_release(void);
+/* j40hip_frame_status in two halves: `begin` enqueues the copy of the status words on `stream`, `end` -- once the caller has waited
+ * for that stream -- reduces them to the frame's verdict without touching the device. VarDCT frames without extra channels. */
+J40HIP_API uint32_t j40hip_frame_status_begin(j40hip_frame *f, void *stream);
+J40HIP_API uint32_t j40hip_frame_status_end(j40hip_frame *f);
+/* the caller guarantees that nothing is pending on the frame's device memory: j40hip_frame_free then skips its device-wide wait */
+J40HIP_API void j40hip_frame_mark_idle(j40hip_frame *f);
+
+/* ---- whole-frame throughput pipeline (j40_amd/csrc/device/pipeline.hip): codestreams in host memory -> RGBA u8x4, every stage of
+ *      many frames in flight: `host_threads` workers parse (j40hip_frame_parse) and upload, one thread batches `batch_frames` uploaded
+ *      frames per entropy launch, up to `max_in_flight` batches on their own streams; host output is copied back on the batch's
+ *      stream behind its kernels. The serving shape of j40_from_memory + j40_next_frame + j40_frame_pixels_u8x4 for many images. ---- */
+typedef struct j40hip_pipeline j40hip_pipeline;
+J40HIP_API j40hip_pipeline *j40hip_pipeline_create(int device, int host_threads, int batch_frames, int max_in_flight, uint32_t *err);
+J40HIP_API void j40hip_pipeline_free(j40hip_pipeline *p);
+/* queues one image. buf is borrowed until the ticket is done. rgba: `stride_bytes` * height bytes of host memory (pinned memory for
+ * full copy speed) or, with device_output != 0, of device memory (no copy back). */
+J40HIP_API uint32_t j40hip_pipeline_submit(j40hip_pipeline *p, const void *buf, size_t size, void *rgba, size_t stride_bytes, int device_output, int64_t *ticket);
+/* waits until everything submitted so far is done */
+J40HIP_API uint32_t j40hip_pipeline_drain(j40hip_pipeline *p);
+/* 0 or the image's 4-char error code, as j40_error would give it ("rnge" for an unknown or unfinished ticket) */
+J40HIP_API uint32_t j40hip_pipeline_result(j40hip_pipeline *p, int64_t ticket);
+/* out4: parse ms and plan-build + upload ms summed over the worker threads, images completed, ms from first submit to last completion */
+J40HIP_API void j40hip_pipeline_stats(j40hip_pipeline *p, double *out4);
+J40HIP_API void j40hip_pipeline_reset_stats(j40hip_pipeline *p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,13 @@ def lib():
         "j40hip_batch_create": (vp, [vp, i64, C.POINTER(u32)]), "j40hip_batch_free": (None, [vp]),
         "j40hip_batch_decode": (u32, [vp, vp, vp, vp]), "j40hip_batch_decode_timed": (u32, [vp, vp, vp, vp, vp]),
         "j40hip_batch_decode_recorded": (u32, [vp, vp, vp, vp, i32]), "j40hip_batch_elapsed": (u32, [vp, i32, vp]), "j40hip_batch_wait_stage": (u32, [vp, i32, i32, vp]),
+        "j40hip_batch_reset": (u32, [vp, vp, i64]),
+        "j40hip_frame_upload_on": (u32, [vp, C.c_int, vp]), "j40hip_thread_release": (None, []),
+        "j40hip_frame_status_begin": (u32, [vp, vp]), "j40hip_frame_status_end": (u32, [vp]), "j40hip_frame_mark_idle": (None, [vp]),
+        "j40hip_frame_after_frame_status": (u32, [vp]),
+        "j40hip_pipeline_create": (vp, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(u32)]), "j40hip_pipeline_free": (None, [vp]),
+        "j40hip_pipeline_submit": (u32, [vp, vp, sz, vp, sz, C.c_int, C.POINTER(i64)]), "j40hip_pipeline_drain": (u32, [vp]),
+        "j40hip_pipeline_result": (u32, [vp, i64]), "j40hip_pipeline_stats": (None, [vp, vp]), "j40hip_pipeline_reset_stats": (None, [vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)  # AttributeError = the library does not export what include/*.h declares
@@ -344,3 +351,53 @@ class Batch:
         if code:
             raise J40Error(err4(code), "in j40hip_batch_decode_timed")
         return ms[0], ms[1], ms[2]
+
+
+class Pipeline:
+    """whole-frame throughput pipeline (include/j40hip.h, j40hip_pipeline_*): codestreams in host memory -> RGBA u8x4 in host or
+    device memory; host worker threads parse and upload, one thread batches the uploaded frames per entropy launch"""
+
+    def __init__(self, device=0, host_threads=0, batch_frames=32, max_in_flight=2):
+        err = C.c_uint32()
+        self.h = lib().j40hip_pipeline_create(device, host_threads, batch_frames, max_in_flight, C.byref(err))
+        if not self.h:
+            raise J40Error(err4(err.value), "in j40hip_pipeline_create")
+        self._keep = []
+
+    def submit(self, data, rgba_ptr, stride_bytes, device_output=False):
+        """data: bytes-like (kept alive until close / drain); rgba_ptr: address of the output image; returns the ticket"""
+        buf = data if isinstance(data, C.Array) else C.create_string_buffer(bytes(data), len(data))
+        self._keep.append(buf)
+        t = C.c_int64()
+        code = lib().j40hip_pipeline_submit(self.h, buf, len(data), rgba_ptr, stride_bytes, 1 if device_output else 0, C.byref(t))
+        if code:
+            raise J40Error(err4(code), "in j40hip_pipeline_submit")
+        return t.value
+
+    def drain(self):
+        code = lib().j40hip_pipeline_drain(self.h)
+        if code:
+            raise J40Error(err4(code), "in j40hip_pipeline_drain")
+        self._keep = []
+
+    def result(self, ticket):
+        return err4(lib().j40hip_pipeline_result(self.h, ticket))
+
+    def stats(self):
+        a = (C.c_double * 4)()
+        lib().j40hip_pipeline_stats(self.h, a)
+        return dict(parse_thread_ms=a[0], upload_thread_ms=a[1], completed=int(a[2]), wall_ms=a[3])
+
+    def reset_stats(self):
+        lib().j40hip_pipeline_reset_stats(self.h)
+
+    def close(self):
+        if self.h:
+            lib().j40hip_pipeline_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -100,16 +100,48 @@ bool DeviceBuffer::alloc(size_t n) {
 	return hipMalloc(&ptr, n ? n : 16) == hipSuccess;
 }
 
-// host-side staging of the plan: every array lands in one blob at a 256-byte aligned offset, one copy moves it
+// host-side staging of the plan: every array lands in one blob at a 256-byte aligned offset, one copy moves it. The blob lives
+// in PINNED host memory owned by the calling thread (grown on demand, reused by that thread's next upload), so the copy is a
+// true asynchronous DMA that overlaps the kernels of other frames; j40hip_thread_release gives it back.
+struct PinnedStage {
+	uint8_t *ptr = nullptr; size_t cap = 0;
+	bool reserve(size_t n, size_t keep) {
+		if (n <= cap) return true;
+		size_t want = std::max(n + n / 4, (size_t) 1 << 20);
+		void *q = nullptr;
+		if (hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); return false; }
+		if (keep) memcpy(q, ptr, keep);
+		if (ptr) (void) hipHostFree(ptr);
+		ptr = (uint8_t *) q; cap = want;
+		return true;
+	}
+	void release() { if (ptr) (void) hipHostFree(ptr); ptr = nullptr; cap = 0; }
+};
+thread_local PinnedStage t_stage;   // (no destructor: at process exit the runtime may be gone before the thread's storage)
+
 struct Stager {
-	std::vector<uint8_t> blob;
+	size_t size = 0; bool ok = true;
 	template <typename T> size_t put(const T *src, size_t n) {
-		const size_t off = (blob.size() + 255) & ~(size_t) 255;
-		blob.resize(off + sizeof(T) * n + 16);
-		if (n) memcpy(blob.data() + off, src, sizeof(T) * n);
+		const size_t off = (size + 255) & ~(size_t) 255, end = off + sizeof(T) * n + 16;
+		if (!ok || !t_stage.reserve(end, size)) { ok = false; return 0; }
+		if (n) memcpy(t_stage.ptr + off, src, sizeof(T) * n);
+		size = end;
 		return off;
 	}
+	const uint8_t *data() const { return t_stage.ptr; }
 };
+
+// the constant tables of the pixel kernels go up once per device (they never change)
+std::mutex g_const_mutex;
+bool g_const_done[16];
+bool ensure_constant_tables(int device) {
+	if (device < 0 || device >= 16) return false;
+	std::lock_guard<std::mutex> lock(g_const_mutex);
+	if (g_const_done[device]) return true;
+	upload_constant_tables(half_secants(), afv_basis(), srgb_u8_thresholds(), nullptr);
+	if (hipStreamSynchronize(nullptr) != hipSuccess) return false;
+	return g_const_done[device] = true;
+}
 
 } // namespace
 
@@ -137,6 +169,7 @@ struct j40hip_device_state {
 	int32_t mod_sections = 0, mod_passes = 1, mod_sections_per_pass = 0;   // sections = LfGlobal's (0 or 1) + passes * per_pass
 	bool mod_local_rcts = false;
 	bool has_trailers = false;           // VarDCT frame whose sections go on with the extra channels' Modular sub-image
+	bool idle = false;                   // j40hip_frame_mark_idle: nothing is pending on this frame's memory, freeing it needs no device-wide wait
 	bool trailers_pending = false;       // ... decoded by a batch since: j40hip_frame_status validates the sub-images before it reports
 	ModLaunchInfo mod_info = {0, 0, 0, 0, 0, 0};
 	std::vector<uint32_t> mod_section_offsets;
@@ -170,7 +203,7 @@ extern "C" void j40hip_release_device(j40hip_frame *f) {
 	if (!f || !f->dev) return;
 	(void) hipSetDevice(f->dev->device);
 	if (f->dev->plan_block || f->dev->work_block) {
-		(void) hipDeviceSynchronize();   // nothing may still be running on memory that is about to be handed to another frame
+		if (!f->dev->idle) (void) hipDeviceSynchronize();   // nothing may still be running on memory that is about to be handed to another frame
 		cache_release(f->dev->device, f->dev->plan_block, f->dev->plan_block_bytes, false);
 		cache_release(f->dev->device, f->dev->work_block, f->dev->work_block_bytes, false);
 	}
@@ -370,7 +403,9 @@ static uint32_t decode_modular(j40hip_frame *h, void *rgba_dev, size_t stride_by
 	return hipGetLastError() == hipSuccess ? 0 : ERR_GPU;
 }
 
-static uint32_t j40hip_frame_upload_body(j40hip_frame *h, int device) {
+// `s`: the stream the copies and fills are enqueued on; the call returns once they have completed (the plan is staged in the
+// calling thread's pinned buffer, which the next upload of this thread reuses)
+static uint32_t upload_impl(j40hip_frame *h, int device, hipStream_t s) {
 	if (!h) return ERR_GPU;
 	if (h->dev) j40hip_release_device(h);
 	if (j40hip_device_count() <= device || hipSetDevice(device) != hipSuccess) return ERR_GPU;
@@ -381,8 +416,7 @@ static uint32_t j40hip_frame_upload_body(j40hip_frame *h, int device) {
 
 	j40hip_device_state *st = new j40hip_device_state();
 	h->dev = st; st->device = device; st->force_dense = h->force_dense;
-	hipStream_t s = nullptr;
-	bool ok = true;
+	bool ok = ensure_constant_tables(device);
 	DevPlan &plan = st->plan;
 	memset(&plan, 0, sizeof plan);
 	st->hf = hp.hf;
@@ -402,8 +436,9 @@ static uint32_t j40hip_frame_upload_body(j40hip_frame *h, int device) {
 	const size_t o_vbs = sg.put(st->vb_sorted.data(), st->vb_sorted.size());
 	const size_t o_evr = sg.put(hp.ev_range.data(), hp.ev_range.size());
 	bool dummy_clean = false;
-	st->plan_block = cache_acquire(device, sg.blob.size(), &st->plan_block_bytes, &dummy_clean);
-	if (!st->plan_block || hipMemcpyAsync(st->plan_block, sg.blob.data(), sg.blob.size(), hipMemcpyHostToDevice, s) != hipSuccess) ok = false;
+	if (!sg.ok) ok = false;
+	st->plan_block = ok ? cache_acquire(device, sg.size, &st->plan_block_bytes, &dummy_clean) : nullptr;
+	if (!st->plan_block || hipMemcpyAsync(st->plan_block, sg.data(), sg.size, hipMemcpyHostToDevice, s) != hipSuccess) ok = false;
 	uint8_t *pb = (uint8_t *) st->plan_block;
 	plan.codestream = pb + o_cs; plan.pool_u8 = pb + o_u8; plan.pool_u16 = (const uint16_t *) (pb + o_u16); plan.pool_i32 = (const int32_t *) (pb + o_i32);
 	plan.pool_u64 = (const uint64_t *) (pb + o_u64); plan.pool_f32 = (const float *) (pb + o_f32); plan.clusters = (const DevCluster *) (pb + o_cl);
@@ -453,12 +488,12 @@ static uint32_t j40hip_frame_upload_body(j40hip_frame *h, int device) {
 	st->total_sections = (int32_t) hp.sections.size();
 	st->has_trailers = hp.frame.sections_have_trailer != 0 && !h->from_view;
 	st->first_group = 0; st->num_groups = num_groups;
-	upload_constant_tables(half_secants(), afv_basis(), srgb_u8_thresholds(), s);
 	for (auto &e : st->ev) if (hipEventCreate(&e) != hipSuccess) ok = false;
 	if (hipStreamSynchronize(s) != hipSuccess) ok = false;
 	if (!ok) { j40hip_release_device(h); return ERR_GPU; }
 	return 0;
 }
+static uint32_t j40hip_frame_upload_body(j40hip_frame *h, int device) { return upload_impl(h, device, nullptr); }
 
 extern "C" void j40hip_frame_force_dense(j40hip_frame *h, int dense) { if (h) h->force_dense = dense != 0; }
 
@@ -600,6 +635,10 @@ struct j40hip_batch {
 	std::vector<j40hip_frame *> frames;
 	DevPlan *d_plans = nullptr;
 	std::vector<DevPlan> plans_host;   // what d_plans holds (batch_enqueue re-uploads it when a member was uploaded again)
+	std::vector<HfLaneWork> work_host;
+	size_t plans_cap = 0, work_cap = 0, k2_cap = 0;
+	bool arrays_dirty = true;          // plans_host / work_host have not been copied to the device yet
+	int side_in_use = 0;               // side streams the current membership spreads its pixel kernels over
 	HfLaneWork *d_work = nullptr;
 	int32_t num_work = 0;
 	bool tables_in_lds = true;
@@ -636,20 +675,20 @@ extern "C" void j40hip_batch_free(j40hip_batch *b) {
 	delete b;
 }
 
-static j40hip_batch *batch_create_body(j40hip_frame *const *frames, int64_t n, uint32_t *err) {
-	uint32_t dummy; if (!err) err = &dummy;
-	*err = 0;
-	if (n <= 0 || !frames) { *err = ERR_RNGE; return nullptr; }
-	j40hip_batch *b = new j40hip_batch();
-	std::vector<DevPlan> plans; std::vector<HfLaneWork> work;
+// (Re)assigns the members of a batch: plans, the entropy kernel's work list and launch geometry. Device arrays are kept and only
+// grown; their contents go up with the next decode (batch_enqueue), stream-ordered. The previous members' decodes must be complete.
+static uint32_t batch_assign(j40hip_batch *b, j40hip_frame *const *frames, int64_t n) {
+	if (n <= 0 || !frames) return ERR_RNGE;
+	b->frames.clear(); b->plans_host.clear(); b->work_host.clear();
+	b->tables_in_lds = true; b->lanes_fast = true; b->lanes_lds_bytes = 0; b->lds_bytes = 0;
 	for (int64_t i = 0; i < n; ++i) {
 		j40hip_frame *h = frames[i];
-		if (!h || !h->dev) { *err = ERR_GPU; delete b; return nullptr; }
-		if (h->dev->is_modular) { *err = ERR_TODO; delete b; return nullptr; }   // Modular frames: decode them one by one
+		if (!h || !h->dev) return ERR_GPU;
+		if (h->dev->is_modular) return ERR_TODO;   // Modular frames: decode them one by one
 		if (i == 0) b->device = h->dev->device;
-		else if (h->dev->device != b->device) { *err = ERR_RNGE; delete b; return nullptr; }
+		else if (h->dev->device != b->device) return ERR_RNGE;
 		b->frames.push_back(h);
-		plans.push_back(h->dev->plan);
+		b->plans_host.push_back(h->dev->plan);
 		b->tables_in_lds = b->tables_in_lds && h->dev->hf.tables_fit_lds;
 		b->lanes_fast = b->lanes_fast && h->dev->hf.lanes_fast;
 		b->lanes_lds_bytes = std::max(b->lanes_lds_bytes, h->dev->hf.lanes_lds_bytes);
@@ -660,10 +699,12 @@ static j40hip_batch *batch_create_body(j40hip_frame *const *frames, int64_t n, u
 	int32_t lanes = 64, total_waves = 0;
 	if (const char *e = getenv("J40HIP_LANES_PER_WAVE")) lanes = std::max(1, std::min(64, atoi(e)));
 	for (j40hip_frame *h : b->frames) total_waves += (h->frame.fh.num_groups + lanes - 1) / lanes;
-	int cus = 256;
-	{ hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, b->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount; }
+	static int cus_of[16];   // (hipGetDeviceProperties takes milliseconds)
+	if (b->device >= 0 && b->device < 16 && !cus_of[b->device]) { hipDeviceProp_t prop; cus_of[b->device] = hipGetDeviceProperties(&prop, b->device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
+	const int cus = b->device >= 0 && b->device < 16 ? cus_of[b->device] : 256;
 	b->waves_per_wg = total_waves <= 2 * cus ? 1 : total_waves <= 4 * cus ? 2 : 4;
 	if (const char *e = getenv("J40HIP_WAVES_PER_WG")) b->waves_per_wg = std::max(1, std::min(4, atoi(e)));
+	std::vector<HfLaneWork> &work = b->work_host;
 	for (size_t i = 0; i < b->frames.size(); ++i) {
 		const int32_t groups = b->frames[i]->frame.fh.num_groups;
 		for (int32_t g = 0; g < groups; g += lanes) work.push_back({(int32_t) i, g, std::min(lanes, groups - g), 0});
@@ -674,15 +715,21 @@ static j40hip_batch *batch_create_body(j40hip_frame *const *frames, int64_t n, u
 		b->lds_bytes = std::max(b->lds_bytes, hf_lanes_lds_bytes(info));
 	}
 	b->num_work = (int32_t) work.size();
-	b->plans_host = plans;
-	bool ok = hipSetDevice(b->device) == hipSuccess;
-	ok = ok && hipMalloc((void **) &b->d_plans, sizeof(DevPlan) * plans.size()) == hipSuccess;
-	ok = ok && hipMalloc((void **) &b->d_work, sizeof(HfLaneWork) * work.size()) == hipSuccess;
-	ok = ok && hipMemcpy(b->d_plans, plans.data(), sizeof(DevPlan) * plans.size(), hipMemcpyHostToDevice) == hipSuccess;
-	ok = ok && hipMemcpy(b->d_work, work.data(), sizeof(HfLaneWork) * work.size(), hipMemcpyHostToDevice) == hipSuccess;
-	for (auto &e : b->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+	if (hipSetDevice(b->device) != hipSuccess) return ERR_GPU;
+	if (b->plans_host.size() > b->plans_cap) {
+		if (b->d_plans) (void) hipFree(b->d_plans);
+		b->plans_cap = b->plans_host.size() + b->plans_host.size() / 2;
+		if (hipMalloc((void **) &b->d_plans, sizeof(DevPlan) * b->plans_cap) != hipSuccess) { b->d_plans = nullptr; b->plans_cap = 0; return ERR_GPU; }
+	}
+	if (work.size() > b->work_cap) {
+		if (b->d_work) (void) hipFree(b->d_work);
+		b->work_cap = work.size() + work.size() / 2;
+		if (hipMalloc((void **) &b->d_work, sizeof(HfLaneWork) * b->work_cap) != hipSuccess) { b->d_work = nullptr; b->work_cap = 0; return ERR_GPU; }
+	}
+	b->arrays_dirty = true;
 	if (const char *e = getenv("J40HIP_K2_BATCHED")) b->k2_batched = atoi(e) != 0;
 	if (b->k2_batched) {
+		b->k2_host.clear(); b->k2_class_start.clear();
 		for (j40hip_frame *h : b->frames) {
 			K2Frame k; memset(&k, 0, sizeof k);
 			k.plan = h->dev->plan; k.sorted = h->dev->d_vb_sorted; k.large_scratch = h->dev->d_large_scratch;
@@ -690,21 +737,39 @@ static j40hip_batch *batch_create_body(j40hip_frame *const *frames, int64_t n, u
 			b->k2_host.push_back(k);
 			b->k2_class_start.insert(b->k2_class_start.end(), h->dev->class_start, h->dev->class_start + 28);
 		}
-		ok = ok && hipMalloc((void **) &b->d_k2, sizeof(K2Frame) * b->k2_host.size()) == hipSuccess;
+		if (b->k2_host.size() > b->k2_cap) {
+			if (b->d_k2) (void) hipFree(b->d_k2);
+			b->k2_cap = b->k2_host.size() + b->k2_host.size() / 2;
+			if (hipMalloc((void **) &b->d_k2, sizeof(K2Frame) * b->k2_cap) != hipSuccess) { b->d_k2 = nullptr; b->k2_cap = 0; return ERR_GPU; }
+		}
 	}
+	// side streams for the pixel kernels: made once, as many as the largest membership so far asks for
 	{
 		int nside = (int) std::min<size_t>(16, b->frames.size());
 		if (const char *e = getenv("J40HIP_SIDE_STREAMS")) nside = std::max(0, std::min(32, atoi(e)));
 		if (nside < 2) nside = 0;
-		for (int i = 0; i < nside && ok; ++i) {
+		while ((int) b->side.size() < nside) {
 			hipStream_t st = nullptr; hipEvent_t ev = nullptr;
-			ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+			if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return ERR_GPU;
 			b->side.push_back(st); b->side_done.push_back(ev);
 		}
-		ok = ok && hipEventCreateWithFlags(&b->fork, hipEventDisableTiming) == hipSuccess;
+		b->side_in_use = nside;
+		if (!b->fork && hipEventCreateWithFlags(&b->fork, hipEventDisableTiming) != hipSuccess) return ERR_GPU;
 	}
-	if (!ok) { *err = ERR_GPU; j40hip_batch_free(b); return nullptr; }
+	for (auto &e : b->ev) if (!e && hipEventCreate(&e) != hipSuccess) return ERR_GPU;
+	return 0;
+}
+
+static j40hip_batch *batch_create_body(j40hip_frame *const *frames, int64_t n, uint32_t *err) {
+	uint32_t dummy; if (!err) err = &dummy;
+	j40hip_batch *b = new j40hip_batch();
+	*err = batch_assign(b, frames, n);
+	if (*err) { j40hip_batch_free(b); return nullptr; }
 	return b;
+}
+extern "C" uint32_t j40hip_batch_reset(j40hip_batch *b, j40hip_frame *const *frames, int64_t n) {
+	if (!b) return ERR_GPU;
+	return guarded([&] { return batch_assign(b, frames, n); });
 }
 
 // ev: four events to record around the three stages (clear | entropy | pixels), or nullptr
@@ -721,8 +786,12 @@ static uint32_t batch_enqueue(j40hip_batch *b, void *const *rgba_dev, const size
 			if (!st || st->is_modular || st->device != b->device) return ERR_GPU;
 			if (memcmp(&b->plans_host[i], &st->plan, sizeof(DevPlan)) != 0) { b->plans_host[i] = st->plan; changed = true; }
 		}
-		if (changed && hipMemcpyAsync(b->d_plans, b->plans_host.data(), sizeof(DevPlan) * b->plans_host.size(), hipMemcpyHostToDevice, s) != hipSuccess) return ERR_GPU;
-		if (changed && hipStreamSynchronize(s) != hipSuccess) return ERR_GPU;   // (pageable source: the copy must have left the vector)
+		if (changed || b->arrays_dirty) {
+			// (pageable sources: the runtime copies them out before the calls return; the vectors live until the next reset anyway)
+			if (hipMemcpyAsync(b->d_plans, b->plans_host.data(), sizeof(DevPlan) * b->plans_host.size(), hipMemcpyHostToDevice, s) != hipSuccess) return ERR_GPU;
+			if (b->arrays_dirty && hipMemcpyAsync(b->d_work, b->work_host.data(), sizeof(HfLaneWork) * b->work_host.size(), hipMemcpyHostToDevice, s) != hipSuccess) return ERR_GPU;
+			b->arrays_dirty = false;
+		}
 	}
 	if (ev) (void) hipEventRecord(ev[0], s);
 	for (j40hip_frame *h : b->frames) {
@@ -752,19 +821,19 @@ static uint32_t batch_enqueue(j40hip_batch *b, void *const *rgba_dev, const size
 		// copied out before the call returns (pageable source)
 		if (changed && hipMemcpyAsync(b->d_k2, b->k2_host.data(), sizeof(K2Frame) * b->k2_host.size(), hipMemcpyHostToDevice, s) != hipSuccess) return ERR_GPU;
 		launch_vardct_batch(b->d_k2, (int32_t) b->frames.size(), b->k2_class_start.data(), s);
-	} else if (b->side.empty()) {
+	} else if (b->side_in_use == 0) {
 		for (size_t i = 0; i < b->frames.size(); ++i) {
 			j40hip_device_state *st = b->frames[i]->dev;
 			launch_vardct_frame(st->plan, st->class_start, st->d_vb_sorted, st->d_large_scratch, (uint8_t *) rgba_dev[i], stride_bytes[i], s);
 		}
 	} else {
 		if (hipEventRecord(b->fork, s) != hipSuccess) return ERR_GPU;
-		for (hipStream_t side : b->side) if (hipStreamWaitEvent(side, b->fork, 0) != hipSuccess) return ERR_GPU;
+		for (int k = 0; k < b->side_in_use; ++k) if (hipStreamWaitEvent(b->side[(size_t) k], b->fork, 0) != hipSuccess) return ERR_GPU;
 		for (size_t i = 0; i < b->frames.size(); ++i) {
 			j40hip_device_state *st = b->frames[i]->dev;
-			launch_vardct_frame(st->plan, st->class_start, st->d_vb_sorted, st->d_large_scratch, (uint8_t *) rgba_dev[i], stride_bytes[i], b->side[i % b->side.size()]);
+			launch_vardct_frame(st->plan, st->class_start, st->d_vb_sorted, st->d_large_scratch, (uint8_t *) rgba_dev[i], stride_bytes[i], b->side[i % (size_t) b->side_in_use]);
 		}
-		for (size_t k = 0; k < b->side.size(); ++k) {
+		for (size_t k = 0; k < (size_t) b->side_in_use; ++k) {
 			if (hipEventRecord(b->side_done[k], b->side[k]) != hipSuccess || hipStreamWaitEvent(s, b->side_done[k], 0) != hipSuccess) return ERR_GPU;
 		}
 	}
@@ -819,6 +888,15 @@ extern "C" uint32_t j40hip_frame_decode(j40hip_frame *h, void *rgba_dev, size_t 
 
 extern "C" uint32_t j40hip_frame_decode_timed(j40hip_frame *h, void *rgba_dev, size_t stride_bytes, void *stream, float *ms3) {
 	return guarded([&] { return decode_impl(h, rgba_dev, stride_bytes, (hipStream_t) stream, ms3); });
+}
+
+// The VarDCT status words reduced to the frame's verdict: the first failing section in the order the reference reads them
+static uint32_t vardct_verdict(const j40hip_frame *h, const std::vector<uint32_t> &status) {
+	const Frame &fr = h->frame;
+	if (fr.toc.single) return status.empty() ? 0 : status[0];
+	size_t best = SIZE_MAX; uint32_t code = 0;
+	for (size_t i = 0; i < status.size(); ++i) if (status[i] && fr.toc.pass_groups[i].offset < best) { best = fr.toc.pass_groups[i].offset; code = status[i]; }
+	return code;
 }
 
 static uint32_t j40hip_frame_status_body(j40hip_frame *h) {
@@ -918,7 +996,7 @@ extern "C" uint32_t j40hip_kat_device_srgb_u8(const float *v_host, size_t n, uin
 	float *dv = nullptr; uint8_t *dout = nullptr;
 	bool ok = hipMalloc((void **) &dv, n * 4 + 16) == hipSuccess && hipMalloc((void **) &dout, n + 16) == hipSuccess;
 	ok = ok && hipMemcpy(dv, v_host, n * 4, hipMemcpyHostToDevice) == hipSuccess;
-	if (ok) { upload_constant_tables(half_secants(), afv_basis(), srgb_u8_thresholds(), nullptr); launch_kat_srgb_u8(dv, n, dout, nullptr); }
+	if (ok) { int dev = 0; ok = hipGetDevice(&dev) == hipSuccess && ensure_constant_tables(dev); if (ok) launch_kat_srgb_u8(dv, n, dout, nullptr); }
 	ok = ok && hipMemcpy(out_host, dout, n, hipMemcpyDeviceToHost) == hipSuccess;
 	if (dv) (void) hipFree(dv);
 	if (dout) (void) hipFree(dout);
@@ -933,3 +1011,21 @@ extern "C" uint32_t j40hip_frame_decode_to_host(j40hip_frame *h, void *rgba_host
 extern "C" j40hip_batch *j40hip_batch_create(j40hip_frame *const *frames, int64_t n, uint32_t *err) {
 	try { return batch_create_body(frames, n, err); } catch (const std::exception &) { if (err) *err = ERR_MEM; return nullptr; }
 }
+extern "C" uint32_t j40hip_frame_upload_on(j40hip_frame *h, int device, void *stream) { return guarded([&] { return upload_impl(h, device, (hipStream_t) stream); }); }
+extern "C" void j40hip_thread_release(void) { t_stage.release(); }
+
+// j40hip_frame_status in two halves for pipelines: `begin` enqueues the copy of the status words on `stream` (no host wait),
+// `end` -- after the caller has waited for that stream -- reduces them to the frame's verdict. VarDCT frames without extra
+// channels only (others: ERR_TODO; use j40hip_frame_status).
+extern "C" uint32_t j40hip_frame_status_begin(j40hip_frame *h, void *stream) {
+	if (!h || !h->dev) return ERR_GPU;
+	j40hip_device_state *st = h->dev;
+	if (st->is_modular || st->has_trailers) return ERR_TODO;
+	st->status_host.assign((size_t) st->total_sections, 0);
+	return hipMemcpyAsync(st->status_host.data(), st->plan.status, sizeof(uint32_t) * st->status_host.size(), hipMemcpyDeviceToHost, (hipStream_t) stream) == hipSuccess ? 0 : ERR_GPU;
+}
+extern "C" uint32_t j40hip_frame_status_end(j40hip_frame *h) {
+	if (!h || !h->dev || h->dev->status_host.size() != (size_t) h->dev->total_sections) return ERR_GPU;
+	return vardct_verdict(h, h->dev->status_host);
+}
+extern "C" void j40hip_frame_mark_idle(j40hip_frame *h) { if (h && h->dev) h->dev->idle = true; }
