@@ -1,23 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- Mpixels/s RGBA-u8x4 decode of a synthetic 8K VarDCT (d1-like) frame on MI355X.
+"""bench.py -- Mpixels/s RGBA-u8x4 decode of synthetic 8K VarDCT (d1-like) frames on MI355X.
 
-A *step* is one pass of the hot path over one batch of frames (`--batch`, default 256 per GPU) whose inputs
-(codestreams, code specs, orders, dequant tables, LF bundles) are already resident in HBM: coefficient clear +
-entropy decode of every pass-group section (K1) + dequant / chroma-from-luma / inverse transforms /
-XYB->sRGB / RGBA pack (K2 family). Outputs stay in HBM. Host parsing and PCIe copies are outside the timed
-region. Two launch modes exist: the throughput mode (default; one section per wavefront LANE, every frame of the
-batch in one entropy launch -- 288 GB of HBM hold the working sets of hundreds of 8K frames) and the latency
-mode (`--batch 1`; one section per wavefront, scalarised decoder; reports `e2e_*` fields for a single frame).
-The default run also times one frame in latency mode and reports it as `latency_mode`.
+THE CLOCK. A *step* is one pass of the whole decode path over one batch of `--batch` frames per GPU:
+codestream bytes -> [host: container / headers / TOC / LfGlobal / HfGlobal / LfGroup parse, plan build, plan upload]
+-> [device: entropy decode of every pass-group section (K1), dequantisation + chroma-from-luma + inverse transforms +
+XYB->sRGB + RGBA pack (K2 family)] -> RGBA u8x4 in the j40_pixels_u8x4 layout, resident in HBM. Every stage of many frames
+is in flight at once (j40hip_pipeline_*: host worker threads, batched entropy launches on alternating streams). Nothing is
+parsed, built or uploaded ahead of the timed region: only the codestream BYTES exist when it starts (SURVEY.md section 8d /
+BASELINE.md section 3: the reference's clock runs from "codestream resident in memory", and so does `cpu_baseline`). `value` stops with
+the pixels in HBM -- the memory of the device that computed them, as the reference's clock stops with them in host memory; the
+same pass with the copy back to (pinned) host memory over PCIe is reported beside it as `host_to_host`, and the part round 1
+reported as `value` -- frames parsed and uploaded ahead of time, kernels only -- as `device_resident`.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): frames are independent units, so every
-rank decodes its own frame (weak scaling, no data-path collective); `value` is the whole-job
-aggregate. `--shard-groups` switches to the north star's single-frame sharding (LF bundle broadcast
-from rank 0, pass groups split in row bands, RGBA bands gathered on rank 0 over RCCL).
+The host part runs on the CPU time the container is given (cgroup cpu.max; 16 CPUs on the bench boxes although 256 are visible),
+which is what bounds `value` today; DESIGN.md section 5 has the breakdown.
 
-Prints ONE JSON line on rank 0.
+Also on the line: `roofline` for the dominant kernel (the entropy launch) measured with HIP events on its launch stream inside
+the timed region; `latency_mode` (one frame alone); BASELINE.json's other configurations (`configs`); `cpu_baseline` = the
+unmodified reference on one host core, same stream; `parity_vs_reference` for a frame decoded inside the timed region.
+
+N > 1 (torch.distributed.run, one rank per GPU): frames are independent, every rank runs its own pipeline on its own frames with
+its share of the host CPUs (weak scaling, no data-path collective); `value` is the whole-job aggregate. `--shard-groups` is the
+north star's single-frame sharding (j40_amd/sharding.py). Prints ONE JSON line on rank 0.
 """
 import argparse
+import concurrent.futures
+import ctypes as C
 import json
 import os
 import sys
@@ -27,11 +35,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+METRIC = "Mpixels/s RGBA-u8x4 decode, 8K VarDCT d1"
+
+
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), else the visible CPU count"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            return max(1, int(int(q) / int(p)))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, q // p)
+    except (OSError, ValueError):
+        pass
+    return os.cpu_count() or 1
+
 
 def cpu_baseline(data, width, height, budget_s=12.0):
     """the unmodified reference (oracle/_ref) on ONE host core, same codestream, bounded sample"""
     from refdec import Ref, REF_SO
-    import ctypes as C
     import numpy as np
     if not os.path.exists(REF_SO):
         return None
@@ -49,28 +75,61 @@ def cpu_baseline(data, width, height, budget_s=12.0):
     best = min(times)
     cpu_baseline.last_pixels = out.reshape(height, width, 4)
     return {"value": round(width * height / best / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "reference",
-            "sample": "%d full decodes of the same %dx%d stream through the reference's public API (best of %d, %.2f s each), 1 of %d host cores" % (len(times), width, height, len(times), best, os.cpu_count() or 1)}
+            "sample": "%d full decodes of the same %dx%d stream through the reference's public API, codestream bytes in memory -> RGBA in memory (best of %d, %.2f s each), 1 host core"
+                      % (len(times), width, height, len(times), best)}
+
+
+def synth_many(specs, workers):
+    """generates (or finds in build/streams) the listed streams, `workers` generator processes at a time"""
+    from streams import synth
+    with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, workers)) as ex:
+        return list(ex.map(lambda s: synth(s[0], s[1], s[2], s[3], **s[4]), specs))
+
+
+def run_pipeline_steps(pipe, bufs, sizes, outs, stride, device_output, steps, torch, dev, dist):
+    """`steps` timed steps: every frame of the batch submitted, then drained; returns (elapsed seconds, tickets of the last step)"""
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    pipe.reset_stats()
+    t0 = time.perf_counter()
+    tickets = []
+    for _ in range(steps):
+        tickets = [pipe.submit_raw(bufs[i], sizes[i], outs[i].data_ptr(), stride, device_output) for i in range(len(bufs))]
+        pipe.drain()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, tickets
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--width", type=int, default=7680)
     ap.add_argument("--height", type=int, default=4320)
     ap.add_argument("--seed", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU; > 1 uses the throughput mode (j40hip_batch_*: one section per lane), 1 the latency mode")
-    ap.add_argument("--distinct", type=int, default=4, help="number of distinct streams a batch cycles through")
-    ap.add_argument("--streams", type=int, default=1, help="throughput mode: sub-batches in flight on separate HIP streams")
+    ap.add_argument("--batch", type=int, default=128, help="frames per step per GPU")
+    ap.add_argument("--distinct", type=int, default=64, help="distinct streams a batch cycles through")
+    ap.add_argument("--pipe-batch", type=int, default=128, help="frames per entropy launch inside the pipeline")
+    ap.add_argument("--host-threads", type=int, default=0, help="pipeline worker threads per GPU (default: the container's CPU quota / GPUs)")
+    ap.add_argument("--resident-batch", type=int, default=256, help="frames of the device-resident section (kernels only, as round 1 measured)")
     ap.add_argument("--shard-groups", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-sections", action="store_true", help="only the timed pipeline (no device-resident / latency / other-config sections)")
+    ap.add_argument("--skip-modular", action="store_true", help="leave BASELINE config 4 (16384 x 16384 Modular) out of `configs`")
     args = ap.parse_args()
 
     import torch
     import numpy as np
     import j40_amd
-    from streams import synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -88,114 +147,210 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=dev)
         dist.barrier()
-
-    W, H = args.width, args.height
-    # every rank decodes its own frame (distinct seed) unless the groups of one frame are sharded
-    seed = args.seed if args.shard_groups else args.seed + rank
-    data = synth("vardct", W, H, seed)
-    t0 = time.perf_counter()
-    frame = j40_amd.Frame(data, threads=min(8, os.cpu_count() or 1))
-    t_parse = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    frame.upload(local_rank)
-    t_upload = time.perf_counter() - t0
-    t_upload_again = None
-    if args.batch == 1 and not args.shard_groups:   # what a server pays per new frame: device blocks are recycled (runtime.hip)
-        other = j40_amd.Frame(data, threads=min(8, os.cpu_count() or 1)); other.upload(local_rank); other.close()
-        t0 = time.perf_counter()
-        frame.upload(local_rank)
-        t_upload_again = time.perf_counter() - t0
     if args.shard_groups:
-        return bench_sharded(args, torch, j40_amd, dist, dev, rank, local_rank, world, data)
+        from streams import synth
+        return bench_sharded(args, torch, j40_amd, dist, dev, rank, local_rank, world, synth("vardct", args.width, args.height, args.seed))
 
-    out = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream(dev)
-    sptr = stream.cuda_stream
-    if args.batch > 1:
-        return bench_batch(args, torch, j40_amd, synth, dist, dev, rank, local_rank, world, frame, data, out)
+    W, H, B = args.width, args.height, args.batch
+    quota = cpu_quota()
+    threads = args.host_threads or max(2, quota // world)
+    D = max(1, min(args.distinct, B))
+    # every rank decodes its own frames (distinct seeds)
+    datas = synth_many([("vardct", W, H, args.seed + 1000 * i + 7 * rank, {}) for i in range(D)], max(1, quota // world))
+    bufs = [C.create_string_buffer(d, len(d)) for d in datas]
+    step_bufs = [bufs[i % D] for i in range(B)]
+    step_sizes = [len(datas[i % D]) for i in range(B)]
+    outs = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(B)]
+    pipe = j40_amd.Pipeline(local_rank, threads, min(args.pipe_batch, B), 1)
 
-    for _ in range(args.warmup):
-        frame.decode(out.data_ptr(), W * 4, sptr)
-    torch.cuda.synchronize(dev)
-    assert frame.status() == "", "decode error: " + frame.status()
-
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    k1_ms, k2_ms, misc_ms = [], [], []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ms = frame.decode_timed(out.data_ptr(), W * 4, sptr)   # HIP events on the launch stream
-        k1_ms.append(float(ms[0])); k2_ms.append(float(ms[1])); misc_ms.append(float(ms[2]))
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert frame.status() == ""
-
+    for _ in range(max(args.warmup, 0)):
+        run_pipeline_steps(pipe, step_bufs, step_sizes, outs, W * 4, True, 1, torch, dev, None)
+    elapsed, tickets = run_pipeline_steps(pipe, step_bufs, step_sizes, outs, W * 4, True, args.steps, torch, dev, dist)
+    st = pipe.stats()
+    for t in tickets:
+        assert pipe.result(t) == "", "decode error: " + pipe.result(t)
     if rank != 0:
+        pipe.close()
         return
-    frames_total = args.steps * world
+
+    frames_total = B * args.steps * world
     value = W * H * frames_total / elapsed / 1e6
-    # roofline of the dominant kernel (K1, entropy decode): algorithmic bytes of the whole path per
-    # frame = RGBA written + codestream read, over K1's average launch time
-    alg_bytes = 4 * W * H + len(data)
-    k1 = sum(k1_ms) / len(k1_ms) / 1e3
-    achieved = alg_bytes / k1 / 1e9
-    # end to end for one frame: host parse + upload + decode + copy back (not the headline)
-    t0 = time.perf_counter()
-    frame.decode(out.data_ptr(), W * 4, sptr)
-    host = out.cpu()
-    t_e2e_tail = time.perf_counter() - t0
+    alg_step = sum(4 * W * H + s for s in step_sizes)            # algorithmic bytes of one step on one GPU: RGBA written + codestream read
+    launches = max(st["launches"], 1)
+    k1_launch_ms = st["k1_ms"] / launches
+    frames_per_launch = st["launch_frames"] / launches
+    alg_launch = alg_step * frames_per_launch / B
+    achieved = alg_launch / (k1_launch_ms / 1e3) / 1e9 if k1_launch_ms > 0 else 0.0
     result = {
-        "metric": "Mpixels/s RGBA-u8x4 decode, 8K VarDCT d1",
-        "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%dx%d VarDCT d1-like synthetic frame (tools/jxlsynth seed %d, %.3f bpp, %d pass groups), one frame per GPU per step, inputs resident in HBM" % (W, H, args.seed, 8.0 * len(data) / (W * H), frame.info["num_groups"]),
-                   "frame_pixels": W * H, "codestream_bytes": len(data), "parallelism": "frames x%d" % world},
+        "metric": METRIC, "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%d x %dx%d VarDCT d1-like synthetic frames per GPU per step (tools/jxlsynth, %d distinct streams, %.3f bpp, %d pass groups each), whole decode "
+                               "path per frame inside the timed region: host parse + plan build + plan upload on %d worker threads (container CPU quota %d of %d visible CPUs) "
+                               "pipelined with batched entropy + pixel kernels (%d frames per entropy launch); codestream bytes in, RGBA u8x4 resident in HBM out"
+                               % (B, W, H, D, 8.0 * sum(step_sizes) / (B * W * H), ((W + 255) // 256) * ((H + 255) // 256), threads, quota, os.cpu_count() or 1, min(args.pipe_batch, B)),
+                   "clock": "codestream bytes in memory -> RGBA u8x4 in device memory, nothing prepared ahead (SURVEY 8d); same start as cpu_baseline, which ends in host memory",
+                   "frame_pixels": W * H, "frames_per_step": B, "codestream_bytes": step_sizes[0], "parallelism": "frames x%d" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": None,
-                     "kernel": "k_hf_entropy", "kernel_ms": round(k1 * 1e3, 4), "algorithmic_bytes_per_launch": alg_bytes},
-        "kernels_ms": {"k_hf_entropy": round(k1 * 1e3, 4), "vardct_to_rgba_kernels": round(sum(k2_ms) / len(k2_ms), 4), "clear_coefficients": round(sum(misc_ms) / len(misc_ms), 4)},
-        "e2e": {"host_parse_ms": round(t_parse * 1e3, 2), "plan_upload_first_ms": round(t_upload * 1e3, 2), "plan_upload_recycled_ms": round(t_upload_again * 1e3, 2),
-                "decode_plus_copy_back_ms": round(t_e2e_tail * 1e3, 2), "mpixels_per_s": round(W * H / (t_parse + t_upload_again + t_e2e_tail) / 1e6, 2)},
+                     "kernel": "k_hf_lanes", "kernel_ms": round(k1_launch_ms, 4), "launches_in_timed_region": st["launches"], "frames_per_launch": round(frames_per_launch, 2),
+                     "algorithmic_bytes_per_launch": int(alg_launch),
+                     "step_frac": round(alg_step * args.steps / elapsed / 8e12, 6),
+                     "note": "HIP events on the launch streams inside the timed region (pipeline stats); step_frac = algorithmic bytes of the steps / wall time / peak"},
+        "pipeline": {"host_parse_ms_per_frame": round(st["parse_thread_ms"] / max(st["completed"], 1), 2), "plan_build_upload_ms_per_frame": round(st["upload_thread_ms"] / max(st["completed"], 1), 2),
+                     "entropy_ms_per_launch": round(k1_launch_ms, 3), "pixel_kernels_ms_per_launch": round(st["k2_ms"] / launches, 3), "host_threads": threads, "cpu_quota": quota},
     }
-    if not args.no_cpu_baseline:
-        cb = cpu_baseline(data, W, H)
+    try:
+        pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if abs(pt.get("frames_per_launch", 0) - frames_per_launch) < 1 and (W, H) == (7680, 4320):
+            result["roofline"]["traffic"] = int((pt["fetch_size_kb"] + pt["write_size_kb"]) * 1000)
+            result["roofline"]["traffic_source"] = pt["source"]
+    except (OSError, ValueError, KeyError):
+        pass
+
+    # parity at the full size: a frame decoded inside the timed region against the reference's pixels (bar: 1 level)
+    if not args.no_cpu_baseline and world == 1:
+        cb = cpu_baseline(datas[0], W, H)
         if cb:
             result["cpu_baseline"] = cb
-    del host
+            d = np.abs(outs[0].cpu().numpy().astype(np.int16) - cpu_baseline.last_pixels.astype(np.int16))
+            result["parity_vs_reference"] = {"max_abs_diff": int(d.max()), "differing_samples": int((d > 0).sum()), "samples": int(d.size)}
+            assert d.max() <= 1, "GPU and reference pixels differ by more than one level"
+
+    if not args.skip_sections and world == 1:
+        # ---- the same steps with the copy back to pinned host memory (the reference's own end point) ----
+        nb = min(B, 32)
+        host_outs = [torch.empty((H, W, 4), dtype=torch.uint8).pin_memory() for _ in range(nb)]
+        run_pipeline_steps(pipe, step_bufs[:nb], step_sizes[:nb], host_outs, W * 4, False, 1, torch, dev, None)
+        e2, tk = run_pipeline_steps(pipe, step_bufs[:nb], step_sizes[:nb], host_outs, W * 4, False, 2, torch, dev, None)
+        assert all(pipe.result(t) == "" for t in tk)
+        assert torch.equal(host_outs[0], outs[0].cpu())
+        result["host_to_host"] = {"value": round(W * H * nb * 2 / e2 / 1e6, 2), "unit": "Mpixels/s", "frames_per_step": nb, "steps": 2,
+                                  "note": "as `value`, plus the copy back into pinned host memory on the batch's stream (PCIe Gen5 x16: 4 B/px is the floor: ~0.53 ms per Mpx at 63 GB/s)"}
+        del host_outs
+        pipe.close()
+        del outs
+        torch.cuda.empty_cache()
+        result.update(sections(args, torch, np, j40_amd, dev, local_rank, datas, quota))
+    else:
+        pipe.close()
     print(json.dumps(result))
 
 
+def sections(args, torch, np, j40_amd, dev, local_rank, datas, quota):
+    """the figures beside `value`: kernels only on frames prepared ahead (round 1's measure), one frame alone, BASELINE's other configs"""
+    from streams import synth
+    W, H = args.width, args.height
+    out = {}
+    main = torch.cuda.current_stream(dev)
+    # ---- device-resident: R frames parsed and uploaded ahead of time, one entropy launch per step ----
+    R = max(1, args.resident_batch)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, quota)) as ex:
+        frames = list(ex.map(lambda i: j40_amd.Frame(datas[i % len(datas)], threads=1), range(R)))
+    for fr in frames:
+        fr.upload(local_rank)
+    routs = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(R)]
+    batch = j40_amd.Batch(frames)
+    ptrs, strides = [o.data_ptr() for o in routs], [W * 4] * R
+    batch.decode_recorded(ptrs, strides, main.cuda_stream, 0)
+    torch.cuda.synchronize(dev)
+    steps = 5
+    t0 = time.perf_counter()
+    for s in range(steps):
+        batch.decode_recorded(ptrs, strides, main.cuda_stream, s)
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    for fr in frames:
+        assert fr.status() == ""
+    k1 = [batch.elapsed(s)[0] for s in range(steps)]; k2 = [batch.elapsed(s)[1] for s in range(steps)]
+    alg = sum(4 * W * H + len(datas[i % len(datas)]) for i in range(R))
+    k1ms = sum(k1) / steps
+    out["device_resident"] = {"value": round(W * H * R * steps / el / 1e6, 2), "unit": "Mpixels/s", "frames_per_step": R, "steps": steps, "ms_per_step": round(el / steps * 1e3, 3),
+                              "k_hf_lanes_ms": round(k1ms, 3), "pixel_kernels_ms": round(sum(k2) / steps, 3),
+                              "roofline_frac_k_hf_lanes": round(alg / (k1ms / 1e3) / 8e12, 6), "roofline_frac_step": round(alg * steps / el / 8e12, 6),
+                              "note": "frames parsed, planned and uploaded before the clock starts; kernels only (what round 1 reported as value)"}
+    # ---- one frame alone, latency mode (one section per wavefront) ----
+    lat = [frames[0].decode_timed(routs[0].data_ptr(), W * 4, main.cuda_stream) for _ in range(3)]
+    out["latency_mode"] = {"frame_ms": round(float(min(sum(map(float, m)) for m in lat)), 3), "k_hf_entropy_ms": round(float(min(float(m[0]) for m in lat)), 3),
+                           "mpixels_per_s": round(W * H / min(sum(map(float, m)) for m in lat) / 1e3, 1)}
+    t0 = time.perf_counter()
+    err, px = j40_amd.decode(datas[0])
+    out["latency_mode"]["public_api_from_memory_to_host_pixels_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+    assert err == ""
+    batch.close()
+    for fr in frames:
+        fr.close()
+    del routs, frames
+    torch.cuda.empty_cache()
+
+    # ---- BASELINE.json's other configurations ----
+    cfg = {}
+    d4k = synth("vardct", 3840, 2160, 102)
+    fr = j40_amd.Frame(d4k, threads=min(8, quota)); fr.upload(local_rank)
+    o = torch.empty((2160, 3840, 4), dtype=torch.uint8, device=dev)
+    ms = min((fr.decode_timed(o.data_ptr(), 3840 * 4, main.cuda_stream) for _ in range(3)), key=lambda m: float(sum(m)))
+    cfg["config2_3840x2160_one_gpu"] = {"frame_ms": round(float(sum(ms)), 3), "entropy_ms": round(float(ms[0]), 3), "pixel_kernels_ms": round(float(ms[1]), 3),
+                                        "mpixels_per_s": round(3840 * 2160 / float(sum(ms)) / 1e3, 1), "mode": "latency (one frame alone, device time)"}
+    fr.close()
+    # config 5: 1024 independent 1920x1080 frames through the pipeline
+    n5, d5 = 1024, 16
+    d1080 = synth_many([("vardct", 1920, 1080, 110 + i, {}) for i in range(d5)], quota)
+    b1080 = [C.create_string_buffer(d, len(d)) for d in d1080]
+    o5 = [torch.empty((1080, 1920, 4), dtype=torch.uint8, device=dev) for _ in range(n5)]
+    pipe = j40_amd.Pipeline(local_rank, max(2, quota), 256, 1)
+    bb = [b1080[i % d5] for i in range(n5)]; ss = [len(d1080[i % d5]) for i in range(n5)]
+    run_pipeline_steps(pipe, bb[:256], ss[:256], o5[:256], 1920 * 4, True, 1, torch, dev, None)
+    e5, tk = run_pipeline_steps(pipe, bb, ss, o5, 1920 * 4, True, 1, torch, dev, None)
+    assert all(pipe.result(t) == "" for t in tk)
+    st = pipe.stats()
+    cfg["config5_1024x_1920x1080_batch"] = {"mpixels_per_s": round(1920 * 1080 * n5 / e5 / 1e6, 1), "seconds": round(e5, 3), "frames": n5, "distinct_streams": d5,
+                                            "entropy_ms_per_launch": round(st["k1_ms"] / max(st["launches"], 1), 3), "frames_per_launch": round(st["launch_frames"] / max(st["launches"], 1), 1),
+                                            "mode": "pipeline (whole path per frame, output in HBM); 256 frames per entropy launch instead of one hipStream per frame"}
+    pipe.close()
+    del o5
+    torch.cuda.empty_cache()
+    # config 1: 256x256 RGBA fjxl-like, single section
+    d1 = synth("modular", 256, 256, 101, alpha=1, prefix=1, lz77=1)
+    fr = j40_amd.Frame(d1); fr.upload(local_rank)
+    o = torch.empty((256, 256, 4), dtype=torch.uint8, device=dev)
+    ms = min((fr.decode_timed(o.data_ptr(), 256 * 4, main.cuda_stream) for _ in range(2)), key=lambda m: float(sum(m)))
+    cfg["config1_256x256_modular_single_section"] = {"frame_ms": round(float(sum(ms)), 3), "mpixels_per_s": round(256 * 256 / float(sum(ms)) / 1e3, 2),
+                                                     "note": "one sequential stream: bound by the serial latency of one wavefront; the reference's single core is faster here"}
+    fr.close()
+    if not args.skip_modular:
+        for key, opts in (("config4_16384x16384_modular_rct_only (reference-pinned)", dict(tree=1, repeat=16)),
+                          ("config4_16384x16384_modular_squeeze_and_rct (round-trip-pinned, PARITY UNPINNED vs libjxl)", dict(tree=1, repeat=16, squeeze=1))):
+            d = synth("modular", 16384, 16384, 21, **opts)
+            fr = j40_amd.Frame(d); fr.upload(local_rank)
+            o = torch.empty((16384, 16384, 4), dtype=torch.uint8, device=dev)
+            ms = fr.decode_timed(o.data_ptr(), 16384 * 4, main.cuda_stream)
+            torch.cuda.synchronize(dev)
+            assert fr.status() == ""
+            cfg[key] = {"frame_ms": round(float(sum(ms)), 2), "sections_ms": round(float(ms[0]), 2), "inverse_transforms_and_pack_ms": round(float(ms[1]), 2),
+                        "mpixels_per_s": round(16384 * 16384 / float(sum(ms)) / 1e3, 1), "codestream_mb": round(len(d) / 1e6, 1)}
+            fr.close()
+            del o
+            torch.cuda.empty_cache()
+    out["configs"] = cfg
+    return out
+
+
 def bench_sharded(args, torch, j40_amd, dist, dev, rank, local_rank, world, data):
-    """the north star's single-frame mode: every step decodes ONE frame whose pass groups are split in row bands over the
-    ranks (j40_amd.sharding): codestream broadcast from rank 0, per-rank partial decode, RGBA bands gathered on rank 0
-    over RCCL. Strong scaling of a latency-bound step: see DESIGN.md section 6 for why this does not speed a frame up."""
+    """the north star's single-frame mode: every step decodes ONE frame whose pass groups are split over the ranks in contiguous
+    ranges balanced by section bytes (j40_amd.sharding): codestream broadcast from rank 0, per-rank partial decode, the pixel
+    rows of every rank's groups sent to rank 0 over RCCL. Strong scaling of a latency-bound step: DESIGN.md section 6."""
     from j40_amd import sharding
     W, H = args.width, args.height
-    if dist is not None:
-        data = sharding.broadcast_bytes(data, dist, dev)
-    frame = j40_amd.Frame(data, threads=min(8, os.cpu_count() or 1))
-    frame.upload(local_rank)
-    first, count, y0, y1 = sharding.rank_share(W, H, frame.info["group_size_shift"], world, rank)
-    frame.set_group_range(first, count)
-    full = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
-    sptr = torch.cuda.current_stream(dev).cuda_stream
+    decode = sharding.hip_range_decoder(local_rank)
 
     def step():
-        if count:
-            frame.decode(full.data_ptr(), W * 4, sptr)
-        return sharding.gather_bands(full[y0:y1], W, H, frame.info["group_size_shift"], dist) if dist is not None else full
+        if dist is not None:
+            return sharding.decode_sharded(data if rank == 0 else b"", dist, decode, dev)
+        err, full, _, _ = decode(data, 0, 1)
+        assert err == "", err
+        return full
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
-    assert frame.status() == ""
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -213,114 +368,11 @@ def bench_sharded(args, torch, j40_amd, dist, dev, rank, local_rank, world, data
     if rank != 0:
         return
     print(json.dumps({
-        "metric": "Mpixels/s RGBA-u8x4 decode, 8K VarDCT d1", "value": round(W * H * args.steps / elapsed / 1e6, 2), "unit": "Mpixels/s", "n_gpus": world,
+        "metric": METRIC, "value": round(W * H * args.steps / elapsed / 1e6, 2), "unit": "Mpixels/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "one %dx%d VarDCT d1-like synthetic frame per step, pass groups split in %d row bands, RGBA gathered on rank 0" % (W, H, world),
-                   "frame_pixels": W * H, "codestream_bytes": len(data), "parallelism": "group rows x%d" % world}}))
-
-
-def bench_batch(args, torch, j40_amd, synth, dist, dev, rank, local_rank, world, frame0, data0, out0):
-    """throughput mode. A step decodes `--batch` frames; they are organised as `--streams` sub-batches, each with its
-    own HIP stream, launched back to back so that one sub-batch's entropy kernel (latency bound, few issue slots)
-    overlaps the pixel kernels (VALU bound) of another. Every launch is measured with HIP events on its own stream."""
-    W, H, B, S = args.width, args.height, args.batch, max(1, min(args.streams, args.batch))
-    datas = [data0] + [synth("vardct", W, H, args.seed + 1000 * (i + 1) + rank) for i in range(min(args.distinct, B) - 1)]
-    frames, outs = [frame0], [out0]
-    for i in range(1, B):
-        fr = j40_amd.Frame(datas[i % len(datas)], threads=min(8, os.cpu_count() or 1))
-        fr.upload(local_rank)
-        frames.append(fr)
-        outs.append(torch.empty((H, W, 4), dtype=torch.uint8, device=dev))
-    subs = []
-    for k in range(S):
-        idx = list(range(k, B, S))
-        subs.append({"batch": j40_amd.Batch([frames[i] for i in idx]), "ptrs": [outs[i].data_ptr() for i in idx], "strides": [W * 4] * len(idx),
-                     "stream": torch.cuda.Stream(device=dev), "n": len(idx)})
-    main = torch.cuda.current_stream(dev)
-
-    def run_step(slot, stagger=False):
-        for k, sb in enumerate(subs):
-            if stagger and k > 0:   # start one entropy launch behind the previous sub-batch: from then on the streams stay out of phase
-                subs[k - 1]["batch"].wait_stage(slot, 2, sb["stream"].cuda_stream)
-            sb["batch"].decode_recorded(sb["ptrs"], sb["strides"], sb["stream"].cuda_stream, slot)
-
-    for w in range(max(args.warmup, 1)):
-        run_step(0, stagger=(w == 0))
-    torch.cuda.synchronize(dev)
-    for fr in frames:
-        assert fr.status() == "", "decode error: " + fr.status()
-    # the batch path must give the pixels of the single-frame path
-    check = torch.empty_like(out0)
-    frame0.decode(check.data_ptr(), W * 4, main.cuda_stream)
-    torch.cuda.synchronize(dev)
-    assert torch.equal(check, out0), "batch and single-frame decodes differ"
-    del check
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for step in range(args.steps):
-        run_step(step)
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    for fr in frames:
-        assert fr.status() == "", "decode error: " + fr.status()
-    if rank != 0:
-        return
-    # dominant kernel: the entropy launch of a sub-batch; average duration and algorithmic bytes per launch
-    k1_ms, k2_ms, misc_ms = [], [], []
-    for step in range(args.steps):
-        for sb in subs:
-            a, b_, c = sb["batch"].elapsed(step)
-            k1_ms.append(a); k2_ms.append(b_); misc_ms.append(c)
-    value = W * H * B * args.steps * world / elapsed / 1e6
-    alg_total = sum(4 * W * H + len(datas[i % len(datas)]) for i in range(B))
-    alg_per_launch = alg_total / S
-    k1 = sum(k1_ms) / len(k1_ms) / 1e3
-    achieved = alg_per_launch / k1 / 1e9
-    result = {
-        "metric": "Mpixels/s RGBA-u8x4 decode, 8K VarDCT d1",
-        "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%d x %dx%d VarDCT d1-like synthetic frames per GPU per step (tools/jxlsynth, %d distinct streams, %.3f bpp, %d pass groups each), throughput mode: %d sub-batches on their own HIP streams, inputs resident in HBM"
-                               % (B, W, H, len(datas), 8.0 * len(data0) / (W * H), frame0.info["num_groups"], S),
-                   "frame_pixels": W * H, "frames_per_step": B, "streams": S, "codestream_bytes": len(data0), "parallelism": "frames x%d" % world},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": None,
-                     "kernel": "k_hf_lanes", "kernel_ms": round(k1 * 1e3, 4), "launches_per_step": S, "algorithmic_bytes_per_launch": int(alg_per_launch)},
-        "kernels_ms": {"k_hf_lanes (per launch, %d frames)" % subs[0]["n"]: round(k1 * 1e3, 4), "vardct_to_rgba_kernels (per sub-batch)": round(sum(k2_ms) / len(k2_ms), 4),
-                       "clear_coefficients (per sub-batch)": round(sum(misc_ms) / len(misc_ms), 4)},
-    }
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure comes from the
-    # committed rocprofv3 passes of this same command (profiles/pmc_traffic.json) and is only reported for a matching launch
-    try:
-        pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if pt.get("frames_per_launch") == subs[0]["n"] and (W, H) == (7680, 4320):
-            result["roofline"]["traffic"] = int((pt["fetch_size_kb"] + pt["write_size_kb"]) * 1000)
-            result["roofline"]["traffic_source"] = pt["source"]
-    except (OSError, ValueError, KeyError):
-        pass
-    # the same frame alone, latency mode (one section per wavefront)
-    lat = [frame0.decode_timed(out0.data_ptr(), W * 4, main.cuda_stream) for _ in range(3)]
-    result["latency_mode"] = {"frame_ms": round(float(min(sum(map(float, m)) for m in lat)), 3), "k_hf_entropy_ms": round(float(min(float(m[0]) for m in lat)), 3),
-                              "mpixels_per_s": round(W * H / min(sum(map(float, m)) for m in lat) / 1e3, 1)}
-    if not args.no_cpu_baseline:
-        cb = cpu_baseline(data0, W, H)
-        if cb:
-            result["cpu_baseline"] = cb
-            # parity at the full size: the frame the batch decoded against the reference's pixels (bar: 1 level)
-            import numpy as np
-            d = np.abs(out0.cpu().numpy().astype(np.int16) - cpu_baseline.last_pixels.astype(np.int16))
-            result["parity_vs_reference"] = {"max_abs_diff": int(d.max()), "differing_samples": int((d > 0).sum()), "samples": int(d.size)}
-            assert d.max() <= 1, "GPU and reference pixels differ by more than one level"
-    print(json.dumps(result))
+        "config": {"workload": "one %dx%d VarDCT d1-like synthetic frame per step, pass groups split over %d ranks (contiguous ranges balanced by section bytes), RGBA gathered on rank 0" % (W, H, world),
+                   "frame_pixels": W * H, "codestream_bytes": len(data), "parallelism": "pass groups x%d" % world}}))
 
 
 if __name__ == "__main__":

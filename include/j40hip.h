@@ -40,6 +40,8 @@ J40HIP_API void j40hip_frame_info(const j40hip_frame *f, int64_t *out);
 /* bytes of the (re-assembled) codestream and number of pass-group sections */
 J40HIP_API size_t j40hip_frame_codestream_size(const j40hip_frame *f);
 J40HIP_API int64_t j40hip_frame_num_sections(const j40hip_frame *f);
+/* bytes of every pass-group section as the TOC lists them (j40.h:5529), pass-major; out may be NULL; returns how many */
+J40HIP_API int64_t j40hip_frame_section_sizes(const j40hip_frame *f, int64_t *out);
 
 /* stage accessors for parity tests (mirror j40__lf_group_st, j40.h:6360-6390) */
 J40HIP_API void j40hip_frame_lf_group_info(const j40hip_frame *f, int64_t gg, int32_t *out9);
@@ -265,8 +267,10 @@ J40HIP_API uint32_t j40hip_pipeline_submit(j40hip_pipeline *p, const void *buf, 
 J40HIP_API uint32_t j40hip_pipeline_drain(j40hip_pipeline *p);
 /* 0 or the image's 4-char error code, as j40_error would give it ("rnge" for an unknown or unfinished ticket) */
 J40HIP_API uint32_t j40hip_pipeline_result(j40hip_pipeline *p, int64_t ticket);
-/* out4: parse ms and plan-build + upload ms summed over the worker threads, images completed, ms from first submit to last completion */
-J40HIP_API void j40hip_pipeline_stats(j40hip_pipeline *p, double *out4);
+/* out8: [0] parse ms and [1] plan-build + upload ms summed over the worker threads, [2] images completed, [3] ms from first submit to
+ * last completion, [4] entropy-stage and [5] pixel-stage ms summed over the batch launches (HIP events on their streams), [6] batch
+ * launches, [7] images in them */
+J40HIP_API void j40hip_pipeline_stats(j40hip_pipeline *p, double *out8);
 J40HIP_API void j40hip_pipeline_reset_stats(j40hip_pipeline *p);
 
 #ifdef __cplusplus

@@ -89,7 +89,7 @@ def lib():
         "j40hip_batch_create": (vp, [vp, i64, C.POINTER(u32)]), "j40hip_batch_free": (None, [vp]),
         "j40hip_batch_decode": (u32, [vp, vp, vp, vp]), "j40hip_batch_decode_timed": (u32, [vp, vp, vp, vp, vp]),
         "j40hip_batch_decode_recorded": (u32, [vp, vp, vp, vp, i32]), "j40hip_batch_elapsed": (u32, [vp, i32, vp]), "j40hip_batch_wait_stage": (u32, [vp, i32, i32, vp]),
-        "j40hip_batch_reset": (u32, [vp, vp, i64]),
+        "j40hip_batch_reset": (u32, [vp, vp, i64]), "j40hip_frame_section_sizes": (i64, [vp, vp]),
         "j40hip_frame_upload_on": (u32, [vp, C.c_int, vp]), "j40hip_thread_release": (None, []),
         "j40hip_frame_status_begin": (u32, [vp, vp]), "j40hip_frame_status_end": (u32, [vp]), "j40hip_frame_mark_idle": (None, [vp]),
         "j40hip_frame_after_frame_status": (u32, [vp]),
@@ -213,6 +213,13 @@ class Frame:
     def force_dense(self, dense=True):
         """dense coefficient planes instead of event lists for the next upload (what the library does by itself after "evof")"""
         lib().j40hip_frame_force_dense(self.h, 1 if dense else 0)
+
+    def section_sizes(self):
+        """bytes of every pass-group section (pass-major), from the TOC"""
+        n = lib().j40hip_frame_section_sizes(self.h, None)
+        a = np.zeros(n, np.int64)
+        lib().j40hip_frame_section_sizes(self.h, a.ctypes.data)
+        return a
 
     def set_group_range(self, first, count):
         self._chk(lib().j40hip_frame_set_group_range(self.h, first, count), "in j40hip_frame_set_group_range")
@@ -374,6 +381,14 @@ class Pipeline:
             raise J40Error(err4(code), "in j40hip_pipeline_submit")
         return t.value
 
+    def submit_raw(self, buf, size, rgba_ptr, stride_bytes, device_output=False):
+        """as submit, for a ctypes buffer the caller keeps alive until the ticket is done"""
+        t = C.c_int64()
+        code = lib().j40hip_pipeline_submit(self.h, buf, size, rgba_ptr, stride_bytes, 1 if device_output else 0, C.byref(t))
+        if code:
+            raise J40Error(err4(code), "in j40hip_pipeline_submit")
+        return t.value
+
     def drain(self):
         code = lib().j40hip_pipeline_drain(self.h)
         if code:
@@ -384,9 +399,9 @@ class Pipeline:
         return err4(lib().j40hip_pipeline_result(self.h, ticket))
 
     def stats(self):
-        a = (C.c_double * 4)()
+        a = (C.c_double * 8)()
         lib().j40hip_pipeline_stats(self.h, a)
-        return dict(parse_thread_ms=a[0], upload_thread_ms=a[1], completed=int(a[2]), wall_ms=a[3])
+        return dict(parse_thread_ms=a[0], upload_thread_ms=a[1], completed=int(a[2]), wall_ms=a[3], k1_ms=a[4], k2_ms=a[5], launches=int(a[6]), launch_frames=int(a[7]))
 
     def reset_stats(self):
         lib().j40hip_pipeline_reset_stats(self.h)

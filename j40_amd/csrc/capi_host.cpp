@@ -137,6 +137,13 @@ void j40hip_frame_info(const j40hip_frame *h, int64_t *out) {
 
 size_t j40hip_frame_codestream_size(const j40hip_frame *h) { return h->cs_size; }
 int64_t j40hip_frame_num_sections(const j40hip_frame *h) { return h->frame.toc.single ? 1 : (int64_t) h->frame.toc.pass_groups.size(); }
+// bytes of every pass-group section as the TOC lists them (j40.h:5529), pass-major; returns how many
+int64_t j40hip_frame_section_sizes(const j40hip_frame *h, int64_t *out) {
+	if (h->frame.toc.single) { if (out) out[0] = (int64_t) h->frame.toc.single_section.size; return 1; }
+	const std::vector<Section> &pg = h->frame.toc.pass_groups;
+	if (out) for (size_t i = 0; i < pg.size(); ++i) out[i] = (int64_t) pg[i].size;
+	return (int64_t) pg.size();
+}
 
 void j40hip_frame_lf_group_info(const j40hip_frame *h, int64_t gg, int32_t *out) {
 	const LfGroup &g = h->frame.lf_groups[(size_t) gg];

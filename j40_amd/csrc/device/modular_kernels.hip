@@ -61,6 +61,19 @@ __global__ void __launch_bounds__(64) k_modular_sections(DevModPlan plan, int32_
 	if (lane == 0) plan.status[s] = err;
 }
 
+// K3, throughput form: one section per LANE (64 sections per wavefront), the generic per-lane decoder with every table in
+// HBM / L2. The lanes of a wavefront sit at different tree nodes and predictors, so the wavefront walks the union of their
+// paths; what it buys is 64 sections per wavefront instead of one, i.e. frames with thousands of sections (or batches of
+// LfGroup streams) fill the machine. Selected by the host when sections >> wave slots (launch_modular_sections).
+__global__ void __launch_bounds__(64) k_modular_sections_lanes(DevModPlan plan, int32_t first_section, int32_t num_sections) {
+	const int32_t s = first_section + (int32_t) (blockIdx.x * 64 + threadIdx.x);
+	if (s >= first_section + num_sections) return;
+	const DevModSection &msec = plan.sections[s];
+	if (msec.preset_status) { plan.status[s] = msec.preset_status; return; }
+	const ModTables t = mod_tables_in_hbm(plan, s);
+	plan.status[s] = decode_modular_section<false, false>(plan, t, s);
+}
+
 // one workgroup per section that lists transforms of its own; runs after K3 (kernel boundary = the planes are visible)
 __global__ void __launch_bounds__(256) k_section_inverse_rcts(DevModPlan plan, int32_t first_section) {
 	section_inverse_rcts(plan, first_section + (int32_t) blockIdx.x, (int32_t) threadIdx.x, 256);
@@ -186,6 +199,11 @@ void launch_modular_sections(const DevModPlan &plan, int32_t first_section, int3
 	const uint32_t wp_bytes = info.uses_wp ? align16(40u * (uint32_t) info.max_width) : 0;
 	const uint32_t lds = align16((uint32_t) info.num_tree_nodes * (uint32_t) sizeof(DevTreeNode)) + align16((uint32_t) info.num_dist + 4)
 		+ align16((uint32_t) info.num_clusters * (uint32_t) sizeof(DevCluster)) + align16(info.table_bytes) + align16(12u * (uint32_t) (info.max_width + 4)) + wp_bytes + 64;
+	static const int lanes_mode = [] { const char *e = getenv("J40HIP_K3_LANES"); return e ? atoi(e) : 0; }();
+	if (lanes_mode == 1 || (lanes_mode == 2 && num_sections >= 1024)) {
+		hipLaunchKernelGGL(k_modular_sections_lanes, dim3((unsigned) ((num_sections + 63) / 64)), dim3(64), 0, stream, plan, first_section, num_sections);
+		return;
+	}
 	if (lds <= 156u * 1024u) {
 		static bool configured = false;
 		if (!configured) { (void) hipFuncSetAttribute((const void *) k_modular_sections<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); configured = true; }

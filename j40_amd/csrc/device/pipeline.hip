@@ -50,6 +50,7 @@ struct Slot {                     // one batch in flight
 	hipEvent_t done = nullptr;
 	j40hip_batch *batch = nullptr;
 	std::vector<Job *> jobs;
+	int64_t batched = 0;          // members of the batch launch (jobs minus the single-frame ones)
 	bool busy = false;
 };
 
@@ -71,6 +72,7 @@ struct j40hip_pipeline {
 	// device images for host output, recycled by size
 	std::vector<std::pair<void *, size_t>> free_images;
 	double parse_ms = 0, upload_ms = 0;  // summed over the worker threads
+	double k1_ms = 0, k2_ms = 0; int64_t launches = 0, launch_frames = 0;   // HIP-event durations of the batches' entropy / pixel stages
 	double first_submit_ms = 0, last_done_ms = 0;
 	std::atomic<int> worker_errors{0};
 };
@@ -157,6 +159,8 @@ uint32_t decode_single(j40hip_pipeline *p, Job *j, hipStream_t s) {
 
 void retire(j40hip_pipeline *p, Slot &slot) {   // GPU thread; waits for the slot's work, then hands the results out
 	const bool ok = hipEventSynchronize(slot.done) == hipSuccess;
+	float ms3[3] = {0, 0, 0};
+	const bool timed = ok && slot.batch && slot.batched > 0 && j40hip_batch_elapsed(slot.batch, 0, ms3) == 0;
 	for (Job *j : slot.jobs) {
 		if (!ok) j->status = E_GPU;
 		else if (!j->single) {
@@ -169,6 +173,7 @@ void retire(j40hip_pipeline *p, Slot &slot) {   // GPU thread; waits for the slo
 		if (!j->device_output && j->dev_rgba) p->free_images.push_back({j->dev_rgba, j->stride * (size_t) j->height});
 	}
 	std::unique_lock<std::mutex> lock(p->m);
+	if (timed) { p->k1_ms += ms3[0]; p->k2_ms += ms3[1]; ++p->launches; p->launch_frames += slot.batched; }
 	for (Job *j : slot.jobs) { --p->resident; complete(p, j); }
 	slot.jobs.clear(); slot.busy = false;
 	p->cv_todo.notify_all();
@@ -199,7 +204,7 @@ void gpu_main(j40hip_pipeline *p) {
 		int si = -1;
 		for (size_t i = 0; i < p->slots.size(); ++i) if (!p->slots[i].busy) { si = (int) i; break; }
 		Slot &slot = p->slots[(size_t) si];
-		slot.busy = true; slot.jobs = take;
+		slot.busy = true; slot.jobs = take; slot.batched = 0;
 		std::vector<j40hip_frame *> frames; std::vector<void *> outs; std::vector<size_t> strides;
 		uint32_t err = 0;
 		for (Job *j : take) {
@@ -208,9 +213,10 @@ void gpu_main(j40hip_pipeline *p) {
 			if (!j->single) { frames.push_back(j->frame); outs.push_back(j->dev_rgba); strides.push_back(j->stride); }
 		}
 		if (!err && !frames.empty()) {
+			slot.batched = (int64_t) frames.size();
 			if (!slot.batch) slot.batch = j40hip_batch_create(frames.data(), (int64_t) frames.size(), &err);
 			else err = j40hip_batch_reset(slot.batch, frames.data(), (int64_t) frames.size());
-			if (!err) err = j40hip_batch_decode(slot.batch, outs.data(), strides.data(), slot.stream);
+			if (!err) err = j40hip_batch_decode_recorded(slot.batch, outs.data(), strides.data(), slot.stream, 0);
 			for (Job *j : take) if (!err && !j->single) {
 				err = j40hip_frame_status_begin(j->frame, slot.stream);
 				if (!err && !j->device_output && hipMemcpyAsync(j->rgba, j->dev_rgba, j->stride * (size_t) j->height, hipMemcpyDeviceToHost, slot.stream) != hipSuccess) err = E_GPU;
@@ -306,17 +312,20 @@ uint32_t j40hip_pipeline_result(j40hip_pipeline *p, int64_t ticket) {
 }
 
 /* out[0] = parse ms summed over the worker threads, out[1] = plan build + upload ms summed, out[2] = frames completed,
- * out[3] = ms from the first submit to the last completion */
+ * out[3] = ms from the first submit to the last completion, out[4] / out[5] = entropy / pixel stage ms summed over the batch launches
+ * (HIP events on the launch streams), out[6] = batch launches, out[7] = frames in them */
 void j40hip_pipeline_stats(j40hip_pipeline *p, double *out4) {
 	if (!p || !out4) return;
 	std::unique_lock<std::mutex> lock(p->m);
 	out4[0] = p->parse_ms; out4[1] = p->upload_ms; out4[2] = (double) p->completed; out4[3] = p->last_done_ms - p->first_submit_ms;
+	out4[4] = p->k1_ms; out4[5] = p->k2_ms; out4[6] = (double) p->launches; out4[7] = (double) p->launch_frames;
 }
 
 void j40hip_pipeline_reset_stats(j40hip_pipeline *p) {
 	if (!p) return;
 	std::unique_lock<std::mutex> lock(p->m);
 	p->parse_ms = p->upload_ms = 0; p->first_submit_ms = 0; p->last_done_ms = 0;
+	p->k1_ms = p->k2_ms = 0; p->launches = p->launch_frames = 0;
 }
 
 } // extern "C"

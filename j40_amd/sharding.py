@@ -1,29 +1,25 @@
-"""j40_amd.sharding -- one frame decoded by several GPUs (BASELINE.json config 2).
+"""j40_amd.sharding -- one frame decoded by several GPUs (BASELINE.json config 3).
 
-The path shards by pass-group section: sections are independent once the LF data is known, so rank r takes a band of
-group rows. What has to move between ranks is small and sits at the two ends of the path:
+The path shards by pass-group section: sections are independent once the LF data is known. Rank r takes a CONTIGUOUS RANGE of
+groups (raster order) whose sections add up to about 1 / world of the frame's section BYTES (the TOC gives every section's size,
+j40.h:5529) -- entropy decode time follows the bytes, and a band of whole group rows can be 40 % off the mean (17 rows over 8 ranks).
+What moves between ranks is small and sits at the two ends of the path:
 
-  * in:  the codestream (a few MB; every rank parses headers, TOC and LF sections itself -- a broadcast of the parsed
-         LF bundle would be ~2.5x larger than the codestream it is derived from, and the host parse is ~10 ms);
-  * out: each rank's RGBA band (4 B/pixel), gathered on rank 0.
+  * in:  the codestream (a few MB), broadcast from rank 0; every rank parses headers, TOC and LF sections itself (the parsed LF
+         bundle would be ~2.5x larger than the codestream it is derived from);
+  * out: the pixels of each rank's groups (4 B/pixel). A contiguous range is at most three rectangles (the tail of its first group
+         row, whole group rows, the head of its last group row); every rank sends its rectangles straight to rank 0 with
+         point-to-point sends -- on xGMI every peer has its own link to rank 0, so the transfers run link-parallel -- and rank 0
+         copies them into place.
 
-There is no collective inside the hot path. `torch.distributed` is the transport: backend "nccl" (= RCCL over xGMI)
-with device tensors on the GPUs, "gloo" with host tensors in the CPU tests (tests/test_sharding.py), where the
-per-band decode is done by the CPU checker instead of the HIP kernels.
+Errors: before anything is gathered the ranks agree (all_reduce MAX) on whether every rank's decode succeeded, so that a failing
+rank cannot leave the others waiting in a receive; a section whose event region overflowed ("evof") is decoded again with dense
+planes first (j40hip_frame_force_dense), which is what the single-GPU public API does.
+
+There is no collective inside the hot path. `torch.distributed` is the transport: backend "nccl" (= RCCL over xGMI) with device
+tensors on the GPUs, "gloo" with host tensors in the CPU tests (tests/test_sharding.py).
 """
 import numpy as np
-
-
-def row_bands(num_group_rows, world):
-    """splits the rows of pass groups into `world` contiguous bands, sizes differing by at most one row;
-    returns [(first_row, rows)] per rank (rows may be 0 when there are more ranks than rows)"""
-    base, extra = divmod(num_group_rows, world)
-    bands, row = [], 0
-    for r in range(world):
-        n = base + (1 if r < extra else 0)
-        bands.append((row, n))
-        row += n
-    return bands
 
 
 def frame_geometry(width, height, group_size_shift):
@@ -31,11 +27,41 @@ def frame_geometry(width, height, group_size_shift):
     return (width + dim - 1) // dim, (height + dim - 1) // dim, dim   # group columns, group rows, group size in pixels
 
 
-def rank_share(width, height, group_size_shift, world, rank):
-    """what `rank` decodes: (first_group, num_groups, y0, y1) with [y0, y1) the pixel rows of its band"""
+def balanced_ranges(section_bytes, world):
+    """contiguous group ranges [(first, count)] per rank, balanced by the bytes of the groups' sections.
+    section_bytes: per group (summed over the passes). Greedy on the prefix sums: rank r ends at the group where the running
+    total first reaches (r + 1) / world of the whole; ranks may end up empty when there are more ranks than groups."""
+    sizes = np.maximum(np.asarray(section_bytes, dtype=np.float64), 1.0)   # (empty sections still cost a lane)
+    n = len(sizes)
+    prefix = np.concatenate([[0.0], np.cumsum(sizes)])
+    total = prefix[-1]
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        g = int(np.searchsorted(prefix, target, side="left"))
+        if g > 0 and abs(prefix[g - 1] - target) <= abs(prefix[min(g, n)] - target):
+            g -= 1
+        cuts.append(min(max(g, cuts[-1]), n))
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1] - cuts[r]) for r in range(world)]
+
+
+def range_rectangles(first, count, width, height, group_size_shift):
+    """the pixel rectangles (x0, y0, x1, y1) a contiguous range of groups covers: at most three"""
     gcols, grows, dim = frame_geometry(width, height, group_size_shift)
-    row0, rows = row_bands(grows, world)[rank]
-    return row0 * gcols, rows * gcols, min(height, row0 * dim), min(height, (row0 + rows) * dim)
+    rects = []
+    g, end = first, first + count
+    while g < end:
+        row, col = divmod(g, gcols)
+        if col == 0 and end - g >= gcols:                      # whole group rows
+            rows = (end - g) // gcols
+            rects.append((0, row * dim, width, min(height, (row + rows) * dim)))
+            g += rows * gcols
+        else:                                                  # part of one group row
+            n = min(gcols - col, end - g)
+            rects.append((col * dim, row * dim, min(width, (col + n) * dim), min(height, (row + 1) * dim)))
+            g += n
+    return rects
 
 
 def broadcast_bytes(data, dist, device="cpu", src=0):
@@ -52,54 +78,97 @@ def broadcast_bytes(data, dist, device="cpu", src=0):
     return bytes(buf.cpu().numpy().tobytes())
 
 
-def gather_bands(band, width, height, group_size_shift, dist, dst=0):
-    """band: this rank's rows [y1 - y0, width, 4] uint8 (torch tensor on the transport's device). Returns the whole
-    frame [height, width, 4] on rank `dst`, None elsewhere. Bands are padded to the tallest one so that a single
-    gather moves them (row counts differ by at most one group row)."""
+def agree_on_errors(code, dist, device="cpu"):
+    """every rank passes its own 4-char code ('' = fine); returns the first failing rank's code on every rank"""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
-    shares = [rank_share(width, height, group_size_shift, world, r) for r in range(world)]
-    tallest = max(y1 - y0 for _, _, y0, y1 in shares)
-    padded = torch.zeros((tallest, width, 4), dtype=torch.uint8, device=band.device)
-    padded[: band.shape[0]] = band
-    parts = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
-    dist.gather(padded, parts, dst=dst)
+    mine = torch.zeros(world, dtype=torch.int64, device=device)
+    mine[rank] = int.from_bytes(code.encode("latin1"), "big") if code else 0
+    dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+    for v in mine.cpu().tolist():
+        if v:
+            return int(v).to_bytes(4, "big").decode("latin1")
+    return ""
+
+
+def gather_rectangles(full, ranges, width, height, group_size_shift, dist, dst=0):
+    """full: [height, width, 4] uint8 on the transport's device, holding this rank's groups. Every rank sends the rectangles of its
+    range to rank `dst` (point-to-point, all posted at once); returns the assembled frame there, None elsewhere."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    ops, landing = [], []
+    for r in range(world):
+        if r == dst:
+            continue
+        for (x0, y0, x1, y1) in range_rectangles(ranges[r][0], ranges[r][1], width, height, group_size_shift):
+            if rank == r:
+                ops.append(dist.P2POp(dist.isend, full[y0:y1, x0:x1].contiguous(), dst))
+            elif rank == dst:
+                buf = torch.empty((y1 - y0, x1 - x0, 4), dtype=torch.uint8, device=full.device)
+                ops.append(dist.P2POp(dist.irecv, buf, r))
+                landing.append((buf, x0, y0, x1, y1))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     if rank != dst:
         return None
-    out = torch.empty((height, width, 4), dtype=torch.uint8, device=band.device)
-    for (_, _, y0, y1), part in zip(shares, parts):
-        out[y0:y1] = part[: y1 - y0]
-    return out
+    for buf, x0, y0, x1, y1 in landing:
+        full[y0:y1, x0:x1] = buf
+    return full
 
 
-def decode_sharded(data, dist, decode_band, device="cpu"):
-    """data: codestream on rank 0. decode_band(data, first_group, num_groups, y0, y1) -> uint8 tensor [y1 - y0, width, 4]
-    on `device` plus (width, height, group_size_shift). Returns the frame on rank 0."""
+def decode_sharded(data, dist, decode_range, device="cpu"):
+    """data: codestream on rank 0. decode_range(data, rank, world) -> (error code, full-frame uint8 tensor [height, width, 4] on
+    `device` with this rank's groups decoded, ranges, (width, height, group_size_shift)). Returns the frame on rank 0; raises
+    the same J40Error on every rank when any rank failed."""
+    import j40_amd
     data = broadcast_bytes(data, dist, device)
-    band, (width, height, shift) = decode_band(data, dist.get_rank(), dist.get_world_size())
-    return gather_bands(band, width, height, shift, dist)
+    err, full, ranges, (width, height, shift) = decode_range(data, dist.get_rank(), dist.get_world_size())
+    err = agree_on_errors(err, dist, device)
+    if err:
+        raise j40_amd.J40Error(err, "in a sharded decode")
+    if str(full.device) != str(device):   # (CPU transport under a GPU decode: the gloo tests)
+        full = full.to(device)
+    return gather_rectangles(full, ranges, width, height, shift, dist)
 
 
-def hip_band_decoder(local_device):
-    """decode_band for decode_sharded on a GPU: the frame's sections of this rank through libj40hip.so"""
+def plan_ranges(frame, world):
+    """the byte-balanced group ranges of a parsed frame"""
+    sizes = frame.section_sizes()
+    ng = frame.info["num_groups"]
+    per_group = sizes.reshape(-1, ng).sum(axis=0) if len(sizes) >= ng and len(sizes) % ng == 0 else np.ones(ng)
+    return balanced_ranges(per_group, world)
+
+
+def hip_range_decoder(local_device):
+    """decode_range for decode_sharded on a GPU: this rank's sections through libj40hip.so (j40hip_frame_set_group_range)"""
     import torch
     import j40_amd
 
-    def decode_band(data, rank, world):
-        fr = j40_amd.Frame(data)
-        fr.upload(local_device)
+    def decode_range(data, rank, world):
+        try:
+            fr = j40_amd.Frame(data)
+        except j40_amd.J40Error as e:
+            return e.code, None, None, (0, 0, 8)
         w, h, shift = fr.width, fr.height, fr.info["group_size_shift"]
-        first, count, y0, y1 = rank_share(w, h, shift, world, rank)
-        fr.set_group_range(first, count)
+        ranges = plan_ranges(fr, world)
+        first, count = ranges[rank]
         full = torch.empty((h, w, 4), dtype=torch.uint8, device="cuda:%d" % local_device)
+        err = ""
         if count:
-            fr.decode(full.data_ptr(), w * 4, torch.cuda.current_stream().cuda_stream)
-            torch.cuda.synchronize()
-            err = fr.status()
-            if err:
-                raise j40_amd.J40Error(err, "in a sharded decode")
-        band = full[y0:y1].contiguous()
+            for attempt in range(2):
+                try:
+                    fr.upload(local_device)
+                    fr.set_group_range(first, count)
+                    fr.decode(full.data_ptr(), w * 4, torch.cuda.current_stream().cuda_stream)
+                    torch.cuda.synchronize()
+                    err = fr.status()
+                except j40_amd.J40Error as e:
+                    err = e.code
+                if err != "evof":
+                    break
+                fr.force_dense(True)   # a section with more non-zero coefficients than its event region holds: dense planes
         fr.close()
-        return band, (w, h, shift)
+        return err, full, ranges, (w, h, shift)
 
-    return decode_band
+    return decode_range

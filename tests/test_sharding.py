@@ -1,5 +1,5 @@
 """multi-GPU decode of one frame, exercised with world_size-2 and -3 gloo jobs on the CPU:
-band arithmetic, codestream broadcast, per-rank partial decode (group ranges), padded gather and reassembly."""
+byte-balanced group ranges, codestream broadcast, per-rank partial decode (group ranges), error agreement, point-to-point gather and reassembly."""
 import os
 import socket
 import subprocess
@@ -11,18 +11,41 @@ import pytest
 from streams import synth, ROOT, CACHE as STREAMS
 
 
-def test_row_bands_cover_every_row_once():
+def test_balanced_ranges_cover_every_group_once_and_follow_the_bytes():
     from j40_amd import sharding
-    for rows in range(1, 40):
+    rng = np.random.default_rng(1)
+    for n in (1, 2, 7, 40, 510):
         for world in (1, 2, 3, 4, 8):
-            bands = sharding.row_bands(rows, world)
-            assert len(bands) == world and bands[0][0] == 0 and sum(n for _, n in bands) == rows
-            assert all(a[0] + a[1] == b[0] for a, b in zip(bands, bands[1:]))
-            assert max(n for _, n in bands) - min(n for _, n in bands) <= 1
-    # the north star's case: 4320 rows of pixels = 17 group rows over 8 GPUs
-    assert [n for _, n in sharding.row_bands(17, 8)] == [3, 2, 2, 2, 2, 2, 2, 2]
-    first, count, y0, y1 = sharding.rank_share(7680, 4320, 8, 8, 7)
-    assert (first, count, y0, y1) == (15 * 30, 2 * 30, 3840, 4320)
+            sizes = rng.integers(0, 20000, n)
+            ranges = sharding.balanced_ranges(sizes, world)
+            assert len(ranges) == world and ranges[0][0] == 0 and sum(c for _, c in ranges) == n
+            assert all(a[0] + a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+            if n >= 8 * world:   # enough groups to balance: no rank carries more than the mean plus the largest section
+                loads = [int(np.maximum(sizes[f:f + c], 1).sum()) for f, c in ranges]
+                assert max(loads) <= np.maximum(sizes, 1).sum() / world + sizes.max() + 1
+    # the north star's case, 8K over 8 GPUs: 510 equal groups -> 64 / 64 / 64 / 63 ... instead of 3 / 2 / 2 ... whole group rows (90 / 60 / 60 ...)
+    counts = [c for _, c in sharding.balanced_ranges(np.full(510, 9000), 8)]
+    assert max(counts) - min(counts) <= 1 and sum(counts) == 510
+
+
+def test_range_rectangles_tile_the_range():
+    from j40_amd import sharding
+    for (w, h, shift) in ((7680, 4320, 8), (600, 520, 8), (520, 776, 7)):
+        gcols, grows, dim = sharding.frame_geometry(w, h, shift)
+        n = gcols * grows
+        for first, count in ((0, n), (0, 1), (3, 5), (gcols - 1, gcols + 2), (n - 1, 1), (gcols, 2 * gcols), (1, n - 1)):
+            if first + count > n:
+                continue
+            rects = sharding.range_rectangles(first, count, w, h, shift)
+            assert len(rects) <= 3
+            cover = np.zeros((h, w), np.int32)
+            for x0, y0, x1, y1 in rects:
+                cover[y0:y1, x0:x1] += 1
+            expect = np.zeros((h, w), np.int32)
+            for g in range(first, first + count):
+                r, c = divmod(g, gcols)
+                expect[r * dim:(r + 1) * dim, c * dim:(c + 1) * dim] = 1
+            assert np.array_equal(cover, expect)
 
 
 def free_port():
@@ -46,6 +69,29 @@ def test_sharded_decode_over_gloo_matches_reference(built, ref, world, w, h):
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharding_worker.py"), str(r), str(world), str(port), path, out], env=env) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
+    got = np.load(out)
+    rerr, expect = ref.decode(data)
+    assert rerr == "" and got.shape == expect.shape
+    assert np.abs(got.astype(np.int32) - expect.astype(np.int32)).max() <= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,w,h", [(2, 1300, 776), (3, 7680, 4320)])
+def test_sharded_decode_with_the_hip_range_decoder(built, ref, world, w, h):
+    """the same job with every rank decoding its byte-balanced group range on the GPU (j40hip_frame_set_group_range through
+    j40_amd.sharding.hip_range_decoder); one process per rank, each on its own device when the box has several, all on device 0
+    otherwise. Transport: gloo (the RCCL transport needs one device per rank)."""
+    data = synth("vardct", w, h, 57)
+    path = os.path.join(STREAMS, "shardhip_%d_%d.jxl" % (w, h))
+    open(path, "wb").write(data)
+    out = os.path.join(STREAMS, "shardhip_%d_%d_w%d.npy" % (w, h, world))
+    if os.path.exists(out):
+        os.remove(out)
+    port = free_port()
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharding_worker.py"), str(r), str(world), str(port), path, out, "hip"], env=env) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
     got = np.load(out)
     rerr, expect = ref.decode(data)
     assert rerr == "" and got.shape == expect.shape
