@@ -189,7 +189,7 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 	if (df.sparse_coeffs) {
 		for (int32_t g = 0; g < num_groups; ++g) {
 			const DevSection &d = hp->sections[(size_t) g];
-			static const size_t per_byte = getenv("J40HIP_EVENTS_PER_BYTE") ? (size_t) atoi(getenv("J40HIP_EVENTS_PER_BYTE")) : 6;   // tests shrink it to reach the fallback
+			static const size_t per_byte = getenv("J40HIP_EVENTS_PER_BYTE") ? (size_t) atoi(getenv("J40HIP_EVENTS_PER_BYTE")) : 4;   // tests shrink it to reach the fallback
 			const size_t worst = (size_t) d.gw8 * (size_t) d.gh8 * 64 * 3, cap = std::min(worst, (size_t) d.size * per_byte + 256);
 			hp->ev_range.push_back((uint32_t) hp->ev_capacity);
 			hp->ev_capacity += cap;
@@ -197,9 +197,9 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 		}
 		if (hp->ev_capacity >= 0xffffffffull) { df.sparse_coeffs = 0; hp->ev_range.clear(); hp->ev_capacity = 0; }
 	}
-	hp->codestream.reserve(cs_size + 16);   // (assign + resize without it reallocates and copies the stream a second time)
+	hp->codestream.reserve(cs_size + 32);   // (assign + resize without it reallocates and copies the stream a second time)
 	hp->codestream.assign(cs, cs + cs_size);
-	hp->codestream.resize(cs_size + 16, 0);
+	hp->codestream.resize(cs_size + 32, 0);   // the lane decoders read up to three words past the position they stop at
 	bool any_lz77 = false;
 	for (const DevCodeSpec &sp : hp->coeff_specs) any_lz77 |= sp.lz77_enabled != 0;
 	hp->lz_window_size = any_lz77 ? 3 * 65536 + 3 * 1024 + 16 : 0;  // bound on the integers one pass-group stream decodes
@@ -450,9 +450,9 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 		}
 		hp->lz_window_size = (uint32_t) std::min<size_t>(most + 16, (size_t) 1 << 26);
 	}
-	hp->codestream.reserve(cs_size + 16);   // (assign + resize without it reallocates and copies the stream a second time)
+	hp->codestream.reserve(cs_size + 32);   // (assign + resize without it reallocates and copies the stream a second time)
 	hp->codestream.assign(cs, cs + cs_size);
-	hp->codestream.resize(cs_size + 16, 0);
+	hp->codestream.resize(cs_size + 32, 0);   // the lane decoders read up to three words past the position they stop at
 	return 0;
 }
 
