@@ -254,7 +254,146 @@ inline int32_t predict(int32_t predictor, const WeightedPredictor &wp, const Nei
 
 } // namespace
 
+// ---- the fast form of the per-pixel loop (same results as the general loop below) ----
+// LfGroup sections are Modular streams of a quarter of a million samples each and the host parses them for every frame: with the
+// pipeline bound by host CPU time their decode loop is worth three things the reference does not do:
+//   * the MA tree is specialised per (channel, stream): nodes that test the channel index or the stream index (properties 0, 1)
+//     are decided once, not once per sample (j40.h:4170-4171 evaluates them per sample) -- the LF trees encoders write split on
+//     exactly those first, so what is left is often a single leaf;
+//   * rANS symbols are decoded inline (no LZ77 state, no call per sample), the bit reader is topped up eight bytes at a time;
+//   * interior samples read their neighbours straight from the rows; the edge rules (j40.h:3965-3990) run for edge samples only.
+namespace {
+
+// copies `tree` with every property-0 / property-1 node replaced by the child it leads to for this channel and stream
+void specialise_tree(const TreeNode *tree, int32_t at, int32_t cidx, int32_t sidx, std::vector<TreeNode> *out) {
+	for (;;) {   // static nodes: follow
+		const TreeNode &n = tree[at];
+		if (n.prop == 0) { at += cidx > n.value ? n.a : n.b; continue; }
+		if (n.prop == 1) { at += sidx > n.value ? n.a : n.b; continue; }
+		break;
+	}
+	const TreeNode &n = tree[at];
+	const size_t me = out->size();
+	out->push_back(n);
+	if (n.prop < 0) return;
+	(*out)[me].a = (int32_t) (out->size() - me);
+	specialise_tree(tree, at + n.a, cidx, sidx, out);
+	(*out)[me].b = (int32_t) (out->size() - me);
+	specialise_tree(tree, at + n.b, cidx, sidx, out);
+}
+
+inline void refill8(BitReader &br) {   // >= 57 bits afterwards while eight bytes remain; else the byte-wise refill
+	if (br.end - br.ptr >= 8) {
+		uint64_t w;
+		memcpy(&w, br.ptr, 8);
+		const int take = (63 - br.nbits) >> 3;
+		br.bits |= w << br.nbits;
+		br.ptr += take; br.nbits += take * 8;
+		if (br.nbits < 64) br.bits &= ((uint64_t) 1 << br.nbits) - 1;
+	} else br.refill();
+}
+inline uint32_t take_bits(BitReader &br, int n) {   // == BitReader::u
+	if (br.nbits < n) { refill8(br); if (br.nbits < n) J40HIP_RAISE("shrt"); }
+	const uint32_t v = (uint32_t) (br.bits & (((uint64_t) 1 << n) - 1));
+	br.bits >>= n; br.nbits -= n;
+	return v;
+}
+// one rANS symbol + hybrid integer (ans_decode + hybrid_int of entropy.cpp; j40.h:2441, 2313)
+inline int32_t rans_value(BitReader &br, uint32_t &state, int32_t log_bucket, const Cluster &cl) {
+	if (state == 0) { state = take_bits(br, 16); state |= take_bits(br, 16) << 16; }
+	const uint32_t idx = state & 0xfff, i = idx >> log_bucket, pos = idx & ((1u << log_bucket) - 1);
+	const AnsEntry e = cl.alias[i];
+	const bool aliased = pos >= (uint32_t) (e & 0xff);
+	const int32_t token = (int32_t) (aliased ? (uint32_t) (e >> 20) & 0xff : i);
+	const uint32_t offset = aliased ? (uint32_t) (e >> 8) & 0xfff : 0;
+	const uint32_t d = aliased ? (uint32_t) (e >> 28) & 0x1fff : (uint32_t) (e >> 41) & 0x1fff;
+	state = d * (state >> 12) + offset + pos;
+	if (state < (1u << 16)) state = (state << 16) | take_bits(br, 16);
+	const HybridCfg &c = cl.cfg;
+	const int32_t split = 1 << c.split_exp;
+	if (token < split) return token;
+	J40HIP_SHOULD(token <= c.max_token, "iovf");
+	const int32_t in_token = c.msb_in_token + c.lsb_in_token;
+	const int32_t midbits = c.split_exp - in_token + ((token - split) >> in_token);
+	const int32_t mid = (int32_t) take_bits(br, midbits);
+	const int32_t top = 1 << c.msb_in_token;
+	const int32_t lo = token & ((1 << c.lsb_in_token) - 1), hi = (token >> c.lsb_in_token) & (top - 1);
+	return ((top | hi) << (midbits + c.lsb_in_token)) | ((mid << c.lsb_in_token) | lo);
+}
+
+// the fast loop: rANS without LZ77, no weighted predictor, no previous-channel properties in the specialised tree
+bool decode_channel_fast(BitReader &br, Modular &m, CodeState &code, int32_t cidx, int64_t sidx) {
+	const CodeSpec *spec = code.spec;
+	if (spec->use_prefix_code || spec->lz77_enabled || code.num_to_copy > 0) return false;
+	std::vector<TreeNode> tree;
+	specialise_tree(m.tree->data(), 0, cidx, (int32_t) sidx, &tree);
+	for (const TreeNode &n : tree) if (n.prop >= 15 || n.prop == -1 - 6 || n.prop < -1 - 13) return false;
+	Plane &c = m.channel[(size_t) cidx];
+	const int32_t w = c.width, h = c.height, log_bucket = 12 - spec->log_alpha_size;
+	const TreeNode *root = tree.data();
+	const bool single = root->prop < 0;
+	const uint8_t *cluster_map = spec->cluster_map.data();
+	const Cluster *clusters = spec->clusters.data();
+	uint32_t state = code.ans_state;
+	struct Restore { CodeState &code; uint32_t &state; ~Restore() { code.ans_state = state; } } restore{code, state};   // (also when an error unwinds)
+	for (int32_t y = 0; y < h; ++y) {
+		int16_t *row = c.row(y);
+		const int16_t *up = y > 0 ? c.row(y - 1) : row, *up2 = y > 1 ? c.row(y - 2) : up;
+		for (int32_t x = 0; x < w; ++x) {
+			Neigh p;
+			if (y >= 2 && x >= 2 && x + 2 < w) {   // interior: every neighbour exists
+				p.w = row[x - 1]; p.n = up[x]; p.nw = up[x - 1]; p.ne = up[x + 1]; p.nn = up2[x]; p.nee = up[x + 2]; p.ww = row[x - 2]; p.nww = up[x - 2];
+			} else p = neighbours(c, x, y);
+			const TreeNode *n = root;
+			if (!single) while (n->prop >= 0) {
+				int32_t val;
+				switch (n->prop) {
+				case 2: val = y; break;
+				case 3: val = x; break;
+				case 4: val = std::abs(p.n); break;
+				case 5: val = std::abs(p.w); break;
+				case 6: val = p.n; break;
+				case 7: val = p.w; break;
+				case 8: val = x > 0 ? p.w - (p.ww + p.nw - p.nww) : p.w; break;
+				case 9: val = p.w + p.n - p.nw; break;
+				case 10: val = p.w - p.nw; break;
+				case 11: val = p.nw - p.n; break;
+				case 12: val = p.n - p.ne; break;
+				case 13: val = p.n - p.nn; break;
+				default: val = p.w - p.ww; break;   // 14
+				}
+				n += val > n->value ? n->a : n->b;
+			}
+			int32_t v = rans_value(br, state, log_bucket, clusters[cluster_map[(size_t) n->value]]);
+			v = unpack_signed(v) * n->b + n->a;
+			int32_t pred;
+			switch (-1 - n->prop) {
+			case 0: pred = 0; break;
+			case 1: pred = p.w; break;
+			case 2: pred = p.n; break;
+			case 3: pred = (p.w + p.n) / 2; break;
+			case 4: pred = std::abs(p.n - p.nw) < std::abs(p.w - p.nw) ? p.w : p.n; break;
+			case 5: pred = clamped_gradient(p.w, p.n, p.nw); break;
+			case 7: pred = p.ne; break;
+			case 8: pred = p.nw; break;
+			case 9: pred = p.ww; break;
+			case 10: pred = (p.w + p.nw) / 2; break;
+			case 11: pred = (p.n + p.nw) / 2; break;
+			case 12: pred = (p.n + p.ne) / 2; break;
+			default: pred = (6 * p.n - 2 * p.nn + 7 * p.w + p.ww + p.nee + 3 * p.ne + 8) / 16; break;   // 13
+			}
+			v += pred;
+			J40HIP_SHOULD(-32768 <= v && v <= 32767, "povf");
+			row[x] = (int16_t) v;
+		}
+	}
+	return true;
+}
+
+} // namespace
+
 void decode_modular_channel(BitReader &br, Modular &m, CodeState &code, int32_t cidx, int64_t sidx) {  // j40.h:4127
+	if (!m.channel[(size_t) cidx].empty() && decode_channel_fast(br, m, code, cidx, sidx)) return;
 	Plane &c = m.channel[(size_t) cidx];
 	if (c.empty()) return;
 	const TreeNode *tree = m.tree->data();
