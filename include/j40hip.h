@@ -31,6 +31,9 @@ typedef struct j40hip_frame j40hip_frame;
  * in `buf` (borrowed until j40hip_frame_free). `threads` = host threads for LfGroup sections.
  * Returns NULL and sets *err (4-char code, same values as the reference's j40_err) on failure. */
 J40HIP_API j40hip_frame *j40hip_frame_parse(const void *buf, size_t size, int threads, uint32_t *err);
+/* flags & 1: leave the tail of every LfGroup -- dequantisation of the LF samples, adaptive smoothing, LLF coefficients (j40.h:6544-6590,
+ * 6492, 5944) -- to the device: j40hip_frame_upload runs it there (device/lf_tail_kernels.hip). Same results; what the pipeline uses. */
+J40HIP_API j40hip_frame *j40hip_frame_parse_ex(const void *buf, size_t size, int threads, uint32_t flags, uint32_t *err);
 J40HIP_API void j40hip_frame_free(j40hip_frame *f);
 
 /* out[0..20] = width, height, is_modular, num_lf_groups, num_groups, num_passes, nb_block_ctx,

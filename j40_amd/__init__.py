@@ -72,6 +72,7 @@ def lib():
         "j40_current_frame": (_FrameHandle, [vp]), "j40_frame_pixels_u8x4": (_Pixels, [vp, i32]),
         "j40_row_u8x4": (vp, [_Pixels, i32]), "j40_free": (None, [vp]),
         "j40hip_frame_parse": (vp, [vp, sz, C.c_int, C.POINTER(u32)]), "j40hip_frame_free": (None, [vp]),
+        "j40hip_frame_parse_ex": (vp, [vp, sz, C.c_int, u32, C.POINTER(u32)]),
         "j40hip_frame_info": (None, [vp, vp]), "j40hip_frame_codestream_size": (sz, [vp]), "j40hip_frame_num_sections": (i64, [vp]),
         "j40hip_frame_lf_group_info": (None, [vp, i64, vp]), "j40hip_frame_lf_group_plane": (C.c_int, [vp, i64, C.c_int, vp]),
         "j40hip_frame_varblocks": (None, [vp, i64, vp, vp]), "j40hip_frame_llf": (None, [vp, i64, C.c_int, vp]),

@@ -6,10 +6,11 @@ using namespace j40hip;
 
 extern "C" {
 
-j40hip_frame *j40hip_frame_parse(const void *buf, size_t size, int threads, uint32_t *err) {
+j40hip_frame *j40hip_frame_parse_ex(const void *buf, size_t size, int threads, uint32_t flags, uint32_t *err) {
 	j40hip_frame *h = new j40hip_frame();
 	uint32_t code = 0;
 	try {
+		h->frame.defer_lf_tail = (flags & 1u) != 0;
 		extract_codestream((const uint8_t *) buf, size, &h->cs, &h->cs_size, &h->cs_storage, &h->container_stray_tail);
 		h->bare_codestream = h->cs == (const uint8_t *) buf && h->cs_size == size;
 		parse_frame(h->cs, h->cs_size, &h->frame, threads);
@@ -19,6 +20,8 @@ j40hip_frame *j40hip_frame_parse(const void *buf, size_t size, int threads, uint
 	if (code) { delete h; return nullptr; }
 	return h;
 }
+
+j40hip_frame *j40hip_frame_parse(const void *buf, size_t size, int threads, uint32_t *err) { return j40hip_frame_parse_ex(buf, size, threads, 0, err); }
 
 // The seam for a host that has done its own parsing (a patched j40: INTEGRATION.md): a frame handle built from the plan view
 // instead of from a bitstream. Everything is copied except the codestream, which must outlive the handle.
@@ -168,6 +171,7 @@ void j40hip_frame_varblocks(const j40hip_frame *h, int64_t gg, int32_t *coeffoff
 }
 
 void j40hip_frame_llf(const j40hip_frame *h, int64_t gg, int c, float *out) {
+	finish_lf_tail(&const_cast<j40hip_frame *>(h)->frame);   // (frames parsed with the tail deferred: compute it here for whoever asks)
 	const LfGroup &g = h->frame.lf_groups[(size_t) gg];
 	memcpy(out, g.llfcoeffs[c].data(), g.llfcoeffs[c].size() * 4);
 }
@@ -215,6 +219,7 @@ static void fill_codespec_view(j40hip_frame *h, const CodeSpec &spec, j40hip_cod
 }
 
 uint32_t j40hip_frame_vardct_view(j40hip_frame *h, j40hip_vardct_view *v) {
+	finish_lf_tail(&h->frame);   // (frames parsed with the tail deferred: the view carries LLF coefficients)
 	const Frame &f = h->frame;
 	if (f.fh.is_modular || f.im.grey || f.fh.do_ycbcr || f.im.bpp < 8 || f.im.exp_bits) return E4("TODO");
 	memset(v, 0, sizeof *v);
@@ -272,6 +277,7 @@ uint32_t j40hip_frame_vardct_view(j40hip_frame *h, j40hip_vardct_view *v) {
 uint32_t j40hip_frame_modular_view(j40hip_frame *h, j40hip_modular_view *v) {
 	HostModPlan hp;
 	if (uint32_t e = build_modular_plan(h->frame, h->cs, h->cs_size, &hp)) return e;
+	finish_lf_tail(&h->frame);
 	const Frame &f = h->frame;
 	memset(v, 0, sizeof *v);
 	h->views = j40hip_frame::Views();

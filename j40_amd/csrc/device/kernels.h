@@ -16,6 +16,11 @@ void launch_vardct_class(const DevPlan &plan, int32_t dctsel, const DevVarblock 
 void launch_vardct_batch(const K2Frame *frames_dev, int32_t nframes, const int32_t *host_class_start, hipStream_t stream);
 void launch_vardct_frame(const DevPlan &plan, const int32_t *class_start, const DevVarblock *sorted, float *large_scratch, uint8_t *rgba, size_t stride, hipStream_t stream);
 
+// LfGroup tail on the device (device/lf_tail_kernels.hip)
+void upload_lf_tail_tables(const float *half_secants, const float *lf2llf, hipStream_t stream);
+void launch_lf_tail(const DevPlan &plan, int32_t num_lf_groups, int32_t max_cells, size_t cells, float *lfs, const DevVarblock *sorted, int32_t count, int32_t first_large, int32_t smooth,
+		const float inv_m_lf[3], hipStream_t stream);
+
 void launch_kat_srgb_u8(const float *v, size_t n, uint8_t *out, hipStream_t stream);
 
 // Modular path (device/modular_kernels.hip)

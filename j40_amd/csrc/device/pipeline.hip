@@ -103,7 +103,7 @@ void worker_main(j40hip_pipeline *p) {
 		}
 		const double t0 = now_ms();
 		uint32_t err = 0;
-		j->frame = j40hip_frame_parse(j->buf, j->size, 1, &err);
+		j->frame = j40hip_frame_parse_ex(j->buf, j->size, 1, 1u, &err);   // (the LfGroup tail runs on the device, at upload)
 		const double t1 = now_ms();
 		if (j->frame) {
 			int64_t info[21];

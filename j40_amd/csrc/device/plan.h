@@ -35,6 +35,8 @@ struct DevLfGroup {
 	int32_t vb_base;     // first varblock in the frame-wide varblock arrays
 	int32_t c64_base;    // first 64x64 cell (chroma-from-luma factors)
 	int32_t nb_varblocks;
+	float mult_lf[3];    // LF dequantisation factors of this group, channels X, Y, B (j40.h:6562; they depend on the group's extra_prec)
+	int32_t pad;
 };
 
 // one (pass, group) TOC section
@@ -64,7 +66,7 @@ struct DevVarblock {
 	float kx_hf;          // chroma-from-luma factors of the block's 64x64 cell: base_corr + inv_colour_factor * x/bfromy (j40.h:7138-7143)
 	int32_t px, py;       // top-left pixel in the frame
 	uint16_t effw, effh;  // visible size
-	uint8_t dctsel, pad[3];
+	uint8_t dctsel, pad[3];   // pad: the block's LF group index, little endian (lf_tail_kernels.hip)
 	int32_t blk;          // ordinal of the block in plan.group_blocks / plan.block_events
 	float kb_hf;
 };
@@ -128,6 +130,9 @@ struct DevPlan {
 	const int32_t *vb_coeffoff_qfidx;
 	const float *vb_hfmul_inv;
 	const int16_t *xfromy, *bfromy;
+	// frames whose LfGroup tail runs on the device (Frame::defer_lf_tail): the decoded LF integers, frame-wide cell arrays like `blocks`,
+	// channels X, Y, B; lf_tail_kernels.hip turns them into `llf` at upload. Null otherwise (then the host filled `llf`).
+	const int16_t *lfraw[3];
 	// working buffers
 	float *coeffs[3];                // [total cells * 64]; one allocation: coeffs[c] = coeffs[0] + c * coeff_stride
 	uint32_t coeff_stride;

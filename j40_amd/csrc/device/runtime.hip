@@ -128,6 +128,12 @@ struct Stager {
 		size = end;
 		return off;
 	}
+	size_t reserve(size_t bytes) {   // room in the device block that nothing is copied into (the bytes staged for it are whatever is there)
+		const size_t off = (size + 255) & ~(size_t) 255, end = off + bytes + 16;
+		if (!ok || !t_stage.reserve(end, size)) { ok = false; return 0; }
+		size = end;
+		return off;
+	}
 	const uint8_t *data() const { return t_stage.ptr; }
 };
 
@@ -139,6 +145,7 @@ bool ensure_constant_tables(int device) {
 	std::lock_guard<std::mutex> lock(g_const_mutex);
 	if (g_const_done[device]) return true;
 	upload_constant_tables(half_secants(), afv_basis(), srgb_u8_thresholds(), nullptr);
+	upload_lf_tail_tables(half_secants(), lf2llf_scales(), nullptr);
 	if (hipStreamSynchronize(nullptr) != hipSuccess) return false;
 	return g_const_done[device] = true;
 }
@@ -420,7 +427,7 @@ static uint32_t upload_impl(j40hip_frame *h, int device, hipStream_t s) {
 	DevPlan &plan = st->plan;
 	memset(&plan, 0, sizeof plan);
 	st->hf = hp.hf;
-	st->vb_sorted = hp.vb_sorted;
+	st->vb_sorted = std::move(hp.vb_sorted);
 	memcpy(st->class_start, hp.class_start, sizeof st->class_start);
 	Stager sg;
 	const size_t o_cs = sg.put(hp.codestream.data(), hp.codestream.size()), o_u8 = sg.put(hp.pool_u8.data(), hp.pool_u8.size());
@@ -430,15 +437,21 @@ static uint32_t upload_impl(j40hip_frame *h, int device, hipStream_t s) {
 	const size_t o_lfg = sg.put(hp.lf_groups.data(), hp.lf_groups.size()), o_sec = sg.put(hp.sections.data(), hp.sections.size());
 	const size_t o_gb = sg.put(hp.group_blocks.data(), hp.group_blocks.size()), o_gbs = sg.put(hp.group_block_start.data(), hp.group_block_start.size());
 	const size_t o_frame = sg.put(&hp.frame, 1), o_blocks = sg.put(hp.blocks.data(), hp.blocks.size()), o_lfi = sg.put(hp.lfindices.data(), hp.lfindices.size());
-	size_t o_llf[3]; for (int c = 0; c < 3; ++c) o_llf[c] = sg.put(hp.llf[c].data(), hp.llf[c].size());
+	const size_t cells = hp.blocks.size();
+	size_t o_llf[3], o_raw[3] = {0, 0, 0};
+	if (hp.lf_tail_pending) {   // the LLF arrays are an output of the device's LfGroup tail: only their place is reserved
+		for (int c = 0; c < 3; ++c) { o_raw[c] = sg.put(hp.lfraw[c].data(), hp.lfraw[c].size()); o_llf[c] = 0; }   // (reserved behind everything that is copied, below)
+	} else for (int c = 0; c < 3; ++c) o_llf[c] = sg.put(hp.llf[c].data(), hp.llf[c].size());
 	const size_t o_vbc = sg.put(hp.vb_coeffoff_qfidx.data(), hp.vb_coeffoff_qfidx.size()), o_vbh = sg.put(hp.vb_hfmul_inv.data(), hp.vb_hfmul_inv.size());
 	const size_t o_xfy = sg.put(hp.xfromy.data(), hp.xfromy.size()), o_bfy = sg.put(hp.bfromy.data(), hp.bfromy.size());
 	const size_t o_vbs = sg.put(st->vb_sorted.data(), st->vb_sorted.size());
 	const size_t o_evr = sg.put(hp.ev_range.data(), hp.ev_range.size());
+	const size_t copy_bytes = sg.size;
+	if (hp.lf_tail_pending) for (int c = 0; c < 3; ++c) o_llf[c] = sg.reserve(sizeof(float) * cells);
 	bool dummy_clean = false;
 	if (!sg.ok) ok = false;
 	st->plan_block = ok ? cache_acquire(device, sg.size, &st->plan_block_bytes, &dummy_clean) : nullptr;
-	if (!st->plan_block || hipMemcpyAsync(st->plan_block, sg.data(), sg.size, hipMemcpyHostToDevice, s) != hipSuccess) ok = false;
+	if (!st->plan_block || hipMemcpyAsync(st->plan_block, sg.data(), copy_bytes, hipMemcpyHostToDevice, s) != hipSuccess) ok = false;
 	uint8_t *pb = (uint8_t *) st->plan_block;
 	plan.codestream = pb + o_cs; plan.pool_u8 = pb + o_u8; plan.pool_u16 = (const uint16_t *) (pb + o_u16); plan.pool_i32 = (const int32_t *) (pb + o_i32);
 	plan.pool_u64 = (const uint64_t *) (pb + o_u64); plan.pool_f32 = (const float *) (pb + o_f32); plan.clusters = (const DevCluster *) (pb + o_cl);
@@ -446,7 +459,7 @@ static uint32_t upload_impl(j40hip_frame *h, int device, hipStream_t s) {
 	plan.group_blocks = (const DevGroupBlock *) (pb + o_gb); plan.group_block_start = (const uint32_t *) (pb + o_gbs); plan.frame = (const DevFrame *) (pb + o_frame);
 	plan.block_ctx_map_off = hp.block_ctx_map_off;
 	plan.blocks = (const int32_t *) (pb + o_blocks); plan.lfindices = pb + o_lfi;
-	for (int c = 0; c < 3; ++c) plan.llf[c] = (const float *) (pb + o_llf[c]);
+	for (int c = 0; c < 3; ++c) { plan.llf[c] = (const float *) (pb + o_llf[c]); plan.lfraw[c] = hp.lf_tail_pending ? (const int16_t *) (pb + o_raw[c]) : nullptr; }
 	plan.vb_coeffoff_qfidx = (const int32_t *) (pb + o_vbc); plan.vb_hfmul_inv = (const float *) (pb + o_vbh);
 	plan.xfromy = (const int16_t *) (pb + o_xfy); plan.bfromy = (const int16_t *) (pb + o_bfy);
 	st->d_vb_sorted = (DevVarblock *) (pb + o_vbs);
@@ -466,7 +479,9 @@ static uint32_t upload_impl(j40hip_frame *h, int device, hipStream_t s) {
 		const size_t w_nz = align(w_blk + blk_bytes), w_status = align(w_nz + (size_t) num_groups * 32 * 32 * 3);
 		const size_t w_endbit = align(w_status + sizeof(uint32_t) * hp.sections.size());
 		const size_t w_lz = align(w_endbit + (hp.frame.sections_have_trailer ? sizeof(uint32_t) * hp.sections.size() : 0)), lz_bytes = sizeof(int32_t) * (size_t) num_groups * hp.lz_window_size;
-		const size_t w_large = align(w_lz + lz_bytes), large_bytes = sizeof(float) * (size_t) hp.max_large * 6 * 65536;
+		// (the 128/256-sized transforms' scratch doubles as the LfGroup tail's: three planes of dequantised, smoothed LF samples, used
+		// once at upload, long before any decode)
+		const size_t w_large = align(w_lz + lz_bytes), large_bytes = std::max(sizeof(float) * (size_t) hp.max_large * 6 * 65536, hp.lf_tail_pending ? sizeof(float) * 3 * cells : (size_t) 0);
 		bool unused_clean = false;
 		st->work_block = cache_acquire(device, w_large + large_bytes + 256, &st->work_block_bytes, &unused_clean);
 		uint8_t *wb = (uint8_t *) st->work_block;
@@ -483,6 +498,11 @@ static uint32_t upload_impl(j40hip_frame *h, int device, hipStream_t s) {
 			plan.lz_window_size = hp.lz_window_size;
 			plan.lz_window = hp.lz_window_size ? (int32_t *) (wb + w_lz) : nullptr;
 			st->d_large_scratch = hp.max_large ? (float *) (wb + w_large) : nullptr;
+			if (hp.lf_tail_pending && ok) {   // the LfGroup tail: LF integers -> LLF coefficients, on the upload stream behind the copy
+				int32_t max_cells = 0;
+				for (const DevLfGroup &g : hp.lf_groups) max_cells = std::max(max_cells, g.width8 * g.height8);
+				launch_lf_tail(plan, (int32_t) hp.lf_groups.size(), max_cells, cells, (float *) (wb + w_large), st->d_vb_sorted, (int32_t) st->vb_sorted.size(), st->class_start[18], hp.lf_smooth ? 1 : 0, hp.inv_m_lf, s);
+			}
 		}
 	}
 	st->total_sections = (int32_t) hp.sections.size();

@@ -563,6 +563,33 @@ static void smooth_lf(const Frame &f, int32_t w8, int32_t h8, std::vector<float>
 	}
 }
 
+// the tail of an LfGroup: dequantisation (j40.h:6562), adaptive smoothing (j40.h:6492), LLF coefficients of every varblock
+// (j40.h:6668-6683, 5944) from the decoded integers and the varblock layout. The device does the same at upload
+// (device/lf_tail_kernels: k_lf_dequant_smooth, k_llf) when Frame::defer_lf_tail is set.
+static void lf_tail_on_host(const Frame &f, LfGroup *gg) {
+	if (!gg->tail_pending) return;
+	const int32_t w8 = gg->width8, h8 = gg->height8;
+	std::vector<float> lfq[3];
+	for (int c = 0; c < 3; ++c) {
+		lfq[c].resize((size_t) w8 * (size_t) h8);
+		for (size_t i = 0; i < lfq[c].size(); ++i) lfq[c][i] = (float) gg->lfraw[c][i] * gg->mult_lf[c];
+	}
+	if (!f.fh.skip_adapt_lf_smooth) smooth_lf(f, w8, h8, lfq);
+	for (int c = 0; c < 3; ++c) gg->llfcoeffs[c].assign((size_t) w8 * (size_t) h8, 0.0f);
+	std::vector<float> scratch(1024);
+	for (const VarblockInfo &vb : gg->varblocks) {
+		const DctSelect &dct = DCT_SELECT[vb.dctsel];
+		const int32_t vw8 = 1 << (dct.log_columns - 3), vh8 = 1 << (dct.log_rows - 3), coeffoff = vb.coeffoff_qfidx & ~15;
+		for (int c = 0; c < 3; ++c) {
+			float *llf = gg->llfcoeffs[c].data() + (coeffoff >> 6);
+			for (int32_t i = 0; i < vh8; ++i) for (int32_t j = 0; j < vw8; ++j) llf[i * vw8 + j] = lfq[c][(size_t) (vb.y8 + i) * (size_t) w8 + (size_t) (vb.x8 + j)];
+			if (vw8 > 1 || vh8 > 1) forward_dct2d_scaled_for_llf(llf, scratch.data(), dct.log_rows - 3, dct.log_columns - 3);
+		}
+	}
+	gg->tail_pending = false;
+}
+void finish_lf_tail(Frame *f) { for (LfGroup &gg : f->lf_groups) if (gg.loaded) lf_tail_on_host(*f, &gg); }
+
 static void read_lf_group(BitReader &br, Frame *f, LfGroup *gg) {  // j40.h:6722
 	const FrameHeader &fh = f->fh;
 	const int64_t sidx0 = 1 + gg->idx, sidx2 = 1 + 2 * fh.num_lf_groups + gg->idx;
@@ -573,7 +600,6 @@ static void read_lf_group(BitReader &br, Frame *f, LfGroup *gg) {  // j40.h:6722
 
 	// LF image: three channels in Y, X, B order
 	const int32_t extra_prec = (int32_t) br.u(2);
-	std::vector<float> lfq[3];
 	{
 		Modular m; m.bpp = f->im.bpp;
 		m.channel.assign(3, Plane());
@@ -582,11 +608,9 @@ static void read_lf_group(BitReader &br, Frame *f, LfGroup *gg) {  // j40.h:6722
 		static const int XYB_FROM_STREAM[3] = {1, 0, 2};
 		const Plane *ch[3];
 		for (int c = 0; c < 3; ++c) {
-			float mult_lf = f->m_lf_scaled[c] / (float) (f->global_scale * f->quant_lf) * (float) (65536 >> extra_prec);  // j40.h:6562
+			gg->mult_lf[c] = f->m_lf_scaled[c] / (float) (f->global_scale * f->quant_lf) * (float) (65536 >> extra_prec);  // j40.h:6562
 			ch[c] = &m.channel[(size_t) XYB_FROM_STREAM[c]];
 			J40HIP_SHOULD(ch[c]->width == w8 && ch[c]->height == h8, "TODO");
-			lfq[c].resize((size_t) w8 * (size_t) h8);
-			for (size_t i = 0; i < lfq[c].size(); ++i) lfq[c][i] = (float) ch[c]->px[i] * mult_lf;
 		}
 		// LF index: thresholds counted on the raw integers; note each factor is a channel's own
 		// threshold count (j40.h:6566-6570)
@@ -596,8 +620,9 @@ static void read_lf_group(BitReader &br, Frame *f, LfGroup *gg) {  // j40.h:6722
 		add(ch[0], f->lf_thr[0], f->nb_lf_thr[0]); mul(f->nb_lf_thr[0] + 1);
 		add(ch[2], f->lf_thr[2], f->nb_lf_thr[2]); mul(f->nb_lf_thr[2] + 1);
 		add(ch[1], f->lf_thr[1], f->nb_lf_thr[1]);
+		for (int c = 0; c < 3; ++c) gg->lfraw[c].swap(m.channel[(size_t) XYB_FROM_STREAM[c]].px);
+		gg->tail_pending = true;
 	}
-	if (!fh.skip_adapt_lf_smooth) smooth_lf(*f, w8, h8, lfq);
 
 	// HF metadata
 	const int32_t nb_varblocks = (int32_t) br.u(ceil_lg32((uint32_t) (w8 * h8))) + 1;
@@ -615,11 +640,9 @@ static void read_lf_group(BitReader &br, Frame *f, LfGroup *gg) {  // j40.h:6722
 	const int32_t log_gsize8 = fh.group_size_shift - 3;
 	gg->blocks.assign((size_t) w8 * (size_t) h8, 0);
 	gg->varblocks.assign((size_t) nb_varblocks, VarblockInfo());
-	for (int c = 0; c < 3; ++c) gg->llfcoeffs[c].assign((size_t) w8 * (size_t) h8, 0.0f);
 	const int16_t *info0 = m.channel[2].row(0), *info1 = m.channel[2].row(1);
 	int32_t voff = 0, coeffoff = 0;
 	uint32_t dct_used = 0, order_used = 0;
-	std::vector<float> scratch(1024);
 	for (int32_t y0 = 0; y0 < h8; ++y0) for (int32_t x0 = 0; x0 < w8; ++x0) {
 		if (gg->blocks[(size_t) y0 * (size_t) w8 + (size_t) x0]) continue;
 		J40HIP_SHOULD(voff < nb_varblocks, "vblk");
@@ -638,16 +661,12 @@ static void read_lf_group(BitReader &br, Frame *f, LfGroup *gg) {  // j40.h:6722
 		const int32_t hfmul_m1 = info1[voff];
 		for (int32_t j = 0; j < f->nb_qf_thr; ++j) vb.coeffoff_qfidx += hfmul_m1 >= f->qf_thr[j];
 		vb.hfmul_inv = 1.0f / ((float) hfmul_m1 + 1.0f);
-		for (int c = 0; c < 3; ++c) {
-			float *llf = gg->llfcoeffs[c].data() + (coeffoff >> 6);
-			for (int32_t i = 0; i < vh8; ++i) for (int32_t j = 0; j < vw8; ++j) llf[i * vw8 + j] = lfq[c][(size_t) (y0 + i) * (size_t) w8 + (size_t) (x0 + j)];
-			if (vw8 > 1 || vh8 > 1) forward_dct2d_scaled_for_llf(llf, scratch.data(), dct.log_rows - 3, dct.log_columns - 3);
-		}
 		coeffoff += 1 << (dct.log_columns + dct.log_rows);
 		++voff;
 	}
 	J40HIP_SHOULD(voff == nb_varblocks, "vblk");
 	gg->loaded = true;
+	if (!f->defer_lf_tail) lf_tail_on_host(*f, gg);
 	static std::mutex mu;
 	std::lock_guard<std::mutex> lock(mu);
 	f->dct_select_used |= dct_used; f->order_used |= order_used;

@@ -73,6 +73,12 @@ struct LfGroup {
 	std::vector<float> llfcoeffs[3];      // [height8 * width8], indexed by coefficient offset / 64
 	std::vector<int16_t> xfromy, bfromy;  // [height64 * width64]
 	bool loaded = false;
+	// Frame::defer_lf_tail: the quantised LF samples as decoded (channel order X, Y, B) and their dequantisation factors; the
+	// dequantisation, the adaptive smoothing and the LLF coefficients (`llfcoeffs`) are then computed on the device at upload
+	// (finish_lf_tail does the same on the host when somebody asks for llfcoeffs)
+	std::vector<int16_t> lfraw[3];
+	float mult_lf[3] = {0.0f, 0.0f, 0.0f};
+	bool tail_pending = false;
 };
 
 struct Frame {
@@ -106,6 +112,9 @@ struct Frame {
 
 	std::vector<LfGroup> lf_groups;
 	size_t single_pass_group_bitpos = 0;
+	// VarDCT frames: leave the tail of every LfGroup (dequantisation, adaptive smoothing, LLF coefficients; j40.h:6544-6590, 6492, 5944)
+	// to the device: the host keeps the decoded integers (LfGroup::lfraw). Set before parse_frame.
+	bool defer_lf_tail = false;
 	// Modular frames: LfGlobal's channel data is left to the device; it starts at this bit of the section
 	bool gm_data_pending = false;
 	size_t gm_data_bitpos = 0;  // single-section VarDCT frames: where the pass group starts
@@ -119,6 +128,8 @@ void extract_codestream(const uint8_t *data, size_t size, const uint8_t **cs, si
 // parses headers, TOC, LfGlobal, HfGlobal and every LfGroup section. `threads` > 1 decodes LfGroup
 // sections concurrently (they are independent given LfGlobal)
 void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads);
+// the LfGroup tail on the host for the groups that still have it pending (dequantise, smooth, LLF): what the device does at upload
+void finish_lf_tail(Frame *f);
 
 struct GroupInfo { int32_t ggidx, gx_in_gg, gy_in_gg, gw, gh; };
 GroupInfo group_info(const FrameHeader &fh, int64_t gidx);  // j40.h:7734

@@ -102,6 +102,9 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 	}
 
 	std::vector<int32_t> vb_lf_group;   // LF group of each entry of vb_sorted, until the block ordinals are resolved
+	{ size_t nvb = 0, ncell = 0; for (const LfGroup &gg : fr.lf_groups) { nvb += gg.varblocks.size(); ncell += gg.blocks.size(); }
+	  hp->vb_sorted.reserve(nvb); vb_lf_group.reserve(nvb); hp->vb_coeffoff_qfidx.reserve(nvb); hp->vb_hfmul_inv.reserve(nvb); hp->group_blocks.reserve(nvb);
+	  hp->blocks.reserve(ncell); hp->lfindices.reserve(ncell); for (int c = 0; c < 3; ++c) hp->llf[c].reserve(ncell); }
 	// LF bundle: frame-wide arrays over all LF groups
 	hp->lf_groups.assign(fr.lf_groups.size(), DevLfGroup());
 	for (size_t g = 0; g < fr.lf_groups.size(); ++g) {
@@ -113,7 +116,11 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 		d.nb_varblocks = (int32_t) gg.varblocks.size();
 		hp->blocks.insert(hp->blocks.end(), gg.blocks.begin(), gg.blocks.end());
 		hp->lfindices.insert(hp->lfindices.end(), gg.lfindices.begin(), gg.lfindices.end());
-		for (int c = 0; c < 3; ++c) hp->llf[c].insert(hp->llf[c].end(), gg.llfcoeffs[c].begin(), gg.llfcoeffs[c].end());
+		for (int c = 0; c < 3; ++c) d.mult_lf[c] = gg.mult_lf[c];
+		if (gg.tail_pending) {   // the device computes the LLF coefficients from the decoded integers (lf_tail_kernels.hip)
+			hp->lf_tail_pending = true;
+			for (int c = 0; c < 3; ++c) hp->lfraw[c].insert(hp->lfraw[c].end(), gg.lfraw[c].begin(), gg.lfraw[c].end());
+		} else for (int c = 0; c < 3; ++c) hp->llf[c].insert(hp->llf[c].end(), gg.llfcoeffs[c].begin(), gg.llfcoeffs[c].end());
 		hp->xfromy.insert(hp->xfromy.end(), gg.xfromy.begin(), gg.xfromy.end());
 		hp->bfromy.insert(hp->bfromy.end(), gg.bfromy.begin(), gg.bfromy.end());
 		for (size_t v = 0; v < gg.varblocks.size(); ++v) {
@@ -131,11 +138,18 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 			dv.px = gg.left + vb.x8 * 8; dv.py = gg.top + vb.y8 * 8;
 			dv.effh = (uint16_t) std::min(gg.height - vb.y8 * 8, 1 << ds.log_rows); dv.effw = (uint16_t) std::min(gg.width - vb.x8 * 8, 1 << ds.log_columns);
 			dv.dctsel = (uint8_t) vb.dctsel;
+			dv.pad[0] = (uint8_t) g; dv.pad[1] = (uint8_t) (g >> 8); dv.pad[2] = (uint8_t) (g >> 16);
 			dv.blk = (int32_t) v;   // resolved to the block's ordinal once the group lists exist
 			hp->vb_sorted.push_back(dv); vb_lf_group.push_back((int32_t) g);
 		}
 	}
 	hp->coeff_floats = hp->blocks.size() * 64;
+	if (hp->lf_tail_pending) {
+		if (fr.lf_groups.size() >= ((size_t) 1 << 24)) return ERR_TODO;
+		for (const LfGroup &gg : fr.lf_groups) if (!gg.tail_pending) return ERR_TODO;   // (all or none)
+		hp->lf_smooth = !fr.fh.skip_adapt_lf_smooth;
+		for (int c = 0; c < 3; ++c) hp->inv_m_lf[c] = (float) (fr.global_scale * fr.quant_lf) / fr.m_lf_scaled[c] / 65536.0f;   // j40.h:6497
+	}
 
 	// sections
 	const int32_t num_groups = (int32_t) fr.fh.num_groups;
@@ -204,9 +218,15 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 	for (const DevCodeSpec &sp : hp->coeff_specs) any_lz77 |= sp.lz77_enabled != 0;
 	hp->lz_window_size = any_lz77 ? 3 * 65536 + 3 * 1024 + 16 : 0;  // bound on the integers one pass-group stream decodes
 	// work lists for the coefficients -> pixels kernels, grouped by DctSelect
-	std::stable_sort(hp->vb_sorted.begin(), hp->vb_sorted.end(), [](const DevVarblock &a, const DevVarblock &b) { return a.dctsel < b.dctsel; });
-	size_t k = 0;
-	for (int d = 0; d <= 27; ++d) { while (k < hp->vb_sorted.size() && hp->vb_sorted[k].dctsel < d) ++k; hp->class_start[d] = (int32_t) k; }
+	{   // a counting sort: 27 classes, stable (a comparison sort of a quarter of a million 40-byte records was a third of this function)
+		size_t count[28] = {0};
+		for (const DevVarblock &v : hp->vb_sorted) ++count[v.dctsel < 27 ? v.dctsel : 27];
+		size_t at[28], k = 0;
+		for (int d = 0; d <= 27; ++d) { hp->class_start[d] = (int32_t) k; at[d] = k; k += count[d]; }
+		std::vector<DevVarblock> sorted(hp->vb_sorted.size());
+		for (const DevVarblock &v : hp->vb_sorted) sorted[at[v.dctsel < 27 ? v.dctsel : 27]++] = v;
+		hp->vb_sorted.swap(sorted);
+	}
 	// K1's LDS budget
 	HfLaunchInfo &hf = hp->hf;
 	hf.block_ctx_size = (uint32_t) fr.block_ctx_map.size(); hf.max_num_dist = hf.max_clusters = hf.max_table_bytes = 0;

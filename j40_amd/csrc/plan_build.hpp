@@ -26,6 +26,10 @@ struct HostPlan {
 	std::vector<uint8_t> lfindices;
 	std::vector<float> llf[3], vb_hfmul_inv;
 	std::vector<int16_t> xfromy, bfromy;
+	// the LfGroup tail left to the device (Frame::defer_lf_tail): decoded LF integers per cell (channels X, Y, B) instead of `llf`
+	bool lf_tail_pending = false, lf_smooth = false;
+	std::vector<int16_t> lfraw[3];
+	float inv_m_lf[3] = {0.0f, 0.0f, 0.0f};
 	std::vector<DevVarblock> vb_sorted;   // by DctSelect
 	bool force_dense = false;             // in: dense coefficient planes even for single-pass frames (fallback after ERR_EVOF)
 	std::vector<uint32_t> ev_range;       // sparse coefficients: [2 * group] first / end event of the group's region

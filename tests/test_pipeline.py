@@ -63,3 +63,28 @@ def test_pipeline_can_be_drained_and_reused(built):
             assert pipe.result(t) == ""
             assert np.array_equal(o.cpu().numpy(), j40_amd.decode(d)[1])
     pipe.close()
+
+
+def test_lf_group_tail_on_the_device_equals_the_host_tail(built):
+    """j40hip_frame_parse_ex(flags = 1) leaves dequantisation, adaptive smoothing and the LLF coefficients of the LfGroups to the
+    device (lf_tail_kernels.hip, run at upload); the pixels must be those of the frame whose tail the host computed, bit for bit --
+    over every transform size (the large ones take the LDS kernel), several LfGroups, and with smoothing off"""
+    import ctypes as C
+    import torch
+    import j40_amd
+    L = j40_amd.lib()
+    for w, h, opts in [(776, 520, dict(maxlog=8, bctx=1, presets=2, orders=1)), (2600, 2100, dict()), (520, 264, dict(fullheader=1, nosmooth=1)), (7680, 4320, dict())]:
+        data = synth("vardct", w, h, 23, **opts)
+        err, expect = j40_amd.decode(data)
+        assert err == ""
+        buf = C.create_string_buffer(data, len(data))
+        e = C.c_uint32()
+        fh = L.j40hip_frame_parse_ex(buf, len(data), 1, 1, C.byref(e))
+        assert fh and e.value == 0
+        assert L.j40hip_frame_upload(fh, 0) == 0
+        out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0")
+        assert L.j40hip_frame_decode(fh, out.data_ptr(), w * 4, torch.cuda.current_stream().cuda_stream) == 0
+        torch.cuda.synchronize()
+        assert L.j40hip_frame_status(fh) == 0
+        assert np.array_equal(out.cpu().numpy(), expect), (w, h, opts)
+        L.j40hip_frame_free(fh)
