@@ -94,9 +94,11 @@ def run_pipeline_steps(pipe, bufs, sizes, outs, stride, device_output, steps, to
     pipe.reset_stats()
     t0 = time.perf_counter()
     tickets = []
+    # the steps are queued back to back and drained once: the pipeline keeps the host threads parsing step k + 1 while the device still
+    # decodes the last batch of step k (a step's frames overwrite the previous step's pixels: same streams, same pixels)
     for _ in range(steps):
         tickets = [pipe.submit_raw(bufs[i], sizes[i], outs[i].data_ptr(), stride, device_output) for i in range(len(bufs))]
-        pipe.drain()
+    pipe.drain()
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
@@ -161,7 +163,7 @@ def main():
     step_bufs = [bufs[i % D] for i in range(B)]
     step_sizes = [len(datas[i % D]) for i in range(B)]
     outs = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(B)]
-    pipe = j40_amd.Pipeline(local_rank, threads, min(args.pipe_batch, B), 1)
+    pipe = j40_amd.Pipeline(local_rank, threads, min(args.pipe_batch, B), 2)
 
     for _ in range(max(args.warmup, 0)):
         run_pipeline_steps(pipe, step_bufs, step_sizes, outs, W * 4, True, 1, torch, dev, None)

@@ -141,16 +141,27 @@ __global__ void __launch_bounds__(64) k_inverse_palette_predicted(const int16_t 
 // in dwords: a lane walking its own row hits its own bank), each lane runs the recurrence over its row's piece, and the
 // 2 * SQZ_CHUNK results per row go out as two coalesced 128-byte writes. `left` (the sample before the pair) stays in a register.
 enum { SQZ_CHUNK = 64 };
-__global__ void __launch_bounds__(64) k_unsqueeze_h(const int16_t *avg, const int16_t *res, int16_t *out, int32_t aw, int32_t ah, int32_t rw) {
+__global__ void __launch_bounds__(64) k_unsqueeze_h(const int16_t *__restrict__ avg, const int16_t *__restrict__ res, int16_t *__restrict__ out, int32_t aw, int32_t ah, int32_t rw) {
 	__shared__ int16_t s_avg[64][SQZ_CHUNK + 2], s_res[64][SQZ_CHUNK + 2], s_out[64][2 * SQZ_CHUNK + 2];
 	const int32_t lane = threadIdx.x, y0 = (int32_t) blockIdx.x * 64, rows = min(64, ah - y0), ow = aw + rw;
 	int32_t left = 0;
 	for (int32_t x0 = 0; x0 < aw; x0 += SQZ_CHUNK) {
-		for (int32_t r = 0; r < rows; ++r) {
-			const size_t ra = (size_t) (y0 + r) * (size_t) aw, rr = (size_t) (y0 + r) * (size_t) rw;
-			if (x0 + lane < aw) s_avg[r][lane] = avg[ra + (size_t) (x0 + lane)];
-			if (lane == 0 && x0 + SQZ_CHUNK < aw) s_avg[r][SQZ_CHUNK] = avg[ra + (size_t) (x0 + SQZ_CHUNK)];
-			if (x0 + lane < rw) s_res[r][lane] = res[rr + (size_t) (x0 + lane)];
+		for (int32_t r0 = 0; r0 < rows; r0 += 8) {   // eight rows' requests in flight before the first one is waited for
+			int16_t va[8], vr[8], ve[8];
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				const int32_t r = min(r0 + j, rows - 1);
+				const size_t ra = (size_t) (y0 + r) * (size_t) aw, rr = (size_t) (y0 + r) * (size_t) rw;
+				va[j] = x0 + lane < aw ? avg[ra + (size_t) (x0 + lane)] : (int16_t) 0;
+				ve[j] = lane == 0 && x0 + SQZ_CHUNK < aw ? avg[ra + (size_t) (x0 + SQZ_CHUNK)] : (int16_t) 0;
+				vr[j] = x0 + lane < rw ? res[rr + (size_t) (x0 + lane)] : (int16_t) 0;
+			}
+#pragma unroll
+			for (int j = 0; j < 8; ++j) if (r0 + j < rows) {
+				s_avg[r0 + j][lane] = va[j];
+				if (lane == 0) s_avg[r0 + j][SQZ_CHUNK] = ve[j];
+				s_res[r0 + j][lane] = vr[j];
+			}
 		}
 		__syncthreads();
 		if (lane < rows) {
@@ -165,7 +176,7 @@ __global__ void __launch_bounds__(64) k_unsqueeze_h(const int16_t *avg, const in
 			if (aw > rw && aw - 1 >= x0 && aw - 1 < x0 + SQZ_CHUNK) s_out[lane][2 * (aw - 1 - x0)] = s_avg[lane][aw - 1 - x0];   // odd width: the last average passes through
 		}
 		__syncthreads();
-		for (int32_t r = 0; r < rows; ++r) {
+		for (int32_t r = 0; r < rows; ++r) {   // (stores do not wait for one another)
 			const size_t ro = (size_t) (y0 + r) * (size_t) ow + (size_t) (2 * x0);
 			if (2 * x0 + lane < ow) out[ro + (size_t) lane] = s_out[r][lane];
 			if (2 * x0 + 64 + lane < ow) out[ro + 64 + (size_t) lane] = s_out[r][64 + lane];
@@ -174,11 +185,34 @@ __global__ void __launch_bounds__(64) k_unsqueeze_h(const int16_t *avg, const in
 	}
 }
 
-// vertical step: one lane per column; consecutive lanes touch consecutive samples of a row, so every access is coalesced
-__global__ void __launch_bounds__(256) k_unsqueeze_v(const int16_t *avg, const int16_t *res, int16_t *out, int32_t aw, int32_t ah, int32_t rh) {
+// vertical step: one lane per column; consecutive lanes touch consecutive samples of a row, so every access is coalesced. The
+// recurrence runs down the column; its inputs do not depend on it, so they are requested SQZ_AHEAD rows ahead of their use (a
+// column of 8192 pairs would otherwise wait for memory 8192 times)
+enum { SQZ_AHEAD = 8 };
+__global__ void __launch_bounds__(256) k_unsqueeze_v(const int16_t *__restrict__ avg, const int16_t *__restrict__ res, int16_t *__restrict__ out, int32_t aw, int32_t ah, int32_t rh) {
 	const int32_t x = (int32_t) (blockIdx.x * blockDim.x + threadIdx.x);
 	if (x >= aw) return;
-	unsqueeze_line(avg + x, aw, rh > 0 ? res + x : avg + x, aw, ah, rh, out + x, aw);
+	const size_t pitch = (size_t) aw;
+	int32_t a_q[SQZ_AHEAD + 1], r_q[SQZ_AHEAD];   // a_q[j] = avg[k + j], r_q[j] = res[k + j] for the block of rows being processed
+	int32_t left = 0;
+	for (int32_t k0 = 0; k0 < rh; k0 += SQZ_AHEAD) {
+#pragma unroll
+		for (int j = 0; j <= SQZ_AHEAD; ++j) a_q[j] = k0 + j < ah ? (int32_t) avg[(size_t) (k0 + j) * pitch + (size_t) x] : 0;
+#pragma unroll
+		for (int j = 0; j < SQZ_AHEAD; ++j) r_q[j] = k0 + j < rh ? (int32_t) res[(size_t) (k0 + j) * pitch + (size_t) x] : 0;
+#pragma unroll
+		for (int j = 0; j < SQZ_AHEAD; ++j) {
+			const int32_t k = k0 + j;
+			if (k < rh) {
+				const int32_t a = a_q[j], next = k + 1 < ah ? a_q[j + 1] : a;
+				int32_t p, q;
+				unsqueeze_pair(a, r_q[j], k > 0 ? left : a, next, &p, &q);
+				out[(size_t) (2 * k) * pitch + (size_t) x] = (int16_t) p; out[(size_t) (2 * k + 1) * pitch + (size_t) x] = (int16_t) q;
+				left = (int16_t) q;
+			}
+		}
+	}
+	if (ah > rh) out[(size_t) (2 * rh) * pitch + (size_t) x] = avg[(size_t) rh * pitch + (size_t) x];
 }
 
 __global__ void __launch_bounds__(256) k_pack_planes(const int16_t *r, const int16_t *g, const int16_t *b, const int16_t *a, int32_t width, int32_t height, int32_t bpp, uint8_t *rgba, size_t stride_bytes) {
