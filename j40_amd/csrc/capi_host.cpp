@@ -274,6 +274,14 @@ uint32_t j40hip_frame_vardct_view(j40hip_frame *h, j40hip_vardct_view *v) {
 	return 0;
 }
 
+// Modular frames: how many of the plan's sections the wave-cooperative kernel takes (modular_coop.hip), out of how many; -1: no plan
+int32_t j40hip_frame_coop_sections(j40hip_frame *h, int32_t *total) {
+	HostModPlan hp;
+	if (build_modular_plan(h->frame, h->cs, h->cs_size, &hp)) return -1;
+	if (total) *total = (int32_t) hp.sections.size();
+	return hp.coop_sections;
+}
+
 uint32_t j40hip_frame_modular_view(j40hip_frame *h, j40hip_modular_view *v) {
 	HostModPlan hp;
 	if (uint32_t e = build_modular_plan(h->frame, h->cs, h->cs_size, &hp)) return e;

@@ -32,6 +32,7 @@ __global__ void __launch_bounds__(64) k_modular_sections(DevModPlan plan, int32_
 	const int32_t lane = threadIdx.x;
 	const int32_t s = first_section + (int32_t) blockIdx.x;
 	const DevModSection &msec = plan.sections[s];
+	if (msec.coop_idx >= 0) return;   // k_modular_coop's
 	if (msec.preset_status) { if (lane == 0) plan.status[s] = msec.preset_status; return; }
 	const DevCodeSpec &spec = plan.spec[msec.spec_idx];
 	ModTables t = mod_tables_in_hbm(plan, s);
@@ -69,6 +70,7 @@ __global__ void __launch_bounds__(64) k_modular_sections_lanes(DevModPlan plan, 
 	const int32_t s = first_section + (int32_t) (blockIdx.x * 64 + threadIdx.x);
 	if (s >= first_section + num_sections) return;
 	const DevModSection &msec = plan.sections[s];
+	if (msec.coop_idx >= 0) return;
 	if (msec.preset_status) { plan.status[s] = msec.preset_status; return; }
 	const ModTables t = mod_tables_in_hbm(plan, s);
 	plan.status[s] = decode_modular_section<false, false>(plan, t, s);
@@ -229,6 +231,9 @@ static unsigned grid_for(size_t n) { size_t b = (n + 255) / 256; return (unsigne
 // sections [first_section, first_section + num_sections): the passes of a multi-pass frame are launched one after the other
 void launch_modular_sections(const DevModPlan &plan, int32_t first_section, int32_t num_sections, const ModLaunchInfo &info, hipStream_t stream) {
 	if (num_sections <= 0) return;
+	// the sections the wave-cooperative kernel takes (modular_coop.hip), then the others
+	if (info.coop_width > 0) launch_modular_coop(plan, first_section, num_sections, info.coop_width, stream);
+	if (info.all_coop) return;
 	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
 	const uint32_t wp_bytes = info.uses_wp ? align16(40u * (uint32_t) info.max_width) : 0;
 	const uint32_t lds = align16((uint32_t) info.num_tree_nodes * (uint32_t) sizeof(DevTreeNode)) + align16((uint32_t) info.num_dist + 4)

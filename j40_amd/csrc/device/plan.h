@@ -184,6 +184,25 @@ struct DevModSection {
 	// frames whose channels differ in size (Squeeze): the section's channels as explicit rectangles,
 	// DevModPlan::chan_rects[chan_off .. chan_off + num_channels). -1: first_channel ... over the rectangle above
 	int32_t chan_off;
+	// >= 0: the section is decoded by the wave-cooperative kernel (modular_coop.hip) with DevModPlan::coop_trees[coop_idx];
+	// -1: by k_modular_sections
+	int32_t coop_idx;
+};
+
+// An MA tree laid out for a wavefront that decodes ONE section with all 64 lanes (k_modular_coop): lane i holds branch node i
+// (property, threshold) and leaf i. Per sample every lane evaluates its node's test at once (one ballot = the outcome of every
+// branch of the tree), and leaf i is the one reached iff the outcomes of its ancestors are the ones on its path:
+// (outcomes & leaf_mask) == leaf_want. The leaf's cluster is resolved on the host (context -> cluster -> hybrid config, alias table).
+// Trees with at most 64 leaves, properties 0..14, no weighted predictor; rANS code specs without LZ77.
+struct DevCoopTree {
+	uint32_t used_props;        // bit q: some branch tests property q
+	int32_t num_nodes, num_leaves, pad;
+	int32_t node_prop[64];      // -1: no branch in this lane
+	int32_t node_thr[64];
+	uint32_t mask_lo[64], mask_hi[64], want_lo[64], want_hi[64];
+	uint32_t leaf_a[64];        // predictor | hybrid-int config << 4 | max_token << 16
+	uint32_t leaf_tab[64];      // the leaf's cluster: first alias entry in the u64 pool
+	int32_t leaf_off[64], leaf_mul[64];
 };
 
 // a coded channel of the frame (or a plane of a section's sub-image): tightly packed int16 rows
@@ -223,6 +242,7 @@ struct DevModPlan {
 	const DevPlaneRef *planes;        // [num_channels] sample planes of the coded channels; meta = 1: meta channel (palette), decoded
 	                                  // whole and never a "previous channel" of image channels
 	const DevChanRect *chan_rects;    // DevModSection::chan_off
+	const DevCoopTree *coop_trees;    // DevModSection::coop_idx
 	int32_t *wp_scratch;              // [num_sections][2 * max_width * 5] weighted-predictor error rows
 	int32_t *lz_window; uint32_t lz_window_size;
 	uint32_t *status;                 // [num_sections]
@@ -261,7 +281,11 @@ struct HfLaunchInfo {
 };
 
 // sizes the host knows about a Modular frame's tree and code tables, to lay out k_modular_sections' LDS
-struct ModLaunchInfo { int32_t num_tree_nodes, num_dist, num_clusters; uint32_t table_bytes; int32_t max_width, uses_wp; };
+struct ModLaunchInfo {
+	int32_t num_tree_nodes, num_dist, num_clusters; uint32_t table_bytes; int32_t max_width, uses_wp;
+	int32_t coop_width;   // widest channel rectangle of the sections k_modular_coop decodes; 0: none
+	int32_t all_coop;     // every section goes to k_modular_coop
+};
 
 enum {
 	ERR_SHRT = ('s' << 24) | ('h' << 16) | ('r' << 8) | 't',

@@ -178,7 +178,7 @@ struct j40hip_device_state {
 	bool has_trailers = false;           // VarDCT frame whose sections go on with the extra channels' Modular sub-image
 	bool idle = false;                   // j40hip_frame_mark_idle: nothing is pending on this frame's memory, freeing it needs no device-wide wait
 	bool trailers_pending = false;       // ... decoded by a batch since: j40hip_frame_status validates the sub-images before it reports
-	ModLaunchInfo mod_info = {0, 0, 0, 0, 0, 0};
+	ModLaunchInfo mod_info = {0, 0, 0, 0, 0, 0, 0, 0};
 	std::vector<uint32_t> mod_section_offsets;
 	struct ModOp { int kind; int16_t *a, *b, *c; const int16_t *src, *aux; size_t n; int32_t p0, p1, p2, p3, p4, p5; int16_t *const *dst_list; const int8_t *wpp; };
 	std::vector<ModOp> mod_ops;          // inverse transforms of the frame, in execution order
@@ -244,10 +244,11 @@ static uint32_t upload_modular(j40hip_frame *h, int device) {
 	plan.spec = st->upload(hp.specs.data(), hp.specs.size(), s, ok);
 	plan.tree = st->upload(hp.tree.data(), hp.tree.size(), s, ok);
 	plan.sections = st->upload(hp.sections.data(), hp.sections.size(), s, ok);
+	if (!hp.coop_trees.empty()) plan.coop_trees = st->upload(hp.coop_trees.data(), hp.coop_trees.size(), s, ok);
 	st->mod_local_rcts = !hp.local_rct.empty();
 	if (st->mod_local_rcts) plan.local_rct = st->upload(hp.local_rct.data(), hp.local_rct.size(), s, ok);
 	st->mod_sections = (int32_t) hp.sections.size(); st->mod_passes = hp.num_passes; st->mod_sections_per_pass = hp.sections_per_pass;
-	st->mod_info = {hp.max_tree_nodes, hp.max_num_dist, hp.max_clusters, hp.max_table_bytes, hp.frame.max_width, hp.any_wp ? 1 : 0};
+	st->mod_info = {hp.max_tree_nodes, hp.max_num_dist, hp.max_clusters, hp.max_table_bytes, hp.frame.max_width, hp.any_wp ? 1 : 0, hp.coop_width, hp.coop_sections == (int32_t) hp.sections.size()};
 	for (const DevModSection &sec : hp.sections) st->mod_section_offsets.push_back(sec.byte_off);
 	const int32_t nch = hp.frame.num_channels;
 	struct Ref { int16_t *p; int32_t w, h; };
@@ -587,6 +588,7 @@ static uint32_t validate_trailers(j40hip_frame *h, hipStream_t s) {
 		plan.spec = tmp.upload(hp.specs.data(), hp.specs.size(), s, ok);
 		plan.tree = tmp.upload(hp.tree.data(), hp.tree.size(), s, ok);
 		plan.sections = tmp.upload(hp.sections.data(), hp.sections.size(), s, ok);
+		if (!hp.coop_trees.empty()) plan.coop_trees = tmp.upload(hp.coop_trees.data(), hp.coop_trees.size(), s, ok);
 		std::vector<DevSubPlane> subp(hp.sub_w.size());
 		size_t total = 0;
 		for (size_t k = 0; k < subp.size(); ++k) total += (size_t) hp.sub_w[k] * (size_t) hp.sub_h[k] + 1;
@@ -598,7 +600,7 @@ static uint32_t validate_trailers(j40hip_frame *h, hipStream_t s) {
 		if (hp.lz_window_size) plan.lz_window = tmp.scratch<int32_t>(hp.sections.size() * hp.lz_window_size, ok);
 		plan.status = tmp.scratch<uint32_t>(hp.sections.size() + 1, ok);
 		if (ok) {
-			const ModLaunchInfo info = {hp.max_tree_nodes, hp.max_num_dist, hp.max_clusters, hp.max_table_bytes, hp.frame.max_width, hp.any_wp ? 1 : 0};
+			const ModLaunchInfo info = {hp.max_tree_nodes, hp.max_num_dist, hp.max_clusters, hp.max_table_bytes, hp.frame.max_width, hp.any_wp ? 1 : 0, hp.coop_width, hp.coop_sections == (int32_t) hp.sections.size()};
 			launch_modular_sections(plan, 0, (int32_t) hp.sections.size(), info, s);
 			ok = hipMemcpyAsync(found.data(), plan.status, sizeof(uint32_t) * found.size(), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
 		}

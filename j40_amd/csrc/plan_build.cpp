@@ -276,6 +276,75 @@ static void attach_tables(const Frame &fr, HostModPlan *hp, int32_t &global_spec
 	hp->any_lz77 = hp->any_lz77 || sp.lz77_enabled; hp->any_wp = hp->any_wp || s->uses_wp;
 }
 
+// the MA tree at hp->tree[tree_off ...] with code spec `spec_idx` as a DevCoopTree, or false when k_modular_coop cannot take it
+static bool build_coop_tree(const HostModPlan &hp, uint32_t tree_off, int32_t tree_nodes, int32_t spec_idx, DevCoopTree *out) {
+	const DevCodeSpec &sp = hp.specs[(size_t) spec_idx];
+	const CodeSpec &hs = hp.host_specs[(size_t) spec_idx];
+	if (sp.use_prefix_code || sp.lz77_enabled || tree_nodes <= 0) return false;
+	memset(out, 0, sizeof *out);
+	for (int i = 0; i < 64; ++i) { out->node_prop[i] = -1; out->want_lo[i] = 1; }   // (mask 0, want 1: never reached)
+	struct Item { int32_t node; uint64_t mask, want; };
+	std::vector<Item> stack{{0, 0, 0}};
+	int32_t nn = 0, nl = 0;
+	while (!stack.empty()) {
+		const Item it = stack.back(); stack.pop_back();
+		if (it.node < 0 || it.node >= tree_nodes) return false;
+		const DevTreeNode &n = hp.tree[(size_t) tree_off + (size_t) it.node];
+		if (n.prop >= 0) {
+			if (n.prop > 14 || nn >= 64) return false;
+			const uint64_t bit = (uint64_t) 1 << nn;
+			out->node_prop[nn] = n.prop; out->node_thr[nn] = n.value; out->used_props |= 1u << n.prop; ++nn;
+			stack.push_back({it.node + n.b, it.mask | bit, it.want});
+			stack.push_back({it.node + n.a, it.mask | bit, it.want | bit});
+		} else {
+			const int32_t predictor = -1 - n.prop;
+			if (predictor == 6 || predictor > 13 || nl >= 64) return false;
+			if (n.value < 0 || n.value >= sp.num_dist || (size_t) n.value >= hs.cluster_map.size()) return false;
+			const DevCluster &cl = hp.clusters[(size_t) sp.cluster_off + (size_t) hs.cluster_map[(size_t) n.value]];
+			if (cl.max_token < 0 || cl.max_token > 0xffff || cl.cfg > 0xfff) return false;
+			out->mask_lo[nl] = (uint32_t) it.mask; out->mask_hi[nl] = (uint32_t) (it.mask >> 32);
+			out->want_lo[nl] = (uint32_t) it.want; out->want_hi[nl] = (uint32_t) (it.want >> 32);
+			out->leaf_a[nl] = (uint32_t) predictor | cl.cfg << 4 | (uint32_t) cl.max_token << 16;
+			out->leaf_tab[nl] = cl.table_off; out->leaf_off[nl] = n.a; out->leaf_mul[nl] = n.b;
+			++nl;
+		}
+	}
+	out->num_nodes = nn; out->num_leaves = nl;
+	return true;
+}
+
+// which sections k_modular_coop decodes: those whose tree / code spec it can take and whose channels are not wider than its row
+// buffers allow
+static void assign_coop(HostModPlan *hp) {
+	static const bool off = [] { const char *e = getenv("J40HIP_NO_COOP"); return e && atoi(e); }();
+	std::vector<std::pair<uint64_t, int32_t>> known;   // (tree_off, spec_idx) -> coop tree or -1
+	hp->coop_width = 0; hp->coop_sections = 0;
+	for (DevModSection &s : hp->sections) {
+		s.coop_idx = -1;
+		if (off || s.preset_status) continue;
+		int32_t widest = 0;
+		for (int32_t c = 0; c < s.num_channels; ++c) {
+			int32_t w;
+			if (s.sub_off >= 0) w = hp->sub_w[(size_t) (s.sub_off + c)];
+			else if (s.chan_off >= 0) w = hp->chan_rects[(size_t) (s.chan_off + c)].w;
+			else w = hp->plane_meta[(size_t) (s.first_channel + c)] ? hp->plane_w[(size_t) (s.first_channel + c)] : s.gw;
+			widest = std::max(widest, w);
+		}
+		if (widest > 4096) continue;
+		const uint64_t key = (uint64_t) s.tree_off << 32 | (uint32_t) s.spec_idx;
+		int32_t idx = -2;
+		for (const auto &k : known) if (k.first == key) { idx = k.second; break; }
+		if (idx == -2) {
+			DevCoopTree t;
+			idx = build_coop_tree(*hp, s.tree_off, s.tree_nodes, s.spec_idx, &t) ? (int32_t) hp->coop_trees.size() : -1;
+			if (idx >= 0) hp->coop_trees.push_back(t);
+			known.push_back({key, idx});
+		}
+		s.coop_idx = idx;
+		if (idx >= 0) { hp->coop_width = std::max(hp->coop_width, widest); ++hp->coop_sections; }
+	}
+}
+
 uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostModPlan *hp) {
 	if (!fr.fh.is_modular) return ERR_TODO;
 	if (cs_size + 16 >= ((size_t) 1 << 29)) return ERR_TODO;   // the kernels address the codestream with 32-bit BIT positions
@@ -473,6 +542,7 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 	hp->codestream.reserve(cs_size + 32);   // (assign + resize without it reallocates and copies the stream a second time)
 	hp->codestream.assign(cs, cs + cs_size);
 	hp->codestream.resize(cs_size + 32, 0);   // the lane decoders read up to three words past the position they stop at
+	assign_coop(hp);
 	return 0;
 }
 
@@ -531,6 +601,7 @@ uint32_t build_trailer_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 		for (const DevModSection &s : hp->sections) { size_t n = 0; for (int32_t c = 0; c < s.num_channels; ++c) n += (size_t) hp->sub_w[(size_t) (s.sub_off + c)] * (size_t) hp->sub_h[(size_t) (s.sub_off + c)]; most = std::max(most, n); }
 		hp->lz_window_size = (uint32_t) std::min<size_t>(most + 16, (size_t) 1 << 26);
 	}
+	assign_coop(hp);
 	return 0;
 }
 

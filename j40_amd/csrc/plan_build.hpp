@@ -76,6 +76,8 @@ struct HostModPlan {
 	std::vector<int32_t> sub_w, sub_h, sub_meta;          // the sub-images' planes, SubImage::first_plane ...
 	std::vector<int32_t> plane_w, plane_h, plane_meta;   // coded channels
 	std::vector<DevChanRect> chan_rects;                  // sections of frames with channels of different sizes (DevModSection::chan_off)
+	std::vector<DevCoopTree> coop_trees;                  // DevModSection::coop_idx
+	int32_t coop_width = 0, coop_sections = 0;            // widest channel / number of the sections k_modular_coop takes
 	std::vector<Transform> transforms;                    // global transforms in coded order
 	int32_t alpha_channel = -1;                           // index (after inverse transforms) of the first alpha extra channel
 	uint32_t lz_window_size = 0;

@@ -431,3 +431,50 @@ extern "C" __attribute__((visibility("default"))) uint64_t hostsim_srgb_u8_sweep
 	}
 	return bad;
 }
+
+// the DevCoopTree of every section k_modular_coop takes (plan_build.cpp, assign_coop), checked against a walk of the MA tree
+// it was built from: for `trials` random property vectors per tree, the leaf the masks select must carry the walk's leaf.
+// returns the number of trees checked, or -(1 + mismatches)
+extern "C" __attribute__((visibility("default"))) int32_t hostsim_coop_check(const uint8_t *buf, size_t size, uint32_t seed, int32_t trials) {
+	Frame fr;
+	const uint8_t *cs; size_t cs_size; std::vector<uint8_t> storage;
+	HostModPlan hp;
+	try {
+		extract_codestream(buf, size, &cs, &cs_size, &storage);
+		parse_frame(cs, cs_size, &fr, 1);
+	} catch (const DecodeError &e) { return 0; }
+	if (!fr.fh.is_modular || build_modular_plan(fr, cs, cs_size, &hp)) return 0;
+	int32_t checked = 0, bad = 0;
+	std::vector<char> seen(hp.coop_trees.size(), 0);
+	auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return seed >> 8; };
+	for (const DevModSection &s : hp.sections) {
+		if (s.coop_idx < 0 || seen[(size_t) s.coop_idx]) continue;
+		seen[(size_t) s.coop_idx] = 1; ++checked;
+		const DevCoopTree &t = hp.coop_trees[(size_t) s.coop_idx];
+		const DevTreeNode *tree = hp.tree.data() + s.tree_off;
+		const DevCodeSpec &sp = hp.specs[(size_t) s.spec_idx];
+		for (int32_t k = 0; k < trials; ++k) {
+			int32_t props[15];
+			for (int q = 0; q < 15; ++q) {
+				// values around the thresholds the tree tests, so that both sides of every branch are taken
+				const int32_t pick = t.num_nodes ? t.node_thr[rnd() % (uint32_t) t.num_nodes] : 0;
+				props[q] = pick + (int32_t) (rnd() % 5) - 2;
+				if (rnd() % 4 == 0) props[q] = (int32_t) (rnd() % 65536) - 32768;
+			}
+			const DevTreeNode *n = tree;
+			while (n->prop >= 0) n += props[n->prop] > n->value ? n->a : n->b;
+			uint64_t outcomes = 0;
+			for (int i = 0; i < 64; ++i) if (t.node_prop[i] >= 0 && props[t.node_prop[i]] > t.node_thr[i]) outcomes |= (uint64_t) 1 << i;
+			int32_t leaf = -1, matches = 0;
+			for (int i = 0; i < 64; ++i) {
+				const uint64_t mask = (uint64_t) t.mask_lo[i] | (uint64_t) t.mask_hi[i] << 32, want = (uint64_t) t.want_lo[i] | (uint64_t) t.want_hi[i] << 32;
+				if ((outcomes & mask) == want) { ++matches; if (leaf < 0) leaf = i; }
+			}
+			const DevCluster &cl = hp.clusters[(size_t) sp.cluster_off + (size_t) hp.pool_u8[sp.cluster_map_off + (uint32_t) n->value]];
+			const bool same = matches == 1 && leaf >= 0 && (int32_t) (t.leaf_a[leaf] & 15) == -1 - n->prop && t.leaf_off[leaf] == n->a && t.leaf_mul[leaf] == n->b
+				&& t.leaf_tab[leaf] == cl.table_off && ((t.leaf_a[leaf] >> 4) & 0xfff) == cl.cfg && (int32_t) (t.leaf_a[leaf] >> 16) == cl.max_token;
+			bad += !same;
+		}
+	}
+	return bad ? -(1 + bad) : checked;
+}

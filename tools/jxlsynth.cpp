@@ -15,6 +15,7 @@
 #include "jxlsynth_modular.hpp"
 #include <cmath>
 #include <map>
+#include <functional>
 
 using namespace synth;
 
@@ -892,6 +893,24 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 			int a = tree.branch(15, 8, l0, l1);       // max weighted-predictor error
 			int b = tree.branch(15, -8, l2, l3);
 			root = tree.branch(0, 1, a, b);
+		} else if (tree_kind == 5) {
+			// a wide tree: every property 0..14, every predictor but the weighted one, offsets and multipliers; 48 leaves
+			static const int PREDS[13] = {5, 1, 2, 3, 4, 0, 7, 8, 9, 10, 11, 12, 13};
+			static const int THR[15] = {1, 2, 60, 90, 30, 25, 110, 130, 2, 120, -1, 3, -4, 5, -2};
+			uint32_t r = 12345u; int leaves = 0, splits = 0;
+			std::function<int(int)> grow = [&](int depth) -> int {
+				r = r * 1664525u + 1013904223u;
+				if (depth == 0 || (depth < 4 && ((r >> 9) & 3) == 0)) {
+					const int k = leaves++;
+					return tree.leaf(PREDS[k % 13], (k % 5) - 2, k % 7 == 3 ? 1 : 0, k % 11 == 5 ? 2 : 0);
+				}
+				const int prop = splits++ % 15;
+				const int thr = THR[prop] + (int) ((r >> 12) % 7) - 3;
+				const int left = grow(depth - 1), right = grow(depth - 1);
+				return tree.branch(prop, thr, left, right);
+			};
+			root = grow(6);
+			while (leaves > 64) die("tree=5 grew past 64 leaves");
 		} else {
 			int l0 = tree.leaf(5), l1 = tree.leaf(5), l2 = tree.leaf(1), l3 = tree.leaf(2), l4 = tree.leaf(5);
 			int a = tree.branch(16, 10, l0, l1);      // previous channel sample
