@@ -40,9 +40,9 @@ build/libhostsim.so: tests/hostsim/hostsim.cpp $(SRC)/plan_build.cpp $(SRC)/entr
 	@mkdir -p build
 	$(CXX) -std=c++17 -O2 -fPIC -shared -ffp-contract=off -Wall -Wextra -Wno-unused-function -Wno-unknown-pragmas -o $@ tests/hostsim/hostsim.cpp $(SRC)/plan_build.cpp $(SRC)/entropy.cpp $(SRC)/modular.cpp $(SRC)/tables.cpp $(SRC)/frame.cpp -lpthread
 
-build/jxlsynth: tools/jxlsynth.cpp $(wildcard tools/*.hpp)
+build/jxlsynth: tools/jxlsynth.cpp $(wildcard tools/*.hpp) $(SRC)/tables.cpp $(SRC)/device/special8_dev.h $(SRC)/device/idct_dev.h
 	@mkdir -p build
-	$(CXX) -O2 -std=c++17 -Wall -Wextra -o $@ $<
+	$(CXX) -O2 -std=c++17 -ffp-contract=off -Wall -Wextra -Wno-unused-function -Wno-unknown-pragmas -o $@ $< $(SRC)/tables.cpp
 
 clean:
 	rm -rf build

@@ -118,9 +118,9 @@ def main():
     ap.add_argument("--width", type=int, default=7680)
     ap.add_argument("--height", type=int, default=4320)
     ap.add_argument("--seed", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--distinct", type=int, default=64, help="distinct streams a batch cycles through")
-    ap.add_argument("--pipe-batch", type=int, default=128, help="frames per entropy launch inside the pipeline")
+    ap.add_argument("--pipe-batch", type=int, default=256, help="frames per entropy launch inside the pipeline")
     ap.add_argument("--host-threads", type=int, default=0, help="pipeline worker threads per GPU (default: the container's CPU quota / GPUs)")
     ap.add_argument("--resident-batch", type=int, default=256, help="frames of the device-resident section (kernels only, as round 1 measured)")
     ap.add_argument("--shard-groups", action="store_true")
@@ -203,7 +203,7 @@ def main():
     try:
         pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if abs(pt.get("frames_per_launch", 0) - frames_per_launch) < 1 and (W, H) == (7680, 4320):
-            result["roofline"]["traffic"] = int((pt["fetch_size_kb"] + pt["write_size_kb"]) * 1000)
+            result["roofline"]["traffic"] = int((pt["fetch_size_kb"] * pt.get("fetch_correction", 1.0) + pt["write_size_kb"]) * 1024)
             result["roofline"]["traffic_source"] = pt["source"]
     except (OSError, ValueError, KeyError):
         pass

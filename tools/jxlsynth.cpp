@@ -4,15 +4,21 @@
 // the tests and bench.py decode: VarDCT frames (all 27 transform types, rANS with clustered
 // contexts, optional custom block-context map / coefficient orders / HF presets / multiple passes)
 // and Modular frames (single- and multi-group, RCT / Palette, prefix codes with LZ77, weighted
-// predictor). Streams are synthesised in the *coefficient / residual domain*: the LF image comes
-// from a smooth procedural picture, HF coefficients are sparse with frequency-decaying
-// magnitudes so that size and symbol statistics resemble a distance-1 encode. The reference
-// decoder (oracle/_ref) is the judge of validity; what a stream decodes to is defined by it.
+// predictor). Two ways to make a VarDCT frame:
+//   forward=1  an ENCODE of a procedural picture: XYB forward, LF = 8x8 means, forward transform per varblock
+//              (jxlsynth_forward.hpp), quantisation at about distance 1 with the library matrices, transform sizes and
+//              HfMul chosen from local activity. Size, symbols per pixel and the spread of the sections' lengths follow
+//              from the picture (1/f detail whose strength varies over the frame: `detail=`). What bench.py decodes.
+//   forward=0  synthesis in the *coefficient domain* (the feature-matrix streams of the tests and the golden fixtures): the
+//              LF image comes from a smooth procedural picture, HF coefficients are sparse with frequency-decaying
+//              magnitudes; every transform type and bitstream feature can be forced into a small frame.
+// The reference decoder (oracle/_ref) is the judge of validity; what a stream decodes to is defined by it.
 //
 // usage: jxlsynth vardct  W H SEED OUT [key=value ...]
 //        jxlsynth modular W H SEED OUT [key=value ...]
 #include "jxlsynth_common.hpp"
 #include "jxlsynth_modular.hpp"
+#include "jxlsynth_forward.hpp"
 #include <cmath>
 #include <map>
 #include <functional>
@@ -207,7 +213,7 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 	const int global_scale = opt.geti("global_scale", 8192), quant_lf = opt.geti("quant_lf", 4);
 	const double density = opt.getd("density", 0.80), decay = opt.getd("decay", 0.84);
 	const int max_log = opt.geti("maxlog", 6);              // largest transform side (log2) used in the mix
-	const int coverage = opt.geti("coverage", 1);           // 1: force every transform type <= maxlog at least once per frame
+	const int coverage = opt.geti("coverage", opt.geti("forward", 0) ? 0 : 1);           // 1: force every transform type <= maxlog at least once per frame
 	const int custom_bctx = opt.geti("bctx", 0);            // custom block context map with LF/QF thresholds
 	const int num_presets = opt.geti("presets", 1);
 	const int custom_orders = opt.geti("orders", 0);
@@ -250,6 +256,59 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 	const double m_lf[3] = {1.0 / 4096, 1.0 / 512, 1.0 / 256};
 	double lfstep[3]; for (int c = 0; c < 3; ++c) lfstep[c] = m_lf[c] / ((double) global_scale * quant_lf) * 65536.0;
 
+	// ---- forward=1: the picture's XYB samples (planes padded to whole cells, edges replicated) ----
+	const int forward = opt.geti("forward", 0);
+	if (forward && (num_passes > 1 || max_log > 6 || opt.geti("cfl", 0))) die("vardct: forward=1 takes one pass, transforms up to 64x64, default chroma-from-luma");
+	const int PW = (W + 7) / 8 * 8, PH = (H + 7) / 8 * 8;
+	std::vector<float> plane[3];
+	std::unique_ptr<synthfwd::Forward> fwdx;
+	if (forward) {
+		fwdx.reset(new synthfwd::Forward());
+		// 1/f detail: octaves of lattice noise from 256-pixel cells down to 2-pixel cells, amplitude falling with the cell size,
+		// its strength modulated by a slowly varying mask (calm and busy regions, like sky and foliage)
+		const double detail = opt.getd("detail", 2.4), beta = opt.getd("beta", 0.35);
+		struct Lattice { int cell, w, h; float amp; std::vector<float> v; };
+		std::vector<Lattice> lat;
+		SplitMix64 lr(seed ^ 0xD37A11ull);
+		for (int cell = 256; cell >= 2; cell /= 2) {
+			Lattice l; l.cell = cell; l.w = PW / cell + 2; l.h = PH / cell + 2; l.amp = (float) (0.2 * detail * pow((double) cell / 256.0, beta));
+			l.v.resize((size_t) l.w * (size_t) l.h);
+			for (auto &v : l.v) v = (float) lr.unit() - 0.5f;
+			lat.push_back(std::move(l));
+		}
+		Lattice mask; mask.cell = 512; mask.w = PW / 512 + 2; mask.h = PH / 512 + 2; mask.amp = 1.0f; mask.v.resize((size_t) mask.w * (size_t) mask.h);
+		for (auto &v : mask.v) { const double u = lr.unit(); v = (float) (0.12 + 1.5 * u * u); }
+		auto sample = [](const Lattice &l, int x, int y) {
+			const float u = (float) x / (float) l.cell, v = (float) y / (float) l.cell;
+			const int iu = (int) u, iv = (int) v; const float fu = u - (float) iu, fv = v - (float) iv;
+			const float *p = l.v.data() + (size_t) iv * (size_t) l.w + (size_t) iu;
+			return (p[0] * (1 - fu) + p[1] * fu) * (1 - fv) + (p[l.w] * (1 - fu) + p[l.w + 1] * fu) * fv;
+		};
+		for (int c = 0; c < 3; ++c) plane[c].resize((size_t) PW * (size_t) PH);
+		const std::string dumpsrc = opt.gets("dumpsrc", "");   // the source picture as sRGB u8 x 3, for the fidelity test
+		std::vector<uint8_t> srcdump(dumpsrc.empty() ? 0 : (size_t) W * (size_t) H * 3);
+		static const float CHROMA[3] = {1.0f, 0.92f, 0.8f};
+		for (int y = 0; y < PH; ++y) for (int x = 0; x < PW; ++x) {
+			const int sx = std::min(x, W - 1), sy = std::min(y, H - 1);
+			float rgb[3]; double xyb[3];
+			pic.rgb((float) sx, (float) sy, rgb);
+			float n = 0;
+			for (const Lattice &l : lat) n += l.amp * sample(l, sx, sy);
+			n *= sample(mask, sx, sy);
+			for (int c = 0; c < 3; ++c) rgb[c] = std::min(0.97f, std::max(0.03f, rgb[c] + n * CHROMA[c]));
+			if (!dumpsrc.empty() && x < W && y < H) for (int c = 0; c < 3; ++c) srcdump[((size_t) y * (size_t) W + (size_t) x) * 3 + (size_t) c] = (uint8_t) lrintf(rgb[c] * 255.0f);
+			to_xyb(rgb, xyb);
+			for (int c = 0; c < 3; ++c) plane[c][(size_t) y * (size_t) PW + (size_t) x] = (float) xyb[c];
+		}
+		if (!dumpsrc.empty()) { FILE *fp = fopen(dumpsrc.c_str(), "wb"); if (!fp || fwrite(srcdump.data(), 1, srcdump.size(), fp) != srcdump.size()) die("cannot write dumpsrc"); fclose(fp); }
+	}
+	// activity of a cell: variance of its Y samples
+	auto cell_activity = [&](int cx, int cy) {
+		double s = 0, s2 = 0;
+		for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) { const double v = plane[1][(size_t) (cy * 8 + y) * (size_t) PW + (size_t) (cx * 8 + x)]; s += v; s2 += v * v; }
+		return std::max(0.0, s2 / 64 - (s / 64) * (s / 64));
+	};
+
 	const int custom_cfl = opt.geti("cfl", 0);
 	const double kx_lf = custom_cfl ? 0.125 + 3.0 / 128.0 : 0.0, kb_lf = custom_cfl ? 0.75 - 2.0 / 128.0 : 1.0;
 
@@ -285,8 +344,12 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 		for (int c = 0; c < 3; ++c) gg.lfq[c] = Channel(gg.w8, gg.h8);
 		for (int y = 0; y < gg.h8; ++y) for (int x = 0; x < gg.w8; ++x) {
 			float rgb[3]; double xyb[3];
-			pic.rgb((float) (gg.left + x * 8) + 3.5f, (float) (gg.top + y * 8) + 3.5f, rgb);
-			to_xyb(rgb, xyb);
+			if (forward) {   // the cell's mean
+				for (int c = 0; c < 3; ++c) { double m = 0; for (int j = 0; j < 8; ++j) for (int i = 0; i < 8; ++i) m += plane[c][(size_t) (gg.top + y * 8 + j) * (size_t) PW + (size_t) (gg.left + x * 8 + i)]; xyb[c] = m / 64; }
+			} else {
+				pic.rgb((float) (gg.left + x * 8) + 3.5f, (float) (gg.top + y * 8) + 3.5f, rgb);
+				to_xyb(rgb, xyb);
+			}
 			gg.lfq[0].at(x, y) = (int32_t) lrint(xyb[1] / lfstep[1]);  // streamed order: Y, X, B
 			gg.lfq[1].at(x, y) = (int32_t) lrint(xyb[0] / lfstep[0]);
 			// the decoder adds kb_lf * Y to the LF of B and kx_lf * Y to X (j40.h:7115-7116, 7159-7171)
@@ -318,14 +381,28 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 				for (int k = 0; k < 27; ++k) if (std::max(DCTSEL[k][0], DCTSEL[k][1]) <= max_log) { if (pick < mixw[k]) { t = k; break; } pick -= mixw[k]; }
 				if (!fits(t)) t = 0;
 			}
+			int hfmul_m1 = 3 + (int) rng.below(10);
+			if (forward) {
+				// what an encoder's heuristics amount to: large transforms only over calm content, the 8x8 specials only where there
+				// is something to localise, finer quantisation (larger HfMul) where errors show (calm areas)
+				auto worst = [&](int tt) { double a = 0; for (int y = y0; y < y0 + (1 << (DCTSEL[tt][0] - 3)); ++y) for (int x = x0; x < x0 + (1 << (DCTSEL[tt][1] - 3)); ++x) a = std::max(a, cell_activity(gg.left / 8 + x, gg.top / 8 + y)); return a; };
+				if (std::max(DCTSEL[t][0], DCTSEL[t][1]) > 3 && worst(t) > 4e-5 * (double) (1 << (12 - DCTSEL[t][0] - DCTSEL[t][1])) ) t = 0;
+				if (DCTSEL[t][0] == 3 && DCTSEL[t][1] == 3) {
+					const double a = worst(t);
+					if (a < 2e-5) t = 0;
+					else if (t == 0 && a > 4e-4 && rng.below(3) == 0) { static const int SP[9] = {1, 2, 3, 12, 13, 14, 15, 16, 17}; t = SP[rng.below(9)]; }
+				}
+				const double a = worst(t);
+				hfmul_m1 = (a < 1e-5 ? 8 : a < 1e-4 ? 7 : a < 1e-3 ? 6 : 5) - 1;
+			}
 			int vw8 = 1 << (DCTSEL[t][1] - 3), vh8 = 1 << (DCTSEL[t][0] - 3), voff = (int) gg.vbs.size();
 			for (int y = y0; y < y0 + vh8; ++y) for (int x = x0; x < x0 + vw8; ++x) gg.blocks[(size_t) y * (size_t) gg.w8 + (size_t) x] = 1 << 20 | voff;
 			gg.blocks[(size_t) y0 * (size_t) gg.w8 + (size_t) x0] = (t + 2) << 20 | voff;
-			gg.vbs.push_back({x0, y0, t, 3 + (int) rng.below(10)});
+			gg.vbs.push_back({x0, y0, t, hfmul_m1});
 		}
 		gg.xfromy = Channel(gg.w64, gg.h64); gg.bfromy = Channel(gg.w64, gg.h64);
-		for (auto &v : gg.xfromy.px) v = (int32_t) rng.below(9) - 4;
-		for (auto &v : gg.bfromy.px) v = (int32_t) rng.below(13) - 6;
+		for (auto &v : gg.xfromy.px) v = forward ? 0 : (int32_t) rng.below(9) - 4;
+		for (auto &v : gg.bfromy.px) v = forward ? 0 : (int32_t) rng.below(13) - 6;
 		gg.blockinfo = Channel((int) gg.vbs.size(), 2);
 		for (size_t i = 0; i < gg.vbs.size(); ++i) { gg.blockinfo.at((int) i, 0) = gg.vbs[i].dctsel; gg.blockinfo.at((int) i, 1) = gg.vbs[i].hfmul_m1; }
 		gg.sharp = Channel(gg.w8, gg.h8);
@@ -458,6 +535,7 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 		}
 	}
 
+	std::vector<float> fpix, fcoef, fydeq;   // forward=1: one block's samples, coefficients, dequantised Y coefficients
 	for (int pass = 0; pass < num_passes; ++pass) {
 		for (int g = 0; g < num_groups; ++g) {
 			hf_enc[(size_t) pass].emplace_back(cspec[(size_t) pass]);
@@ -488,6 +566,31 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 					double p = density * (c == 1 ? 1.0 : c == 0 ? 0.35 : 0.55) / (double) num_passes;
 					std::vector<std::pair<int, int>> coefs;  // (scan index, value)
 					double pk = p; const double dk = pow(decay, 64.0 / (double) size);
+					if (forward) {
+						// the block's samples -> coefficients -> quantised with the weights the decoder divides by (j40.h:7086-7094);
+						// X and B code what is left after the decoder's chroma-from-luma term (default factors: 0 and 1 times the
+						// dequantised Y coefficient, j40.h:7138-7143, 7159-7171)
+						const int R = 1 << log_rows, C = 1 << log_cols;
+						const int px0 = gg.left + (gx8 + x8) * 8, py0 = gg.top + (gy8 + y8) * 8;
+						fpix.resize((size_t) size); fcoef.resize((size_t) size);
+						for (int y = 0; y < R; ++y) for (int x = 0; x < C; ++x) fpix[(size_t) (y * C + x)] = plane[c][(size_t) (py0 + y) * (size_t) PW + (size_t) (px0 + x)];
+						fwdx->analyse(dctsel, fpix.data(), fcoef.data());
+						const float mult1 = 65536.0f / (float) global_scale / (float) (vb.hfmul_m1 + 1);
+						const float mult_c = c == 1 ? mult1 : c == 0 ? mult1 * powf(0.8f, (float) (x_qm - 2)) : mult1 * powf(0.8f, (float) (b_qm - 2));
+						const std::vector<float> &wt = fwdx->weight[dctsel][c];
+						const std::vector<int32_t> &ord = fwdx->order[dctsel];
+						if (c == 1) fydeq.assign((size_t) size, 0.0f);
+						const float dead = (float) opt.getd("deadzone", 0.56);
+						for (int i = first; i < size; ++i) {
+							const int pos = ord[(size_t) i];
+							float target = fcoef[(size_t) pos];
+							if (c == 2) target -= fydeq[(size_t) pos];
+							const float scaled = target * wt[(size_t) pos] / mult_c;
+							const int q = fabsf(scaled) < dead ? 0 : (int) lrintf(scaled);
+							if (c == 1 && q) fydeq[(size_t) pos] = synthfwd::dequant((float) q, 1, mult_c, wt[(size_t) pos]);
+							if (q) coefs.push_back({i, q});
+						}
+					} else {
 					// d1-like statistics: non-zeros concentrate at low frequencies (so the scan ends early, as an
 					// encoder's would) and low frequencies carry the larger magnitudes
 					double cont = opt.getd("cont", 0.86);
@@ -497,6 +600,7 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 							coefs.push_back({i, rng.below(2) ? mag : -mag});
 						}
 						pk *= dk; cont = 0.3 + (cont - 0.3) * pow(dk, 0.6);
+					}
 					}
 					int nz = (int) coefs.size();
 					if (nz > (63 << (log_size - 6))) { coefs.resize((size_t) (63 << (log_size - 6))); nz = (int) coefs.size(); }

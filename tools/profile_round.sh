@@ -11,4 +11,5 @@ cd $R
 python tools/prof_summary.py gpurun_out/kt_$tag gpurun_out/kernel_stats_$tag.txt > /dev/null 2>&1
 python tools/pmc_summary.py gpurun_out/pmc_fetch_$tag gpurun_out/pmc_fetch_$tag.txt > /dev/null 2>&1
 python tools/pmc_summary.py gpurun_out/pmc_write_$tag gpurun_out/pmc_write_$tag.txt > /dev/null 2>&1
+rm -rf gpurun_out/kt_$tag gpurun_out/pmc_fetch_$tag gpurun_out/pmc_write_$tag   # (raw traces: tens of MB; gpurun_out/ travels back only below 64 MiB)
 cut -c1-1800 gpurun_out/bench_$tag.json; head -8 gpurun_out/kernel_stats_$tag.txt
