@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--pipe-batch", type=int, default=256, help="frames per entropy launch inside the pipeline")
     ap.add_argument("--host-threads", type=int, default=0, help="pipeline worker threads per GPU (default: the container's CPU quota / GPUs)")
     ap.add_argument("--resident-batch", type=int, default=256, help="frames of the device-resident section (kernels only, as round 1 measured)")
+    ap.add_argument("--stream", choices=["forward", "coefficient"], default="forward",
+                    help="forward: the generator ENCODES a procedural picture at about distance 1 (tools/jxlsynth forward=1); "
+                         "coefficient: the coefficient-domain synthetic stream rounds 1 and 2 were tuned on")
     ap.add_argument("--shard-groups", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-sections", action="store_true", help="only the timed pipeline (no device-resident / latency / other-config sections)")
@@ -151,14 +154,15 @@ def main():
         dist.barrier()
     if args.shard_groups:
         from streams import synth
-        return bench_sharded(args, torch, j40_amd, dist, dev, rank, local_rank, world, synth("vardct", args.width, args.height, args.seed))
+        return bench_sharded(args, torch, j40_amd, dist, dev, rank, local_rank, world, synth("vardct", args.width, args.height, args.seed, **({"forward": 1} if args.stream == "forward" else {})))
 
     W, H, B = args.width, args.height, args.batch
     quota = cpu_quota()
     threads = args.host_threads or max(2, quota // world)
     D = max(1, min(args.distinct, B))
     # every rank decodes its own frames (distinct seeds)
-    datas = synth_many([("vardct", W, H, args.seed + 1000 * i + 7 * rank, {}) for i in range(D)], max(1, quota // world))
+    stream_opts = {"forward": 1} if args.stream == "forward" else {}
+    datas = synth_many([("vardct", W, H, args.seed + 1000 * i + 7 * rank, stream_opts) for i in range(D)], max(1, quota // world))
     bufs = [C.create_string_buffer(d, len(d)) for d in datas]
     step_bufs = [bufs[i % D] for i in range(B)]
     step_sizes = [len(datas[i % D]) for i in range(B)]
@@ -183,15 +187,17 @@ def main():
     frames_per_launch = st["launch_frames"] / launches
     alg_launch = alg_step * frames_per_launch / B
     achieved = alg_launch / (k1_launch_ms / 1e3) / 1e9 if k1_launch_ms > 0 else 0.0
+    stream_words = ("distance-1 encodes of procedural pictures (tools/jxlsynth forward=1: forward transforms, library matrices" if args.stream == "forward"
+                    else "d1-like synthetic frames (tools/jxlsynth, coefficient-domain synthesis")
     result = {
         "metric": METRIC, "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%d x %dx%d VarDCT d1-like synthetic frames per GPU per step (tools/jxlsynth, %d distinct streams, %.3f bpp, %d pass groups each), whole decode "
+        "config": {"workload": ("%d x %dx%d VarDCT frames per GPU per step, " + stream_words + ", %d distinct streams, %.3f bpp, %d pass groups each), whole decode "
                                "path per frame inside the timed region: host parse + plan build + plan upload on %d worker threads (container CPU quota %d of %d visible CPUs) "
-                               "pipelined with batched entropy + pixel kernels (%d frames per entropy launch); codestream bytes in, RGBA u8x4 resident in HBM out"
+                               "pipelined with batched entropy + pixel kernels (%d frames per entropy launch); codestream bytes in, RGBA u8x4 resident in HBM out")
                                % (B, W, H, D, 8.0 * sum(step_sizes) / (B * W * H), ((W + 255) // 256) * ((H + 255) // 256), threads, quota, os.cpu_count() or 1, min(args.pipe_batch, B)),
                    "clock": "codestream bytes in memory -> RGBA u8x4 in device memory, nothing prepared ahead (SURVEY 8d); same start as cpu_baseline, which ends in host memory",
-                   "frame_pixels": W * H, "frames_per_step": B, "codestream_bytes": step_sizes[0], "parallelism": "frames x%d" % world},
+                   "stream": args.stream, "frame_pixels": W * H, "frames_per_step": B, "codestream_bytes": step_sizes[0], "parallelism": "frames x%d" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": None,
                      "kernel": "k_hf_lanes", "kernel_ms": round(k1_launch_ms, 4), "launches_in_timed_region": st["launches"], "frames_per_launch": round(frames_per_launch, 2),
                      "algorithmic_bytes_per_launch": int(alg_launch),
@@ -202,7 +208,7 @@ def main():
     }
     try:
         pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if abs(pt.get("frames_per_launch", 0) - frames_per_launch) < 1 and (W, H) == (7680, 4320):
+        if abs(pt.get("frames_per_launch", 0) - frames_per_launch) < 1 and (W, H) == (7680, 4320) and pt.get("stream", "coefficient") == args.stream:
             result["roofline"]["traffic"] = int((pt["fetch_size_kb"] * pt.get("fetch_correction", 1.0) + pt["write_size_kb"]) * 1024)
             result["roofline"]["traffic_source"] = pt["source"]
     except (OSError, ValueError, KeyError):

@@ -67,6 +67,19 @@ struct Picture {
 		float su = fu * fu * (3 - 2 * fu), sv = fv * fv * (3 - 2 * fv);
 		return (hv(iu, iv) * (1 - su) + hv(iu + 1, iv) * su) * (1 - sv) + (hv(iu, iv + 1) * (1 - su) + hv(iu + 1, iv + 1) * su) * sv;
 	}
+	// the smooth part of the picture (no rectangles, not clamped) / the rectangles' contribution: forward=1 evaluates the former
+	// on a coarse grid
+	void smooth(float x, float y, float out[3]) const {
+		for (int c = 0; c < 3; ++c) {
+			float v = 0.5f;
+			for (int i = 0; i < 6; ++i) v += amp[i][c] * sinf(fx[i] * x * 6.28318f + fy[i] * y * 6.28318f + ph[i] + (float) c);
+			for (int o = 0; o < 3; ++o) v += (vnoise(x, y, o, c) - 0.5f) * (0.16f / (float) (1 << o));
+			out[c] = v;
+		}
+	}
+	void add_rects(float x, float y, float out[3]) const {
+		for (const Rect &r : rects) if (x >= (float) r.x0 && x < (float) r.x1 && y >= (float) r.y0 && y < (float) r.y1) { out[0] += r.r; out[1] += r.g; out[2] += r.b; }
+	}
 	void rgb(float x, float y, float out[3]) const {
 		for (int c = 0; c < 3; ++c) {
 			float v = 0.5f;
@@ -288,26 +301,45 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 		const std::string dumpsrc = opt.gets("dumpsrc", "");   // the source picture as sRGB u8 x 3, for the fidelity test
 		std::vector<uint8_t> srcdump(dumpsrc.empty() ? 0 : (size_t) W * (size_t) H * 3);
 		static const float CHROMA[3] = {1.0f, 0.92f, 0.8f};
+		// the smooth part of the picture on a grid of 4-pixel cells (it has no feature below ~100 pixels), sRGB -> linear by table
+		const int GW = PW / 4 + 2, GH = PH / 4 + 2;
+		std::vector<float> coarse((size_t) GW * (size_t) GH * 3);
+		for (int gy = 0; gy < GH; ++gy) for (int gx = 0; gx < GW; ++gx) pic.smooth((float) (gx * 4), (float) (gy * 4), &coarse[((size_t) gy * (size_t) GW + (size_t) gx) * 3]);
+		std::vector<float> to_linear(4097);
+		for (int i = 0; i <= 4096; ++i) { const double v = i / 4096.0; to_linear[(size_t) i] = (float) (v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4)); }
 		for (int y = 0; y < PH; ++y) for (int x = 0; x < PW; ++x) {
 			const int sx = std::min(x, W - 1), sy = std::min(y, H - 1);
 			float rgb[3]; double xyb[3];
-			pic.rgb((float) sx, (float) sy, rgb);
+			{
+				const int gx = sx >> 2, gy = sy >> 2; const float fu = (float) (sx & 3) * 0.25f, fv = (float) (sy & 3) * 0.25f;
+				const float *p = &coarse[((size_t) gy * (size_t) GW + (size_t) gx) * 3];
+				for (int c = 0; c < 3; ++c) rgb[c] = (p[c] * (1 - fu) + p[3 + c] * fu) * (1 - fv) + (p[(size_t) GW * 3 + c] * (1 - fu) + p[(size_t) GW * 3 + 3 + c] * fu) * fv;
+				pic.add_rects((float) sx, (float) sy, rgb);
+			}
 			float n = 0;
 			for (const Lattice &l : lat) n += l.amp * sample(l, sx, sy);
 			n *= sample(mask, sx, sy);
 			for (int c = 0; c < 3; ++c) rgb[c] = std::min(0.97f, std::max(0.03f, rgb[c] + n * CHROMA[c]));
 			if (!dumpsrc.empty() && x < W && y < H) for (int c = 0; c < 3; ++c) srcdump[((size_t) y * (size_t) W + (size_t) x) * 3 + (size_t) c] = (uint8_t) lrintf(rgb[c] * 255.0f);
-			to_xyb(rgb, xyb);
+			{   // to_xyb with the table for the transfer function (quantise the sample to the table's grid first: what is
+				// dumped as the source is an 8-bit picture anyway)
+				double lin[3], mix[3];
+				for (int c = 0; c < 3; ++c) { const float t = rgb[c] * 4096.0f; const int i = (int) t; const float f = t - (float) i; lin[c] = to_linear[(size_t) i] * (1 - f) + to_linear[(size_t) std::min(i + 1, 4096)] * f; }
+				for (int c = 0; c < 3; ++c) mix[c] = cbrt(fwd[c][0] * lin[0] + fwd[c][1] * lin[1] + fwd[c][2] * lin[2] - bias) + cbias;
+				xyb[0] = (mix[0] - mix[1]) * 0.5; xyb[1] = (mix[0] + mix[1]) * 0.5; xyb[2] = mix[2];
+			}
 			for (int c = 0; c < 3; ++c) plane[c][(size_t) y * (size_t) PW + (size_t) x] = (float) xyb[c];
 		}
 		if (!dumpsrc.empty()) { FILE *fp = fopen(dumpsrc.c_str(), "wb"); if (!fp || fwrite(srcdump.data(), 1, srcdump.size(), fp) != srcdump.size()) die("cannot write dumpsrc"); fclose(fp); }
 	}
 	// activity of a cell: variance of its Y samples
-	auto cell_activity = [&](int cx, int cy) {
+	std::vector<float> activity(forward ? (size_t) (PW / 8) * (size_t) (PH / 8) : 0);
+	for (int cy = 0; forward && cy < PH / 8; ++cy) for (int cx = 0; cx < PW / 8; ++cx) {
 		double s = 0, s2 = 0;
 		for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) { const double v = plane[1][(size_t) (cy * 8 + y) * (size_t) PW + (size_t) (cx * 8 + x)]; s += v; s2 += v * v; }
-		return std::max(0.0, s2 / 64 - (s / 64) * (s / 64));
-	};
+		activity[(size_t) cy * (size_t) (PW / 8) + (size_t) cx] = (float) std::max(0.0, s2 / 64 - (s / 64) * (s / 64));
+	}
+	auto cell_activity = [&](int cx, int cy) { return (double) activity[(size_t) cy * (size_t) (PW / 8) + (size_t) cx]; };
 
 	const int custom_cfl = opt.geti("cfl", 0);
 	const double kx_lf = custom_cfl ? 0.125 + 3.0 / 128.0 : 0.0, kb_lf = custom_cfl ? 0.75 - 2.0 / 128.0 : 1.0;
