@@ -298,14 +298,18 @@ def test_group_ranges_decode_disjoint_parts_of_the_frame(gpu, ref):
     assert err == ""
     out = torch.full((h, w, 4), 9, dtype=torch.uint8, device="cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
-    for rank in range(3):
-        first, count, y0, y1 = sharding.rank_share(w, h, fr.info["group_size_shift"], 3, rank)
+    ranges = sharding.plan_ranges(fr, 3)   # contiguous, balanced by section bytes
+    assert sum(c for _, c in ranges) == fr.info["num_groups"]
+    for first, count in ranges:
         fr.set_group_range(first, count)
         before = out.clone()
         fr.decode(out.data_ptr(), w * 4, stream)
         torch.cuda.synchronize()
         assert fr.status() == ""
-        assert torch.equal(out[:y0], before[:y0]) and torch.equal(out[y1:], before[y1:])
+        mine = torch.zeros((h, w), dtype=torch.bool, device="cuda:0")
+        for x0, y0, x1, y1 in sharding.range_rectangles(first, count, w, h, fr.info["group_size_shift"]):
+            mine[y0:y1, x0:x1] = True
+        assert torch.equal(out[~mine], before[~mine]), "a range wrote outside its own groups"
     assert np.array_equal(out.cpu().numpy(), whole)
     fr.set_group_range(0, fr.info["num_groups"])
     rerr, expect = ref.decode(data)
