@@ -47,6 +47,7 @@ J40HIP_API int64_t j40hip_frame_num_sections(const j40hip_frame *f);
 J40HIP_API int64_t j40hip_frame_section_sizes(const j40hip_frame *f, int64_t *out);
 /* Modular frames: sections decoded by the wave-cooperative form of the section kernel (diagnostic; -1 when the frame has no Modular plan) */
 J40HIP_API int32_t j40hip_frame_coop_sections(j40hip_frame *f, int32_t *total);
+J40HIP_API int32_t j40hip_frame_quad_sections(j40hip_frame *f);   /* ... of those, decoded four to a wavefront */
 
 /* stage accessors for parity tests (mirror j40__lf_group_st, j40.h:6360-6390) */
 J40HIP_API void j40hip_frame_lf_group_info(const j40hip_frame *f, int64_t gg, int32_t *out9);

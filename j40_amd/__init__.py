@@ -90,7 +90,7 @@ def lib():
         "j40hip_batch_create": (vp, [vp, i64, C.POINTER(u32)]), "j40hip_batch_free": (None, [vp]),
         "j40hip_batch_decode": (u32, [vp, vp, vp, vp]), "j40hip_batch_decode_timed": (u32, [vp, vp, vp, vp, vp]),
         "j40hip_batch_decode_recorded": (u32, [vp, vp, vp, vp, i32]), "j40hip_batch_elapsed": (u32, [vp, i32, vp]), "j40hip_batch_wait_stage": (u32, [vp, i32, i32, vp]),
-        "j40hip_batch_reset": (u32, [vp, vp, i64]), "j40hip_frame_section_sizes": (i64, [vp, vp]), "j40hip_frame_coop_sections": (i32, [vp, vp]),
+        "j40hip_batch_reset": (u32, [vp, vp, i64]), "j40hip_frame_section_sizes": (i64, [vp, vp]), "j40hip_frame_coop_sections": (i32, [vp, vp]), "j40hip_frame_quad_sections": (i32, [vp]),
         "j40hip_frame_upload_on": (u32, [vp, C.c_int, vp]), "j40hip_thread_release": (None, []),
         "j40hip_frame_status_begin": (u32, [vp, vp]), "j40hip_frame_status_end": (u32, [vp]), "j40hip_frame_mark_idle": (None, [vp]),
         "j40hip_frame_after_frame_status": (u32, [vp]),
@@ -220,6 +220,9 @@ class Frame:
         total = C.c_int32(0)
         n = lib().j40hip_frame_coop_sections(self.h, C.byref(total))
         return int(n), int(total.value)
+
+    def quad_sections(self):
+        return int(lib().j40hip_frame_quad_sections(self.h))
 
     def section_sizes(self):
         """bytes of every pass-group section (pass-major), from the TOC"""

@@ -282,6 +282,13 @@ int32_t j40hip_frame_coop_sections(j40hip_frame *h, int32_t *total) {
 	return hp.coop_sections;
 }
 
+// ... and how many of those share wavefronts four at a time (modular_quad.hip); -1: no plan
+int32_t j40hip_frame_quad_sections(j40hip_frame *h) {
+	HostModPlan hp;
+	if (build_modular_plan(h->frame, h->cs, h->cs_size, &hp)) return -1;
+	return hp.quad_sections;
+}
+
 uint32_t j40hip_frame_modular_view(j40hip_frame *h, j40hip_modular_view *v) {
 	HostModPlan hp;
 	if (uint32_t e = build_modular_plan(h->frame, h->cs, h->cs_size, &hp)) return e;

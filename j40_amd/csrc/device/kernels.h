@@ -25,6 +25,7 @@ void launch_kat_srgb_u8(const float *v, size_t n, uint8_t *out, hipStream_t stre
 
 // Modular path (device/modular_kernels.hip)
 void launch_modular_sections(const DevModPlan &plan, int32_t first_section, int32_t num_sections, const ModLaunchInfo &info, hipStream_t stream);
+void launch_modular_quad(const DevModPlan &plan, int32_t first_section, int32_t num_sections, int32_t spec_idx, uint32_t table_span, int32_t max_width, hipStream_t stream);
 void launch_modular_coop(const DevModPlan &plan, int32_t first_section, int32_t num_sections, int32_t max_width, hipStream_t stream);
 void launch_section_inverse_rcts(const DevModPlan &plan, int32_t first_section, int32_t num_sections, hipStream_t stream);
 void launch_paste_plane(const int16_t *src, int32_t w, int32_t h, int16_t *dst, int32_t dst_stride, hipStream_t stream);

@@ -94,13 +94,16 @@ J40_DEV int32_t coop_predict(int32_t predictor, int32_t w, int32_t n, int32_t nw
 	}
 }
 
+// MODE 0: neighbours, properties and prediction on the vector ALU; MODE 1: neighbours and prediction on the scalar unit, only the
+// fifteen property values (which feed per-lane selects anyway) on the vector ALU
+template <int MODE>
 __global__ void __launch_bounds__(64) k_modular_coop(DevModPlan plan, int32_t first_section, int32_t rows_width) {
 	extern __shared__ int32_t coop_rows[];   // [3][rows_width]: the three most recent rows of the channel being decoded
 	const uint32_t lane = threadIdx.x;
 	const int32_t s = first_section + (int32_t) blockIdx.x;
 	const DevModSection sec = plan.sections[s];
 	const int32_t coop = coop_sc(sec.coop_idx);
-	if (coop < 0) return;   // k_modular_sections' section (it also reports the sections that failed on the host)
+	if (coop < 0 || coop_sc(sec.quad)) return;   // k_modular_sections' section (it also reports the sections that failed on the host), or k_modular_quad's
 	const DevModFrame *fp = plan.frame;
 	const int32_t check_end = coop_sc(fp->check_section_end); const uint32_t declared_end = (uint32_t) coop_sc((int32_t) fp->single_declared_end);
 	const DevCoopTree *tree = plan.coop_trees + coop;
@@ -143,7 +146,7 @@ __global__ void __launch_bounds__(64) k_modular_coop(DevModPlan plan, int32_t fi
 					// does as soon as the column index and the values read from the rows are not known to be uniform. The
 					// entropy side (rANS state, bit accumulator, hybrid integer) stays on the scalar unit.
 					int32_t x = xb + i, vnn = coop_rl(vpp, i), r_next = i + 3 < 64 ? coop_rl(vprev, i + 3) : coop_rl(vprev2, i + 3 - 64);
-					asm("" : "+v"(x)); asm("" : "+v"(vnn)); asm("" : "+v"(r_next));
+					if (MODE == 0) { asm("" : "+v"(x)); asm("" : "+v"(vnn)); asm("" : "+v"(r_next)); }
 					const int32_t pw = x > 0 ? c_w : y > 0 ? r_n : 0;
 					const int32_t pn = y > 0 ? r_n : pw;
 					const int32_t pnw = x > 0 && y > 0 ? r_nw : pw;
@@ -153,22 +156,24 @@ __global__ void __launch_bounds__(64) k_modular_coop(DevModPlan plan, int32_t fi
 					const int32_t pww = x > 1 ? c_ww : pw;
 					const int32_t pnww = x > 1 && y > 0 ? r_nww : pww;
 					// every branch's outcome: the value of the property this lane's node tests (j40.h:4141-4155), then one compare
+					int32_t qx = x, qw = pw, qn = pn, qnw = pnw, qne = pne, qnn = pnn, qww = pww, qnww = pnww;
+					if (MODE == 1) { asm("" : "+v"(qx)); asm("" : "+v"(qw)); asm("" : "+v"(qn)); asm("" : "+v"(qnw)); asm("" : "+v"(qne)); asm("" : "+v"(qnn)); asm("" : "+v"(qww)); asm("" : "+v"(qnww)); }
 					int32_t myval = 0;
 					if (used & (1u << 0)) myval = my_prop == 0 ? cidx : myval;
 					if (used & (1u << 1)) myval = my_prop == 1 ? sidx : myval;
 					if (used & (1u << 2)) myval = my_prop == 2 ? y : myval;
-					if (used & (1u << 3)) myval = my_prop == 3 ? x : myval;
-					if (used & (1u << 4)) myval = my_prop == 4 ? mod_abs(pn) : myval;
-					if (used & (1u << 5)) myval = my_prop == 5 ? mod_abs(pw) : myval;
-					if (used & (1u << 6)) myval = my_prop == 6 ? pn : myval;
-					if (used & (1u << 7)) myval = my_prop == 7 ? pw : myval;
-					if (used & (1u << 8)) myval = my_prop == 8 ? (x > 0 ? pw - (pww + pnw - pnww) : pw) : myval;
-					if (used & (1u << 9)) myval = my_prop == 9 ? pw + pn - pnw : myval;
-					if (used & (1u << 10)) myval = my_prop == 10 ? pw - pnw : myval;
-					if (used & (1u << 11)) myval = my_prop == 11 ? pnw - pn : myval;
-					if (used & (1u << 12)) myval = my_prop == 12 ? pn - pne : myval;
-					if (used & (1u << 13)) myval = my_prop == 13 ? pn - pnn : myval;
-					if (used & (1u << 14)) myval = my_prop == 14 ? pw - pww : myval;
+					if (used & (1u << 3)) myval = my_prop == 3 ? qx : myval;
+					if (used & (1u << 4)) myval = my_prop == 4 ? mod_abs(qn) : myval;
+					if (used & (1u << 5)) myval = my_prop == 5 ? mod_abs(qw) : myval;
+					if (used & (1u << 6)) myval = my_prop == 6 ? qn : myval;
+					if (used & (1u << 7)) myval = my_prop == 7 ? qw : myval;
+					if (used & (1u << 8)) myval = my_prop == 8 ? (qx > 0 ? qw - (qww + qnw - qnww) : qw) : myval;
+					if (used & (1u << 9)) myval = my_prop == 9 ? qw + qn - qnw : myval;
+					if (used & (1u << 10)) myval = my_prop == 10 ? qw - qnw : myval;
+					if (used & (1u << 11)) myval = my_prop == 11 ? qnw - qn : myval;
+					if (used & (1u << 12)) myval = my_prop == 12 ? qn - qne : myval;
+					if (used & (1u << 13)) myval = my_prop == 13 ? qn - qnn : myval;
+					if (used & (1u << 14)) myval = my_prop == 14 ? qw - qww : myval;
 					const uint64_t outcomes = __builtin_amdgcn_ballot_w64(my_prop >= 0 && myval > my_thr);
 					const uint64_t reached = __builtin_amdgcn_ballot_w64((((uint32_t) outcomes & my_mlo) == my_wlo) & (((uint32_t) (outcomes >> 32) & my_mhi) == my_whi));
 					const int32_t leaf = (int32_t) __builtin_ctzll(reached);   // exactly one leaf matches
@@ -226,7 +231,9 @@ __global__ void __launch_bounds__(64) k_modular_coop(DevModPlan plan, int32_t fi
 void launch_modular_coop(const DevModPlan &plan, int32_t first_section, int32_t num_sections, int32_t max_width, hipStream_t stream) {
 	if (num_sections <= 0) return;
 	const int32_t rows_width = ((max_width + 63) & ~63) + 64;
-	hipLaunchKernelGGL(k_modular_coop, dim3((unsigned) num_sections), dim3(64), (size_t) rows_width * 12, stream, plan, first_section, rows_width);
+	static const int mode = [] { const char *e = getenv("J40HIP_COOP_MODE"); return e ? atoi(e) : 0; }();
+	if (mode == 1) hipLaunchKernelGGL(k_modular_coop<1>, dim3((unsigned) num_sections), dim3(64), (size_t) rows_width * 12, stream, plan, first_section, rows_width);
+	else hipLaunchKernelGGL(k_modular_coop<0>, dim3((unsigned) num_sections), dim3(64), (size_t) rows_width * 12, stream, plan, first_section, rows_width);
 }
 
 } // namespace j40hip

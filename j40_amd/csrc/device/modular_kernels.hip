@@ -232,7 +232,8 @@ static unsigned grid_for(size_t n) { size_t b = (n + 255) / 256; return (unsigne
 void launch_modular_sections(const DevModPlan &plan, int32_t first_section, int32_t num_sections, const ModLaunchInfo &info, hipStream_t stream) {
 	if (num_sections <= 0) return;
 	// the sections the wave-cooperative kernel takes (modular_coop.hip), then the others
-	if (info.coop_width > 0) launch_modular_coop(plan, first_section, num_sections, info.coop_width, stream);
+	if (info.quad_sections > 0) launch_modular_quad(plan, first_section, num_sections, info.quad_spec, info.quad_table_span, info.quad_width, stream);
+	if (info.coop_width > 0 && info.quad_sections < info.coop_sections) launch_modular_coop(plan, first_section, num_sections, info.coop_width, stream);
 	if (info.all_coop) return;
 	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
 	const uint32_t wp_bytes = info.uses_wp ? align16(40u * (uint32_t) info.max_width) : 0;

@@ -187,6 +187,9 @@ struct DevModSection {
 	// >= 0: the section is decoded by the wave-cooperative kernel (modular_coop.hip) with DevModPlan::coop_trees[coop_idx];
 	// -1: by k_modular_sections
 	int32_t coop_idx;
+	// != 0 (only with coop_idx >= 0): four such sections share a wavefront of k_modular_quad (modular_quad.hip); frames with
+	// thousands of sections
+	int32_t quad;
 };
 
 // An MA tree laid out for a wavefront that decodes ONE section with all 64 lanes (k_modular_coop): lane i holds branch node i
@@ -284,7 +287,11 @@ struct HfLaunchInfo {
 struct ModLaunchInfo {
 	int32_t num_tree_nodes, num_dist, num_clusters; uint32_t table_bytes; int32_t max_width, uses_wp;
 	int32_t coop_width;   // widest channel rectangle of the sections k_modular_coop decodes; 0: none
-	int32_t all_coop;     // every section goes to k_modular_coop
+	int32_t all_coop;     // every section goes to k_modular_coop or k_modular_quad
+	// k_modular_quad: sections flagged `quad` (0: none), the code spec they all decode with, their widest channel
+	int32_t quad_sections, quad_spec, quad_width;
+	int32_t coop_sections;   // sections with coop_idx >= 0 (quad ones included)
+	uint32_t quad_table_span; // alias entries of quad_spec
 };
 
 enum {

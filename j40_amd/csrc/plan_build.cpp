@@ -319,9 +319,10 @@ static void assign_coop(HostModPlan *hp) {
 	static const bool off = [] { const char *e = getenv("J40HIP_NO_COOP"); return e && atoi(e); }();
 	std::vector<std::pair<uint64_t, int32_t>> known;   // (tree_off, spec_idx) -> coop tree or -1
 	hp->coop_width = 0; hp->coop_sections = 0;
+	std::vector<int32_t> section_width;   // widest channel of the sections k_modular_coop could take, -1 for the others
 	for (DevModSection &s : hp->sections) {
 		s.coop_idx = -1;
-		if (off || s.preset_status) continue;
+		if (off || s.preset_status) { section_width.push_back(-1); continue; }
 		int32_t widest = 0;
 		for (int32_t c = 0; c < s.num_channels; ++c) {
 			int32_t w;
@@ -330,7 +331,7 @@ static void assign_coop(HostModPlan *hp) {
 			else w = hp->plane_meta[(size_t) (s.first_channel + c)] ? hp->plane_w[(size_t) (s.first_channel + c)] : s.gw;
 			widest = std::max(widest, w);
 		}
-		if (widest > 4096) continue;
+		if (widest > 4096) { section_width.push_back(-1); continue; }
 		const uint64_t key = (uint64_t) s.tree_off << 32 | (uint32_t) s.spec_idx;
 		int32_t idx = -2;
 		for (const auto &k : known) if (k.first == key) { idx = k.second; break; }
@@ -342,6 +343,28 @@ static void assign_coop(HostModPlan *hp) {
 		}
 		s.coop_idx = idx;
 		if (idx >= 0) { hp->coop_width = std::max(hp->coop_width, widest); ++hp->coop_sections; }
+		section_width.push_back(idx >= 0 ? widest : -1);
+	}
+	// Four sections to a wavefront (k_modular_quad): every instruction then serves four streams. They must share one code spec (its
+	// alias tables are staged in LDS once per workgroup) -- the one most sections use. OFF unless J40HIP_QUAD_MIN=<sections> is set:
+	// measured on 16384 x 16384 (4096 sections) it only ties k_modular_coop (222 vs 226 ms) -- one wavefront per SIMD is bound by the
+	// latency of its own dependent chain; it needs >= 8192 sections (two wavefronts per SIMD) to pay. Kept as a tested variant.
+	static const int32_t quad_min = [] { const char *e = getenv("J40HIP_QUAD_MIN"); return e ? atoi(e) : -1; }();
+	hp->quad_sections = 0; hp->quad_spec = 0; hp->quad_width = 0;
+	for (DevModSection &s : hp->sections) s.quad = 0;
+	if (quad_min >= 0 && hp->coop_sections >= std::max(quad_min, 1)) {
+		std::vector<int32_t> votes(hp->specs.size(), 0);
+		for (const DevModSection &s : hp->sections) if (s.coop_idx >= 0) ++votes[(size_t) s.spec_idx];
+		const int32_t spec = (int32_t) (std::max_element(votes.begin(), votes.end()) - votes.begin());
+		const DevCodeSpec &sp = hp->specs[(size_t) spec];
+		if (sp.table_span * 8u <= 32u * 1024u) {
+			for (size_t i = 0; i < hp->sections.size(); ++i) {
+				DevModSection &s = hp->sections[i];
+				if (s.coop_idx < 0 || s.spec_idx != spec || section_width[i] > 512) continue;
+				s.quad = 1; ++hp->quad_sections; hp->quad_width = std::max(hp->quad_width, section_width[i]);
+			}
+			hp->quad_spec = spec;
+		}
 	}
 }
 

@@ -78,6 +78,7 @@ struct HostModPlan {
 	std::vector<DevChanRect> chan_rects;                  // sections of frames with channels of different sizes (DevModSection::chan_off)
 	std::vector<DevCoopTree> coop_trees;                  // DevModSection::coop_idx
 	int32_t coop_width = 0, coop_sections = 0;            // widest channel / number of the sections k_modular_coop takes
+	int32_t quad_sections = 0, quad_spec = 0, quad_width = 0;   // ... of those, the ones k_modular_quad takes four to a wavefront
 	std::vector<Transform> transforms;                    // global transforms in coded order
 	int32_t alpha_channel = -1;                           // index (after inverse transforms) of the first alpha extra channel
 	uint32_t lz_window_size = 0;

@@ -135,13 +135,16 @@ print(repr(out))
 
 @pytest.mark.gpu
 def test_coop_and_general_kernel_agree(gpu):
-    cases = [c for c in COOP_CASES if c[0] * c[1] > 2000][:10] + [(600, 300, dict(tree=5, squeeze=1)), (2600, 2100, dict(tree=5, squeeze=3))]
+    cases = [c for c in COOP_CASES if c[0] * c[1] > 2000] + [(600, 300, dict(tree=5, squeeze=1)), (2600, 2100, dict(tree=5, squeeze=3)), (2100, 1300, dict(tree=1, alpha=1))]
     script = CHILD % (ROOT, os.path.join(ROOT, "tests"), cases)
     runs = []
-    for no_coop in ("0", "1"):
-        env = dict(os.environ, J40HIP_NO_COOP=no_coop)
+    # the cooperative kernel (default for these sizes), the general kernel only, and four sections per wavefront (k_modular_quad,
+    # normally for frames with thousands of sections) forced onto every section that can take it
+    for extra in ({}, {"J40HIP_NO_COOP": "1"}, {"J40HIP_QUAD_MIN": "1"}):
+        env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         runs.append(eval(r.stdout.strip().splitlines()[-1]))
     assert runs[0] == runs[1]
+    assert runs[0] == runs[2]
     assert any(e == "" for e, _ in runs[0]) and any(e != "" for e, _ in runs[0])

@@ -8,7 +8,7 @@ cases = [("256x256 fjxl-like", 256, 256, dict(alpha=1, prefix=1, lz77=1)), ("204
 if len(sys.argv) > 1: cases = cases[: int(sys.argv[1])]
 for name, w, h, o in cases:
     d = synth("modular", w, h, 21, **o)
-    fr = j40_amd.Frame(d); fr.upload(0)
+    fr = j40_amd.Frame(d); print("   sections (cooperative, all):", fr.coop_sections(), "four to a wavefront:", fr.quad_sections()); fr.upload(0)
     out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0")
     for rep in range(2):
         ms = fr.decode_timed(out.data_ptr(), w * 4, torch.cuda.current_stream().cuda_stream)
