@@ -162,7 +162,8 @@ struct j40hip_device_state {
 	DevPlan plan;
 	bool is_modular = false;
 	int64_t first_group = 0, num_groups = 0;       // range decoded by this process
-	std::vector<DevVarblock> vb_sorted;             // by DctSelect
+	std::vector<DevVarblock> vb_sorted;             // by DctSelect; host copy, fetched from the device on demand (host_vb_sorted)
+	size_t vb_count = 0;
 	int32_t class_start[28];
 	DevVarblock *d_vb_sorted = nullptr;
 	// sharded decode (j40hip_frame_set_group_range): the varblocks of the selected groups, same layout as vb_sorted
@@ -411,6 +412,16 @@ static uint32_t decode_modular(j40hip_frame *h, void *rgba_dev, size_t stride_by
 	return hipGetLastError() == hipSuccess ? 0 : ERR_GPU;
 }
 
+static thread_local HostPlan t_host_plan;
+
+// the frame's varblock list on the host (sharded decodes, stage dumps): copied back from the device when first asked for
+static bool host_vb_sorted(j40hip_device_state *st) {
+	if (st->vb_sorted.size() == st->vb_count) return true;
+	st->vb_sorted.resize(st->vb_count);
+	if (hipSetDevice(st->device) != hipSuccess || hipMemcpy(st->vb_sorted.data(), st->d_vb_sorted, sizeof(DevVarblock) * st->vb_count, hipMemcpyDeviceToHost) != hipSuccess) { st->vb_sorted.clear(); return false; }
+	return true;
+}
+
 // `s`: the stream the copies and fills are enqueued on; the call returns once they have completed (the plan is staged in the
 // calling thread's pinned buffer, which the next upload of this thread reuses)
 static uint32_t upload_impl(j40hip_frame *h, int device, hipStream_t s) {
@@ -418,7 +429,8 @@ static uint32_t upload_impl(j40hip_frame *h, int device, hipStream_t s) {
 	if (h->dev) j40hip_release_device(h);
 	if (j40hip_device_count() <= device || hipSetDevice(device) != hipSuccess) return ERR_GPU;
 	if (h->frame.fh.is_modular) return upload_modular(h, device);
-	HostPlan hp;
+	HostPlan &hp = t_host_plan;   // (this thread's, storage kept from frame to frame)
+	hp.reset();
 	hp.force_dense = h->force_dense;
 	if (uint32_t e = build_vardct_plan(h->frame, h->cs, h->cs_size, &hp)) return e;
 
@@ -428,7 +440,7 @@ static uint32_t upload_impl(j40hip_frame *h, int device, hipStream_t s) {
 	DevPlan &plan = st->plan;
 	memset(&plan, 0, sizeof plan);
 	st->hf = hp.hf;
-	st->vb_sorted = std::move(hp.vb_sorted);
+	st->vb_count = hp.vb_sorted.size();   // (the list itself stays on the device: host_vb_sorted fetches it for the rare callers)
 	memcpy(st->class_start, hp.class_start, sizeof st->class_start);
 	Stager sg;
 	const size_t o_cs = sg.put(hp.codestream.data(), hp.codestream.size()), o_u8 = sg.put(hp.pool_u8.data(), hp.pool_u8.size());
@@ -445,7 +457,7 @@ static uint32_t upload_impl(j40hip_frame *h, int device, hipStream_t s) {
 	} else for (int c = 0; c < 3; ++c) o_llf[c] = sg.put(hp.llf[c].data(), hp.llf[c].size());
 	const size_t o_vbc = sg.put(hp.vb_coeffoff_qfidx.data(), hp.vb_coeffoff_qfidx.size()), o_vbh = sg.put(hp.vb_hfmul_inv.data(), hp.vb_hfmul_inv.size());
 	const size_t o_xfy = sg.put(hp.xfromy.data(), hp.xfromy.size()), o_bfy = sg.put(hp.bfromy.data(), hp.bfromy.size());
-	const size_t o_vbs = sg.put(st->vb_sorted.data(), st->vb_sorted.size());
+	const size_t o_vbs = sg.put(hp.vb_sorted.data(), hp.vb_sorted.size());
 	const size_t o_evr = sg.put(hp.ev_range.data(), hp.ev_range.size());
 	const size_t copy_bytes = sg.size;
 	if (hp.lf_tail_pending) for (int c = 0; c < 3; ++c) o_llf[c] = sg.reserve(sizeof(float) * cells);
@@ -502,7 +514,7 @@ static uint32_t upload_impl(j40hip_frame *h, int device, hipStream_t s) {
 			if (hp.lf_tail_pending && ok) {   // the LfGroup tail: LF integers -> LLF coefficients, on the upload stream behind the copy
 				int32_t max_cells = 0;
 				for (const DevLfGroup &g : hp.lf_groups) max_cells = std::max(max_cells, g.width8 * g.height8);
-				launch_lf_tail(plan, (int32_t) hp.lf_groups.size(), max_cells, cells, (float *) (wb + w_large), st->d_vb_sorted, (int32_t) st->vb_sorted.size(), st->class_start[18], hp.lf_smooth ? 1 : 0, hp.inv_m_lf, s);
+				launch_lf_tail(plan, (int32_t) hp.lf_groups.size(), max_cells, cells, (float *) (wb + w_large), st->d_vb_sorted, (int32_t) st->vb_count, st->class_start[18], hp.lf_smooth ? 1 : 0, hp.inv_m_lf, s);
 			}
 		}
 	}
@@ -530,6 +542,7 @@ static uint32_t j40hip_frame_set_group_range_body(j40hip_frame *h, int64_t first
 	const FrameHeader &fh = h->frame.fh;
 	const int32_t shift = fh.group_size_shift;
 	std::vector<DevVarblock> sel;
+	if (!host_vb_sorted(st)) return ERR_GPU;
 	for (const DevVarblock &vb : st->vb_sorted) {
 		const int64_t gid = ((int64_t) vb.py >> shift) * fh.gcolumns + ((int64_t) vb.px >> shift);
 		if (gid >= first_group && gid < first_group + num_groups) sel.push_back(vb);
@@ -990,6 +1003,7 @@ extern "C" uint32_t j40hip_frame_read_coeffs(j40hip_frame *h, int64_t gg, int c,
 	if (hipMemcpy(table.data(), st->plan.block_events, sizeof(uint32_t) * table.size(), hipMemcpyDeviceToHost) != hipSuccess) return ERR_GPU;
 	memset(out, 0, sizeof(float) * g.blocks.size() * 64);
 	std::vector<CoeffEvent> ev;
+	if (!host_vb_sorted(st)) return ERR_GPU;
 	for (const DevVarblock &vb : st->vb_sorted) {
 		if ((size_t) vb.llf_base < base || (size_t) vb.llf_base >= base + g.blocks.size()) continue;   // another LF group's block
 		const uint32_t *be = table.data() + 4 * (size_t) vb.blk;
@@ -1034,7 +1048,7 @@ extern "C" j40hip_batch *j40hip_batch_create(j40hip_frame *const *frames, int64_
 	try { return batch_create_body(frames, n, err); } catch (const std::exception &) { if (err) *err = ERR_MEM; return nullptr; }
 }
 extern "C" uint32_t j40hip_frame_upload_on(j40hip_frame *h, int device, void *stream) { return guarded([&] { return upload_impl(h, device, (hipStream_t) stream); }); }
-extern "C" void j40hip_thread_release(void) { t_stage.release(); }
+extern "C" void j40hip_thread_release(void) { t_stage.release(); t_host_plan = HostPlan(); }
 
 // j40hip_frame_status in two halves for pipelines: `begin` enqueues the copy of the status words on `stream` (no host wait),
 // `end` -- after the caller has waited for that stream -- reduces them to the frame's verdict. VarDCT frames without extra

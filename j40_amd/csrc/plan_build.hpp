@@ -39,6 +39,15 @@ struct HostPlan {
 	uint32_t lz_window_size = 0;          // 0: no LZ77 in any coefficient code spec
 	int32_t max_large = 0;
 	HfLaunchInfo hf;                     // sizes that shape K1's LDS layout                // most varblocks of one 128/256-sized transform type
+	// empties the plan but keeps the vectors' storage: a worker thread builds one plan after the other into the same object, and
+	// allocating (and page-faulting in) ~35 MB of vectors per 8K frame was a third of the plan build
+	void reset() {
+		codestream.clear(); pool_u8.clear(); pool_u16.clear(); pool_i32.clear(); pool_u64.clear(); pool_f32.clear(); clusters.clear(); coeff_specs.clear();
+		lf_groups.clear(); sections.clear(); group_blocks.clear(); group_block_start.clear(); blocks.clear(); vb_coeffoff_qfidx.clear(); lfindices.clear();
+		for (int c = 0; c < 3; ++c) { llf[c].clear(); lfraw[c].clear(); inv_m_lf[c] = 0.0f; }
+		vb_hfmul_inv.clear(); xfromy.clear(); bfromy.clear(); vb_sorted.clear(); ev_range.clear();
+		block_ctx_map_off = 0; lf_tail_pending = lf_smooth = force_dense = false; ev_capacity = 0; coeff_floats = 0; lz_window_size = 0; max_large = 0;
+	}
 };
 
 // returns 0 or a 4-char error code ("TODO" for frame kinds the hot path does not cover)
