@@ -341,8 +341,11 @@ bool decode_channel_fast(BitReader &br, Modular &m, CodeState &code, int32_t cid
 		const int16_t *up = y > 0 ? c.row(y - 1) : row, *up2 = y > 1 ? c.row(y - 2) : up;
 		for (int32_t x = 0; x < w; ++x) {
 			Neigh p;
-			if (y >= 2 && x >= 2 && x + 2 < w) {   // interior: every neighbour exists
-				p.w = row[x - 1]; p.n = up[x]; p.nw = up[x - 1]; p.ne = up[x + 1]; p.nn = up2[x]; p.nee = up[x + 2]; p.ww = row[x - 2]; p.nww = up[x - 2];
+			if (x >= 2 && x + 2 < w) {   // away from the left and right edges: the fallbacks depend on the row only (j40.h:3965-3990)
+				p.w = row[x - 1]; p.ww = row[x - 2];
+				if (y >= 2) { p.n = up[x]; p.nw = up[x - 1]; p.ne = up[x + 1]; p.nn = up2[x]; p.nee = up[x + 2]; p.nww = up[x - 2]; }
+				else if (y == 1) { p.n = up[x]; p.nw = up[x - 1]; p.ne = up[x + 1]; p.nn = p.n; p.nee = up[x + 2]; p.nww = up[x - 2]; }
+				else { p.n = p.nw = p.ne = p.nn = p.nee = p.w; p.nww = p.ww; }   // first row (the varblock-info channel is two rows of thousands of samples)
 			} else p = neighbours(c, x, y);
 			const TreeNode *n = root;
 			if (!single) while (n->prop >= 0) {

@@ -101,9 +101,8 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 		}
 	}
 
-	std::vector<int32_t> vb_lf_group;   // LF group of each entry of vb_sorted, until the block ordinals are resolved
 	{ size_t nvb = 0, ncell = 0; for (const LfGroup &gg : fr.lf_groups) { nvb += gg.varblocks.size(); ncell += gg.blocks.size(); }
-	  hp->vb_sorted.reserve(nvb); vb_lf_group.reserve(nvb); hp->vb_coeffoff_qfidx.reserve(nvb); hp->vb_hfmul_inv.reserve(nvb); hp->group_blocks.reserve(nvb);
+	  hp->vb_coeffoff_qfidx.reserve(nvb); hp->vb_hfmul_inv.reserve(nvb); hp->group_blocks.reserve(nvb);
 	  hp->blocks.reserve(ncell); hp->lfindices.reserve(ncell); for (int c = 0; c < 3; ++c) hp->llf[c].reserve(ncell); }
 	// LF bundle: frame-wide arrays over all LF groups
 	hp->lf_groups.assign(fr.lf_groups.size(), DevLfGroup());
@@ -123,25 +122,7 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 		} else for (int c = 0; c < 3; ++c) hp->llf[c].insert(hp->llf[c].end(), gg.llfcoeffs[c].begin(), gg.llfcoeffs[c].end());
 		hp->xfromy.insert(hp->xfromy.end(), gg.xfromy.begin(), gg.xfromy.end());
 		hp->bfromy.insert(hp->bfromy.end(), gg.bfromy.begin(), gg.bfromy.end());
-		for (size_t v = 0; v < gg.varblocks.size(); ++v) {
-			const VarblockInfo &vb = gg.varblocks[v];
-			hp->vb_coeffoff_qfidx.push_back(vb.coeffoff_qfidx); hp->vb_hfmul_inv.push_back(vb.hfmul_inv);
-			DevVarblock dv;
-			memset(&dv, 0, sizeof dv);
-			const DctSelect &ds = DCT_SELECT[vb.dctsel];
-			const int32_t coeffoff = vb.coeffoff_qfidx & ~15;
-			dv.coeff_base = d.cell_base * 64 + coeffoff; dv.llf_base = d.cell_base + (coeffoff >> 6);
-			dv.mult1 = df.mult_base * vb.hfmul_inv;
-			const size_t c64 = (size_t) (vb.y8 / 8) * (size_t) gg.width64 + (size_t) (vb.x8 / 8);
-			dv.kx_hf = fr.base_corr_x + fr.inv_colour_factor * (float) gg.xfromy[c64];   // j40.h:7138-7143, one factor per varblock
-			dv.kb_hf = fr.base_corr_b + fr.inv_colour_factor * (float) gg.bfromy[c64];
-			dv.px = gg.left + vb.x8 * 8; dv.py = gg.top + vb.y8 * 8;
-			dv.effh = (uint16_t) std::min(gg.height - vb.y8 * 8, 1 << ds.log_rows); dv.effw = (uint16_t) std::min(gg.width - vb.x8 * 8, 1 << ds.log_columns);
-			dv.dctsel = (uint8_t) vb.dctsel;
-			dv.pad[0] = (uint8_t) g; dv.pad[1] = (uint8_t) (g >> 8); dv.pad[2] = (uint8_t) (g >> 16);
-			dv.blk = (int32_t) v;   // resolved to the block's ordinal once the group lists exist
-			hp->vb_sorted.push_back(dv); vb_lf_group.push_back((int32_t) g);
-		}
+		for (const VarblockInfo &vb : gg.varblocks) { hp->vb_coeffoff_qfidx.push_back(vb.coeffoff_qfidx); hp->vb_hfmul_inv.push_back(vb.hfmul_inv); }
 	}
 	hp->coeff_floats = hp->blocks.size() * 64;
 	if (hp->lf_tail_pending) {
@@ -194,7 +175,6 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 		}
 	}
 	hp->group_block_start[(size_t) num_groups] = (uint32_t) hp->group_blocks.size();
-	for (size_t i = 0; i < hp->vb_sorted.size(); ++i) hp->vb_sorted[i].blk = ordinal[(size_t) vb_lf_group[i]][(size_t) hp->vb_sorted[i].blk];   // blk held the varblock's index in its LF group
 	// single-pass frames: sparse coefficients (DevPlan::events). A group's region is sized from its section: a non-zero
 	// coefficient costs bits, 6 events per byte is far beyond what entropy coding reaches on real data; a section that still
 	// overflows it fails with ERR_EVOF and the frame is decoded with dense planes instead (runtime.hip).
@@ -218,14 +198,34 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 	for (const DevCodeSpec &sp : hp->coeff_specs) any_lz77 |= sp.lz77_enabled != 0;
 	hp->lz_window_size = any_lz77 ? 3 * 65536 + 3 * 1024 + 16 : 0;  // bound on the integers one pass-group stream decodes
 	// work lists for the coefficients -> pixels kernels, grouped by DctSelect
-	{   // a counting sort: 27 classes, stable (a comparison sort of a quarter of a million 40-byte records was a third of this function)
-		size_t count[28] = {0};
-		for (const DevVarblock &v : hp->vb_sorted) ++count[v.dctsel < 27 ? v.dctsel : 27];
-		size_t at[28], k = 0;
+	{   // grouped by DctSelect, in (LF group, varblock) order within a class: counted first, then every record is written straight
+		// to its place (sorting a quarter of a million 40-byte records afterwards was a third of this function)
+		size_t count[28] = {0}, at[28], k = 0, total = 0;
+		for (const LfGroup &gg : fr.lf_groups) { total += gg.varblocks.size(); for (const VarblockInfo &vb : gg.varblocks) ++count[vb.dctsel >= 0 && vb.dctsel < 27 ? vb.dctsel : 27]; }
 		for (int d = 0; d <= 27; ++d) { hp->class_start[d] = (int32_t) k; at[d] = k; k += count[d]; }
-		std::vector<DevVarblock> sorted(hp->vb_sorted.size());
-		for (const DevVarblock &v : hp->vb_sorted) sorted[at[v.dctsel < 27 ? v.dctsel : 27]++] = v;
-		hp->vb_sorted.swap(sorted);
+		hp->vb_sorted.resize(total);
+		for (size_t g = 0; g < fr.lf_groups.size(); ++g) {
+			const LfGroup &gg = fr.lf_groups[g];
+			const DevLfGroup &d = hp->lf_groups[g];
+			for (size_t v = 0; v < gg.varblocks.size(); ++v) {
+				const VarblockInfo &vb = gg.varblocks[v];
+				DevVarblock dv;
+				memset(&dv, 0, sizeof dv);
+				const DctSelect &ds = DCT_SELECT[vb.dctsel];
+				const int32_t coeffoff = vb.coeffoff_qfidx & ~15;
+				dv.coeff_base = d.cell_base * 64 + coeffoff; dv.llf_base = d.cell_base + (coeffoff >> 6);
+				dv.mult1 = df.mult_base * vb.hfmul_inv;
+				const size_t c64 = (size_t) (vb.y8 / 8) * (size_t) gg.width64 + (size_t) (vb.x8 / 8);
+				dv.kx_hf = fr.base_corr_x + fr.inv_colour_factor * (float) gg.xfromy[c64];   // j40.h:7138-7143, one factor per varblock
+				dv.kb_hf = fr.base_corr_b + fr.inv_colour_factor * (float) gg.bfromy[c64];
+				dv.px = gg.left + vb.x8 * 8; dv.py = gg.top + vb.y8 * 8;
+				dv.effh = (uint16_t) std::min(gg.height - vb.y8 * 8, 1 << ds.log_rows); dv.effw = (uint16_t) std::min(gg.width - vb.x8 * 8, 1 << ds.log_columns);
+				dv.dctsel = (uint8_t) vb.dctsel;
+				dv.pad[0] = (uint8_t) g; dv.pad[1] = (uint8_t) (g >> 8); dv.pad[2] = (uint8_t) (g >> 16);
+				dv.blk = ordinal[g][v];   // the block's ordinal in group_blocks / block_events
+				hp->vb_sorted[at[vb.dctsel < 27 ? vb.dctsel : 27]++] = dv;
+			}
+		}
 	}
 	// K1's LDS budget
 	HfLaunchInfo &hf = hp->hf;
