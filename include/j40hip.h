@@ -159,6 +159,12 @@ typedef struct {
  * view instead of from a bitstream; then j40hip_frame_upload / j40hip_frame_decode* as usual. Everything is copied. (The view does
  * not carry the global MA tree, so for frames with extra channels the sub-images behind the coefficients are not validated.) */
 J40HIP_API j40hip_frame *j40hip_frame_from_vardct_view(const j40hip_vardct_view *v, uint32_t *err);
+/* The same seam across processes (the "LF bundle" one rank parses and the others receive): the view flattened
+ * into one relocatable blob. j40hip_frame_lf_bundle returns the bytes it needs and writes them when `capacity` suffices (call it
+ * with out = NULL first); j40hip_frame_from_lf_bundle builds a frame handle from a received blob (everything is copied and
+ * bounds-checked; "rnge" for a malformed blob). */
+J40HIP_API size_t j40hip_frame_lf_bundle(j40hip_frame *f, void *out, size_t capacity, uint32_t *err);
+J40HIP_API j40hip_frame *j40hip_frame_from_lf_bundle(const void *blob, size_t size, uint32_t *err);
 
 /* What the reference reports after a frame that decoded cleanly: "excs" when bytes follow the frame and the reference gets to see
  * them -- always for single-section frames; for frames with several sections only if the frame ends within the first 64 KB its main

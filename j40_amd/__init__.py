@@ -90,7 +90,7 @@ def lib():
         "j40hip_batch_create": (vp, [vp, i64, C.POINTER(u32)]), "j40hip_batch_free": (None, [vp]),
         "j40hip_batch_decode": (u32, [vp, vp, vp, vp]), "j40hip_batch_decode_timed": (u32, [vp, vp, vp, vp, vp]),
         "j40hip_batch_decode_recorded": (u32, [vp, vp, vp, vp, i32]), "j40hip_batch_elapsed": (u32, [vp, i32, vp]), "j40hip_batch_wait_stage": (u32, [vp, i32, i32, vp]),
-        "j40hip_batch_reset": (u32, [vp, vp, i64]), "j40hip_frame_section_sizes": (i64, [vp, vp]), "j40hip_frame_coop_sections": (i32, [vp, vp]), "j40hip_frame_quad_sections": (i32, [vp]),
+        "j40hip_batch_reset": (u32, [vp, vp, i64]), "j40hip_frame_section_sizes": (i64, [vp, vp]), "j40hip_frame_coop_sections": (i32, [vp, vp]), "j40hip_frame_quad_sections": (i32, [vp]), "j40hip_frame_lf_bundle": (sz, [vp, vp, sz, vp]), "j40hip_frame_from_lf_bundle": (vp, [vp, sz, vp]),
         "j40hip_frame_upload_on": (u32, [vp, C.c_int, vp]), "j40hip_thread_release": (None, []),
         "j40hip_frame_status_begin": (u32, [vp, vp]), "j40hip_frame_status_end": (u32, [vp]), "j40hip_frame_mark_idle": (None, [vp]),
         "j40hip_frame_after_frame_status": (u32, [vp]),
@@ -192,6 +192,35 @@ class Frame:
         self.info = dict(zip(INFO_FIELDS, info.tolist()))
         self.width, self.height = self.info["width"], self.info["height"]
         self.codestream_size = L.j40hip_frame_codestream_size(self.h)
+
+    @classmethod
+    def from_lf_bundle(cls, blob: bytes):
+        """a frame handle from the blob Frame.lf_bundle() of another process made (VarDCT frames; nothing is parsed here)"""
+        L = lib()
+        self = cls.__new__(cls)
+        self._buf = C.create_string_buffer(blob, len(blob))
+        err = C.c_uint32()
+        self.h = L.j40hip_frame_from_lf_bundle(self._buf, len(blob), C.byref(err))
+        if not self.h:
+            raise J40Error(err4(err.value), "in j40hip_frame_from_lf_bundle")
+        info = np.zeros(32, np.int64)
+        L.j40hip_frame_info(self.h, info.ctypes.data)
+        self.info = dict(zip(INFO_FIELDS, info.tolist()))
+        self.width, self.height = self.info["width"], self.info["height"]
+        self.codestream_size = L.j40hip_frame_codestream_size(self.h)
+        return self
+
+    def lf_bundle(self) -> bytes:
+        """the parsed frame (codestream + LF bundle + tables) as one relocatable blob: what rank 0 of a sharded decode can
+        broadcast instead of the codestream"""
+        L = lib()
+        err = C.c_uint32()
+        need = L.j40hip_frame_lf_bundle(self.h, None, 0, C.byref(err))
+        self._chk(err.value, "in j40hip_frame_lf_bundle")
+        out = C.create_string_buffer(need)
+        if L.j40hip_frame_lf_bundle(self.h, out, need, C.byref(err)) != need:
+            self._chk(err.value or int.from_bytes(b"!mem", "big"), "in j40hip_frame_lf_bundle")
+        return out.raw
 
     def close(self):
         if self.h:

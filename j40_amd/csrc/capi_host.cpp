@@ -1,4 +1,5 @@
 // j40_amd/csrc/capi_host.cpp -- host half of the thin C-ABI (include/j40hip.h): parse + stage accessors
+#include <type_traits>
 #include "capi.hpp"
 #include "tables.hpp"
 
@@ -274,19 +275,143 @@ uint32_t j40hip_frame_vardct_view(j40hip_frame *h, j40hip_vardct_view *v) {
 	return 0;
 }
 
+// ---- the LF bundle as one relocatable blob (what rank 0 broadcasts when the other ranks are not to parse the
+// stream themselves): the VarDCT plan view with every pointer replaced by its byte offset from the start of the blob ----
+}   // extern "C"
+namespace {
+struct BundleWriter {
+	std::vector<uint8_t> bytes;
+	template <typename T> const T *put(const T *p, size_t n) {   // returns the OFFSET, typed as a pointer
+		if (!p || !n) return nullptr;
+		bytes.resize((bytes.size() + 15) & ~(size_t) 15);
+		const size_t off = bytes.size();
+		bytes.insert(bytes.end(), (const uint8_t *) p, (const uint8_t *) p + n * sizeof(T));
+		return (const T *) (uintptr_t) off;
+	}
+	template <typename T> T *at(const T *off) { return (T *) (bytes.data() + (uintptr_t) off); }
+};
+enum : uint32_t { BUNDLE_MAGIC = 0x424c344au };   // "J4LB"
+struct BundleHeader { uint32_t magic, version; uint64_t size; j40hip_vardct_view view; };
+static size_t order_size(int o) { return (size_t) 1 << (LOG_ORDER_SIZE[o][0] + LOG_ORDER_SIZE[o][1]); }
+// offset -> pointer, bounds checked
+template <typename T> static void bundle_fix(const T *&p, size_t n, uint8_t *base, size_t size) {
+	const size_t off = (size_t) (uintptr_t) p;
+	if (!off) { p = nullptr; return; }
+	if (off >= size || n > (size - off) / sizeof(T)) J40HIP_RAISE("rnge");
+	p = (const T *) (base + off);
+}
+}
+extern "C" {
+
+size_t j40hip_frame_lf_bundle(j40hip_frame *h, void *out, size_t capacity, uint32_t *err) {
+	uint32_t code = 0; size_t need = 0;
+	try {
+		j40hip_vardct_view v;
+		if ((code = j40hip_frame_vardct_view(h, &v)) != 0) { if (err) *err = code; return 0; }
+		BundleWriter w;
+		w.bytes.resize(sizeof(BundleHeader));
+		j40hip_vardct_view o = v;
+		o.codestream = w.put(v.codestream, v.codestream_size);
+		o.block_ctx_map = w.put(v.block_ctx_map, (size_t) v.block_ctx_size);
+		{
+			std::vector<j40hip_codespec_view> specs(v.coeff_specs, v.coeff_specs + v.num_passes);
+			for (j40hip_codespec_view &sv : specs) {
+				std::vector<j40hip_cluster_view> cl(sv.clusters, sv.clusters + sv.num_clusters);
+				for (j40hip_cluster_view &c : cl) { c.D = w.put(c.D, c.D && !sv.use_prefix_code ? (size_t) 1 << sv.log_alpha_size : 0); c.lengths = w.put(c.lengths, c.lengths ? (size_t) c.alphabet_size : 0); }
+				sv.cluster_map = w.put(sv.cluster_map, (size_t) sv.num_dist + (sv.lz77_enabled ? 1 : 0));
+				sv.clusters = w.put(cl.data(), cl.size());
+			}
+			o.coeff_specs = w.put(specs.data(), specs.size());
+		}
+		for (int p = 0; p < 11; ++p) for (int q = 0; q < 13; ++q) for (int c = 0; c < 3; ++c) { const int i = (p * 13 + q) * 3 + c; o.orders[i] = w.put(v.orders[i], v.orders[i] ? order_size(q) : 0); }
+		for (int i = 0; i < 17; ++i) o.dq_matrix[i] = w.put(v.dq_matrix[i], v.dq_matrix[i] ? (size_t) v.dq_size[i] * 3 : 0);
+		{
+			std::vector<j40hip_lf_group_view> groups(v.lf_groups, v.lf_groups + v.num_lf_groups);
+			for (j40hip_lf_group_view &g : groups) {
+				const size_t cells = (size_t) g.width8 * (size_t) g.height8, c64 = (size_t) g.width64 * (size_t) g.height64;
+				g.blocks = w.put(g.blocks, cells); g.lfindices = w.put(g.lfindices, cells);
+				for (int c = 0; c < 3; ++c) g.llfcoeffs[c] = w.put(g.llfcoeffs[c], cells);
+				g.coeffoff_qfidx = w.put(g.coeffoff_qfidx, (size_t) g.nb_varblocks); g.hfmul_inv = w.put(g.hfmul_inv, (size_t) g.nb_varblocks);
+				g.xfromy = w.put(g.xfromy, c64); g.bfromy = w.put(g.bfromy, c64);
+			}
+			o.lf_groups = w.put(groups.data(), groups.size());
+		}
+		o.sections = w.put(v.sections, (size_t) v.num_passes * (size_t) v.num_groups);
+		BundleHeader hd; memset(&hd, 0, sizeof hd);
+		hd.magic = BUNDLE_MAGIC; hd.version = 1; hd.size = w.bytes.size(); hd.view = o;
+		memcpy(w.bytes.data(), &hd, sizeof hd);
+		need = w.bytes.size();
+		if (out && capacity >= need) memcpy(out, w.bytes.data(), need);
+	} catch (const std::exception &) { code = E4("!mem"); need = 0; }
+	if (err) *err = code;
+	return need;
+}
+
+j40hip_frame *j40hip_frame_from_lf_bundle(const void *blob, size_t size, uint32_t *err) {
+	uint32_t code = 0;
+	try {
+		BundleHeader hd;
+		if (!blob || size < sizeof hd) J40HIP_RAISE("rnge");
+		memcpy(&hd, blob, sizeof hd);
+		if (hd.magic != BUNDLE_MAGIC || hd.version != 1 || hd.size != size) J40HIP_RAISE("rnge");
+		std::vector<uint8_t> bytes((const uint8_t *) blob, (const uint8_t *) blob + size);
+		uint8_t *base = bytes.data();
+		auto fix = [&](auto &p, size_t n) { bundle_fix(p, n, base, size); };
+		j40hip_vardct_view &v = ((BundleHeader *) base)->view;
+		if (v.num_passes < 1 || v.num_passes > 11 || v.num_lf_groups < 1 || v.num_groups < 1 || v.block_ctx_size < 0) J40HIP_RAISE("rnge");
+		fix(v.codestream, v.codestream_size); fix(v.block_ctx_map, (size_t) v.block_ctx_size);
+		fix(v.coeff_specs, (size_t) v.num_passes);
+		if (!v.coeff_specs) J40HIP_RAISE("rnge");
+		for (int32_t p = 0; p < v.num_passes; ++p) {
+			j40hip_codespec_view &sv = const_cast<j40hip_codespec_view &>(v.coeff_specs[p]);
+			if (sv.num_clusters < 1 || sv.num_clusters > 256 || sv.num_dist < 1 || (!sv.use_prefix_code && (sv.log_alpha_size < 5 || sv.log_alpha_size > 8))) J40HIP_RAISE("rnge");
+			fix(sv.cluster_map, (size_t) sv.num_dist + (sv.lz77_enabled ? 1 : 0)); fix(sv.clusters, (size_t) sv.num_clusters);
+			if (!sv.cluster_map || !sv.clusters) J40HIP_RAISE("rnge");
+			for (int32_t c = 0; c < sv.num_clusters; ++c) {
+				j40hip_cluster_view &cv = const_cast<j40hip_cluster_view &>(sv.clusters[c]);
+				fix(cv.D, sv.use_prefix_code ? 0 : (size_t) 1 << sv.log_alpha_size); fix(cv.lengths, (size_t) (cv.alphabet_size > 0 ? cv.alphabet_size : 0));
+			}
+		}
+		for (int p = 0; p < 11; ++p) for (int q = 0; q < 13; ++q) for (int c = 0; c < 3; ++c) fix(v.orders[(p * 13 + q) * 3 + c], order_size(q));
+		for (int i = 0; i < 17; ++i) fix(v.dq_matrix[i], (size_t) (v.dq_size[i] > 0 ? v.dq_size[i] : 0) * 3);
+		fix(v.lf_groups, (size_t) v.num_lf_groups);
+		if (!v.lf_groups) J40HIP_RAISE("rnge");
+		for (int32_t g = 0; g < v.num_lf_groups; ++g) {
+			j40hip_lf_group_view &gv = const_cast<j40hip_lf_group_view &>(v.lf_groups[g]);
+			if (gv.width8 < 1 || gv.height8 < 1 || gv.width64 < 1 || gv.height64 < 1 || gv.nb_varblocks < 1) J40HIP_RAISE("rnge");
+			const size_t cells = (size_t) gv.width8 * (size_t) gv.height8, c64 = (size_t) gv.width64 * (size_t) gv.height64;
+			fix(gv.blocks, cells); fix(gv.lfindices, cells);
+			for (int c = 0; c < 3; ++c) fix(gv.llfcoeffs[c], cells);
+			fix(gv.coeffoff_qfidx, (size_t) gv.nb_varblocks); fix(gv.hfmul_inv, (size_t) gv.nb_varblocks);
+			fix(gv.xfromy, c64); fix(gv.bfromy, c64);
+			if (!gv.blocks || !gv.lfindices || !gv.llfcoeffs[0] || !gv.llfcoeffs[1] || !gv.llfcoeffs[2] || !gv.coeffoff_qfidx || !gv.hfmul_inv || !gv.xfromy || !gv.bfromy) J40HIP_RAISE("rnge");
+		}
+		fix(v.sections, (size_t) v.num_passes * (size_t) v.num_groups);
+		if (!v.sections || !v.codestream || !v.block_ctx_map) J40HIP_RAISE("rnge");
+		return j40hip_frame_from_vardct_view(&v, err);   // copies everything
+	} catch (const DecodeError &e) { code = e.code; }
+	catch (const std::exception &) { code = E4("!mem"); }
+	if (err) *err = code;
+	return nullptr;
+}
+
 // Modular frames: how many of the plan's sections the wave-cooperative kernel takes (modular_coop.hip), out of how many; -1: no plan
 int32_t j40hip_frame_coop_sections(j40hip_frame *h, int32_t *total) {
-	HostModPlan hp;
-	if (build_modular_plan(h->frame, h->cs, h->cs_size, &hp)) return -1;
-	if (total) *total = (int32_t) hp.sections.size();
-	return hp.coop_sections;
+	try {
+		HostModPlan hp;
+		if (build_modular_plan(h->frame, h->cs, h->cs_size, &hp)) return -1;
+		if (total) *total = (int32_t) hp.sections.size();
+		return hp.coop_sections;
+	} catch (const std::exception &) { return -1; }
 }
 
 // ... and how many of those share wavefronts four at a time (modular_quad.hip); -1: no plan
 int32_t j40hip_frame_quad_sections(j40hip_frame *h) {
-	HostModPlan hp;
-	if (build_modular_plan(h->frame, h->cs, h->cs_size, &hp)) return -1;
-	return hp.quad_sections;
+	try {
+		HostModPlan hp;
+		if (build_modular_plan(h->frame, h->cs, h->cs_size, &hp)) return -1;
+		return hp.quad_sections;
+	} catch (const std::exception &) { return -1; }
 }
 
 uint32_t j40hip_frame_modular_view(j40hip_frame *h, j40hip_modular_view *v) {

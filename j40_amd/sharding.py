@@ -6,7 +6,8 @@ j40.h:5529) -- entropy decode time follows the bytes, and a band of whole group 
 What moves between ranks is small and sits at the two ends of the path:
 
   * in:  the codestream (a few MB), broadcast from rank 0; every rank parses headers, TOC and LF sections itself (the parsed LF
-         bundle would be ~2.5x larger than the codestream it is derived from);
+         bundle is ~3x larger than the codestream it is derived from). decode_sharded(..., lf_bundle=True) is the other form:
+         rank 0 alone parses and broadcasts the parsed frame as one blob (Frame.lf_bundle / Frame.from_lf_bundle);
   * out: the pixels of each rank's groups (4 B/pixel). A contiguous range is at most three rectangles (the tail of its first group
          row, whole group rows, the head of its last group row); every rank sends its rectangles straight to rank 0 with
          point-to-point sends -- on xGMI every peer has its own link to rank 0, so the transfers run link-parallel -- and rank 0
@@ -70,6 +71,8 @@ def broadcast_bytes(data, dist, device="cpu", src=0):
     rank = dist.get_rank()
     n = torch.tensor([len(data) if rank == src else 0], dtype=torch.int64, device=device)
     dist.broadcast(n, src)
+    if int(n.item()) == 0:
+        return b""
     if rank == src:
         buf = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(device)
     else:
@@ -117,11 +120,31 @@ def gather_rectangles(full, ranges, width, height, group_size_shift, dist, dst=0
     return full
 
 
-def decode_sharded(data, dist, decode_range, device="cpu"):
+def decode_sharded(data, dist, decode_range, device="cpu", lf_bundle=False):
     """data: codestream on rank 0. decode_range(data, rank, world) -> (error code, full-frame uint8 tensor [height, width, 4] on
     `device` with this rank's groups decoded, ranges, (width, height, group_size_shift)). Returns the frame on rank 0; raises
-    the same J40Error on every rank when any rank failed."""
+    the same J40Error on every rank when any rank failed.
+    lf_bundle: rank 0 alone parses the stream and broadcasts the parsed frame -- codestream, LF bundle and tables as one blob
+    (Frame.lf_bundle, SURVEY.md 8e's wording) -- and decode_range is called as decode_range(blob, rank, world, from_bundle=True).
+    The blob is ~3x the codestream; what it saves is the other ranks' host parse (they would run concurrently anyway)."""
     import j40_amd
+    if lf_bundle:
+        blob = b""
+        if dist.get_rank() == 0:
+            try:
+                fr = j40_amd.Frame(data)
+                blob = fr.lf_bundle()
+                fr.close()
+            except j40_amd.J40Error:
+                blob = b""   # every rank then reports the failure of its (empty) bundle
+        blob = broadcast_bytes(blob, dist, device)
+        err, full, ranges, (width, height, shift) = decode_range(blob, dist.get_rank(), dist.get_world_size(), from_bundle=True)
+        err = agree_on_errors(err, dist, device)
+        if err:
+            raise j40_amd.J40Error(err, "in a sharded decode")
+        if str(full.device) != str(device):
+            full = full.to(device)
+        return gather_rectangles(full, ranges, width, height, shift, dist)
     data = broadcast_bytes(data, dist, device)
     err, full, ranges, (width, height, shift) = decode_range(data, dist.get_rank(), dist.get_world_size())
     err = agree_on_errors(err, dist, device)
@@ -145,9 +168,9 @@ def hip_range_decoder(local_device):
     import torch
     import j40_amd
 
-    def decode_range(data, rank, world):
+    def decode_range(data, rank, world, from_bundle=False):
         try:
-            fr = j40_amd.Frame(data)
+            fr = j40_amd.Frame.from_lf_bundle(data) if from_bundle else j40_amd.Frame(data)
         except j40_amd.J40Error as e:
             return e.code, None, None, (0, 0, 8)
         w, h, shift = fr.width, fr.height, fr.info["group_size_shift"]

@@ -3,6 +3,7 @@
  * seam the HIP kernels sit behind. */
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include "../include/j40hip.h"
 
 uint32_t oracle_decode_vardct(const j40hip_vardct_view *v, uint8_t *rgba, float *coeffs_out);
@@ -29,7 +30,7 @@ __attribute__((visibility("default"))) uint32_t oracle_run(const void *buf, size
 
 /* the seam in the other direction: parse -> view -> j40hip_frame_from_vardct_view (a second handle that never saw the
  * bitstream's headers) -> its view -> the oracle. mode 1: decode that second handle on the GPU instead (rgba = host buffer
- * of width * 4 bytes per row). */
+ * of width * 4 bytes per row). Modes 2 / 3: the same, with the view flattened into the LF-bundle blob and rebuilt from it. */
 __attribute__((visibility("default"))) uint32_t seam_roundtrip(const void *buf, size_t size, uint8_t *rgba, int mode) {
 	uint32_t err = 0;
 	int64_t info[32];
@@ -38,7 +39,14 @@ __attribute__((visibility("default"))) uint32_t seam_roundtrip(const void *buf, 
 	if (!f) return err;
 	err = j40hip_frame_vardct_view(f, &v);
 	if (err) { j40hip_frame_free(f); return err; }
-	g = j40hip_frame_from_vardct_view(&v, &err);
+	if (mode >= 2) {   /* through the relocatable blob a sharded decode broadcasts (j40hip_frame_lf_bundle): mode 2 oracle, mode 3 GPU */
+		size_t need = j40hip_frame_lf_bundle(f, NULL, 0, &err);
+		void *blob = need ? malloc(need) : NULL;
+		g = NULL;
+		if (blob && j40hip_frame_lf_bundle(f, blob, need, &err) == need) g = j40hip_frame_from_lf_bundle(blob, need, &err);
+		free(blob);
+		mode -= 2;
+	} else g = j40hip_frame_from_vardct_view(&v, &err);
 	if (g) {
 		j40hip_frame_info(g, info);
 		if (mode == 1) {

@@ -51,9 +51,9 @@ def run(rank, world, port, stream_path, out_path):
     data = open(stream_path, "rb").read() if rank == 0 else b""
     # sys.argv[6] == "hip": the ranks decode their ranges on the GPU (every rank on device 0 of a one-GPU box, else its own) through
     # libj40hip.so; the transport stays gloo with host tensors
-    if len(sys.argv) > 6 and sys.argv[6] == "hip":
+    if len(sys.argv) > 6 and sys.argv[6] in ("hip", "hipbundle"):   # "hipbundle": rank 0 parses alone and broadcasts the LF bundle
         ndev = torch.cuda.device_count()
-        frame = sharding.decode_sharded(data, dist, sharding.hip_range_decoder(rank % max(ndev, 1)))
+        frame = sharding.decode_sharded(data, dist, sharding.hip_range_decoder(rank % max(ndev, 1)), lf_bundle=sys.argv[6] == "hipbundle")
     else:
         frame = sharding.decode_sharded(data, dist, hostsim_range_decoder())
     if rank == 0:

@@ -129,6 +129,9 @@ def test_seam_frame_from_view_decodes_on_the_gpu(gpu, ref):
         buf = C.create_string_buffer(data, len(data))
         assert D.seam_roundtrip(buf, len(data), rgba.ctypes.data, 1) == 0, name
         assert np.array_equal(rgba, direct), name
+        rgba[:] = 0   # the same through the LF-bundle blob
+        assert D.seam_roundtrip(buf, len(data), rgba.ctypes.data, 3) == 0, name
+        assert np.array_equal(rgba, direct), name
 
 
 def test_reference_cli_source_unchanged_runs_on_the_hip_library(gpu, tmp_path):

@@ -100,3 +100,24 @@ def test_seam_frame_from_view_carries_everything(ref, built, name, opts):
     buf = C.create_string_buffer(data, len(data))
     assert D.seam_roundtrip(buf, len(data), rgba.ctypes.data, 0) == 0
     assert np.array_equal(rgba, expect)
+    # ... and so does the LF bundle, the same view flattened into one relocatable blob for another process (a sharded decode's
+    # broadcast): j40hip_frame_lf_bundle -> j40hip_frame_from_lf_bundle
+    rgba[:] = 0
+    assert D.seam_roundtrip(buf, len(data), rgba.ctypes.data, 2) == 0
+    assert np.array_equal(rgba, expect)
+
+
+def test_lf_bundle_blobs_are_checked(built):
+    import j40_amd
+    data = synth("vardct", 392, 264, 81)
+    fr = j40_amd.Frame(data)
+    blob = fr.lf_bundle()
+    fr.close()
+    assert len(blob) > len(data), "the bundle carries the parsed LF data next to the codestream"
+    again = j40_amd.Frame.from_lf_bundle(blob)
+    assert (again.width, again.height) == (392, 264)
+    again.close()
+    # (sizes, counts and the offsets inside the blob are checked; it is a message between the ranks of one job, not an input format)
+    for damaged in (blob[:100], blob[:-1], b"\0" * len(blob), blob[:8] + (len(blob) + 16).to_bytes(8, "little") + blob[16:], blob[:16] + blob[16:].replace(blob[16:24], b"\xff" * 8, 1)):
+        with pytest.raises(j40_amd.J40Error):
+            j40_amd.Frame.from_lf_bundle(damaged)

@@ -76,11 +76,12 @@ def test_sharded_decode_over_gloo_matches_reference(built, ref, world, w, h):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,w,h", [(2, 1300, 776), (3, 7680, 4320)])
-def test_sharded_decode_with_the_hip_range_decoder(built, ref, world, w, h):
+@pytest.mark.parametrize("world,w,h,mode", [(2, 1300, 776, "hip"), (3, 7680, 4320, "hip"), (2, 1300, 776, "hipbundle"), (3, 2600, 2100, "hipbundle")])
+def test_sharded_decode_with_the_hip_range_decoder(built, ref, world, w, h, mode):
     """the same job with every rank decoding its byte-balanced group range on the GPU (j40hip_frame_set_group_range through
     j40_amd.sharding.hip_range_decoder); one process per rank, each on its own device when the box has several, all on device 0
-    otherwise. Transport: gloo (the RCCL transport needs one device per rank)."""
+    otherwise. Transport: gloo (the RCCL transport needs one device per rank). mode "hipbundle": rank 0 parses alone and broadcasts
+    the parsed frame (LF bundle) instead of the codestream."""
     data = synth("vardct", w, h, 57)
     path = os.path.join(STREAMS, "shardhip_%d_%d.jxl" % (w, h))
     open(path, "wb").write(data)
@@ -89,7 +90,7 @@ def test_sharded_decode_with_the_hip_range_decoder(built, ref, world, w, h):
         os.remove(out)
     port = free_port()
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharding_worker.py"), str(r), str(world), str(port), path, out, "hip"], env=env) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharding_worker.py"), str(r), str(world), str(port), path, out, mode], env=env) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=600) == 0
     got = np.load(out)
