@@ -104,7 +104,7 @@ def run_pipeline_steps(pipe, bufs, sizes, outs, stride, device_output, steps, to
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, tickets
@@ -145,12 +145,20 @@ def main():
             __graft_entry__.build()
     if not torch.cuda.is_available() or j40_amd.device_count() == 0:
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    # (J40_BENCH_BACKEND=gloo J40_BENCH_SHARE_DEVICE=1: a dry run of the multi-rank code path on a box with fewer GPUs than ranks;
+    #  the ranks share devices and the collectives go over gloo with host tensors. Not a measurement.)
+    backend = os.environ.get("J40_BENCH_BACKEND", "nccl")
+    if os.environ.get("J40_BENCH_SHARE_DEVICE") == "1":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)   # before the first collective: RCCL binds a rank to its current device
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
         dist.barrier()
     if args.shard_groups:
         from streams import synth
@@ -175,8 +183,38 @@ def main():
     st = pipe.stats()
     for t in tickets:
         assert pipe.result(t) == "", "decode error: " + pipe.result(t)
-    if rank != 0:
+    resident_multi = None
+    if world > 1 and not args.skip_sections:
+        # every rank's kernels alone on frames prepared ahead (what scales with the GPUs when the host's CPU quota does not):
+        # the same figure the single-GPU line carries as `device_resident`, aggregated over the ranks
         pipe.close()
+        del outs
+        torch.cuda.empty_cache()
+        R = max(1, min(args.resident_batch, B))
+        with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+            frames = list(ex.map(lambda i: j40_amd.Frame(datas[i % len(datas)], threads=1), range(R)))
+        for fr in frames:
+            fr.upload(local_rank)
+        routs = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(R)]
+        batch = j40_amd.Batch(frames)
+        ptrs, strides, main = [o.data_ptr() for o in routs], [W * 4] * R, torch.cuda.current_stream(dev)
+        batch.decode_recorded(ptrs, strides, main.cuda_stream, 0)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for k in range(5):
+            batch.decode_recorded(ptrs, strides, main.cuda_stream, k)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert all(fr.status() == "" for fr in frames)
+        resident_multi = {"value": round(W * H * R * 5 * world / float(t.item()) / 1e6, 2), "unit": "Mpixels/s", "frames_per_step_per_gpu": R, "steps": 5,
+                          "note": "kernels only on frames parsed, planned and uploaded ahead, all ranks at once (max over ranks, barriers on both sides)"}
+        del routs, frames, batch
+    if rank != 0:
+        if resident_multi is None:
+            pipe.close()
         return
 
     frames_total = B * args.steps * world
@@ -206,6 +244,8 @@ def main():
         "pipeline": {"host_parse_ms_per_frame": round(st["parse_thread_ms"] / max(st["completed"], 1), 2), "plan_build_upload_ms_per_frame": round(st["upload_thread_ms"] / max(st["completed"], 1), 2),
                      "entropy_ms_per_launch": round(k1_launch_ms, 3), "pixel_kernels_ms_per_launch": round(st["k2_ms"] / launches, 3), "host_threads": threads, "cpu_quota": quota},
     }
+    if resident_multi is not None:
+        result["device_resident"] = resident_multi
     try:
         pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if abs(pt.get("frames_per_launch", 0) - frames_per_launch) < 1 and (W, H) == (7680, 4320) and pt.get("stream", "coefficient") == args.stream:
@@ -359,7 +399,7 @@ def bench_sharded(args, torch, j40_amd, dist, dev, rank, local_rank, world, data
 
     def step():
         if dist is not None:
-            return sharding.decode_sharded(data if rank == 0 else b"", dist, decode, dev)
+            return sharding.decode_sharded(data if rank == 0 else b"", dist, decode, dev if dist.get_backend() == "nccl" else "cpu")
         err, full, _, _ = decode(data, 0, 1)
         assert err == "", err
         return full
@@ -378,7 +418,7 @@ def bench_sharded(args, torch, j40_amd, dist, dev, rank, local_rank, world, data
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank != 0:
