@@ -34,6 +34,12 @@ J40HIP_API j40hip_frame *j40hip_frame_parse(const void *buf, size_t size, int th
 /* flags & 1: leave the tail of every LfGroup -- dequantisation of the LF samples, adaptive smoothing, LLF coefficients (j40.h:6544-6590,
  * 6492, 5944) -- to the device: j40hip_frame_upload runs it there (device/lf_tail_kernels.hip). Same results; what the pipeline uses. */
 J40HIP_API j40hip_frame *j40hip_frame_parse_ex(const void *buf, size_t size, int threads, uint32_t flags, uint32_t *err);
+/* ... with the LfGroup streams (LF coefficients, HF metadata: j40.h:6722-6790) decoded on HIP device `device` on `stream` (a
+ * hipStream_t) instead of the host; `flags` must include 1. The call sleeps while the device works -- meant for many parsing
+ * threads per CPU (the pipeline). Frames outside what the device decoder takes are parsed on the host, same results.
+ * j40hip_frame_lf_on_device tells which it was. */
+J40HIP_API j40hip_frame *j40hip_frame_parse_on(const void *buf, size_t size, int threads, uint32_t flags, int device, void *stream, uint32_t *err);
+J40HIP_API int j40hip_frame_lf_on_device(const j40hip_frame *f);
 J40HIP_API void j40hip_frame_free(j40hip_frame *f);
 
 /* out[0..20] = width, height, is_modular, num_lf_groups, num_groups, num_passes, nb_block_ctx,

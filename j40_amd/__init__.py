@@ -90,7 +90,7 @@ def lib():
         "j40hip_batch_create": (vp, [vp, i64, C.POINTER(u32)]), "j40hip_batch_free": (None, [vp]),
         "j40hip_batch_decode": (u32, [vp, vp, vp, vp]), "j40hip_batch_decode_timed": (u32, [vp, vp, vp, vp, vp]),
         "j40hip_batch_decode_recorded": (u32, [vp, vp, vp, vp, i32]), "j40hip_batch_elapsed": (u32, [vp, i32, vp]), "j40hip_batch_wait_stage": (u32, [vp, i32, i32, vp]),
-        "j40hip_batch_reset": (u32, [vp, vp, i64]), "j40hip_frame_section_sizes": (i64, [vp, vp]), "j40hip_frame_coop_sections": (i32, [vp, vp]), "j40hip_frame_quad_sections": (i32, [vp]), "j40hip_frame_lf_bundle": (sz, [vp, vp, sz, vp]), "j40hip_frame_from_lf_bundle": (vp, [vp, sz, vp]),
+        "j40hip_batch_reset": (u32, [vp, vp, i64]), "j40hip_frame_section_sizes": (i64, [vp, vp]), "j40hip_frame_coop_sections": (i32, [vp, vp]), "j40hip_frame_quad_sections": (i32, [vp]), "j40hip_frame_lf_bundle": (sz, [vp, vp, sz, vp]), "j40hip_frame_parse_on": (vp, [vp, sz, C.c_int, u32, C.c_int, vp, vp]), "j40hip_frame_lf_on_device": (C.c_int, [vp]), "j40hip_frame_from_lf_bundle": (vp, [vp, sz, vp]),
         "j40hip_frame_upload_on": (u32, [vp, C.c_int, vp]), "j40hip_thread_release": (None, []),
         "j40hip_frame_status_begin": (u32, [vp, vp]), "j40hip_frame_status_end": (u32, [vp]), "j40hip_frame_mark_idle": (None, [vp]),
         "j40hip_frame_after_frame_status": (u32, [vp]),
@@ -180,11 +180,15 @@ INFO_FIELDS = ["width", "height", "is_modular", "num_lf_groups", "num_groups", "
 class Frame:
     """thin C-ABI (include/j40hip.h): host parse, plan upload, hot path on a HIP stream"""
 
-    def __init__(self, data: bytes, threads: int = 4):
+    def __init__(self, data: bytes, threads: int = 4, lf_device=None):
+        """lf_device: a HIP device index -- the LfGroup streams are decoded there instead of on the host (j40hip_frame_parse_on)"""
         L = lib()
         self._buf = C.create_string_buffer(data, len(data))
         err = C.c_uint32()
-        self.h = L.j40hip_frame_parse(self._buf, len(data), threads, C.byref(err))
+        if lf_device is None:
+            self.h = L.j40hip_frame_parse(self._buf, len(data), threads, C.byref(err))
+        else:
+            self.h = L.j40hip_frame_parse_on(self._buf, len(data), threads, 1, int(lf_device), None, C.byref(err))
         if not self.h:
             raise J40Error(err4(err.value), "in j40hip_frame_parse")
         info = np.zeros(32, np.int64)
@@ -209,6 +213,9 @@ class Frame:
         self.width, self.height = self.info["width"], self.info["height"]
         self.codestream_size = L.j40hip_frame_codestream_size(self.h)
         return self
+
+    def lf_on_device(self):
+        return bool(lib().j40hip_frame_lf_on_device(self.h))
 
     def lf_bundle(self) -> bytes:
         """the parsed frame (codestream + LF bundle + tables) as one relocatable blob: what rank 0 of a sharded decode can

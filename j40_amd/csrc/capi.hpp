@@ -36,5 +36,7 @@ struct j40hip_frame {
 	} views;
 };
 
+extern "C" j40hip_frame *j40hip_frame_parse_with(const void *buf, size_t size, int threads, uint32_t flags, j40hip::LfDeviceDecoder lf_decoder, void *lf_ctx, uint32_t *err);
+
 // implemented next to the kernels; a no-op when nothing was uploaded
 extern "C" void j40hip_release_device(j40hip_frame *f);

@@ -7,16 +7,21 @@ using namespace j40hip;
 
 extern "C" {
 
-j40hip_frame *j40hip_frame_parse_ex(const void *buf, size_t size, int threads, uint32_t flags, uint32_t *err) {
+j40hip_frame *j40hip_frame_parse_ex(const void *buf, size_t size, int threads, uint32_t flags, uint32_t *err) { return j40hip_frame_parse_with(buf, size, threads, flags, nullptr, nullptr, err); }
+
+// (internal; j40hip_frame_parse_on in device/runtime.hip passes the device's LfGroup decoder)
+j40hip_frame *j40hip_frame_parse_with(const void *buf, size_t size, int threads, uint32_t flags, LfDeviceDecoder lf_decoder, void *lf_ctx, uint32_t *err) {
 	j40hip_frame *h = new j40hip_frame();
 	uint32_t code = 0;
 	try {
 		h->frame.defer_lf_tail = (flags & 1u) != 0;
+		h->frame.lf_decoder = lf_decoder; h->frame.lf_decoder_ctx = lf_ctx;
 		extract_codestream((const uint8_t *) buf, size, &h->cs, &h->cs_size, &h->cs_storage, &h->container_stray_tail);
 		h->bare_codestream = h->cs == (const uint8_t *) buf && h->cs_size == size;
 		parse_frame(h->cs, h->cs_size, &h->frame, threads);
 	} catch (const DecodeError &e) { code = e.code; }
 	catch (const std::bad_alloc &) { code = E4("!mem"); }
+	h->frame.lf_decoder = nullptr; h->frame.lf_decoder_ctx = nullptr;   // (the context lives on the caller's stack)
 	if (err) *err = code;
 	if (code) { delete h; return nullptr; }
 	return h;

@@ -1,0 +1,62 @@
+// j40_amd/csrc/device/lf_decode.hip -- LfGroup sections of VarDCT frames decoded on the device (replaces the
+// stream-decoding half of j40__lf_group, j40.h:6722-6790: j40__modular_channel over the LF coefficient image and over the HF
+// metadata image). One LfGroup section per wavefront, decoded by all 64 lanes together with the wave-cooperative channel decoder
+// (modular_coop_dev.h). The two sub-images are one bit stream without a length in between, so the wavefront goes straight on:
+// LF coefficients -> final rANS state -> varblock count -> second Modular header -> HF metadata -> final rANS state.
+// What the host keeps: everything in front of the first stream (it knows where that is), and everything after the decode that is
+// cheap and irregular -- LF index, varblock placement (frame.cpp, lf_group_finish) -- plus the plan build.
+// Only the plain second header is handled here (global tree, default weighted-predictor parameters, no transforms: what VarDCT
+// encoders write); any other reports ERR_LFFB and the host decodes that section itself.
+#include <hip/hip_runtime.h>
+#include "modular_coop_dev.h"
+#include "kernels.h"
+
+namespace j40hip {
+
+__global__ void __launch_bounds__(64) k_lf_groups(const uint8_t *codestream, const DevLfTask *tasks, const DevCoopTree *tree, const uint64_t *alias_pool, int32_t log_alpha_size,
+		int16_t *out_pool, DevLfResult *results) {
+	const uint32_t lane = threadIdx.x;
+	const DevLfTask *tp = tasks + blockIdx.x;
+	const int32_t w8 = coop_sc(tp->w8), h8 = coop_sc(tp->h8), w64 = coop_sc(tp->w64), h64 = coop_sc(tp->h64);
+	const int32_t sidx0 = coop_sc(tp->sidx0), sidx2 = coop_sc(tp->sidx2), nbvb_bits = coop_sc(tp->nbvb_bits);
+	const uint32_t capacity = (uint32_t) coop_sc((int32_t) tp->out_capacity);
+	int16_t *out = coop_sc_ptr(out_pool) + (uint32_t) coop_sc((int32_t) tp->out_off);
+	const CoopTreeRegs t = coop_load_tree(tree, lane);
+	const int32_t log_bucket = 12 - log_alpha_size;
+	const CoopConstU64 alias = (CoopConstU64) coop_sc_ptr(alias_pool);
+	CoopBits b;
+	coop_bits_init(b, coop_sc_ptr(codestream), (uint32_t) coop_sc((int32_t) tp->byte_off), (uint32_t) coop_sc((int32_t) tp->size), (uint32_t) coop_sc((int32_t) tp->bit_off), lane);
+	uint32_t state = 0, err = 0, status = 0;
+	int32_t nb_varblocks = 0;
+	const uint32_t cells = (uint32_t) w8 * (uint32_t) h8, c64 = (uint32_t) w64 * (uint32_t) h64;
+	// the LF coefficient image
+	for (int32_t c = 0; c < 3 && !b.err && !err; ++c)
+		coop_decode_channel<0, true>(b, state, err, t, alias, log_bucket, c, sidx0, out + (size_t) c * cells, w8, w8, h8, nullptr, 0, lane);
+	status = b.err ? b.err : err;
+	if (!status) status = coop_finish_code(b, state, lane);
+	if (!status) {
+		nb_varblocks = (int32_t) coop_take(b, nbvb_bits, lane) + 1;   // j40.h:6601
+		const uint32_t header = coop_take(b, 4, lane);                // use_global_tree = 1, default wp = 1, no transforms (j40.h:3717-3760)
+		if (b.err) status = b.err;
+		else if (header != 3u) status = ERR_LFFB;
+		else if (3 * cells + 2 * c64 + 2 * (uint32_t) nb_varblocks + cells > capacity) status = ERR_LFFB;   // (more varblocks than cells: the host reports it)
+	}
+	if (!status) {   // the HF metadata image
+		int16_t *meta = out + 3 * (size_t) cells;
+		state = 0;
+		coop_decode_channel<0, true>(b, state, err, t, alias, log_bucket, 0, sidx2, meta, w64, w64, h64, nullptr, 0, lane);
+		if (!b.err && !err) coop_decode_channel<0, true>(b, state, err, t, alias, log_bucket, 1, sidx2, meta + c64, w64, w64, h64, nullptr, 0, lane);
+		if (!b.err && !err) coop_decode_channel<0, true>(b, state, err, t, alias, log_bucket, 2, sidx2, meta + 2 * (size_t) c64, nb_varblocks, nb_varblocks, 2, nullptr, 0, lane);
+		if (!b.err && !err) coop_decode_channel<0, true>(b, state, err, t, alias, log_bucket, 3, sidx2, meta + 2 * (size_t) c64 + 2 * (size_t) nb_varblocks, w8, w8, h8, nullptr, 0, lane);
+		status = b.err ? b.err : err;
+		if (!status) status = coop_finish_code(b, state, lane);
+	}
+	if (lane == 0) { results[blockIdx.x].status = status; results[blockIdx.x].nb_varblocks = nb_varblocks; }
+}
+
+void launch_lf_groups(const uint8_t *codestream, const DevLfTask *tasks, int32_t num_tasks, const DevCoopTree *tree, const uint64_t *alias_pool, int32_t log_alpha_size,
+		int16_t *out_pool, DevLfResult *results, hipStream_t stream) {
+	if (num_tasks > 0) hipLaunchKernelGGL(k_lf_groups, dim3((unsigned) num_tasks), dim3(64), 0, stream, codestream, tasks, tree, alias_pool, log_alpha_size, out_pool, results);
+}
+
+} // namespace j40hip

@@ -412,6 +412,77 @@ static uint32_t decode_modular(j40hip_frame *h, void *rgba_dev, size_t stride_by
 	return hipGetLastError() == hipSuccess ? 0 : ERR_GPU;
 }
 
+// ---- LfGroup streams on the device (lf_decode.hip): Frame::lf_decoder for frames parsed with j40hip_frame_parse_on ----
+struct LfDecodeContext { int device; hipStream_t stream; };
+thread_local PinnedStage t_lf_out;        // results land here; LfDeviceTask's pointers point into it until the thread's next call
+thread_local hipEvent_t t_lf_done = nullptr;
+
+static bool lf_device_decode(void *ctx_, const Frame &f, const uint8_t *cs, size_t cs_size, std::vector<LfDeviceTask> &tasks) {
+	const LfDecodeContext &ctx = *(const LfDecodeContext *) ctx_;
+	if (tasks.empty() || cs_size + 16 >= ((size_t) 1 << 29)) return false;
+	if (hipSetDevice(ctx.device) != hipSuccess) return false;
+	DevCoopTree tree; std::vector<uint64_t> alias; int32_t log_alpha = 0;
+	if (!build_lf_coop(f, &tree, &alias, &log_alpha)) return false;
+	std::vector<DevLfTask> dt(tasks.size());
+	size_t out_elems = 0;
+	for (size_t i = 0; i < tasks.size(); ++i) {
+		const LfDeviceTask &t = tasks[i];
+		DevLfTask &d = dt[i];
+		d.byte_off = (uint32_t) t.byte_off; d.size = (uint32_t) t.size; d.bit_off = t.bit_off;
+		d.w8 = t.w8; d.h8 = t.h8; d.w64 = t.w64; d.h64 = t.h64; d.sidx0 = t.sidx0; d.sidx2 = t.sidx2; d.nbvb_bits = t.nbvb_bits;
+		const size_t cells = (size_t) t.w8 * (size_t) t.h8, c64 = (size_t) t.w64 * (size_t) t.h64;
+		d.out_off = (uint32_t) out_elems; d.out_capacity = (uint32_t) (6 * cells + 2 * c64);
+		out_elems += (d.out_capacity + 63) & ~(size_t) 63;
+	}
+	// codestream (padded), tree, alias tables and tasks go up in one staged copy; one block of device memory holds them, the
+	// output planes and the results
+	Stager sg;
+	const size_t o_cs = sg.put(cs, cs_size); (void) sg.reserve(32);   // (the decoder's word window reads a little past the last section)
+	const size_t o_tree = sg.put(&tree, 1), o_alias = sg.put(alias.data(), alias.size()), o_tasks = sg.put(dt.data(), dt.size());
+	const size_t copy_bytes = sg.size;
+	const size_t o_res = sg.reserve(sizeof(DevLfResult) * dt.size()), o_out = sg.reserve(sizeof(int16_t) * out_elems);
+	if (!sg.ok) return false;
+	memset(t_stage.ptr + o_cs + cs_size, 0, 32);
+	size_t block_bytes = 0; bool clean = false;
+	uint8_t *block = (uint8_t *) cache_acquire(ctx.device, sg.size, &block_bytes, &clean);
+	if (!block) return false;
+	const size_t res_bytes = sizeof(DevLfResult) * dt.size(), out_bytes = sizeof(int16_t) * out_elems, res_off = (out_bytes + 255) & ~(size_t) 255;
+	bool ok = t_lf_out.reserve(res_off + res_bytes + 64, 0);
+	if (ok && !t_lf_done) ok = hipEventCreateWithFlags(&t_lf_done, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;   // (a worker waits here for ~0.1 s: asleep, not spinning)
+	ok = ok && hipMemcpyAsync(block, sg.data(), copy_bytes, hipMemcpyHostToDevice, ctx.stream) == hipSuccess;
+	if (ok) {
+		launch_lf_groups(block + o_cs, (const DevLfTask *) (block + o_tasks), (int32_t) dt.size(), (const DevCoopTree *) (block + o_tree), (const uint64_t *) (block + o_alias), log_alpha,
+			(int16_t *) (block + o_out), (DevLfResult *) (block + o_res), ctx.stream);
+		ok = hipGetLastError() == hipSuccess;
+	}
+	ok = ok && hipMemcpyAsync(t_lf_out.ptr, block + o_out, out_bytes, hipMemcpyDeviceToHost, ctx.stream) == hipSuccess;
+	ok = ok && hipMemcpyAsync(t_lf_out.ptr + res_off, block + o_res, res_bytes, hipMemcpyDeviceToHost, ctx.stream) == hipSuccess;
+	ok = ok && hipEventRecord(t_lf_done, ctx.stream) == hipSuccess && hipEventSynchronize(t_lf_done) == hipSuccess;
+	if (!ok) (void) hipStreamSynchronize(ctx.stream);   // nothing of this call may still be in flight when the block goes back
+	cache_release(ctx.device, block, block_bytes, false);
+	if (!ok) { (void) hipGetLastError(); return false; }
+	const DevLfResult *res = (const DevLfResult *) (t_lf_out.ptr + res_off);
+	const int16_t *out = (const int16_t *) t_lf_out.ptr;
+	for (size_t i = 0; i < tasks.size(); ++i) {
+		LfDeviceTask &t = tasks[i];
+		const size_t cells = (size_t) t.w8 * (size_t) t.h8, c64 = (size_t) t.w64 * (size_t) t.h64;
+		const int16_t *p = out + dt[i].out_off;
+		t.status = res[i].status; t.nb_varblocks = res[i].nb_varblocks;
+		for (int c = 0; c < 3; ++c) t.lf[c] = p + (size_t) c * cells;
+		t.xfromy = p + 3 * cells; t.bfromy = t.xfromy + c64; t.info0 = t.bfromy + c64; t.info1 = t.info0 + (t.nb_varblocks > 0 ? t.nb_varblocks : 0);
+	}
+	return true;
+}
+
+// j40hip_frame_parse_ex with the LfGroup streams decoded on `device` (flags bit 1 must be set: the LF tail runs there too); the call
+// blocks (asleep) while the device works. Frames the device decoder cannot take are parsed on the host as usual.
+extern "C" j40hip_frame *j40hip_frame_parse_on(const void *buf, size_t size, int threads, uint32_t flags, int device, void *stream, uint32_t *err) {
+	LfDecodeContext ctx = {device, (hipStream_t) stream};
+	const bool usable = (flags & 1u) && device >= 0 && device < j40hip_device_count();
+	return j40hip_frame_parse_with(buf, size, threads, flags, usable ? lf_device_decode : nullptr, usable ? &ctx : nullptr, err);
+}
+extern "C" int j40hip_frame_lf_on_device(const j40hip_frame *f) { return f && f->frame.lf_decoded_on_device ? 1 : 0; }
+
 static thread_local HostPlan t_host_plan;
 
 // the frame's varblock list on the host (sharded decodes, stage dumps): copied back from the device when first asked for
@@ -1048,7 +1119,7 @@ extern "C" j40hip_batch *j40hip_batch_create(j40hip_frame *const *frames, int64_
 	try { return batch_create_body(frames, n, err); } catch (const std::exception &) { if (err) *err = ERR_MEM; return nullptr; }
 }
 extern "C" uint32_t j40hip_frame_upload_on(j40hip_frame *h, int device, void *stream) { return guarded([&] { return upload_impl(h, device, (hipStream_t) stream); }); }
-extern "C" void j40hip_thread_release(void) { t_stage.release(); t_host_plan = HostPlan(); }
+extern "C" void j40hip_thread_release(void) { t_stage.release(); t_lf_out.release(); if (t_lf_done) { (void) hipEventDestroy(t_lf_done); t_lf_done = nullptr; } t_host_plan = HostPlan(); }
 
 // j40hip_frame_status in two halves for pipelines: `begin` enqueues the copy of the status words on `stream` (no host wait),
 // `end` -- after the caller has waited for that stream -- reduces them to the frame's verdict. VarDCT frames without extra

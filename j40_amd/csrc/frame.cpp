@@ -590,57 +590,37 @@ static void lf_tail_on_host(const Frame &f, LfGroup *gg) {
 }
 void finish_lf_tail(Frame *f) { for (LfGroup &gg : f->lf_groups) if (gg.loaded) lf_tail_on_host(*f, &gg); }
 
-static void read_lf_group(BitReader &br, Frame *f, LfGroup *gg) {  // j40.h:6722
+// what follows the two Modular sub-images of an LfGroup section (j40.h:6562-6570, 6634-6688): dequantisation factors, LF index,
+// varblock placement. lf: the LF integers in streamed order Y, X, B (moved into gg->lfraw when `take` is given, else copied)
+static void lf_group_finish(Frame *f, LfGroup *gg, int32_t extra_prec, const int16_t *const lf[3], std::vector<int16_t> *take[3],
+		const int16_t *xfromy, const int16_t *bfromy, const int16_t *info0, const int16_t *info1, int32_t nb_varblocks) {
 	const FrameHeader &fh = f->fh;
-	const int64_t sidx0 = 1 + gg->idx, sidx2 = 1 + 2 * fh.num_lf_groups + gg->idx;
-	if (fh.is_modular) { gg->loaded = true; return; }  // nothing is read: no channel has shift >= 3 (j40.h:6731)
 	const int32_t w8 = gg->width8, h8 = gg->height8, w64 = gg->width64, h64 = gg->height64;
-	J40HIP_SHOULD(!fh.use_lf_frame, "TODO");
-	J40HIP_SHOULD(fh.jpeg_upsampling == 0, "TODO");
-
-	// LF image: three channels in Y, X, B order
-	const int32_t extra_prec = (int32_t) br.u(2);
-	{
-		Modular m; m.bpp = f->im.bpp;
-		m.channel.assign(3, Plane());
-		for (Plane &p : m.channel) { p.width = w8; p.height = h8; }
-		decode_modular_image(br, &f->global_tree, &f->global_codespec, sidx0, &m);
-		static const int XYB_FROM_STREAM[3] = {1, 0, 2};
-		const Plane *ch[3];
-		for (int c = 0; c < 3; ++c) {
-			gg->mult_lf[c] = f->m_lf_scaled[c] / (float) (f->global_scale * f->quant_lf) * (float) (65536 >> extra_prec);  // j40.h:6562
-			ch[c] = &m.channel[(size_t) XYB_FROM_STREAM[c]];
-			J40HIP_SHOULD(ch[c]->width == w8 && ch[c]->height == h8, "TODO");
-		}
-		// LF index: thresholds counted on the raw integers; note each factor is a channel's own
-		// threshold count (j40.h:6566-6570)
-		gg->lfindices.assign((size_t) w8 * (size_t) h8, 0);
-		auto add = [&](const Plane *p, const int32_t *thr, int32_t n) { for (size_t i = 0; i < gg->lfindices.size(); ++i) for (int32_t t = 0; t < n; ++t) gg->lfindices[i] = (uint8_t) (gg->lfindices[i] + (p->px[i] > thr[t])); };
-		auto mul = [&](int32_t k) { for (uint8_t &v : gg->lfindices) v = (uint8_t) (v * k); };
-		add(ch[0], f->lf_thr[0], f->nb_lf_thr[0]); mul(f->nb_lf_thr[0] + 1);
-		add(ch[2], f->lf_thr[2], f->nb_lf_thr[2]); mul(f->nb_lf_thr[2] + 1);
-		add(ch[1], f->lf_thr[1], f->nb_lf_thr[1]);
-		for (int c = 0; c < 3; ++c) gg->lfraw[c].swap(m.channel[(size_t) XYB_FROM_STREAM[c]].px);
-		gg->tail_pending = true;
+	const size_t cells = (size_t) w8 * (size_t) h8;
+	static const int XYB_FROM_STREAM[3] = {1, 0, 2};
+	const int16_t *ch[3];
+	for (int c = 0; c < 3; ++c) {
+		gg->mult_lf[c] = f->m_lf_scaled[c] / (float) (f->global_scale * f->quant_lf) * (float) (65536 >> extra_prec);  // j40.h:6562
+		ch[c] = lf[XYB_FROM_STREAM[c]];
 	}
-
-	// HF metadata
-	const int32_t nb_varblocks = (int32_t) br.u(ceil_lg32((uint32_t) (w8 * h8))) + 1;
-	Modular m; m.bpp = f->im.bpp;
-	m.channel.assign(4, Plane());
-	m.channel[0].width = m.channel[1].width = w64; m.channel[0].height = m.channel[1].height = h64;
-	m.channel[2].width = nb_varblocks; m.channel[2].height = 2;
-	m.channel[3].width = w8; m.channel[3].height = h8;
-	decode_modular_image(br, &f->global_tree, &f->global_codespec, sidx2, &m);
-	J40HIP_SHOULD(m.channel.size() == 4 && m.channel[2].width == nb_varblocks && m.channel[2].height == 2, "TODO");
-	gg->xfromy = m.channel[0].px; gg->bfromy = m.channel[1].px;
-	J40HIP_SHOULD((int32_t) gg->xfromy.size() == w64 * h64 && (int32_t) gg->bfromy.size() == w64 * h64, "TODO");
+	// LF index: thresholds counted on the raw integers; note each factor is a channel's own threshold count (j40.h:6566-6570)
+	gg->lfindices.assign(cells, 0);
+	auto add = [&](const int16_t *p, const int32_t *thr, int32_t n) { for (int32_t t = 0; t < n; ++t) for (size_t i = 0; i < cells; ++i) gg->lfindices[i] = (uint8_t) (gg->lfindices[i] + (p[i] > thr[t])); };
+	auto mul = [&](int32_t k) { if (k != 1) for (uint8_t &v : gg->lfindices) v = (uint8_t) (v * k); };
+	add(ch[0], f->lf_thr[0], f->nb_lf_thr[0]); mul(f->nb_lf_thr[0] + 1);
+	add(ch[2], f->lf_thr[2], f->nb_lf_thr[2]); mul(f->nb_lf_thr[2] + 1);
+	add(ch[1], f->lf_thr[1], f->nb_lf_thr[1]);
+	for (int c = 0; c < 3; ++c) {
+		if (take) gg->lfraw[c].swap(*take[XYB_FROM_STREAM[c]]);
+		else gg->lfraw[c].assign(ch[c], ch[c] + cells);
+	}
+	gg->tail_pending = true;
+	gg->xfromy.assign(xfromy, xfromy + (size_t) w64 * (size_t) h64); gg->bfromy.assign(bfromy, bfromy + (size_t) w64 * (size_t) h64);
 
 	// place varblocks in raster order at the first free cell (j40.h:6634-6688)
 	const int32_t log_gsize8 = fh.group_size_shift - 3;
-	gg->blocks.assign((size_t) w8 * (size_t) h8, 0);
+	gg->blocks.assign(cells, 0);
 	gg->varblocks.assign((size_t) nb_varblocks, VarblockInfo());
-	const int16_t *info0 = m.channel[2].row(0), *info1 = m.channel[2].row(1);
 	int32_t voff = 0, coeffoff = 0;
 	uint32_t dct_used = 0, order_used = 0;
 	for (int32_t y0 = 0; y0 < h8; ++y0) for (int32_t x0 = 0; x0 < w8; ++x0) {
@@ -670,6 +650,37 @@ static void read_lf_group(BitReader &br, Frame *f, LfGroup *gg) {  // j40.h:6722
 	static std::mutex mu;
 	std::lock_guard<std::mutex> lock(mu);
 	f->dct_select_used |= dct_used; f->order_used |= order_used;
+}
+
+static void read_lf_group(BitReader &br, Frame *f, LfGroup *gg) {  // j40.h:6722
+	const FrameHeader &fh = f->fh;
+	const int64_t sidx0 = 1 + gg->idx, sidx2 = 1 + 2 * fh.num_lf_groups + gg->idx;
+	if (fh.is_modular) { gg->loaded = true; return; }  // nothing is read: no channel has shift >= 3 (j40.h:6731)
+	const int32_t w8 = gg->width8, h8 = gg->height8, w64 = gg->width64, h64 = gg->height64;
+	J40HIP_SHOULD(!fh.use_lf_frame, "TODO");
+	J40HIP_SHOULD(fh.jpeg_upsampling == 0, "TODO");
+
+	// LF image: three channels in Y, X, B order
+	const int32_t extra_prec = (int32_t) br.u(2);
+	Modular lfm; lfm.bpp = f->im.bpp;
+	lfm.channel.assign(3, Plane());
+	for (Plane &p : lfm.channel) { p.width = w8; p.height = h8; }
+	decode_modular_image(br, &f->global_tree, &f->global_codespec, sidx0, &lfm);
+	for (int c = 0; c < 3; ++c) J40HIP_SHOULD(lfm.channel[(size_t) c].width == w8 && lfm.channel[(size_t) c].height == h8, "TODO");
+
+	// HF metadata
+	const int32_t nb_varblocks = (int32_t) br.u(ceil_lg32((uint32_t) (w8 * h8))) + 1;
+	Modular m; m.bpp = f->im.bpp;
+	m.channel.assign(4, Plane());
+	m.channel[0].width = m.channel[1].width = w64; m.channel[0].height = m.channel[1].height = h64;
+	m.channel[2].width = nb_varblocks; m.channel[2].height = 2;
+	m.channel[3].width = w8; m.channel[3].height = h8;
+	decode_modular_image(br, &f->global_tree, &f->global_codespec, sidx2, &m);
+	J40HIP_SHOULD(m.channel.size() == 4 && m.channel[2].width == nb_varblocks && m.channel[2].height == 2, "TODO");
+	J40HIP_SHOULD((int32_t) m.channel[0].px.size() == w64 * h64 && (int32_t) m.channel[1].px.size() == w64 * h64, "TODO");
+	const int16_t *lf[3] = {lfm.channel[0].px.data(), lfm.channel[1].px.data(), lfm.channel[2].px.data()};
+	std::vector<int16_t> *take[3] = {&lfm.channel[0].px, &lfm.channel[1].px, &lfm.channel[2].px};
+	lf_group_finish(f, gg, extra_prec, lf, take, m.channel[0].px.data(), m.channel[1].px.data(), m.channel[2].row(0), m.channel[2].row(1), nb_varblocks);
 }
 
 static void allocate_lf_groups(Frame *f) {  // j40.h:7659
@@ -803,10 +814,49 @@ void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
 	std::atomic<int64_t> next(0);
 	std::atomic<uint32_t> first_err(0);
 	std::vector<uint32_t> errs((size_t) n, 0);
+	std::vector<char> done((size_t) n, 0);
+	if (f->lf_decoder && !f->fh.is_modular && !f->fh.use_lf_frame && f->fh.jpeg_upsampling == 0 && f->defer_lf_tail) {
+		// the streams of every LfGroup section on the device (device/lf_decode.hip): the host reads what precedes the LF coefficient
+		// stream -- extra precision and the first Modular header, which has to be the plain one --, the device decodes both
+		// sub-images, the host finishes (LF index, varblock placement). Anything irregular: the host path below, unchanged.
+		std::vector<LfDeviceTask> tasks((size_t) n);
+		std::vector<int32_t> extra_prec((size_t) n, 0);
+		bool plain = true;
+		try {
+			for (int64_t i = 0; i < n && plain; ++i) {
+				const LfGroup &gg = f->lf_groups[(size_t) i];
+				BitReader sr(cs + f->toc.lf_groups[(size_t) i].offset, f->toc.lf_groups[(size_t) i].size);
+				extra_prec[(size_t) i] = (int32_t) sr.u(2);
+				Modular m; m.bpp = f->im.bpp;
+				m.channel.assign(3, Plane());
+				for (Plane &p : m.channel) { p.width = gg.width8; p.height = gg.height8; }
+				read_modular_header(sr, &f->global_tree, &f->global_codespec, &m);
+				plain = m.use_global_tree && m.transforms.empty() && m.channel.size() == 3;
+				LfDeviceTask &t = tasks[(size_t) i];
+				t.byte_off = f->toc.lf_groups[(size_t) i].offset; t.size = f->toc.lf_groups[(size_t) i].size; t.bit_off = (uint32_t) sr.bit_position();
+				t.w8 = gg.width8; t.h8 = gg.height8; t.w64 = gg.width64; t.h64 = gg.height64;
+				t.sidx0 = (int32_t) (1 + gg.idx); t.sidx2 = (int32_t) (1 + 2 * f->fh.num_lf_groups + gg.idx);
+				t.nbvb_bits = ceil_lg32((uint32_t) (gg.width8 * gg.height8));
+			}
+		} catch (const DecodeError &) { plain = false; }
+		if (plain && f->lf_decoder(f->lf_decoder_ctx, *f, cs, cs_size, tasks)) {
+			f->lf_decoded_on_device = true;
+			for (int64_t i = 0; i < n; ++i) {
+				const LfDeviceTask &t = tasks[(size_t) i];
+				if (t.status == (uint32_t) E4("lffb")) continue;   // the host decodes this one
+				done[(size_t) i] = 1;
+				if (t.status) { errs[(size_t) i] = t.status; continue; }
+				try { lf_group_finish(f, &f->lf_groups[(size_t) i], extra_prec[(size_t) i], t.lf, nullptr, t.xfromy, t.bfromy, t.info0, t.info1, t.nb_varblocks); }
+				catch (const DecodeError &e) { errs[(size_t) i] = e.code; }
+				catch (const std::exception &) { errs[(size_t) i] = E4("!mem"); }
+			}
+		}
+	}
 	auto worker = [&]() {
 		for (;;) {
 			int64_t i = next.fetch_add(1);
 			if (i >= n) break;
+			if (done[(size_t) i]) continue;
 			try {
 				BitReader sr(cs + f->toc.lf_groups[(size_t) i].offset, f->toc.lf_groups[(size_t) i].size);
 				read_lf_group(sr, f, &f->lf_groups[(size_t) i]);

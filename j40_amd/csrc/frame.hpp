@@ -81,6 +81,20 @@ struct LfGroup {
 	bool tail_pending = false;
 };
 
+// One LfGroup section handed to a device decoder (Frame::lf_decoder; device/lf_decode.hip): the host has read what precedes the
+// LF coefficient stream; the decoder fills in the results (plane pointers stay valid until its next call on the same thread).
+struct LfDeviceTask {
+	size_t byte_off = 0, size = 0; uint32_t bit_off = 0;
+	int32_t w8 = 0, h8 = 0, w64 = 0, h64 = 0, sidx0 = 0, sidx2 = 0, nbvb_bits = 0;
+	uint32_t status = 0;          // 0, the stream's 4-char error, or 'lffb': decode this section on the host
+	int32_t nb_varblocks = 0;
+	const int16_t *lf[3] = {nullptr, nullptr, nullptr};   // streamed order Y, X, B
+	const int16_t *xfromy = nullptr, *bfromy = nullptr, *info0 = nullptr, *info1 = nullptr;
+};
+struct Frame;
+// returns false when it cannot take the frame (tree / code spec outside what the kernel handles, no device): host path
+typedef bool (*LfDeviceDecoder)(void *ctx, const Frame &f, const uint8_t *cs, size_t cs_size, std::vector<LfDeviceTask> &tasks);
+
 struct Frame {
 	ImageMeta im;
 	FrameHeader fh;
@@ -115,6 +129,9 @@ struct Frame {
 	// VarDCT frames: leave the tail of every LfGroup (dequantisation, adaptive smoothing, LLF coefficients; j40.h:6544-6590, 6492, 5944)
 	// to the device: the host keeps the decoded integers (LfGroup::lfraw). Set before parse_frame.
 	bool defer_lf_tail = false;
+	// VarDCT frames with several sections: the LfGroup streams are decoded by this (on the device) instead of the host. Set before parse_frame.
+	LfDeviceDecoder lf_decoder = nullptr; void *lf_decoder_ctx = nullptr;
+	bool lf_decoded_on_device = false;   // out: it was
 	// Modular frames: LfGlobal's channel data is left to the device; it starts at this bit of the section
 	bool gm_data_pending = false;
 	size_t gm_data_bitpos = 0;  // single-section VarDCT frames: where the pass group starts

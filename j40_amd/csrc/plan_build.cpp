@@ -313,6 +313,20 @@ static bool build_coop_tree(const HostModPlan &hp, uint32_t tree_off, int32_t tr
 	return true;
 }
 
+// the global MA tree and code spec of a VarDCT frame laid out for the wave-cooperative decoder (device/lf_decode.hip); false when it
+// cannot take them (prefix codes, LZ77, weighted predictor, previous-channel properties, more than 64 leaves)
+bool build_lf_coop(const Frame &fr, DevCoopTree *tree, std::vector<uint64_t> *alias, int32_t *log_alpha_size) {
+	if (fr.global_tree.empty()) return false;
+	HostModPlan hp;
+	for (const TreeNode &n : fr.global_tree) hp.tree.push_back(DevTreeNode{n.prop, n.value, n.a, n.b});
+	hp.specs.emplace_back(); hp.host_specs.push_back(fr.global_codespec);
+	flatten_code_spec(fr.global_codespec, hp.pool_u8, hp.pool_i32, hp.pool_u64, hp.clusters, &hp.specs.back());
+	if (!build_coop_tree(hp, 0, (int32_t) hp.tree.size(), 0, tree)) return false;
+	alias->swap(hp.pool_u64);
+	*log_alpha_size = hp.specs[0].log_alpha_size;
+	return true;
+}
+
 // which sections k_modular_coop decodes: those whose tree / code spec it can take and whose channels are not wider than its row
 // buffers allow
 static void assign_coop(HostModPlan *hp) {

@@ -50,6 +50,8 @@ struct HostPlan {
 	}
 };
 
+bool build_lf_coop(const Frame &fr, DevCoopTree *tree, std::vector<uint64_t> *alias, int32_t *log_alpha_size);   // see plan_build.cpp
+
 // returns 0 or a 4-char error code ("TODO" for frame kinds the hot path does not cover)
 uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostPlan *out);
 

@@ -88,3 +88,66 @@ def test_lf_group_tail_on_the_device_equals_the_host_tail(built):
         assert L.j40hip_frame_status(fh) == 0
         assert np.array_equal(out.cpu().numpy(), expect), (w, h, opts)
         L.j40hip_frame_free(fh)
+
+
+LF_DEVICE_CASES = [
+    ("vardct", 776, 520, 31, dict()),
+    ("vardct", 2600, 2100, 32, dict(bctx=1)),                  # four LfGroup sections, custom LF thresholds (LF index)
+    ("vardct", 2049, 300, 33, dict(maxlog=8, cfl=1)),          # a 1-cell-wide second LfGroup, 256x256 transforms
+    ("vardct", 1920, 1080, 34, dict(forward=1)),
+    ("vardct", 520, 264, 35, dict(alpha=1)),
+    ("vardct", 520, 264, 36, dict(passes=3)),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,w,h,seed,opts", LF_DEVICE_CASES)
+def test_lf_group_streams_on_the_device_equal_the_host_parse(built, mode, w, h, seed, opts):
+    """j40hip_frame_parse_on: LF coefficients and HF metadata of every LfGroup section decoded by k_lf_groups; everything the
+    host derives from them (LF index, varblock placement, LLF coefficients) and the decoded pixels must equal the host parse's"""
+    import j40_amd
+    data = synth(mode, w, h, seed, **opts)
+    host, dev = j40_amd.Frame(data), j40_amd.Frame(data, lf_device=0)
+    assert dev.lf_on_device() and not host.lf_on_device()
+    assert host.info == dev.info
+    for gg in range(host.info["num_lf_groups"]):
+        assert host.lf_group_info(gg) == dev.lf_group_info(gg)
+        for which in range(4):
+            assert np.array_equal(host.plane(gg, which), dev.plane(gg, which)), (gg, which)
+        for a, b in zip(host.varblocks(gg), dev.varblocks(gg)):
+            assert np.array_equal(a, b)
+        for c in range(3):
+            assert np.array_equal(host.llf(gg, c), dev.llf(gg, c))
+    for f in (host, dev):
+        f.upload(0)
+    (ea, pa), (eb, pb) = host.decode_to_host(), dev.decode_to_host()
+    assert ea == "" and eb == "" and np.array_equal(pa, pb)
+    host.close(); dev.close()
+
+
+@pytest.mark.gpu
+def test_lf_group_streams_on_the_device_report_damage_like_the_host(built, ref):
+    import j40_amd
+    data = synth("vardct", 2600, 2100, 41)
+    fr = j40_amd.Frame(data)
+    # the LfGroup sections lie between LfGlobal / HfGlobal and the pass groups: flip bits in the first fifth of the stream
+    sizes = fr.section_sizes()
+    fr.close()
+    start, end = 200, len(data) - int(sizes.sum())
+    rng = np.random.default_rng(3)
+    seen = set()
+    for _ in range(40):
+        m = bytearray(data)
+        m[int(rng.integers(start, end))] ^= 1 << int(rng.integers(0, 8))
+        outcomes = []
+        for lf_device in (None, 0):
+            try:
+                f = j40_amd.Frame(bytes(m), lf_device=lf_device)
+                outcomes.append(("", [f.plane(g, 0).tobytes() for g in range(f.info["num_lf_groups"])]))
+                f.close()
+            except j40_amd.J40Error as e:
+                outcomes.append((e.code, None))
+        assert outcomes[0] == outcomes[1]
+        assert outcomes[0][0] == ref.decode(bytes(m))[0] or outcomes[0][0] == ""   # (errors behind the LfGroups surface at decode time)
+        seen.add(outcomes[0][0])
+    assert len(seen) >= 2, "the damage should have hit some LfGroup section"
