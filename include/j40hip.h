@@ -277,6 +277,11 @@ J40HIP_API void j40hip_frame_mark_idle(j40hip_frame *f);
  *      stream behind its kernels. The serving shape of j40_from_memory + j40_next_frame + j40_frame_pixels_u8x4 for many images. ---- */
 typedef struct j40hip_pipeline j40hip_pipeline;
 J40HIP_API j40hip_pipeline *j40hip_pipeline_create(int device, int host_threads, int batch_frames, int max_in_flight, uint32_t *err);
+/* flags bit 0: the worker threads parse with j40hip_frame_parse_on -- the LfGroup streams are decoded on the device while the
+ * thread sleeps, so give it several times more host_threads than CPUs (the threads' CPU time is then headers, varblock placement
+ * and plan build only) */
+J40HIP_API j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int batch_frames, int max_in_flight, uint32_t flags, uint32_t *err);
+J40HIP_API int64_t j40hip_pipeline_lf_device_frames(j40hip_pipeline *p);   /* frames whose LfGroup streams the device decoded (since the last reset) */
 J40HIP_API void j40hip_pipeline_free(j40hip_pipeline *p);
 /* queues one image. buf is borrowed until the ticket is done. rgba: `stride_bytes` * height bytes of host memory (pinned memory for
  * full copy speed) or, with device_output != 0, of device memory (no copy back). */

@@ -94,7 +94,7 @@ def lib():
         "j40hip_frame_upload_on": (u32, [vp, C.c_int, vp]), "j40hip_thread_release": (None, []),
         "j40hip_frame_status_begin": (u32, [vp, vp]), "j40hip_frame_status_end": (u32, [vp]), "j40hip_frame_mark_idle": (None, [vp]),
         "j40hip_frame_after_frame_status": (u32, [vp]),
-        "j40hip_pipeline_create": (vp, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(u32)]), "j40hip_pipeline_free": (None, [vp]),
+        "j40hip_pipeline_create": (vp, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(u32)]), "j40hip_pipeline_free": (None, [vp]), "j40hip_pipeline_create_ex": (vp, [C.c_int, C.c_int, C.c_int, C.c_int, u32, C.POINTER(u32)]), "j40hip_pipeline_lf_device_frames": (i64, [vp]),
         "j40hip_pipeline_submit": (u32, [vp, vp, sz, vp, sz, C.c_int, C.POINTER(i64)]), "j40hip_pipeline_drain": (u32, [vp]),
         "j40hip_pipeline_result": (u32, [vp, i64]), "j40hip_pipeline_stats": (None, [vp, vp]), "j40hip_pipeline_reset_stats": (None, [vp]),
     }
@@ -410,12 +410,17 @@ class Pipeline:
     """whole-frame throughput pipeline (include/j40hip.h, j40hip_pipeline_*): codestreams in host memory -> RGBA u8x4 in host or
     device memory; host worker threads parse and upload, one thread batches the uploaded frames per entropy launch"""
 
-    def __init__(self, device=0, host_threads=0, batch_frames=32, max_in_flight=2):
+    def __init__(self, device=0, host_threads=0, batch_frames=32, max_in_flight=2, lf_on_device=False):
+        """lf_on_device: the workers leave the LfGroup streams to the device and sleep meanwhile -- use several times more
+        host_threads than CPUs"""
         err = C.c_uint32()
-        self.h = lib().j40hip_pipeline_create(device, host_threads, batch_frames, max_in_flight, C.byref(err))
+        self.h = lib().j40hip_pipeline_create_ex(device, host_threads, batch_frames, max_in_flight, 1 if lf_on_device else 0, C.byref(err))
         if not self.h:
             raise J40Error(err4(err.value), "in j40hip_pipeline_create")
         self._keep = []
+
+    def lf_device_frames(self):
+        return int(lib().j40hip_pipeline_lf_device_frames(self.h))
 
     def submit(self, data, rgba_ptr, stride_bytes, device_output=False):
         """data: bytes-like (kept alive until close / drain); rgba_ptr: address of the output image; returns the ticket"""

@@ -25,8 +25,7 @@ void launch_kat_srgb_u8(const float *v, size_t n, uint8_t *out, hipStream_t stre
 
 // Modular path (device/modular_kernels.hip)
 void launch_modular_sections(const DevModPlan &plan, int32_t first_section, int32_t num_sections, const ModLaunchInfo &info, hipStream_t stream);
-void launch_lf_groups(const uint8_t *codestream, const DevLfTask *tasks, int32_t num_tasks, const DevCoopTree *tree, const uint64_t *alias_pool, int32_t log_alpha_size,
-		int16_t *out_pool, DevLfResult *results, hipStream_t stream);
+void launch_lf_groups(const DevLfTask *tasks, int32_t num_tasks, hipStream_t stream);
 void launch_modular_quad(const DevModPlan &plan, int32_t first_section, int32_t num_sections, int32_t spec_idx, uint32_t table_span, int32_t max_width, hipStream_t stream);
 void launch_modular_coop(const DevModPlan &plan, int32_t first_section, int32_t num_sections, int32_t max_width, hipStream_t stream);
 void launch_section_inverse_rcts(const DevModPlan &plan, int32_t first_section, int32_t num_sections, hipStream_t stream);

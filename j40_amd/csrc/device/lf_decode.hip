@@ -13,19 +13,20 @@
 
 namespace j40hip {
 
-__global__ void __launch_bounds__(64) k_lf_groups(const uint8_t *codestream, const DevLfTask *tasks, const DevCoopTree *tree, const uint64_t *alias_pool, int32_t log_alpha_size,
-		int16_t *out_pool, DevLfResult *results) {
+__global__ void __launch_bounds__(64) k_lf_groups(const DevLfTask *tasks) {
 	const uint32_t lane = threadIdx.x;
 	const DevLfTask *tp = tasks + blockIdx.x;
 	const int32_t w8 = coop_sc(tp->w8), h8 = coop_sc(tp->h8), w64 = coop_sc(tp->w64), h64 = coop_sc(tp->h64);
 	const int32_t sidx0 = coop_sc(tp->sidx0), sidx2 = coop_sc(tp->sidx2), nbvb_bits = coop_sc(tp->nbvb_bits);
 	const uint32_t capacity = (uint32_t) coop_sc((int32_t) tp->out_capacity);
-	int16_t *out = coop_sc_ptr(out_pool) + (uint32_t) coop_sc((int32_t) tp->out_off);
-	const CoopTreeRegs t = coop_load_tree(tree, lane);
-	const int32_t log_bucket = 12 - log_alpha_size;
-	const CoopConstU64 alias = (CoopConstU64) coop_sc_ptr(alias_pool);
+	int16_t *out = coop_sc_ptr(tp->out);
+	DevLfResult *result = coop_sc_ptr(tp->result);
+	const uint8_t *codestream = coop_sc_ptr(tp->codestream);
+	const CoopTreeRegs t = coop_load_tree(coop_sc_ptr(tp->tree), lane);
+	const int32_t log_bucket = 12 - coop_sc(tp->log_alpha_size);
+	const CoopConstU64 alias = (CoopConstU64) coop_sc_ptr(tp->alias);
 	CoopBits b;
-	coop_bits_init(b, coop_sc_ptr(codestream), (uint32_t) coop_sc((int32_t) tp->byte_off), (uint32_t) coop_sc((int32_t) tp->size), (uint32_t) coop_sc((int32_t) tp->bit_off), lane);
+	coop_bits_init(b, codestream, (uint32_t) coop_sc((int32_t) tp->byte_off), (uint32_t) coop_sc((int32_t) tp->size), (uint32_t) coop_sc((int32_t) tp->bit_off), lane);
 	uint32_t state = 0, err = 0, status = 0;
 	int32_t nb_varblocks = 0;
 	const uint32_t cells = (uint32_t) w8 * (uint32_t) h8, c64 = (uint32_t) w64 * (uint32_t) h64;
@@ -51,12 +52,11 @@ __global__ void __launch_bounds__(64) k_lf_groups(const uint8_t *codestream, con
 		status = b.err ? b.err : err;
 		if (!status) status = coop_finish_code(b, state, lane);
 	}
-	if (lane == 0) { results[blockIdx.x].status = status; results[blockIdx.x].nb_varblocks = nb_varblocks; }
+	if (lane == 0) { result->status = status; result->nb_varblocks = nb_varblocks; }
 }
 
-void launch_lf_groups(const uint8_t *codestream, const DevLfTask *tasks, int32_t num_tasks, const DevCoopTree *tree, const uint64_t *alias_pool, int32_t log_alpha_size,
-		int16_t *out_pool, DevLfResult *results, hipStream_t stream) {
-	if (num_tasks > 0) hipLaunchKernelGGL(k_lf_groups, dim3((unsigned) num_tasks), dim3(64), 0, stream, codestream, tasks, tree, alias_pool, log_alpha_size, out_pool, results);
+void launch_lf_groups(const DevLfTask *tasks, int32_t num_tasks, hipStream_t stream) {
+	if (num_tasks > 0) hipLaunchKernelGGL(k_lf_groups, dim3((unsigned) num_tasks), dim3(64), 0, stream, tasks);
 }
 
 } // namespace j40hip

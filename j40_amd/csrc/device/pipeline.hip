@@ -58,6 +58,8 @@ struct Slot {                     // one batch in flight
 
 struct j40hip_pipeline {
 	int device = 0, batch_frames = 32, max_in_flight = 2;
+	bool lf_on_device = false;          // the workers parse with j40hip_frame_parse_on: LfGroup streams decoded by the device
+	int64_t lf_device_frames = 0;
 	std::mutex m;
 	std::condition_variable cv_todo, cv_ready, cv_done;
 	std::deque<Job *> todo, ready;
@@ -103,7 +105,9 @@ void worker_main(j40hip_pipeline *p) {
 		}
 		const double t0 = now_ms();
 		uint32_t err = 0;
-		j->frame = j40hip_frame_parse_ex(j->buf, j->size, 1, 1u, &err);   // (the LfGroup tail runs on the device, at upload)
+		// (the LfGroup tail runs on the device, at upload; with lf_on_device the LfGroup streams too, while this thread sleeps)
+		j->frame = p->lf_on_device ? j40hip_frame_parse_on(j->buf, j->size, 1, 1u, p->device, stream, &err) : j40hip_frame_parse_ex(j->buf, j->size, 1, 1u, &err);
+		const bool lf_dev = j->frame && j40hip_frame_lf_on_device(j->frame);
 		const double t1 = now_ms();
 		if (j->frame) {
 			int64_t info[21];
@@ -115,7 +119,7 @@ void worker_main(j40hip_pipeline *p) {
 		}
 		const double t2 = now_ms();
 		std::unique_lock<std::mutex> lock(p->m);
-		p->parse_ms += t1 - t0; p->upload_ms += t2 - t1;
+		p->parse_ms += t1 - t0; p->upload_ms += t2 - t1; p->lf_device_frames += lf_dev ? 1 : 0;
 		--p->parsing;
 		if (err) {
 			if (j->frame) { j40hip_frame_mark_idle(j->frame); j40hip_frame_free(j->frame); j->frame = nullptr; }
@@ -236,7 +240,9 @@ void gpu_main(j40hip_pipeline *p) {
 
 extern "C" {
 
-j40hip_pipeline *j40hip_pipeline_create(int device, int host_threads, int batch_frames, int max_in_flight, uint32_t *err) {
+j40hip_pipeline *j40hip_pipeline_create(int device, int host_threads, int batch_frames, int max_in_flight, uint32_t *err) { return j40hip_pipeline_create_ex(device, host_threads, batch_frames, max_in_flight, 0, err); }
+
+j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int batch_frames, int max_in_flight, uint32_t flags, uint32_t *err) {
 	uint32_t dummy; if (!err) err = &dummy;
 	*err = 0;
 	if (j40hip_device_count() <= device || device < 0 || hipSetDevice(device) != hipSuccess) { *err = E_GPU; return nullptr; }
@@ -244,6 +250,7 @@ j40hip_pipeline *j40hip_pipeline_create(int device, int host_threads, int batch_
 	try {
 		p = new j40hip_pipeline();
 		p->device = device;
+		p->lf_on_device = (flags & 1u) != 0;
 		// every frame allocates (and frees) tens of megabytes of tables on its worker thread; as separate mmap()s those serialise all the
 		// threads on the process's address-space lock and fault every page in again. Keep such blocks in the heap instead.
 		if (!getenv("J40HIP_KEEP_MALLOC_DEFAULTS")) { (void) mallopt(M_MMAP_THRESHOLD, 1 << 30); (void) mallopt(M_TRIM_THRESHOLD, (int) (((size_t) 1 << 31) - 1)); (void) mallopt(M_TOP_PAD, 64 << 20); }
@@ -251,7 +258,7 @@ j40hip_pipeline *j40hip_pipeline_create(int device, int host_threads, int batch_
 		p->max_in_flight = max_in_flight < 1 ? 2 : max_in_flight > 8 ? 8 : max_in_flight;
 		p->slots.resize((size_t) p->max_in_flight + 1);
 		for (Slot &s : p->slots) {
-			if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) { *err = E_GPU; break; }
+			if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { *err = E_GPU; break; }
 		}
 		if (!*err) {
 			if (host_threads < 1) host_threads = (int) std::max(1u, std::thread::hardware_concurrency());
@@ -321,11 +328,13 @@ void j40hip_pipeline_stats(j40hip_pipeline *p, double *out4) {
 	out4[4] = p->k1_ms; out4[5] = p->k2_ms; out4[6] = (double) p->launches; out4[7] = (double) p->launch_frames;
 }
 
+int64_t j40hip_pipeline_lf_device_frames(j40hip_pipeline *p) { if (!p) return 0; std::unique_lock<std::mutex> lock(p->m); return p->lf_device_frames; }
+
 void j40hip_pipeline_reset_stats(j40hip_pipeline *p) {
 	if (!p) return;
 	std::unique_lock<std::mutex> lock(p->m);
 	p->parse_ms = p->upload_ms = 0; p->first_submit_ms = 0; p->last_done_ms = 0;
-	p->k1_ms = p->k2_ms = 0; p->launches = p->launch_frames = 0;
+	p->k1_ms = p->k2_ms = 0; p->launches = p->launch_frames = 0; p->lf_device_frames = 0;
 }
 
 } // extern "C"

@@ -288,15 +288,19 @@ struct HfLaunchInfo {
 // stream index sidx0), then the number of varblocks, a second Modular header and the HF metadata (x-from-y and b-from-y maps of
 // w64 x h64, the varblock-info channel of 2 rows x nb_varblocks, the sharpness map of w8 x h8; stream index sidx2). The host
 // reads what precedes the first stream (extra precision, first header) and hands over where it starts.
+struct DevLfResult { uint32_t status; int32_t nb_varblocks; };
 struct DevLfTask {
+	// the frame the section belongs to (one launch takes the LfGroup sections of many frames): its codestream (padded), its
+	// global MA tree laid out for the cooperative decoder, the alias tables of its global code spec
+	const uint8_t *codestream; const DevCoopTree *tree; const uint64_t *alias; int32_t log_alpha_size;
 	uint32_t byte_off, size, bit_off;
 	int32_t w8, h8, w64, h64, sidx0, sidx2;
 	int32_t nbvb_bits;      // ceil(log2(w8 * h8)): the width of the varblock count
-	uint32_t out_off;       // this task's planes in the output pool (int16): lf[3] (w8 * h8 each, streamed order Y, X, B), xfromy, bfromy
-	                        // (w64 * h64 each), varblock info (2 rows of nb_varblocks, pitch nb_varblocks), sharpness (w8 * h8)
-	uint32_t out_capacity;  // int16 elements reserved from out_off on
+	int16_t *out;           // this task's planes: lf[3] (w8 * h8 each, streamed order Y, X, B), xfromy, bfromy (w64 * h64 each), varblock
+	                        // info (2 rows of nb_varblocks, pitch nb_varblocks), sharpness (w8 * h8)
+	uint32_t out_capacity;  // int16 elements reserved at `out`
+	DevLfResult *result;
 };
-struct DevLfResult { uint32_t status; int32_t nb_varblocks; };
 enum { ERR_LFFB = ('l' << 24) | ('f' << 16) | ('f' << 8) | 'b' };   // not an error of the stream: the second Modular header is not the plain one the device handles; the host decodes this section
 
 // sizes the host knows about a Modular frame's tree and code tables, to lay out k_modular_sections' LDS

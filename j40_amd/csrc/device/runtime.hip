@@ -3,6 +3,10 @@
 //
 // No CPU fallback lives here: without a HIP device every entry point returns "!gpu".
 #include <hip/hip_runtime.h>
+#include <deque>
+#include <condition_variable>
+#include <chrono>
+#include <thread>
 #include <algorithm>
 #include <mutex>
 #include <cmath>
@@ -413,51 +417,132 @@ static uint32_t decode_modular(j40hip_frame *h, void *rgba_dev, size_t stride_by
 }
 
 // ---- LfGroup streams on the device (lf_decode.hip): Frame::lf_decoder for frames parsed with j40hip_frame_parse_on ----
+// A parsing thread stages its frame's inputs (codestream, tree, alias tables) into a device block of its own, hands the frame's
+// tasks to the device's LF service and sleeps; the service thread gathers the tasks of every waiting frame into ONE launch
+// (a frame alone is 12 wavefronts for ~0.15 s; and launches from a hundred streams would queue up behind one another on the
+// few hardware queues a process gets), at most two launches in flight; the parsing thread then copies its planes back.
 struct LfDecodeContext { int device; hipStream_t stream; };
 thread_local PinnedStage t_lf_out;        // results land here; LfDeviceTask's pointers point into it until the thread's next call
 thread_local hipEvent_t t_lf_done = nullptr;
 
+struct LfRequest { std::vector<DevLfTask> tasks; bool done = false, ok = false; };
+struct LfService {
+	std::mutex m;
+	std::condition_variable cv_work, cv_done;
+	std::deque<LfRequest *> pending;
+	bool started = false;
+	int device = 0;
+};
+LfService g_lf_service[16];
+
+void lf_service_main(LfService *sv) {
+	struct Flight { std::vector<LfRequest *> reqs; int slot; };
+	hipStream_t stream[2] = {nullptr, nullptr}; hipEvent_t done[2] = {nullptr, nullptr};
+	PinnedStage host_tasks[2]; void *dev_tasks[2] = {nullptr, nullptr}; size_t dev_cap[2] = {0, 0};
+	auto dev_reserve = [&](int slot, size_t bytes) {   // grow-only
+		if (bytes <= dev_cap[slot]) return true;
+		if (dev_tasks[slot]) (void) hipFree(dev_tasks[slot]);
+		dev_tasks[slot] = nullptr; dev_cap[slot] = 0;
+		if (hipMalloc(&dev_tasks[slot], bytes * 2) != hipSuccess) { (void) hipGetLastError(); return false; }
+		dev_cap[slot] = bytes * 2;
+		return true;
+	};
+	bool usable = hipSetDevice(sv->device) == hipSuccess;
+	for (int i = 0; i < 2 && usable; ++i) usable = hipStreamCreateWithFlags(&stream[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&done[i], hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;
+	std::deque<Flight> inflight;
+	int next_slot = 0;
+	for (;;) {
+		std::vector<LfRequest *> take;
+		{
+			std::unique_lock<std::mutex> lock(sv->m);
+			sv->cv_work.wait(lock, [&] { return !sv->pending.empty() || !inflight.empty(); });
+			if (!sv->pending.empty() && inflight.size() < 2) {
+				if (sv->pending.size() < 24) sv->cv_work.wait_for(lock, std::chrono::milliseconds(3));   // let the other parsing threads catch up: one launch for all
+				while (!sv->pending.empty() && take.size() < 160) { take.push_back(sv->pending.front()); sv->pending.pop_front(); }
+			}
+		}
+		if (!take.empty()) {
+			const int slot = next_slot; next_slot ^= 1;
+			size_t n = 0;
+			for (const LfRequest *r : take) n += r->tasks.size();
+			bool ok = usable && host_tasks[slot].reserve(sizeof(DevLfTask) * n + 64, 0) && dev_reserve(slot, sizeof(DevLfTask) * n + 64);
+			if (ok) {
+				DevLfTask *h = (DevLfTask *) host_tasks[slot].ptr; size_t k = 0;
+				for (const LfRequest *r : take) for (const DevLfTask &t : r->tasks) h[k++] = t;
+				ok = hipMemcpyAsync(dev_tasks[slot], h, sizeof(DevLfTask) * n, hipMemcpyHostToDevice, stream[slot]) == hipSuccess;
+				if (ok) { launch_lf_groups((const DevLfTask *) dev_tasks[slot], (int32_t) n, stream[slot]); ok = hipGetLastError() == hipSuccess; }
+				ok = ok && hipEventRecord(done[slot], stream[slot]) == hipSuccess;
+			}
+			if (ok) inflight.push_back(Flight{std::move(take), slot});
+			else {
+				(void) hipGetLastError();
+				std::unique_lock<std::mutex> lock(sv->m);
+				for (LfRequest *r : take) { r->done = true; r->ok = false; }
+				sv->cv_done.notify_all();
+			}
+			if (inflight.size() < 2) continue;   // room for another launch: look for more work first
+		}
+		if (!inflight.empty()) {
+			Flight fl = std::move(inflight.front()); inflight.pop_front();
+			const bool ok = hipEventSynchronize(done[fl.slot]) == hipSuccess;
+			std::unique_lock<std::mutex> lock(sv->m);
+			for (LfRequest *r : fl.reqs) { r->done = true; r->ok = ok; }
+			sv->cv_done.notify_all();
+		}
+	}
+}
+
 static bool lf_device_decode(void *ctx_, const Frame &f, const uint8_t *cs, size_t cs_size, std::vector<LfDeviceTask> &tasks) {
 	const LfDecodeContext &ctx = *(const LfDecodeContext *) ctx_;
-	if (tasks.empty() || cs_size + 16 >= ((size_t) 1 << 29)) return false;
+	if (tasks.empty() || cs_size + 16 >= ((size_t) 1 << 29) || ctx.device < 0 || ctx.device >= 16) return false;
 	if (hipSetDevice(ctx.device) != hipSuccess) return false;
 	DevCoopTree tree; std::vector<uint64_t> alias; int32_t log_alpha = 0;
 	if (!build_lf_coop(f, &tree, &alias, &log_alpha)) return false;
-	std::vector<DevLfTask> dt(tasks.size());
+	// this frame's inputs go up in one staged copy; one block of device memory holds them, the output planes and the results
+	std::vector<size_t> out_off(tasks.size());
 	size_t out_elems = 0;
 	for (size_t i = 0; i < tasks.size(); ++i) {
-		const LfDeviceTask &t = tasks[i];
-		DevLfTask &d = dt[i];
-		d.byte_off = (uint32_t) t.byte_off; d.size = (uint32_t) t.size; d.bit_off = t.bit_off;
-		d.w8 = t.w8; d.h8 = t.h8; d.w64 = t.w64; d.h64 = t.h64; d.sidx0 = t.sidx0; d.sidx2 = t.sidx2; d.nbvb_bits = t.nbvb_bits;
-		const size_t cells = (size_t) t.w8 * (size_t) t.h8, c64 = (size_t) t.w64 * (size_t) t.h64;
-		d.out_off = (uint32_t) out_elems; d.out_capacity = (uint32_t) (6 * cells + 2 * c64);
-		out_elems += (d.out_capacity + 63) & ~(size_t) 63;
+		const size_t cells = (size_t) tasks[i].w8 * (size_t) tasks[i].h8, c64 = (size_t) tasks[i].w64 * (size_t) tasks[i].h64;
+		out_off[i] = out_elems; out_elems += (6 * cells + 2 * c64 + 63) & ~(size_t) 63;
 	}
-	// codestream (padded), tree, alias tables and tasks go up in one staged copy; one block of device memory holds them, the
-	// output planes and the results
 	Stager sg;
 	const size_t o_cs = sg.put(cs, cs_size); (void) sg.reserve(32);   // (the decoder's word window reads a little past the last section)
-	const size_t o_tree = sg.put(&tree, 1), o_alias = sg.put(alias.data(), alias.size()), o_tasks = sg.put(dt.data(), dt.size());
+	const size_t o_tree = sg.put(&tree, 1), o_alias = sg.put(alias.data(), alias.size());
 	const size_t copy_bytes = sg.size;
-	const size_t o_res = sg.reserve(sizeof(DevLfResult) * dt.size()), o_out = sg.reserve(sizeof(int16_t) * out_elems);
+	const size_t o_res = sg.reserve(sizeof(DevLfResult) * tasks.size()), o_out = sg.reserve(sizeof(int16_t) * out_elems);
 	if (!sg.ok) return false;
 	memset(t_stage.ptr + o_cs + cs_size, 0, 32);
 	size_t block_bytes = 0; bool clean = false;
 	uint8_t *block = (uint8_t *) cache_acquire(ctx.device, sg.size, &block_bytes, &clean);
 	if (!block) return false;
-	const size_t res_bytes = sizeof(DevLfResult) * dt.size(), out_bytes = sizeof(int16_t) * out_elems, res_off = (out_bytes + 255) & ~(size_t) 255;
+	const size_t res_bytes = sizeof(DevLfResult) * tasks.size(), out_bytes = sizeof(int16_t) * out_elems, res_off = (out_bytes + 255) & ~(size_t) 255;
 	bool ok = t_lf_out.reserve(res_off + res_bytes + 64, 0);
-	if (ok && !t_lf_done) ok = hipEventCreateWithFlags(&t_lf_done, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;   // (a worker waits here for ~0.1 s: asleep, not spinning)
-	ok = ok && hipMemcpyAsync(block, sg.data(), copy_bytes, hipMemcpyHostToDevice, ctx.stream) == hipSuccess;
+	if (ok && !t_lf_done) ok = hipEventCreateWithFlags(&t_lf_done, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;   // (waits here are sleeps, not spins)
+	auto wait = [&]() { return hipEventRecord(t_lf_done, ctx.stream) == hipSuccess && hipEventSynchronize(t_lf_done) == hipSuccess; };
+	ok = ok && hipMemcpyAsync(block, sg.data(), copy_bytes, hipMemcpyHostToDevice, ctx.stream) == hipSuccess && wait();
+	LfRequest req;
 	if (ok) {
-		launch_lf_groups(block + o_cs, (const DevLfTask *) (block + o_tasks), (int32_t) dt.size(), (const DevCoopTree *) (block + o_tree), (const uint64_t *) (block + o_alias), log_alpha,
-			(int16_t *) (block + o_out), (DevLfResult *) (block + o_res), ctx.stream);
-		ok = hipGetLastError() == hipSuccess;
+		req.tasks.resize(tasks.size());
+		for (size_t i = 0; i < tasks.size(); ++i) {
+			const LfDeviceTask &t = tasks[i];
+			DevLfTask &d = req.tasks[i];
+			d.codestream = block + o_cs; d.tree = (const DevCoopTree *) (block + o_tree); d.alias = (const uint64_t *) (block + o_alias); d.log_alpha_size = log_alpha;
+			d.byte_off = (uint32_t) t.byte_off; d.size = (uint32_t) t.size; d.bit_off = t.bit_off;
+			d.w8 = t.w8; d.h8 = t.h8; d.w64 = t.w64; d.h64 = t.h64; d.sidx0 = t.sidx0; d.sidx2 = t.sidx2; d.nbvb_bits = t.nbvb_bits;
+			d.out = (int16_t *) (block + o_out) + out_off[i]; d.out_capacity = (uint32_t) (6 * (size_t) t.w8 * (size_t) t.h8 + 2 * (size_t) t.w64 * (size_t) t.h64);
+			d.result = (DevLfResult *) (block + o_res) + i;
+		}
+		LfService &sv = g_lf_service[ctx.device];
+		std::unique_lock<std::mutex> lock(sv.m);
+		if (!sv.started) { sv.started = true; sv.device = ctx.device; std::thread(lf_service_main, &sv).detach(); }
+		sv.pending.push_back(&req);
+		sv.cv_work.notify_all();
+		sv.cv_done.wait(lock, [&] { return req.done; });
+		ok = req.ok;
 	}
 	ok = ok && hipMemcpyAsync(t_lf_out.ptr, block + o_out, out_bytes, hipMemcpyDeviceToHost, ctx.stream) == hipSuccess;
 	ok = ok && hipMemcpyAsync(t_lf_out.ptr + res_off, block + o_res, res_bytes, hipMemcpyDeviceToHost, ctx.stream) == hipSuccess;
-	ok = ok && hipEventRecord(t_lf_done, ctx.stream) == hipSuccess && hipEventSynchronize(t_lf_done) == hipSuccess;
+	ok = ok && wait();
 	if (!ok) (void) hipStreamSynchronize(ctx.stream);   // nothing of this call may still be in flight when the block goes back
 	cache_release(ctx.device, block, block_bytes, false);
 	if (!ok) { (void) hipGetLastError(); return false; }
@@ -466,7 +551,7 @@ static bool lf_device_decode(void *ctx_, const Frame &f, const uint8_t *cs, size
 	for (size_t i = 0; i < tasks.size(); ++i) {
 		LfDeviceTask &t = tasks[i];
 		const size_t cells = (size_t) t.w8 * (size_t) t.h8, c64 = (size_t) t.w64 * (size_t) t.h64;
-		const int16_t *p = out + dt[i].out_off;
+		const int16_t *p = out + out_off[i];
 		t.status = res[i].status; t.nb_varblocks = res[i].nb_varblocks;
 		for (int c = 0; c < 3; ++c) t.lf[c] = p + (size_t) c * cells;
 		t.xfromy = p + 3 * cells; t.bfromy = t.xfromy + c64; t.info0 = t.bfromy + c64; t.info1 = t.info0 + (t.nb_varblocks > 0 ? t.nb_varblocks : 0);
@@ -593,7 +678,9 @@ static uint32_t upload_impl(j40hip_frame *h, int device, hipStream_t s) {
 	st->has_trailers = hp.frame.sections_have_trailer != 0 && !h->from_view;
 	st->first_group = 0; st->num_groups = num_groups;
 	for (auto &e : st->ev) if (hipEventCreate(&e) != hipSuccess) ok = false;
-	if (hipStreamSynchronize(s) != hipSuccess) ok = false;
+	// (asleep while the copy runs, like lf_device_decode: a pipeline may have many more uploading threads than CPUs)
+	if (!t_lf_done && hipEventCreateWithFlags(&t_lf_done, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { t_lf_done = nullptr; (void) hipGetLastError(); }
+	if (t_lf_done ? (hipEventRecord(t_lf_done, s) != hipSuccess || hipEventSynchronize(t_lf_done) != hipSuccess) : hipStreamSynchronize(s) != hipSuccess) ok = false;
 	if (!ok) { j40hip_release_device(h); return ERR_GPU; }
 	return 0;
 }
