@@ -321,6 +321,46 @@ inline int32_t rans_value(BitReader &br, uint32_t &state, int32_t log_bucket, co
 	return ((top | hi) << (midbits + c.lsb_in_token)) | ((mid << c.lsb_in_token) | lo);
 }
 
+// channels whose specialised tree is a single leaf (the usual case for LF chroma and for the HF-metadata channels): no tree walk,
+// and with the predictor a compile-time constant only the neighbours it uses are fetched
+template <int PRED>
+static void decode_single_leaf(BitReader &br, Plane &c, uint32_t &state, int32_t log_bucket, const Cluster &cl, int32_t offset, int32_t multiplier) {
+	const int32_t w = c.width, h = c.height;
+	for (int32_t y = 0; y < h; ++y) {
+		int16_t *row = c.row(y);
+		const int16_t *up = y > 0 ? c.row(y - 1) : row, *up2 = y > 1 ? c.row(y - 2) : up;
+		for (int32_t x = 0; x < w; ++x) {
+			// the neighbours with their fallbacks (j40.h:3965-3990); the ones PRED does not use fold away
+			const int32_t pw = x > 0 ? row[x - 1] : y > 0 ? up[x] : 0;
+			const int32_t pn = y > 0 ? up[x] : pw;
+			const int32_t pnw = x > 0 && y > 0 ? up[x - 1] : pw;
+			const int32_t pne = x + 1 < w && y > 0 ? up[x + 1] : pn;
+			const int32_t pnn = y > 1 ? up2[x] : pn;
+			const int32_t pnee = x + 2 < w && y > 0 ? up[x + 2] : pne;
+			const int32_t pww = x > 1 ? row[x - 2] : pw;
+			int32_t pred;
+			switch (PRED) {
+			case 0: pred = 0; break;
+			case 1: pred = pw; break;
+			case 2: pred = pn; break;
+			case 3: pred = (pw + pn) / 2; break;
+			case 4: pred = std::abs(pn - pnw) < std::abs(pw - pnw) ? pw : pn; break;
+			case 5: pred = clamped_gradient(pw, pn, pnw); break;
+			case 7: pred = pne; break;
+			case 8: pred = pnw; break;
+			case 9: pred = pww; break;
+			case 10: pred = (pw + pnw) / 2; break;
+			case 11: pred = (pn + pnw) / 2; break;
+			case 12: pred = (pn + pne) / 2; break;
+			default: pred = (6 * pn - 2 * pnn + 7 * pw + pww + pnee + 3 * pne + 8) / 16; break;   // 13
+			}
+			const int32_t v = unpack_signed(rans_value(br, state, log_bucket, cl)) * multiplier + offset + pred;
+			J40HIP_SHOULD(-32768 <= v && v <= 32767, "povf");
+			row[x] = (int16_t) v;
+		}
+	}
+}
+
 // the fast loop: rANS without LZ77, no weighted predictor, no previous-channel properties in the specialised tree
 bool decode_channel_fast(BitReader &br, Modular &m, CodeState &code, int32_t cidx, int64_t sidx) {
 	const CodeSpec *spec = code.spec;
@@ -336,6 +376,25 @@ bool decode_channel_fast(BitReader &br, Modular &m, CodeState &code, int32_t cid
 	const Cluster *clusters = spec->clusters.data();
 	uint32_t state = code.ans_state;
 	struct Restore { CodeState &code; uint32_t &state; ~Restore() { code.ans_state = state; } } restore{code, state};   // (also when an error unwinds)
+	if (single) {
+		const Cluster &cl = clusters[cluster_map[(size_t) root->value]];
+		switch (-1 - root->prop) {
+		case 0: decode_single_leaf<0>(br, c, state, log_bucket, cl, root->a, root->b); break;
+		case 1: decode_single_leaf<1>(br, c, state, log_bucket, cl, root->a, root->b); break;
+		case 2: decode_single_leaf<2>(br, c, state, log_bucket, cl, root->a, root->b); break;
+		case 3: decode_single_leaf<3>(br, c, state, log_bucket, cl, root->a, root->b); break;
+		case 4: decode_single_leaf<4>(br, c, state, log_bucket, cl, root->a, root->b); break;
+		case 5: decode_single_leaf<5>(br, c, state, log_bucket, cl, root->a, root->b); break;
+		case 7: decode_single_leaf<7>(br, c, state, log_bucket, cl, root->a, root->b); break;
+		case 8: decode_single_leaf<8>(br, c, state, log_bucket, cl, root->a, root->b); break;
+		case 9: decode_single_leaf<9>(br, c, state, log_bucket, cl, root->a, root->b); break;
+		case 10: decode_single_leaf<10>(br, c, state, log_bucket, cl, root->a, root->b); break;
+		case 11: decode_single_leaf<11>(br, c, state, log_bucket, cl, root->a, root->b); break;
+		case 12: decode_single_leaf<12>(br, c, state, log_bucket, cl, root->a, root->b); break;
+		default: decode_single_leaf<13>(br, c, state, log_bucket, cl, root->a, root->b); break;
+		}
+		return true;
+	}
 	for (int32_t y = 0; y < h; ++y) {
 		int16_t *row = c.row(y);
 		const int16_t *up = y > 0 ? c.row(y - 1) : row, *up2 = y > 1 ? c.row(y - 2) : up;
