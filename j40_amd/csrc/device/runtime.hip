@@ -433,7 +433,15 @@ struct LfService {
 	bool started = false;
 	int device = 0;
 };
-LfService g_lf_service[16];
+// (never destroyed: the service threads are detached and sleep on these condition variables for the life of the process; running
+// their destructors at exit with a thread still waiting is undefined behaviour -- it hung interpreters at shutdown)
+LfService *lf_service(int device) {
+	static std::mutex create;
+	static LfService *services[16] = {nullptr};
+	std::lock_guard<std::mutex> lock(create);
+	if (!services[device]) services[device] = new LfService();
+	return services[device];
+}
 
 void lf_service_main(LfService *sv) {
 	struct Flight { std::vector<LfRequest *> reqs; int slot; };
@@ -532,7 +540,7 @@ static bool lf_device_decode(void *ctx_, const Frame &f, const uint8_t *cs, size
 			d.out = (int16_t *) (block + o_out) + out_off[i]; d.out_capacity = (uint32_t) (6 * (size_t) t.w8 * (size_t) t.h8 + 2 * (size_t) t.w64 * (size_t) t.h64);
 			d.result = (DevLfResult *) (block + o_res) + i;
 		}
-		LfService &sv = g_lf_service[ctx.device];
+		LfService &sv = *lf_service(ctx.device);
 		std::unique_lock<std::mutex> lock(sv.m);
 		if (!sv.started) { sv.started = true; sv.device = ctx.device; std::thread(lf_service_main, &sv).detach(); }
 		sv.pending.push_back(&req);
