@@ -262,6 +262,7 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 		}
 		if (!*err) {
 			if (host_threads < 1) host_threads = (int) std::max(1u, std::thread::hardware_concurrency());
+			if (host_threads > 128) host_threads = 128;   // (each worker owns tens of MB of pinned staging; more than this was never exercised)
 			p->gpu = std::thread(gpu_main, p);
 			for (int i = 0; i < host_threads; ++i) p->workers.emplace_back(worker_main, p);
 		}

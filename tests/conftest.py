@@ -12,6 +12,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
+def pytest_unconfigure(config):
+    # The run is over and reported. If tearing the process down wedges (device runtimes unload with helper threads around), let
+    # the kernel end it after three minutes rather than hang whoever waits for it: SIGALRM's default action terminates.
+    import signal
+    if hasattr(signal, "alarm"):
+        signal.signal(signal.SIGALRM, signal.SIG_DFL)
+        signal.alarm(180)
+
+
 def pytest_collection_modifyitems(config, items):
     # tests not marked gpu must pass on a CPU-only box
     pass
