@@ -620,7 +620,7 @@ static void lf_group_finish(Frame *f, LfGroup *gg, int32_t extra_prec, const int
 	// place varblocks in raster order at the first free cell (j40.h:6634-6688)
 	const int32_t log_gsize8 = fh.group_size_shift - 3;
 	gg->blocks.assign(cells, 0);
-	gg->varblocks.assign((size_t) nb_varblocks, VarblockInfo());
+	gg->varblocks.clear(); gg->varblocks.reserve((size_t) nb_varblocks);   // (filled in placement order below: no need to zero 20 bytes per block first)
 	int32_t voff = 0, coeffoff = 0;
 	uint32_t dct_used = 0, order_used = 0;
 	for (int32_t y0 = 0; y0 < h8; ++y0) for (int32_t x0 = 0; x0 < w8; ++x0) {
@@ -636,7 +636,8 @@ static void lf_group_finish(Frame *f, LfGroup *gg, int32_t extra_prec, const int
 		J40HIP_SHOULD(y1 < h8 && (y0 >> log_gsize8) == (y1 >> log_gsize8), "vblk");
 		for (int32_t i = 0; i < vh8; ++i) for (int32_t j = 0; j < vw8; ++j) gg->blocks[(size_t) (y0 + i) * (size_t) w8 + (size_t) (x0 + j)] = 1 << 20 | voff;
 		gg->blocks[(size_t) y0 * (size_t) w8 + (size_t) x0] = (dctsel + 2) << 20 | voff;
-		VarblockInfo &vb = gg->varblocks[(size_t) voff];
+		gg->varblocks.push_back(VarblockInfo());
+		VarblockInfo &vb = gg->varblocks.back();
 		vb.coeffoff_qfidx = coeffoff; vb.x8 = x0; vb.y8 = y0; vb.dctsel = dctsel;
 		const int32_t hfmul_m1 = info1[voff];
 		for (int32_t j = 0; j < f->nb_qf_thr; ++j) vb.coeffoff_qfidx += hfmul_m1 >= f->qf_thr[j];

@@ -203,7 +203,7 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 		size_t count[28] = {0}, at[28], k = 0, total = 0;
 		for (const LfGroup &gg : fr.lf_groups) { total += gg.varblocks.size(); for (const VarblockInfo &vb : gg.varblocks) ++count[vb.dctsel >= 0 && vb.dctsel < 27 ? vb.dctsel : 27]; }
 		for (int d = 0; d <= 27; ++d) { hp->class_start[d] = (int32_t) k; at[d] = k; k += count[d]; }
-		hp->vb_sorted.resize(total);
+		if (hp->vb_sorted.size() != total) hp->vb_sorted.resize(total);   // (every record is written below; a reused plan object keeps last frame's storage)
 		for (size_t g = 0; g < fr.lf_groups.size(); ++g) {
 			const LfGroup &gg = fr.lf_groups[g];
 			const DevLfGroup &d = hp->lf_groups[g];
