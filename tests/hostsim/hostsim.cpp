@@ -478,3 +478,79 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_coop_check(con
 	}
 	return bad ? -(1 + bad) : checked;
 }
+
+// ---- the host glue around the device's LfGroup decoder (frame.cpp: parse_frame's lf_decoder branch, lf_group_finish), exercised
+// without a GPU: a stand-in decoder that does on the host what k_lf_groups does on the device -- start at the bit the task names,
+// decode the LF image, check the final rANS state, read the varblock count and the second header (plain ones only: anything else
+// reports 'lffb'), decode the HF metadata -- and hands back planes in the kernel's layout. The frame parsed through it must
+// equal the frame parsed by read_lf_group. mode 1: the stand-in answers 'lffb' for every second section (host fallback).
+namespace {
+struct FakeLfStore { std::vector<std::vector<int16_t>> planes; int mode = 0; int calls = 0; };
+bool fake_lf_decoder(void *ctx, const Frame &f, const uint8_t *cs, size_t cs_size, std::vector<LfDeviceTask> &tasks) {
+	FakeLfStore &st = *(FakeLfStore *) ctx;
+	++st.calls;
+	st.planes.assign(tasks.size(), std::vector<int16_t>());
+	for (size_t i = 0; i < tasks.size(); ++i) {
+		LfDeviceTask &t = tasks[i];
+		if (t.byte_off + t.size > cs_size) { t.status = ERR_SHRT; continue; }
+		if (st.mode == 1 && (i & 1)) { t.status = (uint32_t) ERR_LFFB; continue; }
+		const size_t cells = (size_t) t.w8 * (size_t) t.h8, c64 = (size_t) t.w64 * (size_t) t.h64;
+		std::vector<int16_t> &out = st.planes[i];
+		try {
+			BitReader br(cs + t.byte_off, t.size);
+			br.skip_bits((int64_t) t.bit_off);
+			Modular a; a.bpp = f.im.bpp; a.use_global_tree = true; a.tree = &f.global_tree; a.codespec = &f.global_codespec;
+			a.channel.assign(3, Plane());
+			for (Plane &p : a.channel) { p.width = t.w8; p.height = t.h8; }
+			allocate_modular(&a);
+			{ CodeState code(a.codespec); for (int32_t c = 0; c < 3; ++c) decode_modular_channel(br, a, code, c, t.sidx0); finish_code(br, code); }
+			t.nb_varblocks = (int32_t) br.u(t.nbvb_bits) + 1;
+			if (br.u(4) != 3u || (size_t) t.nb_varblocks > cells) { t.status = (uint32_t) ERR_LFFB; continue; }
+			Modular b; b.bpp = f.im.bpp; b.use_global_tree = true; b.tree = &f.global_tree; b.codespec = &f.global_codespec;
+			b.channel.assign(4, Plane());
+			b.channel[0].width = b.channel[1].width = t.w64; b.channel[0].height = b.channel[1].height = t.h64;
+			b.channel[2].width = t.nb_varblocks; b.channel[2].height = 2;
+			b.channel[3].width = t.w8; b.channel[3].height = t.h8;
+			allocate_modular(&b);
+			{ CodeState code(b.codespec); for (int32_t c = 0; c < 4; ++c) decode_modular_channel(br, b, code, c, t.sidx2); finish_code(br, code); }
+			out.resize(3 * cells + 2 * c64 + 2 * (size_t) t.nb_varblocks + cells);
+			int16_t *p = out.data();
+			for (int c = 0; c < 3; ++c) { memcpy(p, a.channel[(size_t) c].px.data(), cells * 2); t.lf[c] = p; p += cells; }
+			memcpy(p, b.channel[0].px.data(), c64 * 2); t.xfromy = p; p += c64;
+			memcpy(p, b.channel[1].px.data(), c64 * 2); t.bfromy = p; p += c64;
+			memcpy(p, b.channel[2].px.data(), 2 * (size_t) t.nb_varblocks * 2); t.info0 = p; t.info1 = p + t.nb_varblocks; p += 2 * (size_t) t.nb_varblocks;
+			memcpy(p, b.channel[3].px.data(), cells * 2);
+			t.status = 0;
+		} catch (const DecodeError &e) { t.status = e.code; }
+	}
+	return true;
+}
+}
+
+// returns 0 when both parses agree (or fail with the same code), else a non-zero description: 1 error codes differ, 2 the stand-in
+// was not called, 3 LF groups differ; *err_out = the plain parse's error code
+extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_decoder_glue(const uint8_t *buf, size_t size, int mode, uint32_t *err_out) {
+	const uint8_t *cs; size_t cs_size; std::vector<uint8_t> storage;
+	uint32_t e1 = 0, e2 = 0;
+	Frame plain, hooked;
+	FakeLfStore store; store.mode = mode;
+	plain.defer_lf_tail = hooked.defer_lf_tail = true;
+	try { extract_codestream(buf, size, &cs, &cs_size, &storage); } catch (const DecodeError &e) { if (err_out) *err_out = e.code; return 0; }
+	try { parse_frame(cs, cs_size, &plain, 1); } catch (const DecodeError &e) { e1 = e.code; }
+	hooked.lf_decoder = fake_lf_decoder; hooked.lf_decoder_ctx = &store;
+	try { parse_frame(cs, cs_size, &hooked, 1); } catch (const DecodeError &e) { e2 = e.code; }
+	if (err_out) *err_out = e1;
+	if (e1 != e2) return 1;
+	if (e1) return 0;
+	if (plain.fh.is_modular || plain.toc.single) return 0;   // (those never reach the decoder)
+	if (!store.calls || !hooked.lf_decoded_on_device) return 2;
+	for (size_t g = 0; g < plain.lf_groups.size(); ++g) {
+		const LfGroup &a = plain.lf_groups[g], &b = hooked.lf_groups[g];
+		bool same = a.blocks == b.blocks && a.lfindices == b.lfindices && a.xfromy == b.xfromy && a.bfromy == b.bfromy && a.varblocks.size() == b.varblocks.size();
+		for (int c = 0; same && c < 3; ++c) same = a.lfraw[c] == b.lfraw[c] && a.mult_lf[c] == b.mult_lf[c];
+		for (size_t v = 0; same && v < a.varblocks.size(); ++v)
+			same = a.varblocks[v].coeffoff_qfidx == b.varblocks[v].coeffoff_qfidx && a.varblocks[v].hfmul_inv == b.varblocks[v].hfmul_inv && a.varblocks[v].x8 == b.varblocks[v].x8 && a.varblocks[v].y8 == b.varblocks[v].y8 && a.varblocks[v].dctsel == b.varblocks[v].dctsel;
+		if (!same) return 3;
+	}
+	return plain.dct_select_used == hooked.dct_select_used && plain.order_used == hooked.order_used ? 0 : 3;
+}
