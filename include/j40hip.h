@@ -141,6 +141,9 @@ typedef struct {
 	/* frames whose channels differ in size (after a Squeeze): the section's channels as explicit rectangles,
 	 * chan_rects[6 * (chan_off + i)] = {channel, x0, y0, width, height, hshift | vshift << 8}; -1: first_channel ... over gx, gy, gw, gh */
 	int32_t chan_off;
+	/* the LZ77 distance multiplier of the section's stream + 1 (j40.h:3840-3844), or 0: the widest non-meta channel among the section's
+	 * own channels. LfGlobal's section takes the frame-wide image's, which also counts channels the section does not code */
+	int32_t dist_mult_p1;
 } j40hip_modular_section_view;
 
 typedef struct {

@@ -445,7 +445,7 @@ uint32_t j40hip_frame_modular_view(j40hip_frame *h, j40hip_modular_view *v) {
 		j40hip_modular_section_view sv;
 		sv.byte_off = s.byte_off; sv.size = s.size; sv.bit_off = s.bit_off; sv.gx = s.gx; sv.gy = s.gy; sv.gw = s.gw; sv.gh = s.gh; sv.sidx = s.sidx;
 		sv.first_channel = s.first_channel; sv.num_channels = s.num_channels; memcpy(sv.wp, s.wp, 12);
-		sv.tree_off = s.tree_off; sv.tree_nodes = s.tree_nodes; sv.spec_idx = s.spec_idx; sv.local_off = s.local_off; sv.local_count = s.local_count; sv.sub_off = s.sub_off; sv.sub_tr_off = sv.sub_tr_count = sv.sub_paste = 0; sv.preset_status = s.preset_status; sv.chan_off = s.chan_off;
+		sv.tree_off = s.tree_off; sv.tree_nodes = s.tree_nodes; sv.spec_idx = s.spec_idx; sv.local_off = s.local_off; sv.local_count = s.local_count; sv.sub_off = s.sub_off; sv.sub_tr_off = sv.sub_tr_count = sv.sub_paste = 0; sv.preset_status = s.preset_status; sv.chan_off = s.chan_off; sv.dist_mult_p1 = s.dist_mult_p1;
 		h->views.mod_sections.push_back(sv);
 	}
 	v->sections = h->views.mod_sections.data();

@@ -167,7 +167,8 @@ J40_DEV uint32_t decode_modular_section(const DevModPlan &plan, const ModTables 
 	code_init(code, spec, t.clusters, t.cluster_map, t.alias, t.prefix, window);
 	// LZ77 distance multiplier: widest non-meta channel of this sub-image (j40.h:3841-3844)
 	int32_t dist_mult = 0;
-	for (int32_t cidx = 0; cidx < sec.num_channels; ++cidx) { const ModChan c = mod_channel(plan, sec, cidx); if (!c.meta) dist_mult = mod_max(dist_mult, c.gw); }
+	if (sec.dist_mult_p1) dist_mult = sec.dist_mult_p1 - 1;   // (LfGlobal: the frame-wide image's, see plan.h)
+	else for (int32_t cidx = 0; cidx < sec.num_channels; ++cidx) { const ModChan c = mod_channel(plan, sec, cidx); if (!c.meta) dist_mult = mod_max(dist_mult, c.gw); }
 	dist_mult = mod_min(dist_mult, 1 << 21);
 	ModWP wp;
 	wp.on = sec.uses_wp; wp.width = sec.gw;

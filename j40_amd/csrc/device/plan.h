@@ -187,6 +187,10 @@ struct DevModSection {
 	// >= 0: the section is decoded by the wave-cooperative kernel (modular_coop.hip) with DevModPlan::coop_trees[coop_idx];
 	// -1: by k_modular_sections
 	int32_t coop_idx;
+	// LZ77 distance multiplier of the section's stream + 1 (j40.h:3840-3844), or 0: the widest non-meta channel among the section's own
+	// channels (a pass group's sub-image, j40.h:7024). LfGlobal's section belongs to the frame-wide image: its multiplier comes from
+	// ALL of that image's non-meta channels, also the ones the section itself does not code (multi-group frames: only the palette is)
+	int32_t dist_mult_p1;
 	// != 0 (only with coop_idx >= 0): four such sections share a wavefront of k_modular_quad (modular_quad.hip); frames with
 	// thousands of sections
 	int32_t quad;

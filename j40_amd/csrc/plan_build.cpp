@@ -440,6 +440,7 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 			const Section &ls = fr.toc.single ? fr.toc.single_section : fr.toc.lf_global;
 			s.byte_off = (uint32_t) ls.offset; s.size = (uint32_t) ls.size; s.bit_off = (uint32_t) fr.gm_data_bitpos;
 			s.gw = fr.fh.width; s.gh = fr.fh.height; s.sidx = 0;
+			s.dist_mult_p1 = gm.dist_mult + 1;
 			std::vector<int32_t> chans;
 			for (int32_t c = 0; c < fr.num_gm_channels; ++c) chans.push_back(c);
 			add_rects(&s, chans, 0, 0, 0, true, nullptr);
@@ -496,6 +497,7 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 		s.byte_off = (uint32_t) ls.offset; s.size = (uint32_t) ls.size; s.bit_off = (uint32_t) fr.gm_data_bitpos;
 		s.gx = s.gy = 0; s.gw = fr.fh.width; s.gh = fr.fh.height; s.sidx = 0;
 		s.first_channel = 0; s.num_channels = fr.num_gm_channels;
+		s.dist_mult_p1 = gm.dist_mult + 1;   // the frame-wide image's multiplier (j40.h:3840-3844), not only that of the channels coded here
 		wp_bytes(gm.wp, s.wp);
 		if (!gm.tree || gm.tree->empty() || !gm.codespec) return E4("mtre");
 		attach(gm, &s);

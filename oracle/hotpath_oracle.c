@@ -642,7 +642,10 @@ static uint32_t modular_section(const j40hip_modular_view *v, const j40hip_modul
 	for (ti = 0; ti < sec->tree_nodes; ++ti) if (tree[ti].prop == 15 || tree[ti].prop == -1 - 6) uses_wp = 1;
 	obits_init(&b, v->codestream, sec->byte_off, sec->size, sec->bit_off);
 	ocode_restart(code);
-	for (cidx = 0; cidx < sec->num_channels; ++cidx) {
+	/* j40.h:3840-3844: the widest non-meta channel of the Modular image the stream belongs to -- for LfGlobal's section that is the
+	 * frame-wide image, including channels the section itself does not code (dist_mult_p1); for a pass group its sub-image */
+	if (sec->dist_mult_p1) dist_mult = sec->dist_mult_p1 - 1;
+	else for (cidx = 0; cidx < sec->num_channels; ++cidx) {
 		ochan oc = section_channel(v, sec, planes, cidx);
 		if (!oc.pl->meta) dist_mult = imax32(dist_mult, oc.gw);
 	}

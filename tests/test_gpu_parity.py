@@ -182,6 +182,15 @@ def test_modular_corruption_is_reported(gpu, ref):
     assert rejected >= 1
 
 
+def test_lz77_distance_multiplier_of_lf_global_on_the_gpu(gpu, ref):
+    """see tests/test_hostsim.py::test_lz77_distance_multiplier_of_lf_global_is_the_whole_images: the same damaged stream through K3"""
+    data = bytearray(synth("modular", 645, 28, 75417, palette=3, prefix=1, lz77=1, permute=1))
+    data[1249] ^= 0x08
+    err, rgba = gpu.decode(bytes(data))
+    rerr, expect = ref.decode(bytes(data))
+    assert err == "" and rerr == "" and np.array_equal(rgba, expect)
+
+
 def test_hip_path_against_cpu_oracle(gpu):
     """HIP kernels vs the plain-C restatement (oracle/hotpath_oracle.c), both behind the same plan seam"""
     import ctypes as C

@@ -266,3 +266,25 @@ def test_cooperative_special_transforms_equal_the_reference_bit_for_bit(sim, ref
             got = a.copy()
             sim.hostsim_special8(sel, got.ctypes.data, order)
             assert np.array_equal(expect.view(np.uint32), got.view(np.uint32)), (sel, trial, order)
+
+
+def test_lz77_distance_multiplier_of_lf_global_is_the_whole_images(sim, ref):
+    """LfGlobal's stream belongs to the frame-wide Modular image: its LZ77 special distances are scaled by the widest non-meta
+    channel of THAT image (j40.h:3840-3844), also when the section itself codes only the palette (multi-group frames). Found by
+    tools/fuzz_parity.py: a flipped bit turned a distance token of the palette's stream into a special one, and this decoder
+    (multiplier 0: no image channel in the section) read a different palette entry than the reference -- both without an error."""
+    data = bytearray(synth("modular", 645, 28, 75417, palette=3, prefix=1, lz77=1, permute=1))
+    data[1249] ^= 0x08
+    data = bytes(data)
+    rerr, expect = ref.decode(data)
+    assert rerr == ""
+    got = np.zeros((28, 645, 4), np.uint8)
+    buf = C.create_string_buffer(data, len(data))
+    assert sim.hostsim_decode(buf, len(data), got.ctypes.data, None, 0) == 0
+    assert np.array_equal(got, expect)
+    D = C.CDLL(os.path.join(ROOT, "build", "liboracle_driver.so"))
+    D.oracle_run.restype = C.c_uint32
+    D.oracle_run.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    again = np.zeros((28, 645, 4), np.uint8)
+    assert D.oracle_run(buf, len(data), again.ctypes.data, None) == 0
+    assert np.array_equal(again, expect)

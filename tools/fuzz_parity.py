@@ -59,12 +59,17 @@ def pick_vardct(r):
         o["alpha"] = 1
         if r.random() < .4: o["fullheader"] = 1; o["noxyb"] = r.choice([0, 1])
     elif r.random() < .15: o["bpp"] = r.choice([9, 10, 12, 15])
+    # an encode of a picture instead of coefficient-domain synthesis (the generator takes it with one pass, transforms up to 64x64,
+    # default chroma-from-luma)
+    if r.random() < .3 and "passes" not in o and "cfl" not in o and o.get("maxlog", 6) <= 6:
+        o["forward"] = 1
+        if r.random() < .5: o["detail"] = r.choice([0.5, 1, 3, 5]); o["beta"] = r.choice([0.1, 0.35, 0.8])
     return o
 
 
 def pick_modular(r):
     o = {}
-    if r.random() < .6: o["tree"] = r.choice([1, 2, 3])
+    if r.random() < .6: o["tree"] = r.choice([1, 2, 3, 5, 5])   # (5: 48 leaves over every property and predictor but the weighted one)
     p = r.random()
     if p < .25: o["palette"] = r.choice([1, 2, 3])
     elif p < .5: o["rct"] = r.choice([-1] + list(range(42)))
@@ -139,6 +144,7 @@ def main():
         if not ok:
             bad += 1
             print("MISMATCH", mode, w, h, seed, o, repr(e), repr(mine))
+            open("/tmp/fuzz_mismatch_%d.jxl" % bad, "wb").write(d)   # (the stream as decoded, damage included)
     print("%d cases (%d refused by the generator, %d that the reference rejects, %d that crash it), %d mismatches" % (n, skipped, errors, crashed, bad))
 
 
