@@ -35,56 +35,71 @@ J40_DEV int32_t mod_gradient(int32_t w, int32_t n, int32_t nw) { const int32_t l
 J40_DEV int32_t mod_floor_lg(uint32_t x) { return 31 - __builtin_clz(x); }
 J40_DEV int32_t mod_div24(int32_t i) { return (int32_t) (((int64_t) 1 << 24) / (i + 1)); }  // J40__24DIVP1, j40.h:3905
 
-// weighted predictor (j40.h:3997-4119); `errors` = [2 * width][5] int32 rows, zero-initialised
+// Weighted ("self-correcting") predictor, ISO 18181-1 / j40.h:3997-4119. Four sub-predictors each propose a value; how much say
+// each gets depends on how wrong it recently was around the sample (W, WW, N, NW, NE of the two most recent rows), and the blend's
+// own signed error at W / N / NW / NE corrects three of the proposals. Everything is in 1/8 sample units. The arithmetic is
+// normative (the result has to equal the reference's bit for bit); the decomposition below is this file's own.
+// `errors` = [2 rows][width] cells of five ints: |error| of the four sub-predictors, then the blend's signed error; zero-initialised.
 struct ModWP {
 	int32_t on, width;
-	int32_t p1, p2, p3[5], w[4];
+	int32_t p1, p2, p3[5], w[4];      // header parameters
 	int32_t *errors;
-	int32_t pred[5];
-	int32_t trueerrw, trueerrn, trueerrnw, trueerrne;
+	int32_t pred[5];                  // the four proposals and their blend
+	int32_t blend_err_w, blend_err_n, blend_err_nw, blend_err_ne;   // the blend's signed error at the neighbours (property 15 looks at them too)
 };
+
+struct WpCell { int32_t v[5]; };
+template <bool UNI> J40_DEV WpCell wp_cell(const int32_t *row, int32_t x, bool exists) {   // an absent neighbour counts as error-free
+	WpCell c;
+	for (int k = 0; k < 5; ++k) c.v[k] = uni<UNI>(exists ? row[x * 5 + k] : 0);
+	return c;
+}
+// the say of a sub-predictor: 4 + w * 2^24 / (recent error + 1), the division done on the error's leading bits
+J40_DEV int32_t wp_say(int32_t recent_error, int32_t w) {
+	const int32_t drop = mod_max(mod_floor_lg((uint32_t) recent_error + 1) - 5, 0);
+	return (int32_t) (4 + ((int64_t) w * mod_div24(recent_error >> drop) >> drop));
+}
 
 template <bool UNI = false>
 J40_DEV void wp_before(ModWP &s, int32_t x, int32_t y, const ModNeigh &p) {
 	if (!s.on) return;
-	const int32_t *err = s.errors + (size_t) ((y & 1) ? s.width : 0) * 5, *nerr = s.errors + (size_t) ((y & 1) ? 0 : s.width) * 5;
-	int32_t errw[5], errn[5], errnw[5], errne[5], errww[5], errw2[5];
-	for (int i = 0; i < 5; ++i) {
-		errw[i] = uni<UNI>(x > 0 ? err[(x - 1) * 5 + i] : 0);
-		errn[i] = uni<UNI>(y > 0 ? nerr[x * 5 + i] : 0);
-		errnw[i] = uni<UNI>(x > 0 && y > 0 ? nerr[(x - 1) * 5 + i] : errn[i]);
-		errne[i] = uni<UNI>(x + 1 < s.width && y > 0 ? nerr[(x + 1) * 5 + i] : errn[i]);
-		errww[i] = uni<UNI>(x > 1 ? err[(x - 2) * 5 + i] : 0);
-		errw2[i] = x + 1 < s.width ? 0 : errw[i];
-	}
-	s.trueerrw = errw[4];
-	s.trueerrn = errn[4];
-	s.trueerrnw = x > 0 && y > 0 ? errnw[4] : s.trueerrn;
-	s.trueerrne = x + 1 < s.width && y > 0 ? errne[4] : s.trueerrn;
+	const int32_t *this_row = s.errors + (size_t) ((y & 1) ? s.width : 0) * 5, *row_above = s.errors + (size_t) ((y & 1) ? 0 : s.width) * 5;
+	const bool has_left = x > 0, has_up = y > 0, has_right = x + 1 < s.width;
+	const WpCell west = wp_cell<UNI>(this_row, x - 1, has_left), west2 = wp_cell<UNI>(this_row, x - 2, x > 1);
+	const WpCell north = wp_cell<UNI>(row_above, x, has_up);
+	WpCell north_west = wp_cell<UNI>(row_above, x - 1, has_left && has_up), north_east = wp_cell<UNI>(row_above, x + 1, has_right && has_up);
+	if (!(has_left && has_up)) north_west = north;    // a missing diagonal neighbour is stood in for by the one above
+	if (!(has_right && has_up)) north_east = north;
+	s.blend_err_w = west.v[4]; s.blend_err_n = north.v[4]; s.blend_err_nw = north_west.v[4]; s.blend_err_ne = north_east.v[4];
+	// the four proposals
 	s.pred[0] = (p.w + p.ne - p.n) * 8;
-	s.pred[1] = p.n * 8 - (((s.trueerrw + s.trueerrn + s.trueerrne) * s.p1) >> 5);
-	s.pred[2] = p.w * 8 - (((s.trueerrw + s.trueerrn + s.trueerrnw) * s.p2) >> 5);
-	s.pred[3] = p.n * 8 - ((s.trueerrnw * s.p3[0] + s.trueerrn * s.p3[1] + s.trueerrne * s.p3[2] + (p.nn - p.n) * 8 * s.p3[3] + (p.nw - p.w) * 8 * s.p3[4]) >> 5);
-	int32_t wgt[4], wsum = 0, sum = 0;
-	for (int i = 0; i < 4; ++i) {
-		const int32_t errsum = errn[i] + errw[i] + errnw[i] + errww[i] + errne[i] + errw2[i];
-		const int32_t shift = mod_max(mod_floor_lg((uint32_t) errsum + 1) - 5, 0);
-		wgt[i] = (int32_t) (4 + ((int64_t) s.w[i] * mod_div24(errsum >> shift) >> shift));
+	s.pred[1] = p.n * 8 - (((s.blend_err_w + s.blend_err_n + s.blend_err_ne) * s.p1) >> 5);
+	s.pred[2] = p.w * 8 - (((s.blend_err_w + s.blend_err_n + s.blend_err_nw) * s.p2) >> 5);
+	s.pred[3] = p.n * 8 - ((s.blend_err_nw * s.p3[0] + s.blend_err_n * s.p3[1] + s.blend_err_ne * s.p3[2] + (p.nn - p.n) * 8 * s.p3[3] + (p.nw - p.w) * 8 * s.p3[4]) >> 5);
+	// their say: recent errors of the five neighbours, W once more in the last column (there is no NE to count)
+	int32_t say[4], total = 0;
+	for (int k = 0; k < 4; ++k) {
+		const int32_t recent = north.v[k] + west.v[k] + north_west.v[k] + west2.v[k] + north_east.v[k] + (has_right ? 0 : west.v[k]);
+		say[k] = wp_say(recent, s.w[k]);
+		total += say[k];
 	}
-	const int32_t logw = mod_floor_lg((uint32_t) (wgt[0] + wgt[1] + wgt[2] + wgt[3])) - 4;
-	for (int i = 0; i < 4; ++i) { wgt[i] >>= logw; wsum += wgt[i]; sum += s.pred[i] * wgt[i]; }
-	s.pred[4] = (int32_t) (((int64_t) sum + (wsum >> 1) - 1) * mod_div24(wsum - 1) >> 24);
-	if (((s.trueerrn ^ s.trueerrw) | (s.trueerrn ^ s.trueerrnw)) <= 0) {
+	const int32_t scale = mod_floor_lg((uint32_t) total) - 4;   // keeps the says within a few bits
+	int32_t votes = 0, tally = 0;
+	for (int k = 0; k < 4; ++k) { say[k] >>= scale; votes += say[k]; tally += s.pred[k] * say[k]; }
+	s.pred[4] = (int32_t) (((int64_t) tally + (votes >> 1) - 1) * mod_div24(votes - 1) >> 24);
+	// where the blend's errors at W, N and NW do not all point the same way, the blend stays within what W, N and NE span
+	if (((s.blend_err_n ^ s.blend_err_w) | (s.blend_err_n ^ s.blend_err_nw)) <= 0) {
 		const int32_t lo = mod_min(p.w, mod_min(p.n, p.ne)) * 8, hi = mod_max(p.w, mod_max(p.n, p.ne)) * 8;
 		s.pred[4] = mod_min(mod_max(lo, s.pred[4]), hi);
 	}
 }
 
+// the decoded sample is known: note how far off every proposal and the blend were
 J40_DEV void wp_after(ModWP &s, int32_t x, int32_t y, int32_t val) {
 	if (!s.on) return;
-	int32_t *e = s.errors + ((size_t) ((y & 1) ? s.width : 0) + (size_t) x) * 5;
-	for (int i = 0; i < 4; ++i) e[i] = (mod_abs(s.pred[i] - val * 8) + 3) >> 3;
-	e[4] = s.pred[4] - val * 8;
+	int32_t *cell = s.errors + ((size_t) ((y & 1) ? s.width : 0) + (size_t) x) * 5;
+	for (int k = 0; k < 4; ++k) cell[k] = (mod_abs(s.pred[k] - val * 8) + 3) >> 3;
+	cell[4] = s.pred[4] - val * 8;
 }
 
 J40_DEV int32_t mod_predict(int32_t predictor, const ModWP &wp, const ModNeigh &p, uint32_t *err) {  // j40.h:4080
@@ -177,7 +192,7 @@ J40_DEV uint32_t decode_modular_section(const DevModPlan &plan, const ModTables 
 	for (int i = 0; i < 4; ++i) wp.w[i] = sec.wp[7 + i];
 	wp.errors = nullptr;
 	for (int i = 0; i < 5; ++i) wp.pred[i] = 0;
-	wp.trueerrw = wp.trueerrn = wp.trueerrnw = wp.trueerrne = 0;
+	wp.blend_err_w = wp.blend_err_n = wp.blend_err_nw = wp.blend_err_ne = 0;
 	uint32_t err = 0;
 	for (int32_t cidx = 0; cidx < sec.num_channels && !b.err && !err; ++cidx) {
 		const ModChan chan = mod_channel(plan, sec, cidx);
@@ -190,7 +205,7 @@ J40_DEV uint32_t decode_modular_section(const DevModPlan &plan, const ModTables 
 			if (RING) wp.errors = t.wp_errors; else wp.errors = plan.wp_scratch + (size_t) g * (size_t) (2 * f.max_width * 5);
 			for (int32_t i = 0; i < 2 * gw * 5; ++i) wp.errors[i] = 0;
 			for (int i = 0; i < 5; ++i) wp.pred[i] = 0;
-			wp.trueerrw = wp.trueerrn = wp.trueerrnw = wp.trueerrne = 0;
+			wp.blend_err_w = wp.blend_err_n = wp.blend_err_nw = wp.blend_err_ne = 0;
 		}
 		for (int32_t y = 0; y < gh && !b.err && !err; ++y) {
 			int16_t *row = base + (size_t) y * (size_t) stride;
@@ -239,10 +254,10 @@ J40_DEV uint32_t decode_modular_section(const DevModPlan &plan, const ModTables 
 					case 13: val = p.n - p.nn; break;
 					case 14: val = p.w - p.ww; break;
 					case 15:
-						val = wp.trueerrw;
-						if (mod_abs(val) < mod_abs(wp.trueerrn)) val = wp.trueerrn;
-						if (mod_abs(val) < mod_abs(wp.trueerrnw)) val = wp.trueerrnw;
-						if (mod_abs(val) < mod_abs(wp.trueerrne)) val = wp.trueerrne;
+						val = wp.blend_err_w;   // the largest of the blend's errors at W, N, NW, NE (first wins a tie)
+						if (mod_abs(val) < mod_abs(wp.blend_err_n)) val = wp.blend_err_n;
+						if (mod_abs(val) < mod_abs(wp.blend_err_nw)) val = wp.blend_err_nw;
+						if (mod_abs(val) < mod_abs(wp.blend_err_ne)) val = wp.blend_err_ne;
 						break;
 					default: {
 						// "previous channel" properties: the r-th earlier channel of this sub-image with the same

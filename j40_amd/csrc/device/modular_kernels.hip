@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(64) k_inverse_palette_predicted(const int16_t 
 		int16_t *out = dst[i];
 		if (wp.on) for (int32_t k = 0; k < 2 * width * 5; ++k) wp.errors[k] = 0;
 		for (int k = 0; k < 5; ++k) wp.pred[k] = 0;
-		wp.trueerrw = wp.trueerrn = wp.trueerrnw = wp.trueerrne = 0;
+		wp.blend_err_w = wp.blend_err_n = wp.blend_err_nw = wp.blend_err_ne = 0;
 		for (int32_t y = 0; y < height; ++y) {
 			const int16_t *idxline = idx + (size_t) y * (size_t) width;
 			int16_t *line = out + (size_t) y * (size_t) width;

@@ -154,7 +154,7 @@ static uint32_t hostsim_decode_modular(const Frame &fr, const uint8_t *cs, size_
 				const int16_t *palrow = t.nb_colours > 0 ? pal.p + (size_t) i * (size_t) pal.w : nullptr;
 				std::fill(errs.begin(), errs.end(), 0);
 				for (int k = 0; k < 5; ++k) wp.pred[k] = 0;
-				wp.trueerrw = wp.trueerrn = wp.trueerrnw = wp.trueerrne = 0;
+				wp.blend_err_w = wp.blend_err_n = wp.blend_err_nw = wp.blend_err_ne = 0;
 				for (int32_t y = 0; y < idx.h; ++y) for (int32_t x = 0; x < idx.w; ++x) {
 					const int16_t index = idx.p[(size_t) y * (size_t) idx.w + (size_t) x];
 					int16_t val = palette_value(index, i, palrow, t.nb_colours, fr.im.bpp);
