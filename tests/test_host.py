@@ -79,6 +79,10 @@ def test_golden_fixtures_pin_the_oracle(ref):
         data = open(os.path.join(GOLDEN, name + ".jxl"), "rb").read()
         assert hashlib.sha256(data).hexdigest() == e["stream_sha256"]
         err, rgba = ref.decode(data)
+        if "pinned_by" in e:   # Squeeze: the reference stops with TODO; the fixture holds its decode of the same picture coded without it
+            from streams import synth
+            assert err == "TODO", name
+            err, rgba = ref.decode(synth(e["mode"], e["width"], e["height"], e["seed"], **{k: v for k, v in e["opts"].items() if k != "squeeze"}))
         assert err == "" and sha(rgba) == e["rgba_sha256"], name
 
 
