@@ -169,9 +169,15 @@ def main():
     quota = cpu_quota()
     threads = args.host_threads or max(2, quota // world) * (8 if args.lf_device else 1)
     D = max(1, min(args.distinct, B))
-    # every rank decodes its own frames (distinct seeds)
+    # every rank decodes its own batch of the same D streams: rank 0 generates them with all the CPUs the container has (an 8K
+    # encode takes ~10 s of one core), the other ranks wait and read them from build/streams
     stream_opts = {"forward": 1} if args.stream == "forward" else {}
-    datas = synth_many([("vardct", W, H, args.seed + 1000 * i + 7 * rank, stream_opts) for i in range(D)], max(1, quota // world))
+    specs = [("vardct", W, H, args.seed + 1000 * i, stream_opts) for i in range(D)]
+    if rank == 0:
+        synth_many(specs, max(1, quota))
+    if dist is not None:
+        dist.barrier()
+    datas = synth_many(specs, max(1, quota // world))
     bufs = [C.create_string_buffer(d, len(d)) for d in datas]
     step_bufs = [bufs[i % D] for i in range(B)]
     step_sizes = [len(datas[i % D]) for i in range(B)]
