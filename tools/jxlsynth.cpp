@@ -925,6 +925,7 @@ int run_modular(int W, int H, uint64_t seed, const char *out, const Options &opt
 	const int gcols = (W + gdim - 1) / gdim, grows = (H + gdim - 1) / gdim, num_groups = gcols * grows;
 	const int num_lf_groups = ((W + 8 * gdim - 1) / (8 * gdim)) * ((H + 8 * gdim - 1) / (8 * gdim));
 	const bool single = num_groups == 1;
+	if (single && opt.geti("passes", 1) > 1) die("modular: one group with several passes is not generated (the frame would not be a single section)");
 	// extra=K: K more extra channels (type depth, same bit depth) ahead of the alpha channel, so that alpha is not the first one
 	const int extra = opt.geti("extra", 0);
 	if (extra < 0 || extra + (alpha ? 1 : 0) > 4) die("modular: at most four extra channels (j40.h:3247)");
