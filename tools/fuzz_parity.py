@@ -106,7 +106,7 @@ def main():
     bad = skipped = errors = crashed = 0
     for i in range(n):
         mode = r.choice(["vardct", "modular"])
-        w, h = r.randrange(260 if mode == "vardct" else 9, 900), r.randrange(8, 700)
+        w, h = r.randrange(260 if mode == "vardct" else 9, int(os.environ.get("FUZZ_MAXW", "900"))), r.randrange(8, int(os.environ.get("FUZZ_MAXH", "700")))   # (FUZZ_MAXW > 2048: several LF groups)
         if mode == "vardct" and w * h < 257 * 8 * 2: h = 264
         o = pick_vardct(r) if mode == "vardct" else pick_modular(r)
         seed = r.randrange(1 << 20)
