@@ -7,7 +7,7 @@ ARCH ?= gfx950
 CXXFLAGS = -std=c++17 -O2 -fPIC -Wall -Wextra -ffp-contract=off -fvisibility=hidden
 HIPFLAGS = --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -Wall $(EXTRA_HIPFLAGS)
 SRC = j40_amd/csrc
-HOST_OBJS = build/obj/plan_build.o build/obj/entropy.o build/obj/modular.o build/obj/tables.o build/obj/frame.o build/obj/capi_host.o build/obj/api.o
+HOST_OBJS = build/obj/plan_build.o build/obj/plan_front.o build/obj/entropy.o build/obj/modular.o build/obj/tables.o build/obj/frame.o build/obj/capi_host.o build/obj/api.o
 DEV_OBJS = build/obj/kernels.o build/obj/modular_kernels.o build/obj/runtime.o build/obj/pipeline.o build/obj/lf_tail_kernels.o build/obj/modular_coop.o build/obj/modular_quad.o build/obj/lf_decode.o
 
 .PHONY: all lib tools oracle hostsim clean
@@ -36,9 +36,9 @@ build/liboracle_driver.so: tests/oracle_driver.c build/libj40hip.so oracle/hotpa
 	gcc -O2 -fPIC -shared -Wall -o $@ tests/oracle_driver.c -Lbuild -Loracle -lj40hip -lj40oracle -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../oracle'
 
 # device functions compiled for the CPU, test infrastructure only (tests/hostsim)
-build/libhostsim.so: tests/hostsim/hostsim.cpp $(SRC)/plan_build.cpp $(SRC)/entropy.cpp $(SRC)/modular.cpp $(SRC)/tables.cpp $(SRC)/frame.cpp $(wildcard $(SRC)/device/*.h) $(wildcard $(SRC)/*.hpp)
+build/libhostsim.so: tests/hostsim/hostsim.cpp $(SRC)/plan_build.cpp $(SRC)/plan_front.cpp $(SRC)/entropy.cpp $(SRC)/modular.cpp $(SRC)/tables.cpp $(SRC)/frame.cpp $(wildcard $(SRC)/device/*.h) $(wildcard $(SRC)/*.hpp)
 	@mkdir -p build
-	$(CXX) -std=c++17 -O2 -fPIC -shared -ffp-contract=off -Wall -Wextra -Wno-unused-function -Wno-unknown-pragmas -o $@ tests/hostsim/hostsim.cpp $(SRC)/plan_build.cpp $(SRC)/entropy.cpp $(SRC)/modular.cpp $(SRC)/tables.cpp $(SRC)/frame.cpp -lpthread
+	$(CXX) -std=c++17 -O2 -fPIC -shared -ffp-contract=off -Wall -Wextra -Wno-unused-function -Wno-unknown-pragmas -o $@ tests/hostsim/hostsim.cpp $(SRC)/plan_build.cpp $(SRC)/plan_front.cpp $(SRC)/entropy.cpp $(SRC)/modular.cpp $(SRC)/tables.cpp $(SRC)/frame.cpp -lpthread
 
 build/jxlsynth: tools/jxlsynth.cpp $(wildcard tools/*.hpp) $(SRC)/tables.cpp $(SRC)/device/special8_dev.h $(SRC)/device/idct_dev.h
 	@mkdir -p build

@@ -307,6 +307,59 @@ struct DevLfTask {
 };
 enum { ERR_LFFB = ('l' << 24) | ('f' << 16) | ('f' << 8) | 'b' };   // not an error of the stream: the second Modular header is not the plain one the device handles; the host decodes this section
 
+// ---- the LF-dependent half of a VarDCT frame's plan, built on the device (plan_dev.h, plan_kernels.hip) ----
+// In the pipeline the host parses what precedes the LfGroup sections (headers, TOC, LfGlobal, HfGlobal) and the first bits of
+// every LfGroup section; the sections' streams are decoded by k_lf_groups (or by a host thread, which then uploads the same raw
+// planes), and everything the reference derives from them in j40__lf_group / j40__hf_metadata (j40.h:6722-6790, 6585-6720: LF
+// index, varblock placement, quantisation-field index, coefficient offsets) plus the work lists of K1 / K2 (plan_build.cpp on
+// the host path) is computed by three kernels: place (serial per LfGroup), scan (per frame), emit (per varblock).
+
+// one LfGroup section of a frame: status of its streams and of the placement
+struct DevLfSlot {
+	uint32_t status;        // 0, the 4-char code of the section's streams (k_lf_groups / the host decoder), ERR_LFFB, or a placement error (vblk, dct?)
+	int32_t nb_varblocks;   // as coded in the section (j40.h:6748)
+	uint32_t dct_used;      // bit d: a varblock with DctSelect d was placed (j40.h:6640: which dequantisation matrices / orders the frame needs)
+	int32_t placed;         // varblocks placed; == nb_varblocks when status == 0
+};
+
+// a placed varblock, in placement order (= the reference's varblock index); 16 bytes
+struct DevVbRec {
+	uint32_t coeffoff_qfidx;     // j40__varblock (j40.h:6352)
+	int16_t hfmul_m1;
+	uint8_t x8, y8;              // top-left cell inside the LfGroup (an LfGroup is at most 256 x 256 cells)
+	uint8_t dctsel, grp;         // grp: (y8 >> 5) * 8 + (x8 >> 5), the group inside the LfGroup
+	uint16_t rank_in_group;      // among the group's varblocks in raster order of their top-left cells: the visiting order of j40__hf_coeffs
+	uint32_t rank_in_class;      // among the LfGroup's varblocks with the same DctSelect, in placement order
+};
+
+struct DevPlanBuild {
+	// LfGlobal constants (frame.hpp: Frame)
+	int32_t lf_thr[3][15], qf_thr[15], nb_lf_thr[3], nb_qf_thr;   // thresholds on the raw LF integers, channels X, Y, B (j40.h:6276-6290)
+	int32_t num_lf_groups, num_groups, gcolumns, ggcolumns;
+	int32_t lfidx_size;
+	float mult_base, base_corr_x, base_corr_b, inv_colour_factor;
+	uint32_t block_ctx_map_off;   // into pool_u8
+	const uint8_t *pool_u8;
+	DevLfGroup *lf_groups;        // the plan's array: nb_varblocks is filled in by the placement
+	DevLfSlot *lf_slots;          // [num_lf_groups]
+	const int16_t *lfraw[3];      // decoded LF integers per cell, channels X, Y, B (DevPlan::lfraw)
+	const int16_t *xfromy, *bfromy;   // per 64x64 cell, at DevLfGroup::c64_base
+	// the varblock-info channel of every LfGroup: two rows of nb_varblocks samples (DctSelect; HfMul - 1) at 2 * cell_base, the
+	// second row nb_varblocks after the first (the channel's own pitch)
+	const int16_t *vbinfo;
+	DevVbRec *vb_recs;            // at DevLfGroup::vb_base
+	uint32_t *group_count;        // [num_groups] varblocks per group
+	uint32_t *group_block_start;  // [num_groups + 1] (the plan's array)
+	uint32_t *class_count;        // [num_lf_groups][28] varblocks per DctSelect value; the scan turns it into each (LfGroup, class)'s first index in vb_sorted
+	int32_t *class_start;         // [28] (27 = the number of varblocks)
+	DevGroupBlock *group_blocks;  // the plan's arrays
+	DevVarblock *vb_sorted;
+	// [0] the frame's verdict over LfGroup and pass-group sections (first failing section in file order), [1] flags (bit 0: some
+	// LfGroup reported ERR_LFFB, bit 1: some section ERR_EVOF), [2] union of DevLfSlot::dct_used, [3] varblocks
+	uint32_t *verdict;
+	const uint32_t *lf_section_off;   // [num_lf_groups] byte offset of every LfGroup section (the order the reference reads them in)
+};
+
 // sizes the host knows about a Modular frame's tree and code tables, to lay out k_modular_sections' LDS
 struct ModLaunchInfo {
 	int32_t num_tree_nodes, num_dist, num_clusters; uint32_t table_bytes; int32_t max_width, uses_wp;

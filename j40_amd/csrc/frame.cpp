@@ -456,7 +456,15 @@ static void read_lf_global(BitReader &br, Frame *f) {
 			while (n < nch && f->gmodular.channel[(size_t) n].width <= gdim && f->gmodular.channel[(size_t) n].height <= gdim) ++n;
 			f->num_gm_channels = n;
 		}
-		if (!fh.is_modular) allocate_modular(&f->gmodular);   // (Modular frames are decoded on the device: no host planes)
+		if (!fh.is_modular) {
+			// A squeezed extra-channel image of a VarDCT frame that is not finished inside LfGlobal would need the ModularLfGroup data
+			// between the LF coefficients and the HF metadata of every LfGroup section and shift-aware sub-images behind the
+			// coefficients of every pass group; neither exists here, and the reference stops at the Squeeze parameters (j40.h:3812)
+			bool squeezed = false;
+			for (const Transform &t : f->gmodular.transforms) squeezed = squeezed || t.kind == Transform::SQUEEZE;
+			J40HIP_SHOULD(!squeezed || f->num_gm_channels == (int32_t) f->gmodular.channel.size(), "TODO");
+			allocate_modular(&f->gmodular);   // (Modular frames are decoded on the device: no host planes)
+		}
 		if (fh.is_modular) {
 			// the channel data that follows (j40.h:6334-6337) is decoded by the HIP Modular kernel, which
 			// continues from this bit position inside the section
@@ -634,6 +642,9 @@ static void lf_group_finish(Frame *f, LfGroup *gg, int32_t extra_prec, const int
 		const int32_t x1 = x0 + vw8 - 1, y1 = y0 + vh8 - 1;
 		J40HIP_SHOULD(x1 < w8 && (x0 >> log_gsize8) == (x1 >> log_gsize8), "vblk");
 		J40HIP_SHOULD(y1 < h8 && (y0 >> log_gsize8) == (y1 >> log_gsize8), "vblk");
+		// (the reference does not check this, see its note at j40.h:6691: blocks overlapping earlier ones can add up to more cells
+		// than the LfGroup has, and it then writes past its coefficient arrays; same check as device/plan_dev.h)
+		J40HIP_SHOULD((size_t) coeffoff + ((size_t) 1 << (dct.log_columns + dct.log_rows)) <= cells * 64, "vblk");
 		for (int32_t i = 0; i < vh8; ++i) for (int32_t j = 0; j < vw8; ++j) gg->blocks[(size_t) (y0 + i) * (size_t) w8 + (size_t) (x0 + j)] = 1 << 20 | voff;
 		gg->blocks[(size_t) y0 * (size_t) w8 + (size_t) x0] = (dctsel + 2) << 20 | voff;
 		gg->varblocks.push_back(VarblockInfo());
@@ -653,35 +664,44 @@ static void lf_group_finish(Frame *f, LfGroup *gg, int32_t extra_prec, const int
 	f->dct_select_used |= dct_used; f->order_used |= order_used;
 }
 
-static void read_lf_group(BitReader &br, Frame *f, LfGroup *gg) {  // j40.h:6722
-	const FrameHeader &fh = f->fh;
-	const int64_t sidx0 = 1 + gg->idx, sidx2 = 1 + 2 * fh.num_lf_groups + gg->idx;
-	if (fh.is_modular) { gg->loaded = true; return; }  // nothing is read: no channel has shift >= 3 (j40.h:6731)
-	const int32_t w8 = gg->width8, h8 = gg->height8, w64 = gg->width64, h64 = gg->height64;
+// the streams of an LfGroup section (j40.h:6722-6790) as decoded, nothing derived yet
+void read_lf_group_raw(BitReader &br, const Frame &f, const LfGroup &gg, LfRaw *out) {
+	const FrameHeader &fh = f.fh;
+	const int64_t sidx0 = 1 + gg.idx, sidx2 = 1 + 2 * fh.num_lf_groups + gg.idx;
+	const int32_t w8 = gg.width8, h8 = gg.height8, w64 = gg.width64, h64 = gg.height64;
 	J40HIP_SHOULD(!fh.use_lf_frame, "TODO");
 	J40HIP_SHOULD(fh.jpeg_upsampling == 0, "TODO");
 
 	// LF image: three channels in Y, X, B order
-	const int32_t extra_prec = (int32_t) br.u(2);
-	Modular lfm; lfm.bpp = f->im.bpp;
+	out->extra_prec = (int32_t) br.u(2);
+	Modular lfm; lfm.bpp = f.im.bpp;
 	lfm.channel.assign(3, Plane());
 	for (Plane &p : lfm.channel) { p.width = w8; p.height = h8; }
-	decode_modular_image(br, &f->global_tree, &f->global_codespec, sidx0, &lfm);
+	decode_modular_image(br, &f.global_tree, &f.global_codespec, sidx0, &lfm);
 	for (int c = 0; c < 3; ++c) J40HIP_SHOULD(lfm.channel[(size_t) c].width == w8 && lfm.channel[(size_t) c].height == h8, "TODO");
 
 	// HF metadata
 	const int32_t nb_varblocks = (int32_t) br.u(ceil_lg32((uint32_t) (w8 * h8))) + 1;
-	Modular m; m.bpp = f->im.bpp;
+	Modular m; m.bpp = f.im.bpp;
 	m.channel.assign(4, Plane());
 	m.channel[0].width = m.channel[1].width = w64; m.channel[0].height = m.channel[1].height = h64;
 	m.channel[2].width = nb_varblocks; m.channel[2].height = 2;
 	m.channel[3].width = w8; m.channel[3].height = h8;
-	decode_modular_image(br, &f->global_tree, &f->global_codespec, sidx2, &m);
+	decode_modular_image(br, &f.global_tree, &f.global_codespec, sidx2, &m);
 	J40HIP_SHOULD(m.channel.size() == 4 && m.channel[2].width == nb_varblocks && m.channel[2].height == 2, "TODO");
 	J40HIP_SHOULD((int32_t) m.channel[0].px.size() == w64 * h64 && (int32_t) m.channel[1].px.size() == w64 * h64, "TODO");
-	const int16_t *lf[3] = {lfm.channel[0].px.data(), lfm.channel[1].px.data(), lfm.channel[2].px.data()};
-	std::vector<int16_t> *take[3] = {&lfm.channel[0].px, &lfm.channel[1].px, &lfm.channel[2].px};
-	lf_group_finish(f, gg, extra_prec, lf, take, m.channel[0].px.data(), m.channel[1].px.data(), m.channel[2].row(0), m.channel[2].row(1), nb_varblocks);
+	out->nb_varblocks = nb_varblocks;
+	for (int c = 0; c < 3; ++c) out->lf[c].swap(lfm.channel[(size_t) c].px);
+	out->xfromy.swap(m.channel[0].px); out->bfromy.swap(m.channel[1].px); out->info.swap(m.channel[2].px);
+}
+
+static void read_lf_group(BitReader &br, Frame *f, LfGroup *gg) {  // j40.h:6722
+	if (f->fh.is_modular) { gg->loaded = true; return; }  // nothing is read: no channel has shift >= 3 (j40.h:6731)
+	LfRaw raw;
+	read_lf_group_raw(br, *f, *gg, &raw);
+	const int16_t *lf[3] = {raw.lf[0].data(), raw.lf[1].data(), raw.lf[2].data()};
+	std::vector<int16_t> *take[3] = {&raw.lf[0], &raw.lf[1], &raw.lf[2]};
+	lf_group_finish(f, gg, raw.extra_prec, lf, take, raw.xfromy.data(), raw.bfromy.data(), raw.info.data(), raw.info.data() + raw.nb_varblocks, raw.nb_varblocks);
 }
 
 static void allocate_lf_groups(Frame *f) {  // j40.h:7659
@@ -749,7 +769,8 @@ static void skip_icc(BitReader &br) {
 	finish_code(br, code);
 }
 
-void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
+// signature, image and frame headers, TOC (sections clipped to the bytes that exist), the LfGroups' geometry
+static void parse_headers(const uint8_t *cs, size_t cs_size, Frame *f) {
 	memset(f->order_has_lehmer, 0, sizeof f->order_has_lehmer);
 	BitReader br(cs, cs_size);
 	J40HIP_SHOULD(br.u(16) == 0x0aff, "!jxl");
@@ -771,6 +792,59 @@ void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
 		for (Section &s : f->toc.pass_groups) clip(s);
 	}
 	allocate_lf_groups(f);
+}
+
+// LfGlobal and HfGlobal of a frame with several sections
+static void parse_globals(const uint8_t *cs, Frame *f) {
+	{
+		BitReader sr(cs + f->toc.lf_global.offset, f->toc.lf_global.size);
+		read_lf_global(sr, f);
+		// (no check that the section ends here, in none of the sections of a frame that has several: the reference's
+		// j40__finish_section_state runs j40__no_more_bytes on the section's own state and returns the parent's, j40.h:7778-7795)
+	}
+	if (f->fh.is_modular) {
+		J40HIP_SHOULD(f->toc.hf_global.size == 0, "excs");
+	} else {
+		BitReader sr(cs + f->toc.hf_global.offset, f->toc.hf_global.size);
+		read_hf_global(sr, f);
+	}
+}
+
+// What the pipeline's host stage reads of a VarDCT frame with several sections (device/async.hip): everything in front of the
+// LfGroup sections, and of each of those what precedes its first stream. Returns false -- nothing is lost, parse_frame does it
+// all again -- for frames that are not of that kind. `tasks` (one per LfGroup section): where the streams start; `plain`: whether
+// every section's first Modular header is the plain one k_lf_groups handles (global tree, no transforms).
+bool parse_frame_front(const uint8_t *cs, size_t cs_size, Frame *f, std::vector<LfDeviceTask> *tasks, std::vector<int32_t> *extra_prec, bool *plain) {
+	parse_headers(cs, cs_size, f);
+	if (f->toc.single || f->fh.is_modular) return false;
+	parse_globals(cs, f);
+	if (f->fh.use_lf_frame || f->fh.jpeg_upsampling != 0) return false;
+	const int64_t n = f->fh.num_lf_groups;
+	tasks->assign((size_t) n, LfDeviceTask()); extra_prec->assign((size_t) n, 0);
+	*plain = true;
+	for (int64_t i = 0; i < n; ++i) {
+		const LfGroup &gg = f->lf_groups[(size_t) i];
+		LfDeviceTask &t = (*tasks)[(size_t) i];
+		t.byte_off = f->toc.lf_groups[(size_t) i].offset; t.size = f->toc.lf_groups[(size_t) i].size; t.bit_off = 0;
+		t.w8 = gg.width8; t.h8 = gg.height8; t.w64 = gg.width64; t.h64 = gg.height64;
+		t.sidx0 = (int32_t) (1 + gg.idx); t.sidx2 = (int32_t) (1 + 2 * f->fh.num_lf_groups + gg.idx);
+		t.nbvb_bits = ceil_lg32((uint32_t) (gg.width8 * gg.height8));
+		try {
+			BitReader sr(cs + t.byte_off, t.size);
+			(*extra_prec)[(size_t) i] = (int32_t) sr.u(2);
+			Modular m; m.bpp = f->im.bpp;
+			m.channel.assign(3, Plane());
+			for (Plane &p : m.channel) { p.width = gg.width8; p.height = gg.height8; }
+			read_modular_header(sr, &f->global_tree, &f->global_codespec, &m);
+			if (!(m.use_global_tree && m.transforms.empty() && m.channel.size() == 3)) *plain = false;
+			t.bit_off = (uint32_t) sr.bit_position();
+		} catch (const DecodeError &) { *plain = false; }   // (the section's own decode reports it in its place)
+	}
+	return true;
+}
+
+void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
+	parse_headers(cs, cs_size, f);
 
 	if (f->toc.single) {
 		// one section holds LfGlobal, HfGlobal, LfGroup and PassGroup back to back, read in the order
@@ -798,18 +872,7 @@ void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
 		return;
 	}
 
-	{
-		BitReader sr(cs + f->toc.lf_global.offset, f->toc.lf_global.size);
-		read_lf_global(sr, f);
-		// (no check that the section ends here, in none of the sections of a frame that has several: the reference's
-		// j40__finish_section_state runs j40__no_more_bytes on the section's own state and returns the parent's, j40.h:7778-7795)
-	}
-	if (f->fh.is_modular) {
-		J40HIP_SHOULD(f->toc.hf_global.size == 0, "excs");
-	} else {
-		BitReader sr(cs + f->toc.hf_global.offset, f->toc.hf_global.size);
-		read_hf_global(sr, f);
-	}
+	parse_globals(cs, f);
 	// LfGroup sections are independent of each other
 	const int64_t n = f->fh.num_lf_groups;
 	std::atomic<int64_t> next(0);

@@ -91,6 +91,12 @@ struct LfDeviceTask {
 	const int16_t *lf[3] = {nullptr, nullptr, nullptr};   // streamed order Y, X, B
 	const int16_t *xfromy = nullptr, *bfromy = nullptr, *info0 = nullptr, *info1 = nullptr;
 };
+// the streams of one LfGroup section as decoded (read_lf_group_raw): LF integers in streamed order Y, X, B; chroma-from-luma
+// maps; the varblock-info channel (two rows of nb_varblocks: DctSelect, HfMul - 1). The sharpness map is decoded and dropped.
+struct LfRaw {
+	int32_t extra_prec = 0, nb_varblocks = 0;
+	std::vector<int16_t> lf[3], xfromy, bfromy, info;
+};
 struct Frame;
 // returns false when it cannot take the frame (tree / code spec outside what the kernel handles, no device): host path
 typedef bool (*LfDeviceDecoder)(void *ctx, const Frame &f, const uint8_t *cs, size_t cs_size, std::vector<LfDeviceTask> &tasks);
@@ -145,6 +151,9 @@ void extract_codestream(const uint8_t *data, size_t size, const uint8_t **cs, si
 // parses headers, TOC, LfGlobal, HfGlobal and every LfGroup section. `threads` > 1 decodes LfGroup
 // sections concurrently (they are independent given LfGlobal)
 void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads);
+// the pipeline's host stage (see frame.cpp)
+bool parse_frame_front(const uint8_t *cs, size_t cs_size, Frame *f, std::vector<LfDeviceTask> *tasks, std::vector<int32_t> *extra_prec, bool *plain);
+void read_lf_group_raw(BitReader &br, const Frame &f, const LfGroup &gg, LfRaw *out);
 // the LfGroup tail on the host for the groups that still have it pending (dequantise, smooth, LLF): what the device does at upload
 void finish_lf_tail(Frame *f);
 

@@ -123,6 +123,12 @@ void read_modular_header(BitReader &br, const std::vector<TreeNode> *global_tree
 				J40HIP_SHOULD(st.num_c >= 1 && end_c <= nc, "sqzc");
 				if (st.begin_c < nb_meta) J40HIP_SHOULD(st.in_place && end_c <= nb_meta, "sqzc");   // meta channels: in place, not across the border
 				J40HIP_SHOULD(nc + st.num_c <= 256, "xlim");
+				// (libjxl's MetaSqueeze checks: nothing is squeezed past a shift of 30 or down from an empty channel -- the int8 shifts
+				// would wrap into "meta channel" and the section layout shifts by them)
+				for (int32_t c = st.begin_c; c < end_c; ++c) {
+					const Plane &ch = channel[(size_t) c];
+					J40HIP_SHOULD(ch.hshift <= 30 && ch.vshift <= 30 && ch.width > 0 && ch.height > 0, "sqzc");
+				}
 				apply_squeeze_meta(st, &channel, &nb_meta);
 				m->transforms.push_back(st);
 			}
@@ -634,7 +640,8 @@ static void inverse_squeeze(Modular &m, const Transform &tr) {
 		Plane &avg = m.channel[(size_t) c]; const Plane &res = m.channel[(size_t) (offset + c - tr.begin_c)];
 		Plane out;
 		out.width = tr.horizontal ? avg.width + res.width : avg.width; out.height = tr.horizontal ? avg.height : avg.height + res.height;
-		out.hshift = (int8_t) (avg.hshift - (tr.horizontal ? 1 : 0)); out.vshift = (int8_t) (avg.vshift - (tr.horizontal ? 0 : 1));
+		// (mirrors apply_squeeze_meta: only shifts that the forward step raised -- those of non-meta channels -- come down again)
+		out.hshift = (int8_t) (avg.hshift - (tr.horizontal && avg.hshift > 0 ? 1 : 0)); out.vshift = (int8_t) (avg.vshift - (!tr.horizontal && avg.vshift > 0 ? 1 : 0));
 		const bool allocated = avg.px.size() == (size_t) std::max(avg.width, 0) * (size_t) std::max(avg.height, 0) && res.px.size() == (size_t) std::max(res.width, 0) * (size_t) std::max(res.height, 0);
 		if (allocated) {
 			out.allocate();

@@ -36,15 +36,71 @@ void flatten_code_spec(const CodeSpec &spec, std::vector<uint8_t> &u8, std::vect
 	}
 }
 
-uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostPlan *hp) {
-	if (cs_size + 16 >= ((size_t) 1 << 29)) return ERR_TODO;   // the kernels address the codestream with 32-bit BIT positions
-	if (fr.fh.is_modular) return ERR_TODO;
-	// same limits as j40.h:7867, 7917-7921. (A VarDCT frame of an image without xyb_encoded passes them: the reference
-	// runs the XYB inverse with the default opsin matrix on it all the same, j40.h:7206-7233, and so does K2.)
-	if (fr.im.grey || fr.fh.do_ycbcr) return ERR_TODO;
-	if (fr.im.bpp < 8 || fr.im.exp_bits) return ERR_TODO;
+// one DevSection per (pass, group) TOC section, pass-major
+void fill_sections(const Frame &fr, std::vector<DevSection> *sections) {
+	const int32_t num_groups = (int32_t) fr.fh.num_groups;
+	sections->assign((size_t) fr.fh.num_passes * (size_t) num_groups, DevSection());
+	for (int32_t p = 0; p < fr.fh.num_passes; ++p) for (int32_t g = 0; g < num_groups; ++g) {
+		DevSection &d = (*sections)[(size_t) p * (size_t) num_groups + (size_t) g];
+		const GroupInfo gi = group_info(fr.fh, g);
+		if (fr.toc.single) {
+			d.byte_off = (uint32_t) fr.toc.single_section.offset; d.size = (uint32_t) fr.toc.single_section.size; d.bit_off = (uint32_t) fr.single_pass_group_bitpos;
+		} else {
+			const Section &s0 = fr.toc.pass_groups[(size_t) p * (size_t) num_groups + (size_t) g];
+			d.byte_off = (uint32_t) s0.offset; d.size = (uint32_t) s0.size; d.bit_off = 0;
+		}
+		d.ggidx = gi.ggidx; d.gx8 = gi.gx_in_gg / 8; d.gy8 = gi.gy_in_gg / 8;
+		d.gw8 = ceil_div(gi.gw, 8); d.gh8 = ceil_div(gi.gh, 8);
+		d.gx = fr.lf_groups[(size_t) gi.ggidx].left + gi.gx_in_gg; d.gy = fr.lf_groups[(size_t) gi.ggidx].top + gi.gy_in_gg; d.gw = gi.gw; d.gh = gi.gh;
+	}
+}
 
-	DevFrame &df = hp->frame;
+// sparse coefficients: every group's region of DevPlan::events, sized from its section (see build_vardct_plan). false: the frame
+// needs more events than 32-bit indices reach (then dense planes)
+bool fill_event_ranges(const std::vector<DevSection> &sections, int32_t num_groups, bool sparse, std::vector<uint32_t> *ev_range, size_t *ev_capacity) {
+	ev_range->clear(); *ev_capacity = 0;
+	if (!sparse) return true;
+	for (int32_t g = 0; g < num_groups; ++g) {
+		const DevSection &d = sections[(size_t) g];
+		static const size_t per_byte = getenv("J40HIP_EVENTS_PER_BYTE") ? (size_t) atoi(getenv("J40HIP_EVENTS_PER_BYTE")) : 4;   // tests shrink it to reach the fallback
+		const size_t worst = (size_t) d.gw8 * (size_t) d.gh8 * 64 * 3, cap = std::min(worst, (size_t) d.size * per_byte + 256);
+		ev_range->push_back((uint32_t) *ev_capacity);
+		*ev_capacity += cap;
+		ev_range->push_back((uint32_t) *ev_capacity);
+	}
+	if (*ev_capacity >= 0xffffffffull) { ev_range->clear(); *ev_capacity = 0; return false; }
+	return true;
+}
+
+// K1's LDS budget
+void fill_hf_launch_info(const std::vector<DevCodeSpec> &coeff_specs, uint32_t block_ctx_size, size_t coeff_floats, HfLaunchInfo *out) {
+	HfLaunchInfo &hf = *out;
+	hf.block_ctx_size = block_ctx_size; hf.max_num_dist = hf.max_clusters = hf.max_table_bytes = 0;
+	for (const DevCodeSpec &sp : coeff_specs) {
+		hf.max_num_dist = std::max<uint32_t>(hf.max_num_dist, (uint32_t) sp.num_dist);
+		hf.max_clusters = std::max<uint32_t>(hf.max_clusters, (uint32_t) sp.num_clusters);
+		hf.max_table_bytes = std::max<uint32_t>(hf.max_table_bytes, sp.table_span * (sp.use_prefix_code ? 4u : 8u));
+	}
+	{
+		const uint32_t per_wave = 32 * 32 * 3 + 1024 * (uint32_t) sizeof(DevGroupBlock) + 16;
+		const uint32_t fixed = hf.block_ctx_size + 256 + 64 + HF_WAVES * per_wave;
+		hf.tables_fit_lds = fixed + hf.max_num_dist + hf.max_clusters * (uint32_t) sizeof(DevCluster) + hf.max_table_bytes + 64 <= 150u * 1024u;
+	}
+	{
+		auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+		hf.lanes_fast = true; hf.lanes_lds_bytes = 0;
+		for (const DevCodeSpec &sp : coeff_specs) {
+			hf.lanes_fast = hf.lanes_fast && sp.lane_cfg_off != 0xffffffffu;
+			const uint32_t n = 128 + 64 + 112 + align16((uint32_t) sp.num_dist) + align16(4u * (uint32_t) sp.num_clusters) + 8u * ((uint32_t) sp.num_clusters << sp.log_alpha_size);
+			hf.lanes_lds_bytes = std::max(hf.lanes_lds_bytes, n);
+		}
+		hf.lanes_fast = hf.lanes_fast && hf.lanes_lds_bytes + 4u * HF_LANE_COLS_BYTES <= 156u * 1024u && coeff_floats * 3 * sizeof(float) < 0xffffffffull;
+	}
+}
+
+// the frame-wide scalars of DevFrame (everything but the table offsets)
+void fill_frame_constants(const Frame &fr, DevFrame *out) {
+	DevFrame &df = *out;
 	memset(&df, 0, sizeof df);
 	df.width = fr.fh.width; df.height = fr.fh.height;
 	df.num_passes = fr.fh.num_passes; df.num_groups = (int32_t) fr.fh.num_groups; df.num_lf_groups = (int32_t) fr.fh.num_lf_groups;
@@ -66,6 +122,18 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 	for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) df.opsin_inv_mat[i * 3 + j] = fr.im.opsin_inv_mat[i][j];
 	df.itscale = 255.0f / fr.im.intensity_target;
 
+}
+
+uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostPlan *hp) {
+	if (cs_size + 16 >= ((size_t) 1 << 29)) return ERR_TODO;   // the kernels address the codestream with 32-bit BIT positions
+	if (fr.fh.is_modular) return ERR_TODO;
+	// same limits as j40.h:7867, 7917-7921. (A VarDCT frame of an image without xyb_encoded passes them: the reference
+	// runs the XYB inverse with the default opsin matrix on it all the same, j40.h:7206-7233, and so does K2.)
+	if (fr.im.grey || fr.fh.do_ycbcr) return ERR_TODO;
+	if (fr.im.bpp < 8 || fr.im.exp_bits) return ERR_TODO;
+
+	DevFrame &df = hp->frame;
+	fill_frame_constants(fr, &df);
 	hp->coeff_specs.assign((size_t) fr.fh.num_passes, DevCodeSpec());
 	for (int32_t p = 0; p < fr.fh.num_passes; ++p) flatten_code_spec(fr.coeff_codespec[p], hp->pool_u8, hp->pool_i32, hp->pool_u64, hp->clusters, &hp->coeff_specs[(size_t) p]);
 	hp->block_ctx_map_off = push(hp->pool_u8, fr.block_ctx_map.data(), fr.block_ctx_map.size());
@@ -132,22 +200,8 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 		for (int c = 0; c < 3; ++c) hp->inv_m_lf[c] = (float) (fr.global_scale * fr.quant_lf) / fr.m_lf_scaled[c] / 65536.0f;   // j40.h:6497
 	}
 
-	// sections
 	const int32_t num_groups = (int32_t) fr.fh.num_groups;
-	hp->sections.assign((size_t) fr.fh.num_passes * (size_t) num_groups, DevSection());
-	for (int32_t p = 0; p < fr.fh.num_passes; ++p) for (int32_t g = 0; g < num_groups; ++g) {
-		DevSection &d = hp->sections[(size_t) p * (size_t) num_groups + (size_t) g];
-		const GroupInfo gi = group_info(fr.fh, g);
-		if (fr.toc.single) {
-			d.byte_off = (uint32_t) fr.toc.single_section.offset; d.size = (uint32_t) fr.toc.single_section.size; d.bit_off = (uint32_t) fr.single_pass_group_bitpos;
-		} else {
-			const Section &s0 = fr.toc.pass_groups[(size_t) p * (size_t) num_groups + (size_t) g];
-			d.byte_off = (uint32_t) s0.offset; d.size = (uint32_t) s0.size; d.bit_off = 0;
-		}
-		d.ggidx = gi.ggidx; d.gx8 = gi.gx_in_gg / 8; d.gy8 = gi.gy_in_gg / 8;
-		d.gw8 = ceil_div(gi.gw, 8); d.gh8 = ceil_div(gi.gh, 8);
-		d.gx = fr.lf_groups[(size_t) gi.ggidx].left + gi.gx_in_gg; d.gy = fr.lf_groups[(size_t) gi.ggidx].top + gi.gy_in_gg; d.gw = gi.gw; d.gh = gi.gh;
-	}
+	fill_sections(fr, &hp->sections);
 	// per-group block lists for K1, in the visiting order of j40__hf_coeffs
 	std::vector<std::vector<int32_t>> ordinal(fr.lf_groups.size());   // [LF group][varblock] -> position in group_blocks
 	for (size_t g = 0; g < fr.lf_groups.size(); ++g) ordinal[g].assign(fr.lf_groups[g].varblocks.size(), -1);
@@ -179,18 +233,7 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 	// coefficient costs bits, 6 events per byte is far beyond what entropy coding reaches on real data; a section that still
 	// overflows it fails with ERR_EVOF and the frame is decoded with dense planes instead (runtime.hip).
 	df.sparse_coeffs = fr.fh.num_passes == 1 && !hp->force_dense;
-	hp->ev_range.clear(); hp->ev_capacity = 0;
-	if (df.sparse_coeffs) {
-		for (int32_t g = 0; g < num_groups; ++g) {
-			const DevSection &d = hp->sections[(size_t) g];
-			static const size_t per_byte = getenv("J40HIP_EVENTS_PER_BYTE") ? (size_t) atoi(getenv("J40HIP_EVENTS_PER_BYTE")) : 4;   // tests shrink it to reach the fallback
-			const size_t worst = (size_t) d.gw8 * (size_t) d.gh8 * 64 * 3, cap = std::min(worst, (size_t) d.size * per_byte + 256);
-			hp->ev_range.push_back((uint32_t) hp->ev_capacity);
-			hp->ev_capacity += cap;
-			hp->ev_range.push_back((uint32_t) hp->ev_capacity);
-		}
-		if (hp->ev_capacity >= 0xffffffffull) { df.sparse_coeffs = 0; hp->ev_range.clear(); hp->ev_capacity = 0; }
-	}
+	if (!fill_event_ranges(hp->sections, num_groups, df.sparse_coeffs != 0, &hp->ev_range, &hp->ev_capacity)) df.sparse_coeffs = 0;
 	hp->codestream.reserve(cs_size + 32);   // (assign + resize without it reallocates and copies the stream a second time)
 	hp->codestream.assign(cs, cs + cs_size);
 	hp->codestream.resize(cs_size + 32, 0);   // the lane decoders read up to three words past the position they stop at
@@ -227,29 +270,7 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 			}
 		}
 	}
-	// K1's LDS budget
-	HfLaunchInfo &hf = hp->hf;
-	hf.block_ctx_size = (uint32_t) fr.block_ctx_map.size(); hf.max_num_dist = hf.max_clusters = hf.max_table_bytes = 0;
-	for (const DevCodeSpec &sp : hp->coeff_specs) {
-		hf.max_num_dist = std::max<uint32_t>(hf.max_num_dist, (uint32_t) sp.num_dist);
-		hf.max_clusters = std::max<uint32_t>(hf.max_clusters, (uint32_t) sp.num_clusters);
-		hf.max_table_bytes = std::max<uint32_t>(hf.max_table_bytes, sp.table_span * (sp.use_prefix_code ? 4u : 8u));
-	}
-	{
-		const uint32_t per_wave = 32 * 32 * 3 + 1024 * (uint32_t) sizeof(DevGroupBlock) + 16;
-		const uint32_t fixed = hf.block_ctx_size + 256 + 64 + HF_WAVES * per_wave;
-		hf.tables_fit_lds = fixed + hf.max_num_dist + hf.max_clusters * (uint32_t) sizeof(DevCluster) + hf.max_table_bytes + 64 <= 150u * 1024u;
-	}
-	{
-		auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
-		hf.lanes_fast = true; hf.lanes_lds_bytes = 0;
-		for (const DevCodeSpec &sp : hp->coeff_specs) {
-			hf.lanes_fast = hf.lanes_fast && sp.lane_cfg_off != 0xffffffffu;
-			const uint32_t n = 128 + 64 + 112 + align16((uint32_t) sp.num_dist) + align16(4u * (uint32_t) sp.num_clusters) + 8u * ((uint32_t) sp.num_clusters << sp.log_alpha_size);
-			hf.lanes_lds_bytes = std::max(hf.lanes_lds_bytes, n);
-		}
-		hf.lanes_fast = hf.lanes_fast && hf.lanes_lds_bytes + 4u * HF_LANE_COLS_BYTES <= 156u * 1024u && hp->coeff_floats * 3 * sizeof(float) < 0xffffffffull;
-	}
+	fill_hf_launch_info(hp->coeff_specs, (uint32_t) fr.block_ctx_map.size(), hp->coeff_floats, &hp->hf);
 	hp->max_large = 0;
 	for (int d = 21; d < 27; ++d) hp->max_large = std::max(hp->max_large, hp->class_start[d + 1] - hp->class_start[d]);
 	return 0;

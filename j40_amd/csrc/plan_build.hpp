@@ -105,6 +105,12 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 uint32_t build_trailer_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, const uint32_t *end_bits, const uint32_t *k1_status, HostModPlan *hp,
 		std::vector<std::pair<int32_t, uint32_t>> *trailer_errors, std::vector<int32_t> *section_of);
 
+// pieces of build_vardct_plan shared with the pipeline's front plan (plan_front.cpp)
+void fill_frame_constants(const Frame &fr, DevFrame *out);
+void fill_sections(const Frame &fr, std::vector<DevSection> *sections);
+bool fill_event_ranges(const std::vector<DevSection> &sections, int32_t num_groups, bool sparse, std::vector<uint32_t> *ev_range, size_t *ev_capacity);
+void fill_hf_launch_info(const std::vector<DevCodeSpec> &coeff_specs, uint32_t block_ctx_size, size_t coeff_floats, HfLaunchInfo *out);
+
 // fills a DevCodeSpec and appends its tables to the pools
 void flatten_code_spec(const CodeSpec &spec, std::vector<uint8_t> &u8, std::vector<int32_t> &i32, std::vector<uint64_t> &u64, std::vector<DevCluster> &clusters, DevCodeSpec *out);
 

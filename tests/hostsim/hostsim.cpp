@@ -554,3 +554,104 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_decoder_glu
 	}
 	return plain.dct_select_used == hooked.dct_select_used && plain.order_used == hooked.order_used ? 0 : 3;
 }
+
+// ---- the device-side plan build (device/plan_dev.h) on the CPU, against plan_build.cpp ----
+#include "../../j40_amd/csrc/plan_front.hpp"
+#include "../../j40_amd/csrc/device/plan_dev.h"
+
+// Runs the pipeline's path on the CPU: front parse, the LfGroup sections' raw planes (host decoder), then the three device
+// functions of plan_dev.h in the kernels' orchestration; compares every array they produce with what parse_frame +
+// build_vardct_plan produce. Returns 0 when all agree, -1 when the frame is not one the front plan takes (nothing compared),
+// otherwise the number of the first check that failed; *err_out = the full parse's error code (on error nothing is compared
+// but the LfGroup statuses: the first failing LfGroup in file order must carry that code).
+extern "C" __attribute__((visibility("default"))) int32_t hostsim_device_plan_check(const uint8_t *buf, size_t size, uint32_t *err_out) {
+	const uint8_t *cs; size_t cs_size; std::vector<uint8_t> storage;
+	uint32_t e_full = 0;
+	Frame full, front;
+	full.defer_lf_tail = true;
+	try { extract_codestream(buf, size, &cs, &cs_size, &storage); } catch (const DecodeError &e) { if (err_out) *err_out = e.code; return -1; }
+	try { parse_frame(cs, cs_size, &full, 1); } catch (const DecodeError &e) { e_full = e.code; }
+	if (err_out) *err_out = e_full;
+	std::vector<LfDeviceTask> tasks; std::vector<int32_t> extra_prec; bool plain = true;
+	try { if (!parse_frame_front(cs, cs_size, &front, &tasks, &extra_prec, &plain)) return -1; }
+	catch (const DecodeError &e) { return e.code == e_full ? -1 : 1; }   // an error in front of the LfGroups: both report it
+	StaticTables st;
+	build_static_tables(front, &st);
+	FrontPlan fp;
+	if (build_front_plan(front, st, cs_size, extra_prec, true, &fp)) return -1;
+	const size_t ngg = front.lf_groups.size(), cells = fp.cells;
+	// raw planes, frame-wide arrays as the runtime lays them out
+	std::vector<int16_t> lfraw[3], xfromy(fp.c64s), bfromy(fp.c64s), vbinfo(2 * cells + 2);
+	for (int c = 0; c < 3; ++c) lfraw[c].assign(cells, 0);
+	std::vector<DevLfSlot> slots(ngg);
+	for (size_t g = 0; g < ngg; ++g) {
+		const DevLfGroup &d = fp.lf_groups[g];
+		DevLfSlot &sl = slots[g];
+		memset(&sl, 0, sizeof sl);
+		try {
+			BitReader sr(cs + front.toc.lf_groups[g].offset, front.toc.lf_groups[g].size);
+			LfRaw raw;
+			read_lf_group_raw(sr, front, front.lf_groups[g], &raw);
+			static const int XYB_FROM_STREAM[3] = {1, 0, 2};
+			for (int c = 0; c < 3; ++c) memcpy(lfraw[c].data() + d.cell_base, raw.lf[XYB_FROM_STREAM[c]].data(), raw.lf[0].size() * 2);
+			memcpy(xfromy.data() + d.c64_base, raw.xfromy.data(), raw.xfromy.size() * 2); memcpy(bfromy.data() + d.c64_base, raw.bfromy.data(), raw.bfromy.size() * 2);
+			if ((size_t) raw.nb_varblocks > (size_t) d.width8 * (size_t) d.height8) sl.status = ERR_VBLK;   // (more varblocks than cells: the placement would say so)
+			else memcpy(vbinfo.data() + 2 * (size_t) d.cell_base, raw.info.data(), raw.info.size() * 2);
+			sl.nb_varblocks = raw.nb_varblocks;
+		} catch (const DecodeError &e) { sl.status = e.code; }
+	}
+	std::vector<DevVbRec> recs(cells + 1);
+	std::vector<uint32_t> group_count((size_t) fp.build.num_groups, 0), group_block_start((size_t) fp.build.num_groups + 1, 0), class_count(ngg * 28, 0);
+	std::vector<DevGroupBlock> group_blocks(cells + 1);
+	std::vector<DevVarblock> vb_sorted(cells + 1);
+	int32_t class_start[28];
+	DevPlanBuild pb = fp.build;
+	pb.pool_u8 = fp.pool_u8.data(); pb.lf_groups = fp.lf_groups.data(); pb.lf_slots = slots.data();
+	for (int c = 0; c < 3; ++c) pb.lfraw[c] = lfraw[c].data();
+	pb.xfromy = xfromy.data(); pb.bfromy = bfromy.data(); pb.vbinfo = vbinfo.data(); pb.vb_recs = recs.data();
+	pb.group_count = group_count.data(); pb.group_block_start = group_block_start.data(); pb.class_count = class_count.data(); pb.class_start = class_start;
+	pb.group_blocks = group_blocks.data(); pb.vb_sorted = vb_sorted.data(); pb.lf_section_off = fp.lf_section_off.data();
+	{   // k_plan_place: 64 LfGroups side by side, scratch interleaved
+		std::vector<uint16_t> occ(256 * 64), grp(64 * 64); std::vector<uint32_t> cls(28 * 64);
+		for (size_t g = 0; g < ngg; ++g) plan_place_lf_group(pb, (int32_t) g, occ.data() + g % 64, grp.data() + g % 64, cls.data() + g % 64, 64);
+	}
+	plan_scan_frame(pb);
+	for (size_t g = 0; g < ngg; ++g) for (int32_t v = 0; v < slots[g].placed; ++v) plan_emit_varblock(pb, (int32_t) g, v);
+	// the verdict over the LfGroup sections
+	uint64_t best = ~(uint64_t) 0;
+	for (size_t g = 0; g < ngg; ++g) best = std::min(best, plan_verdict_key(slots[g].status, fp.lf_section_off[g]));
+	const uint32_t lf_err = best == ~(uint64_t) 0 ? 0 : (uint32_t) best;
+	if (e_full) return lf_err == e_full ? 0 : 2;
+	if (lf_err) return 3;
+	HostPlan hp;
+	if (build_vardct_plan(full, cs, cs_size, &hp)) return -1;
+	if (hp.group_block_start != group_block_start) return 4;
+	if (memcmp(hp.group_blocks.data(), group_blocks.data(), sizeof(DevGroupBlock) * hp.group_blocks.size()) != 0) return 5;
+	if (memcmp(hp.class_start, class_start, sizeof class_start) != 0) return 6;
+	if (memcmp(hp.vb_sorted.data(), vb_sorted.data(), sizeof(DevVarblock) * hp.vb_sorted.size()) != 0) return 7;
+	for (size_t g = 0; g < ngg; ++g) {
+		const DevLfGroup &a = hp.lf_groups[g], &b = fp.lf_groups[g];
+		if (a.nb_varblocks != b.nb_varblocks || a.cell_base != b.cell_base || a.c64_base != b.c64_base || memcmp(a.mult_lf, b.mult_lf, sizeof a.mult_lf) != 0 || a.width8 != b.width8 || a.height != b.height) return 8;
+		if (slots[g].dct_used == 0) return 9;
+	}
+	for (int c = 0; c < 3; ++c) if (hp.lfraw[c] != lfraw[c]) return 10;
+	// tables: every table the host path loaded must be in the static set with the same contents
+	const DevFrame &fa = hp.frame, &fb = fp.frame;
+	for (int i = 0; i < 17; ++i) if (fa.dq_off[i] != 0xffffffffu) {
+		if (fb.dq_off[i] == 0xffffffffu || fa.dq_size[i] != fb.dq_size[i] || memcmp(hp.pool_f32.data() + fa.dq_off[i], st.pool_f32.data() + fb.dq_off[i], sizeof(float) * 3 * fa.dq_size[i]) != 0) return 11;
+		if ((fa.dq_scan_off[i] != 0xffffffffu) != (fb.dq_scan_off[i] != 0xffffffffu)) return 12;
+		if (fa.dq_scan_off[i] != 0xffffffffu && memcmp(hp.pool_f32.data() + fa.dq_scan_off[i], st.pool_f32.data() + fb.dq_scan_off[i], sizeof(float) * 3 * fa.dq_size[i]) != 0) return 13;
+	}
+	for (int i = 0; i < 11 * 13 * 3; ++i) if (fa.order_off[i] != 0xffffffffu) {
+		const int o = (i / 3) % 13; const size_t n = (size_t) 1 << (LOG_ORDER_SIZE[o][0] + LOG_ORDER_SIZE[o][1]);
+		if (fb.order_off[i] == 0xffffffffu || memcmp(hp.pool_u16.data() + fa.order_off[i], st.pool_u16.data() + fb.order_off[i], 2 * n) != 0) return 14;
+	}
+	{   // everything else of DevFrame
+		DevFrame x = fa, y = fb;
+		memset(x.order_off, 0, sizeof x.order_off); memset(y.order_off, 0, sizeof y.order_off); memset(x.dq_off, 0, sizeof x.dq_off); memset(y.dq_off, 0, sizeof y.dq_off);
+		memset(x.dq_size, 0, sizeof x.dq_size); memset(y.dq_size, 0, sizeof y.dq_size); memset(x.dq_scan_off, 0, sizeof x.dq_scan_off); memset(y.dq_scan_off, 0, sizeof y.dq_scan_off);
+		if (memcmp(&x, &y, sizeof x) != 0) return 15;
+	}
+	if (hp.ev_range != fp.ev_range || hp.sections.size() != fp.sections.size() || memcmp(hp.sections.data(), fp.sections.data(), sizeof(DevSection) * hp.sections.size()) != 0) return 16;
+	return 0;
+}

@@ -1,0 +1,62 @@
+"""The plan build that the pipeline runs on the device (j40_amd/csrc/device/plan_dev.h: varblock placement, prefix sums, per-varblock
+records for K1 and K2; j40_amd/csrc/plan_front.cpp: everything that does not depend on the LfGroup sections), compiled for the CPU
+(tests/hostsim) and compared array by array with the host path (frame.cpp lf_group_finish + plan_build.cpp), whose products
+tests/test_host.py pins against the reference's internals (j40.h:6585-6720, 6722-6790). On damaged LfGroup sections the device
+path's verdict -- first failing LfGroup section in file order -- must be the host parse's error code. The kernels that run these
+functions are checked on the GPU (tests/test_pipeline.py)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from streams import synth, ROOT, VARDCT_CASES
+
+CASES = [("vardct", 520, 264, 100 + i, opts) for i, (_, opts) in enumerate(VARDCT_CASES)] + [
+    ("vardct", 776, 520, 31, dict()),
+    ("vardct", 2600, 2100, 32, dict(bctx=1)),                  # four LfGroup sections, custom LF thresholds (LF index)
+    ("vardct", 2049, 300, 33, dict(maxlog=8, cfl=1)),          # a 1-cell-wide second LfGroup, 256x256 transforms
+    ("vardct", 776, 520, 3, dict(maxlog=8, bctx=1, presets=2, orders=1)),
+    ("vardct", 1920, 1080, 34, dict(forward=1)),
+    ("vardct", 2600, 2100, 35, dict(forward=1)),
+    ("vardct", 520, 264, 36, dict(passes=3)),
+    ("vardct", 4100, 2100, 37, dict()),                        # 3 x 2 LfGroups
+]
+
+
+@pytest.fixture(scope="module")
+def sim(built):
+    S = C.CDLL(os.path.join(ROOT, "build", "libhostsim.so"))
+    S.hostsim_device_plan_check.restype = C.c_int32
+    S.hostsim_device_plan_check.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
+    return S
+
+
+def check(sim, data):
+    buf = C.create_string_buffer(data, len(data))
+    err = C.c_uint32()
+    return sim.hostsim_device_plan_check(buf, len(data), C.byref(err)), err.value
+
+
+@pytest.mark.parametrize("mode,w,h,seed,opts", CASES)
+def test_device_plan_equals_host_plan(sim, mode, w, h, seed, opts):
+    data = synth(mode, w, h, seed, **opts)
+    rc, err = check(sim, data)
+    assert err == 0
+    if opts.get("alpha"):
+        assert rc == -1          # extra channels: Modular sub-images behind the coefficients, left to the host path
+    else:
+        assert rc == 0, "check %d failed" % rc
+
+
+def test_damaged_lf_sections_get_the_host_parse_verdict(sim):
+    data = synth("vardct", 2600, 2100, 41)
+    rng = np.random.default_rng(11)
+    outcomes = {}
+    for _ in range(80):
+        m = bytearray(data)
+        m[int(rng.integers(150, len(m) // 6))] ^= 1 << int(rng.integers(0, 8))
+        rc, err = check(sim, bytes(m))
+        assert rc in (0, -1), (rc, err)
+        outcomes[err] = outcomes.get(err, 0) + (rc == 0)
+    assert len(outcomes) >= 3 and sum(outcomes.values()) >= 40, outcomes
