@@ -8,7 +8,7 @@ CXXFLAGS = -std=c++17 -O2 -fPIC -Wall -Wextra -ffp-contract=off -fvisibility=hid
 HIPFLAGS = --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -Wall $(EXTRA_HIPFLAGS)
 SRC = j40_amd/csrc
 HOST_OBJS = build/obj/plan_build.o build/obj/plan_front.o build/obj/entropy.o build/obj/modular.o build/obj/tables.o build/obj/frame.o build/obj/capi_host.o build/obj/api.o
-DEV_OBJS = build/obj/kernels.o build/obj/modular_kernels.o build/obj/runtime.o build/obj/pipeline.o build/obj/lf_tail_kernels.o build/obj/modular_coop.o build/obj/modular_quad.o build/obj/lf_decode.o
+DEV_OBJS = build/obj/kernels.o build/obj/modular_kernels.o build/obj/runtime.o build/obj/pipeline.o build/obj/lf_tail_kernels.o build/obj/modular_coop.o build/obj/modular_quad.o build/obj/lf_decode.o build/obj/plan_kernels.o build/obj/async.o
 
 .PHONY: all lib tools oracle hostsim clean
 all: lib tools hostsim oracle

@@ -121,8 +121,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--distinct", type=int, default=64, help="distinct streams a batch cycles through")
     ap.add_argument("--pipe-batch", type=int, default=256, help="frames per entropy launch inside the pipeline")
-    ap.add_argument("--host-threads", type=int, default=0, help="pipeline worker threads per GPU (default: the container's CPU quota / GPUs; 8 times that with --lf-device 1)")
-    ap.add_argument("--lf-device", type=int, default=0, help="1: the LfGroup streams are decoded on the GPU while the parsing thread sleeps (j40hip_frame_parse_on); 0: on the host")
+    ap.add_argument("--host-threads", type=int, default=0, help="pipeline worker threads per GPU (default: the container's CPU quota / GPUs)")
+    ap.add_argument("--lf-streams", choices=["auto", "device", "host"], default="auto",
+                    help="who decodes the LfGroup streams of the batched frames: the GPU (k_lf_groups), the host worker threads, or decided frame by frame (auto: the host threads keep them while the device has batches queued up)")
     ap.add_argument("--resident-batch", type=int, default=256, help="frames of the device-resident section (kernels only, as round 1 measured)")
     ap.add_argument("--stream", choices=["forward", "coefficient"], default="forward",
                     help="forward: the generator ENCODES a procedural picture at about distance 1 (tools/jxlsynth forward=1); "
@@ -167,7 +168,7 @@ def main():
 
     W, H, B = args.width, args.height, args.batch
     quota = cpu_quota()
-    threads = args.host_threads or max(2, quota // world) * (8 if args.lf_device else 1)
+    threads = args.host_threads or max(2, quota // world)
     D = max(1, min(args.distinct, B))
     # every rank decodes its own batch of the same D streams: rank 0 generates them with all the CPUs the container has (an 8K
     # encode takes ~10 s of one core), the other ranks wait and read them from build/streams
@@ -182,13 +183,12 @@ def main():
     step_bufs = [bufs[i % D] for i in range(B)]
     step_sizes = [len(datas[i % D]) for i in range(B)]
     outs = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(B)]
-    pipe = j40_amd.Pipeline(local_rank, threads, min(args.pipe_batch, B), 2, lf_on_device=bool(args.lf_device))
+    pipe = j40_amd.Pipeline(local_rank, threads, min(args.pipe_batch, B), 2, lf_streams=args.lf_streams)
 
     for _ in range(max(args.warmup, 0)):
         run_pipeline_steps(pipe, step_bufs, step_sizes, outs, W * 4, True, 1, torch, dev, None)
     elapsed, tickets = run_pipeline_steps(pipe, step_bufs, step_sizes, outs, W * 4, True, args.steps, torch, dev, dist)
     st = pipe.stats()
-    lf_frames = pipe.lf_device_frames()
     for t in tickets:
         assert pipe.result(t) == "", "decode error: " + pipe.result(t)
     resident_multi = None
@@ -239,9 +239,11 @@ def main():
         "metric": METRIC, "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("%d x %dx%d VarDCT frames per GPU per step, " + stream_words + ", %d distinct streams, %.3f bpp, %d pass groups each), whole decode "
-                               "path per frame inside the timed region: host parse" + (" (LfGroup streams decoded on the GPU)" if args.lf_device else "") + " + plan build + plan upload on %d worker threads (container CPU quota %d of %d visible CPUs) "
-                               "pipelined with batched entropy + pixel kernels (%d frames per entropy launch); codestream bytes in, RGBA u8x4 resident in HBM out")
-                               % (B, W, H, D, 8.0 * sum(step_sizes) / (B * W * H), ((W + 255) // 256) * ((H + 255) // 256), threads, quota, os.cpu_count() or 1, min(args.pipe_batch, B)),
+                               "path per frame inside the timed region: the host parses what precedes the LfGroup sections (%d worker threads, container CPU quota %d of %d visible CPUs) and copies "
+                               "it to the GPU; LfGroup streams (%s), plan build, LfGroup tail, entropy decode and pixel kernels are enqueued per batch of %d frames; "
+                               "codestream bytes in, RGBA u8x4 resident in HBM out")
+                               % (B, W, H, D, 8.0 * sum(step_sizes) / (B * W * H), ((W + 255) // 256) * ((H + 255) // 256), threads, quota, os.cpu_count() or 1,
+                                  {"auto": "GPU or host thread, decided per frame", "device": "GPU", "host": "host threads"}[args.lf_streams], min(args.pipe_batch, B)),
                    "clock": "codestream bytes in memory -> RGBA u8x4 in device memory, nothing prepared ahead (SURVEY 8d); same start as cpu_baseline, which ends in host memory",
                    "stream": args.stream, "frame_pixels": W * H, "frames_per_step": B, "codestream_bytes": step_sizes[0], "parallelism": "frames x%d" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": None,
@@ -249,9 +251,12 @@ def main():
                      "algorithmic_bytes_per_launch": int(alg_launch),
                      "step_frac": round(alg_step * args.steps / elapsed / 8e12, 6),
                      "note": "HIP events on the launch streams inside the timed region (pipeline stats); step_frac = algorithmic bytes of the steps / wall time / peak"},
-        "pipeline": {"host_parse_ms_per_frame": round(st["parse_thread_ms"] / max(st["completed"], 1), 2), "plan_build_upload_ms_per_frame": round(st["upload_thread_ms"] / max(st["completed"], 1), 2),
-                     "entropy_ms_per_launch": round(k1_launch_ms, 3), "pixel_kernels_ms_per_launch": round(st["k2_ms"] / launches, 3), "host_threads": threads, "cpu_quota": quota,
-                     "lf_streams_on_device_frames": lf_frames, "lf_streams": "device (k_lf_groups; the parse time above then includes the thread's sleep while the device decodes)" if args.lf_device else "host"},
+        "pipeline": {"host_stage_ms_per_frame": round(st["parse_thread_ms"] / max(st["completed"] - st["single_frames"], 1), 2),
+                     "lf_streams_plan_tail_ms_per_launch": round(st["lf_plan_ms"] / launches, 3), "entropy_ms_per_launch": round(k1_launch_ms, 3), "pixel_kernels_ms_per_launch": round(st["k2_ms"] / launches, 3),
+                     "host_threads": threads, "cpu_quota": quota, "lf_streams": args.lf_streams, "lf_streams_on_device_frames": st["lf_device_frames"], "frames": st["completed"],
+                     "single_frame_path_frames": st["single_frames"],
+                     "note": "host_stage: ms of one worker thread per frame (headers, TOC, LfGlobal, HfGlobal, staging; plus the LfGroup streams for the frames the host kept); "
+                             "the per-launch figures are HIP-event times on the batch's stream and overlap with other batches' stages"},
     }
     if resident_multi is not None:
         result["device_resident"] = resident_multi

@@ -275,17 +275,22 @@ J40HIP_API uint32_t j40hip_frame_status_end(j40hip_frame *f);
 J40HIP_API void j40hip_frame_mark_idle(j40hip_frame *f);
 
 /* ---- whole-frame throughput pipeline (j40_amd/csrc/device/pipeline.hip): codestreams in host memory -> RGBA u8x4, every stage of
- *      many frames in flight: `host_threads` workers parse (j40hip_frame_parse) and upload, one thread batches `batch_frames` uploaded
- *      frames per entropy launch, up to `max_in_flight` batches on their own streams; host output is copied back on the batch's
- *      stream behind its kernels. The serving shape of j40_from_memory + j40_next_frame + j40_frame_pixels_u8x4 for many images. ---- */
+ *      many frames in flight. `host_threads` workers parse what precedes the LfGroup sections of a frame and copy it to the device
+ *      without waiting for it; one thread enqueues, per batch of `batch_frames` frames, the LfGroup streams, the plan build, the
+ *      entropy decode and the pixel kernels on the batch's stream, up to `max_in_flight` batches on their own streams; host output
+ *      is copied back on the batch's stream behind its kernels. Frames outside that path (Modular, one section, extra channels)
+ *      are decoded by a worker through the single-frame entry points. The serving shape of j40_from_memory + j40_next_frame +
+ *      j40_frame_pixels_u8x4 for many images. ---- */
 typedef struct j40hip_pipeline j40hip_pipeline;
 J40HIP_API j40hip_pipeline *j40hip_pipeline_create(int device, int host_threads, int batch_frames, int max_in_flight, uint32_t *err);
-/* flags bit 0: the worker threads parse with j40hip_frame_parse_on -- the LfGroup streams are decoded on the device while the
- * thread sleeps, so give it several times more host_threads than CPUs (the threads' CPU time is then headers, varblock placement
- * and plan build only) */
+/* flags bits 0-1: who decodes the LfGroup streams (j40.h:6722-6790) of the batched frames: 0 decided frame by frame (the host
+ * threads keep them while the device has batches queued up, else the device takes them), 1 always the device (k_lf_groups),
+ * 2 always the host threads. Bit 2: tune the process's malloc for many threads freeing multi-megabyte blocks (mallopt: mmap
+ * threshold, trim threshold, top pad) -- process-wide, hence opt-in. */
 J40HIP_API j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int batch_frames, int max_in_flight, uint32_t flags, uint32_t *err);
 J40HIP_API int64_t j40hip_pipeline_lf_device_frames(j40hip_pipeline *p);   /* frames whose LfGroup streams the device decoded (since the last reset) */
 J40HIP_API void j40hip_pipeline_free(j40hip_pipeline *p);
+/* frames still queued when the pipeline is freed are dropped; frames already prepared or in flight are decoded first */
 /* queues one image. buf is borrowed until the ticket is done. rgba: `stride_bytes` * height bytes of host memory (pinned memory for
  * full copy speed) or, with device_output != 0, of device memory (no copy back). */
 J40HIP_API uint32_t j40hip_pipeline_submit(j40hip_pipeline *p, const void *buf, size_t size, void *rgba, size_t stride_bytes, int device_output, int64_t *ticket);
@@ -293,10 +298,13 @@ J40HIP_API uint32_t j40hip_pipeline_submit(j40hip_pipeline *p, const void *buf, 
 J40HIP_API uint32_t j40hip_pipeline_drain(j40hip_pipeline *p);
 /* 0 or the image's 4-char error code, as j40_error would give it ("rnge" for an unknown or unfinished ticket) */
 J40HIP_API uint32_t j40hip_pipeline_result(j40hip_pipeline *p, int64_t ticket);
-/* out8: [0] parse ms and [1] plan-build + upload ms summed over the worker threads, [2] images completed, [3] ms from first submit to
- * last completion, [4] entropy-stage and [5] pixel-stage ms summed over the batch launches (HIP events on their streams), [6] batch
- * launches, [7] images in them */
+/* out8: [0] ms the worker threads spent in the host stage of batched frames and [1] in whole single-frame decodes (summed over the
+ * threads), [2] images completed, [3] ms from first submit to last completion, [4] entropy-stage and [5] pixel-stage ms summed over
+ * the batch launches (HIP events on their streams), [6] batch launches, [7] images in them */
 J40HIP_API void j40hip_pipeline_stats(j40hip_pipeline *p, double *out8);
+/* out12: as above, then [8] ms of the batches' first stage (LfGroup streams + plan build + LfGroup tail), [9] images whose LfGroup
+ * streams the device decoded, [10] images decoded on the single-frame path, [11] reserved */
+J40HIP_API void j40hip_pipeline_stats_ex(j40hip_pipeline *p, double *out12);
 J40HIP_API void j40hip_pipeline_reset_stats(j40hip_pipeline *p);
 
 #ifdef __cplusplus

@@ -96,7 +96,7 @@ def lib():
         "j40hip_frame_after_frame_status": (u32, [vp]),
         "j40hip_pipeline_create": (vp, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(u32)]), "j40hip_pipeline_free": (None, [vp]), "j40hip_pipeline_create_ex": (vp, [C.c_int, C.c_int, C.c_int, C.c_int, u32, C.POINTER(u32)]), "j40hip_pipeline_lf_device_frames": (i64, [vp]),
         "j40hip_pipeline_submit": (u32, [vp, vp, sz, vp, sz, C.c_int, C.POINTER(i64)]), "j40hip_pipeline_drain": (u32, [vp]),
-        "j40hip_pipeline_result": (u32, [vp, i64]), "j40hip_pipeline_stats": (None, [vp, vp]), "j40hip_pipeline_reset_stats": (None, [vp]),
+        "j40hip_pipeline_result": (u32, [vp, i64]), "j40hip_pipeline_stats": (None, [vp, vp]), "j40hip_pipeline_stats_ex": (None, [vp, vp]), "j40hip_pipeline_reset_stats": (None, [vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)  # AttributeError = the library does not export what include/*.h declares
@@ -410,11 +410,12 @@ class Pipeline:
     """whole-frame throughput pipeline (include/j40hip.h, j40hip_pipeline_*): codestreams in host memory -> RGBA u8x4 in host or
     device memory; host worker threads parse and upload, one thread batches the uploaded frames per entropy launch"""
 
-    def __init__(self, device=0, host_threads=0, batch_frames=32, max_in_flight=2, lf_on_device=False):
-        """lf_on_device: the workers leave the LfGroup streams to the device and sleep meanwhile -- use several times more
-        host_threads than CPUs"""
+    def __init__(self, device=0, host_threads=0, batch_frames=32, max_in_flight=2, lf_streams="auto", tune_malloc=False):
+        """lf_streams: who decodes the LfGroup streams of the batched frames -- "auto" (decided frame by frame), "device"
+        (k_lf_groups), "host" (the worker threads)"""
         err = C.c_uint32()
-        self.h = lib().j40hip_pipeline_create_ex(device, host_threads, batch_frames, max_in_flight, 1 if lf_on_device else 0, C.byref(err))
+        flags = {"auto": 0, "device": 1, "host": 2}[lf_streams] | (4 if tune_malloc else 0)
+        self.h = lib().j40hip_pipeline_create_ex(device, host_threads, batch_frames, max_in_flight, flags, C.byref(err))
         if not self.h:
             raise J40Error(err4(err.value), "in j40hip_pipeline_create")
         self._keep = []
@@ -450,9 +451,10 @@ class Pipeline:
         return err4(lib().j40hip_pipeline_result(self.h, ticket))
 
     def stats(self):
-        a = (C.c_double * 8)()
-        lib().j40hip_pipeline_stats(self.h, a)
-        return dict(parse_thread_ms=a[0], upload_thread_ms=a[1], completed=int(a[2]), wall_ms=a[3], k1_ms=a[4], k2_ms=a[5], launches=int(a[6]), launch_frames=int(a[7]))
+        a = (C.c_double * 12)()
+        lib().j40hip_pipeline_stats_ex(self.h, a)
+        return dict(parse_thread_ms=a[0], single_thread_ms=a[1], completed=int(a[2]), wall_ms=a[3], k1_ms=a[4], k2_ms=a[5], launches=int(a[6]), launch_frames=int(a[7]),
+                    lf_plan_ms=a[8], lf_device_frames=int(a[9]), single_frames=int(a[10]))
 
     def reset_stats(self):
         lib().j40hip_pipeline_reset_stats(self.h)

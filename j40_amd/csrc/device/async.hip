@@ -1,0 +1,401 @@
+// j40_amd/csrc/device/async.hip -- see async.hpp. The reference work this replaces per frame, stage by stage:
+//   host (here)      container, headers, TOC, LfGlobal, HfGlobal (j40.h:8175-8192), the first bits of every LfGroup section
+//   k_lf_groups      the two Modular sub-images of every LfGroup section (j40.h:6722-6790) -- or the host decoder, when the
+//                    frame's tree / code spec are outside what the kernel takes, or the pipeline sends the frame that way
+//   plan_kernels     LF index, varblock placement, work lists (j40.h:6566-6570, 6634-6701; plan_build.cpp)
+//   lf_tail_kernels  LF dequantisation, smoothing, LLF coefficients (j40.h:6544-6590, 6492, 5944)
+//   k_hf_lanes       j40__pass_group / j40__hf_coeffs of every section (j40.h:7007, 6888)
+//   k_vardct_*       dequantisation, chroma-from-luma, inverse transforms, XYB -> sRGB, pack (j40.h:7053-7247, 7910)
+//   k_plan_verdict   the first failing section in file order
+// Nothing here touches the oracle, and there is no CPU fallback for the hot path: without a HIP device prepare returns nullptr
+// and the caller's single-frame path reports "!gpu".
+#include <hip/hip_runtime.h>
+#include <memory>
+#include <mutex>
+#include <vector>
+#include "../capi.hpp"
+#include "../plan_front.hpp"
+#include "kernels.h"
+#include "runtime_shared.hpp"
+#include "async.hpp"
+
+using namespace j40hip;
+using namespace j40hip_rt;
+
+namespace {
+
+constexpr uint32_t ERR_GPU = ('!' << 24) | ('g' << 16) | ('p' << 8) | 'u';
+constexpr uint32_t ERR_MEM = ('!' << 24) | ('m' << 16) | ('e' << 8) | 'm';
+
+// ---- the static tables on the device, one copy per distinct encoding (plan_front.hpp) ----
+struct StaticEntry {
+	int device = 0;
+	std::vector<uint8_t> key;
+	uint32_t order_off[11 * 13 * 3], dq_off[17], dq_size[17], dq_scan_off[17];
+	bool any_dq_error = false;
+	float *d_f32 = nullptr; uint16_t *d_u16 = nullptr;
+	uint64_t last_use = 0;
+	~StaticEntry() { if (d_f32 || d_u16) { (void) hipSetDevice(device); if (d_f32) (void) hipFree(d_f32); if (d_u16) (void) hipFree(d_u16); } }
+};
+std::mutex g_static_mutex;
+std::vector<std::shared_ptr<StaticEntry>> g_static;
+uint64_t g_static_clock = 0;
+
+std::shared_ptr<StaticEntry> static_tables_for(const Frame &fr, int device) {
+	std::vector<uint8_t> key;
+	static_tables_key(fr, &key);
+	std::lock_guard<std::mutex> lock(g_static_mutex);
+	for (auto &e : g_static) if (e->device == device && e->key == key) { e->last_use = ++g_static_clock; return e; }
+	// (built under the lock: the first frames of a run all want the same entry, and the others should find it rather than build it too)
+	StaticTables st;
+	build_static_tables(fr, &st);
+	auto e = std::make_shared<StaticEntry>();
+	e->device = device; e->key.swap(st.key);
+	memcpy(e->order_off, st.order_off, sizeof e->order_off); memcpy(e->dq_off, st.dq_off, sizeof e->dq_off);
+	memcpy(e->dq_size, st.dq_size, sizeof e->dq_size); memcpy(e->dq_scan_off, st.dq_scan_off, sizeof e->dq_scan_off);
+	for (int i = 0; i < 17; ++i) e->any_dq_error = e->any_dq_error || st.dq_error[i] != 0;
+	if (hipMalloc((void **) &e->d_f32, st.pool_f32.size() * sizeof(float) + 64) != hipSuccess || hipMalloc((void **) &e->d_u16, st.pool_u16.size() * 2 + 64) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+	if (hipMemcpy(e->d_f32, st.pool_f32.data(), st.pool_f32.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+	if (hipMemcpy(e->d_u16, st.pool_u16.data(), st.pool_u16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+	e->last_use = ++g_static_clock;
+	if (g_static.size() >= 16) {   // drop the least recently used entry nobody holds
+		size_t victim = g_static.size();
+		for (size_t i = 0; i < g_static.size(); ++i) if (g_static[i].use_count() == 1 && (victim == g_static.size() || g_static[i]->last_use < g_static[victim]->last_use)) victim = i;
+		if (victim < g_static.size()) g_static.erase(g_static.begin() + (long) victim);
+	}
+	g_static.push_back(e);
+	return e;
+}
+
+// this thread's pinned staging: two buffers, so that the copy of one frame runs while the next one is being staged
+struct AStage { PinnedStage mem; hipEvent_t done = nullptr; bool pending = false; };
+thread_local AStage t_astage[2];
+thread_local int t_astage_next = 0;
+thread_local FrontPlan t_front;
+
+struct Layout {
+	size_t size = 0;
+	size_t take(size_t bytes) { const size_t off = (size + 255) & ~(size_t) 255; size = off + bytes + 16; return off; }
+};
+
+} // namespace
+
+struct j40hip_aframe {
+	j40hip_frame host;            // the parsed front of the frame (and where its codestream lies)
+	int device = 0;
+	std::shared_ptr<StaticEntry> st;
+	void *plan_block = nullptr, *work_block = nullptr; size_t plan_block_bytes = 0, work_block_bytes = 0;
+	DevPlan plan; DevPlanBuild build;
+	HfLaunchInfo hf;
+	std::vector<DevLfTask> lf_tasks;   // empty: the LfGroup streams were decoded on the host
+	int32_t num_lf_groups = 0, max_lf_cells = 0, num_groups = 0, num_passes = 1;
+	size_t cells = 0;
+	bool sparse = true;
+	hipEvent_t uploaded = nullptr;
+};
+
+void j40hip_aframe_free(j40hip_aframe *f) {
+	if (!f) return;
+	(void) hipSetDevice(f->device);
+	cache_release(f->device, f->plan_block, f->plan_block_bytes, false);
+	cache_release(f->device, f->work_block, f->work_block_bytes, false);
+	if (f->uploaded) (void) hipEventDestroy(f->uploaded);
+	delete f;
+}
+int j40hip_aframe_lf_on_device(const j40hip_aframe *f) { return f && !f->lf_tasks.empty(); }
+void j40hip_aframe_size(const j40hip_aframe *f, int64_t *width, int64_t *height) { *width = f->host.frame.fh.width; *height = f->host.frame.fh.height; }
+uint32_t j40hip_aframe_after_frame_status(const j40hip_aframe *f) { return j40hip_frame_after_frame_status(&f->host); }
+
+static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int device, hipStream_t stream, int lf_on_device) {
+	if (j40hip_device_count() <= device || device < 0 || hipSetDevice(device) != hipSuccess || !ensure_constant_tables(device)) return nullptr;
+	std::unique_ptr<j40hip_aframe, void (*)(j40hip_aframe *)> af(new j40hip_aframe(), j40hip_aframe_free);
+	af->device = device;
+	j40hip_frame &h = af->host;
+	Frame &fr = h.frame;
+	std::vector<LfDeviceTask> tasks; std::vector<int32_t> extra_prec; bool plain = true;
+	extract_codestream((const uint8_t *) buf, size, &h.cs, &h.cs_size, &h.cs_storage, &h.container_stray_tail);
+	h.bare_codestream = h.cs == (const uint8_t *) buf && h.cs_size == size;
+	if (!parse_frame_front(h.cs, h.cs_size, &fr, &tasks, &extra_prec, &plain)) return nullptr;
+	af->st = static_tables_for(fr, device);
+	if (!af->st || af->st->any_dq_error) return nullptr;   // (a matrix that does not load: whether it matters depends on the varblocks -- the single-frame path sorts it out)
+	StaticTables offs;   // (offsets only)
+	memcpy(offs.order_off, af->st->order_off, sizeof offs.order_off); memcpy(offs.dq_off, af->st->dq_off, sizeof offs.dq_off);
+	memcpy(offs.dq_size, af->st->dq_size, sizeof offs.dq_size); memcpy(offs.dq_scan_off, af->st->dq_scan_off, sizeof offs.dq_scan_off);
+	FrontPlan &fp = t_front;
+	if (build_front_plan(fr, offs, h.cs_size, extra_prec, lf_on_device != 0 && plain, &fp)) return nullptr;
+	const bool dev_lf = fp.lf_coop;
+	const size_t ngg = fp.lf_groups.size(), cells = fp.cells, c64s = fp.c64s, cs_size = h.cs_size;
+	const int32_t num_groups = fp.frame.num_groups;
+	af->num_lf_groups = (int32_t) ngg; af->max_lf_cells = fp.max_lf_cells; af->num_groups = num_groups; af->num_passes = fp.frame.num_passes; af->cells = cells;
+	af->sparse = fp.frame.sparse_coeffs != 0; af->hf = fp.hf;
+
+	// ---- the plan block: what the host copies first, then what the device produces ----
+	Layout L;
+	const size_t o_cs = L.take(cs_size + 32), o_u8 = L.take(fp.pool_u8.size()), o_i32 = L.take(fp.pool_i32.size() * 4), o_u64 = L.take(fp.pool_u64.size() * 8);
+	const size_t o_cl = L.take(fp.clusters.size() * sizeof(DevCluster)), o_spec = L.take(fp.coeff_specs.size() * sizeof(DevCodeSpec)), o_frame = L.take(sizeof(DevFrame));
+	const size_t o_lfg = L.take(ngg * sizeof(DevLfGroup)), o_sec = L.take(fp.sections.size() * sizeof(DevSection)), o_evr = L.take(fp.ev_range.size() * 4);
+	const size_t o_lso = L.take(ngg * 4), o_slots = L.take(ngg * sizeof(DevLfSlot));
+	const size_t o_tree = dev_lf ? L.take(sizeof(DevCoopTree)) : 0, o_alias = dev_lf ? L.take(fp.lf_alias.size() * 8) : 0;
+	size_t o_raw[3], o_xfy, o_bfy, o_info, copy_bytes = L.size;
+	for (int c = 0; c < 3; ++c) o_raw[c] = L.take(cells * 2 + 64);
+	o_xfy = L.take(c64s * 2); o_bfy = L.take(c64s * 2); o_info = L.take(cells * 4 + 64);
+	if (!dev_lf) copy_bytes = L.size;
+	const size_t o_sharp = dev_lf ? L.take(cells * 2 + 64) : 0;
+	const size_t o_recs = L.take(cells * sizeof(DevVbRec)), o_gcnt = L.take((size_t) num_groups * 4), o_gbs = L.take(((size_t) num_groups + 1) * 4), o_ccnt = L.take(ngg * 28 * 4);
+	const size_t o_gb = L.take(cells * sizeof(DevGroupBlock)), o_vbs = L.take(cells * sizeof(DevVarblock));
+	size_t o_llf[3];
+	for (int c = 0; c < 3; ++c) o_llf[c] = L.take(cells * 4);
+
+	AStage &sg = t_astage[t_astage_next]; t_astage_next ^= 1;
+	if (!sg.done && hipEventCreateWithFlags(&sg.done, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { sg.done = nullptr; (void) hipGetLastError(); return nullptr; }
+	if (sg.pending) { (void) hipEventSynchronize(sg.done); sg.pending = false; }   // (the copy before last: long done)
+	if (!sg.mem.reserve(copy_bytes + 64, 0)) return nullptr;
+	uint8_t *stg = sg.mem.ptr;
+	bool dummy = false;
+	af->plan_block = cache_acquire(device, L.size, &af->plan_block_bytes, &dummy);
+	if (!af->plan_block) return nullptr;
+	uint8_t *pb = (uint8_t *) af->plan_block;
+
+	memcpy(stg + o_cs, h.cs, cs_size); memset(stg + o_cs + cs_size, 0, 32);   // the lane decoders read up to three words past the position they stop at
+	auto put = [&](size_t off, const void *src, size_t bytes) { if (bytes) memcpy(stg + off, src, bytes); };
+	put(o_u8, fp.pool_u8.data(), fp.pool_u8.size()); put(o_i32, fp.pool_i32.data(), fp.pool_i32.size() * 4); put(o_u64, fp.pool_u64.data(), fp.pool_u64.size() * 8);
+	put(o_cl, fp.clusters.data(), fp.clusters.size() * sizeof(DevCluster)); put(o_spec, fp.coeff_specs.data(), fp.coeff_specs.size() * sizeof(DevCodeSpec));
+	put(o_frame, &fp.frame, sizeof(DevFrame)); put(o_lfg, fp.lf_groups.data(), ngg * sizeof(DevLfGroup)); put(o_sec, fp.sections.data(), fp.sections.size() * sizeof(DevSection));
+	put(o_evr, fp.ev_range.data(), fp.ev_range.size() * 4); put(o_lso, fp.lf_section_off.data(), ngg * 4);
+	DevLfSlot *slots = (DevLfSlot *) (stg + o_slots);
+	memset(slots, 0, ngg * sizeof(DevLfSlot));
+	if (dev_lf) {
+		put(o_tree, &fp.lf_tree, sizeof(DevCoopTree)); put(o_alias, fp.lf_alias.data(), fp.lf_alias.size() * 8);
+		af->lf_tasks.resize(ngg);
+		for (size_t g = 0; g < ngg; ++g) {
+			const LfDeviceTask &t = tasks[g];
+			const DevLfGroup &gg = fp.lf_groups[g];
+			DevLfTask &d = af->lf_tasks[g];
+			memset(&d, 0, sizeof d);
+			d.codestream = pb + o_cs; d.tree = (const DevCoopTree *) (pb + o_tree); d.alias = (const uint64_t *) (pb + o_alias); d.log_alpha_size = fp.lf_log_alpha;
+			d.byte_off = (uint32_t) t.byte_off; d.size = (uint32_t) t.size; d.bit_off = t.bit_off;
+			d.w8 = t.w8; d.h8 = t.h8; d.w64 = t.w64; d.h64 = t.h64; d.sidx0 = t.sidx0; d.sidx2 = t.sidx2; d.nbvb_bits = t.nbvb_bits;
+			// streamed order Y, X, B -> the frame-wide planes X, Y, B
+			d.lf[0] = (int16_t *) (pb + o_raw[1]) + gg.cell_base; d.lf[1] = (int16_t *) (pb + o_raw[0]) + gg.cell_base; d.lf[2] = (int16_t *) (pb + o_raw[2]) + gg.cell_base;
+			d.xfromy = (int16_t *) (pb + o_xfy) + gg.c64_base; d.bfromy = (int16_t *) (pb + o_bfy) + gg.c64_base;
+			d.info = (int16_t *) (pb + o_info) + 2 * (size_t) gg.cell_base; d.info_capacity = (uint32_t) (2 * (size_t) gg.width8 * (size_t) gg.height8);
+			d.sharp = (int16_t *) (pb + o_sharp) + gg.cell_base;
+			d.result = (DevLfResult *) ((DevLfSlot *) (pb + o_slots) + g);   // (DevLfSlot begins with the two words of DevLfResult)
+		}
+	} else {
+		// the LfGroup streams on this thread (modular.cpp's fast paths); an error becomes the section's status and takes its place
+		// among the frame's sections like the device decoder's would
+		static const int XYB_FROM_STREAM[3] = {1, 0, 2};
+		for (size_t g = 0; g < ngg; ++g) {
+			const DevLfGroup &gg = fp.lf_groups[g];
+			try {
+				BitReader sr(h.cs + fr.toc.lf_groups[g].offset, fr.toc.lf_groups[g].size);
+				LfRaw raw;
+				read_lf_group_raw(sr, fr, fr.lf_groups[g], &raw);
+				const size_t n = (size_t) gg.width8 * (size_t) gg.height8, n64 = (size_t) gg.width64 * (size_t) gg.height64;
+				if (raw.lf[0].size() != n || raw.xfromy.size() != n64 || raw.bfromy.size() != n64) { slots[g].status = ERR_TODO; continue; }
+				for (int c = 0; c < 3; ++c) memcpy(stg + o_raw[c] + 2 * (size_t) gg.cell_base, raw.lf[XYB_FROM_STREAM[c]].data(), n * 2);
+				memcpy(stg + o_xfy + 2 * (size_t) gg.c64_base, raw.xfromy.data(), n64 * 2); memcpy(stg + o_bfy + 2 * (size_t) gg.c64_base, raw.bfromy.data(), n64 * 2);
+				slots[g].nb_varblocks = raw.nb_varblocks;
+				if ((size_t) raw.nb_varblocks > n) slots[g].status = ERR_VBLK;   // (more varblocks than cells: what the placement would find, j40.h:6689)
+				else memcpy(stg + o_info + 4 * (size_t) gg.cell_base, raw.info.data(), raw.info.size() * 2);
+			} catch (const DecodeError &e) { slots[g].status = e.code; }
+		}
+	}
+
+	// ---- the working set ----
+	Layout W;
+	const size_t stride = (cells * 64 + 63) & ~(size_t) 63;
+	const size_t coeff_bytes = af->sparse ? sizeof(CoeffEvent) * fp.ev_capacity : sizeof(float) * 3 * stride;
+	const size_t w_coeffs = W.take(coeff_bytes), w_blk = af->sparse ? W.take(16 * cells) : 0, w_nz = W.take((size_t) num_groups * 32 * 32 * 3), w_status = W.take(4 * fp.sections.size());
+	const size_t w_lz = fp.lz_window_size ? W.take(4 * (size_t) num_groups * fp.lz_window_size) : 0, w_lfs = W.take(4 * 3 * cells);
+	af->work_block = cache_acquire(device, W.size, &af->work_block_bytes, &dummy);
+	if (!af->work_block) return nullptr;
+	uint8_t *wb = (uint8_t *) af->work_block;
+
+	DevPlan &plan = af->plan;
+	memset(&plan, 0, sizeof plan);
+	plan.frame = (const DevFrame *) (pb + o_frame); plan.codestream = pb + o_cs; plan.pool_u8 = pb + o_u8; plan.pool_u16 = af->st->d_u16; plan.pool_i32 = (const int32_t *) (pb + o_i32);
+	plan.pool_u64 = (const uint64_t *) (pb + o_u64); plan.pool_f32 = af->st->d_f32; plan.clusters = (const DevCluster *) (pb + o_cl); plan.coeff_specs = (const DevCodeSpec *) (pb + o_spec);
+	plan.lf_groups = (const DevLfGroup *) (pb + o_lfg); plan.sections = (const DevSection *) (pb + o_sec);
+	plan.group_blocks = (const DevGroupBlock *) (pb + o_gb); plan.group_block_start = (const uint32_t *) (pb + o_gbs); plan.block_ctx_map_off = fp.block_ctx_map_off;
+	for (int c = 0; c < 3; ++c) { plan.llf[c] = (const float *) (pb + o_llf[c]); plan.lfraw[c] = (const int16_t *) (pb + o_raw[c]); }
+	plan.xfromy = (const int16_t *) (pb + o_xfy); plan.bfromy = (const int16_t *) (pb + o_bfy);
+	plan.ev_range = (const uint32_t *) (pb + o_evr);
+	if (af->sparse) { plan.events = (CoeffEvent *) (wb + w_coeffs); plan.block_events = (uint32_t *) (wb + w_blk); }
+	else for (int c = 0; c < 3; ++c) plan.coeffs[c] = (float *) (wb + w_coeffs) + (size_t) c * stride;
+	plan.coeff_stride = (uint32_t) stride;
+	plan.nonzeros = (int8_t *) (wb + w_nz); plan.status = (uint32_t *) (wb + w_status);
+	plan.lz_window_size = fp.lz_window_size; plan.lz_window = fp.lz_window_size ? (int32_t *) (wb + w_lz) : nullptr;
+
+	DevPlanBuild &bd = af->build;
+	bd = fp.build;
+	bd.pool_u8 = plan.pool_u8; bd.lf_groups = (DevLfGroup *) (pb + o_lfg); bd.lf_slots = (DevLfSlot *) (pb + o_slots);
+	for (int c = 0; c < 3; ++c) bd.lfraw[c] = plan.lfraw[c];
+	bd.xfromy = plan.xfromy; bd.bfromy = plan.bfromy; bd.vbinfo = (const int16_t *) (pb + o_info); bd.vb_recs = (DevVbRec *) (pb + o_recs);
+	bd.group_count = (uint32_t *) (pb + o_gcnt); bd.group_block_start = (uint32_t *) (pb + o_gbs); bd.class_count = (uint32_t *) (pb + o_ccnt);
+	bd.group_blocks = (DevGroupBlock *) (pb + o_gb); bd.vb_sorted = (DevVarblock *) (pb + o_vbs); bd.lf_section_off = (const uint32_t *) (pb + o_lso);
+	bd.lf_scratch = (float *) (wb + w_lfs); bd.lf_smooth = fp.lf_smooth ? 1 : 0; bd.cells = (uint32_t) cells;
+	for (int c = 0; c < 3; ++c) bd.inv_m_lf[c] = fp.inv_m_lf[c];
+	// (class_start and verdict belong to the batch: j40hip_abatch_launch)
+
+	if (hipEventCreateWithFlags(&af->uploaded, hipEventDisableTiming) != hipSuccess) { af->uploaded = nullptr; (void) hipGetLastError(); return nullptr; }
+	if (hipMemcpyAsync(pb, stg, copy_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return nullptr;
+	bool ok = hipEventRecord(sg.done, stream) == hipSuccess;
+	sg.pending = ok;
+	// recycled memory: no entry of the per-block table may point outside the event list (a section that fails leaves entries unwritten)
+	ok = ok && (!af->sparse || hipMemsetAsync(plan.block_events, 0, 16 * cells, stream) == hipSuccess);
+	ok = ok && hipEventRecord(af->uploaded, stream) == hipSuccess;
+	if (!ok) { (void) hipStreamSynchronize(stream); (void) hipGetLastError(); return nullptr; }   // (nothing may be in flight on blocks that go back to the cache)
+	return af.release();
+}
+
+j40hip_aframe *j40hip_aframe_prepare(const void *buf, size_t size, int device, hipStream_t stream, int lf_on_device) {
+	try { return aframe_prepare_body(buf, size, device, stream, lf_on_device); }
+	catch (const DecodeError &) { return nullptr; }
+	catch (const std::exception &) { return nullptr; }
+}
+
+// ---- batches ----
+
+struct j40hip_abatch {
+	int device = 0;
+	PinnedStage host;                 // the batch's arrays, staged; one copy moves them
+	void *dev = nullptr; size_t dev_cap = 0;
+	uint32_t *verdict_host = nullptr; size_t verdict_cap = 0;   // pinned, [frames][4]
+	int32_t nframes = 0;
+	float *large_scratch = nullptr;
+	std::vector<hipStream_t> side; std::vector<hipEvent_t> side_done; hipEvent_t fork = nullptr;
+	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	int cus = 256;
+};
+
+j40hip_abatch *j40hip_abatch_create(int device) {
+	if (hipSetDevice(device) != hipSuccess) return nullptr;
+	j40hip_abatch *b = new j40hip_abatch();
+	b->device = device;
+	bool ok = true;
+	for (auto &e : b->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+	ok = ok && hipEventCreateWithFlags(&b->fork, hipEventDisableTiming) == hipSuccess;
+	int nside = 8;
+	if (const char *e = getenv("J40HIP_SIDE_STREAMS")) nside = std::max(0, std::min(16, atoi(e)));
+	for (int i = 0; i < nside && ok; ++i) {
+		hipStream_t st = nullptr; hipEvent_t ev = nullptr;
+		ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+		if (ok) { b->side.push_back(st); b->side_done.push_back(ev); }
+	}
+	ok = ok && hipMalloc((void **) &b->large_scratch, (size_t) K2_LARGE_WGS * 6 * 65536 * sizeof(float)) == hipSuccess;
+	hipDeviceProp_t prop;
+	if (ok && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) b->cus = prop.multiProcessorCount;
+	if (!ok) { (void) hipGetLastError(); j40hip_abatch_free(b); return nullptr; }
+	return b;
+}
+
+void j40hip_abatch_free(j40hip_abatch *b) {
+	if (!b) return;
+	(void) hipSetDevice(b->device);
+	b->host.release();
+	if (b->dev) (void) hipFree(b->dev);
+	if (b->verdict_host) (void) hipHostFree(b->verdict_host);
+	if (b->large_scratch) (void) hipFree(b->large_scratch);
+	for (auto &e : b->ev) if (e) (void) hipEventDestroy(e);
+	for (auto &e : b->side_done) if (e) (void) hipEventDestroy(e);
+	for (auto &s : b->side) if (s) (void) hipStreamDestroy(s);
+	if (b->fork) (void) hipEventDestroy(b->fork);
+	delete b;
+}
+
+static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frames, int n, void *const *rgba_dev, const size_t *stride_bytes, hipStream_t s) {
+	if (!b || n <= 0) return ERR_GPU;
+	if (hipSetDevice(b->device) != hipSuccess) return ERR_GPU;
+	// geometry of the entropy launch (runtime.hip batch_assign): up to 64 sections of one frame per wavefront, 1 / 2 / 4 wavefronts
+	// per workgroup sharing one copy of their frame's tables
+	bool lanes_fast = true, tables_in_lds = true; uint32_t lanes_lds = 0, generic_lds = 0;
+	int32_t total_waves = 0, nlf = 0, ntasks = 0, max_lf_cells = 0; size_t cells_total = 0, max_frame_cells = 0;
+	for (int i = 0; i < n; ++i) {
+		const j40hip_aframe *f = frames[i];
+		if (!f || f->device != b->device) return ERR_GPU;
+		lanes_fast = lanes_fast && f->hf.lanes_fast; tables_in_lds = tables_in_lds && f->hf.tables_fit_lds; lanes_lds = std::max(lanes_lds, f->hf.lanes_lds_bytes);
+		total_waves += (f->num_groups + 63) / 64; nlf += f->num_lf_groups; ntasks += (int32_t) f->lf_tasks.size();
+		max_lf_cells = std::max(max_lf_cells, f->max_lf_cells); cells_total += f->cells; max_frame_cells = std::max(max_frame_cells, f->cells);
+	}
+	if (const char *e = getenv("J40HIP_GENERIC_LANES")) if (atoi(e)) lanes_fast = false;
+	int32_t waves_per_wg = lanes_fast ? (total_waves <= 2 * b->cus ? 1 : total_waves <= 4 * b->cus ? 2 : 4) : 1;
+	if (const char *e = getenv("J40HIP_WAVES_PER_WG")) if (lanes_fast) waves_per_wg = std::max(1, std::min(4, atoi(e)));
+	std::vector<HfLaneWork> work;
+	for (int i = 0; i < n; ++i) {
+		for (int32_t g = 0; g < frames[i]->num_groups; g += 64) work.push_back({i, g, std::min(64, frames[i]->num_groups - g), 0});
+		while (work.size() % (size_t) waves_per_wg) work.push_back({i, 0, 0, 0});   // a workgroup stays on one frame
+		HfLaunchInfo info = frames[i]->hf; info.tables_fit_lds = tables_in_lds;
+		generic_lds = std::max(generic_lds, hf_lanes_lds_bytes(info));
+	}
+	// ---- the batch's arrays: one staged blob, one copy ----
+	Layout L;
+	const size_t o_plans = L.take(sizeof(DevPlan) * (size_t) n), o_builds = L.take(sizeof(DevPlanBuild) * (size_t) n), o_k2 = L.take(sizeof(K2Frame) * (size_t) n);
+	const size_t o_lfs = L.take(sizeof(DevBatchLf) * (size_t) nlf), o_tasks = L.take(sizeof(DevLfTask) * (size_t) ntasks), o_work = L.take(sizeof(HfLaneWork) * work.size());
+	const size_t copy_bytes = L.size;
+	const size_t o_tiles = L.take(4 * (size_t) K2_NUM_BATCH_LAUNCHES * ((size_t) n + 1)), o_verdict = L.take(16 * (size_t) n);
+	if (!b->host.reserve(copy_bytes + 64, 0)) return ERR_MEM;
+	if (L.size > b->dev_cap) {
+		if (b->dev) (void) hipFree(b->dev);
+		b->dev = nullptr; b->dev_cap = 0;
+		if (hipMalloc(&b->dev, L.size * 2) != hipSuccess) { (void) hipGetLastError(); return ERR_MEM; }
+		b->dev_cap = L.size * 2;
+	}
+	if ((size_t) n * 4 > b->verdict_cap) {
+		if (b->verdict_host) (void) hipHostFree(b->verdict_host);
+		b->verdict_host = nullptr; b->verdict_cap = 0;
+		if (hipHostMalloc((void **) &b->verdict_host, 16 * (size_t) n * 2, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); return ERR_MEM; }
+		b->verdict_cap = (size_t) n * 4 * 2;
+	}
+	uint8_t *hb = b->host.ptr, *db = (uint8_t *) b->dev;
+	DevPlan *h_plans = (DevPlan *) (hb + o_plans); DevPlanBuild *h_builds = (DevPlanBuild *) (hb + o_builds); K2Frame *h_k2 = (K2Frame *) (hb + o_k2);
+	DevBatchLf *h_lfs = (DevBatchLf *) (hb + o_lfs); DevLfTask *h_tasks = (DevLfTask *) (hb + o_tasks);
+	const DevPlan *d_plans = (const DevPlan *) (db + o_plans); const DevPlanBuild *d_builds = (const DevPlanBuild *) (db + o_builds); K2Frame *d_k2 = (K2Frame *) (db + o_k2);
+	const DevBatchLf *d_lfs = (const DevBatchLf *) (db + o_lfs); const DevLfTask *d_tasks = (const DevLfTask *) (db + o_tasks); const HfLaneWork *d_work = (const HfLaneWork *) (db + o_work);
+	size_t at_lf = 0, at_task = 0;
+	for (int i = 0; i < n; ++i) {
+		const j40hip_aframe *f = frames[i];
+		h_plans[i] = f->plan;
+		h_builds[i] = f->build;
+		h_builds[i].class_start = d_k2[i].class_start; h_builds[i].verdict = (uint32_t *) (db + o_verdict) + 4 * (size_t) i;
+		K2Frame &k = h_k2[i];
+		memset(&k, 0, sizeof k);
+		k.plan = f->plan; k.sorted = f->build.vb_sorted; k.large_scratch = nullptr; k.rgba = (uint8_t *) rgba_dev[i]; k.stride = stride_bytes[i];
+		for (int32_t g = 0; g < f->num_lf_groups; ++g) h_lfs[at_lf++] = DevBatchLf{i, g};
+		for (const DevLfTask &t : f->lf_tasks) h_tasks[at_task++] = t;
+	}
+	memcpy(hb + o_work, work.data(), sizeof(HfLaneWork) * work.size());
+	for (int i = 0; i < n; ++i) if (hipStreamWaitEvent(s, frames[i]->uploaded, 0) != hipSuccess) return ERR_GPU;
+	if (hipMemcpyAsync(db, hb, copy_bytes, hipMemcpyHostToDevice, s) != hipSuccess) return ERR_GPU;
+	(void) hipEventRecord(b->ev[0], s);
+	if (ntasks) launch_lf_groups(d_tasks, ntasks, s);
+	launch_plan_build(d_builds, d_lfs, n, nlf, max_lf_cells, s);
+	launch_lf_tail_batch(d_plans, d_builds, d_lfs, n, nlf, max_lf_cells, max_frame_cells, s);
+	for (int i = 0; i < n; ++i) if (!frames[i]->sparse && hipMemsetAsync(frames[i]->plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) frames[i]->plan.coeff_stride, s) != hipSuccess) return ERR_GPU;
+	(void) hipEventRecord(b->ev[1], s);
+	if (lanes_fast) launch_hf_lanes(d_plans, d_work, (int32_t) work.size(), waves_per_wg, lanes_lds, s);
+	else launch_hf_entropy_lanes(d_plans, d_work, (int32_t) work.size(), tables_in_lds, generic_lds, s);
+	(void) hipEventRecord(b->ev[2], s);
+	launch_vardct_batch(d_k2, n, (int32_t *) (db + o_tiles), cells_total, b->large_scratch, s, b->side.data(), (int) b->side.size(), b->fork, b->side_done.data());
+	(void) hipEventRecord(b->ev[3], s);
+	launch_plan_verdict(d_builds, d_plans, n, s);
+	if (hipMemcpyAsync(b->verdict_host, db + o_verdict, 16 * (size_t) n, hipMemcpyDeviceToHost, s) != hipSuccess) return ERR_GPU;
+	b->nframes = n;
+	return hipGetLastError() == hipSuccess ? 0 : ERR_GPU;
+}
+
+uint32_t j40hip_abatch_launch(j40hip_abatch *b, j40hip_aframe *const *frames, int n, void *const *rgba_dev, const size_t *stride_bytes, hipStream_t stream) {
+	try { return abatch_launch_body(b, frames, n, rgba_dev, stride_bytes, stream); } catch (const std::exception &) { return ERR_MEM; }
+}
+
+void j40hip_abatch_result(const j40hip_abatch *b, int i, uint32_t *code, int *redo) {
+	if (!b || i < 0 || i >= b->nframes) { *code = ERR_GPU; *redo = 0; return; }
+	*code = b->verdict_host[4 * (size_t) i]; *redo = b->verdict_host[4 * (size_t) i + 1] != 0;
+}
+
+uint32_t j40hip_abatch_elapsed(j40hip_abatch *b, float *ms3) {
+	if (!b || hipEventSynchronize(b->ev[3]) != hipSuccess) return ERR_GPU;
+	(void) hipEventElapsedTime(&ms3[0], b->ev[0], b->ev[1]); (void) hipEventElapsedTime(&ms3[1], b->ev[1], b->ev[2]); (void) hipEventElapsedTime(&ms3[2], b->ev[2], b->ev[3]);
+	return 0;
+}

@@ -13,13 +13,21 @@ void launch_hf_lanes(const DevPlan *plans, const HfLaneWork *work, int32_t num_w
 void launch_vardct_class(const DevPlan &plan, int32_t dctsel, const DevVarblock *list, int32_t count, float *large_scratch, uint8_t *rgba, size_t stride, hipStream_t stream);
 
 
-void launch_vardct_batch(const K2Frame *frames_dev, int32_t nframes, const int32_t *host_class_start, hipStream_t stream);
+// every frame of a batch: one persistent launch per class of transforms, spread over `nside` side streams that fork from and join
+// `stream` (nside = 0: all on `stream`). tile_prefix_dev: K2_NUM_BATCH_LAUNCHES * (nframes + 1) ints of scratch
+enum { K2_NUM_BATCH_LAUNCHES = 15, K2_LARGE_WGS = 64 };
+void launch_vardct_batch(const K2Frame *frames_dev, int32_t nframes, int32_t *tile_prefix_dev, size_t cells_total, float *large_scratch, hipStream_t stream, hipStream_t *side, int nside, hipEvent_t fork, hipEvent_t *side_done);
 void launch_vardct_frame(const DevPlan &plan, const int32_t *class_start, const DevVarblock *sorted, float *large_scratch, uint8_t *rgba, size_t stride, hipStream_t stream);
 
 // LfGroup tail on the device (device/lf_tail_kernels.hip)
 void upload_lf_tail_tables(const float *half_secants, const float *lf2llf, hipStream_t stream);
 void launch_lf_tail(const DevPlan &plan, int32_t num_lf_groups, int32_t max_cells, size_t cells, float *lfs, const DevVarblock *sorted, int32_t count, int32_t first_large, int32_t smooth,
 		const float inv_m_lf[3], hipStream_t stream);
+
+void launch_lf_tail_batch(const DevPlan *plans, const DevPlanBuild *builds, const DevBatchLf *lfs, int32_t nframes, int32_t nlf, int32_t max_lf_cells, size_t max_frame_cells, hipStream_t stream);
+// the LF-dependent half of the plan of every frame of a batch (device/plan_kernels.hip)
+void launch_plan_build(const DevPlanBuild *builds, const DevBatchLf *lfs, int32_t nframes, int32_t nlf, int32_t max_lf_cells, hipStream_t stream);
+void launch_plan_verdict(const DevPlanBuild *builds, const DevPlan *plans, int32_t nframes, hipStream_t stream);
 
 void launch_kat_srgb_u8(const float *v, size_t n, uint8_t *out, hipStream_t stream);
 

@@ -320,15 +320,25 @@ void launch_hf_entropy_lanes(const DevPlan *plans, const HfLaneWork *work, int32
 // ------------------------------------------------------------------------------------------------
 // K2 common pieces
 
-// batch-wide launches (BATCH): blockIdx.y picks the frame, whose plan, list, count and output replace the kernel arguments;
-// returns false for workgroups past the end of their frame's list (the grid is sized for the longest one)
+// batch-wide launches (BATCH) are persistent: a launch covers one class of transforms over every frame of the batch, its work
+// cut into tiles of `per_wg` varblocks; tile_prefix[f] = tiles of the frames before frame f (built on the device by k_k2_tiles
+// from the frames' class_start, which the device-side plan build writes: the host never learns the counts). Workgroup b takes
+// tiles b, b + gridDim.x, ...: k2_bind finds tile `tile`'s frame and replaces the kernel arguments with that frame's plan, list,
+// count and output; `first` = the tile's first varblock. Returns false past the last tile.
 template <bool BATCH>
-__device__ __forceinline__ bool k2_bind(const K2Frame *batch, int32_t class_a, int32_t class_b, int32_t per_wg, const DevVarblock *&list, int32_t &count, uint8_t *&rgba, size_t &stride, float *&scratch) {
-	if (!BATCH) return true;
-	const K2Frame &fr = batch[blockIdx.y];
+__device__ __forceinline__ bool k2_bind(const K2Frame *batch, const int32_t *tile_prefix, int32_t nframes, int32_t tile, int32_t class_a, int32_t class_b, int32_t per_wg,
+		const DevVarblock *&list, int32_t &count, uint8_t *&rgba, size_t &stride, float *&scratch, int32_t &frame, int32_t &first) {
+	if (!BATCH) { frame = 0; first = (int32_t) blockIdx.x * per_wg; return true; }
+	if (tile >= tile_prefix[nframes]) return false;
+	int32_t lo = 0, hi = nframes - 1;   // last frame whose prefix <= tile
+	while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (tile_prefix[mid] <= tile) lo = mid; else hi = mid - 1; }
+	frame = lo;
+	const K2Frame &fr = batch[lo];
 	const int32_t a = fr.class_start[class_a];
-	list = fr.sorted + a; count = fr.class_start[class_b] - a; rgba = fr.rgba; stride = fr.stride; scratch = fr.large_scratch;
-	return (int32_t) blockIdx.x * per_wg < count;
+	list = fr.sorted + a; count = fr.class_start[class_b] - a; rgba = fr.rgba; stride = fr.stride;
+	(void) scratch;   // (the 128/256-sized transforms' scratch belongs to the workgroup, not to the frame)
+	first = (tile - tile_prefix[lo]) * per_wg;
+	return true;
 }
 
 // exclusive prefix sums of the per-block event counts held by lanes 0..NB-1 of the first wavefront (`mine`, 0 for lanes
@@ -352,99 +362,103 @@ __device__ __forceinline__ void stage_event_prefix(uint32_t mine, uint32_t *pref
 
 template <int LOGR, int LOGC, int NB, bool BATCH>
 __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan_arg, const DevVarblock *list, int32_t count, int32_t param_idx, int32_t order_idx, uint8_t *rgba, size_t stride_bytes,
-		const K2Frame *batch, int32_t class_a, int32_t class_b) {
-	const DevPlan &plan = BATCH ? batch[blockIdx.y].plan : plan_arg;
-	{ float *unused = nullptr; if (!k2_bind<BATCH>(batch, class_a, class_b, NB, list, count, rgba, stride_bytes, unused)) return; }
+		const K2Frame *batch, const int32_t *tile_prefix, int32_t nframes, int32_t class_a, int32_t class_b) {
 	constexpr int R = 1 << LOGR, C = 1 << LOGC, P = C + 1, TILE = R * P;
 	constexpr int LONG = R > C ? R : C;                  // columns of the canonical (short side = rows) layout
 	constexpr int VH8 = (R < C ? R : C) / 8, VW8 = LONG / 8;
 	extern __shared__ __attribute__((aligned(16))) float lds[];   // [NB][3][TILE]
-	const DevFrame &f = *plan.frame;
 	const int32_t tid = threadIdx.x, nthreads = blockDim.x;
-	const int32_t first = blockIdx.x * NB;
-	const int32_t nb = min(NB, count - first);
-	const float *dq = plan.pool_f32 + f.dq_off[param_idx];
-	const int32_t dq_size = R * C;
-	const ColourConsts cc = load_colour_consts(f);
-	const float qbias0 = f.quant_bias[0], qbias1 = f.quant_bias[1], qbias2 = f.quant_bias[2], qbias_num = f.quant_bias_num, kx_lf = f.kx_lf, kb_lf = f.kb_lf;
 	__shared__ VbGeom geom[NB];
 	__shared__ uint32_t g_be[NB][4];   // each block's entry of DevPlan::block_events
 	__shared__ size_t g_out[NB];       // byte offset of each block's top-left pixel in the output
 	__shared__ uint32_t ev_prefix[NB + 1];   // events of the blocks before each block (tiles_scatter_events)
 	J40_STAGE_SRGB_THRESHOLDS(f);
-	uint32_t nevents = 0;
-	if (tid < nb) {
-		const DevVarblock vb = list[first + tid];
-		const VbGeom g = varblock_geometry(plan, vb);
-		geom[tid] = g; g_out[tid] = (size_t) g.py * stride_bytes + (size_t) g.px * 4;
-		if (f.sparse_coeffs) { const uint32_t *be = plan.block_events + 4 * (size_t) vb.blk; for (int k = 0; k < 4; ++k) g_be[tid][k] = be[k]; nevents = be[1] + be[2] + be[3]; }
-	}
-	stage_event_prefix<NB>(nevents, ev_prefix, tid);
 	constexpr int N = R * C;
 	constexpr int PAR = N >= 256 ? 1 : 256 / N;   // blocks a pass of the 256 lanes covers
 	constexpr int PER = N >= 256 ? N / 256 : 1;   // pixel positions per lane
-	// ---- load: dequantise + chroma-from-luma + LLF into the LDS tiles ----
-	if (f.sparse_coeffs) {
-		// single-pass frames: zero the tiles, then scatter the blocks' coefficient events into them (one lane per event over
-		// the whole workgroup: the work is proportional to the non-zeros; chroma-from-luma rides along) and write the LLF
-		// corners (vardct_dev.h). No event lands in an LLF corner, so the two need no barrier between them.
-		for (int32_t w = tid; w < nb * 3 * TILE; w += nthreads) lds[w] = 0.0f;
-		__syncthreads();
-		const uint16_t *order = plan.pool_u16 + f.order_off[order_idx * 3];   // pass 0; the three channels' orders are consecutive
-		const float *dq_scan = plan.pool_f32 + f.dq_scan_off[param_idx];
-		const TileMap map = {R, C, P, 0};
-		const float qbias[3] = {qbias0, qbias1, qbias2};
-		tiles_scatter_events<NB>(plan, geom, g_be, ev_prefix, order, dq_scan, nullptr, N, map, lds, 3 * TILE, TILE, qbias, qbias_num, tid, nthreads);
-		tiles_fill_llf(plan, geom, nb, LONG, VH8, VW8, map, lds, 3 * TILE, TILE, kx_lf, kb_lf, tid, nthreads);
-	} else {
-		// multi-pass frames: dense planes in canonical order, coalesced over the canonical index
-		__syncthreads();
-		for (int32_t w = tid; w < nb * R * C; w += nthreads) {
-			const int32_t b = w / (R * C), i = w - b * (R * C);
-			const VbGeom &g = geom[b];
-			float v[3];
-			load_coeff3(plan, g, dq, dq_size, i, LONG, VH8, VW8, v);
-			const int32_t r = C > R ? i / C : i % R, c = C > R ? i % C : i / R;
-			float *t = lds + (size_t) b * 3 * TILE + r * P + c;
-			t[0] = v[0]; t[TILE] = v[1]; t[2 * TILE] = v[2];
+	for (int32_t tile = blockIdx.x; ; tile += gridDim.x) {
+		int32_t frame, first;
+		{ float *unused = nullptr; if (!k2_bind<BATCH>(batch, tile_prefix, nframes, tile, class_a, class_b, NB, list, count, rgba, stride_bytes, unused, frame, first)) break; }
+		const DevPlan &plan = BATCH ? batch[frame].plan : plan_arg;
+		const DevFrame &f = *plan.frame;
+		const int32_t nb = min(NB, count - first);
+		const float *dq = plan.pool_f32 + f.dq_off[param_idx];
+		const int32_t dq_size = R * C;
+		const ColourConsts cc = load_colour_consts(f);
+		const float qbias0 = f.quant_bias[0], qbias1 = f.quant_bias[1], qbias2 = f.quant_bias[2], qbias_num = f.quant_bias_num, kx_lf = f.kx_lf, kb_lf = f.kb_lf;
+		uint32_t nevents = 0;
+		if (tid < nb) {
+			const DevVarblock vb = list[first + tid];
+			const VbGeom g = varblock_geometry(plan, vb);
+			geom[tid] = g; g_out[tid] = (size_t) g.py * stride_bytes + (size_t) g.px * 4;
+			if (f.sparse_coeffs) { const uint32_t *be = plan.block_events + 4 * (size_t) vb.blk; for (int k = 0; k < 4; ++k) g_be[tid][k] = be[k]; nevents = be[1] + be[2] + be[3]; }
 		}
-	}
-	__syncthreads();
-	// ---- pass 1: IDCT of length C along c, one lane per (block, channel, r) ----
-	for (int32_t w = tid; w < nb * 3 * R; w += nthreads) {
-		float *row = lds + (size_t) (w / R) * TILE + (w % R) * P;
-		float x[C];
-#pragma unroll
-		for (int k = 0; k < C; ++k) x[k] = row[k];
-		Idct1D<C>::run(x, c_half_secants);
-#pragma unroll
-		for (int k = 0; k < C; ++k) row[k] = x[k];
-	}
-	__syncthreads();
-	// ---- pass 2: IDCT of length R along r, one lane per (block, channel, x) ----
-	for (int32_t w = tid; w < nb * 3 * C; w += nthreads) {
-		float *col = lds + (size_t) (w / C) * TILE + (w % C);
-		float x[R];
-#pragma unroll
-		for (int k = 0; k < R; ++k) x[k] = col[k * P];
-		Idct1D<R>::run(x, c_half_secants);
-#pragma unroll
-		for (int k = 0; k < R; ++k) col[k * P] = x[k];
-	}
-	__syncthreads();
-	// ---- colour + pack: a lane owns pixel position (y, x) for every block of the workgroup ----
-#pragma unroll
-	for (int k = 0; k < PER; ++k) {
-		const int32_t p = N >= 256 ? tid + 256 * k : tid % N;
-		const int32_t y = p / C, x = p % C;
-		const uint32_t in_block = (uint32_t) y * (uint32_t) stride_bytes + (uint32_t) x * 4u;   // a block spans < 4 GB of output
-		for (int32_t b = N >= 256 ? 0 : tid / N; b < nb; b += PAR) {
-			const VbGeom &g = geom[b];
-			if (y >= g.effh || x >= g.effw) continue;
-			const float *t = lds + (size_t) b * 3 * TILE + y * P + x;
-			const uint32_t px = xyb_to_rgba8(t[0], t[TILE], t[2 * TILE], cc, srgb_thr);
-			__builtin_nontemporal_store(px, (uint32_t *) (rgba + g_out[b] + in_block));   // written once, never read here: keep it out of the L2's way (-2 %)
+		stage_event_prefix<NB>(nevents, ev_prefix, tid);
+		// ---- load: dequantise + chroma-from-luma + LLF into the LDS tiles ----
+		if (f.sparse_coeffs) {
+			// single-pass frames: zero the tiles, then scatter the blocks' coefficient events into them (one lane per event over
+			// the whole workgroup: the work is proportional to the non-zeros; chroma-from-luma rides along) and write the LLF
+			// corners (vardct_dev.h). No event lands in an LLF corner, so the two need no barrier between them.
+			for (int32_t w = tid; w < nb * 3 * TILE; w += nthreads) lds[w] = 0.0f;
+			__syncthreads();
+			const uint16_t *order = plan.pool_u16 + f.order_off[order_idx * 3];   // pass 0; the three channels' orders are consecutive
+			const float *dq_scan = plan.pool_f32 + f.dq_scan_off[param_idx];
+			const TileMap map = {R, C, P, 0};
+			const float qbias[3] = {qbias0, qbias1, qbias2};
+			tiles_scatter_events<NB>(plan, geom, g_be, ev_prefix, order, dq_scan, nullptr, N, map, lds, 3 * TILE, TILE, qbias, qbias_num, tid, nthreads);
+			tiles_fill_llf(plan, geom, nb, LONG, VH8, VW8, map, lds, 3 * TILE, TILE, kx_lf, kb_lf, tid, nthreads);
+		} else {
+			// multi-pass frames: dense planes in canonical order, coalesced over the canonical index
+			__syncthreads();
+			for (int32_t w = tid; w < nb * R * C; w += nthreads) {
+				const int32_t b = w / (R * C), i = w - b * (R * C);
+				const VbGeom &g = geom[b];
+				float v[3];
+				load_coeff3(plan, g, dq, dq_size, i, LONG, VH8, VW8, v);
+				const int32_t r = C > R ? i / C : i % R, c = C > R ? i % C : i / R;
+				float *t = lds + (size_t) b * 3 * TILE + r * P + c;
+				t[0] = v[0]; t[TILE] = v[1]; t[2 * TILE] = v[2];
+			}
 		}
+		__syncthreads();
+		// ---- pass 1: IDCT of length C along c, one lane per (block, channel, r) ----
+		for (int32_t w = tid; w < nb * 3 * R; w += nthreads) {
+			float *row = lds + (size_t) (w / R) * TILE + (w % R) * P;
+			float x[C];
+#pragma unroll
+			for (int k = 0; k < C; ++k) x[k] = row[k];
+			Idct1D<C>::run(x, c_half_secants);
+#pragma unroll
+			for (int k = 0; k < C; ++k) row[k] = x[k];
+		}
+		__syncthreads();
+		// ---- pass 2: IDCT of length R along r, one lane per (block, channel, x) ----
+		for (int32_t w = tid; w < nb * 3 * C; w += nthreads) {
+			float *col = lds + (size_t) (w / C) * TILE + (w % C);
+			float x[R];
+#pragma unroll
+			for (int k = 0; k < R; ++k) x[k] = col[k * P];
+			Idct1D<R>::run(x, c_half_secants);
+#pragma unroll
+			for (int k = 0; k < R; ++k) col[k * P] = x[k];
+		}
+		__syncthreads();
+		// ---- colour + pack: a lane owns pixel position (y, x) for every block of the workgroup ----
+#pragma unroll
+		for (int k = 0; k < PER; ++k) {
+			const int32_t p = N >= 256 ? tid + 256 * k : tid % N;
+			const int32_t y = p / C, x = p % C;
+			const uint32_t in_block = (uint32_t) y * (uint32_t) stride_bytes + (uint32_t) x * 4u;   // a block spans < 4 GB of output
+			for (int32_t b = N >= 256 ? 0 : tid / N; b < nb; b += PAR) {
+				const VbGeom &g = geom[b];
+				if (y >= g.effh || x >= g.effw) continue;
+				const float *t = lds + (size_t) b * 3 * TILE + y * P + x;
+				const uint32_t px = xyb_to_rgba8(t[0], t[TILE], t[2 * TILE], cc, srgb_thr);
+				__builtin_nontemporal_store(px, (uint32_t *) (rgba + g_out[b] + in_block));   // written once, never read here: keep it out of the L2's way (-2 %)
+			}
+		}
+		if (!BATCH) break;
+		__syncthreads();   // the next tile reuses geom / the LDS tiles
 	}
 }
 
@@ -454,64 +468,69 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan_arg, const DevV
 // take three rounds per phase. Tiles are 65 floats apart (odd: the eight tiles of a wavefront start in different banks).
 
 template <int NB, bool BATCH>
-__global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const DevVarblock *list, int32_t count, uint8_t *rgba, size_t stride_bytes, const K2Frame *batch, int32_t class_a, int32_t class_b) {
-	const DevPlan &plan = BATCH ? batch[blockIdx.y].plan : plan_arg;
-	{ float *unused = nullptr; if (!k2_bind<BATCH>(batch, class_a, class_b, NB, list, count, rgba, stride_bytes, unused)) return; }
+__global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const DevVarblock *list, int32_t count, uint8_t *rgba, size_t stride_bytes, const K2Frame *batch, const int32_t *tile_prefix, int32_t nframes,
+		int32_t class_a, int32_t class_b) {
 	constexpr int P = 65;
 	__shared__ float tiles[NB * 3 * P];   // coefficients in, samples out
 	__shared__ float work[NB * 3 * P];    // between the two phases
-	const DevFrame &f = *plan.frame;
 	const int32_t tid = threadIdx.x, nthreads = blockDim.x;
-	const int32_t first = blockIdx.x * NB;
-	const int32_t nb = min(NB, count - first);
 	__shared__ VbGeom geom[NB];
 	J40_STAGE_SRGB_THRESHOLDS(f);
-	const ColourConsts cc = load_colour_consts(f);
 	__shared__ int32_t g_param[NB], g_sel[NB];
 	__shared__ uint32_t g_be[NB][4], g_dq[NB], ev_prefix[NB + 1];
-	uint32_t nevents = 0;
-	if (tid < nb) {
-		const DevVarblock vb = list[first + tid];
-		geom[tid] = varblock_geometry(plan, vb);
-		if (f.sparse_coeffs) { const uint32_t *be = plan.block_events + 4 * (size_t) vb.blk; for (int k = 0; k < 4; ++k) g_be[tid][k] = be[k]; nevents = be[1] + be[2] + be[3]; }
-		g_sel[tid] = vb.dctsel;
-		g_param[tid] = vb.dctsel == 1 ? 1 : vb.dctsel == 2 ? 2 : vb.dctsel == 3 ? 3 : vb.dctsel <= 13 ? 9 : 10;
-		g_dq[tid] = (uint32_t) f.dq_scan_off[g_param[tid]];
-	}
-	stage_event_prefix<NB>(nevents, ev_prefix, tid);
-	if (f.sparse_coeffs) {
-		for (int32_t w = tid; w < nb * 3 * P; w += nthreads) tiles[w] = 0.0f;
+	for (int32_t tile_at = blockIdx.x; ; tile_at += gridDim.x) {
+		int32_t frame, first;
+		{ float *unused = nullptr; if (!k2_bind<BATCH>(batch, tile_prefix, nframes, tile_at, class_a, class_b, NB, list, count, rgba, stride_bytes, unused, frame, first)) break; }
+		const DevPlan &plan = BATCH ? batch[frame].plan : plan_arg;
+		const DevFrame &f = *plan.frame;
+		const int32_t nb = min(NB, count - first);
+		const ColourConsts cc = load_colour_consts(f);
+		uint32_t nevents = 0;
+		if (tid < nb) {
+			const DevVarblock vb = list[first + tid];
+			geom[tid] = varblock_geometry(plan, vb);
+			if (f.sparse_coeffs) { const uint32_t *be = plan.block_events + 4 * (size_t) vb.blk; for (int k = 0; k < 4; ++k) g_be[tid][k] = be[k]; nevents = be[1] + be[2] + be[3]; }
+			g_sel[tid] = vb.dctsel;
+			g_param[tid] = vb.dctsel == 1 ? 1 : vb.dctsel == 2 ? 2 : vb.dctsel == 3 ? 3 : vb.dctsel <= 13 ? 9 : 10;
+			g_dq[tid] = (uint32_t) f.dq_scan_off[g_param[tid]];
+		}
+		stage_event_prefix<NB>(nevents, ev_prefix, tid);
+		if (f.sparse_coeffs) {
+			for (int32_t w = tid; w < nb * 3 * P; w += nthreads) tiles[w] = 0.0f;
+			__syncthreads();
+			const uint16_t *order = plan.pool_u16 + f.order_off[1 * 3];   // all 8x8 specials share order 1
+			const TileMap map = {8, 8, 8, 1};
+			const float qbias[3] = {f.quant_bias[0], f.quant_bias[1], f.quant_bias[2]};
+			tiles_scatter_events<NB>(plan, geom, g_be, ev_prefix, order, plan.pool_f32, g_dq, 64, map, tiles, 3 * P, P, qbias, f.quant_bias_num, tid, nthreads);
+			tiles_fill_llf(plan, geom, nb, 8, 1, 1, map, tiles, 3 * P, P, f.kx_lf, f.kb_lf, tid, nthreads);
+		} else {
+			__syncthreads();
+			for (int32_t w = tid; w < nb * 64; w += nthreads) {
+				const int32_t b = w >> 6, i = w & 63;
+				float v[3];
+				load_coeff3(plan, geom[b], plan.pool_f32 + f.dq_off[g_param[b]], 64, i, 8, 1, 1, v);
+				float *t = tiles + (size_t) b * 3 * P + i;
+				t[0] = v[0]; t[P] = v[1]; t[2 * P] = v[2];
+			}
+		}
 		__syncthreads();
-		const uint16_t *order = plan.pool_u16 + f.order_off[1 * 3];   // all 8x8 specials share order 1
-		const TileMap map = {8, 8, 8, 1};
-		const float qbias[3] = {f.quant_bias[0], f.quant_bias[1], f.quant_bias[2]};
-		tiles_scatter_events<NB>(plan, geom, g_be, ev_prefix, order, plan.pool_f32, g_dq, 64, map, tiles, 3 * P, P, qbias, f.quant_bias_num, tid, nthreads);
-		tiles_fill_llf(plan, geom, nb, 8, 1, 1, map, tiles, 3 * P, P, f.kx_lf, f.kb_lf, tid, nthreads);
-	} else {
+		const int32_t lane8 = tid & 7;
+		for (int32_t tile = tid >> 3; tile < nb * 3; tile += nthreads >> 3)
+			special8_phase0(g_sel[tile / 3], lane8, tiles + tile * P, work + tile * P, c_half_secants, c_afv_basis);
+		__syncthreads();
+		for (int32_t tile = tid >> 3; tile < nb * 3; tile += nthreads >> 3)
+			special8_phase1(g_sel[tile / 3], lane8, work + tile * P, tiles + tile * P, c_half_secants);
 		__syncthreads();
 		for (int32_t w = tid; w < nb * 64; w += nthreads) {
-			const int32_t b = w >> 6, i = w & 63;
-			float v[3];
-			load_coeff3(plan, geom[b], plan.pool_f32 + f.dq_off[g_param[b]], 64, i, 8, 1, 1, v);
-			float *t = tiles + (size_t) b * 3 * P + i;
-			t[0] = v[0]; t[P] = v[1]; t[2 * P] = v[2];
+			const int32_t b = w >> 6, i = w & 63, y = i >> 3, x = i & 7;
+			const VbGeom &g = geom[b];
+			if (y >= g.effh || x >= g.effw) continue;
+			const float *t = tiles + (size_t) b * 3 * P + i;
+			const uint32_t px = xyb_to_rgba8(t[0], t[P], t[2 * P], cc, srgb_thr);
+			*(uint32_t *) (rgba + (size_t) (g.py + y) * stride_bytes + (size_t) (g.px + x) * 4) = px;
 		}
-	}
-	__syncthreads();
-	const int32_t lane8 = tid & 7;
-	for (int32_t tile = tid >> 3; tile < nb * 3; tile += nthreads >> 3)
-		special8_phase0(g_sel[tile / 3], lane8, tiles + tile * P, work + tile * P, c_half_secants, c_afv_basis);
-	__syncthreads();
-	for (int32_t tile = tid >> 3; tile < nb * 3; tile += nthreads >> 3)
-		special8_phase1(g_sel[tile / 3], lane8, work + tile * P, tiles + tile * P, c_half_secants);
-	__syncthreads();
-	for (int32_t w = tid; w < nb * 64; w += nthreads) {
-		const int32_t b = w >> 6, i = w & 63, y = i >> 3, x = i & 7;
-		const VbGeom &g = geom[b];
-		if (y >= g.effh || x >= g.effw) continue;
-		const float *t = tiles + (size_t) b * 3 * P + i;
-		const uint32_t px = xyb_to_rgba8(t[0], t[P], t[2 * P], cc, srgb_thr);
-		*(uint32_t *) (rgba + (size_t) (g.py + y) * stride_bytes + (size_t) (g.px + x) * 4) = px;
+		if (!BATCH) break;
+		__syncthreads();
 	}
 }
 
@@ -564,49 +583,54 @@ __device__ void idct_sweeps(float *A, float *B, int32_t t, int32_t ncols, int32_
 }
 
 template <bool BATCH>
-__global__ void __launch_bounds__(256) k_vardct_large(DevPlan plan_arg, const DevVarblock *list, int32_t count, float *scratch, uint8_t *rgba, size_t stride_bytes, const K2Frame *batch, int32_t class_a, int32_t class_b) {
-	const DevPlan &plan = BATCH ? batch[blockIdx.y].plan : plan_arg;
-	if (!k2_bind<BATCH>(batch, class_a, class_b, 1, list, count, rgba, stride_bytes, scratch)) return;
-	const DevFrame &f = *plan.frame;
+__global__ void __launch_bounds__(256) k_vardct_large(DevPlan plan_arg, const DevVarblock *list, int32_t count, float *scratch, uint8_t *rgba, size_t stride_bytes, const K2Frame *batch, const int32_t *tile_prefix, int32_t nframes,
+		int32_t class_a, int32_t class_b) {
 	const int32_t tid = threadIdx.x, nthreads = blockDim.x;
-	const DevVarblock vb = list[blockIdx.x];
-	(void) count;
-	const int32_t log_rows = DEV_DCT_SELECT[vb.dctsel][0], log_columns = DEV_DCT_SELECT[vb.dctsel][1];
-	const int32_t R = 1 << log_rows, C = 1 << log_columns, size = R * C;
-	const int32_t long_side = R > C ? R : C, vh8 = (R < C ? R : C) / 8, vw8 = long_side / 8;
-	const int32_t param_idx = vb.dctsel == 21 ? 13 : vb.dctsel <= 23 ? 14 : vb.dctsel == 24 ? 15 : 16;
-	const float *dq = plan.pool_f32 + f.dq_off[param_idx];
 	J40_STAGE_SRGB_THRESHOLDS(f);
-	const ColourConsts cc = load_colour_consts(f);
-	const VbGeom g = varblock_geometry(plan, vb);
-	float *A = scratch + (size_t) blockIdx.x * 6 * 65536, *B = A + 3 * 65536;  // [3][size] each
-	if (f.sparse_coeffs) {   // the tiles live in the HBM scratch here (stores are visible to the workgroup after a barrier + fence)
-		for (int32_t i = tid; i < size; i += nthreads) { A[i] = 0.0f; A[65536 + i] = 0.0f; A[2 * 65536 + i] = 0.0f; }
-		__threadfence_block(); __syncthreads();
-		const uint16_t *order = plan.pool_u16 + f.order_off[DEV_DCT_SELECT[vb.dctsel][2] * 3];
-		const TileMap map = {R, C, C, 0};
-		const float qbias[3] = {f.quant_bias[0], f.quant_bias[1], f.quant_bias[2]};
-		tile_scatter_events(plan, g, plan.block_events + 4 * (size_t) vb.blk, order, plan.pool_f32 + f.dq_scan_off[param_idx], size, map, A, 65536, qbias, f.quant_bias_num, tid, nthreads);
-		tile_fill_llf(plan, g, long_side, vh8, vw8, map, A, 65536, f.kx_lf, f.kb_lf, tid, nthreads);
-		__threadfence_block();
-	} else {
-		for (int32_t i = tid; i < size; i += nthreads) {
-			float v[3];
-			load_coeff3(plan, g, dq, size, i, long_side, vh8, vw8, v);
-			const int32_t r = C > R ? i / C : i % R, c = C > R ? i % C : i / R;
-			A[r * C + c] = v[0]; A[65536 + r * C + c] = v[1]; A[2 * 65536 + r * C + c] = v[2];
+	float *A = scratch + (size_t) blockIdx.x * 6 * 65536, *B = A + 3 * 65536;  // [3][size] each: the workgroup's own
+	for (int32_t tile = blockIdx.x; ; tile += gridDim.x) {
+		int32_t frame, first;
+		if (!k2_bind<BATCH>(batch, tile_prefix, nframes, tile, class_a, class_b, 1, list, count, rgba, stride_bytes, scratch, frame, first)) break;
+		const DevPlan &plan = BATCH ? batch[frame].plan : plan_arg;
+		const DevFrame &f = *plan.frame;
+		const DevVarblock vb = list[first];
+		const int32_t log_rows = DEV_DCT_SELECT[vb.dctsel][0], log_columns = DEV_DCT_SELECT[vb.dctsel][1];
+		const int32_t R = 1 << log_rows, C = 1 << log_columns, size = R * C;
+		const int32_t long_side = R > C ? R : C, vh8 = (R < C ? R : C) / 8, vw8 = long_side / 8;
+		const int32_t param_idx = vb.dctsel == 21 ? 13 : vb.dctsel <= 23 ? 14 : vb.dctsel == 24 ? 15 : 16;
+		const float *dq = plan.pool_f32 + f.dq_off[param_idx];
+		const ColourConsts cc = load_colour_consts(f);
+		const VbGeom g = varblock_geometry(plan, vb);
+		if (f.sparse_coeffs) {   // the tiles live in the HBM scratch here (stores are visible to the workgroup after a barrier + fence)
+			for (int32_t i = tid; i < size; i += nthreads) { A[i] = 0.0f; A[65536 + i] = 0.0f; A[2 * 65536 + i] = 0.0f; }
+			__threadfence_block(); __syncthreads();
+			const uint16_t *order = plan.pool_u16 + f.order_off[DEV_DCT_SELECT[vb.dctsel][2] * 3];
+			const TileMap map = {R, C, C, 0};
+			const float qbias[3] = {f.quant_bias[0], f.quant_bias[1], f.quant_bias[2]};
+			tile_scatter_events(plan, g, plan.block_events + 4 * (size_t) vb.blk, order, plan.pool_f32 + f.dq_scan_off[param_idx], size, map, A, 65536, qbias, f.quant_bias_num, tid, nthreads);
+			tile_fill_llf(plan, g, long_side, vh8, vw8, map, A, 65536, f.kx_lf, f.kb_lf, tid, nthreads);
+			__threadfence_block();
+		} else {
+			for (int32_t i = tid; i < size; i += nthreads) {
+				float v[3];
+				load_coeff3(plan, g, dq, size, i, long_side, vh8, vw8, v);
+				const int32_t r = C > R ? i / C : i % R, c = C > R ? i % C : i / R;
+				A[r * C + c] = v[0]; A[65536 + r * C + c] = v[1]; A[2 * 65536 + r * C + c] = v[2];
+			}
 		}
-	}
-	__syncthreads();
-	for (int ch = 0; ch < 3; ++ch) {
-		idct_sweeps(A + ch * 65536, B + ch * 65536, log_columns, R, 1, C);   // along c for every r: A -> B
-		idct_sweeps(B + ch * 65536, A + ch * 65536, log_rows, C, C, 1);      // along r for every x: B -> A
-	}
-	for (int32_t i = tid; i < size; i += nthreads) {
-		const int32_t y = i / C, x = i - y * C;
-		if (y >= g.effh || x >= g.effw) continue;
-		const uint32_t px = xyb_to_rgba8(A[i], A[65536 + i], A[2 * 65536 + i], cc, srgb_thr);
-		*(uint32_t *) (rgba + (size_t) (g.py + y) * stride_bytes + (size_t) (g.px + x) * 4) = px;
+		__syncthreads();
+		for (int ch = 0; ch < 3; ++ch) {
+			idct_sweeps(A + ch * 65536, B + ch * 65536, log_columns, R, 1, C);   // along c for every r: A -> B
+			idct_sweeps(B + ch * 65536, A + ch * 65536, log_rows, C, C, 1);      // along r for every x: B -> A
+		}
+		for (int32_t i = tid; i < size; i += nthreads) {
+			const int32_t y = i / C, x = i - y * C;
+			if (y >= g.effh || x >= g.effw) continue;
+			const uint32_t px = xyb_to_rgba8(A[i], A[65536 + i], A[2 * 65536 + i], cc, srgb_thr);
+			*(uint32_t *) (rgba + (size_t) (g.py + y) * stride_bytes + (size_t) (g.px + x) * 4) = px;
+		}
+		if (!BATCH) break;
+		__threadfence_block(); __syncthreads();   // the next block reuses the scratch
 	}
 }
 
@@ -639,9 +663,10 @@ void launch_hf_entropy(const DevPlan &plan, const HfLaunchInfo &info, int32_t fi
 	}
 }
 
-// `batch` = nullptr: one frame, everything in the kernel arguments. Otherwise `nframes` frames in one launch (blockIdx.y), the
-// grid sized for `count` = the longest list of the class over the frames; plan / list / rgba / stride are then ignored.
-struct K2Launch { const K2Frame *batch; int32_t nframes, class_a, class_b; };
+// `batch` = nullptr: one frame, everything in the kernel arguments. Otherwise a persistent launch over the tiles of one class of
+// `nframes` frames (k2_bind): `grid` workgroups, tile_prefix = this launch's row of the table k_k2_tiles built; plan / list /
+// count / rgba / stride are then ignored, `large_scratch` holds 6 * 65536 floats per workgroup of the launch.
+struct K2Launch { const K2Frame *batch; const int32_t *tile_prefix; int32_t nframes, class_a, class_b, grid; };
 
 template <int LOGR, int LOGC, int NB>
 static void launch_dct(const DevPlan &plan, const DevVarblock *list, int32_t count, int32_t param_idx, int32_t order_idx, uint8_t *rgba, size_t stride, const K2Launch &bl, hipStream_t stream) {
@@ -653,13 +678,13 @@ static void launch_dct(const DevPlan &plan, const DevVarblock *list, int32_t cou
 		configured = true;
 	}
 	const int32_t blocks = (count + NB - 1) / NB;
-	if (bl.batch) hipLaunchKernelGGL((k_vardct_dct<LOGR, LOGC, NB, true>), dim3((unsigned) blocks, (unsigned) bl.nframes), dim3(256), lds_bytes, stream, plan, list, count, param_idx, order_idx, rgba, stride, bl.batch, bl.class_a, bl.class_b);
-	else hipLaunchKernelGGL((k_vardct_dct<LOGR, LOGC, NB, false>), dim3((unsigned) blocks), dim3(256), lds_bytes, stream, plan, list, count, param_idx, order_idx, rgba, stride, bl.batch, 0, 0);
+	if (bl.batch) hipLaunchKernelGGL((k_vardct_dct<LOGR, LOGC, NB, true>), dim3((unsigned) bl.grid), dim3(256), lds_bytes, stream, plan, list, count, param_idx, order_idx, rgba, stride, bl.batch, bl.tile_prefix, bl.nframes, bl.class_a, bl.class_b);
+	else hipLaunchKernelGGL((k_vardct_dct<LOGR, LOGC, NB, false>), dim3((unsigned) blocks), dim3(256), lds_bytes, stream, plan, list, count, param_idx, order_idx, rgba, stride, bl.batch, nullptr, 1, 0, 0);
 }
 
-// list = varblocks of one DctSelect value (of a run of values for the 8x8 specials)
+// list = varblocks of one DctSelect value (of a run of values for the 8x8 specials and for the 128/256-sized transforms)
 static void launch_vardct_class_impl(const DevPlan &plan, int32_t dctsel, const DevVarblock *list, int32_t count, float *large_scratch, uint8_t *rgba, size_t stride, const K2Launch &bl, hipStream_t stream) {
-	if (count <= 0) return;
+	if (count <= 0 && !bl.batch) return;
 	switch (dctsel) {
 	case 0: launch_dct<3, 3, 16>(plan, list, count, 0, 0, rgba, stride, bl, stream); break;
 	case 4: launch_dct<4, 4, 8>(plan, list, count, 4, 2, rgba, stride, bl, stream); break;
@@ -674,17 +699,17 @@ static void launch_vardct_class_impl(const DevPlan &plan, int32_t dctsel, const 
 	case 19: launch_dct<6, 5, 1>(plan, list, count, 12, 8, rgba, stride, bl, stream); break;
 	case 20: launch_dct<5, 6, 1>(plan, list, count, 12, 8, rgba, stride, bl, stream); break;
 	case 1: case 2: case 3: case 12: case 13: case 14: case 15: case 16: case 17:
-		if (bl.batch) hipLaunchKernelGGL((k_vardct_special<32, true>), dim3((unsigned) ((count + 31) / 32), (unsigned) bl.nframes), dim3(256), 0, stream, plan, list, count, rgba, stride, bl.batch, bl.class_a, bl.class_b);
-		else hipLaunchKernelGGL((k_vardct_special<32, false>), dim3((unsigned) ((count + 31) / 32)), dim3(256), 0, stream, plan, list, count, rgba, stride, bl.batch, 0, 0);
+		if (bl.batch) hipLaunchKernelGGL((k_vardct_special<32, true>), dim3((unsigned) bl.grid), dim3(256), 0, stream, plan, list, count, rgba, stride, bl.batch, bl.tile_prefix, bl.nframes, bl.class_a, bl.class_b);
+		else hipLaunchKernelGGL((k_vardct_special<32, false>), dim3((unsigned) ((count + 31) / 32)), dim3(256), 0, stream, plan, list, count, rgba, stride, bl.batch, nullptr, 1, 0, 0);
 		break;
 	default:
-		if (bl.batch) hipLaunchKernelGGL(k_vardct_large<true>, dim3((unsigned) count, (unsigned) bl.nframes), dim3(256), 0, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, bl.class_a, bl.class_b);
-		else hipLaunchKernelGGL(k_vardct_large<false>, dim3((unsigned) count), dim3(256), 0, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, 0, 0);
+		if (bl.batch) hipLaunchKernelGGL(k_vardct_large<true>, dim3((unsigned) bl.grid), dim3(256), 0, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, bl.tile_prefix, bl.nframes, bl.class_a, bl.class_b);
+		else hipLaunchKernelGGL(k_vardct_large<false>, dim3((unsigned) count), dim3(256), 0, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, nullptr, 1, 0, 0);
 		break;
 	}
 }
 void launch_vardct_class(const DevPlan &plan, int32_t dctsel, const DevVarblock *list, int32_t count, float *large_scratch, uint8_t *rgba, size_t stride, hipStream_t stream) {
-	launch_vardct_class_impl(plan, dctsel, list, count, large_scratch, rgba, stride, K2Launch{nullptr, 1, 0, 0}, stream);
+	launch_vardct_class_impl(plan, dctsel, list, count, large_scratch, rgba, stride, K2Launch{nullptr, nullptr, 1, 0, 0, 0}, stream);
 }
 
 // known-answer hook: the renderer's per-sample tail (sRGB transfer + conversion, j40.h:7213-7240 / 7925-7935)
@@ -715,14 +740,47 @@ void launch_vardct_frame(const DevPlan &plan, const int32_t *class_start, const 
 	for (int d = 0, a, b; d < 27; ++d) if (class_range(d, &a, &b))
 		launch_vardct_class(plan, d, sorted + class_start[a], class_start[b] - class_start[a], large_scratch, rgba, stride, stream);
 }
-// the same for `nframes` frames at once: one launch per class, blockIdx.y = frame. host_class_start: [nframes][28]
-void launch_vardct_batch(const K2Frame *frames_dev, int32_t nframes, const int32_t *host_class_start, hipStream_t stream) {
-	const DevPlan none = DevPlan();
-	for (int d = 0, a, b; d < 27; ++d) if (class_range(d, &a, &b)) {
-		int32_t longest = 0;
-		for (int32_t i = 0; i < nframes; ++i) longest = std::max(longest, host_class_start[28 * i + b] - host_class_start[28 * i + a]);
-		launch_vardct_class_impl(none, d, nullptr, longest, nullptr, nullptr, 0, K2Launch{frames_dev, nframes, a, b}, stream);
+
+// ---- the same for every frame of a batch at once: one persistent launch per class ----
+// The launches of a batch: {first DctSelect, one past the last, varblocks per tile, cells per varblock at least}; the 128/256-sized
+// transforms share one (k_vardct_large looks at each block's DctSelect). Biggest first.
+#define J40_K2_LAUNCH_TABLE {0, 1, 16, 1}, {1, 4, 32, 1}, {12, 18, 32, 1}, {4, 5, 8, 4}, {6, 7, 8, 2}, {7, 8, 8, 2}, {5, 6, 2, 16}, {8, 9, 4, 4}, {9, 10, 4, 4}, {10, 11, 4, 8}, {11, 12, 4, 8}, \
+	{18, 19, 1, 64}, {19, 20, 1, 32}, {20, 21, 1, 32}, {21, 27, 1, 128}
+struct K2BatchLaunch { int16_t a, b, per_wg, min_cells; };
+static const K2BatchLaunch K2_BATCH_LAUNCHES[K2_NUM_BATCH_LAUNCHES] = {J40_K2_LAUNCH_TABLE};
+__device__ static const K2BatchLaunch DEV_K2_BATCH_LAUNCHES[K2_NUM_BATCH_LAUNCHES] = {J40_K2_LAUNCH_TABLE};
+
+// tile_prefix[l * (nframes + 1) + f] = tiles of launch l in the frames before f; one thread per launch
+__global__ void k_k2_tiles(const K2Frame *frames, int32_t nframes, int32_t *tile_prefix) {
+	const int32_t l = threadIdx.x;
+	if (l >= K2_NUM_BATCH_LAUNCHES) return;
+	const int32_t a = DEV_K2_BATCH_LAUNCHES[l].a, b = DEV_K2_BATCH_LAUNCHES[l].b, per = DEV_K2_BATCH_LAUNCHES[l].per_wg;
+	int32_t at = 0;
+	int32_t *row = tile_prefix + l * (nframes + 1);
+	for (int32_t f = 0; f < nframes; ++f) {
+		row[f] = at;
+		const int32_t n = frames[f].class_start[b] - frames[f].class_start[a];
+		at += (n + per - 1) / per;
 	}
+	row[nframes] = at;
+}
+
+// cells_total: 8x8 cells of all frames of the batch (bounds the tiles a launch can have); wgs_cap: most workgroups per launch;
+// large_scratch: 6 * 65536 floats per workgroup of the last launch (K2_LARGE_WGS of them)
+void launch_vardct_batch(const K2Frame *frames_dev, int32_t nframes, int32_t *tile_prefix_dev, size_t cells_total, float *large_scratch, hipStream_t stream, hipStream_t *side, int nside, hipEvent_t fork, hipEvent_t *side_done) {
+	const DevPlan none = DevPlan();
+	hipLaunchKernelGGL(k_k2_tiles, dim3(1), dim3(32), 0, stream, frames_dev, nframes, tile_prefix_dev);
+	if (nside > 0) { (void) hipEventRecord(fork, stream); for (int k = 0; k < nside; ++k) (void) hipStreamWaitEvent(side[k], fork, 0); }
+	static const int wgs_cap = [] { const char *e = getenv("J40HIP_K2_WGS"); return e ? std::max(1, atoi(e)) : 2048; }();
+	for (int l = 0; l < K2_NUM_BATCH_LAUNCHES; ++l) {
+		const auto &L = K2_BATCH_LAUNCHES[l];
+		const size_t bound = cells_total / (size_t) (L.min_cells * L.per_wg) + (size_t) nframes;   // tiles at most
+		int32_t grid = (int32_t) std::min<size_t>(bound, (size_t) wgs_cap);
+		if (L.a == 21) grid = std::min(grid, (int32_t) K2_LARGE_WGS);
+		if (grid < 1) grid = 1;
+		launch_vardct_class_impl(none, L.a, nullptr, 0, large_scratch, nullptr, 0, K2Launch{frames_dev, tile_prefix_dev + (size_t) l * (size_t) (nframes + 1), nframes, L.a, L.b, grid}, nside > 0 ? side[l % nside] : stream);
+	}
+	if (nside > 0) for (int k = 0; k < nside; ++k) { (void) hipEventRecord(side_done[k], side[k]); (void) hipStreamWaitEvent(stream, side_done[k], 0); }
 }
 
 } // namespace j40hip

@@ -18,8 +18,9 @@ __global__ void __launch_bounds__(64) k_lf_groups(const DevLfTask *tasks) {
 	const DevLfTask *tp = tasks + blockIdx.x;
 	const int32_t w8 = coop_sc(tp->w8), h8 = coop_sc(tp->h8), w64 = coop_sc(tp->w64), h64 = coop_sc(tp->h64);
 	const int32_t sidx0 = coop_sc(tp->sidx0), sidx2 = coop_sc(tp->sidx2), nbvb_bits = coop_sc(tp->nbvb_bits);
-	const uint32_t capacity = (uint32_t) coop_sc((int32_t) tp->out_capacity);
-	int16_t *out = coop_sc_ptr(tp->out);
+	const uint32_t info_capacity = (uint32_t) coop_sc((int32_t) tp->info_capacity);
+	int16_t *lf_out[3] = {coop_sc_ptr(tp->lf[0]), coop_sc_ptr(tp->lf[1]), coop_sc_ptr(tp->lf[2])};
+	int16_t *out_xfromy = coop_sc_ptr(tp->xfromy), *out_bfromy = coop_sc_ptr(tp->bfromy), *out_info = coop_sc_ptr(tp->info), *out_sharp = coop_sc_ptr(tp->sharp);
 	DevLfResult *result = coop_sc_ptr(tp->result);
 	const uint8_t *codestream = coop_sc_ptr(tp->codestream);
 	const CoopTreeRegs t = coop_load_tree(coop_sc_ptr(tp->tree), lane);
@@ -29,10 +30,9 @@ __global__ void __launch_bounds__(64) k_lf_groups(const DevLfTask *tasks) {
 	coop_bits_init(b, codestream, (uint32_t) coop_sc((int32_t) tp->byte_off), (uint32_t) coop_sc((int32_t) tp->size), (uint32_t) coop_sc((int32_t) tp->bit_off), lane);
 	uint32_t state = 0, err = 0, status = 0;
 	int32_t nb_varblocks = 0;
-	const uint32_t cells = (uint32_t) w8 * (uint32_t) h8, c64 = (uint32_t) w64 * (uint32_t) h64;
 	// the LF coefficient image
 	for (int32_t c = 0; c < 3 && !b.err && !err; ++c)
-		coop_decode_channel<0, true>(b, state, err, t, alias, log_bucket, c, sidx0, out + (size_t) c * cells, w8, w8, h8, nullptr, 0, lane);
+		coop_decode_channel<0, true>(b, state, err, t, alias, log_bucket, c, sidx0, c == 0 ? lf_out[0] : c == 1 ? lf_out[1] : lf_out[2], w8, w8, h8, nullptr, 0, lane);
 	status = b.err ? b.err : err;
 	if (!status) status = coop_finish_code(b, state, lane);
 	if (!status) {
@@ -40,15 +40,14 @@ __global__ void __launch_bounds__(64) k_lf_groups(const DevLfTask *tasks) {
 		const uint32_t header = coop_take(b, 4, lane);                // use_global_tree = 1, default wp = 1, no transforms (j40.h:3717-3760)
 		if (b.err) status = b.err;
 		else if (header != 3u) status = ERR_LFFB;
-		else if (3 * cells + 2 * c64 + 2 * (uint32_t) nb_varblocks + cells > capacity) status = ERR_LFFB;   // (more varblocks than cells: the host reports it)
+		else if (2 * (uint32_t) nb_varblocks > info_capacity) status = ERR_LFFB;   // (more varblocks than cells: the host reports it)
 	}
 	if (!status) {   // the HF metadata image
-		int16_t *meta = out + 3 * (size_t) cells;
 		state = 0;
-		coop_decode_channel<0, true>(b, state, err, t, alias, log_bucket, 0, sidx2, meta, w64, w64, h64, nullptr, 0, lane);
-		if (!b.err && !err) coop_decode_channel<0, true>(b, state, err, t, alias, log_bucket, 1, sidx2, meta + c64, w64, w64, h64, nullptr, 0, lane);
-		if (!b.err && !err) coop_decode_channel<0, true>(b, state, err, t, alias, log_bucket, 2, sidx2, meta + 2 * (size_t) c64, nb_varblocks, nb_varblocks, 2, nullptr, 0, lane);
-		if (!b.err && !err) coop_decode_channel<0, true>(b, state, err, t, alias, log_bucket, 3, sidx2, meta + 2 * (size_t) c64 + 2 * (size_t) nb_varblocks, w8, w8, h8, nullptr, 0, lane);
+		coop_decode_channel<0, true>(b, state, err, t, alias, log_bucket, 0, sidx2, out_xfromy, w64, w64, h64, nullptr, 0, lane);
+		if (!b.err && !err) coop_decode_channel<0, true>(b, state, err, t, alias, log_bucket, 1, sidx2, out_bfromy, w64, w64, h64, nullptr, 0, lane);
+		if (!b.err && !err) coop_decode_channel<0, true>(b, state, err, t, alias, log_bucket, 2, sidx2, out_info, nb_varblocks, nb_varblocks, 2, nullptr, 0, lane);
+		if (!b.err && !err) coop_decode_channel<0, true>(b, state, err, t, alias, log_bucket, 3, sidx2, out_sharp, w8, w8, h8, nullptr, 0, lane);
 		status = b.err ? b.err : err;
 		if (!status) status = coop_finish_code(b, state, lane);
 	}

@@ -24,10 +24,8 @@ void upload_lf_tail_tables(const float *half_secants, const float *lf2llf, hipSt
 	(void) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tail_lf2llf), lf2llf, sizeof(float) * 64, 0, hipMemcpyHostToDevice, stream);
 }
 
-__global__ void __launch_bounds__(256) k_lf_dequant_smooth(DevPlan plan, float *out0, float *out1, float *out2, int32_t smooth, float inv0, float inv1, float inv2) {
-	const DevLfGroup gg = plan.lf_groups[blockIdx.y];
+__device__ __forceinline__ void lf_dequant_smooth_cell(const DevPlan &plan, const DevLfGroup &gg, int32_t i, float *out0, float *out1, float *out2, int32_t smooth, float inv0, float inv1, float inv2) {
 	const int32_t w8 = gg.width8, h8 = gg.height8;
-	const int32_t i = (int32_t) (blockIdx.x * blockDim.x + threadIdx.x);
 	if (i >= w8 * h8) return;
 	const int32_t y = i / w8, x = i - y * w8;
 	const size_t at = (size_t) gg.cell_base + (size_t) i;
@@ -54,6 +52,18 @@ __global__ void __launch_bounds__(256) k_lf_dequant_smooth(DevPlan plan, float *
 	gap = 3.0f - 4.0f * gap;
 	gap = 0.0f > gap ? 0.0f : gap;
 	for (int c = 0; c < 3; ++c) out[c][at] = (wa[c] - centre[c]) * gap + centre[c];
+}
+
+__global__ void __launch_bounds__(256) k_lf_dequant_smooth(DevPlan plan, float *out0, float *out1, float *out2, int32_t smooth, float inv0, float inv1, float inv2) {
+	lf_dequant_smooth_cell(plan, plan.lf_groups[blockIdx.y], (int32_t) (blockIdx.x * blockDim.x + threadIdx.x), out0, out1, out2, smooth, inv0, inv1, inv2);
+}
+// every LfGroup of a batch (plan_kernels.hip: DevBatchLf)
+__global__ void __launch_bounds__(256) k_lf_dequant_smooth_batch(const DevPlan *plans, const DevPlanBuild *builds, const DevBatchLf *lfs) {
+	const DevBatchLf w = lfs[blockIdx.y];
+	const DevPlan &plan = plans[w.frame];
+	const DevPlanBuild &pb = builds[w.frame];
+	float *lfs0 = pb.lf_scratch;
+	lf_dequant_smooth_cell(plan, plan.lf_groups[w.lfg], (int32_t) (blockIdx.x * blockDim.x + threadIdx.x), lfs0, lfs0 + pb.cells, lfs0 + 2 * (size_t) pb.cells, pb.lf_smooth, pb.inv_m_lf[0], pb.inv_m_lf[1], pb.inv_m_lf[2]);
 }
 
 // forward DCT of length 1 << T over elements S apart, in the reference's order (j40__forward_dct_core, j40.h:5760-5800):
@@ -119,11 +129,8 @@ template <int LR, int LC> __device__ __forceinline__ void llf_small_case(const f
 	for (int k = 0; k < R * C; ++k) llf[k] = buf[k];
 }
 
-// list: the frame's varblocks (any order); blocks with a side of 64 or more are left to k_llf_large
-__global__ void __launch_bounds__(256) k_llf_small(DevPlan plan, const DevVarblock *list, int32_t count, const float *lf0, const float *lf1, const float *lf2, float *llf0, float *llf1, float *llf2) {
-	const int32_t v = (int32_t) (blockIdx.x * blockDim.x + threadIdx.x);
-	if (v >= count) return;
-	const DevVarblock vb = list[v];
+// blocks with a side of 64 or more are left to k_llf_large
+__device__ __forceinline__ void llf_small_one(const DevPlan &plan, const DevVarblock &vb, const float *lf0, const float *lf1, const float *lf2, float *llf0, float *llf1, float *llf2) {
 	const int32_t log_rows = DEV_DCT_SELECT[vb.dctsel][0], log_columns = DEV_DCT_SELECT[vb.dctsel][1];
 	if (log_rows > 5 || log_columns > 5) return;
 	const DevLfGroup gg = plan.lf_groups[(uint32_t) vb.pad[0] | ((uint32_t) vb.pad[1] << 8) | ((uint32_t) vb.pad[2] << 16)];
@@ -146,6 +153,22 @@ __global__ void __launch_bounds__(256) k_llf_small(DevPlan plan, const DevVarblo
 	}
 }
 
+// list: the frame's varblocks (any order)
+__global__ void __launch_bounds__(256) k_llf_small(DevPlan plan, const DevVarblock *list, int32_t count, const float *lf0, const float *lf1, const float *lf2, float *llf0, float *llf1, float *llf2) {
+	const int32_t v = (int32_t) (blockIdx.x * blockDim.x + threadIdx.x);
+	if (v >= count) return;
+	llf_small_one(plan, list[v], lf0, lf1, lf2, llf0, llf1, llf2);
+}
+// every frame of a batch (blockIdx.y); the number of varblocks is the device's to know (DevPlanBuild::class_start[27])
+__global__ void __launch_bounds__(256) k_llf_small_batch(const DevPlan *plans, const DevPlanBuild *builds) {
+	const DevPlan &plan = plans[blockIdx.y];
+	const DevPlanBuild &pb = builds[blockIdx.y];
+	const int32_t v = (int32_t) (blockIdx.x * blockDim.x + threadIdx.x);
+	if (v >= pb.class_start[27]) return;
+	const float *lfs = pb.lf_scratch;
+	llf_small_one(plan, pb.vb_sorted[v], lfs, lfs + pb.cells, lfs + 2 * (size_t) pb.cells, const_cast<float *>(plan.llf[0]), const_cast<float *>(plan.llf[1]), const_cast<float *>(plan.llf[2]));
+}
+
 // run-time form of FwdDct for the large blocks (same arithmetic; elements `stride` apart, in LDS)
 __device__ void fwd_dct_rt(float *out, float *in, int32_t t, int32_t stride) {
 	const int32_t N = 1 << t;
@@ -164,17 +187,12 @@ __device__ void fwd_dct_rt(float *out, float *in, int32_t t, int32_t stride) {
 	out[(N - 1) * stride] = in[(N - 1) * stride];
 }
 
-// list: the varblocks of the classes with a 64-, 128- or 256-sized side (contiguous in the sorted list)
-__global__ void __launch_bounds__(64) k_llf_large(DevPlan plan, const DevVarblock *list, int32_t count, const float *lf0, const float *lf1, const float *lf2, float *llf0, float *llf1, float *llf2) {
-	__shared__ float buf[1024], tmp[1024];
-	if ((int32_t) blockIdx.x >= count) return;
-	const DevVarblock vb = list[blockIdx.x];
+__device__ void llf_large_one(const DevPlan &plan, const DevVarblock &vb, const float *lf0, const float *lf1, const float *lf2, float *llf0, float *llf1, float *llf2, float *buf, float *tmp, int32_t lane) {
 	const int32_t lr = DEV_DCT_SELECT[vb.dctsel][0] - 3, lc = DEV_DCT_SELECT[vb.dctsel][1] - 3, R = 1 << lr, C = 1 << lc;
 	const DevLfGroup gg = plan.lf_groups[(uint32_t) vb.pad[0] | ((uint32_t) vb.pad[1] << 8) | ((uint32_t) vb.pad[2] << 16)];
 	const size_t cell = (size_t) gg.cell_base + (size_t) ((vb.py - gg.top) >> 3) * (size_t) gg.width8 + (size_t) ((vb.px - gg.left) >> 3);
 	const float *lf[3] = {lf0, lf1, lf2};
 	float *llf[3] = {llf0, llf1, llf2};
-	const int32_t lane = threadIdx.x;
 	for (int c = 0; c < 3; ++c) {
 		for (int32_t k = lane; k < R * C; k += 64) buf[k] = lf[c][cell + (size_t) (k / C) * (size_t) gg.width8 + (size_t) (k % C)];
 		__syncthreads();
@@ -194,6 +212,22 @@ __global__ void __launch_bounds__(64) k_llf_large(DevPlan plan, const DevVarbloc
 	}
 }
 
+// list: the varblocks of the classes with a 64-, 128- or 256-sized side (contiguous in the sorted list)
+__global__ void __launch_bounds__(64) k_llf_large(DevPlan plan, const DevVarblock *list, int32_t count, const float *lf0, const float *lf1, const float *lf2, float *llf0, float *llf1, float *llf2) {
+	__shared__ float buf[1024], tmp[1024];
+	if ((int32_t) blockIdx.x >= count) return;
+	llf_large_one(plan, list[blockIdx.x], lf0, lf1, lf2, llf0, llf1, llf2, buf, tmp, threadIdx.x);
+}
+// every frame of a batch (blockIdx.y): the workgroups of a frame share out its large blocks, however many the device found
+__global__ void __launch_bounds__(64) k_llf_large_batch(const DevPlan *plans, const DevPlanBuild *builds) {
+	__shared__ float buf[1024], tmp[1024];
+	const DevPlan &plan = plans[blockIdx.y];
+	const DevPlanBuild &pb = builds[blockIdx.y];
+	const float *lfs = pb.lf_scratch;
+	for (int32_t v = pb.class_start[18] + (int32_t) blockIdx.x; v < pb.class_start[27]; v += (int32_t) gridDim.x)
+		llf_large_one(plan, pb.vb_sorted[v], lfs, lfs + pb.cells, lfs + 2 * (size_t) pb.cells, const_cast<float *>(plan.llf[0]), const_cast<float *>(plan.llf[1]), const_cast<float *>(plan.llf[2]), buf, tmp, threadIdx.x);
+}
+
 // the whole tail of one frame on `stream`: lfs = scratch of three planes of `cells` floats (dequantised + smoothed samples)
 void launch_lf_tail(const DevPlan &plan, int32_t num_lf_groups, int32_t max_cells, size_t cells, float *lfs, const DevVarblock *sorted, int32_t count, int32_t first_large, int32_t smooth,
 		const float inv_m_lf[3], hipStream_t stream) {
@@ -202,6 +236,14 @@ void launch_lf_tail(const DevPlan &plan, int32_t num_lf_groups, int32_t max_cell
 	float *llf0 = const_cast<float *>(plan.llf[0]), *llf1 = const_cast<float *>(plan.llf[1]), *llf2 = const_cast<float *>(plan.llf[2]);
 	if (count > 0) hipLaunchKernelGGL(k_llf_small, dim3((unsigned) ((count + 255) / 256)), dim3(256), 0, stream, plan, sorted, count, lfs, lfs + cells, lfs + 2 * cells, llf0, llf1, llf2);
 	if (count > first_large) hipLaunchKernelGGL(k_llf_large, dim3((unsigned) (count - first_large)), dim3(64), 0, stream, plan, sorted + first_large, count - first_large, lfs, lfs + cells, lfs + 2 * cells, llf0, llf1, llf2);
+}
+
+// the tails of every frame of a batch: nlf LfGroups in all, the largest of max_lf_cells cells; the largest frame of max_frame_cells
+void launch_lf_tail_batch(const DevPlan *plans, const DevPlanBuild *builds, const DevBatchLf *lfs, int32_t nframes, int32_t nlf, int32_t max_lf_cells, size_t max_frame_cells, hipStream_t stream) {
+	if (nframes <= 0 || nlf <= 0 || max_lf_cells <= 0) return;
+	hipLaunchKernelGGL(k_lf_dequant_smooth_batch, dim3((unsigned) ((max_lf_cells + 255) / 256), (unsigned) nlf), dim3(256), 0, stream, plans, builds, lfs);
+	hipLaunchKernelGGL(k_llf_small_batch, dim3((unsigned) ((max_frame_cells + 255) / 256), (unsigned) nframes), dim3(256), 0, stream, plans, builds);
+	hipLaunchKernelGGL(k_llf_large_batch, dim3(32, (unsigned) nframes), dim3(64), 0, stream, plans, builds);
 }
 
 } // namespace j40hip

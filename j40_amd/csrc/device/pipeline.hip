@@ -1,14 +1,21 @@
 // j40_amd/csrc/device/pipeline.hip -- whole-frame throughput pipeline over the thin C-ABI (include/j40hip.h, j40hip_pipeline_*):
 // codestream bytes in host memory -> RGBA u8x4 in device or host memory, with every stage of many frames in flight at once.
 //
-//   host worker threads   container / header / TOC / LfGlobal / HfGlobal / LfGroup parse (j40hip_frame_parse: the reference's
-//                         j40.h:8175-8192 + 7840-7846 work), plan build, plan upload through the thread's pinned staging buffer
-//                         on the thread's own HIP stream (j40hip_frame_upload_on)
-//   one GPU thread        collects uploaded frames into batches, one entropy launch + pixel kernels per batch on the batch slot's
-//                         stream (j40hip_batch_reset / j40hip_batch_decode), then -- host output -- the copy back on the same
-//                         stream, so that the copy of batch k overlaps the kernels of batch k + 1 on the other slot's stream
-//   completion            per-frame status words come back with an asynchronous copy; frames whose sections overflow their event
-//                         region ("evof") or that carry extra channels / are Modular take the single-frame path
+//   host worker threads   VarDCT frames with several sections (async.hip): container, headers, TOC, LfGlobal, HfGlobal (the
+//                         reference's j40.h:8175-8192 work) and the first bits of every LfGroup section; the front of the plan and the
+//                         codestream go to the device with one asynchronous copy, and the thread moves on -- it never waits for the
+//                         device. Whether the thread also decodes the frame's LfGroup streams (j40.h:6722-6790) or leaves them to
+//                         k_lf_groups is decided frame by frame: when the device already has batches queued up the thread keeps the
+//                         streams (the CPU is the faster decoder of one stream), otherwise it hands them over (so that frames reach
+//                         the device sooner).
+//                         Every other frame (Modular, a single section, extra channels, ...) the thread decodes on its own through
+//                         the single-frame entry points (j40hip_frame_parse / upload / decode), on its own stream.
+//   one GPU thread        collects prepared frames into batches; per batch ONE enqueue of LfGroup streams -> plan build -> LfGroup tail
+//                         -> entropy decode -> pixels -> verdict on the batch slot's stream (j40hip_abatch_launch), then -- host
+//                         output -- the copy back on the same stream, so that it overlaps the kernels of the next batch on the other
+//                         slot's stream
+//   completion            one 16-byte verdict per frame comes back with the batch; frames the device wants decoded again (an LfGroup
+//                         header the device decoder does not take, an event region that overflowed) take the single-frame path
 //
 // The reference decodes one image on one core (j40.h:8034: its only threading hook is commented out); this is the serving
 // shape of the same work: frames are independent, so the host part scales over cores and the device part over a batch.
@@ -24,6 +31,8 @@
 #include <thread>
 #include <vector>
 #include "../../../include/j40hip.h"
+#include "async.hpp"
+#include "runtime_shared.hpp"
 
 namespace {
 
@@ -38,8 +47,7 @@ struct Job {
 	int64_t ticket = 0;
 	const void *buf = nullptr; size_t size = 0;
 	void *rgba = nullptr; size_t stride = 0; bool device_output = false;
-	j40hip_frame *frame = nullptr;
-	bool single = false;          // not batchable (Modular frame, extra channels): decoded on its own
+	j40hip_aframe *af = nullptr;
 	int64_t width = 0, height = 0;
 	void *dev_rgba = nullptr;     // host output: the device image the copy back reads
 	uint32_t status = 0;
@@ -48,9 +56,9 @@ struct Job {
 struct Slot {                     // one batch in flight
 	hipStream_t stream = nullptr;
 	hipEvent_t done = nullptr;
-	j40hip_batch *batch = nullptr;
+	j40hip_abatch *batch = nullptr;
 	std::vector<Job *> jobs;
-	int64_t batched = 0;          // members of the batch launch (jobs minus the single-frame ones)
+	uint32_t launch_err = 0;      // the batch could not be enqueued: every member fails with this
 	bool busy = false;
 };
 
@@ -58,23 +66,25 @@ struct Slot {                     // one batch in flight
 
 struct j40hip_pipeline {
 	int device = 0, batch_frames = 32, max_in_flight = 2;
-	bool lf_on_device = false;          // the workers parse with j40hip_frame_parse_on: LfGroup streams decoded by the device
-	int64_t lf_device_frames = 0;
+	int lf_mode = 0;                    // LfGroup streams: 0 decided per frame (see above), 1 always the device, 2 always the host threads
+	int64_t lf_hiwater = 0;             // mode 0: frames prepared-or-in-flight from which on the host threads keep the streams
+	int64_t lf_device_frames = 0, single_frames = 0;
 	std::mutex m;
 	std::condition_variable cv_todo, cv_ready, cv_done;
 	std::deque<Job *> todo, ready;
 	std::vector<uint32_t> results;      // by ticket
 	std::vector<uint8_t> finished;      // by ticket
-	int64_t submitted = 0, completed = 0, resident = 0, parsing = 0;
+	int64_t submitted = 0, completed = 0, resident = 0, parsing = 0, in_flight_frames = 0;
 	bool stop = false;
 	std::vector<std::thread> workers;
 	std::thread gpu;
 	std::vector<Slot> slots;
 	std::deque<int> in_flight;          // slot indices, oldest first
 	// device images for host output, recycled by size
+	std::mutex image_m;
 	std::vector<std::pair<void *, size_t>> free_images;
-	double parse_ms = 0, upload_ms = 0;  // summed over the worker threads
-	double k1_ms = 0, k2_ms = 0; int64_t launches = 0, launch_frames = 0;   // HIP-event durations of the batches' entropy / pixel stages
+	double parse_ms = 0, single_ms = 0;  // summed over the worker threads: the asynchronous path's host stage / whole single-frame decodes
+	double lf_ms = 0, k1_ms = 0, k2_ms = 0; int64_t launches = 0, launch_frames = 0;   // HIP-event durations of the batches' stages
 	double first_submit_ms = 0, last_done_ms = 0;
 	std::atomic<int> worker_errors{0};
 };
@@ -89,45 +99,92 @@ void complete(j40hip_pipeline *p, Job *j) {   // p->m held
 	p->cv_done.notify_all();
 }
 
+void *acquire_image(j40hip_pipeline *p, size_t bytes) {
+	{
+		std::lock_guard<std::mutex> lock(p->image_m);
+		for (size_t i = 0; i < p->free_images.size(); ++i) if (p->free_images[i].second == bytes) { void *q = p->free_images[i].first; p->free_images.erase(p->free_images.begin() + (long) i); return q; }
+	}
+	void *q = nullptr;
+	if (hipMalloc(&q, bytes) != hipSuccess) {
+		(void) hipGetLastError();
+		j40hip_rt::cache_trim(p->device);   // idle blocks of the frame cache: give them back and try once more
+		if (hipMalloc(&q, bytes) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+	}
+	return q;
+}
+void release_image(j40hip_pipeline *p, void *q, size_t bytes) { std::lock_guard<std::mutex> lock(p->image_m); p->free_images.push_back({q, bytes}); }
+
+// The single-frame path, synchronous on `s` (the calling thread sleeps in the waits): frames the batches do not take, and frames a
+// batch wants decoded again. Parses the image itself.
+uint32_t decode_single(j40hip_pipeline *p, Job *j, hipStream_t s) {
+	uint32_t err = 0;
+	j40hip_frame *fr = j40hip_frame_parse_ex(j->buf, j->size, 1, 1u, &err);
+	if (!fr) return err ? err : E_MEM;
+	int64_t info[21];
+	j40hip_frame_info(fr, info);
+	j->width = info[0]; j->height = info[1];
+	if (j->stride < (size_t) j->width * 4) err = E_RNGE;
+	const size_t bytes = j->stride * (size_t) j->height;
+	void *dev = nullptr;
+	if (!err) { dev = j->device_output ? j->rgba : acquire_image(p, bytes); if (!dev) err = E_MEM; }
+	if (!err) err = j40hip_frame_upload_on(fr, p->device, s);
+	if (!err) err = j40hip_frame_decode(fr, dev, j->stride, s);
+	if (!err && hipStreamSynchronize(s) != hipSuccess) err = E_GPU;
+	if (!err) err = j40hip_frame_status(fr);
+	if (err == E_EVOF) {   // a section with more non-zero coefficients than its event region holds: dense planes
+		j40hip_frame_force_dense(fr, 1);
+		err = j40hip_frame_upload_on(fr, p->device, s);
+		if (!err) err = j40hip_frame_decode(fr, dev, j->stride, s);
+		if (!err && hipStreamSynchronize(s) != hipSuccess) err = E_GPU;
+		if (!err) err = j40hip_frame_status(fr);
+	}
+	if (!err) err = j40hip_frame_after_frame_status(fr);
+	if (!err && !j->device_output && hipMemcpyAsync(j->rgba, dev, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) err = E_GPU;
+	if (hipStreamSynchronize(s) != hipSuccess && !err) err = E_GPU;
+	j40hip_frame_mark_idle(fr);   // its stream has been waited for
+	j40hip_frame_free(fr);
+	if (dev && !j->device_output) release_image(p, dev, bytes);
+	return err;
+}
+
 void worker_main(j40hip_pipeline *p) {
 	if (hipSetDevice(p->device) != hipSuccess) { ++p->worker_errors; return; }
 	hipStream_t stream = nullptr;
 	if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { ++p->worker_errors; return; }
 	for (;;) {
 		Job *j = nullptr;
+		bool lf_dev = p->lf_mode == 1;
 		{
 			std::unique_lock<std::mutex> lock(p->m);
-			// back-pressure: uploaded frames hold their working set in HBM until their batch is done
+			// back-pressure: prepared frames hold their working set in HBM until their batch is done
 			p->cv_todo.wait(lock, [&] { return p->stop || (!p->todo.empty() && p->resident < (int64_t) p->batch_frames * (p->max_in_flight + 1)); });
 			if (p->stop) break;
 			j = p->todo.front(); p->todo.pop_front();
 			++p->resident; ++p->parsing;
+			if (p->lf_mode == 0) lf_dev = (int64_t) p->ready.size() + p->in_flight_frames < p->lf_hiwater;
 		}
 		const double t0 = now_ms();
-		uint32_t err = 0;
-		// (the LfGroup tail runs on the device, at upload; with lf_on_device the LfGroup streams too, while this thread sleeps)
-		j->frame = p->lf_on_device ? j40hip_frame_parse_on(j->buf, j->size, 1, 1u, p->device, stream, &err) : j40hip_frame_parse_ex(j->buf, j->size, 1, 1u, &err);
-		const bool lf_dev = j->frame && j40hip_frame_lf_on_device(j->frame);
+		j->af = j40hip_aframe_prepare(j->buf, j->size, p->device, stream, lf_dev ? 1 : 0);
 		const double t1 = now_ms();
-		if (j->frame) {
-			int64_t info[21];
-			j40hip_frame_info(j->frame, info);
-			j->width = info[0]; j->height = info[1];
-			j->single = info[2] != 0 || info[19] != 0;   // Modular frame, or a VarDCT frame with extra channels
-			if (j->stride < (size_t) j->width * 4) err = E_RNGE;
-			if (!err) err = j40hip_frame_upload_on(j->frame, p->device, stream);
-		}
+		bool single = j->af == nullptr;
+		if (j->af) {
+			j40hip_aframe_size(j->af, &j->width, &j->height);
+			if (j->stride < (size_t) j->width * 4) {
+				(void) hipStreamSynchronize(stream);   // (its copy is in flight)
+				j40hip_aframe_free(j->af); j->af = nullptr;
+				j->status = E_RNGE;
+			}
+		} else j->status = decode_single(p, j, stream);
 		const double t2 = now_ms();
 		std::unique_lock<std::mutex> lock(p->m);
-		p->parse_ms += t1 - t0; p->upload_ms += t2 - t1; p->lf_device_frames += lf_dev ? 1 : 0;
 		--p->parsing;
-		if (err) {
-			if (j->frame) { j40hip_frame_mark_idle(j->frame); j40hip_frame_free(j->frame); j->frame = nullptr; }
-			j->status = err;
+		if (single) { p->single_ms += t2 - t0; ++p->single_frames; } else p->parse_ms += t1 - t0;
+		if (!j->af) {
 			--p->resident;
 			complete(p, j);
 			p->cv_todo.notify_all(); p->cv_ready.notify_all();
 		} else {
+			p->lf_device_frames += j40hip_aframe_lf_on_device(j->af);
 			p->ready.push_back(j);
 			p->cv_ready.notify_all();
 		}
@@ -136,50 +193,31 @@ void worker_main(j40hip_pipeline *p) {
 	(void) hipStreamDestroy(stream);
 }
 
-void *acquire_image(j40hip_pipeline *p, size_t bytes) {   // GPU thread only
-	for (size_t i = 0; i < p->free_images.size(); ++i) if (p->free_images[i].second == bytes) { void *q = p->free_images[i].first; p->free_images.erase(p->free_images.begin() + (long) i); return q; }
-	void *q = nullptr;
-	if (hipMalloc(&q, bytes) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
-	return q;
-}
-
-// the single-frame path, synchronous: frames a batch cannot take, and the dense-plane repeat after "evof"
-uint32_t decode_single(j40hip_pipeline *p, Job *j, hipStream_t s) {
-	uint32_t err = j40hip_frame_decode(j->frame, j->dev_rgba, j->stride, s);
-	if (!err && hipStreamSynchronize(s) != hipSuccess) err = E_GPU;
-	if (!err) err = j40hip_frame_status(j->frame);
-	if (err == E_EVOF) {
-		j40hip_frame_force_dense(j->frame, 1);
-		err = j40hip_frame_upload_on(j->frame, p->device, s);
-		if (!err) err = j40hip_frame_decode(j->frame, j->dev_rgba, j->stride, s);
-		if (!err && hipStreamSynchronize(s) != hipSuccess) err = E_GPU;
-		if (!err) err = j40hip_frame_status(j->frame);
-	}
-	if (!err) err = j40hip_frame_after_frame_status(j->frame);
-	if (!err && !j->device_output && hipMemcpyAsync(j->rgba, j->dev_rgba, j->stride * (size_t) j->height, hipMemcpyDeviceToHost, s) != hipSuccess) err = E_GPU;
-	if (!err && hipStreamSynchronize(s) != hipSuccess) err = E_GPU;
-	return err;
-}
-
 void retire(j40hip_pipeline *p, Slot &slot) {   // GPU thread; waits for the slot's work, then hands the results out
 	const bool ok = hipEventSynchronize(slot.done) == hipSuccess;
 	float ms3[3] = {0, 0, 0};
-	const bool timed = ok && slot.batch && slot.batched > 0 && j40hip_batch_elapsed(slot.batch, 0, ms3) == 0;
-	for (Job *j : slot.jobs) {
+	const bool timed = ok && !slot.launch_err && j40hip_abatch_elapsed(slot.batch, ms3) == 0;
+	for (size_t i = 0; i < slot.jobs.size(); ++i) {
+		Job *j = slot.jobs[i];
 		if (!ok) j->status = E_GPU;
-		else if (!j->single) {
-			j->status = j40hip_frame_status_end(j->frame);
-			if (j->status == E_EVOF) j->status = decode_single(p, j, slot.stream);
-			else if (!j->status) j->status = j40hip_frame_after_frame_status(j->frame);
+		else if (slot.launch_err) j->status = slot.launch_err;
+		else if (!j->status) {   // (a copy back that could not be enqueued keeps its error)
+			uint32_t code = 0; int redo = 0;
+			j40hip_abatch_result(slot.batch, (int) i, &code, &redo);
+			if (redo) {
+				j40hip_aframe_free(j->af); j->af = nullptr;
+				if (!j->device_output && j->dev_rgba) { release_image(p, j->dev_rgba, j->stride * (size_t) j->height); j->dev_rgba = nullptr; }
+				j->status = decode_single(p, j, slot.stream);
+			} else j->status = code ? code : j40hip_aframe_after_frame_status(j->af);
 		}
-		j40hip_frame_mark_idle(j->frame);   // its stream has been waited for
-		j40hip_frame_free(j->frame); j->frame = nullptr;
-		if (!j->device_output && j->dev_rgba) p->free_images.push_back({j->dev_rgba, j->stride * (size_t) j->height});
+		if (j->af) { j40hip_aframe_free(j->af); j->af = nullptr; }   // its stream has been waited for
+		if (!j->device_output && j->dev_rgba) release_image(p, j->dev_rgba, j->stride * (size_t) j->height);
 	}
 	std::unique_lock<std::mutex> lock(p->m);
-	if (timed) { p->k1_ms += ms3[0]; p->k2_ms += ms3[1]; ++p->launches; p->launch_frames += slot.batched; }
+	if (timed) { p->lf_ms += ms3[0]; p->k1_ms += ms3[1]; p->k2_ms += ms3[2]; ++p->launches; p->launch_frames += (int64_t) slot.jobs.size(); }
+	p->in_flight_frames -= (int64_t) slot.jobs.size();
 	for (Job *j : slot.jobs) { --p->resident; complete(p, j); }
-	slot.jobs.clear(); slot.busy = false;
+	slot.jobs.clear(); slot.busy = false; slot.launch_err = 0;
 	p->cv_todo.notify_all();
 }
 
@@ -192,12 +230,16 @@ void gpu_main(j40hip_pipeline *p) {
 			auto launchable = [&] {
 				if (p->ready.empty()) return false;
 				if ((int64_t) p->ready.size() >= p->batch_frames) return true;
-				return p->todo.empty() && p->parsing == 0;   // the tail: nothing else is coming
+				return p->stop || (p->todo.empty() && p->parsing == 0);   // the tail: nothing else is coming
 			};
 			p->cv_ready.wait(lock, [&] { return p->stop || launchable() || (!p->in_flight.empty() && p->ready.empty()); });
-			if (p->stop && p->ready.empty() && p->in_flight.empty()) break;
+			if (p->stop && p->ready.empty() && p->in_flight.empty() && p->parsing == 0) break;
 			if (launchable()) {
 				while (!p->ready.empty() && (int64_t) take.size() < p->batch_frames) { take.push_back(p->ready.front()); p->ready.pop_front(); }
+				p->in_flight_frames += (int64_t) take.size();
+			} else if (p->in_flight.empty()) {   // stopping while a worker still finishes its frame
+				p->cv_ready.wait_for(lock, std::chrono::milliseconds(2));
+				continue;
 			}
 		}
 		if (take.empty()) {   // nothing to launch: retire the oldest batch in flight
@@ -208,30 +250,22 @@ void gpu_main(j40hip_pipeline *p) {
 		int si = -1;
 		for (size_t i = 0; i < p->slots.size(); ++i) if (!p->slots[i].busy) { si = (int) i; break; }
 		Slot &slot = p->slots[(size_t) si];
-		slot.busy = true; slot.jobs = take; slot.batched = 0;
-		std::vector<j40hip_frame *> frames; std::vector<void *> outs; std::vector<size_t> strides;
+		slot.busy = true; slot.jobs = take; slot.launch_err = 0;
+		std::vector<j40hip_aframe *> frames; std::vector<void *> outs; std::vector<size_t> strides;
 		uint32_t err = 0;
 		for (Job *j : take) {
 			j->dev_rgba = j->device_output ? j->rgba : acquire_image(p, j->stride * (size_t) j->height);
 			if (!j->dev_rgba) err = E_MEM;
-			if (!j->single) { frames.push_back(j->frame); outs.push_back(j->dev_rgba); strides.push_back(j->stride); }
+			frames.push_back(j->af); outs.push_back(j->dev_rgba); strides.push_back(j->stride);
 		}
-		if (!err && !frames.empty()) {
-			slot.batched = (int64_t) frames.size();
-			if (!slot.batch) slot.batch = j40hip_batch_create(frames.data(), (int64_t) frames.size(), &err);
-			else err = j40hip_batch_reset(slot.batch, frames.data(), (int64_t) frames.size());
-			if (!err) err = j40hip_batch_decode_recorded(slot.batch, outs.data(), strides.data(), slot.stream, 0);
-			for (Job *j : take) if (!err && !j->single) {
-				err = j40hip_frame_status_begin(j->frame, slot.stream);
-				if (!err && !j->device_output && hipMemcpyAsync(j->rgba, j->dev_rgba, j->stride * (size_t) j->height, hipMemcpyDeviceToHost, slot.stream) != hipSuccess) err = E_GPU;
-			}
-		}
-		for (Job *j : take) if (j->single) j->status = err ? err : decode_single(p, j, slot.stream);
-		if (err) for (Job *j : take) if (!j->single) j->status = err;
-		if (hipEventRecord(slot.done, slot.stream) != hipSuccess) for (Job *j : take) j->status = E_GPU;
+		if (!err && !slot.batch) { slot.batch = j40hip_abatch_create(p->device); if (!slot.batch) err = E_GPU; }
+		if (!err) err = j40hip_abatch_launch(slot.batch, frames.data(), (int) frames.size(), outs.data(), strides.data(), slot.stream);
+		if (!err) for (Job *j : take) if (!j->device_output && hipMemcpyAsync(j->rgba, j->dev_rgba, j->stride * (size_t) j->height, hipMemcpyDeviceToHost, slot.stream) != hipSuccess) j->status = E_GPU;
+		slot.launch_err = err;
+		if (hipEventRecord(slot.done, slot.stream) != hipSuccess && !slot.launch_err) slot.launch_err = E_GPU;
 		p->in_flight.push_back(si);
 	}
-	for (Slot &s : p->slots) if (s.batch) { j40hip_batch_free(s.batch); s.batch = nullptr; }
+	for (Slot &s : p->slots) if (s.batch) { j40hip_abatch_free(s.batch); s.batch = nullptr; }
 	for (auto &im : p->free_images) (void) hipFree(im.first);
 	p->free_images.clear();
 }
@@ -250,12 +284,14 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 	try {
 		p = new j40hip_pipeline();
 		p->device = device;
-		p->lf_on_device = (flags & 1u) != 0;
-		// every frame allocates (and frees) tens of megabytes of tables on its worker thread; as separate mmap()s those serialise all the
-		// threads on the process's address-space lock and fault every page in again. Keep such blocks in the heap instead.
-		if (!getenv("J40HIP_KEEP_MALLOC_DEFAULTS")) { (void) mallopt(M_MMAP_THRESHOLD, 1 << 30); (void) mallopt(M_TRIM_THRESHOLD, (int) (((size_t) 1 << 31) - 1)); (void) mallopt(M_TOP_PAD, 64 << 20); }
+		p->lf_mode = (int) (flags & 3u) > 2 ? 0 : (int) (flags & 3u);
+		// (flags bit 2, opt-in: keep multi-megabyte blocks in the heap instead of separate mmap()s -- many threads freeing such blocks
+		// serialise on the process's address-space lock and fault every page in again. Changes process-wide malloc behaviour.)
+		if (flags & 4u) { (void) mallopt(M_MMAP_THRESHOLD, 1 << 30); (void) mallopt(M_TRIM_THRESHOLD, (int) (((size_t) 1 << 31) - 1)); (void) mallopt(M_TOP_PAD, 64 << 20); }
 		p->batch_frames = batch_frames < 1 ? 32 : batch_frames;
 		p->max_in_flight = max_in_flight < 1 ? 2 : max_in_flight > 8 ? 8 : max_in_flight;
+		p->lf_hiwater = (int64_t) p->batch_frames * p->max_in_flight;
+		if (const char *e = getenv("J40HIP_LF_HIWATER")) p->lf_hiwater = atoll(e);
 		p->slots.resize((size_t) p->max_in_flight + 1);
 		for (Slot &s : p->slots) {
 			if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { *err = E_GPU; break; }
@@ -271,14 +307,16 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 	return p;
 }
 
+// Frames still queued are dropped (their tickets never complete); frames already prepared or in flight are decoded first.
 void j40hip_pipeline_free(j40hip_pipeline *p) {
 	if (!p) return;
 	{ std::unique_lock<std::mutex> lock(p->m); p->stop = true; p->cv_todo.notify_all(); p->cv_ready.notify_all(); }
 	for (std::thread &t : p->workers) if (t.joinable()) t.join();
+	{ std::unique_lock<std::mutex> lock(p->m); p->cv_ready.notify_all(); }
 	if (p->gpu.joinable()) p->gpu.join();
 	(void) hipSetDevice(p->device);
 	for (Job *j : p->todo) delete j;
-	for (Job *j : p->ready) { if (j->frame) j40hip_frame_free(j->frame); delete j; }
+	for (Job *j : p->ready) { if (j->af) { (void) hipDeviceSynchronize(); j40hip_aframe_free(j->af); } delete j; }
 	for (Slot &s : p->slots) { if (s.done) (void) hipEventDestroy(s.done); if (s.stream) (void) hipStreamDestroy(s.stream); }
 	delete p;
 }
@@ -319,14 +357,18 @@ uint32_t j40hip_pipeline_result(j40hip_pipeline *p, int64_t ticket) {
 	return p->results[(size_t) ticket];
 }
 
-/* out[0] = parse ms summed over the worker threads, out[1] = plan build + upload ms summed, out[2] = frames completed,
- * out[3] = ms from the first submit to the last completion, out[4] / out[5] = entropy / pixel stage ms summed over the batch launches
- * (HIP events on the launch streams), out[6] = batch launches, out[7] = frames in them */
-void j40hip_pipeline_stats(j40hip_pipeline *p, double *out4) {
-	if (!p || !out4) return;
+/* see include/j40hip.h */
+void j40hip_pipeline_stats(j40hip_pipeline *p, double *out) {
+	if (!p || !out) return;
 	std::unique_lock<std::mutex> lock(p->m);
-	out4[0] = p->parse_ms; out4[1] = p->upload_ms; out4[2] = (double) p->completed; out4[3] = p->last_done_ms - p->first_submit_ms;
-	out4[4] = p->k1_ms; out4[5] = p->k2_ms; out4[6] = (double) p->launches; out4[7] = (double) p->launch_frames;
+	out[0] = p->parse_ms; out[1] = p->single_ms; out[2] = (double) p->completed; out[3] = p->last_done_ms - p->first_submit_ms;
+	out[4] = p->k1_ms; out[5] = p->k2_ms; out[6] = (double) p->launches; out[7] = (double) p->launch_frames;
+}
+void j40hip_pipeline_stats_ex(j40hip_pipeline *p, double *out) {
+	if (!p || !out) return;
+	j40hip_pipeline_stats(p, out);
+	std::unique_lock<std::mutex> lock(p->m);
+	out[8] = p->lf_ms; out[9] = (double) p->lf_device_frames; out[10] = (double) p->single_frames; out[11] = 0;
 }
 
 int64_t j40hip_pipeline_lf_device_frames(j40hip_pipeline *p) { if (!p) return 0; std::unique_lock<std::mutex> lock(p->m); return p->lf_device_frames; }
@@ -334,8 +376,8 @@ int64_t j40hip_pipeline_lf_device_frames(j40hip_pipeline *p) { if (!p) return 0;
 void j40hip_pipeline_reset_stats(j40hip_pipeline *p) {
 	if (!p) return;
 	std::unique_lock<std::mutex> lock(p->m);
-	p->parse_ms = p->upload_ms = 0; p->first_submit_ms = 0; p->last_done_ms = 0;
-	p->k1_ms = p->k2_ms = 0; p->launches = p->launch_frames = 0; p->lf_device_frames = 0;
+	p->parse_ms = p->single_ms = 0; p->first_submit_ms = 0; p->last_done_ms = 0;
+	p->lf_ms = p->k1_ms = p->k2_ms = 0; p->launches = p->launch_frames = 0; p->lf_device_frames = p->single_frames = 0;
 }
 
 } // extern "C"

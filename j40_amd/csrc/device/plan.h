@@ -300,9 +300,11 @@ struct DevLfTask {
 	uint32_t byte_off, size, bit_off;
 	int32_t w8, h8, w64, h64, sidx0, sidx2;
 	int32_t nbvb_bits;      // ceil(log2(w8 * h8)): the width of the varblock count
-	int16_t *out;           // this task's planes: lf[3] (w8 * h8 each, streamed order Y, X, B), xfromy, bfromy (w64 * h64 each), varblock
-	                        // info (2 rows of nb_varblocks, pitch nb_varblocks), sharpness (w8 * h8)
-	uint32_t out_capacity;  // int16 elements reserved at `out`
+	// where the decoded planes go: the LF coefficients in streamed order Y, X, B (w8 * h8 each), the chroma-from-luma maps (w64 * h64
+	// each), the varblock-info channel (2 rows of nb_varblocks, pitch nb_varblocks; info_capacity int16 elements are reserved: a
+	// section that claims more varblocks than that reports ERR_LFFB), the sharpness map (w8 * h8; nobody reads it)
+	int16_t *lf[3], *xfromy, *bfromy, *info, *sharp;
+	uint32_t info_capacity;
 	DevLfResult *result;
 };
 enum { ERR_LFFB = ('l' << 24) | ('f' << 16) | ('f' << 8) | 'b' };   // not an error of the stream: the second Modular header is not the plain one the device handles; the host decodes this section
@@ -358,7 +360,11 @@ struct DevPlanBuild {
 	// LfGroup reported ERR_LFFB, bit 1: some section ERR_EVOF), [2] union of DevLfSlot::dct_used, [3] varblocks
 	uint32_t *verdict;
 	const uint32_t *lf_section_off;   // [num_lf_groups] byte offset of every LfGroup section (the order the reference reads them in)
+	// the LfGroup tail (lf_tail_kernels.hip): scratch of three planes of `cells` floats for the dequantised, smoothed LF samples
+	float *lf_scratch; float inv_m_lf[3]; int32_t lf_smooth; uint32_t cells;
 };
+// one LfGroup of a batch of frames
+struct DevBatchLf { int32_t frame, lfg; };
 
 // sizes the host knows about a Modular frame's tree and code tables, to lay out k_modular_sections' LDS
 struct ModLaunchInfo {
@@ -383,6 +389,8 @@ enum {
 	ERR_PRED = ('p' << 24) | ('r' << 16) | ('e' << 8) | 'd',
 	ERR_TREC = ('t' << 24) | ('r' << 16) | ('e' << 8) | 'c',
 	ERR_TODO = ('T' << 24) | ('O' << 16) | ('D' << 8) | 'O',
+	ERR_VBLK = ('v' << 24) | ('b' << 16) | ('l' << 8) | 'k',
+	ERR_DCTQ = ('d' << 24) | ('c' << 16) | ('t' << 8) | '?',
 	ERR_EVOF = ('e' << 24) | ('v' << 16) | ('o' << 8) | 'f',   // a section's event region is full: decode the frame with dense planes
 };
 

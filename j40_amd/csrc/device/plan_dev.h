@@ -17,7 +17,6 @@
 
 namespace j40hip {
 
-enum { ERR_VBLK = ('v' << 24) | ('b' << 16) | ('l' << 8) | 'k', ERR_DCTQ = ('d' << 24) | ('c' << 16) | ('t' << 8) | '?' };
 enum { PLAN_LOG_GSIZE8 = 5 };   // VarDCT frames: groups of 256 x 256 pixels = 32 x 32 cells (frame.cpp: group_size_shift stays 8)
 
 // occ[x * stride]: the row below the lowest cell any placed block occupies in column x; grp_cnt[64 * stride], cls_cnt[28 * stride]:

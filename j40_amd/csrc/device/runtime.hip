@@ -14,8 +14,10 @@
 #include "../tables.hpp"
 #include "../plan_build.hpp"
 #include "kernels.h"
+#include "runtime_shared.hpp"
 
 using namespace j40hip;
+using namespace j40hip_rt;
 
 namespace {
 
@@ -50,15 +52,17 @@ size_t cache_limit_bytes() {
 	return limit;
 }
 
+} // namespace
+
 // frees every cached block of `device` (they are idle by construction: blocks enter the cache after a device synchronisation)
-void cache_trim(int device) {
+void j40hip_rt::cache_trim(int device) {
 	if (device < 0 || device >= 16) return;
 	std::lock_guard<std::mutex> lock(g_cache_mutex);
 	for (CachedBlock &b : g_cache[device]) (void) hipFree(b.ptr);
 	g_cache[device].clear(); g_cached_bytes[device] = 0;
 }
 
-void *cache_acquire(int device, size_t bytes, size_t *got, bool *clean) {
+void *j40hip_rt::cache_acquire(int device, size_t bytes, size_t *got, bool *clean) {
 	bytes = (bytes + 4095) & ~(size_t) 4095;
 	if (device >= 0 && device < 16) {
 		std::lock_guard<std::mutex> lock(g_cache_mutex);
@@ -82,7 +86,7 @@ void *cache_acquire(int device, size_t bytes, size_t *got, bool *clean) {
 	return p;
 }
 
-void cache_release(int device, void *ptr, size_t bytes, bool clean) {
+void j40hip_rt::cache_release(int device, void *ptr, size_t bytes, bool clean) {
 	if (!ptr) return;
 	if (device >= 0 && device < 16) {
 		std::lock_guard<std::mutex> lock(g_cache_mutex);
@@ -95,6 +99,8 @@ void cache_release(int device, void *ptr, size_t bytes, bool clean) {
 	(void) hipFree(ptr);
 }
 
+namespace {
+
 bool DeviceBuffer::alloc(size_t n) {
 	bytes = n;
 	if (hipMalloc(&ptr, n ? n : 16) == hipSuccess) return true;
@@ -104,23 +110,6 @@ bool DeviceBuffer::alloc(size_t n) {
 	return hipMalloc(&ptr, n ? n : 16) == hipSuccess;
 }
 
-// host-side staging of the plan: every array lands in one blob at a 256-byte aligned offset, one copy moves it. The blob lives
-// in PINNED host memory owned by the calling thread (grown on demand, reused by that thread's next upload), so the copy is a
-// true asynchronous DMA that overlaps the kernels of other frames; j40hip_thread_release gives it back.
-struct PinnedStage {
-	uint8_t *ptr = nullptr; size_t cap = 0;
-	bool reserve(size_t n, size_t keep) {
-		if (n <= cap) return true;
-		size_t want = std::max(n + n / 4, (size_t) 1 << 20);
-		void *q = nullptr;
-		if (hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); return false; }
-		if (keep) memcpy(q, ptr, keep);
-		if (ptr) (void) hipHostFree(ptr);
-		ptr = (uint8_t *) q; cap = want;
-		return true;
-	}
-	void release() { if (ptr) (void) hipHostFree(ptr); ptr = nullptr; cap = 0; }
-};
 thread_local PinnedStage t_stage;   // (no destructor: at process exit the runtime may be gone before the thread's storage)
 
 struct Stager {
@@ -144,7 +133,8 @@ struct Stager {
 // the constant tables of the pixel kernels go up once per device (they never change)
 std::mutex g_const_mutex;
 bool g_const_done[16];
-bool ensure_constant_tables(int device) {
+} // namespace
+bool j40hip_rt::ensure_constant_tables(int device) {
 	if (device < 0 || device >= 16) return false;
 	std::lock_guard<std::mutex> lock(g_const_mutex);
 	if (g_const_done[device]) return true;
@@ -153,8 +143,6 @@ bool ensure_constant_tables(int device) {
 	if (hipStreamSynchronize(nullptr) != hipSuccess) return false;
 	return g_const_done[device] = true;
 }
-
-} // namespace
 
 struct j40hip_device_state {
 	int device = 0;
@@ -511,7 +499,7 @@ static bool lf_device_decode(void *ctx_, const Frame &f, const uint8_t *cs, size
 	size_t out_elems = 0;
 	for (size_t i = 0; i < tasks.size(); ++i) {
 		const size_t cells = (size_t) tasks[i].w8 * (size_t) tasks[i].h8, c64 = (size_t) tasks[i].w64 * (size_t) tasks[i].h64;
-		out_off[i] = out_elems; out_elems += (6 * cells + 2 * c64 + 63) & ~(size_t) 63;
+		out_off[i] = out_elems; out_elems += (6 * cells + 2 * c64 + 63) & ~(size_t) 63;   // lf[3], xfromy, bfromy, info (2 * cells), sharpness
 	}
 	Stager sg;
 	const size_t o_cs = sg.put(cs, cs_size); (void) sg.reserve(32);   // (the decoder's word window reads a little past the last section)
@@ -537,7 +525,12 @@ static bool lf_device_decode(void *ctx_, const Frame &f, const uint8_t *cs, size
 			d.codestream = block + o_cs; d.tree = (const DevCoopTree *) (block + o_tree); d.alias = (const uint64_t *) (block + o_alias); d.log_alpha_size = log_alpha;
 			d.byte_off = (uint32_t) t.byte_off; d.size = (uint32_t) t.size; d.bit_off = t.bit_off;
 			d.w8 = t.w8; d.h8 = t.h8; d.w64 = t.w64; d.h64 = t.h64; d.sidx0 = t.sidx0; d.sidx2 = t.sidx2; d.nbvb_bits = t.nbvb_bits;
-			d.out = (int16_t *) (block + o_out) + out_off[i]; d.out_capacity = (uint32_t) (6 * (size_t) t.w8 * (size_t) t.h8 + 2 * (size_t) t.w64 * (size_t) t.h64);
+			{   // this task's planes, one after the other: lf[3], xfromy, bfromy, varblock info (room for one varblock per cell), sharpness
+				const size_t cells = (size_t) t.w8 * (size_t) t.h8, c64 = (size_t) t.w64 * (size_t) t.h64;
+				int16_t *p = (int16_t *) (block + o_out) + out_off[i];
+				for (int c = 0; c < 3; ++c) d.lf[c] = p + (size_t) c * cells;
+				d.xfromy = p + 3 * cells; d.bfromy = d.xfromy + c64; d.info = d.bfromy + c64; d.sharp = d.info + 2 * cells; d.info_capacity = (uint32_t) (2 * cells);
+			}
 			d.result = (DevLfResult *) (block + o_res) + i;
 		}
 		LfService &sv = *lf_service(ctx.device);
@@ -837,7 +830,7 @@ struct j40hip_batch {
 	DevPlan *d_plans = nullptr;
 	std::vector<DevPlan> plans_host;   // what d_plans holds (batch_enqueue re-uploads it when a member was uploaded again)
 	std::vector<HfLaneWork> work_host;
-	size_t plans_cap = 0, work_cap = 0, k2_cap = 0;
+	size_t plans_cap = 0, work_cap = 0;
 	bool arrays_dirty = true;          // plans_host / work_host have not been copied to the device yet
 	int side_in_use = 0;               // side streams the current membership spreads its pixel kernels over
 	HfLaneWork *d_work = nullptr;
@@ -854,12 +847,6 @@ struct j40hip_batch {
 	std::vector<hipStream_t> side;
 	std::vector<hipEvent_t> side_done;
 	hipEvent_t fork = nullptr;
-	// ... or (J40HIP_K2_BATCHED=1) run as one launch per transform class over all frames (blockIdx.y = frame). Measured slower
-	// than the side streams (33.9 vs 31.5 ms for 128 8K frames): the classes then run one after the other, each with its tail
-	bool k2_batched = false;
-	std::vector<K2Frame> k2_host;   // outputs as of the last decode
-	K2Frame *d_k2 = nullptr;
-	std::vector<int32_t> k2_class_start;   // [frames][28]
 };
 
 extern "C" void j40hip_batch_free(j40hip_batch *b) {
@@ -867,7 +854,6 @@ extern "C" void j40hip_batch_free(j40hip_batch *b) {
 	(void) hipSetDevice(b->device);
 	if (b->d_plans) (void) hipFree(b->d_plans);
 	if (b->d_work) (void) hipFree(b->d_work);
-	if (b->d_k2) (void) hipFree(b->d_k2);
 	for (auto &e : b->ev) if (e) (void) hipEventDestroy(e);
 	for (auto &e : b->slots) if (e) (void) hipEventDestroy(e);
 	for (auto &e : b->side_done) if (e) (void) hipEventDestroy(e);
@@ -928,22 +914,6 @@ static uint32_t batch_assign(j40hip_batch *b, j40hip_frame *const *frames, int64
 		if (hipMalloc((void **) &b->d_work, sizeof(HfLaneWork) * b->work_cap) != hipSuccess) { b->d_work = nullptr; b->work_cap = 0; return ERR_GPU; }
 	}
 	b->arrays_dirty = true;
-	if (const char *e = getenv("J40HIP_K2_BATCHED")) b->k2_batched = atoi(e) != 0;
-	if (b->k2_batched) {
-		b->k2_host.clear(); b->k2_class_start.clear();
-		for (j40hip_frame *h : b->frames) {
-			K2Frame k; memset(&k, 0, sizeof k);
-			k.plan = h->dev->plan; k.sorted = h->dev->d_vb_sorted; k.large_scratch = h->dev->d_large_scratch;
-			memcpy(k.class_start, h->dev->class_start, sizeof k.class_start);
-			b->k2_host.push_back(k);
-			b->k2_class_start.insert(b->k2_class_start.end(), h->dev->class_start, h->dev->class_start + 28);
-		}
-		if (b->k2_host.size() > b->k2_cap) {
-			if (b->d_k2) (void) hipFree(b->d_k2);
-			b->k2_cap = b->k2_host.size() + b->k2_host.size() / 2;
-			if (hipMalloc((void **) &b->d_k2, sizeof(K2Frame) * b->k2_cap) != hipSuccess) { b->d_k2 = nullptr; b->k2_cap = 0; return ERR_GPU; }
-		}
-	}
 	// side streams for the pixel kernels: made once, as many as the largest membership so far asks for
 	{
 		int nside = (int) std::min<size_t>(16, b->frames.size());
@@ -1006,23 +976,7 @@ static uint32_t batch_enqueue(j40hip_batch *b, void *const *rgba_dev, const size
 	if (b->lanes_fast && !getenv("J40HIP_GENERIC_LANES")) launch_hf_lanes(b->d_plans, b->d_work, b->num_work, b->waves_per_wg, b->lanes_lds_bytes, s);
 	else launch_hf_entropy_lanes(b->d_plans, b->d_work, b->num_work, b->tables_in_lds, b->lds_bytes, s);
 	if (ev) (void) hipEventRecord(ev[2], s);
-	if (b->k2_batched) {
-		bool changed = false;
-		for (size_t i = 0; i < b->frames.size(); ++i) {
-			K2Frame &k = b->k2_host[i];
-			const DevPlan &now = b->frames[i]->dev->plan;   // (a frame re-uploaded since, e.g. forced dense, has new pointers)
-			if (k.rgba != (uint8_t *) rgba_dev[i] || k.stride != stride_bytes[i] || memcmp(&k.plan, &now, sizeof now) != 0) {
-				j40hip_device_state *st = b->frames[i]->dev;
-				k.rgba = (uint8_t *) rgba_dev[i]; k.stride = stride_bytes[i]; k.plan = now; k.sorted = st->d_vb_sorted; k.large_scratch = st->d_large_scratch;
-				memcpy(k.class_start, st->class_start, sizeof k.class_start); memcpy(&b->k2_class_start[28 * i], st->class_start, sizeof k.class_start);
-				changed = true;
-			}
-		}
-		// stream-ordered behind the kernels of an earlier decode that may still be reading the array; the host vector is
-		// copied out before the call returns (pageable source)
-		if (changed && hipMemcpyAsync(b->d_k2, b->k2_host.data(), sizeof(K2Frame) * b->k2_host.size(), hipMemcpyHostToDevice, s) != hipSuccess) return ERR_GPU;
-		launch_vardct_batch(b->d_k2, (int32_t) b->frames.size(), b->k2_class_start.data(), s);
-	} else if (b->side_in_use == 0) {
+	if (b->side_in_use == 0) {
 		for (size_t i = 0; i < b->frames.size(); ++i) {
 			j40hip_device_state *st = b->frames[i]->dev;
 			launch_vardct_frame(st->plan, st->class_start, st->d_vb_sorted, st->d_large_scratch, (uint8_t *) rgba_dev[i], stride_bytes[i], s);

@@ -15,8 +15,8 @@ def _mix():
     return [(w, h, synth(m, w, h, s, **o)) for m, w, h, s, o in items]
 
 
-@pytest.mark.parametrize("device_output", [False, True])
-def test_pipeline_matches_single_image_decodes(built, ref, device_output):
+@pytest.mark.parametrize("device_output,lf_streams", [(False, "auto"), (True, "device"), (True, "host")])
+def test_pipeline_matches_single_image_decodes(built, ref, device_output, lf_streams):
     import torch
     import j40_amd
     mix = _mix()
@@ -24,7 +24,7 @@ def test_pipeline_matches_single_image_decodes(built, ref, device_output):
     mix.append((520, 264, bytes(damaged)))
     mix.append((520, 264, mix[0][2][: len(mix[0][2]) - 90]))   # truncated: "shrt"
     mix = mix * 3                                                # 39 images, several batches of 8
-    pipe = j40_amd.Pipeline(device=0, host_threads=6, batch_frames=8, max_in_flight=2)
+    pipe = j40_amd.Pipeline(device=0, host_threads=6, batch_frames=8, max_in_flight=2, lf_streams=lf_streams)
     outs, tickets = [], []
     for w, h, data in mix:
         o = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0") if device_output else torch.zeros((h, w, 4), dtype=torch.uint8).pin_memory()
@@ -46,6 +46,9 @@ def test_pipeline_matches_single_image_decodes(built, ref, device_output):
     assert seen_errors >= 3
     st = pipe.stats()
     assert st["completed"] == len(mix)
+    assert st["launch_frames"] >= 24 and st["single_frames"] >= 9      # both paths were taken
+    if lf_streams != "auto":
+        assert (st["lf_device_frames"] > 0) == (lf_streams == "device")
     pipe.close()
 
 
@@ -102,22 +105,31 @@ LF_DEVICE_CASES = [
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,w,h,seed,opts", LF_DEVICE_CASES)
-def test_lf_group_streams_on_the_device_equal_the_host_parse(built, mode, w, h, seed, opts):
-    """j40hip_frame_parse_on: LF coefficients and HF metadata of every LfGroup section decoded by k_lf_groups; everything the
-    host derives from them (LF index, varblock placement, LLF coefficients) and the decoded pixels must equal the host parse's"""
+def test_lf_group_streams_on_the_device_equal_the_host_parse(built, ref, mode, w, h, seed, opts):
+    """j40hip_frame_parse_on: LF coefficients and HF metadata of every LfGroup section decoded by k_lf_groups; everything derived
+    from them (block map, LF index, chroma-from-luma maps, varblocks, LLF coefficients) must equal the REFERENCE's internals after it
+    has read the same sections (RefStage: j40__lf_group_st, j40.h:6360-6390), and the host parse's; same pixels as the host parse"""
     import j40_amd
+    from refdec import RefStage
     data = synth(mode, w, h, seed, **opts)
     host, dev = j40_amd.Frame(data), j40_amd.Frame(data, lf_device=0)
+    rs = RefStage(ref, data)
     assert dev.lf_on_device() and not host.lf_on_device()
-    assert host.info == dev.info
+    assert host.info == dev.info == rs.info
     for gg in range(host.info["num_lf_groups"]):
-        assert host.lf_group_info(gg) == dev.lf_group_info(gg)
+        assert host.lf_group_info(gg) == dev.lf_group_info(gg) == rs.lf_group_info(gg)
         for which in range(4):
+            assert np.array_equal(rs.plane(gg, which), dev.plane(gg, which)), (gg, which)
             assert np.array_equal(host.plane(gg, which), dev.plane(gg, which)), (gg, which)
+        ra, rb = rs.varblocks(gg)
+        da, db = dev.varblocks(gg)
+        assert np.array_equal(ra, da) and np.array_equal(rb.view(np.uint32), db.view(np.uint32))
         for a, b in zip(host.varblocks(gg), dev.varblocks(gg)):
             assert np.array_equal(a, b)
         for c in range(3):
+            assert np.array_equal(rs.llf(gg, c).view(np.uint32), dev.llf(gg, c).view(np.uint32)), "LLF coefficients must be bit-identical to the reference's"
             assert np.array_equal(host.llf(gg, c), dev.llf(gg, c))
+    rs.close()
     for f in (host, dev):
         f.upload(0)
     (ea, pa), (eb, pb) = host.decode_to_host(), dev.decode_to_host()
@@ -151,3 +163,142 @@ def test_lf_group_streams_on_the_device_report_damage_like_the_host(built, ref):
         assert outcomes[0][0] == ref.decode(bytes(m))[0] or outcomes[0][0] == ""   # (errors behind the LfGroups surface at decode time)
         seen.add(outcomes[0][0])
     assert len(seen) >= 2, "the damage should have hit some LfGroup section"
+
+
+PIPELINE_PLAN_CASES = [
+    ("vardct", 776, 520, 31, dict()),
+    ("vardct", 2600, 2100, 32, dict(bctx=1)),                  # four LfGroup sections, custom LF thresholds (LF index)
+    ("vardct", 2049, 300, 33, dict(maxlog=8, cfl=1)),          # a 1-cell-wide second LfGroup, 256x256 transforms
+    ("vardct", 776, 520, 3, dict(maxlog=8, bctx=1, presets=2, orders=1)),
+    ("vardct", 1920, 1080, 34, dict(forward=1)),
+    ("vardct", 520, 264, 36, dict(passes=3)),
+    ("vardct", 520, 264, 38, dict(hfprefix=1, hflz77=1)),      # the generic entropy kernel
+    ("vardct", 520, 264, 39, dict(dq=2)),                      # custom dequantisation matrices: static tables of their own
+    ("vardct", 4100, 2100, 37, dict()),                        # 3 x 2 LfGroups
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lf_streams", ["device", "host"])
+def test_pipeline_batches_give_the_reference_pixels(built, ref, lf_streams):
+    """every stream family the batched path takes -- LfGroup streams by k_lf_groups or by the host threads, plan build, LfGroup tail,
+    entropy decode, persistent pixel kernels on the device -- against the unmodified reference's pixels (bar: one level; in practice
+    identical), each stream twice in the same batch"""
+    import torch
+    import j40_amd
+    datas = [synth(m, w, h, s, **o) for m, w, h, s, o in PIPELINE_PLAN_CASES]
+    pipe = j40_amd.Pipeline(device=0, host_threads=4, batch_frames=2 * len(datas), max_in_flight=2, lf_streams=lf_streams)
+    outs, tickets = [], []
+    for rep in range(2):
+        for (m, w, h, s, o), data in zip(PIPELINE_PLAN_CASES, datas):
+            outs.append(torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0"))
+            tickets.append(pipe.submit(data, outs[-1].data_ptr(), w * 4, device_output=True))
+    pipe.drain()
+    torch.cuda.synchronize()
+    st = pipe.stats()
+    assert st["single_frames"] == 0 and st["launch_frames"] == 2 * len(datas)
+    for k, t in enumerate(tickets):
+        assert pipe.result(t) == "", (PIPELINE_PLAN_CASES[k % len(datas)], pipe.result(t))
+        rerr, expect = ref.decode(datas[k % len(datas)])
+        assert rerr == ""
+        d = np.abs(outs[k].cpu().numpy().astype(int) - expect.astype(int))
+        assert d.max() <= 1, (PIPELINE_PLAN_CASES[k % len(datas)], int(d.max()), int((d > 0).sum()))
+    pipe.close()
+
+
+@pytest.mark.gpu
+def test_pipeline_reports_damaged_lf_sections_like_the_reference(built, ref):
+    """bit flips in the LfGroup sections (and a few in front of them): the batched path's verdict -- first failing section in file
+    order, whichever stage found it -- is the reference's error code, and undamaged-looking results have the reference's pixels"""
+    import torch
+    import j40_amd
+    data = synth("vardct", 2600, 2100, 41)
+    fr = j40_amd.Frame(data)
+    sizes = fr.section_sizes()
+    fr.close()
+    start, end = 200, len(data) - int(sizes.sum())
+    rng = np.random.default_rng(5)
+    muts = []
+    for _ in range(48):
+        m = bytearray(data)
+        m[int(rng.integers(start, end))] ^= 1 << int(rng.integers(0, 8))
+        muts.append(bytes(m))
+    for lf_streams in ("device", "host"):
+        pipe = j40_amd.Pipeline(device=0, host_threads=4, batch_frames=16, max_in_flight=2, lf_streams=lf_streams)
+        outs = [torch.zeros((2100, 2600, 4), dtype=torch.uint8, device="cuda:0") for _ in muts]
+        ts = [pipe.submit(m, o.data_ptr(), 2600 * 4, device_output=True) for m, o in zip(muts, outs)]
+        pipe.drain()
+        torch.cuda.synchronize()
+        codes = set()
+        for m, o, t in zip(muts, outs, ts):
+            rerr, rpx = ref.decode(m)
+            assert pipe.result(t) == rerr, (lf_streams, pipe.result(t), rerr)
+            codes.add(rerr)
+            if rerr == "":
+                assert np.abs(o.cpu().numpy().astype(int) - rpx.astype(int)).max() <= 1
+        assert len(codes) >= 3, codes
+        pipe.close()
+
+
+@pytest.mark.gpu
+def test_pipeline_freed_with_work_pending_does_not_hang(built):
+    """closing a pipeline that still has submitted, prepared and in-flight frames returns (frames not yet taken by a worker are
+    dropped, the others are decoded first)"""
+    import torch
+    import j40_amd
+    datas = [synth("vardct", 520, 264, 70 + i) for i in range(4)]
+    for batch_frames, n in ((8, 5), (4, 23), (64, 40)):
+        pipe = j40_amd.Pipeline(device=0, host_threads=2, batch_frames=batch_frames, max_in_flight=1)
+        outs = [torch.zeros((264, 520, 4), dtype=torch.uint8, device="cuda:0") for _ in range(n)]
+        for i in range(n):
+            pipe.submit(datas[i % 4], outs[i].data_ptr(), 520 * 4, device_output=True)
+        pipe.close()
+        torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_pipeline_1080p_batch_of_256_frames_pixel_exact_per_stream(built, ref):
+    """BASELINE config 5's shape at a quarter of its size: 256 frames of 1920x1080 (16 distinct streams, the forward-encoded family
+    among them) in batches of 128; every output is compared with the reference's pixels of its stream"""
+    import torch
+    import j40_amd
+    specs = [("vardct", 1920, 1080, 110 + i, dict(forward=1) if i % 4 == 3 else {}) for i in range(16)]
+    datas = [synth(*s[:4], **s[4]) for s in specs]
+    expect = []
+    for d in datas:
+        rerr, px = ref.decode(d)
+        assert rerr == ""
+        expect.append(torch.from_numpy(px))
+    pipe = j40_amd.Pipeline(device=0, host_threads=8, batch_frames=128, max_in_flight=2)
+    outs = [torch.zeros((1080, 1920, 4), dtype=torch.uint8, device="cuda:0") for _ in range(256)]
+    ts = [pipe.submit(datas[i % 16], outs[i].data_ptr(), 1920 * 4, device_output=True) for i in range(256)]
+    pipe.drain()
+    torch.cuda.synchronize()
+    for i, t in enumerate(ts):
+        assert pipe.result(t) == ""
+        d = (outs[i].cpu().to(torch.int16) - expect[i % 16].to(torch.int16)).abs()
+        assert int(d.max()) <= 1, (i, int(d.max()))
+    pipe.close()
+
+
+@pytest.mark.gpu
+def test_pipeline_forward_encoded_8k_frame_matches_reference(built, ref):
+    """the frame bench.py times: a 7680x4320 picture encoded at about distance 1, through the batched path (twice, LfGroup streams
+    once on the device and once on the host threads)"""
+    import torch
+    import j40_amd
+    data = synth("vardct", 7680, 4320, 3, forward=1)
+    rerr, expect = ref.decode(data)
+    assert rerr == ""
+    for lf_streams in ("device", "host"):
+        pipe = j40_amd.Pipeline(device=0, host_threads=2, batch_frames=2, max_in_flight=1, lf_streams=lf_streams)
+        outs = [torch.zeros((4320, 7680, 4), dtype=torch.uint8, device="cuda:0") for _ in range(2)]
+        ts = [pipe.submit(data, o.data_ptr(), 7680 * 4, device_output=True) for o in outs]
+        pipe.drain()
+        torch.cuda.synchronize()
+        for o, t in zip(outs, ts):
+            assert pipe.result(t) == ""
+            d = np.abs(o.cpu().numpy().astype(np.int16) - expect.astype(np.int16))
+            assert d.max() <= 1, (lf_streams, int(d.max()), int((d > 0).sum()))
+        assert pipe.stats()["single_frames"] == 0
+        pipe.close()
