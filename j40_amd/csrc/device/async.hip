@@ -10,6 +10,8 @@
 // Nothing here touches the oracle, and there is no CPU fallback for the hot path: without a HIP device prepare returns nullptr
 // and the caller's single-frame path reports "!gpu".
 #include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -67,11 +69,33 @@ std::shared_ptr<StaticEntry> static_tables_for(const Frame &fr, int device) {
 	return e;
 }
 
-// this thread's pinned staging: two buffers, so that the copy of one frame runs while the next one is being staged
+// This thread's pinned staging buffers. A buffer is free again once the copy out of it has completed -- which can take long after
+// the call returned (the copy waits its turn behind whatever occupies the stream's hardware queue) -- and the thread must never wait
+// for the device: it takes the first free buffer, and makes another one when none is free.
 struct AStage { PinnedStage mem; hipEvent_t done = nullptr; bool pending = false; };
-thread_local AStage t_astage[2];
-thread_local int t_astage_next = 0;
+thread_local std::vector<std::unique_ptr<AStage>> t_astages;   // (no destructor work: j40hip_astage_release, or the process ends)
 thread_local FrontPlan t_front;
+// J40HIP_ASYNC_TIMING=1: where this thread's host stage spends its time (ms; printed when the thread lets go of its staging)
+thread_local double t_prof[8]; thread_local int64_t t_prof_frames = 0;
+double prof_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+AStage *astage_acquire(size_t bytes) {
+	for (auto &s : t_astages) {
+		if (s->pending && hipEventQuery(s->done) != hipSuccess) { (void) hipGetLastError(); continue; }
+		s->pending = false;
+		return s->mem.reserve(bytes, 0) ? s.get() : nullptr;
+	}
+	if (t_astages.size() >= 64) {   // (never seen: the pipeline bounds the frames in flight) wait for the oldest
+		AStage *s = t_astages.front().get();
+		(void) hipEventSynchronize(s->done); s->pending = false;
+		return s->mem.reserve(bytes, 0) ? s : nullptr;
+	}
+	std::unique_ptr<AStage> s(new AStage());
+	if (hipEventCreateWithFlags(&s->done, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+	if (!s->mem.reserve(bytes, 0)) { (void) hipEventDestroy(s->done); return nullptr; }
+	t_astages.push_back(std::move(s));
+	return t_astages.back().get();
+}
 
 struct Layout {
 	size_t size = 0;
@@ -113,9 +137,11 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	j40hip_frame &h = af->host;
 	Frame &fr = h.frame;
 	std::vector<LfDeviceTask> tasks; std::vector<int32_t> extra_prec; bool plain = true;
+	const double tp0 = prof_now();
 	extract_codestream((const uint8_t *) buf, size, &h.cs, &h.cs_size, &h.cs_storage, &h.container_stray_tail);
 	h.bare_codestream = h.cs == (const uint8_t *) buf && h.cs_size == size;
 	if (!parse_frame_front(h.cs, h.cs_size, &fr, &tasks, &extra_prec, &plain)) return nullptr;
+	const double tp1 = prof_now();
 	af->st = static_tables_for(fr, device);
 	if (!af->st || af->st->any_dq_error) return nullptr;   // (a matrix that does not load: whether it matters depends on the varblocks -- the single-frame path sorts it out)
 	StaticTables offs;   // (offsets only)
@@ -124,6 +150,7 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	FrontPlan &fp = t_front;
 	if (build_front_plan(fr, offs, h.cs_size, extra_prec, lf_on_device != 0 && plain, &fp)) return nullptr;
 	const bool dev_lf = fp.lf_coop;
+	const double tp2 = prof_now();
 	const size_t ngg = fp.lf_groups.size(), cells = fp.cells, c64s = fp.c64s, cs_size = h.cs_size;
 	const int32_t num_groups = fp.frame.num_groups;
 	af->num_lf_groups = (int32_t) ngg; af->max_lf_cells = fp.max_lf_cells; af->num_groups = num_groups; af->num_passes = fp.frame.num_passes; af->cells = cells;
@@ -146,15 +173,15 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	size_t o_llf[3];
 	for (int c = 0; c < 3; ++c) o_llf[c] = L.take(cells * 4);
 
-	AStage &sg = t_astage[t_astage_next]; t_astage_next ^= 1;
-	if (!sg.done && hipEventCreateWithFlags(&sg.done, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { sg.done = nullptr; (void) hipGetLastError(); return nullptr; }
-	if (sg.pending) { (void) hipEventSynchronize(sg.done); sg.pending = false; }   // (the copy before last: long done)
-	if (!sg.mem.reserve(copy_bytes + 64, 0)) return nullptr;
+	AStage *sgp = astage_acquire(copy_bytes + 64);
+	if (!sgp) return nullptr;
+	AStage &sg = *sgp;
 	uint8_t *stg = sg.mem.ptr;
 	bool dummy = false;
 	af->plan_block = cache_acquire(device, L.size, &af->plan_block_bytes, &dummy);
 	if (!af->plan_block) return nullptr;
 	uint8_t *pb = (uint8_t *) af->plan_block;
+	const double tp3 = prof_now();
 
 	memcpy(stg + o_cs, h.cs, cs_size); memset(stg + o_cs + cs_size, 0, 32);   // the lane decoders read up to three words past the position they stop at
 	auto put = [&](size_t off, const void *src, size_t bytes) { if (bytes) memcpy(stg + off, src, bytes); };
@@ -164,6 +191,7 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	put(o_evr, fp.ev_range.data(), fp.ev_range.size() * 4); put(o_lso, fp.lf_section_off.data(), ngg * 4);
 	DevLfSlot *slots = (DevLfSlot *) (stg + o_slots);
 	memset(slots, 0, ngg * sizeof(DevLfSlot));
+	const double tp4 = prof_now();
 	if (dev_lf) {
 		put(o_tree, &fp.lf_tree, sizeof(DevCoopTree)); put(o_alias, fp.lf_alias.data(), fp.lf_alias.size() * 8);
 		af->lf_tasks.resize(ngg);
@@ -203,6 +231,7 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 		}
 	}
 
+	const double tp5 = prof_now();
 	// ---- the working set ----
 	Layout W;
 	const size_t stride = (cells * 64 + 63) & ~(size_t) 63;
@@ -239,6 +268,7 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	for (int c = 0; c < 3; ++c) bd.inv_m_lf[c] = fp.inv_m_lf[c];
 	// (class_start and verdict belong to the batch: j40hip_abatch_launch)
 
+	const double tp6 = prof_now();
 	if (hipEventCreateWithFlags(&af->uploaded, hipEventDisableTiming) != hipSuccess) { af->uploaded = nullptr; (void) hipGetLastError(); return nullptr; }
 	if (hipMemcpyAsync(pb, stg, copy_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return nullptr;
 	bool ok = hipEventRecord(sg.done, stream) == hipSuccess;
@@ -247,7 +277,20 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	ok = ok && (!af->sparse || hipMemsetAsync(plan.block_events, 0, 16 * cells, stream) == hipSuccess);
 	ok = ok && hipEventRecord(af->uploaded, stream) == hipSuccess;
 	if (!ok) { (void) hipStreamSynchronize(stream); (void) hipGetLastError(); return nullptr; }   // (nothing may be in flight on blocks that go back to the cache)
+	{ const double tp7 = prof_now(); t_prof[0] += tp1 - tp0; t_prof[1] += tp2 - tp1; t_prof[2] += tp3 - tp2; t_prof[3] += tp4 - tp3; t_prof[4] += tp5 - tp4; t_prof[5] += tp6 - tp5; t_prof[6] += tp7 - tp6; ++t_prof_frames; }
 	return af.release();
+}
+
+void j40hip_astage_release(void) {
+	if (getenv("J40HIP_ASYNC_TIMING") && t_prof_frames) {
+		const double n = (double) t_prof_frames;
+		fprintf(stderr, "[j40hip host stage] %lld frames, ms per frame: front parse %.2f, tables + front plan %.2f, staging buffer + plan block %.2f, copy into staging %.2f, LfGroup streams / tasks %.2f, work block + pointers %.2f, enqueue %.2f; staging buffers %zu\n",
+			(long long) t_prof_frames, t_prof[0] / n, t_prof[1] / n, t_prof[2] / n, t_prof[3] / n, t_prof[4] / n, t_prof[5] / n, t_prof[6] / n, t_astages.size());
+		for (double &v : t_prof) v = 0; t_prof_frames = 0;
+	}
+	for (auto &s : t_astages) { if (s->pending) (void) hipEventSynchronize(s->done); s->mem.release(); if (s->done) (void) hipEventDestroy(s->done); }
+	t_astages.clear();
+	t_front = FrontPlan();
 }
 
 j40hip_aframe *j40hip_aframe_prepare(const void *buf, size_t size, int device, hipStream_t stream, int lf_on_device) {
@@ -264,6 +307,7 @@ struct j40hip_abatch {
 	void *dev = nullptr; size_t dev_cap = 0;
 	uint32_t *verdict_host = nullptr; size_t verdict_cap = 0;   // pinned, [frames][4]
 	int32_t nframes = 0;
+	bool have_totals = false; int32_t last_totals[K2_NUM_BATCH_LAUNCHES];   // tiles per pixel-kernel launch of the batch before (k2_batch_grids)
 	float *large_scratch = nullptr;
 	std::vector<hipStream_t> side; std::vector<hipEvent_t> side_done; hipEvent_t fork = nullptr;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -308,6 +352,7 @@ void j40hip_abatch_free(j40hip_abatch *b) {
 static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frames, int n, void *const *rgba_dev, const size_t *stride_bytes, hipStream_t s) {
 	if (!b || n <= 0) return ERR_GPU;
 	if (hipSetDevice(b->device) != hipSuccess) return ERR_GPU;
+	if (b->have_totals && b->nframes > 0) memcpy(b->last_totals, b->verdict_host + 4 * (size_t) b->nframes, sizeof b->last_totals);   // (the launch before has been waited for)
 	// geometry of the entropy launch (runtime.hip batch_assign): up to 64 sections of one frame per wavefront, 1 / 2 / 4 wavefronts
 	// per workgroup sharing one copy of their frame's tables
 	bool lanes_fast = true, tables_in_lds = true; uint32_t lanes_lds = 0, generic_lds = 0;
@@ -334,7 +379,7 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 	const size_t o_plans = L.take(sizeof(DevPlan) * (size_t) n), o_builds = L.take(sizeof(DevPlanBuild) * (size_t) n), o_k2 = L.take(sizeof(K2Frame) * (size_t) n);
 	const size_t o_lfs = L.take(sizeof(DevBatchLf) * (size_t) nlf), o_tasks = L.take(sizeof(DevLfTask) * (size_t) ntasks), o_work = L.take(sizeof(HfLaneWork) * work.size());
 	const size_t copy_bytes = L.size;
-	const size_t o_tiles = L.take(4 * (size_t) K2_NUM_BATCH_LAUNCHES * ((size_t) n + 1)), o_verdict = L.take(16 * (size_t) n);
+	const size_t o_tiles = L.take(4 * (size_t) K2_NUM_BATCH_LAUNCHES * ((size_t) n + 1)), o_verdict = L.take(16 * (size_t) n + 64);   // (verdicts, then the tile totals)
 	if (!b->host.reserve(copy_bytes + 64, 0)) return ERR_MEM;
 	if (L.size > b->dev_cap) {
 		if (b->dev) (void) hipFree(b->dev);
@@ -342,11 +387,11 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 		if (hipMalloc(&b->dev, L.size * 2) != hipSuccess) { (void) hipGetLastError(); return ERR_MEM; }
 		b->dev_cap = L.size * 2;
 	}
-	if ((size_t) n * 4 > b->verdict_cap) {
+	if ((size_t) n * 4 + 16 > b->verdict_cap) {
 		if (b->verdict_host) (void) hipHostFree(b->verdict_host);
 		b->verdict_host = nullptr; b->verdict_cap = 0;
-		if (hipHostMalloc((void **) &b->verdict_host, 16 * (size_t) n * 2, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); return ERR_MEM; }
-		b->verdict_cap = (size_t) n * 4 * 2;
+		if (hipHostMalloc((void **) &b->verdict_host, 16 * (size_t) n * 2 + 64, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); return ERR_MEM; }
+		b->verdict_cap = (size_t) n * 4 * 2 + 16;
 	}
 	uint8_t *hb = b->host.ptr, *db = (uint8_t *) b->dev;
 	DevPlan *h_plans = (DevPlan *) (hb + o_plans); DevPlanBuild *h_builds = (DevPlanBuild *) (hb + o_builds); K2Frame *h_k2 = (K2Frame *) (hb + o_k2);
@@ -377,11 +422,13 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 	if (lanes_fast) launch_hf_lanes(d_plans, d_work, (int32_t) work.size(), waves_per_wg, lanes_lds, s);
 	else launch_hf_entropy_lanes(d_plans, d_work, (int32_t) work.size(), tables_in_lds, generic_lds, s);
 	(void) hipEventRecord(b->ev[2], s);
-	launch_vardct_batch(d_k2, n, (int32_t *) (db + o_tiles), cells_total, b->large_scratch, s, b->side.data(), (int) b->side.size(), b->fork, b->side_done.data());
+	int32_t grids[K2_NUM_BATCH_LAUNCHES];
+	k2_batch_grids(b->have_totals ? b->last_totals : nullptr, cells_total, n, b->cus * 8, grids);
+	launch_vardct_batch(d_k2, n, (int32_t *) (db + o_tiles), (int32_t *) (db + o_verdict + 16 * (size_t) n), grids, b->large_scratch, s, b->side.data(), (int) b->side.size(), b->fork, b->side_done.data());
 	(void) hipEventRecord(b->ev[3], s);
 	launch_plan_verdict(d_builds, d_plans, n, s);
-	if (hipMemcpyAsync(b->verdict_host, db + o_verdict, 16 * (size_t) n, hipMemcpyDeviceToHost, s) != hipSuccess) return ERR_GPU;
-	b->nframes = n;
+	if (hipMemcpyAsync(b->verdict_host, db + o_verdict, 16 * (size_t) n + 64, hipMemcpyDeviceToHost, s) != hipSuccess) return ERR_GPU;
+	b->nframes = n; b->have_totals = true;
 	return hipGetLastError() == hipSuccess ? 0 : ERR_GPU;
 }
 

@@ -17,6 +17,8 @@ struct j40hip_abatch;
 j40hip_aframe *j40hip_aframe_prepare(const void *buf, size_t size, int device, hipStream_t stream, int lf_on_device);
 // nothing may still be running on the frame's memory
 void j40hip_aframe_free(j40hip_aframe *f);
+// frees the calling thread's pinned staging buffers (before a thread that prepared frames exits)
+void j40hip_astage_release(void);
 int j40hip_aframe_lf_on_device(const j40hip_aframe *f);
 void j40hip_aframe_size(const j40hip_aframe *f, int64_t *width, int64_t *height);
 // what the reference says about bytes behind the frame (j40hip_frame_after_frame_status)

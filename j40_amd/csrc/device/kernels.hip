@@ -323,21 +323,32 @@ void launch_hf_entropy_lanes(const DevPlan *plans, const HfLaneWork *work, int32
 // batch-wide launches (BATCH) are persistent: a launch covers one class of transforms over every frame of the batch, its work
 // cut into tiles of `per_wg` varblocks; tile_prefix[f] = tiles of the frames before frame f (built on the device by k_k2_tiles
 // from the frames' class_start, which the device-side plan build writes: the host never learns the counts). Workgroup b takes
-// tiles b, b + gridDim.x, ...: k2_bind finds tile `tile`'s frame and replaces the kernel arguments with that frame's plan, list,
-// count and output; `first` = the tile's first varblock. Returns false past the last tile.
+// a contiguous run of tiles (one search for its first tile's frame, then it walks along); k2_bind replaces the kernel arguments with
+// the next tile's frame's plan, list, count and output; `first` = the tile's first varblock. Returns false when the run is done.
+struct K2Iter { int32_t tile, tile_end, frame; };
 template <bool BATCH>
-__device__ __forceinline__ bool k2_bind(const K2Frame *batch, const int32_t *tile_prefix, int32_t nframes, int32_t tile, int32_t class_a, int32_t class_b, int32_t per_wg,
-		const DevVarblock *&list, int32_t &count, uint8_t *&rgba, size_t &stride, float *&scratch, int32_t &frame, int32_t &first) {
-	if (!BATCH) { frame = 0; first = (int32_t) blockIdx.x * per_wg; return true; }
-	if (tile >= tile_prefix[nframes]) return false;
+__device__ __forceinline__ K2Iter k2_begin(const int32_t *tile_prefix, int32_t nframes) {
+	K2Iter it = {0, 1, 0};
+	if (!BATCH) return it;
+	const int32_t total = tile_prefix[nframes], chunk = (total + (int32_t) gridDim.x - 1) / (int32_t) gridDim.x;
+	it.tile = (int32_t) blockIdx.x * chunk; it.tile_end = min(total, it.tile + chunk);
 	int32_t lo = 0, hi = nframes - 1;   // last frame whose prefix <= tile
-	while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (tile_prefix[mid] <= tile) lo = mid; else hi = mid - 1; }
-	frame = lo;
-	const K2Frame &fr = batch[lo];
+	while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (tile_prefix[mid] <= it.tile) lo = mid; else hi = mid - 1; }
+	it.frame = lo;
+	return it;
+}
+template <bool BATCH>
+__device__ __forceinline__ bool k2_bind(K2Iter &it, const K2Frame *batch, const int32_t *tile_prefix, int32_t class_a, int32_t class_b, int32_t per_wg,
+		const DevVarblock *&list, int32_t &count, uint8_t *&rgba, size_t &stride, int32_t &frame, int32_t &first) {
+	if (!BATCH) { frame = 0; first = (int32_t) blockIdx.x * per_wg; return it.tile++ == 0; }
+	if (it.tile >= it.tile_end) return false;
+	while (tile_prefix[it.frame + 1] <= it.tile) ++it.frame;   // (frames without tiles of this class)
+	frame = it.frame;
+	const K2Frame &fr = batch[frame];
 	const int32_t a = fr.class_start[class_a];
 	list = fr.sorted + a; count = fr.class_start[class_b] - a; rgba = fr.rgba; stride = fr.stride;
-	(void) scratch;   // (the 128/256-sized transforms' scratch belongs to the workgroup, not to the frame)
-	first = (tile - tile_prefix[lo]) * per_wg;
+	first = (it.tile - tile_prefix[frame]) * per_wg;
+	++it.tile;
 	return true;
 }
 
@@ -376,9 +387,9 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan_arg, const DevV
 	constexpr int N = R * C;
 	constexpr int PAR = N >= 256 ? 1 : 256 / N;   // blocks a pass of the 256 lanes covers
 	constexpr int PER = N >= 256 ? N / 256 : 1;   // pixel positions per lane
-	for (int32_t tile = blockIdx.x; ; tile += gridDim.x) {
+	for (K2Iter it = k2_begin<BATCH>(tile_prefix, nframes); ; ) {
 		int32_t frame, first;
-		{ float *unused = nullptr; if (!k2_bind<BATCH>(batch, tile_prefix, nframes, tile, class_a, class_b, NB, list, count, rgba, stride_bytes, unused, frame, first)) break; }
+		if (!k2_bind<BATCH>(it, batch, tile_prefix, class_a, class_b, NB, list, count, rgba, stride_bytes, frame, first)) break;
 		const DevPlan &plan = BATCH ? batch[frame].plan : plan_arg;
 		const DevFrame &f = *plan.frame;
 		const int32_t nb = min(NB, count - first);
@@ -478,9 +489,9 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const 
 	J40_STAGE_SRGB_THRESHOLDS(f);
 	__shared__ int32_t g_param[NB], g_sel[NB];
 	__shared__ uint32_t g_be[NB][4], g_dq[NB], ev_prefix[NB + 1];
-	for (int32_t tile_at = blockIdx.x; ; tile_at += gridDim.x) {
+	for (K2Iter it = k2_begin<BATCH>(tile_prefix, nframes); ; ) {
 		int32_t frame, first;
-		{ float *unused = nullptr; if (!k2_bind<BATCH>(batch, tile_prefix, nframes, tile_at, class_a, class_b, NB, list, count, rgba, stride_bytes, unused, frame, first)) break; }
+		if (!k2_bind<BATCH>(it, batch, tile_prefix, class_a, class_b, NB, list, count, rgba, stride_bytes, frame, first)) break;
 		const DevPlan &plan = BATCH ? batch[frame].plan : plan_arg;
 		const DevFrame &f = *plan.frame;
 		const int32_t nb = min(NB, count - first);
@@ -588,9 +599,9 @@ __global__ void __launch_bounds__(256) k_vardct_large(DevPlan plan_arg, const De
 	const int32_t tid = threadIdx.x, nthreads = blockDim.x;
 	J40_STAGE_SRGB_THRESHOLDS(f);
 	float *A = scratch + (size_t) blockIdx.x * 6 * 65536, *B = A + 3 * 65536;  // [3][size] each: the workgroup's own
-	for (int32_t tile = blockIdx.x; ; tile += gridDim.x) {
+	for (K2Iter it = k2_begin<BATCH>(tile_prefix, nframes); ; ) {
 		int32_t frame, first;
-		if (!k2_bind<BATCH>(batch, tile_prefix, nframes, tile, class_a, class_b, 1, list, count, rgba, stride_bytes, scratch, frame, first)) break;
+		if (!k2_bind<BATCH>(it, batch, tile_prefix, class_a, class_b, 1, list, count, rgba, stride_bytes, frame, first)) break;
 		const DevPlan &plan = BATCH ? batch[frame].plan : plan_arg;
 		const DevFrame &f = *plan.frame;
 		const DevVarblock vb = list[first];
@@ -750,8 +761,8 @@ struct K2BatchLaunch { int16_t a, b, per_wg, min_cells; };
 static const K2BatchLaunch K2_BATCH_LAUNCHES[K2_NUM_BATCH_LAUNCHES] = {J40_K2_LAUNCH_TABLE};
 __device__ static const K2BatchLaunch DEV_K2_BATCH_LAUNCHES[K2_NUM_BATCH_LAUNCHES] = {J40_K2_LAUNCH_TABLE};
 
-// tile_prefix[l * (nframes + 1) + f] = tiles of launch l in the frames before f; one thread per launch
-__global__ void k_k2_tiles(const K2Frame *frames, int32_t nframes, int32_t *tile_prefix) {
+// tile_prefix[l * (nframes + 1) + f] = tiles of launch l in the frames before f; totals[l] = all of them; one thread per launch
+__global__ void k_k2_tiles(const K2Frame *frames, int32_t nframes, int32_t *tile_prefix, int32_t *totals) {
 	const int32_t l = threadIdx.x;
 	if (l >= K2_NUM_BATCH_LAUNCHES) return;
 	const int32_t a = DEV_K2_BATCH_LAUNCHES[l].a, b = DEV_K2_BATCH_LAUNCHES[l].b, per = DEV_K2_BATCH_LAUNCHES[l].per_wg;
@@ -763,22 +774,41 @@ __global__ void k_k2_tiles(const K2Frame *frames, int32_t nframes, int32_t *tile
 		at += (n + per - 1) / per;
 	}
 	row[nframes] = at;
+	totals[l] = at;
 }
 
-// cells_total: 8x8 cells of all frames of the batch (bounds the tiles a launch can have); wgs_cap: most workgroups per launch;
-// large_scratch: 6 * 65536 floats per workgroup of the last launch (K2_LARGE_WGS of them)
-void launch_vardct_batch(const K2Frame *frames_dev, int32_t nframes, int32_t *tile_prefix_dev, size_t cells_total, float *large_scratch, hipStream_t stream, hipStream_t *side, int nside, hipEvent_t fork, hipEvent_t *side_done) {
-	const DevPlan none = DevPlan();
-	hipLaunchKernelGGL(k_k2_tiles, dim3(1), dim3(32), 0, stream, frames_dev, nframes, tile_prefix_dev);
-	if (nside > 0) { (void) hipEventRecord(fork, stream); for (int k = 0; k < nside; ++k) (void) hipStreamWaitEvent(side[k], fork, 0); }
-	static const int wgs_cap = [] { const char *e = getenv("J40HIP_K2_WGS"); return e ? std::max(1, atoi(e)) : 2048; }();
+// Workgroups per launch. All launches of a batch should be resident together and end together (a persistent workgroup holds its
+// slot until its class is done: a class that filled the machine alone would make the others queue behind it, each with a tail of
+// its own), so the machine's workgroup slots are dealt out in proportion to each class's work. The host does not know this batch's
+// counts; `last_totals` -- the tiles per launch of the batch decoded before (nullptr: none yet) -- is its estimate.
+void k2_batch_grids(const int32_t *last_totals, size_t cells_total, int32_t nframes, int32_t wg_slots, int32_t *grids) {
+	static const double PRIOR[K2_NUM_BATCH_LAUNCHES] = {0.30, 0.12, 0.14, 0.16, 0.05, 0.05, 0.04, 0.02, 0.02, 0.02, 0.02, 0.03, 0.01, 0.01, 0.01};
+	double w[K2_NUM_BATCH_LAUNCHES], sum = 0;
+	for (int l = 0; l < K2_NUM_BATCH_LAUNCHES; ++l) {
+		const auto &L = K2_BATCH_LAUNCHES[l];
+		const double cost = (L.a == 1 || L.a == 12 ? 3.4 : 1.0) * (double) L.per_wg * (double) L.min_cells;   // (the 8x8 specials: 24 ps / pixel against 7)
+		w[l] = last_totals ? (double) last_totals[l] * cost + 1e-3 : PRIOR[l];
+		sum += w[l];
+	}
 	for (int l = 0; l < K2_NUM_BATCH_LAUNCHES; ++l) {
 		const auto &L = K2_BATCH_LAUNCHES[l];
 		const size_t bound = cells_total / (size_t) (L.min_cells * L.per_wg) + (size_t) nframes;   // tiles at most
-		int32_t grid = (int32_t) std::min<size_t>(bound, (size_t) wgs_cap);
-		if (L.a == 21) grid = std::min(grid, (int32_t) K2_LARGE_WGS);
-		if (grid < 1) grid = 1;
-		launch_vardct_class_impl(none, L.a, nullptr, 0, large_scratch, nullptr, 0, K2Launch{frames_dev, tile_prefix_dev + (size_t) l * (size_t) (nframes + 1), nframes, L.a, L.b, grid}, nside > 0 ? side[l % nside] : stream);
+		int64_t g = (int64_t) ((double) wg_slots * w[l] / sum + 0.5);
+		g = std::max<int64_t>(g, 4); g = std::min<int64_t>(g, (int64_t) bound);
+		if (L.a == 21) g = std::min<int64_t>(g, K2_LARGE_WGS);
+		grids[l] = (int32_t) std::max<int64_t>(g, 1);
+	}
+}
+
+// grids: workgroups per launch (k2_batch_grids); large_scratch: 6 * 65536 floats per workgroup of the last launch (K2_LARGE_WGS of
+// them); totals_dev: K2_NUM_BATCH_LAUNCHES ints, the tiles each launch found
+void launch_vardct_batch(const K2Frame *frames_dev, int32_t nframes, int32_t *tile_prefix_dev, int32_t *totals_dev, const int32_t *grids, float *large_scratch, hipStream_t stream, hipStream_t *side, int nside, hipEvent_t fork, hipEvent_t *side_done) {
+	const DevPlan none = DevPlan();
+	hipLaunchKernelGGL(k_k2_tiles, dim3(1), dim3(32), 0, stream, frames_dev, nframes, tile_prefix_dev, totals_dev);
+	if (nside > 0) { (void) hipEventRecord(fork, stream); for (int k = 0; k < nside; ++k) (void) hipStreamWaitEvent(side[k], fork, 0); }
+	for (int l = 0; l < K2_NUM_BATCH_LAUNCHES; ++l) {
+		const auto &L = K2_BATCH_LAUNCHES[l];
+		launch_vardct_class_impl(none, L.a, nullptr, 0, large_scratch, nullptr, 0, K2Launch{frames_dev, tile_prefix_dev + (size_t) l * (size_t) (nframes + 1), nframes, L.a, L.b, grids[l]}, nside > 0 ? side[l % nside] : stream);
 	}
 	if (nside > 0) for (int k = 0; k < nside; ++k) { (void) hipEventRecord(side_done[k], side[k]); (void) hipStreamWaitEvent(stream, side_done[k], 0); }
 }

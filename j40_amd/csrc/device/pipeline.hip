@@ -149,8 +149,12 @@ uint32_t decode_single(j40hip_pipeline *p, Job *j, hipStream_t s) {
 
 void worker_main(j40hip_pipeline *p) {
 	if (hipSetDevice(p->device) != hipSuccess) { ++p->worker_errors; return; }
+	// The thread's copies go on a stream of the highest priority: such streams have hardware queues of their own, so a copy does
+	// not wait its turn behind another stream's long kernel (streams of one priority share a handful of hardware queues in turn)
 	hipStream_t stream = nullptr;
-	if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { ++p->worker_errors; return; }
+	int prio_low = 0, prio_high = 0;
+	(void) hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+	if (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio_high) != hipSuccess) { (void) hipGetLastError(); if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { ++p->worker_errors; return; } }
 	for (;;) {
 		Job *j = nullptr;
 		bool lf_dev = p->lf_mode == 1;
@@ -189,6 +193,8 @@ void worker_main(j40hip_pipeline *p) {
 			p->cv_ready.notify_all();
 		}
 	}
+	(void) hipStreamSynchronize(stream);
+	j40hip_astage_release();
 	j40hip_thread_release();
 	(void) hipStreamDestroy(stream);
 }
@@ -290,7 +296,7 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 		if (flags & 4u) { (void) mallopt(M_MMAP_THRESHOLD, 1 << 30); (void) mallopt(M_TRIM_THRESHOLD, (int) (((size_t) 1 << 31) - 1)); (void) mallopt(M_TOP_PAD, 64 << 20); }
 		p->batch_frames = batch_frames < 1 ? 32 : batch_frames;
 		p->max_in_flight = max_in_flight < 1 ? 2 : max_in_flight > 8 ? 8 : max_in_flight;
-		p->lf_hiwater = (int64_t) p->batch_frames * p->max_in_flight;
+		p->lf_hiwater = (int64_t) p->batch_frames;   // the device has less than one batch's worth queued up: it is about to idle
 		if (const char *e = getenv("J40HIP_LF_HIWATER")) p->lf_hiwater = atoll(e);
 		p->slots.resize((size_t) p->max_in_flight + 1);
 		for (Slot &s : p->slots) {

@@ -16,7 +16,9 @@
 
 namespace j40hip {
 
-__global__ void __launch_bounds__(64) k_plan_place(const DevPlanBuild *builds, const DevBatchLf *lfs, int32_t nlf) {
+// The lane-per-LfGroup form (plan_dev.h's plan_place_lf_group as it stands; J40HIP_PLAN_PLACE_LANES=1): 64 serial walks side by
+// side diverge at every branch and every walk waits on its own dependent loads -- 73 ms for the 3072 LfGroups of 256 8K frames.
+__global__ void __launch_bounds__(64) k_plan_place_lanes(const DevPlanBuild *builds, const DevBatchLf *lfs, int32_t nlf) {
 	__shared__ uint16_t occ[256 * 64];
 	__shared__ uint16_t grp[64 * 64];
 	__shared__ uint32_t cls[28 * 64];
@@ -24,6 +26,95 @@ __global__ void __launch_bounds__(64) k_plan_place(const DevPlanBuild *builds, c
 	if (i >= nlf) return;
 	const DevBatchLf w = lfs[i];
 	plan_place_lf_group(builds[w.frame], w.lfg, occ + threadIdx.x, grp + threadIdx.x, cls + threadIdx.x, 64);
+}
+
+// One LfGroup per WAVEFRONT, the same walk with all of its state in registers and every decision wave-uniform (scalar unit):
+//   * lane c of four registers holds the occupancy of columns c, c + 64, c + 128, c + 192 (the row below the lowest cell a placed
+//     block occupies there); one ballot per quarter gives a row's free cells as a bit mask, and the walk jumps from free cell to
+//     free cell with a find-first-set -- occupied cells cost nothing. A block never straddles a group (32 cells), hence never a
+//     quarter. Blocks one cell high (the 8x8 transforms: most of them) only clear bits of the row's mask;
+//   * the two rows of the varblock-info channel are read 64 entries at a time, one per lane (coalesced), an entry is a readlane;
+//   * lane g counts the blocks of group g, lane d those of DctSelect d; the thresholds of the quantisation-field index sit one per
+//     lane and are counted with a ballot; the transforms' sizes sit one per lane;
+//   * the records of 64 consecutive varblocks collect one per lane and leave as one coalesced store.
+// Same results as plan_place_lf_group (which tests/hostsim checks against the host path): tests/test_pipeline.py runs both forms.
+__device__ __forceinline__ int32_t pp_rl(int32_t v, int32_t lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ int32_t pp_sc(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__global__ void __launch_bounds__(64) k_plan_place(const DevPlanBuild *builds, const DevBatchLf *lfs, int32_t nlf) {
+	const int32_t lane = threadIdx.x;
+	const DevBatchLf w = lfs[blockIdx.x];
+	const DevPlanBuild &pb = builds[w.frame];
+	const int32_t g = w.lfg;
+	DevLfGroup *ggp = pb.lf_groups + g;
+	DevLfSlot *slot = pb.lf_slots + g;
+	const int32_t w8 = pp_sc(ggp->width8), h8 = pp_sc(ggp->height8), cell_base = pp_sc(ggp->cell_base), vb_base = pp_sc(ggp->vb_base);
+	const int32_t ggx = g % pb.ggcolumns, ggy = g / pb.ggcolumns;
+	uint32_t err = (uint32_t) pp_sc((int32_t) slot->status), used = 0;
+	const int32_t nbv = pp_sc(slot->nb_varblocks), nb_qf_thr = pp_sc(pb.nb_qf_thr);
+	const int32_t my_thr = lane < nb_qf_thr ? pb.qf_thr[lane < 15 ? lane : 14] : 0;
+	const int32_t my_dims = lane < 27 ? (int32_t) DEV_DCT_SELECT[lane][0] | ((int32_t) DEV_DCT_SELECT[lane][1] << 8) : 0;
+	int32_t occ0 = 0, occ1 = 0, occ2 = 0, occ3 = 0;
+	int32_t grp_cnt = 0, cls_cnt = 0;   // lane = group inside the LfGroup / DctSelect
+	int32_t voff = 0, coeffoff = 0;
+	if (!err) {
+		const int16_t *info0 = pb.vbinfo + 2 * (size_t) cell_base, *info1 = info0 + nbv;
+		DevVbRec *recs = pb.vb_recs + vb_base;
+		const int32_t coeff_limit = w8 * h8 * 64;
+		int32_t chunk = -1, i0 = 0, i1 = 0;   // info entries chunk * 64 + lane
+		uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;   // the record of varblock (voff & ~63) + lane
+		for (int32_t y0 = 0; y0 < h8 && !err; ++y0) {
+			for (int32_t q = 0; q < 4 && !err; ++q) {
+				if (q * 64 >= w8) break;
+				const int32_t occq = q == 0 ? occ0 : q == 1 ? occ1 : q == 2 ? occ2 : occ3;
+				uint64_t free_mask = __builtin_amdgcn_ballot_w64(occq <= y0 && q * 64 + lane < w8);
+				while (free_mask) {
+					const int32_t bit = (int32_t) __builtin_ctzll(free_mask), x0 = q * 64 + bit;
+					if (voff >= nbv) { err = ERR_VBLK; break; }
+					if ((voff >> 6) != chunk) {
+						chunk = voff >> 6;
+						const int32_t k = chunk * 64 + lane;
+						i0 = k < nbv ? (int32_t) info0[k] : 0; i1 = k < nbv ? (int32_t) info1[k] : 0;
+					}
+					const int32_t dctsel = pp_rl(i0, voff & 63), hfmul_m1 = pp_rl(i1, voff & 63);
+					if (dctsel < 0 || dctsel >= 27) { err = ERR_DCTQ; break; }
+					const int32_t dims = pp_rl(my_dims, dctsel), log_rows = dims & 255, log_columns = dims >> 8;
+					const int32_t vw8 = 1 << (log_columns - 3), vh8 = 1 << (log_rows - 3), x1 = x0 + vw8 - 1, y1 = y0 + vh8 - 1;
+					if (!(x1 < w8 && (x0 >> PLAN_LOG_GSIZE8) == (x1 >> PLAN_LOG_GSIZE8)) || !(y1 < h8 && (y0 >> PLAN_LOG_GSIZE8) == (y1 >> PLAN_LOG_GSIZE8))) { err = ERR_VBLK; break; }
+					if (coeffoff + (1 << (log_rows + log_columns)) > coeff_limit) { err = ERR_VBLK; break; }
+					free_mask &= ~((((uint64_t) 1 << vw8) - 1) << bit);   // (vw8 <= 32)
+					if (vh8 > 1) {
+						const bool mine = lane >= bit && lane < bit + vw8;
+						const int32_t below = y1 + 1;
+						if (q == 0) occ0 = mine && occ0 < below ? below : occ0; else if (q == 1) occ1 = mine && occ1 < below ? below : occ1;
+						else if (q == 2) occ2 = mine && occ2 < below ? below : occ2; else occ3 = mine && occ3 < below ? below : occ3;
+					}
+					const int32_t qf = (int32_t) __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < nb_qf_thr && hfmul_m1 >= my_thr));
+					const int32_t grp = (y0 >> PLAN_LOG_GSIZE8) * 8 + (x0 >> PLAN_LOG_GSIZE8);
+					const int32_t rank_g = pp_rl(grp_cnt, grp), rank_c = pp_rl(cls_cnt, dctsel);
+					grp_cnt += lane == grp; cls_cnt += lane == dctsel;
+					if (lane == (voff & 63)) {
+						r0 = (uint32_t) (coeffoff + qf);
+						r1 = (uint32_t) (uint16_t) (int16_t) hfmul_m1 | (uint32_t) x0 << 16 | (uint32_t) y0 << 24;
+						r2 = (uint32_t) dctsel | (uint32_t) grp << 8 | (uint32_t) rank_g << 16;
+						r3 = (uint32_t) rank_c;
+					}
+					used |= 1u << dctsel;
+					coeffoff += 1 << (log_rows + log_columns);
+					++voff;
+					if ((voff & 63) == 0) ((uint4 *) recs)[voff - 64 + lane] = make_uint4(r0, r1, r2, r3);
+				}
+			}
+		}
+		if ((voff & 63) != 0 && lane < (voff & 63)) ((uint4 *) recs)[(voff & ~63) + lane] = make_uint4(r0, r1, r2, r3);   // (also after an error: the blocks placed before it)
+		if (!err && voff != nbv) err = ERR_VBLK;
+	}
+	if (lane == 0) { slot->status = err; slot->placed = voff; slot->dct_used = used; ggp->nb_varblocks = voff; }
+	{   // every group lies in exactly one LfGroup: plain stores (lane = gy * 8 + gx)
+		const int32_t gx = lane & 7, gy = lane >> 3;
+		if ((gx << PLAN_LOG_GSIZE8) < w8 && (gy << PLAN_LOG_GSIZE8) < h8) pb.group_count[(ggy * 8 + gy) * pb.gcolumns + ggx * 8 + gx] = (uint32_t) grp_cnt;
+	}
+	if (lane < 28) pb.class_count[g * 28 + lane] = lane < 27 ? (uint32_t) cls_cnt : 0u;
 }
 
 __global__ void __launch_bounds__(64) k_plan_scan(const DevPlanBuild *builds, int32_t nframes) {
@@ -67,7 +158,9 @@ __global__ void __launch_bounds__(64) k_plan_verdict(const DevPlanBuild *builds,
 
 void launch_plan_build(const DevPlanBuild *builds, const DevBatchLf *lfs, int32_t nframes, int32_t nlf, int32_t max_lf_cells, hipStream_t stream) {
 	if (nframes <= 0 || nlf <= 0) return;
-	hipLaunchKernelGGL(k_plan_place, dim3((unsigned) ((nlf + 63) / 64)), dim3(64), 0, stream, builds, lfs, nlf);
+	static const bool lanes_form = [] { const char *e = getenv("J40HIP_PLAN_PLACE_LANES"); return e && atoi(e); }();
+	if (lanes_form) hipLaunchKernelGGL(k_plan_place_lanes, dim3((unsigned) ((nlf + 63) / 64)), dim3(64), 0, stream, builds, lfs, nlf);
+	else hipLaunchKernelGGL(k_plan_place, dim3((unsigned) nlf), dim3(64), 0, stream, builds, lfs, nlf);
 	hipLaunchKernelGGL(k_plan_scan, dim3((unsigned) ((nframes + 63) / 64)), dim3(64), 0, stream, builds, nframes);
 	hipLaunchKernelGGL(k_plan_emit, dim3((unsigned) ((max_lf_cells + 255) / 256), (unsigned) nlf), dim3(256), 0, stream, builds, lfs);
 }

@@ -47,8 +47,15 @@ std::vector<CachedBlock> g_cache[16];
 size_t g_cached_bytes[16];
 // upper bound on what the cache keeps (J40HIP_CACHE_GB overrides; 0 disables recycling). When an allocation fails the cache is
 // emptied and the allocation tried again (cache_trim), so idle blocks never turn into a spurious "!gpu"
+// Default: three quarters of the device's memory -- a pipeline returns the working sets of a whole batch at once (256 8K frames:
+// 54 GB), and hipFree / hipMalloc of such blocks cost tens of milliseconds each and synchronise the device.
 size_t cache_limit_bytes() {
-	static const size_t limit = [] { const char *e = getenv("J40HIP_CACHE_GB"); return (size_t) (e ? std::max(0, atoi(e)) : 48) << 30; }();
+	static const size_t limit = [] {
+		if (const char *e = getenv("J40HIP_CACHE_GB")) return (size_t) std::max(0, atoi(e)) << 30;
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); return (size_t) 48 << 30; }
+		return total_b / 4 * 3;
+	}();
 	return limit;
 }
 

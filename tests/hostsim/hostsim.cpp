@@ -655,3 +655,36 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_device_plan_ch
 	if (hp.ev_range != fp.ev_range || hp.sections.size() != fp.sections.size() || memcmp(hp.sections.data(), fp.sections.data(), sizeof(DevSection) * hp.sections.size()) != 0) return 16;
 	return 0;
 }
+
+// timing aid (tools/front_timing.py): the host stage of the pipeline on this CPU, stage by stage; out_ms[0] front parse, [1] static
+// tables key + front plan, [2] the LfGroup streams (host decoder), [3] full parse_frame for comparison
+#include <chrono>
+extern "C" __attribute__((visibility("default"))) int32_t hostsim_front_timing(const uint8_t *buf, size_t size, int32_t iters, double *out_ms) {
+	const uint8_t *cs; size_t cs_size; std::vector<uint8_t> storage;
+	try { extract_codestream(buf, size, &cs, &cs_size, &storage); } catch (const DecodeError &) { return -1; }
+	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	for (int i = 0; i < 4; ++i) out_ms[i] = 0;
+	StaticTables st; bool have_st = false;
+	FrontPlan fp;
+	for (int32_t it = 0; it < iters; ++it) {
+		try {
+			Frame fr;
+			std::vector<LfDeviceTask> tasks; std::vector<int32_t> extra_prec; bool plain = true;
+			double t0 = now();
+			if (!parse_frame_front(cs, cs_size, &fr, &tasks, &extra_prec, &plain)) return -1;
+			double t1 = now();
+			std::vector<uint8_t> key; static_tables_key(fr, &key);
+			if (!have_st) { build_static_tables(fr, &st); have_st = true; t1 = now(); }
+			if (build_front_plan(fr, st, cs_size, extra_prec, true, &fp)) return -1;
+			double t2 = now();
+			for (size_t g = 0; g < fr.lf_groups.size(); ++g) { BitReader sr(cs + fr.toc.lf_groups[g].offset, fr.toc.lf_groups[g].size); LfRaw raw; read_lf_group_raw(sr, fr, fr.lf_groups[g], &raw); }
+			double t3 = now();
+			Frame full; full.defer_lf_tail = true;
+			parse_frame(cs, cs_size, &full, 1);
+			double t4 = now();
+			out_ms[0] += t1 - t0; out_ms[1] += t2 - t1; out_ms[2] += t3 - t2; out_ms[3] += t4 - t3;
+		} catch (const DecodeError &) { return -1; }
+	}
+	for (int i = 0; i < 4; ++i) out_ms[i] /= iters;
+	return 0;
+}
