@@ -321,8 +321,8 @@ j40hip_abatch *j40hip_abatch_create(int device) {
 	bool ok = true;
 	for (auto &e : b->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
 	ok = ok && hipEventCreateWithFlags(&b->fork, hipEventDisableTiming) == hipSuccess;
-	int nside = 8;
-	if (const char *e = getenv("J40HIP_SIDE_STREAMS")) nside = std::max(0, std::min(16, atoi(e)));
+	int nside = 4;   // (kernels.hip: K2_LAUNCH_STREAM)
+	if (const char *e = getenv("J40HIP_SIDE_STREAMS")) nside = std::max(0, std::min(4, atoi(e)));
 	for (int i = 0; i < nside && ok; ++i) {
 		hipStream_t st = nullptr; hipEvent_t ev = nullptr;
 		ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
@@ -423,7 +423,8 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 	else launch_hf_entropy_lanes(d_plans, d_work, (int32_t) work.size(), tables_in_lds, generic_lds, s);
 	(void) hipEventRecord(b->ev[2], s);
 	int32_t grids[K2_NUM_BATCH_LAUNCHES];
-	k2_batch_grids(b->have_totals ? b->last_totals : nullptr, cells_total, n, b->cus * 8, grids);
+	static const int32_t k2_wgs = [] { const char *e = getenv("J40HIP_K2_WGS"); return e ? std::max(1, atoi(e)) : 2048; }();
+	k2_batch_grids(b->have_totals ? b->last_totals : nullptr, cells_total, n, k2_wgs, grids);
 	launch_vardct_batch(d_k2, n, (int32_t *) (db + o_tiles), (int32_t *) (db + o_verdict + 16 * (size_t) n), grids, b->large_scratch, s, b->side.data(), (int) b->side.size(), b->fork, b->side_done.data());
 	(void) hipEventRecord(b->ev[3], s);
 	launch_plan_verdict(d_builds, d_plans, n, s);

@@ -777,24 +777,19 @@ __global__ void k_k2_tiles(const K2Frame *frames, int32_t nframes, int32_t *tile
 	totals[l] = at;
 }
 
-// Workgroups per launch. All launches of a batch should be resident together and end together (a persistent workgroup holds its
-// slot until its class is done: a class that filled the machine alone would make the others queue behind it, each with a tail of
-// its own), so the machine's workgroup slots are dealt out in proportion to each class's work. The host does not know this batch's
-// counts; `last_totals` -- the tiles per launch of the batch decoded before (nullptr: none yet) -- is its estimate.
+// Workgroups per launch, and which of (up to) four side streams a launch goes to. A process gets four hardware queues per
+// priority (GPU_MAX_HW_QUEUES); streams beyond that share them, and kernels in one queue run one after the other. So the fifteen
+// launches are dealt to four streams as four chains of about equal work (measured shares of the picture-encoded 8K stream: the 8x8
+// DCT 18 %, the 8x8 specials 38 %, 16x16 11 %, ...), every launch wide enough to fill the machine on its own: whichever chains are
+// still running share it, and a chain's last kernel has the whole machine for its tail. (Fifteen streams with grids in proportion
+// to the classes' work were measured: 176 ms per 256 frames against 81 -- only four kernels ran at a time, each with a fraction of
+// the machine.)
+static const int8_t K2_LAUNCH_STREAM[K2_NUM_BATCH_LAUNCHES] = {0, 1, 1, 2, 3, 3, 2, 3, 3, 3, 3, 2, 2, 2, 2};
 void k2_batch_grids(const int32_t *last_totals, size_t cells_total, int32_t nframes, int32_t wg_slots, int32_t *grids) {
-	static const double PRIOR[K2_NUM_BATCH_LAUNCHES] = {0.30, 0.12, 0.14, 0.16, 0.05, 0.05, 0.04, 0.02, 0.02, 0.02, 0.02, 0.03, 0.01, 0.01, 0.01};
-	double w[K2_NUM_BATCH_LAUNCHES], sum = 0;
 	for (int l = 0; l < K2_NUM_BATCH_LAUNCHES; ++l) {
 		const auto &L = K2_BATCH_LAUNCHES[l];
-		const double cost = (L.a == 1 || L.a == 12 ? 3.4 : 1.0) * (double) L.per_wg * (double) L.min_cells;   // (the 8x8 specials: 24 ps / pixel against 7)
-		w[l] = last_totals ? (double) last_totals[l] * cost + 1e-3 : PRIOR[l];
-		sum += w[l];
-	}
-	for (int l = 0; l < K2_NUM_BATCH_LAUNCHES; ++l) {
-		const auto &L = K2_BATCH_LAUNCHES[l];
-		const size_t bound = cells_total / (size_t) (L.min_cells * L.per_wg) + (size_t) nframes;   // tiles at most
-		int64_t g = (int64_t) ((double) wg_slots * w[l] / sum + 0.5);
-		g = std::max<int64_t>(g, 4); g = std::min<int64_t>(g, (int64_t) bound);
+		const size_t bound = last_totals ? (size_t) last_totals[l] + (size_t) last_totals[l] / 4 + 8 : cells_total / (size_t) (L.min_cells * L.per_wg) + (size_t) nframes;   // tiles, about
+		int64_t g = std::min<int64_t>((int64_t) bound, wg_slots);
 		if (L.a == 21) g = std::min<int64_t>(g, K2_LARGE_WGS);
 		grids[l] = (int32_t) std::max<int64_t>(g, 1);
 	}
@@ -808,7 +803,7 @@ void launch_vardct_batch(const K2Frame *frames_dev, int32_t nframes, int32_t *ti
 	if (nside > 0) { (void) hipEventRecord(fork, stream); for (int k = 0; k < nside; ++k) (void) hipStreamWaitEvent(side[k], fork, 0); }
 	for (int l = 0; l < K2_NUM_BATCH_LAUNCHES; ++l) {
 		const auto &L = K2_BATCH_LAUNCHES[l];
-		launch_vardct_class_impl(none, L.a, nullptr, 0, large_scratch, nullptr, 0, K2Launch{frames_dev, tile_prefix_dev + (size_t) l * (size_t) (nframes + 1), nframes, L.a, L.b, grids[l]}, nside > 0 ? side[l % nside] : stream);
+		launch_vardct_class_impl(none, L.a, nullptr, 0, large_scratch, nullptr, 0, K2Launch{frames_dev, tile_prefix_dev + (size_t) l * (size_t) (nframes + 1), nframes, L.a, L.b, grids[l]}, nside > 0 ? side[K2_LAUNCH_STREAM[l] % nside] : stream);
 	}
 	if (nside > 0) for (int k = 0; k < nside; ++k) { (void) hipEventRecord(side_done[k], side[k]); (void) hipStreamWaitEvent(stream, side_done[k], 0); }
 }
