@@ -127,6 +127,8 @@ void j40hip_aframe_free(j40hip_aframe *f) {
 	delete f;
 }
 int j40hip_aframe_lf_on_device(const j40hip_aframe *f) { return f && !f->lf_tasks.empty(); }
+int j40hip_aframe_uploaded(const j40hip_aframe *f) { if (!f || hipEventQuery(f->uploaded) == hipSuccess) return 1; (void) hipGetLastError(); return 0; }
+int64_t j40hip_aframe_cells(const j40hip_aframe *f) { return f ? (int64_t) f->cells : 0; }
 void j40hip_aframe_size(const j40hip_aframe *f, int64_t *width, int64_t *height) { *width = f->host.frame.fh.width; *height = f->host.frame.fh.height; }
 uint32_t j40hip_aframe_after_frame_status(const j40hip_aframe *f) { return j40hip_frame_after_frame_status(&f->host); }
 
@@ -162,7 +164,7 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	const size_t o_cl = L.take(fp.clusters.size() * sizeof(DevCluster)), o_spec = L.take(fp.coeff_specs.size() * sizeof(DevCodeSpec)), o_frame = L.take(sizeof(DevFrame));
 	const size_t o_lfg = L.take(ngg * sizeof(DevLfGroup)), o_sec = L.take(fp.sections.size() * sizeof(DevSection)), o_evr = L.take(fp.ev_range.size() * 4);
 	const size_t o_lso = L.take(ngg * 4), o_slots = L.take(ngg * sizeof(DevLfSlot));
-	const size_t o_tree = dev_lf ? L.take(sizeof(DevCoopTree)) : 0, o_alias = dev_lf ? L.take(fp.lf_alias.size() * 8) : 0;
+	const size_t o_tree = dev_lf ? L.take(sizeof(DevCoopTree)) : 0, o_alias = dev_lf ? L.take(fp.lf_alias.size() * 8) : 0, o_tasks = dev_lf ? L.take(ngg * sizeof(DevLfTask)) : 0;
 	size_t o_raw[3], o_xfy, o_bfy, o_info, copy_bytes = L.size;
 	for (int c = 0; c < 3; ++c) o_raw[c] = L.take(cells * 2 + 64);
 	o_xfy = L.take(c64s * 2); o_bfy = L.take(c64s * 2); o_info = L.take(cells * 4 + 64);
@@ -210,6 +212,7 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 			d.sharp = (int16_t *) (pb + o_sharp) + gg.cell_base;
 			d.result = (DevLfResult *) ((DevLfSlot *) (pb + o_slots) + g);   // (DevLfSlot begins with the two words of DevLfResult)
 		}
+		put(o_tasks, af->lf_tasks.data(), ngg * sizeof(DevLfTask));
 	} else {
 		// the LfGroup streams on this thread (modular.cpp's fast paths); an error becomes the section's status and takes its place
 		// among the frame's sections like the device decoder's would
@@ -275,6 +278,10 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	sg.pending = ok;
 	// recycled memory: no entry of the per-block table may point outside the event list (a section that fails leaves entries unwritten)
 	ok = ok && (!af->sparse || hipMemsetAsync(plan.block_events, 0, 16 * cells, stream) == hipSuccess);
+	// The LfGroup streams of this frame on the device: enqueued here, behind the copy, not with the frame's batch -- a section takes
+	// about 0.2 s to decode whatever else runs (one wavefront, a quarter of a million samples in sequence), and a batch should not
+	// wait that long for its slowest member: the batch builder prefers frames whose `uploaded` event has completed
+	if (ok && dev_lf) { launch_lf_groups((const DevLfTask *) (pb + o_tasks), (int32_t) ngg, stream); ok = hipGetLastError() == hipSuccess; }
 	ok = ok && hipEventRecord(af->uploaded, stream) == hipSuccess;
 	if (!ok) { (void) hipStreamSynchronize(stream); (void) hipGetLastError(); return nullptr; }   // (nothing may be in flight on blocks that go back to the cache)
 	{ const double tp7 = prof_now(); t_prof[0] += tp1 - tp0; t_prof[1] += tp2 - tp1; t_prof[2] += tp3 - tp2; t_prof[3] += tp4 - tp3; t_prof[4] += tp5 - tp4; t_prof[5] += tp6 - tp5; t_prof[6] += tp7 - tp6; ++t_prof_frames; }
@@ -356,12 +363,12 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 	// geometry of the entropy launch (runtime.hip batch_assign): up to 64 sections of one frame per wavefront, 1 / 2 / 4 wavefronts
 	// per workgroup sharing one copy of their frame's tables
 	bool lanes_fast = true, tables_in_lds = true; uint32_t lanes_lds = 0, generic_lds = 0;
-	int32_t total_waves = 0, nlf = 0, ntasks = 0, max_lf_cells = 0; size_t cells_total = 0, max_frame_cells = 0;
+	int32_t total_waves = 0, nlf = 0, max_lf_cells = 0; size_t cells_total = 0, max_frame_cells = 0;
 	for (int i = 0; i < n; ++i) {
 		const j40hip_aframe *f = frames[i];
 		if (!f || f->device != b->device) return ERR_GPU;
 		lanes_fast = lanes_fast && f->hf.lanes_fast; tables_in_lds = tables_in_lds && f->hf.tables_fit_lds; lanes_lds = std::max(lanes_lds, f->hf.lanes_lds_bytes);
-		total_waves += (f->num_groups + 63) / 64; nlf += f->num_lf_groups; ntasks += (int32_t) f->lf_tasks.size();
+		total_waves += (f->num_groups + 63) / 64; nlf += f->num_lf_groups;
 		max_lf_cells = std::max(max_lf_cells, f->max_lf_cells); cells_total += f->cells; max_frame_cells = std::max(max_frame_cells, f->cells);
 	}
 	if (const char *e = getenv("J40HIP_GENERIC_LANES")) if (atoi(e)) lanes_fast = false;
@@ -377,7 +384,7 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 	// ---- the batch's arrays: one staged blob, one copy ----
 	Layout L;
 	const size_t o_plans = L.take(sizeof(DevPlan) * (size_t) n), o_builds = L.take(sizeof(DevPlanBuild) * (size_t) n), o_k2 = L.take(sizeof(K2Frame) * (size_t) n);
-	const size_t o_lfs = L.take(sizeof(DevBatchLf) * (size_t) nlf), o_tasks = L.take(sizeof(DevLfTask) * (size_t) ntasks), o_work = L.take(sizeof(HfLaneWork) * work.size());
+	const size_t o_lfs = L.take(sizeof(DevBatchLf) * (size_t) nlf), o_work = L.take(sizeof(HfLaneWork) * work.size());
 	const size_t copy_bytes = L.size;
 	const size_t o_tiles = L.take(4 * (size_t) K2_NUM_BATCH_LAUNCHES * ((size_t) n + 1)), o_verdict = L.take(16 * (size_t) n + 64);   // (verdicts, then the tile totals)
 	if (!b->host.reserve(copy_bytes + 64, 0)) return ERR_MEM;
@@ -395,10 +402,10 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 	}
 	uint8_t *hb = b->host.ptr, *db = (uint8_t *) b->dev;
 	DevPlan *h_plans = (DevPlan *) (hb + o_plans); DevPlanBuild *h_builds = (DevPlanBuild *) (hb + o_builds); K2Frame *h_k2 = (K2Frame *) (hb + o_k2);
-	DevBatchLf *h_lfs = (DevBatchLf *) (hb + o_lfs); DevLfTask *h_tasks = (DevLfTask *) (hb + o_tasks);
+	DevBatchLf *h_lfs = (DevBatchLf *) (hb + o_lfs);
 	const DevPlan *d_plans = (const DevPlan *) (db + o_plans); const DevPlanBuild *d_builds = (const DevPlanBuild *) (db + o_builds); K2Frame *d_k2 = (K2Frame *) (db + o_k2);
-	const DevBatchLf *d_lfs = (const DevBatchLf *) (db + o_lfs); const DevLfTask *d_tasks = (const DevLfTask *) (db + o_tasks); const HfLaneWork *d_work = (const HfLaneWork *) (db + o_work);
-	size_t at_lf = 0, at_task = 0;
+	const DevBatchLf *d_lfs = (const DevBatchLf *) (db + o_lfs); const HfLaneWork *d_work = (const HfLaneWork *) (db + o_work);
+	size_t at_lf = 0;
 	for (int i = 0; i < n; ++i) {
 		const j40hip_aframe *f = frames[i];
 		h_plans[i] = f->plan;
@@ -408,13 +415,11 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 		memset(&k, 0, sizeof k);
 		k.plan = f->plan; k.sorted = f->build.vb_sorted; k.large_scratch = nullptr; k.rgba = (uint8_t *) rgba_dev[i]; k.stride = stride_bytes[i];
 		for (int32_t g = 0; g < f->num_lf_groups; ++g) h_lfs[at_lf++] = DevBatchLf{i, g};
-		for (const DevLfTask &t : f->lf_tasks) h_tasks[at_task++] = t;
 	}
 	memcpy(hb + o_work, work.data(), sizeof(HfLaneWork) * work.size());
 	for (int i = 0; i < n; ++i) if (hipStreamWaitEvent(s, frames[i]->uploaded, 0) != hipSuccess) return ERR_GPU;
 	if (hipMemcpyAsync(db, hb, copy_bytes, hipMemcpyHostToDevice, s) != hipSuccess) return ERR_GPU;
 	(void) hipEventRecord(b->ev[0], s);
-	if (ntasks) launch_lf_groups(d_tasks, ntasks, s);
 	launch_plan_build(d_builds, d_lfs, n, nlf, max_lf_cells, s);
 	launch_lf_tail_batch(d_plans, d_builds, d_lfs, n, nlf, max_lf_cells, max_frame_cells, s);
 	for (int i = 0; i < n; ++i) if (!frames[i]->sparse && hipMemsetAsync(frames[i]->plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) frames[i]->plan.coeff_stride, s) != hipSuccess) return ERR_GPU;

@@ -20,6 +20,9 @@ void j40hip_aframe_free(j40hip_aframe *f);
 // frees the calling thread's pinned staging buffers (before a thread that prepared frames exits)
 void j40hip_astage_release(void);
 int j40hip_aframe_lf_on_device(const j40hip_aframe *f);
+// whether everything prepare enqueued for the frame (copy, LfGroup streams) has completed; 8x8 cells of the frame
+int j40hip_aframe_uploaded(const j40hip_aframe *f);
+int64_t j40hip_aframe_cells(const j40hip_aframe *f);
 void j40hip_aframe_size(const j40hip_aframe *f, int64_t *width, int64_t *height);
 // what the reference says about bytes behind the frame (j40hip_frame_after_frame_status)
 uint32_t j40hip_aframe_after_frame_status(const j40hip_aframe *f);
@@ -33,5 +36,5 @@ uint32_t j40hip_abatch_launch(j40hip_abatch *b, j40hip_aframe *const *frames, in
 // has to be decoded again on the single-frame path (an LfGroup section the device decoder cannot take, or an event region that
 // overflowed)
 void j40hip_abatch_result(const j40hip_abatch *b, int i, uint32_t *code, int *redo);
-// ms of the last launch's stages: [0] LfGroup streams + plan build + LfGroup tail, [1] entropy decode, [2] pixels
+// ms of the last launch's stages: [0] plan build + LfGroup tail, [1] entropy decode, [2] pixels
 uint32_t j40hip_abatch_elapsed(j40hip_abatch *b, float *ms3);

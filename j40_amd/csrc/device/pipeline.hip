@@ -48,7 +48,7 @@ struct Job {
 	const void *buf = nullptr; size_t size = 0;
 	void *rgba = nullptr; size_t stride = 0; bool device_output = false;
 	j40hip_aframe *af = nullptr;
-	int64_t width = 0, height = 0;
+	int64_t width = 0, height = 0, cells = 0;
 	void *dev_rgba = nullptr;     // host output: the device image the copy back reads
 	uint32_t status = 0;
 };
@@ -67,7 +67,10 @@ struct Slot {                     // one batch in flight
 struct j40hip_pipeline {
 	int device = 0, batch_frames = 32, max_in_flight = 2;
 	int lf_mode = 0;                    // LfGroup streams: 0 decided per frame (see above), 1 always the device, 2 always the host threads
-	int64_t lf_hiwater = 0;             // mode 0: frames prepared-or-in-flight from which on the host threads keep the streams
+	// mode 0: the device takes a frame's LfGroup streams when there is a credit for it. Credits come from the device's idle time
+	// between two batches (retire): idle ms / what the streams of a frame cost the device, halved -- the LfGroup kernel slows the
+	// other kernels it runs beside. A busy device earns none, and the host threads keep every frame.
+	double lf_credits = 0, lf_cell_ms = 5.5e-6, last_retire_ms = 0;
 	int64_t lf_device_frames = 0, single_frames = 0;
 	std::mutex m;
 	std::condition_variable cv_todo, cv_ready, cv_done;
@@ -165,7 +168,7 @@ void worker_main(j40hip_pipeline *p) {
 			if (p->stop) break;
 			j = p->todo.front(); p->todo.pop_front();
 			++p->resident; ++p->parsing;
-			if (p->lf_mode == 0) lf_dev = (int64_t) p->ready.size() + p->in_flight_frames < p->lf_hiwater;
+			if (p->lf_mode == 0 && p->lf_credits >= 1.0) { lf_dev = true; p->lf_credits -= 1.0; }
 		}
 		const double t0 = now_ms();
 		j->af = j40hip_aframe_prepare(j->buf, j->size, p->device, stream, lf_dev ? 1 : 0);
@@ -173,6 +176,7 @@ void worker_main(j40hip_pipeline *p) {
 		bool single = j->af == nullptr;
 		if (j->af) {
 			j40hip_aframe_size(j->af, &j->width, &j->height);
+			j->cells = j40hip_aframe_cells(j->af);
 			if (j->stride < (size_t) j->width * 4) {
 				(void) hipStreamSynchronize(stream);   // (its copy is in flight)
 				j40hip_aframe_free(j->af); j->af = nullptr;
@@ -184,11 +188,14 @@ void worker_main(j40hip_pipeline *p) {
 		--p->parsing;
 		if (single) { p->single_ms += t2 - t0; ++p->single_frames; } else p->parse_ms += t1 - t0;
 		if (!j->af) {
+			if (p->lf_mode == 0 && lf_dev) p->lf_credits += 1.0;
 			--p->resident;
 			complete(p, j);
 			p->cv_todo.notify_all(); p->cv_ready.notify_all();
 		} else {
-			p->lf_device_frames += j40hip_aframe_lf_on_device(j->af);
+			const int on_dev = j40hip_aframe_lf_on_device(j->af);
+			p->lf_device_frames += on_dev;
+			if (p->lf_mode == 0 && lf_dev && !on_dev) p->lf_credits += 1.0;   // (its tables are not the device decoder's kind: the credit goes back)
 			p->ready.push_back(j);
 			p->cv_ready.notify_all();
 		}
@@ -219,8 +226,19 @@ void retire(j40hip_pipeline *p, Slot &slot) {   // GPU thread; waits for the slo
 		if (j->af) { j40hip_aframe_free(j->af); j->af = nullptr; }   // its stream has been waited for
 		if (!j->device_output && j->dev_rgba) release_image(p, j->dev_rgba, j->stride * (size_t) j->height);
 	}
+	int64_t cells = 0;
+	for (Job *j : slot.jobs) cells += j->cells;
 	std::unique_lock<std::mutex> lock(p->m);
 	if (timed) { p->lf_ms += ms3[0]; p->k1_ms += ms3[1]; p->k2_ms += ms3[2]; ++p->launches; p->launch_frames += (int64_t) slot.jobs.size(); }
+	{
+		const double now = now_ms();
+		if (timed && p->last_retire_ms > 0 && cells > 0) {
+			const double idle = (now - p->last_retire_ms) - (double) (ms3[0] + ms3[1] + ms3[2]);   // (negative when batches overlap: the device is the bottleneck)
+			const double frame_ms = p->lf_cell_ms * (double) cells / (double) slot.jobs.size();
+			p->lf_credits = std::min((double) p->batch_frames / 4, std::max(0.0, p->lf_credits + 0.5 * idle / frame_ms));
+		}
+		p->last_retire_ms = now;
+	}
 	p->in_flight_frames -= (int64_t) slot.jobs.size();
 	for (Job *j : slot.jobs) { --p->resident; complete(p, j); }
 	slot.jobs.clear(); slot.busy = false; slot.launch_err = 0;
@@ -233,23 +251,39 @@ void gpu_main(j40hip_pipeline *p) {
 		std::vector<Job *> take;
 		{
 			std::unique_lock<std::mutex> lock(p->m);
-			auto launchable = [&] {
-				if (p->ready.empty()) return false;
-				if ((int64_t) p->ready.size() >= p->batch_frames) return true;
-				return p->stop || (p->todo.empty() && p->parsing == 0);   // the tail: nothing else is coming
+			// A batch is made of frames that are ready for it: frames whose LfGroup streams the device is still decoding (0.2 s a
+			// section) stay behind while there are enough others. At the tail (nothing else is coming) everything goes.
+			auto tail = [&] { return p->stop || (p->todo.empty() && p->parsing == 0); };
+			auto collect = [&](bool everything) {
+				std::vector<size_t> pick;
+				for (size_t i = 0; i < p->ready.size() && (int64_t) pick.size() < p->batch_frames; ++i) {
+					Job *j = p->ready[i];
+					if (everything || !j40hip_aframe_lf_on_device(j->af) || j40hip_aframe_uploaded(j->af)) pick.push_back(i);
+				}
+				return pick;
 			};
-			p->cv_ready.wait(lock, [&] { return p->stop || launchable() || (!p->in_flight.empty() && p->ready.empty()); });
+			std::vector<size_t> pick;
+			p->cv_ready.wait(lock, [&] { return p->stop || !p->ready.empty() || !p->in_flight.empty(); });
 			if (p->stop && p->ready.empty() && p->in_flight.empty() && p->parsing == 0) break;
-			if (launchable()) {
-				while (!p->ready.empty() && (int64_t) take.size() < p->batch_frames) { take.push_back(p->ready.front()); p->ready.pop_front(); }
+			if ((int64_t) p->ready.size() >= p->batch_frames) { pick = collect(false); if ((int64_t) pick.size() < p->batch_frames) pick.clear(); }
+			if (pick.empty() && !p->ready.empty() && tail()) pick = collect(true);
+			if (!pick.empty()) {
+				for (size_t i : pick) take.push_back(p->ready[i]);
+				for (size_t k = pick.size(); k-- > 0; ) p->ready.erase(p->ready.begin() + (long) pick[k]);
 				p->in_flight_frames += (int64_t) take.size();
-			} else if (p->in_flight.empty()) {   // stopping while a worker still finishes its frame
-				p->cv_ready.wait_for(lock, std::chrono::milliseconds(2));
-				continue;
+			} else {
+				// Nothing to launch. Retire the oldest batch in flight if that does not mean waiting for it while the next batch fills
+				// up (its launch should not be held back): when it is done already, or when no frame is on its way at all.
+				bool retire_now = false;
+				if (!p->in_flight.empty()) {
+					retire_now = (p->ready.empty() && tail()) || hipEventQuery(p->slots[(size_t) p->in_flight.front()].done) == hipSuccess;
+					if (!retire_now) (void) hipGetLastError();
+				}
+				if (!retire_now) { p->cv_ready.wait_for(lock, std::chrono::milliseconds(1)); continue; }
 			}
 		}
-		if (take.empty()) {   // nothing to launch: retire the oldest batch in flight
-			if (!p->in_flight.empty()) { const int s = p->in_flight.front(); p->in_flight.pop_front(); retire(p, p->slots[(size_t) s]); }
+		if (take.empty()) {   // (the oldest batch in flight is to be retired)
+			const int s = p->in_flight.front(); p->in_flight.pop_front(); retire(p, p->slots[(size_t) s]);
 			continue;
 		}
 		if ((int) p->in_flight.size() >= p->max_in_flight) { const int s = p->in_flight.front(); p->in_flight.pop_front(); retire(p, p->slots[(size_t) s]); }
@@ -296,8 +330,7 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 		if (flags & 4u) { (void) mallopt(M_MMAP_THRESHOLD, 1 << 30); (void) mallopt(M_TRIM_THRESHOLD, (int) (((size_t) 1 << 31) - 1)); (void) mallopt(M_TOP_PAD, 64 << 20); }
 		p->batch_frames = batch_frames < 1 ? 32 : batch_frames;
 		p->max_in_flight = max_in_flight < 1 ? 2 : max_in_flight > 8 ? 8 : max_in_flight;
-		p->lf_hiwater = (int64_t) p->batch_frames;   // the device has less than one batch's worth queued up: it is about to idle
-		if (const char *e = getenv("J40HIP_LF_HIWATER")) p->lf_hiwater = atoll(e);
+		if (const char *e = getenv("J40HIP_LF_CELL_NS")) p->lf_cell_ms = atof(e) * 1e-6;
 		p->slots.resize((size_t) p->max_in_flight + 1);
 		for (Slot &s : p->slots) {
 			if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { *err = E_GPU; break; }
