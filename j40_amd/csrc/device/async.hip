@@ -164,7 +164,7 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	const size_t o_cl = L.take(fp.clusters.size() * sizeof(DevCluster)), o_spec = L.take(fp.coeff_specs.size() * sizeof(DevCodeSpec)), o_frame = L.take(sizeof(DevFrame));
 	const size_t o_lfg = L.take(ngg * sizeof(DevLfGroup)), o_sec = L.take(fp.sections.size() * sizeof(DevSection)), o_evr = L.take(fp.ev_range.size() * 4);
 	const size_t o_lso = L.take(ngg * 4), o_slots = L.take(ngg * sizeof(DevLfSlot));
-	const size_t o_tree = dev_lf ? L.take(sizeof(DevCoopTree)) : 0, o_alias = dev_lf ? L.take(fp.lf_alias.size() * 8) : 0, o_tasks = dev_lf ? L.take(ngg * sizeof(DevLfTask)) : 0;
+	const size_t o_tree = dev_lf ? L.take(sizeof(DevCoopTree)) : 0, o_alias = dev_lf ? L.take(fp.lf_alias.size() * 8) : 0;
 	size_t o_raw[3], o_xfy, o_bfy, o_info, copy_bytes = L.size;
 	for (int c = 0; c < 3; ++c) o_raw[c] = L.take(cells * 2 + 64);
 	o_xfy = L.take(c64s * 2); o_bfy = L.take(c64s * 2); o_info = L.take(cells * 4 + 64);
@@ -212,7 +212,6 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 			d.sharp = (int16_t *) (pb + o_sharp) + gg.cell_base;
 			d.result = (DevLfResult *) ((DevLfSlot *) (pb + o_slots) + g);   // (DevLfSlot begins with the two words of DevLfResult)
 		}
-		put(o_tasks, af->lf_tasks.data(), ngg * sizeof(DevLfTask));
 	} else {
 		// the LfGroup streams on this thread (modular.cpp's fast paths); an error becomes the section's status and takes its place
 		// among the frame's sections like the device decoder's would
@@ -278,10 +277,6 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	sg.pending = ok;
 	// recycled memory: no entry of the per-block table may point outside the event list (a section that fails leaves entries unwritten)
 	ok = ok && (!af->sparse || hipMemsetAsync(plan.block_events, 0, 16 * cells, stream) == hipSuccess);
-	// The LfGroup streams of this frame on the device: enqueued here, behind the copy, not with the frame's batch -- a section takes
-	// about 0.2 s to decode whatever else runs (one wavefront, a quarter of a million samples in sequence), and a batch should not
-	// wait that long for its slowest member: the batch builder prefers frames whose `uploaded` event has completed
-	if (ok && dev_lf) { launch_lf_groups((const DevLfTask *) (pb + o_tasks), (int32_t) ngg, stream); ok = hipGetLastError() == hipSuccess; }
 	ok = ok && hipEventRecord(af->uploaded, stream) == hipSuccess;
 	if (!ok) { (void) hipStreamSynchronize(stream); (void) hipGetLastError(); return nullptr; }   // (nothing may be in flight on blocks that go back to the cache)
 	{ const double tp7 = prof_now(); t_prof[0] += tp1 - tp0; t_prof[1] += tp2 - tp1; t_prof[2] += tp3 - tp2; t_prof[3] += tp4 - tp3; t_prof[4] += tp5 - tp4; t_prof[5] += tp6 - tp5; t_prof[6] += tp7 - tp6; ++t_prof_frames; }
@@ -452,3 +447,54 @@ uint32_t j40hip_abatch_elapsed(j40hip_abatch *b, float *ms3) {
 	(void) hipEventElapsedTime(&ms3[0], b->ev[0], b->ev[1]); (void) hipEventElapsedTime(&ms3[1], b->ev[1], b->ev[2]); (void) hipEventElapsedTime(&ms3[2], b->ev[2], b->ev[3]);
 	return 0;
 }
+
+// ---- the LfGroup streams of several prepared frames in one launch (k_lf_groups), ahead of the frames' batch ----
+// A section takes about 0.2 s to decode whatever else runs (one wavefront, a quarter of a million samples one after the other), so
+// the sections of many frames go into one launch, on a stream of its own, and a frame joins a batch when its launch has completed.
+
+struct j40hip_alf {
+	int device = 0;
+	PinnedStage host; void *dev = nullptr; size_t dev_cap = 0;
+	hipEvent_t done = nullptr;
+};
+
+j40hip_alf *j40hip_alf_create(int device) {
+	if (hipSetDevice(device) != hipSuccess) return nullptr;
+	j40hip_alf *a = new j40hip_alf();
+	a->device = device;
+	if (hipEventCreateWithFlags(&a->done, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); delete a; return nullptr; }
+	return a;
+}
+void j40hip_alf_free(j40hip_alf *a) {
+	if (!a) return;
+	(void) hipSetDevice(a->device);
+	a->host.release();
+	if (a->dev) (void) hipFree(a->dev);
+	if (a->done) (void) hipEventDestroy(a->done);
+	delete a;
+}
+uint32_t j40hip_alf_launch(j40hip_alf *a, j40hip_aframe *const *frames, int n, hipStream_t s) {
+	if (!a || n <= 0 || hipSetDevice(a->device) != hipSuccess) return ERR_GPU;
+	size_t ntasks = 0;
+	for (int i = 0; i < n; ++i) ntasks += frames[i]->lf_tasks.size();
+	const size_t bytes = sizeof(DevLfTask) * ntasks + 64;
+	if (!a->host.reserve(bytes, 0)) return ERR_MEM;
+	if (bytes > a->dev_cap) {
+		if (a->dev) (void) hipFree(a->dev);
+		a->dev = nullptr; a->dev_cap = 0;
+		if (hipMalloc(&a->dev, bytes * 2) != hipSuccess) { (void) hipGetLastError(); return ERR_MEM; }
+		a->dev_cap = bytes * 2;
+	}
+	DevLfTask *h = (DevLfTask *) a->host.ptr; size_t k = 0;
+	for (int i = 0; i < n; ++i) for (const DevLfTask &t : frames[i]->lf_tasks) h[k++] = t;
+	for (int i = 0; i < n; ++i) if (hipStreamWaitEvent(s, frames[i]->uploaded, 0) != hipSuccess) return ERR_GPU;
+	if (ntasks) {
+		if (hipMemcpyAsync(a->dev, h, sizeof(DevLfTask) * ntasks, hipMemcpyHostToDevice, s) != hipSuccess) return ERR_GPU;
+		launch_lf_groups((const DevLfTask *) a->dev, (int32_t) ntasks, s);
+	}
+	if (hipEventRecord(a->done, s) != hipSuccess || hipGetLastError() != hipSuccess) return ERR_GPU;
+	// the frames' batch must wait for this launch, not only for their copies: from now on `uploaded` stands for both
+	for (int i = 0; i < n; ++i) if (hipEventRecord(frames[i]->uploaded, s) != hipSuccess) return ERR_GPU;
+	return 0;
+}
+int j40hip_alf_done(j40hip_alf *a) { if (!a || hipEventQuery(a->done) == hipSuccess) return 1; (void) hipGetLastError(); return 0; }

@@ -9,6 +9,7 @@
 
 struct j40hip_aframe;
 struct j40hip_abatch;
+struct j40hip_alf;
 
 // Host stage of one frame: parse up to the LfGroup sections, build the front plan, copy it (and the codestream) to the device
 // asynchronously on `stream`. lf_on_device != 0: leave the LfGroup streams to k_lf_groups when its tables allow it, else (and
@@ -38,3 +39,11 @@ uint32_t j40hip_abatch_launch(j40hip_abatch *b, j40hip_aframe *const *frames, in
 void j40hip_abatch_result(const j40hip_abatch *b, int i, uint32_t *code, int *redo);
 // ms of the last launch's stages: [0] plan build + LfGroup tail, [1] entropy decode, [2] pixels
 uint32_t j40hip_abatch_elapsed(j40hip_abatch *b, float *ms3);
+
+// The LfGroup streams of `n` prepared frames (those with j40hip_aframe_lf_on_device) in one k_lf_groups launch on `stream`; a frame
+// may join a batch once j40hip_alf_done says the launch has completed (the batch's stream also waits for it). One launch per object
+// at a time.
+j40hip_alf *j40hip_alf_create(int device);
+void j40hip_alf_free(j40hip_alf *a);
+uint32_t j40hip_alf_launch(j40hip_alf *a, j40hip_aframe *const *frames, int n, hipStream_t stream);
+int j40hip_alf_done(j40hip_alf *a);

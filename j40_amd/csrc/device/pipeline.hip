@@ -49,8 +49,16 @@ struct Job {
 	void *rgba = nullptr; size_t stride = 0; bool device_output = false;
 	j40hip_aframe *af = nullptr;
 	int64_t width = 0, height = 0, cells = 0;
+	bool lf_failed = false;       // its LfGroup streams could not be launched on the device
 	void *dev_rgba = nullptr;     // host output: the device image the copy back reads
 	uint32_t status = 0;
+};
+
+struct LfFlight {                 // one launch of LfGroup streams in flight (frames whose streams the device decodes)
+	hipStream_t stream = nullptr;
+	j40hip_alf *alf = nullptr;
+	std::vector<Job *> jobs;
+	bool busy = false;
 };
 
 struct Slot {                     // one batch in flight
@@ -74,7 +82,8 @@ struct j40hip_pipeline {
 	int64_t lf_device_frames = 0, single_frames = 0;
 	std::mutex m;
 	std::condition_variable cv_todo, cv_ready, cv_done;
-	std::deque<Job *> todo, ready;
+	std::deque<Job *> todo, ready, lf_pending;   // lf_pending: prepared, their LfGroup streams still to be launched on the device
+	LfFlight lf_flights[2];
 	std::vector<uint32_t> results;      // by ticket
 	std::vector<uint8_t> finished;      // by ticket
 	int64_t submitted = 0, completed = 0, resident = 0, parsing = 0, in_flight_frames = 0;
@@ -196,7 +205,7 @@ void worker_main(j40hip_pipeline *p) {
 			const int on_dev = j40hip_aframe_lf_on_device(j->af);
 			p->lf_device_frames += on_dev;
 			if (p->lf_mode == 0 && lf_dev && !on_dev) p->lf_credits += 1.0;   // (its tables are not the device decoder's kind: the credit goes back)
-			p->ready.push_back(j);
+			(on_dev ? p->lf_pending : p->ready).push_back(j);
 			p->cv_ready.notify_all();
 		}
 	}
@@ -251,20 +260,31 @@ void gpu_main(j40hip_pipeline *p) {
 		std::vector<Job *> take;
 		{
 			std::unique_lock<std::mutex> lock(p->m);
-			// A batch is made of frames that are ready for it: frames whose LfGroup streams the device is still decoding (0.2 s a
-			// section) stay behind while there are enough others. At the tail (nothing else is coming) everything goes.
-			auto tail = [&] { return p->stop || (p->todo.empty() && p->parsing == 0); };
-			auto collect = [&](bool everything) {
+			auto lf_busy = [&] { return !p->lf_pending.empty() || p->lf_flights[0].busy || p->lf_flights[1].busy; };
+			auto tail = [&] { return p->stop || (p->todo.empty() && p->parsing == 0 && !lf_busy()); };   // nothing else is coming
+			auto collect = [&](bool) {
 				std::vector<size_t> pick;
-				for (size_t i = 0; i < p->ready.size() && (int64_t) pick.size() < p->batch_frames; ++i) {
-					Job *j = p->ready[i];
-					if (everything || !j40hip_aframe_lf_on_device(j->af) || j40hip_aframe_uploaded(j->af)) pick.push_back(i);
-				}
+				for (size_t i = 0; i < p->ready.size() && (int64_t) pick.size() < p->batch_frames; ++i) pick.push_back(i);
 				return pick;
 			};
 			std::vector<size_t> pick;
-			p->cv_ready.wait(lock, [&] { return p->stop || !p->ready.empty() || !p->in_flight.empty(); });
-			if (p->stop && p->ready.empty() && p->in_flight.empty() && p->parsing == 0) break;
+			p->cv_ready.wait(lock, [&] { return p->stop || !p->ready.empty() || !p->in_flight.empty() || lf_busy(); });
+			if (p->stop && p->ready.empty() && p->in_flight.empty() && p->parsing == 0 && !lf_busy()) break;
+			// the LfGroup streams the device decodes: finished launches hand their frames on; waiting frames go into the next launch (a
+			// launch is latency-bound -- about 0.2 s however many sections it has -- so everything waiting goes in)
+			for (LfFlight &fl : p->lf_flights) if (fl.busy && j40hip_alf_done(fl.alf)) {
+				for (Job *j : fl.jobs) p->ready.push_back(j);
+				fl.jobs.clear(); fl.busy = false;
+			}
+			if (!p->lf_pending.empty()) for (LfFlight &fl : p->lf_flights) if (!fl.busy) {
+				std::vector<j40hip_aframe *> frames;
+				while (!p->lf_pending.empty() && (int64_t) fl.jobs.size() < p->batch_frames) { fl.jobs.push_back(p->lf_pending.front()); frames.push_back(p->lf_pending.front()->af); p->lf_pending.pop_front(); }
+				if (!fl.alf) fl.alf = j40hip_alf_create(p->device);
+				const uint32_t e = fl.alf ? j40hip_alf_launch(fl.alf, frames.data(), (int) frames.size(), fl.stream) : E_GPU;
+				if (e) { for (Job *j : fl.jobs) { j->lf_failed = true; p->ready.push_back(j); } fl.jobs.clear(); }   // (they are decoded again on the single-frame path)
+				else fl.busy = true;
+				break;
+			}
 			if ((int64_t) p->ready.size() >= p->batch_frames) { pick = collect(false); if ((int64_t) pick.size() < p->batch_frames) pick.clear(); }
 			if (pick.empty() && !p->ready.empty() && tail()) pick = collect(true);
 			if (!pick.empty()) {
@@ -279,12 +299,28 @@ void gpu_main(j40hip_pipeline *p) {
 					retire_now = (p->ready.empty() && tail()) || hipEventQuery(p->slots[(size_t) p->in_flight.front()].done) == hipSuccess;
 					if (!retire_now) (void) hipGetLastError();
 				}
-				if (!retire_now) { p->cv_ready.wait_for(lock, std::chrono::milliseconds(1)); continue; }
+				if (!retire_now) { p->cv_ready.wait_for(lock, std::chrono::milliseconds(1)); continue; }   // (also how finished LfGroup launches get noticed)
 			}
 		}
 		if (take.empty()) {   // (the oldest batch in flight is to be retired)
 			const int s = p->in_flight.front(); p->in_flight.pop_front(); retire(p, p->slots[(size_t) s]);
 			continue;
+		}
+		{   // frames whose LfGroup streams could not be launched on the device never enter a batch (their planes were never decoded):
+			// the single-frame path, here and now
+			std::vector<Job *> keep;
+			for (Job *j : take) {
+				if (!j->lf_failed) { keep.push_back(j); continue; }
+				(void) hipDeviceSynchronize();
+				j40hip_aframe_free(j->af); j->af = nullptr;
+				j->status = decode_single(p, j, p->slots[0].stream);
+				std::unique_lock<std::mutex> lock(p->m);
+				--p->in_flight_frames; --p->resident;
+				complete(p, j);
+				p->cv_todo.notify_all();
+			}
+			take.swap(keep);
+			if (take.empty()) continue;
 		}
 		if ((int) p->in_flight.size() >= p->max_in_flight) { const int s = p->in_flight.front(); p->in_flight.pop_front(); retire(p, p->slots[(size_t) s]); }
 		int si = -1;
@@ -306,6 +342,7 @@ void gpu_main(j40hip_pipeline *p) {
 		p->in_flight.push_back(si);
 	}
 	for (Slot &s : p->slots) if (s.batch) { j40hip_abatch_free(s.batch); s.batch = nullptr; }
+	for (LfFlight &fl : p->lf_flights) if (fl.alf) { j40hip_alf_free(fl.alf); fl.alf = nullptr; }
 	for (auto &im : p->free_images) (void) hipFree(im.first);
 	p->free_images.clear();
 }
@@ -335,6 +372,7 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 		for (Slot &s : p->slots) {
 			if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { *err = E_GPU; break; }
 		}
+		for (LfFlight &fl : p->lf_flights) if (!*err && hipStreamCreateWithFlags(&fl.stream, hipStreamNonBlocking) != hipSuccess) *err = E_GPU;
 		if (!*err) {
 			if (host_threads < 1) host_threads = (int) std::max(1u, std::thread::hardware_concurrency());
 			if (host_threads > 128) host_threads = 128;   // (each worker owns tens of MB of pinned staging; more than this was never exercised)
@@ -355,7 +393,8 @@ void j40hip_pipeline_free(j40hip_pipeline *p) {
 	if (p->gpu.joinable()) p->gpu.join();
 	(void) hipSetDevice(p->device);
 	for (Job *j : p->todo) delete j;
-	for (Job *j : p->ready) { if (j->af) { (void) hipDeviceSynchronize(); j40hip_aframe_free(j->af); } delete j; }
+	for (std::deque<Job *> *q : {&p->ready, &p->lf_pending}) for (Job *j : *q) { if (j->af) { (void) hipDeviceSynchronize(); j40hip_aframe_free(j->af); } delete j; }
+	for (LfFlight &fl : p->lf_flights) { for (Job *j : fl.jobs) { if (j->af) { (void) hipDeviceSynchronize(); j40hip_aframe_free(j->af); } delete j; } if (fl.stream) (void) hipStreamDestroy(fl.stream); }
 	for (Slot &s : p->slots) { if (s.done) (void) hipEventDestroy(s.done); if (s.stream) (void) hipStreamDestroy(s.stream); }
 	delete p;
 }
