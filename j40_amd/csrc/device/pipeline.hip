@@ -372,7 +372,16 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 		for (Slot &s : p->slots) {
 			if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { *err = E_GPU; break; }
 		}
-		for (LfFlight &fl : p->lf_flights) if (!*err && hipStreamCreateWithFlags(&fl.stream, hipStreamNonBlocking) != hipSuccess) *err = E_GPU;
+		{   // The LfGroup launches run for a quarter of a second each. Streams of one priority share a handful of hardware queues, and a
+			// kernel waits for the kernels ahead of it in its queue whichever stream they came from: on a stream of the batches' priority
+			// such a launch held up a quarter of the pixel kernels (296 ms per batch against 80). Lowest priority: queues of their own.
+			int prio_low = 0, prio_high = 0;
+			(void) hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+			for (LfFlight &fl : p->lf_flights) if (!*err && hipStreamCreateWithPriority(&fl.stream, hipStreamNonBlocking, prio_low) != hipSuccess) {
+				(void) hipGetLastError();
+				if (hipStreamCreateWithFlags(&fl.stream, hipStreamNonBlocking) != hipSuccess) *err = E_GPU;
+			}
+		}
 		if (!*err) {
 			if (host_threads < 1) host_threads = (int) std::max(1u, std::thread::hardware_concurrency());
 			if (host_threads > 128) host_threads = 128;   // (each worker owns tens of MB of pinned staging; more than this was never exercised)

@@ -304,8 +304,16 @@ inline uint32_t take_bits(BitReader &br, int n) {   // == BitReader::u
 	br.bits >>= n; br.nbits -= n;
 	return v;
 }
+// what one rANS symbol + hybrid integer of a cluster needs, as plain ints (HybridCfg's fields are bytes: behind a reference they
+// are reloaded and sign-extended for every symbol, because a byte may alias anything the loop stores)
+struct RansCluster {
+	const AnsEntry *alias;
+	int32_t split_exp, split, in_token, msb, lsb, max_token;
+	explicit RansCluster(const Cluster &cl) : alias(cl.alias.data()), split_exp(cl.cfg.split_exp), split(1 << cl.cfg.split_exp), in_token(cl.cfg.msb_in_token + cl.cfg.lsb_in_token),
+		msb(cl.cfg.msb_in_token), lsb(cl.cfg.lsb_in_token), max_token(cl.cfg.max_token) {}
+};
 // one rANS symbol + hybrid integer (ans_decode + hybrid_int of entropy.cpp; j40.h:2441, 2313)
-inline int32_t rans_value(BitReader &br, uint32_t &state, int32_t log_bucket, const Cluster &cl) {
+inline int32_t rans_value(BitReader &br, uint32_t &state, int32_t log_bucket, const RansCluster &cl) {
 	if (state == 0) { state = take_bits(br, 16); state |= take_bits(br, 16) << 16; }
 	const uint32_t idx = state & 0xfff, i = idx >> log_bucket, pos = idx & ((1u << log_bucket) - 1);
 	const AnsEntry e = cl.alias[i];
@@ -315,27 +323,34 @@ inline int32_t rans_value(BitReader &br, uint32_t &state, int32_t log_bucket, co
 	const uint32_t d = aliased ? (uint32_t) (e >> 28) & 0x1fff : (uint32_t) (e >> 41) & 0x1fff;
 	state = d * (state >> 12) + offset + pos;
 	if (state < (1u << 16)) state = (state << 16) | take_bits(br, 16);
-	const HybridCfg &c = cl.cfg;
-	const int32_t split = 1 << c.split_exp;
-	if (token < split) return token;
-	J40HIP_SHOULD(token <= c.max_token, "iovf");
-	const int32_t in_token = c.msb_in_token + c.lsb_in_token;
-	const int32_t midbits = c.split_exp - in_token + ((token - split) >> in_token);
+	if (token < cl.split) return token;
+	J40HIP_SHOULD(token <= cl.max_token, "iovf");
+	const int32_t midbits = cl.split_exp - cl.in_token + ((token - cl.split) >> cl.in_token);
 	const int32_t mid = (int32_t) take_bits(br, midbits);
-	const int32_t top = 1 << c.msb_in_token;
-	const int32_t lo = token & ((1 << c.lsb_in_token) - 1), hi = (token >> c.lsb_in_token) & (top - 1);
-	return ((top | hi) << (midbits + c.lsb_in_token)) | ((mid << c.lsb_in_token) | lo);
+	const int32_t top = 1 << cl.msb;
+	const int32_t lo = token & ((1 << cl.lsb) - 1), hi = (token >> cl.lsb) & (top - 1);
+	return ((top | hi) << (midbits + cl.lsb)) | ((mid << cl.lsb) | lo);
 }
 
 // channels whose specialised tree is a single leaf (the usual case for LF chroma and for the HF-metadata channels): no tree walk,
 // and with the predictor a compile-time constant only the neighbours it uses are fetched
 template <int PRED>
-static void decode_single_leaf(BitReader &br, Plane &c, uint32_t &state, int32_t log_bucket, const Cluster &cl, int32_t offset, int32_t multiplier) {
+static void decode_single_leaf(BitReader &br_, Plane &c, uint32_t &state_, int32_t log_bucket, const Cluster &cluster, int32_t offset, int32_t multiplier) {
 	const int32_t w = c.width, h = c.height;
+	const RansCluster cl(cluster);
+	// the reader and the rANS state live in locals for the duration (the stores into the plane cannot be proven not to alias them
+	// otherwise, and every symbol would reload and store them); written back at the end -- after an error nobody reads them
+	BitReader br = br_;
+	uint32_t state = state_;
+	// Predictors that look at W, N and NW only: away from the left edge and the first row the three are carried from sample to
+	// sample (one load per sample: N), and none of the edge rules of j40.h:3965-3990 can apply
+	constexpr bool WNNW = PRED == 0 || PRED == 1 || PRED == 2 || PRED == 3 || PRED == 4 || PRED == 5 || PRED == 8 || PRED == 10 || PRED == 11;
 	for (int32_t y = 0; y < h; ++y) {
 		int16_t *row = c.row(y);
 		const int16_t *up = y > 0 ? c.row(y - 1) : row, *up2 = y > 1 ? c.row(y - 2) : up;
-		for (int32_t x = 0; x < w; ++x) {
+		int32_t x = 0;
+		const int32_t edge_until = WNNW && y > 0 ? 1 : w;
+		for (; x < edge_until; ++x) {
 			// the neighbours with their fallbacks (j40.h:3965-3990); the ones PRED does not use fold away
 			const int32_t pw = x > 0 ? row[x - 1] : y > 0 ? up[x] : 0;
 			const int32_t pn = y > 0 ? up[x] : pw;
@@ -364,7 +379,30 @@ static void decode_single_leaf(BitReader &br, Plane &c, uint32_t &state, int32_t
 			J40HIP_SHOULD(-32768 <= v && v <= 32767, "povf");
 			row[x] = (int16_t) v;
 		}
+		if (x < w) {   // (WNNW, y > 0, x = 1)
+			int32_t pw = row[0], pnw = up[0];
+			for (; x < w; ++x) {
+				const int32_t pn = up[x];
+				int32_t pred;
+				switch (PRED) {
+				case 0: pred = 0; break;
+				case 1: pred = pw; break;
+				case 2: pred = pn; break;
+				case 3: pred = (pw + pn) / 2; break;
+				case 4: pred = std::abs(pn - pnw) < std::abs(pw - pnw) ? pw : pn; break;
+				case 5: pred = clamped_gradient(pw, pn, pnw); break;
+				case 8: pred = pnw; break;
+				case 10: pred = (pw + pnw) / 2; break;
+				default: pred = (pn + pnw) / 2; break;   // 11
+				}
+				const int32_t v = unpack_signed(rans_value(br, state, log_bucket, cl)) * multiplier + offset + pred;
+				J40HIP_SHOULD(-32768 <= v && v <= 32767, "povf");
+				row[x] = (int16_t) v;
+				pw = v; pnw = pn;
+			}
+		}
 	}
+	br_ = br; state_ = state;
 }
 
 // the fast loop: rANS without LZ77, no weighted predictor, no previous-channel properties in the specialised tree
@@ -401,6 +439,67 @@ bool decode_channel_fast(BitReader &br, Modular &m, CodeState &code, int32_t cid
 		}
 		return true;
 	}
+	std::vector<RansCluster> rcl;
+	for (const Cluster &cl : spec->clusters) rcl.emplace_back(cl);
+	const RansCluster *rclusters = rcl.data();
+	BitReader lbr = br;   // (in locals for the duration, see decode_single_leaf)
+	struct PutBack { BitReader &to, &from; ~PutBack() { to = from; } } put_back{br, lbr};
+	// Trees that look at W, N and NW only -- properties y, x, |N|, |W|, N, W, W + N - NW, W - NW, NW - N; predictors of the same kind
+	// (the LF trees of VarDCT encoders: gradient predictor, contexts from the local gradient): like decode_single_leaf, away from the
+	// left edge and the first row the three neighbours are carried along, one load per sample, and no edge rule can apply
+	bool wnnw = true;
+	for (const TreeNode &n : tree) {
+		if (n.prop >= 0) wnnw = wnnw && (n.prop <= 7 || (n.prop >= 9 && n.prop <= 11));
+		else { const int32_t pr = -1 - n.prop; wnnw = wnnw && (pr <= 5 || pr == 8 || pr == 10 || pr == 11); }
+	}
+	if (wnnw) {
+		for (int32_t y = 0; y < h; ++y) {
+			int16_t *row = c.row(y);
+			const int16_t *up = y > 0 ? c.row(y - 1) : row;
+			int32_t pw = 0, pnw = 0;
+			for (int32_t x = 0; x < w; ++x) {
+				int32_t pn;
+				if (x == 0 || y == 0) {   // the edge rules (j40.h:3965-3990)
+					pw = x > 0 ? row[x - 1] : y > 0 ? up[x] : 0;
+					pn = y > 0 ? up[x] : pw;
+					pnw = x > 0 && y > 0 ? up[x - 1] : pw;
+				} else pn = up[x];
+				const TreeNode *n = root;
+				while (n->prop >= 0) {
+					int32_t val;
+					switch (n->prop) {
+					case 2: val = y; break;
+					case 3: val = x; break;
+					case 4: val = std::abs(pn); break;
+					case 5: val = std::abs(pw); break;
+					case 6: val = pn; break;
+					case 7: val = pw; break;
+					case 9: val = pw + pn - pnw; break;
+					case 10: val = pw - pnw; break;
+					default: val = pnw - pn; break;   // 11
+					}
+					n += val > n->value ? n->a : n->b;
+				}
+				int32_t v = rans_value(lbr, state, log_bucket, rclusters[cluster_map[(size_t) n->value]]);
+				v = unpack_signed(v) * n->b + n->a;
+				switch (-1 - n->prop) {
+				case 0: break;
+				case 1: v += pw; break;
+				case 2: v += pn; break;
+				case 3: v += (pw + pn) / 2; break;
+				case 4: v += std::abs(pn - pnw) < std::abs(pw - pnw) ? pw : pn; break;
+				case 5: v += clamped_gradient(pw, pn, pnw); break;
+				case 8: v += pnw; break;
+				case 10: v += (pw + pnw) / 2; break;
+				default: v += (pn + pnw) / 2; break;   // 11
+				}
+				J40HIP_SHOULD(-32768 <= v && v <= 32767, "povf");
+				row[x] = (int16_t) v;
+				pw = v; pnw = pn;
+			}
+		}
+		return true;
+	}
 	for (int32_t y = 0; y < h; ++y) {
 		int16_t *row = c.row(y);
 		const int16_t *up = y > 0 ? c.row(y - 1) : row, *up2 = y > 1 ? c.row(y - 2) : up;
@@ -432,7 +531,7 @@ bool decode_channel_fast(BitReader &br, Modular &m, CodeState &code, int32_t cid
 				}
 				n += val > n->value ? n->a : n->b;
 			}
-			int32_t v = rans_value(br, state, log_bucket, clusters[cluster_map[(size_t) n->value]]);
+			int32_t v = rans_value(lbr, state, log_bucket, rclusters[cluster_map[(size_t) n->value]]);
 			v = unpack_signed(v) * n->b + n->a;
 			int32_t pred;
 			switch (-1 - n->prop) {
@@ -457,6 +556,7 @@ bool decode_channel_fast(BitReader &br, Modular &m, CodeState &code, int32_t cid
 	}
 	return true;
 }
+
 
 } // namespace
 

@@ -3,7 +3,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 export J40HIP_ASYNC_TIMING=1
 cd $R
 for m in ${MODES:-host auto}; do
-  timeout 250 python bench.py --skip-sections --steps ${STEPS:-8} --warmup 2 --distinct 16 --no-cpu-baseline --lf-streams $m > gpurun_out/p_$m.json 2> gpurun_out/p_$m.err
+  timeout 250 python bench.py --skip-sections --steps ${STEPS:-8} --warmup ${WARM:-2} --distinct 16 --no-cpu-baseline --lf-streams $m > gpurun_out/p_$m.json 2> gpurun_out/p_$m.err
   python -c "import json; d=json.load(open('gpurun_out/p_$m.json')); print('$m', d['value'], d['ms_per_step'], {k: v for k, v in d['pipeline'].items() if k != 'note'})"
   grep "host stage" gpurun_out/p_$m.err | head -3
 done
