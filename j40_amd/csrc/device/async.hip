@@ -112,6 +112,7 @@ struct j40hip_aframe {
 	DevPlan plan; DevPlanBuild build;
 	HfLaunchInfo hf;
 	std::vector<DevLfTask> lf_tasks;   // empty: the LfGroup streams were decoded on the host
+	DevLfLaneSet lf_set;               // ... else: the frame's sections for k_lf_lanes
 	int32_t num_lf_groups = 0, max_lf_cells = 0, num_groups = 0, num_passes = 1;
 	size_t cells = 0;
 	bool sparse = true;
@@ -151,7 +152,7 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	memcpy(offs.dq_size, af->st->dq_size, sizeof offs.dq_size); memcpy(offs.dq_scan_off, af->st->dq_scan_off, sizeof offs.dq_scan_off);
 	FrontPlan &fp = t_front;
 	if (build_front_plan(fr, offs, h.cs_size, extra_prec, lf_on_device != 0 && plain, &fp)) return nullptr;
-	const bool dev_lf = fp.lf_coop;
+	const bool dev_lf = fp.lf_device;
 	const double tp2 = prof_now();
 	const size_t ngg = fp.lf_groups.size(), cells = fp.cells, c64s = fp.c64s, cs_size = h.cs_size;
 	const int32_t num_groups = fp.frame.num_groups;
@@ -164,7 +165,8 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	const size_t o_cl = L.take(fp.clusters.size() * sizeof(DevCluster)), o_spec = L.take(fp.coeff_specs.size() * sizeof(DevCodeSpec)), o_frame = L.take(sizeof(DevFrame));
 	const size_t o_lfg = L.take(ngg * sizeof(DevLfGroup)), o_sec = L.take(fp.sections.size() * sizeof(DevSection)), o_evr = L.take(fp.ev_range.size() * 4);
 	const size_t o_lso = L.take(ngg * 4), o_slots = L.take(ngg * sizeof(DevLfSlot));
-	const size_t o_tree = dev_lf ? L.take(sizeof(DevCoopTree)) : 0, o_alias = dev_lf ? L.take(fp.lf_alias.size() * 8) : 0;
+	const size_t o_tree = dev_lf ? L.take(fp.lf_tree.size() * sizeof(DevTreeNode)) : 0, o_alias = dev_lf ? L.take(fp.lf_alias.size() * 8) : 0, o_lfmap = dev_lf ? L.take(fp.lf_ctx_map.size()) : 0,
+		o_lfcfg = dev_lf ? L.take(fp.lf_cfg.size() * 4) : 0, o_tasks = dev_lf ? L.take(ngg * sizeof(DevLfTask)) : 0;
 	size_t o_raw[3], o_xfy, o_bfy, o_info, copy_bytes = L.size;
 	for (int c = 0; c < 3; ++c) o_raw[c] = L.take(cells * 2 + 64);
 	o_xfy = L.take(c64s * 2); o_bfy = L.take(c64s * 2); o_info = L.take(cells * 4 + 64);
@@ -195,14 +197,15 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	memset(slots, 0, ngg * sizeof(DevLfSlot));
 	const double tp4 = prof_now();
 	if (dev_lf) {
-		put(o_tree, &fp.lf_tree, sizeof(DevCoopTree)); put(o_alias, fp.lf_alias.data(), fp.lf_alias.size() * 8);
+		put(o_tree, fp.lf_tree.data(), fp.lf_tree.size() * sizeof(DevTreeNode)); put(o_alias, fp.lf_alias.data(), fp.lf_alias.size() * 8);
+		put(o_lfmap, fp.lf_ctx_map.data(), fp.lf_ctx_map.size()); put(o_lfcfg, fp.lf_cfg.data(), fp.lf_cfg.size() * 4);
 		af->lf_tasks.resize(ngg);
 		for (size_t g = 0; g < ngg; ++g) {
 			const LfDeviceTask &t = tasks[g];
 			const DevLfGroup &gg = fp.lf_groups[g];
 			DevLfTask &d = af->lf_tasks[g];
 			memset(&d, 0, sizeof d);
-			d.codestream = pb + o_cs; d.tree = (const DevCoopTree *) (pb + o_tree); d.alias = (const uint64_t *) (pb + o_alias); d.log_alpha_size = fp.lf_log_alpha;
+			d.codestream = pb + o_cs; d.tree = nullptr; d.alias = (const uint64_t *) (pb + o_alias); d.log_alpha_size = fp.lf_log_alpha;   // (k_lf_lanes reads the tables of the frame's DevLfLaneSet)
 			d.byte_off = (uint32_t) t.byte_off; d.size = (uint32_t) t.size; d.bit_off = t.bit_off;
 			d.w8 = t.w8; d.h8 = t.h8; d.w64 = t.w64; d.h64 = t.h64; d.sidx0 = t.sidx0; d.sidx2 = t.sidx2; d.nbvb_bits = t.nbvb_bits;
 			// streamed order Y, X, B -> the frame-wide planes X, Y, B
@@ -212,6 +215,13 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 			d.sharp = (int16_t *) (pb + o_sharp) + gg.cell_base;
 			d.result = (DevLfResult *) ((DevLfSlot *) (pb + o_slots) + g);   // (DevLfSlot begins with the two words of DevLfResult)
 		}
+		put(o_tasks, af->lf_tasks.data(), ngg * sizeof(DevLfTask));
+		DevLfLaneSet &ls = af->lf_set;
+		ls.tasks = (const DevLfTask *) (pb + o_tasks); ls.ntasks = (int32_t) ngg;
+		ls.tree = (const DevTreeNode *) (pb + o_tree); ls.num_nodes = (int32_t) fp.lf_tree.size();
+		ls.ctx_map = pb + o_lfmap; ls.num_dist = (int32_t) fp.lf_ctx_map.size();
+		ls.cluster_cfg = (const uint32_t *) (pb + o_lfcfg); ls.num_clusters = (int32_t) fp.lf_cfg.size();
+		ls.alias = (const uint64_t *) (pb + o_alias); ls.log_alpha = fp.lf_log_alpha; ls.uses = fp.lf_uses; ls.lds_bytes = fp.lf_lds_bytes;
 	} else {
 		// the LfGroup streams on this thread (modular.cpp's fast paths); an error becomes the section's status and takes its place
 		// among the frame's sections like the device decoder's would
@@ -475,9 +485,7 @@ void j40hip_alf_free(j40hip_alf *a) {
 }
 uint32_t j40hip_alf_launch(j40hip_alf *a, j40hip_aframe *const *frames, int n, hipStream_t s) {
 	if (!a || n <= 0 || hipSetDevice(a->device) != hipSuccess) return ERR_GPU;
-	size_t ntasks = 0;
-	for (int i = 0; i < n; ++i) ntasks += frames[i]->lf_tasks.size();
-	const size_t bytes = sizeof(DevLfTask) * ntasks + 64;
+	const size_t bytes = sizeof(DevLfLaneSet) * (size_t) n + 64;
 	if (!a->host.reserve(bytes, 0)) return ERR_MEM;
 	if (bytes > a->dev_cap) {
 		if (a->dev) (void) hipFree(a->dev);
@@ -485,13 +493,12 @@ uint32_t j40hip_alf_launch(j40hip_alf *a, j40hip_aframe *const *frames, int n, h
 		if (hipMalloc(&a->dev, bytes * 2) != hipSuccess) { (void) hipGetLastError(); return ERR_MEM; }
 		a->dev_cap = bytes * 2;
 	}
-	DevLfTask *h = (DevLfTask *) a->host.ptr; size_t k = 0;
-	for (int i = 0; i < n; ++i) for (const DevLfTask &t : frames[i]->lf_tasks) h[k++] = t;
+	DevLfLaneSet *h = (DevLfLaneSet *) a->host.ptr;
+	int32_t max_tasks = 0; uint32_t lds = 0;
+	for (int i = 0; i < n; ++i) { h[i] = frames[i]->lf_set; max_tasks = std::max(max_tasks, h[i].ntasks); lds = std::max(lds, h[i].lds_bytes); }
 	for (int i = 0; i < n; ++i) if (hipStreamWaitEvent(s, frames[i]->uploaded, 0) != hipSuccess) return ERR_GPU;
-	if (ntasks) {
-		if (hipMemcpyAsync(a->dev, h, sizeof(DevLfTask) * ntasks, hipMemcpyHostToDevice, s) != hipSuccess) return ERR_GPU;
-		launch_lf_groups((const DevLfTask *) a->dev, (int32_t) ntasks, s);
-	}
+	if (hipMemcpyAsync(a->dev, h, sizeof(DevLfLaneSet) * (size_t) n, hipMemcpyHostToDevice, s) != hipSuccess) return ERR_GPU;
+	launch_lf_lanes((const DevLfLaneSet *) a->dev, n, max_tasks, lds + 64, s);
 	if (hipEventRecord(a->done, s) != hipSuccess || hipGetLastError() != hipSuccess) return ERR_GPU;
 	// the frames' batch must wait for this launch, not only for their copies: from now on `uploaded` stands for both
 	for (int i = 0; i < n; ++i) if (hipEventRecord(frames[i]->uploaded, s) != hipSuccess) return ERR_GPU;

@@ -9,6 +9,7 @@
 // encoders write); any other reports ERR_LFFB and the host decodes that section itself.
 #include <hip/hip_runtime.h>
 #include "modular_coop_dev.h"
+#include "lf_lanes_dev.h"
 #include "kernels.h"
 
 namespace j40hip {
@@ -52,6 +53,51 @@ __global__ void __launch_bounds__(64) k_lf_groups(const DevLfTask *tasks) {
 		if (!status) status = coop_finish_code(b, state, lane);
 	}
 	if (lane == 0) { result->status = status; result->nb_varblocks = nb_varblocks; }
+}
+
+// One LfGroup section per LANE, one frame (up to 64 of its sections) per wavefront: see lf_lanes_dev.h. blockIdx.x = frame,
+// blockIdx.y = which 64 of its sections. The frame's tree and code tables are staged in LDS.
+__global__ void __launch_bounds__(64) k_lf_lanes(const DevLfLaneSet *sets) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t lfl_lds[];
+	const J40_GLOBAL DevLfLaneSet &set = ((const J40_GLOBAL DevLfLaneSet *) sets)[blockIdx.x];
+	const int32_t lane = threadIdx.x, first = (int32_t) blockIdx.y * 64;
+	const int32_t ntasks = set.ntasks, num_nodes = set.num_nodes, num_dist = set.num_dist, num_clusters = set.num_clusters, log_alpha = set.log_alpha;
+	if (first >= ntasks) return;
+	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+	J40_LDS uint8_t *lds = (J40_LDS uint8_t *) lfl_lds;
+	J40_LDS int32_t *l_tree = (J40_LDS int32_t *) lds;
+	J40_LDS uint8_t *l_map = lds + align16(16u * (uint32_t) num_nodes);
+	J40_LDS uint32_t *l_cfg = (J40_LDS uint32_t *) (l_map + align16((uint32_t) num_dist));
+	J40_LDS uint64_t *l_alias = (J40_LDS uint64_t *) ((J40_LDS uint8_t *) l_cfg + align16(4u * (uint32_t) num_clusters));
+	{
+		const J40_GLOBAL int32_t *tsrc = (const J40_GLOBAL int32_t *) set.tree;
+		for (int32_t i = lane; i < 4 * num_nodes; i += 64) l_tree[i] = tsrc[i];
+		const J40_GLOBAL uint8_t *msrc = (const J40_GLOBAL uint8_t *) set.ctx_map;
+		for (int32_t i = lane; i < num_dist; i += 64) l_map[i] = msrc[i];
+		const J40_GLOBAL uint32_t *csrc = (const J40_GLOBAL uint32_t *) set.cluster_cfg;
+		for (int32_t i = lane; i < num_clusters; i += 64) l_cfg[i] = csrc[i];
+		const J40_GLOBAL uint64_t *asrc = (const J40_GLOBAL uint64_t *) set.alias;
+		for (int32_t i = lane; i < (num_clusters << log_alpha); i += 64) l_alias[i] = asrc[i];
+	}
+	__syncthreads();
+	LaneTables T;
+	T.ctx_map = l_map; T.cluster_cfg = l_cfg; T.alias = l_alias; T.nnz_ctx2 = nullptr; T.freq_ctx2 = nullptr; T.dct_info = nullptr; T.log_alpha = log_alpha; T.log_bucket = 12 - log_alpha;
+	LfLaneFrame F;
+	F.tree = (const J40_LDS DevTreeNode *) l_tree; F.uses = set.uses;
+	const bool active = first + lane < ntasks;
+	const J40_GLOBAL DevLfTask &t = ((const J40_GLOBAL DevLfTask *) set.tasks)[active ? first + lane : first];
+	LfLane L;
+	lf_lane_init(L, t);
+	if (!active) { L.chan = 7; L.setup = false; }
+	while (__builtin_amdgcn_ballot_w64(!lf_lane_done(L))) lf_lane_step(L, t, F, T);
+	if (active) { J40_GLOBAL DevLfResult *r = (J40_GLOBAL DevLfResult *) t.result; r->status = L.err; r->nb_varblocks = L.nb_varblocks; }
+}
+
+void launch_lf_lanes(const DevLfLaneSet *sets, int32_t num_sets, int32_t max_tasks, uint32_t lds_bytes, hipStream_t stream) {
+	if (num_sets <= 0 || max_tasks <= 0) return;
+	static bool configured = false;
+	if (!configured) { (void) hipFuncSetAttribute((const void *) k_lf_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); configured = true; }
+	hipLaunchKernelGGL(k_lf_lanes, dim3((unsigned) num_sets, (unsigned) ((max_tasks + 63) / 64)), dim3(64), lds_bytes, stream, sets);
 }
 
 void launch_lf_groups(const DevLfTask *tasks, int32_t num_tasks, hipStream_t stream) {

@@ -25,6 +25,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -167,9 +168,11 @@ void worker_main(j40hip_pipeline *p) {
 	int prio_low = 0, prio_high = 0;
 	(void) hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
 	if (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio_high) != hipSuccess) { (void) hipGetLastError(); if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { ++p->worker_errors; return; } }
+	double wait_ms = 0, post_ms = 0, busy_ms = 0; int64_t nframes = 0;   // (J40HIP_ASYNC_TIMING)
 	for (;;) {
 		Job *j = nullptr;
 		bool lf_dev = p->lf_mode == 1;
+		const double tw0 = now_ms();
 		{
 			std::unique_lock<std::mutex> lock(p->m);
 			// back-pressure: prepared frames hold their working set in HBM until their batch is done
@@ -180,6 +183,7 @@ void worker_main(j40hip_pipeline *p) {
 			if (p->lf_mode == 0 && p->lf_credits >= 1.0) { lf_dev = true; p->lf_credits -= 1.0; }
 		}
 		const double t0 = now_ms();
+		wait_ms += t0 - tw0;
 		j->af = j40hip_aframe_prepare(j->buf, j->size, p->device, stream, lf_dev ? 1 : 0);
 		const double t1 = now_ms();
 		bool single = j->af == nullptr;
@@ -208,7 +212,10 @@ void worker_main(j40hip_pipeline *p) {
 			(on_dev ? p->lf_pending : p->ready).push_back(j);
 			p->cv_ready.notify_all();
 		}
+		lock.unlock();
+		post_ms += now_ms() - t2; busy_ms += t2 - t0; ++nframes;
 	}
+	if (getenv("J40HIP_ASYNC_TIMING") && nframes) fprintf(stderr, "[j40hip worker] %lld frames, ms per frame: waiting for a job %.2f, working %.2f, handing over %.2f\n", (long long) nframes, wait_ms / (double) nframes, busy_ms / (double) nframes, post_ms / (double) nframes);
 	(void) hipStreamSynchronize(stream);
 	j40hip_astage_release();
 	j40hip_thread_release();

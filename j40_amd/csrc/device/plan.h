@@ -307,6 +307,17 @@ struct DevLfTask {
 	uint32_t info_capacity;
 	DevLfResult *result;
 };
+// the LfGroup sections of one frame for k_lf_lanes (lf_lanes_dev.h: one section per lane): the tasks, and the frame's global MA tree
+// and code spec in the lane decoders' table format (DevCodeSpec::lane_cfg_off)
+struct DevLfLaneSet {
+	const DevLfTask *tasks; int32_t ntasks;
+	const DevTreeNode *tree; int32_t num_nodes;
+	const uint8_t *ctx_map; int32_t num_dist;         // context -> cluster
+	const uint32_t *cluster_cfg; int32_t num_clusters;
+	const uint64_t *alias; int32_t log_alpha;
+	uint32_t uses;                                      // bit 0: the tree looks at NE, 1: NEE, 2: NN
+	uint32_t lds_bytes;                                 // what staging the tables takes
+};
 enum { ERR_LFFB = ('l' << 24) | ('f' << 16) | ('f' << 8) | 'b' };   // not an error of the stream: the second Modular header is not the plain one the device handles; the host decodes this section
 
 // ---- the LF-dependent half of a VarDCT frame's plan, built on the device (plan_dev.h, plan_kernels.hip) ----

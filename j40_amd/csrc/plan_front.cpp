@@ -63,7 +63,41 @@ void build_static_tables(const Frame &fr, StaticTables *st) {
 	}
 }
 
-uint32_t build_front_plan(const Frame &fr, const StaticTables &st, size_t cs_size, const std::vector<int32_t> &extra_prec, bool want_lf_coop, FrontPlan *fp) {
+// the global MA tree and code spec as k_lf_lanes wants them; false when it cannot take them
+static bool build_lf_lanes(const Frame &fr, FrontPlan *fp) {
+	const CodeSpec &spec = fr.global_codespec;
+	if (fr.global_tree.empty() || fr.global_tree.size() > 1024 || spec.use_prefix_code || spec.lz77_enabled || spec.num_clusters < 1 || spec.num_clusters > 256) return false;
+	if (spec.log_alpha_size < 5 || spec.log_alpha_size > 8) return false;
+	for (const Cluster &c : spec.clusters) if (c.alias.size() != ((size_t) 1 << spec.log_alpha_size)) return false;
+	fp->lf_uses = 0;
+	fp->lf_tree.clear();
+	for (const TreeNode &n : fr.global_tree) {
+		if (n.prop >= 0) {
+			if (n.prop > 14) return false;   // the weighted predictor's error, previous channels
+			if (n.prop == 12) fp->lf_uses |= 1u;
+			if (n.prop == 13) fp->lf_uses |= 4u;
+		} else {
+			const int32_t pred = -1 - n.prop;
+			if (pred == 6 || pred > 13) return false;
+			if (n.value < 0 || n.value >= spec.num_dist || (size_t) n.value >= spec.cluster_map.size()) return false;
+			if (pred == 7 || pred == 12) fp->lf_uses |= 1u;
+			if (pred == 13) fp->lf_uses |= 1u | 2u | 4u;
+		}
+		fp->lf_tree.push_back(DevTreeNode{n.prop, n.value, n.a, n.b});
+	}
+	fp->lf_ctx_map.assign(spec.cluster_map.begin(), spec.cluster_map.begin() + spec.num_dist);
+	fp->lf_cfg.clear(); fp->lf_alias.clear();
+	for (const Cluster &c : spec.clusters) {
+		fp->lf_cfg.push_back(c.cfg.packed() | ((uint32_t) std::min(c.cfg.max_token, 0xfffff) << 12));   // (tokens are < 256: clamping max_token keeps `token > max_token` intact)
+		fp->lf_alias.insert(fp->lf_alias.end(), c.alias.begin(), c.alias.end());
+	}
+	fp->lf_log_alpha = spec.log_alpha_size;
+	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+	fp->lf_lds_bytes = align16(16u * (uint32_t) fp->lf_tree.size()) + align16((uint32_t) spec.num_dist) + align16(4u * (uint32_t) spec.num_clusters) + 8u * ((uint32_t) spec.num_clusters << spec.log_alpha_size);
+	return fp->lf_lds_bytes <= 60u * 1024u;
+}
+
+uint32_t build_front_plan(const Frame &fr, const StaticTables &st, size_t cs_size, const std::vector<int32_t> &extra_prec, bool want_lf_device, FrontPlan *fp) {
 	// what build_vardct_plan refuses, plus what the device-side plan build leaves to the host path: a single section (the LfGroup
 	// is then not a section of its own), Modular sub-images behind the coefficients (extra channels), groups other than 256 x 256
 	if (cs_size + 16 >= ((size_t) 1 << 29)) return ERR_TODO;
@@ -114,7 +148,7 @@ uint32_t build_front_plan(const Frame &fr, const StaticTables &st, size_t cs_siz
 	pb.lfidx_size = df.lfidx_size;
 	pb.mult_base = df.mult_base; pb.base_corr_x = fr.base_corr_x; pb.base_corr_b = fr.base_corr_b; pb.inv_colour_factor = fr.inv_colour_factor;
 	pb.block_ctx_map_off = fp->block_ctx_map_off;
-	fp->lf_coop = want_lf_coop && build_lf_coop(fr, &fp->lf_tree, &fp->lf_alias, &fp->lf_log_alpha);
+	fp->lf_device = want_lf_device && build_lf_lanes(fr, fp);
 	return 0;
 }
 

@@ -43,15 +43,18 @@ struct FrontPlan {
 	uint32_t lz_window_size = 0;
 	DevPlanBuild build;                      // constants only; the runtime fills in the pointers
 	bool lf_smooth = false; float inv_m_lf[3] = {0.0f, 0.0f, 0.0f};
-	// the global MA tree and code spec laid out for k_lf_groups; lf_coop = false: the kernel cannot take them (the host decodes the LfGroups)
-	bool lf_coop = false; DevCoopTree lf_tree; std::vector<uint64_t> lf_alias; int32_t lf_log_alpha = 0;
+	// the global MA tree and code spec in the tables of k_lf_lanes (device/lf_lanes_dev.h); lf_device = false: the kernel cannot take
+	// them (prefix codes, LZ77, weighted predictor, previous-channel properties, tables beyond its LDS budget): the host decodes the LfGroups
+	bool lf_device = false;
+	std::vector<DevTreeNode> lf_tree; std::vector<uint8_t> lf_ctx_map; std::vector<uint32_t> lf_cfg; std::vector<uint64_t> lf_alias;
+	int32_t lf_log_alpha = 0; uint32_t lf_uses = 0, lf_lds_bytes = 0;
 	void reset() {
 		pool_u8.clear(); pool_i32.clear(); pool_u64.clear(); clusters.clear(); coeff_specs.clear(); lf_groups.clear(); sections.clear(); ev_range.clear();
-		lf_section_off.clear(); lf_alias.clear(); block_ctx_map_off = 0; ev_capacity = 0; cells = c64s = 0; max_lf_cells = 0; lz_window_size = 0; lf_smooth = lf_coop = false;
+		lf_section_off.clear(); lf_alias.clear(); lf_tree.clear(); lf_ctx_map.clear(); lf_cfg.clear(); block_ctx_map_off = 0; ev_capacity = 0; cells = c64s = 0; max_lf_cells = 0; lz_window_size = 0; lf_smooth = lf_device = false;
 	}
 };
 
 // returns 0, or "TODO" for frames the pipeline's device-side plan build does not take (the caller then uses the host path)
-uint32_t build_front_plan(const Frame &fr, const StaticTables &st, size_t cs_size, const std::vector<int32_t> &extra_prec, bool want_lf_coop, FrontPlan *out);
+uint32_t build_front_plan(const Frame &fr, const StaticTables &st, size_t cs_size, const std::vector<int32_t> &extra_prec, bool want_lf_device, FrontPlan *out);
 
 } // namespace j40hip

@@ -688,3 +688,63 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_front_timing(c
 	for (int i = 0; i < 4; ++i) out_ms[i] /= iters;
 	return 0;
 }
+
+// ---- the lane decoder of the LfGroup sections (device/lf_lanes_dev.h) on the CPU, against the host decoder ----
+#include "../../j40_amd/csrc/device/lf_lanes_dev.h"
+
+// Every LfGroup section of the stream through lf_lane_step (one lane after the other, tables laid out as k_lf_lanes stages them)
+// and through read_lf_group_raw: same status, same planes. Returns 0 when all agree, -1 when the frame is not one the lane decoder
+// takes, else 10 * section + what differed (1 status, 2 varblock count, 3-5 LF planes, 6 x-from-y, 7 b-from-y, 8 varblock info).
+// *sections = how many were compared, *failed = how many of them ended in an error (on both sides).
+extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_lanes_check(const uint8_t *buf, size_t size, int32_t *sections, int32_t *failed) {
+	const uint8_t *cs; size_t cs_size; std::vector<uint8_t> storage;
+	Frame fr;
+	std::vector<LfDeviceTask> tasks; std::vector<int32_t> extra_prec; bool plain = true;
+	if (sections) *sections = 0;
+	if (failed) *failed = 0;
+	try {
+		extract_codestream(buf, size, &cs, &cs_size, &storage);
+		if (!parse_frame_front(cs, cs_size, &fr, &tasks, &extra_prec, &plain)) return -1;
+	} catch (const DecodeError &) { return -1; }
+	if (!plain) return -1;
+	StaticTables st;
+	build_static_tables(fr, &st);
+	FrontPlan fp;
+	if (build_front_plan(fr, st, cs_size, extra_prec, true, &fp) || !fp.lf_device) return -1;
+	std::vector<uint8_t> padded(cs, cs + cs_size);
+	padded.resize(cs_size + 32, 0);
+	LaneTables T;
+	memset(&T, 0, sizeof T);
+	T.ctx_map = fp.lf_ctx_map.data(); T.cluster_cfg = fp.lf_cfg.data(); T.alias = fp.lf_alias.data(); T.log_alpha = fp.lf_log_alpha; T.log_bucket = 12 - fp.lf_log_alpha;
+	LfLaneFrame F;
+	F.tree = fp.lf_tree.data(); F.uses = fp.lf_uses;
+	for (size_t g = 0; g < fr.lf_groups.size(); ++g) {
+		const LfGroup &gg = fr.lf_groups[g];
+		const size_t cells = (size_t) gg.width8 * (size_t) gg.height8, c64 = (size_t) gg.width64 * (size_t) gg.height64;
+		std::vector<int16_t> lf[3], xfy(c64 + 1), bfy(c64 + 1), info(2 * cells + 2), sharp(cells + 1);
+		for (int c = 0; c < 3; ++c) lf[c].assign(cells + 1, 0);
+		DevLfResult res = {0, 0};
+		DevLfTask t;
+		memset(&t, 0, sizeof t);
+		t.codestream = padded.data(); t.byte_off = (uint32_t) tasks[g].byte_off; t.size = (uint32_t) tasks[g].size; t.bit_off = tasks[g].bit_off;
+		t.w8 = gg.width8; t.h8 = gg.height8; t.w64 = gg.width64; t.h64 = gg.height64; t.sidx0 = tasks[g].sidx0; t.sidx2 = tasks[g].sidx2; t.nbvb_bits = tasks[g].nbvb_bits;
+		for (int c = 0; c < 3; ++c) t.lf[c] = lf[c].data();
+		t.xfromy = xfy.data(); t.bfromy = bfy.data(); t.info = info.data(); t.sharp = sharp.data(); t.info_capacity = (uint32_t) (2 * cells); t.result = &res;
+		LfLane L;
+		lf_lane_init(L, t);
+		while (!lf_lane_done(L)) lf_lane_step(L, t, F, T);
+		uint32_t host_err = 0;
+		LfRaw raw;
+		try { BitReader sr(cs + fr.toc.lf_groups[g].offset, fr.toc.lf_groups[g].size); read_lf_group_raw(sr, fr, gg, &raw); } catch (const DecodeError &e) { host_err = e.code; }
+		if (sections) ++*sections;
+		if (L.err == (uint32_t) ERR_LFFB) continue;   // (the host decodes such a section: nothing to compare)
+		if (L.err != host_err) return (int32_t) (10 * g + 1);
+		if (host_err) { if (failed) ++*failed; continue; }
+		if (L.nb_varblocks != raw.nb_varblocks) return (int32_t) (10 * g + 2);
+		for (int c = 0; c < 3; ++c) if (memcmp(lf[c].data(), raw.lf[c].data(), cells * 2) != 0) return (int32_t) (10 * g + 3 + c);
+		if (memcmp(xfy.data(), raw.xfromy.data(), c64 * 2) != 0) return (int32_t) (10 * g + 6);
+		if (memcmp(bfy.data(), raw.bfromy.data(), c64 * 2) != 0) return (int32_t) (10 * g + 7);
+		if (memcmp(info.data(), raw.info.data(), raw.info.size() * 2) != 0) return (int32_t) (10 * g + 8);
+	}
+	return 0;
+}

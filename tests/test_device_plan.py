@@ -60,3 +60,42 @@ def test_damaged_lf_sections_get_the_host_parse_verdict(sim):
         assert rc in (0, -1), (rc, err)
         outcomes[err] = outcomes.get(err, 0) + (rc == 0)
     assert len(outcomes) >= 3 and sum(outcomes.values()) >= 40, outcomes
+
+
+@pytest.fixture(scope="module")
+def lanes(built):
+    S = C.CDLL(os.path.join(ROOT, "build", "libhostsim.so"))
+    S.hostsim_lf_lanes_check.restype = C.c_int32
+    S.hostsim_lf_lanes_check.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    return S
+
+
+def lanes_check(S, data):
+    buf = C.create_string_buffer(data, len(data))
+    n, bad = C.c_int32(), C.c_int32()
+    return S.hostsim_lf_lanes_check(buf, len(data), C.byref(n), C.byref(bad)), n.value, bad.value
+
+
+@pytest.mark.parametrize("mode,w,h,seed,opts", CASES)
+def test_lf_lane_decoder_equals_the_host_decoder(lanes, mode, w, h, seed, opts):
+    """device/lf_lanes_dev.h (one LfGroup section per wavefront lane: k_lf_lanes) compiled for the CPU, every section of every case
+    against frame.cpp's read_lf_group_raw (whose products tests/test_host.py pins against the reference's j40__lf_group): LF
+    integers, chroma-from-luma maps, varblock count and the two rows of the varblock-info channel"""
+    rc, n, bad = lanes_check(lanes, synth(mode, w, h, seed, **opts))
+    if opts.get("alpha"):
+        assert rc == -1          # extra channels: the front plan leaves the frame to the host path
+    else:
+        assert rc == 0 and n >= 1 and bad == 0, (rc, n, bad)
+
+
+def test_lf_lane_decoder_fails_like_the_host_decoder(lanes):
+    data = synth("vardct", 2600, 2100, 41)
+    rng = np.random.default_rng(12)
+    failed = 0
+    for _ in range(80):
+        m = bytearray(data)
+        m[int(rng.integers(150, len(m) // 6))] ^= 1 << int(rng.integers(0, 8))
+        rc, n, bad = lanes_check(lanes, bytes(m))
+        assert rc in (0, -1), rc
+        failed += bad
+    assert failed >= 20
