@@ -117,7 +117,32 @@ struct j40hip_aframe {
 	size_t cells = 0;
 	bool sparse = true;
 	hipEvent_t uploaded = nullptr;
+	struct WorkLayout { size_t size = 0, stride = 0, coeffs = 0, blk = 0, nz = 0, status = 0, lz = 0, lfs = 0, recs = 0, gcnt = 0, gbs = 0, ccnt = 0, gb = 0, vbs = 0, llf[3] = {0, 0, 0}; uint32_t lz_window_size = 0; } wl;
 };
+
+// the frame's working set: acquired when its batch is launched, its per-block table cleared on the batch's stream
+static uint32_t aframe_bind_work(j40hip_aframe *af, hipStream_t s) {
+	if (af->work_block) return 0;
+	bool dummy = false;
+	af->work_block = cache_acquire(af->device, af->wl.size, &af->work_block_bytes, &dummy);
+	if (!af->work_block) return ERR_MEM;
+	uint8_t *wb = (uint8_t *) af->work_block;
+	const j40hip_aframe::WorkLayout &wl = af->wl;
+	DevPlan &plan = af->plan;
+	if (af->sparse) { plan.events = (CoeffEvent *) (wb + wl.coeffs); plan.block_events = (uint32_t *) (wb + wl.blk); }
+	else for (int c = 0; c < 3; ++c) plan.coeffs[c] = (float *) (wb + wl.coeffs) + (size_t) c * wl.stride;
+	plan.coeff_stride = (uint32_t) wl.stride;
+	plan.nonzeros = (int8_t *) (wb + wl.nz); plan.status = (uint32_t *) (wb + wl.status);
+	plan.lz_window_size = wl.lz_window_size; plan.lz_window = wl.lz_window_size ? (int32_t *) (wb + wl.lz) : nullptr;
+	plan.group_blocks = (const DevGroupBlock *) (wb + wl.gb); plan.group_block_start = (const uint32_t *) (wb + wl.gbs);
+	for (int c = 0; c < 3; ++c) plan.llf[c] = (const float *) (wb + wl.llf[c]);
+	DevPlanBuild &bd = af->build;
+	bd.vb_recs = (DevVbRec *) (wb + wl.recs); bd.group_count = (uint32_t *) (wb + wl.gcnt); bd.group_block_start = (uint32_t *) (wb + wl.gbs); bd.class_count = (uint32_t *) (wb + wl.ccnt);
+	bd.group_blocks = (DevGroupBlock *) (wb + wl.gb); bd.vb_sorted = (DevVarblock *) (wb + wl.vbs); bd.lf_scratch = (float *) (wb + wl.lfs);
+	// recycled memory: no entry of the per-block table may point outside the event list (a section that fails leaves entries unwritten)
+	if (af->sparse && hipMemsetAsync(plan.block_events, 0, 16 * af->cells, s) != hipSuccess) return ERR_GPU;
+	return 0;
+}
 
 void j40hip_aframe_free(j40hip_aframe *f) {
 	if (!f) return;
@@ -165,17 +190,15 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	const size_t o_cl = L.take(fp.clusters.size() * sizeof(DevCluster)), o_spec = L.take(fp.coeff_specs.size() * sizeof(DevCodeSpec)), o_frame = L.take(sizeof(DevFrame));
 	const size_t o_lfg = L.take(ngg * sizeof(DevLfGroup)), o_sec = L.take(fp.sections.size() * sizeof(DevSection)), o_evr = L.take(fp.ev_range.size() * 4);
 	const size_t o_lso = L.take(ngg * 4), o_slots = L.take(ngg * sizeof(DevLfSlot));
-	const size_t o_tree = dev_lf ? L.take(fp.lf_tree.size() * sizeof(DevTreeNode)) : 0, o_alias = dev_lf ? L.take(fp.lf_alias.size() * 8) : 0, o_lfmap = dev_lf ? L.take(fp.lf_ctx_map.size()) : 0,
-		o_lfcfg = dev_lf ? L.take(fp.lf_cfg.size() * 4) : 0, o_tasks = dev_lf ? L.take(ngg * sizeof(DevLfTask)) : 0;
+	const size_t o_tree = L.take(fp.lf_tree.size() * sizeof(DevTreeNode)), o_alias = L.take(fp.lf_alias.size() * 8), o_lfmap = L.take(fp.lf_ctx_map.size()),
+		o_lfcfg = L.take(fp.lf_cfg.size() * 4), o_tasks = L.take(ngg * sizeof(DevLfTask));   // (empty without the device decoder's tables)
 	size_t o_raw[3], o_xfy, o_bfy, o_info, copy_bytes = L.size;
 	for (int c = 0; c < 3; ++c) o_raw[c] = L.take(cells * 2 + 64);
 	o_xfy = L.take(c64s * 2); o_bfy = L.take(c64s * 2); o_info = L.take(cells * 4 + 64);
 	if (!dev_lf) copy_bytes = L.size;
-	const size_t o_sharp = dev_lf ? L.take(cells * 2 + 64) : 0;
-	const size_t o_recs = L.take(cells * sizeof(DevVbRec)), o_gcnt = L.take((size_t) num_groups * 4), o_gbs = L.take(((size_t) num_groups + 1) * 4), o_ccnt = L.take(ngg * 28 * 4);
-	const size_t o_gb = L.take(cells * sizeof(DevGroupBlock)), o_vbs = L.take(cells * sizeof(DevVarblock));
-	size_t o_llf[3];
-	for (int c = 0; c < 3; ++c) o_llf[c] = L.take(cells * 4);
+	const size_t o_sharp = L.take(cells * 2 + 64);   // (device decoder only; reserved either way: blocks of one size recycle through the cache whoever decodes the streams)
+	// (everything the plan build and the decode produce lives in the working set, which a frame gets when its batch is launched:
+	// a frame waiting for its LfGroup streams holds 11 MB, not 210)
 
 	AStage *sgp = astage_acquire(copy_bytes + 64);
 	if (!sgp) return nullptr;
@@ -244,49 +267,45 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	}
 
 	const double tp5 = prof_now();
-	// ---- the working set ----
-	Layout W;
-	const size_t stride = (cells * 64 + 63) & ~(size_t) 63;
-	const size_t coeff_bytes = af->sparse ? sizeof(CoeffEvent) * fp.ev_capacity : sizeof(float) * 3 * stride;
-	const size_t w_coeffs = W.take(coeff_bytes), w_blk = af->sparse ? W.take(16 * cells) : 0, w_nz = W.take((size_t) num_groups * 32 * 32 * 3), w_status = W.take(4 * fp.sections.size());
-	const size_t w_lz = fp.lz_window_size ? W.take(4 * (size_t) num_groups * fp.lz_window_size) : 0, w_lfs = W.take(4 * 3 * cells);
-	af->work_block = cache_acquire(device, W.size, &af->work_block_bytes, &dummy);
-	if (!af->work_block) return nullptr;
-	uint8_t *wb = (uint8_t *) af->work_block;
+	// ---- the working set: laid out now, acquired at the batch's launch (aframe_bind_work) ----
+	{
+		Layout W;
+		j40hip_aframe::WorkLayout &wl = af->wl;
+		wl.stride = (cells * 64 + 63) & ~(size_t) 63;
+		const size_t coeff_bytes = af->sparse ? sizeof(CoeffEvent) * fp.ev_capacity : sizeof(float) * 3 * wl.stride;
+		wl.coeffs = W.take(coeff_bytes); wl.blk = af->sparse ? W.take(16 * cells) : 0; wl.nz = W.take((size_t) num_groups * 32 * 32 * 3); wl.status = W.take(4 * fp.sections.size());
+		wl.lz = fp.lz_window_size ? W.take(4 * (size_t) num_groups * fp.lz_window_size) : 0; wl.lfs = W.take(4 * 3 * cells);
+		wl.recs = W.take(cells * sizeof(DevVbRec)); wl.gcnt = W.take((size_t) num_groups * 4); wl.gbs = W.take(((size_t) num_groups + 1) * 4); wl.ccnt = W.take(ngg * 28 * 4);
+		wl.gb = W.take(cells * sizeof(DevGroupBlock)); wl.vbs = W.take(cells * sizeof(DevVarblock));
+		for (int c = 0; c < 3; ++c) wl.llf[c] = W.take(cells * 4);
+		wl.size = W.size; wl.lz_window_size = fp.lz_window_size;
+	}
 
 	DevPlan &plan = af->plan;
 	memset(&plan, 0, sizeof plan);
 	plan.frame = (const DevFrame *) (pb + o_frame); plan.codestream = pb + o_cs; plan.pool_u8 = pb + o_u8; plan.pool_u16 = af->st->d_u16; plan.pool_i32 = (const int32_t *) (pb + o_i32);
 	plan.pool_u64 = (const uint64_t *) (pb + o_u64); plan.pool_f32 = af->st->d_f32; plan.clusters = (const DevCluster *) (pb + o_cl); plan.coeff_specs = (const DevCodeSpec *) (pb + o_spec);
 	plan.lf_groups = (const DevLfGroup *) (pb + o_lfg); plan.sections = (const DevSection *) (pb + o_sec);
-	plan.group_blocks = (const DevGroupBlock *) (pb + o_gb); plan.group_block_start = (const uint32_t *) (pb + o_gbs); plan.block_ctx_map_off = fp.block_ctx_map_off;
-	for (int c = 0; c < 3; ++c) { plan.llf[c] = (const float *) (pb + o_llf[c]); plan.lfraw[c] = (const int16_t *) (pb + o_raw[c]); }
+	plan.block_ctx_map_off = fp.block_ctx_map_off;
+	for (int c = 0; c < 3; ++c) plan.lfraw[c] = (const int16_t *) (pb + o_raw[c]);
 	plan.xfromy = (const int16_t *) (pb + o_xfy); plan.bfromy = (const int16_t *) (pb + o_bfy);
 	plan.ev_range = (const uint32_t *) (pb + o_evr);
-	if (af->sparse) { plan.events = (CoeffEvent *) (wb + w_coeffs); plan.block_events = (uint32_t *) (wb + w_blk); }
-	else for (int c = 0; c < 3; ++c) plan.coeffs[c] = (float *) (wb + w_coeffs) + (size_t) c * stride;
-	plan.coeff_stride = (uint32_t) stride;
-	plan.nonzeros = (int8_t *) (wb + w_nz); plan.status = (uint32_t *) (wb + w_status);
-	plan.lz_window_size = fp.lz_window_size; plan.lz_window = fp.lz_window_size ? (int32_t *) (wb + w_lz) : nullptr;
 
 	DevPlanBuild &bd = af->build;
 	bd = fp.build;
 	bd.pool_u8 = plan.pool_u8; bd.lf_groups = (DevLfGroup *) (pb + o_lfg); bd.lf_slots = (DevLfSlot *) (pb + o_slots);
 	for (int c = 0; c < 3; ++c) bd.lfraw[c] = plan.lfraw[c];
-	bd.xfromy = plan.xfromy; bd.bfromy = plan.bfromy; bd.vbinfo = (const int16_t *) (pb + o_info); bd.vb_recs = (DevVbRec *) (pb + o_recs);
-	bd.group_count = (uint32_t *) (pb + o_gcnt); bd.group_block_start = (uint32_t *) (pb + o_gbs); bd.class_count = (uint32_t *) (pb + o_ccnt);
-	bd.group_blocks = (DevGroupBlock *) (pb + o_gb); bd.vb_sorted = (DevVarblock *) (pb + o_vbs); bd.lf_section_off = (const uint32_t *) (pb + o_lso);
-	bd.lf_scratch = (float *) (wb + w_lfs); bd.lf_smooth = fp.lf_smooth ? 1 : 0; bd.cells = (uint32_t) cells;
+	bd.xfromy = plan.xfromy; bd.bfromy = plan.bfromy; bd.vbinfo = (const int16_t *) (pb + o_info);
+	bd.lf_section_off = (const uint32_t *) (pb + o_lso);
+	bd.lf_smooth = fp.lf_smooth ? 1 : 0; bd.cells = (uint32_t) cells;
 	for (int c = 0; c < 3; ++c) bd.inv_m_lf[c] = fp.inv_m_lf[c];
-	// (class_start and verdict belong to the batch: j40hip_abatch_launch)
+	// (the working set's pointers: aframe_bind_work; class_start and verdict belong to the batch: j40hip_abatch_launch)
 
 	const double tp6 = prof_now();
 	if (hipEventCreateWithFlags(&af->uploaded, hipEventDisableTiming) != hipSuccess) { af->uploaded = nullptr; (void) hipGetLastError(); return nullptr; }
 	if (hipMemcpyAsync(pb, stg, copy_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return nullptr;
 	bool ok = hipEventRecord(sg.done, stream) == hipSuccess;
 	sg.pending = ok;
-	// recycled memory: no entry of the per-block table may point outside the event list (a section that fails leaves entries unwritten)
-	ok = ok && (!af->sparse || hipMemsetAsync(plan.block_events, 0, 16 * cells, stream) == hipSuccess);
 	ok = ok && hipEventRecord(af->uploaded, stream) == hipSuccess;
 	if (!ok) { (void) hipStreamSynchronize(stream); (void) hipGetLastError(); return nullptr; }   // (nothing may be in flight on blocks that go back to the cache)
 	{ const double tp7 = prof_now(); t_prof[0] += tp1 - tp0; t_prof[1] += tp2 - tp1; t_prof[2] += tp3 - tp2; t_prof[3] += tp4 - tp3; t_prof[4] += tp5 - tp4; t_prof[5] += tp6 - tp5; t_prof[6] += tp7 - tp6; ++t_prof_frames; }
@@ -370,15 +389,19 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 	bool lanes_fast = true, tables_in_lds = true; uint32_t lanes_lds = 0, generic_lds = 0;
 	int32_t total_waves = 0, nlf = 0, max_lf_cells = 0; size_t cells_total = 0, max_frame_cells = 0;
 	for (int i = 0; i < n; ++i) {
-		const j40hip_aframe *f = frames[i];
+		j40hip_aframe *f = frames[i];
 		if (!f || f->device != b->device) return ERR_GPU;
+		if (uint32_t e = aframe_bind_work(f, s)) return e;
 		lanes_fast = lanes_fast && f->hf.lanes_fast; tables_in_lds = tables_in_lds && f->hf.tables_fit_lds; lanes_lds = std::max(lanes_lds, f->hf.lanes_lds_bytes);
 		total_waves += (f->num_groups + 63) / 64; nlf += f->num_lf_groups;
 		max_lf_cells = std::max(max_lf_cells, f->max_lf_cells); cells_total += f->cells; max_frame_cells = std::max(max_frame_cells, f->cells);
 	}
 	if (const char *e = getenv("J40HIP_GENERIC_LANES")) if (atoi(e)) lanes_fast = false;
-	int32_t waves_per_wg = lanes_fast ? (total_waves <= 2 * b->cus ? 1 : total_waves <= 4 * b->cus ? 2 : 4) : 1;
-	if (const char *e = getenv("J40HIP_WAVES_PER_WG")) if (lanes_fast) waves_per_wg = std::max(1, std::min(4, atoi(e)));
+	// (eight wavefronts to a workgroup when the launch fills the machine: one copy of the tables per compute unit instead of two
+	// leaves a third of its LDS to whatever else is running -- another batch's pixel kernels, the LfGroup lane decoder -- which
+	// otherwise displaces one of the two workgroups and sends it into a second round: 46 -> 91 ms)
+	int32_t waves_per_wg = lanes_fast ? (total_waves <= 2 * b->cus ? 1 : total_waves <= 4 * b->cus ? 2 : total_waves <= 6 * b->cus || lanes_lds + 8u * HF_LANE_COLS_BYTES > 150u * 1024u ? 4 : 8) : 1;
+	if (const char *e = getenv("J40HIP_WAVES_PER_WG")) if (lanes_fast) waves_per_wg = std::max(1, std::min(lanes_lds + 8u * HF_LANE_COLS_BYTES > 150u * 1024u ? 4 : 8, atoi(e)));
 	std::vector<HfLaneWork> work;
 	for (int i = 0; i < n; ++i) {
 		for (int32_t g = 0; g < frames[i]->num_groups; g += 64) work.push_back({i, g, std::min(64, frames[i]->num_groups - g), 0});

@@ -216,8 +216,11 @@ template <typename T> __device__ __forceinline__ T load_global_pod(const J40_GLO
 // K1, throughput form, fast path (hf_lanes_dev.h): rANS specs without LZ77 whose packed tables fit in LDS.
 // Same launch geometry as k_hf_entropy_lanes: one wavefront per workgroup, up to 64 groups of one frame per
 // wavefront, any number of frames per launch.
-__global__ void __launch_bounds__(256) k_hf_lanes(const DevPlan *plans, const HfLaneWork *work, uint32_t lds_tables_bytes) {
+__global__ void __launch_bounds__(512) k_hf_lanes(const DevPlan *plans, const HfLaneWork *work, uint32_t lds_tables_bytes) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t hf_lds[];
+	// The launch ends with its slowest wavefront, and a wavefront runs as fast as its SIMD issues its instructions: a background
+	// wavefront on the same SIMD (the LfGroup lane decoder of a later batch) took a third of them (46 -> 75 ms). Highest priority here.
+	__builtin_amdgcn_s_setprio(3);
 	// blockDim.x / 64 wavefronts per workgroup, all on the same frame (the host pads the work list), sharing its tables
 	const int32_t tid = threadIdx.x, lane = tid & 63;
 	const HfLaneWork w = work[blockIdx.x * (blockDim.x >> 6) + (tid >> 6)];

@@ -10,8 +10,8 @@
 // coefficient decoder hf_lanes_dev.h, whose bit window and rANS + hybrid-integer step it shares):
 //   * the frame's global MA tree and code spec sit in LDS; the walk starts below the nodes that test the channel or stream index
 //     (decided once per channel);
-//   * W and WW are carried from sample to sample, the row above slides along in registers (one load per sample; NE / NEE / NN only
-//     for trees and predictors that look at them);
+//   * W and WW are carried from sample to sample, the row above slides along in registers: one load per sample, issued two samples
+//     ahead of its use (NN only for trees and predictors that look at it);
 //   * samples are stored as they are decoded, int16, into the frame-wide planes the plan build reads.
 // Takes rANS code specs without LZ77 and trees without the weighted predictor or previous-channel properties (what VarDCT encoders
 // write for these streams); the host checks that (plan_front.cpp) and decodes the sections itself otherwise.
@@ -175,17 +175,17 @@ J40_DEV void lf_lane_step(LfLane &L, const J40_GLOBAL DevLfTask &t, const LfLane
 	L.a0 = L.a1; L.a1 = L.a2; L.a2 = L.a3; L.a3 = L.a4;
 	++L.x;
 	if (L.x < cw) {
-		if (y > 0 && (F.uses & 2u) && L.x + 2 < cw) L.a4 = L.row[L.x + 2 - cw];
-		else if (y > 0 && !(F.uses & 2u) && (F.uses & 1u) && L.x + 1 < cw) L.a3 = L.row[L.x + 1 - cw];
-		else if (y > 0 && !(F.uses & 3u)) L.a2 = L.row[L.x - cw];
+		// (always two samples ahead of the one that needs it: the load -- an L2 round trip, the row above was written by this lane a
+		// few hundred iterations ago -- has two iterations to arrive; loaded just in time it was a third of every iteration)
+		if (y > 0 && L.x + 2 < cw) L.a4 = L.row[L.x + 2 - cw];
 		return;
 	}
 	// next row: preload the row above (the row just written) at 0 .. 2
 	L.x = 0; ++L.y; L.row += cw; L.pw = L.pww = 0; L.a0 = L.a1 = 0;
 	if (L.y < L.chh) {
 		L.a2 = L.row[-cw];
-		L.a3 = cw > 1 && (F.uses & 3u) ? L.row[1 - cw] : 0;
-		L.a4 = cw > 2 && (F.uses & 2u) ? L.row[2 - cw] : 0;
+		L.a3 = cw > 1 ? L.row[1 - cw] : 0;
+		L.a4 = cw > 2 ? L.row[2 - cw] : 0;
 		return;
 	}
 	++L.chan; L.setup = true;

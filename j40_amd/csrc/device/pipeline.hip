@@ -76,15 +76,16 @@ struct Slot {                     // one batch in flight
 struct j40hip_pipeline {
 	int device = 0, batch_frames = 32, max_in_flight = 2;
 	int lf_mode = 0;                    // LfGroup streams: 0 decided per frame (see above), 1 always the device, 2 always the host threads
-	// mode 0: the device takes a frame's LfGroup streams when there is a credit for it. Credits come from the device's idle time
-	// between two batches (retire): idle ms / what the streams of a frame cost the device, halved -- the LfGroup kernel slows the
-	// other kernels it runs beside. A busy device earns none, and the host threads keep every frame.
-	double lf_credits = 0, lf_cell_ms = 5.5e-6, last_retire_ms = 0;
+	// mode 0: a frame's LfGroup streams go to the device (k_lf_lanes: a lane per section, a handful of wavefronts per launch that the
+	// other kernels do not notice, 0.3 s a launch) while fewer than lf_cap frames are in that stage; beyond that the host thread that
+	// prepares a frame decodes its streams itself. Both decoders then run flat out, and neither waits for the other.
+	int64_t lf_stage = 0, lf_cap = 0;
+	double lf_pending_since = 0;
 	int64_t lf_device_frames = 0, single_frames = 0;
 	std::mutex m;
 	std::condition_variable cv_todo, cv_ready, cv_done;
 	std::deque<Job *> todo, ready, lf_pending;   // lf_pending: prepared, their LfGroup streams still to be launched on the device
-	LfFlight lf_flights[2];
+	LfFlight lf_flights[4];
 	std::vector<uint32_t> results;      // by ticket
 	std::vector<uint8_t> finished;      // by ticket
 	int64_t submitted = 0, completed = 0, resident = 0, parsing = 0, in_flight_frames = 0;
@@ -176,11 +177,12 @@ void worker_main(j40hip_pipeline *p) {
 		{
 			std::unique_lock<std::mutex> lock(p->m);
 			// back-pressure: prepared frames hold their working set in HBM until their batch is done
-			p->cv_todo.wait(lock, [&] { return p->stop || (!p->todo.empty() && p->resident < (int64_t) p->batch_frames * (p->max_in_flight + 1)); });
+			p->cv_todo.wait(lock, [&] { return p->stop || (!p->todo.empty() && p->resident < (int64_t) p->batch_frames * (p->max_in_flight + 1) + p->lf_cap); });
 			if (p->stop) break;
 			j = p->todo.front(); p->todo.pop_front();
 			++p->resident; ++p->parsing;
-			if (p->lf_mode == 0 && p->lf_credits >= 1.0) { lf_dev = true; p->lf_credits -= 1.0; }
+			if (p->lf_mode == 0 && p->lf_stage < p->lf_cap) lf_dev = true;
+			if (lf_dev) ++p->lf_stage;
 		}
 		const double t0 = now_ms();
 		wait_ms += t0 - tw0;
@@ -201,14 +203,14 @@ void worker_main(j40hip_pipeline *p) {
 		--p->parsing;
 		if (single) { p->single_ms += t2 - t0; ++p->single_frames; } else p->parse_ms += t1 - t0;
 		if (!j->af) {
-			if (p->lf_mode == 0 && lf_dev) p->lf_credits += 1.0;
+			if (lf_dev) --p->lf_stage;
 			--p->resident;
 			complete(p, j);
 			p->cv_todo.notify_all(); p->cv_ready.notify_all();
 		} else {
 			const int on_dev = j40hip_aframe_lf_on_device(j->af);
 			p->lf_device_frames += on_dev;
-			if (p->lf_mode == 0 && lf_dev && !on_dev) p->lf_credits += 1.0;   // (its tables are not the device decoder's kind: the credit goes back)
+			if (lf_dev && !on_dev) --p->lf_stage;   // (its tables are not the device decoder's kind)
 			(on_dev ? p->lf_pending : p->ready).push_back(j);
 			p->cv_ready.notify_all();
 		}
@@ -242,19 +244,8 @@ void retire(j40hip_pipeline *p, Slot &slot) {   // GPU thread; waits for the slo
 		if (j->af) { j40hip_aframe_free(j->af); j->af = nullptr; }   // its stream has been waited for
 		if (!j->device_output && j->dev_rgba) release_image(p, j->dev_rgba, j->stride * (size_t) j->height);
 	}
-	int64_t cells = 0;
-	for (Job *j : slot.jobs) cells += j->cells;
 	std::unique_lock<std::mutex> lock(p->m);
 	if (timed) { p->lf_ms += ms3[0]; p->k1_ms += ms3[1]; p->k2_ms += ms3[2]; ++p->launches; p->launch_frames += (int64_t) slot.jobs.size(); }
-	{
-		const double now = now_ms();
-		if (timed && p->last_retire_ms > 0 && cells > 0) {
-			const double idle = (now - p->last_retire_ms) - (double) (ms3[0] + ms3[1] + ms3[2]);   // (negative when batches overlap: the device is the bottleneck)
-			const double frame_ms = p->lf_cell_ms * (double) cells / (double) slot.jobs.size();
-			p->lf_credits = std::min((double) p->batch_frames / 4, std::max(0.0, p->lf_credits + 0.5 * idle / frame_ms));
-		}
-		p->last_retire_ms = now;
-	}
 	p->in_flight_frames -= (int64_t) slot.jobs.size();
 	for (Job *j : slot.jobs) { --p->resident; complete(p, j); }
 	slot.jobs.clear(); slot.busy = false; slot.launch_err = 0;
@@ -267,7 +258,7 @@ void gpu_main(j40hip_pipeline *p) {
 		std::vector<Job *> take;
 		{
 			std::unique_lock<std::mutex> lock(p->m);
-			auto lf_busy = [&] { return !p->lf_pending.empty() || p->lf_flights[0].busy || p->lf_flights[1].busy; };
+			auto lf_busy = [&] { bool b = !p->lf_pending.empty(); for (const LfFlight &fl : p->lf_flights) b = b || fl.busy; return b; };
 			auto tail = [&] { return p->stop || (p->todo.empty() && p->parsing == 0 && !lf_busy()); };   // nothing else is coming
 			auto collect = [&](bool) {
 				std::vector<size_t> pick;
@@ -281,14 +272,21 @@ void gpu_main(j40hip_pipeline *p) {
 			// launch is latency-bound -- about 0.2 s however many sections it has -- so everything waiting goes in)
 			for (LfFlight &fl : p->lf_flights) if (fl.busy && j40hip_alf_done(fl.alf)) {
 				for (Job *j : fl.jobs) p->ready.push_back(j);
+				p->lf_stage -= (int64_t) fl.jobs.size();
 				fl.jobs.clear(); fl.busy = false;
+				p->cv_todo.notify_all();
 			}
-			if (!p->lf_pending.empty()) for (LfFlight &fl : p->lf_flights) if (!fl.busy) {
+			// (a launch takes its 0.3 s whether it carries one frame or a batch's worth: wait for a full load unless the frames have
+			// been waiting a while or nothing else is coming)
+			if (p->lf_pending.empty()) p->lf_pending_since = 0;
+			else if (p->lf_pending_since == 0) p->lf_pending_since = now_ms();
+			const bool lf_go = !p->lf_pending.empty() && ((int64_t) p->lf_pending.size() >= p->batch_frames || now_ms() - p->lf_pending_since > 20.0 || p->stop || (p->todo.empty() && p->parsing == 0));
+			if (lf_go) for (LfFlight &fl : p->lf_flights) if (!fl.busy) {
 				std::vector<j40hip_aframe *> frames;
 				while (!p->lf_pending.empty() && (int64_t) fl.jobs.size() < p->batch_frames) { fl.jobs.push_back(p->lf_pending.front()); frames.push_back(p->lf_pending.front()->af); p->lf_pending.pop_front(); }
 				if (!fl.alf) fl.alf = j40hip_alf_create(p->device);
 				const uint32_t e = fl.alf ? j40hip_alf_launch(fl.alf, frames.data(), (int) frames.size(), fl.stream) : E_GPU;
-				if (e) { for (Job *j : fl.jobs) { j->lf_failed = true; p->ready.push_back(j); } fl.jobs.clear(); }   // (they are decoded again on the single-frame path)
+				if (e) { for (Job *j : fl.jobs) { j->lf_failed = true; p->ready.push_back(j); } p->lf_stage -= (int64_t) fl.jobs.size(); fl.jobs.clear(); }   // (they are decoded again on the single-frame path)
 				else fl.busy = true;
 				break;
 			}
@@ -374,7 +372,8 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 		if (flags & 4u) { (void) mallopt(M_MMAP_THRESHOLD, 1 << 30); (void) mallopt(M_TRIM_THRESHOLD, (int) (((size_t) 1 << 31) - 1)); (void) mallopt(M_TOP_PAD, 64 << 20); }
 		p->batch_frames = batch_frames < 1 ? 32 : batch_frames;
 		p->max_in_flight = max_in_flight < 1 ? 2 : max_in_flight > 8 ? 8 : max_in_flight;
-		if (const char *e = getenv("J40HIP_LF_CELL_NS")) p->lf_cell_ms = atof(e) * 1e-6;
+		p->lf_cap = p->lf_mode == 2 ? 0 : (int64_t) p->batch_frames * 3;
+		if (const char *e = getenv("J40HIP_LF_CAP")) p->lf_cap = atoll(e);
 		p->slots.resize((size_t) p->max_in_flight + 1);
 		for (Slot &s : p->slots) {
 			if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { *err = E_GPU; break; }

@@ -148,7 +148,8 @@ uint32_t build_front_plan(const Frame &fr, const StaticTables &st, size_t cs_siz
 	pb.lfidx_size = df.lfidx_size;
 	pb.mult_base = df.mult_base; pb.base_corr_x = fr.base_corr_x; pb.base_corr_b = fr.base_corr_b; pb.inv_colour_factor = fr.inv_colour_factor;
 	pb.block_ctx_map_off = fp->block_ctx_map_off;
-	fp->lf_device = want_lf_device && build_lf_lanes(fr, fp);
+	const bool lanes_ok = build_lf_lanes(fr, fp);   // (always: the tables' room is part of the frame's block whoever decodes the streams)
+	fp->lf_device = want_lf_device && lanes_ok;
 	return 0;
 }
 
