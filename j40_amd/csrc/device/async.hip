@@ -508,7 +508,11 @@ void j40hip_alf_free(j40hip_alf *a) {
 }
 uint32_t j40hip_alf_launch(j40hip_alf *a, j40hip_aframe *const *frames, int n, hipStream_t s) {
 	if (!a || n <= 0 || hipSetDevice(a->device) != hipSuccess) return ERR_GPU;
-	const size_t bytes = sizeof(DevLfLaneSet) * (size_t) n + 64;
+	std::vector<DevLfLaneSet> sets((size_t) n);
+	for (int i = 0; i < n; ++i) sets[(size_t) i] = frames[i]->lf_set;
+	std::vector<DevLfWave> waves;
+	const uint32_t lds = pack_lf_waves(sets.data(), n, &waves);
+	const size_t o_waves = (sizeof(DevLfLaneSet) * (size_t) n + 255) & ~(size_t) 255, bytes = o_waves + sizeof(DevLfWave) * waves.size() + 64;
 	if (!a->host.reserve(bytes, 0)) return ERR_MEM;
 	if (bytes > a->dev_cap) {
 		if (a->dev) (void) hipFree(a->dev);
@@ -516,12 +520,11 @@ uint32_t j40hip_alf_launch(j40hip_alf *a, j40hip_aframe *const *frames, int n, h
 		if (hipMalloc(&a->dev, bytes * 2) != hipSuccess) { (void) hipGetLastError(); return ERR_MEM; }
 		a->dev_cap = bytes * 2;
 	}
-	DevLfLaneSet *h = (DevLfLaneSet *) a->host.ptr;
-	int32_t max_tasks = 0; uint32_t lds = 0;
-	for (int i = 0; i < n; ++i) { h[i] = frames[i]->lf_set; max_tasks = std::max(max_tasks, h[i].ntasks); lds = std::max(lds, h[i].lds_bytes); }
+	memcpy(a->host.ptr, sets.data(), sizeof(DevLfLaneSet) * (size_t) n);
+	memcpy(a->host.ptr + o_waves, waves.data(), sizeof(DevLfWave) * waves.size());
 	for (int i = 0; i < n; ++i) if (hipStreamWaitEvent(s, frames[i]->uploaded, 0) != hipSuccess) return ERR_GPU;
-	if (hipMemcpyAsync(a->dev, h, sizeof(DevLfLaneSet) * (size_t) n, hipMemcpyHostToDevice, s) != hipSuccess) return ERR_GPU;
-	launch_lf_lanes((const DevLfLaneSet *) a->dev, n, max_tasks, lds + 64, s);
+	if (hipMemcpyAsync(a->dev, a->host.ptr, bytes - 64, hipMemcpyHostToDevice, s) != hipSuccess) return ERR_GPU;
+	launch_lf_lanes((const DevLfLaneSet *) a->dev, (const DevLfWave *) ((const uint8_t *) a->dev + o_waves), (int32_t) waves.size(), lds + 64, s);
 	if (hipEventRecord(a->done, s) != hipSuccess || hipGetLastError() != hipSuccess) return ERR_GPU;
 	// the frames' batch must wait for this launch, not only for their copies: from now on `uploaded` stands for both
 	for (int i = 0; i < n; ++i) if (hipEventRecord(frames[i]->uploaded, s) != hipSuccess) return ERR_GPU;

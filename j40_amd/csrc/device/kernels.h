@@ -36,8 +36,11 @@ void launch_kat_srgb_u8(const float *v, size_t n, uint8_t *out, hipStream_t stre
 // Modular path (device/modular_kernels.hip)
 void launch_modular_sections(const DevModPlan &plan, int32_t first_section, int32_t num_sections, const ModLaunchInfo &info, hipStream_t stream);
 void launch_lf_groups(const DevLfTask *tasks, int32_t num_tasks, hipStream_t stream);
-// one section per lane, one frame per wavefront (lf_lanes_dev.h); max_tasks: most sections any set has; lds_bytes: the largest DevLfLaneSet::lds_bytes
-void launch_lf_lanes(const DevLfLaneSet *sets, int32_t num_sets, int32_t max_tasks, uint32_t lds_bytes, hipStream_t stream);
+// one LfGroup section per lane (lf_lanes_dev.h): pack_lf_waves deals the sections of the sets (host copies) to wavefronts and returns
+// the LDS a wavefront needs at most; launch_lf_lanes takes the device copies of both arrays
+#include <vector>
+uint32_t pack_lf_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std::vector<DevLfWave> *waves);
+void launch_lf_lanes(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t num_waves, uint32_t lds_bytes, hipStream_t stream);
 void launch_modular_quad(const DevModPlan &plan, int32_t first_section, int32_t num_sections, int32_t spec_idx, uint32_t table_span, int32_t max_width, hipStream_t stream);
 void launch_modular_coop(const DevModPlan &plan, int32_t first_section, int32_t num_sections, int32_t max_width, hipStream_t stream);
 void launch_section_inverse_rcts(const DevModPlan &plan, int32_t first_section, int32_t num_sections, hipStream_t stream);

@@ -11,6 +11,9 @@
 #include "modular_coop_dev.h"
 #include "lf_lanes_dev.h"
 #include "kernels.h"
+#include <algorithm>
+#include <cstring>
+#include <vector>
 
 namespace j40hip {
 
@@ -55,37 +58,51 @@ __global__ void __launch_bounds__(64) k_lf_groups(const DevLfTask *tasks) {
 	if (lane == 0) { result->status = status; result->nb_varblocks = nb_varblocks; }
 }
 
-// One LfGroup section per LANE, one frame (up to 64 of its sections) per wavefront: see lf_lanes_dev.h. blockIdx.x = frame,
-// blockIdx.y = which 64 of its sections. The frame's tree and code tables are staged in LDS.
-__global__ void __launch_bounds__(64) k_lf_lanes(const DevLfLaneSet *sets) {
+// One LfGroup section per LANE (lf_lanes_dev.h); a wavefront takes the sections of several frames (DevLfWave), each frame's tree and
+// code tables staged in LDS, every lane pointing at its own frame's copy.
+__global__ void __launch_bounds__(64) k_lf_lanes(const DevLfLaneSet *sets, const DevLfWave *waves) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lfl_lds[];
-	const J40_GLOBAL DevLfLaneSet &set = ((const J40_GLOBAL DevLfLaneSet *) sets)[blockIdx.x];
-	const int32_t lane = threadIdx.x, first = (int32_t) blockIdx.y * 64;
-	const int32_t ntasks = set.ntasks, num_nodes = set.num_nodes, num_dist = set.num_dist, num_clusters = set.num_clusters, log_alpha = set.log_alpha;
-	if (first >= ntasks) return;
+	const J40_GLOBAL DevLfWave &wv = ((const J40_GLOBAL DevLfWave *) waves)[blockIdx.x];
+	const int32_t lane = threadIdx.x, num_parts = wv.num_parts;
 	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
 	J40_LDS uint8_t *lds = (J40_LDS uint8_t *) lfl_lds;
-	J40_LDS int32_t *l_tree = (J40_LDS int32_t *) lds;
-	J40_LDS uint8_t *l_map = lds + align16(16u * (uint32_t) num_nodes);
-	J40_LDS uint32_t *l_cfg = (J40_LDS uint32_t *) (l_map + align16((uint32_t) num_dist));
-	J40_LDS uint64_t *l_alias = (J40_LDS uint64_t *) ((J40_LDS uint8_t *) l_cfg + align16(4u * (uint32_t) num_clusters));
-	{
-		const J40_GLOBAL int32_t *tsrc = (const J40_GLOBAL int32_t *) set.tree;
-		for (int32_t i = lane; i < 4 * num_nodes; i += 64) l_tree[i] = tsrc[i];
-		const J40_GLOBAL uint8_t *msrc = (const J40_GLOBAL uint8_t *) set.ctx_map;
-		for (int32_t i = lane; i < num_dist; i += 64) l_map[i] = msrc[i];
-		const J40_GLOBAL uint32_t *csrc = (const J40_GLOBAL uint32_t *) set.cluster_cfg;
-		for (int32_t i = lane; i < num_clusters; i += 64) l_cfg[i] = csrc[i];
-		const J40_GLOBAL uint64_t *asrc = (const J40_GLOBAL uint64_t *) set.alias;
-		for (int32_t i = lane; i < (num_clusters << log_alpha); i += 64) l_alias[i] = asrc[i];
+	// this lane's section and tables
+	const J40_GLOBAL DevLfTask *task = nullptr;
+	LaneTables T;
+	T.ctx_map = nullptr; T.cluster_cfg = nullptr; T.alias = nullptr; T.nnz_ctx2 = nullptr; T.freq_ctx2 = nullptr; T.dct_info = nullptr; T.log_alpha = 5; T.log_bucket = 7;
+	LfLaneFrame F;
+	F.tree = nullptr; F.uses = 0;
+	uint32_t at = 0; int32_t lane0 = 0;
+	for (int32_t p = 0; p < num_parts; ++p) {
+		const J40_GLOBAL DevLfLaneSet &set = ((const J40_GLOBAL DevLfLaneSet *) sets)[wv.part[p].set];
+		const int32_t first = wv.part[p].first_task, count = wv.part[p].count;
+		const int32_t num_nodes = set.num_nodes, num_dist = set.num_dist, num_clusters = set.num_clusters, log_alpha = set.log_alpha;
+		J40_LDS int32_t *l_tree = (J40_LDS int32_t *) (lds + at);
+		J40_LDS uint8_t *l_map = lds + at + align16(16u * (uint32_t) num_nodes);
+		J40_LDS uint32_t *l_cfg = (J40_LDS uint32_t *) (l_map + align16((uint32_t) num_dist));
+		J40_LDS uint64_t *l_alias = (J40_LDS uint64_t *) ((J40_LDS uint8_t *) l_cfg + align16(4u * (uint32_t) num_clusters));
+		{
+			const J40_GLOBAL int32_t *tsrc = (const J40_GLOBAL int32_t *) set.tree;
+			for (int32_t i = lane; i < 4 * num_nodes; i += 64) l_tree[i] = tsrc[i];
+			const J40_GLOBAL uint8_t *msrc = (const J40_GLOBAL uint8_t *) set.ctx_map;
+			for (int32_t i = lane; i < num_dist; i += 64) l_map[i] = msrc[i];
+			const J40_GLOBAL uint32_t *csrc = (const J40_GLOBAL uint32_t *) set.cluster_cfg;
+			for (int32_t i = lane; i < num_clusters; i += 64) l_cfg[i] = csrc[i];
+			const J40_GLOBAL uint64_t *asrc = (const J40_GLOBAL uint64_t *) set.alias;
+			for (int32_t i = lane; i < (num_clusters << log_alpha); i += 64) l_alias[i] = asrc[i];
+		}
+		if (lane >= lane0 && lane < lane0 + count) {
+			task = (const J40_GLOBAL DevLfTask *) set.tasks + (first + lane - lane0);
+			T.ctx_map = l_map; T.cluster_cfg = l_cfg; T.alias = l_alias; T.log_alpha = log_alpha; T.log_bucket = 12 - log_alpha;
+			F.tree = (const J40_LDS DevTreeNode *) l_tree; F.uses = set.uses;
+		}
+		lane0 += count;
+		at += align16(set.lds_bytes);
 	}
 	__syncthreads();
-	LaneTables T;
-	T.ctx_map = l_map; T.cluster_cfg = l_cfg; T.alias = l_alias; T.nnz_ctx2 = nullptr; T.freq_ctx2 = nullptr; T.dct_info = nullptr; T.log_alpha = log_alpha; T.log_bucket = 12 - log_alpha;
-	LfLaneFrame F;
-	F.tree = (const J40_LDS DevTreeNode *) l_tree; F.uses = set.uses;
-	const bool active = first + lane < ntasks;
-	const J40_GLOBAL DevLfTask &t = ((const J40_GLOBAL DevLfTask *) set.tasks)[active ? first + lane : first];
+	const bool active = task != nullptr;
+	if (!active) task = (const J40_GLOBAL DevLfTask *) ((const J40_GLOBAL DevLfLaneSet *) sets)[wv.part[0].set].tasks + wv.part[0].first_task;   // (something valid to point at)
+	const J40_GLOBAL DevLfTask &t = *task;
 	LfLane L;
 	lf_lane_init(L, t);
 	if (!active) { L.chan = 7; L.setup = false; }
@@ -93,11 +110,30 @@ __global__ void __launch_bounds__(64) k_lf_lanes(const DevLfLaneSet *sets) {
 	if (active) { J40_GLOBAL DevLfResult *r = (J40_GLOBAL DevLfResult *) t.result; r->status = L.err; r->nb_varblocks = L.nb_varblocks; }
 }
 
-void launch_lf_lanes(const DevLfLaneSet *sets, int32_t num_sets, int32_t max_tasks, uint32_t lds_bytes, hipStream_t stream) {
-	if (num_sets <= 0 || max_tasks <= 0) return;
+// packs the sections of `sets` into wavefronts (host side): fills `waves`, returns the LDS bytes a wavefront needs at most
+uint32_t pack_lf_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std::vector<DevLfWave> *waves) {
+	const uint32_t budget = 56u * 1024u;
+	uint32_t most = 0, used = 0; int32_t lanes = 0;
+	DevLfWave cur; memset(&cur, 0, sizeof cur);
+	auto flush = [&] { if (cur.num_parts) { waves->push_back(cur); most = std::max(most, used); } memset(&cur, 0, sizeof cur); used = 0; lanes = 0; };
+	for (int32_t i = 0; i < num_sets; ++i) {
+		const uint32_t need = (sets_host[i].lds_bytes + 15u) & ~15u;
+		for (int32_t first = 0; first < sets_host[i].ntasks; ) {
+			if (lanes >= 64 || cur.num_parts >= LF_WAVE_PARTS || (cur.num_parts && used + need > budget)) flush();
+			const int32_t count = std::min(64 - lanes, sets_host[i].ntasks - first);
+			cur.part[cur.num_parts].set = i; cur.part[cur.num_parts].first_task = first; cur.part[cur.num_parts].count = count; ++cur.num_parts;
+			used += need; lanes += count; first += count;
+		}
+	}
+	flush();
+	return most;
+}
+
+void launch_lf_lanes(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t num_waves, uint32_t lds_bytes, hipStream_t stream) {
+	if (num_waves <= 0) return;
 	static bool configured = false;
 	if (!configured) { (void) hipFuncSetAttribute((const void *) k_lf_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); configured = true; }
-	hipLaunchKernelGGL(k_lf_lanes, dim3((unsigned) num_sets, (unsigned) ((max_tasks + 63) / 64)), dim3(64), lds_bytes, stream, sets);
+	hipLaunchKernelGGL(k_lf_lanes, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
 }
 
 void launch_lf_groups(const DevLfTask *tasks, int32_t num_tasks, hipStream_t stream) {

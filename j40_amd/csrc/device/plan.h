@@ -318,6 +318,11 @@ struct DevLfLaneSet {
 	uint32_t uses;                                      // bit 0: the tree looks at NE, 1: NEE, 2: NN
 	uint32_t lds_bytes;                                 // what staging the tables takes
 };
+// A wavefront of k_lf_lanes: up to 64 sections, taken from up to LF_WAVE_PARTS frames (8K frames have 12 LfGroup sections each, 1080p
+// frames one: a frame per wavefront would leave most lanes idle, and idle lanes cost what busy ones cost). A part is a run of
+// sections of one DevLfLaneSet; the tables of every part are staged in LDS side by side.
+enum { LF_WAVE_PARTS = 16 };
+struct DevLfWave { int32_t num_parts, pad; struct { int32_t set, first_task, count, pad; } part[LF_WAVE_PARTS]; };
 enum { ERR_LFFB = ('l' << 24) | ('f' << 16) | ('f' << 8) | 'b' };   // not an error of the stream: the second Modular header is not the plain one the device handles; the host decodes this section
 
 // ---- the LF-dependent half of a VarDCT frame's plan, built on the device (plan_dev.h, plan_kernels.hip) ----
