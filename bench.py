@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=64, help="distinct streams a batch cycles through")
     ap.add_argument("--pipe-batch", type=int, default=256, help="frames per entropy launch inside the pipeline")
     ap.add_argument("--host-threads", type=int, default=0, help="pipeline worker threads per GPU (default: the container's CPU quota / GPUs)")
+    ap.add_argument("--in-flight", type=int, default=2, help="batches the pipeline keeps in flight on the device")
     ap.add_argument("--lf-streams", choices=["auto", "device", "host"], default="auto",
                     help="who decodes the LfGroup streams of the batched frames: the GPU (k_lf_groups), the host worker threads, or decided frame by frame (auto: the host threads keep them while the device has batches queued up)")
     ap.add_argument("--resident-batch", type=int, default=256, help="frames of the device-resident section (kernels only, as round 1 measured)")
@@ -183,7 +184,7 @@ def main():
     step_bufs = [bufs[i % D] for i in range(B)]
     step_sizes = [len(datas[i % D]) for i in range(B)]
     outs = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(B)]
-    pipe = j40_amd.Pipeline(local_rank, threads, min(args.pipe_batch, B), 2, lf_streams=args.lf_streams)
+    pipe = j40_amd.Pipeline(local_rank, threads, min(args.pipe_batch, B), args.in_flight, lf_streams=args.lf_streams)
 
     for _ in range(max(args.warmup, 0)):
         run_pipeline_steps(pipe, step_bufs, step_sizes, outs, W * 4, True, 1, torch, dev, None)

@@ -97,6 +97,17 @@ AStage *astage_acquire(size_t bytes) {
 	return t_astages.back().get();
 }
 
+// events are recycled: creating and destroying one per frame cost the retiring thread a quarter of a millisecond a frame
+std::mutex g_event_mutex;
+std::vector<hipEvent_t> g_event_pool;
+hipEvent_t event_acquire() {
+	{ std::lock_guard<std::mutex> lock(g_event_mutex); if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; } }
+	hipEvent_t e = nullptr;
+	if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+	return e;
+}
+void event_release(hipEvent_t e) { if (e) { std::lock_guard<std::mutex> lock(g_event_mutex); g_event_pool.push_back(e); } }
+
 struct Layout {
 	size_t size = 0;
 	size_t take(size_t bytes) { const size_t off = (size + 255) & ~(size_t) 255; size = off + bytes + 16; return off; }
@@ -117,6 +128,7 @@ struct j40hip_aframe {
 	size_t cells = 0;
 	bool sparse = true;
 	hipEvent_t uploaded = nullptr;
+	hipStream_t up_stream = nullptr; uint64_t up_seq = 0;   // the stream its copy went on, and its place among that stream's frames
 	struct WorkLayout { size_t size = 0, stride = 0, coeffs = 0, blk = 0, nz = 0, status = 0, lz = 0, lfs = 0, recs = 0, gcnt = 0, gbs = 0, ccnt = 0, gb = 0, vbs = 0, llf[3] = {0, 0, 0}; uint32_t lz_window_size = 0; } wl;
 };
 
@@ -139,8 +151,20 @@ static uint32_t aframe_bind_work(j40hip_aframe *af, hipStream_t s) {
 	DevPlanBuild &bd = af->build;
 	bd.vb_recs = (DevVbRec *) (wb + wl.recs); bd.group_count = (uint32_t *) (wb + wl.gcnt); bd.group_block_start = (uint32_t *) (wb + wl.gbs); bd.class_count = (uint32_t *) (wb + wl.ccnt);
 	bd.group_blocks = (DevGroupBlock *) (wb + wl.gb); bd.vb_sorted = (DevVarblock *) (wb + wl.vbs); bd.lf_scratch = (float *) (wb + wl.lfs);
-	// recycled memory: no entry of the per-block table may point outside the event list (a section that fails leaves entries unwritten)
-	if (af->sparse && hipMemsetAsync(plan.block_events, 0, 16 * af->cells, s) != hipSuccess) return ERR_GPU;
+	(void) s;
+	return 0;
+}
+
+// makes `s` wait for the uploads of `n` frames: frames that went up on the same stream completed in order, so the youngest of each
+// stream stands for all of them -- one wait per worker thread instead of one per frame (a wait costs the caller 50 us)
+static uint32_t wait_for_uploads(j40hip_aframe *const *frames, int n, hipStream_t s) {
+	std::vector<const j40hip_aframe *> last;
+	for (int i = 0; i < n; ++i) {
+		bool found = false;
+		for (const j40hip_aframe *&l : last) if (l->up_stream == frames[i]->up_stream) { if (frames[i]->up_seq > l->up_seq) l = frames[i]; found = true; break; }
+		if (!found) last.push_back(frames[i]);
+	}
+	for (const j40hip_aframe *l : last) if (hipStreamWaitEvent(s, l->uploaded, 0) != hipSuccess) return ERR_GPU;
 	return 0;
 }
 
@@ -149,7 +173,7 @@ void j40hip_aframe_free(j40hip_aframe *f) {
 	(void) hipSetDevice(f->device);
 	cache_release(f->device, f->plan_block, f->plan_block_bytes, false);
 	cache_release(f->device, f->work_block, f->work_block_bytes, false);
-	if (f->uploaded) (void) hipEventDestroy(f->uploaded);
+	event_release(f->uploaded);
 	delete f;
 }
 int j40hip_aframe_lf_on_device(const j40hip_aframe *f) { return f && !f->lf_tasks.empty(); }
@@ -302,7 +326,10 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	// (the working set's pointers: aframe_bind_work; class_start and verdict belong to the batch: j40hip_abatch_launch)
 
 	const double tp6 = prof_now();
-	if (hipEventCreateWithFlags(&af->uploaded, hipEventDisableTiming) != hipSuccess) { af->uploaded = nullptr; (void) hipGetLastError(); return nullptr; }
+	af->uploaded = event_acquire();
+	if (!af->uploaded) return nullptr;
+	static thread_local uint64_t t_seq = 0;
+	af->up_stream = stream; af->up_seq = ++t_seq;
 	if (hipMemcpyAsync(pb, stg, copy_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return nullptr;
 	bool ok = hipEventRecord(sg.done, stream) == hipSuccess;
 	sg.pending = ok;
@@ -360,6 +387,7 @@ j40hip_abatch *j40hip_abatch_create(int device) {
 		if (ok) { b->side.push_back(st); b->side_done.push_back(ev); }
 	}
 	ok = ok && hipMalloc((void **) &b->large_scratch, (size_t) K2_LARGE_WGS * 6 * 65536 * sizeof(float)) == hipSuccess;
+	ok = ok && b->host.reserve((size_t) 8 << 20, 0);   // (pinned memory up front: growing it costs a third of a second a time)
 	hipDeviceProp_t prop;
 	if (ok && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) b->cus = prop.multiProcessorCount;
 	if (!ok) { (void) hipGetLastError(); j40hip_abatch_free(b); return nullptr; }
@@ -388,6 +416,7 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 	// per workgroup sharing one copy of their frame's tables
 	bool lanes_fast = true, tables_in_lds = true; uint32_t lanes_lds = 0, generic_lds = 0;
 	int32_t total_waves = 0, nlf = 0, max_lf_cells = 0; size_t cells_total = 0, max_frame_cells = 0;
+	const double tq0 = prof_now();
 	for (int i = 0; i < n; ++i) {
 		j40hip_aframe *f = frames[i];
 		if (!f || f->device != b->device) return ERR_GPU;
@@ -445,13 +474,18 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 		for (int32_t g = 0; g < f->num_lf_groups; ++g) h_lfs[at_lf++] = DevBatchLf{i, g};
 	}
 	memcpy(hb + o_work, work.data(), sizeof(HfLaneWork) * work.size());
-	for (int i = 0; i < n; ++i) if (hipStreamWaitEvent(s, frames[i]->uploaded, 0) != hipSuccess) return ERR_GPU;
+	if (uint32_t e = wait_for_uploads(frames, n, s)) return e;
+	const double tq1 = prof_now();
 	if (hipMemcpyAsync(db, hb, copy_bytes, hipMemcpyHostToDevice, s) != hipSuccess) return ERR_GPU;
+	const double tq2 = prof_now();
+	// recycled memory: no entry of the per-block tables may point outside the event lists (a section that fails leaves entries unwritten)
+	launch_clear_block_events(d_plans, d_builds, n, max_frame_cells, s);
 	(void) hipEventRecord(b->ev[0], s);
 	launch_plan_build(d_builds, d_lfs, n, nlf, max_lf_cells, s);
 	launch_lf_tail_batch(d_plans, d_builds, d_lfs, n, nlf, max_lf_cells, max_frame_cells, s);
 	for (int i = 0; i < n; ++i) if (!frames[i]->sparse && hipMemsetAsync(frames[i]->plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) frames[i]->plan.coeff_stride, s) != hipSuccess) return ERR_GPU;
 	(void) hipEventRecord(b->ev[1], s);
+	const double tq3 = prof_now();
 	if (lanes_fast) launch_hf_lanes(d_plans, d_work, (int32_t) work.size(), waves_per_wg, lanes_lds, s);
 	else launch_hf_entropy_lanes(d_plans, d_work, (int32_t) work.size(), tables_in_lds, generic_lds, s);
 	(void) hipEventRecord(b->ev[2], s);
@@ -463,6 +497,7 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 	launch_plan_verdict(d_builds, d_plans, n, s);
 	if (hipMemcpyAsync(b->verdict_host, db + o_verdict, 16 * (size_t) n + 64, hipMemcpyDeviceToHost, s) != hipSuccess) return ERR_GPU;
 	b->nframes = n; b->have_totals = true;
+	if (getenv("J40HIP_ASYNC_TIMING")) { const double tq4 = prof_now(); fprintf(stderr, "[j40hip batch launch] bind %.2f (+arrays) %.2f, copy %.2f, plan+tail enqueue %.2f, K1+K2+verdict enqueue %.2f ms\n", tq1 - tq0, 0.0, tq2 - tq1, tq3 - tq2, tq4 - tq3); }
 	return hipGetLastError() == hipSuccess ? 0 : ERR_GPU;
 }
 
@@ -496,6 +531,9 @@ j40hip_alf *j40hip_alf_create(int device) {
 	j40hip_alf *a = new j40hip_alf();
 	a->device = device;
 	if (hipEventCreateWithFlags(&a->done, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); delete a; return nullptr; }
+	// (room for a few thousand frames up front: growing pinned memory costs a third of a second a time)
+	if (!a->host.reserve((size_t) 4 << 20, 0) || hipMalloc(&a->dev, (size_t) 4 << 20) != hipSuccess) { (void) hipGetLastError(); j40hip_alf_free(a); return nullptr; }
+	a->dev_cap = (size_t) 4 << 20;
 	return a;
 }
 void j40hip_alf_free(j40hip_alf *a) {
@@ -508,6 +546,7 @@ void j40hip_alf_free(j40hip_alf *a) {
 }
 uint32_t j40hip_alf_launch(j40hip_alf *a, j40hip_aframe *const *frames, int n, hipStream_t s) {
 	if (!a || n <= 0 || hipSetDevice(a->device) != hipSuccess) return ERR_GPU;
+	const double tq0 = prof_now();
 	std::vector<DevLfLaneSet> sets((size_t) n);
 	for (int i = 0; i < n; ++i) sets[(size_t) i] = frames[i]->lf_set;
 	std::vector<DevLfWave> waves;
@@ -522,12 +561,15 @@ uint32_t j40hip_alf_launch(j40hip_alf *a, j40hip_aframe *const *frames, int n, h
 	}
 	memcpy(a->host.ptr, sets.data(), sizeof(DevLfLaneSet) * (size_t) n);
 	memcpy(a->host.ptr + o_waves, waves.data(), sizeof(DevLfWave) * waves.size());
-	for (int i = 0; i < n; ++i) if (hipStreamWaitEvent(s, frames[i]->uploaded, 0) != hipSuccess) return ERR_GPU;
+	const double tq1 = prof_now();
+	if (uint32_t e = wait_for_uploads(frames, n, s)) return e;
 	if (hipMemcpyAsync(a->dev, a->host.ptr, bytes - 64, hipMemcpyHostToDevice, s) != hipSuccess) return ERR_GPU;
+	const double tq2 = prof_now();
 	launch_lf_lanes((const DevLfLaneSet *) a->dev, (const DevLfWave *) ((const uint8_t *) a->dev + o_waves), (int32_t) waves.size(), lds + 64, s);
+	const double tq3 = prof_now();
 	if (hipEventRecord(a->done, s) != hipSuccess || hipGetLastError() != hipSuccess) return ERR_GPU;
-	// the frames' batch must wait for this launch, not only for their copies: from now on `uploaded` stands for both
-	for (int i = 0; i < n; ++i) if (hipEventRecord(frames[i]->uploaded, s) != hipSuccess) return ERR_GPU;
+	if (getenv("J40HIP_ASYNC_TIMING")) fprintf(stderr, "[j40hip lf launch] %d frames, %zu waves: pack %.2f, copy %.2f, launch %.2f, record %.2f ms\n", n, waves.size(), tq1 - tq0, tq2 - tq1, tq3 - tq2, prof_now() - tq3);
+	// (the caller hands the frames to a batch only once j40hip_alf_done says this launch has completed)
 	return 0;
 }
 int j40hip_alf_done(j40hip_alf *a) { if (!a || hipEventQuery(a->done) == hipSuccess) return 1; (void) hipGetLastError(); return 0; }

@@ -29,6 +29,7 @@ void launch_lf_tail(const DevPlan &plan, int32_t num_lf_groups, int32_t max_cell
 void launch_lf_tail_batch(const DevPlan *plans, const DevPlanBuild *builds, const DevBatchLf *lfs, int32_t nframes, int32_t nlf, int32_t max_lf_cells, size_t max_frame_cells, hipStream_t stream);
 // the LF-dependent half of the plan of every frame of a batch (device/plan_kernels.hip)
 void launch_plan_build(const DevPlanBuild *builds, const DevBatchLf *lfs, int32_t nframes, int32_t nlf, int32_t max_lf_cells, hipStream_t stream);
+void launch_clear_block_events(const DevPlan *plans, const DevPlanBuild *builds, int32_t nframes, size_t max_frame_cells, hipStream_t stream);
 void launch_plan_verdict(const DevPlanBuild *builds, const DevPlan *plans, int32_t nframes, hipStream_t stream);
 
 void launch_kat_srgb_u8(const float *v, size_t n, uint8_t *out, hipStream_t stream);

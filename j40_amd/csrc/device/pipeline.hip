@@ -110,7 +110,7 @@ void complete(j40hip_pipeline *p, Job *j) {   // p->m held
 	++p->completed;
 	p->last_done_ms = now_ms();
 	delete j;
-	p->cv_done.notify_all();
+	if (p->completed == p->submitted || (p->completed & 63) == 0) p->cv_done.notify_all();   // (whoever drains polls as well)
 }
 
 void *acquire_image(j40hip_pipeline *p, size_t bytes) {
@@ -254,10 +254,14 @@ void retire(j40hip_pipeline *p, Slot &slot) {   // GPU thread; waits for the slo
 
 void gpu_main(j40hip_pipeline *p) {
 	if (hipSetDevice(p->device) != hipSuccess) { ++p->worker_errors; return; }
+	double t_lf = 0, t_launch = 0, t_retire = 0, t_idle = 0, t_lock = 0; int64_t n_launch = 0, n_lf = 0;   // (J40HIP_ASYNC_TIMING)
+	struct Report { double &a, &b, &c, &d, &e; int64_t &n, &m; ~Report() { if (getenv("J40HIP_ASYNC_TIMING")) fprintf(stderr, "[j40hip gpu thread] ms: LfGroup launches %.1f (%lld), batch launches %.1f (%lld), retiring %.1f, waiting %.1f, for the lock %.1f\n", a, (long long) m, b, (long long) n, c, d, e); } } report{t_lf, t_launch, t_retire, t_idle, t_lock, n_launch, n_lf};
 	for (;;) {
 		std::vector<Job *> take;
 		{
+			const double tl0 = now_ms();
 			std::unique_lock<std::mutex> lock(p->m);
+			t_lock += now_ms() - tl0;
 			auto lf_busy = [&] { bool b = !p->lf_pending.empty(); for (const LfFlight &fl : p->lf_flights) b = b || fl.busy; return b; };
 			auto tail = [&] { return p->stop || (p->todo.empty() && p->parsing == 0 && !lf_busy()); };   // nothing else is coming
 			auto collect = [&](bool) {
@@ -276,39 +280,45 @@ void gpu_main(j40hip_pipeline *p) {
 				fl.jobs.clear(); fl.busy = false;
 				p->cv_todo.notify_all();
 			}
-			// (a launch takes its 0.3 s whether it carries one frame or a batch's worth: wait for a full load unless the frames have
-			// been waiting a while or nothing else is coming)
+			// (a launch takes its 0.3 s whether it carries one frame or two batches' worth: wait for a batch's worth unless no launch is in
+			// flight at all and the frames have been waiting a while, or nothing else is coming)
 			if (p->lf_pending.empty()) p->lf_pending_since = 0;
 			else if (p->lf_pending_since == 0) p->lf_pending_since = now_ms();
-			const bool lf_go = !p->lf_pending.empty() && ((int64_t) p->lf_pending.size() >= p->batch_frames || now_ms() - p->lf_pending_since > 20.0 || p->stop || (p->todo.empty() && p->parsing == 0));
+			bool lf_flying = false;
+			for (const LfFlight &fl : p->lf_flights) lf_flying = lf_flying || fl.busy;
+			const bool lf_go = !p->lf_pending.empty() && ((int64_t) p->lf_pending.size() >= p->batch_frames || (!lf_flying && now_ms() - p->lf_pending_since > 5.0) || p->stop || (p->todo.empty() && p->parsing == 0));
 			if (lf_go) for (LfFlight &fl : p->lf_flights) if (!fl.busy) {
 				std::vector<j40hip_aframe *> frames;
-				while (!p->lf_pending.empty() && (int64_t) fl.jobs.size() < p->batch_frames) { fl.jobs.push_back(p->lf_pending.front()); frames.push_back(p->lf_pending.front()->af); p->lf_pending.pop_front(); }
+				while (!p->lf_pending.empty() && (int64_t) fl.jobs.size() < 2 * p->batch_frames) { fl.jobs.push_back(p->lf_pending.front()); frames.push_back(p->lf_pending.front()->af); p->lf_pending.pop_front(); }
 				if (!fl.alf) fl.alf = j40hip_alf_create(p->device);
+				const double ta = now_ms();
 				const uint32_t e = fl.alf ? j40hip_alf_launch(fl.alf, frames.data(), (int) frames.size(), fl.stream) : E_GPU;
+				t_lf += now_ms() - ta; ++n_lf;
 				if (e) { for (Job *j : fl.jobs) { j->lf_failed = true; p->ready.push_back(j); } p->lf_stage -= (int64_t) fl.jobs.size(); fl.jobs.clear(); }   // (they are decoded again on the single-frame path)
 				else fl.busy = true;
 				break;
 			}
-			if ((int64_t) p->ready.size() >= p->batch_frames) { pick = collect(false); if ((int64_t) pick.size() < p->batch_frames) pick.clear(); }
-			if (pick.empty() && !p->ready.empty() && tail()) pick = collect(true);
+			// This thread never waits for the device while there may be something to enqueue -- a finished LfGroup launch to replace, a
+			// batch to launch: a batch in flight is retired when it is done (polled), and waited for only when nothing else can happen.
+			bool oldest_done = false;
+			if (!p->in_flight.empty()) { oldest_done = hipEventQuery(p->slots[(size_t) p->in_flight.front()].done) == hipSuccess; if (!oldest_done) (void) hipGetLastError(); }
+			if ((int) p->in_flight.size() < p->max_in_flight) {   // (a launch goes before a retirement: the device should not wait for this thread's bookkeeping)
+				if ((int64_t) p->ready.size() >= p->batch_frames) { pick = collect(false); if ((int64_t) pick.size() < p->batch_frames) pick.clear(); }
+				if (pick.empty() && !p->ready.empty() && tail()) pick = collect(true);
+			}
 			if (!pick.empty()) {
 				for (size_t i : pick) take.push_back(p->ready[i]);
 				for (size_t k = pick.size(); k-- > 0; ) p->ready.erase(p->ready.begin() + (long) pick[k]);
 				p->in_flight_frames += (int64_t) take.size();
-			} else {
-				// Nothing to launch. Retire the oldest batch in flight if that does not mean waiting for it while the next batch fills
-				// up (its launch should not be held back): when it is done already, or when no frame is on its way at all.
-				bool retire_now = false;
-				if (!p->in_flight.empty()) {
-					retire_now = (p->ready.empty() && tail()) || hipEventQuery(p->slots[(size_t) p->in_flight.front()].done) == hipSuccess;
-					if (!retire_now) (void) hipGetLastError();
-				}
-				if (!retire_now) { p->cv_ready.wait_for(lock, std::chrono::milliseconds(1)); continue; }   // (also how finished LfGroup launches get noticed)
+			} else if (!oldest_done && !(p->ready.empty() && tail() && !p->in_flight.empty())) {
+				const double tw = now_ms(); p->cv_ready.wait_for(lock, std::chrono::milliseconds(1)); t_idle += now_ms() - tw;
+				continue;
 			}
 		}
 		if (take.empty()) {   // (the oldest batch in flight is to be retired)
+			const double tr = now_ms();
 			const int s = p->in_flight.front(); p->in_flight.pop_front(); retire(p, p->slots[(size_t) s]);
+			t_retire += now_ms() - tr;
 			continue;
 		}
 		{   // frames whose LfGroup streams could not be launched on the device never enter a batch (their planes were never decoded):
@@ -327,7 +337,7 @@ void gpu_main(j40hip_pipeline *p) {
 			take.swap(keep);
 			if (take.empty()) continue;
 		}
-		if ((int) p->in_flight.size() >= p->max_in_flight) { const int s = p->in_flight.front(); p->in_flight.pop_front(); retire(p, p->slots[(size_t) s]); }
+		const double tb = now_ms();
 		int si = -1;
 		for (size_t i = 0; i < p->slots.size(); ++i) if (!p->slots[i].busy) { si = (int) i; break; }
 		Slot &slot = p->slots[(size_t) si];
@@ -345,6 +355,7 @@ void gpu_main(j40hip_pipeline *p) {
 		slot.launch_err = err;
 		if (hipEventRecord(slot.done, slot.stream) != hipSuccess && !slot.launch_err) slot.launch_err = E_GPU;
 		p->in_flight.push_back(si);
+		t_launch += now_ms() - tb; ++n_launch;
 	}
 	for (Slot &s : p->slots) if (s.batch) { j40hip_abatch_free(s.batch); s.batch = nullptr; }
 	for (LfFlight &fl : p->lf_flights) if (fl.alf) { j40hip_alf_free(fl.alf); fl.alf = nullptr; }
@@ -372,7 +383,7 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 		if (flags & 4u) { (void) mallopt(M_MMAP_THRESHOLD, 1 << 30); (void) mallopt(M_TRIM_THRESHOLD, (int) (((size_t) 1 << 31) - 1)); (void) mallopt(M_TOP_PAD, 64 << 20); }
 		p->batch_frames = batch_frames < 1 ? 32 : batch_frames;
 		p->max_in_flight = max_in_flight < 1 ? 2 : max_in_flight > 8 ? 8 : max_in_flight;
-		p->lf_cap = p->lf_mode == 2 ? 0 : (int64_t) p->batch_frames * 3;
+		p->lf_cap = p->lf_mode == 2 ? 0 : (int64_t) p->batch_frames * 8;   // (a frame in this stage holds about 11 MB of device memory)
 		if (const char *e = getenv("J40HIP_LF_CAP")) p->lf_cap = atoll(e);
 		p->slots.resize((size_t) p->max_in_flight + 1);
 		for (Slot &s : p->slots) {

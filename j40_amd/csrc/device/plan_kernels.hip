@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include "plan_dev.h"
 #include "kernels.h"
+#include <algorithm>
 
 namespace j40hip {
 
@@ -154,6 +155,20 @@ __global__ void __launch_bounds__(64) k_plan_verdict(const DevPlanBuild *builds,
 		flags |= __shfl_xor(flags, d); used |= __shfl_xor(used, d);
 	}
 	if (lane == 0) { pb.verdict[0] = best == ~(uint64_t) 0 ? 0u : (uint32_t) best; pb.verdict[1] = flags; pb.verdict[2] = used; pb.verdict[3] = (uint32_t) pb.class_start[27]; }
+}
+
+// clears the per-block event tables (DevPlan::block_events, 16 bytes per cell) of every sparse frame of a batch
+__global__ void __launch_bounds__(256) k_clear_block_events(const DevPlan *plans, const DevPlanBuild *builds) {
+	const DevPlan &plan = plans[blockIdx.y];
+	if (!plan.block_events) return;
+	const uint32_t cells = builds[blockIdx.y].cells;
+	uint4 *p = (uint4 *) plan.block_events;
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < cells; i += gridDim.x * 256u) p[i] = make_uint4(0, 0, 0, 0);
+}
+void launch_clear_block_events(const DevPlan *plans, const DevPlanBuild *builds, int32_t nframes, size_t max_frame_cells, hipStream_t stream) {
+	if (nframes <= 0 || !max_frame_cells) return;
+	const unsigned gx = (unsigned) std::min<size_t>((max_frame_cells + 255) / 256, 256);
+	hipLaunchKernelGGL(k_clear_block_events, dim3(gx, (unsigned) nframes), dim3(256), 0, stream, plans, builds);
 }
 
 void launch_plan_build(const DevPlanBuild *builds, const DevBatchLf *lfs, int32_t nframes, int32_t nlf, int32_t max_lf_cells, hipStream_t stream) {

@@ -1,7 +1,7 @@
 # kernel timeline of the pipeline bench (csv of every dispatch: name, stream/queue, start, end)
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace -- python $R/bench.py --skip-sections --steps 3 --warmup 2 --distinct 16 --no-cpu-baseline --lf-streams ${MODE:-host} > $R/gpurun_out/trace.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace -- python $R/bench.py --skip-sections --steps ${STEPS:-8} --warmup ${WARM:-5} --distinct 16 --no-cpu-baseline --lf-streams ${MODE:-host} > $R/gpurun_out/trace.log 2>&1
 cd $R
 f=$(find gpurun_out/trace -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
