@@ -168,6 +168,21 @@ static uint32_t wait_for_uploads(j40hip_aframe *const *frames, int n, hipStream_
 	return 0;
 }
 
+// Sizes the device memory cache for a pipeline from its first batch: `work_copies` working sets and `front_copies` front blocks
+// (codestream, plan, LfGroup planes) per frame of the batch are acquired and handed back, so that the cache holds them. Growing
+// the cache costs hipMalloc calls of 10 ms and more each, which otherwise land wherever the pipeline first runs at full depth.
+void j40hip_aframes_reserve(j40hip_aframe *const *frames, int n, int work_copies, int front_copies) {
+	struct Held { void *p; size_t bytes; };
+	std::vector<Held> held;
+	for (int c = 0; c < std::max(work_copies, front_copies); ++c) for (int i = 0; i < n; ++i) {
+		const j40hip_aframe *f = frames[i];
+		bool dummy = false; size_t got = 0;
+		if (c < work_copies) if (void *q = cache_acquire(f->device, f->wl.size, &got, &dummy)) held.push_back({q, got});
+		if (c < front_copies) if (void *q = cache_acquire(f->device, f->plan_block_bytes, &got, &dummy)) held.push_back({q, got});
+	}
+	if (n > 0) for (const Held &h : held) cache_release(frames[0]->device, h.p, h.bytes, false);
+}
+
 void j40hip_aframe_free(j40hip_aframe *f) {
 	if (!f) return;
 	(void) hipSetDevice(f->device);

@@ -18,6 +18,8 @@ struct j40hip_alf;
 j40hip_aframe *j40hip_aframe_prepare(const void *buf, size_t size, int device, hipStream_t stream, int lf_on_device);
 // nothing may still be running on the frame's memory
 void j40hip_aframe_free(j40hip_aframe *f);
+// grows the device memory cache by `work_copies` working sets and `front_copies` front blocks per frame (at a pipeline's first batch)
+void j40hip_aframes_reserve(j40hip_aframe *const *frames, int n, int work_copies, int front_copies);
 // frees the calling thread's pinned staging buffers (before a thread that prepared frames exits)
 void j40hip_astage_release(void);
 int j40hip_aframe_lf_on_device(const j40hip_aframe *f);

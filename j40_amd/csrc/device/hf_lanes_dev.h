@@ -103,7 +103,8 @@ J40_DEV uint32_t lane_bit_position(const LaneBits &b) { return 8u * b.pos - (uin
 
 // one symbol: rANS step (j40.h:2441-2466) + hybrid integer (j40.h:2313-2334). *err receives the error the
 // reference would have raised first ("shrt" while renormalising, then "iovf", then "shrt" in the extra bits).
-J40_DEV int32_t lane_symbol(LaneBits &b, uint32_t &state, const LaneTables &t, int32_t ctx, uint32_t end_bit, uint32_t *err) {
+template <class Tables>   // LaneTables, or a set of tables with the same members elsewhere (LfLaneTables, lf_lanes_dev.h)
+J40_DEV int32_t lane_symbol(LaneBits &b, uint32_t &state, const Tables &t, int32_t ctx, uint32_t end_bit, uint32_t *err) {
 	const uint32_t cl = t.ctx_map[ctx];
 	if (state == 0) {   // first symbol of the section (j40.h:2445-2449); the window holds > 32 bits
 		state = lane_bits_take(b, 16); state |= lane_bits_take(b, 16) << 16;

@@ -59,7 +59,8 @@ __global__ void __launch_bounds__(64) k_lf_groups(const DevLfTask *tasks) {
 }
 
 // One LfGroup section per LANE (lf_lanes_dev.h); a wavefront takes the sections of several frames (DevLfWave), each frame's tree and
-// code tables staged in LDS, every lane pointing at its own frame's copy.
+// small code tables staged in LDS, every lane pointing at its own frame's copy. ALIAS_LDS: the alias tables as well.
+template <bool ALIAS_LDS>
 __global__ void __launch_bounds__(64) k_lf_lanes(const DevLfLaneSet *sets, const DevLfWave *waves) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lfl_lds[];
 	const J40_GLOBAL DevLfWave &wv = ((const J40_GLOBAL DevLfWave *) waves)[blockIdx.x];
@@ -68,8 +69,8 @@ __global__ void __launch_bounds__(64) k_lf_lanes(const DevLfLaneSet *sets, const
 	J40_LDS uint8_t *lds = (J40_LDS uint8_t *) lfl_lds;
 	// this lane's section and tables
 	const J40_GLOBAL DevLfTask *task = nullptr;
-	LaneTables T;
-	T.ctx_map = nullptr; T.cluster_cfg = nullptr; T.alias = nullptr; T.nnz_ctx2 = nullptr; T.freq_ctx2 = nullptr; T.dct_info = nullptr; T.log_alpha = 5; T.log_bucket = 7;
+	LfLaneTablesT<ALIAS_LDS> T;
+	T.ctx_map = nullptr; T.cluster_cfg = nullptr; T.alias = nullptr; T.log_alpha = 5; T.log_bucket = 7;
 	LfLaneFrame F;
 	F.tree = nullptr; F.uses = 0;
 	uint32_t at = 0; int32_t lane0 = 0;
@@ -88,26 +89,38 @@ __global__ void __launch_bounds__(64) k_lf_lanes(const DevLfLaneSet *sets, const
 			for (int32_t i = lane; i < num_dist; i += 64) l_map[i] = msrc[i];
 			const J40_GLOBAL uint32_t *csrc = (const J40_GLOBAL uint32_t *) set.cluster_cfg;
 			for (int32_t i = lane; i < num_clusters; i += 64) l_cfg[i] = csrc[i];
-			const J40_GLOBAL uint64_t *asrc = (const J40_GLOBAL uint64_t *) set.alias;
-			for (int32_t i = lane; i < (num_clusters << log_alpha); i += 64) l_alias[i] = asrc[i];
+			if constexpr (ALIAS_LDS) {
+				const J40_GLOBAL uint64_t *asrc = (const J40_GLOBAL uint64_t *) set.alias;
+				for (int32_t i = lane; i < (num_clusters << log_alpha); i += 64) l_alias[i] = asrc[i];
+			}
 		}
 		if (lane >= lane0 && lane < lane0 + count) {
 			task = (const J40_GLOBAL DevLfTask *) set.tasks + (first + lane - lane0);
-			T.ctx_map = l_map; T.cluster_cfg = l_cfg; T.alias = l_alias; T.log_alpha = log_alpha; T.log_bucket = 12 - log_alpha;
+			T.ctx_map = l_map; T.cluster_cfg = l_cfg; T.log_alpha = log_alpha; T.log_bucket = 12 - log_alpha;
+			if constexpr (ALIAS_LDS) T.alias = l_alias; else T.alias = (const J40_GLOBAL uint64_t *) set.alias;
 			F.tree = (const J40_LDS DevTreeNode *) l_tree; F.uses = set.uses;
 		}
 		lane0 += count;
-		at += align16(set.lds_bytes);
+		at += align16(set.lds_bytes) + (ALIAS_LDS ? 8u * ((uint32_t) num_clusters << log_alpha) : 0u);
 	}
 	__syncthreads();
 	const bool active = task != nullptr;
-	if (!active) task = (const J40_GLOBAL DevLfTask *) ((const J40_GLOBAL DevLfLaneSet *) sets)[wv.part[0].set].tasks + wv.part[0].first_task;   // (something valid to point at)
+	if (!active) {   // (something valid to point at)
+		const J40_GLOBAL DevLfLaneSet &set = ((const J40_GLOBAL DevLfLaneSet *) sets)[wv.part[0].set];
+		task = (const J40_GLOBAL DevLfTask *) set.tasks + wv.part[0].first_task;
+	}
 	const J40_GLOBAL DevLfTask &t = *task;
 	LfLane L;
 	lf_lane_init(L, t);
 	if (!active) { L.chan = 7; L.setup = false; }
 	while (__builtin_amdgcn_ballot_w64(!lf_lane_done(L))) lf_lane_step(L, t, F, T);
 	if (active) { J40_GLOBAL DevLfResult *r = (J40_GLOBAL DevLfResult *) t.result; r->status = L.err; r->nb_varblocks = L.nb_varblocks; }
+}
+
+// J40HIP_LF_ALIAS_LDS=1: the alias tables staged in LDS too (frames whose tables do not fit: the host decodes their sections)
+bool lf_lanes_alias_in_lds() {
+	static const bool v = [] { const char *e = getenv("J40HIP_LF_ALIAS_LDS"); return e && atoi(e) != 0; }();
+	return v;
 }
 
 // packs the sections of `sets` into wavefronts (host side): fills `waves`, returns the LDS bytes a wavefront needs at most
@@ -117,7 +130,7 @@ uint32_t pack_lf_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std::vec
 	DevLfWave cur; memset(&cur, 0, sizeof cur);
 	auto flush = [&] { if (cur.num_parts) { waves->push_back(cur); most = std::max(most, used); } memset(&cur, 0, sizeof cur); used = 0; lanes = 0; };
 	for (int32_t i = 0; i < num_sets; ++i) {
-		const uint32_t need = (sets_host[i].lds_bytes + 15u) & ~15u;
+		const uint32_t need = ((sets_host[i].lds_bytes + 15u) & ~15u) + (lf_lanes_alias_in_lds() ? 8u * ((uint32_t) sets_host[i].num_clusters << sets_host[i].log_alpha) : 0u);
 		for (int32_t first = 0; first < sets_host[i].ntasks; ) {
 			if (lanes >= 64 || cur.num_parts >= LF_WAVE_PARTS || (cur.num_parts && used + need > budget)) flush();
 			const int32_t count = std::min(64 - lanes, sets_host[i].ntasks - first);
@@ -132,8 +145,9 @@ uint32_t pack_lf_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std::vec
 void launch_lf_lanes(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t num_waves, uint32_t lds_bytes, hipStream_t stream) {
 	if (num_waves <= 0) return;
 	static bool configured = false;
-	if (!configured) { (void) hipFuncSetAttribute((const void *) k_lf_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); configured = true; }
-	hipLaunchKernelGGL(k_lf_lanes, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
+	if (!configured) { (void) hipFuncSetAttribute((const void *) k_lf_lanes<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); (void) hipFuncSetAttribute((const void *) k_lf_lanes<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); configured = true; }
+	if (lf_lanes_alias_in_lds()) hipLaunchKernelGGL(k_lf_lanes<true>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
+	else hipLaunchKernelGGL(k_lf_lanes<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
 }
 
 void launch_lf_groups(const DevLfTask *tasks, int32_t num_tasks, hipStream_t stream) {

@@ -21,6 +21,23 @@
 
 namespace j40hip {
 
+// The code tables of a lane's frame. The small ones (context map, hybrid-integer configurations) are staged in LDS like the tree;
+// the alias tables (num_clusters << log_alpha entries of 8 bytes: 14 KB for seven clusters of 256 buckets) are read where the
+// host put them: staged in LDS they let a wavefront hold three frames (36 of 64 lanes), and two such workgroups on a compute
+// unit left no room for the coefficient decoder's (k_hf_lanes, 99 KB), which then ran its workgroups in two rounds.
+template <bool ALIAS_LDS> struct LfLaneTablesT {
+	const J40_LDS uint8_t *ctx_map;
+	const J40_LDS uint32_t *cluster_cfg;
+	const J40_GLOBAL uint64_t *alias;
+	int32_t log_alpha, log_bucket;
+};
+template <> struct LfLaneTablesT<true> {
+	const J40_LDS uint8_t *ctx_map;
+	const J40_LDS uint32_t *cluster_cfg;
+	const J40_LDS uint64_t *alias;
+	int32_t log_alpha, log_bucket;
+};
+
 // what the sections of one frame share (wave-uniform)
 struct LfLaneFrame {
 	const J40_LDS DevTreeNode *tree;   // the global MA tree
@@ -109,7 +126,8 @@ J40_DEV void lf_lane_setup(LfLane &L, const J40_GLOBAL DevLfTask &t, const LfLan
 }
 
 // one sample of the lane's stream (or the start of its next channel)
-J40_DEV void lf_lane_step(LfLane &L, const J40_GLOBAL DevLfTask &t, const LfLaneFrame &F, const LaneTables &T) {
+template <class Tables>
+J40_DEV void lf_lane_step(LfLane &L, const J40_GLOBAL DevLfTask &t, const LfLaneFrame &F, const Tables &T) {
 	if (lf_lane_done(L)) return;
 	if (L.setup) { lf_lane_setup(L, t, F); if (L.chan == 7 || L.err) return; }
 	lane_bits_refill(L.b);

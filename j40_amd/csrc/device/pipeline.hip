@@ -89,6 +89,8 @@ struct j40hip_pipeline {
 	std::vector<uint32_t> results;      // by ticket
 	std::vector<uint8_t> finished;      // by ticket
 	int64_t submitted = 0, completed = 0, resident = 0, parsing = 0, in_flight_frames = 0;
+	std::vector<j40hip_aframe *> garbage;   // frames of retired batches: the worker threads free them (60 us each: a batch's worth kept the launching thread busy for 15 ms and more)
+	int64_t full_batches = 0;
 	bool stop = false;
 	std::vector<std::thread> workers;
 	std::thread gpu;
@@ -177,7 +179,14 @@ void worker_main(j40hip_pipeline *p) {
 		{
 			std::unique_lock<std::mutex> lock(p->m);
 			// back-pressure: prepared frames hold their working set in HBM until their batch is done
-			p->cv_todo.wait(lock, [&] { return p->stop || (!p->todo.empty() && p->resident < (int64_t) p->batch_frames * (p->max_in_flight + 1) + p->lf_cap); });
+			p->cv_todo.wait(lock, [&] { return p->stop || !p->garbage.empty() || (!p->todo.empty() && p->resident < (int64_t) p->batch_frames * (p->max_in_flight + 1) + p->lf_cap); });
+			if (!p->garbage.empty()) {
+				std::vector<j40hip_aframe *> mine;
+				for (int k = 0; k < 16 && !p->garbage.empty(); ++k) { mine.push_back(p->garbage.back()); p->garbage.pop_back(); }
+				lock.unlock();
+				for (j40hip_aframe *af : mine) j40hip_aframe_free(af);
+				continue;
+			}
 			if (p->stop) break;
 			j = p->todo.front(); p->todo.pop_front();
 			++p->resident; ++p->parsing;
@@ -228,6 +237,7 @@ void retire(j40hip_pipeline *p, Slot &slot) {   // GPU thread; waits for the slo
 	const bool ok = hipEventSynchronize(slot.done) == hipSuccess;
 	float ms3[3] = {0, 0, 0};
 	const bool timed = ok && !slot.launch_err && j40hip_abatch_elapsed(slot.batch, ms3) == 0;
+	std::vector<j40hip_aframe *> dead;
 	for (size_t i = 0; i < slot.jobs.size(); ++i) {
 		Job *j = slot.jobs[i];
 		if (!ok) j->status = E_GPU;
@@ -241,13 +251,14 @@ void retire(j40hip_pipeline *p, Slot &slot) {   // GPU thread; waits for the slo
 				j->status = decode_single(p, j, slot.stream);
 			} else j->status = code ? code : j40hip_aframe_after_frame_status(j->af);
 		}
-		if (j->af) { j40hip_aframe_free(j->af); j->af = nullptr; }   // its stream has been waited for
+		if (j->af) { dead.push_back(j->af); j->af = nullptr; }   // its stream has been waited for
 		if (!j->device_output && j->dev_rgba) release_image(p, j->dev_rgba, j->stride * (size_t) j->height);
 	}
 	std::unique_lock<std::mutex> lock(p->m);
 	if (timed) { p->lf_ms += ms3[0]; p->k1_ms += ms3[1]; p->k2_ms += ms3[2]; ++p->launches; p->launch_frames += (int64_t) slot.jobs.size(); }
 	p->in_flight_frames -= (int64_t) slot.jobs.size();
 	for (Job *j : slot.jobs) { --p->resident; complete(p, j); }
+	p->garbage.insert(p->garbage.end(), dead.begin(), dead.end());
 	slot.jobs.clear(); slot.busy = false; slot.launch_err = 0;
 	p->cv_todo.notify_all();
 }
@@ -351,12 +362,17 @@ void gpu_main(j40hip_pipeline *p) {
 		}
 		if (!err && !slot.batch) { slot.batch = j40hip_abatch_create(p->device); if (!slot.batch) err = E_GPU; }
 		if (!err) err = j40hip_abatch_launch(slot.batch, frames.data(), (int) frames.size(), outs.data(), strides.data(), slot.stream);
+		// the second full batch says this is a pipeline that will run at depth: size the device memory cache for it now (the device
+		// has two batches to work on meanwhile) rather than wherever the queues first fill up
+		if (!err && (int64_t) frames.size() == p->batch_frames && ++p->full_batches == 2)
+			j40hip_aframes_reserve(frames.data(), (int) frames.size(), p->max_in_flight - 1, (int) (p->max_in_flight - 1 + p->lf_cap / std::max<int64_t>(1, p->batch_frames)));   // (two batches' worth exist)
 		if (!err) for (Job *j : take) if (!j->device_output && hipMemcpyAsync(j->rgba, j->dev_rgba, j->stride * (size_t) j->height, hipMemcpyDeviceToHost, slot.stream) != hipSuccess) j->status = E_GPU;
 		slot.launch_err = err;
 		if (hipEventRecord(slot.done, slot.stream) != hipSuccess && !slot.launch_err) slot.launch_err = E_GPU;
 		p->in_flight.push_back(si);
 		t_launch += now_ms() - tb; ++n_launch;
 	}
+	{ std::unique_lock<std::mutex> lock(p->m); for (j40hip_aframe *af : p->garbage) j40hip_aframe_free(af); p->garbage.clear(); }
 	for (Slot &s : p->slots) if (s.batch) { j40hip_abatch_free(s.batch); s.batch = nullptr; }
 	for (LfFlight &fl : p->lf_flights) if (fl.alf) { j40hip_alf_free(fl.alf); fl.alf = nullptr; }
 	for (auto &im : p->free_images) (void) hipFree(im.first);

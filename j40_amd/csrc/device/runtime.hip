@@ -41,7 +41,14 @@ struct DeviceBuffer {
 // Blocks go back to a per-device free list when a frame lets go of them (after a device synchronisation) and are handed
 // out again to requests of similar size. A block remembers whether its coefficient planes are all-zero ("clean": the
 // pixel kernels leave them that way), so a recycled working set needs no 400 MB clear either.
-struct CachedBlock { void *ptr; size_t bytes; bool clean; };
+//
+// hipMalloc itself takes about a millisecond and serialises callers: a pipeline that grows to its 2800 resident frames (11 MB of
+// codestream and LfGroup planes each) spent its first second inside it, the launching thread waiting behind the workers. Requests
+// between 256 KB and 512 MB are therefore rounded up to a size class (eighth-of-a-power-of-two steps) and served from SLABS: one
+// hipMalloc of up to 1 GB carved into blocks of one class. A slab goes back to the device only when all of its blocks are idle.
+struct CachedBlock { void *ptr; size_t bytes; bool clean; int slab; };
+struct Slab { uint8_t *base; size_t block_bytes; int total, idle; };
+std::vector<Slab> g_slabs[16];
 std::mutex g_cache_mutex;
 std::vector<CachedBlock> g_cache[16];
 size_t g_cached_bytes[16];
@@ -61,28 +68,64 @@ size_t cache_limit_bytes() {
 
 } // namespace
 
-// frees every cached block of `device` (they are idle by construction: blocks enter the cache after a device synchronisation)
+// frees every cached block of `device` that can be freed (they are idle by construction: blocks enter the cache after a device
+// synchronisation); the idle blocks of a slab that still has blocks in use stay
 void j40hip_rt::cache_trim(int device) {
 	if (device < 0 || device >= 16) return;
 	std::lock_guard<std::mutex> lock(g_cache_mutex);
-	for (CachedBlock &b : g_cache[device]) (void) hipFree(b.ptr);
-	g_cache[device].clear(); g_cached_bytes[device] = 0;
+	std::vector<CachedBlock> keep;
+	auto &slabs = g_slabs[device];
+	size_t kept = 0;
+	for (CachedBlock &b : g_cache[device]) {
+		if (b.slab < 0) (void) hipFree(b.ptr);
+		else if (slabs[(size_t) b.slab].idle < slabs[(size_t) b.slab].total) { keep.push_back(b); kept += b.bytes; }
+	}
+	for (Slab &sl : slabs) if (sl.base && sl.idle == sl.total) { (void) hipFree(sl.base); sl.base = nullptr; sl.total = sl.idle = 0; }
+	g_cache[device].swap(keep); g_cached_bytes[device] = kept;
+}
+
+static size_t size_class(size_t bytes) {
+	bytes = (bytes + 4095) & ~(size_t) 4095;
+	if (bytes < ((size_t) 256 << 10) || bytes > ((size_t) 512 << 20)) return bytes;
+	size_t top = (size_t) 1 << 18;
+	while (top * 2 <= bytes) top *= 2;
+	const size_t step = top / 8;
+	return (bytes + step - 1) / step * step;
 }
 
 void *j40hip_rt::cache_acquire(int device, size_t bytes, size_t *got, bool *clean) {
-	bytes = (bytes + 4095) & ~(size_t) 4095;
-	if (device >= 0 && device < 16) {
+	bytes = size_class(bytes);
+	const bool cached = device >= 0 && device < 16;
+	if (cached) {
 		std::lock_guard<std::mutex> lock(g_cache_mutex);
 		auto &list = g_cache[device];
-		for (size_t i = 0; i < list.size(); ++i) if (list[i].bytes >= bytes && list[i].bytes <= bytes + bytes / 4) {
+		for (size_t i = list.size(); i-- > 0; ) if (list[i].bytes >= bytes && list[i].bytes <= bytes + bytes / 4) {   // (newest first: the list is a stack)
 			CachedBlock b = list[i];
 			list.erase(list.begin() + (long) i);
 			g_cached_bytes[device] -= b.bytes;
+			if (b.slab >= 0) --g_slabs[device][(size_t) b.slab].idle;
 			*got = b.bytes; *clean = b.clean;
 			return b.ptr;
 		}
 	}
 	void *p = nullptr;
+	if (cached && bytes >= ((size_t) 256 << 10) && bytes <= ((size_t) 512 << 20)) {   // a slab of this class
+		const int n = (int) std::max<size_t>(2, std::min<size_t>(64, ((size_t) 1 << 30) / bytes));
+		if (hipMalloc(&p, bytes * (size_t) n) == hipSuccess) {
+			std::lock_guard<std::mutex> lock(g_cache_mutex);
+			auto &slabs = g_slabs[device];
+			size_t si = 0;
+			while (si < slabs.size() && slabs[si].base) ++si;
+			if (si == slabs.size()) slabs.push_back(Slab{});
+			slabs[si] = Slab{(uint8_t *) p, bytes, n, n - 1};
+			for (int i = 1; i < n; ++i) g_cache[device].push_back({(uint8_t *) p + (size_t) i * bytes, bytes, false, (int) si});
+			g_cached_bytes[device] += bytes * (size_t) (n - 1);
+			*got = bytes; *clean = false;
+			return p;
+		}
+		(void) hipGetLastError();
+		p = nullptr;
+	}
 	if (hipMalloc(&p, bytes) != hipSuccess) {
 		// out of device memory while blocks sit idle in the cache: give them back and try once more
 		(void) hipGetLastError();
@@ -97,8 +140,26 @@ void j40hip_rt::cache_release(int device, void *ptr, size_t bytes, bool clean) {
 	if (!ptr) return;
 	if (device >= 0 && device < 16) {
 		std::lock_guard<std::mutex> lock(g_cache_mutex);
+		auto &slabs = g_slabs[device];
+		for (size_t si = 0; si < slabs.size(); ++si) {
+			Slab &sl = slabs[si];
+			if (!sl.base || (uint8_t *) ptr < sl.base || (uint8_t *) ptr >= sl.base + sl.block_bytes * (size_t) sl.total) continue;
+			// a slab's block: it can only stay (or the whole slab go, once all of it is idle and the cache is over its limit)
+			g_cache[device].push_back({ptr, sl.block_bytes, clean, (int) si});
+			g_cached_bytes[device] += sl.block_bytes;
+			if (++sl.idle == sl.total && g_cached_bytes[device] > cache_limit_bytes()) {
+				auto &list = g_cache[device];
+				size_t w = 0;
+				for (size_t i = 0; i < list.size(); ++i) if (list[i].slab != (int) si) list[w++] = list[i];
+				list.resize(w);
+				g_cached_bytes[device] -= sl.block_bytes * (size_t) sl.total;
+				(void) hipFree(sl.base);
+				sl.base = nullptr; sl.total = sl.idle = 0;
+			}
+			return;
+		}
 		if (g_cached_bytes[device] + bytes <= cache_limit_bytes()) {
-			g_cache[device].push_back({ptr, bytes, clean});
+			g_cache[device].push_back({ptr, bytes, clean, -1});
 			g_cached_bytes[device] += bytes;
 			return;
 		}

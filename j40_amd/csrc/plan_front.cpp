@@ -93,8 +93,10 @@ static bool build_lf_lanes(const Frame &fr, FrontPlan *fp) {
 	}
 	fp->lf_log_alpha = spec.log_alpha_size;
 	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
-	fp->lf_lds_bytes = align16(16u * (uint32_t) fp->lf_tree.size()) + align16((uint32_t) spec.num_dist) + align16(4u * (uint32_t) spec.num_clusters) + 8u * ((uint32_t) spec.num_clusters << spec.log_alpha_size);
-	return fp->lf_lds_bytes <= 60u * 1024u;
+	// (the alias tables stay in global memory unless J40HIP_LF_ALIAS_LDS asks for them in LDS: lf_decode.hip)
+	fp->lf_lds_bytes = align16(16u * (uint32_t) fp->lf_tree.size()) + align16((uint32_t) spec.num_dist) + align16(4u * (uint32_t) spec.num_clusters);
+	static const bool alias_lds = [] { const char *e = getenv("J40HIP_LF_ALIAS_LDS"); return e && atoi(e) != 0; }();
+	return fp->lf_lds_bytes + (alias_lds ? 8u * ((uint32_t) spec.num_clusters << spec.log_alpha_size) : 0u) <= 56u * 1024u;
 }
 
 uint32_t build_front_plan(const Frame &fr, const StaticTables &st, size_t cs_size, const std::vector<int32_t> &extra_prec, bool want_lf_device, FrontPlan *fp) {
