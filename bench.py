@@ -114,7 +114,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=7680)
     ap.add_argument("--height", type=int, default=4320)
     ap.add_argument("--seed", type=int, default=3)
@@ -123,8 +123,8 @@ def main():
     ap.add_argument("--pipe-batch", type=int, default=256, help="frames per entropy launch inside the pipeline")
     ap.add_argument("--host-threads", type=int, default=0, help="pipeline worker threads per GPU (default: the container's CPU quota / GPUs)")
     ap.add_argument("--in-flight", type=int, default=2, help="batches the pipeline keeps in flight on the device")
-    ap.add_argument("--lf-streams", choices=["auto", "device", "host"], default="auto",
-                    help="who decodes the LfGroup streams of the batched frames: the GPU (k_lf_groups), the host worker threads, or decided frame by frame (auto: the host threads keep them while the device has batches queued up)")
+    ap.add_argument("--lf-streams", choices=["auto", "device", "host"], default="device",
+                    help="who decodes the LfGroup streams of the batched frames: the GPU (k_lf_lanes, a lane per section), the host worker threads, or decided frame by frame (auto: the GPU up to its stage's capacity, the host threads beyond)")
     ap.add_argument("--resident-batch", type=int, default=256, help="frames of the device-resident section (kernels only, as round 1 measured)")
     ap.add_argument("--stream", choices=["forward", "coefficient"], default="forward",
                     help="forward: the generator ENCODES a procedural picture at about distance 1 (tools/jxlsynth forward=1); "
@@ -262,7 +262,7 @@ def main():
     if resident_multi is not None:
         result["device_resident"] = resident_multi
     try:
-        pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        pt = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
         if abs(pt.get("frames_per_launch", 0) - frames_per_launch) < 1 and (W, H) == (7680, 4320) and pt.get("stream", "coefficient") == args.stream:
             result["roofline"]["traffic"] = int((pt["fetch_size_kb"] * pt.get("fetch_correction", 1.0) + pt["write_size_kb"]) * 1024)
             result["roofline"]["traffic_source"] = pt["source"]

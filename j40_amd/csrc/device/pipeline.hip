@@ -76,9 +76,14 @@ struct Slot {                     // one batch in flight
 struct j40hip_pipeline {
 	int device = 0, batch_frames = 32, max_in_flight = 2;
 	int lf_mode = 0;                    // LfGroup streams: 0 decided per frame (see above), 1 always the device, 2 always the host threads
-	// mode 0: a frame's LfGroup streams go to the device (k_lf_lanes: a lane per section, a handful of wavefronts per launch that the
-	// other kernels do not notice, 0.3 s a launch) while fewer than lf_cap frames are in that stage; beyond that the host thread that
-	// prepares a frame decodes its streams itself. Both decoders then run flat out, and neither waits for the other.
+	// mode 0: the device decodes a section in 0.4 s and thousands of them at once (k_lf_lanes: a lane per section, a few dozen
+	// wavefronts per launch that the other kernels hardly notice); a host thread decodes a frame's twelve in 12 ms, one frame at a
+	// time. So the device takes the stream of frames, and the host threads decode a frame's sections themselves when
+	//   * the device's stage is full (lf_cap frames), or
+	//   * frames trickle in (less than a quarter batch waiting, nothing in the stage to join): the frame would wait 0.4 s alone.
+	// (Letting the host threads also cover the first 0.4 s of a run -- decode the first batches' sections while the first launch is
+	// out -- was measured: the fronts of the frames behind them are then prepared late and the gap only moves; 215 against 187 ms
+	// a step over 20 steps.)
 	int64_t lf_stage = 0, lf_cap = 0;
 	double lf_pending_since = 0;
 	int64_t lf_device_frames = 0, single_frames = 0;
@@ -190,7 +195,7 @@ void worker_main(j40hip_pipeline *p) {
 			if (p->stop) break;
 			j = p->todo.front(); p->todo.pop_front();
 			++p->resident; ++p->parsing;
-			if (p->lf_mode == 0 && p->lf_stage < p->lf_cap) lf_dev = true;
+			if (p->lf_mode == 0) lf_dev = p->lf_stage < p->lf_cap && !(p->lf_stage == 0 && (int64_t) p->todo.size() < p->batch_frames / 4);
 			if (lf_dev) ++p->lf_stage;
 		}
 		const double t0 = now_ms();
