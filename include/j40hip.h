@@ -267,6 +267,10 @@ J40HIP_API uint32_t j40hip_batch_reset(j40hip_batch *b, j40hip_frame *const *fra
 J40HIP_API uint32_t j40hip_frame_upload_on(j40hip_frame *f, int device, void *stream);
 /* frees the calling thread's pinned staging buffer (call before a thread that uploaded frames exits) */
 J40HIP_API void j40hip_thread_release(void);
+/* Takes the library's process-wide state down: stops and joins its service threads, frees the cached device memory, pooled events
+ * and cached tables. Optional (a process may simply end); nothing of the library may be running, and objects created before must
+ * have been freed. The library can be used again afterwards. */
+J40HIP_API void j40hip_shutdown(void);
 /* j40hip_frame_status in two halves: `begin` enqueues the copy of the status words on `stream`, `end` -- once the caller has waited
  * for that stream -- reduces them to the frame's verdict without touching the device. VarDCT frames without extra channels. */
 J40HIP_API uint32_t j40hip_frame_status_begin(j40hip_frame *f, void *stream);

@@ -40,7 +40,7 @@ struct StaticEntry {
 	~StaticEntry() { if (d_f32 || d_u16) { (void) hipSetDevice(device); if (d_f32) (void) hipFree(d_f32); if (d_u16) (void) hipFree(d_u16); } }
 };
 std::mutex g_static_mutex;
-std::vector<std::shared_ptr<StaticEntry>> g_static;
+std::vector<std::shared_ptr<StaticEntry>> &g_static = *new std::vector<std::shared_ptr<StaticEntry>>();   // (on the heap: no hipFree from a static destructor at process exit; j40hip_shutdown empties it)
 uint64_t g_static_clock = 0;
 
 std::shared_ptr<StaticEntry> static_tables_for(const Frame &fr, int device) {
@@ -107,6 +107,16 @@ hipEvent_t event_acquire() {
 	return e;
 }
 void event_release(hipEvent_t e) { if (e) { std::lock_guard<std::mutex> lock(g_event_mutex); g_event_pool.push_back(e); } }
+
+} // namespace
+// j40hip_shutdown's share of this file: the table cache and the event pool (nothing of the library may be running)
+void j40hip_async_shutdown(void) {
+	{ std::lock_guard<std::mutex> lock(g_static_mutex); g_static.clear(); }
+	std::lock_guard<std::mutex> lock(g_event_mutex);
+	for (hipEvent_t e : g_event_pool) (void) hipEventDestroy(e);
+	g_event_pool.clear();
+}
+namespace {
 
 struct Layout {
 	size_t size = 0;

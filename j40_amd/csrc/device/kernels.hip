@@ -6,7 +6,8 @@
 //                       NB varblocks per workgroup (replaces j40__dequant_hf, j40.h:7053,
 //                       j40__combine_vardct_from_lf_group, j40.h:7099, j40__render_to_u8x4_rgba, j40.h:7910)
 //   k_vardct_special    K2s: the 8x8 "special" transforms (Hornuss, DCT2x2, DCT4x4, DCT4x8/8x4, AFV)
-//   k_vardct_large      K2l: 128/256-sized transforms, butterflies swept through an HBM scratch
+//   k_vardct_large      K2l: 128/256-sized transforms: the tile in an HBM scratch, the 1-D transforms taken through LDS a panel of
+//                       vectors at a time (idct_panels)
 //
 // Compiled with -ffp-contract=off: the float path has to keep the reference's operation order.
 #include <hip/hip_runtime.h>
@@ -553,17 +554,18 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const 
 // are swept over an HBM scratch (two ping-pong buffers per channel), one __syncthreads per level.
 // Same arithmetic as the recursion: depth d works on sub-vectors of length N >> d (j40.h:5802-5841).
 
-__device__ void idct_sweeps(float *A, float *B, int32_t t, int32_t ncols, int32_t stride_k, int32_t stride_col) {
+template <class Ptr>   // float * (HBM scratch) or J40_LDS float * (a panel in LDS, idct_panels)
+__device__ void idct_sweeps(Ptr A, Ptr B, int32_t t, int32_t ncols, int32_t stride_k, int32_t stride_col) {
 	// on return the result is in B (A is clobbered); A = input
 	const int32_t N = 1 << t, half = N >> 1;
 	const int32_t tid = threadIdx.x, nthreads = blockDim.x;
 	if (t == 0) { for (int32_t w = tid; w < ncols; w += nthreads) B[w * stride_col] = A[w * stride_col]; __syncthreads(); return; }
 	for (int32_t d = 0; d <= t - 2; ++d) {  // downward: split even / odd
-		const float *src = (d & 1) ? B : A; float *dst = (d & 1) ? A : B;
+		const Ptr src = (d & 1) ? B : A; const Ptr dst = (d & 1) ? A : B;
 		const int32_t n = N >> d, hn = n >> 1;
 		for (int32_t w = tid; w < ncols * half; w += nthreads) {
 			const int32_t col = w % ncols, j = w / ncols, o = (j / hn) * n, i = j % hn;
-			const float *s = src + col * stride_col; float *q = dst + col * stride_col;
+			const Ptr s = src + col * stride_col; const Ptr q = dst + col * stride_col;
 			q[(o + i) * stride_k] = s[(o + 2 * i) * stride_k];
 			q[(o + hn + i) * stride_k] = i == 0 ? J40_SQRT2F * s[(o + 1) * stride_k] : s[(o + 2 * i - 1) * stride_k] + s[(o + 2 * i + 1) * stride_k];
 		}
@@ -571,7 +573,7 @@ __device__ void idct_sweeps(float *A, float *B, int32_t t, int32_t ncols, int32_
 	}
 	{   // length-2 tails at depth t - 1
 		const int32_t d = t - 1;
-		const float *src = (d & 1) ? B : A; float *dst = (d & 1) ? A : B;
+		const Ptr src = (d & 1) ? B : A; const Ptr dst = (d & 1) ? A : B;
 		for (int32_t w = tid; w < ncols * half; w += nthreads) {
 			const int32_t col = w % ncols, o = (w / ncols) * 2;
 			const float p = src[col * stride_col + o * stride_k], q = src[col * stride_col + (o + 1) * stride_k];
@@ -581,11 +583,11 @@ __device__ void idct_sweeps(float *A, float *B, int32_t t, int32_t ncols, int32_
 		__syncthreads();
 	}
 	for (int32_t d = t - 2; d >= 0; --d) {  // upward: combine halves
-		const float *src = (d & 1) ? B : A; float *dst = (d & 1) ? A : B;
+		const Ptr src = (d & 1) ? B : A; const Ptr dst = (d & 1) ? A : B;
 		const int32_t n = N >> d, hn = n >> 1;
 		for (int32_t w = tid; w < ncols * half; w += nthreads) {
 			const int32_t col = w % ncols, j = w / ncols, o = (j / hn) * n, i = j % hn;
-			const float *s = src + col * stride_col; float *q = dst + col * stride_col;
+			const Ptr s = src + col * stride_col; const Ptr q = dst + col * stride_col;
 			const float x = s[(o + i) * stride_k], y = s[(o + hn + i) * stride_k];
 			const float m = c_half_secants[hn + i];
 			const float ym = y * m;
@@ -596,12 +598,36 @@ __device__ void idct_sweeps(float *A, float *B, int32_t t, int32_t ncols, int32_
 	}
 }
 
+// The same sweeps with the vectors in LDS: the 1-D transforms of `nvec` vectors of length N = 1 << t (element k of vector v at
+// src[v * stride_col + k * stride_k]; one of the two strides is 1) are taken through LDS a PANEL of M vectors at a time, N * M <=
+// 16384 floats, both ping-pong buffers of the sweeps in LDS (2 * (16384 + 256) floats: the panel's rows are M + 1 apart so that
+// the transposing copy does not hit one bank). The result goes to dst, same layout; src is left alone. Every value takes the same
+// operations in the same order as in idct_sweeps over the HBM scratch (15 levels of 256-point butterflies = 15 round trips through
+// HBM per dimension there, one here).
+constexpr int LARGE_PANEL_FLOATS = 16384 + 256;
+__device__ void idct_panels(const float *src, float *dst, int32_t t, int32_t nvec, int32_t stride_k, int32_t stride_col, J40_LDS float *lds) {
+	const int32_t N = 1 << t, M = min(nvec, 16384 >> t), P = M + 1;
+	const int32_t tid = threadIdx.x, nthreads = blockDim.x;
+	J40_LDS float *la = lds, *lb = lds + LARGE_PANEL_FLOATS;
+	for (int32_t v0 = 0; v0 < nvec; v0 += M) {
+		if (stride_k == 1) for (int32_t w = tid; w < N * M; w += nthreads) { const int32_t m = w >> t, k = w & (N - 1); la[k * P + m] = src[(size_t) (v0 + m) * stride_col + k]; }
+		else for (int32_t w = tid; w < N * M; w += nthreads) { const int32_t k = w / M, m = w - k * M; la[k * P + m] = src[(size_t) k * stride_k + v0 + m]; }
+		__syncthreads();
+		idct_sweeps(la, lb, t, M, P, 1);   // result in lb
+		if (stride_k == 1) for (int32_t w = tid; w < N * M; w += nthreads) { const int32_t m = w >> t, k = w & (N - 1); dst[(size_t) (v0 + m) * stride_col + k] = lb[k * P + m]; }
+		else for (int32_t w = tid; w < N * M; w += nthreads) { const int32_t k = w / M, m = w - k * M; dst[(size_t) k * stride_k + v0 + m] = lb[k * P + m]; }
+		__syncthreads();
+	}
+}
+
 template <bool BATCH>
 __global__ void __launch_bounds__(256) k_vardct_large(DevPlan plan_arg, const DevVarblock *list, int32_t count, float *scratch, uint8_t *rgba, size_t stride_bytes, const K2Frame *batch, const int32_t *tile_prefix, int32_t nframes,
 		int32_t class_a, int32_t class_b) {
 	const int32_t tid = threadIdx.x, nthreads = blockDim.x;
 	J40_STAGE_SRGB_THRESHOLDS(f);
 	float *A = scratch + (size_t) blockIdx.x * 6 * 65536, *B = A + 3 * 65536;  // [3][size] each: the workgroup's own
+	extern __shared__ __attribute__((aligned(16))) float large_lds[];   // 2 * LARGE_PANEL_FLOATS (idct_panels)
+	J40_LDS float *panels = (J40_LDS float *) large_lds;
 	for (K2Iter it = k2_begin<BATCH>(tile_prefix, nframes); ; ) {
 		int32_t frame, first;
 		if (!k2_bind<BATCH>(it, batch, tile_prefix, class_a, class_b, 1, list, count, rgba, stride_bytes, frame, first)) break;
@@ -634,9 +660,11 @@ __global__ void __launch_bounds__(256) k_vardct_large(DevPlan plan_arg, const De
 		}
 		__syncthreads();
 		for (int ch = 0; ch < 3; ++ch) {
-			idct_sweeps(A + ch * 65536, B + ch * 65536, log_columns, R, 1, C);   // along c for every r: A -> B
-			idct_sweeps(B + ch * 65536, A + ch * 65536, log_rows, C, C, 1);      // along r for every x: B -> A
+			idct_panels(A + ch * 65536, B + ch * 65536, log_columns, R, 1, C, panels);   // along c for every r: A -> B
+			__threadfence_block(); __syncthreads();
+			idct_panels(B + ch * 65536, A + ch * 65536, log_rows, C, C, 1, panels);      // along r for every x: B -> A
 		}
+		__threadfence_block(); __syncthreads();
 		for (int32_t i = tid; i < size; i += nthreads) {
 			const int32_t y = i / C, x = i - y * C;
 			if (y >= g.effh || x >= g.effw) continue;
@@ -717,8 +745,17 @@ static void launch_vardct_class_impl(const DevPlan &plan, int32_t dctsel, const 
 		else hipLaunchKernelGGL((k_vardct_special<32, false>), dim3((unsigned) ((count + 31) / 32)), dim3(256), 0, stream, plan, list, count, rgba, stride, bl.batch, nullptr, 1, 0, 0);
 		break;
 	default:
-		if (bl.batch) hipLaunchKernelGGL(k_vardct_large<true>, dim3((unsigned) bl.grid), dim3(256), 0, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, bl.tile_prefix, bl.nframes, bl.class_a, bl.class_b);
-		else hipLaunchKernelGGL(k_vardct_large<false>, dim3((unsigned) count), dim3(256), 0, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, nullptr, 1, 0, 0);
+		{
+			constexpr size_t lds_bytes = 2 * (size_t) LARGE_PANEL_FLOATS * sizeof(float);
+			static bool configured = false;
+			if (!configured) {
+				(void) hipFuncSetAttribute((const void *) k_vardct_large<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
+				(void) hipFuncSetAttribute((const void *) k_vardct_large<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
+				configured = true;
+			}
+			if (bl.batch) hipLaunchKernelGGL(k_vardct_large<true>, dim3((unsigned) bl.grid), dim3(256), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, bl.tile_prefix, bl.nframes, bl.class_a, bl.class_b);
+			else hipLaunchKernelGGL(k_vardct_large<false>, dim3((unsigned) count), dim3(256), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, nullptr, 1, 0, 0);
+		}
 		break;
 	}
 }

@@ -15,6 +15,7 @@
 #include "../plan_build.hpp"
 #include "kernels.h"
 #include "runtime_shared.hpp"
+#include "async.hpp"
 
 using namespace j40hip;
 using namespace j40hip_rt;
@@ -486,17 +487,19 @@ struct LfService {
 	std::mutex m;
 	std::condition_variable cv_work, cv_done;
 	std::deque<LfRequest *> pending;
-	bool started = false;
+	bool started = false, stop = false;
 	int device = 0;
+	std::thread thread;
 };
-// (never destroyed: the service threads are detached and sleep on these condition variables for the life of the process; running
-// their destructors at exit with a thread still waiting is undefined behaviour -- it hung interpreters at shutdown)
+// The services live on the heap and are taken down by j40hip_shutdown only (which stops and JOINS their threads): a process that
+// never calls it leaves them asleep on their condition variables until it ends, and no destructor of a static object runs with a
+// thread still waiting on it (that was undefined behaviour, and hung interpreters at exit).
+std::mutex g_lf_service_mutex;
+LfService *g_lf_services[16] = {nullptr};
 LfService *lf_service(int device) {
-	static std::mutex create;
-	static LfService *services[16] = {nullptr};
-	std::lock_guard<std::mutex> lock(create);
-	if (!services[device]) services[device] = new LfService();
-	return services[device];
+	std::lock_guard<std::mutex> lock(g_lf_service_mutex);
+	if (!g_lf_services[device]) g_lf_services[device] = new LfService();
+	return g_lf_services[device];
 }
 
 void lf_service_main(LfService *sv) {
@@ -519,7 +522,8 @@ void lf_service_main(LfService *sv) {
 		std::vector<LfRequest *> take;
 		{
 			std::unique_lock<std::mutex> lock(sv->m);
-			sv->cv_work.wait(lock, [&] { return !sv->pending.empty() || !inflight.empty(); });
+			sv->cv_work.wait(lock, [&] { return sv->stop || !sv->pending.empty() || !inflight.empty(); });
+			if (sv->stop && sv->pending.empty() && inflight.empty()) break;
 			if (!sv->pending.empty() && inflight.size() < 2) {
 				if (sv->pending.size() < 24) sv->cv_work.wait_for(lock, std::chrono::milliseconds(3));   // let the other parsing threads catch up: one launch for all
 				while (!sv->pending.empty() && take.size() < 160) { take.push_back(sv->pending.front()); sv->pending.pop_front(); }
@@ -553,6 +557,12 @@ void lf_service_main(LfService *sv) {
 			for (LfRequest *r : fl.reqs) { r->done = true; r->ok = ok; }
 			sv->cv_done.notify_all();
 		}
+	}
+	for (int i = 0; i < 2; ++i) {
+		if (stream[i]) { (void) hipStreamSynchronize(stream[i]); (void) hipStreamDestroy(stream[i]); }
+		if (done[i]) (void) hipEventDestroy(done[i]);
+		if (dev_tasks[i]) (void) hipFree(dev_tasks[i]);
+		host_tasks[i].release();
 	}
 }
 
@@ -603,7 +613,7 @@ static bool lf_device_decode(void *ctx_, const Frame &f, const uint8_t *cs, size
 		}
 		LfService &sv = *lf_service(ctx.device);
 		std::unique_lock<std::mutex> lock(sv.m);
-		if (!sv.started) { sv.started = true; sv.device = ctx.device; std::thread(lf_service_main, &sv).detach(); }
+		if (!sv.started) { sv.started = true; sv.device = ctx.device; sv.thread = std::thread(lf_service_main, &sv); }
 		sv.pending.push_back(&req);
 		sv.cv_work.notify_all();
 		sv.cv_done.wait(lock, [&] { return req.done; });
@@ -1236,6 +1246,23 @@ extern "C" j40hip_batch *j40hip_batch_create(j40hip_frame *const *frames, int64_
 	try { return batch_create_body(frames, n, err); } catch (const std::exception &) { if (err) *err = ERR_MEM; return nullptr; }
 }
 extern "C" uint32_t j40hip_frame_upload_on(j40hip_frame *h, int device, void *stream) { return guarded([&] { return upload_impl(h, device, (hipStream_t) stream); }); }
+// Takes the library's process-wide state down: stops and joins the LfGroup service threads, gives the cached device memory back.
+// No other call into the library may be running or follow on objects created before. Optional: a process may also just end.
+extern "C" void j40hip_shutdown(void) {
+	std::vector<LfService *> services;
+	{ std::lock_guard<std::mutex> lock(g_lf_service_mutex); for (LfService *&sv : g_lf_services) if (sv) { services.push_back(sv); sv = nullptr; } }
+	for (LfService *sv : services) {
+		{ std::lock_guard<std::mutex> lock(sv->m); sv->stop = true; }
+		sv->cv_work.notify_all();
+		if (sv->thread.joinable()) sv->thread.join();
+		delete sv;
+	}
+	j40hip_async_shutdown();
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) { (void) hipGetLastError(); n = 0; }
+	for (int d = 0; d < n && d < 16; ++d) if (hipSetDevice(d) == hipSuccess) { (void) hipDeviceSynchronize(); cache_trim(d); }
+	j40hip_thread_release();
+}
 extern "C" void j40hip_thread_release(void) { t_stage.release(); t_lf_out.release(); if (t_lf_done) { (void) hipEventDestroy(t_lf_done); t_lf_done = nullptr; } t_host_plan = HostPlan(); }
 
 // j40hip_frame_status in two halves for pipelines: `begin` enqueues the copy of the status words on `stream` (no host wait),

@@ -743,6 +743,33 @@ static void rct_pixel(int32_t type7, int16_t *q0, int16_t *q1, int16_t *q2) {
 
 /* undoes `trs` last to first on the image planes[0 .. *np) (j40__inverse_transform, j40.h:4506): the frame, or the sub-image of a
  * section with a palette of its own. wpb: the weighted predictor parameters of that image's header. */
+/* the Squeeze transform's "tendency" (ISO 18181-1): from the previous output sample B, the current average a and the next average n;
+ * non-zero on monotone runs only, clamped so that both samples of the pair stay between their neighbours. Division truncates. */
+static int32_t osq_tendency(int32_t B, int32_t a, int32_t n) {
+	int32_t diff = 0;
+	if (B >= a && a >= n) {
+		diff = (4 * B - 3 * n - a + 6) / 12;
+		if (diff - (diff & 1) > 2 * (B - a)) diff = 2 * (B - a) + 1;
+		if (diff + (diff & 1) > 2 * (a - n)) diff = 2 * (a - n);
+	} else if (B <= a && a <= n) {
+		diff = (4 * B - 3 * n - a - 6) / 12;
+		if (diff + (diff & 1) < 2 * (B - a)) diff = 2 * (B - a) - 1;
+		if (diff - (diff & 1) < 2 * (a - n)) diff = 2 * (a - n);
+	}
+	return diff;
+}
+/* known-answer hooks (tests/test_squeeze.py): the tendency, and one line of n_avg averages and n_res residuals joined */
+ORACLE_API int32_t oracle_kat_squeeze_tendency(int32_t B, int32_t a, int32_t n) { return osq_tendency(B, a, n); }
+ORACLE_API void oracle_kat_unsqueeze_line(const int16_t *avg, int32_t n_avg, const int16_t *res, int32_t n_res, int16_t *out) {
+	int32_t k, left = 0;
+	for (k = 0; k < n_res; ++k) {
+		int32_t a = avg[k], next = k + 1 < n_avg ? avg[k + 1] : a, B = k > 0 ? left : a, diff = osq_tendency(B, a, next) + res[k], A = a + diff / 2;
+		out[2 * k] = (int16_t) A; out[2 * k + 1] = (int16_t) (A - diff);
+		left = (int16_t) (A - diff);
+	}
+	if (n_avg > n_res) out[2 * n_res] = avg[n_res];
+}
+
 static uint32_t undo_transforms(oplane *planes, int32_t *np, const j40hip_transform_view *trs, int32_t ntr, const int8_t *wpb, int32_t bpp) {
 	static const uint8_t PERM[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
 	uint32_t err = 0;
@@ -814,17 +841,8 @@ static uint32_t undo_transforms(oplane *planes, int32_t *np, const j40hip_transf
 					#define SQ_AT(pl, k) ((pl)->px[tr->horizontal ? (size_t) line * (size_t) (pl)->w + (size_t) (k) : (size_t) (k) * (size_t) (pl)->w + (size_t) line])
 					int32_t left = 0;
 					for (kk = 0; kk < n_res; ++kk) {
-						int32_t a = SQ_AT(avg, kk), next = kk + 1 < n_avg ? SQ_AT(avg, kk + 1) : a, B = kk > 0 ? left : a, diff = 0, A;
-						if (B >= a && a >= next) {
-							diff = (4 * B - 3 * next - a + 6) / 12;
-							if (diff - (diff & 1) > 2 * (B - a)) diff = 2 * (B - a) + 1;
-							if (diff + (diff & 1) > 2 * (a - next)) diff = 2 * (a - next);
-						} else if (B <= a && a <= next) {
-							diff = (4 * B - 3 * next - a - 6) / 12;
-							if (diff + (diff & 1) < 2 * (B - a)) diff = 2 * (B - a) - 1;
-							if (diff - (diff & 1) < 2 * (a - next)) diff = 2 * (a - next);
-						}
-						diff += SQ_AT(res, kk);
+						int32_t a = SQ_AT(avg, kk), next = kk + 1 < n_avg ? SQ_AT(avg, kk + 1) : a, B = kk > 0 ? left : a, diff, A;
+						diff = osq_tendency(B, a, next) + SQ_AT(res, kk);
 						A = a + diff / 2;
 						SQ_AT(&out, 2 * kk) = (int16_t) A; SQ_AT(&out, 2 * kk + 1) = (int16_t) (A - diff);
 						left = (int16_t) (A - diff);

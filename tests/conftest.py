@@ -12,13 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
-def pytest_unconfigure(config):
-    # The run is over and reported. If tearing the process down wedges (device runtimes unload with helper threads around), let
-    # the kernel end it after three minutes rather than hang whoever waits for it: SIGALRM's default action terminates.
-    import signal
-    if hasattr(signal, "alarm"):
-        signal.signal(signal.SIGALRM, signal.SIG_DFL)
-        signal.alarm(180)
+def pytest_sessionfinish(session, exitstatus):
+    # the library's service threads are joined and its device memory handed back before the interpreter unloads the HIP runtime
+    # (j40hip_shutdown); nothing else is needed for a clean exit
+    import gc
+    gc.collect()
+    try:
+        import j40_amd
+        j40_amd.shutdown()
+    except Exception:
+        pass
 
 
 def pytest_collection_modifyitems(config, items):

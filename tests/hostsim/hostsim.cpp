@@ -748,3 +748,9 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_lanes_check
 	}
 	return 0;
 }
+
+// ---- known-answer hooks for the inverse Squeeze step (device/squeeze_dev.h), tests/test_squeeze.py ----
+extern "C" __attribute__((visibility("default"))) int32_t hostsim_squeeze_tendency(int32_t B, int32_t a, int32_t n) { return squeeze_tendency(B, a, n); }
+extern "C" __attribute__((visibility("default"))) void hostsim_unsqueeze_line(const int16_t *avg, int32_t n_avg, const int16_t *res, int32_t n_res, int16_t *out) {
+	unsqueeze_line(avg, 1, res, 1, n_avg, n_res, out, 1);
+}

@@ -129,3 +129,72 @@ def test_config4_16384_squeeze_and_rct_round_trip(built, ref):
     t = torch.from_numpy(tile).to("cuda:0")
     assert bool((out.view(16, 1024, 16, 1024, 4) == t.view(1, 1024, 1, 1024, 4)).all())
     fr.close()
+
+
+# ---- known answers, worked out by hand from the standard's formulas (ISO 18181-1, Squeeze: tendency and the pair rule) ----
+# PARITY UNPINNED against libjxl all the same: these pin the arithmetic to the text of the standard as read here, the round trips
+# above pin the transform as a whole to the generator's independent forward step.
+TENDENCY_KAT = [
+    # (B, a, n) -> X
+    ((10, 10, 10), 0),     # (40 - 30 - 10 + 6) / 12 = 0
+    ((20, 14, 2), 5),      # 66 / 12 = 5; 5 - 1 = 4 <= 12; 5 + 1 = 6 <= 24
+    ((20, 19, 0), 3),      # 67 / 12 = 5; 5 - 1 = 4 > 2 (B - a) = 2 -> 2 * 1 + 1 = 3; 3 + 1 <= 38
+    ((40, 12, 11), 2),     # 121 / 12 = 10; 10 <= 56; 10 > 2 (a - n) = 2 -> 2
+    ((10, 10, 4), 1),      # 24 / 12 = 2; 2 > 0 -> 2 * 0 + 1 = 1; 1 + 1 <= 12
+    ((2, 14, 20), -6),     # rising: (8 - 60 - 14 - 6) / 12 = -6; -6 >= -24; -6 >= -12
+    ((0, 1, 20), -3),      # -67 / 12 = -5 (towards zero); -5 + 1 = -4 < 2 (B - a) = -2 -> -3; -3 - 1 = -4 >= -38
+    ((0, 19, 20), -2),     # -85 / 12 = -7; -7 + 1 = -6 >= -38; -7 - 1 = -8 < 2 (a - n) = -2 -> -2
+    ((10, 10, 14), -1),    # rising with B = a: (40 - 42 - 10 - 6) / 12 = -18 / 12 = -1; -1 + 1 = 0 >= 0; -1 - 1 = -2 >= -8
+    ((5, 9, 3), 0),        # not monotone
+    ((9, 5, 8), 0),
+]
+LINE_KAT = [
+    # (averages, residuals) -> samples
+    (([10], [0]), [10, 10]),
+    (([10], [3]), [11, 8]),                         # diff 3: A = 10 + 1; forward check: (11 + 8 + 1) >> 1 = 10, 11 - 8 = 3
+    (([10], [-3]), [9, 12]),                        # diff -3: A = 10 + (-3 / 2 = -1)
+    (([10, 14, 2], [3, 1, -2]), [11, 9, 14, 13, 1, 3]),
+    #   k = 0: left = 10, next = 14: tendency -1, diff 2, A = 11 -> 11, 9
+    #   k = 1: left = 9, a = 14, next = 2: not monotone, diff 1, A = 14 -> 14, 13
+    #   k = 2: left = 13, a = 2, next = 2 (last): 50 / 12 = 4 > 2 (a - n) = 0 -> 0; diff -2, A = 2 - 1 -> 1, 3
+    (([10, 14, 2], [3, 1]), [11, 9, 14, 13, 2]),   # one residual fewer: the last average passes through
+    (([32767], [2]), [-32768, 32766]),             # 16-bit buffers wrap (j40.h:3169)
+    (([14], [1]), [14, 13]),
+]
+
+
+def test_squeeze_known_answers_from_the_standards_formulas(built):
+    S = C.CDLL(os.path.join(ROOT, "build", "libhostsim.so"))
+    D = C.CDLL(os.path.join(ROOT, "build", "liboracle_driver.so"))
+    for lib, prefix in ((S, "hostsim_"), (D, "oracle_kat_")):
+        tend = getattr(lib, prefix + "squeeze_tendency")
+        tend.restype = C.c_int32
+        tend.argtypes = [C.c_int32] * 3
+        line = getattr(lib, prefix + "unsqueeze_line")
+        line.restype = None
+        line.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+        for (B, a, n), want in TENDENCY_KAT:
+            assert tend(B, a, n) == want, (prefix, B, a, n)
+        for (avg, res), want in LINE_KAT:
+            av, rs = np.array(avg, dtype=np.int16), np.array(res + [0], dtype=np.int16)
+            out = np.zeros(len(avg) + len(res), dtype=np.int16)
+            line(av.ctypes.data, len(avg), rs.ctypes.data, len(res), out.ctypes.data)
+            assert out.tolist() == want, (prefix, avg, res)
+    # the pair rule is the forward rule's inverse: avg = (A + B + (A > B)) >> 1, residual = A - B - tendency
+    tend = S.hostsim_squeeze_tendency
+    line = S.hostsim_unsqueeze_line
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        n = int(rng.integers(2, 40))
+        px = rng.integers(-300, 300, size=n).astype(np.int64)
+        n_avg, n_res = (n + 1) // 2, n // 2
+        avg = [int((px[2 * k] + px[2 * k + 1] + (1 if px[2 * k] > px[2 * k + 1] else 0)) >> 1) if 2 * k + 1 < n else int(px[2 * k]) for k in range(n_avg)]
+        res = []
+        for k in range(n_res):
+            left = int(px[2 * k - 1]) if k > 0 else avg[k]
+            nxt = avg[k + 1] if k + 1 < n_avg else avg[k]
+            res.append(int(px[2 * k] - px[2 * k + 1]) - tend(left, avg[k], nxt))
+        av, rs = np.array(avg, dtype=np.int16), np.array(res + [0], dtype=np.int16)
+        out = np.zeros(n, dtype=np.int16)
+        line(av.ctypes.data, n_avg, rs.ctypes.data, n_res, out.ctypes.data)
+        assert out.tolist() == px.tolist()
