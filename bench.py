@@ -129,7 +129,8 @@ def main():
     ap.add_argument("--stream", choices=["forward", "coefficient"], default="forward",
                     help="forward: the generator ENCODES a procedural picture at about distance 1 (tools/jxlsynth forward=1); "
                          "coefficient: the coefficient-domain synthetic stream rounds 1 and 2 were tuned on")
-    ap.add_argument("--shard-groups", action="store_true")
+    ap.add_argument("--shard-groups", action="store_true", help="single-frame mode: ONE frame per step, its pass groups split over the ranks (j40_amd.sharding)")
+    ap.add_argument("--shard-kind", choices=["vardct", "modular"], default="vardct", help="--shard-groups: a VarDCT frame, or a Modular lossless frame (RCT only; e.g. --width 16384 --height 16384 = BASELINE config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-sections", action="store_true", help="only the timed pipeline (no device-resident / latency / other-config sections)")
     ap.add_argument("--skip-modular", action="store_true", help="leave BASELINE config 4 (16384 x 16384 Modular) out of `configs`")
@@ -165,6 +166,8 @@ def main():
         dist.barrier()
     if args.shard_groups:
         from streams import synth
+        if args.shard_kind == "modular":
+            return bench_sharded(args, torch, j40_amd, dist, dev, rank, local_rank, world, synth("modular", args.width, args.height, args.seed, tree=1, repeat=1 if args.width * args.height <= (1 << 24) else 16))
         return bench_sharded(args, torch, j40_amd, dist, dev, rank, local_rank, world, synth("vardct", args.width, args.height, args.seed, **({"forward": 1} if args.stream == "forward" else {})))
 
     W, H, B = args.width, args.height, args.batch
@@ -442,7 +445,7 @@ def bench_sharded(args, torch, j40_amd, dist, dev, rank, local_rank, world, data
         "metric": METRIC, "value": round(W * H * args.steps / elapsed / 1e6, 2), "unit": "Mpixels/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "one %dx%d VarDCT d1-like synthetic frame per step, pass groups split over %d ranks (contiguous ranges balanced by section bytes), RGBA gathered on rank 0" % (W, H, world),
+        "config": {"workload": "one %dx%d %s synthetic frame per step, pass groups split over %d ranks (contiguous ranges balanced by section bytes), RGBA gathered on rank 0" % (W, H, "Modular lossless (RCT)" if args.shard_kind == "modular" else "VarDCT d1-like", world),
                    "frame_pixels": W * H, "codestream_bytes": len(data), "parallelism": "pass groups x%d" % world}}))
 
 

@@ -51,6 +51,7 @@ void launch_inverse_palette_plain(const int16_t *idx, const int16_t *palrow, int
 void launch_inverse_palette_predicted(const int16_t *idx, const int16_t *pal, int32_t pal_stride, int16_t *const *dst_dev, int32_t num_c, int32_t width, int32_t height,
 		int32_t nb_colours, int32_t nb_deltas, int32_t d_pred, int32_t bpp, const int8_t *wpp_dev, int32_t *wp_scratch, uint32_t *status, hipStream_t stream);
 void launch_inverse_squeeze(const int16_t *avg, const int16_t *res, int16_t *out, int32_t aw, int32_t ah, int32_t rw, int32_t rh, bool horizontal, hipStream_t stream);
+void launch_pack_planes_rect(const int16_t *r, const int16_t *g, const int16_t *b, const int16_t *a, int32_t plane_width, int32_t x0, int32_t y0, int32_t rw, int32_t rh, int32_t bpp, uint8_t *rgba, size_t stride, hipStream_t stream);
 void launch_pack_planes(const int16_t *r, const int16_t *g, const int16_t *b, const int16_t *a, int32_t width, int32_t height, int32_t bpp, uint8_t *rgba, size_t stride, hipStream_t stream);
 
 } // namespace j40hip

@@ -226,6 +226,16 @@ __global__ void __launch_bounds__(256) k_pack_planes(const int16_t *r, const int
 	}
 }
 
+// the same over one rectangle of the picture (a group range's, sharded decodes): planes are `plane_width` samples wide
+__global__ void __launch_bounds__(256) k_pack_planes_rect(const int16_t *r, const int16_t *g, const int16_t *b, const int16_t *a, int32_t plane_width, int32_t x0, int32_t y0, int32_t rw, int32_t rh, int32_t bpp, uint8_t *rgba, size_t stride_bytes) {
+	const size_t n = (size_t) rw * (size_t) rh;
+	const int32_t opaque = (1 << bpp) - 1;
+	for (size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t) gridDim.x * blockDim.x) {
+		const size_t y = k / (size_t) rw + (size_t) y0, x = k % (size_t) rw + (size_t) x0, i = y * (size_t) plane_width + x;
+		*(uint32_t *) (rgba + y * stride_bytes + x * 4) = pack_rgba8(r[i], g[i], b[i], a ? a[i] : opaque, bpp);
+	}
+}
+
 static unsigned grid_for(size_t n) { size_t b = (n + 255) / 256; return (unsigned) (b < 1 ? 1 : b > 8192 ? 8192 : b); }
 
 // sections [first_section, first_section + num_sections): the passes of a multi-pass frame are launched one after the other
@@ -277,6 +287,11 @@ void launch_inverse_squeeze(const int16_t *avg, const int16_t *res, int16_t *out
 }
 void launch_pack_planes(const int16_t *r, const int16_t *g, const int16_t *b, const int16_t *a, int32_t width, int32_t height, int32_t bpp, uint8_t *rgba, size_t stride, hipStream_t stream) {
 	hipLaunchKernelGGL(k_pack_planes, dim3(grid_for((size_t) width * (size_t) height)), dim3(256), 0, stream, r, g, b, a, width, height, bpp, rgba, stride);
+}
+
+void launch_pack_planes_rect(const int16_t *r, const int16_t *g, const int16_t *b, const int16_t *a, int32_t plane_width, int32_t x0, int32_t y0, int32_t rw, int32_t rh, int32_t bpp, uint8_t *rgba, size_t stride, hipStream_t stream) {
+	if (rw <= 0 || rh <= 0) return;
+	hipLaunchKernelGGL(k_pack_planes_rect, dim3(grid_for((size_t) rw * (size_t) rh)), dim3(256), 0, stream, r, g, b, a, plane_width, x0, y0, rw, rh, bpp, rgba, stride);
 }
 
 } // namespace j40hip

@@ -410,4 +410,20 @@ enum {
 	ERR_EVOF = ('e' << 24) | ('v' << 16) | ('o' << 8) | 'f',   // a section's event region is full: decode the frame with dense planes
 };
 
+// the pixel rectangles {x0, y0, x1, y1} a contiguous range of groups (raster order) covers: at most three -- the tail of its first
+// group row, whole group rows, the head of its last group row (j40_amd/sharding.py range_rectangles is the same arithmetic)
+static inline int group_range_rects(int64_t first, int64_t count, int32_t width, int32_t height, int32_t group_shift, int32_t rects[3][4]) {
+	const int64_t dim = (int64_t) 1 << group_shift, gcols = (width + dim - 1) / dim;
+	int n = 0;
+	for (int64_t g = first, end = first + count; g < end && n < 3; ) {
+		const int64_t row = g / gcols, col = g % gcols;
+		int64_t x0, y0, x1, y1;
+		if (col == 0 && end - g >= gcols) { const int64_t rows = (end - g) / gcols; x0 = 0; y0 = row * dim; x1 = width; y1 = (row + rows) * dim; g += rows * gcols; }
+		else { const int64_t k = (gcols - col < end - g) ? gcols - col : end - g; x0 = col * dim; y0 = row * dim; x1 = (col + k) * dim; y1 = (row + 1) * dim; g += k; }
+		rects[n][0] = (int32_t) x0; rects[n][1] = (int32_t) y0; rects[n][2] = (int32_t) (x1 < width ? x1 : width); rects[n][3] = (int32_t) (y1 < height ? y1 : height);
+		++n;
+	}
+	return n;
+}
+
 } // namespace j40hip

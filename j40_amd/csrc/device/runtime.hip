@@ -450,9 +450,13 @@ static uint32_t decode_modular(j40hip_frame *h, void *rgba_dev, size_t stride_by
 	// LfGlobal's section and the first pass together, then every further pass on its own: a pass rewrites what the one before
 	// it wrote (j40.h:7025-7033), so they must not overlap; the sections' own RCTs only matter for the last pass
 	const int32_t per_pass = st->mod_sections_per_pass, lead = st->mod_sections - per_pass * st->mod_passes;
-	launch_modular_sections(plan, 0, lead + per_pass, st->mod_info, s);
-	for (int32_t p = 1; p < st->mod_passes; ++p) launch_modular_sections(plan, lead + p * per_pass, per_pass, st->mod_info, s);
-	if (st->mod_local_rcts) launch_section_inverse_rcts(plan, lead + (st->mod_passes - 1) * per_pass, per_pass, s);
+	// (sharded decodes, j40hip_frame_set_group_range: LfGlobal's section and this process' groups of every pass)
+	const bool ranged = per_pass > 0 && !(st->first_group == 0 && st->num_groups == (int64_t) per_pass);
+	const int32_t g0 = ranged ? (int32_t) st->first_group : 0, gn = ranged ? (int32_t) st->num_groups : per_pass;
+	if (ranged) { launch_modular_sections(plan, 0, lead, st->mod_info, s); launch_modular_sections(plan, lead + g0, gn, st->mod_info, s); }
+	else launch_modular_sections(plan, 0, lead + per_pass, st->mod_info, s);
+	for (int32_t p = 1; p < st->mod_passes; ++p) launch_modular_sections(plan, lead + p * per_pass + g0, gn, st->mod_info, s);
+	if (st->mod_local_rcts) launch_section_inverse_rcts(plan, lead + (st->mod_passes - 1) * per_pass + g0, gn, s);
 	if (ms3) (void) hipEventRecord(st->ev[2], s);
 	for (const std::vector<j40hip_device_state::ModOp> *ops : {&st->mod_sub_ops, &st->mod_ops}) for (const auto &op : *ops) {
 		if (op.kind == 0) launch_inverse_rct(op.a, op.b, op.c, op.n, op.p0, s);
@@ -461,8 +465,12 @@ static uint32_t decode_modular(j40hip_frame *h, void *rgba_dev, size_t stride_by
 		else if (op.kind == 4) launch_inverse_squeeze(op.src, op.aux, op.a, op.p0, op.p1, op.p2, op.p3, op.p4 != 0, s);
 		else launch_paste_plane(op.src, op.p0, op.p1, op.a, op.p2, s);
 	}
-	launch_pack_planes(st->final_planes[0], st->final_planes[1], st->final_planes[2], st->alpha_channel >= 0 ? st->final_planes[(size_t) st->alpha_channel] : nullptr,
-		fr.fh.width, fr.fh.height, fr.im.bpp, (uint8_t *) rgba_dev, stride_bytes, s);
+	const int16_t *alpha = st->alpha_channel >= 0 ? st->final_planes[(size_t) st->alpha_channel] : nullptr;
+	if (ranged) {   // only this process' pixels are written
+		int32_t rects[3][4];
+		const int nr = group_range_rects(g0, gn, fr.fh.width, fr.fh.height, fr.fh.group_size_shift, rects);
+		for (int k = 0; k < nr; ++k) launch_pack_planes_rect(st->final_planes[0], st->final_planes[1], st->final_planes[2], alpha, fr.fh.width, rects[k][0], rects[k][1], rects[k][2] - rects[k][0], rects[k][3] - rects[k][1], fr.im.bpp, (uint8_t *) rgba_dev, stride_bytes, s);
+	} else launch_pack_planes(st->final_planes[0], st->final_planes[1], st->final_planes[2], alpha, fr.fh.width, fr.fh.height, fr.im.bpp, (uint8_t *) rgba_dev, stride_bytes, s);
 	if (ms3) {
 		(void) hipEventRecord(st->ev[3], s);
 		if (hipEventSynchronize(st->ev[3]) != hipSuccess) return ERR_GPU;
@@ -771,7 +779,18 @@ static uint32_t j40hip_frame_set_group_range_body(j40hip_frame *h, int64_t first
 	if (!h || !h->dev) return ERR_GPU;
 	if (first_group < 0 || num_groups < 0 || first_group + num_groups > h->frame.fh.num_groups) return ERR_RNGE;
 	j40hip_device_state *st = h->dev;
-	if (st->is_modular) return first_group == 0 && num_groups == h->frame.fh.num_groups ? 0 : ERR_TODO;   // Modular frames are decoded whole
+	if (st->is_modular) {
+		// Modular frames: the groups' sections are independent of each other (no predictor looks across a group's edge), and so are
+		// the per-pixel inverse transforms (RCT, plain palette); a palette with predicted deltas or a Squeeze step reads across
+		// groups, and frames coded with Squeeze have no one-section-per-group layout at all: those are decoded whole
+		const bool whole = first_group == 0 && num_groups == h->frame.fh.num_groups;
+		if (!whole) {
+			if (st->mod_sections_per_pass != (int32_t) h->frame.fh.num_groups) return ERR_TODO;
+			for (const auto &op : st->mod_ops) if (op.kind == 2 || op.kind == 4) return ERR_TODO;
+		}
+		st->first_group = first_group; st->num_groups = num_groups;
+		return 0;
+	}
 	st->first_group = first_group; st->num_groups = num_groups;
 	if (first_group == 0 && num_groups == h->frame.fh.num_groups) return 0;
 	// varblocks never straddle a group (the largest transform is one group wide), so the pixel kernels' work lists are

@@ -72,6 +72,9 @@ void idct_cols_dyn(float *t, int n, int cols, int pitch, const float *hs) {
 
 } // namespace
 
+// group range for the next hostsim_decode calls (mirrors j40hip_frame_set_group_range; count < 0: every group)
+static int64_t g_first_group = 0, g_group_count = -1;
+
 // Modular frames: K3 / K4 / K5 device functions with the runtime's orchestration (device/runtime.hip)
 static uint32_t hostsim_decode_modular(const Frame &fr, const uint8_t *cs, size_t cs_size, uint8_t *rgba) {
 	HostModPlan hp;
@@ -100,7 +103,17 @@ static uint32_t hostsim_decode_modular(const Frame &fr, const uint8_t *cs, size_
 	plan.wp_scratch = hp.frame.tree_uses_wp ? wps.data() : nullptr;
 	plan.lz_window = window.empty() ? nullptr : window.data(); plan.lz_window_size = hp.lz_window_size; plan.status = status.data();
 	std::vector<int32_t> ring(3 * ((size_t) hp.frame.max_width + 4) + 8, 0x7fff0000), wperr(10 * (size_t) hp.frame.max_width + 8);
+	// a group range (hostsim_set_group_range, mirrors j40hip_frame_set_group_range for Modular frames): LfGlobal's section and the
+	// range's groups of every pass are decoded, and only the range's rectangles are written
+	const int32_t per_pass = hp.sections_per_pass, lead = hp.frame.num_sections - per_pass * hp.num_passes;
+	const bool ranged = g_group_count >= 0 && !(g_first_group == 0 && g_group_count == (int64_t) fr.fh.num_groups);
+	if (ranged) {
+		if (per_pass != (int32_t) fr.fh.num_groups) return ERR_TODO;
+		for (const Transform &t : hp.transforms) if (t.kind == Transform::SQUEEZE || (t.kind == Transform::PALETTE && t.nb_deltas > 0)) return ERR_TODO;
+	}
+	auto in_range = [&](int32_t sct) { if (!ranged || sct < lead) return true; const int32_t g = (sct - lead) % per_pass; return g >= g_first_group && g < g_first_group + g_group_count; };
 	for (int32_t sct = 0; sct < hp.frame.num_sections; ++sct) {
+		if (!in_range(sct)) continue;
 		if (hp.sections[(size_t) sct].preset_status) { status[(size_t) sct] = hp.sections[(size_t) sct].preset_status; continue; }
 		ModTables mt = mod_tables_in_hbm(plan, sct);
 		mt.rows = ring.data(); mt.rows_width = hp.frame.max_width + 4; mt.wp_errors = wperr.data(); mt.wp_errors_width = hp.frame.max_width;   // as the kernel lays them out in LDS
@@ -113,7 +126,7 @@ static uint32_t hostsim_decode_modular(const Frame &fr, const uint8_t *cs, size_
 		if (status.back()) return status.back();
 	}
 	plan.local_rct = hp.local_rct.data();
-	for (int32_t sct = 0; sct < hp.frame.num_sections; ++sct) for (int32_t lane = 0; lane < 3; ++lane) section_inverse_rcts(plan, sct, lane, 3);
+	for (int32_t sct = 0; sct < hp.frame.num_sections; ++sct) if (in_range(sct)) for (int32_t lane = 0; lane < 3; ++lane) section_inverse_rcts(plan, sct, lane, 3);
 	static const uint8_t PERM[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
 	std::vector<std::vector<int16_t>> extra;
 	extra.reserve(1024);
@@ -193,15 +206,16 @@ static uint32_t hostsim_decode_modular(const Frame &fr, const uint8_t *cs, size_
 	const int32_t W = hp.frame.width, H = hp.frame.height;
 	if (planes.size() < 3) return ERR_TODO;
 	const int32_t opaque = (1 << fr.im.bpp) - 1;
-	for (size_t i = 0; i < (size_t) W * (size_t) H; ++i) {
+	int32_t rects[3][4] = {{0, 0, W, H}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+	const int nr = ranged ? group_range_rects(g_first_group, g_group_count, W, H, fr.fh.group_size_shift, rects) : 1;
+	for (int k = 0; k < nr; ++k) for (int32_t y = rects[k][1]; y < rects[k][3]; ++y) for (int32_t x = rects[k][0]; x < rects[k][2]; ++x) {
+		const size_t i = (size_t) y * (size_t) W + (size_t) x;
 		const uint32_t px = pack_rgba8(planes[0].p[i], planes[1].p[i], planes[2].p[i], hp.alpha_channel >= 0 ? planes[(size_t) hp.alpha_channel].p[i] : opaque, fr.im.bpp);
 		memcpy(rgba + i * 4, &px, 4);
 	}
 	return 0;
 }
 
-// group range for the next hostsim_decode calls (mirrors j40hip_frame_set_group_range; count < 0: every group)
-static int64_t g_first_group = 0, g_group_count = -1;
 extern "C" __attribute__((visibility("default"))) void hostsim_set_group_range(int64_t first, int64_t count) { g_first_group = first; g_group_count = count; }
 
 // decodes a stream with the device functions on the CPU.
