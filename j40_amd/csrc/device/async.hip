@@ -237,7 +237,7 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	Layout L;
 	const size_t o_cs = L.take(cs_size + 32), o_u8 = L.take(fp.pool_u8.size()), o_i32 = L.take(fp.pool_i32.size() * 4), o_u64 = L.take(fp.pool_u64.size() * 8);
 	const size_t o_cl = L.take(fp.clusters.size() * sizeof(DevCluster)), o_spec = L.take(fp.coeff_specs.size() * sizeof(DevCodeSpec)), o_frame = L.take(sizeof(DevFrame));
-	const size_t o_lfg = L.take(ngg * sizeof(DevLfGroup)), o_sec = L.take(fp.sections.size() * sizeof(DevSection)), o_evr = L.take(fp.ev_range.size() * 4);
+	const size_t o_lfg = L.take(ngg * sizeof(DevLfGroup)), o_sec = L.take(fp.sections.size() * sizeof(DevSection)), o_evr = L.take(fp.ev_range.size() * 4), o_order = L.take(fp.lane_order.size() * 4);
 	const size_t o_lso = L.take(ngg * 4), o_slots = L.take(ngg * sizeof(DevLfSlot));
 	const size_t o_tree = L.take(fp.lf_tree.size() * sizeof(DevTreeNode)), o_alias = L.take(fp.lf_alias.size() * 8), o_lfmap = L.take(fp.lf_ctx_map.size()),
 		o_lfcfg = L.take(fp.lf_cfg.size() * 4), o_tasks = L.take(ngg * sizeof(DevLfTask));   // (empty without the device decoder's tables)
@@ -264,7 +264,7 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	put(o_u8, fp.pool_u8.data(), fp.pool_u8.size()); put(o_i32, fp.pool_i32.data(), fp.pool_i32.size() * 4); put(o_u64, fp.pool_u64.data(), fp.pool_u64.size() * 8);
 	put(o_cl, fp.clusters.data(), fp.clusters.size() * sizeof(DevCluster)); put(o_spec, fp.coeff_specs.data(), fp.coeff_specs.size() * sizeof(DevCodeSpec));
 	put(o_frame, &fp.frame, sizeof(DevFrame)); put(o_lfg, fp.lf_groups.data(), ngg * sizeof(DevLfGroup)); put(o_sec, fp.sections.data(), fp.sections.size() * sizeof(DevSection));
-	put(o_evr, fp.ev_range.data(), fp.ev_range.size() * 4); put(o_lso, fp.lf_section_off.data(), ngg * 4);
+	put(o_evr, fp.ev_range.data(), fp.ev_range.size() * 4); put(o_order, fp.lane_order.data(), fp.lane_order.size() * 4); put(o_lso, fp.lf_section_off.data(), ngg * 4);
 	DevLfSlot *slots = (DevLfSlot *) (stg + o_slots);
 	memset(slots, 0, ngg * sizeof(DevLfSlot));
 	const double tp4 = prof_now();
@@ -339,6 +339,8 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	for (int c = 0; c < 3; ++c) plan.lfraw[c] = (const int16_t *) (pb + o_raw[c]);
 	plan.xfromy = (const int16_t *) (pb + o_xfy); plan.bfromy = (const int16_t *) (pb + o_bfy);
 	plan.ev_range = (const uint32_t *) (pb + o_evr);
+	static const bool raster_lanes = [] { const char *e = getenv("J40HIP_K1_RASTER"); return e && atoi(e) != 0; }();   // (the lanes in group order, as before: for comparisons)
+	plan.lane_order = raster_lanes ? nullptr : (const uint32_t *) (pb + o_order);
 
 	DevPlanBuild &bd = af->build;
 	bd = fp.build;
@@ -458,8 +460,13 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 	if (const char *e = getenv("J40HIP_WAVES_PER_WG")) if (lanes_fast) waves_per_wg = std::max(1, std::min(lanes_lds + 8u * HF_LANE_COLS_BYTES > 150u * 1024u ? 4 : 8, atoi(e)));
 	std::vector<HfLaneWork> work;
 	for (int i = 0; i < n; ++i) {
+		const size_t first_entry = work.size();
 		for (int32_t g = 0; g < frames[i]->num_groups; g += 64) work.push_back({i, g, std::min(64, frames[i]->num_groups - g), 0});
 		while (work.size() % (size_t) waves_per_wg) work.push_back({i, 0, 0, 0});   // a workgroup stays on one frame
+		// The lanes take the groups by decreasing section size (DevPlan::lane_order), so a workgroup's wavefronts come longest
+		// first. A workgroup's wavefront w runs on SIMD w % 4: the second half of every workgroup is reversed, which puts the
+		// longest beside the shortest, the second longest beside the second shortest ... -- four SIMDs with about equal work
+		for (size_t a = first_entry; a + (size_t) waves_per_wg <= work.size(); a += (size_t) waves_per_wg) std::reverse(work.begin() + (long) (a + (size_t) waves_per_wg / 2), work.begin() + (long) (a + (size_t) waves_per_wg));
 		HfLaunchInfo info = frames[i]->hf; info.tables_fit_lds = tables_in_lds;
 		generic_lds = std::max(generic_lds, hf_lanes_lds_bytes(info));
 	}

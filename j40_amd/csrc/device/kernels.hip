@@ -228,7 +228,8 @@ __global__ void __launch_bounds__(512) k_hf_lanes(const DevPlan *plans, const Hf
 	const J40_GLOBAL DevPlan &plan = ((const J40_GLOBAL DevPlan *) plans)[w.frame];
 	const J40_GLOBAL DevFrame &df = *(const J40_GLOBAL DevFrame *) plan.frame;
 	const bool active = lane < w.num_groups;
-	const int32_t g = w.first_group + (active ? lane : 0);
+	const J40_GLOBAL uint32_t *lane_order = (const J40_GLOBAL uint32_t *) plan.lane_order;
+	const int32_t slot = w.first_group + (active ? lane : 0), g = lane_order ? (int32_t) lane_order[slot] : slot;
 	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
 	LaneFrame f;
 	f.nb_block_ctx = df.nb_block_ctx; f.num_hf_presets = df.num_hf_presets; f.preset_bits = df.preset_bits; f.check_section_end = df.check_section_end; f.single_declared_end = df.single_declared_end;

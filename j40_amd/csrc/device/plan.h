@@ -152,6 +152,8 @@ struct DevPlan {
 	uint32_t *status;                // [num_passes * num_groups] 4-char codes
 	uint32_t *section_end_bit;       // [num_passes * num_groups] or null: where each section's HF coefficients ended (absolute bit),
 	                                 // written by the latency-form entropy kernel of frames whose sections go on with a Modular sub-image
+	const uint32_t *lane_order;      // [num_groups] or null: the group k_hf_lanes gives its k-th lane -- the groups by decreasing section size, so
+	                                 // that the 64 lanes of a wavefront decode sections of about the same length (null: group k)
 };
 
 // ---- Modular frames ----

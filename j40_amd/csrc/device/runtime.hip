@@ -293,6 +293,7 @@ static uint32_t upload_modular(j40hip_frame *h, int device) {
 	if (uint32_t e = build_modular_plan(h->frame, h->cs, h->cs_size, &hp)) return e;
 	j40hip_device_state *st = new j40hip_device_state();
 	h->dev = st; st->device = device; st->is_modular = true;
+	st->first_group = 0; st->num_groups = h->frame.fh.num_groups;   // (j40hip_frame_set_group_range narrows it)
 	hipStream_t s = nullptr;
 	bool ok = true;
 	DevModPlan &plan = st->mod;

@@ -134,6 +134,19 @@ uint32_t build_front_plan(const Frame &fr, const StaticTables &st, size_t cs_siz
 	fp->lf_smooth = !fr.fh.skip_adapt_lf_smooth;
 	for (int c = 0; c < 3; ++c) fp->inv_m_lf[c] = (float) (fr.global_scale * fr.quant_lf) / fr.m_lf_scaled[c] / 65536.0f;   // j40.h:6497
 	fill_sections(fr, &fp->sections);
+	{   // K1's lanes take the groups by decreasing section size: a wavefront runs as long as its longest section, and 64 sections
+		// picked in raster order always hold one near the frame's longest (1.9 x the mean); 64 neighbours in size end together
+		const int32_t ng = (int32_t) fr.fh.num_groups;
+		std::vector<uint64_t> key((size_t) ng);
+		for (int32_t g = 0; g < ng; ++g) {
+			uint64_t bytes = 0;
+			for (int32_t p = 0; p < fr.fh.num_passes; ++p) bytes += fp->sections[(size_t) p * (size_t) ng + (size_t) g].size;
+			key[(size_t) g] = (std::min<uint64_t>(bytes, 0xffffffffu) << 32) | (uint32_t) (0xffffffffu - (uint32_t) g);   // (ties: the lower group first)
+		}
+		std::sort(key.begin(), key.end(), [](uint64_t a, uint64_t b) { return a > b; });
+		fp->lane_order.resize((size_t) ng);
+		for (int32_t k = 0; k < ng; ++k) fp->lane_order[(size_t) k] = 0xffffffffu - (uint32_t) key[(size_t) k];
+	}
 	const int32_t num_groups = (int32_t) fr.fh.num_groups;
 	df.sparse_coeffs = fr.fh.num_passes == 1;
 	if (!fill_event_ranges(fp->sections, num_groups, df.sparse_coeffs != 0, &fp->ev_range, &fp->ev_capacity)) df.sparse_coeffs = 0;

@@ -37,6 +37,7 @@ struct FrontPlan {
 	std::vector<DevSection> sections;
 	std::vector<uint32_t> ev_range; size_t ev_capacity = 0;
 	std::vector<uint32_t> lf_section_off;
+	std::vector<uint32_t> lane_order;        // DevPlan::lane_order: the groups by decreasing section bytes (summed over the passes)
 	size_t cells = 0, c64s = 0;
 	int32_t max_lf_cells = 0;                // cells of the largest LfGroup
 	HfLaunchInfo hf;
@@ -50,7 +51,7 @@ struct FrontPlan {
 	int32_t lf_log_alpha = 0; uint32_t lf_uses = 0, lf_lds_bytes = 0;
 	void reset() {
 		pool_u8.clear(); pool_i32.clear(); pool_u64.clear(); clusters.clear(); coeff_specs.clear(); lf_groups.clear(); sections.clear(); ev_range.clear();
-		lf_section_off.clear(); lf_alias.clear(); lf_tree.clear(); lf_ctx_map.clear(); lf_cfg.clear(); block_ctx_map_off = 0; ev_capacity = 0; cells = c64s = 0; max_lf_cells = 0; lz_window_size = 0; lf_smooth = lf_device = false;
+		lf_section_off.clear(); lane_order.clear(); lf_alias.clear(); lf_tree.clear(); lf_ctx_map.clear(); lf_cfg.clear(); block_ctx_map_off = 0; ev_capacity = 0; cells = c64s = 0; max_lf_cells = 0; lz_window_size = 0; lf_smooth = lf_device = false;
 	}
 };
 
