@@ -522,7 +522,7 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 	else launch_hf_entropy_lanes(d_plans, d_work, (int32_t) work.size(), tables_in_lds, generic_lds, s);
 	(void) hipEventRecord(b->ev[2], s);
 	int32_t grids[K2_NUM_BATCH_LAUNCHES];
-	static const int32_t k2_wgs = [] { const char *e = getenv("J40HIP_K2_WGS"); return e ? std::max(1, atoi(e)) : 2048; }();
+	static const int32_t k2_wgs = [] { const char *e = getenv("J40HIP_K2_WGS"); return e ? std::max(1, atoi(e)) : 32768; }();
 	k2_batch_grids(b->have_totals ? b->last_totals : nullptr, cells_total, n, k2_wgs, grids);
 	launch_vardct_batch(d_k2, n, (int32_t *) (db + o_tiles), (int32_t *) (db + o_verdict + 16 * (size_t) n), grids, b->large_scratch, s, b->side.data(), (int) b->side.size(), b->fork, b->side_done.data());
 	(void) hipEventRecord(b->ev[3], s);

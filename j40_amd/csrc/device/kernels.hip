@@ -12,6 +12,8 @@
 // Compiled with -ffp-contract=off: the float path has to keep the reference's operation order.
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <cstring>
+#include <cstdlib>
 #include "hf_dev.h"
 #include "hf_lanes_dev.h"
 #include "idct_dev.h"
@@ -725,15 +727,18 @@ static void launch_dct(const DevPlan &plan, const DevVarblock *list, int32_t cou
 	else hipLaunchKernelGGL((k_vardct_dct<LOGR, LOGC, NB, false>), dim3((unsigned) blocks), dim3(256), lds_bytes, stream, plan, list, count, param_idx, order_idx, rgba, stride, bl.batch, nullptr, 1, 0, 0);
 }
 
+// J40HIP_K2_WIDE: bit 0: the batched 8x8 DCT takes 32 blocks per workgroup instead of 16, bit 1: 16x8 / 8x16 take 16 instead of 8 (experiments)
+static int k2_wide() { static const int v = [] { const char *e = getenv("J40HIP_K2_WIDE"); return e ? atoi(e) : 0; }(); return v; }
+
 // list = varblocks of one DctSelect value (of a run of values for the 8x8 specials and for the 128/256-sized transforms)
 static void launch_vardct_class_impl(const DevPlan &plan, int32_t dctsel, const DevVarblock *list, int32_t count, float *large_scratch, uint8_t *rgba, size_t stride, const K2Launch &bl, hipStream_t stream) {
 	if (count <= 0 && !bl.batch) return;
 	switch (dctsel) {
-	case 0: launch_dct<3, 3, 16>(plan, list, count, 0, 0, rgba, stride, bl, stream); break;
+	case 0: if (bl.batch && (k2_wide() & 1)) launch_dct<3, 3, 32>(plan, list, count, 0, 0, rgba, stride, bl, stream); else launch_dct<3, 3, 16>(plan, list, count, 0, 0, rgba, stride, bl, stream); break;
 	case 4: launch_dct<4, 4, 8>(plan, list, count, 4, 2, rgba, stride, bl, stream); break;
 	case 5: launch_dct<5, 5, 2>(plan, list, count, 5, 3, rgba, stride, bl, stream); break;
-	case 6: launch_dct<4, 3, 8>(plan, list, count, 6, 4, rgba, stride, bl, stream); break;
-	case 7: launch_dct<3, 4, 8>(plan, list, count, 6, 4, rgba, stride, bl, stream); break;
+	case 6: if (bl.batch && (k2_wide() & 2)) launch_dct<4, 3, 16>(plan, list, count, 6, 4, rgba, stride, bl, stream); else launch_dct<4, 3, 8>(plan, list, count, 6, 4, rgba, stride, bl, stream); break;
+	case 7: if (bl.batch && (k2_wide() & 2)) launch_dct<3, 4, 16>(plan, list, count, 6, 4, rgba, stride, bl, stream); else launch_dct<3, 4, 8>(plan, list, count, 6, 4, rgba, stride, bl, stream); break;
 	case 8: launch_dct<5, 3, 4>(plan, list, count, 7, 5, rgba, stride, bl, stream); break;
 	case 9: launch_dct<3, 5, 4>(plan, list, count, 7, 5, rgba, stride, bl, stream); break;
 	case 10: launch_dct<5, 4, 4>(plan, list, count, 8, 6, rgba, stride, bl, stream); break;
@@ -799,14 +804,17 @@ void launch_vardct_frame(const DevPlan &plan, const int32_t *class_start, const 
 #define J40_K2_LAUNCH_TABLE {0, 1, 16, 1}, {1, 4, 32, 1}, {12, 18, 32, 1}, {4, 5, 8, 4}, {6, 7, 8, 2}, {7, 8, 8, 2}, {5, 6, 2, 16}, {8, 9, 4, 4}, {9, 10, 4, 4}, {10, 11, 4, 8}, {11, 12, 4, 8}, \
 	{18, 19, 1, 64}, {19, 20, 1, 32}, {20, 21, 1, 32}, {21, 27, 1, 128}
 struct K2BatchLaunch { int16_t a, b, per_wg, min_cells; };
-static const K2BatchLaunch K2_BATCH_LAUNCHES[K2_NUM_BATCH_LAUNCHES] = {J40_K2_LAUNCH_TABLE};
-__device__ static const K2BatchLaunch DEV_K2_BATCH_LAUNCHES[K2_NUM_BATCH_LAUNCHES] = {J40_K2_LAUNCH_TABLE};
+struct K2Table { K2BatchLaunch l[K2_NUM_BATCH_LAUNCHES]; };
+static const K2Table &k2_table() {
+	static const K2Table t = [] { K2Table t = {{J40_K2_LAUNCH_TABLE}}; if (k2_wide() & 1) t.l[0].per_wg = 32; if (k2_wide() & 2) t.l[4].per_wg = t.l[5].per_wg = 16; return t; }();
+	return t;
+}
 
 // tile_prefix[l * (nframes + 1) + f] = tiles of launch l in the frames before f; totals[l] = all of them; one thread per launch
-__global__ void k_k2_tiles(const K2Frame *frames, int32_t nframes, int32_t *tile_prefix, int32_t *totals) {
+__global__ void k_k2_tiles(const K2Frame *frames, int32_t nframes, int32_t *tile_prefix, int32_t *totals, K2Table table) {
 	const int32_t l = threadIdx.x;
 	if (l >= K2_NUM_BATCH_LAUNCHES) return;
-	const int32_t a = DEV_K2_BATCH_LAUNCHES[l].a, b = DEV_K2_BATCH_LAUNCHES[l].b, per = DEV_K2_BATCH_LAUNCHES[l].per_wg;
+	const int32_t a = table.l[l].a, b = table.l[l].b, per = table.l[l].per_wg;
 	int32_t at = 0;
 	int32_t *row = tile_prefix + l * (nframes + 1);
 	for (int32_t f = 0; f < nframes; ++f) {
@@ -825,10 +833,17 @@ __global__ void k_k2_tiles(const K2Frame *frames, int32_t nframes, int32_t *tile
 // still running share it, and a chain's last kernel has the whole machine for its tail. (Fifteen streams with grids in proportion
 // to the classes' work were measured: 176 ms per 256 frames against 81 -- only four kernels ran at a time, each with a fraction of
 // the machine.)
-static const int8_t K2_LAUNCH_STREAM[K2_NUM_BATCH_LAUNCHES] = {0, 1, 1, 2, 3, 3, 2, 3, 3, 3, 3, 2, 2, 2, 2};
+// (the second launch of the specials goes behind the 8x8 DCT: beside the first it made its chain the longest by 15 ms, alone at the
+// end with two workgroups per compute unit. J40HIP_K2_CHAINS=<15 digits>: another assignment, for experiments)
+static const int8_t *k2_launch_stream() {
+	static int8_t chain[K2_NUM_BATCH_LAUNCHES] = {0, 1, 0, 2, 3, 3, 2, 3, 3, 3, 3, 2, 2, 2, 2};
+	static const bool once = [] { const char *e = getenv("J40HIP_K2_CHAINS"); if (e && strlen(e) == K2_NUM_BATCH_LAUNCHES) for (int i = 0; i < K2_NUM_BATCH_LAUNCHES; ++i) chain[i] = (int8_t) ((e[i] - '0') & 3); return true; }();
+	(void) once;
+	return chain;
+}
 void k2_batch_grids(const int32_t *last_totals, size_t cells_total, int32_t nframes, int32_t wg_slots, int32_t *grids) {
 	for (int l = 0; l < K2_NUM_BATCH_LAUNCHES; ++l) {
-		const auto &L = K2_BATCH_LAUNCHES[l];
+		const auto &L = k2_table().l[l];
 		const size_t bound = last_totals ? (size_t) last_totals[l] + (size_t) last_totals[l] / 4 + 8 : cells_total / (size_t) (L.min_cells * L.per_wg) + (size_t) nframes;   // tiles, about
 		int64_t g = std::min<int64_t>((int64_t) bound, wg_slots);
 		if (L.a == 21) g = std::min<int64_t>(g, K2_LARGE_WGS);
@@ -840,11 +855,11 @@ void k2_batch_grids(const int32_t *last_totals, size_t cells_total, int32_t nfra
 // them); totals_dev: K2_NUM_BATCH_LAUNCHES ints, the tiles each launch found
 void launch_vardct_batch(const K2Frame *frames_dev, int32_t nframes, int32_t *tile_prefix_dev, int32_t *totals_dev, const int32_t *grids, float *large_scratch, hipStream_t stream, hipStream_t *side, int nside, hipEvent_t fork, hipEvent_t *side_done) {
 	const DevPlan none = DevPlan();
-	hipLaunchKernelGGL(k_k2_tiles, dim3(1), dim3(32), 0, stream, frames_dev, nframes, tile_prefix_dev, totals_dev);
+	hipLaunchKernelGGL(k_k2_tiles, dim3(1), dim3(32), 0, stream, frames_dev, nframes, tile_prefix_dev, totals_dev, k2_table());
 	if (nside > 0) { (void) hipEventRecord(fork, stream); for (int k = 0; k < nside; ++k) (void) hipStreamWaitEvent(side[k], fork, 0); }
 	for (int l = 0; l < K2_NUM_BATCH_LAUNCHES; ++l) {
-		const auto &L = K2_BATCH_LAUNCHES[l];
-		launch_vardct_class_impl(none, L.a, nullptr, 0, large_scratch, nullptr, 0, K2Launch{frames_dev, tile_prefix_dev + (size_t) l * (size_t) (nframes + 1), nframes, L.a, L.b, grids[l]}, nside > 0 ? side[K2_LAUNCH_STREAM[l] % nside] : stream);
+		const auto &L = k2_table().l[l];
+		launch_vardct_class_impl(none, L.a, nullptr, 0, large_scratch, nullptr, 0, K2Launch{frames_dev, tile_prefix_dev + (size_t) l * (size_t) (nframes + 1), nframes, L.a, L.b, grids[l]}, nside > 0 ? side[k2_launch_stream()[l] % nside] : stream);
 	}
 	if (nside > 0) for (int k = 0; k < nside; ++k) { (void) hipEventRecord(side_done[k], side[k]); (void) hipStreamWaitEvent(stream, side_done[k], 0); }
 }
