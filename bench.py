@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--stream", choices=["forward", "coefficient"], default="forward",
                     help="forward: the generator ENCODES a procedural picture at about distance 1 (tools/jxlsynth forward=1); "
                          "coefficient: the coefficient-domain synthetic stream rounds 1 and 2 were tuned on")
+    ap.add_argument("--maxlog", type=int, default=0, help="--stream coefficient: largest transform side (log2) in the mix; 8 brings in the 128/256-sized transforms (k_vardct_large)")
     ap.add_argument("--shard-groups", action="store_true", help="single-frame mode: ONE frame per step, its pass groups split over the ranks (j40_amd.sharding)")
     ap.add_argument("--shard-kind", choices=["vardct", "modular"], default="vardct", help="--shard-groups: a VarDCT frame, or a Modular lossless frame (RCT only; e.g. --width 16384 --height 16384 = BASELINE config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -176,7 +177,7 @@ def main():
     D = max(1, min(args.distinct, B))
     # every rank decodes its own batch of the same D streams: rank 0 generates them with all the CPUs the container has (an 8K
     # encode takes ~10 s of one core), the other ranks wait and read them from build/streams
-    stream_opts = {"forward": 1} if args.stream == "forward" else {}
+    stream_opts = {"forward": 1} if args.stream == "forward" else ({"maxlog": args.maxlog} if args.maxlog else {})
     specs = [("vardct", W, H, args.seed + 1000 * i, stream_opts) for i in range(D)]
     if rank == 0:
         synth_many(specs, max(1, quota))

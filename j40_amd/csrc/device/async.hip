@@ -394,10 +394,22 @@ struct j40hip_abatch {
 	int32_t nframes = 0;
 	bool have_totals = false; int32_t last_totals[K2_NUM_BATCH_LAUNCHES];   // tiles per pixel-kernel launch of the batch before (k2_batch_grids)
 	float *large_scratch = nullptr;
+	bool shared_side = false;
 	std::vector<hipStream_t> side; std::vector<hipEvent_t> side_done; hipEvent_t fork = nullptr;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 	int cus = 256;
 };
+
+// How a pipeline's streams are laid over the hardware queues. A process gets four queues per stream priority, streams of one
+// priority share them in creation order, and kernels in one queue run one after the other. Layout 0 (the first form): every batch
+// slot has its own stream and its own four pixel-kernel streams, all of normal priority -- ten and more streams on four queues, so a
+// batch's plan build and entropy decode sat in a queue behind the pixel kernels of the batch before it and the batches ran one
+// after the other. Layout 1: ONE set of four pixel-kernel streams per device at normal priority (a queue each, every batch's chains
+// in order), the slots' streams (plan build, LfGroup tail, entropy decode) at high priority beside the copies.
+int j40hip_stream_layout(void) {
+	static const int v = [] { const char *e = getenv("J40HIP_STREAM_LAYOUT"); return e ? atoi(e) : 1; }();
+	return v;
+}
 
 j40hip_abatch *j40hip_abatch_create(int device) {
 	if (hipSetDevice(device) != hipSuccess) return nullptr;
@@ -408,9 +420,17 @@ j40hip_abatch *j40hip_abatch_create(int device) {
 	ok = ok && hipEventCreateWithFlags(&b->fork, hipEventDisableTiming) == hipSuccess;
 	int nside = 4;   // (kernels.hip: K2_LAUNCH_STREAM)
 	if (const char *e = getenv("J40HIP_SIDE_STREAMS")) nside = std::max(0, std::min(4, atoi(e)));
+	b->shared_side = j40hip_stream_layout() == 1;
 	for (int i = 0; i < nside && ok; ++i) {
 		hipStream_t st = nullptr; hipEvent_t ev = nullptr;
-		ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+		if (b->shared_side) {   // the device's four pixel-kernel streams, shared by every batch (see j40hip_stream_layout)
+			static std::mutex m; static hipStream_t shared[16][4] = {};
+			std::lock_guard<std::mutex> lock(m);
+			if (device < 16 && !shared[device][i]) ok = hipStreamCreateWithFlags(&shared[device][i], hipStreamNonBlocking) == hipSuccess;
+			st = device < 16 ? shared[device][i] : nullptr;
+			ok = ok && st != nullptr;
+		} else ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
 		if (ok) { b->side.push_back(st); b->side_done.push_back(ev); }
 	}
 	ok = ok && hipMalloc((void **) &b->large_scratch, (size_t) K2_LARGE_WGS * 6 * 65536 * sizeof(float)) == hipSuccess;
@@ -430,7 +450,7 @@ void j40hip_abatch_free(j40hip_abatch *b) {
 	if (b->large_scratch) (void) hipFree(b->large_scratch);
 	for (auto &e : b->ev) if (e) (void) hipEventDestroy(e);
 	for (auto &e : b->side_done) if (e) (void) hipEventDestroy(e);
-	for (auto &s : b->side) if (s) (void) hipStreamDestroy(s);
+	if (!b->shared_side) for (auto &s : b->side) if (s) (void) hipStreamDestroy(s);
 	if (b->fork) (void) hipEventDestroy(b->fork);
 	delete b;
 }

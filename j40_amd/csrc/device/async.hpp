@@ -52,3 +52,5 @@ int j40hip_alf_done(j40hip_alf *a);
 
 // j40hip_shutdown's share of async.hip: the static-table cache and the event pool
 void j40hip_async_shutdown(void);
+// 0: every batch slot with its own pixel-kernel streams, all of normal priority; 1: one set per device, slot streams at high priority (async.hip)
+int j40hip_stream_layout(void);

@@ -81,6 +81,9 @@ struct j40hip_pipeline {
 	// time. So the device takes the stream of frames, and the host threads decode a frame's sections themselves when
 	//   * the device's stage is full (lf_cap frames), or
 	//   * frames trickle in (less than a quarter batch waiting, nothing in the stage to join): the frame would wait 0.4 s alone.
+	// (Measured and dropped: half of the threads decoding a frame's streams themselves whenever the device's stage is primed -- 190 ms
+	// a step against 182 with the device alone; the cores are not as idle as the worker threads are: the launching thread and
+	// the runtime's own threads need them.)
 	// (Letting the host threads also cover the first 0.4 s of a run -- decode the first batches' sections while the first launch is
 	// out -- was measured: the fronts of the frames behind them are then prepared late and the gap only moves; 215 against 187 ms
 	// a step over 20 steps.)
@@ -168,7 +171,7 @@ uint32_t decode_single(j40hip_pipeline *p, Job *j, hipStream_t s) {
 	return err;
 }
 
-void worker_main(j40hip_pipeline *p) {
+void worker_main(j40hip_pipeline *p, int) {
 	if (hipSetDevice(p->device) != hipSuccess) { ++p->worker_errors; return; }
 	// The thread's copies go on a stream of the highest priority: such streams have hardware queues of their own, so a copy does
 	// not wait its turn behind another stream's long kernel (streams of one priority share a handful of hardware queues in turn)
@@ -408,7 +411,10 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 		if (const char *e = getenv("J40HIP_LF_CAP")) p->lf_cap = atoll(e);
 		p->slots.resize((size_t) p->max_in_flight + 1);
 		for (Slot &s : p->slots) {
-			if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { *err = E_GPU; break; }
+			bool made = false;
+			if (j40hip_stream_layout() == 1) { int lo = 0, hi = 0; made = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, hi) == hipSuccess; if (!made) (void) hipGetLastError(); }
+			if (!made && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) { *err = E_GPU; break; }
+			if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { *err = E_GPU; break; }
 		}
 		{   // The LfGroup launches run for a quarter of a second each. Streams of one priority share a handful of hardware queues, and a
 			// kernel waits for the kernels ahead of it in its queue whichever stream they came from: on a stream of the batches' priority
@@ -424,7 +430,7 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 			if (host_threads < 1) host_threads = (int) std::max(1u, std::thread::hardware_concurrency());
 			if (host_threads > 128) host_threads = 128;   // (each worker owns tens of MB of pinned staging; more than this was never exercised)
 			p->gpu = std::thread(gpu_main, p);
-			for (int i = 0; i < host_threads; ++i) p->workers.emplace_back(worker_main, p);
+			for (int i = 0; i < host_threads; ++i) p->workers.emplace_back(worker_main, p, i);
 		}
 	} catch (const std::exception &) { *err = E_MEM; }
 	if (*err) { if (p) j40hip_pipeline_free(p); return nullptr; }
