@@ -307,7 +307,9 @@ J40HIP_API uint32_t j40hip_pipeline_result(j40hip_pipeline *p, int64_t ticket);
  * the batch launches (HIP events on their streams), [6] batch launches, [7] images in them */
 J40HIP_API void j40hip_pipeline_stats(j40hip_pipeline *p, double *out8);
 /* out12: as above, then [8] ms of the batches' first stage (LfGroup streams + plan build + LfGroup tail), [9] images whose LfGroup
- * streams the device decoded, [10] images decoded on the single-frame path, [11] reserved */
+ * streams the device decoded, [10] images decoded on the single-frame path, [11] ms of k_hf_lanes itself summed over the launches,
+ * as the device recorded them (first wavefront's start to last one's end: the duration rocprofv3 reports; [4] also counts what the
+ * launch waited for behind other kernels) */
 J40HIP_API void j40hip_pipeline_stats_ex(j40hip_pipeline *p, double *out12);
 J40HIP_API void j40hip_pipeline_reset_stats(j40hip_pipeline *p);
 

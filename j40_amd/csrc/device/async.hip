@@ -397,6 +397,8 @@ struct j40hip_abatch {
 	bool shared_side = false;
 	std::vector<hipStream_t> side; std::vector<hipEvent_t> side_done; hipEvent_t fork = nullptr;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t k1_ev[2] = {nullptr, nullptr};   // recorded by the device at k_hf_lanes' start and end (hipExtLaunchKernelGGL)
+	bool k1_timed = false;
 	int cus = 256;
 };
 
@@ -417,6 +419,7 @@ j40hip_abatch *j40hip_abatch_create(int device) {
 	b->device = device;
 	bool ok = true;
 	for (auto &e : b->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+	for (auto &e : b->k1_ev) ok = ok && hipEventCreate(&e) == hipSuccess;
 	ok = ok && hipEventCreateWithFlags(&b->fork, hipEventDisableTiming) == hipSuccess;
 	int nside = 4;   // (kernels.hip: K2_LAUNCH_STREAM)
 	if (const char *e = getenv("J40HIP_SIDE_STREAMS")) nside = std::max(0, std::min(4, atoi(e)));
@@ -449,6 +452,7 @@ void j40hip_abatch_free(j40hip_abatch *b) {
 	if (b->verdict_host) (void) hipHostFree(b->verdict_host);
 	if (b->large_scratch) (void) hipFree(b->large_scratch);
 	for (auto &e : b->ev) if (e) (void) hipEventDestroy(e);
+	for (auto &e : b->k1_ev) if (e) (void) hipEventDestroy(e);
 	for (auto &e : b->side_done) if (e) (void) hipEventDestroy(e);
 	if (!b->shared_side) for (auto &s : b->side) if (s) (void) hipStreamDestroy(s);
 	if (b->fork) (void) hipEventDestroy(b->fork);
@@ -538,7 +542,8 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 	for (int i = 0; i < n; ++i) if (!frames[i]->sparse && hipMemsetAsync(frames[i]->plan.coeffs[0], 0, sizeof(float) * 3 * (size_t) frames[i]->plan.coeff_stride, s) != hipSuccess) return ERR_GPU;
 	(void) hipEventRecord(b->ev[1], s);
 	const double tq3 = prof_now();
-	if (lanes_fast) launch_hf_lanes(d_plans, d_work, (int32_t) work.size(), waves_per_wg, lanes_lds, s);
+	b->k1_timed = lanes_fast;
+	if (lanes_fast) launch_hf_lanes(d_plans, d_work, (int32_t) work.size(), waves_per_wg, lanes_lds, s, b->k1_ev[0], b->k1_ev[1]);
 	else launch_hf_entropy_lanes(d_plans, d_work, (int32_t) work.size(), tables_in_lds, generic_lds, s);
 	(void) hipEventRecord(b->ev[2], s);
 	int32_t grids[K2_NUM_BATCH_LAUNCHES];
@@ -565,6 +570,9 @@ void j40hip_abatch_result(const j40hip_abatch *b, int i, uint32_t *code, int *re
 uint32_t j40hip_abatch_elapsed(j40hip_abatch *b, float *ms3) {
 	if (!b || hipEventSynchronize(b->ev[3]) != hipSuccess) return ERR_GPU;
 	(void) hipEventElapsedTime(&ms3[0], b->ev[0], b->ev[1]); (void) hipEventElapsedTime(&ms3[1], b->ev[1], b->ev[2]); (void) hipEventElapsedTime(&ms3[2], b->ev[2], b->ev[3]);
+	// [3]: k_hf_lanes alone, from its first wavefront's start to its last one's end (0: the batch took another entropy kernel)
+	ms3[3] = 0;
+	if (b->k1_timed && hipEventElapsedTime(&ms3[3], b->k1_ev[0], b->k1_ev[1]) != hipSuccess) { (void) hipGetLastError(); ms3[3] = 0; }
 	return 0;
 }
 

@@ -39,8 +39,10 @@ uint32_t j40hip_abatch_launch(j40hip_abatch *b, j40hip_aframe *const *frames, in
 // has to be decoded again on the single-frame path (an LfGroup section the device decoder cannot take, or an event region that
 // overflowed)
 void j40hip_abatch_result(const j40hip_abatch *b, int i, uint32_t *code, int *redo);
-// ms of the last launch's stages: [0] plan build + LfGroup tail, [1] entropy decode, [2] pixels
-uint32_t j40hip_abatch_elapsed(j40hip_abatch *b, float *ms3);
+// ms of the last launch's stages: [0] plan build + LfGroup tail, [1] entropy decode, [2] pixels (HIP events on the batch's stream: a
+// stage's time includes what its kernels waited for), [3] k_hf_lanes' own duration as the device recorded it (start of its first
+// wavefront to the end of its last: what rocprofv3 reports)
+uint32_t j40hip_abatch_elapsed(j40hip_abatch *b, float *ms4);
 
 // The LfGroup streams of `n` prepared frames (those with j40hip_aframe_lf_on_device) in one k_lf_groups launch on `stream`; a frame
 // may join a batch once j40hip_alf_done says the launch has completed (the batch's stream also waits for it). One launch per object

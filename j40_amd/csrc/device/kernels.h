@@ -9,14 +9,14 @@ void upload_constant_tables(const float *half_secants, const float *afv_basis, c
 void launch_hf_entropy(const DevPlan &plan, const HfLaunchInfo &info, int32_t first_group, int32_t num_groups, hipStream_t stream);
 uint32_t hf_lanes_lds_bytes(const HfLaunchInfo &info);
 void launch_hf_entropy_lanes(const DevPlan *plans, const HfLaneWork *work, int32_t num_work, bool tables_in_lds, uint32_t lds_bytes, hipStream_t stream);
-void launch_hf_lanes(const DevPlan *plans, const HfLaneWork *work, int32_t num_work, int32_t waves_per_wg, uint32_t lds_bytes, hipStream_t stream);
+void launch_hf_lanes(const DevPlan *plans, const HfLaneWork *work, int32_t num_work, int32_t waves_per_wg, uint32_t lds_bytes, hipStream_t stream, hipEvent_t started = nullptr, hipEvent_t stopped = nullptr);
 void launch_vardct_class(const DevPlan &plan, int32_t dctsel, const DevVarblock *list, int32_t count, float *large_scratch, uint8_t *rgba, size_t stride, hipStream_t stream);
 
 
 // every frame of a batch: one persistent launch per class of transforms, spread over `nside` side streams that fork from and join
 // `stream` (nside = 0: all on `stream`). tile_prefix_dev: K2_NUM_BATCH_LAUNCHES * (nframes + 1) ints of scratch; totals_dev:
 // K2_NUM_BATCH_LAUNCHES ints (out: tiles per launch); grids: workgroups per launch, from k2_batch_grids
-enum { K2_NUM_BATCH_LAUNCHES = 15, K2_LARGE_WGS = 64 };
+enum { K2_NUM_BATCH_LAUNCHES = 15, K2_LARGE_WGS = 256 };
 void k2_batch_grids(const int32_t *last_totals, size_t cells_total, int32_t nframes, int32_t wg_slots, int32_t *grids);
 void launch_vardct_batch(const K2Frame *frames_dev, int32_t nframes, int32_t *tile_prefix_dev, int32_t *totals_dev, const int32_t *grids, float *large_scratch, hipStream_t stream, hipStream_t *side, int nside, hipEvent_t fork, hipEvent_t *side_done);
 void launch_vardct_frame(const DevPlan &plan, const int32_t *class_start, const DevVarblock *sorted, float *large_scratch, uint8_t *rgba, size_t stride, hipStream_t stream);

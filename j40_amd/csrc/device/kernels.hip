@@ -11,6 +11,7 @@
 //
 // Compiled with -ffp-contract=off: the float path has to keep the reference's operation order.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <type_traits>
 #include <cstring>
 #include <cstdlib>
@@ -297,12 +298,15 @@ __global__ void __launch_bounds__(512) k_hf_lanes(const DevPlan *plans, const Hf
 }
 
 // num_work must be a multiple of waves_per_wg, each aligned run of waves_per_wg entries on one frame
-void launch_hf_lanes(const DevPlan *plans, const HfLaneWork *work, int32_t num_work, int32_t waves_per_wg, uint32_t lds_bytes, hipStream_t stream) {
+void launch_hf_lanes(const DevPlan *plans, const HfLaneWork *work, int32_t num_work, int32_t waves_per_wg, uint32_t lds_bytes, hipStream_t stream, hipEvent_t started, hipEvent_t stopped) {
 	if (num_work <= 0) return;
 	static bool configured = false;
 	if (!configured) { (void) hipFuncSetAttribute((const void *) k_hf_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); configured = true; }
 	const uint32_t tables = (lds_bytes + 15u) & ~15u;
-	hipLaunchKernelGGL(k_hf_lanes, dim3((unsigned) (num_work / waves_per_wg)), dim3(64u * (unsigned) waves_per_wg), tables + (uint32_t) waves_per_wg * HF_LANE_COLS_BYTES, stream, plans, work, tables);
+	// (started / stopped: events the device records when the kernel's first wavefront starts and its last one ends -- the kernel's own
+	// duration, as rocprofv3 reports it, without the time the launch waited in its queue)
+	if (started && stopped) hipExtLaunchKernelGGL(k_hf_lanes, dim3((unsigned) (num_work / waves_per_wg)), dim3(64u * (unsigned) waves_per_wg), tables + (uint32_t) waves_per_wg * HF_LANE_COLS_BYTES, stream, started, stopped, 0, plans, work, tables);
+	else hipLaunchKernelGGL(k_hf_lanes, dim3((unsigned) (num_work / waves_per_wg)), dim3(64u * (unsigned) waves_per_wg), tables + (uint32_t) waves_per_wg * HF_LANE_COLS_BYTES, stream, plans, work, tables);
 }
 
 // LDS bytes k_hf_entropy_lanes needs for one frame

@@ -108,7 +108,7 @@ struct j40hip_pipeline {
 	std::mutex image_m;
 	std::vector<std::pair<void *, size_t>> free_images;
 	double parse_ms = 0, single_ms = 0;  // summed over the worker threads: the asynchronous path's host stage / whole single-frame decodes
-	double lf_ms = 0, k1_ms = 0, k2_ms = 0; int64_t launches = 0, launch_frames = 0;   // HIP-event durations of the batches' stages
+	double lf_ms = 0, k1_ms = 0, k2_ms = 0, k1_kernel_ms = 0; int64_t launches = 0, launch_frames = 0;   // HIP-event durations of the batches' stages
 	double first_submit_ms = 0, last_done_ms = 0;
 	std::atomic<int> worker_errors{0};
 };
@@ -243,7 +243,7 @@ void worker_main(j40hip_pipeline *p, int) {
 
 void retire(j40hip_pipeline *p, Slot &slot) {   // GPU thread; waits for the slot's work, then hands the results out
 	const bool ok = hipEventSynchronize(slot.done) == hipSuccess;
-	float ms3[3] = {0, 0, 0};
+	float ms3[4] = {0, 0, 0, 0};
 	const bool timed = ok && !slot.launch_err && j40hip_abatch_elapsed(slot.batch, ms3) == 0;
 	std::vector<j40hip_aframe *> dead;
 	for (size_t i = 0; i < slot.jobs.size(); ++i) {
@@ -263,7 +263,7 @@ void retire(j40hip_pipeline *p, Slot &slot) {   // GPU thread; waits for the slo
 		if (!j->device_output && j->dev_rgba) release_image(p, j->dev_rgba, j->stride * (size_t) j->height);
 	}
 	std::unique_lock<std::mutex> lock(p->m);
-	if (timed) { p->lf_ms += ms3[0]; p->k1_ms += ms3[1]; p->k2_ms += ms3[2]; ++p->launches; p->launch_frames += (int64_t) slot.jobs.size(); }
+	if (timed) { p->lf_ms += ms3[0]; p->k1_ms += ms3[1]; p->k2_ms += ms3[2]; p->k1_kernel_ms += ms3[3]; ++p->launches; p->launch_frames += (int64_t) slot.jobs.size(); }
 	p->in_flight_frames -= (int64_t) slot.jobs.size();
 	for (Job *j : slot.jobs) { --p->resident; complete(p, j); }
 	p->garbage.insert(p->garbage.end(), dead.begin(), dead.end());
@@ -499,7 +499,7 @@ void j40hip_pipeline_stats_ex(j40hip_pipeline *p, double *out) {
 	if (!p || !out) return;
 	j40hip_pipeline_stats(p, out);
 	std::unique_lock<std::mutex> lock(p->m);
-	out[8] = p->lf_ms; out[9] = (double) p->lf_device_frames; out[10] = (double) p->single_frames; out[11] = 0;
+	out[8] = p->lf_ms; out[9] = (double) p->lf_device_frames; out[10] = (double) p->single_frames; out[11] = p->k1_kernel_ms;
 }
 
 int64_t j40hip_pipeline_lf_device_frames(j40hip_pipeline *p) { if (!p) return 0; std::unique_lock<std::mutex> lock(p->m); return p->lf_device_frames; }
@@ -508,7 +508,7 @@ void j40hip_pipeline_reset_stats(j40hip_pipeline *p) {
 	if (!p) return;
 	std::unique_lock<std::mutex> lock(p->m);
 	p->parse_ms = p->single_ms = 0; p->first_submit_ms = 0; p->last_done_ms = 0;
-	p->lf_ms = p->k1_ms = p->k2_ms = 0; p->launches = p->launch_frames = 0; p->lf_device_frames = p->single_frames = 0;
+	p->lf_ms = p->k1_ms = p->k2_ms = p->k1_kernel_ms = 0; p->launches = p->launch_frames = 0; p->lf_device_frames = p->single_frames = 0;
 }
 
 } // extern "C"
