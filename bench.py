@@ -305,6 +305,21 @@ def main():
         del host_outs, step_outs
         pipe.close()
         torch.cuda.empty_cache()
+        # ---- k_hf_lanes with the device to itself: one batch in flight, the LfGroup streams decoded by the host threads (nothing else
+        # runs beside the kernel). The timed region above overlaps it with the previous batch's pixel kernels and the lane decoder of
+        # the LfGroup streams, which is what makes `value` -- and stretches the kernel. Same frames, same launch geometry.
+        outs2 = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(B)]
+        alone = j40_amd.Pipeline(local_rank, threads, min(args.pipe_batch, B), 1, lf_streams="host")
+        run_pipeline_steps(alone, step_bufs, step_sizes, outs2, W * 4, True, 1, torch, dev, None)
+        run_pipeline_steps(alone, step_bufs, step_sizes, outs2, W * 4, True, 2, torch, dev, None)
+        sa = alone.stats()
+        alone.close()
+        del outs2
+        torch.cuda.empty_cache()
+        if sa["launches"] and sa["k1_kernel_ms"] > 0:
+            ms = sa["k1_kernel_ms"] / sa["launches"]
+            result["roofline"]["kernel_alone"] = {"kernel_ms": round(ms, 4), "achieved": round(alg_launch / (ms / 1e3) / 1e9, 3), "frac": round(alg_launch / (ms / 1e3) / 8e12, 6), "launches": sa["launches"],
+                                                  "how": "same frames and launch geometry, one batch in flight, LfGroup streams on the host threads: no other kernel beside k_hf_lanes (device-recorded start/end events)"}
         result.update(sections(args, torch, np, j40_amd, dev, local_rank, datas, quota))
     else:
         pipe.close()

@@ -408,6 +408,9 @@ struct j40hip_abatch {
 // batch's plan build and entropy decode sat in a queue behind the pixel kernels of the batch before it and the batches ran one
 // after the other. Layout 1: ONE set of four pixel-kernel streams per device at normal priority (a queue each, every batch's chains
 // in order), the slots' streams (plan build, LfGroup tail, entropy decode) at high priority beside the copies.
+// Layout 2 (for comparison): as 1, but every batch on one and the same stream, i.e. one batch after the other: k_hf_lanes then runs
+// without another batch's pixel kernels beside it (48-52 ms instead of 52-75) and the steps take 8-15 % longer (195-200 ms
+// against 169-186).
 int j40hip_stream_layout(void) {
 	static const int v = [] { const char *e = getenv("J40HIP_STREAM_LAYOUT"); return e ? atoi(e) : 1; }();
 	return v;
@@ -423,7 +426,7 @@ j40hip_abatch *j40hip_abatch_create(int device) {
 	ok = ok && hipEventCreateWithFlags(&b->fork, hipEventDisableTiming) == hipSuccess;
 	int nside = 4;   // (kernels.hip: K2_LAUNCH_STREAM)
 	if (const char *e = getenv("J40HIP_SIDE_STREAMS")) nside = std::max(0, std::min(4, atoi(e)));
-	b->shared_side = j40hip_stream_layout() == 1;
+	b->shared_side = j40hip_stream_layout() >= 1;
 	for (int i = 0; i < nside && ok; ++i) {
 		hipStream_t st = nullptr; hipEvent_t ev = nullptr;
 		if (b->shared_side) {   // the device's four pixel-kernel streams, shared by every batch (see j40hip_stream_layout)

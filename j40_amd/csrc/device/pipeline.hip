@@ -412,7 +412,8 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 		p->slots.resize((size_t) p->max_in_flight + 1);
 		for (Slot &s : p->slots) {
 			bool made = false;
-			if (j40hip_stream_layout() == 1) { int lo = 0, hi = 0; made = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, hi) == hipSuccess; if (!made) (void) hipGetLastError(); }
+			if (j40hip_stream_layout() == 2 && &s != &p->slots[0]) { s.stream = p->slots[0].stream; made = true; }   // layout 2: every batch on ONE stream (one after the other), the pixel-kernel streams shared as in 1
+			else if (j40hip_stream_layout() >= 1) { int lo = 0, hi = 0; made = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, hi) == hipSuccess; if (!made) (void) hipGetLastError(); }
 			if (!made && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) { *err = E_GPU; break; }
 			if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { *err = E_GPU; break; }
 		}
@@ -448,7 +449,7 @@ void j40hip_pipeline_free(j40hip_pipeline *p) {
 	for (Job *j : p->todo) delete j;
 	for (std::deque<Job *> *q : {&p->ready, &p->lf_pending}) for (Job *j : *q) { if (j->af) { (void) hipDeviceSynchronize(); j40hip_aframe_free(j->af); } delete j; }
 	for (LfFlight &fl : p->lf_flights) { for (Job *j : fl.jobs) { if (j->af) { (void) hipDeviceSynchronize(); j40hip_aframe_free(j->af); } delete j; } if (fl.stream) (void) hipStreamDestroy(fl.stream); }
-	for (Slot &s : p->slots) { if (s.done) (void) hipEventDestroy(s.done); if (s.stream) (void) hipStreamDestroy(s.stream); }
+	for (Slot &s : p->slots) { if (s.done) (void) hipEventDestroy(s.done); if (s.stream && (&s == &p->slots[0] || s.stream != p->slots[0].stream)) (void) hipStreamDestroy(s.stream); }
 	delete p;
 }
 
