@@ -485,16 +485,15 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan_arg, const DevV
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2s: the 8x8 special transforms (special8_dev.h), cooperative: eight lanes per (block, channel) tile, two phases with a
-// barrier between them. The 256 lanes of a workgroup are 32 tiles x 8 lanes; a workgroup's NB blocks x 3 channels = 96 tiles
-// take three rounds per phase. Tiles are 65 floats apart (odd: the eight tiles of a wavefront start in different banks).
+// K2s: the 8x8 special transforms (special8_dev.h), cooperative: eight lanes per (block, channel) tile, two phases, in place.
+// The 256 lanes of a workgroup are 32 tiles x 8 lanes; a workgroup's NB blocks x 3 channels = 96 tiles take three rounds.
+// Tiles are 72 floats apart with rows of 9 (conflict-free along rows and down columns: special8_dev.h).
 
 template <int NB, bool BATCH>
 __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const DevVarblock *list, int32_t count, uint8_t *rgba, size_t stride_bytes, const K2Frame *batch, const int32_t *tile_prefix, int32_t nframes,
 		int32_t class_a, int32_t class_b) {
-	constexpr int P = 65;
-	__shared__ float tiles[NB * 3 * P];   // coefficients in, samples out
-	__shared__ float work[NB * 3 * P];    // between the two phases
+	constexpr int P = SP8_TILE;
+	__shared__ float tiles[NB * 3 * P];   // coefficients in, samples out: both phases work in place (special8_dev.h)
 	const int32_t tid = threadIdx.x, nthreads = blockDim.x;
 	__shared__ VbGeom geom[NB];
 	J40_STAGE_SRGB_THRESHOLDS(f);
@@ -521,7 +520,7 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const 
 			for (int32_t w = tid; w < nb * 3 * P; w += nthreads) tiles[w] = 0.0f;
 			__syncthreads();
 			const uint16_t *order = plan.pool_u16 + f.order_off[1 * 3];   // all 8x8 specials share order 1
-			const TileMap map = {8, 8, 8, 1};
+			const TileMap map = {8, 8, SP8_PITCH, 1};
 			const float qbias[3] = {f.quant_bias[0], f.quant_bias[1], f.quant_bias[2]};
 			tiles_scatter_events<NB>(plan, geom, g_be, ev_prefix, order, plan.pool_f32, g_dq, 64, map, tiles, 3 * P, P, qbias, f.quant_bias_num, tid, nthreads);
 			tiles_fill_llf(plan, geom, nb, 8, 1, 1, map, tiles, 3 * P, P, f.kx_lf, f.kb_lf, tid, nthreads);
@@ -531,23 +530,27 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const 
 				const int32_t b = w >> 6, i = w & 63;
 				float v[3];
 				load_coeff3(plan, geom[b], plan.pool_f32 + f.dq_off[g_param[b]], 64, i, 8, 1, 1, v);
-				float *t = tiles + (size_t) b * 3 * P + i;
+				float *t = tiles + (size_t) b * 3 * P + SP8(i);
 				t[0] = v[0]; t[P] = v[1]; t[2 * P] = v[2];
 			}
 		}
 		__syncthreads();
+		// eight lanes per tile, the eight tiles of a wavefront side by side; a tile's lanes sit in one wavefront, so the two phases
+		// need no workgroup barrier between them, only their order (SP8_LOADS_DONE)
 		const int32_t lane8 = tid & 7;
-		for (int32_t tile = tid >> 3; tile < nb * 3; tile += nthreads >> 3)
-			special8_phase0(g_sel[tile / 3], lane8, tiles + tile * P, work + tile * P, c_half_secants, c_afv_basis);
-		__syncthreads();
-		for (int32_t tile = tid >> 3; tile < nb * 3; tile += nthreads >> 3)
-			special8_phase1(g_sel[tile / 3], lane8, work + tile * P, tiles + tile * P, c_half_secants);
+		for (int32_t tile = tid >> 3; tile < nb * 3; tile += nthreads >> 3) {
+			float *t = tiles + tile * P;
+			const int32_t sel = g_sel[tile / 3];
+			special8_phase0(sel, lane8, (const float *) t, t, c_half_secants, c_afv_basis, true);
+			SP8_LOADS_DONE();
+			special8_phase1(sel, lane8, (const float *) t, t, c_half_secants, true);
+		}
 		__syncthreads();
 		for (int32_t w = tid; w < nb * 64; w += nthreads) {
 			const int32_t b = w >> 6, i = w & 63, y = i >> 3, x = i & 7;
 			const VbGeom &g = geom[b];
 			if (y >= g.effh || x >= g.effw) continue;
-			const float *t = tiles + (size_t) b * 3 * P + i;
+			const float *t = tiles + (size_t) b * 3 * P + SP8(i);
 			const uint32_t px = xyb_to_rgba8(t[0], t[P], t[2 * P], cc, srgb_thr);
 			*(uint32_t *) (rgba + (size_t) (g.py + y) * stride_bytes + (size_t) (g.px + x) * 4) = px;
 		}

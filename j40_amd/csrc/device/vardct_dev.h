@@ -49,9 +49,9 @@ J40_DEV void load_coeff3(const DevPlan &plan, const VbGeom &g, const float *dq, 
 //   chroma-from-luma contributions;  3. tile_fill_llf: the LLF corner (no event lands there).
 // Same values as load_coeff3 computes per position: a zero coefficient dequantises to +0 and 0 + 0 * k = +0.
 struct TileMap {
-	int32_t rows, columns, pitch, linear;   // linear: the 8x8 special transforms keep canonical index i at i
+	int32_t rows, columns, pitch, linear;   // linear: the 8x8 special transforms keep canonical index i in row i / 8, column i % 8 (rows `pitch` apart)
 	J40_DEVM int32_t at(int32_t i) const {
-		if (linear) return i;
+		if (linear) return (i >> 3) * pitch + (i & 7);
 		const int32_t r = columns > rows ? i / columns : i % rows, c = columns > rows ? i % columns : i / rows;   // j40.h:5978-5985
 		return r * pitch + c;
 	}

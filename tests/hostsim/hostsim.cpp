@@ -329,7 +329,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 	const float *hs = half_secants(), *afv = afv_basis();
 	const DevFrame &f = hp.frame;
 	const size_t stride = (size_t) f.width * 4;
-	std::vector<float> A(3 * 65536), B(3 * 65536), scratch(3 * 65);
+	std::vector<float> A(3 * 65536), B(3 * 65536), scratch(SP8_TILE), scratch2(SP8_TILE);
 	for (const DevVarblock &vb : hp.vb_sorted) {
 		if (g_group_count >= 0) {   // sharded decode: varblocks of the selected groups only
 			const int64_t gid = ((int64_t) vb.py >> fr.fh.group_size_shift) * fr.fh.gcolumns + ((int64_t) vb.px >> fr.fh.group_size_shift);
@@ -343,7 +343,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 		const VbGeom g = varblock_geometry(plan, vb);
 		const bool special = (vb.dctsel >= 1 && vb.dctsel <= 3) || (vb.dctsel >= 12 && vb.dctsel <= 17);
 		const bool large = log_rows > 6 || log_columns > 6;
-		const int P = special ? 8 : large ? C : C + 1;
+		const int P = special ? SP8_PITCH : large ? C : C + 1;   // (the specials' tiles: rows 9 apart, special8_dev.h)
 		if (f.sparse_coeffs) {   // the pixel kernels' way: zeroed tiles, scattered events, LLF corner, chroma-from-luma in place
 			for (int ch = 0; ch < 3; ++ch) std::fill(A.begin() + (size_t) ch * 65536, A.begin() + (size_t) ch * 65536 + std::min<size_t>(65536, (size_t) R * (size_t) P), 0.0f);
 			const TileMap map = {R, C, P, special ? 1 : 0};
@@ -369,8 +369,10 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 			float *t = A.data() + (size_t) ch * 65536;
 			if (special) {   // the cooperative form (k_vardct_special): two phases of eight lanes; here one lane after the other, in an
 				// order that changes with the block so that a dependence between the lanes of a phase would show
-				for (int l = 0; l < 8; ++l) special8_phase0(vb.dctsel, (vb.blk & 1) ? 7 - l : l, t, scratch.data(), hs, afv);
-				for (int l = 0; l < 8; ++l) special8_phase1(vb.dctsel, (vb.blk & 2) ? 7 - l : l, scratch.data(), t, hs);
+				// (out of place here: the kernel's lanes run in lockstep and work in place -- every phase loads all it needs before it stores)
+				for (int l = 0; l < 8; ++l) special8_phase0(vb.dctsel, (vb.blk & 1) ? 7 - l : l, (const float *) t, scratch.data(), hs, afv, false);
+				for (int l = 0; l < 8; ++l) special8_phase1(vb.dctsel, (vb.blk & 2) ? 7 - l : l, (const float *) scratch.data(), scratch2.data(), hs, false);
+				memcpy(t, scratch2.data(), sizeof(float) * SP8_TILE);
 			}
 			else if (large) {
 				idct_sweeps_host(t, B.data() + (size_t) ch * 65536, log_columns, R, 1, C, hs);
@@ -388,12 +390,26 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 // known-answer hook: one 8x8 special transform (DctSelect 1-3, 12-17) through the cooperative device functions; `order` permutes
 // the lanes of both phases (0: ascending, 1: descending, 2: odd lanes first)
 extern "C" __attribute__((visibility("default"))) void hostsim_special8(int dctsel, float *tile64, int order) {
-	float mid[64];
-	for (int k = 0; k < 64; ++k) mid[k] = -12345.0f;
+	float in[SP8_TILE], mid[SP8_TILE], out[SP8_TILE];
+	for (int k = 0; k < SP8_TILE; ++k) { in[k] = 0.0f; mid[k] = -12345.0f; out[k] = -54321.0f; }   // both phases must rewrite every value
+	for (int k = 0; k < 64; ++k) in[SP8(k)] = tile64[k];
 	auto lane_of = [order](int l) { return order == 0 ? l : order == 1 ? 7 - l : (l < 4 ? 2 * l + 1 : 2 * (l - 4)); };
-	for (int l = 0; l < 8; ++l) special8_phase0(dctsel, lane_of(l), tile64, mid, half_secants(), afv_basis());
-	for (int k = 0; k < 64; ++k) tile64[k] = -54321.0f;   // phase 1 must rewrite every sample
-	for (int l = 0; l < 8; ++l) special8_phase1(dctsel, lane_of(l), mid, tile64, half_secants());
+	for (int l = 0; l < 8; ++l) special8_phase0(dctsel, lane_of(l), (const float *) in, mid, half_secants(), afv_basis(), false);
+	for (int l = 0; l < 8; ++l) special8_phase1(dctsel, lane_of(l), (const float *) mid, out, half_secants(), false);
+	for (int k = 0; k < 64; ++k) tile64[k] = out[SP8(k)];
+}
+
+// the same with both phases IN PLACE on one tile, the eight lanes of a phase in lockstep as a wavefront runs them: a lane's loads
+// see the tile as it was before the phase (every phase loads all it needs before it stores anything), its stores land in the tile
+extern "C" __attribute__((visibility("default"))) void hostsim_special8_in_place(int dctsel, float *tile64) {
+	float tile[SP8_TILE], before[SP8_TILE];
+	for (int k = 0; k < SP8_TILE; ++k) tile[k] = 0.0f;
+	for (int k = 0; k < 64; ++k) tile[SP8(k)] = tile64[k];
+	memcpy(before, tile, sizeof tile);
+	for (int l = 0; l < 8; ++l) special8_phase0(dctsel, l, (const float *) before, tile, half_secants(), afv_basis(), true);
+	memcpy(before, tile, sizeof tile);
+	for (int l = 0; l < 8; ++l) special8_phase1(dctsel, l, (const float *) before, tile, half_secants(), true);
+	for (int k = 0; k < 64; ++k) tile64[k] = tile[SP8(k)];
 }
 
 // sweeps float bit patterns [first, last] with stride `step` through pow_1_over_2p4 and counts results that

@@ -250,10 +250,12 @@ def test_nsym4_simple_prefix_code_follows_the_reference_and_documents_the_rfc_di
 
 @pytest.mark.parametrize("sel", [1, 2, 3, 12, 13, 14, 15, 16, 17])
 def test_cooperative_special_transforms_equal_the_reference_bit_for_bit(sim, ref, sel):
-    """The nine 8x8 special transforms as k_vardct_special runs them (special8_dev.h: eight lanes per tile, two out-of-place
-    phases) against the reference's routines (j40.h:5993-6246 via ref_kat_inverse_by_dctsel): identical floats, whatever the
-    order in which the lanes of a phase run."""
+    """The nine 8x8 special transforms as k_vardct_special runs them (special8_dev.h: eight lanes per tile, two phases over tiles
+    with rows nine floats apart) against the reference's routines (j40.h:5993-6246 via ref_kat_inverse_by_dctsel): identical floats
+    -- out of place whatever the order in which the lanes of a phase run, and in place with the lanes in lockstep (the kernel's
+    form: every phase loads all it needs before it stores anything)."""
     sim.hostsim_special8.argtypes = [C.c_int, C.c_void_p, C.c_int]
+    sim.hostsim_special8_in_place.argtypes = [C.c_int, C.c_void_p]
     rng = np.random.default_rng(sel)
     for trial in range(120):
         a = (rng.standard_normal(64) * (10.0 ** rng.integers(-3, 3))).astype(np.float32)
@@ -266,6 +268,9 @@ def test_cooperative_special_transforms_equal_the_reference_bit_for_bit(sim, ref
             got = a.copy()
             sim.hostsim_special8(sel, got.ctypes.data, order)
             assert np.array_equal(expect.view(np.uint32), got.view(np.uint32)), (sel, trial, order)
+        got = a.copy()
+        sim.hostsim_special8_in_place(sel, got.ctypes.data)
+        assert np.array_equal(expect.view(np.uint32), got.view(np.uint32)), (sel, trial, "in place")
 
 
 def test_lz77_distance_multiplier_of_lf_global_is_the_whole_images(sim, ref):

@@ -79,12 +79,13 @@ struct Forward {
 		}
 		for (int sel = 0; sel < 27; ++sel) if (is_special(sel)) {
 			std::vector<double> m(64 * 64);
-			float tile[64], mid[80];
+			float tile[j40hip::SP8_TILE], mid[j40hip::SP8_TILE], out[j40hip::SP8_TILE];   // (tiles with rows nine floats apart: special8_dev.h)
 			for (int k = 0; k < 64; ++k) {
-				for (int i = 0; i < 64; ++i) tile[i] = i == k ? 1.0f : 0.0f;
-				for (int l = 0; l < 8; ++l) j40hip::special8_phase0(sel, l, tile, mid, hs, afv);
-				for (int l = 0; l < 8; ++l) j40hip::special8_phase1(sel, l, mid, tile, hs);
-				for (int i = 0; i < 64; ++i) m[(size_t) i * 64 + (size_t) k] = tile[i];
+				for (int i = 0; i < j40hip::SP8_TILE; ++i) tile[i] = mid[i] = out[i] = 0.0f;
+				tile[SP8(k)] = 1.0f;
+				for (int l = 0; l < 8; ++l) j40hip::special8_phase0(sel, l, (const float *) tile, mid, hs, afv, false);
+				for (int l = 0; l < 8; ++l) j40hip::special8_phase1(sel, l, (const float *) mid, out, hs, false);
+				for (int i = 0; i < 64; ++i) m[(size_t) i * 64 + (size_t) k] = out[SP8(i)];
 			}
 			if (!invert(m, 64)) throw std::runtime_error("singular special synthesis matrix");
 			special[sel] = m;
