@@ -853,7 +853,9 @@ void k2_batch_grids(const int32_t *last_totals, size_t cells_total, int32_t nfra
 		const auto &L = k2_table().l[l];
 		const size_t bound = last_totals ? (size_t) last_totals[l] + (size_t) last_totals[l] / 4 + 8 : cells_total / (size_t) (L.min_cells * L.per_wg) + (size_t) nframes;   // tiles, about
 		int64_t g = std::min<int64_t>((int64_t) bound, wg_slots);
-		if (L.a == 21) g = std::min<int64_t>(g, K2_LARGE_WGS);
+		// (the 128/256-sized transforms' workgroups want 133 KB of LDS each: a launch waits for compute units to drain even when it
+		// has nothing to do -- 11 ms at the end of its chain with 256 workgroups -- so a batch following one without such blocks gets one)
+		if (L.a == 21) g = last_totals && last_totals[l] == 0 ? 1 : std::min<int64_t>(g, K2_LARGE_WGS);
 		grids[l] = (int32_t) std::max<int64_t>(g, 1);
 	}
 }
