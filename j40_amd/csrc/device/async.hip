@@ -109,9 +109,17 @@ hipEvent_t event_acquire() {
 void event_release(hipEvent_t e) { if (e) { std::lock_guard<std::mutex> lock(g_event_mutex); g_event_pool.push_back(e); } }
 
 } // namespace
-// j40hip_shutdown's share of this file: the table cache and the event pool (nothing of the library may be running)
+// the pixel-kernel streams every batch of a device shares (stream layout 1, j40hip_stream_layout)
+static std::mutex g_shared_side_mutex;
+static hipStream_t g_shared_side[16][4] = {};
+
+// j40hip_shutdown's share of this file: the table cache, the event pool and the shared streams (nothing of the library may be running)
 void j40hip_async_shutdown(void) {
 	{ std::lock_guard<std::mutex> lock(g_static_mutex); g_static.clear(); }
+	{
+		std::lock_guard<std::mutex> lock(g_shared_side_mutex);
+		for (int d = 0; d < 16; ++d) for (hipStream_t &st : g_shared_side[d]) if (st) { if (hipSetDevice(d) == hipSuccess) { (void) hipStreamSynchronize(st); (void) hipStreamDestroy(st); } st = nullptr; }
+	}
 	std::lock_guard<std::mutex> lock(g_event_mutex);
 	for (hipEvent_t e : g_event_pool) (void) hipEventDestroy(e);
 	g_event_pool.clear();
@@ -430,10 +438,9 @@ j40hip_abatch *j40hip_abatch_create(int device) {
 	for (int i = 0; i < nside && ok; ++i) {
 		hipStream_t st = nullptr; hipEvent_t ev = nullptr;
 		if (b->shared_side) {   // the device's four pixel-kernel streams, shared by every batch (see j40hip_stream_layout)
-			static std::mutex m; static hipStream_t shared[16][4] = {};
-			std::lock_guard<std::mutex> lock(m);
-			if (device < 16 && !shared[device][i]) ok = hipStreamCreateWithFlags(&shared[device][i], hipStreamNonBlocking) == hipSuccess;
-			st = device < 16 ? shared[device][i] : nullptr;
+			std::lock_guard<std::mutex> lock(g_shared_side_mutex);
+			if (device < 16 && !g_shared_side[device][i]) ok = hipStreamCreateWithFlags(&g_shared_side[device][i], hipStreamNonBlocking) == hipSuccess;
+			st = device < 16 ? g_shared_side[device][i] : nullptr;
 			ok = ok && st != nullptr;
 		} else ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
 		ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;

@@ -719,6 +719,29 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_front_timing(c
 	return 0;
 }
 
+// the order in which k_hf_lanes' lanes take a frame's groups (FrontPlan::lane_order) and the bytes of each group's sections, summed
+// over the passes; returns the number of groups (or -1)
+extern "C" __attribute__((visibility("default"))) int32_t hostsim_lane_order(const uint8_t *buf, size_t size, uint32_t *order, uint64_t *bytes, int32_t capacity) {
+	const uint8_t *cs; size_t cs_size; std::vector<uint8_t> storage;
+	try {
+		extract_codestream(buf, size, &cs, &cs_size, &storage);
+		Frame fr;
+		std::vector<LfDeviceTask> tasks; std::vector<int32_t> extra_prec; bool plain = true;
+		if (!parse_frame_front(cs, cs_size, &fr, &tasks, &extra_prec, &plain)) return -1;
+		StaticTables st; build_static_tables(fr, &st);
+		FrontPlan fp;
+		if (build_front_plan(fr, st, cs_size, extra_prec, true, &fp)) return -1;
+		const int32_t ng = (int32_t) fr.fh.num_groups;
+		if ((int32_t) fp.lane_order.size() != ng || ng > capacity) return -1;
+		for (int32_t g = 0; g < ng; ++g) {
+			order[g] = fp.lane_order[(size_t) g];
+			bytes[g] = 0;
+			for (int32_t p = 0; p < fr.fh.num_passes; ++p) bytes[g] += fp.sections[(size_t) p * (size_t) ng + (size_t) g].size;
+		}
+		return ng;
+	} catch (const DecodeError &) { return -1; }
+}
+
 // ---- the lane decoder of the LfGroup sections (device/lf_lanes_dev.h) on the CPU, against the host decoder ----
 #include "../../j40_amd/csrc/device/lf_lanes_dev.h"
 

@@ -99,3 +99,24 @@ def test_lf_lane_decoder_fails_like_the_host_decoder(lanes):
         assert rc in (0, -1), rc
         failed += bad
     assert failed >= 20
+
+
+def test_lanes_take_the_groups_by_decreasing_section_size(built):
+    """DevPlan::lane_order (plan_front.cpp): a permutation of the frame's groups, section bytes (summed over the passes) never
+    increasing along it, ties in group order -- so that the 64 lanes of a k_hf_lanes wavefront decode sections of about one length"""
+    S = C.CDLL(os.path.join(ROOT, "build", "libhostsim.so"))
+    S.hostsim_lane_order.restype = C.c_int32
+    S.hostsim_lane_order.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int32]
+    for (w, h, seed, opts) in [(1920, 1080, 31, dict(forward=1)), (1300, 776, 32, dict(passes=3)), (520, 264, 33, dict())]:
+        data = synth("vardct", w, h, seed, **opts)
+        buf = C.create_string_buffer(data, len(data))
+        order, size = np.zeros(4096, np.uint32), np.zeros(4096, np.uint64)
+        n = S.hostsim_lane_order(buf, len(data), order.ctypes.data, size.ctypes.data, 4096)
+        assert n == ((w + 255) // 256) * ((h + 255) // 256)
+        order, size = order[:n], size[:n]
+        assert sorted(order.tolist()) == list(range(n))
+        along = size[order]
+        assert np.all(along[:-1] >= along[1:])
+        for a, b in zip(range(n - 1), range(1, n)):
+            if along[a] == along[b]:
+                assert order[a] < order[b]
