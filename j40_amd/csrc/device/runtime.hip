@@ -15,6 +15,7 @@
 #include "../plan_build.hpp"
 #include "kernels.h"
 #include "runtime_shared.hpp"
+#include "block_cache.hpp"
 #include "async.hpp"
 
 using namespace j40hip;
@@ -38,21 +39,10 @@ struct DeviceBuffer {
 	void release() { if (ptr) (void) hipFree(ptr); ptr = nullptr; }
 };
 
-// Device memory is recycled across frames: hipMalloc / hipFree of a 1.2 GB working set cost far more than an 8K decode.
-// Blocks go back to a per-device free list when a frame lets go of them (after a device synchronisation) and are handed
-// out again to requests of similar size. A block remembers whether its coefficient planes are all-zero ("clean": the
-// pixel kernels leave them that way), so a recycled working set needs no 400 MB clear either.
-//
-// hipMalloc itself takes about a millisecond and serialises callers: a pipeline that grows to its 2800 resident frames (11 MB of
-// codestream and LfGroup planes each) spent its first second inside it, the launching thread waiting behind the workers. Requests
-// between 256 KB and 512 MB are therefore rounded up to a size class (eighth-of-a-power-of-two steps) and served from SLABS: one
-// hipMalloc of up to 1 GB carved into blocks of one class. A slab goes back to the device only when all of its blocks are idle.
-struct CachedBlock { void *ptr; size_t bytes; bool clean; int slab; };
-struct Slab { uint8_t *base; size_t block_bytes; int total, idle; };
-std::vector<Slab> g_slabs[16];
+// The device memory cache: one BlockCacheCore (block_cache.hpp: free list, size classes, slabs) per device behind one mutex; the
+// slow part -- hipMalloc / hipFree -- happens outside the lock.
 std::mutex g_cache_mutex;
-std::vector<CachedBlock> g_cache[16];
-size_t g_cached_bytes[16];
+BlockCacheCore g_cache[16];
 // upper bound on what the cache keeps (J40HIP_CACHE_GB overrides; 0 disables recycling). When an allocation fails the cache is
 // emptied and the allocation tried again (cache_trim), so idle blocks never turn into a spurious "!gpu"
 // Default: three quarters of the device's memory -- a pipeline returns the working sets of a whole batch at once (256 8K frames:
@@ -73,54 +63,24 @@ size_t cache_limit_bytes() {
 // synchronisation); the idle blocks of a slab that still has blocks in use stay
 void j40hip_rt::cache_trim(int device) {
 	if (device < 0 || device >= 16) return;
-	std::lock_guard<std::mutex> lock(g_cache_mutex);
-	std::vector<CachedBlock> keep;
-	auto &slabs = g_slabs[device];
-	size_t kept = 0;
-	for (CachedBlock &b : g_cache[device]) {
-		if (b.slab < 0) (void) hipFree(b.ptr);
-		else if (slabs[(size_t) b.slab].idle < slabs[(size_t) b.slab].total) { keep.push_back(b); kept += b.bytes; }
-	}
-	for (Slab &sl : slabs) if (sl.base && sl.idle == sl.total) { (void) hipFree(sl.base); sl.base = nullptr; sl.total = sl.idle = 0; }
-	g_cache[device].swap(keep); g_cached_bytes[device] = kept;
-}
-
-static size_t size_class(size_t bytes) {
-	bytes = (bytes + 4095) & ~(size_t) 4095;
-	if (bytes < ((size_t) 256 << 10) || bytes > ((size_t) 512 << 20)) return bytes;
-	size_t top = (size_t) 1 << 18;
-	while (top * 2 <= bytes) top *= 2;
-	const size_t step = top / 8;
-	return (bytes + step - 1) / step * step;
+	std::vector<void *> gone;
+	{ std::lock_guard<std::mutex> lock(g_cache_mutex); g_cache[device].trim(&gone); }
+	for (void *q : gone) (void) hipFree(q);
 }
 
 void *j40hip_rt::cache_acquire(int device, size_t bytes, size_t *got, bool *clean) {
-	bytes = size_class(bytes);
+	bytes = BlockCacheCore::size_class(bytes);
 	const bool cached = device >= 0 && device < 16;
 	if (cached) {
 		std::lock_guard<std::mutex> lock(g_cache_mutex);
-		auto &list = g_cache[device];
-		for (size_t i = list.size(); i-- > 0; ) if (list[i].bytes >= bytes && list[i].bytes <= bytes + bytes / 4) {   // (newest first: the list is a stack)
-			CachedBlock b = list[i];
-			list.erase(list.begin() + (long) i);
-			g_cached_bytes[device] -= b.bytes;
-			if (b.slab >= 0) --g_slabs[device][(size_t) b.slab].idle;
-			*got = b.bytes; *clean = b.clean;
-			return b.ptr;
-		}
+		if (void *q = g_cache[device].take(bytes, got, clean)) return q;
 	}
 	void *p = nullptr;
-	if (cached && bytes >= ((size_t) 256 << 10) && bytes <= ((size_t) 512 << 20)) {   // a slab of this class
-		const int n = (int) std::max<size_t>(2, std::min<size_t>(64, ((size_t) 1 << 30) / bytes));
+	if (cached && BlockCacheCore::slab_class(bytes)) {
+		const int n = BlockCacheCore::slab_blocks(bytes);
 		if (hipMalloc(&p, bytes * (size_t) n) == hipSuccess) {
 			std::lock_guard<std::mutex> lock(g_cache_mutex);
-			auto &slabs = g_slabs[device];
-			size_t si = 0;
-			while (si < slabs.size() && slabs[si].base) ++si;
-			if (si == slabs.size()) slabs.push_back(Slab{});
-			slabs[si] = Slab{(uint8_t *) p, bytes, n, n - 1};
-			for (int i = 1; i < n; ++i) g_cache[device].push_back({(uint8_t *) p + (size_t) i * bytes, bytes, false, (int) si});
-			g_cached_bytes[device] += bytes * (size_t) (n - 1);
+			g_cache[device].adopt_slab(p, bytes, n);
 			*got = bytes; *clean = false;
 			return p;
 		}
@@ -139,33 +99,12 @@ void *j40hip_rt::cache_acquire(int device, size_t bytes, size_t *got, bool *clea
 
 void j40hip_rt::cache_release(int device, void *ptr, size_t bytes, bool clean) {
 	if (!ptr) return;
+	void *gone = ptr;
 	if (device >= 0 && device < 16) {
 		std::lock_guard<std::mutex> lock(g_cache_mutex);
-		auto &slabs = g_slabs[device];
-		for (size_t si = 0; si < slabs.size(); ++si) {
-			Slab &sl = slabs[si];
-			if (!sl.base || (uint8_t *) ptr < sl.base || (uint8_t *) ptr >= sl.base + sl.block_bytes * (size_t) sl.total) continue;
-			// a slab's block: it can only stay (or the whole slab go, once all of it is idle and the cache is over its limit)
-			g_cache[device].push_back({ptr, sl.block_bytes, clean, (int) si});
-			g_cached_bytes[device] += sl.block_bytes;
-			if (++sl.idle == sl.total && g_cached_bytes[device] > cache_limit_bytes()) {
-				auto &list = g_cache[device];
-				size_t w = 0;
-				for (size_t i = 0; i < list.size(); ++i) if (list[i].slab != (int) si) list[w++] = list[i];
-				list.resize(w);
-				g_cached_bytes[device] -= sl.block_bytes * (size_t) sl.total;
-				(void) hipFree(sl.base);
-				sl.base = nullptr; sl.total = sl.idle = 0;
-			}
-			return;
-		}
-		if (g_cached_bytes[device] + bytes <= cache_limit_bytes()) {
-			g_cache[device].push_back({ptr, bytes, clean, -1});
-			g_cached_bytes[device] += bytes;
-			return;
-		}
+		g_cache[device].give(ptr, bytes, clean, cache_limit_bytes(), &gone);
 	}
-	(void) hipFree(ptr);
+	if (gone) (void) hipFree(gone);
 }
 
 namespace {

@@ -807,3 +807,90 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_squeeze_tenden
 extern "C" __attribute__((visibility("default"))) void hostsim_unsqueeze_line(const int16_t *avg, int32_t n_avg, const int16_t *res, int32_t n_res, int16_t *out) {
 	unsqueeze_line(avg, 1, res, 1, n_avg, n_res, out, 1);
 }
+
+// ---- the device memory cache's bookkeeping (device/block_cache.hpp) on the CPU: a backend with a byte budget stands in for
+// hipMalloc / hipFree, the driver below is runtime.hip's cache_acquire / cache_release / cache_trim line for line ----
+#include "../../j40_amd/csrc/device/block_cache.hpp"
+#include <map>
+#include <random>
+// Random acquire / release / trim sequences; checks after every step: no two live blocks overlap, every live block lies inside a
+// live backend allocation, the cache's byte count equals the sum of its idle blocks, a slab is only freed with all blocks idle,
+// trim leaves nothing idle but blocks of partly used slabs, an allocation that fails with idle blocks around succeeds after the
+// trim. Returns 0, or the number of the first check that failed.
+extern "C" __attribute__((visibility("default"))) int32_t hostsim_block_cache_selftest(uint32_t seed, int32_t steps, uint64_t budget, uint64_t limit) {
+	using j40hip_rt::BlockCacheCore;
+	BlockCacheCore cache;
+	std::map<uintptr_t, size_t> backend;   // live backend allocations: base -> bytes (addresses are made up: nothing is dereferenced)
+	uint64_t used = 0; uintptr_t next_addr = (uintptr_t) 1 << 40;
+	auto b_alloc = [&](size_t bytes) -> void * { if (used + bytes > budget) return nullptr; used += bytes; const uintptr_t a = next_addr; next_addr += (bytes + 4095) & ~(uintptr_t) 4095; backend[a] = bytes; return (void *) a; };
+	auto b_free = [&](void *q) -> bool { auto it = backend.find((uintptr_t) q); if (it == backend.end()) return false; used -= it->second; backend.erase(it); return true; };
+	struct Live { void *p; size_t got; };
+	std::vector<Live> live;
+	bool bad_free = false;
+	auto trim = [&] { std::vector<void *> gone; cache.trim(&gone); for (void *q : gone) if (!b_free(q)) bad_free = true; };
+	auto acquire = [&](size_t bytes, size_t *got) -> void * {
+		bool clean = false;
+		bytes = BlockCacheCore::size_class(bytes);
+		if (void *q = cache.take(bytes, got, &clean)) return q;
+		if (BlockCacheCore::slab_class(bytes)) {
+			const int n = BlockCacheCore::slab_blocks(bytes);
+			if (void *q = b_alloc(bytes * (size_t) n)) { cache.adopt_slab(q, bytes, n); *got = bytes; return q; }
+		}
+		void *q = b_alloc(bytes);
+		if (!q) { trim(); q = b_alloc(bytes); }
+		if (q) *got = bytes;
+		return q;
+	};
+	auto release = [&](const Live &l) { void *gone = nullptr; cache.give(l.p, l.got, false, (size_t) limit, &gone); if (gone && !b_free(gone)) bad_free = true; };
+	auto check = [&]() -> int32_t {
+		if (bad_free) return 1;   // something was freed that the backend never handed out (or twice)
+		size_t sum = 0;
+		for (const auto &b : cache.idle) sum += b.bytes;
+		if (sum != cache.idle_bytes) return 2;
+		std::vector<std::pair<uintptr_t, uintptr_t>> spans;
+		for (const Live &l : live) spans.push_back({(uintptr_t) l.p, (uintptr_t) l.p + l.got});
+		for (const auto &b : cache.idle) spans.push_back({(uintptr_t) b.ptr, (uintptr_t) b.ptr + b.bytes});
+		std::sort(spans.begin(), spans.end());
+		for (size_t i = 1; i < spans.size(); ++i) if (spans[i].first < spans[i - 1].second) return 3;   // two blocks overlap
+		for (const auto &sp : spans) {   // inside a live backend allocation
+			auto it = backend.upper_bound(sp.first);
+			if (it == backend.begin()) return 4;
+			--it;
+			if (sp.second > it->first + it->second) return 4;
+		}
+		for (const auto &sl : cache.slabs) if (sl.base) {   // a slab's idle count is what the idle list says
+			int n = 0;
+			for (const auto &b : cache.idle) if (b.slab >= 0 && &cache.slabs[(size_t) b.slab] == &sl) ++n;
+			if (n != sl.idle || sl.idle > sl.total) return 5;
+			if (!backend.count((uintptr_t) sl.base)) return 6;
+		}
+		return 0;
+	};
+	std::mt19937_64 rng(seed);
+	static const size_t SIZES[] = {4096, 100000, 300000, 1 << 20, 12 << 20, 13 << 20, 211 << 20, 220 << 20, (size_t) 600 << 20};
+	for (int32_t s = 0; s < steps; ++s) {
+		const uint64_t r = rng();
+		if ((r & 7) < 4 || live.empty()) {
+			size_t got = 0;
+			const size_t want = SIZES[(r >> 8) % (sizeof SIZES / sizeof SIZES[0])] + (size_t) ((r >> 16) & 0xfff);
+			const bool idle_before = !cache.idle.empty();
+			void *q = acquire(want, &got);
+			if (q) { if (got < want) return 7; live.push_back({q, got}); }
+			else if (idle_before && used + BlockCacheCore::size_class(want) <= budget) return 8;   // refused although trimming would have made room
+		} else if ((r & 7) < 7) {
+			const size_t i = (size_t) ((r >> 8) % live.size());
+			release(live[i]);
+			live[i] = live.back(); live.pop_back();
+		} else {
+			trim();
+			for (const auto &b : cache.idle) if (b.slab < 0 || cache.slabs[(size_t) b.slab].idle == cache.slabs[(size_t) b.slab].total) return 9;
+		}
+		if (const int32_t e = check()) return e;
+	}
+	for (const Live &l : live) release(l);
+	live.clear();
+	trim();
+	if (const int32_t e = check()) return e;
+	if (!cache.idle.empty() || cache.idle_bytes != 0 || used != 0 || !backend.empty()) return 10;   // everything went back
+	return 0;
+}

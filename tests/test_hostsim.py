@@ -293,3 +293,13 @@ def test_lz77_distance_multiplier_of_lf_global_is_the_whole_images(sim, ref):
     again = np.zeros((28, 645, 4), np.uint8)
     assert D.oracle_run(buf, len(data), again.ctypes.data, None) == 0
     assert np.array_equal(again, expect)
+
+
+def test_device_memory_cache_bookkeeping(sim):
+    """device/block_cache.hpp (free list, size classes, slabs) driven like runtime.hip drives it, over a backend with a byte budget:
+    random acquire / release / trim sequences keep every invariant (no overlapping blocks, byte counts, slabs freed only when idle,
+    a failed allocation retried after a trim), with a roomy and with a tight budget and cache limit"""
+    sim.hostsim_block_cache_selftest.restype = C.c_int32
+    sim.hostsim_block_cache_selftest.argtypes = [C.c_uint32, C.c_int32, C.c_uint64, C.c_uint64]
+    for seed, budget, limit in [(1, 288 << 30, 216 << 30), (2, 8 << 30, 6 << 30), (3, 3 << 30, 1 << 30), (4, 2 << 30, 0), (5, 64 << 30, 1 << 40)]:
+        assert sim.hostsim_block_cache_selftest(seed, 4000, budget, limit) == 0, (seed, budget, limit)
