@@ -28,12 +28,16 @@ build/obj/%.o: $(SRC)/device/%.hip $(wildcard $(SRC)/device/*.h) $(wildcard $(SR
 build/libj40hip.so: $(HOST_OBJS) $(DEV_OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^ -lpthread
 
-hostsim: build/libhostsim.so build/liboracle_driver.so
+hostsim: build/libhostsim.so build/liboracle_driver.so build/api_threads
 # test-only glue: parses a stream with the product's host parser, takes the plan view and hands it to
 # the CPU oracle (oracle/libj40oracle.so)
 build/liboracle_driver.so: tests/oracle_driver.c build/libj40hip.so oracle/hotpath_oracle.c include/j40hip.h
 	$(MAKE) -C oracle restatement
 	gcc -O2 -fPIC -shared -Wall -o $@ tests/oracle_driver.c -Lbuild -Loracle -lj40hip -lj40oracle -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../oracle'
+
+# test-only: many threads running the reference's public API sequence (dj40.c's) against the product library
+build/api_threads: tests/api_threads.c include/j40.h build/libj40hip.so
+	gcc -O2 -Wall -Wextra -pthread -Iinclude -o $@ tests/api_threads.c -Lbuild -lj40hip -Wl,-rpath,'$$ORIGIN'
 
 # device functions compiled for the CPU, test infrastructure only (tests/hostsim)
 build/libhostsim.so: tests/hostsim/hostsim.cpp $(SRC)/plan_build.cpp $(SRC)/plan_front.cpp $(SRC)/entropy.cpp $(SRC)/modular.cpp $(SRC)/tables.cpp $(SRC)/frame.cpp $(wildcard $(SRC)/device/*.h) $(wildcard $(SRC)/*.hpp)

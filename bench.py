@@ -6,11 +6,12 @@ codestream bytes -> [host: container / headers / TOC / LfGlobal / HfGlobal / LfG
 -> [device: entropy decode of every pass-group section (K1), dequantisation + chroma-from-luma + inverse transforms +
 XYB->sRGB + RGBA pack (K2 family)] -> RGBA u8x4 in the j40_pixels_u8x4 layout, resident in HBM. Every stage of many frames
 is in flight at once (j40hip_pipeline_*: host worker threads, batched entropy launches on alternating streams). Nothing is
-parsed, built or uploaded ahead of the timed region: only the codestream BYTES exist when it starts (SURVEY.md section 8d /
-BASELINE.md section 3: the reference's clock runs from "codestream resident in memory", and so does `cpu_baseline`). `value` stops with
-the pixels in HBM -- the memory of the device that computed them, as the reference's clock stops with them in host memory; the
-same pass with the copy back to (pinned) host memory over PCIe is reported beside it as `host_to_host`, and the part round 1
-reported as `value` -- frames parsed and uploaded ahead of time, kernels only -- as `device_resident`.
+parsed, built or uploaded ahead of the timed region: only the codestream BYTES exist when it starts, and `value` stops when the
+RGBA of every frame is back in (pinned) HOST memory -- SURVEY.md section 8d / BASELINE.md section 3: "codestream in host memory ->
+RGBA in host memory in the j40_pixels_u8x4 layout", the same two end points as the reference's clock and as `cpu_baseline`
+beside it. The copy back is 4 B/px over PCIe (133 MB per 8K frame), which is what bounds `value`. The same pass with the pixels
+left in HBM is reported as `device_output` (rounds 2 and 3 reported that as `value`), and the part round 1 reported -- frames
+parsed and uploaded ahead of time, kernels only -- as `device_resident`.
 
 The host part runs on the CPU time the container is given (cgroup cpu.max; 16 CPUs on the bench boxes although 256 are visible),
 which is what bounds `value` today; DESIGN.md section 5 has the breakdown.
@@ -79,6 +80,65 @@ def cpu_baseline(data, width, height, budget_s=12.0):
                       % (len(times), width, height, len(times), best)}
 
 
+def _cpu_worker(job):
+    """one worker PROCESS of cpu_baseline_many: decodes its share of the streams `rounds` times through the reference (no GPU, no torch)"""
+    paths, width, height, rounds = job
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from refdec import Ref
+    import numpy as np
+    ref = Ref()
+    out = np.zeros(width * height * 4, np.uint8)
+    bufs = []
+    for p in paths:
+        d = open(p, "rb").read()
+        bufs.append((C.create_string_buffer(d, len(d)), len(d)))
+    if rounds == 0:
+        return 0
+    n = 0
+    for _ in range(rounds):
+        for b, size in bufs:
+            if ref.lib.ref_decode_into(b, size, out.ctypes.data, out.size):
+                return -1
+            n += 1
+    return n
+
+
+def cpu_baseline_many(datas, width, height, procs, budget_s=10.0):
+    """SURVEY 8d / BASELINE.md 3 for the batch configuration: the unmodified reference in N = #cores worker PROCESSES, each decoding
+    its own share of the frames on one core (the reference is single-threaded by design, j40.h:8034); bounded sample"""
+    import multiprocessing as mp
+    import tempfile
+    from refdec import REF_SO
+    if not os.path.exists(REF_SO):
+        return None
+    procs = max(1, procs)
+    with tempfile.TemporaryDirectory() as td:
+        paths = []
+        for i, d in enumerate(datas):
+            paths.append(os.path.join(td, "%d.jxl" % i))
+            open(paths[-1], "wb").write(d)
+        per = max(1, len(paths) // procs) if len(paths) >= procs else 1
+        shares = [[paths[(k * per + j) % len(paths)] for j in range(per)] for k in range(procs)]
+        ctx = mp.get_context("spawn")   # (no fork: this process has the HIP runtime loaded)
+        with ctx.Pool(procs) as pool:
+            pool.map(_cpu_worker, [(sh, width, height, 0) for sh in shares])    # workers up, library loaded, files read
+            t0 = time.perf_counter()
+            one = pool.map(_cpu_worker, [(sh, width, height, 1) for sh in shares])
+            t_one = time.perf_counter() - t0
+            if min(one) < 0:
+                return None
+            rounds = max(1, min(50, int(budget_s / max(t_one, 1e-3))))
+            t0 = time.perf_counter()
+            done = pool.map(_cpu_worker, [(sh, width, height, rounds) for sh in shares])
+            el = time.perf_counter() - t0
+    if min(done) < 0:
+        return None
+    frames = sum(done)
+    return {"value": round(width * height * frames / el / 1e6, 2), "unit": "Mpixels/s", "cores": procs, "kind": "reference",
+            "sample": "%d worker processes (one per CPU of the container's quota), each decoding its own %d streams %d times through the reference's public API: %d frames of %dx%d in %.2f s"
+                      % (procs, per, rounds, frames, width, height, el)}
+
+
 def synth_many(specs, workers):
     """generates (or finds in build/streams) the listed streams, `workers` generator processes at a time"""
     from streams import synth
@@ -123,6 +183,8 @@ def main():
     ap.add_argument("--pipe-batch", type=int, default=256, help="frames per entropy launch inside the pipeline")
     ap.add_argument("--host-threads", type=int, default=0, help="pipeline worker threads per GPU (default: the container's CPU quota / GPUs)")
     ap.add_argument("--in-flight", type=int, default=2, help="batches the pipeline keeps in flight on the device")
+    ap.add_argument("--device-output-steps", type=int, default=6, help="steps of the `device_output` section (pixels left in HBM)")
+    ap.add_argument("--host-buffers", type=int, default=0, help="pinned landing buffers for the pixels (default: one per distinct stream, at most 64; 24 per rank with several ranks)")
     ap.add_argument("--lf-streams", choices=["auto", "device", "host"], default="device",
                     help="who decodes the LfGroup streams of the batched frames: the GPU (k_lf_lanes, a lane per section), the host worker threads, or decided frame by frame (auto: the GPU up to its stage's capacity, the host threads beyond)")
     ap.add_argument("--resident-batch", type=int, default=256, help="frames of the device-resident section (kernels only, as round 1 measured)")
@@ -132,6 +194,9 @@ def main():
     ap.add_argument("--maxlog", type=int, default=0, help="--stream coefficient: largest transform side (log2) in the mix; 8 brings in the 128/256-sized transforms (k_vardct_large)")
     ap.add_argument("--shard-groups", action="store_true", help="single-frame mode: ONE frame per step, its pass groups split over the ranks (j40_amd.sharding)")
     ap.add_argument("--shard-kind", choices=["vardct", "modular"], default="vardct", help="--shard-groups: a VarDCT frame, or a Modular lossless frame (RCT only; e.g. --width 16384 --height 16384 = BASELINE config 4)")
+    ap.add_argument("--config5-batch", type=int, default=256, help="config 5 (1024 x 1920x1080): frames per entropy launch")
+    ap.add_argument("--config5-in-flight", type=int, default=4)
+    ap.add_argument("--config5-lf", choices=["auto", "device", "host"], default="host")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-sections", action="store_true", help="only the timed pipeline (no device-resident / latency / other-config sections)")
     ap.add_argument("--skip-modular", action="store_true", help="leave BASELINE config 4 (16384 x 16384 Modular) out of `configs`")
@@ -187,21 +252,42 @@ def main():
     bufs = [C.create_string_buffer(d, len(d)) for d in datas]
     step_bufs = [bufs[i % D] for i in range(B)]
     step_sizes = [len(datas[i % D]) for i in range(B)]
-    outs = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(B)]
     pipe = j40_amd.Pipeline(local_rank, threads, min(args.pipe_batch, B), args.in_flight, lf_streams=args.lf_streams)
+    # the pixels land in pinned host memory, used round-robin: frame i and frame i + D are the same stream, hence the same pixels
+    # (letting the pixel kernels store straight into pinned memory instead was measured: 5.1 Gpx/s against 7.5 for the copy)
+    nh = args.host_buffers or min(D, B, 64 if world == 1 else 24)
+    host_outs = [torch.empty((H, W, 4), dtype=torch.uint8).pin_memory() for _ in range(nh)]
+    step_outs = [host_outs[i % nh] for i in range(B)]
 
     for _ in range(max(args.warmup, 0)):
-        run_pipeline_steps(pipe, step_bufs, step_sizes, outs, W * 4, True, 1, torch, dev, None)
-    elapsed, tickets = run_pipeline_steps(pipe, step_bufs, step_sizes, outs, W * 4, True, args.steps, torch, dev, dist)
+        run_pipeline_steps(pipe, step_bufs, step_sizes, step_outs, W * 4, False, 1, torch, dev, None)
+    elapsed, tickets = run_pipeline_steps(pipe, step_bufs, step_sizes, step_outs, W * 4, False, args.steps, torch, dev, dist)
     st = pipe.stats()
     for t in tickets:
         assert pipe.result(t) == "", "decode error: " + pipe.result(t)
+    first_pixels = host_outs[0].clone()
+    # ---- the same steps with the pixels left in HBM (what rounds 2 and 3 reported as `value`) ----
+    device_output = None
+    if not args.skip_sections or world > 1:
+        outs = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(B)]
+        run_pipeline_steps(pipe, step_bufs, step_sizes, outs, W * 4, True, 1, torch, dev, None)
+        e_dev, tk = run_pipeline_steps(pipe, step_bufs, step_sizes, outs, W * 4, True, max(1, args.device_output_steps), torch, dev, dist)
+        sd = pipe.stats()
+        assert all(pipe.result(t) == "" for t in tk)
+        assert torch.equal(outs[0].cpu(), first_pixels)
+        dl = max(sd["launches"], 1)
+        device_output = {"value": round(W * H * B * max(1, args.device_output_steps) * world / e_dev / 1e6, 2), "unit": "Mpixels/s", "frames_per_step": B, "steps": max(1, args.device_output_steps),
+                         "ms_per_step": round(e_dev / max(1, args.device_output_steps) * 1e3, 3),
+                         "k_hf_lanes_ms_per_launch": round((sd["k1_kernel_ms"] / dl) or (sd["k1_ms"] / dl), 3), "pixel_kernels_ms_per_launch": round(sd["k2_ms"] / dl, 3),
+                         "lf_streams_plan_tail_ms_per_launch": round(sd["lf_plan_ms"] / dl, 3),
+                         "note": "as `value`, but the RGBA stays in device memory (no copy back): the device is the bound here, PCIe is for `value`"}
+        del outs
+        torch.cuda.empty_cache()
     resident_multi = None
     if world > 1 and not args.skip_sections:
         # every rank's kernels alone on frames prepared ahead (what scales with the GPUs when the host's CPU quota does not):
         # the same figure the single-GPU line carries as `device_resident`, aggregated over the ranks
         pipe.close()
-        del outs
         torch.cuda.empty_cache()
         R = max(1, min(args.resident_batch, B))
         with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
@@ -247,16 +333,16 @@ def main():
         "config": {"workload": ("%d x %dx%d VarDCT frames per GPU per step, " + stream_words + ", %d distinct streams, %.3f bpp, %d pass groups each), whole decode "
                                "path per frame inside the timed region: the host parses what precedes the LfGroup sections (%d worker threads, container CPU quota %d of %d visible CPUs) and copies "
                                "it to the GPU; LfGroup streams (%s), plan build, LfGroup tail, entropy decode and pixel kernels are enqueued per batch of %d frames; "
-                               "codestream bytes in, RGBA u8x4 resident in HBM out")
+                               "the RGBA of each frame is copied back into pinned host memory behind its batch's kernels; codestream bytes in host memory in, RGBA u8x4 in host memory out")
                                % (B, W, H, D, 8.0 * sum(step_sizes) / (B * W * H), ((W + 255) // 256) * ((H + 255) // 256), threads, quota, os.cpu_count() or 1,
                                   {"auto": "GPU or host thread, decided per frame", "device": "GPU", "host": "host threads"}[args.lf_streams], min(args.pipe_batch, B)),
-                   "clock": "codestream bytes in memory -> RGBA u8x4 in device memory, nothing prepared ahead (SURVEY 8d); same start as cpu_baseline, which ends in host memory",
+                   "clock": "codestream bytes in host memory -> RGBA u8x4 in (pinned) host memory, nothing prepared ahead (SURVEY 8d / BASELINE.md 3: the same two end points as cpu_baseline); bound by the copy back, 4 B/px over PCIe; the same pass with the pixels left in HBM: `device_output`",
                    "stream": args.stream, "frame_pixels": W * H, "frames_per_step": B, "codestream_bytes": step_sizes[0], "parallelism": "frames x%d" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": None,
                      "kernel": "k_hf_lanes", "kernel_ms": round(k1_launch_ms, 4), "launches_in_timed_region": st["launches"], "frames_per_launch": round(frames_per_launch, 2),
                      "algorithmic_bytes_per_launch": int(alg_launch),
                      "step_frac": round(alg_step * args.steps / elapsed / 8e12, 6),
-                     "note": "kernel_ms: k_hf_lanes' own duration inside the timed region, from HIP events the device records at the kernel's start and end (hipExtLaunchKernelGGL; what rocprofv3 --kernel-trace reports), averaged over the launches; other batches' pixel kernels and the LfGroup lane decoder run beside it (alone on the device it takes 40.3 ms: DESIGN.md section 4); step_frac = algorithmic bytes of the steps / wall time / peak"},
+                     "note": "kernel_ms: k_hf_lanes' own duration inside the timed region, from HIP events the device records at the kernel's start and end (hipExtLaunchKernelGGL; what rocprofv3 --kernel-trace reports), averaged over the launches; other batches' stages run beside it (`kernel_alone`: the same launch with the device to itself); step_frac = algorithmic bytes of the steps / wall time / peak -- the wall time of `value` is PCIe time, see device_output for the device's own pace"},
         "pipeline": {"host_stage_ms_per_frame": round(st["parse_thread_ms"] / max(st["completed"] - st["single_frames"], 1), 2),
                      "lf_streams_plan_tail_ms_per_launch": round(st["lf_plan_ms"] / launches, 3), "entropy_ms_per_launch": round(k1_stage_ms, 3), "pixel_kernels_ms_per_launch": round(st["k2_ms"] / launches, 3),
                      "host_threads": threads, "cpu_quota": quota, "lf_streams": args.lf_streams, "lf_streams_on_device_frames": st["lf_device_frames"], "frames": st["completed"],
@@ -264,10 +350,15 @@ def main():
                      "note": "host_stage: ms of one worker thread per frame (headers, TOC, LfGlobal, HfGlobal, staging; plus the LfGroup streams for the frames the host kept); "
                              "the per-launch figures are HIP-event times on the batch's stream and overlap with other batches' stages"},
     }
+    if device_output is not None:
+        device_output["roofline_frac_step"] = round(alg_step / (device_output["ms_per_step"] / 1e3) / 8e12, 6)
+        result["device_output"] = device_output
+    result["pcie"] = {"bytes_back_per_step": 4 * W * H * B, "achieved_gb_per_s": round(4 * W * H * frames_total / world / elapsed / 1e9, 2),
+                      "note": "RGBA copied back per GPU during the timed region / wall time; a Gen5 x16 link moved 57 GB/s device-to-host on these boxes (tools/pcie_probe.py): 14.2 Gpx/s is the ceiling of `value` per GPU"}
     if resident_multi is not None:
         result["device_resident"] = resident_multi
     try:
-        pt = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+        pt = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
         if abs(pt.get("frames_per_launch", 0) - frames_per_launch) < 1 and (W, H) == (7680, 4320) and pt.get("stream", "coefficient") == args.stream:
             result["roofline"]["traffic"] = int((pt["fetch_size_kb"] * pt.get("fetch_correction", 1.0) + pt["write_size_kb"]) * 1024)
             result["roofline"]["traffic_source"] = pt["source"]
@@ -279,29 +370,11 @@ def main():
         cb = cpu_baseline(datas[0], W, H)
         if cb:
             result["cpu_baseline"] = cb
-            d = np.abs(outs[0].cpu().numpy().astype(np.int16) - cpu_baseline.last_pixels.astype(np.int16))
+            d = np.abs(first_pixels.numpy().astype(np.int16) - cpu_baseline.last_pixels.astype(np.int16))
             result["parity_vs_reference"] = {"max_abs_diff": int(d.max()), "differing_samples": int((d > 0).sum()), "samples": int(d.size)}
             assert d.max() <= 1, "GPU and reference pixels differ by more than one level"
 
     if not args.skip_sections and world == 1:
-        # ---- the same steps with the copy back to pinned host memory (the reference's own end point) ----
-        # (the device images of the timed steps go first: this section's frames get theirs from the pipeline)
-        first_pixels = outs[0].cpu()
-        del outs
-        torch.cuda.empty_cache()
-        nh = min(D, B, 64)   # pinned landing buffers, used round-robin: frame i and frame i + D are the same stream, hence the same pixels
-        host_outs = [torch.empty((H, W, 4), dtype=torch.uint8).pin_memory() for _ in range(nh)]
-        step_outs = [host_outs[i % nh] for i in range(B)]
-        # (letting the pixel kernels store straight into the pinned buffers instead was measured: 5.1 Gpx/s against 7.5 for the copy)
-        run_pipeline_steps(pipe, step_bufs, step_sizes, step_outs, W * 4, False, 1, torch, dev, None)
-        h2h_steps = 4
-        e2, tk = run_pipeline_steps(pipe, step_bufs, step_sizes, step_outs, W * 4, False, h2h_steps, torch, dev, None)
-        assert all(pipe.result(t) == "" for t in tk)
-        assert torch.equal(host_outs[0], first_pixels)
-        result["host_to_host"] = {"value": round(W * H * B * h2h_steps / e2 / 1e6, 2), "unit": "Mpixels/s", "frames_per_step": B, "steps": h2h_steps,
-                                  "note": "as `value`, plus the copy back into pinned host memory behind each batch's kernels (the reference's own end point, SURVEY 8d); "
-                                          "4 B/px over PCIe Gen5 x16 (57 GB/s measured, tools/pcie_probe.py) is 2.3 ms per 8K frame and overlaps with the host work of the next batch; "
-                                          "the last batch's copy (0.6 s for 256 frames) is a tail no step hides, so this figure rises with the number of steps"}
         del host_outs, step_outs
         pipe.close()
         torch.cuda.empty_cache()
@@ -381,21 +454,34 @@ def sections(args, torch, np, j40_amd, dev, local_rank, datas, quota):
     cfg["config2_3840x2160_one_gpu"] = {"frame_ms": round(float(sum(ms)), 3), "entropy_ms": round(float(ms[0]), 3), "pixel_kernels_ms": round(float(ms[1]), 3),
                                         "mpixels_per_s": round(3840 * 2160 / float(sum(ms)) / 1e3, 1), "mode": "latency (one frame alone, device time)"}
     fr.close()
-    # config 5: 1024 independent 1920x1080 frames through the pipeline
+    # config 5: 1024 independent 1920x1080 frames through the pipeline. Sections are the unit of the entropy launch (40 per frame:
+    # 256 frames are 256 wavefronts, one per compute unit), so the frames go in large batches, several in flight; the LfGroup
+    # streams of such small frames (one section of 130 k samples each) are decoded by the host threads: 0.8 ms of one core per
+    # frame against 0.15 s of latency for the lane decoder's launch
     n5, d5 = 1024, 16
     d1080 = synth_many([("vardct", 1920, 1080, 110 + i, {}) for i in range(d5)], quota)
     b1080 = [C.create_string_buffer(d, len(d)) for d in d1080]
     o5 = [torch.empty((1080, 1920, 4), dtype=torch.uint8, device=dev) for _ in range(n5)]
-    pipe = j40_amd.Pipeline(local_rank, max(2, quota), 256, 1)
+    pipe = j40_amd.Pipeline(local_rank, max(2, quota), args.config5_batch, args.config5_in_flight, lf_streams=args.config5_lf)
     bb = [b1080[i % d5] for i in range(n5)]; ss = [len(d1080[i % d5]) for i in range(n5)]
-    run_pipeline_steps(pipe, bb[:256], ss[:256], o5[:256], 1920 * 4, True, 1, torch, dev, None)
-    e5, tk = run_pipeline_steps(pipe, bb, ss, o5, 1920 * 4, True, 1, torch, dev, None)
-    assert all(pipe.result(t) == "" for t in tk)
-    st = pipe.stats()
+    run_pipeline_steps(pipe, bb, ss, o5, 1920 * 4, True, 1, torch, dev, None)
+    e5 = None
+    for _ in range(3):
+        e, tk = run_pipeline_steps(pipe, bb, ss, o5, 1920 * 4, True, 1, torch, dev, None)
+        assert all(pipe.result(t) == "" for t in tk)
+        if e5 is None or e < e5:
+            e5, st = e, pipe.stats()
+    for i in range(d5):   # per-stream pixels: frame i and frame i + 16 k decode the same stream
+        assert torch.equal(o5[i], o5[i + d5 * (n5 // d5 - 1)])
     cfg["config5_1024x_1920x1080_batch"] = {"mpixels_per_s": round(1920 * 1080 * n5 / e5 / 1e6, 1), "seconds": round(e5, 3), "frames": n5, "distinct_streams": d5,
                                             "entropy_ms_per_launch": round(st["k1_ms"] / max(st["launches"], 1), 3), "frames_per_launch": round(st["launch_frames"] / max(st["launches"], 1), 1),
-                                            "mode": "pipeline (whole path per frame, output in HBM); 256 frames per entropy launch instead of one hipStream per frame"}
+                                            "launches": st["launches"], "lf_streams": args.config5_lf, "in_flight": args.config5_in_flight,
+                                            "mode": "pipeline (whole path per frame, codestream bytes in host memory -> RGBA in HBM; best of 3 passes over the 1024 frames); %d frames = %d sections per entropy launch instead of one hipStream per frame" % (args.config5_batch, 40 * args.config5_batch)}
     pipe.close()
+    if not args.no_cpu_baseline:
+        cb5 = cpu_baseline_many(d1080, 1920, 1080, quota)
+        if cb5:
+            cfg["config5_1024x_1920x1080_batch"]["cpu_baseline"] = cb5
     del o5
     torch.cuda.empty_cache()
     # config 1: 256x256 RGBA fjxl-like, single section

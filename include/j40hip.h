@@ -298,6 +298,16 @@ J40HIP_API void j40hip_pipeline_free(j40hip_pipeline *p);
 /* queues one image. buf is borrowed until the ticket is done. rgba: `stride_bytes` * height bytes of host memory (pinned memory for
  * full copy speed) or, with device_output != 0, of device memory (no copy back). */
 J40HIP_API uint32_t j40hip_pipeline_submit(j40hip_pipeline *p, const void *buf, size_t size, void *rgba, size_t stride_bytes, int device_output, int64_t *ticket);
+/* One image, synchronously: queued like a submitted one, the calling thread sleeps until it is done; returns 0 or the image's 4-char
+ * code. The pixel memory is asked for through `alloc` once the image's size is known (called once, on a pipeline thread, before
+ * anything is written; it returns host memory -- pinned for full copy speed -- of *stride_bytes * height bytes, *stride_bytes >=
+ * 4 * width, or NULL: "!mem"). Any number of threads may call this at once: their images share the pipeline's batches. This is what
+ * j40_next_frame (include/j40.h) runs on when several threads are inside the public API at once. */
+typedef void *(*j40hip_output_alloc)(void *ctx, int64_t width, int64_t height, size_t *stride_bytes);
+J40HIP_API uint32_t j40hip_pipeline_run(j40hip_pipeline *p, const void *buf, size_t size, j40hip_output_alloc alloc, void *ctx);
+/* > 0: a prepared image waits at most `ms` for its batch to fill up while the device has a free batch slot (serving: images arrive
+ * one by one); 0 (default): a partial batch is launched only when nothing else is queued */
+J40HIP_API void j40hip_pipeline_set_max_wait_ms(j40hip_pipeline *p, double ms);
 /* waits until everything submitted so far is done */
 J40HIP_API uint32_t j40hip_pipeline_drain(j40hip_pipeline *p);
 /* 0 or the image's 4-char error code, as j40_error would give it ("rnge" for an unknown or unfinished ticket) */

@@ -49,6 +49,10 @@ class _Pixels(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("stride_bytes", C.c_int32), ("data", C.c_void_p)]
 
 
+# j40hip_output_alloc (include/j40hip.h): (ctx, width, height, *stride_bytes) -> host memory for the pixels
+OUTPUT_ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_size_t))
+
+
 def lib():
     """loads build/libj40hip.so; raises if it has not been built (no fallback)."""
     global _lib
@@ -96,6 +100,7 @@ def lib():
         "j40hip_frame_after_frame_status": (u32, [vp]),
         "j40hip_pipeline_create": (vp, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(u32)]), "j40hip_pipeline_free": (None, [vp]), "j40hip_pipeline_create_ex": (vp, [C.c_int, C.c_int, C.c_int, C.c_int, u32, C.POINTER(u32)]), "j40hip_pipeline_lf_device_frames": (i64, [vp]),
         "j40hip_pipeline_submit": (u32, [vp, vp, sz, vp, sz, C.c_int, C.POINTER(i64)]), "j40hip_pipeline_drain": (u32, [vp]),
+        "j40hip_pipeline_run": (u32, [vp, vp, sz, OUTPUT_ALLOC, vp]), "j40hip_pipeline_set_max_wait_ms": (None, [vp, C.c_double]),
         "j40hip_pipeline_result": (u32, [vp, i64]), "j40hip_pipeline_stats": (None, [vp, vp]), "j40hip_pipeline_stats_ex": (None, [vp, vp]), "j40hip_pipeline_reset_stats": (None, [vp]),
     }
     for name, (res, args) in sigs.items():
@@ -417,9 +422,12 @@ class Pipeline:
     """whole-frame throughput pipeline (include/j40hip.h, j40hip_pipeline_*): codestreams in host memory -> RGBA u8x4 in host or
     device memory; host worker threads parse and upload, one thread batches the uploaded frames per entropy launch"""
 
-    def __init__(self, device=0, host_threads=0, batch_frames=32, max_in_flight=2, lf_streams="auto", tune_malloc=False):
+    def __init__(self, device=0, host_threads=0, batch_frames=32, max_in_flight=2, lf_streams="auto", tune_malloc=False, lf_on_device=None):
         """lf_streams: who decodes the LfGroup streams of the batched frames -- "auto" (decided frame by frame), "device"
-        (k_lf_groups), "host" (the worker threads)"""
+        (k_lf_lanes), "host" (the worker threads). `lf_on_device` is the deprecated spelling of rounds 1-2: True = "device",
+        False = "host"."""
+        if lf_on_device is not None:
+            lf_streams = "device" if lf_on_device else "host"
         err = C.c_uint32()
         flags = {"auto": 0, "device": 1, "host": 2}[lf_streams] | (4 if tune_malloc else 0)
         self.h = lib().j40hip_pipeline_create_ex(device, host_threads, batch_frames, max_in_flight, flags, C.byref(err))
@@ -448,6 +456,24 @@ class Pipeline:
             raise J40Error(err4(code), "in j40hip_pipeline_submit")
         return t.value
 
+    def run(self, data):
+        """one image, synchronously (j40hip_pipeline_run): the calling thread sleeps until it is done; any number of threads may call
+        this at once and share the pipeline's batches. Returns (err4, rgba ndarray [height, width, 4] or None)."""
+        buf = data if isinstance(data, C.Array) else C.create_string_buffer(bytes(data), len(data))
+        got = {}
+
+        def alloc(ctx, width, height, stride_out):
+            got["a"] = np.empty((int(height), int(width), 4), np.uint8)
+            stride_out[0] = int(width) * 4
+            return got["a"].ctypes.data
+
+        cb = OUTPUT_ALLOC(alloc)
+        code = lib().j40hip_pipeline_run(self.h, buf, len(data), cb, None)
+        return err4(code), (got.get("a") if not code else None)
+
+    def set_max_wait_ms(self, ms):
+        lib().j40hip_pipeline_set_max_wait_ms(self.h, float(ms))
+
     def drain(self):
         code = lib().j40hip_pipeline_drain(self.h)
         if code:
@@ -460,7 +486,7 @@ class Pipeline:
     def stats(self):
         a = (C.c_double * 12)()
         lib().j40hip_pipeline_stats_ex(self.h, a)
-        return dict(parse_thread_ms=a[0], single_thread_ms=a[1], completed=int(a[2]), wall_ms=a[3], k1_ms=a[4], k2_ms=a[5], launches=int(a[6]), launch_frames=int(a[7]),
+        return dict(parse_thread_ms=a[0], single_thread_ms=a[1], upload_thread_ms=a[1],   # (upload_thread_ms: the key's name until round 3) completed=int(a[2]), wall_ms=a[3], k1_ms=a[4], k2_ms=a[5], launches=int(a[6]), launch_frames=int(a[7]),
                     lf_plan_ms=a[8], lf_device_frames=int(a[9]), single_frames=int(a[10]), k1_kernel_ms=a[11])
 
     def reset_stats(self):

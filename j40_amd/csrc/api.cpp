@@ -4,7 +4,9 @@
 #define J40_API __attribute__((visibility("default")))
 #include "../../include/j40.h"
 #include "capi.hpp"
+#include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -48,7 +50,7 @@ struct j40__inner {
 	void *owned;                                             // file contents (from_file)
 	j40hip_frame *frame;
 	int decoded, rendered;
-	uint8_t *pixels; int32_t width, height, stride_bytes;
+	uint8_t *pixels; size_t pixels_bytes; int32_t width, height, stride_bytes;   // image-owned plane: pinned host memory from the library's pool
 };
 
 namespace {
@@ -81,7 +83,7 @@ void free_inner(j40__inner *inner) {
 	if (inner->frame) j40hip_frame_free(inner->frame);
 	if (inner->freefunc && inner->buf) inner->freefunc(inner->buf);
 	free(inner->owned);
-	free(inner->pixels);
+	if (inner->pixels) j40hip_pinned_release(inner->pixels, inner->pixels_bytes);
 	inner->magic = 0;
 	free(inner);
 }
@@ -92,30 +94,70 @@ j40__inner *new_inner() {
 	return inner;
 }
 
-// the whole decode: host parse, upload, hot path on the GPU, RGBA into the image-owned plane
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// The image-owned pixel plane in the reference's layout: rows of stride = 32 * ceil((4 * width + 1) / 32) bytes, 32-byte aligned
+// (forced padding, j40.h:1061-1065, 7939). Pinned host memory, so that the copy from the device runs at the link's rate.
+uint32_t make_plane(j40__inner *inner, int64_t width, int64_t height) {
+	const int64_t stride = (width * 4 + 1 + 31) / 32 * 32;
+	if (width >= INT32_MAX / 4 || stride > INT32_MAX || height > INT32_MAX) return code4("bigg");
+	inner->width = (int32_t) width; inner->height = (int32_t) height; inner->stride_bytes = (int32_t) stride;
+	inner->pixels_bytes = (size_t) stride * (size_t) height;
+	inner->pixels = (uint8_t *) j40hip_pinned_acquire(inner->pixels_bytes);
+	return inner->pixels ? 0 : code4("!mem");
+}
+
+void *serve_alloc(void *ctx, int64_t width, int64_t height, size_t *stride_bytes) {   // (j40hip_output_alloc: called on a pipeline thread)
+	j40__inner *inner = (j40__inner *) ctx;
+	if (make_plane(inner, width, height)) return nullptr;
+	*stride_bytes = (size_t) inner->stride_bytes;
+	return inner->pixels;
+}
+
+// How j40_next_frame decodes. The reference decodes on the calling thread and so does the LATENCY path here: host parse, upload,
+// one section per wavefront, copy back -- the shortest way for one image. When several threads are inside the API at once their
+// images are handed to the process-wide pipeline of the device instead (SERVING: j40hip_pipeline_run, device/pipeline.hip) and share
+// its batches -- one entropy launch for all of them, the copies back at the link's rate; the calling thread sleeps meanwhile.
+// J40HIP_SERVE=1 always serves, =0 never does; default: serve when another call is in progress, or was within the last 200 ms.
+std::atomic<int> g_inside{0};
+std::atomic<int64_t> g_last_overlap_ms{-1000000};
+int serve_policy() { static const int v = [] { const char *e = getenv("J40HIP_SERVE"); return !e || !*e ? 2 : atoi(e) != 0 ? 1 : 0; }(); return v; }
+int device_index() { const char *e = getenv("J40HIP_DEVICE"); return e ? atoi(e) : 0; }
+
+// the whole decode: RGBA into the image-owned plane
 j40_err advance(j40__inner *inner, int origin) {
 	if (inner->decoded) return 0;
+	struct Inside { int n; Inside() : n(++g_inside) {} ~Inside() { --g_inside; } } inside;
+	const int policy = serve_policy();
+	const int64_t now = (int64_t) now_ms();
+	if (inside.n > 1) g_last_overlap_ms.store(now);
+	const bool serve = policy == 1 || (policy == 2 && (inside.n > 1 || now - g_last_overlap_ms.load() < 200));
+	static const bool timing = getenv("J40HIP_API_TIMING") != nullptr;
 	uint32_t err = 0;
-	inner->frame = j40hip_frame_parse(inner->buf, inner->size, 4, &err);
+	if (serve) {
+		j40hip_pipeline *p = j40hip_serve_pipeline(device_index(), &err);
+		if (p) err = j40hip_pipeline_run(p, inner->buf, inner->size, serve_alloc, inner);
+		if (err) { inner->origin = origin; inner->err = err; return err; }
+		inner->decoded = 1;
+		return 0;
+	}
+	const double t0 = now_ms();
+	double t1 = t0, t2 = t0, t3 = t0;
+	static const int parse_threads = [] { const char *e = getenv("J40HIP_PARSE_THREADS"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
+	inner->frame = j40hip_frame_parse(inner->buf, inner->size, parse_threads, &err);
+	t1 = now_ms();
+	if (!err && j40hip_device_count() <= device_index()) err = code4("!gpu");   // (before the plane: pinned memory needs the device too)
 	if (!err) {
 		int64_t info[32];
 		j40hip_frame_info(inner->frame, info);
-		inner->width = (int32_t) info[0]; inner->height = (int32_t) info[1];
-		int64_t stride = ((int64_t) inner->width * 4 + 1 + 31) / 32 * 32;       // forced padding, j40.h:1061-1065, 7939
-		if (inner->width >= INT32_MAX / 4 || stride > INT32_MAX) err = code4("bigg");
-		else {
-			inner->stride_bytes = (int32_t) stride;
-			void *p = nullptr;
-			if (posix_memalign(&p, 32, (size_t) stride * (size_t) inner->height)) err = code4("!mem");
-			else inner->pixels = (uint8_t *) p;
-		}
+		err = make_plane(inner, info[0], info[1]);
 	}
-	if (!err) {
-		const char *dev = getenv("J40HIP_DEVICE");
-		err = j40hip_frame_upload(inner->frame, dev ? atoi(dev) : 0);
-	}
+	t2 = now_ms();
+	if (!err) err = j40hip_frame_upload(inner->frame, device_index());
+	t3 = now_ms();
 	if (!err) err = j40hip_frame_decode_to_host(inner->frame, inner->pixels, (size_t) inner->stride_bytes);
 	if (!err) err = j40hip_frame_after_frame_status(inner->frame);   // bytes behind the frame (j40__no_more_bytes, j40.h:8215)
+	if (timing) fprintf(stderr, "[j40 api] %d x %d: parse %.2f ms, plane %.2f ms, plan + upload %.2f ms, decode + copy back %.2f ms\n", inner->width, inner->height, t1 - t0, t2 - t1, t3 - t2, now_ms() - t3);
 	if (err) { inner->origin = origin; inner->err = err; return err; }
 	inner->decoded = 1;
 	return 0;

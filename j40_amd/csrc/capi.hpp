@@ -40,3 +40,10 @@ extern "C" j40hip_frame *j40hip_frame_parse_with(const void *buf, size_t size, i
 
 // implemented next to the kernels; a no-op when nothing was uploaded
 extern "C" void j40hip_release_device(j40hip_frame *f);
+
+// internal to the library (api.cpp <-> the device side): the process-wide serving pipeline of a device (device/pipeline.hip) and
+// the pool of pinned host planes the public API hands out as image pixels (device/runtime.hip)
+extern "C" j40hip_pipeline *j40hip_serve_pipeline(int device, uint32_t *err);
+extern "C" void j40hip_serve_shutdown(void);
+extern "C" void *j40hip_pinned_acquire(size_t bytes);
+extern "C" void j40hip_pinned_release(void *ptr, size_t bytes);

@@ -192,11 +192,21 @@ static uint32_t wait_for_uploads(j40hip_aframe *const *frames, int n, hipStream_
 void j40hip_aframes_reserve(j40hip_aframe *const *frames, int n, int work_copies, int front_copies) {
 	struct Held { void *p; size_t bytes; };
 	std::vector<Held> held;
-	for (int c = 0; c < std::max(work_copies, front_copies); ++c) for (int i = 0; i < n; ++i) {
+	// best effort: stops while a sixth of the device's memory is still free (the frames in flight and the caller's images need room,
+	// and a failed hipMalloc inside cache_acquire would trim the very cache this is filling)
+	size_t free_b = 0, total_b = 0;
+	auto room = [&](size_t want) {
+		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); return false; }
+		return free_b > total_b / 6 + want;
+	};
+	bool go = true;
+	for (int c = 0; go && c < std::max(work_copies, front_copies); ++c) for (int i = 0; go && i < n; ++i) {
 		const j40hip_aframe *f = frames[i];
 		bool dummy = false; size_t got = 0;
-		if (c < work_copies) if (void *q = cache_acquire(f->device, f->wl.size, &got, &dummy)) held.push_back({q, got});
-		if (c < front_copies) if (void *q = cache_acquire(f->device, f->plan_block_bytes, &got, &dummy)) held.push_back({q, got});
+		if ((i & 15) == 0) go = room(16 * (f->wl.size + f->plan_block_bytes));
+		if (!go) break;
+		if (c < work_copies) { if (void *q = cache_acquire(f->device, f->wl.size, &got, &dummy)) held.push_back({q, got}); else go = false; }
+		if (go && c < front_copies) { if (void *q = cache_acquire(f->device, f->plan_block_bytes, &got, &dummy)) held.push_back({q, got}); else go = false; }
 	}
 	if (n > 0) for (const Held &h : held) cache_release(frames[0]->device, h.p, h.bytes, false);
 }
@@ -476,14 +486,14 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 	// geometry of the entropy launch (runtime.hip batch_assign): up to 64 sections of one frame per wavefront, 1 / 2 / 4 wavefronts
 	// per workgroup sharing one copy of their frame's tables
 	bool lanes_fast = true, tables_in_lds = true; uint32_t lanes_lds = 0, generic_lds = 0;
-	int32_t total_waves = 0, nlf = 0, max_lf_cells = 0; size_t cells_total = 0, max_frame_cells = 0;
+	int32_t total_waves = 0, max_frame_waves = 1, nlf = 0, max_lf_cells = 0; size_t cells_total = 0, max_frame_cells = 0;
 	const double tq0 = prof_now();
 	for (int i = 0; i < n; ++i) {
 		j40hip_aframe *f = frames[i];
 		if (!f || f->device != b->device) return ERR_GPU;
 		if (uint32_t e = aframe_bind_work(f, s)) return e;
 		lanes_fast = lanes_fast && f->hf.lanes_fast; tables_in_lds = tables_in_lds && f->hf.tables_fit_lds; lanes_lds = std::max(lanes_lds, f->hf.lanes_lds_bytes);
-		total_waves += (f->num_groups + 63) / 64; nlf += f->num_lf_groups;
+		total_waves += (f->num_groups + 63) / 64; max_frame_waves = std::max(max_frame_waves, (f->num_groups + 63) / 64); nlf += f->num_lf_groups;
 		max_lf_cells = std::max(max_lf_cells, f->max_lf_cells); cells_total += f->cells; max_frame_cells = std::max(max_frame_cells, f->cells);
 	}
 	if (const char *e = getenv("J40HIP_GENERIC_LANES")) if (atoi(e)) lanes_fast = false;
@@ -491,6 +501,8 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 	// leaves a third of its LDS to whatever else is running -- another batch's pixel kernels, the LfGroup lane decoder -- which
 	// otherwise displaces one of the two workgroups and sends it into a second round: 46 -> 91 ms)
 	int32_t waves_per_wg = lanes_fast ? (total_waves <= 2 * b->cus ? 1 : total_waves <= 4 * b->cus ? 2 : total_waves <= 6 * b->cus || lanes_lds + 8u * HF_LANE_COLS_BYTES > 150u * 1024u ? 4 : 8) : 1;
+	// (a workgroup stays on one frame: with frames of a wavefront or two -- 1920 x 1080 is 40 sections -- larger workgroups would be padding)
+	while (waves_per_wg > 1 && waves_per_wg / 2 >= max_frame_waves) waves_per_wg /= 2;
 	if (const char *e = getenv("J40HIP_WAVES_PER_WG")) if (lanes_fast) waves_per_wg = std::max(1, std::min(lanes_lds + 8u * HF_LANE_COLS_BYTES > 150u * 1024u ? 4 : 8, atoi(e)));
 	std::vector<HfLaneWork> work;
 	for (int i = 0; i < n; ++i) {

@@ -50,10 +50,17 @@ struct Job {
 	void *rgba = nullptr; size_t stride = 0; bool device_output = false;
 	j40hip_aframe *af = nullptr;
 	int64_t width = 0, height = 0, cells = 0;
+	double ready_ms = 0;          // when it became ready for a batch
 	bool lf_failed = false;       // its LfGroup streams could not be launched on the device
 	void *dev_rgba = nullptr;     // host output: the device image the copy back reads
 	uint32_t status = 0;
+	// j40hip_pipeline_run: the caller sleeps on `waiter` until the image is done, and its pixel memory is asked for once the
+	// image's size is known (`alloc`, called on a pipeline thread)
+	j40hip_output_alloc alloc = nullptr; void *alloc_ctx = nullptr;
+	struct Waiter *waiter = nullptr;
 };
+
+struct Waiter { std::mutex m; std::condition_variable cv; bool done = false; uint32_t status = 0; };
 
 struct LfFlight {                 // one launch of LfGroup streams in flight (frames whose streams the device decodes)
 	hipStream_t stream = nullptr;
@@ -62,11 +69,19 @@ struct LfFlight {                 // one launch of LfGroup streams in flight (fr
 	bool busy = false;
 };
 
-struct Slot {                     // one batch in flight
+// One batch in flight. Its frames are handed back in GROUPS as the device gets through them: `kdone` follows the batch's kernels
+// and the copy of its verdicts on the batch's stream; frames whose pixels go to host memory are copied on the pipeline's copy
+// stream behind it, and every few frames an event is recorded there -- a frame is complete (its caller woken) when its group's
+// event has passed, not when the whole batch's copies are through (256 8K frames are 0.6 s of PCIe traffic).
+struct Slot {
 	hipStream_t stream = nullptr;
-	hipEvent_t done = nullptr;
+	hipEvent_t kdone = nullptr;
 	j40hip_abatch *batch = nullptr;
 	std::vector<Job *> jobs;
+	std::vector<hipEvent_t> group_ev;   // made on demand, kept
+	std::vector<int> group_end;         // jobs [group_end[g - 1], group_end[g]) complete with group_ev[g]
+	int next_group = 0;
+	bool failed = false;                // the device reported an error for this batch: everything still pending fails with "!gpu"
 	uint32_t launch_err = 0;      // the batch could not be enqueued: every member fails with this
 	bool busy = false;
 };
@@ -75,6 +90,7 @@ struct Slot {                     // one batch in flight
 
 struct j40hip_pipeline {
 	int device = 0, batch_frames = 32, max_in_flight = 2;
+	double max_wait_ms = 0;             // > 0: a prepared frame waits at most this long for a full batch while a slot is free (serving; j40hip_pipeline_set_max_wait_ms)
 	int lf_mode = 0;                    // LfGroup streams: 0 decided per frame (see above), 1 always the device, 2 always the host threads
 	// mode 0: the device decodes a section in 0.4 s and thousands of them at once (k_lf_lanes: a lane per section, a few dozen
 	// wavefronts per launch that the other kernels hardly notice); a host thread decodes a frame's twelve in 12 ms, one frame at a
@@ -104,6 +120,7 @@ struct j40hip_pipeline {
 	std::thread gpu;
 	std::vector<Slot> slots;
 	std::deque<int> in_flight;          // slot indices, oldest first
+	hipStream_t copy_stream = nullptr;  // every copy of pixels back to host memory, in launch order: one DMA queue at the link's rate
 	// device images for host output, recycled by size
 	std::mutex image_m;
 	std::vector<std::pair<void *, size_t>> free_images;
@@ -116,9 +133,10 @@ struct j40hip_pipeline {
 namespace {
 
 void complete(j40hip_pipeline *p, Job *j) {   // p->m held
-	if ((size_t) j->ticket < p->results.size()) { p->results[(size_t) j->ticket] = j->status; p->finished[(size_t) j->ticket] = 1; }
+	if (j->ticket >= 0 && (size_t) j->ticket < p->results.size()) { p->results[(size_t) j->ticket] = j->status; p->finished[(size_t) j->ticket] = 1; }
 	++p->completed;
 	p->last_done_ms = now_ms();
+	if (Waiter *w = j->waiter) { std::lock_guard<std::mutex> wl(w->m); w->status = j->status; w->done = true; w->cv.notify_one(); }   // (notified under its lock: the waiter's stack frame may be gone right after)
 	delete j;
 	if (p->completed == p->submitted || (p->completed & 63) == 0) p->cv_done.notify_all();   // (whoever drains polls as well)
 }
@@ -138,6 +156,17 @@ void *acquire_image(j40hip_pipeline *p, size_t bytes) {
 }
 void release_image(j40hip_pipeline *p, void *q, size_t bytes) { std::lock_guard<std::mutex> lock(p->image_m); p->free_images.push_back({q, bytes}); }
 
+// the image's pixel memory, once its size is known (j40hip_pipeline_run: asked for here; j40hip_pipeline_submit: the caller's)
+uint32_t ensure_output(Job *j) {
+	if (j->rgba) return j->stride < (size_t) j->width * 4 ? E_RNGE : 0;
+	if (!j->alloc) return E_RNGE;
+	size_t stride = 0;
+	j->rgba = j->alloc(j->alloc_ctx, j->width, j->height, &stride);
+	j->stride = stride;
+	if (!j->rgba) return E_MEM;
+	return j->stride < (size_t) j->width * 4 ? E_RNGE : 0;
+}
+
 // The single-frame path, synchronous on `s` (the calling thread sleeps in the waits): frames the batches do not take, and frames a
 // batch wants decoded again. Parses the image itself.
 uint32_t decode_single(j40hip_pipeline *p, Job *j, hipStream_t s) {
@@ -147,7 +176,7 @@ uint32_t decode_single(j40hip_pipeline *p, Job *j, hipStream_t s) {
 	int64_t info[21];
 	j40hip_frame_info(fr, info);
 	j->width = info[0]; j->height = info[1];
-	if (j->stride < (size_t) j->width * 4) err = E_RNGE;
+	err = ensure_output(j);
 	const size_t bytes = j->stride * (size_t) j->height;
 	void *dev = nullptr;
 	if (!err) { dev = j->device_output ? j->rgba : acquire_image(p, bytes); if (!dev) err = E_MEM; }
@@ -209,10 +238,10 @@ void worker_main(j40hip_pipeline *p, int) {
 		if (j->af) {
 			j40hip_aframe_size(j->af, &j->width, &j->height);
 			j->cells = j40hip_aframe_cells(j->af);
-			if (j->stride < (size_t) j->width * 4) {
+			if (uint32_t e = ensure_output(j)) {
 				(void) hipStreamSynchronize(stream);   // (its copy is in flight)
 				j40hip_aframe_free(j->af); j->af = nullptr;
-				j->status = E_RNGE;
+				j->status = e;
 			}
 		} else j->status = decode_single(p, j, stream);
 		const double t2 = now_ms();
@@ -228,6 +257,7 @@ void worker_main(j40hip_pipeline *p, int) {
 			const int on_dev = j40hip_aframe_lf_on_device(j->af);
 			p->lf_device_frames += on_dev;
 			if (lf_dev && !on_dev) --p->lf_stage;   // (its tables are not the device decoder's kind)
+			j->ready_ms = t2;
 			(on_dev ? p->lf_pending : p->ready).push_back(j);
 			p->cv_ready.notify_all();
 		}
@@ -241,40 +271,124 @@ void worker_main(j40hip_pipeline *p, int) {
 	(void) hipStreamDestroy(stream);
 }
 
-void retire(j40hip_pipeline *p, Slot &slot) {   // GPU thread; waits for the slot's work, then hands the results out
-	const bool ok = hipEventSynchronize(slot.done) == hipSuccess;
-	float ms3[4] = {0, 0, 0, 0};
-	const bool timed = ok && !slot.launch_err && j40hip_abatch_elapsed(slot.batch, ms3) == 0;
-	std::vector<j40hip_aframe *> dead;
-	for (size_t i = 0; i < slot.jobs.size(); ++i) {
-		Job *j = slot.jobs[i];
-		if (!ok) j->status = E_GPU;
-		else if (slot.launch_err) j->status = slot.launch_err;
-		else if (!j->status) {   // (a copy back that could not be enqueued keeps its error)
-			uint32_t code = 0; int redo = 0;
-			j40hip_abatch_result(slot.batch, (int) i, &code, &redo);
-			if (redo) {
-				j40hip_aframe_free(j->af); j->af = nullptr;
-				if (!j->device_output && j->dev_rgba) { release_image(p, j->dev_rgba, j->stride * (size_t) j->height); j->dev_rgba = nullptr; }
-				j->status = decode_single(p, j, slot.stream);
-			} else j->status = code ? code : j40hip_aframe_after_frame_status(j->af);
+// Hands back the frames of `slot` whose group events have passed (`block`: waits for the next group first). Returns true when the
+// slot has nothing pending any more (it is then free for another batch). GPU thread only.
+bool progress(j40hip_pipeline *p, Slot &slot, bool block) {
+	const int ngroups = (int) slot.group_end.size();
+	bool first = true;
+	while (slot.next_group < ngroups) {
+		hipEvent_t ev = slot.group_ev[(size_t) slot.next_group];
+		if (!slot.launch_err && !slot.failed) {
+			hipError_t q = block && first ? hipEventSynchronize(ev) : hipEventQuery(ev);
+			if (q == hipErrorNotReady) { (void) hipGetLastError(); return false; }
+			if (q != hipSuccess) { (void) hipGetLastError(); slot.failed = true; }
 		}
-		if (j->af) { dead.push_back(j->af); j->af = nullptr; }   // its stream has been waited for
-		if (!j->device_output && j->dev_rgba) release_image(p, j->dev_rgba, j->stride * (size_t) j->height);
+		first = false;
+		if (slot.next_group == 0 && !slot.launch_err && !slot.failed) {   // the kernels and the verdicts are through: the stages' times
+			float ms3[4] = {0, 0, 0, 0};
+			if (j40hip_abatch_elapsed(slot.batch, ms3) == 0) {
+				std::unique_lock<std::mutex> lock(p->m);
+				p->lf_ms += ms3[0]; p->k1_ms += ms3[1]; p->k2_ms += ms3[2]; p->k1_kernel_ms += ms3[3]; ++p->launches; p->launch_frames += (int64_t) slot.jobs.size();
+			}
+		}
+		const int begin = slot.next_group ? slot.group_end[(size_t) slot.next_group - 1] : 0, end = slot.group_end[(size_t) slot.next_group];
+		std::vector<j40hip_aframe *> dead;
+		for (int i = begin; i < end; ++i) {
+			Job *j = slot.jobs[(size_t) i];
+			if (slot.failed) j->status = E_GPU;
+			else if (slot.launch_err) j->status = slot.launch_err;
+			else if (!j->status) {   // (a copy back that could not be enqueued keeps its error)
+				uint32_t code = 0; int redo = 0;
+				j40hip_abatch_result(slot.batch, i, &code, &redo);
+				if (redo) {
+					// (the frame's memory goes back to the cache: the batch's kernels are through -- the verdicts follow them on its stream)
+					j40hip_aframe_free(j->af); j->af = nullptr;
+					if (!j->device_output && j->dev_rgba) { release_image(p, j->dev_rgba, j->stride * (size_t) j->height); j->dev_rgba = nullptr; }
+					j->status = decode_single(p, j, slot.stream);
+				} else j->status = code ? code : j40hip_aframe_after_frame_status(j->af);
+			}
+			if (j->af) { dead.push_back(j->af); j->af = nullptr; }
+			if (!j->device_output && j->dev_rgba) { release_image(p, j->dev_rgba, j->stride * (size_t) j->height); j->dev_rgba = nullptr; }
+		}
+		{
+			std::unique_lock<std::mutex> lock(p->m);
+			p->in_flight_frames -= (int64_t) (end - begin);
+			for (int i = begin; i < end; ++i) { --p->resident; complete(p, slot.jobs[(size_t) i]); slot.jobs[(size_t) i] = nullptr; }
+			p->garbage.insert(p->garbage.end(), dead.begin(), dead.end());
+			p->cv_todo.notify_all();
+		}
+		++slot.next_group;
 	}
-	std::unique_lock<std::mutex> lock(p->m);
-	if (timed) { p->lf_ms += ms3[0]; p->k1_ms += ms3[1]; p->k2_ms += ms3[2]; p->k1_kernel_ms += ms3[3]; ++p->launches; p->launch_frames += (int64_t) slot.jobs.size(); }
-	p->in_flight_frames -= (int64_t) slot.jobs.size();
-	for (Job *j : slot.jobs) { --p->resident; complete(p, j); }
-	p->garbage.insert(p->garbage.end(), dead.begin(), dead.end());
-	slot.jobs.clear(); slot.busy = false; slot.launch_err = 0;
-	p->cv_todo.notify_all();
+	slot.jobs.clear(); slot.group_end.clear(); slot.next_group = 0; slot.busy = false; slot.launch_err = 0; slot.failed = false;
+	return true;
+}
+
+// Enqueues one batch on a free slot: device images for the frames whose pixels go to host memory, the whole decode on the slot's
+// stream, the copies back on the copy stream in groups. On "!mem" nothing stays enqueued or bound to the slot and the caller may
+// try again (later, or with fewer frames); any other error is the batch's verdict (the slot is pushed and retires with it).
+uint32_t launch_batch(j40hip_pipeline *p, std::vector<Job *> &take, int si) {
+	Slot &slot = p->slots[(size_t) si];
+	std::vector<j40hip_aframe *> frames; std::vector<void *> outs; std::vector<size_t> strides;
+	uint32_t err = 0;
+	bool host_out = false;
+	for (Job *j : take) {
+		if (!j->dev_rgba) j->dev_rgba = j->device_output ? j->rgba : acquire_image(p, j->stride * (size_t) j->height);
+		if (!j->dev_rgba) err = E_MEM;
+		host_out = host_out || !j->device_output;
+		frames.push_back(j->af); outs.push_back(j->dev_rgba); strides.push_back(j->stride);
+	}
+	if (!err && !slot.batch) { slot.batch = j40hip_abatch_create(p->device); if (!slot.batch) err = E_GPU; }
+	if (!err) err = j40hip_abatch_launch(slot.batch, frames.data(), (int) frames.size(), outs.data(), strides.data(), slot.stream);
+	if (err == E_MEM) {
+		// (abatch_launch binds the working sets before it enqueues anything, so nothing is in flight; the frames keep what they got)
+		for (Job *j : take) if (!j->device_output && j->dev_rgba) { release_image(p, j->dev_rgba, j->stride * (size_t) j->height); j->dev_rgba = nullptr; }
+		return E_MEM;
+	}
+	slot.busy = true; slot.jobs = take; slot.launch_err = err; slot.failed = false; slot.next_group = 0; slot.group_end.clear();
+	// the second full batch says this is a pipeline that will run at depth: size the device memory cache for it now (the device
+	// has two batches to work on meanwhile) rather than wherever the queues first fill up
+	if (!err && (int64_t) frames.size() == p->batch_frames && ++p->full_batches == 2)
+		j40hip_aframes_reserve(frames.data(), (int) frames.size(), p->max_in_flight - 1, (int) (p->max_in_flight - 1 + p->lf_cap / std::max<int64_t>(1, p->batch_frames)));   // (two batches' worth exist)
+	if (hipEventRecord(slot.kdone, slot.stream) != hipSuccess && !slot.launch_err) slot.launch_err = E_GPU;
+	const int n = (int) take.size();
+	// groups: without copies the whole batch is one group that ends with the kernels; with copies about sixteen per batch
+	const int per_group = host_out ? std::max(1, (n + 15) / 16) : n;
+	hipStream_t gs = host_out ? p->copy_stream : slot.stream;
+	if (host_out && !slot.launch_err && hipStreamWaitEvent(p->copy_stream, slot.kdone, 0) != hipSuccess) slot.launch_err = E_GPU;
+	for (int i = 0; i < n; ++i) {
+		Job *j = take[(size_t) i];
+		if (!slot.launch_err && !j->device_output && hipMemcpyAsync(j->rgba, j->dev_rgba, j->stride * (size_t) j->height, hipMemcpyDeviceToHost, p->copy_stream) != hipSuccess) j->status = E_GPU;
+		if ((i + 1) % per_group == 0 || i + 1 == n) {
+			const size_t g = slot.group_end.size();
+			while (slot.group_ev.size() <= g) { hipEvent_t e = nullptr; if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { (void) hipGetLastError(); break; } slot.group_ev.push_back(e); }
+			if (slot.group_ev.size() <= g) { if (!slot.launch_err) slot.launch_err = E_GPU; slot.group_ev.resize(g + 1, slot.kdone); }
+			if (!slot.launch_err && hipEventRecord(slot.group_ev[g], gs) != hipSuccess) slot.launch_err = E_GPU;
+			slot.group_end.push_back(i + 1);
+		}
+	}
+	if (slot.launch_err) { (void) hipStreamSynchronize(slot.stream); if (host_out) (void) hipStreamSynchronize(p->copy_stream); }   // (whatever did get enqueued: nothing may run on memory that is handed back)
+	p->in_flight.push_back(si);
+	return slot.launch_err;
 }
 
 void gpu_main(j40hip_pipeline *p) {
 	if (hipSetDevice(p->device) != hipSuccess) { ++p->worker_errors; return; }
 	double t_lf = 0, t_launch = 0, t_retire = 0, t_idle = 0, t_lock = 0; int64_t n_launch = 0, n_lf = 0;   // (J40HIP_ASYNC_TIMING)
 	struct Report { double &a, &b, &c, &d, &e; int64_t &n, &m; ~Report() { if (getenv("J40HIP_ASYNC_TIMING")) fprintf(stderr, "[j40hip gpu thread] ms: LfGroup launches %.1f (%lld), batch launches %.1f (%lld), retiring %.1f, waiting %.1f, for the lock %.1f\n", a, (long long) m, b, (long long) n, c, d, e); } } report{t_lf, t_launch, t_retire, t_idle, t_lock, n_launch, n_lf};
+	// slots with something to hand back, oldest first; free slots leave the list
+	auto retire_ready = [&](bool block_on_oldest) {
+		const double tr = now_ms();
+		bool any = false;
+		for (size_t k = 0; k < p->in_flight.size(); ) {
+			Slot &slot = p->slots[(size_t) p->in_flight[k]];
+			const int before = slot.next_group;
+			if (progress(p, slot, block_on_oldest && k == 0)) { p->in_flight.erase(p->in_flight.begin() + (long) k); any = true; continue; }
+			any = any || slot.next_group != before;
+			++k;
+		}
+		t_retire += now_ms() - tr;
+		return any;
+	};
 	for (;;) {
 		std::vector<Job *> take;
 		{
@@ -283,18 +397,12 @@ void gpu_main(j40hip_pipeline *p) {
 			t_lock += now_ms() - tl0;
 			auto lf_busy = [&] { bool b = !p->lf_pending.empty(); for (const LfFlight &fl : p->lf_flights) b = b || fl.busy; return b; };
 			auto tail = [&] { return p->stop || (p->todo.empty() && p->parsing == 0 && !lf_busy()); };   // nothing else is coming
-			auto collect = [&](bool) {
-				std::vector<size_t> pick;
-				for (size_t i = 0; i < p->ready.size() && (int64_t) pick.size() < p->batch_frames; ++i) pick.push_back(i);
-				return pick;
-			};
-			std::vector<size_t> pick;
 			p->cv_ready.wait(lock, [&] { return p->stop || !p->ready.empty() || !p->in_flight.empty() || lf_busy(); });
 			if (p->stop && p->ready.empty() && p->in_flight.empty() && p->parsing == 0 && !lf_busy()) break;
 			// the LfGroup streams the device decodes: finished launches hand their frames on; waiting frames go into the next launch (a
 			// launch is latency-bound -- about 0.2 s however many sections it has -- so everything waiting goes in)
 			for (LfFlight &fl : p->lf_flights) if (fl.busy && j40hip_alf_done(fl.alf)) {
-				for (Job *j : fl.jobs) p->ready.push_back(j);
+				for (Job *j : fl.jobs) { j->ready_ms = now_ms(); p->ready.push_back(j); }
 				p->lf_stage -= (int64_t) fl.jobs.size();
 				fl.jobs.clear(); fl.busy = false;
 				p->cv_todo.notify_all();
@@ -318,27 +426,23 @@ void gpu_main(j40hip_pipeline *p) {
 				break;
 			}
 			// This thread never waits for the device while there may be something to enqueue -- a finished LfGroup launch to replace, a
-			// batch to launch: a batch in flight is retired when it is done (polled), and waited for only when nothing else can happen.
-			bool oldest_done = false;
-			if (!p->in_flight.empty()) { oldest_done = hipEventQuery(p->slots[(size_t) p->in_flight.front()].done) == hipSuccess; if (!oldest_done) (void) hipGetLastError(); }
+			// batch to launch: batches in flight are handed back group by group as their events pass (polled), and waited for only when
+			// nothing else can happen.
 			if ((int) p->in_flight.size() < p->max_in_flight) {   // (a launch goes before a retirement: the device should not wait for this thread's bookkeeping)
-				if ((int64_t) p->ready.size() >= p->batch_frames) { pick = collect(false); if ((int64_t) pick.size() < p->batch_frames) pick.clear(); }
-				if (pick.empty() && !p->ready.empty() && tail()) pick = collect(true);
-			}
-			if (!pick.empty()) {
-				for (size_t i : pick) take.push_back(p->ready[i]);
-				for (size_t k = pick.size(); k-- > 0; ) p->ready.erase(p->ready.begin() + (long) pick[k]);
+				const bool waited = p->max_wait_ms > 0 && !p->ready.empty() && now_ms() - p->ready.front()->ready_ms >= p->max_wait_ms;
+				const int64_t want = (int64_t) p->ready.size() >= p->batch_frames ? p->batch_frames : (!p->ready.empty() && (waited || tail())) ? (int64_t) p->ready.size() : 0;
+				for (int64_t i = 0; i < want; ++i) { take.push_back(p->ready.front()); p->ready.pop_front(); }
 				p->in_flight_frames += (int64_t) take.size();
-			} else if (!oldest_done && !(p->ready.empty() && tail() && !p->in_flight.empty())) {
+			}
+			if (take.empty()) {
+				// (polled, never slept on: a frame that becomes ready meanwhile must not wait for a batch in flight; the workers' notifications
+				// end the wait early)
+				lock.unlock();
+				if (retire_ready(false)) continue;
+				lock.lock();
 				const double tw = now_ms(); p->cv_ready.wait_for(lock, std::chrono::milliseconds(1)); t_idle += now_ms() - tw;
 				continue;
 			}
-		}
-		if (take.empty()) {   // (the oldest batch in flight is to be retired)
-			const double tr = now_ms();
-			const int s = p->in_flight.front(); p->in_flight.pop_front(); retire(p, p->slots[(size_t) s]);
-			t_retire += now_ms() - tr;
-			continue;
 		}
 		{   // frames whose LfGroup streams could not be launched on the device never enter a batch (their planes were never decoded):
 			// the single-frame path, here and now
@@ -357,27 +461,27 @@ void gpu_main(j40hip_pipeline *p) {
 			if (take.empty()) continue;
 		}
 		const double tb = now_ms();
-		int si = -1;
-		for (size_t i = 0; i < p->slots.size(); ++i) if (!p->slots[i].busy) { si = (int) i; break; }
-		Slot &slot = p->slots[(size_t) si];
-		slot.busy = true; slot.jobs = take; slot.launch_err = 0;
-		std::vector<j40hip_aframe *> frames; std::vector<void *> outs; std::vector<size_t> strides;
-		uint32_t err = 0;
-		for (Job *j : take) {
-			j->dev_rgba = j->device_output ? j->rgba : acquire_image(p, j->stride * (size_t) j->height);
-			if (!j->dev_rgba) err = E_MEM;
-			frames.push_back(j->af); outs.push_back(j->dev_rgba); strides.push_back(j->stride);
+		for (;;) {
+			int si = -1;
+			for (size_t i = 0; i < p->slots.size(); ++i) if (!p->slots[i].busy) { si = (int) i; break; }
+			if (launch_batch(p, take, si) != E_MEM) break;
+			// Out of device memory with the working sets bound at launch: wait for a batch in flight to hand its memory back and try
+			// again; with nothing in flight give idle cache blocks back and halve the batch (the rest goes back to the queue); a single
+			// frame that still does not fit fails with "!mem"
+			if (!p->in_flight.empty()) { retire_ready(true); continue; }
+			j40hip_rt::cache_trim(p->device);
+			if (take.size() > 1) {
+				std::unique_lock<std::mutex> lock(p->m);
+				const size_t keep = take.size() / 2;
+				while (take.size() > keep) { p->ready.push_front(take.back()); take.pop_back(); --p->in_flight_frames; }
+				continue;
+			}
+			Slot &slot = p->slots[(size_t) si];   // one frame, nothing in flight, nothing cached: it does not fit
+			slot.busy = true; slot.jobs = take; slot.launch_err = E_MEM; slot.next_group = 0; slot.group_end.assign(1, (int) take.size());
+			if (slot.group_ev.empty()) slot.group_ev.push_back(slot.kdone);
+			p->in_flight.push_back(si);
+			break;
 		}
-		if (!err && !slot.batch) { slot.batch = j40hip_abatch_create(p->device); if (!slot.batch) err = E_GPU; }
-		if (!err) err = j40hip_abatch_launch(slot.batch, frames.data(), (int) frames.size(), outs.data(), strides.data(), slot.stream);
-		// the second full batch says this is a pipeline that will run at depth: size the device memory cache for it now (the device
-		// has two batches to work on meanwhile) rather than wherever the queues first fill up
-		if (!err && (int64_t) frames.size() == p->batch_frames && ++p->full_batches == 2)
-			j40hip_aframes_reserve(frames.data(), (int) frames.size(), p->max_in_flight - 1, (int) (p->max_in_flight - 1 + p->lf_cap / std::max<int64_t>(1, p->batch_frames)));   // (two batches' worth exist)
-		if (!err) for (Job *j : take) if (!j->device_output && hipMemcpyAsync(j->rgba, j->dev_rgba, j->stride * (size_t) j->height, hipMemcpyDeviceToHost, slot.stream) != hipSuccess) j->status = E_GPU;
-		slot.launch_err = err;
-		if (hipEventRecord(slot.done, slot.stream) != hipSuccess && !slot.launch_err) slot.launch_err = E_GPU;
-		p->in_flight.push_back(si);
 		t_launch += now_ms() - tb; ++n_launch;
 	}
 	{ std::unique_lock<std::mutex> lock(p->m); for (j40hip_aframe *af : p->garbage) j40hip_aframe_free(af); p->garbage.clear(); }
@@ -415,8 +519,9 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 			if (j40hip_stream_layout() == 2 && &s != &p->slots[0]) { s.stream = p->slots[0].stream; made = true; }   // layout 2: every batch on ONE stream (one after the other), the pixel-kernel streams shared as in 1
 			else if (j40hip_stream_layout() >= 1) { int lo = 0, hi = 0; made = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, hi) == hipSuccess; if (!made) (void) hipGetLastError(); }
 			if (!made && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) { *err = E_GPU; break; }
-			if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { *err = E_GPU; break; }
+			if (hipEventCreateWithFlags(&s.kdone, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { *err = E_GPU; break; }
 		}
+		if (!*err && hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) *err = E_GPU;
 		{   // The LfGroup launches run for a quarter of a second each. Streams of one priority share a handful of hardware queues, and a
 			// kernel waits for the kernels ahead of it in its queue whichever stream they came from: on a stream of the batches' priority
 			// such a launch held up a quarter of the pixel kernels (296 ms per batch against 80). Lowest priority: queues of their own.
@@ -449,7 +554,12 @@ void j40hip_pipeline_free(j40hip_pipeline *p) {
 	for (Job *j : p->todo) delete j;
 	for (std::deque<Job *> *q : {&p->ready, &p->lf_pending}) for (Job *j : *q) { if (j->af) { (void) hipDeviceSynchronize(); j40hip_aframe_free(j->af); } delete j; }
 	for (LfFlight &fl : p->lf_flights) { for (Job *j : fl.jobs) { if (j->af) { (void) hipDeviceSynchronize(); j40hip_aframe_free(j->af); } delete j; } if (fl.stream) (void) hipStreamDestroy(fl.stream); }
-	for (Slot &s : p->slots) { if (s.done) (void) hipEventDestroy(s.done); if (s.stream && (&s == &p->slots[0] || s.stream != p->slots[0].stream)) (void) hipStreamDestroy(s.stream); }
+	for (Slot &s : p->slots) {
+		for (hipEvent_t e : s.group_ev) if (e && e != s.kdone) (void) hipEventDestroy(e);
+		if (s.kdone) (void) hipEventDestroy(s.kdone);
+		if (s.stream && (&s == &p->slots[0] || s.stream != p->slots[0].stream)) (void) hipStreamDestroy(s.stream);
+	}
+	if (p->copy_stream) (void) hipStreamDestroy(p->copy_stream);
 	delete p;
 }
 
@@ -460,7 +570,7 @@ uint32_t j40hip_pipeline_submit(j40hip_pipeline *p, const void *buf, size_t size
 		Job *j = new Job();
 		j->buf = buf; j->size = size; j->rgba = rgba; j->stride = stride_bytes; j->device_output = device_output != 0;
 		std::unique_lock<std::mutex> lock(p->m);
-		j->ticket = p->submitted++;
+		j->ticket = (int64_t) p->results.size(); ++p->submitted;
 		p->results.push_back(0); p->finished.push_back(0);
 		if (p->first_submit_ms == 0) p->first_submit_ms = now_ms();
 		if (ticket) *ticket = j->ticket;
@@ -469,6 +579,31 @@ uint32_t j40hip_pipeline_submit(j40hip_pipeline *p, const void *buf, size_t size
 	} catch (const std::exception &) { return E_MEM; }
 	return 0;
 }
+
+// One image, synchronously: queued like j40hip_pipeline_submit's, the calling thread sleeps until it is done. The pixel memory is
+// asked for through `alloc` once the image's size is known. What j40_next_frame calls when it serves many threads (api.cpp).
+uint32_t j40hip_pipeline_run(j40hip_pipeline *p, const void *buf, size_t size, j40hip_output_alloc alloc, void *ctx) {
+	if (!p || !buf || !alloc) return E_RNGE;
+	if (p->worker_errors.load()) return E_GPU;
+	Waiter w;
+	try {
+		Job *j = new Job();
+		j->buf = buf; j->size = size; j->alloc = alloc; j->alloc_ctx = ctx; j->waiter = &w; j->ticket = -1;
+		std::unique_lock<std::mutex> lock(p->m);
+		++p->submitted;
+		if (p->first_submit_ms == 0) p->first_submit_ms = now_ms();
+		p->todo.push_back(j);
+		p->cv_todo.notify_one();
+	} catch (const std::exception &) { return E_MEM; }
+	std::unique_lock<std::mutex> wl(w.m);
+	while (!w.done) {
+		w.cv.wait_for(wl, std::chrono::milliseconds(200));
+		if (!w.done && p->worker_errors.load()) { wl.unlock(); std::unique_lock<std::mutex> lock(p->m); p->cv_ready.notify_all(); lock.unlock(); wl.lock(); }
+	}
+	return w.status;
+}
+
+void j40hip_pipeline_set_max_wait_ms(j40hip_pipeline *p, double ms) { if (p) { std::unique_lock<std::mutex> lock(p->m); p->max_wait_ms = ms; } }
 
 uint32_t j40hip_pipeline_drain(j40hip_pipeline *p) {
 	if (!p) return E_RNGE;
@@ -510,6 +645,49 @@ void j40hip_pipeline_reset_stats(j40hip_pipeline *p) {
 	std::unique_lock<std::mutex> lock(p->m);
 	p->parse_ms = p->single_ms = 0; p->first_submit_ms = 0; p->last_done_ms = 0;
 	p->lf_ms = p->k1_ms = p->k2_ms = p->k1_kernel_ms = 0; p->launches = p->launch_frames = 0; p->lf_device_frames = p->single_frames = 0;
+}
+
+
+// ---- the process-wide pipelines behind the public API (api.cpp): j40_next_frame hands its image to the pipeline of its device when
+// several threads are inside the API at once (or J40HIP_SERVE=1), so that callers of the unchanged ten-function sequence share
+// batches. One per device, made on first use, taken down by j40hip_shutdown. Knobs (environment, read once): J40HIP_SERVE_THREADS
+// (host threads; default: the container's CPU quota), J40HIP_SERVE_BATCH (frames per entropy launch, 64), J40HIP_SERVE_IN_FLIGHT (3),
+// J40HIP_SERVE_LF (host | device | auto: who decodes the LfGroup streams; host -- a frame must not wait 0.4 s for the lane decoder),
+// J40HIP_SERVE_WAIT_MS (how long a prepared frame waits for a fuller batch, 3).
+static std::mutex g_serve_mutex;
+static j40hip_pipeline *g_serve[16] = {nullptr};
+
+static int cpu_quota() {
+	unsigned hw = std::thread::hardware_concurrency();
+	int n = hw ? (int) hw : 4;
+	if (FILE *fp = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+		char q[64] = {0}; long long period = 0;
+		if (fscanf(fp, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) { const long long c = atoll(q) / period; if (c >= 1 && c < n) n = (int) c; }
+		fclose(fp);
+	}
+	return n;
+}
+
+j40hip_pipeline *j40hip_serve_pipeline(int device, uint32_t *err) {
+	uint32_t dummy; if (!err) err = &dummy;
+	*err = 0;
+	if (device < 0 || device >= 16) { *err = E_GPU; return nullptr; }
+	std::lock_guard<std::mutex> lock(g_serve_mutex);
+	if (g_serve[device]) return g_serve[device];
+	auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; };
+	const int threads = std::max(1, env_int("J40HIP_SERVE_THREADS", cpu_quota()));
+	uint32_t lf = 2;
+	if (const char *e = getenv("J40HIP_SERVE_LF")) lf = !strcmp(e, "device") ? 1u : !strcmp(e, "auto") ? 0u : 2u;
+	j40hip_pipeline *p = j40hip_pipeline_create_ex(device, threads, std::max(1, env_int("J40HIP_SERVE_BATCH", 64)), env_int("J40HIP_SERVE_IN_FLIGHT", 3), lf, err);
+	if (!p) return nullptr;
+	const char *w = getenv("J40HIP_SERVE_WAIT_MS");
+	j40hip_pipeline_set_max_wait_ms(p, w && *w ? atof(w) : 3.0);
+	return g_serve[device] = p;
+}
+
+void j40hip_serve_shutdown(void) {
+	std::lock_guard<std::mutex> lock(g_serve_mutex);
+	for (j40hip_pipeline *&p : g_serve) if (p) { j40hip_pipeline_free(p); p = nullptr; }
 }
 
 } // extern "C"

@@ -42,18 +42,30 @@ struct DeviceBuffer {
 // The device memory cache: one BlockCacheCore (block_cache.hpp: free list, size classes, slabs) per device behind one mutex; the
 // slow part -- hipMalloc / hipFree -- happens outside the lock.
 std::mutex g_cache_mutex;
+std::condition_variable g_cache_cv;      // a slab of some class has been adopted (or its allocation failed)
 BlockCacheCore g_cache[16];
-// upper bound on what the cache keeps (J40HIP_CACHE_GB overrides; 0 disables recycling). When an allocation fails the cache is
-// emptied and the allocation tried again (cache_trim), so idle blocks never turn into a spurious "!gpu"
-// Default: three quarters of the device's memory -- a pipeline returns the working sets of a whole batch at once (256 8K frames:
-// 54 GB), and hipFree / hipMalloc of such blocks cost tens of milliseconds each and synchronise the device.
-size_t cache_limit_bytes() {
-	static const size_t limit = [] {
-		if (const char *e = getenv("J40HIP_CACHE_GB")) return (size_t) std::max(0, atoi(e)) << 30;
-		size_t free_b = 0, total_b = 0;
-		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); return (size_t) 48 << 30; }
-		return total_b / 4 * 3;
-	}();
+std::vector<size_t> g_slab_pending[16];  // size classes whose slab some thread is allocating right now
+// Upper bound on what the cache of ONE device keeps idle, per process (J40HIP_CACHE_GB overrides; 0 disables recycling and slabs).
+// When an allocation fails the cache is emptied and the allocation tried again (cache_trim), so idle blocks never turn into a
+// spurious "!gpu". Default: 60 % of the device's memory -- a pipeline returns the working sets of a whole batch at once (256 8K
+// frames: 54 GB), and hipFree / hipMalloc of such blocks cost tens of milliseconds each and synchronise the device. Processes that
+// share a device (several ranks on one GPU, multi-tenant serving) each keep up to this much: set J40HIP_CACHE_GB to the device's
+// memory divided by their number, less what the frames in flight need.
+std::mutex g_limit_mutex;
+size_t g_limit[16]; bool g_limit_known[16];
+size_t cache_limit_bytes(int device) {   // (never called with g_cache_mutex held: hipMemGetInfo takes its time)
+	if (device < 0 || device >= 16) return 0;
+	{ std::lock_guard<std::mutex> lock(g_limit_mutex); if (g_limit_known[device]) return g_limit[device]; }
+	size_t limit = (size_t) 48 << 30;
+	if (const char *e = getenv("J40HIP_CACHE_GB")) limit = (size_t) std::max(0, atoi(e)) << 30;
+	else {
+		int cur = -1; size_t free_b = 0, total_b = 0;
+		const bool switched = hipGetDevice(&cur) == hipSuccess && cur != device && hipSetDevice(device) == hipSuccess;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) limit = total_b / 10 * 6; else (void) hipGetLastError();
+		if (switched) (void) hipSetDevice(cur);
+	}
+	std::lock_guard<std::mutex> lock(g_limit_mutex);
+	g_limit[device] = limit; g_limit_known[device] = true;
 	return limit;
 }
 
@@ -71,21 +83,36 @@ void j40hip_rt::cache_trim(int device) {
 void *j40hip_rt::cache_acquire(int device, size_t bytes, size_t *got, bool *clean) {
 	bytes = BlockCacheCore::size_class(bytes);
 	const bool cached = device >= 0 && device < 16;
+	const size_t limit = cached ? cache_limit_bytes(device) : 0;
+	bool slab = cached && limit > 0 && BlockCacheCore::slab_class(bytes);
 	if (cached) {
-		std::lock_guard<std::mutex> lock(g_cache_mutex);
-		if (void *q = g_cache[device].take(bytes, got, clean)) return q;
+		// One thread per size class allocates a slab; whoever else misses the class meanwhile waits for it and looks again (when a
+		// pipeline starts, every worker misses the empty cache at the same moment: each of them used to allocate a slab of its own)
+		std::unique_lock<std::mutex> lock(g_cache_mutex);
+		for (;;) {
+			if (void *q = g_cache[device].take(bytes, got, clean)) return q;
+			std::vector<size_t> &pend = g_slab_pending[device];
+			if (!slab || std::find(pend.begin(), pend.end(), bytes) == pend.end()) { if (slab) pend.push_back(bytes); break; }
+			g_cache_cv.wait(lock);
+		}
 	}
 	void *p = nullptr;
-	if (cached && BlockCacheCore::slab_class(bytes)) {
-		const int n = BlockCacheCore::slab_blocks(bytes);
-		if (hipMalloc(&p, bytes * (size_t) n) == hipSuccess) {
+	if (slab) {
+		// a slab is up to 64 blocks / 1 GB; smaller when the device is short of memory or the cache near its limit (its idle blocks count)
+		int n = BlockCacheCore::slab_blocks(bytes);
+		size_t free_b = 0, total_b = 0, idle_b = 0;
+		{ std::lock_guard<std::mutex> lock(g_cache_mutex); idle_b = g_cache[device].idle_bytes; }
+		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); free_b = 0; }
+		while (n > 1 && (bytes * (size_t) n > free_b / 4 || idle_b + bytes * (size_t) (n - 1) > limit)) n /= 2;
+		if (n > 1 && hipMalloc(&p, bytes * (size_t) n) != hipSuccess) { (void) hipGetLastError(); p = nullptr; }
+		{
 			std::lock_guard<std::mutex> lock(g_cache_mutex);
-			g_cache[device].adopt_slab(p, bytes, n);
-			*got = bytes; *clean = false;
-			return p;
+			if (p) g_cache[device].adopt_slab(p, bytes, n);
+			std::vector<size_t> &pend = g_slab_pending[device];
+			pend.erase(std::find(pend.begin(), pend.end(), bytes));
 		}
-		(void) hipGetLastError();
-		p = nullptr;
+		g_cache_cv.notify_all();
+		if (p) { *got = bytes; *clean = false; return p; }
 	}
 	if (hipMalloc(&p, bytes) != hipSuccess) {
 		// out of device memory while blocks sit idle in the cache: give them back and try once more
@@ -101,10 +128,48 @@ void j40hip_rt::cache_release(int device, void *ptr, size_t bytes, bool clean) {
 	if (!ptr) return;
 	void *gone = ptr;
 	if (device >= 0 && device < 16) {
+		const size_t limit = cache_limit_bytes(device);
 		std::lock_guard<std::mutex> lock(g_cache_mutex);
-		g_cache[device].give(ptr, bytes, clean, cache_limit_bytes(), &gone);
+		g_cache[device].give(ptr, bytes, clean, limit, &gone);
 	}
 	if (gone) (void) hipFree(gone);
+}
+
+// ---- pinned host memory for pixels that go back to the caller (the public API's image planes): pinning 133 MB takes tens of
+// milliseconds, so planes are recycled by size across images. J40HIP_PINNED_POOL_GB bounds what sits idle (default 16; 0: nothing kept).
+namespace {
+std::mutex g_pinned_mutex;
+std::vector<std::pair<void *, size_t>> g_pinned_idle;
+size_t g_pinned_idle_bytes = 0;
+size_t pinned_limit() { static const size_t v = [] { const char *e = getenv("J40HIP_PINNED_POOL_GB"); return (size_t) (e ? std::max(0, atoi(e)) : 16) << 30; }(); return v; }
+}
+extern "C" void *j40hip_pinned_acquire(size_t bytes) {
+	bytes = (bytes + 4095) & ~(size_t) 4095;
+	{
+		std::lock_guard<std::mutex> lock(g_pinned_mutex);
+		for (size_t i = g_pinned_idle.size(); i-- > 0; ) if (g_pinned_idle[i].second == bytes) {
+			void *q = g_pinned_idle[i].first;
+			g_pinned_idle.erase(g_pinned_idle.begin() + (long) i); g_pinned_idle_bytes -= bytes;
+			return q;
+		}
+	}
+	void *q = nullptr;
+	if (hipHostMalloc(&q, bytes ? bytes : 4096, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+	return q;
+}
+extern "C" void j40hip_pinned_release(void *ptr, size_t bytes) {
+	if (!ptr) return;
+	bytes = (bytes + 4095) & ~(size_t) 4095;
+	{
+		std::lock_guard<std::mutex> lock(g_pinned_mutex);
+		if (g_pinned_idle_bytes + bytes <= pinned_limit()) { g_pinned_idle.push_back({ptr, bytes}); g_pinned_idle_bytes += bytes; return; }
+	}
+	(void) hipHostFree(ptr);
+}
+static void pinned_trim() {
+	std::vector<std::pair<void *, size_t>> gone;
+	{ std::lock_guard<std::mutex> lock(g_pinned_mutex); gone.swap(g_pinned_idle); g_pinned_idle_bytes = 0; }
+	for (auto &b : gone) (void) hipHostFree(b.first);
 }
 
 namespace {
@@ -1216,7 +1281,9 @@ extern "C" void j40hip_shutdown(void) {
 		if (sv->thread.joinable()) sv->thread.join();
 		delete sv;
 	}
+	j40hip_serve_shutdown();
 	j40hip_async_shutdown();
+	pinned_trim();
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess) { (void) hipGetLastError(); n = 0; }
 	for (int d = 0; d < n && d < 16; ++d) if (hipSetDevice(d) == hipSuccess) { (void) hipDeviceSynchronize(); cache_trim(d); }
