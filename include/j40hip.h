@@ -323,6 +323,36 @@ J40HIP_API void j40hip_pipeline_stats(j40hip_pipeline *p, double *out8);
 J40HIP_API void j40hip_pipeline_stats_ex(j40hip_pipeline *p, double *out12);
 J40HIP_API void j40hip_pipeline_reset_stats(j40hip_pipeline *p);
 
+/* ---- stage dump of the pipeline's DEVICE stages, for parity tests (tests/test_device_stages.py): one image goes through the same
+ *      enqueue a batch of one takes -- front parse on the host; the LfGroup streams on the device (k_lf_lanes) when `lf_on_device`
+ *      and the frame's tables allow it, else by the host decoder; plan build (k_plan_place / _scan / _emit), LfGroup tail, entropy
+ *      decode, pixel kernels, verdict -- and what every stage produced is copied back and handed out in the layout of the reference's
+ *      j40__lf_group_st (j40.h:6360-6390), like the j40hip_frame_lf_group_* accessors do for the host parse. NULL + "TODO" for
+ *      images the batched path does not take. ---- */
+typedef struct j40hip_stage_dump j40hip_stage_dump;
+J40HIP_API j40hip_stage_dump *j40hip_stage_dump_create(const void *buf, size_t size, int device, int lf_on_device, uint32_t *err);
+J40HIP_API void j40hip_stage_dump_free(j40hip_stage_dump *d);
+/* out8: [0] the frame's verdict (k_plan_verdict: 0 or the first failing section's 4-char code, LfGroup and pass-group sections alike),
+ * [1] flags: bit 0 an LfGroup section the device decoder leaves to the host, bit 1 an event region overflowed, bit 2 the LfGroup
+ * streams were decoded on the device, [2] LfGroups, [3] groups, [4] width, [5] height, [6] union of the DctSelect values placed, [7] varblocks */
+J40HIP_API void j40hip_stage_dump_info(const j40hip_stage_dump *d, uint32_t *out8);
+/* out10: left, top, width, height, width8, height8, width64, height64, varblocks placed, the section's status (4-char code or 0) */
+J40HIP_API int j40hip_stage_dump_lf_group_info(const j40hip_stage_dump *d, int64_t gg, int32_t *out10);
+/* which: 0 blocks (i32 w8*h8, the reference's encoding, rebuilt from the device's varblock records), 1 lfindices (u8 w8*h8, from the
+ * decoded LF integers with the frame's thresholds, j40.h:6566-6570), 2 xfromy / 3 bfromy (i16 w64*h64), 4 sharpness (i16 w8*h8; only
+ * when the device decoded the streams), 5 / 6 / 7 the raw LF integers of X / Y / B (i16 w8*h8) */
+J40HIP_API int j40hip_stage_dump_plane(const j40hip_stage_dump *d, int64_t gg, int which, void *out);
+/* varblocks in placement order (= the reference's varblock index): coeffoff_qfidx, hfmul.inv, and (optional) x8, y8, DctSelect; returns how many */
+J40HIP_API int j40hip_stage_dump_varblocks(const j40hip_stage_dump *d, int64_t gg, int32_t *coeffoff_qfidx, float *hfmul_inv, int32_t *x8_y8_dctsel);
+J40HIP_API int j40hip_stage_dump_llf(const j40hip_stage_dump *d, int64_t gg, int c, float *out);
+/* the entropy kernel's block list of one group (frame-wide group index), in j40__hf_coeffs' visiting order: per block
+ * coeffoff_qfidx, pos_dct (y8 * 32 + x8 inside the group | DctSelect << 10), bctx3 (block context of Y | X << 4 | B << 8); returns the count */
+J40HIP_API int64_t j40hip_stage_dump_group_blocks(const j40hip_stage_dump *d, int64_t group, uint32_t *out3, int64_t capacity);
+/* the pixel kernels' work list (sorted by DctSelect; class_start28[27] = varblocks): out8 = px, py, effw, effh, dctsel, blk, llf_base,
+ * coeff_base; out3 = mult1, kx_hf, kb_hf; returns the count */
+J40HIP_API int64_t j40hip_stage_dump_sorted_varblocks(const j40hip_stage_dump *d, int32_t *out8, float *out3, int32_t *class_start28, int64_t capacity);
+J40HIP_API int j40hip_stage_dump_rgba(const j40hip_stage_dump *d, uint8_t *out);   /* width * 4 bytes per row */
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,6 +101,10 @@ def lib():
         "j40hip_pipeline_create": (vp, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(u32)]), "j40hip_pipeline_free": (None, [vp]), "j40hip_pipeline_create_ex": (vp, [C.c_int, C.c_int, C.c_int, C.c_int, u32, C.POINTER(u32)]), "j40hip_pipeline_lf_device_frames": (i64, [vp]),
         "j40hip_pipeline_submit": (u32, [vp, vp, sz, vp, sz, C.c_int, C.POINTER(i64)]), "j40hip_pipeline_drain": (u32, [vp]),
         "j40hip_pipeline_run": (u32, [vp, vp, sz, OUTPUT_ALLOC, vp]), "j40hip_pipeline_set_max_wait_ms": (None, [vp, C.c_double]),
+        "j40hip_stage_dump_create": (vp, [vp, sz, C.c_int, C.c_int, C.POINTER(u32)]), "j40hip_stage_dump_free": (None, [vp]), "j40hip_stage_dump_info": (None, [vp, vp]),
+        "j40hip_stage_dump_lf_group_info": (C.c_int, [vp, i64, vp]), "j40hip_stage_dump_plane": (C.c_int, [vp, i64, C.c_int, vp]),
+        "j40hip_stage_dump_varblocks": (C.c_int, [vp, i64, vp, vp, vp]), "j40hip_stage_dump_llf": (C.c_int, [vp, i64, C.c_int, vp]),
+        "j40hip_stage_dump_group_blocks": (i64, [vp, i64, vp, i64]), "j40hip_stage_dump_sorted_varblocks": (i64, [vp, vp, vp, vp, i64]), "j40hip_stage_dump_rgba": (C.c_int, [vp, vp]),
         "j40hip_pipeline_result": (u32, [vp, i64]), "j40hip_pipeline_stats": (None, [vp, vp]), "j40hip_pipeline_stats_ex": (None, [vp, vp]), "j40hip_pipeline_reset_stats": (None, [vp]),
     }
     for name, (res, args) in sigs.items():
@@ -416,6 +420,79 @@ class Batch:
         if code:
             raise J40Error(err4(code), "in j40hip_batch_decode_timed")
         return ms[0], ms[1], ms[2]
+
+
+class StageDump:
+    """j40hip_stage_dump_*: one image through the pipeline's device stages, every stage's product copied back (parity tests)"""
+
+    def __init__(self, data, device=0, lf_on_device=True):
+        self._buf = C.create_string_buffer(bytes(data), len(data))
+        err = C.c_uint32()
+        self.h = lib().j40hip_stage_dump_create(self._buf, len(data), device, 1 if lf_on_device else 0, C.byref(err))
+        if not self.h:
+            raise J40Error(err4(err.value), "in j40hip_stage_dump_create")
+        a = np.zeros(8, np.uint32)
+        lib().j40hip_stage_dump_info(self.h, a.ctypes.data)
+        self.verdict, self.flags = err4(int(a[0])), int(a[1])
+        self.lf_on_device = bool(a[1] & 4)
+        self.num_lf_groups, self.num_groups, self.width, self.height, self.dct_used, self.num_varblocks = (int(v) for v in a[2:8])
+
+    def lf_group_info(self, gg):
+        a = np.zeros(10, np.int32)
+        assert lib().j40hip_stage_dump_lf_group_info(self.h, gg, a.ctypes.data) == 0
+        d = dict(zip(["left", "top", "width", "height", "width8", "height8", "width64", "height64", "nb_varblocks"], a[:9].tolist()))
+        d["status"] = err4(int(a[9]) & 0xffffffff)
+        return d
+
+    def plane(self, gg, which):
+        gi = self.lf_group_info(gg)
+        c8, c64 = (gi["height8"], gi["width8"]), (gi["height64"], gi["width64"])
+        shape, dt = {0: (c8, np.int32), 1: (c8, np.uint8), 2: (c64, np.int16), 3: (c64, np.int16), 4: (c8, np.int16), 5: (c8, np.int16), 6: (c8, np.int16), 7: (c8, np.int16)}[which]
+        a = np.zeros(shape, dt)
+        if lib().j40hip_stage_dump_plane(self.h, gg, which, a.ctypes.data) != 0:
+            return None
+        return a
+
+    def varblocks(self, gg):
+        n = self.lf_group_info(gg)["nb_varblocks"]
+        a, b, c = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float32), np.zeros((max(n, 1), 3), np.int32)
+        assert lib().j40hip_stage_dump_varblocks(self.h, gg, a.ctypes.data, b.ctypes.data, c.ctypes.data) == n
+        return a[:n], b[:n], c[:n]
+
+    def llf(self, gg, c):
+        gi = self.lf_group_info(gg)
+        a = np.zeros(gi["height8"] * gi["width8"], np.float32)
+        assert lib().j40hip_stage_dump_llf(self.h, gg, c, a.ctypes.data) == 0
+        return a
+
+    def group_blocks(self, group):
+        a = np.zeros((1024, 3), np.uint32)
+        n = lib().j40hip_stage_dump_group_blocks(self.h, group, a.ctypes.data, 1024)
+        assert 0 <= n <= 1024
+        return a[:n]
+
+    def sorted_varblocks(self):
+        cap = max(self.num_varblocks, 1)
+        a, f, cs = np.zeros((cap, 8), np.int32), np.zeros((cap, 3), np.float32), np.zeros(28, np.int32)
+        n = lib().j40hip_stage_dump_sorted_varblocks(self.h, a.ctypes.data, f.ctypes.data, cs.ctypes.data, cap)
+        assert 0 <= n <= cap
+        return a[:n], f[:n], cs
+
+    def rgba(self):
+        a = np.zeros((self.height, self.width, 4), np.uint8)
+        assert lib().j40hip_stage_dump_rgba(self.h, a.ctypes.data) == 0
+        return a
+
+    def close(self):
+        if self.h:
+            lib().j40hip_stage_dump_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Pipeline:

@@ -418,6 +418,7 @@ struct j40hip_abatch {
 	hipEvent_t k1_ev[2] = {nullptr, nullptr};   // recorded by the device at k_hf_lanes' start and end (hipExtLaunchKernelGGL)
 	bool k1_timed = false;
 	int cus = 256;
+	size_t last_o_k2 = 0;             // where the last launch's K2Frame array lies in `dev` (the stage dump reads class_start there)
 };
 
 // How a pipeline's streams are laid over the hardware queues. A process gets four queues per stream priority, streams of one
@@ -536,6 +537,7 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 		b->verdict_cap = (size_t) n * 4 * 2 + 16;
 	}
 	uint8_t *hb = b->host.ptr, *db = (uint8_t *) b->dev;
+	b->last_o_k2 = o_k2;
 	DevPlan *h_plans = (DevPlan *) (hb + o_plans); DevPlanBuild *h_builds = (DevPlanBuild *) (hb + o_builds); K2Frame *h_k2 = (K2Frame *) (hb + o_k2);
 	DevBatchLf *h_lfs = (DevBatchLf *) (hb + o_lfs);
 	const DevPlan *d_plans = (const DevPlan *) (db + o_plans); const DevPlanBuild *d_builds = (const DevPlanBuild *) (db + o_builds); K2Frame *d_k2 = (K2Frame *) (db + o_k2);
@@ -655,3 +657,186 @@ uint32_t j40hip_alf_launch(j40hip_alf *a, j40hip_aframe *const *frames, int n, h
 	return 0;
 }
 int j40hip_alf_done(j40hip_alf *a) { if (!a || hipEventQuery(a->done) == hipSuccess) return 1; (void) hipGetLastError(); return 0; }
+
+// ---- stage dump (include/j40hip.h, j40hip_stage_dump_*): ONE image through the pipeline's device stages -- LfGroup streams
+// (k_lf_lanes, or the host decoder), plan build (k_plan_place / _scan / _emit), LfGroup tail, entropy decode, pixels, verdict --
+// and everything they produced copied back, so that the parity tests can hold each stage's product against the reference's
+// j40__lf_group_st (j40.h:6360-6390) ON THE DEVICE THAT COMPUTED IT (tests/test_device_stages.py). Test access only: nothing here
+// is on the product's path.
+struct j40hip_stage_dump {
+	DevPlanBuild build;                 // (host copy: thresholds, geometry; its pointers are device pointers and not used)
+	std::vector<DevLfGroup> lf_groups; std::vector<DevLfSlot> slots;
+	std::vector<int16_t> lfraw[3], xfromy, bfromy, vbinfo, sharp;
+	std::vector<DevVbRec> recs; std::vector<uint32_t> group_block_start; std::vector<DevGroupBlock> group_blocks;
+	std::vector<DevVarblock> sorted; int32_t class_start[28];
+	std::vector<float> llf[3];
+	std::vector<uint8_t> rgba;
+	uint32_t verdict[4]; int32_t width = 0, height = 0, num_groups = 0; bool lf_device = false; size_t cells = 0, c64s = 0;
+};
+
+extern "C" j40hip_stage_dump *j40hip_stage_dump_create(const void *buf, size_t size, int device, int lf_on_device, uint32_t *err) {
+	uint32_t dummy; if (!err) err = &dummy;
+	*err = ERR_GPU;
+	if (j40hip_device_count() <= device || device < 0 || hipSetDevice(device) != hipSuccess) return nullptr;
+	hipStream_t s = nullptr;
+	if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+	j40hip_aframe *af = j40hip_aframe_prepare(buf, size, device, s, lf_on_device);
+	j40hip_abatch *b = nullptr; j40hip_alf *alf = nullptr; void *img = nullptr;
+	std::unique_ptr<j40hip_stage_dump> d(new j40hip_stage_dump());
+	auto fail = [&](uint32_t code) {
+		(void) hipStreamSynchronize(s);
+		if (af) j40hip_aframe_free(af);
+		if (b) j40hip_abatch_free(b);
+		if (alf) j40hip_alf_free(alf);
+		if (img) (void) hipFree(img);
+		j40hip_astage_release();
+		(void) hipStreamDestroy(s);
+		*err = code;
+		return (j40hip_stage_dump *) nullptr;
+	};
+	if (!af) return fail(ERR_TODO);   // (not a frame the batched path takes -- or not a frame at all: the single-frame path would tell)
+	try {
+		d->lf_device = j40hip_aframe_lf_on_device(af) != 0;
+		if (d->lf_device) {
+			alf = j40hip_alf_create(device);
+			if (!alf) return fail(ERR_GPU);
+			if (uint32_t e = j40hip_alf_launch(alf, &af, 1, s)) return fail(e);
+		}
+		int64_t w = 0, h = 0;
+		j40hip_aframe_size(af, &w, &h);
+		d->width = (int32_t) w; d->height = (int32_t) h; d->num_groups = af->num_groups; d->cells = af->cells;
+		const size_t stride = (size_t) w * 4;
+		if (hipMalloc(&img, stride * (size_t) h) != hipSuccess) return fail(ERR_MEM);
+		b = j40hip_abatch_create(device);
+		if (!b) return fail(ERR_GPU);
+		if (uint32_t e = j40hip_abatch_launch(b, &af, 1, &img, &stride, s)) return fail(e);
+		if (hipStreamSynchronize(s) != hipSuccess) return fail(ERR_GPU);
+		const DevPlanBuild &bd = af->build;
+		d->build = bd;
+		const size_t ngg = (size_t) af->num_lf_groups, cells = af->cells;
+		bool ok = true;
+		auto pull = [&](void *dst, const void *src, size_t bytes) { if (bytes && hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) ok = false; };
+		d->lf_groups.resize(ngg); d->slots.resize(ngg);
+		pull(d->lf_groups.data(), bd.lf_groups, ngg * sizeof(DevLfGroup)); pull(d->slots.data(), bd.lf_slots, ngg * sizeof(DevLfSlot));
+		size_t c64s = 0;
+		for (const DevLfGroup &g : d->lf_groups) c64s = std::max(c64s, (size_t) g.c64_base + (size_t) g.width64 * (size_t) g.height64);
+		d->c64s = c64s;
+		for (int c = 0; c < 3; ++c) { d->lfraw[c].resize(cells); pull(d->lfraw[c].data(), bd.lfraw[c], cells * 2); d->llf[c].resize(cells); pull(d->llf[c].data(), af->plan.llf[c], cells * 4); }
+		d->xfromy.resize(c64s); d->bfromy.resize(c64s); pull(d->xfromy.data(), bd.xfromy, c64s * 2); pull(d->bfromy.data(), bd.bfromy, c64s * 2);
+		d->vbinfo.resize(2 * cells); pull(d->vbinfo.data(), bd.vbinfo, 4 * cells);
+		if (d->lf_device && !af->lf_tasks.empty()) {   // the sharpness map: only the device decoder keeps it (frame-wide cell array)
+			d->sharp.resize(cells);
+			pull(d->sharp.data(), (const uint8_t *) af->lf_tasks[0].sharp - 2 * (size_t) d->lf_groups[0].cell_base, cells * 2);
+		}
+		d->recs.resize(cells); pull(d->recs.data(), bd.vb_recs, cells * sizeof(DevVbRec));
+		d->group_block_start.resize((size_t) af->num_groups + 1); pull(d->group_block_start.data(), bd.group_block_start, d->group_block_start.size() * 4);
+		d->group_blocks.resize(cells); pull(d->group_blocks.data(), bd.group_blocks, cells * sizeof(DevGroupBlock));
+		d->sorted.resize(cells); pull(d->sorted.data(), bd.vb_sorted, cells * sizeof(DevVarblock));
+		pull(d->class_start, ((const K2Frame *) ((const uint8_t *) b->dev + b->last_o_k2))->class_start, sizeof d->class_start);
+		memcpy(d->verdict, b->verdict_host, sizeof d->verdict);
+		d->rgba.resize(stride * (size_t) h); pull(d->rgba.data(), img, d->rgba.size());
+		if (!ok) return fail(ERR_GPU);
+	} catch (const std::exception &) { return fail(ERR_MEM); }
+	(void) fail(0);   // (releases everything but the dump)
+	return d.release();
+}
+
+extern "C" void j40hip_stage_dump_free(j40hip_stage_dump *d) { delete d; }
+
+extern "C" void j40hip_stage_dump_info(const j40hip_stage_dump *d, uint32_t *out8) {
+	out8[0] = d->verdict[0]; out8[1] = d->verdict[1] | (d->lf_device ? 4u : 0u); out8[2] = (uint32_t) d->lf_groups.size(); out8[3] = (uint32_t) d->num_groups;
+	out8[4] = (uint32_t) d->width; out8[5] = (uint32_t) d->height; out8[6] = d->verdict[2]; out8[7] = d->verdict[3];
+}
+
+extern "C" int j40hip_stage_dump_lf_group_info(const j40hip_stage_dump *d, int64_t gg, int32_t *out10) {
+	if (!d || gg < 0 || (size_t) gg >= d->lf_groups.size()) return -1;
+	const DevLfGroup &g = d->lf_groups[(size_t) gg];
+	const int32_t v[10] = {g.left, g.top, g.width, g.height, g.width8, g.height8, g.width64, g.height64, d->slots[(size_t) gg].placed, (int32_t) d->slots[(size_t) gg].status};
+	memcpy(out10, v, sizeof v);
+	return 0;
+}
+
+extern "C" int j40hip_stage_dump_plane(const j40hip_stage_dump *d, int64_t gg, int which, void *out) {
+	if (!d || gg < 0 || (size_t) gg >= d->lf_groups.size()) return -1;
+	const DevLfGroup &g = d->lf_groups[(size_t) gg];
+	const size_t n = (size_t) g.width8 * (size_t) g.height8, n64 = (size_t) g.width64 * (size_t) g.height64;
+	if (which == 0) {   // the reference's block map (j40.h:6360, 6693-6697): (DctSelect + 2) << 20 | varblock at the top-left cell, 1 << 20 | varblock elsewhere
+		int32_t *o = (int32_t *) out;
+		for (size_t i = 0; i < n; ++i) o[i] = 0;
+		const int32_t placed = d->slots[(size_t) gg].placed;
+		for (int32_t v = 0; v < placed; ++v) {
+			const DevVbRec &r = d->recs[(size_t) g.vb_base + (size_t) v];
+			const int32_t vw8 = 1 << (DCT_SELECT[r.dctsel].log_columns - 3), vh8 = 1 << (DCT_SELECT[r.dctsel].log_rows - 3);
+			for (int32_t y = 0; y < vh8; ++y) for (int32_t x = 0; x < vw8; ++x) {
+				const size_t at = (size_t) (r.y8 + y) * (size_t) g.width8 + (size_t) (r.x8 + x);
+				if (at < n) o[at] = ((x == 0 && y == 0 ? r.dctsel + 2 : 1) << 20) | v;
+			}
+		}
+		return 0;
+	}
+	if (which == 1) {   // the LF index of every cell from the decoded LF integers (j40.h:6566-6570; plan_dev.h computes it at the varblocks' top-left cells)
+		const DevPlanBuild &pb = d->build;
+		uint8_t *o = (uint8_t *) out;
+		for (size_t i = 0; i < n; ++i) {
+			const size_t cell = (size_t) g.cell_base + i;
+			const int32_t vx = d->lfraw[0][cell], vy = d->lfraw[1][cell], vb = d->lfraw[2][cell];
+			uint8_t lfidx = 0;
+			for (int32_t t = 0; t < pb.nb_lf_thr[0]; ++t) lfidx = (uint8_t) (lfidx + (vx > pb.lf_thr[0][t]));
+			lfidx = (uint8_t) (lfidx * (pb.nb_lf_thr[0] + 1));
+			for (int32_t t = 0; t < pb.nb_lf_thr[2]; ++t) lfidx = (uint8_t) (lfidx + (vb > pb.lf_thr[2][t]));
+			lfidx = (uint8_t) (lfidx * (pb.nb_lf_thr[2] + 1));
+			for (int32_t t = 0; t < pb.nb_lf_thr[1]; ++t) lfidx = (uint8_t) (lfidx + (vy > pb.lf_thr[1][t]));
+			o[i] = lfidx;
+		}
+		return 0;
+	}
+	if (which == 2 || which == 3) { memcpy(out, (which == 2 ? d->xfromy : d->bfromy).data() + g.c64_base, n64 * 2); return 0; }
+	if (which == 4) { if (d->sharp.empty()) return -1; memcpy(out, d->sharp.data() + g.cell_base, n * 2); return 0; }
+	if (which >= 5 && which <= 7) { memcpy(out, d->lfraw[which - 5].data() + g.cell_base, n * 2); return 0; }
+	return -1;
+}
+
+extern "C" int j40hip_stage_dump_varblocks(const j40hip_stage_dump *d, int64_t gg, int32_t *coeffoff_qfidx, float *hfmul_inv, int32_t *x8_y8_dctsel) {
+	if (!d || gg < 0 || (size_t) gg >= d->lf_groups.size()) return -1;
+	const DevLfGroup &g = d->lf_groups[(size_t) gg];
+	const int32_t placed = d->slots[(size_t) gg].placed;
+	for (int32_t v = 0; v < placed; ++v) {
+		const DevVbRec &r = d->recs[(size_t) g.vb_base + (size_t) v];
+		coeffoff_qfidx[v] = (int32_t) r.coeffoff_qfidx;
+		hfmul_inv[v] = 1.0f / ((float) r.hfmul_m1 + 1.0f);   // j40.h:6699
+		if (x8_y8_dctsel) { x8_y8_dctsel[3 * v] = r.x8; x8_y8_dctsel[3 * v + 1] = r.y8; x8_y8_dctsel[3 * v + 2] = r.dctsel; }
+	}
+	return placed;
+}
+
+extern "C" int j40hip_stage_dump_llf(const j40hip_stage_dump *d, int64_t gg, int c, float *out) {
+	if (!d || gg < 0 || (size_t) gg >= d->lf_groups.size() || c < 0 || c > 2) return -1;
+	const DevLfGroup &g = d->lf_groups[(size_t) gg];
+	memcpy(out, d->llf[c].data() + g.cell_base, (size_t) g.width8 * (size_t) g.height8 * 4);
+	return 0;
+}
+
+extern "C" int64_t j40hip_stage_dump_group_blocks(const j40hip_stage_dump *d, int64_t group, uint32_t *out3, int64_t capacity) {
+	if (!d || group < 0 || group >= d->num_groups) return -1;
+	const uint32_t a = d->group_block_start[(size_t) group], b = d->group_block_start[(size_t) group + 1];
+	if (b < a || b > d->group_blocks.size()) return -1;
+	for (uint32_t k = a; k < b && (int64_t) (k - a) < capacity; ++k) { const DevGroupBlock &gb = d->group_blocks[k]; uint32_t *o = out3 + 3 * (size_t) (k - a); o[0] = gb.coeffoff_qfidx; o[1] = gb.pos_dct; o[2] = gb.bctx3; }
+	return (int64_t) (b - a);
+}
+
+extern "C" int64_t j40hip_stage_dump_sorted_varblocks(const j40hip_stage_dump *d, int32_t *out8, float *out3, int32_t *class_start28, int64_t capacity) {
+	if (!d) return -1;
+	memcpy(class_start28, d->class_start, sizeof d->class_start);
+	const int64_t n = d->class_start[27];
+	if (n < 0 || (size_t) n > d->sorted.size()) return -1;
+	for (int64_t k = 0; k < n && k < capacity; ++k) {
+		const DevVarblock &v = d->sorted[(size_t) k];
+		int32_t *o = out8 + 8 * k; float *f = out3 + 3 * k;
+		o[0] = v.px; o[1] = v.py; o[2] = v.effw; o[3] = v.effh; o[4] = v.dctsel; o[5] = v.blk; o[6] = v.llf_base; o[7] = v.coeff_base;
+		f[0] = v.mult1; f[1] = v.kx_hf; f[2] = v.kb_hf;
+	}
+	return n;
+}
+
+extern "C" int j40hip_stage_dump_rgba(const j40hip_stage_dump *d, uint8_t *out) { if (!d) return -1; memcpy(out, d->rgba.data(), d->rgba.size()); return 0; }
+
