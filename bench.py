@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--config5-batch", type=int, default=256, help="config 5 (1024 x 1920x1080): frames per entropy launch")
     ap.add_argument("--config5-in-flight", type=int, default=4)
     ap.add_argument("--config5-lf", choices=["auto", "device", "host"], default="host")
+    ap.add_argument("--sharded-record", action="store_true", help="add the `sharded` record (one frame split by group ranges) also on one rank; with several ranks it is always there")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-sections", action="store_true", help="only the timed pipeline (no device-resident / latency / other-config sections)")
     ap.add_argument("--skip-modular", action="store_true", help="leave BASELINE config 4 (16384 x 16384 Modular) out of `configs`")
@@ -223,7 +224,7 @@ def main():
     torch.cuda.set_device(local_rank)   # before the first collective: RCCL binds a rank to its current device
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("J40_BENCH_FORCE_DIST") == "1":   # (J40_BENCH_FORCE_DIST: the process group also for one rank -- a dry run of the RCCL calls on a one-GPU box)
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
@@ -311,6 +312,12 @@ def main():
         resident_multi = {"value": round(W * H * R * 5 * world / float(t.item()) / 1e6, 2), "unit": "Mpixels/s", "frames_per_step_per_gpu": R, "steps": 5,
                           "note": "kernels only on frames parsed, planned and uploaded ahead, all ranks at once (max over ranks, barriers on both sides)"}
         del routs, frames, batch
+    sharded = None
+    if (world > 1 or args.sharded_record or dist is not None) and not args.skip_sections:
+        if resident_multi is None:
+            pipe.close()
+            torch.cuda.empty_cache()
+        sharded = sharded_records(args, torch, j40_amd, dist, dev, rank, local_rank, world)
     if rank != 0:
         if resident_multi is None:
             pipe.close()
@@ -357,6 +364,8 @@ def main():
                       "note": "RGBA copied back per GPU during the timed region / wall time; a Gen5 x16 link moved 57 GB/s device-to-host on these boxes (tools/pcie_probe.py): 14.2 Gpx/s is the ceiling of `value` per GPU"}
     if resident_multi is not None:
         result["device_resident"] = resident_multi
+    if sharded is not None:
+        result["sharded"] = sharded
     try:
         pt = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
         if abs(pt.get("frames_per_launch", 0) - frames_per_launch) < 1 and (W, H) == (7680, 4320) and pt.get("stream", "coefficient") == args.stream:
@@ -510,12 +519,10 @@ def sections(args, torch, np, j40_amd, dev, local_rank, datas, quota):
     return out
 
 
-def bench_sharded(args, torch, j40_amd, dist, dev, rank, local_rank, world, data):
-    """the north star's single-frame mode: every step decodes ONE frame whose pass groups are split over the ranks in contiguous
-    ranges balanced by section bytes (j40_amd.sharding): codestream broadcast from rank 0, per-rank partial decode, the pixel
-    rows of every rank's groups sent to rank 0 over RCCL. Strong scaling of a latency-bound step: DESIGN.md section 6."""
+def time_sharded(steps, warmup, torch, j40_amd, dist, dev, rank, local_rank, data):
+    """seconds per step of one frame decoded by group ranges over the ranks (j40_amd.sharding): codestream broadcast from rank 0,
+    per-rank partial decode, pixel rectangles sent to rank 0 (device tensors under nccl); max over the ranks"""
     from j40_amd import sharding
-    W, H = args.width, args.height
     decode = sharding.hip_range_decoder(local_rank)
 
     def step():
@@ -525,14 +532,14 @@ def bench_sharded(args, torch, j40_amd, dist, dev, rank, local_rank, world, data
         assert err == "", err
         return full
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize(dev)
     if dist is not None:
@@ -542,11 +549,37 @@ def bench_sharded(args, torch, j40_amd, dist, dev, rank, local_rank, world, data
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    return elapsed / steps
+
+
+def sharded_records(args, torch, j40_amd, dist, dev, rank, local_rank, world):
+    """the north star's split beside the frame-parallel figure (every rank calls this): one 7680x4320 VarDCT frame and, unless
+    --skip-modular, one 16384x16384 Modular frame (RCT only) decoded by contiguous group ranges balanced by section bytes"""
+    from streams import synth
+    out = {}
+    d8k = synth("vardct", 7680, 4320, args.seed, **({"forward": 1} if args.stream == "forward" else {})) if rank == 0 else b""
+    sec = time_sharded(5, 1, torch, j40_amd, dist, dev, rank, local_rank, d8k)
+    out["vardct_7680x4320"] = {"ms_per_frame": round(sec * 1e3, 3), "mpixels_per_s": round(7680 * 4320 / sec / 1e6, 1), "steps": 5}
+    if not args.skip_modular:
+        dm = synth("modular", 16384, 16384, 21, tree=1, repeat=16) if rank == 0 else b""
+        sec = time_sharded(2, 1, torch, j40_amd, dist, dev, rank, local_rank, dm)
+        out["modular_16384x16384_rct"] = {"ms_per_frame": round(sec * 1e3, 2), "mpixels_per_s": round(16384 * 16384 / sec / 1e6, 1), "steps": 2, "codestream_mb": round(len(dm) / 1e6, 1) if rank == 0 else None}
+    out["note"] = ("one frame per step, its pass groups split over %d ranks in contiguous ranges balanced by section bytes; codestream broadcast from rank 0, every rank parses it, decodes its "
+                   "range (j40hip_frame_set_group_range) and sends its pixel rectangles to rank 0 point-to-point (device tensors over RCCL). Strong scaling of a latency-bound step: "
+                   "one 8K frame's 510 sections already run concurrently on one GPU and the step is its longest section (DESIGN.md section 6)") % world
+    out["backend"] = dist.get_backend() if dist is not None else "none"
+    return out
+
+
+def bench_sharded(args, torch, j40_amd, dist, dev, rank, local_rank, world, data):
+    """the north star's single-frame mode as the whole run (--shard-groups)"""
+    W, H = args.width, args.height
+    sec = time_sharded(args.steps, args.warmup, torch, j40_amd, dist, dev, rank, local_rank, data)
     if rank != 0:
         return
     print(json.dumps({
-        "metric": METRIC, "value": round(W * H * args.steps / elapsed / 1e6, 2), "unit": "Mpixels/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+        "metric": METRIC, "value": round(W * H / sec / 1e6, 2), "unit": "Mpixels/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec * 1e3, 4), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "one %dx%d %s synthetic frame per step, pass groups split over %d ranks (contiguous ranges balanced by section bytes), RGBA gathered on rank 0" % (W, H, "Modular lossless (RCT)" if args.shard_kind == "modular" else "VarDCT d1-like", world),
                    "frame_pixels": W * H, "codestream_bytes": len(data), "parallelism": "pass groups x%d" % world}}))

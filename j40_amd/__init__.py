@@ -563,7 +563,8 @@ class Pipeline:
     def stats(self):
         a = (C.c_double * 12)()
         lib().j40hip_pipeline_stats_ex(self.h, a)
-        return dict(parse_thread_ms=a[0], single_thread_ms=a[1], upload_thread_ms=a[1],   # (upload_thread_ms: the key's name until round 3) completed=int(a[2]), wall_ms=a[3], k1_ms=a[4], k2_ms=a[5], launches=int(a[6]), launch_frames=int(a[7]),
+        # (upload_thread_ms: single_thread_ms under the name it had until round 3)
+        return dict(parse_thread_ms=a[0], single_thread_ms=a[1], upload_thread_ms=a[1], completed=int(a[2]), wall_ms=a[3], k1_ms=a[4], k2_ms=a[5], launches=int(a[6]), launch_frames=int(a[7]),
                     lf_plan_ms=a[8], lf_device_frames=int(a[9]), single_frames=int(a[10]), k1_kernel_ms=a[11])
 
     def reset_stats(self):

@@ -143,8 +143,10 @@ j40_err advance(j40__inner *inner, int origin) {
 	}
 	const double t0 = now_ms();
 	double t1 = t0, t2 = t0, t3 = t0;
-	static const int parse_threads = [] { const char *e = getenv("J40HIP_PARSE_THREADS"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
-	inner->frame = j40hip_frame_parse(inner->buf, inner->size, parse_threads, &err);
+	// (LfGroup sections are independent: an 8K frame has twelve; their tail -- dequantisation, smoothing, LLF coefficients -- runs on
+	// the device at upload, flags = 1)
+	static const int parse_threads = [] { const char *e = getenv("J40HIP_PARSE_THREADS"); return e && atoi(e) > 0 ? atoi(e) : 12; }();
+	inner->frame = j40hip_frame_parse_ex(inner->buf, inner->size, parse_threads, 1u, &err);
 	t1 = now_ms();
 	if (!err && j40hip_device_count() <= device_index()) err = code4("!gpu");   // (before the plane: pinned memory needs the device too)
 	if (!err) {

@@ -246,7 +246,8 @@ struct j40hip_device_state {
 	bool trailers_pending = false;       // ... decoded by a batch since: j40hip_frame_status validates the sub-images before it reports
 	ModLaunchInfo mod_info = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 	std::vector<uint32_t> mod_section_offsets;
-	struct ModOp { int kind; int16_t *a, *b, *c; const int16_t *src, *aux; size_t n; int32_t p0, p1, p2, p3, p4, p5; int16_t *const *dst_list; const int8_t *wpp; };
+	// group: the group whose section's sub-image the op belongs to (mod_sub_ops; a ranged decode skips the ops of groups it did not decode), -1: the frame's
+	struct ModOp { int kind; int16_t *a, *b, *c; const int16_t *src, *aux; size_t n; int32_t p0, p1, p2, p3, p4, p5; int16_t *const *dst_list; const int8_t *wpp; int32_t group; };
 	std::vector<ModOp> mod_ops;          // inverse transforms of the frame, in execution order
 	std::vector<ModOp> mod_sub_ops;      // before them: inverse transforms of the sections' own sub-images and their paste (kind 3)
 	std::vector<int16_t *> final_planes; // channel list after the inverse transforms
@@ -347,7 +348,8 @@ static uint32_t upload_modular(j40hip_frame *h, int device) {
 	// inverse transforms, last to first (j40.h:4513-4521), resolved to plane pointers now: of the frame, and before that of the
 	// sub-images of the sections that list a palette of their own (undone there, then pasted over the section's rectangle)
 	static const uint8_t PERM[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
-	auto schedule = [&](std::vector<Ref> &planes, const std::vector<Transform> &trs, const int8_t *wpb, std::vector<j40hip_device_state::ModOp> &ops) {
+	auto schedule = [&](std::vector<Ref> &planes, const std::vector<Transform> &trs, const int8_t *wpb, std::vector<j40hip_device_state::ModOp> &ops, int32_t group) {
+		const size_t ops_before = ops.size();
 		for (size_t ti = trs.size(); ti-- > 0; ) {
 			const Transform &t = trs[ti];
 			if (t.kind == Transform::RCT) {
@@ -400,6 +402,7 @@ static uint32_t upload_modular(j40hip_frame *h, int device) {
 				if (ok) planes.erase(planes.begin() + offset, planes.begin() + offset + t.num_c);
 			} else { ok = false; }
 		}
+		for (size_t k = ops_before; k < ops.size(); ++k) ops[k].group = group;
 	};
 	if (!hp.sub_images.empty()) {
 		std::vector<DevSubPlane> subp(hp.sub_w.size());
@@ -415,13 +418,16 @@ static uint32_t upload_modular(j40hip_frame *h, int device) {
 			for (const Transform &t : si.transforms) palette_wp |= t.kind == Transform::PALETTE && t.nb_deltas > 0 && t.d_pred == 6;
 			std::vector<Ref> sp;
 			for (int32_t k = 0; k < si.num_planes; ++k) sp.push_back({subp[(size_t) (si.first_plane + k)].ptr, subp[(size_t) (si.first_plane + k)].w, subp[(size_t) (si.first_plane + k)].h});
-			schedule(sp, si.transforms, si.wp, st->mod_sub_ops);
+			// (sections: LfGlobal's first, then passes x groups)
+			const int32_t lead_sections = (int32_t) hp.sections.size() - hp.sections_per_pass * hp.num_passes;
+			const int32_t sub_group = si.section >= lead_sections && hp.sections_per_pass > 0 ? (si.section - lead_sections) % hp.sections_per_pass : -1;
+			schedule(sp, si.transforms, si.wp, st->mod_sub_ops, sub_group);
 			const DevModSection &sec = hp.sections[(size_t) si.section];
 			for (size_t c = 0; c < sp.size() && ok; ++c) {   // paste: rows of the sub-image over the section's rectangle
 				const Ref &dst = planes[(size_t) sec.first_channel + c];
 				if (sp[c].w != sec.gw || sp[c].h != sec.gh || (size_t) sec.first_channel + c >= planes.size()) { ok = false; break; }
 				j40hip_device_state::ModOp op; memset(&op, 0, sizeof op);
-				op.kind = 3; op.src = sp[c].p; op.a = dst.p + (size_t) sec.gy * (size_t) dst.w + (size_t) sec.gx; op.p0 = sp[c].w; op.p1 = sp[c].h; op.p2 = dst.w;
+				op.kind = 3; op.src = sp[c].p; op.a = dst.p + (size_t) sec.gy * (size_t) dst.w + (size_t) sec.gx; op.p0 = sp[c].w; op.p1 = sp[c].h; op.p2 = dst.w; op.group = sub_group;
 				st->mod_sub_ops.push_back(op);
 			}
 		}
@@ -430,7 +436,7 @@ static uint32_t upload_modular(j40hip_frame *h, int device) {
 	{
 		int8_t gwp[12]; const WPParams &wp = h->frame.gmodular.wp;
 		gwp[0] = wp.p1; gwp[1] = wp.p2; for (int i = 0; i < 5; ++i) gwp[2 + i] = wp.p3[i]; for (int i = 0; i < 4; ++i) gwp[7 + i] = wp.w[i]; gwp[11] = 0;
-		schedule(planes, hp.transforms, gwp, st->mod_ops);
+		schedule(planes, hp.transforms, gwp, st->mod_ops, -1);
 	}
 	for (const Ref &p : planes) { st->final_planes.push_back(p.p); st->final_w.push_back(p.w); st->final_h.push_back(p.h); }
 	st->alpha_channel = hp.alpha_channel;
@@ -464,6 +470,7 @@ static uint32_t decode_modular(j40hip_frame *h, void *rgba_dev, size_t stride_by
 	if (st->mod_local_rcts) launch_section_inverse_rcts(plan, lead + (st->mod_passes - 1) * per_pass + g0, gn, s);
 	if (ms3) (void) hipEventRecord(st->ev[2], s);
 	for (const std::vector<j40hip_device_state::ModOp> *ops : {&st->mod_sub_ops, &st->mod_ops}) for (const auto &op : *ops) {
+		if (ranged && op.group >= 0 && (op.group < g0 || op.group >= g0 + gn)) continue;   // the sub-image of a group this process did not decode
 		if (op.kind == 0) launch_inverse_rct(op.a, op.b, op.c, op.n, op.p0, s);
 		else if (op.kind == 1) launch_inverse_palette_plain(op.src, op.aux, op.a, op.n, op.p0, op.p1, fr.im.bpp, s);
 		else if (op.kind == 2) launch_inverse_palette_predicted(op.src, op.aux, op.p0, op.dst_list, op.p1, op.p2, op.p3, op.p4, op.p5 & 0xffffff, op.p5 >> 24, fr.im.bpp, op.wpp, st->pal_wp_scratch, st->mod_extra_status, s);
