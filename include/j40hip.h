@@ -290,7 +290,8 @@ J40HIP_API j40hip_pipeline *j40hip_pipeline_create(int device, int host_threads,
 /* flags bits 0-1: who decodes the LfGroup streams (j40.h:6722-6790) of the batched frames: 0 decided frame by frame (the host
  * threads keep them while the device has batches queued up, else the device takes them), 1 always the device (k_lf_groups),
  * 2 always the host threads. Bit 2: tune the process's malloc for many threads freeing multi-megabyte blocks (mallopt: mmap
- * threshold, trim threshold, top pad) -- process-wide, hence opt-in. */
+ * threshold, trim threshold, top pad) -- process-wide, hence opt-in. Bit 3: do not size the device memory cache for the pipeline's full
+ * depth at its second full batch (a serving pipeline whose batches fill up only now and then). */
 J40HIP_API j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int batch_frames, int max_in_flight, uint32_t flags, uint32_t *err);
 J40HIP_API int64_t j40hip_pipeline_lf_device_frames(j40hip_pipeline *p);   /* frames whose LfGroup streams the device decoded (since the last reset) */
 J40HIP_API void j40hip_pipeline_free(j40hip_pipeline *p);

@@ -103,8 +103,8 @@ J40_DEV uint32_t decode_hf_section(const DevPlan &plan, const DevFrame &f, const
 				const int32_t ucoeff = code_symbol<UNI>(b, code, ctx, 0, plan.lz_window_size);
 				if (ucoeff) {
 					if (SCAN) {
-						if (ev_at >= t.ev_end) { bits_set_error(b, ERR_EVOF); break; }
-						CoeffEvent ev; ev.pos = (uint32_t) i; ev.value = unpack_signed_dev(ucoeff);
+						if (ev_at >= t.ev_end || !coeff_event_fits(unpack_signed_dev(ucoeff))) { bits_set_error(b, ERR_EVOF); break; }
+						CoeffEvent ev; ev.packed = coeff_event_pack((uint32_t) i, unpack_signed_dev(ucoeff));
 						plan.events[ev_at++] = ev;
 					} else coeffs[uni<UNI>((uint32_t) order[i])] += (float) unpack_signed_dev(ucoeff);
 				}
@@ -192,8 +192,8 @@ J40_DEV uint32_t decode_hf_section_flat(const DevPlan &plan, const DevFrame &f, 
 		} else {
 			if (v) {
 				if (SCAN) {
-					if (ev_at >= t.ev_end) bits_set_error(b, ERR_EVOF);
-					else { CoeffEvent ev; ev.pos = (uint32_t) i; ev.value = unpack_signed_dev(v); plan.events[ev_at++] = ev; }
+					if (ev_at >= t.ev_end || !coeff_event_fits(unpack_signed_dev(v))) bits_set_error(b, ERR_EVOF);
+					else { CoeffEvent ev; ev.packed = coeff_event_pack((uint32_t) i, unpack_signed_dev(v)); plan.events[ev_at++] = ev; }
 				} else coeffs[order[i]] += (float) unpack_signed_dev(v);
 			}
 			prev = v != 0;

@@ -228,9 +228,10 @@ J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t,
 			in_coeffs = nz > 0;
 		} else {
 			const bool nonzero = v != 0 && e2 == 0;
-			if (SCAN) {   // one sequential 8-byte store per non-zero coefficient
-				const bool full = nonzero && ev_at >= ev_end;
-				if (nonzero && !full) ((J40_GLOBAL uint64_t *) G.events)[ev_at] = (uint64_t) (uint32_t) i | ((uint64_t) (uint32_t) unpack_signed_dev(v) << 32);   // CoeffEvent {pos, value}
+			if (SCAN) {   // one sequential 4-byte store per non-zero coefficient (CoeffEvent: position | value << 16)
+				const int32_t sv = unpack_signed_dev(v);
+				const bool full = nonzero && (ev_at >= ev_end || !coeff_event_fits(sv));
+				if (nonzero && !full) ((J40_GLOBAL uint32_t *) G.events)[ev_at] = coeff_event_pack((uint32_t) i, sv);
 				ev_at += nonzero && !full ? 1u : 0u;
 				e2 = e2 ? e2 : full ? (uint32_t) ERR_EVOF : 0u;
 			} else if (nonzero) G.coeffs[coeff_at + order[i]] += (float) unpack_signed_dev(v);

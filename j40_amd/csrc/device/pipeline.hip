@@ -54,6 +54,8 @@ struct Job {
 	bool lf_failed = false;       // its LfGroup streams could not be launched on the device
 	void *dev_rgba = nullptr;     // host output: the device image the copy back reads
 	uint32_t status = 0;
+	bool redo = false;            // its batch wants it decoded again on the single-frame path
+	bool counted = true;          // counts towards the pipeline's resident frames (until its device memory has gone back to the cache)
 	// j40hip_pipeline_run: the caller sleeps on `waiter` until the image is done, and its pixel memory is asked for once the
 	// image's size is known (`alloc`, called on a pipeline thread)
 	j40hip_output_alloc alloc = nullptr; void *alloc_ctx = nullptr;
@@ -81,6 +83,7 @@ struct Slot {
 	std::vector<hipEvent_t> group_ev;   // made on demand, kept
 	std::vector<int> group_end;         // jobs [group_end[g - 1], group_end[g]) complete with group_ev[g]
 	int next_group = 0;
+	bool harvested = false;             // the kernels are through: verdicts read, the frames' device memory handed back (the copies may still run)
 	bool failed = false;                // the device reported an error for this batch: everything still pending fails with "!gpu"
 	uint32_t launch_err = 0;      // the batch could not be enqueued: every member fails with this
 	bool busy = false;
@@ -115,6 +118,7 @@ struct j40hip_pipeline {
 	int64_t submitted = 0, completed = 0, resident = 0, parsing = 0, in_flight_frames = 0;
 	std::vector<j40hip_aframe *> garbage;   // frames of retired batches: the worker threads free them (60 us each: a batch's worth kept the launching thread busy for 15 ms and more)
 	int64_t full_batches = 0;
+	bool reserve = true;                // size the device memory cache for the full depth at the second full batch (flags bit 3 of create_ex: not)
 	bool stop = false;
 	std::vector<std::thread> workers;
 	std::thread gpu;
@@ -276,6 +280,38 @@ void worker_main(j40hip_pipeline *p, int) {
 bool progress(j40hip_pipeline *p, Slot &slot, bool block) {
 	const int ngroups = (int) slot.group_end.size();
 	bool first = true;
+	if (!slot.harvested && !slot.launch_err && !slot.failed) {
+		// The batch's kernels and the copy of its verdicts are through (kdone): every frame's code is known and its working set --
+		// 0.2 GB per 8K frame -- goes back to the cache now, not when the copies of the pixels have drained (0.6 s per 256 frames
+		// over PCIe, during which the next batches want that memory)
+		hipError_t q = block ? hipEventSynchronize(slot.kdone) : hipEventQuery(slot.kdone);
+		if (q == hipErrorNotReady) { (void) hipGetLastError(); return false; }
+		first = false;
+		if (q != hipSuccess) { (void) hipGetLastError(); slot.failed = true; }
+		else {
+			float ms3[4] = {0, 0, 0, 0};
+			const bool timed = j40hip_abatch_elapsed(slot.batch, ms3) == 0;
+			std::vector<j40hip_aframe *> dead;
+			for (size_t i = 0; i < slot.jobs.size(); ++i) {
+				Job *j = slot.jobs[i];
+				if (!j->status) {   // (a copy back that could not be enqueued keeps its error)
+					uint32_t code = 0; int redo = 0;
+					j40hip_abatch_result(slot.batch, (int) i, &code, &redo);
+					j->redo = redo != 0;
+					if (!redo) j->status = code ? code : j40hip_aframe_after_frame_status(j->af);
+				}
+				if (j->af) { dead.push_back(j->af); j->af = nullptr; }
+			}
+			std::unique_lock<std::mutex> lock(p->m);
+			if (timed) { p->lf_ms += ms3[0]; p->k1_ms += ms3[1]; p->k2_ms += ms3[2]; p->k1_kernel_ms += ms3[3]; ++p->launches; p->launch_frames += (int64_t) slot.jobs.size(); }
+			// (the back-pressure on the worker threads counts frames that hold device memory: these no longer do -- what waits for the
+			// copy back is bounded by the batch slots)
+			for (Job *j : slot.jobs) if (j->counted) { j->counted = false; --p->resident; }
+			p->garbage.insert(p->garbage.end(), dead.begin(), dead.end());
+			p->cv_todo.notify_all();
+		}
+		slot.harvested = true;
+	}
 	while (slot.next_group < ngroups) {
 		hipEvent_t ev = slot.group_ev[(size_t) slot.next_group];
 		if (!slot.launch_err && !slot.failed) {
@@ -284,28 +320,15 @@ bool progress(j40hip_pipeline *p, Slot &slot, bool block) {
 			if (q != hipSuccess) { (void) hipGetLastError(); slot.failed = true; }
 		}
 		first = false;
-		if (slot.next_group == 0 && !slot.launch_err && !slot.failed) {   // the kernels and the verdicts are through: the stages' times
-			float ms3[4] = {0, 0, 0, 0};
-			if (j40hip_abatch_elapsed(slot.batch, ms3) == 0) {
-				std::unique_lock<std::mutex> lock(p->m);
-				p->lf_ms += ms3[0]; p->k1_ms += ms3[1]; p->k2_ms += ms3[2]; p->k1_kernel_ms += ms3[3]; ++p->launches; p->launch_frames += (int64_t) slot.jobs.size();
-			}
-		}
 		const int begin = slot.next_group ? slot.group_end[(size_t) slot.next_group - 1] : 0, end = slot.group_end[(size_t) slot.next_group];
 		std::vector<j40hip_aframe *> dead;
 		for (int i = begin; i < end; ++i) {
 			Job *j = slot.jobs[(size_t) i];
 			if (slot.failed) j->status = E_GPU;
 			else if (slot.launch_err) j->status = slot.launch_err;
-			else if (!j->status) {   // (a copy back that could not be enqueued keeps its error)
-				uint32_t code = 0; int redo = 0;
-				j40hip_abatch_result(slot.batch, i, &code, &redo);
-				if (redo) {
-					// (the frame's memory goes back to the cache: the batch's kernels are through -- the verdicts follow them on its stream)
-					j40hip_aframe_free(j->af); j->af = nullptr;
-					if (!j->device_output && j->dev_rgba) { release_image(p, j->dev_rgba, j->stride * (size_t) j->height); j->dev_rgba = nullptr; }
-					j->status = decode_single(p, j, slot.stream);
-				} else j->status = code ? code : j40hip_aframe_after_frame_status(j->af);
+			else if (j->redo) {
+				if (!j->device_output && j->dev_rgba) { release_image(p, j->dev_rgba, j->stride * (size_t) j->height); j->dev_rgba = nullptr; }
+				j->status = decode_single(p, j, slot.stream);
 			}
 			if (j->af) { dead.push_back(j->af); j->af = nullptr; }
 			if (!j->device_output && j->dev_rgba) { release_image(p, j->dev_rgba, j->stride * (size_t) j->height); j->dev_rgba = nullptr; }
@@ -313,13 +336,13 @@ bool progress(j40hip_pipeline *p, Slot &slot, bool block) {
 		{
 			std::unique_lock<std::mutex> lock(p->m);
 			p->in_flight_frames -= (int64_t) (end - begin);
-			for (int i = begin; i < end; ++i) { --p->resident; complete(p, slot.jobs[(size_t) i]); slot.jobs[(size_t) i] = nullptr; }
+			for (int i = begin; i < end; ++i) { if (slot.jobs[(size_t) i]->counted) --p->resident; complete(p, slot.jobs[(size_t) i]); slot.jobs[(size_t) i] = nullptr; }
 			p->garbage.insert(p->garbage.end(), dead.begin(), dead.end());
 			p->cv_todo.notify_all();
 		}
 		++slot.next_group;
 	}
-	slot.jobs.clear(); slot.group_end.clear(); slot.next_group = 0; slot.busy = false; slot.launch_err = 0; slot.failed = false;
+	slot.jobs.clear(); slot.group_end.clear(); slot.next_group = 0; slot.busy = false; slot.launch_err = 0; slot.failed = false; slot.harvested = false;
 	return true;
 }
 
@@ -344,10 +367,10 @@ uint32_t launch_batch(j40hip_pipeline *p, std::vector<Job *> &take, int si) {
 		for (Job *j : take) if (!j->device_output && j->dev_rgba) { release_image(p, j->dev_rgba, j->stride * (size_t) j->height); j->dev_rgba = nullptr; }
 		return E_MEM;
 	}
-	slot.busy = true; slot.jobs = take; slot.launch_err = err; slot.failed = false; slot.next_group = 0; slot.group_end.clear();
+	slot.busy = true; slot.jobs = take; slot.launch_err = err; slot.failed = false; slot.harvested = false; slot.next_group = 0; slot.group_end.clear();
 	// the second full batch says this is a pipeline that will run at depth: size the device memory cache for it now (the device
 	// has two batches to work on meanwhile) rather than wherever the queues first fill up
-	if (!err && (int64_t) frames.size() == p->batch_frames && ++p->full_batches == 2)
+	if (!err && p->reserve && (int64_t) frames.size() == p->batch_frames && ++p->full_batches == 2)
 		j40hip_aframes_reserve(frames.data(), (int) frames.size(), p->max_in_flight - 1, (int) (p->max_in_flight - 1 + p->lf_cap / std::max<int64_t>(1, p->batch_frames)));   // (two batches' worth exist)
 	if (hipEventRecord(slot.kdone, slot.stream) != hipSuccess && !slot.launch_err) slot.launch_err = E_GPU;
 	const int n = (int) take.size();
@@ -477,7 +500,7 @@ void gpu_main(j40hip_pipeline *p) {
 				continue;
 			}
 			Slot &slot = p->slots[(size_t) si];   // one frame, nothing in flight, nothing cached: it does not fit
-			slot.busy = true; slot.jobs = take; slot.launch_err = E_MEM; slot.next_group = 0; slot.group_end.assign(1, (int) take.size());
+			slot.busy = true; slot.jobs = take; slot.launch_err = E_MEM; slot.harvested = false; slot.next_group = 0; slot.group_end.assign(1, (int) take.size());
 			if (slot.group_ev.empty()) slot.group_ev.push_back(slot.kdone);
 			p->in_flight.push_back(si);
 			break;
@@ -508,6 +531,7 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 		p->lf_mode = (int) (flags & 3u) > 2 ? 0 : (int) (flags & 3u);
 		// (flags bit 2, opt-in: keep multi-megabyte blocks in the heap instead of separate mmap()s -- many threads freeing such blocks
 		// serialise on the process's address-space lock and fault every page in again. Changes process-wide malloc behaviour.)
+		p->reserve = !(flags & 8u);
 		if (flags & 4u) { (void) mallopt(M_MMAP_THRESHOLD, 1 << 30); (void) mallopt(M_TRIM_THRESHOLD, (int) (((size_t) 1 << 31) - 1)); (void) mallopt(M_TOP_PAD, 64 << 20); }
 		p->batch_frames = batch_frames < 1 ? 32 : batch_frames;
 		p->max_in_flight = max_in_flight < 1 ? 2 : max_in_flight > 8 ? 8 : max_in_flight;
@@ -678,10 +702,10 @@ j40hip_pipeline *j40hip_serve_pipeline(int device, uint32_t *err) {
 	const int threads = std::max(1, env_int("J40HIP_SERVE_THREADS", cpu_quota()));
 	uint32_t lf = 2;
 	if (const char *e = getenv("J40HIP_SERVE_LF")) lf = !strcmp(e, "device") ? 1u : !strcmp(e, "auto") ? 0u : 2u;
-	j40hip_pipeline *p = j40hip_pipeline_create_ex(device, threads, std::max(1, env_int("J40HIP_SERVE_BATCH", 64)), env_int("J40HIP_SERVE_IN_FLIGHT", 3), lf, err);
+	j40hip_pipeline *p = j40hip_pipeline_create_ex(device, threads, std::max(1, env_int("J40HIP_SERVE_BATCH", 64)), env_int("J40HIP_SERVE_IN_FLIGHT", 6), lf | 8u, err);
 	if (!p) return nullptr;
 	const char *w = getenv("J40HIP_SERVE_WAIT_MS");
-	j40hip_pipeline_set_max_wait_ms(p, w && *w ? atof(w) : 3.0);
+	j40hip_pipeline_set_max_wait_ms(p, w && *w ? atof(w) : 40.0);
 	return g_serve[device] = p;
 }
 

@@ -105,7 +105,31 @@ struct DevFrame {
 	                                         // end of the codestream, stopping short of this is `shrt`, going past it `excs` (j40.h:7796-7803)
 };
 
-struct CoeffEvent { uint32_t pos; int32_t value; };   // one non-zero quantised HF coefficient: scan position inside its block
+// one non-zero quantised HF coefficient in FOUR bytes: scan position inside its block (a block has at most 256 x 256 positions) in the
+// low half, the value as int16 in the high half. A coefficient beyond 16 bits -- legal, never seen -- makes its section report ERR_EVOF
+// like a full event region does, and the frame is decoded with dense planes. (Eight-byte events until round 3: the entropy kernel
+// wrote 27 GB of them per 256 8K frames and the pixel kernels read them back; half of that now, and 72 MB less per frame in flight.)
+struct CoeffEvent { uint32_t packed; };
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+uint32_t coeff_event_pack(uint32_t pos, int32_t value) { return (pos & 0xffffu) | ((uint32_t) value << 16); }
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+uint32_t coeff_event_pos(CoeffEvent e) { return e.packed & 0xffffu; }
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+int32_t coeff_event_value(CoeffEvent e) { return (int32_t) (int16_t) (e.packed >> 16); }
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+bool coeff_event_fits(int32_t value) { return value >= -32768 && value <= 32767; }
 
 // everything a kernel needs, passed by value
 struct DevPlan {
@@ -409,7 +433,7 @@ enum {
 	ERR_TODO = ('T' << 24) | ('O' << 16) | ('D' << 8) | 'O',
 	ERR_VBLK = ('v' << 24) | ('b' << 16) | ('l' << 8) | 'k',
 	ERR_DCTQ = ('d' << 24) | ('c' << 16) | ('t' << 8) | '?',
-	ERR_EVOF = ('e' << 24) | ('v' << 16) | ('o' << 8) | 'f',   // a section's event region is full: decode the frame with dense planes
+	ERR_EVOF = ('e' << 24) | ('v' << 16) | ('o' << 8) | 'f',   // a section's event region is full, or a coefficient does not fit an event's 16 bits: decode the frame with dense planes
 };
 
 // the pixel rectangles {x0, y0, x1, y1} a contiguous range of groups (raster order) covers: at most three -- the tail of its first

@@ -1242,7 +1242,7 @@ extern "C" uint32_t j40hip_frame_read_coeffs(j40hip_frame *h, int64_t gg, int c,
 		if (hipMemcpy(ev.data(), st->plan.events + be[0] + skip, sizeof(CoeffEvent) * n, hipMemcpyDeviceToHost) != hipSuccess) return ERR_GPU;
 		const std::vector<int32_t> &order = h->frame.orders[0][DCT_SELECT[vb.dctsel].order_idx][(size_t) c];
 		float *blk = out + ((size_t) vb.llf_base - base) * 64;
-		for (const CoeffEvent &e : ev) blk[order[e.pos]] = (float) e.value;
+		for (const CoeffEvent &e : ev) blk[order[coeff_event_pos(e)]] = (float) coeff_event_value(e);
 	}
 	return 0;
 }

@@ -75,8 +75,9 @@ J40_DEV void tile_scatter_one(const DevPlan &plan, const GEOM &g, const BE &be, 
 	const uint32_t first = be[0], n0 = be[1], n1 = be[2];
 	const int32_t c = e < n0 ? 1 : e < n0 + n1 ? 0 : 2;   // events come in the order the channels are coded: Y, X, B
 	const CoeffEvent ev = plan.events[first + e];
-	const int32_t at = map.at(order[c * n + (int32_t) ev.pos]);
-	const float v = dequant_coeff((float) ev.value, quant_bias[c], quant_bias_num, g.mult[c], dq_scan[c * n + (int32_t) ev.pos]);
+	const int32_t pos = (int32_t) coeff_event_pos(ev);
+	const int32_t at = map.at(order[c * n + pos]);
+	const float v = dequant_coeff((float) coeff_event_value(ev), quant_bias[c], quant_bias_num, g.mult[c], dq_scan[c * n + pos]);
 	if (c == 1) {
 		tile[cstride + at] = v;
 		tile_add(&tile[at], v * g.kx_hf);

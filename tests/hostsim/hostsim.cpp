@@ -292,7 +292,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 			const uint32_t *be = block_events.data() + 4 * (size_t) vb.blk;
 			const uint32_t skip = c == 1 ? 0 : c == 0 ? be[1] : be[1] + be[2], n = be[c == 1 ? 1 : c == 0 ? 2 : 3];
 			const std::vector<int32_t> &order = fr.orders[0][DCT_SELECT[vb.dctsel].order_idx][(size_t) c];
-			for (uint32_t e = 0; e < n; ++e) { const CoeffEvent &ev = events[be[0] + skip + e]; dst[(size_t) vb.coeff_base + (size_t) order[ev.pos]] = (float) ev.value; }
+			for (uint32_t e = 0; e < n; ++e) { const CoeffEvent &ev = events[be[0] + skip + e]; dst[(size_t) vb.coeff_base + (size_t) order[coeff_event_pos(ev)]] = (float) coeff_event_value(ev); }
 		}
 	}
 	// the Modular sub-images behind the coefficients (VarDCT frames with extra channels), as runtime.hip's validate_trailers does
