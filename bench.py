@@ -183,7 +183,9 @@ def main():
     ap.add_argument("--pipe-batch", type=int, default=256, help="frames per entropy launch inside the pipeline")
     ap.add_argument("--host-threads", type=int, default=0, help="pipeline worker threads per GPU (default: the container's CPU quota / GPUs)")
     ap.add_argument("--in-flight", type=int, default=2, help="batches the pipeline keeps in flight on the device")
-    ap.add_argument("--device-output-steps", type=int, default=6, help="steps of the `device_output` section (pixels left in HBM)")
+    ap.add_argument("--device-output-steps", type=int, default=4, help="steps of the `device_output` section (pixels left in HBM)")
+    ap.add_argument("--device-output-batch", type=int, default=512, help="frames per step and per entropy launch of the `device_output` section")
+    ap.add_argument("--device-output-lf", choices=["auto", "device", "host"], default="device")
     ap.add_argument("--host-buffers", type=int, default=0, help="pinned landing buffers for the pixels (default: one per distinct stream, at most 64; 24 per rank with several ranks)")
     ap.add_argument("--lf-streams", choices=["auto", "device", "host"], default="device",
                     help="who decodes the LfGroup streams of the batched frames: the GPU (k_lf_lanes, a lane per section), the host worker threads, or decided frame by frame (auto: the GPU up to its stage's capacity, the host threads beyond)")
@@ -267,22 +269,37 @@ def main():
     for t in tickets:
         assert pipe.result(t) == "", "decode error: " + pipe.result(t)
     first_pixels = host_outs[0].clone()
-    # ---- the same steps with the pixels left in HBM (what rounds 2 and 3 reported as `value`) ----
+    # ---- the same path with the pixels left in HBM (what rounds 2 and 3 reported as `value`): the device's own pace. Its own
+    # pipeline: without the copies nothing holds a batch's memory back, so the entropy launch takes 512 frames -- more sections
+    # than the machine has lanes, handed out through per-frame queues (k_hf_lanes) -- and the LfGroup streams stay on the GPU.
     device_output = None
     if not args.skip_sections or world > 1:
-        outs = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(B)]
-        run_pipeline_steps(pipe, step_bufs, step_sizes, outs, W * 4, True, 1, torch, dev, None)
-        e_dev, tk = run_pipeline_steps(pipe, step_bufs, step_sizes, outs, W * 4, True, max(1, args.device_output_steps), torch, dev, dist)
-        sd = pipe.stats()
-        assert all(pipe.result(t) == "" for t in tk)
+        pipe.close()
+        torch.cuda.empty_cache()
+        Bd = max(1, args.device_output_batch)
+        nd = min(Bd, 256)   # device images, shared by frames i and i + 256 k: the same stream (64 distinct ones), hence the same pixels
+        outs = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(nd)]
+        dbufs = [bufs[i % D] for i in range(Bd)]; dsizes = [len(datas[i % D]) for i in range(Bd)]; douts = [outs[i % nd] for i in range(Bd)]
+        dpipe = j40_amd.Pipeline(local_rank, threads, Bd, args.in_flight, lf_streams=args.device_output_lf)
+        run_pipeline_steps(dpipe, dbufs, dsizes, douts, W * 4, True, 1, torch, dev, None)
+        dsteps = max(1, args.device_output_steps)
+        e_dev, tk = run_pipeline_steps(dpipe, dbufs, dsizes, douts, W * 4, True, dsteps, torch, dev, dist)
+        sd = dpipe.stats()
+        assert all(dpipe.result(t) == "" for t in tk)
         assert torch.equal(outs[0].cpu(), first_pixels)
+        dpipe.close()
         dl = max(sd["launches"], 1)
-        device_output = {"value": round(W * H * B * max(1, args.device_output_steps) * world / e_dev / 1e6, 2), "unit": "Mpixels/s", "frames_per_step": B, "steps": max(1, args.device_output_steps),
-                         "ms_per_step": round(e_dev / max(1, args.device_output_steps) * 1e3, 3),
-                         "k_hf_lanes_ms_per_launch": round((sd["k1_kernel_ms"] / dl) or (sd["k1_ms"] / dl), 3), "pixel_kernels_ms_per_launch": round(sd["k2_ms"] / dl, 3),
-                         "lf_streams_plan_tail_ms_per_launch": round(sd["lf_plan_ms"] / dl, 3),
-                         "note": "as `value`, but the RGBA stays in device memory (no copy back): the device is the bound here, PCIe is for `value`"}
-        del outs
+        k1d = (sd["k1_kernel_ms"] / dl) or (sd["k1_ms"] / dl)
+        fpl = sd["launch_frames"] / dl
+        alg_d = sum(4 * W * H + s for s in dsizes) / Bd   # per frame
+        device_output = {"value": round(W * H * Bd * dsteps * world / e_dev / 1e6, 2), "unit": "Mpixels/s", "frames_per_step": Bd, "steps": dsteps,
+                         "ms_per_step": round(e_dev / dsteps * 1e3, 3), "ms_per_256_frames": round(e_dev / dsteps * 1e3 * 256 / Bd, 3), "frames_per_launch": round(fpl, 1), "lf_streams": args.device_output_lf,
+                         "k_hf_lanes_ms_per_launch": round(k1d, 3), "k_hf_lanes_roofline_frac": round(alg_d * fpl / (k1d / 1e3) / 8e12, 6) if k1d > 0 else None,
+                         "pixel_kernels_ms_per_launch": round(sd["k2_ms"] / dl, 3), "lf_streams_plan_tail_ms_per_launch": round(sd["lf_plan_ms"] / dl, 3),
+                         "roofline_frac_step": round(alg_d * Bd / (e_dev / dsteps) / 8e12, 6),
+                         "note": "as `value`, but the RGBA stays in device memory (no copy back): the device is the bound here, PCIe is for `value`. %d frames per entropy launch: "
+                                 "more sections than the machine has lanes, so every frame's lanes take its sections from a queue, largest first (k_hf_lanes, queued form)" % Bd}
+        del outs, douts
         torch.cuda.empty_cache()
     resident_multi = None
     if world > 1 and not args.skip_sections:
@@ -358,7 +375,6 @@ def main():
                              "the per-launch figures are HIP-event times on the batch's stream and overlap with other batches' stages"},
     }
     if device_output is not None:
-        device_output["roofline_frac_step"] = round(alg_step / (device_output["ms_per_step"] / 1e3) / 8e12, 6)
         result["device_output"] = device_output
     result["pcie"] = {"bytes_back_per_step": 4 * W * H * B, "achieved_gb_per_s": round(4 * W * H * frames_total / world / elapsed / 1e9, 2),
                       "note": "RGBA copied back per GPU during the timed region / wall time; a Gen5 x16 link moved 57 GB/s device-to-host on these boxes (tools/pcie_probe.py): 14.2 Gpx/s is the ceiling of `value` per GPU"}

@@ -505,8 +505,34 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 	// (a workgroup stays on one frame: with frames of a wavefront or two -- 1920 x 1080 is 40 sections -- larger workgroups would be padding)
 	while (waves_per_wg > 1 && waves_per_wg / 2 >= max_frame_waves) waves_per_wg /= 2;
 	if (const char *e = getenv("J40HIP_WAVES_PER_WG")) if (lanes_fast) waves_per_wg = std::max(1, std::min(lanes_lds + 8u * HF_LANE_COLS_BYTES > 150u * 1024u ? 4 : 8, atoi(e)));
+	// More sections than the machine has lanes for (2048 wavefronts: eight per compute unit is what the tables' LDS leaves room
+	// for): the QUEUED form -- every frame gets one workgroup of `queue_waves` wavefronts, whose lanes take the frame's sections by
+	// decreasing size, first one each, then from a counter as they finish (k_hf_lanes) -- keeps every lane busy until its frame runs
+	// out of sections; one section per lane would run in rounds, each as long as its longest section. Single-pass frames only.
+	// J40HIP_K1_QUEUE_WAVES: 0 never, n > 0 always with n wavefronts per frame (tests), unset: decided here.
+	int32_t queue_waves = 0;
+	{
+		static const int forced = [] { const char *e = getenv("J40HIP_K1_QUEUE_WAVES"); return e ? atoi(e) : -1; }();
+		bool single_pass = true;
+		for (int i = 0; i < n; ++i) single_pass = single_pass && frames[i]->num_passes == 1 && frames[i]->sparse;
+		const int32_t capacity = 8 * b->cus;
+		if (lanes_fast && single_pass && forced != 0 && (forced > 0 || total_waves > capacity)) {
+			int32_t want = forced > 0 ? forced : std::max<int32_t>(1, (int32_t) ((int64_t) max_frame_waves * capacity / total_waves));
+			want = std::min(want, std::min<int32_t>(8, max_frame_waves));
+			while (want > 1 && lanes_lds + (uint32_t) want * HF_LANE_COLS_BYTES > 80u * 1024u && lanes_lds + 8u * HF_LANE_COLS_BYTES <= 150u * 1024u) --want;   // two workgroups per compute unit
+			queue_waves = 1;
+			while (queue_waves * 2 <= want) queue_waves *= 2;
+			waves_per_wg = queue_waves;
+		}
+	}
 	std::vector<HfLaneWork> work;
+	std::vector<uint32_t> queue_start;
 	for (int i = 0; i < n; ++i) {
+		if (queue_waves) {
+			for (int32_t k = 0; k < queue_waves; ++k) work.push_back({i, 64 * k, std::max(0, std::min(64, frames[i]->num_groups - 64 * k)), 1});
+			queue_start.push_back((uint32_t) std::min(frames[i]->num_groups, 64 * queue_waves));
+			continue;
+		}
 		const size_t first_entry = work.size();
 		for (int32_t g = 0; g < frames[i]->num_groups; g += 64) work.push_back({i, g, std::min(64, frames[i]->num_groups - g), 0});
 		while (work.size() % (size_t) waves_per_wg) work.push_back({i, 0, 0, 0});   // a workgroup stays on one frame
@@ -514,13 +540,15 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 		// first. A workgroup's wavefront w runs on SIMD w % 4: the second half of every workgroup is reversed, which puts the
 		// longest beside the shortest, the second longest beside the second shortest ... -- four SIMDs with about equal work
 		for (size_t a = first_entry; a + (size_t) waves_per_wg <= work.size(); a += (size_t) waves_per_wg) std::reverse(work.begin() + (long) (a + (size_t) waves_per_wg / 2), work.begin() + (long) (a + (size_t) waves_per_wg));
+	}
+	for (int i = 0; i < n; ++i) {
 		HfLaunchInfo info = frames[i]->hf; info.tables_fit_lds = tables_in_lds;
 		generic_lds = std::max(generic_lds, hf_lanes_lds_bytes(info));
 	}
 	// ---- the batch's arrays: one staged blob, one copy ----
 	Layout L;
 	const size_t o_plans = L.take(sizeof(DevPlan) * (size_t) n), o_builds = L.take(sizeof(DevPlanBuild) * (size_t) n), o_k2 = L.take(sizeof(K2Frame) * (size_t) n);
-	const size_t o_lfs = L.take(sizeof(DevBatchLf) * (size_t) nlf), o_work = L.take(sizeof(HfLaneWork) * work.size());
+	const size_t o_lfs = L.take(sizeof(DevBatchLf) * (size_t) nlf), o_work = L.take(sizeof(HfLaneWork) * work.size()), o_queue = L.take(4 * (size_t) n);
 	const size_t copy_bytes = L.size;
 	const size_t o_tiles = L.take(4 * (size_t) K2_NUM_BATCH_LAUNCHES * ((size_t) n + 1)), o_verdict = L.take(16 * (size_t) n + 64);   // (verdicts, then the tile totals)
 	if (!b->host.reserve(copy_bytes + 64, 0)) return ERR_MEM;
@@ -554,6 +582,7 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 		for (int32_t g = 0; g < f->num_lf_groups; ++g) h_lfs[at_lf++] = DevBatchLf{i, g};
 	}
 	memcpy(hb + o_work, work.data(), sizeof(HfLaneWork) * work.size());
+	if (queue_waves) memcpy(hb + o_queue, queue_start.data(), 4 * queue_start.size());
 	if (uint32_t e = wait_for_uploads(frames, n, s)) return e;
 	const double tq1 = prof_now();
 	if (hipMemcpyAsync(db, hb, copy_bytes, hipMemcpyHostToDevice, s) != hipSuccess) return ERR_GPU;
@@ -567,7 +596,7 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 	(void) hipEventRecord(b->ev[1], s);
 	const double tq3 = prof_now();
 	b->k1_timed = lanes_fast;
-	if (lanes_fast) launch_hf_lanes(d_plans, d_work, (int32_t) work.size(), waves_per_wg, lanes_lds, s, b->k1_ev[0], b->k1_ev[1]);
+	if (lanes_fast) launch_hf_lanes(d_plans, d_work, (int32_t) work.size(), waves_per_wg, lanes_lds, s, b->k1_ev[0], b->k1_ev[1], queue_waves ? (uint32_t *) (db + o_queue) : nullptr);
 	else launch_hf_entropy_lanes(d_plans, d_work, (int32_t) work.size(), tables_in_lds, generic_lds, s);
 	(void) hipEventRecord(b->ev[2], s);
 	int32_t grids[K2_NUM_BATCH_LAUNCHES];

@@ -147,34 +147,77 @@ J40_DEV void lane_store_block_events(const LaneGlobals &G, uint32_t blk, uint32_
 	e[0] = (uint64_t) first | ((uint64_t) n0 << 32); e[1] = (uint64_t) n1 | ((uint64_t) n2 << 32);
 }
 
-// decodes one (pass, group) section; same results and status codes as decode_hf_section (hf_dev.h).
-// cols[(c * 32 + x) * col_stride]: non-zero count (per 8x8 cell) of the last block written into cell column x, channel c
-template <bool SCAN>
-J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t, const LaneGlobals &G, const DevSection &sec, uint32_t cell_base,
-		uint32_t block_first, int32_t nblocks, uint32_t ev_first, uint32_t ev_end, J40_LDS int8_t *cols, int32_t col_stride, int32_t pass, J40_GLOBAL uint32_t *end_bit_out = nullptr) {
-	const uint32_t start_bit = 8u * sec.byte_off + sec.bit_off, end_bit = 8u * (sec.byte_off + sec.size);
+// what the decoder needs to start on a section
+struct LaneSection {
+	uint32_t start_bit, end_bit;       // the section's bits in the codestream
+	uint32_t cell_base;                // of its LfGroup
+	uint32_t block_first; int32_t nblocks;   // its group's block list
+	uint32_t ev_first, ev_end;         // its region of the event list (sparse coefficients)
+};
+
+// Decodes the sections `src` hands out, one after the other, on this lane; each section's status goes back through src.done.
+// `Source`: bool next(LaneSection &) -- false: nothing left for this lane --, void done(uint32_t status, uint32_t end_bit).
+// A lane that finishes a section takes the next one INSIDE the symbol loop, so the other lanes of its wavefront never wait for it:
+// with more sections than lanes (sections handed out by decreasing size through a counter the lanes of a frame share, kernels.hip:
+// k_hf_lanes) a wavefront's lanes stay busy until the frame runs out of sections, instead of idling behind its longest one.
+// Same results and status codes per section as decode_hf_section (hf_dev.h).
+// cols[(c * 32 + x) * col_stride]: non-zero count (per 8x8 cell) of the last block written into cell column x, channel c. It needs
+// no reset between sections: a block reads only columns a block of its own section wrote before it (blocks tile the group in
+// raster order of their top-left cells).
+template <bool SCAN, class Source>
+J40_DEV void decode_hf_sections_lane(const LaneFrame &f, const LaneTables &t, const LaneGlobals &G, Source &src, J40_LDS int8_t *cols, int32_t col_stride, int32_t pass) {
+	LaneSection S;
+	S.start_bit = S.end_bit = S.cell_base = S.block_first = S.ev_first = S.ev_end = 0; S.nblocks = 0;
 	LaneBits b;
-	lane_bits_init(b, G.codestream, start_bit);
-	lane_bits_refill(b);
-	uint32_t err = 0;
-	const uint32_t preset = lane_bits_take(b, f.preset_bits);
-	if (lane_bit_position(b) > end_bit) err = ERR_SHRT;
-	else if ((int32_t) preset >= f.num_hf_presets) err = ERR_RNGE;
+	b.base = G.codestream; b.bits = 0; b.nbits = 0; b.pos = 0; b.ahead = 0;
 	const int32_t nb_block_ctx = f.nb_block_ctx;
-	const int32_t ctxoff = 495 * nb_block_ctx * (int32_t) preset;
-	const uint32_t cell64 = cell_base * 64u;
+	uint32_t err = 0, end_bit = 0, cell64 = 0, block_first = 0;
+	int32_t nblocks = 0, ctxoff = 0;
+	bool have = false;   // a section is being decoded
 	int32_t k = 0, c_yxb = 0;
-	bool in_coeffs = false, done = nblocks == 0 || err != 0;
+	bool in_coeffs = false, done = true;
 	uint32_t state = 0;
 	int32_t x8 = 0, y8 = 0, log_columns = 3, order_idx = 0, shift = 0, size = 64;
 	uint32_t coeffoff = 0, coeff_at = 0, bctx3 = 0;
 	int32_t c = 1, bctx = 0, nz = 0, i = 0, prev = 0, cctx = 0;
 	const J40_GLOBAL uint16_t *order = nullptr;
-	uint32_t ev_at = ev_first, chan_first = ev_first;   // SCAN: next free event of this section's region, first event of the current channel
-	uint32_t blk_first = ev_first, blk_n0 = 0, blk_n1 = 0;   // the block's table entry, stored in one piece after its third channel
+	uint32_t ev_at = 0, ev_end = 0, chan_first = 0;   // SCAN: next free event of this section's region, first event of the current channel
+	uint32_t blk_first = 0, blk_n0 = 0, blk_n1 = 0;   // the block's table entry, stored in one piece after its third channel
 	uint32_t next0 = 0, next1 = 0;   // descriptor of block k, requested one block ahead
-	if (!done) { const J40_GLOBAL uint32_t *p = G.group_blocks + 2u * block_first; next0 = p[0]; next1 = p[1]; }
-	for (uint32_t turn = 0; !done; ++turn) {
+	for (uint32_t turn = 0; ; ++turn) {
+		if (done) {   // (rare: twice per section)
+			if (have) {
+				// ---- the section's end ----
+				if (SCAN && !err && nblocks > 0) lane_store_block_events(G, block_first + (uint32_t) nblocks - 1u, blk_first, blk_n0, blk_n1, ev_at - chan_first);   // the last block
+				if (!err) {   // j40.h:2884-2893: the final state, or the untouched initial state, must be 0x130000
+					if (state == 0) { lane_bits_refill(b); state = lane_bits_take(b, 16); state |= lane_bits_take(b, 16) << 16; if (lane_bit_position(b) > end_bit) err = ERR_SHRT; }
+					if (!err && state != 0x130000) err = ERR_ANS;
+				}
+				if (!err && f.check_section_end) {   // single-section frames: zero padding up to the byte boundary, then no byte of the section left (j40.h:8203, 7796)
+					const uint32_t at = lane_bit_position(b), padn = (0u - at) & 7u;
+					if (padn > (uint32_t) b.nbits) lane_bits_refill(b);
+					if (lane_bits_take(b, (int32_t) padn)) err = ERR_PAD0;
+					else if (at + padn != 8u * f.single_declared_end) err = at + padn < 8u * f.single_declared_end ? (uint32_t) ERR_SHRT : (uint32_t) ERR_EXCS;
+				}
+				src.done(err, lane_bit_position(b));   // (the position: frames with extra channels, their Modular sub-image starts there -- validate_trailers, runtime.hip)
+			}
+			have = src.next(S);
+			if (!have) break;
+			// ---- the section's start ----
+			end_bit = S.end_bit; cell64 = S.cell_base * 64u; block_first = S.block_first; nblocks = S.nblocks;
+			lane_bits_init(b, G.codestream, S.start_bit);
+			lane_bits_refill(b);
+			err = 0;
+			const uint32_t preset = lane_bits_take(b, f.preset_bits);
+			if (lane_bit_position(b) > end_bit) err = ERR_SHRT;
+			else if ((int32_t) preset >= f.num_hf_presets) err = ERR_RNGE;
+			ctxoff = 495 * nb_block_ctx * (int32_t) preset;
+			k = 0; c_yxb = 0; in_coeffs = false; state = 0;
+			ev_at = chan_first = blk_first = S.ev_first; ev_end = S.ev_end; blk_n0 = blk_n1 = 0;
+			done = nblocks == 0 || err != 0;
+			if (done) continue;   // (nothing to decode: its end is the next turn's business)
+			{ const J40_GLOBAL uint32_t *p = G.group_blocks + 2u * block_first; next0 = p[0]; next1 = p[1]; }
+		}
 		// Block starts are rare (3 per block against dozens of coefficient symbols) but with 64 lanes some lane starts a block in
 		// nearly every iteration, and then the whole wavefront walks the block-start code. It is therefore only executed every
 		// NZ_PERIOD-th iteration: a lane that reaches a block start in between sits out until then (J40_LANE_NZ_PERIOD = 1: never)
@@ -249,19 +292,26 @@ J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t,
 		err = e2 ? e2 : err;
 		done = e2 != 0 || (next_block && k >= nblocks);
 	}
-	if (SCAN && !err && nblocks > 0) lane_store_block_events(G, block_first + (uint32_t) nblocks - 1u, blk_first, blk_n0, blk_n1, ev_at - chan_first);   // the last block
-	if (!err) {   // j40.h:2884-2893: the final state, or the untouched initial state, must be 0x130000
-		if (state == 0) { lane_bits_refill(b); state = lane_bits_take(b, 16); state |= lane_bits_take(b, 16) << 16; if (lane_bit_position(b) > end_bit) err = ERR_SHRT; }
-		if (!err && state != 0x130000) err = ERR_ANS;
-	}
-	if (!err && f.check_section_end) {   // single-section frames: zero padding up to the byte boundary, then no byte of the section left (j40.h:8203, 7796)
-		const uint32_t at = lane_bit_position(b), padn = (0u - at) & 7u;
-		if (padn > (uint32_t) b.nbits) lane_bits_refill(b);
-		if (lane_bits_take(b, (int32_t) padn)) err = ERR_PAD0;
-		else if (at + padn != 8u * f.single_declared_end) err = at + padn < 8u * f.single_declared_end ? (uint32_t) ERR_SHRT : (uint32_t) ERR_EXCS;
-	}
-	if (end_bit_out) *end_bit_out = lane_bit_position(b);   // frames with extra channels: their Modular sub-image starts here (validate_trailers, runtime.hip)
-	return err;
+}
+
+// one section, handed over by the caller (the CPU build of tests/hostsim; frames of one wavefront's worth)
+struct LaneOneSection {
+	LaneSection S; bool taken; uint32_t status, end_bit;
+	J40_DEVM bool next(LaneSection &out) { if (taken) return false; taken = true; out = S; return true; }
+	J40_DEVM void done(uint32_t st, uint32_t eb) { status = st; end_bit = eb; }
+};
+
+// decodes one (pass, group) section; same results and status codes as decode_hf_section (hf_dev.h).
+template <bool SCAN>
+J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t, const LaneGlobals &G, const DevSection &sec, uint32_t cell_base,
+		uint32_t block_first, int32_t nblocks, uint32_t ev_first, uint32_t ev_end, J40_LDS int8_t *cols, int32_t col_stride, int32_t pass, J40_GLOBAL uint32_t *end_bit_out = nullptr) {
+	LaneOneSection src;
+	src.S.start_bit = 8u * sec.byte_off + sec.bit_off; src.S.end_bit = 8u * (sec.byte_off + sec.size);
+	src.S.cell_base = cell_base; src.S.block_first = block_first; src.S.nblocks = nblocks; src.S.ev_first = ev_first; src.S.ev_end = ev_end;
+	src.taken = false; src.status = 0; src.end_bit = 0;
+	decode_hf_sections_lane<SCAN>(f, t, G, src, cols, col_stride, pass);
+	if (end_bit_out) *end_bit_out = src.end_bit;
+	return src.status;
 }
 
 } // namespace j40hip

@@ -9,7 +9,7 @@ void upload_constant_tables(const float *half_secants, const float *afv_basis, c
 void launch_hf_entropy(const DevPlan &plan, const HfLaunchInfo &info, int32_t first_group, int32_t num_groups, hipStream_t stream);
 uint32_t hf_lanes_lds_bytes(const HfLaunchInfo &info);
 void launch_hf_entropy_lanes(const DevPlan *plans, const HfLaneWork *work, int32_t num_work, bool tables_in_lds, uint32_t lds_bytes, hipStream_t stream);
-void launch_hf_lanes(const DevPlan *plans, const HfLaneWork *work, int32_t num_work, int32_t waves_per_wg, uint32_t lds_bytes, hipStream_t stream, hipEvent_t started = nullptr, hipEvent_t stopped = nullptr);
+void launch_hf_lanes(const DevPlan *plans, const HfLaneWork *work, int32_t num_work, int32_t waves_per_wg, uint32_t lds_bytes, hipStream_t stream, hipEvent_t started = nullptr, hipEvent_t stopped = nullptr, uint32_t *queue = nullptr);
 void launch_vardct_class(const DevPlan &plan, int32_t dctsel, const DevVarblock *list, int32_t count, float *large_scratch, uint8_t *rgba, size_t stride, hipStream_t stream);
 
 

@@ -218,9 +218,37 @@ template <typename T> __device__ __forceinline__ T load_global_pod(const J40_GLO
 }
 
 // K1, throughput form, fast path (hf_lanes_dev.h): rANS specs without LZ77 whose packed tables fit in LDS.
-// Same launch geometry as k_hf_entropy_lanes: one wavefront per workgroup, up to 64 groups of one frame per
-// wavefront, any number of frames per launch.
-__global__ void __launch_bounds__(512) k_hf_lanes(const DevPlan *plans, const HfLaneWork *work, uint32_t lds_tables_bytes) {
+// One section per wavefront LANE, blockDim.x / 64 wavefronts per workgroup sharing one copy of their frame's tables, any number of
+// frames per launch. Two ways the lanes get their sections (HfLaneWork::pad):
+//   0  static: lane l of the wavefront takes slot first_group + l of its frame's lane order, and is done with it;
+//   1  queued: the same to begin with, and a lane that has finished a section takes the frame's next slot from a counter all the
+//      frame's lanes share (`queue[frame]`, which the host starts at the number of lanes the frame was given) -- for launches with
+//      more sections than the machine has lanes: the sections go out by decreasing size, so the lanes of a frame end together.
+// what hands a lane its sections (hf_lanes_dev.h: decode_hf_sections_lane)
+struct LaneQueue {
+	const J40_GLOBAL DevSection *sections; const J40_GLOBAL DevLfGroup *lf_groups; const J40_GLOBAL uint32_t *block_start, *ev_range, *lane_order;
+	J40_GLOBAL uint32_t *status, *end_bits, *counter;
+	int32_t num_groups, pass, slot, g; bool scan;
+	__device__ __forceinline__ bool next(LaneSection &S) {
+		int32_t s = slot;
+		slot = -1;
+		if (s < 0) { if (!counter) return false; s = (int32_t) atomicAdd((uint32_t *) counter, 1u); }
+		if (s >= num_groups) return false;
+		g = lane_order ? (int32_t) lane_order[s] : s;
+		const DevSection sec = load_global_pod(sections + (pass * num_groups + g));
+		S.start_bit = 8u * sec.byte_off + sec.bit_off; S.end_bit = 8u * (sec.byte_off + sec.size);
+		S.cell_base = (uint32_t) lf_groups[sec.ggidx].cell_base;
+		S.block_first = block_start[g]; S.nblocks = (int32_t) (block_start[g + 1] - S.block_first);
+		S.ev_first = scan ? ev_range[2 * g] : 0u; S.ev_end = scan ? ev_range[2 * g + 1] : 0u;
+		return true;
+	}
+	__device__ __forceinline__ void done(uint32_t st, uint32_t end_bit) {
+		status[pass * num_groups + g] = st;
+		if (end_bits) end_bits[pass * num_groups + g] = end_bit;
+	}
+};
+
+__global__ void __launch_bounds__(512) k_hf_lanes(const DevPlan *plans, const HfLaneWork *work, uint32_t lds_tables_bytes, uint32_t *queue) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t hf_lds[];
 	// The launch ends with its slowest wavefront, and a wavefront runs as fast as its SIMD issues its instructions: a background
 	// wavefront on the same SIMD (the LfGroup lane decoder of a later batch) took a third of them (46 -> 75 ms). Highest priority here.
@@ -231,8 +259,6 @@ __global__ void __launch_bounds__(512) k_hf_lanes(const DevPlan *plans, const Hf
 	const J40_GLOBAL DevPlan &plan = ((const J40_GLOBAL DevPlan *) plans)[w.frame];
 	const J40_GLOBAL DevFrame &df = *(const J40_GLOBAL DevFrame *) plan.frame;
 	const bool active = lane < w.num_groups;
-	const J40_GLOBAL uint32_t *lane_order = (const J40_GLOBAL uint32_t *) plan.lane_order;
-	const int32_t slot = w.first_group + (active ? lane : 0), g = lane_order ? (int32_t) lane_order[slot] : slot;
 	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
 	LaneFrame f;
 	f.nb_block_ctx = df.nb_block_ctx; f.num_hf_presets = df.num_hf_presets; f.preset_bits = df.preset_bits; f.check_section_end = df.check_section_end; f.single_declared_end = df.single_declared_end;
@@ -243,7 +269,6 @@ __global__ void __launch_bounds__(512) k_hf_lanes(const DevPlan *plans, const Hf
 	G.group_blocks = (const J40_GLOBAL uint32_t *) plan.group_blocks;
 	G.coeffs = (J40_GLOBAL float *) plan.coeffs[0];
 	G.events = (J40_GLOBAL CoeffEvent *) plan.events; G.block_events = (J40_GLOBAL uint32_t *) plan.block_events;
-	const J40_GLOBAL uint32_t *ev_range = (const J40_GLOBAL uint32_t *) plan.ev_range;
 	G.pool_u16 = (const J40_GLOBAL uint16_t *) plan.pool_u16;
 	G.coeff_stride = plan.coeff_stride;
 	const J40_GLOBAL uint8_t *pool_u8 = (const J40_GLOBAL uint8_t *) plan.pool_u8;
@@ -251,11 +276,14 @@ __global__ void __launch_bounds__(512) k_hf_lanes(const DevPlan *plans, const Hf
 	const J40_GLOBAL uint64_t *pool_u64 = (const J40_GLOBAL uint64_t *) plan.pool_u64;
 	const J40_GLOBAL DevCodeSpec *specs = (const J40_GLOBAL DevCodeSpec *) plan.coeff_specs;
 	const J40_GLOBAL DevCluster *clusters = (const J40_GLOBAL DevCluster *) plan.clusters;
-	const J40_GLOBAL DevSection *sections = (const J40_GLOBAL DevSection *) plan.sections;
-	const J40_GLOBAL DevLfGroup *lf_groups = (const J40_GLOBAL DevLfGroup *) plan.lf_groups;
-	const J40_GLOBAL uint32_t *block_start = (const J40_GLOBAL uint32_t *) plan.group_block_start;
-	J40_GLOBAL uint32_t *status = (J40_GLOBAL uint32_t *) plan.status;
-	J40_GLOBAL uint32_t *end_bits = df.sections_have_trailer ? (J40_GLOBAL uint32_t *) plan.section_end_bit : nullptr;
+	LaneQueue q;
+	q.sections = (const J40_GLOBAL DevSection *) plan.sections; q.lf_groups = (const J40_GLOBAL DevLfGroup *) plan.lf_groups;
+	q.block_start = (const J40_GLOBAL uint32_t *) plan.group_block_start; q.ev_range = (const J40_GLOBAL uint32_t *) plan.ev_range;
+	q.lane_order = (const J40_GLOBAL uint32_t *) plan.lane_order;
+	q.status = (J40_GLOBAL uint32_t *) plan.status; q.end_bits = df.sections_have_trailer ? (J40_GLOBAL uint32_t *) plan.section_end_bit : nullptr;
+	// (queued lanes only in single-pass frames: the passes of a group accumulate into the same coefficients, one after the other on one lane)
+	q.counter = w.pad && queue && num_passes == 1 ? (J40_GLOBAL uint32_t *) queue + w.frame : nullptr;
+	q.num_groups = num_groups; q.scan = scan != 0; q.g = 0;
 
 	J40_LDS uint8_t *lds = (J40_LDS uint8_t *) hf_lds;
 	J40_LDS int16_t *l_nnz = (J40_LDS int16_t *) lds;
@@ -268,8 +296,6 @@ __global__ void __launch_bounds__(512) k_hf_lanes(const DevPlan *plans, const Hf
 	t.nnz_ctx2 = l_nnz; t.freq_ctx2 = l_freq; t.dct_info = l_dct;
 	// per-wave column predictor state behind the tables: [3][32][64 lanes] bytes
 	J40_LDS int8_t *l_cols = (J40_LDS int8_t *) (lds + lds_tables_bytes + (uint32_t) (tid >> 6) * HF_LANE_COLS_BYTES) + lane;
-	const uint32_t block_first = block_start[g];
-	const int32_t nblocks = (int32_t) (block_start[g + 1] - block_first);
 	for (int32_t pass = 0; pass < num_passes; ++pass) {
 		const J40_GLOBAL DevCodeSpec &spec = specs[pass];
 		__syncthreads();   // previous pass' tables are no longer in use
@@ -288,25 +314,22 @@ __global__ void __launch_bounds__(512) k_hf_lanes(const DevPlan *plans, const Hf
 		}
 		t.ctx_map = l_map; t.cluster_cfg = l_cfg; t.alias = l_alias; t.log_alpha = log_alpha; t.log_bucket = 12 - log_alpha;
 		__syncthreads();
-		if (active) {
-			const DevSection sec = load_global_pod(sections + (pass * num_groups + g));
-			const uint32_t cell_base = (uint32_t) lf_groups[sec.ggidx].cell_base;
-			status[pass * num_groups + g] = scan ? decode_hf_section_lane<true>(f, t, G, sec, cell_base, block_first, nblocks, ev_range[2 * g], ev_range[2 * g + 1], l_cols, 64, pass, end_bits ? end_bits + (pass * num_groups + g) : nullptr)
-			                                     : decode_hf_section_lane<false>(f, t, G, sec, cell_base, block_first, nblocks, 0, 0, l_cols, 64, pass, end_bits ? end_bits + (pass * num_groups + g) : nullptr);
-		}
+		q.pass = pass; q.slot = active ? w.first_group + lane : -1;
+		if (scan) decode_hf_sections_lane<true>(f, t, G, q, l_cols, 64, pass);
+		else decode_hf_sections_lane<false>(f, t, G, q, l_cols, 64, pass);
 	}
 }
 
-// num_work must be a multiple of waves_per_wg, each aligned run of waves_per_wg entries on one frame
-void launch_hf_lanes(const DevPlan *plans, const HfLaneWork *work, int32_t num_work, int32_t waves_per_wg, uint32_t lds_bytes, hipStream_t stream, hipEvent_t started, hipEvent_t stopped) {
+// `queue`: one counter per frame of the batch for the queued form (HfLaneWork::pad), or null
+void launch_hf_lanes(const DevPlan *plans, const HfLaneWork *work, int32_t num_work, int32_t waves_per_wg, uint32_t lds_bytes, hipStream_t stream, hipEvent_t started, hipEvent_t stopped, uint32_t *queue) {
 	if (num_work <= 0) return;
 	static bool configured = false;
 	if (!configured) { (void) hipFuncSetAttribute((const void *) k_hf_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); configured = true; }
 	const uint32_t tables = (lds_bytes + 15u) & ~15u;
 	// (started / stopped: events the device records when the kernel's first wavefront starts and its last one ends -- the kernel's own
 	// duration, as rocprofv3 reports it, without the time the launch waited in its queue)
-	if (started && stopped) hipExtLaunchKernelGGL(k_hf_lanes, dim3((unsigned) (num_work / waves_per_wg)), dim3(64u * (unsigned) waves_per_wg), tables + (uint32_t) waves_per_wg * HF_LANE_COLS_BYTES, stream, started, stopped, 0, plans, work, tables);
-	else hipLaunchKernelGGL(k_hf_lanes, dim3((unsigned) (num_work / waves_per_wg)), dim3(64u * (unsigned) waves_per_wg), tables + (uint32_t) waves_per_wg * HF_LANE_COLS_BYTES, stream, plans, work, tables);
+	if (started && stopped) hipExtLaunchKernelGGL(k_hf_lanes, dim3((unsigned) (num_work / waves_per_wg)), dim3(64u * (unsigned) waves_per_wg), tables + (uint32_t) waves_per_wg * HF_LANE_COLS_BYTES, stream, started, stopped, 0, plans, work, tables, queue);
+	else hipLaunchKernelGGL(k_hf_lanes, dim3((unsigned) (num_work / waves_per_wg)), dim3(64u * (unsigned) waves_per_wg), tables + (uint32_t) waves_per_wg * HF_LANE_COLS_BYTES, stream, plans, work, tables, queue);
 }
 
 // LDS bytes k_hf_entropy_lanes needs for one frame

@@ -535,7 +535,8 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 		if (flags & 4u) { (void) mallopt(M_MMAP_THRESHOLD, 1 << 30); (void) mallopt(M_TRIM_THRESHOLD, (int) (((size_t) 1 << 31) - 1)); (void) mallopt(M_TOP_PAD, 64 << 20); }
 		p->batch_frames = batch_frames < 1 ? 32 : batch_frames;
 		p->max_in_flight = max_in_flight < 1 ? 2 : max_in_flight > 8 ? 8 : max_in_flight;
-		p->lf_cap = p->lf_mode == 2 ? 0 : (int64_t) p->batch_frames * 8;   // (a frame in this stage holds about 11 MB of device memory)
+		// (a frame in this stage holds about 12 MB of device memory; eight batches' worth, at most 2048 frames or two batches')
+		p->lf_cap = p->lf_mode == 2 ? 0 : std::min<int64_t>((int64_t) p->batch_frames * 8, std::max<int64_t>(2048, (int64_t) p->batch_frames * 2));
 		if (const char *e = getenv("J40HIP_LF_CAP")) p->lf_cap = atoll(e);
 		p->slots.resize((size_t) p->max_in_flight + 1);
 		for (Slot &s : p->slots) {

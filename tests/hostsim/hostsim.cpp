@@ -9,6 +9,7 @@
 #include "../../j40_amd/csrc/plan_build.hpp"
 #include "../../j40_amd/csrc/tables.hpp"
 #include "../../j40_amd/csrc/device/hf_dev.h"
+#include <algorithm>
 #include "../../j40_amd/csrc/device/hf_lanes_dev.h"
 #include "../../j40_amd/csrc/device/vardct_dev.h"
 #include "../../j40_amd/csrc/device/special8_dev.h"
@@ -272,6 +273,28 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 			t.alias = plan.pool_u64 + plan.clusters[spec.cluster_off].table_off;
 			t.nnz_ctx2 = DEV_NNZ_CTX2; t.freq_ctx2 = DEV_FREQ_CTX2; t.dct_info = dct.data();
 			t.log_alpha = spec.log_alpha_size; t.log_bucket = 12 - spec.log_alpha_size;
+			if (only_entropy & 8) {
+				// bit 3: ONE lane takes every section of the pass, the largest first -- the form in which k_hf_lanes' lanes take a further
+				// section from their frame's queue when they have finished one (decode_hf_sections_lane, column state carried over)
+				struct Queue {
+					const DevPlan &plan; const HostPlan &hp; int32_t pass; std::vector<int32_t> order; size_t at; int32_t cur; std::vector<uint32_t> &status;
+					bool next(LaneSection &S) {
+						if (at >= order.size()) return false;
+						cur = order[at++];
+						const DevSection &sec = plan.sections[pass * hp.frame.num_groups + cur];
+						S.start_bit = 8u * sec.byte_off + sec.bit_off; S.end_bit = 8u * (sec.byte_off + sec.size);
+						S.cell_base = (uint32_t) plan.lf_groups[sec.ggidx].cell_base;
+						S.block_first = plan.group_block_start[cur]; S.nblocks = (int32_t) (plan.group_block_start[cur + 1] - S.block_first);
+						S.ev_first = hp.frame.sparse_coeffs ? hp.ev_range[2 * (size_t) cur] : 0; S.ev_end = hp.frame.sparse_coeffs ? hp.ev_range[2 * (size_t) cur + 1] : 0;
+						return true;
+					}
+					void done(uint32_t st, uint32_t) { status[(size_t) (pass * hp.frame.num_groups + cur)] = st; }
+				} q{plan, hp, pass, {}, 0, 0, status};
+				for (int32_t g = 0; g < df.num_groups; ++g) q.order.push_back(g);
+				std::stable_sort(q.order.begin(), q.order.end(), [&](int32_t a, int32_t b) { return plan.sections[pass * df.num_groups + a].size > plan.sections[pass * df.num_groups + b].size; });
+				if (df.sparse_coeffs) decode_hf_sections_lane<true>(lf, t, G, q, cols.data(), 1, pass);
+				else decode_hf_sections_lane<false>(lf, t, G, q, cols.data(), 1, pass);
+			} else
 			for (int32_t g = 0; g < df.num_groups; ++g) {
 				const DevSection &sec = plan.sections[pass * df.num_groups + g];
 				const uint32_t b0 = plan.group_block_start[g], b1 = plan.group_block_start[g + 1];

@@ -60,6 +60,30 @@ def test_flat_lane_decoder_matches_nested_decoder(sim, name, opts):
         assert err == 0x544F444F
     else:
         assert err == 0 and np.array_equal(a, c)
+        # ... and with ONE lane taking every section of a pass from a queue, the largest first (k_hf_lanes' lanes take a further
+        # section of their frame when they have finished one: decode_hf_sections_lane)
+        q = np.zeros((3, n), np.float32)
+        assert sim.hostsim_decode(buf, len(data), rgba.ctypes.data, q.ctypes.data, 13) == 0
+        assert np.array_equal(a, q)
+
+
+def test_queued_lane_decoder_on_multi_group_frames_and_damage(sim):
+    """decode_hf_sections_lane with many sections per lane: a 1920x1080 picture-encoded frame (40 sections, one lane takes them all),
+    a three-pass frame, and bit flips -- coefficients and the frame's status equal the nested decoder's, section by section"""
+    rng = np.random.default_rng(5)
+    for (w, h, seed, opts) in [(1920, 1080, 34, dict(forward=1)), (1300, 776, 32, dict(passes=3)), (776, 520, 3, dict(maxlog=8, bctx=1, presets=2, orders=1))]:
+        data = synth("vardct", w, h, seed, **opts)
+        n = ((w + 7) // 8) * ((h + 7) // 8) * 64 * 4
+        a = np.zeros((3, n), np.float32); q = np.zeros((3, n), np.float32); rgba = np.zeros((h, w, 4), np.uint8)
+        buf = C.create_string_buffer(data, len(data))
+        assert sim.hostsim_decode(buf, len(data), rgba.ctypes.data, a.ctypes.data, 1) == 0
+        assert sim.hostsim_decode(buf, len(data), rgba.ctypes.data, q.ctypes.data, 13) == 0
+        assert np.array_equal(a, q) and np.abs(a).sum() > 0
+        for trial in range(12):
+            bad = bytearray(data)
+            bad[int(rng.integers(len(bad) // 3, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+            bb = C.create_string_buffer(bytes(bad), len(bad))
+            assert sim.hostsim_decode(bb, len(bad), rgba.ctypes.data, a.ctypes.data, 1) == sim.hostsim_decode(bb, len(bad), rgba.ctypes.data, q.ctypes.data, 13)
 
 
 @pytest.mark.parametrize("name,w,h,opts", MODULAR_CASES)

@@ -3,8 +3,11 @@ and the reference: same pixels, same error codes, whatever mix of images goes in
 import numpy as np
 import pytest
 
+import os
+
 from streams import synth
 
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
@@ -302,3 +305,46 @@ def test_pipeline_forward_encoded_8k_frame_matches_reference(built, ref):
             assert d.max() <= 1, (lf_streams, int(d.max()), int((d > 0).sum()))
         assert pipe.stats()["single_frames"] == 0
         pipe.close()
+
+
+def test_queued_entropy_lanes_give_the_single_frame_pixels(built, ref, tmp_path):
+    """k_hf_lanes' queued form -- a frame's lanes take its sections from a shared counter, largest first, a lane going on to the next
+    section when it has finished one (kernels.hip LaneQueue, hf_lanes_dev.h decode_hf_sections_lane) -- is what launches with more
+    sections than the machine has lanes use (512 8K frames). Forced here with one and two wavefronts per frame (J40HIP_K1_QUEUE_WAVES,
+    read once per process: a child process): 8K, 4K and 1080p frames, a damaged one among them, against the latency path's pixels
+    and codes, and the first against the reference"""
+    import subprocess, sys, os, json
+    script = r'''
+import sys, json, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import j40_amd
+from streams import synth
+from refdec import Ref
+items = [synth("vardct", 7680, 4320, 3, forward=1), synth("vardct", 3840, 2160, 102), synth("vardct", 1920, 1080, 34, forward=1), synth("vardct", 1920, 1080, 7), synth("vardct", 2600, 2100, 32, bctx=1)]
+bad = bytearray(items[0]); bad[len(bad) * 3 // 4] ^= 0x20
+items.append(bytes(bad))
+items = items * 2
+pipe = j40_amd.Pipeline(device=0, host_threads=4, batch_frames=len(items), max_in_flight=1, lf_streams="host")
+outs, tickets = [], []
+for d in items:
+    fr = j40_amd.Frame(d); w, h = fr.width, fr.height; fr.close()
+    o = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0"); outs.append(o)
+    tickets.append(pipe.submit(d, o.data_ptr(), w * 4, device_output=True))
+pipe.drain(); torch.cuda.synchronize()
+res = {"codes": [pipe.result(t) for t in tickets], "launch_frames": pipe.stats()["launch_frames"], "equal": [], "expected": []}
+for d, o, t in zip(items, outs, tickets):
+    err, px = j40_amd.decode(d)
+    res["expected"].append(err)
+    res["equal"].append(bool(err != "" or np.array_equal(o.cpu().numpy(), px)))
+rerr, rpx = Ref().decode(items[0])
+res["ref_max_diff"] = int(np.abs(outs[0].cpu().numpy().astype(np.int16) - rpx.astype(np.int16)).max())
+pipe.close(); j40_amd.shutdown()
+print(json.dumps(res))
+''' % (ROOT_DIR, os.path.join(ROOT_DIR, "tests"))
+    for waves in ("1", "2"):
+        env = dict(os.environ); env["J40HIP_K1_QUEUE_WAVES"] = waves
+        out = subprocess.run([sys.executable, "-c", script], check=True, capture_output=True, text=True, timeout=900, env=env)
+        res = json.loads(out.stdout.strip().splitlines()[-1])
+        assert res["codes"] == res["expected"] and res["codes"][5] != "" and res["codes"][0] == "", res
+        assert all(res["equal"]) and res["ref_max_diff"] <= 1, res
+        assert res["launch_frames"] >= 10, res
