@@ -20,6 +20,7 @@
 #include "idct_dev.h"
 #include "vardct_dev.h"
 #include "special8_dev.h"
+#include "hf_uni_dev.h"
 #include "kernels.h"
 
 namespace j40hip {
@@ -127,6 +128,58 @@ __global__ void __launch_bounds__(64 * HF_WAVES) k_hf_entropy(DevPlan plan, int3
 			const uint32_t err = f.sparse_coeffs ? decode_hf_section<true, true>(plan, f, spec, t, pass, sec) : decode_hf_section<false, true>(plan, f, spec, t, pass, sec);
 			if (lane == 0) plan.status[pass * f.num_groups + g] = err;
 		}
+	}
+}
+
+// K1, latency form, fast path (hf_uni_dev.h): single-pass frames coded with rANS and no LZ77, at most 64 clusters, tables that fit
+// in LDS -- what k_hf_lanes takes in a batch. One section per wavefront like k_hf_entropy, the same packed tables as k_hf_lanes.
+__global__ void __launch_bounds__(64 * HF_WAVES) k_hf_entropy_fast(DevPlan plan, int32_t first_group, int32_t num_groups, uint32_t tables_bytes, uint32_t wave_bytes) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t hf_lds[];
+	const DevFrame &f = *plan.frame;
+	const int32_t tid = threadIdx.x, lane = tid & 63;
+	const int32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int32_t local = blockIdx.x * HF_WAVES + wave;
+	const bool active = local < num_groups;
+	const int32_t g = first_group + local;
+	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+	const DevCodeSpec &spec = plan.coeff_specs[0];
+	const int32_t num_dist = spec.num_dist, num_clusters = spec.num_clusters, log_alpha = spec.log_alpha_size;
+	J40_LDS uint8_t *lds = (J40_LDS uint8_t *) hf_lds;
+	J40_LDS uint8_t *l_map = lds;
+	J40_LDS uint64_t *l_alias = (J40_LDS uint64_t *) (lds + align16((uint32_t) num_dist));
+	{
+		const uint32_t *msrc = (const uint32_t *) (plan.pool_u8 + spec.cluster_map_off);   // the u8 pool keeps 4-byte alignment per table
+		J40_LDS uint32_t *mdst = (J40_LDS uint32_t *) l_map;
+		for (int32_t i = tid; i < (num_dist + 3) / 4; i += blockDim.x) mdst[i] = msrc[i];
+		const uint64_t *asrc = plan.pool_u64 + plan.clusters[spec.cluster_off].table_off;
+		for (uint32_t i = tid; i < ((uint32_t) num_clusters << log_alpha); i += blockDim.x) l_alias[i] = asrc[i];
+	}
+	UniTables t;
+	t.ctx_map = l_map; t.alias = l_alias; t.log_alpha = log_alpha; t.log_bucket = 12 - log_alpha; t.num_dist = num_dist;
+	{
+		const int32_t *csrc = plan.pool_i32 + spec.lane_cfg_off;
+		lr_fill(t.cfg, [&](int32_t i) { return i < num_clusters ? csrc[i] : 0; });
+		lr_fill(t.nnz2, [&](int32_t i) { return (int32_t) DEV_NNZ_CTX2[i]; });
+		lr_fill(t.freq2, [&](int32_t i) { return (int32_t) DEV_FREQ_CTX2[i]; });
+		lr_fill(t.dct, [&](int32_t i) { return i < 27 ? (int32_t) DEV_DCT_SELECT[i][0] | ((int32_t) DEV_DCT_SELECT[i][1] << 8) | ((int32_t) DEV_DCT_SELECT[i][2] << 16) : 0; });
+	}
+	HfTables h;
+	h.clusters = nullptr; h.cluster_map = nullptr; h.alias = nullptr; h.prefix = nullptr; h.block_ctx_map = nullptr; h.nnz_ctx2 = nullptr; h.freq_ctx2 = nullptr; h.window = nullptr;
+	h.nonzeros = (int8_t *) (hf_lds + tables_bytes + (uint32_t) wave * wave_bytes);
+	DevGroupBlock *l_blocks = (DevGroupBlock *) (hf_lds + tables_bytes + (uint32_t) wave * wave_bytes + 32 * 32 * 3);
+	h.blocks = l_blocks; h.nblocks = 0; h.block_first = 0; h.ev_first = h.ev_end = 0;
+	if (active) {
+		const uint32_t b0 = plan.group_block_start[g], b1 = plan.group_block_start[g + 1];
+		h.block_first = b0; h.ev_first = plan.ev_range[2 * g]; h.ev_end = plan.ev_range[2 * g + 1];
+		h.nblocks = (int32_t) (b1 - b0);
+		const uint64_t *src = (const uint64_t *) (plan.group_blocks + b0);
+		uint64_t *dst = (uint64_t *) l_blocks;
+		for (int32_t i = lane; i < h.nblocks; i += 64) dst[i] = src[i];
+	}
+	__syncthreads();
+	if (active) {
+		const uint32_t err = decode_hf_section_fast<true>(plan, f, t, h, plan.sections[g]);
+		if (lane == 0) plan.status[g] = err;
 	}
 }
 
@@ -716,6 +769,17 @@ void launch_hf_entropy(const DevPlan &plan, const HfLaunchInfo &info, int32_t fi
 	if (num_groups <= 0) return;
 	HfLdsLayout lay;
 	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+	{
+		// single-pass frames (sparse coefficients) with the throughput kernel's kind of tables: the fast path (J40HIP_K1_FAST=0: never)
+		static const bool allowed = [] { const char *e = getenv("J40HIP_K1_FAST"); return !e || atoi(e) != 0; }();
+		const uint32_t tables = align16(align16(info.max_num_dist) + info.max_table_bytes), wave_bytes = align16(32 * 32 * 3 + 1024 * (uint32_t) sizeof(DevGroupBlock));
+		if (allowed && info.lanes_fast && plan.events && info.max_clusters <= 64 && tables + HF_WAVES * wave_bytes <= 150u * 1024u) {
+			static bool configured = false;
+			if (!configured) { (void) hipFuncSetAttribute((const void *) k_hf_entropy_fast, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); configured = true; }
+			hipLaunchKernelGGL(k_hf_entropy_fast, dim3((unsigned) ((num_groups + HF_WAVES - 1) / HF_WAVES)), dim3(64 * HF_WAVES), tables + HF_WAVES * wave_bytes, stream, plan, first_group, num_groups, tables, wave_bytes);
+			return;
+		}
+	}
 	uint32_t off = 0;
 	lay.off_bctx = off; off = align16(off + info.block_ctx_size);
 	lay.off_nnz = off; off += 128;

@@ -83,6 +83,7 @@ struct Slot {
 	std::vector<hipEvent_t> group_ev;   // made on demand, kept
 	std::vector<int> group_end;         // jobs [group_end[g - 1], group_end[g]) complete with group_ev[g]
 	int next_group = 0;
+	double t_launch = 0, t_harvest = 0;  // (J40HIP_ASYNC_TIMING)
 	bool harvested = false;             // the kernels are through: verdicts read, the frames' device memory handed back (the copies may still run)
 	bool failed = false;                // the device reported an error for this batch: everything still pending fails with "!gpu"
 	uint32_t launch_err = 0;      // the batch could not be enqueued: every member fails with this
@@ -310,7 +311,7 @@ bool progress(j40hip_pipeline *p, Slot &slot, bool block) {
 			p->garbage.insert(p->garbage.end(), dead.begin(), dead.end());
 			p->cv_todo.notify_all();
 		}
-		slot.harvested = true;
+		slot.harvested = true; slot.t_harvest = now_ms();
 	}
 	while (slot.next_group < ngroups) {
 		hipEvent_t ev = slot.group_ev[(size_t) slot.next_group];
@@ -342,6 +343,8 @@ bool progress(j40hip_pipeline *p, Slot &slot, bool block) {
 		}
 		++slot.next_group;
 	}
+	static const bool timing = getenv("J40HIP_ASYNC_TIMING") != nullptr;
+	if (timing) fprintf(stderr, "[j40hip batch] %zu frames in %d groups: launched at %.1f, kernels + verdicts through after %.1f ms, last pixels back after another %.1f ms\n", slot.jobs.size(), ngroups, slot.t_launch, slot.t_harvest - slot.t_launch, now_ms() - slot.t_harvest);
 	slot.jobs.clear(); slot.group_end.clear(); slot.next_group = 0; slot.busy = false; slot.launch_err = 0; slot.failed = false; slot.harvested = false;
 	return true;
 }
@@ -367,7 +370,7 @@ uint32_t launch_batch(j40hip_pipeline *p, std::vector<Job *> &take, int si) {
 		for (Job *j : take) if (!j->device_output && j->dev_rgba) { release_image(p, j->dev_rgba, j->stride * (size_t) j->height); j->dev_rgba = nullptr; }
 		return E_MEM;
 	}
-	slot.busy = true; slot.jobs = take; slot.launch_err = err; slot.failed = false; slot.harvested = false; slot.next_group = 0; slot.group_end.clear();
+	slot.busy = true; slot.jobs = take; slot.launch_err = err; slot.failed = false; slot.harvested = false; slot.next_group = 0; slot.group_end.clear(); slot.t_launch = now_ms();
 	// the second full batch says this is a pipeline that will run at depth: size the device memory cache for it now (the device
 	// has two batches to work on meanwhile) rather than wherever the queues first fill up
 	if (!err && p->reserve && (int64_t) frames.size() == p->batch_frames && ++p->full_batches == 2)
@@ -375,7 +378,8 @@ uint32_t launch_batch(j40hip_pipeline *p, std::vector<Job *> &take, int si) {
 	if (hipEventRecord(slot.kdone, slot.stream) != hipSuccess && !slot.launch_err) slot.launch_err = E_GPU;
 	const int n = (int) take.size();
 	// groups: without copies the whole batch is one group that ends with the kernels; with copies about sixteen per batch
-	const int per_group = host_out ? std::max(1, (n + 15) / 16) : n;
+	static const int groups = [] { const char *e = getenv("J40HIP_COPY_GROUPS"); return e && atoi(e) > 0 ? atoi(e) : 16; }();
+	const int per_group = host_out ? std::max(1, (n + groups - 1) / groups) : n;
 	hipStream_t gs = host_out ? p->copy_stream : slot.stream;
 	if (host_out && !slot.launch_err && hipStreamWaitEvent(p->copy_stream, slot.kdone, 0) != hipSuccess) slot.launch_err = E_GPU;
 	for (int i = 0; i < n; ++i) {
@@ -546,7 +550,13 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 			if (!made && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) { *err = E_GPU; break; }
 			if (hipEventCreateWithFlags(&s.kdone, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { *err = E_GPU; break; }
 		}
-		if (!*err && hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) *err = E_GPU;
+		if (!*err) {
+			// (J40HIP_COPY_PRIORITY: low | normal | high -- which set of hardware queues the copy stream's event markers go through)
+			int lo = 0, hi = 0; (void) hipDeviceGetStreamPriorityRange(&lo, &hi);
+			const char *e = getenv("J40HIP_COPY_PRIORITY");
+			const int prio = e && !strcmp(e, "low") ? lo : e && !strcmp(e, "high") ? hi : (lo + hi) / 2;
+			if (hipStreamCreateWithPriority(&p->copy_stream, hipStreamNonBlocking, prio) != hipSuccess) { (void) hipGetLastError(); if (hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) *err = E_GPU; }
+		}
 		{   // The LfGroup launches run for a quarter of a second each. Streams of one priority share a handful of hardware queues, and a
 			// kernel waits for the kernels ahead of it in its queue whichever stream they came from: on a stream of the batches' priority
 			// such a launch held up a quarter of the pixel kernels (296 ms per batch against 80). Lowest priority: queues of their own.

@@ -5,7 +5,10 @@
  * those of a lone call. The first decode of every file is kept (and optionally written out raw, for the comparison with the
  * reference's pixels in tests/test_api_threads.py); every later decode of that file must equal it byte for byte.
  *
- *   api_threads <threads> <images per thread> [--dump DIR] [--warm N] file.jxl [file.jxl ...]
+ *   api_threads <threads> <images per thread> [--dump DIR] [--warm N] [--verify-every K] file.jxl [file.jxl ...]
+ *
+ * --verify-every K: compare only every K-th decode of a thread with the file's first decode (the comparison reads 133 MB per 8K image:
+ * a throughput measurement on a box with few CPUs should not spend them there; the tests verify every decode)
  *
  * prints one JSON line: wall time of the timed part, Mpixel/s, the latency of the calls, errors, mismatches. */
 #include <pthread.h>
@@ -18,7 +21,7 @@
 
 typedef struct { char *path; void *data; size_t size; uint8_t *first; int32_t w, h; pthread_mutex_t m; char err[8]; } file_t;
 
-static file_t *files; static int nfiles, nthreads, per_thread, warm;
+static file_t *files; static int nfiles, nthreads, per_thread, warm, verify_every = 1;
 static const char *dump_dir;
 static pthread_barrier_t start_line;
 static double *latency_ms; static long mismatches, errors; static double pixels_done;
@@ -27,7 +30,7 @@ static pthread_mutex_t tally = PTHREAD_MUTEX_INITIALIZER;
 static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; }
 
 /* one image through the public API; returns 0 when it decoded and agreed with the file's first decode */
-static int decode_one(file_t *f, double *ms) {
+static int decode_one(file_t *f, double *ms, int verify) {
 	j40_image image;
 	const double t0 = now_ms();
 	j40_from_memory(&image, f->data, f->size, NULL);
@@ -46,7 +49,8 @@ static int decode_one(file_t *f, double *ms) {
 			pthread_mutex_unlock(&f->m);
 		} else {
 			pthread_mutex_unlock(&f->m);
-			if (px.width != f->w || px.height != f->h) bad = 1;
+			if (!verify) ;
+			else if (px.width != f->w || px.height != f->h) bad = 1;
 			else for (int32_t y = 0; y < px.height && !bad; ++y) if (memcmp(f->first + (size_t) y * px.width * 4, j40_row_u8x4(px, y), (size_t) px.width * 4)) bad = 1;
 		}
 		pthread_mutex_lock(&tally); pixels_done += (double) px.width * px.height; mismatches += bad; pthread_mutex_unlock(&tally);
@@ -66,10 +70,10 @@ static int decode_one(file_t *f, double *ms) {
 static void *thread_main(void *arg) {
 	const int t = (int) (intptr_t) arg;
 	double ms;
-	for (int i = 0; i < warm; ++i) decode_one(&files[(t + i) % nfiles], &ms);
+	for (int i = 0; i < warm; ++i) decode_one(&files[(t + i) % nfiles], &ms, 1);
 	pthread_barrier_wait(&start_line);
 	pthread_barrier_wait(&start_line);   /* (the main thread resets the tallies and starts the clock in between) */
-	for (int i = 0; i < per_thread; ++i) { decode_one(&files[(t + warm + i) % nfiles], &ms); latency_ms[(size_t) t * per_thread + i] = ms; }
+	for (int i = 0; i < per_thread; ++i) { decode_one(&files[(t + warm + i) % nfiles], &ms, (i + t) % verify_every == 0); latency_ms[(size_t) t * per_thread + i] = ms; }
 	return NULL;
 }
 
@@ -82,6 +86,7 @@ int main(int argc, char **argv) {
 	while (a + 1 < argc && argv[a][0] == '-') {
 		if (!strcmp(argv[a], "--dump")) dump_dir = argv[a + 1];
 		else if (!strcmp(argv[a], "--warm")) warm = atoi(argv[a + 1]);
+		else if (!strcmp(argv[a], "--verify-every")) verify_every = atoi(argv[a + 1]) > 0 ? atoi(argv[a + 1]) : 1;
 		else { fprintf(stderr, "unknown option %s\n", argv[a]); return 2; }
 		a += 2;
 	}
@@ -119,8 +124,8 @@ int main(int argc, char **argv) {
 		if (!fp || fwrite(files[i].first, 1, (size_t) files[i].w * 4 * files[i].h, fp) != (size_t) files[i].w * 4 * files[i].h) { perror(path); return 2; }
 		fclose(fp);
 	}
-	printf("{\"threads\": %d, \"images\": %zu, \"files\": %d, \"seconds\": %.4f, \"mpixels_per_s\": %.1f, \"latency_ms\": {\"min\": %.2f, \"median\": %.2f, \"p90\": %.2f, \"max\": %.2f}, \"errors\": %ld, \"mismatches\": %ld, \"warm_errors\": %ld, \"warm_mismatches\": %ld, \"file_errors\": [",
-		nthreads, n, nfiles, seconds, pixels_done / seconds / 1e6, latency_ms[0], latency_ms[n / 2], latency_ms[n * 9 / 10], latency_ms[n - 1], errors - warm_errors, mismatches - warm_mismatches, warm_errors, warm_mismatches);
+	printf("{\"threads\": %d, \"images\": %zu, \"verify_every\": %d, \"files\": %d, \"seconds\": %.4f, \"mpixels_per_s\": %.1f, \"latency_ms\": {\"min\": %.2f, \"median\": %.2f, \"p90\": %.2f, \"max\": %.2f}, \"errors\": %ld, \"mismatches\": %ld, \"warm_errors\": %ld, \"warm_mismatches\": %ld, \"file_errors\": [",
+		nthreads, n, verify_every, nfiles, seconds, pixels_done / seconds / 1e6, latency_ms[0], latency_ms[n / 2], latency_ms[n * 9 / 10], latency_ms[n - 1], errors - warm_errors, mismatches - warm_mismatches, warm_errors, warm_mismatches);
 	for (int i = 0; i < nfiles; ++i) printf("%s\"%s\"", i ? ", " : "", files[i].err);
 	printf("]}\n");
 	return 0;

@@ -11,6 +11,7 @@
 #include "../../j40_amd/csrc/device/hf_dev.h"
 #include <algorithm>
 #include "../../j40_amd/csrc/device/hf_lanes_dev.h"
+#include "../../j40_amd/csrc/device/hf_uni_dev.h"
 #include "../../j40_amd/csrc/device/vardct_dev.h"
 #include "../../j40_amd/csrc/device/special8_dev.h"
 #include "../../j40_amd/csrc/device/modular_dev.h"
@@ -258,6 +259,28 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 	std::vector<uint32_t> end_bits(status.size(), 0);
 	plan.section_end_bit = hp.frame.sections_have_trailer ? end_bits.data() : nullptr;
 
+	if (only_entropy & 16) {   // bit 4: the latency kernel's fast path (hf_uni_dev.h: k_hf_entropy_fast), one section after the other
+		const DevFrame &df = hp.frame;
+		if (!hp.hf.lanes_fast || !df.sparse_coeffs || df.num_passes != 1 || hp.hf.max_clusters > 64) return ERR_TODO;
+		const DevCodeSpec &spec = hp.coeff_specs[0];
+		UniTables t;
+		t.ctx_map = plan.pool_u8 + spec.cluster_map_off; t.alias = plan.pool_u64 + plan.clusters[spec.cluster_off].table_off;
+		t.log_alpha = spec.log_alpha_size; t.log_bucket = 12 - spec.log_alpha_size; t.num_dist = spec.num_dist;
+		const int32_t *csrc = plan.pool_i32 + spec.lane_cfg_off;
+		lr_fill(t.cfg, [&](int32_t i) { return i < spec.num_clusters ? csrc[i] : 0; });
+		lr_fill(t.nnz2, [&](int32_t i) { return (int32_t) DEV_NNZ_CTX2[i]; });
+		lr_fill(t.freq2, [&](int32_t i) { return (int32_t) DEV_FREQ_CTX2[i]; });
+		lr_fill(t.dct, [&](int32_t i) { return i < 27 ? (int32_t) DEV_DCT_SELECT[i][0] | ((int32_t) DEV_DCT_SELECT[i][1] << 8) | ((int32_t) DEV_DCT_SELECT[i][2] << 16) : 0; });
+		for (int32_t g = 0; g < df.num_groups; ++g) {
+			HfTables h;
+			memset(&h, 0, sizeof h);
+			h.blocks = plan.group_blocks + plan.group_block_start[g];
+			h.nblocks = (int32_t) (plan.group_block_start[g + 1] - plan.group_block_start[g]);
+			h.nonzeros = plan.nonzeros + (size_t) g * (32 * 32 * 3);
+			h.block_first = plan.group_block_start[g]; h.ev_first = plan.ev_range[2 * g]; h.ev_end = plan.ev_range[2 * g + 1];
+			status[(size_t) g] = decode_hf_section_fast<false>(plan, df, t, h, plan.sections[g]);
+		}
+	} else
 	if (only_entropy & 4) {   // bit 2: the throughput kernel's fast path (hf_lanes_dev.h), tables laid out as the kernel stages them
 		if (!hp.hf.lanes_fast) return ERR_TODO;
 		const DevFrame &df = hp.frame;

@@ -285,6 +285,36 @@ def test_pipeline_1080p_batch_of_256_frames_pixel_exact_per_stream(built, ref):
 
 
 @pytest.mark.gpu
+def test_config5_1024_frames_of_1080p_pixel_exact_per_stream(built, ref):
+    """BASELINE config 5 at its stated size: 1024 independent 1920x1080 VarDCT frames (16 distinct streams, a quarter of them
+    picture-encoded) the way bench.py runs them -- 256 frames = 10 240 sections per entropy launch, four batches in flight, the
+    LfGroup streams on the host threads --, EVERY one of the 1024 outputs compared with the reference's pixels of its stream
+    (on the device: a reference image per stream is uploaded once)"""
+    import torch
+    import j40_amd
+    specs = [("vardct", 1920, 1080, 110 + i, dict(forward=1) if i % 4 == 3 else {}) for i in range(16)]
+    datas = [synth(*s[:4], **s[4]) for s in specs]
+    expect = []
+    for d in datas:
+        rerr, px = ref.decode(d)
+        assert rerr == ""
+        expect.append(torch.from_numpy(px).to("cuda:0").to(torch.int16))
+    pipe = j40_amd.Pipeline(device=0, host_threads=8, batch_frames=256, max_in_flight=4, lf_streams="host")
+    outs = [torch.zeros((1080, 1920, 4), dtype=torch.uint8, device="cuda:0") for _ in range(1024)]
+    ts = [pipe.submit(datas[i % 16], outs[i].data_ptr(), 1920 * 4, device_output=True) for i in range(1024)]
+    pipe.drain()
+    torch.cuda.synchronize()
+    worst = 0
+    for i, t in enumerate(ts):
+        assert pipe.result(t) == ""
+        worst = max(worst, int((outs[i].to(torch.int16) - expect[i % 16]).abs().max()))
+    assert worst <= 1, worst
+    st = pipe.stats()
+    assert st["completed"] == 1024 and st["launch_frames"] == 1024 and st["lf_device_frames"] == 0
+    pipe.close()
+
+
+@pytest.mark.gpu
 def test_pipeline_forward_encoded_8k_frame_matches_reference(built, ref):
     """the frame bench.py times: a 7680x4320 picture encoded at about distance 1, through the batched path (twice, LfGroup streams
     once on the device and once on the host threads)"""

@@ -1,0 +1,64 @@
+#!/bin/bash
+# Round 4's closing evidence in one GPU call, every part on the SAME commit, the counter passes last:
+#   1. the GPU suite                                  -> gpurun_out/r04/gputest.txt
+#   2. the default bench line (what the driver runs)  -> gpurun_out/r04/bench_default.json
+#   3. rocprofv3 --kernel-trace --stats of the timed region (bench.py --skip-sections: the host-to-host steps only) and of the
+#      device_output section's pipeline (512 frames per entropy launch: the queued k_hf_lanes)
+#   4. the --maxlog 8 stream (128 / 256-sized transforms: k_vardct_large)
+#   5. PMC passes over the timed region, one counter group per pass (FETCH_SIZE; WRITE_SIZE; SQ groups), from which
+#      profiles/r04_pmc_traffic.json (bench.py's roofline.traffic) is made
+# usage: bash tools/r04_final.sh   (on the GPU box, from the repo root; copy gpurun_out/r04/*.txt|json into profiles/ afterwards)
+set -u
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/r04; mkdir -p $O
+cd $R
+python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1
+git rev-parse HEAD > $O/commit.txt 2>/dev/null
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/gputest.txt
+cd /tmp && export TMPDIR=/tmp
+timeout 1500 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
+T="--skip-sections --no-cpu-baseline --steps 6 --warmup 2"
+rocprofv3 --kernel-trace --stats -d $O/kt -- python $R/bench.py $T > $O/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/kt_dev -- python $R/tools/device_output_probe.py 512 3 device > $O/kt_dev.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/kt_maxlog8 -- python $R/bench.py $T --stream coefficient --maxlog 8 --batch 64 --pipe-batch 64 --distinct 8 --steps 3 --warmup 1 > $O/kt_maxlog8.log 2>&1
+P="--skip-sections --no-cpu-baseline --steps 2 --warmup 1"
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch --output-format csv -- python $R/bench.py $P > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write --output-format csv -- python $R/bench.py $P > $O/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT -d $O/sq1 --output-format csv -- python $R/bench.py $P > $O/sq1.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_LDS_IDX_ACTIVE -d $O/sq2 --output-format csv -- python $R/bench.py $P > $O/sq2.log 2>&1
+cd $R
+python tools/prof_summary.py $O/kt $O/kernel_stats_timed_region.txt > /dev/null 2>&1
+python tools/prof_summary.py $O/kt_dev $O/kernel_stats_device_output_b512.txt > /dev/null 2>&1
+python tools/prof_summary.py $O/kt_maxlog8 $O/kernel_stats_maxlog8_b64.txt > /dev/null 2>&1
+python tools/pmc_summary.py $O/pmc_fetch $O/pmc_fetch_timed_region.txt > /dev/null 2>&1
+python tools/pmc_summary.py $O/pmc_write $O/pmc_write_timed_region.txt > /dev/null 2>&1
+python tools/pmc_summary.py $O/sq1 $O/sq_counters_1.txt > /dev/null 2>&1
+python tools/pmc_summary.py $O/sq2 $O/sq_counters_2.txt > /dev/null 2>&1
+rm -rf $O/kt $O/kt_dev $O/kt_maxlog8 $O/pmc_fetch $O/pmc_write $O/sq1 $O/sq2   # (raw traces: tens of MB; gpurun_out/ travels back only below 64 MiB)
+python - <<'PY'
+import json, re
+O = "gpurun_out/r04/"
+def counter(path, kernel, name):
+    lines = open(path).read().split("\n")
+    for i, l in enumerate(lines):
+        if l.startswith(kernel):
+            for m in lines[i + 1:i + 12]:
+                if name in m:
+                    return float(re.search(r"avg=([0-9.e+]+)", m).group(1))
+    return None
+try:
+    f = counter(O + "pmc_fetch_timed_region.txt", "j40hip::k_hf_lanes", "FETCH_SIZE")
+    w = counter(O + "pmc_write_timed_region.txt", "j40hip::k_hf_lanes", "WRITE_SIZE")
+    if f and w:
+        json.dump({"kernel": "k_hf_lanes", "stream": "forward", "frames_per_launch": 256, "frame": "7680x4320, tools/jxlsynth forward=1, seeds 3 + 1000 i",
+                   "commit": open(O + "commit.txt").read().strip() if __import__("os").path.exists(O + "commit.txt") else None,
+                   "fetch_size_kb": f, "write_size_kb": w, "fetch_correction": 2.0,
+                   "source": "profiles/r04_pmc_fetch_timed_region.txt, profiles/r04_pmc_write_timed_region.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --skip-sections`, per k_hf_lanes launch, by tools/r04_final.sh on the commit named here; KB of 1024 B; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md (128-B requests tallied at 64 B) -- calibrated there for wide coalesced reads only, so for this kernel's 4-byte per-lane reads it is an upper bound; WRITE_SIZE as reported)"},
+                  open(O + "pmc_traffic.json", "w"))
+        print("traffic", f, w)
+except Exception as e:
+    print("no traffic file:", e)
+d = json.load(open(O + "bench_default.json"))
+print({k: d[k] for k in ("value", "ms_per_step", "steps", "warmup")}); r = d["roofline"]; print({k: r[k] for k in r if k not in ("note", "traffic_source")})
+PY
+cat $O/gputest.txt; head -12 $O/kernel_stats_timed_region.txt | cut -c1-170; ls -la $O
