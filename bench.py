@@ -183,8 +183,9 @@ def main():
     ap.add_argument("--pipe-batch", type=int, default=256, help="frames per entropy launch inside the pipeline")
     ap.add_argument("--host-threads", type=int, default=0, help="pipeline worker threads per GPU (default: the container's CPU quota / GPUs)")
     ap.add_argument("--in-flight", type=int, default=2, help="batches the pipeline keeps in flight on the device")
-    ap.add_argument("--device-output-steps", type=int, default=4, help="steps of the `device_output` section (pixels left in HBM)")
-    ap.add_argument("--device-output-batch", type=int, default=512, help="frames per step and per entropy launch of the `device_output` section")
+    ap.add_argument("--device-output-steps", type=int, default=12, help="steps of the `device_output` section (pixels left in HBM)")
+    ap.add_argument("--device-output-batch", type=int, default=256, help="frames per step and per entropy launch of the `device_output` section")
+    ap.add_argument("--queued-batch", type=int, default=512, help="frames per entropy launch of the `k_hf_lanes_queued` section (0: skip it)")
     ap.add_argument("--device-output-lf", choices=["auto", "device", "host"], default="device")
     ap.add_argument("--host-buffers", type=int, default=0, help="pinned landing buffers for the pixels (default: one per distinct stream, at most 64; 24 per rank with several ranks)")
     ap.add_argument("--lf-streams", choices=["auto", "device", "host"], default="device",
@@ -196,8 +197,8 @@ def main():
     ap.add_argument("--maxlog", type=int, default=0, help="--stream coefficient: largest transform side (log2) in the mix; 8 brings in the 128/256-sized transforms (k_vardct_large)")
     ap.add_argument("--shard-groups", action="store_true", help="single-frame mode: ONE frame per step, its pass groups split over the ranks (j40_amd.sharding)")
     ap.add_argument("--shard-kind", choices=["vardct", "modular"], default="vardct", help="--shard-groups: a VarDCT frame, or a Modular lossless frame (RCT only; e.g. --width 16384 --height 16384 = BASELINE config 4)")
-    ap.add_argument("--config5-batch", type=int, default=256, help="config 5 (1024 x 1920x1080): frames per entropy launch")
-    ap.add_argument("--config5-in-flight", type=int, default=4)
+    ap.add_argument("--config5-batch", type=int, default=512, help="config 5 (1024 x 1920x1080): frames per entropy launch")
+    ap.add_argument("--config5-in-flight", type=int, default=2)
     ap.add_argument("--config5-lf", choices=["auto", "device", "host"], default="host")
     ap.add_argument("--sharded-record", action="store_true", help="add the `sharded` record (one frame split by group ranges) also on one rank; with several ranks it is always there")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -269,9 +270,8 @@ def main():
     for t in tickets:
         assert pipe.result(t) == "", "decode error: " + pipe.result(t)
     first_pixels = host_outs[0].clone()
-    # ---- the same path with the pixels left in HBM (what rounds 2 and 3 reported as `value`): the device's own pace. Its own
-    # pipeline: without the copies nothing holds a batch's memory back, so the entropy launch takes 512 frames -- more sections
-    # than the machine has lanes, handed out through per-frame queues (k_hf_lanes) -- and the LfGroup streams stay on the GPU.
+    # ---- the same path with the pixels left in HBM (what rounds 2 and 3 reported as `value`): the device's own pace, its own pipeline,
+    # the LfGroup streams on the GPU
     device_output = None
     if not args.skip_sections or world > 1:
         pipe.close()
@@ -297,8 +297,28 @@ def main():
                          "k_hf_lanes_ms_per_launch": round(k1d, 3), "k_hf_lanes_roofline_frac": round(alg_d * fpl / (k1d / 1e3) / 8e12, 6) if k1d > 0 else None,
                          "pixel_kernels_ms_per_launch": round(sd["k2_ms"] / dl, 3), "lf_streams_plan_tail_ms_per_launch": round(sd["lf_plan_ms"] / dl, 3),
                          "roofline_frac_step": round(alg_d * Bd / (e_dev / dsteps) / 8e12, 6),
-                         "note": "as `value`, but the RGBA stays in device memory (no copy back): the device is the bound here, PCIe is for `value`. %d frames per entropy launch: "
-                                 "more sections than the machine has lanes, so every frame's lanes take its sections from a queue, largest first (k_hf_lanes, queued form)" % Bd}
+                         "note": "as `value`, but the RGBA stays in device memory (no copy back): the device is the bound here, PCIe is for `value`"}
+        # ---- k_hf_lanes' queued form: launches with more sections than the machine has lanes (512 8K frames = 261 120 sections
+        # against 131 072 lanes at the two wavefronts per SIMD the tables' LDS allows): every frame's lanes take its sections from a
+        # shared counter, largest first. One batch in flight, so that nothing runs beside the kernel.
+        if args.queued_batch > 0 and world == 1:
+            Bq = args.queued_batch
+            qbufs = [bufs[i % D] for i in range(Bq)]; qsizes = [len(datas[i % D]) for i in range(Bq)]; qouts = [outs[i % nd] for i in range(Bq)]
+            qpipe = j40_amd.Pipeline(local_rank, threads, Bq, 1, lf_streams="host")
+            run_pipeline_steps(qpipe, qbufs, qsizes, qouts, W * 4, True, 1, torch, dev, None)
+            eq, tk = run_pipeline_steps(qpipe, qbufs, qsizes, qouts, W * 4, True, 2, torch, dev, None)
+            sq = qpipe.stats()
+            assert all(qpipe.result(t) == "" for t in tk)
+            assert torch.equal(outs[0].cpu(), first_pixels)
+            qpipe.close()
+            ql = max(sq["launches"], 1)
+            if sq["k1_kernel_ms"] > 0 and abs(sq["launch_frames"] / ql - Bq) < 1:
+                kq = sq["k1_kernel_ms"] / ql
+                device_output["k_hf_lanes_queued"] = {"frames_per_launch": Bq, "kernel_ms": round(kq, 3), "ms_per_256_frames": round(kq * 256 / Bq, 3),
+                                                      "achieved": round(alg_d * Bq / (kq / 1e3) / 1e9, 3), "frac": round(alg_d * Bq / (kq / 1e3) / 8e12, 6), "launches": sq["launches"],
+                                                      "how": "one batch of %d frames in flight, LfGroup streams on the host threads: k_hf_lanes alone on the device (device-recorded start/end events); "
+                                                             "the same launch with one section per lane runs in two rounds (J40HIP_K1_QUEUE_WAVES=0: 103 ms, DESIGN.md section 4)" % Bq}
+            del qouts
         del outs, douts
         torch.cuda.empty_cache()
     resident_multi = None

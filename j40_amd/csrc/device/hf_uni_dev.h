@@ -10,10 +10,12 @@
 //     are formed while the current symbol is still being decoded and their clusters fetched by ONE LDS read (lane 0 reads the
 //     context map for prev = 0, lane 1 for prev = 1); when the symbol is known its successor's cluster is a v_readlane away;
 //   * that leaves one LDS read on a coefficient's chain: the alias entry (j40__ans_code, j40.h:2441-2461), addressed by cluster and state.
-// Same packed tables as k_hf_lanes (DevCodeSpec::lane_cfg_off, AnsEntry); same bit reader and error order as the general form
-// (entropy_dev.h). tests/hostsim compiles this for the CPU (lane tables as arrays) and compares it with the general form.
+//   * the bit reader is the lane decoder's (absolute position, reads that never fail, one refill point per symbol, renormalisation
+//     and extra bits always taken with length 0 when they do not apply) on scalar registers: a symbol is straight-line scalar code
+//     with a handful of branches (the general reader's refill logic, inlined four times per symbol, was most of its instructions).
+// Same packed tables as k_hf_lanes (DevCodeSpec::lane_cfg_off, AnsEntry) and the lane decoder's error rules. tests/hostsim compiles this for the CPU (lane tables as arrays) and compares it with the general form.
 #pragma once
-#include "hf_dev.h"
+#include "hf_lanes_dev.h"
 
 namespace j40hip {
 
@@ -42,53 +44,105 @@ struct UniTables {
 	int32_t log_alpha, log_bucket, num_dist;
 };
 
-// one symbol of cluster `cl`: rANS step (j40.h:2441-2466) + hybrid integer (j40.h:2313-2334); errors through `b` like code_symbol
+// LSB-first bit window like LaneBits (hf_lanes_dev.h) with wave-uniform state: the window, its fill and the position live in scalar
+// registers; only the word requested ahead sits in a vector register until it is appended. Absolute position of the next unread bit
+// = 8 * pos - nbits; reads never fail (the codestream buffer is padded), the caller compares the position with the section's end.
+struct UBits {
+	const J40_GLOBAL uint8_t *base;
+	uint64_t bits;
+	int32_t nbits;
+	uint32_t pos;
+	uint32_t ahead;
+};
+template <bool UNI> J40_DEV void ub_init(UBits &b, const J40_GLOBAL uint8_t *base, uint32_t start_bit) {
+	b.base = base;
+	const uint32_t pos0 = (start_bit >> 3) & ~3u, skip = start_bit - 8u * pos0;   // skip < 32
+	b.bits = (uint64_t) (uni<UNI>(lane_load32(base, pos0)) >> skip);
+	b.nbits = 32 - (int32_t) skip;
+	b.pos = pos0 + 4;
+	b.ahead = lane_load32(base, b.pos);
+}
+template <bool UNI> J40_DEV void ub_refill(UBits &b) {   // > 32 bits buffered afterwards
+	if (b.nbits <= 32) {
+		b.bits |= (uint64_t) uni<UNI>(b.ahead) << b.nbits;
+		b.nbits += 32;
+		b.pos += 4u;
+		b.ahead = lane_load32(b.base, b.pos);
+	}
+}
+J40_DEV uint32_t ub_take(UBits &b, int32_t n) {   // 0 <= n <= 31, n <= nbits
+	const uint32_t v = (uint32_t) b.bits & ((1u << n) - 1u);
+	b.bits >>= n; b.nbits -= n;
+	return v;
+}
+J40_DEV uint32_t ub_position(const UBits &b) { return 8u * b.pos - (uint32_t) b.nbits; }
+
+// one symbol of cluster `cl`: rANS step (j40.h:2441-2466) + hybrid integer (j40.h:2313-2334), the branch-light form of lane_symbol
+// (hf_lanes_dev.h) on scalars: renormalisation and extra bits are always taken, with length 0 when they do not apply; *err receives
+// the error the reference would have raised first ("shrt" while renormalising, then "iovf", then "shrt" in the extra bits).
+// The window holds > 32 bits on entry (ub_refill).
 template <bool UNI>
-J40_DEV int32_t uni_symbol(DevBits &b, uint32_t &state, const UniTables &t, uint32_t cl) {
-	if (state == 0) { state = bits_u<UNI>(b, 16); state |= bits_u<UNI>(b, 16) << 16; }
+J40_DEV int32_t uni_symbol(UBits &b, uint32_t &state, const UniTables &t, uint32_t cl, uint32_t end_bit, uint32_t *err) {
+	if (state == 0) {   // first symbol of the section (j40.h:2445-2449)
+		state = ub_take(b, 16); state |= ub_take(b, 16) << 16;
+		ub_refill<UNI>(b);
+	}
 	const uint32_t idx = state & 0xfff, i = idx >> t.log_bucket, pos = idx & ((1u << t.log_bucket) - 1);
 	const uint64_t e = uni64<UNI>(t.alias[(cl << t.log_alpha) + i]);
 	const uint32_t m = (uint32_t) lr_get(t.cfg, (int32_t) cl);
-	const bool aliased = pos >= (uint32_t) (e & 0xff);
-	int32_t token = (int32_t) (aliased ? (uint32_t) (e >> 20) & 0xff : i);
-	const uint32_t offset = aliased ? (uint32_t) (e >> 8) & 0xfff : 0;
-	const uint32_t d = aliased ? (uint32_t) (e >> 28) & 0x1fff : (uint32_t) (e >> 41) & 0x1fff;
+	const uint32_t elo = (uint32_t) e, ehi = (uint32_t) (e >> 32);
+	const bool aliased = pos >= (elo & 0xff);
+	const int32_t token = (int32_t) (aliased ? (elo >> 20) & 0xff : i);
+	const uint32_t offset = aliased ? (elo >> 8) & 0xfff : 0;
+	const uint32_t d = aliased ? (uint32_t) (e >> 28) & 0x1fff : (ehi >> 9) & 0x1fff;
 	state = d * (state >> 12) + offset + pos;
-	if (state < (1u << 16)) state = (state << 16) | bits_u<UNI>(b, 16);
-	// hybrid integer (hybrid_int_dev, entropy_dev.h)
-	const int32_t split_exp = (int32_t) (m & 15), msb = (int32_t) ((m >> 4) & 15), lsb = (int32_t) ((m >> 8) & 15), max_token = (int32_t) (m >> 12);
-	const int32_t split = 1 << split_exp;
-	if (token < split) return token;
-	if (token > max_token) { token = max_token; bits_set_error(b, ERR_IOVF); }
-	const int32_t in_token = msb + lsb;
-	const int32_t midbits = split_exp - in_token + ((token - split) >> in_token);
-	const int32_t mid = (int32_t) bits_u<UNI>(b, midbits);
+	const bool renorm = state < (1u << 16);
+	const uint32_t low = ub_take(b, renorm ? 16 : 0);
+	state = renorm ? (state << 16) | low : state;
+	const bool short1 = ub_position(b) > end_bit;
+	const int32_t split_exp = (int32_t) (m & 15), split = 1 << split_exp;
+	if (token < split) { *err = short1 ? (uint32_t) ERR_SHRT : 0u; return token; }   // (a scalar branch: most coefficient tokens are literal)
+	const int32_t mt = (int32_t) (m >> 12);
+	const bool iovf = token > mt;
+	const int32_t tok = iovf ? mt : token;
+	const int32_t msb = (int32_t) ((m >> 4) & 15), lsb = (int32_t) ((m >> 8) & 15), in_token = msb + lsb;
+	const int32_t midbits = split_exp - in_token + ((tok - split) >> in_token);
+	if (midbits > b.nbits) ub_refill<UNI>(b);   // rare: more than ~17 extra bits
+	const int32_t mid = (int32_t) ub_take(b, midbits);
+	const bool short2 = ub_position(b) > end_bit;
 	const int32_t top = 1 << msb;
-	const int32_t lo = token & ((1 << lsb) - 1), hi = (token >> lsb) & (top - 1);
+	const int32_t lo = tok & ((1 << lsb) - 1), hi = (tok >> lsb) & (top - 1);
+	*err = short1 ? (uint32_t) ERR_SHRT : iovf ? (uint32_t) ERR_IOVF : short2 ? (uint32_t) ERR_SHRT : 0u;
 	return ((top | hi) << (midbits + lsb)) | ((mid << lsb) | lo);
 }
 
-// the single-pass, sparse-coefficient section decode of decode_hf_section<true, UNI> (hf_dev.h) over the packed tables; `blocks`,
-// `nonzeros` as there (HfTables). Returns the section's status.
+// The single-pass, sparse-coefficient section decode: the loop nest of decode_hf_section<true, UNI> (hf_dev.h) with the error rules of
+// the lane decoder (decode_hf_sections_lane, hf_lanes_dev.h: the first error of a symbol ends the section), which tests/hostsim holds
+// against the general decoder and the reference on damaged streams. `blocks`, `nonzeros` as in HfTables. Returns the section's status.
 template <bool UNI>
 J40_DEV uint32_t decode_hf_section_fast(const DevPlan &plan, const DevFrame &f, const UniTables &t, const HfTables &h, const DevSection &sec) {
-	DevBits b;
-	bits_init<UNI>(b, plan.codestream, sec.byte_off, sec.size, sec.bit_off);
-	const uint32_t preset = bits_u<UNI>(b, f.preset_bits);
-	if ((int32_t) preset >= f.num_hf_presets) bits_set_error(b, ERR_RNGE);
+	const uint32_t start_bit = 8u * sec.byte_off + sec.bit_off, end_bit = 8u * (sec.byte_off + sec.size);
+	UBits b;
+	ub_init<UNI>(b, (const J40_GLOBAL uint8_t *) plan.codestream, start_bit);
+	ub_refill<UNI>(b);
+	uint32_t err = 0;
+	const uint32_t preset = ub_take(b, f.preset_bits);
+	if (ub_position(b) > end_bit) err = ERR_SHRT;
+	else if ((int32_t) preset >= f.num_hf_presets) err = ERR_RNGE;
 	const int32_t ctxoff = 495 * f.nb_block_ctx * (int32_t) preset;
 	const int32_t gw8 = sec.gw8, nb_block_ctx = f.nb_block_ctx, last_ctx = t.num_dist - 1;
 	uint32_t state = 0;
 	uint32_t ev_at = h.ev_first;
-	for (int32_t k = 0; k < h.nblocks && !b.err; ++k) {
-		plan.block_events[4 * (size_t) (h.block_first + (uint32_t) k)] = ev_at;
+	for (int32_t k = 0; k < h.nblocks && !err; ++k) {
+		const uint32_t blk_first = ev_at;
+		uint32_t counts[3] = {0, 0, 0};
 		const uint32_t w = uni<UNI>(((const uint32_t *) (h.blocks + k))[1]);   // DevGroupBlock: pos_dct | bctx3 << 16
 		const int32_t pos_dct = (int32_t) (w & 0xffff), bctx3 = (int32_t) (w >> 16);
 		const int32_t dctsel = pos_dct >> 10, x8 = pos_dct & 31, y8 = (pos_dct >> 5) & 31, nzpos = y8 * gw8 + x8;
 		const int32_t di = lr_get(t.dct, dctsel);
 		const int32_t log_rows = di & 255, log_columns = (di >> 8) & 255;
 		const int32_t log_size = log_rows + log_columns, shift = log_size - 6, size = 1 << log_size, round = (1 << shift) - 1;
-		for (int32_t c_yxb = 0; c_yxb < 3 && !b.err; ++c_yxb) {
+		for (int32_t c_yxb = 0; c_yxb < 3 && !err; ++c_yxb) {
 			const int32_t c = c_yxb == 0 ? 1 : c_yxb == 1 ? 0 : 2;
 			const uint32_t chan_first = ev_at;
 			const int32_t bctx = (bctx3 >> (4 * c_yxb)) & 15;
@@ -98,17 +152,19 @@ J40_DEV uint32_t decode_hf_section_fast(const DevPlan &plan, const DevFrame &f, 
 			else nz = y8 > 0 ? h.nonzeros[(nzpos - gw8) * 3 + c] : 32;
 			nz = uni<UNI>(nz);
 			const int32_t nzctx = ctxoff + bctx + (nz < 8 ? nz : 4 + nz / 2) * nb_block_ctx;
-			nz = uni_symbol<UNI>(b, state, t, uni<UNI>((uint32_t) t.ctx_map[nzctx]));
-			if (nz > (63 << shift)) { bits_set_error(b, ERR_COEF); break; }
+			uint32_t e2;
+			ub_refill<UNI>(b);
+			nz = uni_symbol<UNI>(b, state, t, uni<UNI>((uint32_t) t.ctx_map[nzctx]), end_bit, &e2);
+			e2 = e2 ? e2 : nz > (63 << shift) ? (uint32_t) ERR_COEF : 0u;
+			if (e2) { err = e2; break; }
 			const int32_t qnz = (nz + round) >> shift;
 			for (int32_t i = 0; i < (1 << (log_rows - 3)); ++i) for (int32_t j = 0; j < (1 << (log_columns - 3)); ++j)
 				h.nonzeros[(nzpos + i * gw8 + j) * 3 + c] = (int8_t) qnz;
 			const int32_t cctx = ctxoff + 458 * bctx + 37 * nb_block_ctx;
 			int32_t prev = nz <= (size >> 4);
 			int32_t i = 1 << shift;
-			if (nz > 0 && i < size) {
-				int32_t ctx = cctx + lr_get(t.nnz2, (nz + round) >> shift) + lr_get(t.freq2, i >> shift) + prev;
-				uint32_t cl = uni<UNI>((uint32_t) t.ctx_map[ctx]);
+			if (nz > 0) {   // (i < size: the first coefficient position is 1 << shift < 64 << shift)
+				uint32_t cl = uni<UNI>((uint32_t) t.ctx_map[cctx + lr_get(t.nnz2, (nz + round) >> shift) + lr_get(t.freq2, i >> shift) + prev]);
 				for (;;) {
 					// the two contexts the next coefficient can have (prev = 0: nz stays; prev = 1: one non-zero fewer), fetched now
 					SpecPair next;
@@ -118,31 +174,42 @@ J40_DEV uint32_t decode_hf_section_fast(const DevPlan &plan, const DevFrame &f, 
 						ca = ca > last_ctx ? last_ctx : ca; cb = cb > last_ctx ? last_ctx : cb;   // (past the block's last position: never used)
 						spec_issue(next, t.ctx_map, ca, cb);
 					}
-					const int32_t ucoeff = uni_symbol<UNI>(b, state, t, cl);
-					if (ucoeff) {
-						if (ev_at >= h.ev_end || !coeff_event_fits(unpack_signed_dev(ucoeff))) { bits_set_error(b, ERR_EVOF); break; }
-						CoeffEvent ev; ev.packed = coeff_event_pack((uint32_t) i, unpack_signed_dev(ucoeff));
-						plan.events[ev_at++] = ev;
+					ub_refill<UNI>(b);
+					const int32_t v = uni_symbol<UNI>(b, state, t, cl, end_bit, &e2);
+					const bool nonzero = v != 0 && e2 == 0;
+					if (nonzero) {
+						const int32_t sv = unpack_signed_dev(v);
+						if (ev_at >= h.ev_end || !coeff_event_fits(sv)) e2 = ERR_EVOF;
+						else { CoeffEvent ev; ev.packed = coeff_event_pack((uint32_t) i, sv); plan.events[ev_at++] = ev; }
 					}
-					prev = ucoeff != 0;
+					prev = v != 0;
 					nz -= prev;
-					if (b.err) break;
 					++i;
-					if (!(nz > 0 && i < size)) break;
+					e2 = e2 ? e2 : nz != 0 && i >= size ? (uint32_t) ERR_COEF : 0u;   // non-zeros left but no coefficient left (j40.h:6996)
+					if (e2) { err = e2; break; }
+					if (nz == 0) break;
 					cl = spec_take(next, prev);
 				}
 			}
-			plan.block_events[4 * (size_t) (h.block_first + (uint32_t) k) + 1 + (size_t) c_yxb] = ev_at - chan_first;
-			if (nz != 0) bits_set_error(b, ERR_COEF);
+			counts[c_yxb] = ev_at - chan_first;
+		}
+		if (!err) {   // the block's entry of DevPlan::block_events in one piece, like the lane decoder (a section that fails leaves its last block's entry as it was)
+			uint32_t *be = plan.block_events + 4 * (size_t) (h.block_first + (uint32_t) k);
+			be[0] = blk_first; be[1] = counts[0]; be[2] = counts[1]; be[3] = counts[2];
 		}
 	}
-	if (!b.err) {   // code_finish, j40.h:2884
-		if (state) { if (state != 0x130000) bits_set_error(b, ERR_ANS); }
-		else { if (bits_u<UNI>(b, 16) != 0x0000) bits_set_error(b, ERR_ANS); if (bits_u<UNI>(b, 16) != 0x0013) bits_set_error(b, ERR_ANS); }
+	if (!err) {   // j40.h:2884-2893: the final state, or the untouched initial state, must be 0x130000
+		if (state == 0) { ub_refill<UNI>(b); state = ub_take(b, 16); state |= ub_take(b, 16) << 16; if (ub_position(b) > end_bit) err = ERR_SHRT; }
+		if (!err && state != 0x130000) err = ERR_ANS;
 	}
-	if (!b.err && f.check_section_end) bits_finish_section(b, f.single_declared_end);
-	if (f.sections_have_trailer && plan.section_end_bit) plan.section_end_bit[&sec - plan.sections] = 8u * b.pos - (uint32_t) b.nbits;   // the extra channels' sub-image starts here
-	return b.err;
+	if (!err && f.check_section_end) {   // single-section frames: zero padding up to the byte boundary, then no byte of the section left (j40.h:8203, 7796)
+		const uint32_t at = ub_position(b), padn = (0u - at) & 7u;
+		if (padn > (uint32_t) b.nbits) ub_refill<UNI>(b);
+		if (ub_take(b, (int32_t) padn)) err = ERR_PAD0;
+		else if (at + padn != 8u * f.single_declared_end) err = at + padn < 8u * f.single_declared_end ? (uint32_t) ERR_SHRT : (uint32_t) ERR_EXCS;
+	}
+	if (f.sections_have_trailer && plan.section_end_bit) plan.section_end_bit[&sec - plan.sections] = ub_position(b);   // the extra channels' sub-image starts here
+	return err;
 }
 
 } // namespace j40hip
