@@ -17,9 +17,16 @@ git rev-parse HEAD > $O/commit.txt 2>/dev/null
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/gputest.txt
 cd /tmp && export TMPDIR=/tmp
 timeout 1500 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
+timeout 1200 python $R/bench.py --steps 20 --warmup 5 --skip-modular > $O/bench_steps20_warmup5.json 2> $O/bench_steps20_warmup5.err
+P8K=$(ls $R/build/streams/vardct_7680_4320_*forward-1.jxl | head -4 | tr '\n' ' ')
+J40HIP_API_TIMING=1 J40HIP_SERVE=0 timeout 300 $R/build/api_threads 1 8 --warm 2 $P8K > $O/api_one_thread_latency.json 2> $O/api_one_thread_latency.err
+timeout 300 $R/build/api_threads 64 8 --warm 3 --verify-every 8 $P8K > $O/api_64_threads.json 2> $O/api_64_threads.err
+timeout 300 $R/build/api_threads 128 8 --warm 3 --verify-every 8 $P8K > $O/api_128_threads.json 2> $O/api_128_threads.err
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 $R/tools/rccl_dry_run.py > $O/rccl_dry_run.json 2> $O/rccl_dry_run.err
+J40_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 $R/bench.py --gpus 1 --shard-groups --steps 5 --warmup 1 > $O/sharded_world1_nccl.json 2> $O/sharded_world1_nccl.err
 T="--skip-sections --no-cpu-baseline --steps 6 --warmup 2"
 rocprofv3 --kernel-trace --stats -d $O/kt -- python $R/bench.py $T > $O/kt.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/kt_dev -- python $R/tools/device_output_probe.py 512 3 device > $O/kt_dev.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/kt_dev -- python $R/tools/device_output_probe.py 512 3 host 1 > $O/kt_dev.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/kt_maxlog8 -- python $R/bench.py $T --stream coefficient --maxlog 8 --batch 64 --pipe-batch 64 --distinct 8 --steps 3 --warmup 1 > $O/kt_maxlog8.log 2>&1
 P="--skip-sections --no-cpu-baseline --steps 2 --warmup 1"
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch --output-format csv -- python $R/bench.py $P > $O/pmc_fetch.log 2>&1
