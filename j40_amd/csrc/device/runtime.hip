@@ -136,12 +136,14 @@ void j40hip_rt::cache_release(int device, void *ptr, size_t bytes, bool clean) {
 }
 
 // ---- pinned host memory for pixels that go back to the caller (the public API's image planes): pinning 133 MB takes tens of
-// milliseconds, so planes are recycled by size across images. J40HIP_PINNED_POOL_GB bounds what sits idle (default 16; 0: nothing kept).
+// milliseconds (0.2 s for 133 MB measured, as long again to unpin), so planes are recycled by size across images.
+// J40HIP_PINNED_POOL_GB bounds what sits idle (default 32: 240 planes of an 8K image -- with 128 callers and a 16 GB bound every
+// j40_free beyond the 123rd plane unpinned it and the next image pinned a new one; 0: nothing kept).
 namespace {
 std::mutex g_pinned_mutex;
 std::vector<std::pair<void *, size_t>> g_pinned_idle;
 size_t g_pinned_idle_bytes = 0;
-size_t pinned_limit() { static const size_t v = [] { const char *e = getenv("J40HIP_PINNED_POOL_GB"); return (size_t) (e ? std::max(0, atoi(e)) : 16) << 30; }(); return v; }
+size_t pinned_limit() { static const size_t v = [] { const char *e = getenv("J40HIP_PINNED_POOL_GB"); return (size_t) (e ? std::max(0, atoi(e)) : 32) << 30; }(); return v; }
 }
 extern "C" void *j40hip_pinned_acquire(size_t bytes) {
 	bytes = (bytes + 4095) & ~(size_t) 4095;
