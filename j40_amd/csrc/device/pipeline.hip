@@ -586,9 +586,11 @@ void j40hip_pipeline_free(j40hip_pipeline *p) {
 	{ std::unique_lock<std::mutex> lock(p->m); p->cv_ready.notify_all(); }
 	if (p->gpu.joinable()) p->gpu.join();
 	(void) hipSetDevice(p->device);
-	for (Job *j : p->todo) delete j;
-	for (std::deque<Job *> *q : {&p->ready, &p->lf_pending}) for (Job *j : *q) { if (j->af) { (void) hipDeviceSynchronize(); j40hip_aframe_free(j->af); } delete j; }
-	for (LfFlight &fl : p->lf_flights) { for (Job *j : fl.jobs) { if (j->af) { (void) hipDeviceSynchronize(); j40hip_aframe_free(j->af); } delete j; } if (fl.stream) (void) hipStreamDestroy(fl.stream); }
+	// (images that never ran: a thread asleep in j40hip_pipeline_run on one of them is woken with "!gpu" rather than left there)
+	auto abandon = [](Job *j) { if (Waiter *w = j->waiter) { std::lock_guard<std::mutex> wl(w->m); w->status = E_GPU; w->done = true; w->cv.notify_one(); } delete j; };
+	for (Job *j : p->todo) abandon(j);
+	for (std::deque<Job *> *q : {&p->ready, &p->lf_pending}) for (Job *j : *q) { if (j->af) { (void) hipDeviceSynchronize(); j40hip_aframe_free(j->af); } abandon(j); }
+	for (LfFlight &fl : p->lf_flights) { for (Job *j : fl.jobs) { if (j->af) { (void) hipDeviceSynchronize(); j40hip_aframe_free(j->af); } abandon(j); } if (fl.stream) (void) hipStreamDestroy(fl.stream); }
 	for (Slot &s : p->slots) {
 		for (hipEvent_t e : s.group_ev) if (e && e != s.kdone) (void) hipEventDestroy(e);
 		if (s.kdone) (void) hipEventDestroy(s.kdone);
