@@ -114,6 +114,8 @@ struct j40hip_pipeline {
 	std::condition_variable cv_todo, cv_ready, cv_done;
 	std::deque<Job *> todo, ready, lf_pending;   // lf_pending: prepared, their LfGroup streams still to be launched on the device
 	LfFlight lf_flights[4];
+	int lf_flights_used = 4;            // how many of them launch (J40HIP_LF_FLIGHTS); a launch carries up to lf_flight_frames frames
+	int64_t lf_flight_frames = 0;
 	std::vector<uint32_t> results;      // by ticket
 	std::vector<uint8_t> finished;      // by ticket
 	int64_t submitted = 0, completed = 0, resident = 0, parsing = 0, in_flight_frames = 0;
@@ -441,9 +443,10 @@ void gpu_main(j40hip_pipeline *p) {
 			bool lf_flying = false;
 			for (const LfFlight &fl : p->lf_flights) lf_flying = lf_flying || fl.busy;
 			const bool lf_go = !p->lf_pending.empty() && ((int64_t) p->lf_pending.size() >= p->batch_frames || (!lf_flying && now_ms() - p->lf_pending_since > 5.0) || p->stop || (p->todo.empty() && p->parsing == 0));
-			if (lf_go) for (LfFlight &fl : p->lf_flights) if (!fl.busy) {
+			if (lf_go) for (int fi = 0; fi < p->lf_flights_used; ++fi) if (!p->lf_flights[fi].busy) {
+				LfFlight &fl = p->lf_flights[fi];
 				std::vector<j40hip_aframe *> frames;
-				while (!p->lf_pending.empty() && (int64_t) fl.jobs.size() < 2 * p->batch_frames) { fl.jobs.push_back(p->lf_pending.front()); frames.push_back(p->lf_pending.front()->af); p->lf_pending.pop_front(); }
+				while (!p->lf_pending.empty() && (int64_t) fl.jobs.size() < p->lf_flight_frames) { fl.jobs.push_back(p->lf_pending.front()); frames.push_back(p->lf_pending.front()->af); p->lf_pending.pop_front(); }
 				if (!fl.alf) fl.alf = j40hip_alf_create(p->device);
 				const double ta = now_ms();
 				const uint32_t e = fl.alf ? j40hip_alf_launch(fl.alf, frames.data(), (int) frames.size(), fl.stream) : E_GPU;
@@ -542,6 +545,14 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 		// (a frame in this stage holds about 12 MB of device memory; eight batches' worth, at most 2048 frames or two batches')
 		p->lf_cap = p->lf_mode == 2 ? 0 : std::min<int64_t>((int64_t) p->batch_frames * 8, std::max<int64_t>(2048, (int64_t) p->batch_frames * 2));
 		if (const char *e = getenv("J40HIP_LF_CAP")) p->lf_cap = atoll(e);
+		// LfGroup launches in flight at once, and frames per launch. A launch lasts 0.4-0.8 s whatever it carries and occupies a hardware
+		// queue of its own for that long; with four of them active beside the batches' streams, the pixel-kernel streams and the copy
+		// stream the process has more active queues than the device schedules at once, and the copies back -- blit kernels on their
+		// queue -- crawled (2.6-5.3 s per 256-frame batch instead of 0.6 s for the first twenty seconds of a long run, until the
+		// LfGroup stage had run ahead: DESIGN.md section 5). Two flights of up to four batches' worth each.
+		p->lf_flights_used = 2; p->lf_flight_frames = (int64_t) p->batch_frames * 4;
+		if (const char *e = getenv("J40HIP_LF_FLIGHTS")) p->lf_flights_used = std::max(1, std::min(4, atoi(e)));
+		if (const char *e = getenv("J40HIP_LF_FLIGHT_FRAMES")) p->lf_flight_frames = std::max<int64_t>(1, atoll(e));
 		p->slots.resize((size_t) p->max_in_flight + 1);
 		for (Slot &s : p->slots) {
 			bool made = false;
