@@ -72,27 +72,38 @@ std::shared_ptr<StaticEntry> static_tables_for(const Frame &fr, int device) {
 // This thread's pinned staging buffers. A buffer is free again once the copy out of it has completed -- which can take long after
 // the call returned (the copy waits its turn behind whatever occupies the stream's hardware queue) -- and the thread must never wait
 // for the device: it takes the first free buffer, and makes another one when none is free.
-struct AStage { PinnedStage mem; hipEvent_t done = nullptr; bool pending = false; };
+struct AStage { PinnedStage mem; hipEvent_t done = nullptr; bool pending = false; uint64_t seq = 0; };
 thread_local std::vector<std::unique_ptr<AStage>> t_astages;   // (no destructor work: j40hip_astage_release, or the process ends)
+thread_local uint64_t t_astage_seq = 0;
 thread_local FrontPlan t_front;
 // J40HIP_ASYNC_TIMING=1: where this thread's host stage spends its time (ms; printed when the thread lets go of its staging)
 thread_local double t_prof[8]; thread_local int64_t t_prof_frames = 0;
 double prof_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// At most J40HIP_STAGE_BUFFERS (6) buffers per thread; when all of them are still being copied out the thread sleeps on the oldest.
+// (Round 3 let a thread make up to 64: when a run floods the pipeline -- thousands of frames queued at once -- every worker kept
+// pinning new 12 MB buffers, 40 and more each, for the first twenty seconds, and while memory is being pinned the copies of pixels
+// back to the host crawl: 2.6-5.3 s per 256-frame batch instead of 0.6 s)
 AStage *astage_acquire(size_t bytes) {
+	static const size_t cap = [] { const char *e = getenv("J40HIP_STAGE_BUFFERS"); return (size_t) (e && atoi(e) > 0 ? atoi(e) : 6); }();
 	for (auto &s : t_astages) {
 		if (s->pending && hipEventQuery(s->done) != hipSuccess) { (void) hipGetLastError(); continue; }
 		s->pending = false;
+		s->seq = ++t_astage_seq;
 		return s->mem.reserve(bytes, 0) ? s.get() : nullptr;
 	}
-	if (t_astages.size() >= 64) {   // (never seen: the pipeline bounds the frames in flight) wait for the oldest
+	if (t_astages.size() >= cap) {   // wait for the one whose copy was enqueued first
 		AStage *s = t_astages.front().get();
+		for (auto &o : t_astages) if (o->seq < s->seq) s = o.get();
 		(void) hipEventSynchronize(s->done); s->pending = false;
+		s->seq = ++t_astage_seq;
 		return s->mem.reserve(bytes, 0) ? s : nullptr;
 	}
 	std::unique_ptr<AStage> s(new AStage());
 	if (hipEventCreateWithFlags(&s->done, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
-	if (!s->mem.reserve(bytes, 0)) { (void) hipEventDestroy(s->done); return nullptr; }
+	// (full size at once: a buffer that grows is a buffer pinned again)
+	if (!s->mem.reserve(std::max(bytes, (size_t) 16 << 20), 0)) { (void) hipEventDestroy(s->done); return nullptr; }
+	s->seq = ++t_astage_seq;
 	t_astages.push_back(std::move(s));
 	return t_astages.back().get();
 }
