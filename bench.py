@@ -188,7 +188,7 @@ def main():
     ap.add_argument("--queued-batch", type=int, default=512, help="frames per entropy launch of the `k_hf_lanes_queued` section (0: skip it)")
     ap.add_argument("--device-output-lf", choices=["auto", "device", "host"], default="device")
     ap.add_argument("--host-buffers", type=int, default=0, help="pinned landing buffers for the pixels (default: one per distinct stream, at most 64; 24 per rank with several ranks)")
-    ap.add_argument("--lf-streams", choices=["auto", "device", "host"], default="device",
+    ap.add_argument("--lf-streams", choices=["auto", "device", "host"], default="auto",
                     help="who decodes the LfGroup streams of the batched frames: the GPU (k_lf_lanes, a lane per section), the host worker threads, or decided frame by frame (auto: the GPU up to its stage's capacity, the host threads beyond)")
     ap.add_argument("--resident-batch", type=int, default=256, help="frames of the device-resident section (kernels only, as round 1 measured)")
     ap.add_argument("--stream", choices=["forward", "coefficient"], default="forward",
