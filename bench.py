@@ -188,7 +188,7 @@ def main():
     ap.add_argument("--queued-batch", type=int, default=512, help="frames per entropy launch of the `k_hf_lanes_queued` section (0: skip it)")
     ap.add_argument("--device-output-lf", choices=["auto", "device", "host"], default="device")
     ap.add_argument("--host-buffers", type=int, default=0, help="pinned landing buffers for the pixels (default: one per distinct stream, at most 64; 24 per rank with several ranks)")
-    ap.add_argument("--lf-streams", choices=["auto", "device", "host"], default="auto",
+    ap.add_argument("--lf-streams", choices=["auto", "device", "host"], default="device",
                     help="who decodes the LfGroup streams of the batched frames: the GPU (k_lf_lanes, a lane per section), the host worker threads, or decided frame by frame (auto: the GPU up to its stage's capacity, the host threads beyond)")
     ap.add_argument("--resident-batch", type=int, default=256, help="frames of the device-resident section (kernels only, as round 1 measured)")
     ap.add_argument("--stream", choices=["forward", "coefficient"], default="forward",
@@ -242,7 +242,14 @@ def main():
 
     W, H, B = args.width, args.height, args.batch
     quota = cpu_quota()
-    threads = args.host_threads or max(2, quota // world)
+    # Worker threads of the pipelines whose LfGroup streams the GPU decodes (the timed region, `device_output`): FOUR, not the quota.
+    # A frame's host stage is 1-2 ms, so two threads already feed the 430 frames/s the PCIe link takes and four the 1 450 the
+    # device takes -- and sixteen of them, waking together after every batch beside the launching thread and the HIP runtime's own
+    # threads, run the container into its CPU quota: the cgroup then throttles every thread of the process (cpu.stat: 221 of 1 282
+    # periods throttled in a long run), and the copies back, whose completion the runtime handles on the host, crawl -- 6.6 Gpx/s
+    # with 16 threads against 12.5 with 4 and 13.4 with 2 on the same box, same run (gpurun_out/r04n).
+    threads = args.host_threads or max(2, min(4, quota // world))
+    threads_host_lf = args.host_threads or max(2, quota // world)   # (pipelines whose worker threads decode the LfGroup streams themselves)
     D = max(1, min(args.distinct, B))
     # every rank decodes its own batch of the same D streams: rank 0 generates them with all the CPUs the container has (an 8K
     # encode takes ~10 s of one core), the other ranks wait and read them from build/streams
@@ -304,7 +311,7 @@ def main():
         if args.queued_batch > 0 and world == 1:
             Bq = args.queued_batch
             qbufs = [bufs[i % D] for i in range(Bq)]; qsizes = [len(datas[i % D]) for i in range(Bq)]; qouts = [outs[i % nd] for i in range(Bq)]
-            qpipe = j40_amd.Pipeline(local_rank, threads, Bq, 1, lf_streams="host")
+            qpipe = j40_amd.Pipeline(local_rank, threads_host_lf, Bq, 1, lf_streams="host")
             run_pipeline_steps(qpipe, qbufs, qsizes, qouts, W * 4, True, 1, torch, dev, None)
             eq, tk = run_pipeline_steps(qpipe, qbufs, qsizes, qouts, W * 4, True, 2, torch, dev, None)
             sq = qpipe.stats()
@@ -427,7 +434,7 @@ def main():
         # runs beside the kernel). The timed region above overlaps it with the previous batch's pixel kernels and the lane decoder of
         # the LfGroup streams, which is what makes `value` -- and stretches the kernel. Same frames, same launch geometry.
         outs2 = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(B)]
-        alone = j40_amd.Pipeline(local_rank, threads, min(args.pipe_batch, B), 1, lf_streams="host")
+        alone = j40_amd.Pipeline(local_rank, threads_host_lf, min(args.pipe_batch, B), 1, lf_streams="host")
         run_pipeline_steps(alone, step_bufs, step_sizes, outs2, W * 4, True, 1, torch, dev, None)
         run_pipeline_steps(alone, step_bufs, step_sizes, outs2, W * 4, True, 2, torch, dev, None)
         sa = alone.stats()

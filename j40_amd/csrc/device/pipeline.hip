@@ -35,6 +35,8 @@
 #include "async.hpp"
 #include "runtime_shared.hpp"
 
+static int cpu_quota();   // (CPUs' worth of time the container may use; defined with the serving pipeline below)
+
 namespace {
 
 constexpr uint32_t E_GPU = ('!' << 24) | ('g' << 16) | ('p' << 8) | 'u';
@@ -579,7 +581,9 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 			}
 		}
 		if (!*err) {
-			if (host_threads < 1) host_threads = (int) std::max(1u, std::thread::hardware_concurrency());
+			// (default: the container's CPU quota less two, at most 16 -- never the visible CPU count: a quota-limited container that runs
+			// more busy threads than its quota gets ALL its threads throttled, the HIP runtime's included)
+			if (host_threads < 1) host_threads = std::max(2, std::min(16, cpu_quota() - 2));
 			if (host_threads > 128) host_threads = 128;   // (each worker owns tens of MB of pinned staging; more than this was never exercised)
 			p->gpu = std::thread(gpu_main, p);
 			for (int i = 0; i < host_threads; ++i) p->workers.emplace_back(worker_main, p, i);
