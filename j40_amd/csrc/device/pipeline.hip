@@ -703,7 +703,7 @@ void j40hip_pipeline_reset_stats(j40hip_pipeline *p) {
 // ---- the process-wide pipelines behind the public API (api.cpp): j40_next_frame hands its image to the pipeline of its device when
 // several threads are inside the API at once (or J40HIP_SERVE=1), so that callers of the unchanged ten-function sequence share
 // batches. One per device, made on first use, taken down by j40hip_shutdown. Knobs (environment, read once): J40HIP_SERVE_THREADS
-// (host threads; default: the container's CPU quota less four), J40HIP_SERVE_BATCH (frames per entropy launch, 64), J40HIP_SERVE_IN_FLIGHT (3),
+// (host threads; default: half the container's CPU quota), J40HIP_SERVE_BATCH (frames per entropy launch, 64), J40HIP_SERVE_IN_FLIGHT (3),
 // J40HIP_SERVE_LF (host | device | auto: who decodes the LfGroup streams; host -- a frame must not wait 0.4 s for the lane decoder),
 // J40HIP_SERVE_WAIT_MS (how long a prepared frame waits for a fuller batch, 3).
 static std::mutex g_serve_mutex;
@@ -727,9 +727,10 @@ j40hip_pipeline *j40hip_serve_pipeline(int device, uint32_t *err) {
 	std::lock_guard<std::mutex> lock(g_serve_mutex);
 	if (g_serve[device]) return g_serve[device];
 	auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; };
-	// (four CPUs of the quota stay with the callers, the launching thread and the HIP runtime's own threads: with every CPU decoding
-	// LfGroup streams the copies back were submitted late -- 9.6 Gpixel/s with 12 of 16 against 6.4 with 16)
-	const int threads = std::max(1, env_int("J40HIP_SERVE_THREADS", std::max(2, cpu_quota() - 4)));
+	// (half of the container's CPU quota: the callers, the launching thread and the HIP runtime's own threads need the rest -- a
+	// process that runs into its quota has ALL its threads throttled and the copies back crawl. 64 callers over 8K streams on a
+	// 16-CPU quota: 9.9 Gpixel/s with 6 or 8 pipeline threads, 8.2 with 12, 6.4 with 16, 6.2 with 4)
+	const int threads = std::max(1, env_int("J40HIP_SERVE_THREADS", std::max(2, cpu_quota() / 2)));
 	uint32_t lf = 2;
 	if (const char *e = getenv("J40HIP_SERVE_LF")) lf = !strcmp(e, "device") ? 1u : !strcmp(e, "auto") ? 0u : 2u;
 	j40hip_pipeline *p = j40hip_pipeline_create_ex(device, threads, std::max(1, env_int("J40HIP_SERVE_BATCH", 64)), env_int("J40HIP_SERVE_IN_FLIGHT", 6), lf | 8u, err);
