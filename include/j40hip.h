@@ -286,6 +286,9 @@ J40HIP_API void j40hip_frame_mark_idle(j40hip_frame *f);
  *      are decoded by a worker through the single-frame entry points. The serving shape of j40_from_memory + j40_next_frame +
  *      j40_frame_pixels_u8x4 for many images. ---- */
 typedef struct j40hip_pipeline j40hip_pipeline;
+/* host_threads < 1: the container's CPU quota (cgroup cpu.max) less two, at most 16 -- never the visible CPU count. Keep the busy threads
+ * of the process below its quota: a cgroup that runs into it throttles every thread of the process, the HIP runtime's included, and
+ * the copies back to the host then crawl. With the LfGroup streams on the GPU a frame's host stage is 1-2 ms: two to four threads. */
 J40HIP_API j40hip_pipeline *j40hip_pipeline_create(int device, int host_threads, int batch_frames, int max_in_flight, uint32_t *err);
 /* flags bits 0-1: who decodes the LfGroup streams (j40.h:6722-6790) of the batched frames: 0 decided frame by frame (the host
  * threads keep them while the device has batches queued up, else the device takes them), 1 always the device (k_lf_groups),
