@@ -265,11 +265,11 @@ j40_pixels_u8x4 j40_frame_pixels_u8x4(const j40_frame *frame, int32_t channel) {
 		"111111111111111111111", "100011111111111111111", "101111111111111111111", "100010001000100010001",
 		"101110111011101010111", "100010111011100010111", "111111111111111111111"};
 	static uint8_t error_pixels[21 * 7 * 4];
-	static bool error_pixels_ready = false;
-	if (!error_pixels_ready) {
+	static const bool error_pixels_ready = [] {   // (a function-local static: filled once, also with many threads in here)
 		for (int y = 0; y < 7; ++y) for (int x = 0; x < 21; ++x) { uint8_t *p = error_pixels + (y * 21 + x) * 4; p[0] = 255; p[1] = 0; p[2] = 0; p[3] = ERR_ROWS[y][x] == '1' ? 255 : 0; }
-		error_pixels_ready = true;
-	}
+		return true;
+	}();
+	(void) error_pixels_ready;
 	const j40_pixels_u8x4 ERROR_PIXELS = {21, 7, 21 * 4, error_pixels};
 	if (!frame || frame->magic != FRAME_MAGIC) return ERROR_PIXELS;
 	j40__inner *inner = frame->inner;

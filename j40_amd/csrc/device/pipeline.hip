@@ -5,17 +5,17 @@
 //                         reference's j40.h:8175-8192 work) and the first bits of every LfGroup section; the front of the plan and the
 //                         codestream go to the device with one asynchronous copy, and the thread moves on -- it never waits for the
 //                         device. Whether the thread also decodes the frame's LfGroup streams (j40.h:6722-6790) or leaves them to
-//                         k_lf_groups is decided frame by frame: when the device already has batches queued up the thread keeps the
-//                         streams (the CPU is the faster decoder of one stream), otherwise it hands them over (so that frames reach
-//                         the device sooner).
+//                         the device's lane decoder (k_lf_lanes) is the pipeline's mode or, in mode 0, decided frame by frame
+//                         (j40hip_pipeline: lf_mode).
 //                         Every other frame (Modular, a single section, extra channels, ...) the thread decodes on its own through
 //                         the single-frame entry points (j40hip_frame_parse / upload / decode), on its own stream.
 //   one GPU thread        collects prepared frames into batches; per batch ONE enqueue of LfGroup streams -> plan build -> LfGroup tail
 //                         -> entropy decode -> pixels -> verdict on the batch slot's stream (j40hip_abatch_launch), then -- host
-//                         output -- the copy back on the same stream, so that it overlaps the kernels of the next batch on the other
-//                         slot's stream
-//   completion            one 16-byte verdict per frame comes back with the batch; frames the device wants decoded again (an LfGroup
-//                         header the device decoder does not take, an event region that overflowed) take the single-frame path
+//                         output -- the copies back on the pipeline's copy stream behind the batch's kernels, in groups of frames
+//                         with an event each; the thread polls, it never sleeps on the device while something could be enqueued
+//   completion            one 16-byte verdict per frame comes back with the batch's kernels (the frames' device memory goes back to the
+//                         cache then); a frame is complete when its group's copies are through; frames the device wants decoded again
+//                         (an LfGroup header the device decoder does not take, an event region that overflowed) take the single-frame path
 //
 // The reference decodes one image on one core (j40.h:8034: its only threading hook is commented out); this is the serving
 // shape of the same work: frames are independent, so the host part scales over cores and the device part over a batch.
@@ -638,19 +638,33 @@ uint32_t j40hip_pipeline_run(j40hip_pipeline *p, const void *buf, size_t size, j
 	if (!p || !buf || !alloc) return E_RNGE;
 	if (p->worker_errors.load()) return E_GPU;
 	Waiter w;
+	Job *j = nullptr;
 	try {
-		Job *j = new Job();
+		j = new Job();
 		j->buf = buf; j->size = size; j->alloc = alloc; j->alloc_ctx = ctx; j->waiter = &w; j->ticket = -1;
 		std::unique_lock<std::mutex> lock(p->m);
 		++p->submitted;
 		if (p->first_submit_ms == 0) p->first_submit_ms = now_ms();
 		p->todo.push_back(j);
 		p->cv_todo.notify_one();
-	} catch (const std::exception &) { return E_MEM; }
+	} catch (const std::exception &) { delete j; return E_MEM; }
 	std::unique_lock<std::mutex> wl(w.m);
 	while (!w.done) {
 		w.cv.wait_for(wl, std::chrono::milliseconds(200));
-		if (!w.done && p->worker_errors.load()) { wl.unlock(); std::unique_lock<std::mutex> lock(p->m); p->cv_ready.notify_all(); lock.unlock(); wl.lock(); }
+		if (w.done || !p->worker_errors.load()) continue;
+		// a pipeline thread could not start (no device, no stream): an image still in the queue may never be taken -- it comes out
+		// again and fails with "!gpu"; one that a thread did take completes as usual
+		wl.unlock();
+		{
+			std::unique_lock<std::mutex> lock(p->m);
+			for (auto it = p->todo.begin(); it != p->todo.end(); ++it) if (*it == j) {
+				p->todo.erase(it); ++p->completed; p->cv_done.notify_all();
+				delete j;
+				return E_GPU;
+			}
+			p->cv_ready.notify_all();
+		}
+		wl.lock();
 	}
 	return w.status;
 }
@@ -703,9 +717,10 @@ void j40hip_pipeline_reset_stats(j40hip_pipeline *p) {
 // ---- the process-wide pipelines behind the public API (api.cpp): j40_next_frame hands its image to the pipeline of its device when
 // several threads are inside the API at once (or J40HIP_SERVE=1), so that callers of the unchanged ten-function sequence share
 // batches. One per device, made on first use, taken down by j40hip_shutdown. Knobs (environment, read once): J40HIP_SERVE_THREADS
-// (host threads; default: half the container's CPU quota), J40HIP_SERVE_BATCH (frames per entropy launch, 64), J40HIP_SERVE_IN_FLIGHT (3),
+// (host threads; default: half the container's CPU quota), J40HIP_SERVE_BATCH (frames per entropy launch, 64), J40HIP_SERVE_IN_FLIGHT (6),
 // J40HIP_SERVE_LF (host | device | auto: who decodes the LfGroup streams; host -- a frame must not wait 0.4 s for the lane decoder),
-// J40HIP_SERVE_WAIT_MS (how long a prepared frame waits for a fuller batch, 3).
+// J40HIP_SERVE_WAIT_MS (how long a prepared frame waits for a fuller batch while a slot is free, 100: with blocking callers the
+// queue stops growing when every caller has an image in it, and "nothing else is coming" launches the batch at once).
 static std::mutex g_serve_mutex;
 static j40hip_pipeline *g_serve[16] = {nullptr};
 
