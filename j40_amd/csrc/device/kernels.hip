@@ -6,8 +6,8 @@
 //                       NB varblocks per workgroup (replaces j40__dequant_hf, j40.h:7053,
 //                       j40__combine_vardct_from_lf_group, j40.h:7099, j40__render_to_u8x4_rgba, j40.h:7910)
 //   k_vardct_special    K2s: the 8x8 "special" transforms (Hornuss, DCT2x2, DCT4x4, DCT4x8/8x4, AFV)
-//   k_vardct_large      K2l: 128/256-sized transforms: the tile in an HBM scratch, the 1-D transforms taken through LDS a panel of
-//                       vectors at a time (idct_panels)
+//   k_vardct_large      K2l: 128/256-sized transforms (large_dev.h): the top levels of the recursion over the tile in LDS, 64-point
+//                       sub-vectors in registers; tiles up to 128x128 live in LDS, 256-sized ones in an HBM scratch
 //
 // Compiled with -ffp-contract=off: the float path has to keep the reference's operation order.
 #include <hip/hip_runtime.h>
@@ -20,6 +20,7 @@
 #include "idct_dev.h"
 #include "vardct_dev.h"
 #include "special8_dev.h"
+#include "large_dev.h"
 #include "hf_uni_dev.h"
 #include "kernels.h"
 
@@ -690,7 +691,6 @@ __device__ void idct_sweeps(Ptr A, Ptr B, int32_t t, int32_t ncols, int32_t stri
 // the transposing copy does not hit one bank). The result goes to dst, same layout; src is left alone. Every value takes the same
 // operations in the same order as in idct_sweeps over the HBM scratch (15 levels of 256-point butterflies = 15 round trips through
 // HBM per dimension there, one here).
-constexpr int LARGE_PANEL_FLOATS = 16384 + 256;
 __device__ void idct_panels(const float *src, float *dst, int32_t t, int32_t nvec, int32_t stride_k, int32_t stride_col, J40_LDS float *lds) {
 	const int32_t N = 1 << t, M = min(nvec, 16384 >> t), P = M + 1;
 	const int32_t tid = threadIdx.x, nthreads = blockDim.x;
@@ -706,13 +706,22 @@ __device__ void idct_panels(const float *src, float *dst, int32_t t, int32_t nve
 	}
 }
 
-template <bool BATCH>
+// what large_dev.h's passes run on: every lane makes the call, a barrier follows (stores to the workgroup's scratch in HBM are
+// visible to its other lanes behind it)
+struct WorkgroupExec {
+	template <class F> __device__ __forceinline__ void run(F f) { f((int32_t) threadIdx.x, (int32_t) blockDim.x); __threadfence_block(); __syncthreads(); }
+};
+
+// REG64: the top levels of the recursion in LDS, 64-point sub-vectors in registers (large_dev.h); a tile that fits one LDS buffer
+// (128x128, 128x64, 64x128) takes both dimensions there and makes ONE trip through the scratch per channel. !REG64: round 3's
+// form -- every level of the butterflies as a sweep over an LDS panel, two trips per channel (J40HIP_LARGE_IDCT=sweeps).
+template <bool BATCH, bool REG64>
 __global__ void __launch_bounds__(256) k_vardct_large(DevPlan plan_arg, const DevVarblock *list, int32_t count, float *scratch, uint8_t *rgba, size_t stride_bytes, const K2Frame *batch, const int32_t *tile_prefix, int32_t nframes,
 		int32_t class_a, int32_t class_b) {
 	const int32_t tid = threadIdx.x, nthreads = blockDim.x;
 	J40_STAGE_SRGB_THRESHOLDS(f);
 	float *A = scratch + (size_t) blockIdx.x * 6 * 65536, *B = A + 3 * 65536;  // [3][size] each: the workgroup's own
-	extern __shared__ __attribute__((aligned(16))) float large_lds[];   // 2 * LARGE_PANEL_FLOATS (idct_panels)
+	extern __shared__ __attribute__((aligned(16))) float large_lds[];   // 2 * LARGE_PANEL_FLOATS
 	J40_LDS float *panels = (J40_LDS float *) large_lds;
 	for (K2Iter it = k2_begin<BATCH>(tile_prefix, nframes); ; ) {
 		int32_t frame, first;
@@ -722,43 +731,50 @@ __global__ void __launch_bounds__(256) k_vardct_large(DevPlan plan_arg, const De
 		const DevVarblock vb = list[first];
 		const int32_t log_rows = DEV_DCT_SELECT[vb.dctsel][0], log_columns = DEV_DCT_SELECT[vb.dctsel][1];
 		const int32_t R = 1 << log_rows, C = 1 << log_columns, size = R * C;
-		const int32_t long_side = R > C ? R : C, vh8 = (R < C ? R : C) / 8, vw8 = long_side / 8;
-		const int32_t param_idx = vb.dctsel == 21 ? 13 : vb.dctsel <= 23 ? 14 : vb.dctsel == 24 ? 15 : 16;
-		const float *dq = plan.pool_f32 + f.dq_off[param_idx];
 		const ColourConsts cc = load_colour_consts(f);
 		const VbGeom g = varblock_geometry(plan, vb);
-		if (f.sparse_coeffs) {   // the tiles live in the HBM scratch here (stores are visible to the workgroup after a barrier + fence)
-			for (int32_t i = tid; i < size; i += nthreads) { A[i] = 0.0f; A[65536 + i] = 0.0f; A[2 * 65536 + i] = 0.0f; }
-			__threadfence_block(); __syncthreads();
-			const uint16_t *order = plan.pool_u16 + f.order_off[DEV_DCT_SELECT[vb.dctsel][2] * 3];
-			const TileMap map = {R, C, C, 0};
-			const float qbias[3] = {f.quant_bias[0], f.quant_bias[1], f.quant_bias[2]};
-			tile_scatter_events(plan, g, plan.block_events + 4 * (size_t) vb.blk, order, plan.pool_f32 + f.dq_scan_off[param_idx], size, map, A, 65536, qbias, f.quant_bias_num, tid, nthreads);
-			tile_fill_llf(plan, g, long_side, vh8, vw8, map, A, 65536, f.kx_lf, f.kb_lf, tid, nthreads);
-			__threadfence_block();
+		LargeSamples S;
+		if constexpr (REG64) {
+			WorkgroupExec ex;
+			S = large_block(ex, plan, vb, g, panels, A, B, c_half_secants);
 		} else {
-			for (int32_t i = tid; i < size; i += nthreads) {
-				float v[3];
-				load_coeff3(plan, g, dq, size, i, long_side, vh8, vw8, v);
-				const int32_t r = C > R ? i / C : i % R, c = C > R ? i % C : i / R;
-				A[r * C + c] = v[0]; A[65536 + r * C + c] = v[1]; A[2 * 65536 + r * C + c] = v[2];
+			const int32_t long_side = R > C ? R : C, vh8 = (R < C ? R : C) / 8, vw8 = long_side / 8;
+			const int32_t param_idx = vb.dctsel == 21 ? 13 : vb.dctsel <= 23 ? 14 : vb.dctsel == 24 ? 15 : 16;
+			const float *dq = plan.pool_f32 + f.dq_off[param_idx];
+			if (f.sparse_coeffs) {   // the tiles live in the HBM scratch here (stores are visible to the workgroup after a barrier + fence)
+				for (int32_t i = tid; i < size; i += nthreads) { A[i] = 0.0f; A[65536 + i] = 0.0f; A[2 * 65536 + i] = 0.0f; }
+				__threadfence_block(); __syncthreads();
+				const uint16_t *order = plan.pool_u16 + f.order_off[DEV_DCT_SELECT[vb.dctsel][2] * 3];
+				const TileMap map = {R, C, C, 0};
+				const float qbias[3] = {f.quant_bias[0], f.quant_bias[1], f.quant_bias[2]};
+				tile_scatter_events(plan, g, plan.block_events + 4 * (size_t) vb.blk, order, plan.pool_f32 + f.dq_scan_off[param_idx], size, map, A, 65536, qbias, f.quant_bias_num, tid, nthreads);
+				tile_fill_llf(plan, g, long_side, vh8, vw8, map, A, 65536, f.kx_lf, f.kb_lf, tid, nthreads);
+				__threadfence_block();
+			} else {
+				for (int32_t i = tid; i < size; i += nthreads) {
+					float v[3];
+					load_coeff3(plan, g, dq, size, i, long_side, vh8, vw8, v);
+					const int32_t r = C > R ? i / C : i % R, c = C > R ? i % C : i / R;
+					A[r * C + c] = v[0]; A[65536 + r * C + c] = v[1]; A[2 * 65536 + r * C + c] = v[2];
+				}
 			}
-		}
-		__syncthreads();
-		for (int ch = 0; ch < 3; ++ch) {
-			idct_panels(A + ch * 65536, B + ch * 65536, log_columns, R, 1, C, panels);   // along c for every r: A -> B
+			__syncthreads();
+			for (int ch = 0; ch < 3; ++ch) {
+				idct_panels(A + ch * 65536, B + ch * 65536, log_columns, R, 1, C, panels);   // along c for every r: A -> B
+				__threadfence_block(); __syncthreads();
+				idct_panels(B + ch * 65536, A + ch * 65536, log_rows, C, C, 1, panels);      // along r for every x: B -> A
+			}
 			__threadfence_block(); __syncthreads();
-			idct_panels(B + ch * 65536, A + ch * 65536, log_rows, C, C, 1, panels);      // along r for every x: B -> A
+			for (int ch = 0; ch < 3; ++ch) { S.p[ch] = A + ch * 65536; S.pitch[ch] = C; }
 		}
-		__threadfence_block(); __syncthreads();
 		for (int32_t i = tid; i < size; i += nthreads) {
-			const int32_t y = i / C, x = i - y * C;
+			const int32_t y = i >> log_columns, x = i & (C - 1);
 			if (y >= g.effh || x >= g.effw) continue;
-			const uint32_t px = xyb_to_rgba8(A[i], A[65536 + i], A[2 * 65536 + i], cc, srgb_thr);
+			const uint32_t px = xyb_to_rgba8(S.p[0][y * S.pitch[0] + x], S.p[1][y * S.pitch[1] + x], S.p[2][y * S.pitch[2] + x], cc, srgb_thr);
 			*(uint32_t *) (rgba + (size_t) (g.py + y) * stride_bytes + (size_t) (g.px + x) * 4) = px;
 		}
 		if (!BATCH) break;
-		__threadfence_block(); __syncthreads();   // the next block reuses the scratch
+		__threadfence_block(); __syncthreads();   // the next block reuses the scratch and the LDS tiles
 	}
 }
 
@@ -849,12 +865,21 @@ static void launch_vardct_class_impl(const DevPlan &plan, int32_t dctsel, const 
 			constexpr size_t lds_bytes = 2 * (size_t) LARGE_PANEL_FLOATS * sizeof(float);
 			static bool configured = false;
 			if (!configured) {
-				(void) hipFuncSetAttribute((const void *) k_vardct_large<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
-				(void) hipFuncSetAttribute((const void *) k_vardct_large<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
+				(void) hipFuncSetAttribute((const void *) k_vardct_large<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
+				(void) hipFuncSetAttribute((const void *) k_vardct_large<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
+				(void) hipFuncSetAttribute((const void *) k_vardct_large<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
+				(void) hipFuncSetAttribute((const void *) k_vardct_large<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
 				configured = true;
 			}
-			if (bl.batch) hipLaunchKernelGGL(k_vardct_large<true>, dim3((unsigned) bl.grid), dim3(256), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, bl.tile_prefix, bl.nframes, bl.class_a, bl.class_b);
-			else hipLaunchKernelGGL(k_vardct_large<false>, dim3((unsigned) count), dim3(256), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, nullptr, 1, 0, 0);
+			// (J40HIP_LARGE_IDCT=sweeps: round 3's kernel, every butterfly level as a sweep over an LDS panel -- kept for comparison)
+			static const bool reg64 = [] { const char *e = getenv("J40HIP_LARGE_IDCT"); return !(e && !strcmp(e, "sweeps")); }();
+			if (bl.batch) {
+				if (reg64) hipLaunchKernelGGL((k_vardct_large<true, true>), dim3((unsigned) bl.grid), dim3(256), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, bl.tile_prefix, bl.nframes, bl.class_a, bl.class_b);
+				else hipLaunchKernelGGL((k_vardct_large<true, false>), dim3((unsigned) bl.grid), dim3(256), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, bl.tile_prefix, bl.nframes, bl.class_a, bl.class_b);
+			} else {
+				if (reg64) hipLaunchKernelGGL((k_vardct_large<false, true>), dim3((unsigned) count), dim3(256), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, nullptr, 1, 0, 0);
+				else hipLaunchKernelGGL((k_vardct_large<false, false>), dim3((unsigned) count), dim3(256), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, nullptr, 1, 0, 0);
+			}
 		}
 		break;
 	}

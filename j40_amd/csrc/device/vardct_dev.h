@@ -57,6 +57,16 @@ struct TileMap {
 	}
 };
 
+// the same for tiles whose power-of-two sides are known at run time only (k_vardct_large): shifts, no division per event
+struct TileMapLog {
+	int32_t log_rows, log_columns, pitch;
+	J40_DEVM int32_t at(int32_t i) const {
+		const bool wide = log_columns > log_rows;
+		const int32_t r = wide ? i >> log_columns : i & ((1 << log_rows) - 1), c = wide ? i & ((1 << log_columns) - 1) : i >> log_rows;
+		return r * pitch + c;
+	}
+};
+
 // `be`: the block's entry of DevPlan::block_events (first event, counts in emission order Y, X, B). `dq_scan`: the weights in
 // scan order (DevFrame::dq_scan_off). Chroma-from-luma rides along: a Y coefficient also contributes kx * Y to X and kb * Y to B
 // at its position, so X and B are accumulated (x + kx * y has two addends, and IEEE addition commutes, so the order in which
@@ -69,9 +79,9 @@ J40_DEV void tile_add(float *p, float v) {
 #endif
 }
 // event `e` (0-based within the block) of the block whose entry of DevPlan::block_events is `be`
-template <typename BE, typename GEOM, typename TILE, typename ORD, typename DQ>
+template <typename BE, typename GEOM, typename TILE, typename ORD, typename DQ, typename MAP>
 J40_DEV void tile_scatter_one(const DevPlan &plan, const GEOM &g, const BE &be, uint32_t e, ORD order /* pass 0: [3][n] */, DQ dq_scan /* [3][n] */, int32_t n,
-		const TileMap &map, TILE tile, int32_t cstride, const float quant_bias[3], float quant_bias_num) {
+		const MAP &map, TILE tile, int32_t cstride, const float quant_bias[3], float quant_bias_num) {
 	const uint32_t first = be[0], n0 = be[1], n1 = be[2];
 	const int32_t c = e < n0 ? 1 : e < n0 + n1 ? 0 : 2;   // events come in the order the channels are coded: Y, X, B
 	const CoeffEvent ev = plan.events[first + e];
@@ -84,8 +94,9 @@ J40_DEV void tile_scatter_one(const DevPlan &plan, const GEOM &g, const BE &be, 
 		tile_add(&tile[2 * cstride + at], v * g.kb_hf);
 	} else tile_add(&tile[c * cstride + at], v);
 }
+template <typename MAP>
 J40_DEV void tile_scatter_events(const DevPlan &plan, const VbGeom &g, const uint32_t be[4], const uint16_t *order, const float *dq_scan, int32_t n,
-		const TileMap &map, float *tile, int32_t cstride, const float quant_bias[3], float quant_bias_num, int32_t lane, int32_t nlanes) {
+		const MAP &map, float *tile, int32_t cstride, const float quant_bias[3], float quant_bias_num, int32_t lane, int32_t nlanes) {
 	const uint32_t total = be[1] + be[2] + be[3];
 	for (uint32_t e = (uint32_t) lane; e < total; e += (uint32_t) nlanes) tile_scatter_one(plan, g, be, e, order, dq_scan, n, map, tile, cstride, quant_bias, quant_bias_num);
 }
@@ -118,12 +129,43 @@ J40_DEV void tiles_fill_llf(const DevPlan &plan, const VbGeom *geom, int32_t nb,
 	}
 }
 
-J40_DEV void tile_fill_llf(const DevPlan &plan, const VbGeom &g, int32_t long_side, int32_t vh8, int32_t vw8, const TileMap &map, float *tile, int32_t cstride, float kx_lf, float kb_lf,
+template <typename MAP>
+J40_DEV void tile_fill_llf(const DevPlan &plan, const VbGeom &g, int32_t long_side, int32_t vh8, int32_t vw8, const MAP &map, float *tile, int32_t cstride, float kx_lf, float kb_lf,
 		int32_t lane, int32_t nlanes) {
 	for (int32_t k = lane; k < vh8 * vw8; k += nlanes) {
 		const int32_t srow = k / vw8, scol = k - srow * vw8, at = map.at(srow * long_side + scol), l = g.llf_base + k;
 		const float lx = plan.llf[0][l], ly = plan.llf[1][l], lb = plan.llf[2][l];
 		tile[at] = lx + ly * kx_lf; tile[cstride + at] = ly; tile[2 * cstride + at] = lb + ly * kb_lf;
+	}
+}
+
+// ONE channel of a block at a time (k_vardct_large's 128x128 tiles: LDS holds one channel with its work buffer, not three): the
+// channel's own events, and for X and B the Y events' chroma-from-luma contributions -- the same two addends per position as in
+// tile_scatter_one, whichever arrives first. `tile`: the channel's tile, zeroed.
+template <typename TILE, typename MAP>
+J40_DEV void tile_scatter_channel(const DevPlan &plan, const VbGeom &g, const uint32_t be[4], int32_t ch, const uint16_t *order, const float *dq_scan, int32_t n,
+		const MAP &map, TILE tile, const float quant_bias[3], float quant_bias_num, int32_t lane, int32_t nlanes) {
+	const uint32_t first = be[0], n0 = be[1], n1 = be[2], total = be[1] + be[2] + be[3];
+	// (Y, X, B in this order: Y's events are wanted by every channel, X's and B's by their own)
+	const uint32_t end = ch == 1 ? n0 : ch == 0 ? n0 + n1 : total;
+	for (uint32_t e = (uint32_t) lane; e < end; e += (uint32_t) nlanes) {
+		const int32_t c = e < n0 ? 1 : e < n0 + n1 ? 0 : 2;
+		if (c != ch && c != 1) continue;   // (B's pass walks over X's events)
+		const CoeffEvent ev = plan.events[first + e];
+		const int32_t pos = (int32_t) coeff_event_pos(ev);
+		const int32_t at = map.at(order[c * n + pos]);
+		const float v = dequant_coeff((float) coeff_event_value(ev), quant_bias[c], quant_bias_num, g.mult[c], dq_scan[c * n + pos]);
+		if (ch == 1) tile[at] = v;
+		else tile_add((float *) &tile[at], c == ch ? v : v * (ch == 0 ? g.kx_hf : g.kb_hf));
+	}
+}
+template <typename TILE, typename MAP>
+J40_DEV void tile_fill_llf_channel(const DevPlan &plan, const VbGeom &g, int32_t ch, int32_t long_side, int32_t vh8, int32_t vw8, const MAP &map, TILE tile, float kx_lf, float kb_lf,
+		int32_t lane, int32_t nlanes) {
+	for (int32_t k = lane; k < vh8 * vw8; k += nlanes) {
+		const int32_t srow = k / vw8, scol = k - srow * vw8, at = map.at(srow * long_side + scol), l = g.llf_base + k;
+		const float ly = plan.llf[1][l];
+		tile[at] = ch == 1 ? ly : ch == 0 ? plan.llf[0][l] + ly * kx_lf : plan.llf[2][l] + ly * kb_lf;
 	}
 }
 

@@ -14,6 +14,7 @@
 #include "../../j40_amd/csrc/device/hf_uni_dev.h"
 #include "../../j40_amd/csrc/device/vardct_dev.h"
 #include "../../j40_amd/csrc/device/special8_dev.h"
+#include "../../j40_amd/csrc/device/large_dev.h"
 #include "../../j40_amd/csrc/device/modular_dev.h"
 #include "../../j40_amd/csrc/device/squeeze_dev.h"
 
@@ -58,6 +59,13 @@ void idct_sweeps_host(float *A, float *B, int32_t t, int32_t ncols, int32_t stri
 		}
 	}
 }
+
+// large_dev.h's passes on the CPU: the calls of a workgroup's 256 lanes one after the other, in an order that changes from phase to
+// phase (a phase in which one lane read what another wrote would show)
+struct HostExec {
+	int phase = 0;
+	template <class F> void run(F f) { if (phase++ & 1) for (int tid = 255; tid >= 0; --tid) f(tid, 256); else for (int tid = 0; tid < 256; ++tid) f(tid, 256); }
+};
 
 template <int N> void idct_rows(float *tile, int rows, int pitch, const float *hs) {  // along c for each r
 	for (int r = 0; r < rows; ++r) { float x[N]; for (int k = 0; k < N; ++k) x[k] = tile[r * pitch + k]; Idct1D<N>::run(x, hs); for (int k = 0; k < N; ++k) tile[r * pitch + k] = x[k]; }
@@ -390,6 +398,19 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 		const bool special = (vb.dctsel >= 1 && vb.dctsel <= 3) || (vb.dctsel >= 12 && vb.dctsel <= 17);
 		const bool large = log_rows > 6 || log_columns > 6;
 		const int P = special ? SP8_PITCH : large ? C : C + 1;   // (the specials' tiles: rows 9 apart, special8_dev.h)
+		// k_vardct_large's whole block (large_dev.h: where the tile lives, the channel-at-a-time scatter of the 128x128 tiles, the recursion's
+		// top levels over 64-point sub-vectors in registers), lane by lane. HOSTSIM_LARGE_SWEEPS=1: the model of round 3's kernel instead
+		// (the tile in the scratch, every butterfly level as a sweep), which must give the same bits
+		if (large && getenv("HOSTSIM_LARGE_SWEEPS") == nullptr) {
+			HostExec ex;
+			std::vector<float> panels(2 * LARGE_PANEL_FLOATS, -1.0f);
+			const LargeSamples S = large_block(ex, plan, vb, g, panels.data(), A.data(), B.data(), hs);
+			for (int y = 0; y < g.effh; ++y) for (int x = 0; x < g.effw; ++x) {
+				const uint32_t px = xyb_to_rgba8(S.p[0][y * S.pitch[0] + x], S.p[1][y * S.pitch[1] + x], S.p[2][y * S.pitch[2] + x], f, srgb_u8_thresholds());
+				memcpy(rgba + (size_t) (g.py + y) * stride + (size_t) (g.px + x) * 4, &px, 4);
+			}
+			continue;
+		}
 		if (f.sparse_coeffs) {   // the pixel kernels' way: zeroed tiles, scattered events, LLF corner, chroma-from-luma in place
 			for (int ch = 0; ch < 3; ++ch) std::fill(A.begin() + (size_t) ch * 65536, A.begin() + (size_t) ch * 65536 + std::min<size_t>(65536, (size_t) R * (size_t) P), 0.0f);
 			const TileMap map = {R, C, P, special ? 1 : 0};

@@ -67,6 +67,41 @@ def test_flat_lane_decoder_matches_nested_decoder(sim, name, opts):
         assert np.array_equal(a, q)
 
 
+def test_large_transforms_levels_in_lds_and_64_point_registers_equal_the_sweeps_and_the_reference(ref, sim):
+    """k_vardct_large's block function (large_dev.h: the top one or two levels of the recursion over the tile, every 64-point
+    sub-vector through Idct1D<64> in a lane's registers; 128x64 tiles live in LDS all three channels at once, 128x128 ones a channel at
+    a time with its events scattered per channel, 256-sized ones go through the scratch panel by panel; dense planes of two-pass
+    frames) run on the CPU lane by lane: the same bits as the model of round 3's kernel (every level a sweep over a tile in the
+    scratch), the reference's pixels, over streams in which every one of the six 128 / 256-sized transforms occurs
+    (j40.h:5972-5990, 5802-5841)"""
+    from refdec import RefStage
+    seen = set()
+    for (w, h, seed, opts) in [(1300, 1040, 5, {}), (776, 520, 31, {}), (1040, 1300, 8, {}), (1040, 776, 12, dict(passes=2)), (1040, 776, 13, dict(cfl=1)),
+                               (520, 1300, 14, dict(dq=2, bctx=1))]:
+        data = synth("vardct", w, h, seed, maxlog=8, **opts)
+        rs = RefStage(ref, data)
+        for g in range(rs.info["num_lf_groups"]):
+            sel = (rs.plane(g, 0) >> 20) & 31
+            seen |= set((sel[sel >= 2] - 2).tolist())
+        assert rs.combine() == ""
+        want = rs.rgba().astype(np.int32)
+        rs.close()
+        buf = C.create_string_buffer(data, len(data))
+        outs = []
+        for sweeps in (False, True):
+            if sweeps:
+                os.environ["HOSTSIM_LARGE_SWEEPS"] = "1"
+            try:
+                rgba = np.zeros((h, w, 4), np.uint8)
+                assert sim.hostsim_decode(buf, len(data), rgba.ctypes.data, None, 0) == 0
+            finally:
+                os.environ.pop("HOSTSIM_LARGE_SWEEPS", None)
+            outs.append(rgba)
+        assert np.array_equal(outs[0], outs[1])
+        assert np.abs(want - outs[0]).max() <= 1
+    assert {21, 22, 23, 24, 25, 26} <= seen, sorted(seen)
+
+
 def test_fast_latency_decoder_matches_nested_decoder(sim, ref):
     """decode_hf_section_fast (hf_uni_dev.h: the latency kernel's fast path -- tables across lanes, the next coefficient's cluster
     fetched for both outcomes of the current one) against decode_hf_section on every single-pass rANS case: coefficients, and on

@@ -55,6 +55,40 @@ def test_pipeline_matches_single_image_decodes(built, ref, device_output, lf_str
     pipe.close()
 
 
+LARGE_CASES = [(1300, 1040, 5, dict(maxlog=8)), (776, 520, 31, dict(maxlog=8)), (1040, 1300, 8, dict(maxlog=8)),
+               (1040, 776, 12, dict(maxlog=8, passes=2)), (1040, 776, 13, dict(maxlog=8, cfl=1)), (520, 1300, 14, dict(maxlog=8, dq=2, bctx=1))]
+
+
+@pytest.mark.gpu
+def test_large_transforms_through_both_kernels_give_the_reference_pixels(built, ref):
+    """k_vardct_large (large_dev.h: the recursion's top levels over the tile in LDS, 64-point sub-vectors in registers; 128x64 and
+    128x128 tiles live in LDS, 256-sized ones go through the scratch in panels) over streams in which all six 128 / 256-sized
+    transforms occur, single-pass and two-pass, with chroma-from-luma maps: the single-frame launch (public API) and the batch-wide
+    persistent launch (pipeline) both give the reference's pixels -- in practice without a differing sample (j40.h:5972-5990)"""
+    import torch
+    import j40_amd
+    datas = [synth("vardct", w, h, seed, **o) for (w, h, seed, o) in LARGE_CASES]
+    pipe = j40_amd.Pipeline(device=0, host_threads=4, batch_frames=8, max_in_flight=2)
+    outs = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0") for (w, h, _, _) in LARGE_CASES]
+    tickets = [pipe.submit(d, o.data_ptr(), o.shape[1] * 4, device_output=True) for d, o in zip(datas, outs)]
+    pipe.drain()
+    torch.cuda.synchronize()
+    st = pipe.stats()
+    differing = 0
+    for (w, h, seed, o), d, out, t in zip(LARGE_CASES, datas, outs, tickets):
+        rerr, want = ref.decode(d)
+        assert rerr == ""
+        err, single = j40_amd.decode(d)
+        assert err == "" and pipe.result(t) == ""
+        batched = out.cpu().numpy()
+        assert np.abs(want.astype(int) - single.astype(int)).max() <= 1, (w, h, o)
+        assert np.array_equal(single, batched), (w, h, o)
+        differing += int((want != single).sum())
+    assert st["launch_frames"] >= 5   # (the two-pass frame takes the single-frame path inside the pipeline)
+    pipe.close()
+    print("large transforms: %d samples differ from the reference's over %d frames" % (differing, len(datas)))
+
+
 def test_pipeline_can_be_drained_and_reused(built):
     import torch
     import j40_amd
