@@ -715,8 +715,14 @@ struct WorkgroupExec {
 // REG64: the top levels of the recursion in LDS, 64-point sub-vectors in registers (large_dev.h); a tile that fits one LDS buffer
 // (128x128, 128x64, 64x128) takes both dimensions there and makes ONE trip through the scratch per channel. !REG64: round 3's
 // form -- every level of the butterflies as a sweep over an LDS panel, two trips per channel (J40HIP_LARGE_IDCT=sweeps).
+// 512 lanes: two wavefronts per SIMD under the 133 KB of LDS -- the levels, the scatter and the colour conversion run twice as wide, the
+// 256 64-point sub-vectors of a pass keep half of them busy (43 against 51 ms for the pixel stage of the maxlog-8 bench stream;
+// the batch-wide instantiation then spills 1 KB per lane to scratch and is faster all the same)
+#ifndef J40_LARGE_THREADS
+#define J40_LARGE_THREADS 512
+#endif
 template <bool BATCH, bool REG64>
-__global__ void __launch_bounds__(256) k_vardct_large(DevPlan plan_arg, const DevVarblock *list, int32_t count, float *scratch, uint8_t *rgba, size_t stride_bytes, const K2Frame *batch, const int32_t *tile_prefix, int32_t nframes,
+__global__ void __launch_bounds__(J40_LARGE_THREADS) k_vardct_large(DevPlan plan_arg, const DevVarblock *list, int32_t count, float *scratch, uint8_t *rgba, size_t stride_bytes, const K2Frame *batch, const int32_t *tile_prefix, int32_t nframes,
 		int32_t class_a, int32_t class_b) {
 	const int32_t tid = threadIdx.x, nthreads = blockDim.x;
 	J40_STAGE_SRGB_THRESHOLDS(f);
@@ -874,11 +880,11 @@ static void launch_vardct_class_impl(const DevPlan &plan, int32_t dctsel, const 
 			// (J40HIP_LARGE_IDCT=sweeps: round 3's kernel, every butterfly level as a sweep over an LDS panel -- kept for comparison)
 			static const bool reg64 = [] { const char *e = getenv("J40HIP_LARGE_IDCT"); return !(e && !strcmp(e, "sweeps")); }();
 			if (bl.batch) {
-				if (reg64) hipLaunchKernelGGL((k_vardct_large<true, true>), dim3((unsigned) bl.grid), dim3(256), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, bl.tile_prefix, bl.nframes, bl.class_a, bl.class_b);
-				else hipLaunchKernelGGL((k_vardct_large<true, false>), dim3((unsigned) bl.grid), dim3(256), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, bl.tile_prefix, bl.nframes, bl.class_a, bl.class_b);
+				if (reg64) hipLaunchKernelGGL((k_vardct_large<true, true>), dim3((unsigned) bl.grid), dim3(J40_LARGE_THREADS), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, bl.tile_prefix, bl.nframes, bl.class_a, bl.class_b);
+				else hipLaunchKernelGGL((k_vardct_large<true, false>), dim3((unsigned) bl.grid), dim3(J40_LARGE_THREADS), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, bl.tile_prefix, bl.nframes, bl.class_a, bl.class_b);
 			} else {
-				if (reg64) hipLaunchKernelGGL((k_vardct_large<false, true>), dim3((unsigned) count), dim3(256), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, nullptr, 1, 0, 0);
-				else hipLaunchKernelGGL((k_vardct_large<false, false>), dim3((unsigned) count), dim3(256), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, nullptr, 1, 0, 0);
+				if (reg64) hipLaunchKernelGGL((k_vardct_large<false, true>), dim3((unsigned) count), dim3(J40_LARGE_THREADS), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, nullptr, 1, 0, 0);
+				else hipLaunchKernelGGL((k_vardct_large<false, false>), dim3((unsigned) count), dim3(J40_LARGE_THREADS), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, nullptr, 1, 0, 0);
 			}
 		}
 		break;

@@ -125,7 +125,9 @@ bool lf_lanes_alias_in_lds() {
 
 // packs the sections of `sets` into wavefronts (host side): fills `waves`, returns the LDS bytes a wavefront needs at most
 uint32_t pack_lf_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std::vector<DevLfWave> *waves) {
-	const uint32_t budget = 56u * 1024u;
+	// (J40HIP_LF_LDS_KB: the LDS a wavefront's frames may take together -- with the alias tables in LDS, 30 keeps it to one 8K frame per
+	// wavefront and two such workgroups beside a coefficient decoder's 99 KB on a compute unit)
+	static const uint32_t budget = [] { const char *e = getenv("J40HIP_LF_LDS_KB"); return (e && atoi(e) > 0 ? (uint32_t) atoi(e) : 56u) * 1024u; }();
 	uint32_t most = 0, used = 0; int32_t lanes = 0;
 	DevLfWave cur; memset(&cur, 0, sizeof cur);
 	auto flush = [&] { if (cur.num_parts) { waves->push_back(cur); most = std::max(most, used); } memset(&cur, 0, sizeof cur); used = 0; lanes = 0; };
