@@ -408,15 +408,54 @@ void launch_hf_entropy_lanes(const DevPlan *plans, const HfLaneWork *work, int32
 // ------------------------------------------------------------------------------------------------
 // K2 common pieces
 
+// Instrumented build (-DJ40_K2_PHASES, tools/build_variant.sh; never the product's): lane 0 of every workgroup of k_vardct_dct adds up
+// the shader clock (s_memtime) it spends in each phase of a tile -- as wave 0 sees it: a phase ends behind its barrier -- and adds the
+// sums to g_k2_phase[shape][phase] when it is done; j40hip_debug_k2_phases copies the table out. Phases: 0 prologue (bind, geometry,
+// event prefix), 1 zeroing + barrier, 2 event scatter + LLF + barrier, 3 pass 1 + barrier, 4 pass 2 + barrier, 5 colour + stores,
+// 6 the barrier behind them, 7 tiles counted.
+#ifdef J40_K2_PHASES
+__device__ unsigned long long g_k2_phase[64][8];
+#define K2_PHASES_BEGIN unsigned long long k2_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long k2_last = __builtin_amdgcn_s_memtime()
+#define K2_PHASE(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); k2_acc[i] += now_ - k2_last; k2_last = now_; } while (0)
+#define K2_PHASES_END(slot) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_k2_phase[slot][i_], k2_acc[i_]); } while (0)
+extern "C" __attribute__((visibility("default"))) void j40hip_debug_k2_phases(unsigned long long *out, int reset) {
+	(void) hipDeviceSynchronize();
+	(void) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k2_phase), sizeof(unsigned long long) * 64 * 8, 0, hipMemcpyDeviceToHost);
+	if (reset) { static unsigned long long zero[64 * 8]; (void) hipMemcpyToSymbol(HIP_SYMBOL(g_k2_phase), zero, sizeof zero, 0, hipMemcpyHostToDevice); }
+}
+#else
+#define K2_PHASES_BEGIN do { } while (0)
+#define K2_PHASE(i) do { } while (0)
+#define K2_PHASES_END(slot) do { } while (0)
+#endif
+
 // batch-wide launches (BATCH) are persistent: a launch covers one class of transforms over every frame of the batch, its work
 // cut into tiles of `per_wg` varblocks; tile_prefix[f] = tiles of the frames before frame f (built on the device by k_k2_tiles
 // from the frames' class_start, which the device-side plan build writes: the host never learns the counts). Workgroup b takes
 // a contiguous run of tiles (one search for its first tile's frame, then it walks along); k2_bind replaces the kernel arguments with
 // the next tile's frame's plan, list, count and output; `first` = the tile's first varblock. Returns false when the run is done.
-struct K2Iter { int32_t tile, tile_end, frame; };
+// the frame state below is the same in every lane; said so to the compiler (v_readfirstlane), it lives in scalar registers across the
+// tiles of a frame instead of fifty vector registers per lane
+__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) v); }
+__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ size_t uni(size_t v) { return (size_t) uni((uint32_t) v) | (size_t) uni((uint32_t) (v >> 32)) << 32; }
+template <typename T> __device__ __forceinline__ T *uni(T *p) { return (T *) uni((size_t) p); }
+__device__ __forceinline__ void uniform_plan(DevPlan &p) {   // (the fields the pixel kernels read)
+	p.frame = uni(p.frame); p.pool_u16 = uni(p.pool_u16); p.pool_f32 = uni(p.pool_f32); p.events = uni(p.events); p.block_events = uni(p.block_events);
+	for (int c = 0; c < 3; ++c) { p.llf[c] = uni(p.llf[c]); p.coeffs[c] = uni(p.coeffs[c]); }
+	p.coeff_stride = uni(p.coeff_stride);
+}
+__device__ __forceinline__ void uniform_colour(ColourConsts &c) {
+	for (int i = 0; i < 3; ++i) { c.cbrt_opsin_bias[i] = uni(c.cbrt_opsin_bias[i]); c.opsin_bias[i] = uni(c.opsin_bias[i]); }
+	for (int i = 0; i < 9; ++i) c.m[i] = uni(c.m[i]);
+	c.itscale = uni(c.itscale); c.bpp = uni(c.bpp);
+}
+
+struct K2Iter { int32_t tile, tile_end, frame, frame_first, frame_end; };   // tiles [frame_first, frame_end) are `frame`'s
 template <bool BATCH>
 __device__ __forceinline__ K2Iter k2_begin(const int32_t *tile_prefix, int32_t nframes) {
-	K2Iter it = {0, 1, 0};
+	K2Iter it = {0, 1, 0, 0, 0};
 	if (!BATCH) return it;
 	const int32_t total = tile_prefix[nframes], chunk = (total + (int32_t) gridDim.x - 1) / (int32_t) gridDim.x;
 	it.tile = (int32_t) blockIdx.x * chunk; it.tile_end = min(total, it.tile + chunk);
@@ -425,17 +464,25 @@ __device__ __forceinline__ K2Iter k2_begin(const int32_t *tile_prefix, int32_t n
 	it.frame = lo;
 	return it;
 }
+// A workgroup's run of tiles stays inside one frame for hundreds of tiles: the frame's list, count and output are fetched when the
+// run ENTERS a frame (`entered`), not per tile -- per tile the bind is arithmetic on registers (round 4: the instrumented build put
+// a third of a tile's time into its prologue, a chain of dependent loads of which these were the head).
 template <bool BATCH>
 __device__ __forceinline__ bool k2_bind(K2Iter &it, const K2Frame *batch, const int32_t *tile_prefix, int32_t class_a, int32_t class_b, int32_t per_wg,
-		const DevVarblock *&list, int32_t &count, uint8_t *&rgba, size_t &stride, int32_t &frame, int32_t &first) {
-	if (!BATCH) { frame = 0; first = (int32_t) blockIdx.x * per_wg; return it.tile++ == 0; }
+		const DevVarblock *&list, int32_t &count, uint8_t *&rgba, size_t &stride, int32_t &frame, int32_t &first, bool &entered) {
+	if (!BATCH) { frame = 0; first = (int32_t) blockIdx.x * per_wg; entered = it.tile == 0; return it.tile++ == 0; }
 	if (it.tile >= it.tile_end) return false;
-	while (tile_prefix[it.frame + 1] <= it.tile) ++it.frame;   // (frames without tiles of this class)
+	entered = it.tile >= it.frame_end;   // (frame_end starts at 0: the first tile always enters)
+	if (entered) {
+		while (tile_prefix[it.frame + 1] <= it.tile) ++it.frame;   // (frames without tiles of this class)
+		it.frame = uni(it.frame);
+		it.frame_first = uni(tile_prefix[it.frame]); it.frame_end = uni(tile_prefix[it.frame + 1]);
+		const K2Frame &fr = batch[it.frame];
+		const int32_t a = fr.class_start[class_a];
+		list = uni(fr.sorted + a); count = uni(fr.class_start[class_b] - a); rgba = uni(fr.rgba); stride = uni(fr.stride);
+	}
 	frame = it.frame;
-	const K2Frame &fr = batch[frame];
-	const int32_t a = fr.class_start[class_a];
-	list = fr.sorted + a; count = fr.class_start[class_b] - a; rgba = fr.rgba; stride = fr.stride;
-	first = (it.tile - tile_prefix[frame]) * per_wg;
+	first = (it.tile - it.frame_first) * per_wg;
 	++it.tile;
 	return true;
 }
@@ -475,33 +522,50 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan_arg, const DevV
 	constexpr int N = R * C;
 	constexpr int PAR = N >= 256 ? 1 : 256 / N;   // blocks a pass of the 256 lanes covers
 	constexpr int PER = N >= 256 ? N / 256 : 1;   // pixel positions per lane
+	K2_PHASES_BEGIN;
+	// what a frame's tiles share, fetched when the workgroup's run of tiles enters the frame (wave-uniform: scalar registers)
+	DevPlan plan = plan_arg;
+	ColourConsts cc;
+	const float *dq = nullptr, *dq_scan = nullptr; const uint16_t *order = nullptr;
+	float qbias0 = 0, qbias1 = 0, qbias2 = 0, qbias_num = 0, kx_lf = 0, kb_lf = 0, x_qm_mul = 0, b_qm_mul = 0;
+	bool sparse = false;
 	for (K2Iter it = k2_begin<BATCH>(tile_prefix, nframes); ; ) {
-		int32_t frame, first;
-		if (!k2_bind<BATCH>(it, batch, tile_prefix, class_a, class_b, NB, list, count, rgba, stride_bytes, frame, first)) break;
-		const DevPlan &plan = BATCH ? batch[frame].plan : plan_arg;
-		const DevFrame &f = *plan.frame;
+		int32_t frame, first; bool entered;
+		if (!k2_bind<BATCH>(it, batch, tile_prefix, class_a, class_b, NB, list, count, rgba, stride_bytes, frame, first, entered)) break;
+		if (entered) {
+			if (BATCH) { plan = batch[frame].plan; uniform_plan(plan); }
+			const DevFrame &f = *plan.frame;
+			cc = load_colour_consts(f); uniform_colour(cc);
+			dq = uni(plan.pool_f32 + f.dq_off[param_idx]);
+			order = uni(plan.pool_u16 + f.order_off[order_idx * 3]);   // pass 0; the three channels' orders are consecutive
+			dq_scan = uni(plan.pool_f32 + f.dq_scan_off[param_idx]);
+			qbias0 = uni(f.quant_bias[0]); qbias1 = uni(f.quant_bias[1]); qbias2 = uni(f.quant_bias[2]); qbias_num = uni(f.quant_bias_num); kx_lf = uni(f.kx_lf); kb_lf = uni(f.kb_lf);
+			x_qm_mul = uni(f.x_qm_mul); b_qm_mul = uni(f.b_qm_mul); sparse = uni((int32_t) f.sparse_coeffs) != 0;
+		}
 		const int32_t nb = min(NB, count - first);
-		const float *dq = plan.pool_f32 + f.dq_off[param_idx];
 		const int32_t dq_size = R * C;
-		const ColourConsts cc = load_colour_consts(f);
-		const float qbias0 = f.quant_bias[0], qbias1 = f.quant_bias[1], qbias2 = f.quant_bias[2], qbias_num = f.quant_bias_num, kx_lf = f.kx_lf, kb_lf = f.kb_lf;
+		// (asking for the tile's records first and zeroing the tiles while they are on their way was measured: nineteen registers more
+		// and 67.2 against 64.4 ms for the stage)
+		if (sparse) for (int32_t w = tid; w < nb * 3 * TILE; w += nthreads) lds[w] = 0.0f;
 		uint32_t nevents = 0;
 		if (tid < nb) {
 			const DevVarblock vb = list[first + tid];
-			const VbGeom g = varblock_geometry(plan, vb);
+			VbGeom g;
+			g.coeff_base = vb.coeff_base; g.llf_base = vb.llf_base;
+			g.mult[1] = vb.mult1; g.mult[0] = vb.mult1 * x_qm_mul; g.mult[2] = vb.mult1 * b_qm_mul;   // (varblock_geometry with the frame's factors at hand; j40.h:7078-7080)
+			g.kx_hf = vb.kx_hf; g.kb_hf = vb.kb_hf; g.px = vb.px; g.py = vb.py; g.effw = vb.effw; g.effh = vb.effh;
 			geom[tid] = g; g_out[tid] = (size_t) g.py * stride_bytes + (size_t) g.px * 4;
-			if (f.sparse_coeffs) { const uint32_t *be = plan.block_events + 4 * (size_t) vb.blk; for (int k = 0; k < 4; ++k) g_be[tid][k] = be[k]; nevents = be[1] + be[2] + be[3]; }
+			if (sparse) { const uint32_t *be = plan.block_events + 4 * (size_t) vb.blk; for (int k = 0; k < 4; ++k) g_be[tid][k] = be[k]; nevents = be[1] + be[2] + be[3]; }
 		}
 		stage_event_prefix<NB>(nevents, ev_prefix, tid);
+		K2_PHASE(0);
 		// ---- load: dequantise + chroma-from-luma + LLF into the LDS tiles ----
-		if (f.sparse_coeffs) {
-			// single-pass frames: zero the tiles, then scatter the blocks' coefficient events into them (one lane per event over
-			// the whole workgroup: the work is proportional to the non-zeros; chroma-from-luma rides along) and write the LLF
-			// corners (vardct_dev.h). No event lands in an LLF corner, so the two need no barrier between them.
-			for (int32_t w = tid; w < nb * 3 * TILE; w += nthreads) lds[w] = 0.0f;
+		if (sparse) {
+			// single-pass frames: the tiles are zeroed (above), then the blocks' coefficient events are scattered into them (one lane per
+			// event over the whole workgroup: the work is proportional to the non-zeros; chroma-from-luma rides along) and the LLF
+			// corners written (vardct_dev.h). No event lands in an LLF corner, so the two need no barrier between them.
 			__syncthreads();
-			const uint16_t *order = plan.pool_u16 + f.order_off[order_idx * 3];   // pass 0; the three channels' orders are consecutive
-			const float *dq_scan = plan.pool_f32 + f.dq_scan_off[param_idx];
+			K2_PHASE(1);
 			const TileMap map = {R, C, P, 0};
 			const float qbias[3] = {qbias0, qbias1, qbias2};
 			tiles_scatter_events<NB>(plan, geom, g_be, ev_prefix, order, dq_scan, nullptr, N, map, lds, 3 * TILE, TILE, qbias, qbias_num, tid, nthreads);
@@ -520,6 +584,7 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan_arg, const DevV
 			}
 		}
 		__syncthreads();
+		K2_PHASE(2);
 		// ---- pass 1: IDCT of length C along c, one lane per (block, channel, r) ----
 		for (int32_t w = tid; w < nb * 3 * R; w += nthreads) {
 			float *row = lds + (size_t) (w / R) * TILE + (w % R) * P;
@@ -531,6 +596,7 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan_arg, const DevV
 			for (int k = 0; k < C; ++k) row[k] = x[k];
 		}
 		__syncthreads();
+		K2_PHASE(3);
 		// ---- pass 2: IDCT of length R along r, one lane per (block, channel, x) ----
 		for (int32_t w = tid; w < nb * 3 * C; w += nthreads) {
 			float *col = lds + (size_t) (w / C) * TILE + (w % C);
@@ -542,6 +608,7 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan_arg, const DevV
 			for (int k = 0; k < R; ++k) col[k * P] = x[k];
 		}
 		__syncthreads();
+		K2_PHASE(4);
 		// ---- colour + pack: a lane owns pixel position (y, x) for every block of the workgroup ----
 #pragma unroll
 		for (int k = 0; k < PER; ++k) {
@@ -556,9 +623,15 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan_arg, const DevV
 				__builtin_nontemporal_store(px, (uint32_t *) (rgba + g_out[b] + in_block));   // written once, never read here: keep it out of the L2's way (-2 %)
 			}
 		}
+		K2_PHASE(5);
 		if (!BATCH) break;
 		__syncthreads();   // the next tile reuses geom / the LDS tiles
+		K2_PHASE(6);
+#ifdef J40_K2_PHASES
+		++k2_acc[7];
+#endif
 	}
+	K2_PHASES_END(LOGR * 8 + LOGC);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -576,31 +649,48 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const 
 	J40_STAGE_SRGB_THRESHOLDS(f);
 	__shared__ int32_t g_param[NB], g_sel[NB];
 	__shared__ uint32_t g_be[NB][4], g_dq[NB], ev_prefix[NB + 1];
+	// what a frame's tiles share, fetched when the workgroup's run of tiles enters the frame (k_vardct_dct)
+	DevPlan plan = plan_arg;
+	ColourConsts cc;
+	const uint16_t *order = nullptr;
+	float qbias[3] = {0, 0, 0}, qbias_num = 0, kx_lf = 0, kb_lf = 0, x_qm_mul = 0, b_qm_mul = 0;
+	uint32_t dq_scan_off[5] = {0, 0, 0, 0, 0};   // of the parameter sets 1, 2, 3, 9, 10
+	bool sparse = false;
 	for (K2Iter it = k2_begin<BATCH>(tile_prefix, nframes); ; ) {
-		int32_t frame, first;
-		if (!k2_bind<BATCH>(it, batch, tile_prefix, class_a, class_b, NB, list, count, rgba, stride_bytes, frame, first)) break;
-		const DevPlan &plan = BATCH ? batch[frame].plan : plan_arg;
+		int32_t frame, first; bool entered;
+		if (!k2_bind<BATCH>(it, batch, tile_prefix, class_a, class_b, NB, list, count, rgba, stride_bytes, frame, first, entered)) break;
+		if (entered) {
+			if (BATCH) { plan = batch[frame].plan; uniform_plan(plan); }
+			const DevFrame &fe = *plan.frame;
+			cc = load_colour_consts(fe); uniform_colour(cc);
+			order = uni(plan.pool_u16 + fe.order_off[1 * 3]);   // all 8x8 specials share order 1
+			qbias[0] = uni(fe.quant_bias[0]); qbias[1] = uni(fe.quant_bias[1]); qbias[2] = uni(fe.quant_bias[2]); qbias_num = uni(fe.quant_bias_num); kx_lf = uni(fe.kx_lf); kb_lf = uni(fe.kb_lf);
+			x_qm_mul = uni(fe.x_qm_mul); b_qm_mul = uni(fe.b_qm_mul); sparse = uni((int32_t) fe.sparse_coeffs) != 0;
+			dq_scan_off[0] = uni((uint32_t) fe.dq_scan_off[1]); dq_scan_off[1] = uni((uint32_t) fe.dq_scan_off[2]); dq_scan_off[2] = uni((uint32_t) fe.dq_scan_off[3]);
+			dq_scan_off[3] = uni((uint32_t) fe.dq_scan_off[9]); dq_scan_off[4] = uni((uint32_t) fe.dq_scan_off[10]);
+		}
 		const DevFrame &f = *plan.frame;
 		const int32_t nb = min(NB, count - first);
-		const ColourConsts cc = load_colour_consts(f);
+		if (sparse) for (int32_t w = tid; w < nb * 3 * P; w += nthreads) tiles[w] = 0.0f;
 		uint32_t nevents = 0;
 		if (tid < nb) {
 			const DevVarblock vb = list[first + tid];
-			geom[tid] = varblock_geometry(plan, vb);
-			if (f.sparse_coeffs) { const uint32_t *be = plan.block_events + 4 * (size_t) vb.blk; for (int k = 0; k < 4; ++k) g_be[tid][k] = be[k]; nevents = be[1] + be[2] + be[3]; }
+			VbGeom g;
+			g.coeff_base = vb.coeff_base; g.llf_base = vb.llf_base;
+			g.mult[1] = vb.mult1; g.mult[0] = vb.mult1 * x_qm_mul; g.mult[2] = vb.mult1 * b_qm_mul;   // (varblock_geometry; j40.h:7078-7080)
+			g.kx_hf = vb.kx_hf; g.kb_hf = vb.kb_hf; g.px = vb.px; g.py = vb.py; g.effw = vb.effw; g.effh = vb.effh;
+			geom[tid] = g;
+			if (sparse) { const uint32_t *be = plan.block_events + 4 * (size_t) vb.blk; for (int k = 0; k < 4; ++k) g_be[tid][k] = be[k]; nevents = be[1] + be[2] + be[3]; }
 			g_sel[tid] = vb.dctsel;
 			g_param[tid] = vb.dctsel == 1 ? 1 : vb.dctsel == 2 ? 2 : vb.dctsel == 3 ? 3 : vb.dctsel <= 13 ? 9 : 10;
-			g_dq[tid] = (uint32_t) f.dq_scan_off[g_param[tid]];
+			g_dq[tid] = vb.dctsel == 1 ? dq_scan_off[0] : vb.dctsel == 2 ? dq_scan_off[1] : vb.dctsel == 3 ? dq_scan_off[2] : vb.dctsel <= 13 ? dq_scan_off[3] : dq_scan_off[4];
 		}
 		stage_event_prefix<NB>(nevents, ev_prefix, tid);
-		if (f.sparse_coeffs) {
-			for (int32_t w = tid; w < nb * 3 * P; w += nthreads) tiles[w] = 0.0f;
+		if (sparse) {
 			__syncthreads();
-			const uint16_t *order = plan.pool_u16 + f.order_off[1 * 3];   // all 8x8 specials share order 1
 			const TileMap map = {8, 8, SP8_PITCH, 1};
-			const float qbias[3] = {f.quant_bias[0], f.quant_bias[1], f.quant_bias[2]};
-			tiles_scatter_events<NB>(plan, geom, g_be, ev_prefix, order, plan.pool_f32, g_dq, 64, map, tiles, 3 * P, P, qbias, f.quant_bias_num, tid, nthreads);
-			tiles_fill_llf(plan, geom, nb, 8, 1, 1, map, tiles, 3 * P, P, f.kx_lf, f.kb_lf, tid, nthreads);
+			tiles_scatter_events<NB>(plan, geom, g_be, ev_prefix, order, plan.pool_f32, g_dq, 64, map, tiles, 3 * P, P, qbias, qbias_num, tid, nthreads);
+			tiles_fill_llf(plan, geom, nb, 8, 1, 1, map, tiles, 3 * P, P, kx_lf, kb_lf, tid, nthreads);
 		} else {
 			__syncthreads();
 			for (int32_t w = tid; w < nb * 64; w += nthreads) {
@@ -730,8 +820,8 @@ __global__ void __launch_bounds__(J40_LARGE_THREADS) k_vardct_large(DevPlan plan
 	extern __shared__ __attribute__((aligned(16))) float large_lds[];   // 2 * LARGE_PANEL_FLOATS
 	J40_LDS float *panels = (J40_LDS float *) large_lds;
 	for (K2Iter it = k2_begin<BATCH>(tile_prefix, nframes); ; ) {
-		int32_t frame, first;
-		if (!k2_bind<BATCH>(it, batch, tile_prefix, class_a, class_b, 1, list, count, rgba, stride_bytes, frame, first)) break;
+		int32_t frame, first; bool entered;
+		if (!k2_bind<BATCH>(it, batch, tile_prefix, class_a, class_b, 1, list, count, rgba, stride_bytes, frame, first, entered)) break;
 		const DevPlan &plan = BATCH ? batch[frame].plan : plan_arg;
 		const DevFrame &f = *plan.frame;
 		const DevVarblock vb = list[first];

@@ -20,6 +20,11 @@ sb = [bufs[i % D] for i in range(B)]; ss = [len(datas[i % D]) for i in range(B)]
 pipe = j40_amd.Pipeline(0, max(2, cpu_quota() // 2), B, 1, lf_streams="host")
 run_pipeline_steps(pipe, sb, ss, so, W * 4, True, 1, torch, dev, None)
 pipe.reset_stats()
+phases = None
+if os.environ.get("PROBE_K2_PHASES"):   # (a library built with -DJ40_K2_PHASES: kernels.hip)
+    phases = (C.c_ulonglong * (64 * 8))()
+    j40_amd.lib().j40hip_debug_k2_phases.argtypes = [C.c_void_p, C.c_int]
+    j40_amd.lib().j40hip_debug_k2_phases(phases, 1)
 el, tk = run_pipeline_steps(pipe, sb, ss, so, W * 4, True, steps, torch, dev, None)
 st = pipe.stats()
 assert all(pipe.result(t) == "" for t in tk)
@@ -27,5 +32,15 @@ n = max(st["launches"], 1)
 print(json.dumps({"lib": os.path.basename(j40_amd.LIB_PATH), "frames_per_launch": st["launch_frames"] / n, "launches": st["launches"], "k_hf_lanes_ms_per_launch": round(st["k1_kernel_ms"] / n, 3),
                   "entropy_stage_ms_per_launch": round(st["k1_ms"] / n, 3), "pixel_kernels_ms_per_launch": round(st["k2_ms"] / n, 3), "lf_plan_tail_ms_per_launch": round(st["lf_plan_ms"] / n, 3),
                   "ms_per_step": round(el / steps * 1e3, 2)}))
+if phases is not None:
+    j40_amd.lib().j40hip_debug_k2_phases(phases, 0)
+    names = ["prologue", "zero", "scatter+llf", "pass1", "pass2", "colour", "end barrier"]
+    total_all = sum(phases[s * 8 + k] for s in range(64) for k in range(7)) or 1
+    for slot in range(64):
+        row = [phases[slot * 8 + k] for k in range(8)]
+        if row[7]:
+            tot = sum(row[:7])
+            print(json.dumps({"k_vardct_dct": "%dx%d" % (1 << (slot // 8), 1 << (slot % 8)), "tiles": row[7], "share_of_all_shapes": round(tot / total_all, 4), "clocks_per_tile": round(tot / row[7], 1),
+                              "phases": {n: round(v / tot, 4) for n, v in zip(names, row[:7])}}))
 pipe.close()
 j40_amd.shutdown()
