@@ -112,6 +112,11 @@ def main():
         w, h = r.randrange(260 if mode == "vardct" else 9, int(os.environ.get("FUZZ_MAXW", "900"))), r.randrange(8, int(os.environ.get("FUZZ_MAXH", "700")))   # (FUZZ_MAXW > 2048: several LF groups)
         if mode == "vardct" and w * h < 257 * 8 * 2: h = 264
         o = pick_vardct(r) if mode == "vardct" else pick_modular(r)
+        if mode == "vardct" and os.environ.get("FUZZ_FORCE"):   # e.g. FUZZ_FORCE=maxlog=8: every VarDCT stream with 128 / 256-sized transforms
+            for kv in os.environ["FUZZ_FORCE"].split(","):
+                k, v = kv.split("=")
+                o[k] = int(v)
+            if "maxlog" in o and o["maxlog"] > 6: o.pop("forward", None); o.pop("detail", None); o.pop("beta", None)
         seed = r.randrange(1 << 20)
         try:
             d = synth(mode, w, h, seed, **o)
