@@ -19,6 +19,7 @@ j40hip_frame *j40hip_frame_parse_with(const void *buf, size_t size, int threads,
 		extract_codestream((const uint8_t *) buf, size, &h->cs, &h->cs_size, &h->cs_storage, &h->container_stray_tail);
 		h->bare_codestream = h->cs == (const uint8_t *) buf && h->cs_size == size;
 		parse_frame(h->cs, h->cs_size, &h->frame, threads);
+		h->threads = threads < 1 ? 1 : threads > 16 ? 16 : threads;
 	} catch (const DecodeError &e) { code = e.code; }
 	catch (const std::bad_alloc &) { code = E4("!mem"); }
 	h->frame.lf_decoder = nullptr; h->frame.lf_decoder_ctx = nullptr;   // (the context lives on the caller's stack)

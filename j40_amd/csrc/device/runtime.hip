@@ -689,7 +689,7 @@ static uint32_t upload_impl(j40hip_frame *h, int device, hipStream_t s) {
 	HostPlan &hp = t_host_plan;   // (this thread's, storage kept from frame to frame)
 	hp.reset();
 	hp.force_dense = h->force_dense;
-	if (uint32_t e = build_vardct_plan(h->frame, h->cs, h->cs_size, &hp)) return e;
+	if (uint32_t e = build_vardct_plan(h->frame, h->cs, h->cs_size, &hp, h->threads)) return e;
 
 	j40hip_device_state *st = new j40hip_device_state();
 	h->dev = st; st->device = device; st->force_dense = h->force_dense;

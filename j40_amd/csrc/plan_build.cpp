@@ -1,9 +1,40 @@
 // j40_amd/csrc/plan_build.cpp -- see plan_build.hpp
 #include "plan_build.hpp"
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <thread>
 
 namespace j40hip {
+
+namespace {
+// a team of threads for build_vardct_plan's big loops: body(tid, team size, barrier) runs on the calling thread and team - 1 more;
+// the body allocates nothing and throws nothing (a thread that left before a barrier would strand the others)
+struct TeamBarrier {
+	std::atomic<int> waiting{0}, generation{0}, team{1};
+	void wait() {
+		const int n = team.load(std::memory_order_acquire);
+		if (n <= 1) return;
+		const int g = generation.load(std::memory_order_acquire);
+		if (waiting.fetch_add(1, std::memory_order_acq_rel) + 1 == n) { waiting.store(0, std::memory_order_relaxed); generation.fetch_add(1, std::memory_order_release); }
+		else while (generation.load(std::memory_order_acquire) == g) std::this_thread::yield();
+	}
+};
+template <class F> void run_team(int threads, F &body) {
+	TeamBarrier bar;
+	if (threads <= 1) { body(0, 1, bar); return; }
+	std::vector<std::thread> pool;
+	std::atomic<int> go{0};   // the team's size, once it is known how many threads could be started
+	try {
+		for (int t = 1; t < threads; ++t) pool.emplace_back([&, t] { int n; while ((n = go.load(std::memory_order_acquire)) == 0) std::this_thread::yield(); if (t < n) body(t, n, bar); });
+	} catch (const std::exception &) { }   // (as many as there are)
+	const int n = (int) pool.size() + 1;
+	bar.team.store(n, std::memory_order_release);
+	go.store(n, std::memory_order_release);
+	body(0, n, bar);
+	for (std::thread &t : pool) t.join();
+}
+} // namespace
 
 template <typename T> static uint32_t push(std::vector<T> &pool, const T *p, size_t n) { uint32_t off = (uint32_t) pool.size(); pool.insert(pool.end(), p, p + n); return off; }
 
@@ -124,7 +155,7 @@ void fill_frame_constants(const Frame &fr, DevFrame *out) {
 
 }
 
-uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostPlan *hp) {
+uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostPlan *hp, int threads) {
 	if (cs_size + 16 >= ((size_t) 1 << 29)) return ERR_TODO;   // the kernels address the codestream with 32-bit BIT positions
 	if (fr.fh.is_modular) return ERR_TODO;
 	// same limits as j40.h:7867, 7917-7921. (A VarDCT frame of an image without xyb_encoded passes them: the reference
@@ -169,87 +200,123 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 		}
 	}
 
-	{ size_t nvb = 0, ncell = 0; for (const LfGroup &gg : fr.lf_groups) { nvb += gg.varblocks.size(); ncell += gg.blocks.size(); }
-	  hp->vb_coeffoff_qfidx.reserve(nvb); hp->vb_hfmul_inv.reserve(nvb); hp->group_blocks.reserve(nvb);
-	  hp->blocks.reserve(ncell); hp->lfindices.reserve(ncell); for (int c = 0; c < 3; ++c) hp->llf[c].reserve(ncell); }
-	// LF bundle: frame-wide arrays over all LF groups
-	hp->lf_groups.assign(fr.lf_groups.size(), DevLfGroup());
-	for (size_t g = 0; g < fr.lf_groups.size(); ++g) {
+	// ---- the frame-wide arrays: LF bundle, K1's block lists, K2's work list. Every piece has its place before anything is written
+	// (offsets from the LfGroups' and groups' sizes), so the pieces are written by a team of threads when the caller has them
+	// (j40_next_frame's single-image path: 8 ms of one core per 8K frame otherwise, a quarter of the call) -- the same bytes either way.
+	const size_t nlf = fr.lf_groups.size();
+	const int32_t num_groups = (int32_t) fr.fh.num_groups;
+	size_t nvb = 0, ncell = 0, nc64 = 0;
+	hp->lf_groups.assign(nlf, DevLfGroup());
+	bool any_tail = false, all_tail = true;
+	for (size_t g = 0; g < nlf; ++g) {
 		const LfGroup &gg = fr.lf_groups[g];
 		DevLfGroup &d = hp->lf_groups[g];
 		d.left = gg.left; d.top = gg.top; d.width = gg.width; d.height = gg.height;
 		d.width8 = gg.width8; d.height8 = gg.height8; d.width64 = gg.width64; d.height64 = gg.height64;
-		d.cell_base = (int32_t) hp->blocks.size(); d.vb_base = (int32_t) hp->vb_coeffoff_qfidx.size(); d.c64_base = (int32_t) hp->xfromy.size();
+		d.cell_base = (int32_t) ncell; d.vb_base = (int32_t) nvb; d.c64_base = (int32_t) nc64;
 		d.nb_varblocks = (int32_t) gg.varblocks.size();
-		hp->blocks.insert(hp->blocks.end(), gg.blocks.begin(), gg.blocks.end());
-		hp->lfindices.insert(hp->lfindices.end(), gg.lfindices.begin(), gg.lfindices.end());
 		for (int c = 0; c < 3; ++c) d.mult_lf[c] = gg.mult_lf[c];
-		if (gg.tail_pending) {   // the device computes the LLF coefficients from the decoded integers (lf_tail_kernels.hip)
-			hp->lf_tail_pending = true;
-			for (int c = 0; c < 3; ++c) hp->lfraw[c].insert(hp->lfraw[c].end(), gg.lfraw[c].begin(), gg.lfraw[c].end());
-		} else for (int c = 0; c < 3; ++c) hp->llf[c].insert(hp->llf[c].end(), gg.llfcoeffs[c].begin(), gg.llfcoeffs[c].end());
-		hp->xfromy.insert(hp->xfromy.end(), gg.xfromy.begin(), gg.xfromy.end());
-		hp->bfromy.insert(hp->bfromy.end(), gg.bfromy.begin(), gg.bfromy.end());
-		for (const VarblockInfo &vb : gg.varblocks) { hp->vb_coeffoff_qfidx.push_back(vb.coeffoff_qfidx); hp->vb_hfmul_inv.push_back(vb.hfmul_inv); }
+		any_tail = any_tail || gg.tail_pending; all_tail = all_tail && gg.tail_pending;
+		if (gg.lfindices.size() != gg.blocks.size() || gg.bfromy.size() != gg.xfromy.size()) return ERR_RNGE;   // (cannot happen: lf_group_finish sizes them alike)
+		for (int c = 0; c < 3; ++c) if ((gg.tail_pending ? gg.lfraw[c].size() : gg.llfcoeffs[c].size()) != gg.blocks.size()) return ERR_RNGE;
+		ncell += gg.blocks.size(); nvb += gg.varblocks.size(); nc64 += gg.xfromy.size();
 	}
-	hp->coeff_floats = hp->blocks.size() * 64;
-	if (hp->lf_tail_pending) {
-		if (fr.lf_groups.size() >= ((size_t) 1 << 24)) return ERR_TODO;
-		for (const LfGroup &gg : fr.lf_groups) if (!gg.tail_pending) return ERR_TODO;   // (all or none)
+	hp->coeff_floats = ncell * 64;
+	hp->lf_tail_pending = any_tail;
+	if (any_tail) {   // the device computes the LLF coefficients from the decoded integers (lf_tail_kernels.hip)
+		if (nlf >= ((size_t) 1 << 24)) return ERR_TODO;
+		if (!all_tail) return ERR_TODO;   // (all or none)
 		hp->lf_smooth = !fr.fh.skip_adapt_lf_smooth;
 		for (int c = 0; c < 3; ++c) hp->inv_m_lf[c] = (float) (fr.global_scale * fr.quant_lf) / fr.m_lf_scaled[c] / 65536.0f;   // j40.h:6497
 	}
-
-	const int32_t num_groups = (int32_t) fr.fh.num_groups;
+	hp->blocks.resize(ncell); hp->lfindices.resize(ncell);
+	for (int c = 0; c < 3; ++c) { if (any_tail) hp->lfraw[c].resize(ncell); else hp->llf[c].resize(ncell); }
+	hp->xfromy.resize(nc64); hp->bfromy.resize(nc64);
+	hp->vb_coeffoff_qfidx.resize(nvb); hp->vb_hfmul_inv.resize(nvb);
+	hp->group_blocks.resize(nvb);   // (every varblock is in exactly one group's list: its top-left cell's group)
+	if (hp->vb_sorted.size() != nvb) hp->vb_sorted.resize(nvb);   // (every record is written below; a reused plan object keeps last frame's storage)
 	fill_sections(fr, &hp->sections);
-	// per-group block lists for K1, in the visiting order of j40__hf_coeffs
-	std::vector<std::vector<int32_t>> ordinal(fr.lf_groups.size());   // [LF group][varblock] -> position in group_blocks
-	for (size_t g = 0; g < fr.lf_groups.size(); ++g) ordinal[g].assign(fr.lf_groups[g].varblocks.size(), -1);
 	hp->group_block_start.assign((size_t) num_groups + 1, 0);
-	for (int32_t g = 0; g < num_groups; ++g) {
-		hp->group_block_start[(size_t) g] = (uint32_t) hp->group_blocks.size();
-		const DevSection &d = hp->sections[(size_t) g];
-		const LfGroup &gg = fr.lf_groups[(size_t) d.ggidx];
-		for (int32_t y8 = 0; y8 < d.gh8; ++y8) for (int32_t x8 = 0; x8 < d.gw8; ++x8) {
-			const size_t cell = (size_t) (d.gy8 + y8) * (size_t) gg.width8 + (size_t) (d.gx8 + x8);
-			const int32_t blk = gg.blocks[cell];
-			if ((blk >> 20) < 2) continue;
-			DevGroupBlock gb;
-			gb.coeffoff_qfidx = (uint32_t) gg.varblocks[(size_t) (blk & 0xfffff)].coeffoff_qfidx;
-			gb.pos_dct = (uint16_t) ((y8 * 32 + x8) | (((blk >> 20) - 2) << 10));
-			{   // block context per channel: block_ctx_map[(c_yxb * 13 + order) * (nb_qf_thr + 1) + qfidx) * lfidx_size + lfidx]
-				const int32_t dctsel = (blk >> 20) - 2, nb_qf1 = fr.nb_qf_thr + 1, lfidx_size = df.lfidx_size;
-				const int32_t bctx0 = (DCT_SELECT[dctsel].order_idx * nb_qf1 + (int32_t) (gb.coeffoff_qfidx & 15u)) * lfidx_size + gg.lfindices[cell];
-				uint32_t v = 0;
-				for (int32_t c_yxb = 0; c_yxb < 3; ++c_yxb) v |= (uint32_t) (fr.block_ctx_map[(size_t) (bctx0 + 13 * nb_qf1 * lfidx_size * c_yxb)] & 15) << (4 * c_yxb);
-				gb.bctx3 = (uint16_t) v;
-			}
-			ordinal[(size_t) d.ggidx][(size_t) (blk & 0xfffff)] = (int32_t) hp->group_blocks.size();
-			hp->group_blocks.push_back(gb);
-		}
-	}
-	hp->group_block_start[(size_t) num_groups] = (uint32_t) hp->group_blocks.size();
-	// single-pass frames: sparse coefficients (DevPlan::events). A group's region is sized from its section: a non-zero
-	// coefficient costs bits, 6 events per byte is far beyond what entropy coding reaches on real data; a section that still
-	// overflows it fails with ERR_EVOF and the frame is decoded with dense planes instead (runtime.hip).
-	df.sparse_coeffs = fr.fh.num_passes == 1 && !hp->force_dense;
-	if (!fill_event_ranges(hp->sections, num_groups, df.sparse_coeffs != 0, &hp->ev_range, &hp->ev_capacity)) df.sparse_coeffs = 0;
-	hp->codestream.reserve(cs_size + 32);   // (assign + resize without it reallocates and copies the stream a second time)
-	hp->codestream.assign(cs, cs + cs_size);
-	hp->codestream.resize(cs_size + 32, 0);   // the lane decoders read up to three words past the position they stop at
-	bool any_lz77 = false;
-	for (const DevCodeSpec &sp : hp->coeff_specs) any_lz77 |= sp.lz77_enabled != 0;
-	hp->lz_window_size = any_lz77 ? 3 * 65536 + 3 * 1024 + 16 : 0;  // bound on the integers one pass-group stream decodes
-	// work lists for the coefficients -> pixels kernels, grouped by DctSelect
-	{   // grouped by DctSelect, in (LF group, varblock) order within a class: counted first, then every record is written straight
-		// to its place (sorting a quarter of a million 40-byte records afterwards was a third of this function)
-		size_t count[28] = {0}, at[28], k = 0, total = 0;
-		for (const LfGroup &gg : fr.lf_groups) { total += gg.varblocks.size(); for (const VarblockInfo &vb : gg.varblocks) ++count[vb.dctsel >= 0 && vb.dctsel < 27 ? vb.dctsel : 27]; }
-		for (int d = 0; d <= 27; ++d) { hp->class_start[d] = (int32_t) k; at[d] = k; k += count[d]; }
-		if (hp->vb_sorted.size() != total) hp->vb_sorted.resize(total);   // (every record is written below; a reused plan object keeps last frame's storage)
-		for (size_t g = 0; g < fr.lf_groups.size(); ++g) {
+	std::vector<std::vector<int32_t>> ordinal(nlf);   // [LF group][varblock] -> position in group_blocks
+	for (size_t g = 0; g < nlf; ++g) ordinal[g].assign(fr.lf_groups[g].varblocks.size(), -1);
+	std::vector<uint32_t> class_count(nlf * 28, 0), class_at(nlf * 28, 0), group_count((size_t) num_groups, 0);
+	bool consistent = true;
+
+	auto body = [&](int tid, int team, TeamBarrier &bar) {
+		// A: the LF bundle's pieces to their places; varblocks per (LfGroup, transform class); blocks per group
+		for (size_t g = (size_t) tid; g < nlf; g += (size_t) team) {
 			const LfGroup &gg = fr.lf_groups[g];
 			const DevLfGroup &d = hp->lf_groups[g];
+			std::copy(gg.blocks.begin(), gg.blocks.end(), hp->blocks.begin() + d.cell_base);
+			std::copy(gg.lfindices.begin(), gg.lfindices.end(), hp->lfindices.begin() + d.cell_base);
+			for (int c = 0; c < 3; ++c) {
+				if (any_tail) std::copy(gg.lfraw[c].begin(), gg.lfraw[c].end(), hp->lfraw[c].begin() + d.cell_base);
+				else std::copy(gg.llfcoeffs[c].begin(), gg.llfcoeffs[c].end(), hp->llf[c].begin() + d.cell_base);
+			}
+			std::copy(gg.xfromy.begin(), gg.xfromy.end(), hp->xfromy.begin() + d.c64_base);
+			std::copy(gg.bfromy.begin(), gg.bfromy.end(), hp->bfromy.begin() + d.c64_base);
+			uint32_t *cnt = class_count.data() + g * 28;
+			for (size_t v = 0; v < gg.varblocks.size(); ++v) {
+				const VarblockInfo &vb = gg.varblocks[v];
+				hp->vb_coeffoff_qfidx[(size_t) d.vb_base + v] = vb.coeffoff_qfidx; hp->vb_hfmul_inv[(size_t) d.vb_base + v] = vb.hfmul_inv;
+				++cnt[vb.dctsel >= 0 && vb.dctsel < 27 ? vb.dctsel : 27];
+			}
+		}
+		for (int32_t g = tid; g < num_groups; g += team) {
+			const DevSection &d = hp->sections[(size_t) g];
+			const LfGroup &gg = fr.lf_groups[(size_t) d.ggidx];
+			uint32_t n = 0;
+			for (int32_t y8 = 0; y8 < d.gh8; ++y8) {
+				const int32_t *row = gg.blocks.data() + (size_t) (d.gy8 + y8) * (size_t) gg.width8 + (size_t) d.gx8;
+				for (int32_t x8 = 0; x8 < d.gw8; ++x8) n += (row[x8] >> 20) >= 2;
+			}
+			group_count[(size_t) g] = n;
+		}
+		bar.wait();
+		if (tid == 0) {   // where every group's list and every (LfGroup, class) run of records starts
+			uint32_t at = 0;
+			for (int32_t g = 0; g < num_groups; ++g) { hp->group_block_start[(size_t) g] = at; at += group_count[(size_t) g]; }
+			hp->group_block_start[(size_t) num_groups] = at;
+			consistent = at == nvb;
+			uint32_t k = 0;
+			for (int d = 0; d <= 27; ++d) {   // grouped by DctSelect, in (LF group, varblock) order within a class
+				hp->class_start[d] = (int32_t) k;
+				for (size_t g = 0; g < nlf; ++g) { class_at[g * 28 + (size_t) d] = k; k += class_count[g * 28 + (size_t) d]; }
+			}
+		}
+		bar.wait();
+		if (!consistent) return;
+		// B: per-group block lists for K1, in the visiting order of j40__hf_coeffs
+		for (int32_t g = tid; g < num_groups; g += team) {
+			const DevSection &d = hp->sections[(size_t) g];
+			const LfGroup &gg = fr.lf_groups[(size_t) d.ggidx];
+			uint32_t at = hp->group_block_start[(size_t) g];
+			const int32_t nb_qf1 = fr.nb_qf_thr + 1, lfidx_size = df.lfidx_size;
+			for (int32_t y8 = 0; y8 < d.gh8; ++y8) for (int32_t x8 = 0; x8 < d.gw8; ++x8) {
+				const size_t cell = (size_t) (d.gy8 + y8) * (size_t) gg.width8 + (size_t) (d.gx8 + x8);
+				const int32_t blk = gg.blocks[cell];
+				if ((blk >> 20) < 2) continue;
+				DevGroupBlock gb;
+				gb.coeffoff_qfidx = (uint32_t) gg.varblocks[(size_t) (blk & 0xfffff)].coeffoff_qfidx;
+				gb.pos_dct = (uint16_t) ((y8 * 32 + x8) | (((blk >> 20) - 2) << 10));
+				{   // block context per channel: block_ctx_map[(c_yxb * 13 + order) * (nb_qf_thr + 1) + qfidx) * lfidx_size + lfidx]
+					const int32_t dctsel = (blk >> 20) - 2;
+					const int32_t bctx0 = (DCT_SELECT[dctsel].order_idx * nb_qf1 + (int32_t) (gb.coeffoff_qfidx & 15u)) * lfidx_size + gg.lfindices[cell];
+					uint32_t v = 0;
+					for (int32_t c_yxb = 0; c_yxb < 3; ++c_yxb) v |= (uint32_t) (fr.block_ctx_map[(size_t) (bctx0 + 13 * nb_qf1 * lfidx_size * c_yxb)] & 15) << (4 * c_yxb);
+					gb.bctx3 = (uint16_t) v;
+				}
+				ordinal[(size_t) d.ggidx][(size_t) (blk & 0xfffff)] = (int32_t) at;
+				hp->group_blocks[at++] = gb;
+			}
+		}
+		bar.wait();
+		// C: work lists for the coefficients -> pixels kernels: every record straight to its place (sorting a quarter of a million
+		// 40-byte records afterwards was a third of this function)
+		for (size_t g = (size_t) tid; g < nlf; g += (size_t) team) {
+			const LfGroup &gg = fr.lf_groups[g];
+			const DevLfGroup &d = hp->lf_groups[g];
+			uint32_t *at = class_at.data() + g * 28;
 			for (size_t v = 0; v < gg.varblocks.size(); ++v) {
 				const VarblockInfo &vb = gg.varblocks[v];
 				DevVarblock dv;
@@ -269,7 +336,21 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 				hp->vb_sorted[at[vb.dctsel < 27 ? vb.dctsel : 27]++] = dv;
 			}
 		}
-	}
+	};
+	run_team(threads, body);
+	if (!consistent) return ERR_RNGE;   // (a varblock without a top-left cell: the parse does not produce such frames, a caller's plan view may)
+
+	// single-pass frames: sparse coefficients (DevPlan::events). A group's region is sized from its section: a non-zero
+	// coefficient costs bits, 6 events per byte is far beyond what entropy coding reaches on real data; a section that still
+	// overflows it fails with ERR_EVOF and the frame is decoded with dense planes instead (runtime.hip).
+	df.sparse_coeffs = fr.fh.num_passes == 1 && !hp->force_dense;
+	if (!fill_event_ranges(hp->sections, num_groups, df.sparse_coeffs != 0, &hp->ev_range, &hp->ev_capacity)) df.sparse_coeffs = 0;
+	hp->codestream.reserve(cs_size + 32);   // (assign + resize without it reallocates and copies the stream a second time)
+	hp->codestream.assign(cs, cs + cs_size);
+	hp->codestream.resize(cs_size + 32, 0);   // the lane decoders read up to three words past the position they stop at
+	bool any_lz77 = false;
+	for (const DevCodeSpec &sp : hp->coeff_specs) any_lz77 |= sp.lz77_enabled != 0;
+	hp->lz_window_size = any_lz77 ? 3 * 65536 + 3 * 1024 + 16 : 0;  // bound on the integers one pass-group stream decodes
 	fill_hf_launch_info(hp->coeff_specs, (uint32_t) fr.block_ctx_map.size(), hp->coeff_floats, &hp->hf);
 	hp->max_large = 0;
 	for (int d = 21; d < 27; ++d) hp->max_large = std::max(hp->max_large, hp->class_start[d + 1] - hp->class_start[d]);

@@ -53,7 +53,8 @@ struct HostPlan {
 bool build_lf_coop(const Frame &fr, DevCoopTree *tree, std::vector<uint64_t> *alias, int32_t *log_alpha_size);   // see plan_build.cpp
 
 // returns 0 or a 4-char error code ("TODO" for frame kinds the hot path does not cover)
-uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostPlan *out);
+// threads: how many may work on the frame-wide arrays together (1: the calling thread alone; the arrays are the same either way)
+uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostPlan *out, int threads = 1);
 
 // single-pass frames keep HF coefficients in scan order on the device (DevFrame::scan_order_coeffs);
 // this rewrites LF group `gg`, channel c in place into the canonical layout the reference uses

@@ -786,6 +786,29 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_front_timing(c
 	return 0;
 }
 
+// build_vardct_plan with a team of `threads` threads against the calling thread alone: every frame-wide array byte for byte.
+// returns 0, a negative number when the frame does not parse, or the number of the first array that differs
+extern "C" __attribute__((visibility("default"))) int32_t hostsim_plan_threads_check(const uint8_t *buf, size_t size, int32_t threads) {
+	const uint8_t *cs; size_t cs_size; std::vector<uint8_t> storage;
+	Frame fr;
+	try { extract_codestream(buf, size, &cs, &cs_size, &storage); parse_frame(cs, cs_size, &fr, 1); } catch (const DecodeError &) { return -1; }
+	HostPlan a, b;
+	const uint32_t ea = build_vardct_plan(fr, cs, cs_size, &a, 1), eb = build_vardct_plan(fr, cs, cs_size, &b, threads);
+	if (ea != eb) return 1;
+	if (ea) return -2;
+	auto same = [](const auto &x, const auto &y) { return x.size() == y.size() && (x.empty() || memcmp(x.data(), y.data(), x.size() * sizeof(x[0])) == 0); };
+	if (!same(a.lf_groups, b.lf_groups)) return 2;
+	if (!same(a.blocks, b.blocks) || !same(a.lfindices, b.lfindices)) return 3;
+	for (int c = 0; c < 3; ++c) if (!same(a.llf[c], b.llf[c]) || !same(a.lfraw[c], b.lfraw[c])) return 4;
+	if (!same(a.xfromy, b.xfromy) || !same(a.bfromy, b.bfromy)) return 5;
+	if (!same(a.vb_coeffoff_qfidx, b.vb_coeffoff_qfidx) || !same(a.vb_hfmul_inv, b.vb_hfmul_inv)) return 6;
+	if (!same(a.group_block_start, b.group_block_start) || !same(a.group_blocks, b.group_blocks)) return 7;
+	if (memcmp(a.class_start, b.class_start, sizeof a.class_start) != 0 || !same(a.vb_sorted, b.vb_sorted)) return 8;
+	if (!same(a.sections, b.sections) || !same(a.ev_range, b.ev_range) || a.ev_capacity != b.ev_capacity || !same(a.codestream, b.codestream)) return 9;
+	if (a.vb_sorted.empty() || a.group_blocks.size() != a.vb_sorted.size()) return 10;
+	return 0;
+}
+
 // the order in which k_hf_lanes' lanes take a frame's groups (FrontPlan::lane_order) and the bytes of each group's sections, summed
 // over the passes; returns the number of groups (or -1)
 extern "C" __attribute__((visibility("default"))) int32_t hostsim_lane_order(const uint8_t *buf, size_t size, uint32_t *order, uint64_t *bytes, int32_t capacity) {

@@ -49,6 +49,22 @@ def test_device_plan_equals_host_plan(sim, mode, w, h, seed, opts):
         assert rc == 0, "check %d failed" % rc
 
 
+@pytest.mark.parametrize("threads", [2, 5, 12])
+def test_plan_built_by_a_team_of_threads_equals_the_plan_of_one(built, threads):
+    """build_vardct_plan's frame-wide arrays (LF bundle, K1's block lists, K2's sorted work list) written by a team of threads -- what
+    the single-image path of j40_next_frame does with the threads it parsed with -- are byte for byte those of the calling thread
+    alone, on frames from one LfGroup to the 8K bench frame's twelve"""
+    S = C.CDLL(os.path.join(ROOT, "build", "libhostsim.so"))
+    S.hostsim_plan_threads_check.restype = C.c_int32
+    S.hostsim_plan_threads_check.argtypes = [C.c_void_p, C.c_size_t, C.c_int32]
+    cases = CASES[-8:] + [("vardct", 7680, 4320, 3, dict(forward=1)), ("vardct", 520, 264, 41, dict(alpha=1))]
+    for mode, w, h, seed, opts in cases:
+        data = synth(mode, w, h, seed, **opts)
+        buf = C.create_string_buffer(data, len(data))
+        for _ in range(3 if w < 3000 else 1):   # (a race would not show every time)
+            assert S.hostsim_plan_threads_check(buf, len(data), threads) == 0, (w, h, opts)
+
+
 def test_damaged_lf_sections_get_the_host_parse_verdict(sim):
     data = synth("vardct", 2600, 2100, 41)
     rng = np.random.default_rng(11)
