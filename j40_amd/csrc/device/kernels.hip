@@ -433,9 +433,11 @@ extern "C" __attribute__((visibility("default"))) void j40hip_debug_k2_phases(un
 // cut into tiles of `per_wg` varblocks; tile_prefix[f] = tiles of the frames before frame f (built on the device by k_k2_tiles
 // from the frames' class_start, which the device-side plan build writes: the host never learns the counts). Workgroup b takes
 // a contiguous run of tiles (one search for its first tile's frame, then it walks along); k2_bind replaces the kernel arguments with
-// the next tile's frame's plan, list, count and output; `first` = the tile's first varblock. Returns false when the run is done.
-// the frame state below is the same in every lane; said so to the compiler (v_readfirstlane), it lives in scalar registers across the
-// tiles of a frame instead of fifty vector registers per lane
+// the next tile's frame's list, count and output when the run enters another frame; `first` = the tile's first varblock. Returns
+// false when the run is done.
+//
+// What a frame's tiles share (its plan's pointers, colour constants, lists) is the same in every lane; said so to the compiler
+// (uni(): v_readfirstlane), it lives in scalar registers across the tiles of a frame instead of fifty vector registers per lane.
 __device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) v); }
 __device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
