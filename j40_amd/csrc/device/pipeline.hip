@@ -727,11 +727,16 @@ static j40hip_pipeline *g_serve[16] = {nullptr};
 static int cpu_quota() {
 	unsigned hw = std::thread::hardware_concurrency();
 	int n = hw ? (int) hw : 4;
-	if (FILE *fp = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+	if (FILE *fp = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2
 		char q[64] = {0}; long long period = 0;
 		if (fscanf(fp, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) { const long long c = atoll(q) / period; if (c >= 1 && c < n) n = (int) c; }
 		fclose(fp);
+		return n;
 	}
+	long long quota = -1, period = 0;   // cgroup v1
+	if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fp, "%lld", &quota) != 1) quota = -1; fclose(fp); }
+	if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lld", &period) != 1) period = 0; fclose(fp); }
+	if (quota > 0 && period > 0) { const long long c = quota / period; if (c >= 1 && c < n) n = (int) c; }
 	return n;
 }
 
