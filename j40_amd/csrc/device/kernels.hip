@@ -21,6 +21,7 @@
 #include "vardct_dev.h"
 #include "special8_dev.h"
 #include "large_dev.h"
+#include "k2_iter_dev.h"
 #include "hf_uni_dev.h"
 #include "kernels.h"
 
@@ -438,11 +439,6 @@ extern "C" __attribute__((visibility("default"))) void j40hip_debug_k2_phases(un
 //
 // What a frame's tiles share (its plan's pointers, colour constants, lists) is the same in every lane; said so to the compiler
 // (uni(): v_readfirstlane), it lives in scalar registers across the tiles of a frame instead of fifty vector registers per lane.
-__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) v); }
-__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-__device__ __forceinline__ size_t uni(size_t v) { return (size_t) uni((uint32_t) v) | (size_t) uni((uint32_t) (v >> 32)) << 32; }
-template <typename T> __device__ __forceinline__ T *uni(T *p) { return (T *) uni((size_t) p); }
 __device__ __forceinline__ void uniform_plan(DevPlan &p) {   // (the fields the pixel kernels read)
 	p.frame = uni(p.frame); p.pool_u16 = uni(p.pool_u16); p.pool_f32 = uni(p.pool_f32); p.events = uni(p.events); p.block_events = uni(p.block_events);
 	for (int c = 0; c < 3; ++c) { p.llf[c] = uni(p.llf[c]); p.coeffs[c] = uni(p.coeffs[c]); }
@@ -454,39 +450,17 @@ __device__ __forceinline__ void uniform_colour(ColourConsts &c) {
 	c.itscale = uni(c.itscale); c.bpp = uni(c.bpp);
 }
 
-struct K2Iter { int32_t tile, tile_end, frame, frame_first, frame_end; };   // tiles [frame_first, frame_end) are `frame`'s
+// (K2Iter, k2_run_begin, k2_run_bind: k2_iter_dev.h -- also compiled for the CPU, where tests/hostsim walks every workgroup's run)
 template <bool BATCH>
 __device__ __forceinline__ K2Iter k2_begin(const int32_t *tile_prefix, int32_t nframes) {
-	K2Iter it = {0, 1, 0, 0, 0};
-	if (!BATCH) return it;
-	const int32_t total = tile_prefix[nframes], chunk = (total + (int32_t) gridDim.x - 1) / (int32_t) gridDim.x;
-	it.tile = (int32_t) blockIdx.x * chunk; it.tile_end = min(total, it.tile + chunk);
-	int32_t lo = 0, hi = nframes - 1;   // last frame whose prefix <= tile
-	while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (tile_prefix[mid] <= it.tile) lo = mid; else hi = mid - 1; }
-	it.frame = lo;
-	return it;
+	if (!BATCH) return K2Iter{0, 1, 0, 0, 0};
+	return k2_run_begin(tile_prefix, nframes, (int32_t) blockIdx.x, (int32_t) gridDim.x);
 }
-// A workgroup's run of tiles stays inside one frame for hundreds of tiles: the frame's list, count and output are fetched when the
-// run ENTERS a frame (`entered`), not per tile -- per tile the bind is arithmetic on registers (round 4: the instrumented build put
-// a third of a tile's time into its prologue, a chain of dependent loads of which these were the head).
 template <bool BATCH>
 __device__ __forceinline__ bool k2_bind(K2Iter &it, const K2Frame *batch, const int32_t *tile_prefix, int32_t class_a, int32_t class_b, int32_t per_wg,
 		const DevVarblock *&list, int32_t &count, uint8_t *&rgba, size_t &stride, int32_t &frame, int32_t &first, bool &entered) {
 	if (!BATCH) { frame = 0; first = (int32_t) blockIdx.x * per_wg; entered = it.tile == 0; return it.tile++ == 0; }
-	if (it.tile >= it.tile_end) return false;
-	entered = it.tile >= it.frame_end;   // (frame_end starts at 0: the first tile always enters)
-	if (entered) {
-		while (tile_prefix[it.frame + 1] <= it.tile) ++it.frame;   // (frames without tiles of this class)
-		it.frame = uni(it.frame);
-		it.frame_first = uni(tile_prefix[it.frame]); it.frame_end = uni(tile_prefix[it.frame + 1]);
-		const K2Frame &fr = batch[it.frame];
-		const int32_t a = fr.class_start[class_a];
-		list = uni(fr.sorted + a); count = uni(fr.class_start[class_b] - a); rgba = uni(fr.rgba); stride = uni(fr.stride);
-	}
-	frame = it.frame;
-	first = (it.tile - it.frame_first) * per_wg;
-	++it.tile;
-	return true;
+	return k2_run_bind(it, batch, tile_prefix, class_a, class_b, per_wg, list, count, rgba, stride, frame, first, entered);
 }
 
 // exclusive prefix sums of the per-block event counts held by lanes 0..NB-1 of the first wavefront (`mine`, 0 for lanes

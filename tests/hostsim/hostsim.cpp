@@ -15,6 +15,7 @@
 #include "../../j40_amd/csrc/device/vardct_dev.h"
 #include "../../j40_amd/csrc/device/special8_dev.h"
 #include "../../j40_amd/csrc/device/large_dev.h"
+#include "../../j40_amd/csrc/device/k2_iter_dev.h"
 #include "../../j40_amd/csrc/device/modular_dev.h"
 #include "../../j40_amd/csrc/device/squeeze_dev.h"
 
@@ -783,6 +784,44 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_front_timing(c
 		} catch (const DecodeError &) { return -1; }
 	}
 	for (int i = 0; i < 4; ++i) out_ms[i] /= iters;
+	return 0;
+}
+
+// The persistent pixel kernels' walk over their tiles (k2_iter_dev.h), every workgroup of a launch one after the other: `counts[f]` =
+// varblocks of the launch's class in frame f (frames without any among them), tiles of `per_wg` varblocks, `grid` workgroups.
+// Every tile of every frame must be taken exactly once with its first varblock, the frame's list / count / output bound when --
+// and only when -- a run enters a frame. Returns 0 or the number of the check that failed.
+extern "C" __attribute__((visibility("default"))) int32_t hostsim_k2_runs_check(const int32_t *counts, int32_t nframes, int32_t per_wg, int32_t grid) {
+	std::vector<K2Frame> frames((size_t) nframes);
+	std::vector<DevVarblock> store(16);
+	std::vector<int32_t> prefix((size_t) nframes + 1, 0);
+	const int32_t class_a = 4, class_b = 7;   // (a class spanning several DctSelect values, like the specials')
+	for (int32_t f = 0; f < nframes; ++f) {
+		memset(&frames[(size_t) f], 0, sizeof(K2Frame));
+		K2Frame &fr = frames[(size_t) f];
+		fr.sorted = store.data() + f % 7; fr.rgba = (uint8_t *) store.data() + 1000 * f; fr.stride = 4096 + (size_t) f;
+		for (int d = 0; d < 28; ++d) fr.class_start[d] = d <= class_a ? 11 * f : d < class_b ? 11 * f + counts[f] / 2 : 11 * f + counts[f];
+		prefix[(size_t) f + 1] = prefix[(size_t) f] + (counts[f] + per_wg - 1) / per_wg;   // as k_k2_tiles lays it out
+	}
+	std::vector<int32_t> taken((size_t) prefix[(size_t) nframes], 0);
+	for (int32_t block = 0; block < grid; ++block) {
+		const DevVarblock *list = nullptr; int32_t count = -1; uint8_t *rgba = nullptr; size_t stride = 0;
+		int32_t last_frame = -1;
+		for (K2Iter it = k2_run_begin(prefix.data(), nframes, block, grid); ; ) {
+			int32_t frame, first; bool entered;
+			if (!k2_run_bind(it, frames.data(), prefix.data(), class_a, class_b, per_wg, list, count, rgba, stride, frame, first, entered)) break;
+			if (frame < 0 || frame >= nframes) return 1;
+			if (entered != (frame != last_frame)) return 2;
+			last_frame = frame;
+			const K2Frame &fr = frames[(size_t) frame];
+			if (list != fr.sorted + fr.class_start[class_a] || count != counts[frame] || rgba != fr.rgba || stride != fr.stride) return 3;
+			if (first < 0 || first >= count || first % per_wg != 0) return 4;
+			const int32_t tile = prefix[(size_t) frame] + first / per_wg;
+			if (tile >= prefix[(size_t) frame + 1]) return 5;
+			++taken[(size_t) tile];
+		}
+	}
+	for (int32_t t : taken) if (t != 1) return 6;
 	return 0;
 }
 

@@ -102,6 +102,27 @@ def test_large_transforms_levels_in_lds_and_64_point_registers_equal_the_sweeps_
     assert {21, 22, 23, 24, 25, 26} <= seen, sorted(seen)
 
 
+def test_persistent_pixel_kernels_take_every_tile_once(sim):
+    """k2_iter_dev.h, the walk of a persistent workgroup over its run of tiles (kernels.hip binds a frame's list, count and output
+    only when the run enters the frame): over random batches -- frames without a block of the class, fewer tiles than workgroups,
+    one workgroup, thousands -- every tile of every frame is taken exactly once with its first varblock and the frame's bindings"""
+    sim.hostsim_k2_runs_check.restype = C.c_int32
+    sim.hostsim_k2_runs_check.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    rng = np.random.default_rng(4)
+    for trial in range(400):
+        nframes = int(rng.integers(1, 40))
+        counts = rng.integers(0, 2000, nframes).astype(np.int32)
+        counts[rng.random(nframes) < 0.3] = 0
+        if trial % 7 == 0:
+            counts[:] = 0
+            counts[int(rng.integers(0, nframes))] = int(rng.integers(1, 5))
+        per_wg = int(rng.choice([1, 2, 4, 8, 16, 32]))
+        grid = int(rng.choice([1, 2, 3, 64, 257, 1024, 5000]))
+        if trial == 3:
+            counts[:] = 0   # (a batch without a block of the class: every run is empty)
+        assert sim.hostsim_k2_runs_check(counts.ctypes.data, nframes, per_wg, grid) == 0, (counts.tolist(), per_wg, grid)
+
+
 def test_fast_latency_decoder_matches_nested_decoder(sim, ref):
     """decode_hf_section_fast (hf_uni_dev.h: the latency kernel's fast path -- tables across lanes, the next coefficient's cluster
     fetched for both outcomes of the current one) against decode_hf_section on every single-pass rANS case: coefficients, and on
