@@ -674,7 +674,9 @@ uint32_t j40hip_alf_launch(j40hip_alf *a, j40hip_aframe *const *frames, int n, h
 	std::vector<DevLfLaneSet> sets((size_t) n);
 	for (int i = 0; i < n; ++i) sets[(size_t) i] = frames[i]->lf_set;
 	std::vector<DevLfWave> waves;
-	const uint32_t lds = pack_lf_waves(sets.data(), n, &waves);
+	uint32_t lds = lf_rows_enabled() ? pack_lf_row_waves(sets.data(), n, &waves) : 0u;
+	const bool rows = lds != 0;
+	if (!rows) lds = pack_lf_waves(sets.data(), n, &waves);
 	const size_t o_waves = (sizeof(DevLfLaneSet) * (size_t) n + 255) & ~(size_t) 255, bytes = o_waves + sizeof(DevLfWave) * waves.size() + 64;
 	if (!a->host.reserve(bytes, 0)) return ERR_MEM;
 	if (bytes > a->dev_cap) {
@@ -689,7 +691,8 @@ uint32_t j40hip_alf_launch(j40hip_alf *a, j40hip_aframe *const *frames, int n, h
 	if (uint32_t e = wait_for_uploads(frames, n, s)) return e;
 	if (hipMemcpyAsync(a->dev, a->host.ptr, bytes - 64, hipMemcpyHostToDevice, s) != hipSuccess) return ERR_GPU;
 	const double tq2 = prof_now();
-	launch_lf_lanes((const DevLfLaneSet *) a->dev, (const DevLfWave *) ((const uint8_t *) a->dev + o_waves), (int32_t) waves.size(), lds + 64, s);
+	if (rows) launch_lf_rows((const DevLfLaneSet *) a->dev, (const DevLfWave *) ((const uint8_t *) a->dev + o_waves), (int32_t) waves.size(), lds + 64, s);
+	else launch_lf_lanes((const DevLfLaneSet *) a->dev, (const DevLfWave *) ((const uint8_t *) a->dev + o_waves), (int32_t) waves.size(), lds + 64, s);
 	const double tq3 = prof_now();
 	if (hipEventRecord(a->done, s) != hipSuccess || hipGetLastError() != hipSuccess) return ERR_GPU;
 	if (getenv("J40HIP_ASYNC_TIMING")) fprintf(stderr, "[j40hip lf launch] %d frames, %zu waves: pack %.2f, copy %.2f, launch %.2f, record %.2f ms\n", n, waves.size(), tq1 - tq0, tq2 - tq1, tq3 - tq2, prof_now() - tq3);

@@ -103,16 +103,16 @@ J40_DEV uint32_t lane_bit_position(const LaneBits &b) { return 8u * b.pos - (uin
 
 // one symbol: rANS step (j40.h:2441-2466) + hybrid integer (j40.h:2313-2334). *err receives the error the
 // reference would have raised first ("shrt" while renormalising, then "iovf", then "shrt" in the extra bits).
-template <class Tables>   // LaneTables, or a set of tables with the same members elsewhere (LfLaneTables, lf_lanes_dev.h)
-J40_DEV int32_t lane_symbol(LaneBits &b, uint32_t &state, const Tables &t, int32_t ctx, uint32_t end_bit, uint32_t *err) {
-	const uint32_t cl = t.ctx_map[ctx];
+// `alias`: the tables of all clusters ([cluster << log_alpha | bucket]); cl, m: the symbol's cluster and that cluster's
+// configuration word (LaneTables::cluster_cfg) -- looked up by the caller, who may have them at hand already (lf_rows_dev.h)
+template <class AliasPtr>
+J40_DEV int32_t lane_symbol_in_cluster(LaneBits &b, uint32_t &state, AliasPtr alias, int32_t log_alpha, int32_t log_bucket, uint32_t cl, uint32_t m, uint32_t end_bit, uint32_t *err) {
 	if (state == 0) {   // first symbol of the section (j40.h:2445-2449); the window holds > 32 bits
 		state = lane_bits_take(b, 16); state |= lane_bits_take(b, 16) << 16;
 		lane_bits_refill(b);
 	}
-	const uint32_t idx = state & 0xfff, i = idx >> t.log_bucket, pos = idx & ((1u << t.log_bucket) - 1);
-	const uint64_t e = t.alias[(cl << t.log_alpha) + i];
-	const uint32_t m = t.cluster_cfg[cl];
+	const uint32_t idx = state & 0xfff, i = idx >> log_bucket, pos = idx & ((1u << log_bucket) - 1);
+	const uint64_t e = alias[(cl << log_alpha) + i];
 	const uint32_t elo = (uint32_t) e, ehi = (uint32_t) (e >> 32);
 	const bool aliased = pos >= (elo & 0xff);
 	const int32_t token = (int32_t) (aliased ? (elo >> 20) & 0xff : i);
@@ -139,6 +139,11 @@ J40_DEV int32_t lane_symbol(LaneBits &b, uint32_t &state, const Tables &t, int32
 	const int32_t value = ((top | hi) << (midbits + lsb)) | ((mid << lsb) | lo);
 	*err = short1 ? (uint32_t) ERR_SHRT : iovf ? (uint32_t) ERR_IOVF : short2 ? (uint32_t) ERR_SHRT : 0u;
 	return big ? value : token;
+}
+template <class Tables>   // LaneTables, or a set of tables with the same members elsewhere (LfLaneTables, lf_lanes_dev.h)
+J40_DEV int32_t lane_symbol(LaneBits &b, uint32_t &state, const Tables &t, int32_t ctx, uint32_t end_bit, uint32_t *err) {
+	const uint32_t cl = t.ctx_map[ctx];
+	return lane_symbol_in_cluster(b, state, t.alias, t.log_alpha, t.log_bucket, cl, t.cluster_cfg[cl], end_bit, err);
 }
 
 // the entry of DevPlan::block_events of a finished block {first event, n_Y, n_X, n_B}, one 16-byte store

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include "modular_coop_dev.h"
 #include "lf_lanes_dev.h"
+#include "lf_rows_dev.h"
 #include "kernels.h"
 #include <algorithm>
 #include <cstring>
@@ -117,6 +118,78 @@ __global__ void __launch_bounds__(64) k_lf_lanes(const DevLfLaneSet *sets, const
 	if (active) { J40_GLOBAL DevLfResult *r = (J40_GLOBAL DevLfResult *) t.result; r->status = L.err; r->nb_varblocks = L.nb_varblocks; }
 }
 
+// the pieces of rows the lanes' last steps completed, copied out by the whole wavefront: lane i takes samples i, i + 64, ... of
+// each piece, so a piece leaves as runs of 128 consecutive bytes (`wins`: the window of lane 0)
+J40_DEV void lf_row_flush_wave(LfRowLane &L, int32_t lane, const J40_LDS int16_t *wins) {
+	uint64_t need = __builtin_amdgcn_ballot_w64(L.flush_n > 0);
+	const uint64_t dst_bits = (uint64_t) (uintptr_t) L.flush_dst;
+	while (need) {
+		const int32_t j = (int32_t) __builtin_ctzll(need);
+		need &= need - 1;
+		const int32_t n = __builtin_amdgcn_readlane(L.flush_n, j);
+		const uint64_t d = (uint64_t) (uint32_t) __builtin_amdgcn_readlane((int32_t) (uint32_t) dst_bits, j) | ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int32_t) (uint32_t) (dst_bits >> 32), j) << 32);
+		J40_GLOBAL int16_t *dst = (J40_GLOBAL int16_t *) (uintptr_t) d;
+		const J40_LDS int16_t *src = wins + j * LF_ROW_PITCH;
+		for (int32_t i = lane; i < n; i += 64) dst[i] = src[i];
+	}
+	L.flush_n = 0;
+}
+
+// One LfGroup section per LANE, tree + alias tables + row windows in LDS (lf_rows_dev.h). A wavefront takes the sections of the
+// frames pack_lf_row_waves gave it; LDS: per part the staged tree and the alias tables, then one window per section.
+__global__ void __launch_bounds__(64) k_lf_rows(const DevLfLaneSet *sets, const DevLfWave *waves) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t lfr_lds[];
+	const J40_GLOBAL DevLfWave &wv = ((const J40_GLOBAL DevLfWave *) waves)[blockIdx.x];
+	const int32_t lane = threadIdx.x, num_parts = wv.num_parts;
+	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+	J40_LDS uint8_t *lds = (J40_LDS uint8_t *) lfr_lds;
+	const J40_GLOBAL DevLfTask *task = nullptr;
+	LfRowTables T;
+	T.tree = nullptr; T.alias = nullptr; T.log_alpha = 5; T.log_bucket = 7; T.uses = 0;
+	uint32_t at = 0; int32_t lane0 = 0;
+	for (int32_t p = 0; p < num_parts; ++p) {
+		const J40_GLOBAL DevLfLaneSet &set = ((const J40_GLOBAL DevLfLaneSet *) sets)[wv.part[p].set];
+		const int32_t first = wv.part[p].first_task, count = wv.part[p].count;
+		const int32_t num_nodes = set.num_nodes, num_clusters = set.num_clusters, log_alpha = set.log_alpha;
+		J40_LDS int32_t *l_tree = (J40_LDS int32_t *) (lds + at);
+		J40_LDS uint64_t *l_alias = (J40_LDS uint64_t *) (lds + at + align16(16u * (uint32_t) num_nodes));
+		{
+			const J40_GLOBAL int32_t *tsrc = (const J40_GLOBAL int32_t *) set.tree;
+			const J40_GLOBAL uint8_t *msrc = (const J40_GLOBAL uint8_t *) set.ctx_map;
+			const J40_GLOBAL uint32_t *csrc = (const J40_GLOBAL uint32_t *) set.cluster_cfg;
+			for (int32_t i = lane; i < num_nodes; i += 64) {
+				const int32_t prop = tsrc[4 * i]; int32_t value = tsrc[4 * i + 1];
+				if (prop < 0) { const uint32_t cl = msrc[value]; value = lf_rows_leaf_word(cl, csrc[cl]); }   // (the host checked value < num_dist)
+				l_tree[4 * i] = prop; l_tree[4 * i + 1] = value; l_tree[4 * i + 2] = tsrc[4 * i + 2]; l_tree[4 * i + 3] = tsrc[4 * i + 3];
+			}
+			const J40_GLOBAL uint64_t *asrc = (const J40_GLOBAL uint64_t *) set.alias;
+			for (int32_t i = lane; i < (num_clusters << log_alpha); i += 64) l_alias[i] = asrc[i];
+		}
+		if (lane >= lane0 && lane < lane0 + count) {
+			task = (const J40_GLOBAL DevLfTask *) set.tasks + (first + lane - lane0);
+			T.tree = (const J40_LDS DevTreeNode *) l_tree; T.alias = l_alias; T.log_alpha = log_alpha; T.log_bucket = 12 - log_alpha; T.uses = set.uses;
+		}
+		lane0 += count;
+		at += lf_rows_table_bytes(num_nodes, num_clusters, log_alpha);
+	}
+	J40_LDS int16_t *wins = (J40_LDS int16_t *) (lds + at);
+	__syncthreads();
+	const bool active = task != nullptr;
+	if (!active) {   // (something valid to point at)
+		const J40_GLOBAL DevLfLaneSet &set = ((const J40_GLOBAL DevLfLaneSet *) sets)[wv.part[0].set];
+		task = (const J40_GLOBAL DevLfTask *) set.tasks + wv.part[0].first_task;
+	}
+	const J40_GLOBAL DevLfTask &t = *task;
+	LfRowLane L;
+	lf_row_init(L, t, wins + (active ? lane : 0) * LF_ROW_PITCH);
+	if (!active) { L.chan = 7; L.setup = false; }
+	while (__builtin_amdgcn_ballot_w64(!lf_row_done(L))) {
+		lf_row_step(L, t, T);
+		if (__builtin_amdgcn_ballot_w64(L.flush_n > 0)) lf_row_flush_wave(L, lane, wins);
+	}
+	if (active) { J40_GLOBAL DevLfResult *r = (J40_GLOBAL DevLfResult *) t.result; r->status = L.err; r->nb_varblocks = L.nb_varblocks; }
+}
+
 // J40HIP_LF_ALIAS_LDS=1: the alias tables staged in LDS too (frames whose tables do not fit: the host decodes their sections)
 bool lf_lanes_alias_in_lds() {
 	static const bool v = [] { const char *e = getenv("J40HIP_LF_ALIAS_LDS"); return e && atoi(e) != 0; }();
@@ -150,6 +223,46 @@ void launch_lf_lanes(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t n
 	if (!configured) { (void) hipFuncSetAttribute((const void *) k_lf_lanes<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); (void) hipFuncSetAttribute((const void *) k_lf_lanes<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); configured = true; }
 	if (lf_lanes_alias_in_lds()) hipLaunchKernelGGL(k_lf_lanes<true>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
 	else hipLaunchKernelGGL(k_lf_lanes<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
+}
+
+// J40HIP_LF_KERNEL=lanes: the older decoder (tables' alias entries and rows in global memory) for every launch; default: k_lf_rows
+// for every launch whose frames' tables fit its LDS budget
+bool lf_rows_enabled() {
+	static const bool v = [] { const char *e = getenv("J40HIP_LF_KERNEL"); return !(e && strcmp(e, "lanes") == 0); }();
+	return v;
+}
+
+// packs the sections of `sets` into wavefronts of k_lf_rows; returns the LDS bytes a wavefront needs at most, 0 when some frame's
+// tables do not fit (the launch then goes to k_lf_lanes). J40HIP_LF_ROWS_LDS_KB: what a wavefront's tables and windows may take
+// together (default 48: two 8K frames of seven clusters x 256 buckets -- 2 x (14.5 KB + 12 windows) = 41 KB -- so that such a
+// workgroup still fits beside the coefficient decoder's 99 KB on a compute unit)
+uint32_t pack_lf_row_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std::vector<DevLfWave> *waves) {
+	static const uint32_t budget = [] { const char *e = getenv("J40HIP_LF_ROWS_LDS_KB"); return (e && atoi(e) > 0 ? (uint32_t) atoi(e) : 48u) * 1024u; }();
+	const uint32_t win_bytes = 2u * LF_ROW_PITCH;
+	uint32_t most = 0, used = 0; int32_t lanes = 0;
+	DevLfWave cur; memset(&cur, 0, sizeof cur);
+	auto flush = [&] { if (cur.num_parts) { waves->push_back(cur); most = std::max(most, used); } memset(&cur, 0, sizeof cur); used = 0; lanes = 0; };
+	for (int32_t i = 0; i < num_sets; ++i) {
+		const uint32_t tables = lf_rows_table_bytes(sets_host[i].num_nodes, sets_host[i].num_clusters, sets_host[i].log_alpha);
+		if (tables + win_bytes > 60u * 1024u) { waves->clear(); return 0; }
+		for (int32_t first = 0; first < sets_host[i].ntasks; ) {
+			if (lanes >= 64 || cur.num_parts >= LF_WAVE_PARTS || (cur.num_parts && used + tables + win_bytes > budget)) flush();
+			// as many of the frame's sections as fit the budget (a wavefront's first frame may exceed it, up to the 60 KB a workgroup asks for at most)
+			const uint32_t limit = cur.num_parts ? budget : std::min(60u * 1024u, std::max(budget, tables + win_bytes));
+			const int32_t count = std::min(std::min(64 - lanes, sets_host[i].ntasks - first), std::max(1, (int32_t) ((limit - used - tables) / win_bytes)));
+			cur.part[cur.num_parts].set = i; cur.part[cur.num_parts].first_task = first; cur.part[cur.num_parts].count = count; ++cur.num_parts;
+			used += tables + (uint32_t) count * win_bytes; lanes += count; first += count;
+		}
+	}
+	flush();
+	return most;
+}
+
+void launch_lf_rows(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t num_waves, uint32_t lds_bytes, hipStream_t stream) {
+	if (num_waves <= 0) return;
+	static bool configured = false;
+	if (!configured) { (void) hipFuncSetAttribute((const void *) k_lf_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); configured = true; }
+	hipLaunchKernelGGL(k_lf_rows, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
 }
 
 void launch_lf_groups(const DevLfTask *tasks, int32_t num_tasks, hipStream_t stream) {

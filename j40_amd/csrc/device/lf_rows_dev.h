@@ -1,0 +1,228 @@
+// j40_amd/csrc/device/lf_rows_dev.h -- the LfGroup sections of VarDCT frames, one section per wavefront LANE, with everything a
+// sample's dependent chain touches held in LDS (k_lf_rows, lf_decode.hip; SURVEY.md 8f-1: the two Modular sub-images of
+// j40__lf_group, j40.h:6722-6790 = j40__modular_channel, j40.h:4127-4240, over the LF coefficient image and the HF metadata image).
+//
+// lf_lanes_dev.h's decoder (same decomposition: a lane is a section, an iteration is one sample of every lane) spent ~2600 cycles
+// per sample on ~130 instructions: what it waited for was memory. Its alias entry came from global memory (an L2 round trip on the
+// chain of every sample), the row above was loaded from global memory two samples ahead, every sample was a 2-byte global store,
+// and on gfx9 one counter (vmcnt) covers loads AND stores: each wait for the alias entry also waited for the store of the sample
+// before. Here no sample of a row touches vector memory:
+//   * the alias tables of the lane's frame sit in LDS beside its tree (8 bytes per bucket: 14 KB for seven clusters of 256);
+//   * a leaf of the staged tree carries its cluster and that cluster's hybrid-integer configuration (context map and configuration
+//     table resolved while staging: two dependent LDS reads fewer per sample), and the node a channel's walk starts from is kept
+//     in registers -- a channel whose subtree is a single leaf reads nothing but its alias entry;
+//   * every lane owns a window of LF_ROW_WIN samples in LDS. The row being decoded is written there; the slot of sample x holds
+//     the row ABOVE's sample x until it is overwritten, so the same window serves the neighbours N, NW, NE, NEE, NWW (read two
+//     samples ahead of their use, off the chain). A finished row leaves as one coalesced copy done by all 64 lanes together
+//     (lf_row_flush_wave): 2-byte stores of consecutive addresses instead of 64 scattered ones per iteration, and nothing waits
+//     for them;
+//   * channels wider than the window (the varblock-info channel: two rows of up to 65 536 samples) go through the window in
+//     pieces and read the row above from global memory like the older decoder did.
+// What is left in vector memory: the codestream word requested one refill ahead (once in several samples) and the row copies.
+// Same streams as lf_lanes_dev.h (rANS without LZ77, no weighted predictor, no previous-channel properties, plain second header),
+// same samples, same status codes: tests/hostsim runs both against the host decoder.
+#pragma once
+#include "lf_lanes_dev.h"
+
+namespace j40hip {
+
+enum { LF_ROW_WIN = 256,             // samples per lane window: an LfGroup is at most 256 cells wide (2048 pixels)
+       LF_ROW_PITCH = LF_ROW_WIN + 2 };   // int16 units between the windows of neighbouring lanes (129 dwords: lanes at the same x hit distinct banks)
+
+// the tables of a lane's frame as k_lf_rows stages them
+struct LfRowTables {
+	const J40_LDS DevTreeNode *tree;   // leaves: value = cluster << 24 | configuration word of the cluster (lf_rows_leaf_word)
+	const J40_LDS uint64_t *alias;
+	int32_t log_alpha, log_bucket;
+	uint32_t uses;                     // LfLaneFrame::uses
+};
+
+// what a staged leaf carries instead of its context: `cfg` as in LaneTables::cluster_cfg (max_token from bit 12 up; tokens are
+// < 256, so clamping it to 12 bits keeps `token > max_token` intact)
+J40_DEV int32_t lf_rows_leaf_word(uint32_t cluster, uint32_t cfg) {
+	const uint32_t mt = cfg >> 12;
+	return (int32_t) ((cfg & 0xfffu) | ((mt > 0xfffu ? 0xfffu : mt) << 12) | (cluster << 24));
+}
+
+// LDS bytes of one frame's staged tables (tree nodes, then the alias tables)
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline uint32_t lf_rows_table_bytes(int32_t num_nodes, int32_t num_clusters, int32_t log_alpha) {
+	return ((16u * (uint32_t) num_nodes + 15u) & ~15u) + 8u * ((uint32_t) num_clusters << log_alpha);
+}
+
+struct LfRowLane {
+	LaneBits b;
+	uint32_t state, err, end_bit;
+	int32_t chan;                      // as LfLane::chan
+	int32_t x, y, cw, chh;
+	int32_t r_prop, r_value, r_a, r_b, root;   // the node the channel's walk starts from, and where it is
+	int32_t pw, pww;
+	int32_t a0, a1, a2, a3, a4;        // the row above at x - 2 .. x + 2
+	J40_GLOBAL int16_t *row;           // the channel's current row in global memory
+	J40_LDS int16_t *win;              // this lane's window
+	int32_t nb_varblocks;
+	bool setup;
+	int32_t flush_n;                   // > 0: the step completed a piece of a row: win[0 .. flush_n) belongs at flush_dst
+	J40_GLOBAL int16_t *flush_dst;
+};
+
+J40_DEV void lf_row_fail(LfRowLane &L, uint32_t e) { if (!L.err) L.err = e; L.chan = 7; L.setup = false; }
+J40_DEV bool lf_row_done(const LfRowLane &L) { return L.chan == 7 && !L.setup; }
+
+J40_DEV uint32_t lf_row_take(LfRowLane &L, int32_t n) {   // header bits (n <= 31)
+	if (L.b.nbits < n) lane_bits_refill(L.b);
+	const uint32_t v = lane_bits_take(L.b, n);
+	if (lane_bit_position(L.b) > L.end_bit) lf_row_fail(L, ERR_SHRT);
+	return v;
+}
+
+J40_DEV void lf_row_finish_code(LfRowLane &L) {   // j40.h:2884
+	if (L.state == 0) { lane_bits_refill(L.b); L.state = lf_row_take(L, 16); L.state |= lf_row_take(L, 16) << 16; }
+	if (!L.err && L.state != 0x130000) lf_row_fail(L, ERR_ANS);
+	L.state = 0;
+}
+
+J40_DEV void lf_row_init(LfRowLane &L, const J40_GLOBAL DevLfTask &t, J40_LDS int16_t *win) {
+	lane_bits_init(L.b, (const J40_GLOBAL uint8_t *) t.codestream, 8u * t.byte_off + t.bit_off);
+	L.state = 0; L.err = 0; L.end_bit = 8u * (t.byte_off + t.size);
+	L.chan = 0; L.setup = true; L.nb_varblocks = 0;
+	L.x = L.y = 0; L.cw = L.chh = 0; L.root = 0; L.r_prop = -1; L.r_value = L.r_a = L.r_b = 0;
+	L.pw = L.pww = 0; L.a0 = L.a1 = L.a2 = L.a3 = L.a4 = 0; L.row = nullptr; L.win = win;
+	L.flush_n = 0; L.flush_dst = nullptr;
+	if (8u * t.byte_off + t.bit_off > L.end_bit) lf_row_fail(L, ERR_SHRT);
+}
+
+// starts channel L.chan: as lf_lane_setup, and fetches the node the channel's walk starts from
+J40_DEV void lf_row_setup(LfRowLane &L, const J40_GLOBAL DevLfTask &t, const LfRowTables &T) {
+	for (;;) {
+		if (L.chan == 3) {
+			lf_row_finish_code(L);
+			if (L.err) return;
+			L.nb_varblocks = (int32_t) lf_row_take(L, t.nbvb_bits) + 1;
+			const uint32_t header = lf_row_take(L, 4);   // use_global_tree = 1, default wp = 1, no transforms (j40.h:3717-3760)
+			if (L.err) return;
+			if (header != 3u || 2u * (uint32_t) L.nb_varblocks > t.info_capacity) { lf_row_fail(L, ERR_LFFB); return; }
+		}
+		if (L.chan == 7) { lf_row_finish_code(L); L.chan = 7; L.setup = false; return; }
+		int32_t cw, chh; J40_GLOBAL int16_t *base;
+		switch (L.chan) {
+		case 0: case 1: case 2: cw = t.w8; chh = t.h8; base = (J40_GLOBAL int16_t *) t.lf[L.chan]; break;
+		case 3: cw = t.w64; chh = t.h64; base = (J40_GLOBAL int16_t *) t.xfromy; break;
+		case 4: cw = t.w64; chh = t.h64; base = (J40_GLOBAL int16_t *) t.bfromy; break;
+		case 5: cw = L.nb_varblocks; chh = 2; base = (J40_GLOBAL int16_t *) t.info; break;
+		default: cw = t.w8; chh = t.h8; base = (J40_GLOBAL int16_t *) t.sharp; break;
+		}
+		if (cw <= 0 || chh <= 0) { ++L.chan; continue; }
+		L.cw = cw; L.chh = chh; L.row = base; L.x = L.y = 0; L.pw = L.pww = 0; L.a0 = L.a1 = L.a2 = L.a3 = L.a4 = 0;
+		const int32_t cidx = L.chan < 3 ? L.chan : L.chan - 3, sidx = L.chan < 3 ? t.sidx0 : t.sidx2;
+		int32_t at = 0;
+		DevTreeNode n;
+		for (;;) {
+			n = lf_node(T.tree, at);
+			if (n.prop == 0) at += cidx > n.value ? n.a : n.b;
+			else if (n.prop == 1) at += sidx > n.value ? n.a : n.b;
+			else break;
+		}
+		L.root = at; L.r_prop = n.prop; L.r_value = n.value; L.r_a = n.a; L.r_b = n.b;
+		L.setup = false;
+		return;
+	}
+}
+
+// one sample of the lane's stream (or the start of its next channel). The caller copies a completed piece out (L.flush_n) before
+// the lane's next step.
+J40_DEV void lf_row_step(LfRowLane &L, const J40_GLOBAL DevLfTask &t, const LfRowTables &T) {
+	if (lf_row_done(L)) return;
+	if (L.setup) { lf_row_setup(L, t, T); if (L.chan == 7 || L.err) return; }
+	lane_bits_refill(L.b);
+	const int32_t x = L.x, y = L.y, cw = L.cw;
+	const bool wide = cw > LF_ROW_WIN;
+	// neighbours (j40.h:3965-3990)
+	const int32_t pw = x > 0 ? L.pw : y > 0 ? L.a2 : 0;
+	const int32_t pn = y > 0 ? L.a2 : pw;
+	const int32_t pnw = x > 0 && y > 0 ? L.a1 : pw;
+	const int32_t pne = x + 1 < cw && y > 0 ? L.a3 : pn;
+	const int32_t pnee = x + 2 < cw && y > 0 ? L.a4 : pne;
+	const int32_t pww = x > 1 ? L.pww : pw;
+	const int32_t pnww = x > 1 && y > 0 ? L.a0 : pww;
+	int32_t pnn = pn;
+	if ((T.uses & 4u) && y > 1) pnn = L.row[x - 2 * cw];   // (two rows up: copied out a row ago)
+	// the tree walk (j40.h:4181-4216) from the channel's node
+	DevTreeNode n;
+	n.prop = L.r_prop; n.value = L.r_value; n.a = L.r_a; n.b = L.r_b;
+	int32_t at = L.root;
+	while (n.prop >= 0) {
+		int32_t val;
+		switch (n.prop) {
+		case 0: val = L.chan < 3 ? L.chan : L.chan - 3; break;
+		case 1: val = L.chan < 3 ? t.sidx0 : t.sidx2; break;
+		case 2: val = y; break;
+		case 3: val = x; break;
+		case 4: val = mod_abs(pn); break;
+		case 5: val = mod_abs(pw); break;
+		case 6: val = pn; break;
+		case 7: val = pw; break;
+		case 8: val = x > 0 ? pw - (pww + pnw - pnww) : pw; break;
+		case 9: val = pw + pn - pnw; break;
+		case 10: val = pw - pnw; break;
+		case 11: val = pnw - pn; break;
+		case 12: val = pn - pne; break;
+		case 13: val = pn - pnn; break;
+		default: val = pw - pww; break;   // 14 (the host admits no other)
+		}
+		at += val > n.value ? n.a : n.b;
+		n = lf_node(T.tree, at);
+	}
+	uint32_t e2;
+	const uint32_t word = (uint32_t) n.value;
+	const int32_t u = lane_symbol_in_cluster(L.b, L.state, T.alias, T.log_alpha, T.log_bucket, word >> 24, word & 0xffffffu, L.end_bit, &e2);
+	int32_t v = unpack_signed_dev(u) * n.b + n.a;
+	switch (-1 - n.prop) {   // j40.h:4080
+	case 0: break;
+	case 1: v += pw; break;
+	case 2: v += pn; break;
+	case 3: v += (pw + pn) / 2; break;
+	case 4: v += mod_abs(pn - pnw) < mod_abs(pw - pnw) ? pw : pn; break;
+	case 5: v += mod_gradient(pw, pn, pnw); break;
+	case 7: v += pne; break;
+	case 8: v += pnw; break;
+	case 9: v += pww; break;
+	case 10: v += (pw + pnw) / 2; break;
+	case 11: v += (pn + pnw) / 2; break;
+	case 12: v += (pn + pne) / 2; break;
+	default: v += (6 * pn - 2 * pnn + 7 * pw + pww + pnee + 3 * pne + 8) / 16; break;   // 13
+	}
+	if (e2) { lf_row_fail(L, e2); return; }
+	if (v < -32768 || v > 32767) { lf_row_fail(L, ERR_POVF); return; }
+	L.win[x & (LF_ROW_WIN - 1)] = (int16_t) v;
+	L.pww = L.pw; L.pw = v;
+	L.a0 = L.a1; L.a1 = L.a2; L.a2 = L.a3; L.a3 = L.a4;
+	const int32_t nx = x + 1;
+	L.x = nx;
+	if (nx < cw) {
+		// the sample that enters the registers is x + 3 of the row above: still in its slot of the window (this row has reached
+		// x), or -- rows wider than the window -- in the row as copied out
+		if (y > 0 && nx + 2 < cw) L.a4 = wide ? (int32_t) L.row[nx + 2 - cw] : (int32_t) L.win[nx + 2];
+		if (wide && (nx & (LF_ROW_WIN - 1)) == 0) { L.flush_n = LF_ROW_WIN; L.flush_dst = L.row + (nx - LF_ROW_WIN); }
+		return;
+	}
+	// the row is complete: its last piece goes out; the next row finds this one in the window (or in global memory)
+	L.flush_n = ((cw - 1) & (LF_ROW_WIN - 1)) + 1; L.flush_dst = L.row + (cw - L.flush_n);
+	L.x = 0; L.y = y + 1; L.row += cw; L.pw = L.pww = 0; L.a0 = L.a1 = 0;
+	if (L.y < L.chh) {
+		if (wide) { L.a2 = L.row[-cw]; L.a3 = L.row[1 - cw]; L.a4 = L.row[2 - cw]; }   // (cw > 256)
+		else { L.a2 = L.win[0]; L.a3 = cw > 1 ? L.win[1] : 0; L.a4 = cw > 2 ? L.win[2] : 0; }
+		return;
+	}
+	++L.chan; L.setup = true;
+}
+
+// the copy a step asked for, by the lane itself (tests/hostsim; the kernel's lanes do it together: lf_row_flush_wave)
+J40_DEV void lf_row_flush_serial(LfRowLane &L) {
+	for (int32_t i = 0; i < L.flush_n; ++i) L.flush_dst[i] = L.win[i];
+	L.flush_n = 0;
+}
+
+} // namespace j40hip

@@ -931,6 +931,88 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_lanes_check
 	return 0;
 }
 
+// ---- the same sections through the row-window form of the lane decoder (device/lf_rows_dev.h, k_lf_rows) ----
+#include "../../j40_amd/csrc/device/lf_rows_dev.h"
+
+// As hostsim_lf_lanes_check, for lf_row_step: tables staged as k_lf_rows stages them (leaves carrying cluster and configuration),
+// `lanes` sections decoded in lockstep (one step each per turn, as a wavefront's lanes run) with their windows side by side at
+// LF_ROW_PITCH, completed pieces copied out between the steps. `win` caps the row length served from the window for the test's
+// purposes only through the stream's own sizes (LF_ROW_WIN is a compile-time constant); frames wider than 256 cells per LfGroup
+// do not exist, the varblock-info channel exercises the wide path.
+extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_check(const uint8_t *buf, size_t size, int32_t lanes, int32_t *sections, int32_t *failed) {
+	const uint8_t *cs; size_t cs_size; std::vector<uint8_t> storage;
+	Frame fr;
+	std::vector<LfDeviceTask> tasks; std::vector<int32_t> extra_prec; bool plain = true;
+	if (sections) *sections = 0;
+	if (failed) *failed = 0;
+	try {
+		extract_codestream(buf, size, &cs, &cs_size, &storage);
+		if (!parse_frame_front(cs, cs_size, &fr, &tasks, &extra_prec, &plain)) return -1;
+	} catch (const DecodeError &) { return -1; }
+	if (!plain) return -1;
+	StaticTables st;
+	build_static_tables(fr, &st);
+	FrontPlan fp;
+	if (build_front_plan(fr, st, cs_size, extra_prec, true, &fp) || !fp.lf_device) return -1;
+	std::vector<uint8_t> padded(cs, cs + cs_size);
+	padded.resize(cs_size + 32, 0);
+	// the staged tree
+	std::vector<DevTreeNode> tree = fp.lf_tree;
+	for (DevTreeNode &n : tree) if (n.prop < 0) { const uint32_t cl = fp.lf_ctx_map[(size_t) n.value]; n.value = lf_rows_leaf_word(cl, fp.lf_cfg[cl]); }
+	LfRowTables T;
+	T.tree = tree.data(); T.alias = fp.lf_alias.data(); T.log_alpha = fp.lf_log_alpha; T.log_bucket = 12 - fp.lf_log_alpha; T.uses = fp.lf_uses;
+	if (lanes < 1) lanes = 1;
+	if (lanes > 64) lanes = 64;
+	struct Out { std::vector<int16_t> lf[3], xfy, bfy, info, sharp; DevLfResult res; DevLfTask t; };
+	const size_t ng = fr.lf_groups.size();
+	for (size_t g0 = 0; g0 < ng; g0 += (size_t) lanes) {
+		const size_t n = std::min((size_t) lanes, ng - g0);
+		std::vector<Out> out(n);
+		std::vector<LfRowLane> L(n);
+		std::vector<int16_t> wins((size_t) LF_ROW_PITCH * n, (int16_t) 0x5a5a);
+		for (size_t k = 0; k < n; ++k) {
+			const size_t g = g0 + k;
+			const LfGroup &gg = fr.lf_groups[g];
+			const size_t cells = (size_t) gg.width8 * (size_t) gg.height8, c64 = (size_t) gg.width64 * (size_t) gg.height64;
+			Out &o = out[k];
+			for (int c = 0; c < 3; ++c) o.lf[c].assign(cells + 1, 0);
+			o.xfy.assign(c64 + 1, 0); o.bfy.assign(c64 + 1, 0); o.info.assign(2 * cells + 2, 0); o.sharp.assign(cells + 1, 0);
+			o.res = DevLfResult{0, 0};
+			DevLfTask &t = o.t;
+			memset(&t, 0, sizeof t);
+			t.codestream = padded.data(); t.byte_off = (uint32_t) tasks[g].byte_off; t.size = (uint32_t) tasks[g].size; t.bit_off = tasks[g].bit_off;
+			t.w8 = gg.width8; t.h8 = gg.height8; t.w64 = gg.width64; t.h64 = gg.height64; t.sidx0 = tasks[g].sidx0; t.sidx2 = tasks[g].sidx2; t.nbvb_bits = tasks[g].nbvb_bits;
+			for (int c = 0; c < 3; ++c) t.lf[c] = o.lf[c].data();
+			t.xfromy = o.xfy.data(); t.bfromy = o.bfy.data(); t.info = o.info.data(); t.sharp = o.sharp.data(); t.info_capacity = (uint32_t) (2 * cells); t.result = &o.res;
+			lf_row_init(L[k], t, wins.data() + (size_t) LF_ROW_PITCH * k);
+		}
+		for (bool any = true; any; ) {
+			any = false;
+			for (size_t k = 0; k < n; ++k) if (!lf_row_done(L[k])) { lf_row_step(L[k], out[k].t, T); any = true; }
+			for (size_t k = 0; k < n; ++k) if (L[k].flush_n > 0) lf_row_flush_serial(L[k]);
+		}
+		for (size_t k = 0; k < n; ++k) {
+			const size_t g = g0 + k;
+			const LfGroup &gg = fr.lf_groups[g];
+			const size_t cells = (size_t) gg.width8 * (size_t) gg.height8, c64 = (size_t) gg.width64 * (size_t) gg.height64;
+			uint32_t host_err = 0;
+			LfRaw raw;
+			try { BitReader sr(cs + fr.toc.lf_groups[g].offset, fr.toc.lf_groups[g].size); read_lf_group_raw(sr, fr, gg, &raw); } catch (const DecodeError &e) { host_err = e.code; }
+			if (sections) ++*sections;
+			if (L[k].err == (uint32_t) ERR_LFFB) continue;
+			if (L[k].err != host_err) return (int32_t) (10 * g + 1);
+			if (host_err) { if (failed) ++*failed; continue; }
+			if (L[k].nb_varblocks != raw.nb_varblocks) return (int32_t) (10 * g + 2);
+			for (int c = 0; c < 3; ++c) if (memcmp(out[k].lf[c].data(), raw.lf[c].data(), cells * 2) != 0) return (int32_t) (10 * g + 3 + c);
+			if (memcmp(out[k].xfy.data(), raw.xfromy.data(), c64 * 2) != 0) return (int32_t) (10 * g + 6);
+			if (memcmp(out[k].bfy.data(), raw.bfromy.data(), c64 * 2) != 0) return (int32_t) (10 * g + 7);
+			if (memcmp(out[k].info.data(), raw.info.data(), raw.info.size() * 2) != 0) return (int32_t) (10 * g + 8);
+			for (size_t i = cells; i < out[k].lf[0].size(); ++i) if (out[k].lf[0][i] || out[k].lf[1][i] || out[k].lf[2][i] || out[k].sharp[i]) return (int32_t) (10 * g + 9);   // (nothing written past a plane)
+		}
+	}
+	return 0;
+}
+
 // ---- known-answer hooks for the inverse Squeeze step (device/squeeze_dev.h), tests/test_squeeze.py ----
 extern "C" __attribute__((visibility("default"))) int32_t hostsim_squeeze_tendency(int32_t B, int32_t a, int32_t n) { return squeeze_tendency(B, a, n); }
 extern "C" __attribute__((visibility("default"))) void hostsim_unsqueeze_line(const int16_t *avg, int32_t n_avg, const int16_t *res, int32_t n_res, int16_t *out) {

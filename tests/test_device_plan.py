@@ -21,6 +21,9 @@ CASES = [("vardct", 520, 264, 100 + i, opts) for i, (_, opts) in enumerate(VARDC
     ("vardct", 2600, 2100, 35, dict(forward=1)),
     ("vardct", 520, 264, 36, dict(passes=3)),
     ("vardct", 4100, 2100, 37, dict()),                        # 3 x 2 LfGroups
+    ("vardct", 2600, 2100, 51, dict(lftree=1)),                # every LfGroup channel under a subtree of sample properties; predictors reaching NE, NEE, NN, NWW
+    ("vardct", 520, 264, 52, dict(lftree=1, cfl=1)),
+    ("vardct", 2049, 300, 53, dict(lftree=1, forward=1)),      # (with a 1-cell-wide LfGroup)
 ]
 
 
@@ -112,6 +115,42 @@ def test_lf_lane_decoder_fails_like_the_host_decoder(lanes):
         m = bytearray(data)
         m[int(rng.integers(150, len(m) // 6))] ^= 1 << int(rng.integers(0, 8))
         rc, n, bad = lanes_check(lanes, bytes(m))
+        assert rc in (0, -1), rc
+        failed += bad
+    assert failed >= 20
+
+
+def rows_check(S, data, lanes):
+    S.hostsim_lf_rows_check.restype = C.c_int32
+    S.hostsim_lf_rows_check.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    buf = C.create_string_buffer(data, len(data))
+    n, bad = C.c_int32(), C.c_int32()
+    return S.hostsim_lf_rows_check(buf, len(data), lanes, C.byref(n), C.byref(bad)), n.value, bad.value
+
+
+@pytest.mark.parametrize("mode,w,h,seed,opts", CASES)
+def test_lf_row_window_decoder_equals_the_host_decoder(lanes, mode, w, h, seed, opts):
+    """device/lf_rows_dev.h (k_lf_rows: a section per lane, tree + alias tables + a 256-sample window per lane in LDS, finished rows
+    copied out in one piece) compiled for the CPU with the tables staged as the kernel stages them, the frame's sections stepped in
+    lockstep as a wavefront's lanes are: same planes, varblock counts and status as frame.cpp's read_lf_group_raw (pinned against the
+    reference's j40__lf_group by tests/test_host.py). The varblock-info channel (2 rows of hundreds to thousands of samples) is the
+    case of rows wider than the window."""
+    for nl in (1, 64):
+        rc, n, bad = rows_check(lanes, synth(mode, w, h, seed, **opts), nl)
+        if opts.get("alpha"):
+            assert rc == -1
+        else:
+            assert rc == 0 and n >= 1 and bad == 0, (rc, n, bad, nl)
+
+
+def test_lf_row_window_decoder_fails_like_the_host_decoder(lanes):
+    data = synth("vardct", 2600, 2100, 41)
+    rng = np.random.default_rng(12)
+    failed = 0
+    for _ in range(80):
+        m = bytearray(data)
+        m[int(rng.integers(150, len(m) // 6))] ^= 1 << int(rng.integers(0, 8))
+        rc, n, bad = rows_check(lanes, bytes(m), 4)
         assert rc in (0, -1), rc
         failed += bad
     assert failed >= 20

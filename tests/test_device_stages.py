@@ -34,6 +34,7 @@ CASES = [
     ("vardct", 4100, 2100, 37, dict(presets=2, orders=1)),     # 3 x 2 LfGroups
     ("vardct", 776, 520, 3, dict(maxlog=8, bctx=1, presets=2, orders=1)),
     ("vardct", 7680, 4320, 3, dict(forward=1)),                # the bench stream
+    ("vardct", 2600, 2100, 51, dict(lftree=1)),                # LfGroup channels under subtrees of sample properties, predictors reaching NE, NEE, NN, NWW
 ]
 
 

@@ -443,7 +443,24 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 
 	// ---- global MA tree: splits on stream index (property 1) and channel (property 0) ----
 	MATree tree;
-	{
+	if (opt.geti("lftree", 0)) {
+		// lftree=1: below the stream / channel splits every LfGroup channel gets a subtree of its own over the sample properties, with
+		// predictors that look at NE, NEE, NN, NWW -- also the varblock-info channel, whose second row is thousands of samples wide
+		int y0 = tree.leaf(13), y1 = tree.leaf(5), y2 = tree.leaf(7), y3 = tree.leaf(12, 1);
+		int ya = tree.branch(12, 2, y0, y1), yb = tree.branch(13, 0, y2, y3);   // N - NE, N - NN
+		int lf_ysplit = tree.branch(9, 120, ya, yb);                             // W + N - NW
+		int lf_x = tree.branch(8, 0, tree.leaf(9), tree.leaf(10));               // W - (WW + NW - NWW)
+		int lf_b = tree.branch(14, 1, tree.leaf(11, -1), tree.branch(4, 3, tree.leaf(3), tree.leaf(4)));   // W - WW, |N|
+		int lf_xb = tree.branch(0, 1, lf_b, lf_x);
+		int lf = tree.branch(0, 0, lf_xb, lf_ysplit);
+		int cfl = tree.branch(5, 2, tree.leaf(1), tree.leaf(8));                 // |W|
+		int binfo = tree.branch(6, 3, tree.leaf(5), tree.branch(3, 300, tree.leaf(2), tree.branch(2, 0, tree.leaf(13), tree.leaf(0))));   // N, x, y
+		int sharp = tree.branch(2, 5, tree.branch(11, 0, tree.leaf(4), tree.leaf(12)), tree.branch(7, 3, tree.leaf(2), tree.leaf(10)));   // y, NW - N, W
+		int meta_hi = tree.branch(0, 2, sharp, binfo);
+		int meta = tree.branch(0, 1, meta_hi, cfl);
+		int root = tree.branch(1, 2 * num_lf_groups, meta, lf);
+		tree.finalise(root);
+	} else {
 		int lf_y = tree.leaf(5), lf_x = tree.leaf(5), lf_b = tree.leaf(4);
 		int lf_yhi = tree.leaf(5);
 		int lf_ysplit = tree.branch(9, 120, lf_yhi, lf_y);          // W+N-NW > 120
