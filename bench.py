@@ -56,6 +56,31 @@ def cpu_quota():
     return os.cpu_count() or 1
 
 
+def pin_to_gpu_numa_node(torch, local_rank):
+    """binds this rank (and the threads it starts: pipeline workers, the launching thread, the HIP runtime's) to the CPUs of its GPU's
+    NUMA node, so that staging buffers and the pinned landing buffers of the pixels are node-local and N ranks' copies back do not
+    all cross the sockets' link. Returns what was done for the bench line; J40_BENCH_NUMA=0 leaves the affinity alone."""
+    if os.environ.get("J40_BENCH_NUMA") == "0":
+        return {"pinned": False, "why": "J40_BENCH_NUMA=0"}
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return {"pinned": False, "why": "the device reports no NUMA node", "pci": bdf}
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return {"pinned": False, "why": "none of node %d's CPUs is allowed to this process" % node, "pci": bdf}
+        os.sched_setaffinity(0, cpus)
+        return {"pinned": True, "node": node, "cpus": len(cpus), "pci": bdf}
+    except (OSError, ValueError, AttributeError) as e:
+        return {"pinned": False, "why": "%s: %s" % (type(e).__name__, e)}
+
+
 def cpu_baseline(data, width, height, budget_s=12.0):
     """the unmodified reference (oracle/_ref) on ONE host core, same codestream, bounded sample"""
     from refdec import Ref, REF_SO
@@ -226,6 +251,7 @@ def main():
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)   # before the first collective: RCCL binds a rank to its current device
     dev = torch.device("cuda", local_rank)
+    numa = pin_to_gpu_numa_node(torch, local_rank) if world > 1 or os.environ.get("J40_BENCH_NUMA") == "1" else {"pinned": False, "why": "one rank"}
     dist = None
     if world > 1 or os.environ.get("J40_BENCH_FORCE_DIST") == "1":   # (J40_BENCH_FORCE_DIST: the process group also for one rank -- a dry run of the RCCL calls on a one-GPU box)
         import torch.distributed as dist
@@ -248,8 +274,9 @@ def main():
     # threads, run the container into its CPU quota: the cgroup then throttles every thread of the process (cpu.stat: 221 of 1 282
     # periods throttled in a long run), and the copies back, whose completion the runtime handles on the host, crawl -- 6.6 Gpx/s
     # with 16 threads against 12.5 with 4 and 13.4 with 2 on the same box, same run (gpurun_out/r04n).
-    threads = args.host_threads or max(2, min(4, quota // world))
-    threads_host_lf = args.host_threads or max(2, quota // world)   # (pipelines whose worker threads decode the LfGroup streams themselves)
+    # (several ranks share the quota: quota / world each, at least one -- 8 ranks on a 16-CPU quota get two)
+    threads = args.host_threads or (max(2, min(4, quota)) if world == 1 else max(1, min(4, quota // world)))
+    threads_host_lf = args.host_threads or (max(2, quota) if world == 1 else max(1, quota // world))   # (pipelines whose worker threads decode the LfGroup streams themselves)
     D = max(1, min(args.distinct, B))
     # every rank decodes its own batch of the same D streams: rank 0 generates them with all the CPUs the container has (an 8K
     # encode takes ~10 s of one core), the other ranks wait and read them from build/streams
@@ -396,7 +423,7 @@ def main():
                      "note": "kernel_ms: k_hf_lanes' own duration inside the timed region, from HIP events the device records at the kernel's start and end (hipExtLaunchKernelGGL; what rocprofv3 --kernel-trace reports), averaged over the launches; other batches' stages run beside it (`kernel_alone`: the same launch with the device to itself); step_frac = algorithmic bytes of the steps / wall time / peak -- the wall time of `value` is PCIe time, see device_output for the device's own pace"},
         "pipeline": {"host_stage_ms_per_frame": round(st["parse_thread_ms"] / max(st["completed"] - st["single_frames"], 1), 2),
                      "lf_streams_plan_tail_ms_per_launch": round(st["lf_plan_ms"] / launches, 3), "entropy_ms_per_launch": round(k1_stage_ms, 3), "pixel_kernels_ms_per_launch": round(st["k2_ms"] / launches, 3),
-                     "host_threads": threads, "cpu_quota": quota, "lf_streams": args.lf_streams, "lf_streams_on_device_frames": st["lf_device_frames"], "frames": st["completed"],
+                     "host_threads": threads, "cpu_quota": quota, "cpu_quota_per_rank": round(quota / world, 2), "numa": numa, "lf_streams": args.lf_streams, "lf_streams_on_device_frames": st["lf_device_frames"], "frames": st["completed"],
                      "single_frame_path_frames": st["single_frames"],
                      "note": "host_stage: ms of one worker thread per frame (headers, TOC, LfGlobal, HfGlobal, staging; plus the LfGroup streams for the frames the host kept); "
                              "the per-launch figures are HIP-event times on the batch's stream and overlap with other batches' stages"},
@@ -409,13 +436,47 @@ def main():
         result["device_resident"] = resident_multi
     if sharded is not None:
         result["sharded"] = sharded
+    # ---- the stages of a batch, each with its own duration inside the timed region and its roofline fraction (algorithmic bytes of
+    # the frames the launch carries / its duration / 8 TB/s); `kernel` = the stage furthest below the roofline, i.e. the longest per frame
+    alg_frame = alg_step / B
+    def stage(name, kernel, ms, frames, how):
+        if not ms or ms <= 0 or frames <= 0:
+            return None
+        ach = alg_frame * frames / (ms / 1e3) / 1e9
+        return {"stage": name, "kernel": kernel, "kernel_ms": round(ms, 4), "frames_per_launch": round(frames, 2), "ms_per_256_frames": round(ms * 256 / frames, 3),
+                "achieved": round(ach, 3), "frac": round(ach / 8000.0, 6), "traffic": None, "how": how}
+    lfl = max(st.get("lf_launches", 0), 1)
+    stages = [
+        stage("LfGroup streams (j40.h:6722-6790)", "k_lf_rows" if os.environ.get("J40HIP_LF_KERNEL") != "lanes" else "k_lf_lanes", st.get("lf_kernel_ms", 0) / lfl, st.get("lf_launch_frames", 0) / lfl,
+              "device-recorded start / end events of each launch (hipExtLaunchKernelGGL), averaged over %d launches; a launch carries what was waiting, up to two batches' worth, on a low-priority stream beside the other stages" % st.get("lf_launches", 0)),
+        stage("plan build + LfGroup tail (j40.h:6585-6720, 6544-6590, 5944)", "k_plan_place / _scan / _emit, k_lf_dequant_smooth_batch, k_llf_small_batch, k_llf_large_batch", st["lf_plan_ms"] / launches, frames_per_launch,
+              "HIP events on the batch's stream around the stage (includes what the stage waited for behind other kernels)"),
+        stage("entropy decode (j40.h:6888-7005)", "k_hf_lanes", k1_launch_ms, frames_per_launch, "device-recorded start / end events of the kernel"),
+        stage("pixels (j40.h:7053-7247, 5690-6246)", "k_vardct_dct<...> x 12, k_vardct_special x 2, k_vardct_large", st["k2_ms"] / launches, frames_per_launch,
+              "HIP events around the stage: four chains of persistent launches on four streams, fork to join"),
+    ]
+    stages = [x for x in stages if x]
+    result["roofline"]["stages"] = stages
     try:
-        pt = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
-        if abs(pt.get("frames_per_launch", 0) - frames_per_launch) < 1 and (W, H) == (7680, 4320) and pt.get("stream", "coefficient") == args.stream:
-            result["roofline"]["traffic"] = int((pt["fetch_size_kb"] * pt.get("fetch_correction", 1.0) + pt["write_size_kb"]) * 1024)
+        pt = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")))
+        if (W, H) == (7680, 4320) and pt.get("stream", "coefficient") == args.stream:
+            corr = pt.get("fetch_correction", 1.0)
+            for x in stages:
+                for key, rec in pt.get("stages", {}).items():
+                    if x["stage"].startswith(key) and abs(rec.get("frames_per_launch", 0) - x["frames_per_launch"]) <= 0.5 * x["frames_per_launch"]:
+                        x["traffic"] = int((rec["fetch_kb"] * corr + rec["write_kb"]) * 1024 * x["frames_per_launch"] / rec["frames_per_launch"])
+                        x["traffic_fetch_kb_uncorrected"] = rec["fetch_kb"]; x["traffic_write_kb"] = rec["write_kb"]
             result["roofline"]["traffic_source"] = pt["source"]
     except (OSError, ValueError, KeyError):
         pass
+    if stages:
+        worst = min(stages, key=lambda x: x["frac"])
+        result["roofline"].update({"kernel": worst["kernel"], "stage": worst["stage"], "kernel_ms": worst["kernel_ms"], "frames_per_launch": worst["frames_per_launch"],
+                                   "achieved": worst["achieved"], "frac": worst["frac"], "traffic": worst["traffic"], "algorithmic_bytes_per_launch": int(alg_frame * worst["frames_per_launch"])})
+        result["roofline"]["note"] = ("`kernel` is the stage of a batch that is furthest below the HBM roofline inside the timed region (the longest per frame): its own duration from events the device "
+                                      "records, its algorithmic bytes = (4 B/px RGBA + codestream bytes) of the frames its launch carries; `stages` lists all four with the same arithmetic and, per stage, the PMC traffic "
+                                      "(FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE) from the tracked rocprofv3 passes; `stages_alone`: the same launches with the device to themselves; "
+                                      "step_frac = algorithmic bytes of the steps / wall time / peak -- the wall time of `value` is PCIe time, see device_output for the device's own pace")
 
     # parity at the full size: a frame decoded inside the timed region against the reference's pixels (bar: 1 level)
     if not args.no_cpu_baseline and world == 1:
@@ -443,8 +504,32 @@ def main():
         torch.cuda.empty_cache()
         if sa["launches"] and sa["k1_kernel_ms"] > 0:
             ms = sa["k1_kernel_ms"] / sa["launches"]
-            result["roofline"]["kernel_alone"] = {"kernel_ms": round(ms, 4), "achieved": round(alg_launch / (ms / 1e3) / 1e9, 3), "frac": round(alg_launch / (ms / 1e3) / 8e12, 6), "launches": sa["launches"],
+            result["roofline"]["kernel_alone"] = {"kernel": "k_hf_lanes", "kernel_ms": round(ms, 4), "achieved": round(alg_launch / (ms / 1e3) / 1e9, 3), "frac": round(alg_launch / (ms / 1e3) / 8e12, 6), "launches": sa["launches"],
                                                   "how": "same frames and launch geometry, one batch in flight, LfGroup streams on the host threads: no other kernel beside k_hf_lanes (device-recorded start/end events)"}
+            fa = sa["launch_frames"] / sa["launches"]
+            alone_stages = [stage("plan build + LfGroup tail", "k_plan_*, LfGroup tail kernels", sa["lf_plan_ms"] / sa["launches"], fa, "one batch in flight, LfGroup streams on the host threads"),
+                            stage("entropy decode", "k_hf_lanes", ms, fa, "one batch in flight, LfGroup streams on the host threads"),
+                            stage("pixels", "k_vardct_*", sa["k2_ms"] / sa["launches"], fa, "one batch in flight, LfGroup streams on the host threads")]
+            # the lane decoder of the LfGroup streams alone: one batch in flight and one step at a time, so that its launch is the only
+            # thing on the device (the batch cannot start before it ends, and the step is drained before the next one)
+            outs3 = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(min(B, 256))]
+            lfa = j40_amd.Pipeline(local_rank, threads, min(args.pipe_batch, B), 1, lf_streams="device")
+            so3 = [outs3[i % len(outs3)] for i in range(B)]
+            run_pipeline_steps(lfa, step_bufs, step_sizes, so3, W * 4, True, 1, torch, dev, None)
+            acc = {"ms": 0.0, "n": 0, "frames": 0, "waves": 0}
+            for _ in range(2):
+                run_pipeline_steps(lfa, step_bufs, step_sizes, so3, W * 4, True, 1, torch, dev, None)
+                sl = lfa.stats()
+                acc["ms"] += sl["lf_kernel_ms"]; acc["n"] += sl["lf_launches"]; acc["frames"] += sl["lf_launch_frames"]; acc["waves"] += sl["lf_launch_waves"]
+            lfa.close()
+            del outs3, so3
+            torch.cuda.empty_cache()
+            if acc["n"]:
+                x = stage("LfGroup streams", "k_lf_rows" if os.environ.get("J40HIP_LF_KERNEL") != "lanes" else "k_lf_lanes", acc["ms"] / acc["n"], acc["frames"] / acc["n"],
+                          "one batch in flight, one step at a time: the launch has the device to itself (%d launches, %.0f wavefronts each)" % (acc["n"], acc["waves"] / acc["n"]))
+                if x:
+                    alone_stages.insert(0, x)
+            result["roofline"]["stages_alone"] = [x for x in alone_stages if x]
         result.update(sections(args, torch, np, j40_amd, dev, local_rank, datas, quota))
     else:
         pipe.close()
@@ -487,10 +572,20 @@ def sections(args, torch, np, j40_amd, dev, local_rank, datas, quota):
     lat = [frames[0].decode_timed(routs[0].data_ptr(), W * 4, main.cuda_stream) for _ in range(3)]
     out["latency_mode"] = {"frame_ms": round(float(min(sum(map(float, m)) for m in lat)), 3), "k_hf_entropy_ms": round(float(min(float(m[0]) for m in lat)), 3),
                            "mpixels_per_s": round(W * H / min(sum(map(float, m)) for m in lat) / 1e3, 1)}
-    t0 = time.perf_counter()
-    err, px = j40_amd.decode(datas[0])
-    out["latency_mode"]["public_api_from_memory_to_host_pixels_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
-    assert err == ""
+    # the unchanged public API, one caller: j40_from_memory -> j40_next_frame -> j40_frame_pixels_u8x4 (host pixels) -> j40_free. The first
+    # call pays for what a process pays once (pinning the image plane, growing the device memory cache, the latency path's streams);
+    # the median of the following calls is what a caller decoding image after image sees
+    api_ms = []
+    b0 = C.create_string_buffer(datas[0], len(datas[0]))
+    for _ in range(7):
+        err, ms_call, _ = j40_amd.decode_timed(b0, len(datas[0]))
+        api_ms.append(ms_call)
+        assert err == ""
+    warm = sorted(api_ms[1:])
+    out["latency_mode"]["public_api_from_memory_to_host_pixels_ms"] = round(api_ms[0], 2)
+    out["latency_mode"]["public_api_cold_ms"] = round(api_ms[0], 2)
+    out["latency_mode"]["public_api_warm_median_ms"] = round(warm[len(warm) // 2], 2)
+    out["latency_mode"]["public_api_warm_calls_ms"] = [round(v, 2) for v in api_ms[1:]]
     batch.close()
     for fr in frames:
         fr.close()
@@ -499,13 +594,35 @@ def sections(args, torch, np, j40_amd, dev, local_rank, datas, quota):
 
     # ---- BASELINE.json's other configurations ----
     cfg = {}
-    d4k = synth("vardct", 3840, 2160, 102)
+    # config 2: ONE 3840x2160 frame, a distance-1 encode of a procedural picture like the 8K bench stream (forward=1). Device time of
+    # the latency path's kernels, and the contract clock of SURVEY 8d for one image: the public API, codestream bytes in host memory
+    # -> RGBA in host memory (cold first call, median of the following ones), with the reference on one core beside it
+    d4k = synth("vardct", 3840, 2160, 102, forward=1)
     fr = j40_amd.Frame(d4k, threads=min(8, quota)); fr.upload(local_rank)
     o = torch.empty((2160, 3840, 4), dtype=torch.uint8, device=dev)
     ms = min((fr.decode_timed(o.data_ptr(), 3840 * 4, main.cuda_stream) for _ in range(3)), key=lambda m: float(sum(m)))
     cfg["config2_3840x2160_one_gpu"] = {"frame_ms": round(float(sum(ms)), 3), "entropy_ms": round(float(ms[0]), 3), "pixel_kernels_ms": round(float(ms[1]), 3),
-                                        "mpixels_per_s": round(3840 * 2160 / float(sum(ms)) / 1e3, 1), "mode": "latency (one frame alone, device time)"}
+                                        "mpixels_per_s": round(3840 * 2160 / float(sum(ms)) / 1e3, 1), "mode": "latency (one frame alone, device time)",
+                                        "stream": "forward-encoded at about distance 1 (tools/jxlsynth forward=1), %d bytes, %.3f bpp" % (len(d4k), 8.0 * len(d4k) / (3840 * 2160))}
     fr.close()
+    api4k = []
+    px4k = None
+    b4k = C.create_string_buffer(d4k, len(d4k))
+    for k in range(7):
+        err, ms_call, got = j40_amd.decode_timed(b4k, len(d4k), want_pixels=(k == 6))
+        api4k.append(ms_call)
+        assert err == ""
+        px4k = got if got is not None else px4k
+    warm4k = sorted(api4k[1:])
+    cfg["config2_3840x2160_one_gpu"]["host_to_host"] = {"cold_ms": round(api4k[0], 2), "warm_median_ms": round(warm4k[len(warm4k) // 2], 2), "mpixels_per_s": round(3840 * 2160 / warm4k[len(warm4k) // 2] / 1e3, 1),
+                                                        "clock": "j40_from_memory -> j40_next_frame -> j40_frame_pixels_u8x4 -> j40_free on one thread: codestream bytes in host memory -> RGBA in host memory (SURVEY 8d)"}
+    if not args.no_cpu_baseline:
+        cb2 = cpu_baseline(d4k, 3840, 2160, budget_s=4.0)
+        if cb2:
+            cfg["config2_3840x2160_one_gpu"]["cpu_baseline"] = cb2
+            d = np.abs(np.asarray(px4k)[:, :, :].astype(np.int16) - cpu_baseline.last_pixels.astype(np.int16))
+            cfg["config2_3840x2160_one_gpu"]["parity_vs_reference"] = {"max_abs_diff": int(d.max()), "differing_samples": int((d > 0).sum()), "samples": int(d.size)}
+            assert d.max() <= 1
     # config 5: 1024 independent 1920x1080 frames through the pipeline. Sections are the unit of the entropy launch (40 per frame:
     # 256 frames are 256 wavefronts, one per compute unit), so the frames go in large batches, several in flight; the LfGroup
     # streams of such small frames (one section of 130 k samples each) are decoded by the host threads: 0.8 ms of one core per
@@ -577,6 +694,15 @@ def time_sharded(steps, warmup, torch, j40_amd, dist, dev, rank, local_rank, dat
 
     for _ in range(warmup):
         step()
+    # (outside the clock) the assembled frame against the same stream decoded whole by rank 0 alone
+    got = step()
+    time_sharded.pixels_equal = None
+    if rank == 0:
+        err, whole, _, _ = decode(data, 0, 1)
+        assert err == "", err
+        time_sharded.pixels_equal = bool(torch.equal(got.cpu(), whole.cpu()))
+        del whole
+    del got
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
@@ -602,11 +728,12 @@ def sharded_records(args, torch, j40_amd, dist, dev, rank, local_rank, world):
     out = {}
     d8k = synth("vardct", 7680, 4320, args.seed, **({"forward": 1} if args.stream == "forward" else {})) if rank == 0 else b""
     sec = time_sharded(5, 1, torch, j40_amd, dist, dev, rank, local_rank, d8k)
-    out["vardct_7680x4320"] = {"ms_per_frame": round(sec * 1e3, 3), "mpixels_per_s": round(7680 * 4320 / sec / 1e6, 1), "steps": 5}
+    out["vardct_7680x4320"] = {"ms_per_frame": round(sec * 1e3, 3), "mpixels_per_s": round(7680 * 4320 / sec / 1e6, 1), "steps": 5, "pixels_equal_single_decode": time_sharded.pixels_equal}
     if not args.skip_modular:
         dm = synth("modular", 16384, 16384, 21, tree=1, repeat=16) if rank == 0 else b""
         sec = time_sharded(2, 1, torch, j40_amd, dist, dev, rank, local_rank, dm)
-        out["modular_16384x16384_rct"] = {"ms_per_frame": round(sec * 1e3, 2), "mpixels_per_s": round(16384 * 16384 / sec / 1e6, 1), "steps": 2, "codestream_mb": round(len(dm) / 1e6, 1) if rank == 0 else None}
+        out["modular_16384x16384_rct"] = {"ms_per_frame": round(sec * 1e3, 2), "mpixels_per_s": round(16384 * 16384 / sec / 1e6, 1), "steps": 2, "codestream_mb": round(len(dm) / 1e6, 1) if rank == 0 else None,
+                                          "pixels_equal_single_decode": time_sharded.pixels_equal}
     out["note"] = ("one frame per step, its pass groups split over %d ranks in contiguous ranges balanced by section bytes; codestream broadcast from rank 0, every rank parses it, decodes its "
                    "range (j40hip_frame_set_group_range) and sends its pixel rectangles to rank 0 point-to-point (device tensors over RCCL). Strong scaling of a latency-bound step: "
                    "one 8K frame's 510 sections already run concurrently on one GPU and the step is its longest section (DESIGN.md section 6)") % world

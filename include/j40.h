@@ -54,6 +54,7 @@ typedef void (*j40_memory_free_func)(void *data);
 #define J40_RGBA 0x1755 /* j40.h:228 */
 
 typedef uint8_t j40_u8x4[4];
+typedef float j40_f32x4[4]; /* j40.h:256: declared there ahead of a float API that does not exist yet; kept so that sources naming it compile */
 
 /* j40.h:244-251 */
 typedef struct {

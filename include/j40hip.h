@@ -325,6 +325,10 @@ J40HIP_API void j40hip_pipeline_stats(j40hip_pipeline *p, double *out8);
  * as the device recorded them (first wavefront's start to last one's end: the duration rocprofv3 reports; [4] also counts what the
  * launch waited for behind other kernels) */
 J40HIP_API void j40hip_pipeline_stats_ex(j40hip_pipeline *p, double *out12);
+/* out5: the launches of the LfGroup lane decoder (k_lf_rows / k_lf_lanes; j40__lf_group's two Modular streams, j40.h:6722-6790) since
+ * the last reset: [0] their durations summed, ms, as the device recorded them (first wavefront's start to last one's end), [1]
+ * launches, [2] frames, [3] LfGroup sections and [4] wavefronts in them */
+J40HIP_API void j40hip_pipeline_lf_stats(j40hip_pipeline *p, double *out5);
 J40HIP_API void j40hip_pipeline_reset_stats(j40hip_pipeline *p);
 
 /* ---- stage dump of the pipeline's DEVICE stages, for parity tests (tests/test_device_stages.py): one image goes through the same

@@ -105,7 +105,7 @@ def lib():
         "j40hip_stage_dump_lf_group_info": (C.c_int, [vp, i64, vp]), "j40hip_stage_dump_plane": (C.c_int, [vp, i64, C.c_int, vp]),
         "j40hip_stage_dump_varblocks": (C.c_int, [vp, i64, vp, vp, vp]), "j40hip_stage_dump_llf": (C.c_int, [vp, i64, C.c_int, vp]),
         "j40hip_stage_dump_group_blocks": (i64, [vp, i64, vp, i64]), "j40hip_stage_dump_sorted_varblocks": (i64, [vp, vp, vp, vp, i64]), "j40hip_stage_dump_rgba": (C.c_int, [vp, vp]),
-        "j40hip_pipeline_result": (u32, [vp, i64]), "j40hip_pipeline_stats": (None, [vp, vp]), "j40hip_pipeline_stats_ex": (None, [vp, vp]), "j40hip_pipeline_reset_stats": (None, [vp]),
+        "j40hip_pipeline_result": (u32, [vp, i64]), "j40hip_pipeline_stats": (None, [vp, vp]), "j40hip_pipeline_stats_ex": (None, [vp, vp]), "j40hip_pipeline_lf_stats": (None, [vp, vp]), "j40hip_pipeline_reset_stats": (None, [vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)  # AttributeError = the library does not export what include/*.h declares
@@ -186,6 +186,32 @@ def decode(data: bytes):
     err = img.error()
     img.free()
     return err, out
+
+
+def decode_timed(buf, size, want_pixels=False):
+    """the reference's call sequence (dj40.c) on an existing ctypes buffer, timed from j40_from_memory to the return of
+    j40_frame_pixels_u8x4 -- the pixels are then in host memory, in the image's own plane; no copy into numpy inside the clock.
+    Returns (err4, milliseconds, pixels or None)"""
+    import time
+    L = lib()
+    img = Image()
+    t0 = time.perf_counter()
+    L.j40_from_memory(C.byref(img._img), buf, size, None)
+    img._live = True
+    img.output_format()
+    ok = img.next_frame()
+    px = None
+    if ok:
+        fr = L.j40_current_frame(C.byref(img._img))
+        px = L.j40_frame_pixels_u8x4(C.byref(fr), J40_RGBA)
+    ms = (time.perf_counter() - t0) * 1e3
+    err = img.error()
+    out = None
+    if ok and want_pixels and not err:
+        rows = np.ctypeslib.as_array(C.cast(px.data, C.POINTER(C.c_uint8)), shape=(px.height, px.stride_bytes))
+        out = rows[:, : px.width * 4].reshape(px.height, px.width, 4).copy()
+    img.free()
+    return err, ms, out
 
 
 INFO_FIELDS = ["width", "height", "is_modular", "num_lf_groups", "num_groups", "num_passes", "nb_block_ctx", "block_ctx_size",
@@ -564,8 +590,11 @@ class Pipeline:
         a = (C.c_double * 12)()
         lib().j40hip_pipeline_stats_ex(self.h, a)
         # (upload_thread_ms: single_thread_ms under the name it had until round 3)
+        b = (C.c_double * 5)()
+        lib().j40hip_pipeline_lf_stats(self.h, b)
         return dict(parse_thread_ms=a[0], single_thread_ms=a[1], upload_thread_ms=a[1], completed=int(a[2]), wall_ms=a[3], k1_ms=a[4], k2_ms=a[5], launches=int(a[6]), launch_frames=int(a[7]),
-                    lf_plan_ms=a[8], lf_device_frames=int(a[9]), single_frames=int(a[10]), k1_kernel_ms=a[11])
+                    lf_plan_ms=a[8], lf_device_frames=int(a[9]), single_frames=int(a[10]), k1_kernel_ms=a[11],
+                    lf_kernel_ms=b[0], lf_launches=int(b[1]), lf_launch_frames=int(b[2]), lf_launch_sections=int(b[3]), lf_launch_waves=int(b[4]))
 
     def reset_stats(self):
         lib().j40hip_pipeline_reset_stats(self.h)

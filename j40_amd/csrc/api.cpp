@@ -2,6 +2,8 @@
 // hot path. Handle states, magic numbers, error strings and the placeholder image follow the
 // reference's observable behaviour (j40.h:7970-8119, 8245-8477).
 #define J40_API __attribute__((visibility("default")))
+#include <algorithm>
+#include <sys/stat.h>
 #include "../../include/j40.h"
 #include "capi.hpp"
 #include <atomic>
@@ -47,7 +49,8 @@ struct j40__inner {
 	int saved_errno;
 	char errbuf[256];
 	void *buf; size_t size; j40_memory_free_func freefunc;   // borrowed input
-	void *owned;                                             // file contents (from_file)
+	void *owned;                                             // file contents (from_file), read by the first j40_next_frame
+	FILE *fp;                                                // from_file: the open file until then
 	j40hip_frame *frame;
 	int decoded, rendered;
 	uint8_t *pixels; size_t pixels_bytes; int32_t width, height, stride_bytes;   // image-owned plane: pinned host memory from the library's pool
@@ -83,6 +86,7 @@ void free_inner(j40__inner *inner) {
 	if (inner->frame) j40hip_frame_free(inner->frame);
 	if (inner->freefunc && inner->buf) inner->freefunc(inner->buf);
 	free(inner->owned);
+	if (inner->fp) fclose(inner->fp);
 	if (inner->pixels) j40hip_pinned_release(inner->pixels, inner->pixels_bytes);
 	inner->magic = 0;
 	free(inner);
@@ -127,6 +131,36 @@ int device_index() { const char *e = getenv("J40HIP_DEVICE"); return e ? atoi(e)
 // the whole decode: RGBA into the image-owned plane
 j40_err advance(j40__inner *inner, int origin) {
 	if (inner->decoded) return 0;
+	if (inner->fp) {
+		// j40_from_file opened the file; it is read here, by the first call that needs its bytes, as the reference reads it
+		// (j40__file_source_read, j40.h:1241-1256: fread until end of file; a failing read raises `read` with the errno kept; what
+		// is missing from a truncated file surfaces as `shrt` from whoever needs the bytes). The file's size is asked for up front so
+		// that the bytes land in one allocation; a source that cannot say (a pipe) grows its buffer.
+		FILE *fp = inner->fp;
+		inner->fp = nullptr;
+		const int saved = errno;
+		errno = 0;
+		size_t cap = 1 << 16, size = 0;
+		struct stat sb;
+		if (fstat(fileno(fp), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) cap = (size_t) sb.st_size + 1;
+		uint8_t *data = (uint8_t *) malloc(cap);
+		uint32_t ferr = data ? 0 : code4("!mem");
+		while (!ferr) {
+			if (size == cap) {
+				uint8_t *more = (uint8_t *) realloc(data, cap * 2);
+				if (!more) { ferr = code4("!mem"); break; }
+				data = more; cap *= 2;
+			}
+			const size_t n = fread(data + size, 1, cap - size, fp);
+			if (n > 0) { size += n; continue; }
+			if (!feof(fp)) { inner->saved_errno = errno; ferr = code4("read"); }
+			break;
+		}
+		fclose(fp);
+		errno = saved;
+		if (ferr) { free(data); inner->origin = origin; inner->err = ferr; return ferr; }
+		inner->owned = data; inner->buf = data; inner->size = size; inner->freefunc = nullptr;
+	}
 	struct Inside { int n; Inside() : n(++g_inside) {} ~Inside() { --g_inside; } } inside;
 	const int policy = serve_policy();
 	const int64_t now = (int64_t) now_ms();
@@ -145,7 +179,9 @@ j40_err advance(j40__inner *inner, int origin) {
 	double t1 = t0, t2 = t0, t3 = t0;
 	// (LfGroup sections are independent: an 8K frame has twelve; their tail -- dequantisation, smoothing, LLF coefficients -- runs on
 	// the device at upload, flags = 1)
-	static const int parse_threads = [] { const char *e = getenv("J40HIP_PARSE_THREADS"); return e && atoi(e) > 0 ? atoi(e) : 12; }();
+	// (no more threads than the container's CPU quota: a process over its quota has all its threads throttled, the HIP runtime's too;
+	// frames with fewer LfGroups and groups than that get a smaller team: parse_frame, build_vardct_plan)
+	static const int parse_threads = [] { const char *e = getenv("J40HIP_PARSE_THREADS"); return e && atoi(e) > 0 ? atoi(e) : std::max(1, std::min(12, j40hip_cpu_quota())); }();
 	inner->frame = j40hip_frame_parse_ex(inner->buf, inner->size, parse_threads, 1u, &err);
 	t1 = now_ms();
 	if (!err && j40hip_device_count() <= device_index()) err = code4("!gpu");   // (before the plane: pinned memory needs the device too)
@@ -218,14 +254,8 @@ j40_err j40_from_file(j40_image *image, const char *path) {
 	errno = 0;
 	FILE *fp = fopen(path, "rb");
 	if (!fp) { int e = errno; errno = saved; free_inner(inner); return set_alt_magic(code4("open"), e, O_from_file, image); }
-	std::vector<uint8_t> data; uint8_t chunk[65536]; size_t n;
-	while ((n = fread(chunk, 1, sizeof chunk, fp)) > 0) data.insert(data.end(), chunk, chunk + n);
-	fclose(fp);
 	errno = saved;
-	inner->owned = malloc(data.size() ? data.size() : 1);
-	if (!inner->owned) { free_inner(inner); return set_alt_magic(code4("!mem"), 0, O_from_file, image); }
-	memcpy(inner->owned, data.data(), data.size());
-	inner->buf = inner->owned; inner->size = data.size(); inner->freefunc = nullptr;
+	inner->fp = fp;   // (read by j40_next_frame: j40.h:8354 opens the source and reads nothing either)
 	image->magic = IMAGE_MAGIC; image->u.inner = inner;
 	return 0;
 }

@@ -46,5 +46,8 @@ extern "C" void j40hip_release_device(j40hip_frame *f);
 // the pool of pinned host planes the public API hands out as image pixels (device/runtime.hip)
 extern "C" j40hip_pipeline *j40hip_serve_pipeline(int device, uint32_t *err);
 extern "C" void j40hip_serve_shutdown(void);
+// CPUs' worth of time the process may use: the visible CPUs, or the cgroup's quota (v2 cpu.max, v1 cfs_quota_us) when that is less.
+// A process that runs into its quota has ALL its threads throttled, the HIP runtime's included: thread counts are sized from this.
+extern "C" int j40hip_cpu_quota();
 extern "C" void *j40hip_pinned_acquire(size_t bytes);
 extern "C" void j40hip_pinned_release(void *ptr, size_t bytes);

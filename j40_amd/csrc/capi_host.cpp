@@ -1,4 +1,7 @@
 // j40_amd/csrc/capi_host.cpp -- host half of the thin C-ABI (include/j40hip.h): parse + stage accessors
+#include <cstdio>
+#include <cstring>
+#include <thread>
 #include <type_traits>
 #include "capi.hpp"
 #include "tables.hpp"
@@ -488,3 +491,19 @@ float j40hip_kat_half_secant(int i) { return half_secants()[i]; }
 float j40hip_kat_lf2llf_scale(int i) { return lf2llf_scales()[i]; }
 
 } // extern "C"
+
+extern "C" __attribute__((visibility("default"))) int j40hip_cpu_quota() {
+	unsigned hw = std::thread::hardware_concurrency();
+	int n = hw ? (int) hw : 4;
+	if (FILE *fp = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2
+		char q[64] = {0}; long long period = 0;
+		if (fscanf(fp, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) { const long long c = atoll(q) / period; if (c >= 1 && c < n) n = (int) c; }
+		fclose(fp);
+		return n;
+	}
+	long long quota = -1, period = 0;   // cgroup v1
+	if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fp, "%lld", &quota) != 1) quota = -1; fclose(fp); }
+	if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lld", &period) != 1) period = 0; fclose(fp); }
+	if (quota > 0 && period > 0) { const long long c = quota / period; if (c >= 1 && c < n) n = (int) c; }
+	return n;
+}

@@ -648,6 +648,8 @@ struct j40hip_alf {
 	int device = 0;
 	PinnedStage host; void *dev = nullptr; size_t dev_cap = 0;
 	hipEvent_t done = nullptr;
+	hipEvent_t kev[2] = {nullptr, nullptr};   // recorded by the device at the lane decoder's start and end (hipExtLaunchKernelGGL)
+	int frames = 0, sections = 0, waves = 0;
 };
 
 j40hip_alf *j40hip_alf_create(int device) {
@@ -655,6 +657,7 @@ j40hip_alf *j40hip_alf_create(int device) {
 	j40hip_alf *a = new j40hip_alf();
 	a->device = device;
 	if (hipEventCreateWithFlags(&a->done, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); delete a; return nullptr; }
+	for (hipEvent_t &e : a->kev) if (hipEventCreate(&e) != hipSuccess) { (void) hipGetLastError(); e = nullptr; }
 	// (room for a few thousand frames up front: growing pinned memory costs a third of a second a time)
 	if (!a->host.reserve((size_t) 4 << 20, 0) || hipMalloc(&a->dev, (size_t) 4 << 20) != hipSuccess) { (void) hipGetLastError(); j40hip_alf_free(a); return nullptr; }
 	a->dev_cap = (size_t) 4 << 20;
@@ -666,6 +669,7 @@ void j40hip_alf_free(j40hip_alf *a) {
 	a->host.release();
 	if (a->dev) (void) hipFree(a->dev);
 	if (a->done) (void) hipEventDestroy(a->done);
+	for (hipEvent_t e : a->kev) if (e) (void) hipEventDestroy(e);
 	delete a;
 }
 uint32_t j40hip_alf_launch(j40hip_alf *a, j40hip_aframe *const *frames, int n, hipStream_t s) {
@@ -691,12 +695,26 @@ uint32_t j40hip_alf_launch(j40hip_alf *a, j40hip_aframe *const *frames, int n, h
 	if (uint32_t e = wait_for_uploads(frames, n, s)) return e;
 	if (hipMemcpyAsync(a->dev, a->host.ptr, bytes - 64, hipMemcpyHostToDevice, s) != hipSuccess) return ERR_GPU;
 	const double tq2 = prof_now();
-	if (rows) launch_lf_rows((const DevLfLaneSet *) a->dev, (const DevLfWave *) ((const uint8_t *) a->dev + o_waves), (int32_t) waves.size(), lds + 64, s);
-	else launch_lf_lanes((const DevLfLaneSet *) a->dev, (const DevLfWave *) ((const uint8_t *) a->dev + o_waves), (int32_t) waves.size(), lds + 64, s);
+	a->frames = n; a->waves = (int) waves.size(); a->sections = 0;
+	for (const DevLfLaneSet &ls : sets) a->sections += ls.ntasks;
+	hipEvent_t k0 = a->kev[0] && a->kev[1] ? a->kev[0] : nullptr, k1 = k0 ? a->kev[1] : nullptr;
+	if (rows) launch_lf_rows((const DevLfLaneSet *) a->dev, (const DevLfWave *) ((const uint8_t *) a->dev + o_waves), (int32_t) waves.size(), lds + 64, s, k0, k1);
+	else launch_lf_lanes((const DevLfLaneSet *) a->dev, (const DevLfWave *) ((const uint8_t *) a->dev + o_waves), (int32_t) waves.size(), lds + 64, s, k0, k1);
 	const double tq3 = prof_now();
 	if (hipEventRecord(a->done, s) != hipSuccess || hipGetLastError() != hipSuccess) return ERR_GPU;
 	if (getenv("J40HIP_ASYNC_TIMING")) fprintf(stderr, "[j40hip lf launch] %d frames, %zu waves: pack %.2f, copy %.2f, launch %.2f, record %.2f ms\n", n, waves.size(), tq1 - tq0, tq2 - tq1, tq3 - tq2, prof_now() - tq3);
 	// (the caller hands the frames to a batch only once j40hip_alf_done says this launch has completed)
+	return 0;
+}
+// the finished launch's own duration (device-recorded start / end), frames, sections and wavefronts; 0 when it could be read
+int j40hip_alf_elapsed(j40hip_alf *a, float *ms, int *frames, int *sections, int *waves) {
+	if (!a || !a->kev[0] || !a->kev[1]) return -1;
+	float t = 0;
+	if (hipEventElapsedTime(&t, a->kev[0], a->kev[1]) != hipSuccess) { (void) hipGetLastError(); return -1; }
+	if (ms) *ms = t;
+	if (frames) *frames = a->frames;
+	if (sections) *sections = a->sections;
+	if (waves) *waves = a->waves;
 	return 0;
 }
 int j40hip_alf_done(j40hip_alf *a) { if (!a || hipEventQuery(a->done) == hipSuccess) return 1; (void) hipGetLastError(); return 0; }

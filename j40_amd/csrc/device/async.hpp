@@ -51,6 +51,7 @@ j40hip_alf *j40hip_alf_create(int device);
 void j40hip_alf_free(j40hip_alf *a);
 uint32_t j40hip_alf_launch(j40hip_alf *a, j40hip_aframe *const *frames, int n, hipStream_t stream);
 int j40hip_alf_done(j40hip_alf *a);
+int j40hip_alf_elapsed(j40hip_alf *a, float *ms, int *frames, int *sections, int *waves);   // the finished launch: the kernel's own duration (device-recorded events); 0 = read
 
 // j40hip_shutdown's share of async.hip: the static-table cache and the event pool
 void j40hip_async_shutdown(void);

@@ -146,6 +146,8 @@ J40_DEV int32_t lane_symbol(LaneBits &b, uint32_t &state, const Tables &t, int32
 	return lane_symbol_in_cluster(b, state, t.alias, t.log_alpha, t.log_bucket, cl, t.cluster_cfg[cl], end_bit, err);
 }
 
+typedef uint32_t LaneEventQuad __attribute__((vector_size(16)));   // four events, one 16-byte store
+
 // the entry of DevPlan::block_events of a finished block {first event, n_Y, n_X, n_B}, one 16-byte store
 J40_DEV void lane_store_block_events(const LaneGlobals &G, uint32_t blk, uint32_t first, uint32_t n0, uint32_t n1, uint32_t n2) {
 	J40_GLOBAL uint64_t *e = (J40_GLOBAL uint64_t *) (G.block_events + 4u * blk);
@@ -169,8 +171,13 @@ struct LaneSection {
 // cols[(c * 32 + x) * col_stride]: non-zero count (per 8x8 cell) of the last block written into cell column x, channel c. It needs
 // no reset between sections: a block reads only columns a block of its own section wrote before it (blocks tile the group in
 // raster order of their top-left cells).
+// ring[(n % HF_LANE_RING_SLOTS) * ring_stride]: the lane's n-th event until it has left for global memory (SCAN). Events are written
+// there and leave J40_LANE_EV_FLUSH at a time as ONE aligned store (the regions of DevPlan::events start at multiples of 32 events):
+// a lane's 4-byte stores, each into a line of its own that its next store reaches hundreds of cycles later, left the L2 as partly
+// written sectors over and over -- 21 GB of writes per 256 8K frames for 4 GB of events. The check runs every J40_LANE_EV_FLUSH-th
+// turn (a turn adds at most one event, so twice that many slots suffice); what is left at a section's end leaves word by word.
 template <bool SCAN, class Source>
-J40_DEV void decode_hf_sections_lane(const LaneFrame &f, const LaneTables &t, const LaneGlobals &G, Source &src, J40_LDS int8_t *cols, int32_t col_stride, int32_t pass) {
+J40_DEV void decode_hf_sections_lane(const LaneFrame &f, const LaneTables &t, const LaneGlobals &G, Source &src, J40_LDS int8_t *cols, int32_t col_stride, int32_t pass, J40_LDS uint32_t *ring = nullptr, int32_t ring_stride = 0) {
 	LaneSection S;
 	S.start_bit = S.end_bit = S.cell_base = S.block_first = S.ev_first = S.ev_end = 0; S.nblocks = 0;
 	LaneBits b;
@@ -187,12 +194,14 @@ J40_DEV void decode_hf_sections_lane(const LaneFrame &f, const LaneTables &t, co
 	int32_t c = 1, bctx = 0, nz = 0, i = 0, prev = 0, cctx = 0;
 	const J40_GLOBAL uint16_t *order = nullptr;
 	uint32_t ev_at = 0, ev_end = 0, chan_first = 0;   // SCAN: next free event of this section's region, first event of the current channel
+	uint32_t ev_flushed = 0;                          // SCAN: events before this one are in global memory
 	uint32_t blk_first = 0, blk_n0 = 0, blk_n1 = 0;   // the block's table entry, stored in one piece after its third channel
 	uint32_t next0 = 0, next1 = 0;   // descriptor of block k, requested one block ahead
 	for (uint32_t turn = 0; ; ++turn) {
 		if (done) {   // (rare: twice per section)
 			if (have) {
 				// ---- the section's end ----
+				if (SCAN && J40_LANE_EV_FLUSH) for (; ev_flushed < ev_at; ++ev_flushed) ((J40_GLOBAL uint32_t *) G.events)[ev_flushed] = ring[(int32_t) (ev_flushed % (uint32_t) HF_LANE_RING_SLOTS) * ring_stride];
 				if (SCAN && !err && nblocks > 0) lane_store_block_events(G, block_first + (uint32_t) nblocks - 1u, blk_first, blk_n0, blk_n1, ev_at - chan_first);   // the last block
 				if (!err) {   // j40.h:2884-2893: the final state, or the untouched initial state, must be 0x130000
 					if (state == 0) { lane_bits_refill(b); state = lane_bits_take(b, 16); state |= lane_bits_take(b, 16) << 16; if (lane_bit_position(b) > end_bit) err = ERR_SHRT; }
@@ -218,7 +227,7 @@ J40_DEV void decode_hf_sections_lane(const LaneFrame &f, const LaneTables &t, co
 			else if ((int32_t) preset >= f.num_hf_presets) err = ERR_RNGE;
 			ctxoff = 495 * nb_block_ctx * (int32_t) preset;
 			k = 0; c_yxb = 0; in_coeffs = false; state = 0;
-			ev_at = chan_first = blk_first = S.ev_first; ev_end = S.ev_end; blk_n0 = blk_n1 = 0;
+			ev_at = chan_first = blk_first = ev_flushed = S.ev_first; ev_end = S.ev_end; blk_n0 = blk_n1 = 0;
 			done = nblocks == 0 || err != 0;
 			if (done) continue;   // (nothing to decode: its end is the next turn's business)
 			{ const J40_GLOBAL uint32_t *p = G.group_blocks + 2u * block_first; next0 = p[0]; next1 = p[1]; }
@@ -228,6 +237,19 @@ J40_DEV void decode_hf_sections_lane(const LaneFrame &f, const LaneTables &t, co
 		// NZ_PERIOD-th iteration: a lane that reaches a block start in between sits out until then (J40_LANE_NZ_PERIOD = 1: never)
 #ifndef J40_LANE_NZ_PERIOD
 #define J40_LANE_NZ_PERIOD 8
+#endif
+#if J40_LANE_EV_FLUSH
+		if (SCAN && (turn % J40_LANE_EV_FLUSH) == 0 && ev_at - ev_flushed >= (uint32_t) J40_LANE_EV_FLUSH) {
+			const J40_LDS uint32_t *r = ring + (int32_t) (ev_flushed % (uint32_t) HF_LANE_RING_SLOTS) * ring_stride;   // (a run of slots: regions and pieces are aligned)
+			J40_GLOBAL uint32_t *dst = (J40_GLOBAL uint32_t *) G.events + ev_flushed;
+#pragma unroll
+			for (int32_t k4 = 0; k4 < J40_LANE_EV_FLUSH; k4 += 4) {
+				LaneEventQuad q4;
+				q4[0] = r[k4 * ring_stride]; q4[1] = r[(k4 + 1) * ring_stride]; q4[2] = r[(k4 + 2) * ring_stride]; q4[3] = r[(k4 + 3) * ring_stride];
+				*(J40_GLOBAL LaneEventQuad *) (dst + k4) = q4;
+			}
+			ev_flushed += (uint32_t) J40_LANE_EV_FLUSH;
+		}
 #endif
 		if (!in_coeffs && (turn % J40_LANE_NZ_PERIOD) != 0) continue;
 		lane_bits_refill(b);
@@ -279,7 +301,10 @@ J40_DEV void decode_hf_sections_lane(const LaneFrame &f, const LaneTables &t, co
 			if (SCAN) {   // one sequential 4-byte store per non-zero coefficient (CoeffEvent: position | value << 16)
 				const int32_t sv = unpack_signed_dev(v);
 				const bool full = nonzero && (ev_at >= ev_end || !coeff_event_fits(sv));
-				if (nonzero && !full) ((J40_GLOBAL uint32_t *) G.events)[ev_at] = coeff_event_pack((uint32_t) i, sv);
+				if (nonzero && !full) {
+					if (J40_LANE_EV_FLUSH) ring[(int32_t) (ev_at % (uint32_t) HF_LANE_RING_SLOTS) * ring_stride] = coeff_event_pack((uint32_t) i, sv);
+					else ((J40_GLOBAL uint32_t *) G.events)[ev_at] = coeff_event_pack((uint32_t) i, sv);
+				}
 				ev_at += nonzero && !full ? 1u : 0u;
 				e2 = e2 ? e2 : full ? (uint32_t) ERR_EVOF : 0u;
 			} else if (nonzero) G.coeffs[coeff_at + order[i]] += (float) unpack_signed_dev(v);
@@ -309,12 +334,13 @@ struct LaneOneSection {
 // decodes one (pass, group) section; same results and status codes as decode_hf_section (hf_dev.h).
 template <bool SCAN>
 J40_DEV uint32_t decode_hf_section_lane(const LaneFrame &f, const LaneTables &t, const LaneGlobals &G, const DevSection &sec, uint32_t cell_base,
-		uint32_t block_first, int32_t nblocks, uint32_t ev_first, uint32_t ev_end, J40_LDS int8_t *cols, int32_t col_stride, int32_t pass, J40_GLOBAL uint32_t *end_bit_out = nullptr) {
+		uint32_t block_first, int32_t nblocks, uint32_t ev_first, uint32_t ev_end, J40_LDS int8_t *cols, int32_t col_stride, int32_t pass, J40_GLOBAL uint32_t *end_bit_out = nullptr,
+		J40_LDS uint32_t *ring = nullptr, int32_t ring_stride = 0) {
 	LaneOneSection src;
 	src.S.start_bit = 8u * sec.byte_off + sec.bit_off; src.S.end_bit = 8u * (sec.byte_off + sec.size);
 	src.S.cell_base = cell_base; src.S.block_first = block_first; src.S.nblocks = nblocks; src.S.ev_first = ev_first; src.S.ev_end = ev_end;
 	src.taken = false; src.status = 0; src.end_bit = 0;
-	decode_hf_sections_lane<SCAN>(f, t, G, src, cols, col_stride, pass);
+	decode_hf_sections_lane<SCAN>(f, t, G, src, cols, col_stride, pass, ring, ring_stride);
 	if (end_bit_out) *end_bit_out = src.end_bit;
 	return src.status;
 }

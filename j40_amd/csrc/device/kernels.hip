@@ -351,6 +351,8 @@ __global__ void __launch_bounds__(512) k_hf_lanes(const DevPlan *plans, const Hf
 	t.nnz_ctx2 = l_nnz; t.freq_ctx2 = l_freq; t.dct_info = l_dct;
 	// per-wave column predictor state behind the tables: [3][32][64 lanes] bytes
 	J40_LDS int8_t *l_cols = (J40_LDS int8_t *) (lds + lds_tables_bytes + (uint32_t) (tid >> 6) * HF_LANE_COLS_BYTES) + lane;
+	// ... and the lanes' event rings behind it: [HF_LANE_RING_SLOTS][64 lanes] words
+	J40_LDS uint32_t *l_ring = (J40_LDS uint32_t *) (lds + lds_tables_bytes + (uint32_t) (tid >> 6) * HF_LANE_COLS_BYTES + HF_LANE_PRED_BYTES) + lane;
 	for (int32_t pass = 0; pass < num_passes; ++pass) {
 		const J40_GLOBAL DevCodeSpec &spec = specs[pass];
 		__syncthreads();   // previous pass' tables are no longer in use
@@ -370,7 +372,7 @@ __global__ void __launch_bounds__(512) k_hf_lanes(const DevPlan *plans, const Hf
 		t.ctx_map = l_map; t.cluster_cfg = l_cfg; t.alias = l_alias; t.log_alpha = log_alpha; t.log_bucket = 12 - log_alpha;
 		__syncthreads();
 		q.pass = pass; q.slot = active ? w.first_group + lane : -1;
-		if (scan) decode_hf_sections_lane<true>(f, t, G, q, l_cols, 64, pass);
+		if (scan) decode_hf_sections_lane<true>(f, t, G, q, l_cols, 64, pass, l_ring, 64);
 		else decode_hf_sections_lane<false>(f, t, G, q, l_cols, 64, pass);
 	}
 }
@@ -463,6 +465,18 @@ __device__ __forceinline__ bool k2_bind(K2Iter &it, const K2Frame *batch, const 
 	return k2_run_bind(it, batch, tile_prefix, class_a, class_b, per_wg, list, count, rgba, stride, frame, first, entered);
 }
 
+// clears `n` floats of LDS tiles (n a multiple of four, the tiles 16-byte aligned: every tile size here is) with 16-byte stores: a
+// quarter of the LDS instructions of a float at a time (J40_K2_ZERO_SCALAR: the older loop, for comparison)
+__device__ __forceinline__ void zero_tiles(float *t, int32_t n, int32_t tid, int32_t nthreads) {
+#ifdef J40_K2_ZERO_SCALAR
+	for (int32_t w = tid; w < n; w += nthreads) t[w] = 0.0f;
+#else
+	typedef float f4 __attribute__((ext_vector_type(4)));
+	const f4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+	for (int32_t w = 4 * tid; w < n; w += 4 * nthreads) *(f4 *) (t + w) = z;
+#endif
+}
+
 // exclusive prefix sums of the per-block event counts held by lanes 0..NB-1 of the first wavefront (`mine`, 0 for lanes
 // past the last block) -> prefix[0..NB]; visible to the workgroup after its next barrier
 template <int NB>
@@ -522,7 +536,7 @@ __global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan_arg, const DevV
 		const int32_t dq_size = R * C;
 		// (asking for the tile's records first and zeroing the tiles while they are on their way was measured: nineteen registers more
 		// and 67.2 against 64.4 ms for the stage)
-		if (sparse) for (int32_t w = tid; w < nb * 3 * TILE; w += nthreads) lds[w] = 0.0f;
+		if (sparse) zero_tiles(lds, nb * 3 * TILE, tid, nthreads);
 		uint32_t nevents = 0;
 		if (tid < nb) {
 			const DevVarblock vb = list[first + tid];
@@ -619,7 +633,7 @@ template <int NB, bool BATCH>
 __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const DevVarblock *list, int32_t count, uint8_t *rgba, size_t stride_bytes, const K2Frame *batch, const int32_t *tile_prefix, int32_t nframes,
 		int32_t class_a, int32_t class_b) {
 	constexpr int P = SP8_TILE;
-	__shared__ float tiles[NB * 3 * P];   // coefficients in, samples out: both phases work in place (special8_dev.h)
+	__shared__ __attribute__((aligned(16))) float tiles[NB * 3 * P];   // coefficients in, samples out: both phases work in place (special8_dev.h)
 	const int32_t tid = threadIdx.x, nthreads = blockDim.x;
 	__shared__ VbGeom geom[NB];
 	J40_STAGE_SRGB_THRESHOLDS(f);
@@ -647,7 +661,7 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const 
 		}
 		const DevFrame &f = *plan.frame;
 		const int32_t nb = min(NB, count - first);
-		if (sparse) for (int32_t w = tid; w < nb * 3 * P; w += nthreads) tiles[w] = 0.0f;
+		if (sparse) zero_tiles(tiles, nb * 3 * P, tid, nthreads);
 		uint32_t nevents = 0;
 		if (tid < nb) {
 			const DevVarblock vb = list[first + tid];

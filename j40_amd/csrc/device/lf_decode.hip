@@ -8,6 +8,7 @@
 // Only the plain second header is handled here (global tree, default weighted-predictor parameters, no transforms: what VarDCT
 // encoders write); any other reports ERR_LFFB and the host decodes that section itself.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include "modular_coop_dev.h"
 #include "lf_lanes_dev.h"
 #include "lf_rows_dev.h"
@@ -217,11 +218,12 @@ uint32_t pack_lf_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std::vec
 	return most;
 }
 
-void launch_lf_lanes(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t num_waves, uint32_t lds_bytes, hipStream_t stream) {
+void launch_lf_lanes(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t num_waves, uint32_t lds_bytes, hipStream_t stream, hipEvent_t started, hipEvent_t stopped) {
 	if (num_waves <= 0) return;
 	static bool configured = false;
 	if (!configured) { (void) hipFuncSetAttribute((const void *) k_lf_lanes<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); (void) hipFuncSetAttribute((const void *) k_lf_lanes<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); configured = true; }
 	if (lf_lanes_alias_in_lds()) hipLaunchKernelGGL(k_lf_lanes<true>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
+	else if (started && stopped) hipExtLaunchKernelGGL(k_lf_lanes<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, started, stopped, 0, sets, waves);
 	else hipLaunchKernelGGL(k_lf_lanes<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
 }
 
@@ -258,11 +260,12 @@ uint32_t pack_lf_row_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std:
 	return most;
 }
 
-void launch_lf_rows(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t num_waves, uint32_t lds_bytes, hipStream_t stream) {
+void launch_lf_rows(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t num_waves, uint32_t lds_bytes, hipStream_t stream, hipEvent_t started, hipEvent_t stopped) {
 	if (num_waves <= 0) return;
 	static bool configured = false;
 	if (!configured) { (void) hipFuncSetAttribute((const void *) k_lf_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); configured = true; }
-	hipLaunchKernelGGL(k_lf_rows, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
+	if (started && stopped) hipExtLaunchKernelGGL(k_lf_rows, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, started, stopped, 0, sets, waves);
+	else hipLaunchKernelGGL(k_lf_rows, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
 }
 
 void launch_lf_groups(const DevLfTask *tasks, int32_t num_tasks, hipStream_t stream) {

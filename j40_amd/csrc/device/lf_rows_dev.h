@@ -160,17 +160,7 @@ J40_DEV void lf_row_step(LfRowLane &L, const J40_GLOBAL DevLfTask &t, const LfRo
 		case 1: val = L.chan < 3 ? t.sidx0 : t.sidx2; break;
 		case 2: val = y; break;
 		case 3: val = x; break;
-		case 4: val = mod_abs(pn); break;
-		case 5: val = mod_abs(pw); break;
-		case 6: val = pn; break;
-		case 7: val = pw; break;
-		case 8: val = x > 0 ? pw - (pww + pnw - pnww) : pw; break;
-		case 9: val = pw + pn - pnw; break;
-		case 10: val = pw - pnw; break;
-		case 11: val = pnw - pn; break;
-		case 12: val = pn - pne; break;
-		case 13: val = pn - pnn; break;
-		default: val = pw - pww; break;   // 14 (the host admits no other)
+		default: val = neighbour_property(n.prop, x, pw, pn, pnw, pne, pnn, pww, pnww); break;   // 4..14 (props_dev.h; the host admits no other)
 		}
 		at += val > n.value ? n.a : n.b;
 		n = lf_node(T.tree, at);

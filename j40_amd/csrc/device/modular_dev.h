@@ -4,6 +4,7 @@
 // j40__inverse_rct16 / j40__inverse_palette16 (j40.h:4318, 4402) and j40__render_to_u8x4_rgba (j40.h:7910).
 #pragma once
 #include "entropy_dev.h"
+#include "props_dev.h"
 
 namespace j40hip {
 
@@ -242,17 +243,8 @@ J40_DEV uint32_t decode_modular_section(const DevModPlan &plan, const ModTables 
 					case 1: val = sec.sidx; break;
 					case 2: val = y; break;
 					case 3: val = x; break;
-					case 4: val = mod_abs(p.n); break;
-					case 5: val = mod_abs(p.w); break;
-					case 6: val = p.n; break;
-					case 7: val = p.w; break;
-					case 8: val = x > 0 ? p.w - (p.ww + p.nw - p.nww) : p.w; break;
-					case 9: val = p.w + p.n - p.nw; break;
-					case 10: val = p.w - p.nw; break;
-					case 11: val = p.nw - p.n; break;
-					case 12: val = p.n - p.ne; break;
-					case 13: val = p.n - p.nn; break;
-					case 14: val = p.w - p.ww; break;
+					case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14:
+						val = neighbour_property(node.prop, x, p.w, p.n, p.nw, p.ne, p.nn, p.ww, p.nww); break;   // (props_dev.h)
 					case 15:
 						val = wp.blend_err_w;   // the largest of the blend's errors at W, N, NW, NE (first wins a tie)
 						if (mod_abs(val) < mod_abs(wp.blend_err_n)) val = wp.blend_err_n;

@@ -32,6 +32,7 @@
 #include <thread>
 #include <vector>
 #include "../../../include/j40hip.h"
+#include "../capi.hpp"
 #include "async.hpp"
 #include "runtime_shared.hpp"
 
@@ -135,8 +136,13 @@ struct j40hip_pipeline {
 	std::vector<std::pair<void *, size_t>> free_images;
 	double parse_ms = 0, single_ms = 0;  // summed over the worker threads: the asynchronous path's host stage / whole single-frame decodes
 	double lf_ms = 0, k1_ms = 0, k2_ms = 0, k1_kernel_ms = 0; int64_t launches = 0, launch_frames = 0;   // HIP-event durations of the batches' stages
+	double lf_kernel_ms = 0; int64_t lf_launches = 0, lf_launch_frames = 0, lf_launch_sections = 0, lf_launch_waves = 0;   // the LfGroup lane decoder's launches (device-recorded start / end)
 	double first_submit_ms = 0, last_done_ms = 0;
-	std::atomic<int> worker_errors{0};
+	// threads that could not start (no device, no stream). The pipeline is broken -- queued images fail with "!gpu" -- only when no
+	// worker is left or the GPU thread is gone: one worker without a stream does not stop the others from serving
+	std::atomic<int> workers_alive{0};
+	std::atomic<bool> gpu_thread_dead{false};
+	bool broken() const { return gpu_thread_dead.load() || workers_alive.load() <= 0; }
 };
 
 namespace {
@@ -210,13 +216,13 @@ uint32_t decode_single(j40hip_pipeline *p, Job *j, hipStream_t s) {
 }
 
 void worker_main(j40hip_pipeline *p, int) {
-	if (hipSetDevice(p->device) != hipSuccess) { ++p->worker_errors; return; }
+	if (hipSetDevice(p->device) != hipSuccess) { --p->workers_alive; return; }
 	// The thread's copies go on a stream of the highest priority: such streams have hardware queues of their own, so a copy does
 	// not wait its turn behind another stream's long kernel (streams of one priority share a handful of hardware queues in turn)
 	hipStream_t stream = nullptr;
 	int prio_low = 0, prio_high = 0;
 	(void) hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-	if (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio_high) != hipSuccess) { (void) hipGetLastError(); if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { ++p->worker_errors; return; } }
+	if (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio_high) != hipSuccess) { (void) hipGetLastError(); if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); --p->workers_alive; return; } }
 	double wait_ms = 0, post_ms = 0, busy_ms = 0; int64_t nframes = 0;   // (J40HIP_ASYNC_TIMING)
 	for (;;) {
 		Job *j = nullptr;
@@ -318,8 +324,8 @@ bool progress(j40hip_pipeline *p, Slot &slot, bool block) {
 		slot.harvested = true; slot.t_harvest = now_ms();
 	}
 	while (slot.next_group < ngroups) {
-		hipEvent_t ev = slot.group_ev[(size_t) slot.next_group];
 		if (!slot.launch_err && !slot.failed) {
+			hipEvent_t ev = slot.group_ev[(size_t) slot.next_group];
 			hipError_t q = block && first ? hipEventSynchronize(ev) : hipEventQuery(ev);
 			if (q == hipErrorNotReady) { (void) hipGetLastError(); return false; }
 			if (q != hipSuccess) { (void) hipGetLastError(); slot.failed = true; }
@@ -392,7 +398,7 @@ uint32_t launch_batch(j40hip_pipeline *p, std::vector<Job *> &take, int si) {
 		if ((i + 1) % per_group == 0 || i + 1 == n) {
 			const size_t g = slot.group_end.size();
 			while (slot.group_ev.size() <= g) { hipEvent_t e = nullptr; if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { (void) hipGetLastError(); break; } slot.group_ev.push_back(e); }
-			if (slot.group_ev.size() <= g) { if (!slot.launch_err) slot.launch_err = E_GPU; slot.group_ev.resize(g + 1, slot.kdone); }
+			if (slot.group_ev.size() <= g && !slot.launch_err) slot.launch_err = E_GPU;   // (no event: progress() asks none of a slot with a launch error)
 			if (!slot.launch_err && hipEventRecord(slot.group_ev[g], gs) != hipSuccess) slot.launch_err = E_GPU;
 			slot.group_end.push_back(i + 1);
 		}
@@ -403,7 +409,7 @@ uint32_t launch_batch(j40hip_pipeline *p, std::vector<Job *> &take, int si) {
 }
 
 void gpu_main(j40hip_pipeline *p) {
-	if (hipSetDevice(p->device) != hipSuccess) { ++p->worker_errors; return; }
+	if (hipSetDevice(p->device) != hipSuccess) { p->gpu_thread_dead = true; return; }
 	double t_lf = 0, t_launch = 0, t_retire = 0, t_idle = 0, t_lock = 0; int64_t n_launch = 0, n_lf = 0;   // (J40HIP_ASYNC_TIMING)
 	struct Report { double &a, &b, &c, &d, &e; int64_t &n, &m; ~Report() { if (getenv("J40HIP_ASYNC_TIMING")) fprintf(stderr, "[j40hip gpu thread] ms: LfGroup launches %.1f (%lld), batch launches %.1f (%lld), retiring %.1f, waiting %.1f, for the lock %.1f\n", a, (long long) m, b, (long long) n, c, d, e); } } report{t_lf, t_launch, t_retire, t_idle, t_lock, n_launch, n_lf};
 	// slots with something to hand back, oldest first; free slots leave the list
@@ -433,6 +439,7 @@ void gpu_main(j40hip_pipeline *p) {
 			// the LfGroup streams the device decodes: finished launches hand their frames on; waiting frames go into the next launch (a
 			// launch is latency-bound -- about 0.2 s however many sections it has -- so everything waiting goes in)
 			for (LfFlight &fl : p->lf_flights) if (fl.busy && j40hip_alf_done(fl.alf)) {
+				{ float ms = 0; int nf = 0, ns = 0, nw = 0; if (j40hip_alf_elapsed(fl.alf, &ms, &nf, &ns, &nw) == 0) { p->lf_kernel_ms += ms; ++p->lf_launches; p->lf_launch_frames += nf; p->lf_launch_sections += ns; p->lf_launch_waves += nw; } }
 				for (Job *j : fl.jobs) { j->ready_ms = now_ms(); p->ready.push_back(j); }
 				p->lf_stage -= (int64_t) fl.jobs.size();
 				fl.jobs.clear(); fl.busy = false;
@@ -501,6 +508,12 @@ void gpu_main(j40hip_pipeline *p) {
 			// again; with nothing in flight give idle cache blocks back and halve the batch (the rest goes back to the queue); a single
 			// frame that still does not fit fails with "!mem"
 			if (!p->in_flight.empty()) { retire_ready(true); continue; }
+			{   // (what harvested batches handed back waits for the worker threads to free it: free it here before concluding anything)
+				std::vector<j40hip_aframe *> dead;
+				{ std::unique_lock<std::mutex> lock(p->m); dead.swap(p->garbage); }
+				for (j40hip_aframe *af : dead) j40hip_aframe_free(af);
+				if (!dead.empty()) continue;
+			}
 			j40hip_rt::cache_trim(p->device);
 			if (take.size() > 1) {
 				std::unique_lock<std::mutex> lock(p->m);
@@ -509,8 +522,7 @@ void gpu_main(j40hip_pipeline *p) {
 				continue;
 			}
 			Slot &slot = p->slots[(size_t) si];   // one frame, nothing in flight, nothing cached: it does not fit
-			slot.busy = true; slot.jobs = take; slot.launch_err = E_MEM; slot.harvested = false; slot.next_group = 0; slot.group_end.assign(1, (int) take.size());
-			if (slot.group_ev.empty()) slot.group_ev.push_back(slot.kdone);
+			slot.busy = true; slot.jobs = take; slot.launch_err = E_MEM; slot.harvested = false; slot.next_group = 0; slot.group_end.assign(1, (int) take.size());   // (progress() asks no event of a slot with a launch error)
 			p->in_flight.push_back(si);
 			break;
 		}
@@ -586,6 +598,7 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 			if (host_threads < 1) host_threads = std::max(2, std::min(16, cpu_quota() - 2));
 			if (host_threads > 128) host_threads = 128;   // (each worker owns tens of MB of pinned staging; more than this was never exercised)
 			p->gpu = std::thread(gpu_main, p);
+			p->workers_alive = host_threads;
 			for (int i = 0; i < host_threads; ++i) p->workers.emplace_back(worker_main, p, i);
 		}
 	} catch (const std::exception &) { *err = E_MEM; }
@@ -607,7 +620,7 @@ void j40hip_pipeline_free(j40hip_pipeline *p) {
 	for (std::deque<Job *> *q : {&p->ready, &p->lf_pending}) for (Job *j : *q) { if (j->af) { (void) hipDeviceSynchronize(); j40hip_aframe_free(j->af); } abandon(j); }
 	for (LfFlight &fl : p->lf_flights) { for (Job *j : fl.jobs) { if (j->af) { (void) hipDeviceSynchronize(); j40hip_aframe_free(j->af); } abandon(j); } if (fl.stream) (void) hipStreamDestroy(fl.stream); }
 	for (Slot &s : p->slots) {
-		for (hipEvent_t e : s.group_ev) if (e && e != s.kdone) (void) hipEventDestroy(e);
+		for (hipEvent_t e : s.group_ev) if (e) (void) hipEventDestroy(e);
 		if (s.kdone) (void) hipEventDestroy(s.kdone);
 		if (s.stream && (&s == &p->slots[0] || s.stream != p->slots[0].stream)) (void) hipStreamDestroy(s.stream);
 	}
@@ -617,7 +630,7 @@ void j40hip_pipeline_free(j40hip_pipeline *p) {
 
 uint32_t j40hip_pipeline_submit(j40hip_pipeline *p, const void *buf, size_t size, void *rgba, size_t stride_bytes, int device_output, int64_t *ticket) {
 	if (!p || !buf || !rgba) return E_RNGE;
-	if (p->worker_errors.load()) return E_GPU;
+	if (p->broken()) return E_GPU;
 	try {
 		Job *j = new Job();
 		j->buf = buf; j->size = size; j->rgba = rgba; j->stride = stride_bytes; j->device_output = device_output != 0;
@@ -636,7 +649,7 @@ uint32_t j40hip_pipeline_submit(j40hip_pipeline *p, const void *buf, size_t size
 // asked for through `alloc` once the image's size is known. What j40_next_frame calls when it serves many threads (api.cpp).
 uint32_t j40hip_pipeline_run(j40hip_pipeline *p, const void *buf, size_t size, j40hip_output_alloc alloc, void *ctx) {
 	if (!p || !buf || !alloc) return E_RNGE;
-	if (p->worker_errors.load()) return E_GPU;
+	if (p->broken()) return E_GPU;
 	Waiter w;
 	Job *j = nullptr;
 	try {
@@ -651,15 +664,21 @@ uint32_t j40hip_pipeline_run(j40hip_pipeline *p, const void *buf, size_t size, j
 	std::unique_lock<std::mutex> wl(w.m);
 	while (!w.done) {
 		w.cv.wait_for(wl, std::chrono::milliseconds(200));
-		if (w.done || !p->worker_errors.load()) continue;
-		// a pipeline thread could not start (no device, no stream): an image still in the queue may never be taken -- it comes out
-		// again and fails with "!gpu"; one that a thread did take completes as usual
+		if (w.done || !p->broken()) continue;
+		// no worker could start, or the GPU thread could not: an image still in a queue nobody serves comes out again and fails with
+		// "!gpu" -- the queue of the workers, or (GPU thread gone, workers alive) the queues behind them; an image a live thread holds
+		// completes as usual
 		wl.unlock();
 		{
 			std::unique_lock<std::mutex> lock(p->m);
-			for (auto it = p->todo.begin(); it != p->todo.end(); ++it) if (*it == j) {
-				p->todo.erase(it); ++p->completed; p->cv_done.notify_all();
+			std::deque<Job *> *queues[3] = {&p->todo, &p->ready, &p->lf_pending};
+			for (int qi = 0; qi < (p->gpu_thread_dead.load() ? 3 : 1); ++qi) for (auto it = queues[qi]->begin(); it != queues[qi]->end(); ++it) if (*it == j) {
+				queues[qi]->erase(it); ++p->completed; p->cv_done.notify_all();
+				if (qi) { --p->resident; if (qi == 2) --p->lf_stage; }
+				j40hip_aframe *af = j->af;
 				delete j;
+				lock.unlock();
+				if (af) { (void) hipSetDevice(p->device); (void) hipDeviceSynchronize(); j40hip_aframe_free(af); }
 				return E_GPU;
 			}
 			p->cv_ready.notify_all();
@@ -676,7 +695,7 @@ uint32_t j40hip_pipeline_drain(j40hip_pipeline *p) {
 	std::unique_lock<std::mutex> lock(p->m);
 	p->cv_ready.notify_all();
 	while (p->completed < p->submitted) {
-		if (p->worker_errors.load()) return E_GPU;
+		if (p->broken()) return E_GPU;
 		p->cv_done.wait_for(lock, std::chrono::milliseconds(50));
 		p->cv_ready.notify_all();   // (the tail condition of the GPU thread depends on counters the workers change)
 	}
@@ -703,6 +722,13 @@ void j40hip_pipeline_stats_ex(j40hip_pipeline *p, double *out) {
 	std::unique_lock<std::mutex> lock(p->m);
 	out[8] = p->lf_ms; out[9] = (double) p->lf_device_frames; out[10] = (double) p->single_frames; out[11] = p->k1_kernel_ms;
 }
+/* out[0..4]: the LfGroup lane decoder's launches since the last reset -- summed kernel duration in ms (device-recorded start / end
+   events), launches, frames, sections, wavefronts */
+void j40hip_pipeline_lf_stats(j40hip_pipeline *p, double *out) {
+	if (!p || !out) return;
+	std::unique_lock<std::mutex> lock(p->m);
+	out[0] = p->lf_kernel_ms; out[1] = (double) p->lf_launches; out[2] = (double) p->lf_launch_frames; out[3] = (double) p->lf_launch_sections; out[4] = (double) p->lf_launch_waves;
+}
 
 int64_t j40hip_pipeline_lf_device_frames(j40hip_pipeline *p) { if (!p) return 0; std::unique_lock<std::mutex> lock(p->m); return p->lf_device_frames; }
 
@@ -711,6 +737,7 @@ void j40hip_pipeline_reset_stats(j40hip_pipeline *p) {
 	std::unique_lock<std::mutex> lock(p->m);
 	p->parse_ms = p->single_ms = 0; p->first_submit_ms = 0; p->last_done_ms = 0;
 	p->lf_ms = p->k1_ms = p->k2_ms = p->k1_kernel_ms = 0; p->launches = p->launch_frames = 0; p->lf_device_frames = p->single_frames = 0;
+	p->lf_kernel_ms = 0; p->lf_launches = p->lf_launch_frames = p->lf_launch_sections = p->lf_launch_waves = 0;
 }
 
 
@@ -724,21 +751,7 @@ void j40hip_pipeline_reset_stats(j40hip_pipeline *p) {
 static std::mutex g_serve_mutex;
 static j40hip_pipeline *g_serve[16] = {nullptr};
 
-static int cpu_quota() {
-	unsigned hw = std::thread::hardware_concurrency();
-	int n = hw ? (int) hw : 4;
-	if (FILE *fp = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2
-		char q[64] = {0}; long long period = 0;
-		if (fscanf(fp, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) { const long long c = atoll(q) / period; if (c >= 1 && c < n) n = (int) c; }
-		fclose(fp);
-		return n;
-	}
-	long long quota = -1, period = 0;   // cgroup v1
-	if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fp, "%lld", &quota) != 1) quota = -1; fclose(fp); }
-	if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lld", &period) != 1) period = 0; fclose(fp); }
-	if (quota > 0 && period > 0) { const long long c = quota / period; if (c >= 1 && c < n) n = (int) c; }
-	return n;
-}
+static int cpu_quota() { return j40hip_cpu_quota(); }   // (capi_host.cpp)
 
 j40hip_pipeline *j40hip_serve_pipeline(int device, uint32_t *err) {
 	uint32_t dummy; if (!err) err = &dummy;

@@ -300,7 +300,13 @@ enum { SRGB_THRESHOLDS = 258, SRGB_BUCKET_LO = (127 - 13) << 7, SRGB_BUCKET_HI =
        SRGB_TABLE_FLOATS = SRGB_THRESHOLDS + SRGB_BUCKETS / 4 };
 
 enum { HF_WAVES = 4 };
-enum { HF_LANE_COLS_BYTES = 3 * 32 * 64 };   // k_hf_lanes: per-wavefront column state of the non-zero-count predictor  // groups (wavefronts) per K1 workgroup
+// k_hf_lanes keeps per wavefront, behind its frame's tables: the column state of the non-zero-count predictor ([3][32][64 lanes]
+// bytes) and the lanes' event rings (hf_lanes_dev.h: a lane's coefficient events collect in LDS and leave J40_LANE_EV_FLUSH at a
+// time as one aligned 16- or 32-byte store; [2 * J40_LANE_EV_FLUSH][64 lanes] words; 0: every event is a 4-byte store of its own)
+#ifndef J40_LANE_EV_FLUSH
+#define J40_LANE_EV_FLUSH 8
+#endif
+enum { HF_LANE_PRED_BYTES = 3 * 32 * 64, HF_LANE_RING_SLOTS = 2 * J40_LANE_EV_FLUSH, HF_LANE_COLS_BYTES = HF_LANE_PRED_BYTES + HF_LANE_RING_SLOTS * 64 * 4 };
 
 // what the host knows about the entropy tables' sizes, to lay out K1's LDS
 struct HfLaunchInfo {

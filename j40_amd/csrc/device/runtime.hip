@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <mutex>
 #include <cmath>
+#include <unistd.h>
 #include "../capi.hpp"
 #include "../tables.hpp"
 #include "../plan_build.hpp"
@@ -137,41 +138,80 @@ void j40hip_rt::cache_release(int device, void *ptr, size_t bytes, bool clean) {
 
 // ---- pinned host memory for pixels that go back to the caller (the public API's image planes): pinning 133 MB takes tens of
 // milliseconds (0.2 s for 133 MB measured, as long again to unpin), so planes are recycled by size across images.
-// J40HIP_PINNED_POOL_GB bounds what sits idle (default 32: 240 planes of an 8K image -- with 128 callers and a 16 GB bound every
-// j40_free beyond the 123rd plane unpinned it and the next image pinned a new one; 0: nothing kept).
+// What sits idle is bounded three ways (a drop-in caller never calls j40hip_shutdown, and pinned memory cannot be swapped):
+//   * J40HIP_PINNED_POOL_GB (default: the smaller of 32 GB -- 240 planes of an 8K image; with 128 callers and a 16 GB bound every
+//     j40_free beyond the 123rd plane unpinned it and the next image pinned a new one -- and a quarter of the machine's memory;
+//     0: nothing kept);
+//   * a plane that does not fit is made room for by unpinning the planes that have been idle longest (a process that moves on to
+//     another image size does not keep the old size's planes and pin / unpin every image of the new one);
+//   * planes idle for more than J40HIP_PINNED_IDLE_S seconds (default 30) are unpinned at the library's next acquire or release.
 namespace {
+struct PinnedIdle { void *ptr; size_t bytes; double since; };
 std::mutex g_pinned_mutex;
-std::vector<std::pair<void *, size_t>> g_pinned_idle;
+std::vector<PinnedIdle> g_pinned_idle;   // oldest first
 size_t g_pinned_idle_bytes = 0;
-size_t pinned_limit() { static const size_t v = [] { const char *e = getenv("J40HIP_PINNED_POOL_GB"); return (size_t) (e ? std::max(0, atoi(e)) : 32) << 30; }(); return v; }
+size_t pinned_limit() {
+	static const size_t v = [] {
+		if (const char *e = getenv("J40HIP_PINNED_POOL_GB")) return (size_t) std::max(0, atoi(e)) << 30;
+		const long pages = sysconf(_SC_PHYS_PAGES), page = sysconf(_SC_PAGESIZE);
+		const size_t ram = pages > 0 && page > 0 ? (size_t) pages * (size_t) page : (size_t) 128 << 30;
+		return std::min((size_t) 32 << 30, ram / 4);
+	}();
+	return v;
+}
+double pinned_idle_seconds() { static const double v = [] { const char *e = getenv("J40HIP_PINNED_IDLE_S"); return e && atof(e) > 0 ? atof(e) : 30.0; }(); return v; }
+double pinned_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// (under g_pinned_mutex) moves to `gone`: planes idle for too long, then the oldest ones until `incoming` more bytes fit the bound
+void pinned_make_room(size_t incoming, std::vector<void *> *gone) {
+	const double now = pinned_now(), keep = pinned_idle_seconds();
+	size_t n = 0;
+	while (n < g_pinned_idle.size() && (now - g_pinned_idle[n].since > keep || g_pinned_idle_bytes + incoming > pinned_limit())) {
+		gone->push_back(g_pinned_idle[n].ptr); g_pinned_idle_bytes -= g_pinned_idle[n].bytes; ++n;
+	}
+	g_pinned_idle.erase(g_pinned_idle.begin(), g_pinned_idle.begin() + (long) n);
+}
 }
 extern "C" void *j40hip_pinned_acquire(size_t bytes) {
 	bytes = (bytes + 4095) & ~(size_t) 4095;
+	std::vector<void *> gone;
+	void *q = nullptr;
 	{
 		std::lock_guard<std::mutex> lock(g_pinned_mutex);
-		for (size_t i = g_pinned_idle.size(); i-- > 0; ) if (g_pinned_idle[i].second == bytes) {
-			void *q = g_pinned_idle[i].first;
+		for (size_t i = g_pinned_idle.size(); i-- > 0; ) if (g_pinned_idle[i].bytes == bytes) {   // the most recently used plane of this size
+			q = g_pinned_idle[i].ptr;
 			g_pinned_idle.erase(g_pinned_idle.begin() + (long) i); g_pinned_idle_bytes -= bytes;
-			return q;
+			break;
 		}
+		pinned_make_room(q ? 0 : bytes, &gone);   // (a miss: the plane pinned now will come back to the pool)
 	}
-	void *q = nullptr;
+	for (void *g : gone) (void) hipHostFree(g);
+	if (q) return q;
 	if (hipHostMalloc(&q, bytes ? bytes : 4096, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
 	return q;
 }
 extern "C" void j40hip_pinned_release(void *ptr, size_t bytes) {
 	if (!ptr) return;
 	bytes = (bytes + 4095) & ~(size_t) 4095;
+	std::vector<void *> gone;
 	{
 		std::lock_guard<std::mutex> lock(g_pinned_mutex);
-		if (g_pinned_idle_bytes + bytes <= pinned_limit()) { g_pinned_idle.push_back({ptr, bytes}); g_pinned_idle_bytes += bytes; return; }
+		pinned_make_room(bytes, &gone);
+		if (g_pinned_idle_bytes + bytes <= pinned_limit()) { g_pinned_idle.push_back({ptr, bytes, pinned_now()}); g_pinned_idle_bytes += bytes; ptr = nullptr; }
 	}
-	(void) hipHostFree(ptr);
+	for (void *g : gone) (void) hipHostFree(g);
+	if (ptr) (void) hipHostFree(ptr);
+}
+// (what the pool holds: tests/test_api_threads.py)
+extern "C" __attribute__((visibility("default"))) void j40hip_pinned_pool_stats(uint64_t *idle_bytes, uint64_t *idle_planes, uint64_t *limit_bytes) {
+	std::lock_guard<std::mutex> lock(g_pinned_mutex);
+	if (idle_bytes) *idle_bytes = g_pinned_idle_bytes;
+	if (idle_planes) *idle_planes = g_pinned_idle.size();
+	if (limit_bytes) *limit_bytes = pinned_limit();
 }
 static void pinned_trim() {
-	std::vector<std::pair<void *, size_t>> gone;
+	std::vector<PinnedIdle> gone;
 	{ std::lock_guard<std::mutex> lock(g_pinned_mutex); gone.swap(g_pinned_idle); g_pinned_idle_bytes = 0; }
-	for (auto &b : gone) (void) hipHostFree(b.first);
+	for (auto &b : gone) (void) hipHostFree(b.ptr);
 }
 
 namespace {

@@ -1,6 +1,7 @@
 // j40_amd/csrc/modular.cpp -- see modular.hpp
 #include "modular.hpp"
 #include "device/squeeze_dev.h"
+#include "device/props_dev.h"
 #include <algorithm>
 
 namespace j40hip {
@@ -470,13 +471,7 @@ bool decode_channel_fast(BitReader &br, Modular &m, CodeState &code, int32_t cid
 					switch (n->prop) {
 					case 2: val = y; break;
 					case 3: val = x; break;
-					case 4: val = std::abs(pn); break;
-					case 5: val = std::abs(pw); break;
-					case 6: val = pn; break;
-					case 7: val = pw; break;
-					case 9: val = pw + pn - pnw; break;
-					case 10: val = pw - pnw; break;
-					default: val = pnw - pn; break;   // 11
+					default: val = neighbour_property(n->prop, x, pw, pn, pnw, 0, 0, 0, 0); break;   // 4..7, 9..11 (the path's precondition): N, W, NW suffice
 					}
 					n += val > n->value ? n->a : n->b;
 				}
@@ -517,17 +512,7 @@ bool decode_channel_fast(BitReader &br, Modular &m, CodeState &code, int32_t cid
 				switch (n->prop) {
 				case 2: val = y; break;
 				case 3: val = x; break;
-				case 4: val = std::abs(p.n); break;
-				case 5: val = std::abs(p.w); break;
-				case 6: val = p.n; break;
-				case 7: val = p.w; break;
-				case 8: val = x > 0 ? p.w - (p.ww + p.nw - p.nww) : p.w; break;
-				case 9: val = p.w + p.n - p.nw; break;
-				case 10: val = p.w - p.nw; break;
-				case 11: val = p.nw - p.n; break;
-				case 12: val = p.n - p.ne; break;
-				case 13: val = p.n - p.nn; break;
-				default: val = p.w - p.ww; break;   // 14
+				default: val = neighbour_property(n->prop, x, p.w, p.n, p.nw, p.ne, p.nn, p.ww, p.nww); break;   // 4..14 (device/props_dev.h)
 				}
 				n += val > n->value ? n->a : n->b;
 			}
@@ -586,17 +571,8 @@ void decode_modular_channel(BitReader &br, Modular &m, CodeState &code, int32_t 
 				case 1: val = (int32_t) sidx; break;
 				case 2: val = y; break;
 				case 3: val = x; break;
-				case 4: val = std::abs(p.n); break;
-				case 5: val = std::abs(p.w); break;
-				case 6: val = p.n; break;
-				case 7: val = p.w; break;
-				case 8: val = x > 0 ? p.w - (p.ww + p.nw - p.nww) : p.w; break;
-				case 9: val = p.w + p.n - p.nw; break;
-				case 10: val = p.w - p.nw; break;
-				case 11: val = p.nw - p.n; break;
-				case 12: val = p.n - p.ne; break;
-				case 13: val = p.n - p.nn; break;
-				case 14: val = p.w - p.ww; break;
+				case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14:
+					val = neighbour_property(n->prop, x, p.w, p.n, p.nw, p.ne, p.nn, p.ww, p.nww); break;   // (device/props_dev.h)
 				case 15:
 					val = wp.trueerrw;
 					if (std::abs(val) < std::abs(wp.trueerrn)) val = wp.trueerrn;

@@ -95,6 +95,7 @@ bool fill_event_ranges(const std::vector<DevSection> &sections, int32_t num_grou
 		const DevSection &d = sections[(size_t) g];
 		static const size_t per_byte = getenv("J40HIP_EVENTS_PER_BYTE") ? (size_t) atoi(getenv("J40HIP_EVENTS_PER_BYTE")) : 4;   // tests shrink it to reach the fallback
 		const size_t worst = (size_t) d.gw8 * (size_t) d.gh8 * 64 * 3, cap = std::min(worst, (size_t) d.size * per_byte + 256);
+		*ev_capacity = (*ev_capacity + 31) & ~(size_t) 31;   // regions start on a 128-byte line: the entropy kernel writes them in aligned pieces (hf_lanes_dev.h)
 		ev_range->push_back((uint32_t) *ev_capacity);
 		*ev_capacity += cap;
 		ev_range->push_back((uint32_t) *ev_capacity);
@@ -337,7 +338,9 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 			}
 		}
 	};
-	run_team(threads, body);
+	// (a team no larger than the work has pieces -- LfGroups in phase A, groups behind it -- and none for frames of a few groups:
+	// starting eleven threads for a 64 x 64 image costs more than its plan)
+	run_team(num_groups + (int32_t) nlf <= 8 ? 1 : std::min(threads, std::max((int32_t) nlf, num_groups)), body);
 	if (!consistent) return ERR_RNGE;   // (a varblock without a top-left cell: the parse does not produce such frames, a caller's plan view may)
 
 	// single-pass frames: sparse coefficients (DevPlan::events). A group's region is sized from its section: a non-zero

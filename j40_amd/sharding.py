@@ -66,19 +66,30 @@ def range_rectangles(first, count, width, height, group_size_shift):
 
 
 def broadcast_bytes(data, dist, device="cpu", src=0):
-    """the codestream from rank `src` to every rank; `data` is ignored on the other ranks"""
+    """the codestream from rank `src` to every rank; `data` is ignored on the other ranks. The source keeps the bytes it has (nothing
+    comes back from the device for it); a receiving rank needs them in HOST memory -- its parser reads headers, TOC and the LF sections
+    there -- so what arrived in a device tensor (RCCL moves device memory) is copied down once, through a pinned buffer"""
     import torch
     rank = dist.get_rank()
     n = torch.tensor([len(data) if rank == src else 0], dtype=torch.int64, device=device)
     dist.broadcast(n, src)
-    if int(n.item()) == 0:
+    size = int(n.item())
+    if size == 0:
         return b""
+    on_device = str(device) != "cpu"
     if rank == src:
-        buf = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(device)
-    else:
-        buf = torch.empty(int(n.item()), dtype=torch.uint8, device=device)
+        buf = torch.frombuffer(bytearray(data), dtype=torch.uint8)
+        if on_device:
+            buf = buf.to(device, non_blocking=True)
+        dist.broadcast(buf, src)
+        return data if isinstance(data, bytes) else bytes(data)
+    buf = torch.empty(size, dtype=torch.uint8, device=device)
     dist.broadcast(buf, src)
-    return bytes(buf.cpu().numpy().tobytes())
+    if on_device:
+        host = torch.empty(size, dtype=torch.uint8, pin_memory=True)
+        host.copy_(buf, non_blocking=False)
+        buf = host
+    return buf.numpy().tobytes()
 
 
 def agree_on_errors(code, dist, device="cpu"):

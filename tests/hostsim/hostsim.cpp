@@ -296,6 +296,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 		LaneFrame lf = {df.nb_block_ctx, df.num_hf_presets, df.preset_bits, df.check_section_end, df.single_declared_end, df.order_off};
 		LaneGlobals G = {plan.codestream, (const uint32_t *) plan.group_blocks, plan.coeffs[0], plan.events, plan.block_events, plan.pool_u16, plan.coeff_stride};
 		std::vector<int8_t> cols(3 * 32);
+		std::vector<uint32_t> ring((size_t) HF_LANE_RING_SLOTS + 1, 0xdeadbeefu);   // the lane's event ring (slots one word apart)
 		std::vector<uint32_t> dct(27);
 		for (int d = 0; d < 27; ++d) dct[(size_t) d] = (uint32_t) DEV_DCT_SELECT[d][0] | ((uint32_t) DEV_DCT_SELECT[d][1] << 8) | ((uint32_t) DEV_DCT_SELECT[d][2] << 16);
 		for (int32_t pass = 0; pass < df.num_passes; ++pass) {
@@ -324,14 +325,14 @@ extern "C" __attribute__((visibility("default"))) uint32_t hostsim_decode(const 
 				} q{plan, hp, pass, {}, 0, 0, status};
 				for (int32_t g = 0; g < df.num_groups; ++g) q.order.push_back(g);
 				std::stable_sort(q.order.begin(), q.order.end(), [&](int32_t a, int32_t b) { return plan.sections[pass * df.num_groups + a].size > plan.sections[pass * df.num_groups + b].size; });
-				if (df.sparse_coeffs) decode_hf_sections_lane<true>(lf, t, G, q, cols.data(), 1, pass);
+				if (df.sparse_coeffs) decode_hf_sections_lane<true>(lf, t, G, q, cols.data(), 1, pass, ring.data(), 1);
 				else decode_hf_sections_lane<false>(lf, t, G, q, cols.data(), 1, pass);
 			} else
 			for (int32_t g = 0; g < df.num_groups; ++g) {
 				const DevSection &sec = plan.sections[pass * df.num_groups + g];
 				const uint32_t b0 = plan.group_block_start[g], b1 = plan.group_block_start[g + 1];
 				const uint32_t cell_base = (uint32_t) plan.lf_groups[sec.ggidx].cell_base;
-				status[(size_t) (pass * df.num_groups + g)] = df.sparse_coeffs ? decode_hf_section_lane<true>(lf, t, G, sec, cell_base, b0, (int32_t) (b1 - b0), hp.ev_range[2 * (size_t) g], hp.ev_range[2 * (size_t) g + 1], cols.data(), 1, pass)
+				status[(size_t) (pass * df.num_groups + g)] = df.sparse_coeffs ? decode_hf_section_lane<true>(lf, t, G, sec, cell_base, b0, (int32_t) (b1 - b0), hp.ev_range[2 * (size_t) g], hp.ev_range[2 * (size_t) g + 1], cols.data(), 1, pass, nullptr, ring.data(), 1)
 					: decode_hf_section_lane<false>(lf, t, G, sec, cell_base, b0, (int32_t) (b1 - b0), 0, 0, cols.data(), 1, pass);
 			}
 		}

@@ -199,3 +199,28 @@ def test_bytes_behind_the_frame_like_the_reference(ref):
             code = L.j40hip_frame_after_frame_status(fr.h)
             assert ("" if code == 0 else code.to_bytes(4, "big").decode("latin1")) == rerr, (mode, w, h, o, n, rerr)
             fr.close()
+
+
+def test_from_file_opens_now_and_reads_at_next_frame_like_the_reference(built, tmp_path):
+    """j40_from_file only opens the file (j40.h:8342-8361); the bytes are read by j40_next_frame (j40.h:1241-1256, 1307-1343): a path
+    that cannot be opened fails in from_file with `open` and the errno text, a directory opens and then fails to READ (`read`) inside
+    j40_next_frame, an empty or truncated file ends in `shrt` there. The reference's own dj40.c, built unchanged against both
+    libraries (oracle/Makefile `dropin`), must print the same line and exit the same way -- none of these cases reaches the GPU."""
+    import subprocess
+    exe_ref, exe_hip = os.path.join(ROOT, "oracle", "_ref", "dj40-ref"), os.path.join(ROOT, "oracle", "_ref", "dj40-hip")
+    if not (os.path.exists(exe_ref) and os.path.exists(exe_hip)):
+        pytest.skip("oracle/_ref/dj40-* not built (needs the reference sources at build time)")
+    from streams import synth
+    good = synth("vardct", 520, 264, 300)
+    (tmp_path / "empty.jxl").write_bytes(b"")
+    (tmp_path / "headers_only.jxl").write_bytes(good[:40])
+    (tmp_path / "two_bytes.jxl").write_bytes(good[:2])
+    (tmp_path / "not_jxl.jxl").write_bytes(b"GIF89a" + bytes(64))
+    (tmp_path / "a_directory").mkdir()
+    for name in ("missing.jxl", "a_directory", "empty.jxl", "two_bytes.jxl", "headers_only.jxl", "not_jxl.jxl"):
+        runs = [subprocess.run([exe, str(tmp_path / name), str(tmp_path / "out.png")], capture_output=True, text=True, timeout=60) for exe in (exe_ref, exe_hip)]
+        assert runs[0].returncode == runs[1].returncode != 0, (name, runs[0].stderr, runs[1].stderr)
+        assert runs[0].stderr == runs[1].stderr, (name, runs[0].stderr, runs[1].stderr)
+    msg = subprocess.run([exe_hip, str(tmp_path / "a_directory"), str(tmp_path / "out.png")], capture_output=True, text=True).stderr
+    assert "(read)" in msg and "j40_next_frame" in msg, msg
+
