@@ -496,8 +496,13 @@ __device__ __forceinline__ void stage_event_prefix(uint32_t mine, uint32_t *pref
 // thanks to the odd pitch. Arithmetic = j40__inverse_dct2d (j40.h:5972): IDCT over the columns
 // dimension first, then over rows.
 
+// (J40_K2_WAVES_PER_EU: an experiment's knob -- asks the compiler to fit the small shapes' kernels into the registers that many
+// wavefronts per SIMD leave)
+#ifndef J40_K2_WAVES_PER_EU
+#define J40_K2_WAVES_PER_EU 1
+#endif
 template <int LOGR, int LOGC, int NB, bool BATCH>
-__global__ void __launch_bounds__(256) k_vardct_dct(DevPlan plan_arg, const DevVarblock *list, int32_t count, int32_t param_idx, int32_t order_idx, uint8_t *rgba, size_t stride_bytes,
+__global__ void __launch_bounds__(256, (LOGR + LOGC <= 7 ? J40_K2_WAVES_PER_EU : 1)) k_vardct_dct(DevPlan plan_arg, const DevVarblock *list, int32_t count, int32_t param_idx, int32_t order_idx, uint8_t *rgba, size_t stride_bytes,
 		const K2Frame *batch, const int32_t *tile_prefix, int32_t nframes, int32_t class_a, int32_t class_b) {
 	constexpr int R = 1 << LOGR, C = 1 << LOGC, P = C + 1, TILE = R * P;
 	constexpr int LONG = R > C ? R : C;                  // columns of the canonical (short side = rows) layout

@@ -28,10 +28,10 @@ __global__ void __launch_bounds__(256) k(uint64_t *out, const uint32_t *chase, u
 		if (KIND == 4) { R16(asm volatile("ds_read_b32 %0, %0\n s_waitcnt lgkmcnt(0)" : "+v"(addr));) }
 		if (KIND == 5) { R16(asm volatile("v_cmp_gt_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(kk) : "vcc");) }
 		if (KIND == 6) { R16(asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a) : "v"(kk));) }
-		if (KIND == 7) { R16(asm volatile("v_readfirstlane_b32 s20, %0\n s_add_u32 s20, s20, 1\n v_mov_b32 %0, s20" : "+v"(a) : : "s20");) }
-		if (KIND == 8) { R16(asm volatile("s_add_u32 s20, s20, 1" : : : "s20");) }
-		if (KIND == 9) { R16(asm volatile("v_cmp_gt_u32 vcc, %0, %1\n s_and_saveexec_b64 s[20:21], vcc\n s_cbranch_execz 1f\n v_add_u32 %0, %0, 1\n 1:\n s_or_b64 exec, exec, s[20:21]" : "+v"(a) : "v"(0xfffffff0u) : "vcc", "s20", "s21");) }   // branch never skipped... (exec non-zero)
-		if (KIND == 10) { R16(asm volatile("v_cmp_gt_u32 vcc, %1, %0\n s_and_saveexec_b64 s[20:21], vcc\n s_cbranch_execz 1f\n v_add_u32 %0, %0, 1\n 1:\n s_or_b64 exec, exec, s[20:21]" : "+v"(a) : "v"(0u) : "vcc", "s20", "s21");) }   // always skipped (exec zero -> taken branch)
+		if (KIND == 7) { R16(asm volatile("v_readfirstlane_b32 s20, %0\n s_add_u32 s20, s20, 1\n v_mov_b32 %0, s20" : "+v"(a) : : "s20", "scc");) }
+		if (KIND == 8) { R16(asm volatile("s_add_u32 s20, s20, 1" : : : "s20", "scc");) }
+		if (KIND == 9) { R16(asm volatile("v_cmp_gt_u32 vcc, %0, %1\n s_and_saveexec_b64 s[20:21], vcc\n s_cbranch_execz 1f\n v_add_u32 %0, %0, 1\n 1:\n s_or_b64 exec, exec, s[20:21]" : "+v"(a) : "v"(0xfffffff0u) : "vcc", "s20", "s21", "scc");) }   // branch never skipped... (exec non-zero)
+		if (KIND == 10) { R16(asm volatile("v_cmp_gt_u32 vcc, %1, %0\n s_and_saveexec_b64 s[20:21], vcc\n s_cbranch_execz 1f\n v_add_u32 %0, %0, 1\n 1:\n s_or_b64 exec, exec, s[20:21]" : "+v"(a) : "v"(0u) : "vcc", "s20", "s21", "scc");) }   // always skipped (exec zero -> taken branch)
 		if (KIND == 11) { R16(gp = chase + *(volatile const uint32_t *) gp;) }   // dependent global loads (L2 / L1 hits)
 		if (KIND == 12) { R16({ const uint64_t v = ((volatile uint64_t *) lds)[addr >> 3]; addr = (uint32_t) v & 8184u; }) }
 		if (KIND == 13) { R16(asm volatile("v_bfe_u32 %0, %0, 0, 31\n v_lshlrev_b32 %0, 1, %0" : "+v"(a));) }
@@ -60,18 +60,16 @@ int main() {
 	hipMemcpy(chase, h.data(), 4096 * 4, hipMemcpyHostToDevice);
 	hipMemset(sink, 0, 4096);
 	int clk = 0; hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0);
-	printf("{\"clock_khz\": %d,\n", clk);
+	printf("{\"clock_khz\": %d,\n", clk); fflush(stdout);
 	const char *names[] = {"v_add dependent", "v_add 2 chains (per instr)", "v_add 4 chains (per instr)", "v_lshrrev_b64 dependent", "ds_read_b32 chase", "v_cmp+v_cndmask pair",
 		"v_mul_lo_u32 dependent", "readfirstlane+s_add+v_mov triple", "s_add dependent", "if-block not skipped (5 instr)", "if-block skipped, branch taken (4 instr)", "global load chase", "ds_read_b64 chase", "v_bfe+v_lshl pair", "store + global load chase"};
 	for (int w = 0; w < 3; ++w) {
 		const int threads = w == 0 ? 64 : w == 1 ? 256 : 512;   // 1 wavefront; 4 = one per SIMD; 8 = two per SIMD
 		printf(" \"%d wavefronts in the workgroup (cycles per unit on wavefront 0)\": {", threads / 64);
-		double v[15];
-		v[0] = run<0>(threads, 1, out, chase, sink); v[1] = run<1>(threads, 2, out, chase, sink); v[2] = run<2>(threads, 4, out, chase, sink); v[3] = run<3>(threads, 1, out, chase, sink);
-		v[4] = run<4>(threads, 1, out, chase, sink); v[5] = run<5>(threads, 1, out, chase, sink); v[6] = run<6>(threads, 1, out, chase, sink); v[7] = run<7>(threads, 1, out, chase, sink);
-		v[8] = run<8>(threads, 1, out, chase, sink); v[9] = run<9>(threads, 1, out, chase, sink); v[10] = run<10>(threads, 1, out, chase, sink); v[11] = run<11>(threads, 1, out, chase, sink);
-		v[12] = run<12>(threads, 1, out, chase, sink); v[13] = run<13>(threads, 1, out, chase, sink); v[14] = run<14>(threads, 1, out, chase, sink);
-		for (int i = 0; i < 15; ++i) printf("%s\"%s\": %.1f", i ? ", " : "", names[i], v[i]);
+		typedef double (*RunFn)(int, int, uint64_t *, uint32_t *, uint32_t *);
+		const RunFn fns[15] = {run<0>, run<1>, run<2>, run<3>, run<4>, run<5>, run<6>, run<7>, run<8>, run<9>, run<10>, run<11>, run<12>, run<13>, run<14>};
+		const int per[15] = {1, 2, 4, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+		for (int i = 0; i < 15; ++i) { printf("%s\"%s\": %.1f", i ? ", " : "", names[i], fns[i](threads, per[i], out, chase, sink)); fflush(stdout); }
 		printf("}%s\n", w < 2 ? "," : "");
 	}
 	printf("}\n");
