@@ -105,9 +105,12 @@ J40_DEV uint32_t lane_bit_position(const LaneBits &b) { return 8u * b.pos - (uin
 // reference would have raised first ("shrt" while renormalising, then "iovf", then "shrt" in the extra bits).
 // `alias`: the tables of all clusters ([cluster << log_alpha | bucket]); cl, m: the symbol's cluster and that cluster's
 // configuration word (LaneTables::cluster_cfg) -- looked up by the caller, who may have them at hand already (lf_rows_dev.h)
-template <class AliasPtr>
+// STRAIGHT: the caller vouches that the state has been read (state != 0) and that the cluster's tokens never ask for more than 17
+// extra bits (33 buffered - 16 of a renormalisation): the symbol is then one basic block, no branch at all -- a lone wavefront pays
+// about sixty cycles for every `if` it walks past, taken or not (lf_rows_dev.h)
+template <bool STRAIGHT = false, class AliasPtr>
 J40_DEV int32_t lane_symbol_in_cluster(LaneBits &b, uint32_t &state, AliasPtr alias, int32_t log_alpha, int32_t log_bucket, uint32_t cl, uint32_t m, uint32_t end_bit, uint32_t *err) {
-	if (state == 0) {   // first symbol of the section (j40.h:2445-2449); the window holds > 32 bits
+	if (!STRAIGHT && state == 0) {   // first symbol of the section (j40.h:2445-2449); the window holds > 32 bits
 		state = lane_bits_take(b, 16); state |= lane_bits_take(b, 16) << 16;
 		lane_bits_refill(b);
 	}
@@ -131,7 +134,7 @@ J40_DEV int32_t lane_symbol_in_cluster(LaneBits &b, uint32_t &state, AliasPtr al
 	const int32_t tok = iovf ? mt : token;
 	const int32_t msb = (int32_t) ((m >> 4) & 15), lsb = (int32_t) ((m >> 8) & 15), in_token = msb + lsb;
 	const int32_t midbits = big ? split_exp - in_token + ((tok - split) >> in_token) : 0;
-	if (midbits > b.nbits) lane_bits_refill(b);   // rare: more than ~17 extra bits (nbits <= 31 here, so the refill appends)
+	if (!STRAIGHT && midbits > b.nbits) lane_bits_refill(b);   // rare: more than ~17 extra bits (nbits <= 31 here, so the refill appends)
 	const int32_t mid = (int32_t) lane_bits_take(b, midbits);
 	const bool short2 = lane_bit_position(b) > end_bit;
 	const int32_t top = 1 << msb;

@@ -183,10 +183,18 @@ __global__ void __launch_bounds__(64) k_lf_rows(const DevLfLaneSet *sets, const 
 	const J40_GLOBAL DevLfTask &t = *task;
 	LfRowLane L;
 	lf_row_init(L, t, wins + (active ? lane : 0) * LF_ROW_PITCH);
-	if (!active) { L.chan = 7; L.setup = false; }
-	while (__builtin_amdgcn_ballot_w64(!lf_row_done(L))) {
-		lf_row_step(L, t, T);
-		if (__builtin_amdgcn_ballot_w64(L.flush_n > 0)) lf_row_flush_wave(L, lane, wins);
+	if (!active) { L.chan = 7; L.setup = false; }   // (the first general step finds it finished)
+	// every iteration each lane decodes one sample: the lanes inside a run of plain samples take the straight-line step together;
+	// then, if some lane is at a channel start, a row's end or in a channel of another form, those lanes take the general step
+	// (which says how long the lane's next run is) and finished rows leave
+	for (;;) {
+		const bool plain = L.plain_left > 0;
+		if (plain) lf_row_step_plain(L, T);
+		if (__builtin_amdgcn_ballot_w64(!plain & L.live)) {
+			if (!plain) lf_row_step(L, t, T);
+			if (__builtin_amdgcn_ballot_w64(L.flush_n > 0)) lf_row_flush_wave(L, lane, wins);
+			if (!__builtin_amdgcn_ballot_w64(L.live)) break;
+		}
 	}
 	if (active) { J40_GLOBAL DevLfResult *r = (J40_GLOBAL DevLfResult *) t.result; r->status = L.err; r->nb_varblocks = L.nb_varblocks; }
 }

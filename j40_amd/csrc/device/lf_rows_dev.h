@@ -38,10 +38,14 @@ struct LfRowTables {
 };
 
 // what a staged leaf carries instead of its context: `cfg` as in LaneTables::cluster_cfg (max_token from bit 12 up; tokens are
-// < 256, so clamping it to 12 bits keeps `token > max_token` intact)
+// < 256, so clamping it to 11 bits keeps `token > max_token` intact), the cluster in the top byte, and bit 23 when a token of the
+// cluster can ask for more than 17 extra bits (a second refill inside the symbol: not for the straight-line step)
+enum { LF_LEAF_CFG_MASK = 0x7fffff, LF_LEAF_WIDE = 1 << 23 };
 J40_DEV int32_t lf_rows_leaf_word(uint32_t cluster, uint32_t cfg) {
-	const uint32_t mt = cfg >> 12;
-	return (int32_t) ((cfg & 0xfffu) | ((mt > 0xfffu ? 0xfffu : mt) << 12) | (cluster << 24));
+	const uint32_t mt = cfg >> 12, split_exp = cfg & 15u, in_token = ((cfg >> 4) & 15u) + ((cfg >> 8) & 15u);
+	const uint32_t top_token = mt > 255u ? 255u : mt, split = 1u << split_exp;
+	const uint32_t most_extra = top_token >= split ? split_exp - in_token + ((top_token - split) >> in_token) : 0u;   // (split_exp >= in_token: j40.h:2313)
+	return (int32_t) ((cfg & 0xfffu) | ((mt > 0x7ffu ? 0x7ffu : mt) << 12) | (most_extra > 17u ? (uint32_t) LF_LEAF_WIDE : 0u) | (cluster << 24));
 }
 
 // LDS bytes of one frame's staged tables (tree nodes, then the alias tables)
@@ -66,6 +70,16 @@ struct LfRowLane {
 	bool setup;
 	int32_t flush_n;                   // > 0: the step completed a piece of a row: win[0 .. flush_n) belongs at flush_dst
 	J40_GLOBAL int16_t *flush_dst;
+	// the channel in the form lf_row_step_plain takes (lf_row_plan_channel): its subtree is one leaf, or one test over two leaves
+	// that predict alike
+	int32_t plain_left;                // how many of the lane's next samples take the straight-line step (set by the general step)
+	bool live;                         // not finished (lf_row_done), as of the lane's last general step
+	bool plain_ok, plain_wide;         // plain_wide: rows wider than the window, and nothing of the channel looks at the row above
+	int32_t k_thr; uint32_t k_word_gt, k_word_le;            // the test's threshold; the leaf words behind "greater" and "not greater"
+	int32_t c_x, c_y, c_w, c_n, c_nw, c_ne, c_ww, c_nww;     // the tested property as a signed sum of position and neighbours ...
+	bool c_abs, c_first;                                     // ... its magnitude (4, 5); W itself in the first column (8)
+	int32_t p_kind, p_w, p_n, p_nw, p_ne, p_ww; bool p_half; // the prediction: 0 a sum of neighbours (halved: the averages), 1 "select", 2 the clamped gradient
+	int32_t p_mul, p_off;                                    // the leaves' multiplier and offset
 };
 
 J40_DEV void lf_row_fail(LfRowLane &L, uint32_t e) { if (!L.err) L.err = e; L.chan = 7; L.setup = false; }
@@ -91,7 +105,69 @@ J40_DEV void lf_row_init(LfRowLane &L, const J40_GLOBAL DevLfTask &t, J40_LDS in
 	L.x = L.y = 0; L.cw = L.chh = 0; L.root = 0; L.r_prop = -1; L.r_value = L.r_a = L.r_b = 0;
 	L.pw = L.pww = 0; L.a0 = L.a1 = L.a2 = L.a3 = L.a4 = 0; L.row = nullptr; L.win = win;
 	L.flush_n = 0; L.flush_dst = nullptr;
+	L.plain_left = 0; L.live = true;
+	L.plain_ok = L.plain_wide = false; L.k_thr = 0; L.k_word_gt = L.k_word_le = 0;
+	L.c_x = L.c_y = L.c_w = L.c_n = L.c_nw = L.c_ne = L.c_ww = L.c_nww = 0; L.c_abs = L.c_first = false;
+	L.p_kind = 0; L.p_w = L.p_n = L.p_nw = L.p_ne = L.p_ww = 0; L.p_half = false; L.p_mul = 1; L.p_off = 0;
 	if (8u * t.byte_off + t.bit_off > L.end_bit) lf_row_fail(L, ERR_SHRT);
+}
+
+// Can the channel that starts at L.root go through lf_row_step_plain? Its subtree has to be a single leaf, or ONE test of a
+// property of the sample's position / neighbourhood (2..12, 14: no test that needs the row two up) over two leaves with the same
+// predictor, offset and multiplier -- what encoders write for these channels: libjxl's LF trees test the gradient property and
+// predict with the clamped gradient throughout --, the predictor one of 0..5, 7..12, the rows no wider than the window, and no
+// token of the leaves' clusters may ask for a second refill. Fills in the channel's constants; any other channel keeps the general step.
+J40_DEV void lf_row_plan_channel(LfRowLane &L, const LfRowTables &T) {
+	L.plain_ok = L.plain_wide = false;
+	DevTreeNode leaf;
+	leaf.prop = L.r_prop; leaf.value = L.r_value; leaf.a = L.r_a; leaf.b = L.r_b;
+	L.c_x = L.c_y = L.c_w = L.c_n = L.c_nw = L.c_ne = L.c_ww = L.c_nww = 0; L.c_abs = L.c_first = false; L.k_thr = 0;
+	if (L.r_prop >= 0) {
+		const DevTreeNode gt = lf_node(T.tree, L.root + L.r_a), le = lf_node(T.tree, L.root + L.r_b);
+		if (gt.prop >= 0 || le.prop != gt.prop || le.a != gt.a || le.b != gt.b) return;
+		switch (L.r_prop) {
+		case 2: L.c_y = 1; break;
+		case 3: L.c_x = 1; break;
+		case 4: L.c_n = 1; L.c_abs = true; break;
+		case 5: L.c_w = 1; L.c_abs = true; break;
+		case 6: L.c_n = 1; break;
+		case 7: L.c_w = 1; break;
+		case 8: L.c_w = 1; L.c_ww = -1; L.c_nw = -1; L.c_nww = 1; L.c_first = true; break;
+		case 9: L.c_w = 1; L.c_n = 1; L.c_nw = -1; break;
+		case 10: L.c_w = 1; L.c_nw = -1; break;
+		case 11: L.c_nw = 1; L.c_n = -1; break;
+		case 12: L.c_n = 1; L.c_ne = -1; break;
+		case 14: L.c_w = 1; L.c_ww = -1; break;
+		default: return;   // 13 looks two rows up (0 and 1 were decided when the channel started)
+		}
+		L.k_thr = L.r_value; L.k_word_gt = (uint32_t) gt.value; L.k_word_le = (uint32_t) le.value;
+		leaf = gt;
+	} else L.k_word_gt = L.k_word_le = (uint32_t) L.r_value;
+	if ((L.k_word_gt | L.k_word_le) & (uint32_t) LF_LEAF_WIDE) return;
+	L.p_kind = 0; L.p_w = L.p_n = L.p_nw = L.p_ne = L.p_ww = 0; L.p_half = false;
+	switch (-1 - leaf.prop) {   // j40.h:4080
+	case 0: break;
+	case 1: L.p_w = 1; break;
+	case 2: L.p_n = 1; break;
+	case 3: L.p_w = 1; L.p_n = 1; L.p_half = true; break;
+	case 4: L.p_kind = 1; break;
+	case 5: L.p_kind = 2; break;
+	case 7: L.p_ne = 1; break;
+	case 8: L.p_nw = 1; break;
+	case 9: L.p_ww = 1; break;
+	case 10: L.p_w = 1; L.p_nw = 1; L.p_half = true; break;
+	case 11: L.p_n = 1; L.p_nw = 1; L.p_half = true; break;
+	case 12: L.p_n = 1; L.p_ne = 1; L.p_half = true; break;
+	default: return;   // 13 (the weighted average looks two rows up and two to the right)
+	}
+	L.p_off = leaf.a; L.p_mul = leaf.b;
+	if (L.cw > LF_ROW_WIN) {
+		// rows wider than the window (the varblock-info channel) keep the row above in global memory: plain only when neither the test
+		// nor the prediction looks up -- W and WW travel in registers -- and then not for a row's first sample (W falls back to N there)
+		if (L.c_n | L.c_nw | L.c_ne | L.c_nww | L.p_n | L.p_nw | L.p_ne | L.p_kind) return;
+		L.plain_wide = true;
+	}
+	L.plain_ok = true;
 }
 
 // starts channel L.chan: as lf_lane_setup, and fetches the node the channel's walk starts from
@@ -126,6 +202,7 @@ J40_DEV void lf_row_setup(LfRowLane &L, const J40_GLOBAL DevLfTask &t, const LfR
 			else break;
 		}
 		L.root = at; L.r_prop = n.prop; L.r_value = n.value; L.r_a = n.a; L.r_b = n.b;
+		lf_row_plan_channel(L, T);
 		L.setup = false;
 		return;
 	}
@@ -133,7 +210,7 @@ J40_DEV void lf_row_setup(LfRowLane &L, const J40_GLOBAL DevLfTask &t, const LfR
 
 // one sample of the lane's stream (or the start of its next channel). The caller copies a completed piece out (L.flush_n) before
 // the lane's next step.
-J40_DEV void lf_row_step(LfRowLane &L, const J40_GLOBAL DevLfTask &t, const LfRowTables &T) {
+J40_DEV void lf_row_step_general(LfRowLane &L, const J40_GLOBAL DevLfTask &t, const LfRowTables &T) {
 	if (lf_row_done(L)) return;
 	if (L.setup) { lf_row_setup(L, t, T); if (L.chan == 7 || L.err) return; }
 	lane_bits_refill(L.b);
@@ -167,7 +244,7 @@ J40_DEV void lf_row_step(LfRowLane &L, const J40_GLOBAL DevLfTask &t, const LfRo
 	}
 	uint32_t e2;
 	const uint32_t word = (uint32_t) n.value;
-	const int32_t u = lane_symbol_in_cluster(L.b, L.state, T.alias, T.log_alpha, T.log_bucket, word >> 24, word & 0xffffffu, L.end_bit, &e2);
+	const int32_t u = lane_symbol_in_cluster(L.b, L.state, T.alias, T.log_alpha, T.log_bucket, word >> 24, word & (uint32_t) LF_LEAF_CFG_MASK, L.end_bit, &e2);
 	int32_t v = unpack_signed_dev(u) * n.b + n.a;
 	switch (-1 - n.prop) {   // j40.h:4080
 	case 0: break;
@@ -207,6 +284,85 @@ J40_DEV void lf_row_step(LfRowLane &L, const J40_GLOBAL DevLfTask &t, const LfRo
 		return;
 	}
 	++L.chan; L.setup = true;
+}
+
+// ---- the straight-line step ----
+// Measured on an MI355X (tools/ubench/lone_wave.hip), a wavefront alone on its SIMD: a dependent vector instruction every 8.6
+// cycles (5.3 with four independent chains), an LDS read 56-67, an L1-hit global load 200 -- and SIXTY cycles for every `if` the
+// wavefront walks past (compare, s_and_saveexec, s_cbranch_execz, s_or), whether its body runs or not. The general step above is
+// some fifty of those per sample (the switches over properties and predictors, refills, edges, errors): 3 200 cycles per sample
+// whatever its memory accesses cost, which is why moving them to LDS alone changed nothing (434 ms per launch against 410).
+// lf_row_step_plain is the same sample as ONE basic block: the property is a signed sum with per-channel coefficients, the tree
+// walk a compare and a select, the refill, the renormalisation, the extra bits, the prediction (a sum, "select" and the clamped
+// gradient all computed, one chosen) and the error bookkeeping are selects. A lane takes it when its channel has the form
+// lf_row_plan_channel accepts, its first symbol has been read and the sample is not the last of its row; everything else -- channel
+// starts, row ends, other trees -- is the general step, which the kernel runs for the lanes that need it after the others' plain
+// step. The general step leaves the number of plain samples that follow (plain_left), so that the choice costs one compare.
+// how many samples from here on are plain ones: to the last but one of the row (the last one ends the row: the general step), in
+// wide rows from the second sample to the one before the next piece of the window is complete
+J40_DEV int32_t lf_row_plain_run(const LfRowLane &L) {
+	const bool can = L.plain_ok & !L.setup & (L.chan < 7) & (L.state != 0) & (!L.plain_wide | (L.x > 0));
+	const int32_t last = L.plain_wide ? mod_min(L.cw - 1, L.x | (LF_ROW_WIN - 1)) : L.cw - 1;   // the first sample that is not plain
+	return can ? mod_max(last - L.x, 0) : 0;
+}
+// the step the kernel gives the lanes that are not in a run of plain samples; leaves the length of the run that follows
+J40_DEV void lf_row_step(LfRowLane &L, const J40_GLOBAL DevLfTask &t, const LfRowTables &T) {
+	lf_row_step_general(L, t, T);
+	L.plain_left = lf_row_plain_run(L);
+	L.live = !lf_row_done(L);
+}
+
+// a * b + c for a coefficient -1 .. 1 and a sample or position within 17 bits: v_mad_i32_i24, one full-rate instruction (the
+// compiler turns __mul24 into a sign extension and a quarter-rate 32-bit multiply here)
+#ifdef __HIPCC__
+J40_DEV int32_t lf_mad24(int32_t a, int32_t b, int32_t c) { int32_t d; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+#else
+J40_DEV int32_t lf_mad24(int32_t a, int32_t b, int32_t c) { return a * b + c; }
+#endif
+// unpack_signed_dev for the token values a symbol without an error yields (0 <= u < 2^30), as two instructions instead of a branch
+J40_DEV int32_t lf_unzigzag(int32_t u) { return (int32_t) ((uint32_t) u >> 1) ^ -(u & 1); }
+
+J40_DEV void lf_row_step_plain(LfRowLane &L, const LfRowTables &T) {
+	LaneBits &b = L.b;
+	{   // lane_bits_refill as selects; the word after next is asked for every time (the same word again when nothing was appended)
+		const bool need = b.nbits <= 32;
+		b.bits |= (uint64_t) (need ? b.ahead : 0u) << (need ? b.nbits : 0);
+		b.nbits += need ? 32 : 0; b.pos += need ? 4u : 0u;
+		b.ahead = lane_load32(b.base, b.pos);
+	}
+	const int32_t x = L.x, y = L.y, cw = L.cw;
+	const int32_t slot = x & (LF_ROW_WIN - 1);   // (= x unless the row is wider than the window)
+	const int32_t ahead3 = L.win[slot + 3];   // the row above at x + 3, for the next sample's registers (asked for early; slots past the row's end are never looked at)
+	const bool up = y > 0, left = x > 0;
+	const int32_t pw = left ? L.pw : up ? L.a2 : 0;
+	const int32_t pn = up ? L.a2 : pw;
+	const int32_t pnw = left && up ? L.a1 : pw;
+	const int32_t pne = x + 1 < cw && up ? L.a3 : pn;
+	const int32_t pww = x > 1 ? L.pww : pw;
+	const int32_t pnww = x > 1 && up ? L.a0 : pww;
+	// the property and the walk: one test, or none (both words the leaf's)
+	int32_t val = lf_mad24(L.c_x, x, lf_mad24(L.c_y, y, lf_mad24(L.c_w, pw, lf_mad24(L.c_n, pn, 0)))) + lf_mad24(L.c_nw, pnw, lf_mad24(L.c_ne, pne, lf_mad24(L.c_ww, pww, lf_mad24(L.c_nww, pnww, 0))));   // (two chains of four)
+	val = L.c_abs ? mod_abs(val) : val;
+	val = L.c_first && !left ? pw : val;
+	const uint32_t word = val > L.k_thr ? L.k_word_gt : L.k_word_le;
+	uint32_t e2;
+	const int32_t u = lane_symbol_in_cluster<true>(b, L.state, T.alias, T.log_alpha, T.log_bucket, word >> 24, word & (uint32_t) LF_LEAF_CFG_MASK, L.end_bit, &e2);
+	// the prediction
+	int32_t lin = lf_mad24(L.p_w, pw, lf_mad24(L.p_n, pn, 0)) + lf_mad24(L.p_nw, pnw, lf_mad24(L.p_ne, pne, lf_mad24(L.p_ww, pww, 0)));
+	lin = L.p_half ? (lin + (int32_t) ((uint32_t) lin >> 31)) >> 1 : lin;   // (a + b) / 2, towards zero
+	const int32_t sel = mod_abs(pn - pnw) < mod_abs(pw - pnw) ? pw : pn;
+	const int32_t grad = mod_gradient(pw, pn, pnw);
+	const int32_t pred = L.p_kind == 1 ? sel : L.p_kind == 2 ? grad : lin;
+	const int32_t v = lf_unzigzag(u) * L.p_mul + L.p_off + pred;
+	const uint32_t code = e2 ? e2 : v < -32768 || v > 32767 ? (uint32_t) ERR_POVF : 0u;
+	// an error ends the lane (what it leaves behind is never looked at); otherwise the sample is stored and the registers slide
+	L.err = L.err ? L.err : code;
+	L.chan = code ? 7 : L.chan;
+	L.plain_left = code ? 0 : L.plain_left - 1;   // (after an error the general step finds the lane finished)
+	L.win[slot] = (int16_t) v;
+	L.pww = L.pw; L.pw = v;
+	L.a0 = L.a1; L.a1 = L.a2; L.a2 = L.a3; L.a3 = L.a4; L.a4 = ahead3;
+	L.x = x + 1;
 }
 
 // the copy a step asked for, by the lane itself (tests/hostsim; the kernel's lanes do it together: lf_row_flush_wave)

@@ -88,7 +88,18 @@ static bool build_lf_lanes(const Frame &fr, FrontPlan *fp) {
 	fp->lf_ctx_map.assign(spec.cluster_map.begin(), spec.cluster_map.begin() + spec.num_dist);
 	fp->lf_cfg.clear(); fp->lf_alias.clear();
 	for (const Cluster &c : spec.clusters) {
-		fp->lf_cfg.push_back(c.cfg.packed() | ((uint32_t) std::min(c.cfg.max_token, 0xfffff) << 12));   // (tokens are < 256: clamping max_token keeps `token > max_token` intact)
+		// The largest token the cluster's tables can produce: bucket i yields i below its cutoff and its alias symbol from there on
+		// (AnsEntry, entropy.hpp). max_token is clamped to it -- `token > max_token` (j40.h:2316) is unchanged for every token that can
+		// come out -- so that the lane decoder can tell from the configuration word how many extra bits a symbol may ask for at most
+		// (lf_rows_dev.h: lf_rows_leaf_word).
+		const uint32_t bucket = 4096u >> spec.log_alpha_size;
+		int32_t top = 0;
+		for (size_t i = 0; i < c.alias.size(); ++i) {
+			const uint32_t lo = (uint32_t) c.alias[i], cutoff = lo & 0xff;
+			if (cutoff > 0) top = std::max(top, (int32_t) i);
+			if (cutoff < bucket) top = std::max(top, (int32_t) ((lo >> 20) & 0xff));
+		}
+		fp->lf_cfg.push_back(c.cfg.packed() | ((uint32_t) std::min(c.cfg.max_token, top) << 12));
 		fp->lf_alias.insert(fp->lf_alias.end(), c.alias.begin(), c.alias.end());
 	}
 	fp->lf_log_alpha = spec.log_alpha_size;

@@ -940,6 +940,15 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_lanes_check
 // LF_ROW_PITCH, completed pieces copied out between the steps. `win` caps the row length served from the window for the test's
 // purposes only through the stream's own sizes (LF_ROW_WIN is a compile-time constant); frames wider than 256 cells per LfGroup
 // do not exist, the varblock-info channel exercises the wide path.
+static int64_t plain_steps = 0, general_steps = 0;
+static int32_t general_only = 0;
+// (how many samples of the last checks went through the straight-line step / the general one; mode 1: the general step only)
+extern "C" __attribute__((visibility("default"))) void hostsim_lf_rows_counts(int64_t *plain, int64_t *general, int32_t reset, int32_t mode) {
+	if (plain) *plain = plain_steps;
+	if (general) *general = general_steps;
+	if (reset) plain_steps = general_steps = 0;
+	general_only = mode;
+}
 extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_check(const uint8_t *buf, size_t size, int32_t lanes, int32_t *sections, int32_t *failed) {
 	const uint8_t *cs; size_t cs_size; std::vector<uint8_t> storage;
 	Frame fr;
@@ -989,7 +998,10 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_check(
 		}
 		for (bool any = true; any; ) {
 			any = false;
-			for (size_t k = 0; k < n; ++k) if (!lf_row_done(L[k])) { lf_row_step(L[k], out[k].t, T); any = true; }
+			for (size_t k = 0; k < n; ++k) if (!lf_row_done(L[k])) {   // (the kernel's dispatch: the straight-line step where the lane's sample allows it)
+				if (L[k].plain_left > 0 && !(general_only & 1)) { lf_row_step_plain(L[k], T); ++plain_steps; } else { lf_row_step(L[k], out[k].t, T); ++general_steps; }
+				any = true;
+			}
 			for (size_t k = 0; k < n; ++k) if (L[k].flush_n > 0) lf_row_flush_serial(L[k]);
 		}
 		for (size_t k = 0; k < n; ++k) {

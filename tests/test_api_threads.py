@@ -95,3 +95,49 @@ def test_64_threads_over_8k_streams_through_the_public_api(built, ref, tmp_path)
     _check_against_reference(ref, str(tmp_path), paths, [""] * 4)
     print("64 threads x 3 8K images through j40_next_frame: %.0f Mpx/s, latency median %.0f ms" % (r["mpixels_per_s"], r["latency_ms"]["median"]))
     assert r["mpixels_per_s"] > 2000, r   # (a floor far below what is measured: the 0.39 Gpx/s of one call at a time would fail it)
+
+
+@pytest.mark.gpu
+def test_pinned_plane_pool_is_bounded_evicts_the_oldest_and_expires(built):
+    """the pool of pinned image planes behind j40_frame_pixels_u8x4 (runtime.hip: j40hip_pinned_acquire / _release; a drop-in caller
+    never calls j40hip_shutdown): what sits idle never exceeds the bound, a new plane size displaces the planes idle longest instead
+    of being pinned and unpinned per image, a plane of a size in the pool is reused, idle planes are unpinned after the idle time"""
+    code = r'''
+import ctypes as C, time, sys
+sys.path.insert(0, %r)
+import j40_amd
+L = j40_amd.lib()
+L.j40hip_pinned_acquire.restype = C.c_void_p; L.j40hip_pinned_acquire.argtypes = [C.c_size_t]
+L.j40hip_pinned_release.argtypes = [C.c_void_p, C.c_size_t]
+L.j40hip_pinned_pool_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
+def stats():
+    a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    L.j40hip_pinned_pool_stats(C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+MB = 1 << 20
+assert stats() == (0, 0, 1 << 30)                       # J40HIP_PINNED_POOL_GB=1
+big = [L.j40hip_pinned_acquire(300 * MB) for _ in range(4)]
+assert all(big)
+for p in big: L.j40hip_pinned_release(p, 300 * MB)
+idle, planes, limit = stats()
+assert idle <= limit and planes == 3, (idle, planes)    # the fourth did not fit: the OLDEST made room for it
+again = L.j40hip_pinned_acquire(300 * MB)
+assert again in big[1:] and stats()[1] == 2             # reused, not pinned anew
+L.j40hip_pinned_release(again, 300 * MB)
+small = [L.j40hip_pinned_acquire(200 * MB) for _ in range(3)]   # another image size: the old size's planes leave as these come back
+for p in small: L.j40hip_pinned_release(p, 200 * MB)
+idle, planes, limit = stats()
+assert idle <= limit and idle >= 600 * MB, (idle, planes)
+q = L.j40hip_pinned_acquire(200 * MB)
+assert q in small
+L.j40hip_pinned_release(q, 200 * MB)
+time.sleep(1.3)                                          # J40HIP_PINNED_IDLE_S=1
+r = L.j40hip_pinned_acquire(4096); L.j40hip_pinned_release(r, 4096)
+idle, planes, limit = stats()
+assert planes == 1 and idle == 4096, (idle, planes)     # everything older than a second was unpinned at this call
+print("ok")
+''' % ROOT
+    env = dict(os.environ, J40HIP_PINNED_POOL_GB="1", J40HIP_PINNED_IDLE_S="1")
+    import sys
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert run.returncode == 0 and run.stdout.strip().endswith("ok"), run.stderr[-2000:]

@@ -24,6 +24,10 @@ CASES = [("vardct", 520, 264, 100 + i, opts) for i, (_, opts) in enumerate(VARDC
     ("vardct", 2600, 2100, 51, dict(lftree=1)),                # every LfGroup channel under a subtree of sample properties; predictors reaching NE, NEE, NN, NWW
     ("vardct", 520, 264, 52, dict(lftree=1, cfl=1)),
     ("vardct", 2049, 300, 53, dict(lftree=1, forward=1)),      # (with a 1-cell-wide LfGroup)
+    ("vardct", 2600, 2100, 61, dict(lftree=2)),                # every LfGroup channel one test over two leaves that predict alike: the lane decoder's straight-line step
+    ("vardct", 2600, 2100, 62, dict(lftree=3)),                # ... with the other properties and predictors it takes
+    ("vardct", 520, 264, 63, dict(lftree=2, cfl=1)),
+    ("vardct", 2049, 300, 64, dict(lftree=3, forward=1)),
 ]
 
 
@@ -135,12 +139,22 @@ def test_lf_row_window_decoder_equals_the_host_decoder(lanes, mode, w, h, seed, 
     lockstep as a wavefront's lanes are: same planes, varblock counts and status as frame.cpp's read_lf_group_raw (pinned against the
     reference's j40__lf_group by tests/test_host.py). The varblock-info channel (2 rows of hundreds to thousands of samples) is the
     case of rows wider than the window."""
-    for nl in (1, 64):
+    lanes.hostsim_lf_rows_counts.argtypes = [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32, C.c_int32]
+    for nl, general_only in ((1, 0), (64, 0), (3, 1)):
+        lanes.hostsim_lf_rows_counts(None, None, 1, general_only)
         rc, n, bad = rows_check(lanes, synth(mode, w, h, seed, **opts), nl)
+        plain, general = C.c_int64(), C.c_int64()
+        lanes.hostsim_lf_rows_counts(C.byref(plain), C.byref(general), 1, 0)
         if opts.get("alpha"):
             assert rc == -1
+            continue
+        assert rc == 0 and n >= 1 and bad == 0, (rc, n, bad, nl)
+        # the straight-line step (lf_row_step_plain) takes nearly every sample of the trees it accepts -- the generator's default LF
+        # tree and lftree=2/3 --, none of the others (lftree=1); with it switched off the general step alone gives the same planes
+        if general_only or opts.get("lftree") == 1:
+            assert plain.value == 0 and general.value > 0
         else:
-            assert rc == 0 and n >= 1 and bad == 0, (rc, n, bad, nl)
+            assert plain.value > 20 * general.value, (plain.value, general.value)
 
 
 def test_lf_row_window_decoder_fails_like_the_host_decoder(lanes):

@@ -35,6 +35,8 @@ CASES = [
     ("vardct", 776, 520, 3, dict(maxlog=8, bctx=1, presets=2, orders=1)),
     ("vardct", 7680, 4320, 3, dict(forward=1)),                # the bench stream
     ("vardct", 2600, 2100, 51, dict(lftree=1)),                # LfGroup channels under subtrees of sample properties, predictors reaching NE, NEE, NN, NWW
+    ("vardct", 2600, 2100, 61, dict(lftree=2)),                # one test over two like leaves per channel: k_lf_rows' straight-line step on other properties / predictors than the default tree's
+    ("vardct", 2049, 300, 64, dict(lftree=3, forward=1)),
 ]
 
 

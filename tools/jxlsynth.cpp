@@ -443,7 +443,30 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 
 	// ---- global MA tree: splits on stream index (property 1) and channel (property 0) ----
 	MATree tree;
-	if (opt.geti("lftree", 0)) {
+	if (opt.geti("lftree", 0) == 2) {
+		// lftree=2: every LfGroup channel under ONE test of a sample property over two leaves that predict alike (what libjxl's fixed LF
+		// trees look like, with other properties and predictors), offsets and multipliers on some
+		auto pair = [&](int prop, int thr, int pred, int off = 0, int mshift = 0, int mbits = 0) { int a = tree.leaf(pred, off, mshift, mbits), b = tree.leaf(pred, off, mshift, mbits); return tree.branch(prop, thr, a, b); };
+		int lf_y = pair(9, 100, 5), lf_x = pair(8, 0, 4), lf_b = pair(5, 2, 3, 1);
+		int lf_xb = tree.branch(0, 1, lf_b, lf_x);
+		int lf = tree.branch(0, 0, lf_xb, lf_y);
+		int cfl = pair(2, 3, 1), binfo = pair(3, 300, 9, 0, 0, 0), sharp = pair(12, 0, 12, -1);
+		int meta_hi = tree.branch(0, 2, sharp, binfo);
+		int meta = tree.branch(0, 1, meta_hi, cfl);
+		int root = tree.branch(1, 2 * num_lf_groups, meta, lf);
+		tree.finalise(root);
+	} else if (opt.geti("lftree", 0) == 3) {
+		// lftree=3: as 2 with the other testable properties and predictors
+		auto pair = [&](int prop, int thr, int pred, int off = 0, int mshift = 0, int mbits = 0) { int a = tree.leaf(pred, off, mshift, mbits), b = tree.leaf(pred, off, mshift, mbits); return tree.branch(prop, thr, a, b); };
+		int lf_y = pair(10, 0, 10), lf_x = pair(11, 1, 11), lf_b = pair(14, -1, 8);
+		int lf_xb = tree.branch(0, 1, lf_b, lf_x);
+		int lf = tree.branch(0, 0, lf_xb, lf_y);
+		int cfl = pair(7, 0, 2), binfo = pair(14, 2, 1, 0, 0, 0), sharp = pair(4, 3, 7, 0, 1, 1);
+		int meta_hi = tree.branch(0, 2, sharp, binfo);
+		int meta = tree.branch(0, 1, meta_hi, cfl);
+		int root = tree.branch(1, 2 * num_lf_groups, meta, lf);
+		tree.finalise(root);
+	} else if (opt.geti("lftree", 0)) {
 		// lftree=1: below the stream / channel splits every LfGroup channel gets a subtree of its own over the sample properties, with
 		// predictors that look at NE, NEE, NN, NWW -- also the varblock-info channel, whose second row is thousands of samples wide
 		int y0 = tree.leaf(13), y1 = tree.leaf(5), y2 = tree.leaf(7), y3 = tree.leaf(12, 1);
