@@ -25,6 +25,10 @@ build/obj/%.o: $(SRC)/device/%.hip $(wildcard $(SRC)/device/*.h) $(wildcard $(SR
 	@mkdir -p build/obj
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+# lf_decode.hip: k_lf_rows steps two LfGroup sections per lane side by side; the two sections' instructions are independent and the
+# scheduler is asked to interleave them rather than to keep register pressure low (a wavefront alone on its SIMD, 512 registers its own)
+build/obj/lf_decode.o: EXTRA_HIPFLAGS += -mllvm -amdgpu-sched-strategy=max-ilp
+
 build/libj40hip.so: $(HOST_OBJS) $(DEV_OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^ -lpthread
 

@@ -316,7 +316,11 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 			d.sharp = (int16_t *) (pb + o_sharp) + gg.cell_base;
 			d.result = (DevLfResult *) ((DevLfSlot *) (pb + o_slots) + g);   // (DevLfSlot begins with the two words of DevLfResult)
 		}
-		put(o_tasks, af->lf_tasks.data(), ngg * sizeof(DevLfTask));
+		{   // the device sees the sections by decreasing size: k_lf_rows gives a lane two neighbours of the list, which should end together
+			std::vector<DevLfTask> by_size = af->lf_tasks;
+			std::stable_sort(by_size.begin(), by_size.end(), [](const DevLfTask &a, const DevLfTask &b) { return a.size > b.size; });
+			put(o_tasks, by_size.data(), ngg * sizeof(DevLfTask));
+		}
 		DevLfLaneSet &ls = af->lf_set;
 		ls.tasks = (const DevLfTask *) (pb + o_tasks); ls.ntasks = (int32_t) ngg;
 		ls.tree = (const DevTreeNode *) (pb + o_tree); ls.num_nodes = (int32_t) fp.lf_tree.size();

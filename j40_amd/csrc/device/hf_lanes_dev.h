@@ -242,7 +242,13 @@ J40_DEV void decode_hf_sections_lane(const LaneFrame &f, const LaneTables &t, co
 #define J40_LANE_NZ_PERIOD 8
 #endif
 #if J40_LANE_EV_FLUSH
-		if (SCAN && (turn % J40_LANE_EV_FLUSH) == 0 && ev_at - ev_flushed >= (uint32_t) J40_LANE_EV_FLUSH) {
+		// (the turn is the same in every lane: a scalar branch that skips the per-lane test seven turns in eight -- kept apart from it by
+		// the empty statement, or the compiler folds both into one vector condition evaluated every turn)
+		if (SCAN && (turn % J40_LANE_EV_FLUSH) == 0) {
+#ifdef __HIPCC__
+			asm volatile("");
+#endif
+			if (ev_at - ev_flushed >= (uint32_t) J40_LANE_EV_FLUSH) {
 			const J40_LDS uint32_t *r = ring + (int32_t) (ev_flushed % (uint32_t) HF_LANE_RING_SLOTS) * ring_stride;   // (a run of slots: regions and pieces are aligned)
 			J40_GLOBAL uint32_t *dst = (J40_GLOBAL uint32_t *) G.events + ev_flushed;
 #pragma unroll
@@ -252,6 +258,7 @@ J40_DEV void decode_hf_sections_lane(const LaneFrame &f, const LaneTables &t, co
 				*(J40_GLOBAL LaneEventQuad *) (dst + k4) = q4;
 			}
 			ev_flushed += (uint32_t) J40_LANE_EV_FLUSH;
+			}
 		}
 #endif
 		if (!in_coeffs && (turn % J40_LANE_NZ_PERIOD) != 0) continue;

@@ -120,34 +120,42 @@ __global__ void __launch_bounds__(64) k_lf_lanes(const DevLfLaneSet *sets, const
 }
 
 // the pieces of rows the lanes' last steps completed, copied out by the whole wavefront: lane i takes samples i, i + 64, ... of
-// each piece, so a piece leaves as runs of 128 consecutive bytes (`wins`: the window of lane 0)
-J40_DEV void lf_row_flush_wave(LfRowLane &L, int32_t lane, const J40_LDS int16_t *wins) {
+// each piece, so a piece leaves as runs of 128 consecutive bytes
+J40_DEV void lf_row_flush_wave(LfRowLane &L, int32_t lane) {
 	uint64_t need = __builtin_amdgcn_ballot_w64(L.flush_n > 0);
 	const uint64_t dst_bits = (uint64_t) (uintptr_t) L.flush_dst;
+	const uint32_t win_bits = (uint32_t) (uintptr_t) L.win;
 	while (need) {
 		const int32_t j = (int32_t) __builtin_ctzll(need);
 		need &= need - 1;
 		const int32_t n = __builtin_amdgcn_readlane(L.flush_n, j);
 		const uint64_t d = (uint64_t) (uint32_t) __builtin_amdgcn_readlane((int32_t) (uint32_t) dst_bits, j) | ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int32_t) (uint32_t) (dst_bits >> 32), j) << 32);
 		J40_GLOBAL int16_t *dst = (J40_GLOBAL int16_t *) (uintptr_t) d;
-		const J40_LDS int16_t *src = wins + j * LF_ROW_PITCH;
+		const J40_LDS int16_t *src = (const J40_LDS int16_t *) (uintptr_t) (uint32_t) __builtin_amdgcn_readlane((int32_t) win_bits, j);
 		for (int32_t i = lane; i < n; i += 64) dst[i] = src[i];
 	}
 	L.flush_n = 0;
 }
 
-// One LfGroup section per LANE, tree + alias tables + row windows in LDS (lf_rows_dev.h). A wavefront takes the sections of the
-// frames pack_lf_row_waves gave it; LDS: per part the staged tree and the alias tables, then one window per section.
+// One LfGroup section per LANE -- or, PAIRS, two: the lane steps both side by side, which nearly doubles what a wavefront alone on
+// its SIMD gets out of its issue slots (lf_rows_dev.h: lf_row_step_plain2) --, tree + alias tables + row windows in LDS. A wavefront
+// takes the sections of the frames pack_lf_row_waves gave it; LDS: per part the staged tree and the alias tables, then one window
+// per section. A part's sections go to its lanes two at a time in list order (the host lists them by decreasing size).
+template <bool PAIRS>
 __global__ void __launch_bounds__(64) k_lf_rows(const DevLfLaneSet *sets, const DevLfWave *waves) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lfr_lds[];
 	const J40_GLOBAL DevLfWave &wv = ((const J40_GLOBAL DevLfWave *) waves)[blockIdx.x];
 	const int32_t lane = threadIdx.x, num_parts = wv.num_parts;
 	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
 	J40_LDS uint8_t *lds = (J40_LDS uint8_t *) lfr_lds;
-	const J40_GLOBAL DevLfTask *task = nullptr;
-	LfRowTables T;
+	// the wavefront's sections, part after part, are numbered 0, 1, ...: lane l takes section l, or, PAIRS, sections 2l and 2l + 1 --
+	// of one frame or of two (each with its frame's tables)
+	const J40_GLOBAL DevLfTask *task = nullptr, *task_b = nullptr;
+	LfRowTables T, TB;
 	T.tree = nullptr; T.alias = nullptr; T.log_alpha = 5; T.log_bucket = 7; T.uses = 0;
-	uint32_t at = 0; int32_t lane0 = 0;
+	TB = T;
+	const int32_t my_section = PAIRS ? 2 * lane : lane;
+	uint32_t at = 0; int32_t section0 = 0;
 	for (int32_t p = 0; p < num_parts; ++p) {
 		const J40_GLOBAL DevLfLaneSet &set = ((const J40_GLOBAL DevLfLaneSet *) sets)[wv.part[p].set];
 		const int32_t first = wv.part[p].first_task, count = wv.part[p].count;
@@ -166,35 +174,62 @@ __global__ void __launch_bounds__(64) k_lf_rows(const DevLfLaneSet *sets, const 
 			const J40_GLOBAL uint64_t *asrc = (const J40_GLOBAL uint64_t *) set.alias;
 			for (int32_t i = lane; i < (num_clusters << log_alpha); i += 64) l_alias[i] = asrc[i];
 		}
-		if (lane >= lane0 && lane < lane0 + count) {
-			task = (const J40_GLOBAL DevLfTask *) set.tasks + (first + lane - lane0);
+		if (my_section >= section0 && my_section < section0 + count) {
+			task = (const J40_GLOBAL DevLfTask *) set.tasks + (first + my_section - section0);
 			T.tree = (const J40_LDS DevTreeNode *) l_tree; T.alias = l_alias; T.log_alpha = log_alpha; T.log_bucket = 12 - log_alpha; T.uses = set.uses;
 		}
-		lane0 += count;
+		if (PAIRS && my_section + 1 >= section0 && my_section + 1 < section0 + count) {
+			task_b = (const J40_GLOBAL DevLfTask *) set.tasks + (first + my_section + 1 - section0);
+			TB.tree = (const J40_LDS DevTreeNode *) l_tree; TB.alias = l_alias; TB.log_alpha = log_alpha; TB.log_bucket = 12 - log_alpha; TB.uses = set.uses;
+		}
+		section0 += count;
 		at += lf_rows_table_bytes(num_nodes, num_clusters, log_alpha);
 	}
 	J40_LDS int16_t *wins = (J40_LDS int16_t *) (lds + at);
 	__syncthreads();
-	const bool active = task != nullptr;
+	const bool active = task != nullptr, active_b = task_b != nullptr;
 	if (!active) {   // (something valid to point at)
 		const J40_GLOBAL DevLfLaneSet &set = ((const J40_GLOBAL DevLfLaneSet *) sets)[wv.part[0].set];
 		task = (const J40_GLOBAL DevLfTask *) set.tasks + wv.part[0].first_task;
 	}
-	const J40_GLOBAL DevLfTask &t = *task;
+	if (!active_b) { task_b = task; TB = T; }
+	const J40_GLOBAL DevLfTask &t = *task, &tb = *task_b;
 	LfRowLane L;
-	lf_row_init(L, t, wins + (active ? lane : 0) * LF_ROW_PITCH);
+	lf_row_init(L, t, wins + (active ? my_section : 0) * LF_ROW_PITCH);   // (a lane without a section never writes its window)
 	if (!active) { L.chan = 7; L.setup = false; }   // (the first general step finds it finished)
-	// every iteration each lane decodes one sample: the lanes inside a run of plain samples take the straight-line step together;
-	// then, if some lane is at a channel start, a row's end or in a channel of another form, those lanes take the general step
-	// (which says how long the lane's next run is) and finished rows leave
-	for (;;) {
-		const bool plain = L.plain_left > 0;
-		if (plain) lf_row_step_plain(L, T);
-		if (__builtin_amdgcn_ballot_w64(!plain & L.live)) {
-			if (!plain) lf_row_step(L, t, T);
-			if (__builtin_amdgcn_ballot_w64(L.flush_n > 0)) lf_row_flush_wave(L, lane, wins);
-			if (!__builtin_amdgcn_ballot_w64(L.live)) break;
+	if (!PAIRS) {
+		// every iteration each lane decodes one sample: the lanes inside a run of plain samples take the straight-line step together;
+		// then, if some lane is at a channel start, a row's end or in a channel of another form, those lanes take the general step
+		// (which says how long the lane's next run is) and finished rows leave
+		for (;;) {
+			const bool plain = L.plain_left > 0;
+			if (plain) lf_row_step_plain(L, T);
+			if (__builtin_amdgcn_ballot_w64(!plain & L.live)) {
+				if (!plain) lf_row_step(L, t, T);
+				if (__builtin_amdgcn_ballot_w64(L.flush_n > 0)) lf_row_flush_wave(L, lane);
+				if (!__builtin_amdgcn_ballot_w64(L.live)) break;
+			}
 		}
+	} else {
+		LfRowLane M;   // the lane's second section
+		lf_row_init(M, tb, wins + (active_b ? my_section + 1 : 0) * LF_ROW_PITCH);
+		if (!active_b) { M.chan = 7; M.setup = false; }
+		for (;;) {
+			const bool pl = L.plain_left > 0, pm = M.plain_left > 0;
+			if (pl & pm) lf_row_step_plain2(L, M, T, TB);       // both sections' samples side by side: the common case
+			else {
+				if (pl) lf_row_step_plain(L, T);
+				if (pm) lf_row_step_plain(M, TB);
+			}
+			if (__builtin_amdgcn_ballot_w64((!pl & L.live) | (!pm & M.live))) {
+				if (!pl) lf_row_step(L, t, T);
+				if (!pm) lf_row_step(M, tb, TB);
+				if (__builtin_amdgcn_ballot_w64(L.flush_n > 0)) lf_row_flush_wave(L, lane);
+				if (__builtin_amdgcn_ballot_w64(M.flush_n > 0)) lf_row_flush_wave(M, lane);
+				if (!__builtin_amdgcn_ballot_w64(L.live | M.live)) break;
+			}
+		}
+		if (active_b) { J40_GLOBAL DevLfResult *r = (J40_GLOBAL DevLfResult *) tb.result; r->status = M.err; r->nb_varblocks = M.nb_varblocks; }
 	}
 	if (active) { J40_GLOBAL DevLfResult *r = (J40_GLOBAL DevLfResult *) t.result; r->status = L.err; r->nb_varblocks = L.nb_varblocks; }
 }
@@ -235,20 +270,22 @@ void launch_lf_lanes(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t n
 	else hipLaunchKernelGGL(k_lf_lanes<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
 }
 
-// J40HIP_LF_KERNEL=lanes: the older decoder (tables' alias entries and rows in global memory) for every launch; default: k_lf_rows
-// for every launch whose frames' tables fit its LDS budget
-bool lf_rows_enabled() {
-	static const bool v = [] { const char *e = getenv("J40HIP_LF_KERNEL"); return !(e && strcmp(e, "lanes") == 0); }();
+// J40HIP_LF_KERNEL: "lanes" = the older decoder (alias entries and rows in global memory) for every launch; "rows1" = k_lf_rows with
+// one section per lane; default: k_lf_rows with two sections per lane, for every launch whose frames' tables fit its LDS budget
+static int lf_rows_mode() {
+	static const int v = [] { const char *e = getenv("J40HIP_LF_KERNEL"); return e && strcmp(e, "lanes") == 0 ? 0 : e && strcmp(e, "rows1") == 0 ? 1 : 2; }();
 	return v;
 }
+bool lf_rows_enabled() { return lf_rows_mode() != 0; }
 
-// packs the sections of `sets` into wavefronts of k_lf_rows; returns the LDS bytes a wavefront needs at most, 0 when some frame's
-// tables do not fit (the launch then goes to k_lf_lanes). J40HIP_LF_ROWS_LDS_KB: what a wavefront's tables and windows may take
-// together (default 48: two 8K frames of seven clusters x 256 buckets -- 2 x (14.5 KB + 12 windows) = 41 KB -- so that such a
-// workgroup still fits beside the coefficient decoder's 99 KB on a compute unit)
+// packs the sections of `sets` into wavefronts of k_lf_rows (64 lanes, one or two sections each); returns the LDS bytes a wavefront
+// needs at most, 0 when some frame's tables do not fit (the launch then goes to k_lf_lanes). J40HIP_LF_ROWS_LDS_KB: what a
+// wavefront's tables and windows may take together (default 48: two 8K frames of seven clusters x 256 buckets -- 2 x (14.5 KB + 12
+// windows) = 41 KB -- so that such a workgroup still fits beside the coefficient decoder's on a compute unit)
 uint32_t pack_lf_row_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std::vector<DevLfWave> *waves) {
 	static const uint32_t budget = [] { const char *e = getenv("J40HIP_LF_ROWS_LDS_KB"); return (e && atoi(e) > 0 ? (uint32_t) atoi(e) : 48u) * 1024u; }();
 	const uint32_t win_bytes = 2u * LF_ROW_PITCH;
+	const int32_t per = lf_rows_mode() == 2 ? 2 : 1;
 	uint32_t most = 0, used = 0; int32_t lanes = 0;
 	DevLfWave cur; memset(&cur, 0, sizeof cur);
 	auto flush = [&] { if (cur.num_parts) { waves->push_back(cur); most = std::max(most, used); } memset(&cur, 0, sizeof cur); used = 0; lanes = 0; };
@@ -256,12 +293,13 @@ uint32_t pack_lf_row_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std:
 		const uint32_t tables = lf_rows_table_bytes(sets_host[i].num_nodes, sets_host[i].num_clusters, sets_host[i].log_alpha);
 		if (tables + win_bytes > 60u * 1024u) { waves->clear(); return 0; }
 		for (int32_t first = 0; first < sets_host[i].ntasks; ) {
-			if (lanes >= 64 || cur.num_parts >= LF_WAVE_PARTS || (cur.num_parts && used + tables + win_bytes > budget)) flush();
+			if (lanes >= 64 * per || cur.num_parts >= LF_WAVE_PARTS || (cur.num_parts && used + tables + win_bytes > budget)) flush();
 			// as many of the frame's sections as fit the budget (a wavefront's first frame may exceed it, up to the 60 KB a workgroup asks for at most)
 			const uint32_t limit = cur.num_parts ? budget : std::min(60u * 1024u, std::max(budget, tables + win_bytes));
-			const int32_t count = std::min(std::min(64 - lanes, sets_host[i].ntasks - first), std::max(1, (int32_t) ((limit - used - tables) / win_bytes)));
+			const int32_t room = std::max(1, (int32_t) ((limit - used - tables) / win_bytes));
+			const int32_t count = std::min(std::min(64 * per - lanes, sets_host[i].ntasks - first), room);
 			cur.part[cur.num_parts].set = i; cur.part[cur.num_parts].first_task = first; cur.part[cur.num_parts].count = count; ++cur.num_parts;
-			used += tables + (uint32_t) count * win_bytes; lanes += count; first += count;
+			used += tables + (uint32_t) count * win_bytes; lanes += count; first += count;   // (`lanes` counts sections: 64 or 128 a wavefront)
 		}
 	}
 	flush();
@@ -271,9 +309,11 @@ uint32_t pack_lf_row_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std:
 void launch_lf_rows(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t num_waves, uint32_t lds_bytes, hipStream_t stream, hipEvent_t started, hipEvent_t stopped) {
 	if (num_waves <= 0) return;
 	static bool configured = false;
-	if (!configured) { (void) hipFuncSetAttribute((const void *) k_lf_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); configured = true; }
-	if (started && stopped) hipExtLaunchKernelGGL(k_lf_rows, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, started, stopped, 0, sets, waves);
-	else hipLaunchKernelGGL(k_lf_rows, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
+	if (!configured) { (void) hipFuncSetAttribute((const void *) k_lf_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); (void) hipFuncSetAttribute((const void *) k_lf_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); configured = true; }
+	const bool pairs = lf_rows_mode() == 2;
+	if (started && stopped) { if (pairs) hipExtLaunchKernelGGL(k_lf_rows<true>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, started, stopped, 0, sets, waves); else hipExtLaunchKernelGGL(k_lf_rows<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, started, stopped, 0, sets, waves); }
+	else if (pairs) hipLaunchKernelGGL(k_lf_rows<true>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
+	else hipLaunchKernelGGL(k_lf_rows<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
 }
 
 void launch_lf_groups(const DevLfTask *tasks, int32_t num_tasks, hipStream_t stream) {

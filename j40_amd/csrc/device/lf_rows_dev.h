@@ -322,7 +322,17 @@ J40_DEV int32_t lf_mad24(int32_t a, int32_t b, int32_t c) { return a * b + c; }
 // unpack_signed_dev for the token values a symbol without an error yields (0 <= u < 2^30), as two instructions instead of a branch
 J40_DEV int32_t lf_unzigzag(int32_t u) { return (int32_t) ((uint32_t) u >> 1) ^ -(u & 1); }
 
-J40_DEV void lf_row_step_plain(LfRowLane &L, const LfRowTables &T) {
+// The step in three phases, so that TWO sections can go through it side by side on one lane (lf_row_step_plain2): everything that
+// reads LDS comes before anything that writes it, and between the phases the two sections' instructions are independent of each
+// other -- the compiler interleaves them, and a wavefront alone on its SIMD issues independent instructions every 5-6 cycles
+// where a dependent chain gets one every 8.6.
+struct LfPlainCtx {
+	int32_t x, slot, ahead3, pw, pn, pnw, pne, pww;
+	uint32_t word, idx, bucket; uint64_t entry;
+};
+
+// refill, neighbours, the property and the walk; asks LDS for the alias entry and the row above's next sample
+J40_DEV void lf_plain_front(LfRowLane &L, const LfRowTables &T, LfPlainCtx &c) {
 	LaneBits &b = L.b;
 	{   // lane_bits_refill as selects; the word after next is asked for every time (the same word again when nothing was appended)
 		const bool need = b.nbits <= 32;
@@ -331,8 +341,8 @@ J40_DEV void lf_row_step_plain(LfRowLane &L, const LfRowTables &T) {
 		b.ahead = lane_load32(b.base, b.pos);
 	}
 	const int32_t x = L.x, y = L.y, cw = L.cw;
-	const int32_t slot = x & (LF_ROW_WIN - 1);   // (= x unless the row is wider than the window)
-	const int32_t ahead3 = L.win[slot + 3];   // the row above at x + 3, for the next sample's registers (asked for early; slots past the row's end are never looked at)
+	c.x = x; c.slot = x & (LF_ROW_WIN - 1);   // (= x unless the row is wider than the window)
+	c.ahead3 = L.win[c.slot + 3];   // the row above at x + 3, for the next sample's registers (slots past the row's end are never looked at)
 	const bool up = y > 0, left = x > 0;
 	const int32_t pw = left ? L.pw : up ? L.a2 : 0;
 	const int32_t pn = up ? L.a2 : pw;
@@ -340,29 +350,84 @@ J40_DEV void lf_row_step_plain(LfRowLane &L, const LfRowTables &T) {
 	const int32_t pne = x + 1 < cw && up ? L.a3 : pn;
 	const int32_t pww = x > 1 ? L.pww : pw;
 	const int32_t pnww = x > 1 && up ? L.a0 : pww;
+	c.pw = pw; c.pn = pn; c.pnw = pnw; c.pne = pne; c.pww = pww;
 	// the property and the walk: one test, or none (both words the leaf's)
 	int32_t val = lf_mad24(L.c_x, x, lf_mad24(L.c_y, y, lf_mad24(L.c_w, pw, lf_mad24(L.c_n, pn, 0)))) + lf_mad24(L.c_nw, pnw, lf_mad24(L.c_ne, pne, lf_mad24(L.c_ww, pww, lf_mad24(L.c_nww, pnww, 0))));   // (two chains of four)
 	val = L.c_abs ? mod_abs(val) : val;
 	val = L.c_first && !left ? pw : val;
-	const uint32_t word = val > L.k_thr ? L.k_word_gt : L.k_word_le;
-	uint32_t e2;
-	const int32_t u = lane_symbol_in_cluster<true>(b, L.state, T.alias, T.log_alpha, T.log_bucket, word >> 24, word & (uint32_t) LF_LEAF_CFG_MASK, L.end_bit, &e2);
+	c.word = val > L.k_thr ? L.k_word_gt : L.k_word_le;
+	// the alias entry of the state's bucket in the leaf's cluster (lane_symbol_in_cluster)
+	c.idx = L.state & 0xfff; c.bucket = c.idx >> T.log_bucket;
+	c.entry = T.alias[((c.word >> 24) << T.log_alpha) + c.bucket];
+}
+
+// the symbol (rANS step + hybrid integer, lane_symbol_in_cluster<STRAIGHT> from the alias entry on), the prediction, the sample;
+// returns the sample, *code = the error this sample raises (0: none)
+J40_DEV int32_t lf_plain_middle(LfRowLane &L, const LfRowTables &T, const LfPlainCtx &c, uint32_t *code) {
+	LaneBits &b = L.b;
+	const uint32_t m = c.word & (uint32_t) LF_LEAF_CFG_MASK, pos = c.idx & ((1u << T.log_bucket) - 1);
+	const uint32_t elo = (uint32_t) c.entry, ehi = (uint32_t) (c.entry >> 32);
+	const bool aliased = pos >= (elo & 0xff);
+	const int32_t token = (int32_t) (aliased ? (elo >> 20) & 0xff : c.bucket);
+	const uint32_t offset = aliased ? (elo >> 8) & 0xfff : 0;
+	const uint32_t d = aliased ? (uint32_t) (c.entry >> 28) & 0x1fff : (ehi >> 9) & 0x1fff;
+	uint32_t state = d * (L.state >> 12) + offset + pos;
+	const bool renorm = state < (1u << 16);
+	const uint32_t low = lane_bits_take(b, renorm ? 16 : 0);
+	L.state = renorm ? (state << 16) | low : state;
+	const bool short1 = lane_bit_position(b) > L.end_bit;
+	const int32_t split_exp = (int32_t) (m & 15), split = 1 << split_exp;
+	const bool big = token >= split;
+	const int32_t mt = (int32_t) (m >> 12);
+	const bool iovf = big && token > mt;
+	const int32_t tok = iovf ? mt : token;
+	const int32_t msb = (int32_t) ((m >> 4) & 15), lsb = (int32_t) ((m >> 8) & 15), in_token = msb + lsb;
+	const int32_t midbits = big ? split_exp - in_token + ((tok - split) >> in_token) : 0;   // (<= 17: lf_rows_leaf_word; the window holds them)
+	const int32_t mid = (int32_t) lane_bits_take(b, midbits);
+	const bool short2 = lane_bit_position(b) > L.end_bit;
+	const int32_t top = 1 << msb;
+	const int32_t lo = tok & ((1 << lsb) - 1), hi = (tok >> lsb) & (top - 1);
+	const int32_t value = ((top | hi) << (midbits + lsb)) | ((mid << lsb) | lo);
+	const uint32_t e2 = short1 ? (uint32_t) ERR_SHRT : iovf ? (uint32_t) ERR_IOVF : short2 ? (uint32_t) ERR_SHRT : 0u;
+	const int32_t u = big ? value : token;
 	// the prediction
-	int32_t lin = lf_mad24(L.p_w, pw, lf_mad24(L.p_n, pn, 0)) + lf_mad24(L.p_nw, pnw, lf_mad24(L.p_ne, pne, lf_mad24(L.p_ww, pww, 0)));
+	int32_t lin = lf_mad24(L.p_w, c.pw, lf_mad24(L.p_n, c.pn, 0)) + lf_mad24(L.p_nw, c.pnw, lf_mad24(L.p_ne, c.pne, lf_mad24(L.p_ww, c.pww, 0)));
 	lin = L.p_half ? (lin + (int32_t) ((uint32_t) lin >> 31)) >> 1 : lin;   // (a + b) / 2, towards zero
-	const int32_t sel = mod_abs(pn - pnw) < mod_abs(pw - pnw) ? pw : pn;
-	const int32_t grad = mod_gradient(pw, pn, pnw);
+	const int32_t sel = mod_abs(c.pn - c.pnw) < mod_abs(c.pw - c.pnw) ? c.pw : c.pn;
+	const int32_t grad = mod_gradient(c.pw, c.pn, c.pnw);
 	const int32_t pred = L.p_kind == 1 ? sel : L.p_kind == 2 ? grad : lin;
 	const int32_t v = lf_unzigzag(u) * L.p_mul + L.p_off + pred;
-	const uint32_t code = e2 ? e2 : v < -32768 || v > 32767 ? (uint32_t) ERR_POVF : 0u;
-	// an error ends the lane (what it leaves behind is never looked at); otherwise the sample is stored and the registers slide
+	*code = e2 ? e2 : v < -32768 || v > 32767 ? (uint32_t) ERR_POVF : 0u;
+	return v;
+}
+
+// an error ends the lane (what it leaves behind is never looked at); otherwise the sample is stored and the registers slide
+J40_DEV void lf_plain_commit(LfRowLane &L, const LfPlainCtx &c, int32_t v, uint32_t code) {
 	L.err = L.err ? L.err : code;
 	L.chan = code ? 7 : L.chan;
 	L.plain_left = code ? 0 : L.plain_left - 1;   // (after an error the general step finds the lane finished)
-	L.win[slot] = (int16_t) v;
+	L.win[c.slot] = (int16_t) v;
 	L.pww = L.pw; L.pw = v;
-	L.a0 = L.a1; L.a1 = L.a2; L.a2 = L.a3; L.a3 = L.a4; L.a4 = ahead3;
-	L.x = x + 1;
+	L.a0 = L.a1; L.a1 = L.a2; L.a2 = L.a3; L.a3 = L.a4; L.a4 = c.ahead3;
+	L.x = c.x + 1;
+}
+
+J40_DEV void lf_row_step_plain(LfRowLane &L, const LfRowTables &T) {
+	LfPlainCtx c; uint32_t code;
+	lf_plain_front(L, T, c);
+	const int32_t v = lf_plain_middle(L, T, c, &code);
+	lf_plain_commit(L, c, v, code);
+}
+
+// two sections (each with the tables of its frame), one sample each
+J40_DEV void lf_row_step_plain2(LfRowLane &A, LfRowLane &B, const LfRowTables &TA, const LfRowTables &TB) {
+	LfPlainCtx ca, cb; uint32_t code_a, code_b;
+	lf_plain_front(A, TA, ca);
+	lf_plain_front(B, TB, cb);
+	const int32_t va = lf_plain_middle(A, TA, ca, &code_a);
+	const int32_t vb = lf_plain_middle(B, TB, cb, &code_b);
+	lf_plain_commit(A, ca, va, code_a);
+	lf_plain_commit(B, cb, vb, code_b);
 }
 
 // the copy a step asked for, by the lane itself (tests/hostsim; the kernel's lanes do it together: lf_row_flush_wave)

@@ -171,7 +171,7 @@ void pinned_make_room(size_t incoming, std::vector<void *> *gone) {
 	g_pinned_idle.erase(g_pinned_idle.begin(), g_pinned_idle.begin() + (long) n);
 }
 }
-extern "C" void *j40hip_pinned_acquire(size_t bytes) {
+extern "C" __attribute__((visibility("default"))) void *j40hip_pinned_acquire(size_t bytes) {
 	bytes = (bytes + 4095) & ~(size_t) 4095;
 	std::vector<void *> gone;
 	void *q = nullptr;
@@ -189,7 +189,7 @@ extern "C" void *j40hip_pinned_acquire(size_t bytes) {
 	if (hipHostMalloc(&q, bytes ? bytes : 4096, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
 	return q;
 }
-extern "C" void j40hip_pinned_release(void *ptr, size_t bytes) {
+extern "C" __attribute__((visibility("default"))) void j40hip_pinned_release(void *ptr, size_t bytes) {
 	if (!ptr) return;
 	bytes = (bytes + 4095) & ~(size_t) 4095;
 	std::vector<void *> gone;

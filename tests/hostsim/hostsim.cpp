@@ -998,9 +998,22 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_check(
 		}
 		for (bool any = true; any; ) {
 			any = false;
-			for (size_t k = 0; k < n; ++k) if (!lf_row_done(L[k])) {   // (the kernel's dispatch: the straight-line step where the lane's sample allows it)
-				if (L[k].plain_left > 0 && !(general_only & 1)) { lf_row_step_plain(L[k], T); ++plain_steps; } else { lf_row_step(L[k], out[k].t, T); ++general_steps; }
+			// (the kernel's dispatch: the straight-line step where the lane's sample allows it; mode bit 1: two sections per lane, both
+			// through lf_row_step_plain2 when both are inside a run -- k_lf_rows<true>)
+			const size_t per = (general_only & 2) ? 2 : 1;
+			for (size_t k = 0; k < n; k += per) {
+				const bool two = per == 2 && k + 1 < n;
+				LfRowLane &A = L[k], &B = L[two ? k + 1 : k];
+				if (lf_row_done(A) && (!two || lf_row_done(B))) continue;
 				any = true;
+				const bool pa = A.plain_left > 0 && !(general_only & 1), pb = two && B.plain_left > 0 && !(general_only & 1);
+				if (pa && pb) { lf_row_step_plain2(A, B, T, T); plain_steps += 2; }
+				else {
+					if (pa) { lf_row_step_plain(A, T); ++plain_steps; }
+					if (pb) { lf_row_step_plain(B, T); ++plain_steps; }
+				}
+				if (!pa && !lf_row_done(A)) { lf_row_step(A, out[k].t, T); ++general_steps; }
+				if (two && !pb && !lf_row_done(B)) { lf_row_step(B, out[k + 1].t, T); ++general_steps; }
 			}
 			for (size_t k = 0; k < n; ++k) if (L[k].flush_n > 0) lf_row_flush_serial(L[k]);
 		}

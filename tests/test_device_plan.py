@@ -140,7 +140,7 @@ def test_lf_row_window_decoder_equals_the_host_decoder(lanes, mode, w, h, seed, 
     reference's j40__lf_group by tests/test_host.py). The varblock-info channel (2 rows of hundreds to thousands of samples) is the
     case of rows wider than the window."""
     lanes.hostsim_lf_rows_counts.argtypes = [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32, C.c_int32]
-    for nl, general_only in ((1, 0), (64, 0), (3, 1)):
+    for nl, general_only in ((1, 0), (64, 0), (3, 1), (64, 2), (5, 2)):   # (mode 2: two sections per lane, as k_lf_rows<true> steps them)
         lanes.hostsim_lf_rows_counts(None, None, 1, general_only)
         rc, n, bad = rows_check(lanes, synth(mode, w, h, seed, **opts), nl)
         plain, general = C.c_int64(), C.c_int64()
@@ -151,7 +151,7 @@ def test_lf_row_window_decoder_equals_the_host_decoder(lanes, mode, w, h, seed, 
         assert rc == 0 and n >= 1 and bad == 0, (rc, n, bad, nl)
         # the straight-line step (lf_row_step_plain) takes nearly every sample of the trees it accepts -- the generator's default LF
         # tree and lftree=2/3 --, none of the others (lftree=1); with it switched off the general step alone gives the same planes
-        if general_only or opts.get("lftree") == 1:
+        if (general_only & 1) or opts.get("lftree") == 1:
             assert plain.value == 0 and general.value > 0
         else:
             assert plain.value > 20 * general.value, (plain.value, general.value)

@@ -15,7 +15,8 @@ for o in plan_build plan_front entropy modular tables frame capi_host api kernel
 	for s in "${SRCS[@]}"; do
 		if [ "$s" = "$o.hip" ]; then
 			use=build/obj/variant_$NAME/$o.o
-			/opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -Wall $FLAGS -c j40_amd/csrc/device/$o.hip -o $use
+			PER=""; if [ "$o" = "lf_decode" ]; then PER="-mllvm -amdgpu-sched-strategy=max-ilp"; fi   # (as the Makefile)
+			/opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -Wall $PER $FLAGS -c j40_amd/csrc/device/$o.hip -o $use
 		elif [ "$s" = "$o.cpp" ]; then
 			use=build/obj/variant_$NAME/$o.o
 			g++ -std=c++17 -O2 -fPIC -Wall -Wextra -ffp-contract=off -fvisibility=hidden $FLAGS -c j40_amd/csrc/$o.cpp -o $use

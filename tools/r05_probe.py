@@ -13,7 +13,7 @@ import j40_amd
 from bench import run_pipeline_steps, synth_many, cpu_quota
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-steps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+steps = int(os.environ.get("PROBE_STEPS", sys.argv[3] if len(sys.argv) > 3 else 4))
 only = os.environ.get("PROBE_ONLY", "")
 W, H = 7680, 4320
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
