@@ -270,10 +270,11 @@ void launch_lf_lanes(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t n
 	else hipLaunchKernelGGL(k_lf_lanes<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
 }
 
-// J40HIP_LF_KERNEL: "lanes" = the older decoder (alias entries and rows in global memory) for every launch; "rows1" = k_lf_rows with
-// one section per lane; default: k_lf_rows with two sections per lane, for every launch whose frames' tables fit its LDS budget
+// J40HIP_LF_KERNEL: "lanes" = the older decoder (alias entries and rows in global memory) for every launch; "rows2" = k_lf_rows with
+// two sections per lane (measured: 430 ms per launch against 215 -- the second section's instructions cost what the first one's
+// do, see lf_rows_dev.h); default: k_lf_rows with one section per lane, for every launch whose frames' tables fit its LDS budget
 static int lf_rows_mode() {
-	static const int v = [] { const char *e = getenv("J40HIP_LF_KERNEL"); return e && strcmp(e, "lanes") == 0 ? 0 : e && strcmp(e, "rows1") == 0 ? 1 : 2; }();
+	static const int v = [] { const char *e = getenv("J40HIP_LF_KERNEL"); return e && strcmp(e, "lanes") == 0 ? 0 : e && strcmp(e, "rows2") == 0 ? 2 : 1; }();
 	return v;
 }
 bool lf_rows_enabled() { return lf_rows_mode() != 0; }

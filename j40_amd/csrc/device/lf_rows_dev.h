@@ -322,10 +322,13 @@ J40_DEV int32_t lf_mad24(int32_t a, int32_t b, int32_t c) { return a * b + c; }
 // unpack_signed_dev for the token values a symbol without an error yields (0 <= u < 2^30), as two instructions instead of a branch
 J40_DEV int32_t lf_unzigzag(int32_t u) { return (int32_t) ((uint32_t) u >> 1) ^ -(u & 1); }
 
-// The step in three phases, so that TWO sections can go through it side by side on one lane (lf_row_step_plain2): everything that
-// reads LDS comes before anything that writes it, and between the phases the two sections' instructions are independent of each
-// other -- the compiler interleaves them, and a wavefront alone on its SIMD issues independent instructions every 5-6 cycles
-// where a dependent chain gets one every 8.6.
+// The step in three phases, so that TWO sections can go through it side by side on one lane (lf_row_step_plain2, k_lf_rows<true>):
+// everything that reads LDS comes before anything that writes it, and between the phases the two sections' instructions are
+// independent of each other; compiled with the max-ILP scheduling strategy they do come out interleaved. MEASURED AND NOT THE DEFAULT:
+// a launch of 128 8K frames takes 421-450 ms with two sections per lane against 212-222 ms with one -- the same cycles per sample.
+// The step runs at about nine cycles per instruction either way (1 690 cycles for its 185, mostly 8-byte encodings); the
+// microbenchmark's best, four independent chains of 4-byte instructions, was 5.3. What bounds a lone wavefront here is not the
+// dependence between its instructions but how fast it is fed them, and only fewer (or shorter) instructions per sample help.
 struct LfPlainCtx {
 	int32_t x, slot, ahead3, pw, pn, pnw, pne, pww;
 	uint32_t word, idx, bucket; uint64_t entry;
