@@ -5,7 +5,12 @@ HIPCC ?= $(ROCM)/bin/hipcc
 CXX ?= g++
 ARCH ?= gfx950
 CXXFLAGS = -std=c++17 -O2 -fPIC -Wall -Wextra -ffp-contract=off -fvisibility=hidden
-HIPFLAGS = --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -Wall $(EXTRA_HIPFLAGS)
+# EVENT_RING=8 (or 4): k_hf_lanes' coefficient events leave through per-lane rings in LDS as aligned 32- (16-) byte stores
+# (device/plan.h: J40_LANE_EV_FLUSH; default 0 = a 4-byte store per event). The CPU build of the device functions (libhostsim.so)
+# always carries the rings, so that tests/test_hostsim.py keeps that path exact.
+EVENT_RING ?= 0
+CXXFLAGS += -DJ40_LANE_EV_FLUSH=$(EVENT_RING)
+HIPFLAGS = --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -Wall -DJ40_LANE_EV_FLUSH=$(EVENT_RING) $(EXTRA_HIPFLAGS)
 SRC = j40_amd/csrc
 HOST_OBJS = build/obj/plan_build.o build/obj/plan_front.o build/obj/entropy.o build/obj/modular.o build/obj/tables.o build/obj/frame.o build/obj/capi_host.o build/obj/api.o
 DEV_OBJS = build/obj/kernels.o build/obj/modular_kernels.o build/obj/runtime.o build/obj/pipeline.o build/obj/lf_tail_kernels.o build/obj/modular_coop.o build/obj/modular_quad.o build/obj/lf_decode.o build/obj/plan_kernels.o build/obj/async.o
@@ -46,7 +51,7 @@ build/api_threads: tests/api_threads.c include/j40.h build/libj40hip.so
 # device functions compiled for the CPU, test infrastructure only (tests/hostsim)
 build/libhostsim.so: tests/hostsim/hostsim.cpp $(SRC)/plan_build.cpp $(SRC)/plan_front.cpp $(SRC)/entropy.cpp $(SRC)/modular.cpp $(SRC)/tables.cpp $(SRC)/frame.cpp $(wildcard $(SRC)/device/*.h) $(wildcard $(SRC)/*.hpp)
 	@mkdir -p build
-	$(CXX) -std=c++17 -O2 -fPIC -shared -ffp-contract=off -Wall -Wextra -Wno-unused-function -Wno-unknown-pragmas -o $@ tests/hostsim/hostsim.cpp $(SRC)/plan_build.cpp $(SRC)/plan_front.cpp $(SRC)/entropy.cpp $(SRC)/modular.cpp $(SRC)/tables.cpp $(SRC)/frame.cpp -lpthread
+	$(CXX) -std=c++17 -O2 -fPIC -shared -ffp-contract=off -Wall -Wextra -Wno-unused-function -Wno-unknown-pragmas -DJ40_LANE_EV_FLUSH=8 -o $@ tests/hostsim/hostsim.cpp $(SRC)/plan_build.cpp $(SRC)/plan_front.cpp $(SRC)/entropy.cpp $(SRC)/modular.cpp $(SRC)/tables.cpp $(SRC)/frame.cpp -lpthread
 
 build/jxlsynth: tools/jxlsynth.cpp $(wildcard tools/*.hpp) $(SRC)/tables.cpp $(SRC)/device/special8_dev.h $(SRC)/device/idct_dev.h
 	@mkdir -p build

@@ -448,7 +448,7 @@ def main():
     lfl = max(st.get("lf_launches", 0), 1)
     stages = [
         stage("LfGroup streams (j40.h:6722-6790)", "k_lf_rows" if os.environ.get("J40HIP_LF_KERNEL") != "lanes" else "k_lf_lanes", st.get("lf_kernel_ms", 0) / lfl, st.get("lf_launch_frames", 0) / lfl,
-              "device-recorded start / end events of each launch (hipExtLaunchKernelGGL), averaged over %d launches; a launch carries what was waiting, up to two batches' worth, on a low-priority stream beside the other stages" % st.get("lf_launches", 0)),
+              "device-recorded start / end events of each launch (hipExtLaunchKernelGGL), averaged over %d launches; a launch carries what was waiting, up to four batches' worth, on a low-priority stream beside the other stages, and lasts as long as its longest section whatever it carries (a section is one lane): ms_per_256_frames is what its frames' share of it comes to, not a cost per frame" % st.get("lf_launches", 0)),
         stage("plan build + LfGroup tail (j40.h:6585-6720, 6544-6590, 5944)", "k_plan_place / _scan / _emit, k_lf_dequant_smooth_batch, k_llf_small_batch, k_llf_large_batch", st["lf_plan_ms"] / launches, frames_per_launch,
               "HIP events on the batch's stream around the stage (includes what the stage waited for behind other kernels)"),
         stage("entropy decode (j40.h:6888-7005)", "k_hf_lanes", k1_launch_ms, frames_per_launch, "device-recorded start / end events of the kernel"),
@@ -513,7 +513,9 @@ def main():
             # the lane decoder of the LfGroup streams alone: one batch in flight and one step at a time, so that its launch is the only
             # thing on the device (the batch cannot start before it ends, and the step is drained before the next one)
             outs3 = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(min(B, 256))]
+            os.environ["J40HIP_LF_WAIT_MS"] = "500"   # (this pipeline's launches wait for the whole batch: one launch of B frames, as in the steady state)
             lfa = j40_amd.Pipeline(local_rank, threads, min(args.pipe_batch, B), 1, lf_streams="device")
+            del os.environ["J40HIP_LF_WAIT_MS"]
             so3 = [outs3[i % len(outs3)] for i in range(B)]
             run_pipeline_steps(lfa, step_bufs, step_sizes, so3, W * 4, True, 1, torch, dev, None)
             acc = {"ms": 0.0, "n": 0, "frames": 0, "waves": 0}

@@ -119,6 +119,7 @@ struct j40hip_pipeline {
 	LfFlight lf_flights[4];
 	int lf_flights_used = 4;            // how many of them launch (J40HIP_LF_FLIGHTS); a launch carries up to lf_flight_frames frames
 	int64_t lf_flight_frames = 0;
+	double lf_wait_ms = 5.0;            // how long frames wait for a batch's worth of company before a launch takes them alone (J40HIP_LF_WAIT_MS)
 	std::vector<uint32_t> results;      // by ticket
 	std::vector<uint8_t> finished;      // by ticket
 	int64_t submitted = 0, completed = 0, resident = 0, parsing = 0, in_flight_frames = 0;
@@ -451,7 +452,7 @@ void gpu_main(j40hip_pipeline *p) {
 			else if (p->lf_pending_since == 0) p->lf_pending_since = now_ms();
 			bool lf_flying = false;
 			for (const LfFlight &fl : p->lf_flights) lf_flying = lf_flying || fl.busy;
-			const bool lf_go = !p->lf_pending.empty() && ((int64_t) p->lf_pending.size() >= p->batch_frames || (!lf_flying && now_ms() - p->lf_pending_since > 5.0) || p->stop || (p->todo.empty() && p->parsing == 0));
+			const bool lf_go = !p->lf_pending.empty() && ((int64_t) p->lf_pending.size() >= p->batch_frames || (!lf_flying && now_ms() - p->lf_pending_since > p->lf_wait_ms) || p->stop || (p->todo.empty() && p->parsing == 0));
 			if (lf_go) for (int fi = 0; fi < p->lf_flights_used; ++fi) if (!p->lf_flights[fi].busy) {
 				LfFlight &fl = p->lf_flights[fi];
 				std::vector<j40hip_aframe *> frames;
@@ -567,6 +568,7 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 		p->lf_flights_used = 2; p->lf_flight_frames = (int64_t) p->batch_frames * 4;
 		if (const char *e = getenv("J40HIP_LF_FLIGHTS")) p->lf_flights_used = std::max(1, std::min(4, atoi(e)));
 		if (const char *e = getenv("J40HIP_LF_FLIGHT_FRAMES")) p->lf_flight_frames = std::max<int64_t>(1, atoll(e));
+		if (const char *e = getenv("J40HIP_LF_WAIT_MS")) p->lf_wait_ms = std::max(0.0, atof(e));
 		p->slots.resize((size_t) p->max_in_flight + 1);
 		for (Slot &s : p->slots) {
 			bool made = false;

@@ -301,12 +301,18 @@ enum { SRGB_THRESHOLDS = 258, SRGB_BUCKET_LO = (127 - 13) << 7, SRGB_BUCKET_HI =
 
 enum { HF_WAVES = 4 };
 // k_hf_lanes keeps per wavefront, behind its frame's tables: the column state of the non-zero-count predictor ([3][32][64 lanes]
-// bytes) and the lanes' event rings (hf_lanes_dev.h: a lane's coefficient events collect in LDS and leave J40_LANE_EV_FLUSH at a
-// time as one aligned 16- or 32-byte store; [2 * J40_LANE_EV_FLUSH][64 lanes] words; 0: every event is a 4-byte store of its own)
+// bytes) and, when built with J40_LANE_EV_FLUSH > 0 (make EVENT_RING=8), the lanes' event rings (hf_lanes_dev.h: a lane's coefficient
+// events collect in LDS and leave J40_LANE_EV_FLUSH at a time as one aligned 16- or 32-byte store; [2 * J40_LANE_EV_FLUSH][64 lanes]
+// words). The default build has none -- every event is a 4-byte store of its own. Measured with rings of 2 x 8 (2 x 4) slots, 256
+// 8K frames per launch: WRITE_SIZE 20.6 -> 10.5 (15.0) GB, but k_hf_lanes alone 41.9 -> 44.0 (45.2) ms, 32 (16) KB more LDS per
+// workgroup of eight wavefronts -- 131 KB: no pixel-kernel workgroup but the 8x8 transform's fits beside it any more, and the queued
+// form (512 frames per launch) gets two wavefronts per workgroup instead of four, 68 ms per 256 frames instead of 34. The writes were
+// never what the kernel waited for (0.5 TB/s); the ring stays a build option (profiles/r05_event_ring_*.jsonl).
 #ifndef J40_LANE_EV_FLUSH
-#define J40_LANE_EV_FLUSH 8
+#define J40_LANE_EV_FLUSH 0
 #endif
-enum { HF_LANE_PRED_BYTES = 3 * 32 * 64, HF_LANE_RING_SLOTS = 2 * J40_LANE_EV_FLUSH, HF_LANE_COLS_BYTES = HF_LANE_PRED_BYTES + HF_LANE_RING_SLOTS * 64 * 4 };
+enum { HF_LANE_PRED_BYTES = 3 * 32 * 64, HF_LANE_RING_SLOTS = J40_LANE_EV_FLUSH ? 2 * J40_LANE_EV_FLUSH : 1 /* (never indexed without rings) */,
+       HF_LANE_COLS_BYTES = HF_LANE_PRED_BYTES + (J40_LANE_EV_FLUSH ? HF_LANE_RING_SLOTS * 64 * 4 : 0) };
 
 // what the host knows about the entropy tables' sizes, to lay out K1's LDS
 struct HfLaunchInfo {

@@ -38,7 +38,9 @@ if only in ("", "alone"):
     out["alone"] = per_launch(pipe.stats())
     pipe.close()
 if only in ("", "lf_alone"):
+    os.environ["J40HIP_LF_WAIT_MS"] = "500"   # (one launch per step: it waits for the whole batch)
     pipe = j40_amd.Pipeline(0, 4, B, 1, lf_streams="device")
+    del os.environ["J40HIP_LF_WAIT_MS"]
     run_pipeline_steps(pipe, sb, ss, so, W * 4, True, 1, torch, dev, None)
     acc = []
     for _ in range(2):
