@@ -34,6 +34,17 @@ J40HIP_API j40hip_frame *j40hip_frame_parse(const void *buf, size_t size, int th
 /* flags & 1: leave the tail of every LfGroup -- dequantisation of the LF samples, adaptive smoothing, LLF coefficients (j40.h:6544-6590,
  * 6492, 5944) -- to the device: j40hip_frame_upload runs it there (device/lf_tail_kernels.hip). Same results; what the pipeline uses. */
 J40HIP_API j40hip_frame *j40hip_frame_parse_ex(const void *buf, size_t size, int threads, uint32_t flags, uint32_t *err);
+/* Streaming input (what replaces the reference's refillable source and backing buffer, j40.h:1220-1386, 1676-1812, for a buffer
+ * that is still being filled -- a file being read, j40_from_file): `buf` has room for the `size` bytes the stream will have, and
+ * the parse runs while they arrive. need(ctx, n) is called -- also from the parse's worker threads -- before any byte below n is
+ * read and returns once bytes [0, n) are there (or the source has ended: what is missing is then a truncated stream, "shrt" where
+ * the reference raises it); have(ctx) says how many are there now. The parse asks for the signature first; a bare codestream's
+ * headers and TOC are parsed on growing prefixes, then LfGlobal, HfGlobal and each LfGroup section as its bytes are due, so the
+ * host's part of the decode overlaps the arrival of the pass-group sections (most of the file), which only the device reads:
+ * wait for the rest before j40hip_frame_upload. A container is parsed once it is complete. Same frame as j40hip_frame_parse_ex. */
+typedef void (*j40hip_need_bytes)(void *ctx, size_t upto);
+typedef size_t (*j40hip_have_bytes)(void *ctx);
+J40HIP_API j40hip_frame *j40hip_frame_parse_streamed(const void *buf, size_t size, int threads, uint32_t flags, j40hip_need_bytes need, j40hip_have_bytes have, void *ctx, uint32_t *err);
 /* ... with the LfGroup streams (LF coefficients, HF metadata: j40.h:6722-6790) decoded on HIP device `device` on `stream` (a
  * hipStream_t) instead of the host; `flags` must include 1. The call sleeps while the device works -- meant for many parsing
  * threads per CPU (the pipeline). Frames outside what the device decoder takes are parsed on the host, same results.

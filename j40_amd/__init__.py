@@ -240,6 +240,50 @@ class Frame:
         self.codestream_size = L.j40hip_frame_codestream_size(self.h)
 
     @classmethod
+    def parse_streamed(cls, data: bytes, step: int = 4096, threads: int = 4, flags: int = 0, log=None):
+        """j40hip_frame_parse_streamed over a buffer that fills up as the parser asks (include/j40hip.h): the buffer starts as
+        0xAA bytes and every need(n) reveals the stream's bytes up to n rounded up to a multiple of `step` -- a parser that read a
+        byte it had not asked for would see rubbish. log (a list) receives every n asked for."""
+        L = lib()
+        self = cls.__new__(cls)
+        n = len(data)
+        self._buf = (C.c_uint8 * max(n, 1)).from_buffer(bytearray(b"\xaa" * max(n, 1)))
+        have = [0]
+        import threading
+        lock = threading.Lock()
+
+        def need(_ctx, upto):
+            with lock:
+                if log is not None:
+                    log.append(int(upto))
+                want = min(n, (int(upto) + step - 1) // step * step)
+                if want > have[0]:
+                    C.memmove(C.addressof(self._buf) + have[0], data[have[0]:want], want - have[0])
+                    have[0] = want
+
+        def have_now(_ctx):
+            with lock:
+                return have[0]
+
+        NEED = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t)
+        HAVE = C.CFUNCTYPE(C.c_size_t, C.c_void_p)
+        self._cb = (NEED(need), HAVE(have_now))
+        L.j40hip_frame_parse_streamed.restype = C.c_void_p
+        L.j40hip_frame_parse_streamed.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, NEED, HAVE, C.c_void_p, C.POINTER(C.c_uint32)]
+        err = C.c_uint32()
+        self.h = L.j40hip_frame_parse_streamed(self._buf, n, threads, flags, self._cb[0], self._cb[1], None, C.byref(err))
+        self.revealed = have[0]
+        if not self.h:
+            raise J40Error(err4(err.value), "in j40hip_frame_parse_streamed")
+        need(None, n)   # (the rest arrives before anything else looks at the buffer)
+        info = np.zeros(32, np.int64)
+        L.j40hip_frame_info(self.h, info.ctypes.data)
+        self.info = dict(zip(INFO_FIELDS, info.tolist()))
+        self.width, self.height = self.info["width"], self.info["height"]
+        self.codestream_size = L.j40hip_frame_codestream_size(self.h)
+        return self
+
+    @classmethod
     def from_lf_bundle(cls, blob: bytes):
         """a frame handle from the blob Frame.lf_bundle() of another process made (VarDCT frames; nothing is parsed here)"""
         L = lib()

@@ -7,6 +7,11 @@
 #include "../../include/j40.h"
 #include "capi.hpp"
 #include <atomic>
+#include <new>
+#include <thread>
+#include <mutex>
+#include <memory>
+#include <condition_variable>
 #include <cerrno>
 #include <chrono>
 #include <cstdio>
@@ -128,39 +133,71 @@ std::atomic<int64_t> g_last_overlap_ms{-1000000};
 int serve_policy() { static const int v = [] { const char *e = getenv("J40HIP_SERVE"); return !e || !*e ? 2 : atoi(e) != 0 ? 1 : 0; }(); return v; }
 int device_index() { const char *e = getenv("J40HIP_DEVICE"); return e ? atoi(e) : 0; }
 
+// ---- j40_from_file's source (the reference's refillable file source and backing buffer, j40.h:1220-1386,
+// 1676-1812). j40_from_file opens the file and reads nothing (j40.h:8342-8361); the bytes are read by the first j40_next_frame, as
+// the reference's are (j40__file_source_read, j40.h:1241-1256: fread until the end of the file; a failing read raises `read` with
+// the errno kept; what a truncated file lacks surfaces as `shrt` from whoever needs the bytes). A regular file is read by a thread
+// of its own WHILE the calling thread parses it (j40hip_frame_parse_streamed: headers and TOC on the prefix that has arrived, LfGlobal,
+// HfGlobal and each LfGroup section as its bytes are due): the host's part of the decode overlaps the arrival of the pass-group
+// sections, which are most of the file and which only the device reads. J40HIP_STREAM=0, a source without a size (a pipe) or a
+// call that is served by the pipeline: the whole file first.
+struct FileSource {
+	FILE *fp = nullptr; uint8_t *data = nullptr; size_t size = 0;
+	std::mutex m; std::condition_variable cv;
+	size_t have = 0; bool done = false; bool failed = false; int saved_errno = 0;
+	std::thread reader;
+	void run() {
+		const int saved = errno;
+		size_t at = 0;
+		while (at < size) {
+			errno = 0;
+			const size_t n = fread(data + at, 1, std::min<size_t>(size - at, (size_t) 1 << 20), fp);
+			if (n == 0) { if (!feof(fp)) { std::lock_guard<std::mutex> lock(m); failed = true; saved_errno = errno; } break; }   // (a file that ends early: what is missing stays zero, a truncated stream)
+			at += n;
+			{ std::lock_guard<std::mutex> lock(m); have = at; }
+			cv.notify_all();
+		}
+		errno = saved;
+		{ std::lock_guard<std::mutex> lock(m); done = true; }
+		cv.notify_all();
+	}
+	static void need(void *ctx, size_t upto) { FileSource *s = (FileSource *) ctx; std::unique_lock<std::mutex> lock(s->m); s->cv.wait(lock, [&] { return s->done || s->have >= upto; }); }
+	static size_t have_now(void *ctx) { FileSource *s = (FileSource *) ctx; std::lock_guard<std::mutex> lock(s->m); return s->done ? s->size : s->have; }
+};
+int stream_policy() { static const int v = [] { const char *e = getenv("J40HIP_STREAM"); return !e || !*e || atoi(e) != 0 ? 1 : 0; }(); return v; }
+
+// the whole file, now (the served path, pipes, J40HIP_STREAM=0); 0 or the error code
+uint32_t read_whole_file(j40__inner *inner) {
+	FILE *fp = inner->fp;
+	inner->fp = nullptr;
+	const int saved = errno;
+	errno = 0;
+	size_t cap = 1 << 16, size = 0;
+	struct stat sb;
+	if (fstat(fileno(fp), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) cap = (size_t) sb.st_size + 1;   // (one allocation; a source that cannot say grows its buffer)
+	uint8_t *data = (uint8_t *) malloc(cap);
+	uint32_t ferr = data ? 0 : code4("!mem");
+	while (!ferr) {
+		if (size == cap) {
+			uint8_t *more = (uint8_t *) realloc(data, cap * 2);
+			if (!more) { ferr = code4("!mem"); break; }
+			data = more; cap *= 2;
+		}
+		const size_t n = fread(data + size, 1, cap - size, fp);
+		if (n > 0) { size += n; continue; }
+		if (!feof(fp)) { inner->saved_errno = errno; ferr = code4("read"); }
+		break;
+	}
+	fclose(fp);
+	errno = saved;
+	if (ferr) { free(data); return ferr; }
+	inner->owned = data; inner->buf = data; inner->size = size; inner->freefunc = nullptr;
+	return 0;
+}
+
 // the whole decode: RGBA into the image-owned plane
 j40_err advance(j40__inner *inner, int origin) {
 	if (inner->decoded) return 0;
-	if (inner->fp) {
-		// j40_from_file opened the file; it is read here, by the first call that needs its bytes, as the reference reads it
-		// (j40__file_source_read, j40.h:1241-1256: fread until end of file; a failing read raises `read` with the errno kept; what
-		// is missing from a truncated file surfaces as `shrt` from whoever needs the bytes). The file's size is asked for up front so
-		// that the bytes land in one allocation; a source that cannot say (a pipe) grows its buffer.
-		FILE *fp = inner->fp;
-		inner->fp = nullptr;
-		const int saved = errno;
-		errno = 0;
-		size_t cap = 1 << 16, size = 0;
-		struct stat sb;
-		if (fstat(fileno(fp), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) cap = (size_t) sb.st_size + 1;
-		uint8_t *data = (uint8_t *) malloc(cap);
-		uint32_t ferr = data ? 0 : code4("!mem");
-		while (!ferr) {
-			if (size == cap) {
-				uint8_t *more = (uint8_t *) realloc(data, cap * 2);
-				if (!more) { ferr = code4("!mem"); break; }
-				data = more; cap *= 2;
-			}
-			const size_t n = fread(data + size, 1, cap - size, fp);
-			if (n > 0) { size += n; continue; }
-			if (!feof(fp)) { inner->saved_errno = errno; ferr = code4("read"); }
-			break;
-		}
-		fclose(fp);
-		errno = saved;
-		if (ferr) { free(data); inner->origin = origin; inner->err = ferr; return ferr; }
-		inner->owned = data; inner->buf = data; inner->size = size; inner->freefunc = nullptr;
-	}
 	struct Inside { int n; Inside() : n(++g_inside) {} ~Inside() { --g_inside; } } inside;
 	const int policy = serve_policy();
 	const int64_t now = (int64_t) now_ms();
@@ -168,6 +205,31 @@ j40_err advance(j40__inner *inner, int origin) {
 	const bool serve = policy == 1 || (policy == 2 && (inside.n > 1 || now - g_last_overlap_ms.load() < 200));
 	static const bool timing = getenv("J40HIP_API_TIMING") != nullptr;
 	uint32_t err = 0;
+	std::unique_ptr<FileSource> src;
+	if (inner->fp) {
+		struct stat sb;
+		if (!serve && stream_policy() && fstat(fileno(inner->fp), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+			src.reset(new (std::nothrow) FileSource());
+			uint8_t *data = src ? (uint8_t *) calloc((size_t) sb.st_size, 1) : nullptr;
+			if (!data) { src.reset(); err = code4("!mem"); }
+			else {
+				src->fp = inner->fp; src->data = data; src->size = (size_t) sb.st_size;
+				inner->fp = nullptr; inner->owned = data; inner->buf = data; inner->size = src->size; inner->freefunc = nullptr;
+				try { src->reader = std::thread([s = src.get()] { s->run(); }); }
+				catch (const std::exception &) { src->run(); }   // (no thread to be had: read it here)
+			}
+		} else err = read_whole_file(inner);
+		if (err) { inner->origin = origin; inner->err = err; return err; }
+	}
+	// (whatever happens below, the reader has finished and the file is closed before this call returns)
+	struct Joined { FileSource *s; ~Joined() { if (s) { if (s->reader.joinable()) s->reader.join(); fclose(s->fp); } } } joined{src.get()};
+	auto read_failed = [&]() -> bool {   // the file could not be read to its end: `read`, whatever the parse made of what there was
+		if (!src) return false;
+		FileSource::need(src.get(), src->size);
+		if (!src->failed) return false;
+		inner->saved_errno = src->saved_errno; inner->origin = origin; inner->err = code4("read");
+		return true;
+	};
 	if (serve) {
 		j40hip_pipeline *p = j40hip_serve_pipeline(device_index(), &err);
 		if (p) err = j40hip_pipeline_run(p, inner->buf, inner->size, serve_alloc, inner);
@@ -182,7 +244,9 @@ j40_err advance(j40__inner *inner, int origin) {
 	// (no more threads than the container's CPU quota: a process over its quota has all its threads throttled, the HIP runtime's too;
 	// frames with fewer LfGroups and groups than that get a smaller team: parse_frame, build_vardct_plan)
 	static const int parse_threads = [] { const char *e = getenv("J40HIP_PARSE_THREADS"); return e && atoi(e) > 0 ? atoi(e) : std::max(1, std::min(12, j40hip_cpu_quota())); }();
-	inner->frame = j40hip_frame_parse_ex(inner->buf, inner->size, parse_threads, 1u, &err);
+	inner->frame = src ? j40hip_frame_parse_streamed(inner->buf, inner->size, parse_threads, 1u, FileSource::need, FileSource::have_now, src.get(), &err)
+	                   : j40hip_frame_parse_ex(inner->buf, inner->size, parse_threads, 1u, &err);
+	if (read_failed()) return inner->err;   // (also: the rest of the file is there from here on -- the upload copies the codestream)
 	t1 = now_ms();
 	if (!err && j40hip_device_count() <= device_index()) err = code4("!gpu");   // (before the plane: pinned memory needs the device too)
 	if (!err) {

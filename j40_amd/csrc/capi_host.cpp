@@ -33,6 +33,30 @@ j40hip_frame *j40hip_frame_parse_with(const void *buf, size_t size, int threads,
 
 j40hip_frame *j40hip_frame_parse(const void *buf, size_t size, int threads, uint32_t *err) { return j40hip_frame_parse_ex(buf, size, threads, 0, err); }
 
+j40hip_frame *j40hip_frame_parse_streamed(const void *buf, size_t size, int threads, uint32_t flags, j40hip_need_bytes need, j40hip_have_bytes have, void *ctx, uint32_t *err) {
+	if (!need || !have) return j40hip_frame_parse_ex(buf, size, threads, flags, err);
+	need(ctx, size < 2 ? size : 2);
+	const uint8_t *p = (const uint8_t *) buf;
+	if (size < 2 || !(p[0] == 0xff && p[1] == 0x0a)) {   // a container (or nothing a decoder knows): its boxes are walked once all of it is there
+		need(ctx, size);
+		return j40hip_frame_parse_ex(buf, size, threads, flags, err);
+	}
+	j40hip_frame *h = new j40hip_frame();
+	uint32_t code = 0;
+	try {
+		h->frame.defer_lf_tail = (flags & 1u) != 0;
+		h->frame.need_bytes = need; h->frame.have_bytes = have; h->frame.need_ctx = ctx;
+		h->cs = p; h->cs_size = size; h->bare_codestream = true;
+		parse_frame(h->cs, h->cs_size, &h->frame, threads);
+		h->threads = threads < 1 ? 1 : threads > 16 ? 16 : threads;
+	} catch (const DecodeError &e) { code = e.code; }
+	catch (const std::bad_alloc &) { code = E4("!mem"); }
+	h->frame.need_bytes = nullptr; h->frame.have_bytes = nullptr; h->frame.need_ctx = nullptr;   // (the source lives with the caller)
+	if (err) *err = code;
+	if (code) { delete h; return nullptr; }
+	return h;
+}
+
 // The seam for a host that has done its own parsing (a patched j40: INTEGRATION.md): a frame handle built from the plan view
 // instead of from a bitstream. Everything is copied except the codestream, which must outlive the handle.
 j40hip_frame *j40hip_frame_from_vardct_view(const j40hip_vardct_view *v, uint32_t *err) {
@@ -259,6 +283,7 @@ uint32_t j40hip_frame_vardct_view(j40hip_frame *h, j40hip_vardct_view *v) {
 	}
 	for (const LfGroup &g : f.lf_groups) {
 		j40hip_lf_group_view gv;
+		memset(&gv, 0, sizeof gv);   // (its padding too: the view travels byte for byte in j40hip_frame_lf_bundle's blob)
 		gv.left = g.left; gv.top = g.top; gv.width = g.width; gv.height = g.height; gv.width8 = g.width8; gv.height8 = g.height8; gv.width64 = g.width64; gv.height64 = g.height64;
 		gv.nb_varblocks = (int32_t) g.varblocks.size(); gv.blocks = g.blocks.data(); gv.lfindices = g.lfindices.data();
 		for (int c = 0; c < 3; ++c) gv.llfcoeffs[c] = g.llfcoeffs[c].data();

@@ -770,9 +770,10 @@ static void skip_icc(BitReader &br) {
 }
 
 // signature, image and frame headers, TOC (sections clipped to the bytes that exist), the LfGroups' geometry
-static void parse_headers(const uint8_t *cs, size_t cs_size, Frame *f) {
+// `limit`: how much of the codestream's cs_size bytes may be read (streaming input: what has arrived; else cs_size)
+static void parse_headers_within(const uint8_t *cs, size_t limit, size_t cs_size, Frame *f) {
 	memset(f->order_has_lehmer, 0, sizeof f->order_has_lehmer);
-	BitReader br(cs, cs_size);
+	BitReader br(cs, limit);
 	J40HIP_SHOULD(br.u(16) == 0x0aff, "!jxl");
 	read_image_metadata(br, &f->im);
 	if (f->im.want_icc) skip_icc(br);
@@ -793,9 +794,27 @@ static void parse_headers(const uint8_t *cs, size_t cs_size, Frame *f) {
 	}
 	allocate_lf_groups(f);
 }
+// Headers and TOC. With a streaming source (Frame::need_bytes) their extent is not known ahead: they are parsed on the prefix that
+// has arrived and, when that runs out ("shrt": every bit read until then was real, so any other error is the stream's own), again
+// on a longer one -- a few hundred bytes for most streams, an embedded ICC profile's worth for some.
+static void parse_headers(const uint8_t *cs, size_t cs_size, Frame *f) {
+	if (!f->need_bytes || !f->have_bytes) { parse_headers_within(cs, cs_size, cs_size, f); return; }
+	size_t want = std::min<size_t>(cs_size, 4096);
+	for (;;) {
+		f->need(want);
+		const size_t have = std::min(cs_size, std::max(want, f->have_bytes(f->need_ctx)));
+		try { parse_headers_within(cs, have, cs_size, f); return; }
+		catch (const DecodeError &e) {
+			if (e.code != (uint32_t) E4("shrt") || have >= cs_size) throw;
+			*f = [&] { Frame fresh; fresh.need_bytes = f->need_bytes; fresh.need_ctx = f->need_ctx; fresh.have_bytes = f->have_bytes; fresh.defer_lf_tail = f->defer_lf_tail; fresh.lf_decoder = f->lf_decoder; fresh.lf_decoder_ctx = f->lf_decoder_ctx; return fresh; }();
+			want = std::min(cs_size, std::max(have * 2, have + 4096));
+		}
+	}
+}
 
 // LfGlobal and HfGlobal of a frame with several sections
 static void parse_globals(const uint8_t *cs, Frame *f) {
+	f->need(std::max(f->toc.lf_global.offset + f->toc.lf_global.size, f->toc.hf_global.offset + f->toc.hf_global.size));
 	{
 		BitReader sr(cs + f->toc.lf_global.offset, f->toc.lf_global.size);
 		read_lf_global(sr, f);
@@ -849,6 +868,7 @@ void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
 	if (f->toc.single) {
 		// one section holds LfGlobal, HfGlobal, LfGroup and PassGroup back to back, read in the order
 		// the reference reads them (j40.h:8189-8199)
+		f->need(cs_size);
 		BitReader sr(cs + f->toc.single_section.offset, f->toc.single_section.size);
 		read_lf_global(sr, f);
 		if (f->fh.is_modular) return;   // LfGroup / PassGroup read nothing for single-group Modular frames (j40.h:6731, 7024)
@@ -879,6 +899,7 @@ void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
 	std::atomic<uint32_t> first_err(0);
 	std::vector<uint32_t> errs((size_t) n, 0);
 	std::vector<char> done((size_t) n, 0);
+	if (f->lf_decoder) f->need(cs_size);   // (the device reads the sections out of the whole codestream)
 	if (f->lf_decoder && !f->fh.is_modular && !f->fh.use_lf_frame && f->fh.jpeg_upsampling == 0 && f->defer_lf_tail) {
 		// the streams of every LfGroup section on the device (device/lf_decode.hip): the host reads what precedes the LF coefficient
 		// stream -- extra precision and the first Modular header, which has to be the plain one --, the device decodes both
@@ -922,6 +943,7 @@ void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
 			if (i >= n) break;
 			if (done[(size_t) i]) continue;
 			try {
+				f->need(f->toc.lf_groups[(size_t) i].offset + f->toc.lf_groups[(size_t) i].size);   // (streaming input: this section's bytes)
 				BitReader sr(cs + f->toc.lf_groups[(size_t) i].offset, f->toc.lf_groups[(size_t) i].size);
 				read_lf_group(sr, f, &f->lf_groups[(size_t) i]);
 			} catch (const DecodeError &e) { errs[(size_t) i] = e.code; }

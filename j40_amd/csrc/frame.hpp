@@ -138,6 +138,14 @@ struct Frame {
 	// VarDCT frames with several sections: the LfGroup streams are decoded by this (on the device) instead of the host. Set before parse_frame.
 	LfDeviceDecoder lf_decoder = nullptr; void *lf_decoder_ctx = nullptr;
 	bool lf_decoded_on_device = false;   // out: it was
+	// Streaming input (the reference's refillable source, j40.h:1220-1386, 1676-1812): the codestream's bytes arrive
+	// while it is parsed. need_bytes(ctx, n) returns once bytes [0, n) of the buffer are there (or the source has ended: what is
+	// missing then reads as a truncated stream). parse_frame asks before it touches anything: the headers on growing prefixes, then
+	// LfGlobal, HfGlobal and every LfGroup section as their bytes are due -- the pass-group sections, most of the file, are not the
+	// host's to read. nullptr: everything is there. Set before parse_frame; called from the LfGroup worker threads too.
+	void (*need_bytes)(void *ctx, size_t upto) = nullptr; void *need_ctx = nullptr;
+	size_t (*have_bytes)(void *ctx) = nullptr;   // how many bytes are there now (with need_bytes)
+	void need(size_t upto) const { if (need_bytes) need_bytes(need_ctx, upto); }
 	// Modular frames: LfGlobal's channel data is left to the device; it starts at this bit of the section
 	bool gm_data_pending = false;
 	size_t gm_data_bitpos = 0;  // single-section VarDCT frames: where the pass group starts

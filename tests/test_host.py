@@ -224,3 +224,43 @@ def test_from_file_opens_now_and_reads_at_next_frame_like_the_reference(built, t
     msg = subprocess.run([exe_hip, str(tmp_path / "a_directory"), str(tmp_path / "out.png")], capture_output=True, text=True).stderr
     assert "(read)" in msg and "j40_next_frame" in msg, msg
 
+
+def test_streamed_parse_reads_only_what_it_asked_for_and_gives_the_same_frame(built):
+    """SURVEY.md 8f-3 (the reference's refillable source, j40.h:1220-1386, 1676-1812): j40hip_frame_parse_streamed parses while the
+    bytes arrive. The buffer here starts as rubbish and fills only as far as the parser's need(n) calls say (rounded up to 64 bytes or
+    4 KB): the parsed frame -- headers, TOC, LfGlobal, HfGlobal, every LfGroup's planes and varblocks, serialised by lf_bundle -- must
+    be the one the whole buffer gives; when the host's parse returns, the pass-group sections (most of the file) have not been asked
+    for; truncated and damaged streams fail with the whole-buffer parse's code; containers are parsed once complete"""
+    import j40_amd
+    from streams import synth
+    cases = [("vardct", 2600, 2100, 41, dict()), ("vardct", 1920, 1080, 34, dict(forward=1)), ("vardct", 520, 264, 7, dict(icc=700)), ("vardct", 264, 200, 11, dict()),
+             ("vardct", 776, 520, 31, dict(passes=2, permute=1)), ("vardct", 520, 264, 8, dict(container=2))]
+    for mode, w, h, seed, opts in cases:
+        data = synth(mode, w, h, seed, **opts)
+        whole = j40_amd.Frame(data, threads=3)
+        want = whole.lf_bundle()
+        whole.close()
+        for step in (64, 4096):
+            log = []
+            fr = j40_amd.Frame.parse_streamed(data, step=step, threads=3, log=log)
+            assert fr.lf_bundle() == want, (w, h, opts, step)
+            if not opts.get("container") and w >= 1900 and not opts.get("permute"):
+                assert fr.revealed < len(data) // 2, (fr.revealed, len(data))   # the coefficient sections were never asked for
+                assert log[0] == 2 and len(log) >= 4   # the signature, the headers' prefix, the global sections, the LfGroup sections
+            fr.close()
+    data = synth("vardct", 2600, 2100, 41)
+    rng = np.random.default_rng(5)
+    for trial in range(24):
+        bad = bytearray(data)
+        if trial % 3 == 0:
+            bad = bad[: int(rng.integers(2, len(data) // 8))]
+        else:
+            bad[int(rng.integers(2, len(data) // 8))] ^= 1 << int(rng.integers(0, 8))
+        codes = []
+        for parse in (lambda b: j40_amd.Frame(b, threads=2), lambda b: j40_amd.Frame.parse_streamed(b, step=64, threads=2)):
+            try:
+                f = parse(bytes(bad)); f.close(); codes.append("")
+            except j40_amd.J40Error as e:
+                codes.append(e.code)
+        assert codes[0] == codes[1], (trial, codes)
+
