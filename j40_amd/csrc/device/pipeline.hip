@@ -119,6 +119,7 @@ struct j40hip_pipeline {
 	LfFlight lf_flights[4];
 	int lf_flights_used = 4;            // how many of them launch (J40HIP_LF_FLIGHTS); a launch carries up to lf_flight_frames frames
 	int64_t lf_flight_frames = 0;
+	int64_t lf_auto_min = 0;            // mode 0: with nothing in the device's stage, fewer frames than this waiting are the host threads' (J40HIP_LF_AUTO_MIN)
 	double lf_wait_ms = 5.0;            // how long frames wait for a batch's worth of company before a launch takes them alone (J40HIP_LF_WAIT_MS)
 	std::vector<uint32_t> results;      // by ticket
 	std::vector<uint8_t> finished;      // by ticket
@@ -243,7 +244,7 @@ void worker_main(j40hip_pipeline *p, int) {
 			if (p->stop) break;
 			j = p->todo.front(); p->todo.pop_front();
 			++p->resident; ++p->parsing;
-			if (p->lf_mode == 0) lf_dev = p->lf_stage < p->lf_cap && !(p->lf_stage == 0 && (int64_t) p->todo.size() < p->batch_frames / 4);
+			if (p->lf_mode == 0) lf_dev = p->lf_stage < p->lf_cap && !(p->lf_stage == 0 && (int64_t) p->todo.size() < p->lf_auto_min);
 			if (lf_dev) ++p->lf_stage;
 		}
 		const double t0 = now_ms();
@@ -569,6 +570,8 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 		if (const char *e = getenv("J40HIP_LF_FLIGHTS")) p->lf_flights_used = std::max(1, std::min(4, atoi(e)));
 		if (const char *e = getenv("J40HIP_LF_FLIGHT_FRAMES")) p->lf_flight_frames = std::max<int64_t>(1, atoll(e));
 		if (const char *e = getenv("J40HIP_LF_WAIT_MS")) p->lf_wait_ms = std::max(0.0, atof(e));
+		p->lf_auto_min = p->batch_frames / 4;
+		if (const char *e = getenv("J40HIP_LF_AUTO_MIN")) p->lf_auto_min = std::max<int64_t>(0, atoll(e));
 		p->slots.resize((size_t) p->max_in_flight + 1);
 		for (Slot &s : p->slots) {
 			bool made = false;
@@ -747,7 +750,8 @@ void j40hip_pipeline_reset_stats(j40hip_pipeline *p) {
 // several threads are inside the API at once (or J40HIP_SERVE=1), so that callers of the unchanged ten-function sequence share
 // batches. One per device, made on first use, taken down by j40hip_shutdown. Knobs (environment, read once): J40HIP_SERVE_THREADS
 // (host threads; default: half the container's CPU quota), J40HIP_SERVE_BATCH (frames per entropy launch, 64), J40HIP_SERVE_IN_FLIGHT (6),
-// J40HIP_SERVE_LF (host | device | auto: who decodes the LfGroup streams; host -- a frame must not wait 0.4 s for the lane decoder),
+// J40HIP_SERVE_LF (host | device | auto: who decodes the LfGroup streams; auto -- bursts of ten frames per pipeline thread and more go
+// to the device's lane decoder, smaller ones to the host threads: a frame should not wait 0.2 s for a launch it has to itself),
 // J40HIP_SERVE_WAIT_MS (how long a prepared frame waits for a fuller batch while a slot is free, 100: with blocking callers the
 // queue stops growing when every caller has an image in it, and "nothing else is coming" launches the batch at once).
 static std::mutex g_serve_mutex;
@@ -766,10 +770,15 @@ j40hip_pipeline *j40hip_serve_pipeline(int device, uint32_t *err) {
 	// process that runs into its quota has ALL its threads throttled and the copies back crawl. 64 callers over 8K streams on a
 	// 16-CPU quota: 9.9 Gpixel/s with 6 or 8 pipeline threads, 8.2 with 12, 6.4 with 16, 6.2 with 4)
 	const int threads = std::max(1, env_int("J40HIP_SERVE_THREADS", std::max(2, cpu_quota() / 2)));
-	uint32_t lf = 2;
+	// Who decodes the LfGroup streams of the served frames: a host thread takes 12 ms per 8K frame, the device's lane decoder 0.17-0.2 s
+	// per launch whatever it carries. Round 5, 8K streams, 8 pipeline threads: 64 callers 9.9 Gpixel/s with the host threads against 4.1
+	// with the device, 128 callers 3.9 (p90 1.4 s) against 7.7 (p90 0.57 s). So "auto": a burst of at least ten frames per pipeline
+	// thread goes to the device (and what arrives while its stage is busy follows), smaller ones stay with the host threads.
+	uint32_t lf = 0;
 	if (const char *e = getenv("J40HIP_SERVE_LF")) lf = !strcmp(e, "device") ? 1u : !strcmp(e, "auto") ? 0u : 2u;
 	j40hip_pipeline *p = j40hip_pipeline_create_ex(device, threads, std::max(1, env_int("J40HIP_SERVE_BATCH", 64)), env_int("J40HIP_SERVE_IN_FLIGHT", 6), lf | 8u, err);
 	if (!p) return nullptr;
+	if (!getenv("J40HIP_LF_AUTO_MIN")) { std::unique_lock<std::mutex> plock(p->m); p->lf_auto_min = 10 * (int64_t) threads; }
 	const char *w = getenv("J40HIP_SERVE_WAIT_MS");
 	j40hip_pipeline_set_max_wait_ms(p, w && *w ? atof(w) : 100.0);
 	return g_serve[device] = p;
