@@ -496,6 +496,19 @@ __device__ __forceinline__ void stage_event_prefix(uint32_t mine, uint32_t *pref
 // thanks to the odd pitch. Arithmetic = j40__inverse_dct2d (j40.h:5972): IDCT over the columns
 // dimension first, then over rows.
 
+// The run's next tile, when it lies in the same frame (k2_run_bind has stepped `it.tile` to it), starts NB records further on: lanes
+// 0 .. NB - 1 fetch the ordinals (`blk`) of its blocks now, one word each, and have them a whole tile's work later -- the next
+// prologue then asks for a block's record and for its entry of block_events side by side (J40_K2_NO_PREFETCH: as before, the entry
+// after the record)
+#ifdef J40_K2_NO_PREFETCH
+#define K2_PREFETCH_BLK(NB_) do { next_blk_valid = false; } while (0)
+#else
+#define K2_PREFETCH_BLK(NB_) do { \
+		next_blk_valid = BATCH && it.tile < it.tile_end && it.tile < it.frame_end; \
+		if (next_blk_valid && first + (NB_) + tid < count && tid < (NB_)) next_blk = list[first + (NB_) + tid].blk; \
+	} while (0)
+#endif
+
 // (J40_K2_WAVES_PER_EU: an experiment's knob -- asks the compiler to fit the small shapes' kernels into the registers that many
 // wavefronts per SIMD leave)
 #ifndef J40_K2_WAVES_PER_EU
@@ -524,6 +537,7 @@ __global__ void __launch_bounds__(256, (LOGR + LOGC <= 7 ? J40_K2_WAVES_PER_EU :
 	const float *dq = nullptr, *dq_scan = nullptr; const uint16_t *order = nullptr;
 	float qbias0 = 0, qbias1 = 0, qbias2 = 0, qbias_num = 0, kx_lf = 0, kb_lf = 0, x_qm_mul = 0, b_qm_mul = 0;
 	bool sparse = false;
+	int32_t next_blk = 0; bool next_blk_valid = false;   // lane b: the ordinal of block b of the run's NEXT tile, fetched while this one is worked on
 	for (K2Iter it = k2_begin<BATCH>(tile_prefix, nframes); ; ) {
 		int32_t frame, first; bool entered;
 		if (!k2_bind<BATCH>(it, batch, tile_prefix, class_a, class_b, NB, list, count, rgba, stride_bytes, frame, first, entered)) break;
@@ -545,13 +559,19 @@ __global__ void __launch_bounds__(256, (LOGR + LOGC <= 7 ? J40_K2_WAVES_PER_EU :
 		uint32_t nevents = 0;
 		if (tid < nb) {
 			const DevVarblock vb = list[first + tid];
+			// (the block's entry of block_events is asked for together with its record when the tile before this one fetched its
+			// ordinal ahead -- K2_PREFETCH_BLK below --: one round trip to memory in front of the tile instead of two in a row)
+			const int32_t blk = next_blk_valid ? next_blk : vb.blk;
+			uint32_t be0 = 0, be1 = 0, be2 = 0, be3 = 0;
+			if (sparse) { const uint32_t *be = plan.block_events + 4 * (size_t) blk; be0 = be[0]; be1 = be[1]; be2 = be[2]; be3 = be[3]; }
 			VbGeom g;
 			g.coeff_base = vb.coeff_base; g.llf_base = vb.llf_base;
 			g.mult[1] = vb.mult1; g.mult[0] = vb.mult1 * x_qm_mul; g.mult[2] = vb.mult1 * b_qm_mul;   // (varblock_geometry with the frame's factors at hand; j40.h:7078-7080)
 			g.kx_hf = vb.kx_hf; g.kb_hf = vb.kb_hf; g.px = vb.px; g.py = vb.py; g.effw = vb.effw; g.effh = vb.effh;
 			geom[tid] = g; g_out[tid] = (size_t) g.py * stride_bytes + (size_t) g.px * 4;
-			if (sparse) { const uint32_t *be = plan.block_events + 4 * (size_t) vb.blk; for (int k = 0; k < 4; ++k) g_be[tid][k] = be[k]; nevents = be[1] + be[2] + be[3]; }
+			if (sparse) { g_be[tid][0] = be0; g_be[tid][1] = be1; g_be[tid][2] = be2; g_be[tid][3] = be3; nevents = be1 + be2 + be3; }
 		}
+		K2_PREFETCH_BLK(NB);
 		stage_event_prefix<NB>(nevents, ev_prefix, tid);
 		K2_PHASE(0);
 		// ---- load: dequantise + chroma-from-luma + LLF into the LDS tiles ----
@@ -651,6 +671,7 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const 
 	float qbias[3] = {0, 0, 0}, qbias_num = 0, kx_lf = 0, kb_lf = 0, x_qm_mul = 0, b_qm_mul = 0;
 	uint32_t dq_scan_off[5] = {0, 0, 0, 0, 0};   // of the parameter sets 1, 2, 3, 9, 10
 	bool sparse = false;
+	int32_t next_blk = 0; bool next_blk_valid = false;   // (k_vardct_dct: the next tile's block ordinals, fetched ahead)
 	for (K2Iter it = k2_begin<BATCH>(tile_prefix, nframes); ; ) {
 		int32_t frame, first; bool entered;
 		if (!k2_bind<BATCH>(it, batch, tile_prefix, class_a, class_b, NB, list, count, rgba, stride_bytes, frame, first, entered)) break;
@@ -670,16 +691,20 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const 
 		uint32_t nevents = 0;
 		if (tid < nb) {
 			const DevVarblock vb = list[first + tid];
+			const int32_t blk = next_blk_valid ? next_blk : vb.blk;   // (k_vardct_dct)
+			uint32_t be0 = 0, be1 = 0, be2 = 0, be3 = 0;
+			if (sparse) { const uint32_t *be = plan.block_events + 4 * (size_t) blk; be0 = be[0]; be1 = be[1]; be2 = be[2]; be3 = be[3]; }
 			VbGeom g;
 			g.coeff_base = vb.coeff_base; g.llf_base = vb.llf_base;
 			g.mult[1] = vb.mult1; g.mult[0] = vb.mult1 * x_qm_mul; g.mult[2] = vb.mult1 * b_qm_mul;   // (varblock_geometry; j40.h:7078-7080)
 			g.kx_hf = vb.kx_hf; g.kb_hf = vb.kb_hf; g.px = vb.px; g.py = vb.py; g.effw = vb.effw; g.effh = vb.effh;
 			geom[tid] = g;
-			if (sparse) { const uint32_t *be = plan.block_events + 4 * (size_t) vb.blk; for (int k = 0; k < 4; ++k) g_be[tid][k] = be[k]; nevents = be[1] + be[2] + be[3]; }
+			if (sparse) { g_be[tid][0] = be0; g_be[tid][1] = be1; g_be[tid][2] = be2; g_be[tid][3] = be3; nevents = be1 + be2 + be3; }
 			g_sel[tid] = vb.dctsel;
 			g_param[tid] = vb.dctsel == 1 ? 1 : vb.dctsel == 2 ? 2 : vb.dctsel == 3 ? 3 : vb.dctsel <= 13 ? 9 : 10;
 			g_dq[tid] = vb.dctsel == 1 ? dq_scan_off[0] : vb.dctsel == 2 ? dq_scan_off[1] : vb.dctsel == 3 ? dq_scan_off[2] : vb.dctsel <= 13 ? dq_scan_off[3] : dq_scan_off[4];
 		}
+		K2_PREFETCH_BLK(NB);
 		stage_event_prefix<NB>(nevents, ev_prefix, tid);
 		if (sparse) {
 			__syncthreads();

@@ -750,7 +750,7 @@ void j40hip_pipeline_reset_stats(j40hip_pipeline *p) {
 // several threads are inside the API at once (or J40HIP_SERVE=1), so that callers of the unchanged ten-function sequence share
 // batches. One per device, made on first use, taken down by j40hip_shutdown. Knobs (environment, read once): J40HIP_SERVE_THREADS
 // (host threads; default: half the container's CPU quota), J40HIP_SERVE_BATCH (frames per entropy launch, 64), J40HIP_SERVE_IN_FLIGHT (6),
-// J40HIP_SERVE_LF (host | device | auto: who decodes the LfGroup streams; auto -- bursts of ten frames per pipeline thread and more go
+// J40HIP_SERVE_LF (host | device | auto: who decodes the LfGroup streams; auto -- bursts of twelve frames per pipeline thread and more go
 // to the device's lane decoder, smaller ones to the host threads: a frame should not wait 0.2 s for a launch it has to itself),
 // J40HIP_SERVE_WAIT_MS (how long a prepared frame waits for a fuller batch while a slot is free, 100: with blocking callers the
 // queue stops growing when every caller has an image in it, and "nothing else is coming" launches the batch at once).
@@ -772,13 +772,13 @@ j40hip_pipeline *j40hip_serve_pipeline(int device, uint32_t *err) {
 	const int threads = std::max(1, env_int("J40HIP_SERVE_THREADS", std::max(2, cpu_quota() / 2)));
 	// Who decodes the LfGroup streams of the served frames: a host thread takes 12 ms per 8K frame, the device's lane decoder 0.17-0.2 s
 	// per launch whatever it carries. Round 5, 8K streams, 8 pipeline threads: 64 callers 9.9 Gpixel/s with the host threads against 4.1
-	// with the device, 128 callers 3.9 (p90 1.4 s) against 7.7 (p90 0.57 s). So "auto": a burst of at least ten frames per pipeline
+	// with the device, 128 callers 3.9 (p90 1.4 s) against 7.7 (p90 0.57 s). So "auto": a burst of at least twelve frames per pipeline
 	// thread goes to the device (and what arrives while its stage is busy follows), smaller ones stay with the host threads.
 	uint32_t lf = 0;
 	if (const char *e = getenv("J40HIP_SERVE_LF")) lf = !strcmp(e, "device") ? 1u : !strcmp(e, "auto") ? 0u : 2u;
 	j40hip_pipeline *p = j40hip_pipeline_create_ex(device, threads, std::max(1, env_int("J40HIP_SERVE_BATCH", 64)), env_int("J40HIP_SERVE_IN_FLIGHT", 6), lf | 8u, err);
 	if (!p) return nullptr;
-	if (!getenv("J40HIP_LF_AUTO_MIN")) { std::unique_lock<std::mutex> plock(p->m); p->lf_auto_min = 10 * (int64_t) threads; }
+	if (!getenv("J40HIP_LF_AUTO_MIN")) { std::unique_lock<std::mutex> plock(p->m); p->lf_auto_min = 12 * (int64_t) threads; }
 	const char *w = getenv("J40HIP_SERVE_WAIT_MS");
 	j40hip_pipeline_set_max_wait_ms(p, w && *w ? atof(w) : 100.0);
 	return g_serve[device] = p;
