@@ -509,10 +509,11 @@ __device__ __forceinline__ void stage_event_prefix(uint32_t mine, uint32_t *pref
 	} while (0)
 #endif
 
-// (J40_K2_WAVES_PER_EU: an experiment's knob -- asks the compiler to fit the small shapes' kernels into the registers that many
-// wavefronts per SIMD leave)
+// J40_K2_WAVES_PER_EU: the kernels of the small shapes (up to 16 x 8) are asked to fit the registers that eight wavefronts per SIMD
+// leave -- 53-58 instead of 72-77, no spills --, which pays once the prologue's two loads travel together: pixel stage of 256 8K frames
+// alone 58.8-59.2 ms without the prefetch, 57.6-58.7 with it, 56.6-56.8 with both (profiles/r05_ab_k2_prefetch_next_tile_blk_call_h.jsonl)
 #ifndef J40_K2_WAVES_PER_EU
-#define J40_K2_WAVES_PER_EU 1
+#define J40_K2_WAVES_PER_EU 8
 #endif
 template <int LOGR, int LOGC, int NB, bool BATCH>
 __global__ void __launch_bounds__(256, (LOGR + LOGC <= 7 ? J40_K2_WAVES_PER_EU : 1)) k_vardct_dct(DevPlan plan_arg, const DevVarblock *list, int32_t count, int32_t param_idx, int32_t order_idx, uint8_t *rgba, size_t stride_bytes,

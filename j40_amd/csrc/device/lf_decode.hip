@@ -198,17 +198,19 @@ __global__ void __launch_bounds__(64) k_lf_rows(const DevLfLaneSet *sets, const 
 	lf_row_init(L, t, wins + (active ? my_section : 0) * LF_ROW_PITCH);   // (a lane without a section never writes its window)
 	if (!active) { L.chan = 7; L.setup = false; }   // (the first general step finds it finished)
 	if (!PAIRS) {
-		// every iteration each lane decodes one sample: the lanes inside a run of plain samples take the straight-line step together;
-		// then, if some lane is at a channel start, a row's end or in a channel of another form, those lanes take the general step
-		// (which says how long the lane's next run is) and finished rows leave
+		// Every pass: the lanes run through their stretches of plain samples (lf_row_run_plain, in the instantiation that covers what
+		// their channels need), until some live lane is at a channel start, a row's end or in a channel of another form; those lanes
+		// then take the general step (which says how long the lane's next run is), finished rows leave, and the needs are taken again
+		uint32_t need = LF_NEED_ALL;
 		for (;;) {
+			lf_row_run_plain(L, T, need);
 			const bool plain = L.plain_left > 0;
-			if (plain) lf_row_step_plain(L, T);
-			if (__builtin_amdgcn_ballot_w64(!plain & L.live)) {
-				if (!plain) lf_row_step(L, t, T);
-				if (__builtin_amdgcn_ballot_w64(L.flush_n > 0)) lf_row_flush_wave(L, lane);
-				if (!__builtin_amdgcn_ballot_w64(L.live)) break;
-			}
+			if (!plain) lf_row_step(L, t, T);
+			if (__builtin_amdgcn_ballot_w64(L.flush_n > 0)) lf_row_flush_wave(L, lane);
+			if (!__builtin_amdgcn_ballot_w64(L.live)) break;
+			const uint32_t mine = lf_plain_needs(L);
+			need = 0;
+			for (uint32_t bit = 1; bit <= 16; bit <<= 1) need |= __builtin_amdgcn_ballot_w64((mine & bit) != 0) ? bit : 0u;
 		}
 	} else {
 		LfRowLane M;   // the lane's second section

@@ -329,12 +329,21 @@ J40_DEV int32_t lf_unzigzag(int32_t u) { return (int32_t) ((uint32_t) u >> 1) ^ 
 // The step runs at about nine cycles per instruction either way (1 690 cycles for its 185, mostly 8-byte encodings); the
 // microbenchmark's best, four independent chains of 4-byte instructions, was 5.3. What bounds a lone wavefront here is not the
 // dependence between its instructions but how fast it is fed them, and only fewer (or shorter) instructions per sample help.
+// What the lanes of a wavefront need of the step, taken together (wave-uniform; lf_plain_needs, recomputed whenever a lane has been
+// through the general step): the step is instantiated for every combination and the kernel jumps to the one that covers its lanes --
+// a wavefront whose lanes all sit in leaf-only channels predicted by the clamped gradient runs 150 instructions a sample, not 185.
+enum { LF_NEED_TEST = 1,    // some lane's channel has a test (two different leaf words)
+       LF_NEED_LIN = 2, LF_NEED_SEL = 4, LF_NEED_GRAD = 8,   // the predictions some lane uses: a (halved) sum of neighbours, "select", the clamped gradient
+       LF_NEED_MUL = 16,    // some lane's leaves have a multiplier other than 1 or an offset
+       LF_NEED_ALL = 31 };
+
 struct LfPlainCtx {
 	int32_t x, slot, ahead3, pw, pn, pnw, pne, pww;
 	uint32_t word, idx, bucket; uint64_t entry;
 };
 
 // refill, neighbours, the property and the walk; asks LDS for the alias entry and the row above's next sample
+template <uint32_t NEED>
 J40_DEV void lf_plain_front(LfRowLane &L, const LfRowTables &T, LfPlainCtx &c) {
 	LaneBits &b = L.b;
 	{   // lane_bits_refill as selects; the word after next is asked for every time (the same word again when nothing was appended)
@@ -355,10 +364,12 @@ J40_DEV void lf_plain_front(LfRowLane &L, const LfRowTables &T, LfPlainCtx &c) {
 	const int32_t pnww = x > 1 && up ? L.a0 : pww;
 	c.pw = pw; c.pn = pn; c.pnw = pnw; c.pne = pne; c.pww = pww;
 	// the property and the walk: one test, or none (both words the leaf's)
-	int32_t val = lf_mad24(L.c_x, x, lf_mad24(L.c_y, y, lf_mad24(L.c_w, pw, lf_mad24(L.c_n, pn, 0)))) + lf_mad24(L.c_nw, pnw, lf_mad24(L.c_ne, pne, lf_mad24(L.c_ww, pww, lf_mad24(L.c_nww, pnww, 0))));   // (two chains of four)
-	val = L.c_abs ? mod_abs(val) : val;
-	val = L.c_first && !left ? pw : val;
-	c.word = val > L.k_thr ? L.k_word_gt : L.k_word_le;
+	if (NEED & LF_NEED_TEST) {
+		int32_t val = lf_mad24(L.c_x, x, lf_mad24(L.c_y, y, lf_mad24(L.c_w, pw, lf_mad24(L.c_n, pn, 0)))) + lf_mad24(L.c_nw, pnw, lf_mad24(L.c_ne, pne, lf_mad24(L.c_ww, pww, lf_mad24(L.c_nww, pnww, 0))));   // (two chains of four)
+		val = L.c_abs ? mod_abs(val) : val;
+		val = L.c_first && !left ? pw : val;
+		c.word = val > L.k_thr ? L.k_word_gt : L.k_word_le;
+	} else c.word = L.k_word_le;   // (no lane tests anything: both words are the leaf's)
 	// the alias entry of the state's bucket in the leaf's cluster (lane_symbol_in_cluster)
 	c.idx = L.state & 0xfff; c.bucket = c.idx >> T.log_bucket;
 	c.entry = T.alias[((c.word >> 24) << T.log_alpha) + c.bucket];
@@ -366,6 +377,7 @@ J40_DEV void lf_plain_front(LfRowLane &L, const LfRowTables &T, LfPlainCtx &c) {
 
 // the symbol (rANS step + hybrid integer, lane_symbol_in_cluster<STRAIGHT> from the alias entry on), the prediction, the sample;
 // returns the sample, *code = the error this sample raises (0: none)
+template <uint32_t NEED>
 J40_DEV int32_t lf_plain_middle(LfRowLane &L, const LfRowTables &T, const LfPlainCtx &c, uint32_t *code) {
 	LaneBits &b = L.b;
 	const uint32_t m = c.word & (uint32_t) LF_LEAF_CFG_MASK, pos = c.idx & ((1u << T.log_bucket) - 1);
@@ -394,12 +406,20 @@ J40_DEV int32_t lf_plain_middle(LfRowLane &L, const LfRowTables &T, const LfPlai
 	const uint32_t e2 = short1 ? (uint32_t) ERR_SHRT : iovf ? (uint32_t) ERR_IOVF : short2 ? (uint32_t) ERR_SHRT : 0u;
 	const int32_t u = big ? value : token;
 	// the prediction
-	int32_t lin = lf_mad24(L.p_w, c.pw, lf_mad24(L.p_n, c.pn, 0)) + lf_mad24(L.p_nw, c.pnw, lf_mad24(L.p_ne, c.pne, lf_mad24(L.p_ww, c.pww, 0)));
-	lin = L.p_half ? (lin + (int32_t) ((uint32_t) lin >> 31)) >> 1 : lin;   // (a + b) / 2, towards zero
-	const int32_t sel = mod_abs(c.pn - c.pnw) < mod_abs(c.pw - c.pnw) ? c.pw : c.pn;
-	const int32_t grad = mod_gradient(c.pw, c.pn, c.pnw);
-	const int32_t pred = L.p_kind == 1 ? sel : L.p_kind == 2 ? grad : lin;
-	const int32_t v = lf_unzigzag(u) * L.p_mul + L.p_off + pred;
+	int32_t pred = 0;
+	if (NEED & LF_NEED_LIN) {
+		int32_t lin = lf_mad24(L.p_w, c.pw, lf_mad24(L.p_n, c.pn, 0)) + lf_mad24(L.p_nw, c.pnw, lf_mad24(L.p_ne, c.pne, lf_mad24(L.p_ww, c.pww, 0)));
+		pred = L.p_half ? (lin + (int32_t) ((uint32_t) lin >> 31)) >> 1 : lin;   // (a + b) / 2, towards zero
+	}
+	if (NEED & LF_NEED_SEL) {
+		const int32_t sel = mod_abs(c.pn - c.pnw) < mod_abs(c.pw - c.pnw) ? c.pw : c.pn;
+		pred = (NEED & (LF_NEED_LIN | LF_NEED_GRAD)) ? (L.p_kind == 1 ? sel : pred) : sel;   // (the only kind around: no lane to tell apart)
+	}
+	if (NEED & LF_NEED_GRAD) {
+		const int32_t grad = mod_gradient(c.pw, c.pn, c.pnw);
+		pred = (NEED & (LF_NEED_LIN | LF_NEED_SEL)) ? (L.p_kind == 2 ? grad : pred) : grad;
+	}
+	const int32_t v = ((NEED & LF_NEED_MUL) ? lf_unzigzag(u) * L.p_mul + L.p_off : lf_unzigzag(u)) + pred;
 	*code = e2 ? e2 : v < -32768 || v > 32767 ? (uint32_t) ERR_POVF : 0u;
 	return v;
 }
@@ -415,20 +435,66 @@ J40_DEV void lf_plain_commit(LfRowLane &L, const LfPlainCtx &c, int32_t v, uint3
 	L.x = c.x + 1;
 }
 
-J40_DEV void lf_row_step_plain(LfRowLane &L, const LfRowTables &T) {
+template <uint32_t NEED>
+J40_DEV void lf_row_step_plain_for(LfRowLane &L, const LfRowTables &T) {
 	LfPlainCtx c; uint32_t code;
-	lf_plain_front(L, T, c);
-	const int32_t v = lf_plain_middle(L, T, c, &code);
+	lf_plain_front<NEED>(L, T, c);
+	const int32_t v = lf_plain_middle<NEED>(L, T, c, &code);
 	lf_plain_commit(L, c, v, code);
 }
+J40_DEV void lf_row_step_plain(LfRowLane &L, const LfRowTables &T) { lf_row_step_plain_for<LF_NEED_ALL>(L, T); }
+
+// this lane's share of the wavefront's needs (0 for a lane that takes no plain step)
+J40_DEV uint32_t lf_plain_needs(const LfRowLane &L) {
+	if (!(L.live & L.plain_ok)) return 0;
+	return (L.k_word_gt != L.k_word_le ? (uint32_t) LF_NEED_TEST : 0u) | (L.p_kind == 0 ? (uint32_t) LF_NEED_LIN : L.p_kind == 1 ? (uint32_t) LF_NEED_SEL : (uint32_t) LF_NEED_GRAD)
+		| (L.p_mul != 1 || L.p_off != 0 ? (uint32_t) LF_NEED_MUL : 0u);
+}
+// the step for lanes whose needs add up to `need`
+#define LF_PLAIN_CASE(n) case n: lf_row_step_plain_for<n>(L, T); break;
+J40_DEV void lf_row_step_plain_needs(LfRowLane &L, const LfRowTables &T, uint32_t need) {
+	switch (need) {
+	LF_PLAIN_CASE(0) LF_PLAIN_CASE(1) LF_PLAIN_CASE(2) LF_PLAIN_CASE(3) LF_PLAIN_CASE(4) LF_PLAIN_CASE(5) LF_PLAIN_CASE(6) LF_PLAIN_CASE(7)
+	LF_PLAIN_CASE(8) LF_PLAIN_CASE(9) LF_PLAIN_CASE(10) LF_PLAIN_CASE(11) LF_PLAIN_CASE(12) LF_PLAIN_CASE(13) LF_PLAIN_CASE(14) LF_PLAIN_CASE(15)
+	LF_PLAIN_CASE(16) LF_PLAIN_CASE(17) LF_PLAIN_CASE(18) LF_PLAIN_CASE(19) LF_PLAIN_CASE(20) LF_PLAIN_CASE(21) LF_PLAIN_CASE(22) LF_PLAIN_CASE(23)
+	LF_PLAIN_CASE(24) LF_PLAIN_CASE(25) LF_PLAIN_CASE(26) LF_PLAIN_CASE(27) LF_PLAIN_CASE(28) LF_PLAIN_CASE(29) LF_PLAIN_CASE(30)
+	default: lf_row_step_plain_for<LF_NEED_ALL>(L, T); break;
+	}
+}
+#undef LF_PLAIN_CASE
+#ifdef __HIPCC__
+// The kernel's inner loop: the wavefront's lanes step through their runs of plain samples until some live lane is out of its run
+// (a channel start, a row's end: the caller's business). The choice among the instantiations is made once per such stretch -- a
+// wave-uniform switch is a tree of scalar branches, too dear to walk per sample --, a stretch being hundreds of samples.
+template <uint32_t NEED>
+J40_DEV void lf_row_run_plain_for(LfRowLane &L, const LfRowTables &T) {
+	for (;;) {   // (the lanes in a run step at least once per call: a lane that stays in a channel of another form does not hold them up)
+		const bool plain = L.plain_left > 0;
+		if (!__builtin_amdgcn_ballot_w64(plain)) return;
+		if (plain) lf_row_step_plain_for<NEED>(L, T);
+		if (__builtin_amdgcn_ballot_w64(!(L.plain_left > 0) & L.live)) return;
+	}
+}
+#define LF_PLAIN_CASE(n) case n: lf_row_run_plain_for<n>(L, T); break;
+J40_DEV void lf_row_run_plain(LfRowLane &L, const LfRowTables &T, uint32_t need) {
+	switch (need) {
+	LF_PLAIN_CASE(0) LF_PLAIN_CASE(1) LF_PLAIN_CASE(2) LF_PLAIN_CASE(3) LF_PLAIN_CASE(4) LF_PLAIN_CASE(5) LF_PLAIN_CASE(6) LF_PLAIN_CASE(7)
+	LF_PLAIN_CASE(8) LF_PLAIN_CASE(9) LF_PLAIN_CASE(10) LF_PLAIN_CASE(11) LF_PLAIN_CASE(12) LF_PLAIN_CASE(13) LF_PLAIN_CASE(14) LF_PLAIN_CASE(15)
+	LF_PLAIN_CASE(16) LF_PLAIN_CASE(17) LF_PLAIN_CASE(18) LF_PLAIN_CASE(19) LF_PLAIN_CASE(20) LF_PLAIN_CASE(21) LF_PLAIN_CASE(22) LF_PLAIN_CASE(23)
+	LF_PLAIN_CASE(24) LF_PLAIN_CASE(25) LF_PLAIN_CASE(26) LF_PLAIN_CASE(27) LF_PLAIN_CASE(28) LF_PLAIN_CASE(29) LF_PLAIN_CASE(30)
+	default: lf_row_run_plain_for<LF_NEED_ALL>(L, T); break;
+	}
+}
+#endif
+#undef LF_PLAIN_CASE
 
 // two sections (each with the tables of its frame), one sample each
 J40_DEV void lf_row_step_plain2(LfRowLane &A, LfRowLane &B, const LfRowTables &TA, const LfRowTables &TB) {
 	LfPlainCtx ca, cb; uint32_t code_a, code_b;
-	lf_plain_front(A, TA, ca);
-	lf_plain_front(B, TB, cb);
-	const int32_t va = lf_plain_middle(A, TA, ca, &code_a);
-	const int32_t vb = lf_plain_middle(B, TB, cb, &code_b);
+	lf_plain_front<LF_NEED_ALL>(A, TA, ca);
+	lf_plain_front<LF_NEED_ALL>(B, TB, cb);
+	const int32_t va = lf_plain_middle<LF_NEED_ALL>(A, TA, ca, &code_a);
+	const int32_t vb = lf_plain_middle<LF_NEED_ALL>(B, TB, cb, &code_b);
 	lf_plain_commit(A, ca, va, code_a);
 	lf_plain_commit(B, cb, vb, code_b);
 }

@@ -940,7 +940,7 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_lanes_check
 // LF_ROW_PITCH, completed pieces copied out between the steps. `win` caps the row length served from the window for the test's
 // purposes only through the stream's own sizes (LF_ROW_WIN is a compile-time constant); frames wider than 256 cells per LfGroup
 // do not exist, the varblock-info channel exercises the wide path.
-static int64_t plain_steps = 0, general_steps = 0;
+static int64_t plain_steps = 0, general_steps = 0, need_seen[32];
 static int32_t general_only = 0;
 // (how many samples of the last checks went through the straight-line step / the general one; mode 1: the general step only)
 extern "C" __attribute__((visibility("default"))) void hostsim_lf_rows_counts(int64_t *plain, int64_t *general, int32_t reset, int32_t mode) {
@@ -949,6 +949,8 @@ extern "C" __attribute__((visibility("default"))) void hostsim_lf_rows_counts(in
 	if (reset) plain_steps = general_steps = 0;
 	general_only = mode;
 }
+// (how often each combination of needs -- LF_NEED_* -- was what the stepped lanes asked for, since the library was loaded)
+extern "C" __attribute__((visibility("default"))) void hostsim_lf_rows_needs_seen(int64_t *out32) { for (int i = 0; i < 32; ++i) out32[i] = need_seen[i]; }
 extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_check(const uint8_t *buf, size_t size, int32_t lanes, int32_t *sections, int32_t *failed) {
 	const uint8_t *cs; size_t cs_size; std::vector<uint8_t> storage;
 	Frame fr;
@@ -1001,6 +1003,11 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_check(
 			// (the kernel's dispatch: the straight-line step where the lane's sample allows it; mode bit 1: two sections per lane, both
 			// through lf_row_step_plain2 when both are inside a run -- k_lf_rows<true>)
 			const size_t per = (general_only & 2) ? 2 : 1;
+			// (what the stepped lanes ask of the plain step together, as the kernel works it out after every general step: the
+			// instantiation that covers them all)
+			uint32_t need = 0;
+			for (size_t k = 0; k < n; ++k) need |= lf_plain_needs(L[k]);
+			if (per == 1) ++need_seen[need & 31];
 			for (size_t k = 0; k < n; k += per) {
 				const bool two = per == 2 && k + 1 < n;
 				LfRowLane &A = L[k], &B = L[two ? k + 1 : k];
@@ -1009,7 +1016,7 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_check(
 				const bool pa = A.plain_left > 0 && !(general_only & 1), pb = two && B.plain_left > 0 && !(general_only & 1);
 				if (pa && pb) { lf_row_step_plain2(A, B, T, T); plain_steps += 2; }
 				else {
-					if (pa) { lf_row_step_plain(A, T); ++plain_steps; }
+					if (pa) { if (per == 1) lf_row_step_plain_needs(A, T, need); else lf_row_step_plain(A, T); ++plain_steps; }
 					if (pb) { lf_row_step_plain(B, T); ++plain_steps; }
 				}
 				if (!pa && !lf_row_done(A)) { lf_row_step(A, out[k].t, T); ++general_steps; }

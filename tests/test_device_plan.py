@@ -189,3 +189,18 @@ def test_lanes_take_the_groups_by_decreasing_section_size(built):
         for a, b in zip(range(n - 1), range(1, n)):
             if along[a] == along[b]:
                 assert order[a] < order[b]
+
+
+def test_lf_row_window_decoder_specialised_steps_all_ran(lanes):
+    """lf_row_step_plain_needs: the plain step instantiated per combination of what a wavefront's lanes need (a test or none, which
+    predictions, multipliers); the cases above and below run at least eight different combinations through it, each against the host
+    decoder's planes"""
+    for (w, h, seed, opts) in [(2600, 2100, 61, dict(lftree=2)), (2600, 2100, 62, dict(lftree=3)), (1920, 1080, 34, dict(forward=1)), (520, 264, 63, dict(lftree=2, cfl=1))]:
+        for nl in (1, 2, 64):
+            rc, n, bad = rows_check(lanes, synth("vardct", w, h, seed, **opts), nl)
+            assert rc == 0 and bad == 0
+    seen = (C.c_int64 * 32)()
+    lanes.hostsim_lf_rows_needs_seen(seen)
+    used = [i for i in range(32) if seen[i]]
+    assert len(used) >= 8, used
+
