@@ -51,7 +51,7 @@ if only in ("", "lf_alone"):
     pipe.close()
 if only in ("", "device"):
     pipe = j40_amd.Pipeline(0, int(os.environ.get("PROBE_THREADS", "4")), B, 2, lf_streams="device")
-    run_pipeline_steps(pipe, sb, ss, so, W * 4, True, 1, torch, dev, None)
+    run_pipeline_steps(pipe, sb, ss, so, W * 4, True, 2, torch, dev, None)   # (two: the cache is sized at the second full batch)
     el, tk = run_pipeline_steps(pipe, sb, ss, so, W * 4, True, steps, torch, dev, None)
     assert all(pipe.result(t) == "" for t in tk)
     out["device"] = dict(per_launch(pipe.stats()), ms_per_step=round(el / steps * 1e3, 2), mpixels_per_s=round(W * H * B * steps / el / 1e6, 1), steps=steps)
