@@ -7,7 +7,7 @@
 #      alone, the pipeline with the pixels left in HBM (the stages overlapped as in the steady state)
 #   4. PMC passes over that last command, one counter group per pass (FETCH_SIZE; WRITE_SIZE; two SQ groups), j40hip's kernels only
 #      -> r05_pmc_traffic.json (bench.py's roofline.stages[].traffic)
-#   5. the public API: one caller (latency), 64 and 128 callers
+#   0. (first, on the fresh box) the public API: one caller (latency), 64 and 128 callers; config 5 with the LfGroup streams on either side
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/r05; mkdir -p $O
@@ -16,6 +16,17 @@ export TMPDIR=/tmp
 timeout 300 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1
 COMMIT=$(cat $R/.commit_for_profiles 2>/dev/null || echo unknown)
 echo $COMMIT > $O/commit.txt
+python - <<'PY' > $O/synth.log 2>&1
+import sys; sys.path.insert(0, "tests")
+from streams import synth
+for i in range(4): synth("vardct", 7680, 4320, 3 + 1000 * i, forward=1)
+PY
+P8K=$(ls $R/build/streams/vardct_7680_4320_*forward-1.jxl | head -4 | tr '\n' ' ')
+J40HIP_API_TIMING=1 J40HIP_SERVE=0 timeout 200 $R/build/api_threads 1 8 --warm 2 $P8K > $O/api_one_thread_latency.json 2> $O/api_one_thread_latency.err
+timeout 300 $R/build/api_threads 64 8 --warm 3 --verify-every 8 $P8K > $O/api_64_threads.json 2> $O/api_64_threads.err
+timeout 300 $R/build/api_threads 128 8 --warm 3 --verify-every 8 $P8K > $O/api_128_threads.json 2> $O/api_128_threads.err
+timeout 120 python $R/tools/config5_probe.py 512 2 host > $O/config5_lf_host.json 2> $O/config5_lf_host.err
+timeout 120 python $R/tools/config5_probe.py 512 2 device 4 > $O/config5_lf_device.json 2> $O/config5_lf_device.err
 timeout 900 python -u -m pytest tests -m gpu -q -p no:cacheprovider > $O/gputest_full.txt 2>&1; tail -n 6 $O/gputest_full.txt > $O/gputest.txt; echo "gputest rc=$?" >> $O/rc.txt
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc=$?" >> $O/rc.txt
 timeout 600 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench_default rc=$?" >> $O/rc.txt
@@ -35,9 +46,5 @@ rm -rf /tmp/pmc_fetch /tmp/pmc_write
 pmc sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU"
 pmc sq2 "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_INSTS_SMEM"
 rm -rf /tmp/pmc_sq1 /tmp/pmc_sq2
-P8K=$(ls $R/build/streams/vardct_7680_4320_*forward-1.jxl | head -4 | tr '\n' ' ')
-J40HIP_API_TIMING=1 J40HIP_SERVE=0 timeout 200 $R/build/api_threads 1 8 --warm 2 $P8K > $O/api_one_thread_latency.json 2> $O/api_one_thread_latency.err
-timeout 300 $R/build/api_threads 64 8 --warm 3 --verify-every 8 $P8K > $O/api_64_threads.json 2> $O/api_64_threads.err
-timeout 300 $R/build/api_threads 128 8 --warm 3 --verify-every 8 $P8K > $O/api_128_threads.json 2> $O/api_128_threads.err
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 $R/tools/rccl_dry_run.py > $O/rccl_dry_run.json 2> $O/rccl_dry_run.err
-cat $O/rc.txt; cat $O/gputest.txt; tail -n 4 $O/smoke.txt; cut -c1-700 $O/bench_default.json; echo; cut -c1-300 $O/bench_steps20_warmup5.json; echo; cat $O/probe_*.json | cut -c1-900; grep -h "k_lf_rows\|k_hf_lanes\|k_vardct_dct<3, 3\|k_vardct_special\|k_plan_place" $O/kernel_stats_*.txt | cut -c1-60,108-190; cat $O/pmc_traffic.log | cut -c1-900; tail -n 1 $O/api_one_thread_latency.json | cut -c1-400; tail -n 1 $O/api_64_threads.json | cut -c1-400; tail -n 1 $O/api_128_threads.json | cut -c1-400; tail -n 1 $O/rccl_dry_run.json | cut -c1-300
+cat $O/rc.txt; cat $O/gputest.txt; tail -n 4 $O/smoke.txt; cut -c1-700 $O/bench_default.json; echo; cut -c1-300 $O/bench_steps20_warmup5.json; echo; cat $O/probe_*.json | cut -c1-900; grep -h "k_lf_rows\|k_hf_lanes\|k_vardct_dct<3, 3\|k_vardct_special\|k_plan_place" $O/kernel_stats_*.txt | cut -c1-60,108-190; cat $O/pmc_traffic.log | cut -c1-900; tail -n 1 $O/api_one_thread_latency.json | cut -c1-400; tail -n 1 $O/api_64_threads.json | cut -c1-400; tail -n 1 $O/api_128_threads.json | cut -c1-400; tail -n 1 $O/rccl_dry_run.json | cut -c1-300; cat $O/config5_lf_host.json $O/config5_lf_device.json
