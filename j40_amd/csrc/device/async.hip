@@ -504,6 +504,9 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 	bool lanes_fast = true, tables_in_lds = true; uint32_t lanes_lds = 0, generic_lds = 0;
 	int32_t total_waves = 0, max_frame_waves = 1, nlf = 0, max_lf_cells = 0; size_t cells_total = 0, max_frame_cells = 0;
 	const double tq0 = prof_now();
+	uint64_t cc0[10] = {0}, cc1[10] = {0};
+	const bool timing = getenv("J40HIP_ASYNC_TIMING") != nullptr;
+	if (timing) j40hip_cache_counters(cc0);
 	for (int i = 0; i < n; ++i) {
 		j40hip_aframe *f = frames[i];
 		if (!f || f->device != b->device) return ERR_GPU;
@@ -555,6 +558,10 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 		// first. A workgroup's wavefront w runs on SIMD w % 4: the second half of every workgroup is reversed, which puts the
 		// longest beside the shortest, the second longest beside the second shortest ... -- four SIMDs with about equal work
 		for (size_t a = first_entry; a + (size_t) waves_per_wg <= work.size(); a += (size_t) waves_per_wg) std::reverse(work.begin() + (long) (a + (size_t) waves_per_wg / 2), work.begin() + (long) (a + (size_t) waves_per_wg));
+		// (... and, bit 1 of `pad`, the second half at a lower priority than the first when two wavefronts share a SIMD: the launch
+		// ends with the wavefronts that have the largest sections, which then wait for nobody. J40HIP_K1_RANK_PRIO=0: all alike)
+		static const bool rank_prio = [] { const char *e = getenv("J40HIP_K1_RANK_PRIO"); return e ? atoi(e) != 0 : false; }();
+		if (rank_prio && waves_per_wg >= 8) for (size_t a = first_entry; a + (size_t) waves_per_wg <= work.size(); a += (size_t) waves_per_wg) for (size_t k = (size_t) waves_per_wg / 2; k < (size_t) waves_per_wg; ++k) work[a + k].pad |= 2;
 	}
 	for (int i = 0; i < n; ++i) {
 		HfLaunchInfo info = frames[i]->hf; info.tables_fit_lds = tables_in_lds;
@@ -600,6 +607,7 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 	if (queue_waves) memcpy(hb + o_queue, queue_start.data(), 4 * queue_start.size());
 	if (uint32_t e = wait_for_uploads(frames, n, s)) return e;
 	const double tq1 = prof_now();
+	if (timing) j40hip_cache_counters(cc1);
 	if (hipMemcpyAsync(db, hb, copy_bytes, hipMemcpyHostToDevice, s) != hipSuccess) return ERR_GPU;
 	const double tq2 = prof_now();
 	// recycled memory: no entry of the per-block tables may point outside the event lists (a section that fails leaves entries unwritten)
@@ -622,7 +630,12 @@ static uint32_t abatch_launch_body(j40hip_abatch *b, j40hip_aframe *const *frame
 	launch_plan_verdict(d_builds, d_plans, n, s);
 	if (hipMemcpyAsync(b->verdict_host, db + o_verdict, 16 * (size_t) n + 64, hipMemcpyDeviceToHost, s) != hipSuccess) return ERR_GPU;
 	b->nframes = n; b->have_totals = true;
-	if (getenv("J40HIP_ASYNC_TIMING")) { const double tq4 = prof_now(); fprintf(stderr, "[j40hip batch launch] bind %.2f (+arrays) %.2f, copy %.2f, plan+tail enqueue %.2f, K1+K2+verdict enqueue %.2f ms\n", tq1 - tq0, 0.0, tq2 - tq1, tq3 - tq2, tq4 - tq3); }
+	if (timing) {
+		const double tq4 = prof_now();
+		fprintf(stderr, "[j40hip batch launch] bind %.2f (+arrays) %.2f, copy %.2f, plan+tail enqueue %.2f, K1+K2+verdict enqueue %.2f ms; the cache meanwhile (every thread's calls): %llu acquires, %llu hits, %llu + %llu hipMalloc %.2f ms, %llu hipFree %.2f ms, lock %.2f ms, search %.2f ms, %llu idle blocks\n",
+			tq1 - tq0, 0.0, tq2 - tq1, tq3 - tq2, tq4 - tq3, (unsigned long long) (cc1[0] - cc0[0]), (unsigned long long) (cc1[1] - cc0[1]), (unsigned long long) (cc1[2] - cc0[2]), (unsigned long long) (cc1[3] - cc0[3]), (double) (cc1[7] - cc0[7]) * 1e-3,
+			(unsigned long long) (cc1[4] - cc0[4]), (double) (cc1[8] - cc0[8]) * 1e-3, (double) (cc1[5] - cc0[5]) * 1e-3, (double) (cc1[6] - cc0[6]) * 1e-3, (unsigned long long) cc1[9]);
+	}
 	return hipGetLastError() == hipSuccess ? 0 : ERR_GPU;
 }
 

@@ -33,7 +33,7 @@ static const int16_t DEV_NNZ_CTX2[64] = {
 	360, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412, 412,
 };
 
-J40_DEV int32_t unpack_signed_dev(int32_t x) { return (x & 1) ? -(x / 2 + 1) : x / 2; }
+J40_DEV int32_t unpack_signed_dev(int32_t x) { return (x / 2) ^ -(x & 1); }   // (x & 1) ? -(x / 2 + 1) : x / 2 for every x (-(h + 1) = ~h), without the branch the compiler made of it
 
 // what one section decode reads besides the bitstream. The kernel stages these in LDS when they fit
 // (the serial decoder then never waits on HBM for a table), otherwise they point into HBM.

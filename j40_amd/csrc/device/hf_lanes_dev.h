@@ -108,9 +108,10 @@ J40_DEV uint32_t lane_bit_position(const LaneBits &b) { return 8u * b.pos - (uin
 // STRAIGHT: the caller vouches that the state has been read (state != 0) and that the cluster's tokens never ask for more than 17
 // extra bits (33 buffered - 16 of a renormalisation): the symbol is then one basic block, no branch at all -- a lone wavefront pays
 // about sixty cycles for every `if` it walks past, taken or not (lf_rows_dev.h)
-template <bool STRAIGHT = false, class AliasPtr>
+// STARTED: only the first of the two is vouched for (the state has been read; a token may still ask for a second refill).
+template <bool STRAIGHT = false, bool STARTED = false, class AliasPtr>
 J40_DEV int32_t lane_symbol_in_cluster(LaneBits &b, uint32_t &state, AliasPtr alias, int32_t log_alpha, int32_t log_bucket, uint32_t cl, uint32_t m, uint32_t end_bit, uint32_t *err) {
-	if (!STRAIGHT && state == 0) {   // first symbol of the section (j40.h:2445-2449); the window holds > 32 bits
+	if (!STRAIGHT && !STARTED && state == 0) {   // first symbol of the section (j40.h:2445-2449); the window holds > 32 bits
 		state = lane_bits_take(b, 16); state |= lane_bits_take(b, 16) << 16;
 		lane_bits_refill(b);
 	}
@@ -179,6 +180,15 @@ struct LaneSection {
 // a lane's 4-byte stores, each into a line of its own that its next store reaches hundreds of cycles later, left the L2 as partly
 // written sectors over and over -- 21 GB of writes per 256 8K frames for 4 GB of events. The check runs every J40_LANE_EV_FLUSH-th
 // turn (a turn adds at most one event, so twice that many slots suffice); what is left at a section's end leaves word by word.
+#ifndef J40_LANE_NZ_PERIOD
+#define J40_LANE_NZ_PERIOD 8
+#endif
+#ifndef J40_LANE_STRAIGHT_COEFFS
+#define J40_LANE_STRAIGHT_COEFFS 1
+#endif
+#ifndef J40_LANE_REFILL_SELECTS
+#define J40_LANE_REFILL_SELECTS 0   // (measured with the event ring, whose turns store nothing: call K)
+#endif
 template <bool SCAN, class Source>
 J40_DEV void decode_hf_sections_lane(const LaneFrame &f, const LaneTables &t, const LaneGlobals &G, Source &src, J40_LDS int8_t *cols, int32_t col_stride, int32_t pass, J40_LDS uint32_t *ring = nullptr, int32_t ring_stride = 0) {
 	LaneSection S;
@@ -201,6 +211,74 @@ J40_DEV void decode_hf_sections_lane(const LaneFrame &f, const LaneTables &t, co
 	uint32_t blk_first = 0, blk_n0 = 0, blk_n1 = 0;   // the block's table entry, stored in one piece after its third channel
 	uint32_t next0 = 0, next1 = 0;   // descriptor of block k, requested one block ahead
 	for (uint32_t turn = 0; ; ++turn) {
+#if J40_LANE_EV_FLUSH
+		// (the turn is the same in every lane: a scalar branch that skips the per-lane test seven turns in eight -- kept apart from it by
+		// the empty statement, or the compiler folds both into one vector condition evaluated every turn)
+		if (SCAN && (turn % J40_LANE_EV_FLUSH) == 0) {
+#ifdef __HIPCC__
+			asm volatile("");
+#endif
+			if (ev_at - ev_flushed >= (uint32_t) J40_LANE_EV_FLUSH) {
+			const J40_LDS uint32_t *r = ring + (int32_t) (ev_flushed % (uint32_t) HF_LANE_RING_SLOTS) * ring_stride;   // (a run of slots: regions and pieces are aligned)
+			J40_GLOBAL uint32_t *dst = (J40_GLOBAL uint32_t *) G.events + ev_flushed;
+#pragma unroll
+			for (int32_t k4 = 0; k4 < J40_LANE_EV_FLUSH; k4 += 4) {
+				LaneEventQuad q4;
+				q4[0] = r[k4 * ring_stride]; q4[1] = r[(k4 + 1) * ring_stride]; q4[2] = r[(k4 + 2) * ring_stride]; q4[3] = r[(k4 + 3) * ring_stride];
+				*(J40_GLOBAL LaneEventQuad *) (dst + k4) = q4;
+			}
+			ev_flushed += (uint32_t) J40_LANE_EV_FLUSH;
+			}
+		}
+#endif
+		// ---- a coefficient of the current (block, channel), sparse form: the symbol nine turns in ten, on a path of its own ----
+		// A wavefront alone on its SIMD pays about sixty cycles for every `if` it walks past, executed or not (lf_rows_dev.h), and the
+		// turn below -- written for both kinds of symbol, section starts and ends -- is ten of them. A lane inside a channel's
+		// coefficients takes this block instead: the refill, the two context look-ups, the symbol (its state has been read: no first-
+		// symbol test), the event, the counts; the channel's end, an error or the section's end leave `in_coeffs` / `done` for the
+		// general turn, which then runs on every NZ_PERIOD-th turn only and only for the lanes that are not here.
+		if (SCAN && J40_LANE_STRAIGHT_COEFFS) {
+			if (in_coeffs && !done && state != 0) {   // (a state of zero is read afresh, j40.h:2445: the general turn's business, if a stream ever gets there)
+				if (J40_LANE_REFILL_SELECTS) {   // lane_bits_refill as selects (lf_rows_dev.h); the word after next is asked for every turn
+					const bool need = b.nbits <= 32;
+					b.bits |= (uint64_t) (need ? b.ahead : 0u) << (need ? b.nbits : 0);
+					b.nbits += need ? 32 : 0; b.pos += need ? 4u : 0u;
+					b.ahead = lane_load32(b.base, b.pos);
+				} else lane_bits_refill(b);
+				const int32_t cctx_now = cctx + t.nnz_ctx2[(nz + (1 << shift) - 1) >> shift] + t.freq_ctx2[i >> shift] + prev;
+				uint32_t e2;
+				const uint32_t cl = t.ctx_map[cctx_now];
+				const int32_t v = lane_symbol_in_cluster<false, true>(b, state, t.alias, t.log_alpha, t.log_bucket, cl, t.cluster_cfg[cl], end_bit, &e2);
+				const bool nonzero = v != 0 && e2 == 0;
+				const int32_t sv = unpack_signed_dev(v);
+				const bool full = nonzero && (ev_at >= ev_end || !coeff_event_fits(sv));
+				if (nonzero && !full) {
+					if (J40_LANE_EV_FLUSH) ring[(int32_t) (ev_at % (uint32_t) HF_LANE_RING_SLOTS) * ring_stride] = coeff_event_pack((uint32_t) i, sv);
+					else ((J40_GLOBAL uint32_t *) G.events)[ev_at] = coeff_event_pack((uint32_t) i, sv);
+				}
+				ev_at += nonzero && !full ? 1u : 0u;
+				e2 = e2 ? e2 : full ? (uint32_t) ERR_EVOF : 0u;
+				prev = v != 0;
+				nz -= prev;
+				++i;
+				in_coeffs = nz != 0;
+				e2 = e2 ? e2 : in_coeffs && i >= size ? (uint32_t) ERR_COEF : 0u;   // non-zeros left but no coefficient left (j40.h:6996)
+				const bool next_channel = !in_coeffs && e2 == 0;
+				c_yxb += next_channel ? 1 : 0;
+				const bool next_block = next_channel && c_yxb == 3;
+				c_yxb = next_block ? 0 : c_yxb;
+				k += next_block ? 1 : 0;
+				err = e2 ? e2 : err;
+				done = e2 != 0 || (next_block && k >= nblocks);
+			}
+			// (the turn is the same in every lane: a scalar branch seven turns in eight, kept apart from the per-lane test by the empty
+			// statement -- folded into one vector condition, every turn would pay for an `if`)
+			if ((turn % J40_LANE_NZ_PERIOD) != 0) continue;
+#ifdef __HIPCC__
+			asm volatile("");
+#endif
+			if (in_coeffs && !done && state != 0) continue;
+		}
 		if (done) {   // (rare: twice per section)
 			if (have) {
 				// ---- the section's end ----
@@ -238,29 +316,6 @@ J40_DEV void decode_hf_sections_lane(const LaneFrame &f, const LaneTables &t, co
 		// Block starts are rare (3 per block against dozens of coefficient symbols) but with 64 lanes some lane starts a block in
 		// nearly every iteration, and then the whole wavefront walks the block-start code. It is therefore only executed every
 		// NZ_PERIOD-th iteration: a lane that reaches a block start in between sits out until then (J40_LANE_NZ_PERIOD = 1: never)
-#ifndef J40_LANE_NZ_PERIOD
-#define J40_LANE_NZ_PERIOD 8
-#endif
-#if J40_LANE_EV_FLUSH
-		// (the turn is the same in every lane: a scalar branch that skips the per-lane test seven turns in eight -- kept apart from it by
-		// the empty statement, or the compiler folds both into one vector condition evaluated every turn)
-		if (SCAN && (turn % J40_LANE_EV_FLUSH) == 0) {
-#ifdef __HIPCC__
-			asm volatile("");
-#endif
-			if (ev_at - ev_flushed >= (uint32_t) J40_LANE_EV_FLUSH) {
-			const J40_LDS uint32_t *r = ring + (int32_t) (ev_flushed % (uint32_t) HF_LANE_RING_SLOTS) * ring_stride;   // (a run of slots: regions and pieces are aligned)
-			J40_GLOBAL uint32_t *dst = (J40_GLOBAL uint32_t *) G.events + ev_flushed;
-#pragma unroll
-			for (int32_t k4 = 0; k4 < J40_LANE_EV_FLUSH; k4 += 4) {
-				LaneEventQuad q4;
-				q4[0] = r[k4 * ring_stride]; q4[1] = r[(k4 + 1) * ring_stride]; q4[2] = r[(k4 + 2) * ring_stride]; q4[3] = r[(k4 + 3) * ring_stride];
-				*(J40_GLOBAL LaneEventQuad *) (dst + k4) = q4;
-			}
-			ev_flushed += (uint32_t) J40_LANE_EV_FLUSH;
-			}
-		}
-#endif
 		if (!in_coeffs && (turn % J40_LANE_NZ_PERIOD) != 0) continue;
 		lane_bits_refill(b);
 		int32_t ctx;

@@ -311,6 +311,7 @@ __global__ void __launch_bounds__(512) k_hf_lanes(const DevPlan *plans, const Hf
 	// blockDim.x / 64 wavefronts per workgroup, all on the same frame (the host pads the work list), sharing its tables
 	const int32_t tid = threadIdx.x, lane = tid & 63;
 	const HfLaneWork w = work[blockIdx.x * (blockDim.x >> 6) + (tid >> 6)];
+	if (__builtin_amdgcn_readfirstlane(w.pad) & 2) __builtin_amdgcn_s_setprio(2);   // (the lighter wavefront of the two on this SIMD: async.hip)
 	const J40_GLOBAL DevPlan &plan = ((const J40_GLOBAL DevPlan *) plans)[w.frame];
 	const J40_GLOBAL DevFrame &df = *(const J40_GLOBAL DevFrame *) plan.frame;
 	const bool active = lane < w.num_groups;

@@ -9,6 +9,7 @@
 #include <thread>
 #include <algorithm>
 #include <mutex>
+#include <atomic>
 #include <cmath>
 #include <unistd.h>
 #include "../capi.hpp"
@@ -52,6 +53,11 @@ std::vector<size_t> g_slab_pending[16];  // size classes whose slab some thread 
 // frames: 54 GB), and hipFree / hipMalloc of such blocks cost tens of milliseconds each and synchronise the device. Processes that
 // share a device (several ranks on one GPU, multi-tenant serving) each keep up to this much: set J40HIP_CACHE_GB to the device's
 // memory divided by their number, less what the frames in flight need.
+// what the cache did, for J40HIP_ASYNC_TIMING (j40hip_cache_counters): calls, and the milliseconds spent waiting for the lock, searching
+// the free list, inside hipMalloc and inside hipFree
+struct CacheCounters { std::atomic<uint64_t> acquires{0}, hits{0}, slab_mallocs{0}, plain_mallocs{0}, frees{0}, lock_us{0}, take_us{0}, malloc_us{0}, free_us{0}, idle_blocks{0}; };
+CacheCounters g_cache_counters;
+inline uint64_t cache_us() { return (uint64_t) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 std::mutex g_limit_mutex;
 size_t g_limit[16]; bool g_limit_known[16];
 size_t cache_limit_bytes(int device) {   // (never called with g_cache_mutex held: hipMemGetInfo takes its time)
@@ -89,9 +95,15 @@ void *j40hip_rt::cache_acquire(int device, size_t bytes, size_t *got, bool *clea
 	if (cached) {
 		// One thread per size class allocates a slab; whoever else misses the class meanwhile waits for it and looks again (when a
 		// pipeline starts, every worker misses the empty cache at the same moment: each of them used to allocate a slab of its own)
+		const uint64_t tl0 = cache_us();
 		std::unique_lock<std::mutex> lock(g_cache_mutex);
+		const uint64_t tl1 = cache_us();
+		g_cache_counters.lock_us += tl1 - tl0; ++g_cache_counters.acquires;
 		for (;;) {
-			if (void *q = g_cache[device].take(bytes, got, clean)) return q;
+			const uint64_t tt0 = cache_us();
+			void *q = g_cache[device].take(bytes, got, clean);
+			g_cache_counters.take_us += cache_us() - tt0; g_cache_counters.idle_blocks = g_cache[device].idle.size();
+			if (q) { ++g_cache_counters.hits; return q; }
 			std::vector<size_t> &pend = g_slab_pending[device];
 			if (!slab || std::find(pend.begin(), pend.end(), bytes) == pend.end()) { if (slab) pend.push_back(bytes); break; }
 			g_cache_cv.wait(lock);
@@ -105,7 +117,9 @@ void *j40hip_rt::cache_acquire(int device, size_t bytes, size_t *got, bool *clea
 		{ std::lock_guard<std::mutex> lock(g_cache_mutex); idle_b = g_cache[device].idle_bytes; }
 		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); free_b = 0; }
 		while (n > 1 && (bytes * (size_t) n > free_b / 4 || idle_b + bytes * (size_t) (n - 1) > limit)) n /= 2;
+		const uint64_t tm0 = cache_us();
 		if (n > 1 && hipMalloc(&p, bytes * (size_t) n) != hipSuccess) { (void) hipGetLastError(); p = nullptr; }
+		g_cache_counters.malloc_us += cache_us() - tm0; ++g_cache_counters.slab_mallocs;
 		{
 			std::lock_guard<std::mutex> lock(g_cache_mutex);
 			if (p) g_cache[device].adopt_slab(p, bytes, n);
@@ -115,7 +129,10 @@ void *j40hip_rt::cache_acquire(int device, size_t bytes, size_t *got, bool *clea
 		g_cache_cv.notify_all();
 		if (p) { *got = bytes; *clean = false; return p; }
 	}
-	if (hipMalloc(&p, bytes) != hipSuccess) {
+	const uint64_t tm0 = cache_us();
+	const hipError_t first_try = hipMalloc(&p, bytes);
+	g_cache_counters.malloc_us += cache_us() - tm0; ++g_cache_counters.plain_mallocs;
+	if (first_try != hipSuccess) {
 		// out of device memory while blocks sit idle in the cache: give them back and try once more
 		(void) hipGetLastError();
 		cache_trim(device);
@@ -133,7 +150,14 @@ void j40hip_rt::cache_release(int device, void *ptr, size_t bytes, bool clean) {
 		std::lock_guard<std::mutex> lock(g_cache_mutex);
 		g_cache[device].give(ptr, bytes, clean, limit, &gone);
 	}
-	if (gone) (void) hipFree(gone);
+	if (gone) { const uint64_t tf0 = cache_us(); (void) hipFree(gone); g_cache_counters.free_us += cache_us() - tf0; ++g_cache_counters.frees; }
+}
+
+// out[10]: acquires, hits, slab allocations, plain allocations, frees, then microseconds: lock, free-list search, hipMalloc, hipFree; idle blocks now
+extern "C" __attribute__((visibility("default"))) void j40hip_cache_counters(uint64_t *out) {
+	const CacheCounters &c = g_cache_counters;
+	out[0] = c.acquires; out[1] = c.hits; out[2] = c.slab_mallocs; out[3] = c.plain_mallocs; out[4] = c.frees;
+	out[5] = c.lock_us; out[6] = c.take_us; out[7] = c.malloc_us; out[8] = c.free_us; out[9] = c.idle_blocks;
 }
 
 // ---- pinned host memory for pixels that go back to the caller (the public API's image planes): pinning 133 MB takes tens of

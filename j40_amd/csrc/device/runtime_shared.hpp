@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <hip/hip_runtime.h>
 
+extern "C" void j40hip_cache_counters(uint64_t *out);   // runtime.hip: what the device memory cache did (J40HIP_ASYNC_TIMING)
+
 namespace j40hip_rt {
 
 // a block of at least `bytes` (rounded up to 4 KB) from the device's cache or from hipMalloc; null when the device is out of memory
