@@ -324,6 +324,16 @@ def main():
         sd = dpipe.stats()
         assert all(dpipe.result(t) == "" for t in tk)
         assert torch.equal(outs[0].cpu(), first_pixels)
+        # the same pipeline over a third of the steps: a region starts with an empty pipeline (barrier + synchronise on both sides), so
+        # its first batch waits for the first LfGroup launch, the plan build and the entropy decode with nothing beside them; what a
+        # step costs once the stages overlap is the DIFFERENCE of the two regions over the difference of their step counts
+        steady = None
+        if dsteps >= 6:
+            ssteps = dsteps // 3
+            e_short, tk2 = run_pipeline_steps(dpipe, dbufs, dsizes, douts, W * 4, True, ssteps, torch, dev, dist)
+            assert all(dpipe.result(t) == "" for t in tk2)
+            steady = {"ms_per_step": round((e_dev - e_short) / (dsteps - ssteps) * 1e3, 3), "fill_ms": round((e_short - ssteps * (e_dev - e_short) / (dsteps - ssteps)) * 1e3, 3),
+                      "how": "(%d steps: %.1f ms) - (%d steps: %.1f ms) over %d steps; fill_ms = what a region costs beyond its steps at that pace (the empty pipeline's head and tail)" % (dsteps, e_dev * 1e3, ssteps, e_short * 1e3, dsteps - ssteps)}
         dpipe.close()
         dl = max(sd["launches"], 1)
         k1d = (sd["k1_kernel_ms"] / dl) or (sd["k1_ms"] / dl)
@@ -334,7 +344,8 @@ def main():
                          "k_hf_lanes_ms_per_launch": round(k1d, 3), "k_hf_lanes_roofline_frac": round(alg_d * fpl / (k1d / 1e3) / 8e12, 6) if k1d > 0 else None,
                          "pixel_kernels_ms_per_launch": round(sd["k2_ms"] / dl, 3), "lf_streams_plan_tail_ms_per_launch": round(sd["lf_plan_ms"] / dl, 3),
                          "roofline_frac_step": round(alg_d * Bd / (e_dev / dsteps) / 8e12, 6),
-                         "note": "as `value`, but the RGBA stays in device memory (no copy back): the device is the bound here, PCIe is for `value`"}
+                         "steady": steady,
+                         "note": "as `value`, but the RGBA stays in device memory (no copy back): the device is the bound here, PCIe is for `value`; ms_per_step includes filling and draining the pipeline once per region, `steady` takes that out"}
         # ---- k_hf_lanes' queued form: launches with more sections than the machine has lanes (512 8K frames = 261 120 sections
         # against 131 072 lanes at the two wavefronts per SIMD the tables' LDS allows): every frame's lanes take its sections from a
         # shared counter, largest first. One batch in flight, so that nothing runs beside the kernel.
@@ -466,7 +477,7 @@ def main():
             corr = pt.get("fetch_correction", 1.0)
             for x in stages:
                 for key, rec in pt.get("stages", {}).items():
-                    if x["stage"].startswith(key) and abs(rec.get("frames_per_launch", 0) - x["frames_per_launch"]) <= 0.5 * x["frames_per_launch"]:
+                    if x["stage"].startswith(key) and rec.get("frames_per_launch", 0) > 0:   # (scaled to this run's frames per launch: the LfGroup launches carry what was waiting)
                         x["traffic"] = int((rec["fetch_kb"] * corr + rec["write_kb"]) * 1024 * x["frames_per_launch"] / rec["frames_per_launch"])
                         x["traffic_fetch_kb_uncorrected"] = rec["fetch_kb"]; x["traffic_write_kb"] = rec["write_kb"]
             result["roofline"]["traffic_source"] = pt["source"]

@@ -120,6 +120,7 @@ struct j40hip_pipeline {
 	int lf_flights_used = 4;            // how many of them launch (J40HIP_LF_FLIGHTS); a launch carries up to lf_flight_frames frames
 	int64_t lf_flight_frames = 0;
 	int64_t lf_auto_min = 0;            // mode 0: with nothing in the device's stage, fewer frames than this waiting are the host threads' (J40HIP_LF_AUTO_MIN)
+	double lf_wait_burst = 10.0;        // ... times this when the frames queued behind them can fill the batch (J40HIP_LF_WAIT_BURST)
 	double lf_wait_ms = 5.0;            // how long frames wait for a batch's worth of company before a launch takes them alone (J40HIP_LF_WAIT_MS)
 	std::vector<uint32_t> results;      // by ticket
 	std::vector<uint8_t> finished;      // by ticket
@@ -453,7 +454,12 @@ void gpu_main(j40hip_pipeline *p) {
 			else if (p->lf_pending_since == 0) p->lf_pending_since = now_ms();
 			bool lf_flying = false;
 			for (const LfFlight &fl : p->lf_flights) lf_flying = lf_flying || fl.busy;
-			const bool lf_go = !p->lf_pending.empty() && ((int64_t) p->lf_pending.size() >= p->batch_frames || (!lf_flying && now_ms() - p->lf_pending_since > p->lf_wait_ms) || p->stop || (p->todo.empty() && p->parsing == 0));
+			// (... "a while": lf_wait_ms when what is queued behind them cannot fill the batch anyway; ten times that when it can -- the
+			// head of a burst: 57 frames left after 5 ms, the batch they belong to then waited for the SECOND launch, 0.17 s later, to
+			// bring its other 199, call K's timeline)
+			const int64_t coming = (int64_t) p->todo.size() + p->parsing, missing = p->batch_frames - (int64_t) p->lf_pending.size();
+			const double lf_waited = p->lf_pending.empty() ? 0.0 : now_ms() - p->lf_pending_since;
+			const bool lf_go = !p->lf_pending.empty() && (missing <= 0 || (!lf_flying && lf_waited > (coming >= missing ? p->lf_wait_burst : 1.0) * p->lf_wait_ms) || p->stop || (p->todo.empty() && p->parsing == 0));
 			if (lf_go) for (int fi = 0; fi < p->lf_flights_used; ++fi) if (!p->lf_flights[fi].busy) {
 				LfFlight &fl = p->lf_flights[fi];
 				std::vector<j40hip_aframe *> frames;
@@ -570,6 +576,7 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 		if (const char *e = getenv("J40HIP_LF_FLIGHTS")) p->lf_flights_used = std::max(1, std::min(4, atoi(e)));
 		if (const char *e = getenv("J40HIP_LF_FLIGHT_FRAMES")) p->lf_flight_frames = std::max<int64_t>(1, atoll(e));
 		if (const char *e = getenv("J40HIP_LF_WAIT_MS")) p->lf_wait_ms = std::max(0.0, atof(e));
+		if (const char *e = getenv("J40HIP_LF_WAIT_BURST")) p->lf_wait_burst = std::max(1.0, atof(e));
 		p->lf_auto_min = p->batch_frames / 4;
 		if (const char *e = getenv("J40HIP_LF_AUTO_MIN")) p->lf_auto_min = std::max<int64_t>(0, atoll(e));
 		p->slots.resize((size_t) p->max_in_flight + 1);
