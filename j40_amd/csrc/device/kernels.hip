@@ -674,6 +674,7 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const 
 	uint32_t dq_scan_off[5] = {0, 0, 0, 0, 0};   // of the parameter sets 1, 2, 3, 9, 10
 	bool sparse = false;
 	int32_t next_blk = 0; bool next_blk_valid = false;   // (k_vardct_dct: the next tile's block ordinals, fetched ahead)
+	K2_PHASES_BEGIN;
 	for (K2Iter it = k2_begin<BATCH>(tile_prefix, nframes); ; ) {
 		int32_t frame, first; bool entered;
 		if (!k2_bind<BATCH>(it, batch, tile_prefix, class_a, class_b, NB, list, count, rgba, stride_bytes, frame, first, entered)) break;
@@ -689,7 +690,9 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const 
 		}
 		const DevFrame &f = *plan.frame;
 		const int32_t nb = min(NB, count - first);
+		K2_PHASE(0);
 		if (sparse) zero_tiles(tiles, nb * 3 * P, tid, nthreads);
+		K2_PHASE(1);
 		uint32_t nevents = 0;
 		if (tid < nb) {
 			const DevVarblock vb = list[first + tid];
@@ -724,6 +727,7 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const 
 			}
 		}
 		__syncthreads();
+		K2_PHASE(2);
 		// eight lanes per tile, the eight tiles of a wavefront side by side; a tile's lanes sit in one wavefront, so the two phases
 		// need no workgroup barrier between them, only their order (SP8_LOADS_DONE)
 		const int32_t lane8 = tid & 7;
@@ -735,6 +739,7 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const 
 			special8_phase1(sel, lane8, (const float *) t, t, c_half_secants, true);
 		}
 		__syncthreads();
+		K2_PHASE(3);
 		for (int32_t w = tid; w < nb * 64; w += nthreads) {
 			const int32_t b = w >> 6, i = w & 63, y = i >> 3, x = i & 7;
 			const VbGeom &g = geom[b];
@@ -743,9 +748,15 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const 
 			const uint32_t px = xyb_to_rgba8(t[0], t[P], t[2 * P], cc, srgb_thr);
 			*(uint32_t *) (rgba + (size_t) (g.py + y) * stride_bytes + (size_t) (g.px + x) * 4) = px;
 		}
+		K2_PHASE(5);
 		if (!BATCH) break;
 		__syncthreads();
+		K2_PHASE(6);
+#ifdef J40_K2_PHASES
+		++k2_acc[7];
+#endif
 	}
+	K2_PHASES_END(class_a == 1 ? 0 : 1);   // (slots no k_vardct_dct shape uses)
 }
 
 // ------------------------------------------------------------------------------------------------

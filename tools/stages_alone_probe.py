@@ -40,7 +40,7 @@ if phases is not None:
         row = [phases[slot * 8 + k] for k in range(8)]
         if row[7]:
             tot = sum(row[:7])
-            print(json.dumps({"k_vardct_dct": "%dx%d" % (1 << (slot // 8), 1 << (slot % 8)), "tiles": row[7], "share_of_all_shapes": round(tot / total_all, 4), "clocks_per_tile": round(tot / row[7], 1),
+            print(json.dumps({"kernel": "k_vardct_special, DctSelect %s" % ("1-3" if slot == 0 else "12-17") if slot < 2 else "k_vardct_dct %dx%d" % (1 << (slot // 8), 1 << (slot % 8)), "tiles": row[7], "share_of_all_shapes": round(tot / total_all, 4), "clocks_per_tile": round(tot / row[7], 1),
                               "phases": {n: round(v / tot, 4) for n, v in zip(names, row[:7])}}))
 pipe.close()
 j40_amd.shutdown()
