@@ -16,7 +16,7 @@ void launch_vardct_class(const DevPlan &plan, int32_t dctsel, const DevVarblock 
 // every frame of a batch: one persistent launch per class of transforms, spread over `nside` side streams that fork from and join
 // `stream` (nside = 0: all on `stream`). tile_prefix_dev: K2_NUM_BATCH_LAUNCHES * (nframes + 1) ints of scratch; totals_dev:
 // K2_NUM_BATCH_LAUNCHES ints (out: tiles per launch); grids: workgroups per launch, from k2_batch_grids
-enum { K2_NUM_BATCH_LAUNCHES = 15, K2_LARGE_WGS = 256 };
+enum { K2_NUM_BATCH_LAUNCHES = 16, K2_LARGE_WGS = 256 };
 void k2_batch_grids(const int32_t *last_totals, size_t cells_total, int32_t nframes, int32_t wg_slots, int32_t *grids);
 void launch_vardct_batch(const K2Frame *frames_dev, int32_t nframes, int32_t *tile_prefix_dev, int32_t *totals_dev, const int32_t *grids, float *large_scratch, hipStream_t stream, hipStream_t *side, int nside, hipEvent_t fork, hipEvent_t *side_done);
 void launch_vardct_frame(const DevPlan &plan, const int32_t *class_start, const DevVarblock *sorted, float *large_scratch, uint8_t *rgba, size_t stride, hipStream_t stream);

@@ -656,8 +656,36 @@ __global__ void __launch_bounds__(256, (LOGR + LOGC <= 7 ? J40_K2_WAVES_PER_EU :
 // The 256 lanes of a workgroup are 32 tiles x 8 lanes; a workgroup's NB blocks x 3 channels = 96 tiles take three rounds.
 // Tiles are 72 floats apart with rows of 9 (conflict-free along rows and down columns: special8_dev.h).
 
-template <int NB, bool BATCH>
-__global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const DevVarblock *list, int32_t count, uint8_t *rgba, size_t stride_bytes, const K2Frame *batch, const int32_t *tile_prefix, int32_t nframes,
+// J40_K2_SPECIAL_NB blocks per tile, J40_K2_SPECIAL_THREADS lanes per workgroup, J40_K2_SPECIAL_WAVES wavefronts per SIMD asked of the
+// register allocator. A tile's time is mostly waiting (events and LLF: 42-53 %, the stores 27 %: the instrumented build's clocks,
+// call M), so what a compute unit gets done is how many workgroups it holds: 32 blocks x 3 x 72 floats = 32.8 KB of LDS and 145
+// registers held it to three workgroups of four wavefronts.
+#ifndef J40_K2_SPECIAL_NB
+#define J40_K2_SPECIAL_NB 16
+#endif
+#ifndef J40_K2_SPECIAL_THREADS
+#define J40_K2_SPECIAL_THREADS 256
+#endif
+#ifndef J40_K2_SPECIAL_WAVES
+#define J40_K2_SPECIAL_WAVES 8
+#endif
+#ifndef J40_K2_SPECIAL_WAVES_AFV
+#define J40_K2_SPECIAL_WAVES_AFV 5
+#endif
+// SET: which of the nine transforms the instantiation carries -- 1: DctSelect 1-3 (Hornuss, DCT2x2, DCT4x4), 2: 12-13 (the two halves
+// forms), 3: 14-17 (AFV) -- a launch each: with all nine inlined into one kernel the AFV paths' 145 registers set the occupancy of all.
+template <int SET> __device__ __forceinline__ void special8_set_phase0(int sel, int lane, const float *src, float *dst, const float *hs, const float *afv_basis) {
+	if (SET == 1) { if (sel == 1) hornuss_phase0(lane, src, dst); else if (sel == 2) pyramid_phase0(lane, src, dst, true); else quadrants_phase0(lane, src, dst, hs); }
+	else if (SET == 2) { if (sel == 12) wide_halves_phase0(lane, src, dst, hs); else tall_halves_phase0(lane, src, dst, hs); }
+	else afv_phase0(lane, src, dst, hs, afv_basis);
+}
+template <int SET> __device__ __forceinline__ void special8_set_phase1(int sel, int lane, const float *mid, float *dst, const float *hs) {
+	if (SET == 1) { if (sel == 1) copy_row_phase1(lane, mid, dst, true); else if (sel == 2) pyramid_phase1(lane, mid, dst); else quadrants_phase1(lane, mid, dst, hs); }
+	else if (SET == 2) { if (sel == 12) wide_halves_phase1(lane, mid, dst, hs); else tall_halves_phase1(lane, mid, dst, hs); }
+	else afv_phase1(lane, mid, dst, hs, (sel - 14) & 1, (sel - 14) >> 1);
+}
+template <int NB, bool BATCH, int SET>
+__device__ __forceinline__ void vardct_special_body(DevPlan plan_arg, const DevVarblock *list, int32_t count, uint8_t *rgba, size_t stride_bytes, const K2Frame *batch, const int32_t *tile_prefix, int32_t nframes,
 		int32_t class_a, int32_t class_b) {
 	constexpr int P = SP8_TILE;
 	__shared__ __attribute__((aligned(16))) float tiles[NB * 3 * P];   // coefficients in, samples out: both phases work in place (special8_dev.h)
@@ -734,9 +762,9 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const 
 		for (int32_t tile = tid >> 3; tile < nb * 3; tile += nthreads >> 3) {
 			float *t = tiles + tile * P;
 			const int32_t sel = g_sel[tile / 3];
-			special8_phase0(sel, lane8, (const float *) t, t, c_half_secants, c_afv_basis, true);
+			special8_set_phase0<SET>(sel, lane8, (const float *) t, t, c_half_secants, c_afv_basis);
 			SP8_LOADS_DONE();
-			special8_phase1(sel, lane8, (const float *) t, t, c_half_secants, true);
+			special8_set_phase1<SET>(sel, lane8, (const float *) t, t, c_half_secants);
 		}
 		__syncthreads();
 		K2_PHASE(3);
@@ -756,8 +784,22 @@ __global__ void __launch_bounds__(256) k_vardct_special(DevPlan plan_arg, const 
 		++k2_acc[7];
 #endif
 	}
-	K2_PHASES_END(class_a == 1 ? 0 : 1);   // (slots no k_vardct_dct shape uses)
+	K2_PHASES_END(SET - 1);   // (slots no k_vardct_dct shape uses)
 }
+
+// the three kernels: the sets' transforms need 98 / 106 / 118 registers left alone; sets 1 and 2 fit the 64 that eight wavefronts per
+// SIMD leave (one register spilled / none), the AFV set gets the 96 of five (J40_K2_SPECIAL_WAVES, J40_K2_SPECIAL_WAVES_AFV)
+#define J40_SPECIAL_KERNEL(NAME_, SET_, WAVES_) \
+template <int NB, bool BATCH> \
+__global__ void __launch_bounds__(J40_K2_SPECIAL_THREADS) __attribute__((amdgpu_waves_per_eu(WAVES_))) NAME_(DevPlan plan_arg, const DevVarblock *list, int32_t count, uint8_t *rgba, size_t stride_bytes, const K2Frame *batch, \
+		const int32_t *tile_prefix, int32_t nframes, int32_t class_a, int32_t class_b) { \
+	vardct_special_body<NB, BATCH, SET_>(plan_arg, list, count, rgba, stride_bytes, batch, tile_prefix, nframes, class_a, class_b); \
+}
+J40_SPECIAL_KERNEL(k_vardct_special_123, 1, J40_K2_SPECIAL_WAVES)
+J40_SPECIAL_KERNEL(k_vardct_special_halves, 2, J40_K2_SPECIAL_WAVES)
+J40_SPECIAL_KERNEL(k_vardct_special_afv, 3, J40_K2_SPECIAL_WAVES_AFV)
+#undef J40_SPECIAL_KERNEL
+
 
 // ------------------------------------------------------------------------------------------------
 // K2l: transforms with a 128- or 256-sized side. One workgroup per varblock; the butterfly levels
@@ -985,10 +1027,14 @@ static void launch_vardct_class_impl(const DevPlan &plan, int32_t dctsel, const 
 	case 18: launch_dct<6, 6, 1>(plan, list, count, 11, 7, rgba, stride, bl, stream); break;
 	case 19: launch_dct<6, 5, 1>(plan, list, count, 12, 8, rgba, stride, bl, stream); break;
 	case 20: launch_dct<5, 6, 1>(plan, list, count, 12, 8, rgba, stride, bl, stream); break;
-	case 1: case 2: case 3: case 12: case 13: case 14: case 15: case 16: case 17:
-		if (bl.batch) hipLaunchKernelGGL((k_vardct_special<32, true>), dim3((unsigned) bl.grid), dim3(256), 0, stream, plan, list, count, rgba, stride, bl.batch, bl.tile_prefix, bl.nframes, bl.class_a, bl.class_b);
-		else hipLaunchKernelGGL((k_vardct_special<32, false>), dim3((unsigned) ((count + 31) / 32)), dim3(256), 0, stream, plan, list, count, rgba, stride, bl.batch, nullptr, 1, 0, 0);
-		break;
+#define J40_LAUNCH_SPECIAL(KERNEL_) do { \
+		if (bl.batch) hipLaunchKernelGGL((KERNEL_<J40_K2_SPECIAL_NB, true>), dim3((unsigned) bl.grid), dim3(J40_K2_SPECIAL_THREADS), 0, stream, plan, list, count, rgba, stride, bl.batch, bl.tile_prefix, bl.nframes, bl.class_a, bl.class_b); \
+		else hipLaunchKernelGGL((KERNEL_<J40_K2_SPECIAL_NB, false>), dim3((unsigned) ((count + J40_K2_SPECIAL_NB - 1) / J40_K2_SPECIAL_NB)), dim3(J40_K2_SPECIAL_THREADS), 0, stream, plan, list, count, rgba, stride, bl.batch, nullptr, 1, 0, 0); \
+	} while (0)
+	case 1: case 2: case 3: J40_LAUNCH_SPECIAL(k_vardct_special_123); break;
+	case 12: case 13: J40_LAUNCH_SPECIAL(k_vardct_special_halves); break;
+	case 14: case 15: case 16: case 17: J40_LAUNCH_SPECIAL(k_vardct_special_afv); break;
+#undef J40_LAUNCH_SPECIAL
 	default:
 		{
 			constexpr size_t lds_bytes = 2 * (size_t) LARGE_PANEL_FLOATS * sizeof(float);
@@ -1034,11 +1080,11 @@ void launch_kat_srgb_u8(const float *v, size_t n, uint8_t *out, hipStream_t stre
 	hipLaunchKernelGGL(k_kat_srgb_u8, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, v, n, out);
 }
 
-// every class of one frame; the nine 8x8 special transforms (DctSelect 1-3 and 12-17, contiguous in the
-// sorted list) share two launches since k_vardct_special dispatches per varblock
+// every class of one frame; the nine 8x8 special transforms (DctSelect 1-3, 12-13 and 14-17, each run contiguous in the
+// sorted list) share three launches: k_vardct_special dispatches per varblock among the transforms of its set
 static bool class_range(int d, int *a, int *b) {
-	if (d == 2 || d == 3 || (d >= 13 && d <= 17)) return false;
-	*a = d; *b = d == 1 ? 4 : d == 12 ? 18 : d + 1;
+	if (d == 2 || d == 3 || d == 13 || (d >= 15 && d <= 17)) return false;
+	*a = d; *b = d == 1 ? 4 : d == 12 ? 14 : d == 14 ? 18 : d + 1;
 	return true;
 }
 void launch_vardct_frame(const DevPlan &plan, const int32_t *class_start, const DevVarblock *sorted, float *large_scratch, uint8_t *rgba, size_t stride, hipStream_t stream) {
@@ -1049,12 +1095,12 @@ void launch_vardct_frame(const DevPlan &plan, const int32_t *class_start, const 
 // ---- the same for every frame of a batch at once: one persistent launch per class ----
 // The launches of a batch: {first DctSelect, one past the last, varblocks per tile, cells per varblock at least}; the 128/256-sized
 // transforms share one (k_vardct_large looks at each block's DctSelect). Biggest first.
-#define J40_K2_LAUNCH_TABLE {0, 1, 16, 1}, {1, 4, 32, 1}, {12, 18, 32, 1}, {4, 5, 8, 4}, {6, 7, 8, 2}, {7, 8, 8, 2}, {5, 6, 2, 16}, {8, 9, 4, 4}, {9, 10, 4, 4}, {10, 11, 4, 8}, {11, 12, 4, 8}, \
+#define J40_K2_LAUNCH_TABLE {0, 1, 16, 1}, {1, 4, J40_K2_SPECIAL_NB, 1}, {12, 14, J40_K2_SPECIAL_NB, 1}, {14, 18, J40_K2_SPECIAL_NB, 1}, {4, 5, 8, 4}, {6, 7, 8, 2}, {7, 8, 8, 2}, {5, 6, 2, 16}, {8, 9, 4, 4}, {9, 10, 4, 4}, {10, 11, 4, 8}, {11, 12, 4, 8}, \
 	{18, 19, 1, 64}, {19, 20, 1, 32}, {20, 21, 1, 32}, {21, 27, 1, 128}
 struct K2BatchLaunch { int16_t a, b, per_wg, min_cells; };
 struct K2Table { K2BatchLaunch l[K2_NUM_BATCH_LAUNCHES]; };
 static const K2Table &k2_table() {
-	static const K2Table t = [] { K2Table t = {{J40_K2_LAUNCH_TABLE}}; if (k2_wide() & 1) t.l[0].per_wg = 32; if (k2_wide() & 2) t.l[4].per_wg = t.l[5].per_wg = 16; return t; }();
+	static const K2Table t = [] { K2Table t = {{J40_K2_LAUNCH_TABLE}}; if (k2_wide() & 1) t.l[0].per_wg = 32; if (k2_wide() & 2) t.l[5].per_wg = t.l[6].per_wg = 16; return t; }();
 	return t;
 }
 
@@ -1075,16 +1121,16 @@ __global__ void k_k2_tiles(const K2Frame *frames, int32_t nframes, int32_t *tile
 }
 
 // Workgroups per launch, and which of (up to) four side streams a launch goes to. A process gets four hardware queues per
-// priority (GPU_MAX_HW_QUEUES); streams beyond that share them, and kernels in one queue run one after the other. So the fifteen
+// priority (GPU_MAX_HW_QUEUES); streams beyond that share them, and kernels in one queue run one after the other. So the sixteen
 // launches are dealt to four streams as four chains of about equal work (measured shares of the picture-encoded 8K stream: the 8x8
 // DCT 18 %, the 8x8 specials 38 %, 16x16 11 %, ...), every launch wide enough to fill the machine on its own: whichever chains are
 // still running share it, and a chain's last kernel has the whole machine for its tail. (Fifteen streams with grids in proportion
 // to the classes' work were measured: 176 ms per 256 frames against 81 -- only four kernels ran at a time, each with a fraction of
 // the machine.)
 // (the second launch of the specials goes behind the 8x8 DCT: beside the first it made its chain the longest by 15 ms, alone at the
-// end with two workgroups per compute unit. J40HIP_K2_CHAINS=<15 digits>: another assignment, for experiments)
+// end with two workgroups per compute unit. J40HIP_K2_CHAINS=<16 digits>: another assignment, for experiments)
 static const int8_t *k2_launch_stream() {
-	static int8_t chain[K2_NUM_BATCH_LAUNCHES] = {0, 1, 0, 2, 3, 3, 2, 3, 3, 3, 3, 2, 2, 2, 2};
+	static int8_t chain[K2_NUM_BATCH_LAUNCHES] = {0, 1, 0, 1, 2, 3, 3, 2, 3, 3, 3, 3, 2, 2, 2, 2};
 	static const bool once = [] { const char *e = getenv("J40HIP_K2_CHAINS"); if (e && strlen(e) == K2_NUM_BATCH_LAUNCHES) for (int i = 0; i < K2_NUM_BATCH_LAUNCHES; ++i) chain[i] = (int8_t) ((e[i] - '0') & 3); return true; }();
 	(void) once;
 	return chain;
