@@ -501,6 +501,70 @@ __device__ __forceinline__ void stage_event_prefix(uint32_t mine, uint32_t *pref
 // 0 .. NB - 1 fetch the ordinals (`blk`) of its blocks now, one word each, and have them a whole tile's work later -- the next
 // prologue then asks for a block's record and for its entry of block_events side by side (J40_K2_NO_PREFETCH: as before, the entry
 // after the record)
+// ---- J40_K2_AHEAD (the default): the records of the run's next TWO tiles and the block_events entries of its next tile are on their
+// way while a tile is worked on, and they travel without registers: global_load_lds_dword has the memory system write a lane's dword
+// to LDS at M0 + 4 * lane. A tile's prologue was a round trip to memory for its records (with the entry of block_events beside it
+// once the ordinals were prefetched) in front of the round trip for its events -- a quarter of the 8x8 kernel's time per tile (the
+// instrumented build, call M) with every wavefront slot of the machine taken, so a slot's time is what the stage costs. Now:
+//   tile k, first thing, wavefront 0: asks for the records of tile k + 2 (ring of three slots) and, with the ordinals of tile k + 1's
+//   records (asked for during tile k - 1, in LDS since), for the entries of tile k + 1 (ring of two);
+//   wavefront 0 waits for its counter (vmcnt(0)) just before the barrier behind the scatter phase -- its own event loads have come
+//   back by then, so the wait is short -- and that barrier publishes what has arrived to the other wavefronts;
+//   tile k itself finds its records and entries in LDS.
+// Where a run starts or enters another frame nothing is on its way: wavefront 0 fetches the tile's own records and entries the same
+// way and waits for them (the two round trips the prologue always had). The compiler does not know the instruction (inline assembly:
+// told about it, it orders every later LDS read of the same array behind the copy, i.e. behind the round trip): the waits are the
+// two above, by hand. M0 is not used by anything else in these kernels.
+#ifndef J40_K2_AHEAD
+#define J40_K2_AHEAD 1
+#endif
+static_assert(sizeof(DevVarblock) == 40, "K2Ahead copies records as ten dwords");
+__device__ __forceinline__ void k2_copy_dword_to_lds(const uint32_t *src_of_lane, uint32_t lds_byte_address) {
+	asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(src_of_lane), "s"(lds_byte_address) : "memory");
+}
+__device__ __forceinline__ void k2_copies_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int NB> struct K2Ahead {
+	enum { REC_DW = 10, REC_SLOT = NB * REC_DW, BE_SLOT = NB * 4 };
+	uint32_t *rec, *be;   // LDS: [3][REC_SLOT], [2][BE_SLOT]
+	__device__ __forceinline__ static uint32_t lds_address(const uint32_t *p) { return (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) (uint32_t) (uintptr_t) p); }   // (the low half of a flat LDS address is the LDS offset)
+	__device__ __forceinline__ const uint32_t *records(int32_t k) const { return rec + (k % 3) * REC_SLOT; }
+	__device__ __forceinline__ const uint32_t *entries(int32_t k) const { return be + (k & 1) * BE_SLOT; }
+	// wavefront 0, lane = 0 .. 63: tile k of `list` (its blocks k * NB ...)
+	__device__ __forceinline__ void ask_records(const DevVarblock *list, int32_t count, int32_t k, int32_t lane) const {
+		const int32_t first = k * NB, n = min(NB, count - first) * REC_DW;
+		const uint32_t *src = (const uint32_t *) (list + first);
+		const uint32_t base = lds_address(records(k));
+#pragma unroll
+		for (int32_t j = 0; j * 64 < REC_SLOT; ++j) { const int32_t d = j * 64 + lane; if (d < n) k2_copy_dword_to_lds(src + d, base + (uint32_t) j * 256u); }
+	}
+	// ... the entries of block_events of tile k's `nb` blocks; the tile's records are in LDS
+	__device__ __forceinline__ void ask_entries(const uint32_t *block_events, int32_t nb, int32_t k, int32_t lane) const {
+		const uint32_t *r = records(k);
+		const uint32_t base = lds_address(entries(k));
+#pragma unroll
+		for (int32_t j = 0; j * 64 < BE_SLOT; ++j) {
+			const int32_t l = j * 64 + lane;
+			if (l < nb * 4) { const uint32_t blk = r[(l >> 2) * REC_DW + 8]; k2_copy_dword_to_lds(block_events + 4 * (size_t) blk + (uint32_t) (l & 3), base + (uint32_t) j * 256u); }
+		}
+	}
+};
+// the tile's prologue for both kernel families: `k` = the tile's number in its frame's list; true: records and entries are in LDS
+#define K2_AHEAD_PROLOGUE(NB_) \
+	const int32_t ahead_k = first / (NB_); \
+	if (BATCH && J40_K2_AHEAD) { \
+		const bool next_ok = it.tile < it.tile_end && it.tile < it.frame_end, next2_ok = it.tile + 1 < it.tile_end && it.tile + 1 < it.frame_end; \
+		if (tid < 64) { \
+			if (entered) { \
+				ahead.ask_records(list, count, ahead_k, tid); \
+				if (next_ok) ahead.ask_records(list, count, ahead_k + 1, tid); \
+				k2_copies_wait(); \
+				if (sparse) { ahead.ask_entries(plan.block_events, nb, ahead_k, tid); k2_copies_wait(); } \
+			} \
+			if (next2_ok) ahead.ask_records(list, count, ahead_k + 2, tid); \
+			if (next_ok && sparse) ahead.ask_entries(plan.block_events, min((NB_), count - first - (NB_)), ahead_k + 1, tid); \
+		} \
+	}
+
 #ifdef J40_K2_NO_PREFETCH
 #define K2_PREFETCH_BLK(NB_) do { next_blk_valid = false; } while (0)
 #else
@@ -539,7 +603,9 @@ __global__ void __launch_bounds__(256, (LOGR + LOGC <= 7 ? J40_K2_WAVES_PER_EU :
 	const float *dq = nullptr, *dq_scan = nullptr; const uint16_t *order = nullptr;
 	float qbias0 = 0, qbias1 = 0, qbias2 = 0, qbias_num = 0, kx_lf = 0, kb_lf = 0, x_qm_mul = 0, b_qm_mul = 0;
 	bool sparse = false;
-	int32_t next_blk = 0; bool next_blk_valid = false;   // lane b: the ordinal of block b of the run's NEXT tile, fetched while this one is worked on
+	int32_t next_blk = 0; bool next_blk_valid = false;   // lane b: the ordinal of block b of the run's NEXT tile, fetched while this one is worked on (J40_K2_AHEAD=0)
+	__shared__ uint32_t ahead_rec[3 * K2Ahead<NB>::REC_SLOT], ahead_be[2 * K2Ahead<NB>::BE_SLOT];
+	const K2Ahead<NB> ahead = {ahead_rec, ahead_be};
 	for (K2Iter it = k2_begin<BATCH>(tile_prefix, nframes); ; ) {
 		int32_t frame, first; bool entered;
 		if (!k2_bind<BATCH>(it, batch, tile_prefix, class_a, class_b, NB, list, count, rgba, stride_bytes, frame, first, entered)) break;
@@ -557,15 +623,22 @@ __global__ void __launch_bounds__(256, (LOGR + LOGC <= 7 ? J40_K2_WAVES_PER_EU :
 		const int32_t dq_size = R * C;
 		// (asking for the tile's records first and zeroing the tiles while they are on their way was measured: nineteen registers more
 		// and 67.2 against 64.4 ms for the stage)
+		K2_AHEAD_PROLOGUE(NB)
 		if (sparse) zero_tiles(lds, nb * 3 * TILE, tid, nthreads);
 		uint32_t nevents = 0;
 		if (tid < nb) {
-			const DevVarblock vb = list[first + tid];
-			// (the block's entry of block_events is asked for together with its record when the tile before this one fetched its
-			// ordinal ahead -- K2_PREFETCH_BLK below --: one round trip to memory in front of the tile instead of two in a row)
-			const int32_t blk = next_blk_valid ? next_blk : vb.blk;
+			DevVarblock vb;
 			uint32_t be0 = 0, be1 = 0, be2 = 0, be3 = 0;
-			if (sparse) { const uint32_t *be = plan.block_events + 4 * (size_t) blk; be0 = be[0]; be1 = be[1]; be2 = be[2]; be3 = be[3]; }
+			if (BATCH && J40_K2_AHEAD) {   // record and entry are in LDS (K2Ahead)
+				vb = *(const DevVarblock *) (ahead.records(ahead_k) + tid * 10);
+				if (sparse) { const uint32_t *be = ahead.entries(ahead_k) + tid * 4; be0 = be[0]; be1 = be[1]; be2 = be[2]; be3 = be[3]; }
+			} else {
+				vb = list[first + tid];
+				// (the block's entry of block_events is asked for together with its record when the tile before this one fetched its
+				// ordinal ahead -- K2_PREFETCH_BLK below --: one round trip to memory in front of the tile instead of two in a row)
+				const int32_t blk = next_blk_valid ? next_blk : vb.blk;
+				if (sparse) { const uint32_t *be = plan.block_events + 4 * (size_t) blk; be0 = be[0]; be1 = be[1]; be2 = be[2]; be3 = be[3]; }
+			}
 			VbGeom g;
 			g.coeff_base = vb.coeff_base; g.llf_base = vb.llf_base;
 			g.mult[1] = vb.mult1; g.mult[0] = vb.mult1 * x_qm_mul; g.mult[2] = vb.mult1 * b_qm_mul;   // (varblock_geometry with the frame's factors at hand; j40.h:7078-7080)
@@ -573,7 +646,7 @@ __global__ void __launch_bounds__(256, (LOGR + LOGC <= 7 ? J40_K2_WAVES_PER_EU :
 			geom[tid] = g; g_out[tid] = (size_t) g.py * stride_bytes + (size_t) g.px * 4;
 			if (sparse) { g_be[tid][0] = be0; g_be[tid][1] = be1; g_be[tid][2] = be2; g_be[tid][3] = be3; nevents = be1 + be2 + be3; }
 		}
-		K2_PREFETCH_BLK(NB);
+		if (!(BATCH && J40_K2_AHEAD)) K2_PREFETCH_BLK(NB);
 		stage_event_prefix<NB>(nevents, ev_prefix, tid);
 		K2_PHASE(0);
 		// ---- load: dequantise + chroma-from-luma + LLF into the LDS tiles ----
@@ -600,6 +673,7 @@ __global__ void __launch_bounds__(256, (LOGR + LOGC <= 7 ? J40_K2_WAVES_PER_EU :
 				t[0] = v[0]; t[TILE] = v[1]; t[2 * TILE] = v[2];
 			}
 		}
+		if (BATCH && J40_K2_AHEAD && tid < 64) k2_copies_wait();   // (what wavefront 0 asked for at the tile's start has arrived: K2Ahead)
 		__syncthreads();
 		K2_PHASE(2);
 		// ---- pass 1: IDCT of length C along c, one lane per (block, channel, r) ----
@@ -702,6 +776,8 @@ __device__ __forceinline__ void vardct_special_body(DevPlan plan_arg, const DevV
 	uint32_t dq_scan_off[5] = {0, 0, 0, 0, 0};   // of the parameter sets 1, 2, 3, 9, 10
 	bool sparse = false;
 	int32_t next_blk = 0; bool next_blk_valid = false;   // (k_vardct_dct: the next tile's block ordinals, fetched ahead)
+	__shared__ uint32_t ahead_rec[3 * K2Ahead<NB>::REC_SLOT], ahead_be[2 * K2Ahead<NB>::BE_SLOT];
+	const K2Ahead<NB> ahead = {ahead_rec, ahead_be};
 	K2_PHASES_BEGIN;
 	for (K2Iter it = k2_begin<BATCH>(tile_prefix, nframes); ; ) {
 		int32_t frame, first; bool entered;
@@ -719,14 +795,21 @@ __device__ __forceinline__ void vardct_special_body(DevPlan plan_arg, const DevV
 		const DevFrame &f = *plan.frame;
 		const int32_t nb = min(NB, count - first);
 		K2_PHASE(0);
+		K2_AHEAD_PROLOGUE(NB)
 		if (sparse) zero_tiles(tiles, nb * 3 * P, tid, nthreads);
 		K2_PHASE(1);
 		uint32_t nevents = 0;
 		if (tid < nb) {
-			const DevVarblock vb = list[first + tid];
-			const int32_t blk = next_blk_valid ? next_blk : vb.blk;   // (k_vardct_dct)
+			DevVarblock vb;
 			uint32_t be0 = 0, be1 = 0, be2 = 0, be3 = 0;
-			if (sparse) { const uint32_t *be = plan.block_events + 4 * (size_t) blk; be0 = be[0]; be1 = be[1]; be2 = be[2]; be3 = be[3]; }
+			if (BATCH && J40_K2_AHEAD) {   // (k_vardct_dct)
+				vb = *(const DevVarblock *) (ahead.records(ahead_k) + tid * 10);
+				if (sparse) { const uint32_t *be = ahead.entries(ahead_k) + tid * 4; be0 = be[0]; be1 = be[1]; be2 = be[2]; be3 = be[3]; }
+			} else {
+				vb = list[first + tid];
+				const int32_t blk = next_blk_valid ? next_blk : vb.blk;
+				if (sparse) { const uint32_t *be = plan.block_events + 4 * (size_t) blk; be0 = be[0]; be1 = be[1]; be2 = be[2]; be3 = be[3]; }
+			}
 			VbGeom g;
 			g.coeff_base = vb.coeff_base; g.llf_base = vb.llf_base;
 			g.mult[1] = vb.mult1; g.mult[0] = vb.mult1 * x_qm_mul; g.mult[2] = vb.mult1 * b_qm_mul;   // (varblock_geometry; j40.h:7078-7080)
@@ -737,7 +820,7 @@ __device__ __forceinline__ void vardct_special_body(DevPlan plan_arg, const DevV
 			g_param[tid] = vb.dctsel == 1 ? 1 : vb.dctsel == 2 ? 2 : vb.dctsel == 3 ? 3 : vb.dctsel <= 13 ? 9 : 10;
 			g_dq[tid] = vb.dctsel == 1 ? dq_scan_off[0] : vb.dctsel == 2 ? dq_scan_off[1] : vb.dctsel == 3 ? dq_scan_off[2] : vb.dctsel <= 13 ? dq_scan_off[3] : dq_scan_off[4];
 		}
-		K2_PREFETCH_BLK(NB);
+		if (!(BATCH && J40_K2_AHEAD)) K2_PREFETCH_BLK(NB);
 		stage_event_prefix<NB>(nevents, ev_prefix, tid);
 		if (sparse) {
 			__syncthreads();
@@ -754,6 +837,7 @@ __device__ __forceinline__ void vardct_special_body(DevPlan plan_arg, const DevV
 				t[0] = v[0]; t[P] = v[1]; t[2 * P] = v[2];
 			}
 		}
+		if (BATCH && J40_K2_AHEAD && tid < 64) k2_copies_wait();   // (K2Ahead)
 		__syncthreads();
 		K2_PHASE(2);
 		// eight lanes per tile, the eight tiles of a wavefront side by side; a tile's lanes sit in one wavefront, so the two phases
