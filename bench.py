@@ -466,7 +466,7 @@ def main():
         stage("plan build + LfGroup tail (j40.h:6585-6720, 6544-6590, 5944)", "k_plan_place / _scan / _emit, k_lf_dequant_smooth_batch, k_llf_small_batch, k_llf_large_batch", st["lf_plan_ms"] / launches, frames_per_launch,
               "HIP events on the batch's stream around the stage (includes what the stage waited for behind other kernels)"),
         stage("entropy decode (j40.h:6888-7005)", "k_hf_lanes", k1_launch_ms, frames_per_launch, "device-recorded start / end events of the kernel"),
-        stage("pixels (j40.h:7053-7247, 5690-6246)", "k_vardct_dct<...> x 12, k_vardct_special x 2, k_vardct_large", st["k2_ms"] / launches, frames_per_launch,
+        stage("pixels (j40.h:7053-7247, 5690-6246)", "k_vardct_dct<...> x 12, k_vardct_special_{123,halves,afv}, k_vardct_large", st["k2_ms"] / launches, frames_per_launch,
               "HIP events around the stage: four chains of persistent launches on four streams, fork to join"),
     ]
     stages = [x for x in stages if x]

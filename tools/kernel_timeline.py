@@ -3,10 +3,15 @@
 duration, its queue and a short name, in start order -- who runs beside whom in the pipeline's steady state -- and, per 50 ms
 window, how many of j40hip's stages had a kernel running.
 usage: python tools/kernel_timeline.py <dir with *.db> out.txt [min ms] [skip ms from the first dispatch] [at most ms]"""
-import glob, sqlite3, sys
+import glob, re, sqlite3, sys
 
 
 def short(name):
+    m = re.match(r"_ZN6j40hip(\d+)", name)   # (rocpd keeps mangled names: namespace j40hip, then the length-prefixed kernel name)
+    if m:
+        at = m.end(); n = int(m.group(1)); rest = name[at + n:]
+        t = re.match(r"I((?:L[ib]\d+E)+)E", rest)   # template arguments that are integer / bool literals
+        return (name[at:at + n] + ("<" + ",".join(re.findall(r"L[ib](\d+)E", t.group(1))) + ">" if t else ""))[:44]
     n = name.replace("j40hip::", "").replace("void ", "")
     n = n.split("(")[0]
     return n[:44]

@@ -7,7 +7,8 @@ rm -f $D/r05_gputest_*_passed.txt
 cp $S/gputest.txt $D/r05_gputest_${n}_passed.txt
 for f in api_one_thread_latency.json api_64_threads.json api_128_threads.json bench_default.json bench_steps20_warmup5.json smoke.txt \
 	kernel_stats_device_output_b256.txt kernel_stats_lf_launch_alone_b256.txt kernel_stats_one_batch_alone_b256.txt \
-	probe_device_output_b256.json probe_lf_launch_alone_b256.json probe_one_batch_alone_b256.json pmc_traffic.json rccl_dry_run.json; do
+	probe_device_output_b256.json probe_lf_launch_alone_b256.json probe_one_batch_alone_b256.json pmc_traffic.json rccl_dry_run.json \
+	timeline_device_output_b256.txt timeline_one_batch_alone_b256.txt; do
 	cp $S/$f $D/r05_$f
 done
 cp $S/pmc_fetch.txt $D/r05_pmc_fetch_device_output.txt

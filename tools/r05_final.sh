@@ -3,7 +3,7 @@
 # profiles/ as r05_*). Every step under a timeout.
 #   1. the GPU suite, smoke()
 #   2. the default bench line and the driver's (--steps 20 --warmup 5)
-#   3. rocprofv3 --kernel-trace --stats: one batch alone (the stages' kernels with the device to themselves), the LfGroup launch
+#   3. rocprofv3 --kernel-trace --stats (+ tools/kernel_timeline.py: who runs beside whom): one batch alone (the stages' kernels with the device to themselves), the LfGroup launch
 #      alone, the pipeline with the pixels left in HBM (the stages overlapped as in the steady state)
 #   4. PMC passes over that last command, one counter group per pass (FETCH_SIZE; WRITE_SIZE; two SQ groups), j40hip's kernels only
 #      -> r05_pmc_traffic.json (bench.py's roofline.stages[].traffic)
@@ -32,7 +32,7 @@ timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>
 timeout 600 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench_default rc=$?" >> $O/rc.txt
 timeout 600 python $R/bench.py --steps 20 --warmup 5 > $O/bench_steps20_warmup5.json 2> $O/bench_steps20_warmup5.err; echo "bench_steps20 rc=$?" >> $O/rc.txt
 kt() { name=$1; shift; ( cd /tmp && timeout 240 env "$@" rocprofv3 --kernel-trace --stats -d /tmp/kt_$name -- python $R/tools/r05_probe.py 256 16 6 > $O/kt_$name.log 2>&1 ); echo "kt_$name rc=$?" >> $O/rc.txt
-	python tools/prof_summary.py /tmp/kt_$name $O/kernel_stats_$name.txt > /dev/null 2>&1; rm -rf /tmp/kt_$name; grep -h '^{' $O/kt_$name.log > $O/probe_$name.json; }
+	python tools/prof_summary.py /tmp/kt_$name $O/kernel_stats_$name.txt > /dev/null 2>&1; python tools/kernel_timeline.py /tmp/kt_$name $O/timeline_$name.txt 1.0 0 > /dev/null 2>&1; rm -rf /tmp/kt_$name; grep -h '^{' $O/kt_$name.log > $O/probe_$name.json; }
 kt one_batch_alone_b256 PROBE_ONLY=alone
 kt lf_launch_alone_b256 PROBE_ONLY=lf_alone
 kt device_output_b256 PROBE_ONLY=device
