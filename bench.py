@@ -81,6 +81,28 @@ def pin_to_gpu_numa_node(torch, local_rank):
         return {"pinned": False, "why": "%s: %s" % (type(e).__name__, e)}
 
 
+def cgroup_cpu_stat():
+    """the container's CPU accounting (cgroup v2: cpu.stat; v1: cpu/cpu.stat + cpuacct/cpuacct.usage), or None: what the process group
+    used and how often the kernel throttled it -- the copies back are completed by host threads, and a throttled process's copies crawl"""
+    def pairs(path):
+        out = {}
+        for line in open(path):
+            k, _, v = line.partition(" ")
+            out[k] = int(v)
+        return out
+    try:
+        return pairs("/sys/fs/cgroup/cpu.stat")
+    except (OSError, ValueError):
+        pass
+    try:
+        out = pairs("/sys/fs/cgroup/cpu/cpu.stat")
+        out["usage_usec"] = int(open("/sys/fs/cgroup/cpuacct/cpuacct.usage").read()) // 1000
+        out["throttled_usec"] = out.get("throttled_time", 0) // 1000
+        return out
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(data, width, height, budget_s=12.0):
     """the unmodified reference (oracle/_ref) on ONE host core, same codestream, bounded sample"""
     from refdec import Ref, REF_SO
@@ -299,7 +321,9 @@ def main():
 
     for _ in range(max(args.warmup, 0)):
         run_pipeline_steps(pipe, step_bufs, step_sizes, step_outs, W * 4, False, 1, torch, dev, None)
+    cg0 = cgroup_cpu_stat()
     elapsed, tickets = run_pipeline_steps(pipe, step_bufs, step_sizes, step_outs, W * 4, False, args.steps, torch, dev, dist)
+    cg1 = cgroup_cpu_stat()
     st = pipe.stats()
     for t in tickets:
         assert pipe.result(t) == "", "decode error: " + pipe.result(t)
@@ -435,7 +459,10 @@ def main():
                      "algorithmic_bytes_per_launch": int(alg_launch),
                      "step_frac": round(alg_step * args.steps / elapsed / 8e12, 6),
                      "note": "kernel_ms: k_hf_lanes' own duration inside the timed region, from HIP events the device records at the kernel's start and end (hipExtLaunchKernelGGL; what rocprofv3 --kernel-trace reports), averaged over the launches; other batches' stages run beside it (`kernel_alone`: the same launch with the device to itself); step_frac = algorithmic bytes of the steps / wall time / peak -- the wall time of `value` is PCIe time, see device_output for the device's own pace"},
-        "pipeline": {"host_stage_ms_per_frame": round(st["parse_thread_ms"] / max(st["completed"] - st["single_frames"], 1), 2),
+        "pipeline": {"cgroup_cpu_in_region": None if not (cg0 and cg1) else {"cpus_used_on_average": round((cg1["usage_usec"] - cg0["usage_usec"]) / 1e6 / max(elapsed, 1e-9), 2),
+                                                                                   "periods": cg1.get("nr_periods", 0) - cg0.get("nr_periods", 0), "periods_throttled": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0),
+                                                                                   "throttled_s": round((cg1.get("throttled_usec", 0) - cg0.get("throttled_usec", 0)) / 1e6, 3)},
+                     "host_stage_ms_per_frame": round(st["parse_thread_ms"] / max(st["completed"] - st["single_frames"], 1), 2),
                      "lf_streams_plan_tail_ms_per_launch": round(st["lf_plan_ms"] / launches, 3), "entropy_ms_per_launch": round(k1_stage_ms, 3), "pixel_kernels_ms_per_launch": round(st["k2_ms"] / launches, 3),
                      "host_threads": threads, "cpu_quota": quota, "cpu_quota_per_rank": round(quota / world, 2), "numa": numa, "lf_streams": args.lf_streams, "lf_streams_on_device_frames": st["lf_device_frames"], "frames": st["completed"],
                      "single_frame_path_frames": st["single_frames"],
