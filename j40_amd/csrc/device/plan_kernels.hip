@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(64) k_plan_place_lanes(const DevPlanBuild *bui
 //   * lane g counts the blocks of group g, lane d those of DctSelect d; the thresholds of the quantisation-field index sit one per
 //     lane and are counted with a ballot; the transforms' sizes sit one per lane;
 //   * the records of 64 consecutive varblocks collect one per lane and leave as one coalesced store.
-// Same results as plan_place_lf_group (which tests/hostsim checks against the host path): tests/test_pipeline.py runs both forms.
+// Same results as plan_place_lf_group (which tests/hostsim checks against the host path): tests/test_device_stages.py runs every form.
 __device__ __forceinline__ int32_t pp_rl(int32_t v, int32_t lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ int32_t pp_sc(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(64) k_plan_place_walk(const DevPlanBuild *buil
 // already (the info channel's entries sit one per lane). The ranks: the count before the chunk (lane = group / class, fetched with a
 // bpermute) plus the varblocks of the same group / class in lower lanes -- one ballot per distinct group / class of the chunk.
 // Same products as the walk above and as plan_place_lf_group (tests/test_device_stages.py pins them against the reference's
-// internals, tests/test_pipeline.py runs the forms against each other); J40HIP_PLAN_PLACE_FORM=1 selects the walk above.
+// internals -- the earlier forms too, each in a process of its own); J40HIP_PLAN_PLACE_FORM=1 selects the walk above.
 __device__ __forceinline__ int32_t pp_below(uint64_t m) { return (int32_t) __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u)); }   // set bits of m below this lane
 
 __global__ void __launch_bounds__(64) k_plan_place(const DevPlanBuild *builds, const DevBatchLf *lfs, int32_t nlf) {

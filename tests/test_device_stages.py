@@ -146,3 +146,17 @@ def test_damaged_lf_sections_get_the_reference_verdict_from_the_device_stages(bu
         rejected += rerr != ""
         sd.close()
     assert agreed >= 25 and rejected >= 10, (agreed, rejected)
+
+
+@pytest.mark.parametrize("env", [{"J40HIP_PLAN_PLACE_FORM": "1"}, {"J40HIP_PLAN_PLACE_LANES": "1"}], ids=["walk", "lanes"])
+def test_the_placement_kernels_earlier_forms_give_the_same_products(built, env):
+    """k_plan_place_walk (everything inside the serial walk) and k_plan_place_lanes (an LfGroup per lane) stay in the library for
+    comparisons; the form is read once per process, so each runs the comparison above -- three streams, both damaged-section
+    cases -- in a process of its own"""
+    import os, subprocess, sys
+    from streams import ROOT
+    run = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_device_stages.py"),
+                          "-k", "(equal_the_reference_internals and (2600-2100-32 or 2049-300-33 or 776-520-3-)) or damaged"],
+                         cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-2000:]
+    assert " passed" in run.stdout and "failed" not in run.stdout, run.stdout[-1000:]
