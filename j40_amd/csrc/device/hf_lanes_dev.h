@@ -237,6 +237,9 @@ J40_DEV void decode_hf_sections_lane(const LaneFrame &f, const LaneTables &t, co
 		// coefficients takes this block instead: the refill, the two context look-ups, the symbol (its state has been read: no first-
 		// symbol test), the event, the counts; the channel's end, an error or the section's end leave `in_coeffs` / `done` for the
 		// general turn, which then runs on every NZ_PERIOD-th turn only and only for the lanes that are not here.
+		// (With the event ring: a lane adds at most one event a turn here too -- one that leaves its coefficients in this block takes a
+		// count symbol in the general turn, not a coefficient; the one exception would be a state of exactly zero behind a symbol, which
+		// sends the lane's next coefficient through the general turn in the same turn: the ring's 2 F slots then hold F - 1 + F + 1.)
 		if (SCAN && J40_LANE_STRAIGHT_COEFFS) {
 			if (in_coeffs && !done && state != 0) {   // (a state of zero is read afresh, j40.h:2445: the general turn's business, if a stream ever gets there)
 				if (J40_LANE_REFILL_SELECTS) {   // lane_bits_refill as selects (lf_rows_dev.h); the word after next is asked for every turn
