@@ -318,6 +318,25 @@ def main():
     nh = args.host_buffers or min(D, B, 64 if world == 1 else 24)
     host_outs = [torch.empty((H, W, 4), dtype=torch.uint8).pin_memory() for _ in range(nh)]
     step_outs = [host_outs[i % nh] for i in range(B)]
+    # the link as this process finds it, before anything else runs: one device image copied into every landing buffer in turn (the
+    # copy the pipeline issues per frame: hipMemcpyAsync of 133 MB, device -> pinned host), each timed by itself on an idle device
+    link_probe = None
+    try:
+        src = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
+        rates = []
+        for rep in range(2):
+            for hbuf in host_outs:
+                torch.cuda.synchronize(dev); t0 = time.perf_counter()
+                hbuf.copy_(src, non_blocking=True)
+                torch.cuda.synchronize(dev)
+                if rep:
+                    rates.append(hbuf.numel() / (time.perf_counter() - t0) / 1e9)
+        rates.sort()
+        link_probe = {"d2h_gb_per_s_per_landing_buffer": {"min": round(rates[0], 2), "median": round(rates[len(rates) // 2], 2), "max": round(rates[-1], 2), "buffers": len(rates)},
+                      "how": "before the warm-up, idle device: one 133 MB device image copied into each pinned landing buffer by itself (second pass timed)"}
+        del src
+    except RuntimeError as e:
+        link_probe = {"error": str(e)[:200]}
 
     for _ in range(max(args.warmup, 0)):
         run_pipeline_steps(pipe, step_bufs, step_sizes, step_outs, W * 4, False, 1, torch, dev, None)
@@ -472,7 +491,12 @@ def main():
     if device_output is not None:
         result["device_output"] = device_output
     result["pcie"] = {"bytes_back_per_step": 4 * W * H * B, "achieved_gb_per_s": round(4 * W * H * frames_total / world / elapsed / 1e9, 2),
-                      "note": "RGBA copied back per GPU during the timed region / wall time; a Gen5 x16 link moved 57 GB/s device-to-host on these boxes (tools/pcie_probe.py): 14.2 Gpx/s is the ceiling of `value` per GPU"}
+                      "note": "RGBA copied back per GPU during the timed region / wall time; a Gen5 x16 link moved 57 GB/s device-to-host on these boxes (tools/pcie_probe.py): 14.2 Gpx/s is the ceiling of `value` per GPU",
+                      "link_probe": link_probe}
+    if link_probe and "d2h_gb_per_s_per_landing_buffer" in link_probe:
+        med = link_probe["d2h_gb_per_s_per_landing_buffer"]["median"]
+        result["pcie"]["slow_run"] = bool(result["pcie"]["achieved_gb_per_s"] < 0.85 * med)
+        result["pcie"]["slow_run_rule"] = "the region's copy rate below 0.85 x the idle link's (median of the probe)"
     if resident_multi is not None:
         result["device_resident"] = resident_multi
     if sharded is not None:

@@ -134,6 +134,7 @@ struct j40hip_pipeline {
 	std::vector<Slot> slots;
 	std::deque<int> in_flight;          // slot indices, oldest first
 	hipStream_t copy_stream = nullptr;  // every copy of pixels back to host memory, in launch order: one DMA queue at the link's rate
+	std::vector<hipStream_t> copy_streams;   // copy_stream first; J40HIP_COPY_STREAMS=n: the groups of a batch's copies go to n streams in turn
 	// device images for host output, recycled by size
 	std::mutex image_m;
 	std::vector<std::pair<void *, size_t>> free_images;
@@ -394,10 +395,11 @@ uint32_t launch_batch(j40hip_pipeline *p, std::vector<Job *> &take, int si) {
 	static const int groups = [] { const char *e = getenv("J40HIP_COPY_GROUPS"); return e && atoi(e) > 0 ? atoi(e) : 16; }();
 	const int per_group = host_out ? std::max(1, (n + groups - 1) / groups) : n;
 	hipStream_t gs = host_out ? p->copy_stream : slot.stream;
-	if (host_out && !slot.launch_err && hipStreamWaitEvent(p->copy_stream, slot.kdone, 0) != hipSuccess) slot.launch_err = E_GPU;
+	if (host_out) for (hipStream_t cs : p->copy_streams) if (!slot.launch_err && hipStreamWaitEvent(cs, slot.kdone, 0) != hipSuccess) slot.launch_err = E_GPU;
 	for (int i = 0; i < n; ++i) {
 		Job *j = take[(size_t) i];
-		if (!slot.launch_err && !j->device_output && hipMemcpyAsync(j->rgba, j->dev_rgba, j->stride * (size_t) j->height, hipMemcpyDeviceToHost, p->copy_stream) != hipSuccess) j->status = E_GPU;
+		if (host_out) gs = p->copy_streams[slot.group_end.size() % p->copy_streams.size()];   // (a group's copies and its event on one stream)
+		if (!slot.launch_err && !j->device_output && hipMemcpyAsync(j->rgba, j->dev_rgba, j->stride * (size_t) j->height, hipMemcpyDeviceToHost, gs) != hipSuccess) j->status = E_GPU;
 		if ((i + 1) % per_group == 0 || i + 1 == n) {
 			const size_t g = slot.group_end.size();
 			while (slot.group_ev.size() <= g) { hipEvent_t e = nullptr; if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { (void) hipGetLastError(); break; } slot.group_ev.push_back(e); }
@@ -406,7 +408,7 @@ uint32_t launch_batch(j40hip_pipeline *p, std::vector<Job *> &take, int si) {
 			slot.group_end.push_back(i + 1);
 		}
 	}
-	if (slot.launch_err) { (void) hipStreamSynchronize(slot.stream); if (host_out) (void) hipStreamSynchronize(p->copy_stream); }   // (whatever did get enqueued: nothing may run on memory that is handed back)
+	if (slot.launch_err) { (void) hipStreamSynchronize(slot.stream); if (host_out) for (hipStream_t cs : p->copy_streams) (void) hipStreamSynchronize(cs); }   // (whatever did get enqueued: nothing may run on memory that is handed back)
 	p->in_flight.push_back(si);
 	return slot.launch_err;
 }
@@ -592,7 +594,25 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 			int lo = 0, hi = 0; (void) hipDeviceGetStreamPriorityRange(&lo, &hi);
 			const char *e = getenv("J40HIP_COPY_PRIORITY");
 			const int prio = e && !strcmp(e, "low") ? lo : e && !strcmp(e, "high") ? hi : (lo + hi) / 2;
-			if (hipStreamCreateWithPriority(&p->copy_stream, hipStreamNonBlocking, prio) != hipSuccess) { (void) hipGetLastError(); if (hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) *err = E_GPU; }
+			// (J40HIP_COPY_STREAM=mask: a stream with a CU mask -- all CUs -- has a hardware queue of its own, shared with no other stream;
+			// J40HIP_COPY_STREAMS=n: n such streams, a batch's copy groups dealt out in turn)
+			const char *kind = getenv("J40HIP_COPY_STREAM");
+			const int ncopy = [] { const char *c = getenv("J40HIP_COPY_STREAMS"); return c && atoi(c) > 0 ? std::min(8, atoi(c)) : 1; }();
+			for (int k = 0; k < ncopy && !*err; ++k) {
+				hipStream_t cs = nullptr;
+				if (kind && !strcmp(kind, "mask")) {
+					hipDeviceProp_t pr;
+					if (hipGetDeviceProperties(&pr, p->device) == hipSuccess) {
+						const int cus = pr.multiProcessorCount;
+						std::vector<uint32_t> mask((size_t) (cus + 31) / 32, 0xffffffffu);
+						if (cus % 32) mask.back() = (1u << (cus % 32)) - 1u;
+						if (hipExtStreamCreateWithCUMask(&cs, (uint32_t) mask.size(), mask.data()) != hipSuccess) { (void) hipGetLastError(); cs = nullptr; }
+					}
+				}
+				if (!cs && hipStreamCreateWithPriority(&cs, hipStreamNonBlocking, prio) != hipSuccess) { (void) hipGetLastError(); if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) *err = E_GPU; }
+				if (cs) p->copy_streams.push_back(cs);
+			}
+			if (!p->copy_streams.empty()) p->copy_stream = p->copy_streams[0];
 		}
 		{   // The LfGroup launches run for a quarter of a second each. Streams of one priority share a handful of hardware queues, and a
 			// kernel waits for the kernels ahead of it in its queue whichever stream they came from: on a stream of the batches' priority
@@ -636,7 +656,7 @@ void j40hip_pipeline_free(j40hip_pipeline *p) {
 		if (s.kdone) (void) hipEventDestroy(s.kdone);
 		if (s.stream && (&s == &p->slots[0] || s.stream != p->slots[0].stream)) (void) hipStreamDestroy(s.stream);
 	}
-	if (p->copy_stream) (void) hipStreamDestroy(p->copy_stream);
+	for (hipStream_t cs : p->copy_streams) if (cs) (void) hipStreamDestroy(cs);
 	delete p;
 }
 

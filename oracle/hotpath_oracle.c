@@ -924,3 +924,143 @@ ORACLE_API uint32_t oracle_decode_modular(const j40hip_modular_view *v, uint8_t 
 	for (c = 0; c < nplanes; ++c) free(planes[c].px);
 	return err;
 }
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Restoration filters: Gaborish (j40.h:7271-7325) and the edge-preserving filter (j40.h:7338-7625), restated over
+ * the whole picture (the reference notes that they apply to the entire image, j40.h:7268), out of place: every output sample is a
+ * function of the step's INPUT planes (the reference works in place behind line buffers that hold the input rows, which is the
+ * same thing). The reference defines these routines and never calls them; tests/test_oracle.py pins this restatement against the
+ * routines themselves (oracle/ref_harness.c: ref_kat_gaborish, ref_kat_epf), bit for bit. What they compute is kept as it stands
+ * there, also where it departs from ISO 18181-1: the filter taps are fetched at (x + k[1], y + k[0]) while the distances are taken
+ * towards (x + k[0], y + k[1]) (j40.h:7338, 7490, 7551); the border weight applies where BOTH coordinates are at a block edge
+ * (j40.h:7529); twelve-tap kernel with repeated entries (j40.h:7579); the sign of the weight slope (j40.h:7466). */
+
+static int32_t omirror(int32_t c, int32_t size) {  /* j40.h:7327 */
+	for (;;) { if (c < 0) c = -c - 1; else if (c >= size) c = size * 2 - 1 - c; else return c; }
+}
+static int osurely_nonzero(float x) { return isfinite(x) && fabs(x) >= 1e-8f; }  /* j40.h:625 */
+
+/* three planes of w*h floats, in place; weights6 = gab.weights[c][j]. 0, "gab0" (j40.h:7289) or "!mem". */
+ORACLE_API uint32_t oracle_gaborish(float *px, float *py, float *pb, int32_t w, int32_t h, const float *weights6) {
+	float *planes[3], *in = (float *) malloc(sizeof(float) * (size_t) w * (size_t) h);
+	int32_t c, x, y;
+	planes[0] = px; planes[1] = py; planes[2] = pb;
+	if (!in) return E4('!', 'm', 'e', 'm');
+	for (c = 0; c < 3; ++c) {
+		float w0 = 1.0f, w1 = weights6[c * 2], w2 = weights6[c * 2 + 1], wsum = w0 + w1 * 4 + w2 * 4;
+		if (!osurely_nonzero(wsum)) { free(in); return E4('g', 'a', 'b', '0'); }
+		w0 /= wsum; w1 /= wsum; w2 /= wsum;
+		memcpy(in, planes[c], sizeof(float) * (size_t) w * (size_t) h);
+		for (y = 0; y < h; ++y) {
+			const float *n = in + (size_t) (y > 0 ? y - 1 : 0) * (size_t) w, *l = in + (size_t) y * (size_t) w, *s = in + (size_t) (y + 1 < h ? y + 1 : y) * (size_t) w;
+			float *o = planes[c] + (size_t) y * (size_t) w;
+			if (w < 2) continue;  /* (the reference reads index 1 of a one-sample row: not restated) */
+			o[0] = n[0] * (w2 + w1) + n[1] * w2 + l[0] * (w1 + w0) + l[1] * w1 + s[0] * (w2 + w1) + s[1] * w2;
+			for (x = 1; x < w - 1; ++x) o[x] = n[x - 1] * w2 + n[x] * w1 + n[x + 1] * w2 + l[x - 1] * w1 + l[x] * w0 + l[x + 1] * w1 + s[x - 1] * w2 + s[x] * w1 + s[x + 1] * w2;
+			o[w - 1] = n[w - 2] * w2 + n[w - 1] * (w1 + w2) + l[w - 2] * w1 + l[w - 1] * (w0 + w1) + s[w - 2] * w2 + s[w - 1] * (w1 + w2);
+		}
+	}
+	free(in);
+	return 0;
+}
+
+/* |in(x, y) - in(x + dx, y + dy)| with both positions mirrored into the picture: one entry of j40__epf_distance's plane (j40.h:7338-7369) */
+static float oepf_dist(const float *in, int32_t w, int32_t h, int32_t x, int32_t y, int32_t dx, int32_t dy) {
+	return fabsf(in[(size_t) omirror(y, h) * (size_t) w + (size_t) omirror(x, w)] - in[(size_t) omirror(y + dy, h) * (size_t) w + (size_t) omirror(x + dx, w)]);
+}
+
+/* A tap of the weighted sum: the step's input at (x + k1, y + k0), mirrored (the reference's `lines[2 + k0][c][x + k1]`, j40.h:7551;
+ * k0 = k1 = 0 is the centre sample, j40.h:7536).
+ * quirk = 0: exactly that -- what the routine's steady-state loop sets out to do (j40.h:7505-7512), and what the HIP kernels compute by
+ * default. quirk = 1: what j40__epf_step ACTUALLY reads, so that this file can be held against the routine bit for bit, all channels.
+ * Its line buffer gives each channel three row slots (`cstride = stride * 3`, j40.h:7437) for FOUR buffered rows (j40.h:7482), so the
+ * fourth row slot of channel c is the first of channel c + 1, and a channel's rows are copied in after its predecessor's
+ * (j40.h:7499-7511): for c < 2 the row "y" read at y % 4 == 0 is channel c + 1's row y + 1, and the row "y - 1" read at y % 4 == 1 is
+ * channel c + 1's row y. And the mirrored borders of the three rows buffered before the loop are written with `c * cstride` added to
+ * row pointers that already include it (j40.h:7484-7488): right for channel 0; channel 1's land in channel 2's slots (computed from
+ * rows not yet copied in), channel 2's past the end of the buffer -- so where rows 0 and 1 read picture row 0 from those first buffers,
+ * channels 1 and 2 find border slots nobody wrote: 0.0f under the zero-filling allocator of oracle/ref_harness.c (REF_ZEROED_ALLOC),
+ * heap corruption under malloc. */
+static float oepf_tap(float *const in[3], int32_t w, int32_t h, int32_t x, int32_t y, int32_t k0, int32_t k1, int c, int quirk) {
+	int32_t xx = x + k1, yy = y + k0;
+	if (quirk) {
+		if (c < 2 && ((k0 == 0 && (y & 3) == 0) || (k0 == -1 && (y & 3) == 1))) { ++c; ++yy; }   /* the slot holds the next channel's row */
+		else if (c > 0 && (xx < 0 || xx >= w) && ((y == 0 && k0 <= 0) || (y == 1 && k0 < 0))) return 0.0f;   /* a border slot of the first buffers */
+	}
+	return in[c][(size_t) omirror(yy, h) * (size_t) w + (size_t) omirror(xx, w)];
+}
+
+/* one j40__epf_step (j40.h:7427-7576) */
+static void oepf_step(float *planes[3], float *in[3], int32_t w, int32_t h, int32_t w8, const float *recip_sigmas, float sigma_scale, float border_sad_mul,
+		const float *channel_scale, int32_t nk, const int32_t (*k)[2], int cross, int quirk) {
+	int32_t x, y, c, i;
+	float border_sigma_scale;
+	sigma_scale *= 1.9330952441687859f;
+	border_sigma_scale = sigma_scale * border_sad_mul;
+	for (c = 0; c < 3; ++c) memcpy(in[c], planes[c], sizeof(float) * (size_t) w * (size_t) h);
+	for (y = 0; y < h; ++y) for (x = 0; x < w; ++x) {
+		float rs = recip_sigmas[(size_t) (y / 8) * (size_t) w8 + (size_t) (x / 8)], ism, sum_w = 1.0f, sum[3];
+		if (rs < 0.0f) continue;  /* the whole cell keeps its samples (j40.h:7521-7524) */
+		ism = rs * (((((x + 1) | (y + 1)) & 7) < 2) ? border_sigma_scale : sigma_scale);
+		for (c = 0; c < 3; ++c) sum[c] = oepf_tap(in, w, h, x, y, 0, 0, c, quirk);
+		for (i = 0; i < nk; ++i) {
+			float dist = 0.0f, weight;
+			for (c = 0; c < 3; ++c) {
+				if (cross) dist += channel_scale[c] * (oepf_dist(in[c], w, h, x, y, k[i][0], k[i][1]) + oepf_dist(in[c], w, h, x - 1, y, k[i][0], k[i][1]) +
+					oepf_dist(in[c], w, h, x, y - 1, k[i][0], k[i][1]) + oepf_dist(in[c], w, h, x, y + 1, k[i][0], k[i][1]) + oepf_dist(in[c], w, h, x + 1, y, k[i][0], k[i][1]));
+				else dist += channel_scale[c] * oepf_dist(in[c], w, h, x, y, k[i][0], k[i][1]);
+			}
+			weight = 1.0f + dist * ism;
+			weight = 0.0f > weight ? 0.0f : weight;
+			sum_w += weight;
+			for (c = 0; c < 3; ++c) sum[c] += oepf_tap(in, w, h, x, y, k[i][0], k[i][1], c, quirk) * weight;
+		}
+		for (c = 0; c < 3; ++c) planes[c][(size_t) y * (size_t) w + (size_t) x] = sum[c] / sum_w;
+	}
+}
+
+static const int32_t OEPF_K12[12][2] = {{0, -2}, {-1, -1}, {-1, 0}, {-1, 1}, {0, -2}, {0, -1}, {0, 1}, {0, 2}, {-1, 1}, {-1, 0}, {-1, 1}, {0, 2}};  /* j40.h:7579 */
+static const int32_t OEPF_K4[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};
+
+/* one step by itself (0, 1, 2 as j40__epf runs them, j40.h:7606-7616) on a given plane of reciprocal sigmas */
+ORACLE_API uint32_t oracle_epf_step(float *px, float *py, float *pb, int32_t w, int32_t h, const float *recip_sigmas, int32_t step, const float *params15, int32_t quirk) {
+	float *planes[3], *in[3];
+	int c;
+	planes[0] = px; planes[1] = py; planes[2] = pb;
+	for (c = 0; c < 3; ++c) in[c] = (float *) malloc(sizeof(float) * (size_t) w * (size_t) h);
+	if (in[0] && in[1] && in[2]) oepf_step(planes, in, w, h, (w + 7) / 8, recip_sigmas, step == 0 ? params15[12] : step == 1 ? 1.0f : params15[13], params15[14], params15 + 8,
+		step == 0 ? 12 : 4, step == 0 ? OEPF_K12 : OEPF_K4, step != 2, quirk);
+	for (c = 0; c < 3; ++c) free(in[c]);
+	return in[0] && in[1] && in[2] ? 0 : E4('!', 'm', 'e', 'm');
+}
+
+/* three planes of w*h floats, in place. sharpness: int16[w8*h8] as decoded; hfmul_inv: float[w8*h8], the HfMul reciprocal of the
+ * varblock covering each cell; params15 = sharp_lut[8], channel_scale[3], quant_mul, pass0_sigma_scale, pass2_sigma_scale,
+ * border_sad_mul; sigma_out (optional): the plane of j40__epf_recip_sigmas (j40.h:7374-7425); quirk: see oepf_tap. 0, "epf0", "shrp" or "!mem". */
+ORACLE_API uint32_t oracle_epf(float *px, float *py, float *pb, int32_t w, int32_t h, const int16_t *sharpness, const float *hfmul_inv, int32_t iters,
+		const float *params15, float *sigma_out, int32_t quirk) {
+	int32_t w8 = (w + 7) / 8, h8 = (h + 7) / 8, i, c;
+	float lut[8], *rs, *planes[3], *in[3] = {NULL, NULL, NULL};
+	uint16_t ub = 0;
+	uint32_t err = 0;
+	if (iters <= 0) return 0;
+	planes[0] = px; planes[1] = py; planes[2] = pb;
+	for (i = 0; i < 8; ++i) {
+		float q = params15[11] * params15[i];
+		if (!osurely_nonzero(q)) return E4('e', 'p', 'f', '0');
+		lut[i] = 1.0f / q;
+	}
+	rs = (float *) malloc(sizeof(float) * (size_t) w8 * (size_t) h8);
+	for (c = 0; c < 3; ++c) in[c] = (float *) malloc(sizeof(float) * (size_t) w * (size_t) h);
+	if (!rs || !in[0] || !in[1] || !in[2]) { err = E4('!', 'm', 'e', 'm'); goto done; }
+	for (i = 0; i < w8 * h8; ++i) { ub |= (uint16_t) sharpness[i]; rs[i] = lut[sharpness[i] & 7]; }
+	if (!(ub < 8)) { err = E4('s', 'h', 'r', 'p'); goto done; }
+	for (i = 0; i < w8 * h8; ++i) { rs[i] *= hfmul_inv[i]; if (rs[i] > 1.0f / 0.3f) rs[i] = -1.0f; }
+	if (sigma_out) memcpy(sigma_out, rs, sizeof(float) * (size_t) w8 * (size_t) h8);
+	if (iters >= 3) oepf_step(planes, in, w, h, w8, rs, params15[12], params15[14], params15 + 8, 12, OEPF_K12, 1, quirk);
+	if (iters >= 1) oepf_step(planes, in, w, h, w8, rs, 1.0f, params15[14], params15 + 8, 4, OEPF_K4, 1, quirk);
+	if (iters >= 2) oepf_step(planes, in, w, h, w8, rs, params15[13], params15[14], params15 + 8, 4, OEPF_K4, 0, quirk);
+done:
+	free(rs); for (c = 0; c < 3; ++c) free(in[c]);
+	return err;
+}

@@ -16,6 +16,26 @@
  * Build flags: -O3 without -march=native / -mfma (the VarDCT float path is contraction sensitive,
  * see j40.h:5834 and SURVEY.md section 0 fact 7).
  */
+#include <stdlib.h>
+#include <string.h>
+#ifdef REF_ZEROED_ALLOC
+/* _ref/libj40ref_zalloc.so: the same sources with the reference's allocator hooks (J40_MALLOC ..., j40.h:413-417) pointed at an
+ * allocator that zero-fills and leaves slack on both sides of every block. Needed to run j40__epf_step at all (the KATs of the
+ * restoration filters below; nothing else uses this build): the routine -- never called by the reference -- sets up the mirrored
+ * borders of its line buffer with `c * cstride` added to row pointers that already include it (j40.h:7484-7488), so channel 1's
+ * borders land in channel 2's slots, channel 2's past the end of the buffer, and the first two picture rows then read border
+ * slots of channels 1 and 2 that were never written; and its rotating row 0 writes one float in front of the buffer
+ * (`lines[3][c][-2]` once `linebuf + 1` has rotated into slot 3, j40.h:7512). Under malloc that is heap corruption ("double free or
+ * corruption" at the routine's own j40__free); under this allocator it is deterministic: the unwritten slots read 0.0f. */
+#define REF_SLACK 256
+static void *ref_zmalloc(size_t n) { char *p = (char *) calloc(1, n * 2 + 4096 + 2 * REF_SLACK); return p ? p + REF_SLACK : NULL; }
+static void ref_zfree(void *q) { if (q) free((char *) q - REF_SLACK); }
+static void *ref_zrealloc(void *q, size_t n) { char *p = (char *) realloc(q ? (char *) q - REF_SLACK : NULL, n * 2 + 4096 + 2 * REF_SLACK); return p ? p + REF_SLACK : NULL; }
+#define J40_MALLOC ref_zmalloc
+#define J40_CALLOC(n, s) ref_zmalloc((size_t) (n) * (size_t) (s))
+#define J40_REALLOC ref_zrealloc
+#define J40_FREE ref_zfree
+#endif
 #define J40_CONFIRM_THAT_THIS_IS_EXPERIMENTAL_AND_POTENTIALLY_UNSAFE
 #define J40_IMPLEMENTATION
 #include "j40.h"
@@ -368,4 +388,146 @@ REF_API void ref_kat_inverse_rct16(int16_t *p0, int16_t *p1, int16_t *p2, int32_
 		for (y = 0; y < h; ++y) memcpy(src[i] + (size_t) y * (size_t) w, J40__I16_PIXELS(&ch[i], y), sizeof(int16_t) * (size_t) w);
 		j40__free_plane(&ch[i]);
 	}
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* restoration filters: the reference's own routines (j40__gaborish j40.h:7271, j40__epf j40.h:7578 with j40__epf_distance 7338,
+ * j40__epf_recip_sigmas 7374, j40__epf_step 7427). The reference declares and defines them and never calls them (its decode
+ * ignores the frame header's `gab` / `epf` fields, j40.h:5339-5366); here they run on caller-supplied planes so that the HIP
+ * kernels and the restatement in hotpath_oracle.c can be held against them. */
+
+/* frame header's RestorationFilter as the reference parsed it (needs a staged decode): out[0] gab.enabled, out[1..6] gab.weights[c][j],
+ * out[7] epf.iters, out[8..15] sharp_lut, out[16..18] channel_scale, out[19] quant_mul, out[20] pass0_sigma_scale, out[21]
+ * pass2_sigma_scale, out[22] border_sad_mul, out[23] sigma_for_modular */
+REF_API void ref_stage_restoration(ref_stage *s, float *out24) {
+	j40__frame_st *f = &s->inner->frame;
+	int i, j, k = 0;
+	out24[k++] = (float) f->gab.enabled;
+	for (i = 0; i < 3; ++i) for (j = 0; j < 2; ++j) out24[k++] = f->gab.weights[i][j];
+	out24[k++] = (float) f->epf.iters;
+	for (i = 0; i < 8; ++i) out24[k++] = f->epf.sharp_lut[i];
+	for (i = 0; i < 3; ++i) out24[k++] = f->epf.channel_scale[i];
+	out24[k++] = f->epf.quant_mul; out24[k++] = f->epf.pass0_sigma_scale; out24[k++] = f->epf.pass2_sigma_scale;
+	out24[k++] = f->epf.border_sad_mul; out24[k++] = f->epf.sigma_for_modular;
+}
+
+static int ref_planes_in(j40__st *st, float *const src[3], int32_t w, int32_t h, j40__plane ch[3]) {
+	int c, y;
+	memset(ch, 0, sizeof(j40__plane) * 3);
+	for (c = 0; c < 3; ++c) {
+		if (j40__init_plane(st, J40__PLANE_F32, w, h, 0, &ch[c])) return -1;
+		for (y = 0; y < h; ++y) memcpy(J40__F32_PIXELS(&ch[c], y), src[c] + (size_t) y * (size_t) w, sizeof(float) * (size_t) w);
+	}
+	return 0;
+}
+static void ref_planes_out(float *const dst[3], int32_t w, int32_t h, j40__plane ch[3]) {
+	int c, y;
+	for (c = 0; c < 3; ++c) {
+		if (!ch[c].pixels) continue;
+		for (y = 0; y < h; ++y) memcpy(dst[c] + (size_t) y * (size_t) w, J40__F32_PIXELS(&ch[c], y), sizeof(float) * (size_t) w);
+		j40__free_plane(&ch[c]);
+	}
+}
+
+/* j40__gaborish on three tightly packed w*h planes, in place; weights6 = gab.weights[c][j]. Returns the reference's error code. */
+REF_API uint32_t ref_kat_gaborish(float *x, float *y, float *b, int32_t w, int32_t h, const float *weights6) {
+	j40__st stbuf, *st = &stbuf;
+	j40__frame_st *f = (j40__frame_st *) calloc(1, sizeof(j40__frame_st));
+	j40__plane ch[3];
+	float *p[3];
+	int i, j;
+	memset(st, 0, sizeof *st);
+	st->frame = f;
+	f->gab.enabled = 1;
+	for (i = 0; i < 3; ++i) for (j = 0; j < 2; ++j) f->gab.weights[i][j] = weights6[i * 2 + j];
+	p[0] = x; p[1] = y; p[2] = b;
+	if (ref_planes_in(st, p, w, h, ch) == 0) j40__gaborish(st, ch);
+	ref_planes_out(p, w, h, ch);
+	free(f);
+	return st->err;
+}
+
+/* one j40__epf_step (j40.h:7427) by itself, as j40__epf would call it (j40.h:7606-7616): step 0 = twelve taps, cross-shaped distances,
+ * pass0_sigma_scale; 1 = four taps, cross, scale 1; 2 = four taps, plain distances, pass2_sigma_scale. recip_sigmas: the w8*h8 plane
+ * of j40__epf_recip_sigmas. params15 as below. ONLY in the REF_ZEROED_ALLOC build (see the top of this file). */
+REF_API uint32_t ref_kat_epf_step(float *x, float *y, float *b, int32_t w, int32_t h, const float *recip_sigmas, int32_t step, const float *params15) {
+	static const int32_t K12[][2] = {{0,-2}, {-1,-1}, {-1,0}, {-1,1}, {0,-2}, {0,-1}, {0,1}, {0,2}, {-1,1}, {-1,0}, {-1,1}, {0,2}};  /* as j40.h:7579-7581 */
+	static const int32_t K4[][2] = {{0,-1}, {-1,0}, {1,0}, {0,1}};
+	j40__st stbuf, *st = &stbuf;
+	j40__frame_st *f = (j40__frame_st *) calloc(1, sizeof(j40__frame_st));
+	j40__lf_group_st gg;
+	j40__plane ch[3], rs = J40__INIT, distances[12][3] = J40__INIT;
+	float *p[3];
+	int32_t w8 = (w + 7) / 8, h8 = (h + 7) / 8, i, k, c, y8, nk = step == 0 ? 12 : 4;
+#ifndef REF_ZEROED_ALLOC
+	(void) x; (void) y; (void) b; (void) recip_sigmas; (void) params15; (void) gg; (void) ch; (void) rs; (void) distances; (void) p; (void) w8; (void) h8; (void) i; (void) k; (void) c; (void) y8; (void) nk; (void) st; (void) K12; (void) K4;
+	free(f);
+	return J40__4("TODO");
+#else
+	memset(st, 0, sizeof *st); memset(&gg, 0, sizeof gg); memset(ch, 0, sizeof ch);
+	st->frame = f;
+	for (i = 0; i < 3; ++i) f->epf.channel_scale[i] = params15[8 + i];
+	f->epf.border_sad_mul = params15[14];
+	gg.width = w; gg.height = h; gg.width8 = w8; gg.height8 = h8;
+	p[0] = x; p[1] = y; p[2] = b;
+	if (j40__init_plane(st, J40__PLANE_F32, w8, h8, J40__PLANE_FORCE_PAD, &rs)) goto done;
+	for (y8 = 0; y8 < h8; ++y8) memcpy(J40__F32_PIXELS(&rs, y8), recip_sigmas + (size_t) y8 * (size_t) w8, sizeof(float) * (size_t) w8);
+	for (k = 0; k < nk; ++k) for (c = 0; c < 3; ++c) if (j40__init_plane(st, J40__PLANE_F32, w + 2, h + 2, 0, &distances[k][c])) goto done;
+	if (ref_planes_in(st, p, w, h, ch)) goto done;
+	j40__epf_step(st, ch, step == 0 ? params15[12] : step == 1 ? 1.0f : params15[13], &rs, nk, step == 0 ? K12 : K4, distances, step != 2, &gg);
+done:
+	ref_planes_out(p, w, h, ch);
+	j40__free_plane(&rs);
+	for (k = 0; k < 12; ++k) for (c = 0; c < 3; ++c) j40__free_plane(&distances[k][c]);
+	free(f);
+	return st->err;
+#endif
+}
+
+/* j40__epf on three tightly packed w*h planes, in place, with ONE LfGroup-shaped record spanning the whole picture (the reference
+ * notes that the filters run over the entire image, j40.h:7268): `sharpness` is the w8*h8 map (int16, as decoded), `hfmul_inv` the
+ * HfMul reciprocal of the varblock covering each 8x8 cell (w8*h8; the harness gives every cell a varblock record of its own, which
+ * needs w8*h8 <= 2^20 -- the width of the reference's varblock index). params15 = sharp_lut[8], channel_scale[3], quant_mul,
+ * pass0_sigma_scale, pass2_sigma_scale, border_sad_mul. sigma_out (optional): j40__epf_recip_sigmas' plane (w8*h8). */
+REF_API uint32_t ref_kat_epf(float *x, float *y, float *b, int32_t w, int32_t h, const int16_t *sharpness, const float *hfmul_inv,
+		int32_t iters, const float *params15, float *sigma_out) {
+	j40__st stbuf, *st = &stbuf;
+	j40__frame_st *f = (j40__frame_st *) calloc(1, sizeof(j40__frame_st));
+	j40__lf_group_st gg;
+	j40__plane ch[3];
+	float *p[3];
+	int32_t w8 = (w + 7) / 8, h8 = (h + 7) / 8, i, y8, x8;
+	memset(st, 0, sizeof *st);
+	memset(&gg, 0, sizeof gg);
+	memset(ch, 0, sizeof ch);
+	st->frame = f;
+	if ((int64_t) w8 * h8 > (1 << 20)) { free(f); return J40__4("rnge"); }
+	f->is_modular = 0;
+	f->epf.iters = iters;
+	for (i = 0; i < 8; ++i) f->epf.sharp_lut[i] = params15[i];
+	for (i = 0; i < 3; ++i) f->epf.channel_scale[i] = params15[8 + i];
+	f->epf.quant_mul = params15[11]; f->epf.pass0_sigma_scale = params15[12]; f->epf.pass2_sigma_scale = params15[13]; f->epf.border_sad_mul = params15[14];
+	f->epf.sigma_for_modular = 1.0f;
+	gg.width = w; gg.height = h; gg.width8 = w8; gg.height8 = h8; gg.width64 = (w + 63) / 64; gg.height64 = (h + 63) / 64;
+	gg.nb_varblocks = w8 * h8;
+	gg.varblocks = (j40__varblock *) calloc((size_t) (w8 * h8), sizeof(j40__varblock));
+	p[0] = x; p[1] = y; p[2] = b;
+	if (!gg.varblocks || j40__init_plane(st, J40__PLANE_I16, w8, h8, 0, &gg.sharpness) || j40__init_plane(st, J40__PLANE_I32, w8, h8, 0, &gg.blocks)) goto done;
+	for (y8 = 0; y8 < h8; ++y8) for (x8 = 0; x8 < w8; ++x8) {
+		int32_t cell = y8 * w8 + x8;
+		J40__I16_PIXELS(&gg.sharpness, y8)[x8] = sharpness[cell];
+		J40__I32_PIXELS(&gg.blocks, y8)[x8] = cell | (2 << 20);
+		gg.varblocks[cell].hfmul.inv = hfmul_inv[cell];
+	}
+	if (sigma_out) {
+		j40__plane rs = J40__INIT;
+		if (!j40__epf_recip_sigmas(st, &gg, &rs)) { ref_copy_plane(&rs, sigma_out, 4); j40__free_plane(&rs); }
+		if (st->err) goto done;
+	}
+	if (ref_planes_in(st, p, w, h, ch) == 0) j40__epf(st, ch, &gg);
+done:
+	ref_planes_out(p, w, h, ch);
+	j40__free_plane(&gg.sharpness); j40__free_plane(&gg.blocks);
+	free(gg.varblocks); free(f);
+	return st->err;
 }
