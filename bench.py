@@ -492,7 +492,9 @@ def main():
         result["device_output"] = device_output
     result["pcie"] = {"bytes_back_per_step": 4 * W * H * B, "achieved_gb_per_s": round(4 * W * H * frames_total / world / elapsed / 1e9, 2),
                       "note": "RGBA copied back per GPU during the timed region / wall time; a Gen5 x16 link moved 57 GB/s device-to-host on these boxes (tools/pcie_probe.py): 14.2 Gpx/s is the ceiling of `value` per GPU",
-                      "link_probe": link_probe}
+                      "link_probe": link_probe,
+                      "copy_engine": j40_amd.copy_engine(local_rank),
+                      "copy_engine_note": "the copies back are issued on ONE SDMA engine the library measured as the fastest of the device's sixteen (hsa_amd_memory_async_copy_on_engine; j40_amd/csrc/device/hostcopy.hip): hipMemcpyAsync lets the runtime take whichever engine is free, and they range from 57 to 7 GB/s device to host -- that was rounds 4-5's 'slow runs'"}
     if link_probe and "d2h_gb_per_s_per_landing_buffer" in link_probe:
         med = link_probe["d2h_gb_per_s_per_landing_buffer"]["median"]
         result["pcie"]["slow_run"] = bool(result["pcie"]["achieved_gb_per_s"] < 0.85 * med)

@@ -342,6 +342,13 @@ J40HIP_API void j40hip_pipeline_stats_ex(j40hip_pipeline *p, double *out12);
 J40HIP_API void j40hip_pipeline_lf_stats(j40hip_pipeline *p, double *out5);
 J40HIP_API void j40hip_pipeline_reset_stats(j40hip_pipeline *p);
 
+/* The SDMA engine the pipeline's copies back to host memory go to on `device` (hsa_amd_memory_async_copy_on_engine; -1: none, the
+ * copies are hipMemcpyAsync). An MI355X has sixteen engines of very different device-to-host rates (57 ... 7 GB/s) and hipMemcpyAsync
+ * takes whichever is free; the library measures them once per process and device (32 MB each, at its first pipeline or at this call)
+ * and keeps the fastest. gbps16 (optional): the measured GB/s per engine, 0 = not measured, < 0 = failed; masks2 (optional): the
+ * runtime's masks {free, recommended} for the direction. J40HIP_COPY_ENGINE=hip: never; =<n>: engine n, unmeasured. */
+J40HIP_API int j40hip_copy_engine(int device, double *gbps16, uint32_t *masks2);
+
 /* ---- stage dump of the pipeline's DEVICE stages, for parity tests (tests/test_device_stages.py): one image goes through the same
  *      enqueue a batch of one takes -- front parse on the host; the LfGroup streams on the device (k_lf_lanes) when `lf_on_device`
  *      and the frame's tables allow it, else by the host decoder; plan build (k_plan_place / _scan / _emit), LfGroup tail, entropy

@@ -105,6 +105,7 @@ def lib():
         "j40hip_stage_dump_lf_group_info": (C.c_int, [vp, i64, vp]), "j40hip_stage_dump_plane": (C.c_int, [vp, i64, C.c_int, vp]),
         "j40hip_stage_dump_varblocks": (C.c_int, [vp, i64, vp, vp, vp]), "j40hip_stage_dump_llf": (C.c_int, [vp, i64, C.c_int, vp]),
         "j40hip_stage_dump_group_blocks": (i64, [vp, i64, vp, i64]), "j40hip_stage_dump_sorted_varblocks": (i64, [vp, vp, vp, vp, i64]), "j40hip_stage_dump_rgba": (C.c_int, [vp, vp]),
+        "j40hip_copy_engine": (C.c_int, [C.c_int, vp, vp]),
         "j40hip_pipeline_result": (u32, [vp, i64]), "j40hip_pipeline_stats": (None, [vp, vp]), "j40hip_pipeline_stats_ex": (None, [vp, vp]), "j40hip_pipeline_lf_stats": (None, [vp, vp]), "j40hip_pipeline_reset_stats": (None, [vp]),
     }
     for name, (res, args) in sigs.items():
@@ -118,6 +119,15 @@ def lib():
 
 def device_count():
     return lib().j40hip_device_count()
+
+
+def copy_engine(device=0):
+    """j40hip_copy_engine: the SDMA engine the pipeline's copies back to host memory go to on `device` (-1: hipMemcpyAsync), the measured
+    device-to-host GB/s per engine and the runtime's {free, recommended} masks"""
+    import numpy as np
+    rates = np.zeros(16, np.float64); masks = np.zeros(2, np.uint32)
+    e = lib().j40hip_copy_engine(device, rates.ctypes.data, masks.ctypes.data)
+    return {"engine": e, "d2h_gb_per_s_per_engine": {str(i): round(float(r), 1) for i, r in enumerate(rates) if r != 0}, "engines_free_mask": hex(int(masks[0])), "engines_recommended_mask": hex(int(masks[1]))}
 
 
 def shutdown():

@@ -1,0 +1,199 @@
+// j40_amd/csrc/device/hostcopy.hip -- pixels back to host memory on an SDMA engine of OUR choosing (hsa_amd_memory_async_copy_on_engine).
+//
+// Why not hipMemcpyAsync: the runtime picks an SDMA engine per copy among those it finds free, and on an MI355X the sixteen engines are
+// not alike -- measured on the bench boxes (tools/ubench/copy_probe.hip, profiles/r06_sdma_engines.txt), device to host, 133 MB copies:
+// engines 0, 2, 3 move 56.8 GB/s (the PCIe Gen5 x16 link's rate), engine 1 30, engines 4-7 12.8, 8-11 10, 12-15 7 GB/s. While the worker
+// threads' uploads keep the good engines busy now and then, a frame's 133 MB of RGBA lands on whichever engine was free: batches
+// whose copies took 1.08 s, 3.1 s or 5.3 s instead of 0.6 s (30, 11 and 6.5 GB/s: the rates of engines 1, 4-7 and 12-15) were what
+// rounds 4 and 5 recorded as the contract clock's "slow runs" (DESIGN.md section 5). Here the engine is measured once per process and
+// device and every copy back goes to the fastest one.
+//
+// A copy issued here is ordered with no HIP stream: the caller issues it once the source is complete (the pipeline: when it has seen
+// the batch's `kdone` event pass) and polls / waits for the ticket.
+#include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+#include "hostcopy.hpp"
+
+namespace {
+
+struct DeviceCopier {
+	bool tried = false, usable = false;
+	hsa_agent_t gpu{}, cpu{};
+	uint32_t engine_bit = 0; int engine = -1;
+	uint32_t free_mask = 0, preferred_mask = 0;
+	double gbps[16] = {0};
+	std::vector<hsa_signal_t> free_signals;
+};
+std::mutex g_m;
+DeviceCopier g_dev[16];
+bool g_hsa_up = false, g_hsa_failed = false;
+
+struct FindAgents { uint32_t want_bdf, want_domain; hsa_agent_t gpu, cpu; bool have_gpu, have_cpu; };
+hsa_status_t agent_cb(hsa_agent_t a, void *data) {
+	FindAgents *f = (FindAgents *) data;
+	hsa_device_type_t t;
+	if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+	if (t == HSA_DEVICE_TYPE_CPU && !f->have_cpu) { f->cpu = a; f->have_cpu = true; }
+	if (t == HSA_DEVICE_TYPE_GPU && !f->have_gpu) {
+		uint32_t bdf = 0, domain = 0;
+		(void) hsa_agent_get_info(a, (hsa_agent_info_t) HSA_AMD_AGENT_INFO_BDFID, &bdf);
+		(void) hsa_agent_get_info(a, (hsa_agent_info_t) HSA_AMD_AGENT_INFO_DOMAIN, &domain);
+		if (bdf == f->want_bdf && domain == f->want_domain) { f->gpu = a; f->have_gpu = true; }
+	}
+	return HSA_STATUS_SUCCESS;
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+bool wait_signal(hsa_signal_t s) {
+	hsa_signal_value_t v;
+	while ((v = hsa_signal_wait_scacquire(s, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED)) >= 1) {}
+	return v == 0;
+}
+
+// g_m held. Finds the device's agents, measures the engines, keeps the fastest.
+void set_up(int device, DeviceCopier &d) {
+	d.tried = true;
+	const char *env = getenv("J40HIP_COPY_ENGINE");   // "hip": hipMemcpyAsync as before; a number: that SDMA engine, unmeasured
+	if (env && !strcmp(env, "hip")) return;
+	if (!g_hsa_up) {
+		if (g_hsa_failed || hsa_init() != HSA_STATUS_SUCCESS) { g_hsa_failed = true; return; }   // (reference-counted: the HIP runtime holds it open already)
+		g_hsa_up = true;
+	}
+	hipDeviceProp_t pr;
+	if (hipGetDeviceProperties(&pr, device) != hipSuccess) { (void) hipGetLastError(); return; }
+	FindAgents f{};
+	f.want_bdf = ((uint32_t) pr.pciBusID << 8) | ((uint32_t) pr.pciDeviceID << 3); f.want_domain = (uint32_t) pr.pciDomainID;
+	if (hsa_iterate_agents(agent_cb, &f) != HSA_STATUS_SUCCESS || !f.have_gpu || !f.have_cpu) return;
+	d.gpu = f.gpu; d.cpu = f.cpu;
+	if (hsa_amd_memory_copy_engine_status(d.cpu, d.gpu, &d.free_mask) != HSA_STATUS_SUCCESS || !d.free_mask) {
+		// ("out of resources": no engine reported free right now -- the mask of all of them is still what can be asked for)
+		if (!d.free_mask) d.free_mask = 0xffffu;
+	}
+	(void) hsa_amd_memory_get_preferred_copy_engine(d.cpu, d.gpu, &d.preferred_mask);
+	if (env && env[0] >= '0' && env[0] <= '9') { d.engine = atoi(env) & 15; d.engine_bit = 1u << d.engine; d.usable = true; return; }
+	// measure: 32 MB device -> pinned host on each engine by itself (one short copy first: an engine's queue is made at its first use)
+	const size_t bytes = (size_t) 32 << 20;
+	void *dev = nullptr, *host = nullptr;
+	int prev = 0; (void) hipGetDevice(&prev);
+	if (hipSetDevice(device) != hipSuccess || hipMalloc(&dev, bytes) != hipSuccess) { (void) hipGetLastError(); (void) hipSetDevice(prev); return; }
+	if (hipHostMalloc(&host, bytes, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); (void) hipFree(dev); (void) hipSetDevice(prev); return; }
+	hsa_signal_t sig;
+	if (hsa_signal_create(1, 0, nullptr, &sig) == HSA_STATUS_SUCCESS) {
+		int best = -1;
+		for (int pass = 0; pass < 2 && (best < 0 || d.gbps[best] < 45.0); ++pass) {   // (a recommended engine below 45 GB/s: look at the others too)
+			// first the engines the runtime recommends for this direction, then -- if none of them works -- all the others
+			const uint32_t mask = pass == 0 ? (d.preferred_mask & d.free_mask) : (d.free_mask & ~d.preferred_mask);
+			for (int e = 0; e < 16; ++e) if (mask >> e & 1u) {
+				bool ok = true;
+				double t = 0;
+				for (int k = 0; k < 2 && ok; ++k) {
+					hsa_signal_store_relaxed(sig, 1);
+					const double t0 = now_s();
+					ok = hsa_amd_memory_async_copy_on_engine(host, d.cpu, dev, d.gpu, k ? bytes : (size_t) 1 << 20, 0, nullptr, sig, (hsa_amd_sdma_engine_id_t) (1u << e), true) == HSA_STATUS_SUCCESS && wait_signal(sig);
+					t = now_s() - t0;
+				}
+				d.gbps[e] = ok ? (double) bytes / t / 1e9 : -1.0;
+				if (ok && (best < 0 || d.gbps[e] > d.gbps[best] * 1.03)) best = e;   // (ties go to the lower engine)
+			}
+		}
+		if (best >= 0) { d.engine = best; d.engine_bit = 1u << best; d.usable = true; }
+		(void) hsa_signal_destroy(sig);
+	}
+	(void) hipHostFree(host); (void) hipFree(dev); (void) hipSetDevice(prev);
+	if (getenv("J40HIP_ASYNC_TIMING") || getenv("J40HIP_COPY_REPORT")) {
+		fprintf(stderr, "[j40hip hostcopy] device %d: SDMA engines free 0x%x, recommended 0x%x; device-to-host GB/s:", device, d.free_mask, d.preferred_mask);
+		for (int e = 0; e < 16; ++e) if (d.gbps[e] != 0) fprintf(stderr, " %d:%.1f", e, d.gbps[e]);
+		fprintf(stderr, " -> engine %d\n", d.engine);
+	}
+}
+
+}  // namespace
+
+namespace j40hip_rt {
+
+int hostcopy_engine(int device, double *gbps16, uint32_t *masks2) {
+	if (device < 0 || device >= 16) return -1;
+	std::lock_guard<std::mutex> lock(g_m);
+	DeviceCopier &d = g_dev[device];
+	if (!d.tried) set_up(device, d);
+	if (gbps16) memcpy(gbps16, d.gbps, sizeof d.gbps);
+	if (masks2) { masks2[0] = d.free_mask; masks2[1] = d.preferred_mask; }
+	return d.usable ? d.engine : -1;
+}
+
+int hostcopy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes, uint64_t *ticket) {
+	if (device < 0 || device >= 16 || !bytes) return 1;
+	// the destination has to be memory the device can write: hipHostMalloc'ed or hipHostRegister'ed (whose device-side address may differ)
+	hipPointerAttribute_t attr;
+	if (hipPointerGetAttributes(&attr, dst_host) != hipSuccess) { (void) hipGetLastError(); return 1; }
+	if (attr.type != hipMemoryTypeHost || !attr.devicePointer) return 1;
+	hsa_signal_t sig{};
+	hsa_agent_t gpu, cpu; uint32_t bit;
+	{
+		std::lock_guard<std::mutex> lock(g_m);
+		DeviceCopier &d = g_dev[device];
+		if (!d.tried) set_up(device, d);
+		if (!d.usable) return 1;
+		gpu = d.gpu; cpu = d.cpu; bit = d.engine_bit;
+		if (!d.free_signals.empty()) { sig = d.free_signals.back(); d.free_signals.pop_back(); }
+	}
+	if (!sig.handle && hsa_signal_create(1, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) return 1;
+	hsa_signal_store_relaxed(sig, 1);
+	if (hsa_amd_memory_async_copy_on_engine(attr.devicePointer, cpu, src_dev, gpu, bytes, 0, nullptr, sig, (hsa_amd_sdma_engine_id_t) bit, true) != HSA_STATUS_SUCCESS) {
+		std::lock_guard<std::mutex> lock(g_m);
+		g_dev[device].free_signals.push_back(sig);
+		return 1;
+	}
+	*ticket = sig.handle;
+	return 0;
+}
+
+bool hostcopy_ready(int device) {
+	if (device < 0 || device >= 16) return false;
+	std::lock_guard<std::mutex> lock(g_m);
+	return g_dev[device].tried && g_dev[device].usable;
+}
+
+// the synchronous form for single-image paths: on the measured engine when the process has measured one already (a pipeline did),
+// else false -- the caller's hipMemcpy (the measurement costs tens of milliseconds: not worth one image's copy)
+bool hostcopy_d2h_sync(int device, void *dst_host, const void *src_dev, size_t bytes) {
+	if (!hostcopy_ready(device)) return false;
+	uint64_t t = 0;
+	if (hostcopy_d2h(device, dst_host, src_dev, bytes, &t) != 0) return false;
+	const bool ok = hostcopy_wait(t);
+	hostcopy_release(device, t);
+	return ok;
+}
+
+int hostcopy_state(uint64_t ticket) {
+	hsa_signal_t s; s.handle = ticket;
+	const hsa_signal_value_t v = hsa_signal_load_scacquire(s);
+	return v >= 1 ? 0 : v == 0 ? 1 : -1;
+}
+
+bool hostcopy_wait(uint64_t ticket) { hsa_signal_t s; s.handle = ticket; return wait_signal(s); }
+
+void hostcopy_release(int device, uint64_t ticket) {
+	if (device < 0 || device >= 16 || !ticket) return;
+	hsa_signal_t s; s.handle = ticket;
+	std::lock_guard<std::mutex> lock(g_m);
+	g_dev[device].free_signals.push_back(s);
+}
+
+void hostcopy_shutdown() {
+	std::lock_guard<std::mutex> lock(g_m);
+	for (DeviceCopier &d : g_dev) { for (hsa_signal_t s : d.free_signals) (void) hsa_signal_destroy(s); d.free_signals.clear(); }
+}
+
+}  // namespace j40hip_rt
+
+// which SDMA engine the copies back of `device` go to (-1: hipMemcpyAsync), with the measurement behind the choice (include/j40hip.h)
+extern "C" __attribute__((visibility("default"))) int j40hip_copy_engine(int device, double *gbps16, uint32_t *masks2) { return j40hip_rt::hostcopy_engine(device, gbps16, masks2); }

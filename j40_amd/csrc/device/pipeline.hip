@@ -35,6 +35,7 @@
 #include "../capi.hpp"
 #include "async.hpp"
 #include "runtime_shared.hpp"
+#include "hostcopy.hpp"
 
 static int cpu_quota();   // (CPUs' worth of time the container may use; defined with the serving pipeline below)
 
@@ -56,6 +57,7 @@ struct Job {
 	double ready_ms = 0;          // when it became ready for a batch
 	bool lf_failed = false;       // its LfGroup streams could not be launched on the device
 	void *dev_rgba = nullptr;     // host output: the device image the copy back reads
+	uint64_t copy_ticket = 0;     // ... its copy back on the SDMA engine (hostcopy.hpp), once issued
 	uint32_t status = 0;
 	bool redo = false;            // its batch wants it decoded again on the single-frame path
 	bool counted = true;          // counts towards the pipeline's resident frames (until its device memory has gone back to the cache)
@@ -86,6 +88,8 @@ struct Slot {
 	std::vector<hipEvent_t> group_ev;   // made on demand, kept
 	std::vector<int> group_end;         // jobs [group_end[g - 1], group_end[g]) complete with group_ev[g]
 	int next_group = 0;
+	bool copies_deferred = false;       // host output on the SDMA engine: the copies are issued when the kernels are seen to be through (progress)
+	std::vector<uint8_t> group_has_ev;  // ... groups with a copy that went through hipMemcpyAsync after all (an unpinned destination): group_ev[g] counts
 	double t_launch = 0, t_harvest = 0;  // (J40HIP_ASYNC_TIMING)
 	bool harvested = false;             // the kernels are through: verdicts read, the frames' device memory handed back (the copies may still run)
 	bool failed = false;                // the device reported an error for this batch: everything still pending fails with "!gpu"
@@ -134,6 +138,7 @@ struct j40hip_pipeline {
 	std::vector<Slot> slots;
 	std::deque<int> in_flight;          // slot indices, oldest first
 	hipStream_t copy_stream = nullptr;  // every copy of pixels back to host memory, in launch order: one DMA queue at the link's rate
+	bool sdma_copies = false;           // host output goes back on the SDMA engine measured for the device (hostcopy.hpp)
 	std::vector<hipStream_t> copy_streams;   // copy_stream first; J40HIP_COPY_STREAMS=n: the groups of a batch's copies go to n streams in turn
 	// device images for host output, recycled by size
 	std::mutex image_m;
@@ -211,7 +216,8 @@ uint32_t decode_single(j40hip_pipeline *p, Job *j, hipStream_t s) {
 		if (!err) err = j40hip_frame_status(fr);
 	}
 	if (!err) err = j40hip_frame_after_frame_status(fr);
-	if (!err && !j->device_output && hipMemcpyAsync(j->rgba, dev, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) err = E_GPU;
+	// (the stream has been waited for above: the copy may go to the measured SDMA engine)
+	if (!err && !j->device_output && !j40hip_rt::hostcopy_d2h_sync(p->device, j->rgba, dev, bytes) && hipMemcpyAsync(j->rgba, dev, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) err = E_GPU;
 	if (hipStreamSynchronize(s) != hipSuccess && !err) err = E_GPU;
 	j40hip_frame_mark_idle(fr);   // its stream has been waited for
 	j40hip_frame_free(fr);
@@ -290,6 +296,31 @@ void worker_main(j40hip_pipeline *p, int) {
 	(void) hipStreamDestroy(stream);
 }
 
+// Host output through the SDMA engine (hostcopy.hpp): the batch's kernels are through, its frames' pixels go back now, in launch order.
+// A frame whose destination is not pinned memory goes through hipMemcpyAsync on the copy stream instead, with an event for its group.
+void issue_copies(j40hip_pipeline *p, Slot &slot) {
+	const int ngroups = (int) slot.group_end.size();
+	slot.group_has_ev.assign((size_t) ngroups, 0);
+	for (int g = 0; g < ngroups; ++g) {
+		const int begin = g ? slot.group_end[(size_t) g - 1] : 0, end = slot.group_end[(size_t) g];
+		for (int i = begin; i < end; ++i) {
+			Job *j = slot.jobs[(size_t) i];
+			if (j->device_output || j->status || j->redo || !j->dev_rgba) continue;
+			const size_t bytes = j->stride * (size_t) j->height;
+			if (j40hip_rt::hostcopy_d2h(p->device, j->rgba, j->dev_rgba, bytes, &j->copy_ticket) == 0) continue;
+			j->copy_ticket = 0;
+			if (hipMemcpyAsync(j->rgba, j->dev_rgba, bytes, hipMemcpyDeviceToHost, p->copy_stream) != hipSuccess) { (void) hipGetLastError(); j->status = E_GPU; }
+			else slot.group_has_ev[(size_t) g] = 1;
+		}
+		if (slot.group_has_ev[(size_t) g]) {
+			while (slot.group_ev.size() <= (size_t) g) { hipEvent_t e = nullptr; if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { (void) hipGetLastError(); break; } slot.group_ev.push_back(e); }
+			if (slot.group_ev.size() <= (size_t) g || hipEventRecord(slot.group_ev[(size_t) g], p->copy_stream) != hipSuccess) {
+				(void) hipGetLastError(); (void) hipStreamSynchronize(p->copy_stream); slot.group_has_ev[(size_t) g] = 0;   // (no event to ask: wait here, once)
+			}
+		}
+	}
+}
+
 // Hands back the frames of `slot` whose group events have passed (`block`: waits for the next group first). Returns true when the
 // slot has nothing pending any more (it is then free for another batch). GPU thread only.
 bool progress(j40hip_pipeline *p, Slot &slot, bool block) {
@@ -317,6 +348,7 @@ bool progress(j40hip_pipeline *p, Slot &slot, bool block) {
 				}
 				if (j->af) { dead.push_back(j->af); j->af = nullptr; }
 			}
+			if (slot.copies_deferred) issue_copies(p, slot);
 			std::unique_lock<std::mutex> lock(p->m);
 			if (timed) { p->lf_ms += ms3[0]; p->k1_ms += ms3[1]; p->k2_ms += ms3[2]; p->k1_kernel_ms += ms3[3]; ++p->launches; p->launch_frames += (int64_t) slot.jobs.size(); }
 			// (the back-pressure on the worker threads counts frames that hold device memory: these no longer do -- what waits for the
@@ -328,14 +360,26 @@ bool progress(j40hip_pipeline *p, Slot &slot, bool block) {
 		slot.harvested = true; slot.t_harvest = now_ms();
 	}
 	while (slot.next_group < ngroups) {
-		if (!slot.launch_err && !slot.failed) {
+		const int begin = slot.next_group ? slot.group_end[(size_t) slot.next_group - 1] : 0, end = slot.group_end[(size_t) slot.next_group];
+		if (!slot.launch_err && !slot.failed && (!slot.copies_deferred || slot.group_has_ev[(size_t) slot.next_group])) {
 			hipEvent_t ev = slot.group_ev[(size_t) slot.next_group];
 			hipError_t q = block && first ? hipEventSynchronize(ev) : hipEventQuery(ev);
 			if (q == hipErrorNotReady) { (void) hipGetLastError(); return false; }
 			if (q != hipSuccess) { (void) hipGetLastError(); slot.failed = true; }
 		}
+		if (slot.copies_deferred) {
+			// the group's copies on the SDMA engine: issued in order on one engine, so the last one is the one to sleep on
+			for (int i = end - 1; i >= begin; --i) {
+				Job *j = slot.jobs[(size_t) i];
+				if (!j->copy_ticket) continue;
+				int st = j40hip_rt::hostcopy_state(j->copy_ticket);
+				if (st == 0 && block && first) st = j40hip_rt::hostcopy_wait(j->copy_ticket) ? 1 : -1;
+				if (st == 0) return false;
+				if (st < 0 && !j->status) j->status = E_GPU;
+				j40hip_rt::hostcopy_release(p->device, j->copy_ticket); j->copy_ticket = 0;
+			}
+		}
 		first = false;
-		const int begin = slot.next_group ? slot.group_end[(size_t) slot.next_group - 1] : 0, end = slot.group_end[(size_t) slot.next_group];
 		std::vector<j40hip_aframe *> dead;
 		for (int i = begin; i < end; ++i) {
 			Job *j = slot.jobs[(size_t) i];
@@ -359,7 +403,7 @@ bool progress(j40hip_pipeline *p, Slot &slot, bool block) {
 	}
 	static const bool timing = getenv("J40HIP_ASYNC_TIMING") != nullptr;
 	if (timing) fprintf(stderr, "[j40hip batch] %zu frames in %d groups: launched at %.1f, kernels + verdicts through after %.1f ms, last pixels back after another %.1f ms\n", slot.jobs.size(), ngroups, slot.t_launch, slot.t_harvest - slot.t_launch, now_ms() - slot.t_harvest);
-	slot.jobs.clear(); slot.group_end.clear(); slot.next_group = 0; slot.busy = false; slot.launch_err = 0; slot.failed = false; slot.harvested = false;
+	slot.jobs.clear(); slot.group_end.clear(); slot.next_group = 0; slot.busy = false; slot.launch_err = 0; slot.failed = false; slot.harvested = false; slot.copies_deferred = false;
 	return true;
 }
 
@@ -395,9 +439,13 @@ uint32_t launch_batch(j40hip_pipeline *p, std::vector<Job *> &take, int si) {
 	static const int groups = [] { const char *e = getenv("J40HIP_COPY_GROUPS"); return e && atoi(e) > 0 ? atoi(e) : 16; }();
 	const int per_group = host_out ? std::max(1, (n + groups - 1) / groups) : n;
 	hipStream_t gs = host_out ? p->copy_stream : slot.stream;
-	if (host_out) for (hipStream_t cs : p->copy_streams) if (!slot.launch_err && hipStreamWaitEvent(cs, slot.kdone, 0) != hipSuccess) slot.launch_err = E_GPU;
+	// host output: on the SDMA engine measured for this device, issued when the kernels are seen to be through (issue_copies) -- or,
+	// without it (J40HIP_COPY_ENGINE=hip, no HSA), hipMemcpyAsync on the copy stream(s) behind the batch's kernels
+	slot.copies_deferred = host_out && p->sdma_copies;
+	if (host_out && !slot.copies_deferred) for (hipStream_t cs : p->copy_streams) if (!slot.launch_err && hipStreamWaitEvent(cs, slot.kdone, 0) != hipSuccess) slot.launch_err = E_GPU;
 	for (int i = 0; i < n; ++i) {
 		Job *j = take[(size_t) i];
+		if (slot.copies_deferred) { if ((i + 1) % per_group == 0 || i + 1 == n) slot.group_end.push_back(i + 1); continue; }
 		if (host_out) gs = p->copy_streams[slot.group_end.size() % p->copy_streams.size()];   // (a group's copies and its event on one stream)
 		if (!slot.launch_err && !j->device_output && hipMemcpyAsync(j->rgba, j->dev_rgba, j->stride * (size_t) j->height, hipMemcpyDeviceToHost, gs) != hipSuccess) j->status = E_GPU;
 		if ((i + 1) % per_group == 0 || i + 1 == n) {
@@ -613,6 +661,7 @@ j40hip_pipeline *j40hip_pipeline_create_ex(int device, int host_threads, int bat
 				if (cs) p->copy_streams.push_back(cs);
 			}
 			if (!p->copy_streams.empty()) p->copy_stream = p->copy_streams[0];
+			p->sdma_copies = j40hip_rt::hostcopy_engine(p->device, nullptr, nullptr) >= 0;   // (measures the engines on the process's first pipeline)
 		}
 		{   // The LfGroup launches run for a quarter of a second each. Streams of one priority share a handful of hardware queues, and a
 			// kernel waits for the kernels ahead of it in its queue whichever stream they came from: on a stream of the batches' priority

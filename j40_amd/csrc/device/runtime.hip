@@ -17,6 +17,7 @@
 #include "../plan_build.hpp"
 #include "kernels.h"
 #include "runtime_shared.hpp"
+#include "hostcopy.hpp"
 #include "block_cache.hpp"
 #include "async.hpp"
 
@@ -1278,7 +1279,8 @@ static uint32_t j40hip_frame_decode_to_host_body(j40hip_frame *h, void *rgba_hos
 		if (!err && hipStreamSynchronize(nullptr) != hipSuccess) err = ERR_GPU;
 		if (!err) err = j40hip_frame_status(h);
 	}
-	if (!err && hipMemcpy(rgba_host, d, bytes, hipMemcpyDeviceToHost) != hipSuccess) err = ERR_GPU;
+	// (the decode has been waited for: the copy may go to the SDMA engine a pipeline of this process measured, hostcopy.hpp)
+	if (!err && !hostcopy_d2h_sync(device, rgba_host, d, bytes) && hipMemcpy(rgba_host, d, bytes, hipMemcpyDeviceToHost) != hipSuccess) err = ERR_GPU;
 	(void) hipDeviceSynchronize();
 	cache_release(device, d, got, false);
 	return err;
@@ -1356,6 +1358,7 @@ extern "C" void j40hip_shutdown(void) {
 	}
 	j40hip_serve_shutdown();
 	j40hip_async_shutdown();
+	hostcopy_shutdown();
 	pinned_trim();
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess) { (void) hipGetLastError(); n = 0; }
