@@ -338,8 +338,12 @@ def main():
     except RuntimeError as e:
         link_probe = {"error": str(e)[:200]}
 
-    for _ in range(max(args.warmup, 0)):
-        run_pipeline_steps(pipe, step_bufs, step_sizes, step_outs, W * 4, False, 1, torch, dev, None)
+    # the W untimed steps, queued back to back like the timed ones: the pipeline reaches the depth it has in the timed region (frames
+    # parsed ahead, three batches' working sets, the device memory cache grown to hold them) before the clock starts -- W steps drained
+    # one by one never get there, and a fresh box then spent 2 s of its first timed steps in hipMalloc (call D, run 1: 12.7 Gpx/s
+    # against 13.4-13.5 for the five runs after it)
+    if args.warmup > 0:
+        run_pipeline_steps(pipe, step_bufs, step_sizes, step_outs, W * 4, False, args.warmup, torch, dev, None)
     cg0 = cgroup_cpu_stat()
     elapsed, tickets = run_pipeline_steps(pipe, step_bufs, step_sizes, step_outs, W * 4, False, args.steps, torch, dev, dist)
     cg1 = cgroup_cpu_stat()

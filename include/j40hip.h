@@ -240,6 +240,32 @@ J40HIP_API uint32_t j40hip_frame_read_coeffs(j40hip_frame *f, int64_t gg, int c,
 /*   int16 sample planes (Modular frames) before packing: channel c, w*h */
 J40HIP_API uint32_t j40hip_frame_read_plane_i16(j40hip_frame *f, int c, int16_t *out);
 
+/* ---- restoration filters: Gaborish and the edge-preserving filter between the inverse transforms and the colour
+ *      conversion, over the whole picture. The reference parses the frame header's RestorationFilter bundle (j40.h:5339-5366) and never
+ *      looks at it again -- its j40__gaborish (j40.h:7271) and j40__epf (j40.h:7578) are defined and never called -- so by DEFAULT
+ *      nothing runs and the decode matches j40. mode 1 (or J40HIP_RESTORATION=1 in the environment): the filters a VarDCT frame
+ *      signals run, stated as those two routines state them (j40_amd/csrc/device/restore_dev.h); mode 2 (J40HIP_RESTORATION=j40):
+ *      bit for bit what the routines compute as they stand, including the edge-preserving filter's aliased line buffers (X and Y
+ *      read the next channel's rows on half of the lines; the routine only runs at all under an allocator with slack). Their own
+ *      complaints -- "gab0", "epf0" (the DEFAULT sharpness table starts with 0: every frame that keeps it), "shrp" -- are reported
+ *      behind the sections' codes (j40hip_frame_status) and the picture is then left unfiltered. Single-frame entry points and the
+ *      public API; a pipeline decodes such frames on its single-frame path. Modular frames: not filtered (the reference's routines
+ *      take float planes only). ---- */
+typedef struct {
+	int32_t gab_enabled; float gab_weights[3][2];
+	int32_t epf_iters; float epf_sharp_lut[8], epf_channel_scale[3], epf_quant_mul, epf_pass0_sigma_scale, epf_pass2_sigma_scale, epf_border_sad_mul, epf_sigma_for_modular;
+} j40hip_restoration;
+J40HIP_API void j40hip_frame_restoration(const j40hip_frame *f, j40hip_restoration *out);   /* as parsed (mirrors j40__frame_st::gab / ::epf, j40.h:5085-5100) */
+J40HIP_API void j40hip_frame_set_restoration(j40hip_frame *f, int mode);                    /* -1: as the environment says (default), 0 off, 1 on, 2 as j40's routines stand */
+J40HIP_API int j40hip_frame_sharpness(const j40hip_frame *f, int64_t gg, int16_t *out);     /* LfGroup gg's sharpness map as decoded (i16 w8*h8; j40__lf_group_st::sharpness) */
+/* after a decode that ran the filters, stream synchronised: stage 0 the XYB samples as the inverse transforms left them, 1 the filtered
+ * ones ([3][height][width] floats); 2 the reciprocal-sigma plane of the edge-preserving filter (w8*h8 floats, < 0: the cell is skipped) */
+J40HIP_API uint32_t j40hip_frame_read_xyb(j40hip_frame *f, int stage, float *out);
+J40HIP_API float j40hip_frame_restoration_ms(const j40hip_frame *f);   /* device time of the filter kernels in the last decode (J40HIP_RESTORATION_TIMING=1) */
+/* known-answer hook: the filter kernels on caller-supplied planes (xyb: [3][h][w] floats, host, in place), a w8*h8 sharpness map and the
+ * HfMul reciprocal of the varblock covering each cell; mode 1 or 2; sigma_out optional. 0 or "gab0" / "epf0" / "shrp" / "!gpu". */
+J40HIP_API uint32_t j40hip_kat_device_restoration(float *xyb, int32_t w, int32_t h, const int16_t *sharpness, const float *hfmul_inv, const j40hip_restoration *r, int mode, int device, float *sigma_out);
+
 /* per-kernel device time of the last j40hip_frame_decode_timed call, measured with HIP events on
  * the launch stream: ms[0] = entropy decode, ms[1] = coefficients -> pixels, ms[2] = other */
 J40HIP_API uint32_t j40hip_frame_decode_timed(j40hip_frame *f, void *rgba_dev, size_t stride_bytes, void *stream, float *ms3);
@@ -345,8 +371,9 @@ J40HIP_API void j40hip_pipeline_reset_stats(j40hip_pipeline *p);
 /* The SDMA engine the pipeline's copies back to host memory go to on `device` (hsa_amd_memory_async_copy_on_engine; -1: none, the
  * copies are hipMemcpyAsync). An MI355X has sixteen engines of very different device-to-host rates (57 ... 7 GB/s) and hipMemcpyAsync
  * takes whichever is free; the library measures them once per process and device (32 MB each, at its first pipeline or at this call)
- * and keeps the fastest. gbps16 (optional): the measured GB/s per engine, 0 = not measured, < 0 = failed; masks2 (optional): the
- * runtime's masks {free, recommended} for the direction. J40HIP_COPY_ENGINE=hip: never; =<n>: engine n, unmeasured. */
+ * and keeps the fastest. gbps16 (optional): the measured GB/s per engine, 0 = not measured, < 0 = failed; masks2 (optional, THREE
+ * words): the runtime's masks {free, recommended} for the direction and the engines set aside for the worker threads' uploads (an
+ * SDMA engine works on one copy at a time: an upload sharing the engine of the copies back waits behind 133 MB transfers). J40HIP_COPY_ENGINE=hip: never; =<n>: engine n, unmeasured. */
 J40HIP_API int j40hip_copy_engine(int device, double *gbps16, uint32_t *masks2);
 
 /* ---- stage dump of the pipeline's DEVICE stages, for parity tests (tests/test_device_stages.py): one image goes through the same

@@ -106,6 +106,9 @@ def lib():
         "j40hip_stage_dump_varblocks": (C.c_int, [vp, i64, vp, vp, vp]), "j40hip_stage_dump_llf": (C.c_int, [vp, i64, C.c_int, vp]),
         "j40hip_stage_dump_group_blocks": (i64, [vp, i64, vp, i64]), "j40hip_stage_dump_sorted_varblocks": (i64, [vp, vp, vp, vp, i64]), "j40hip_stage_dump_rgba": (C.c_int, [vp, vp]),
         "j40hip_copy_engine": (C.c_int, [C.c_int, vp, vp]),
+        "j40hip_frame_restoration": (None, [vp, vp]), "j40hip_frame_set_restoration": (None, [vp, C.c_int]), "j40hip_frame_sharpness": (C.c_int, [vp, i64, vp]),
+        "j40hip_frame_read_xyb": (u32, [vp, C.c_int, vp]), "j40hip_frame_restoration_ms": (C.c_float, [vp]),
+        "j40hip_kat_device_restoration": (u32, [vp, i32, i32, vp, vp, vp, C.c_int, C.c_int, vp]),
         "j40hip_pipeline_result": (u32, [vp, i64]), "j40hip_pipeline_stats": (None, [vp, vp]), "j40hip_pipeline_stats_ex": (None, [vp, vp]), "j40hip_pipeline_lf_stats": (None, [vp, vp]), "j40hip_pipeline_reset_stats": (None, [vp]),
     }
     for name, (res, args) in sigs.items():
@@ -125,9 +128,9 @@ def copy_engine(device=0):
     """j40hip_copy_engine: the SDMA engine the pipeline's copies back to host memory go to on `device` (-1: hipMemcpyAsync), the measured
     device-to-host GB/s per engine and the runtime's {free, recommended} masks"""
     import numpy as np
-    rates = np.zeros(16, np.float64); masks = np.zeros(2, np.uint32)
+    rates = np.zeros(16, np.float64); masks = np.zeros(3, np.uint32)
     e = lib().j40hip_copy_engine(device, rates.ctypes.data, masks.ctypes.data)
-    return {"engine": e, "d2h_gb_per_s_per_engine": {str(i): round(float(r), 1) for i, r in enumerate(rates) if r != 0}, "engines_free_mask": hex(int(masks[0])), "engines_recommended_mask": hex(int(masks[1]))}
+    return {"engine": e, "d2h_gb_per_s_per_engine": {str(i): round(float(r), 1) for i, r in enumerate(rates) if r != 0}, "engines_free_mask": hex(int(masks[0])), "engines_recommended_mask": hex(int(masks[1])), "upload_engines_mask": hex(int(masks[2]))}
 
 
 def shutdown():
@@ -227,6 +230,32 @@ def decode_timed(buf, size, want_pixels=False):
 INFO_FIELDS = ["width", "height", "is_modular", "num_lf_groups", "num_groups", "num_passes", "nb_block_ctx", "block_ctx_size",
                "num_hf_presets", "global_scale", "quant_lf", "x_qm_scale", "b_qm_scale", "nb_qf_thr", "nb_lf_thr0", "nb_lf_thr1",
                "nb_lf_thr2", "group_size_shift", "bpp", "num_extra_channels", "xyb_encoded"]
+
+
+class Restoration(C.Structure):
+    """j40hip_restoration (include/j40hip.h): the frame header's RestorationFilter bundle"""
+    _fields_ = [("gab_enabled", C.c_int32), ("gab_weights", C.c_float * 6), ("epf_iters", C.c_int32), ("epf_sharp_lut", C.c_float * 8), ("epf_channel_scale", C.c_float * 3),
+                ("epf_quant_mul", C.c_float), ("epf_pass0_sigma_scale", C.c_float), ("epf_pass2_sigma_scale", C.c_float), ("epf_border_sad_mul", C.c_float), ("epf_sigma_for_modular", C.c_float)]
+
+    def as_list(self):
+        """the 24 numbers in the order oracle/ref_harness.c's ref_stage_restoration writes them"""
+        return ([float(self.gab_enabled)] + list(self.gab_weights) + [float(self.epf_iters)] + list(self.epf_sharp_lut) + list(self.epf_channel_scale)
+                + [self.epf_quant_mul, self.epf_pass0_sigma_scale, self.epf_pass2_sigma_scale, self.epf_border_sad_mul, self.epf_sigma_for_modular])
+
+    def params15(self):
+        """sharp_lut[8], channel_scale[3], quant_mul, pass0, pass2, border_sad_mul: what the checkers' filter entry points take"""
+        return np.array(list(self.epf_sharp_lut) + list(self.epf_channel_scale) + [self.epf_quant_mul, self.epf_pass0_sigma_scale, self.epf_pass2_sigma_scale, self.epf_border_sad_mul], np.float32)
+
+
+def kat_device_restoration(planes, sharpness, hfmul_inv, r, mode=1, device=0):
+    """j40hip_kat_device_restoration: the filter kernels on caller planes [3, h, w] float32 (a copy is filtered and returned with the
+    reciprocal-sigma plane); returns (4-char code, planes, sigma)"""
+    a = np.ascontiguousarray(planes, np.float32).copy()
+    _, h, w = a.shape
+    sh = np.ascontiguousarray(sharpness, np.int16); hf = np.ascontiguousarray(hfmul_inv, np.float32)
+    sigma = np.zeros(((h + 7) // 8, (w + 7) // 8), np.float32)
+    code = lib().j40hip_kat_device_restoration(a.ctypes.data, w, h, sh.ctypes.data, hf.ctypes.data, C.byref(r), mode, device, sigma.ctypes.data)
+    return err4(code), a, sigma
 
 
 class Frame:
@@ -381,6 +410,32 @@ class Frame:
         out = np.zeros((self.height, self.width, 4), np.uint8)
         code = lib().j40hip_frame_decode_to_host(self.h, out.ctypes.data, self.width * 4)
         return err4(code), out
+
+    # ---- restoration filters (include/j40hip.h) ----
+    def restoration(self):
+        """the frame header's RestorationFilter bundle as parsed (j40hip_restoration)"""
+        r = Restoration()
+        lib().j40hip_frame_restoration(self.h, C.byref(r))
+        return r
+
+    def set_restoration(self, mode):
+        """-1: as J40HIP_RESTORATION says, 0: off (what j40 does), 1: the filters the frame signals, 2: exactly as j40's routines stand"""
+        lib().j40hip_frame_set_restoration(self.h, int(mode))
+
+    def sharpness(self, gg):
+        gi = self.lf_group_info(gg)
+        a = np.zeros((gi["height8"], gi["width8"]), np.int16)
+        assert lib().j40hip_frame_sharpness(self.h, gg, a.ctypes.data) == 0
+        return a
+
+    def read_xyb(self, stage):
+        """after a decode that ran the filters: stage 0 / 1 -> [3, height, width] float32 (before / after them), 2 -> the reciprocal sigmas [h8, w8]"""
+        a = np.zeros((3, self.height, self.width), np.float32) if stage < 2 else np.zeros(((self.height + 7) // 8, (self.width + 7) // 8), np.float32)
+        self._chk(lib().j40hip_frame_read_xyb(self.h, stage, a.ctypes.data), "in j40hip_frame_read_xyb")
+        return a
+
+    def restoration_ms(self):
+        return float(lib().j40hip_frame_restoration_ms(self.h))
 
     # ---- stage accessors ----
     def lf_group_info(self, gg):

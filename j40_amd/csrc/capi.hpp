@@ -17,6 +17,7 @@ struct j40hip_frame {
 	j40hip::Frame frame;
 	j40hip_device_state *dev = nullptr;
 	bool force_dense = false;        // upload with dense coefficient planes (set after a decode ran out of event space, ERR_EVOF)
+	int restoration = -1;            // the restoration filters (j40hip_frame_set_restoration): -1 as J40HIP_RESTORATION says, 0 off, 1 on, 2 as j40's routines stand
 	int threads = 1;                 // what the frame was parsed with: the plan build at upload may use as many (plan_build.cpp)
 	// backing storage of the plan views (include/j40hip.h)
 	struct Views {

@@ -19,6 +19,7 @@
 #include "../plan_front.hpp"
 #include "kernels.h"
 #include "runtime_shared.hpp"
+#include "hostcopy.hpp"
 #include "async.hpp"
 
 using namespace j40hip;
@@ -247,6 +248,10 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	extract_codestream((const uint8_t *) buf, size, &h.cs, &h.cs_size, &h.cs_storage, &h.container_stray_tail);
 	h.bare_codestream = h.cs == (const uint8_t *) buf && h.cs_size == size;
 	if (!parse_frame_front(h.cs, h.cs_size, &fr, &tasks, &extra_prec, &plain)) return nullptr;
+	{   // the restoration filters asked for (J40HIP_RESTORATION) and signalled by the frame: the single-frame path runs them (runtime.hip: decode_restored)
+		static const bool restoration = [] { const char *e = getenv("J40HIP_RESTORATION"); return e && (!strcmp(e, "j40") || atoi(e) > 0); }();
+		if (restoration && (fr.fh.restoration.gab || fr.fh.restoration.epf_iters > 0)) return nullptr;
+	}
 	const double tp1 = prof_now();
 	af->st = static_tables_for(fr, device);
 	if (!af->st || af->st->any_dq_error) return nullptr;   // (a matrix that does not load: whether it matters depends on the varblocks -- the single-frame path sorts it out)
@@ -390,7 +395,9 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	if (!af->uploaded) return nullptr;
 	static thread_local uint64_t t_seq = 0;
 	af->up_stream = stream; af->up_seq = ++t_seq;
-	if (hipMemcpyAsync(pb, stg, copy_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return nullptr;
+	// the upload: on an SDMA engine of this thread's own, kept apart from the copies back (hostcopy.hpp; the thread sleeps the quarter of a
+	// millisecond it takes, and the events below then pass at once), or -- where that is not available -- hipMemcpyAsync on the thread's stream
+	if (!j40hip_rt::hostcopy_h2d_sync(device, pb, stg, copy_bytes) && hipMemcpyAsync(pb, stg, copy_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return nullptr;
 	bool ok = hipEventRecord(sg.done, stream) == hipSuccess;
 	sg.pending = ok;
 	ok = ok && hipEventRecord(af->uploaded, stream) == hipSuccess;

@@ -28,7 +28,9 @@ struct DeviceCopier {
 	hsa_agent_t gpu{}, cpu{};
 	uint32_t engine_bit = 0; int engine = -1;
 	uint32_t free_mask = 0, preferred_mask = 0;
-	double gbps[16] = {0};
+	double gbps[16] = {0}, gbps_h2d[16] = {0};
+	std::vector<int> h2d_engines;   // engines for the uploads, fastest first: host-to-device within a quarter of the best, the copy-back engine left out
+	int h2d_next = 0;
 	std::vector<hsa_signal_t> free_signals;
 };
 std::mutex g_m;
@@ -105,13 +107,43 @@ void set_up(int device, DeviceCopier &d) {
 			}
 		}
 		if (best >= 0) { d.engine = best; d.engine_bit = 1u << best; d.usable = true; }
+		// the other direction (the worker threads' uploads: the plan's front and the codestream, 4-12 MB a frame), 8 MB per engine. An SDMA
+		// engine works on one copy at a time: an upload that shares the engine of the copies back waits behind 133 MB transfers, so the
+		// uploads get engines of their own -- and the engines that are slow device-to-host (4-7: 12.6 GB/s) are nearly as good as the
+		// best host-to-device (50.9 against 57.3 GB/s)
+		if (d.usable) {
+			uint32_t h2d_free = 0;
+			if (hsa_amd_memory_copy_engine_status(d.gpu, d.cpu, &h2d_free) != HSA_STATUS_SUCCESS || !h2d_free) h2d_free = 0xffffu;
+			const size_t hb = (size_t) 8 << 20;
+			double top = 0;
+			for (int e = 0; e < 16; ++e) if ((h2d_free >> e & 1u) && e != d.engine) {
+				bool ok = true; double t = 0;
+				for (int k = 0; k < 2 && ok; ++k) {
+					hsa_signal_store_relaxed(sig, 1);
+					const double t0 = now_s();
+					ok = hsa_amd_memory_async_copy_on_engine(dev, d.gpu, host, d.cpu, k ? hb : (size_t) 1 << 20, 0, nullptr, sig, (hsa_amd_sdma_engine_id_t) (1u << e), true) == HSA_STATUS_SUCCESS && wait_signal(sig);
+					t = now_s() - t0;
+				}
+				d.gbps_h2d[e] = ok ? (double) hb / t / 1e9 : -1.0;
+				if (ok && d.gbps_h2d[e] > top) top = d.gbps_h2d[e];
+			}
+			for (int pass = 0; pass < 2; ++pass) for (int e = 15; e >= 0; --e) {
+				// (first the engines that are poor at copying back -- nobody else wants them --, then the good ones)
+				const bool poor_d2h = d.gbps[e] > 0 && d.gbps[e] < 0.5 * d.gbps[d.engine];
+				if (d.gbps_h2d[e] >= 0.75 * top && d.gbps_h2d[e] > 0 && (pass == 0) == poor_d2h) d.h2d_engines.push_back(e);
+			}
+		}
 		(void) hsa_signal_destroy(sig);
 	}
 	(void) hipHostFree(host); (void) hipFree(dev); (void) hipSetDevice(prev);
 	if (getenv("J40HIP_ASYNC_TIMING") || getenv("J40HIP_COPY_REPORT")) {
 		fprintf(stderr, "[j40hip hostcopy] device %d: SDMA engines free 0x%x, recommended 0x%x; device-to-host GB/s:", device, d.free_mask, d.preferred_mask);
 		for (int e = 0; e < 16; ++e) if (d.gbps[e] != 0) fprintf(stderr, " %d:%.1f", e, d.gbps[e]);
-		fprintf(stderr, " -> engine %d\n", d.engine);
+		fprintf(stderr, " -> engine %d; host-to-device GB/s:", d.engine);
+		for (int e = 0; e < 16; ++e) if (d.gbps_h2d[e] != 0) fprintf(stderr, " %d:%.1f", e, d.gbps_h2d[e]);
+		fprintf(stderr, " -> uploads on");
+		for (int e : d.h2d_engines) fprintf(stderr, " %d", e);
+		fprintf(stderr, "\n");
 	}
 }
 
@@ -125,6 +157,7 @@ int hostcopy_engine(int device, double *gbps16, uint32_t *masks2) {
 	DeviceCopier &d = g_dev[device];
 	if (!d.tried) set_up(device, d);
 	if (gbps16) memcpy(gbps16, d.gbps, sizeof d.gbps);
+	if (masks2) { masks2[2] = 0; for (int e : d.h2d_engines) masks2[2] |= 1u << e; }
 	if (masks2) { masks2[0] = d.free_mask; masks2[1] = d.preferred_mask; }
 	return d.usable ? d.engine : -1;
 }
@@ -170,6 +203,30 @@ bool hostcopy_d2h_sync(int device, void *dst_host, const void *src_dev, size_t b
 	if (hostcopy_d2h(device, dst_host, src_dev, bytes, &t) != 0) return false;
 	const bool ok = hostcopy_wait(t);
 	hostcopy_release(device, t);
+	return ok;
+}
+
+// An upload from pinned host memory on an SDMA engine that is this thread's (dealt out in turn among the engines set aside for
+// uploads), synchronous: the calling thread sleeps for the quarter of a millisecond it takes. false: not available (the caller's
+// hipMemcpyAsync). The destination is complete on return: kernels launched afterwards, on any stream, see it.
+bool hostcopy_h2d_sync(int device, void *dst_dev, const void *src_host, size_t bytes) {
+	if (device < 0 || device >= 16 || !bytes) return false;
+	static thread_local int t_engine[16] = {0};   // engine + 1
+	hsa_signal_t sig{};
+	hsa_agent_t gpu, cpu;
+	{
+		std::lock_guard<std::mutex> lock(g_m);
+		DeviceCopier &d = g_dev[device];
+		if (!d.tried || !d.usable || d.h2d_engines.empty()) return false;   // (measured by the process's first pipeline)
+		if (!t_engine[device]) t_engine[device] = 1 + d.h2d_engines[(size_t) (d.h2d_next++ % (int) d.h2d_engines.size())];
+		gpu = d.gpu; cpu = d.cpu;
+		if (!d.free_signals.empty()) { sig = d.free_signals.back(); d.free_signals.pop_back(); }
+	}
+	if (!sig.handle && hsa_signal_create(1, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) return false;
+	hsa_signal_store_relaxed(sig, 1);
+	const bool issued = hsa_amd_memory_async_copy_on_engine(dst_dev, gpu, src_host, cpu, bytes, 0, nullptr, sig, (hsa_amd_sdma_engine_id_t) (1u << (t_engine[device] - 1)), true) == HSA_STATUS_SUCCESS;
+	const bool ok = issued && wait_signal(sig);
+	{ std::lock_guard<std::mutex> lock(g_m); g_dev[device].free_signals.push_back(sig); }
 	return ok;
 }
 

@@ -13,11 +13,14 @@ int hostcopy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes, 
 // the source must be complete
 bool hostcopy_d2h_sync(int device, void *dst_host, const void *src_dev, size_t bytes);
 bool hostcopy_ready(int device);
+// an upload from pinned host memory, synchronous (the thread sleeps while it runs), on an SDMA engine kept apart from the copies back;
+// false: not available (no engine measured yet -- a pipeline does that -- or no HSA): the caller's hipMemcpyAsync
+bool hostcopy_h2d_sync(int device, void *dst_dev, const void *src_host, size_t bytes);
 int hostcopy_state(uint64_t ticket);            // 0 running, 1 done, -1 failed
 bool hostcopy_wait(uint64_t ticket);            // sleeps until it is through; false: the copy failed
 void hostcopy_release(int device, uint64_t ticket);   // the ticket's signal goes back to the pool (after done / failed)
 // the engine chosen for `device` (-1: none), the measured device-to-host GB/s per engine (0: not measured) and the runtime's masks
-// {free, recommended}; measures on first use
+// {free, recommended, set aside for uploads} (three words); measures on first use
 int hostcopy_engine(int device, double *gbps16, uint32_t *masks2);
 void hostcopy_shutdown();
 

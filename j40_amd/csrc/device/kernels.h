@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "plan.h"
+#include "restore_dev.h"
 
 namespace j40hip {
 
@@ -20,6 +21,15 @@ enum { K2_NUM_BATCH_LAUNCHES = 16, K2_LARGE_WGS = 256 };
 void k2_batch_grids(const int32_t *last_totals, size_t cells_total, int32_t nframes, int32_t wg_slots, int32_t *grids);
 void launch_vardct_batch(const K2Frame *frames_dev, int32_t nframes, int32_t *tile_prefix_dev, int32_t *totals_dev, const int32_t *grids, float *large_scratch, hipStream_t stream, hipStream_t *side, int nside, hipEvent_t fork, hipEvent_t *side_done);
 void launch_vardct_frame(const DevPlan &plan, const int32_t *class_start, const DevVarblock *sorted, float *large_scratch, uint8_t *rgba, size_t stride, hipStream_t stream);
+
+// the restoration filters (device/restore_kernels.h, restore_dev.h): the pixel kernels with the samples left in XYB (three float planes of
+// `stride` bytes per row, one behind the other), the reciprocal-sigma plane, Gaborish + the edge-preserving filter's steps between
+// `xyb` and `tmp` (returns where the result lies), the colour tail on planes
+void launch_vardct_frame_xyb(const DevPlan &plan, const int32_t *class_start, const DevVarblock *sorted, float *large_scratch, float *xyb, size_t stride, hipStream_t stream);
+void launch_epf_sigma(const DevPlan &plan, int32_t num_lf_groups, const int16_t *sharpness, const RestoreParams &p, float *sigma, uint32_t *sharp_or, hipStream_t stream);
+void launch_epf_sigma_cells(const int16_t *sharpness, const float *hfmul_inv, const RestoreParams &p, float *sigma, uint32_t *sharp_or, hipStream_t stream);
+float *launch_restoration(float *xyb, float *tmp, size_t pitch, const RestoreParams &p, bool gab, int32_t epf_iters, const float *sigma, hipStream_t stream);
+void launch_xyb_to_rgba(const float *xyb, size_t pitch, const DevFrame *frame_dev, int32_t width, int32_t height, uint8_t *rgba, size_t stride_bytes, hipStream_t stream);
 
 // LfGroup tail on the device (device/lf_tail_kernels.hip)
 void upload_lf_tail_tables(const float *half_secants, const float *lf2llf, hipStream_t stream);

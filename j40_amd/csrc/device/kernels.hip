@@ -23,6 +23,7 @@
 #include "large_dev.h"
 #include "k2_iter_dev.h"
 #include "hf_uni_dev.h"
+#include "restore_dev.h"
 #include "kernels.h"
 
 namespace j40hip {
@@ -580,7 +581,14 @@ template <int NB> struct K2Ahead {
 #ifndef J40_K2_WAVES_PER_EU
 #define J40_K2_WAVES_PER_EU 8
 #endif
-template <int LOGR, int LOGC, int NB, bool BATCH>
+// XYB = true (single-frame launches only; the restoration filters' input, restore_kernels.hip): the samples leave as they come out of
+// the inverse transforms -- three float planes of the frame, X, Y, B, `stride_bytes` per row (4 bytes a sample, like RGBA), one
+// behind the other from `rgba` -- instead of going through the colour conversion. The fused default is not touched by it.
+__device__ __forceinline__ void store_xyb(uint8_t *base, size_t off, size_t plane_bytes, float sx, float sy, float sb) {
+	*(float *) (base + off) = sx; *(float *) (base + plane_bytes + off) = sy; *(float *) (base + 2 * plane_bytes + off) = sb;
+}
+
+template <int LOGR, int LOGC, int NB, bool BATCH, bool XYB = false>
 __global__ void __launch_bounds__(256, (LOGR + LOGC <= 7 ? J40_K2_WAVES_PER_EU : 1)) k_vardct_dct(DevPlan plan_arg, const DevVarblock *list, int32_t count, int32_t param_idx, int32_t order_idx, uint8_t *rgba, size_t stride_bytes,
 		const K2Frame *batch, const int32_t *tile_prefix, int32_t nframes, int32_t class_a, int32_t class_b) {
 	constexpr int R = 1 << LOGR, C = 1 << LOGC, P = C + 1, TILE = R * P;
@@ -710,6 +718,7 @@ __global__ void __launch_bounds__(256, (LOGR + LOGC <= 7 ? J40_K2_WAVES_PER_EU :
 				const VbGeom &g = geom[b];
 				if (y >= g.effh || x >= g.effw) continue;
 				const float *t = lds + (size_t) b * 3 * TILE + y * P + x;
+				if constexpr (XYB) { store_xyb(rgba, g_out[b] + in_block, stride_bytes * (size_t) plan.frame->height, t[0], t[TILE], t[2 * TILE]); continue; }
 				const uint32_t px = xyb_to_rgba8(t[0], t[TILE], t[2 * TILE], cc, srgb_thr);
 				__builtin_nontemporal_store(px, (uint32_t *) (rgba + g_out[b] + in_block));   // written once, never read here: keep it out of the L2's way (-2 %)
 			}
@@ -758,7 +767,7 @@ template <int SET> __device__ __forceinline__ void special8_set_phase1(int sel, 
 	else if (SET == 2) { if (sel == 12) wide_halves_phase1(lane, mid, dst, hs); else tall_halves_phase1(lane, mid, dst, hs); }
 	else afv_phase1(lane, mid, dst, hs, (sel - 14) & 1, (sel - 14) >> 1);
 }
-template <int NB, bool BATCH, int SET>
+template <int NB, bool BATCH, int SET, bool XYB = false>
 __device__ __forceinline__ void vardct_special_body(DevPlan plan_arg, const DevVarblock *list, int32_t count, uint8_t *rgba, size_t stride_bytes, const K2Frame *batch, const int32_t *tile_prefix, int32_t nframes,
 		int32_t class_a, int32_t class_b) {
 	constexpr int P = SP8_TILE;
@@ -857,6 +866,7 @@ __device__ __forceinline__ void vardct_special_body(DevPlan plan_arg, const DevV
 			const VbGeom &g = geom[b];
 			if (y >= g.effh || x >= g.effw) continue;
 			const float *t = tiles + (size_t) b * 3 * P + SP8(i);
+			if constexpr (XYB) { store_xyb(rgba, (size_t) (g.py + y) * stride_bytes + (size_t) (g.px + x) * 4, stride_bytes * (size_t) f.height, t[0], t[P], t[2 * P]); continue; }
 			const uint32_t px = xyb_to_rgba8(t[0], t[P], t[2 * P], cc, srgb_thr);
 			*(uint32_t *) (rgba + (size_t) (g.py + y) * stride_bytes + (size_t) (g.px + x) * 4) = px;
 		}
@@ -874,10 +884,10 @@ __device__ __forceinline__ void vardct_special_body(DevPlan plan_arg, const DevV
 // the three kernels: the sets' transforms need 98 / 106 / 118 registers left alone; sets 1 and 2 fit the 64 that eight wavefronts per
 // SIMD leave (one register spilled / none), the AFV set gets the 96 of five (J40_K2_SPECIAL_WAVES, J40_K2_SPECIAL_WAVES_AFV)
 #define J40_SPECIAL_KERNEL(NAME_, SET_, WAVES_) \
-template <int NB, bool BATCH> \
+template <int NB, bool BATCH, bool XYB = false> \
 __global__ void __launch_bounds__(J40_K2_SPECIAL_THREADS) __attribute__((amdgpu_waves_per_eu(WAVES_))) NAME_(DevPlan plan_arg, const DevVarblock *list, int32_t count, uint8_t *rgba, size_t stride_bytes, const K2Frame *batch, \
 		const int32_t *tile_prefix, int32_t nframes, int32_t class_a, int32_t class_b) { \
-	vardct_special_body<NB, BATCH, SET_>(plan_arg, list, count, rgba, stride_bytes, batch, tile_prefix, nframes, class_a, class_b); \
+	vardct_special_body<NB, BATCH, SET_, XYB>(plan_arg, list, count, rgba, stride_bytes, batch, tile_prefix, nframes, class_a, class_b); \
 }
 J40_SPECIAL_KERNEL(k_vardct_special_123, 1, J40_K2_SPECIAL_WAVES)
 J40_SPECIAL_KERNEL(k_vardct_special_halves, 2, J40_K2_SPECIAL_WAVES)
@@ -970,7 +980,7 @@ struct WorkgroupExec {
 #ifndef J40_LARGE_THREADS
 #define J40_LARGE_THREADS 512
 #endif
-template <bool BATCH, bool REG64>
+template <bool BATCH, bool REG64, bool XYB = false>
 __global__ void __launch_bounds__(J40_LARGE_THREADS) k_vardct_large(DevPlan plan_arg, const DevVarblock *list, int32_t count, float *scratch, uint8_t *rgba, size_t stride_bytes, const K2Frame *batch, const int32_t *tile_prefix, int32_t nframes,
 		int32_t class_a, int32_t class_b) {
 	const int32_t tid = threadIdx.x, nthreads = blockDim.x;
@@ -1025,6 +1035,7 @@ __global__ void __launch_bounds__(J40_LARGE_THREADS) k_vardct_large(DevPlan plan
 		for (int32_t i = tid; i < size; i += nthreads) {
 			const int32_t y = i >> log_columns, x = i & (C - 1);
 			if (y >= g.effh || x >= g.effw) continue;
+			if constexpr (XYB) { store_xyb(rgba, (size_t) (g.py + y) * stride_bytes + (size_t) (g.px + x) * 4, stride_bytes * (size_t) f.height, S.p[0][y * S.pitch[0] + x], S.p[1][y * S.pitch[1] + x], S.p[2][y * S.pitch[2] + x]); continue; }
 			const uint32_t px = xyb_to_rgba8(S.p[0][y * S.pitch[0] + x], S.p[1][y * S.pitch[1] + x], S.p[2][y * S.pitch[2] + x], cc, srgb_thr);
 			*(uint32_t *) (rgba + (size_t) (g.py + y) * stride_bytes + (size_t) (g.px + x) * 4) = px;
 		}
@@ -1076,7 +1087,7 @@ void launch_hf_entropy(const DevPlan &plan, const HfLaunchInfo &info, int32_t fi
 // `batch` = nullptr: one frame, everything in the kernel arguments. Otherwise a persistent launch over the tiles of one class of
 // `nframes` frames (k2_bind): `grid` workgroups, tile_prefix = this launch's row of the table k_k2_tiles built; plan / list /
 // count / rgba / stride are then ignored, `large_scratch` holds 6 * 65536 floats per workgroup of the launch.
-struct K2Launch { const K2Frame *batch; const int32_t *tile_prefix; int32_t nframes, class_a, class_b, grid; };
+struct K2Launch { const K2Frame *batch; const int32_t *tile_prefix; int32_t nframes, class_a, class_b, grid; int32_t xyb; };   // xyb: single-frame launches, store_xyb instead of the colour tail
 
 template <int LOGR, int LOGC, int NB>
 static void launch_dct(const DevPlan &plan, const DevVarblock *list, int32_t count, int32_t param_idx, int32_t order_idx, uint8_t *rgba, size_t stride, const K2Launch &bl, hipStream_t stream) {
@@ -1085,10 +1096,12 @@ static void launch_dct(const DevPlan &plan, const DevVarblock *list, int32_t cou
 	if (!configured) {
 		(void) hipFuncSetAttribute((const void *) k_vardct_dct<LOGR, LOGC, NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
 		(void) hipFuncSetAttribute((const void *) k_vardct_dct<LOGR, LOGC, NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
+		(void) hipFuncSetAttribute((const void *) k_vardct_dct<LOGR, LOGC, NB, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
 		configured = true;
 	}
 	const int32_t blocks = (count + NB - 1) / NB;
-	if (bl.batch) hipLaunchKernelGGL((k_vardct_dct<LOGR, LOGC, NB, true>), dim3((unsigned) bl.grid), dim3(256), lds_bytes, stream, plan, list, count, param_idx, order_idx, rgba, stride, bl.batch, bl.tile_prefix, bl.nframes, bl.class_a, bl.class_b);
+	if (!bl.batch && bl.xyb) hipLaunchKernelGGL((k_vardct_dct<LOGR, LOGC, NB, false, true>), dim3((unsigned) blocks), dim3(256), lds_bytes, stream, plan, list, count, param_idx, order_idx, rgba, stride, bl.batch, nullptr, 1, 0, 0);
+	else if (bl.batch) hipLaunchKernelGGL((k_vardct_dct<LOGR, LOGC, NB, true>), dim3((unsigned) bl.grid), dim3(256), lds_bytes, stream, plan, list, count, param_idx, order_idx, rgba, stride, bl.batch, bl.tile_prefix, bl.nframes, bl.class_a, bl.class_b);
 	else hipLaunchKernelGGL((k_vardct_dct<LOGR, LOGC, NB, false>), dim3((unsigned) blocks), dim3(256), lds_bytes, stream, plan, list, count, param_idx, order_idx, rgba, stride, bl.batch, nullptr, 1, 0, 0);
 }
 
@@ -1112,7 +1125,8 @@ static void launch_vardct_class_impl(const DevPlan &plan, int32_t dctsel, const 
 	case 19: launch_dct<6, 5, 1>(plan, list, count, 12, 8, rgba, stride, bl, stream); break;
 	case 20: launch_dct<5, 6, 1>(plan, list, count, 12, 8, rgba, stride, bl, stream); break;
 #define J40_LAUNCH_SPECIAL(KERNEL_) do { \
-		if (bl.batch) hipLaunchKernelGGL((KERNEL_<J40_K2_SPECIAL_NB, true>), dim3((unsigned) bl.grid), dim3(J40_K2_SPECIAL_THREADS), 0, stream, plan, list, count, rgba, stride, bl.batch, bl.tile_prefix, bl.nframes, bl.class_a, bl.class_b); \
+		if (!bl.batch && bl.xyb) hipLaunchKernelGGL((KERNEL_<J40_K2_SPECIAL_NB, false, true>), dim3((unsigned) ((count + J40_K2_SPECIAL_NB - 1) / J40_K2_SPECIAL_NB)), dim3(J40_K2_SPECIAL_THREADS), 0, stream, plan, list, count, rgba, stride, bl.batch, nullptr, 1, 0, 0); \
+		else if (bl.batch) hipLaunchKernelGGL((KERNEL_<J40_K2_SPECIAL_NB, true>), dim3((unsigned) bl.grid), dim3(J40_K2_SPECIAL_THREADS), 0, stream, plan, list, count, rgba, stride, bl.batch, bl.tile_prefix, bl.nframes, bl.class_a, bl.class_b); \
 		else hipLaunchKernelGGL((KERNEL_<J40_K2_SPECIAL_NB, false>), dim3((unsigned) ((count + J40_K2_SPECIAL_NB - 1) / J40_K2_SPECIAL_NB)), dim3(J40_K2_SPECIAL_THREADS), 0, stream, plan, list, count, rgba, stride, bl.batch, nullptr, 1, 0, 0); \
 	} while (0)
 	case 1: case 2: case 3: J40_LAUNCH_SPECIAL(k_vardct_special_123); break;
@@ -1128,6 +1142,7 @@ static void launch_vardct_class_impl(const DevPlan &plan, int32_t dctsel, const 
 				(void) hipFuncSetAttribute((const void *) k_vardct_large<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
 				(void) hipFuncSetAttribute((const void *) k_vardct_large<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
 				(void) hipFuncSetAttribute((const void *) k_vardct_large<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
+				(void) hipFuncSetAttribute((const void *) k_vardct_large<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
 				configured = true;
 			}
 			// (J40HIP_LARGE_IDCT=sweeps: round 3's kernel, every butterfly level as a sweep over an LDS panel -- kept for comparison)
@@ -1144,7 +1159,7 @@ static void launch_vardct_class_impl(const DevPlan &plan, int32_t dctsel, const 
 	}
 }
 void launch_vardct_class(const DevPlan &plan, int32_t dctsel, const DevVarblock *list, int32_t count, float *large_scratch, uint8_t *rgba, size_t stride, hipStream_t stream) {
-	launch_vardct_class_impl(plan, dctsel, list, count, large_scratch, rgba, stride, K2Launch{nullptr, nullptr, 1, 0, 0, 0}, stream);
+	launch_vardct_class_impl(plan, dctsel, list, count, large_scratch, rgba, stride, K2Launch{nullptr, nullptr, 1, 0, 0, 0, 0}, stream);
 }
 
 // known-answer hook: the renderer's per-sample tail (sRGB transfer + conversion, j40.h:7213-7240 / 7925-7935)
@@ -1174,6 +1189,11 @@ static bool class_range(int d, int *a, int *b) {
 void launch_vardct_frame(const DevPlan &plan, const int32_t *class_start, const DevVarblock *sorted, float *large_scratch, uint8_t *rgba, size_t stride, hipStream_t stream) {
 	for (int d = 0, a, b; d < 27; ++d) if (class_range(d, &a, &b))
 		launch_vardct_class(plan, d, sorted + class_start[a], class_start[b] - class_start[a], large_scratch, rgba, stride, stream);
+}
+// the same with the samples left in XYB: three float planes of the frame from `xyb`, `stride` bytes per row (store_xyb)
+void launch_vardct_frame_xyb(const DevPlan &plan, const int32_t *class_start, const DevVarblock *sorted, float *large_scratch, float *xyb, size_t stride, hipStream_t stream) {
+	for (int d = 0, a, b; d < 27; ++d) if (class_range(d, &a, &b))
+		launch_vardct_class_impl(plan, d, sorted + class_start[a], class_start[b] - class_start[a], large_scratch, (uint8_t *) xyb, stride, K2Launch{nullptr, nullptr, 1, 0, 0, 0, 1}, stream);
 }
 
 // ---- the same for every frame of a batch at once: one persistent launch per class ----
@@ -1239,9 +1259,13 @@ void launch_vardct_batch(const K2Frame *frames_dev, int32_t nframes, int32_t *ti
 	if (nside > 0) { (void) hipEventRecord(fork, stream); for (int k = 0; k < nside; ++k) (void) hipStreamWaitEvent(side[k], fork, 0); }
 	for (int l = 0; l < K2_NUM_BATCH_LAUNCHES; ++l) {
 		const auto &L = k2_table().l[l];
-		launch_vardct_class_impl(none, L.a, nullptr, 0, large_scratch, nullptr, 0, K2Launch{frames_dev, tile_prefix_dev + (size_t) l * (size_t) (nframes + 1), nframes, L.a, L.b, grids[l]}, nside > 0 ? side[k2_launch_stream()[l] % nside] : stream);
+		launch_vardct_class_impl(none, L.a, nullptr, 0, large_scratch, nullptr, 0, K2Launch{frames_dev, tile_prefix_dev + (size_t) l * (size_t) (nframes + 1), nframes, L.a, L.b, grids[l], 0}, nside > 0 ? side[k2_launch_stream()[l] % nside] : stream);
 	}
 	if (nside > 0) for (int k = 0; k < nside; ++k) { (void) hipEventRecord(side_done[k], side[k]); (void) hipStreamWaitEvent(stream, side_done[k], 0); }
 }
+
+// ------------------------------------------------------------------------------------------------
+// the restoration filters (they share this unit's constant tables)
+#include "restore_kernels.h"
 
 } // namespace j40hip

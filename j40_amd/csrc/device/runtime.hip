@@ -28,6 +28,7 @@ namespace {
 
 constexpr uint32_t ERR_GPU = ('!' << 24) | ('g' << 16) | ('p' << 8) | 'u';
 constexpr uint32_t ERR_MEM = ('!' << 24) | ('m' << 16) | ('e' << 8) | 'm';
+constexpr uint32_t ERR4(char a, char b, char c, char d) { return ((uint32_t) (uint8_t) a << 24) | ((uint32_t) (uint8_t) b << 16) | ((uint32_t) (uint8_t) c << 8) | (uint32_t) (uint8_t) d; }
 
 // no exception crosses the C ABI: a parse error keeps its code, anything else (std::bad_alloc from a vector, ...) is "!mem"
 template <typename F> uint32_t guarded(F f) {
@@ -324,6 +325,12 @@ struct j40hip_device_state {
 	uint32_t *mod_extra_status = nullptr;
 	std::vector<uint32_t> status_host;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	// the restoration filters (decode_impl, restore_*): made at the first decode that runs them, kept with the frame
+	float *d_xyb = nullptr, *d_xyb_tmp = nullptr, *d_sigma = nullptr; int16_t *d_sharp = nullptr;
+	const float *d_restored = nullptr;   // where the last decode's filtered planes lie (d_xyb or d_xyb_tmp)
+	uint32_t restore_err = 0;            // the last decode's "gab0" / "epf0" / "shrp" (reported behind the sections' codes)
+	int restore_ran = 0;                 // the mode the last decode ran the filters in (0: it did not)
+	float restore_ms = 0;
 
 	template <typename T> T *upload(const T *src, size_t n, hipStream_t s, bool &ok) {
 		DeviceBuffer b;
@@ -721,6 +728,7 @@ static bool lf_device_decode(void *ctx_, const Frame &f, const uint8_t *cs, size
 		t.status = res[i].status; t.nb_varblocks = res[i].nb_varblocks;
 		for (int c = 0; c < 3; ++c) t.lf[c] = p + (size_t) c * cells;
 		t.xfromy = p + 3 * cells; t.bfromy = t.xfromy + c64; t.info0 = t.bfromy + c64; t.info1 = t.info0 + (t.nb_varblocks > 0 ? t.nb_varblocks : 0);
+		t.sharp = t.info0 + 2 * cells;
 	}
 	return true;
 }
@@ -963,6 +971,89 @@ static uint32_t validate_trailers(j40hip_frame *h, hipStream_t s) {
 	return ok ? 0 : ERR_GPU;
 }
 
+// ---- restoration filters (device/restore_dev.h, restore_kernels.h) ----
+// Off unless asked for: j40 parses the frame header's RestorationFilter bundle and ignores it (j40.h:5339-5366; its j40__gaborish /
+// j40__epf are never called), and the default decode matches j40. J40HIP_RESTORATION=1 (or j40hip_frame_set_restoration(f, 1)) runs the
+// filters a VarDCT frame signals; =j40 (2) runs them exactly as j40's routines stand, aliased line buffers and all (restore_dev.h).
+static int restoration_mode(const j40hip_frame *h) {
+	if (h->restoration >= 0) return h->restoration;
+	static const int env = [] { const char *e = getenv("J40HIP_RESTORATION"); return !e ? 0 : !strcmp(e, "j40") ? 2 : atoi(e) > 0 ? 1 : 0; }();
+	return env;
+}
+static bool surely_nonzero(float x) { return std::isfinite(x) && std::fabs(x) >= 1e-8f; }   // j40.h:625
+// the kernels' parameters from the frame header's; 0 or the reference routines' own complaints: "gab0" (j40.h:7289), "epf0" (j40.h:7384)
+static uint32_t restore_params(const FrameHeader &fh, int mode, RestoreParams *p) {
+	const FrameHeader::Restoration &r = fh.restoration;
+	memset(p, 0, sizeof *p);
+	p->width = fh.width; p->height = fh.height; p->w8 = (fh.width + 7) / 8; p->h8 = (fh.height + 7) / 8;
+	p->quirk = mode == 2 ? 1 : 0;
+	if (r.gab) for (int c = 0; c < 3; ++c) {
+		float w0 = 1.0f, w1 = r.gab_weights[c][0], w2 = r.gab_weights[c][1];
+		const float wsum = w0 + w1 * 4 + w2 * 4;
+		if (!surely_nonzero(wsum)) return ERR4('g', 'a', 'b', '0');
+		p->gab_w[c][0] = w0 / wsum; p->gab_w[c][1] = w1 / wsum; p->gab_w[c][2] = w2 / wsum;
+	}
+	if (r.epf_iters > 0) {
+		for (int i = 0; i < 8; ++i) {
+			const float q = r.quant_mul * r.sharp_lut[i];
+			if (!surely_nonzero(q)) return ERR4('e', 'p', 'f', '0');
+			p->inv_quant_sharp_lut[i] = 1.0f / q;
+		}
+		const float scale[3] = {r.pass0_sigma_scale, 1.0f, r.pass2_sigma_scale};
+		for (int k = 0; k < 3; ++k) { p->sigma_scale[k] = scale[k] * 1.9330952441687859f; p->border_scale[k] = p->sigma_scale[k] * r.border_sad_mul; }   // j40.h:7466-7467
+		for (int c = 0; c < 3; ++c) p->channel_scale[c] = r.channel_scale[c];
+	}
+	return 0;
+}
+static uint32_t decode_restored(j40hip_frame *h, uint8_t *rgba_dev, size_t stride_bytes, int mode, hipStream_t s) {
+	j40hip_device_state *st = h->dev;
+	const Frame &fr = h->frame;
+	const FrameHeader::Restoration &r = fr.fh.restoration;
+	const int32_t W = fr.fh.width, H = fr.fh.height;
+	const size_t cells = (size_t) ((W + 7) / 8) * (size_t) ((H + 7) / 8), plane = (size_t) W * (size_t) H;
+	RestoreParams p;
+	uint32_t perr = restore_params(fr.fh, mode, &p);
+	if (!perr && r.gab && W < 2) perr = ERR_TODO;   // (j40__gaborish reads sample 1 of every row, j40.h:7304)
+	// the sharpness map: frame-wide, in the cell order of `blocks` (LfGroup after LfGroup); "shrp" as j40__epf_recip_sigmas finds it (j40.h:7399)
+	std::vector<int16_t> sharp;
+	if (!perr && r.epf_iters > 0) {
+		sharp.reserve(cells);
+		uint16_t ub = 0;
+		for (const LfGroup &gg : fr.lf_groups) {
+			if (gg.sharpness.size() != (size_t) gg.width8 * (size_t) gg.height8) { perr = ERR_TODO; break; }   // (a frame handle built without it: from a view or an LF bundle)
+			for (int16_t v : gg.sharpness) ub |= (uint16_t) v;
+			sharp.insert(sharp.end(), gg.sharpness.begin(), gg.sharpness.end());
+		}
+		if (!perr && !(ub < 8)) perr = ERR4('s', 'h', 'r', 'p');
+	}
+	if (perr) {   // the filters cannot run: the picture without them, and the complaint behind the sections' own (j40hip_frame_status)
+		st->restore_err = perr;
+		launch_vardct_frame(st->plan, st->class_start, st->d_vb_sorted, st->d_large_scratch, rgba_dev, stride_bytes, s);
+		return 0;
+	}
+	bool ok = true;
+	if (!st->d_xyb) { st->d_xyb = st->scratch<float>(3 * plane, ok); st->d_xyb_tmp = st->scratch<float>(3 * plane, ok); st->d_sigma = st->scratch<float>(cells + 64, ok); }
+	if (r.epf_iters > 0 && !st->d_sharp) st->d_sharp = st->upload(sharp.data(), sharp.size(), s, ok);
+	if (!ok) return ERR_MEM;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	static const bool timed = getenv("J40HIP_RESTORATION_TIMING") != nullptr;
+	launch_vardct_frame_xyb(st->plan, st->class_start, st->d_vb_sorted, st->d_large_scratch, st->d_xyb, (size_t) W * 4, s);
+	if (timed && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) (void) hipEventRecord(e0, s);
+	uint32_t *sharp_or = (uint32_t *) (st->d_sigma + cells);   // (the device's own OR of the sharpness values: unused, the host checked)
+	if (r.epf_iters > 0) {
+		if (hipMemsetAsync(sharp_or, 0, 4, s) != hipSuccess) return ERR_GPU;
+		launch_epf_sigma(st->plan, (int32_t) fr.lf_groups.size(), st->d_sharp, p, st->d_sigma, sharp_or, s);
+	}
+	st->d_restored = launch_restoration(st->d_xyb, st->d_xyb_tmp, (size_t) W, p, r.gab, r.epf_iters, st->d_sigma, s);
+	if (e0 && e1) (void) hipEventRecord(e1, s);
+	launch_xyb_to_rgba(st->d_restored, (size_t) W, st->plan.frame, W, H, rgba_dev, stride_bytes, s);
+	st->restore_ran = mode;
+	if (e0 && e1) { if (hipEventSynchronize(e1) == hipSuccess) (void) hipEventElapsedTime(&st->restore_ms, e0, e1); }
+	if (e0) (void) hipEventDestroy(e0);
+	if (e1) (void) hipEventDestroy(e1);
+	return 0;
+}
+
 static uint32_t decode_impl(j40hip_frame *h, void *rgba_dev, size_t stride_bytes, hipStream_t s, float *ms3) {
 	if (!h || !h->dev) return ERR_GPU;
 	j40hip_device_state *st = h->dev;
@@ -978,7 +1069,13 @@ static uint32_t decode_impl(j40hip_frame *h, void *rgba_dev, size_t stride_bytes
 	if (ms3) (void) hipEventRecord(st->ev[1], s);
 	launch_hf_entropy(plan, st->hf, (int32_t) st->first_group, (int32_t) st->num_groups, s);
 	if (ms3) (void) hipEventRecord(st->ev[2], s);
-	if (whole) {
+	st->restore_ran = 0; st->restore_err = 0;
+	const int rmode = restoration_mode(h);
+	if (rmode && whole && (fr.fh.restoration.gab || fr.fh.restoration.epf_iters > 0)) {
+		// the restoration filters asked for and signalled: the pixel kernels leave the samples in XYB planes, Gaborish and the
+		// edge-preserving filter run over the whole picture, the colour tail follows on the filtered planes (restore_kernels.h)
+		if (uint32_t e = decode_restored(h, (uint8_t *) rgba_dev, stride_bytes, rmode, s)) return e;
+	} else if (whole) {
 		launch_vardct_frame(plan, st->class_start, st->d_vb_sorted, st->d_large_scratch, (uint8_t *) rgba_dev, stride_bytes, s);
 	} else {
 		// sharded decode: only the varblocks of this process' groups
@@ -1252,10 +1349,10 @@ static uint32_t j40hip_frame_status_body(j40hip_frame *h) {
 	if (hipMemcpy(st->status_host.data(), st->plan.status, sizeof(uint32_t) * st->status_host.size(), hipMemcpyDeviceToHost) != hipSuccess) return ERR_GPU;
 	// the reference reports the first failing section in the order it reads them (TOC order)
 	const Frame &fr = h->frame;
-	if (fr.toc.single) return st->status_host.empty() ? 0 : st->status_host[0];
+	if (fr.toc.single) return st->status_host.empty() ? st->restore_err : st->status_host[0] ? st->status_host[0] : st->restore_err;
 	std::vector<std::pair<size_t, uint32_t>> bad;
 	for (size_t i = 0; i < st->status_host.size(); ++i) if (st->status_host[i]) bad.push_back({fr.toc.pass_groups[i].offset, st->status_host[i]});
-	if (bad.empty()) return 0;
+	if (bad.empty()) return st->restore_err;   // (the filters run behind the last section: their complaint comes after every section's)
 	return std::min_element(bad.begin(), bad.end())->second;
 }
 
@@ -1284,6 +1381,90 @@ static uint32_t j40hip_frame_decode_to_host_body(j40hip_frame *h, void *rgba_hos
 	(void) hipDeviceSynchronize();
 	cache_release(device, d, got, false);
 	return err;
+}
+
+extern "C" void j40hip_frame_set_restoration(j40hip_frame *h, int mode) { if (h) h->restoration = mode < 0 ? -1 : mode > 2 ? 2 : mode; }
+extern "C" void j40hip_frame_restoration(const j40hip_frame *h, j40hip_restoration *out) {
+	if (!h || !out) return;
+	const FrameHeader::Restoration &r = h->frame.fh.restoration;
+	out->gab_enabled = r.gab ? 1 : 0;
+	for (int c = 0; c < 3; ++c) for (int j = 0; j < 2; ++j) out->gab_weights[c][j] = r.gab_weights[c][j];
+	out->epf_iters = r.epf_iters;
+	for (int i = 0; i < 8; ++i) out->epf_sharp_lut[i] = r.sharp_lut[i];
+	for (int c = 0; c < 3; ++c) out->epf_channel_scale[c] = r.channel_scale[c];
+	out->epf_quant_mul = r.quant_mul; out->epf_pass0_sigma_scale = r.pass0_sigma_scale; out->epf_pass2_sigma_scale = r.pass2_sigma_scale;
+	out->epf_border_sad_mul = r.border_sad_mul; out->epf_sigma_for_modular = r.sigma_for_modular;
+}
+// the sharpness map of LfGroup gg as decoded (i16 w8*h8), like j40hip_frame_lf_group_plane's planes
+extern "C" int j40hip_frame_sharpness(const j40hip_frame *h, int64_t gg, int16_t *out) {
+	if (!h || gg < 0 || (size_t) gg >= h->frame.lf_groups.size()) return -1;
+	const LfGroup &g = h->frame.lf_groups[(size_t) gg];
+	if (g.sharpness.size() != (size_t) g.width8 * (size_t) g.height8) return -1;
+	memcpy(out, g.sharpness.data(), g.sharpness.size() * 2);
+	return 0;
+}
+// after a decode that ran the filters (synchronised): stage 0 the samples as the inverse transforms left them, 1 the filtered ones --
+// three planes of width * height floats (X, Y, B); stage 2: the reciprocal-sigma plane (w8 * h8 floats)
+extern "C" uint32_t j40hip_frame_read_xyb(j40hip_frame *h, int stage, float *out) {
+	if (!h || !h->dev || !h->dev->restore_ran || !h->dev->d_xyb) return ERR_RNGE;
+	j40hip_device_state *st = h->dev;
+	const FrameHeader &fh = h->frame.fh;
+	const size_t plane = (size_t) fh.width * (size_t) fh.height, cells = (size_t) ((fh.width + 7) / 8) * (size_t) ((fh.height + 7) / 8);
+	if (hipSetDevice(st->device) != hipSuccess) return ERR_GPU;
+	if (stage == 2) return hipMemcpy(out, st->d_sigma, cells * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : ERR_GPU;
+	if (stage == 1) return hipMemcpy(out, st->d_restored, 3 * plane * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : ERR_GPU;
+	// stage 0: the planes the pixel kernels wrote are the filters' first input; they survive only when the result lies in the other buffer
+	// pair at every step's end -- re-run the pixel kernels into the spare buffer instead
+	const float *src = st->d_xyb;
+	const FrameHeader::Restoration &r = fh.restoration;
+	const int steps = (r.gab ? 1 : 0) + (r.epf_iters >= 3 ? 3 : r.epf_iters);
+	if (steps >= 2) {   // d_xyb has been written over by the second step: once more, into whichever buffer the result does not occupy
+		float *spare = st->d_restored == st->d_xyb ? st->d_xyb_tmp : st->d_xyb;
+		launch_vardct_frame_xyb(st->plan, st->class_start, st->d_vb_sorted, st->d_large_scratch, spare, (size_t) fh.width * 4, nullptr);
+		if (hipStreamSynchronize(nullptr) != hipSuccess) return ERR_GPU;
+		src = spare;
+	}
+	return hipMemcpy(out, src, 3 * plane * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : ERR_GPU;
+}
+extern "C" float j40hip_frame_restoration_ms(const j40hip_frame *h) { return h && h->dev ? h->dev->restore_ms : 0.0f; }
+// known-answer hook: the filter kernels on caller-supplied planes ([3][h][w] floats, in place), a w8*h8 sharpness map and the HfMul
+// reciprocal of the varblock covering each cell; mode 1 / 2 as j40hip_frame_set_restoration; sigma_out (optional): w8*h8 floats
+extern "C" uint32_t j40hip_kat_device_restoration(float *xyb, int32_t w, int32_t h, const int16_t *sharpness, const float *hfmul_inv, const j40hip_restoration *r, int mode, int device, float *sigma_out) {
+	return guarded([&]() -> uint32_t {
+		if (!xyb || !r || w < 1 || h < 1 || j40hip_device_count() <= device || hipSetDevice(device) != hipSuccess) return ERR_GPU;
+		if (!ensure_constant_tables(device)) return ERR_GPU;
+		FrameHeader fh;
+		fh.width = w; fh.height = h;
+		fh.restoration.gab = r->gab_enabled != 0;
+		for (int c = 0; c < 3; ++c) for (int j = 0; j < 2; ++j) fh.restoration.gab_weights[c][j] = r->gab_weights[c][j];
+		fh.restoration.epf_iters = r->epf_iters;
+		for (int i = 0; i < 8; ++i) fh.restoration.sharp_lut[i] = r->epf_sharp_lut[i];
+		for (int c = 0; c < 3; ++c) fh.restoration.channel_scale[c] = r->epf_channel_scale[c];
+		fh.restoration.quant_mul = r->epf_quant_mul; fh.restoration.pass0_sigma_scale = r->epf_pass0_sigma_scale; fh.restoration.pass2_sigma_scale = r->epf_pass2_sigma_scale;
+		fh.restoration.border_sad_mul = r->epf_border_sad_mul;
+		RestoreParams p;
+		if (uint32_t e = restore_params(fh, mode, &p)) return e;
+		if (fh.restoration.gab && w < 2) return ERR_TODO;
+		const size_t plane = (size_t) w * (size_t) h, cells = (size_t) p.w8 * (size_t) p.h8;
+		if (r->epf_iters > 0) { uint16_t ub = 0; for (size_t i = 0; i < cells; ++i) ub |= (uint16_t) sharpness[i]; if (!(ub < 8)) return ERR4('s', 'h', 'r', 'p'); }
+		j40hip_device_state tmp; tmp.device = device;
+		bool ok = true;
+		float *d_a = tmp.upload(xyb, 3 * plane, nullptr, ok), *d_b = tmp.scratch<float>(3 * plane, ok), *d_sigma = tmp.scratch<float>(cells + 64, ok);
+		if (ok && r->epf_iters > 0) {
+			int16_t *d_sh = tmp.upload(sharpness, cells, nullptr, ok);
+			float *d_hf = tmp.upload(hfmul_inv, cells, nullptr, ok);
+			if (ok) { (void) hipMemsetAsync(d_sigma + cells, 0, 4, nullptr); launch_epf_sigma_cells(d_sh, d_hf, p, d_sigma, (uint32_t *) (d_sigma + cells), nullptr); }
+		}
+		if (ok) {
+			const float *res = launch_restoration(d_a, d_b, (size_t) w, p, fh.restoration.gab, r->epf_iters, d_sigma, nullptr);
+			ok = hipMemcpy(xyb, res, 3 * plane * 4, hipMemcpyDeviceToHost) == hipSuccess;
+			if (ok && sigma_out && r->epf_iters > 0) ok = hipMemcpy(sigma_out, d_sigma, cells * 4, hipMemcpyDeviceToHost) == hipSuccess;
+		}
+		(void) hipDeviceSynchronize();
+		for (auto &b : tmp.buffers) b.release();
+		tmp.buffers.clear();
+		return ok ? 0 : ERR_GPU;
+	});
 }
 
 extern "C" uint32_t j40hip_frame_read_coeffs(j40hip_frame *h, int64_t gg, int c, float *out) {

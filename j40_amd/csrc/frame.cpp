@@ -328,15 +328,16 @@ static void read_frame_header(BitReader &br, const ImageMeta &im, FrameHeader *f
 		skip_name(br);
 		{   // RestorationFilter. The reference reads the conditional fields even when all_default is
 			// set (j40.h:5339-5366); a drop-in has to consume the same bits.
+			FrameHeader::Restoration &rf = f->restoration;
 			bool all_default = br.u(1);
-			bool gab = all_default ? true : br.u(1);
-			if (gab && br.u(1)) for (int i = 0; i < 6; ++i) (void) br.f16();
-			int32_t epf_iters = all_default ? 2 : (int32_t) br.u(2);
-			if (epf_iters) {
-				if (!f->is_modular && br.u(1)) for (int i = 0; i < 8; ++i) (void) br.f16();
-				if (br.u(1)) { for (int i = 0; i < 3; ++i) (void) br.f16(); br.skip_bits_like_reference(32); }
-				if (br.u(1)) { if (!f->is_modular) (void) br.f16(); for (int i = 0; i < 3; ++i) (void) br.f16(); }
-				if (f->is_modular) (void) br.f16();
+			rf.gab = all_default ? true : br.u(1);
+			if (rf.gab && br.u(1)) for (int i = 0; i < 3; ++i) for (int j = 0; j < 2; ++j) rf.gab_weights[i][j] = br.f16();
+			rf.epf_iters = all_default ? 2 : (int32_t) br.u(2);
+			if (rf.epf_iters) {
+				if (!f->is_modular && br.u(1)) for (int i = 0; i < 8; ++i) rf.sharp_lut[i] = br.f16();
+				if (br.u(1)) { for (int i = 0; i < 3; ++i) rf.channel_scale[i] = br.f16(); br.skip_bits_like_reference(32); }
+				if (br.u(1)) { if (!f->is_modular) rf.quant_mul = br.f16(); rf.pass0_sigma_scale = br.f16(); rf.pass2_sigma_scale = br.f16(); rf.border_sad_mul = br.f16(); }
+				if (f->is_modular) rf.sigma_for_modular = br.f16();
 			}
 			if (!all_default) read_extensions(br);
 		}
@@ -692,7 +693,7 @@ void read_lf_group_raw(BitReader &br, const Frame &f, const LfGroup &gg, LfRaw *
 	J40HIP_SHOULD((int32_t) m.channel[0].px.size() == w64 * h64 && (int32_t) m.channel[1].px.size() == w64 * h64, "TODO");
 	out->nb_varblocks = nb_varblocks;
 	for (int c = 0; c < 3; ++c) out->lf[c].swap(lfm.channel[(size_t) c].px);
-	out->xfromy.swap(m.channel[0].px); out->bfromy.swap(m.channel[1].px); out->info.swap(m.channel[2].px);
+	out->xfromy.swap(m.channel[0].px); out->bfromy.swap(m.channel[1].px); out->info.swap(m.channel[2].px); out->sharp.swap(m.channel[3].px);
 }
 
 static void read_lf_group(BitReader &br, Frame *f, LfGroup *gg) {  // j40.h:6722
@@ -702,6 +703,7 @@ static void read_lf_group(BitReader &br, Frame *f, LfGroup *gg) {  // j40.h:6722
 	const int16_t *lf[3] = {raw.lf[0].data(), raw.lf[1].data(), raw.lf[2].data()};
 	std::vector<int16_t> *take[3] = {&raw.lf[0], &raw.lf[1], &raw.lf[2]};
 	lf_group_finish(f, gg, raw.extra_prec, lf, take, raw.xfromy.data(), raw.bfromy.data(), raw.info.data(), raw.info.data() + raw.nb_varblocks, raw.nb_varblocks);
+	gg->sharpness.swap(raw.sharp);
 }
 
 static void allocate_lf_groups(Frame *f) {  // j40.h:7659
@@ -931,7 +933,10 @@ void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
 				if (t.status == (uint32_t) E4("lffb")) continue;   // the host decodes this one
 				done[(size_t) i] = 1;
 				if (t.status) { errs[(size_t) i] = t.status; continue; }
-				try { lf_group_finish(f, &f->lf_groups[(size_t) i], extra_prec[(size_t) i], t.lf, nullptr, t.xfromy, t.bfromy, t.info0, t.info1, t.nb_varblocks); }
+				try {
+					lf_group_finish(f, &f->lf_groups[(size_t) i], extra_prec[(size_t) i], t.lf, nullptr, t.xfromy, t.bfromy, t.info0, t.info1, t.nb_varblocks);
+					if (t.sharp) f->lf_groups[(size_t) i].sharpness.assign(t.sharp, t.sharp + (size_t) t.w8 * (size_t) t.h8);
+				}
 				catch (const DecodeError &e) { errs[(size_t) i] = e.code; }
 				catch (const std::exception &) { errs[(size_t) i] = E4("!mem"); }
 			}

@@ -41,6 +41,16 @@ struct FrameHeader {
 	int32_t x0 = 0, y0 = 0, width = 0, height = 0;
 	int32_t grows = 0, gcolumns = 0, ggrows = 0, ggcolumns = 0;
 	int64_t num_groups = 0, num_lf_groups = 0;
+	// RestorationFilter as the reference parses it (defaults j40.h:5196-5208, fields j40.h:5339-5366). The reference reads it and never
+	// looks at it again; here it is kept for the restoration filters (device/restore_dev.h), which run only when asked for.
+	struct Restoration {
+		bool gab = true;
+		float gab_weights[3][2] = {{0.115169525f, 0.061248592f}, {0.115169525f, 0.061248592f}, {0.115169525f, 0.061248592f}};
+		int32_t epf_iters = 2;
+		float sharp_lut[8] = {0.0f / 7.0f, 1.0f / 7.0f, 2.0f / 7.0f, 3.0f / 7.0f, 4.0f / 7.0f, 5.0f / 7.0f, 6.0f / 7.0f, 7.0f / 7.0f};
+		float channel_scale[3] = {40.0f, 5.0f, 3.5f};
+		float quant_mul = 0.46f, pass0_sigma_scale = 0.9f, pass2_sigma_scale = 6.5f, border_sad_mul = 2.0f / 3.0f, sigma_for_modular = 1.0f;
+	} restoration;
 };
 
 struct Section { size_t offset = 0, size = 0; };  // byte range inside the codestream
@@ -72,6 +82,7 @@ struct LfGroup {
 	std::vector<VarblockInfo> varblocks;
 	std::vector<float> llfcoeffs[3];      // [height8 * width8], indexed by coefficient offset / 64
 	std::vector<int16_t> xfromy, bfromy;  // [height64 * width64]
+	std::vector<int16_t> sharpness;       // [height8 * width8], as decoded (the reference's j40__lf_group_st::sharpness; read by the edge-preserving filter only)
 	bool loaded = false;
 	// Frame::defer_lf_tail: the quantised LF samples as decoded (channel order X, Y, B) and their dequantisation factors; the
 	// dequantisation, the adaptive smoothing and the LLF coefficients (`llfcoeffs`) are then computed on the device at upload
@@ -89,13 +100,13 @@ struct LfDeviceTask {
 	uint32_t status = 0;          // 0, the stream's 4-char error, or 'lffb': decode this section on the host
 	int32_t nb_varblocks = 0;
 	const int16_t *lf[3] = {nullptr, nullptr, nullptr};   // streamed order Y, X, B
-	const int16_t *xfromy = nullptr, *bfromy = nullptr, *info0 = nullptr, *info1 = nullptr;
+	const int16_t *xfromy = nullptr, *bfromy = nullptr, *info0 = nullptr, *info1 = nullptr, *sharp = nullptr;
 };
 // the streams of one LfGroup section as decoded (read_lf_group_raw): LF integers in streamed order Y, X, B; chroma-from-luma
-// maps; the varblock-info channel (two rows of nb_varblocks: DctSelect, HfMul - 1). The sharpness map is decoded and dropped.
+// maps; the varblock-info channel (two rows of nb_varblocks: DctSelect, HfMul - 1); the sharpness map.
 struct LfRaw {
 	int32_t extra_prec = 0, nb_varblocks = 0;
-	std::vector<int16_t> lf[3], xfromy, bfromy, info;
+	std::vector<int16_t> lf[3], xfromy, bfromy, info, sharp;
 };
 struct Frame;
 // returns false when it cannot take the frame (tree / code spec outside what the kernel handles, no device): host path

@@ -440,7 +440,10 @@ static int16_t to_i16(float t) {
 }
 
 /* j40__dequant_hf (j40.h:7053) + j40__combine_vardct_from_lf_group (j40.h:7099) + render (j40.h:7910) */
-static void combine_lf_group(const j40hip_vardct_view *v, const j40hip_lf_group_view *gg, float *const coeffs[3], uint8_t *rgba) {
+/* xyb_out (optional): the samples as the inverse transforms leave them, before the colour conversion, into three frame-wide planes of
+ * width * height floats (X, Y, B) -- what the restoration filters work on. */
+static void colour_samples(const j40hip_vardct_view *v, float *const samples[3], int32_t ggw, int32_t ggh, int32_t left, int32_t top, uint8_t *rgba);
+static void combine_lf_group(const j40hip_vardct_view *v, const j40hip_lf_group_view *gg, float *const coeffs[3], uint8_t *rgba, float *xyb_out) {
 	static const float QM_SCALE[8] = {1.5625f, 1.25f, 1.0f, 0.8f, 0.64f, 0.512f, 0.4096f, 0.32768f};
 	int32_t ggw8 = gg->width8, ggh8 = gg->height8, ggw = gg->width, ggh = gg->height, x8, y8, x, y, i, c;
 	float x_qm = QM_SCALE[v->x_qm_scale], b_qm = QM_SCALE[v->b_qm_scale];
@@ -488,11 +491,23 @@ static void combine_lf_group(const j40hip_vardct_view *v, const j40hip_lf_group_
 			for (y = 0; y < effvh; ++y) for (x = 0; x < effvw; ++x) samples[c][(y8 * 8 + y) * ggw + (x8 * 8 + x)] = scratch[y << log_columns | x];
 		}
 	}
+	if (xyb_out) for (c = 0; c < 3; ++c) for (y = 0; y < ggh; ++y)
+		memcpy(xyb_out + (size_t) c * (size_t) v->width * (size_t) v->height + (size_t) (gg->top + y) * (size_t) v->width + (size_t) gg->left, samples[c] + (size_t) y * (size_t) ggw, sizeof(float) * (size_t) ggw);
+	if (rgba) colour_samples(v, samples, ggw, ggh, gg->left, gg->top, rgba);
+	for (c = 0; c < 3; ++c) free(samples[c]);
+	free(scratch);
+	(void) cbrt_bias; (void) itscale;
+}
+
+/* XYB -> linear -> sRGB -> u8 (j40.h:7204-7240) + render (j40.h:7910): samples[c] = ggw * ggh floats placed at (left, top) of the frame */
+static void colour_samples(const j40hip_vardct_view *v, float *const samples[3], int32_t ggw, int32_t ggh, int32_t left, int32_t top, uint8_t *rgba) {
+	float cbrt_bias[3], itscale = 255.0f / v->intensity_target;
+	int32_t x, y, c;
 	for (c = 0; c < 3; ++c) cbrt_bias[c] = cbrtf(v->opsin_bias[c]);
 	for (y = 0; y < ggh; ++y) for (x = 0; x < ggw; ++x) {
 		int32_t pos = y * ggw + x;
 		float p[3], s[3];
-		uint8_t *out = rgba + ((size_t) (gg->top + y) * (size_t) v->width + (size_t) (gg->left + x)) * 4;
+		uint8_t *out = rgba + ((size_t) (top + y) * (size_t) v->width + (size_t) (left + x)) * 4;
 		p[0] = samples[1][pos] + samples[0][pos]; p[1] = samples[1][pos] - samples[0][pos]; p[2] = samples[2][pos];
 		for (c = 0; c < 3; ++c) { float pp = p[c] - cbrt_bias[c]; s[c] = (pp * pp * pp + v->opsin_bias[c]) * itscale; }
 		for (c = 0; c < 3; ++c) {
@@ -502,14 +517,23 @@ static void combine_lf_group(const j40hip_vardct_view *v, const j40hip_lf_group_
 		}
 		out[3] = 255;
 	}
-	for (c = 0; c < 3; ++c) free(samples[c]);
-	free(scratch);
+}
+
+/* the colour conversion alone, on three frame-wide planes of width * height floats (the restoration filters' output) */
+ORACLE_API void oracle_xyb_to_rgba(const j40hip_vardct_view *v, const float *xyb, uint8_t *rgba) {
+	float *planes[3];
+	int c;
+	for (c = 0; c < 3; ++c) planes[c] = (float *) xyb + (size_t) c * (size_t) v->width * (size_t) v->height;
+	colour_samples(v, planes, v->width, v->height, 0, 0, rgba);
 }
 
 /* Decodes a VarDCT frame described by `v` into tightly packed RGBA. coeffs_out (optional): per LF
  * group and channel the quantised coefficients as the reference holds them before dequantisation,
  * concatenated [lf group][channel][width8 * height8 * 64]. Returns 0 or the first error. */
-ORACLE_API uint32_t oracle_decode_vardct(const j40hip_vardct_view *v, uint8_t *rgba, float *coeffs_out) {
+ORACLE_API uint32_t oracle_decode_vardct_xyb(const j40hip_vardct_view *v, uint8_t *rgba, float *coeffs_out, float *xyb_out);
+ORACLE_API uint32_t oracle_decode_vardct(const j40hip_vardct_view *v, uint8_t *rgba, float *coeffs_out) { return oracle_decode_vardct_xyb(v, rgba, coeffs_out, NULL); }
+/* ... xyb_out (optional): three planes of width * height floats, the samples before the colour conversion */
+ORACLE_API uint32_t oracle_decode_vardct_xyb(const j40hip_vardct_view *v, uint8_t *rgba, float *coeffs_out, float *xyb_out) {
 	float ***coeffs = (float ***) calloc((size_t) v->num_lf_groups, sizeof(float **));
 	ocode *codes = (ocode *) calloc((size_t) v->num_passes, sizeof(ocode));
 	uint32_t err = 0;
@@ -529,7 +553,7 @@ ORACLE_API uint32_t oracle_decode_vardct(const j40hip_vardct_view *v, uint8_t *r
 		size_t n = (size_t) (v->lf_groups[g].width8 * v->lf_groups[g].height8) * 64;
 		memcpy(coeffs_out + off, coeffs[g][c], sizeof(float) * n); off += n;
 	}
-	if (!err && rgba) for (g = 0; g < v->num_lf_groups; ++g) combine_lf_group(v, &v->lf_groups[g], coeffs[g], rgba);
+	if (!err && (rgba || xyb_out)) for (g = 0; g < v->num_lf_groups; ++g) combine_lf_group(v, &v->lf_groups[g], coeffs[g], rgba, xyb_out);
 	for (pass = 0; pass < v->num_passes; ++pass) ocode_free(&codes[pass]);
 	for (g = 0; g < v->num_lf_groups; ++g) { for (c = 0; c < 3; ++c) free(coeffs[g][c]); free(coeffs[g]); }
 	free(coeffs); free(codes);

@@ -1138,3 +1138,66 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_block_cache_se
 	if (!cache.idle.empty() || cache.idle_bytes != 0 || used != 0 || !backend.empty()) return 10;   // everything went back
 	return 0;
 }
+
+// ---- the restoration filters' device functions (device/restore_dev.h) run sample by sample on the CPU, out of place like the kernels
+// (restore_kernels.h): three planes [3][h][w] in place; sharpness / hfmul_inv per 8x8 cell; params24 in ref_stage_restoration's order
+// (gab.enabled, gab.weights[3][2], epf.iters, sharp_lut[8], channel_scale[3], quant_mul, pass0, pass2, border_sad_mul, sigma_for_modular);
+// mode 1: the filters as intended, 2: as j40's routines stand. Returns 0 or the routines' own 4-char complaint.
+#include "../../j40_amd/csrc/device/restore_dev.h"
+namespace {
+struct HostPlanes { const float *p[3]; size_t pitch; float operator()(int32_t c, int32_t x, int32_t y) const { return p[c][(size_t) y * pitch + (size_t) x]; } };
+template <int STEP> void hostsim_epf_step(const j40hip::RestoreParams &p, const std::vector<float> &sigma, std::vector<float> &a, std::vector<float> &b) {
+	const size_t plane = (size_t) p.width * (size_t) p.height;
+	const HostPlanes in = {{a.data(), a.data() + plane, a.data() + 2 * plane}, (size_t) p.width};
+	for (int32_t y = 0; y < p.height; ++y) for (int32_t x = 0; x < p.width; ++x) {
+		const float rs = sigma[(size_t) (y >> 3) * (size_t) p.w8 + (size_t) (x >> 3)];
+		float v[3];
+		if (rs < 0.0f) for (int c = 0; c < 3; ++c) v[c] = in(c, x, y);
+		else j40hip::epf_sample<STEP>(in, p, x, y, rs, v);
+		for (int c = 0; c < 3; ++c) b[(size_t) c * plane + (size_t) y * (size_t) p.width + (size_t) x] = v[c];
+	}
+	a.swap(b);
+}
+}
+extern "C" __attribute__((visibility("default"))) uint32_t hostsim_restoration(float *xyb, int32_t w, int32_t h, const int16_t *sharpness, const float *hfmul_inv, const float *params24, int32_t mode, float *sigma_out) {
+	using namespace j40hip;
+	auto nonzero = [](float x) { return std::isfinite(x) && std::fabs(x) >= 1e-8f; };
+	auto e4 = [](const char *s) { return ((uint32_t) (uint8_t) s[0] << 24) | ((uint32_t) (uint8_t) s[1] << 16) | ((uint32_t) (uint8_t) s[2] << 8) | (uint32_t) (uint8_t) s[3]; };
+	RestoreParams p;
+	memset(&p, 0, sizeof p);
+	p.width = w; p.height = h; p.w8 = (w + 7) / 8; p.h8 = (h + 7) / 8; p.quirk = mode == 2;
+	const bool gab = params24[0] != 0.0f; const int iters = (int) params24[7];
+	if (gab) for (int c = 0; c < 3; ++c) {
+		const float w1 = params24[1 + c * 2], w2 = params24[2 + c * 2], wsum = 1.0f + w1 * 4 + w2 * 4;
+		if (!nonzero(wsum)) return e4("gab0");
+		p.gab_w[c][0] = 1.0f / wsum; p.gab_w[c][1] = w1 / wsum; p.gab_w[c][2] = w2 / wsum;
+	}
+	if (iters > 0) {
+		for (int i = 0; i < 8; ++i) { const float q = params24[19] * params24[8 + i]; if (!nonzero(q)) return e4("epf0"); p.inv_quant_sharp_lut[i] = 1.0f / q; }
+		const float scale[3] = {params24[20], 1.0f, params24[21]};
+		for (int k = 0; k < 3; ++k) { p.sigma_scale[k] = scale[k] * 1.9330952441687859f; p.border_scale[k] = p.sigma_scale[k] * params24[22]; }
+		for (int c = 0; c < 3; ++c) p.channel_scale[c] = params24[16 + c];
+	}
+	const size_t plane = (size_t) w * (size_t) h, cells = (size_t) p.w8 * (size_t) p.h8;
+	std::vector<float> a(xyb, xyb + 3 * plane), b(3 * plane), sigma(cells);
+	if (iters > 0) {
+		uint16_t ub = 0;
+		for (size_t i = 0; i < cells; ++i) ub |= (uint16_t) sharpness[i];
+		if (!(ub < 8)) return e4("shrp");
+		for (size_t i = 0; i < cells; ++i) sigma[i] = epf_recip_sigma(p, sharpness[i], hfmul_inv[i]);
+		if (sigma_out) memcpy(sigma_out, sigma.data(), cells * 4);
+	}
+	if (gab) {
+		if (w < 2) return e4("TODO");
+		for (int c = 0; c < 3; ++c) for (int32_t y = 0; y < h; ++y) {
+			const float *base = a.data() + (size_t) c * plane, *n = base + (size_t) (y > 0 ? y - 1 : 0) * (size_t) w, *l = base + (size_t) y * (size_t) w, *s = base + (size_t) (y + 1 < h ? y + 1 : y) * (size_t) w;
+			for (int32_t x = 0; x < w; ++x) b[(size_t) c * plane + (size_t) y * (size_t) w + (size_t) x] = gaborish_sample(n, l, s, x, w, p.gab_w[c][0], p.gab_w[c][1], p.gab_w[c][2]);
+		}
+		a.swap(b);
+	}
+	if (iters >= 3) hostsim_epf_step<0>(p, sigma, a, b);
+	if (iters >= 1) hostsim_epf_step<1>(p, sigma, a, b);
+	if (iters >= 2) hostsim_epf_step<2>(p, sigma, a, b);
+	memcpy(xyb, a.data(), 3 * plane * 4);
+	return 0;
+}

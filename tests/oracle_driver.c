@@ -8,6 +8,31 @@
 
 uint32_t oracle_decode_vardct(const j40hip_vardct_view *v, uint8_t *rgba, float *coeffs_out);
 uint32_t oracle_decode_modular(const j40hip_modular_view *v, uint8_t *rgba);
+uint32_t oracle_decode_vardct_xyb(const j40hip_vardct_view *v, uint8_t *rgba, float *coeffs_out, float *xyb_out);
+void oracle_xyb_to_rgba(const j40hip_vardct_view *v, const float *xyb, uint8_t *rgba);
+
+/* the restoration filters' two ends through the oracle: the XYB samples of a VarDCT stream as the inverse transforms leave them (three
+ * planes of width * height floats) and, separately, the colour conversion of such planes with the stream's colour parameters */
+__attribute__((visibility("default"))) uint32_t oracle_run_xyb(const void *buf, size_t size, float *xyb_out) {
+	uint32_t err = 0;
+	j40hip_vardct_view v;
+	j40hip_frame *f = j40hip_frame_parse(buf, size, 1, &err);
+	if (!f) return err;
+	err = j40hip_frame_vardct_view(f, &v);
+	if (!err) err = oracle_decode_vardct_xyb(&v, NULL, NULL, xyb_out);
+	j40hip_frame_free(f);
+	return err;
+}
+__attribute__((visibility("default"))) uint32_t oracle_colour(const void *buf, size_t size, const float *xyb, uint8_t *rgba) {
+	uint32_t err = 0;
+	j40hip_vardct_view v;
+	j40hip_frame *f = j40hip_frame_parse(buf, size, 1, &err);
+	if (!f) return err;
+	err = j40hip_frame_vardct_view(f, &v);
+	if (!err) oracle_xyb_to_rgba(&v, xyb, rgba);
+	j40hip_frame_free(f);
+	return err;
+}
 
 __attribute__((visibility("default"))) uint32_t oracle_run(const void *buf, size_t size, uint8_t *rgba, float *coeffs_out) {
 	uint32_t err = 0;

@@ -865,10 +865,33 @@ static int run_vardct(int W, int H, uint64_t seed, const char *out, const Option
 		for (int i = -1; i < with_alpha; ++i) cs.u32(0, 0, 0, 1, 0, 2, 0, 3, 2);  // blend mode: replace (the frame's, then each extra channel's, j40.h:5299)
 		cs.put(1, 1);                       // is_last
 		cs.u32(0, 0, 0, 0, 4, 16, 5, 48, 10);  // name length 0
-		cs.put(0, 1);                       // restoration: !all_default (the reference mis-parses all_default = 1)
-		cs.put(0, 1);                       // gab disabled
-		cs.put(0, 2);                       // epf iterations 0
-		cs.u64(0);                          // restoration extensions
+		// RestorationFilter (j40.h:5339-5366). gab=1: Gaborish with the default weights, gab=2: custom weights; epf=1..3: iterations of the
+		// edge-preserving filter, always with a custom sharpness table (the default table's first entry is 0, which the reference's
+		// j40__epf_recip_sigmas rejects with "epf0", j40.h:7384; epflut=0 writes the default all the same), epfw=1: custom channel
+		// scales, epfs=1: custom sigma parameters; rfdefault=1: all_default = 1 (the reference then still reads the conditional bits)
+		const int gab = opt.geti("gab", 0), epf = opt.geti("epf", 0);
+		if (opt.geti("rfdefault", 0)) { cs.put(1, 1); cs.put(0, 1); cs.put(0, 1); cs.put(0, 1); cs.put(0, 1); }   // all_default; then gab_custom 0, sharp_custom 0, weight_custom 0, sigma_custom 0
+		else {
+			cs.put(0, 1);                       // restoration: !all_default
+			cs.put(gab ? 1 : 0, 1);
+			if (gab) {
+				cs.put(gab == 2 ? 1 : 0, 1);
+				if (gab == 2) { const float w[6] = {0.125f, 0.0625f, 0.1875f, 0.03125f, 0.09375f, 0.078125f}; for (float v : w) cs.f16(v); }
+			}
+			cs.put((uint64_t) epf, 2);
+			if (epf) {
+				const int lut = opt.geti("epflut", 1);
+				cs.put(lut ? 1 : 0, 1);
+				if (lut) { const float t[8] = {0.25f, 0.375f, 0.5f, 0.625f, 0.75f, 1.0f, 1.25f, 1.5f}; for (float v : t) cs.f16(v); }
+				const int ew = opt.geti("epfw", 0);
+				cs.put(ew ? 1 : 0, 1);
+				if (ew) { cs.f16(32.0f); cs.f16(6.0f); cs.f16(3.0f); cs.put(0, 32); }
+				const int es = opt.geti("epfs", 0);
+				cs.put(es ? 1 : 0, 1);
+				if (es) { cs.f16(0.5f); cs.f16(0.75f); cs.f16(5.0f); cs.f16(0.625f); }
+			}
+			cs.u64(0);                          // restoration extensions
+		}
 		cs.u64(0);                          // frame extensions
 	}
 	// TOC (j40.h:5505-5531)
