@@ -6,8 +6,8 @@ CXX ?= g++
 ARCH ?= gfx950
 CXXFLAGS = -std=c++17 -O2 -fPIC -Wall -Wextra -ffp-contract=off -fvisibility=hidden
 # EVENT_RING=8 (or 4): k_hf_lanes' coefficient events leave through per-lane rings in LDS as aligned 32- (16-) byte stores
-# (device/plan.h: J40_LANE_EV_FLUSH; default 0 = a 4-byte store per event). The CPU build of the device functions (libhostsim.so)
-# always carries the rings, so that tests/test_hostsim.py keeps that path exact.
+# (device/plan.h: J40_LANE_EV_FLUSH; default 0 = a 4-byte store per event). The CPU build of the device functions exists in both
+# forms: libhostsim.so with the product's setting, libhostsim_ring8.so with the rings (tests/test_hostsim.py runs through both).
 EVENT_RING ?= 0
 CXXFLAGS += -DJ40_LANE_EV_FLUSH=$(EVENT_RING)
 HIPFLAGS = --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -Wall -DJ40_LANE_EV_FLUSH=$(EVENT_RING) $(EXTRA_HIPFLAGS)
@@ -37,7 +37,7 @@ build/obj/lf_decode.o: EXTRA_HIPFLAGS += -mllvm -amdgpu-sched-strategy=max-ilp
 build/libj40hip.so: $(HOST_OBJS) $(DEV_OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^ -lpthread -lhsa-runtime64
 
-hostsim: build/libhostsim.so build/liboracle_driver.so build/api_threads
+hostsim: build/libhostsim.so build/libhostsim_ring8.so build/liboracle_driver.so build/api_threads
 # test-only glue: parses a stream with the product's host parser, takes the plan view and hands it to
 # the CPU oracle (oracle/libj40oracle.so)
 build/liboracle_driver.so: tests/oracle_driver.c build/libj40hip.so oracle/hotpath_oracle.c include/j40hip.h
@@ -49,9 +49,14 @@ build/api_threads: tests/api_threads.c include/j40.h build/libj40hip.so
 	gcc -O2 -Wall -Wextra -pthread -Iinclude -o $@ tests/api_threads.c -Lbuild -lj40hip -Wl,-rpath,'$$ORIGIN'
 
 # device functions compiled for the CPU, test infrastructure only (tests/hostsim)
-build/libhostsim.so: tests/hostsim/hostsim.cpp $(SRC)/plan_build.cpp $(SRC)/plan_front.cpp $(SRC)/entropy.cpp $(SRC)/modular.cpp $(SRC)/tables.cpp $(SRC)/frame.cpp $(wildcard $(SRC)/device/*.h) $(wildcard $(SRC)/*.hpp)
+HOSTSIM_SRC = tests/hostsim/hostsim.cpp $(SRC)/plan_build.cpp $(SRC)/plan_front.cpp $(SRC)/entropy.cpp $(SRC)/modular.cpp $(SRC)/tables.cpp $(SRC)/frame.cpp
+HOSTSIM_FLAGS = -std=c++17 -O2 -fPIC -shared -ffp-contract=off -Wall -Wextra -Wno-unused-function -Wno-unknown-pragmas
+build/libhostsim.so: $(HOSTSIM_SRC) $(wildcard $(SRC)/device/*.h) $(wildcard $(SRC)/*.hpp)
 	@mkdir -p build
-	$(CXX) -std=c++17 -O2 -fPIC -shared -ffp-contract=off -Wall -Wextra -Wno-unused-function -Wno-unknown-pragmas -DJ40_LANE_EV_FLUSH=8 -o $@ tests/hostsim/hostsim.cpp $(SRC)/plan_build.cpp $(SRC)/plan_front.cpp $(SRC)/entropy.cpp $(SRC)/modular.cpp $(SRC)/tables.cpp $(SRC)/frame.cpp -lpthread
+	$(CXX) $(HOSTSIM_FLAGS) -DJ40_LANE_EV_FLUSH=$(EVENT_RING) -o $@ $(HOSTSIM_SRC) -lpthread
+build/libhostsim_ring8.so: $(HOSTSIM_SRC) $(wildcard $(SRC)/device/*.h) $(wildcard $(SRC)/*.hpp)
+	@mkdir -p build
+	$(CXX) $(HOSTSIM_FLAGS) -DJ40_LANE_EV_FLUSH=8 -o $@ $(HOSTSIM_SRC) -lpthread
 
 build/jxlsynth: tools/jxlsynth.cpp $(wildcard tools/*.hpp) $(SRC)/tables.cpp $(SRC)/device/special8_dev.h $(SRC)/device/idct_dev.h
 	@mkdir -p build

@@ -13,11 +13,12 @@ beside it. The copy back is 4 B/px over PCIe (133 MB per 8K frame), which is wha
 left in HBM is reported as `device_output` (rounds 2 and 3 reported that as `value`), and the part round 1 reported -- frames
 parsed and uploaded ahead of time, kernels only -- as `device_resident`.
 
-The host part runs on the CPU time the container is given (cgroup cpu.max; 16 CPUs on the bench boxes although 256 are visible),
-which is what bounds `value` today; DESIGN.md section 5 has the breakdown.
+The host part runs on the CPU time the container is given (cgroup cpu.max; 16 CPUs on the bench boxes although 256 are visible): four
+worker threads at half a millisecond a frame. What bounds `value` is the PCIe link: 133 MB of RGBA per frame, copied back on the SDMA
+engine the library measured as the device's fastest (j40_amd/csrc/device/hostcopy.hip); DESIGN.md section 5 has the breakdown.
 
-Also on the line: `roofline` for the dominant kernel (the entropy launch) measured with HIP events on its launch stream inside
-the timed region; `latency_mode` (one frame alone); BASELINE.json's other configurations (`configs`); `cpu_baseline` = the
+Also on the line: `roofline` (the stage of a batch furthest below the HBM roofline -- the LfGroup launch, k_lf_rows -- with the four stages'
+own durations inside the timed region and alone, device-recorded); `latency_mode` (one frame alone); BASELINE.json's other configurations (`configs`); `cpu_baseline` = the
 unmodified reference on one host core, same stream; `parity_vs_reference` for a frame decoded inside the timed region.
 
 N > 1 (torch.distributed.run, one rank per GPU): frames are independent, every rank runs its own pipeline on its own frames with
@@ -44,13 +45,13 @@ def cpu_quota():
     try:
         q, p = open("/sys/fs/cgroup/cpu.max").read().split()
         if q != "max":
-            return max(1, int(int(q) / int(p)))
+            return max(1, -(-int(q) // int(p)))   # (rounded up, like j40hip_cpu_quota)
     except (OSError, ValueError):
         pass
     try:
         q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
         if q > 0:
-            return max(1, q // p)
+            return max(1, -(-q // p))
     except (OSError, ValueError):
         pass
     return os.cpu_count() or 1

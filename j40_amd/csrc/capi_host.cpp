@@ -51,6 +51,7 @@ j40hip_frame *j40hip_frame_parse_streamed(const void *buf, size_t size, int thre
 		h->threads = threads < 1 ? 1 : threads > 16 ? 16 : threads;
 	} catch (const DecodeError &e) { code = e.code; }
 	catch (const std::bad_alloc &) { code = E4("!mem"); }
+	catch (const std::exception &) { code = E4("!mem"); }   // (std::system_error from a worker thread that could not start: nothing may cross the C boundary)
 	h->frame.need_bytes = nullptr; h->frame.have_bytes = nullptr; h->frame.need_ctx = nullptr;   // (the source lives with the caller)
 	if (err) *err = code;
 	if (code) { delete h; return nullptr; }
@@ -522,13 +523,14 @@ extern "C" __attribute__((visibility("default"))) int j40hip_cpu_quota() {
 	int n = hw ? (int) hw : 4;
 	if (FILE *fp = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2
 		char q[64] = {0}; long long period = 0;
-		if (fscanf(fp, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) { const long long c = atoll(q) / period; if (c >= 1 && c < n) n = (int) c; }
+		// (rounded UP and at least 1: a quota of half a CPU is one thread's worth, not "no quota" -- which used to read as every visible CPU)
+		if (fscanf(fp, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0 && atoll(q) > 0) { const long long c = std::max<long long>(1, (atoll(q) + period - 1) / period); if (c < n) n = (int) c; }
 		fclose(fp);
 		return n;
 	}
 	long long quota = -1, period = 0;   // cgroup v1
 	if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fp, "%lld", &quota) != 1) quota = -1; fclose(fp); }
 	if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lld", &period) != 1) period = 0; fclose(fp); }
-	if (quota > 0 && period > 0) { const long long c = quota / period; if (c >= 1 && c < n) n = (int) c; }
+	if (quota > 0 && period > 0) { const long long c = std::max<long long>(1, (quota + period - 1) / period); if (c < n) n = (int) c; }
 	return n;
 }

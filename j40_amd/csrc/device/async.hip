@@ -674,6 +674,7 @@ struct j40hip_alf {
 	hipEvent_t done = nullptr;
 	hipEvent_t kev[2] = {nullptr, nullptr};   // recorded by the device at the lane decoder's start and end (hipExtLaunchKernelGGL)
 	int frames = 0, sections = 0, waves = 0;
+	int lanes_frames = 0;   // frames of the last launch that k_lf_lanes took (their tables exceed k_lf_rows' LDS, or J40HIP_LF_KERNEL=lanes)
 };
 
 j40hip_alf *j40hip_alf_create(int device) {
@@ -702,9 +703,16 @@ uint32_t j40hip_alf_launch(j40hip_alf *a, j40hip_aframe *const *frames, int n, h
 	std::vector<DevLfLaneSet> sets((size_t) n);
 	for (int i = 0; i < n; ++i) sets[(size_t) i] = frames[i]->lf_set;
 	std::vector<DevLfWave> waves;
-	uint32_t lds = lf_rows_enabled() ? pack_lf_row_waves(sets.data(), n, &waves) : 0u;
-	const bool rows = lds != 0;
+	// k_lf_rows for every frame whose tables fit a wavefront's LDS, k_lf_lanes for the others (alone: one outlier frame no longer
+	// sends the whole flight to the slower kernel); the wavefronts of both in one array, the rows' first
+	std::vector<int32_t> oversized;
+	uint32_t lds = lf_rows_enabled() ? pack_lf_row_waves(sets.data(), n, &waves, &oversized) : 0u;
+	const bool rows = lf_rows_enabled();
+	const size_t row_waves = rows ? waves.size() : 0;
+	uint32_t lds_lanes = 0;
 	if (!rows) lds = pack_lf_waves(sets.data(), n, &waves);
+	else if (!oversized.empty()) lds_lanes = pack_lf_waves(sets.data(), n, &waves, &oversized);
+	a->lanes_frames = rows ? (int) oversized.size() : n;
 	const size_t o_waves = (sizeof(DevLfLaneSet) * (size_t) n + 255) & ~(size_t) 255, bytes = o_waves + sizeof(DevLfWave) * waves.size() + 64;
 	if (!a->host.reserve(bytes, 0)) return ERR_MEM;
 	if (bytes > a->dev_cap) {
@@ -722,8 +730,12 @@ uint32_t j40hip_alf_launch(j40hip_alf *a, j40hip_aframe *const *frames, int n, h
 	a->frames = n; a->waves = (int) waves.size(); a->sections = 0;
 	for (const DevLfLaneSet &ls : sets) a->sections += ls.ntasks;
 	hipEvent_t k0 = a->kev[0] && a->kev[1] ? a->kev[0] : nullptr, k1 = k0 ? a->kev[1] : nullptr;
-	if (rows) launch_lf_rows((const DevLfLaneSet *) a->dev, (const DevLfWave *) ((const uint8_t *) a->dev + o_waves), (int32_t) waves.size(), lds + 64, s, k0, k1);
-	else launch_lf_lanes((const DevLfLaneSet *) a->dev, (const DevLfWave *) ((const uint8_t *) a->dev + o_waves), (int32_t) waves.size(), lds + 64, s, k0, k1);
+	const DevLfWave *dw = (const DevLfWave *) ((const uint8_t *) a->dev + o_waves);
+	if (rows) {
+		const bool both = row_waves > 0 && waves.size() > row_waves;
+		launch_lf_rows((const DevLfLaneSet *) a->dev, dw, (int32_t) row_waves, lds + 64, s, k0, both ? nullptr : k1);
+		launch_lf_lanes((const DevLfLaneSet *) a->dev, dw + row_waves, (int32_t) (waves.size() - row_waves), lds_lanes + 64, s, row_waves ? nullptr : k0, k1);
+	} else launch_lf_lanes((const DevLfLaneSet *) a->dev, dw, (int32_t) waves.size(), lds + 64, s, k0, k1);
 	const double tq3 = prof_now();
 	if (hipEventRecord(a->done, s) != hipSuccess || hipGetLastError() != hipSuccess) return ERR_GPU;
 	if (getenv("J40HIP_ASYNC_TIMING")) fprintf(stderr, "[j40hip lf launch] %d frames, %zu waves: pack %.2f, copy %.2f, launch %.2f, record %.2f ms\n", n, waves.size(), tq1 - tq0, tq2 - tq1, tq3 - tq2, prof_now() - tq3);

@@ -50,12 +50,12 @@ void launch_lf_groups(const DevLfTask *tasks, int32_t num_tasks, hipStream_t str
 // one LfGroup section per lane (lf_lanes_dev.h): pack_lf_waves deals the sections of the sets (host copies) to wavefronts and returns
 // the LDS a wavefront needs at most; launch_lf_lanes takes the device copies of both arrays
 #include <vector>
-uint32_t pack_lf_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std::vector<DevLfWave> *waves);
+uint32_t pack_lf_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std::vector<DevLfWave> *waves, const std::vector<int32_t> *only = nullptr);
 void launch_lf_lanes(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t num_waves, uint32_t lds_bytes, hipStream_t stream, hipEvent_t started = nullptr, hipEvent_t stopped = nullptr);
 // the same with tree, alias tables and row windows in LDS (lf_rows_dev.h, k_lf_rows): pack_lf_row_waves returns 0 when some frame's
-// tables do not fit a wavefront's LDS (the launch then takes k_lf_lanes); lf_rows_enabled: J40HIP_LF_KERNEL != "lanes"
+// tables do not fit a wavefront's LDS -- with `oversized`, those frames alone are listed for k_lf_lanes --; lf_rows_enabled: J40HIP_LF_KERNEL != "lanes"
 bool lf_rows_enabled();
-uint32_t pack_lf_row_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std::vector<DevLfWave> *waves);
+uint32_t pack_lf_row_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std::vector<DevLfWave> *waves, std::vector<int32_t> *oversized = nullptr);
 void launch_lf_rows(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t num_waves, uint32_t lds_bytes, hipStream_t stream, hipEvent_t started = nullptr, hipEvent_t stopped = nullptr);
 void launch_modular_quad(const DevModPlan &plan, int32_t first_section, int32_t num_sections, int32_t spec_idx, uint32_t table_span, int32_t max_width, hipStream_t stream);
 void launch_modular_coop(const DevModPlan &plan, int32_t first_section, int32_t num_sections, int32_t max_width, hipStream_t stream);

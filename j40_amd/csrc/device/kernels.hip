@@ -517,14 +517,22 @@ __device__ __forceinline__ void stage_event_prefix(uint32_t mine, uint32_t *pref
 // told about it, it orders every later LDS read of the same array behind the copy, i.e. behind the round trip): the waits are the
 // two above, by hand. M0 is not used by anything else in these kernels.
 #ifndef J40_K2_AHEAD
+// (global_load_lds_dword is a gfx9 instruction: the library is written for gfx950; built for anything else -- the Makefile's ARCH can be
+// overridden -- the prologue falls back to K2_PREFETCH_BLK)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx940__) && !defined(__gfx90a__)
+#define J40_K2_AHEAD 0
+#else
 #define J40_K2_AHEAD 1
+#endif
 #endif
 static_assert(sizeof(DevVarblock) == 40, "K2Ahead copies records as ten dwords");
 __device__ __forceinline__ void k2_copy_dword_to_lds(const uint32_t *src_of_lane, uint32_t lds_byte_address) {
-	asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(src_of_lane), "s"(lds_byte_address) : "memory");
+	asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(src_of_lane), "s"(lds_byte_address) : "memory", "m0");
 }
 __device__ __forceinline__ void k2_copies_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <int NB> struct K2Ahead {
+	// (wavefront 0 alone issues the copies and waits for them, and lanes 0 .. nb - 1 read the records back without a barrier: they have to be its lanes)
+	static_assert(NB <= 64, "K2Ahead: a tile's blocks must fit wavefront 0");
 	enum { REC_DW = 10, REC_SLOT = NB * REC_DW, BE_SLOT = NB * 4 };
 	uint32_t *rec, *be;   // LDS: [3][REC_SLOT], [2][BE_SLOT]
 	__device__ __forceinline__ static uint32_t lds_address(const uint32_t *p) { return (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) (uint32_t) (uintptr_t) p); }   // (the low half of a flat LDS address is the LDS offset)
@@ -1150,6 +1158,8 @@ static void launch_vardct_class_impl(const DevPlan &plan, int32_t dctsel, const 
 			if (bl.batch) {
 				if (reg64) hipLaunchKernelGGL((k_vardct_large<true, true>), dim3((unsigned) bl.grid), dim3(J40_LARGE_THREADS), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, bl.tile_prefix, bl.nframes, bl.class_a, bl.class_b);
 				else hipLaunchKernelGGL((k_vardct_large<true, false>), dim3((unsigned) bl.grid), dim3(J40_LARGE_THREADS), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, bl.tile_prefix, bl.nframes, bl.class_a, bl.class_b);
+			} else if (bl.xyb) {
+				hipLaunchKernelGGL((k_vardct_large<false, true, true>), dim3((unsigned) count), dim3(J40_LARGE_THREADS), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, nullptr, 1, 0, 0);
 			} else {
 				if (reg64) hipLaunchKernelGGL((k_vardct_large<false, true>), dim3((unsigned) count), dim3(J40_LARGE_THREADS), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, nullptr, 1, 0, 0);
 				else hipLaunchKernelGGL((k_vardct_large<false, false>), dim3((unsigned) count), dim3(J40_LARGE_THREADS), lds_bytes, stream, plan, list, count, large_scratch, rgba, stride, bl.batch, nullptr, 1, 0, 0);

@@ -243,14 +243,15 @@ bool lf_lanes_alias_in_lds() {
 }
 
 // packs the sections of `sets` into wavefronts (host side): fills `waves`, returns the LDS bytes a wavefront needs at most
-uint32_t pack_lf_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std::vector<DevLfWave> *waves) {
+uint32_t pack_lf_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std::vector<DevLfWave> *waves, const std::vector<int32_t> *only) {
 	// (J40HIP_LF_LDS_KB: the LDS a wavefront's frames may take together -- with the alias tables in LDS, 30 keeps it to one 8K frame per
 	// wavefront and two such workgroups beside a coefficient decoder's 99 KB on a compute unit)
 	static const uint32_t budget = [] { const char *e = getenv("J40HIP_LF_LDS_KB"); return (e && atoi(e) > 0 ? (uint32_t) atoi(e) : 56u) * 1024u; }();
 	uint32_t most = 0, used = 0; int32_t lanes = 0;
 	DevLfWave cur; memset(&cur, 0, sizeof cur);
 	auto flush = [&] { if (cur.num_parts) { waves->push_back(cur); most = std::max(most, used); } memset(&cur, 0, sizeof cur); used = 0; lanes = 0; };
-	for (int32_t i = 0; i < num_sets; ++i) {
+	for (int32_t k = 0; k < (only ? (int32_t) only->size() : num_sets); ++k) {
+		const int32_t i = only ? (*only)[(size_t) k] : k;   // (`only`: just these sets -- the ones k_lf_rows could not take)
 		const uint32_t need = ((sets_host[i].lds_bytes + 15u) & ~15u) + (lf_lanes_alias_in_lds() ? 8u * ((uint32_t) sets_host[i].num_clusters << sets_host[i].log_alpha) : 0u);
 		for (int32_t first = 0; first < sets_host[i].ntasks; ) {
 			if (lanes >= 64 || cur.num_parts >= LF_WAVE_PARTS || (cur.num_parts && used + need > budget)) flush();
@@ -268,7 +269,7 @@ void launch_lf_lanes(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t n
 	static bool configured = false;
 	if (!configured) { (void) hipFuncSetAttribute((const void *) k_lf_lanes<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); (void) hipFuncSetAttribute((const void *) k_lf_lanes<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); configured = true; }
 	if (lf_lanes_alias_in_lds()) hipLaunchKernelGGL(k_lf_lanes<true>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
-	else if (started && stopped) hipExtLaunchKernelGGL(k_lf_lanes<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, started, stopped, 0, sets, waves);
+	else if (started || stopped) hipExtLaunchKernelGGL(k_lf_lanes<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, started, stopped, 0, sets, waves);
 	else hipLaunchKernelGGL(k_lf_lanes<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
 }
 
@@ -282,10 +283,10 @@ static int lf_rows_mode() {
 bool lf_rows_enabled() { return lf_rows_mode() != 0; }
 
 // packs the sections of `sets` into wavefronts of k_lf_rows (64 lanes, one or two sections each); returns the LDS bytes a wavefront
-// needs at most, 0 when some frame's tables do not fit (the launch then goes to k_lf_lanes). J40HIP_LF_ROWS_LDS_KB: what a
+// needs at most; the sets whose tables do not fit are left out and listed in `oversized` (k_lf_lanes takes them; without the list: 0 and no wavefronts). J40HIP_LF_ROWS_LDS_KB: what a
 // wavefront's tables and windows may take together (default 48: two 8K frames of seven clusters x 256 buckets -- 2 x (14.5 KB + 12
 // windows) = 41 KB -- so that such a workgroup still fits beside the coefficient decoder's on a compute unit)
-uint32_t pack_lf_row_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std::vector<DevLfWave> *waves) {
+uint32_t pack_lf_row_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std::vector<DevLfWave> *waves, std::vector<int32_t> *oversized) {
 	static const uint32_t budget = [] { const char *e = getenv("J40HIP_LF_ROWS_LDS_KB"); return (e && atoi(e) > 0 ? (uint32_t) atoi(e) : 48u) * 1024u; }();
 	const uint32_t win_bytes = 2u * LF_ROW_PITCH;
 	const int32_t per = lf_rows_mode() == 2 ? 2 : 1;
@@ -294,7 +295,8 @@ uint32_t pack_lf_row_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std:
 	auto flush = [&] { if (cur.num_parts) { waves->push_back(cur); most = std::max(most, used); } memset(&cur, 0, sizeof cur); used = 0; lanes = 0; };
 	for (int32_t i = 0; i < num_sets; ++i) {
 		const uint32_t tables = lf_rows_table_bytes(sets_host[i].num_nodes, sets_host[i].num_clusters, sets_host[i].log_alpha);
-		if (tables + win_bytes > 60u * 1024u) { waves->clear(); return 0; }
+		// (a frame whose tree and alias tables exceed a wavefront's LDS goes to k_lf_lanes -- that frame alone, not the launch's other frames)
+		if (tables + win_bytes > 60u * 1024u) { if (oversized) { oversized->push_back(i); continue; } waves->clear(); return 0; }
 		for (int32_t first = 0; first < sets_host[i].ntasks; ) {
 			if (lanes >= 64 * per || cur.num_parts >= LF_WAVE_PARTS || (cur.num_parts && used + tables + win_bytes > budget)) flush();
 			// as many of the frame's sections as fit the budget (a wavefront's first frame may exceed it, up to the 60 KB a workgroup asks for at most)
@@ -314,7 +316,7 @@ void launch_lf_rows(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t nu
 	static bool configured = false;
 	if (!configured) { (void) hipFuncSetAttribute((const void *) k_lf_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); (void) hipFuncSetAttribute((const void *) k_lf_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); configured = true; }
 	const bool pairs = lf_rows_mode() == 2;
-	if (started && stopped) { if (pairs) hipExtLaunchKernelGGL(k_lf_rows<true>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, started, stopped, 0, sets, waves); else hipExtLaunchKernelGGL(k_lf_rows<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, started, stopped, 0, sets, waves); }
+	if (started || stopped) { if (pairs) hipExtLaunchKernelGGL(k_lf_rows<true>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, started, stopped, 0, sets, waves); else hipExtLaunchKernelGGL(k_lf_rows<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, started, stopped, 0, sets, waves); }
 	else if (pairs) hipLaunchKernelGGL(k_lf_rows<true>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
 	else hipLaunchKernelGGL(k_lf_rows<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
 }

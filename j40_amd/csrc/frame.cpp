@@ -808,7 +808,7 @@ static void parse_headers(const uint8_t *cs, size_t cs_size, Frame *f) {
 		try { parse_headers_within(cs, have, cs_size, f); return; }
 		catch (const DecodeError &e) {
 			if (e.code != (uint32_t) E4("shrt") || have >= cs_size) throw;
-			*f = [&] { Frame fresh; fresh.need_bytes = f->need_bytes; fresh.need_ctx = f->need_ctx; fresh.have_bytes = f->have_bytes; fresh.defer_lf_tail = f->defer_lf_tail; fresh.lf_decoder = f->lf_decoder; fresh.lf_decoder_ctx = f->lf_decoder_ctx; return fresh; }();
+			*f = f->with_same_inputs();
 			want = std::min(cs_size, std::max(have * 2, have + 4096));
 		}
 	}

@@ -157,6 +157,14 @@ struct Frame {
 	void (*need_bytes)(void *ctx, size_t upto) = nullptr; void *need_ctx = nullptr;
 	size_t (*have_bytes)(void *ctx) = nullptr;   // how many bytes are there now (with need_bytes)
 	void need(size_t upto) const { if (need_bytes) need_bytes(need_ctx, upto); }
+	// A fresh Frame with the fields a caller sets BEFORE parse_frame -- the ones declared above, from defer_lf_tail on -- and nothing
+	// else (the streaming header parse starts over with one when the prefix it had ran out). A field added to that set goes in here.
+	Frame with_same_inputs() const {
+		Frame g;
+		g.defer_lf_tail = defer_lf_tail; g.lf_decoder = lf_decoder; g.lf_decoder_ctx = lf_decoder_ctx;
+		g.need_bytes = need_bytes; g.need_ctx = need_ctx; g.have_bytes = have_bytes;
+		return g;
+	}
 	// Modular frames: LfGlobal's channel data is left to the device; it starts at this bit of the section
 	bool gm_data_pending = false;
 	size_t gm_data_bitpos = 0;  // single-section VarDCT frames: where the pass group starts

@@ -10,9 +10,12 @@ import pytest
 from streams import synth, VARDCT_CASES, MODULAR_CASES, ROOT
 
 
-@pytest.fixture(scope="module")
-def sim(built):
-    S = C.CDLL(os.path.join(ROOT, "build", "libhostsim.so"))
+# libhostsim.so: the device functions compiled with the product's setting of J40_LANE_EV_FLUSH (the coefficient events leave with one store
+# each); libhostsim_ring8.so: with the per-lane event rings (the build option EVENT_RING=8). The lane decoder's straight coefficient path
+# differs between the two, so every test here runs through both.
+@pytest.fixture(scope="module", params=["libhostsim.so", "libhostsim_ring8.so"], ids=["events_as_shipped", "event_rings_of_8"])
+def sim(built, request):
+    S = C.CDLL(os.path.join(ROOT, "build", request.param))
     S.hostsim_decode.restype = C.c_uint32
     S.hostsim_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
     return S

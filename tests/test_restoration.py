@@ -267,17 +267,25 @@ def test_restored_decode_of_streams(libs, ref, name, w, h, opts, mode):
 
 @pytest.mark.gpu
 def test_default_sharpness_table_is_rejected_like_the_routine_rejects_it(ref):
-    """epf with the DEFAULT sharpness table: j40__epf_recip_sigmas raises "epf0" (its first entry is 0, j40.h:5200, 7384); the decode then
-    leaves the picture unfiltered and reports the code behind the sections' own"""
+    """epf with the DEFAULT sharpness table: j40__epf_recip_sigmas raises "epf0" (its first entry is 0, j40.h:5200, 7384), and so does a
+    decode that was asked to run the filters -- behind the sections' own codes; without the filters the frame decodes like in j40"""
     import j40_amd
     data = synth("vardct", 264, 200, 9, fullheader=1, epf=2, epflut=0)
     f = j40_amd.Frame(data); f.upload(0); f.set_restoration(1)
-    err, rgba = f.decode_to_host()
+    err, _ = f.decode_to_host()
     assert err == "epf0"
     f.set_restoration(0)
     err, plain = f.decode_to_host()
-    assert err == "" and np.array_equal(rgba, plain)
+    rerr, expect = ref.decode(data)
+    assert err == rerr == "" and np.abs(plain.astype(np.int32) - expect.astype(np.int32)).max() <= 1
     f.close()
+    # a damaged section's code comes first
+    bad = bytearray(data); bad[len(bad) // 2] ^= 0x10
+    rerr, _ = ref.decode(bytes(bad))
+    if rerr:
+        g = j40_amd.Frame(bytes(bad)); g.upload(0); g.set_restoration(1)
+        assert g.decode_to_host()[0] == rerr
+        g.close()
 
 
 @pytest.mark.gpu
