@@ -666,6 +666,32 @@ def sections(args, torch, np, j40_amd, dev, local_rank, datas, quota):
     del routs, frames
     torch.cuda.empty_cache()
 
+    # ---- the restoration filters (Gaborish + two steps of the edge-preserving filter), opt-in; one 8K frame that signals them,
+    # decoded with and without them on the single-frame path: the filter kernels' own device time (HIP events around them), their
+    # algorithmic bytes -- 12 B/px read + 12 B/px written per pass over the three float planes, three passes -- against the HBM peak
+    try:
+        os.environ["J40HIP_RESTORATION_TIMING"] = "1"
+        dr = synth("vardct", W, H, args.seed, fullheader=1, gab=1, epf=2)
+        fr = j40_amd.Frame(dr, threads=min(8, quota)); fr.upload(local_rank)
+        o = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
+        plain = min(float(sum(fr.decode_timed(o.data_ptr(), W * 4, main.cuda_stream))) for _ in range(3))
+        fr.set_restoration(1)
+        with_f, filt = [], []
+        for _ in range(3):
+            with_f.append(float(sum(fr.decode_timed(o.data_ptr(), W * 4, main.cuda_stream)))); filt.append(fr.restoration_ms())
+        assert fr.status() == ""
+        passes = 3
+        alg_f = passes * 24 * W * H + 4 * ((W + 7) // 8) * ((H + 7) // 8) * 2
+        fms = min(filt)
+        out["restoration"] = {"stream": "%dx%d VarDCT, Gaborish + 2 steps of the edge-preserving filter signalled (tools/jxlsynth fullheader=1 gab=1 epf=2)" % (W, H),
+                              "frame_ms_filters_off": round(plain, 3), "frame_ms_filters_on": round(min(with_f), 3), "filter_kernels_ms": round(fms, 3),
+                              "roofline": {"bound": "hbm", "achieved": round(alg_f / (fms / 1e3) / 1e9, 3) if fms > 0 else None, "peak": 8000.0, "unit": "GB/s", "frac": round(alg_f / (fms / 1e3) / 8e12, 6) if fms > 0 else None,
+                                           "algorithmic_bytes": alg_f, "kernels": "k_epf_sigma, k_gaborish, k_epf<1>, k_epf<2> (restore_kernels.h)"},
+                              "note": "off by default (j40 ignores the frame header's RestorationFilter bundle); J40HIP_RESTORATION=1 or j40hip_frame_set_restoration; parity: tests/test_restoration.py (the HIP kernels against the reference's own j40__gaborish / j40__epf, bit for bit)"}
+        fr.close(); del o
+    except Exception as e:   # (a measurement beside the contract's: never the reason the line is missing)
+        out["restoration"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
     # ---- BASELINE.json's other configurations ----
     cfg = {}
     # config 2: ONE 3840x2160 frame, a distance-1 encode of a procedural picture like the 8K bench stream (forward=1). Device time of

@@ -280,12 +280,18 @@ def test_default_sharpness_table_is_rejected_like_the_routine_rejects_it(ref):
     assert err == rerr == "" and np.abs(plain.astype(np.int32) - expect.astype(np.int32)).max() <= 1
     f.close()
     # a damaged section's code comes first
-    bad = bytearray(data); bad[len(bad) // 2] ^= 0x10
-    rerr, _ = ref.decode(bytes(bad))
-    if rerr:
-        g = j40_amd.Frame(bytes(bad)); g.upload(0); g.set_restoration(1)
-        assert g.decode_to_host()[0] == rerr
-        g.close()
+    for at in (len(data) * 3 // 4, len(data) * 7 // 8, len(data) - 40):
+        bad = bytearray(data); bad[at] ^= 0x10
+        rerr, _ = ref.decode(bytes(bad))
+        if not rerr:
+            continue
+        try:
+            g = j40_amd.Frame(bytes(bad)); g.upload(0); g.set_restoration(1)
+            code = g.decode_to_host()[0]
+            g.close()
+        except j40_amd.J40Error as e:
+            code = e.code
+        assert code == rerr, at
 
 
 @pytest.mark.gpu
