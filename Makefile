@@ -13,7 +13,7 @@ CXXFLAGS += -DJ40_LANE_EV_FLUSH=$(EVENT_RING)
 HIPFLAGS = --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -Wall -DJ40_LANE_EV_FLUSH=$(EVENT_RING) $(EXTRA_HIPFLAGS)
 SRC = j40_amd/csrc
 HOST_OBJS = build/obj/plan_build.o build/obj/plan_front.o build/obj/entropy.o build/obj/modular.o build/obj/tables.o build/obj/frame.o build/obj/capi_host.o build/obj/api.o
-DEV_OBJS = build/obj/kernels.o build/obj/modular_kernels.o build/obj/runtime.o build/obj/pipeline.o build/obj/lf_tail_kernels.o build/obj/modular_coop.o build/obj/modular_quad.o build/obj/lf_decode.o build/obj/plan_kernels.o build/obj/async.o build/obj/hostcopy.o
+DEV_OBJS = build/obj/kernels.o build/obj/modular_kernels.o build/obj/runtime.o build/obj/pipeline.o build/obj/lf_tail_kernels.o build/obj/modular_coop.o build/obj/modular_quad.o build/obj/modular_split.o build/obj/lf_decode.o build/obj/plan_kernels.o build/obj/async.o build/obj/hostcopy.o
 
 .PHONY: all lib tools oracle hostsim clean
 all: lib tools hostsim oracle

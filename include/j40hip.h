@@ -65,6 +65,9 @@ J40HIP_API int64_t j40hip_frame_section_sizes(const j40hip_frame *f, int64_t *ou
 /* Modular frames: sections decoded by the wave-cooperative form of the section kernel (diagnostic; -1 when the frame has no Modular plan) */
 J40HIP_API int32_t j40hip_frame_coop_sections(j40hip_frame *f, int32_t *total);
 J40HIP_API int32_t j40hip_frame_quad_sections(j40hip_frame *f);   /* ... of those, decoded four to a wavefront */
+/* sections whose MA tree looks only at a sample's position (properties 0-3, no weighted predictor -- what fast lossless encoders write): decoded
+ * in two passes, the stream's tokens first, the prediction behind them (modular_split.hip); J40HIP_NO_SPLIT=1 leaves them to the one-pass kernels */
+J40HIP_API int32_t j40hip_frame_split_sections(j40hip_frame *f);
 
 /* stage accessors for parity tests (mirror j40__lf_group_st, j40.h:6360-6390) */
 J40HIP_API void j40hip_frame_lf_group_info(const j40hip_frame *f, int64_t gg, int32_t *out9);

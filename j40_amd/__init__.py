@@ -94,7 +94,7 @@ def lib():
         "j40hip_batch_create": (vp, [vp, i64, C.POINTER(u32)]), "j40hip_batch_free": (None, [vp]),
         "j40hip_batch_decode": (u32, [vp, vp, vp, vp]), "j40hip_batch_decode_timed": (u32, [vp, vp, vp, vp, vp]),
         "j40hip_batch_decode_recorded": (u32, [vp, vp, vp, vp, i32]), "j40hip_batch_elapsed": (u32, [vp, i32, vp]), "j40hip_batch_wait_stage": (u32, [vp, i32, i32, vp]),
-        "j40hip_batch_reset": (u32, [vp, vp, i64]), "j40hip_frame_section_sizes": (i64, [vp, vp]), "j40hip_frame_coop_sections": (i32, [vp, vp]), "j40hip_frame_quad_sections": (i32, [vp]), "j40hip_frame_lf_bundle": (sz, [vp, vp, sz, vp]), "j40hip_frame_parse_on": (vp, [vp, sz, C.c_int, u32, C.c_int, vp, vp]), "j40hip_frame_lf_on_device": (C.c_int, [vp]), "j40hip_frame_from_lf_bundle": (vp, [vp, sz, vp]),
+        "j40hip_batch_reset": (u32, [vp, vp, i64]), "j40hip_frame_section_sizes": (i64, [vp, vp]), "j40hip_frame_coop_sections": (i32, [vp, vp]), "j40hip_frame_quad_sections": (i32, [vp]), "j40hip_frame_split_sections": (i32, [vp]), "j40hip_frame_lf_bundle": (sz, [vp, vp, sz, vp]), "j40hip_frame_parse_on": (vp, [vp, sz, C.c_int, u32, C.c_int, vp, vp]), "j40hip_frame_lf_on_device": (C.c_int, [vp]), "j40hip_frame_from_lf_bundle": (vp, [vp, sz, vp]),
         "j40hip_frame_upload_on": (u32, [vp, C.c_int, vp]), "j40hip_thread_release": (None, []), "j40hip_shutdown": (None, []),
         "j40hip_frame_status_begin": (u32, [vp, vp]), "j40hip_frame_status_end": (u32, [vp]), "j40hip_frame_mark_idle": (None, [vp]),
         "j40hip_frame_after_frame_status": (u32, [vp]),
@@ -384,6 +384,10 @@ class Frame:
 
     def quad_sections(self):
         return int(lib().j40hip_frame_quad_sections(self.h))
+
+    def split_sections(self):
+        """sections the two-pass Modular decoder takes (position-only MA trees; modular_split.hip)"""
+        return int(lib().j40hip_frame_split_sections(self.h))
 
     def section_sizes(self):
         """bytes of every pass-group section (pass-major), from the TOC"""

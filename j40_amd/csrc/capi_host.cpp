@@ -449,6 +449,15 @@ int32_t j40hip_frame_quad_sections(j40hip_frame *h) {
 	} catch (const std::exception &) { return -1; }
 }
 
+// ... and how many sections the two-pass decoder takes (modular_split.hip: position-only MA trees); -1: no plan
+int32_t j40hip_frame_split_sections(j40hip_frame *h) {
+	try {
+		HostModPlan hp;
+		if (build_modular_plan(h->frame, h->cs, h->cs_size, &hp)) return -1;
+		return hp.split_sections;
+	} catch (const std::exception &) { return -1; }
+}
+
 uint32_t j40hip_frame_modular_view(j40hip_frame *h, j40hip_modular_view *v) {
 	HostModPlan hp;
 	if (uint32_t e = build_modular_plan(h->frame, h->cs, h->cs_size, &hp)) return e;

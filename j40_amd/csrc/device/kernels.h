@@ -58,6 +58,7 @@ bool lf_rows_enabled();
 uint32_t pack_lf_row_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std::vector<DevLfWave> *waves, std::vector<int32_t> *oversized = nullptr);
 void launch_lf_rows(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t num_waves, uint32_t lds_bytes, hipStream_t stream, hipEvent_t started = nullptr, hipEvent_t stopped = nullptr);
 void launch_modular_quad(const DevModPlan &plan, int32_t first_section, int32_t num_sections, int32_t spec_idx, uint32_t table_span, int32_t max_width, hipStream_t stream);
+void launch_modular_split(const DevModPlan &plan, int32_t first_section, int32_t num_sections, const ModLaunchInfo &info, hipStream_t stream);
 void launch_modular_coop(const DevModPlan &plan, int32_t first_section, int32_t num_sections, int32_t max_width, hipStream_t stream);
 void launch_section_inverse_rcts(const DevModPlan &plan, int32_t first_section, int32_t num_sections, hipStream_t stream);
 void launch_paste_plane(const int16_t *src, int32_t w, int32_t h, int16_t *dst, int32_t dst_stride, hipStream_t stream);

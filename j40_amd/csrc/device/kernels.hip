@@ -527,7 +527,7 @@ __device__ __forceinline__ void stage_event_prefix(uint32_t mine, uint32_t *pref
 #endif
 static_assert(sizeof(DevVarblock) == 40, "K2Ahead copies records as ten dwords");
 __device__ __forceinline__ void k2_copy_dword_to_lds(const uint32_t *src_of_lane, uint32_t lds_byte_address) {
-	asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(src_of_lane), "s"(lds_byte_address) : "memory", "m0");
+	asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(src_of_lane), "s"(lds_byte_address) : "memory");   // (m0 cannot be named as clobbered: it is reserved to the compiler, which sets it itself only for movrel / GWS / LDS-direct -- none of which these kernels use)
 }
 __device__ __forceinline__ void k2_copies_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <int NB> struct K2Ahead {

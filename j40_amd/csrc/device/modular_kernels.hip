@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(64) k_modular_sections(DevModPlan plan, int32_
 	const int32_t lane = threadIdx.x;
 	const int32_t s = first_section + (int32_t) blockIdx.x;
 	const DevModSection &msec = plan.sections[s];
-	if (msec.coop_idx >= 0) return;   // k_modular_coop's
+	if (msec.coop_idx >= 0 || msec.split) return;   // k_modular_coop's, modular_split.hip's
 	if (msec.preset_status) { if (lane == 0) plan.status[s] = msec.preset_status; return; }
 	const DevCodeSpec &spec = plan.spec[msec.spec_idx];
 	ModTables t = mod_tables_in_hbm(plan, s);
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(64) k_modular_sections_lanes(DevModPlan plan, 
 	const int32_t s = first_section + (int32_t) (blockIdx.x * 64 + threadIdx.x);
 	if (s >= first_section + num_sections) return;
 	const DevModSection &msec = plan.sections[s];
-	if (msec.coop_idx >= 0) return;
+	if (msec.coop_idx >= 0 || msec.split) return;
 	if (msec.preset_status) { plan.status[s] = msec.preset_status; return; }
 	const ModTables t = mod_tables_in_hbm(plan, s);
 	plan.status[s] = decode_modular_section<false, false>(plan, t, s);
@@ -244,6 +244,7 @@ void launch_modular_sections(const DevModPlan &plan, int32_t first_section, int3
 	// the sections the wave-cooperative kernel takes (modular_coop.hip), then the others
 	if (info.quad_sections > 0) launch_modular_quad(plan, first_section, num_sections, info.quad_spec, info.quad_table_span, info.quad_width, stream);
 	if (info.coop_width > 0 && info.quad_sections < info.coop_sections) launch_modular_coop(plan, first_section, num_sections, info.coop_width, stream);
+	if (info.split_sections > 0) launch_modular_split(plan, first_section, num_sections, info, stream);   // (sections with a position-only tree: modular_split.hip)
 	if (info.all_coop) return;
 	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
 	const uint32_t wp_bytes = info.uses_wp ? align16(40u * (uint32_t) info.max_width) : 0;

@@ -220,6 +220,11 @@ struct DevModSection {
 	// != 0 (only with coop_idx >= 0): four such sections share a wavefront of k_modular_quad (modular_quad.hip); frames with
 	// thousands of sections
 	int32_t quad;
+	// != 0: the section's MA tree looks only at where a sample is (properties 0-3, no weighted predictor): decoded in two passes by
+	// modular_split.hip -- its residual tokens at DevModPlan::residuals + res_off (res_count of them, stream order). 2: the tree tests
+	// the column (property 3), so the leaf is looked up per sample, not per row
+	int32_t split;
+	uint32_t res_off, res_count;
 };
 
 // An MA tree laid out for a wavefront that decodes ONE section with all 64 lanes (k_modular_coop): lane i holds branch node i
@@ -279,6 +284,8 @@ struct DevModPlan {
 	int32_t *wp_scratch;              // [num_sections][2 * max_width * 5] weighted-predictor error rows
 	int32_t *lz_window; uint32_t lz_window_size;
 	uint32_t *status;                 // [num_sections]
+	int32_t *residuals;               // the split sections' residual tokens (DevModSection::res_off); also their LZ77 windows
+	uint32_t *split_state;            // [num_sections][3]: the token pass's code and ordinal, the prediction pass's first overflowing ordinal
 };
 
 // one frame of a batch-wide launch of the pixel kernels (blockIdx.y): what the single-frame launch passes as kernel arguments
@@ -429,6 +436,8 @@ struct ModLaunchInfo {
 	int32_t quad_sections, quad_spec, quad_width;
 	int32_t coop_sections;   // sections with coop_idx >= 0 (quad ones included)
 	uint32_t quad_table_span; // alias entries of quad_spec
+	// modular_split.hip: sections flagged `split` (0: none), their widest channel, the most channels one of them codes
+	int32_t split_sections, split_width, split_channels;
 };
 
 enum {

@@ -312,7 +312,7 @@ struct j40hip_device_state {
 	bool has_trailers = false;           // VarDCT frame whose sections go on with the extra channels' Modular sub-image
 	bool idle = false;                   // j40hip_frame_mark_idle: nothing is pending on this frame's memory, freeing it needs no device-wide wait
 	bool trailers_pending = false;       // ... decoded by a batch since: j40hip_frame_status validates the sub-images before it reports
-	ModLaunchInfo mod_info = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	ModLaunchInfo mod_info = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 	std::vector<uint32_t> mod_section_offsets;
 	// group: the group whose section's sub-image the op belongs to (mod_sub_ops; a ranged decode skips the ops of groups it did not decode), -1: the frame's
 	struct ModOp { int kind; int16_t *a, *b, *c; const int16_t *src, *aux; size_t n; int32_t p0, p1, p2, p3, p4, p5; int16_t *const *dst_list; const int8_t *wpp; int32_t group; };
@@ -390,7 +390,7 @@ static uint32_t upload_modular(j40hip_frame *h, int device) {
 	st->mod_local_rcts = !hp.local_rct.empty();
 	if (st->mod_local_rcts) plan.local_rct = st->upload(hp.local_rct.data(), hp.local_rct.size(), s, ok);
 	st->mod_sections = (int32_t) hp.sections.size(); st->mod_passes = hp.num_passes; st->mod_sections_per_pass = hp.sections_per_pass;
-	st->mod_info = {hp.max_tree_nodes, hp.max_num_dist, hp.max_clusters, hp.max_table_bytes, hp.frame.max_width, hp.any_wp ? 1 : 0, hp.coop_width, hp.coop_sections == (int32_t) hp.sections.size(), hp.quad_sections, hp.quad_spec, hp.quad_width, hp.coop_sections, hp.quad_sections ? hp.specs[(size_t) hp.quad_spec].table_span : 0u};
+	st->mod_info = {hp.max_tree_nodes, hp.max_num_dist, hp.max_clusters, hp.max_table_bytes, hp.frame.max_width, hp.any_wp ? 1 : 0, hp.coop_width, hp.coop_sections + hp.split_sections == (int32_t) hp.sections.size(), hp.quad_sections, hp.quad_spec, hp.quad_width, hp.coop_sections, hp.quad_sections ? hp.specs[(size_t) hp.quad_spec].table_span : 0u, hp.split_sections, hp.split_width, hp.split_channels};
 	for (const DevModSection &sec : hp.sections) st->mod_section_offsets.push_back(sec.byte_off);
 	const int32_t nch = hp.frame.num_channels;
 	struct Ref { int16_t *p; int32_t w, h; };
@@ -416,6 +416,8 @@ static uint32_t upload_modular(j40hip_frame *h, int device) {
 	plan.lz_window_size = hp.lz_window_size;
 	if (hp.lz_window_size) plan.lz_window = st->scratch<int32_t>((size_t) hp.sections.size() * hp.lz_window_size, ok);
 	plan.status = st->scratch<uint32_t>(hp.sections.size() + 1, ok);
+	// sections decoded in two passes (modular_split.hip): their residual tokens -- also their LZ77 windows -- and the passes' notes
+	if (hp.split_sections) { plan.residuals = st->scratch<int32_t>(hp.split_samples + 64, ok); plan.split_state = st->scratch<uint32_t>(3 * hp.sections.size() + 4, ok); }
 	st->mod_extra_status = const_cast<uint32_t *>(plan.status) + hp.sections.size();
 	st->total_sections = (int32_t) hp.sections.size();
 
@@ -955,8 +957,9 @@ static uint32_t validate_trailers(j40hip_frame *h, hipStream_t s) {
 		plan.lz_window_size = hp.lz_window_size;
 		if (hp.lz_window_size) plan.lz_window = tmp.scratch<int32_t>(hp.sections.size() * hp.lz_window_size, ok);
 		plan.status = tmp.scratch<uint32_t>(hp.sections.size() + 1, ok);
+		if (hp.split_sections) { plan.residuals = tmp.scratch<int32_t>(hp.split_samples + 64, ok); plan.split_state = tmp.scratch<uint32_t>(3 * hp.sections.size() + 4, ok); }
 		if (ok) {
-			const ModLaunchInfo info = {hp.max_tree_nodes, hp.max_num_dist, hp.max_clusters, hp.max_table_bytes, hp.frame.max_width, hp.any_wp ? 1 : 0, hp.coop_width, hp.coop_sections == (int32_t) hp.sections.size(), hp.quad_sections, hp.quad_spec, hp.quad_width, hp.coop_sections, hp.quad_sections ? hp.specs[(size_t) hp.quad_spec].table_span : 0u};
+			const ModLaunchInfo info = {hp.max_tree_nodes, hp.max_num_dist, hp.max_clusters, hp.max_table_bytes, hp.frame.max_width, hp.any_wp ? 1 : 0, hp.coop_width, hp.coop_sections + hp.split_sections == (int32_t) hp.sections.size(), hp.quad_sections, hp.quad_spec, hp.quad_width, hp.coop_sections, hp.quad_sections ? hp.specs[(size_t) hp.quad_spec].table_span : 0u, hp.split_sections, hp.split_width, hp.split_channels};
 			launch_modular_sections(plan, 0, (int32_t) hp.sections.size(), info, s);
 			ok = hipMemcpyAsync(found.data(), plan.status, sizeof(uint32_t) * found.size(), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
 		}

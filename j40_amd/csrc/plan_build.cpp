@@ -487,6 +487,84 @@ static void assign_coop(HostModPlan *hp) {
 	}
 }
 
+// after assign_split took sections away from k_modular_coop / k_modular_quad: their counts and widths again
+static void recount_coop(HostModPlan *hp);
+// Which sections modular_split.hip decodes in two passes (token parse, then prediction): those whose MA tree looks only at where a
+// sample is -- properties 0-3 -- and predicts without the weighted predictor; fast lossless encoders write nothing else (one gradient
+// leaf per channel). They leave k_modular_coop's list. J40HIP_NO_SPLIT=1: none (the one-pass kernels, for comparison).
+static void assign_split(HostModPlan *hp) {
+	static const bool off = [] { const char *e = getenv("J40HIP_NO_SPLIT"); return e && atoi(e); }();
+	hp->split_sections = 0; hp->split_width = 0; hp->split_channels = 0; hp->split_samples = 0;
+	std::vector<std::pair<uint64_t, int32_t>> known;   // (tree_off, tree_nodes) -> 0 no, 1 yes, 2 yes and it tests the column
+	auto tree_kind = [&](uint32_t tree_off, int32_t tree_nodes, int32_t spec_idx) {
+		if (tree_nodes <= 0) return 0;
+		const DevCodeSpec &sp = hp->specs[(size_t) spec_idx];
+		int32_t kind = 1;
+		// every node reachable from the root: a branch on properties 0-3 with both children inside the tree, or a leaf with a predictor
+		// the prediction pass has (0-13 but the weighted one) and a context the code spec knows
+		std::vector<int32_t> stack{0}; std::vector<uint8_t> seen((size_t) tree_nodes, 0);
+		while (!stack.empty()) {
+			const int32_t at = stack.back(); stack.pop_back();
+			if (at < 0 || at >= tree_nodes) return 0;
+			if (seen[(size_t) at]) return 0;   // (not a tree)
+			seen[(size_t) at] = 1;
+			const DevTreeNode &n = hp->tree[(size_t) tree_off + (size_t) at];
+			if (n.prop >= 0) {
+				if (n.prop > 3) return 0;
+				if (n.prop == 3) kind = 2;
+				stack.push_back(at + n.a); stack.push_back(at + n.b);
+			} else {
+				const int32_t predictor = -1 - n.prop;
+				if (predictor == 6 || predictor > 13) return 0;
+				if (n.value < 0 || n.value >= sp.num_dist) return 0;
+			}
+		}
+		return kind;
+	};
+	for (DevModSection &s : hp->sections) {
+		s.split = 0; s.res_off = 0; s.res_count = 0;
+		if (off || s.uses_wp) continue;
+		int32_t widest = 0; size_t samples = 0;
+		for (int32_t c = 0; c < s.num_channels; ++c) {
+			int32_t w, h;
+			if (s.sub_off >= 0) { w = hp->sub_w[(size_t) (s.sub_off + c)]; h = hp->sub_h[(size_t) (s.sub_off + c)]; }
+			else if (s.chan_off >= 0) { w = hp->chan_rects[(size_t) (s.chan_off + c)].w; h = hp->chan_rects[(size_t) (s.chan_off + c)].h; }
+			else if (hp->plane_meta[(size_t) (s.first_channel + c)]) { w = hp->plane_w[(size_t) (s.first_channel + c)]; h = hp->plane_h[(size_t) (s.first_channel + c)]; }
+			else { w = s.gw; h = s.gh; }
+			widest = std::max(widest, w);
+			if (w > 0 && h > 0) samples += (size_t) w * (size_t) h;
+		}
+		if (widest > 8192 || samples == 0 || hp->split_samples + samples >= ((size_t) 1 << 32) - 64) continue;
+		int32_t kind = -1;
+		const uint64_t key = (uint64_t) s.tree_off << 32 | (uint32_t) s.spec_idx;
+		for (const auto &k : known) if (k.first == key) { kind = k.second; break; }
+		if (kind < 0) { kind = s.preset_status ? 0 : tree_kind(s.tree_off, s.tree_nodes, s.spec_idx); if (!s.preset_status) known.push_back({key, kind}); }
+		if (!kind) continue;
+		s.split = kind; s.coop_idx = -1; s.quad = 0;
+		s.res_off = (uint32_t) hp->split_samples; s.res_count = (uint32_t) samples;
+		hp->split_samples += (samples + 63) & ~(size_t) 63;
+		++hp->split_sections; hp->split_width = std::max(hp->split_width, widest); hp->split_channels = std::max(hp->split_channels, s.num_channels);
+	}
+}
+
+static void recount_coop(HostModPlan *hp) {
+	if (!hp->split_sections) return;
+	hp->coop_sections = 0; hp->quad_sections = 0; hp->coop_width = 0; hp->quad_width = 0;
+	for (const DevModSection &s : hp->sections) {
+		if (s.coop_idx < 0) continue;
+		int32_t widest = 0;
+		for (int32_t c = 0; c < s.num_channels; ++c) {
+			int32_t w;
+			if (s.sub_off >= 0) w = hp->sub_w[(size_t) (s.sub_off + c)];
+			else if (s.chan_off >= 0) w = hp->chan_rects[(size_t) (s.chan_off + c)].w;
+			else w = hp->plane_meta[(size_t) (s.first_channel + c)] ? hp->plane_w[(size_t) (s.first_channel + c)] : s.gw;
+			widest = std::max(widest, w);
+		}
+		++hp->coop_sections; hp->coop_width = std::max(hp->coop_width, widest);
+		if (s.quad) { ++hp->quad_sections; hp->quad_width = std::max(hp->quad_width, widest); }
+	}
+}
+
 uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostModPlan *hp) {
 	if (!fr.fh.is_modular) return ERR_TODO;
 	if (cs_size + 16 >= ((size_t) 1 << 29)) return ERR_TODO;   // the kernels address the codestream with 32-bit BIT positions
@@ -687,6 +765,8 @@ uint32_t build_modular_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 	hp->codestream.assign(cs, cs + cs_size);
 	hp->codestream.resize(cs_size + 32, 0);   // the lane decoders read up to three words past the position they stop at
 	assign_coop(hp);
+	assign_split(hp);
+	recount_coop(hp);
 	return 0;
 }
 
@@ -746,6 +826,8 @@ uint32_t build_trailer_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, 
 		hp->lz_window_size = (uint32_t) std::min<size_t>(most + 16, (size_t) 1 << 26);
 	}
 	assign_coop(hp);
+	assign_split(hp);
+	recount_coop(hp);
 	return 0;
 }
 

@@ -91,6 +91,9 @@ struct HostModPlan {
 	std::vector<DevCoopTree> coop_trees;                  // DevModSection::coop_idx
 	int32_t coop_width = 0, coop_sections = 0;            // widest channel / number of the sections k_modular_coop takes
 	int32_t quad_sections = 0, quad_spec = 0, quad_width = 0;   // ... of those, the ones k_modular_quad takes four to a wavefront
+	// sections decoded in two passes by modular_split.hip (position-only MA tree): how many, their residual tokens in all, their widest
+	// channel, the most channels one of them codes
+	int32_t split_sections = 0, split_width = 0, split_channels = 0; size_t split_samples = 0;
 	std::vector<Transform> transforms;                    // global transforms in coded order
 	int32_t alpha_channel = -1;                           // index (after inverse transforms) of the first alpha extra channel
 	uint32_t lz_window_size = 0;
