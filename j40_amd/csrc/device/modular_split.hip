@@ -18,6 +18,11 @@
 namespace j40hip {
 
 
+enum { SPLIT_CHUNK_WORDS = 1024 };   // the token pass's window on the codestream in LDS (k_modular_tokens, the 64-at-a-time mode)
+// J40HIP_SPLIT_NO_FAST=1: every symbol through the scalar decoder (the sixty-four-at-a-time mode off, for comparison)
+__device__ bool g_split_no_fast = false;
+__device__ __forceinline__ bool split_no_fast() { return g_split_no_fast; }
+
 template <bool IN_LDS>
 __global__ void __launch_bounds__(64) k_modular_tokens(DevModPlan plan, int32_t first_section) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t split_lds[];
@@ -48,34 +53,48 @@ __global__ void __launch_bounds__(64) k_modular_tokens(DevModPlan plan, int32_t 
 		__syncthreads();
 	}
 	const DevModFrame f = *plan.frame;
-	DevBits b;
-	bits_init<true>(b, plan.codestream, sec.byte_off, sec.size, sec.bit_off);
+	const uint32_t start_bit = 8u * sec.byte_off + sec.bit_off, end_bit = 8u * (sec.byte_off + sec.size);
+	UBits b;
+	ub_init<true>(b, (const J40_GLOBAL uint8_t *) plan.codestream, start_bit);
 	DevCode code;
 	code_init(code, spec, t.clusters, t.cluster_map, t.alias, t.prefix, nullptr);
+	const bool prefix = code.use_prefix_code != 0;
+	uint32_t state = 0, err = 0;
 	int32_t dist_mult = 0;   // LZ77 distance multiplier: widest non-meta channel of this sub-image (j40.h:3841-3844; decode_modular_section)
 	if (sec.dist_mult_p1) dist_mult = sec.dist_mult_p1 - 1;
 	else for (int32_t cidx = 0; cidx < sec.num_channels; ++cidx) { const ModChan c = mod_channel(plan, sec, cidx); if (!c.meta) dist_mult = mod_max(dist_mult, c.gw); }
 	dist_mult = mod_min(dist_mult, 1 << 21);
 	int32_t *out = plan.residuals + sec.res_off;
 	// n: values written (= the reference's num_decoded); `pend`: the last n - flushed of them, one per lane, not yet in memory
-	uint32_t n = 0, flushed = 0, err_at = 0xffffffffu;
+	uint32_t n = 0, flushed = 0;
 	int32_t pend = 0;
 	auto flush = [&]() {   // (wave-uniform: everybody calls it together)
 		const uint32_t k = n - flushed;
 		if ((uint32_t) lane < k) out[flushed + (uint32_t) lane] = pend;
 		flushed = n;
 	};
+	auto next_token = [&](const ClusterRegs &cl) { return prefix ? split_prefix_token<true>(b, code.prefix, cl, end_bit, &err) : split_ans_token<true>(b, state, code.alias, code.log_bucket, cl, end_bit, &err); };
 	// an LZ77 run in progress: `run_left` values still to copy, value j of the run comes from out[run_base + (run_done + j) % run_dist]
 	uint32_t run_left = 0, run_base = 0, run_dist = 0, run_done = 0;
 	const bool uses_x = sec.split == 2;
-	for (int32_t cidx = 0; cidx < sec.num_channels && !b.err; ++cidx) {
+	// Prefix codes, the leaf fixed along a row: SIXTY-FOUR symbols are decoded at once, lane i the one that would start at bit P + i --
+	// token, extra bits, value, length, all of it a function of the 33 bits at that position and of the row's cluster -- and the stream's
+	// real symbols are then picked out by walking the lengths (two cross-lane reads and an add per symbol instead of a hundred scalar
+	// instructions). A lane whose symbol is none of the plain kind (an LZ77 token, a code beyond the first table, an error, more than 32
+	// bits in all) says length 255, and the walk hands that one symbol to the scalar decoder below. P: the next unread bit in this mode.
+	const bool fast = prefix && !uses_x && !split_no_fast();
+	uint32_t P = start_bit, chunk_bit0 = 0xffffffffu;
+	__shared__ uint32_t chunk[SPLIT_CHUNK_WORDS + 8];
+	const J40_GLOBAL uint32_t *words = (const J40_GLOBAL uint32_t *) plan.codestream;
+	for (int32_t cidx = 0; cidx < sec.num_channels && !err; ++cidx) {
 		const ModChan chan = mod_channel(plan, sec, cidx);
 		const int32_t gw = chan.gw, gh = chan.gh;
 		if (gw <= 0 || gh <= 0) continue;
-		for (int32_t y = 0; y < gh && !b.err; ++y) {
+		for (int32_t y = 0; y < gh && !err; ++y) {
 			SplitLeaf leaf = split_leaf<true>(t.tree, cidx, sec.sidx, y, 0);
 			ClusterRegs cl = load_cluster<true>(code, leaf.ctx);
-			for (int32_t x = 0; x < gw && !b.err; ) {
+			const int32_t split_exp = (int32_t) (cl.cfg & 15), hsplit = 1 << split_exp, msb = (int32_t) ((cl.cfg >> 4) & 15), lsb = (int32_t) ((cl.cfg >> 8) & 15), in_token = msb + lsb;
+			for (int32_t x = 0; x < gw; ) {
 				if (run_left) {
 					// the rest of the run that fits this row: the sources lie before the run's start, all of them in memory (flushed there)
 					const uint32_t k = mod_min((int32_t) run_left, gw - x);
@@ -88,22 +107,73 @@ __global__ void __launch_bounds__(64) k_modular_tokens(DevModPlan plan, int32_t 
 					n += k; flushed = n; run_left -= k; run_done += k; x += (int32_t) k;
 					continue;
 				}
+				if (fast) {
+					// the stream's next 4 KB wait in LDS: a window's two words are an LDS read away, not a trip to the L2
+					if (P < chunk_bit0 || P + 160u > chunk_bit0 + 32u * SPLIT_CHUNK_WORDS) {
+						const uint32_t w0 = P >> 5, wlast = (end_bit >> 5) + 6;   // (nothing behind the section's end but the buffer's padding is read)
+						for (uint32_t i = (uint32_t) lane; i < SPLIT_CHUNK_WORDS; i += 64) chunk[i] = words[w0 + i < wlast ? w0 + i : wlast];
+						chunk_bit0 = w0 << 5;
+						__builtin_amdgcn_s_waitcnt(0);
+					}
+					const uint32_t p = P - chunk_bit0 + (uint32_t) lane, wi = p >> 5, sh = p & 31u;
+					const uint64_t ww = (((uint64_t) chunk[wi + 1] << 32) | (uint64_t) chunk[wi]) >> sh;   // >= 33 bits of the stream from bit P + lane on
+					const int32_t *table = code.prefix + cl.table_off;
+					const int32_t entry = table[(uint32_t) ww & ((1u << cl.fast_len) - 1)];
+					const int32_t len1 = entry & 15, tok = entry >> 16;
+					const int32_t tk = mod_min(tok, cl.max_token);
+					const int32_t midbits = tok < hsplit ? 0 : split_exp - in_token + ((tk - hsplit) >> in_token);
+					const int32_t tot = len1 + midbits;
+					const bool plain = entry >= 0 && tok < code.min_symbol && tok <= mod_max(cl.max_token, hsplit - 1) && midbits >= 0 && tot <= 32;
+					const int32_t mid = (int32_t) ((uint32_t) (ww >> len1) & (midbits >= 32 ? 0xffffffffu : (1u << (midbits & 31)) - 1u));
+					const int32_t top = 1 << msb, lo = tk & ((1 << lsb) - 1), hi = (tk >> lsb) & (top - 1);
+					const int32_t val = tok < hsplit ? tok : ((top | hi) << ((midbits + lsb) & 31)) | ((mid << lsb) | lo);
+					// lanes whose symbol the walk must not take: not of the plain kind, or ending behind the section's end
+					const uint64_t stop = __builtin_amdgcn_ballot_w64(!plain || P + (uint32_t) lane + (uint32_t) tot > end_bit);
+					const uint32_t rem = (uint32_t) (gw - x);
+					uint32_t off = 0, cnt = 0; uint64_t starts = 0; bool slow = false;
+					if (!(stop & 1u) && __builtin_amdgcn_readfirstlane(tot) == 0) {
+						// a code of ONE symbol that is a literal: no bits, the rest of the row is that value
+						const int32_t v = __builtin_amdgcn_readfirstlane(val);
+						for (uint32_t j = (uint32_t) lane; j < rem; j += 64) out[n + j] = v;
+						n += rem; flushed = n; x = gw;
+						continue;
+					}
+					while (off < 64u && cnt < rem) {
+						if ((stop >> off) & 1u) { slow = true; break; }
+						starts |= (uint64_t) 1 << off;
+						off += (uint32_t) __builtin_amdgcn_readlane(tot, (int32_t) off);
+						++cnt;
+					}
+					// the walk's symbols leave in stream order: the k-th start lane stores to n + k
+					if ((starts >> lane) & 1u) out[n + (uint32_t) __builtin_popcountll(starts & (((uint64_t) 1 << lane) - 1u))] = val;
+					n += cnt; flushed = n; x += (int32_t) cnt; P += off;
+					if (!slow) continue;
+					{   // this one symbol the long way: the scalar decoder's window set up at P out of the same LDS chunk (three words; the words after
+						// them it asks for itself, from memory, ahead of their use)
+						const uint32_t rel = P - chunk_bit0, wi = rel >> 5, sh = rel & 31u;
+						const uint32_t w0 = uni<true>(chunk[wi]), w1 = uni<true>(chunk[wi + 1]);
+						b.bits = (((uint64_t) w1 << 32) | (uint64_t) w0) >> sh; b.nbits = 64 - (int32_t) sh;
+						b.pos = ((chunk_bit0 >> 5) + wi + 2) * 4u; b.ahead = chunk[wi + 2];
+					}
+				}
 				if (uses_x) { leaf = split_leaf<true>(t.tree, cidx, sec.sidx, y, x); cl = load_cluster<true>(code, leaf.ctx); }
-				int32_t token = cluster_token<true>(b, code, cl);
+				int32_t token = next_token(cl);
 				if (token < code.min_symbol) {   // (min_symbol is out of reach when the code has no LZ77, j40.h:2823)
-					token = hybrid_int_dev<true>(b, token, cl.cfg, cl.max_token);
-					if (b.err) { err_at = n; break; }
+					token = split_hybrid<true>(b, token, cl.cfg, cl.max_token, end_bit, &err);
+					if (err) break;
 					pend = lane == (int32_t) (n - flushed) ? token : pend;   // (lane n - flushed of `pend` := the wave-uniform token: a compare and a select)
 					++n; ++x;
-					if (n - flushed == 64) flush();
+					if (n - flushed == 64 || fast) flush();   // (the sixty-four-at-a-time mode stores its values itself: nothing may wait in `pend` beside it)
+					if (fast) P = ub_position(b);
 					continue;
 				}
-				// an LZ77 run starts (code_lz77_copy): its length from this token, its distance from the stream's last context
+				// an LZ77 run starts (j40.h:2823-2866): its length from this token, its distance from the stream's last context
 				const ClusterRegs lz = load_cluster<true>(code, code.num_dist - 1);
-				const int32_t num_to_copy = hybrid_int_dev<true>(b, token - code.min_symbol, code.lz_len_cfg, code.lz_len_max_token) + code.min_length;
-				token = cluster_token<true>(b, code, lz);
-				int32_t distance = hybrid_int_dev<true>(b, token, lz.cfg, lz.max_token);
-				if (b.err) { err_at = n; break; }
+				const int32_t num_to_copy = split_hybrid<true>(b, token - code.min_symbol, code.lz_len_cfg, code.lz_len_max_token, end_bit, &err) + code.min_length;
+				token = next_token(lz);
+				int32_t distance = split_hybrid<true>(b, token, lz.cfg, lz.max_token, end_bit, &err);
+				if (err) break;
+				if (fast) P = ub_position(b);
 				if (!dist_mult) ++distance;
 				else if (distance >= 120) distance -= 119;
 				else {
@@ -116,14 +186,14 @@ __global__ void __launch_bounds__(64) k_modular_tokens(DevModPlan plan, int32_t 
 				flush();
 				__builtin_amdgcn_s_waitcnt(0);   // (the run reads what was just stored)
 				run_left = (uint32_t) mod_max(num_to_copy, 0); run_base = n - (uint32_t) distance; run_dist = (uint32_t) distance; run_done = 0;
-				if (run_left > sec.res_count - n) { run_left = sec.res_count - n; }   // (a run past the section's last sample: the values it still codes are never asked for)
+				if (run_left > sec.res_count - n) run_left = sec.res_count - n;   // (a run past the section's last sample: the values it still codes are never asked for)
 			}
-			if (b.err && err_at == 0xffffffffu) err_at = n;
 		}
 	}
+	if (fast && !err) ub_init<true>(b, (const J40_GLOBAL uint8_t *) plan.codestream, P);   // (what follows the last symbol is read through the window again)
 	flush();
-	if (!b.err) { code_finish<true>(b, code); if (!b.err && f.check_section_end) bits_finish_section(b, f.single_declared_end); if (b.err) err_at = n; }
-	if (lane == 0) { note[0] = b.err; note[1] = b.err ? err_at : 0xffffffffu; note[2] = 0xffffffffu; }
+	split_finish<true>(b, prefix, state, end_bit, f.check_section_end != 0, f.single_declared_end, &err);
+	if (lane == 0) { note[0] = err; note[1] = err ? n : 0xffffffffu; note[2] = 0xffffffffu; }
 }
 
 // value of `v` in the lane above (lane 0: its own)
@@ -203,12 +273,14 @@ __global__ void k_modular_split_status(DevModPlan plan, int32_t first_section, i
 
 void launch_modular_split(const DevModPlan &plan, int32_t first_section, int32_t num_sections, const ModLaunchInfo &info, hipStream_t stream) {
 	if (num_sections <= 0 || info.split_sections <= 0) return;
+	static const bool once = [] { const char *e = getenv("J40HIP_SPLIT_NO_FAST"); const bool v = e && atoi(e) != 0; if (v) (void) hipMemcpyToSymbol(HIP_SYMBOL(g_split_no_fast), &v, sizeof v); return true; }();
+	(void) once;
 	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
 	const uint32_t lds = align16((uint32_t) info.num_tree_nodes * (uint32_t) sizeof(DevTreeNode)) + align16((uint32_t) info.num_dist + 4)
 		+ align16((uint32_t) info.num_clusters * (uint32_t) sizeof(DevCluster)) + align16(info.table_bytes) + 64;
-	if (lds <= 156u * 1024u) {
+	if (lds <= 150u * 1024u) {   // (beside the kernel's own 4 KB window on the codestream)
 		static bool configured = false;
-		if (!configured) { (void) hipFuncSetAttribute((const void *) k_modular_tokens<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); configured = true; }
+		if (!configured) { (void) hipFuncSetAttribute((const void *) k_modular_tokens<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 154 * 1024); configured = true; }
 		hipLaunchKernelGGL(k_modular_tokens<true>, dim3((unsigned) num_sections), dim3(64), lds, stream, plan, first_section);
 	} else hipLaunchKernelGGL(k_modular_tokens<false>, dim3((unsigned) num_sections), dim3(64), 0, stream, plan, first_section);
 	const int32_t row_floats = (info.split_width + 3) & ~3;
