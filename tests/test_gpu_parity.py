@@ -182,6 +182,40 @@ def test_modular_corruption_is_reported(gpu, ref):
     assert rejected >= 1
 
 
+@pytest.mark.parametrize("opts", [dict(alpha=1, prefix=1, lz77=1), dict(alpha=1), dict(prefix=1), dict(lz77=1, groupshift=7), dict(palette=2, alpha=1, prefix=1, lz77=1)],
+                         ids=["config1_prefix_lz77", "ans", "prefix", "ans_lz77_group128", "palette_prefix_lz77"])
+def test_two_pass_modular_sections_pixels_and_codes(gpu, ref, opts):
+    """sections with a position-only MA tree go through the two-pass decoder (modular_split.hip: the stream's tokens first -- prefix codes
+    sixty-four symbols at a time --, the prediction behind them): the reference's pixels on the clean stream, and on 60 damaged ones
+    (a flipped bit, a truncation, bytes appended) the reference's pixels or the reference's 4-char code"""
+    import j40_amd
+    data = synth("modular", 256, 256, 101, **opts)
+    f = j40_amd.Frame(data)
+    assert f.split_sections() >= 1
+    f.close()
+    err, rgba = gpu.decode(data)
+    rerr, expect = ref.decode(data)
+    assert err == rerr == "" and np.array_equal(rgba, expect)
+    rng = np.random.default_rng(5)
+    rejected = 0
+    for k in range(60):
+        m = bytearray(data)
+        if k % 10 == 8:
+            m = m[:int(rng.integers(len(m) // 3, len(m) - 1))]
+        elif k % 10 == 9:
+            m += bytes(int(rng.integers(1, 9)))
+        else:
+            m[int(rng.integers(40, len(m)))] ^= 1 << int(rng.integers(0, 8))
+        rerr, rexp = ref.decode(bytes(m))
+        err, got = gpu.decode(bytes(m))
+        assert err == rerr, (k, err, rerr)
+        if rerr == "":
+            assert np.array_equal(got, rexp), k
+        else:
+            rejected += 1
+    assert rejected >= 5
+
+
 def test_lz77_distance_multiplier_of_lf_global_on_the_gpu(gpu, ref):
     """see tests/test_hostsim.py::test_lz77_distance_multiplier_of_lf_global_is_the_whole_images: the same damaged stream through K3"""
     data = bytearray(synth("modular", 645, 28, 75417, palette=3, prefix=1, lz77=1, permute=1))

@@ -44,11 +44,13 @@ def test_coop_tree_selects_the_leaf_the_walk_reaches(built, w, h, opts):
     data = synth("modular", w, h, 7, **opts)
     fr = j40_amd.Frame(data)
     coop, total = fr.coop_sections()
+    split = fr.split_sections()
     fr.close()
-    assert coop == total and total >= 1, "every section of these streams is the cooperative kernel's"
+    # (a tree without a branch looks at nothing: the two-pass decoder takes its sections, modular_split.hip)
+    assert coop + split == total and total >= 1 and (split == 0 or opts.get("tree") == 0), "every section of these streams is the cooperative kernel's"
     buf = C.create_string_buffer(data, len(data))
     checked = _hostsim().hostsim_coop_check(buf, len(data), 99, 20000)
-    assert checked >= 1, "mismatches: %d" % (-checked - 1)
+    assert checked >= (1 if coop else 0), "mismatches: %d" % (-checked - 1)
 
 
 def test_what_the_cooperative_kernel_leaves_to_the_general_one(built):
@@ -140,7 +142,7 @@ def test_coop_and_general_kernel_agree(gpu):
     runs = []
     # the cooperative kernel (default for these sizes), the general kernel only, and four sections per wavefront (k_modular_quad,
     # normally for frames with thousands of sections) forced onto every section that can take it
-    for extra in ({}, {"J40HIP_NO_COOP": "1"}, {"J40HIP_QUAD_MIN": "1"}):
+    for extra in ({}, {"J40HIP_NO_COOP": "1"}, {"J40HIP_QUAD_MIN": "1"}, {"J40HIP_NO_SPLIT": "1"}, {"J40HIP_SPLIT_NO_FAST": "1"}):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -148,3 +150,18 @@ def test_coop_and_general_kernel_agree(gpu):
     assert runs[0] == runs[1]
     assert runs[0] == runs[2]
     assert any(e == "" for e, _ in runs[0]) and any(e != "" for e, _ in runs[0])
+
+
+def test_which_sections_the_two_pass_decoder_takes(built):
+    """modular_split.hip takes the sections whose MA tree looks only at a sample's position (properties 0-3) and predicts without the
+    weighted predictor -- none of those with neighbour properties, the weighted predictor or previous-channel properties"""
+    import j40_amd
+    from streams import synth
+    want = {(): True, (("tree", 1),): False, (("tree", 2),): False, (("tree", 3), ("alpha", 1)): False, (("prefix", 1), ("lz77", 1), ("alpha", 1)): True, (("palette", 2), ("alpha", 1)): True}
+    for opts, takes in want.items():
+        f = j40_amd.Frame(synth("modular", 300, 200, 7, **dict(opts)))
+        coop, total = f.coop_sections()
+        split = f.split_sections()
+        assert (split > 0) == takes, (opts, split, coop, total)
+        assert split + coop <= total
+        f.close()
