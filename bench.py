@@ -211,8 +211,12 @@ def run_pipeline_steps(pipe, bufs, sizes, outs, stride, device_output, steps, to
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    run_pipeline_steps.per_rank = [elapsed]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, t)   # (each rank's own clock, for the line's per-rank PCIe figures)
+        run_pipeline_steps.per_rank = [float(x.item()) for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, tickets
@@ -347,6 +351,7 @@ def main():
         run_pipeline_steps(pipe, step_bufs, step_sizes, step_outs, W * 4, False, args.warmup, torch, dev, None)
     cg0 = cgroup_cpu_stat()
     elapsed, tickets = run_pipeline_steps(pipe, step_bufs, step_sizes, step_outs, W * 4, False, args.steps, torch, dev, dist)
+    per_rank_elapsed = list(run_pipeline_steps.per_rank)
     cg1 = cgroup_cpu_stat()
     st = pipe.stats()
     for t in tickets:
@@ -497,6 +502,9 @@ def main():
         result["device_output"] = device_output
     result["pcie"] = {"bytes_back_per_step": 4 * W * H * B, "achieved_gb_per_s": round(4 * W * H * frames_total / world / elapsed / 1e9, 2),
                       "note": "RGBA copied back per GPU during the timed region / wall time; a Gen5 x16 link moved 57 GB/s device-to-host on these boxes (tools/pcie_probe.py): 14.2 Gpx/s is the ceiling of `value` per GPU",
+                      "per_rank_gb_per_s": [round(4 * W * H * B * args.steps / e / 1e9, 2) for e in per_rank_elapsed],
+                      "host_memory_landing_gb_per_s": round(sum(4 * W * H * B * args.steps / e / 1e9 for e in per_rank_elapsed), 2),
+                      "per_rank_note": "each rank's own copy rate over its own clock (barrier to barrier); their sum is what the host's memory takes in -- N ranks land N x 53 GB/s of RGBA in one host's DRAM, beside N x 1.1 GB/s of uploads",
                       "link_probe": link_probe,
                       "copy_engine": j40_amd.copy_engine(local_rank),
                       "copy_engine_note": "the copies back are issued on ONE SDMA engine the library measured as the fastest of the device's sixteen (hsa_amd_memory_async_copy_on_engine; j40_amd/csrc/device/hostcopy.hip): hipMemcpyAsync lets the runtime take whichever engine is free, and they range from 57 to 7 GB/s device to host -- that was rounds 4-5's 'slow runs'"}
@@ -828,7 +836,8 @@ def sharded_records(args, torch, j40_amd, dist, dev, rank, local_rank, world):
     out = {}
     d8k = synth("vardct", 7680, 4320, args.seed, **({"forward": 1} if args.stream == "forward" else {})) if rank == 0 else b""
     sec = time_sharded(5, 1, torch, j40_amd, dist, dev, rank, local_rank, d8k)
-    out["vardct_7680x4320"] = {"ms_per_frame": round(sec * 1e3, 3), "mpixels_per_s": round(7680 * 4320 / sec / 1e6, 1), "steps": 5, "pixels_equal_single_decode": time_sharded.pixels_equal}
+    out["vardct_7680x4320"] = {"ms_per_frame": round(sec * 1e3, 3), "mpixels_per_s": round(7680 * 4320 / sec / 1e6, 1), "steps": 5, "pixels_equal_single_decode": time_sharded.pixels_equal,
+                               "broadcast": "the parsed frame (LF bundle: codestream + LfGroup planes + tables, one parse on rank 0)" if __import__("j40_amd.sharding", fromlist=["x"]).LAST_FORM["lf_bundle"] else "the codestream (every rank parses it itself, concurrently)"}
     if not args.skip_modular:
         dm = synth("modular", 16384, 16384, 21, tree=1, repeat=16) if rank == 0 else b""
         sec = time_sharded(2, 1, torch, j40_amd, dist, dev, rank, local_rank, dm)

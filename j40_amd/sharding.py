@@ -65,31 +65,33 @@ def range_rectangles(first, count, width, height, group_size_shift):
     return rects
 
 
-def broadcast_bytes(data, dist, device="cpu", src=0):
-    """the codestream from rank `src` to every rank; `data` is ignored on the other ranks. The source keeps the bytes it has (nothing
+def broadcast_bytes(data, dist, device="cpu", src=0, tag=None):
+    """(tag: an integer that travels with the length -- the source's `tag` is returned beside the bytes on every rank as (bytes, tag))
+    the codestream from rank `src` to every rank; `data` is ignored on the other ranks. The source keeps the bytes it has (nothing
     comes back from the device for it); a receiving rank needs them in HOST memory -- its parser reads headers, TOC and the LF sections
     there -- so what arrived in a device tensor (RCCL moves device memory) is copied down once, through a pinned buffer"""
     import torch
     rank = dist.get_rank()
-    n = torch.tensor([len(data) if rank == src else 0], dtype=torch.int64, device=device)
+    n = torch.tensor([len(data) if rank == src else 0, int(tag or 0) if rank == src else 0], dtype=torch.int64, device=device)
     dist.broadcast(n, src)
-    size = int(n.item())
+    size, got_tag = int(n[0].item()), int(n[1].item())
+    done = (lambda b: (b, got_tag)) if tag is not None else (lambda b: b)
     if size == 0:
-        return b""
+        return done(b"")
     on_device = str(device) != "cpu"
     if rank == src:
         buf = torch.frombuffer(bytearray(data), dtype=torch.uint8)
         if on_device:
             buf = buf.to(device, non_blocking=True)
         dist.broadcast(buf, src)
-        return data if isinstance(data, bytes) else bytes(data)
+        return done(data if isinstance(data, bytes) else bytes(data))
     buf = torch.empty(size, dtype=torch.uint8, device=device)
     dist.broadcast(buf, src)
     if on_device:
         host = torch.empty(size, dtype=torch.uint8, pin_memory=True)
         host.copy_(buf, non_blocking=False)
         buf = host
-    return buf.numpy().tobytes()
+    return done(buf.numpy().tobytes())
 
 
 def agree_on_errors(code, dist, device="cpu"):
@@ -131,33 +133,39 @@ def gather_rectangles(full, ranges, width, height, group_size_shift, dist, dst=0
     return full
 
 
-def decode_sharded(data, dist, decode_range, device="cpu", lf_bundle=False):
+LAST_FORM = {"lf_bundle": None}   # which form the last decode_sharded of this process took (bench.py puts it on the `sharded` record)
+
+
+def decode_sharded(data, dist, decode_range, device="cpu", lf_bundle=None):
     """data: codestream on rank 0. decode_range(data, rank, world) -> (error code, full-frame uint8 tensor [height, width, 4] on
     `device` with this rank's groups decoded, ranges, (width, height, group_size_shift)). Returns the frame on rank 0; raises
     the same J40Error on every rank when any rank failed.
     lf_bundle: rank 0 alone parses the stream and broadcasts the parsed frame -- codestream, LF bundle and tables as one blob
     (Frame.lf_bundle, SURVEY.md 8e's wording) -- and decode_range is called as decode_range(blob, rank, world, from_bundle=True).
-    The blob is ~3x the codestream; what it saves is the other ranks' host parse (they would run concurrently anyway)."""
+    The blob is ~3x the codestream; what it saves is the other ranks' host parse (they would run concurrently anyway).
+    lf_bundle=None (default): the bundle from four ranks up -- one parse instead of N, and N - 1 ranks' host threads left alone, which is
+    what counts when eight ranks share one container's CPU quota; below that every rank parses the 4-5 MB codestream itself, concurrently,
+    which is as fast and moves a third of the bytes."""
     import j40_amd
-    if lf_bundle:
-        blob = b""
-        if dist.get_rank() == 0:
-            try:
-                fr = j40_amd.Frame(data)
-                blob = fr.lf_bundle()
-                fr.close()
-            except j40_amd.J40Error:
-                blob = b""   # every rank then reports the failure of its (empty) bundle
-        blob = broadcast_bytes(blob, dist, device)
-        err, full, ranges, (width, height, shift) = decode_range(blob, dist.get_rank(), dist.get_world_size(), from_bundle=True)
-        err = agree_on_errors(err, dist, device)
-        if err:
-            raise j40_amd.J40Error(err, "in a sharded decode")
-        if str(full.device) != str(device):
-            full = full.to(device)
-        return gather_rectangles(full, ranges, width, height, shift, dist)
-    data = broadcast_bytes(data, dist, device)
-    err, full, ranges, (width, height, shift) = decode_range(data, dist.get_rank(), dist.get_world_size())
+    if lf_bundle is None:
+        lf_bundle = dist.get_world_size() >= 4
+    # one message from rank 0, tagged: 1 = the parsed frame's blob, 0 = the codestream (asked for, or because the frame has no bundle
+    # form -- Modular frames -- or rank 0's parse failed: every rank then parses the codestream and reports what it finds)
+    body, is_bundle = data, 0
+    if dist.get_rank() == 0 and lf_bundle:
+        try:
+            fr = j40_amd.Frame(data)
+            body, is_bundle = fr.lf_bundle(), 1
+            fr.close()
+        except j40_amd.J40Error:
+            body, is_bundle = data, 0
+    body, is_bundle = broadcast_bytes(body, dist, device, tag=is_bundle)
+    from_bundle = bool(is_bundle)
+    LAST_FORM["lf_bundle"] = from_bundle
+    if from_bundle:
+        err, full, ranges, (width, height, shift) = decode_range(body, dist.get_rank(), dist.get_world_size(), from_bundle=True)
+    else:
+        err, full, ranges, (width, height, shift) = decode_range(body, dist.get_rank(), dist.get_world_size())
     err = agree_on_errors(err, dist, device)
     if err:
         raise j40_amd.J40Error(err, "in a sharded decode")

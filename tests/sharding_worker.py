@@ -47,8 +47,20 @@ def run(rank, world, port, stream_path, out_path):
     import torch
     import torch.distributed as dist
     from j40_amd import sharding
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    rccl = len(sys.argv) > 6 and sys.argv[6] == "rccl"   # one device per rank, device tensors over RCCL (backend "nccl"), the LF-bundle choice left to decode_sharded
+    if rccl:
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     data = open(stream_path, "rb").read() if rank == 0 else b""
+    if rccl:
+        frame = sharding.decode_sharded(data, dist, sharding.hip_range_decoder(rank), torch.device("cuda", rank))
+        if rank == 0:
+            np.save(out_path, frame.cpu().numpy())
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # sys.argv[6] == "hip": the ranks decode their ranges on the GPU (every rank on device 0 of a one-GPU box, else its own) through
     # libj40hip.so; the transport stays gloo with host tensors
     if len(sys.argv) > 6 and sys.argv[6] in ("hip", "hipbundle"):   # "hipbundle": rank 0 parses alone and broadcasts the LF bundle

@@ -123,3 +123,30 @@ def test_sharded_decode_with_the_hip_range_decoder(built, ref, world, w, h, mode
     rerr, expect = ref.decode(data)
     assert rerr == "" and got.shape == expect.shape
     assert np.abs(got.astype(np.int32) - expect.astype(np.int32)).max() <= (0 if modular else 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_decode_over_rccl_one_gpu_per_rank(built, ref, world):
+    """the north star's form -- one process per GPU, pixel rectangles as device tensors over RCCL/xGMI (backend "nccl"), from four ranks
+    up the parsed frame broadcast instead of the codestream -- on a box that HAS that many GPUs. The bench boxes of this build have
+    one: the test then SKIPS, loudly, and RCCL between ranks stays unexecuted here (world 1: tools/rccl_dry_run.py)."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < world:
+        pytest.skip("RCCL between ranks NOT exercised: this box has %d GPU(s), the test needs %d (one per rank)" % (n, world))
+    w, h = 7680, 4320
+    data = synth("vardct", w, h, 57)
+    path = os.path.join(STREAMS, "shardrccl_%d_%d.jxl" % (w, h))
+    open(path, "wb").write(data)
+    out = os.path.join(STREAMS, "shardrccl_%d_%d_w%d.npy" % (w, h, world))
+    if os.path.exists(out):
+        os.remove(out)
+    port = free_port()
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharding_worker.py"), str(r), str(world), str(port), path, out, "rccl"], env=env) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    got = np.load(out)
+    rerr, expect = ref.decode(data)
+    assert rerr == "" and np.abs(got.astype(np.int32) - expect.astype(np.int32)).max() <= 1
