@@ -538,7 +538,8 @@ def main():
     stages = [x for x in stages if x]
     result["roofline"]["stages"] = stages
     try:
-        pt = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")))
+        import glob
+        pt = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_traffic.json")))[-1]))   # (the latest round's counter passes: tools/r06_final.sh)
         if (W, H) == (7680, 4320) and pt.get("stream", "coefficient") == args.stream:
             corr = pt.get("fetch_correction", 1.0)
             for x in stages:

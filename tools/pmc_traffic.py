@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r05_pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; csv output) over the same command: the
+"""profiles/r0N_pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; csv output) over the same command: the
 counters of every kernel summed per STAGE of a batch and divided by the launches, for bench.py's roofline.stages[].traffic.
 usage: python tools/pmc_traffic.py <fetch dir> <write dir> <out.json> <frames per batch launch> <frames per LfGroup launch> <commit> <command>"""
 import collections, csv, glob, json, re, sys
@@ -31,7 +31,7 @@ def main(fetch_dir, write_dir, out, batch_frames, lf_frames, commit, command):
                                "frames_per_launch": float(lf_frames if kind == "lf" else batch_frames), "launches_counted": [lf, lw]}
     for k in sorted(set(ft) | set(wt)):
         res["kernels"][k[:90]] = {"fetch_kb_per_dispatch": round(ft.get(k, 0) / max(fn.get(k, 1), 1), 1), "write_kb_per_dispatch": round(wt.get(k, 0) / max(wn.get(k, 1), 1), 1), "dispatches": [fn.get(k, 0), wn.get(k, 0)]}
-    res["source"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `%s` on commit %s (tools/r05_final.sh); KB as reported, per launch: every kernel of a stage summed, divided by the stage's "
+    res["source"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `%s` on commit %s (tools/r06_final.sh; round 5: tools/r05_final.sh); KB as reported, per launch: every kernel of a stage summed, divided by the stage's "
                      "launches; FETCH_SIZE is doubled by bench.py per the gfx950 note in MI355X_MICROARCH.md (128-byte requests tallied at 64) -- calibrated there for wide coalesced reads, an upper bound for narrow ones; "
                      "under --pmc the kernels run one at a time, the LfGroup launches carry what was waiting then") % (command, commit)
     json.dump(res, open(out, "w"), indent=1)
