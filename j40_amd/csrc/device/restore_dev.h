@@ -68,23 +68,31 @@ J40_DEV float epf_recip_sigma(const RestoreParams &p, int32_t sharpness, float h
 #define J40_EPF_K12 {{0, -2}, {-1, -1}, {-1, 0}, {-1, 1}, {0, -2}, {0, -1}, {0, 1}, {0, 2}, {-1, 1}, {-1, 0}, {-1, 1}, {0, 2}}
 #define J40_EPF_K4 {{0, -1}, {-1, 0}, {1, 0}, {0, 1}}
 
-// ACC(c, x, y): the step's input sample of channel c at (x, y), both inside the picture.
-// |in(x, y) - in(x + dx, y + dy)| with both positions mirrored into the picture: an entry of j40__epf_distance's plane (j40.h:7338-7369)
+// ACC(c, x, y): the step's input sample of channel c at (x, y) MIRRORED INTO THE PICTURE -- the coordinates may lie up to three
+// samples outside it (an accessor over the planes mirrors them itself, EpfMirrored below; the kernels' LDS tiles were filled mirrored).
+// |in(x, y) - in(x + dx, y + dy)|: an entry of j40__epf_distance's plane (j40.h:7338-7369)
 template <typename ACC>
 J40_DEV float epf_distance(const ACC &in, int32_t c, int32_t w, int32_t h, int32_t x, int32_t y, int32_t dx, int32_t dy) {
-	return restore_fabs(in(c, restore_mirror(x, w), restore_mirror(y, h)) - in(c, restore_mirror(x + dx, w), restore_mirror(y + dy, h)));
+	(void) w; (void) h;
+	return restore_fabs(in(c, x, y) - in(c, x + dx, y + dy));
 }
+// an accessor over planes that takes inside coordinates only, made into one that mirrors
+template <typename INSIDE> struct EpfMirrored {
+	INSIDE in; int32_t w, h;
+	J40_DEVM float operator()(int32_t c, int32_t x, int32_t y) const { return in(c, restore_mirror(x, w), restore_mirror(y, h)); }
+};
 
 // a tap of the weighted sum (the reference's lines[2 + k0][c][x + k1], j40.h:7536, 7551); quirk: the header of this file
 template <typename ACC>
 J40_DEV float epf_tap(const ACC &in, int32_t c, int32_t w, int32_t h, int32_t x, int32_t y, int32_t k0, int32_t k1, int32_t quirk) {
+	(void) h;
 	const int32_t xx = x + k1;
 	int32_t yy = y + k0;
 	if (quirk) {
 		if (c < 2 && ((k0 == 0 && (y & 3) == 0) || (k0 == -1 && (y & 3) == 1))) { ++c; ++yy; }   // the row slot holds the next channel's row
 		else if (c > 0 && (xx < 0 || xx >= w) && ((y == 0 && k0 <= 0) || (y == 1 && k0 < 0))) return 0.0f;   // a border slot nobody wrote
 	}
-	return in(c, restore_mirror(xx, w), restore_mirror(yy, h));
+	return in(c, xx, yy);
 }
 
 // One output sample triple of step STEP (0: twelve taps, cross-shaped distances; 1: four taps, cross; 2: four taps, plain distances;

@@ -1148,7 +1148,8 @@ namespace {
 struct HostPlanes { const float *p[3]; size_t pitch; float operator()(int32_t c, int32_t x, int32_t y) const { return p[c][(size_t) y * pitch + (size_t) x]; } };
 template <int STEP> void hostsim_epf_step(const j40hip::RestoreParams &p, const std::vector<float> &sigma, std::vector<float> &a, std::vector<float> &b) {
 	const size_t plane = (size_t) p.width * (size_t) p.height;
-	const HostPlanes in = {{a.data(), a.data() + plane, a.data() + 2 * plane}, (size_t) p.width};
+	const HostPlanes inside = {{a.data(), a.data() + plane, a.data() + 2 * plane}, (size_t) p.width};
+	const j40hip::EpfMirrored<HostPlanes> in = {inside, p.width, p.height};
 	for (int32_t y = 0; y < p.height; ++y) for (int32_t x = 0; x < p.width; ++x) {
 		const float rs = sigma[(size_t) (y >> 3) * (size_t) p.w8 + (size_t) (x >> 3)];
 		float v[3];
