@@ -319,7 +319,7 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 			d.xfromy = (int16_t *) (pb + o_xfy) + gg.c64_base; d.bfromy = (int16_t *) (pb + o_bfy) + gg.c64_base;
 			d.info = (int16_t *) (pb + o_info) + 2 * (size_t) gg.cell_base; d.info_capacity = (uint32_t) (2 * (size_t) gg.width8 * (size_t) gg.height8);
 			d.sharp = (int16_t *) (pb + o_sharp) + gg.cell_base;
-			d.result = (DevLfResult *) ((DevLfSlot *) (pb + o_slots) + g);   // (DevLfSlot begins with the two words of DevLfResult)
+			d.result = (DevLfResult *) ((DevLfSlot *) (pb + o_slots) + g);   // (DevLfSlot's four words are DevLfResult's: the last two are the LfGroup decoder's scratch until k_lf_predict has zeroed them)
 		}
 		{   // the device sees the sections by decreasing size: k_lf_rows gives a lane two neighbours of the list, which should end together
 			std::vector<DevLfTask> by_size = af->lf_tasks;

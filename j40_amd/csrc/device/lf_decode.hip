@@ -142,7 +142,7 @@ J40_DEV void lf_row_flush_wave(LfRowLane &L, int32_t lane) {
 // takes the sections of the frames pack_lf_row_waves gave it; LDS: per part the staged tree and the alias tables, then one window
 // per section. A part's sections go to its lanes two at a time in list order (the host lists them by decreasing size).
 template <bool PAIRS>
-__global__ void __launch_bounds__(64) k_lf_rows(const DevLfLaneSet *sets, const DevLfWave *waves) {
+__global__ void __launch_bounds__(64) k_lf_rows(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t raw) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lfr_lds[];
 	const J40_GLOBAL DevLfWave &wv = ((const J40_GLOBAL DevLfWave *) waves)[blockIdx.x];
 	const int32_t lane = threadIdx.x, num_parts = wv.num_parts;
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(64) k_lf_rows(const DevLfLaneSet *sets, const 
 		}
 		if (my_section >= section0 && my_section < section0 + count) {
 			task = (const J40_GLOBAL DevLfTask *) set.tasks + (first + my_section - section0);
-			T.tree = (const J40_LDS DevTreeNode *) l_tree; T.alias = l_alias; T.log_alpha = log_alpha; T.log_bucket = 12 - log_alpha; T.uses = set.uses;
+			T.tree = (const J40_LDS DevTreeNode *) l_tree; T.alias = l_alias; T.log_alpha = log_alpha; T.log_bucket = 12 - log_alpha; T.uses = set.uses | (!PAIRS && raw ? (uint32_t) LF_USES_RAW : 0u);
 		}
 		if (PAIRS && my_section + 1 >= section0 && my_section + 1 < section0 + count) {
 			task_b = (const J40_GLOBAL DevLfTask *) set.tasks + (first + my_section + 1 - section0);
@@ -233,7 +233,72 @@ __global__ void __launch_bounds__(64) k_lf_rows(const DevLfLaneSet *sets, const 
 		}
 		if (active_b) { J40_GLOBAL DevLfResult *r = (J40_GLOBAL DevLfResult *) tb.result; r->status = M.err; r->nb_varblocks = M.nb_varblocks; }
 	}
-	if (active) { J40_GLOBAL DevLfResult *r = (J40_GLOBAL DevLfResult *) t.result; r->status = L.err; r->nb_varblocks = L.nb_varblocks; }
+	if (active) {
+		J40_GLOBAL DevLfResult *r = (J40_GLOBAL DevLfResult *) t.result; r->status = L.err; r->nb_varblocks = L.nb_varblocks;
+		if (!PAIRS && raw) { r->raw_mask = L.raw_mask; r->stopped_at = L.stopped_at; }   // (for k_lf_predict, which follows on the stream)
+	}
+}
+
+// The predictions of the channels k_lf_rows left as residuals (lf_rows_dev.h, RAW channels): one wavefront per section, channel after
+// channel in stream order; 64 rows at a time go to the 64 lanes, each lane three columns behind the lane above it, which hands
+// it the row above through one cross-lane move per step (k_modular_predict's scheme, modular_split.hip); the last row of a band
+// waits in LDS for the next band's first lane. In place: a sample is read (as a residual) by the lane that replaces it, once.
+// Workgroup b: section b % 64 of wavefront b / 64 of the launch's list.
+__global__ void __launch_bounds__(64) k_lf_predict(const DevLfLaneSet *sets, const DevLfWave *waves) {
+	__shared__ int32_t above[LF_ROW_WIN + 4];
+	const J40_GLOBAL DevLfWave &wv = ((const J40_GLOBAL DevLfWave *) waves)[blockIdx.x >> 6];
+	const int32_t my_section = (int32_t) (blockIdx.x & 63), lane = threadIdx.x;
+	const J40_GLOBAL DevLfTask *task = nullptr;
+	int32_t section0 = 0;
+	for (int32_t p = 0; p < wv.num_parts; ++p) {
+		const int32_t count = wv.part[p].count;
+		if (my_section >= section0 && my_section < section0 + count) task = (const J40_GLOBAL DevLfTask *) ((const J40_GLOBAL DevLfLaneSet *) sets)[wv.part[p].set].tasks + (wv.part[p].first_task + my_section - section0);
+		section0 += count;
+	}
+	if (!task) return;
+	const J40_GLOBAL DevLfTask &t = *task;
+	J40_GLOBAL DevLfResult *r = (J40_GLOBAL DevLfResult *) t.result;
+	const uint32_t raw_mask = r->raw_mask, stopped_at = r->stopped_at;
+	const int32_t nb_varblocks = r->nb_varblocks;
+	bool povf = false;
+	for (int32_t chan = 0; chan < 7 && !povf; ++chan) {
+		const int32_t nib = (int32_t) ((raw_mask >> (4 * chan)) & 15u);
+		if (nib < 2) continue;
+		const int32_t predictor = nib - 1;
+		int32_t cw, chh;
+		J40_GLOBAL int16_t *plane = lf_channel_plane(t, chan, nb_varblocks, &cw, &chh);
+		const int32_t limit = lf_channel_complete(stopped_at, chan, cw, chh);
+		if (limit <= 0 || cw > LF_ROW_WIN) continue;   // (rows wider than the window are never left as residuals with something to predict)
+		const int32_t rows = (limit + cw - 1) / cw;
+		for (int32_t y0 = 0; y0 < rows; y0 += 64) {
+			__threadfence();   // (the band before wrote row y0 - 1: this wavefront's own stores, made visible to its loads)
+			__syncthreads();
+			for (int32_t x = lane; x < cw; x += 64) above[x] = y0 > 0 ? (int32_t) plane[(size_t) (y0 - 1) * (size_t) cw + (size_t) x] : 0;
+			__syncthreads();
+			const int32_t y = y0 + lane;
+			const int32_t width = y < rows ? mod_min(cw, limit - y * cw) : 0;   // (the lane's last row may be a piece of one)
+			J40_GLOBAL int16_t *row = plane + (size_t) (y < rows ? y : 0) * (size_t) cw;
+			int32_t r_nww = 0, r_nw = 0, r_n = 0, r_ne = 0, r_nee = 0, c_w = 0, c_ww = 0;
+			const int32_t steps = cw + 3 * 63 + 3;
+			for (int32_t tstep = 0; tstep < steps; ++tstep) {
+				const int32_t x = tstep - 3 * lane - 2;   // (every lane starts two columns early: its registers fill with the row above at 0, 1, 2)
+				int32_t in_nee = __builtin_amdgcn_ds_bpermute((lane > 0 ? lane - 1 : 0) << 2, c_w);   // the row above at x + 2: what the lane above computed a step ago
+				if (lane == 0) in_nee = x + 2 >= 0 && x + 2 < cw ? above[x + 2] : 0;
+				r_nww = r_nw; r_nw = r_n; r_n = r_ne; r_ne = r_nee; r_nee = in_nee;   // now centred on x
+				if (x >= 0 && x < width) {
+					const int32_t v = lf_predict_value(row[x], predictor, x, y, cw, c_w, c_ww, r_nww, r_nw, r_n, r_ne);
+					povf |= v < -32768 || v > 32767;
+					row[x] = (int16_t) v;
+					c_ww = c_w; c_w = v;
+				}
+			}
+		}
+		povf = __builtin_amdgcn_ballot_w64(povf) != 0;   // (channels follow one another in the stream: the first one with such a sample decides)
+	}
+	if (lane == 0) {
+		if (povf) r->status = ERR_POVF;   // (before the place the lane stopped: only such samples were looked at)
+		r->raw_mask = 0; r->stopped_at = 0;   // (the words are the plan build's from here on: DevLfSlot)
+	}
 }
 
 // J40HIP_LF_ALIAS_LDS=1: the alias tables staged in LDS too (frames whose tables do not fit: the host decodes their sections)
@@ -311,14 +376,27 @@ uint32_t pack_lf_row_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std:
 	return most;
 }
 
+// J40HIP_LF_RAW=0: every channel predicted by the lane that parses it, as before round 6 (A/B runs, tests)
+static bool lf_rows_raw() {
+	static const bool v = [] { const char *e = getenv("J40HIP_LF_RAW"); return !(e && atoi(e) == 0 && e[0] != 0); }();
+	return v;
+}
+// k_lf_rows, then -- when it leaves leaf-only channels as residuals -- k_lf_predict; `started` / `stopped`: the device's clock before
+// the first and after the last of them
 void launch_lf_rows(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t num_waves, uint32_t lds_bytes, hipStream_t stream, hipEvent_t started, hipEvent_t stopped) {
 	if (num_waves <= 0) return;
 	static bool configured = false;
 	if (!configured) { (void) hipFuncSetAttribute((const void *) k_lf_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); (void) hipFuncSetAttribute((const void *) k_lf_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); configured = true; }
 	const bool pairs = lf_rows_mode() == 2;
-	if (started || stopped) { if (pairs) hipExtLaunchKernelGGL(k_lf_rows<true>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, started, stopped, 0, sets, waves); else hipExtLaunchKernelGGL(k_lf_rows<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, started, stopped, 0, sets, waves); }
-	else if (pairs) hipLaunchKernelGGL(k_lf_rows<true>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
-	else hipLaunchKernelGGL(k_lf_rows<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
+	const int32_t raw = !pairs && lf_rows_raw() ? 1 : 0;
+	hipEvent_t rows_stopped = raw ? nullptr : stopped;
+	if (started || rows_stopped) { if (pairs) hipExtLaunchKernelGGL(k_lf_rows<true>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, started, rows_stopped, 0, sets, waves, raw); else hipExtLaunchKernelGGL(k_lf_rows<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, started, rows_stopped, 0, sets, waves, raw); }
+	else if (pairs) hipLaunchKernelGGL(k_lf_rows<true>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves, raw);
+	else hipLaunchKernelGGL(k_lf_rows<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves, raw);
+	if (raw) {
+		if (stopped) hipExtLaunchKernelGGL(k_lf_predict, dim3((unsigned) num_waves * 64u), dim3(64), 0, stream, nullptr, stopped, 0, sets, waves);
+		else hipLaunchKernelGGL(k_lf_predict, dim3((unsigned) num_waves * 64u), dim3(64), 0, stream, sets, waves);
+	}
 }
 
 void launch_lf_groups(const DevLfTask *tasks, int32_t num_tasks, hipStream_t stream) {

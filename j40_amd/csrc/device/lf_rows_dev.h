@@ -21,10 +21,26 @@
 // What is left in vector memory: the codestream word requested one refill ahead (once in several samples) and the row copies.
 // Same streams as lf_lanes_dev.h (rANS without LZ77, no weighted predictor, no previous-channel properties, plain second header),
 // same samples, same status codes: tests/hostsim runs both against the host decoder.
+//
+// RAW channels (round 6). A channel whose subtree is a single leaf is coded with one context whatever its samples come to, so nothing a
+// lane's parse needs depends on the prediction: the lane stores the RESIDUAL (unpacked, times the leaf's multiplier, plus its
+// offset) where the sample belongs and skips the neighbours, the prediction and the registers that slide along the row above -- the
+// straight-line step without any of that (no lane of the wavefront predicting) is 65 instructions instead of 100-165 --, and
+// k_lf_predict (lf_decode.hip) adds the predictions afterwards, a wavefront per section, 64 rows at a time each three columns behind
+// the row above (lf_predict_* below: the neighbour rules of j40.h:3965-3990 and the predictors of j40.h:4080 on final samples; the
+// first sample that leaves the int16 range is "povf" if it lies before whatever else ended the lane). A residual that does not fit
+// the plane's 16 bits says nothing about its sample (the prediction may bring it back): the lane reports ERR_LFFB and the host
+// decodes the section, as for any other form the device does not take.
 #pragma once
 #include "lf_lanes_dev.h"
+#include "modular_dev.h"
 
 namespace j40hip {
+
+enum { LF_USES_RAW = 1u << 8 };   // LfRowTables::uses: leaf-only channels leave residuals for k_lf_predict (set by the kernel, not the host's tree scan)
+// DevLfResult::raw_mask: four bits per channel 0..6, predictor + 1 of a channel left as residuals (0: the channel holds samples);
+// DevLfResult::stopped_at: channel << 24 | samples of that channel completed, where the lane ended (7 << 24: all of the section)
+J40_DEV uint32_t lf_stopped_at(int32_t chan, int32_t done) { return ((uint32_t) chan << 24) | (uint32_t) done; }
 
 enum { LF_ROW_WIN = 256,             // samples per lane window: an LfGroup is at most 256 cells wide (2048 pixels)
        LF_ROW_PITCH = LF_ROW_WIN + 2 };   // int16 units between the windows of neighbouring lanes (129 dwords: lanes at the same x hit distinct banks)
@@ -74,6 +90,8 @@ struct LfRowLane {
 	// that predict alike
 	int32_t plain_left;                // how many of the lane's next samples take the straight-line step (set by the general step)
 	bool live;                         // not finished (lf_row_done), as of the lane's last general step
+	bool raw;                          // the channel is left as residuals (the header of this file)
+	uint32_t raw_mask, stopped_at;     // DevLfResult's words
 	bool plain_ok, plain_wide;         // plain_wide: rows wider than the window, and nothing of the channel looks at the row above
 	int32_t k_thr; uint32_t k_word_gt, k_word_le;            // the test's threshold; the leaf words behind "greater" and "not greater"
 	int32_t c_x, c_y, c_w, c_n, c_nw, c_ne, c_ww, c_nww;     // the tested property as a signed sum of position and neighbours ...
@@ -82,7 +100,12 @@ struct LfRowLane {
 	int32_t p_mul, p_off;                                    // the leaves' multiplier and offset
 };
 
-J40_DEV void lf_row_fail(LfRowLane &L, uint32_t e) { if (!L.err) L.err = e; L.chan = 7; L.setup = false; }
+// (where a lane ends: the channel it was in and how many of its samples are complete -- x, y still say so)
+J40_DEV void lf_row_fail(LfRowLane &L, uint32_t e) {
+	if (!L.err) L.err = e;
+	if (L.chan < 7) L.stopped_at = lf_stopped_at(L.chan, L.setup ? 0 : L.y * L.cw + L.x);
+	L.chan = 7; L.setup = false;
+}
 J40_DEV bool lf_row_done(const LfRowLane &L) { return L.chan == 7 && !L.setup; }
 
 J40_DEV uint32_t lf_row_take(LfRowLane &L, int32_t n) {   // header bits (n <= 31)
@@ -106,6 +129,7 @@ J40_DEV void lf_row_init(LfRowLane &L, const J40_GLOBAL DevLfTask &t, J40_LDS in
 	L.pw = L.pww = 0; L.a0 = L.a1 = L.a2 = L.a3 = L.a4 = 0; L.row = nullptr; L.win = win;
 	L.flush_n = 0; L.flush_dst = nullptr;
 	L.plain_left = 0; L.live = true;
+	L.raw = false; L.raw_mask = 0; L.stopped_at = lf_stopped_at(7, 0);
 	L.plain_ok = L.plain_wide = false; L.k_thr = 0; L.k_word_gt = L.k_word_le = 0;
 	L.c_x = L.c_y = L.c_w = L.c_n = L.c_nw = L.c_ne = L.c_ww = L.c_nww = 0; L.c_abs = L.c_first = false;
 	L.p_kind = 0; L.p_w = L.p_n = L.p_nw = L.p_ne = L.p_ww = 0; L.p_half = false; L.p_mul = 1; L.p_off = 0;
@@ -118,7 +142,7 @@ J40_DEV void lf_row_init(LfRowLane &L, const J40_GLOBAL DevLfTask &t, J40_LDS in
 // predict with the clamped gradient throughout --, the predictor one of 0..5, 7..12, the rows no wider than the window, and no
 // token of the leaves' clusters may ask for a second refill. Fills in the channel's constants; any other channel keeps the general step.
 J40_DEV void lf_row_plan_channel(LfRowLane &L, const LfRowTables &T) {
-	L.plain_ok = L.plain_wide = false;
+	L.plain_ok = L.plain_wide = false; L.raw = false;
 	DevTreeNode leaf;
 	leaf.prop = L.r_prop; leaf.value = L.r_value; leaf.a = L.r_a; leaf.b = L.r_b;
 	L.c_x = L.c_y = L.c_w = L.c_n = L.c_nw = L.c_ne = L.c_ww = L.c_nww = 0; L.c_abs = L.c_first = false; L.k_thr = 0;
@@ -168,6 +192,13 @@ J40_DEV void lf_row_plan_channel(LfRowLane &L, const LfRowTables &T) {
 		L.plain_wide = true;
 	}
 	L.plain_ok = true;
+	// a single leaf: residuals now, predictions later -- rows wider than the window only when there is nothing to predict (a wide
+	// row's prediction would be one lane's walk along it)
+	const int32_t predictor = -1 - leaf.prop;
+	if ((T.uses & (uint32_t) LF_USES_RAW) && L.r_prop < 0 && (!L.plain_wide || predictor == 0)) {
+		L.raw = true;
+		L.raw_mask |= (uint32_t) (predictor + 1) << (4 * L.chan);
+	}
 }
 
 // starts channel L.chan: as lf_lane_setup, and fetches the node the channel's walk starts from
@@ -212,6 +243,12 @@ J40_DEV void lf_row_setup(LfRowLane &L, const J40_GLOBAL DevLfTask &t, const LfR
 // the lane's next step.
 J40_DEV void lf_row_step_general(LfRowLane &L, const J40_GLOBAL DevLfTask &t, const LfRowTables &T) {
 	if (lf_row_done(L)) return;
+	if (L.err) {   // the straight-line step raised it (lf_plain_commit moved x past the sample): the lane ends here, x - 1 samples into its row
+		L.x -= 1;
+		if (L.raw && !L.plain_wide && L.x > 0) { L.flush_n = L.x; L.flush_dst = L.row; }   // (k_lf_predict looks at the samples before it)
+		lf_row_fail(L, L.err);
+		return;
+	}
 	if (L.setup) { lf_row_setup(L, t, T); if (L.chan == 7 || L.err) return; }
 	lane_bits_refill(L.b);
 	const int32_t x = L.x, y = L.y, cw = L.cw;
@@ -246,7 +283,7 @@ J40_DEV void lf_row_step_general(LfRowLane &L, const J40_GLOBAL DevLfTask &t, co
 	const uint32_t word = (uint32_t) n.value;
 	const int32_t u = lane_symbol_in_cluster(L.b, L.state, T.alias, T.log_alpha, T.log_bucket, word >> 24, word & (uint32_t) LF_LEAF_CFG_MASK, L.end_bit, &e2);
 	int32_t v = unpack_signed_dev(u) * n.b + n.a;
-	switch (-1 - n.prop) {   // j40.h:4080
+	if (!L.raw) switch (-1 - n.prop) {   // j40.h:4080
 	case 0: break;
 	case 1: v += pw; break;
 	case 2: v += pn; break;
@@ -261,8 +298,11 @@ J40_DEV void lf_row_step_general(LfRowLane &L, const J40_GLOBAL DevLfTask &t, co
 	case 12: v += (pn + pne) / 2; break;
 	default: v += (6 * pn - 2 * pnn + 7 * pw + pww + pnee + 3 * pne + 8) / 16; break;   // 13
 	}
-	if (e2) { lf_row_fail(L, e2); return; }
-	if (v < -32768 || v > 32767) { lf_row_fail(L, ERR_POVF); return; }
+	if (e2 || v < -32768 || v > 32767) {
+		if (L.raw && !wide && x > 0) { L.flush_n = x; L.flush_dst = L.row; }
+		lf_row_fail(L, e2 ? e2 : L.raw ? (uint32_t) ERR_LFFB : (uint32_t) ERR_POVF);
+		return;
+	}
 	L.win[x & (LF_ROW_WIN - 1)] = (int16_t) v;
 	L.pww = L.pw; L.pw = v;
 	L.a0 = L.a1; L.a1 = L.a2; L.a2 = L.a3; L.a3 = L.a4;
@@ -335,7 +375,8 @@ J40_DEV int32_t lf_unzigzag(int32_t u) { return (int32_t) ((uint32_t) u >> 1) ^ 
 enum { LF_NEED_TEST = 1,    // some lane's channel has a test (two different leaf words)
        LF_NEED_LIN = 2, LF_NEED_SEL = 4, LF_NEED_GRAD = 8,   // the predictions some lane uses: a (halved) sum of neighbours, "select", the clamped gradient
        LF_NEED_MUL = 16,    // some lane's leaves have a multiplier other than 1 or an offset
-       LF_NEED_ALL = 31 };
+       LF_NEED_ALL = 31,
+       LF_NEED_PRED = LF_NEED_TEST | LF_NEED_LIN | LF_NEED_SEL | LF_NEED_GRAD };   // none of these: every lane of the step is in a RAW channel
 
 struct LfPlainCtx {
 	int32_t x, slot, ahead3, pw, pn, pnw, pne, pww;
@@ -354,6 +395,13 @@ J40_DEV void lf_plain_front(LfRowLane &L, const LfRowTables &T, LfPlainCtx &c) {
 	}
 	const int32_t x = L.x, y = L.y, cw = L.cw;
 	c.x = x; c.slot = x & (LF_ROW_WIN - 1);   // (= x unless the row is wider than the window)
+	if (!(NEED & LF_NEED_PRED)) {   // residuals only: no neighbour is looked at
+		c.ahead3 = 0; c.pw = c.pn = c.pnw = c.pne = c.pww = 0;
+		c.word = L.k_word_le;
+		c.idx = L.state & 0xfff; c.bucket = c.idx >> T.log_bucket;
+		c.entry = T.alias[((c.word >> 24) << T.log_alpha) + c.bucket];
+		return;
+	}
 	c.ahead3 = L.win[c.slot + 3];   // the row above at x + 3, for the next sample's registers (slots past the row's end are never looked at)
 	const bool up = y > 0, left = x > 0;
 	const int32_t pw = left ? L.pw : up ? L.a2 : 0;
@@ -419,19 +467,24 @@ J40_DEV int32_t lf_plain_middle(LfRowLane &L, const LfRowTables &T, const LfPlai
 		const int32_t grad = mod_gradient(c.pw, c.pn, c.pnw);
 		pred = (NEED & (LF_NEED_LIN | LF_NEED_SEL)) ? (L.p_kind == 2 ? grad : pred) : grad;
 	}
-	const int32_t v = ((NEED & LF_NEED_MUL) ? lf_unzigzag(u) * L.p_mul + L.p_off : lf_unzigzag(u)) + pred;
-	*code = e2 ? e2 : v < -32768 || v > 32767 ? (uint32_t) ERR_POVF : 0u;
+	const int32_t res = (NEED & LF_NEED_MUL) ? lf_unzigzag(u) * L.p_mul + L.p_off : lf_unzigzag(u);
+	const int32_t v = (NEED & LF_NEED_PRED) ? res + (L.raw ? 0 : pred) : res;
+	const uint32_t range = (NEED & LF_NEED_PRED) ? (L.raw ? (uint32_t) ERR_LFFB : (uint32_t) ERR_POVF) : (uint32_t) ERR_LFFB;   // (a residual too wide for the plane: the header of this file)
+	*code = e2 ? e2 : v < -32768 || v > 32767 ? range : 0u;
 	return v;
 }
 
-// an error ends the lane (what it leaves behind is never looked at); otherwise the sample is stored and the registers slide
+// an error ends the lane's run (the general step it goes to next ends the lane and notes where: what the failing sample left in the
+// window is never looked at); otherwise the sample is stored and the registers slide
+template <uint32_t NEED>
 J40_DEV void lf_plain_commit(LfRowLane &L, const LfPlainCtx &c, int32_t v, uint32_t code) {
 	L.err = L.err ? L.err : code;
-	L.chan = code ? 7 : L.chan;
-	L.plain_left = code ? 0 : L.plain_left - 1;   // (after an error the general step finds the lane finished)
+	L.plain_left = code ? 0 : L.plain_left - 1;
 	L.win[c.slot] = (int16_t) v;
-	L.pww = L.pw; L.pw = v;
-	L.a0 = L.a1; L.a1 = L.a2; L.a2 = L.a3; L.a3 = L.a4; L.a4 = c.ahead3;
+	if (NEED & LF_NEED_PRED) {
+		L.pww = L.pw; L.pw = v;
+		L.a0 = L.a1; L.a1 = L.a2; L.a2 = L.a3; L.a3 = L.a4; L.a4 = c.ahead3;
+	}
 	L.x = c.x + 1;
 }
 
@@ -440,13 +493,14 @@ J40_DEV void lf_row_step_plain_for(LfRowLane &L, const LfRowTables &T) {
 	LfPlainCtx c; uint32_t code;
 	lf_plain_front<NEED>(L, T, c);
 	const int32_t v = lf_plain_middle<NEED>(L, T, c, &code);
-	lf_plain_commit(L, c, v, code);
+	lf_plain_commit<NEED>(L, c, v, code);
 }
 J40_DEV void lf_row_step_plain(LfRowLane &L, const LfRowTables &T) { lf_row_step_plain_for<LF_NEED_ALL>(L, T); }
 
 // this lane's share of the wavefront's needs (0 for a lane that takes no plain step)
 J40_DEV uint32_t lf_plain_needs(const LfRowLane &L) {
 	if (!(L.live & L.plain_ok)) return 0;
+	if (L.raw) return L.p_mul != 1 || L.p_off != 0 ? (uint32_t) LF_NEED_MUL : 0u;   // (nothing of the prediction)
 	return (L.k_word_gt != L.k_word_le ? (uint32_t) LF_NEED_TEST : 0u) | (L.p_kind == 0 ? (uint32_t) LF_NEED_LIN : L.p_kind == 1 ? (uint32_t) LF_NEED_SEL : (uint32_t) LF_NEED_GRAD)
 		| (L.p_mul != 1 || L.p_off != 0 ? (uint32_t) LF_NEED_MUL : 0u);
 }
@@ -495,8 +549,64 @@ J40_DEV void lf_row_step_plain2(LfRowLane &A, LfRowLane &B, const LfRowTables &T
 	lf_plain_front<LF_NEED_ALL>(B, TB, cb);
 	const int32_t va = lf_plain_middle<LF_NEED_ALL>(A, TA, ca, &code_a);
 	const int32_t vb = lf_plain_middle<LF_NEED_ALL>(B, TB, cb, &code_b);
-	lf_plain_commit(A, ca, va, code_a);
-	lf_plain_commit(B, cb, vb, code_b);
+	lf_plain_commit<LF_NEED_ALL>(A, ca, va, code_a);
+	lf_plain_commit<LF_NEED_ALL>(B, cb, vb, code_b);
+}
+
+// ---- the predictions of RAW channels (k_lf_predict; tests/hostsim runs the serial form) ----
+// where channel `chan` of a section lies and how large it is (as lf_row_setup has it)
+J40_DEV J40_GLOBAL int16_t *lf_channel_plane(const J40_GLOBAL DevLfTask &t, int32_t chan, int32_t nb_varblocks, int32_t *cw, int32_t *chh) {
+	switch (chan) {
+	case 0: case 1: case 2: *cw = t.w8; *chh = t.h8; return (J40_GLOBAL int16_t *) t.lf[chan];
+	case 3: *cw = t.w64; *chh = t.h64; return (J40_GLOBAL int16_t *) t.xfromy;
+	case 4: *cw = t.w64; *chh = t.h64; return (J40_GLOBAL int16_t *) t.bfromy;
+	case 5: *cw = nb_varblocks; *chh = 2; return (J40_GLOBAL int16_t *) t.info;
+	default: *cw = t.w8; *chh = t.h8; return (J40_GLOBAL int16_t *) t.sharp;
+	}
+}
+// how many samples of channel `chan` the lane completed, given where it stopped
+J40_DEV int32_t lf_channel_complete(uint32_t stopped_at, int32_t chan, int32_t cw, int32_t chh) {
+	const int32_t at_chan = (int32_t) (stopped_at >> 24), done = (int32_t) (stopped_at & 0xffffffu);
+	return chan < at_chan ? cw * chh : chan == at_chan ? done : 0;
+}
+// one sample: residual + prediction from the (final) neighbours, edge rules of j40.h:3965-3990
+J40_DEV int32_t lf_predict_value(int32_t res, int32_t predictor, int32_t x, int32_t y, int32_t cw, int32_t w, int32_t ww, int32_t nww, int32_t nw, int32_t n, int32_t ne) {
+	ModNeigh p;
+	p.w = x > 0 ? w : y > 0 ? n : 0;
+	p.n = y > 0 ? n : p.w;
+	p.nw = x > 0 && y > 0 ? nw : p.w;
+	p.ne = x + 1 < cw && y > 0 ? ne : p.n;
+	p.ww = x > 1 ? ww : p.w;
+	p.nww = x > 1 && y > 0 ? nww : p.ww;
+	p.nn = p.n; p.nee = p.ne;   // (no channel left as residuals predicts from them: lf_row_plan_channel)
+	const ModWP no_wp = ModWP();
+	uint32_t err = 0;
+	return res + mod_predict(predictor, no_wp, p, &err);
+}
+// the first `limit` samples of a channel, in place, one after the other; returns the first position that leaves the int16 range (-1: none)
+J40_DEV int32_t lf_predict_channel_serial(J40_GLOBAL int16_t *plane, int32_t cw, int32_t limit, int32_t predictor) {
+	int32_t first = -1;
+	for (int32_t pos = 0; pos < limit; ++pos) {
+		const int32_t y = pos / cw, x = pos - y * cw;
+		const J40_GLOBAL int16_t *up = plane + (pos - x - cw), *row = plane + (pos - x);
+		const int32_t v = lf_predict_value(plane[pos], predictor, x, y, cw, x > 0 ? row[x - 1] : 0, x > 1 ? row[x - 2] : 0, x > 1 && y > 0 ? up[x - 2] : 0,
+			x > 0 && y > 0 ? up[x - 1] : 0, y > 0 ? up[x] : 0, x + 1 < cw && y > 0 ? up[x + 1] : 0);
+		if ((v < -32768 || v > 32767) && first < 0) first = pos;
+		plane[pos] = (int16_t) v;
+	}
+	return first;
+}
+// a section's RAW channels in stream order (serial); returns the section's status: "povf" if a sample before the place the lane
+// stopped leaves the range, else the lane's
+J40_DEV uint32_t lf_predict_section_serial(const J40_GLOBAL DevLfTask &t, uint32_t status, int32_t nb_varblocks, uint32_t raw_mask, uint32_t stopped_at) {
+	for (int32_t chan = 0; chan < 7; ++chan) {
+		const int32_t nib = (int32_t) ((raw_mask >> (4 * chan)) & 15u);
+		if (nib < 2) continue;   // samples already (0), or nothing to add (predictor 0)
+		int32_t cw, chh;
+		J40_GLOBAL int16_t *plane = lf_channel_plane(t, chan, nb_varblocks, &cw, &chh);
+		if (lf_predict_channel_serial(plane, cw, lf_channel_complete(stopped_at, chan, cw, chh), nib - 1) >= 0) return ERR_POVF;
+	}
+	return status;
 }
 
 // the copy a step asked for, by the lane itself (tests/hostsim; the kernel's lanes do it together: lf_row_flush_wave)

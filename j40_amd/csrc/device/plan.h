@@ -337,7 +337,7 @@ struct HfLaunchInfo {
 // stream index sidx0), then the number of varblocks, a second Modular header and the HF metadata (x-from-y and b-from-y maps of
 // w64 x h64, the varblock-info channel of 2 rows x nb_varblocks, the sharpness map of w8 x h8; stream index sidx2). The host
 // reads what precedes the first stream (extra precision, first header) and hands over where it starts.
-struct DevLfResult { uint32_t status; int32_t nb_varblocks; };
+struct DevLfResult { uint32_t status; int32_t nb_varblocks; uint32_t raw_mask, stopped_at; };   // raw_mask / stopped_at: k_lf_rows' notes for k_lf_predict (lf_rows_dev.h), zero again once it has run
 struct DevLfTask {
 	// the frame the section belongs to (one launch takes the LfGroup sections of many frames): its codestream (padded), its
 	// global MA tree laid out for the cooperative decoder, the alias tables of its global code spec

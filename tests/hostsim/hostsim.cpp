@@ -906,7 +906,7 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_lanes_check
 		const size_t cells = (size_t) gg.width8 * (size_t) gg.height8, c64 = (size_t) gg.width64 * (size_t) gg.height64;
 		std::vector<int16_t> lf[3], xfy(c64 + 1), bfy(c64 + 1), info(2 * cells + 2), sharp(cells + 1);
 		for (int c = 0; c < 3; ++c) lf[c].assign(cells + 1, 0);
-		DevLfResult res = {0, 0};
+		DevLfResult res = {0, 0, 0, 0};
 		DevLfTask t;
 		memset(&t, 0, sizeof t);
 		t.codestream = padded.data(); t.byte_off = (uint32_t) tasks[g].byte_off; t.size = (uint32_t) tasks[g].size; t.bit_off = tasks[g].bit_off;
@@ -940,7 +940,7 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_lanes_check
 // LF_ROW_PITCH, completed pieces copied out between the steps. `win` caps the row length served from the window for the test's
 // purposes only through the stream's own sizes (LF_ROW_WIN is a compile-time constant); frames wider than 256 cells per LfGroup
 // do not exist, the varblock-info channel exercises the wide path.
-static int64_t plain_steps = 0, general_steps = 0, need_seen[32];
+static int64_t plain_steps = 0, general_steps = 0, need_seen[32], raw_seen = 0;
 static int32_t general_only = 0;
 // (how many samples of the last checks went through the straight-line step / the general one; mode 1: the general step only)
 extern "C" __attribute__((visibility("default"))) void hostsim_lf_rows_counts(int64_t *plain, int64_t *general, int32_t reset, int32_t mode) {
@@ -951,6 +951,8 @@ extern "C" __attribute__((visibility("default"))) void hostsim_lf_rows_counts(in
 }
 // (how often each combination of needs -- LF_NEED_* -- was what the stepped lanes asked for, since the library was loaded)
 extern "C" __attribute__((visibility("default"))) void hostsim_lf_rows_needs_seen(int64_t *out32) { for (int i = 0; i < 32; ++i) out32[i] = need_seen[i]; }
+// (how many channels the checks' lanes left as residuals, since the library was loaded)
+extern "C" __attribute__((visibility("default"))) int64_t hostsim_lf_rows_raw_channels() { return raw_seen; }
 extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_check(const uint8_t *buf, size_t size, int32_t lanes, int32_t *sections, int32_t *failed) {
 	const uint8_t *cs; size_t cs_size; std::vector<uint8_t> storage;
 	Frame fr;
@@ -973,6 +975,9 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_check(
 	for (DevTreeNode &n : tree) if (n.prop < 0) { const uint32_t cl = fp.lf_ctx_map[(size_t) n.value]; n.value = lf_rows_leaf_word(cl, fp.lf_cfg[cl]); }
 	LfRowTables T;
 	T.tree = tree.data(); T.alias = fp.lf_alias.data(); T.log_alpha = fp.lf_log_alpha; T.log_bucket = 12 - fp.lf_log_alpha; T.uses = fp.lf_uses;
+	// (as the kernel runs by default: leaf-only channels are left as residuals and predicted afterwards; mode bit 2: every channel predicted
+	// by its lane; two sections per lane never leave residuals)
+	if (!(general_only & 4) && !(general_only & 2)) T.uses |= (uint32_t) LF_USES_RAW;
 	if (lanes < 1) lanes = 1;
 	if (lanes > 64) lanes = 64;
 	struct Out { std::vector<int16_t> lf[3], xfy, bfy, info, sharp; DevLfResult res; DevLfTask t; };
@@ -989,7 +994,7 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_check(
 			Out &o = out[k];
 			for (int c = 0; c < 3; ++c) o.lf[c].assign(cells + 1, 0);
 			o.xfy.assign(c64 + 1, 0); o.bfy.assign(c64 + 1, 0); o.info.assign(2 * cells + 2, 0); o.sharp.assign(cells + 1, 0);
-			o.res = DevLfResult{0, 0};
+			o.res = DevLfResult{0, 0, 0, 0};
 			DevLfTask &t = o.t;
 			memset(&t, 0, sizeof t);
 			t.codestream = padded.data(); t.byte_off = (uint32_t) tasks[g].byte_off; t.size = (uint32_t) tasks[g].size; t.bit_off = tasks[g].bit_off;
@@ -1032,8 +1037,10 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_check(
 			LfRaw raw;
 			try { BitReader sr(cs + fr.toc.lf_groups[g].offset, fr.toc.lf_groups[g].size); read_lf_group_raw(sr, fr, gg, &raw); } catch (const DecodeError &e) { host_err = e.code; }
 			if (sections) ++*sections;
-			if (L[k].err == (uint32_t) ERR_LFFB) continue;
-			if (L[k].err != host_err) return (int32_t) (10 * g + 1);
+			for (int c = 0; c < 7; ++c) if ((L[k].raw_mask >> (4 * c)) & 15u) ++raw_seen;
+			const uint32_t status = lf_predict_section_serial(out[k].t, L[k].err, L[k].nb_varblocks, L[k].raw_mask, L[k].stopped_at);   // k_lf_predict's part
+			if (status == (uint32_t) ERR_LFFB) continue;
+			if (status != host_err) return (int32_t) (10 * g + 1);
 			if (host_err) { if (failed) ++*failed; continue; }
 			if (L[k].nb_varblocks != raw.nb_varblocks) return (int32_t) (10 * g + 2);
 			for (int c = 0; c < 3; ++c) if (memcmp(out[k].lf[c].data(), raw.lf[c].data(), cells * 2) != 0) return (int32_t) (10 * g + 3 + c);
@@ -1044,6 +1051,80 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_check(
 		}
 	}
 	return 0;
+}
+
+// The wavefront's schedule as k_lf_rows runs it (lf_decode.hip: runs of plain steps until some live lane leaves its run, then the general
+// step for those lanes), over `copies` x the frame's sections side by side: how many wave-level plain iterations and general-step
+// rounds a wavefront goes through, and per combination of needs how many plain iterations -- what the kernel's duration is made of
+// (MEASUREMENT AID for tools/lf_rows_schedule.py; decodes into scratch planes, checks nothing).
+// out: [0] plain iterations, [1] general rounds, [2] samples of the longest lane, [3] samples of all lanes, [4 + need] plain iterations by need
+extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_schedule(const uint8_t *buf, size_t size, int32_t copies, int64_t *out36) {
+	const uint8_t *cs; size_t cs_size; std::vector<uint8_t> storage;
+	Frame fr;
+	std::vector<LfDeviceTask> tasks; std::vector<int32_t> extra_prec; bool plain = true;
+	try {
+		extract_codestream(buf, size, &cs, &cs_size, &storage);
+		if (!parse_frame_front(cs, cs_size, &fr, &tasks, &extra_prec, &plain)) return -1;
+	} catch (const DecodeError &) { return -1; }
+	if (!plain) return -1;
+	StaticTables st;
+	build_static_tables(fr, &st);
+	FrontPlan fp;
+	if (build_front_plan(fr, st, cs_size, extra_prec, true, &fp) || !fp.lf_device) return -1;
+	std::vector<uint8_t> padded(cs, cs + cs_size);
+	padded.resize(cs_size + 32, 0);
+	std::vector<DevTreeNode> tree = fp.lf_tree;
+	for (DevTreeNode &n : tree) if (n.prop < 0) { const uint32_t cl = fp.lf_ctx_map[(size_t) n.value]; n.value = lf_rows_leaf_word(cl, fp.lf_cfg[cl]); }
+	LfRowTables T;
+	T.tree = tree.data(); T.alias = fp.lf_alias.data(); T.log_alpha = fp.lf_log_alpha; T.log_bucket = 12 - fp.lf_log_alpha; T.uses = fp.lf_uses;
+	if (copies > 0) T.uses |= (uint32_t) LF_USES_RAW;   // (copies < 0: every channel predicted by its lane)
+	copies = copies < 0 ? -copies : copies;
+	struct Out { std::vector<int16_t> lf[3], xfy, bfy, info, sharp; DevLfResult res; DevLfTask t; };
+	const size_t ng = fr.lf_groups.size(), n = std::min((size_t) 64, ng * (size_t) std::max(copies, 1));
+	std::vector<Out> out(n);
+	std::vector<LfRowLane> L(n);
+	std::vector<int16_t> wins((size_t) LF_ROW_PITCH * n, 0);
+	for (size_t k = 0; k < n; ++k) {
+		const size_t g = k % ng;
+		const LfGroup &gg = fr.lf_groups[g];
+		const size_t cells = (size_t) gg.width8 * (size_t) gg.height8, c64 = (size_t) gg.width64 * (size_t) gg.height64;
+		Out &o = out[k];
+		for (int c = 0; c < 3; ++c) o.lf[c].assign(cells + 1, 0);
+		o.xfy.assign(c64 + 1, 0); o.bfy.assign(c64 + 1, 0); o.info.assign(2 * cells + 2, 0); o.sharp.assign(cells + 1, 0);
+		o.res = DevLfResult{0, 0, 0, 0};
+		DevLfTask &t = o.t;
+		memset(&t, 0, sizeof t);
+		t.codestream = padded.data(); t.byte_off = (uint32_t) tasks[g].byte_off; t.size = (uint32_t) tasks[g].size; t.bit_off = tasks[g].bit_off;
+		t.w8 = gg.width8; t.h8 = gg.height8; t.w64 = gg.width64; t.h64 = gg.height64; t.sidx0 = tasks[g].sidx0; t.sidx2 = tasks[g].sidx2; t.nbvb_bits = tasks[g].nbvb_bits;
+		for (int c = 0; c < 3; ++c) t.lf[c] = o.lf[c].data();
+		t.xfromy = o.xfy.data(); t.bfromy = o.bfy.data(); t.info = o.info.data(); t.sharp = o.sharp.data(); t.info_capacity = (uint32_t) (2 * cells); t.result = &o.res;
+		lf_row_init(L[k], t, wins.data() + (size_t) LF_ROW_PITCH * k);
+	}
+	for (int i = 0; i < 36; ++i) out36[i] = 0;
+	std::vector<int64_t> samples(n, 0);
+	uint32_t need = LF_NEED_ALL;
+	for (;;) {
+		for (;;) {   // lf_row_run_plain_for
+			bool any_plain = false;
+			for (size_t k = 0; k < n; ++k) any_plain |= L[k].plain_left > 0;
+			if (!any_plain) break;
+			++out36[0]; ++out36[4 + (need & 31)];
+			for (size_t k = 0; k < n; ++k) if (L[k].plain_left > 0) { lf_row_step_plain_needs(L[k], T, need); ++samples[k]; }
+			bool leave = false;
+			for (size_t k = 0; k < n; ++k) leave |= !(L[k].plain_left > 0) && L[k].live;
+			if (leave) break;
+		}
+		++out36[1];
+		for (size_t k = 0; k < n; ++k) if (!(L[k].plain_left > 0)) { const bool was = L[k].live && !L[k].setup; lf_row_step(L[k], out[k].t, T); if (was) ++samples[k]; }
+		for (size_t k = 0; k < n; ++k) if (L[k].flush_n > 0) lf_row_flush_serial(L[k]);
+		bool live = false;
+		for (size_t k = 0; k < n; ++k) live |= L[k].live;
+		if (!live) break;
+		need = 0;
+		for (size_t k = 0; k < n; ++k) need |= lf_plain_needs(L[k]);
+	}
+	for (size_t k = 0; k < n; ++k) { out36[2] = std::max(out36[2], samples[k]); out36[3] += samples[k]; }
+	return (int32_t) n;
 }
 
 // ---- known-answer hooks for the inverse Squeeze step (device/squeeze_dev.h), tests/test_squeeze.py ----

@@ -140,7 +140,11 @@ def test_lf_row_window_decoder_equals_the_host_decoder(lanes, mode, w, h, seed, 
     reference's j40__lf_group by tests/test_host.py). The varblock-info channel (2 rows of hundreds to thousands of samples) is the
     case of rows wider than the window."""
     lanes.hostsim_lf_rows_counts.argtypes = [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32, C.c_int32]
-    for nl, general_only in ((1, 0), (64, 0), (3, 1), (64, 2), (5, 2)):   # (mode 2: two sections per lane, as k_lf_rows<true> steps them)
+    # (mode bit 1: two sections per lane, as k_lf_rows<true> steps them; bit 2: no channel left as residuals for k_lf_predict -- the
+    # default leaves every leaf-only channel, predicted afterwards by lf_predict_section_serial, the kernel's arithmetic in stream order)
+    lanes.hostsim_lf_rows_raw_channels.restype = C.c_int64
+    raw_before = lanes.hostsim_lf_rows_raw_channels()
+    for nl, general_only in ((1, 0), (64, 0), (3, 1), (64, 2), (5, 2), (64, 4), (7, 5)):
         lanes.hostsim_lf_rows_counts(None, None, 1, general_only)
         rc, n, bad = rows_check(lanes, synth(mode, w, h, seed, **opts), nl)
         plain, general = C.c_int64(), C.c_int64()
@@ -155,6 +159,8 @@ def test_lf_row_window_decoder_equals_the_host_decoder(lanes, mode, w, h, seed, 
             assert plain.value == 0 and general.value > 0
         else:
             assert plain.value > 20 * general.value, (plain.value, general.value)
+    if not opts.get("alpha") and not opts.get("lftree"):   # the default LF tree: X, B and the HF metadata channels hang under single leaves
+        assert lanes.hostsim_lf_rows_raw_channels() > raw_before
 
 
 def test_lf_row_window_decoder_fails_like_the_host_decoder(lanes):
@@ -196,9 +202,11 @@ def test_lf_row_window_decoder_specialised_steps_all_ran(lanes):
     predictions, multipliers); the cases above and below run at least eight different combinations through it, each against the host
     decoder's planes"""
     for (w, h, seed, opts) in [(2600, 2100, 61, dict(lftree=2)), (2600, 2100, 62, dict(lftree=3)), (1920, 1080, 34, dict(forward=1)), (520, 264, 63, dict(lftree=2, cfl=1))]:
-        for nl in (1, 2, 64):
-            rc, n, bad = rows_check(lanes, synth("vardct", w, h, seed, **opts), nl)
-            assert rc == 0 and bad == 0
+        for general_only in (4, 0):   # every channel predicted by its lane (the combinations of predictions), then the default
+            lanes.hostsim_lf_rows_counts(None, None, 1, general_only)
+            for nl in (1, 2, 64):
+                rc, n, bad = rows_check(lanes, synth("vardct", w, h, seed, **opts), nl)
+                assert rc == 0 and bad == 0
     seen = (C.c_int64 * 32)()
     lanes.hostsim_lf_rows_needs_seen(seen)
     used = [i for i in range(32) if seen[i]]

@@ -35,6 +35,11 @@ __global__ void __launch_bounds__(256) k(uint64_t *out, const uint32_t *chase, u
 		if (KIND == 11) { R16(gp = chase + *(volatile const uint32_t *) gp;) }   // dependent global loads (L2 / L1 hits)
 		if (KIND == 12) { R16({ const uint64_t v = ((volatile uint64_t *) lds)[addr >> 3]; addr = (uint32_t) v & 8184u; }) }
 		if (KIND == 13) { R16(asm volatile("v_bfe_u32 %0, %0, 0, 31\n v_lshlrev_b32 %0, 1, %0" : "+v"(a));) }
+		if (KIND == 15) { R16(asm volatile("v_add_u32_e64 %0, %0, %1" : "+v"(a) : "v"(kk));) }   // the 8-byte encoding of the same instruction
+		if (KIND == 16) { R16(asm volatile("v_add_u32_e64 %0, %0, %4\n v_add_u32_e64 %1, %1, %4\n v_add_u32_e64 %2, %2, %4\n v_add_u32_e64 %3, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(kk));) }
+		if (KIND == 17) { R16(asm volatile("v_add_u32 %0, 0x12345, %0\n v_add_u32 %1, 0x12345, %1\n v_add_u32 %2, 0x12345, %2\n v_add_u32 %3, 0x12345, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }   // 4 + 4 bytes of literal
+		if (KIND == 18) { R16(asm volatile("v_add3_u32 %0, %0, %4, %4\n v_add3_u32 %1, %1, %4, %4\n v_add3_u32 %2, %2, %4, %4\n v_add3_u32 %3, %3, %4, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(kk));) }
+		if (KIND == 19) { R16(asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n s_add_u32 s20, s20, 1\n s_add_u32 s21, s21, 1\n s_add_u32 s22, s22, 1\n s_add_u32 s23, s23, 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(kk) : "s20", "s21", "s22", "s23", "scc");) }   // vector and scalar side by side
 		if (KIND == 14) { R16(sink[64 + (threadIdx.x & 63)] = a; gp = chase + *(volatile const uint32_t *) gp;) }   // a store in flight before every dependent load
 	}
 	const uint64_t t1 = __builtin_readcyclecounter();
@@ -62,14 +67,14 @@ int main() {
 	int clk = 0; hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0);
 	printf("{\"clock_khz\": %d,\n", clk); fflush(stdout);
 	const char *names[] = {"v_add dependent", "v_add 2 chains (per instr)", "v_add 4 chains (per instr)", "v_lshrrev_b64 dependent", "ds_read_b32 chase", "v_cmp+v_cndmask pair",
-		"v_mul_lo_u32 dependent", "readfirstlane+s_add+v_mov triple", "s_add dependent", "if-block not skipped (5 instr)", "if-block skipped, branch taken (4 instr)", "global load chase", "ds_read_b64 chase", "v_bfe+v_lshl pair", "store + global load chase"};
+		"v_mul_lo_u32 dependent", "readfirstlane+s_add+v_mov triple", "s_add dependent", "if-block not skipped (5 instr)", "if-block skipped, branch taken (4 instr)", "global load chase", "ds_read_b64 chase", "v_bfe+v_lshl pair", "store + global load chase", "v_add_u32_e64 (8-byte encoding) dependent", "v_add_u32_e64 4 chains (per instr)", "v_add_u32 with a 32-bit literal, 4 chains (per instr)", "v_add3_u32 4 chains (per instr)", "4 v_add chains + 4 s_add chains (per instr)"};
 	for (int w = 0; w < 2; ++w) {   // (a third row of 512 lanes -- two wavefronts per SIMD -- never launched under __launch_bounds__(256) and repeated a stale counter: dropped)
 		const int threads = w == 0 ? 64 : 256;   // 1 wavefront; 4 = one per SIMD
 		printf(" \"%d wavefronts in the workgroup (cycles per unit on wavefront 0)\": {", threads / 64);
 		typedef double (*RunFn)(int, int, uint64_t *, uint32_t *, uint32_t *);
-		const RunFn fns[15] = {run<0>, run<1>, run<2>, run<3>, run<4>, run<5>, run<6>, run<7>, run<8>, run<9>, run<10>, run<11>, run<12>, run<13>, run<14>};
-		const int per[15] = {1, 2, 4, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
-		for (int i = 0; i < 15; ++i) { printf("%s\"%s\": %.1f", i ? ", " : "", names[i], fns[i](threads, per[i], out, chase, sink)); fflush(stdout); }
+		const RunFn fns[20] = {run<0>, run<1>, run<2>, run<3>, run<4>, run<5>, run<6>, run<7>, run<8>, run<9>, run<10>, run<11>, run<12>, run<13>, run<14>, run<15>, run<16>, run<17>, run<18>, run<19>};
+		const int per[20] = {1, 2, 4, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 4, 4, 4, 8};
+		for (int i = 0; i < 20; ++i) { printf("%s\"%s\": %.1f", i ? ", " : "", names[i], fns[i](threads, per[i], out, chase, sink)); fflush(stdout); }
 		printf("}%s\n", w < 1 ? "," : "");
 	}
 	printf("}\n");
