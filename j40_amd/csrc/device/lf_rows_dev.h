@@ -522,14 +522,13 @@ J40_DEV void lf_row_step_plain_needs(LfRowLane &L, const LfRowTables &T, uint32_
 // wave-uniform switch is a tree of scalar branches, too dear to walk per sample --, a stretch being hundreds of samples.
 template <uint32_t NEED>
 J40_DEV void lf_row_run_plain_for(LfRowLane &L, const LfRowTables &T) {
-	// The lanes in a run step until one of them is out of its run -- or once, when some live lane is waiting for the general step
-	// (a lane that stays in a channel of another form does not hold the others up). The execution mask is set once for the stretch:
-	// the loop's own test is a comparison of two scalars.
-	const bool plain = L.plain_left > 0;
-	const bool waiting = __builtin_amdgcn_ballot_w64(!plain & L.live) != 0;
-	if (plain) {
-		const uint64_t stepping = __builtin_amdgcn_ballot_w64(true);
-		do lf_row_step_plain_for<NEED>(L, T); while (!waiting && __builtin_amdgcn_ballot_w64(L.plain_left > 0) == stepping);
+	// (Measured in round 6: the same loop with the execution mask set once per stretch -- `if (plain) do step while (all still plain)`,
+	// the loop's own test a comparison of two scalars -- is SLOWER, 151 ms per launch against 135: profiles/r06_lf_rows_*_call_h*.)
+	for (;;) {   // (the lanes in a run step at least once per call: a lane that stays in a channel of another form does not hold them up)
+		const bool plain = L.plain_left > 0;
+		if (!__builtin_amdgcn_ballot_w64(plain)) return;
+		if (plain) lf_row_step_plain_for<NEED>(L, T);
+		if (__builtin_amdgcn_ballot_w64(!(L.plain_left > 0) & L.live)) return;
 	}
 }
 #define LF_PLAIN_CASE(n) case n: lf_row_run_plain_for<n>(L, T); break;
