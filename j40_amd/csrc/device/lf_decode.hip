@@ -240,43 +240,41 @@ __global__ void __launch_bounds__(64) k_lf_rows(const DevLfLaneSet *sets, const 
 }
 
 // The predictions of the channels k_lf_rows left as residuals (lf_rows_dev.h, RAW channels): one wavefront per section, channel after
-// channel in stream order. 64 rows at a time go to the 64 lanes, each lane three columns behind the lane above it, which hands it
-// the row above through one cross-lane move per step (k_modular_predict's scheme, modular_split.hip); the band's last row is read
-// back for the next band's first lane. A lane asks for its row's residuals eight steps before it needs them (a register per step
-// in flight: no LDS tile, so that several wavefronts share a SIMD and cover each other's waits -- with a tile of 64 rows in LDS the
-// kernel took 9.8 ms per launch of 256 frames, a wavefront per SIMD) and replaces each by its sample, once.
-// Workgroup b: section b % 64 of wavefront b / 64 of the launch's list.
-enum { LF_PREDICT_AHEAD = 8 };
+// channel in stream order. 64 rows at a time wait in LDS (copied in and out in runs of consecutive addresses: with every lane on a
+// row of its own in global memory a load or store is 64 cache lines, and the kernel took 18 ms per launch of 256 frames whether one
+// wavefront or three shared a SIMD) and go to the 64 lanes, each lane three columns behind the lane above it, which hands it the row
+// above through one cross-lane move per step (k_modular_predict's scheme, modular_split.hip); the band's last row stays behind for
+// the next band's first lane. The step is one basic block: positions outside the row read a clamped slot and write the row's spare
+// slot. A sample is read (as a residual) by the lane that replaces it, once. Workgroup b: section b % 64 of wavefront b / 64 of the
+// launch's list.
 template <int PRED>
-__device__ __forceinline__ bool lf_predict_band(J40_GLOBAL int16_t *row, const J40_LDS int32_t *above, int32_t lane, int32_t y, int32_t cw, int32_t width) {
+__device__ __forceinline__ bool lf_predict_band(J40_LDS int16_t *tile, const J40_LDS int32_t *above, int32_t lane, int32_t y, int32_t cw, int32_t width) {
+	J40_LDS int16_t *row = tile + lane * LF_ROW_PITCH;
 	int32_t r_nww = 0, r_nw = 0, r_n = 0, r_ne = 0, r_nee = 0, c_w = 0, c_ww = 0;
 	bool povf = false;
-	const int32_t last = width > 0 ? width - 1 : 0;   // (a lane without a row reads its band's first sample over and over, and stores nothing)
-	int32_t q[LF_PREDICT_AHEAD];
-#pragma unroll
-	for (int32_t k = 0; k < LF_PREDICT_AHEAD; ++k) q[k] = row[mod_min(mod_max(k - 3 * lane - 2, 0), last)];
+	const int32_t last = width > 0 ? width - 1 : 0;
+	int32_t next = row[mod_min(mod_max(-3 * lane - 2, 0), last)];   // the residual of the step to come (read a step ahead of its use)
 	const int32_t steps = cw + 3 * 63 + 3;
-	for (int32_t tstep0 = 0; tstep0 < steps; tstep0 += LF_PREDICT_AHEAD) {
-#pragma unroll
-		for (int32_t k = 0; k < LF_PREDICT_AHEAD; ++k) {
-			const int32_t x = tstep0 + k - 3 * lane - 2;   // (every lane starts two columns early: its registers fill with the row above at 0, 1, 2)
-			const int32_t res = q[k];
-			q[k] = row[mod_min(mod_max(x + LF_PREDICT_AHEAD, 0), last)];
-			int32_t in_nee = __builtin_amdgcn_ds_bpermute((lane > 0 ? lane - 1 : 0) << 2, c_w);   // the row above at x + 2: what the lane above computed a step ago
-			const int32_t from_above = above[mod_min(mod_max(x + 2, 0), LF_ROW_WIN)];
-			if (lane == 0) in_nee = x + 2 >= 0 && x + 2 < cw ? from_above : 0;
-			r_nww = r_nw; r_nw = r_n; r_n = r_ne; r_ne = r_nee; r_nee = in_nee;   // now centred on x
-			const bool valid = x >= 0 && x < width;
-			const int32_t v = lf_predict_value(res, PRED, x, y, cw, c_w, c_ww, r_nww, r_nw, r_n, r_ne);
-			povf |= valid && (v < -32768 || v > 32767);
-			if (valid) row[x] = (int16_t) v;
-			c_ww = valid ? c_w : c_ww; c_w = valid ? v : c_w;
-		}
+	for (int32_t tstep = 0; tstep < steps; ++tstep) {
+		const int32_t x = tstep - 3 * lane - 2;   // (every lane starts two columns early: its registers fill with the row above at 0, 1, 2)
+		const int32_t res = next;
+		next = row[mod_min(mod_max(x + 1, 0), last)];
+		int32_t in_nee = __builtin_amdgcn_ds_bpermute((lane > 0 ? lane - 1 : 0) << 2, c_w);   // the row above at x + 2: what the lane above computed a step ago
+		const int32_t from_above = above[mod_min(mod_max(x + 2, 0), LF_ROW_WIN)];
+		in_nee = lane == 0 ? (x + 2 >= 0 && x + 2 < cw ? from_above : 0) : in_nee;
+		r_nww = r_nw; r_nw = r_n; r_n = r_ne; r_ne = r_nee; r_nee = in_nee;   // now centred on x
+		const bool valid = x >= 0 && x < width;
+		const int32_t v = lf_predict_value(res, PRED, x, y, cw, c_w, c_ww, r_nww, r_nw, r_n, r_ne);
+		povf |= valid && (v < -32768 || v > 32767);
+		row[valid ? x : LF_ROW_WIN] = (int16_t) v;   // (slot 256 of a lane's 258 is nobody's sample)
+		c_ww = valid ? c_w : c_ww; c_w = valid ? v : c_w;
 	}
 	return povf;
 }
 __global__ void __launch_bounds__(64) k_lf_predict(const DevLfLaneSet *sets, const DevLfWave *waves) {
+	__shared__ int16_t tile_lds[64 * LF_ROW_PITCH];
 	__shared__ int32_t above_lds[LF_ROW_WIN + 4];
+	J40_LDS int16_t *tile = (J40_LDS int16_t *) tile_lds;
 	J40_LDS int32_t *above = (J40_LDS int32_t *) above_lds;
 	const J40_GLOBAL DevLfWave &wv = ((const J40_GLOBAL DevLfWave *) waves)[blockIdx.x >> 6];
 	const int32_t my_section = (int32_t) (blockIdx.x & 63), lane = threadIdx.x;
@@ -302,28 +300,38 @@ __global__ void __launch_bounds__(64) k_lf_predict(const DevLfLaneSet *sets, con
 		if (limit <= 0 || cw > LF_ROW_WIN) continue;   // (rows wider than the window are never left as residuals with something to predict)
 		const int32_t rows = (limit + cw - 1) / cw;
 		for (int32_t y0 = 0; y0 < rows; y0 += 64) {
-			__threadfence();   // (the band before wrote row y0 - 1: this wavefront's own stores, made visible to its loads)
 			__syncthreads();
-			for (int32_t x = lane; x <= LF_ROW_WIN; x += 64) above[x] = y0 > 0 && x < cw ? (int32_t) plane[(size_t) (y0 - 1) * (size_t) cw + (size_t) x] : 0;
+			for (int32_t x = lane; x <= LF_ROW_WIN; x += 64) above[x] = y0 > 0 && x < cw ? (int32_t) tile[63 * LF_ROW_PITCH + x] : 0;   // the band before left its last row
+			__syncthreads();
+			J40_GLOBAL int16_t *band = plane + (size_t) y0 * (size_t) cw;
+			const int32_t n = mod_min(limit - y0 * cw, 64 * cw);
+			{
+				int32_t ry = lane / cw, rx = lane - ry * cw;
+				for (int32_t i = lane; i < n; i += 64) { tile[ry * LF_ROW_PITCH + rx] = band[i]; rx += 64; while (rx >= cw) { rx -= cw; ++ry; } }
+			}
 			__syncthreads();
 			const int32_t y = y0 + lane;
 			const int32_t width = y < rows ? mod_min(cw, limit - y * cw) : 0;   // (the section's last row may be a piece of one)
-			J40_GLOBAL int16_t *row = plane + (size_t) (y < rows ? y : y0) * (size_t) cw;
 			bool bad;
 			switch (nib - 1) {
-			case 1: bad = lf_predict_band<1>(row, above, lane, y, cw, width); break;
-			case 2: bad = lf_predict_band<2>(row, above, lane, y, cw, width); break;
-			case 3: bad = lf_predict_band<3>(row, above, lane, y, cw, width); break;
-			case 4: bad = lf_predict_band<4>(row, above, lane, y, cw, width); break;
-			case 5: bad = lf_predict_band<5>(row, above, lane, y, cw, width); break;
-			case 7: bad = lf_predict_band<7>(row, above, lane, y, cw, width); break;
-			case 8: bad = lf_predict_band<8>(row, above, lane, y, cw, width); break;
-			case 9: bad = lf_predict_band<9>(row, above, lane, y, cw, width); break;
-			case 10: bad = lf_predict_band<10>(row, above, lane, y, cw, width); break;
-			case 11: bad = lf_predict_band<11>(row, above, lane, y, cw, width); break;
-			default: bad = lf_predict_band<12>(row, above, lane, y, cw, width); break;
+			case 1: bad = lf_predict_band<1>(tile, above, lane, y, cw, width); break;
+			case 2: bad = lf_predict_band<2>(tile, above, lane, y, cw, width); break;
+			case 3: bad = lf_predict_band<3>(tile, above, lane, y, cw, width); break;
+			case 4: bad = lf_predict_band<4>(tile, above, lane, y, cw, width); break;
+			case 5: bad = lf_predict_band<5>(tile, above, lane, y, cw, width); break;
+			case 7: bad = lf_predict_band<7>(tile, above, lane, y, cw, width); break;
+			case 8: bad = lf_predict_band<8>(tile, above, lane, y, cw, width); break;
+			case 9: bad = lf_predict_band<9>(tile, above, lane, y, cw, width); break;
+			case 10: bad = lf_predict_band<10>(tile, above, lane, y, cw, width); break;
+			case 11: bad = lf_predict_band<11>(tile, above, lane, y, cw, width); break;
+			default: bad = lf_predict_band<12>(tile, above, lane, y, cw, width); break;
 			}
 			povf |= bad;
+			__syncthreads();
+			{
+				int32_t ry = lane / cw, rx = lane - ry * cw;
+				for (int32_t i = lane; i < n; i += 64) { band[i] = tile[ry * LF_ROW_PITCH + rx]; rx += 64; while (rx >= cw) { rx -= cw; ++ry; } }
+			}
 		}
 		povf = __builtin_amdgcn_ballot_w64(povf) != 0;   // (channels follow one another in the stream: the first one with such a sample decides)
 	}
