@@ -272,7 +272,7 @@ __device__ __forceinline__ bool lf_predict_band(J40_LDS int16_t *tile, const J40
 	return povf;
 }
 __global__ void __launch_bounds__(64) k_lf_predict(const DevLfLaneSet *sets, const DevLfWave *waves) {
-	__shared__ int16_t tile_lds[64 * LF_ROW_PITCH];
+	__shared__ int16_t tile_lds[65 * LF_ROW_PITCH];   // (a row more than the band: the copy in goes two rows at a time)
 	__shared__ int32_t above_lds[LF_ROW_WIN + 4];
 	J40_LDS int16_t *tile = (J40_LDS int16_t *) tile_lds;
 	J40_LDS int32_t *above = (J40_LDS int32_t *) above_lds;
@@ -305,9 +305,21 @@ __global__ void __launch_bounds__(64) k_lf_predict(const DevLfLaneSet *sets, con
 			__syncthreads();
 			J40_GLOBAL int16_t *band = plane + (size_t) y0 * (size_t) cw;
 			const int32_t n = mod_min(limit - y0 * cw, 64 * cw);
-			{
-				int32_t ry = lane / cw, rx = lane - ry * cw;
-				for (int32_t i = lane; i < n; i += 64) { tile[ry * LF_ROW_PITCH + rx] = band[i]; rx += 64; while (rx >= cw) { rx -= cw; ++ry; } }
+			// (row by row, a lane every 64th sample of a row, eight loads asked for before the first is stored: a loop of one load and one
+			// store per turn waits for global memory 256 times a band, longer than the band's prediction takes)
+			for (int32_t ry = 0; ry * cw < n; ry += 2) {
+				int16_t a[4], b[4];
+#pragma unroll
+				for (int32_t k = 0; k < 4; ++k) {
+					const int32_t x = lane + 64 * k, i = ry * cw + x;
+					a[k] = x < cw && i < n ? band[i] : (int16_t) 0;
+					b[k] = x < cw && i + cw < n ? band[i + cw] : (int16_t) 0;
+				}
+#pragma unroll
+				for (int32_t k = 0; k < 4; ++k) {
+					const int32_t x = lane + 64 * k;
+					if (x < cw) { tile[ry * LF_ROW_PITCH + x] = a[k]; tile[(ry + 1) * LF_ROW_PITCH + x] = b[k]; }   // (ry + 1 <= 64: the tile has 64 rows and the window's two spare slots more)
+				}
 			}
 			__syncthreads();
 			const int32_t y = y0 + lane;
@@ -328,9 +340,12 @@ __global__ void __launch_bounds__(64) k_lf_predict(const DevLfLaneSet *sets, con
 			}
 			povf |= bad;
 			__syncthreads();
-			{
-				int32_t ry = lane / cw, rx = lane - ry * cw;
-				for (int32_t i = lane; i < n; i += 64) { band[i] = tile[ry * LF_ROW_PITCH + rx]; rx += 64; while (rx >= cw) { rx -= cw; ++ry; } }
+			for (int32_t ry = 0; ry * cw < n; ++ry) {
+#pragma unroll
+				for (int32_t k = 0; k < 4; ++k) {
+					const int32_t x = lane + 64 * k, i = ry * cw + x;
+					if (x < cw && i < n) band[i] = tile[ry * LF_ROW_PITCH + x];
+				}
 			}
 		}
 		povf = __builtin_amdgcn_ballot_w64(povf) != 0;   // (channels follow one another in the stream: the first one with such a sample decides)
