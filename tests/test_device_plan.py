@@ -212,3 +212,12 @@ def test_lf_row_window_decoder_specialised_steps_all_ran(lanes):
     used = [i for i in range(32) if seen[i]]
     assert len(used) >= 8, used
 
+
+
+def test_lf_row_window_decoder_on_damaged_streams_of_every_tree(lanes):
+    """tools/lf_rows_sweep.py, a short run: random sizes, the generator's four LF trees, bit flips inside the LfGroup sections; the lane
+    decoder with its residual channels predicted afterwards (k_lf_predict's arithmetic in stream order) ends every section with the
+    host decoder's code -- also where a sample of a residual channel leaves the range before whatever stopped the lane -- and the same planes"""
+    import subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lf_rows_sweep.py"), "60", "5"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-400:] + out.stderr[-400:]
