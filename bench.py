@@ -17,7 +17,7 @@ The host part runs on the CPU time the container is given (cgroup cpu.max; 16 CP
 worker threads at half a millisecond a frame. What bounds `value` is the PCIe link: 133 MB of RGBA per frame, copied back on the SDMA
 engine the library measured as the device's fastest (j40_amd/csrc/device/hostcopy.hip); DESIGN.md section 5 has the breakdown.
 
-Also on the line: `roofline` (the stage of a batch furthest below the HBM roofline -- the LfGroup launch, k_lf_rows -- with the four stages'
+Also on the line: `roofline` (the stage of a batch furthest below the HBM roofline -- the LfGroup launch, k_lf_rows + k_lf_predict -- with the four stages'
 own durations inside the timed region and alone, device-recorded); `latency_mode` (one frame alone); BASELINE.json's other configurations (`configs`); `cpu_baseline` = the
 unmodified reference on one host core, same stream; `parity_vs_reference` for a frame decoded inside the timed region.
 
@@ -185,6 +185,12 @@ def cpu_baseline_many(datas, width, height, procs, budget_s=10.0):
     return {"value": round(width * height * frames / el / 1e6, 2), "unit": "Mpixels/s", "cores": procs, "kind": "reference",
             "sample": "%d worker processes (one per CPU of the container's quota), each decoding its own %d streams %d times through the reference's public API: %d frames of %dx%d in %.2f s"
                       % (procs, per, rounds, frames, width, height, el)}
+
+
+def _lf_kernel_name():
+    if os.environ.get("J40HIP_LF_KERNEL") == "lanes":
+        return "k_lf_lanes"
+    return "k_lf_rows" if os.environ.get("J40HIP_LF_RAW") == "0" else "k_lf_rows + k_lf_predict (leaf-only channels left as residuals, predicted afterwards)"
 
 
 def synth_many(specs, workers):
@@ -527,7 +533,7 @@ def main():
                 "achieved": round(ach, 3), "frac": round(ach / 8000.0, 6), "traffic": None, "how": how}
     lfl = max(st.get("lf_launches", 0), 1)
     stages = [
-        stage("LfGroup streams (j40.h:6722-6790)", "k_lf_rows" if os.environ.get("J40HIP_LF_KERNEL") != "lanes" else "k_lf_lanes", st.get("lf_kernel_ms", 0) / lfl, st.get("lf_launch_frames", 0) / lfl,
+        stage("LfGroup streams (j40.h:6722-6790)", _lf_kernel_name(), st.get("lf_kernel_ms", 0) / lfl, st.get("lf_launch_frames", 0) / lfl,
               "device-recorded start / end events of each launch (hipExtLaunchKernelGGL), averaged over %d launches; a launch carries what was waiting, up to four batches' worth, on a low-priority stream beside the other stages, and lasts as long as its longest section whatever it carries (a section is one lane): ms_per_256_frames is what its frames' share of it comes to, not a cost per frame" % st.get("lf_launches", 0)),
         stage("plan build + LfGroup tail (j40.h:6585-6720, 6544-6590, 5944)", "k_plan_place / _scan / _emit, k_lf_dequant_smooth_batch, k_llf_small_batch, k_llf_large_batch", st["lf_plan_ms"] / launches, frames_per_launch,
               "HIP events on the batch's stream around the stage (includes what the stage waited for behind other kernels)"),
@@ -608,7 +614,7 @@ def main():
             del outs3, so3
             torch.cuda.empty_cache()
             if acc["n"]:
-                x = stage("LfGroup streams", "k_lf_rows" if os.environ.get("J40HIP_LF_KERNEL") != "lanes" else "k_lf_lanes", acc["ms"] / acc["n"], acc["frames"] / acc["n"],
+                x = stage("LfGroup streams", _lf_kernel_name(), acc["ms"] / acc["n"], acc["frames"] / acc["n"],
                           "one batch in flight, one step at a time: the launch has the device to itself (%d launches, %.0f wavefronts each)" % (acc["n"], acc["waves"] / acc["n"]))
                 if x:
                     alone_stages.insert(0, x)

@@ -4,7 +4,7 @@ counters of every kernel summed per STAGE of a batch and divided by the launches
 usage: python tools/pmc_traffic.py <fetch dir> <write dir> <out.json> <frames per batch launch> <frames per LfGroup launch> <commit> <command>"""
 import collections, csv, glob, json, re, sys
 
-STAGES = [("LfGroup streams", r"k_lf_rows|k_lf_lanes", "lf"), ("plan build + LfGroup tail", r"k_plan_|k_lf_dequant|k_llf_|k_clear_block_events", "batch"),
+STAGES = [("LfGroup streams", r"k_lf_rows|k_lf_lanes|k_lf_predict", "lf"), ("plan build + LfGroup tail", r"k_plan_|k_lf_dequant|k_llf_|k_clear_block_events", "batch"),
           ("entropy decode", r"k_hf_lanes|k_hf_entropy", "batch"), ("pixels", r"k_vardct_|k_k2_tiles", "batch")]
 
 
