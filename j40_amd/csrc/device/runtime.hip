@@ -764,7 +764,11 @@ static uint32_t upload_impl(j40hip_frame *h, int device, hipStream_t s) {
 	HostPlan &hp = t_host_plan;   // (this thread's, storage kept from frame to frame)
 	hp.reset();
 	hp.force_dense = h->force_dense;
+	static const bool timing = getenv("J40HIP_API_TIMING") != nullptr;   // (where an upload's time goes: plan build, staging, copy + LfGroup tail)
+	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double tu0 = timing ? now() : 0;
 	if (uint32_t e = build_vardct_plan(h->frame, h->cs, h->cs_size, &hp, h->threads)) return e;
+	const double tu1 = timing ? now() : 0;
 
 	j40hip_device_state *st = new j40hip_device_state();
 	h->dev = st; st->device = device; st->force_dense = h->force_dense;
@@ -795,6 +799,7 @@ static uint32_t upload_impl(j40hip_frame *h, int device, hipStream_t s) {
 	if (hp.lf_tail_pending) for (int c = 0; c < 3; ++c) o_llf[c] = sg.reserve(sizeof(float) * cells);
 	bool dummy_clean = false;
 	if (!sg.ok) ok = false;
+	const double tu2 = timing ? now() : 0;
 	st->plan_block = ok ? cache_acquire(device, sg.size, &st->plan_block_bytes, &dummy_clean) : nullptr;
 	if (!st->plan_block || hipMemcpyAsync(st->plan_block, sg.data(), copy_bytes, hipMemcpyHostToDevice, s) != hipSuccess) ok = false;
 	uint8_t *pb = (uint8_t *) st->plan_block;
@@ -857,6 +862,7 @@ static uint32_t upload_impl(j40hip_frame *h, int device, hipStream_t s) {
 	// (asleep while the copy runs, like lf_device_decode: a pipeline may have many more uploading threads than CPUs)
 	if (!t_lf_done && hipEventCreateWithFlags(&t_lf_done, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { t_lf_done = nullptr; (void) hipGetLastError(); }
 	if (t_lf_done ? (hipEventRecord(t_lf_done, s) != hipSuccess || hipEventSynchronize(t_lf_done) != hipSuccess) : hipStreamSynchronize(s) != hipSuccess) ok = false;
+	if (timing) fprintf(stderr, "[j40hip upload] plan build %.2f ms (%d threads), staging %.2f ms (%.1f MB), copy + LfGroup tail + wait %.2f ms\n", tu1 - tu0, h->threads, tu2 - tu1, (double) copy_bytes / 1e6, now() - tu2);
 	if (!ok) { j40hip_release_device(h); return ERR_GPU; }
 	return 0;
 }

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <thread>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 
 namespace j40hip {
@@ -865,7 +866,11 @@ bool parse_frame_front(const uint8_t *cs, size_t cs_size, Frame *f, std::vector<
 }
 
 void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
+	static const bool timing = getenv("J40HIP_API_TIMING") != nullptr;   // (where a parse's time goes)
+	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double tp0 = timing ? now() : 0;
 	parse_headers(cs, cs_size, f);
+	const double tp1 = timing ? now() : 0;
 
 	if (f->toc.single) {
 		// one section holds LfGlobal, HfGlobal, LfGroup and PassGroup back to back, read in the order
@@ -895,6 +900,7 @@ void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
 	}
 
 	parse_globals(cs, f);
+	const double tp2 = timing ? now() : 0;
 	// LfGroup sections are independent of each other
 	const int64_t n = f->fh.num_lf_groups;
 	std::atomic<int64_t> next(0);
@@ -968,7 +974,9 @@ void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
 		if (code) raise(code);
 	}
 	(void) first_err;
+	const double tp3 = timing ? now() : 0;
 	if (!f->fh.is_modular) prepare_tables(f);
+	if (timing) fprintf(stderr, "[j40hip parse] headers + TOC %.2f ms, LfGlobal + HfGlobal %.2f ms, %lld LfGroups on %d threads %.2f ms, tables %.2f ms\n", tp1 - tp0, tp2 - tp1, (long long) n, nthreads, tp3 - tp2, now() - tp3);
 }
 
 } // namespace j40hip
