@@ -255,12 +255,41 @@ thread_local PinnedStage t_stage;   // (no destructor: at process exit the runti
 
 struct Stager {
 	size_t size = 0; bool ok = true;
+	// deferred: put() notes the copy, flush() makes them all, shared out by bytes over a few threads (an 8K frame's plan is 30 MB: a
+	// millisecond of one core's memcpy on the single-image path); the sources have to live until then
+	bool deferred = false;
+	struct Copy { size_t off; const uint8_t *src; size_t bytes; };
+	std::vector<Copy> copies;
 	template <typename T> size_t put(const T *src, size_t n) {
 		const size_t off = (size + 255) & ~(size_t) 255, end = off + sizeof(T) * n + 16;
 		if (!ok || !t_stage.reserve(end, size)) { ok = false; return 0; }
-		if (n) memcpy(t_stage.ptr + off, src, sizeof(T) * n);
-		size = end;
+		if (n) { if (deferred) copies.push_back({off, (const uint8_t *) src, sizeof(T) * n}); else memcpy(t_stage.ptr + off, src, sizeof(T) * n); }
+		if (!deferred) size = end;
+		else size = end;   // (a grown buffer keeps the bytes below `size`: nothing of the noted copies is there yet, and nothing needs to be)
 		return off;
+	}
+	void flush(int threads) {
+		if (!deferred || !ok) { copies.clear(); return; }
+		size_t total = 0;
+		for (const Copy &c : copies) total += c.bytes;
+		const int n = total < ((size_t) 4 << 20) ? 1 : std::max(1, std::min(threads, 8));
+		uint8_t *base = t_stage.ptr;
+		auto work = [&](int t) {
+			const size_t lo = total / (size_t) n * (size_t) t, hi = t + 1 == n ? total : total / (size_t) n * (size_t) (t + 1);
+			size_t at = 0;
+			for (const Copy &c : copies) {
+				const size_t a = std::max(lo, at), b = std::min(hi, at + c.bytes);
+				if (a < b) memcpy(base + c.off + (a - at), c.src + (a - at), b - a);
+				at += c.bytes;
+			}
+		};
+		std::vector<std::thread> pool;
+		try { for (int t = 1; t < n; ++t) pool.emplace_back(work, t); } catch (const std::exception &) {}
+		const int started = (int) pool.size() + 1;
+		work(0);
+		for (int t = started; t < n; ++t) work(t);   // (threads that could not be had: their share here)
+		for (auto &th : pool) th.join();
+		copies.clear();
 	}
 	size_t reserve(size_t bytes) {   // room in the device block that nothing is copied into (the bytes staged for it are whatever is there)
 		const size_t off = (size + 255) & ~(size_t) 255, end = off + bytes + 16;
@@ -779,6 +808,7 @@ static uint32_t upload_impl(j40hip_frame *h, int device, hipStream_t s) {
 	st->vb_count = hp.vb_sorted.size();   // (the list itself stays on the device: host_vb_sorted fetches it for the rare callers)
 	memcpy(st->class_start, hp.class_start, sizeof st->class_start);
 	Stager sg;
+	sg.deferred = h->threads > 1;
 	const size_t o_cs = sg.put(hp.codestream.data(), hp.codestream.size()), o_u8 = sg.put(hp.pool_u8.data(), hp.pool_u8.size());
 	const size_t o_u16 = sg.put(hp.pool_u16.data(), hp.pool_u16.size()), o_i32 = sg.put(hp.pool_i32.data(), hp.pool_i32.size());
 	const size_t o_u64 = sg.put(hp.pool_u64.data(), hp.pool_u64.size()), o_f32 = sg.put(hp.pool_f32.data(), hp.pool_f32.size());
@@ -799,6 +829,7 @@ static uint32_t upload_impl(j40hip_frame *h, int device, hipStream_t s) {
 	if (hp.lf_tail_pending) for (int c = 0; c < 3; ++c) o_llf[c] = sg.reserve(sizeof(float) * cells);
 	bool dummy_clean = false;
 	if (!sg.ok) ok = false;
+	sg.flush(h->threads);
 	const double tu2 = timing ? now() : 0;
 	st->plan_block = ok ? cache_acquire(device, sg.size, &st->plan_block_bytes, &dummy_clean) : nullptr;
 	if (!st->plan_block || hipMemcpyAsync(st->plan_block, sg.data(), copy_bytes, hipMemcpyHostToDevice, s) != hipSuccess) ok = false;

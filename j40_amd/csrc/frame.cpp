@@ -965,7 +965,8 @@ void parse_frame(const uint8_t *cs, size_t cs_size, Frame *f, int threads) {
 	if (nthreads <= 1) worker();
 	else {
 		std::vector<std::thread> pool;
-		for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
+		for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);   // (the calling thread is one of the team)
+		worker();
 		for (auto &t : pool) t.join();
 	}
 	{   // the first failing section in the order the reference reads them: by offset (a permuted TOC stores them out of index order, j40.h:5608)

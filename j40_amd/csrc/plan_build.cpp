@@ -244,6 +244,11 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 	bool consistent = true;
 
 	auto body = [&](int tid, int team, TeamBarrier &bar) {
+		if (tid == team - 1) {   // (the thread with the smallest LfGroup of phase A: the codestream's padded copy, a third of a millisecond for 8K)
+			hp->codestream.reserve(cs_size + 32);   // (assign + resize without it reallocates and copies the stream a second time)
+			hp->codestream.assign(cs, cs + cs_size);
+			hp->codestream.resize(cs_size + 32, 0);   // the lane decoders read up to three words past the position they stop at
+		}
 		// A: the LF bundle's pieces to their places; varblocks per (LfGroup, transform class); blocks per group
 		for (size_t g = (size_t) tid; g < nlf; g += (size_t) team) {
 			const LfGroup &gg = fr.lf_groups[g];
@@ -348,9 +353,6 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 	// overflows it fails with ERR_EVOF and the frame is decoded with dense planes instead (runtime.hip).
 	df.sparse_coeffs = fr.fh.num_passes == 1 && !hp->force_dense;
 	if (!fill_event_ranges(hp->sections, num_groups, df.sparse_coeffs != 0, &hp->ev_range, &hp->ev_capacity)) df.sparse_coeffs = 0;
-	hp->codestream.reserve(cs_size + 32);   // (assign + resize without it reallocates and copies the stream a second time)
-	hp->codestream.assign(cs, cs + cs_size);
-	hp->codestream.resize(cs_size + 32, 0);   // the lane decoders read up to three words past the position they stop at
 	bool any_lz77 = false;
 	for (const DevCodeSpec &sp : hp->coeff_specs) any_lz77 |= sp.lz77_enabled != 0;
 	hp->lz_window_size = any_lz77 ? 3 * 65536 + 3 * 1024 + 16 : 0;  // bound on the integers one pass-group stream decodes
