@@ -230,12 +230,14 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 		hp->lf_smooth = !fr.fh.skip_adapt_lf_smooth;
 		for (int c = 0; c < 3; ++c) hp->inv_m_lf[c] = (float) (fr.global_scale * fr.quant_lf) / fr.m_lf_scaled[c] / 65536.0f;   // j40.h:6497
 	}
-	hp->blocks.resize(ncell); hp->lfindices.resize(ncell);
-	for (int c = 0; c < 3; ++c) { if (any_tail) hp->lfraw[c].resize(ncell); else hp->llf[c].resize(ncell); }
+	// (every element of these is written below; a reused plan object keeps last frame's storage, and its size when the frame's is the same)
+	auto sized = [](auto &v, size_t n) { if (v.size() != n) v.resize(n); };
+	sized(hp->blocks, ncell); sized(hp->lfindices, ncell);
+	for (int c = 0; c < 3; ++c) { if (any_tail) { sized(hp->lfraw[c], ncell); hp->llf[c].clear(); } else { sized(hp->llf[c], ncell); hp->lfraw[c].clear(); } }
 	hp->xfromy.resize(nc64); hp->bfromy.resize(nc64);
-	hp->vb_coeffoff_qfidx.resize(nvb); hp->vb_hfmul_inv.resize(nvb);
-	hp->group_blocks.resize(nvb);   // (every varblock is in exactly one group's list: its top-left cell's group)
-	if (hp->vb_sorted.size() != nvb) hp->vb_sorted.resize(nvb);   // (every record is written below; a reused plan object keeps last frame's storage)
+	sized(hp->vb_coeffoff_qfidx, nvb); sized(hp->vb_hfmul_inv, nvb);
+	sized(hp->group_blocks, nvb);   // (every varblock is in exactly one group's list: its top-left cell's group)
+	sized(hp->vb_sorted, nvb);
 	fill_sections(fr, &hp->sections);
 	hp->group_block_start.assign((size_t) num_groups + 1, 0);
 	std::vector<std::vector<int32_t>> ordinal(nlf);   // [LF group][varblock] -> position in group_blocks

@@ -43,9 +43,11 @@ struct HostPlan {
 	// allocating (and page-faulting in) ~35 MB of vectors per 8K frame was a third of the plan build
 	void reset() {
 		codestream.clear(); pool_u8.clear(); pool_u16.clear(); pool_i32.clear(); pool_u64.clear(); pool_f32.clear(); clusters.clear(); coeff_specs.clear();
-		lf_groups.clear(); sections.clear(); group_blocks.clear(); group_block_start.clear(); blocks.clear(); vb_coeffoff_qfidx.clear(); lfindices.clear();
-		for (int c = 0; c < 3; ++c) { llf[c].clear(); lfraw[c].clear(); inv_m_lf[c] = 0.0f; }
-		vb_hfmul_inv.clear(); xfromy.clear(); bfromy.clear(); ev_range.clear();   // (vb_sorted keeps its size: build_vardct_plan overwrites every record)
+		lf_groups.clear(); sections.clear(); group_block_start.clear();
+		for (int c = 0; c < 3; ++c) inv_m_lf[c] = 0.0f;
+		xfromy.clear(); bfromy.clear(); ev_range.clear();
+		// (vb_sorted, group_blocks, blocks, lfindices, the LF planes and the per-varblock arrays keep their sizes: build_vardct_plan sizes
+		// them to the frame and overwrites every element -- a thread that decodes frame after frame of one size does not zero 10 MB a frame)
 		block_ctx_map_off = 0; lf_tail_pending = lf_smooth = force_dense = false; ev_capacity = 0; coeff_floats = 0; lz_window_size = 0; max_large = 0;
 	}
 };
