@@ -23,6 +23,7 @@ for i in range(4): synth("vardct", 7680, 4320, 3 + 1000 * i, forward=1)
 PY
 P8K=$(ls $R/build/streams/vardct_7680_4320_*forward-1.jxl | head -4 | tr '\n' ' ')
 J40HIP_API_TIMING=1 J40HIP_SERVE=0 timeout 200 $R/build/api_threads 1 8 --warm 2 $P8K > $O/api_one_thread_latency.json 2> $O/api_one_thread_latency.err
+for n in 64 128; do timeout 300 $R/build/api_threads $n 8 --warm 3 --verify-every 8 $P8K > $O/api_${n}_threads.json 2> $O/api_${n}_threads.err; echo "api_$n rc=$?" >> $O/rc.txt; done
 timeout 1500 python -u -m pytest tests -m gpu -q -p no:cacheprovider > $O/gputest_full.txt 2>&1; tail -n 6 $O/gputest_full.txt > $O/gputest.txt; echo "gputest rc=$?" >> $O/rc.txt
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc=$?" >> $O/rc.txt
 timeout 600 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench_default rc=$?" >> $O/rc.txt
@@ -30,6 +31,9 @@ timeout 600 python $R/bench.py --steps 20 --warmup 5 > $O/bench_steps20_warmup5.
 # the contract clock in five fresh processes at the driver's flags, the copies' engines on each line
 for i in 1 2 3 4 5; do timeout 200 python $R/bench.py --skip-sections --no-cpu-baseline --steps 20 --warmup 5 >> $O/contract_clock_five_runs.jsonl 2>> $O/contract_clock_five_runs.err; echo "clock$i rc=$?" >> $O/rc.txt; done
 timeout 300 python $R/tools/modular_split_probe.py > $O/modular_split_probe.json 2> $O/modular_split_probe.err; echo "split_probe rc=$?" >> $O/rc.txt
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_restore -- python $R/tools/restore_probe.py 3 > $O/restoration_probe.txt 2>&1 ); echo "restore_probe rc=$?" >> $O/rc.txt
+cp "$(find /tmp/kt_restore -name '*kernel_stats.csv' | head -1)" $O/restoration_kernel_stats.csv 2>/dev/null; rm -rf /tmp/kt_restore
+FUZZ_FLIPS=0.3 timeout 1500 python $R/tools/fuzz_parity.py 220 606 gpu > $O/fuzz_gpu.txt 2>&1; echo "fuzz_gpu rc=$?" >> $O/rc.txt
 kt() { name=$1; shift; ( cd /tmp && timeout 240 env "$@" rocprofv3 --kernel-trace --stats -d /tmp/kt_$name -- python $R/tools/r05_probe.py 256 16 6 > $O/kt_$name.log 2>&1 ); echo "kt_$name rc=$?" >> $O/rc.txt
 	python tools/prof_summary.py /tmp/kt_$name $O/kernel_stats_$name.txt > /dev/null 2>&1; python tools/kernel_timeline.py /tmp/kt_$name $O/timeline_$name.txt 1.0 0 > /dev/null 2>&1; rm -rf /tmp/kt_$name; grep -h '^{' $O/kt_$name.log > $O/probe_$name.json; }
 kt one_batch_alone_b256 PROBE_ONLY=alone
@@ -51,4 +55,4 @@ import json
 for l in open('$O/contract_clock_five_runs.jsonl'):
     if l.startswith('{'):
         r=json.loads(l); print('clock', r['value'], r['ms_per_step'], r['pcie']['achieved_gb_per_s'], r['pcie'].get('slow_run'), r['pcie'].get('copy_engine',{}).get('engine'))
-"; cat $O/modular_split_probe.json | head -60
+"; cat $O/modular_split_probe.json | head -60; tail -n 3 $O/fuzz_gpu.txt; cat $O/restoration_probe.txt | tail -n 3; grep -E "k_epf|k_gaborish" $O/restoration_kernel_stats.csv | cut -c1-160; for n in 64 128; do tail -n 1 $O/api_${n}_threads.json | cut -c1-300; done
