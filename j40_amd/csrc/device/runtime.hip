@@ -264,8 +264,7 @@ struct Stager {
 		const size_t off = (size + 255) & ~(size_t) 255, end = off + sizeof(T) * n + 16;
 		if (!ok || !t_stage.reserve(end, size)) { ok = false; return 0; }
 		if (n) { if (deferred) copies.push_back({off, (const uint8_t *) src, sizeof(T) * n}); else memcpy(t_stage.ptr + off, src, sizeof(T) * n); }
-		if (!deferred) size = end;
-		else size = end;   // (a grown buffer keeps the bytes below `size`: nothing of the noted copies is there yet, and nothing needs to be)
+		size = end;   // (deferred: a grown buffer keeps the bytes below `size` -- nothing of the noted copies is there yet, and nothing needs to be)
 		return off;
 	}
 	void flush(int threads) {
