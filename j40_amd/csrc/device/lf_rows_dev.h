@@ -495,24 +495,6 @@ J40_DEV void lf_row_step_plain_for(LfRowLane &L, const LfRowTables &T) {
 	const int32_t v = lf_plain_middle<NEED>(L, T, c, &code);
 	lf_plain_commit<NEED>(L, c, v, code);
 }
-// TWO samples of a lane that has at least two left in its run, as one basic block: the second sample's alias entry can be asked for
-// as soon as the first one's state is known, while the first one's integer is still being put together, checked and stored -- a
-// wavefront alone on its SIMD issues an instruction every 5.3 cycles at best and the single step runs at 8 (its chain), so the
-// pair's instructions fill each other's waits; and the loop's own tests are paid once per two samples. A lane whose first sample
-// raised an error goes through the second one's instructions without effect (its position and run length stay: the general step
-// that follows ends the lane, lf_row_step_general).
-template <uint32_t NEED>
-J40_DEV void lf_row_step_plain_pair(LfRowLane &L, const LfRowTables &T) {
-	lf_row_step_plain_for<NEED>(L, T);
-	const bool dead = L.err != 0;
-	const int32_t x = L.x;
-	LfPlainCtx c; uint32_t code;
-	lf_plain_front<NEED>(L, T, c);
-	const int32_t v = lf_plain_middle<NEED>(L, T, c, &code);
-	lf_plain_commit<NEED>(L, c, v, code);
-	L.x = dead ? x : L.x;
-	L.plain_left = dead ? 0 : L.plain_left;
-}
 J40_DEV void lf_row_step_plain(LfRowLane &L, const LfRowTables &T) { lf_row_step_plain_for<LF_NEED_ALL>(L, T); }
 
 // this lane's share of the wavefront's needs (0 for a lane that takes no plain step)
@@ -534,18 +516,6 @@ J40_DEV void lf_row_step_plain_needs(LfRowLane &L, const LfRowTables &T, uint32_
 	}
 }
 #undef LF_PLAIN_CASE
-// ... and two samples at a time (lf_row_step_plain_pair), for lanes with at least two left in their run
-#define LF_PLAIN_CASE(n) case n: lf_row_step_plain_pair<n>(L, T); break;
-J40_DEV void lf_row_step_plain_pair_needs(LfRowLane &L, const LfRowTables &T, uint32_t need) {
-	switch (need) {
-	LF_PLAIN_CASE(0) LF_PLAIN_CASE(1) LF_PLAIN_CASE(2) LF_PLAIN_CASE(3) LF_PLAIN_CASE(4) LF_PLAIN_CASE(5) LF_PLAIN_CASE(6) LF_PLAIN_CASE(7)
-	LF_PLAIN_CASE(8) LF_PLAIN_CASE(9) LF_PLAIN_CASE(10) LF_PLAIN_CASE(11) LF_PLAIN_CASE(12) LF_PLAIN_CASE(13) LF_PLAIN_CASE(14) LF_PLAIN_CASE(15)
-	LF_PLAIN_CASE(16) LF_PLAIN_CASE(17) LF_PLAIN_CASE(18) LF_PLAIN_CASE(19) LF_PLAIN_CASE(20) LF_PLAIN_CASE(21) LF_PLAIN_CASE(22) LF_PLAIN_CASE(23)
-	LF_PLAIN_CASE(24) LF_PLAIN_CASE(25) LF_PLAIN_CASE(26) LF_PLAIN_CASE(27) LF_PLAIN_CASE(28) LF_PLAIN_CASE(29) LF_PLAIN_CASE(30)
-	default: lf_row_step_plain_pair<LF_NEED_ALL>(L, T); break;
-	}
-}
-#undef LF_PLAIN_CASE
 #ifdef __HIPCC__
 // The kernel's inner loop: the wavefront's lanes step through their runs of plain samples until some live lane is out of its run
 // (a channel start, a row's end: the caller's business). The choice among the instantiations is made once per such stretch -- a
@@ -557,9 +527,7 @@ J40_DEV void lf_row_run_plain_for(LfRowLane &L, const LfRowTables &T) {
 	for (;;) {   // (the lanes in a run step at least once per call: a lane that stays in a channel of another form does not hold them up)
 		const bool plain = L.plain_left > 0;
 		if (!__builtin_amdgcn_ballot_w64(plain)) return;
-		// two samples at a time while every stepping lane has two left and no live lane waits for the general step
-		if (!__builtin_amdgcn_ballot_w64((plain & (L.plain_left < 2)) | (!plain & L.live))) { if (plain) lf_row_step_plain_pair<NEED>(L, T); }
-		else if (plain) lf_row_step_plain_for<NEED>(L, T);
+		if (plain) lf_row_step_plain_for<NEED>(L, T);
 		if (__builtin_amdgcn_ballot_w64(!(L.plain_left > 0) & L.live)) return;
 	}
 }

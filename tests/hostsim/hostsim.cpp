@@ -1021,11 +1021,7 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_check(
 				const bool pa = A.plain_left > 0 && !(general_only & 1), pb = two && B.plain_left > 0 && !(general_only & 1);
 				if (pa && pb) { lf_row_step_plain2(A, B, T, T); plain_steps += 2; }
 				else {
-					if (pa) {
-						// (as the kernel's loop: two samples in one go where the lane has two left -- lf_row_step_plain_pair; mode bit 3: singly)
-						if (per == 1 && A.plain_left >= 2 && !(general_only & 8)) { lf_row_step_plain_pair_needs(A, T, need); plain_steps += 2; }
-						else { if (per == 1) lf_row_step_plain_needs(A, T, need); else lf_row_step_plain(A, T); ++plain_steps; }
-					}
+					if (pa) { if (per == 1) lf_row_step_plain_needs(A, T, need); else lf_row_step_plain(A, T); ++plain_steps; }
 					if (pb) { lf_row_step_plain(B, T); ++plain_steps; }
 				}
 				if (!pa && !lf_row_done(A)) { lf_row_step(A, out[k].t, T); ++general_steps; }
