@@ -412,3 +412,42 @@ print(json.dumps(res))
         assert res["codes"] == res["expected"] and res["codes"][5] != "" and res["codes"][0] == "", res
         assert all(res["equal"]) and res["ref_max_diff"] <= 1, res
         assert res["launch_frames"] >= 10, res
+
+
+COPY_WORKER = r"""
+import hashlib, json, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, j40_amd
+from streams import synth
+items = [("vardct", 520, 264, 41, {}), ("vardct", 1920, 1080, 7, {}), ("vardct", 2600, 2100, 61, {"lftree": 2}), ("modular", 600, 300, 5, {"tree": 1})] * 4
+pipe = j40_amd.Pipeline(device=0, host_threads=4, batch_frames=4, max_in_flight=2)
+outs, tickets = [], []
+for m, w, h, s, o in items:
+    d = synth(m, w, h, s, **o)
+    t = torch.zeros((h, w, 4), dtype=torch.uint8).pin_memory()
+    outs.append(t); tickets.append(pipe.submit(d, t.data_ptr(), w * 4))
+pipe.drain()
+codes = [pipe.result(t) for t in tickets]
+pipe.close()
+err, one = j40_amd.decode(synth("vardct", 2600, 2100, 61, lftree=2))   # the single-image path's copy back
+print(json.dumps({"codes": codes, "sha": [hashlib.sha256(o.numpy().tobytes()).hexdigest() for o in outs], "one": hashlib.sha256(one.tobytes()).hexdigest(), "engine": j40_amd.copy_engine(0)["engine"]}))
+"""
+
+
+def test_copies_through_every_way_give_the_same_pixels(built):
+    """hostcopy.hip: the copies back on the SDMA engine the library measured as the fastest (the default), on a named one
+    (J40HIP_COPY_ENGINE=1), and through hipMemcpyAsync as before round 6 (J40HIP_COPY_ENGINE=hip) -- pipeline and single-image path,
+    each way in a process of its own (the choice is made once per process): same codes, same pixels"""
+    import json, subprocess, sys
+    seen = {}
+    for way in ("", "1", "hip"):
+        env = dict(os.environ)
+        env.pop("J40HIP_COPY_ENGINE", None)
+        if way: env["J40HIP_COPY_ENGINE"] = way
+        run = subprocess.run([sys.executable, "-c", COPY_WORKER % (ROOT_DIR, os.path.join(ROOT_DIR, "tests"))], env=env, capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0, run.stderr[-2000:]
+        seen[way] = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+    assert all(c == "" for c in seen[""]["codes"])
+    assert seen[""]["engine"] >= 0 and seen["1"]["engine"] == 1 and seen["hip"]["engine"] < 0
+    for way in ("1", "hip"):
+        assert seen[way]["codes"] == seen[""]["codes"] and seen[way]["sha"] == seen[""]["sha"] and seen[way]["one"] == seen[""]["one"], way
