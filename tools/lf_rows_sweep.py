@@ -8,7 +8,17 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from streams import synth
+from streams import SYNTH
+import subprocess
+import tempfile
+
+
+def synth(mode, w, h, seed, **opts):
+    """like streams.synth, without leaving the stream in the on-disk cache (hundreds of them would travel to the GPU box)"""
+    with tempfile.NamedTemporaryFile(suffix=".jxl") as tmp:
+        subprocess.run([SYNTH, mode, str(w), str(h), str(seed), tmp.name] + ["%s=%s" % kv for kv in sorted(opts.items())], check=True, stderr=subprocess.DEVNULL)
+        return open(tmp.name, "rb").read()
+
 
 S = C.CDLL(os.path.join(ROOT, "build", "libhostsim.so"))
 S.hostsim_lf_rows_check.restype = C.c_int32
