@@ -2,6 +2,7 @@
 #include "plan_build.hpp"
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <thread>
 
@@ -157,6 +158,9 @@ void fill_frame_constants(const Frame &fr, DevFrame *out) {
 }
 
 uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, HostPlan *hp, int threads) {
+	static const bool timing = getenv("J40HIP_PLAN_TIMING") != nullptr;
+	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double tb0 = timing ? now() : 0; double tbA = 0, tbB = 0, tbC = 0;
 	if (cs_size + 16 >= ((size_t) 1 << 29)) return ERR_TODO;   // the kernels address the codestream with 32-bit BIT positions
 	if (fr.fh.is_modular) return ERR_TODO;
 	// same limits as j40.h:7867, 7917-7921. (A VarDCT frame of an image without xyb_encoded passes them: the reference
@@ -242,29 +246,37 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 	hp->group_block_start.assign((size_t) num_groups + 1, 0);
 	std::vector<std::vector<int32_t>> ordinal(nlf);   // [LF group][varblock] -> position in group_blocks
 	for (size_t g = 0; g < nlf; ++g) ordinal[g].assign(fr.lf_groups[g].varblocks.size(), -1);
-	std::vector<uint32_t> class_count(nlf * 28, 0), class_at(nlf * 28, 0), group_count((size_t) num_groups, 0);
+	// (an LfGroup's cells and varblocks go to the team in NCH pieces: an 8K frame has six full LfGroups and six slivers, and a thread
+	// per LfGroup left half the team waiting for the other half)
+	enum { NCH = 4 };
+	std::vector<uint32_t> class_count(nlf * NCH * 28, 0), class_at(nlf * NCH * 28, 0), group_count((size_t) num_groups, 0);
 	bool consistent = true;
+	auto piece = [](size_t n, size_t ch, size_t *first, size_t *end) { *first = n * ch / NCH; *end = n * (ch + 1) / NCH; };
 
+	const double tb1 = timing ? now() : 0;
 	auto body = [&](int tid, int team, TeamBarrier &bar) {
 		if (tid == team - 1) {   // (the thread with the smallest LfGroup of phase A: the codestream's padded copy, a third of a millisecond for 8K)
 			hp->codestream.reserve(cs_size + 32);   // (assign + resize without it reallocates and copies the stream a second time)
 			hp->codestream.assign(cs, cs + cs_size);
 			hp->codestream.resize(cs_size + 32, 0);   // the lane decoders read up to three words past the position they stop at
 		}
-		// A: the LF bundle's pieces to their places; varblocks per (LfGroup, transform class); blocks per group
-		for (size_t g = (size_t) tid; g < nlf; g += (size_t) team) {
+		// A: the LF bundle's pieces to their places; varblocks per (LfGroup piece, transform class); blocks per group
+		for (size_t u = (size_t) tid; u < nlf * NCH; u += (size_t) team) {
+			const size_t g = u / NCH, ch = u % NCH;
 			const LfGroup &gg = fr.lf_groups[g];
 			const DevLfGroup &d = hp->lf_groups[g];
-			std::copy(gg.blocks.begin(), gg.blocks.end(), hp->blocks.begin() + d.cell_base);
-			std::copy(gg.lfindices.begin(), gg.lfindices.end(), hp->lfindices.begin() + d.cell_base);
+			size_t c0, c1, q0, q1, v0, v1;
+			piece(gg.blocks.size(), ch, &c0, &c1); piece(gg.xfromy.size(), ch, &q0, &q1); piece(gg.varblocks.size(), ch, &v0, &v1);
+			std::copy(gg.blocks.begin() + (long) c0, gg.blocks.begin() + (long) c1, hp->blocks.begin() + d.cell_base + (long) c0);
+			std::copy(gg.lfindices.begin() + (long) c0, gg.lfindices.begin() + (long) c1, hp->lfindices.begin() + d.cell_base + (long) c0);
 			for (int c = 0; c < 3; ++c) {
-				if (any_tail) std::copy(gg.lfraw[c].begin(), gg.lfraw[c].end(), hp->lfraw[c].begin() + d.cell_base);
-				else std::copy(gg.llfcoeffs[c].begin(), gg.llfcoeffs[c].end(), hp->llf[c].begin() + d.cell_base);
+				if (any_tail) std::copy(gg.lfraw[c].begin() + (long) c0, gg.lfraw[c].begin() + (long) c1, hp->lfraw[c].begin() + d.cell_base + (long) c0);
+				else std::copy(gg.llfcoeffs[c].begin() + (long) c0, gg.llfcoeffs[c].begin() + (long) c1, hp->llf[c].begin() + d.cell_base + (long) c0);
 			}
-			std::copy(gg.xfromy.begin(), gg.xfromy.end(), hp->xfromy.begin() + d.c64_base);
-			std::copy(gg.bfromy.begin(), gg.bfromy.end(), hp->bfromy.begin() + d.c64_base);
-			uint32_t *cnt = class_count.data() + g * 28;
-			for (size_t v = 0; v < gg.varblocks.size(); ++v) {
+			std::copy(gg.xfromy.begin() + (long) q0, gg.xfromy.begin() + (long) q1, hp->xfromy.begin() + d.c64_base + (long) q0);
+			std::copy(gg.bfromy.begin() + (long) q0, gg.bfromy.begin() + (long) q1, hp->bfromy.begin() + d.c64_base + (long) q0);
+			uint32_t *cnt = class_count.data() + u * 28;
+			for (size_t v = v0; v < v1; ++v) {
 				const VarblockInfo &vb = gg.varblocks[v];
 				hp->vb_coeffoff_qfidx[(size_t) d.vb_base + v] = vb.coeffoff_qfidx; hp->vb_hfmul_inv[(size_t) d.vb_base + v] = vb.hfmul_inv;
 				++cnt[vb.dctsel >= 0 && vb.dctsel < 27 ? vb.dctsel : 27];
@@ -281,6 +293,7 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 			group_count[(size_t) g] = n;
 		}
 		bar.wait();
+		if (timing && tid == 0) tbA = now();
 		if (tid == 0) {   // where every group's list and every (LfGroup, class) run of records starts
 			uint32_t at = 0;
 			for (int32_t g = 0; g < num_groups; ++g) { hp->group_block_start[(size_t) g] = at; at += group_count[(size_t) g]; }
@@ -289,7 +302,7 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 			uint32_t k = 0;
 			for (int d = 0; d <= 27; ++d) {   // grouped by DctSelect, in (LF group, varblock) order within a class
 				hp->class_start[d] = (int32_t) k;
-				for (size_t g = 0; g < nlf; ++g) { class_at[g * 28 + (size_t) d] = k; k += class_count[g * 28 + (size_t) d]; }
+				for (size_t u = 0; u < nlf * NCH; ++u) { class_at[u * 28 + (size_t) d] = k; k += class_count[u * 28 + (size_t) d]; }
 			}
 		}
 		bar.wait();
@@ -319,13 +332,17 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 			}
 		}
 		bar.wait();
+		if (timing && tid == 0) tbB = now();
 		// C: work lists for the coefficients -> pixels kernels: every record straight to its place (sorting a quarter of a million
 		// 40-byte records afterwards was a third of this function)
-		for (size_t g = (size_t) tid; g < nlf; g += (size_t) team) {
+		for (size_t u = (size_t) tid; u < nlf * NCH; u += (size_t) team) {
+			const size_t g = u / NCH;
 			const LfGroup &gg = fr.lf_groups[g];
 			const DevLfGroup &d = hp->lf_groups[g];
-			uint32_t *at = class_at.data() + g * 28;
-			for (size_t v = 0; v < gg.varblocks.size(); ++v) {
+			uint32_t *at = class_at.data() + u * 28;
+			size_t v0, v1;
+			piece(gg.varblocks.size(), u % NCH, &v0, &v1);
+			for (size_t v = v0; v < v1; ++v) {
 				const VarblockInfo &vb = gg.varblocks[v];
 				DevVarblock dv;
 				memset(&dv, 0, sizeof dv);
@@ -347,7 +364,8 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 	};
 	// (a team no larger than the work has pieces -- LfGroups in phase A, groups behind it -- and none for frames of a few groups:
 	// starting eleven threads for a 64 x 64 image costs more than its plan)
-	run_team(num_groups + (int32_t) nlf <= 8 ? 1 : std::min(threads, std::max((int32_t) nlf, num_groups)), body);
+	run_team(num_groups + (int32_t) nlf <= 8 ? 1 : std::min(threads, std::max((int32_t) nlf * NCH, num_groups)), body);
+	tbC = timing ? now() : 0;
 	if (!consistent) return ERR_RNGE;   // (a varblock without a top-left cell: the parse does not produce such frames, a caller's plan view may)
 
 	// single-pass frames: sparse coefficients (DevPlan::events). A group's region is sized from its section: a non-zero
@@ -361,6 +379,7 @@ uint32_t build_vardct_plan(const Frame &fr, const uint8_t *cs, size_t cs_size, H
 	fill_hf_launch_info(hp->coeff_specs, (uint32_t) fr.block_ctx_map.size(), hp->coeff_floats, &hp->hf);
 	hp->max_large = 0;
 	for (int d = 21; d < 27; ++d) hp->max_large = std::max(hp->max_large, hp->class_start[d + 1] - hp->class_start[d]);
+	if (timing) fprintf(stderr, "[j40hip plan] before the team %.2f ms, phase A %.2f, B %.2f, C + join %.2f, after %.2f\n", tb1 - tb0, tbA - tb1, tbB - tbA, tbC - tbB, now() - tbC);
 	return 0;
 }
 
