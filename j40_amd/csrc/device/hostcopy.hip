@@ -60,6 +60,17 @@ bool wait_signal(hsa_signal_t s) {
 	return v == 0;
 }
 
+// the measurement's wait: a copy of 32 MB that has not completed after five seconds never will (an engine that does not answer) -- the
+// measurement is given up, its buffers are left alone (the engine may still write them) and the copies stay with hipMemcpyAsync
+bool wait_signal_bounded(hsa_signal_t s, bool *stuck) {
+	const double deadline = now_s() + 5.0;
+	for (;;) {
+		const hsa_signal_value_t v = hsa_signal_wait_scacquire(s, HSA_SIGNAL_CONDITION_LT, 1, (uint64_t) 1 << 24, HSA_WAIT_STATE_BLOCKED);
+		if (v < 1) return v == 0;
+		if (now_s() > deadline) { *stuck = true; return false; }
+	}
+}
+
 // g_m held. Finds the device's agents, measures the engines, keeps the fastest.
 void set_up(int device, DeviceCopier &d) {
 	d.tried = true;
@@ -88,9 +99,10 @@ void set_up(int device, DeviceCopier &d) {
 	if (hipSetDevice(device) != hipSuccess || hipMalloc(&dev, bytes) != hipSuccess) { (void) hipGetLastError(); (void) hipSetDevice(prev); return; }
 	if (hipHostMalloc(&host, bytes, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); (void) hipFree(dev); (void) hipSetDevice(prev); return; }
 	hsa_signal_t sig;
+	bool stuck = false;
 	if (hsa_signal_create(1, 0, nullptr, &sig) == HSA_STATUS_SUCCESS) {
 		int best = -1;
-		for (int pass = 0; pass < 2 && (best < 0 || d.gbps[best] < 45.0); ++pass) {   // (a recommended engine below 45 GB/s: look at the others too)
+		for (int pass = 0; pass < 2 && !stuck && (best < 0 || d.gbps[best] < 45.0); ++pass) {   // (a recommended engine below 45 GB/s: look at the others too)
 			// first the engines the runtime recommends for this direction, then -- if none of them works -- all the others
 			const uint32_t mask = pass == 0 ? (d.preferred_mask & d.free_mask) : (d.free_mask & ~d.preferred_mask);
 			for (int e = 0; e < 16; ++e) if (mask >> e & 1u) {
@@ -99,14 +111,15 @@ void set_up(int device, DeviceCopier &d) {
 				for (int k = 0; k < 2 && ok; ++k) {
 					hsa_signal_store_relaxed(sig, 1);
 					const double t0 = now_s();
-					ok = hsa_amd_memory_async_copy_on_engine(host, d.cpu, dev, d.gpu, k ? bytes : (size_t) 1 << 20, 0, nullptr, sig, (hsa_amd_sdma_engine_id_t) (1u << e), true) == HSA_STATUS_SUCCESS && wait_signal(sig);
+					ok = hsa_amd_memory_async_copy_on_engine(host, d.cpu, dev, d.gpu, k ? bytes : (size_t) 1 << 20, 0, nullptr, sig, (hsa_amd_sdma_engine_id_t) (1u << e), true) == HSA_STATUS_SUCCESS && wait_signal_bounded(sig, &stuck);
 					t = now_s() - t0;
 				}
+				if (stuck) break;
 				d.gbps[e] = ok ? (double) bytes / t / 1e9 : -1.0;
 				if (ok && (best < 0 || d.gbps[e] > d.gbps[best] * 1.03)) best = e;   // (ties go to the lower engine)
 			}
 		}
-		if (best >= 0) { d.engine = best; d.engine_bit = 1u << best; d.usable = true; }
+		if (best >= 0 && !stuck) { d.engine = best; d.engine_bit = 1u << best; d.usable = true; }
 		// the other direction (the worker threads' uploads: the plan's front and the codestream, 4-12 MB a frame), 8 MB per engine. An SDMA
 		// engine works on one copy at a time: an upload that shares the engine of the copies back waits behind 133 MB transfers, so the
 		// uploads get engines of their own -- and the engines that are slow device-to-host (4-7: 12.6 GB/s) are nearly as good as the
@@ -121,9 +134,10 @@ void set_up(int device, DeviceCopier &d) {
 				for (int k = 0; k < 2 && ok; ++k) {
 					hsa_signal_store_relaxed(sig, 1);
 					const double t0 = now_s();
-					ok = hsa_amd_memory_async_copy_on_engine(dev, d.gpu, host, d.cpu, k ? hb : (size_t) 1 << 20, 0, nullptr, sig, (hsa_amd_sdma_engine_id_t) (1u << e), true) == HSA_STATUS_SUCCESS && wait_signal(sig);
+					ok = hsa_amd_memory_async_copy_on_engine(dev, d.gpu, host, d.cpu, k ? hb : (size_t) 1 << 20, 0, nullptr, sig, (hsa_amd_sdma_engine_id_t) (1u << e), true) == HSA_STATUS_SUCCESS && wait_signal_bounded(sig, &stuck);
 					t = now_s() - t0;
 				}
+				if (stuck) break;
 				d.gbps_h2d[e] = ok ? (double) hb / t / 1e9 : -1.0;
 				if (ok && d.gbps_h2d[e] > top) top = d.gbps_h2d[e];
 			}
@@ -133,9 +147,11 @@ void set_up(int device, DeviceCopier &d) {
 				if (d.gbps_h2d[e] >= 0.75 * top && d.gbps_h2d[e] > 0 && (pass == 0) == poor_d2h) d.h2d_engines.push_back(e);
 			}
 		}
-		(void) hsa_signal_destroy(sig);
+		if (stuck) { d.usable = false; d.h2d_engines.clear(); }
+		else (void) hsa_signal_destroy(sig);
 	}
-	(void) hipHostFree(host); (void) hipFree(dev); (void) hipSetDevice(prev);
+	if (!stuck) { (void) hipHostFree(host); (void) hipFree(dev); }
+	(void) hipSetDevice(prev);
 	if (getenv("J40HIP_ASYNC_TIMING") || getenv("J40HIP_COPY_REPORT")) {
 		fprintf(stderr, "[j40hip hostcopy] device %d: SDMA engines free 0x%x, recommended 0x%x; device-to-host GB/s:", device, d.free_mask, d.preferred_mask);
 		for (int e = 0; e < 16; ++e) if (d.gbps[e] != 0) fprintf(stderr, " %d:%.1f", e, d.gbps[e]);
