@@ -269,7 +269,7 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 
 	// ---- the plan block: what the host copies first, then what the device produces ----
 	Layout L;
-	const size_t o_cs = L.take(cs_size + 32), o_u8 = L.take(fp.pool_u8.size()), o_i32 = L.take(fp.pool_i32.size() * 4), o_u64 = L.take(fp.pool_u64.size() * 8);
+	const size_t o_cs = L.take(cs_size + LF_CODESTREAM_PAD), o_u8 = L.take(fp.pool_u8.size()), o_i32 = L.take(fp.pool_i32.size() * 4), o_u64 = L.take(fp.pool_u64.size() * 8);
 	const size_t o_cl = L.take(fp.clusters.size() * sizeof(DevCluster)), o_spec = L.take(fp.coeff_specs.size() * sizeof(DevCodeSpec)), o_frame = L.take(sizeof(DevFrame));
 	const size_t o_lfg = L.take(ngg * sizeof(DevLfGroup)), o_sec = L.take(fp.sections.size() * sizeof(DevSection)), o_evr = L.take(fp.ev_range.size() * 4), o_order = L.take(fp.lane_order.size() * 4);
 	const size_t o_lso = L.take(ngg * 4), o_slots = L.take(ngg * sizeof(DevLfSlot));
@@ -293,7 +293,7 @@ static j40hip_aframe *aframe_prepare_body(const void *buf, size_t size, int devi
 	uint8_t *pb = (uint8_t *) af->plan_block;
 	const double tp3 = prof_now();
 
-	memcpy(stg + o_cs, h.cs, cs_size); memset(stg + o_cs + cs_size, 0, 32);   // the lane decoders read up to three words past the position they stop at
+	memcpy(stg + o_cs, h.cs, cs_size); memset(stg + o_cs + cs_size, 0, LF_CODESTREAM_PAD);   // the lane decoders read past the position they stop at (plan.h)
 	auto put = [&](size_t off, const void *src, size_t bytes) { if (bytes) memcpy(stg + off, src, bytes); };
 	put(o_u8, fp.pool_u8.data(), fp.pool_u8.size()); put(o_i32, fp.pool_i32.data(), fp.pool_i32.size() * 4); put(o_u64, fp.pool_u64.data(), fp.pool_u64.size() * 8);
 	put(o_cl, fp.clusters.data(), fp.clusters.size() * sizeof(DevCluster)); put(o_spec, fp.coeff_specs.data(), fp.coeff_specs.size() * sizeof(DevCodeSpec));

@@ -137,31 +137,26 @@ J40_DEV void lf_row_flush_wave(LfRowLane &L, int32_t lane) {
 	L.flush_n = 0;
 }
 
-// One LfGroup section per LANE -- or, PAIRS, two: the lane steps both side by side, which nearly doubles what a wavefront alone on
-// its SIMD gets out of its issue slots (lf_rows_dev.h: lf_row_step_plain2) --, tree + alias tables + row windows in LDS. A wavefront
-// takes the sections of the frames pack_lf_row_waves gave it; LDS: per part the staged tree and the alias tables, then one window
-// per section. A part's sections go to its lanes two at a time in list order (the host lists them by decreasing size).
-template <bool PAIRS>
+// One LfGroup section per LANE, tree + fast entries (lf_rows_dev.h) + row windows in LDS. A wavefront takes the sections of the frames
+// pack_lf_row_waves gave it; LDS: per part the staged tree and the fast entries made from the frame's alias tables, then one window
+// per section. A part's sections go to its lanes in list order (the host lists them by decreasing size).
 __global__ void __launch_bounds__(64) k_lf_rows(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t raw) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lfr_lds[];
 	const J40_GLOBAL DevLfWave &wv = ((const J40_GLOBAL DevLfWave *) waves)[blockIdx.x];
 	const int32_t lane = threadIdx.x, num_parts = wv.num_parts;
 	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
 	J40_LDS uint8_t *lds = (J40_LDS uint8_t *) lfr_lds;
-	// the wavefront's sections, part after part, are numbered 0, 1, ...: lane l takes section l, or, PAIRS, sections 2l and 2l + 1 --
-	// of one frame or of two (each with its frame's tables)
-	const J40_GLOBAL DevLfTask *task = nullptr, *task_b = nullptr;
-	LfRowTables T, TB;
-	T.tree = nullptr; T.alias = nullptr; T.log_alpha = 5; T.log_bucket = 7; T.uses = 0;
-	TB = T;
-	const int32_t my_section = PAIRS ? 2 * lane : lane;
+	// the wavefront's sections, part after part, are numbered 0, 1, ...: lane l takes section l
+	const J40_GLOBAL DevLfTask *task = nullptr;
+	LfRowTables T;
+	T.tree = nullptr; T.fast = nullptr; T.alias = nullptr; T.log_alpha = 5; T.log_bucket = 7; T.uses = 0;
 	uint32_t at = 0; int32_t section0 = 0;
 	for (int32_t p = 0; p < num_parts; ++p) {
 		const J40_GLOBAL DevLfLaneSet &set = ((const J40_GLOBAL DevLfLaneSet *) sets)[wv.part[p].set];
 		const int32_t first = wv.part[p].first_task, count = wv.part[p].count;
 		const int32_t num_nodes = set.num_nodes, num_clusters = set.num_clusters, log_alpha = set.log_alpha;
 		J40_LDS int32_t *l_tree = (J40_LDS int32_t *) (lds + at);
-		J40_LDS uint64_t *l_alias = (J40_LDS uint64_t *) (lds + at + align16(16u * (uint32_t) num_nodes));
+		J40_LDS LfFastQuad *l_fast = (J40_LDS LfFastQuad *) (lds + at + align16(16u * (uint32_t) num_nodes));
 		{
 			const J40_GLOBAL int32_t *tsrc = (const J40_GLOBAL int32_t *) set.tree;
 			const J40_GLOBAL uint8_t *msrc = (const J40_GLOBAL uint8_t *) set.ctx_map;
@@ -172,70 +167,45 @@ __global__ void __launch_bounds__(64) k_lf_rows(const DevLfLaneSet *sets, const 
 				l_tree[4 * i] = prop; l_tree[4 * i + 1] = value; l_tree[4 * i + 2] = tsrc[4 * i + 2]; l_tree[4 * i + 3] = tsrc[4 * i + 3];
 			}
 			const J40_GLOBAL uint64_t *asrc = (const J40_GLOBAL uint64_t *) set.alias;
-			for (int32_t i = lane; i < (num_clusters << log_alpha); i += 64) l_alias[i] = asrc[i];
+			for (int32_t i = lane; i < (num_clusters << log_alpha); i += 64) l_fast[i] = lf_rows_fast_entry(asrc[i], (uint32_t) i & ((1u << log_alpha) - 1u), csrc[i >> log_alpha]);
 		}
-		if (my_section >= section0 && my_section < section0 + count) {
-			task = (const J40_GLOBAL DevLfTask *) set.tasks + (first + my_section - section0);
-			T.tree = (const J40_LDS DevTreeNode *) l_tree; T.alias = l_alias; T.log_alpha = log_alpha; T.log_bucket = 12 - log_alpha; T.uses = set.uses | (!PAIRS && raw ? (uint32_t) LF_USES_RAW : 0u);
-		}
-		if (PAIRS && my_section + 1 >= section0 && my_section + 1 < section0 + count) {
-			task_b = (const J40_GLOBAL DevLfTask *) set.tasks + (first + my_section + 1 - section0);
-			TB.tree = (const J40_LDS DevTreeNode *) l_tree; TB.alias = l_alias; TB.log_alpha = log_alpha; TB.log_bucket = 12 - log_alpha; TB.uses = set.uses;
+		if (lane >= section0 && lane < section0 + count) {
+			task = (const J40_GLOBAL DevLfTask *) set.tasks + (first + lane - section0);
+			T.tree = (const J40_LDS DevTreeNode *) l_tree; T.fast = (const J40_LDS uint32_t *) l_fast; T.alias = (const J40_GLOBAL uint64_t *) set.alias;
+			T.log_alpha = log_alpha; T.log_bucket = 12 - log_alpha; T.uses = set.uses | (raw ? (uint32_t) LF_USES_RAW : 0u);
 		}
 		section0 += count;
 		at += lf_rows_table_bytes(num_nodes, num_clusters, log_alpha);
 	}
 	J40_LDS int16_t *wins = (J40_LDS int16_t *) (lds + at);
 	__syncthreads();
-	const bool active = task != nullptr, active_b = task_b != nullptr;
+	const bool active = task != nullptr;
 	if (!active) {   // (something valid to point at)
 		const J40_GLOBAL DevLfLaneSet &set = ((const J40_GLOBAL DevLfLaneSet *) sets)[wv.part[0].set];
 		task = (const J40_GLOBAL DevLfTask *) set.tasks + wv.part[0].first_task;
+		T.tree = (const J40_LDS DevTreeNode *) lds; T.fast = (const J40_LDS uint32_t *) lds; T.alias = (const J40_GLOBAL uint64_t *) set.alias;
 	}
-	if (!active_b) { task_b = task; TB = T; }
-	const J40_GLOBAL DevLfTask &t = *task, &tb = *task_b;
+	const J40_GLOBAL DevLfTask &t = *task;
 	LfRowLane L;
-	lf_row_init(L, t, wins + (active ? my_section : 0) * LF_ROW_PITCH);   // (a lane without a section never writes its window)
+	lf_row_init(L, t, wins + (active ? lane : 0) * LF_ROW_PITCH);   // (a lane without a section never writes its window)
 	if (!active) { L.chan = 7; L.setup = false; }   // (the first general step finds it finished)
-	if (!PAIRS) {
-		// Every pass: the lanes run through their stretches of plain samples (lf_row_run_plain, in the instantiation that covers what
-		// their channels need), until some live lane is at a channel start, a row's end or in a channel of another form; those lanes
-		// then take the general step (which says how long the lane's next run is), finished rows leave, and the needs are taken again
-		uint32_t need = LF_NEED_ALL;
-		for (;;) {
-			lf_row_run_plain(L, T, need);
-			const bool plain = L.plain_left > 0;
-			if (!plain) lf_row_step(L, t, T);
-			if (__builtin_amdgcn_ballot_w64(L.flush_n > 0)) lf_row_flush_wave(L, lane);
-			if (!__builtin_amdgcn_ballot_w64(L.live)) break;
-			const uint32_t mine = lf_plain_needs(L);
-			need = 0;
-			for (uint32_t bit = 1; bit <= 16; bit <<= 1) need |= __builtin_amdgcn_ballot_w64((mine & bit) != 0) ? bit : 0u;
-		}
-	} else {
-		LfRowLane M;   // the lane's second section
-		lf_row_init(M, tb, wins + (active_b ? my_section + 1 : 0) * LF_ROW_PITCH);
-		if (!active_b) { M.chan = 7; M.setup = false; }
-		for (;;) {
-			const bool pl = L.plain_left > 0, pm = M.plain_left > 0;
-			if (pl & pm) lf_row_step_plain2(L, M, T, TB);       // both sections' samples side by side: the common case
-			else {
-				if (pl) lf_row_step_plain(L, T);
-				if (pm) lf_row_step_plain(M, TB);
-			}
-			if (__builtin_amdgcn_ballot_w64((!pl & L.live) | (!pm & M.live))) {
-				if (!pl) lf_row_step(L, t, T);
-				if (!pm) lf_row_step(M, tb, TB);
-				if (__builtin_amdgcn_ballot_w64(L.flush_n > 0)) lf_row_flush_wave(L, lane);
-				if (__builtin_amdgcn_ballot_w64(M.flush_n > 0)) lf_row_flush_wave(M, lane);
-				if (!__builtin_amdgcn_ballot_w64(L.live | M.live)) break;
-			}
-		}
-		if (active_b) { J40_GLOBAL DevLfResult *r = (J40_GLOBAL DevLfResult *) tb.result; r->status = M.err; r->nb_varblocks = M.nb_varblocks; }
+	// Every pass: the lanes run through their stretches of plain samples (lf_row_run_plain, in the instantiation that covers what
+	// their channels need), until some live lane is at a channel start, a row's end or in a channel of another form; those lanes
+	// then take the general step (which says how long the lane's next run is), finished rows leave, and the needs are taken again
+	uint32_t need = LF_NEED_ALL;
+	for (;;) {
+		lf_row_run_plain(L, T, need);
+		const bool plain = L.plain_left > 0;
+		if (!plain) lf_row_step(L, t, T);
+		if (__builtin_amdgcn_ballot_w64(L.flush_n > 0)) lf_row_flush_wave(L, lane);
+		if (!__builtin_amdgcn_ballot_w64(L.live)) break;
+		const uint32_t mine = lf_plain_needs(L);
+		need = 0;
+		for (uint32_t bit = 1; bit <= 16; bit <<= 1) need |= __builtin_amdgcn_ballot_w64((mine & bit) != 0) ? bit : 0u;
 	}
 	if (active) {
 		J40_GLOBAL DevLfResult *r = (J40_GLOBAL DevLfResult *) t.result; r->status = L.err; r->nb_varblocks = L.nb_varblocks;
-		if (!PAIRS && raw) { r->raw_mask = L.raw_mask; r->stopped_at = L.stopped_at; }   // (for k_lf_predict, which follows on the stream)
+		if (raw) { r->raw_mask = L.raw_mask; r->stopped_at = L.stopped_at; }   // (for k_lf_predict, which follows on the stream)
 	}
 }
 
@@ -351,7 +321,7 @@ __global__ void __launch_bounds__(64) k_lf_predict(const DevLfLaneSet *sets, con
 		povf = __builtin_amdgcn_ballot_w64(povf) != 0;   // (channels follow one another in the stream: the first one with such a sample decides)
 	}
 	if (lane == 0) {
-		if (povf) r->status = ERR_POVF;   // (before the place the lane stopped: only such samples were looked at)
+		if (povf && r->status != (uint32_t) ERR_LFFB) r->status = ERR_POVF;   // (before the place the lane stopped: only such samples were looked at; a lane that gave up -- "lffb" -- may have left garbage there, and the host decodes its section anyway)
 		r->raw_mask = 0; r->stopped_at = 0;   // (the words are the plan build's from here on: DevLfSlot)
 	}
 }
@@ -393,23 +363,21 @@ void launch_lf_lanes(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t n
 	else hipLaunchKernelGGL(k_lf_lanes<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves);
 }
 
-// J40HIP_LF_KERNEL: "lanes" = the older decoder (alias entries and rows in global memory) for every launch; "rows2" = k_lf_rows with
-// two sections per lane (measured: 430 ms per launch against 215 -- the second section's instructions cost what the first one's
-// do, see lf_rows_dev.h); default: k_lf_rows with one section per lane, for every launch whose frames' tables fit its LDS budget
+// J40HIP_LF_KERNEL=lanes: the older decoder (alias entries and rows in global memory) for every launch; default: k_lf_rows, for
+// every frame whose tables fit its LDS budget
 static int lf_rows_mode() {
-	static const int v = [] { const char *e = getenv("J40HIP_LF_KERNEL"); return e && strcmp(e, "lanes") == 0 ? 0 : e && strcmp(e, "rows2") == 0 ? 2 : 1; }();
+	static const int v = [] { const char *e = getenv("J40HIP_LF_KERNEL"); return e && strcmp(e, "lanes") == 0 ? 0 : 1; }();
 	return v;
 }
 bool lf_rows_enabled() { return lf_rows_mode() != 0; }
 
-// packs the sections of `sets` into wavefronts of k_lf_rows (64 lanes, one or two sections each); returns the LDS bytes a wavefront
+// packs the sections of `sets` into wavefronts of k_lf_rows (64 lanes, a section each); returns the LDS bytes a wavefront
 // needs at most; the sets whose tables do not fit are left out and listed in `oversized` (k_lf_lanes takes them; without the list: 0 and no wavefronts). J40HIP_LF_ROWS_LDS_KB: what a
-// wavefront's tables and windows may take together (default 48: two 8K frames of seven clusters x 256 buckets -- 2 x (14.5 KB + 12
-// windows) = 41 KB -- so that such a workgroup still fits beside the coefficient decoder's on a compute unit)
+// wavefront's tables and windows may take together (default 48: one 8K frame of seven clusters x 256 buckets -- 28.5 KB of tables + 12 windows =
+// 35 KB -- so that such a workgroup still fits beside the coefficient decoder's 99 KB on a compute unit)
 uint32_t pack_lf_row_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std::vector<DevLfWave> *waves, std::vector<int32_t> *oversized) {
 	static const uint32_t budget = [] { const char *e = getenv("J40HIP_LF_ROWS_LDS_KB"); return (e && atoi(e) > 0 ? (uint32_t) atoi(e) : 48u) * 1024u; }();
 	const uint32_t win_bytes = 2u * LF_ROW_PITCH;
-	const int32_t per = lf_rows_mode() == 2 ? 2 : 1;
 	uint32_t most = 0, used = 0; int32_t lanes = 0;
 	DevLfWave cur; memset(&cur, 0, sizeof cur);
 	auto flush = [&] { if (cur.num_parts) { waves->push_back(cur); most = std::max(most, used); } memset(&cur, 0, sizeof cur); used = 0; lanes = 0; };
@@ -418,13 +386,13 @@ uint32_t pack_lf_row_waves(const DevLfLaneSet *sets_host, int32_t num_sets, std:
 		// (a frame whose tree and alias tables exceed a wavefront's LDS goes to k_lf_lanes -- that frame alone, not the launch's other frames)
 		if (tables + win_bytes > 60u * 1024u) { if (oversized) { oversized->push_back(i); continue; } waves->clear(); return 0; }
 		for (int32_t first = 0; first < sets_host[i].ntasks; ) {
-			if (lanes >= 64 * per || cur.num_parts >= LF_WAVE_PARTS || (cur.num_parts && used + tables + win_bytes > budget)) flush();
+			if (lanes >= 64 || cur.num_parts >= LF_WAVE_PARTS || (cur.num_parts && used + tables + win_bytes > budget)) flush();
 			// as many of the frame's sections as fit the budget (a wavefront's first frame may exceed it, up to the 60 KB a workgroup asks for at most)
 			const uint32_t limit = cur.num_parts ? budget : std::min(60u * 1024u, std::max(budget, tables + win_bytes));
 			const int32_t room = std::max(1, (int32_t) ((limit - used - tables) / win_bytes));
-			const int32_t count = std::min(std::min(64 * per - lanes, sets_host[i].ntasks - first), room);
+			const int32_t count = std::min(std::min(64 - lanes, sets_host[i].ntasks - first), room);
 			cur.part[cur.num_parts].set = i; cur.part[cur.num_parts].first_task = first; cur.part[cur.num_parts].count = count; ++cur.num_parts;
-			used += tables + (uint32_t) count * win_bytes; lanes += count; first += count;   // (`lanes` counts sections: 64 or 128 a wavefront)
+			used += tables + (uint32_t) count * win_bytes; lanes += count; first += count;
 		}
 	}
 	flush();
@@ -441,13 +409,11 @@ static bool lf_rows_raw() {
 void launch_lf_rows(const DevLfLaneSet *sets, const DevLfWave *waves, int32_t num_waves, uint32_t lds_bytes, hipStream_t stream, hipEvent_t started, hipEvent_t stopped) {
 	if (num_waves <= 0) return;
 	static bool configured = false;
-	if (!configured) { (void) hipFuncSetAttribute((const void *) k_lf_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); (void) hipFuncSetAttribute((const void *) k_lf_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); configured = true; }
-	const bool pairs = lf_rows_mode() == 2;
-	const int32_t raw = !pairs && lf_rows_raw() ? 1 : 0;
+	if (!configured) { (void) hipFuncSetAttribute((const void *) k_lf_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); configured = true; }
+	const int32_t raw = lf_rows_raw() ? 1 : 0;
 	hipEvent_t rows_stopped = raw ? nullptr : stopped;
-	if (started || rows_stopped) { if (pairs) hipExtLaunchKernelGGL(k_lf_rows<true>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, started, rows_stopped, 0, sets, waves, raw); else hipExtLaunchKernelGGL(k_lf_rows<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, started, rows_stopped, 0, sets, waves, raw); }
-	else if (pairs) hipLaunchKernelGGL(k_lf_rows<true>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves, raw);
-	else hipLaunchKernelGGL(k_lf_rows<false>, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves, raw);
+	if (started || rows_stopped) hipExtLaunchKernelGGL(k_lf_rows, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, started, rows_stopped, 0, sets, waves, raw);
+	else hipLaunchKernelGGL(k_lf_rows, dim3((unsigned) num_waves), dim3(64), lds_bytes, stream, sets, waves, raw);
 	if (raw) {
 		if (stopped) hipExtLaunchKernelGGL(k_lf_predict, dim3((unsigned) num_waves * 64u), dim3(64), 0, stream, nullptr, stopped, 0, sets, waves);
 		else hipLaunchKernelGGL(k_lf_predict, dim3((unsigned) num_waves * 64u), dim3(64), 0, stream, sets, waves);

@@ -7,7 +7,10 @@
 // chain of every sample), the row above was loaded from global memory two samples ahead, every sample was a 2-byte global store,
 // and on gfx9 one counter (vmcnt) covers loads AND stores: each wait for the alias entry also waited for the store of the sample
 // before. Here no sample of a row touches vector memory:
-//   * the alias tables of the lane's frame sit in LDS beside its tree (8 bytes per bucket: 14 KB for seven clusters of 256);
+//   * the alias tables of the lane's frame sit in LDS beside its tree, 16 bytes per bucket (28 KB for seven clusters of 256) in a form
+//     made for the straight-line step (round 6, "fast entries" below): both symbols a bucket can yield come with their frequency,
+//     their offset and their HYBRID INTEGER worked out -- how many extra bits the token asks for and the value those bits are added
+//     to --, so that a sample's symbol is one 16-byte read, two selects and a handful of bit-field moves;
 //   * a leaf of the staged tree carries its cluster and that cluster's hybrid-integer configuration (context map and configuration
 //     table resolved while staging: two dependent LDS reads fewer per sample), and the node a channel's walk starts from is kept
 //     in registers -- a channel whose subtree is a single leaf reads nothing but its alias entry;
@@ -48,28 +51,65 @@ enum { LF_ROW_WIN = 256,             // samples per lane window: an LfGroup is a
 // the tables of a lane's frame as k_lf_rows stages them
 struct LfRowTables {
 	const J40_LDS DevTreeNode *tree;   // leaves: value = cluster << 24 | configuration word of the cluster (lf_rows_leaf_word)
-	const J40_LDS uint64_t *alias;
+	const J40_LDS uint32_t *fast;      // the fast entries, four words per bucket ([cluster << log_alpha | bucket]): the straight-line step's
+	const J40_GLOBAL uint64_t *alias;  // the alias tables as the host built them, in global memory: the general step's (one sample in sixty)
 	int32_t log_alpha, log_bucket;
 	uint32_t uses;                     // LfLaneFrame::uses
 };
 
+// A fast entry: what the straight-line step needs of a bucket, for the symbol the bucket keeps ("left": the bucket's own index) and the
+// one it is aliased to ("right"), made from the host's 8-byte alias entry and the cluster's hybrid-integer configuration when the
+// tables are staged (j40.h:2441-2466 and 2313-2334 evaluated per symbol instead of per sample):
+//   word 0: cutoff (8 bits) | left frequency (13) << 8 | left extra bits (5) << 21 | left "iovf" << 26
+//   word 1: right frequency (13) | right extra bits (5) << 13 | right "iovf" << 18 | right offset (12) << 19
+//   word 2, 3: the left / right token's value with all its extra bits zero -- the token itself below the split; a token above the
+//     cluster's max_token ("iovf", an error of the stream) gets 2^30, which no plane holds: LF_FAST_IOVF_BASE
+// so that (word 0 >> 8) and word 1 have one layout: frequency, extra bits, "iovf", offset (zero on the left).
+// The extra bits come out of the low dword of the bit window together with a renormalisation's 16: a cluster whose tokens can ask for
+// more than 16 is LF_LEAF_WIDE and keeps the general step (entries of such a cluster are never read).
+typedef uint32_t LfFastQuad __attribute__((vector_size(16)));
+enum { LF_FAST_IOVF = 1u << 18, LF_FAST_IOVF_BASE = 1u << 30 };
+J40_DEV void lf_rows_token_info(uint32_t tok, uint32_t cfg, uint32_t *base, uint32_t *extra, uint32_t *iovf) {
+	const uint32_t split_exp = cfg & 15u, split = 1u << split_exp, msb = (cfg >> 4) & 15u, lsb = (cfg >> 8) & 15u, in_token = msb + lsb, mt = cfg >> 12;
+	*base = tok; *extra = 0; *iovf = 0;
+	if (tok < split) return;
+	if (tok > mt) { *base = (uint32_t) LF_FAST_IOVF_BASE; *iovf = 1; return; }
+	const uint32_t midbits = split_exp - in_token + ((tok - split) >> in_token);   // (split_exp >= in_token: j40.h:2313)
+	if (midbits > 16u) { *base = 0; return; }   // (a wide cluster's: not read)
+	const uint32_t top = 1u << msb, lo = tok & ((1u << lsb) - 1u), hi = (tok >> lsb) & (top - 1u);
+	*base = ((top | hi) << (midbits + lsb)) | lo; *extra = midbits;
+}
+// `e`: the host's entry of `bucket` (lane_symbol_in_cluster reads the same fields), `cfg`: the cluster's configuration word (LaneTables::cluster_cfg)
+J40_DEV LfFastQuad lf_rows_fast_entry(uint64_t e, uint32_t bucket, uint32_t cfg) {
+	const uint32_t elo = (uint32_t) e, ehi = (uint32_t) (e >> 32);
+	const uint32_t cutoff = elo & 0xffu, off_r = (elo >> 8) & 0xfffu, tok_r = (elo >> 20) & 0xffu, d_r = (uint32_t) (e >> 28) & 0x1fffu, d_l = (ehi >> 9) & 0x1fffu;
+	uint32_t base_l, extra_l, iovf_l, base_r, extra_r, iovf_r;
+	lf_rows_token_info(bucket, cfg, &base_l, &extra_l, &iovf_l);
+	lf_rows_token_info(tok_r, cfg, &base_r, &extra_r, &iovf_r);
+	LfFastQuad q;
+	q[0] = cutoff | (d_l << 8) | (extra_l << 21) | (iovf_l << 26);
+	q[1] = d_r | (extra_r << 13) | (iovf_r << 18) | (off_r << 19);
+	q[2] = base_l; q[3] = base_r;
+	return q;
+}
+
 // what a staged leaf carries instead of its context: `cfg` as in LaneTables::cluster_cfg (max_token from bit 12 up; tokens are
 // < 256, so clamping it to 11 bits keeps `token > max_token` intact), the cluster in the top byte, and bit 23 when a token of the
-// cluster can ask for more than 17 extra bits (a second refill inside the symbol: not for the straight-line step)
+// cluster can ask for more than 16 extra bits (with a renormalisation's 16 more than the window's low dword: not for the straight-line step)
 enum { LF_LEAF_CFG_MASK = 0x7fffff, LF_LEAF_WIDE = 1 << 23 };
 J40_DEV int32_t lf_rows_leaf_word(uint32_t cluster, uint32_t cfg) {
 	const uint32_t mt = cfg >> 12, split_exp = cfg & 15u, in_token = ((cfg >> 4) & 15u) + ((cfg >> 8) & 15u);
 	const uint32_t top_token = mt > 255u ? 255u : mt, split = 1u << split_exp;
 	const uint32_t most_extra = top_token >= split ? split_exp - in_token + ((top_token - split) >> in_token) : 0u;   // (split_exp >= in_token: j40.h:2313)
-	return (int32_t) ((cfg & 0xfffu) | ((mt > 0x7ffu ? 0x7ffu : mt) << 12) | (most_extra > 17u ? (uint32_t) LF_LEAF_WIDE : 0u) | (cluster << 24));
+	return (int32_t) ((cfg & 0xfffu) | ((mt > 0x7ffu ? 0x7ffu : mt) << 12) | (most_extra > 16u ? (uint32_t) LF_LEAF_WIDE : 0u) | (cluster << 24));
 }
 
-// LDS bytes of one frame's staged tables (tree nodes, then the alias tables)
+// LDS bytes of one frame's staged tables (tree nodes, then the fast entries)
 #ifdef __HIPCC__
 __host__ __device__
 #endif
 inline uint32_t lf_rows_table_bytes(int32_t num_nodes, int32_t num_clusters, int32_t log_alpha) {
-	return ((16u * (uint32_t) num_nodes + 15u) & ~15u) + 8u * ((uint32_t) num_clusters << log_alpha);
+	return ((16u * (uint32_t) num_nodes + 15u) & ~15u) + 16u * ((uint32_t) num_clusters << log_alpha);
 }
 
 struct LfRowLane {
@@ -90,6 +130,10 @@ struct LfRowLane {
 	// that predict alike
 	int32_t plain_left;                // how many of the lane's next samples take the straight-line step (set by the general step)
 	bool live;                         // not finished (lf_row_done), as of the lane's last general step
+	// what the straight-line steps since the last general step found wrong, looked at by the next general step (lf_row_deferred): an
+	// error there makes the lane report ERR_LFFB -- the host decodes the section and names the error
+	uint32_t acc_range, acc_iovf;      // OR of (sample + 32768): bits from 16 up say a sample left the plane's range; OR of the symbols' LF_FAST_IOVF bits
+	bool deferred_real;                // the lane ended on such a finding and it is an error of the stream (not a residual too wide for the plane)
 	bool raw;                          // the channel is left as residuals (the header of this file)
 	uint32_t raw_mask, stopped_at;     // DevLfResult's words
 	bool plain_ok, plain_wide;         // plain_wide: rows wider than the window, and nothing of the channel looks at the row above
@@ -128,7 +172,7 @@ J40_DEV void lf_row_init(LfRowLane &L, const J40_GLOBAL DevLfTask &t, J40_LDS in
 	L.x = L.y = 0; L.cw = L.chh = 0; L.root = 0; L.r_prop = -1; L.r_value = L.r_a = L.r_b = 0;
 	L.pw = L.pww = 0; L.a0 = L.a1 = L.a2 = L.a3 = L.a4 = 0; L.row = nullptr; L.win = win;
 	L.flush_n = 0; L.flush_dst = nullptr;
-	L.plain_left = 0; L.live = true;
+	L.plain_left = 0; L.live = true; L.acc_range = L.acc_iovf = 0; L.deferred_real = false;
 	L.raw = false; L.raw_mask = 0; L.stopped_at = lf_stopped_at(7, 0);
 	L.plain_ok = L.plain_wide = false; L.k_thr = 0; L.k_word_gt = L.k_word_le = 0;
 	L.c_x = L.c_y = L.c_w = L.c_n = L.c_nw = L.c_ne = L.c_ww = L.c_nww = 0; L.c_abs = L.c_first = false;
@@ -239,16 +283,27 @@ J40_DEV void lf_row_setup(LfRowLane &L, const J40_GLOBAL DevLfTask &t, const LfR
 	}
 }
 
+// The straight-line step checks nothing by itself: the bit position only grows, so one look at it at the end of a run tells whether any
+// symbol of the run read past the section's end ("shrt"); samples outside the plane's range ("povf", or a residual too wide) and tokens
+// above max_token ("iovf") leave a bit in an accumulator. Whatever came first, what followed it in the run is garbage (bounded: a run is
+// at most LF_ROW_WIN - 1 samples, the codestream is padded for the words such a run can ask for past its end), so the lane cannot
+// name the error: it ends with ERR_LFFB, the frame is decoded again by the host's decoder, which does (streams without errors never get
+// here; frames with a damaged LfGroup section pay the single-frame path). Nothing of the run's row counts as complete.
+J40_DEV bool lf_row_deferred(LfRowLane &L) {
+	const bool overrun = lane_bit_position(L.b) > L.end_bit && L.chan < 7 && !L.setup;
+	const bool range = (L.acc_range >> 16) != 0, iovf = (L.acc_iovf & (uint32_t) LF_FAST_IOVF) != 0;
+	if (!(overrun | range | iovf)) return false;
+	L.deferred_real = overrun | iovf | (range & !L.raw);
+	L.x = 0;
+	lf_row_fail(L, ERR_LFFB);
+	return true;
+}
+
 // one sample of the lane's stream (or the start of its next channel). The caller copies a completed piece out (L.flush_n) before
 // the lane's next step.
 J40_DEV void lf_row_step_general(LfRowLane &L, const J40_GLOBAL DevLfTask &t, const LfRowTables &T) {
 	if (lf_row_done(L)) return;
-	if (L.err) {   // the straight-line step raised it (lf_plain_commit moved x past the sample): the lane ends here, x - 1 samples into its row
-		L.x -= 1;
-		if (L.raw && !L.plain_wide && L.x > 0) { L.flush_n = L.x; L.flush_dst = L.row; }   // (k_lf_predict looks at the samples before it)
-		lf_row_fail(L, L.err);
-		return;
-	}
+	if (lf_row_deferred(L)) return;   // (the straight-line steps since the last general step ran into something)
 	if (L.setup) { lf_row_setup(L, t, T); if (L.chan == 7 || L.err) return; }
 	lane_bits_refill(L.b);
 	const int32_t x = L.x, y = L.y, cw = L.cw;
@@ -362,140 +417,101 @@ J40_DEV int32_t lf_mad24(int32_t a, int32_t b, int32_t c) { return a * b + c; }
 // unpack_signed_dev for the token values a symbol without an error yields (0 <= u < 2^30), as two instructions instead of a branch
 J40_DEV int32_t lf_unzigzag(int32_t u) { return (int32_t) ((uint32_t) u >> 1) ^ -(u & 1); }
 
-// The step in three phases, so that TWO sections can go through it side by side on one lane (lf_row_step_plain2, k_lf_rows<true>):
-// everything that reads LDS comes before anything that writes it, and between the phases the two sections' instructions are
-// independent of each other; compiled with the max-ILP scheduling strategy they do come out interleaved. MEASURED AND NOT THE DEFAULT:
-// a launch of 128 8K frames takes 421-450 ms with two sections per lane against 212-222 ms with one -- the same cycles per sample.
-// The step runs at about nine cycles per instruction either way (1 690 cycles for its 185, mostly 8-byte encodings); the
-// microbenchmark's best, four independent chains of 4-byte instructions, was 5.3. What bounds a lone wavefront here is not the
-// dependence between its instructions but how fast it is fed them, and only fewer (or shorter) instructions per sample help.
-// What the lanes of a wavefront need of the step, taken together (wave-uniform; lf_plain_needs, recomputed whenever a lane has been
-// through the general step): the step is instantiated for every combination and the kernel jumps to the one that covers its lanes --
-// a wavefront whose lanes all sit in leaf-only channels predicted by the clamped gradient runs 150 instructions a sample, not 185.
+// Round 5 measured (and kept out of the default, since removed) two sections per lane side by side: 421-450 ms per launch against
+// 212-222 -- a lone wavefront is bound by how fast it is fed instructions (six to nine cycles each), not by the dependences between
+// them, and only fewer instructions per sample help. So: the step is instantiated for what the lanes of the wavefront need of it,
+// taken together (wave-uniform; lf_plain_needs, recomputed whenever a lane has been through the general step) -- a wavefront whose
+// lanes all sit in channels left as residuals runs no neighbour, no property and no prediction at all --, and (round 6, second half)
+// the symbol itself comes out of a FAST ENTRY (above): the hybrid integer is worked out per symbol when the tables are staged, the
+// two bit-window reads of a symbol (a renormalisation's 16 bits, the token's extra bits) are one shift, nothing is checked per sample
+// (lf_row_deferred) and the run's length is known before it starts (lf_row_run_plain_for): 105 -> ~60 instructions for a residual sample.
 enum { LF_NEED_TEST = 1,    // some lane's channel has a test (two different leaf words)
        LF_NEED_LIN = 2, LF_NEED_SEL = 4, LF_NEED_GRAD = 8,   // the predictions some lane uses: a (halved) sum of neighbours, "select", the clamped gradient
        LF_NEED_MUL = 16,    // some lane's leaves have a multiplier other than 1 or an offset
        LF_NEED_ALL = 31,
        LF_NEED_PRED = LF_NEED_TEST | LF_NEED_LIN | LF_NEED_SEL | LF_NEED_GRAD };   // none of these: every lane of the step is in a RAW channel
 
-struct LfPlainCtx {
-	int32_t x, slot, ahead3, pw, pn, pnw, pne, pww;
-	uint32_t word, idx, bucket; uint64_t entry;
-};
+#ifdef __HIPCC__
+J40_DEV uint32_t lf_bfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }   // (off + width <= 32)
+// (state << 16) | (window & 0xffff) for a state below 2^16, one byte permute
+J40_DEV uint32_t lf_renorm_word(uint32_t state, uint32_t window) { return __builtin_amdgcn_perm(state, window, 0x05040100u); }
+#else
+J40_DEV uint32_t lf_bfe(uint32_t v, uint32_t off, uint32_t width) { return width ? (v >> off) & (0xffffffffu >> (32u - width)) : 0u; }
+J40_DEV uint32_t lf_renorm_word(uint32_t state, uint32_t window) { return (state << 16) | (window & 0xffffu); }
+#endif
 
-// refill, neighbours, the property and the walk; asks LDS for the alias entry and the row above's next sample
+// One sample, one basic block. The lane's channel has the form lf_row_plan_channel accepts, its first symbol has been read and the
+// sample is not the last of its row (lf_row_plain_run). Checks nothing (lf_row_deferred does, after the run) and leaves plain_left
+// alone (the caller counts). `wp`: the sample's slot of the lane's window (a run never wraps around the window: lf_row_plain_run), moved
+// on by the step -- as is L.x when something of the step looks at it; when nothing does (residuals only) the caller adds the run's length.
 template <uint32_t NEED>
-J40_DEV void lf_plain_front(LfRowLane &L, const LfRowTables &T, LfPlainCtx &c) {
+J40_DEV void lf_row_step_plain_for(LfRowLane &L, const LfRowTables &T, J40_LDS int16_t *&wp) {
 	LaneBits &b = L.b;
 	{   // lane_bits_refill as selects; the word after next is asked for every time (the same word again when nothing was appended)
 		const bool need = b.nbits <= 32;
-		b.bits |= (uint64_t) (need ? b.ahead : 0u) << (need ? b.nbits : 0);
-		b.nbits += need ? 32 : 0; b.pos += need ? 4u : 0u;
+		const uint32_t inc = need ? 4u : 0u;
+		b.bits |= (uint64_t) (need ? b.ahead : 0u) << (b.nbits & 63);   // (nothing appended: zero, shifted by whatever)
+		b.nbits += (int32_t) (8u * inc); b.pos += inc;
 		b.ahead = lane_load32(b.base, b.pos);
 	}
-	const int32_t x = L.x, y = L.y, cw = L.cw;
-	c.x = x; c.slot = x & (LF_ROW_WIN - 1);   // (= x unless the row is wider than the window)
-	if (!(NEED & LF_NEED_PRED)) {   // residuals only: no neighbour is looked at
-		c.ahead3 = 0; c.pw = c.pn = c.pnw = c.pne = c.pww = 0;
-		c.word = L.k_word_le;
-		c.idx = L.state & 0xfff; c.bucket = c.idx >> T.log_bucket;
-		c.entry = T.alias[((c.word >> 24) << T.log_alpha) + c.bucket];
-		return;
+	uint32_t word = L.k_word_le;   // (no lane tests anything: both words are the leaf's)
+	int32_t pw = 0, pn = 0, pnw = 0, pne = 0, pww = 0, ahead3 = 0;
+	if (NEED & LF_NEED_PRED) {
+		const int32_t x = L.x, y = L.y, cw = L.cw;
+		L.x = x + 1;
+		ahead3 = wp[3];   // the row above at x + 3, for the next sample's registers (slots past the row's end are never looked at)
+		const bool up = y > 0, left = x > 0;
+		pw = left ? L.pw : up ? L.a2 : 0;
+		pn = up ? L.a2 : pw;
+		pnw = left && up ? L.a1 : pw;
+		pne = x + 1 < cw && up ? L.a3 : pn;
+		pww = x > 1 ? L.pww : pw;
+		// the property and the walk: one test, or none
+		if (NEED & LF_NEED_TEST) {
+			const int32_t pnww = x > 1 && up ? L.a0 : pww;
+			int32_t val = lf_mad24(L.c_x, x, lf_mad24(L.c_y, y, lf_mad24(L.c_w, pw, lf_mad24(L.c_n, pn, 0)))) + lf_mad24(L.c_nw, pnw, lf_mad24(L.c_ne, pne, lf_mad24(L.c_ww, pww, lf_mad24(L.c_nww, pnww, 0))));   // (two chains of four)
+			val = L.c_abs ? mod_abs(val) : val;
+			val = L.c_first && !left ? pw : val;
+			word = val > L.k_thr ? L.k_word_gt : L.k_word_le;
+		}
 	}
-	c.ahead3 = L.win[c.slot + 3];   // the row above at x + 3, for the next sample's registers (slots past the row's end are never looked at)
-	const bool up = y > 0, left = x > 0;
-	const int32_t pw = left ? L.pw : up ? L.a2 : 0;
-	const int32_t pn = up ? L.a2 : pw;
-	const int32_t pnw = left && up ? L.a1 : pw;
-	const int32_t pne = x + 1 < cw && up ? L.a3 : pn;
-	const int32_t pww = x > 1 ? L.pww : pw;
-	const int32_t pnww = x > 1 && up ? L.a0 : pww;
-	c.pw = pw; c.pn = pn; c.pnw = pnw; c.pne = pne; c.pww = pww;
-	// the property and the walk: one test, or none (both words the leaf's)
-	if (NEED & LF_NEED_TEST) {
-		int32_t val = lf_mad24(L.c_x, x, lf_mad24(L.c_y, y, lf_mad24(L.c_w, pw, lf_mad24(L.c_n, pn, 0)))) + lf_mad24(L.c_nw, pnw, lf_mad24(L.c_ne, pne, lf_mad24(L.c_ww, pww, lf_mad24(L.c_nww, pnww, 0))));   // (two chains of four)
-		val = L.c_abs ? mod_abs(val) : val;
-		val = L.c_first && !left ? pw : val;
-		c.word = val > L.k_thr ? L.k_word_gt : L.k_word_le;
-	} else c.word = L.k_word_le;   // (no lane tests anything: both words are the leaf's)
-	// the alias entry of the state's bucket in the leaf's cluster (lane_symbol_in_cluster)
-	c.idx = L.state & 0xfff; c.bucket = c.idx >> T.log_bucket;
-	c.entry = T.alias[((c.word >> 24) << T.log_alpha) + c.bucket];
-}
-
-// the symbol (rANS step + hybrid integer, lane_symbol_in_cluster<STRAIGHT> from the alias entry on), the prediction, the sample;
-// returns the sample, *code = the error this sample raises (0: none)
-template <uint32_t NEED>
-J40_DEV int32_t lf_plain_middle(LfRowLane &L, const LfRowTables &T, const LfPlainCtx &c, uint32_t *code) {
-	LaneBits &b = L.b;
-	const uint32_t m = c.word & (uint32_t) LF_LEAF_CFG_MASK, pos = c.idx & ((1u << T.log_bucket) - 1);
-	const uint32_t elo = (uint32_t) c.entry, ehi = (uint32_t) (c.entry >> 32);
-	const bool aliased = pos >= (elo & 0xff);
-	const int32_t token = (int32_t) (aliased ? (elo >> 20) & 0xff : c.bucket);
-	const uint32_t offset = aliased ? (elo >> 8) & 0xfff : 0;
-	const uint32_t d = aliased ? (uint32_t) (c.entry >> 28) & 0x1fff : (ehi >> 9) & 0x1fff;
-	uint32_t state = d * (L.state >> 12) + offset + pos;
+	// the symbol: rANS step (j40.h:2441-2466) and hybrid integer (j40.h:2313-2334) from the fast entry of the state's bucket in the leaf's cluster
+	const uint32_t st = L.state, bucket = lf_bfe(st, (uint32_t) T.log_bucket, (uint32_t) T.log_alpha), pos = st & ((1u << T.log_bucket) - 1u);
+	const LfFastQuad e = *(const J40_LDS LfFastQuad *) (T.fast + 4u * ((word >> 24) << T.log_alpha) + 4u * bucket);
+	const bool aliased = pos >= (e[0] & 0xffu);
+	const uint32_t w = aliased ? e[1] : e[0] >> 8, base = aliased ? e[3] : e[2];
+	const uint32_t state = (w & 0x1fffu) * (st >> 12) + (w >> 19) + pos;   // (both factors below 2^24; bits 19 up: the offset, nothing above it)
 	const bool renorm = state < (1u << 16);
-	const uint32_t low = lane_bits_take(b, renorm ? 16 : 0);
-	L.state = renorm ? (state << 16) | low : state;
-	const bool short1 = lane_bit_position(b) > L.end_bit;
-	const int32_t split_exp = (int32_t) (m & 15), split = 1 << split_exp;
-	const bool big = token >= split;
-	const int32_t mt = (int32_t) (m >> 12);
-	const bool iovf = big && token > mt;
-	const int32_t tok = iovf ? mt : token;
-	const int32_t msb = (int32_t) ((m >> 4) & 15), lsb = (int32_t) ((m >> 8) & 15), in_token = msb + lsb;
-	const int32_t midbits = big ? split_exp - in_token + ((tok - split) >> in_token) : 0;   // (<= 17: lf_rows_leaf_word; the window holds them)
-	const int32_t mid = (int32_t) lane_bits_take(b, midbits);
-	const bool short2 = lane_bit_position(b) > L.end_bit;
-	const int32_t top = 1 << msb;
-	const int32_t lo = tok & ((1 << lsb) - 1), hi = (tok >> lsb) & (top - 1);
-	const int32_t value = ((top | hi) << (midbits + lsb)) | ((mid << lsb) | lo);
-	const uint32_t e2 = short1 ? (uint32_t) ERR_SHRT : iovf ? (uint32_t) ERR_IOVF : short2 ? (uint32_t) ERR_SHRT : 0u;
-	const int32_t u = big ? value : token;
+	const uint32_t window = (uint32_t) b.bits, skip = renorm ? 16u : 0u, extra = (w >> 13) & 31u;   // (<= 16 + 16 of the > 32 bits the window holds)
+	L.state = renorm ? lf_renorm_word(state, window) : state;
+	const uint32_t mid = lf_bfe(window, skip, extra), taken = skip + extra;
+	b.bits >>= taken; b.nbits -= (int32_t) taken;
+	const int32_t u = (int32_t) (base + (mid << ((word >> 8) & 15u)));   // (the token's value: its bits are apart from the extra bits')
 	// the prediction
 	int32_t pred = 0;
 	if (NEED & LF_NEED_LIN) {
-		int32_t lin = lf_mad24(L.p_w, c.pw, lf_mad24(L.p_n, c.pn, 0)) + lf_mad24(L.p_nw, c.pnw, lf_mad24(L.p_ne, c.pne, lf_mad24(L.p_ww, c.pww, 0)));
+		int32_t lin = lf_mad24(L.p_w, pw, lf_mad24(L.p_n, pn, 0)) + lf_mad24(L.p_nw, pnw, lf_mad24(L.p_ne, pne, lf_mad24(L.p_ww, pww, 0)));
 		pred = L.p_half ? (lin + (int32_t) ((uint32_t) lin >> 31)) >> 1 : lin;   // (a + b) / 2, towards zero
 	}
 	if (NEED & LF_NEED_SEL) {
-		const int32_t sel = mod_abs(c.pn - c.pnw) < mod_abs(c.pw - c.pnw) ? c.pw : c.pn;
+		const int32_t sel = mod_abs(pn - pnw) < mod_abs(pw - pnw) ? pw : pn;
 		pred = (NEED & (LF_NEED_LIN | LF_NEED_GRAD)) ? (L.p_kind == 1 ? sel : pred) : sel;   // (the only kind around: no lane to tell apart)
 	}
 	if (NEED & LF_NEED_GRAD) {
-		const int32_t grad = mod_gradient(c.pw, c.pn, c.pnw);
+		const int32_t grad = mod_gradient(pw, pn, pnw);
 		pred = (NEED & (LF_NEED_LIN | LF_NEED_SEL)) ? (L.p_kind == 2 ? grad : pred) : grad;
 	}
 	const int32_t res = (NEED & LF_NEED_MUL) ? lf_unzigzag(u) * L.p_mul + L.p_off : lf_unzigzag(u);
 	const int32_t v = (NEED & LF_NEED_PRED) ? res + (L.raw ? 0 : pred) : res;
-	const uint32_t range = (NEED & LF_NEED_PRED) ? (L.raw ? (uint32_t) ERR_LFFB : (uint32_t) ERR_POVF) : (uint32_t) ERR_LFFB;   // (a residual too wide for the plane: the header of this file)
-	*code = e2 ? e2 : v < -32768 || v > 32767 ? range : 0u;
-	return v;
-}
-
-// an error ends the lane's run (the general step it goes to next ends the lane and notes where: what the failing sample left in the
-// window is never looked at); otherwise the sample is stored and the registers slide
-template <uint32_t NEED>
-J40_DEV void lf_plain_commit(LfRowLane &L, const LfPlainCtx &c, int32_t v, uint32_t code) {
-	L.err = L.err ? L.err : code;
-	L.plain_left = code ? 0 : L.plain_left - 1;
-	L.win[c.slot] = (int16_t) v;
+	// what lf_row_deferred looks at: the sample's range (LF_FAST_IOVF_BASE is outside it unless a multiplier folds it back: then the bit)
+	L.acc_range |= (uint32_t) (v + 32768);
+	if (NEED & LF_NEED_MUL) L.acc_iovf |= w;
+	*wp++ = (int16_t) v;
 	if (NEED & LF_NEED_PRED) {
 		L.pww = L.pw; L.pw = v;
-		L.a0 = L.a1; L.a1 = L.a2; L.a2 = L.a3; L.a3 = L.a4; L.a4 = c.ahead3;
+		L.a0 = L.a1; L.a1 = L.a2; L.a2 = L.a3; L.a3 = L.a4; L.a4 = ahead3;
 	}
-	L.x = c.x + 1;
 }
-
-template <uint32_t NEED>
-J40_DEV void lf_row_step_plain_for(LfRowLane &L, const LfRowTables &T) {
-	LfPlainCtx c; uint32_t code;
-	lf_plain_front<NEED>(L, T, c);
-	const int32_t v = lf_plain_middle<NEED>(L, T, c, &code);
-	lf_plain_commit<NEED>(L, c, v, code);
-}
-J40_DEV void lf_row_step_plain(LfRowLane &L, const LfRowTables &T) { lf_row_step_plain_for<LF_NEED_ALL>(L, T); }
 
 // this lane's share of the wavefront's needs (0 for a lane that takes no plain step)
 J40_DEV uint32_t lf_plain_needs(const LfRowLane &L) {
@@ -504,31 +520,39 @@ J40_DEV uint32_t lf_plain_needs(const LfRowLane &L) {
 	return (L.k_word_gt != L.k_word_le ? (uint32_t) LF_NEED_TEST : 0u) | (L.p_kind == 0 ? (uint32_t) LF_NEED_LIN : L.p_kind == 1 ? (uint32_t) LF_NEED_SEL : (uint32_t) LF_NEED_GRAD)
 		| (L.p_mul != 1 || L.p_off != 0 ? (uint32_t) LF_NEED_MUL : 0u);
 }
-// the step for lanes whose needs add up to `need`
-#define LF_PLAIN_CASE(n) case n: lf_row_step_plain_for<n>(L, T); break;
+// one sample of a lane inside its run, through the step for lanes whose needs add up to `need` (tests/hostsim; the kernel: lf_row_run_plain)
+#define LF_PLAIN_CASE(n) case n: lf_row_step_plain_for<n>(L, T, wp); break;
 J40_DEV void lf_row_step_plain_needs(LfRowLane &L, const LfRowTables &T, uint32_t need) {
+	J40_LDS int16_t *wp = L.win + (L.x & (LF_ROW_WIN - 1));
+	if (!(need & (uint32_t) LF_NEED_PRED)) L.x += 1;
 	switch (need) {
 	LF_PLAIN_CASE(0) LF_PLAIN_CASE(1) LF_PLAIN_CASE(2) LF_PLAIN_CASE(3) LF_PLAIN_CASE(4) LF_PLAIN_CASE(5) LF_PLAIN_CASE(6) LF_PLAIN_CASE(7)
 	LF_PLAIN_CASE(8) LF_PLAIN_CASE(9) LF_PLAIN_CASE(10) LF_PLAIN_CASE(11) LF_PLAIN_CASE(12) LF_PLAIN_CASE(13) LF_PLAIN_CASE(14) LF_PLAIN_CASE(15)
 	LF_PLAIN_CASE(16) LF_PLAIN_CASE(17) LF_PLAIN_CASE(18) LF_PLAIN_CASE(19) LF_PLAIN_CASE(20) LF_PLAIN_CASE(21) LF_PLAIN_CASE(22) LF_PLAIN_CASE(23)
 	LF_PLAIN_CASE(24) LF_PLAIN_CASE(25) LF_PLAIN_CASE(26) LF_PLAIN_CASE(27) LF_PLAIN_CASE(28) LF_PLAIN_CASE(29) LF_PLAIN_CASE(30)
-	default: lf_row_step_plain_for<LF_NEED_ALL>(L, T); break;
+	default: lf_row_step_plain_for<LF_NEED_ALL>(L, T, wp); break;
 	}
+	L.plain_left -= 1;
 }
 #undef LF_PLAIN_CASE
 #ifdef __HIPCC__
-// The kernel's inner loop: the wavefront's lanes step through their runs of plain samples until some live lane is out of its run
-// (a channel start, a row's end: the caller's business). The choice among the instantiations is made once per such stretch -- a
-// wave-uniform switch is a tree of scalar branches, too dear to walk per sample --, a stretch being hundreds of samples.
+// The kernel's inner loop: the wavefront's lanes step through their runs of plain samples until some live lane is out of its run (a
+// channel start, a row's end: the caller's business). Nothing inside a run can end it early (lf_row_deferred), so its length is known
+// beforehand: the shortest run among the lanes that are in one -- or ONE step when some live lane is not (a lane that stays in a
+// channel of another form does not hold the others up, and they do not hold it up either). The loop is a scalar count; the choice among
+// the instantiations is made once per such stretch (a wave-uniform switch is a tree of scalar branches, too dear to walk per sample).
 template <uint32_t NEED>
 J40_DEV void lf_row_run_plain_for(LfRowLane &L, const LfRowTables &T) {
-	// (Measured in round 6: the same loop with the execution mask set once per stretch -- `if (plain) do step while (all still plain)`,
-	// the loop's own test a comparison of two scalars -- is SLOWER, 151 ms per launch against 135: profiles/r06_lf_rows_*_call_h*.)
-	for (;;) {   // (the lanes in a run step at least once per call: a lane that stays in a channel of another form does not hold them up)
-		const bool plain = L.plain_left > 0;
-		if (!__builtin_amdgcn_ballot_w64(plain)) return;
-		if (plain) lf_row_step_plain_for<NEED>(L, T);
-		if (__builtin_amdgcn_ballot_w64(!(L.plain_left > 0) & L.live)) return;
+	const bool plain = L.plain_left > 0;
+	if (!__builtin_amdgcn_ballot_w64(plain)) return;
+	int32_t shortest = plain ? L.plain_left : 0x7fffffff;
+	for (int32_t d = 32; d >= 1; d >>= 1) shortest = mod_min(shortest, __shfl_xor(shortest, d));
+	const int32_t n = __builtin_amdgcn_ballot_w64(!plain & L.live) ? 1 : __builtin_amdgcn_readfirstlane(shortest);
+	if (plain) {
+		J40_LDS int16_t *wp = L.win + (L.x & (LF_ROW_WIN - 1));   // (= x unless the row is wider than the window)
+		for (int32_t i = 0; i < n; ++i) lf_row_step_plain_for<NEED>(L, T, wp);
+		if (!(NEED & LF_NEED_PRED)) L.x += n;
+		L.plain_left -= n;
 	}
 }
 #define LF_PLAIN_CASE(n) case n: lf_row_run_plain_for<n>(L, T); break;
@@ -541,19 +565,8 @@ J40_DEV void lf_row_run_plain(LfRowLane &L, const LfRowTables &T, uint32_t need)
 	default: lf_row_run_plain_for<LF_NEED_ALL>(L, T); break;
 	}
 }
-#endif
 #undef LF_PLAIN_CASE
-
-// two sections (each with the tables of its frame), one sample each
-J40_DEV void lf_row_step_plain2(LfRowLane &A, LfRowLane &B, const LfRowTables &TA, const LfRowTables &TB) {
-	LfPlainCtx ca, cb; uint32_t code_a, code_b;
-	lf_plain_front<LF_NEED_ALL>(A, TA, ca);
-	lf_plain_front<LF_NEED_ALL>(B, TB, cb);
-	const int32_t va = lf_plain_middle<LF_NEED_ALL>(A, TA, ca, &code_a);
-	const int32_t vb = lf_plain_middle<LF_NEED_ALL>(B, TB, cb, &code_b);
-	lf_plain_commit<LF_NEED_ALL>(A, ca, va, code_a);
-	lf_plain_commit<LF_NEED_ALL>(B, cb, vb, code_b);
-}
+#endif
 
 // ---- the predictions of RAW channels (k_lf_predict; tests/hostsim runs the serial form) ----
 // where channel `chan` of a section lies and how large it is (as lf_row_setup has it)
@@ -601,6 +614,7 @@ J40_DEV int32_t lf_predict_channel_serial(J40_GLOBAL int16_t *plane, int32_t cw,
 // a section's RAW channels in stream order (serial); returns the section's status: "povf" if a sample before the place the lane
 // stopped leaves the range, else the lane's
 J40_DEV uint32_t lf_predict_section_serial(const J40_GLOBAL DevLfTask &t, uint32_t status, int32_t nb_varblocks, uint32_t raw_mask, uint32_t stopped_at) {
+	if (status == (uint32_t) ERR_LFFB) return status;   // (the lane gave up, perhaps over garbage: the host decodes the section)
 	for (int32_t chan = 0; chan < 7; ++chan) {
 		const int32_t nib = (int32_t) ((raw_mask >> (4 * chan)) & 15u);
 		if (nib < 2) continue;   // samples already (0), or nothing to add (predictor 0)

@@ -368,6 +368,10 @@ struct DevLfLaneSet {
 // sections of one DevLfLaneSet; the tables of every part are staged in LDS side by side.
 enum { LF_WAVE_PARTS = 16 };
 struct DevLfWave { int32_t num_parts, pad; struct { int32_t set, first_task, count, pad; } part[LF_WAVE_PARTS]; };
+// Readable bytes behind a frame's codestream on the device: the lane decoders ask for up to three words past the position they stop
+// at, and k_lf_rows' straight-line runs look at their position only when a run is over (lf_rows_dev.h, lf_row_deferred): a run is at
+// most 255 samples of at most 32 bits each
+enum { LF_CODESTREAM_PAD = 1280 };
 enum { ERR_LFFB = ('l' << 24) | ('f' << 16) | ('f' << 8) | 'b' };   // not an error of the stream: the second Modular header is not the plain one the device handles; the host decodes this section
 
 // ---- the LF-dependent half of a VarDCT frame's plan, built on the device (plan_dev.h, plan_kernels.hip) ----

@@ -940,7 +940,7 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_lanes_check
 // LF_ROW_PITCH, completed pieces copied out between the steps. `win` caps the row length served from the window for the test's
 // purposes only through the stream's own sizes (LF_ROW_WIN is a compile-time constant); frames wider than 256 cells per LfGroup
 // do not exist, the varblock-info channel exercises the wide path.
-static int64_t plain_steps = 0, general_steps = 0, need_seen[32], raw_seen = 0;
+static int64_t plain_steps = 0, general_steps = 0, need_seen[32], raw_seen = 0, deferred_sections = 0;
 static int32_t general_only = 0;
 // (how many samples of the last checks went through the straight-line step / the general one; mode 1: the general step only)
 extern "C" __attribute__((visibility("default"))) void hostsim_lf_rows_counts(int64_t *plain, int64_t *general, int32_t reset, int32_t mode) {
@@ -953,6 +953,8 @@ extern "C" __attribute__((visibility("default"))) void hostsim_lf_rows_counts(in
 extern "C" __attribute__((visibility("default"))) void hostsim_lf_rows_needs_seen(int64_t *out32) { for (int i = 0; i < 32; ++i) out32[i] = need_seen[i]; }
 // (how many channels the checks' lanes left as residuals, since the library was loaded)
 extern "C" __attribute__((visibility("default"))) int64_t hostsim_lf_rows_raw_channels() { return raw_seen; }
+// (how many sections ended "lffb" because a run of straight-line steps ran into an error of the stream -- each checked to be one the host's decoder reports too)
+extern "C" __attribute__((visibility("default"))) int64_t hostsim_lf_rows_deferred_sections() { return deferred_sections; }
 extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_check(const uint8_t *buf, size_t size, int32_t lanes, int32_t *sections, int32_t *failed) {
 	const uint8_t *cs; size_t cs_size; std::vector<uint8_t> storage;
 	Frame fr;
@@ -969,15 +971,17 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_check(
 	FrontPlan fp;
 	if (build_front_plan(fr, st, cs_size, extra_prec, true, &fp) || !fp.lf_device) return -1;
 	std::vector<uint8_t> padded(cs, cs + cs_size);
-	padded.resize(cs_size + 32, 0);
+	padded.resize(cs_size + LF_CODESTREAM_PAD, 0);
 	// the staged tree
 	std::vector<DevTreeNode> tree = fp.lf_tree;
 	for (DevTreeNode &n : tree) if (n.prop < 0) { const uint32_t cl = fp.lf_ctx_map[(size_t) n.value]; n.value = lf_rows_leaf_word(cl, fp.lf_cfg[cl]); }
+	std::vector<LfFastQuad> fast(fp.lf_alias.size());   // (k_lf_rows' staging: lf_decode.hip)
+	for (size_t i = 0; i < fast.size(); ++i) fast[i] = lf_rows_fast_entry(fp.lf_alias[i], (uint32_t) i & ((1u << fp.lf_log_alpha) - 1u), fp.lf_cfg[i >> fp.lf_log_alpha]);
 	LfRowTables T;
-	T.tree = tree.data(); T.alias = fp.lf_alias.data(); T.log_alpha = fp.lf_log_alpha; T.log_bucket = 12 - fp.lf_log_alpha; T.uses = fp.lf_uses;
+	T.tree = tree.data(); T.fast = (const uint32_t *) fast.data(); T.alias = fp.lf_alias.data(); T.log_alpha = fp.lf_log_alpha; T.log_bucket = 12 - fp.lf_log_alpha; T.uses = fp.lf_uses;
 	// (as the kernel runs by default: leaf-only channels are left as residuals and predicted afterwards; mode bit 2: every channel predicted
-	// by its lane; two sections per lane never leave residuals)
-	if (!(general_only & 4) && !(general_only & 2)) T.uses |= (uint32_t) LF_USES_RAW;
+	// by its lane)
+	if (!(general_only & 4)) T.uses |= (uint32_t) LF_USES_RAW;
 	if (lanes < 1) lanes = 1;
 	if (lanes > 64) lanes = 64;
 	struct Out { std::vector<int16_t> lf[3], xfy, bfy, info, sharp; DevLfResult res; DevLfTask t; };
@@ -1005,27 +1009,17 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_check(
 		}
 		for (bool any = true; any; ) {
 			any = false;
-			// (the kernel's dispatch: the straight-line step where the lane's sample allows it; mode bit 1: two sections per lane, both
-			// through lf_row_step_plain2 when both are inside a run -- k_lf_rows<true>)
-			const size_t per = (general_only & 2) ? 2 : 1;
-			// (what the stepped lanes ask of the plain step together, as the kernel works it out after every general step: the
-			// instantiation that covers them all)
+			// (the kernel's dispatch: the straight-line step where the lane's sample allows it, in the instantiation that covers what the
+			// stepped lanes ask of it together, as the kernel works that out after every general step)
 			uint32_t need = 0;
 			for (size_t k = 0; k < n; ++k) need |= lf_plain_needs(L[k]);
-			if (per == 1) ++need_seen[need & 31];
-			for (size_t k = 0; k < n; k += per) {
-				const bool two = per == 2 && k + 1 < n;
-				LfRowLane &A = L[k], &B = L[two ? k + 1 : k];
-				if (lf_row_done(A) && (!two || lf_row_done(B))) continue;
+			++need_seen[need & 31];
+			for (size_t k = 0; k < n; ++k) {
+				LfRowLane &A = L[k];
+				if (lf_row_done(A)) continue;
 				any = true;
-				const bool pa = A.plain_left > 0 && !(general_only & 1), pb = two && B.plain_left > 0 && !(general_only & 1);
-				if (pa && pb) { lf_row_step_plain2(A, B, T, T); plain_steps += 2; }
-				else {
-					if (pa) { if (per == 1) lf_row_step_plain_needs(A, T, need); else lf_row_step_plain(A, T); ++plain_steps; }
-					if (pb) { lf_row_step_plain(B, T); ++plain_steps; }
-				}
-				if (!pa && !lf_row_done(A)) { lf_row_step(A, out[k].t, T); ++general_steps; }
-				if (two && !pb && !lf_row_done(B)) { lf_row_step(B, out[k + 1].t, T); ++general_steps; }
+				if (A.plain_left > 0 && !(general_only & 1)) { lf_row_step_plain_needs(A, T, need); ++plain_steps; }
+				else { lf_row_step(A, out[k].t, T); ++general_steps; }
 			}
 			for (size_t k = 0; k < n; ++k) if (L[k].flush_n > 0) lf_row_flush_serial(L[k]);
 		}
@@ -1039,7 +1033,12 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_check(
 			if (sections) ++*sections;
 			for (int c = 0; c < 7; ++c) if ((L[k].raw_mask >> (4 * c)) & 15u) ++raw_seen;
 			const uint32_t status = lf_predict_section_serial(out[k].t, L[k].err, L[k].nb_varblocks, L[k].raw_mask, L[k].stopped_at);   // k_lf_predict's part
-			if (status == (uint32_t) ERR_LFFB) continue;
+			if (status == (uint32_t) ERR_LFFB) {
+				// the lane gave the section up: over a form it does not take, a residual too wide for the plane -- or over what a run of
+				// straight-line steps ran into (lf_row_deferred), and then the stream has an error, which the host's decoder names
+				if (L[k].deferred_real) { if (!host_err) return (int32_t) (10 * g + 1); ++deferred_sections; if (failed) ++*failed; }
+				continue;
+			}
 			if (status != host_err) return (int32_t) (10 * g + 1);
 			if (host_err) { if (failed) ++*failed; continue; }
 			if (L[k].nb_varblocks != raw.nb_varblocks) return (int32_t) (10 * g + 2);
@@ -1072,11 +1071,13 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_schedu
 	FrontPlan fp;
 	if (build_front_plan(fr, st, cs_size, extra_prec, true, &fp) || !fp.lf_device) return -1;
 	std::vector<uint8_t> padded(cs, cs + cs_size);
-	padded.resize(cs_size + 32, 0);
+	padded.resize(cs_size + LF_CODESTREAM_PAD, 0);
 	std::vector<DevTreeNode> tree = fp.lf_tree;
 	for (DevTreeNode &n : tree) if (n.prop < 0) { const uint32_t cl = fp.lf_ctx_map[(size_t) n.value]; n.value = lf_rows_leaf_word(cl, fp.lf_cfg[cl]); }
+	std::vector<LfFastQuad> fast(fp.lf_alias.size());   // (k_lf_rows' staging: lf_decode.hip)
+	for (size_t i = 0; i < fast.size(); ++i) fast[i] = lf_rows_fast_entry(fp.lf_alias[i], (uint32_t) i & ((1u << fp.lf_log_alpha) - 1u), fp.lf_cfg[i >> fp.lf_log_alpha]);
 	LfRowTables T;
-	T.tree = tree.data(); T.alias = fp.lf_alias.data(); T.log_alpha = fp.lf_log_alpha; T.log_bucket = 12 - fp.lf_log_alpha; T.uses = fp.lf_uses;
+	T.tree = tree.data(); T.fast = (const uint32_t *) fast.data(); T.alias = fp.lf_alias.data(); T.log_alpha = fp.lf_log_alpha; T.log_bucket = 12 - fp.lf_log_alpha; T.uses = fp.lf_uses;
 	if (copies > 0) T.uses |= (uint32_t) LF_USES_RAW;   // (copies < 0: every channel predicted by its lane)
 	copies = copies < 0 ? -copies : copies;
 	struct Out { std::vector<int16_t> lf[3], xfy, bfy, info, sharp; DevLfResult res; DevLfTask t; };

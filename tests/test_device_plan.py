@@ -144,7 +144,7 @@ def test_lf_row_window_decoder_equals_the_host_decoder(lanes, mode, w, h, seed, 
     # default leaves every leaf-only channel, predicted afterwards by lf_predict_section_serial, the kernel's arithmetic in stream order)
     lanes.hostsim_lf_rows_raw_channels.restype = C.c_int64
     raw_before = lanes.hostsim_lf_rows_raw_channels()
-    for nl, general_only in ((1, 0), (64, 0), (3, 1), (64, 2), (5, 2), (64, 4), (7, 5)):
+    for nl, general_only in ((1, 0), (64, 0), (3, 1), (64, 4), (7, 5)):
         lanes.hostsim_lf_rows_counts(None, None, 1, general_only)
         rc, n, bad = rows_check(lanes, synth(mode, w, h, seed, **opts), nl)
         plain, general = C.c_int64(), C.c_int64()

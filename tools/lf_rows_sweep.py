@@ -46,4 +46,6 @@ for i in range(n):
     cases += 1; failed += 1 if bad.value else 0
     if rc != 0:
         print("MISMATCH rc=%d case %d %dx%d %s flips=%d" % (rc, i, w, h, opts, flips)); sys.exit(1)
-print("%d cases decoded by both (%d with a failing section, same codes), %d streams the front end refused; 0 mismatches" % (cases, failed, skipped))
+S.hostsim_lf_rows_deferred_sections.restype = C.c_int64
+print("%d cases decoded by both (%d with a failing section: same codes, or -- %d sections -- a run of straight-line steps ran into the error, the lane said 'lffb' and the host's decoder did report one), %d streams the front end refused; 0 mismatches"
+      % (cases, failed, S.hostsim_lf_rows_deferred_sections(), skipped))
