@@ -215,8 +215,8 @@ __global__ void __launch_bounds__(64) k_lf_rows(const DevLfLaneSet *sets, const 
 // wavefront or three shared a SIMD) and go to the 64 lanes, each lane three columns behind the lane above it, which hands it the row
 // above through one cross-lane move per step (k_modular_predict's scheme, modular_split.hip); the band's last row stays behind for
 // the next band's first lane. The step is one basic block: positions outside the row read a clamped slot and write the row's spare
-// slot. A sample is read (as a residual) by the lane that replaces it, once. Workgroup b: section b % 64 of wavefront b / 64 of the
-// launch's list.
+// slot. A sample is read (as a residual) by the lane that replaces it, once. Workgroup b: section b / W of wavefront b % W of the
+// launch's list of W.
 template <int PRED>
 __device__ __forceinline__ bool lf_predict_band(J40_LDS int16_t *tile, const J40_LDS int32_t *above, int32_t lane, int32_t y, int32_t cw, int32_t width) {
 	J40_LDS int16_t *row = tile + lane * LF_ROW_PITCH;
@@ -246,8 +246,11 @@ __global__ void __launch_bounds__(64) k_lf_predict(const DevLfLaneSet *sets, con
 	__shared__ int32_t above_lds[LF_ROW_WIN + 4];
 	J40_LDS int16_t *tile = (J40_LDS int16_t *) tile_lds;
 	J40_LDS int32_t *above = (J40_LDS int32_t *) above_lds;
-	const J40_GLOBAL DevLfWave &wv = ((const J40_GLOBAL DevLfWave *) waves)[blockIdx.x >> 6];
-	const int32_t my_section = (int32_t) (blockIdx.x & 63), lane = threadIdx.x;
+	// (section-major: the workgroups that have a section come first whatever the wavefronts' fill -- with twelve sections per wavefront
+	// of k_lf_rows and the wavefront's 64 workgroups side by side, half of the XCDs got two sections for the others' one: 9.0 ms against 4.6)
+	const uint32_t num_waves = gridDim.x >> 6;
+	const J40_GLOBAL DevLfWave &wv = ((const J40_GLOBAL DevLfWave *) waves)[blockIdx.x % num_waves];
+	const int32_t my_section = (int32_t) (blockIdx.x / num_waves), lane = threadIdx.x;
 	const J40_GLOBAL DevLfTask *task = nullptr;
 	int32_t section0 = 0;
 	for (int32_t p = 0; p < wv.num_parts; ++p) {

@@ -130,6 +130,7 @@ struct LfRowLane {
 	// that predict alike
 	int32_t plain_left;                // how many of the lane's next samples take the straight-line step (set by the general step)
 	bool live;                         // not finished (lf_row_done), as of the lane's last general step
+	bool in_run;                       // the lane's last step started a run of plain samples: when it is over, lf_row_run_end (not the general step) follows
 	// what the straight-line steps since the last general step found wrong, looked at by the next general step (lf_row_deferred): an
 	// error there makes the lane report ERR_LFFB -- the host decodes the section and names the error
 	uint32_t acc_range, acc_iovf;      // OR of (sample + 32768): bits from 16 up say a sample left the plane's range; OR of the symbols' LF_FAST_IOVF bits
@@ -172,7 +173,7 @@ J40_DEV void lf_row_init(LfRowLane &L, const J40_GLOBAL DevLfTask &t, J40_LDS in
 	L.x = L.y = 0; L.cw = L.chh = 0; L.root = 0; L.r_prop = -1; L.r_value = L.r_a = L.r_b = 0;
 	L.pw = L.pww = 0; L.a0 = L.a1 = L.a2 = L.a3 = L.a4 = 0; L.row = nullptr; L.win = win;
 	L.flush_n = 0; L.flush_dst = nullptr;
-	L.plain_left = 0; L.live = true; L.acc_range = L.acc_iovf = 0; L.deferred_real = false;
+	L.plain_left = 0; L.live = true; L.in_run = false; L.acc_range = L.acc_iovf = 0; L.deferred_real = false;
 	L.raw = false; L.raw_mask = 0; L.stopped_at = lf_stopped_at(7, 0);
 	L.plain_ok = L.plain_wide = false; L.k_thr = 0; L.k_word_gt = L.k_word_le = 0;
 	L.c_x = L.c_y = L.c_w = L.c_n = L.c_nw = L.c_ne = L.c_ww = L.c_nww = 0; L.c_abs = L.c_first = false;
@@ -393,17 +394,36 @@ J40_DEV void lf_row_step_general(LfRowLane &L, const J40_GLOBAL DevLfTask &t, co
 // lf_row_plan_channel accepts, its first symbol has been read and the sample is not the last of its row; everything else -- channel
 // starts, row ends, other trees -- is the general step, which the kernel runs for the lanes that need it after the others' plain
 // step. The general step leaves the number of plain samples that follow (plain_left), so that the choice costs one compare.
-// how many samples from here on are plain ones: to the last but one of the row (the last one ends the row: the general step), in
-// wide rows from the second sample to the one before the next piece of the window is complete
+// how many samples from here on are plain ones: to the end of the row, in wide rows from the second sample to the end of the window's
+// current piece (what follows a run -- the row's or the piece's copy out, the next row's start -- is lf_row_run_end's)
 J40_DEV int32_t lf_row_plain_run(const LfRowLane &L) {
 	const bool can = L.plain_ok & !L.setup & (L.chan < 7) & (L.state != 0) & (!L.plain_wide | (L.x > 0));
-	const int32_t last = L.plain_wide ? mod_min(L.cw - 1, L.x | (LF_ROW_WIN - 1)) : L.cw - 1;   // the first sample that is not plain
-	return can ? mod_max(last - L.x, 0) : 0;
+	const int32_t last = L.plain_wide ? mod_min(L.cw - 1, L.x | (LF_ROW_WIN - 1)) : L.cw - 1;   // the run's last sample
+	return can ? mod_max(last + 1 - L.x, 0) : 0;
+}
+// what the general step does behind a row's (or, in wide rows, a window piece's) last sample, for a lane whose run of plain samples
+// just got there: the run's findings, the copy out, the next row's start or the channel's end
+J40_DEV void lf_row_run_end(LfRowLane &L) {
+	if (lf_row_deferred(L)) return;
+	const int32_t cw = L.cw, nx = L.x;
+	if (nx < cw) {   // (a wide row's piece: nx is a multiple of the window)
+		L.flush_n = LF_ROW_WIN; L.flush_dst = L.row + (nx - LF_ROW_WIN);
+		return;
+	}
+	L.flush_n = ((cw - 1) & (LF_ROW_WIN - 1)) + 1; L.flush_dst = L.row + (cw - L.flush_n);
+	L.x = 0; L.y += 1; L.row += cw; L.pw = L.pww = 0; L.a0 = L.a1 = 0;
+	if (L.y < L.chh) {
+		if (cw > LF_ROW_WIN) { L.a2 = L.row[-cw]; L.a3 = L.row[1 - cw]; L.a4 = L.row[2 - cw]; }   // (a wide row's first sample is the general step's: W falls back to N there)
+		else { L.a2 = L.win[0]; L.a3 = cw > 1 ? L.win[1] : 0; L.a4 = cw > 2 ? L.win[2] : 0; }
+		return;
+	}
+	++L.chan; L.setup = true;
 }
 // the step the kernel gives the lanes that are not in a run of plain samples; leaves the length of the run that follows
 J40_DEV void lf_row_step(LfRowLane &L, const J40_GLOBAL DevLfTask &t, const LfRowTables &T) {
-	lf_row_step_general(L, t, T);
+	if (L.in_run) lf_row_run_end(L); else lf_row_step_general(L, t, T);
 	L.plain_left = lf_row_plain_run(L);
+	L.in_run = L.plain_left > 0;
 	L.live = !lf_row_done(L);
 }
 

@@ -1019,7 +1019,7 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_check(
 				if (lf_row_done(A)) continue;
 				any = true;
 				if (A.plain_left > 0 && !(general_only & 1)) { lf_row_step_plain_needs(A, T, need); ++plain_steps; }
-				else { lf_row_step(A, out[k].t, T); ++general_steps; }
+				else { if (general_only & 1) A.in_run = false; lf_row_step(A, out[k].t, T); ++general_steps; }   // (mode bit 0: every sample through the general step, also inside what would be a run)
 			}
 			for (size_t k = 0; k < n; ++k) if (L[k].flush_n > 0) lf_row_flush_serial(L[k]);
 		}
@@ -1116,7 +1116,7 @@ extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_schedu
 			if (leave) break;
 		}
 		++out36[1];
-		for (size_t k = 0; k < n; ++k) if (!(L[k].plain_left > 0)) { const bool was = L[k].live && !L[k].setup; lf_row_step(L[k], out[k].t, T); if (was) ++samples[k]; }
+		for (size_t k = 0; k < n; ++k) if (!(L[k].plain_left > 0)) { const bool was = L[k].live && !L[k].setup && !L[k].in_run; lf_row_step(L[k], out[k].t, T); if (was) ++samples[k]; }
 		for (size_t k = 0; k < n; ++k) if (L[k].flush_n > 0) lf_row_flush_serial(L[k]);
 		bool live = false;
 		for (size_t k = 0; k < n; ++k) live |= L[k].live;
