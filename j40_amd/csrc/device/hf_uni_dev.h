@@ -54,20 +54,58 @@ struct UBits {
 	uint32_t pos;
 	uint32_t ahead;
 };
+// Round 6, three things about how the compiler lays this decoder out on the scalar unit, each behind a switch for
+// the A/B runs (tools/r06_l.sh):
+//   J40_UNI_SLOAD  the codestream's words come through the SCALAR cache (s_load_dword: the address is wave-uniform, the buffer is not
+//                  written while the kernel runs). As a vector load the word asked for ahead lived in a vector register across the
+//                  symbol loop, the loop's back edge copied it, and the copy waited (s_waitcnt vmcnt(0)) for the load -- and for every
+//                  event store before it: once per SYMBOL. With scalar loads nothing of the loop waits on the vector memory counter.
+//   J40_UNI_SMUL   d * (state >> 12) as s_mul_i32: told that both factors are below 2^24 the compiler picks the 24-bit multiply, which
+//                  exists on the vector unit only (two moves, v_mad_u32_u24, a nop and a v_readfirstlane per symbol).
+//   J40_UNI_PREV   "was the coefficient non-zero" stays a scalar condition (s_cselect between the two candidate clusters' lanes) instead
+//                  of becoming a lane index by way of a vector select and a v_readfirstlane.
+#ifndef J40_UNI_SLOAD
+#define J40_UNI_SLOAD 1
+#endif
+#ifndef J40_UNI_SMUL
+#define J40_UNI_SMUL 1
+#endif
+#ifndef J40_UNI_PREV
+#define J40_UNI_PREV 1
+#endif
+//   J40_UNI_FLOW   errors leave the symbol and the coefficient loop where they are found (a scalar compare and a branch each) instead of
+//                  travelling as values: `nonzero = v != 0 && e2 == 0` and `e2 ? e2 : nz != 0 && i >= size ? "coef" : 0` came out as
+//                  64-bit lane masks put together with s_cselect_b64 / s_and_b64 (some twenty-five scalar instructions a symbol); and the
+//                  renormalisation is a branch taken once in four or five symbols instead of a 16-or-0-bit read every time.
+#ifndef J40_UNI_FLOW
+#define J40_UNI_FLOW 1
+#endif
+template <bool UNI> J40_DEV uint32_t ub_load32(const J40_GLOBAL uint8_t *base, uint32_t pos) {
+#ifdef __HIPCC__
+	if (UNI && J40_UNI_SLOAD) return *(const __attribute__((address_space(4))) uint32_t *) (uintptr_t) (base + pos);
+#endif
+	return lane_load32(base, pos);
+}
+template <bool UNI> J40_DEV uint32_t ub_mul(uint32_t a, uint32_t b) {
+#ifdef __HIPCC__
+	if (UNI && J40_UNI_SMUL) { uint32_t r; asm("s_mul_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b)); return r; }
+#endif
+	return a * b;
+}
 template <bool UNI> J40_DEV void ub_init(UBits &b, const J40_GLOBAL uint8_t *base, uint32_t start_bit) {
 	b.base = base;
 	const uint32_t pos0 = (start_bit >> 3) & ~3u, skip = start_bit - 8u * pos0;   // skip < 32
-	b.bits = (uint64_t) (uni<UNI>(lane_load32(base, pos0)) >> skip);
+	b.bits = (uint64_t) (uni<UNI>(ub_load32<UNI>(base, pos0)) >> skip);
 	b.nbits = 32 - (int32_t) skip;
 	b.pos = pos0 + 4;
-	b.ahead = lane_load32(base, b.pos);
+	b.ahead = ub_load32<UNI>(base, b.pos);
 }
 template <bool UNI> J40_DEV void ub_refill(UBits &b) {   // > 32 bits buffered afterwards
 	if (b.nbits <= 32) {
 		b.bits |= (uint64_t) uni<UNI>(b.ahead) << b.nbits;
 		b.nbits += 32;
 		b.pos += 4u;
-		b.ahead = lane_load32(b.base, b.pos);
+		b.ahead = ub_load32<UNI>(b.base, b.pos);
 	}
 }
 J40_DEV uint32_t ub_take(UBits &b, int32_t n) {   // 0 <= n <= 31, n <= nbits
@@ -95,7 +133,27 @@ J40_DEV int32_t uni_symbol(UBits &b, uint32_t &state, const UniTables &t, uint32
 	const int32_t token = (int32_t) (aliased ? (elo >> 20) & 0xff : i);
 	const uint32_t offset = aliased ? (elo >> 8) & 0xfff : 0;
 	const uint32_t d = aliased ? (uint32_t) (e >> 28) & 0x1fff : (ehi >> 9) & 0x1fff;
-	state = d * (state >> 12) + offset + pos;
+	state = ub_mul<UNI>(d, state >> 12) + offset + pos;
+	if (J40_UNI_FLOW) {
+		*err = 0;
+		if (state < (1u << 16)) {
+			const uint32_t low = ub_take(b, 16);
+			state = (state << 16) | low;
+			if (ub_position(b) > end_bit) { *err = ERR_SHRT; return 0; }
+		}
+		const int32_t split_exp = (int32_t) (m & 15), split = 1 << split_exp;
+		if (token < split) return token;   // (most coefficient tokens are literal)
+		const int32_t mt = (int32_t) (m >> 12);
+		if (token > mt) { *err = ERR_IOVF; return 0; }
+		const int32_t msb = (int32_t) ((m >> 4) & 15), lsb = (int32_t) ((m >> 8) & 15), in_token = msb + lsb;
+		const int32_t midbits = split_exp - in_token + ((token - split) >> in_token);
+		if (midbits > b.nbits) ub_refill<UNI>(b);   // rare: more than ~17 extra bits
+		const int32_t mid = (int32_t) ub_take(b, midbits);
+		if (ub_position(b) > end_bit) { *err = ERR_SHRT; return 0; }
+		const int32_t top = 1 << msb;
+		const int32_t lo = token & ((1 << lsb) - 1), hi = (token >> lsb) & (top - 1);
+		return ((top | hi) << (midbits + lsb)) | ((mid << lsb) | lo);
+	}
 	const bool renorm = state < (1u << 16);
 	const uint32_t low = ub_take(b, renorm ? 16 : 0);
 	state = renorm ? (state << 16) | low : state;
@@ -176,19 +234,33 @@ J40_DEV uint32_t decode_hf_section_fast(const DevPlan &plan, const DevFrame &f, 
 					}
 					ub_refill<UNI>(b);
 					const int32_t v = uni_symbol<UNI>(b, state, t, cl, end_bit, &e2);
+					if (J40_UNI_FLOW) {
+						if (e2) { err = e2; break; }
+						const uint32_t c0 = spec_take(next, 0), c1 = spec_take(next, 1);
+						if (v != 0) {
+							const int32_t sv = unpack_signed_dev(v);
+							if (ev_at >= h.ev_end || !coeff_event_fits(sv)) { err = ERR_EVOF; break; }
+							CoeffEvent ev; ev.packed = coeff_event_pack((uint32_t) i, sv); plan.events[ev_at++] = ev;
+							if (--nz == 0) break;
+							cl = c1;
+						} else cl = c0;
+						if (++i >= size) { err = ERR_COEF; break; }   // non-zeros left but no coefficient left (j40.h:6996)
+						continue;
+					}
 					const bool nonzero = v != 0 && e2 == 0;
 					if (nonzero) {
 						const int32_t sv = unpack_signed_dev(v);
 						if (ev_at >= h.ev_end || !coeff_event_fits(sv)) e2 = ERR_EVOF;
 						else { CoeffEvent ev; ev.packed = coeff_event_pack((uint32_t) i, sv); plan.events[ev_at++] = ev; }
 					}
-					prev = v != 0;
-					nz -= prev;
+					if (J40_UNI_PREV) nz = v != 0 ? nz - 1 : nz;
+					else { prev = v != 0; nz -= prev; }
 					++i;
 					e2 = e2 ? e2 : nz != 0 && i >= size ? (uint32_t) ERR_COEF : 0u;   // non-zeros left but no coefficient left (j40.h:6996)
 					if (e2) { err = e2; break; }
 					if (nz == 0) break;
-					cl = spec_take(next, prev);
+					if (J40_UNI_PREV) { const uint32_t c0 = spec_take(next, 0), c1 = spec_take(next, 1); cl = v != 0 ? c1 : c0; }
+					else cl = spec_take(next, prev);
 				}
 			}
 			counts[c_yxb] = ev_at - chan_first;
