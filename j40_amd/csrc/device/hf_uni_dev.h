@@ -36,6 +36,19 @@ J40_DEV void spec_issue(SpecPair &s, const uint8_t *ctx_map, int32_t a, int32_t 
 J40_DEV uint32_t spec_take(const SpecPair &s, int32_t which) { return (uint32_t) (which ? s.b : s.a); }
 #endif
 
+// the two candidate contexts' bases, even lanes the one for "the coefficient was zero", odd lanes the other: a per-lane vector that
+// changes only when a non-zero coefficient changes the count of those left; per symbol the frequency context is added and the
+// context map read (spec_issue_base)
+#ifdef __HIPCC__
+struct SpecBase { int32_t v; };
+J40_DEV void spec_base(SpecBase &s, int32_t a, int32_t b) { s.v = (threadIdx.x & 1) ? b : a; }
+J40_DEV void spec_issue_base(SpecPair &p, const J40_LDS uint8_t *ctx_map, const SpecBase &s, int32_t fq, int32_t last_ctx) { const int32_t c = s.v + fq; p.v = (int32_t) ctx_map[c > last_ctx ? last_ctx : c]; }
+#else
+struct SpecBase { int32_t a, b; };
+J40_DEV void spec_base(SpecBase &s, int32_t a, int32_t b) { s.a = a; s.b = b; }
+J40_DEV void spec_issue_base(SpecPair &p, const uint8_t *ctx_map, const SpecBase &s, int32_t fq, int32_t last_ctx) { const int32_t ca = s.a + fq, cb = s.b + fq; p.a = ctx_map[ca > last_ctx ? last_ctx : ca]; p.b = ctx_map[cb > last_ctx ? last_ctx : cb]; }
+#endif
+
 struct UniTables {
 	const J40_LDS uint8_t *ctx_map;     // [num_dist] context -> cluster
 	const J40_LDS uint64_t *alias;      // [cluster << log_alpha | bucket], AnsEntry (entropy.hpp)
@@ -79,6 +92,14 @@ struct UBits {
 //                  renormalisation is a branch taken once in four or five symbols instead of a 16-or-0-bit read every time.
 #ifndef J40_UNI_FLOW
 #define J40_UNI_FLOW 1
+#endif
+//   J40_UNI_TIGHT  the coefficient symbol written out inside its loop (decode_hf_section_fast): an error is `err = ...; break` -- a compare
+//                  and a branch to the loop's exit, no value that says "all went well" merged over three paths --; the two candidate
+//                  contexts keep what a zero coefficient does not change (the non-zero count's share: two table reads, seven scalar
+//                  instructions) in a per-lane vector that only a non-zero coefficient rebuilds; the alias entry's address is a bit-field
+//                  extract, a shift and a shift-add.
+#ifndef J40_UNI_TIGHT
+#define J40_UNI_TIGHT 1
 #endif
 template <bool UNI> J40_DEV uint32_t ub_load32(const J40_GLOBAL uint8_t *base, uint32_t pos) {
 #ifdef __HIPCC__
@@ -222,6 +243,65 @@ J40_DEV uint32_t decode_hf_section_fast(const DevPlan &plan, const DevFrame &f, 
 			int32_t prev = nz <= (size >> 4);
 			int32_t i = 1 << shift;
 			if (nz > 0) {   // (i < size: the first coefficient position is 1 << shift < 64 << shift)
+				if (J40_UNI_TIGHT) {
+					int32_t nn_a = lr_get(t.nnz2, (nz + round) >> shift), nn_b = lr_get(t.nnz2, (nz - 1 + round) >> shift);
+					uint32_t cl = uni<UNI>((uint32_t) t.ctx_map[cctx + nn_a + lr_get(t.freq2, i >> shift) + prev]);
+					SpecBase sb;
+					spec_base(sb, cctx + nn_a, cctx + nn_b + 1);
+					const uint32_t pos_mask = (1u << t.log_bucket) - 1u, la3 = (uint32_t) t.log_alpha + 3u;
+					const J40_LDS uint8_t *alias_bytes = (const J40_LDS uint8_t *) t.alias;
+					for (;;) {
+						SpecPair next;
+						spec_issue_base(next, t.ctx_map, sb, lr_get(t.freq2, ((i + 1) >> shift) & 63), last_ctx);
+						ub_refill<UNI>(b);
+						if (state == 0) {   // (j40.h:2445-2449; a stream whose state comes to exactly zero mid-section)
+							state = ub_take(b, 16); state |= ub_take(b, 16) << 16;
+							ub_refill<UNI>(b);
+						}
+						// the symbol: rANS step (j40.h:2441-2466) ...
+						const uint32_t bucket = (state >> t.log_bucket) & ((1u << t.log_alpha) - 1u), pos = state & pos_mask;
+						const uint64_t e = uni64<UNI>(*(const J40_LDS uint64_t *) (alias_bytes + ((cl << la3) + (bucket << 3))));
+						const uint32_t m = (uint32_t) lr_get(t.cfg, (int32_t) cl);
+						const uint32_t elo = (uint32_t) e;
+						const bool aliased = pos >= (elo & 0xff);
+						const int32_t token = (int32_t) (aliased ? (elo >> 20) & 0xff : bucket);
+						const uint32_t offset = aliased ? (elo >> 8) & 0xfff : 0u;
+						const uint32_t d = (uint32_t) (e >> (aliased ? 28 : 41)) & 0x1fff;
+						state = ub_mul<UNI>(d, state >> 12) + offset + pos;
+						if (state < (1u << 16)) {
+							const uint32_t low = ub_take(b, 16);
+							state = (state << 16) | low;
+							if (ub_position(b) > end_bit) { err = ERR_SHRT; break; }
+						}
+						// ... and hybrid integer (j40.h:2313-2334): most coefficient tokens are literal
+						int32_t v = token;
+						const int32_t split_exp = (int32_t) (m & 15), split = 1 << split_exp;
+						if (token >= split) {
+							if (token > (int32_t) (m >> 12)) { err = ERR_IOVF; break; }
+							const int32_t msb = (int32_t) ((m >> 4) & 15), lsb = (int32_t) ((m >> 8) & 15), in_token = msb + lsb;
+							const int32_t midbits = split_exp - in_token + ((token - split) >> in_token);
+							if (midbits > b.nbits) ub_refill<UNI>(b);   // rare: more than ~17 extra bits
+							const int32_t mid = (int32_t) ub_take(b, midbits);
+							if (ub_position(b) > end_bit) { err = ERR_SHRT; break; }
+							const int32_t top = 1 << msb;
+							const int32_t lo = token & ((1 << lsb) - 1), hi = (token >> lsb) & (top - 1);
+							v = ((top | hi) << (midbits + lsb)) | ((mid << lsb) | lo);
+						}
+						const uint32_t c0 = spec_take(next, 0), c1 = spec_take(next, 1);
+						if (v != 0) {
+							const int32_t sv = unpack_signed_dev(v);
+							if (ev_at >= h.ev_end || !coeff_event_fits(sv)) { err = ERR_EVOF; break; }
+							CoeffEvent ev; ev.packed = coeff_event_pack((uint32_t) i, sv); plan.events[ev_at++] = ev;
+							if (--nz == 0) break;
+							cl = c1;
+							nn_a = nn_b; nn_b = lr_get(t.nnz2, (nz - 1 + round) >> shift);
+							spec_base(sb, cctx + nn_a, cctx + nn_b + 1);
+						} else cl = c0;
+						if (++i >= size) { err = ERR_COEF; break; }   // non-zeros left but no coefficient left (j40.h:6996)
+					}
+					counts[c_yxb] = ev_at - chan_first;
+					continue;
+				}
 				uint32_t cl = uni<UNI>((uint32_t) t.ctx_map[cctx + lr_get(t.nnz2, (nz + round) >> shift) + lr_get(t.freq2, i >> shift) + prev]);
 				for (;;) {
 					// the two contexts the next coefficient can have (prev = 0: nz stays; prev = 1: one non-zero fewer), fetched now
