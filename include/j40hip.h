@@ -236,6 +236,10 @@ J40HIP_API uint32_t j40hip_frame_status(j40hip_frame *f);
 
 /* Convenience for the public API: decode + copy to host rows of `stride_bytes`. Synchronous. */
 J40HIP_API uint32_t j40hip_frame_decode_to_host(j40hip_frame *f, void *rgba_host, size_t stride_bytes);
+/* How j40hip_frame_decode_to_host last decoded the frame: k > 0 -- in two phases, the k longest pass-group sections on a stream of
+ * their own beside the others, the image on its way over the link while they finish (device/runtime.hip; J40HIP_TWO_PHASE=0: never);
+ * 0: in one; -1: not decoded to the host since its upload. Same pixels, same codes either way. */
+J40HIP_API int32_t j40hip_frame_two_phase_sections(const j40hip_frame *f);
 
 /* Stage dumps for parity tests (device -> host copies, synchronous):
  *   quantised HF coefficients of LF group gg, channel c (f32[w8*h8*64], as j40__hf_coeffs leaves them) */

@@ -87,7 +87,7 @@ def lib():
         "j40hip_kat_lf2llf_scale": (C.c_float, [C.c_int]),
         "j40hip_device_count": (C.c_int, []), "j40hip_frame_upload": (u32, [vp, C.c_int]),
         "j40hip_frame_set_group_range": (u32, [vp, i64, i64]), "j40hip_frame_decode": (u32, [vp, vp, sz, vp]),
-        "j40hip_frame_status": (u32, [vp]), "j40hip_frame_decode_to_host": (u32, [vp, vp, sz]),
+        "j40hip_frame_status": (u32, [vp]), "j40hip_frame_decode_to_host": (u32, [vp, vp, sz]), "j40hip_frame_two_phase_sections": (C.c_int32, [vp]),
         "j40hip_frame_read_coeffs": (u32, [vp, i64, C.c_int, vp]), "j40hip_frame_read_plane_i16": (u32, [vp, C.c_int, vp]),
         "j40hip_frame_decode_timed": (u32, [vp, vp, sz, vp, vp]), "j40hip_frame_force_dense": (None, [vp, C.c_int]),
         "j40hip_kat_device_srgb_u8": (u32, [vp, sz, vp]),
@@ -414,6 +414,10 @@ class Frame:
         out = np.zeros((self.height, self.width, 4), np.uint8)
         code = lib().j40hip_frame_decode_to_host(self.h, out.ctypes.data, self.width * 4)
         return err4(code), out
+
+    def two_phase_sections(self):
+        """how decode_to_host last went: k > 0 = two phases with the k longest sections beside the others, 0 = one, -1 = not yet"""
+        return lib().j40hip_frame_two_phase_sections(self.h)
 
     # ---- restoration filters (include/j40hip.h) ----
     def restoration(self):

@@ -8,6 +8,13 @@ namespace j40hip {
 
 void upload_constant_tables(const float *half_secants, const float *afv_basis, const float *srgb_thr, hipStream_t stream);
 void launch_hf_entropy(const DevPlan &plan, const HfLaunchInfo &info, int32_t first_group, int32_t num_groups, hipStream_t stream);
+// the single-image path's two phases (runtime.hip): is the fast entropy kernel the one this frame gets; that kernel over the groups
+// order[first .. first + count); the block_events entries of the groups order[0 .. k) copied from `shadow` into the plan's table
+bool hf_entropy_fast_path(const DevPlan &plan, const HfLaunchInfo &info);
+void launch_hf_entropy_fast_ordered(const DevPlan &plan, const HfLaunchInfo &info, const uint32_t *order, int32_t first, int32_t count, hipStream_t stream);
+void launch_merge_block_events(const DevPlan &plan, const uint32_t *order, int32_t k, const uint32_t *shadow, hipStream_t stream);
+// the rectangles of the groups order[0 .. k) out of the device image into a host image the device can write (pinned)
+void launch_store_group_rects(const uint32_t *order, int32_t k, int32_t gcolumns, int32_t shift, int32_t width, int32_t height, const uint8_t *src, uint8_t *dst_host_mapped, size_t stride_bytes, hipStream_t stream);
 uint32_t hf_lanes_lds_bytes(const HfLaunchInfo &info);
 void launch_hf_entropy_lanes(const DevPlan *plans, const HfLaneWork *work, int32_t num_work, bool tables_in_lds, uint32_t lds_bytes, hipStream_t stream);
 void launch_hf_lanes(const DevPlan *plans, const HfLaneWork *work, int32_t num_work, int32_t waves_per_wg, uint32_t lds_bytes, hipStream_t stream, hipEvent_t started = nullptr, hipEvent_t stopped = nullptr, uint32_t *queue = nullptr);

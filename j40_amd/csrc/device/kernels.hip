@@ -136,14 +136,15 @@ __global__ void __launch_bounds__(64 * HF_WAVES) k_hf_entropy(DevPlan plan, int3
 
 // K1, latency form, fast path (hf_uni_dev.h): single-pass frames coded with rANS and no LZ77, at most 64 clusters, tables that fit
 // in LDS -- what k_hf_lanes takes in a batch. One section per wavefront like k_hf_entropy, the same packed tables as k_hf_lanes.
-__global__ void __launch_bounds__(64 * HF_WAVES) k_hf_entropy_fast(DevPlan plan, int32_t first_group, int32_t num_groups, uint32_t tables_bytes, uint32_t wave_bytes) {
+// `order`: null, or the groups in the order the launch takes them (the single-image path's two launches: runtime.hip, "two phases").
+__global__ void __launch_bounds__(64 * HF_WAVES) k_hf_entropy_fast(DevPlan plan, int32_t first_group, int32_t num_groups, uint32_t tables_bytes, uint32_t wave_bytes, const uint32_t *order) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t hf_lds[];
 	const DevFrame &f = *plan.frame;
 	const int32_t tid = threadIdx.x, lane = tid & 63;
 	const int32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int32_t local = blockIdx.x * HF_WAVES + wave;
 	const bool active = local < num_groups;
-	const int32_t g = first_group + local;
+	const int32_t g = order ? (active ? (int32_t) __builtin_amdgcn_readfirstlane((int32_t) order[first_group + local]) : 0) : first_group + local;
 	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
 	const DevCodeSpec &spec = plan.coeff_specs[0];
 	const int32_t num_dist = spec.num_dist, num_clusters = spec.num_clusters, log_alpha = spec.log_alpha_size;
@@ -1055,6 +1056,46 @@ __global__ void __launch_bounds__(J40_LARGE_THREADS) k_vardct_large(DevPlan plan
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 
+// does launch_hf_entropy take the fast path (k_hf_entropy_fast) for this frame?
+bool hf_entropy_fast_path(const DevPlan &plan, const HfLaunchInfo &info) {
+	static const bool allowed = [] { const char *e = getenv("J40HIP_K1_FAST"); return !e || atoi(e) != 0; }();
+	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+	const uint32_t tables = align16(align16(info.max_num_dist) + info.max_table_bytes), wave_bytes = align16(32 * 32 * 3 + 1024 * (uint32_t) sizeof(DevGroupBlock));
+	return allowed && info.lanes_fast && plan.events && info.max_clusters <= 64 && tables + HF_WAVES * wave_bytes <= 150u * 1024u;
+}
+// the fast path over the groups order[first .. first + count) (the caller has asked hf_entropy_fast_path)
+void launch_hf_entropy_fast_ordered(const DevPlan &plan, const HfLaunchInfo &info, const uint32_t *order, int32_t first, int32_t count, hipStream_t stream) {
+	if (count <= 0) return;
+	auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+	const uint32_t tables = align16(align16(info.max_num_dist) + info.max_table_bytes), wave_bytes = align16(32 * 32 * 3 + 1024 * (uint32_t) sizeof(DevGroupBlock));
+	static bool configured = false;
+	if (!configured) { (void) hipFuncSetAttribute((const void *) k_hf_entropy_fast, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); configured = true; }
+	hipLaunchKernelGGL(k_hf_entropy_fast, dim3((unsigned) ((count + HF_WAVES - 1) / HF_WAVES)), dim3(64 * HF_WAVES), tables + HF_WAVES * wave_bytes, stream, plan, first, count, tables, wave_bytes, order);
+}
+// block_events entries of the groups order[0 .. k): dst[i] = src[i] over each group's blocks (one workgroup per group)
+__global__ void __launch_bounds__(256) k_merge_block_events(const uint32_t *group_block_start, const uint32_t *order, const uint4 *src, uint4 *dst) {
+	const uint32_t g = order[blockIdx.x], b0 = group_block_start[g], b1 = group_block_start[g + 1];
+	for (uint32_t i = b0 + threadIdx.x; i < b1; i += 256) dst[i] = src[i];
+}
+// the rectangles of the groups order[0 .. k) of the device image `src` written into the (pinned, device-visible) host image `dst`:
+// workgroup (row, i) copies one row of group i's rectangle, a dword per lane and turn
+__global__ void __launch_bounds__(256) k_store_group_rects(const uint32_t *order, int32_t gcolumns, int32_t shift, int32_t width, int32_t height, const uint8_t *src, uint8_t *dst, size_t stride_bytes) {
+	const uint32_t g = order[blockIdx.y];
+	const int32_t x0 = (int32_t) (g % (uint32_t) gcolumns) << shift, y = ((int32_t) (g / (uint32_t) gcolumns) << shift) + (int32_t) blockIdx.x;
+	if (y >= height) return;
+	const int32_t w = min(1 << shift, width - x0);
+	const size_t off = (size_t) y * stride_bytes + (size_t) x0 * 4;
+	const uint32_t *s = (const uint32_t *) (src + off);
+	uint32_t *d = (uint32_t *) (dst + off);
+	for (int32_t x = threadIdx.x; x < w; x += 256) d[x] = s[x];
+}
+void launch_store_group_rects(const uint32_t *order, int32_t k, int32_t gcolumns, int32_t shift, int32_t width, int32_t height, const uint8_t *src, uint8_t *dst_host_mapped, size_t stride_bytes, hipStream_t stream) {
+	if (k > 0) hipLaunchKernelGGL(k_store_group_rects, dim3(1u << shift, (unsigned) k), dim3(256), 0, stream, order, gcolumns, shift, width, height, src, dst_host_mapped, stride_bytes);
+}
+void launch_merge_block_events(const DevPlan &plan, const uint32_t *order, int32_t k, const uint32_t *shadow, hipStream_t stream) {
+	if (k > 0) hipLaunchKernelGGL(k_merge_block_events, dim3((unsigned) k), dim3(256), 0, stream, plan.group_block_start, order, (const uint4 *) shadow, (uint4 *) plan.block_events);
+}
+
 void launch_hf_entropy(const DevPlan &plan, const HfLaunchInfo &info, int32_t first_group, int32_t num_groups, hipStream_t stream) {
 	if (num_groups <= 0) return;
 	HfLdsLayout lay;
@@ -1066,7 +1107,7 @@ void launch_hf_entropy(const DevPlan &plan, const HfLaunchInfo &info, int32_t fi
 		if (allowed && info.lanes_fast && plan.events && info.max_clusters <= 64 && tables + HF_WAVES * wave_bytes <= 150u * 1024u) {
 			static bool configured = false;
 			if (!configured) { (void) hipFuncSetAttribute((const void *) k_hf_entropy_fast, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); configured = true; }
-			hipLaunchKernelGGL(k_hf_entropy_fast, dim3((unsigned) ((num_groups + HF_WAVES - 1) / HF_WAVES)), dim3(64 * HF_WAVES), tables + HF_WAVES * wave_bytes, stream, plan, first_group, num_groups, tables, wave_bytes);
+			hipLaunchKernelGGL(k_hf_entropy_fast, dim3((unsigned) ((num_groups + HF_WAVES - 1) / HF_WAVES)), dim3(64 * HF_WAVES), tables + HF_WAVES * wave_bytes, stream, plan, first_group, num_groups, tables, wave_bytes, (const uint32_t *) nullptr);
 			return;
 		}
 	}

@@ -353,6 +353,13 @@ struct j40hip_device_state {
 	uint32_t *mod_extra_status = nullptr;
 	std::vector<uint32_t> status_host;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	// the single-image path's two phases (decode_two_phase): the groups by decreasing section size, the `two_k` first of them decoded
+	// beside the rest with their block_events entries in a table of their own; -1: not looked at yet, 0: not for this frame
+	int32_t two_k = -1;
+	uint32_t *d_two_order = nullptr, *d_two_shadow = nullptr;   // (one block of the device memory cache: two_block)
+	void *two_block = nullptr; size_t two_block_bytes = 0;
+	std::vector<uint32_t> two_order;
+	hipStream_t two_stream = nullptr; hipEvent_t two_ev[3] = {nullptr, nullptr, nullptr};
 	// the restoration filters (decode_impl, restore_*): made at the first decode that runs them, kept with the frame
 	float *d_xyb = nullptr, *d_xyb_tmp = nullptr, *d_sigma = nullptr; int16_t *d_sharp = nullptr;
 	const float *d_restored = nullptr;   // where the last decode's filtered planes lie (d_xyb or d_xyb_tmp)
@@ -382,6 +389,10 @@ extern "C" void j40hip_release_device(j40hip_frame *f) {
 		if (!f->dev->idle) (void) hipDeviceSynchronize();   // nothing may still be running on memory that is about to be handed to another frame
 		cache_release(f->dev->device, f->dev->plan_block, f->dev->plan_block_bytes, false);
 		cache_release(f->dev->device, f->dev->work_block, f->dev->work_block_bytes, false);
+	}
+	if (f->dev->two_block) {
+		if (!f->dev->idle) (void) hipDeviceSynchronize();
+		cache_release(f->dev->device, f->dev->two_block, f->dev->two_block_bytes, false);
 	}
 	for (auto &b : f->dev->buffers) b.release();
 	for (auto &e : f->dev->ev) if (e) (void) hipEventDestroy(e);
@@ -1395,6 +1406,126 @@ static uint32_t j40hip_frame_status_body(j40hip_frame *h) {
 	return std::min_element(bad.begin(), bad.end())->second;
 }
 
+// ---- the single-image path in two phases (round 6) ----
+// One image alone is its longest section: every section has a wavefront and a SIMD of its own, the entropy launch lasts as long as the
+// longest of them (1.9 x the mean in the bench's 8K frame), and 133 MB of pixels then take 2.3 ms over the link while the device has
+// nothing left to do. Here the few longest sections -- those within the copy's time of the longest -- are decoded by a launch of their
+// own on a second stream, beside the launch of all the others; when THAT one is through the pixel kernels run over the whole frame
+// (the long sections' blocks, whose block_events entries are still zero, come out as their LF only) and the whole image starts over
+// the link; when the long sections are through their block_events entries -- written to a table of their own meanwhile, so that the
+// first pass never sees one half written -- are merged in, the pixel kernels run again (0.3 ms; same pixels everywhere else), and
+// only the long sections' groups, a 256 x 256 rectangle each, follow the image over the link. Same pixels and codes as the one-phase
+// decode (tests/test_gpu_parity.py runs both); J40HIP_TWO_PHASE=0: never.
+struct TwoPhaseThread {   // a thread's second stream and events on a device (made once: hipStreamCreate is not for the path of one image)
+	int device = -1; hipStream_t s = nullptr; hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+	~TwoPhaseThread() { if (s) { (void) hipStreamDestroy(s); for (auto &e : ev) if (e) (void) hipEventDestroy(e); } }
+	bool get(int dev) {
+		if (s && device == dev) return true;
+		if (s) { (void) hipStreamDestroy(s); for (auto &e : ev) if (e) (void) hipEventDestroy(e); s = nullptr; }
+		if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { s = nullptr; (void) hipGetLastError(); return false; }
+		for (auto &e : ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); return false; }
+		device = dev;
+		return true;
+	}
+};
+static thread_local TwoPhaseThread t_two_phase;
+
+// decides once per upload whether the frame is decoded in two phases and with which groups on the second stream (st->two_k of st->two_order)
+static void two_phase_plan(j40hip_frame *h, size_t image_bytes) {
+	j40hip_device_state *st = h->dev;
+	st->two_k = 0;
+	const char *env = getenv("J40HIP_TWO_PHASE");   // (looked at per upload: tests switch it between frames)
+	const bool allowed = !env || atoi(env) != 0;
+	const Frame &fr = h->frame;
+	const int64_t ng = fr.fh.num_groups;
+	if (!allowed || st->is_modular || !st->plan.events || !st->plan.block_events || st->has_trailers || fr.toc.single || fr.fh.num_passes != 1 || ng < 64 || image_bytes < ((size_t) 16 << 20)) return;
+	if (st->first_group != 0 || st->num_groups != ng || fr.toc.pass_groups.size() != (size_t) ng) return;
+	if (!hf_entropy_fast_path(st->plan, st->hf)) return;
+	std::vector<uint32_t> order((size_t) ng);
+	for (int64_t g = 0; g < ng; ++g) order[(size_t) g] = (uint32_t) g;
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return fr.toc.pass_groups[a].size > fr.toc.pass_groups[b].size; });
+	// a section takes about a microsecond a byte on its wavefront, the link 57 GB/s: the sections within the copy's time of the longest
+	const double copy_us = (double) image_bytes / 57e3, longest = (double) fr.toc.pass_groups[order[0]].size;
+	int32_t k = 0;
+	while (k < (int32_t) ng && k < 64 && (double) fr.toc.pass_groups[order[(size_t) k]].size > longest - 1.25 * copy_us) ++k;
+	if (k < 1 || k > ng / 4) return;
+	// the order and the long sections' table: one recycled block (a hipMalloc of 16 MB is a millisecond, on the path of one image)
+	const size_t order_bytes = ((size_t) ng * 4 + 255) & ~(size_t) 255, shadow_bytes = 16 * st->num_blocks;
+	bool clean = false;
+	st->two_block = cache_acquire(st->device, order_bytes + shadow_bytes, &st->two_block_bytes, &clean);
+	if (!st->two_block) return;
+	st->d_two_order = (uint32_t *) st->two_block; st->d_two_shadow = (uint32_t *) ((uint8_t *) st->two_block + order_bytes);
+	if (hipMemcpy(st->d_two_order, order.data(), (size_t) ng * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemsetAsync(st->d_two_shadow, 0, shadow_bytes, nullptr) != hipSuccess) { (void) hipGetLastError(); return; }   // (the fill: ahead of the decode's launches on its stream)
+	st->two_order = std::move(order);
+	st->two_k = k;
+}
+
+// pixels of a whole VarDCT frame into rgba_host; d: the device image (stride_bytes per row). Returns the frame's code like decode_impl +
+// j40hip_frame_status would; *done = false: nothing was enqueued, the caller decodes the usual way.
+static uint32_t decode_two_phase(j40hip_frame *h, uint8_t *d, uint8_t *rgba_host, size_t stride_bytes, bool *done) {
+	*done = false;
+	j40hip_device_state *st = h->dev;
+	const Frame &fr = h->frame;
+	const size_t bytes = stride_bytes * (size_t) fr.fh.height;
+	if (st->two_k < 0) two_phase_plan(h, bytes);
+	if (st->two_k <= 0 || restoration_mode(h) != 0) return 0;
+	TwoPhaseThread &tp = t_two_phase;
+	if (!tp.get(st->device)) return 0;
+	*done = true;
+	static const bool timing = getenv("J40HIP_API_TIMING") != nullptr;
+	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double t0 = timing ? now() : 0;
+	const DevPlan &plan = st->plan;
+	const int32_t ng = (int32_t) fr.fh.num_groups, k = st->two_k;
+	hipStream_t s0 = nullptr, s1 = tp.s;
+	st->trailers_pending = false; st->restore_ran = 0; st->restore_err = 0;
+	if (hipMemsetAsync(plan.status, 0, sizeof(uint32_t) * (size_t) st->total_sections, s0) != hipSuccess) return ERR_GPU;
+	if (hipEventRecord(tp.ev[0], s0) != hipSuccess || hipStreamWaitEvent(s1, tp.ev[0], 0) != hipSuccess) return ERR_GPU;
+	DevPlan plan_long = plan;
+	plan_long.block_events = st->d_two_shadow;
+	launch_hf_entropy_fast_ordered(plan_long, st->hf, st->d_two_order, 0, k, s1);          // the long sections, on their own
+	launch_hf_entropy_fast_ordered(plan, st->hf, st->d_two_order, k, ng - k, s0);           // all the others
+	launch_vardct_frame(plan, st->class_start, st->d_vb_sorted, st->d_large_scratch, d, stride_bytes, s0);
+	if (hipEventRecord(tp.ev[1], s0) != hipSuccess || hipStreamWaitEvent(s1, tp.ev[1], 0) != hipSuccess) return ERR_GPU;
+	launch_merge_block_events(plan, st->d_two_order, k, st->d_two_shadow, s1);
+	launch_vardct_frame(plan, st->class_start, st->d_vb_sorted, st->d_large_scratch, d, stride_bytes, s1);
+	if (hipEventRecord(tp.ev[2], s1) != hipSuccess) return ERR_GPU;
+	if (hipGetLastError() != hipSuccess) return ERR_GPU;
+	// the image of the first pass over the link while the long sections are still being decoded: the copy the one-phase decode issues,
+	// behind the first pass on its stream (the host waits in it)
+	const double t1 = timing ? now() : 0;
+	if (hipEventSynchronize(tp.ev[1]) != hipSuccess) return ERR_GPU;
+	const double t2 = timing ? now() : 0;
+	if (!hostcopy_d2h_sync(st->device, rgba_host, d, bytes) && hipMemcpy(rgba_host, d, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ERR_GPU;
+	const double t3 = timing ? now() : 0;
+	// the long sections' groups, one rectangle each, on top: written by a kernel where the device can reach the host's image (pinned
+	// memory: the public API's planes) -- a 2-D copy per rectangle is 0.1 ms each --, else copied one by one
+	uint8_t *mapped = nullptr;
+	{
+		hipPointerAttribute_t at;
+		if (hipPointerGetAttributes(&at, rgba_host) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) mapped = (uint8_t *) at.devicePointer;
+		else (void) hipGetLastError();
+	}
+	const int32_t shift = fr.fh.group_size_shift, gdim = 1 << shift;
+	if (mapped) launch_store_group_rects(st->d_two_order, k, fr.fh.gcolumns, shift, fr.fh.width, fr.fh.height, d, mapped, stride_bytes, s1);
+	else {
+		if (hipEventSynchronize(tp.ev[2]) != hipSuccess) return ERR_GPU;
+		for (int32_t i = 0; i < k; ++i) {
+			const int64_t g = st->two_order[(size_t) i], gx = g % fr.fh.gcolumns, gy = g / fr.fh.gcolumns;
+			const size_t x0 = (size_t) gx << shift, y0 = (size_t) gy << shift;
+			const size_t w = std::min<size_t>((size_t) gdim, (size_t) fr.fh.width - x0), rows = std::min<size_t>((size_t) gdim, (size_t) fr.fh.height - y0);
+			const size_t off = y0 * stride_bytes + x0 * 4;
+			if (hipMemcpy2DAsync(rgba_host + off, stride_bytes, d + off, stride_bytes, w * 4, rows, hipMemcpyDeviceToHost, s1) != hipSuccess) return ERR_GPU;
+		}
+	}
+	const double t4 = timing ? now() : 0;
+	if (hipStreamSynchronize(s1) != hipSuccess) return ERR_GPU;
+	if (timing) fprintf(stderr, "[j40hip two phases] %d long sections of %d: enqueued %.2f ms, the others + first pass through after %.2f, image over the link %.2f, long sections + second pass + %d rectangles (%s) another %.2f ms\n",
+		k, ng, t1 - t0, t2 - t1, t3 - t2, k, mapped ? "a kernel's stores" : "2-D copies", now() - t3);
+	(void) t4;
+	return j40hip_frame_status(h);
+}
+
 static uint32_t j40hip_frame_decode_to_host_body(j40hip_frame *h, void *rgba_host, size_t stride_bytes) {
 	if (!h || !h->dev) return ERR_GPU;
 	const Frame &fr = h->frame;
@@ -1405,7 +1536,15 @@ static uint32_t j40hip_frame_decode_to_host_body(j40hip_frame *h, void *rgba_hos
 	size_t got = 0; bool clean = false;
 	void *d = cache_acquire(device, bytes, &got, &clean);
 	if (!d) return ERR_GPU;
-	uint32_t err = decode_impl(h, d, stride_bytes, nullptr, nullptr);
+	bool two_phase = false;
+	uint32_t err = decode_two_phase(h, (uint8_t *) d, (uint8_t *) rgba_host, stride_bytes, &two_phase);
+	if (two_phase && err != ERR_EVOF) {   // (the pixels are in rgba_host, or the frame has failed; "evof": the dense form below)
+		(void) hipDeviceSynchronize();
+		cache_release(device, d, got, false);
+		return err;
+	}
+	if (two_phase) (void) hipDeviceSynchronize();
+	err = decode_impl(h, d, stride_bytes, nullptr, nullptr);
 	if (!err && hipStreamSynchronize(nullptr) != hipSuccess) err = ERR_GPU;
 	if (!err) err = j40hip_frame_status(h);
 	if (err == ERR_EVOF) {   // a section with more non-zero coefficients than its event region holds: decode with dense planes
@@ -1560,6 +1699,7 @@ extern "C" uint32_t j40hip_kat_device_srgb_u8(const float *v_host, size_t n, uin
 extern "C" uint32_t j40hip_frame_upload(j40hip_frame *h, int device) { return guarded([&] { return j40hip_frame_upload_body(h, device); }); }
 extern "C" uint32_t j40hip_frame_set_group_range(j40hip_frame *h, int64_t first_group, int64_t num_groups) { return guarded([&] { return j40hip_frame_set_group_range_body(h, first_group, num_groups); }); }
 extern "C" uint32_t j40hip_frame_status(j40hip_frame *h) { return guarded([&] { return j40hip_frame_status_body(h); }); }
+extern "C" int32_t j40hip_frame_two_phase_sections(const j40hip_frame *h) { return h && h->dev ? h->dev->two_k : -1; }
 extern "C" uint32_t j40hip_frame_decode_to_host(j40hip_frame *h, void *rgba_host, size_t stride_bytes) { return guarded([&] { return j40hip_frame_decode_to_host_body(h, rgba_host, stride_bytes); }); }
 extern "C" j40hip_batch *j40hip_batch_create(j40hip_frame *const *frames, int64_t n, uint32_t *err) {
 	try { return batch_create_body(frames, n, err); } catch (const std::exception &) { if (err) *err = ERR_MEM; return nullptr; }

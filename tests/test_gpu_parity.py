@@ -569,3 +569,51 @@ def test_section_ends_and_bytes_behind_the_frame_like_the_reference(gpu, ref):
         rerr, px = ref.decode(bytes(b))
         err, out = gpu.decode(bytes(b))
         assert err == rerr and (rerr != "" or np.array_equal(px, out))
+
+
+def test_single_image_two_phases_equal_one_phase(gpu, ref):
+    """j40hip_frame_decode_to_host in two phases (runtime.hip: the longest sections on a stream of their own, the image on its way over the
+    link while they finish, their groups' rectangles on top) against the same call with J40HIP_TWO_PHASE=0, and against the reference:
+    same pixels, same codes -- whole frames, a repeated decode of one upload, streams with a flipped bit in the pass-group sections"""
+    cases = [("vardct", 2600, 2100, 71, dict(forward=1)), ("vardct", 4096, 2304, 72, dict()), ("vardct", 3000, 2100, 73, dict(forward=1))]
+    rng = np.random.default_rng(5)
+    used = damaged = 0
+    for (mode, w, h, seed, opts) in cases:
+        data = synth(mode, w, h, seed, **opts)
+        variants = [data]
+        for _ in range(3):   # (behind the LfGroup sections: a pass-group section, most of the time)
+            m = bytearray(data)
+            m[int(rng.integers(len(m) // 3, len(m) - 16))] ^= 1 << int(rng.integers(0, 8))
+            variants.append(bytes(m))
+        for i, d in enumerate(variants):
+            out = {}
+            for two in ("1", "0"):
+                os.environ["J40HIP_TWO_PHASE"] = two
+                try:
+                    fr = gpu.Frame(d, threads=4)
+                except gpu.J40Error as e:
+                    out[two] = (e.code, None, 0)
+                    continue
+                fr.upload(0)
+                code, px = fr.decode_to_host()
+                k = fr.two_phase_sections()
+                if two == "1" and i == 0:
+                    code2, px2 = fr.decode_to_host()   # (the same upload again: the long sections' entries are in the table by now)
+                    assert code2 == code and np.array_equal(px, px2)
+                out[two] = (code, px, k)
+                fr.close()
+            os.environ.pop("J40HIP_TWO_PHASE", None)
+            assert out["1"][0] == out["0"][0], (w, h, i, out["1"][0], out["0"][0])
+            assert out["0"][2] <= 0
+            if out["1"][2] > 0:
+                used += 1
+            if out["1"][0] == "":
+                assert np.array_equal(out["1"][1], out["0"][1]), (w, h, i)
+            else:
+                damaged += 1
+            if i == 0:
+                rerr, expect = ref.decode(d)
+                assert rerr == "" and out["1"][0] == ""
+                dmax, ndiff = compare(out["1"][1], expect)
+                assert dmax <= 1 and ndiff <= 6000, (dmax, ndiff)
+    assert used >= 3, used
