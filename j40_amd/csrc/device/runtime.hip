@@ -1468,7 +1468,7 @@ static uint32_t decode_two_phase(j40hip_frame *h, uint8_t *d, uint8_t *rgba_host
 	const Frame &fr = h->frame;
 	const size_t bytes = stride_bytes * (size_t) fr.fh.height;
 	if (st->two_k < 0) two_phase_plan(h, bytes);
-	if (st->two_k <= 0 || restoration_mode(h) != 0) return 0;
+	if (st->two_k <= 0 || restoration_mode(h) != 0 || st->first_group != 0 || st->num_groups != fr.fh.num_groups) return 0;   // (a group range set since: the usual way)
 	TwoPhaseThread &tp = t_two_phase;
 	if (!tp.get(st->device)) return 0;
 	*done = true;
