@@ -1416,19 +1416,34 @@ static uint32_t j40hip_frame_status_body(j40hip_frame *h) {
 // first pass never sees one half written -- are merged in, the pixel kernels run again (0.3 ms; same pixels everywhere else), and
 // only the long sections' groups, a 256 x 256 rectangle each, follow the image over the link. Same pixels and codes as the one-phase
 // decode (tests/test_gpu_parity.py runs both); J40HIP_TWO_PHASE=0: never.
-struct TwoPhaseThread {   // a thread's second stream and events on a device (made once: hipStreamCreate is not for the path of one image)
+struct TwoPhaseStream {   // a second stream and three events on a device, borrowed for one decode (hipStreamCreate is not for the path of one image)
 	int device = -1; hipStream_t s = nullptr; hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-	~TwoPhaseThread() { if (s) { (void) hipStreamDestroy(s); for (auto &e : ev) if (e) (void) hipEventDestroy(e); } }
-	bool get(int dev) {
-		if (s && device == dev) return true;
-		if (s) { (void) hipStreamDestroy(s); for (auto &e : ev) if (e) (void) hipEventDestroy(e); s = nullptr; }
-		if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { s = nullptr; (void) hipGetLastError(); return false; }
-		for (auto &e : ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); return false; }
-		device = dev;
-		return true;
-	}
 };
-static thread_local TwoPhaseThread t_two_phase;
+static std::mutex g_two_phase_mutex;
+static std::vector<TwoPhaseStream> g_two_phase_idle;   // (handed back after every decode; j40hip_shutdown destroys them)
+static bool two_phase_borrow(int dev, TwoPhaseStream *out) {
+	{
+		std::lock_guard<std::mutex> lock(g_two_phase_mutex);
+		for (size_t i = 0; i < g_two_phase_idle.size(); ++i) if (g_two_phase_idle[i].device == dev) { *out = g_two_phase_idle[i]; g_two_phase_idle.erase(g_two_phase_idle.begin() + (long) i); return true; }
+	}
+	TwoPhaseStream t;
+	t.device = dev;
+	if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); return false; }
+	for (auto &e : t.ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+		(void) hipGetLastError();
+		for (auto &d : t.ev) if (d) (void) hipEventDestroy(d);
+		(void) hipStreamDestroy(t.s);
+		return false;
+	}
+	*out = t;
+	return true;
+}
+static void two_phase_return(const TwoPhaseStream &t) { std::lock_guard<std::mutex> lock(g_two_phase_mutex); g_two_phase_idle.push_back(t); }
+static void two_phase_shutdown() {
+	std::vector<TwoPhaseStream> all;
+	{ std::lock_guard<std::mutex> lock(g_two_phase_mutex); all.swap(g_two_phase_idle); }
+	for (TwoPhaseStream &t : all) { if (hipSetDevice(t.device) != hipSuccess) continue; (void) hipStreamDestroy(t.s); for (auto &e : t.ev) if (e) (void) hipEventDestroy(e); }
+}
 
 // decides once per upload whether the frame is decoded in two phases and with which groups on the second stream (st->two_k of st->two_order)
 static void two_phase_plan(j40hip_frame *h, size_t image_bytes) {
@@ -1469,8 +1484,9 @@ static uint32_t decode_two_phase(j40hip_frame *h, uint8_t *d, uint8_t *rgba_host
 	const size_t bytes = stride_bytes * (size_t) fr.fh.height;
 	if (st->two_k < 0) two_phase_plan(h, bytes);
 	if (st->two_k <= 0 || restoration_mode(h) != 0 || st->first_group != 0 || st->num_groups != fr.fh.num_groups) return 0;   // (a group range set since: the usual way)
-	TwoPhaseThread &tp = t_two_phase;
-	if (!tp.get(st->device)) return 0;
+	TwoPhaseStream tp;
+	if (!two_phase_borrow(st->device, &tp)) return 0;
+	struct GiveBack { const TwoPhaseStream &t; ~GiveBack() { (void) hipStreamSynchronize(t.s); two_phase_return(t); } } give_back{tp};   // (whatever way the decode ends: nothing of it is left on the stream)
 	*done = true;
 	static const bool timing = getenv("J40HIP_API_TIMING") != nullptr;
 	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1718,6 +1734,7 @@ extern "C" void j40hip_shutdown(void) {
 	}
 	j40hip_serve_shutdown();
 	j40hip_async_shutdown();
+	two_phase_shutdown();
 	hostcopy_shutdown();
 	pinned_trim();
 	int n = 0;
