@@ -675,6 +675,12 @@ def sections(args, torch, np, j40_amd, dev, local_rank, datas, quota):
     out["latency_mode"]["public_api_cold_ms"] = round(api_ms[0], 2)
     out["latency_mode"]["public_api_warm_median_ms"] = round(warm[len(warm) // 2], 2)
     out["latency_mode"]["public_api_warm_calls_ms"] = [round(v, 2) for v in api_ms[1:]]
+    # how the public API's call decodes a lone image: j40hip_frame_decode_to_host in two phases (the longest pass-group sections on a stream of
+    # their own, the image over the link while they finish: DESIGN.md section 4 "One image alone") -- how many sections that was for this frame
+    frames[0].decode_to_host()
+    out["latency_mode"]["two_phase_long_sections"] = int(frames[0].two_phase_sections())
+    out["latency_mode"]["note"] = ("frame_ms / k_hf_entropy_ms: the frame alone on the device in ONE phase (device-recorded: entropy launch, pixel kernels; no copy); "
+                                   "public_api_*: host bytes -> host pixels through the unchanged API, which decodes in two phases when two_phase_long_sections > 0 (J40HIP_TWO_PHASE=0: never)")
     batch.close()
     for fr in frames:
         fr.close()
