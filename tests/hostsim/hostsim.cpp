@@ -955,6 +955,62 @@ extern "C" __attribute__((visibility("default"))) void hostsim_lf_rows_needs_see
 extern "C" __attribute__((visibility("default"))) int64_t hostsim_lf_rows_raw_channels() { return raw_seen; }
 // (how many sections ended "lffb" because a run of straight-line steps ran into an error of the stream -- each checked to be one the host's decoder reports too)
 extern "C" __attribute__((visibility("default"))) int64_t hostsim_lf_rows_deferred_sections() { return deferred_sections; }
+// The fast entries by themselves (lf_rows_fast_entry + the symbol arithmetic of lf_row_step_plain_for) against lane_symbol_in_cluster on
+// random alias entries, hybrid-integer configurations (every split_exp / msb / lsb the format allows, max_token anywhere), states and
+// bit windows -- what the generator's streams, which use few configurations, do not reach. For every draw without an error: the same
+// value, the same next state, the same number of bits taken; "iovf" draws must come out as the entry's flag (and LF_FAST_IOVF_BASE).
+// Returns the number of draws compared, -(draw + 1) at the first difference.
+extern "C" __attribute__((visibility("default"))) int64_t hostsim_lf_fast_entry_check(uint32_t seed, int32_t draws) {
+	uint64_t rng = 0x9e3779b97f4a7c15ull ^ ((uint64_t) seed << 17);
+	auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+	int64_t compared = 0;
+	for (int32_t k = 0; k < draws; ++k) {
+		const int32_t log_alpha = 5 + (int32_t) (next() % 4), log_bucket = 12 - log_alpha;
+		const uint32_t split_exp = (uint32_t) (next() % 16);
+		uint32_t msb = 0, lsb = 0;
+		if (split_exp) { msb = (uint32_t) (next() % (split_exp + 1)); lsb = (uint32_t) (next() % (split_exp - msb + 1)); }
+		const uint32_t max_token = (next() & 3) ? (uint32_t) (next() % 300) : 0xfffffu;
+		const uint32_t cfg = split_exp | (msb << 4) | (lsb << 8) | (max_token << 12);
+		const uint32_t bucket = (uint32_t) (next() % (1u << log_alpha)), cutoff = (uint32_t) (next() % ((1u << log_bucket) + 1));
+		const uint32_t off_r = (uint32_t) (next() & 0xfff), tok_r = (uint32_t) (next() & 0xff), d_r = 1 + (uint32_t) (next() % 4096), d_l = 1 + (uint32_t) (next() % 4096);
+		const uint64_t e = (uint64_t) cutoff | ((uint64_t) off_r << 8) | ((uint64_t) tok_r << 20) | ((uint64_t) d_r << 28) | ((uint64_t) d_l << 41);
+		// the cluster's widest token decides whether the straight-line step takes the cluster at all (lf_rows_leaf_word)
+		if ((uint32_t) lf_rows_leaf_word(0, cfg) & (uint32_t) LF_LEAF_WIDE) continue;
+		std::vector<uint64_t> alias((size_t) 1 << log_alpha, 0);
+		alias[bucket] = e;
+		uint32_t state = 0x10000u + (uint32_t) (next() % 0xfff00000u);
+		state = (state & ~0xfffu) | (bucket << log_bucket) | (uint32_t) (next() % (1u << log_bucket));
+		uint32_t words[6];
+		for (uint32_t &w : words) w = (uint32_t) next();
+		LaneBits b;
+		lane_bits_init(b, (const uint8_t *) words, 0);
+		lane_bits_refill(b);
+		LaneBits b2 = b;
+		uint32_t state_a = state, err_a = 0;
+		const int32_t v_a = lane_symbol_in_cluster<true>(b, state_a, alias.data(), log_alpha, log_bucket, 0u, cfg, 0xffffffffu, &err_a);
+		// the step's arithmetic
+		const LfFastQuad q = lf_rows_fast_entry(e, bucket, cfg);
+		const uint32_t pos = state & ((1u << log_bucket) - 1u);
+		const bool aliased = pos >= (q[0] & 0xffu);
+		const uint32_t w = aliased ? q[1] : q[0] >> 8, base = aliased ? q[3] : q[2];
+		uint32_t state_b = (w & 0x1fffu) * (state >> 12) + (w >> 19) + pos;
+		const bool renorm = state_b < (1u << 16);
+		const uint32_t window = (uint32_t) b2.bits, skip = renorm ? 16u : 0u, extra = (w >> 13) & 31u;
+		state_b = renorm ? lf_renorm_word(state_b, window) : state_b;
+		const uint32_t mid = lf_bfe(window, skip, extra), taken = skip + extra;
+		const int32_t v_b = (int32_t) (base + (mid << lsb));
+		if (err_a == (uint32_t) ERR_IOVF) {
+			if (!(w & (uint32_t) LF_FAST_IOVF) || base != (uint32_t) LF_FAST_IOVF_BASE) return -(int64_t) (k + 1);
+			++compared;
+			continue;
+		}
+		if (err_a || (w & (uint32_t) LF_FAST_IOVF)) return -(int64_t) (k + 1);
+		if (v_a != v_b || state_a != state_b || (uint32_t) (b2.nbits - b.nbits) != taken) return -(int64_t) (k + 1);
+		++compared;
+	}
+	return compared;
+}
+
 extern "C" __attribute__((visibility("default"))) int32_t hostsim_lf_rows_check(const uint8_t *buf, size_t size, int32_t lanes, int32_t *sections, int32_t *failed) {
 	const uint8_t *cs; size_t cs_size; std::vector<uint8_t> storage;
 	Frame fr;

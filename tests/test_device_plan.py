@@ -163,6 +163,20 @@ def test_lf_row_window_decoder_equals_the_host_decoder(lanes, mode, w, h, seed, 
         assert lanes.hostsim_lf_rows_raw_channels() > raw_before
 
 
+def test_lf_fast_entries_equal_the_symbol_decoder_on_random_configurations(lanes):
+    """lf_rows_fast_entry (the alias entry and the hybrid integer worked out per symbol: what k_lf_rows' straight-line step reads) against
+    lane_symbol_in_cluster on random entries, every split_exp / msb_in_token / lsb_in_token combination the format allows, max_token
+    anywhere, random states and bit windows: same value, same next state, same bits taken; a token above max_token is the entry's flag"""
+    lanes.hostsim_lf_fast_entry_check.restype = C.c_int64
+    lanes.hostsim_lf_fast_entry_check.argtypes = [C.c_uint32, C.c_int32]
+    total = 0
+    for seed in range(8):
+        n = lanes.hostsim_lf_fast_entry_check(seed, 200000)
+        assert n > 0, (seed, n)
+        total += n
+    assert total > 400000, total
+
+
 def test_lf_row_window_decoder_fails_like_the_host_decoder(lanes):
     data = synth("vardct", 2600, 2100, 41)
     rng = np.random.default_rng(12)
