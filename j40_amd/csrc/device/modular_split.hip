@@ -76,6 +76,12 @@ __global__ void __launch_bounds__(64) k_modular_tokens(DevModPlan plan, int32_t 
 	auto next_token = [&](const ClusterRegs &cl) { return prefix ? split_prefix_token<true>(b, code.prefix, cl, end_bit, &err) : split_ans_token<true>(b, state, code.alias, code.log_bucket, cl, end_bit, &err); };
 	// an LZ77 run in progress: `run_left` values still to copy, value j of the run comes from out[run_base + (run_done + j) % run_dist]
 	uint32_t run_left = 0, run_base = 0, run_dist = 0, run_done = 0;
+	// A run at distance 1 -- "the value before, n times", what run-length passes of encoders write -- repeats a value this wavefront decoded
+	// a moment ago: it is kept (last_val; last_known: false behind a run copied out of memory) and the run becomes stores of it, without the
+	// wait for the stores before it and the round trip to the L2 that a run copied out of the window pays (config 1: 24.7 -> 23.6 ms.
+	// Also measured in round 6, call O, and not kept: a run's start -- length token, distance symbol, both hybrid integers -- worked out by
+	// the lanes of the 64-at-a-time mode like a literal is: 23.6 -> 32 ms, every iteration pays for it and run starts are not where the time is)
+	int32_t last_val = 0; bool last_known = false, run_fill = false;
 	const bool uses_x = sec.split == 2;
 	// Prefix codes, the leaf fixed along a row: SIXTY-FOUR symbols are decoded at once, lane i the one that would start at bit P + i --
 	// token, extra bits, value, length, all of it a function of the 33 bits at that position and of the row's cluster -- and the stream's
@@ -98,7 +104,8 @@ __global__ void __launch_bounds__(64) k_modular_tokens(DevModPlan plan, int32_t 
 				if (run_left) {
 					// the rest of the run that fits this row: the sources lie before the run's start, all of them in memory (flushed there)
 					const uint32_t k = mod_min((int32_t) run_left, gw - x);
-					for (uint32_t j0 = 0; j0 < k; j0 += 64) {
+					if (run_fill) for (uint32_t j0 = 0; j0 < k; j0 += 64) { const uint32_t j = j0 + (uint32_t) lane; if (j < k) out[n + j] = last_val; }
+					else for (uint32_t j0 = 0; j0 < k; j0 += 64) {
 						const uint32_t j = j0 + (uint32_t) lane;
 						// (agent-scope loads: what this wavefront stored a moment ago, from the L2 -- never a line the vector L1 took in earlier; a run
 						// that starts before the first decoded value copies zeros, j40.h:2858)
@@ -136,6 +143,7 @@ __global__ void __launch_bounds__(64) k_modular_tokens(DevModPlan plan, int32_t 
 						const int32_t v = __builtin_amdgcn_readfirstlane(val);
 						for (uint32_t j = (uint32_t) lane; j < rem; j += 64) out[n + j] = v;
 						n += rem; flushed = n; x = gw;
+						last_val = v; last_known = true;
 						continue;
 					}
 					while (off < 64u && cnt < rem) {
@@ -146,6 +154,7 @@ __global__ void __launch_bounds__(64) k_modular_tokens(DevModPlan plan, int32_t 
 					}
 					// the walk's symbols leave in stream order: the k-th start lane stores to n + k
 					if ((starts >> lane) & 1u) out[n + (uint32_t) __builtin_popcountll(starts & (((uint64_t) 1 << lane) - 1u))] = val;
+					if (cnt) { last_val = __builtin_amdgcn_readlane(val, 63 - __builtin_clzll(starts)); last_known = true; }   // (the walk's last symbol)
 					n += cnt; flushed = n; x += (int32_t) cnt; P += off;
 					if (!slow) continue;
 					{   // this one symbol the long way: the scalar decoder's window set up at P out of the same LDS chunk (three words; the words after
@@ -162,6 +171,7 @@ __global__ void __launch_bounds__(64) k_modular_tokens(DevModPlan plan, int32_t 
 					token = split_hybrid<true>(b, token, cl.cfg, cl.max_token, end_bit, &err);
 					if (err) break;
 					pend = lane == (int32_t) (n - flushed) ? token : pend;   // (lane n - flushed of `pend` := the wave-uniform token: a compare and a select)
+					last_val = token; last_known = true;
 					++n; ++x;
 					if (n - flushed == 64 || fast) flush();   // (the sixty-four-at-a-time mode stores its values itself: nothing may wait in `pend` beside it)
 					if (fast) P = ub_position(b);
@@ -184,7 +194,8 @@ __global__ void __launch_bounds__(64) k_modular_tokens(DevModPlan plan, int32_t 
 				if ((uint32_t) distance > n) distance = (int32_t) n;
 				if (distance > (1 << 20)) distance = 1 << 20;
 				flush();
-				__builtin_amdgcn_s_waitcnt(0);   // (the run reads what was just stored)
+				run_fill = distance == 1 && last_known;   // (n >= 1 then: the value before the run is last_val, and stays the last one behind it)
+				if (!run_fill) { __builtin_amdgcn_s_waitcnt(0); last_known = false; }   // (the run reads what was just stored; what it ends on is not kept)
 				run_left = (uint32_t) mod_max(num_to_copy, 0); run_base = n - (uint32_t) distance; run_dist = (uint32_t) distance; run_done = 0;
 				if (run_left > sec.res_count - n) run_left = sec.res_count - n;   // (a run past the section's last sample: the values it still codes are never asked for)
 			}
