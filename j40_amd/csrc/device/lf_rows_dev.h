@@ -388,7 +388,7 @@ J40_DEV void lf_row_step_general(LfRowLane &L, const J40_GLOBAL DevLfTask &t, co
 // wavefront walks past (compare, s_and_saveexec, s_cbranch_execz, s_or), whether its body runs or not. The general step above is
 // some fifty of those per sample (the switches over properties and predictors, refills, edges, errors): 3 200 cycles per sample
 // whatever its memory accesses cost, which is why moving them to LDS alone changed nothing (434 ms per launch against 410).
-// lf_row_step_plain is the same sample as ONE basic block: the property is a signed sum with per-channel coefficients, the tree
+// lf_row_step_plain_for is the same sample as ONE basic block: the property is a signed sum with per-channel coefficients, the tree
 // walk a compare and a select, the refill, the renormalisation, the extra bits, the prediction (a sum, "select" and the clamped
 // gradient all computed, one chosen) and the error bookkeeping are selects. A lane takes it when its channel has the form
 // lf_row_plan_channel accepts, its first symbol has been read and the sample is not the last of its row; everything else -- channel

@@ -140,7 +140,7 @@ def test_lf_row_window_decoder_equals_the_host_decoder(lanes, mode, w, h, seed, 
     reference's j40__lf_group by tests/test_host.py). The varblock-info channel (2 rows of hundreds to thousands of samples) is the
     case of rows wider than the window."""
     lanes.hostsim_lf_rows_counts.argtypes = [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32, C.c_int32]
-    # (mode bit 1: two sections per lane, as k_lf_rows<true> steps them; bit 2: no channel left as residuals for k_lf_predict -- the
+    # (mode bit 0: every sample through the general step; bit 2: no channel left as residuals for k_lf_predict -- the
     # default leaves every leaf-only channel, predicted afterwards by lf_predict_section_serial, the kernel's arithmetic in stream order)
     lanes.hostsim_lf_rows_raw_channels.restype = C.c_int64
     raw_before = lanes.hostsim_lf_rows_raw_channels()
