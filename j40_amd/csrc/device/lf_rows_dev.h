@@ -390,10 +390,10 @@ J40_DEV void lf_row_step_general(LfRowLane &L, const J40_GLOBAL DevLfTask &t, co
 // whatever its memory accesses cost, which is why moving them to LDS alone changed nothing (434 ms per launch against 410).
 // lf_row_step_plain_for is the same sample as ONE basic block: the property is a signed sum with per-channel coefficients, the tree
 // walk a compare and a select, the refill, the renormalisation, the extra bits, the prediction (a sum, "select" and the clamped
-// gradient all computed, one chosen) and the error bookkeeping are selects. A lane takes it when its channel has the form
-// lf_row_plan_channel accepts, its first symbol has been read and the sample is not the last of its row; everything else -- channel
-// starts, row ends, other trees -- is the general step, which the kernel runs for the lanes that need it after the others' plain
-// step. The general step leaves the number of plain samples that follow (plain_left), so that the choice costs one compare.
+// gradient all computed, one chosen) are selects; errors are looked for when a run is over (lf_row_deferred). A lane takes it when its
+// channel has the form lf_row_plan_channel accepts and its first symbol has been read, to the end of its row (lf_row_run_end follows);
+// everything else -- channel starts, other trees -- is the general step, which the kernel runs for the lanes that need it after the
+// others' plain steps. lf_row_step leaves the number of plain samples that follow (plain_left), so that the choice costs one compare.
 // how many samples from here on are plain ones: to the end of the row, in wide rows from the second sample to the end of the window's
 // current piece (what follows a run -- the row's or the piece's copy out, the next row's start -- is lf_row_run_end's)
 J40_DEV int32_t lf_row_plain_run(const LfRowLane &L) {
